@@ -1,0 +1,570 @@
+"""CPU oracle (numpy) for Palace's partial-assembly operator apply and its Krylov loop.
+
+*** TEST INFRASTRUCTURE — not product code.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.  The product path (palace_amd/) never does. ***
+
+What it restates, function by function (all paths relative to the reference tree):
+  * libCEED operator semantics `v += E^T B^T D B E u` with *dense* non-tensor H(curl) basis tables,
+    exactly what Palace asks libCEED for (palace/fem/libceed/basis.cpp:40-85,
+    palace/fem/libceed/restriction.cpp:362-384, palace/fem/libceed/operator.cpp:148-190).
+    libCEED itself (pinned 95bd1e908b16e04a70015e3a9a7fddec5e9c3fc8, cmake/ExternalGitTags.cmake:78-79)
+    is not vendored; its published semantics for CEED_EVAL_INTERP / CEED_EVAL_CURL on an H(curl)
+    basis are `(B u)[d, q] = sum_j interp[(d Q + q) P + j] u_j`.
+  * geometry factors  : palace/fem/qfunctions/33/geom_33_qf.h:9-33
+  * D, curl-curl      : palace/fem/qfunctions/33/hdiv_33_qf.h:10-30
+  * D, mass / H1 diff : palace/fem/qfunctions/33/hcurl_33_qf.h:10-28
+  * D, curl-curl+mass : palace/fem/qfunctions/33/hdivmass_33_qf.h:10-44
+  * coefficient ctx   : palace/fem/libceed/coefficient.cpp:51-131, palace/fem/qfunctions/coeff/coeff_qf.h
+  * ParOperator BCs   : palace/linalg/rap.cpp:195-234, :154-193
+  * PCG               : palace/linalg/iterative.cpp:360-486
+  * Chebyshev 4th kind: palace/linalg/chebyshev.cpp:160-220;  lambda_max: palace/linalg/operator.cpp:583-631
+  * V-cycle           : palace/linalg/gmg.cpp:171-205
+
+Pinning: the D stage is checked against the *real* reference QFunction headers
+compiled into oracle/_ref (tests/test_oracle_ref.py, fixtures in tests/golden/); the whole chain
+mesh -> basis -> E/B/D -> eigenproblem is pinned on the reference's own regression data
+test/data/regression/ref/cylinder/cavity_pec/eig.csv (tests/test_oracle_eigen.py).  The basis
+tables and dof numbering that MFEM (not vendored) would supply are NOT pinned entry by entry —
+only through those basis-invariant results.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ---------------------------------------------------------------------------------------------
+# 1-D pieces (independent of palace_amd.fem.basis1d on purpose: different algorithm)
+# ---------------------------------------------------------------------------------------------
+
+def gl_points(n):
+    """Gauss-Legendre on [0,1] via the Golub-Welsch eigenvalue problem."""
+    if n == 1:
+        return np.array([0.5]), np.array([1.0])
+    k = np.arange(1, n)
+    beta = k / np.sqrt(4.0 * k * k - 1.0)
+    T = np.diag(beta, 1) + np.diag(beta, -1)
+    lam, V = np.linalg.eigh(T)
+    w = 2.0 * V[0, :] ** 2
+    # polish with Newton on P_n
+    x = lam
+    for _ in range(3):
+        P0, P1 = np.ones_like(x), x
+        for m in range(2, n + 1):
+            P0, P1 = P1, ((2 * m - 1) * x * P1 - (m - 1) * P0) / m
+        dP = n * (x * P1 - P0) / (x * x - 1.0)
+        x = x - P1 / dP
+    P0, P1 = np.ones_like(x), x
+    for m in range(2, n + 1):
+        P0, P1 = P1, ((2 * m - 1) * x * P1 - (m - 1) * P0) / m
+    dP = n * (x * P1 - P0) / (x * x - 1.0)
+    w = 2.0 / ((1.0 - x * x) * dP * dP)
+    return 0.5 * (x + 1.0), 0.5 * w
+
+
+def gll_points(n):
+    """Gauss-Lobatto points on [0,1]: eigenvalues of the Jacobi matrix for P'_{n-1} plus ends."""
+    if n == 2:
+        return np.array([0.0, 1.0])
+    m = n - 2  # interior points = roots of P'_{n-1} = Jacobi(1,1) polynomial of degree m
+    k = np.arange(1, m)
+    beta = np.sqrt(k * (k + 2.0) / ((2.0 * k + 1.0) * (2.0 * k + 3.0)))
+    T = np.diag(beta, 1) + np.diag(beta, -1)
+    x = np.linalg.eigvalsh(T) if m > 1 else np.array([0.0])
+    N = n - 1
+    for _ in range(3):  # Newton on P'_N via (1-x^2) P'_N = N (P_{N-1} - x P_N)
+        P0, P1 = np.ones_like(x), x
+        for j in range(2, N + 1):
+            P0, P1 = P1, ((2 * j - 1) * x * P1 - (j - 1) * P0) / j
+        f = P0 - x * P1            # proportional to (1-x^2) P'_N
+        df = -(N + 1) * P1         # d/dx (P_{N-1} - x P_N) = -(N+1) P_N
+        x = x - f / df
+    x = np.concatenate([[-1.0], np.sort(x), [1.0]])
+    return 0.5 * (x + 1.0)
+
+
+def lagrange(nodes, x, i):
+    """l_i(x), l_i'(x) on `nodes` at scalar x (direct product formulas)."""
+    n = len(nodes)
+    val, denom = 1.0, 1.0
+    for m in range(n):
+        if m != i:
+            val *= x - nodes[m]
+            denom *= nodes[i] - nodes[m]
+    der = 0.0
+    for m in range(n):
+        if m == i:
+            continue
+        t = 1.0
+        for l in range(n):
+            if l != i and l != m:
+                t *= x - nodes[l]
+        der += t
+    return val / denom, der / denom
+
+
+def hex_quadrature(q1d):
+    """Tensor Gauss-Legendre rule, point index q = qx + q1d (qy + q1d qz)."""
+    x, w = gl_points(q1d)
+    pts = np.array([[x[a], x[b], x[c]] for c in range(q1d) for b in range(q1d) for a in range(q1d)])
+    wts = np.array([w[a] * w[b] * w[c] for c in range(q1d) for b in range(q1d) for a in range(q1d)])
+    return pts, wts
+
+
+# ---------------------------------------------------------------------------------------------
+# Dense reference-element tables, as `fe.GetDofToQuad(ir, DofToQuad::FULL)` gives Palace
+# (basis.cpp:43-83): interp[(d*Q+q)*P + j], curl[(d*Q+q)*P + j], native dof order via dof_map.
+# ---------------------------------------------------------------------------------------------
+
+def nd_hex_dense_tables(p, q1d, dof_map):
+    """Direct point-wise evaluation of every Nedelec hex shape function and its curl.
+
+    dof_map[lex] = native index (or -1-native for a flipped shape function)."""
+    cp, op = gll_points(p + 1), gl_points(p)[0]
+    pts, _ = hex_quadrature(q1d)
+    Q, P = pts.shape[0], 3 * p * (p + 1) ** 2
+    interp = np.zeros((3, Q, P))
+    curl = np.zeros((3, Q, P))
+    for comp in range(3):
+        n = [p + 1] * 3
+        n[comp] = p
+        nodes = [cp, cp, cp]
+        nodes[comp] = op
+        for k in range(n[2]):
+            for j in range(n[1]):
+                for i in range(n[0]):
+                    lex = comp * p * (p + 1) ** 2 + i + n[0] * (j + n[1] * k)
+                    nat = dof_map[lex]
+                    s = 1.0
+                    if nat < 0:
+                        nat, s = -1 - nat, -1.0
+                    for q in range(Q):
+                        vx, dx = lagrange(nodes[0], pts[q, 0], i)
+                        vy, dy = lagrange(nodes[1], pts[q, 1], j)
+                        vz, dz = lagrange(nodes[2], pts[q, 2], k)
+                        val = vx * vy * vz
+                        grad = (dx * vy * vz, vx * dy * vz, vx * vy * dz)
+                        interp[comp, q, nat] = s * val
+                        # curl(f e_c): components (e_a x ...)
+                        if comp == 0:   # f e_x -> (0, df/dz, -df/dy)
+                            curl[1, q, nat], curl[2, q, nat] = s * grad[2], -s * grad[1]
+                        elif comp == 1:  # f e_y -> (-df/dz, 0, df/dx)
+                            curl[0, q, nat], curl[2, q, nat] = -s * grad[2], s * grad[0]
+                        else:           # f e_z -> (df/dy, -df/dx, 0)
+                            curl[0, q, nat], curl[1, q, nat] = s * grad[1], -s * grad[0]
+    return interp.reshape(-1), curl.reshape(-1)
+
+
+def h1_hex_dense_tables(p, q1d):
+    """H1 tensor element, lexicographic dofs: interp[q*P + j], grad[(d*Q+q)*P + j]."""
+    cp = gll_points(p + 1)
+    pts, _ = hex_quadrature(q1d)
+    n1 = p + 1
+    Q, P = pts.shape[0], n1**3
+    interp = np.zeros((Q, P))
+    grad = np.zeros((3, Q, P))
+    for k in range(n1):
+        for j in range(n1):
+            for i in range(n1):
+                lex = i + n1 * (j + n1 * k)
+                for q in range(Q):
+                    vx, dx = lagrange(cp, pts[q, 0], i)
+                    vy, dy = lagrange(cp, pts[q, 1], j)
+                    vz, dz = lagrange(cp, pts[q, 2], k)
+                    interp[q, lex] = vx * vy * vz
+                    grad[0, q, lex] = dx * vy * vz
+                    grad[1, q, lex] = vx * dy * vz
+                    grad[2, q, lex] = vx * vy * dz
+    return interp.reshape(-1), grad.reshape(-1)
+
+
+def mesh_q2_grad_table(q1d):
+    """grad table of the tri-quadratic mesh-node basis at the quadrature points:
+    G[d, q, n] for lattice node n = i + 3 j + 9 k (nodes at {0, 1/2, 1}^3)."""
+    nodes = np.array([0.0, 0.5, 1.0])
+    pts, _ = hex_quadrature(q1d)
+    Q = pts.shape[0]
+    G = np.zeros((3, Q, 27))
+    for k in range(3):
+        for j in range(3):
+            for i in range(3):
+                n = i + 3 * j + 9 * k
+                for q in range(Q):
+                    vx, dx = lagrange(nodes, pts[q, 0], i)
+                    vy, dy = lagrange(nodes, pts[q, 1], j)
+                    vz, dz = lagrange(nodes, pts[q, 2], k)
+                    G[0, q, n], G[1, q, n], G[2, q, n] = dx * vy * vz, vx * dy * vz, vx * vy * dz
+    return G
+
+
+# ---------------------------------------------------------------------------------------------
+# QFunctions (column-major 3x3: M[i + 3 j] = M_ij)
+# ---------------------------------------------------------------------------------------------
+
+def adjJt33(J):
+    """utils_33_qf.h:20-37.  J: [..., 9] column-major.  Returns (adj(J)^T, det J)."""
+    A = np.empty_like(J)
+    A[..., 0] = J[..., 4] * J[..., 8] - J[..., 7] * J[..., 5]
+    A[..., 3] = J[..., 7] * J[..., 2] - J[..., 1] * J[..., 8]
+    A[..., 6] = J[..., 1] * J[..., 5] - J[..., 4] * J[..., 2]
+    A[..., 1] = J[..., 6] * J[..., 5] - J[..., 3] * J[..., 8]
+    A[..., 4] = J[..., 0] * J[..., 8] - J[..., 6] * J[..., 2]
+    A[..., 7] = J[..., 3] * J[..., 2] - J[..., 0] * J[..., 5]
+    A[..., 2] = J[..., 3] * J[..., 7] - J[..., 6] * J[..., 4]
+    A[..., 5] = J[..., 6] * J[..., 1] - J[..., 0] * J[..., 7]
+    A[..., 8] = J[..., 0] * J[..., 4] - J[..., 3] * J[..., 1]
+    det = J[..., 0] * A[..., 0] + J[..., 1] * A[..., 1] + J[..., 2] * A[..., 2]
+    return A, det
+
+
+def mult_AtBCx33(A, B, C, x):
+    """utils_33_qf.h:64-84: y = A^T B C x, matrices [..., 9] column-major, x [..., 3]."""
+    y0 = C[..., 0] * x[..., 0] + C[..., 3] * x[..., 1] + C[..., 6] * x[..., 2]
+    y1 = C[..., 1] * x[..., 0] + C[..., 4] * x[..., 1] + C[..., 7] * x[..., 2]
+    y2 = C[..., 2] * x[..., 0] + C[..., 5] * x[..., 1] + C[..., 8] * x[..., 2]
+    z0 = B[..., 0] * y0 + B[..., 3] * y1 + B[..., 6] * y2
+    z1 = B[..., 1] * y0 + B[..., 4] * y1 + B[..., 7] * y2
+    z2 = B[..., 2] * y0 + B[..., 5] * y1 + B[..., 8] * y2
+    out = np.empty(np.broadcast_shapes(z0.shape, A[..., 0].shape) + (3,))
+    out[..., 0] = A[..., 0] * z0 + A[..., 1] * z1 + A[..., 2] * z2
+    out[..., 1] = A[..., 3] * z0 + A[..., 4] * z1 + A[..., 5] * z2
+    out[..., 2] = A[..., 6] * z0 + A[..., 7] * z1 + A[..., 8] * z2
+    return out
+
+
+def build_geom_factor_33(attr, qw, J):
+    """geom_33_qf.h:9-33.  attr [NE], qw [Q], J [NE, Q, 9] column-major (J[i+3j] = dx_i/dxi_j).
+    Returns geom [NE, 11, Q]: attr, w detJ, adj(J)^T / detJ."""
+    NE, Q = J.shape[0], J.shape[1]
+    A, det = adjJt33(J)
+    geom = np.empty((NE, 11, Q))
+    geom[:, 0, :] = attr[:, None]
+    geom[:, 1, :] = qw[None, :] * det
+    geom[:, 2:, :] = np.transpose(A / det[..., None], (0, 2, 1))
+    return geom
+
+
+class CoeffCtx:
+    """CeedIntScalar context (coeff_qf.h:7-45; packing coefficient.cpp:51-118):
+    [nattr][attr->mat (nattr)][nmat][nmat*9 doubles col-major]; 8-byte slots."""
+
+    def __init__(self, attr_mat=None, mat_coeff=None, a=1.0):
+        if attr_mat is None:  # no coefficient: identity scaled by a (coefficient.cpp:55-64)
+            self.attr_mat = np.zeros(0, dtype=np.int32)
+            self.mat = (a * np.eye(3)).reshape(1, 9)
+        else:
+            attr_mat = np.asarray(attr_mat, dtype=np.int32)
+            mats = [np.asarray(m, dtype=np.float64) for m in mat_coeff]
+            nmat = len(mats)
+            full = np.zeros((nmat + 1, 9))
+            for k, mk in enumerate(mats):
+                if mk.size == 1:
+                    full[k] = (a * float(mk.reshape(-1)[0]) * np.eye(3)).reshape(-1)
+                else:
+                    full[k] = (a * mk).reshape(3, 3).T.reshape(-1)  # column-major
+            self.attr_mat = np.where(attr_mat < 0, nmat, attr_mat).astype(np.int32)
+            self.mat = full
+
+    def pack(self) -> np.ndarray:
+        """The raw blob as 8-byte slots (ints in the low 4 bytes), returned as float64 view."""
+        nattr, nmat = self.attr_mat.size, self.mat.shape[0]
+        raw = np.zeros(2 + nattr + 9 * nmat, dtype=np.float64)
+        iv = raw.view(np.int32).reshape(-1, 2)
+        iv[0, 0] = nattr
+        iv[1 : 1 + nattr, 0] = self.attr_mat
+        iv[1 + nattr, 0] = nmat
+        raw[2 + nattr :] = self.mat.reshape(-1)
+        return raw
+
+    def unpack3(self, attr):
+        """CoeffUnpack3 (coeff_3_qf.h:9-24): attr (1-based ints) -> [..., 9]."""
+        if self.attr_mat.size > 0:
+            k = self.attr_mat[attr - 1]
+        else:
+            k = np.zeros_like(attr)
+        return self.mat[k]
+
+
+def pack_pair(ctx_mass: CoeffCtx, ctx: CoeffCtx) -> np.ndarray:
+    """coefficient.cpp:120-131: mass context first."""
+    return np.concatenate([ctx_mass.pack(), ctx.pack()])
+
+
+def apply_hcurl_33(ctx: CoeffCtx, geom, u):
+    """hcurl_33_qf.h:10-28.  geom [NE, 11, Q], u [NE, 3, Q] -> v [NE, 3, Q]."""
+    attr = geom[:, 0, :].astype(np.int32)
+    wdetJ = geom[:, 1, :]
+    adj = np.transpose(geom[:, 2:, :], (0, 2, 1))  # [NE, Q, 9]
+    C = ctx.unpack3(attr)
+    v = mult_AtBCx33(adj, C, adj, np.transpose(u, (0, 2, 1)))
+    return np.transpose(wdetJ[..., None] * v, (0, 2, 1))
+
+
+def apply_hdiv_33(ctx: CoeffCtx, geom, u):
+    """hdiv_33_qf.h:10-30: J/detJ = adj(adjJt)^T recomputed per point."""
+    attr = geom[:, 0, :].astype(np.int32)
+    wdetJ = geom[:, 1, :]
+    adj = np.transpose(geom[:, 2:, :], (0, 2, 1))
+    Jl, _ = adjJt33(adj)
+    C = ctx.unpack3(attr)
+    v = mult_AtBCx33(Jl, C, Jl, np.transpose(u, (0, 2, 1)))
+    return np.transpose(wdetJ[..., None] * v, (0, 2, 1))
+
+
+def apply_hdivmass_33(ctx_mass: CoeffCtx, ctx_curl: CoeffCtx, geom, u, curlu):
+    """hdivmass_33_qf.h:10-44 (mass coefficient first, then the curl-curl one)."""
+    return apply_hcurl_33(ctx_mass, geom, u), apply_hdiv_33(ctx_curl, geom, curlu)
+
+
+# ---------------------------------------------------------------------------------------------
+# Operator: E, B, D, B^T, E^T
+# ---------------------------------------------------------------------------------------------
+
+QF_HDIV, QF_HCURL, QF_HDIVMASS, QF_HCURLMASS, QF_H1MASS = "hdiv_33", "hcurl_33", "hdivmass_33", "hcurlmass_33", "h1_1"
+
+
+class CeedOperatorOracle:
+    """One libCEED sub-operator on one element block (one geometry x one integrator).
+
+    offsets [NE, P] int32, orients [NE, P] bool or None (CeedElemRestrictionCreateOriented),
+    interp / deriv dense tables, geom [NE, 11, Q], a QFunction name and its context(s).
+    """
+
+    def __init__(self, lsize, offsets, orients, interp, deriv, geom, qf, ctx, ctx2=None, vector_fe=True):
+        self.lsize = int(lsize)
+        self.off = np.asarray(offsets)
+        self.NE, self.P = self.off.shape
+        self.sgn = None if orients is None else np.where(np.asarray(orients), -1.0, 1.0)
+        self.Q = geom.shape[2]
+        self.vector_fe = vector_fe
+        if vector_fe:
+            self.interp = np.asarray(interp).reshape(3, self.Q, self.P)
+        else:
+            self.interp = np.asarray(interp).reshape(1, self.Q, self.P)
+        self.deriv = np.asarray(deriv).reshape(3, self.Q, self.P)
+        self.geom, self.qf, self.ctx, self.ctx2 = geom, qf, ctx, ctx2
+
+    def _restrict(self, x, sl):
+        u = x[self.off[sl]]
+        return u if self.sgn is None else u * self.sgn[sl]
+
+    def _qfunction(self, geom, ue):
+        """B, D, B^T on element-local vectors ue [ne, P] -> ve [ne, P]."""
+        qf = self.qf
+        if qf == QF_HDIV:      # curl-curl (integ/curlcurl.cpp:48-52,60-61)
+            cu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            cv = apply_hdiv_33(self.ctx, geom, cu)
+            return np.einsum("dqj,edq->ej", self.deriv, cv)
+        if qf == QF_HCURL and self.vector_fe:   # ND mass (integ/vecfemass.cpp)
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            v = apply_hcurl_33(self.ctx, geom, u)
+            return np.einsum("dqj,edq->ej", self.interp, v)
+        if qf == QF_HCURL:     # H1 diffusion: hcurl Piola on grad u (integ/diffusion.cpp)
+            gu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            gv = apply_hcurl_33(self.ctx, geom, gu)
+            return np.einsum("dqj,edq->ej", self.deriv, gv)
+        if qf == QF_HDIVMASS:  # curl-curl + mass (integ/curlcurlmass.cpp:41-45,55-64)
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            cu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            v, cv = apply_hdivmass_33(self.ctx, self.ctx2, geom, u, cu)
+            return np.einsum("dqj,edq->ej", self.interp, v) + np.einsum("dqj,edq->ej", self.deriv, cv)
+        if qf == QF_HCURLMASS:  # H1 diffusion + mass (hcurlmass_33_qf.h): mass ctx first
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            gu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            attr = geom[:, 0, :].astype(np.int32)
+            c = self.ctx.unpack3(attr)[..., 0]  # scalar mass coefficient (1x1)
+            v = (geom[:, 1, :] * c)[:, None, :] * u
+            gv = apply_hcurl_33(self.ctx2, geom, gu)
+            return np.einsum("dqj,edq->ej", self.interp, v) + np.einsum("dqj,edq->ej", self.deriv, gv)
+        if qf == QF_H1MASS:    # H1 mass (h1_1_qf.h): v = c wdetJ u
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            attr = geom[:, 0, :].astype(np.int32)
+            c = self.ctx.unpack3(attr)[..., 0]
+            v = (geom[:, 1, :] * c)[:, None, :] * u
+            return np.einsum("dqj,edq->ej", self.interp, v)
+        raise ValueError(qf)
+
+    def apply_add(self, x, y, chunk=2048):
+        """CeedOperatorApplyAdd."""
+        for a in range(0, self.NE, chunk):
+            sl = slice(a, min(self.NE, a + chunk))
+            ve = self._qfunction(self.geom[sl], self._restrict(x, sl))
+            if self.sgn is not None:
+                ve = ve * self.sgn[sl]
+            np.add.at(y, self.off[sl].ravel(), ve.ravel())
+        return y
+
+    def element_matrices(self, sl=slice(None)):
+        """A_e [ne, P, P] in native local order including orientation signs."""
+        ne = self.geom[sl].shape[0]
+        I = np.eye(self.P)
+        Ae = np.empty((ne, self.P, self.P))
+        for j in range(self.P):
+            Ae[:, :, j] = self._qfunction(self.geom[sl], np.broadcast_to(I[j], (ne, self.P)))
+        if self.sgn is not None:
+            s = self.sgn[sl]
+            Ae = Ae * s[:, :, None] * s[:, None, :]
+        return Ae
+
+    def assemble_sparse(self):
+        import scipy.sparse as sp
+
+        rows, cols, vals = [], [], []
+        for a in range(0, self.NE, 256):
+            sl = slice(a, min(self.NE, a + 256))
+            Ae = self.element_matrices(sl)
+            off = self.off[sl]
+            rows.append(np.repeat(off[:, :, None], self.P, axis=2).ravel())
+            cols.append(np.repeat(off[:, None, :], self.P, axis=1).ravel())
+            vals.append(Ae.ravel())
+        A = sp.coo_matrix(
+            (np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+            shape=(self.lsize, self.lsize),
+        )
+        return A.tocsr()
+
+    def diagonal(self):
+        """True diagonal of the assembled operator (libCEED's LinearAssembleAddDiagonal is exact
+        for oriented restrictions; reference operator.cpp:116-143)."""
+        d = np.zeros(self.lsize)
+        for a in range(0, self.NE, 256):
+            sl = slice(a, min(self.NE, a + 256))
+            Ae = self.element_matrices(sl)
+            np.add.at(d, self.off[sl].ravel(), np.einsum("ejj->ej", Ae).ravel())
+        return d
+
+
+# ---------------------------------------------------------------------------------------------
+# ParOperator boundary-condition logic (serial: P = identity)
+# ---------------------------------------------------------------------------------------------
+
+DIAG_ONE, DIAG_ZERO = 1, 0
+
+
+class ParOperatorOracle:
+    """rap.cpp:195-234 with a trivial prolongation (one rank)."""
+
+    def __init__(self, ops, ess, diag_policy=DIAG_ONE):
+        self.ops = list(ops)
+        self.ess = np.asarray(ess, dtype=np.int64)
+        self.policy = diag_policy
+        self.n = self.ops[0].lsize
+
+    def mult(self, x):
+        tx = x.copy()
+        tx[self.ess] = 0.0
+        y = np.zeros(self.n)
+        for op in self.ops:
+            op.apply_add(tx, y)
+        y[self.ess] = x[self.ess] if self.policy == DIAG_ONE else 0.0
+        return y
+
+    def diagonal(self):
+        d = np.zeros(self.n)
+        for op in self.ops:
+            d += op.diagonal()
+        d[self.ess] = 1.0 if self.policy == DIAG_ONE else 0.0
+        return d
+
+
+# ---------------------------------------------------------------------------------------------
+# Krylov loop
+# ---------------------------------------------------------------------------------------------
+
+def spectral_norm_power(mult, n, tol=1e-4, max_it=1000, seed=0, u0=None):
+    """linalg/operator.cpp:583-631 with herm=True."""
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1.0, 1.0, n) if u0 is None else u0.copy()
+    u /= np.linalg.norm(u)
+    l0 = 0.0
+    l = 0.0
+    it = 0
+    while it < max_it:
+        v = mult(u)
+        u = v
+        l = np.linalg.norm(u)
+        u = u / l
+        if it > 0 and abs(l - l0) / l0 < tol:
+            break
+        l0 = l
+        it += 1
+    return l
+
+
+class ChebyshevOracle:
+    """chebyshev.cpp:160-220 (4th kind)."""
+
+    def __init__(self, A, order, sf_max=1.0, lambda_max=None, u0=None):
+        self.A, self.order = A, order
+        self.dinv = 1.0 / A.diagonal()
+        if lambda_max is None:
+            lambda_max = spectral_norm_power(lambda u: self.dinv * A.mult(u), A.n, u0=u0)
+        self.lambda_max = sf_max * lambda_max
+
+    def mult2(self, x, y, initial_guess):
+        if initial_guess:
+            r = x - self.A.mult(y)
+        else:
+            r = x.copy()
+            y = np.zeros_like(x)
+        lam = self.lambda_max
+        d = 4.0 / (3.0 * lam) * self.dinv * r
+        for k in range(1, self.order):
+            y = y + d
+            r = r - self.A.mult(d)
+            sd = (2.0 * k - 1.0) / (2.0 * k + 3.0)
+            sr = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lam)
+            d = sd * d + sr * self.dinv * r
+        return y + d
+
+
+class GMGOracle:
+    """gmg.cpp:171-205.  A[l] ParOperatorOracle per level (0 = coarsest), P[l] prolongation
+    callables (mult, mult_transpose) from level l to l+1, B[l] smoothers, B[0] coarse solver
+    callable x -> y."""
+
+    def __init__(self, A, P, smoothers, coarse_solve, ess_lists):
+        self.A, self.P, self.B, self.coarse, self.ess = A, P, smoothers, coarse_solve, ess_lists
+
+    def vcycle(self, l, x, y, initial_guess):
+        if l == 0:
+            return self.coarse(x)
+        y = self.B[l].mult2(x, y, initial_guess)
+        r = x - self.A[l].mult(y)
+        xc = self.P[l - 1][1](r)
+        xc[self.ess[l - 1]] = 0.0
+        yc = self.vcycle(l - 1, xc, None, False)
+        y = y + self.P[l - 1][0](yc)
+        return self.B[l].mult2(x, y, True)
+
+    def mult(self, x):
+        return self.vcycle(len(self.A) - 1, x, None, False)
+
+
+def pcg(A_mult, b, B_mult=None, rel_tol=0.0, abs_tol=0.0, max_it=100):
+    """iterative.cpp:360-486, zero initial guess.  Returns (x, iterations, residual history)."""
+    x = np.zeros_like(b)
+    r = b.copy()
+    z = B_mult(r) if B_mult else r.copy()
+    beta = float(z @ r)
+    res = np.sqrt(abs(beta))
+    initial_res = res
+    eps = max(rel_tol * initial_res, abs_tol)
+    hist = [res]
+    it = 0
+    converged = res < eps
+    beta_prev = 0.0
+    p = None
+    while it < max_it and not converged:
+        p = z.copy() if it == 0 else z + (beta / beta_prev) * p
+        z = A_mult(p)
+        denom = float(z @ p)
+        alpha = beta / denom
+        x = x + alpha * p
+        r = r - alpha * z
+        beta_prev = beta
+        z = B_mult(r) if B_mult else r.copy()
+        beta = float(z @ r)
+        res = np.sqrt(abs(beta))
+        hist.append(res)
+        converged = res < eps
+        it += 1
+    return x, it, hist
