@@ -1,0 +1,168 @@
+/*
+ * palace_amd.h — C ABI of the MI355X-native partial-assembly operator library (libpalace_amd.so).
+ *
+ * This is the drop-in boundary for Palace's libCEED glue: every entry point replaces one libCEED
+ * call sequence that `palace/fem/libceed/` issues today.  Citations are file:line in the
+ * reference tree (awslabs/palace).  Rules of the ABI:
+ *   - plain C: pointers, sizes, enums; no C++/torch/mfem types; no exceptions cross it;
+ *   - every function returns 0 on success, non-zero on error; the message is retrieved with
+ *     pa_last_error() (reference convention: int codes + CeedGetErrorMessage, libceed/ceed.hpp:13-33);
+ *   - descriptor arrays are HOST pointers and are copied at creation (the reference passes
+ *     CEED_COPY_VALUES: restriction.cpp:195,367, integrator.cpp:447-448);
+ *   - x / y vectors are DEVICE pointers owned by the caller, never copied (CEED_USE_POINTER,
+ *     operator.cpp:170-176); work is enqueued on the hipStream_t passed as `void *stream` and is
+ *     asynchronous with respect to the host;
+ *   - one apply at a time per operator (the reference's Mult is not re-entrant either,
+ *     operator.hpp:38).
+ */
+#ifndef PALACE_AMD_H
+#define PALACE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pa_geom pa_geom; /* ceed::CeedGeomFactorData, fem/mesh.hpp:27-69 (shared, ref-counted) */
+typedef struct pa_op pa_op;     /* palace::ceed::Operator,   fem/libceed/operator.hpp:32-65           */
+
+/* Evaluation-mode bitmask, identical to palace::ceed::EvalMode (fem/libceed/integrator.hpp:15-23). */
+enum pa_eval_mode {
+  PA_EVAL_WEIGHT = 1 << 0,
+  PA_EVAL_NONE = 1 << 1,
+  PA_EVAL_INTERP = 1 << 2,
+  PA_EVAL_GRAD = 1 << 3,
+  PA_EVAL_DIV = 1 << 4,
+  PA_EVAL_CURL = 1 << 5
+};
+
+/* QFunctions (the pointwise D stage).  Each id names the reference QFunction it reproduces. */
+enum pa_qfunction {
+  PA_QF_HDIV_33 = 0,      /* f_apply_hdiv_33      fem/qfunctions/33/hdiv_33_qf.h:10-30      curl-curl        */
+  PA_QF_HCURL_33 = 1,     /* f_apply_hcurl_33     fem/qfunctions/33/hcurl_33_qf.h:10-28     ND mass, H1 diffusion */
+  PA_QF_HDIVMASS_33 = 2,  /* f_apply_hdivmass_33  fem/qfunctions/33/hdivmass_33_qf.h:10-44  curl-curl + mass */
+  PA_QF_HCURLMASS_33 = 3, /* f_apply_hcurlmass_33 fem/qfunctions/33/hcurlmass_33_qf.h       H1 diffusion + mass */
+  PA_QF_H1_1 = 4          /* f_apply_h1_1         fem/qfunctions/1/h1_1_qf.h                H1 mass          */
+};
+
+enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1 };
+
+/*
+ * Element restriction E — what Palace hands to CeedElemRestrictionCreate / ...CreateOriented
+ * (fem/libceed/restriction.cpp:364-383 native, :192-203 lexicographic).
+ *   offsets[j + elem_size*e] : L-vector index of local dof j of element e (native local order)
+ *   orients[j + elem_size*e] : non-zero => u_e[j] = -x[offset]  (may be NULL: no flips)
+ */
+typedef struct {
+  int32_t num_elem;
+  int32_t elem_size;
+  int32_t lsize;
+  const int32_t *offsets;
+  const uint8_t *orients;
+} pa_restriction_desc;
+
+/*
+ * Basis B/G on tensor-product hexahedra.  Palace gives libCEED the dense DofToQuad::FULL tables
+ * for vector elements (fem/libceed/basis.cpp:40-85) and 1-D tables for scalar tensor elements
+ * (:15-38).  The same MFEM element also provides its 1-D closed/open tables
+ * (VectorTensorFiniteElement::GetDofToQuad / GetDofToQuadOpen) and its lexicographic->native map
+ * (TensorBasisElement::GetDofMap()); this library takes those and uses sum factorisation, so the
+ * apply stays HBM-bound instead of dense-GEMM-bound.  The dense tables are optional: when given
+ * they are checked at creation against the Kronecker product of the 1-D tables (max-norm 1e-12).
+ *
+ *   order      p.  HCURL: P = 3 p (p+1)^2 ; H1: P = (p+1)^3
+ *   q1d        quadrature points per direction, Q = q1d^3, point index q = qx + q1d (qy + q1d qz)
+ *   Bc, Gc     closed (Gauss-Lobatto) basis values / derivatives at the 1-D points, [q1d][p+1]
+ *   Bo         open (Gauss-Legendre) basis values, [q1d][p]           (HCURL only)
+ *   dof_map    [P] tensor index -> native local index, negative value -1-n = native n with flipped
+ *              sign; NULL = identity (H1 lexicographic restriction, restriction.cpp:134-136)
+ *   Tensor index of HCURL dofs: x-block i + p (j + (p+1) k), then y-block i + (p+1)(j + p k), then
+ *   z-block i + (p+1)(j + (p+1) k), the open direction having p entries.
+ *   interp     optional dense [qcomp*Q][P] (native dof order), deriv optional dense curl/grad [3*Q][P]
+ */
+typedef struct {
+  int32_t fe_type;
+  int32_t order;
+  int32_t q1d;
+  const double *Bc;
+  const double *Gc;
+  const double *Bo;
+  const int32_t *dof_map;
+  const double *interp;
+  const double *deriv;
+} pa_basis_desc;
+
+/*
+ * Mesh geometry — what fem/mesh.cpp:146-209 hands to AssembleCeedGeometryData
+ * (fem/libceed/integrator.cpp:335-421): nodal coordinates of a tensor H1 mesh space of order
+ * `mesh_order` (2 for the 27-node hexes), its element restriction, its 1-D tables at the
+ * quadrature points, the quadrature weights and the per-element (1-based, local) attribute.
+ *   node_offsets[n + npe*e]  node id of lattice node n = i + (mesh_order+1) (j + (mesh_order+1) k)
+ *   nodes[3*id + c]          coordinate c of node id (byVDIM ordering)
+ *   mesh_B, mesh_G           [q1d][mesh_order+1] nodal basis values / derivatives at the 1-D points
+ *   qweight1d                [q1d]; the point weight is the product of the three 1-D weights
+ */
+typedef struct {
+  int32_t num_elem;
+  int32_t mesh_order;
+  int32_t q1d;
+  int32_t num_nodes;
+  const int32_t *node_offsets;
+  const double *nodes;
+  const int32_t *attr;
+  const double *mesh_B;
+  const double *mesh_G;
+  const double *qweight1d;
+} pa_mesh_desc;
+
+/* --- library ------------------------------------------------------------------------------- */
+const char *pa_last_error(void);
+const char *pa_version(void);
+/* Number of visible HIP devices (0 => none; every compute entry point then fails loudly). */
+int pa_device_count(void);
+
+/* --- geometry factors: replaces AssembleCeedGeometryData + f_build_geom_factor_33
+ *     (fem/libceed/integrator.cpp:335-421, fem/qfunctions/33/geom_33_qf.h:9-33).
+ *     Result: double[num_elem][11][Q] = {attr, w detJ, adj(J)^T/detJ (col-major)} in HBM. */
+int pa_geom_create(const pa_mesh_desc *mesh, void *stream, pa_geom **geom);
+int pa_geom_retain(pa_geom *geom);
+void pa_geom_destroy(pa_geom *geom);
+/* Device pointer to the geometry data and its length in doubles (tests / diagnostics). */
+int pa_geom_data(const pa_geom *geom, const double **dev_ptr, size_t *count);
+
+/* --- operator: replaces ceed::Operator (fem/libceed/operator.cpp) ---------------------------- */
+/* Operator::Operator(h, w), operator.cpp:17-42. */
+int pa_op_create(int32_t height, int32_t width, pa_op **op);
+/* AddSubOperator(AssembleCeedOperator(info, ctx, ...)) — operator.cpp:60-87 +
+ * fem/libceed/integrator.cpp:423-513.  `ctx` is the CeedIntScalar blob Palace packs in
+ * fem/libceed/coefficient.cpp:51-131 (8-byte slots; pair contexts: mass first).  trial_ops /
+ * test_ops are pa_eval_mode masks and must be what the reference integrator sets for this
+ * QFunction (e.g. Curl|Interp for PA_QF_HDIVMASS_33, fem/integ/curlcurlmass.cpp:55-56). */
+int pa_op_add_sub(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
+                  const pa_basis_desc *basis, int32_t qfunction, const void *ctx, size_t ctx_size,
+                  uint32_t trial_ops, uint32_t test_ops);
+/* Operator::Finalize(), operator.cpp:89-101. */
+int pa_op_finalize(pa_op *op);
+/* CeedOperatorCoarsen (operator.cpp:525-585): same QFunctions, contexts and geometry data as
+ * `fine`, coarse restriction + basis.  `fine` must have a single element block. */
+int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_basis_desc *basis,
+                  pa_op **coarse);
+/* Operator::AddMult with a == 1 (operator.cpp:192-212): y += A x on L-vectors (device pointers). */
+int pa_op_apply_add(pa_op *op, const double *x, double *y, void *stream);
+/* Operator::Mult (operator.cpp:182-190): y = A x. */
+int pa_op_mult(pa_op *op, const double *x, double *y, void *stream);
+/* Operator::AssembleDiagonal (operator.cpp:116-143): diag = diag(A) (zeroed first). */
+int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream);
+int pa_op_height(const pa_op *op);
+int pa_op_width(const pa_op *op);
+/* Algorithmic HBM bytes of one apply_add by SURVEY.md 8(d)'s formula
+ * NE (Q G 8 + P (4 + o)) + 16 N_L with G = 11, o = 1. */
+double pa_op_algorithmic_bytes(const pa_op *op);
+void pa_op_destroy(pa_op *op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PALACE_AMD_H */

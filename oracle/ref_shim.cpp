@@ -1,0 +1,16 @@
+// Build recipe input for oracle/_ref/libpalace_qf_ref.so: compiles the reference's own QFunction
+// headers *where they lie* under /root/reference/palace (nothing is copied into this repo).
+// The five macros below are what libCEED's <ceed/types.h> would provide; everything else is the
+// reference's code.  TEST INFRASTRUCTURE ONLY (validates oracle/palace_oracle.py and oracle_c.c).
+#include <cstdint>
+typedef int32_t CeedInt;
+typedef double CeedScalar;
+#define CEED_QFUNCTION(name) extern "C" int name
+#define CEED_QFUNCTION_HELPER static inline
+#define CeedPragmaSIMD
+#include "fem/qfunctions/33/geom_33_qf.h"
+#include "fem/qfunctions/33/hcurl_33_qf.h"
+#include "fem/qfunctions/33/hdiv_33_qf.h"
+#include "fem/qfunctions/33/hdivmass_33_qf.h"
+#include "fem/qfunctions/33/hcurlmass_33_qf.h"
+#include "fem/qfunctions/1/h1_1_qf.h"

@@ -1,0 +1,213 @@
+"""Host-side mirror of `palace::ceed::Operator` / `BilinearForm::PartialAssemble` over the C ABI.
+
+Reference: palace/fem/libceed/operator.hpp:32-65 (Mult / AddMult / AssembleDiagonal on L-vectors),
+palace/fem/bilinearform.cpp:27-107 (loop over geometries x integrators adding sub-operators),
+palace/fem/integ/{curlcurl,vecfemass,curlcurlmass}.cpp (QFunction + eval modes + context per
+integrator), palace/fem/libceed/coefficient.cpp:51-131 (context packing).
+
+Vectors are float64 torch tensors on the GPU; torch is only the owner of device memory and the
+stream — every FLOP happens in libpalace_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .fem.basis1d import Tables1D
+from .fem.fespace import H1HexSpace, NDHexSpace
+from .fem.mesh import HexMesh, _q2_1d
+
+QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1 = range(5)
+EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
+FE_H1, FE_HCURL = 0, 1
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def coefficient_context(dim, attr_mat=None, mat_coeff=None, a=1.0):
+    """PopulateCoefficientContext (coefficient.cpp:51-118) -> 8-byte-slot blob (float64 view).
+
+    attr_mat[i] = material index of (1-based) attribute i+1, negative = unassigned (zero);
+    mat_coeff[k] = scalar or dim x dim matrix.  attr_mat=None: identity scaled by a."""
+    d2 = dim * dim
+    if attr_mat is None:
+        raw = np.zeros(2 + d2)
+        iv = raw.view(np.int32).reshape(-1, 2)
+        iv[0, 0], iv[1, 0] = 0, 1
+        raw[2:] = (a * np.eye(dim)).reshape(-1)
+        return raw
+    attr_mat = np.asarray(attr_mat, dtype=np.int32)
+    nmat = len(mat_coeff)
+    raw = np.zeros(2 + attr_mat.size + d2 * (nmat + 1))
+    iv = raw.view(np.int32).reshape(-1, 2)
+    iv[0, 0] = attr_mat.size
+    iv[1 : 1 + attr_mat.size, 0] = np.where(attr_mat < 0, nmat, attr_mat)
+    iv[1 + attr_mat.size, 0] = nmat + 1
+    base = 2 + attr_mat.size
+    for k, m in enumerate(mat_coeff):
+        m = np.asarray(m, dtype=np.float64)
+        full = a * float(m.reshape(-1)[0]) * np.eye(dim) if m.size == 1 else a * m.reshape(dim, dim)
+        raw[base + d2 * k : base + d2 * (k + 1)] = full.T.reshape(-1)  # column-major
+    return raw
+
+
+class GeomFactorData:
+    """ceed::CeedGeomFactorData (fem/mesh.hpp:27-69) for one hex block, built on the device."""
+
+    def __init__(self, mesh: HexMesh, q1d: int):
+        from .fem.basis1d import gauss_legendre
+
+        self.mesh, self.q1d = mesh, q1d
+        qx, qw = gauss_legendre(q1d)
+        B, G = _q2_1d(qx)
+        self._keep = dict(
+            off=np.ascontiguousarray(mesh.elem_nodes, dtype=np.int32),
+            nodes=np.ascontiguousarray(mesh.x, dtype=np.float64),
+            attr=np.ascontiguousarray(mesh.attr, dtype=np.int32),
+            B=np.ascontiguousarray(B), G=np.ascontiguousarray(G), w=np.ascontiguousarray(qw))
+        k = self._keep
+        desc = _lib.MeshDesc(mesh.ne, 2, q1d, mesh.x.shape[0], _ptr(k["off"]), _ptr(k["nodes"]),
+                             _ptr(k["attr"]), _ptr(k["B"]), _ptr(k["G"]), _ptr(k["w"]))
+        self.handle = C.c_void_p()
+        L = _lib.load()
+        _lib.check(L.pa_geom_create(C.byref(desc), _stream(), C.byref(self.handle)))
+        self.Q = q1d**3
+
+    def to_numpy(self):
+        """Copy the [ne][11][Q] geometry data back (tests / diagnostics)."""
+        import torch
+
+        L = _lib.load()
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(L.pa_geom_data(self.handle, C.byref(p), C.byref(n)))
+
+        class _View:  # device memory owned by the library, exposed through the array interface
+            __cuda_array_interface__ = dict(shape=(n.value,), typestr="<f8", data=(p.value, True), version=2)
+
+        torch.cuda.synchronize()
+        return torch.as_tensor(_View(), device="cuda").cpu().numpy().reshape(self.mesh.ne, 11, self.Q)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().pa_geom_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _basis_desc(space, q1d, dense=None):
+    p = space.p
+    t = Tables1D(p, q1d)
+    keep = dict(Bc=np.ascontiguousarray(t.Bc), Gc=np.ascontiguousarray(t.Gc),
+                Bo=np.ascontiguousarray(t.Bo))
+    if isinstance(space, NDHexSpace):
+        keep["dof_map"] = np.ascontiguousarray(space.dof_map_native(), dtype=np.int32)
+        fe = FE_HCURL
+    else:
+        keep["dof_map"] = None
+        fe = FE_H1
+    interp = deriv = None
+    if dense is not None:
+        keep["interp"] = interp = np.ascontiguousarray(dense[0])
+        keep["deriv"] = deriv = np.ascontiguousarray(dense[1])
+    desc = _lib.BasisDesc(fe, p, q1d, _ptr(keep["Bc"]), _ptr(keep["Gc"]), _ptr(keep["Bo"]),
+                          _ptr(keep["dof_map"]), _ptr(interp), _ptr(deriv))
+    return desc, keep
+
+
+def _restriction_desc(space):
+    if isinstance(space, NDHexSpace):
+        off, ori = space.native_restriction()
+        keep = dict(off=np.ascontiguousarray(off, dtype=np.int32),
+                    ori=np.ascontiguousarray(ori, dtype=np.uint8))
+    else:
+        keep = dict(off=np.ascontiguousarray(space.elem_dof_lex, dtype=np.int32), ori=None)
+    desc = _lib.RestrictionDesc(space.mesh.ne, space.P, space.ndofs, _ptr(keep["off"]), _ptr(keep["ori"]))
+    return desc, keep
+
+
+class Operator:
+    """palace::ceed::Operator: a sum of partially assembled sub-operators on L-vectors."""
+
+    def __init__(self, height, width, handle=None):
+        self.height, self.width = height, width
+        self.handle = C.c_void_p() if handle is None else handle
+        if handle is None:
+            _lib.check(_lib.load().pa_op_create(height, width, C.byref(self.handle)))
+
+    def add_integrator(self, geom: GeomFactorData, space, qf, ctx_blob, ops, dense=None):
+        r, k1 = _restriction_desc(space)
+        b, k2 = _basis_desc(space, geom.q1d, dense)
+        ctx = np.ascontiguousarray(ctx_blob)
+        _lib.check(_lib.load().pa_op_add_sub(self.handle, geom.handle, C.byref(r), C.byref(b),
+                                             C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes),
+                                             C.c_uint32(ops), C.c_uint32(ops)))
+        return self
+
+    def finalize(self):
+        _lib.check(_lib.load().pa_op_finalize(self.handle))
+        return self
+
+    def coarsen(self, geom: GeomFactorData, space_coarse):
+        """CeedOperatorCoarsen (operator.cpp:525-585)."""
+        r, k1 = _restriction_desc(space_coarse)
+        b, k2 = _basis_desc(space_coarse, geom.q1d)
+        h = C.c_void_p()
+        _lib.check(_lib.load().pa_op_coarsen(self.handle, C.byref(r), C.byref(b), C.byref(h)))
+        return Operator(space_coarse.ndofs, space_coarse.ndofs, handle=h)
+
+    def mult(self, x, y):
+        _lib.check(_lib.load().pa_op_mult(self.handle, C.c_void_p(x.data_ptr()),
+                                          C.c_void_p(y.data_ptr()), _stream()))
+        return y
+
+    def add_mult(self, x, y, a=1.0):
+        if a != 1.0:  # operator.cpp:194
+            raise _lib.PalaceAmdError("ceed::Operator::AddMult only supports coefficient = 1.0!")
+        _lib.check(_lib.load().pa_op_apply_add(self.handle, C.c_void_p(x.data_ptr()),
+                                               C.c_void_p(y.data_ptr()), _stream()))
+        return y
+
+    def assemble_diagonal(self, diag):
+        _lib.check(_lib.load().pa_op_assemble_diagonal(self.handle, C.c_void_p(diag.data_ptr()), _stream()))
+        return diag
+
+    def algorithmic_bytes(self):
+        return _lib.load().pa_op_algorithmic_bytes(self.handle)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().pa_op_destroy(self.handle)
+        except Exception:
+            pass
+
+
+# ---- the integrators of the hot path (fem/integ/*.cpp) ----------------------------------------
+
+def curlcurl_operator(geom, nd: NDHexSpace, ctx_curl, dense=None):
+    """CurlCurlIntegrator (fem/integ/curlcurl.cpp:23-75): f_apply_hdiv_33, Curl/Curl."""
+    return Operator(nd.ndofs, nd.ndofs).add_integrator(geom, nd, QF_HDIV_33, ctx_curl, EVAL_CURL, dense).finalize()
+
+
+def ndmass_operator(geom, nd: NDHexSpace, ctx_mass, dense=None):
+    """VectorFEMassIntegrator (fem/integ/vecfemass.cpp): f_apply_hcurl_33, Interp/Interp."""
+    return Operator(nd.ndofs, nd.ndofs).add_integrator(geom, nd, QF_HCURL_33, ctx_mass, EVAL_INTERP, dense).finalize()
+
+
+def curlcurlmass_operator(geom, nd: NDHexSpace, ctx_mass, ctx_curl, dense=None):
+    """CurlCurlMassIntegrator (fem/integ/curlcurlmass.cpp:16-68): f_apply_hdivmass_33; the paired
+    context is mass first, then curl-curl (coefficient.cpp:120-131)."""
+    ctx = np.concatenate([ctx_mass, ctx_curl])
+    return Operator(nd.ndofs, nd.ndofs).add_integrator(
+        geom, nd, QF_HDIVMASS_33, ctx, EVAL_CURL | EVAL_INTERP, dense).finalize()

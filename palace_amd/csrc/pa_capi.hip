@@ -1,0 +1,378 @@
+// C ABI of libpalace_amd.so (declared in include/palace_amd.h): object lifetime, descriptor
+// validation and set-up on the host; all arithmetic lives in the HIP kernels.
+#include <cmath>
+#include <cstring>
+
+#include "pa_internal.hpp"
+
+namespace pa {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+static void require_device() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    throw Error("no HIP device visible: libpalace_amd has no CPU fallback");
+}
+
+// coeff_qf.h:7-45 — [nattr][attr->mat ...][nmat][nmat*dim*dim doubles]; 8-byte slots.
+void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t slot_offset) {
+  const size_t nslots = bytes / 8;
+  const unsigned char *base = static_cast<const unsigned char *>(blob);
+  auto slot_int = [&](size_t i) {
+    PA_REQUIRE(slot_offset + i < nslots, "coefficient context truncated");
+    int32_t v;
+    std::memcpy(&v, base + 8 * (slot_offset + i), 4);
+    return v;
+  };
+  auto slot_dbl = [&](size_t i) {
+    PA_REQUIRE(slot_offset + i < nslots, "coefficient context truncated");
+    double v;
+    std::memcpy(&v, base + 8 * (slot_offset + i), 8);
+    return v;
+  };
+  const int nattr = slot_int(0);
+  PA_REQUIRE(nattr >= 0, "negative attribute count in coefficient context");
+  out.attr_mat.resize(nattr);
+  for (int i = 0; i < nattr; i++) out.attr_mat[i] = slot_int(1 + i);
+  const int nmat = slot_int(1 + nattr);
+  PA_REQUIRE(nmat > 0, "coefficient context without materials");
+  out.dim = dim;
+  out.mat.resize((size_t)nmat * dim * dim);
+  for (size_t i = 0; i < out.mat.size(); i++) out.mat[i] = slot_dbl(2 + nattr + i);
+  for (int i = 0; i < nattr; i++)
+    PA_REQUIRE(out.attr_mat[i] >= 0 && out.attr_mat[i] < nmat, "attribute maps to missing material");
+  out.slots = 2 + nattr + out.mat.size();
+  out.d_attr_mat = nattr ? dev_upload(out.attr_mat.data(), (size_t)nattr) : nullptr;
+  out.d_mat = dev_upload(out.mat.data(), out.mat.size());
+}
+
+static int expected_P(int fe_type, int p) {
+  return fe_type == PA_FE_HCURL ? 3 * p * (p + 1) * (p + 1) : (p + 1) * (p + 1) * (p + 1);
+}
+
+// Dense table of the tensor element (native dof order) from the 1-D tables, to validate what the
+// caller passed as DofToQuad::FULL data (basis.cpp:43-83).
+static void check_dense_tables(const pa_basis_desc &b, int P, int Q) {
+  if (!b.interp && !b.deriv) return;
+  const int p = b.order, q1 = b.q1d, nc = p + 1;
+  auto nat = [&](int l, double &sgn) {
+    int n = b.dof_map ? b.dof_map[l] : l;
+    sgn = 1.0;
+    if (n < 0) n = -1 - n, sgn = -1.0;
+    return n;
+  };
+  double worst = 0.0;
+  if (b.fe_type == PA_FE_HCURL) {
+    for (int C = 0; C < 3; C++) {
+      const int ni = C == 0 ? p : nc, nj = C == 1 ? p : nc, nk = C == 2 ? p : nc;
+      const double *TX = C == 0 ? b.Bo : b.Bc, *TY = C == 1 ? b.Bo : b.Bc, *TZ = C == 2 ? b.Bo : b.Bc;
+      for (int k = 0; k < nk; k++)
+        for (int j = 0; j < nj; j++)
+          for (int i = 0; i < ni; i++) {
+            double sgn;
+            const int n = nat(C * p * nc * nc + i + ni * (j + nj * k), sgn);
+            for (int qz = 0; qz < q1; qz++)
+              for (int qy = 0; qy < q1; qy++)
+                for (int qx = 0; qx < q1; qx++) {
+                  const int q = qx + q1 * (qy + q1 * qz);
+                  const double bx = TX[qx * ni + i], by = TY[qy * nj + j], bz = TZ[qz * nk + k];
+                  const double gx = C == 0 ? 0 : b.Gc[qx * nc + i], gy = C == 1 ? 0 : b.Gc[qy * nc + j],
+                               gz = C == 2 ? 0 : b.Gc[qz * nc + k];
+                  const double f = sgn * bx * by * bz;
+                  const double dx = sgn * gx * by * bz, dy = sgn * bx * gy * bz, dz = sgn * bx * by * gz;
+                  double val[3] = {0, 0, 0}, cv[3];
+                  val[C] = f;
+                  if (C == 0) cv[0] = 0, cv[1] = dz, cv[2] = -dy;
+                  if (C == 1) cv[0] = -dz, cv[1] = 0, cv[2] = dx;
+                  if (C == 2) cv[0] = dy, cv[1] = -dx, cv[2] = 0;
+                  for (int d = 0; d < 3; d++) {
+                    if (b.interp) worst = std::fmax(worst, std::fabs(b.interp[((size_t)d * Q + q) * P + n] - val[d]));
+                    if (b.deriv) worst = std::fmax(worst, std::fabs(b.deriv[((size_t)d * Q + q) * P + n] - cv[d]));
+                  }
+                }
+          }
+    }
+  } else {
+    for (int k = 0; k < nc; k++)
+      for (int j = 0; j < nc; j++)
+        for (int i = 0; i < nc; i++) {
+          double sgn;
+          const int n = nat(i + nc * (j + nc * k), sgn);
+          for (int qz = 0; qz < q1; qz++)
+            for (int qy = 0; qy < q1; qy++)
+              for (int qx = 0; qx < q1; qx++) {
+                const int q = qx + q1 * (qy + q1 * qz);
+                const double bx = b.Bc[qx * nc + i], by = b.Bc[qy * nc + j], bz = b.Bc[qz * nc + k];
+                const double gx = b.Gc[qx * nc + i], gy = b.Gc[qy * nc + j], gz = b.Gc[qz * nc + k];
+                if (b.interp) worst = std::fmax(worst, std::fabs(b.interp[(size_t)q * P + n] - bx * by * bz));
+                if (b.deriv) {
+                  const double gr[3] = {gx * by * bz, bx * gy * bz, bx * by * gz};
+                  for (int d = 0; d < 3; d++)
+                    worst = std::fmax(worst, std::fabs(b.deriv[((size_t)d * Q + q) * P + n] - gr[d]));
+                }
+              }
+        }
+  }
+  if (!(worst < 1e-10))
+    throw Error("dense basis table does not match the tensor product of the 1-D tables (max diff " +
+                std::to_string(worst) + ")");
+}
+
+static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_basis_desc &b, int qf,
+                       const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops) {
+  require_device();
+  PA_REQUIRE(geom && geom->d_geom, "geometry data missing");
+  PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_H1, "unknown finite element type");
+  PA_REQUIRE(b.order >= 1 && b.order + 1 <= kMaxP1 + 1, "unsupported element order");
+  PA_REQUIRE(b.q1d == geom->q1d, "basis and geometry data use different quadrature rules");
+  PA_REQUIRE(b.Bc && b.Gc && (b.fe_type == PA_FE_H1 || b.Bo), "1-D basis tables missing");
+  PA_REQUIRE(r.num_elem == geom->ne, "restriction and geometry data disagree on element count");
+  const int P = expected_P(b.fe_type, b.order);
+  PA_REQUIRE(r.elem_size == P, "restriction element size does not match the basis");
+  PA_REQUIRE(r.offsets, "restriction offsets missing");
+  PA_REQUIRE(trial_ops == test_ops, "only symmetric trial/test evaluation modes are supported");
+  uint32_t want = 0;
+  switch (qf) {
+    case PA_QF_HDIV_33: want = PA_EVAL_CURL; break;
+    case PA_QF_HCURL_33: want = b.fe_type == PA_FE_HCURL ? PA_EVAL_INTERP : PA_EVAL_GRAD; break;
+    case PA_QF_HDIVMASS_33: want = PA_EVAL_CURL | PA_EVAL_INTERP; break;
+    case PA_QF_HCURLMASS_33: want = PA_EVAL_GRAD | PA_EVAL_INTERP; break;
+    case PA_QF_H1_1: want = PA_EVAL_INTERP; break;
+    default: throw Error("unknown QFunction id");
+  }
+  PA_REQUIRE(trial_ops == want, "evaluation modes do not match the QFunction's inputs");
+  const bool nd_qf = qf == PA_QF_HDIV_33 || qf == PA_QF_HDIVMASS_33 ||
+                     (qf == PA_QF_HCURL_33 && b.fe_type == PA_FE_HCURL);
+  PA_REQUIRE(nd_qf == (b.fe_type == PA_FE_HCURL), "QFunction does not match the element type");
+
+  auto *so = new SubOp;
+  so->geom = geom;
+  geom->refcount++;
+  so->fe_type = b.fe_type, so->p = b.order, so->q1d = b.q1d, so->P = P, so->Q = geom->Q;
+  so->ne = r.num_elem, so->lsize = r.lsize, so->qf = qf;
+  so->trial_ops = trial_ops, so->test_ops = test_ops;
+  const int nc = b.order + 1;
+  so->Bc.assign(b.Bc, b.Bc + b.q1d * nc);
+  so->Gc.assign(b.Gc, b.Gc + b.q1d * nc);
+  if (b.Bo) so->Bo.assign(b.Bo, b.Bo + b.q1d * b.order);
+  check_dense_tables(b, P, geom->Q);
+
+  // signed tensor-order index array (restriction.cpp:290-296 semantics folded with dof_map)
+  std::vector<int32_t> lidx((size_t)r.num_elem * P);
+  std::vector<char> seen(P);
+  for (int l = 0; l < P; l++) {
+    int n = b.dof_map ? b.dof_map[l] : l;
+    if (n < 0) n = -1 - n;
+    PA_REQUIRE(n >= 0 && n < P && !seen[n], "dof_map is not a signed permutation");
+    seen[n] = 1;
+  }
+  for (int e = 0; e < r.num_elem; e++)
+    for (int l = 0; l < P; l++) {
+      int n = b.dof_map ? b.dof_map[l] : l;
+      bool neg = false;
+      if (n < 0) n = -1 - n, neg = true;
+      const size_t k = (size_t)e * P + n;
+      const int32_t off = r.offsets[k];
+      PA_REQUIRE(off >= 0 && off < r.lsize, "restriction offset out of range");
+      if (r.orients && r.orients[k]) neg = !neg;
+      lidx[(size_t)e * P + l] = neg ? -1 - off : off;
+    }
+  so->d_lidx = dev_upload(lidx.data(), lidx.size());
+
+  so->ctx_blob.assign((const uint8_t *)ctx, (const uint8_t *)ctx + ctx_size);
+  PA_REQUIRE(ctx && ctx_size >= 24 && ctx_size % 8 == 0, "coefficient context missing or malformed");
+  switch (qf) {
+    case PA_QF_HDIV_33:
+    case PA_QF_HCURL_33:
+      parse_coeff(ctx, ctx_size, 3, so->c0, 0);
+      break;
+    case PA_QF_HDIVMASS_33:
+      parse_coeff(ctx, ctx_size, 3, so->c0, 0);
+      parse_coeff(ctx, ctx_size, 3, so->c1, so->c0.slots);
+      break;
+    case PA_QF_HCURLMASS_33:
+      parse_coeff(ctx, ctx_size, 1, so->c0, 0);
+      parse_coeff(ctx, ctx_size, 3, so->c1, so->c0.slots);
+      break;
+    case PA_QF_H1_1:
+      parse_coeff(ctx, ctx_size, 1, so->c0, 0);
+      break;
+  }
+  return so;
+}
+
+static void free_sub(SubOp *so) {
+  if (!so) return;
+  hipFree(so->d_lidx);
+  hipFree(so->c0.d_attr_mat), hipFree(so->c0.d_mat);
+  hipFree(so->c1.d_attr_mat), hipFree(so->c1.d_mat);
+  pa_geom_destroy(static_cast<pa_geom *>(so->geom));
+  delete so;
+}
+
+static void apply_add(pa_op *op, const double *x, double *y, hipStream_t s) {
+  PA_REQUIRE(op && x && y, "null argument");
+  PA_REQUIRE(!op->subs.empty(), "operator has no sub-operators");
+  for (const SubOp *so : op->subs) {
+    if (so->fe_type == PA_FE_HCURL)
+      launch_nd_hex_apply(*so, x, y, s);
+    else
+      launch_h1_hex_apply(*so, x, y, s);
+  }
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+extern "C" {
+
+const char *pa_last_error(void) { return g_error.c_str(); }
+
+const char *pa_version(void) { return "palace_amd 0.1 (gfx950)"; }
+
+int pa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pa_geom_create(const pa_mesh_desc *mesh, void *stream, pa_geom **geom) {
+  return guarded([&] {
+    require_device();
+    PA_REQUIRE(mesh && geom, "null argument");
+    PA_REQUIRE(mesh->num_elem > 0 && mesh->mesh_order >= 1 && mesh->q1d >= 1 && mesh->q1d <= kMaxQ1,
+               "bad mesh descriptor");
+    PA_REQUIRE(mesh->node_offsets && mesh->nodes && mesh->attr && mesh->mesh_B && mesh->mesh_G &&
+                   mesh->qweight1d,
+               "mesh descriptor arrays missing");
+    auto *g = new pa_geom;
+    try {
+      launch_geom(*mesh, *g, (hipStream_t)stream);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *geom = g;
+  });
+}
+
+int pa_geom_retain(pa_geom *geom) {
+  return guarded([&] {
+    PA_REQUIRE(geom, "null argument");
+    geom->refcount++;
+  });
+}
+
+void pa_geom_destroy(pa_geom *geom) {
+  if (!geom) return;
+  if (--geom->refcount == 0) {
+    hipFree(geom->d_geom);
+    delete geom;
+  }
+}
+
+int pa_geom_data(const pa_geom *geom, const double **dev_ptr, size_t *count) {
+  return guarded([&] {
+    PA_REQUIRE(geom && dev_ptr && count, "null argument");
+    *dev_ptr = geom->d_geom;
+    *count = (size_t)geom->ne * 11 * geom->Q;
+  });
+}
+
+int pa_op_create(int32_t height, int32_t width, pa_op **op) {
+  return guarded([&] {
+    PA_REQUIRE(op && height > 0 && width > 0, "bad operator size");
+    auto *o = new pa_op;
+    o->height = height, o->width = width;
+    *op = o;
+  });
+}
+
+int pa_op_add_sub(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
+                  const pa_basis_desc *basis, int32_t qfunction, const void *ctx, size_t ctx_size,
+                  uint32_t trial_ops, uint32_t test_ops) {
+  return guarded([&] {
+    PA_REQUIRE(op && geom && restr && basis, "null argument");
+    PA_REQUIRE(op->height == op->width, "only square operators are supported");
+    PA_REQUIRE(restr->lsize == op->width, "dimensions mismatch for sub-operator");  // operator.cpp:69-71
+    op->subs.push_back(make_sub(geom, *restr, *basis, qfunction, ctx, ctx_size, trial_ops, test_ops));
+    op->finalized = false;
+  });
+}
+
+int pa_op_finalize(pa_op *op) {
+  return guarded([&] {
+    PA_REQUIRE(op, "null argument");
+    PA_REQUIRE(!op->subs.empty(), "operator has no sub-operators");
+    op->finalized = true;
+  });
+}
+
+int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_basis_desc *basis,
+                  pa_op **coarse) {
+  return guarded([&] {
+    PA_REQUIRE(fine && restr && basis && coarse, "null argument");
+    PA_REQUIRE(!fine->subs.empty(), "fine operator has no sub-operators");
+    auto *o = new pa_op;
+    o->height = o->width = restr->lsize;
+    try {
+      for (const SubOp *fs : fine->subs) {
+        PA_REQUIRE(fs->ne == restr->num_elem, "coarsening needs one element block (same elements)");
+        o->subs.push_back(make_sub(static_cast<pa_geom *>(fs->geom), *restr, *basis, fs->qf,
+                                   fs->ctx_blob.data(), fs->ctx_blob.size(), fs->trial_ops,
+                                   fs->test_ops));
+      }
+    } catch (...) {
+      pa_op_destroy(o);
+      throw;
+    }
+    o->finalized = true;
+    *coarse = o;
+  });
+}
+
+int pa_op_apply_add(pa_op *op, const double *x, double *y, void *stream) {
+  return guarded([&] { apply_add(op, x, y, (hipStream_t)stream); });
+}
+
+int pa_op_mult(pa_op *op, const double *x, double *y, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && y, "null argument");
+    PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, (hipStream_t)stream));
+    apply_add(op, x, y, (hipStream_t)stream);
+  });
+}
+
+int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && diag, "null argument");
+    PA_HIP(hipMemsetAsync(diag, 0, sizeof(double) * (size_t)op->height, (hipStream_t)stream));
+    for (const SubOp *so : op->subs) {
+      if (so->fe_type == PA_FE_HCURL)
+        launch_nd_hex_diag(*so, diag, (hipStream_t)stream);
+      else
+        launch_h1_hex_diag(*so, diag, (hipStream_t)stream);
+    }
+  });
+}
+
+int pa_op_height(const pa_op *op) { return op ? op->height : -1; }
+int pa_op_width(const pa_op *op) { return op ? op->width : -1; }
+
+double pa_op_algorithmic_bytes(const pa_op *op) {
+  if (!op) return 0.0;
+  double bytes = 0.0;
+  for (const SubOp *so : op->subs) bytes += (double)so->ne * ((double)so->Q * 11 * 8 + (double)so->P * 5);
+  return bytes + 16.0 * op->height;
+}
+
+void pa_op_destroy(pa_op *op) {
+  if (!op) return;
+  for (SubOp *so : op->subs) free_sub(so);
+  delete op;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Internal declarations shared by the HIP translation units of libpalace_amd.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/palace_amd.h"
+
+namespace pa {
+
+void set_error(const std::string &msg);
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define PA_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t err__ = (expr);                                                               \
+    if (err__ != hipSuccess)                                                                 \
+      throw pa::Error(std::string(#expr) + " failed: " + hipGetErrorString(err__) + " (" +   \
+                      __FILE__ + ":" + std::to_string(__LINE__) + ")");                      \
+  } while (0)
+
+#define PA_REQUIRE(cond, msg)                                                   \
+  do {                                                                          \
+    if (!(cond)) throw pa::Error(std::string(msg) + " [" #cond "]");            \
+  } while (0)
+
+// Every C entry point is wrapped: no exception crosses the ABI.
+template <typename F>
+int guarded(F &&f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception &e) {
+    set_error(e.what());
+    return 1;
+  } catch (...) {
+    set_error("unknown error");
+    return 1;
+  }
+}
+
+template <typename T>
+T *dev_alloc(size_t n) {
+  T *p = nullptr;
+  if (n == 0) n = 1;
+  PA_HIP(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+  return p;
+}
+
+template <typename T>
+T *dev_upload(const T *host, size_t n, hipStream_t s = nullptr) {
+  T *p = dev_alloc<T>(n);
+  if (n) PA_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+  PA_HIP(hipStreamSynchronize(s));
+  return p;
+}
+
+constexpr int kMaxP1 = 6;  // closed nodes p+1 <= 7
+constexpr int kMaxQ1 = 7;
+
+// Geometry factor data (fem/mesh.hpp:27-69): double[ne][11][Q] in HBM.
+struct Geom {
+  int ne = 0, q1d = 0, Q = 0;
+  double *d_geom = nullptr;
+  int refcount = 1;
+};
+
+// Parsed coefficient context (coeff_qf.h layout) living in device memory.
+struct CoeffDev {
+  const int32_t *attr_mat = nullptr;  // [nattr] (device) or nullptr when nattr == 0
+  const double *mat = nullptr;        // [nmat * dim*dim] (device), column-major
+  int nattr = 0;
+};
+
+struct CoeffHost {
+  std::vector<int32_t> attr_mat;
+  std::vector<double> mat;
+  int dim = 3;
+  size_t slots = 0;  // number of 8-byte slots this context occupied in the blob
+  int32_t *d_attr_mat = nullptr;
+  double *d_mat = nullptr;
+  CoeffDev dev() const { return CoeffDev{d_attr_mat, d_mat, (int)attr_mat.size()}; }
+};
+
+struct SubOp {
+  Geom *geom = nullptr;
+  int fe_type = 0, p = 0, q1d = 0, P = 0, Q = 0, ne = 0, lsize = 0;
+  int qf = 0;
+  uint32_t trial_ops = 0, test_ops = 0;
+  int32_t *d_lidx = nullptr;  // [ne][P] signed tensor-order index: >=0 dof, <0 => -(1+dof) flipped
+  std::vector<double> Bc, Gc, Bo;
+  std::vector<uint8_t> ctx_blob;
+  CoeffHost c0, c1;
+};
+
+void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t slot_offset);
+
+// kernels (pa_geom.hip, pa_nd_hex.hip, pa_h1_hex.hip)
+void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s);
+void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, hipStream_t s);
+void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
+void launch_h1_hex_apply(const SubOp &so, const double *x, double *y, hipStream_t s);
+void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);
+
+}  // namespace pa
+
+struct pa_geom : pa::Geom {};
+
+struct pa_op {
+  int height = 0, width = 0;
+  bool finalized = false;
+  std::vector<pa::SubOp *> subs;
+};

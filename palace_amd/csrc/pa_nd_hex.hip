@@ -1,0 +1,511 @@
+// Fused E -> B/G -> D -> B^T/G^T -> E^T for Nedelec hexahedra (gfx950, FP64).
+//
+// Replaces what libCEED does inside CeedOperatorApplyAdd for Palace's curl-curl, ND-mass and
+// curl-curl+mass integrators (reference fem/libceed/operator.cpp:148-178; integrators
+// fem/integ/{curlcurl,vecfemass,curlcurlmass}.cpp; D from fem/qfunctions/33/{hdiv_33,hcurl_33,
+// hdivmass_33}_qf.h).  The reference feeds libCEED dense [3Q x P] tables (fem/libceed/basis.cpp:
+// 40-85), which makes p=3 compute-bound; here the tensor structure of the element is used
+// (sum factorisation), the whole chain runs in one kernel and nothing but x, the index array and
+// the geometry data is read from HBM, and only y is written (FP64 hardware atomics).
+//
+// Mapping (CDNA4, 64-lane waves): one element per Q1*Q1 lanes, 64/(Q1*Q1) elements per wave.
+// Lane (a, b) owns one line of the element along the direction being contracted; the two
+// re-distributions per component go through LDS and stay inside the wave, so there is no
+// workgroup barrier anywhere: waves are independent and overlap each other's HBM latency.
+//   pass X: lane (j,k)   contracts i  -> qx     tables of comp's x-direction
+//   pass Y: lane (qx,k)  contracts j  -> qy
+//   pass Z: lane (qx,qy) contracts k  -> qz     => lane (qx,qy) holds the qz column
+// D runs on the qz column in registers; the transposed passes mirror the above and end in the
+// signed scatter-add.  Tables are kernel arguments (scalar loads, SGPR operands).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "pa_internal.hpp"
+
+namespace pa {
+
+template <int P1, int Q1>
+struct NDTab {
+  double Bo[Q1 * P1];
+  double Bc[Q1 * (P1 + 1)];
+  double Gc[Q1 * (P1 + 1)];
+};
+
+template <int P1, int Q1>
+struct NDArgs {
+  int ne;
+  const int32_t *lidx;
+  const double *geom;
+  const double *x;
+  double *y;
+  CoeffDev c_mass, c_curl;
+  NDTab<P1, Q1> tab;
+};
+
+__device__ __forceinline__ void wave_sync() {
+  // Intra-wave LDS hand-off: the LDS executes a wave's DS operations in order; the fences stop
+  // the compiler from moving accesses across, the barrier is a scheduling no-op for one wave.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// fem/qfunctions/33/utils_33_qf.h:20-37 (adjugate-transpose, no determinant)
+__device__ __forceinline__ void adjJt33(const double J[9], double A[9]) {
+  A[0] = J[4] * J[8] - J[7] * J[5];
+  A[3] = J[7] * J[2] - J[1] * J[8];
+  A[6] = J[1] * J[5] - J[4] * J[2];
+  A[1] = J[6] * J[5] - J[3] * J[8];
+  A[4] = J[0] * J[8] - J[6] * J[2];
+  A[7] = J[3] * J[2] - J[0] * J[5];
+  A[2] = J[3] * J[7] - J[6] * J[4];
+  A[5] = J[6] * J[1] - J[0] * J[7];
+  A[8] = J[0] * J[4] - J[3] * J[1];
+}
+
+// utils_33_qf.h:64-84: y = s * A^T B C x (column-major 3x3)
+__device__ __forceinline__ void mult_AtBCx33(const double A[9], const double B[9],
+                                             const double C[9], const double x0, const double x1,
+                                             const double x2, const double s, double &y0,
+                                             double &y1, double &y2) {
+  const double t0 = C[0] * x0 + C[3] * x1 + C[6] * x2;
+  const double t1 = C[1] * x0 + C[4] * x1 + C[7] * x2;
+  const double t2 = C[2] * x0 + C[5] * x1 + C[8] * x2;
+  const double z0 = B[0] * t0 + B[3] * t1 + B[6] * t2;
+  const double z1 = B[1] * t0 + B[4] * t1 + B[7] * t2;
+  const double z2 = B[2] * t0 + B[5] * t1 + B[8] * t2;
+  y0 = s * (A[0] * z0 + A[1] * z1 + A[2] * z2);
+  y1 = s * (A[3] * z0 + A[4] * z1 + A[5] * z2);
+  y2 = s * (A[6] * z0 + A[7] * z1 + A[8] * z2);
+}
+
+// coeff_3_qf.h:9-24
+__device__ __forceinline__ void coeff_unpack3(const CoeffDev &c, int attr, double C[9]) {
+  const int k = (c.nattr > 0) ? c.attr_mat[attr - 1] : 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = c.mat[9 * k + i];
+}
+
+template <int P1, int Q1>
+struct NDLayout {
+  static constexpr int NC = P1 + 1;
+  static constexpr int T = Q1 * Q1;
+  static constexpr int EPW = 64 / T;
+  // LDS per element: A = 2 fields [Q1][NC][NC] (after pass X), B = 3 fields [Q1][Q1][NC]
+  static constexpr int A_FIELD = Q1 * NC * NC;
+  static constexpr int B_FIELD = Q1 * Q1 * NC;
+  static constexpr int ELEM = 2 * A_FIELD + 3 * B_FIELD;
+  // odd multiple of 16 doubles between elements: the two elements of a 32-lane read group land
+  // on opposite halves of the 64 banks
+  static constexpr int ELEM_PAD = ((ELEM + 15) / 16 * 16) | 16;
+  __device__ static __forceinline__ int ia(int f, int qx, int j, int k) {
+    return f * A_FIELD + (qx * NC + j) * NC + k;
+  }
+  __device__ static __forceinline__ int ib(int f, int qx, int qy, int k) {
+    return 2 * A_FIELD + f * B_FIELD + (qx * Q1 + qy) * NC + k;
+  }
+};
+
+// ---- forward passes for component C -------------------------------------------------------
+template <int C, int P1, int Q1, bool USE_U, bool USE_C>
+__device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e, const bool active,
+                                            const bool lane_ok, const int ta, const int tb,
+                                            double *__restrict__ sm, double (&U)[3][Q1],
+                                            double (&CU)[3][Q1]) {
+  using L = NDLayout<P1, Q1>;
+  constexpr int NC = L::NC;
+  constexpr int P = 3 * P1 * NC * NC;
+  constexpr int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
+  constexpr int off = C * P1 * NC * NC;
+  const double *TX = (C == 0) ? a.tab.Bo : a.tab.Bc;
+  const double *TY = (C == 1) ? a.tab.Bo : a.tab.Bc;
+  const double *TZ = (C == 2) ? a.tab.Bo : a.tab.Bc;
+  const double *Gc = a.tab.Gc;
+  constexpr bool DX = USE_C && C != 0, DY = USE_C && C != 1, DZ = USE_C && C != 2;
+
+  // pass X: lane (j, k) = (ta, tb)
+  {
+    const bool act = ta < nj && tb < nk;
+    double u[ni];
+#pragma unroll
+    for (int i = 0; i < ni; i++) {
+      double val = 0.0;
+      if (active && act) {
+        const int s = a.lidx[(size_t)e * P + off + i + ni * (ta + nj * tb)];
+        const double xv = a.x[s >= 0 ? s : -1 - s];
+        val = s >= 0 ? xv : -xv;
+      }
+      u[i] = val;
+    }
+#pragma unroll
+    for (int qx = 0; qx < Q1; qx++) {
+      double v = 0.0, d = 0.0;
+#pragma unroll
+      for (int i = 0; i < ni; i++) {
+        v += TX[qx * ni + i] * u[i];
+        if (DX) d += Gc[qx * NC + i] * u[i];
+      }
+      if (lane_ok && act) {
+        sm[L::ia(0, qx, ta, tb)] = v;
+        if (DX) sm[L::ia(1, qx, ta, tb)] = d;
+      }
+    }
+  }
+  wave_sync();
+  // pass Y: lane (qx, k) = (ta, tb)
+  {
+    const bool act = tb < nk;
+    double v[nj], d[nj];
+#pragma unroll
+    for (int j = 0; j < nj; j++) {
+      v[j] = sm[L::ia(0, ta, j, act ? tb : 0)];
+      if (DX) d[j] = sm[L::ia(1, ta, j, act ? tb : 0)];
+    }
+#pragma unroll
+    for (int qy = 0; qy < Q1; qy++) {
+      double vv = 0.0, vd = 0.0, dv = 0.0;
+#pragma unroll
+      for (int j = 0; j < nj; j++) {
+        vv += TY[qy * nj + j] * v[j];
+        if (DY) vd += Gc[qy * NC + j] * v[j];
+        if (DX) dv += TY[qy * nj + j] * d[j];
+      }
+      if (lane_ok && act) {
+        sm[L::ib(0, ta, qy, tb)] = vv;
+        if (DY) sm[L::ib(1, ta, qy, tb)] = vd;
+        if (DX) sm[L::ib(2, ta, qy, tb)] = dv;
+      }
+    }
+  }
+  wave_sync();
+  // pass Z: lane (qx, qy) = (ta, tb)
+  {
+    double vv[nk], vd[nk], dv[nk];
+#pragma unroll
+    for (int k = 0; k < nk; k++) {
+      vv[k] = sm[L::ib(0, ta, tb, k)];
+      if (DY) vd[k] = sm[L::ib(1, ta, tb, k)];
+      if (DX) dv[k] = sm[L::ib(2, ta, tb, k)];
+    }
+#pragma unroll
+    for (int qz = 0; qz < Q1; qz++) {
+      double val = 0.0, dz = 0.0, dy = 0.0, dx = 0.0;
+#pragma unroll
+      for (int k = 0; k < nk; k++) {
+        if (USE_U) val += TZ[qz * nk + k] * vv[k];
+        if (DZ) dz += Gc[qz * NC + k] * vv[k];
+        if (DY) dy += TZ[qz * nk + k] * vd[k];
+        if (DX) dx += TZ[qz * nk + k] * dv[k];
+      }
+      if (USE_U) U[C][qz] = val;
+      if (USE_C) {
+        // curl(f e_x) = (0, dz f, -dy f); curl(f e_y) = (-dz f, 0, dx f); curl(f e_z) = (dy f, -dx f, 0)
+        if (C == 0) CU[1][qz] += dz, CU[2][qz] -= dy;
+        if (C == 1) CU[0][qz] -= dz, CU[2][qz] += dx;
+        if (C == 2) CU[0][qz] += dy, CU[1][qz] -= dx;
+      }
+    }
+  }
+  wave_sync();
+}
+
+// ---- transposed passes for component C ------------------------------------------------------
+template <int C, int P1, int Q1, bool USE_U, bool USE_C>
+__device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e, const bool active,
+                                            const bool lane_ok, const int ta, const int tb,
+                                            double *__restrict__ sm, const double (&V)[3][Q1],
+                                            const double (&CV)[3][Q1]) {
+  using L = NDLayout<P1, Q1>;
+  constexpr int NC = L::NC;
+  constexpr int P = 3 * P1 * NC * NC;
+  constexpr int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
+  constexpr int off = C * P1 * NC * NC;
+  const double *TX = (C == 0) ? a.tab.Bo : a.tab.Bc;
+  const double *TY = (C == 1) ? a.tab.Bo : a.tab.Bc;
+  const double *TZ = (C == 2) ? a.tab.Bo : a.tab.Bc;
+  const double *Gc = a.tab.Gc;
+  constexpr bool DX = USE_C && C != 0, DY = USE_C && C != 1, DZ = USE_C && C != 2;
+
+  // pass Z^T: lane (qx, qy)
+  {
+#pragma unroll
+    for (int k = 0; k < nk; k++) {
+      double vv = 0.0, vd = 0.0, dv = 0.0;
+#pragma unroll
+      for (int qz = 0; qz < Q1; qz++) {
+        // test function curl: C=0 -> (0, dz, -dy); C=1 -> (-dz, 0, dx); C=2 -> (dy, -dx, 0)
+        double wdz = 0.0, wdy = 0.0, wdx = 0.0;
+        if (USE_C) {
+          if (C == 0) wdz = CV[1][qz], wdy = -CV[2][qz];
+          if (C == 1) wdz = -CV[0][qz], wdx = CV[2][qz];
+          if (C == 2) wdy = CV[0][qz], wdx = -CV[1][qz];
+        }
+        if (USE_U) vv += TZ[qz * nk + k] * V[C][qz];
+        if (DZ) vv += Gc[qz * NC + k] * wdz;
+        if (DY) vd += TZ[qz * nk + k] * wdy;
+        if (DX) dv += TZ[qz * nk + k] * wdx;
+      }
+      if (lane_ok) {
+        sm[L::ib(0, ta, tb, k)] = vv;
+        if (DY) sm[L::ib(1, ta, tb, k)] = vd;
+        if (DX) sm[L::ib(2, ta, tb, k)] = dv;
+      }
+    }
+  }
+  wave_sync();
+  // pass Y^T: lane (qx, k)
+  {
+    const bool act = tb < nk;
+    double vv[Q1], vd[Q1], dv[Q1];
+#pragma unroll
+    for (int qy = 0; qy < Q1; qy++) {
+      vv[qy] = sm[L::ib(0, ta, qy, act ? tb : 0)];
+      if (DY) vd[qy] = sm[L::ib(1, ta, qy, act ? tb : 0)];
+      if (DX) dv[qy] = sm[L::ib(2, ta, qy, act ? tb : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < nj; j++) {
+      double v = 0.0, d = 0.0;
+#pragma unroll
+      for (int qy = 0; qy < Q1; qy++) {
+        v += TY[qy * nj + j] * vv[qy];
+        if (DY) v += Gc[qy * NC + j] * vd[qy];
+        if (DX) d += TY[qy * nj + j] * dv[qy];
+      }
+      if (lane_ok && act) {
+        sm[L::ia(0, ta, j, tb)] = v;
+        if (DX) sm[L::ia(1, ta, j, tb)] = d;
+      }
+    }
+  }
+  wave_sync();
+  // pass X^T: lane (j, k), then the signed scatter-add E^T
+  {
+    const bool act = ta < nj && tb < nk;
+    double v[Q1], d[Q1];
+#pragma unroll
+    for (int qx = 0; qx < Q1; qx++) {
+      v[qx] = sm[L::ia(0, qx, act ? ta : 0, act ? tb : 0)];
+      if (DX) d[qx] = sm[L::ia(1, qx, act ? ta : 0, act ? tb : 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < ni; i++) {
+      double r = 0.0;
+#pragma unroll
+      for (int qx = 0; qx < Q1; qx++) {
+        r += TX[qx * ni + i] * v[qx];
+        if (DX) r += Gc[qx * NC + i] * d[qx];
+      }
+      if (active && act) {
+        const int s = a.lidx[(size_t)e * P + off + i + ni * (ta + nj * tb)];
+        unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? r : -r);
+      }
+    }
+  }
+  wave_sync();
+}
+
+constexpr int kWavesPerBlock = 4;
+
+template <int P1, int Q1, bool USE_U, bool USE_C>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void nd_hex_apply_kernel(const NDArgs<P1, Q1> a) {
+  using L = NDLayout<P1, Q1>;
+  constexpr int Q = Q1 * Q1 * Q1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / L::T, t = lane - sub * L::T;
+  const int ta = t % Q1, tb = t / Q1;
+  const bool lane_ok = sub < L::EPW;
+  const int e = (blockIdx.x * kWavesPerBlock + wave) * L::EPW + sub;
+  const bool active = lane_ok && e < a.ne;
+  double *sm = smem + (size_t)(wave * L::EPW + (lane_ok ? sub : 0)) * L::ELEM_PAD;
+
+  double U[3][Q1], CU[3][Q1];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int q = 0; q < Q1; q++) U[c][q] = 0.0, CU[c][q] = 0.0;
+
+  nd_fwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+
+  // D at the Q1 points of this lane's column (hcurl_33 / hdiv_33 / hdivmass_33)
+  const double *g = a.geom + (size_t)(active ? e : 0) * 11 * Q;
+#pragma unroll
+  for (int qz = 0; qz < Q1; qz++) {
+    const int q = ta + Q1 * (tb + Q1 * qz);
+    double adj[9], Cm[9];
+    const int attr = (int)g[q];
+    const double wdetJ = g[Q + q];
+#pragma unroll
+    for (int c = 0; c < 9; c++) adj[c] = g[(2 + c) * Q + q];
+    if (USE_U) {
+      coeff_unpack3(a.c_mass, attr, Cm);
+      mult_AtBCx33(adj, Cm, adj, U[0][qz], U[1][qz], U[2][qz], wdetJ, U[0][qz], U[1][qz], U[2][qz]);
+    }
+    if (USE_C) {
+      double Jl[9];
+      coeff_unpack3(a.c_curl, attr, Cm);
+      adjJt33(adj, Jl);
+      mult_AtBCx33(Jl, Cm, Jl, CU[0][qz], CU[1][qz], CU[2][qz], wdetJ, CU[0][qz], CU[1][qz],
+                   CU[2][qz]);
+    }
+  }
+
+  nd_bwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_bwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_bwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+}
+
+template <int P1, int Q1>
+static void fill_tab(const SubOp &so, NDTab<P1, Q1> &t) {
+  for (int i = 0; i < Q1 * P1; i++) t.Bo[i] = so.Bo[i];
+  for (int i = 0; i < Q1 * (P1 + 1); i++) t.Bc[i] = so.Bc[i], t.Gc[i] = so.Gc[i];
+}
+
+template <int P1, int Q1>
+static void launch_pq(const SubOp &so, const double *x, double *y, hipStream_t s) {
+  using L = NDLayout<P1, Q1>;
+  NDArgs<P1, Q1> a;
+  a.ne = so.ne;
+  a.lidx = so.d_lidx;
+  a.geom = so.geom->d_geom;
+  a.x = x;
+  a.y = y;
+  fill_tab(so, a.tab);
+  const int epb = kWavesPerBlock * L::EPW;
+  const dim3 grid((so.ne + epb - 1) / epb), block(64 * kWavesPerBlock);
+  const size_t lds = sizeof(double) * (size_t)epb * L::ELEM_PAD;
+  switch (so.qf) {
+    case PA_QF_HDIV_33:
+      a.c_curl = so.c0.dev();
+      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, false, true>), grid, block, lds, s, a);
+      break;
+    case PA_QF_HCURL_33:
+      a.c_mass = so.c0.dev();
+      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, true, false>), grid, block, lds, s, a);
+      break;
+    case PA_QF_HDIVMASS_33:
+      a.c_mass = so.c0.dev();
+      a.c_curl = so.c1.dev();
+      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, true, true>), grid, block, lds, s, a);
+      break;
+    default:
+      throw Error("QFunction not available for H(curl) hexahedra");
+  }
+  PA_HIP(hipGetLastError());
+}
+
+#define PA_ND_DISPATCH(FN, ...)                                                           \
+  switch (so.p * 16 + so.q1d) {                                                            \
+    case 1 * 16 + 2: FN<1, 2>(__VA_ARGS__); break;                                         \
+    case 1 * 16 + 3: FN<1, 3>(__VA_ARGS__); break;                                         \
+    case 2 * 16 + 3: FN<2, 3>(__VA_ARGS__); break;                                         \
+    case 1 * 16 + 4: FN<1, 4>(__VA_ARGS__); break;                                         \
+    case 2 * 16 + 4: FN<2, 4>(__VA_ARGS__); break;                                         \
+    case 3 * 16 + 4: FN<3, 4>(__VA_ARGS__); break;                                         \
+    case 1 * 16 + 5: FN<1, 5>(__VA_ARGS__); break;                                         \
+    case 2 * 16 + 5: FN<2, 5>(__VA_ARGS__); break;                                         \
+    case 3 * 16 + 5: FN<3, 5>(__VA_ARGS__); break;                                         \
+    case 4 * 16 + 5: FN<4, 5>(__VA_ARGS__); break;                                         \
+    default:                                                                               \
+      throw Error("no H(curl) hex kernel for order " + std::to_string(so.p) + " with " +   \
+                  std::to_string(so.q1d) + " points per direction");                       \
+  }
+
+void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, hipStream_t s) {
+  PA_ND_DISPATCH(launch_pq, so, x, y, s)
+}
+
+// ---- diagonal -------------------------------------------------------------------------------
+// diag_l = sum_q [ phi_l^T Mm phi_l + curl(phi_l)^T Mc curl(phi_l) ] with the pointwise matrices
+// Mm = w detJ adj^T C adj and Mc = w detJ Jl^T C Jl of the D stage.  Set-up only (reference
+// operator.cpp:116-143 / CeedOperatorLinearAssembleAddDiagonal): one workgroup per element,
+// matrices staged in LDS, one thread per local dof.
+template <int P1, int Q1>
+__global__ void nd_hex_diag_kernel(const NDArgs<P1, Q1> a, const bool use_u, const bool use_c) {
+  constexpr int NC = P1 + 1, Q = Q1 * Q1 * Q1, P = 3 * P1 * NC * NC;
+  __shared__ double Mm[Q][9], Mc[Q][9];
+  const int e = blockIdx.x;
+  const double *g = a.geom + (size_t)e * 11 * Q;
+  for (int q = threadIdx.x; q < Q; q += blockDim.x) {
+    double adj[9], Cm[9], Jl[9];
+    const int attr = (int)g[q];
+    const double w = g[Q + q];
+    for (int c = 0; c < 9; c++) adj[c] = g[(2 + c) * Q + q];
+    for (int col = 0; col < 3; col++) {
+      const double e0 = col == 0, e1 = col == 1, e2 = col == 2;
+      double y0 = 0, y1 = 0, y2 = 0;
+      if (use_u) {
+        coeff_unpack3(a.c_mass, attr, Cm);
+        mult_AtBCx33(adj, Cm, adj, e0, e1, e2, w, y0, y1, y2);
+      }
+      Mm[q][0 + 3 * col] = y0, Mm[q][1 + 3 * col] = y1, Mm[q][2 + 3 * col] = y2;
+      y0 = y1 = y2 = 0;
+      if (use_c) {
+        coeff_unpack3(a.c_curl, attr, Cm);
+        adjJt33(adj, Jl);
+        mult_AtBCx33(Jl, Cm, Jl, e0, e1, e2, w, y0, y1, y2);
+      }
+      Mc[q][0 + 3 * col] = y0, Mc[q][1 + 3 * col] = y1, Mc[q][2 + 3 * col] = y2;
+    }
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < P; l += blockDim.x) {
+    const int C = l / (P1 * NC * NC);
+    const int r = l - C * P1 * NC * NC;
+    const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC;
+    const int i = r % ni, j = (r / ni) % nj, k = r / (ni * nj);
+    const double *TX = (C == 0) ? a.tab.Bo : a.tab.Bc;
+    const double *TY = (C == 1) ? a.tab.Bo : a.tab.Bc;
+    const double *TZ = (C == 2) ? a.tab.Bo : a.tab.Bc;
+    const int nk = (C == 2) ? P1 : NC;
+    double acc = 0.0;
+    for (int qz = 0; qz < Q1; qz++)
+      for (int qy = 0; qy < Q1; qy++)
+        for (int qx = 0; qx < Q1; qx++) {
+          const int q = qx + Q1 * (qy + Q1 * qz);
+          const double bx = TX[qx * ni + i], by = TY[qy * nj + j], bz = TZ[qz * nk + k];
+          const double gx = (C == 0) ? 0.0 : a.tab.Gc[qx * NC + i];
+          const double gy = (C == 1) ? 0.0 : a.tab.Gc[qy * NC + j];
+          const double gz = (C == 2) ? 0.0 : a.tab.Gc[qz * NC + k];
+          const double f = bx * by * bz;
+          const double dx = gx * by * bz, dy = bx * gy * bz, dz = bx * by * gz;
+          double cv[3];
+          if (C == 0) cv[0] = 0.0, cv[1] = dz, cv[2] = -dy;
+          if (C == 1) cv[0] = -dz, cv[1] = 0.0, cv[2] = dx;
+          if (C == 2) cv[0] = dy, cv[1] = -dx, cv[2] = 0.0;
+          acc += Mm[q][C + 3 * C] * f * f;
+          for (int r2 = 0; r2 < 3; r2++)
+            for (int c2 = 0; c2 < 3; c2++) acc += cv[r2] * Mc[q][r2 + 3 * c2] * cv[c2];
+        }
+    const int s = a.lidx[(size_t)e * P + l];
+    unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], acc);
+  }
+}
+
+template <int P1, int Q1>
+static void launch_diag_pq(const SubOp &so, double *diag, hipStream_t s) {
+  NDArgs<P1, Q1> a;
+  a.ne = so.ne;
+  a.lidx = so.d_lidx;
+  a.geom = so.geom->d_geom;
+  a.x = nullptr;
+  a.y = diag;
+  fill_tab(so, a.tab);
+  bool use_u = false, use_c = false;
+  switch (so.qf) {
+    case PA_QF_HDIV_33: a.c_curl = so.c0.dev(), use_c = true; break;
+    case PA_QF_HCURL_33: a.c_mass = so.c0.dev(), use_u = true; break;
+    case PA_QF_HDIVMASS_33: a.c_mass = so.c0.dev(), a.c_curl = so.c1.dev(), use_u = use_c = true; break;
+    default: throw Error("QFunction not available for H(curl) hexahedra");
+  }
+  hipLaunchKernelGGL((nd_hex_diag_kernel<P1, Q1>), dim3(so.ne), dim3(128), 0, s, a, use_u, use_c);
+  PA_HIP(hipGetLastError());
+}
+
+void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s) {
+  PA_ND_DISPATCH(launch_diag_pq, so, diag, s)
+}
+
+}  // namespace pa

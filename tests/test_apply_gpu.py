@@ -1,0 +1,155 @@
+"""Parity of the HIP operator apply (through the C ABI) against the oracle.
+
+Criterion = the reference's own operator test, test/unit/test-libceed.cpp:245-282:
+||y_test - y_ref||^2 < 1e-12 * max(||y_ref||^2, 1) on a random x (we gate the relative L2 error at
+1e-12, far tighter)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from palace_amd import ceed  # noqa: E402
+from palace_amd.fem.fespace import NDHexSpace  # noqa: E402
+from palace_amd.fem.mesh import ogrid_cylinder, refine_uniform  # noqa: E402
+from tests import util  # noqa: E402
+
+RTOL = 1e-12
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _multi_attr(mesh):
+    """Give the mesh three attributes so the attribute->material indirection is exercised."""
+    m = type(mesh)(x=mesh.x, elem_nodes=mesh.elem_nodes, attr=(np.arange(mesh.ne) % 3 + 1).astype(np.int32))
+    return m
+
+
+def test_geometry_factors(cylinder_mesh):
+    for q1d in (2, 3, 4, 5):
+        g = ceed.GeomFactorData(cylinder_mesh, q1d).to_numpy()
+        ref = util.oracle_geom(cylinder_mesh, q1d)
+        assert np.array_equal(g[:, 0, :], ref[:, 0, :])
+        np.testing.assert_allclose(g[:, 1:, :], ref[:, 1:, :], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+@pytest.mark.parametrize("qf", ["hdiv", "hcurl", "hdivmass"])
+def test_apply_cylinder_mesh(cylinder_mesh, p, qf):
+    mesh = _multi_attr(cylinder_mesh)
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    _, b_a = util.make_ctx("aniso", nattr=3)
+    _, b_s = util.make_ctx("scalar", nattr=3)
+    dense = util.dense_tables(nd, q1d)
+    if qf == "hdiv":
+        op, blob = ceed.curlcurl_operator(geom, nd, b_a, dense), b_a
+    elif qf == "hcurl":
+        op, blob = ceed.ndmass_operator(geom, nd, b_a, dense), b_a
+    else:
+        op, blob = ceed.curlcurlmass_operator(geom, nd, b_s, b_a, dense), np.concatenate([b_s, b_a])
+    rng = np.random.default_rng(1)
+    x = rng.uniform(0, 1, nd.ndofs)
+    y = op.mult(_dev(x), torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")).cpu().numpy()
+    ref = util.oracle_apply_c(nd, util.oracle_geom(mesh, q1d), qf, blob, x, q1d)
+    assert _rel(y, ref) < RTOL
+    # AddMult accumulates
+    y2 = op.add_mult(_dev(x), _dev(ref.copy())).cpu().numpy()
+    assert _rel(y2, 2 * ref) < RTOL
+
+
+@pytest.mark.parametrize("p_coarse,p_fine", [(1, 3), (2, 3), (1, 2), (2, 4), (1, 4)])
+def test_coarsened_operator(cylinder_mesh, p_coarse, p_fine):
+    """CeedOperatorCoarsen: coarse basis on the fine level's quadrature/geometry data."""
+    mesh = cylinder_mesh
+    q1d = p_fine + 1
+    ndf, ndc = NDHexSpace(mesh, p_fine), NDHexSpace(mesh, p_coarse)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    _, b_s = util.make_ctx("scalar")
+    _, b_i = util.make_ctx("identity")
+    fine = ceed.curlcurlmass_operator(geom, ndf, b_s, b_i)
+    coarse = fine.coarsen(geom, ndc)
+    x = np.random.default_rng(2).uniform(-1, 1, ndc.ndofs)
+    y = coarse.mult(_dev(x), torch.empty(ndc.ndofs, dtype=torch.float64, device="cuda")).cpu().numpy()
+    ref = util.oracle_apply_c(ndc, util.oracle_geom(mesh, q1d), "hdivmass", np.concatenate([b_s, b_i]), x, q1d)
+    assert _rel(y, ref) < RTOL
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_diagonal(cylinder_mesh, p):
+    mesh = _multi_attr(cylinder_mesh)
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    cs, b_s = util.make_ctx("scalar", nattr=3)
+    ca, b_a = util.make_ctx("aniso", nattr=3)
+    op = ceed.curlcurlmass_operator(geom, nd, b_s, b_a)
+    d = op.assemble_diagonal(torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")).cpu().numpy()
+    ref = util.oracle_operator(nd, util.oracle_geom(mesh, q1d), "hdivmass", cs, ca, q1d).diagonal()
+    assert _rel(d, ref) < RTOL
+
+
+@pytest.mark.parametrize("n,nz", [(1, 1), (1, 3), (2, 3), (3, 2)])
+def test_ragged_element_counts(n, nz):
+    """Element counts that do not fill the last wave / workgroup (5, 15, 60, 90 elements)."""
+    mesh = ogrid_cylinder(n, nz)
+    p, q1d = 3, 4
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    _, b_s = util.make_ctx("scalar")
+    _, b_i = util.make_ctx("identity")
+    op = ceed.curlcurlmass_operator(geom, nd, b_s, b_i)
+    x = np.random.default_rng(3).uniform(0, 1, nd.ndofs)
+    y = op.mult(_dev(x), torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")).cpu().numpy()
+    ref = util.oracle_apply_c(nd, util.oracle_geom(mesh, q1d), "hdivmass", np.concatenate([b_s, b_i]), x, q1d)
+    assert _rel(y, ref) < RTOL
+
+
+def test_refined_mesh_and_properties(cylinder_mesh):
+    """640 elements (one uniform refinement of the reference mesh): parity, symmetry
+    x^T K y = y^T K x, linearity, positive semi-definiteness of K."""
+    mesh = refine_uniform(cylinder_mesh)
+    p, q1d = 3, 4
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    _, b_i = util.make_ctx("identity")
+    K = ceed.curlcurl_operator(geom, nd, b_i)
+    rng = np.random.default_rng(4)
+    x, z = rng.uniform(-1, 1, nd.ndofs), rng.uniform(-1, 1, nd.ndofs)
+    n = nd.ndofs
+    new = lambda: torch.empty(n, dtype=torch.float64, device="cuda")  # noqa: E731
+    Kx, Kz = K.mult(_dev(x), new()).cpu().numpy(), K.mult(_dev(z), new()).cpu().numpy()
+    ref = util.oracle_apply_c(nd, util.oracle_geom(mesh, q1d), "hdiv", b_i, x, q1d)
+    assert _rel(Kx, ref) < RTOL
+    assert abs(z @ Kx - x @ Kz) < 1e-11 * abs(z @ Kx)
+    Kxz = K.mult(_dev(2.0 * x - 3.0 * z), new()).cpu().numpy()
+    assert _rel(Kxz, 2.0 * Kx - 3.0 * Kz) < 1e-12
+    assert x @ Kx > 0
+
+
+def test_error_paths(cylinder_mesh):
+    """Mismatched descriptors are rejected with a message (no exception crosses the ABI)."""
+    from palace_amd import lib
+
+    mesh = cylinder_mesh
+    nd = NDHexSpace(mesh, 2)
+    geom = ceed.GeomFactorData(mesh, 3)
+    _, b_i = util.make_ctx("identity")
+    with pytest.raises(lib.PalaceAmdError, match="evaluation modes"):
+        ceed.Operator(nd.ndofs, nd.ndofs).add_integrator(geom, nd, ceed.QF_HDIV_33, b_i, ceed.EVAL_INTERP)
+    geom4 = ceed.GeomFactorData(mesh, 4)
+    bad = util.dense_tables(nd, 4)
+    with pytest.raises(lib.PalaceAmdError, match="dense basis table"):
+        ceed.curlcurl_operator(geom4, nd, b_i, dense=(bad[0] * 1.001, bad[1]))
+    op = ceed.curlcurl_operator(geom, nd, b_i)
+    x = torch.zeros(nd.ndofs, dtype=torch.float64, device="cuda")
+    with pytest.raises(lib.PalaceAmdError, match="coefficient = 1.0"):
+        op.add_mult(x, x, a=2.0)
