@@ -1,0 +1,110 @@
+/*
+ * palace_amd_linalg.h — C ABI over the C++ host layer that mirrors palace::linalg on HBM vectors
+ * (palace_amd/csrc/linalg.hpp).  Palace itself would use the C++ classes directly (same names:
+ * ParOperator, CgSolver, GmresSolver, ChebyshevSmoother, GeometricMultigridSolver); this C face
+ * exists so the same objects can be driven from tests / bench (ctypes) and from other languages.
+ * Same rules as palace_amd.h: 0 = success, pa_last_error() for the message, device pointers for
+ * vectors, host pointers for descriptors (copied).
+ */
+#ifndef PALACE_AMD_LINALG_H
+#define PALACE_AMD_LINALG_H
+
+#include "palace_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pa_context pa_context; /* stream + communicator                          */
+typedef struct pa_halo pa_halo;       /* conforming prolongation P of one space (MPI halo in the reference) */
+typedef struct pa_par_op pa_par_op;   /* palace::ParOperator, linalg/rap.cpp             */
+typedef struct pa_interp pa_interp;   /* p-prolongation / discrete gradient, fem/bilinearform.cpp:203-282 */
+typedef struct pa_solver pa_solver;   /* palace::Solver<Operator>, linalg/solver.hpp     */
+
+/* --- context: everything created from it is enqueued on `stream` (a hipStream_t) ------------- */
+int pa_context_create(void *stream, pa_context **ctx);
+void pa_context_destroy(pa_context *ctx);
+int pa_context_synchronize(pa_context *ctx);
+
+/* --- RCCL communicator (replaces MPI_Comm on the hot path: utils/communication.hpp:249-273) -- */
+/* rank 0 fills 128 bytes; the caller broadcasts them to all ranks by any means */
+int pa_comm_unique_id(char *out128);
+int pa_context_init_comm(pa_context *ctx, int rank, int size, const char *unique_id128);
+int pa_context_rank(const pa_context *ctx);
+int pa_context_size(const pa_context *ctx);
+/* in-place sum of n doubles (device memory) over all ranks */
+int pa_allreduce_sum(pa_context *ctx, double *dev_buf, int n);
+
+/* Halo plan of one space.  Local vector layout: true (owned) dofs [0, n_true), then ghosts.
+ *   nbr[k]                         neighbour rank
+ *   send_idx[send_off[k]..send_off[k+1])  owned local dofs whose values neighbour k needs
+ *   recv_idx[recv_off[k]..recv_off[k+1])  ghost slots owned by neighbour k
+ * Both sides must list a pair's dofs in the same order. */
+int pa_halo_create(pa_context *ctx, int nnbr, const int *nbr, const int *send_off,
+                   const int32_t *send_idx, const int *recv_off, const int32_t *recv_idx,
+                   pa_halo **halo);
+void pa_halo_destroy(pa_halo *halo);
+/* P and P^T on a local vector (device pointer) — exposed for tests */
+int pa_halo_prolongate(pa_context *ctx, pa_halo *halo, double *lx);
+int pa_halo_restrict_add(pa_context *ctx, pa_halo *halo, double *ly);
+
+/* --- ParOperator (linalg/rap.cpp:154-234) ---------------------------------------------------- */
+enum pa_diag_policy { PA_DIAG_ZERO = 0, PA_DIAG_ONE = 1 };
+/* `local` stays owned by the caller and must outlive the ParOperator; halo may be NULL (one rank) */
+int pa_par_op_create(pa_context *ctx, pa_op *local, int n_true, const int32_t *ess_tdofs, int n_ess,
+                     int diag_policy, pa_halo *halo, pa_par_op **A);
+void pa_par_op_destroy(pa_par_op *A);
+int pa_par_op_mult(pa_par_op *A, const double *x, double *y);
+int pa_par_op_assemble_diagonal(pa_par_op *A, double *diag);
+
+/* --- vectors (linalg/vector.cpp) ------------------------------------------------------------- */
+int pa_vec_dot(pa_context *ctx, const double *x, const double *y, int n, double *result);
+int pa_vec_axpby(pa_context *ctx, double a, const double *x, double b, double *y, int n);
+int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed);
+
+/* --- solvers --------------------------------------------------------------------------------- */
+/* ChebyshevSmoother / ChebyshevSmoother1stKind (linalg/chebyshev.cpp); SetOperator(A) is done here:
+ * diagonal assembly + power iteration for lambda_max (linalg/operator.cpp:583-631). */
+int pa_chebyshev_create(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max,
+                        int fourth_kind, pa_solver **S);
+int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max);
+/* JacobiSmoother (linalg/jacobi.cpp) */
+int pa_jacobi_create(pa_context *ctx, pa_par_op *A, pa_solver **S);
+/* CgSolver / GmresSolver / FgmresSolver (linalg/iterative.cpp).  precond may be NULL. */
+int pa_cg_create(pa_context *ctx, pa_par_op *A, pa_solver *precond, double rel_tol, double abs_tol,
+                 int max_it, int print, pa_solver **S);
+int pa_gmres_create(pa_context *ctx, pa_par_op *A, pa_solver *precond, double rel_tol, double abs_tol,
+                    int max_it, int restart, int flexible, int print, pa_solver **S);
+/* GeometricMultigridSolver (linalg/gmg.cpp): levels 0 (coarsest) .. nlevels-1; P[l] maps level l to
+ * l+1; `coarse` solves on level 0 (ownership of `coarse` passes to the multigrid solver). */
+int pa_gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *const *P,
+                  pa_solver *coarse, int cycle_it, int smooth_it, int cheby_order, double cheby_sf_max,
+                  double cheby_sf_min, int cheby_4th_kind, pa_solver **S);
+/* x = S(b) on T-vectors; initial_guess != 0 uses x as the starting iterate (Krylov solvers) */
+int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess);
+int pa_solver_stats(const pa_solver *S, int *iterations, double *initial_res, double *final_res,
+                    int *converged);
+void pa_solver_destroy(pa_solver *S);
+
+/* --- p-prolongation between two spaces on the same mesh (fem/bilinearform.cpp:203-282,
+ *     fem/libceed/basis.cpp:116-165 `InitMfemInterpolatorBasis`, fem/libceed/integrator.cpp:515-548):
+ *     element-local interpolation applied through E / E^T, output scaled by the inverse (local) dof
+ *     multiplicity (bilinearform.cpp:256-279).  The element matrix MFEM's GetTransferMatrix gives
+ *     for these nodal tensor elements is the Kronecker product of two 1-D nodal interpolation
+ *     matrices, which is what is passed:
+ *       Ic [p_f+1][p_c+1]  coarse closed basis evaluated at the fine closed nodes
+ *       Io [p_f][p_c]      coarse open basis evaluated at the fine open nodes (HCURL only)
+ *     In parallel the wrapper is ParOperator(P, coarse, fine, use_R = true) (fem/fespace.cpp): the
+ *     coarse input is halo-prolongated, the fine output restricted to owned dofs. */
+int pa_interp_create(pa_context *ctx, const pa_restriction_desc *coarse_restr,
+                     const pa_basis_desc *coarse_basis, const pa_restriction_desc *fine_restr,
+                     const pa_basis_desc *fine_basis, const double *Ic, const double *Io,
+                     pa_halo *coarse_halo, int n_true_coarse, int n_true_fine, pa_interp **P);
+int pa_interp_mult(pa_interp *P, const double *x_coarse, double *y_fine);
+int pa_interp_mult_transpose(pa_interp *P, const double *x_fine, double *y_coarse);
+void pa_interp_destroy(pa_interp *P);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -568,3 +568,64 @@ def pcg(A_mult, b, B_mult=None, rel_tol=0.0, abs_tol=0.0, max_it=100):
         converged = res < eps
         it += 1
     return x, it, hist
+
+
+# ---------------------------------------------------------------------------------------------
+# p-prolongation (fem/bilinearform.cpp:203-282, fem/libceed/basis.cpp:116-165): element matrix =
+# nodal interpolation of the coarse shape functions at the fine dofs (what MFEM's
+# GetTransferMatrix returns for nodal elements), applied through E / E^T with the inverse
+# multiplicity of the fine restriction.
+# ---------------------------------------------------------------------------------------------
+
+def nd_hex_interp_lex(pc, pf):
+    """Dense [P_f, P_c] element interpolation matrix in tensor (lexicographic) dof order."""
+    cpc, opc = gll_points(pc + 1), gl_points(pc)[0]
+    cpf, opf = gll_points(pf + 1), gl_points(pf)[0]
+    Pc, Pf = 3 * pc * (pc + 1) ** 2, 3 * pf * (pf + 1) ** 2
+    M = np.zeros((Pf, Pc))
+    for comp in range(3):
+        ncd = [pc + 1] * 3
+        ncd[comp] = pc
+        nfd = [pf + 1] * 3
+        nfd[comp] = pf
+        nodes_c = [cpc] * 3
+        nodes_c[comp] = opc
+        nodes_f = [cpf] * 3
+        nodes_f[comp] = opf
+        for kf in range(nfd[2]):
+            for jf in range(nfd[1]):
+                for i_f in range(nfd[0]):
+                    lf = comp * pf * (pf + 1) ** 2 + i_f + nfd[0] * (jf + nfd[1] * kf)
+                    pt = (nodes_f[0][i_f], nodes_f[1][jf], nodes_f[2][kf])
+                    for kc in range(ncd[2]):
+                        for jc in range(ncd[1]):
+                            for ic in range(ncd[0]):
+                                lc = comp * pc * (pc + 1) ** 2 + ic + ncd[0] * (jc + ncd[1] * kc)
+                                M[lf, lc] = (lagrange(nodes_c[0], pt[0], ic)[0] * lagrange(nodes_c[1], pt[1], jc)[0]
+                                             * lagrange(nodes_c[2], pt[2], kc)[0])
+    return M
+
+
+class InterpOracle:
+    """y_f = D^-1 sum_e E_f^T I E_c x_c and its transpose (serial)."""
+
+    def __init__(self, dof_c, sgn_c, dof_f, sgn_f, n_c, n_f, M):
+        self.dc, self.sc, self.df, self.sf = dof_c, sgn_c.astype(np.float64), dof_f, sgn_f.astype(np.float64)
+        self.nc, self.nf, self.M = n_c, n_f, M
+        mult = np.zeros(n_f)
+        np.add.at(mult, dof_f.ravel(), 1.0)
+        self.inv_mult = 1.0 / mult
+
+    def mult(self, x):
+        ue = x[self.dc] * self.sc
+        ve = (ue @ self.M.T) * self.sf
+        y = np.zeros(self.nf)
+        np.add.at(y, self.df.ravel(), ve.ravel())
+        return y * self.inv_mult
+
+    def mult_transpose(self, x):
+        ue = (x * self.inv_mult)[self.df] * self.sf
+        ve = (ue @ self.M) * self.sc
+        y = np.zeros(self.nc)
+        np.add.at(y, self.dc.ravel(), ve.ravel())
+        return y

@@ -92,7 +92,7 @@ class GeomFactorData:
         _lib.check(L.pa_geom_data(self.handle, C.byref(p), C.byref(n)))
 
         class _View:  # device memory owned by the library, exposed through the array interface
-            __cuda_array_interface__ = dict(shape=(n.value,), typestr="<f8", data=(p.value, True), version=2)
+            __cuda_array_interface__ = dict(shape=(n.value,), typestr="<f8", data=(p.value, False), version=2)
 
         torch.cuda.synchronize()
         return torch.as_tensor(_View(), device="cuda").cpu().numpy().reshape(self.mesh.ne, 11, self.Q)

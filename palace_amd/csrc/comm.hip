@@ -1,0 +1,165 @@
+#include "comm.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <string>
+
+#include "pa_internal.hpp"
+
+namespace palace {
+
+namespace {
+
+// RCCL is resolved lazily so that the single-GPU path has no load-time dependency on it.
+typedef struct { char internal[128]; } ncclUniqueId_t;
+typedef int (*fn_get_id)(ncclUniqueId_t *);
+typedef int (*fn_init_rank)(void **, int, ncclUniqueId_t, int);
+typedef int (*fn_destroy)(void *);
+typedef int (*fn_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_send)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_recv)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_void)(void);
+typedef const char *(*fn_errstr)(int);
+
+struct Rccl {
+  void *h = nullptr;
+  fn_get_id GetUniqueId = nullptr;
+  fn_init_rank CommInitRank = nullptr;
+  fn_destroy CommDestroy = nullptr;
+  fn_allreduce AllReduce = nullptr;
+  fn_send Send = nullptr;
+  fn_recv Recv = nullptr;
+  fn_void GroupStart = nullptr, GroupEnd = nullptr;
+  fn_errstr GetErrorString = nullptr;
+  Rccl() {
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) throw pa::Error(std::string("cannot load librccl.so: ") + dlerror());
+    auto sym = [&](const char *n) {
+      void *p = dlsym(h, n);
+      if (!p) throw pa::Error(std::string("missing RCCL symbol ") + n);
+      return p;
+    };
+    GetUniqueId = (fn_get_id)sym("ncclGetUniqueId");
+    CommInitRank = (fn_init_rank)sym("ncclCommInitRank");
+    CommDestroy = (fn_destroy)sym("ncclCommDestroy");
+    AllReduce = (fn_allreduce)sym("ncclAllReduce");
+    Send = (fn_send)sym("ncclSend");
+    Recv = (fn_recv)sym("ncclRecv");
+    GroupStart = (fn_void)sym("ncclGroupStart");
+    GroupEnd = (fn_void)sym("ncclGroupEnd");
+    GetErrorString = (fn_errstr)sym("ncclGetErrorString");
+  }
+};
+Rccl &rccl() {
+  static Rccl r;
+  return r;
+}
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values (rccl.h)
+
+#define PA_NCCL(expr)                                                                           \
+  do {                                                                                          \
+    int rc__ = (expr);                                                                          \
+    if (rc__ != 0) throw pa::Error(std::string(#expr) + " failed: " + rccl().GetErrorString(rc__)); \
+  } while (0)
+
+__global__ void k_pack(const double *__restrict__ v, const int32_t *__restrict__ idx, int n, double *__restrict__ buf) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = v[idx[i]];
+}
+__global__ void k_unpack(double *__restrict__ v, const int32_t *__restrict__ idx, int n, const double *__restrict__ buf) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[idx[i]] = buf[i];
+}
+// An owned dof may be shared with several neighbours: its index then appears once per neighbour
+// and the adds must not race; contributions are applied neighbour by neighbour.
+__global__ void k_unpack_add(double *__restrict__ v, const int32_t *__restrict__ idx, int n, const double *__restrict__ buf) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[idx[i]] += buf[i];
+}
+inline int blocks(int n) { return std::max(1, std::min(1024, (n + 255) / 256)); }
+
+}  // namespace
+
+void Comm::GetUniqueId(char *out) {
+  ncclUniqueId_t id;
+  PA_NCCL(rccl().GetUniqueId(&id));
+  std::memcpy(out, id.internal, kUniqueIdBytes);
+}
+
+Comm::Comm(int rank, int size, const char *unique_id) : rank_(rank), size_(size) {
+  ncclUniqueId_t id;
+  std::memcpy(id.internal, unique_id, kUniqueIdBytes);
+  PA_NCCL(rccl().CommInitRank(&nccl_, size, id, rank));
+}
+
+Comm::~Comm() {
+  if (nccl_) rccl().CommDestroy(nccl_);
+}
+
+Halo::~Halo() {
+  (void)hipFree(d_send_idx_), (void)hipFree(d_recv_idx_), (void)hipFree(d_sendbuf_), (void)hipFree(d_recvbuf_);
+}
+
+Halo::Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int32_t *send_idx, const int *recv_off,
+           const int32_t *recv_idx)
+    : comm_(&comm) {
+  nbr_.assign(nbr, nbr + nnbr);
+  send_off_.assign(send_off, send_off + nnbr + 1);
+  recv_off_.assign(recv_off, recv_off + nnbr + 1);
+  nsend_ = send_off_[nnbr], nrecv_ = recv_off_[nnbr];
+  d_send_idx_ = pa::dev_upload(send_idx, (size_t)nsend_);
+  d_recv_idx_ = pa::dev_upload(recv_idx, (size_t)nrecv_);
+  const int nbuf = std::max(nsend_, nrecv_);
+  d_sendbuf_ = pa::dev_alloc<double>((size_t)nbuf);
+  d_recvbuf_ = pa::dev_alloc<double>((size_t)nbuf);
+}
+
+void Comm::AllReduceSum(double *d_buf, int n, hipStream_t s) {
+  if (size_ == 1) return;
+  PA_NCCL(rccl().AllReduce(d_buf, d_buf, (size_t)n, kNcclFloat64, kNcclSum, nccl_, s));
+}
+
+void Comm::Barrier(hipStream_t s) {
+  static double *d_one = pa::dev_alloc<double>(1);
+  AllReduceSum(d_one, 1, s);
+  PA_HIP(hipStreamSynchronize(s));
+}
+
+void Halo::Prolongate(double *d_lx, hipStream_t s) const {
+  void *nccl_ = comm_->nccl_;
+  if (nbr_.empty()) return;
+  if (nsend_) hipLaunchKernelGGL(k_pack, dim3(blocks(nsend_)), dim3(256), 0, s, d_lx, d_send_idx_, nsend_, d_sendbuf_);
+  PA_NCCL(rccl().GroupStart());
+  for (size_t k = 0; k < nbr_.size(); k++) {
+    const int ns = send_off_[k + 1] - send_off_[k], nr = recv_off_[k + 1] - recv_off_[k];
+    if (ns) PA_NCCL(rccl().Send(d_sendbuf_ + send_off_[k], (size_t)ns, kNcclFloat64, nbr_[k], nccl_, s));
+    if (nr) PA_NCCL(rccl().Recv(d_recvbuf_ + recv_off_[k], (size_t)nr, kNcclFloat64, nbr_[k], nccl_, s));
+  }
+  PA_NCCL(rccl().GroupEnd());
+  if (nrecv_) hipLaunchKernelGGL(k_unpack, dim3(blocks(nrecv_)), dim3(256), 0, s, d_lx, d_recv_idx_, nrecv_, d_recvbuf_);
+  PA_HIP(hipGetLastError());
+}
+
+void Halo::RestrictAdd(double *d_ly, hipStream_t s) const {
+  void *nccl_ = comm_->nccl_;
+  if (nbr_.empty()) return;
+  // roles reversed: ghosts are packed and sent to their owners
+  if (nrecv_) hipLaunchKernelGGL(k_pack, dim3(blocks(nrecv_)), dim3(256), 0, s, d_ly, d_recv_idx_, nrecv_, d_sendbuf_);
+  PA_NCCL(rccl().GroupStart());
+  for (size_t k = 0; k < nbr_.size(); k++) {
+    const int ns = recv_off_[k + 1] - recv_off_[k], nr = send_off_[k + 1] - send_off_[k];
+    if (ns) PA_NCCL(rccl().Send(d_sendbuf_ + recv_off_[k], (size_t)ns, kNcclFloat64, nbr_[k], nccl_, s));
+    if (nr) PA_NCCL(rccl().Recv(d_recvbuf_ + send_off_[k], (size_t)nr, kNcclFloat64, nbr_[k], nccl_, s));
+  }
+  PA_NCCL(rccl().GroupEnd());
+  for (size_t k = 0; k < nbr_.size(); k++) {
+    const int nr = send_off_[k + 1] - send_off_[k];
+    if (nr)
+      hipLaunchKernelGGL(k_unpack_add, dim3(blocks(nr)), dim3(256), 0, s, d_ly, d_send_idx_ + send_off_[k], nr,
+                         d_recvbuf_ + send_off_[k]);
+  }
+  PA_HIP(hipGetLastError());
+}
+
+}  // namespace palace

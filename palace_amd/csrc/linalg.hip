@@ -1,0 +1,593 @@
+// Device vector kernels and the Krylov / smoother / multigrid loop (see linalg.hpp for the
+// reference symbols each class follows).  All kernels are 1-D streaming FP64 kernels, grid-stride,
+// 16 B per lane; reductions use wavefront shuffles + one LDS stage and a second, single-block pass
+// so the summation order (and with it iteration counts) is reproducible run to run.
+#include "linalg.hpp"
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+
+#include "comm.hpp"
+
+namespace palace {
+
+// ---- Vector -----------------------------------------------------------------------------------
+Vector &Vector::operator=(Vector &&o) noexcept {
+  if (this != &o) {
+    if (own_ && d_) (void)hipFree(d_);
+    d_ = o.d_, n_ = o.n_, own_ = o.own_;
+    o.d_ = nullptr, o.n_ = 0, o.own_ = false;
+  }
+  return *this;
+}
+Vector::~Vector() {
+  if (own_ && d_) (void)hipFree(d_);
+}
+void Vector::SetSize(int n) {
+  if (own_ && n == n_) return;
+  if (own_ && d_) (void)hipFree(d_);
+  d_ = pa::dev_alloc<double>((size_t)n);
+  n_ = n, own_ = true;
+}
+void Vector::MakeRef(double *ext, int n) {
+  if (own_ && d_) (void)hipFree(d_);
+  d_ = ext, n_ = n, own_ = false;
+}
+
+// ---- kernels ----------------------------------------------------------------------------------
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 2048;  // 256 CUs x 8
+
+inline int grid_for(long long n) {
+  long long b = (n + kBlock - 1) / kBlock;
+  return (int)std::max(1LL, std::min<long long>(b, kMaxBlocks));
+}
+
+#define PA_STRIDE_LOOP(i, n)                                                                  \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n);               \
+       i += (long long)gridDim.x * blockDim.x)
+
+__global__ void k_fill(double *x, long long n, double s) { PA_STRIDE_LOOP(i, n) x[i] = s; }
+__global__ void k_axpy(double a, const double *__restrict__ x, double *__restrict__ y, long long n) {
+  PA_STRIDE_LOOP(i, n) y[i] += a * x[i];
+}
+__global__ void k_axpby(double a, const double *__restrict__ x, double b, double *__restrict__ y, long long n) {
+  PA_STRIDE_LOOP(i, n) y[i] = a * x[i] + b * y[i];
+}
+__global__ void k_axpbypcz(double a, const double *__restrict__ x, double b, const double *__restrict__ y, double g,
+                           double *__restrict__ z, long long n) {
+  PA_STRIDE_LOOP(i, n) z[i] = a * x[i] + b * y[i] + g * z[i];
+}
+__global__ void k_set_sub(double *x, const int32_t *__restrict__ rows, int n, double s) {
+  PA_STRIDE_LOOP(i, n) x[rows[i]] = s;
+}
+__global__ void k_set_sub_vec(double *x, const int32_t *__restrict__ rows, int n, const double *__restrict__ y) {
+  PA_STRIDE_LOOP(i, n) x[rows[i]] = y[rows[i]];
+}
+__global__ void k_scale(const double *__restrict__ d, double *__restrict__ y, long long n) {
+  PA_STRIDE_LOOP(i, n) y[i] *= d[i];
+}
+__global__ void k_recip(double *x, long long n) { PA_STRIDE_LOOP(i, n) x[i] = 1.0 / x[i]; }
+__global__ void k_scal(double a, double *x, long long n) { PA_STRIDE_LOOP(i, n) x[i] *= a; }
+__global__ void k_cheb0(double sr, const double *__restrict__ di, const double *__restrict__ r, double *__restrict__ d,
+                        long long n) {
+  PA_STRIDE_LOOP(i, n) d[i] = sr * di[i] * r[i];
+}
+__global__ void k_chebk(double sd, double sr, const double *__restrict__ di, const double *__restrict__ r,
+                        double *__restrict__ d, long long n) {
+  PA_STRIDE_LOOP(i, n) d[i] = sd * d[i] + sr * di[i] * r[i];
+}
+__global__ void k_random(double *x, long long n, uint64_t seed) {
+  PA_STRIDE_LOOP(i, n) {
+    // splitmix64 on (seed, i): counter-based, reproducible for any launch shape
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)i + 0x632BE59BD9B4E019ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    x[i] = 2.0 * ((double)(z >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double part[kBlock / 64];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) part[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kBlock / 64; i++) t += part[i];
+  return t;  // valid on thread 0
+}
+
+__global__ void k_dot_partial(const double *__restrict__ x, const double *__restrict__ y, long long n,
+                              double *__restrict__ partial) {
+  double s = 0.0;
+  PA_STRIDE_LOOP(i, n) s += x[i] * y[i];
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void k_dot_final(const double *__restrict__ partial, int nb, double *__restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partial[i];
+  s = block_sum(s);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+struct Scratch {
+  double *d_partial = nullptr;  // [kMaxBlocks + 8]
+  double *h_result = nullptr;   // pinned
+  Scratch() {
+    d_partial = pa::dev_alloc<double>(kMaxBlocks + 8);
+    PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_result), 8 * sizeof(double), hipHostMallocDefault));
+  }
+};
+Scratch &scratch() {
+  static Scratch s;
+  return s;
+}
+
+#define PA_LAUNCH(kernel, n, stream, ...)                                                  \
+  do {                                                                                     \
+    if ((n) > 0) {                                                                         \
+      hipLaunchKernelGGL(kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, __VA_ARGS__); \
+      PA_HIP(hipGetLastError());                                                           \
+    }                                                                                      \
+  } while (0)
+
+}  // namespace
+
+namespace linalg {
+
+void Copy(const Context &c, const Vector &x, Vector &y) {
+  PA_REQUIRE(x.Size() == y.Size(), "size mismatch in Copy");
+  if (x.Data() != y.Data())
+    PA_HIP(hipMemcpyAsync(y.Data(), x.Data(), sizeof(double) * (size_t)x.Size(), hipMemcpyDeviceToDevice, c.stream));
+}
+void Fill(const Context &c, Vector &x, double s) {
+  if (s == 0.0)
+    PA_HIP(hipMemsetAsync(x.Data(), 0, sizeof(double) * (size_t)x.Size(), c.stream));
+  else
+    PA_LAUNCH(k_fill, x.Size(), c.stream, x.Data(), (long long)x.Size(), s);
+}
+void AXPY(const Context &c, double a, const Vector &x, Vector &y) {
+  PA_LAUNCH(k_axpy, x.Size(), c.stream, a, x.Data(), y.Data(), (long long)x.Size());
+}
+void AXPBY(const Context &c, double a, const Vector &x, double b, Vector &y) {
+  PA_LAUNCH(k_axpby, x.Size(), c.stream, a, x.Data(), b, y.Data(), (long long)x.Size());
+}
+void AXPBYPCZ(const Context &c, double a, const Vector &x, double b, const Vector &y, double g, Vector &z) {
+  PA_LAUNCH(k_axpbypcz, x.Size(), c.stream, a, x.Data(), b, y.Data(), g, z.Data(), (long long)x.Size());
+}
+void SetSubVector(const Context &c, Vector &x, const int32_t *rows, int n, double s) {
+  PA_LAUNCH(k_set_sub, n, c.stream, x.Data(), rows, n, s);
+}
+void SetSubVector(const Context &c, Vector &x, const int32_t *rows, int n, const Vector &y) {
+  PA_LAUNCH(k_set_sub_vec, n, c.stream, x.Data(), rows, n, y.Data());
+}
+void Scale(const Context &c, const Vector &d, Vector &y) {
+  PA_LAUNCH(k_scale, y.Size(), c.stream, d.Data(), y.Data(), (long long)y.Size());
+}
+void Reciprocal(const Context &c, Vector &x) { PA_LAUNCH(k_recip, x.Size(), c.stream, x.Data(), (long long)x.Size()); }
+
+double Dot(const Context &c, const Vector &x, const Vector &y) {
+  PA_REQUIRE(x.Size() == y.Size(), "size mismatch in Dot");
+  Scratch &s = scratch();
+  const int nb = grid_for(x.Size());
+  hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(kBlock), 0, c.stream, x.Data(), y.Data(), (long long)x.Size(),
+                     s.d_partial);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kBlock), 0, c.stream, s.d_partial, nb, s.d_partial + kMaxBlocks);
+  PA_HIP(hipGetLastError());
+  if (c.comm) c.comm->AllReduceSum(s.d_partial + kMaxBlocks, 1, c.stream);  // Mpi::GlobalSum
+  PA_HIP(hipMemcpyAsync(s.h_result, s.d_partial + kMaxBlocks, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  PA_HIP(hipStreamSynchronize(c.stream));
+  return s.h_result[0];
+}
+double Norml2(const Context &c, const Vector &x) { return std::sqrt(Dot(c, x, x)); }
+double Normalize(const Context &c, Vector &x) {
+  const double nrm = Norml2(c, x);
+  PA_REQUIRE(nrm > 0.0, "zero vector norm in normalization");
+  PA_LAUNCH(k_scal, x.Size(), c.stream, 1.0 / nrm, x.Data(), (long long)x.Size());
+  return nrm;
+}
+void SetRandom(const Context &c, Vector &x, uint64_t seed) {
+  const uint64_t rank_seed = seed + (c.comm ? 7919ull * (uint64_t)c.comm->Rank() : 0ull);
+  PA_LAUNCH(k_random, x.Size(), c.stream, x.Data(), (long long)x.Size(), rank_seed);
+}
+void ChebyOrder0(const Context &c, double sr, const Vector &dinv, const Vector &r, Vector &d) {
+  PA_LAUNCH(k_cheb0, d.Size(), c.stream, sr, dinv.Data(), r.Data(), d.Data(), (long long)d.Size());
+}
+void ChebyOrderK(const Context &c, double sd, double sr, const Vector &dinv, const Vector &r, Vector &d) {
+  PA_LAUNCH(k_chebk, d.Size(), c.stream, sd, sr, dinv.Data(), r.Data(), d.Data(), (long long)d.Size());
+}
+
+// Power iteration on D^{-1} A (chebyshev.cpp:14-28 + linalg/operator.cpp:583-631, herm = true)
+double SpectralNorm(const Context &c, const Operator &A, const Vector &dinv, double tol, int max_it, uint64_t seed) {
+  Vector u(A.Height()), v(A.Height());
+  SetRandom(c, u, seed);
+  Normalize(c, u);
+  double l = 0.0, l0 = 0.0;
+  int it = 0;
+  while (it < max_it) {
+    A.Mult(u, v);
+    Scale(c, dinv, v);
+    Copy(c, v, u);
+    l = Normalize(c, u);
+    if (it > 0 && std::abs(l - l0) / l0 < tol) break;
+    l0 = l;
+    it++;
+  }
+  return l;
+}
+
+}  // namespace linalg
+
+// ---- Operator defaults ------------------------------------------------------------------------
+void Operator::AddMult(const Vector &, Vector &, double) const { throw pa::Error("AddMult not implemented"); }
+void Operator::AssembleDiagonal(Vector &) const { throw pa::Error("AssembleDiagonal not implemented"); }
+void Solver::Mult2(const Vector &, Vector &, Vector &) const { throw pa::Error("Mult2 not implemented"); }
+
+namespace ceed {
+Operator::Operator(const Context &ctx, pa_op *op, bool own)
+    : palace::Operator(pa_op_height(op), pa_op_width(op)), op_(op), own_(own), ctx_(&ctx) {}
+Operator::~Operator() {
+  if (own_) pa_op_destroy(op_);
+}
+static void check(int rc) {
+  if (rc) throw pa::Error(pa_last_error());
+}
+void Operator::Mult(const Vector &x, Vector &y) const { check(pa_op_mult(op_, x.Data(), y.Data(), ctx_->stream)); }
+void Operator::AddMult(const Vector &x, Vector &y, double a) const {
+  PA_REQUIRE(a == 1.0, "ceed::Operator::AddMult only supports coefficient = 1.0!");  // operator.cpp:194
+  check(pa_op_apply_add(op_, x.Data(), y.Data(), ctx_->stream));
+}
+void Operator::AssembleDiagonal(Vector &diag) const { check(pa_op_assemble_diagonal(op_, diag.Data(), ctx_->stream)); }
+}  // namespace ceed
+
+// ---- ParOperator ------------------------------------------------------------------------------
+ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, const int32_t *ess_host, int n_ess,
+                         DiagonalPolicy policy, const Halo *halo)
+    : Operator(n_true, n_true), ctx_(&ctx), A_(&A), halo_(halo), n_true_(n_true), n_local_(A.Height()),
+      n_ess_(n_ess), policy_(policy) {
+  PA_REQUIRE(A.Height() == A.Width(), "ParOperator needs a square local operator");
+  PA_REQUIRE(n_true <= n_local_, "more true dofs than local dofs");
+  PA_REQUIRE(halo != nullptr || n_true == n_local_, "local != true dofs requires a halo plan");
+  for (int i = 0; i < n_ess; i++) PA_REQUIRE(ess_host[i] >= 0 && ess_host[i] < n_true, "essential dof out of range");
+  if (n_ess) d_ess_ = pa::dev_upload(ess_host, (size_t)n_ess, ctx.stream);
+  lx_.SetSize(n_local_);
+  ly_.SetSize(n_local_);
+}
+ParOperator::~ParOperator() {
+  if (d_ess_) (void)hipFree(d_ess_);
+}
+
+void ParOperator::Mult(const Vector &x, Vector &y) const {
+  // rap.cpp:195-234.  tx = x, tx[ess] = 0; lx = P tx; ly = A lx; y = P^T ly; y[ess] = x[ess] | 0
+  const Context &c = *ctx_;
+  Vector tx(lx_.Data(), n_true_);
+  linalg::Copy(c, x, tx);
+  if (n_ess_) linalg::SetSubVector(c, tx, d_ess_, n_ess_, 0.0);
+  if (halo_) halo_->Prolongate(lx_.Data(), c.stream);  // owners -> sharers (P)
+  A_->Mult(lx_, ly_);
+  if (halo_) halo_->RestrictAdd(ly_.Data(), c.stream);  // sharers -> owners, summed (P^T)
+  Vector ty(ly_.Data(), n_true_);
+  linalg::Copy(c, ty, y);
+  if (n_ess_) {
+    if (policy_ == DiagonalPolicy::DIAG_ONE)
+      linalg::SetSubVector(c, y, d_ess_, n_ess_, x);
+    else
+      linalg::SetSubVector(c, y, d_ess_, n_ess_, 0.0);
+  }
+}
+
+void ParOperator::AssembleDiagonal(Vector &diag) const {
+  // rap.cpp:154-193 (conforming meshes: |P|^T = P^T)
+  const Context &c = *ctx_;
+  A_->AssembleDiagonal(ly_);
+  if (halo_) halo_->RestrictAdd(ly_.Data(), c.stream);
+  Vector ty(ly_.Data(), n_true_);
+  linalg::Copy(c, ty, diag);
+  if (n_ess_) linalg::SetSubVector(c, diag, d_ess_, n_ess_, policy_ == DiagonalPolicy::DIAG_ONE ? 1.0 : 0.0);
+}
+
+// ---- smoothers --------------------------------------------------------------------------------
+void JacobiSmoother::SetOperator(const Operator &op) {
+  A_ = &op, height = op.Height(), width = op.Width();
+  dinv_.SetSize(height);
+  op.AssembleDiagonal(dinv_);
+  linalg::Reciprocal(*ctx_, dinv_);
+}
+void JacobiSmoother::Mult(const Vector &x, Vector &y) const {
+  // jacobi.cpp:74-104 with zero initial guess: y = D^{-1} x
+  linalg::ChebyOrder0(*ctx_, 1.0, dinv_, x, y);
+}
+
+void ChebyshevSmoother::SetOperator(const Operator &op) {
+  // chebyshev.cpp:169-188 (4th kind) / :232-257 (1st kind)
+  A_ = &op, height = op.Height(), width = op.Width();
+  d_.SetSize(height), dinv_.SetSize(height), r_.SetSize(height), t_.SetSize(height);
+  op.AssembleDiagonal(dinv_);
+  linalg::Reciprocal(*ctx_, dinv_);
+  lambda_max_ = sf_max_ * linalg::SpectralNorm(*ctx_, op, dinv_);
+  PA_REQUIRE(lambda_max_ > 0.0, "Encountered zero maximum eigenvalue in Chebyshev smoother!");
+  if (!fourth_kind_ && sf_min_ <= 0.0) sf_min_ = 1.69 / (std::pow(order_, 1.68) + 2.11 * order_ + 1.98);
+}
+void ChebyshevSmoother::Mult(const Vector &x, Vector &y) const { Mult2(x, y, r_); }
+void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
+  const Context &c = *ctx_;
+  for (int it = 0; it < pc_it_; it++) {
+    if (initial_guess || it > 0) {
+      A_->Mult(y, r);
+      linalg::AXPBY(c, 1.0, x, -1.0, r);
+    } else {
+      linalg::Copy(c, x, r);
+      linalg::Fill(c, y, 0.0);
+    }
+    if (fourth_kind_) {  // chebyshev.cpp:204-218
+      linalg::ChebyOrder0(c, 4.0 / (3.0 * lambda_max_), dinv_, r, d_);
+      for (int k = 1; k < order_; k++) {
+        linalg::AXPY(c, 1.0, d_, y);
+        A_->Mult(d_, t_);
+        linalg::AXPY(c, -1.0, t_, r);
+        const double sd = (2.0 * k - 1.0) / (2.0 * k + 3.0);
+        const double sr = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lambda_max_);
+        linalg::ChebyOrderK(c, sd, sr, dinv_, r, d_);
+      }
+    } else {  // chebyshev.cpp:275-291
+      const double lmax = lambda_max_, lmin = sf_min_ * lmax;
+      const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+      linalg::ChebyOrder0(c, 1.0 / theta, dinv_, r, d_);
+      double rhop = delta / theta;
+      for (int k = 1; k < order_; k++) {
+        linalg::AXPY(c, 1.0, d_, y);
+        A_->Mult(d_, t_);
+        linalg::AXPY(c, -1.0, t_, r);
+        const double rho = 1.0 / (2.0 * theta / delta - rhop);
+        linalg::ChebyOrderK(c, rho * rhop, 2.0 * rho / delta, dinv_, r, d_);
+        rhop = rho;
+      }
+    }
+    linalg::AXPY(c, 1.0, d_, y);
+  }
+}
+
+// ---- PCG (iterative.cpp:360-486) ----------------------------------------------------------------
+void CgSolver::Mult(const Vector &b, Vector &x) const {
+  const Context &c = *ctx_;
+  PA_REQUIRE(A_, "Operator must be set for CgSolver::Mult!");
+  const int n = A_->Height();
+  r_.SetSize(n), z_.SetSize(n), p_.SetSize(n);
+  double beta, beta_prev = 0.0, alpha, denom, res, eps;
+  if (initial_guess) {
+    A_->Mult(x, r_);
+    linalg::AXPBY(c, 1.0, b, -1.0, r_);
+  } else {
+    linalg::Copy(c, b, r_);
+    linalg::Fill(c, x, 0.0);
+  }
+  if (B_) B_->Mult(r_, z_); else linalg::Copy(c, r_, z_);
+  beta = linalg::Dot(c, z_, r_);
+  PA_REQUIRE(std::isfinite(beta), "PCG preconditioner is not positive definite: (Br, r) not finite");
+  res = std::sqrt(std::abs(beta));
+  if (initial_guess) {
+    double beta_rhs;
+    if (B_) {
+      B_->Mult(b, p_);
+      beta_rhs = linalg::Dot(c, p_, b);
+    } else {
+      beta_rhs = linalg::Norml2(c, b);
+    }
+    initial_res_ = std::sqrt(std::abs(beta_rhs));
+  } else {
+    initial_res_ = res;
+  }
+  eps = std::max(rel_tol_ * initial_res_, abs_tol_);
+  converged_ = (res < eps);
+  int it = 0;
+  for (; it < max_it_ && !converged_; it++) {
+    if (print_ > 1) std::printf("  %3d KSP residual norm ||r||_B = %.6e\n", it, res);
+    if (!it)
+      linalg::Copy(c, z_, p_);
+    else
+      linalg::AXPBY(c, 1.0, z_, beta / beta_prev, p_);
+    A_->Mult(p_, z_);
+    denom = linalg::Dot(c, z_, p_);
+    PA_REQUIRE(std::isfinite(denom), "PCG operator is not positive definite: (Ap, p) not finite");
+    alpha = beta / denom;
+    linalg::AXPY(c, alpha, p_, x);
+    linalg::AXPY(c, -alpha, z_, r_);
+    beta_prev = beta;
+    if (B_) B_->Mult(r_, z_); else linalg::Copy(c, r_, z_);
+    beta = linalg::Dot(c, z_, r_);
+    PA_REQUIRE(std::isfinite(beta), "PCG preconditioner is not positive definite: (Br, r) not finite");
+    res = std::sqrt(std::abs(beta));
+    converged_ = (res < eps);
+  }
+  if (print_ > 0)
+    std::printf("  PCG solver %s in %d iterations (res %.3e, initial %.3e)\n",
+                converged_ ? "converged" : "did NOT converge", it, res, initial_res_);
+  final_res_ = res, final_it_ = it;
+}
+
+// ---- GMRES / FGMRES (iterative.cpp:543-871), real scalars, MGS (orthog.hpp:41-55) ---------------
+namespace {
+// LAPACK dlartg semantics used by the reference (iterative.cpp:72-241): r = sqrt(f^2+g^2)
+inline void GeneratePlaneRotation(double dx, double dy, double &cs, double &sn) {
+  if (dy == 0.0) {
+    cs = 1.0, sn = 0.0;
+  } else if (dx == 0.0) {
+    cs = 0.0, sn = 1.0;
+  } else {
+    const double r = std::copysign(std::hypot(dx, dy), dx);
+    cs = dx / r, sn = dy / r;
+  }
+}
+inline void ApplyPlaneRotation(double &dx, double &dy, double cs, double sn) {
+  const double t = cs * dx + sn * dy;
+  dy = -sn * dx + cs * dy;
+  dx = t;
+}
+}  // namespace
+
+void GmresSolver::Mult(const Vector &b, Vector &x) const {
+  const Context &c = *ctx_;
+  PA_REQUIRE(A_, "Operator must be set for GmresSolver::Mult!");
+  const int n = A_->Height();
+  const int m = (max_dim_ > 0) ? std::min(max_dim_, max_it_) : max_it_;
+  r_.SetSize(n);
+  if ((int)V_.size() < m + 1) V_.resize(m + 1);
+  if (flexible_ && (int)Z_.size() < m + 1) Z_.resize(m + 1);
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), s(m + 1), cs(m + 1), sn(m + 1);
+  auto Hij = [&](int i, int j) -> double & { return H[(size_t)j * (m + 1) + i]; };
+  auto ensure = [&](std::vector<Vector> &W, int j) {
+    if (W[j].Size() != n) W[j].SetSize(n);
+  };
+  // residual (left preconditioning for GMRES: r = B (b - A x); FGMRES: r = b - A x)
+  bool initial_guess_or_restart_ = initial_guess;
+  auto initial_residual = [&]() {
+    ensure(V_, 0);
+    if (initial_guess_or_restart_) {
+      A_->Mult(x, r_);
+      linalg::AXPBY(c, 1.0, b, -1.0, r_);
+    } else {
+      linalg::Copy(c, b, r_);
+      linalg::Fill(c, x, 0.0);
+    }
+    if (B_ && !flexible_) B_->Mult(r_, V_[0]); else linalg::Copy(c, r_, V_[0]);
+    return linalg::Norml2(c, V_[0]);
+  };
+  double beta = initial_residual();
+  if (initial_guess) {
+    // initial_res from the preconditioned right-hand side (iterative.cpp:572-584)
+    if (B_ && !flexible_) {
+      ensure(V_, 1);
+      B_->Mult(b, V_[1]);
+      initial_res_ = linalg::Norml2(c, V_[1]);
+    } else {
+      initial_res_ = linalg::Norml2(c, b);
+    }
+  } else {
+    initial_res_ = beta;
+  }
+  const double eps = std::max(rel_tol_ * initial_res_, abs_tol_);
+  converged_ = (beta < eps);
+  int it = 0;
+  double res = beta;
+  while (it < max_it_ && !converged_) {
+    if (beta == 0.0) break;
+    {
+      Vector &v0 = V_[0];
+      hipLaunchKernelGGL(k_scal, dim3(grid_for(n)), dim3(kBlock), 0, c.stream, 1.0 / beta, v0.Data(), (long long)n);
+    }
+    std::fill(s.begin(), s.end(), 0.0);
+    s[0] = beta;
+    int j = 0;
+    for (; j < m && it < max_it_; j++, it++) {
+      ensure(V_, j + 1);
+      Vector &w = V_[j + 1];
+      if (flexible_) {
+        ensure(Z_, j);
+        if (B_) B_->Mult(V_[j], Z_[j]); else linalg::Copy(c, V_[j], Z_[j]);
+        A_->Mult(Z_[j], w);
+      } else {
+        A_->Mult(V_[j], r_);
+        if (B_) B_->Mult(r_, w); else linalg::Copy(c, r_, w);
+      }
+      for (int i = 0; i <= j; i++) {  // modified Gram-Schmidt
+        Hij(i, j) = linalg::Dot(c, w, V_[i]);
+        linalg::AXPY(c, -Hij(i, j), V_[i], w);
+      }
+      Hij(j + 1, j) = linalg::Norml2(c, w);
+      if (Hij(j + 1, j) != 0.0)
+        hipLaunchKernelGGL(k_scal, dim3(grid_for(n)), dim3(kBlock), 0, c.stream, 1.0 / Hij(j + 1, j), w.Data(),
+                           (long long)n);
+      for (int k = 0; k < j; k++) ApplyPlaneRotation(Hij(k, j), Hij(k + 1, j), cs[k], sn[k]);
+      GeneratePlaneRotation(Hij(j, j), Hij(j + 1, j), cs[j], sn[j]);
+      ApplyPlaneRotation(Hij(j, j), Hij(j + 1, j), cs[j], sn[j]);
+      ApplyPlaneRotation(s[j], s[j + 1], cs[j], sn[j]);
+      res = std::abs(s[j + 1]);
+      if (print_ > 1) std::printf("  %3d (restart %d) KSP residual norm %.6e\n", it + 1, j + 1, res);
+      converged_ = (res < eps);
+      if (converged_) { j++, it++; break; }
+    }
+    // back substitution and solution update
+    for (int i = j - 1; i >= 0; i--) {
+      s[i] /= Hij(i, i);
+      for (int k = i - 1; k >= 0; k--) s[k] -= Hij(k, i) * s[i];
+    }
+    for (int k = 0; k < j; k++) linalg::AXPY(c, s[k], flexible_ ? Z_[k] : V_[k], x);
+    if (converged_) break;
+    initial_guess_or_restart_ = true;
+    beta = initial_residual();
+    res = beta;
+    converged_ = (beta < eps);
+  }
+  if (print_ > 0)
+    std::printf("  GMRES solver %s in %d iterations (res %.3e, initial %.3e)\n",
+                converged_ ? "converged" : "did NOT converge", it, res, initial_res_);
+  final_res_ = res, final_it_ = it;
+}
+
+// ---- geometric multigrid (gmg.cpp) ---------------------------------------------------------------
+GeometricMultigridSolver::GeometricMultigridSolver(const Context &ctx, std::unique_ptr<Solver> &&coarse_solver,
+                                                   const std::vector<const Operator *> &P, int cycle_it, int smooth_it,
+                                                   int cheby_order, double cheby_sf_max, double cheby_sf_min,
+                                                   bool cheby_4th_kind)
+    : ctx_(&ctx), pc_it_(cycle_it), P_(P), A_(P.size() + 1), B_(P.size() + 1), X_(P.size() + 1), Y_(P.size() + 1),
+      R_(P.size() + 1) {
+  B_[0] = std::move(coarse_solver);
+  for (size_t l = 1; l < B_.size(); l++)
+    B_[l] = std::make_unique<ChebyshevSmoother>(ctx, smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind, cheby_sf_min);
+}
+
+void GeometricMultigridSolver::SetOperators(const std::vector<const ParOperator *> &ops) {
+  PA_REQUIRE(ops.size() == A_.size(), "Invalid number of levels for operators in multigrid solver setup!");
+  for (size_t l = 0; l < ops.size(); l++) {
+    A_[l] = ops[l];
+    PA_REQUIRE(A_[l]->Width() == A_[l]->Height(), "Invalid operator sizes for GeometricMultigridSolver!");
+    if (l + 1 < ops.size()) PA_REQUIRE(A_[l]->Height() == P_[l]->Width(), "Prolongation / operator size mismatch");
+    if (l > 0) PA_REQUIRE(A_[l]->Height() == P_[l - 1]->Height(), "Prolongation / operator size mismatch");
+    B_[l]->SetOperator(*A_[l]);
+    X_[l].SetSize(A_[l]->Height()), Y_[l].SetSize(A_[l]->Height()), R_[l].SetSize(A_[l]->Height());
+  }
+  height = width = ops.back()->Height();
+}
+
+void GeometricMultigridSolver::Mult(const Vector &x, Vector &y) const {
+  const int L = (int)A_.size();
+  linalg::Copy(*ctx_, x, X_[L - 1]);
+  for (int it = 0; it < pc_it_; it++) VCycle(L - 1, it > 0);
+  linalg::Copy(*ctx_, Y_[L - 1], y);
+}
+
+void GeometricMultigridSolver::VCycle(int l, bool initial_guess) const {
+  // gmg.cpp:171-205
+  const Context &c = *ctx_;
+  B_[l]->SetInitialGuess(initial_guess);
+  if (l == 0) {
+    B_[l]->Mult(X_[l], Y_[l]);
+    return;
+  }
+  B_[l]->Mult2(X_[l], Y_[l], R_[l]);
+  A_[l]->Mult(Y_[l], R_[l]);
+  linalg::AXPBY(c, 1.0, X_[l], -1.0, R_[l]);
+  P_[l - 1]->MultTranspose(R_[l], X_[l - 1]);
+  if (A_[l - 1]->NumEssentialTrueDofs())
+    linalg::SetSubVector(c, X_[l - 1], A_[l - 1]->GetEssentialTrueDofs(), A_[l - 1]->NumEssentialTrueDofs(), 0.0);
+  VCycle(l - 1, false);
+  P_[l - 1]->Mult(Y_[l - 1], R_[l]);
+  linalg::AXPY(c, 1.0, R_[l], Y_[l]);
+  B_[l]->SetInitialGuess(true);
+  B_[l]->MultTranspose2(X_[l], Y_[l], R_[l]);
+}
+
+}  // namespace palace

@@ -1,0 +1,272 @@
+// Host-side C++ mirror of the pieces of palace::linalg that sit on the hot path, written against
+// device (HBM) vectors and HIP streams.  Names, argument meaning and conventions follow the
+// reference so Palace's drivers can use these objects in place of its own:
+//   Operator / Solver            palace/linalg/operator.hpp:21, palace/linalg/solver.hpp:21-65
+//   ceed::Operator               palace/fem/libceed/operator.hpp:32-65
+//   ParOperator                  palace/linalg/rap.hpp, rap.cpp:154-234
+//   linalg:: vector kernels      palace/linalg/vector.cpp:276-592,665-698, vector.hpp:247-270
+//   CgSolver                     palace/linalg/iterative.cpp:360-486
+//   GmresSolver                  palace/linalg/iterative.cpp:543-705 (MGS, orthog.hpp:41-55)
+//   ChebyshevSmoother (4th kind) palace/linalg/chebyshev.cpp:160-220, 1st kind :222-293
+//   JacobiSmoother               palace/linalg/jacobi.cpp:74-104
+//   GeometricMultigridSolver     palace/linalg/gmg.cpp:16-205
+//   SpectralNorm                 palace/linalg/operator.cpp:583-631
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "pa_internal.hpp"
+
+namespace palace {
+
+class Comm;  // RCCL communicator (comm.hpp); nullptr = single process
+class Halo;  // conforming prolongation of one space across ranks (comm.hpp)
+
+// Execution context shared by the objects of one solve: the stream everything is enqueued on and
+// the communicator used by global reductions / halo exchanges.
+struct Context {
+  hipStream_t stream = nullptr;
+  Comm *comm = nullptr;
+};
+
+// Device vector: owning, or a view of caller memory (mfem::Vector with device memory in Palace).
+class Vector {
+  double *d_ = nullptr;
+  int n_ = 0;
+  bool own_ = false;
+
+public:
+  Vector() = default;
+  explicit Vector(int n) { SetSize(n); }
+  Vector(double *ext, int n) : d_(ext), n_(n), own_(false) {}
+  Vector(const Vector &) = delete;
+  Vector &operator=(const Vector &) = delete;
+  Vector(Vector &&o) noexcept : d_(o.d_), n_(o.n_), own_(o.own_) { o.d_ = nullptr, o.n_ = 0, o.own_ = false; }
+  Vector &operator=(Vector &&o) noexcept;
+  ~Vector();
+  void SetSize(int n);
+  void MakeRef(double *ext, int n);
+  int Size() const { return n_; }
+  double *Data() { return d_; }
+  const double *Data() const { return d_; }
+};
+
+namespace linalg {
+
+// y = x ; x = s
+void Copy(const Context &c, const Vector &x, Vector &y);
+void Fill(const Context &c, Vector &x, double s);
+// vector.cpp:702-785
+void AXPY(const Context &c, double alpha, const Vector &x, Vector &y);
+void AXPBY(const Context &c, double alpha, const Vector &x, double beta, Vector &y);
+void AXPBYPCZ(const Context &c, double alpha, const Vector &x, double beta, const Vector &y, double gamma,
+              Vector &z);
+// x[rows] = s ; x[rows] = y[rows]   (vector.cpp:461-510)
+void SetSubVector(const Context &c, Vector &x, const int32_t *d_rows, int nrows, double s);
+void SetSubVector(const Context &c, Vector &x, const int32_t *d_rows, int nrows, const Vector &y);
+// y = x .* y, x = 1 ./ x
+void Scale(const Context &c, const Vector &d, Vector &y);
+void Reciprocal(const Context &c, Vector &x);
+// Global inner product of T-vectors: local wavefront/LDS tree reduction + allreduce
+// (vector.hpp:247-260).
+double Dot(const Context &c, const Vector &x, const Vector &y);
+double Norml2(const Context &c, const Vector &x);
+// x /= ||x||, returns the norm (vector.hpp:264-270)
+double Normalize(const Context &c, Vector &x);
+// Deterministic uniform [-1, 1) fill from a counter-based generator (stands in for
+// SetRandom, vector.cpp:595-605; the reference's stream comes from MFEM and is not reproducible)
+void SetRandom(const Context &c, Vector &x, uint64_t seed);
+// chebyshev.cpp:69-156
+void ChebyOrder0(const Context &c, double sr, const Vector &dinv, const Vector &r, Vector &d);
+void ChebyOrderK(const Context &c, double sd, double sr, const Vector &dinv, const Vector &r, Vector &d);
+// y += d, then d = sd d + sr dinv .* r is what the smoother does around an operator apply; the
+// fused form saves one pass over d:  y += d  (returned separately to keep the reference order)
+
+}  // namespace linalg
+
+// mfem::Operator as Palace uses it (linalg/operator.hpp:21).
+class Operator {
+protected:
+  int height = 0, width = 0;
+
+public:
+  Operator(int h = 0, int w = 0) : height(h), width(w) {}
+  virtual ~Operator() = default;
+  int Height() const { return height; }
+  int Width() const { return width; }
+  virtual void Mult(const Vector &x, Vector &y) const = 0;
+  virtual void MultTranspose(const Vector &x, Vector &y) const { Mult(x, y); }
+  // y += a A x
+  virtual void AddMult(const Vector &x, Vector &y, double a = 1.0) const;
+  virtual void AssembleDiagonal(Vector &diag) const;
+};
+
+namespace ceed {
+
+// palace::ceed::Operator over the C ABI (non-owning or owning handle).
+class Operator : public palace::Operator {
+  pa_op *op_;
+  bool own_;
+  const Context *ctx_;
+
+public:
+  Operator(const Context &ctx, pa_op *op, bool own);
+  ~Operator() override;
+  pa_op *Handle() const { return op_; }
+  void Mult(const Vector &x, Vector &y) const override;
+  void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
+  void AssembleDiagonal(Vector &diag) const override;
+};
+
+}  // namespace ceed
+
+// ParOperator (rap.cpp:154-234): y = P^T A P x with essential-dof handling.  True dofs of this
+// rank are the first n_true entries of the local (L-) vector; shared dofs owned elsewhere follow
+// (see comm.hpp); with one rank P is the identity.
+class ParOperator : public Operator {
+public:
+  enum class DiagonalPolicy { DIAG_ZERO = 0, DIAG_ONE = 1 };
+
+private:
+  const Context *ctx_;
+  const Operator *A_;
+  const Halo *halo_;
+  int n_true_, n_local_;
+  int32_t *d_ess_ = nullptr;
+  int n_ess_ = 0;
+  DiagonalPolicy policy_;
+  mutable Vector lx_, ly_;
+
+public:
+  ParOperator(const Context &ctx, const Operator &A, int n_true, const int32_t *ess_host, int n_ess,
+              DiagonalPolicy policy, const Halo *halo = nullptr);
+  ~ParOperator() override;
+  const int32_t *GetEssentialTrueDofs() const { return d_ess_; }
+  int NumEssentialTrueDofs() const { return n_ess_; }
+  const Operator &LocalOperator() const { return *A_; }
+  void Mult(const Vector &x, Vector &y) const override;
+  void AssembleDiagonal(Vector &diag) const override;
+};
+
+// Solver<Operator> (solver.hpp:21-65)
+class Solver : public Operator {
+protected:
+  bool initial_guess = false;
+
+public:
+  virtual void SetOperator(const Operator &op) = 0;
+  void SetInitialGuess(bool guess = true) { initial_guess = guess; }
+  // y <- y + B (x - A y) style entry points used by the V-cycle (gmg.cpp:184,204)
+  virtual void Mult2(const Vector &x, Vector &y, Vector &r) const;
+  virtual void MultTranspose2(const Vector &x, Vector &y, Vector &r) const { Mult2(x, y, r); }
+};
+
+namespace linalg {
+double SpectralNorm(const Context &c, const Operator &A, const Vector &dinv, double tol = 1e-4, int max_it = 1000,
+                    uint64_t seed = 0);
+}
+
+class JacobiSmoother : public Solver {
+  const Context *ctx_;
+  const Operator *A_ = nullptr;
+  Vector dinv_;
+
+public:
+  explicit JacobiSmoother(const Context &ctx) : ctx_(&ctx) {}
+  void SetOperator(const Operator &op) override;
+  void Mult(const Vector &x, Vector &y) const override;
+};
+
+class ChebyshevSmoother : public Solver {
+  const Context *ctx_;
+  int pc_it_, order_;
+  double sf_max_, lambda_max_ = 0.0;
+  bool fourth_kind_;
+  double sf_min_;
+  const Operator *A_ = nullptr;
+  Vector dinv_;
+  mutable Vector d_, r_, t_;
+
+public:
+  ChebyshevSmoother(const Context &ctx, int smooth_it, int poly_order, double sf_max = 1.0, bool fourth_kind = true,
+                    double sf_min = 0.0)
+      : ctx_(&ctx), pc_it_(smooth_it), order_(poly_order), sf_max_(sf_max), fourth_kind_(fourth_kind),
+        sf_min_(sf_min) {}
+  void SetOperator(const Operator &op) override;
+  double LambdaMax() const { return lambda_max_; }
+  void Mult(const Vector &x, Vector &y) const override;
+  void Mult2(const Vector &x, Vector &y, Vector &r) const override;
+};
+
+// Iterative solver base (iterative.hpp:25-115)
+class IterativeSolver : public Solver {
+protected:
+  const Context *ctx_;
+  const Operator *A_ = nullptr;
+  const Solver *B_ = nullptr;
+  double rel_tol_ = 0.0, abs_tol_ = 0.0;
+  int max_it_ = 100;
+  mutable bool converged_ = false;
+  mutable double initial_res_ = 1.0, final_res_ = 0.0;
+  mutable int final_it_ = 0;
+  int print_ = 0;
+
+public:
+  explicit IterativeSolver(const Context &ctx, int print = 0) : ctx_(&ctx), print_(print) {}
+  void SetOperator(const Operator &op) override { A_ = &op, height = op.Height(), width = op.Width(); }
+  void SetPreconditioner(const Solver &pc) { B_ = &pc; }
+  void SetTol(double tol) { rel_tol_ = tol; }
+  void SetAbsTol(double tol) { abs_tol_ = tol; }
+  void SetMaxIter(int its) { max_it_ = its; }
+  bool GetConverged() const { return converged_; }
+  double GetInitialRes() const { return initial_res_; }
+  double GetFinalRes() const { return final_res_; }
+  int GetNumIterations() const { return final_it_; }
+};
+
+class CgSolver : public IterativeSolver {
+  mutable Vector r_, z_, p_;
+
+public:
+  using IterativeSolver::IterativeSolver;
+  void Mult(const Vector &b, Vector &x) const override;
+};
+
+class GmresSolver : public IterativeSolver {
+  int max_dim_ = -1;
+  bool flexible_ = false;  // FGMRES (right preconditioning, stores Z)
+  mutable std::vector<Vector> V_, Z_;
+  mutable Vector r_;
+
+public:
+  GmresSolver(const Context &ctx, int print = 0, bool flexible = false) : IterativeSolver(ctx, print), flexible_(flexible) {}
+  void SetRestartDim(int dim) { max_dim_ = dim; }
+  void Mult(const Vector &b, Vector &x) const override;
+};
+
+// GeometricMultigridSolver (gmg.cpp): levels 0 (coarsest) .. L-1, prolongations P[l]: level l -> l+1
+class GeometricMultigridSolver : public Solver {
+  const Context *ctx_;
+  int pc_it_;
+  std::vector<const Operator *> P_;
+  std::vector<const ParOperator *> A_;
+  std::vector<std::unique_ptr<Solver>> B_;
+  mutable std::vector<Vector> X_, Y_, R_;
+  void VCycle(int l, bool initial_guess) const;
+
+public:
+  GeometricMultigridSolver(const Context &ctx, std::unique_ptr<Solver> &&coarse_solver,
+                           const std::vector<const Operator *> &P, int cycle_it, int smooth_it, int cheby_order,
+                           double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true);
+  // Operators for every level (the reference passes a MultigridOperator, gmg.cpp:69-123)
+  void SetOperators(const std::vector<const ParOperator *> &ops);
+  void SetOperator(const Operator &) override { throw pa::Error("use SetOperators for multigrid"); }
+  void Mult(const Vector &x, Vector &y) const override;
+  const Solver &Smoother(int l) const { return *B_[l]; }
+};
+
+}  // namespace palace

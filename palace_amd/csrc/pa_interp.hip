@@ -1,0 +1,286 @@
+// p-prolongation / restriction between Nedelec (or H1) spaces of two orders on the same hex mesh.
+//
+// Replaces the libCEED "interpolator" operator Palace builds in DiscreteLinearOperator::
+// PartialAssemble (reference fem/bilinearform.cpp:203-282; identity QFunction + projection-matrix
+// basis, fem/libceed/integrator.cpp:515-548, fem/libceed/basis.cpp:116-165) and the multiplicity
+// scaling around it (fem/libceed/operator.cpp:182-240).  The element matrix is a Kronecker product
+// of 1-D nodal interpolation matrices, applied by sum factorisation; mapping as in pa_nd_hex.hip:
+// (p_f+1)^2 lanes per element, hand-offs through LDS inside the wave.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "linalg.hpp"
+#include "comm.hpp"
+
+namespace palace {
+
+namespace {
+
+constexpr int kMaxN = 6;  // closed nodes per direction
+
+struct InterpArgs {
+  int ne, fe_type, pc, pf;
+  const int32_t *lidx_c, *lidx_f;
+  const double *Ic, *Io;      // device: [(pf+1)*(pc+1)], [pf*pc]
+  const double *inv_mult;     // [n_local_fine]
+  const double *x;
+  double *y;
+};
+
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One component block: coarse dims (nc[0..2]) -> fine dims (nf[0..2]); M[d] the 1-D matrix
+// [nf[d]][nc[d]] of direction d.  TRANSPOSE applies the transposed element matrix.
+template <bool TRANSPOSE>
+__device__ void interp_block(const InterpArgs &a, const int e, const bool active, const bool lane_ok,
+                             const int ta, const int tb, double *sm, const int off_c, const int off_f,
+                             const int Pc, const int Pf, const int nc0, const int nc1, const int nc2,
+                             const int nf0, const int nf1, const int nf2, const double *M0,
+                             const double *M1, const double *M2) {
+  const int n1c = a.pf + 1;
+  double *sA = sm, *sB = sm + n1c * n1c * n1c;
+  if (!TRANSPOSE) {
+    // pass X: lane (j_c, k_c) -> fine i
+    {
+      const bool act = ta < nc1 && tb < nc2;
+      double u[kMaxN];
+      for (int i = 0; i < nc0; i++) {
+        double v = 0.0;
+        if (active && act) {
+          const int s = a.lidx_c[(size_t)e * Pc + off_c + i + nc0 * (ta + nc1 * tb)];
+          const double xv = a.x[s >= 0 ? s : -1 - s];
+          v = s >= 0 ? xv : -xv;
+        }
+        u[i] = v;
+      }
+      for (int fi = 0; fi < nf0; fi++) {
+        double v = 0.0;
+        for (int i = 0; i < nc0; i++) v += M0[fi * nc0 + i] * u[i];
+        if (lane_ok && act) sA[(fi * nc1 + ta) * nc2 + tb] = v;
+      }
+    }
+    wsync();
+    // pass Y: lane (i_f, k_c) -> fine j
+    {
+      const bool act = ta < nf0 && tb < nc2;
+      double u[kMaxN];
+      for (int j = 0; j < nc1; j++) u[j] = sA[((act ? ta : 0) * nc1 + j) * nc2 + (act ? tb : 0)];
+      for (int fj = 0; fj < nf1; fj++) {
+        double v = 0.0;
+        for (int j = 0; j < nc1; j++) v += M1[fj * nc1 + j] * u[j];
+        if (lane_ok && act) sB[(ta * nf1 + fj) * nc2 + tb] = v;
+      }
+    }
+    wsync();
+    // pass Z: lane (i_f, j_f) -> fine k, scale by 1/multiplicity, scatter-add
+    {
+      const bool act = ta < nf0 && tb < nf1;
+      double u[kMaxN];
+      for (int k = 0; k < nc2; k++) u[k] = sB[((act ? ta : 0) * nf1 + (act ? tb : 0)) * nc2 + k];
+      for (int fk = 0; fk < nf2; fk++) {
+        double v = 0.0;
+        for (int k = 0; k < nc2; k++) v += M2[fk * nc2 + k] * u[k];
+        if (active && act) {
+          const int s = a.lidx_f[(size_t)e * Pf + off_f + ta + nf0 * (tb + nf1 * fk)];
+          const int g = s >= 0 ? s : -1 - s;
+          unsafeAtomicAdd(&a.y[g], (s >= 0 ? v : -v) * a.inv_mult[g]);
+        }
+      }
+    }
+    wsync();
+  } else {
+    // pass Z^T: lane (i_f, j_f): gather fine (scaled), contract fine k -> coarse k
+    {
+      const bool act = ta < nf0 && tb < nf1;
+      double u[kMaxN];
+      for (int fk = 0; fk < nf2; fk++) {
+        double v = 0.0;
+        if (active && act) {
+          const int s = a.lidx_f[(size_t)e * Pf + off_f + ta + nf0 * (tb + nf1 * fk)];
+          const int g = s >= 0 ? s : -1 - s;
+          const double xv = a.x[g] * a.inv_mult[g];
+          v = s >= 0 ? xv : -xv;
+        }
+        u[fk] = v;
+      }
+      for (int k = 0; k < nc2; k++) {
+        double v = 0.0;
+        for (int fk = 0; fk < nf2; fk++) v += M2[fk * nc2 + k] * u[fk];
+        if (lane_ok && act) sB[(ta * nf1 + tb) * nc2 + k] = v;
+      }
+    }
+    wsync();
+    // pass Y^T: lane (i_f, k_c): contract fine j -> coarse j
+    {
+      const bool act = ta < nf0 && tb < nc2;
+      double u[kMaxN];
+      for (int fj = 0; fj < nf1; fj++) u[fj] = sB[((act ? ta : 0) * nf1 + fj) * nc2 + (act ? tb : 0)];
+      for (int j = 0; j < nc1; j++) {
+        double v = 0.0;
+        for (int fj = 0; fj < nf1; fj++) v += M1[fj * nc1 + j] * u[fj];
+        if (lane_ok && act) sA[(ta * nc1 + j) * nc2 + tb] = v;
+      }
+    }
+    wsync();
+    // pass X^T: lane (j_c, k_c): contract fine i -> coarse i, scatter-add
+    {
+      const bool act = ta < nc1 && tb < nc2;
+      double u[kMaxN];
+      for (int fi = 0; fi < nf0; fi++) u[fi] = sA[(fi * nc1 + (act ? ta : 0)) * nc2 + (act ? tb : 0)];
+      for (int i = 0; i < nc0; i++) {
+        double v = 0.0;
+        for (int fi = 0; fi < nf0; fi++) v += M0[fi * nc0 + i] * u[fi];
+        if (active && act) {
+          const int s = a.lidx_c[(size_t)e * Pc + off_c + i + nc0 * (ta + nc1 * tb)];
+          unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? v : -v);
+        }
+      }
+    }
+    wsync();
+  }
+}
+
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void interp_kernel(const InterpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int n1 = a.pf + 1, T = n1 * n1, EPW = 64 / T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / T, t = lane - sub * T;
+  const int ta = t % n1, tb = t / n1;
+  const bool lane_ok = sub < EPW;
+  const int e = (blockIdx.x * 4 + wave) * EPW + sub;
+  const bool active = lane_ok && e < a.ne;
+  double *sm = smem + (size_t)(wave * EPW + (lane_ok ? sub : 0)) * (2 * n1 * n1 * n1);
+  const int pc = a.pc, pf = a.pf, ncc = pc + 1, nfc = pf + 1;
+  if (a.fe_type == PA_FE_HCURL) {
+    const int Pc = 3 * pc * ncc * ncc, Pf = 3 * pf * nfc * nfc;
+    for (int C = 0; C < 3; C++) {
+      const int nc0 = C == 0 ? pc : ncc, nc1 = C == 1 ? pc : ncc, nc2 = C == 2 ? pc : ncc;
+      const int nf0 = C == 0 ? pf : nfc, nf1 = C == 1 ? pf : nfc, nf2 = C == 2 ? pf : nfc;
+      interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, C * pc * ncc * ncc, C * pf * nfc * nfc, Pc, Pf,
+                              nc0, nc1, nc2, nf0, nf1, nf2, C == 0 ? a.Io : a.Ic, C == 1 ? a.Io : a.Ic,
+                              C == 2 ? a.Io : a.Ic);
+    }
+  } else {
+    interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, 0, 0, ncc * ncc * ncc, nfc * nfc * nfc, ncc, ncc,
+                            ncc, nfc, nfc, nfc, a.Ic, a.Ic, a.Ic);
+  }
+}
+
+__global__ void k_count_mult(const int32_t *__restrict__ lidx, long long n, double *__restrict__ mult) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int s = lidx[i];
+    unsafeAtomicAdd(&mult[s >= 0 ? s : -1 - s], 1.0);
+  }
+}
+__global__ void k_invert(double *x, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    x[i] = x[i] > 0.0 ? 1.0 / x[i] : 0.0;
+}
+
+std::vector<int32_t> signed_lex_index(const pa_restriction_desc &r, const pa_basis_desc &b, int P) {
+  std::vector<int32_t> lidx((size_t)r.num_elem * P);
+  for (int e = 0; e < r.num_elem; e++)
+    for (int l = 0; l < P; l++) {
+      int n = b.dof_map ? b.dof_map[l] : l;
+      bool neg = false;
+      if (n < 0) n = -1 - n, neg = true;
+      const size_t k = (size_t)e * P + n;
+      if (r.orients && r.orients[k]) neg = !neg;
+      lidx[(size_t)e * P + l] = neg ? -1 - r.offsets[k] : r.offsets[k];
+    }
+  return lidx;
+}
+
+}  // namespace
+
+// The prolongation as an Operator on T-vectors: Mult coarse -> fine, MultTranspose fine -> coarse.
+class InterpOperator : public Operator {
+  const Context *ctx_;
+  const Halo *halo_c_;
+  int fe_type_, pc_, pf_, ne_, nl_c_, nl_f_, nt_c_, nt_f_;
+  int32_t *d_lidx_c_ = nullptr, *d_lidx_f_ = nullptr;
+  double *d_Ic_ = nullptr, *d_Io_ = nullptr, *d_inv_mult_ = nullptr;
+  mutable Vector lc_, lf_;
+
+  template <bool TR>
+  void launch(const double *x, double *y) const {
+    InterpArgs a{ne_, fe_type_, pc_, pf_, d_lidx_c_, d_lidx_f_, d_Ic_, d_Io_, d_inv_mult_, x, y};
+    const int n1 = pf_ + 1, epw = 64 / (n1 * n1), epb = 4 * epw;
+    const size_t lds = sizeof(double) * (size_t)epb * 2 * n1 * n1 * n1;
+    hipLaunchKernelGGL((interp_kernel<TR>), dim3((ne_ + epb - 1) / epb), dim3(256), lds, ctx_->stream, a);
+    PA_HIP(hipGetLastError());
+  }
+
+public:
+  InterpOperator(const Context &ctx, const pa_restriction_desc &rc, const pa_basis_desc &bc,
+                 const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic, const double *Io,
+                 const Halo *halo_c, int nt_c, int nt_f)
+      : Operator(nt_f, nt_c), ctx_(&ctx), halo_c_(halo_c), fe_type_(bc.fe_type), pc_(bc.order), pf_(bf.order),
+        ne_(rc.num_elem), nl_c_(rc.lsize), nl_f_(rf.lsize), nt_c_(nt_c), nt_f_(nt_f) {
+    PA_REQUIRE(bc.fe_type == bf.fe_type, "prolongation needs the same element family on both levels");
+    PA_REQUIRE(rc.num_elem == rf.num_elem, "prolongation needs the same mesh on both levels");
+    PA_REQUIRE(pf_ + 1 <= kMaxN && pc_ <= pf_, "unsupported orders for prolongation");
+    PA_REQUIRE(Ic && (fe_type_ == PA_FE_H1 || Io), "1-D interpolation matrices missing");
+    PA_REQUIRE(nt_c <= nl_c_ && nt_f <= nl_f_, "true dof counts exceed local sizes");
+    PA_REQUIRE(halo_c || nt_c == nl_c_, "ghost dofs on the coarse level need a halo plan");
+    const int Pc = fe_type_ == PA_FE_HCURL ? 3 * pc_ * (pc_ + 1) * (pc_ + 1) : (pc_ + 1) * (pc_ + 1) * (pc_ + 1);
+    const int Pf = fe_type_ == PA_FE_HCURL ? 3 * pf_ * (pf_ + 1) * (pf_ + 1) : (pf_ + 1) * (pf_ + 1) * (pf_ + 1);
+    PA_REQUIRE(rc.elem_size == Pc && rf.elem_size == Pf, "restriction sizes do not match the bases");
+    auto lc = signed_lex_index(rc, bc, Pc), lf = signed_lex_index(rf, bf, Pf);
+    d_lidx_c_ = pa::dev_upload(lc.data(), lc.size(), ctx.stream);
+    d_lidx_f_ = pa::dev_upload(lf.data(), lf.size(), ctx.stream);
+    d_Ic_ = pa::dev_upload(Ic, (size_t)(pf_ + 1) * (pc_ + 1), ctx.stream);
+    if (Io) d_Io_ = pa::dev_upload(Io, (size_t)pf_ * pc_, ctx.stream);
+    // local dof multiplicity of the fine restriction (CeedElemRestrictionGetMultiplicity,
+    // bilinearform.cpp:256-279)
+    d_inv_mult_ = pa::dev_alloc<double>((size_t)nl_f_);
+    PA_HIP(hipMemsetAsync(d_inv_mult_, 0, sizeof(double) * (size_t)nl_f_, ctx.stream));
+    const long long n = (long long)lf.size();
+    hipLaunchKernelGGL(k_count_mult, dim3(1024), dim3(256), 0, ctx.stream, d_lidx_f_, n, d_inv_mult_);
+    hipLaunchKernelGGL(k_invert, dim3(1024), dim3(256), 0, ctx.stream, d_inv_mult_, (long long)nl_f_);
+    PA_HIP(hipGetLastError());
+    lc_.SetSize(nl_c_), lf_.SetSize(nl_f_);
+  }
+  ~InterpOperator() override {
+    (void)hipFree(d_lidx_c_), (void)hipFree(d_lidx_f_), (void)hipFree(d_Ic_), (void)hipFree(d_Io_),
+        (void)hipFree(d_inv_mult_);
+  }
+  // y_f = R_f D^-1 E_f^T I E_c P_c x_c
+  void Mult(const Vector &x, Vector &y) const override {
+    const Context &c = *ctx_;
+    PA_REQUIRE(x.Size() == nt_c_ && y.Size() == nt_f_, "size mismatch in prolongation");
+    Vector tc(lc_.Data(), nt_c_);
+    linalg::Copy(c, x, tc);
+    if (halo_c_) halo_c_->Prolongate(lc_.Data(), c.stream);
+    linalg::Fill(c, lf_, 0.0);
+    launch<false>(lc_.Data(), lf_.Data());
+    Vector tf(lf_.Data(), nt_f_);
+    linalg::Copy(c, tf, y);
+  }
+  // x_c = P_c^T E_c^T I^T E_f D^-1 R_f^T y_f
+  void MultTranspose(const Vector &x, Vector &y) const override {
+    const Context &c = *ctx_;
+    PA_REQUIRE(x.Size() == nt_f_ && y.Size() == nt_c_, "size mismatch in restriction");
+    Vector tf(lf_.Data(), nt_f_);
+    linalg::Copy(c, x, tf);
+    if (nl_f_ > nt_f_)
+      PA_HIP(hipMemsetAsync(lf_.Data() + nt_f_, 0, sizeof(double) * (size_t)(nl_f_ - nt_f_), c.stream));
+    linalg::Fill(c, lc_, 0.0);
+    launch<true>(lf_.Data(), lc_.Data());
+    if (halo_c_) halo_c_->RestrictAdd(lc_.Data(), c.stream);
+    Vector tc(lc_.Data(), nt_c_);
+    linalg::Copy(c, tc, y);
+  }
+};
+
+Operator *make_interp_operator(const Context &ctx, const pa_restriction_desc &rc, const pa_basis_desc &bc,
+                               const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic,
+                               const double *Io, const Halo *halo_c, int nt_c, int nt_f) {
+  return new InterpOperator(ctx, rc, bc, rf, bf, Ic, Io, halo_c, nt_c, nt_f);
+}
+
+}  // namespace palace

@@ -1,0 +1,275 @@
+// C ABI over the C++ host layer (include/palace_amd_linalg.h).
+#include <memory>
+
+#include "../../include/palace_amd_linalg.h"
+#include "comm.hpp"
+#include "linalg.hpp"
+
+using namespace palace;
+
+namespace palace {
+Operator *make_interp_operator(const Context &ctx, const pa_restriction_desc &rc, const pa_basis_desc &bc,
+                               const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic,
+                               const double *Io, const Halo *halo_c, int nt_c, int nt_f);
+}
+
+struct pa_context {
+  Context ctx;
+  std::unique_ptr<Comm> comm;
+};
+struct pa_halo {
+  std::unique_ptr<Halo> halo;
+};
+struct pa_par_op {
+  pa_context *ctx;
+  std::unique_ptr<ceed::Operator> local;
+  std::unique_ptr<ParOperator> op;
+};
+struct pa_interp {
+  pa_context *ctx;
+  std::unique_ptr<Operator> op;
+};
+struct pa_solver {
+  pa_context *ctx;
+  std::unique_ptr<Solver> solver;
+  std::vector<pa_solver *> owned;  // sub-solvers whose lifetime is tied to this one
+  ~pa_solver() {
+    for (auto *s : owned) delete s;
+  }
+};
+
+using pa::guarded;
+
+extern "C" {
+
+int pa_context_create(void *stream, pa_context **ctx) {
+  return guarded([&] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+      throw pa::Error("no HIP device visible: libpalace_amd has no CPU fallback");
+    auto *c = new pa_context;
+    c->ctx.stream = (hipStream_t)stream;
+    *ctx = c;
+  });
+}
+void pa_context_destroy(pa_context *ctx) { delete ctx; }
+int pa_context_synchronize(pa_context *ctx) {
+  return guarded([&] { PA_HIP(hipStreamSynchronize(ctx->ctx.stream)); });
+}
+
+int pa_comm_unique_id(char *out128) {
+  return guarded([&] { Comm::GetUniqueId(out128); });
+}
+int pa_context_init_comm(pa_context *ctx, int rank, int size, const char *id) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && id && size >= 1 && rank >= 0 && rank < size, "bad communicator arguments");
+    ctx->comm = std::make_unique<Comm>(rank, size, id);
+    ctx->ctx.comm = ctx->comm.get();
+  });
+}
+int pa_context_rank(const pa_context *ctx) { return ctx && ctx->comm ? ctx->comm->Rank() : 0; }
+int pa_context_size(const pa_context *ctx) { return ctx && ctx->comm ? ctx->comm->Size() : 1; }
+int pa_allreduce_sum(pa_context *ctx, double *buf, int n) {
+  return guarded([&] {
+    if (ctx->comm) ctx->comm->AllReduceSum(buf, n, ctx->ctx.stream);
+  });
+}
+
+int pa_halo_create(pa_context *ctx, int nnbr, const int *nbr, const int *send_off, const int32_t *send_idx,
+                   const int *recv_off, const int32_t *recv_idx, pa_halo **halo) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && ctx->comm, "halo plan needs a communicator (pa_context_init_comm)");
+    auto *h = new pa_halo;
+    h->halo = std::make_unique<Halo>(*ctx->comm, nnbr, nbr, send_off, send_idx, recv_off, recv_idx);
+    *halo = h;
+  });
+}
+void pa_halo_destroy(pa_halo *halo) { delete halo; }
+int pa_halo_prolongate(pa_context *ctx, pa_halo *halo, double *lx) {
+  return guarded([&] { halo->halo->Prolongate(lx, ctx->ctx.stream); });
+}
+int pa_halo_restrict_add(pa_context *ctx, pa_halo *halo, double *ly) {
+  return guarded([&] { halo->halo->RestrictAdd(ly, ctx->ctx.stream); });
+}
+
+int pa_par_op_create(pa_context *ctx, pa_op *local, int n_true, const int32_t *ess, int n_ess, int policy,
+                     pa_halo *halo, pa_par_op **A) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && local && A, "null argument");
+    auto *p = new pa_par_op;
+    p->ctx = ctx;
+    p->local = std::make_unique<ceed::Operator>(ctx->ctx, local, false);
+    p->op = std::make_unique<ParOperator>(ctx->ctx, *p->local, n_true, ess, n_ess,
+                                          policy == PA_DIAG_ONE ? ParOperator::DiagonalPolicy::DIAG_ONE
+                                                                : ParOperator::DiagonalPolicy::DIAG_ZERO,
+                                          halo ? halo->halo.get() : nullptr);
+    *A = p;
+  });
+}
+void pa_par_op_destroy(pa_par_op *A) { delete A; }
+int pa_par_op_mult(pa_par_op *A, const double *x, double *y) {
+  return guarded([&] {
+    Vector vx(const_cast<double *>(x), A->op->Width()), vy(y, A->op->Height());
+    A->op->Mult(vx, vy);
+  });
+}
+int pa_par_op_assemble_diagonal(pa_par_op *A, double *diag) {
+  return guarded([&] {
+    Vector d(diag, A->op->Height());
+    A->op->AssembleDiagonal(d);
+  });
+}
+
+int pa_vec_dot(pa_context *ctx, const double *x, const double *y, int n, double *result) {
+  return guarded([&] {
+    Vector vx(const_cast<double *>(x), n), vy(const_cast<double *>(y), n);
+    *result = linalg::Dot(ctx->ctx, vx, vy);
+  });
+}
+int pa_vec_axpby(pa_context *ctx, double a, const double *x, double b, double *y, int n) {
+  return guarded([&] {
+    Vector vx(const_cast<double *>(x), n), vy(y, n);
+    linalg::AXPBY(ctx->ctx, a, vx, b, vy);
+  });
+}
+int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed) {
+  return guarded([&] {
+    Vector vx(x, n);
+    linalg::SetRandom(ctx->ctx, vx, seed);
+  });
+}
+
+int pa_chebyshev_create(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max, int fourth_kind,
+                        pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(order > 0, "Polynomial order for Chebyshev smoothing must be positive!");
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    auto cheb = std::make_unique<ChebyshevSmoother>(ctx->ctx, smooth_it, order, sf_max, fourth_kind != 0);
+    cheb->SetOperator(*A->op);
+    s->solver = std::move(cheb);
+    *S = s;
+  });
+}
+int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max) {
+  return guarded([&] {
+    auto *c = dynamic_cast<const ChebyshevSmoother *>(S->solver.get());
+    PA_REQUIRE(c, "not a Chebyshev smoother");
+    *lambda_max = c->LambdaMax();
+  });
+}
+int pa_jacobi_create(pa_context *ctx, pa_par_op *A, pa_solver **S) {
+  return guarded([&] {
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    auto j = std::make_unique<JacobiSmoother>(ctx->ctx);
+    j->SetOperator(*A->op);
+    s->solver = std::move(j);
+    *S = s;
+  });
+}
+static void configure(IterativeSolver &k, pa_par_op *A, pa_solver *pc, double rel, double abs, int max_it) {
+  k.SetOperator(*A->op);
+  if (pc) k.SetPreconditioner(*pc->solver);
+  k.SetTol(rel), k.SetAbsTol(abs), k.SetMaxIter(max_it);
+}
+int pa_cg_create(pa_context *ctx, pa_par_op *A, pa_solver *pc, double rel, double abs, int max_it, int print,
+                 pa_solver **S) {
+  return guarded([&] {
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    auto k = std::make_unique<CgSolver>(ctx->ctx, print);
+    configure(*k, A, pc, rel, abs, max_it);
+    s->solver = std::move(k);
+    *S = s;
+  });
+}
+int pa_gmres_create(pa_context *ctx, pa_par_op *A, pa_solver *pc, double rel, double abs, int max_it, int restart,
+                    int flexible, int print, pa_solver **S) {
+  return guarded([&] {
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    auto k = std::make_unique<GmresSolver>(ctx->ctx, print, flexible != 0);
+    configure(*k, A, pc, rel, abs, max_it);
+    k->SetRestartDim(restart);
+    s->solver = std::move(k);
+    *S = s;
+  });
+}
+int pa_gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *const *P, pa_solver *coarse,
+                  int cycle_it, int smooth_it, int cheby_order, double sf_max, double sf_min, int fourth,
+                  pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(nlevels >= 1 && A && coarse, "Empty finite element space hierarchy during multigrid solver setup!");
+    std::vector<const Operator *> Pv;
+    std::vector<const ParOperator *> Av;
+    for (int l = 0; l + 1 < nlevels; l++) Pv.push_back(P[l]->op.get());
+    for (int l = 0; l < nlevels; l++) Av.push_back(A[l]->op.get());
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    // the coarse solver object is kept alive by the multigrid solver; its Solver is borrowed
+    struct Borrowed : Solver {
+      Solver *inner;
+      explicit Borrowed(Solver *i) : inner(i) {}
+      void SetOperator(const Operator &) override {}
+      void Mult(const Vector &x, Vector &y) const override {
+        inner->SetInitialGuess(false);
+        inner->Mult(x, y);
+      }
+    };
+    s->owned.push_back(coarse);
+    auto g = std::make_unique<GeometricMultigridSolver>(ctx->ctx, std::make_unique<Borrowed>(coarse->solver.get()),
+                                                        Pv, cycle_it, smooth_it, cheby_order, sf_max, sf_min,
+                                                        fourth != 0);
+    g->SetOperators(Av);
+    s->solver = std::move(g);
+    *S = s;
+  });
+}
+int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess) {
+  return guarded([&] {
+    const int n = S->solver->Height();
+    Vector vb(const_cast<double *>(b), n), vx(x, n);
+    S->solver->SetInitialGuess(initial_guess != 0);
+    S->solver->Mult(vb, vx);
+  });
+}
+int pa_solver_stats(const pa_solver *S, int *its, double *initial_res, double *final_res, int *converged) {
+  return guarded([&] {
+    auto *k = dynamic_cast<const IterativeSolver *>(S->solver.get());
+    PA_REQUIRE(k, "not an iterative solver");
+    if (its) *its = k->GetNumIterations();
+    if (initial_res) *initial_res = k->GetInitialRes();
+    if (final_res) *final_res = k->GetFinalRes();
+    if (converged) *converged = k->GetConverged();
+  });
+}
+void pa_solver_destroy(pa_solver *S) { delete S; }
+
+int pa_interp_create(pa_context *ctx, const pa_restriction_desc *rc, const pa_basis_desc *bc,
+                     const pa_restriction_desc *rf, const pa_basis_desc *bf, const double *Ic, const double *Io,
+                     pa_halo *coarse_halo, int nt_c, int nt_f, pa_interp **P) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && rc && bc && rf && bf && P, "null argument");
+    auto *p = new pa_interp;
+    p->ctx = ctx;
+    p->op.reset(make_interp_operator(ctx->ctx, *rc, *bc, *rf, *bf, Ic, Io,
+                                     coarse_halo ? coarse_halo->halo.get() : nullptr, nt_c, nt_f));
+    *P = p;
+  });
+}
+int pa_interp_mult(pa_interp *P, const double *x, double *y) {
+  return guarded([&] {
+    Vector vx(const_cast<double *>(x), P->op->Width()), vy(y, P->op->Height());
+    P->op->Mult(vx, vy);
+  });
+}
+int pa_interp_mult_transpose(pa_interp *P, const double *x, double *y) {
+  return guarded([&] {
+    Vector vx(const_cast<double *>(x), P->op->Height()), vy(y, P->op->Width());
+    P->op->MultTranspose(vx, vy);
+  });
+}
+void pa_interp_destroy(pa_interp *P) { delete P; }
+
+}  // extern "C"

@@ -42,6 +42,10 @@ struct NDArgs {
 };
 
 __device__ __forceinline__ void wave_sync() {
+#ifdef PA_SYNC_BLOCK
+  __syncthreads();
+  return;
+#endif
   // Intra-wave LDS hand-off: the LDS executes a wave's DS operations in order; the fences stop
   // the compiler from moving accesses across, the barrier is a scheduling no-op for one wave.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

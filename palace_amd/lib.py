@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpalace_amd.so")
+LIB_PATH = os.environ.get("PALACE_AMD_LIB", os.path.join(_HERE, "lib", "libpalace_amd.so"))
 
 _lib = None
 

@@ -1,0 +1,233 @@
+"""ctypes face of the C++ host layer that mirrors palace::linalg (include/palace_amd_linalg.h,
+palace_amd/csrc/linalg.hpp): ParOperator, Chebyshev / Jacobi smoothers, CG / GMRES, geometric
+multigrid and the p-prolongation, all on float64 CUDA tensors owned by torch."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .ceed import Operator, _basis_desc, _ptr, _restriction_desc
+from .fem.basis1d import gauss_legendre, gauss_lobatto, lagrange_eval
+
+DIAG_ZERO, DIAG_ONE = 0, 1
+
+
+def _L():
+    L = _lib.load()
+    if not getattr(L, "_linalg_typed", False):
+        for name in ("pa_context_destroy", "pa_halo_destroy", "pa_par_op_destroy", "pa_solver_destroy",
+                     "pa_interp_destroy"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.pa_vec_axpby.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+        L.pa_chebyshev_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.pa_cg_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                   C.c_void_p]
+        L.pa_gmres_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]
+        L.pa_gmg_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.pa_vec_set_random.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+        L._linalg_typed = True
+    return L
+
+
+class Context:
+    """Stream + (optional) RCCL communicator."""
+
+    def __init__(self, stream=None):
+        import torch
+
+        self.torch_stream = torch.cuda.current_stream() if stream is None else stream
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_context_create(C.c_void_p(self.torch_stream.cuda_stream), C.byref(self.handle)))
+        self.rank, self.size = 0, 1
+
+    def init_comm_from_torch_distributed(self):
+        """Create the RCCL communicator; the 128-byte unique id travels over torch.distributed."""
+        import torch
+        import torch.distributed as dist
+
+        L = _L()
+        rank, size = dist.get_rank(), dist.get_world_size()
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.pa_comm_unique_id(buf))
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().numpy().tobytes())
+        _lib.check(L.pa_context_init_comm(self.handle, rank, size, raw))
+        self.rank, self.size = rank, size
+
+    def synchronize(self):
+        _lib.check(_L().pa_context_synchronize(self.handle))
+
+    def dot(self, x, y):
+        out = C.c_double()
+        _lib.check(_L().pa_vec_dot(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                   C.c_int(x.numel()), C.byref(out)))
+        return out.value
+
+    def set_random(self, x, seed):
+        _lib.check(_L().pa_vec_set_random(self.handle, C.c_void_p(x.data_ptr()), x.numel(), seed))
+        return x
+
+    def __del__(self):
+        try:
+            _L().pa_context_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Halo:
+    def __init__(self, ctx: Context, nbr, send_lists, recv_lists):
+        """send_lists[k] / recv_lists[k]: local dof indices exchanged with neighbour nbr[k]."""
+        self.ctx = ctx
+        nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+        so = np.zeros(len(nbr) + 1, dtype=np.int32)
+        ro = np.zeros(len(nbr) + 1, dtype=np.int32)
+        so[1:] = np.cumsum([len(s) for s in send_lists])
+        ro[1:] = np.cumsum([len(r) for r in recv_lists])
+        si = np.ascontiguousarray(np.concatenate(send_lists) if len(nbr) else np.zeros(0), dtype=np.int32)
+        ri = np.ascontiguousarray(np.concatenate(recv_lists) if len(nbr) else np.zeros(0), dtype=np.int32)
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_halo_create(ctx.handle, len(nbr), _ptr(nbr), _ptr(so), _ptr(si), _ptr(ro), _ptr(ri),
+                                       C.byref(self.handle)))
+
+    def __del__(self):
+        try:
+            _L().pa_halo_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class ParOperator:
+    """palace::ParOperator (rap.cpp:154-234) on T-vectors."""
+
+    def __init__(self, ctx: Context, local: Operator, ess_tdofs, diag_policy=DIAG_ONE, n_true=None, halo=None):
+        self.ctx, self.local, self.halo = ctx, local, halo
+        self.n = local.height if n_true is None else n_true
+        ess = np.ascontiguousarray(ess_tdofs, dtype=np.int32)
+        self.ess = ess
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_par_op_create(ctx.handle, local.handle, self.n, _ptr(ess), ess.size, diag_policy,
+                                         halo.handle if halo else None, C.byref(self.handle)))
+
+    def mult(self, x, y):
+        _lib.check(_L().pa_par_op_mult(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+        return y
+
+    def assemble_diagonal(self, d):
+        _lib.check(_L().pa_par_op_assemble_diagonal(self.handle, C.c_void_p(d.data_ptr())))
+        return d
+
+    def __del__(self):
+        try:
+            _L().pa_par_op_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Solver:
+    def __init__(self, ctx, handle, keep=()):
+        self.ctx, self.handle, self._keep = ctx, handle, keep
+        self._owned_by_parent = False
+
+    def mult(self, b, x, initial_guess=False):
+        _lib.check(_L().pa_solver_mult(self.handle, C.c_void_p(b.data_ptr()), C.c_void_p(x.data_ptr()),
+                                       int(initial_guess)))
+        return x
+
+    def stats(self):
+        its, conv = C.c_int(), C.c_int()
+        r0, r1 = C.c_double(), C.c_double()
+        _lib.check(_L().pa_solver_stats(self.handle, C.byref(its), C.byref(r0), C.byref(r1), C.byref(conv)))
+        return dict(iterations=its.value, initial_res=r0.value, final_res=r1.value, converged=bool(conv.value))
+
+    def lambda_max(self):
+        v = C.c_double()
+        _lib.check(_L().pa_chebyshev_lambda_max(self.handle, C.byref(v)))
+        return v.value
+
+    def __del__(self):
+        try:
+            if not self._owned_by_parent:
+                _L().pa_solver_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def chebyshev(ctx, A: ParOperator, order, smooth_it=1, sf_max=1.0, fourth_kind=True):
+    h = C.c_void_p()
+    _lib.check(_L().pa_chebyshev_create(ctx.handle, A.handle, smooth_it, order, sf_max, int(fourth_kind), C.byref(h)))
+    return Solver(ctx, h, (A,))
+
+
+def jacobi(ctx, A: ParOperator):
+    h = C.c_void_p()
+    _lib.check(_L().pa_jacobi_create(ctx.handle, A.handle, C.byref(h)))
+    return Solver(ctx, h, (A,))
+
+
+def cg(ctx, A: ParOperator, precond=None, rel_tol=0.0, abs_tol=0.0, max_it=100, print_level=0):
+    h = C.c_void_p()
+    _lib.check(_L().pa_cg_create(ctx.handle, A.handle, precond.handle if precond else None, rel_tol, abs_tol,
+                                 max_it, print_level, C.byref(h)))
+    return Solver(ctx, h, (A, precond))
+
+
+def gmres(ctx, A: ParOperator, precond=None, rel_tol=0.0, abs_tol=0.0, max_it=100, restart=-1, flexible=False,
+          print_level=0):
+    h = C.c_void_p()
+    _lib.check(_L().pa_gmres_create(ctx.handle, A.handle, precond.handle if precond else None, rel_tol, abs_tol,
+                                    max_it, restart, int(flexible), print_level, C.byref(h)))
+    return Solver(ctx, h, (A, precond))
+
+
+class Interp:
+    """p-prolongation between two spaces on the same mesh (bilinearform.cpp:203-282)."""
+
+    def __init__(self, ctx, space_c, space_f, coarse_halo=None, n_true_c=None, n_true_f=None):
+        self.ctx = ctx
+        pc, pf = space_c.p, space_f.p
+        Ic, _ = lagrange_eval(gauss_lobatto(pc + 1), gauss_lobatto(pf + 1))
+        Io, _ = lagrange_eval(gauss_legendre(pc)[0], gauss_legendre(pf)[0])
+        Ic, Io = np.ascontiguousarray(Ic), np.ascontiguousarray(Io)
+        rc, k1 = _restriction_desc(space_c)
+        rf, k2 = _restriction_desc(space_f)
+        bc, k3 = _basis_desc(space_c, pf + 1)
+        bf, k4 = _basis_desc(space_f, pf + 1)
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_interp_create(ctx.handle, C.byref(rc), C.byref(bc), C.byref(rf), C.byref(bf), _ptr(Ic),
+                                         _ptr(Io), coarse_halo.handle if coarse_halo else None,
+                                         space_c.ndofs if n_true_c is None else n_true_c,
+                                         space_f.ndofs if n_true_f is None else n_true_f, C.byref(self.handle)))
+
+    def mult(self, x, y):
+        _lib.check(_L().pa_interp_mult(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+        return y
+
+    def mult_transpose(self, x, y):
+        _lib.check(_L().pa_interp_mult_transpose(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+        return y
+
+    def __del__(self):
+        try:
+            _L().pa_interp_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def gmg(ctx, A_levels, P_levels, coarse: Solver, cycle_it=1, smooth_it=1, cheby_order=4, sf_max=1.0, sf_min=0.0,
+        fourth_kind=True):
+    """GeometricMultigridSolver (gmg.cpp); takes ownership of `coarse`."""
+    n = len(A_levels)
+    Ah = (C.c_void_p * n)(*[a.handle for a in A_levels])
+    Ph = (C.c_void_p * max(1, n - 1))(*[p.handle for p in P_levels])
+    h = C.c_void_p()
+    _lib.check(_L().pa_gmg_create(ctx.handle, n, Ah, Ph, coarse.handle, cycle_it, smooth_it, cheby_order, sf_max,
+                                  sf_min, int(fourth_kind), C.byref(h)))
+    coarse._owned_by_parent = True
+    return Solver(ctx, h, (A_levels, P_levels, coarse))
