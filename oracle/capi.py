@@ -51,8 +51,12 @@ def build_geom_33(attr, qw, J):
     return geom
 
 
-def apply_add(off, ori, interp, deriv, geom, qf, ctx_blob, x, y):
+def apply_add(off, ori, interp, deriv, geom, qf, ctx_blob, x, y, threads=None):
+    """threads: OpenMP team size (default: 1 per 256 elements, capped at the core count)."""
     ne, P = off.shape
+    if threads is None:
+        threads = max(1, min(os.cpu_count() or 1, ne // 256))
+    lib().oc_set_num_threads(C.c_int(threads))
     Q = geom.shape[2]
     off = np.ascontiguousarray(off, dtype=np.int32)
     ori8 = None if ori is None else np.ascontiguousarray(ori, dtype=np.uint8)

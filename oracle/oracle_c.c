@@ -225,6 +225,14 @@ void oc_apply_add(int ne, int P, int Q, const int32_t *off, const uint8_t *ori,
   }
 }
 
+void oc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+
 int oc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -158,6 +158,32 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
   so->Gc.assign(b.Gc, b.Gc + b.q1d * nc);
   if (b.Bo) so->Bo.assign(b.Bo, b.Bo + b.q1d * b.order);
   check_dense_tables(b, P, geom->Q);
+  // the kernels rely on the mirror symmetry of Gauss-Legendre / Gauss-Lobatto tables
+  {
+    double worst = 0.0;
+    const int q1 = b.q1d;
+    for (int q = 0; q < q1; q++) {
+      for (int i = 0; i < nc; i++) {
+        worst = std::fmax(worst, std::fabs(so->Bc[q * nc + i] - so->Bc[(q1 - 1 - q) * nc + (nc - 1 - i)]));
+        worst = std::fmax(worst, std::fabs(so->Gc[q * nc + i] + so->Gc[(q1 - 1 - q) * nc + (nc - 1 - i)]));
+      }
+      if (b.Bo)
+        for (int i = 0; i < b.order; i++)
+          worst = std::fmax(worst, std::fabs(so->Bo[q * b.order + i] -
+                                             so->Bo[(q1 - 1 - q) * b.order + (b.order - 1 - i)]));
+    }
+    if (!(worst < 1e-12)) {
+      delete so;
+      geom->refcount--;
+      throw Error("1-D basis tables are not mirror-symmetric (non Gauss-Legendre/Lobatto nodes?)");
+    }
+    std::vector<double> tab;
+    tab.insert(tab.end(), so->Bo.begin(), so->Bo.end());
+    if (so->Bo.empty()) tab.assign((size_t)b.q1d * b.order, 0.0);
+    tab.insert(tab.end(), so->Bc.begin(), so->Bc.end());
+    tab.insert(tab.end(), so->Gc.begin(), so->Gc.end());
+    so->d_tab = dev_upload(tab.data(), tab.size());
+  }
 
   // signed tensor-order index array (restriction.cpp:290-296 semantics folded with dof_map)
   std::vector<int32_t> lidx((size_t)r.num_elem * P);
@@ -200,12 +226,23 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
       parse_coeff(ctx, ctx_size, 1, so->c0, 0);
       break;
   }
+  auto is_iso = [](const CoeffHost &c) {
+    if (c.dim != 3) return true;
+    for (size_t k = 0; k + 9 <= c.mat.size(); k += 9)
+      for (int i = 0; i < 9; i++) {
+        const bool diag = (i % 4 == 0);
+        if (diag ? c.mat[k + i] != c.mat[k] : c.mat[k + i] != 0.0) return false;
+      }
+    return true;
+  };
+  so->iso = is_iso(so->c0) && (so->c1.mat.empty() || is_iso(so->c1));
   return so;
 }
 
 static void free_sub(SubOp *so) {
   if (!so) return;
   hipFree(so->d_lidx);
+  hipFree(so->d_tab);
   hipFree(so->c0.d_attr_mat), hipFree(so->c0.d_mat);
   hipFree(so->c1.d_attr_mat), hipFree(so->c1.d_mat);
   pa_geom_destroy(static_cast<pa_geom *>(so->geom));

@@ -96,7 +96,9 @@ struct SubOp {
   int qf = 0;
   uint32_t trial_ops = 0, test_ops = 0;
   int32_t *d_lidx = nullptr;  // [ne][P] signed tensor-order index: >=0 dof, <0 => -(1+dof) flipped
-  std::vector<double> Bc, Gc, Bo;
+  std::vector<double> Bc, Gc, Bo;  // full 1-D tables [q1d][n] (host)
+  double *d_tab = nullptr;        // the same on the device: [Bo | Bc | Gc]
+  bool iso = false;               // every material coefficient is a multiple of the identity
   std::vector<uint8_t> ctx_blob;
   CoeffHost c0, c1;
 };

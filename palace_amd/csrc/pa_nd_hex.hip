@@ -16,19 +16,38 @@
 //   pass Y: lane (qx,k)  contracts j  -> qy
 //   pass Z: lane (qx,qy) contracts k  -> qz     => lane (qx,qy) holds the qz column
 // D runs on the qz column in registers; the transposed passes mirror the above and end in the
-// signed scatter-add.  Tables are kernel arguments (scalar loads, SGPR operands).
+// signed scatter-add.  The geometry data of the lane's Q1 points (the dominant HBM stream) is
+// requested first thing, so its latency hides behind the forward contraction.  The 1-D tables are
+// kernel arguments: scalar loads, SGPR operands of the FMAs.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "pa_internal.hpp"
 
 namespace pa {
 
+// The 1-D tables are mirror-symmetric (Gauss-Legendre / Gauss-Lobatto nodes and points):
+//   B[q][i] = B[Q1-1-q][n-1-i],  G[q][i] = -G[Q1-1-q][n-1-i].
+// Only the first (Q1+1)/2 rows travel as kernel arguments, so every entry stays in an SGPR for the
+// whole kernel (p = 3: 22 doubles instead of 44) and nothing is spilled.  pa_op_add_sub verifies
+// the symmetry of the tables it is given.
 template <int P1, int Q1>
 struct NDTab {
-  double Bo[Q1 * P1];
-  double Bc[Q1 * (P1 + 1)];
-  double Gc[Q1 * (P1 + 1)];
+  static constexpr int QH = (Q1 + 1) / 2;
+  double Bo[QH * P1];
+  double Bc[QH * (P1 + 1)];
+  double Gc[QH * (P1 + 1)];
 };
+
+// value-type (even symmetry) and derivative-type (odd symmetry) table access; q and i are
+// compile-time constants after unrolling
+template <int N, int Q1>
+__device__ __forceinline__ double tab_even(const double *H, const int q, const int i) {
+  return (q < (Q1 + 1) / 2) ? H[q * N + i] : H[(Q1 - 1 - q) * N + (N - 1 - i)];
+}
+template <int N, int Q1>
+__device__ __forceinline__ double tab_odd(const double *H, const int q, const int i) {
+  return (q < (Q1 + 1) / 2) ? H[q * N + i] : -H[(Q1 - 1 - q) * N + (N - 1 - i)];
+}
 
 template <int P1, int Q1>
 struct NDArgs {
@@ -42,10 +61,6 @@ struct NDArgs {
 };
 
 __device__ __forceinline__ void wave_sync() {
-#ifdef PA_SYNC_BLOCK
-  __syncthreads();
-  return;
-#endif
   // Intra-wave LDS hand-off: the LDS executes a wave's DS operations in order; the fences stop
   // the compiler from moving accesses across, the barrier is a scheduling no-op for one wave.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -82,9 +97,24 @@ __device__ __forceinline__ void mult_AtBCx33(const double A[9], const double B[9
   y2 = s * (A[6] * z0 + A[7] * z1 + A[8] * z2);
 }
 
+// The same product when the coefficient is c * I (every material isotropic): y = (s c) A^T A x
+__device__ __forceinline__ void mult_AtAx33(const double A[9], const double x0, const double x1,
+                                            const double x2, const double sc, double &y0, double &y1,
+                                            double &y2) {
+  const double t0 = A[0] * x0 + A[3] * x1 + A[6] * x2;
+  const double t1 = A[1] * x0 + A[4] * x1 + A[7] * x2;
+  const double t2 = A[2] * x0 + A[5] * x1 + A[8] * x2;
+  y0 = sc * (A[0] * t0 + A[1] * t1 + A[2] * t2);
+  y1 = sc * (A[3] * t0 + A[4] * t1 + A[5] * t2);
+  y2 = sc * (A[6] * t0 + A[7] * t1 + A[8] * t2);
+}
+
 // coeff_3_qf.h:9-24
+__device__ __forceinline__ int coeff_index(const CoeffDev &c, int attr) {
+  return (c.nattr > 0) ? c.attr_mat[attr - 1] : 0;
+}
 __device__ __forceinline__ void coeff_unpack3(const CoeffDev &c, int attr, double C[9]) {
-  const int k = (c.nattr > 0) ? c.attr_mat[attr - 1] : 0;
+  const int k = coeff_index(c, attr);
 #pragma unroll
   for (int i = 0; i < 9; i++) C[i] = c.mat[9 * k + i];
 }
@@ -145,8 +175,8 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
       double v = 0.0, d = 0.0;
 #pragma unroll
       for (int i = 0; i < ni; i++) {
-        v += TX[qx * ni + i] * u[i];
-        if (DX) d += Gc[qx * NC + i] * u[i];
+        v += tab_even<ni, Q1>(TX, qx, i) * u[i];
+        if (DX) d += tab_odd<NC, Q1>(Gc, qx, i) * u[i];
       }
       if (lane_ok && act) {
         sm[L::ia(0, qx, ta, tb)] = v;
@@ -169,9 +199,9 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
       double vv = 0.0, vd = 0.0, dv = 0.0;
 #pragma unroll
       for (int j = 0; j < nj; j++) {
-        vv += TY[qy * nj + j] * v[j];
-        if (DY) vd += Gc[qy * NC + j] * v[j];
-        if (DX) dv += TY[qy * nj + j] * d[j];
+        vv += tab_even<nj, Q1>(TY, qy, j) * v[j];
+        if (DY) vd += tab_odd<NC, Q1>(Gc, qy, j) * v[j];
+        if (DX) dv += tab_even<nj, Q1>(TY, qy, j) * d[j];
       }
       if (lane_ok && act) {
         sm[L::ib(0, ta, qy, tb)] = vv;
@@ -195,10 +225,10 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
       double val = 0.0, dz = 0.0, dy = 0.0, dx = 0.0;
 #pragma unroll
       for (int k = 0; k < nk; k++) {
-        if (USE_U) val += TZ[qz * nk + k] * vv[k];
-        if (DZ) dz += Gc[qz * NC + k] * vv[k];
-        if (DY) dy += TZ[qz * nk + k] * vd[k];
-        if (DX) dx += TZ[qz * nk + k] * dv[k];
+        if (USE_U) val += tab_even<nk, Q1>(TZ, qz, k) * vv[k];
+        if (DZ) dz += tab_odd<NC, Q1>(Gc, qz, k) * vv[k];
+        if (DY) dy += tab_even<nk, Q1>(TZ, qz, k) * vd[k];
+        if (DX) dx += tab_even<nk, Q1>(TZ, qz, k) * dv[k];
       }
       if (USE_U) U[C][qz] = val;
       if (USE_C) {
@@ -243,10 +273,10 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
           if (C == 1) wdz = -CV[0][qz], wdx = CV[2][qz];
           if (C == 2) wdy = CV[0][qz], wdx = -CV[1][qz];
         }
-        if (USE_U) vv += TZ[qz * nk + k] * V[C][qz];
-        if (DZ) vv += Gc[qz * NC + k] * wdz;
-        if (DY) vd += TZ[qz * nk + k] * wdy;
-        if (DX) dv += TZ[qz * nk + k] * wdx;
+        if (USE_U) vv += tab_even<nk, Q1>(TZ, qz, k) * V[C][qz];
+        if (DZ) vv += tab_odd<NC, Q1>(Gc, qz, k) * wdz;
+        if (DY) vd += tab_even<nk, Q1>(TZ, qz, k) * wdy;
+        if (DX) dv += tab_even<nk, Q1>(TZ, qz, k) * wdx;
       }
       if (lane_ok) {
         sm[L::ib(0, ta, tb, k)] = vv;
@@ -271,9 +301,9 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
       double v = 0.0, d = 0.0;
 #pragma unroll
       for (int qy = 0; qy < Q1; qy++) {
-        v += TY[qy * nj + j] * vv[qy];
-        if (DY) v += Gc[qy * NC + j] * vd[qy];
-        if (DX) d += TY[qy * nj + j] * dv[qy];
+        v += tab_even<nj, Q1>(TY, qy, j) * vv[qy];
+        if (DY) v += tab_odd<NC, Q1>(Gc, qy, j) * vd[qy];
+        if (DX) d += tab_even<nj, Q1>(TY, qy, j) * dv[qy];
       }
       if (lane_ok && act) {
         sm[L::ia(0, ta, j, tb)] = v;
@@ -296,8 +326,8 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
       double r = 0.0;
 #pragma unroll
       for (int qx = 0; qx < Q1; qx++) {
-        r += TX[qx * ni + i] * v[qx];
-        if (DX) r += Gc[qx * NC + i] * d[qx];
+        r += tab_even<ni, Q1>(TX, qx, i) * v[qx];
+        if (DX) r += tab_odd<NC, Q1>(Gc, qx, i) * d[qx];
       }
       if (active && act) {
         const int s = a.lidx[(size_t)e * P + off + i + ni * (ta + nj * tb)];
@@ -310,8 +340,10 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
 
 constexpr int kWavesPerBlock = 4;
 
-template <int P1, int Q1, bool USE_U, bool USE_C>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void nd_hex_apply_kernel(const NDArgs<P1, Q1> a) {
+// ISO: every material coefficient is a multiple of the identity (checked at creation), so D needs
+// one scalar per context instead of a 3x3 matrix.
+template <int P1, int Q1, bool USE_U, bool USE_C, bool ISO>
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(const NDArgs<P1, Q1> a) {
   using L = NDLayout<P1, Q1>;
   constexpr int Q = Q1 * Q1 * Q1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -322,6 +354,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void nd_hex_apply_kernel(const
   const int e = (blockIdx.x * kWavesPerBlock + wave) * L::EPW + sub;
   const bool active = lane_ok && e < a.ne;
   double *sm = smem + (size_t)(wave * L::EPW + (lane_ok ? sub : 0)) * L::ELEM_PAD;
+
+  // Geometry data of this lane's Q1 quadrature points: issue the loads now (10 doubles per point,
+  // the dominant HBM stream) and consume them after the forward contraction.
+  const double *g = a.geom + (size_t)(active ? e : 0) * 11 * Q + ta + Q1 * tb;
+  double gd[Q1][10];
+  int attr[Q1];
+#pragma unroll
+  for (int qz = 0; qz < Q1; qz++) {
+    attr[qz] = (int)g[Q1 * Q1 * qz];
+#pragma unroll
+    for (int c = 0; c < 10; c++) gd[qz][c] = g[(1 + c) * Q + Q1 * Q1 * qz];
+  }
 
   double U[3][Q1], CU[3][Q1];
 #pragma unroll
@@ -334,25 +378,34 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void nd_hex_apply_kernel(const
   nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
 
   // D at the Q1 points of this lane's column (hcurl_33 / hdiv_33 / hdivmass_33)
-  const double *g = a.geom + (size_t)(active ? e : 0) * 11 * Q;
 #pragma unroll
   for (int qz = 0; qz < Q1; qz++) {
-    const int q = ta + Q1 * (tb + Q1 * qz);
-    double adj[9], Cm[9];
-    const int attr = (int)g[q];
-    const double wdetJ = g[Q + q];
-#pragma unroll
-    for (int c = 0; c < 9; c++) adj[c] = g[(2 + c) * Q + q];
-    if (USE_U) {
-      coeff_unpack3(a.c_mass, attr, Cm);
-      mult_AtBCx33(adj, Cm, adj, U[0][qz], U[1][qz], U[2][qz], wdetJ, U[0][qz], U[1][qz], U[2][qz]);
-    }
-    if (USE_C) {
-      double Jl[9];
-      coeff_unpack3(a.c_curl, attr, Cm);
-      adjJt33(adj, Jl);
-      mult_AtBCx33(Jl, Cm, Jl, CU[0][qz], CU[1][qz], CU[2][qz], wdetJ, CU[0][qz], CU[1][qz],
-                   CU[2][qz]);
+    const double wdetJ = gd[qz][0];
+    const double *adj = &gd[qz][1];
+    if (ISO) {
+      if (USE_U) {
+        const double c = a.c_mass.mat[9 * coeff_index(a.c_mass, attr[qz])];
+        mult_AtAx33(adj, U[0][qz], U[1][qz], U[2][qz], wdetJ * c, U[0][qz], U[1][qz], U[2][qz]);
+      }
+      if (USE_C) {
+        double Jl[9];
+        const double c = a.c_curl.mat[9 * coeff_index(a.c_curl, attr[qz])];
+        adjJt33(adj, Jl);
+        mult_AtAx33(Jl, CU[0][qz], CU[1][qz], CU[2][qz], wdetJ * c, CU[0][qz], CU[1][qz], CU[2][qz]);
+      }
+    } else {
+      double Cm[9];
+      if (USE_U) {
+        coeff_unpack3(a.c_mass, attr[qz], Cm);
+        mult_AtBCx33(adj, Cm, adj, U[0][qz], U[1][qz], U[2][qz], wdetJ, U[0][qz], U[1][qz], U[2][qz]);
+      }
+      if (USE_C) {
+        double Jl[9];
+        coeff_unpack3(a.c_curl, attr[qz], Cm);
+        adjJt33(adj, Jl);
+        mult_AtBCx33(Jl, Cm, Jl, CU[0][qz], CU[1][qz], CU[2][qz], wdetJ, CU[0][qz], CU[1][qz],
+                     CU[2][qz]);
+      }
     }
   }
 
@@ -363,8 +416,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void nd_hex_apply_kernel(const
 
 template <int P1, int Q1>
 static void fill_tab(const SubOp &so, NDTab<P1, Q1> &t) {
-  for (int i = 0; i < Q1 * P1; i++) t.Bo[i] = so.Bo[i];
-  for (int i = 0; i < Q1 * (P1 + 1); i++) t.Bc[i] = so.Bc[i], t.Gc[i] = so.Gc[i];
+  constexpr int QH = NDTab<P1, Q1>::QH;
+  for (int i = 0; i < QH * P1; i++) t.Bo[i] = so.Bo[i];
+  for (int i = 0; i < QH * (P1 + 1); i++) t.Bc[i] = so.Bc[i], t.Gc[i] = so.Gc[i];
+}
+
+template <int P1, int Q1, bool U, bool C>
+static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+  if (iso)
+    hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true>), grid, block, lds, s, a);
+  else
+    hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false>), grid, block, lds, s, a);
 }
 
 template <int P1, int Q1>
@@ -383,16 +445,16 @@ static void launch_pq(const SubOp &so, const double *x, double *y, hipStream_t s
   switch (so.qf) {
     case PA_QF_HDIV_33:
       a.c_curl = so.c0.dev();
-      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, false, true>), grid, block, lds, s, a);
+      launch_iso<P1, Q1, false, true>(a, so.iso, grid, block, lds, s);
       break;
     case PA_QF_HCURL_33:
       a.c_mass = so.c0.dev();
-      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, true, false>), grid, block, lds, s, a);
+      launch_iso<P1, Q1, true, false>(a, so.iso, grid, block, lds, s);
       break;
     case PA_QF_HDIVMASS_33:
       a.c_mass = so.c0.dev();
       a.c_curl = so.c1.dev();
-      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, true, true>), grid, block, lds, s, a);
+      launch_iso<P1, Q1, true, true>(a, so.iso, grid, block, lds, s);
       break;
     default:
       throw Error("QFunction not available for H(curl) hexahedra");
@@ -425,11 +487,21 @@ void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, hipStream_
 // diag_l = sum_q [ phi_l^T Mm phi_l + curl(phi_l)^T Mc curl(phi_l) ] with the pointwise matrices
 // Mm = w detJ adj^T C adj and Mc = w detJ Jl^T C Jl of the D stage.  Set-up only (reference
 // operator.cpp:116-143 / CeedOperatorLinearAssembleAddDiagonal): one workgroup per element,
-// matrices staged in LDS, one thread per local dof.
-template <int P1, int Q1>
-__global__ void nd_hex_diag_kernel(const NDArgs<P1, Q1> a, const bool use_u, const bool use_c) {
-  constexpr int NC = P1 + 1, Q = Q1 * Q1 * Q1, P = 3 * P1 * NC * NC;
-  __shared__ double Mm[Q][9], Mc[Q][9];
+// matrices staged in LDS, one thread per local dof; full 1-D tables read from device memory.
+struct NDDiagArgs {
+  int ne, p, q1;
+  const int32_t *lidx;
+  const double *geom;
+  double *y;
+  CoeffDev c_mass, c_curl;
+  const double *Bo, *Bc, *Gc;  // device, full [q1][n]
+  bool use_u, use_c;
+};
+
+__global__ void nd_hex_diag_kernel(const NDDiagArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  const int P1 = a.p, Q1 = a.q1, NC = P1 + 1, Q = Q1 * Q1 * Q1, P = 3 * P1 * NC * NC;
+  double *Mm = dsm, *Mc = dsm + 9 * Q;
   const int e = blockIdx.x;
   const double *g = a.geom + (size_t)e * 11 * Q;
   for (int q = threadIdx.x; q < Q; q += blockDim.x) {
@@ -440,76 +512,71 @@ __global__ void nd_hex_diag_kernel(const NDArgs<P1, Q1> a, const bool use_u, con
     for (int col = 0; col < 3; col++) {
       const double e0 = col == 0, e1 = col == 1, e2 = col == 2;
       double y0 = 0, y1 = 0, y2 = 0;
-      if (use_u) {
+      if (a.use_u) {
         coeff_unpack3(a.c_mass, attr, Cm);
         mult_AtBCx33(adj, Cm, adj, e0, e1, e2, w, y0, y1, y2);
       }
-      Mm[q][0 + 3 * col] = y0, Mm[q][1 + 3 * col] = y1, Mm[q][2 + 3 * col] = y2;
+      Mm[9 * q + 0 + 3 * col] = y0, Mm[9 * q + 1 + 3 * col] = y1, Mm[9 * q + 2 + 3 * col] = y2;
       y0 = y1 = y2 = 0;
-      if (use_c) {
+      if (a.use_c) {
         coeff_unpack3(a.c_curl, attr, Cm);
         adjJt33(adj, Jl);
         mult_AtBCx33(Jl, Cm, Jl, e0, e1, e2, w, y0, y1, y2);
       }
-      Mc[q][0 + 3 * col] = y0, Mc[q][1 + 3 * col] = y1, Mc[q][2 + 3 * col] = y2;
+      Mc[9 * q + 0 + 3 * col] = y0, Mc[9 * q + 1 + 3 * col] = y1, Mc[9 * q + 2 + 3 * col] = y2;
     }
   }
   __syncthreads();
   for (int l = threadIdx.x; l < P; l += blockDim.x) {
     const int C = l / (P1 * NC * NC);
     const int r = l - C * P1 * NC * NC;
-    const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC;
+    const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
     const int i = r % ni, j = (r / ni) % nj, k = r / (ni * nj);
-    const double *TX = (C == 0) ? a.tab.Bo : a.tab.Bc;
-    const double *TY = (C == 1) ? a.tab.Bo : a.tab.Bc;
-    const double *TZ = (C == 2) ? a.tab.Bo : a.tab.Bc;
-    const int nk = (C == 2) ? P1 : NC;
+    const double *TX = (C == 0) ? a.Bo : a.Bc;
+    const double *TY = (C == 1) ? a.Bo : a.Bc;
+    const double *TZ = (C == 2) ? a.Bo : a.Bc;
     double acc = 0.0;
     for (int qz = 0; qz < Q1; qz++)
       for (int qy = 0; qy < Q1; qy++)
         for (int qx = 0; qx < Q1; qx++) {
           const int q = qx + Q1 * (qy + Q1 * qz);
           const double bx = TX[qx * ni + i], by = TY[qy * nj + j], bz = TZ[qz * nk + k];
-          const double gx = (C == 0) ? 0.0 : a.tab.Gc[qx * NC + i];
-          const double gy = (C == 1) ? 0.0 : a.tab.Gc[qy * NC + j];
-          const double gz = (C == 2) ? 0.0 : a.tab.Gc[qz * NC + k];
+          const double gx = (C == 0) ? 0.0 : a.Gc[qx * NC + i];
+          const double gy = (C == 1) ? 0.0 : a.Gc[qy * NC + j];
+          const double gz = (C == 2) ? 0.0 : a.Gc[qz * NC + k];
           const double f = bx * by * bz;
           const double dx = gx * by * bz, dy = bx * gy * bz, dz = bx * by * gz;
           double cv[3];
           if (C == 0) cv[0] = 0.0, cv[1] = dz, cv[2] = -dy;
           if (C == 1) cv[0] = -dz, cv[1] = 0.0, cv[2] = dx;
           if (C == 2) cv[0] = dy, cv[1] = -dx, cv[2] = 0.0;
-          acc += Mm[q][C + 3 * C] * f * f;
+          acc += Mm[9 * q + C + 3 * C] * f * f;
           for (int r2 = 0; r2 < 3; r2++)
-            for (int c2 = 0; c2 < 3; c2++) acc += cv[r2] * Mc[q][r2 + 3 * c2] * cv[c2];
+            for (int c2 = 0; c2 < 3; c2++) acc += cv[r2] * Mc[9 * q + r2 + 3 * c2] * cv[c2];
         }
     const int s = a.lidx[(size_t)e * P + l];
     unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], acc);
   }
 }
 
-template <int P1, int Q1>
-static void launch_diag_pq(const SubOp &so, double *diag, hipStream_t s) {
-  NDArgs<P1, Q1> a;
-  a.ne = so.ne;
+void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s) {
+  NDDiagArgs a;
+  a.ne = so.ne, a.p = so.p, a.q1 = so.q1d;
   a.lidx = so.d_lidx;
   a.geom = so.geom->d_geom;
-  a.x = nullptr;
   a.y = diag;
-  fill_tab(so, a.tab);
-  bool use_u = false, use_c = false;
+  const int nc = so.p + 1;
+  a.Bo = so.d_tab, a.Bc = so.d_tab + so.q1d * so.p, a.Gc = a.Bc + so.q1d * nc;
+  a.use_u = a.use_c = false;
   switch (so.qf) {
-    case PA_QF_HDIV_33: a.c_curl = so.c0.dev(), use_c = true; break;
-    case PA_QF_HCURL_33: a.c_mass = so.c0.dev(), use_u = true; break;
-    case PA_QF_HDIVMASS_33: a.c_mass = so.c0.dev(), a.c_curl = so.c1.dev(), use_u = use_c = true; break;
+    case PA_QF_HDIV_33: a.c_curl = so.c0.dev(), a.use_c = true; break;
+    case PA_QF_HCURL_33: a.c_mass = so.c0.dev(), a.use_u = true; break;
+    case PA_QF_HDIVMASS_33: a.c_mass = so.c0.dev(), a.c_curl = so.c1.dev(), a.use_u = a.use_c = true; break;
     default: throw Error("QFunction not available for H(curl) hexahedra");
   }
-  hipLaunchKernelGGL((nd_hex_diag_kernel<P1, Q1>), dim3(so.ne), dim3(128), 0, s, a, use_u, use_c);
+  const size_t lds = sizeof(double) * 18 * (size_t)so.Q;
+  hipLaunchKernelGGL(nd_hex_diag_kernel, dim3(so.ne), dim3(128), lds, s, a);
   PA_HIP(hipGetLastError());
-}
-
-void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s) {
-  PA_ND_DISPATCH(launch_diag_pq, so, diag, s)
 }
 
 }  // namespace pa

@@ -135,10 +135,12 @@ class NDHexSpace:
         self.elem_dof_lex = dof.astype(np.int32)
         self.elem_sign_lex = sgn
 
-    def ess_dofs(self) -> np.ndarray:
-        """Sorted global dofs with vanishing tangential trace on the mesh boundary (PEC)."""
+    def ess_dofs(self, face_mask=None) -> np.ndarray:
+        """Sorted global dofs with vanishing tangential trace on the mesh boundary (PEC).
+        face_mask [nfaces] overrides the set of boundary faces (default: faces with one element)."""
         mesh, p = self.mesh, self.p
-        bmask = mesh.boundary_face_mask[mesh.elem_faces]  # [NE, 6]
+        fm = mesh.boundary_face_mask if face_mask is None else face_mask
+        bmask = fm[mesh.elem_faces]  # [NE, 6]
         out = []
         for lf, (nax, side, uax, vax) in enumerate(HEX_FACE_AXES):
             el = np.nonzero(bmask[:, lf])[0]

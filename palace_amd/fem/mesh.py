@@ -75,18 +75,22 @@ class HexMesh:
         ev = verts[:, HEX_EDGES]  # [NE, 12, 2]
         lo, hi = ev.min(axis=2), ev.max(axis=2)
         ekey = lo * nv + hi
-        ukey, einv = np.unique(ekey, return_inverse=True)
+        ukey, efirst, einv = np.unique(ekey, return_index=True, return_inverse=True)
+        edge_verts = np.stack([lo.ravel()[efirst], hi.ravel()[efirst]], axis=1)
         # faces: keyed by their three smallest vertices
         fv = np.sort(verts[:, HEX_FACES_UV], axis=2)  # [NE, 6, 4]
         if nv >= 2_000_000:
             raise ValueError("mesh too large for the int64 face key")
         fkey = (fv[..., 0] * nv + fv[..., 1]) * nv + fv[..., 2]
-        ufkey, finv, fcount = np.unique(fkey, return_inverse=True, return_counts=True)
+        ufkey, ffirst, finv, fcount = np.unique(fkey, return_index=True, return_inverse=True, return_counts=True)
+        face_verts = fv.reshape(-1, 4)[ffirst]
         self._topo = dict(
             nv=nv,
             vert_nodes=vid,
             verts=verts,
             nedges=ukey.size,
+            edge_verts=edge_verts,
+            face_verts=face_verts,
             elem_edges=einv.reshape(self.ne, 12),
             nfaces=ufkey.size,
             elem_faces=finv.reshape(self.ne, 6),
@@ -112,6 +116,24 @@ class HexMesh:
     def nfaces(self):
         self._build_topology()
         return self._topo["nfaces"]
+
+    @property
+    def edge_verts(self):
+        """[nedges, 2] vertex ids (ascending) of every edge."""
+        self._build_topology()
+        return self._topo["edge_verts"]
+
+    @property
+    def face_verts(self):
+        """[nfaces, 4] vertex ids (ascending) of every face."""
+        self._build_topology()
+        return self._topo["face_verts"]
+
+    @property
+    def vert_coords(self):
+        """[nv, 3] coordinates of the vertices."""
+        self._build_topology()
+        return self.x[self._topo["vert_nodes"]]
 
     @property
     def elem_edges(self):
@@ -273,18 +295,25 @@ def read_gmsh22(path: str) -> HexMesh:
 # ---- merging helper ------------------------------------------------------------------------
 
 def _merge_points(pts: np.ndarray, tol: float):
-    """Merge coincident points: returns (unique_pts, inverse).  Lattice rounding with a
-    post-check (two unique points closer than tol => retry with a shifted lattice)."""
+    """Merge coincident points: returns (unique_pts, inverse).  Points are snapped to a lattice of
+    pitch `tol` (three 21-bit integer coordinates packed into one int64 key); a post-check on a
+    half-shifted lattice catches the rare point that straddles a cell boundary and retries with a
+    different offset."""
+    lo = pts.min(axis=0)
+    span = float(np.max(pts.max(axis=0) - lo))
+    if span / tol >= 2**21 - 2:
+        raise ValueError("merge tolerance too small for the 21-bit lattice")
+
+    def keys(shift):
+        q = np.floor((pts - lo) / tol + shift).astype(np.int64)
+        return (q[:, 0] << 42) | (q[:, 1] << 21) | q[:, 2]
+
     for shift in (0.137, 0.379, 0.613, 0.859):
-        key = np.floor(pts / tol + shift).astype(np.int64)
-        _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
-        inv = inv.reshape(-1)
+        _, first, inv = np.unique(keys(shift), return_index=True, return_inverse=True)
         upts = pts[first]
-        # post-check: every point must be within tol/10 of its representative
         if np.max(np.abs(upts[inv] - pts)) < 0.1 * tol:
-            # and no split clusters: check on a coarser shifted lattice that counts agree
-            key2 = np.floor(upts / tol + shift + 0.5).astype(np.int64)
-            if np.unique(key2, axis=0).shape[0] == upts.shape[0]:
+            k2 = np.unique(keys(shift + 0.5)[first])
+            if k2.size == first.size:
                 return upts, inv
     raise RuntimeError("point merge failed")
 
@@ -306,7 +335,7 @@ def refine_uniform(mesh: HexMesh) -> HexMesh:
                 children.append(blk.reshape(mesh.ne, 27, 3))
     pts = np.stack(children, axis=1).reshape(-1, 3)  # [NE*8*27, 3]
     lo, hi = mesh.bounding_box()
-    upts, inv = _merge_points(pts, 1e-7 * float(np.max(hi - lo)))
+    upts, inv = _merge_points(pts, 1e-6 * float(np.max(hi - lo)))
     out = HexMesh(x=upts, elem_nodes=inv.reshape(mesh.ne * 8, 27), attr=np.repeat(mesh.attr, 8))
     out.check()
     return out
@@ -370,7 +399,7 @@ def ogrid_cylinder(n: int, nz: int, radius: float = 2.74, height: float | None =
         offset += nzz * ny2 * nx2
     pts = np.concatenate(pts_list)
     conn = np.concatenate(conn_list)
-    upts, inv = _merge_points(pts, 1e-7 * radius)
+    upts, inv = _merge_points(pts, 1e-6 * max(2.0 * radius, height))
     mesh = HexMesh(x=upts, elem_nodes=inv[conn], attr=np.ones(conn.shape[0], dtype=np.int32))
     mesh.check()
     return mesh

@@ -1,0 +1,229 @@
+"""Element partition of the cylinder across GPUs (one z-slab per rank) and the halo plans that
+implement the conforming prolongation P / P^T of every multigrid level.
+
+Reference: Palace partitions elements with METIS (utils/geodata.cpp:3587-3596), each rank's
+L-vector holds every dof of its elements, true dofs have one owner and `y = P^T A_local P x`
+(linalg/rap.cpp:195-234); P / P^T live in MFEM's ParFiniteElementSpace (not vendored).  Here the
+O-grid cylinder is cut into slabs of whole element layers: rank r owns layers [r nz, (r+1) nz) and
+the dofs on its top interface plane; the dofs on its bottom plane are ghosts owned by rank r-1.
+Local numbering = owned dofs first, ghosts last, so a T-vector is a prefix of the L-vector.
+
+Both sides of an interface enumerate the shared entities in the same order without communicating:
+entities in the plane are sorted by the lattice key of their (x, y) midpoint, which both ranks
+compute from bit-identical cross-section coordinates; edge direction / face frame on the plane are
+fixed by vertex ids whose relative order within a plane is the same on both ranks (see
+`_merge_points`: ids follow the (x, y, z) lattice order).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .fespace import NDHexSpace
+from .mesh import HexMesh, ogrid_cylinder
+
+
+def slab_shape(dofs_per_rank: float, p: int):
+    """(n, nz) of one slab with about dofs_per_rank Nedelec dofs of order p (5 n^2 nz elements)."""
+    ne = dofs_per_rank / (3.0 * p**3)
+    n = max(1, int(round((ne / (5 * 1.15)) ** (1.0 / 3.0))))
+    nz = max(1, int(round(ne / (5 * n * n))))
+    return n, nz
+
+
+def _plane_key(xy: np.ndarray, scale: float) -> np.ndarray:
+    q = np.round(xy * scale).astype(np.int64) + (1 << 30)
+    return (q[:, 0] << 32) | q[:, 1]
+
+
+class SlabNDSpace(NDHexSpace):
+    """Nedelec space on one slab, renumbered owned-first, with its halo lists.
+
+    n_true, ndofs (= n_local); halo: neighbours + send/recv index lists; ess(): essential TRUE dofs
+    (PEC wall + the physical bottom/top caps of the whole cylinder)."""
+
+    def __init__(self, mesh: HexMesh, p: int, rank: int, world: int, z_lo: float, z_hi: float, radius: float):
+        super().__init__(mesh, p)
+        self.rank, self.world = rank, world
+        tol = 1e-6 * radius
+        vz = mesh.vert_coords[:, 2]
+        scale = 1.0 / (1e-6 * radius)
+
+        def plane_dofs(z):
+            """Dofs living in the plane z = const, in the canonical cross-rank order."""
+            inp = np.abs(vz - z) < tol
+            ev, fv = mesh.edge_verts, mesh.face_verts
+            e_in = np.nonzero(inp[ev].all(axis=1))[0]
+            f_in = np.nonzero(inp[fv].all(axis=1))[0]
+            vc = mesh.vert_coords[:, :2]
+            e_in = e_in[np.argsort(_plane_key(vc[ev[e_in]].mean(axis=1), scale), kind="stable")]
+            f_in = f_in[np.argsort(_plane_key(vc[fv[f_in]].mean(axis=1), scale), kind="stable")]
+            n_e, n_f, _ = self.n_per
+            de = (self.edge_base + e_in[:, None] * n_e + np.arange(n_e)[None, :]).ravel()
+            df = (self.face_base + f_in[:, None] * n_f + np.arange(n_f)[None, :]).ravel()
+            return np.concatenate([de, df]).astype(np.int64), f_in
+
+        bottom, f_bot = plane_dofs(z_lo)
+        top, f_top = plane_dofs(z_hi)
+        n_old = self.ndofs
+        ghosts = bottom if rank > 0 else np.zeros(0, dtype=np.int64)
+        is_ghost = np.zeros(n_old, dtype=bool)
+        is_ghost[ghosts] = True
+        perm = np.empty(n_old, dtype=np.int64)
+        self.n_true = n_old - ghosts.size
+        perm[~is_ghost] = np.arange(self.n_true)
+        perm[ghosts] = self.n_true + np.arange(ghosts.size)  # ghost slots in canonical order
+        self.elem_dof_lex = perm[self.elem_dof_lex].astype(np.int32)
+        self._perm = perm
+        # essential dofs: boundary faces minus the interface planes
+        fmask = mesh.boundary_face_mask.copy()
+        if rank > 0:
+            fmask[f_bot] = False
+        if rank < world - 1:
+            fmask[f_top] = False
+        ess = super().ess_dofs(face_mask=fmask)
+        self._ess_true = ess[ess < self.n_true]
+        # halo plan
+        self.nbr, self.send, self.recv = [], [], []
+        if rank > 0:
+            self.nbr.append(rank - 1)
+            self.send.append(np.zeros(0, dtype=np.int32))
+            self.recv.append(perm[bottom].astype(np.int32))
+        if rank < world - 1:
+            self.nbr.append(rank + 1)
+            self.send.append(perm[top].astype(np.int32))
+            self.recv.append(np.zeros(0, dtype=np.int32))
+
+    def ess_dofs(self, face_mask=None):
+        return self._ess_true
+
+
+def levels_for(p: int):
+    """p-coarsening sequence of the reference (LOGARITHMIC: p -> (p + 1) / 2 down to 1,
+    fem/multigrid.hpp:44-69)."""
+    out = [p]
+    while out[-1] > 1:
+        out.append((out[-1] + 1) // 2)
+    return out[::-1]
+
+
+class SlabProblem:
+    """Everything bench.py / the multi-rank tests need on one rank: the slab mesh, the level spaces,
+    device geometry data, operators, halo objects and solvers."""
+
+    def __init__(self, ctx, rank, world, p, dofs_per_rank, levels=True, radius=2.74, shape=None, device=True):
+        self.ctx, self.rank, self.world, self.p = ctx, rank, world, p
+        n, nz = shape if shape is not None else slab_shape(dofs_per_rank, p)
+        h_layer = 2.0 * radius / max(1, round(1.15 * n))  # roughly isotropic elements
+        self.height = nz * h_layer
+        z_lo = rank * self.height
+        mesh = ogrid_cylinder(n, nz, radius=radius, height=self.height)
+        mesh.x = mesh.x.copy()
+        mesh.x[:, 2] += z_lo
+        self.mesh, self.radius = mesh, radius
+        self.orders = levels_for(p) if levels else [p]
+        self.spaces = [SlabNDSpace(mesh, q, rank, world, z_lo, z_lo + self.height, radius) for q in self.orders]
+        self.n_true = [s.n_true for s in self.spaces]
+        self.n_local = [s.ndofs for s in self.spaces]
+        self.ess = [s.ess_dofs() for s in self.spaces]
+        self.q1d = p + 1
+        if device:
+            self._device_setup()
+
+    # ---- device objects ---------------------------------------------------------------------
+    def _device_setup(self):
+        from .. import ceed, linalg
+
+        self.geom = ceed.GeomFactorData(self.mesh, self.q1d)
+        self.halos = [linalg.Halo(self.ctx, s.nbr, s.send, s.recv) if self.world > 1 else None for s in self.spaces]
+        self.local_curlcurl = ceed.curlcurl_operator(self.geom, self.spaces[-1], ceed.coefficient_context(3))
+        self._keep = []
+
+    def global_true_dofs(self):
+        if self.world == 1:
+            return self.n_true[-1]
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([self.n_true[-1]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        return int(t.item())
+
+    def curlcurl_par_operator(self):
+        from .. import linalg
+
+        return linalg.ParOperator(self.ctx, self.local_curlcurl, self.ess[-1], linalg.DIAG_ONE,
+                                  n_true=self.n_true[-1], halo=self.halos[-1])
+
+    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=50):
+        """PCG on (K + M) with the p-multigrid preconditioner configured as the reference does for
+        p = 3 (iodata.cpp:533-564: 4th-kind Chebyshev of order max(2p, 4), 1 smoothing step, 1 V-cycle);
+        level 0 is solved by Jacobi-PCG (the reference uses AMS from HYPRE there, linalg/ams.cpp)."""
+        import torch
+
+        from .. import ceed, linalg
+
+        ctx = self.ctx
+        mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([eps_r])])
+        curl = ceed.coefficient_context(3)
+        fine = ceed.curlcurlmass_operator(self.geom, self.spaces[-1], mass, curl)
+        local = [fine.coarsen(self.geom, s) for s in self.spaces[:-1]] + [fine]
+        A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE, n_true=nt, halo=h)
+             for op, e, nt, h in zip(local, self.ess, self.n_true, self.halos)]
+        P = [linalg.Interp(ctx, self.spaces[l], self.spaces[l + 1], coarse_halo=self.halos[l],
+                           n_true_c=self.n_true[l], n_true_f=self.n_true[l + 1]) for l in range(len(A) - 1)]
+        if len(A) > 1:
+            coarse = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
+            B = linalg.gmg(ctx, A, P, coarse, cheby_order=max(2 * self.p, 4))
+        else:
+            B = linalg.jacobi(ctx, A[0])
+        K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)
+        n = self.n_true[-1]
+        ones = torch.ones(n, dtype=torch.float64, device="cuda")
+        b = torch.empty_like(ones)
+        A[-1].mult(ones, b)
+        b[torch.from_numpy(self.ess[-1].astype(np.int64)).cuda()] = 0.0
+        x = torch.zeros_like(b)
+        self._keep.append((local, A, P, B))
+        return K, b, x
+
+
+# ---- host-side executors of a halo plan over torch.distributed (CPU tests, gloo) -------------
+
+def prolongate_dist(space, lx):
+    """lx[ghosts] <- owner values, using torch.distributed point-to-point (any backend)."""
+    import torch
+    import torch.distributed as dist
+
+    reqs, bufs = [], []
+    for nb, s, r in zip(space.nbr, space.send, space.recv):
+        if s.size:
+            reqs.append(dist.isend(lx[torch.from_numpy(s.astype(np.int64))].contiguous(), nb))
+        if r.size:
+            buf = torch.empty(r.size, dtype=lx.dtype)
+            bufs.append((r, buf))
+            reqs.append(dist.irecv(buf, nb))
+    for q in reqs:
+        q.wait()
+    for r, buf in bufs:
+        lx[torch.from_numpy(r.astype(np.int64))] = buf
+    return lx
+
+
+def restrict_add_dist(space, ly):
+    """ly[owned shared] += ghost contributions of the sharers."""
+    import torch
+    import torch.distributed as dist
+
+    reqs, bufs = [], []
+    for nb, s, r in zip(space.nbr, space.send, space.recv):
+        if r.size:
+            reqs.append(dist.isend(ly[torch.from_numpy(r.astype(np.int64))].contiguous(), nb))
+        if s.size:
+            buf = torch.empty(s.size, dtype=ly.dtype)
+            bufs.append((s, buf))
+            reqs.append(dist.irecv(buf, nb))
+    for q in reqs:
+        q.wait()
+    for s, buf in bufs:
+        ly.index_add_(0, torch.from_numpy(s.astype(np.int64)), buf)
+    return ly

@@ -59,3 +59,63 @@ def oracle_operator(nd, geom, qf, ctx, ctx2=None, q1d=None):
     off, ori = nd.native_restriction()
     interp, curl = dense_tables(nd, q1d)
     return po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, geom, QF_MAP[qf][0], ctx, ctx2)
+
+
+class FastParOperatorOracle(po.ParOperatorOracle):
+    """ParOperatorOracle whose local apply runs through the C oracle (same restatement, compiled)."""
+
+    def __init__(self, nd, geom, qf, blob, ess, q1d, ctx, ctx2=None, policy=po.DIAG_ONE):
+        self.nd, self.geom, self.qf, self.blob, self.q1d = nd, geom, qf, blob, q1d
+        self.ess = np.asarray(ess, dtype=np.int64)
+        self.policy = policy
+        self.n = nd.ndofs
+        self._np_op = oracle_operator(nd, geom, qf, ctx, ctx2, q1d)
+        self._diag = None
+
+    def mult(self, x):
+        tx = x.copy()
+        tx[self.ess] = 0.0
+        y = oracle_apply_c(self.nd, self.geom, self.qf, self.blob, tx, self.q1d)
+        y[self.ess] = x[self.ess] if self.policy == po.DIAG_ONE else 0.0
+        return y
+
+    def diagonal(self):
+        if self._diag is None:
+            d = self._np_op.diagonal()
+            d[self.ess] = 1.0 if self.policy == po.DIAG_ONE else 0.0
+            self._diag = d
+        return self._diag
+
+
+def nd_interpolate(space, F):
+    """Nodal interpolant of a smooth vector field F(x) -> [.., 3] in an NDHexSpace-like space:
+    dof = F(x_node) . (J e_c) (covariant Piola), written through the signed element->dof map.
+    Returns the local vector (size space.ndofs)."""
+    from palace_amd.fem.basis1d import gauss_legendre, gauss_lobatto
+    from palace_amd.fem.mesh import _q2_1d
+
+    p, mesh = space.p, space.mesh
+    cp, op = gauss_lobatto(p + 1), gauss_legendre(p)[0]
+    pts, comps = [], []
+    for c in range(3):
+        n = [p + 1] * 3
+        n[c] = p
+        nodes = [cp, cp, cp]
+        nodes[c] = op
+        for k in range(n[2]):
+            for j in range(n[1]):
+                for i in range(n[0]):
+                    pts.append([nodes[0][i], nodes[1][j], nodes[2][k]])
+                    comps.append(c)
+    pts, comps = np.array(pts), np.array(comps)
+    J = mesh.jacobian_at(pts)  # [e, l, i, d]
+    Bx, _ = _q2_1d(pts[:, 0])
+    By, _ = _q2_1d(pts[:, 1])
+    Bz, _ = _q2_1d(pts[:, 2])
+    X = mesh.elem_coords().reshape(mesh.ne, 3, 3, 3, 3)
+    xp = np.einsum("lk,lj,li,ekjic->elc", Bz, By, Bx, X)
+    t = np.take_along_axis(J, comps[None, :, None, None].repeat(mesh.ne, 0).repeat(3, 2), axis=3)[..., 0]
+    val = np.einsum("elc,elc->el", F(xp), t) * space.elem_sign_lex
+    out = np.zeros(space.ndofs)
+    out[space.elem_dof_lex] = val
+    return out
