@@ -1,6 +1,7 @@
 // C ABI of libpalace_amd.so (declared in include/palace_amd.h): object lifetime, descriptor
 // validation and set-up on the host; all arithmetic lives in the HIP kernels.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "pa_internal.hpp"
@@ -206,6 +207,27 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
       lidx[(size_t)e * P + l] = neg ? -1 - off : off;
     }
   so->d_lidx = dev_upload(lidx.data(), lidx.size());
+  // transpose map for the gather form of E^T (counting sort by dof; element order preserved, so the
+  // summation order of every dof is fixed) unless PALACE_AMD_SCATTER=atomic asks for the atomic form
+  const char *mode = getenv("PALACE_AMD_SCATTER");
+  if (!(mode && std::string(mode) == "atomic")) {
+    const size_t nnz = lidx.size();
+    std::vector<int32_t> tptr((size_t)r.lsize + 1, 0), tent(nnz);
+    for (size_t k = 0; k < nnz; k++) {
+      const int32_t s = lidx[k];
+      tptr[(size_t)(s >= 0 ? s : -1 - s) + 1]++;
+    }
+    for (int d = 0; d < r.lsize; d++) tptr[d + 1] += tptr[d];
+    std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+    for (size_t k = 0; k < nnz; k++) {
+      const int32_t s = lidx[k];
+      const int d = s >= 0 ? s : -1 - s;
+      tent[fill[d]++] = s >= 0 ? (int32_t)k : -1 - (int32_t)k;
+    }
+    so->d_tptr = dev_upload(tptr.data(), tptr.size());
+    so->d_tent = dev_upload(tent.data(), tent.size());
+    so->d_ye = dev_alloc<double>(nnz);
+  }
 
   so->ctx_blob.assign((const uint8_t *)ctx, (const uint8_t *)ctx + ctx_size);
   PA_REQUIRE(ctx && ctx_size >= 24 && ctx_size % 8 == 0, "coefficient context missing or malformed");
@@ -242,6 +264,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
 static void free_sub(SubOp *so) {
   if (!so) return;
   hipFree(so->d_lidx);
+  hipFree(so->d_ye), hipFree(so->d_tptr), hipFree(so->d_tent);
   hipFree(so->d_tab);
   hipFree(so->c0.d_attr_mat), hipFree(so->c0.d_mat);
   hipFree(so->c1.d_attr_mat), hipFree(so->c1.d_mat);
@@ -249,14 +272,27 @@ static void free_sub(SubOp *so) {
   delete so;
 }
 
-static void apply_add(pa_op *op, const double *x, double *y, hipStream_t s) {
+// y (+)= A x.  overwrite: the first sub-operator writes y instead of accumulating (Mult without a
+// separate memset when E^T runs as a gather).
+static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s) {
   PA_REQUIRE(op && x && y, "null argument");
   PA_REQUIRE(!op->subs.empty(), "operator has no sub-operators");
+  PA_REQUIRE(x != y, "in-place apply is not supported");
+  bool first = true;
   for (const SubOp *so : op->subs) {
-    if (so->fe_type == PA_FE_HCURL)
-      launch_nd_hex_apply(*so, x, y, s);
-    else
+    if (so->fe_type == PA_FE_HCURL) {
+      if (so->d_ye) {
+        launch_nd_hex_apply(*so, x, nullptr, so->d_ye, s);
+        launch_et_gather(*so, y, !(overwrite && first), s);
+      } else {
+        if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
+        launch_nd_hex_apply(*so, x, y, nullptr, s);
+      }
+    } else {
+      if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
       launch_h1_hex_apply(*so, x, y, s);
+    }
+    first = false;
   }
 }
 
@@ -372,14 +408,12 @@ int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_
 }
 
 int pa_op_apply_add(pa_op *op, const double *x, double *y, void *stream) {
-  return guarded([&] { apply_add(op, x, y, (hipStream_t)stream); });
+  return guarded([&] { apply(op, x, y, false, (hipStream_t)stream); });
 }
 
 int pa_op_mult(pa_op *op, const double *x, double *y, void *stream) {
   return guarded([&] {
-    PA_REQUIRE(op && y, "null argument");
-    PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, (hipStream_t)stream));
-    apply_add(op, x, y, (hipStream_t)stream);
+    apply(op, x, y, true, (hipStream_t)stream);
   });
 }
 

@@ -96,6 +96,10 @@ struct SubOp {
   int qf = 0;
   uint32_t trial_ops = 0, test_ops = 0;
   int32_t *d_lidx = nullptr;  // [ne][P] signed tensor-order index: >=0 dof, <0 => -(1+dof) flipped
+  // E^T as a gather (default): E-vector scratch and the CSR transpose of lidx
+  double *d_ye = nullptr;      // [ne][P]
+  int32_t *d_tptr = nullptr;   // [lsize + 1]
+  int32_t *d_tent = nullptr;   // [ne * P] signed positions into d_ye
   std::vector<double> Bc, Gc, Bo;  // full 1-D tables [q1d][n] (host)
   double *d_tab = nullptr;        // the same on the device: [Bo | Bc | Gc]
   bool iso = false;               // every material coefficient is a multiple of the identity
@@ -107,7 +111,8 @@ void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t
 
 // kernels (pa_geom.hip, pa_nd_hex.hip, pa_h1_hex.hip)
 void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s);
-void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, hipStream_t s);
+void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, hipStream_t s);
+void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 void launch_h1_hex_apply(const SubOp &so, const double *x, double *y, hipStream_t s);
 void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);

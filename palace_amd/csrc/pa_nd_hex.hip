@@ -55,7 +55,8 @@ struct NDArgs {
   const int32_t *lidx;
   const double *geom;
   const double *x;
-  double *y;
+  double *y;   // L-vector target of the atomic scatter (EVEC == false)
+  double *ye;  // E-vector target [ne][P], tensor order, unsigned (EVEC == true)
   CoeffDev c_mass, c_curl;
   NDTab<P1, Q1> tab;
 };
@@ -243,7 +244,7 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
 }
 
 // ---- transposed passes for component C ------------------------------------------------------
-template <int C, int P1, int Q1, bool USE_U, bool USE_C>
+template <int C, int P1, int Q1, bool USE_U, bool USE_C, bool EVEC>
 __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e, const bool active,
                                             const bool lane_ok, const int ta, const int tb,
                                             double *__restrict__ sm, const double (&V)[3][Q1],
@@ -330,8 +331,13 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
         if (DX) r += tab_odd<NC, Q1>(Gc, qx, i) * d[qx];
       }
       if (active && act) {
-        const int s = a.lidx[(size_t)e * P + off + i + ni * (ta + nj * tb)];
-        unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? r : -r);
+        const size_t pos = (size_t)e * P + off + i + ni * (ta + nj * tb);
+        if (EVEC) {
+          a.ye[pos] = r;  // signs and the sum over elements happen in et_gather_kernel
+        } else {
+          const int s = a.lidx[pos];
+          unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? r : -r);
+        }
       }
     }
   }
@@ -342,7 +348,7 @@ constexpr int kWavesPerBlock = 4;
 
 // ISO: every material coefficient is a multiple of the identity (checked at creation), so D needs
 // one scalar per context instead of a 3x3 matrix.
-template <int P1, int Q1, bool USE_U, bool USE_C, bool ISO>
+template <int P1, int Q1, bool USE_U, bool USE_C, bool ISO, bool EVEC>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(const NDArgs<P1, Q1> a) {
   using L = NDLayout<P1, Q1>;
   constexpr int Q = Q1 * Q1 * Q1;
@@ -409,9 +415,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
     }
   }
 
-  nd_bwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
-  nd_bwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
-  nd_bwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_bwd_comp<0, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_bwd_comp<1, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_bwd_comp<2, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, sm, U, CU);
 }
 
 template <int P1, int Q1>
@@ -423,14 +429,19 @@ static void fill_tab(const SubOp &so, NDTab<P1, Q1> &t) {
 
 template <int P1, int Q1, bool U, bool C>
 static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-  if (iso)
-    hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true>), grid, block, lds, s, a);
+  const bool evec = a.ye != nullptr;
+  if (iso && evec)
+    hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true, true>), grid, block, lds, s, a);
+  else if (iso)
+    hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true, false>), grid, block, lds, s, a);
+  else if (evec)
+    hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false, true>), grid, block, lds, s, a);
   else
-    hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false, false>), grid, block, lds, s, a);
 }
 
 template <int P1, int Q1>
-static void launch_pq(const SubOp &so, const double *x, double *y, hipStream_t s) {
+static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, hipStream_t s) {
   using L = NDLayout<P1, Q1>;
   NDArgs<P1, Q1> a;
   a.ne = so.ne;
@@ -438,6 +449,7 @@ static void launch_pq(const SubOp &so, const double *x, double *y, hipStream_t s
   a.geom = so.geom->d_geom;
   a.x = x;
   a.y = y;
+  a.ye = ye;
   fill_tab(so, a.tab);
   const int epb = kWavesPerBlock * L::EPW;
   const dim3 grid((so.ne + epb - 1) / epb), block(64 * kWavesPerBlock);
@@ -479,8 +491,32 @@ static void launch_pq(const SubOp &so, const double *x, double *y, hipStream_t s
                   std::to_string(so.q1d) + " points per direction");                       \
   }
 
-void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, hipStream_t s) {
-  PA_ND_DISPATCH(launch_pq, so, x, y, s)
+// ye != nullptr: write the element-local results (E-vector) instead of scattering atomically into y
+void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, hipStream_t s) {
+  PA_ND_DISPATCH(launch_pq, so, x, y, ye, s)
+}
+
+// ---- E^T as a gather: y_d (+)= sum over the element-local copies of dof d -----------------------
+// tptr/tent: transpose of the signed tensor-order index array (CSR by L-dof); entry t >= 0 reads
+// ye[t], t < 0 reads -ye[-1-t].  One thread per dof, fixed summation order => reproducible.
+__global__ void et_gather_kernel(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                                 const double *__restrict__ ye, double *__restrict__ y, const int accumulate) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const int b = tptr[d], e = tptr[d + 1];
+  double s = 0.0;
+  for (int k = b; k < e; k++) {
+    const int t = tent[k];
+    s += t >= 0 ? ye[t] : -ye[-1 - t];
+  }
+  y[d] = accumulate ? y[d] + s : s;
+}
+
+void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s) {
+  const int bs = 256;
+  hipLaunchKernelGGL(et_gather_kernel, dim3((so.lsize + bs - 1) / bs), dim3(bs), 0, s, so.lsize, so.d_tptr, so.d_tent,
+                     so.d_ye, y, accumulate ? 1 : 0);
+  PA_HIP(hipGetLastError());
 }
 
 // ---- diagonal -------------------------------------------------------------------------------

@@ -1,0 +1,20 @@
+"""Profile target: a few launches of the fused ND p=3 apply kernel at the bench size."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from palace_amd import ceed, linalg
+from palace_amd.fem.partition import SlabProblem
+ctx = linalg.Context()
+prob = SlabProblem(ctx, 0, 1, 3, float(os.environ.get("DOFS", "10e6")), levels=False)
+which = os.environ.get("OP", "curl")
+if which == "curl":
+    op = prob.local_curlcurl
+else:
+    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
+    op = ceed.curlcurlmass_operator(prob.geom, prob.spaces[-1], mass, ceed.coefficient_context(3))
+n = prob.n_local[-1]
+x = torch.rand(n, dtype=torch.float64, device="cuda"); y = torch.zeros(n, dtype=torch.float64, device="cuda")
+for _ in range(int(os.environ.get("REPS", "10"))):
+    op.add_mult(x, y)
+torch.cuda.synchronize()
+print("done", n)
