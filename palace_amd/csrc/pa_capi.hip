@@ -219,10 +219,26 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     }
     for (int d = 0; d < r.lsize; d++) tptr[d + 1] += tptr[d];
     std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+    // position of tensor dof l inside an element's E-vector record (the layout the element kernel
+    // stores coalesced): H(curl): [C][i][j + nj k]; H1: tensor order itself
+    std::vector<int32_t> epos(P);
+    if (b.fe_type == PA_FE_HCURL) {
+      const int p = b.order, ncl = p + 1;
+      for (int C = 0; C < 3; C++) {
+        const int ni = C == 0 ? p : ncl, nj = C == 1 ? p : ncl, nk = C == 2 ? p : ncl;
+        for (int k = 0; k < nk; k++)
+          for (int j = 0; j < nj; j++)
+            for (int i = 0; i < ni; i++)
+              epos[C * p * ncl * ncl + i + ni * (j + nj * k)] = C * p * ncl * ncl + i * (nj * nk) + j + nj * k;
+      }
+    } else {
+      for (int l = 0; l < P; l++) epos[l] = l;
+    }
     for (size_t k = 0; k < nnz; k++) {
       const int32_t s = lidx[k];
       const int d = s >= 0 ? s : -1 - s;
-      tent[fill[d]++] = s >= 0 ? (int32_t)k : -1 - (int32_t)k;
+      const int32_t pos = (int32_t)((k / P) * P + epos[k % P]);
+      tent[fill[d]++] = s >= 0 ? pos : -1 - pos;
     }
     so->d_tptr = dev_upload(tptr.data(), tptr.size());
     so->d_tent = dev_upload(tent.data(), tent.size());

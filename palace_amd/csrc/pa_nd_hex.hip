@@ -331,11 +331,12 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
         if (DX) r += tab_odd<NC, Q1>(Gc, qx, i) * d[qx];
       }
       if (active && act) {
-        const size_t pos = (size_t)e * P + off + i + ni * (ta + nj * tb);
         if (EVEC) {
-          a.ye[pos] = r;  // signs and the sum over elements happen in et_gather_kernel
+          // E-vector layout [e][C][i][j + nj k]: the lanes of an element store a contiguous run per
+          // (C, i); signs and the sum over elements happen in et_gather_kernel
+          a.ye[(size_t)e * P + off + i * (nj * nk) + ta + nj * tb] = r;
         } else {
-          const int s = a.lidx[pos];
+          const int s = a.lidx[(size_t)e * P + off + i + ni * (ta + nj * tb)];
           unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? r : -r);
         }
       }
@@ -505,9 +506,28 @@ __global__ void et_gather_kernel(const int n, const int32_t *__restrict__ tptr, 
   if (d >= n) return;
   const int b = tptr[d], e = tptr[d + 1];
   double s = 0.0;
-  for (int k = b; k < e; k++) {
-    const int t = tent[k];
-    s += t >= 0 ? ye[t] : -ye[-1 - t];
+  int k = b;
+  // dofs have 1 (interior), 2 (face) or ~4 (edge) copies: fetch four at a time so the loads overlap
+  for (; k + 4 <= e; k += 4) {
+    const int t0 = tent[k], t1 = tent[k + 1], t2 = tent[k + 2], t3 = tent[k + 3];
+    const double v0 = ye[t0 >= 0 ? t0 : -1 - t0], v1 = ye[t1 >= 0 ? t1 : -1 - t1];
+    const double v2 = ye[t2 >= 0 ? t2 : -1 - t2], v3 = ye[t3 >= 0 ? t3 : -1 - t3];
+    s += t0 >= 0 ? v0 : -v0;
+    s += t1 >= 0 ? v1 : -v1;
+    s += t2 >= 0 ? v2 : -v2;
+    s += t3 >= 0 ? v3 : -v3;
+  }
+  if (k + 2 <= e) {
+    const int t0 = tent[k], t1 = tent[k + 1];
+    const double v0 = ye[t0 >= 0 ? t0 : -1 - t0], v1 = ye[t1 >= 0 ? t1 : -1 - t1];
+    s += t0 >= 0 ? v0 : -v0;
+    s += t1 >= 0 ? v1 : -v1;
+    k += 2;
+  }
+  if (k < e) {
+    const int t0 = tent[k];
+    const double v0 = ye[t0 >= 0 ? t0 : -1 - t0];
+    s += t0 >= 0 ? v0 : -v0;
   }
   y[d] = accumulate ? y[d] + s : s;
 }
