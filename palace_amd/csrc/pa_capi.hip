@@ -122,7 +122,8 @@ static void check_dense_tables(const pa_basis_desc &b, int P, int Q) {
 }
 
 static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_basis_desc &b, int qf,
-                       const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops) {
+                       const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops,
+                       QData *shared_qd = nullptr) {
   require_device();
   PA_REQUIRE(geom && geom->d_geom, "geometry data missing");
   PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_H1, "unknown finite element type");
@@ -274,6 +275,24 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     return true;
   };
   so->iso = is_iso(so->c0) && (so->c1.mat.empty() || is_iso(so->c1));
+  // Pre-assembled packed symmetric D (default for symmetric coefficients; PALACE_AMD_QDATA=0 keeps
+  // the reference-default matrix-free D from the geometry factors)
+  auto is_sym = [](const CoeffHost &c) {
+    if (c.dim != 3) return true;
+    for (size_t k = 0; k + 9 <= c.mat.size(); k += 9)
+      if (c.mat[k + 1] != c.mat[k + 3] || c.mat[k + 2] != c.mat[k + 6] || c.mat[k + 5] != c.mat[k + 7]) return false;
+    return true;
+  };
+  const char *qmode = getenv("PALACE_AMD_QDATA");
+  const bool want_qd = !(qmode && std::string(qmode) == "0") && b.fe_type == PA_FE_HCURL && is_sym(so->c0) &&
+                       (so->c1.mat.empty() || is_sym(so->c1));
+  if (shared_qd) {
+    so->qd = shared_qd;
+    shared_qd->refcount++;
+  } else if (want_qd) {
+    launch_nd_hex_qdata(*so, nullptr);
+    PA_HIP(hipStreamSynchronize(nullptr));
+  }
   return so;
 }
 
@@ -281,6 +300,10 @@ static void free_sub(SubOp *so) {
   if (!so) return;
   hipFree(so->d_lidx);
   hipFree(so->d_ye), hipFree(so->d_tptr), hipFree(so->d_tent);
+  if (so->qd && --so->qd->refcount == 0) {
+    hipFree(so->qd->d);
+    delete so->qd;
+  }
   hipFree(so->d_tab);
   hipFree(so->c0.d_attr_mat), hipFree(so->c0.d_mat);
   hipFree(so->c1.d_attr_mat), hipFree(so->c1.d_mat);
@@ -412,7 +435,7 @@ int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_
         PA_REQUIRE(fs->ne == restr->num_elem, "coarsening needs one element block (same elements)");
         o->subs.push_back(make_sub(static_cast<pa_geom *>(fs->geom), *restr, *basis, fs->qf,
                                    fs->ctx_blob.data(), fs->ctx_blob.size(), fs->trial_ops,
-                                   fs->test_ops));
+                                   fs->test_ops, fs->qd));
       }
     } catch (...) {
       pa_op_destroy(o);

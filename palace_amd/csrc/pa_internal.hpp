@@ -90,8 +90,18 @@ struct CoeffHost {
   CoeffDev dev() const { return CoeffDev{d_attr_mat, d_mat, (int)attr_mat.size()}; }
 };
 
+// Packed symmetric pointwise operators (pre-assembled D): double[ne][ncomp][Q], the six upper
+// entries of  w detJ adj^T C adj  (mass part, if any) followed by the six of  w detJ Jl^T C Jl
+// (curl-curl part, if any).  Shared between an operator and its p-coarsened copies.
+struct QData {
+  double *d = nullptr;
+  int ncomp = 0;
+  int refcount = 1;
+};
+
 struct SubOp {
   Geom *geom = nullptr;
+  QData *qd = nullptr;  // nullptr: matrix-free D from the geometry data (the reference default)
   int fe_type = 0, p = 0, q1d = 0, P = 0, Q = 0, ne = 0, lsize = 0;
   int qf = 0;
   uint32_t trial_ops = 0, test_ops = 0;
@@ -113,6 +123,7 @@ void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t
 void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s);
 void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, hipStream_t s);
 void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s);
+void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 void launch_h1_hex_apply(const SubOp &so, const double *x, double *y, hipStream_t s);
 void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);
