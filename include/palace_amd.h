@@ -153,6 +153,13 @@ int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_
 int pa_op_apply_add(pa_op *op, const double *x, double *y, void *stream);
 /* Operator::Mult (operator.cpp:182-190): y = A x. */
 int pa_op_mult(pa_op *op, const double *x, double *y, void *stream);
+/* Fused form of what ParOperator::Mult does around the local apply for square operators
+ * (linalg/rap.cpp:207-220: tx = x; tx[ess] = 0; ly = A P tx): after pa_op_set_essential(list of
+ * essential L-dofs), pa_op_mult_essential computes y = A (x with the listed entries read as zero)
+ * without copying x.  The rows of y at essential dofs are NOT fixed up here (rap.cpp:223-233 does
+ * that after P^T). */
+int pa_op_set_essential(pa_op *op, const int32_t *ess_ldofs, int32_t n);
+int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream);
 /* Operator::AssembleDiagonal (operator.cpp:116-143): diag = diag(A) (zeroed first). */
 int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream);
 int pa_op_height(const pa_op *op);

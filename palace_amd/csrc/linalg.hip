@@ -80,6 +80,26 @@ __global__ void k_chebk(double sd, double sr, const double *__restrict__ di, con
                         double *__restrict__ d, long long n) {
   PA_STRIDE_LOOP(i, n) d[i] = sd * d[i] + sr * di[i] * r[i];
 }
+// one Chebyshev step around the operator apply t = A d (chebyshev.cpp:208-216 fused into one pass):
+//   y += d;  r -= t;  d = sd d + sr dinv .* r
+__global__ void k_cheb_step(double sd, double sr, const double *__restrict__ di, const double *__restrict__ t,
+                            double *__restrict__ r, double *__restrict__ d, double *__restrict__ y, long long n) {
+  PA_STRIDE_LOOP(i, n) {
+    const double dv = d[i];
+    const double rv = r[i] - t[i];
+    y[i] += dv;
+    r[i] = rv;
+    d[i] = sd * dv + sr * di[i] * rv;
+  }
+}
+// x += a p;  r -= a z   (the two AXPYs of a CG iteration, iterative.cpp:448-449)
+__global__ void k_cg_update(double a, const double *__restrict__ p, const double *__restrict__ z,
+                            double *__restrict__ x, double *__restrict__ r, long long n) {
+  PA_STRIDE_LOOP(i, n) {
+    x[i] += a * p[i];
+    r[i] -= a * z[i];
+  }
+}
 __global__ void k_random(double *x, long long n, uint64_t seed) {
   PA_STRIDE_LOOP(i, n) {
     // splitmix64 on (seed, i): counter-based, reproducible for any launch shape
@@ -206,6 +226,14 @@ void SetRandom(const Context &c, Vector &x, uint64_t seed) {
 void ChebyOrder0(const Context &c, double sr, const Vector &dinv, const Vector &r, Vector &d) {
   PA_LAUNCH(k_cheb0, d.Size(), c.stream, sr, dinv.Data(), r.Data(), d.Data(), (long long)d.Size());
 }
+void ChebyStep(const Context &c, double sd, double sr, const Vector &dinv, const Vector &t, Vector &r, Vector &d,
+               Vector &y) {
+  PA_LAUNCH(k_cheb_step, d.Size(), c.stream, sd, sr, dinv.Data(), t.Data(), r.Data(), d.Data(), y.Data(),
+            (long long)d.Size());
+}
+void CgUpdate(const Context &c, double a, const Vector &p, const Vector &z, Vector &x, Vector &r) {
+  PA_LAUNCH(k_cg_update, x.Size(), c.stream, a, p.Data(), z.Data(), x.Data(), r.Data(), (long long)x.Size());
+}
 void ChebyOrderK(const Context &c, double sd, double sr, const Vector &dinv, const Vector &r, Vector &d) {
   PA_LAUNCH(k_chebk, d.Size(), c.stream, sd, sr, dinv.Data(), r.Data(), d.Data(), (long long)d.Size());
 }
@@ -251,6 +279,10 @@ void Operator::AddMult(const Vector &x, Vector &y, double a) const {
   check(pa_op_apply_add(op_, x.Data(), y.Data(), ctx_->stream));
 }
 void Operator::AssembleDiagonal(Vector &diag) const { check(pa_op_assemble_diagonal(op_, diag.Data(), ctx_->stream)); }
+void Operator::SetEssential(const int32_t *ess_host, int n) { check(pa_op_set_essential(op_, ess_host, n)); }
+void Operator::MultEssential(const Vector &x, Vector &y) const {
+  check(pa_op_mult_essential(op_, x.Data(), y.Data(), ctx_->stream));
+}
 }  // namespace ceed
 
 // ---- ParOperator ------------------------------------------------------------------------------
@@ -265,6 +297,14 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
   if (n_ess) d_ess_ = pa::dev_upload(ess_host, (size_t)n_ess, ctx.stream);
   lx_.SetSize(n_local_);
   ly_.SetSize(n_local_);
+  // One rank (P = identity): let the element kernel read essential entries as zero and write y
+  // in place, instead of copying x and y through the L-vectors.
+  if (!halo && n_ess) {
+    if (auto *c = dynamic_cast<const ceed::Operator *>(&A)) {
+      const_cast<ceed::Operator *>(c)->SetEssential(ess_host, n_ess);
+      A_fused_ = c;
+    }
+  }
 }
 ParOperator::~ParOperator() {
   if (d_ess_) (void)hipFree(d_ess_);
@@ -273,6 +313,14 @@ ParOperator::~ParOperator() {
 void ParOperator::Mult(const Vector &x, Vector &y) const {
   // rap.cpp:195-234.  tx = x, tx[ess] = 0; lx = P tx; ly = A lx; y = P^T ly; y[ess] = x[ess] | 0
   const Context &c = *ctx_;
+  if (A_fused_ && x.Data() != y.Data()) {
+    A_fused_->MultEssential(x, y);
+    if (policy_ == DiagonalPolicy::DIAG_ONE)
+      linalg::SetSubVector(c, y, d_ess_, n_ess_, x);
+    else
+      linalg::SetSubVector(c, y, d_ess_, n_ess_, 0.0);
+    return;
+  }
   Vector tx(lx_.Data(), n_true_);
   linalg::Copy(c, x, tx);
   if (n_ess_) linalg::SetSubVector(c, tx, d_ess_, n_ess_, 0.0);
@@ -335,12 +383,10 @@ void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
     if (fourth_kind_) {  // chebyshev.cpp:204-218
       linalg::ChebyOrder0(c, 4.0 / (3.0 * lambda_max_), dinv_, r, d_);
       for (int k = 1; k < order_; k++) {
-        linalg::AXPY(c, 1.0, d_, y);
-        A_->Mult(d_, t_);
-        linalg::AXPY(c, -1.0, t_, r);
         const double sd = (2.0 * k - 1.0) / (2.0 * k + 3.0);
         const double sr = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lambda_max_);
-        linalg::ChebyOrderK(c, sd, sr, dinv_, r, d_);
+        A_->Mult(d_, t_);
+        linalg::ChebyStep(c, sd, sr, dinv_, t_, r, d_, y);  // y += d; r -= A d; d = sd d + sr D^-1 r
       }
     } else {  // chebyshev.cpp:275-291
       const double lmax = lambda_max_, lmin = sf_min_ * lmax;
@@ -348,11 +394,9 @@ void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
       linalg::ChebyOrder0(c, 1.0 / theta, dinv_, r, d_);
       double rhop = delta / theta;
       for (int k = 1; k < order_; k++) {
-        linalg::AXPY(c, 1.0, d_, y);
-        A_->Mult(d_, t_);
-        linalg::AXPY(c, -1.0, t_, r);
         const double rho = 1.0 / (2.0 * theta / delta - rhop);
-        linalg::ChebyOrderK(c, rho * rhop, 2.0 * rho / delta, dinv_, r, d_);
+        A_->Mult(d_, t_);
+        linalg::ChebyStep(c, rho * rhop, 2.0 * rho / delta, dinv_, t_, r, d_, y);
         rhop = rho;
       }
     }
@@ -403,8 +447,7 @@ void CgSolver::Mult(const Vector &b, Vector &x) const {
     denom = linalg::Dot(c, z_, p_);
     PA_REQUIRE(std::isfinite(denom), "PCG operator is not positive definite: (Ap, p) not finite");
     alpha = beta / denom;
-    linalg::AXPY(c, alpha, p_, x);
-    linalg::AXPY(c, -alpha, z_, r_);
+    linalg::CgUpdate(c, alpha, p_, z_, x, r_);  // x += alpha p; r -= alpha z
     beta_prev = beta;
     if (B_) B_->Mult(r_, z_); else linalg::Copy(c, r_, z_);
     beta = linalg::Dot(c, z_, r_);

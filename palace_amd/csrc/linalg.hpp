@@ -83,8 +83,12 @@ void SetRandom(const Context &c, Vector &x, uint64_t seed);
 // chebyshev.cpp:69-156
 void ChebyOrder0(const Context &c, double sr, const Vector &dinv, const Vector &r, Vector &d);
 void ChebyOrderK(const Context &c, double sd, double sr, const Vector &dinv, const Vector &r, Vector &d);
-// y += d, then d = sd d + sr dinv .* r is what the smoother does around an operator apply; the
-// fused form saves one pass over d:  y += d  (returned separately to keep the reference order)
+// fused forms of consecutive reference kernels (same arithmetic, one pass):
+//   ChebyStep: y += d; r -= t; d = sd d + sr dinv .* r      (chebyshev.cpp:208-216, t = A d)
+//   CgUpdate : x += a p; r -= a z                            (iterative.cpp:448-449)
+void ChebyStep(const Context &c, double sd, double sr, const Vector &dinv, const Vector &t, Vector &r, Vector &d,
+               Vector &y);
+void CgUpdate(const Context &c, double a, const Vector &p, const Vector &z, Vector &x, Vector &r);
 
 }  // namespace linalg
 
@@ -120,6 +124,9 @@ public:
   void Mult(const Vector &x, Vector &y) const override;
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
   void AssembleDiagonal(Vector &diag) const override;
+  // y = A (x with the essential entries read as zero), no copy of x (pa_op_mult_essential)
+  void SetEssential(const int32_t *ess_host, int n);
+  void MultEssential(const Vector &x, Vector &y) const;
 };
 
 }  // namespace ceed
@@ -134,6 +141,7 @@ public:
 private:
   const Context *ctx_;
   const Operator *A_;
+  const ceed::Operator *A_fused_ = nullptr;  // single rank: BC masking fused into the local apply
   const Halo *halo_;
   int n_true_, n_local_;
   int32_t *d_ess_ = nullptr;

@@ -208,6 +208,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
       lidx[(size_t)e * P + l] = neg ? -1 - off : off;
     }
   so->d_lidx = dev_upload(lidx.data(), lidx.size());
+  PA_REQUIRE(r.lsize < kEssBit, "too many local dofs for the index encoding");
   // transpose map for the gather form of E^T (counting sort by dof; element order preserved, so the
   // summation order of every dof is fixed) unless PALACE_AMD_SCATTER=atomic asks for the atomic form
   const char *mode = getenv("PALACE_AMD_SCATTER");
@@ -245,6 +246,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     so->d_tent = dev_upload(tent.data(), tent.size());
     so->d_ye = dev_alloc<double>(nnz);
   }
+  so->h_lidx = std::move(lidx);
 
   so->ctx_blob.assign((const uint8_t *)ctx, (const uint8_t *)ctx + ctx_size);
   PA_REQUIRE(ctx && ctx_size >= 24 && ctx_size % 8 == 0, "coefficient context missing or malformed");
@@ -299,6 +301,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
 static void free_sub(SubOp *so) {
   if (!so) return;
   hipFree(so->d_lidx);
+  hipFree(so->d_lidx_bc);
   hipFree(so->d_ye), hipFree(so->d_tptr), hipFree(so->d_tent);
   if (so->qd && --so->qd->refcount == 0) {
     hipFree(so->qd->d);
@@ -313,7 +316,7 @@ static void free_sub(SubOp *so) {
 
 // y (+)= A x.  overwrite: the first sub-operator writes y instead of accumulating (Mult without a
 // separate memset when E^T runs as a gather).
-static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s) {
+static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s, bool masked = false) {
   PA_REQUIRE(op && x && y, "null argument");
   PA_REQUIRE(!op->subs.empty(), "operator has no sub-operators");
   PA_REQUIRE(x != y, "in-place apply is not supported");
@@ -321,11 +324,11 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   for (const SubOp *so : op->subs) {
     if (so->fe_type == PA_FE_HCURL) {
       if (so->d_ye) {
-        launch_nd_hex_apply(*so, x, nullptr, so->d_ye, s);
+        launch_nd_hex_apply(*so, x, nullptr, so->d_ye, masked, s);
         launch_et_gather(*so, y, !(overwrite && first), s);
       } else {
         if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
-        launch_nd_hex_apply(*so, x, y, nullptr, s);
+        launch_nd_hex_apply(*so, x, y, nullptr, masked, s);
       }
     } else {
       if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
@@ -453,6 +456,35 @@ int pa_op_apply_add(pa_op *op, const double *x, double *y, void *stream) {
 int pa_op_mult(pa_op *op, const double *x, double *y, void *stream) {
   return guarded([&] {
     apply(op, x, y, true, (hipStream_t)stream);
+  });
+}
+
+int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
+  return guarded([&] {
+    PA_REQUIRE(op && (ess || n == 0), "null argument");
+    std::vector<char> flag((size_t)op->width, 0);
+    for (int i = 0; i < n; i++) {
+      PA_REQUIRE(ess[i] >= 0 && ess[i] < op->width, "essential dof out of range");
+      flag[ess[i]] = 1;
+    }
+    for (SubOp *so : op->subs) {
+      PA_REQUIRE(so->fe_type == PA_FE_HCURL, "essential-dof masking is implemented for H(curl) blocks");
+      std::vector<int32_t> bc(so->h_lidx);
+      for (auto &s : bc) {
+        const int d = s >= 0 ? s : -1 - s;
+        if (flag[d]) s = s >= 0 ? (d | kEssBit) : -1 - (d | kEssBit);
+      }
+      hipFree(so->d_lidx_bc);
+      so->d_lidx_bc = dev_upload(bc.data(), bc.size());
+    }
+    op->has_essential = true;
+  });
+}
+
+int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && op->has_essential, "pa_op_set_essential has not been called");
+    apply(op, x, y, true, (hipStream_t)stream, true);
   });
 }
 

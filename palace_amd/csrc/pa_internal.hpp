@@ -63,6 +63,7 @@ T *dev_upload(const T *host, size_t n, hipStream_t s = nullptr) {
   return p;
 }
 
+constexpr int kEssBit = 1 << 30;  // flag in the gather index: read this dof as zero
 constexpr int kMaxP1 = 6;  // closed nodes p+1 <= 7
 constexpr int kMaxQ1 = 7;
 
@@ -106,6 +107,8 @@ struct SubOp {
   int qf = 0;
   uint32_t trial_ops = 0, test_ops = 0;
   int32_t *d_lidx = nullptr;  // [ne][P] signed tensor-order index: >=0 dof, <0 => -(1+dof) flipped
+  int32_t *d_lidx_bc = nullptr;  // copy with kEssBit on essential dofs (pa_op_set_essential)
+  std::vector<int32_t> h_lidx;   // host copy (needed to build d_lidx_bc)
   // E^T as a gather (default): E-vector scratch and the CSR transpose of lidx
   double *d_ye = nullptr;      // [ne][P]
   int32_t *d_tptr = nullptr;   // [lsize + 1]
@@ -121,7 +124,7 @@ void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t
 
 // kernels (pa_geom.hip, pa_nd_hex.hip, pa_h1_hex.hip)
 void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s);
-void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, hipStream_t s);
+void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s);
 void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s);
 void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
@@ -135,5 +138,6 @@ struct pa_geom : pa::Geom {};
 struct pa_op {
   int height = 0, width = 0;
   bool finalized = false;
+  bool has_essential = false;
   std::vector<pa::SubOp *> subs;
 };

@@ -52,7 +52,8 @@ __device__ __forceinline__ double tab_odd(const double *H, const int q, const in
 template <int P1, int Q1>
 struct NDArgs {
   int ne;
-  const int32_t *lidx;
+  const int32_t *lidx;     // signed tensor-order index (scatter side)
+  const int32_t *lidx_in;  // the same with kEssBit set on dofs to be read as zero (gather side)
   const double *geom;
   const double *qdata;  // packed symmetric D, [ne][NG][Q] (QD == true)
   const double *x;
@@ -174,8 +175,10 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
     for (int i = 0; i < ni; i++) {
       double val = 0.0;
       if (active && act) {
-        const int s = a.lidx[(size_t)e * P + off + i + ni * (ta + nj * tb)];
-        const double xv = a.x[s >= 0 ? s : -1 - s];
+        // essential dofs are flagged in the gather index: read as zero (ParOperator's tx[ess] = 0)
+        const int s = a.lidx_in[(size_t)e * P + off + i + ni * (ta + nj * tb)];
+        const int d = s >= 0 ? s : -1 - s;
+        const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
         val = s >= 0 ? xv : -xv;
       }
       u[i] = val;
@@ -475,11 +478,12 @@ static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block,
 }
 
 template <int P1, int Q1>
-static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, hipStream_t s) {
+static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s) {
   using L = NDLayout<P1, Q1>;
   NDArgs<P1, Q1> a;
   a.ne = so.ne;
   a.lidx = so.d_lidx;
+  a.lidx_in = (masked && so.d_lidx_bc) ? so.d_lidx_bc : so.d_lidx;
   a.geom = so.geom->d_geom;
   a.qdata = so.qd ? so.qd->d : nullptr;
   a.x = x;
@@ -527,8 +531,9 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, h
   }
 
 // ye != nullptr: write the element-local results (E-vector) instead of scattering atomically into y
-void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, hipStream_t s) {
-  PA_ND_DISPATCH(launch_pq, so, x, y, ye, s)
+// masked: gather through the essential-dof-flagged index array (pa_op_set_essential)
+void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s) {
+  PA_ND_DISPATCH(launch_pq, so, x, y, ye, masked, s)
 }
 
 // ---- E^T as a gather: y_d (+)= sum over the element-local copies of dof d -----------------------
