@@ -244,29 +244,32 @@ def build_geom_factor_33(attr, qw, J):
 
 class CoeffCtx:
     """CeedIntScalar context (coeff_qf.h:7-45; packing coefficient.cpp:51-118):
-    [nattr][attr->mat (nattr)][nmat][nmat*9 doubles col-major]; 8-byte slots."""
+    [nattr][attr->mat (nattr)][nmat][nmat*dim*dim doubles col-major]; 8-byte slots.
+    dim = 3 for matrix coefficients, 1 for the scalar ones of the H1 mass QFunctions."""
 
-    def __init__(self, attr_mat=None, mat_coeff=None, a=1.0):
+    def __init__(self, attr_mat=None, mat_coeff=None, a=1.0, dim=3):
+        self.dim = dim
+        d2 = dim * dim
         if attr_mat is None:  # no coefficient: identity scaled by a (coefficient.cpp:55-64)
             self.attr_mat = np.zeros(0, dtype=np.int32)
-            self.mat = (a * np.eye(3)).reshape(1, 9)
+            self.mat = (a * np.eye(dim)).reshape(1, d2)
         else:
             attr_mat = np.asarray(attr_mat, dtype=np.int32)
             mats = [np.asarray(m, dtype=np.float64) for m in mat_coeff]
             nmat = len(mats)
-            full = np.zeros((nmat + 1, 9))
+            full = np.zeros((nmat + 1, d2))
             for k, mk in enumerate(mats):
                 if mk.size == 1:
-                    full[k] = (a * float(mk.reshape(-1)[0]) * np.eye(3)).reshape(-1)
+                    full[k] = (a * float(mk.reshape(-1)[0]) * np.eye(dim)).reshape(-1)
                 else:
-                    full[k] = (a * mk).reshape(3, 3).T.reshape(-1)  # column-major
+                    full[k] = (a * mk).reshape(dim, dim).T.reshape(-1)  # column-major
             self.attr_mat = np.where(attr_mat < 0, nmat, attr_mat).astype(np.int32)
             self.mat = full
 
     def pack(self) -> np.ndarray:
         """The raw blob as 8-byte slots (ints in the low 4 bytes), returned as float64 view."""
         nattr, nmat = self.attr_mat.size, self.mat.shape[0]
-        raw = np.zeros(2 + nattr + 9 * nmat, dtype=np.float64)
+        raw = np.zeros(2 + nattr + self.mat.size, dtype=np.float64)
         iv = raw.view(np.int32).reshape(-1, 2)
         iv[0, 0] = nattr
         iv[1 : 1 + nattr, 0] = self.attr_mat
@@ -275,7 +278,7 @@ class CoeffCtx:
         return raw
 
     def unpack3(self, attr):
-        """CoeffUnpack3 (coeff_3_qf.h:9-24): attr (1-based ints) -> [..., 9]."""
+        """CoeffUnpack3 / CoeffUnpack1 (coeff_3_qf.h:9-24, coeff_1_qf.h): attr (1-based) -> [..., dim*dim]."""
         if self.attr_mat.size > 0:
             k = self.attr_mat[attr - 1]
         else:

@@ -211,3 +211,21 @@ def curlcurlmass_operator(geom, nd: NDHexSpace, ctx_mass, ctx_curl, dense=None):
     ctx = np.concatenate([ctx_mass, ctx_curl])
     return Operator(nd.ndofs, nd.ndofs).add_integrator(
         geom, nd, QF_HDIVMASS_33, ctx, EVAL_CURL | EVAL_INTERP, dense).finalize()
+
+
+def diffusion_operator(geom, h1: H1HexSpace, ctx_diff, dense=None):
+    """DiffusionIntegrator (fem/integ/diffusion.cpp): f_apply_hcurl_33 on grad u, Grad/Grad."""
+    return Operator(h1.ndofs, h1.ndofs).add_integrator(geom, h1, QF_HCURL_33, ctx_diff, EVAL_GRAD, dense).finalize()
+
+
+def h1mass_operator(geom, h1: H1HexSpace, ctx_mass1, dense=None):
+    """MassIntegrator (fem/integ/mass.cpp): f_apply_h1_1, Interp/Interp, scalar (dim-1) context."""
+    return Operator(h1.ndofs, h1.ndofs).add_integrator(geom, h1, QF_H1_1, ctx_mass1, EVAL_INTERP, dense).finalize()
+
+
+def diffusionmass_operator(geom, h1: H1HexSpace, ctx_mass1, ctx_diff, dense=None):
+    """DiffusionMassIntegrator (fem/integ/diffusionmass.cpp): f_apply_hcurlmass_33, mass context (dim 1)
+    first, then the diffusion one (dim 3)."""
+    ctx = np.concatenate([ctx_mass1, ctx_diff])
+    return Operator(h1.ndofs, h1.ndofs).add_integrator(
+        geom, h1, QF_HCURLMASS_33, ctx, EVAL_GRAD | EVAL_INTERP, dense).finalize()

@@ -212,7 +212,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
   // transpose map for the gather form of E^T (counting sort by dof; element order preserved, so the
   // summation order of every dof is fixed) unless PALACE_AMD_SCATTER=atomic asks for the atomic form
   const char *mode = getenv("PALACE_AMD_SCATTER");
-  if (!(mode && std::string(mode) == "atomic")) {
+  if (!(mode && std::string(mode) == "atomic") || b.fe_type == PA_FE_H1) {
     const size_t nnz = lidx.size();
     std::vector<int32_t> tptr((size_t)r.lsize + 1, 0), tent(nnz);
     for (size_t k = 0; k < nnz; k++) {
@@ -234,7 +234,10 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
               epos[C * p * ncl * ncl + i + ni * (j + nj * k)] = C * p * ncl * ncl + i * (nj * nk) + j + nj * k;
       }
     } else {
-      for (int l = 0; l < P; l++) epos[l] = l;
+      const int ncl = b.order + 1;
+      for (int k = 0; k < ncl; k++)
+        for (int j = 0; j < ncl; j++)
+          for (int i = 0; i < ncl; i++) epos[i + ncl * (j + ncl * k)] = i * (ncl * ncl) + j + ncl * k;
     }
     for (size_t k = 0; k < nnz; k++) {
       const int32_t s = lidx[k];
@@ -286,13 +289,16 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     return true;
   };
   const char *qmode = getenv("PALACE_AMD_QDATA");
-  const bool want_qd = !(qmode && std::string(qmode) == "0") && b.fe_type == PA_FE_HCURL && is_sym(so->c0) &&
+  const bool want_qd = !(qmode && std::string(qmode) == "0") && is_sym(so->c0) &&
                        (so->c1.mat.empty() || is_sym(so->c1));
   if (shared_qd) {
     so->qd = shared_qd;
     shared_qd->refcount++;
   } else if (want_qd) {
-    launch_nd_hex_qdata(*so, nullptr);
+    if (b.fe_type == PA_FE_HCURL)
+      launch_nd_hex_qdata(*so, nullptr);
+    else
+      launch_h1_hex_qdata(*so, nullptr);
     PA_HIP(hipStreamSynchronize(nullptr));
   }
   return so;
@@ -331,8 +337,8 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
         launch_nd_hex_apply(*so, x, y, nullptr, masked, s);
       }
     } else {
-      if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
-      launch_h1_hex_apply(*so, x, y, s);
+      launch_h1_hex_apply(*so, x, masked, s);
+      launch_et_gather(*so, y, !(overwrite && first), s);
     }
     first = false;
   }
@@ -468,7 +474,6 @@ int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
       flag[ess[i]] = 1;
     }
     for (SubOp *so : op->subs) {
-      PA_REQUIRE(so->fe_type == PA_FE_HCURL, "essential-dof masking is implemented for H(curl) blocks");
       std::vector<int32_t> bc(so->h_lidx);
       for (auto &s : bc) {
         const int d = s >= 0 ? s : -1 - s;

@@ -128,7 +128,8 @@ void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye
 void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s);
 void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
-void launch_h1_hex_apply(const SubOp &so, const double *x, double *y, hipStream_t s);
+void launch_h1_hex_apply(const SubOp &so, const double *x, bool masked, hipStream_t s);
+void launch_h1_hex_qdata(SubOp &so, hipStream_t s);
 void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 
 }  // namespace pa

@@ -154,7 +154,7 @@ class SlabProblem:
         return linalg.ParOperator(self.ctx, self.local_curlcurl, self.ess[-1], linalg.DIAG_ONE,
                                   n_true=self.n_true[-1], halo=self.halos[-1])
 
-    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=50):
+    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8):
         """PCG on (K + M) with the p-multigrid preconditioner configured as the reference does for
         p = 3 (iodata.cpp:533-564: 4th-kind Chebyshev of order max(2p, 4), 1 smoothing step, 1 V-cycle);
         level 0 is solved by Jacobi-PCG (the reference uses AMS from HYPRE there, linalg/ams.cpp)."""
