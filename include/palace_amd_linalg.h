@@ -80,6 +80,13 @@ int pa_gmres_create(pa_context *ctx, pa_par_op *A, pa_solver *precond, double re
 int pa_gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *const *P,
                   pa_solver *coarse, int cycle_it, int smooth_it, int cheby_order, double cheby_sf_max,
                   double cheby_sf_min, int cheby_4th_kind, pa_solver **S);
+/* The same with the Hiptmair (distributive relaxation) smoother on levels >= 1 (linalg/gmg.cpp:41-60,
+ * linalg/distrelaxation.cpp): A_aux[l] = auxiliary H1 operator of level l, G[l] = discrete gradient of
+ * level l (entries for level 0 may be NULL). */
+int pa_gmg_create_aux(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *const *P,
+                      pa_par_op *const *A_aux, pa_interp *const *G, pa_solver *coarse, int cycle_it,
+                      int smooth_it, int cheby_order, double cheby_sf_max, double cheby_sf_min,
+                      int cheby_4th_kind, pa_solver **S);
 /* x = S(b) on T-vectors; initial_guess != 0 uses x as the starting iterate (Krylov solvers) */
 int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess);
 int pa_solver_stats(const pa_solver *S, int *iterations, double *initial_res, double *final_res,
@@ -100,6 +107,13 @@ int pa_interp_create(pa_context *ctx, const pa_restriction_desc *coarse_restr,
                      const pa_basis_desc *coarse_basis, const pa_restriction_desc *fine_restr,
                      const pa_basis_desc *fine_basis, const double *Ic, const double *Io,
                      pa_halo *coarse_halo, int n_true_coarse, int n_true_fine, pa_interp **P);
+/* Discrete gradient G : H1(p) -> ND(p) on the same mesh (the auxiliary-space transfer of the Hiptmair
+ * smoother; fem/bilinearform.cpp:203-282 with the gradient interpolator, basis.cpp:139-143).
+ *   Dg [p][p+1]  derivative of the closed (Gauss-Lobatto) basis at the open (Gauss-Legendre) nodes
+ * Mult = G, MultTranspose = G^T through pa_interp_mult / pa_interp_mult_transpose. */
+int pa_gradient_create(pa_context *ctx, const pa_restriction_desc *h1_restr, const pa_basis_desc *h1_basis,
+                       const pa_restriction_desc *nd_restr, const pa_basis_desc *nd_basis, const double *Dg,
+                       pa_halo *h1_halo, int n_true_h1, int n_true_nd, pa_interp **G);
 int pa_interp_mult(pa_interp *P, const double *x_coarse, double *y_fine);
 int pa_interp_mult_transpose(pa_interp *P, const double *x_fine, double *y_coarse);
 void pa_interp_destroy(pa_interp *P);

@@ -632,3 +632,26 @@ class InterpOracle:
         y = np.zeros(self.nc)
         np.add.at(y, self.dc.ravel(), ve.ravel())
         return y
+
+
+def nd_hex_gradient_lex(p):
+    """Dense [P_ND, P_H1] discrete gradient of the order-p hex pair in tensor dof order: the ND dof
+    (C; i, j, k) of grad(phi) is d/dx_C of the H1 interpolant at the ND node (nodal interpolation of
+    the gradient, what mfem::GradientInterpolator / ProjectGrad builds; basis.cpp:139-143)."""
+    cp, op = gll_points(p + 1), gl_points(p)[0]
+    n1 = p + 1
+    M = np.zeros((3 * p * n1 * n1, n1**3))
+    for comp in range(3):
+        nd = [n1] * 3
+        nd[comp] = p
+        for k in range(nd[2]):
+            for j in range(nd[1]):
+                for i in range(nd[0]):
+                    row = comp * p * n1 * n1 + i + nd[0] * (j + nd[1] * k)
+                    idx = [i, j, k]
+                    for a in range(n1):
+                        col_idx = list(idx)
+                        col_idx[comp] = a
+                        col = col_idx[0] + n1 * (col_idx[1] + n1 * col_idx[2])
+                        M[row, col] = lagrange(cp, op[idx[comp]], a)[1]
+    return M

@@ -404,6 +404,66 @@ void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
   }
 }
 
+// ---- Hiptmair smoother (distrelaxation.cpp) -----------------------------------------------------------
+DistRelaxationSmoother::DistRelaxationSmoother(const Context &ctx, const Operator &G, int smooth_it, int cheby_smooth_it,
+                                               int cheby_order, double sf_max, double sf_min, bool fourth)
+    : ctx_(&ctx), pc_it_(smooth_it), G_(&G) {
+  B_ = std::make_unique<ChebyshevSmoother>(ctx, cheby_smooth_it, cheby_order, sf_max, fourth, sf_min);
+  B_G_ = std::make_unique<ChebyshevSmoother>(ctx, cheby_smooth_it, cheby_order, sf_max, fourth, sf_min);
+  B_G_->SetInitialGuess(false);
+}
+void DistRelaxationSmoother::SetOperators(const Operator &op, const ParOperator &op_G) {
+  PA_REQUIRE(op.Height() == G_->Height() && op.Width() == G_->Height() && op_G.Height() == G_->Width() &&
+                 op_G.Width() == G_->Width(),
+             "Invalid operator sizes for DistRelaxationSmoother!");
+  A_ = &op, A_G_ = &op_G;
+  x_G_.SetSize(op_G.Height()), y_G_.SetSize(op_G.Height()), r_G_.SetSize(op_G.Height());
+  t_.SetSize(op.Height());
+  B_->SetOperator(op);
+  B_G_->SetOperator(op_G);
+  height = op.Height(), width = op.Width();
+}
+void DistRelaxationSmoother::Mult(const Vector &x, Vector &y) const { Mult2(x, y, t_); }
+void DistRelaxationSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
+  const Context &c = *ctx_;
+  for (int it = 0; it < pc_it_; it++) {
+    // y = y + B (x - A y)
+    B_->SetInitialGuess(initial_guess || it > 0);
+    B_->Mult2(x, y, r);
+    // y = y + G B_G G^T (x - A y)
+    A_->Mult(y, r);
+    linalg::AXPBY(c, 1.0, x, -1.0, r);
+    G_->MultTranspose(r, x_G_);
+    if (A_G_->NumEssentialTrueDofs())
+      linalg::SetSubVector(c, x_G_, A_G_->GetEssentialTrueDofs(), A_G_->NumEssentialTrueDofs(), 0.0);
+    B_G_->Mult2(x_G_, y_G_, r_G_);
+    G_->Mult(y_G_, r);  // RealAddMult(G, y_G, y)
+    linalg::AXPY(c, 1.0, r, y);
+  }
+}
+void DistRelaxationSmoother::MultTranspose2(const Vector &x, Vector &y, Vector &r) const {
+  const Context &c = *ctx_;
+  B_->SetInitialGuess(true);
+  for (int it = 0; it < pc_it_; it++) {
+    // y = y + G B_G^T G^T (x - A y)
+    if (initial_guess || it > 0) {
+      A_->Mult(y, r);
+      linalg::AXPBY(c, 1.0, x, -1.0, r);
+      G_->MultTranspose(r, x_G_);
+    } else {
+      linalg::Fill(c, y, 0.0);
+      G_->MultTranspose(x, x_G_);
+    }
+    if (A_G_->NumEssentialTrueDofs())
+      linalg::SetSubVector(c, x_G_, A_G_->GetEssentialTrueDofs(), A_G_->NumEssentialTrueDofs(), 0.0);
+    B_G_->MultTranspose2(x_G_, y_G_, r_G_);
+    G_->Mult(y_G_, r);
+    linalg::AXPY(c, 1.0, r, y);
+    // y = y + B^T (x - A y)
+    B_->MultTranspose2(x, y, r);
+  }
+}
+
 // ---- PCG (iterative.cpp:360-486) ----------------------------------------------------------------
 void CgSolver::Mult(const Vector &b, Vector &x) const {
   const Context &c = *ctx_;
@@ -584,22 +644,37 @@ void GmresSolver::Mult(const Vector &b, Vector &x) const {
 GeometricMultigridSolver::GeometricMultigridSolver(const Context &ctx, std::unique_ptr<Solver> &&coarse_solver,
                                                    const std::vector<const Operator *> &P, int cycle_it, int smooth_it,
                                                    int cheby_order, double cheby_sf_max, double cheby_sf_min,
-                                                   bool cheby_4th_kind)
+                                                   bool cheby_4th_kind, const std::vector<const Operator *> *G)
     : ctx_(&ctx), pc_it_(cycle_it), P_(P), A_(P.size() + 1), B_(P.size() + 1), X_(P.size() + 1), Y_(P.size() + 1),
       R_(P.size() + 1) {
+  PA_REQUIRE(!G || G->size() == B_.size(),
+             "Invalid input for distributive relaxation smoother auxiliary space transfer operators!");
   B_[0] = std::move(coarse_solver);
-  for (size_t l = 1; l < B_.size(); l++)
-    B_[l] = std::make_unique<ChebyshevSmoother>(ctx, smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind, cheby_sf_min);
+  for (size_t l = 1; l < B_.size(); l++) {
+    if (G)  // gmg.cpp:41-47: cheby_smooth_it = 1 inside the distributive relaxation
+      B_[l] = std::make_unique<DistRelaxationSmoother>(ctx, *(*G)[l], smooth_it, 1, cheby_order, cheby_sf_max,
+                                                       cheby_sf_min, cheby_4th_kind);
+    else
+      B_[l] = std::make_unique<ChebyshevSmoother>(ctx, smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind,
+                                                  cheby_sf_min);
+  }
 }
 
-void GeometricMultigridSolver::SetOperators(const std::vector<const ParOperator *> &ops) {
+void GeometricMultigridSolver::SetOperators(const std::vector<const ParOperator *> &ops,
+                                            const std::vector<const ParOperator *> *aux_ops) {
   PA_REQUIRE(ops.size() == A_.size(), "Invalid number of levels for operators in multigrid solver setup!");
   for (size_t l = 0; l < ops.size(); l++) {
     A_[l] = ops[l];
     PA_REQUIRE(A_[l]->Width() == A_[l]->Height(), "Invalid operator sizes for GeometricMultigridSolver!");
     if (l + 1 < ops.size()) PA_REQUIRE(A_[l]->Height() == P_[l]->Width(), "Prolongation / operator size mismatch");
     if (l > 0) PA_REQUIRE(A_[l]->Height() == P_[l - 1]->Height(), "Prolongation / operator size mismatch");
-    B_[l]->SetOperator(*A_[l]);
+    if (auto *dist = dynamic_cast<DistRelaxationSmoother *>(B_[l].get())) {
+      PA_REQUIRE(aux_ops && aux_ops->size() == ops.size(),
+                 "Distributive relaxation smoother relies on both primary space and auxiliary space operators!");
+      dist->SetOperators(*A_[l], *(*aux_ops)[l]);
+    } else {
+      B_[l]->SetOperator(*A_[l]);
+    }
     X_[l].SetSize(A_[l]->Height()), Y_[l].SetSize(A_[l]->Height()), R_[l].SetSize(A_[l]->Height());
   }
   height = width = ops.back()->Height();

@@ -210,6 +210,27 @@ public:
   void Mult2(const Vector &x, Vector &y, Vector &r) const override;
 };
 
+// Hiptmair distributive relaxation (distrelaxation.cpp:14-151): Chebyshev on the Nedelec operator,
+// then Chebyshev on the auxiliary H1 operator through the discrete gradient G.
+class DistRelaxationSmoother : public Solver {
+  const Context *ctx_;
+  int pc_it_;
+  const Operator *G_;
+  const Operator *A_ = nullptr;
+  const ParOperator *A_G_ = nullptr;
+  std::unique_ptr<ChebyshevSmoother> B_, B_G_;
+  mutable Vector x_G_, y_G_, r_G_, t_;
+
+public:
+  DistRelaxationSmoother(const Context &ctx, const Operator &G, int smooth_it, int cheby_smooth_it, int cheby_order,
+                         double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true);
+  void SetOperator(const Operator &) override { throw pa::Error("use SetOperators(op, op_G)"); }
+  void SetOperators(const Operator &op, const ParOperator &op_G);
+  void Mult(const Vector &x, Vector &y) const override;
+  void Mult2(const Vector &x, Vector &y, Vector &r) const override;
+  void MultTranspose2(const Vector &x, Vector &y, Vector &r) const override;
+};
+
 // Iterative solver base (iterative.hpp:25-115)
 class IterativeSolver : public Solver {
 protected:
@@ -267,11 +288,15 @@ class GeometricMultigridSolver : public Solver {
   void VCycle(int l, bool initial_guess) const;
 
 public:
+  // G (optional): discrete gradients per level => DistRelaxationSmoother on levels >= 1 (gmg.cpp:41-60)
   GeometricMultigridSolver(const Context &ctx, std::unique_ptr<Solver> &&coarse_solver,
                            const std::vector<const Operator *> &P, int cycle_it, int smooth_it, int cheby_order,
-                           double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true);
-  // Operators for every level (the reference passes a MultigridOperator, gmg.cpp:69-123)
-  void SetOperators(const std::vector<const ParOperator *> &ops);
+                           double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true,
+                           const std::vector<const Operator *> *G = nullptr);
+  // Operators for every level (the reference passes a MultigridOperator, gmg.cpp:69-123); aux_ops are
+  // the auxiliary-space (H1) operators required when G was given
+  void SetOperators(const std::vector<const ParOperator *> &ops,
+                    const std::vector<const ParOperator *> *aux_ops = nullptr);
   void SetOperator(const Operator &) override { throw pa::Error("use SetOperators for multigrid"); }
   void Mult(const Vector &x, Vector &y) const override;
   const Solver &Smoother(int l) const { return *B_[l]; }

@@ -18,6 +18,7 @@ namespace {
 constexpr int kMaxN = 6;  // closed nodes per direction
 
 struct InterpArgs {
+  int kind;  // 0: p-prolongation within one element family; 1: discrete gradient H1(p) -> ND(p)
   int ne, fe_type, pc, pf;
   const int32_t *lidx_c, *lidx_f;
   const double *Ic, *Io;      // device: [(pf+1)*(pc+1)], [pf*pc]
@@ -155,7 +156,17 @@ __global__ __launch_bounds__(256) void interp_kernel(const InterpArgs a) {
   const bool active = lane_ok && e < a.ne;
   double *sm = smem + (size_t)(wave * EPW + (lane_ok ? sub : 0)) * (2 * n1 * n1 * n1);
   const int pc = a.pc, pf = a.pf, ncc = pc + 1, nfc = pf + 1;
-  if (a.fe_type == PA_FE_HCURL) {
+  if (a.kind == 1) {
+    // discrete gradient (fem/bilinearform.cpp:203-282 with mfem::GradientInterpolator /
+    // ProjectGrad, basis.cpp:139-143): ND dof (C; i,j,k) = d/dx_C of the H1 interpolant at the ND
+    // node, i.e. the 1-D matrix Io = l_a'(open point i) along C and the identity (Ic) elsewhere
+    const int Pc = nfc * nfc * nfc, Pf = 3 * pf * nfc * nfc;
+    for (int C = 0; C < 3; C++) {
+      const int nf0 = C == 0 ? pf : nfc, nf1 = C == 1 ? pf : nfc, nf2 = C == 2 ? pf : nfc;
+      interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, 0, C * pf * nfc * nfc, Pc, Pf, nfc, nfc, nfc, nf0,
+                              nf1, nf2, C == 0 ? a.Io : a.Ic, C == 1 ? a.Io : a.Ic, C == 2 ? a.Io : a.Ic);
+    }
+  } else if (a.fe_type == PA_FE_HCURL) {
     const int Pc = 3 * pc * ncc * ncc, Pf = 3 * pf * nfc * nfc;
     for (int C = 0; C < 3; C++) {
       const int nc0 = C == 0 ? pc : ncc, nc1 = C == 1 ? pc : ncc, nc2 = C == 2 ? pc : ncc;
@@ -201,6 +212,7 @@ std::vector<int32_t> signed_lex_index(const pa_restriction_desc &r, const pa_bas
 class InterpOperator : public Operator {
   const Context *ctx_;
   const Halo *halo_c_;
+  int kind_ = 0;
   int fe_type_, pc_, pf_, ne_, nl_c_, nl_f_, nt_c_, nt_f_;
   int32_t *d_lidx_c_ = nullptr, *d_lidx_f_ = nullptr;
   double *d_Ic_ = nullptr, *d_Io_ = nullptr, *d_inv_mult_ = nullptr;
@@ -208,7 +220,7 @@ class InterpOperator : public Operator {
 
   template <bool TR>
   void launch(const double *x, double *y) const {
-    InterpArgs a{ne_, fe_type_, pc_, pf_, d_lidx_c_, d_lidx_f_, d_Ic_, d_Io_, d_inv_mult_, x, y};
+    InterpArgs a{kind_, ne_, fe_type_, pc_, pf_, d_lidx_c_, d_lidx_f_, d_Ic_, d_Io_, d_inv_mult_, x, y};
     const int n1 = pf_ + 1, epw = 64 / (n1 * n1), epb = 4 * epw;
     const size_t lds = sizeof(double) * (size_t)epb * 2 * n1 * n1 * n1;
     hipLaunchKernelGGL((interp_kernel<TR>), dim3((ne_ + epb - 1) / epb), dim3(256), lds, ctx_->stream, a);
@@ -218,23 +230,28 @@ class InterpOperator : public Operator {
 public:
   InterpOperator(const Context &ctx, const pa_restriction_desc &rc, const pa_basis_desc &bc,
                  const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic, const double *Io,
-                 const Halo *halo_c, int nt_c, int nt_f)
-      : Operator(nt_f, nt_c), ctx_(&ctx), halo_c_(halo_c), fe_type_(bc.fe_type), pc_(bc.order), pf_(bf.order),
-        ne_(rc.num_elem), nl_c_(rc.lsize), nl_f_(rf.lsize), nt_c_(nt_c), nt_f_(nt_f) {
-    PA_REQUIRE(bc.fe_type == bf.fe_type, "prolongation needs the same element family on both levels");
+                 const Halo *halo_c, int nt_c, int nt_f, int kind)
+      : Operator(nt_f, nt_c), ctx_(&ctx), halo_c_(halo_c), kind_(kind), fe_type_(bc.fe_type), pc_(bc.order),
+        pf_(bf.order), ne_(rc.num_elem), nl_c_(rc.lsize), nl_f_(rf.lsize), nt_c_(nt_c), nt_f_(nt_f) {
+    if (kind == 1) {
+      PA_REQUIRE(bc.fe_type == PA_FE_H1 && bf.fe_type == PA_FE_HCURL && bc.order == bf.order,
+                 "discrete gradient maps H1(p) to ND(p)");
+    } else {
+      PA_REQUIRE(bc.fe_type == bf.fe_type, "prolongation needs the same element family on both levels");
+    }
     PA_REQUIRE(rc.num_elem == rf.num_elem, "prolongation needs the same mesh on both levels");
     PA_REQUIRE(pf_ + 1 <= kMaxN && pc_ <= pf_, "unsupported orders for prolongation");
-    PA_REQUIRE(Ic && (fe_type_ == PA_FE_H1 || Io), "1-D interpolation matrices missing");
+    PA_REQUIRE(Ic && (kind == 0 && fe_type_ == PA_FE_H1 ? true : Io != nullptr), "1-D interpolation matrices missing");
     PA_REQUIRE(nt_c <= nl_c_ && nt_f <= nl_f_, "true dof counts exceed local sizes");
     PA_REQUIRE(halo_c || nt_c == nl_c_, "ghost dofs on the coarse level need a halo plan");
-    const int Pc = fe_type_ == PA_FE_HCURL ? 3 * pc_ * (pc_ + 1) * (pc_ + 1) : (pc_ + 1) * (pc_ + 1) * (pc_ + 1);
-    const int Pf = fe_type_ == PA_FE_HCURL ? 3 * pf_ * (pf_ + 1) * (pf_ + 1) : (pf_ + 1) * (pf_ + 1) * (pf_ + 1);
+    const int Pc = bc.fe_type == PA_FE_HCURL ? 3 * pc_ * (pc_ + 1) * (pc_ + 1) : (pc_ + 1) * (pc_ + 1) * (pc_ + 1);
+    const int Pf = bf.fe_type == PA_FE_HCURL ? 3 * pf_ * (pf_ + 1) * (pf_ + 1) : (pf_ + 1) * (pf_ + 1) * (pf_ + 1);
     PA_REQUIRE(rc.elem_size == Pc && rf.elem_size == Pf, "restriction sizes do not match the bases");
     auto lc = signed_lex_index(rc, bc, Pc), lf = signed_lex_index(rf, bf, Pf);
     d_lidx_c_ = pa::dev_upload(lc.data(), lc.size(), ctx.stream);
     d_lidx_f_ = pa::dev_upload(lf.data(), lf.size(), ctx.stream);
     d_Ic_ = pa::dev_upload(Ic, (size_t)(pf_ + 1) * (pc_ + 1), ctx.stream);
-    if (Io) d_Io_ = pa::dev_upload(Io, (size_t)pf_ * pc_, ctx.stream);
+    if (Io) d_Io_ = pa::dev_upload(Io, kind == 1 ? (size_t)pf_ * (pf_ + 1) : (size_t)pf_ * pc_, ctx.stream);
     // local dof multiplicity of the fine restriction (CeedElemRestrictionGetMultiplicity,
     // bilinearform.cpp:256-279)
     d_inv_mult_ = pa::dev_alloc<double>((size_t)nl_f_);
@@ -279,8 +296,8 @@ public:
 
 Operator *make_interp_operator(const Context &ctx, const pa_restriction_desc &rc, const pa_basis_desc &bc,
                                const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic,
-                               const double *Io, const Halo *halo_c, int nt_c, int nt_f) {
-  return new InterpOperator(ctx, rc, bc, rf, bf, Ic, Io, halo_c, nt_c, nt_f);
+                               const double *Io, const Halo *halo_c, int nt_c, int nt_f, int kind) {
+  return new InterpOperator(ctx, rc, bc, rf, bf, Ic, Io, halo_c, nt_c, nt_f, kind);
 }
 
 }  // namespace palace

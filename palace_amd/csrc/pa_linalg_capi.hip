@@ -10,7 +10,7 @@ using namespace palace;
 namespace palace {
 Operator *make_interp_operator(const Context &ctx, const pa_restriction_desc &rc, const pa_basis_desc &bc,
                                const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic,
-                               const double *Io, const Halo *halo_c, int nt_c, int nt_f);
+                               const double *Io, const Halo *halo_c, int nt_c, int nt_f, int kind);
 }
 
 struct pa_context {
@@ -196,15 +196,37 @@ int pa_gmres_create(pa_context *ctx, pa_par_op *A, pa_solver *pc, double rel, do
     *S = s;
   });
 }
+static void gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *const *P, pa_par_op *const *A_aux,
+                       pa_interp *const *G, pa_solver *coarse, int cycle_it, int smooth_it, int cheby_order,
+                       double sf_max, double sf_min, int fourth, pa_solver **S);
+
 int pa_gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *const *P, pa_solver *coarse,
                   int cycle_it, int smooth_it, int cheby_order, double sf_max, double sf_min, int fourth,
                   pa_solver **S) {
   return guarded([&] {
+    gmg_create(ctx, nlevels, A, P, nullptr, nullptr, coarse, cycle_it, smooth_it, cheby_order, sf_max, sf_min, fourth, S);
+  });
+}
+int pa_gmg_create_aux(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *const *P, pa_par_op *const *A_aux,
+                      pa_interp *const *G, pa_solver *coarse, int cycle_it, int smooth_it, int cheby_order,
+                      double sf_max, double sf_min, int fourth, pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(A_aux && G, "auxiliary operators and discrete gradients are required");
+    gmg_create(ctx, nlevels, A, P, A_aux, G, coarse, cycle_it, smooth_it, cheby_order, sf_max, sf_min, fourth, S);
+  });
+}
+
+static void gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *const *P, pa_par_op *const *A_aux,
+                       pa_interp *const *G, pa_solver *coarse, int cycle_it, int smooth_it, int cheby_order,
+                       double sf_max, double sf_min, int fourth, pa_solver **S) {
+  {
     PA_REQUIRE(nlevels >= 1 && A && coarse, "Empty finite element space hierarchy during multigrid solver setup!");
-    std::vector<const Operator *> Pv;
-    std::vector<const ParOperator *> Av;
+    std::vector<const Operator *> Pv, Gv;
+    std::vector<const ParOperator *> Av, Xv;
     for (int l = 0; l + 1 < nlevels; l++) Pv.push_back(P[l]->op.get());
     for (int l = 0; l < nlevels; l++) Av.push_back(A[l]->op.get());
+    if (G)
+      for (int l = 0; l < nlevels; l++) Gv.push_back(G[l] ? G[l]->op.get() : nullptr), Xv.push_back(A_aux[l] ? A_aux[l]->op.get() : nullptr);
     auto *s = new pa_solver;
     s->ctx = ctx;
     // the coarse solver object is kept alive by the multigrid solver; its Solver is borrowed
@@ -220,11 +242,11 @@ int pa_gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_interp *
     s->owned.push_back(coarse);
     auto g = std::make_unique<GeometricMultigridSolver>(ctx->ctx, std::make_unique<Borrowed>(coarse->solver.get()),
                                                         Pv, cycle_it, smooth_it, cheby_order, sf_max, sf_min,
-                                                        fourth != 0);
-    g->SetOperators(Av);
+                                                        fourth != 0, G ? &Gv : nullptr);
+    g->SetOperators(Av, G ? &Xv : nullptr);
     s->solver = std::move(g);
     *S = s;
-  });
+  }
 }
 int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess) {
   return guarded([&] {
@@ -254,8 +276,23 @@ int pa_interp_create(pa_context *ctx, const pa_restriction_desc *rc, const pa_ba
     auto *p = new pa_interp;
     p->ctx = ctx;
     p->op.reset(make_interp_operator(ctx->ctx, *rc, *bc, *rf, *bf, Ic, Io,
-                                     coarse_halo ? coarse_halo->halo.get() : nullptr, nt_c, nt_f));
+                                     coarse_halo ? coarse_halo->halo.get() : nullptr, nt_c, nt_f, 0));
     *P = p;
+  });
+}
+int pa_gradient_create(pa_context *ctx, const pa_restriction_desc *rh, const pa_basis_desc *bh,
+                       const pa_restriction_desc *rn, const pa_basis_desc *bn, const double *Dg, pa_halo *h1_halo,
+                       int nt_h1, int nt_nd, pa_interp **G) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && rh && bh && rn && bn && Dg && G, "null argument");
+    const int n = bn->order + 1;
+    std::vector<double> I((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++) I[(size_t)i * n + i] = 1.0;
+    auto *p = new pa_interp;
+    p->ctx = ctx;
+    p->op.reset(make_interp_operator(ctx->ctx, *rh, *bh, *rn, *bn, I.data(), Dg,
+                                     h1_halo ? h1_halo->halo.get() : nullptr, nt_h1, nt_nd, 1));
+    *G = p;
   });
 }
 int pa_interp_mult(pa_interp *P, const double *x, double *y) {

@@ -220,14 +220,45 @@ class Interp:
             pass
 
 
+class Gradient(Interp):
+    """Discrete gradient G : H1(p) -> ND(p) (the auxiliary-space transfer of the Hiptmair smoother)."""
+
+    def __init__(self, ctx, h1_space, nd_space, h1_halo=None, n_true_h1=None, n_true_nd=None):
+        self.ctx = ctx
+        p = nd_space.p
+        assert h1_space.p == p
+        _, Dg = lagrange_eval(gauss_lobatto(p + 1), gauss_legendre(p)[0])  # [p][p+1]
+        Dg = np.ascontiguousarray(Dg)
+        rh, k1 = _restriction_desc(h1_space)
+        rn, k2 = _restriction_desc(nd_space)
+        bh, k3 = _basis_desc(h1_space, p + 1)
+        bn, k4 = _basis_desc(nd_space, p + 1)
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_gradient_create(ctx.handle, C.byref(rh), C.byref(bh), C.byref(rn), C.byref(bn), _ptr(Dg),
+                                           h1_halo.handle if h1_halo else None,
+                                           h1_space.ndofs if n_true_h1 is None else n_true_h1,
+                                           nd_space.ndofs if n_true_nd is None else n_true_nd, C.byref(self.handle)))
+
+
 def gmg(ctx, A_levels, P_levels, coarse: Solver, cycle_it=1, smooth_it=1, cheby_order=4, sf_max=1.0, sf_min=0.0,
-        fourth_kind=True):
-    """GeometricMultigridSolver (gmg.cpp); takes ownership of `coarse`."""
+        fourth_kind=True, A_aux=None, G=None):
+    """GeometricMultigridSolver (gmg.cpp); takes ownership of `coarse`.  With A_aux (H1 ParOperators)
+    and G (discrete gradients) per level the smoother is the Hiptmair DistRelaxationSmoother."""
     n = len(A_levels)
     Ah = (C.c_void_p * n)(*[a.handle for a in A_levels])
     Ph = (C.c_void_p * max(1, n - 1))(*[p.handle for p in P_levels])
     h = C.c_void_p()
-    _lib.check(_L().pa_gmg_create(ctx.handle, n, Ah, Ph, coarse.handle, cycle_it, smooth_it, cheby_order, sf_max,
-                                  sf_min, int(fourth_kind), C.byref(h)))
+    if G is None:
+        _lib.check(_L().pa_gmg_create(ctx.handle, n, Ah, Ph, coarse.handle, cycle_it, smooth_it, cheby_order,
+                                      sf_max, sf_min, int(fourth_kind), C.byref(h)))
+    else:
+        Xh = (C.c_void_p * n)(*[(a.handle if a is not None else None) for a in A_aux])
+        Gh = (C.c_void_p * n)(*[(g.handle if g is not None else None) for g in G])
+        L = _L()
+        L.pa_gmg_create_aux.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                        C.c_void_p]
+        _lib.check(L.pa_gmg_create_aux(ctx.handle, n, Ah, Ph, Xh, Gh, coarse.handle, cycle_it, smooth_it,
+                                       cheby_order, sf_max, sf_min, int(fourth_kind), C.byref(h)))
     coarse._owned_by_parent = True
-    return Solver(ctx, h, (A_levels, P_levels, coarse))
+    return Solver(ctx, h, (A_levels, P_levels, coarse, A_aux, G))
