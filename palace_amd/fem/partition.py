@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .fespace import NDHexSpace
+from .fespace import H1HexSpace, NDHexSpace
 from .mesh import HexMesh, ogrid_cylinder
 
 
@@ -97,6 +97,81 @@ class SlabNDSpace(NDHexSpace):
         return self._ess_true
 
 
+class SlabH1Space(H1HexSpace):
+    """H1 space on one slab (the auxiliary space of the Hiptmair smoother), renumbered owned-first,
+    with its halo lists; essential dofs = all boundary nodes of the whole cylinder."""
+
+    def __init__(self, mesh: HexMesh, p: int, rank: int, world: int, z_lo: float, z_hi: float, radius: float):
+        super().__init__(mesh, p)
+        self.rank, self.world = rank, world
+        tol = 1e-6 * radius
+        vc = mesh.vert_coords
+        scale = 1.0 / (1e-6 * radius)
+        n_e, n_f = p - 1, (p - 1) ** 2
+
+        def plane_dofs(z):
+            inp = np.abs(vc[:, 2] - z) < tol
+            ev, fv = mesh.edge_verts, mesh.face_verts
+            v_in = np.nonzero(inp)[0]
+            e_in = np.nonzero(inp[ev].all(axis=1))[0]
+            f_in = np.nonzero(inp[fv].all(axis=1))[0]
+            v_in = v_in[np.argsort(_plane_key(vc[v_in, :2], scale), kind="stable")]
+            e_in = e_in[np.argsort(_plane_key(vc[ev[e_in], :2].mean(axis=1), scale), kind="stable")]
+            f_in = f_in[np.argsort(_plane_key(vc[fv[f_in], :2].mean(axis=1), scale), kind="stable")]
+            de = (self.edge_base + e_in[:, None] * n_e + np.arange(n_e)[None, :]).ravel()
+            df = (self.face_base + f_in[:, None] * n_f + np.arange(n_f)[None, :]).ravel()
+            return np.concatenate([self.vert_base + v_in, de, df]).astype(np.int64), f_in
+
+        bottom, f_bot = plane_dofs(z_lo)
+        top, f_top = plane_dofs(z_hi)
+        n_old = self.ndofs
+        ghosts = bottom if rank > 0 else np.zeros(0, dtype=np.int64)
+        is_ghost = np.zeros(n_old, dtype=bool)
+        is_ghost[ghosts] = True
+        perm = np.empty(n_old, dtype=np.int64)
+        self.n_true = n_old - ghosts.size
+        perm[~is_ghost] = np.arange(self.n_true)
+        perm[ghosts] = self.n_true + np.arange(ghosts.size)
+        self.elem_dof_lex = perm[self.elem_dof_lex].astype(np.int32)
+        fmask = mesh.boundary_face_mask.copy()
+        if rank > 0:
+            fmask[f_bot] = False
+        if rank < world - 1:
+            fmask[f_top] = False
+        ess = self._ess_with_mask(fmask)
+        self._ess_true = ess[ess < self.n_true]
+        self.nbr, self.send, self.recv = [], [], []
+        if rank > 0:
+            self.nbr.append(rank - 1)
+            self.send.append(np.zeros(0, dtype=np.int32))
+            self.recv.append(perm[bottom].astype(np.int32))
+        if rank < world - 1:
+            self.nbr.append(rank + 1)
+            self.send.append(perm[top].astype(np.int32))
+            self.recv.append(np.zeros(0, dtype=np.int32))
+
+    def _ess_with_mask(self, fmask):
+        from .mesh import HEX_FACE_AXES
+
+        mesh, p = self.mesh, self.p
+        n1 = p + 1
+        bmask = fmask[mesh.elem_faces]
+        out = []
+        for lf, (nax, side, uax, vax) in enumerate(HEX_FACE_AXES):
+            el = np.nonzero(bmask[:, lf])[0]
+            if el.size == 0:
+                continue
+            rng = [np.arange(n1)] * 3
+            rng[nax] = np.array([side * p])
+            K, J, I = np.meshgrid(rng[2], rng[1], rng[0], indexing="ij")
+            lex = (I + n1 * (J + n1 * K)).ravel()
+            out.append(self.elem_dof_lex[el][:, lex].ravel())
+        return np.unique(np.concatenate(out)).astype(np.int32) if out else np.zeros(0, np.int32)
+
+    def ess_dofs(self):
+        return self._ess_true
+
+
 def levels_for(p: int):
     """p-coarsening sequence of the reference (LOGARITHMIC: p -> (p + 1) / 2 down to 1,
     fem/multigrid.hpp:44-69)."""
@@ -154,7 +229,7 @@ class SlabProblem:
         return linalg.ParOperator(self.ctx, self.local_curlcurl, self.ess[-1], linalg.DIAG_ONE,
                                   n_true=self.n_true[-1], halo=self.halos[-1])
 
-    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8):
+    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False):
         """PCG on (K + M) with the p-multigrid preconditioner configured as the reference does for
         p = 3 (iodata.cpp:533-564: 4th-kind Chebyshev of order max(2p, 4), 1 smoothing step, 1 V-cycle);
         level 0 is solved by Jacobi-PCG (the reference uses AMS from HYPRE there, linalg/ams.cpp)."""
@@ -171,9 +246,26 @@ class SlabProblem:
              for op, e, nt, h in zip(local, self.ess, self.n_true, self.halos)]
         P = [linalg.Interp(ctx, self.spaces[l], self.spaces[l + 1], coarse_halo=self.halos[l],
                            n_true_c=self.n_true[l], n_true_f=self.n_true[l + 1]) for l in range(len(A) - 1)]
+        aux = {}
+        if hiptmair:
+            # auxiliary-space smoothing (reference default for driven / eigenmode problems,
+            # iodata.cpp:519-532): H1 diffusion with the mass coefficient, discrete gradients
+            z_lo = self.rank * self.height
+            h1s = [SlabH1Space(self.mesh, q, self.rank, self.world, z_lo, z_lo + self.height, self.radius)
+                   for q in self.orders]
+            h1_halos = [linalg.Halo(ctx, s.nbr, s.send, s.recv) if self.world > 1 else None for s in h1s]
+            fine_h1 = ceed.diffusion_operator(self.geom, h1s[-1], mass)
+            loc_h1 = [fine_h1.coarsen(self.geom, s) for s in h1s[:-1]] + [fine_h1]
+            # PEC: the auxiliary potential vanishes on the boundary
+            A_h1 = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE, n_true=s.n_true, halo=h)
+                    for op, s, h in zip(loc_h1, h1s, h1_halos)]
+            G = [linalg.Gradient(ctx, h, n, h1_halo=hh, n_true_h1=h.n_true, n_true_nd=n.n_true)
+                 for h, n, hh in zip(h1s, self.spaces, h1_halos)]
+            aux = dict(A_aux=A_h1, G=G)
+            self._keep.append((h1s, loc_h1, h1_halos))
         if len(A) > 1:
             coarse = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
-            B = linalg.gmg(ctx, A, P, coarse, cheby_order=max(2 * self.p, 4))
+            B = linalg.gmg(ctx, A, P, coarse, cheby_order=max(2 * self.p, 4), **aux)
         else:
             B = linalg.jacobi(ctx, A[0])
         K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)

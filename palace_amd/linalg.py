@@ -61,6 +61,13 @@ class Context:
         _lib.check(L.pa_context_init_comm(self.handle, rank, size, raw))
         self.rank, self.size = rank, size
 
+    def init_comm_single(self):
+        """One-rank communicator (exercises RCCL init / allreduce without a second GPU)."""
+        L = _L()
+        buf = C.create_string_buffer(128)
+        _lib.check(L.pa_comm_unique_id(buf))
+        _lib.check(L.pa_context_init_comm(self.handle, 0, 1, buf.raw))
+
     def synchronize(self):
         _lib.check(_L().pa_context_synchronize(self.handle))
 

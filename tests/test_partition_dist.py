@@ -26,6 +26,10 @@ def _field(x):
                      0.2 * x[..., 0] * x[..., 1] + np.sin(0.3 * x[..., 2])], axis=-1)
 
 
+def _potential(x):
+    return np.sin(0.4 * x[..., 0]) * np.cos(0.3 * x[..., 1]) + 0.1 * x[..., 2] ** 2
+
+
 def _worker(rank, world, port, p, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -65,6 +69,38 @@ def _worker(rank, world, port, p, out):
             g = torch.tensor([ghost_err], dtype=torch.float64)
             dist.all_reduce(g, op=dist.ReduceOp.MAX)
             res[sp.p] = loc.tolist() + [float(g.item())]
+        # H1 auxiliary space (Hiptmair): diffusion operator energy and the discrete gradient
+        from palace_amd.fem.partition import SlabH1Space
+
+        z_lo = rank * prob.height
+        for sp_nd in prob.spaces:
+            q = sp_nd.p
+            h1 = SlabH1Space(prob.mesh, q, rank, world, z_lo, z_lo + prob.height, RADIUS)
+            q1d = p + 1
+            geom = util.oracle_geom(prob.mesh, q1d)
+            interp, grad = po.h1_hex_dense_tables(q, q1d)
+            A = po.CeedOperatorOracle(h1.ndofs, h1.elem_dof_lex, None, interp, grad, geom, po.QF_HCURL,
+                                      po.CoeffCtx(), vector_fe=False)
+            phi = util.h1_interpolate(h1, _potential)
+            nt = h1.n_true
+            tx = phi[:nt].copy()
+            tx[h1.ess_dofs()] = 0.0
+            lx = torch.zeros(h1.ndofs, dtype=torch.float64)
+            lx[:nt] = torch.from_numpy(tx)
+            prolongate_dist(h1, lx)
+            ly = restrict_add_dist(h1, torch.from_numpy(A.apply_add(lx.numpy(), np.zeros(h1.ndofs))))
+            y = ly.numpy()[:nt].copy()
+            y[h1.ess_dofs()] = 0.0
+            # gradient: G phi on local vectors (H1 ghosts filled by P), owned ND entries only
+            Gm = po.InterpOracle(h1.elem_dof_lex, np.ones(h1.elem_dof_lex.shape, dtype=np.int8), sp_nd.elem_dof_lex,
+                                 sp_nd.elem_sign_lex, h1.ndofs, sp_nd.ndofs, po.nd_hex_gradient_lex(q))
+            lphi = torch.zeros(h1.ndofs, dtype=torch.float64)
+            lphi[:nt] = torch.from_numpy(phi[:nt])
+            prolongate_dist(h1, lphi)
+            gphi = Gm.mult(lphi.numpy())[: sp_nd.n_true]
+            loc = torch.tensor([nt, tx @ tx, tx @ y, y @ y, h1.ess_dofs().size, gphi @ gphi], dtype=torch.float64)
+            dist.all_reduce(loc)
+            res[("h1", q)] = loc.tolist()
         if rank == 0:
             out.put(res)
     finally:
@@ -93,6 +129,22 @@ def _serial(p):
         y = util.oracle_apply_c(sp, geom, "hdivmass", np.concatenate([bm, bc]), x, q1d)
         y[ess] = 0.0
         out[q] = [sp.ndofs, x @ x, x @ y, y @ y, ess.size]
+        from oracle import palace_oracle as po
+        from palace_amd.fem.fespace import H1HexSpace
+
+        h1 = H1HexSpace(mesh, q)
+        interp, grad = po.h1_hex_dense_tables(q, q1d)
+        A = po.CeedOperatorOracle(h1.ndofs, h1.elem_dof_lex, None, interp, grad, geom, po.QF_HCURL, po.CoeffCtx(),
+                                  vector_fe=False)
+        phi = util.h1_interpolate(h1, _potential)
+        Gm = po.InterpOracle(h1.elem_dof_lex, np.ones(h1.elem_dof_lex.shape, dtype=np.int8), sp.elem_dof_lex,
+                             sp.elem_sign_lex, h1.ndofs, sp.ndofs, po.nd_hex_gradient_lex(q))
+        gphi = Gm.mult(phi)
+        e1 = h1.ess_dofs()
+        phi[e1] = 0.0
+        yh = A.apply_add(phi, np.zeros(h1.ndofs))
+        yh[e1] = 0.0
+        out[("h1", q)] = [h1.ndofs, phi @ phi, phi @ yh, yh @ yh, e1.size, gphi @ gphi]
     return out
 
 
@@ -113,6 +165,10 @@ def test_two_rank_operator_matches_serial(p):
         s = ref[q]
         assert int(r[0]) == s[0], "true dof count"
         assert int(r[4]) == s[4], "essential dof count"
+        if isinstance(q, tuple):  # H1 auxiliary space: energies + ||G phi||^2
+            for a, b in zip(r[1:4] + r[5:6], s[1:4] + s[5:6]):
+                assert abs(a - b) <= 1e-11 * abs(b), (q, r, s)
+            continue
         assert r[5] < 1e-12, "ghost values after P differ from the local interpolant"
         for a, b in zip(r[1:4], s[1:4]):
             assert abs(a - b) <= 1e-11 * abs(b), (q, r, s)

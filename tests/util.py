@@ -119,3 +119,21 @@ def nd_interpolate(space, F):
     out = np.zeros(space.ndofs)
     out[space.elem_dof_lex] = val
     return out
+
+
+def h1_interpolate(space, f):
+    """Nodal interpolant of a scalar function f(x) in an H1HexSpace-like space (local vector)."""
+    from palace_amd.fem.basis1d import gauss_lobatto
+    from palace_amd.fem.mesh import _q2_1d
+
+    p, mesh = space.p, space.mesh
+    cp = gauss_lobatto(p + 1)
+    pts = np.array([[cp[i], cp[j], cp[k]] for k in range(p + 1) for j in range(p + 1) for i in range(p + 1)])
+    Bx, _ = _q2_1d(pts[:, 0])
+    By, _ = _q2_1d(pts[:, 1])
+    Bz, _ = _q2_1d(pts[:, 2])
+    X = mesh.elem_coords().reshape(mesh.ne, 3, 3, 3, 3)
+    xp = np.einsum("lk,lj,li,ekjic->elc", Bz, By, Bx, X)
+    out = np.zeros(space.ndofs)
+    out[space.elem_dof_lex] = f(xp)
+    return out
