@@ -130,23 +130,47 @@ __device__ __forceinline__ void coeff_unpack3(const CoeffDev &c, int attr, doubl
   for (int i = 0; i < 9; i++) C[i] = c.mat[9 * k + i];
 }
 
+// LDS strides of the two contraction buffers, A[f][qx][j][k] and B[f][qx][qy][k].  A dense layout
+// makes three of the four lane patterns 4-way bank conflicted at p = 3 (ds_read_b64: 32-lane groups
+// over 64 dword banks; ds_write_b64: 16-lane groups over 32); the padded strides below come from
+// scripts/lds_layout_search.py and are conflict-free for the listed (P1, Q1).
+template <int P1, int Q1>
+struct NDStrides {
+  static constexpr int NC = P1 + 1;
+  static constexpr int Sj = NC, Sq = NC * NC, Ty = NC, Tq = NC * Q1, EPAD = 0;
+};
+template <>
+struct NDStrides<3, 4> {
+  static constexpr int Sj = 4, Sq = 20, Ty = 5, Tq = 20, EPAD = 0;  // 400 doubles per element
+};
+template <>
+struct NDStrides<2, 4> {
+  static constexpr int Sj = 3, Sq = 12, Ty = 3, Tq = 12, EPAD = 0;  // 240
+};
+template <>
+struct NDStrides<1, 4> {
+  static constexpr int Sj = 2, Sq = 4, Ty = 3, Tq = 12, EPAD = 0;  // 176
+};
+
 template <int P1, int Q1>
 struct NDLayout {
+  using S = NDStrides<P1, Q1>;
   static constexpr int NC = P1 + 1;
   static constexpr int T = Q1 * Q1;
   static constexpr int EPW = 64 / T;
   // LDS per element: A = 2 fields [Q1][NC][NC] (after pass X), B = 3 fields [Q1][Q1][NC]
-  static constexpr int A_FIELD = Q1 * NC * NC;
-  static constexpr int B_FIELD = Q1 * Q1 * NC;
+  static constexpr int A_FIELD = S::Sq * Q1;
+  static constexpr int B_FIELD = S::Tq * Q1;
   static constexpr int ELEM = 2 * A_FIELD + 3 * B_FIELD;
-  // odd multiple of 16 doubles between elements: the two elements of a 32-lane read group land
-  // on opposite halves of the 64 banks
-  static constexpr int ELEM_PAD = ((ELEM + 15) / 16 * 16) | 16;
+  static constexpr bool TUNED = (S::Sq != NC * NC) || (S::Tq != NC * Q1) || (P1 == 1 && Q1 == 4);
+  // tuned layouts carry their own element stride; otherwise an odd multiple of 16 doubles, so the
+  // two elements of a 32-lane read group land on opposite halves of the 64 banks
+  static constexpr int ELEM_PAD = TUNED ? ELEM + S::EPAD : (((ELEM + 15) / 16 * 16) | 16);
   __device__ static __forceinline__ int ia(int f, int qx, int j, int k) {
-    return f * A_FIELD + (qx * NC + j) * NC + k;
+    return f * A_FIELD + qx * S::Sq + j * S::Sj + k;
   }
   __device__ static __forceinline__ int ib(int f, int qx, int qy, int k) {
-    return 2 * A_FIELD + f * B_FIELD + (qx * Q1 + qy) * NC + k;
+    return 2 * A_FIELD + f * B_FIELD + qx * S::Tq + qy * S::Ty + k;
   }
 };
 
