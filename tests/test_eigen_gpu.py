@@ -1,0 +1,72 @@
+"""Device operators vs the reference's regression data: the eigenvectors of the cylinder cavity
+(p = 4, the reference's own 80-hex27 mesh) are computed on the host from the oracle's assembled K, M;
+the Rayleigh quotients x^T K x / x^T M x evaluated with the *device* curl-curl and mass operators must
+reproduce the frequencies of test/data/regression/ref/cylinder/cavity_pec/eig.csv (reference gate
+1e-4, here 1e-8)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import scipy.sparse.linalg as spla  # noqa: E402
+
+from oracle import palace_oracle as po  # noqa: E402
+from palace_amd import ceed  # noqa: E402
+from palace_amd.fem.fespace import NDHexSpace  # noqa: E402
+from tests import util  # noqa: E402
+from tests.test_oracle_eigen import C0, EIG_CSV_RE, L0  # noqa: E402
+
+
+def test_device_rayleigh_quotients_match_eig_csv(cylinder_mesh):
+    mesh, p, q1d = cylinder_mesh, 4, 5
+    nd = NDHexSpace(mesh, p)
+    ogeom = util.oracle_geom(mesh, q1d)
+    off, ori = nd.native_restriction()
+    interp, curl = po.nd_hex_dense_tables(p, q1d, nd.dof_map_native())
+    cM = po.CoeffCtx(attr_mat=[0], mat_coeff=[np.array([2.08])])
+    Ko = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HDIV, po.CoeffCtx()).assemble_sparse()
+    Mo = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HCURL, cM).assemble_sparse()
+    free = np.setdiff1d(np.arange(nd.ndofs), nd.ess_dofs())
+    sigma = (2 * np.pi * 4.0e9 * L0 / C0) ** 2
+    lam, V = spla.eigsh(Ko[free][:, free].tocsc(), k=30, M=Mo[free][:, free].tocsc(), sigma=sigma, which="LM", tol=1e-12)
+    order = np.argsort(lam)
+    lam, V = lam[order], V[:, order]
+    keep = lam > 1e-3
+    lam, V = lam[keep][:15], V[:, keep][:, :15]
+    geom = ceed.GeomFactorData(mesh, q1d)
+    K = ceed.curlcurl_operator(geom, nd, ceed.coefficient_context(3))
+    M = ceed.ndmass_operator(geom, nd, cM.pack())
+    new = lambda: torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")  # noqa: E731
+    f = []
+    for m in range(15):
+        x = np.zeros(nd.ndofs)
+        x[free] = V[:, m]
+        xd = torch.from_numpy(x).cuda()
+        kx, mx = K.mult(xd, new()), M.mult(xd, new())
+        rq = float(xd @ kx) / float(xd @ mx)
+        f.append(np.sqrt(rq / (1 - 1j * 4e-4)).real * C0 / L0 / (2 * np.pi) / 1e9)
+    rel = np.abs(np.array(f) - EIG_CSV_RE) / EIG_CSV_RE
+    assert rel.max() < 1e-8, rel
+
+
+def test_multi_rank_code_path_with_empty_halo(cylinder_mesh):
+    """ParOperator with a communicator and a halo plan that has no neighbours must take the
+    general (P, P^T) path and agree with the fused single-rank path."""
+    from palace_amd import linalg
+
+    mesh, p = cylinder_mesh, 3
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, p + 1)
+    op = ceed.curlcurl_operator(geom, nd, ceed.coefficient_context(3))
+    ctx = linalg.Context()
+    ctx.init_comm_single()
+    halo = linalg.Halo(ctx, [], [], [])
+    A1 = linalg.ParOperator(ctx, op, nd.ess_dofs(), linalg.DIAG_ONE, halo=halo)
+    op2 = ceed.curlcurl_operator(geom, nd, ceed.coefficient_context(3))
+    A2 = linalg.ParOperator(linalg.Context(), op2, nd.ess_dofs(), linalg.DIAG_ONE)
+    x = torch.rand(nd.ndofs, dtype=torch.float64, device="cuda")
+    y1 = A1.mult(x, torch.empty_like(x))
+    y2 = A2.mult(x, torch.empty_like(x))
+    assert float((y1 - y2).norm() / y2.norm()) < 1e-14
+    assert abs(ctx.dot(x, x) - float(x @ x)) < 1e-10 * float(x @ x)  # allreduce over one rank
