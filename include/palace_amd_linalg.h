@@ -20,6 +20,7 @@ typedef struct pa_halo pa_halo;       /* conforming prolongation P of one space 
 typedef struct pa_par_op pa_par_op;   /* palace::ParOperator, linalg/rap.cpp             */
 typedef struct pa_interp pa_interp;   /* p-prolongation / discrete gradient, fem/bilinearform.cpp:203-282 */
 typedef struct pa_solver pa_solver;   /* palace::Solver<Operator>, linalg/solver.hpp     */
+typedef struct pa_csolver pa_csolver; /* Krylov solver on ComplexOperator (ComplexVector = two real vectors) */
 
 /* --- context: everything created from it is enqueued on `stream` (a hipStream_t) ------------- */
 int pa_context_create(void *stream, pa_context **ctx);
@@ -92,6 +93,18 @@ int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess);
 int pa_solver_stats(const pa_solver *S, int *iterations, double *initial_res, double *final_res,
                     int *converged);
 void pa_solver_destroy(pa_solver *S);
+
+/* --- complex operators: ComplexWrapperOperator (linalg/operator.cpp:58-134) over two real
+ *     ParOperators (real part with its DIAG policy, imaginary part DIAG_ZERO, rap.cpp:450-457) and
+ *     the complex instantiation of GmresSolver (linalg/iterative.cpp:543-705) with a real
+ *     preconditioner applied to the real and imaginary parts (linalg/gmg.cpp:147-168). ------------ */
+int pa_complex_op_mult(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, const double *xr, const double *xi,
+                       double *yr, double *yi);
+int pa_complex_gmres_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_solver *precond, double rel_tol,
+                            double abs_tol, int max_it, int restart, int print, pa_csolver **S);
+int pa_csolver_mult(pa_csolver *S, const double *br, const double *bi, double *xr, double *xi, int initial_guess);
+int pa_csolver_stats(const pa_csolver *S, int *iterations, double *initial_res, double *final_res, int *converged);
+void pa_csolver_destroy(pa_csolver *S);
 
 /* --- p-prolongation between two spaces on the same mesh (fem/bilinearform.cpp:203-282,
  *     fem/libceed/basis.cpp:116-165 `InitMfemInterpolatorBasis`, fem/libceed/integrator.cpp:515-548):

@@ -3,6 +3,7 @@
 
 #include "../../include/palace_amd_linalg.h"
 #include "comm.hpp"
+#include "complex.hpp"
 #include "linalg.hpp"
 
 using namespace palace;
@@ -36,6 +37,12 @@ struct pa_solver {
   ~pa_solver() {
     for (auto *s : owned) delete s;
   }
+};
+
+struct pa_csolver {
+  pa_context *ctx;
+  std::unique_ptr<ComplexWrapperOperator> A;
+  std::unique_ptr<ComplexGmresSolver> solver;
 };
 
 using pa::guarded;
@@ -267,6 +274,48 @@ int pa_solver_stats(const pa_solver *S, int *its, double *initial_res, double *f
   });
 }
 void pa_solver_destroy(pa_solver *S) { delete S; }
+
+int pa_complex_op_mult(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, const double *xr, const double *xi, double *yr,
+                       double *yi) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && (Ar || Ai), "null argument");
+    ComplexWrapperOperator A(ctx->ctx, Ar ? Ar->op.get() : nullptr, Ai ? Ai->op.get() : nullptr);
+    const int n = A.Height();
+    ComplexVector x(const_cast<double *>(xr), const_cast<double *>(xi), n), y(yr, yi, n);
+    A.Mult(x, y);
+  });
+}
+int pa_complex_gmres_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_solver *precond, double rel_tol,
+                            double abs_tol, int max_it, int restart, int print, pa_csolver **S) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && (Ar || Ai) && S, "null argument");
+    auto *s = new pa_csolver;
+    s->ctx = ctx;
+    s->A = std::make_unique<ComplexWrapperOperator>(ctx->ctx, Ar ? Ar->op.get() : nullptr, Ai ? Ai->op.get() : nullptr);
+    s->solver = std::make_unique<ComplexGmresSolver>(ctx->ctx, print);
+    s->solver->SetOperator(*s->A);
+    if (precond) s->solver->SetPreconditioner(*precond->solver);
+    s->solver->SetTol(rel_tol), s->solver->SetAbsTol(abs_tol), s->solver->SetMaxIter(max_it);
+    s->solver->SetRestartDim(restart);
+    *S = s;
+  });
+}
+int pa_csolver_mult(pa_csolver *S, const double *br, const double *bi, double *xr, double *xi, int initial_guess) {
+  return guarded([&] {
+    const int n = S->A->Height();
+    ComplexVector b(const_cast<double *>(br), const_cast<double *>(bi), n), x(xr, xi, n);
+    S->solver->Mult(b, x, initial_guess != 0);
+  });
+}
+int pa_csolver_stats(const pa_csolver *S, int *its, double *initial_res, double *final_res, int *converged) {
+  return guarded([&] {
+    if (its) *its = S->solver->GetNumIterations();
+    if (initial_res) *initial_res = S->solver->GetInitialRes();
+    if (final_res) *final_res = S->solver->GetFinalRes();
+    if (converged) *converged = S->solver->GetConverged();
+  });
+}
+void pa_csolver_destroy(pa_csolver *S) { delete S; }
 
 int pa_interp_create(pa_context *ctx, const pa_restriction_desc *rc, const pa_basis_desc *bc,
                      const pa_restriction_desc *rf, const pa_basis_desc *bf, const double *Ic, const double *Io,

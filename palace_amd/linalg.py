@@ -269,3 +269,46 @@ def gmg(ctx, A_levels, P_levels, coarse: Solver, cycle_it=1, smooth_it=1, cheby_
                                        cheby_order, sf_max, sf_min, int(fourth_kind), C.byref(h)))
     coarse._owned_by_parent = True
     return Solver(ctx, h, (A_levels, P_levels, coarse, A_aux, G))
+
+
+# ---- complex layer (ComplexVector = a pair of real tensors) ------------------------------------
+
+def complex_mult(ctx, Ar, Ai, xr, xi, yr, yi):
+    """ComplexWrapperOperator::Mult (linalg/operator.cpp:98-134): y = (Ar + i Ai) x."""
+    _lib.check(_L().pa_complex_op_mult(ctx.handle, Ar.handle if Ar else None, Ai.handle if Ai else None,
+                                       C.c_void_p(xr.data_ptr()), C.c_void_p(xi.data_ptr()),
+                                       C.c_void_p(yr.data_ptr()), C.c_void_p(yi.data_ptr())))
+    return yr, yi
+
+
+class ComplexGmres:
+    """GmresSolver<ComplexOperator> (linalg/iterative.cpp:543-705), real preconditioner on both parts."""
+
+    def __init__(self, ctx, Ar, Ai, precond=None, rel_tol=1e-8, abs_tol=0.0, max_it=200, restart=-1, print_level=0):
+        L = _L()
+        L.pa_complex_gmres_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                              C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.pa_csolver_destroy.restype = None
+        L.pa_csolver_destroy.argtypes = [C.c_void_p]
+        self.ctx, self._keep = ctx, (Ar, Ai, precond)
+        self.handle = C.c_void_p()
+        _lib.check(L.pa_complex_gmres_create(ctx.handle, Ar.handle if Ar else None, Ai.handle if Ai else None,
+                                             precond.handle if precond else None, rel_tol, abs_tol, max_it, restart,
+                                             print_level, C.byref(self.handle)))
+
+    def mult(self, br, bi, xr, xi, initial_guess=False):
+        _lib.check(_L().pa_csolver_mult(self.handle, C.c_void_p(br.data_ptr()), C.c_void_p(bi.data_ptr()),
+                                        C.c_void_p(xr.data_ptr()), C.c_void_p(xi.data_ptr()), int(initial_guess)))
+        return xr, xi
+
+    def stats(self):
+        its, conv = C.c_int(), C.c_int()
+        r0, r1 = C.c_double(), C.c_double()
+        _lib.check(_L().pa_csolver_stats(self.handle, C.byref(its), C.byref(r0), C.byref(r1), C.byref(conv)))
+        return dict(iterations=its.value, initial_res=r0.value, final_res=r1.value, converged=bool(conv.value))
+
+    def __del__(self):
+        try:
+            _L().pa_csolver_destroy(self.handle)
+        except Exception:
+            pass
