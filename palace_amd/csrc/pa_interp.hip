@@ -22,10 +22,18 @@ struct InterpArgs {
   int ne, fe_type, pc, pf;
   const int32_t *lidx_c, *lidx_f;
   const double *Ic, *Io;      // device: [(pf+1)*(pc+1)], [pf*pc]
-  const double *inv_mult;     // [n_local_fine]
   const double *x;
-  double *y;
+  double *y;      // forward: fine L-vector (owner copies store, no atomics)
+  double *ye_c;   // transpose: coarse E-vector [ne][Pc], summed per dof by k_gather
 };
+
+// Every fine dof is shared by several elements that all compute the same interpolated value (the
+// row of the element matrix for a shared dof only involves coarse dofs of the shared entity), so
+// instead of adding all copies and scaling by 1/multiplicity (bilinearform.cpp:256-279) exactly one
+// copy - the owner, flagged in the fine index array - is stored: no atomics, no memset, fixed
+// result.  The transpose reads the fine vector through the same owner mask, which is the exact
+// transpose of that operator.
+constexpr int kOwnBit = 1 << 29;
 
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -37,7 +45,8 @@ __device__ __forceinline__ void wsync() {
 // [nf[d]][nc[d]] of direction d.  TRANSPOSE applies the transposed element matrix.
 template <bool TRANSPOSE>
 __device__ void interp_block(const InterpArgs &a, const int e, const bool active, const bool lane_ok,
-                             const int ta, const int tb, double *sm, const int off_c, const int off_f,
+                             const int ta, const int tb, double *sm, const bool accumulate, const int off_c,
+                             const int off_f,
                              const int Pc, const int Pf, const int nc0, const int nc1, const int nc2,
                              const int nf0, const int nf1, const int nf2, const double *M0,
                              const double *M1, const double *M2) {
@@ -87,7 +96,7 @@ __device__ void interp_block(const InterpArgs &a, const int e, const bool active
         if (active && act) {
           const int s = a.lidx_f[(size_t)e * Pf + off_f + ta + nf0 * (tb + nf1 * fk)];
           const int g = s >= 0 ? s : -1 - s;
-          unsafeAtomicAdd(&a.y[g], (s >= 0 ? v : -v) * a.inv_mult[g]);
+          if (g & kOwnBit) a.y[g & ~kOwnBit] = s >= 0 ? v : -v;
         }
       }
     }
@@ -102,7 +111,7 @@ __device__ void interp_block(const InterpArgs &a, const int e, const bool active
         if (active && act) {
           const int s = a.lidx_f[(size_t)e * Pf + off_f + ta + nf0 * (tb + nf1 * fk)];
           const int g = s >= 0 ? s : -1 - s;
-          const double xv = a.x[g] * a.inv_mult[g];
+          const double xv = (g & kOwnBit) ? a.x[g & ~kOwnBit] : 0.0;
           v = s >= 0 ? xv : -xv;
         }
         u[fk] = v;
@@ -135,8 +144,10 @@ __device__ void interp_block(const InterpArgs &a, const int e, const bool active
         double v = 0.0;
         for (int fi = 0; fi < nf0; fi++) v += M0[fi * nc0 + i] * u[fi];
         if (active && act) {
-          const int s = a.lidx_c[(size_t)e * Pc + off_c + i + nc0 * (ta + nc1 * tb)];
-          unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? v : -v);
+          // coarse E-vector (unsigned); the three components of a gradient hit the same entries
+          // from the same lane, one after the other
+          double *dst = &a.ye_c[(size_t)e * Pc + off_c + i + nc0 * (ta + nc1 * tb)];
+          *dst = accumulate ? *dst + v : v;
         }
       }
     }
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256) void interp_kernel(const InterpArgs a) {
     const int Pc = nfc * nfc * nfc, Pf = 3 * pf * nfc * nfc;
     for (int C = 0; C < 3; C++) {
       const int nf0 = C == 0 ? pf : nfc, nf1 = C == 1 ? pf : nfc, nf2 = C == 2 ? pf : nfc;
-      interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, 0, C * pf * nfc * nfc, Pc, Pf, nfc, nfc, nfc, nf0,
+      interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, C > 0, 0, C * pf * nfc * nfc, Pc, Pf, nfc, nfc, nfc, nf0,
                               nf1, nf2, C == 0 ? a.Io : a.Ic, C == 1 ? a.Io : a.Ic, C == 2 ? a.Io : a.Ic);
     }
   } else if (a.fe_type == PA_FE_HCURL) {
@@ -171,25 +182,27 @@ __global__ __launch_bounds__(256) void interp_kernel(const InterpArgs a) {
     for (int C = 0; C < 3; C++) {
       const int nc0 = C == 0 ? pc : ncc, nc1 = C == 1 ? pc : ncc, nc2 = C == 2 ? pc : ncc;
       const int nf0 = C == 0 ? pf : nfc, nf1 = C == 1 ? pf : nfc, nf2 = C == 2 ? pf : nfc;
-      interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, C * pc * ncc * ncc, C * pf * nfc * nfc, Pc, Pf,
+      interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, false, C * pc * ncc * ncc, C * pf * nfc * nfc, Pc, Pf,
                               nc0, nc1, nc2, nf0, nf1, nf2, C == 0 ? a.Io : a.Ic, C == 1 ? a.Io : a.Ic,
                               C == 2 ? a.Io : a.Ic);
     }
   } else {
-    interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, 0, 0, ncc * ncc * ncc, nfc * nfc * nfc, ncc, ncc,
+    interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, false, 0, 0, ncc * ncc * ncc, nfc * nfc * nfc, ncc, ncc,
                             ncc, nfc, nfc, nfc, a.Ic, a.Ic, a.Ic);
   }
 }
 
-__global__ void k_count_mult(const int32_t *__restrict__ lidx, long long n, double *__restrict__ mult) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const int s = lidx[i];
-    unsafeAtomicAdd(&mult[s >= 0 ? s : -1 - s], 1.0);
+// coarse E^T as a gather (same scheme as pa::et_gather_kernel)
+__global__ void k_gather(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                         const double *__restrict__ ye, double *__restrict__ y) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  double s = 0.0;
+  for (int k = tptr[d]; k < tptr[d + 1]; k++) {
+    const int t = tent[k];
+    s += t >= 0 ? ye[t] : -ye[-1 - t];
   }
-}
-__global__ void k_invert(double *x, long long n) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    x[i] = x[i] > 0.0 ? 1.0 / x[i] : 0.0;
+  y[d] = s;
 }
 
 std::vector<int32_t> signed_lex_index(const pa_restriction_desc &r, const pa_basis_desc &b, int P) {
@@ -215,12 +228,13 @@ class InterpOperator : public Operator {
   int kind_ = 0;
   int fe_type_, pc_, pf_, ne_, nl_c_, nl_f_, nt_c_, nt_f_;
   int32_t *d_lidx_c_ = nullptr, *d_lidx_f_ = nullptr;
-  double *d_Ic_ = nullptr, *d_Io_ = nullptr, *d_inv_mult_ = nullptr;
+  double *d_Ic_ = nullptr, *d_Io_ = nullptr, *d_ye_c_ = nullptr;
+  int32_t *d_tptr_c_ = nullptr, *d_tent_c_ = nullptr;
   mutable Vector lc_, lf_;
 
   template <bool TR>
   void launch(const double *x, double *y) const {
-    InterpArgs a{kind_, ne_, fe_type_, pc_, pf_, d_lidx_c_, d_lidx_f_, d_Ic_, d_Io_, d_inv_mult_, x, y};
+    InterpArgs a{kind_, ne_, fe_type_, pc_, pf_, d_lidx_c_, d_lidx_f_, d_Ic_, d_Io_, x, y, d_ye_c_};
     const int n1 = pf_ + 1, epw = 64 / (n1 * n1), epb = 4 * epw;
     const size_t lds = sizeof(double) * (size_t)epb * 2 * n1 * n1 * n1;
     hipLaunchKernelGGL((interp_kernel<TR>), dim3((ne_ + epb - 1) / epb), dim3(256), lds, ctx_->stream, a);
@@ -248,33 +262,53 @@ public:
     const int Pf = bf.fe_type == PA_FE_HCURL ? 3 * pf_ * (pf_ + 1) * (pf_ + 1) : (pf_ + 1) * (pf_ + 1) * (pf_ + 1);
     PA_REQUIRE(rc.elem_size == Pc && rf.elem_size == Pf, "restriction sizes do not match the bases");
     auto lc = signed_lex_index(rc, bc, Pc), lf = signed_lex_index(rf, bf, Pf);
+    PA_REQUIRE(nl_f_ < kOwnBit, "too many fine dofs for the owner-flag encoding");
+    {  // owner copy of every fine dof = its first occurrence in element order
+      std::vector<char> seen((size_t)nl_f_, 0);
+      for (auto &sg : lf) {
+        const int g = sg >= 0 ? sg : -1 - sg;
+        if (!seen[g]) {
+          seen[g] = 1;
+          sg = sg >= 0 ? (g | kOwnBit) : -1 - (g | kOwnBit);
+        }
+      }
+    }
+    {  // transpose map of the coarse index array
+      const size_t nnz = lc.size();
+      std::vector<int32_t> tptr((size_t)nl_c_ + 1, 0), tent(nnz);
+      for (size_t k = 0; k < nnz; k++) tptr[(size_t)(lc[k] >= 0 ? lc[k] : -1 - lc[k]) + 1]++;
+      for (int d = 0; d < nl_c_; d++) tptr[d + 1] += tptr[d];
+      std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+      for (size_t k = 0; k < nnz; k++) {
+        const int d = lc[k] >= 0 ? lc[k] : -1 - lc[k];
+        tent[fill[d]++] = lc[k] >= 0 ? (int32_t)k : -1 - (int32_t)k;
+      }
+      d_tptr_c_ = pa::dev_upload(tptr.data(), tptr.size(), ctx.stream);
+      d_tent_c_ = pa::dev_upload(tent.data(), tent.size(), ctx.stream);
+      d_ye_c_ = pa::dev_alloc<double>(nnz);
+    }
     d_lidx_c_ = pa::dev_upload(lc.data(), lc.size(), ctx.stream);
     d_lidx_f_ = pa::dev_upload(lf.data(), lf.size(), ctx.stream);
     d_Ic_ = pa::dev_upload(Ic, (size_t)(pf_ + 1) * (pc_ + 1), ctx.stream);
     if (Io) d_Io_ = pa::dev_upload(Io, kind == 1 ? (size_t)pf_ * (pf_ + 1) : (size_t)pf_ * pc_, ctx.stream);
-    // local dof multiplicity of the fine restriction (CeedElemRestrictionGetMultiplicity,
-    // bilinearform.cpp:256-279)
-    d_inv_mult_ = pa::dev_alloc<double>((size_t)nl_f_);
-    PA_HIP(hipMemsetAsync(d_inv_mult_, 0, sizeof(double) * (size_t)nl_f_, ctx.stream));
-    const long long n = (long long)lf.size();
-    hipLaunchKernelGGL(k_count_mult, dim3(1024), dim3(256), 0, ctx.stream, d_lidx_f_, n, d_inv_mult_);
-    hipLaunchKernelGGL(k_invert, dim3(1024), dim3(256), 0, ctx.stream, d_inv_mult_, (long long)nl_f_);
-    PA_HIP(hipGetLastError());
     lc_.SetSize(nl_c_), lf_.SetSize(nl_f_);
   }
   ~InterpOperator() override {
     (void)hipFree(d_lidx_c_), (void)hipFree(d_lidx_f_), (void)hipFree(d_Ic_), (void)hipFree(d_Io_),
-        (void)hipFree(d_inv_mult_);
+        (void)hipFree(d_ye_c_), (void)hipFree(d_tptr_c_), (void)hipFree(d_tent_c_);
   }
   // y_f = R_f D^-1 E_f^T I E_c P_c x_c
   void Mult(const Vector &x, Vector &y) const override {
     const Context &c = *ctx_;
     PA_REQUIRE(x.Size() == nt_c_ && y.Size() == nt_f_, "size mismatch in prolongation");
+    if (!halo_c_ && nt_c_ == nl_c_ && nt_f_ == nl_f_) {  // one rank: no staging copies
+      launch<false>(x.Data(), y.Data());
+      return;
+    }
     Vector tc(lc_.Data(), nt_c_);
     linalg::Copy(c, x, tc);
     if (halo_c_) halo_c_->Prolongate(lc_.Data(), c.stream);
-    linalg::Fill(c, lf_, 0.0);
-    launch<false>(lc_.Data(), lf_.Data());
+    launch<false>(lc_.Data(), lf_.Data());  // every fine local dof is stored exactly once
     Vector tf(lf_.Data(), nt_f_);
     linalg::Copy(c, tf, y);
   }
@@ -282,12 +316,21 @@ public:
   void MultTranspose(const Vector &x, Vector &y) const override {
     const Context &c = *ctx_;
     PA_REQUIRE(x.Size() == nt_f_ && y.Size() == nt_c_, "size mismatch in restriction");
+    if (!halo_c_ && nt_c_ == nl_c_ && nt_f_ == nl_f_) {
+      launch<true>(x.Data(), nullptr);
+      hipLaunchKernelGGL(k_gather, dim3((nl_c_ + 255) / 256), dim3(256), 0, c.stream, nl_c_, d_tptr_c_, d_tent_c_,
+                         d_ye_c_, y.Data());
+      PA_HIP(hipGetLastError());
+      return;
+    }
     Vector tf(lf_.Data(), nt_f_);
     linalg::Copy(c, x, tf);
     if (nl_f_ > nt_f_)
       PA_HIP(hipMemsetAsync(lf_.Data() + nt_f_, 0, sizeof(double) * (size_t)(nl_f_ - nt_f_), c.stream));
-    linalg::Fill(c, lc_, 0.0);
-    launch<true>(lf_.Data(), lc_.Data());
+    launch<true>(lf_.Data(), nullptr);
+    hipLaunchKernelGGL(k_gather, dim3((nl_c_ + 255) / 256), dim3(256), 0, c.stream, nl_c_, d_tptr_c_, d_tent_c_,
+                       d_ye_c_, lc_.Data());
+    PA_HIP(hipGetLastError());
     if (halo_c_) halo_c_->RestrictAdd(lc_.Data(), c.stream);
     Vector tc(lc_.Data(), nt_c_);
     linalg::Copy(c, tc, y);
