@@ -61,6 +61,9 @@ struct NDArgs {
   double *ye;  // E-vector target [ne][P], tensor order, unsigned (EVEC == true)
   CoeffDev c_mass, c_curl;
   NDTab<P1, Q1> tab;
+#ifdef PA_ABLATION
+  int dbg;  // timing experiments only: 1 no E-vector store, 4 no q-data/geometry loads, 8 no gather
+#endif
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -140,10 +143,6 @@ struct NDStrides {
   static constexpr int Sj = NC, Sq = NC * NC, Ty = NC, Tq = NC * Q1, EPAD = 0;
 };
 template <>
-struct NDStrides<3, 4> {
-  static constexpr int Sj = 4, Sq = 20, Ty = 5, Tq = 20, EPAD = 0;  // 400 doubles per element
-};
-template <>
 struct NDStrides<2, 4> {
   static constexpr int Sj = 3, Sq = 12, Ty = 3, Tq = 12, EPAD = 0;  // 240
 };
@@ -172,12 +171,31 @@ struct NDLayout {
   __device__ static __forceinline__ int ib(int f, int qx, int qy, int k) {
     return 2 * A_FIELD + f * B_FIELD + qx * S::Tq + qy * S::Ty + k;
   }
+  __device__ static __forceinline__ int parity_xor(int) { return 0; }
+};
+
+// p = 3 (NC = Q1 = 4): every buffer is a 4x4x4 block, so an XOR swizzle makes all four lane patterns
+// conflict-free without padding: index = qx*16 + ((j ^ qx) << 2) + (k ^ qx); the odd element of a
+// 32-lane read group flips bit 4.  320 doubles = 2.5 KB per element => 16 waves per CU fit in LDS
+// (the padded layout needed 3.2 KB => 12 waves).
+template <>
+struct NDLayout<3, 4> {
+  static constexpr int NC = 4, T = 16, EPW = 4;
+  static constexpr int A_FIELD = 64, B_FIELD = 64;
+  static constexpr int ELEM = 320, ELEM_PAD = 320;
+  __device__ static __forceinline__ int ia(int f, int qx, int j, int k) {
+    return f * 64 + qx * 16 + (((j ^ qx) & 3) << 2) + ((k ^ qx) & 3);
+  }
+  __device__ static __forceinline__ int ib(int f, int qx, int qy, int k) {
+    return 128 + f * 64 + qx * 16 + (((qy ^ qx) & 3) << 2) + ((k ^ qx) & 3);
+  }
+  __device__ static __forceinline__ int parity_xor(int sub) { return (sub & 1) << 4; }
 };
 
 // ---- forward passes for component C -------------------------------------------------------
 template <int C, int P1, int Q1, bool USE_U, bool USE_C>
 __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e, const bool active,
-                                            const bool lane_ok, const int ta, const int tb,
+                                            const bool lane_ok, const int ta, const int tb, const int lx,
                                             double *__restrict__ sm, double (&U)[3][Q1],
                                             double (&CU)[3][Q1]) {
   using L = NDLayout<P1, Q1>;
@@ -202,7 +220,11 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
         // essential dofs are flagged in the gather index: read as zero (ParOperator's tx[ess] = 0)
         const int s = a.lidx_in[(size_t)e * P + off + i + ni * (ta + nj * tb)];
         const int d = s >= 0 ? s : -1 - s;
+#ifdef PA_ABLATION
+        const double xv = (a.dbg & 8) ? (double)d : ((d & kEssBit) ? 0.0 : a.x[d & ~kEssBit]);
+#else
         const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
+#endif
         val = s >= 0 ? xv : -xv;
       }
       u[i] = val;
@@ -216,8 +238,8 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
         if (DX) d += tab_odd<NC, Q1>(Gc, qx, i) * u[i];
       }
       if (lane_ok && act) {
-        sm[L::ia(0, qx, ta, tb)] = v;
-        if (DX) sm[L::ia(1, qx, ta, tb)] = d;
+        sm[L::ia(0, qx, ta, tb) ^ lx] = v;
+        if (DX) sm[L::ia(1, qx, ta, tb) ^ lx] = d;
       }
     }
   }
@@ -228,8 +250,8 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
     double v[nj], d[nj];
 #pragma unroll
     for (int j = 0; j < nj; j++) {
-      v[j] = sm[L::ia(0, ta, j, act ? tb : 0)];
-      if (DX) d[j] = sm[L::ia(1, ta, j, act ? tb : 0)];
+      v[j] = sm[L::ia(0, ta, j, act ? tb : 0) ^ lx];
+      if (DX) d[j] = sm[L::ia(1, ta, j, act ? tb : 0) ^ lx];
     }
 #pragma unroll
     for (int qy = 0; qy < Q1; qy++) {
@@ -241,9 +263,9 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
         if (DX) dv += tab_even<nj, Q1>(TY, qy, j) * d[j];
       }
       if (lane_ok && act) {
-        sm[L::ib(0, ta, qy, tb)] = vv;
-        if (DY) sm[L::ib(1, ta, qy, tb)] = vd;
-        if (DX) sm[L::ib(2, ta, qy, tb)] = dv;
+        sm[L::ib(0, ta, qy, tb) ^ lx] = vv;
+        if (DY) sm[L::ib(1, ta, qy, tb) ^ lx] = vd;
+        if (DX) sm[L::ib(2, ta, qy, tb) ^ lx] = dv;
       }
     }
   }
@@ -253,9 +275,9 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
     double vv[nk], vd[nk], dv[nk];
 #pragma unroll
     for (int k = 0; k < nk; k++) {
-      vv[k] = sm[L::ib(0, ta, tb, k)];
-      if (DY) vd[k] = sm[L::ib(1, ta, tb, k)];
-      if (DX) dv[k] = sm[L::ib(2, ta, tb, k)];
+      vv[k] = sm[L::ib(0, ta, tb, k) ^ lx];
+      if (DY) vd[k] = sm[L::ib(1, ta, tb, k) ^ lx];
+      if (DX) dv[k] = sm[L::ib(2, ta, tb, k) ^ lx];
     }
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
@@ -282,7 +304,7 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
 // ---- transposed passes for component C ------------------------------------------------------
 template <int C, int P1, int Q1, bool USE_U, bool USE_C, bool EVEC>
 __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e, const bool active,
-                                            const bool lane_ok, const int ta, const int tb,
+                                            const bool lane_ok, const int ta, const int tb, const int lx,
                                             double *__restrict__ sm, const double (&V)[3][Q1],
                                             const double (&CV)[3][Q1]) {
   using L = NDLayout<P1, Q1>;
@@ -316,9 +338,9 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
         if (DX) dv += tab_even<nk, Q1>(TZ, qz, k) * wdx;
       }
       if (lane_ok) {
-        sm[L::ib(0, ta, tb, k)] = vv;
-        if (DY) sm[L::ib(1, ta, tb, k)] = vd;
-        if (DX) sm[L::ib(2, ta, tb, k)] = dv;
+        sm[L::ib(0, ta, tb, k) ^ lx] = vv;
+        if (DY) sm[L::ib(1, ta, tb, k) ^ lx] = vd;
+        if (DX) sm[L::ib(2, ta, tb, k) ^ lx] = dv;
       }
     }
   }
@@ -329,9 +351,9 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
     double vv[Q1], vd[Q1], dv[Q1];
 #pragma unroll
     for (int qy = 0; qy < Q1; qy++) {
-      vv[qy] = sm[L::ib(0, ta, qy, act ? tb : 0)];
-      if (DY) vd[qy] = sm[L::ib(1, ta, qy, act ? tb : 0)];
-      if (DX) dv[qy] = sm[L::ib(2, ta, qy, act ? tb : 0)];
+      vv[qy] = sm[L::ib(0, ta, qy, act ? tb : 0) ^ lx];
+      if (DY) vd[qy] = sm[L::ib(1, ta, qy, act ? tb : 0) ^ lx];
+      if (DX) dv[qy] = sm[L::ib(2, ta, qy, act ? tb : 0) ^ lx];
     }
 #pragma unroll
     for (int j = 0; j < nj; j++) {
@@ -343,8 +365,8 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
         if (DX) d += tab_even<nj, Q1>(TY, qy, j) * dv[qy];
       }
       if (lane_ok && act) {
-        sm[L::ia(0, ta, j, tb)] = v;
-        if (DX) sm[L::ia(1, ta, j, tb)] = d;
+        sm[L::ia(0, ta, j, tb) ^ lx] = v;
+        if (DX) sm[L::ia(1, ta, j, tb) ^ lx] = d;
       }
     }
   }
@@ -355,8 +377,8 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
     double v[Q1], d[Q1];
 #pragma unroll
     for (int qx = 0; qx < Q1; qx++) {
-      v[qx] = sm[L::ia(0, qx, act ? ta : 0, act ? tb : 0)];
-      if (DX) d[qx] = sm[L::ia(1, qx, act ? ta : 0, act ? tb : 0)];
+      v[qx] = sm[L::ia(0, qx, act ? ta : 0, act ? tb : 0) ^ lx];
+      if (DX) d[qx] = sm[L::ia(1, qx, act ? ta : 0, act ? tb : 0) ^ lx];
     }
 #pragma unroll
     for (int i = 0; i < ni; i++) {
@@ -367,6 +389,12 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
         if (DX) r += tab_odd<NC, Q1>(Gc, qx, i) * d[qx];
       }
       if (active && act) {
+#ifdef PA_ABLATION
+        if (a.dbg & 1) {
+          asm volatile("" ::"v"(r));
+          continue;
+        }
+#endif
         if (EVEC) {
           // E-vector layout [e][C][i][j + nj k]: the lanes of an element store a contiguous run per
           // (C, i); signs and the sum over elements happen in et_gather_kernel
@@ -381,7 +409,7 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
   wave_sync();
 }
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 2;  // small workgroups pack the 160 KB LDS tighter (no workgroup barriers are used)
 
 // ISO: every material coefficient is a multiple of the identity (checked at creation), so D needs
 // one scalar per context instead of a 3x3 matrix.
@@ -399,6 +427,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   const int e = (blockIdx.x * kWavesPerBlock + wave) * L::EPW + sub;
   const bool active = lane_ok && e < a.ne;
   double *sm = smem + (size_t)(wave * L::EPW + (lane_ok ? sub : 0)) * L::ELEM_PAD;
+  const int lx = L::parity_xor(sub);  // swizzled layouts: odd elements use the other half of the banks
 
   // Geometry (or packed q-data) of this lane's Q1 quadrature points: issue the loads now (the
   // dominant HBM stream) and consume them after the forward contraction.
@@ -411,7 +440,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
     for (int qz = 0; qz < Q1; qz++) {
       attr[qz] = 0;
 #pragma unroll
-      for (int c = 0; c < NG; c++) gd[qz][c] = g[c * Q + Q1 * Q1 * qz];
+      for (int c = 0; c < NG; c++) {
+#ifdef PA_ABLATION
+        if (a.dbg & 4) {
+          gd[qz][c] = 1.0 + 0.01 * c + 1e-3 * lane;
+          continue;
+        }
+#endif
+        gd[qz][c] = g[c * Q + Q1 * Q1 * qz];
+      }
     }
   } else {
     const double *g = a.geom + (size_t)(active ? e : 0) * 11 * Q + ta + Q1 * tb;
@@ -429,9 +466,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
 #pragma unroll
     for (int q = 0; q < Q1; q++) U[c][q] = 0.0, CU[c][q] = 0.0;
 
-  nd_fwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
-  nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
-  nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_fwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
+  nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
+  nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
 
   // D at the Q1 points of this lane's column (hcurl_33 / hdiv_33 / hdivmass_33)
 #pragma unroll
@@ -471,9 +508,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
     }
   }
 
-  nd_bwd_comp<0, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, sm, U, CU);
-  nd_bwd_comp<1, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, sm, U, CU);
-  nd_bwd_comp<2, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, sm, U, CU);
+  nd_bwd_comp<0, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
+  nd_bwd_comp<1, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
+  nd_bwd_comp<2, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
 }
 
 template <int P1, int Q1>
@@ -514,6 +551,9 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
   a.y = y;
   a.ye = ye;
   fill_tab(so, a.tab);
+#ifdef PA_ABLATION
+  a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
+#endif
   const int epb = kWavesPerBlock * L::EPW;
   const dim3 grid((so.ne + epb - 1) / epb), block(64 * kWavesPerBlock);
   const size_t lds = sizeof(double) * (size_t)epb * L::ELEM_PAD;
