@@ -1,5 +1,6 @@
 // C ABI of libpalace_amd.so (declared in include/palace_amd.h): object lifetime, descriptor
 // validation and set-up on the host; all arithmetic lives in the HIP kernels.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -209,47 +210,50 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     }
   so->d_lidx = dev_upload(lidx.data(), lidx.size());
   PA_REQUIRE(r.lsize < kEssBit, "too many local dofs for the index encoding");
+  PA_REQUIRE(P < 65536, "element too large for the 16-bit slot permutation");
+  // Sorted order of the element's entries (by global dof, stable): what E gathers and E^T stores
+  // in, so that one load/store instruction touches neighbouring dofs.
+  const size_t nnz = lidx.size();
+  std::vector<int32_t> sidx(nnz);
+  std::vector<uint16_t> perm(nnz);
+  {
+    std::vector<int> ord(P);
+    for (int e = 0; e < r.num_elem; e++) {
+      const int32_t *le = &lidx[(size_t)e * P];
+      for (int l = 0; l < P; l++) ord[l] = l;
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int c2) {
+        const int da = le[a] >= 0 ? le[a] : -1 - le[a], dc = le[c2] >= 0 ? le[c2] : -1 - le[c2];
+        return da < dc;
+      });
+      for (int m = 0; m < P; m++) {
+        sidx[(size_t)e * P + m] = le[ord[m]];
+        perm[(size_t)e * P + m] = (uint16_t)ord[m];
+      }
+    }
+  }
+  so->d_sidx = dev_upload(sidx.data(), nnz);
+  so->d_perm = dev_upload(perm.data(), nnz);
   // transpose map for the gather form of E^T (counting sort by dof; element order preserved, so the
   // summation order of every dof is fixed) unless PALACE_AMD_SCATTER=atomic asks for the atomic form
   const char *mode = getenv("PALACE_AMD_SCATTER");
   if (!(mode && std::string(mode) == "atomic") || b.fe_type == PA_FE_H1) {
-    const size_t nnz = lidx.size();
     std::vector<int32_t> tptr((size_t)r.lsize + 1, 0), tent(nnz);
     for (size_t k = 0; k < nnz; k++) {
-      const int32_t s = lidx[k];
+      const int32_t s = sidx[k];
       tptr[(size_t)(s >= 0 ? s : -1 - s) + 1]++;
     }
     for (int d = 0; d < r.lsize; d++) tptr[d + 1] += tptr[d];
     std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
-    // position of tensor dof l inside an element's E-vector record (the layout the element kernel
-    // stores coalesced): H(curl): [C][i][j + nj k]; H1: tensor order itself
-    std::vector<int32_t> epos(P);
-    if (b.fe_type == PA_FE_HCURL) {
-      const int p = b.order, ncl = p + 1;
-      for (int C = 0; C < 3; C++) {
-        const int ni = C == 0 ? p : ncl, nj = C == 1 ? p : ncl, nk = C == 2 ? p : ncl;
-        for (int k = 0; k < nk; k++)
-          for (int j = 0; j < nj; j++)
-            for (int i = 0; i < ni; i++)
-              epos[C * p * ncl * ncl + i + ni * (j + nj * k)] = C * p * ncl * ncl + i * (nj * nk) + j + nj * k;
-      }
-    } else {
-      const int ncl = b.order + 1;
-      for (int k = 0; k < ncl; k++)
-        for (int j = 0; j < ncl; j++)
-          for (int i = 0; i < ncl; i++) epos[i + ncl * (j + ncl * k)] = i * (ncl * ncl) + j + ncl * k;
-    }
-    for (size_t k = 0; k < nnz; k++) {
-      const int32_t s = lidx[k];
+    for (size_t k = 0; k < nnz; k++) {  // E-vector position of a sorted entry is its own index
+      const int32_t s = sidx[k];
       const int d = s >= 0 ? s : -1 - s;
-      const int32_t pos = (int32_t)((k / P) * P + epos[k % P]);
-      tent[fill[d]++] = s >= 0 ? pos : -1 - pos;
+      tent[fill[d]++] = s >= 0 ? (int32_t)k : -1 - (int32_t)k;
     }
     so->d_tptr = dev_upload(tptr.data(), tptr.size());
     so->d_tent = dev_upload(tent.data(), tent.size());
     so->d_ye = dev_alloc<double>(nnz);
   }
-  so->h_lidx = std::move(lidx);
+  so->h_sidx = std::move(sidx);
 
   so->ctx_blob.assign((const uint8_t *)ctx, (const uint8_t *)ctx + ctx_size);
   PA_REQUIRE(ctx && ctx_size >= 24 && ctx_size % 8 == 0, "coefficient context missing or malformed");
@@ -307,7 +311,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
 static void free_sub(SubOp *so) {
   if (!so) return;
   hipFree(so->d_lidx);
-  hipFree(so->d_lidx_bc);
+  hipFree(so->d_sidx), hipFree(so->d_sidx_bc), hipFree(so->d_perm);
   hipFree(so->d_ye), hipFree(so->d_tptr), hipFree(so->d_tent);
   if (so->qd && --so->qd->refcount == 0) {
     hipFree(so->qd->d);
@@ -474,13 +478,13 @@ int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
       flag[ess[i]] = 1;
     }
     for (SubOp *so : op->subs) {
-      std::vector<int32_t> bc(so->h_lidx);
+      std::vector<int32_t> bc(so->h_sidx);
       for (auto &s : bc) {
         const int d = s >= 0 ? s : -1 - s;
         if (flag[d]) s = s >= 0 ? (d | kEssBit) : -1 - (d | kEssBit);
       }
-      hipFree(so->d_lidx_bc);
-      so->d_lidx_bc = dev_upload(bc.data(), bc.size());
+      hipFree(so->d_sidx_bc);
+      so->d_sidx_bc = dev_upload(bc.data(), bc.size());
     }
     op->has_essential = true;
   });

@@ -29,7 +29,8 @@ __device__ __forceinline__ double h1_odd(const double *H, const int q, const int
 template <int P1, int Q1>
 struct H1Args {
   int ne;
-  const int32_t *lidx_in;  // tensor-order index, kEssBit = read as zero
+  const int32_t *sidx_in;  // sorted-order index (see pa_nd_hex.hip), kEssBit = read as zero
+  const uint16_t *perm;    // tensor-order slot of sorted entry m
   const double *geom;
   const double *qdata;
   const double *x;
@@ -114,20 +115,32 @@ __global__ __launch_bounds__(64 * kH1Waves, 2) void h1_hex_apply_kernel(const H1
     }
   }
 
+  // E: sorted-order gather staged through LDS into tensor order
+  constexpr int NPL = (P + L::T - 1) / L::T;
+  int lp[NPL];
+#pragma unroll
+  for (int r = 0; r < NPL; r++) {
+    const int m = t + L::T * r;
+    lp[r] = 0;
+    if (active && m < P) {
+      const int s = a.sidx_in[(size_t)e * P + m];
+      lp[r] = a.perm[(size_t)e * P + m];
+      sm[lp[r]] = (s & kEssBit) ? 0.0 : a.x[s & ~kEssBit];
+    }
+  }
+  h1_wave_sync();
+  double u[NC];
+  {
+    const bool act = ta < NC && tb < NC;
+#pragma unroll
+    for (int i = 0; i < NC; i++) u[i] = act ? sm[i + NC * (ta + NC * tb)] : 0.0;
+  }
+  h1_wave_sync();
+
   double V[Q1], GV[3][Q1];
   // ---- forward: pass X, lane (j, k)
   {
     const bool act = ta < NC && tb < NC;
-    double u[NC];
-#pragma unroll
-    for (int i = 0; i < NC; i++) {
-      double val = 0.0;
-      if (active && act) {
-        const int s = a.lidx_in[(size_t)e * P + i + NC * (ta + NC * tb)];
-        val = (s & kEssBit) ? 0.0 : a.x[s & ~kEssBit];
-      }
-      u[i] = val;
-    }
 #pragma unroll
     for (int qx = 0; qx < Q1; qx++) {
       double v = 0.0, d = 0.0;
@@ -285,8 +298,22 @@ __global__ __launch_bounds__(64 * kH1Waves, 2) void h1_hex_apply_kernel(const H1
         r += h1_even<NC, Q1>(Bc, qx, i) * v[qx];
         if (USE_G) r += h1_odd<NC, Q1>(Gc, qx, i) * d[qx];
       }
-      if (active && act) a.ye[(size_t)e * P + i * (NC * NC) + ta + NC * tb] = r;
+      u[i] = r;
     }
+  }
+  h1_wave_sync();
+  // E^T, first half: results into tensor order in LDS, then out in sorted order (coalesced)
+  {
+    const bool act = lane_ok && ta < NC && tb < NC;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+      if (act) sm[i + NC * (ta + NC * tb)] = u[i];
+  }
+  h1_wave_sync();
+#pragma unroll
+  for (int r = 0; r < NPL; r++) {
+    const int m = t + L::T * r;
+    if (active && m < P) a.ye[(size_t)e * P + m] = sm[lp[r]];
   }
 }
 
@@ -296,7 +323,8 @@ static void h1_launch_pq(const SubOp &so, const double *x, bool masked, hipStrea
   constexpr int QH = H1Tab<P1, Q1>::QH;
   H1Args<P1, Q1> a;
   a.ne = so.ne;
-  a.lidx_in = (masked && so.d_lidx_bc) ? so.d_lidx_bc : so.d_lidx;
+  a.sidx_in = (masked && so.d_sidx_bc) ? so.d_sidx_bc : so.d_sidx;
+  a.perm = so.d_perm;
   a.geom = so.geom->d_geom;
   a.qdata = so.qd ? so.qd->d : nullptr;
   a.x = x;

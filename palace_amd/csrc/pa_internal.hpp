@@ -107,8 +107,11 @@ struct SubOp {
   int qf = 0;
   uint32_t trial_ops = 0, test_ops = 0;
   int32_t *d_lidx = nullptr;  // [ne][P] signed tensor-order index: >=0 dof, <0 => -(1+dof) flipped
-  int32_t *d_lidx_bc = nullptr;  // copy with kEssBit on essential dofs (pa_op_set_essential)
-  std::vector<int32_t> h_lidx;   // host copy (needed to build d_lidx_bc)
+  // sorted order of E / E^T: entry m of element e is its m-th smallest global dof
+  int32_t *d_sidx = nullptr;     // [ne][P] signed sorted index
+  int32_t *d_sidx_bc = nullptr;  // copy with kEssBit on essential dofs (pa_op_set_essential)
+  uint16_t *d_perm = nullptr;    // [ne][P] tensor-order slot of sorted entry m
+  std::vector<int32_t> h_sidx;   // host copy (needed to build d_sidx_bc)
   // E^T as a gather (default): E-vector scratch and the CSR transpose of lidx
   double *d_ye = nullptr;      // [ne][P]
   int32_t *d_tptr = nullptr;   // [lsize + 1]

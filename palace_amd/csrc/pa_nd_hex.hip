@@ -52,8 +52,12 @@ __device__ __forceinline__ double tab_odd(const double *H, const int q, const in
 template <int P1, int Q1>
 struct NDArgs {
   int ne;
-  const int32_t *lidx;     // signed tensor-order index (scatter side)
-  const int32_t *lidx_in;  // the same with kEssBit set on dofs to be read as zero (gather side)
+  // E / E^T run in "sorted order": entry m of an element is its m-th smallest global dof, so the
+  // lanes of one load / store instruction touch neighbouring dofs (few cache lines) instead of one
+  // line per lane; perm[m] is the tensor-order slot of entry m (staging through LDS).
+  const int32_t *sidx;     // signed sorted index (scatter side, atomic form only)
+  const int32_t *sidx_in;  // the same with kEssBit set on dofs to be read as zero (gather side)
+  const uint16_t *perm;    // [ne][P] tensor-order slot of sorted entry m
   const double *geom;
   const double *qdata;  // packed symmetric D, [ne][NG][Q] (QD == true)
   const double *x;
@@ -196,8 +200,8 @@ struct NDLayout<3, 4> {
 template <int C, int P1, int Q1, bool USE_U, bool USE_C>
 __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e, const bool active,
                                             const bool lane_ok, const int ta, const int tb, const int lx,
-                                            double *__restrict__ sm, double (&U)[3][Q1],
-                                            double (&CU)[3][Q1]) {
+                                            double *__restrict__ sm, const double (&u)[P1 + 1],
+                                            double (&U)[3][Q1], double (&CU)[3][Q1]) {
   using L = NDLayout<P1, Q1>;
   constexpr int NC = L::NC;
   constexpr int P = 3 * P1 * NC * NC;
@@ -212,23 +216,6 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
   // pass X: lane (j, k) = (ta, tb)
   {
     const bool act = ta < nj && tb < nk;
-    double u[ni];
-#pragma unroll
-    for (int i = 0; i < ni; i++) {
-      double val = 0.0;
-      if (active && act) {
-        // essential dofs are flagged in the gather index: read as zero (ParOperator's tx[ess] = 0)
-        const int s = a.lidx_in[(size_t)e * P + off + i + ni * (ta + nj * tb)];
-        const int d = s >= 0 ? s : -1 - s;
-#ifdef PA_ABLATION
-        const double xv = (a.dbg & 8) ? (double)d : ((d & kEssBit) ? 0.0 : a.x[d & ~kEssBit]);
-#else
-        const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
-#endif
-        val = s >= 0 ? xv : -xv;
-      }
-      u[i] = val;
-    }
 #pragma unroll
     for (int qx = 0; qx < Q1; qx++) {
       double v = 0.0, d = 0.0;
@@ -302,11 +289,11 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
 }
 
 // ---- transposed passes for component C ------------------------------------------------------
-template <int C, int P1, int Q1, bool USE_U, bool USE_C, bool EVEC>
+template <int C, int P1, int Q1, bool USE_U, bool USE_C>
 __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e, const bool active,
                                             const bool lane_ok, const int ta, const int tb, const int lx,
-                                            double *__restrict__ sm, const double (&V)[3][Q1],
-                                            const double (&CV)[3][Q1]) {
+                                            double *__restrict__ sm, double (&rout)[P1 + 1],
+                                            const double (&V)[3][Q1], const double (&CV)[3][Q1]) {
   using L = NDLayout<P1, Q1>;
   constexpr int NC = L::NC;
   constexpr int P = 3 * P1 * NC * NC;
@@ -388,22 +375,7 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
         r += tab_even<ni, Q1>(TX, qx, i) * v[qx];
         if (DX) r += tab_odd<NC, Q1>(Gc, qx, i) * d[qx];
       }
-      if (active && act) {
-#ifdef PA_ABLATION
-        if (a.dbg & 1) {
-          asm volatile("" ::"v"(r));
-          continue;
-        }
-#endif
-        if (EVEC) {
-          // E-vector layout [e][C][i][j + nj k]: the lanes of an element store a contiguous run per
-          // (C, i); signs and the sum over elements happen in et_gather_kernel
-          a.ye[(size_t)e * P + off + i * (nj * nk) + ta + nj * tb] = r;
-        } else {
-          const int s = a.lidx[(size_t)e * P + off + i + ni * (ta + nj * tb)];
-          unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? r : -r);
-        }
-      }
+      rout[i] = r;
     }
   }
   wave_sync();
@@ -460,15 +432,47 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
     }
   }
 
+  // E: sorted-order gather, staged through LDS into tensor order
+  constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + L::T - 1) / L::T;
+  int lp[NPL];
+#pragma unroll
+  for (int r = 0; r < NPL; r++) {
+    const int m = t + L::T * r;
+    lp[r] = 0;
+    if (active && m < PP) {
+      const int s = a.sidx_in[(size_t)e * PP + m];
+      lp[r] = a.perm[(size_t)e * PP + m];
+      const int d = s >= 0 ? s : -1 - s;
+      // essential dofs are flagged in the gather index: read as zero (ParOperator's tx[ess] = 0)
+#ifdef PA_ABLATION
+      const double xv = (a.dbg & 8) ? (double)d : ((d & kEssBit) ? 0.0 : a.x[d & ~kEssBit]);
+#else
+      const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
+#endif
+      sm[lp[r]] = s >= 0 ? xv : -xv;
+    }
+  }
+  wave_sync();
+  double uin[3][NC];
+#pragma unroll
+  for (int C = 0; C < 3; C++) {
+    const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
+    const bool act = ta < nj && tb < nk;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+      uin[C][i] = (act && i < ni) ? sm[C * P1 * NC * NC + i + ni * (ta + nj * tb)] : 0.0;
+  }
+  wave_sync();
+
   double U[3][Q1], CU[3][Q1];
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
     for (int q = 0; q < Q1; q++) U[c][q] = 0.0, CU[c][q] = 0.0;
 
-  nd_fwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
-  nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
-  nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
+  nd_fwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, uin[0], U, CU);
+  nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, uin[1], U, CU);
+  nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, uin[2], U, CU);
 
   // D at the Q1 points of this lane's column (hcurl_33 / hdiv_33 / hdivmass_33)
 #pragma unroll
@@ -508,9 +512,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
     }
   }
 
-  nd_bwd_comp<0, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
-  nd_bwd_comp<1, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
-  nd_bwd_comp<2, P1, Q1, USE_U, USE_C, EVEC>(a, e, active, lane_ok, ta, tb, lx, sm, U, CU);
+  nd_bwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, uin[0], U, CU);
+  nd_bwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, uin[1], U, CU);
+  nd_bwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, uin[2], U, CU);
+
+  // E^T, first half: element-local results back into tensor order in LDS, then out in sorted order
+  // (coalesced E-vector store; signs and the sum over elements happen in et_gather_kernel)
+#pragma unroll
+  for (int C = 0; C < 3; C++) {
+    const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
+    const bool act = lane_ok && ta < nj && tb < nk;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+      if (act && i < ni) sm[C * P1 * NC * NC + i + ni * (ta + nj * tb)] = uin[C][i];
+  }
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < NPL; r++) {
+    const int m = t + L::T * r;
+    if (active && m < PP) {
+      const double v = sm[lp[r]];
+#ifdef PA_ABLATION
+      if (a.dbg & 1) {
+        asm volatile("" ::"v"(v));
+        continue;
+      }
+#endif
+      if (EVEC) {
+        a.ye[(size_t)e * PP + m] = v;
+      } else {
+        const int s = a.sidx[(size_t)e * PP + m];
+        unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? v : -v);
+      }
+    }
+  }
 }
 
 template <int P1, int Q1>
@@ -543,8 +578,9 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
   using L = NDLayout<P1, Q1>;
   NDArgs<P1, Q1> a;
   a.ne = so.ne;
-  a.lidx = so.d_lidx;
-  a.lidx_in = (masked && so.d_lidx_bc) ? so.d_lidx_bc : so.d_lidx;
+  a.sidx = so.d_sidx;
+  a.sidx_in = (masked && so.d_sidx_bc) ? so.d_sidx_bc : so.d_sidx;
+  a.perm = so.d_perm;
   a.geom = so.geom->d_geom;
   a.qdata = so.qd ? so.qd->d : nullptr;
   a.x = x;
