@@ -61,6 +61,13 @@ typedef struct {
   int32_t lsize;
   const int32_t *offsets;
   const uint8_t *orients;
+  /* CeedElemRestrictionCreateCurlOriented (restriction.cpp:299-369): the tridiagonal dof
+   * transformation of element e, curl_orients[3*(j + elem_size*e) + {0,1,2}] = {sub, main, super}
+   * diagonal of row j, dof signs folded in:
+   *   u_e[j] = T[3j] x[off[j-1]] + T[3j+1] x[off[j]] + T[3j+2] x[off[j+1]],  E^T applies T^T.
+   * NULL unless the space has a non-identity DofTransformation (ND on tetrahedra / prisms, p >= 2).
+   * Only the dense-table path (pa_op_add_sub_dense) accepts it; `orients` must then be NULL. */
+  const int8_t *curl_orients;
 } pa_restriction_desc;
 
 /*
@@ -117,6 +124,42 @@ typedef struct {
   const double *qweight1d;
 } pa_mesh_desc;
 
+/*
+ * Basis B/G of a non-tensor element (tetrahedra, prisms, ... and hexahedra when the caller only has
+ * the dense tables): exactly what InitNonTensorBasis hands to CeedBasisCreateHcurl / CeedBasisCreateH1
+ * (fem/libceed/basis.cpp:40-85), from MFEM's DofToQuad::FULL tables.
+ *   interp [qcomp*Q][P] row-major, row = c*Q + q ; qcomp = 3 for HCURL, 1 for H1
+ *   deriv  [3*Q][P]     curl (HCURL) or gradient (H1) in reference coordinates
+ */
+typedef struct {
+  int32_t fe_type;
+  int32_t num_dofs;  /* P */
+  int32_t num_qpts;  /* Q */
+  const double *interp;
+  const double *deriv;
+} pa_dense_basis_desc;
+
+/*
+ * Mesh geometry of a non-tensor element block: nodal H1 mesh space given by the dense gradient
+ * table of its nodal basis at the quadrature points (the non-tensor branch of what fem/mesh.cpp:146-209
+ * passes to AssembleCeedGeometryData).
+ *   node_offsets[n + npe*e]   node id of local mesh node n of element e
+ *   nodes[3*id + c]           coordinates (byVDIM)
+ *   mesh_grad[(d*Q + q)*npe + n]  d phi_n / d xi_d at point q
+ *   qweight[q]
+ */
+typedef struct {
+  int32_t num_elem;
+  int32_t nodes_per_elem;
+  int32_t num_qpts;
+  int32_t num_nodes;
+  const int32_t *node_offsets;
+  const double *nodes;
+  const int32_t *attr;
+  const double *mesh_grad;
+  const double *qweight;
+} pa_mesh_dense_desc;
+
 /* --- library ------------------------------------------------------------------------------- */
 const char *pa_last_error(void);
 const char *pa_version(void);
@@ -127,6 +170,11 @@ int pa_device_count(void);
  *     (fem/libceed/integrator.cpp:335-421, fem/qfunctions/33/geom_33_qf.h:9-33).
  *     Result: double[num_elem][11][Q] = {attr, w detJ, adj(J)^T/detJ (col-major)} in HBM. */
 int pa_geom_create(const pa_mesh_desc *mesh, void *stream, pa_geom **geom);
+/* The same for a non-tensor element block.  The data is kept element-blocked for the MFMA kernel:
+ * double[ceil(ne/16)][11][Qpad][16] (Qpad = Q rounded up to 16), entry (e, c, q) at
+ * ((e/16 * 11 + c) * Qpad + q) * 16 + e%16; pa_geom_layout reports {ne, Q, Qpad, block}. */
+int pa_geom_create_dense(const pa_mesh_dense_desc *mesh, void *stream, pa_geom **geom);
+int pa_geom_layout(const pa_geom *geom, int32_t out[4]);
 int pa_geom_retain(pa_geom *geom);
 void pa_geom_destroy(pa_geom *geom);
 /* Device pointer to the geometry data and its length in doubles (tests / diagnostics). */
@@ -143,6 +191,12 @@ int pa_op_create(int32_t height, int32_t width, pa_op **op);
 int pa_op_add_sub(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
                   const pa_basis_desc *basis, int32_t qfunction, const void *ctx, size_t ctx_size,
                   uint32_t trial_ops, uint32_t test_ops);
+/* The same with dense basis tables (any element type): E (plain, oriented or curl-oriented), the
+ * dense [qcomp*Q x P] contractions on the FP64 matrix cores (v_mfma_f64_16x16x4), D, and the
+ * transposes.  `geom` must come from pa_geom_create_dense. */
+int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
+                        const pa_dense_basis_desc *basis, int32_t qfunction, const void *ctx,
+                        size_t ctx_size, uint32_t trial_ops, uint32_t test_ops);
 /* Operator::Finalize(), operator.cpp:89-101. */
 int pa_op_finalize(pa_op *op);
 /* CeedOperatorCoarsen (operator.cpp:525-585): same QFunctions, contexts and geometry data as

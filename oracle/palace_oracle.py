@@ -331,11 +331,16 @@ class CeedOperatorOracle:
     interp / deriv dense tables, geom [NE, 11, Q], a QFunction name and its context(s).
     """
 
-    def __init__(self, lsize, offsets, orients, interp, deriv, geom, qf, ctx, ctx2=None, vector_fe=True):
+    def __init__(self, lsize, offsets, orients, interp, deriv, geom, qf, ctx, ctx2=None, vector_fe=True,
+                 curl_orients=None):
         self.lsize = int(lsize)
         self.off = np.asarray(offsets)
         self.NE, self.P = self.off.shape
         self.sgn = None if orients is None else np.where(np.asarray(orients), -1.0, 1.0)
+        # CeedElemRestrictionCreateCurlOriented (restriction.cpp:299-369): int8 [NE, P, 3] rows
+        # {sub, main, super} of the element's tridiagonal dof transformation T_e
+        self.cor = None if curl_orients is None else np.asarray(curl_orients, dtype=np.float64).reshape(self.NE, self.P, 3)
+        assert self.sgn is None or self.cor is None
         self.Q = geom.shape[2]
         self.vector_fe = vector_fe
         if vector_fe:
@@ -347,7 +352,25 @@ class CeedOperatorOracle:
 
     def _restrict(self, x, sl):
         u = x[self.off[sl]]
+        if self.cor is not None:  # u_e = T_e x_e  [libCEED CeedElemRestrictionApply, NOTRANSPOSE]
+            t = self.cor[sl]
+            v = t[:, :, 1] * u
+            v[:, 1:] += t[:, 1:, 0] * u[:, :-1]
+            v[:, :-1] += t[:, :-1, 2] * u[:, 1:]
+            return v
         return u if self.sgn is None else u * self.sgn[sl]
+
+    def _restrict_t(self, ve, sl, unsigned=False):
+        """Element-local part of E^T (before the scatter-add): T_e^T v_e, or the signs."""
+        if self.cor is not None:
+            t = np.abs(self.cor[sl]) if unsigned else self.cor[sl]
+            w = t[:, :, 1] * ve
+            w[:, :-1] += t[:, 1:, 0] * ve[:, 1:]
+            w[:, 1:] += t[:, :-1, 2] * ve[:, :-1]
+            return w
+        if self.sgn is None or unsigned:
+            return ve
+        return ve * self.sgn[sl]
 
     def _qfunction(self, geom, ue):
         """B, D, B^T on element-local vectors ue [ne, P] -> ve [ne, P]."""
@@ -389,9 +412,7 @@ class CeedOperatorOracle:
         """CeedOperatorApplyAdd."""
         for a in range(0, self.NE, chunk):
             sl = slice(a, min(self.NE, a + chunk))
-            ve = self._qfunction(self.geom[sl], self._restrict(x, sl))
-            if self.sgn is not None:
-                ve = ve * self.sgn[sl]
+            ve = self._restrict_t(self._qfunction(self.geom[sl], self._restrict(x, sl)), sl)
             np.add.at(y, self.off[sl].ravel(), ve.ravel())
         return y
 
@@ -405,7 +426,24 @@ class CeedOperatorOracle:
         if self.sgn is not None:
             s = self.sgn[sl]
             Ae = Ae * s[:, :, None] * s[:, None, :]
+        if self.cor is not None:  # T_e^T A_e T_e
+            t = self.cor[sl]
+            T = np.zeros((ne, self.P, self.P))
+            r = np.arange(self.P)
+            T[:, r, r] = t[:, :, 1]
+            T[:, r[1:], r[:-1]] = t[:, 1:, 0]
+            T[:, r[:-1], r[1:]] = t[:, :-1, 2]
+            Ae = np.einsum("eai,eab,ebj->eij", T, Ae, T)
         return Ae
+
+    def raw_element_diagonals(self, sl=slice(None)):
+        """diag(B^T D B) per element, before any restriction."""
+        ne = self.geom[sl].shape[0]
+        I = np.eye(self.P)
+        d = np.empty((ne, self.P))
+        for j in range(self.P):
+            d[:, j] = self._qfunction(self.geom[sl], np.broadcast_to(I[j], (ne, self.P)))[:, j]
+        return d
 
     def assemble_sparse(self):
         import scipy.sparse as sp
@@ -430,8 +468,14 @@ class CeedOperatorOracle:
         d = np.zeros(self.lsize)
         for a in range(0, self.NE, 256):
             sl = slice(a, min(self.NE, a + 256))
-            Ae = self.element_matrices(sl)
-            np.add.at(d, self.off[sl].ravel(), np.einsum("ejj->ej", Ae).ravel())
+            if self.cor is not None:
+                # libCEED pushes the element diagonals through the transpose of the UNSIGNED copy of the
+                # restriction (CeedElemRestrictionCreateUnsignedCopy in CeedOperatorLinearAssembleAddDiagonal
+                # [external, published behaviour]): |T_e|^T diag(B^T D B), not diag(T_e^T A_e T_e)
+                de = self._restrict_t(self.raw_element_diagonals(sl), sl, unsigned=True)
+            else:
+                de = np.einsum("ejj->ej", self.element_matrices(sl))
+            np.add.at(d, self.off[sl].ravel(), de.ravel())
         return d
 
 

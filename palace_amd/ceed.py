@@ -105,6 +105,76 @@ class GeomFactorData:
             pass
 
 
+class DenseGeomFactorData:
+    """ceed::CeedGeomFactorData for one NON-tensor element block (tetrahedra, ...): the mesh nodal basis
+    enters through its dense gradient table at the quadrature points (fem/mesh.cpp:146-209 with a
+    non-tensor mesh basis).  elem_nodes [ne, npe], nodes [nn, 3], attr [ne] (1-based),
+    mesh_grad [3, Q, npe], qweight [Q]."""
+
+    def __init__(self, elem_nodes, nodes, attr, mesh_grad, qweight):
+        self.ne, self.npe = elem_nodes.shape
+        self.Q = len(qweight)
+        self._keep = dict(off=np.ascontiguousarray(elem_nodes, dtype=np.int32),
+                          nodes=np.ascontiguousarray(nodes, dtype=np.float64),
+                          attr=np.ascontiguousarray(attr, dtype=np.int32),
+                          grad=np.ascontiguousarray(mesh_grad, dtype=np.float64),
+                          w=np.ascontiguousarray(qweight, dtype=np.float64))
+        k = self._keep
+        assert k["grad"].shape == (3, self.Q, self.npe)
+        desc = _lib.MeshDenseDesc(self.ne, self.npe, self.Q, k["nodes"].shape[0], _ptr(k["off"]), _ptr(k["nodes"]),
+                                  _ptr(k["attr"]), _ptr(k["grad"]), _ptr(k["w"]))
+        self.handle = C.c_void_p()
+        _lib.check(_lib.load().pa_geom_create_dense(C.byref(desc), _stream(), C.byref(self.handle)))
+
+    def to_numpy(self):
+        """The geometry data in the reference layout [ne][11][Q] (undoing the 16-element blocking)."""
+        import torch
+
+        L = _lib.load()
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(L.pa_geom_data(self.handle, C.byref(p), C.byref(n)))
+        lay = (C.c_int32 * 4)()
+        _lib.check(L.pa_geom_layout(self.handle, lay))
+        ne, Q, Qpad, eb = list(lay)
+
+        class _View:
+            __cuda_array_interface__ = dict(shape=(n.value,), typestr="<f8", data=(p.value, False), version=2)
+
+        torch.cuda.synchronize()
+        raw = torch.as_tensor(_View(), device="cuda").cpu().numpy().reshape(-1, 11, Qpad, eb)
+        return np.ascontiguousarray(raw.transpose(0, 3, 1, 2).reshape(-1, 11, Qpad)[:ne, :, :Q])
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().pa_geom_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class DenseBlock:
+    """What Palace hands to libCEED for one (geometry, space) pair on the non-tensor path: the native
+    restriction (fem/libceed/restriction.cpp:207-385: offsets + bool orients, or + int8 tridiagonal
+    curl_orients [ne, P, 3]) and the dense basis tables (fem/libceed/basis.cpp:40-85:
+    interp [qcomp, Q, P], deriv [3, Q, P])."""
+
+    def __init__(self, fe_type, lsize, offsets, interp, deriv, orients=None, curl_orients=None):
+        self.fe_type, self.lsize = fe_type, int(lsize)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        self.ne, self.P = self.offsets.shape
+        self.orients = None if orients is None else np.ascontiguousarray(orients, dtype=np.uint8)
+        self.curl_orients = None if curl_orients is None else np.ascontiguousarray(curl_orients, dtype=np.int8)
+        self.interp = None if interp is None else np.ascontiguousarray(interp, dtype=np.float64)
+        self.deriv = None if deriv is None else np.ascontiguousarray(deriv, dtype=np.float64)
+        self.Q = (self.deriv if self.deriv is not None else self.interp).shape[-2]
+
+    def descs(self):
+        r = _lib.RestrictionDesc(self.ne, self.P, self.lsize, _ptr(self.offsets), _ptr(self.orients),
+                                 _ptr(self.curl_orients))
+        b = _lib.DenseBasisDesc(self.fe_type, self.P, self.Q, _ptr(self.interp), _ptr(self.deriv))
+        return r, b
+
+
 def _basis_desc(space, q1d, dense=None):
     p = space.p
     t = Tables1D(p, q1d)
@@ -152,6 +222,15 @@ class Operator:
         _lib.check(_lib.load().pa_op_add_sub(self.handle, geom.handle, C.byref(r), C.byref(b),
                                              C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes),
                                              C.c_uint32(ops), C.c_uint32(ops)))
+        return self
+
+    def add_dense_integrator(self, geom: DenseGeomFactorData, block: DenseBlock, qf, ctx_blob, ops):
+        """AddSubOperator for a non-tensor element block (dense tables on the FP64 matrix cores)."""
+        r, b = block.descs()
+        ctx = np.ascontiguousarray(ctx_blob)
+        _lib.check(_lib.load().pa_op_add_sub_dense(self.handle, geom.handle, C.byref(r), C.byref(b),
+                                                   C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes),
+                                                   C.c_uint32(ops), C.c_uint32(ops)))
         return self
 
     def finalize(self):

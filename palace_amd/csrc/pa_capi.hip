@@ -14,8 +14,10 @@ void set_error(const std::string &msg) { g_error = msg; }
 
 static void require_device() {
   int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
-    throw Error("no HIP device visible: libpalace_amd has no CPU fallback");
+  const hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess || n == 0)
+    throw Error(std::string("no HIP device visible: libpalace_amd has no CPU fallback (hipGetDeviceCount: ") +
+                hipGetErrorString(err) + ", " + std::to_string(n) + " devices)");
 }
 
 // coeff_qf.h:7-45 — [nattr][attr->mat ...][nmat][nmat*dim*dim doubles]; 8-byte slots.
@@ -127,6 +129,8 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
                        QData *shared_qd = nullptr) {
   require_device();
   PA_REQUIRE(geom && geom->d_geom, "geometry data missing");
+  PA_REQUIRE(geom->eb == 0, "geometry data of a dense element block: use pa_op_add_sub_dense");
+  PA_REQUIRE(!r.curl_orients, "the curl-oriented restriction needs the dense-table path (pa_op_add_sub_dense)");
   PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_H1, "unknown finite element type");
   PA_REQUIRE(b.order >= 1 && b.order + 1 <= kMaxP1 + 1, "unsupported element order");
   PA_REQUIRE(b.q1d == geom->q1d, "basis and geometry data use different quadrature rules");
@@ -328,7 +332,7 @@ static void free_sub(SubOp *so) {
 // separate memset when E^T runs as a gather).
 static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s, bool masked = false) {
   PA_REQUIRE(op && x && y, "null argument");
-  PA_REQUIRE(!op->subs.empty(), "operator has no sub-operators");
+  PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty(), "operator has no sub-operators");
   PA_REQUIRE(x != y, "in-place apply is not supported");
   bool first = true;
   for (const SubOp *so : op->subs) {
@@ -344,6 +348,11 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
       launch_h1_hex_apply(*so, x, masked, s);
       launch_et_gather(*so, y, !(overwrite && first), s);
     }
+    first = false;
+  }
+  for (const DenseSub *ds : op->dsubs) {
+    launch_dense_apply(*ds, x, masked, s);
+    launch_dense_gather(*ds, y, !(overwrite && first), s);
     first = false;
   }
 }
@@ -384,6 +393,28 @@ int pa_geom_create(const pa_mesh_desc *mesh, void *stream, pa_geom **geom) {
   });
 }
 
+int pa_geom_create_dense(const pa_mesh_dense_desc *mesh, void *stream, pa_geom **geom) {
+  return guarded([&] {
+    require_device();
+    PA_REQUIRE(mesh && geom, "null argument");
+    auto *g = new pa_geom;
+    try {
+      launch_geom_dense(*mesh, *g, (hipStream_t)stream);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *geom = g;
+  });
+}
+
+int pa_geom_layout(const pa_geom *geom, int32_t out[4]) {
+  return guarded([&] {
+    PA_REQUIRE(geom && out, "null argument");
+    out[0] = geom->ne, out[1] = geom->Q, out[2] = geom->eb ? geom->Qpad : geom->Q, out[3] = geom->eb;
+  });
+}
+
 int pa_geom_retain(pa_geom *geom) {
   return guarded([&] {
     PA_REQUIRE(geom, "null argument");
@@ -403,7 +434,8 @@ int pa_geom_data(const pa_geom *geom, const double **dev_ptr, size_t *count) {
   return guarded([&] {
     PA_REQUIRE(geom && dev_ptr && count, "null argument");
     *dev_ptr = geom->d_geom;
-    *count = (size_t)geom->ne * 11 * geom->Q;
+    *count = geom->eb ? (size_t)((geom->ne + geom->eb - 1) / geom->eb) * 11 * geom->Qpad * geom->eb
+                      : (size_t)geom->ne * 11 * geom->Q;
   });
 }
 
@@ -428,10 +460,23 @@ int pa_op_add_sub(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
   });
 }
 
+int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
+                        const pa_dense_basis_desc *basis, int32_t qfunction, const void *ctx,
+                        size_t ctx_size, uint32_t trial_ops, uint32_t test_ops) {
+  return guarded([&] {
+    require_device();
+    PA_REQUIRE(op && geom && restr && basis, "null argument");
+    PA_REQUIRE(!op->finalized, "operator already finalized");
+    PA_REQUIRE(op->height == op->width, "only square operators are supported");
+    op->dsubs.push_back(
+        make_dense_sub(geom, *restr, *basis, qfunction, ctx, ctx_size, trial_ops, test_ops, op->height));
+  });
+}
+
 int pa_op_finalize(pa_op *op) {
   return guarded([&] {
     PA_REQUIRE(op, "null argument");
-    PA_REQUIRE(!op->subs.empty(), "operator has no sub-operators");
+    PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty(), "operator has no sub-operators");
     op->finalized = true;
   });
 }
@@ -486,6 +531,7 @@ int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
       hipFree(so->d_sidx_bc);
       so->d_sidx_bc = dev_upload(bc.data(), bc.size());
     }
+    for (DenseSub *ds : op->dsubs) dense_set_essential(*ds, flag);
     op->has_essential = true;
   });
 }
@@ -507,6 +553,7 @@ int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream) {
       else
         launch_h1_hex_diag(*so, diag, (hipStream_t)stream);
     }
+    for (const DenseSub *ds : op->dsubs) launch_dense_diag(*ds, diag, (hipStream_t)stream);
   });
 }
 
@@ -517,12 +564,15 @@ double pa_op_algorithmic_bytes(const pa_op *op) {
   if (!op) return 0.0;
   double bytes = 0.0;
   for (const SubOp *so : op->subs) bytes += (double)so->ne * ((double)so->Q * 11 * 8 + (double)so->P * 5);
+  for (const DenseSub *ds : op->dsubs)  // o = 3 for the curl-oriented restriction
+    bytes += (double)ds->ne * ((double)ds->Q * 11 * 8 + (double)ds->P * (ds->d_co ? 7 : 5));
   return bytes + 16.0 * op->height;
 }
 
 void pa_op_destroy(pa_op *op) {
   if (!op) return;
   for (SubOp *so : op->subs) free_sub(so);
+  for (DenseSub *ds : op->dsubs) free_dense_sub(ds);
   delete op;
 }
 

@@ -68,8 +68,11 @@ constexpr int kMaxP1 = 6;  // closed nodes p+1 <= 7
 constexpr int kMaxQ1 = 7;
 
 // Geometry factor data (fem/mesh.hpp:27-69): double[ne][11][Q] in HBM.
+// Dense (non-tensor) element blocks keep it element-blocked for the MFMA kernel instead:
+// double[ceil(ne/16)][11][Qpad][16] (eb == 16).
 struct Geom {
   int ne = 0, q1d = 0, Q = 0;
+  int eb = 0, Qpad = 0;
   double *d_geom = nullptr;
   int refcount = 1;
 };
@@ -123,6 +126,27 @@ struct SubOp {
   CoeffHost c0, c1;
 };
 
+// One sub-operator on a non-tensor element block (pa_dense.hip): dense tables on the FP64 matrix cores.
+struct DenseSub {
+  Geom *geom = nullptr;
+  int fe_type = 0, P = 0, Q = 0, Qpad = 0, nch = 0, ne = 0, nb = 0, lsize = 0, KP = 0, PT = 0;
+  int qf = 0, mode = 0;
+  uint32_t trial_ops = 0, test_ops = 0;
+  int32_t *d_idx = nullptr;     // [nb][4 KP][16] signed index (oriented: <0 => -(1+dof) flipped); pads read zero
+  int32_t *d_idx_bc = nullptr;  // copy with kEssBit on essential dofs
+  uint32_t *d_co = nullptr;     // [nb][4 KP][16] packed int8 {sub, main, super} (curl-oriented) or nullptr
+  std::vector<int32_t> h_idx;
+  double *d_Tf = nullptr, *d_Tt = nullptr;  // MFMA A-operand fragments of the tables (forward / transposed)
+  double *d_interp = nullptr, *d_deriv = nullptr;  // plain tables (diagonal assembly)
+  int32_t *d_off = nullptr;    // plain [ne][P] offsets (diagonal assembly)
+  int8_t *d_cor = nullptr;     // plain curl_orients or nullptr
+  uint8_t *d_ori = nullptr;
+  double *d_ye = nullptr;      // E-vector [nb][4 KP][16]
+  int32_t *d_tptr = nullptr, *d_tent = nullptr;
+  std::vector<uint8_t> ctx_blob;
+  CoeffHost c0, c1;
+};
+
 void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t slot_offset);
 
 // kernels (pa_geom.hip, pa_nd_hex.hip, pa_h1_hex.hip)
@@ -135,6 +159,18 @@ void launch_h1_hex_apply(const SubOp &so, const double *x, bool masked, hipStrea
 void launch_h1_hex_qdata(SubOp &so, hipStream_t s);
 void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 
+// pa_dense.hip
+void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s);
+DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_dense_basis_desc &b, int qf,
+                         const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops, int height);
+void free_dense_sub(DenseSub *ds);
+void dense_set_essential(DenseSub &ds, const std::vector<char> &flag);
+void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStream_t s);
+void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s);
+void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s);
+void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y,
+                          bool accumulate, hipStream_t s);
+
 }  // namespace pa
 
 struct pa_geom : pa::Geom {};
@@ -144,4 +180,5 @@ struct pa_op {
   bool finalized = false;
   bool has_essential = false;
   std::vector<pa::SubOp *> subs;
+  std::vector<pa::DenseSub *> dsubs;
 };

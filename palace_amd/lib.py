@@ -19,7 +19,18 @@ class PalaceAmdError(RuntimeError):
 
 class RestrictionDesc(C.Structure):
     _fields_ = [("num_elem", C.c_int32), ("elem_size", C.c_int32), ("lsize", C.c_int32),
-                ("offsets", C.c_void_p), ("orients", C.c_void_p)]
+                ("offsets", C.c_void_p), ("orients", C.c_void_p), ("curl_orients", C.c_void_p)]
+
+
+class DenseBasisDesc(C.Structure):
+    _fields_ = [("fe_type", C.c_int32), ("num_dofs", C.c_int32), ("num_qpts", C.c_int32),
+                ("interp", C.c_void_p), ("deriv", C.c_void_p)]
+
+
+class MeshDenseDesc(C.Structure):
+    _fields_ = [("num_elem", C.c_int32), ("nodes_per_elem", C.c_int32), ("num_qpts", C.c_int32),
+                ("num_nodes", C.c_int32), ("node_offsets", C.c_void_p), ("nodes", C.c_void_p),
+                ("attr", C.c_void_p), ("mesh_grad", C.c_void_p), ("qweight", C.c_void_p)]
 
 
 class BasisDesc(C.Structure):
@@ -43,6 +54,10 @@ def load():
         raise PalaceAmdError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
             " (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # torch owns the device context and ships its own HIP runtime: load it first so that this library
+    # binds to the runtime already in the process instead of bringing a second one
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     lib.pa_last_error.restype = C.c_char_p
     lib.pa_version.restype = C.c_char_p

@@ -77,6 +77,12 @@ class Context:
                                    C.c_int(x.numel()), C.byref(out)))
         return out.value
 
+    def axpby(self, a, x, b, y):
+        """y = a x + b y (linalg::AXPBY, vector.cpp:530-557)."""
+        _lib.check(_L().pa_vec_axpby(self.handle, a, C.c_void_p(x.data_ptr()), b, C.c_void_p(y.data_ptr()),
+                                     C.c_int(x.numel())))
+        return y
+
     def set_random(self, x, seed):
         _lib.check(_L().pa_vec_set_random(self.handle, C.c_void_p(x.data_ptr()), x.numel(), seed))
         return x

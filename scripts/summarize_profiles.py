@@ -1,0 +1,56 @@
+"""Summarise gpurun_out/prof_* (written by scripts/profile_round.sh) into profiles/r01_*."""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+TAG = os.environ.get("ROUND_TAG", "r01")
+PROF = os.path.join(OUT, "profiles_new")
+os.makedirs(PROF, exist_ok=True)
+
+def find(d, suffix):
+    f = glob.glob(os.path.join(OUT, d, "**", "*" + suffix), recursive=True)
+    return f[0] if f else None
+
+for d, name in (("prof_bench", "bench_kernel_stats.csv"), ("prof_curlmass", "apply_curlmass_kernel_stats.csv")):
+    f = find(d, "kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(PROF, f"{TAG}_{name}"))
+log = os.path.join(OUT, "prof_bench.log")
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith('{"metric"'):
+            open(os.path.join(PROF, f"{TAG}_bench_under_rocprof.json"), "w").write(line)
+
+pmc = {}
+for d in sorted(glob.glob(os.path.join(OUT, "prof_pmc*"))):
+    f = find(os.path.basename(d), "counter_collection.csv")
+    if not f or not os.path.isdir(d):
+        continue
+    acc = {}
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "nd_hex_apply" in k:
+            k = "nd_hex_apply_kernel"
+        elif "et_gather" in k:
+            k = "et_gather_kernel"
+        elif "k_axpby" in k:
+            k = "calibration_axpby"
+        else:
+            continue
+        key = (k, row["Counter_Name"])
+        s, n = acc.get(key, (0.0, set()))
+        n.add(row["Dispatch_Id"])
+        acc[key] = (s + float(row["Counter_Value"]), n)
+    for (k, c), (s, n) in acc.items():
+        pmc.setdefault(k, {})[c] = s / max(1, len(n))
+if pmc:
+    note = ("rocprofv3 --kernel-trace --pmc, one counter group per run (scripts/profile_round.sh; 10M-dof ND p=3 curl-curl "
+            "apply); averages per dispatch. FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE "
+            "is exact only after the x2 correction for 16-B/lane streaming loads and uncalibrated for the 8-B/lane and "
+            "gather loads of these kernels (MI355X_MICROARCH.md, HBM section), so both raw and x2 are given.")
+    tot_f = sum(v.get("FETCH_SIZE", 0.0) for v in pmc.values()) * 1024
+    tot_w = sum(v.get("WRITE_SIZE", 0.0) for v in pmc.values()) * 1024
+    json.dump({"note": note, "kernels": pmc,
+               "per_apply_bytes": {"fetch_raw": tot_f, "fetch_x2": 2 * tot_f, "write_raw": tot_w,
+                                   "traffic_raw": tot_f + tot_w}},
+              open(os.path.join(PROF, f"{TAG}_apply_pmc.json"), "w"), indent=1)
+print(sorted(os.listdir(PROF)))
