@@ -1,0 +1,146 @@
+"""Tetrahedral Nedelec / H1 spaces through the dense MFMA path vs the oracle.
+
+The spaces come from palace_amd.fem.tet (the role MFEM plays for the reference): order-p first-kind
+Nedelec tets with the curl-oriented (tridiagonal int8) restriction of
+fem/libceed/restriction.cpp:299-369 for p >= 2, nodal H1 tets, straight (tet4) and curved (tet10)
+geometry.  Parity is GPU vs oracle on the same tables; the tables themselves are pinned by
+tests/test_tet_space.py (exact sequence property, analytic cavity eigenvalues)."""
+import numpy as np
+import pytest
+
+from oracle import palace_oracle as po
+from tests import util
+
+pytestmark = pytest.mark.gpu
+REL = 1e-12
+
+
+def _warp(X):
+    x, y, z = X[:, 0], X[:, 1], X[:, 2]
+    return np.stack([x + 0.04 * np.sin(2 * y + z), y + 0.05 * x * z, z - 0.03 * np.cos(3 * x) * y], axis=1)
+
+
+def _mesh(kind):
+    from palace_amd.fem import tet
+
+    m = tet.cube_tet_mesh(3)
+    m.attr[:] = 1 + (np.arange(m.ne) % 2)
+    if kind == "tet10":
+        m2 = tet.to_quadratic(m, _warp)
+        m2.attr[:] = m.attr
+        return m2
+    return m
+
+
+def _geom(mesh, pts, wts):
+    from palace_amd import ceed
+
+    G = mesh.geometry_grad_table(pts)
+    g = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, G, wts)
+    J = mesh.jacobians(pts)
+    Jcm = np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 9)
+    return g, po.build_geom_factor_33(mesh.attr.astype(np.float64), wts, Jcm)
+
+
+@pytest.mark.parametrize("kind", ["tet4", "tet10"])
+def test_tet_geometry(kind):
+    from palace_amd.fem import tet
+
+    mesh = _mesh(kind)
+    pts, wts = tet.tet_quadrature(3)
+    g, ref = _geom(mesh, pts, wts)
+    got = g.to_numpy()
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    # volumes: sum of w detJ
+    if kind == "tet4":
+        assert abs(ref[:, 1, :].sum() - 1.0) < 1e-13
+
+
+ND_MODES = [("curl", "QF_HDIV_33", po.QF_HDIV, "C"), ("vmass", "QF_HCURL_33", po.QF_HCURL, "I"),
+            ("curlmass", "QF_HDIVMASS_33", po.QF_HDIVMASS, "CI")]
+
+
+@pytest.mark.parametrize("mode", ND_MODES, ids=[m[0] for m in ND_MODES])
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["tet4", "tet10"])
+def test_nd_tet_apply(kind, p, mode):
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import tet
+
+    name, qf_name, qf_o, ops_s = mode
+    mesh = _mesh(kind)
+    nd = tet.NDTetSpace(mesh, p)
+    pts, wts = tet.tet_quadrature(p + 1)
+    interp, curl = nd.elem.tables(pts)
+    geom, ogeom = _geom(mesh, pts, wts)
+    c3, b3 = util.make_ctx("aniso", 2)
+    cm, bm = util.make_ctx("scalar", 2)
+    ctxs, blob = ((cm, c3), np.concatenate([bm, b3])) if name == "curlmass" else ((c3, None), b3)
+    if nd.diagonal_transform:
+        block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, orients=nd.orients)
+        orc = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, interp, curl, ogeom, qf_o, *ctxs)
+    else:
+        block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, curl_orients=nd.curl_orients)
+        orc = po.CeedOperatorOracle(nd.ndofs, nd.offsets, None, interp, curl, ogeom, qf_o, *ctxs,
+                                    curl_orients=nd.curl_orients)
+    ops = sum({"C": ceed.EVAL_CURL, "I": ceed.EVAL_INTERP}[c] for c in ops_s)
+    op = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(geom, block, getattr(ceed, qf_name), blob, ops).finalize()
+    rng = np.random.default_rng(p)
+    x = rng.uniform(-1, 1, nd.ndofs)
+    y_ref = orc.apply_add(x, np.zeros(nd.ndofs))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    op.mult(xd, yd)
+    err = np.abs(yd.cpu().numpy() - y_ref).max() / np.abs(y_ref).max()
+    assert err < REL, f"Mult rel err {err:.3e}"
+    d_ref = orc.diagonal()
+    dd = torch.empty_like(xd)
+    op.assemble_diagonal(dd)
+    err = np.abs(dd.cpu().numpy() - d_ref).max() / np.abs(d_ref).max()
+    assert err < REL, f"diagonal rel err {err:.3e}"
+
+
+H1_MODES = [("diff", "QF_HCURL_33", po.QF_HCURL, "G"), ("mass", "QF_H1_1", po.QF_H1MASS, "I"),
+            ("diffmass", "QF_HCURLMASS_33", po.QF_HCURLMASS, "GI")]
+
+
+@pytest.mark.parametrize("mode", H1_MODES, ids=[m[0] for m in H1_MODES])
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_h1_tet_apply(p, mode):
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import tet
+
+    name, qf_name, qf_o, ops_s = mode
+    mesh = _mesh("tet10")
+    h1 = tet.H1TetSpace(mesh, p)
+    pts, wts = tet.tet_quadrature(p + 1)
+    interp, grad = h1.elem.tables(pts)
+    geom, ogeom = _geom(mesh, pts, wts)
+    c3, b3 = util.make_ctx("aniso", 2)
+    c1 = po.CoeffCtx(attr_mat=[0, 0], mat_coeff=[np.array([1.7])], dim=1)
+    if name == "diff":
+        ctxs, blob = (c3, None), b3
+    elif name == "mass":
+        ctxs, blob = (c1, None), c1.pack()
+    else:
+        ctxs, blob = (c1, c3), np.concatenate([c1.pack(), b3])
+    block = ceed.DenseBlock(ceed.FE_H1, h1.ndofs, h1.offsets, interp, grad)
+    ops = sum({"G": ceed.EVAL_GRAD, "I": ceed.EVAL_INTERP}[c] for c in ops_s)
+    op = ceed.Operator(h1.ndofs, h1.ndofs).add_dense_integrator(geom, block, getattr(ceed, qf_name), blob, ops).finalize()
+    orc = po.CeedOperatorOracle(h1.ndofs, h1.offsets, None, interp, grad, ogeom, qf_o, *ctxs, vector_fe=False)
+    rng = np.random.default_rng(p)
+    x = rng.uniform(-1, 1, h1.ndofs)
+    y_ref = orc.apply_add(x, np.zeros(h1.ndofs))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    op.mult(xd, yd)
+    err = np.abs(yd.cpu().numpy() - y_ref).max() / np.abs(y_ref).max()
+    assert err < REL, f"Mult rel err {err:.3e}"
+    if name == "diff":  # constants are in the kernel of the stiffness operator
+        one = torch.ones_like(xd)
+        op.mult(one, yd)
+        assert float(yd.abs().max()) < 1e-11 * float(np.abs(y_ref).max())
