@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "pa_device.hpp"
 #include "pa_internal.hpp"
@@ -74,13 +75,22 @@ void mode_comps(int mode, int &nci, int &ncd) {
 struct DenseArgs {
   int ne, nb, P, Q, Qpad, nch, KP;
   const int32_t *idx;
-  const uint32_t *co;
+  const uint16_t *co;  // 2-bit fields {sub, main, super} of row d of T_e and {T[d-1][d], T[d+1][d]} of column d
   const double *geom;
   const double *Tf, *Tt;
+  const double *L;      // resident form of the tables: [rows][S], rows in tile order (see make_dense_sub)
+  const double *qdata;  // packed pre-assembled D: [nb][ncq][Qpad][16]
+  int ncq, Q4;  // q-data components and its point stride (Q rounded up to a multiple of 4)
+  int dbg;  // ablation bits (PA_ABLATION builds only)
   const double *x;
   double *ye;
   CoeffDev c0, c1;
 };
+
+// 2-bit two's-complement field k of a packed curl-orientation word: -1, 0 or 1
+__device__ __forceinline__ double co_field(const int c, const int k) {
+  return (double)((c << (30 - 2 * k)) >> 30);
+}
 
 // The pointwise D stage on the NCT components of one quadrature point (in place).
 template <int MODE>
@@ -112,17 +122,136 @@ __device__ __forceinline__ void dense_D(const DenseArgs &a, const double wdetJ, 
 }
 
 constexpr int kDenseWaves = 4;
+constexpr int kDenseThreads = 64 * kDenseWaves;
+
+// Components of field F of a mode (field 0 = the interp part if the mode has one, then the
+// curl / gradient part) and the number of components before it.
+template <int MODE, int F>
+struct FieldTraits {
+  using M = ModeTraits<MODE>;
+  static constexpr int NF = (M::NCI > 0 ? 1 : 0) + (M::NCD > 0 ? 1 : 0);
+  static constexpr int NC = (NF == 2) ? (F == 0 ? M::NCI : M::NCD) : M::NCT;
+  static constexpr int CB = (NF == 2 && F == 1) ? M::NCI : 0;
+};
+
+// D on the components of one field at one quadrature point (in place).  The paired QFunctions
+// (hdivmass_33, hcurlmass_33) act on their two inputs independently, so the fields can be processed
+// one after the other with the same geometry registers.
+template <int MODE, int F>
+__device__ __forceinline__ void dense_D_field(const DenseArgs &a, const double wdetJ, const double (&adj)[9],
+                                              const int attr, double *v) {
+  double Cm[9];
+  constexpr bool second = (F == 1);
+  if (MODE == MODE_CURL || (MODE == MODE_CURLMASS && second)) {  // hdiv_33_qf.h:10-30, hdivmass_33_qf.h:30-42
+    double Jl[9];
+    coeff_unpack3(second ? a.c1 : a.c0, attr, Cm);
+    adjJt33(adj, Jl);
+    mult_AtBCx33(Jl, Cm, Jl, v[0], v[1], v[2], wdetJ, v[0], v[1], v[2]);
+  } else if (MODE == MODE_VMASS || MODE == MODE_DIFF || MODE == MODE_CURLMASS || (MODE == MODE_DIFFMASS && second)) {
+    coeff_unpack3(second ? a.c1 : a.c0, attr, Cm);  // hcurl_33_qf.h:10-28
+    mult_AtBCx33(adj, Cm, adj, v[0], v[1], v[2], wdetJ, v[0], v[1], v[2]);
+  } else {  // scalar mass: h1_1_qf.h, first half of hcurlmass_33_qf.h
+    v[0] *= a.c0.mat[coeff_index(a.c0, attr)] * wdetJ;
+  }
+}
+
+// One field of one 16-point chunk: stage the forward fragments in LDS, B, D, stage the transposed
+// fragments, B^T.  `stage` arrives holding this field's forward fragments (prefetched) and leaves
+// holding the next field's (if any).
+template <int PT, int MODE, int F>
+__device__ __forceinline__ void dense_field(const DenseArgs &a, const int lane, const int tid, const int,
+                                            double *__restrict__ tab, const double *__restrict__ tf_next,
+                                            const bool has_next, const int n_next, const double *__restrict__ tt,
+                                            const double (&u)[4 * PT], const double (&gd)[4][10],
+                                            const int (&attr)[4], double4_t (&yacc)[PT],
+                                            double (&stage)[3 * PT], const int n_this) {
+  using FT = FieldTraits<MODE, F>;
+  constexpr int NC = FT::NC, KPMAX = 4 * PT, NST = 3 * PT, KP = KPMAX;
+  __syncthreads();  // every wave is done reading the previous fragments
+#pragma unroll
+  for (int r = 0; r < NST; r++) {
+    const int i = tid + kDenseThreads * r;
+    if (i < n_this) tab[i] = stage[r];
+  }
+  __syncthreads();
+  // ---- B: NC tiles of 16 rows = 4 points x (4 NC) (point group, component) pairs
+  double4_t acc[NC];
+#pragma unroll
+  for (int t = 0; t < NC; t++) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < KPMAX; s++) {
+    if (s < KP) {
+#pragma unroll
+      for (int t = 0; t < NC; t++)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tab[(s * NC + t) * 64 + lane], u[s], acc[t], 0, 0, 0);
+    }
+  }
+  // transposed fragments on their way while D runs
+  constexpr int n_t = 4 * NC * PT * 64;
+#pragma unroll
+  for (int r = 0; r < NST; r++) {
+    const int i = tid + kDenseThreads * r;
+    if (i < n_t) stage[r] = tt[i];
+  }
+  // ---- D
+#pragma unroll
+  for (int gl = 0; gl < 4; gl++) {
+    double v[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) v[k] = acc[(gl * NC + k) >> 2][(gl * NC + k) & 3];
+    double adj[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) adj[k] = gd[gl][1 + k];
+    dense_D_field<MODE, F>(a, gd[gl][0], adj, attr[gl], v);
+#pragma unroll
+    for (int k = 0; k < NC; k++) acc[(gl * NC + k) >> 2][(gl * NC + k) & 3] = v[k];
+  }
+  __syncthreads();  // forward fragments no longer needed
+#pragma unroll
+  for (int r = 0; r < NST; r++) {
+    const int i = tid + kDenseThreads * r;
+    if (i < n_t) tab[i] = stage[r];
+  }
+  __syncthreads();
+  // next field's forward fragments on their way while B^T runs
+  if (has_next) {
+#pragma unroll
+    for (int r = 0; r < NST; r++) {
+      const int i = tid + kDenseThreads * r;
+      if (i < n_next) stage[r] = tf_next[i];
+    }
+  }
+  // ---- B^T: the C layout above is the B-operand layout of the transposed product
+#pragma unroll
+  for (int pi = 0; pi < 4 * NC; pi++) {
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++)
+      yacc[pt] = __builtin_amdgcn_mfma_f64_16x16x4f64(tab[(pi * PT + pt) * 64 + lane], acc[pi >> 2][pi & 3], yacc[pt], 0, 0, 0);
+  }
+}
 
 template <int PT, int MODE>
-__global__ __launch_bounds__(64 * kDenseWaves, (PT <= 4 ? 2 : 1)) void dense_apply_kernel(const DenseArgs a) {
+__global__ __launch_bounds__(kDenseThreads, (PT <= 4 ? 2 : 1)) void dense_apply_kernel(const DenseArgs a) {
   using M = ModeTraits<MODE>;
-  constexpr int NCT = M::NCT, KPMAX = 4 * PT;
+  using F0 = FieldTraits<MODE, 0>;
+  using F1 = FieldTraits<MODE, 1>;
+  constexpr int NCT = M::NCT, KPMAX = 4 * PT, NF = F0::NF;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * kDenseWaves + wave;
-  if (b >= a.nb) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b_raw = blockIdx.x * kDenseWaves + wave;
+  const bool valid = b_raw < a.nb;  // surplus waves of the last workgroup redo the last block (barriers)
+  const int b = valid ? b_raw : a.nb - 1;
   const int j = lane & 15, kq = lane >> 4;
-  const int KP = a.KP;
+  constexpr int KP = 4 * PT;  // the host pads every element block to 4 PT dof slots
+
+  // forward fragments of the first field, requested before anything else
+  double stage[3 * PT];
+  const int n_f0 = KP * F0::NC * 64, n_f1 = KP * F1::NC * 64;
+#pragma unroll
+  for (int r = 0; r < 3 * PT; r++) {
+    const int i = tid + kDenseThreads * r;
+    if (i < n_f0) stage[r] = a.Tf[i];
+  }
 
   // ---- E: gather straight into the MFMA B-operand layout
   double u[KPMAX];
@@ -137,8 +266,9 @@ __global__ __launch_bounds__(64 * kDenseWaves, (PT <= 4 ? 2 : 1)) void dense_app
       u[s] = sg >= 0 ? xv : -xv;
     }
   }
-  const uint32_t *co = a.co ? a.co + (size_t)b * KP * 64 : nullptr;
+  const uint16_t *co = a.co ? a.co + (size_t)b * KP * 64 : nullptr;
   double *sm = smem + (size_t)wave * KPMAX * 64;
+  double *tab = smem + (a.co ? (size_t)kDenseWaves * KPMAX * 64 : 0);
   if (co) {  // curl-oriented: u_e = T x_e, T tridiagonal (restriction.cpp:299-369)
 #pragma unroll
     for (int s = 0; s < KPMAX; s++)
@@ -147,12 +277,12 @@ __global__ __launch_bounds__(64 * kDenseWaves, (PT <= 4 ? 2 : 1)) void dense_app
 #pragma unroll
     for (int s = 0; s < KPMAX; s++) {
       if (s < KP) {
-        const uint32_t c = co[s * 64 + lane];
+        const int c = co[s * 64 + lane];
         const int dof = 4 * s + kq;
-        const double lo = dof > 0 ? sm[(dof - 1) * 16 + j] : 0.0;
-        const double hi = dof + 1 < 4 * KP ? sm[(dof + 1) * 16 + j] : 0.0;
-        u[s] = (double)(int8_t)(c & 0xff) * lo + (double)(int8_t)((c >> 8) & 0xff) * u[s] +
-               (double)(int8_t)((c >> 16) & 0xff) * hi;
+        // out-of-range neighbours have a zero coefficient: clamp the address instead of branching
+        const double lo = sm[max(dof - 1, 0) * 16 + j];
+        const double hi = sm[min(dof + 1, 4 * KP - 1) * 16 + j];
+        u[s] = co_field(c, 0) * lo + co_field(c, 1) * u[s] + co_field(c, 2) * hi;
       }
     }
     wave_sync();
@@ -162,8 +292,9 @@ __global__ __launch_bounds__(64 * kDenseWaves, (PT <= 4 ? 2 : 1)) void dense_app
 #pragma unroll
   for (int pt = 0; pt < PT; pt++) yacc[pt] = double4_t{0.0, 0.0, 0.0, 0.0};
 
+  const size_t tf_chunk = (size_t)KP * NCT * 64, tt_chunk = (size_t)4 * NCT * PT * 64;
   for (int c = 0; c < a.nch; c++) {
-    // geometry of this lane's 4 points of the chunk (q = 16 c + 4 gl + kq), requested up front
+    // geometry of this lane's 4 points of the chunk (q = 16 c + 4 gl + kq)
     double gd[4][10];
     int attr[4];
     {
@@ -175,41 +306,17 @@ __global__ __launch_bounds__(64 * kDenseWaves, (PT <= 4 ? 2 : 1)) void dense_app
         for (int k = 0; k < 10; k++) gd[gl][k] = g[((size_t)(1 + k) * a.Qpad) * kEB + gl * 64];
       }
     }
-    // ---- B: NCT tiles of 16 rows = 4 points x (4 NCT) (group, component) pairs
-    double4_t acc[NCT];
-#pragma unroll
-    for (int t = 0; t < NCT; t++) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-    const double *tf = a.Tf + (size_t)c * KP * NCT * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < KPMAX; s++) {
-      if (s < KP) {
-#pragma unroll
-        for (int t = 0; t < NCT; t++)
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[(s * NCT + t) * 64], u[s], acc[t], 0, 0, 0);
-      }
-    }
-    // ---- D
-#pragma unroll
-    for (int gl = 0; gl < 4; gl++) {
-      double v[NCT];
-#pragma unroll
-      for (int k = 0; k < NCT; k++) v[k] = acc[(gl * NCT + k) >> 2][(gl * NCT + k) & 3];
-      double adj[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) adj[k] = gd[gl][1 + k];
-      dense_D<MODE>(a, gd[gl][0], adj, attr[gl], v);
-#pragma unroll
-      for (int k = 0; k < NCT; k++) acc[(gl * NCT + k) >> 2][(gl * NCT + k) & 3] = v[k];
-    }
-    // ---- B^T: the C layout above is the B-operand layout of the transposed product
-    const double *tt = a.Tt + (size_t)c * 4 * NCT * PT * 64 + lane;
-#pragma unroll
-    for (int pi = 0; pi < 4 * NCT; pi++) {
-#pragma unroll
-      for (int pt = 0; pt < PT; pt++)
-        yacc[pt] = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[(pi * PT + pt) * 64], acc[pi >> 2][pi & 3], yacc[pt], 0, 0, 0);
+    const double *tf = a.Tf + c * tf_chunk, *tt = a.Tt + c * tt_chunk;
+    const bool more = c + 1 < a.nch;
+    if (NF == 1) {
+      dense_field<PT, MODE, 0>(a, lane, tid, KP, tab, tf + tf_chunk, more, n_f0, tt, u, gd, attr, yacc, stage, n_f0);
+    } else {
+      dense_field<PT, MODE, 0>(a, lane, tid, KP, tab, tf + n_f0, true, n_f1, tt, u, gd, attr, yacc, stage, n_f0);
+      dense_field<PT, MODE, 1>(a, lane, tid, KP, tab, tf + tf_chunk, more, n_f0, tt + (size_t)4 * F0::NC * PT * 64, u, gd,
+                               attr, yacc, stage, n_f1);
     }
   }
+  if (!valid) return;
 
   // ---- E^T, first half: E-vector in the same [dof][element] block layout (coalesced); signs of the
   // oriented restriction and the sum over elements happen in the gather kernel
@@ -223,11 +330,9 @@ __global__ __launch_bounds__(64 * kDenseWaves, (PT <= 4 ? 2 : 1)) void dense_app
     for (int s = 0; s < KPMAX; s++) {
       if (s < KP) {
         const int dof = 4 * s + kq;
-        const uint32_t cm = co[s * 64 + lane];
-        double w = (double)(int8_t)((cm >> 8) & 0xff) * yacc[s >> 2][s & 3];
-        if (dof > 0) w += (double)(int8_t)((co[s * 64 + lane - 16] >> 16) & 0xff) * sm[(dof - 1) * 16 + j];
-        if (dof + 1 < 4 * KP) w += (double)(int8_t)(co[s * 64 + lane + 16] & 0xff) * sm[(dof + 1) * 16 + j];
-        ye[s * 64 + lane] = w;
+        const int cm = co[s * 64 + lane];
+        ye[s * 64 + lane] = co_field(cm, 1) * yacc[s >> 2][s & 3] + co_field(cm, 3) * sm[max(dof - 1, 0) * 16 + j] +
+                            co_field(cm, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
       }
     }
   } else {
@@ -237,13 +342,297 @@ __global__ __launch_bounds__(64 * kDenseWaves, (PT <= 4 ? 2 : 1)) void dense_app
   }
 }
 
+// ---- fast path: tables resident in LDS, pre-assembled packed D, persistent workgroups ---------------
+// One copy of the tables, L[row][S] with rows in tile order and the row stride S = 18 (mod 32) doubles,
+// serves both products: the forward A operand reads L[16 t + i][4 s + kq] (bank = 18 i + kq: all 32
+// lanes of a half-wave distinct) and the transposed one L[4 pi + kq][16 pt + i] (two banks shared by
+// two lanes).  No barrier after the initial load: every wave walks its own element blocks.
+template <int PT>
+struct ResidentStride {
+  static constexpr int S = 16 * PT + ((PT & 1) ? 2 : 18);
+};
+
+constexpr int kResWaves = 8;
+
+template <int MODE, int F>
+__device__ __forceinline__ void dense_D_packed(const double *m, double *v) {
+  using FT = FieldTraits<MODE, F>;
+  if (FT::NC == 3) {
+    sym_mv(m, v[0], v[1], v[2], v[0], v[1], v[2]);
+  } else {
+    v[0] *= m[0];
+  }
+}
+
+template <int PT, int MODE, int F>
+__device__ __forceinline__ void resident_field(const double *__restrict__ Lf, const double *__restrict__ Lb, const int,
+                                               const double (&u)[4 * PT], const double (&qd)[4][6],
+                                               double4_t (&yacc)[PT]) {
+  using FT = FieldTraits<MODE, F>;
+  constexpr int NC = FT::NC, KPMAX = 4 * PT, S = ResidentStride<PT>::S, KP = KPMAX;
+  double4_t acc[NC];
+#pragma unroll
+  for (int t = 0; t < NC; t++) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < KPMAX; s++) {
+    if (s < KP) {
+#pragma unroll
+      for (int t = 0; t < NC; t++)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lf[16 * t * S + 4 * s], u[s], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int gl = 0; gl < 4; gl++) {
+    double v[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) v[k] = acc[(gl * NC + k) >> 2][(gl * NC + k) & 3];
+    dense_D_packed<MODE, F>(qd[gl], v);
+#pragma unroll
+    for (int k = 0; k < NC; k++) acc[(gl * NC + k) >> 2][(gl * NC + k) & 3] = v[k];
+  }
+#pragma unroll
+  for (int pi = 0; pi < 4 * NC; pi++) {
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++)
+      yacc[pt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lb[4 * pi * S + 16 * pt], acc[pi >> 2][pi & 3], yacc[pt], 0, 0, 0);
+  }
+}
+
+// q-data of the 4 point groups of one chunk; `ng` = valid groups left (the last chunk may be partial)
+template <int MODE, int F>
+__device__ __forceinline__ void load_qd(const double *__restrict__ q, const size_t cs, const int ng, double (&qd)[4][6]) {
+  constexpr int NQ = FieldTraits<MODE, F>::NC == 3 ? 6 : 1;
+#pragma unroll
+  for (int gl = 0; gl < 4; gl++)
+#pragma unroll
+    for (int k = 0; k < NQ; k++) qd[gl][k] = (gl < ng) ? q[k * cs + gl * 64] : 0.0;
+}
+
+template <int PT, int MODE>
+__global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel(const DenseArgs a, const int rows) {
+  using M = ModeTraits<MODE>;
+  using F0 = FieldTraits<MODE, 0>;
+  using F1 = FieldTraits<MODE, 1>;
+  constexpr int NCT = M::NCT, KPMAX = 4 * PT, NF = F0::NF, S = ResidentStride<PT>::S;
+  constexpr int NQ0 = F0::NC == 3 ? 6 : 1, NQ1 = F1::NC == 3 ? 6 : 1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  constexpr int KP = 4 * PT;  // the host pads every element block to 4 PT dof slots
+  double *L = smem;
+  double *sm = smem + (size_t)rows * S + (size_t)wave * KPMAX * 64;
+  {
+    const int n = rows * S;
+    for (int i = tid; i < n; i += 64 * kResWaves) L[i] = a.L[i];
+  }
+  __syncthreads();
+  const double *Lf = L + j * S + kq;   // forward operand of this lane:   row 16 t + i, column 4 s + kq
+  const double *Lb = L + kq * S + j;   // transposed operand of this lane: row 4 pi + kq, column 16 pt + i
+  const size_t cs = (size_t)a.Q4 * kEB;
+  const int ngroups = a.Q4 / 4;
+
+  for (int b = blockIdx.x * kResWaves + wave; b < a.nb; b += gridDim.x * kResWaves) {
+    // ---- E
+    double u[KPMAX];
+    const int32_t *idx = a.idx + (size_t)b * KP * 64;
+#pragma unroll
+    for (int s = 0; s < KPMAX; s++) {
+      u[s] = 0.0;
+      if (s < KP) {
+        const int sg = idx[s * 64 + lane];
+        const int d = sg >= 0 ? sg : -1 - sg;
+#ifdef PA_ABLATION
+        const double xv = (a.dbg & 1) ? (double)d : ((d & kEssBit) ? 0.0 : a.x[d & ~kEssBit]);
+#else
+        const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
+#endif
+        u[s] = sg >= 0 ? xv : -xv;
+      }
+    }
+#ifdef PA_ABLATION
+    const double *q = a.qdata + ((a.dbg & 2) ? (size_t)0 : (size_t)b * a.ncq * cs) + lane;
+#else
+    const double *q = a.qdata + (size_t)b * a.ncq * cs + lane;
+#endif
+    double qd[4][6];
+    load_qd<MODE, 0>(q, cs, ngroups, qd);
+#ifdef PA_ABLATION
+    const uint16_t *co = (a.co && !(a.dbg & 16)) ? a.co + (size_t)b * KP * 64 : nullptr;
+#else
+    const uint16_t *co = a.co ? a.co + (size_t)b * KP * 64 : nullptr;
+#endif
+    if (co) {
+#pragma unroll
+      for (int s = 0; s < KPMAX; s++)
+        if (s < KP) sm[s * 64 + lane] = u[s];
+      wave_sync();
+#pragma unroll
+      for (int s = 0; s < KPMAX; s++) {
+        if (s < KP) {
+          const int c = co[s * 64 + lane];
+          const int dof = 4 * s + kq;
+          // out-of-range neighbours have a zero coefficient: clamp the address instead of branching
+          const double lo = sm[max(dof - 1, 0) * 16 + j];
+          const double hi = sm[min(dof + 1, 4 * KP - 1) * 16 + j];
+          u[s] = co_field(c, 0) * lo + co_field(c, 1) * u[s] + co_field(c, 2) * hi;
+        }
+      }
+      wave_sync();
+    }
+    double4_t yacc[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++) yacc[pt] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+#ifdef PA_ABLATION
+    const int nch_eff = (a.dbg & 4) ? 0 : a.nch;
+    if (a.dbg & 4) {
+#pragma unroll
+      for (int pt = 0; pt < PT; pt++)
+        yacc[pt] = double4_t{u[(4 * pt) % KPMAX] + qd[0][0], u[(4 * pt + 1) % KPMAX], u[(4 * pt + 2) % KPMAX], u[(4 * pt + 3) % KPMAX]};
+    }
+#else
+    const int nch_eff = a.nch;
+#endif
+    for (int c = 0; c < nch_eff; c++) {
+      const int r0 = c * NCT * 16;
+      if (NF == 1) {
+        double qn[4][6];
+        if (c + 1 < a.nch) load_qd<MODE, 0>(q + 16 * (c + 1) * kEB, cs, ngroups - 4 * (c + 1), qn);
+        resident_field<PT, MODE, 0>(Lf + r0 * S, Lb + r0 * S, KP, u, qd, yacc);
+        if (c + 1 < a.nch) {
+#pragma unroll
+          for (int gl = 0; gl < 4; gl++)
+#pragma unroll
+            for (int k = 0; k < NQ0; k++) qd[gl][k] = qn[gl][k];
+        }
+      } else {
+        double qn[4][6];
+        load_qd<MODE, 1>(q + NQ0 * cs + 16 * c * kEB, cs, ngroups - 4 * c, qn);
+        resident_field<PT, MODE, 0>(Lf + r0 * S, Lb + r0 * S, KP, u, qd, yacc);
+        if (c + 1 < a.nch) load_qd<MODE, 0>(q + 16 * (c + 1) * kEB, cs, ngroups - 4 * (c + 1), qd);
+        resident_field<PT, MODE, 1>(Lf + (r0 + 16 * F0::NC) * S, Lb + (r0 + 16 * F0::NC) * S, KP, u, qn, yacc);
+      }
+    }
+
+    // ---- E^T, first half
+#ifdef PA_ABLATION
+    double *ye = a.ye + ((a.dbg & 8) ? (size_t)(blockIdx.x * kResWaves + wave) : (size_t)b) * KP * 64;
+#else
+    double *ye = a.ye + (size_t)b * KP * 64;
+#endif
+    if (co) {
+#pragma unroll
+      for (int s = 0; s < KPMAX; s++)
+        if (s < KP) sm[s * 64 + lane] = yacc[s >> 2][s & 3];
+      wave_sync();
+#pragma unroll
+      for (int s = 0; s < KPMAX; s++) {
+        if (s < KP) {
+          const int dof = 4 * s + kq;
+          const int cm = co[s * 64 + lane];
+          ye[s * 64 + lane] = co_field(cm, 1) * yacc[s >> 2][s & 3] + co_field(cm, 3) * sm[max(dof - 1, 0) * 16 + j] +
+                              co_field(cm, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
+        }
+      }
+      wave_sync();
+    } else {
+#pragma unroll
+      for (int s = 0; s < KPMAX; s++)
+        if (s < KP) ye[s * 64 + lane] = yacc[s >> 2][s & 3];
+    }
+  }
+}
+
+// packed D (set-up): one thread per point; columns of D through the reference QFunction arithmetic
+template <int MODE>
+__global__ void dense_qdata_kernel(const DenseArgs a, double *__restrict__ qd) {
+  using F0 = FieldTraits<MODE, 0>;
+  using F1 = FieldTraits<MODE, 1>;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / a.Q);
+  if (e >= a.ne) return;
+  const int q = (int)(gid - (long long)e * a.Q);
+  const size_t cs = (size_t)a.Qpad * kEB;
+  const double *g = a.geom + ((size_t)(e / kEB) * 11 * a.Qpad + q) * kEB + (e % kEB);
+  double *out = qd + ((size_t)(e / kEB) * a.ncq * a.Q4 + q) * kEB + (e % kEB);
+  const size_t os = (size_t)a.Q4 * kEB;
+  double adj[9];
+  for (int k = 0; k < 9; k++) adj[k] = g[(2 + k) * cs];
+  const double wdetJ = g[cs];
+  const int attr = (int)g[0];
+  int o = 0;
+  auto field = [&](auto tag) {
+    constexpr int F = decltype(tag)::value;
+    constexpr int NC = FieldTraits<MODE, F>::NC;
+    if (NC == 3) {
+      double Mx[9];
+      for (int col = 0; col < 3; col++) {
+        double v[3] = {col == 0 ? 1.0 : 0.0, col == 1 ? 1.0 : 0.0, col == 2 ? 1.0 : 0.0};
+        dense_D_field<MODE, F>(a, wdetJ, adj, attr, v);
+        Mx[0 + 3 * col] = v[0], Mx[1 + 3 * col] = v[1], Mx[2 + 3 * col] = v[2];
+      }
+      out[(o + 0) * os] = Mx[0];
+      out[(o + 1) * os] = 0.5 * (Mx[3] + Mx[1]);
+      out[(o + 2) * os] = 0.5 * (Mx[6] + Mx[2]);
+      out[(o + 3) * os] = Mx[4];
+      out[(o + 4) * os] = 0.5 * (Mx[7] + Mx[5]);
+      out[(o + 5) * os] = Mx[8];
+      o += 6;
+    } else {
+      double v[1] = {1.0};
+      dense_D_field<MODE, F>(a, wdetJ, adj, attr, v);
+      out[o * os] = v[0];
+      o += 1;
+    }
+  };
+  field(std::integral_constant<int, 0>{});
+  if (F0::NF == 2) field(std::integral_constant<int, 1>{});
+}
+
+template <int PT>
+void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
+  const int rows = ds.L_rows;
+  const size_t shm = sizeof(double) * ((size_t)rows * ResidentStride<PT>::S + (ds.d_co ? (size_t)kResWaves * 4 * PT * 64 : 0));
+  int grid = (ds.nb + kResWaves - 1) / kResWaves;
+  if (grid > ds.num_cu) grid = ds.num_cu;
+  switch (ds.mode) {
+#define PA_RES_CASE(MODE)                                                                                \
+  case MODE: {                                                                                           \
+    static bool attr_set = false;                                                                        \
+    if (!attr_set) {                                                                                     \
+      PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE>,                    \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
+      attr_set = true;                                                                                   \
+    }                                                                                                    \
+    hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows); \
+  } break;
+    PA_RES_CASE(MODE_CURL)
+    PA_RES_CASE(MODE_VMASS)
+    PA_RES_CASE(MODE_CURLMASS)
+    PA_RES_CASE(MODE_DIFF)
+    PA_RES_CASE(MODE_DIFFMASS)
+    PA_RES_CASE(MODE_MASS)
+#undef PA_RES_CASE
+  }
+}
+
 template <int PT>
 void launch_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
-  const dim3 grid((ds.nb + kDenseWaves - 1) / kDenseWaves), block(64 * kDenseWaves);
-  const size_t shm = ds.d_co ? sizeof(double) * kDenseWaves * 4 * PT * 64 : 0;
+  const dim3 grid((ds.nb + kDenseWaves - 1) / kDenseWaves), block(kDenseThreads);
+  // LDS: the fragments of one field of one chunk (forward and transposed share the buffer) and, for
+  // the curl-oriented restriction, the per-wave neighbour exchange
+  const size_t shm = sizeof(double) * ((size_t)3 * PT * kDenseThreads + (ds.d_co ? (size_t)kDenseWaves * 4 * PT * 64 : 0));
   switch (ds.mode) {
-#define PA_DENSE_CASE(MODE) \
-  case MODE: hipLaunchKernelGGL((dense_apply_kernel<PT, MODE>), grid, block, shm, s, a); break;
+#define PA_DENSE_CASE(MODE)                                                                              \
+  case MODE: {                                                                                           \
+    static bool attr_set = false;                                                                        \
+    if (!attr_set) {                                                                                     \
+      PA_HIP(hipFuncSetAttribute((const void *)dense_apply_kernel<PT, MODE>,                             \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
+      attr_set = true;                                                                                   \
+    }                                                                                                    \
+    hipLaunchKernelGGL((dense_apply_kernel<PT, MODE>), grid, block, shm, s, a);                          \
+  } break;
     PA_DENSE_CASE(MODE_CURL)
     PA_DENSE_CASE(MODE_VMASS)
     PA_DENSE_CASE(MODE_CURLMASS)
@@ -326,6 +715,11 @@ DenseArgs make_args(const DenseSub &ds) {
   DenseArgs a;
   a.ne = ds.ne, a.nb = ds.nb, a.P = ds.P, a.Q = ds.Q, a.Qpad = ds.Qpad, a.nch = ds.nch, a.KP = ds.KP;
   a.idx = ds.d_idx, a.co = ds.d_co, a.geom = ds.geom->d_geom, a.Tf = ds.d_Tf, a.Tt = ds.d_Tt;
+  a.L = ds.d_L, a.qdata = ds.d_qdata, a.ncq = ds.ncq, a.Q4 = (ds.Q + 3) / 4 * 4;
+  a.dbg = 0;
+#ifdef PA_ABLATION
+  a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
+#endif
   a.x = nullptr, a.ye = ds.d_ye;
   a.c0 = ds.c0.dev(), a.c1 = ds.c1.dev();
   return a;
@@ -392,14 +786,14 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   ds->geom = geom;
   geom->refcount++;
   ds->fe_type = b.fe_type, ds->P = P, ds->Q = Q, ds->Qpad = geom->Qpad, ds->nch = geom->Qpad / 16;
-  ds->ne = ne, ds->nb = (ne + kEB - 1) / kEB, ds->lsize = r.lsize, ds->KP = (P + 3) / 4, ds->PT = PT;
+  ds->ne = ne, ds->nb = (ne + kEB - 1) / kEB, ds->lsize = r.lsize, ds->KP = 4 * PT, ds->PT = PT;
   ds->qf = qf, ds->mode = mode, ds->trial_ops = trial_ops, ds->test_ops = test_ops;
   const int KP = ds->KP, nb = ds->nb, nch = ds->nch;
 
   // ---- E: block-transposed index (+ packed tridiagonal rows)
   const size_t nslot = (size_t)nb * KP * 64;
   std::vector<int32_t> idx(nslot, kEssBit);
-  std::vector<uint32_t> co(r.curl_orients ? nslot : 0, 0u);
+  std::vector<uint16_t> co(r.curl_orients ? nslot : 0, 0u);
   for (int e = 0; e < ne; e++) {
     for (int d = 0; d < P; d++) {
       const int32_t off = r.offsets[(size_t)e * P + d];
@@ -408,7 +802,11 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       idx[pos] = (r.orients && r.orients[(size_t)e * P + d]) ? -1 - off : off;
       if (r.curl_orients) {
         const int8_t *t = r.curl_orients + 3 * ((size_t)e * P + d);
-        co[pos] = (uint32_t)(uint8_t)t[0] | ((uint32_t)(uint8_t)t[1] << 8) | ((uint32_t)(uint8_t)t[2] << 16);
+        const int8_t up = d > 0 ? t[-3 + 2] : 0, dn = d + 1 < P ? t[3 + 0] : 0;  // T[d-1][d], T[d+1][d]
+        // MFEM's ND face transformations only contain -1, 0, 1 (the reference stores them as int8,
+        // restriction.cpp:318-336); two bits per entry
+        for (int8_t v : {t[0], t[1], t[2]}) PA_REQUIRE(v >= -1 && v <= 1, "curl-orientation entries must be -1, 0 or 1");
+        co[pos] = (uint16_t)((t[0] & 3) | ((t[1] & 3) << 2) | ((t[2] & 3) << 4) | ((up & 3) << 6) | ((dn & 3) << 8));
       }
     }
   }
@@ -439,21 +837,27 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
     return cidx < nci ? b.interp[((size_t)cidx * Q + q) * P + p] : b.deriv[((size_t)(cidx - nci) * Q + q) * P + p];
   };
   std::vector<double> Tf((size_t)nch * KP * nct * 64), Tt((size_t)nch * 4 * nct * PT * 64);
-  for (int c = 0; c < nch; c++) {
-    for (int s = 0; s < KP; s++)
-      for (int t = 0; t < nct; t++)
-        for (int lane = 0; lane < 64; lane++) {
-          const int i = lane & 15, kq = lane >> 4;
-          const int pi = 4 * t + (i >> 2), gl = pi / nct, cidx = pi % nct;
-          Tf[(((size_t)c * KP + s) * nct + t) * 64 + lane] = tab(cidx, 16 * c + 4 * gl + (i & 3), 4 * s + kq);
-        }
-    for (int pi = 0; pi < 4 * nct; pi++)
-      for (int pt = 0; pt < PT; pt++)
-        for (int lane = 0; lane < 64; lane++) {
-          const int i = lane & 15, kq = lane >> 4;
-          const int gl = pi / nct, cidx = pi % nct;
-          Tt[(((size_t)c * 4 * nct + pi) * PT + pt) * 64 + lane] = tab(cidx, 16 * c + 4 * gl + kq, 16 * pt + i);
-        }
+  {
+    const int nf = (nci > 0 ? 1 : 0) + (ncd > 0 ? 1 : 0);
+    size_t of = 0, ot = 0;
+    for (int c = 0; c < nch; c++)
+      for (int f = 0; f < nf; f++) {
+        const int nc = (nf == 2) ? (f == 0 ? nci : ncd) : nct, cb = (nf == 2 && f == 1) ? nci : 0;
+        for (int s = 0; s < KP; s++)
+          for (int t = 0; t < nc; t++)
+            for (int lane = 0; lane < 64; lane++) {
+              const int i = lane & 15, kq = lane >> 4;
+              const int pi = 4 * t + (i >> 2), gl = pi / nc, k = pi % nc;
+              Tf[of++] = tab(cb + k, 16 * c + 4 * gl + (i & 3), 4 * s + kq);
+            }
+        for (int pi = 0; pi < 4 * nc; pi++)
+          for (int pt = 0; pt < PT; pt++)
+            for (int lane = 0; lane < 64; lane++) {
+              const int i = lane & 15, kq = lane >> 4;
+              const int gl = pi / nc, k = pi % nc;
+              Tt[ot++] = tab(cb + k, 16 * c + 4 * gl + kq, 16 * pt + i);
+            }
+      }
   }
   ds->d_Tf = dev_upload(Tf.data(), Tf.size());
   ds->d_Tt = dev_upload(Tt.data(), Tt.size());
@@ -484,6 +888,62 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       parse_coeff(ctx, ctx_size, 1, ds->c0, 0);
       break;
   }
+
+  // ---- fast path: tables resident in LDS (one copy, rows in tile order, stride S) + packed D.
+  // Needs symmetric coefficients and tables that fit; PALACE_AMD_DENSE=staged keeps the general kernel.
+  {
+    auto is_sym = [](const CoeffHost &c) {
+      if (c.dim != 3) return true;
+      for (size_t k = 0; k + 9 <= c.mat.size(); k += 9)
+        if (c.mat[k + 1] != c.mat[k + 3] || c.mat[k + 2] != c.mat[k + 6] || c.mat[k + 5] != c.mat[k + 7]) return false;
+      return true;
+    };
+    const int S = 16 * PT + ((PT & 1) ? 2 : 18);
+    const int rows = nch * nct * 16;
+    const size_t lds = sizeof(double) * ((size_t)rows * S + (r.curl_orients ? (size_t)8 * 4 * PT * 64 : 0));
+    const char *force = getenv("PALACE_AMD_DENSE");
+    const bool staged = force && std::string(force) == "staged";
+    if (!staged && lds <= 150 * 1024 && is_sym(ds->c0) && (ds->c1.mat.empty() || is_sym(ds->c1))) {
+      const int nf = (nci > 0 ? 1 : 0) + (ncd > 0 ? 1 : 0);
+      std::vector<double> L((size_t)rows * S, 0.0);
+      for (int c = 0; c < nch; c++)
+        for (int f = 0; f < nf; f++) {
+          const int nc = (nf == 2) ? (f == 0 ? nci : ncd) : nct, cb = (nf == 2 && f == 1) ? nci : 0;
+          for (int row = 0; row < 16 * nc; row++) {
+            const int pi = row >> 2, kqp = row & 3, gl = pi / nc, k = pi % nc;
+            for (int d = 0; d < P; d++)
+              L[((size_t)(c * nct + cb) * 16 + row) * S + d] = tab(cb + k, 16 * c + 4 * gl + kqp, d);
+          }
+        }
+      ds->d_L = dev_upload(L.data(), L.size());
+      ds->L_rows = rows;
+      ds->ncq = (nci == 3 ? 6 : nci) + (ncd == 3 ? 6 : ncd);
+      const size_t nq = (size_t)nb * ds->ncq * ((Q + 3) / 4 * 4) * kEB;
+      ds->d_qdata = dev_alloc<double>(nq);
+      PA_HIP(hipMemset(ds->d_qdata, 0, sizeof(double) * nq));
+      hipDeviceProp_t prop;
+      int dev = 0;
+      PA_HIP(hipGetDevice(&dev));
+      PA_HIP(hipGetDeviceProperties(&prop, dev));
+      ds->num_cu = prop.multiProcessorCount;
+      DenseArgs a = make_args(*ds);
+      const long long n = (long long)ne * Q;
+      const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+      switch (mode) {
+#define PA_QD_CASE(MODE) \
+  case MODE: hipLaunchKernelGGL((dense_qdata_kernel<MODE>), grid, block, 0, nullptr, a, ds->d_qdata); break;
+        PA_QD_CASE(MODE_CURL)
+        PA_QD_CASE(MODE_VMASS)
+        PA_QD_CASE(MODE_CURLMASS)
+        PA_QD_CASE(MODE_DIFF)
+        PA_QD_CASE(MODE_DIFFMASS)
+        PA_QD_CASE(MODE_MASS)
+#undef PA_QD_CASE
+      }
+      PA_HIP(hipGetLastError());
+      PA_HIP(hipStreamSynchronize(nullptr));
+    }
+  }
   return ds;
 }
 
@@ -491,6 +951,7 @@ void free_dense_sub(DenseSub *ds) {
   if (!ds) return;
   hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co);
   hipFree(ds->d_Tf), hipFree(ds->d_Tt), hipFree(ds->d_interp), hipFree(ds->d_deriv);
+  hipFree(ds->d_L), hipFree(ds->d_qdata);
   hipFree(ds->d_off), hipFree(ds->d_cor), hipFree(ds->d_ori);
   hipFree(ds->d_ye), hipFree(ds->d_tptr), hipFree(ds->d_tent);
   hipFree(ds->c0.d_attr_mat), hipFree(ds->c0.d_mat);
@@ -514,6 +975,18 @@ void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStr
   DenseArgs a = make_args(ds);
   a.x = x;
   if (masked && ds.d_idx_bc) a.idx = ds.d_idx_bc;
+  if (ds.d_L) {
+    switch (ds.PT) {
+      case 1: launch_resident_pt<1>(ds, a, s); break;
+      case 2: launch_resident_pt<2>(ds, a, s); break;
+      case 3: launch_resident_pt<3>(ds, a, s); break;
+      case 4: launch_resident_pt<4>(ds, a, s); break;
+      case 6: launch_resident_pt<6>(ds, a, s); break;
+      default: throw Error("resident dense kernel not instantiated for this element size");
+    }
+    PA_HIP(hipGetLastError());
+    return;
+  }
   switch (ds.PT) {
     case 1: launch_pt<1>(ds, a, s); break;
     case 2: launch_pt<2>(ds, a, s); break;

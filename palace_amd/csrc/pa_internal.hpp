@@ -134,9 +134,12 @@ struct DenseSub {
   uint32_t trial_ops = 0, test_ops = 0;
   int32_t *d_idx = nullptr;     // [nb][4 KP][16] signed index (oriented: <0 => -(1+dof) flipped); pads read zero
   int32_t *d_idx_bc = nullptr;  // copy with kEssBit on essential dofs
-  uint32_t *d_co = nullptr;     // [nb][4 KP][16] packed int8 {sub, main, super} (curl-oriented) or nullptr
+  uint16_t *d_co = nullptr;     // [nb][4 KP][16] packed int8 rows / columns of T_e (curl-oriented) or nullptr
   std::vector<int32_t> h_idx;
   double *d_Tf = nullptr, *d_Tt = nullptr;  // MFMA A-operand fragments of the tables (forward / transposed)
+  double *d_L = nullptr;       // LDS-resident form of the tables (fast path) or nullptr
+  double *d_qdata = nullptr;   // packed pre-assembled D [nb][ncq][Qpad][16] (fast path)
+  int L_rows = 0, ncq = 0, num_cu = 0;
   double *d_interp = nullptr, *d_deriv = nullptr;  // plain tables (diagonal assembly)
   int32_t *d_off = nullptr;    // plain [ne][P] offsets (diagonal assembly)
   int8_t *d_cor = nullptr;     // plain curl_orients or nullptr

@@ -49,6 +49,45 @@ def tet_quadrature(n):
     return np.array(pts), np.array(wts)
 
 
+def _orbit(bary):
+    return np.array(sorted(set(itertools.permutations(bary))))
+
+
+def tet_quadrature_symmetric(order):
+    """Fully symmetric positive interior rules: 4 points (degree 2), 14 points (degree 5), 24 points
+    (degree 6, Keast) — the point counts the reference gets from MFEM for orders 2 / 5 / 6
+    ('Q = size of MFEM's order-2p tet rule').  The orbit parameters were obtained by
+    solving the moment equations (tests/test_tet_space.py checks exactness); higher orders fall back to
+    the conical product rule."""
+    if order <= 2:
+        a = (5.0 - np.sqrt(5.0)) / 20.0
+        orbits = [((a, a, a, 1 - 3 * a), 1.0 / 24.0)]
+    elif order <= 5:
+        orbits = [((0.3108859192633006,) * 3 + (1 - 3 * 0.3108859192633006,), 0.01878132095300307),
+                  ((0.09273525031089183,) * 3 + (1 - 3 * 0.09273525031089183,), 0.01224884051939384),
+                  ((0.04550370412564658, 0.04550370412564658, 0.5 - 0.04550370412564658, 0.5 - 0.04550370412564658),
+                   0.007091003462846512)]
+    elif order <= 6:
+        a1, a2, a3 = 0.32233789014228087, 0.04067395853460012, 0.21460287125920982
+        b1, b2 = 0.06366100187502555, 0.2696723314583101
+        orbits = [((a1, a1, a1, 1 - 3 * a1), 0.009226196923940297), ((a2, a2, a2, 1 - 3 * a2), 0.0016795351758862424),
+                  ((a3, a3, a3, 1 - 3 * a3), 0.006653791709692282), ((b1, b1, b2, 1 - 2 * b1 - b2), 0.008035714285715949)]
+    else:
+        return tet_quadrature(order // 2 + 1)
+    pts, wts = [], []
+    for bary, w in orbits:
+        o = _orbit(bary)
+        pts.append(o[:, 1:])
+        wts += [w] * len(o)
+    wts = np.array(wts)
+    return np.concatenate(pts), wts / wts.sum() / 6.0
+
+
+def default_tet_rule(p):
+    """Quadrature of order 2p, the reference default (fem/integrator.cpp:14-39)."""
+    return tet_quadrature_symmetric(2 * p)
+
+
 # ---- polynomials on the reference tet (monomials in centred coordinates) -------------------------
 
 _CENTROID = np.array([0.25, 0.25, 0.25])

@@ -68,3 +68,18 @@ def test_h1_tet_partition_of_unity_and_laplace():
                                   vector_fe=False).assemble_sparse()
         assert abs(A - A.T).max() < 1e-12
         assert np.abs(A @ np.ones(h1.ndofs)).max() < 1e-11
+
+
+def test_tet_quadrature_exactness():
+    from math import factorial
+
+    for rule, deg, npts in ((lambda: tet.tet_quadrature_symmetric(2), 2, 4), (lambda: tet.tet_quadrature_symmetric(4), 5, 14),
+                            (lambda: tet.tet_quadrature_symmetric(6), 6, 24), (lambda: tet.tet_quadrature(4), 7, 64)):
+        x, w = rule()
+        assert len(w) == npts and w.min() > 0 and x.min() > 0 and x.sum(axis=1).max() < 1
+        for d in range(deg + 1):
+            for a in range(d + 1):
+                for b in range(d + 1 - a):
+                    c = d - a - b
+                    exact = factorial(a) * factorial(b) * factorial(c) / factorial(a + b + c + 3)
+                    assert abs((w * x[:, 0] ** a * x[:, 1] ** b * x[:, 2] ** c).sum() - exact) < 2e-15
