@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--pcg-iters", type=int, default=50, help="fixed PCG iterations for iterations/s (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-dofs", type=float, default=1.0e6, help="size of the CPU baseline sample")
+    ap.add_argument("--no-tets", action="store_true", help="skip the tetrahedral (dense MFMA path) leg")
+    ap.add_argument("--tet-n", type=int, default=36, help="cubes per direction of the Kuhn-split tet mesh")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the RCCL communicator even with one rank (exercises the multi-GPU code path)")
     return ap.parse_args()
@@ -76,6 +78,51 @@ def cpu_baseline(order, target_dofs):
     return {"value": nd.ndofs * reps / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
             "sample": f"curl-curl apply, ND p={order}, {mesh.ne} hex27 elements, {nd.ndofs} dofs, {reps} applies "
                       f"in {dt:.1f} s; oracle/oracle_c.c (dense-table libCEED-style CPU path restated), OpenMP"}
+
+
+def tets_leg(order, n, reps=20):
+    """The non-tensor path (dense tables on the FP64 matrix cores): Nedelec tets of the same order on a
+    Kuhn-split cube, curl-curl and curl-curl+mass `ceed::Operator::Mult`, order-2p symmetric quadrature
+    (the reference's default rule size).  Reported beside the headline, N = 1 only."""
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import tet
+
+    mesh = tet.cube_tet_mesh(n)
+    nd = tet.NDTetSpace(mesh, order)
+    pts, wts = tet.default_tet_rule(order)
+    interp, curl = nd.elem.tables(pts)
+    geom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, mesh.geometry_grad_table(pts), wts)
+    kw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+    block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, **kw)
+    ident = ceed.coefficient_context(3)
+    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
+    ops = {"curlcurl": (ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(
+                            geom, block, ceed.QF_HDIV_33, ident, ceed.EVAL_CURL).finalize(), 3),
+           "curlcurl_mass": (ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(
+                                 geom, block, ceed.QF_HDIVMASS_33, np.concatenate([mass, ident]),
+                                 ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize(), 6)}
+    x = torch.rand(nd.ndofs, dtype=torch.float64, device="cuda")
+    y = torch.zeros_like(x)
+    out = {"workload": f"ND p={order} tetrahedra (curl-oriented restriction), {mesh.ne} tets, {nd.ndofs} dofs, "
+                       f"P={nd.P}, Q={len(wts)}; dense [3Q x P] tables on v_mfma_f64_16x16x4", "dofs": nd.ndofs}
+    for name, (op, nct) in ops.items():
+        for _ in range(3):
+            op.mult(x, y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            op.mult(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        alg = op.algorithmic_bytes()
+        out[name] = {"ms": ms, "dof_per_s": nd.ndofs / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
+                     "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
+                     "table_TFLOPs": mesh.ne * (2 * 2 * nct * len(wts) * nd.P) / ms / 1e9}
+    return out
 
 
 def main():
@@ -164,8 +211,19 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / nk
     alg_bytes = local_op.algorithmic_bytes()
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM traffic of the same launch from the PMC passes (collected by scripts/profile_round.sh in separate
+    # rocprofv3 --pmc runs, summary committed under profiles/): raw FETCH_SIZE + WRITE_SIZE bytes
+    traffic, traffic_note = None, "no PMC summary under profiles/"
+    pmc_file = os.path.join(ROOT, "profiles", "r01_apply_pmc.json")
+    if os.path.exists(pmc_file) and abs(args.dofs - 10.0e6) < 1 and p == 3:
+        pmc = json.load(open(pmc_file))
+        pb = pmc["per_apply_bytes"]
+        traffic = pb.get("traffic_corrected") or pb["traffic_raw"]
+        traffic_note = ("FETCH_SIZE + WRITE_SIZE per apply from profiles/r01_apply_pmc.json (separate --pmc passes of the "
+                        "same kernels at this size), each divided by the fraction the same counters report on a known "
+                        "stream in the same run; " + pmc.get("calibration", "uncalibrated"))
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                 "kernel": "pa::nd_hex_apply_kernel<3,4,curl,qdata> + pa::et_gather_kernel (E^T)", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_formula": "NE*(Q*11*8 + P*5) + 16*N_L (SURVEY.md 8d, G=11)"}
@@ -202,6 +260,10 @@ def main():
                          "'hiptmair' = auxiliary-space smoother (reference default for driven/eigenmode); level 0: "
                          "8 Jacobi-PCG iterations (stand-in for AMS)")
 
+    tets = None
+    if rank == 0 and world == 1 and not args.no_tets:
+        tets = tets_leg(p, args.tet_n)
+
     cpu = None
     if rank == 0 and not args.no_cpu:
         cpu = cpu_baseline(p, args.cpu_dofs)
@@ -219,7 +281,7 @@ def main():
                        "true_dofs_per_gpu": n_true, "global_true_dofs": n_global, "q1d": p + 1,
                        "scaling_mode": "weak: one z-slab of the cylinder per GPU, same element count per GPU",
                        "parallelism": f"element partition x{world}, RCCL halo (P / P^T) + allreduce dots"},
-            "roofline": roofline, "cpu_baseline": cpu, "pcg": pcg, "setup_s": t_setup,
+            "roofline": roofline, "cpu_baseline": cpu, "pcg": pcg, "tets_mfma": tets, "setup_s": t_setup,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

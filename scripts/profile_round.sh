@@ -7,10 +7,10 @@
 set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
-mkdir -p $OUT
+rm -rf $OUT/prof_bench $OUT/prof_curlmass $OUT/prof_pmc* && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $REPO/bench.py --no-cpu > $OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $REPO/bench.py --no-cpu --no-tets > $OUT/prof_bench.log 2>&1
 OP=curlmass REPS=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_curlmass -- python $REPO/scripts/profile_apply.py > $OUT/prof_curlmass.log 2>&1
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
@@ -20,4 +20,4 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
   OP=curl REPS=10 timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/prof_pmc$i -- python $REPO/scripts/profile_apply.py > $OUT/prof_pmc$i.log 2>&1
 done
 cd $REPO
-python scripts/summarize_profiles.py
+CAL_N=$(grep -h '^done' $OUT/prof_pmc1.log | awk '{print $2}') python scripts/summarize_profiles.py

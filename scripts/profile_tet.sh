@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the dense MFMA (tetrahedra) path: kernel stats + PMC passes.
 set -u
-REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
+REPO=$(pwd); OUT=$REPO/gpurun_out; rm -rf $OUT/prof_tet $OUT/prof_tet_pmc*; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
 cd $REPO
@@ -28,7 +28,9 @@ for d in sorted(glob.glob(os.path.join(OUT, "prof_tet_pmc*"))):
         acc = {}
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "dense_apply" in k: k = "dense_apply<" + k.split("dense_apply_kernel<")[1].split(">")[0] + ">"
+            if "dense_apply" in k:
+                import re
+                k = re.search(r"dense_apply\w*<[^>]*>", k).group(0)
             elif "et_gather" in k: k = "et_gather"
             else: continue
             key = (k, row["Counter_Name"]); s, n = acc.get(key, (0.0, set())); n.add(row["Dispatch_Id"]); acc[key] = (s + float(row["Counter_Value"]), n)

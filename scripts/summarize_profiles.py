@@ -47,10 +47,22 @@ if pmc:
             "apply); averages per dispatch. FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE "
             "is exact only after the x2 correction for 16-B/lane streaming loads and uncalibrated for the 8-B/lane and "
             "gather loads of these kernels (MI355X_MICROARCH.md, HBM section), so both raw and x2 are given.")
-    tot_f = sum(v.get("FETCH_SIZE", 0.0) for v in pmc.values()) * 1024
-    tot_w = sum(v.get("WRITE_SIZE", 0.0) for v in pmc.values()) * 1024
-    json.dump({"note": note, "kernels": pmc,
+    apply_k = {k: v for k, v in pmc.items() if k != "calibration_axpby"}
+    tot_f = sum(v.get("FETCH_SIZE", 0.0) for v in apply_k.values()) * 1024
+    tot_w = sum(v.get("WRITE_SIZE", 0.0) for v in apply_k.values()) * 1024
+    calib = "no calibration stream in this run"
+    cal = pmc.get("calibration_axpby")
+    n_cal = int(os.environ.get("CAL_N", "0"))
+    rf = rw = None
+    if cal and n_cal:
+        rf = cal.get("FETCH_SIZE", 0) * 1024 / (16.0 * n_cal)
+        rw = cal.get("WRITE_SIZE", 0) * 1024 / (8.0 * n_cal)
+        calib = (f"calibration on y = a x + b y over {n_cal} doubles (8 B/lane loads, known 16 B read + 8 B written per "
+                 f"entry): FETCH_SIZE reports {cal.get('FETCH_SIZE', 0) * 1024 / (16.0 * n_cal):.3f} of the read bytes, "
+                 f"WRITE_SIZE {cal.get('WRITE_SIZE', 0) * 1024 / (8.0 * n_cal):.3f} of the written bytes")
+    json.dump({"note": note, "calibration": calib, "kernels": pmc,
                "per_apply_bytes": {"fetch_raw": tot_f, "fetch_x2": 2 * tot_f, "write_raw": tot_w,
-                                   "traffic_raw": tot_f + tot_w}},
+                                   "traffic_raw": tot_f + tot_w,
+                                   "traffic_corrected": (tot_f / rf + tot_w / rw) if rf and rw else None}},
               open(os.path.join(PROF, f"{TAG}_apply_pmc.json"), "w"), indent=1)
 print(sorted(os.listdir(PROF)))
