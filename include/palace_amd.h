@@ -203,6 +203,10 @@ int pa_op_finalize(pa_op *op);
  * `fine`, coarse restriction + basis.  `fine` must have a single element block. */
 int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_basis_desc *basis,
                   pa_op **coarse);
+/* The same for an operator made of dense sub-operators (same geometry data, quadrature rule, QFunction
+ * and contexts; coarse restriction and dense tables evaluated at the FINE level's quadrature points). */
+int pa_op_coarsen_dense(const pa_op *fine, const pa_restriction_desc *restr, const pa_dense_basis_desc *basis,
+                        pa_op **coarse);
 /* Operator::AddMult with a == 1 (operator.cpp:192-212): y += A x on L-vectors (device pointers). */
 int pa_op_apply_add(pa_op *op, const double *x, double *y, void *stream);
 /* Operator::Mult (operator.cpp:182-190): y = A x. */

@@ -127,6 +127,14 @@ int pa_interp_create(pa_context *ctx, const pa_restriction_desc *coarse_restr,
 int pa_gradient_create(pa_context *ctx, const pa_restriction_desc *h1_restr, const pa_basis_desc *h1_basis,
                        const pa_restriction_desc *nd_restr, const pa_basis_desc *nd_basis, const double *Dg,
                        pa_halo *h1_halo, int n_true_h1, int n_true_nd, pa_interp **G);
+/* The same two operators for non-tensor elements (tetrahedra, ...): the element projection matrix
+ * M [P_range][P_domain] (row-major) MFEM's GetTransferMatrix / discrete-gradient interpolator gives
+ * (basis.cpp:132-150), with the native restrictions of both spaces.  When the range space has a dof
+ * transformation its restriction must be the one Palace builds for an interpolator range
+ * (InvTransformDual, restriction.cpp:318-336). */
+int pa_interp_create_dense(pa_context *ctx, const pa_restriction_desc *domain_restr,
+                           const pa_restriction_desc *range_restr, const double *M, pa_halo *domain_halo,
+                           int n_true_domain, int n_true_range, pa_interp **P);
 int pa_interp_mult(pa_interp *P, const double *x_coarse, double *y_fine);
 int pa_interp_mult_transpose(pa_interp *P, const double *x_fine, double *y_coarse);
 void pa_interp_destroy(pa_interp *P);

@@ -699,3 +699,55 @@ def nd_hex_gradient_lex(p):
                         col = col_idx[0] + n1 * (col_idx[1] + n1 * col_idx[2])
                         M[row, col] = lagrange(cp, op[idx[comp]], a)[1]
     return M
+
+
+class DenseInterpOracle:
+    """The interpolator operator of DiscreteLinearOperator::PartialAssemble (bilinearform.cpp:203-282) for
+    general elements: y = D^-1 sum_e E_range^T M E_domain x, D = dof multiplicity of the range space
+    (:256-279); restrictions plain / oriented / curl-oriented, the range one in its interpolator-range
+    (dual inverse) form (restriction.cpp:318-336)."""
+
+    def __init__(self, dom, rng, M):
+        self.M = np.asarray(M, dtype=np.float64)
+        self.dom, self.rng = dom, rng
+        self.mult_r = np.bincount(np.asarray(rng["offsets"]).ravel(), minlength=rng["lsize"]).astype(np.float64)
+
+    @staticmethod
+    def _apply_rows(r, u):
+        """u_e = T u (rows of the tridiagonal / sign matrix applied)."""
+        if r.get("curl_orients") is not None:
+            t = np.asarray(r["curl_orients"], dtype=np.float64)
+            v = t[:, :, 1] * u
+            v[:, 1:] += t[:, 1:, 0] * u[:, :-1]
+            v[:, :-1] += t[:, :-1, 2] * u[:, 1:]
+            return v
+        if r.get("orients") is not None:
+            return u * np.where(np.asarray(r["orients"]), -1.0, 1.0)
+        return u
+
+    @staticmethod
+    def _apply_rows_t(r, v):
+        if r.get("curl_orients") is not None:
+            t = np.asarray(r["curl_orients"], dtype=np.float64)
+            w = t[:, :, 1] * v
+            w[:, :-1] += t[:, 1:, 0] * v[:, 1:]
+            w[:, 1:] += t[:, :-1, 2] * v[:, :-1]
+            return w
+        if r.get("orients") is not None:
+            return v * np.where(np.asarray(r["orients"]), -1.0, 1.0)
+        return v
+
+    def mult(self, x):
+        u = self._apply_rows(self.dom, x[self.dom["offsets"]])
+        w = self._apply_rows_t(self.rng, u @ self.M.T)
+        y = np.zeros(self.rng["lsize"])
+        np.add.at(y, np.asarray(self.rng["offsets"]).ravel(), w.ravel())
+        return y / self.mult_r
+
+    def mult_transpose(self, x):
+        z = (x / self.mult_r)[self.rng["offsets"]]
+        u = self._apply_rows(self.rng, z) @ self.M
+        w = self._apply_rows_t(self.dom, u)
+        y = np.zeros(self.dom["lsize"])
+        np.add.at(y, np.asarray(self.dom["offsets"]).ravel(), w.ravel())
+        return y

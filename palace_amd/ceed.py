@@ -245,6 +245,13 @@ class Operator:
         _lib.check(_lib.load().pa_op_coarsen(self.handle, C.byref(r), C.byref(b), C.byref(h)))
         return Operator(space_coarse.ndofs, space_coarse.ndofs, handle=h)
 
+    def coarsen_dense(self, block: "DenseBlock"):
+        """CeedOperatorCoarsen for dense sub-operators: coarse restriction + tables at the fine rule."""
+        r, b = block.descs()
+        h = C.c_void_p()
+        _lib.check(_lib.load().pa_op_coarsen_dense(self.handle, C.byref(r), C.byref(b), C.byref(h)))
+        return Operator(block.lsize, block.lsize, handle=h)
+
     def mult(self, x, y):
         _lib.check(_lib.load().pa_op_mult(self.handle, C.c_void_p(x.data_ptr()),
                                           C.c_void_p(y.data_ptr()), _stream()))

@@ -504,6 +504,26 @@ int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_
   });
 }
 
+int pa_op_coarsen_dense(const pa_op *fine, const pa_restriction_desc *restr, const pa_dense_basis_desc *basis,
+                        pa_op **coarse) {
+  return guarded([&] {
+    PA_REQUIRE(fine && restr && basis && coarse, "null argument");
+    PA_REQUIRE(fine->finalized && fine->subs.empty() && !fine->dsubs.empty(), "fine operator has no dense sub-operators");
+    auto *o = new pa_op;
+    o->height = o->width = restr->lsize;
+    try {
+      for (const DenseSub *fs : fine->dsubs)
+        o->dsubs.push_back(make_dense_sub(static_cast<pa_geom *>(fs->geom), *restr, *basis, fs->qf, fs->ctx_blob.data(),
+                                          fs->ctx_blob.size(), fs->trial_ops, fs->test_ops, o->height));
+    } catch (...) {
+      pa_op_destroy(o);
+      throw;
+    }
+    o->finalized = true;
+    *coarse = o;
+  });
+}
+
 int pa_op_apply_add(pa_op *op, const double *x, double *y, void *stream) {
   return guarded([&] { apply(op, x, y, false, (hipStream_t)stream); });
 }

@@ -219,7 +219,219 @@ std::vector<int32_t> signed_lex_index(const pa_restriction_desc &r, const pa_bas
   return lidx;
 }
 
+// ---- dense element interpolator (tetrahedra and other non-tensor elements) ----------------------
+// The libCEED interpolator operator of DiscreteLinearOperator::PartialAssemble for a general element:
+// identity QFunction + the P_range x P_domain element projection matrix as "basis"
+// (fem/libceed/basis.cpp:116-165), domain restriction as for any operator, range restriction built
+// with the DUAL inverse transformation when the space has one (restriction.cpp:318-336): with
+// domain rows T (u_e = T x_e) and range rows B (E_range^T applies B^T),
+//     y_range = D^-1 sum_e  S_e^T  B_e^T  M  T_e  x_domain[off_e]
+// Every copy of a shared range dof is equal, so one owner copy is stored instead of summing and
+// scaling by the inverse multiplicity (as in interp_kernel above); the transpose reads through the
+// same owner mask.  One wave per element; P <= 256 on either side.
+struct DenseInterpArgs {
+  int ne, Pd, Pr;
+  const int32_t *off_d, *off_r;   // [ne][P]; range offsets carry kOwnBit on the owner copy
+  const int8_t *sgn_d, *sgn_r;    // oriented: +-1 per entry, or nullptr
+  const int8_t *T_d, *B_r;        // curl-oriented: [ne][P][3] {sub, main, super}, or nullptr
+  const double *M;                // [Pr][Pd]
+  const double *x;
+  double *y;     // forward: range L-vector
+  double *ye_d;  // transpose: domain E-vector [ne][Pd]
+};
+
+constexpr int kDenseInterpMaxP = 256;
+
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(64) void dense_interp_kernel(const DenseInterpArgs a) {
+  __shared__ double s0[kDenseInterpMaxP], s1[kDenseInterpMaxP];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const int32_t *od = a.off_d + (size_t)e * a.Pd, *orr = a.off_r + (size_t)e * a.Pr;
+  if (!TRANSPOSE) {
+    for (int i = lane; i < a.Pd; i += 64) {
+      double v = a.x[od[i]];
+      if (a.sgn_d) v *= (double)a.sgn_d[(size_t)e * a.Pd + i];
+      s0[i] = v;
+    }
+    wsync();
+    if (a.T_d) {  // u = T x_e
+      const int8_t *T = a.T_d + 3 * (size_t)e * a.Pd;
+      for (int i = lane; i < a.Pd; i += 64)
+        s1[i] = (double)T[3 * i] * s0[max(i - 1, 0)] + (double)T[3 * i + 1] * s0[i] +
+                (double)T[3 * i + 2] * s0[min(i + 1, a.Pd - 1)];
+      wsync();
+      for (int i = lane; i < a.Pd; i += 64) s0[i] = s1[i];
+      wsync();
+    }
+    for (int j = lane; j < a.Pr; j += 64) {  // v = M u
+      const double *row = a.M + (size_t)j * a.Pd;
+      double v = 0.0;
+      for (int i = 0; i < a.Pd; i++) v += row[i] * s0[i];
+      s1[j] = v;
+    }
+    wsync();
+    const int8_t *B = a.B_r ? a.B_r + 3 * (size_t)e * a.Pr : nullptr;
+    for (int j = lane; j < a.Pr; j += 64) {  // w = B^T v (or the sign), owner copy stored
+      const int o = orr[j];
+      if (!(o & kOwnBit)) continue;
+      double w;
+      if (B) {
+        w = (double)B[3 * j + 1] * s1[j];
+        if (j > 0) w += (double)B[3 * (j - 1) + 2] * s1[j - 1];
+        if (j + 1 < a.Pr) w += (double)B[3 * (j + 1)] * s1[j + 1];
+      } else {
+        w = a.sgn_r ? (double)a.sgn_r[(size_t)e * a.Pr + j] * s1[j] : s1[j];
+      }
+      a.y[o & ~kOwnBit] = w;
+    }
+  } else {
+    for (int j = lane; j < a.Pr; j += 64) {  // z = owner-masked range values
+      const int o = orr[j];
+      double v = (o & kOwnBit) ? a.x[o & ~kOwnBit] : 0.0;
+      if (a.sgn_r) v *= (double)a.sgn_r[(size_t)e * a.Pr + j];
+      s0[j] = v;
+    }
+    wsync();
+    if (a.B_r) {  // v = B z
+      const int8_t *B = a.B_r + 3 * (size_t)e * a.Pr;
+      for (int j = lane; j < a.Pr; j += 64)
+        s1[j] = (double)B[3 * j] * s0[max(j - 1, 0)] + (double)B[3 * j + 1] * s0[j] +
+                (double)B[3 * j + 2] * s0[min(j + 1, a.Pr - 1)];
+      wsync();
+      for (int j = lane; j < a.Pr; j += 64) s0[j] = s1[j];
+      wsync();
+    }
+    for (int i = lane; i < a.Pd; i += 64) {  // u = M^T v
+      double v = 0.0;
+      for (int j = 0; j < a.Pr; j++) v += a.M[(size_t)j * a.Pd + i] * s0[j];
+      s1[i] = v;
+    }
+    wsync();
+    const int8_t *T = a.T_d ? a.T_d + 3 * (size_t)e * a.Pd : nullptr;
+    for (int i = lane; i < a.Pd; i += 64) {  // w = T^T u (or the sign) into the domain E-vector
+      double w;
+      if (T) {
+        w = (double)T[3 * i + 1] * s1[i];
+        if (i > 0) w += (double)T[3 * (i - 1) + 2] * s1[i - 1];
+        if (i + 1 < a.Pd) w += (double)T[3 * (i + 1)] * s1[i + 1];
+      } else {
+        w = a.sgn_d ? (double)a.sgn_d[(size_t)e * a.Pd + i] * s1[i] : s1[i];
+      }
+      a.ye_d[(size_t)e * a.Pd + i] = w;
+    }
+  }
+}
+
+class DenseInterpOperator : public Operator {
+  const Context *ctx_;
+  const Halo *halo_d_;
+  int ne_, Pd_, Pr_, nl_d_, nl_r_, nt_d_, nt_r_;
+  int32_t *d_off_d_ = nullptr, *d_off_r_ = nullptr, *d_tptr_ = nullptr, *d_tent_ = nullptr;
+  int8_t *d_sgn_d_ = nullptr, *d_sgn_r_ = nullptr, *d_T_d_ = nullptr, *d_B_r_ = nullptr;
+  double *d_M_ = nullptr, *d_ye_ = nullptr;
+  mutable Vector ld_, lr_;
+
+  template <bool TR>
+  void launch(const double *x, double *y) const {
+    DenseInterpArgs a{ne_, Pd_, Pr_, d_off_d_, d_off_r_, d_sgn_d_, d_sgn_r_, d_T_d_, d_B_r_, d_M_, x, y, d_ye_};
+    hipLaunchKernelGGL((dense_interp_kernel<TR>), dim3(ne_), dim3(64), 0, ctx_->stream, a);
+    PA_HIP(hipGetLastError());
+  }
+  static int8_t *signs(const pa_restriction_desc &r, hipStream_t s) {
+    if (!r.orients) return nullptr;
+    std::vector<int8_t> v((size_t)r.num_elem * r.elem_size);
+    for (size_t k = 0; k < v.size(); k++) v[k] = r.orients[k] ? -1 : 1;
+    return pa::dev_upload(v.data(), v.size(), s);
+  }
+
+public:
+  DenseInterpOperator(const Context &ctx, const pa_restriction_desc &rd, const pa_restriction_desc &rr, const double *M,
+                      const Halo *halo_d, int nt_d, int nt_r)
+      : Operator(nt_r, nt_d), ctx_(&ctx), halo_d_(halo_d), ne_(rd.num_elem), Pd_(rd.elem_size), Pr_(rr.elem_size),
+        nl_d_(rd.lsize), nl_r_(rr.lsize), nt_d_(nt_d), nt_r_(nt_r) {
+    PA_REQUIRE(rd.num_elem == rr.num_elem, "interpolation needs the same mesh on both sides");
+    PA_REQUIRE(M && rd.offsets && rr.offsets, "null argument");
+    PA_REQUIRE(Pd_ <= kDenseInterpMaxP && Pr_ <= kDenseInterpMaxP, "element too large for the dense interpolator");
+    PA_REQUIRE(!(rd.orients && rd.curl_orients) && !(rr.orients && rr.curl_orients), "restriction is oriented or curl-oriented");
+    PA_REQUIRE(nt_d <= nl_d_ && nt_r <= nl_r_, "true dof counts exceed local sizes");
+    PA_REQUIRE(halo_d || nt_d == nl_d_, "ghost dofs on the domain side need a halo plan");
+    PA_REQUIRE(nl_r_ < kOwnBit, "too many range dofs for the owner-flag encoding");
+    const size_t nd = (size_t)ne_ * Pd_, nr = (size_t)ne_ * Pr_;
+    std::vector<int32_t> offr(rr.offsets, rr.offsets + nr);
+    {
+      std::vector<char> seen((size_t)nl_r_, 0);
+      for (auto &o : offr) {
+        PA_REQUIRE(o >= 0 && o < nl_r_, "range offset out of range");
+        if (!seen[o]) seen[o] = 1, o |= kOwnBit;
+      }
+    }
+    {
+      std::vector<int32_t> tptr((size_t)nl_d_ + 1, 0), tent(nd);
+      for (size_t k = 0; k < nd; k++) {
+        PA_REQUIRE(rd.offsets[k] >= 0 && rd.offsets[k] < nl_d_, "domain offset out of range");
+        tptr[(size_t)rd.offsets[k] + 1]++;
+      }
+      for (int d = 0; d < nl_d_; d++) tptr[d + 1] += tptr[d];
+      std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+      for (size_t k = 0; k < nd; k++) tent[fill[rd.offsets[k]]++] = (int32_t)k;
+      d_tptr_ = pa::dev_upload(tptr.data(), tptr.size(), ctx.stream);
+      d_tent_ = pa::dev_upload(tent.data(), tent.size(), ctx.stream);
+      d_ye_ = pa::dev_alloc<double>(nd);
+    }
+    d_off_d_ = pa::dev_upload(rd.offsets, nd, ctx.stream);
+    d_off_r_ = pa::dev_upload(offr.data(), nr, ctx.stream);
+    d_sgn_d_ = signs(rd, ctx.stream), d_sgn_r_ = signs(rr, ctx.stream);
+    if (rd.curl_orients) d_T_d_ = pa::dev_upload(rd.curl_orients, 3 * nd, ctx.stream);
+    if (rr.curl_orients) d_B_r_ = pa::dev_upload(rr.curl_orients, 3 * nr, ctx.stream);
+    d_M_ = pa::dev_upload(M, (size_t)Pr_ * Pd_, ctx.stream);
+    ld_.SetSize(nl_d_), lr_.SetSize(nl_r_);
+  }
+  ~DenseInterpOperator() override {
+    (void)hipFree(d_off_d_), (void)hipFree(d_off_r_), (void)hipFree(d_tptr_), (void)hipFree(d_tent_);
+    (void)hipFree(d_sgn_d_), (void)hipFree(d_sgn_r_), (void)hipFree(d_T_d_), (void)hipFree(d_B_r_);
+    (void)hipFree(d_M_), (void)hipFree(d_ye_);
+  }
+  void Mult(const Vector &x, Vector &y) const override {
+    const Context &c = *ctx_;
+    PA_REQUIRE(x.Size() == nt_d_ && y.Size() == nt_r_, "size mismatch in interpolation");
+    if (!halo_d_ && nt_d_ == nl_d_ && nt_r_ == nl_r_) {
+      launch<false>(x.Data(), y.Data());
+      return;
+    }
+    Vector td(ld_.Data(), nt_d_);
+    linalg::Copy(c, x, td);
+    if (halo_d_) halo_d_->Prolongate(ld_.Data(), c.stream);
+    launch<false>(ld_.Data(), lr_.Data());
+    Vector tr(lr_.Data(), nt_r_);
+    linalg::Copy(c, tr, y);
+  }
+  void MultTranspose(const Vector &x, Vector &y) const override {
+    const Context &c = *ctx_;
+    PA_REQUIRE(x.Size() == nt_r_ && y.Size() == nt_d_, "size mismatch in restriction");
+    const bool serial = !halo_d_ && nt_d_ == nl_d_ && nt_r_ == nl_r_;
+    if (!serial) {
+      Vector tr(lr_.Data(), nt_r_);
+      linalg::Copy(c, x, tr);
+      if (nl_r_ > nt_r_)
+        PA_HIP(hipMemsetAsync(lr_.Data() + nt_r_, 0, sizeof(double) * (size_t)(nl_r_ - nt_r_), c.stream));
+    }
+    launch<true>(serial ? x.Data() : lr_.Data(), nullptr);
+    hipLaunchKernelGGL(k_gather, dim3((nl_d_ + 255) / 256), dim3(256), 0, c.stream, nl_d_, d_tptr_, d_tent_, d_ye_,
+                       serial ? y.Data() : ld_.Data());
+    PA_HIP(hipGetLastError());
+    if (serial) return;
+    if (halo_d_) halo_d_->RestrictAdd(ld_.Data(), c.stream);
+    Vector td(ld_.Data(), nt_d_);
+    linalg::Copy(c, td, y);
+  }
+};
+
 }  // namespace
+
+Operator *make_dense_interp_operator(const Context &ctx, const pa_restriction_desc &rd, const pa_restriction_desc &rr,
+                                     const double *M, const Halo *halo_d, int nt_d, int nt_r) {
+  return new DenseInterpOperator(ctx, rd, rr, M, halo_d, nt_d, nt_r);
+}
 
 // The prolongation as an Operator on T-vectors: Mult coarse -> fine, MultTranspose fine -> coarse.
 class InterpOperator : public Operator {

@@ -9,6 +9,8 @@
 using namespace palace;
 
 namespace palace {
+Operator *make_dense_interp_operator(const Context &ctx, const pa_restriction_desc &rd, const pa_restriction_desc &rr,
+                                     const double *M, const Halo *halo_d, int nt_d, int nt_r);
 Operator *make_interp_operator(const Context &ctx, const pa_restriction_desc &rc, const pa_basis_desc &bc,
                                const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic,
                                const double *Io, const Halo *halo_c, int nt_c, int nt_f, int kind);
@@ -342,6 +344,17 @@ int pa_gradient_create(pa_context *ctx, const pa_restriction_desc *rh, const pa_
     p->op.reset(make_interp_operator(ctx->ctx, *rh, *bh, *rn, *bn, I.data(), Dg,
                                      h1_halo ? h1_halo->halo.get() : nullptr, nt_h1, nt_nd, 1));
     *G = p;
+  });
+}
+int pa_interp_create_dense(pa_context *ctx, const pa_restriction_desc *dom, const pa_restriction_desc *range,
+                           const double *M, pa_halo *dom_halo, int nt_dom, int nt_range, pa_interp **P) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && dom && range && M && P, "null argument");
+    auto *p = new pa_interp;
+    p->ctx = ctx;
+    p->op.reset(make_dense_interp_operator(ctx->ctx, *dom, *range, M, dom_halo ? dom_halo->halo.get() : nullptr, nt_dom,
+                                           nt_range));
+    *P = p;
   });
 }
 int pa_interp_mult(pa_interp *P, const double *x, double *y) {

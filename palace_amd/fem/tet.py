@@ -512,6 +512,32 @@ class NDTetSpace:
         self.diagonal_transform = bool(np.all(T[:, :, 0] == 0) and np.all(T[:, :, 2] == 0))
         self.orients = (T[:, :, 1] < 0) if self.diagonal_transform else None
 
+    def restriction(self, interp_range=False):
+        """dict(offsets, lsize, orients | curl_orients) as the C ABI takes it.  interp_range: the form
+        Palace builds for the RANGE of an interpolator (InvTransformDual, restriction.cpp:318-336): rows of
+        B with E_range^T = B^T = T^-1, i.e. B = T^-T, again 2x2 integer blocks."""
+        r = dict(offsets=self.offsets, lsize=self.ndofs)
+        if self.diagonal_transform:
+            r["orients"] = self.orients  # +-1: its own inverse
+            return r
+        if not interp_range:
+            r["curl_orients"] = self.curl_orients
+            return r
+        T = self.curl_orients.astype(np.int64)
+        B = np.zeros_like(T)
+        B[:, :, 1] = T[:, :, 1]  # diagonal (+-1) entries: own inverse
+        p = self.p
+        n_f = p * (p - 1)
+        base = 6 * p
+        for j0 in range(base, base + 4 * n_f, 2):
+            a, b, c, d = T[:, j0, 1], T[:, j0, 2], T[:, j0 + 1, 0], T[:, j0 + 1, 1]
+            det = a * d - b * c
+            assert np.all(np.abs(det) == 1)
+            B[:, j0, 1], B[:, j0, 2] = d * det, -c * det          # rows of T^-T = (1/det) [[d, -c], [-b, a]]
+            B[:, j0 + 1, 0], B[:, j0 + 1, 1] = -b * det, a * det
+        r["curl_orients"] = B.astype(np.int8)
+        return r
+
     def ess_dofs(self, face_mask=None):
         """Dofs on boundary faces (all of them, or those selected by face_mask over mesh.face_verts)."""
         m = self.mesh
@@ -559,8 +585,32 @@ class NDTetSpace:
         return x
 
 
+def nd_tet_transfer_matrix(pc, pf):
+    """Element matrix of the p-prolongation ND(pc) -> ND(pf) (MFEM GetTransferMatrix, basis.cpp:132-138):
+    fine dof functionals applied to the coarse basis, [P_f, P_c]."""
+    fine = NDTetElement(pf)
+    interp, _ = NDTetElement(pc).tables(fine.dof_pts)      # [3, P_f, P_c]
+    return np.ascontiguousarray(np.einsum("dji,jd->ji", interp, fine.dof_tans))
+
+
+def h1_tet_transfer_matrix(pc, pf):
+    interp, _ = H1TetElement(pc).tables(h1_tet_nodes(pf))  # [1, P_f, P_c]
+    return np.ascontiguousarray(interp[0])
+
+
+def tet_gradient_matrix(p):
+    """Element matrix of the discrete gradient H1(p) -> ND(p) (basis.cpp:139-143): ND functionals of the
+    gradients of the H1 basis, [P_nd, P_h1]."""
+    nd = NDTetElement(p)
+    _, grad = H1TetElement(p).tables(nd.dof_pts)           # [3, P_nd, P_h1]
+    return np.ascontiguousarray(np.einsum("dji,jd->ji", grad, nd.dof_tans))
+
+
 class H1TetSpace:
     """Order-p nodal H1 space on a TetMesh: global dofs = vertices | edges | faces | interiors."""
+
+    def restriction(self, interp_range=False):
+        return dict(offsets=self.offsets, lsize=self.ndofs)
 
     def __init__(self, mesh: TetMesh, p: int):
         self.mesh, self.p = mesh, p

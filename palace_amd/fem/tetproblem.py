@@ -1,0 +1,80 @@
+"""A PEC cavity problem on a tetrahedral mesh, all p-levels: spaces, dense-path operators, dense
+interpolators — the tetrahedral counterpart of partition.SlabProblem (one rank)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import tet
+
+
+class TetProblem:
+    def __init__(self, ctx, mesh: tet.TetMesh, p: int, orders=None):
+        from .. import ceed
+
+        self.ctx, self.mesh, self.p = ctx, mesh, p
+        self.orders = list(range(1, p + 1)) if orders is None else list(orders)
+        self.spaces = [tet.NDTetSpace(mesh, q) for q in self.orders]
+        self.pts, self.wts = tet.default_tet_rule(p)  # every level integrates with the fine rule
+        self.geom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr,
+                                             mesh.geometry_grad_table(self.pts), self.wts)
+        self.ess = [s.ess_dofs() for s in self.spaces]
+        self._keep = []
+
+    def nd_block(self, s):
+        from .. import ceed
+
+        interp, curl = s.elem.tables(self.pts)
+        kw = dict(orients=s.orients) if s.diagonal_transform else dict(curl_orients=s.curl_orients)
+        return ceed.DenseBlock(ceed.FE_HCURL, s.ndofs, s.offsets, interp, curl, **kw)
+
+    def h1_block(self, s):
+        from .. import ceed
+
+        interp, grad = s.elem.tables(self.pts)
+        return ceed.DenseBlock(ceed.FE_H1, s.ndofs, s.offsets, interp, grad)
+
+    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False):
+        """Same configuration as SlabProblem.pcg_gmg_solver (reference iodata.cpp:519-564)."""
+        import torch
+
+        from .. import ceed, linalg
+
+        ctx = self.ctx
+        mass = ceed.coefficient_context(3, attr_mat=[0] * int(self.mesh.attr.max()), mat_coeff=[np.array([eps_r])])
+        curl = ceed.coefficient_context(3)
+        blocks = [self.nd_block(s) for s in self.spaces]
+        fine = ceed.Operator(self.spaces[-1].ndofs, self.spaces[-1].ndofs).add_dense_integrator(
+            self.geom, blocks[-1], ceed.QF_HDIVMASS_33, np.concatenate([mass, curl]),
+            ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
+        local = [fine.coarsen_dense(b) for b in blocks[:-1]] + [fine]
+        A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE) for op, e in zip(local, self.ess)]
+        P = [linalg.DenseInterp(ctx, self.spaces[l].restriction(), self.spaces[l + 1].restriction(interp_range=True),
+                                tet.nd_tet_transfer_matrix(self.orders[l], self.orders[l + 1]))
+             for l in range(len(A) - 1)]
+        aux = {}
+        if hiptmair:
+            h1s = [tet.H1TetSpace(self.mesh, q) for q in self.orders]
+            hb = [self.h1_block(s) for s in h1s]
+            fine_h1 = ceed.Operator(h1s[-1].ndofs, h1s[-1].ndofs).add_dense_integrator(
+                self.geom, hb[-1], ceed.QF_HCURL_33, mass, ceed.EVAL_GRAD).finalize()
+            loc_h1 = [fine_h1.coarsen_dense(b) for b in hb[:-1]] + [fine_h1]
+            A_h1 = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE) for op, s in zip(loc_h1, h1s)]
+            G = [linalg.DenseInterp(ctx, h.restriction(), n.restriction(interp_range=True), tet.tet_gradient_matrix(q))
+                 for h, n, q in zip(h1s, self.spaces, self.orders)]
+            aux = dict(A_aux=A_h1, G=G)
+            self._keep.append((h1s, loc_h1, hb))
+        if len(A) > 1:
+            coarse = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
+            B = linalg.gmg(ctx, A, P, coarse, cheby_order=max(2 * self.p, 4), **aux)
+        else:
+            B = linalg.jacobi(ctx, A[0])
+        K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)
+        n = self.spaces[-1].ndofs
+        ones = torch.ones(n, dtype=torch.float64, device="cuda")
+        b = torch.empty_like(ones)
+        A[-1].mult(ones, b)
+        b[torch.from_numpy(self.ess[-1].astype(np.int64)).cuda()] = 0.0
+        x = torch.zeros_like(b)
+        self._keep.append((blocks, local, A, P, B))
+        self.A = A
+        return K, b, x

@@ -233,6 +233,34 @@ class Interp:
             pass
 
 
+class DenseInterp(Interp):
+    """Element-matrix interpolator between two spaces on the same non-tensor mesh (p-prolongation or
+    discrete gradient on tetrahedra): pa_interp_create_dense.  `dom` / `rng` are dicts with `offsets`
+    [ne, P], `lsize`, and optionally `orients` (bool) or `curl_orients` (int8 [ne, P, 3]; for the range the
+    dual-inverse form, restriction.cpp:318-336); M is the [P_range, P_domain] element matrix."""
+
+    def __init__(self, ctx, dom, rng, M, dom_halo=None, n_true_dom=None, n_true_rng=None):
+        self.ctx = ctx
+        keep = []
+
+        def desc(r):
+            off = np.ascontiguousarray(r["offsets"], dtype=np.int32)
+            ori = None if r.get("orients") is None else np.ascontiguousarray(r["orients"], dtype=np.uint8)
+            cor = None if r.get("curl_orients") is None else np.ascontiguousarray(r["curl_orients"], dtype=np.int8)
+            keep.extend([off, ori, cor])
+            return _lib.RestrictionDesc(off.shape[0], off.shape[1], int(r["lsize"]), _ptr(off), _ptr(ori), _ptr(cor))
+
+        rd, rr = desc(dom), desc(rng)
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        assert M.shape == (rng["offsets"].shape[1], dom["offsets"].shape[1])
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_interp_create_dense(ctx.handle, C.byref(rd), C.byref(rr), _ptr(M),
+                                               dom_halo.handle if dom_halo else None,
+                                               int(dom["lsize"]) if n_true_dom is None else n_true_dom,
+                                               int(rng["lsize"]) if n_true_rng is None else n_true_rng,
+                                               C.byref(self.handle)))
+
+
 class Gradient(Interp):
     """Discrete gradient G : H1(p) -> ND(p) (the auxiliary-space transfer of the Hiptmair smoother)."""
 

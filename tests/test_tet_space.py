@@ -83,3 +83,48 @@ def test_tet_quadrature_exactness():
                     c = d - a - b
                     exact = factorial(a) * factorial(b) * factorial(c) / factorial(a + b + c + 3)
                     assert abs((w * x[:, 0] ** a * x[:, 1] ** b * x[:, 2] ** c).sum() - exact) < 2e-15
+
+
+@pytest.mark.parametrize("pc,pf", [(1, 2), (2, 3), (1, 3)])
+def test_tet_prolongation_and_gradient_oracle(pc, pf):
+    """CPU: the dense interpolator oracle with the dual-inverse range restriction reproduces fields of the
+    coarse space exactly, and the discrete gradient commutes with nodal interpolation."""
+    mesh = tet.to_quadratic(tet.cube_tet_mesh(2), lambda X: X + 0.03 * np.sin(3 * X[:, [1, 2, 0]]))
+    ndc, ndf = tet.NDTetSpace(mesh, pc), tet.NDTetSpace(mesh, pf)
+    P = po.DenseInterpOracle(ndc.restriction(), ndf.restriction(interp_range=True), tet.nd_tet_transfer_matrix(pc, pf))
+    F = _field(pc)   # gradient of a degree-pc polynomial: in ND(pc) on straight elements ...
+    meshs = tet.cube_tet_mesh(2)
+    ndc_s, ndf_s = tet.NDTetSpace(meshs, pc), tet.NDTetSpace(meshs, pf)
+    Ps = po.DenseInterpOracle(ndc_s.restriction(), ndf_s.restriction(interp_range=True), tet.nd_tet_transfer_matrix(pc, pf))
+    xc, xf = ndc_s.interpolate(F), ndf_s.interpolate(F)
+    assert np.abs(Ps.mult(xc) - xf).max() < 1e-12 * np.abs(xf).max()
+    # ... on the curved mesh: the prolongation of any coarse vector is the same FUNCTION, so the fine
+    # mass form of P x equals the coarse mass form of x
+    pts, wts = tet.tet_quadrature(pf + 1)
+    geom = _geom(mesh, pts, wts)
+
+    def mass(nd):
+        interp, curl = nd.elem.tables(pts)
+        kw = dict(curl_orients=nd.curl_orients)
+        return po.CeedOperatorOracle(nd.ndofs, nd.offsets, None, interp, curl, geom, po.QF_HCURL, po.CoeffCtx(), **kw)
+
+    x = np.random.default_rng(0).uniform(-1, 1, ndc.ndofs)
+    Mc, Mf = mass(ndc), mass(ndf)
+    y = P.mult(x)
+    a = x @ Mc.apply_add(x, np.zeros(ndc.ndofs))
+    b = y @ Mf.apply_add(y, np.zeros(ndf.ndofs))
+    assert abs(a - b) < 1e-11 * abs(a)
+    # transpose consistency
+    z = np.random.default_rng(1).uniform(-1, 1, ndf.ndofs)
+    assert abs(z @ P.mult(x) - P.mult_transpose(z) @ x) < 1e-12 * np.abs(z).sum()
+    # gradient: G (nodal values of phi) = ND interpolant of grad phi, for a polynomial of degree pf
+    h1 = tet.H1TetSpace(meshs, pf)
+    G = po.DenseInterpOracle(h1.restriction(), ndf_s.restriction(interp_range=True), tet.tet_gradient_matrix(pf))
+    nodes = np.zeros((h1.ndofs, 3))
+    Xn = np.einsum("qn,eni->eqi", np.stack([1 - h1.elem.nodes.sum(axis=1), *h1.elem.nodes.T], axis=1), meshs.verts[meshs.tets])
+    nodes[h1.offsets.ravel()] = Xn.reshape(-1, 3)
+    x_, y_, z_ = nodes.T
+    phi = {1: x_ + 2 * y_ - z_, 2: x_ * y_ + x_**2 - y_ * z_ + 1.5 * z_**2, 3: x_**2 * y_ + x_ * z_**2 - y_**2 * z_}[pf]
+    g = G.mult(phi)
+    ref = ndf_s.interpolate(_field(pf))
+    assert np.abs(g - ref).max() < 1e-11 * np.abs(ref).max()
