@@ -122,6 +122,22 @@ def tets_leg(order, n, reps=20):
         out[name] = {"ms": ms, "dof_per_s": nd.ndofs / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
                      "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
                      "table_TFLOPs": mesh.ne * (2 * 2 * nct * len(wts) * nd.P) / ms / 1e9}
+    # PCG + p-multigrid (p = 1..order) with the auxiliary-space smoother on the same mesh
+    from palace_amd import linalg
+    from palace_amd.fem.tetproblem import TetProblem
+
+    prob = TetProblem(linalg.Context(), mesh, order)
+    solver, b, xs = prob.pcg_gmg_solver(max_it=400, rel_tol=1e-8, hiptmair=True)
+    solver.mult(b, xs)  # warm-up
+    xs.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    solver.mult(b, xs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = solver.stats()
+    out["pcg_hiptmair"] = {"iterations_to_1e-8": st["iterations"], "seconds": dt, "iters_per_s": st["iterations"] / dt,
+                           "converged": st["converged"]}
     return out
 
 

@@ -56,6 +56,10 @@ int pa_par_op_create(pa_context *ctx, pa_op *local, int n_true, const int32_t *e
                      int diag_policy, pa_halo *halo, pa_par_op **A);
 void pa_par_op_destroy(pa_par_op *A);
 int pa_par_op_mult(pa_par_op *A, const double *x, double *y);
+/* ParOperator::AddMult (rap.cpp:277-318): y += a (P^T A P with the essential-dof handling) x. */
+int pa_par_op_add_mult(pa_par_op *A, const double *x, double *y, double a);
+/* ParOperator::EliminateRHS (rap.cpp:56-82): b -= A_unconstrained x|ess ; b[ess] = x[ess] (DIAG_ONE) or 0. */
+int pa_par_op_eliminate_rhs(pa_par_op *A, const double *x, double *b);
 int pa_par_op_assemble_diagonal(pa_par_op *A, double *diag);
 
 /* --- vectors (linalg/vector.cpp) ------------------------------------------------------------- */

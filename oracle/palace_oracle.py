@@ -504,6 +504,21 @@ class ParOperatorOracle:
         y[self.ess] = x[self.ess] if self.policy == DIAG_ONE else 0.0
         return y
 
+    def add_mult(self, x, y, a=1.0):
+        """rap.cpp:277-318."""
+        return y + a * self.mult(x)
+
+    def eliminate_rhs(self, x, b):
+        """rap.cpp:56-82."""
+        tx = np.zeros(self.n)
+        tx[self.ess] = x[self.ess]
+        y = np.zeros(self.n)
+        for op in self.ops:
+            op.apply_add(tx, y)
+        b = b - y
+        b[self.ess] = x[self.ess] if self.policy == DIAG_ONE else 0.0
+        return b
+
     def diagonal(self):
         d = np.zeros(self.n)
         for op in self.ops:

@@ -337,6 +337,33 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
   }
 }
 
+void ParOperator::AddMult(const Vector &x, Vector &y, double a) const {
+  if (tt_.Size() != n_true_) tt_.SetSize(n_true_);
+  Mult(x, tt_);
+  linalg::AXPY(*ctx_, a, tt_, y);
+}
+
+void ParOperator::EliminateRHS(const Vector &x, Vector &b) const {
+  // rap.cpp:56-82: tx = 0, tx[ess] = x[ess]; b -= P^T A P tx (unconstrained A); b[ess] = x[ess] | 0
+  const Context &c = *ctx_;
+  Vector tx(lx_.Data(), n_true_);
+  linalg::Fill(c, tx, 0.0);
+  if (n_ess_) linalg::SetSubVector(c, tx, d_ess_, n_ess_, x);
+  if (halo_) halo_->Prolongate(lx_.Data(), c.stream);
+  else if (n_local_ > n_true_)
+    PA_HIP(hipMemsetAsync(lx_.Data() + n_true_, 0, sizeof(double) * (size_t)(n_local_ - n_true_), c.stream));
+  A_->Mult(lx_, ly_);
+  if (halo_) halo_->RestrictAdd(ly_.Data(), c.stream);
+  Vector ty(ly_.Data(), n_true_);
+  linalg::AXPY(c, -1.0, ty, b);
+  if (n_ess_) {
+    if (policy_ == DiagonalPolicy::DIAG_ONE)
+      linalg::SetSubVector(c, b, d_ess_, n_ess_, x);
+    else
+      linalg::SetSubVector(c, b, d_ess_, n_ess_, 0.0);
+  }
+}
+
 void ParOperator::AssembleDiagonal(Vector &diag) const {
   // rap.cpp:154-193 (conforming meshes: |P|^T = P^T)
   const Context &c = *ctx_;

@@ -157,7 +157,18 @@ public:
   int NumEssentialTrueDofs() const { return n_ess_; }
   const Operator &LocalOperator() const { return *A_; }
   void Mult(const Vector &x, Vector &y) const override;
+  // rap.cpp:236-275 (the local operators of this library are symmetric: ceed::Operator forwards its
+  // transpose to the forward apply like the reference's SymmetricOperator, operator.hpp:69-79)
+  void MultTranspose(const Vector &x, Vector &y) const override { Mult(x, y); }
+  // y += a A x  (rap.cpp:277-318) / its transpose (:320-361)
+  void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
+  void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const { AddMult(x, y, a); }
+  // b -= A_unconstrained (x restricted to the essential dofs); b[ess] = x[ess] | 0  (rap.cpp:56-82)
+  void EliminateRHS(const Vector &x, Vector &b) const;
   void AssembleDiagonal(Vector &diag) const override;
+
+private:
+  mutable Vector tt_;
 };
 
 // Solver<Operator> (solver.hpp:21-65)

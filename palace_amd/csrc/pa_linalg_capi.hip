@@ -122,6 +122,20 @@ int pa_par_op_mult(pa_par_op *A, const double *x, double *y) {
     A->op->Mult(vx, vy);
   });
 }
+int pa_par_op_add_mult(pa_par_op *A, const double *x, double *y, double a) {
+  return guarded([&] {
+    PA_REQUIRE(A && x && y, "null argument");
+    Vector vx(const_cast<double *>(x), A->op->Width()), vy(y, A->op->Height());
+    A->op->AddMult(vx, vy, a);
+  });
+}
+int pa_par_op_eliminate_rhs(pa_par_op *A, const double *x, double *b) {
+  return guarded([&] {
+    PA_REQUIRE(A && x && b, "null argument");
+    Vector vx(const_cast<double *>(x), A->op->Width()), vb(b, A->op->Height());
+    A->op->EliminateRHS(vx, vb);
+  });
+}
 int pa_par_op_assemble_diagonal(pa_par_op *A, double *diag) {
   return guarded([&] {
     Vector d(diag, A->op->Height());

@@ -132,6 +132,15 @@ class ParOperator:
         _lib.check(_L().pa_par_op_mult(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
         return y
 
+    def add_mult(self, x, y, a=1.0):
+        _lib.check(_L().pa_par_op_add_mult(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                           C.c_double(a)))
+        return y
+
+    def eliminate_rhs(self, x, b):
+        _lib.check(_L().pa_par_op_eliminate_rhs(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(b.data_ptr())))
+        return b
+
     def assemble_diagonal(self, d):
         _lib.check(_L().pa_par_op_assemble_diagonal(self.handle, C.c_void_p(d.data_ptr())))
         return d

@@ -72,6 +72,28 @@ def test_par_operator_mult_and_diagonal(prob):
     assert _rel(d, prob.oA[-1].diagonal()) < 1e-12
 
 
+def test_par_operator_add_mult_and_eliminate_rhs(prob):
+    """rap.cpp:277-318 and :56-82 against the oracle restatement (both diagonal policies)."""
+    sp = prob.spaces[1]
+    n = sp.ndofs
+    rng = np.random.default_rng(5)
+    x, y0, b0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    for policy, opol in ((linalg.DIAG_ONE, po.DIAG_ONE), (linalg.DIAG_ZERO, po.DIAG_ZERO)):
+        A = linalg.ParOperator(prob.ctx, prob.local[1], sp.ess_dofs(), policy)
+        oA = util.FastParOperatorOracle(sp, prob.ogeom, "hdivmass", np.concatenate([prob.bm, prob.bc]), sp.ess_dofs(),
+                                        prob.q1d, prob.cm, prob.cc, policy=opol)
+        y = A.add_mult(_dev(x), _dev(y0), -0.75).cpu().numpy()
+        ref = y0 - 0.75 * oA.mult(x)
+        assert _rel(y, ref) < 1e-12
+        b = A.eliminate_rhs(_dev(x), _dev(b0)).cpu().numpy()
+        tx = np.zeros(n)
+        tx[sp.ess_dofs()] = x[sp.ess_dofs()]
+        full = util.oracle_apply_c(sp, prob.ogeom, "hdivmass", np.concatenate([prob.bm, prob.bc]), tx, prob.q1d)
+        refb = b0 - full
+        refb[sp.ess_dofs()] = x[sp.ess_dofs()] if opol == po.DIAG_ONE else 0.0
+        assert _rel(b, refb) < 1e-12
+
+
 @pytest.mark.parametrize("l", [0, 1])
 def test_prolongation_and_transpose(prob, l):
     nc, nf = prob.spaces[l].ndofs, prob.spaces[l + 1].ndofs
