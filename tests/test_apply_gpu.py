@@ -66,6 +66,60 @@ def test_apply_cylinder_mesh(cylinder_mesh, p, qf):
     assert _rel(y2, 2 * ref) < RTOL
 
 
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+@pytest.mark.parametrize("qf", ["hdiv", "hcurl", "hdivmass"])
+@pytest.mark.parametrize("variant", ["matrix_free", "nonsym", "iso_matrix_free", "atomic"])
+def test_apply_variants(cylinder_mesh, monkeypatch, p, qf, variant):
+    """The other forms of the same kernel: D recomputed from the geometry factors exactly as the
+    reference QFunctions do (PALACE_AMD_QDATA=0: general / isotropic coefficient; always for a
+    non-symmetric coefficient) and E^T as an atomic scatter (PALACE_AMD_SCATTER=atomic)."""
+    if variant in ("matrix_free", "iso_matrix_free"):
+        monkeypatch.setenv("PALACE_AMD_QDATA", "0")
+    if variant == "atomic":
+        monkeypatch.setenv("PALACE_AMD_SCATTER", "atomic")
+    mesh = _multi_attr(cylinder_mesh)
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    kind = {"matrix_free": "aniso", "nonsym": "nonsym", "iso_matrix_free": "scalar", "atomic": "aniso"}[variant]
+    _, b_a = util.make_ctx(kind, nattr=3)
+    _, b_s = util.make_ctx("scalar", nattr=3)
+    if qf == "hdiv":
+        op, blob = ceed.curlcurl_operator(geom, nd, b_a), b_a
+    elif qf == "hcurl":
+        op, blob = ceed.ndmass_operator(geom, nd, b_a), b_a
+    else:
+        op, blob = ceed.curlcurlmass_operator(geom, nd, b_s, b_a), np.concatenate([b_s, b_a])
+    x = np.random.default_rng(2).uniform(-1, 1, nd.ndofs)
+    y = op.mult(_dev(x), torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")).cpu().numpy()
+    ref = util.oracle_apply_c(nd, util.oracle_geom(mesh, q1d), qf, blob, x, q1d)
+    assert _rel(y, ref) < RTOL
+    y2 = op.add_mult(_dev(x), _dev(ref.copy())).cpu().numpy()
+    assert _rel(y2, 2 * ref) < RTOL
+
+
+@pytest.mark.parametrize("p,q1d", [(1, 3), (2, 4), (2, 5), (3, 5), (1, 5)])
+@pytest.mark.parametrize("qf", ["hdiv", "hdivmass"])
+@pytest.mark.parametrize("variant", ["qdata", "matrix_free"])
+def test_apply_overintegrated(cylinder_mesh, monkeypatch, p, q1d, qf, variant):
+    """Coarse-level shapes: basis of order p on a finer rule (every instantiated (P1, Q1) pair)."""
+    if variant == "matrix_free":
+        monkeypatch.setenv("PALACE_AMD_QDATA", "0")
+    mesh = _multi_attr(cylinder_mesh)
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    _, b_a = util.make_ctx("aniso", nattr=3)
+    _, b_s = util.make_ctx("scalar", nattr=3)
+    if qf == "hdiv":
+        op, blob = ceed.curlcurl_operator(geom, nd, b_a), b_a
+    else:
+        op, blob = ceed.curlcurlmass_operator(geom, nd, b_s, b_a), np.concatenate([b_s, b_a])
+    x = np.random.default_rng(3).uniform(-1, 1, nd.ndofs)
+    y = op.mult(_dev(x), torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")).cpu().numpy()
+    ref = util.oracle_apply_c(nd, util.oracle_geom(mesh, q1d), qf, blob, x, q1d)
+    assert _rel(y, ref) < RTOL
+
+
 @pytest.mark.parametrize("p_coarse,p_fine", [(1, 3), (2, 3), (1, 2), (2, 4), (1, 4)])
 def test_coarsened_operator(cylinder_mesh, p_coarse, p_fine):
     """CeedOperatorCoarsen: coarse basis on the fine level's quadrature/geometry data."""

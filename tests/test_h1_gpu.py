@@ -47,7 +47,10 @@ def _ctxs():
 
 @pytest.mark.parametrize("p,q1d", [(1, 2), (2, 3), (3, 4), (1, 4), (2, 4), (4, 5)])
 @pytest.mark.parametrize("qf", ["diffusion", "mass", "diffusionmass"])
-def test_h1_apply_and_diagonal(cylinder_mesh, p, q1d, qf):
+@pytest.mark.parametrize("dstage", ["qdata", "matrix_free"])
+def test_h1_apply_and_diagonal(cylinder_mesh, monkeypatch, p, q1d, qf, dstage):
+    if dstage == "matrix_free":  # D from the geometry factors, as the reference QFunctions compute it
+        monkeypatch.setenv("PALACE_AMD_QDATA", "0")
     mesh = _multi_attr(cylinder_mesh)
     h1 = H1HexSpace(mesh, p)
     geom = ceed.GeomFactorData(mesh, q1d)

@@ -37,6 +37,10 @@ def make_ctx(kind, nattr=1):
         spd = A @ A.T + 2.0 * np.eye(3)
         mats = [spd, np.array([0.7])]
         c = po.CoeffCtx(attr_mat=[i % 2 for i in range(nattr)], mat_coeff=mats, a=1.3)
+    elif kind == "nonsym":  # general (non-symmetric) 3x3 material: only the matrix-free D can apply it
+        rng = np.random.default_rng(9)
+        A = rng.uniform(-1, 1, (3, 3)) + 3.0 * np.eye(3)
+        c = po.CoeffCtx(attr_mat=[i % 2 for i in range(nattr)], mat_coeff=[A, np.array([0.7])], a=1.1)
     else:
         raise ValueError(kind)
     return c, c.pack()
