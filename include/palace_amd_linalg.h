@@ -93,6 +93,10 @@ int pa_gmg_create_aux(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_inte
                       int smooth_it, int cheby_order, double cheby_sf_max, double cheby_sf_min,
                       int cheby_4th_kind, pa_solver **S);
 /* x = S(b) on T-vectors; initial_guess != 0 uses x as the starting iterate (Krylov solvers) */
+/* Gram-Schmidt variant of (F)GMRES: 0 = MGS (default), 1 = CGS, 2 = CGS2 (config "Orthogonalization",
+ * linalg/orthog.hpp:41-89).  The classical variants do all inner products of a column in one pass over
+ * the new vector and one all-reduce. */
+int pa_gmres_set_orthogonalization(pa_solver *S, int kind);
 int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess);
 int pa_solver_stats(const pa_solver *S, int *iterations, double *initial_res, double *final_res,
                     int *converged);

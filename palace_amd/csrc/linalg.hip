@@ -143,12 +143,58 @@ __global__ void k_dot_final(const double *__restrict__ partial, int nb, double *
   if (threadIdx.x == 0) out[0] = s;
 }
 
+// Batched form for classical Gram-Schmidt (orthog.hpp:57-89): up to kDotBatch inner products (w, V_j) in
+// one pass over w, and w -= sum_j h_j V_j in one pass; one all-reduce for the whole column.
+constexpr int kDotBatch = 8;
+struct VecPtrs {
+  const double *v[kDotBatch];
+};
+struct Coefs {
+  double h[kDotBatch];
+};
+__global__ void k_multi_dot_partial(const double *__restrict__ w, const VecPtrs V, int m, long long n,
+                                    double *__restrict__ partial) {
+  double s[kDotBatch];
+#pragma unroll
+  for (int j = 0; j < kDotBatch; j++) s[j] = 0.0;
+  PA_STRIDE_LOOP(i, n) {
+    const double wi = w[i];
+#pragma unroll
+    for (int j = 0; j < kDotBatch; j++)
+      if (j < m) s[j] += wi * V.v[j][i];
+  }
+#pragma unroll
+  for (int j = 0; j < kDotBatch; j++) {
+    const double t = block_sum(s[j]);
+    if (threadIdx.x == 0) partial[(size_t)j * gridDim.x + blockIdx.x] = t;
+    __syncthreads();
+  }
+}
+__global__ void k_multi_dot_final(const double *__restrict__ partial, int nb, int m, double *__restrict__ out) {
+  for (int j = 0; j < m; j++) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partial[(size_t)j * nb + i];
+    s = block_sum(s);
+    if (threadIdx.x == 0) out[j] = s;
+    __syncthreads();
+  }
+}
+__global__ void k_multi_axpy(const Coefs a, const VecPtrs V, int m, double *__restrict__ w, long long n) {
+  PA_STRIDE_LOOP(i, n) {
+    double wi = w[i];
+#pragma unroll
+    for (int j = 0; j < kDotBatch; j++)
+      if (j < m) wi -= a.h[j] * V.v[j][i];
+    w[i] = wi;
+  }
+}
+
 struct Scratch {
-  double *d_partial = nullptr;  // [kMaxBlocks + 8]
+  double *d_partial = nullptr;  // [kDotBatch * kMaxBlocks + kDotBatch]
   double *h_result = nullptr;   // pinned
   Scratch() {
-    d_partial = pa::dev_alloc<double>(kMaxBlocks + 8);
-    PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_result), 8 * sizeof(double), hipHostMallocDefault));
+    d_partial = pa::dev_alloc<double>((size_t)kDotBatch * kMaxBlocks + kMaxBlocks + kDotBatch);
+    PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_result), kDotBatch * sizeof(double), hipHostMallocDefault));
   }
 };
 Scratch &scratch() {
@@ -211,6 +257,34 @@ double Dot(const Context &c, const Vector &x, const Vector &y) {
   PA_HIP(hipMemcpyAsync(s.h_result, s.d_partial + kMaxBlocks, sizeof(double), hipMemcpyDeviceToHost, c.stream));
   PA_HIP(hipStreamSynchronize(c.stream));
   return s.h_result[0];
+}
+// H[j] = (w, V[j]) for j < m (global), batches of kDotBatch; w -= sum_j H[j] V[j] if `subtract`
+void MultiDot(const Context &c, const Vector &w, const std::vector<Vector> &V, int m, double *H) {
+  Scratch &s = scratch();
+  const int nb = grid_for(w.Size());
+  double *d_out = s.d_partial + (size_t)kDotBatch * kMaxBlocks;
+  for (int j0 = 0; j0 < m; j0 += kDotBatch) {
+    const int mb = std::min(kDotBatch, m - j0);
+    VecPtrs P{};
+    for (int j = 0; j < mb; j++) P.v[j] = V[j0 + j].Data();
+    hipLaunchKernelGGL(k_multi_dot_partial, dim3(nb), dim3(kBlock), 0, c.stream, w.Data(), P, mb, (long long)w.Size(),
+                       s.d_partial);
+    hipLaunchKernelGGL(k_multi_dot_final, dim3(1), dim3(kBlock), 0, c.stream, s.d_partial, nb, mb, d_out);
+    PA_HIP(hipGetLastError());
+    if (c.comm) c.comm->AllReduceSum(d_out, mb, c.stream);
+    PA_HIP(hipMemcpyAsync(s.h_result, d_out, sizeof(double) * mb, hipMemcpyDeviceToHost, c.stream));
+    PA_HIP(hipStreamSynchronize(c.stream));
+    for (int j = 0; j < mb; j++) H[j0 + j] = s.h_result[j];
+  }
+}
+void MultiAXPY(const Context &c, const double *H, const std::vector<Vector> &V, int m, Vector &w) {
+  for (int j0 = 0; j0 < m; j0 += kDotBatch) {
+    const int mb = std::min(kDotBatch, m - j0);
+    VecPtrs P{};
+    Coefs a{};
+    for (int j = 0; j < mb; j++) P.v[j] = V[j0 + j].Data(), a.h[j] = H[j0 + j];
+    PA_LAUNCH(k_multi_axpy, w.Size(), c.stream, a, P, mb, w.Data(), (long long)w.Size());
+  }
 }
 double Norml2(const Context &c, const Vector &x) { return std::sqrt(Dot(c, x, x)); }
 double Normalize(const Context &c, Vector &x) {
@@ -632,9 +706,20 @@ void GmresSolver::Mult(const Vector &b, Vector &x) const {
         A_->Mult(V_[j], r_);
         if (B_) B_->Mult(r_, w); else linalg::Copy(c, r_, w);
       }
-      for (int i = 0; i <= j; i++) {  // modified Gram-Schmidt
-        Hij(i, j) = linalg::Dot(c, w, V_[i]);
-        linalg::AXPY(c, -Hij(i, j), V_[i], w);
+      if (orthog_ == Orthogonalization::MGS) {  // orthog.hpp:41-55
+        for (int i = 0; i <= j; i++) {
+          Hij(i, j) = linalg::Dot(c, w, V_[i]);
+          linalg::AXPY(c, -Hij(i, j), V_[i], w);
+        }
+      } else {  // classical Gram-Schmidt, optionally iterated once (orthog.hpp:57-89)
+        linalg::MultiDot(c, w, V_, j + 1, &Hij(0, j));
+        linalg::MultiAXPY(c, &Hij(0, j), V_, j + 1, w);
+        if (orthog_ == Orthogonalization::CGS2) {
+          std::vector<double> dH(j + 1);
+          linalg::MultiDot(c, w, V_, j + 1, dH.data());
+          linalg::MultiAXPY(c, dH.data(), V_, j + 1, w);
+          for (int i = 0; i <= j; i++) Hij(i, j) += dH[i];
+        }
       }
       Hij(j + 1, j) = linalg::Norml2(c, w);
       if (Hij(j + 1, j) != 0.0)

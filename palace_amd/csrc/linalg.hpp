@@ -187,6 +187,9 @@ public:
 namespace linalg {
 double SpectralNorm(const Context &c, const Operator &A, const Vector &dinv, double tol = 1e-4, int max_it = 1000,
                     uint64_t seed = 0);
+// batched inner products / updates of classical Gram-Schmidt (orthog.hpp:57-89): one pass, one all-reduce
+void MultiDot(const Context &c, const Vector &w, const std::vector<Vector> &V, int m, double *H);
+void MultiAXPY(const Context &c, const double *H, const std::vector<Vector> &V, int m, Vector &w);
 }
 
 class JacobiSmoother : public Solver {
@@ -276,15 +279,19 @@ public:
   void Mult(const Vector &b, Vector &x) const override;
 };
 
+enum class Orthogonalization { MGS = 0, CGS = 1, CGS2 = 2 };  // config "Orthogonalization", orthog.hpp:41-89
+
 class GmresSolver : public IterativeSolver {
   int max_dim_ = -1;
   bool flexible_ = false;  // FGMRES (right preconditioning, stores Z)
+  Orthogonalization orthog_ = Orthogonalization::MGS;
   mutable std::vector<Vector> V_, Z_;
   mutable Vector r_;
 
 public:
   GmresSolver(const Context &ctx, int print = 0, bool flexible = false) : IterativeSolver(ctx, print), flexible_(flexible) {}
   void SetRestartDim(int dim) { max_dim_ = dim; }
+  void SetOrthogonalization(Orthogonalization o) { orthog_ = o; }
   void Mult(const Vector &b, Vector &x) const override;
 };
 

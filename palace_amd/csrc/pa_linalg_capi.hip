@@ -271,6 +271,14 @@ static void gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_int
     *S = s;
   }
 }
+int pa_gmres_set_orthogonalization(pa_solver *S, int kind) {
+  return guarded([&] {
+    PA_REQUIRE(S && kind >= 0 && kind <= 2, "bad argument");
+    auto *g = dynamic_cast<GmresSolver *>(S->solver.get());
+    PA_REQUIRE(g, "not a GMRES solver");
+    g->SetOrthogonalization(static_cast<Orthogonalization>(kind));
+  });
+}
 int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess) {
   return guarded([&] {
     const int n = S->solver->Height();

@@ -201,10 +201,11 @@ def cg(ctx, A: ParOperator, precond=None, rel_tol=0.0, abs_tol=0.0, max_it=100, 
 
 
 def gmres(ctx, A: ParOperator, precond=None, rel_tol=0.0, abs_tol=0.0, max_it=100, restart=-1, flexible=False,
-          print_level=0):
+          print_level=0, orthogonalization="MGS"):
     h = C.c_void_p()
     _lib.check(_L().pa_gmres_create(ctx.handle, A.handle, precond.handle if precond else None, rel_tol, abs_tol,
                                     max_it, restart, int(flexible), print_level, C.byref(h)))
+    _lib.check(_L().pa_gmres_set_orthogonalization(h, {"MGS": 0, "CGS": 1, "CGS2": 2}[orthogonalization]))
     return Solver(ctx, h, (A, precond))
 
 

@@ -165,6 +165,25 @@ def test_gmres_jacobi(prob):
         assert np.linalg.norm(prob.oA[l].mult(x) - b) < 1e-5 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("orthog", ["CGS", "CGS2"])
+def test_gmres_classical_gram_schmidt(prob, orthog):
+    """orthog.hpp:57-89: the batched classical variants reach the same solution; iteration counts of CGS2
+    equal those of MGS (both keep the basis orthogonal to rounding)."""
+    l = 1
+    n = prob.spaces[l].ndofs
+    b = prob.oA[l].mult(np.ones(n))
+    b[prob.spaces[l].ess_dofs()] = 0.0
+    ref = linalg.gmres(prob.ctx, prob.A[l], linalg.jacobi(prob.ctx, prob.A[l]), rel_tol=1e-10, max_it=400, restart=150)
+    x_ref = ref.mult(_dev(b), _new(n)).cpu().numpy()
+    K = linalg.gmres(prob.ctx, prob.A[l], linalg.jacobi(prob.ctx, prob.A[l]), rel_tol=1e-10, max_it=400, restart=150,
+                     orthogonalization=orthog)
+    x = K.mult(_dev(b), _new(n)).cpu().numpy()
+    assert K.stats()["converged"]
+    assert _rel(x, x_ref) < 1e-7
+    if orthog == "CGS2":
+        assert abs(K.stats()["iterations"] - ref.stats()["iterations"]) <= 1
+
+
 def test_gmg_vcycle_and_pcg(prob):
     """One V-cycle (levels p = 1,2,3; 4th-kind Chebyshev order 6) as the reference configures it
     (iodata.cpp:533-564), then PCG + GMG iteration counts vs the oracle."""
