@@ -220,6 +220,17 @@ int pa_op_set_essential(pa_op *op, const int32_t *ess_ldofs, int32_t n);
 int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream);
 /* Operator::AssembleDiagonal (operator.cpp:116-143): diag = diag(A) (zeroed first). */
 int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream);
+/* CeedOperatorFullAssemble (operator.cpp:455-523; BilinearForm::FullAssemble / ParOperator::ParallelAssemble,
+ * linalg/rap.cpp:84-152): the local operator as CSR in device memory, for coarse solvers that need a
+ * matrix.  Pattern = union of the element connectivities (sorted columns); values recovered from the
+ * operator's own apply (one apply per colour of a distance-2 colouring), so they are exactly what Mult
+ * produces.  skip_zeros drops entries that are exactly zero (operator.cpp:262-313). */
+typedef struct pa_csr pa_csr;
+int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **csr);
+/* Device pointers (int32 row pointers / column indices, double values); any output may be NULL. */
+int pa_csr_get(const pa_csr *csr, int32_t *nrows, int64_t *nnz, const int32_t **rowptr, const int32_t **colidx,
+               const double **values);
+void pa_csr_destroy(pa_csr *csr);
 int pa_op_height(const pa_op *op);
 int pa_op_width(const pa_op *op);
 /* Algorithmic HBM bytes of one apply_add by SURVEY.md 8(d)'s formula

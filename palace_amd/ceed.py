@@ -268,6 +268,32 @@ class Operator:
         _lib.check(_lib.load().pa_op_assemble_diagonal(self.handle, C.c_void_p(diag.data_ptr()), _stream()))
         return diag
 
+    def full_assemble(self, skip_zeros=False):
+        """CeedOperatorFullAssemble -> scipy.sparse.csr_matrix (values copied back from the device)."""
+        import scipy.sparse as sp
+        import torch
+
+        L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(L.pa_op_full_assemble(self.handle, int(skip_zeros), _stream(), C.byref(h)))
+        n, nnz = C.c_int32(), C.c_int64()
+        rp, ci, va = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(L.pa_csr_get(h, C.byref(n), C.byref(nnz), C.byref(rp), C.byref(ci), C.byref(va)))
+
+        def view(ptr, count, typestr, dtype):
+            class _V:
+                __cuda_array_interface__ = dict(shape=(count,), typestr=typestr, data=(ptr.value, False), version=2)
+            return torch.as_tensor(_V(), device="cuda").cpu().numpy().astype(dtype)
+
+        torch.cuda.synchronize()
+        rowptr = view(rp, n.value + 1, "<i4", np.int32)
+        col = view(ci, max(1, nnz.value), "<i4", np.int32)[: nnz.value]
+        val = view(va, max(1, nnz.value), "<f8", np.float64)[: nnz.value]
+        L.pa_csr_destroy.restype = None
+        L.pa_csr_destroy.argtypes = [C.c_void_p]
+        L.pa_csr_destroy(h)
+        return sp.csr_matrix((val, col, rowptr), shape=(n.value, n.value))
+
     def algorithmic_bytes(self):
         return _lib.load().pa_op_algorithmic_bytes(self.handle)
 

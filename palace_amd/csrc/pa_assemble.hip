@@ -1,0 +1,176 @@
+// Full assembly of a partially assembled operator into CSR on the device.
+//
+// Replaces CeedOperatorFullAssemble (reference fem/libceed/operator.cpp:455-523; called from
+// BilinearForm::FullAssemble and ParOperator::ParallelAssemble, linalg/rap.cpp:84-152, when a coarse
+// solver needs a matrix).  The sparsity pattern is the union of the element connectivities; the
+// values are obtained from the operator's own apply by probing: the columns are coloured so that no
+// two columns of one colour share a row (distance-2 colouring), one apply per colour recovers all
+// entries of those columns.  Every entry is therefore exactly what Mult produces, for every element
+// type, restriction kind and D-stage variant, with no second implementation of the element matrices.
+// Meant for the coarsest levels (p = 1: ~33 colours on hexahedra); the cost is #colours applies.
+#include <algorithm>
+#include <numeric>
+
+#include "pa_internal.hpp"
+
+struct pa_csr {
+  int32_t nrows = 0;
+  int64_t nnz = 0;
+  int32_t *d_rowptr = nullptr, *d_col = nullptr;
+  double *d_val = nullptr;
+};
+
+namespace pa {
+
+namespace {
+
+__global__ void k_probe_vector(const int n, const int32_t *__restrict__ color, const int c, double *__restrict__ x) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < n) x[d] = (color[d] == c) ? 1.0 : 0.0;
+}
+
+__global__ void k_extract(const long long nnz, const int32_t *__restrict__ row_of, const int32_t *__restrict__ col,
+                          const int32_t *__restrict__ color, const int c, const double *__restrict__ y,
+                          double *__restrict__ val) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nnz && color[col[k]] == c) val[k] = y[row_of[k]];
+}
+
+}  // namespace
+
+void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s);
+
+}  // namespace pa
+
+using namespace pa;
+
+extern "C" {
+
+int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
+  return guarded([&] {
+    PA_REQUIRE(op && out, "null argument");
+    PA_REQUIRE(op->finalized && op->height == op->width, "full assembly needs a finalized square operator");
+    hipStream_t s = (hipStream_t)stream;
+    const int n = op->height;
+    // ---- pattern: union of the element connectivities
+    struct Conn {
+      int ne, P;
+      std::vector<int32_t> off;
+    };
+    std::vector<Conn> conns;
+    for (const SubOp *so : op->subs) {
+      Conn c{so->ne, so->P, {}};
+      c.off.resize(so->h_sidx.size());
+      for (size_t k = 0; k < c.off.size(); k++) c.off[k] = so->h_sidx[k] >= 0 ? so->h_sidx[k] : -1 - so->h_sidx[k];
+      conns.push_back(std::move(c));
+    }
+    for (const DenseSub *ds : op->dsubs) conns.push_back(Conn{ds->ne, ds->P, ds->h_off});
+    std::vector<int64_t> cnt((size_t)n + 1, 0);
+    for (const Conn &c : conns)
+      for (size_t k = 0; k < c.off.size(); k++) cnt[(size_t)c.off[k] + 1] += c.P;
+    for (int r = 0; r < n; r++) cnt[r + 1] += cnt[r];
+    PA_REQUIRE(cnt[n] < (int64_t)1 << 31, "operator too large for full assembly (int32 CSR)");
+    std::vector<int32_t> cols((size_t)cnt[n]);
+    {
+      std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+      for (const Conn &c : conns)
+        for (int e = 0; e < c.ne; e++) {
+          const int32_t *oe = &c.off[(size_t)e * c.P];
+          for (int i = 0; i < c.P; i++) {
+            int64_t &f = fill[oe[i]];
+            for (int j = 0; j < c.P; j++) cols[(size_t)f++] = oe[j];
+          }
+        }
+    }
+    std::vector<int32_t> rowptr((size_t)n + 1, 0), col;
+    col.reserve(cols.size() / 2);
+    for (int r = 0; r < n; r++) {
+      auto b = cols.begin() + cnt[r], e = cols.begin() + cnt[r + 1];
+      std::sort(b, e);
+      e = std::unique(b, e);
+      col.insert(col.end(), b, e);
+      rowptr[r + 1] = (int32_t)col.size();
+    }
+    cols.clear();
+    cols.shrink_to_fit();
+    const int64_t nnz = (int64_t)col.size();
+    // ---- distance-2 colouring of the columns (symmetric pattern: neighbours of neighbours)
+    std::vector<int32_t> color((size_t)n, -1), mark;
+    int ncolors = 0;
+    for (int d = 0; d < n; d++) {
+      if ((int)mark.size() < ncolors + 1) mark.resize(ncolors + 1, -1);
+      for (int32_t a = rowptr[d]; a < rowptr[d + 1]; a++) {
+        const int r = col[a];
+        for (int32_t b2 = rowptr[r]; b2 < rowptr[r + 1]; b2++) {
+          const int cc = color[col[b2]];
+          if (cc >= 0) mark[cc] = d;
+        }
+      }
+      int c = 0;
+      while (c < ncolors && mark[c] == d) c++;
+      if (c == ncolors) ncolors++, mark.push_back(-1);
+      color[d] = c;
+    }
+    // ---- values by probing
+    std::vector<int32_t> row_of((size_t)nnz);
+    for (int r = 0; r < n; r++)
+      for (int32_t a = rowptr[r]; a < rowptr[r + 1]; a++) row_of[a] = r;
+    auto *m = new pa_csr;
+    m->nrows = n;
+    int32_t *d_color = dev_upload(color.data(), color.size(), s), *d_row_of = dev_upload(row_of.data(), row_of.size(), s);
+    int32_t *d_col = dev_upload(col.data(), col.size(), s);
+    double *d_val = dev_alloc<double>((size_t)nnz), *d_x = dev_alloc<double>((size_t)n), *d_y = dev_alloc<double>((size_t)n);
+    PA_HIP(hipMemsetAsync(d_val, 0, sizeof(double) * (size_t)nnz, s));
+    for (int c = 0; c < ncolors; c++) {
+      hipLaunchKernelGGL(k_probe_vector, dim3((n + 255) / 256), dim3(256), 0, s, n, d_color, c, d_x);
+      apply_for_assembly(op, d_x, d_y, s);
+      hipLaunchKernelGGL(k_extract, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, (long long)nnz, d_row_of, d_col,
+                         d_color, c, d_y, d_val);
+    }
+    PA_HIP(hipGetLastError());
+    PA_HIP(hipStreamSynchronize(s));
+    hipFree(d_color), hipFree(d_row_of), hipFree(d_x), hipFree(d_y);
+    if (skip_zeros) {  // operator.cpp:262-313: drop the entries that are exactly zero
+      std::vector<double> val((size_t)nnz);
+      PA_HIP(hipMemcpy(val.data(), d_val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
+      std::vector<int32_t> rp((size_t)n + 1, 0), cl;
+      std::vector<double> vl;
+      cl.reserve((size_t)nnz), vl.reserve((size_t)nnz);
+      for (int r = 0; r < n; r++) {
+        for (int32_t a = rowptr[r]; a < rowptr[r + 1]; a++)
+          if (val[a] != 0.0) cl.push_back(col[a]), vl.push_back(val[a]);
+        rp[r + 1] = (int32_t)cl.size();
+      }
+      hipFree(d_col), hipFree(d_val);
+      m->nnz = (int64_t)cl.size();
+      m->d_rowptr = dev_upload(rp.data(), rp.size(), s);
+      m->d_col = dev_upload(cl.data(), cl.size(), s);
+      m->d_val = dev_upload(vl.data(), vl.size(), s);
+    } else {
+      m->nnz = nnz;
+      m->d_rowptr = dev_upload(rowptr.data(), rowptr.size(), s);
+      m->d_col = d_col, m->d_val = d_val;
+    }
+    *out = m;
+  });
+}
+
+int pa_csr_get(const pa_csr *m, int32_t *nrows, int64_t *nnz, const int32_t **rowptr, const int32_t **colidx,
+               const double **values) {
+  return guarded([&] {
+    PA_REQUIRE(m, "null argument");
+    if (nrows) *nrows = m->nrows;
+    if (nnz) *nnz = m->nnz;
+    if (rowptr) *rowptr = m->d_rowptr;
+    if (colidx) *colidx = m->d_col;
+    if (values) *values = m->d_val;
+  });
+}
+
+void pa_csr_destroy(pa_csr *m) {
+  if (!m) return;
+  hipFree(m->d_rowptr), hipFree(m->d_col), hipFree(m->d_val);
+  delete m;
+}
+
+}  // extern "C"

@@ -357,6 +357,8 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   }
 }
 
+void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s) { apply(op, x, y, true, s); }
+
 }  // namespace pa
 
 using namespace pa;

@@ -865,6 +865,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   if (nci) ds->d_interp = dev_upload(b.interp, (size_t)nci * Q * P);
   if (ncd) ds->d_deriv = dev_upload(b.deriv, (size_t)3 * Q * P);
   ds->d_off = dev_upload(r.offsets, (size_t)ne * P);
+  ds->h_off.assign(r.offsets, r.offsets + (size_t)ne * P);
   if (r.curl_orients) ds->d_cor = dev_upload(r.curl_orients, (size_t)3 * ne * P);
 
   // ---- D: coefficient context(s)

@@ -136,6 +136,7 @@ struct DenseSub {
   int32_t *d_idx_bc = nullptr;  // copy with kEssBit on essential dofs
   uint16_t *d_co = nullptr;     // [nb][4 KP][16] packed int8 rows / columns of T_e (curl-oriented) or nullptr
   std::vector<int32_t> h_idx;
+  std::vector<int32_t> h_off;  // plain [ne][P] offsets (full assembly)
   double *d_Tf = nullptr, *d_Tt = nullptr;  // MFMA A-operand fragments of the tables (forward / transposed)
   double *d_L = nullptr;       // LDS-resident form of the tables (fast path) or nullptr
   double *d_qdata = nullptr;   // packed pre-assembled D [nb][ncq][Qpad][16] (fast path)
