@@ -44,7 +44,11 @@ enum pa_qfunction {
   PA_QF_HCURL_33 = 1,     /* f_apply_hcurl_33     fem/qfunctions/33/hcurl_33_qf.h:10-28     ND mass, H1 diffusion */
   PA_QF_HDIVMASS_33 = 2,  /* f_apply_hdivmass_33  fem/qfunctions/33/hdivmass_33_qf.h:10-44  curl-curl + mass */
   PA_QF_HCURLMASS_33 = 3, /* f_apply_hcurlmass_33 fem/qfunctions/33/hcurlmass_33_qf.h       H1 diffusion + mass */
-  PA_QF_H1_1 = 4          /* f_apply_h1_1         fem/qfunctions/1/h1_1_qf.h                H1 mass          */
+  PA_QF_H1_1 = 4,         /* f_apply_h1_1         fem/qfunctions/1/h1_1_qf.h                H1 mass          */
+  /* 2-D (space_dim = dim = 2; dense-table path only), fem/integ/curlcurl.cpp:40-47,65-68 */
+  PA_QF_HCURL_22 = 5,     /* f_apply_hcurl_22     fem/qfunctions/22/hcurl_22_qf.h:10-30     ND mass          */
+  PA_QF_L2_1 = 6,         /* f_apply_l2_1         fem/qfunctions/1/l2_1_qf.h:10-24          curl-curl (scalar curl, q_w input) */
+  PA_QF_HDIVMASS_22 = 7   /* f_apply_hdivmass_22  fem/qfunctions/22/hdivmass_22_qf.h:11-37  curl-curl + mass */
 };
 
 enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1 };
@@ -128,8 +132,9 @@ typedef struct {
  * Basis B/G of a non-tensor element (tetrahedra, prisms, ... and hexahedra when the caller only has
  * the dense tables): exactly what InitNonTensorBasis hands to CeedBasisCreateHcurl / CeedBasisCreateH1
  * (fem/libceed/basis.cpp:40-85), from MFEM's DofToQuad::FULL tables.
- *   interp [qcomp*Q][P] row-major, row = c*Q + q ; qcomp = 3 for HCURL, 1 for H1
- *   deriv  [3*Q][P]     curl (HCURL) or gradient (H1) in reference coordinates
+ *   interp [qcomp*Q][P] row-major, row = c*Q + q ; qcomp = dim for HCURL, 1 for H1
+ *   deriv  [3*Q][P]     curl (HCURL) or gradient (H1) in reference coordinates; [Q][P] for the scalar
+ *                       curl of 2-D HCURL elements
  */
 typedef struct {
   int32_t fe_type;
@@ -158,6 +163,10 @@ typedef struct {
   const int32_t *attr;
   const double *mesh_grad;
   const double *qweight;
+  /* space dimension = element dimension: 3 (default when 0) or 2.  In 2-D nodes are [num_nodes][2],
+   * mesh_grad is [2][Q][npe] and the geometry data has 6 rows {attr, w detJ, adj(J)^T/detJ}
+   * (fem/qfunctions/22/geom_22_qf.h:9-30). */
+  int32_t dim;
 } pa_mesh_dense_desc;
 
 /* --- library ------------------------------------------------------------------------------- */

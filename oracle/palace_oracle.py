@@ -317,11 +317,64 @@ def apply_hdivmass_33(ctx_mass: CoeffCtx, ctx_curl: CoeffCtx, geom, u, curlu):
     return apply_hcurl_33(ctx_mass, geom, u), apply_hdiv_33(ctx_curl, geom, curlu)
 
 
+# ---- 2-D (space_dim = dim = 2) variants: fem/qfunctions/22/*.h, fem/qfunctions/1/l2_1_qf.h --------
+
+def build_geom_factor_22(attr, qw, J):
+    """geom_22_qf.h:9-30.  J [NE, Q, 4] column-major (J: 0 2 / 1 3).  Returns geom [NE, 6, Q]:
+    attr, w detJ, adj(J)^T / detJ (utils_22_qf.h:20-31: {J3, -J2, -J1, J0} / det)."""
+    det = J[..., 0] * J[..., 3] - J[..., 1] * J[..., 2]
+    NE, Q = det.shape
+    geom = np.empty((NE, 6, Q))
+    geom[:, 0, :] = attr[:, None]
+    geom[:, 1, :] = qw[None, :] * det
+    geom[:, 2, :] = J[..., 3] / det
+    geom[:, 3, :] = -J[..., 2] / det
+    geom[:, 4, :] = -J[..., 1] / det
+    geom[:, 5, :] = J[..., 0] / det
+    return geom
+
+
+def _unpack2(ctx, attr):
+    k = ctx.attr_mat[attr - 1] if ctx.attr_mat.size else np.zeros_like(attr)
+    return ctx.mat[k]  # [..., 4] column-major
+
+
+def _unpack1(ctx, attr):
+    k = ctx.attr_mat[attr - 1] if ctx.attr_mat.size else np.zeros_like(attr)
+    return ctx.mat[k][..., 0]
+
+
+def apply_hcurl_22(ctx, geom, u):
+    """hcurl_22_qf.h:10-30: v = w detJ A^T C A u with A = adjJt (utils_22_qf.h MultAtBCx22)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    wdetJ = geom[:, 1, :]
+    A = [geom[:, 2 + k, :] for k in range(4)]
+    C = _unpack2(ctx, attr)
+    x0, x1 = u[:, 0, :], u[:, 1, :]
+    y0 = A[0] * x0 + A[2] * x1
+    y1 = A[1] * x0 + A[3] * x1
+    z0 = C[..., 0] * y0 + C[..., 2] * y1
+    z1 = C[..., 1] * y0 + C[..., 3] * y1
+    return np.stack([wdetJ * (A[0] * z0 + A[1] * z1), wdetJ * (A[2] * z0 + A[3] * z1)], axis=1)
+
+
+def apply_l2_1(ctx, geom, qw, u):
+    """l2_1_qf.h:10-24 (2-D curl-curl, integ/curlcurl.cpp:43-47,65-68): v = (c qw^2 / w detJ) u, scalar."""
+    attr = geom[:, 0, :].astype(np.int32)
+    return (_unpack1(ctx, attr) * qw[None, :] ** 2 / geom[:, 1, :])[:, None, :] * u
+
+
+def apply_hdivmass_22(ctx_mass, ctx_curl, geom, qw, u, curlu):
+    """hdivmass_22_qf.h:11-37 (mass context, dim 2, first; then the scalar curl-curl one)."""
+    return apply_hcurl_22(ctx_mass, geom, u), apply_l2_1(ctx_curl, geom, qw, curlu)
+
+
 # ---------------------------------------------------------------------------------------------
 # Operator: E, B, D, B^T, E^T
 # ---------------------------------------------------------------------------------------------
 
 QF_HDIV, QF_HCURL, QF_HDIVMASS, QF_HCURLMASS, QF_H1MASS = "hdiv_33", "hcurl_33", "hdivmass_33", "hcurlmass_33", "h1_1"
+QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22 = "hcurl_22", "l2_1", "hdivmass_22"
 
 
 class CeedOperatorOracle:
@@ -332,7 +385,8 @@ class CeedOperatorOracle:
     """
 
     def __init__(self, lsize, offsets, orients, interp, deriv, geom, qf, ctx, ctx2=None, vector_fe=True,
-                 curl_orients=None):
+                 curl_orients=None, qw=None):
+        self.qw = qw  # quadrature weights: the extra q_w input of the 2-D curl-curl QFunctions
         self.lsize = int(lsize)
         self.off = np.asarray(offsets)
         self.NE, self.P = self.off.shape
@@ -343,11 +397,12 @@ class CeedOperatorOracle:
         assert self.sgn is None or self.cor is None
         self.Q = geom.shape[2]
         self.vector_fe = vector_fe
+        dim = 2 if geom.shape[1] == 6 else 3
         if vector_fe:
-            self.interp = np.asarray(interp).reshape(3, self.Q, self.P)
+            self.interp = np.asarray(interp).reshape(dim, self.Q, self.P)
         else:
             self.interp = np.asarray(interp).reshape(1, self.Q, self.P)
-        self.deriv = np.asarray(deriv).reshape(3, self.Q, self.P)
+        self.deriv = np.asarray(deriv).reshape(1 if (dim == 2 and vector_fe) else dim, self.Q, self.P)
         self.geom, self.qf, self.ctx, self.ctx2 = geom, qf, ctx, ctx2
 
     def _restrict(self, x, sl):
@@ -375,6 +430,17 @@ class CeedOperatorOracle:
     def _qfunction(self, geom, ue):
         """B, D, B^T on element-local vectors ue [ne, P] -> ve [ne, P]."""
         qf = self.qf
+        if qf == QF_L2_1:      # 2-D curl-curl
+            cu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            return np.einsum("dqj,edq->ej", self.deriv, apply_l2_1(self.ctx, geom, self.qw, cu))
+        if qf == QF_HCURL_22:  # 2-D ND mass
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            return np.einsum("dqj,edq->ej", self.interp, apply_hcurl_22(self.ctx, geom, u))
+        if qf == QF_HDIVMASS_22:
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            cu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            v, cv = apply_hdivmass_22(self.ctx, self.ctx2, geom, self.qw, u, cu)
+            return np.einsum("dqj,edq->ej", self.interp, v) + np.einsum("dqj,edq->ej", self.deriv, cv)
         if qf == QF_HDIV:      # curl-curl (integ/curlcurl.cpp:48-52,60-61)
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
             cv = apply_hdiv_33(self.ctx, geom, cu)

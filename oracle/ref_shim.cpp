@@ -14,3 +14,7 @@ typedef double CeedScalar;
 #include "fem/qfunctions/33/hdivmass_33_qf.h"
 #include "fem/qfunctions/33/hcurlmass_33_qf.h"
 #include "fem/qfunctions/1/h1_1_qf.h"
+#include "fem/qfunctions/22/geom_22_qf.h"
+#include "fem/qfunctions/22/hcurl_22_qf.h"
+#include "fem/qfunctions/22/hdivmass_22_qf.h"
+#include "fem/qfunctions/1/l2_1_qf.h"

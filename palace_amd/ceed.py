@@ -19,7 +19,7 @@ from .fem.basis1d import Tables1D
 from .fem.fespace import H1HexSpace, NDHexSpace
 from .fem.mesh import HexMesh, _q2_1d
 
-QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1 = range(5)
+QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1, QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22 = range(8)
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
 FE_H1, FE_HCURL = 0, 1
 
@@ -114,15 +114,16 @@ class DenseGeomFactorData:
     def __init__(self, elem_nodes, nodes, attr, mesh_grad, qweight):
         self.ne, self.npe = elem_nodes.shape
         self.Q = len(qweight)
+        self.dim = int(np.asarray(mesh_grad).shape[0])  # 3, or 2 for the reference's 2-D cases (6 geometry rows)
         self._keep = dict(off=np.ascontiguousarray(elem_nodes, dtype=np.int32),
                           nodes=np.ascontiguousarray(nodes, dtype=np.float64),
                           attr=np.ascontiguousarray(attr, dtype=np.int32),
                           grad=np.ascontiguousarray(mesh_grad, dtype=np.float64),
                           w=np.ascontiguousarray(qweight, dtype=np.float64))
         k = self._keep
-        assert k["grad"].shape == (3, self.Q, self.npe)
+        assert k["grad"].shape == (self.dim, self.Q, self.npe) and k["nodes"].shape[1] == self.dim
         desc = _lib.MeshDenseDesc(self.ne, self.npe, self.Q, k["nodes"].shape[0], _ptr(k["off"]), _ptr(k["nodes"]),
-                                  _ptr(k["attr"]), _ptr(k["grad"]), _ptr(k["w"]))
+                                  _ptr(k["attr"]), _ptr(k["grad"]), _ptr(k["w"]), self.dim)
         self.handle = C.c_void_p()
         _lib.check(_lib.load().pa_geom_create_dense(C.byref(desc), _stream(), C.byref(self.handle)))
 
@@ -136,13 +137,15 @@ class DenseGeomFactorData:
         lay = (C.c_int32 * 4)()
         _lib.check(L.pa_geom_layout(self.handle, lay))
         ne, Q, Qpad, eb = list(lay)
+        rows = 6 if eb < 0 else 11
+        eb = abs(eb)
 
         class _View:
             __cuda_array_interface__ = dict(shape=(n.value,), typestr="<f8", data=(p.value, False), version=2)
 
         torch.cuda.synchronize()
-        raw = torch.as_tensor(_View(), device="cuda").cpu().numpy().reshape(-1, 11, Qpad, eb)
-        return np.ascontiguousarray(raw.transpose(0, 3, 1, 2).reshape(-1, 11, Qpad)[:ne, :, :Q])
+        raw = torch.as_tensor(_View(), device="cuda").cpu().numpy().reshape(-1, rows, Qpad, eb)
+        return np.ascontiguousarray(raw.transpose(0, 3, 1, 2).reshape(-1, rows, Qpad)[:ne, :, :Q])
 
     def __del__(self):
         try:

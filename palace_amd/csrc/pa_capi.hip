@@ -414,6 +414,7 @@ int pa_geom_layout(const pa_geom *geom, int32_t out[4]) {
   return guarded([&] {
     PA_REQUIRE(geom && out, "null argument");
     out[0] = geom->ne, out[1] = geom->Q, out[2] = geom->eb ? geom->Qpad : geom->Q, out[3] = geom->eb;
+    if (geom->dim == 2) out[3] = -geom->eb;  // 2-D block: 6 rows instead of 11
   });
 }
 
@@ -428,6 +429,7 @@ void pa_geom_destroy(pa_geom *geom) {
   if (!geom) return;
   if (--geom->refcount == 0) {
     hipFree(geom->d_geom);
+    hipFree(geom->d_qw);
     delete geom;
   }
 }
@@ -436,7 +438,7 @@ int pa_geom_data(const pa_geom *geom, const double **dev_ptr, size_t *count) {
   return guarded([&] {
     PA_REQUIRE(geom && dev_ptr && count, "null argument");
     *dev_ptr = geom->d_geom;
-    *count = geom->eb ? (size_t)((geom->ne + geom->eb - 1) / geom->eb) * 11 * geom->Qpad * geom->eb
+    *count = geom->eb ? (size_t)((geom->ne + geom->eb - 1) / geom->eb) * geom->nrows * geom->Qpad * geom->eb
                       : (size_t)geom->ne * 11 * geom->Q;
   });
 }
@@ -586,8 +588,8 @@ double pa_op_algorithmic_bytes(const pa_op *op) {
   if (!op) return 0.0;
   double bytes = 0.0;
   for (const SubOp *so : op->subs) bytes += (double)so->ne * ((double)so->Q * 11 * 8 + (double)so->P * 5);
-  for (const DenseSub *ds : op->dsubs)  // o = 3 for the curl-oriented restriction
-    bytes += (double)ds->ne * ((double)ds->Q * 11 * 8 + (double)ds->P * (ds->d_co ? 7 : 5));
+  for (const DenseSub *ds : op->dsubs)  // o = 3 for the curl-oriented restriction; G = 11 (3-D) or 6 (2-D)
+    bytes += (double)ds->ne * ((double)ds->Q * ds->geom->nrows * 8 + (double)ds->P * (ds->d_co ? 7 : 5));
   return bytes + 16.0 * op->height;
 }
 

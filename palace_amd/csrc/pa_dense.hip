@@ -44,17 +44,30 @@ enum DenseMode {
   MODE_CURLMASS = 2,  // ND curl-curl + mass       f_apply_hdivmass_33
   MODE_DIFF = 3,      // H1 diffusion              f_apply_hcurl_33 on grad u
   MODE_DIFFMASS = 4,  // H1 diffusion + mass       f_apply_hcurlmass_33
-  MODE_MASS = 5       // H1 mass                   f_apply_h1_1
+  MODE_MASS = 5,      // H1 mass                   f_apply_h1_1
+  // 2-D (fast path only: tables resident in LDS + packed D)
+  MODE_CURL2 = 6,     // 2-D ND curl-curl          f_apply_l2_1 on the scalar curl (q_w input)
+  MODE_VMASS2 = 7,    // 2-D ND mass               f_apply_hcurl_22
+  MODE_CURLMASS2 = 8  // 2-D ND curl-curl + mass   f_apply_hdivmass_22
 };
 
 template <int MODE>
 struct ModeTraits {
-  static constexpr int NCI = (MODE == MODE_VMASS || MODE == MODE_CURLMASS) ? 3 : (MODE == MODE_DIFFMASS || MODE == MODE_MASS) ? 1 : 0;
-  static constexpr int NCD = (MODE == MODE_VMASS || MODE == MODE_MASS) ? 0 : 3;
+  static constexpr int NCI = (MODE == MODE_VMASS || MODE == MODE_CURLMASS) ? 3
+                             : (MODE == MODE_VMASS2 || MODE == MODE_CURLMASS2) ? 2
+                             : (MODE == MODE_DIFFMASS || MODE == MODE_MASS) ? 1 : 0;
+  static constexpr int NCD = (MODE == MODE_VMASS || MODE == MODE_MASS || MODE == MODE_VMASS2) ? 0
+                             : (MODE == MODE_CURL2 || MODE == MODE_CURLMASS2) ? 1 : 3;
   static constexpr int NCT = NCI + NCD;
 };
 
-int mode_of(int fe_type, int qf) {
+int mode_of(int fe_type, int qf, int dim) {
+  if (dim == 2) {
+    if (fe_type == PA_FE_HCURL && qf == PA_QF_L2_1) return MODE_CURL2;
+    if (fe_type == PA_FE_HCURL && qf == PA_QF_HCURL_22) return MODE_VMASS2;
+    if (fe_type == PA_FE_HCURL && qf == PA_QF_HDIVMASS_22) return MODE_CURLMASS2;
+    throw Error("QFunction does not match a 2-D H(curl) element");
+  }
   if (fe_type == PA_FE_HCURL) {
     if (qf == PA_QF_HDIV_33) return MODE_CURL;
     if (qf == PA_QF_HCURL_33) return MODE_VMASS;
@@ -68,8 +81,11 @@ int mode_of(int fe_type, int qf) {
 }
 
 void mode_comps(int mode, int &nci, int &ncd) {
-  nci = (mode == MODE_VMASS || mode == MODE_CURLMASS) ? 3 : (mode == MODE_DIFFMASS || mode == MODE_MASS) ? 1 : 0;
-  ncd = (mode == MODE_VMASS || mode == MODE_MASS) ? 0 : 3;
+  nci = (mode == MODE_VMASS || mode == MODE_CURLMASS) ? 3
+        : (mode == MODE_VMASS2 || mode == MODE_CURLMASS2) ? 2
+        : (mode == MODE_DIFFMASS || mode == MODE_MASS) ? 1 : 0;
+  ncd = (mode == MODE_VMASS || mode == MODE_MASS || mode == MODE_VMASS2) ? 0
+        : (mode == MODE_CURL2 || mode == MODE_CURLMASS2) ? 1 : 3;
 }
 
 struct DenseArgs {
@@ -77,6 +93,7 @@ struct DenseArgs {
   const int32_t *idx;
   const uint16_t *co;  // 2-bit fields {sub, main, super} of row d of T_e and {T[d-1][d], T[d+1][d]} of column d
   const double *geom;
+  const double *qw;     // quadrature weights (2-D curl-curl)
   const double *Tf, *Tt;
   const double *L;      // resident form of the tables: [rows][S], rows in tile order (see make_dense_sub)
   const double *qdata;  // packed pre-assembled D: [nb][ncq][Qpad][16]
@@ -359,6 +376,10 @@ __device__ __forceinline__ void dense_D_packed(const double *m, double *v) {
   using FT = FieldTraits<MODE, F>;
   if (FT::NC == 3) {
     sym_mv(m, v[0], v[1], v[2], v[0], v[1], v[2]);
+  } else if (FT::NC == 2) {  // packed symmetric 2x2 {00, 01, 11}
+    const double x0 = v[0], x1 = v[1];
+    v[0] = m[0] * x0 + m[1] * x1;
+    v[1] = m[1] * x0 + m[2] * x1;
   } else {
     v[0] *= m[0];
   }
@@ -401,7 +422,7 @@ __device__ __forceinline__ void resident_field(const double *__restrict__ Lf, co
 // q-data of the 4 point groups of one chunk; `ng` = valid groups left (the last chunk may be partial)
 template <int MODE, int F>
 __device__ __forceinline__ void load_qd(const double *__restrict__ q, const size_t cs, const int ng, double (&qd)[4][6]) {
-  constexpr int NQ = FieldTraits<MODE, F>::NC == 3 ? 6 : 1;
+  constexpr int NQ = FieldTraits<MODE, F>::NC == 3 ? 6 : (FieldTraits<MODE, F>::NC == 2 ? 3 : 1);
 #pragma unroll
   for (int gl = 0; gl < 4; gl++)
 #pragma unroll
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
   using F0 = FieldTraits<MODE, 0>;
   using F1 = FieldTraits<MODE, 1>;
   constexpr int NCT = M::NCT, KPMAX = 4 * PT, NF = F0::NF, S = ResidentStride<PT>::S;
-  constexpr int NQ0 = F0::NC == 3 ? 6 : 1, NQ1 = F1::NC == 3 ? 6 : 1;
+  constexpr int NQ0 = F0::NC == 3 ? 6 : (F0::NC == 2 ? 3 : 1), NQ1 = F1::NC == 3 ? 6 : (F1::NC == 2 ? 3 : 1);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -589,6 +610,83 @@ __global__ void dense_qdata_kernel(const DenseArgs a, double *__restrict__ qd) {
   if (F0::NF == 2) field(std::integral_constant<int, 1>{});
 }
 
+// 2-D: packed D from the 6-row geometry data {attr, w detJ, adj(J)^T/detJ} and the quadrature weights
+// (hcurl_22_qf.h:10-30 -> symmetric 2x2 {00, 01, 11};  l2_1_qf.h:10-24 -> the scalar c qw^2 / (w detJ))
+template <int MODE>
+__global__ void dense_qdata2_kernel(const DenseArgs a, double *__restrict__ qd) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / a.Q);
+  if (e >= a.ne) return;
+  const int q = (int)(gid - (long long)e * a.Q);
+  const size_t cs = (size_t)a.Qpad * kEB, os = (size_t)a.Q4 * kEB;
+  const double *g = a.geom + ((size_t)(e / kEB) * 6 * a.Qpad + q) * kEB + (e % kEB);
+  double *out = qd + ((size_t)(e / kEB) * a.ncq * a.Q4 + q) * kEB + (e % kEB);
+  const int attr = (int)g[0];
+  const double wdetJ = g[cs];
+  const double A[4] = {g[2 * cs], g[3 * cs], g[4 * cs], g[5 * cs]};
+  int o = 0;
+  if (MODE == MODE_VMASS2 || MODE == MODE_CURLMASS2) {
+    const double *C = a.c0.mat + 4 * coeff_index(a.c0, attr);  // CoeffUnpack2, column-major
+    double Mx[4];
+    for (int col = 0; col < 2; col++) {  // MultAtBCx22(adjJt, coeff, adjJt, e_col) * wdetJ (utils_22_qf.h)
+      const double x0 = col == 0 ? 1.0 : 0.0, x1 = col == 1 ? 1.0 : 0.0;
+      const double y0 = A[0] * x0 + A[2] * x1, y1 = A[1] * x0 + A[3] * x1;
+      const double z0 = C[0] * y0 + C[2] * y1, z1 = C[1] * y0 + C[3] * y1;
+      Mx[0 + 2 * col] = wdetJ * (A[0] * z0 + A[1] * z1);
+      Mx[1 + 2 * col] = wdetJ * (A[2] * z0 + A[3] * z1);
+    }
+    out[0] = Mx[0], out[os] = 0.5 * (Mx[1] + Mx[2]), out[2 * os] = Mx[3];
+    o = 3;
+  }
+  if (MODE == MODE_CURL2 || MODE == MODE_CURLMASS2) {
+    const CoeffDev &cc = (MODE == MODE_CURL2) ? a.c0 : a.c1;
+    const double w = a.qw[q];
+    out[o * os] = cc.mat[coeff_index(cc, attr)] * w * w / wdetJ;
+  }
+}
+
+// Diagonal from the packed D (any mode that has q-data): d_e[j] = sum_q b_j^T D b_j, pushed through the
+// transpose of the unsigned restriction (see dense_diag_kernel)
+template <int MODE>
+__global__ void dense_diag_qd_kernel(const DenseArgs a, const int32_t *__restrict__ off, const int8_t *__restrict__ cor,
+                                     const double *__restrict__ interp, const double *__restrict__ deriv,
+                                     double *__restrict__ diag) {
+  using M = ModeTraits<MODE>;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / a.P);
+  if (e >= a.ne) return;
+  const int jd = (int)(gid - (long long)e * a.P);
+  const size_t os = (size_t)a.Q4 * kEB;
+  const double *qd = a.qdata + ((size_t)(e / kEB) * a.ncq * a.Q4) * kEB + (e % kEB);
+  double d = 0.0;
+  for (int q = 0; q < a.Q; q++) {
+    int o = 0;
+    auto part = [&](const double *tab, int nc) {
+      double v[3], w[3];
+      for (int k = 0; k < nc; k++) v[k] = w[k] = tab[((size_t)k * a.Q + q) * a.P + jd];
+      double m[6];
+      const int nq = nc == 3 ? 6 : (nc == 2 ? 3 : 1);
+      for (int k = 0; k < nq; k++) m[k] = qd[(size_t)(o + k) * os + (size_t)q * kEB];
+      if (nc == 3) sym_mv(m, v[0], v[1], v[2], w[0], w[1], w[2]);
+      else if (nc == 2) w[0] = m[0] * v[0] + m[1] * v[1], w[1] = m[1] * v[0] + m[2] * v[1];
+      else w[0] = m[0] * v[0];
+      for (int k = 0; k < nc; k++) d += v[k] * w[k];
+      o += nq;
+    };
+    if (M::NCI > 0) part(interp, M::NCI);
+    if (M::NCD > 0) part(deriv, M::NCD);
+  }
+  const int32_t *oe = off + (size_t)e * a.P;
+  if (cor) {
+    const int8_t *t = cor + 3 * ((size_t)e * a.P + jd);
+    if (t[1]) unsafeAtomicAdd(&diag[oe[jd]], fabs((double)t[1]) * d);
+    if (jd > 0 && t[0]) unsafeAtomicAdd(&diag[oe[jd - 1]], fabs((double)t[0]) * d);
+    if (jd + 1 < a.P && t[2]) unsafeAtomicAdd(&diag[oe[jd + 1]], fabs((double)t[2]) * d);
+  } else {
+    unsafeAtomicAdd(&diag[oe[jd]], d);
+  }
+}
+
 template <int PT>
 void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
   const int rows = ds.L_rows;
@@ -612,6 +710,9 @@ void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
     PA_RES_CASE(MODE_DIFF)
     PA_RES_CASE(MODE_DIFFMASS)
     PA_RES_CASE(MODE_MASS)
+    PA_RES_CASE(MODE_CURL2)
+    PA_RES_CASE(MODE_VMASS2)
+    PA_RES_CASE(MODE_CURLMASS2)
 #undef PA_RES_CASE
   }
 }
@@ -675,6 +776,33 @@ __global__ void geom_dense_kernel(const int ne, const int Q, const int Qpad, con
   for (int c = 0; c < 9; c++) g[(2 + c) * cs] = A[c] / det;
 }
 
+// fem/qfunctions/22/geom_22_qf.h:9-30: {attr, w detJ, adj(J)^T / detJ} with adj(J)^T = {J3, -J2, -J1, J0}
+__global__ void geom_dense2_kernel(const int ne, const int Q, const int Qpad, const int npe,
+                                   const int32_t *__restrict__ node_off, const double *__restrict__ nodes,
+                                   const int32_t *__restrict__ attr, const double *__restrict__ grad,
+                                   const double *__restrict__ w, double *__restrict__ geom) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / Q);
+  if (e >= ne) return;
+  const int q = (int)(gid - (long long)e * Q);
+  double J[4] = {0, 0, 0, 0};
+  for (int n = 0; n < npe; n++) {
+    const int id = node_off[(size_t)e * npe + n];
+    const double d0 = grad[((size_t)0 * Q + q) * npe + n], d1 = grad[((size_t)1 * Q + q) * npe + n];
+    for (int c = 0; c < 2; c++) {
+      const double X = nodes[2 * (size_t)id + c];
+      J[c + 0] += X * d0;
+      J[c + 2] += X * d1;
+    }
+  }
+  const double det = J[0] * J[3] - J[1] * J[2];
+  double *g = geom + ((size_t)(e / kEB) * 6 * Qpad + q) * kEB + (e % kEB);
+  const size_t cs = (size_t)Qpad * kEB;
+  g[0] = (double)attr[e];
+  g[cs] = w[q] * det;
+  g[2 * cs] = J[3] / det, g[3 * cs] = -J[2] / det, g[4 * cs] = -J[1] / det, g[5 * cs] = J[0] / det;
+}
+
 // ---- diagonal (set-up): one thread per (element, local dof) --------------------------------------
 // CeedOperatorLinearAssembleAddDiagonal [libCEED, external]: element diagonals d_e[j] = sum_q b_j^T D b_j
 // pushed through the transpose of the UNSIGNED restriction (for the curl-oriented one: |T|^T d_e).
@@ -714,7 +842,7 @@ __global__ void dense_diag_kernel(const DenseArgs a, const int32_t *__restrict__
 DenseArgs make_args(const DenseSub &ds) {
   DenseArgs a;
   a.ne = ds.ne, a.nb = ds.nb, a.P = ds.P, a.Q = ds.Q, a.Qpad = ds.Qpad, a.nch = ds.nch, a.KP = ds.KP;
-  a.idx = ds.d_idx, a.co = ds.d_co, a.geom = ds.geom->d_geom, a.Tf = ds.d_Tf, a.Tt = ds.d_Tt;
+  a.idx = ds.d_idx, a.co = ds.d_co, a.geom = ds.geom->d_geom, a.qw = ds.geom->d_qw, a.Tf = ds.d_Tf, a.Tt = ds.d_Tt;
   a.L = ds.d_L, a.qdata = ds.d_qdata, a.ncq = ds.ncq, a.Q4 = (ds.Q + 3) / 4 * 4;
   a.dbg = 0;
 #ifdef PA_ABLATION
@@ -729,24 +857,32 @@ DenseArgs make_args(const DenseSub &ds) {
 
 void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
   const int ne = mesh.num_elem, npe = mesh.nodes_per_elem, Q = mesh.num_qpts;
+  const int dim = mesh.dim == 0 ? 3 : mesh.dim;
+  PA_REQUIRE(dim == 2 || dim == 3, "space dimension must be 2 or 3");
   PA_REQUIRE(ne > 0 && npe > 0 && Q > 0 && mesh.num_nodes > 0, "empty mesh description");
   PA_REQUIRE(mesh.node_offsets && mesh.nodes && mesh.attr && mesh.mesh_grad && mesh.qweight, "null mesh array");
   for (size_t i = 0; i < (size_t)ne * npe; i++)
     PA_REQUIRE(mesh.node_offsets[i] >= 0 && mesh.node_offsets[i] < mesh.num_nodes, "mesh node id out of range");
   for (int e = 0; e < ne; e++) PA_REQUIRE(mesh.attr[e] >= 1, "element attributes are 1-based");
   int32_t *d_off = dev_upload(mesh.node_offsets, (size_t)ne * npe, s);
-  double *d_nodes = dev_upload(mesh.nodes, (size_t)mesh.num_nodes * 3, s);
+  double *d_nodes = dev_upload(mesh.nodes, (size_t)mesh.num_nodes * dim, s);
   int32_t *d_attr = dev_upload(mesh.attr, (size_t)ne, s);
-  double *d_grad = dev_upload(mesh.mesh_grad, (size_t)3 * Q * npe, s);
+  double *d_grad = dev_upload(mesh.mesh_grad, (size_t)dim * Q * npe, s);
   double *d_w = dev_upload(mesh.qweight, (size_t)Q, s);
   g.ne = ne, g.q1d = 0, g.Q = Q, g.eb = kEB, g.Qpad = (Q + 15) / 16 * 16;
-  const size_t nb = (size_t)(ne + kEB - 1) / kEB, count = nb * 11 * g.Qpad * kEB;
+  g.dim = dim, g.nrows = dim == 2 ? 6 : 11;
+  g.d_qw = dev_upload(mesh.qweight, (size_t)Q, s);
+  const size_t nb = (size_t)(ne + kEB - 1) / kEB, count = nb * g.nrows * g.Qpad * kEB;
   g.d_geom = dev_alloc<double>(count);
   PA_HIP(hipMemsetAsync(g.d_geom, 0, sizeof(double) * count, s));
   const long long n = (long long)ne * Q;
   const int bs = 256;
-  hipLaunchKernelGGL(geom_dense_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, ne, Q, g.Qpad, npe, d_off,
-                     d_nodes, d_attr, d_grad, d_w, g.d_geom);
+  if (dim == 2)
+    hipLaunchKernelGGL(geom_dense2_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, ne, Q, g.Qpad, npe, d_off,
+                       d_nodes, d_attr, d_grad, d_w, g.d_geom);
+  else
+    hipLaunchKernelGGL(geom_dense_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, ne, Q, g.Qpad, npe, d_off,
+                       d_nodes, d_attr, d_grad, d_w, g.d_geom);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(s));
   hipFree(d_off), hipFree(d_nodes), hipFree(d_attr), hipFree(d_grad), hipFree(d_w);
@@ -762,7 +898,8 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   PA_REQUIRE(!(r.orients && r.curl_orients), "restriction is either oriented or curl-oriented");
   PA_REQUIRE(r.lsize < (1 << 29), "too many local dofs for the index encoding");
   const int P = b.num_dofs, Q = b.num_qpts, ne = r.num_elem;
-  const int mode = mode_of(b.fe_type, qf);
+  const int dim = geom->dim;
+  const int mode = mode_of(b.fe_type, qf, dim);
   int nci, ncd;
   mode_comps(mode, nci, ncd);
   const int nct = nci + ncd;
@@ -771,7 +908,9 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   {
     const uint32_t want_i = nci ? PA_EVAL_INTERP : 0u;
     const uint32_t want_d = ncd ? (b.fe_type == PA_FE_HCURL ? PA_EVAL_CURL : PA_EVAL_GRAD) : 0u;
-    PA_REQUIRE(trial_ops == (want_i | want_d) && test_ops == trial_ops, "eval modes do not match the QFunction");
+    // 2-D curl-curl adds the Weight input (integ/curlcurl.cpp:65-68): accepted, the weights live in the geometry data
+    const uint32_t got = trial_ops & ~(uint32_t)PA_EVAL_WEIGHT;
+    PA_REQUIRE(got == (want_i | want_d) && test_ops == trial_ops, "eval modes do not match the QFunction");
   }
   static const int kPT[] = {1, 2, 3, 4, 6, 9};
   int PT = 0;
@@ -863,7 +1002,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   ds->d_Tt = dev_upload(Tt.data(), Tt.size());
   // plain copies for the diagonal kernel
   if (nci) ds->d_interp = dev_upload(b.interp, (size_t)nci * Q * P);
-  if (ncd) ds->d_deriv = dev_upload(b.deriv, (size_t)3 * Q * P);
+  if (ncd) ds->d_deriv = dev_upload(b.deriv, (size_t)ncd * Q * P);
   ds->d_off = dev_upload(r.offsets, (size_t)ne * P);
   ds->h_off.assign(r.offsets, r.offsets + (size_t)ne * P);
   if (r.curl_orients) ds->d_cor = dev_upload(r.curl_orients, (size_t)3 * ne * P);
@@ -886,7 +1025,15 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       parse_coeff(ctx, ctx_size, 3, ds->c1, ds->c0.slots);
       break;
     case MODE_MASS:
+    case MODE_CURL2:
       parse_coeff(ctx, ctx_size, 1, ds->c0, 0);
+      break;
+    case MODE_VMASS2:
+      parse_coeff(ctx, ctx_size, 2, ds->c0, 0);
+      break;
+    case MODE_CURLMASS2:
+      parse_coeff(ctx, ctx_size, 2, ds->c0, 0);
+      parse_coeff(ctx, ctx_size, 1, ds->c1, ds->c0.slots);
       break;
   }
 
@@ -894,6 +1041,11 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   // Needs symmetric coefficients and tables that fit; PALACE_AMD_DENSE=staged keeps the general kernel.
   {
     auto is_sym = [](const CoeffHost &c) {
+      if (c.dim == 2) {
+        for (size_t k = 0; k + 4 <= c.mat.size(); k += 4)
+          if (c.mat[k + 1] != c.mat[k + 2]) return false;
+        return true;
+      }
       if (c.dim != 3) return true;
       for (size_t k = 0; k + 9 <= c.mat.size(); k += 9)
         if (c.mat[k + 1] != c.mat[k + 3] || c.mat[k + 2] != c.mat[k + 6] || c.mat[k + 5] != c.mat[k + 7]) return false;
@@ -918,7 +1070,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
         }
       ds->d_L = dev_upload(L.data(), L.size());
       ds->L_rows = rows;
-      ds->ncq = (nci == 3 ? 6 : nci) + (ncd == 3 ? 6 : ncd);
+      ds->ncq = (nci == 3 ? 6 : (nci == 2 ? 3 : nci)) + (ncd == 3 ? 6 : ncd);
       const size_t nq = (size_t)nb * ds->ncq * ((Q + 3) / 4 * 4) * kEB;
       ds->d_qdata = dev_alloc<double>(nq);
       PA_HIP(hipMemset(ds->d_qdata, 0, sizeof(double) * nq));
@@ -940,11 +1092,18 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
         PA_QD_CASE(MODE_DIFFMASS)
         PA_QD_CASE(MODE_MASS)
 #undef PA_QD_CASE
+#define PA_QD2_CASE(MODE) \
+  case MODE: hipLaunchKernelGGL((dense_qdata2_kernel<MODE>), grid, block, 0, nullptr, a, ds->d_qdata); break;
+        PA_QD2_CASE(MODE_CURL2)
+        PA_QD2_CASE(MODE_VMASS2)
+        PA_QD2_CASE(MODE_CURLMASS2)
+#undef PA_QD2_CASE
       }
       PA_HIP(hipGetLastError());
       PA_HIP(hipStreamSynchronize(nullptr));
     }
   }
+  PA_REQUIRE(dim == 3 || ds->d_L, "2-D blocks need symmetric coefficients and tables that fit in LDS (fast path only)");
   return ds;
 }
 
@@ -1021,6 +1180,15 @@ void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s) {
     PA_DIAG_CASE(MODE_DIFFMASS)
     PA_DIAG_CASE(MODE_MASS)
 #undef PA_DIAG_CASE
+#define PA_DIAG2_CASE(MODE)                                                                                     \
+  case MODE:                                                                                                    \
+    hipLaunchKernelGGL((dense_diag_qd_kernel<MODE>), grid, block, 0, s, a, ds.d_off, ds.d_cor, ds.d_interp, ds.d_deriv, \
+                       diag);                                                                                   \
+    break;
+    PA_DIAG2_CASE(MODE_CURL2)
+    PA_DIAG2_CASE(MODE_VMASS2)
+    PA_DIAG2_CASE(MODE_CURLMASS2)
+#undef PA_DIAG2_CASE
   }
   PA_HIP(hipGetLastError());
 }

@@ -1,0 +1,234 @@
+"""Triangular meshes and 2-D Nedelec spaces (host-side set-up for the reference's cavity2d case; the
+role MFEM plays for Palace).  Order-p first-kind Nedelec triangles (p per edge, p(p-1) interior), nodal
+basis dual to tangential point functionals; tri3 / tri6 geometry; conical (collapsed Gauss-Jacobi)
+quadrature with p+1 points per direction (degree 2p+1 >= the default order 2p, fem/integrator.cpp:14-39).
+In 2-D there is no dof transformation (fem/libceed/restriction.cpp:234-238): the restriction is the
+oriented one."""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from .basis1d import gauss_legendre
+
+REF_VERTS = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+LOCAL_EDGES = [(0, 1), (1, 2), (2, 0)]
+_C = np.array([1.0 / 3.0, 1.0 / 3.0])
+
+
+def tri_quadrature(n):
+    from scipy.special import roots_jacobi
+
+    t1, w1 = roots_jacobi(n, 1.0, 0.0)
+    t0, w0 = roots_jacobi(n, 0.0, 0.0)
+    u, wu = 0.5 * (1 + t1), w1 / 4.0
+    v, wv = 0.5 * (1 + t0), w0 / 2.0
+    pts = np.array([[u[a], v[b] * (1 - u[a])] for a in range(n) for b in range(n)])
+    wts = np.array([wu[a] * wv[b] for a in range(n) for b in range(n)])
+    return pts, wts
+
+
+def _monos(lo, hi):
+    return [(a, d - a) for d in range(lo, hi + 1) for a in range(d + 1)]
+
+
+def _mv(e, z):
+    return z[..., 0] ** e[0] * z[..., 1] ** e[1]
+
+
+def _mg(e, z):
+    g = np.zeros(z.shape)
+    if e[0] > 0:
+        g[..., 0] = e[0] * _mv((e[0] - 1, e[1]), z)
+    if e[1] > 0:
+        g[..., 1] = e[1] * _mv((e[0], e[1] - 1), z)
+    return g
+
+
+class NDTriElement:
+    """R_p = P_{p-1}^2 + (-z_y, z_x) P~_{p-1} on the reference triangle (z = centred coordinates)."""
+
+    def __init__(self, p):
+        self.p, self.P = p, p * (p + 2)
+        # candidates as lists of (component, exponent, coefficient)
+        self.cands = [[(c, e, 1.0)] for e in _monos(0, p - 1) for c in range(2)]
+        for e in _monos(p - 1, p - 1):
+            self.cands.append([(0, (e[0], e[1] + 1), -1.0), (1, (e[0] + 1, e[1]), 1.0)])
+        eo = gauss_legendre(p)[0]
+        pts, tans = [], []
+        for a, b in LOCAL_EDGES:
+            for t in eo:
+                pts.append((1 - t) * REF_VERTS[a] + t * REF_VERTS[b])
+                tans.append(REF_VERTS[b] - REF_VERTS[a])
+        if p >= 2:
+            for i in range(p - 1):
+                for j in range(p - 1 - i):
+                    k = p - 2 - i - j
+                    l = np.array([i + 1, j + 1, k + 1]) / (p + 1)
+                    x = l[0] * REF_VERTS[0] + l[1] * REF_VERTS[1] + l[2] * REF_VERTS[2]
+                    pts += [x, x]
+                    tans += [np.array([1.0, 0.0]), np.array([0.0, 1.0])]
+        self.dof_pts, self.dof_tans = np.array(pts), np.array(tans)
+        assert len(pts) == self.P
+        Vm = np.array([np.einsum("nd,nd->n", self._eval(c, self.dof_pts), self.dof_tans) for c in self.cands]).T
+        self.coef = np.linalg.pinv(Vm, rcond=1e-12)
+        assert np.abs(Vm @ self.coef - np.eye(self.P)).max() < 1e-10
+
+    @staticmethod
+    def _eval(c, x):
+        z = x - _C
+        v = np.zeros(z.shape)
+        for comp, e, a in c:
+            v[..., comp] += a * _mv(e, z)
+        return v
+
+    @staticmethod
+    def _curl(c, x):
+        z = x - _C
+        w = np.zeros(z.shape[:-1])
+        for comp, e, a in c:
+            g = a * _mg(e, z)
+            w += g[..., 0] if comp == 1 else -g[..., 1]   # d_x v_y - d_y v_x
+        return w
+
+    def tables(self, x):
+        """interp [2, Q, P], curl [1, Q, P]."""
+        val = np.array([self._eval(c, x) for c in self.cands])       # [k, Q, 2]
+        cur = np.array([self._curl(c, x) for c in self.cands])       # [k, Q]
+        return (np.ascontiguousarray(np.einsum("kqd,kj->dqj", val, self.coef)),
+                np.ascontiguousarray(np.einsum("kq,kj->qj", cur, self.coef)[None]))
+
+
+class TriMesh:
+    """tris [ne, 3] vertex ids; geometry nodes order 1 (vertices) or 2 (tri6: + edge midpoints in
+    LOCAL_EDGES order)."""
+
+    def __init__(self, verts, tris, attr=None, elem_nodes=None, nodes=None, bdr_edges=None, bdr_attr=None):
+        self.verts, self.tris = np.asarray(verts, dtype=np.float64), np.asarray(tris, dtype=np.int64)
+        self.ne = self.tris.shape[0]
+        self.attr = np.ones(self.ne, dtype=np.int32) if attr is None else np.asarray(attr, dtype=np.int32)
+        self.nodes = self.verts if nodes is None else np.asarray(nodes, dtype=np.float64)
+        self.elem_nodes = self.tris if elem_nodes is None else np.asarray(elem_nodes, dtype=np.int64)
+        self.mesh_order = 1 if self.elem_nodes.shape[1] == 3 else 2
+        self.bdr_edges, self.bdr_attr = bdr_edges, bdr_attr
+        X = self.verts[self.tris]
+        d1, d2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+        if np.any(d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0] <= 0):
+            raise ValueError("inverted triangles")
+        e = np.stack([np.sort(self.tris[:, list(le)], axis=1) for le in LOCAL_EDGES], axis=1)
+        ue, inv, cnt = np.unique(e.reshape(-1, 2), axis=0, return_inverse=True, return_counts=True)
+        self.edge_verts, self.elem_edges = ue, inv.reshape(self.ne, 3)
+        self.boundary_edge_mask = cnt == 1
+
+    def geometry_grad_table(self, x):
+        l = np.stack([1 - x.sum(axis=1), x[:, 0], x[:, 1]], axis=1)
+        dl = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+        Q = x.shape[0]
+        if self.mesh_order == 1:
+            return np.ascontiguousarray(np.broadcast_to(dl.T[:, None, :], (2, Q, 3)))
+        G = np.zeros((2, Q, 6))
+        for i in range(3):
+            G[:, :, i] = ((4 * l[:, i] - 1)[None, :]) * dl[i][:, None]
+        for k, (a, b) in enumerate(LOCAL_EDGES):
+            G[:, :, 3 + k] = 4 * (l[:, a][None, :] * dl[b][:, None] + l[:, b][None, :] * dl[a][:, None])
+        return G
+
+    def jacobians(self, x):
+        return np.einsum("dqn,eni->eqid", self.geometry_grad_table(x), self.nodes[self.elem_nodes])
+
+
+def read_gmsh22_tris(path):
+    """Gmsh 2.2 (binary / ASCII) with tri3 (type 2) or tri6 (type 9) elements and 2- / 3-node boundary
+    lines (types 1 / 8): the reference's examples/cavity2d/mesh/cavity2d.msh."""
+    data = open(path, "rb").read()
+
+    def section(name):
+        a = data.index(b"$" + name + b"\n") + len(name) + 2
+        return a, data.index(b"$End" + name)
+
+    a, _ = section(b"MeshFormat")
+    binary = int(data[a : data.index(b"\n", a)].split()[1]) == 1
+    a, b = section(b"Nodes")
+    nl = data.index(b"\n", a)
+    nn = int(data[a:nl])
+    if binary:
+        rec = np.frombuffer(data, dtype=np.dtype([("i", "<i4"), ("x", "<f8", 3)]), count=nn, offset=nl + 1)
+        ids, xyz = rec["i"].astype(np.int64), rec["x"].copy()
+    else:
+        rows = np.array(data[nl + 1 : b].split(), dtype=np.float64).reshape(nn, 4)
+        ids, xyz = rows[:, 0].astype(np.int64), rows[:, 1:]
+    idmap = np.full(ids.max() + 1, -1, dtype=np.int64)
+    idmap[ids] = np.arange(nn)
+    a, b = section(b"Elements")
+    nl = data.index(b"\n", a)
+    nelem = int(data[a:nl])
+    npe = {2: 3, 9: 6, 1: 2, 8: 3, 15: 1}
+    tri, tattr, lin, lattr = [], [], [], []
+    if binary:
+        off, done = nl + 1, 0
+        while done < nelem:
+            et, nf, nt = struct.unpack_from("<iii", data, off)
+            off += 12
+            w = 1 + nt + npe[et]
+            rec = np.frombuffer(data, dtype="<i4", count=w * nf, offset=off).reshape(nf, w)
+            off += 4 * w * nf
+            if et in (2, 9):
+                tri.append(rec[:, 1 + nt :]), tattr.append(rec[:, 1])
+            elif et in (1, 8):
+                lin.append(rec[:, 1 + nt :]), lattr.append(rec[:, 1])
+            done += nf
+    else:
+        for line in data[nl + 1 : b].splitlines():
+            r = [int(v) for v in line.split()]
+            if not r:
+                continue
+            et, nt = r[1], r[2]
+            if et in (2, 9):
+                tri.append(np.array([r[3 + nt :]])), tattr.append(np.array([r[3]]))
+            elif et in (1, 8):
+                lin.append(np.array([r[3 + nt :]])), lattr.append(np.array([r[3]]))
+    en = idmap[np.concatenate(tri)]
+    X = xyz[en[:, :3], :2]
+    d1, d2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+    neg = d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0] < 0
+    if np.any(neg):  # swap vertices 1 <-> 2 (gmsh tri6 edges (0,1),(1,2),(2,0) -> (0,2),(2,1),(1,0))
+        sw = [0, 2, 1] if en.shape[1] == 3 else [0, 2, 1, 5, 4, 3]
+        en[neg] = en[neg][:, sw]
+    t = en[:, :3]
+    used, inv = np.unique(t, return_inverse=True)
+    vmap = np.full(nn, -1, dtype=np.int64)
+    vmap[used] = np.arange(used.size)
+    be = vmap[idmap[np.concatenate(lin)][:, :2]] if lin else None
+    quad = en.shape[1] == 6
+    return TriMesh(xyz[used, :2], inv.reshape(-1, 3), np.concatenate(tattr), elem_nodes=en if quad else None,
+                   nodes=xyz[:, :2] if quad else None, bdr_edges=be, bdr_attr=np.concatenate(lattr) if lin else None)
+
+
+class NDTriSpace:
+    """Order-p Nedelec space on a TriMesh: global dofs = edges | interiors; oriented restriction."""
+
+    def __init__(self, mesh: TriMesh, p: int):
+        self.mesh, self.p = mesh, p
+        self.elem = NDTriElement(p)
+        self.P = self.elem.P
+        ne, t = mesh.ne, mesh.tris
+        n_i = p * (p - 1)
+        NE_ = mesh.edge_verts.shape[0]
+        self.ndofs = NE_ * p + ne * n_i
+        off = np.zeros((ne, self.P), dtype=np.int64)
+        ori = np.zeros((ne, self.P), dtype=bool)
+        for k, (a, b) in enumerate(LOCAL_EDGES):
+            flip = t[:, a] > t[:, b]
+            for i in range(p):
+                off[:, k * p + i] = mesh.elem_edges[:, k] * p + np.where(flip, p - 1 - i, i)
+                ori[:, k * p + i] = flip
+        for i in range(n_i):
+            off[:, 3 * p + i] = NE_ * p + np.arange(ne) * n_i + i
+        self.offsets, self.orients = off.astype(np.int32), ori
+
+    def ess_dofs(self, edge_mask=None):
+        m = self.mesh
+        em = m.boundary_edge_mask if edge_mask is None else edge_mask
+        edges = np.nonzero(em)[0]
+        return (edges[:, None] * self.p + np.arange(self.p)[None, :]).ravel().astype(np.int32)

@@ -67,5 +67,42 @@ def mesh_fixture():
     print("wrote cylinder_hex_mesh.npz")
 
 
+def fixtures_2d():
+    """2-D QFunction vectors through the reference headers + the reference's cavity2d mesh and its
+    regression eigenfrequencies (test/data/regression/ref/cavity2d/eigenmode/eig.csv)."""
+    from palace_amd.fem import tri
+
+    capi.build(ref=True)
+    rng = np.random.default_rng(20260926)
+    Q = 36
+    J = (np.eye(2).reshape(4, 1) + 0.3 * rng.uniform(-1, 1, (4, Q))) * rng.uniform(0.5, 2.0, (1, Q))
+    attr = rng.integers(1, 3, Q).astype(np.float64)
+    qw = rng.uniform(0.01, 0.2, Q)
+    geom = np.zeros((6, Q))
+    capi.ref_call("f_build_geom_factor_22", None, Q, [attr, qw, np.ascontiguousarray(J)], [geom])
+    A = rng.uniform(-1, 1, (2, 2))
+    c2 = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[A @ A.T + 2 * np.eye(2), np.array([0.6])], a=1.2, dim=2)
+    c1 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([1.9]), np.array([0.4])], dim=1)
+    u, cu = rng.uniform(-1, 1, (2, Q)), rng.uniform(-1, 1, (1, Q))
+    out = dict(Q=Q, J=J, attr=attr, qw=qw, geom=geom, u=u, cu=cu, ctx2=c2.pack(), ctx1=c1.pack())
+    v = np.zeros((2, Q))
+    capi.ref_call("f_apply_hcurl_22", c2.pack(), Q, [geom, u], [v])
+    out["hcurl_22"] = v.copy()
+    w = np.zeros((1, Q))
+    capi.ref_call("f_apply_l2_1", c1.pack(), Q, [geom, qw, cu], [w])
+    out["l2_1"] = w.copy()
+    pair = np.concatenate([c2.pack(), c1.pack()])
+    v2, w2 = np.zeros((2, Q)), np.zeros((1, Q))
+    capi.ref_call("f_apply_hdivmass_22", pair, Q, [geom, qw, u, cu], [v2, w2])
+    out["hdivmass_22_v"], out["hdivmass_22_cv"], out["ctx_pair"] = v2, w2, pair
+    np.savez(os.path.join(ROOT, "tests", "golden", "qf2d_golden.npz"), **out)
+    m = tri.read_gmsh22_tris("/root/reference/examples/cavity2d/mesh/cavity2d.msh")
+    eig = np.loadtxt("/root/reference/test/data/regression/ref/cavity2d/eigenmode/eig.csv", delimiter=",", skiprows=1)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "cavity2d_mesh.npz"), nodes=m.nodes,
+                        elem_nodes=m.elem_nodes.astype(np.int32), attr=m.attr, eig_re_GHz=eig[:, 1], eig_im_GHz=eig[:, 2])
+    print("wrote qf2d_golden.npz, cavity2d_mesh.npz")
+
+
 if __name__ == "__main__":
     mesh_fixture()
+    fixtures_2d()

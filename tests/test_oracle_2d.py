@@ -1,0 +1,76 @@
+"""2-D path (the reference's examples/cavity2d, order-2 Nedelec triangles): the oracle's restatement of
+fem/qfunctions/22/*.h and fem/qfunctions/1/l2_1_qf.h against vectors produced by the reference's own
+headers, and the whole chain against the reference's regression eigenfrequencies
+(test/data/regression/ref/cavity2d/eigenmode/eig.csv; the reference gates them at rtol 1e-4)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import palace_oracle as po
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "qf2d_golden.npz"))
+TOL = 1e-13
+
+
+def _ctx(blob, dim):
+    iv = np.asarray(blob).view(np.int32).reshape(-1, 2)[:, 0]
+    nattr = int(iv[0])
+    nmat = int(iv[1 + nattr])
+    c = po.CoeffCtx(dim=dim)
+    c.attr_mat = iv[1 : 1 + nattr].astype(np.int32)
+    c.mat = np.asarray(blob)[2 + nattr : 2 + nattr + nmat * dim * dim].reshape(nmat, dim * dim)
+    return c, 2 + nattr + nmat * dim * dim
+
+
+def test_geom_factor_22():
+    geom = po.build_geom_factor_22(np.ones(1), G["qw"], G["J"].T[None])
+    np.testing.assert_allclose(geom[0, 1:], G["geom"][1:], rtol=TOL, atol=TOL)
+
+
+def test_qfunctions_22():
+    geom = G["geom"][None]
+    c2, n2 = _ctx(G["ctx2"], 2)
+    c1, _ = _ctx(G["ctx1"], 1)
+    np.testing.assert_allclose(po.apply_hcurl_22(c2, geom, G["u"][None])[0], G["hcurl_22"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(po.apply_l2_1(c1, geom, G["qw"], G["cu"][None])[0], G["l2_1"], rtol=TOL, atol=TOL)
+    pm, n = _ctx(G["ctx_pair"], 2)
+    pc, _ = _ctx(G["ctx_pair"][n:], 1)
+    v, cv = po.apply_hdivmass_22(pm, pc, geom, G["qw"], G["u"][None], G["cu"][None])
+    np.testing.assert_allclose(v[0], G["hdivmass_22_v"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(cv[0], G["hdivmass_22_cv"], rtol=TOL, atol=TOL)
+
+
+def test_cavity2d_eigenfrequencies():
+    """Order-2 Nedelec triangles on the reference's own mesh, eps_r = 2.08 with loss tangent 4e-4, PEC:
+    K x = omega^2 eps M x  ->  f = sqrt(lambda / (eps_r (1 - i tan d))) c0 / 2 pi."""
+    import scipy.sparse.linalg as spl
+
+    from palace_amd.fem import tri
+
+    M_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "cavity2d_mesh.npz"))
+    en = M_["elem_nodes"].astype(np.int64)
+    used, inv = np.unique(en[:, :3], return_inverse=True)
+    mesh = tri.TriMesh(M_["nodes"][used], inv.reshape(-1, 3), M_["attr"], elem_nodes=en, nodes=M_["nodes"])
+    nd = tri.NDTriSpace(mesh, 2)
+    pts, wts = tri.tri_quadrature(3)
+    interp, curl = nd.elem.tables(pts)
+    J = mesh.jacobians(pts)
+    geom = po.build_geom_factor_22(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 4))
+    K = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, interp, curl, geom, po.QF_L2_1, po.CoeffCtx(dim=1),
+                              qw=wts).assemble_sparse()
+    M = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, interp, curl, geom, po.QF_HCURL_22,
+                              po.CoeffCtx(dim=2)).assemble_sparse()
+    free = np.setdiff1d(np.arange(nd.ndofs), nd.ess_dofs())
+    # shift-invert next to each expected eigenvalue (the huge gradient null space sits at zero)
+    Kf, Mf = K[free][:, free].tocsc(), M[free][:, free].tocsc()
+    lam_ref = (2 * np.pi * M_["eig_re_GHz"] * 1e9 / 299792458.0) ** 2 * 2.08
+    found = []
+    for target in np.unique(np.round(lam_ref, 1)):
+        vals = spl.eigsh(Kf, k=3, M=Mf, sigma=1.001 * target, which="LM", return_eigenvectors=False)
+        found += [v for v in vals if abs(v - target) < 0.02 * target]
+    lam = np.sort(np.array(found))
+    assert lam.size == 5
+    f = np.sqrt(lam / (2.08 * (1.0 - 4e-4j))) * 299792458.0 / (2 * np.pi) / 1e9
+    np.testing.assert_allclose(f.real, M_["eig_re_GHz"], rtol=1e-7)
+    np.testing.assert_allclose(f.imag, M_["eig_im_GHz"], rtol=1e-5)
