@@ -237,6 +237,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
   }
   so->d_sidx = dev_upload(sidx.data(), nnz);
   so->d_perm = dev_upload(perm.data(), nnz);
+  so->h_perm = perm;
   // transpose map for the gather form of E^T (counting sort by dof; element order preserved, so the
   // summation order of every dof is fixed) unless PALACE_AMD_SCATTER=atomic asks for the atomic form
   const char *mode = getenv("PALACE_AMD_SCATTER");
@@ -315,7 +316,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
 static void free_sub(SubOp *so) {
   if (!so) return;
   hipFree(so->d_lidx);
-  hipFree(so->d_sidx), hipFree(so->d_sidx_bc), hipFree(so->d_perm);
+  hipFree(so->d_sidx), hipFree(so->d_sidx_bc), hipFree(so->d_perm), hipFree(so->d_perm_x), hipFree(so->d_shared);
   hipFree(so->d_ye), hipFree(so->d_tptr), hipFree(so->d_tent);
   if (so->qd && --so->qd->refcount == 0) {
     hipFree(so->qd->d);
@@ -338,7 +339,7 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   for (const SubOp *so : op->subs) {
     if (so->fe_type == PA_FE_HCURL) {
       if (so->d_ye) {
-        launch_nd_hex_apply(*so, x, nullptr, so->d_ye, masked, s);
+        launch_nd_hex_apply(*so, x, y, so->d_ye, masked, s, !(overwrite && first));
         launch_et_gather(*so, y, !(overwrite && first), s);
       } else {
         if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
@@ -355,6 +356,32 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
     launch_dense_gather(*ds, y, !(overwrite && first), s);
     first = false;
   }
+}
+
+// Operators with a single H(curl) hex block: dofs with exactly one element copy skip the E-vector
+// (PALACE_AMD_DIRECT=0 keeps every dof on the gather path).
+void finalize_exclusive(pa_op *op) {
+  const char *mode = getenv("PALACE_AMD_DIRECT");
+  if (mode && std::string(mode) == "0") return;
+  if (op->subs.size() != 1 || !op->dsubs.empty()) return;
+  SubOp *so = op->subs[0];
+  if (so->fe_type != PA_FE_HCURL || !so->d_ye || so->d_perm_x) return;
+  const size_t nnz = so->h_sidx.size();
+  std::vector<int32_t> count((size_t)so->lsize, 0);
+  for (size_t k = 0; k < nnz; k++) count[so->h_sidx[k] >= 0 ? so->h_sidx[k] : -1 - so->h_sidx[k]]++;
+  std::vector<uint16_t> px(so->h_perm);
+  size_t nex = 0;
+  for (size_t k = 0; k < nnz; k++)
+    if (count[so->h_sidx[k] >= 0 ? so->h_sidx[k] : -1 - so->h_sidx[k]] == 1) px[k] |= (uint16_t)kExclBit16, nex++;
+  if (nex == 0) return;
+  std::vector<int32_t> shared;
+  shared.reserve((size_t)so->lsize);
+  // dofs without any copy (count == 0) stay on the list so that Mult still writes their zero
+  for (int d = 0; d < so->lsize; d++)
+    if (count[d] != 1) shared.push_back(d);
+  so->d_perm_x = dev_upload(px.data(), px.size());
+  so->d_shared = dev_upload(shared.data(), shared.size());
+  so->n_shared = (int)shared.size();
 }
 
 void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s) { apply(op, x, y, true, s); }
@@ -481,6 +508,7 @@ int pa_op_finalize(pa_op *op) {
   return guarded([&] {
     PA_REQUIRE(op, "null argument");
     PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty(), "operator has no sub-operators");
+    finalize_exclusive(op);
     op->finalized = true;
   });
 }
@@ -503,6 +531,7 @@ int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_
       pa_op_destroy(o);
       throw;
     }
+    finalize_exclusive(o);
     o->finalized = true;
     *coarse = o;
   });

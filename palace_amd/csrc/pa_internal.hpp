@@ -11,6 +11,9 @@
 
 #include "../../include/palace_amd.h"
 
+struct pa_op;
+typedef struct pa_op pa_op_fwd;
+
 namespace pa {
 
 void set_error(const std::string &msg);
@@ -64,6 +67,7 @@ T *dev_upload(const T *host, size_t n, hipStream_t s = nullptr) {
 }
 
 constexpr int kEssBit = 1 << 30;  // flag in the gather index: read this dof as zero
+constexpr int kExclBit16 = 1 << 15;  // flag in the slot permutation: this entry is the only copy of its dof
 constexpr int kMaxP1 = 6;  // closed nodes p+1 <= 7
 constexpr int kMaxQ1 = 7;
 
@@ -116,6 +120,12 @@ struct SubOp {
   int32_t *d_sidx = nullptr;     // [ne][P] signed sorted index
   int32_t *d_sidx_bc = nullptr;  // copy with kEssBit on essential dofs (pa_op_set_essential)
   uint16_t *d_perm = nullptr;    // [ne][P] tensor-order slot of sorted entry m
+  // Exclusive dofs (one element copy only, e.g. element interiors): stored straight into y by the
+  // element kernel instead of going through the E-vector; the gather kernel then only visits the rest.
+  uint16_t *d_perm_x = nullptr;  // perm with kExclBit16 on exclusive entries (set at finalize)
+  int32_t *d_shared = nullptr;   // list of the dofs the gather kernel still has to sum
+  int n_shared = 0;
+  std::vector<uint16_t> h_perm;
   std::vector<int32_t> h_sidx;   // host copy (needed to build d_sidx_bc)
   // E^T as a gather (default): E-vector scratch and the CSR transpose of lidx
   double *d_ye = nullptr;      // [ne][P]
@@ -157,7 +167,9 @@ void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t
 
 // kernels (pa_geom.hip, pa_nd_hex.hip, pa_h1_hex.hip)
 void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s);
-void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s);
+void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
+                         bool accumulate = true);
+void finalize_exclusive(pa_op_fwd *op);
 void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s);
 void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
@@ -175,7 +187,7 @@ void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStr
 void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s);
 void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s);
 void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y,
-                          bool accumulate, hipStream_t s);
+                          bool accumulate, hipStream_t s, const int32_t *list = nullptr);
 
 }  // namespace pa
 

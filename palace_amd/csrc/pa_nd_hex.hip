@@ -63,7 +63,9 @@ struct NDArgs {
   const double *qdata;  // packed symmetric D, [ne][NG][Q] (QD == true)
   const double *x;
   double *y;   // L-vector target of the atomic scatter (EVEC == false)
-  double *ye;  // E-vector target [ne][P], tensor order, unsigned (EVEC == true)
+  double *ye;  // E-vector target [ne][P], sorted order, unsigned (EVEC == true)
+  int direct;      // EVEC: entries flagged kExclBit16 in perm go straight to y (they are the only copy)
+  int accumulate;  // for those: y += v instead of y = v
   CoeffDev c_mass, c_curl;
   NDTab<P1, Q1> tab;
 #ifdef PA_ABLATION
@@ -321,7 +323,9 @@ constexpr int kWavesPerBlock = 2;  // small workgroups pack the 160 KB LDS tight
 // one scalar per context instead of a 3x3 matrix.
 // QD: D is read as packed symmetric matrices (pre-assembled q-data) instead of being rebuilt from
 // the geometry factors: 6 (12) doubles per point instead of 11, and 9 (18) FMAs instead of ~60.
-template <int P1, int Q1, bool USE_U, bool USE_C, bool ISO, bool EVEC, bool QD>
+// DIRECT (only with EVEC && QD): entries flagged in `perm` are the only copy of their dof and are stored
+// straight into y.
+template <int P1, int Q1, bool USE_U, bool USE_C, bool ISO, bool EVEC, bool QD, bool DIRECT = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(const NDArgs<P1, Q1> a) {
   using L = NDLayout<P1, Q1>;
   constexpr int Q = Q1 * Q1 * Q1;
@@ -337,32 +341,38 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
 
   // Geometry (or packed q-data) of this lane's Q1 quadrature points: issue the loads now (the
   // dominant HBM stream) and consume them after the forward contraction.
+  // (Matrix-free D at Q1 >= 5 loads its geometry point by point inside the D loop instead: holding
+  // 50 doubles across the contraction made those instantiations spill hundreds of registers.)
   constexpr int NG = QD ? (USE_U ? 6 : 0) + (USE_C ? 6 : 0) : 10;
-  double gd[Q1][NG];
-  int attr[Q1];
+  constexpr bool LATE = !QD && Q1 >= 5;
+  double gd[LATE ? 1 : Q1][NG];
+  int attr[LATE ? 1 : Q1];
+  const double *glate = a.geom + (size_t)(active ? e : 0) * 11 * Q + ta + Q1 * tb;
   if (QD) {
     const double *g = a.qdata + (size_t)(active ? e : 0) * NG * Q + ta + Q1 * tb;
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
-      attr[qz] = 0;
+      constexpr int gs = LATE ? 0 : 1;
+      attr[gs * qz] = 0;
 #pragma unroll
       for (int c = 0; c < NG; c++) {
 #ifdef PA_ABLATION
         if (a.dbg & 4) {
-          gd[qz][c] = 1.0 + 0.01 * c + 1e-3 * lane;
+          gd[gs * qz][c] = 1.0 + 0.01 * c + 1e-3 * lane;
           continue;
         }
 #endif
-        gd[qz][c] = g[c * Q + Q1 * Q1 * qz];
+        gd[gs * qz][c] = g[c * Q + Q1 * Q1 * qz];
       }
     }
-  } else {
-    const double *g = a.geom + (size_t)(active ? e : 0) * 11 * Q + ta + Q1 * tb;
+  } else if (!LATE) {
+    const double *g = glate;
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
-      attr[qz] = (int)g[Q1 * Q1 * qz];
+      constexpr int gs = LATE ? 0 : 1;
+      attr[gs * qz] = (int)g[Q1 * Q1 * qz];
 #pragma unroll
-      for (int c = 0; c < 10; c++) gd[qz][c] = g[(1 + c) * Q + Q1 * Q1 * qz];
+      for (int c = 0; c < 10; c++) gd[gs * qz][c] = g[(1 + c) * Q + Q1 * Q1 * qz];
     }
   }
 
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
     lp[r] = 0;
     if (active && m < PP) {
       const int s = a.sidx_in[(size_t)e * PP + m];
-      lp[r] = a.perm[(size_t)e * PP + m];
+      lp[r] = a.perm[(size_t)e * PP + m];  // may carry kExclBit16 (used by the store below)
       const int d = s >= 0 ? s : -1 - s;
       // essential dofs are flagged in the gather index: read as zero (ParOperator's tx[ess] = 0)
 #ifdef PA_ABLATION
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
 #else
       const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
 #endif
-      sm[lp[r]] = s >= 0 ? xv : -xv;
+      sm[DIRECT ? (lp[r] & (kExclBit16 - 1)) : lp[r]] = s >= 0 ? xv : -xv;
     }
   }
   wave_sync();
@@ -411,34 +421,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   // D at the Q1 points of this lane's column (hcurl_33 / hdiv_33 / hdivmass_33)
 #pragma unroll
   for (int qz = 0; qz < Q1; qz++) {
+    constexpr int gq = LATE ? 0 : 1;  // index stride into the (pre)loaded geometry / q-data
     if (QD) {
-      if (USE_U) sym_mv(&gd[qz][0], U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
+      if (USE_U) sym_mv(&gd[gq * qz][0], U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
       if (USE_C)
-        sym_mv(&gd[qz][USE_U ? 6 : 0], CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
+        sym_mv(&gd[gq * qz][USE_U ? 6 : 0], CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
       continue;
     }
-    const double wdetJ = gd[qz][0];
-    const double *adj = &gd[qz][1];
+    if (LATE) {
+      attr[0] = (int)glate[Q1 * Q1 * qz];
+#pragma unroll
+      for (int c = 0; c < 10; c++) gd[0][c] = glate[(1 + c) * Q + Q1 * Q1 * qz];
+    }
+    const double wdetJ = gd[gq * qz][0];
+    const double *adj = &gd[gq * qz][1];
     if (ISO) {
       if (USE_U) {
-        const double c = a.c_mass.mat[9 * coeff_index(a.c_mass, attr[qz])];
+        const double c = a.c_mass.mat[9 * coeff_index(a.c_mass, attr[gq * qz])];
         mult_AtAx33(adj, U[0][qz], U[1][qz], U[2][qz], wdetJ * c, U[0][qz], U[1][qz], U[2][qz]);
       }
       if (USE_C) {
         double Jl[9];
-        const double c = a.c_curl.mat[9 * coeff_index(a.c_curl, attr[qz])];
+        const double c = a.c_curl.mat[9 * coeff_index(a.c_curl, attr[gq * qz])];
         adjJt33(adj, Jl);
         mult_AtAx33(Jl, CU[0][qz], CU[1][qz], CU[2][qz], wdetJ * c, CU[0][qz], CU[1][qz], CU[2][qz]);
       }
     } else {
       double Cm[9];
       if (USE_U) {
-        coeff_unpack3(a.c_mass, attr[qz], Cm);
+        coeff_unpack3(a.c_mass, attr[gq * qz], Cm);
         mult_AtBCx33(adj, Cm, adj, U[0][qz], U[1][qz], U[2][qz], wdetJ, U[0][qz], U[1][qz], U[2][qz]);
       }
       if (USE_C) {
         double Jl[9];
-        coeff_unpack3(a.c_curl, attr[qz], Cm);
+        coeff_unpack3(a.c_curl, attr[gq * qz], Cm);
         adjJt33(adj, Jl);
         mult_AtBCx33(Jl, Cm, Jl, CU[0][qz], CU[1][qz], CU[2][qz], wdetJ, CU[0][qz], CU[1][qz],
                      CU[2][qz]);
@@ -465,7 +481,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   for (int r = 0; r < NPL; r++) {
     const int m = t + L::T * r;
     if (active && m < PP) {
-      const double v = sm[lp[r]];
+      const double v = sm[DIRECT ? (lp[r] & (kExclBit16 - 1)) : lp[r]];
 #ifdef PA_ABLATION
       if (a.dbg & 1) {
         asm volatile("" ::"v"(v));
@@ -473,7 +489,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
       }
 #endif
       if (EVEC) {
-        a.ye[(size_t)e * PP + m] = v;
+        if (DIRECT && (lp[r] & kExclBit16)) {  // only copy of this dof: no E-vector round trip, no gather
+          const int s = a.sidx[(size_t)e * PP + m];
+          double *dst = &a.y[s >= 0 ? s : -1 - s];
+          const double sv = s >= 0 ? v : -v;
+          *dst = a.accumulate ? *dst + sv : sv;
+        } else {
+          a.ye[(size_t)e * PP + m] = v;
+        }
       } else {
         const int s = a.sidx[(size_t)e * PP + m];
         unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? v : -v);
@@ -489,11 +512,17 @@ static void fill_tab(const SubOp &so, NDTab<P1, Q1> &t) {
   for (int i = 0; i < QH * (P1 + 1); i++) t.Bc[i] = so.Bc[i], t.Gc[i] = so.Gc[i];
 }
 
+// The exclusive-dof store is used by the q-data kernels with Q1 <= 4 (the Q1 = 5 instantiations are
+// short of SGPRs as it is); the gather kernel must make the same choice.
+static bool use_direct(const SubOp &so) { return so.d_perm_x && so.d_shared && so.qd && so.q1d <= 4; }
+
 template <int P1, int Q1, bool U, bool C>
 static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   const bool evec = a.ye != nullptr;
   if (a.qdata) {
-    if (evec)
+    if (evec && a.direct && Q1 <= 4)
+      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false, true, true, (Q1 <= 4)>), grid, block, lds, s, a);
+    else if (evec)
       hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false, true, true>), grid, block, lds, s, a);
     else
       hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false, false, true>), grid, block, lds, s, a);
@@ -508,13 +537,16 @@ static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block,
 }
 
 template <int P1, int Q1>
-static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s) {
+static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
+                      bool accumulate) {
   using L = NDLayout<P1, Q1>;
   NDArgs<P1, Q1> a;
   a.ne = so.ne;
   a.sidx = so.d_sidx;
   a.sidx_in = (masked && so.d_sidx_bc) ? so.d_sidx_bc : so.d_sidx;
-  a.perm = so.d_perm;
+  a.direct = (ye != nullptr && use_direct(so)) ? 1 : 0;
+  a.perm = a.direct ? so.d_perm_x : so.d_perm;
+  a.accumulate = accumulate ? 1 : 0;
   a.geom = so.geom->d_geom;
   a.qdata = so.qd ? so.qd->d : nullptr;
   a.x = x;
@@ -566,17 +598,20 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
 
 // ye != nullptr: write the element-local results (E-vector) instead of scattering atomically into y
 // masked: gather through the essential-dof-flagged index array (pa_op_set_essential)
-void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s) {
-  PA_ND_DISPATCH(launch_pq, so, x, y, ye, masked, s)
+void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
+                         bool accumulate) {
+  PA_ND_DISPATCH(launch_pq, so, x, y, ye, masked, s, accumulate)
 }
 
 // ---- E^T as a gather: y_d (+)= sum over the element-local copies of dof d -----------------------
 // tptr/tent: transpose of the signed tensor-order index array (CSR by L-dof); entry t >= 0 reads
 // ye[t], t < 0 reads -ye[-1-t].  One thread per dof, fixed summation order => reproducible.
 __global__ void et_gather_kernel(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
-                                 const double *__restrict__ ye, double *__restrict__ y, const int accumulate) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= n) return;
+                                 const double *__restrict__ ye, double *__restrict__ y, const int accumulate,
+                                 const int32_t *__restrict__ list) {
+  const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k0 >= n) return;
+  const int d = list ? list[k0] : k0;  // list: only the dofs with more than one copy
   const int b = tptr[d], e = tptr[d + 1];
   double s = 0.0;
   int k = b;
@@ -606,15 +641,19 @@ __global__ void et_gather_kernel(const int n, const int32_t *__restrict__ tptr, 
 }
 
 void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y,
-                          bool accumulate, hipStream_t s) {
+                          bool accumulate, hipStream_t s, const int32_t *list) {
   const int bs = 256;
+  if (n == 0) return;
   hipLaunchKernelGGL(et_gather_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, tptr, tent, ye, y,
-                     accumulate ? 1 : 0);
+                     accumulate ? 1 : 0, list);
   PA_HIP(hipGetLastError());
 }
 
 void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s) {
-  launch_et_gather_raw(so.lsize, so.d_tptr, so.d_tent, so.d_ye, y, accumulate, s);
+  if (use_direct(so))  // the element kernel stored the exclusive dofs itself
+    launch_et_gather_raw(so.n_shared, so.d_tptr, so.d_tent, so.d_ye, y, accumulate, s, so.d_shared);
+  else
+    launch_et_gather_raw(so.lsize, so.d_tptr, so.d_tent, so.d_ye, y, accumulate, s);
 }
 
 // ---- packed symmetric q-data (set-up) -----------------------------------------------------------
