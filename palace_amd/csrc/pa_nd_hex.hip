@@ -31,23 +31,40 @@ namespace pa {
 // Only the first (Q1+1)/2 rows travel as kernel arguments, so every entry stays in an SGPR for the
 // whole kernel (p = 3: 22 doubles instead of 44) and nothing is spilled.  pa_op_add_sub verifies
 // the symmetry of the tables it is given.
+// For odd Q1 the middle row is its own mirror image, so only its first half is kept as well
+// (p = 4: 35 doubles instead of 42 -- the Q1 = 5 instantiations are the ones short of SGPRs).
+template <int N, int Q1>
+struct HalfTab {
+  static constexpr int QH = (Q1 + 1) / 2;
+  static constexpr int LEN = (Q1 & 1) ? (QH - 1) * N + (N + 1) / 2 : QH * N;
+};
 template <int P1, int Q1>
 struct NDTab {
   static constexpr int QH = (Q1 + 1) / 2;
-  double Bo[QH * P1];
-  double Bc[QH * (P1 + 1)];
-  double Gc[QH * (P1 + 1)];
+  double Bo[HalfTab<P1, Q1>::LEN];
+  double Bc[HalfTab<P1 + 1, Q1>::LEN];
+  double Gc[HalfTab<P1 + 1, Q1>::LEN];
 };
 
 // value-type (even symmetry) and derivative-type (odd symmetry) table access; q and i are
 // compile-time constants after unrolling
 template <int N, int Q1>
 __device__ __forceinline__ double tab_even(const double *H, const int q, const int i) {
-  return (q < (Q1 + 1) / 2) ? H[q * N + i] : H[(Q1 - 1 - q) * N + (N - 1 - i)];
+  constexpr int QH = (Q1 + 1) / 2;
+  const int qq = (q < QH) ? q : Q1 - 1 - q, ii = (q < QH) ? i : N - 1 - i;
+  if ((Q1 & 1) && qq == QH - 1) return H[(QH - 1) * N + (ii < (N + 1) / 2 ? ii : N - 1 - ii)];
+  return H[qq * N + ii];
 }
 template <int N, int Q1>
 __device__ __forceinline__ double tab_odd(const double *H, const int q, const int i) {
-  return (q < (Q1 + 1) / 2) ? H[q * N + i] : -H[(Q1 - 1 - q) * N + (N - 1 - i)];
+  constexpr int QH = (Q1 + 1) / 2;
+  const int qq = (q < QH) ? q : Q1 - 1 - q, ii = (q < QH) ? i : N - 1 - i;
+  const double sg = (q < QH) ? 1.0 : -1.0;
+  if ((Q1 & 1) && qq == QH - 1) {  // middle row: antisymmetric in i, centre entry zero
+    if ((N & 1) && ii == N / 2) return 0.0;
+    return (ii < N / 2) ? sg * H[(QH - 1) * N + ii] : -sg * H[(QH - 1) * N + (N - 1 - ii)];
+  }
+  return sg * H[qq * N + ii];
 }
 
 template <int P1, int Q1>
@@ -507,9 +524,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
 
 template <int P1, int Q1>
 static void fill_tab(const SubOp &so, NDTab<P1, Q1> &t) {
-  constexpr int QH = NDTab<P1, Q1>::QH;
-  for (int i = 0; i < QH * P1; i++) t.Bo[i] = so.Bo[i];
-  for (int i = 0; i < QH * (P1 + 1); i++) t.Bc[i] = so.Bc[i], t.Gc[i] = so.Gc[i];
+  // the kept entries are a prefix of the full row-major tables
+  for (int i = 0; i < HalfTab<P1, Q1>::LEN; i++) t.Bo[i] = so.Bo[i];
+  for (int i = 0; i < HalfTab<P1 + 1, Q1>::LEN; i++) t.Bc[i] = so.Bc[i], t.Gc[i] = so.Gc[i];
 }
 
 // The exclusive-dof store is used by the q-data kernels with Q1 <= 4 (the Q1 = 5 instantiations are
