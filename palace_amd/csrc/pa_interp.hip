@@ -25,6 +25,7 @@ struct InterpArgs {
   const double *x;
   double *y;      // forward: fine L-vector (owner copies store, no atomics)
   double *ye_c;   // transpose: coarse E-vector [ne][Pc], summed per dof by k_gather
+  double Ic_s[25], Io_s[20];  // Ic / Io by value for the specialised kernels (pf <= 4): scalar operands
 };
 
 // Every fine dof is shared by several elements that all compute the same interpolated value (the
@@ -189,6 +190,155 @@ __global__ __launch_bounds__(256) void interp_kernel(const InterpArgs a) {
   } else {
     interp_block<TRANSPOSE>(a, e, active, lane_ok, ta, tb, sm, false, 0, 0, ncc * ncc * ncc, nfc * nfc * nfc, ncc, ncc,
                             ncc, nfc, nfc, nfc, a.Ic, a.Ic, a.Ic);
+  }
+}
+
+// ---- specialised forms (orders known at compile time, pf <= 4): loops unrolled, line data in registers,
+// 1-D matrices as scalar operands.  Same passes and the same owner-copy semantics as above.
+template <bool TRANSPOSE, int NC0, int NC1, int NC2, int NF0, int NF1, int NF2, int N1>
+__device__ __forceinline__ void interp_block_s(const InterpArgs &a, const int e, const bool active, const bool lane_ok,
+                                               const int ta, const int tb, double *sm, const bool accumulate,
+                                               const int off_c, const int off_f, const int Pc, const int Pf,
+                                               const double *M0, const double *M1, const double *M2) {
+  double *sA = sm, *sB = sm + N1 * N1 * N1;
+  if (!TRANSPOSE) {
+    {
+      const bool act = ta < NC1 && tb < NC2;
+      double u[NC0];
+#pragma unroll
+      for (int i = 0; i < NC0; i++) {
+        double v = 0.0;
+        if (active && act) {
+          const int s = a.lidx_c[(size_t)e * Pc + off_c + i + NC0 * (ta + NC1 * tb)];
+          const double xv = a.x[s >= 0 ? s : -1 - s];
+          v = s >= 0 ? xv : -xv;
+        }
+        u[i] = v;
+      }
+#pragma unroll
+      for (int fi = 0; fi < NF0; fi++) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < NC0; i++) v += M0[fi * NC0 + i] * u[i];
+        if (lane_ok && act) sA[(fi * NC1 + ta) * NC2 + tb] = v;
+      }
+    }
+    wsync();
+    {
+      const bool act = ta < NF0 && tb < NC2;
+      double u[NC1];
+#pragma unroll
+      for (int j = 0; j < NC1; j++) u[j] = sA[((act ? ta : 0) * NC1 + j) * NC2 + (act ? tb : 0)];
+#pragma unroll
+      for (int fj = 0; fj < NF1; fj++) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < NC1; j++) v += M1[fj * NC1 + j] * u[j];
+        if (lane_ok && act) sB[(ta * NF1 + fj) * NC2 + tb] = v;
+      }
+    }
+    wsync();
+    {
+      const bool act = ta < NF0 && tb < NF1;
+      double u[NC2];
+#pragma unroll
+      for (int k = 0; k < NC2; k++) u[k] = sB[((act ? ta : 0) * NF1 + (act ? tb : 0)) * NC2 + k];
+#pragma unroll
+      for (int fk = 0; fk < NF2; fk++) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < NC2; k++) v += M2[fk * NC2 + k] * u[k];
+        if (active && act) {
+          const int s = a.lidx_f[(size_t)e * Pf + off_f + ta + NF0 * (tb + NF1 * fk)];
+          const int g = s >= 0 ? s : -1 - s;
+          if (g & kOwnBit) a.y[g & ~kOwnBit] = s >= 0 ? v : -v;
+        }
+      }
+    }
+    wsync();
+  } else {
+    {
+      const bool act = ta < NF0 && tb < NF1;
+      double u[NF2];
+#pragma unroll
+      for (int fk = 0; fk < NF2; fk++) {
+        double v = 0.0;
+        if (active && act) {
+          const int s = a.lidx_f[(size_t)e * Pf + off_f + ta + NF0 * (tb + NF1 * fk)];
+          const int g = s >= 0 ? s : -1 - s;
+          const double xv = (g & kOwnBit) ? a.x[g & ~kOwnBit] : 0.0;
+          v = s >= 0 ? xv : -xv;
+        }
+        u[fk] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < NC2; k++) {
+        double v = 0.0;
+#pragma unroll
+        for (int fk = 0; fk < NF2; fk++) v += M2[fk * NC2 + k] * u[fk];
+        if (lane_ok && act) sB[(ta * NF1 + tb) * NC2 + k] = v;
+      }
+    }
+    wsync();
+    {
+      const bool act = ta < NF0 && tb < NC2;
+      double u[NF1];
+#pragma unroll
+      for (int fj = 0; fj < NF1; fj++) u[fj] = sB[((act ? ta : 0) * NF1 + fj) * NC2 + (act ? tb : 0)];
+#pragma unroll
+      for (int j = 0; j < NC1; j++) {
+        double v = 0.0;
+#pragma unroll
+        for (int fj = 0; fj < NF1; fj++) v += M1[fj * NC1 + j] * u[fj];
+        if (lane_ok && act) sA[(ta * NC1 + j) * NC2 + tb] = v;
+      }
+    }
+    wsync();
+    {
+      const bool act = ta < NC1 && tb < NC2;
+      double u[NF0];
+#pragma unroll
+      for (int fi = 0; fi < NF0; fi++) u[fi] = sA[(fi * NC1 + (act ? ta : 0)) * NC2 + (act ? tb : 0)];
+#pragma unroll
+      for (int i = 0; i < NC0; i++) {
+        double v = 0.0;
+#pragma unroll
+        for (int fi = 0; fi < NF0; fi++) v += M0[fi * NC0 + i] * u[fi];
+        if (active && act) {
+          double *dst = &a.ye_c[(size_t)e * Pc + off_c + i + NC0 * (ta + NC1 * tb)];
+          *dst = accumulate ? *dst + v : v;
+        }
+      }
+    }
+    wsync();
+  }
+}
+
+// KIND 0: ND prolongation, 1: discrete gradient H1(PF) -> ND(PF), 2: H1 prolongation
+template <bool TRANSPOSE, int KIND, int PC, int PF>
+__global__ __launch_bounds__(256) void interp_kernel_s(const InterpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int N1 = PF + 1, T = N1 * N1, EPW = 64 / T, NCC = PC + 1, NFC = PF + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / T, t = lane - sub * T;
+  const int ta = t % N1, tb = t / N1;
+  const bool lane_ok = sub < EPW;
+  const int e = (blockIdx.x * 4 + wave) * EPW + sub;
+  const bool active = lane_ok && e < a.ne;
+  double *sm = smem + (size_t)(wave * EPW + (lane_ok ? sub : 0)) * (2 * N1 * N1 * N1);
+  const double *Ic = a.Ic_s, *Io = a.Io_s;
+  if (KIND == 1) {
+    constexpr int Pc = NFC * NFC * NFC, Pf = 3 * PF * NFC * NFC;
+    interp_block_s<TRANSPOSE, NFC, NFC, NFC, PF, NFC, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, false, 0, 0, Pc, Pf, Io, Ic, Ic);
+    interp_block_s<TRANSPOSE, NFC, NFC, NFC, NFC, PF, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, true, 0, PF * NFC * NFC, Pc, Pf, Ic, Io, Ic);
+    interp_block_s<TRANSPOSE, NFC, NFC, NFC, NFC, NFC, PF, N1>(a, e, active, lane_ok, ta, tb, sm, true, 0, 2 * PF * NFC * NFC, Pc, Pf, Ic, Ic, Io);
+  } else if (KIND == 0) {
+    constexpr int Pc = 3 * PC * NCC * NCC, Pf = 3 * PF * NFC * NFC;
+    interp_block_s<TRANSPOSE, PC, NCC, NCC, PF, NFC, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, false, 0, 0, Pc, Pf, Io, Ic, Ic);
+    interp_block_s<TRANSPOSE, NCC, PC, NCC, NFC, PF, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, false, PC * NCC * NCC, PF * NFC * NFC, Pc, Pf, Ic, Io, Ic);
+    interp_block_s<TRANSPOSE, NCC, NCC, PC, NFC, NFC, PF, N1>(a, e, active, lane_ok, ta, tb, sm, false, 2 * PC * NCC * NCC, 2 * PF * NFC * NFC, Pc, Pf, Ic, Ic, Io);
+  } else {
+    interp_block_s<TRANSPOSE, NCC, NCC, NCC, NFC, NFC, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, false, 0, 0, NCC * NCC * NCC, NFC * NFC * NFC, Ic, Ic, Ic);
   }
 }
 
@@ -442,14 +592,36 @@ class InterpOperator : public Operator {
   int32_t *d_lidx_c_ = nullptr, *d_lidx_f_ = nullptr;
   double *d_Ic_ = nullptr, *d_Io_ = nullptr, *d_ye_c_ = nullptr;
   int32_t *d_tptr_c_ = nullptr, *d_tent_c_ = nullptr;
+  std::vector<double> h_Ic_, h_Io_;
   mutable Vector lc_, lf_;
 
   template <bool TR>
   void launch(const double *x, double *y) const {
-    InterpArgs a{kind_, ne_, fe_type_, pc_, pf_, d_lidx_c_, d_lidx_f_, d_Ic_, d_Io_, x, y, d_ye_c_};
+    InterpArgs a{kind_, ne_, fe_type_, pc_, pf_, d_lidx_c_, d_lidx_f_, d_Ic_, d_Io_, x, y, d_ye_c_, {}, {}};
     const int n1 = pf_ + 1, epw = 64 / (n1 * n1), epb = 4 * epw;
     const size_t lds = sizeof(double) * (size_t)epb * 2 * n1 * n1 * n1;
-    hipLaunchKernelGGL((interp_kernel<TR>), dim3((ne_ + epb - 1) / epb), dim3(256), lds, ctx_->stream, a);
+    const dim3 grid((ne_ + epb - 1) / epb), block(256);
+    bool done = false;
+    if (pf_ <= 4 && h_Ic_.size() <= 25 && h_Io_.size() <= 20) {
+      for (size_t i = 0; i < h_Ic_.size(); i++) a.Ic_s[i] = h_Ic_[i];
+      for (size_t i = 0; i < h_Io_.size(); i++) a.Io_s[i] = h_Io_[i];
+      const int k = kind_ == 1 ? 1 : (fe_type_ == PA_FE_HCURL ? 0 : 2);
+      done = true;
+#define PA_INTERP_CASE(K, PC, PF)                                                                      \
+  case (K) * 100 + (PC) * 10 + (PF):                                                                     \
+    hipLaunchKernelGGL((interp_kernel_s<TR, K, PC, PF>), grid, block, lds, ctx_->stream, a);             \
+    break;
+      switch (k * 100 + pc_ * 10 + pf_) {
+        PA_INTERP_CASE(0, 1, 2) PA_INTERP_CASE(0, 1, 3) PA_INTERP_CASE(0, 2, 3) PA_INTERP_CASE(0, 1, 4)
+        PA_INTERP_CASE(0, 2, 4) PA_INTERP_CASE(0, 3, 4)
+        PA_INTERP_CASE(2, 1, 2) PA_INTERP_CASE(2, 1, 3) PA_INTERP_CASE(2, 2, 3) PA_INTERP_CASE(2, 1, 4)
+        PA_INTERP_CASE(2, 2, 4) PA_INTERP_CASE(2, 3, 4)
+        PA_INTERP_CASE(1, 1, 1) PA_INTERP_CASE(1, 2, 2) PA_INTERP_CASE(1, 3, 3) PA_INTERP_CASE(1, 4, 4)
+        default: done = false;
+      }
+#undef PA_INTERP_CASE
+    }
+    if (!done) hipLaunchKernelGGL((interp_kernel<TR>), grid, block, lds, ctx_->stream, a);
     PA_HIP(hipGetLastError());
   }
 
@@ -502,7 +674,12 @@ public:
     d_lidx_c_ = pa::dev_upload(lc.data(), lc.size(), ctx.stream);
     d_lidx_f_ = pa::dev_upload(lf.data(), lf.size(), ctx.stream);
     d_Ic_ = pa::dev_upload(Ic, (size_t)(pf_ + 1) * (pc_ + 1), ctx.stream);
-    if (Io) d_Io_ = pa::dev_upload(Io, kind == 1 ? (size_t)pf_ * (pf_ + 1) : (size_t)pf_ * pc_, ctx.stream);
+    h_Ic_.assign(Ic, Ic + (size_t)(pf_ + 1) * (pc_ + 1));
+    if (Io) {
+      const size_t nio = kind == 1 ? (size_t)pf_ * (pf_ + 1) : (size_t)pf_ * pc_;
+      d_Io_ = pa::dev_upload(Io, nio, ctx.stream);
+      h_Io_.assign(Io, Io + nio);
+    }
     lc_.SetSize(nl_c_), lf_.SetSize(nl_f_);
   }
   ~InterpOperator() override {
