@@ -48,7 +48,10 @@ enum pa_qfunction {
   /* 2-D (space_dim = dim = 2; dense-table path only), fem/integ/curlcurl.cpp:40-47,65-68 */
   PA_QF_HCURL_22 = 5,     /* f_apply_hcurl_22     fem/qfunctions/22/hcurl_22_qf.h:10-30     ND mass          */
   PA_QF_L2_1 = 6,         /* f_apply_l2_1         fem/qfunctions/1/l2_1_qf.h:10-24          curl-curl (scalar curl, q_w input) */
-  PA_QF_HDIVMASS_22 = 7   /* f_apply_hdivmass_22  fem/qfunctions/22/hdivmass_22_qf.h:11-37  curl-curl + mass */
+  PA_QF_HDIVMASS_22 = 7,  /* f_apply_hdivmass_22  fem/qfunctions/22/hdivmass_22_qf.h:11-37  curl-curl + mass */
+  /* boundary elements (dim = 2 in space_dim = 3; dense-table path only) */
+  PA_QF_HCURL_32 = 8      /* f_apply_hcurl_32     fem/qfunctions/32/hcurl_32_qf.h:10-30     ND surface mass (impedance,
+                             absorbing and lumped-port boundary terms) */
 };
 
 enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1 };
@@ -167,6 +170,10 @@ typedef struct {
    * mesh_grad is [2][Q][npe] and the geometry data has 6 rows {attr, w detJ, adj(J)^T/detJ}
    * (fem/qfunctions/22/geom_22_qf.h:9-30). */
   int32_t dim;
+  /* space dimension when it differs from the element dimension: 3 with dim = 2 for boundary elements
+   * (nodes [num_nodes][3], 8 geometry rows {attr, w detJ, adj(J)^T/detJ (3x2)}, geom_32_qf.h:9-33);
+   * 0 = same as dim. */
+  int32_t space_dim;
 } pa_mesh_dense_desc;
 
 /* --- library ------------------------------------------------------------------------------- */
@@ -184,6 +191,8 @@ int pa_geom_create(const pa_mesh_desc *mesh, void *stream, pa_geom **geom);
  * ((e/16 * 11 + c) * Qpad + q) * 16 + e%16; pa_geom_layout reports {ne, Q, Qpad, block}. */
 int pa_geom_create_dense(const pa_mesh_dense_desc *mesh, void *stream, pa_geom **geom);
 int pa_geom_layout(const pa_geom *geom, int32_t out[4]);
+/* Rows of geometry data per point: 11 (3-D), 6 (2-D), 8 (2-D elements in 3-D space). */
+int pa_geom_num_rows(const pa_geom *geom);
 int pa_geom_retain(pa_geom *geom);
 void pa_geom_destroy(pa_geom *geom);
 /* Device pointer to the geometry data and its length in doubles (tests / diagnostics). */

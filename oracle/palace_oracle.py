@@ -369,10 +369,43 @@ def apply_hdivmass_22(ctx_mass, ctx_curl, geom, qw, u, curlu):
     return apply_hcurl_22(ctx_mass, geom, u), apply_l2_1(ctx_curl, geom, qw, curlu)
 
 
+# ---- boundary elements (dim = 2 in space_dim = 3): fem/qfunctions/32/*.h --------------------------------
+
+def build_geom_factor_32(attr, qw, J):
+    """geom_32_qf.h:9-33, utils_32_qf.h:23-40.  J [NE, Q, 6] column-major 3x2 (J: 0 3 / 1 4 / 2 5).
+    Returns geom [NE, 8, Q]: attr, w detJ (detJ = sqrt(EG - F^2)), adj(J)^T / detJ (3x2)."""
+    E = J[..., 0] ** 2 + J[..., 1] ** 2 + J[..., 2] ** 2
+    G = J[..., 3] ** 2 + J[..., 4] ** 2 + J[..., 5] ** 2
+    F = J[..., 0] * J[..., 3] + J[..., 1] * J[..., 4] + J[..., 2] * J[..., 5]
+    d = np.sqrt(E * G - F * F)
+    NE, Q = d.shape
+    geom = np.empty((NE, 8, Q))
+    geom[:, 0, :] = attr[:, None]
+    geom[:, 1, :] = qw[None, :] * d
+    for k in range(3):
+        geom[:, 2 + k, :] = (G * J[..., k] - F * J[..., 3 + k]) / d / d
+        geom[:, 5 + k, :] = (E * J[..., 3 + k] - F * J[..., k]) / d / d
+    return geom
+
+
+def apply_hcurl_32(ctx, geom, u):
+    """hcurl_32_qf.h:10-30: v = w detJ A^T C A u, A = adjJt (3x2), C 3x3 (utils_32_qf.h:53-72)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    wdetJ = geom[:, 1, :]
+    A = [geom[:, 2 + k, :] for k in range(6)]
+    C = ctx.unpack3(attr)
+    x0, x1 = u[:, 0, :], u[:, 1, :]
+    y = [A[0] * x0 + A[3] * x1, A[1] * x0 + A[4] * x1, A[2] * x0 + A[5] * x1]
+    z = [C[..., 0 + r] * y[0] + C[..., 3 + r] * y[1] + C[..., 6 + r] * y[2] for r in range(3)]
+    return np.stack([wdetJ * (A[0] * z[0] + A[1] * z[1] + A[2] * z[2]),
+                     wdetJ * (A[3] * z[0] + A[4] * z[1] + A[5] * z[2])], axis=1)
+
+
 # ---------------------------------------------------------------------------------------------
 # Operator: E, B, D, B^T, E^T
 # ---------------------------------------------------------------------------------------------
 
+QF_HCURL_32 = "hcurl_32"
 QF_HDIV, QF_HCURL, QF_HDIVMASS, QF_HCURLMASS, QF_H1MASS = "hdiv_33", "hcurl_33", "hdivmass_33", "hcurlmass_33", "h1_1"
 QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22 = "hcurl_22", "l2_1", "hdivmass_22"
 
@@ -397,7 +430,7 @@ class CeedOperatorOracle:
         assert self.sgn is None or self.cor is None
         self.Q = geom.shape[2]
         self.vector_fe = vector_fe
-        dim = 2 if geom.shape[1] == 6 else 3
+        dim = 2 if geom.shape[1] in (6, 8) else 3  # 6 rows: 2-D; 8 rows: boundary elements (2 in 3)
         if vector_fe:
             self.interp = np.asarray(interp).reshape(dim, self.Q, self.P)
         else:
@@ -433,6 +466,9 @@ class CeedOperatorOracle:
         if qf == QF_L2_1:      # 2-D curl-curl
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
             return np.einsum("dqj,edq->ej", self.deriv, apply_l2_1(self.ctx, geom, self.qw, cu))
+        if qf == QF_HCURL_32:  # boundary ND mass (surface impedance / absorbing / lumped-port terms)
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            return np.einsum("dqj,edq->ej", self.interp, apply_hcurl_32(self.ctx, geom, u))
         if qf == QF_HCURL_22:  # 2-D ND mass
             u = np.einsum("dqj,ej->edq", self.interp, ue)
             return np.einsum("dqj,edq->ej", self.interp, apply_hcurl_22(self.ctx, geom, u))

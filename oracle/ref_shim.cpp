@@ -18,3 +18,5 @@ typedef double CeedScalar;
 #include "fem/qfunctions/22/hcurl_22_qf.h"
 #include "fem/qfunctions/22/hdivmass_22_qf.h"
 #include "fem/qfunctions/1/l2_1_qf.h"
+#include "fem/qfunctions/32/geom_32_qf.h"
+#include "fem/qfunctions/32/hcurl_32_qf.h"

@@ -19,7 +19,7 @@ from .fem.basis1d import Tables1D
 from .fem.fespace import H1HexSpace, NDHexSpace
 from .fem.mesh import HexMesh, _q2_1d
 
-QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1, QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22 = range(8)
+QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1, QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22, QF_HCURL_32 = range(9)
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
 FE_H1, FE_HCURL = 0, 1
 
@@ -114,16 +114,17 @@ class DenseGeomFactorData:
     def __init__(self, elem_nodes, nodes, attr, mesh_grad, qweight):
         self.ne, self.npe = elem_nodes.shape
         self.Q = len(qweight)
-        self.dim = int(np.asarray(mesh_grad).shape[0])  # 3, or 2 for the reference's 2-D cases (6 geometry rows)
+        self.dim = int(np.asarray(mesh_grad).shape[0])  # element dimension: 3, or 2 (2-D cases, boundary elements)
+        self.space_dim = int(np.asarray(nodes).shape[1])  # 3 with dim 2: boundary elements (8 geometry rows)
         self._keep = dict(off=np.ascontiguousarray(elem_nodes, dtype=np.int32),
                           nodes=np.ascontiguousarray(nodes, dtype=np.float64),
                           attr=np.ascontiguousarray(attr, dtype=np.int32),
                           grad=np.ascontiguousarray(mesh_grad, dtype=np.float64),
                           w=np.ascontiguousarray(qweight, dtype=np.float64))
         k = self._keep
-        assert k["grad"].shape == (self.dim, self.Q, self.npe) and k["nodes"].shape[1] == self.dim
+        assert k["grad"].shape == (self.dim, self.Q, self.npe)
         desc = _lib.MeshDenseDesc(self.ne, self.npe, self.Q, k["nodes"].shape[0], _ptr(k["off"]), _ptr(k["nodes"]),
-                                  _ptr(k["attr"]), _ptr(k["grad"]), _ptr(k["w"]), self.dim)
+                                  _ptr(k["attr"]), _ptr(k["grad"]), _ptr(k["w"]), self.dim, self.space_dim)
         self.handle = C.c_void_p()
         _lib.check(_lib.load().pa_geom_create_dense(C.byref(desc), _stream(), C.byref(self.handle)))
 
@@ -137,8 +138,7 @@ class DenseGeomFactorData:
         lay = (C.c_int32 * 4)()
         _lib.check(L.pa_geom_layout(self.handle, lay))
         ne, Q, Qpad, eb = list(lay)
-        rows = 6 if eb < 0 else 11
-        eb = abs(eb)
+        rows = L.pa_geom_num_rows(self.handle)
 
         class _View:
             __cuda_array_interface__ = dict(shape=(n.value,), typestr="<f8", data=(p.value, False), version=2)

@@ -441,9 +441,10 @@ int pa_geom_layout(const pa_geom *geom, int32_t out[4]) {
   return guarded([&] {
     PA_REQUIRE(geom && out, "null argument");
     out[0] = geom->ne, out[1] = geom->Q, out[2] = geom->eb ? geom->Qpad : geom->Q, out[3] = geom->eb;
-    if (geom->dim == 2) out[3] = -geom->eb;  // 2-D block: 6 rows instead of 11
   });
 }
+
+int pa_geom_num_rows(const pa_geom *geom) { return geom ? geom->nrows : -1; }
 
 int pa_geom_retain(pa_geom *geom) {
   return guarded([&] {

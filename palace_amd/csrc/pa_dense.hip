@@ -61,7 +61,11 @@ struct ModeTraits {
   static constexpr int NCT = NCI + NCD;
 };
 
-int mode_of(int fe_type, int qf, int dim) {
+int mode_of(int fe_type, int qf, int dim, int sdim) {
+  if (dim == 2 && sdim == 3) {
+    if (fe_type == PA_FE_HCURL && qf == PA_QF_HCURL_32) return MODE_VMASS2;  // same apply, D from the 3x2 geometry
+    throw Error("QFunction does not match an H(curl) boundary element");
+  }
   if (dim == 2) {
     if (fe_type == PA_FE_HCURL && qf == PA_QF_L2_1) return MODE_CURL2;
     if (fe_type == PA_FE_HCURL && qf == PA_QF_HCURL_22) return MODE_VMASS2;
@@ -803,6 +807,64 @@ __global__ void geom_dense2_kernel(const int ne, const int Q, const int Qpad, co
   g[2 * cs] = J[3] / det, g[3 * cs] = -J[2] / det, g[4 * cs] = -J[1] / det, g[5 * cs] = J[0] / det;
 }
 
+// fem/qfunctions/32/geom_32_qf.h:9-33 with utils_32_qf.h:23-40: J is 3x2, detJ = sqrt(E G - F^2)
+__global__ void geom_dense32_kernel(const int ne, const int Q, const int Qpad, const int npe,
+                                    const int32_t *__restrict__ node_off, const double *__restrict__ nodes,
+                                    const int32_t *__restrict__ attr, const double *__restrict__ grad,
+                                    const double *__restrict__ w, double *__restrict__ geom) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / Q);
+  if (e >= ne) return;
+  const int q = (int)(gid - (long long)e * Q);
+  double J[6] = {0, 0, 0, 0, 0, 0};
+  for (int n = 0; n < npe; n++) {
+    const int id = node_off[(size_t)e * npe + n];
+    const double d0 = grad[((size_t)0 * Q + q) * npe + n], d1 = grad[((size_t)1 * Q + q) * npe + n];
+    for (int c = 0; c < 3; c++) {
+      const double X = nodes[3 * (size_t)id + c];
+      J[c + 0] += X * d0;
+      J[c + 3] += X * d1;
+    }
+  }
+  const double E = J[0] * J[0] + J[1] * J[1] + J[2] * J[2], G = J[3] * J[3] + J[4] * J[4] + J[5] * J[5];
+  const double F = J[0] * J[3] + J[1] * J[4] + J[2] * J[5];
+  const double d = sqrt(E * G - F * F);
+  double *g = geom + ((size_t)(e / kEB) * 8 * Qpad + q) * kEB + (e % kEB);
+  const size_t cs = (size_t)Qpad * kEB;
+  g[0] = (double)attr[e];
+  g[cs] = w[q] * d;
+  for (int k = 0; k < 3; k++) {
+    g[(2 + k) * cs] = (G * J[k] - F * J[3 + k]) / d / d;
+    g[(5 + k) * cs] = (E * J[3 + k] - F * J[k]) / d / d;
+  }
+}
+
+// packed 2x2 D of the boundary mass: w detJ A^T C A with A = adjJt (3x2), C 3x3 (hcurl_32_qf.h:10-30,
+// MultAtBCx32 utils_32_qf.h:53-72)
+__global__ void dense_qdata32_kernel(const DenseArgs a, double *__restrict__ qd) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / a.Q);
+  if (e >= a.ne) return;
+  const int q = (int)(gid - (long long)e * a.Q);
+  const size_t cs = (size_t)a.Qpad * kEB, os = (size_t)a.Q4 * kEB;
+  const double *g = a.geom + ((size_t)(e / kEB) * 8 * a.Qpad + q) * kEB + (e % kEB);
+  double *out = qd + ((size_t)(e / kEB) * a.ncq * a.Q4 + q) * kEB + (e % kEB);
+  const int attr = (int)g[0];
+  const double wdetJ = g[cs];
+  double A[6], C[9], Mx[4];
+  for (int k = 0; k < 6; k++) A[k] = g[(2 + k) * cs];
+  coeff_unpack3(a.c0, attr, C);
+  for (int col = 0; col < 2; col++) {
+    const double x0 = col == 0 ? 1.0 : 0.0, x1 = col == 1 ? 1.0 : 0.0;
+    const double y0 = A[0] * x0 + A[3] * x1, y1 = A[1] * x0 + A[4] * x1, t = A[2] * x0 + A[5] * x1;
+    const double z0 = C[0] * y0 + C[3] * y1 + C[6] * t, z1 = C[1] * y0 + C[4] * y1 + C[7] * t,
+                 z2 = C[2] * y0 + C[5] * y1 + C[8] * t;
+    Mx[0 + 2 * col] = wdetJ * (A[0] * z0 + A[1] * z1 + A[2] * z2);
+    Mx[1 + 2 * col] = wdetJ * (A[3] * z0 + A[4] * z1 + A[5] * z2);
+  }
+  out[0] = Mx[0], out[os] = 0.5 * (Mx[1] + Mx[2]), out[2 * os] = Mx[3];
+}
+
 // ---- diagonal (set-up): one thread per (element, local dof) --------------------------------------
 // CeedOperatorLinearAssembleAddDiagonal [libCEED, external]: element diagonals d_e[j] = sum_q b_j^T D b_j
 // pushed through the transpose of the UNSIGNED restriction (for the curl-oriented one: |T|^T d_e).
@@ -858,26 +920,31 @@ DenseArgs make_args(const DenseSub &ds) {
 void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
   const int ne = mesh.num_elem, npe = mesh.nodes_per_elem, Q = mesh.num_qpts;
   const int dim = mesh.dim == 0 ? 3 : mesh.dim;
-  PA_REQUIRE(dim == 2 || dim == 3, "space dimension must be 2 or 3");
+  const int sdim = mesh.space_dim == 0 ? dim : mesh.space_dim;
+  PA_REQUIRE(dim == 2 || dim == 3, "element dimension must be 2 or 3");
+  PA_REQUIRE(sdim == dim || (dim == 2 && sdim == 3), "space dimension must equal the element dimension, or be 3 for 2-D elements");
   PA_REQUIRE(ne > 0 && npe > 0 && Q > 0 && mesh.num_nodes > 0, "empty mesh description");
   PA_REQUIRE(mesh.node_offsets && mesh.nodes && mesh.attr && mesh.mesh_grad && mesh.qweight, "null mesh array");
   for (size_t i = 0; i < (size_t)ne * npe; i++)
     PA_REQUIRE(mesh.node_offsets[i] >= 0 && mesh.node_offsets[i] < mesh.num_nodes, "mesh node id out of range");
   for (int e = 0; e < ne; e++) PA_REQUIRE(mesh.attr[e] >= 1, "element attributes are 1-based");
   int32_t *d_off = dev_upload(mesh.node_offsets, (size_t)ne * npe, s);
-  double *d_nodes = dev_upload(mesh.nodes, (size_t)mesh.num_nodes * dim, s);
+  double *d_nodes = dev_upload(mesh.nodes, (size_t)mesh.num_nodes * sdim, s);
   int32_t *d_attr = dev_upload(mesh.attr, (size_t)ne, s);
   double *d_grad = dev_upload(mesh.mesh_grad, (size_t)dim * Q * npe, s);
   double *d_w = dev_upload(mesh.qweight, (size_t)Q, s);
   g.ne = ne, g.q1d = 0, g.Q = Q, g.eb = kEB, g.Qpad = (Q + 15) / 16 * 16;
-  g.dim = dim, g.nrows = dim == 2 ? 6 : 11;
+  g.dim = dim, g.sdim = sdim, g.nrows = dim == 3 ? 11 : (sdim == 3 ? 8 : 6);
   g.d_qw = dev_upload(mesh.qweight, (size_t)Q, s);
   const size_t nb = (size_t)(ne + kEB - 1) / kEB, count = nb * g.nrows * g.Qpad * kEB;
   g.d_geom = dev_alloc<double>(count);
   PA_HIP(hipMemsetAsync(g.d_geom, 0, sizeof(double) * count, s));
   const long long n = (long long)ne * Q;
   const int bs = 256;
-  if (dim == 2)
+  if (dim == 2 && sdim == 3)
+    hipLaunchKernelGGL(geom_dense32_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, ne, Q, g.Qpad, npe, d_off,
+                       d_nodes, d_attr, d_grad, d_w, g.d_geom);
+  else if (dim == 2)
     hipLaunchKernelGGL(geom_dense2_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, ne, Q, g.Qpad, npe, d_off,
                        d_nodes, d_attr, d_grad, d_w, g.d_geom);
   else
@@ -899,7 +966,8 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   PA_REQUIRE(r.lsize < (1 << 29), "too many local dofs for the index encoding");
   const int P = b.num_dofs, Q = b.num_qpts, ne = r.num_elem;
   const int dim = geom->dim;
-  const int mode = mode_of(b.fe_type, qf, dim);
+  const int sdim = geom->sdim;
+  const int mode = mode_of(b.fe_type, qf, dim, sdim);
   int nci, ncd;
   mode_comps(mode, nci, ncd);
   const int nct = nci + ncd;
@@ -1029,7 +1097,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       parse_coeff(ctx, ctx_size, 1, ds->c0, 0);
       break;
     case MODE_VMASS2:
-      parse_coeff(ctx, ctx_size, 2, ds->c0, 0);
+      parse_coeff(ctx, ctx_size, sdim == 3 ? 3 : 2, ds->c0, 0);  // boundary elements take the 3x3 material
       break;
     case MODE_CURLMASS2:
       parse_coeff(ctx, ctx_size, 2, ds->c0, 0);
@@ -1082,6 +1150,9 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       DenseArgs a = make_args(*ds);
       const long long n = (long long)ne * Q;
       const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+      if (dim == 2 && sdim == 3) {
+        hipLaunchKernelGGL(dense_qdata32_kernel, grid, block, 0, nullptr, a, ds->d_qdata);
+      } else
       switch (mode) {
 #define PA_QD_CASE(MODE) \
   case MODE: hipLaunchKernelGGL((dense_qdata_kernel<MODE>), grid, block, 0, nullptr, a, ds->d_qdata); break;

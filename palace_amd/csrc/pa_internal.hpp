@@ -77,7 +77,7 @@ constexpr int kMaxQ1 = 7;
 struct Geom {
   int ne = 0, q1d = 0, Q = 0;
   int eb = 0, Qpad = 0;
-  int dim = 3, nrows = 11;        // 2-D blocks: 6 rows {attr, w detJ, adj(J)^T/detJ (2x2)}
+  int dim = 3, sdim = 3, nrows = 11;  // 2-D blocks: 6 rows {attr, w detJ, adj(J)^T/detJ (2x2)}; boundary (2 in 3): 8 rows
   double *d_qw = nullptr;         // quadrature weights (the q_w input of the 2-D curl-curl QFunctions)
   double *d_geom = nullptr;
   int refcount = 1;

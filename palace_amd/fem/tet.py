@@ -672,3 +672,60 @@ def to_quadratic(mesh: TetMesh, warp=None) -> TetMesh:
     if warp is not None:
         nodes = warp(nodes)
     return TetMesh(nodes[: mesh.nv], mesh.tets, mesh.attr, elem_nodes=en, nodes=nodes)
+
+
+class NDTetBoundaryBlock:
+    """The boundary-element block of an NDTetSpace over a set of boundary faces (what Palace builds for
+    surface integrators: 2-D Nedelec triangles in 3-D space whose dofs are the adjacent tetrahedron's face /
+    edge dofs, fem/libceed/restriction.cpp:15-111).  Every triangle takes its vertices in the GLOBAL
+    (sorted) face frame, so its interior dof pairs coincide with the space's face dofs and only the third
+    edge (G2 -> G0) is flipped: plain oriented restriction."""
+
+    def __init__(self, space: NDTetSpace, faces, attr=None):
+        from . import tri
+
+        mesh, p = space.mesh, space.p
+        self.space, self.faces = space, np.asarray(faces, dtype=np.int64)
+        fv = mesh.face_verts[self.faces]                       # [nf, 3] ascending global vertex ids
+        self.ne = fv.shape[0]
+        self.elem = tri.NDTriElement(p)
+        self.P = self.elem.P
+        n_e, n_f = p, p * (p - 1)
+        ekey = {tuple(e): i for i, e in enumerate(map(tuple, mesh.edge_verts))}
+        off = np.zeros((self.ne, self.P), dtype=np.int64)
+        ori = np.zeros((self.ne, self.P), dtype=bool)
+        for k, (a, b) in enumerate(tri.LOCAL_EDGES):
+            flip = a > b  # local vertices are in ascending global order
+            ge = np.array([ekey[(min(f[a], f[b]), max(f[a], f[b]))] for f in fv])
+            for i in range(p):
+                off[:, k * p + i] = ge * n_e + (p - 1 - i if flip else i)
+                ori[:, k * p + i] = flip
+        for i in range(n_f):
+            off[:, 3 * p + i] = space.face_base + self.faces * n_f + i
+        self.offsets, self.orients = off.astype(np.int32), ori
+        self.attr = np.ones(self.ne, dtype=np.int32) if attr is None else np.asarray(attr, dtype=np.int32)
+        # geometry nodes: the three vertices (+ the three edge midpoints of a tet10 mesh, LOCAL_EDGES order of tri)
+        if mesh.mesh_order == 1:
+            self.nodes, self.elem_nodes = mesh.verts, fv
+        else:
+            mid = np.full(mesh.edge_verts.shape[0], -1, dtype=np.int64)
+            mid[mesh.elem_edges.ravel()] = mesh.elem_nodes[:, 4:].ravel()
+            em = np.stack([[mid[ekey[(min(f[a], f[b]), max(f[a], f[b]))]] for (a, b) in tri.LOCAL_EDGES] for f in fv])
+            # vertex ids of the tet mesh index `verts`; tet10 geometry nodes index `nodes`: map vertices through the
+            # corner entries of elem_nodes
+            v2n = np.full(mesh.nv, -1, dtype=np.int64)
+            v2n[mesh.tets.ravel()] = mesh.elem_nodes[:, :4].ravel()
+            self.nodes, self.elem_nodes = mesh.nodes, np.concatenate([v2n[fv], em], axis=1)
+
+    def geometry_grad_table(self, x):
+        from . import tri
+
+        return tri.TriMesh.geometry_grad_table(self, x)
+
+    @property
+    def mesh_order(self):
+        return self.space.mesh.mesh_order
+
+    def jacobians(self, x):
+        """J[e, q, i, d]: 3 x 2."""
+        return np.einsum("dqn,eni->eqid", self.geometry_grad_table(x), self.nodes[self.elem_nodes])

@@ -30,7 +30,8 @@ class DenseBasisDesc(C.Structure):
 class MeshDenseDesc(C.Structure):
     _fields_ = [("num_elem", C.c_int32), ("nodes_per_elem", C.c_int32), ("num_qpts", C.c_int32),
                 ("num_nodes", C.c_int32), ("node_offsets", C.c_void_p), ("nodes", C.c_void_p),
-                ("attr", C.c_void_p), ("mesh_grad", C.c_void_p), ("qweight", C.c_void_p), ("dim", C.c_int32)]
+                ("attr", C.c_void_p), ("mesh_grad", C.c_void_p), ("qweight", C.c_void_p), ("dim", C.c_int32),
+                ("space_dim", C.c_int32)]
 
 
 class BasisDesc(C.Structure):

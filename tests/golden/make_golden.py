@@ -95,6 +95,15 @@ def fixtures_2d():
     v2, w2 = np.zeros((2, Q)), np.zeros((1, Q))
     capi.ref_call("f_apply_hdivmass_22", pair, Q, [geom, qw, u, cu], [v2, w2])
     out["hdivmass_22_v"], out["hdivmass_22_cv"], out["ctx_pair"] = v2, w2, pair
+    # boundary elements (dim 2 in space_dim 3)
+    J32 = rng.uniform(-1, 1, (6, Q)) + np.array([1, 0, 0, 0, 1, 0.3]).reshape(6, 1)
+    g32 = np.zeros((8, Q))
+    capi.ref_call("f_build_geom_factor_32", None, Q, [attr, qw, np.ascontiguousarray(J32)], [g32])
+    B3 = rng.uniform(-1, 1, (3, 3))
+    c3 = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[B3 @ B3.T + 2 * np.eye(3), np.array([0.8])], a=0.9)
+    v32 = np.zeros((2, Q))
+    capi.ref_call("f_apply_hcurl_32", c3.pack(), Q, [g32, u], [v32])
+    out.update(J32=J32, geom32=g32, ctx3=c3.pack(), hcurl_32=v32)
     np.savez(os.path.join(ROOT, "tests", "golden", "qf2d_golden.npz"), **out)
     m = tri.read_gmsh22_tris("/root/reference/examples/cavity2d/mesh/cavity2d.msh")
     eig = np.loadtxt("/root/reference/test/data/regression/ref/cavity2d/eigenmode/eig.csv", delimiter=",", skiprows=1)

@@ -41,6 +41,14 @@ def test_qfunctions_22():
     np.testing.assert_allclose(cv[0], G["hdivmass_22_cv"], rtol=TOL, atol=TOL)
 
 
+def test_boundary_qfunctions_32():
+    geom = po.build_geom_factor_32(np.ones(1), G["qw"], G["J32"].T[None])
+    np.testing.assert_allclose(geom[0, 1:], G["geom32"][1:], rtol=1e-12, atol=1e-13)
+    c3, _ = _ctx(G["ctx3"], 3)
+    v = po.apply_hcurl_32(c3, G["geom32"][None], G["u"][None])[0]
+    np.testing.assert_allclose(v, G["hcurl_32"], rtol=1e-12, atol=1e-13)
+
+
 def test_cavity2d_eigenfrequencies():
     """Order-2 Nedelec triangles on the reference's own mesh, eps_r = 2.08 with loss tangent 4e-4, PEC:
     K x = omega^2 eps M x  ->  f = sqrt(lambda / (eps_r (1 - i tan d))) c0 / 2 pi."""

@@ -144,3 +144,44 @@ def test_h1_tet_apply(p, mode):
         one = torch.ones_like(xd)
         op.mult(one, yd)
         assert float(yd.abs().max()) < 1e-11 * float(np.abs(y_ref).max())
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["tet4", "tet10"])
+def test_nd_tet_boundary_mass(kind, p):
+    """Surface (impedance / absorbing-boundary type) mass term on the boundary triangles of a tet mesh:
+    f_apply_hcurl_32 on 2-D Nedelec triangles in 3-D space whose dofs are the tetrahedral space's face / edge dofs
+    (SURVEY.md 8f-2), alone and added to the volume operator in one ceed::Operator."""
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import tet, tri
+
+    mesh = _mesh(kind)
+    nd = tet.NDTetSpace(mesh, p)
+    faces = np.nonzero(mesh.boundary_face_mask)[0]
+    battr = 1 + (np.arange(faces.size) % 2)
+    blk = tet.NDTetBoundaryBlock(nd, faces, battr)
+    pts, wts = tri.tri_quadrature(p + 1)
+    interp, curl = blk.elem.tables(pts)
+    bgeom = ceed.DenseGeomFactorData(blk.elem_nodes, blk.nodes, blk.attr, blk.geometry_grad_table(pts), wts)
+    J = blk.jacobians(pts)
+    og = po.build_geom_factor_32(blk.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(blk.ne, -1, 6))
+    got = bgeom.to_numpy()
+    assert got.shape == og.shape and np.abs(got - og).max() <= 1e-13 * np.abs(og).max()
+    c3, b3 = util.make_ctx("aniso", 2)
+    block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, blk.offsets, interp, None, orients=blk.orients)
+    op = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(bgeom, block, ceed.QF_HCURL_32, b3, ceed.EVAL_INTERP).finalize()
+    orc = po.CeedOperatorOracle(nd.ndofs, blk.offsets, blk.orients, interp, curl, og, po.QF_HCURL_32, c3)
+    x = np.random.default_rng(p).uniform(-1, 1, nd.ndofs)
+    ref = orc.apply_add(x, np.zeros(nd.ndofs))
+    y = torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")
+    op.mult(torch.from_numpy(x).cuda(), y)
+    assert np.abs(y.cpu().numpy() - ref).max() < REL * np.abs(ref).max()
+    if kind == "tet4":  # flat faces of the unit cube, identity material: sum over faces of area * |E_tangential|^2
+        ident = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(
+            bgeom, block, ceed.QF_HCURL_32, ceed.coefficient_context(3), ceed.EVAL_INTERP).finalize()
+        xe = nd.interpolate(lambda X: np.broadcast_to(np.array([1.0, 2.0, 3.0]), X.shape))
+        xd = torch.from_numpy(xe).cuda()
+        ident.mult(xd, y)
+        assert abs(float(xd @ y) - 56.0) < 1e-11 * 56.0
