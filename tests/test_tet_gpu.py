@@ -178,6 +178,20 @@ def test_nd_tet_boundary_mass(kind, p):
     y = torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")
     op.mult(torch.from_numpy(x).cuda(), y)
     assert np.abs(y.cpu().numpy() - ref).max() < REL * np.abs(ref).max()
+    # volume mass + boundary term as two sub-operators of ONE ceed::Operator (how Palace composes K, M and the
+    # impedance term): the apply is the sum of the two
+    vpts, vwts = tet.default_tet_rule(p)
+    vint, vcurl = nd.elem.tables(vpts)
+    vgeom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, mesh.geometry_grad_table(vpts), vwts)
+    kw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+    vblock = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, vint, vcurl, **kw)
+    vol = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(vgeom, vblock, ceed.QF_HCURL_33, b3, ceed.EVAL_INTERP).finalize()
+    both = (ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(vgeom, vblock, ceed.QF_HCURL_33, b3, ceed.EVAL_INTERP)
+            .add_dense_integrator(bgeom, block, ceed.QF_HCURL_32, b3, ceed.EVAL_INTERP).finalize())
+    yv, yb = torch.empty_like(y), torch.empty_like(y)
+    vol.mult(torch.from_numpy(x).cuda(), yv)
+    both.mult(torch.from_numpy(x).cuda(), yb)
+    assert float((yb - (yv + y)).abs().max()) < 1e-13 * float(yv.abs().max())
     if kind == "tet4":  # flat faces of the unit cube, identity material: sum over faces of area * |E_tangential|^2
         ident = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(
             bgeom, block, ceed.QF_HCURL_32, ceed.coefficient_context(3), ceed.EVAL_INTERP).finalize()
