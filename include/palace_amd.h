@@ -236,6 +236,10 @@ int pa_op_mult(pa_op *op, const double *x, double *y, void *stream);
  * that after P^T). */
 int pa_op_set_essential(pa_op *op, const int32_t *ess_ldofs, int32_t n);
 int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream);
+/* The same with the row fix-up of rap.cpp:223-233 fused into the E^T kernels when the operator supports it:
+ * y[ess] = x[ess] (diag_policy 1, DIAG_ONE) or 0 (DIAG_ZERO).  *handled = 1 if the rows were written, 0 if the
+ * caller still has to do it. */
+int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_policy, void *stream, int *handled);
 /* Operator::AssembleDiagonal (operator.cpp:116-143): diag = diag(A) (zeroed first). */
 int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream);
 /* CeedOperatorFullAssemble (operator.cpp:455-523; BilinearForm::FullAssemble / ParOperator::ParallelAssemble,

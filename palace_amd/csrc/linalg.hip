@@ -354,6 +354,11 @@ void Operator::AddMult(const Vector &x, Vector &y, double a) const {
 }
 void Operator::AssembleDiagonal(Vector &diag) const { check(pa_op_assemble_diagonal(op_, diag.Data(), ctx_->stream)); }
 void Operator::SetEssential(const int32_t *ess_host, int n) { check(pa_op_set_essential(op_, ess_host, n)); }
+bool Operator::MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const {
+  int handled = 0;
+  check(pa_op_mult_essential_diag(op_, x.Data(), y.Data(), diag_one ? 1 : 0, ctx_->stream, &handled));
+  return handled != 0;
+}
 void Operator::MultEssential(const Vector &x, Vector &y) const {
   check(pa_op_mult_essential(op_, x.Data(), y.Data(), ctx_->stream));
 }
@@ -388,7 +393,7 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
   // rap.cpp:195-234.  tx = x, tx[ess] = 0; lx = P tx; ly = A lx; y = P^T ly; y[ess] = x[ess] | 0
   const Context &c = *ctx_;
   if (A_fused_ && x.Data() != y.Data()) {
-    A_fused_->MultEssential(x, y);
+    if (A_fused_->MultEssentialDiag(x, y, policy_ == DiagonalPolicy::DIAG_ONE)) return;
     if (policy_ == DiagonalPolicy::DIAG_ONE)
       linalg::SetSubVector(c, y, d_ess_, n_ess_, x);
     else

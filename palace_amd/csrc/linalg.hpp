@@ -127,6 +127,8 @@ public:
   // y = A (x with the essential entries read as zero), no copy of x (pa_op_mult_essential)
   void SetEssential(const int32_t *ess_host, int n);
   void MultEssential(const Vector &x, Vector &y) const;
+  // the same + y[ess] = x[ess] | 0 inside the E^T kernels; returns false if the caller must fix the rows up
+  bool MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const;
 };
 
 }  // namespace ceed

@@ -316,7 +316,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
 static void free_sub(SubOp *so) {
   if (!so) return;
   hipFree(so->d_lidx);
-  hipFree(so->d_sidx), hipFree(so->d_sidx_bc), hipFree(so->d_perm), hipFree(so->d_perm_x), hipFree(so->d_shared);
+  hipFree(so->d_sidx), hipFree(so->d_sidx_bc), hipFree(so->d_perm), hipFree(so->d_perm_x), hipFree(so->d_shared), hipFree(so->d_shared_bc);
   hipFree(so->d_ye), hipFree(so->d_tptr), hipFree(so->d_tent);
   if (so->qd && --so->qd->refcount == 0) {
     hipFree(so->qd->d);
@@ -331,7 +331,8 @@ static void free_sub(SubOp *so) {
 
 // y (+)= A x.  overwrite: the first sub-operator writes y instead of accumulating (Mult without a
 // separate memset when E^T runs as a gather).
-static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s, bool masked = false) {
+static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s, bool masked = false,
+                  int ess_policy = -1) {
   PA_REQUIRE(op && x && y, "null argument");
   PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty(), "operator has no sub-operators");
   PA_REQUIRE(x != y, "in-place apply is not supported");
@@ -339,8 +340,8 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   for (const SubOp *so : op->subs) {
     if (so->fe_type == PA_FE_HCURL) {
       if (so->d_ye) {
-        launch_nd_hex_apply(*so, x, y, so->d_ye, masked, s, !(overwrite && first));
-        launch_et_gather(*so, y, !(overwrite && first), s);
+        launch_nd_hex_apply(*so, x, y, so->d_ye, masked, s, !(overwrite && first), ess_policy);
+        launch_et_gather(*so, y, !(overwrite && first), s, x, ess_policy);
       } else {
         if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
         launch_nd_hex_apply(*so, x, y, nullptr, masked, s);
@@ -382,6 +383,7 @@ void finalize_exclusive(pa_op *op) {
   so->d_perm_x = dev_upload(px.data(), px.size());
   so->d_shared = dev_upload(shared.data(), shared.size());
   so->n_shared = (int)shared.size();
+  so->h_shared = std::move(shared);
 }
 
 void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s) { apply(op, x, y, true, s); }
@@ -586,6 +588,14 @@ int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
       so->d_sidx_bc = dev_upload(bc.data(), bc.size());
     }
     for (DenseSub *ds : op->dsubs) dense_set_essential(*ds, flag);
+    for (SubOp *so : op->subs)
+      if (so->d_shared) {  // flagged copy of the gather list: essential rows are fixed up inside the gather kernel
+        std::vector<int32_t> lb(so->h_shared);
+        for (auto &d : lb)
+          if (flag[d]) d |= kEssBit;
+        hipFree(so->d_shared_bc);
+        so->d_shared_bc = dev_upload(lb.data(), lb.size());
+      }
     op->has_essential = true;
   });
 }
@@ -594,6 +604,15 @@ int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream) {
   return guarded([&] {
     PA_REQUIRE(op && op->has_essential, "pa_op_set_essential has not been called");
     apply(op, x, y, true, (hipStream_t)stream, true);
+  });
+}
+
+int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_policy, void *stream, int *handled) {
+  return guarded([&] {
+    PA_REQUIRE(op && op->has_essential && handled, "pa_op_set_essential has not been called");
+    const bool fuse = op->subs.size() == 1 && op->dsubs.empty() && nd_hex_fuses_essential(*op->subs[0]);
+    apply(op, x, y, true, (hipStream_t)stream, true, fuse ? (diag_policy ? 1 : 0) : -1);
+    *handled = fuse ? 1 : 0;
   });
 }
 

@@ -124,6 +124,8 @@ struct SubOp {
   // element kernel instead of going through the E-vector; the gather kernel then only visits the rest.
   uint16_t *d_perm_x = nullptr;  // perm with kExclBit16 on exclusive entries (set at finalize)
   int32_t *d_shared = nullptr;   // list of the dofs the gather kernel still has to sum
+  int32_t *d_shared_bc = nullptr;  // the same with kEssBit on essential dofs (pa_op_set_essential)
+  std::vector<int32_t> h_shared;
   int n_shared = 0;
   std::vector<uint16_t> h_perm;
   std::vector<int32_t> h_sidx;   // host copy (needed to build d_sidx_bc)
@@ -168,9 +170,11 @@ void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t
 // kernels (pa_geom.hip, pa_nd_hex.hip, pa_h1_hex.hip)
 void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s);
 void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
-                         bool accumulate = true);
+                         bool accumulate = true, int ess_policy = -1);
+bool nd_hex_fuses_essential(const SubOp &so);
 void finalize_exclusive(pa_op_fwd *op);
-void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s);
+void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x = nullptr,
+                      int ess_policy = -1);
 void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 void launch_h1_hex_apply(const SubOp &so, const double *x, bool masked, hipStream_t s);
@@ -187,7 +191,8 @@ void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStr
 void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s);
 void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s);
 void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y,
-                          bool accumulate, hipStream_t s, const int32_t *list = nullptr);
+                          bool accumulate, hipStream_t s, const int32_t *list = nullptr, const double *x = nullptr,
+                          int ess_policy = -1);
 
 }  // namespace pa
 

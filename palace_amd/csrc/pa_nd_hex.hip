@@ -83,6 +83,7 @@ struct NDArgs {
   double *ye;  // E-vector target [ne][P], sorted order, unsigned (EVEC == true)
   int direct;      // EVEC: entries flagged kExclBit16 in perm go straight to y (they are the only copy)
   int accumulate;  // for those: y += v instead of y = v
+  int ess_policy;  // -1, or ParOperator's row fix-up fused in: y[ess] = x[ess] (1) / 0 (0) (rap.cpp:223-233)
   CoeffDev c_mass, c_curl;
   NDTab<P1, Q1> tab;
 #ifdef PA_ABLATION
@@ -507,10 +508,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
 #endif
       if (EVEC) {
         if (DIRECT && (lp[r] & kExclBit16)) {  // only copy of this dof: no E-vector round trip, no gather
-          const int s = a.sidx[(size_t)e * PP + m];
-          double *dst = &a.y[s >= 0 ? s : -1 - s];
+          const int s = a.sidx_in[(size_t)e * PP + m];  // carries kEssBit on essential dofs when masked
+          const int df = s >= 0 ? s : -1 - s, d = df & ~kEssBit;
+          double *dst = &a.y[d];
           const double sv = s >= 0 ? v : -v;
-          *dst = a.accumulate ? *dst + sv : sv;
+          if ((df & kEssBit) && a.ess_policy >= 0)
+            *dst = a.ess_policy ? a.x[d] : 0.0;
+          else
+            *dst = a.accumulate ? *dst + sv : sv;
         } else {
           a.ye[(size_t)e * PP + m] = v;
         }
@@ -555,7 +560,7 @@ static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block,
 
 template <int P1, int Q1>
 static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
-                      bool accumulate) {
+                      bool accumulate, int ess_policy) {
   using L = NDLayout<P1, Q1>;
   NDArgs<P1, Q1> a;
   a.ne = so.ne;
@@ -564,6 +569,7 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
   a.direct = (ye != nullptr && use_direct(so)) ? 1 : 0;
   a.perm = a.direct ? so.d_perm_x : so.d_perm;
   a.accumulate = accumulate ? 1 : 0;
+  a.ess_policy = (a.direct && masked) ? ess_policy : -1;
   a.geom = so.geom->d_geom;
   a.qdata = so.qd ? so.qd->d : nullptr;
   a.x = x;
@@ -616,8 +622,8 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
 // ye != nullptr: write the element-local results (E-vector) instead of scattering atomically into y
 // masked: gather through the essential-dof-flagged index array (pa_op_set_essential)
 void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
-                         bool accumulate) {
-  PA_ND_DISPATCH(launch_pq, so, x, y, ye, masked, s, accumulate)
+                         bool accumulate, int ess_policy) {
+  PA_ND_DISPATCH(launch_pq, so, x, y, ye, masked, s, accumulate, ess_policy)
 }
 
 // ---- E^T as a gather: y_d (+)= sum over the element-local copies of dof d -----------------------
@@ -625,10 +631,15 @@ void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye
 // ye[t], t < 0 reads -ye[-1-t].  One thread per dof, fixed summation order => reproducible.
 __global__ void et_gather_kernel(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
                                  const double *__restrict__ ye, double *__restrict__ y, const int accumulate,
-                                 const int32_t *__restrict__ list) {
+                                 const int32_t *__restrict__ list, const double *__restrict__ x, const int ess_policy) {
   const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
   if (k0 >= n) return;
-  const int d = list ? list[k0] : k0;  // list: only the dofs with more than one copy
+  const int dl = list ? list[k0] : k0;  // list: only the dofs with more than one copy (kEssBit: essential)
+  const int d = dl & ~kEssBit;
+  if ((dl & kEssBit) && ess_policy >= 0) {  // ParOperator's essential rows (rap.cpp:223-233), fused
+    y[d] = ess_policy ? x[d] : 0.0;
+    return;
+  }
   const int b = tptr[d], e = tptr[d + 1];
   double s = 0.0;
   int k = b;
@@ -658,16 +669,20 @@ __global__ void et_gather_kernel(const int n, const int32_t *__restrict__ tptr, 
 }
 
 void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y,
-                          bool accumulate, hipStream_t s, const int32_t *list) {
+                          bool accumulate, hipStream_t s, const int32_t *list, const double *x, int ess_policy) {
   const int bs = 256;
   if (n == 0) return;
   hipLaunchKernelGGL(et_gather_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, tptr, tent, ye, y,
-                     accumulate ? 1 : 0, list);
+                     accumulate ? 1 : 0, list, x, ess_policy);
   PA_HIP(hipGetLastError());
 }
 
-void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s) {
-  if (use_direct(so))  // the element kernel stored the exclusive dofs itself
+bool nd_hex_fuses_essential(const SubOp &so) { return use_direct(so) && so.d_shared_bc != nullptr; }
+
+void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, int ess_policy) {
+  if (use_direct(so) && ess_policy >= 0 && so.d_shared_bc)
+    launch_et_gather_raw(so.n_shared, so.d_tptr, so.d_tent, so.d_ye, y, accumulate, s, so.d_shared_bc, x, ess_policy);
+  else if (use_direct(so))  // the element kernel stored the exclusive dofs itself
     launch_et_gather_raw(so.n_shared, so.d_tptr, so.d_tent, so.d_ye, y, accumulate, s, so.d_shared);
   else
     launch_et_gather_raw(so.lsize, so.d_tptr, so.d_tent, so.d_ye, y, accumulate, s);
