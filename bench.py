@@ -251,7 +251,8 @@ def main():
     if args.pcg_iters > 0:
         pcg = {}
         for name, hip in (("chebyshev", False), ("hiptmair", True)):
-            solver, b, xs = prob.pcg_gmg_solver(max_it=args.pcg_iters, hiptmair=hip)
+            coarse = "cg" if hip else "chebyshev"
+            solver, b, xs = prob.pcg_gmg_solver(max_it=args.pcg_iters, hiptmair=hip, coarse=coarse)
             solver.mult(b, xs)  # warm-up solve (also first-touch of all work vectors)
             barrier()
             t0 = time.perf_counter()
@@ -261,7 +262,7 @@ def main():
             st = solver.stats()
             entry = {"iters_per_s": st["iterations"] / dt, "iterations": st["iterations"], "seconds": dt,
                      "final_rel_res": st["final_res"] / st["initial_res"]}
-            solver, b, xs = prob.pcg_gmg_solver(max_it=400, rel_tol=1e-8, hiptmair=hip)
+            solver, b, xs = prob.pcg_gmg_solver(max_it=400, rel_tol=1e-8, hiptmair=hip, coarse=coarse)
             barrier()
             t0 = time.perf_counter()
             solver.mult(b, xs)
@@ -274,8 +275,8 @@ def main():
         pcg["config"] = (f"PCG on K+M (eps_r=2.08), p-multigrid levels p={','.join(str(q) for q in prob.orders)}, "
                          f"4th-kind Chebyshev order {max(2 * p, 4)}, 1 V-cycle "
                          "per iteration; 'chebyshev' = plain smoother (reference default for magnetostatics), "
-                         "'hiptmair' = auxiliary-space smoother (reference default for driven/eigenmode); level 0: "
-                         "8 Jacobi-PCG iterations (stand-in for AMS)")
+                         "'hiptmair' = auxiliary-space smoother (reference default for driven/eigenmode); level 0 (stand-in for AMS): "
+                         "Chebyshev-Jacobi order 4 with the plain smoother, 8 Jacobi-PCG iterations with the auxiliary-space one")
 
     tets = None
     if rank == 0 and world == 1 and not args.no_tets:

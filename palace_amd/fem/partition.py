@@ -229,7 +229,8 @@ class SlabProblem:
         return linalg.ParOperator(self.ctx, self.local_curlcurl, self.ess[-1], linalg.DIAG_ONE,
                                   n_true=self.n_true[-1], halo=self.halos[-1])
 
-    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False):
+    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False,
+                       coarse="cg"):
         """PCG on (K + M) with the p-multigrid preconditioner configured as the reference does for
         p = 3 (iodata.cpp:533-564: 4th-kind Chebyshev of order max(2p, 4), 1 smoothing step, 1 V-cycle);
         level 0 is solved by Jacobi-PCG (the reference uses AMS from HYPRE there, linalg/ams.cpp)."""
@@ -264,8 +265,15 @@ class SlabProblem:
             aux = dict(A_aux=A_h1, G=G)
             self._keep.append((h1s, loc_h1, h1_halos))
         if len(A) > 1:
-            coarse = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
-            B = linalg.gmg(ctx, A, P, coarse, cheby_order=max(2 * self.p, 4), **aux)
+            # level 0: the reference calls AMS (HYPRE) here.  Stand-ins: "cg" = a few Jacobi-PCG iterations (needed by
+            # the auxiliary-space configuration, where level 0 must really reduce the error), "chebyshev" = a fixed
+            # Chebyshev-Jacobi smoother of order 4 (better with the plain smoother on the cylinder: an inexact inner CG is
+            # a nonlinear preconditioner and costs the outer PCG 40 % more iterations; scripts/coarse_tune.py)
+            if coarse == "chebyshev":
+                csolver = linalg.chebyshev(ctx, A[0], 4)
+            else:
+                csolver = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
+            B = linalg.gmg(ctx, A, P, csolver, cheby_order=max(2 * self.p, 4), **aux)
         else:
             B = linalg.jacobi(ctx, A[0])
         K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)

@@ -33,7 +33,8 @@ class TetProblem:
         interp, grad = s.elem.tables(self.pts)
         return ceed.DenseBlock(ceed.FE_H1, s.ndofs, s.offsets, interp, grad)
 
-    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False):
+    def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False,
+                       coarse="cg"):
         """Same configuration as SlabProblem.pcg_gmg_solver (reference iodata.cpp:519-564)."""
         import torch
 
@@ -64,8 +65,15 @@ class TetProblem:
             aux = dict(A_aux=A_h1, G=G)
             self._keep.append((h1s, loc_h1, hb))
         if len(A) > 1:
-            coarse = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
-            B = linalg.gmg(ctx, A, P, coarse, cheby_order=max(2 * self.p, 4), **aux)
+            # level 0: the reference calls AMS (HYPRE) here.  Stand-ins: "cg" = a few Jacobi-PCG iterations (needed by
+            # the auxiliary-space configuration, where level 0 must really reduce the error), "chebyshev" = a fixed
+            # Chebyshev-Jacobi smoother of order 4 (better with the plain smoother on the cylinder: an inexact inner CG is
+            # a nonlinear preconditioner and costs the outer PCG 40 % more iterations; scripts/coarse_tune.py)
+            if coarse == "chebyshev":
+                csolver = linalg.chebyshev(ctx, A[0], 4)
+            else:
+                csolver = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
+            B = linalg.gmg(ctx, A, P, csolver, cheby_order=max(2 * self.p, 4), **aux)
         else:
             B = linalg.jacobi(ctx, A[0])
         K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)
