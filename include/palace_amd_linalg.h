@@ -54,6 +54,10 @@ enum pa_diag_policy { PA_DIAG_ZERO = 0, PA_DIAG_ONE = 1 };
 /* `local` stays owned by the caller and must outlive the ParOperator; halo may be NULL (one rank) */
 int pa_par_op_create(pa_context *ctx, pa_op *local, int n_true, const int32_t *ess_tdofs, int n_ess,
                      int diag_policy, pa_halo *halo, pa_par_op **A);
+/* BuildParSumOperator (linalg/rap.cpp:843-919): ParOperator around sum_k coeffs[k] * locals[k] (the
+ * BaseSumOperator of linalg/operator.hpp:132-270), e.g. a0 K + a1 C + a2 M.  The locals stay owned by the caller. */
+int pa_par_sum_op_create(pa_context *ctx, int nterms, pa_op *const *locals, const double *coeffs, int n_true,
+                         const int32_t *ess_tdofs, int n_ess, int diag_policy, pa_halo *halo, pa_par_op **A);
 void pa_par_op_destroy(pa_par_op *A);
 int pa_par_op_mult(pa_par_op *A, const double *x, double *y);
 /* ParOperator::AddMult (rap.cpp:277-318): y += a (P^T A P with the essential-dof handling) x. */

@@ -365,6 +365,37 @@ void Operator::MultEssential(const Vector &x, Vector &y) const {
 }  // namespace ceed
 
 // ---- ParOperator ------------------------------------------------------------------------------
+// ---- SumOperator (operator.hpp:132-270) ---------------------------------------------------------
+void SumOperator::AddOperator(const Operator &op, double a) {
+  PA_REQUIRE(op.Height() == height && op.Width() == width, "Invalid Operator dimensions for BaseSumOperator!");
+  ops_.emplace_back(&op, a);
+}
+void SumOperator::Mult(const Vector &x, Vector &y) const {
+  PA_REQUIRE(!ops_.empty(), "empty SumOperator");
+  ops_[0].first->Mult(x, y);  // operator.hpp:208-221 (first term written, the others accumulated)
+  if (ops_[0].second != 1.0) linalg::AXPBY(*ctx_, 0.0, y, ops_[0].second, y);
+  for (size_t k = 1; k < ops_.size(); k++) {
+    if (z_.Size() != height) z_.SetSize(height);
+    ops_[k].first->Mult(x, z_);
+    linalg::AXPY(*ctx_, ops_[k].second, z_, y);
+  }
+}
+void SumOperator::AddMult(const Vector &x, Vector &y, double a) const {
+  if (z_.Size() != height) z_.SetSize(height);
+  for (const auto &[op, c] : ops_) {
+    op->Mult(x, z_);
+    linalg::AXPY(*ctx_, a * c, z_, y);
+  }
+}
+void SumOperator::AssembleDiagonal(Vector &diag) const {
+  linalg::Fill(*ctx_, diag, 0.0);
+  if (z_.Size() != height) z_.SetSize(height);
+  for (const auto &[op, c] : ops_) {
+    op->AssembleDiagonal(z_);
+    linalg::AXPY(*ctx_, c, z_, diag);
+  }
+}
+
 ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, const int32_t *ess_host, int n_ess,
                          DiagonalPolicy policy, const Halo *halo)
     : Operator(n_true, n_true), ctx_(&ctx), A_(&A), halo_(halo), n_true_(n_true), n_local_(A.Height()),

@@ -133,6 +133,23 @@ public:
 
 }  // namespace ceed
 
+// BaseSumOperator<Operator> (linalg/operator.hpp:132-270): y = sum_k a_k A_k x over operators of equal size
+// (non-owning).  Palace's BuildParSumOperator (linalg/rap.cpp:843-919) wraps such a sum of local operators in
+// one ParOperator to form a0 K + a1 C + a2 M.
+class SumOperator : public Operator {
+  const Context *ctx_;
+  std::vector<std::pair<const Operator *, double>> ops_;
+  mutable Vector z_;
+
+public:
+  SumOperator(const Context &ctx, int h, int w) : Operator(h, w), ctx_(&ctx) {}
+  void AddOperator(const Operator &op, double a = 1.0);
+  void Mult(const Vector &x, Vector &y) const override;
+  void MultTranspose(const Vector &x, Vector &y) const override { Mult(x, y); }
+  void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
+  void AssembleDiagonal(Vector &diag) const override;
+};
+
 // ParOperator (rap.cpp:154-234): y = P^T A P x with essential-dof handling.  True dofs of this
 // rank are the first n_true entries of the local (L-) vector; shared dofs owned elsewhere follow
 // (see comm.hpp); with one rank P is the identity.

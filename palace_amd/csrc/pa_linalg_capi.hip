@@ -26,6 +26,8 @@ struct pa_halo {
 struct pa_par_op {
   pa_context *ctx;
   std::unique_ptr<ceed::Operator> local;
+  std::vector<std::unique_ptr<ceed::Operator>> terms;  // BuildParSumOperator: the local operators of the sum
+  std::unique_ptr<SumOperator> sum;
   std::unique_ptr<ParOperator> op;
 };
 struct pa_interp {
@@ -109,6 +111,26 @@ int pa_par_op_create(pa_context *ctx, pa_op *local, int n_true, const int32_t *e
     p->ctx = ctx;
     p->local = std::make_unique<ceed::Operator>(ctx->ctx, local, false);
     p->op = std::make_unique<ParOperator>(ctx->ctx, *p->local, n_true, ess, n_ess,
+                                          policy == PA_DIAG_ONE ? ParOperator::DiagonalPolicy::DIAG_ONE
+                                                                : ParOperator::DiagonalPolicy::DIAG_ZERO,
+                                          halo ? halo->halo.get() : nullptr);
+    *A = p;
+  });
+}
+int pa_par_sum_op_create(pa_context *ctx, int nterms, pa_op *const *locals, const double *coeffs, int n_true,
+                         const int32_t *ess, int n_ess, int policy, pa_halo *halo, pa_par_op **A) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && locals && coeffs && A && nterms >= 1, "bad argument");
+    auto *p = new pa_par_op;
+    p->ctx = ctx;
+    const int n = pa_op_height(locals[0]);
+    p->sum = std::make_unique<SumOperator>(ctx->ctx, n, n);
+    for (int k = 0; k < nterms; k++) {
+      PA_REQUIRE(locals[k], "null local operator");
+      p->terms.push_back(std::make_unique<ceed::Operator>(ctx->ctx, locals[k], false));
+      p->sum->AddOperator(*p->terms.back(), coeffs[k]);
+    }
+    p->op = std::make_unique<ParOperator>(ctx->ctx, *p->sum, n_true, ess, n_ess,
                                           policy == PA_DIAG_ONE ? ParOperator::DiagonalPolicy::DIAG_ONE
                                                                 : ParOperator::DiagonalPolicy::DIAG_ZERO,
                                           halo ? halo->halo.get() : nullptr);

@@ -152,6 +152,21 @@ class ParOperator:
             pass
 
 
+class ParSumOperator(ParOperator):
+    """BuildParSumOperator (rap.cpp:843-919): ParOperator around sum_k coeffs[k] * locals[k]."""
+
+    def __init__(self, ctx: Context, locals_, coeffs, ess_tdofs, diag_policy=DIAG_ONE, n_true=None, halo=None):
+        self.ctx, self.local, self.halo = ctx, list(locals_), halo
+        self.n = self.local[0].height if n_true is None else n_true
+        ess = np.ascontiguousarray(ess_tdofs, dtype=np.int32)
+        self.ess = ess
+        hs = (C.c_void_p * len(self.local))(*[o.handle for o in self.local])
+        cs = np.ascontiguousarray(coeffs, dtype=np.float64)
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_par_sum_op_create(ctx.handle, len(self.local), hs, _ptr(cs), self.n, _ptr(ess), ess.size,
+                                             diag_policy, halo.handle if halo else None, C.byref(self.handle)))
+
+
 class Solver:
     def __init__(self, ctx, handle, keep=()):
         self.ctx, self.handle, self._keep = ctx, handle, keep

@@ -94,6 +94,29 @@ def test_par_operator_add_mult_and_eliminate_rhs(prob):
         assert _rel(b, refb) < 1e-12
 
 
+def test_par_sum_operator(prob):
+    """BuildParSumOperator: a0 K + a1 M as one ParOperator (essential rows handled once, after the sum)."""
+    sp = prob.spaces[1]
+    n = sp.ndofs
+    Kop = ceed.curlcurl_operator(prob.geom, sp, prob.bc)
+    Mop = ceed.ndmass_operator(prob.geom, sp, prob.bm)
+    a0, a1 = 1.0, -0.37
+    A = linalg.ParSumOperator(prob.ctx, [Kop, Mop], [a0, a1], sp.ess_dofs(), linalg.DIAG_ONE)
+    x = np.random.default_rng(9).uniform(-1, 1, n)
+    y = A.mult(_dev(x), _new(n)).cpu().numpy()
+    oK = util.FastParOperatorOracle(sp, prob.ogeom, "hdiv", prob.bc, [], prob.q1d, prob.cc)
+    oM = util.FastParOperatorOracle(sp, prob.ogeom, "hcurl", prob.bm, [], prob.q1d, prob.cm)
+    tx = x.copy()
+    tx[sp.ess_dofs()] = 0.0
+    ref = a0 * oK.mult(tx) + a1 * oM.mult(tx)
+    ref[sp.ess_dofs()] = x[sp.ess_dofs()]
+    assert _rel(y, ref) < 1e-12
+    d = A.assemble_diagonal(_new(n)).cpu().numpy()
+    dref = a0 * oK._np_op.diagonal() + a1 * oM._np_op.diagonal()
+    dref[sp.ess_dofs()] = 1.0
+    assert _rel(d, dref) < 1e-12
+
+
 @pytest.mark.parametrize("l", [0, 1])
 def test_prolongation_and_transpose(prob, l):
     nc, nf = prob.spaces[l].ndofs, prob.spaces[l + 1].ndofs
