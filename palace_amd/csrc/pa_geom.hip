@@ -78,7 +78,9 @@ void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s) {
                      q1d, m1, d_off, d_nodes, d_attr, d_B, d_G, d_w, g.d_geom);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(s));
-  hipFree(d_off), hipFree(d_nodes), hipFree(d_attr), hipFree(d_B), hipFree(d_G), hipFree(d_w);
+  hipFree(d_off), hipFree(d_nodes), hipFree(d_B), hipFree(d_G), hipFree(d_w);
+  g.d_attr_e = d_attr;
+  g.w1.assign(mesh.qweight1d, mesh.qweight1d + q1d);
 }
 
 }  // namespace pa

@@ -71,6 +71,8 @@ constexpr int kExclBit16 = 1 << 15;  // flag in the slot permutation: this entry
 constexpr int kMaxP1 = 6;  // closed nodes p+1 <= 7
 constexpr int kMaxQ1 = 7;
 
+struct QData;
+
 // Geometry factor data (fem/mesh.hpp:27-69): double[ne][11][Q] in HBM.
 // Dense (non-tensor) element blocks keep it element-blocked for the MFMA kernel instead:
 // double[ceil(ne/16)][11][Qpad][16] (eb == 16).
@@ -80,6 +82,9 @@ struct Geom {
   int dim = 3, sdim = 3, nrows = 11;  // 2-D blocks: 6 rows {attr, w detJ, adj(J)^T/detJ (2x2)}; boundary (2 in 3): 8 rows
   double *d_qw = nullptr;         // quadrature weights (the q_w input of the 2-D curl-curl QFunctions)
   double *d_geom = nullptr;
+  QData *metric = nullptr;        // lazily built G = J^T J [ne][6][Q] (tensor hex blocks), see QData
+  int32_t *d_attr_e = nullptr;    // [ne] element attributes (metric form: coefficient lookup in the kernel)
+  std::vector<double> w1;         // 1-D quadrature weights (tensor hex blocks)
   int refcount = 1;
 };
 
@@ -107,6 +112,10 @@ struct QData {
   double *d = nullptr;
   int ncomp = 0;
   int refcount = 1;
+  // metric form (isotropic coefficients): H = (w / |detJ|) J^T J (six entries) and |detJ| / w per point, a
+  // property of the mesh alone, shared by every operator and p-level on it.  Both pointwise operators follow
+  // from it in registers:  (w / detJ) J^T c J = c H,   w detJ adj^T c adj = c (|detJ| / w) adj(H).
+  bool metric = false;
 };
 
 struct SubOp {
@@ -176,6 +185,7 @@ void finalize_exclusive(pa_op_fwd *op);
 void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x = nullptr,
                       int ess_policy = -1);
 void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
+void launch_nd_hex_metric(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 void launch_h1_hex_apply(const SubOp &so, const double *x, bool masked, hipStream_t s);
 void launch_h1_hex_qdata(SubOp &so, hipStream_t s);

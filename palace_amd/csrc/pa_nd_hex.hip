@@ -86,6 +86,7 @@ struct NDArgs {
   int ess_policy;  // -1, or ParOperator's row fix-up fused in: y[ess] = x[ess] (1) / 0 (0) (rap.cpp:223-233)
   CoeffDev c_mass, c_curl;
   NDTab<P1, Q1> tab;
+  const int32_t *attr_e;     // metric form: element attributes
 #ifdef PA_ABLATION
   int dbg;  // timing experiments only: 1 no E-vector store, 4 no q-data/geometry loads, 8 no gather
 #endif
@@ -361,13 +362,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   // dominant HBM stream) and consume them after the forward contraction.
   // (Matrix-free D at Q1 >= 5 loads its geometry point by point inside the D loop instead: holding
   // 50 doubles across the contraction made those instantiations spill hundreds of registers.)
-  constexpr int NG = QD ? (USE_U ? 6 : 0) + (USE_C ? 6 : 0) : 10;
+  constexpr bool METRIC = QD && ISO;  // q-data = G = J^T J (6 per point), coefficients applied here
+  constexpr int NG = QD ? (METRIC ? (USE_U ? 7 : 6) : (USE_U ? 6 : 0) + (USE_C ? 6 : 0)) : 10;
   constexpr bool LATE = !QD && Q1 >= 5;
   double gd[LATE ? 1 : Q1][NG];
   int attr[LATE ? 1 : Q1];
   const double *glate = a.geom + (size_t)(active ? e : 0) * 11 * Q + ta + Q1 * tb;
   if (QD) {
-    const double *g = a.qdata + (size_t)(active ? e : 0) * NG * Q + ta + Q1 * tb;
+    const double *g = a.qdata + (size_t)(active ? e : 0) * (METRIC ? 7 : NG) * Q + ta + Q1 * tb;
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
       constexpr int gs = LATE ? 0 : 1;
@@ -436,10 +438,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, uin[1], U, CU);
   nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, active, lane_ok, ta, tb, lx, sm, uin[2], U, CU);
 
+  const int attr_m = METRIC ? a.attr_e[active ? e : 0] : 1;
   // D at the Q1 points of this lane's column (hcurl_33 / hdiv_33 / hdivmass_33)
 #pragma unroll
   for (int qz = 0; qz < Q1; qz++) {
     constexpr int gq = LATE ? 0 : 1;  // index stride into the (pre)loaded geometry / q-data
+    if (METRIC) {
+      // q-data = H = (w / |detJ|) J^T J {00, 01, 02, 11, 12, 22} and, for the mass part, |detJ| / w:
+      //   (w / detJ) J^T c J = c H,   w detJ adj^T c adj = c (|detJ| / w) adj(H)
+      const double *H = &gd[gq * qz][0];
+      if (USE_U) {
+        const double cm = gd[gq * qz][6] * a.c_mass.mat[9 * coeff_index(a.c_mass, attr_m)];
+        const double m[6] = {cm * (H[3] * H[5] - H[4] * H[4]), cm * (H[2] * H[4] - H[1] * H[5]), cm * (H[1] * H[4] - H[2] * H[3]),
+                             cm * (H[0] * H[5] - H[2] * H[2]), cm * (H[1] * H[2] - H[0] * H[4]), cm * (H[0] * H[3] - H[1] * H[1])};
+        sym_mv(m, U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
+      }
+      if (USE_C) {
+        const double cc = a.c_curl.mat[9 * coeff_index(a.c_curl, attr_m)];
+        const double m[6] = {cc * H[0], cc * H[1], cc * H[2], cc * H[3], cc * H[4], cc * H[5]};
+        sym_mv(m, CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one point at a time: keeps the live range of the temporaries short
+      continue;
+    }
     if (QD) {
       if (USE_U) sym_mv(&gd[gq * qz][0], U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
       if (USE_C)
@@ -541,7 +562,14 @@ static bool use_direct(const SubOp &so) { return so.d_perm_x && so.d_shared && s
 template <int P1, int Q1, bool U, bool C>
 static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   const bool evec = a.ye != nullptr;
-  if (a.qdata) {
+  if (a.qdata && a.attr_e) {  // metric form of the q-data
+    if (evec && a.direct && Q1 <= 4)
+      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true, true, true, (Q1 <= 4)>), grid, block, lds, s, a);
+    else if (evec)
+      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true, true, true>), grid, block, lds, s, a);
+    else
+      hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true, false, true>), grid, block, lds, s, a);
+  } else if (a.qdata) {
     if (evec && a.direct && Q1 <= 4)
       hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false, true, true, (Q1 <= 4)>), grid, block, lds, s, a);
     else if (evec)
@@ -572,6 +600,8 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
   a.ess_policy = (a.direct && masked) ? ess_policy : -1;
   a.geom = so.geom->d_geom;
   a.qdata = so.qd ? so.qd->d : nullptr;
+  a.attr_e = nullptr;
+  if (so.qd && so.qd->metric) a.attr_e = so.geom->d_attr_e;
   a.x = x;
   a.y = y;
   a.ye = ye;
@@ -742,6 +772,45 @@ void launch_nd_hex_qdata(SubOp &so, hipStream_t s) {
                      so.geom->d_geom, cm, cc, (int)use_u, (int)use_c, qd->d);
   PA_HIP(hipGetLastError());
   so.qd = qd;
+}
+
+// Metric q-data from the geometry factors: adjJt33(adj) = J / detJ (the trick hdiv_33_qf.h uses), detJ =
+// (w detJ) / w; stored per point: H = (w / |detJ|) J^T J (six entries) and |detJ| / w.  One thread per point.
+__global__ void nd_hex_metric_kernel(const int ne, const int q1d, const double *__restrict__ geom,
+                                     const double *__restrict__ w1, double *__restrict__ qd) {
+  const int Q = q1d * q1d * q1d;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / Q);
+  if (e >= ne) return;
+  const int q = (int)(gid - (long long)e * Q);
+  const double *g = geom + (size_t)e * 11 * Q;
+  double adj[9], Jl[9];
+  for (int c = 0; c < 9; c++) adj[c] = g[(2 + c) * Q + q];
+  adjJt33(adj, Jl);
+  const double w = w1[q % q1d] * w1[(q / q1d) % q1d] * w1[q / (q1d * q1d)];
+  const double det = g[Q + q] / w;
+  const double k = w * fabs(det);  // (w / |det|) (det Jl)^T (det Jl) = w |det| Jl^T Jl
+  double *out = qd + (size_t)e * 7 * Q + q;
+  int o = 0;
+  for (int i = 0; i < 3; i++)
+    for (int j = i; j < 3; j++)
+      out[(o++) * Q] = k * (Jl[3 * i] * Jl[3 * j] + Jl[3 * i + 1] * Jl[3 * j + 1] + Jl[3 * i + 2] * Jl[3 * j + 2]);
+  out[6 * Q] = fabs(det) / w;
+}
+
+void launch_nd_hex_metric(SubOp &so, hipStream_t s) {
+  Geom &g = *so.geom;
+  auto *qd = new QData;
+  qd->ncomp = 7, qd->metric = true;
+  qd->d = dev_alloc<double>((size_t)so.ne * 7 * so.Q);
+  double *d_w = dev_upload(g.w1.data(), g.w1.size(), s);
+  const long long n = (long long)so.ne * so.Q;
+  hipLaunchKernelGGL(nd_hex_metric_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, so.ne, so.q1d, g.d_geom, d_w,
+                     qd->d);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(s));
+  hipFree(d_w);
+  g.metric = qd;  // the geometry data holds the first reference
 }
 
 // ---- diagonal -------------------------------------------------------------------------------

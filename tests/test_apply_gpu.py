@@ -68,7 +68,7 @@ def test_apply_cylinder_mesh(cylinder_mesh, p, qf):
 
 @pytest.mark.parametrize("p", [1, 2, 3, 4])
 @pytest.mark.parametrize("qf", ["hdiv", "hcurl", "hdivmass"])
-@pytest.mark.parametrize("variant", ["matrix_free", "nonsym", "iso_matrix_free", "atomic"])
+@pytest.mark.parametrize("variant", ["matrix_free", "nonsym", "iso_matrix_free", "atomic", "metric", "iso_qdata"])
 def test_apply_variants(cylinder_mesh, monkeypatch, p, qf, variant):
     """The other forms of the same kernel: D recomputed from the geometry factors exactly as the
     reference QFunctions do (PALACE_AMD_QDATA=0: general / isotropic coefficient; always for a
@@ -77,11 +77,16 @@ def test_apply_variants(cylinder_mesh, monkeypatch, p, qf, variant):
         monkeypatch.setenv("PALACE_AMD_QDATA", "0")
     if variant == "atomic":
         monkeypatch.setenv("PALACE_AMD_SCATTER", "atomic")
+    if variant == "metric":     # isotropic coefficients through H = (w/|detJ|) J^T J for every operator type
+        monkeypatch.setenv("PALACE_AMD_DSTAGE", "metric")
+    if variant == "iso_qdata":  # ... and through the per-operator packed D
+        monkeypatch.setenv("PALACE_AMD_DSTAGE", "qdata")
     mesh = _multi_attr(cylinder_mesh)
     q1d = p + 1
     nd = NDHexSpace(mesh, p)
     geom = ceed.GeomFactorData(mesh, q1d)
-    kind = {"matrix_free": "aniso", "nonsym": "nonsym", "iso_matrix_free": "scalar", "atomic": "aniso"}[variant]
+    kind = {"matrix_free": "aniso", "nonsym": "nonsym", "iso_matrix_free": "scalar", "atomic": "aniso", "metric": "scalar",
+            "iso_qdata": "scalar"}[variant]
     _, b_a = util.make_ctx(kind, nattr=3)
     _, b_s = util.make_ctx("scalar", nattr=3)
     if qf == "hdiv":
