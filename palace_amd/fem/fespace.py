@@ -288,3 +288,74 @@ class H1HexSpace:
             lex = (I + n1 * (J + n1 * K)).ravel()
             out.append(self.elem_dof_lex[el][:, lex].ravel())
         return np.unique(np.concatenate(out)).astype(np.int32) if out else np.zeros(0, np.int32)
+
+
+class NDHexBoundaryBlock:
+    """Boundary-element block of an NDHexSpace over a set of boundary faces: 2-D Nedelec quadrilaterals in 3-D
+    space whose dofs are the adjacent hexahedron's dofs on that face (what Palace builds for surface integrators,
+    fem/libceed/restriction.cpp:15-111 `GetFaceDofsFromAdjacentElement`).  The quad inherits the (u, v) axes of
+    the element's local face, so its tensor dofs are the element's lexicographic face dofs, signs included.
+
+    Local dof order: u-component block a + p b (a open along u, b closed along v), then the v-component block
+    a + (p + 1) b (a closed along u, b open along v).  Quadrature: q1d x q1d tensor rule, q = qu + q1d qv."""
+
+    def __init__(self, space: NDHexSpace, face_mask=None, attr=None):
+        from .mesh import HEX_FACE_AXES
+
+        mesh, p = space.mesh, space.p
+        self.space, self.p = space, p
+        fm = mesh.boundary_face_mask if face_mask is None else face_mask
+        bmask = fm[mesh.elem_faces]
+        offs, signs, nodes, faces = [], [], [], []
+        for lf, (nax, side, uax, vax) in enumerate(HEX_FACE_AXES):
+            el = np.nonzero(bmask[:, lf])[0]
+            if el.size == 0:
+                continue
+            lex = []
+            for comp, na, nb in ((uax, p, p + 1), (vax, p + 1, p)):
+                B, A = np.meshgrid(np.arange(nb), np.arange(na), indexing="ij")   # a fastest
+                ijk = [None, None, None]
+                ijk[nax] = np.full(A.size, side * p)
+                ijk[uax], ijk[vax] = A.ravel(), B.ravel()
+                lex.append(nd_lex_index(p, comp, *ijk))
+            lex = np.concatenate(lex)
+            offs.append(space.elem_dof_lex[el][:, lex])
+            signs.append(space.elem_sign_lex[el][:, lex])
+            iv, iu = np.meshgrid(np.arange(3), np.arange(3), indexing="ij")   # node n = iu + 3 iv
+            nijk = [None, None, None]
+            nijk[nax] = np.full(9, side * 2)
+            nijk[uax], nijk[vax] = iu.ravel(), iv.ravel()
+            lat = nijk[0] + 3 * (nijk[1] + 3 * nijk[2])
+            nodes.append(mesh.elem_nodes[el][:, lat])
+            faces.append(mesh.elem_faces[el, lf])
+        self.offsets = np.concatenate(offs).astype(np.int32)
+        self.orients = np.concatenate(signs) < 0
+        self.elem_nodes = np.concatenate(nodes).astype(np.int64)
+        self.faces = np.concatenate(faces)
+        self.nodes = mesh.x
+        self.ne, self.P = self.offsets.shape
+        self.attr = np.ones(self.ne, dtype=np.int32) if attr is None else np.asarray(attr, dtype=np.int32)
+
+    def tables(self, q1d):
+        """(interp [2, Q, P], mesh_grad [2, Q, 9], weights [Q]) of the quad at the q1d x q1d Gauss-Legendre rule."""
+        from .basis1d import Tables1D
+        from .mesh import _q2_1d
+
+        p = self.p
+        t = Tables1D(p, q1d)
+        Q = q1d * q1d
+        interp = np.zeros((2, Q, self.P))
+        for qv in range(q1d):
+            for qu in range(q1d):
+                q = qu + q1d * qv
+                interp[0, q, : p * (p + 1)] = np.outer(t.Bc[qv], t.Bo[qu]).ravel()     # index a + p b
+                interp[1, q, p * (p + 1):] = np.outer(t.Bo[qv], t.Bc[qu]).ravel()      # index a + (p + 1) b
+        B2, G2 = _q2_1d(t.qx)
+        grad = np.zeros((2, Q, 9))
+        for qv in range(q1d):
+            for qu in range(q1d):
+                q = qu + q1d * qv
+                grad[0, q] = np.outer(B2[qv], G2[qu]).ravel()   # node iu + 3 iv
+                grad[1, q] = np.outer(G2[qv], B2[qu]).ravel()
+        w = np.outer(t.qw, t.qw).ravel()
+        return interp, grad, w

@@ -159,3 +159,47 @@ def test_dense_matches_tensor_kernel(cylinder_mesh):
         _lib.check(_lib.load().pa_op_mult_essential(o.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert float((y1 - y2).abs().max() / y2.abs().max()) < REL
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_hex_boundary_mass(cylinder_mesh, p):
+    """Surface Nedelec mass (f_apply_hcurl_32) on the boundary quadrilaterals of a hexahedral space, alone and as a
+    second sub-operator next to the sum-factorised volume operator (impedance-type boundary term)."""
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem.fespace import NDHexBoundaryBlock, NDHexSpace
+
+    mesh = cylinder_mesh
+    nd = NDHexSpace(mesh, p)
+    blk = NDHexBoundaryBlock(nd, attr=1 + (np.arange(int(mesh.boundary_face_mask[mesh.elem_faces].sum())) % 2))
+    interp, grad, w = blk.tables(p + 1)
+    bgeom = ceed.DenseGeomFactorData(blk.elem_nodes, blk.nodes, blk.attr, grad, w)
+    J = np.einsum("dqn,eni->eqid", grad, blk.nodes[blk.elem_nodes])
+    og = po.build_geom_factor_32(blk.attr.astype(np.float64), w, np.transpose(J, (0, 1, 3, 2)).reshape(blk.ne, -1, 6))
+    got = bgeom.to_numpy()
+    assert np.abs(got - og).max() <= 1e-13 * np.abs(og).max()
+    c3, b3 = util.make_ctx("aniso", 2)
+    block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, blk.offsets, interp, None, orients=blk.orients)
+    bop = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(bgeom, block, ceed.QF_HCURL_32, b3, ceed.EVAL_INTERP).finalize()
+    orc = po.CeedOperatorOracle(nd.ndofs, blk.offsets, blk.orients, interp, np.zeros((1, len(w), blk.P)), og,
+                                po.QF_HCURL_32, c3)
+    x = np.random.default_rng(p).uniform(-1, 1, nd.ndofs)
+    ref = orc.apply_add(x, np.zeros(nd.ndofs))
+    xd = torch.from_numpy(x).cuda()
+    yb = torch.empty_like(xd)
+    bop.mult(xd, yb)
+    assert np.abs(yb.cpu().numpy() - ref).max() < REL * np.abs(ref).max()
+    # volume K + M (tensor kernel) and the boundary term in one operator
+    q1d = p + 1
+    vgeom = ceed.GeomFactorData(mesh, q1d)
+    _, bs = util.make_ctx("scalar", int(mesh.attr.max()))
+    _, bi = util.make_ctx("identity")
+    vol = ceed.curlcurlmass_operator(vgeom, nd, bs, bi)
+    both = (ceed.Operator(nd.ndofs, nd.ndofs)
+            .add_integrator(vgeom, nd, ceed.QF_HDIVMASS_33, np.concatenate([bs, bi]), ceed.EVAL_CURL | ceed.EVAL_INTERP)
+            .add_dense_integrator(bgeom, block, ceed.QF_HCURL_32, b3, ceed.EVAL_INTERP).finalize())
+    yv, ya = torch.empty_like(xd), torch.empty_like(xd)
+    vol.mult(xd, yv)
+    both.mult(xd, ya)
+    assert float((ya - (yv + yb)).abs().max()) < 1e-13 * float(yv.abs().max())
