@@ -240,6 +240,13 @@ int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream);
  * y[ess] = x[ess] (diag_policy 1, DIAG_ONE) or 0 (DIAG_ZERO).  *handled = 1 if the rows were written, 0 if the
  * caller still has to do it. */
 int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_policy, void *stream, int *handled);
+/* Two right-hand sides in one pass: y0 = A x0, y1 = A x1.  This is what ComplexWrapperOperator::Mult needs
+ * (linalg/operator.cpp:98-134: Ar and Ai are each applied to the real and to the imaginary part); the element's index
+ * arrays and D-stage data are read once for both vectors.  The *_essential_diag form is the two-vector version of
+ * pa_op_mult_essential_diag. */
+int pa_op_mult2(pa_op *op, const double *x0, const double *x1, double *y0, double *y1, void *stream);
+int pa_op_mult2_essential_diag(pa_op *op, const double *x0, const double *x1, double *y0, double *y1, int diag_policy,
+                               void *stream, int *handled);
 /* Operator::AssembleDiagonal (operator.cpp:116-143): diag = diag(A) (zeroed first). */
 int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream);
 /* CeedOperatorFullAssemble (operator.cpp:455-523; BilinearForm::FullAssemble / ParOperator::ParallelAssemble,

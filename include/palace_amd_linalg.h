@@ -112,6 +112,11 @@ void pa_solver_destroy(pa_solver *S);
  *     preconditioner applied to the real and imaginary parts (linalg/gmg.cpp:147-168). ------------ */
 int pa_complex_op_mult(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, const double *xr, const double *xi,
                        double *yr, double *yi);
+/* Persistent ComplexWrapperOperator (keeps its work vectors): y = (Ar + i Ai) x. */
+typedef struct pa_complex_op pa_complex_op;
+int pa_complex_op_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_complex_op **A);
+int pa_complex_op_apply(pa_complex_op *A, const double *xr, const double *xi, double *yr, double *yi);
+void pa_complex_op_destroy(pa_complex_op *A);
 int pa_complex_gmres_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_solver *precond, double rel_tol,
                             double abs_tol, int max_it, int restart, int print, pa_csolver **S);
 int pa_csolver_mult(pa_csolver *S, const double *br, const double *bi, double *xr, double *xi, int initial_guess);

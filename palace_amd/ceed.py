@@ -260,6 +260,12 @@ class Operator:
                                           C.c_void_p(y.data_ptr()), _stream()))
         return y
 
+    def mult2(self, x0, x1, y0, y1):
+        """y0 = A x0, y1 = A x1 in one pass over the element data (pa_op_mult2)."""
+        _lib.check(_lib.load().pa_op_mult2(self.handle, C.c_void_p(x0.data_ptr()), C.c_void_p(x1.data_ptr()),
+                                           C.c_void_p(y0.data_ptr()), C.c_void_p(y1.data_ptr()), _stream()))
+        return y0, y1
+
     def add_mult(self, x, y, a=1.0):
         if a != 1.0:  # operator.cpp:194
             raise _lib.PalaceAmdError("ceed::Operator::AddMult only supports coefficient = 1.0!")

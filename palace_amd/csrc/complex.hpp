@@ -50,7 +50,7 @@ public:
 class ComplexWrapperOperator : public ComplexOperator {
   const Context *ctx_;
   const Operator *Ar_, *Ai_;
-  mutable Vector t_;
+  mutable Vector t_, t2_;
 
 public:
   ComplexWrapperOperator(const Context &ctx, const Operator *Ar, const Operator *Ai);

@@ -359,6 +359,14 @@ bool Operator::MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) cons
   check(pa_op_mult_essential_diag(op_, x.Data(), y.Data(), diag_one ? 1 : 0, ctx_->stream, &handled));
   return handled != 0;
 }
+void Operator::Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const {
+  check(pa_op_mult2(op_, x0.Data(), x1.Data(), y0.Data(), y1.Data(), ctx_->stream));
+}
+bool Operator::Mult2EssentialDiag(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1, bool diag_one) const {
+  int handled = 0;
+  check(pa_op_mult2_essential_diag(op_, x0.Data(), x1.Data(), y0.Data(), y1.Data(), diag_one ? 1 : 0, ctx_->stream, &handled));
+  return handled != 0;
+}
 void Operator::MultEssential(const Vector &x, Vector &y) const {
   check(pa_op_mult_essential(op_, x.Data(), y.Data(), ctx_->stream));
 }
@@ -445,6 +453,22 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
     else
       linalg::SetSubVector(c, y, d_ess_, n_ess_, 0.0);
   }
+}
+
+void ParOperator::Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const {
+  const Context &c = *ctx_;
+  if (A_fused_) {
+    const bool one = policy_ == DiagonalPolicy::DIAG_ONE;
+    if (!A_fused_->Mult2EssentialDiag(x0, x1, y0, y1, one)) {
+      if (one)
+        linalg::SetSubVector(c, y0, d_ess_, n_ess_, x0), linalg::SetSubVector(c, y1, d_ess_, n_ess_, x1);
+      else
+        linalg::SetSubVector(c, y0, d_ess_, n_ess_, 0.0), linalg::SetSubVector(c, y1, d_ess_, n_ess_, 0.0);
+    }
+    return;
+  }
+  Mult(x0, y0);
+  Mult(x1, y1);
 }
 
 void ParOperator::AddMult(const Vector &x, Vector &y, double a) const {

@@ -129,6 +129,9 @@ public:
   void MultEssential(const Vector &x, Vector &y) const;
   // the same + y[ess] = x[ess] | 0 inside the E^T kernels; returns false if the caller must fix the rows up
   bool MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const;
+  // two right-hand sides in one pass over the element data (pa_op_mult2 / pa_op_mult2_essential_diag)
+  void Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const;
+  bool Mult2EssentialDiag(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1, bool diag_one) const;
 };
 
 }  // namespace ceed
@@ -182,6 +185,8 @@ public:
   // y += a A x  (rap.cpp:277-318) / its transpose (:320-361)
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
   void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const { AddMult(x, y, a); }
+  // y0 = A x0, y1 = A x1: the real and imaginary parts of a complex vector through one real operator
+  void Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const;
   // b -= A_unconstrained (x restricted to the essential dofs); b[ess] = x[ess] | 0  (rap.cpp:56-82)
   void EliminateRHS(const Vector &x, Vector &b) const;
   void AssembleDiagonal(Vector &diag) const override;

@@ -332,7 +332,7 @@ static void free_sub(SubOp *so) {
   if (!so) return;
   hipFree(so->d_lidx);
   hipFree(so->d_sidx), hipFree(so->d_sidx_bc), hipFree(so->d_perm), hipFree(so->d_perm_x), hipFree(so->d_shared), hipFree(so->d_shared_bc);
-  hipFree(so->d_ye), hipFree(so->d_tptr), hipFree(so->d_tent);
+  hipFree(so->d_ye), hipFree(so->d_ye2), hipFree(so->d_tptr), hipFree(so->d_tent);
   if (so->qd && --so->qd->refcount == 0) {
     hipFree(so->qd->d);
     delete so->qd;
@@ -399,6 +399,25 @@ void finalize_exclusive(pa_op *op) {
   so->d_shared = dev_upload(shared.data(), shared.size());
   so->n_shared = (int)shared.size();
   so->h_shared = std::move(shared);
+}
+
+// y0 = A x0, y1 = A x1 (overwrite).  One pass over the index / q-data streams when the operator is a single
+// H(curl) hex block on the q-data path, else two applies.
+static bool apply2(pa_op *op, const double *x0, const double *x1, double *y0, double *y1, hipStream_t s, bool masked,
+                   int ess_policy) {
+  PA_REQUIRE(op && x0 && x1 && y0 && y1, "null argument");
+  PA_REQUIRE(x0 != y0 && x0 != y1 && x1 != y0 && x1 != y1 && y0 != y1, "in-place apply is not supported");
+  if (op->subs.size() == 1 && op->dsubs.empty() && nd_hex_supports_two_rhs(*op->subs[0])) {
+    SubOp *so = op->subs[0];
+    if (!so->d_ye2) so->d_ye2 = dev_alloc<double>((size_t)so->ne * so->P);
+    const int pol = nd_hex_fuses_essential(*so) ? ess_policy : -1;
+    launch_nd_hex_apply(*so, x0, y0, so->d_ye, masked, s, false, pol, x1, y1, so->d_ye2);
+    launch_et_gather2(*so, y0, y1, false, s, x0, x1, pol);
+    return pol >= 0;
+  }
+  apply(op, x0, y0, true, s, masked, -1);
+  apply(op, x1, y1, true, s, masked, -1);
+  return false;
 }
 
 void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s) { apply(op, x, y, true, s); }
@@ -633,6 +652,18 @@ int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_po
     const bool fuse = op->subs.size() == 1 && op->dsubs.empty() && nd_hex_fuses_essential(*op->subs[0]);
     apply(op, x, y, true, (hipStream_t)stream, true, fuse ? (diag_policy ? 1 : 0) : -1);
     *handled = fuse ? 1 : 0;
+  });
+}
+
+int pa_op_mult2(pa_op *op, const double *x0, const double *x1, double *y0, double *y1, void *stream) {
+  return guarded([&] { apply2(op, x0, x1, y0, y1, (hipStream_t)stream, false, -1); });
+}
+
+int pa_op_mult2_essential_diag(pa_op *op, const double *x0, const double *x1, double *y0, double *y1, int diag_policy,
+                               void *stream, int *handled) {
+  return guarded([&] {
+    PA_REQUIRE(op && op->has_essential && handled, "pa_op_set_essential has not been called");
+    *handled = apply2(op, x0, x1, y0, y1, (hipStream_t)stream, true, diag_policy ? 1 : 0) ? 1 : 0;
   });
 }
 

@@ -140,6 +140,7 @@ struct SubOp {
   std::vector<int32_t> h_sidx;   // host copy (needed to build d_sidx_bc)
   // E^T as a gather (default): E-vector scratch and the CSR transpose of lidx
   double *d_ye = nullptr;      // [ne][P]
+  double *d_ye2 = nullptr;     // second E-vector (two right-hand sides), allocated on first use
   int32_t *d_tptr = nullptr;   // [lsize + 1]
   int32_t *d_tent = nullptr;   // [ne * P] signed positions into d_ye
   std::vector<double> Bc, Gc, Bo;  // full 1-D tables [q1d][n] (host)
@@ -179,7 +180,11 @@ void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t
 // kernels (pa_geom.hip, pa_nd_hex.hip, pa_h1_hex.hip)
 void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s);
 void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
-                         bool accumulate = true, int ess_policy = -1);
+                         bool accumulate = true, int ess_policy = -1, const double *x1 = nullptr, double *y1 = nullptr,
+                         double *ye1 = nullptr);
+bool nd_hex_supports_two_rhs(const SubOp &so);
+void launch_et_gather2(const SubOp &so, double *y0, double *y1, bool accumulate, hipStream_t s, const double *x0,
+                       const double *x1, int ess_policy);
 bool nd_hex_fuses_essential(const SubOp &so);
 void finalize_exclusive(pa_op_fwd *op);
 void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x = nullptr,

@@ -331,6 +331,26 @@ int pa_complex_op_mult(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, const doub
     A.Mult(x, y);
   });
 }
+struct pa_complex_op {
+  std::unique_ptr<ComplexWrapperOperator> A;
+};
+int pa_complex_op_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_complex_op **A) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && (Ar || Ai) && A, "null argument");
+    auto *p = new pa_complex_op;
+    p->A = std::make_unique<ComplexWrapperOperator>(ctx->ctx, Ar ? Ar->op.get() : nullptr, Ai ? Ai->op.get() : nullptr);
+    *A = p;
+  });
+}
+int pa_complex_op_apply(pa_complex_op *A, const double *xr, const double *xi, double *yr, double *yi) {
+  return guarded([&] {
+    PA_REQUIRE(A && xr && xi && yr && yi, "null argument");
+    const int n = A->A->Height();
+    ComplexVector x(const_cast<double *>(xr), const_cast<double *>(xi), n), y(yr, yi, n);
+    A->A->Mult(x, y);
+  });
+}
+void pa_complex_op_destroy(pa_complex_op *A) { delete A; }
 int pa_complex_gmres_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_solver *precond, double rel_tol,
                             double abs_tol, int max_it, int restart, int print, pa_csolver **S) {
   return guarded([&] {

@@ -81,6 +81,9 @@ struct NDArgs {
   const double *x;
   double *y;   // L-vector target of the atomic scatter (EVEC == false)
   double *ye;  // E-vector target [ne][P], sorted order, unsigned (EVEC == true)
+  // second right-hand side (NRHS == 2: y1 = A x1 in the same pass over the index and q-data streams)
+  const double *x1;
+  double *y1, *ye1;
   int direct;      // EVEC: entries flagged kExclBit16 in perm go straight to y (they are the only copy)
   int accumulate;  // for those: y += v instead of y = v
   int ess_policy;  // -1, or ParOperator's row fix-up fused in: y[ess] = x[ess] (1) / 0 (0) (rap.cpp:223-233)
@@ -344,7 +347,9 @@ constexpr int kWavesPerBlock = 2;  // small workgroups pack the 160 KB LDS tight
 // the geometry factors: 6 (12) doubles per point instead of 11, and 9 (18) FMAs instead of ~60.
 // DIRECT (only with EVEC && QD): entries flagged in `perm` are the only copy of their dof and are stored
 // straight into y.
-template <int P1, int Q1, bool USE_U, bool USE_C, bool ISO, bool EVEC, bool QD, bool DIRECT = false>
+// NRHS == 2: two input vectors share one pass over the element's index arrays and D-stage data (the complex
+// operator's Ar (xr, xi) / Ai (xr, xi) pairs, linalg/operator.cpp:98-134); the pipeline runs twice per element.
+template <int P1, int Q1, bool USE_U, bool USE_C, bool ISO, bool EVEC, bool QD, bool DIRECT = false, int NRHS = 1>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(const NDArgs<P1, Q1> a) {
   using L = NDLayout<P1, Q1>;
   constexpr int Q = Q1 * Q1 * Q1;
@@ -399,19 +404,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   // E: sorted-order gather, staged through LDS into tensor order
   constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + L::T - 1) / L::T;
   int lp[NPL];
+  int sg[NRHS > 1 ? NPL : 1];  // NRHS > 1: the index words are loaded once and kept
 #pragma unroll
   for (int r = 0; r < NPL; r++) {
     const int m = t + L::T * r;
     lp[r] = 0;
+    if (NRHS > 1) sg[r] = 0;
     if (active && m < PP) {
-      const int s = a.sidx_in[(size_t)e * PP + m];
       lp[r] = a.perm[(size_t)e * PP + m];  // may carry kExclBit16 (used by the store below)
+      if (NRHS > 1) sg[r] = a.sidx_in[(size_t)e * PP + m];
+    }
+  }
+#pragma unroll  // straight-line copies: the table operands are re-read from the kernel arguments, not held in a loop
+  for (int rhs = 0; rhs < NRHS; rhs++) {
+  const double *xin = (NRHS > 1 && rhs) ? a.x1 : a.x;
+  double *yout = (NRHS > 1 && rhs) ? a.y1 : a.y;
+  double *yeout = (NRHS > 1 && rhs) ? a.ye1 : a.ye;
+#pragma unroll
+  for (int r = 0; r < NPL; r++) {
+    const int m = t + L::T * r;
+    if (active && m < PP) {
+      const int s = (NRHS > 1) ? sg[r] : a.sidx_in[(size_t)e * PP + m];
       const int d = s >= 0 ? s : -1 - s;
       // essential dofs are flagged in the gather index: read as zero (ParOperator's tx[ess] = 0)
 #ifdef PA_ABLATION
-      const double xv = (a.dbg & 8) ? (double)d : ((d & kEssBit) ? 0.0 : a.x[d & ~kEssBit]);
+      const double xv = (a.dbg & 8) ? (double)d : ((d & kEssBit) ? 0.0 : xin[d & ~kEssBit]);
 #else
-      const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
+      const double xv = (d & kEssBit) ? 0.0 : xin[d & ~kEssBit];
 #endif
       sm[DIRECT ? (lp[r] & (kExclBit16 - 1)) : lp[r]] = s >= 0 ? xv : -xv;
     }
@@ -529,23 +548,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
 #endif
       if (EVEC) {
         if (DIRECT && (lp[r] & kExclBit16)) {  // only copy of this dof: no E-vector round trip, no gather
-          const int s = a.sidx_in[(size_t)e * PP + m];  // carries kEssBit on essential dofs when masked
+          const int s = (NRHS > 1) ? sg[r] : a.sidx_in[(size_t)e * PP + m];  // carries kEssBit on essential dofs when masked
           const int df = s >= 0 ? s : -1 - s, d = df & ~kEssBit;
-          double *dst = &a.y[d];
+          double *dst = &yout[d];
           const double sv = s >= 0 ? v : -v;
           if ((df & kEssBit) && a.ess_policy >= 0)
-            *dst = a.ess_policy ? a.x[d] : 0.0;
+            *dst = a.ess_policy ? xin[d] : 0.0;
           else
             *dst = a.accumulate ? *dst + sv : sv;
         } else {
-          a.ye[(size_t)e * PP + m] = v;
+          yeout[(size_t)e * PP + m] = v;
         }
       } else {
         const int s = a.sidx[(size_t)e * PP + m];
-        unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], s >= 0 ? v : -v);
+        unsafeAtomicAdd(&yout[s >= 0 ? s : -1 - s], s >= 0 ? v : -v);
       }
     }
   }
+  if (NRHS > 1) wave_sync();  // the LDS strip is reused by the next right-hand side
+  }  // rhs
 }
 
 template <int P1, int Q1>
@@ -562,6 +583,20 @@ static bool use_direct(const SubOp &so) { return so.d_perm_x && so.d_shared && s
 template <int P1, int Q1, bool U, bool C>
 static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   const bool evec = a.ye != nullptr;
+  if (a.x1) {  // two right-hand sides (q-data forms with the E-vector, Q1 <= 4; the caller checks)
+    if (a.attr_e) {
+      if (a.direct)
+        hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true, true, true, (Q1 <= 4), (Q1 <= 4 ? 2 : 1)>), grid, block, lds, s, a);
+      else
+        hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true, true, true, false, (Q1 <= 4 ? 2 : 1)>), grid, block, lds, s, a);
+    } else {
+      if (a.direct)
+        hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false, true, true, (Q1 <= 4), (Q1 <= 4 ? 2 : 1)>), grid, block, lds, s, a);
+      else
+        hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, false, true, true, false, (Q1 <= 4 ? 2 : 1)>), grid, block, lds, s, a);
+    }
+    return;
+  }
   if (a.qdata && a.attr_e) {  // metric form of the q-data
     if (evec && a.direct && Q1 <= 4)
       hipLaunchKernelGGL((nd_hex_apply_kernel<P1, Q1, U, C, true, true, true, (Q1 <= 4)>), grid, block, lds, s, a);
@@ -588,7 +623,7 @@ static void launch_iso(const NDArgs<P1, Q1> &a, bool iso, dim3 grid, dim3 block,
 
 template <int P1, int Q1>
 static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
-                      bool accumulate, int ess_policy) {
+                      bool accumulate, int ess_policy, const double *x1, double *y1, double *ye1) {
   using L = NDLayout<P1, Q1>;
   NDArgs<P1, Q1> a;
   a.ne = so.ne;
@@ -605,6 +640,7 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
   a.x = x;
   a.y = y;
   a.ye = ye;
+  a.x1 = x1, a.y1 = y1, a.ye1 = ye1;
   fill_tab(so, a.tab);
 #ifdef PA_ABLATION
   a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
@@ -651,9 +687,11 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
 
 // ye != nullptr: write the element-local results (E-vector) instead of scattering atomically into y
 // masked: gather through the essential-dof-flagged index array (pa_op_set_essential)
+bool nd_hex_supports_two_rhs(const SubOp &so) { return so.fe_type == PA_FE_HCURL && so.qd && so.d_ye && so.q1d <= 4; }
+
 void launch_nd_hex_apply(const SubOp &so, const double *x, double *y, double *ye, bool masked, hipStream_t s,
-                         bool accumulate, int ess_policy) {
-  PA_ND_DISPATCH(launch_pq, so, x, y, ye, masked, s, accumulate, ess_policy)
+                         bool accumulate, int ess_policy, const double *x1, double *y1, double *ye1) {
+  PA_ND_DISPATCH(launch_pq, so, x, y, ye, masked, s, accumulate, ess_policy, x1, y1, ye1)
 }
 
 // ---- E^T as a gather: y_d (+)= sum over the element-local copies of dof d -----------------------
@@ -696,6 +734,43 @@ __global__ void et_gather_kernel(const int n, const int32_t *__restrict__ tptr, 
     s += t0 >= 0 ? v0 : -v0;
   }
   y[d] = accumulate ? y[d] + s : s;
+}
+
+// the same for two E-vector / y pairs with one read of the transpose map
+__global__ void et_gather2_kernel(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                                  const double *__restrict__ ye0, const double *__restrict__ ye1, double *__restrict__ y0,
+                                  double *__restrict__ y1, const int accumulate, const int32_t *__restrict__ list,
+                                  const double *__restrict__ x0, const double *__restrict__ x1, const int ess_policy) {
+  const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k0 >= n) return;
+  const int dl = list ? list[k0] : k0;
+  const int d = dl & ~kEssBit;
+  if ((dl & kEssBit) && ess_policy >= 0) {
+    y0[d] = ess_policy ? x0[d] : 0.0;
+    y1[d] = ess_policy ? x1[d] : 0.0;
+    return;
+  }
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = tptr[d]; k < tptr[d + 1]; k++) {
+    const int t = tent[k];
+    const int u = t >= 0 ? t : -1 - t;
+    const double v0 = ye0[u], v1 = ye1[u];
+    s0 += t >= 0 ? v0 : -v0;
+    s1 += t >= 0 ? v1 : -v1;
+  }
+  y0[d] = accumulate ? y0[d] + s0 : s0;
+  y1[d] = accumulate ? y1[d] + s1 : s1;
+}
+
+void launch_et_gather2(const SubOp &so, double *y0, double *y1, bool accumulate, hipStream_t s, const double *x0,
+                       const double *x1, int ess_policy) {
+  const bool dir = use_direct(so);
+  const int n = dir ? so.n_shared : so.lsize;
+  const int32_t *list = dir ? ((ess_policy >= 0 && so.d_shared_bc) ? so.d_shared_bc : so.d_shared) : nullptr;
+  if (n == 0) return;
+  hipLaunchKernelGGL(et_gather2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, so.d_tptr, so.d_tent, so.d_ye, so.d_ye2, y0,
+                     y1, accumulate ? 1 : 0, list, x0, x1, (dir && so.d_shared_bc) ? ess_policy : -1);
+  PA_HIP(hipGetLastError());
 }
 
 void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y,

@@ -332,6 +332,30 @@ def gmg(ctx, A_levels, P_levels, coarse: Solver, cycle_it=1, smooth_it=1, cheby_
 
 # ---- complex layer (ComplexVector = a pair of real tensors) ------------------------------------
 
+class ComplexOperator:
+    """Persistent ComplexWrapperOperator (linalg/operator.cpp:58-134): y = (Ar + i Ai) x."""
+
+    def __init__(self, ctx, Ar, Ai):
+        self.ctx, self._keep = ctx, (Ar, Ai)
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_complex_op_create(ctx.handle, Ar.handle if Ar else None, Ai.handle if Ai else None,
+                                             C.byref(self.handle)))
+
+    def mult(self, xr, xi, yr, yi):
+        _lib.check(_L().pa_complex_op_apply(self.handle, C.c_void_p(xr.data_ptr()), C.c_void_p(xi.data_ptr()),
+                                            C.c_void_p(yr.data_ptr()), C.c_void_p(yi.data_ptr())))
+        return yr, yi
+
+    def __del__(self):
+        try:
+            L = _L()
+            L.pa_complex_op_destroy.restype = None
+            L.pa_complex_op_destroy.argtypes = [C.c_void_p]
+            L.pa_complex_op_destroy(self.handle)
+        except Exception:
+            pass
+
+
 def complex_mult(ctx, Ar, Ai, xr, xi, yr, yi):
     """ComplexWrapperOperator::Mult (linalg/operator.cpp:98-134): y = (Ar + i Ai) x."""
     _lib.check(_L().pa_complex_op_mult(ctx.handle, Ar.handle if Ar else None, Ai.handle if Ai else None,

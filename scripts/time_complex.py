@@ -1,0 +1,24 @@
+"""Complex operator apply (ComplexWrapperOperator::Mult with Ar = K - w^2 M, Ai = w C) at the bench size."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from palace_amd import ceed, linalg
+from palace_amd.fem.partition import SlabProblem
+ctx = linalg.Context()
+prob = SlabProblem(ctx, 0, 1, 3, 10e6, levels=False)
+nd = prob.spaces[-1]
+mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([-2.08 * 0.3])])
+cond = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([0.05])])
+Ar = linalg.ParOperator(ctx, ceed.curlcurlmass_operator(prob.geom, nd, mass, ceed.coefficient_context(3)), prob.ess[-1], linalg.DIAG_ONE)
+Ai = linalg.ParOperator(ctx, ceed.ndmass_operator(prob.geom, nd, cond), prob.ess[-1], linalg.DIAG_ZERO)
+n = nd.ndofs
+xr, xi = torch.rand(n, dtype=torch.float64, device="cuda"), torch.rand(n, dtype=torch.float64, device="cuda")
+yr, yi = torch.empty_like(xr), torch.empty_like(xr)
+A = linalg.ComplexOperator(ctx, Ar, Ai)
+for _ in range(3): A.mult(xr, xi, yr, yi)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(20): A.mult(xr, xi, yr, yi)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print(f"complex Mult (Ar = K - w^2 M, Ai = w C), {n} complex dofs: {ms:.4f} ms  {n/ms/1e6:.2f} G complex dof/s")

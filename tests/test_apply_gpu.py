@@ -125,6 +125,26 @@ def test_apply_overintegrated(cylinder_mesh, monkeypatch, p, q1d, qf, variant):
     assert _rel(y, ref) < RTOL
 
 
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+@pytest.mark.parametrize("qf", ["hdiv", "hdivmass"])
+@pytest.mark.parametrize("coef", ["scalar", "aniso"])
+def test_two_right_hand_sides(cylinder_mesh, p, qf, coef):
+    """pa_op_mult2: both vectors through one pass (bit-identical to two separate applies: same arithmetic per vector)."""
+    mesh = _multi_attr(cylinder_mesh)
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, p + 1)
+    _, b_a = util.make_ctx(coef, nattr=3)
+    _, b_s = util.make_ctx("scalar", nattr=3)
+    op = ceed.curlcurl_operator(geom, nd, b_a) if qf == "hdiv" else ceed.curlcurlmass_operator(geom, nd, b_s, b_a)
+    rng = np.random.default_rng(4)
+    x0, x1 = _dev(rng.uniform(-1, 1, nd.ndofs)), _dev(rng.uniform(-1, 1, nd.ndofs))
+    y0, y1, r0, r1 = (torch.empty_like(x0) for _ in range(4))
+    op.mult2(x0, x1, y0, y1)
+    op.mult(x0, r0)
+    op.mult(x1, r1)
+    assert torch.equal(y0, r0) and torch.equal(y1, r1)
+
+
 @pytest.mark.parametrize("p_coarse,p_fine", [(1, 3), (2, 3), (1, 2), (2, 4), (1, 4)])
 def test_coarsened_operator(cylinder_mesh, p_coarse, p_fine):
     """CeedOperatorCoarsen: coarse basis on the fine level's quadrature/geometry data."""
