@@ -238,7 +238,30 @@ def main():
         traffic_note = ("FETCH_SIZE + WRITE_SIZE per apply from profiles/r01_apply_pmc.json (separate --pmc passes of the "
                         "same kernels at this size), each divided by the fraction the same counters report on a known "
                         "stream in the same run; " + pmc.get("calibration", "uncalibrated"))
+    # measured peaks of this GPU in the same run: a streaming y = a x + b y over 2 x 0.5 GB
+    # (16 B read + 8 B written per entry) and the FP64 matrix-core micro-kernel; `peak` stays the guide's figure
+    def _event_ms(fn, reps):
+        fn()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a0.record()
+        for _ in range(reps):
+            fn()
+        a1.record()
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1) / reps
+    ns = 1 << 26
+    sx = torch.ones(ns, dtype=torch.float64, device="cuda")
+    sy = torch.ones(ns, dtype=torch.float64, device="cuda")
+    stream_ms = _event_ms(lambda: ctx.axpby(0.5, sx, 0.5, sy), 20)
+    measured_stream = 24.0 * ns / (stream_ms * 1e-3) / 1e9
+    mf = {}
+    mfma_ms = _event_ms(lambda: mf.__setitem__("flops", ctx.bench_mfma_f64(4096, 4096, sx)), 5)
+    measured_mfma = mf["flops"] / (mfma_ms * 1e-3) / 1e12
+    del sx, sy
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "measured_stream_GBps": measured_stream, "frac_of_measured_stream": achieved / measured_stream,
+                "measured_mfma_f64_TFLOPs": measured_mfma,
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                 "kernel": "pa::nd_hex_apply_kernel<3,4,curl,qdata> + pa::et_gather_kernel (E^T)", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -281,6 +304,10 @@ def main():
     tets = None
     if rank == 0 and world == 1 and not args.no_tets:
         tets = tets_leg(p, args.tet_n)
+        for key in ("curlcurl", "curlcurl_mass"):
+            if tets and key in tets:
+                tets[key]["frac_of_measured_mfma_f64"] = tets[key]["table_TFLOPs"] / measured_mfma
+                tets[key]["frac_of_measured_stream"] = tets[key]["algorithmic_GBps"] / measured_stream
 
     cpu = None
     if rank == 0 and not args.no_cpu:

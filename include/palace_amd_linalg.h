@@ -69,6 +69,10 @@ int pa_par_op_assemble_diagonal(pa_par_op *A, double *diag);
 /* --- vectors (linalg/vector.cpp) ------------------------------------------------------------- */
 int pa_vec_dot(pa_context *ctx, const double *x, const double *y, int n, double *result);
 int pa_vec_axpby(pa_context *ctx, double a, const double *x, double b, double *y, int n);
+/* Measurement aid (SURVEY.md 8d "measure both peaks in the same run"): launches n_blocks x 256 threads that each
+ * issue `iters` rounds of eight independent v_mfma_f64_16x16x4_f64; *flops_per_launch receives the flop count.
+ * Time it with events on the context's stream; `scratch` is any device buffer of >= 1 double (never written). */
+int pa_bench_mfma_f64(pa_context *ctx, int iters, int n_blocks, double *scratch, double *flops_per_launch);
 int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed);
 
 /* --- solvers --------------------------------------------------------------------------------- */

@@ -50,55 +50,161 @@ inline int grid_for(long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n);               \
        i += (long long)gridDim.x * blockDim.x)
 
-__global__ void k_fill(double *x, long long n, double s) { PA_STRIDE_LOOP(i, n) x[i] = s; }
-__global__ void k_axpy(double a, const double *__restrict__ x, double *__restrict__ y, long long n) {
-  PA_STRIDE_LOOP(i, n) y[i] += a * x[i];
+// Streaming vector kernels move 16 bytes per lane (one dwordx4 access; 8-byte lanes reach ~0.6-0.7x of that
+// rate on this memory system, MI355X_MICROARCH.md) whenever every pointer is 16-byte aligned; the scalar
+// instantiation serves unaligned sub-vectors and the odd tail entry.
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <int W>
+struct Lane {
+  using type = double;
+};
+template <>
+struct Lane<2> {
+  using type = d2;
+};
+template <int W, class Op>
+__global__ __launch_bounds__(256) void k_ew(const Op op, long long n) {
+  using T = typename Lane<W>::type;
+  const long long nv = n / W;
+  PA_STRIDE_LOOP(i, nv) op.template at<T>(i);
+  if (W > 1) {
+    const long long j = nv * W + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) op.template at<double>(j);
+  }
 }
-__global__ void k_axpby(double a, const double *__restrict__ x, double b, double *__restrict__ y, long long n) {
-  PA_STRIDE_LOOP(i, n) y[i] = a * x[i] + b * y[i];
+template <class T>
+__device__ __forceinline__ T *as(double *p) {
+  return reinterpret_cast<T *>(p);
 }
-__global__ void k_axpbypcz(double a, const double *__restrict__ x, double b, const double *__restrict__ y, double g,
-                           double *__restrict__ z, long long n) {
-  PA_STRIDE_LOOP(i, n) z[i] = a * x[i] + b * y[i] + g * z[i];
+template <class T>
+__device__ __forceinline__ const T *as(const double *p) {
+  return reinterpret_cast<const T *>(p);
 }
+inline uintptr_t bits(const void *p) { return reinterpret_cast<uintptr_t>(p); }
+
+struct OpFill {
+  double *x;
+  double s;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(x)[i] = T{} + s;
+  }
+  uintptr_t align() const { return bits(x); }
+};
+struct OpAxpy {
+  double a;
+  const double *x;
+  double *y;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(y)[i] += a * as<T>(x)[i];
+  }
+  uintptr_t align() const { return bits(x) | bits(y); }
+};
+struct OpAxpby {
+  double a;
+  const double *x;
+  double b;
+  double *y;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(y)[i] = a * as<T>(x)[i] + b * as<T>(y)[i];
+  }
+  uintptr_t align() const { return bits(x) | bits(y); }
+};
+struct OpAxpbypcz {
+  double a;
+  const double *x;
+  double b;
+  const double *y;
+  double g;
+  double *z;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(z)[i] = a * as<T>(x)[i] + b * as<T>(y)[i] + g * as<T>(z)[i];
+  }
+  uintptr_t align() const { return bits(x) | bits(y) | bits(z); }
+};
+struct OpScale {
+  const double *d;
+  double *y;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(y)[i] *= as<T>(d)[i];
+  }
+  uintptr_t align() const { return bits(d) | bits(y); }
+};
+struct OpRecip {
+  double *x;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(x)[i] = 1.0 / as<T>(x)[i];
+  }
+  uintptr_t align() const { return bits(x); }
+};
+struct OpScal {
+  double a;
+  double *x;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(x)[i] *= a;
+  }
+  uintptr_t align() const { return bits(x); }
+};
+struct OpCheb0 {
+  double sr;
+  const double *di, *r;
+  double *d;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(d)[i] = sr * as<T>(di)[i] * as<T>(r)[i];
+  }
+  uintptr_t align() const { return bits(di) | bits(r) | bits(d); }
+};
+struct OpChebK {
+  double sd, sr;
+  const double *di, *r;
+  double *d;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(d)[i] = sd * as<T>(d)[i] + sr * as<T>(di)[i] * as<T>(r)[i];
+  }
+  uintptr_t align() const { return bits(di) | bits(r) | bits(d); }
+};
+// one Chebyshev step around the operator apply t = A d (chebyshev.cpp:208-216 fused into one pass):
+//   y += d;  r -= t;  d = sd d + sr dinv .* r
+struct OpChebStep {
+  double sd, sr;
+  const double *di, *t;
+  double *r, *d, *y;
+  template <class T>
+  __device__ void at(long long i) const {
+    const T dv = as<T>(d)[i], yv = as<T>(y)[i], dinv = as<T>(di)[i];  // every load before the first store
+    const T rv = as<T>(r)[i] - as<T>(t)[i];
+    as<T>(y)[i] = yv + dv;
+    as<T>(r)[i] = rv;
+    as<T>(d)[i] = sd * dv + sr * dinv * rv;
+  }
+  uintptr_t align() const { return bits(di) | bits(t) | bits(r) | bits(d) | bits(y); }
+};
+// x += a p;  r -= a z   (the two AXPYs of a CG iteration, iterative.cpp:448-449)
+struct OpCgUpdate {
+  double a;
+  const double *p, *z;
+  double *x, *r;
+  template <class T>
+  __device__ void at(long long i) const {
+    const T xv = as<T>(x)[i] + a * as<T>(p)[i], rv = as<T>(r)[i] - a * as<T>(z)[i];
+    as<T>(x)[i] = xv;
+    as<T>(r)[i] = rv;
+  }
+  uintptr_t align() const { return bits(p) | bits(z) | bits(x) | bits(r); }
+};
 __global__ void k_set_sub(double *x, const int32_t *__restrict__ rows, int n, double s) {
   PA_STRIDE_LOOP(i, n) x[rows[i]] = s;
 }
 __global__ void k_set_sub_vec(double *x, const int32_t *__restrict__ rows, int n, const double *__restrict__ y) {
   PA_STRIDE_LOOP(i, n) x[rows[i]] = y[rows[i]];
-}
-__global__ void k_scale(const double *__restrict__ d, double *__restrict__ y, long long n) {
-  PA_STRIDE_LOOP(i, n) y[i] *= d[i];
-}
-__global__ void k_recip(double *x, long long n) { PA_STRIDE_LOOP(i, n) x[i] = 1.0 / x[i]; }
-__global__ void k_scal(double a, double *x, long long n) { PA_STRIDE_LOOP(i, n) x[i] *= a; }
-__global__ void k_cheb0(double sr, const double *__restrict__ di, const double *__restrict__ r, double *__restrict__ d,
-                        long long n) {
-  PA_STRIDE_LOOP(i, n) d[i] = sr * di[i] * r[i];
-}
-__global__ void k_chebk(double sd, double sr, const double *__restrict__ di, const double *__restrict__ r,
-                        double *__restrict__ d, long long n) {
-  PA_STRIDE_LOOP(i, n) d[i] = sd * d[i] + sr * di[i] * r[i];
-}
-// one Chebyshev step around the operator apply t = A d (chebyshev.cpp:208-216 fused into one pass):
-//   y += d;  r -= t;  d = sd d + sr dinv .* r
-__global__ void k_cheb_step(double sd, double sr, const double *__restrict__ di, const double *__restrict__ t,
-                            double *__restrict__ r, double *__restrict__ d, double *__restrict__ y, long long n) {
-  PA_STRIDE_LOOP(i, n) {
-    const double dv = d[i];
-    const double rv = r[i] - t[i];
-    y[i] += dv;
-    r[i] = rv;
-    d[i] = sd * dv + sr * di[i] * rv;
-  }
-}
-// x += a p;  r -= a z   (the two AXPYs of a CG iteration, iterative.cpp:448-449)
-__global__ void k_cg_update(double a, const double *__restrict__ p, const double *__restrict__ z,
-                            double *__restrict__ x, double *__restrict__ r, long long n) {
-  PA_STRIDE_LOOP(i, n) {
-    x[i] += a * p[i];
-    r[i] -= a * z[i];
-  }
 }
 __global__ void k_random(double *x, long long n, uint64_t seed) {
   PA_STRIDE_LOOP(i, n) {
@@ -129,10 +235,21 @@ __device__ __forceinline__ double block_sum(double v) {
   return t;  // valid on thread 0
 }
 
-__global__ void k_dot_partial(const double *__restrict__ x, const double *__restrict__ y, long long n,
-                              double *__restrict__ partial) {
-  double s = 0.0;
-  PA_STRIDE_LOOP(i, n) s += x[i] * y[i];
+__device__ __forceinline__ double hsum(double v) { return v; }
+__device__ __forceinline__ double hsum(d2 v) { return v.x + v.y; }
+
+template <int W>
+__global__ __launch_bounds__(256) void k_dot_partial(const double *__restrict__ x, const double *__restrict__ y,
+                                                     long long n, double *__restrict__ partial) {
+  using T = typename Lane<W>::type;
+  const long long nv = n / W;
+  T acc = T{};
+  PA_STRIDE_LOOP(i, nv) acc += as<T>(x)[i] * as<T>(y)[i];
+  double s = hsum(acc);
+  if (W > 1) {
+    const long long j = nv * W + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) s += x[j] * y[j];
+  }
   s = block_sum(s);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
@@ -152,16 +269,30 @@ struct VecPtrs {
 struct Coefs {
   double h[kDotBatch];
 };
-__global__ void k_multi_dot_partial(const double *__restrict__ w, const VecPtrs V, int m, long long n,
-                                    double *__restrict__ partial) {
-  double s[kDotBatch];
+template <int W>
+__global__ __launch_bounds__(256) void k_multi_dot_partial(const double *__restrict__ w, const VecPtrs V, int m,
+                                                           long long n, double *__restrict__ partial) {
+  using T = typename Lane<W>::type;
+  const long long nv = n / W;
+  T acc[kDotBatch];
 #pragma unroll
-  for (int j = 0; j < kDotBatch; j++) s[j] = 0.0;
-  PA_STRIDE_LOOP(i, n) {
-    const double wi = w[i];
+  for (int j = 0; j < kDotBatch; j++) acc[j] = T{};
+  PA_STRIDE_LOOP(i, nv) {
+    const T wi = as<T>(w)[i];
 #pragma unroll
     for (int j = 0; j < kDotBatch; j++)
-      if (j < m) s[j] += wi * V.v[j][i];
+      if (j < m) acc[j] += wi * as<T>(V.v[j])[i];
+  }
+  double s[kDotBatch];
+#pragma unroll
+  for (int j = 0; j < kDotBatch; j++) s[j] = hsum(acc[j]);
+  if (W > 1) {
+    const long long i = nv * W + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+#pragma unroll
+      for (int j = 0; j < kDotBatch; j++)
+        if (j < m) s[j] += w[i] * V.v[j][i];
+    }
   }
 #pragma unroll
   for (int j = 0; j < kDotBatch; j++) {
@@ -179,15 +310,25 @@ __global__ void k_multi_dot_final(const double *__restrict__ partial, int nb, in
     __syncthreads();
   }
 }
-__global__ void k_multi_axpy(const Coefs a, const VecPtrs V, int m, double *__restrict__ w, long long n) {
-  PA_STRIDE_LOOP(i, n) {
-    double wi = w[i];
+struct OpMultiAxpy {
+  Coefs a;
+  VecPtrs V;
+  int m;
+  double *w;
+  template <class T>
+  __device__ void at(long long i) const {
+    T wi = as<T>(w)[i];
 #pragma unroll
     for (int j = 0; j < kDotBatch; j++)
-      if (j < m) wi -= a.h[j] * V.v[j][i];
-    w[i] = wi;
+      if (j < m) wi -= a.h[j] * as<T>(V.v[j])[i];
+    as<T>(w)[i] = wi;
   }
-}
+  uintptr_t align() const {
+    uintptr_t b = bits(w);
+    for (int j = 0; j < m; j++) b |= bits(V.v[j]);
+    return b;
+  }
+};
 
 struct Scratch {
   double *d_partial = nullptr;  // [kDotBatch * kMaxBlocks + kDotBatch]
@@ -210,6 +351,17 @@ Scratch &scratch() {
     }                                                                                      \
   } while (0)
 
+// 16-byte lanes when every pointer allows it; the grid covers the lane count
+template <class Op>
+void launch_ew(const Op &op, long long n, hipStream_t stream) {
+  if (n <= 0) return;
+  if ((op.align() & 15) == 0 && n >= 2)
+    hipLaunchKernelGGL((k_ew<2, Op>), dim3(grid_for((n + 1) / 2)), dim3(kBlock), 0, stream, op, n);
+  else
+    hipLaunchKernelGGL((k_ew<1, Op>), dim3(grid_for(n)), dim3(kBlock), 0, stream, op, n);
+  PA_HIP(hipGetLastError());
+}
+
 }  // namespace
 
 namespace linalg {
@@ -223,16 +375,16 @@ void Fill(const Context &c, Vector &x, double s) {
   if (s == 0.0)
     PA_HIP(hipMemsetAsync(x.Data(), 0, sizeof(double) * (size_t)x.Size(), c.stream));
   else
-    PA_LAUNCH(k_fill, x.Size(), c.stream, x.Data(), (long long)x.Size(), s);
+    launch_ew(OpFill{x.Data(), s}, x.Size(), c.stream);
 }
 void AXPY(const Context &c, double a, const Vector &x, Vector &y) {
-  PA_LAUNCH(k_axpy, x.Size(), c.stream, a, x.Data(), y.Data(), (long long)x.Size());
+  launch_ew(OpAxpy{a, x.Data(), y.Data()}, x.Size(), c.stream);
 }
 void AXPBY(const Context &c, double a, const Vector &x, double b, Vector &y) {
-  PA_LAUNCH(k_axpby, x.Size(), c.stream, a, x.Data(), b, y.Data(), (long long)x.Size());
+  launch_ew(OpAxpby{a, x.Data(), b, y.Data()}, x.Size(), c.stream);
 }
 void AXPBYPCZ(const Context &c, double a, const Vector &x, double b, const Vector &y, double g, Vector &z) {
-  PA_LAUNCH(k_axpbypcz, x.Size(), c.stream, a, x.Data(), b, y.Data(), g, z.Data(), (long long)x.Size());
+  launch_ew(OpAxpbypcz{a, x.Data(), b, y.Data(), g, z.Data()}, x.Size(), c.stream);
 }
 void SetSubVector(const Context &c, Vector &x, const int32_t *rows, int n, double s) {
   PA_LAUNCH(k_set_sub, n, c.stream, x.Data(), rows, n, s);
@@ -241,16 +393,21 @@ void SetSubVector(const Context &c, Vector &x, const int32_t *rows, int n, const
   PA_LAUNCH(k_set_sub_vec, n, c.stream, x.Data(), rows, n, y.Data());
 }
 void Scale(const Context &c, const Vector &d, Vector &y) {
-  PA_LAUNCH(k_scale, y.Size(), c.stream, d.Data(), y.Data(), (long long)y.Size());
+  launch_ew(OpScale{d.Data(), y.Data()}, y.Size(), c.stream);
 }
-void Reciprocal(const Context &c, Vector &x) { PA_LAUNCH(k_recip, x.Size(), c.stream, x.Data(), (long long)x.Size()); }
+void Reciprocal(const Context &c, Vector &x) { launch_ew(OpRecip{x.Data()}, x.Size(), c.stream); }
 
 double Dot(const Context &c, const Vector &x, const Vector &y) {
   PA_REQUIRE(x.Size() == y.Size(), "size mismatch in Dot");
   Scratch &s = scratch();
-  const int nb = grid_for(x.Size());
-  hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(kBlock), 0, c.stream, x.Data(), y.Data(), (long long)x.Size(),
-                     s.d_partial);
+  const bool wide = ((bits(x.Data()) | bits(y.Data())) & 15) == 0 && x.Size() >= 2;
+  const int nb = grid_for(wide ? (x.Size() + 1) / 2 : x.Size());
+  if (wide)
+    hipLaunchKernelGGL(k_dot_partial<2>, dim3(nb), dim3(kBlock), 0, c.stream, x.Data(), y.Data(), (long long)x.Size(),
+                       s.d_partial);
+  else
+    hipLaunchKernelGGL(k_dot_partial<1>, dim3(nb), dim3(kBlock), 0, c.stream, x.Data(), y.Data(), (long long)x.Size(),
+                       s.d_partial);
   hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kBlock), 0, c.stream, s.d_partial, nb, s.d_partial + kMaxBlocks);
   PA_HIP(hipGetLastError());
   if (c.comm) c.comm->AllReduceSum(s.d_partial + kMaxBlocks, 1, c.stream);  // Mpi::GlobalSum
@@ -267,8 +424,14 @@ void MultiDot(const Context &c, const Vector &w, const std::vector<Vector> &V, i
     const int mb = std::min(kDotBatch, m - j0);
     VecPtrs P{};
     for (int j = 0; j < mb; j++) P.v[j] = V[j0 + j].Data();
-    hipLaunchKernelGGL(k_multi_dot_partial, dim3(nb), dim3(kBlock), 0, c.stream, w.Data(), P, mb, (long long)w.Size(),
-                       s.d_partial);
+    uintptr_t al = bits(w.Data());
+    for (int j = 0; j < mb; j++) al |= bits(P.v[j]);
+    if ((al & 15) == 0)
+      hipLaunchKernelGGL(k_multi_dot_partial<2>, dim3(nb), dim3(kBlock), 0, c.stream, w.Data(), P, mb,
+                         (long long)w.Size(), s.d_partial);
+    else
+      hipLaunchKernelGGL(k_multi_dot_partial<1>, dim3(nb), dim3(kBlock), 0, c.stream, w.Data(), P, mb,
+                         (long long)w.Size(), s.d_partial);
     hipLaunchKernelGGL(k_multi_dot_final, dim3(1), dim3(kBlock), 0, c.stream, s.d_partial, nb, mb, d_out);
     PA_HIP(hipGetLastError());
     if (c.comm) c.comm->AllReduceSum(d_out, mb, c.stream);
@@ -283,14 +446,14 @@ void MultiAXPY(const Context &c, const double *H, const std::vector<Vector> &V, 
     VecPtrs P{};
     Coefs a{};
     for (int j = 0; j < mb; j++) P.v[j] = V[j0 + j].Data(), a.h[j] = H[j0 + j];
-    PA_LAUNCH(k_multi_axpy, w.Size(), c.stream, a, P, mb, w.Data(), (long long)w.Size());
+    launch_ew(OpMultiAxpy{a, P, mb, w.Data()}, w.Size(), c.stream);
   }
 }
 double Norml2(const Context &c, const Vector &x) { return std::sqrt(Dot(c, x, x)); }
 double Normalize(const Context &c, Vector &x) {
   const double nrm = Norml2(c, x);
   PA_REQUIRE(nrm > 0.0, "zero vector norm in normalization");
-  PA_LAUNCH(k_scal, x.Size(), c.stream, 1.0 / nrm, x.Data(), (long long)x.Size());
+  launch_ew(OpScal{1.0 / nrm, x.Data()}, x.Size(), c.stream);
   return nrm;
 }
 void SetRandom(const Context &c, Vector &x, uint64_t seed) {
@@ -298,18 +461,17 @@ void SetRandom(const Context &c, Vector &x, uint64_t seed) {
   PA_LAUNCH(k_random, x.Size(), c.stream, x.Data(), (long long)x.Size(), rank_seed);
 }
 void ChebyOrder0(const Context &c, double sr, const Vector &dinv, const Vector &r, Vector &d) {
-  PA_LAUNCH(k_cheb0, d.Size(), c.stream, sr, dinv.Data(), r.Data(), d.Data(), (long long)d.Size());
+  launch_ew(OpCheb0{sr, dinv.Data(), r.Data(), d.Data()}, d.Size(), c.stream);
 }
 void ChebyStep(const Context &c, double sd, double sr, const Vector &dinv, const Vector &t, Vector &r, Vector &d,
                Vector &y) {
-  PA_LAUNCH(k_cheb_step, d.Size(), c.stream, sd, sr, dinv.Data(), t.Data(), r.Data(), d.Data(), y.Data(),
-            (long long)d.Size());
+  launch_ew(OpChebStep{sd, sr, dinv.Data(), t.Data(), r.Data(), d.Data(), y.Data()}, d.Size(), c.stream);
 }
 void CgUpdate(const Context &c, double a, const Vector &p, const Vector &z, Vector &x, Vector &r) {
-  PA_LAUNCH(k_cg_update, x.Size(), c.stream, a, p.Data(), z.Data(), x.Data(), r.Data(), (long long)x.Size());
+  launch_ew(OpCgUpdate{a, p.Data(), z.Data(), x.Data(), r.Data()}, x.Size(), c.stream);
 }
 void ChebyOrderK(const Context &c, double sd, double sr, const Vector &dinv, const Vector &r, Vector &d) {
-  PA_LAUNCH(k_chebk, d.Size(), c.stream, sd, sr, dinv.Data(), r.Data(), d.Data(), (long long)d.Size());
+  launch_ew(OpChebK{sd, sr, dinv.Data(), r.Data(), d.Data()}, d.Size(), c.stream);
 }
 
 // Power iteration on D^{-1} A (chebyshev.cpp:14-28 + linalg/operator.cpp:583-631, herm = true)
@@ -750,7 +912,7 @@ void GmresSolver::Mult(const Vector &b, Vector &x) const {
     if (beta == 0.0) break;
     {
       Vector &v0 = V_[0];
-      hipLaunchKernelGGL(k_scal, dim3(grid_for(n)), dim3(kBlock), 0, c.stream, 1.0 / beta, v0.Data(), (long long)n);
+      launch_ew(OpScal{1.0 / beta, v0.Data()}, n, c.stream);
     }
     std::fill(s.begin(), s.end(), 0.0);
     s[0] = beta;
@@ -783,8 +945,7 @@ void GmresSolver::Mult(const Vector &b, Vector &x) const {
       }
       Hij(j + 1, j) = linalg::Norml2(c, w);
       if (Hij(j + 1, j) != 0.0)
-        hipLaunchKernelGGL(k_scal, dim3(grid_for(n)), dim3(kBlock), 0, c.stream, 1.0 / Hij(j + 1, j), w.Data(),
-                           (long long)n);
+        launch_ew(OpScal{1.0 / Hij(j + 1, j), w.Data()}, n, c.stream);
       for (int k = 0; k < j; k++) ApplyPlaneRotation(Hij(k, j), Hij(k + 1, j), cs[k], sn[k]);
       GeneratePlaneRotation(Hij(j, j), Hij(j + 1, j), cs[j], sn[j]);
       ApplyPlaneRotation(Hij(j, j), Hij(j + 1, j), cs[j], sn[j]);

@@ -177,6 +177,31 @@ int pa_vec_axpby(pa_context *ctx, double a, const double *x, double b, double *y
     linalg::AXPBY(ctx->ctx, a, vx, b, vy);
   });
 }
+// Measured FP64 matrix-core peak (bench.py's denominator beside the data-sheet figure): every wave
+// keeps eight independent 16x16 accumulators and issues `iters` rounds of v_mfma_f64_16x16x4_f64 on them.
+typedef double pa_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(const int iters, double *__restrict__ out) {
+  pa_d4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = pa_d4{0.0, 0.0, 0.0, 0.0};
+  double a = 1e-3 * (threadIdx.x & 63), b = 1.0 + 1e-6 * (threadIdx.x & 15);
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  if (s == -1.0) out[0] = s;  // keeps the chain alive, never true
+}
+int pa_bench_mfma_f64(pa_context *ctx, int iters, int n_blocks, double *scratch, double *flops_per_launch) {
+  return guarded([&] {
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(n_blocks), dim3(256), 0, ctx->ctx.stream, iters, scratch);
+    PA_HIP(hipGetLastError());
+    // one MFMA = 16 x 16 x 4 multiply-adds; 4 waves per block, 8 per round
+    *flops_per_launch = 2.0 * 16 * 16 * 4 * 8.0 * iters * 4.0 * n_blocks;
+  });
+}
 int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed) {
   return guarded([&] {
     Vector vx(x, n);

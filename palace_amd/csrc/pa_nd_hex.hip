@@ -86,6 +86,7 @@ struct NDArgs {
   double *y1, *ye1;
   int direct;      // EVEC: entries flagged kExclBit16 in perm go straight to y (they are the only copy)
   int accumulate;  // for those: y += v instead of y = v
+  int xcd_chunk;   // > 0: workgroups are dealt to the 8 XCDs round-robin; give each XCD one contiguous element range
   int ess_policy;  // -1, or ParOperator's row fix-up fused in: y[ess] = x[ess] (1) / 0 (0) (rap.cpp:223-233)
   CoeffDev c_mass, c_curl;
   NDTab<P1, Q1> tab;
@@ -358,7 +359,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   const int sub = lane / L::T, t = lane - sub * L::T;
   const int ta = t % Q1, tb = t / Q1;
   const bool lane_ok = sub < L::EPW;
-  const int e = (blockIdx.x * kWavesPerBlock + wave) * L::EPW + sub;
+  const int bid = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int e = (bid * kWavesPerBlock + wave) * L::EPW + sub;
   const bool active = lane_ok && e < a.ne;
   double *sm = smem + (size_t)(wave * L::EPW + (lane_ok ? sub : 0)) * L::ELEM_PAD;
   const int lx = L::parity_xor(sub);  // swizzled layouts: odd elements use the other half of the banks
@@ -646,7 +648,10 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
   a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
 #endif
   const int epb = kWavesPerBlock * L::EPW;
-  const dim3 grid((so.ne + epb - 1) / epb), block(64 * kWavesPerBlock);
+  const int nblk = (so.ne + epb - 1) / epb;
+  static const bool xcd_map = !(getenv("PALACE_AMD_XCD") && atoi(getenv("PALACE_AMD_XCD")) == 0);
+  a.xcd_chunk = (xcd_map && nblk >= 64) ? (nblk + 7) / 8 : 0;
+  const dim3 grid(a.xcd_chunk > 0 ? 8 * a.xcd_chunk : nblk), block(64 * kWavesPerBlock);
   const size_t lds = sizeof(double) * (size_t)epb * L::ELEM_PAD;
   switch (so.qf) {
     case PA_QF_HDIV_33:

@@ -22,6 +22,7 @@ def _L():
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [C.c_void_p]
         L.pa_vec_axpby.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+        L.pa_bench_mfma_f64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
         L.pa_chebyshev_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
         L.pa_cg_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.c_void_p]
@@ -82,6 +83,13 @@ class Context:
         _lib.check(_L().pa_vec_axpby(self.handle, a, C.c_void_p(x.data_ptr()), b, C.c_void_p(y.data_ptr()),
                                      C.c_int(x.numel())))
         return y
+
+    def bench_mfma_f64(self, iters, n_blocks, scratch):
+        """Launch the FP64 matrix-core peak micro-kernel once; returns the flops of the launch."""
+        fl = C.c_double(0.0)
+        _lib.check(_L().pa_bench_mfma_f64(self.handle, C.c_int(iters), C.c_int(n_blocks), C.c_void_p(scratch.data_ptr()),
+                                          C.byref(fl)))
+        return fl.value
 
     def set_random(self, x, seed):
         _lib.check(_L().pa_vec_set_random(self.handle, C.c_void_p(x.data_ptr()), x.numel(), seed))
