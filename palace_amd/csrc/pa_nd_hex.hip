@@ -371,11 +371,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   // 50 doubles across the contraction made those instantiations spill hundreds of registers.)
   constexpr bool METRIC = QD && ISO;  // q-data = G = J^T J (6 per point), coefficients applied here
   constexpr int NG = QD ? (METRIC ? (USE_U ? 7 : 6) : (USE_U ? 6 : 0) + (USE_C ? 6 : 0)) : 10;
-  constexpr bool LATE = !QD && Q1 >= 5;
+  // two right-hand sides, curl-curl + mass in the metric form: the q-data is read again per point for each right-hand
+  // side (the second time from L2) instead of being held, which keeps the kernel free of register spills
+  constexpr bool LATEQ = METRIC && USE_U && USE_C && NRHS > 1;
+  constexpr bool LATE = (!QD && Q1 >= 5) || LATEQ;
   double gd[LATE ? 1 : Q1][NG];
   int attr[LATE ? 1 : Q1];
   const double *glate = a.geom + (size_t)(active ? e : 0) * 11 * Q + ta + Q1 * tb;
-  if (QD) {
+  const double *gq_late = a.qdata + (size_t)(active ? e : 0) * 7 * Q + ta + Q1 * tb;
+  if (QD && !LATEQ) {
     const double *g = a.qdata + (size_t)(active ? e : 0) * (METRIC ? 7 : NG) * Q + ta + Q1 * tb;
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
@@ -467,6 +471,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
     if (METRIC) {
       // q-data = H = (w / |detJ|) J^T J {00, 01, 02, 11, 12, 22} and, for the mass part, |detJ| / w:
       //   (w / detJ) J^T c J = c H,   w detJ adj^T c adj = c (|detJ| / w) adj(H)
+      if (LATEQ) {
+#pragma unroll
+        for (int c = 0; c < NG; c++) gd[0][c] = gq_late[c * Q + Q1 * Q1 * qz];
+      }
       const double *H = &gd[gq * qz][0];
       if (USE_U) {
         const double cm = gd[gq * qz][6] * a.c_mass.mat[9 * coeff_index(a.c_mass, attr_m)];
