@@ -7,8 +7,9 @@ PROF = os.path.join(OUT, "profiles_new")
 os.makedirs(PROF, exist_ok=True)
 
 def find(d, suffix):
+    # gpurun merges every call's output into the same local directory: take the newest file
     f = glob.glob(os.path.join(OUT, d, "**", "*" + suffix), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None
 
 for d, name in (("prof_bench", "bench_kernel_stats.csv"), ("prof_curlmass", "apply_curlmass_kernel_stats.csv")):
     f = find(d, "kernel_stats.csv")
@@ -32,7 +33,7 @@ for d in sorted(glob.glob(os.path.join(OUT, "prof_pmc*"))):
             k = "nd_hex_apply_kernel"
         elif "et_gather" in k:
             k = "et_gather_kernel"
-        elif "k_axpby" in k:
+        elif "k_axpby" in k or "OpAxpby" in k:
             k = "calibration_axpby"
         else:
             continue
@@ -57,7 +58,7 @@ if pmc:
     if cal and n_cal:
         rf = cal.get("FETCH_SIZE", 0) * 1024 / (16.0 * n_cal)
         rw = cal.get("WRITE_SIZE", 0) * 1024 / (8.0 * n_cal)
-        calib = (f"calibration on y = a x + b y over {n_cal} doubles (8 B/lane loads, known 16 B read + 8 B written per "
+        calib = (f"calibration on y = a x + b y over {n_cal} doubles (16 B/lane loads, known 16 B read + 8 B written per "
                  f"entry): FETCH_SIZE reports {cal.get('FETCH_SIZE', 0) * 1024 / (16.0 * n_cal):.3f} of the read bytes, "
                  f"WRITE_SIZE {cal.get('WRITE_SIZE', 0) * 1024 / (8.0 * n_cal):.3f} of the written bytes")
     json.dump({"note": note, "calibration": calib, "kernels": pmc,
