@@ -58,6 +58,11 @@ int pa_par_op_create(pa_context *ctx, pa_op *local, int n_true, const int32_t *e
  * BaseSumOperator of linalg/operator.hpp:132-270), e.g. a0 K + a1 C + a2 M.  The locals stay owned by the caller. */
 int pa_par_sum_op_create(pa_context *ctx, int nterms, pa_op *const *locals, const double *coeffs, int n_true,
                          const int32_t *ess_tdofs, int n_ess, int diag_policy, pa_halo *halo, pa_par_op **A);
+/* ParOperator around an assembled local operator (ParOperator::ParallelAssemble, linalg/rap.cpp:84-152: the reference
+ * assembles the coarsest multigrid level because its solver needs a matrix).  `csr` comes from pa_op_full_assemble,
+ * stays owned by the caller and must outlive the ParOperator; the local apply is a device CSR matrix-vector product. */
+int pa_par_op_create_assembled(pa_context *ctx, const pa_csr *csr, int n_true, const int32_t *ess_tdofs, int n_ess,
+                               int diag_policy, pa_halo *halo, pa_par_op **A);
 void pa_par_op_destroy(pa_par_op *A);
 int pa_par_op_mult(pa_par_op *A, const double *x, double *y);
 /* ParOperator::AddMult (rap.cpp:277-318): y += a (P^T A P with the essential-dof handling) x. */

@@ -209,6 +209,26 @@ def _restriction_desc(space):
     return desc, keep
 
 
+class DeviceCsr:
+    """Owner of a pa_csr (device arrays of a fully assembled local operator)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        L = _lib.load()
+        n, nnz = C.c_int32(), C.c_int64()
+        _lib.check(L.pa_csr_get(self.handle, C.byref(n), C.byref(nnz), None, None, None))
+        self.nrows, self.nnz = n.value, nnz.value
+
+    def __del__(self):
+        try:
+            L = _lib.load()
+            L.pa_csr_destroy.restype = None
+            L.pa_csr_destroy.argtypes = [C.c_void_p]
+            L.pa_csr_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class Operator:
     """palace::ceed::Operator: a sum of partially assembled sub-operators on L-vectors."""
 
@@ -276,6 +296,12 @@ class Operator:
     def assemble_diagonal(self, diag):
         _lib.check(_lib.load().pa_op_assemble_diagonal(self.handle, C.c_void_p(diag.data_ptr()), _stream()))
         return diag
+
+    def full_assemble_device(self, skip_zeros=False):
+        """CeedOperatorFullAssemble, kept in HBM: a DeviceCsr for linalg.AssembledParOperator."""
+        h = C.c_void_p()
+        _lib.check(_lib.load().pa_op_full_assemble(self.handle, int(skip_zeros), _stream(), C.byref(h)))
+        return DeviceCsr(h)
 
     def full_assemble(self, skip_zeros=False):
         """CeedOperatorFullAssemble -> scipy.sparse.csr_matrix (values copied back from the device)."""

@@ -1,0 +1,119 @@
+// Assembled (CSR) operator on the device: the coarsest multigrid level as a matrix.
+//
+// Reference: the coarsest level of the hierarchy is fully assembled (ParOperator::ParallelAssemble,
+// linalg/rap.cpp:84-152, from CeedOperatorFullAssemble, fem/libceed/operator.cpp:455-523) because its solver
+// (AMS / BoomerAMG through HYPRE) needs a matrix.  Here the matrix comes from pa_op_full_assemble and stays in
+// HBM; the apply is a sparse matrix-vector product, which at p = 1 moves ~3x fewer bytes than the matrix-free
+// operator carrying the fine level's quadrature data.
+#include "linalg.hpp"
+
+namespace palace {
+
+namespace {
+
+// one row per group of LPR lanes: coalesced (col, val) reads, the gather of x is the only indirection
+template <int LPR>
+__global__ __launch_bounds__(256) void k_csr_spmv(const int n, const int32_t *__restrict__ rowptr,
+                                                  const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                  const double *__restrict__ x, double *__restrict__ y, const double a,
+                                                  const int add) {
+  const int row = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPR);
+  const int l = threadIdx.x % LPR;
+  double s = 0.0;
+  if (row < n) {
+    const int32_t b = rowptr[row], e = rowptr[row + 1];
+    for (int32_t k = b + l; k < e; k += LPR) s += val[k] * x[col[k]];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LPR);
+  if (row < n && l == 0) y[row] = add ? y[row] + a * s : a * s;
+}
+
+// ParOperator's essential-dof handling applied to the matrix once (what the reference's ParallelAssemble does through
+// EliminateBC, linalg/rap.cpp:131-149): rows and columns of essential dofs are zeroed, their diagonal is 1 or 0
+__global__ void k_csr_eliminate(const int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                const double *__restrict__ val, const uint8_t *__restrict__ ess, const double diag,
+                                double *__restrict__ out) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const bool re = ess[row];
+  for (int32_t k = rowptr[row]; k < rowptr[row + 1]; k++) {
+    const int c = col[k];
+    out[k] = (re || ess[c]) ? ((re && c == row) ? diag : 0.0) : val[k];
+  }
+}
+__global__ void k_flag(const int n, const int32_t *__restrict__ list, uint8_t *__restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[list[i]] = 1;
+}
+
+__global__ void k_csr_diag(const int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                           const double *__restrict__ val, double *__restrict__ d) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double s = 0.0;
+  for (int32_t k = rowptr[row]; k < rowptr[row + 1]; k++)
+    if (col[k] == row) s += val[k];
+  d[row] = s;
+}
+
+}  // namespace
+
+CsrOperator::CsrOperator(const Context &ctx, const pa_csr *m) : Operator(m->nrows, m->nrows), ctx_(&ctx), m_(m) {
+  const double avg = m->nrows ? (double)m->nnz / m->nrows : 0.0;
+  lanes_ = avg > 24.0 ? 16 : (avg > 12.0 ? 8 : 4);
+}
+
+CsrOperator::~CsrOperator() {
+  if (d_val_bc_) (void)hipFree(d_val_bc_);
+}
+
+void CsrOperator::EliminateEssential(const int32_t *d_ess, int n_ess, bool diag_one) {
+  if (!height) return;
+  if (!d_val_bc_) d_val_bc_ = pa::dev_alloc<double>((size_t)m_->nnz);
+  uint8_t *flag = pa::dev_alloc<uint8_t>((size_t)height);
+  PA_HIP(hipMemsetAsync(flag, 0, (size_t)height, ctx_->stream));
+  if (n_ess) hipLaunchKernelGGL(k_flag, dim3((n_ess + 255) / 256), dim3(256), 0, ctx_->stream, n_ess, d_ess, flag);
+  hipLaunchKernelGGL(k_csr_eliminate, dim3((height + 255) / 256), dim3(256), 0, ctx_->stream, height, m_->d_rowptr,
+                     m_->d_col, m_->d_val, flag, diag_one ? 1.0 : 0.0, d_val_bc_);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(ctx_->stream));
+  PA_HIP(hipFree(flag));
+}
+
+void CsrOperator::MultUnconstrained(const Vector &x, Vector &y) const {
+  double *keep = d_val_bc_;
+  d_val_bc_ = nullptr;
+  Apply(x, y, 1.0, false);
+  d_val_bc_ = keep;
+}
+
+void CsrOperator::Apply(const Vector &x, Vector &y, double a, bool add) const {
+  PA_REQUIRE(x.Size() == width && y.Size() == height, "size mismatch in CsrOperator");
+  if (!height) return;
+  const double *vals = d_val_bc_ ? d_val_bc_ : m_->d_val;
+  const long long threads = (long long)height * lanes_;
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  if (lanes_ == 16)
+    hipLaunchKernelGGL(k_csr_spmv<16>, grid, block, 0, ctx_->stream, height, m_->d_rowptr, m_->d_col, vals, x.Data(),
+                       y.Data(), a, (int)add);
+  else if (lanes_ == 8)
+    hipLaunchKernelGGL(k_csr_spmv<8>, grid, block, 0, ctx_->stream, height, m_->d_rowptr, m_->d_col, vals, x.Data(),
+                       y.Data(), a, (int)add);
+  else
+    hipLaunchKernelGGL(k_csr_spmv<4>, grid, block, 0, ctx_->stream, height, m_->d_rowptr, m_->d_col, vals, x.Data(),
+                       y.Data(), a, (int)add);
+  PA_HIP(hipGetLastError());
+}
+
+void CsrOperator::Mult(const Vector &x, Vector &y) const { Apply(x, y, 1.0, false); }
+void CsrOperator::AddMult(const Vector &x, Vector &y, double a) const { Apply(x, y, a, true); }
+void CsrOperator::AssembleDiagonal(Vector &diag) const {
+  PA_REQUIRE(diag.Size() == height, "size mismatch in CsrOperator::AssembleDiagonal");
+  if (!height) return;
+  hipLaunchKernelGGL(k_csr_diag, dim3((height + 255) / 256), dim3(256), 0, ctx_->stream, height, m_->d_rowptr, m_->d_col,
+                     d_val_bc_ ? d_val_bc_ : m_->d_val, diag.Data());
+  PA_HIP(hipGetLastError());
+}
+
+}  // namespace palace

@@ -585,6 +585,12 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
       A_fused_ = c;
     }
   }
+  if (!halo) {
+    if (auto *m = dynamic_cast<const CsrOperator *>(&A)) {
+      const_cast<CsrOperator *>(m)->EliminateEssential(d_ess_, n_ess, policy == DiagonalPolicy::DIAG_ONE);
+      A_csr_ = m;
+    }
+  }
 }
 ParOperator::~ParOperator() {
   if (d_ess_) (void)hipFree(d_ess_);
@@ -599,6 +605,10 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
       linalg::SetSubVector(c, y, d_ess_, n_ess_, x);
     else
       linalg::SetSubVector(c, y, d_ess_, n_ess_, 0.0);
+    return;
+  }
+  if (A_csr_ && x.Data() != y.Data()) {
+    A_csr_->Mult(x, y);  // essential rows / columns live in the matrix
     return;
   }
   Vector tx(lx_.Data(), n_true_);
@@ -648,7 +658,10 @@ void ParOperator::EliminateRHS(const Vector &x, Vector &b) const {
   if (halo_) halo_->Prolongate(lx_.Data(), c.stream);
   else if (n_local_ > n_true_)
     PA_HIP(hipMemsetAsync(lx_.Data() + n_true_, 0, sizeof(double) * (size_t)(n_local_ - n_true_), c.stream));
-  A_->Mult(lx_, ly_);
+  if (A_csr_)
+    A_csr_->MultUnconstrained(lx_, ly_);
+  else
+    A_->Mult(lx_, ly_);
   if (halo_) halo_->RestrictAdd(ly_.Data(), c.stream);
   Vector ty(ly_.Data(), n_true_);
   linalg::AXPY(c, -1.0, ty, b);

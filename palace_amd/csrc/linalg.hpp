@@ -153,6 +153,26 @@ public:
   void AssembleDiagonal(Vector &diag) const override;
 };
 
+// Local operator held as an assembled CSR matrix in device memory (csr_op.hip): what the reference's coarsest level
+// becomes through ParOperator::ParallelAssemble (linalg/rap.cpp:84-152).  Non-owning view of a pa_csr.
+class CsrOperator : public Operator {
+  const Context *ctx_;
+  const pa_csr *m_;
+  int lanes_;
+  mutable double *d_val_bc_ = nullptr;  // values with the essential rows / columns eliminated (owned)
+  void Apply(const Vector &x, Vector &y, double a, bool add) const;
+
+public:
+  CsrOperator(const Context &ctx, const pa_csr *m);
+  ~CsrOperator() override;
+  // one rank: fold ParOperator's essential-dof handling into the matrix (rows and columns zeroed, diagonal 1 | 0)
+  void EliminateEssential(const int32_t *d_ess, int n_ess, bool diag_one);
+  void MultUnconstrained(const Vector &x, Vector &y) const;
+  void Mult(const Vector &x, Vector &y) const override;
+  void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
+  void AssembleDiagonal(Vector &diag) const override;
+};
+
 // ParOperator (rap.cpp:154-234): y = P^T A P x with essential-dof handling.  True dofs of this
 // rank are the first n_true entries of the local (L-) vector; shared dofs owned elsewhere follow
 // (see comm.hpp); with one rank P is the identity.
@@ -164,6 +184,7 @@ private:
   const Context *ctx_;
   const Operator *A_;
   const ceed::Operator *A_fused_ = nullptr;  // single rank: BC masking fused into the local apply
+  const CsrOperator *A_csr_ = nullptr;       // single rank, assembled local operator: BCs eliminated in the matrix
   const Halo *halo_;
   int n_true_, n_local_;
   int32_t *d_ess_ = nullptr;

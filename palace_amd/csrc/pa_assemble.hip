@@ -13,12 +13,6 @@
 
 #include "pa_internal.hpp"
 
-struct pa_csr {
-  int32_t nrows = 0;
-  int64_t nnz = 0;
-  int32_t *d_rowptr = nullptr, *d_col = nullptr;
-  double *d_val = nullptr;
-};
 
 namespace pa {
 

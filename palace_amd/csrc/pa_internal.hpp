@@ -14,6 +14,14 @@
 struct pa_op;
 typedef struct pa_op pa_op_fwd;
 
+// CSR of a fully assembled local operator (pa_op_full_assemble), device arrays
+struct pa_csr {
+  int32_t nrows = 0;
+  int64_t nnz = 0;
+  int32_t *d_rowptr = nullptr, *d_col = nullptr;
+  double *d_val = nullptr;
+};
+
 namespace pa {
 
 void set_error(const std::string &msg);

@@ -28,6 +28,7 @@ struct pa_par_op {
   std::unique_ptr<ceed::Operator> local;
   std::vector<std::unique_ptr<ceed::Operator>> terms;  // BuildParSumOperator: the local operators of the sum
   std::unique_ptr<SumOperator> sum;
+  std::unique_ptr<CsrOperator> csr;  // assembled local operator (coarsest level)
   std::unique_ptr<ParOperator> op;
 };
 struct pa_interp {
@@ -111,6 +112,20 @@ int pa_par_op_create(pa_context *ctx, pa_op *local, int n_true, const int32_t *e
     p->ctx = ctx;
     p->local = std::make_unique<ceed::Operator>(ctx->ctx, local, false);
     p->op = std::make_unique<ParOperator>(ctx->ctx, *p->local, n_true, ess, n_ess,
+                                          policy == PA_DIAG_ONE ? ParOperator::DiagonalPolicy::DIAG_ONE
+                                                                : ParOperator::DiagonalPolicy::DIAG_ZERO,
+                                          halo ? halo->halo.get() : nullptr);
+    *A = p;
+  });
+}
+int pa_par_op_create_assembled(pa_context *ctx, const pa_csr *csr, int n_true, const int32_t *ess, int n_ess,
+                               int policy, pa_halo *halo, pa_par_op **A) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && csr && A, "null argument");
+    auto *p = new pa_par_op;
+    p->ctx = ctx;
+    p->csr = std::make_unique<CsrOperator>(ctx->ctx, csr);
+    p->op = std::make_unique<ParOperator>(ctx->ctx, *p->csr, n_true, ess, n_ess,
                                           policy == PA_DIAG_ONE ? ParOperator::DiagonalPolicy::DIAG_ONE
                                                                 : ParOperator::DiagonalPolicy::DIAG_ZERO,
                                           halo ? halo->halo.get() : nullptr);

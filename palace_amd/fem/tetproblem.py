@@ -34,7 +34,7 @@ class TetProblem:
         return ceed.DenseBlock(ceed.FE_H1, s.ndofs, s.offsets, interp, grad)
 
     def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False,
-                       coarse="cg"):
+                       coarse="cg", coarse_assembled=True):
         """Same configuration as SlabProblem.pcg_gmg_solver (reference iodata.cpp:519-564)."""
         import torch
 
@@ -49,6 +49,8 @@ class TetProblem:
             ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
         local = [fine.coarsen_dense(b) for b in blocks[:-1]] + [fine]
         A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE) for op, e in zip(local, self.ess)]
+        if coarse_assembled and len(A) > 1:  # coarsest level as a device CSR matrix (rap.cpp:84-152)
+            A[0] = linalg.AssembledParOperator(ctx, local[0].full_assemble_device(), self.ess[0], linalg.DIAG_ONE)
         P = [linalg.DenseInterp(ctx, self.spaces[l].restriction(), self.spaces[l + 1].restriction(interp_range=True),
                                 tet.nd_tet_transfer_matrix(self.orders[l], self.orders[l + 1]))
              for l in range(len(A) - 1)]

@@ -160,6 +160,20 @@ class ParOperator:
             pass
 
 
+class AssembledParOperator(ParOperator):
+    """ParOperator around an assembled local operator (ParOperator::ParallelAssemble, rap.cpp:84-152): the coarsest
+    level as a device CSR matrix; `csr` is a ceed.DeviceCsr from Operator.full_assemble_device()."""
+
+    def __init__(self, ctx: Context, csr, ess_tdofs, diag_policy=DIAG_ONE, n_true=None, halo=None):
+        self.ctx, self.local, self.halo = ctx, csr, halo
+        self.n = csr.nrows if n_true is None else n_true
+        ess = np.ascontiguousarray(ess_tdofs, dtype=np.int32)
+        self.ess = ess
+        self.handle = C.c_void_p()
+        _lib.check(_L().pa_par_op_create_assembled(ctx.handle, csr.handle, self.n, _ptr(ess), ess.size, diag_policy,
+                                                   halo.handle if halo else None, C.byref(self.handle)))
+
+
 class ParSumOperator(ParOperator):
     """BuildParSumOperator (rap.cpp:843-919): ParOperator around sum_k coeffs[k] * locals[k]."""
 

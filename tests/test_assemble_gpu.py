@@ -59,3 +59,49 @@ def test_full_assemble_tets(p):
                                 po.QF_HDIV, po.CoeffCtx(),
                                 curl_orients=None if nd.diagonal_transform else nd.curl_orients).assemble_sparse()
     assert abs(A - ref).max() < 1e-12 * abs(ref).max()
+
+
+@pytest.mark.parametrize("policy", ["one", "zero"])
+@pytest.mark.parametrize("p", [1, 2])
+def test_assembled_par_operator(cylinder_mesh, p, policy):
+    """ParOperator around the device CSR (pa_par_op_create_assembled; ParOperator::ParallelAssemble,
+    linalg/rap.cpp:84-152) = ParOperator around the matrix-free operator: Mult, AddMult, diagonal, EliminateRHS."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem.fespace import NDHexSpace
+
+    mesh = cylinder_mesh
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, p + 1)
+    _, bs = util.make_ctx("scalar", int(mesh.attr.max()))
+    _, bc = util.make_ctx("scalar", int(mesh.attr.max()))
+    op = ceed.curlcurlmass_operator(geom, nd, bs, bc)
+    ctx = linalg.Context()
+    ess = nd.ess_dofs()
+    pol = linalg.DIAG_ONE if policy == "one" else linalg.DIAG_ZERO
+    A_mf = linalg.ParOperator(ctx, op, ess, pol)
+    csr = op.full_assemble_device()
+    assert csr.nrows == nd.ndofs and csr.nnz > 0
+    A_as = linalg.AssembledParOperator(ctx, csr, ess, pol)
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.uniform(-1, 1, nd.ndofs)).cuda()
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    A_mf.mult(x, y0)
+    A_as.mult(x, y1)
+    scale = float(y0.abs().max())
+    assert float((y0 - y1).abs().max()) < 1e-12 * scale
+    z0 = torch.from_numpy(rng.uniform(-1, 1, nd.ndofs)).cuda()
+    z1 = z0.clone()
+    A_mf.add_mult(x, z0, -0.7)
+    A_as.add_mult(x, z1, -0.7)
+    assert float((z0 - z1).abs().max()) < 1e-12 * scale
+    d0, d1 = torch.empty_like(x), torch.empty_like(x)
+    A_mf.assemble_diagonal(d0)
+    A_as.assemble_diagonal(d1)
+    assert float((d0 - d1).abs().max()) < 1e-12 * float(d0.abs().max())
+    b0 = torch.from_numpy(rng.uniform(-1, 1, nd.ndofs)).cuda()
+    b1 = b0.clone()
+    A_mf.eliminate_rhs(x, b0)
+    A_as.eliminate_rhs(x, b1)
+    assert float((b0 - b1).abs().max()) < 1e-12 * max(scale, float(b0.abs().max()))
