@@ -54,7 +54,7 @@ enum pa_qfunction {
                              absorbing and lumped-port boundary terms) */
 };
 
-enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1 };
+enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1, PA_FE_HDIV = 2 /* dense path only: RT mass (Interp + hdiv_33) */ };
 
 /*
  * Element restriction E — what Palace hands to CeedElemRestrictionCreate / ...CreateOriented

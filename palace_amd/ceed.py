@@ -21,7 +21,7 @@ from .fem.mesh import HexMesh, _q2_1d
 
 QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1, QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22, QF_HCURL_32 = range(9)
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
-FE_H1, FE_HCURL = 0, 1
+FE_H1, FE_HCURL, FE_HDIV = 0, 1, 2
 
 
 def _ptr(a):

@@ -958,6 +958,16 @@ void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
 DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_dense_basis_desc &b, int qf,
                          const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops, int height) {
   PA_REQUIRE(geom && geom->eb == kEB, "geometry data must come from pa_geom_create_dense");
+  if (b.fe_type == PA_FE_HDIV) {
+    // H(div) mass (fem/integ/vecfemass.cpp with an RT space: Interp + f_apply_hdiv_33, the contravariant Piola map) is
+    // the arithmetic of the curl-curl operator with the value table in the place of the curl table
+    PA_REQUIRE(qf == PA_QF_HDIV_33 && trial_ops == PA_EVAL_INTERP && test_ops == PA_EVAL_INTERP && geom->dim == 3 &&
+                   geom->sdim == 3,
+               "H(div) elements: only the mass operator (Interp, hdiv_33) in 3-D is supported");
+    pa_dense_basis_desc alias = b;
+    alias.fe_type = PA_FE_HCURL, alias.deriv = b.interp, alias.interp = nullptr;
+    return make_dense_sub(geom, r, alias, qf, ctx, ctx_size, PA_EVAL_CURL, PA_EVAL_CURL, height);
+  }
   PA_REQUIRE(b.fe_type == PA_FE_H1 || b.fe_type == PA_FE_HCURL, "unknown element type");
   PA_REQUIRE(b.num_dofs > 0 && b.num_qpts == geom->Q, "basis and geometry data disagree on the quadrature rule");
   PA_REQUIRE(r.num_elem == geom->ne && r.elem_size == b.num_dofs, "restriction does not match mesh / basis");

@@ -1,0 +1,128 @@
+"""H(div) mass operator on Raviart-Thomas tetrahedra and the discrete curl ND -> RT on the device vs the oracle
+(the flux B = curl A after a solve, drivers/eigensolver.cpp:469-477, and the RT mass of the
+flux error estimator, linalg/errorestimator.cpp).  The RT space itself is pinned by tests/test_rt_space.py."""
+import numpy as np
+import pytest
+
+from oracle import palace_oracle as po
+from tests import util
+
+pytestmark = pytest.mark.gpu
+REL = 1e-12
+
+
+def _warp(X):
+    x, y, z = X[:, 0], X[:, 1], X[:, 2]
+    return np.stack([x + 0.04 * np.sin(2 * y + z), y + 0.05 * x * z, z - 0.03 * np.cos(3 * x) * y], axis=1)
+
+
+def _mesh(kind):
+    from palace_amd.fem import tet
+
+    m = tet.cube_tet_mesh(3)
+    m.attr[:] = 1 + (np.arange(m.ne) % 2)
+    if kind == "tet10":
+        m2 = tet.to_quadratic(m, _warp)
+        m2.attr[:] = m.attr
+        return m2
+    return m
+
+
+def _geom(mesh, pts, wts):
+    from palace_amd import ceed
+
+    g = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, mesh.geometry_grad_table(pts), wts)
+    J = mesh.jacobians(pts)
+    Jcm = np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 9)
+    return g, po.build_geom_factor_33(mesh.attr.astype(np.float64), wts, Jcm)
+
+
+@pytest.mark.parametrize("coeff", ["scalar", "aniso"])
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["tet4", "tet10"])
+def test_rt_mass_apply(kind, p, coeff):
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import rt, tet
+
+    mesh = _mesh(kind)
+    sp = rt.RTTetSpace(mesh, p)
+    pts, wts = tet.tet_quadrature(p + 1)
+    interp, _ = sp.elem.tables(pts)
+    geom, ogeom = _geom(mesh, pts, wts)
+    c, blob = util.make_ctx(coeff, 2)
+    block = ceed.DenseBlock(ceed.FE_HDIV, sp.ndofs, sp.offsets, interp, None, orients=sp.orients)
+    op = ceed.Operator(sp.ndofs, sp.ndofs).add_dense_integrator(geom, block, ceed.QF_HDIV_33, blob,
+                                                                ceed.EVAL_INTERP).finalize()
+    orc = po.CeedOperatorOracle(sp.ndofs, sp.offsets, sp.orients, interp, interp, ogeom, po.QF_HDIV, c)
+    x = np.random.default_rng(p).uniform(-1, 1, sp.ndofs)
+    ref = orc.apply_add(x, np.zeros(sp.ndofs))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    op.mult(xd, yd)
+    assert np.abs(yd.cpu().numpy() - ref).max() < REL * np.abs(ref).max()
+    dd = torch.empty_like(xd)
+    op.assemble_diagonal(dd)
+    dref = orc.diagonal()
+    assert np.abs(dd.cpu().numpy() - dref).max() < REL * np.abs(dref).max()
+    assert float(dd.min()) > 0.0
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_discrete_curl_and_flux_energy(p):
+    """B = C A on the device = the oracle's interpolator; (K A, A) = (M_RT B, B) with all three operators on the GPU."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem import rt, tet
+
+    ctx = linalg.Context()
+    mesh = _mesh("tet10")
+    nd, sp = tet.NDTetSpace(mesh, p), rt.RTTetSpace(mesh, p)
+    Cm = rt.tet_curl_matrix(p)
+    C = linalg.DenseInterp(ctx, nd.restriction(), sp.restriction(interp_range=True), Cm)
+    orc = po.DenseInterpOracle(nd.restriction(), sp.restriction(interp_range=True), Cm)
+    rng = np.random.default_rng(p)
+    a = rng.uniform(-1, 1, nd.ndofs)
+    ad = torch.from_numpy(a).cuda()
+    b = torch.empty(sp.ndofs, dtype=torch.float64, device="cuda")
+    C.mult(ad, b)
+    ref = orc.mult(a)
+    assert np.abs(b.cpu().numpy() - ref).max() < REL * np.abs(ref).max()
+    z = rng.uniform(-1, 1, sp.ndofs)
+    at = torch.empty_like(ad)
+    C.mult_transpose(torch.from_numpy(z).cuda(), at)
+    assert abs(z @ b.cpu().numpy() - at.cpu().numpy() @ a) < REL * np.abs(z).sum() * float(b.abs().max())
+    # energy identity with the matrix-free operators
+    pts, wts = tet.tet_quadrature(p + 1)
+    geom, _ = _geom(mesh, pts, wts)
+    interp, curl = nd.elem.tables(pts)
+    kw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+    K = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(
+        geom, ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, **kw), ceed.QF_HDIV_33,
+        ceed.coefficient_context(3), ceed.EVAL_CURL).finalize()
+    rint, _ = sp.elem.tables(pts)
+    M = ceed.Operator(sp.ndofs, sp.ndofs).add_dense_integrator(
+        geom, ceed.DenseBlock(ceed.FE_HDIV, sp.ndofs, sp.offsets, rint, None, orients=sp.orients), ceed.QF_HDIV_33,
+        ceed.coefficient_context(3), ceed.EVAL_INTERP).finalize()
+    ka, mb = torch.empty_like(ad), torch.empty_like(b)
+    K.mult(ad, ka)
+    M.mult(b, mb)
+    e_k, e_m = float(ad @ ka), float(b @ mb)
+    assert abs(e_k - e_m) < 1e-11 * abs(e_k)
+
+
+def test_rt_rejects_other_qfunctions():
+    from palace_amd import ceed
+    from palace_amd.fem import rt, tet
+
+    mesh = _mesh("tet4")
+    sp = rt.RTTetSpace(mesh, 1)
+    pts, wts = tet.tet_quadrature(2)
+    interp, _ = sp.elem.tables(pts)
+    geom, _ = _geom(mesh, pts, wts)
+    block = ceed.DenseBlock(ceed.FE_HDIV, sp.ndofs, sp.offsets, interp, None, orients=sp.orients)
+    with pytest.raises(RuntimeError, match="H\\(div\\)"):
+        ceed.Operator(sp.ndofs, sp.ndofs).add_dense_integrator(geom, block, ceed.QF_HCURL_33,
+                                                               ceed.coefficient_context(3), ceed.EVAL_INTERP)
