@@ -235,3 +235,41 @@ def test_gmg_vcycle_and_pcg(prob):
     st = K.stats()
     assert st["converged"] and abs(st["iterations"] - it) <= 1, (st, it)
     assert _rel(x, xo) < 1e-6
+
+
+@pytest.mark.parametrize("offset", [0, 1])
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 100003])
+def test_vector_kernels_any_size_and_alignment(n, offset):
+    """The streaming kernels use 16-byte lanes when every pointer allows it and the scalar form otherwise
+    (sub-vectors at odd offsets), with the odd tail entry handled separately: AXPBY (vector.cpp:530-557) and the
+    two-stage dot against torch."""
+    import torch
+
+    from palace_amd import linalg
+
+    ctx = linalg.Context()
+    g = torch.Generator(device="cpu").manual_seed(n + offset)
+    xb = torch.rand(n + 4, dtype=torch.float64, generator=g).cuda()
+    yb = torch.rand(n + 4, dtype=torch.float64, generator=g).cuda()
+    x, y = xb[offset:offset + n], yb[offset:offset + n]
+    ref = 0.3 * x - 1.7 * y
+    guard = yb.clone()
+    d_ref = float(x.double() @ y.double())
+    d = ctx.dot(x, y)
+    assert abs(d - d_ref) <= 1e-13 * max(1.0, abs(d_ref)) * max(1, n) ** 0.5
+    ctx.axpby(0.3, x, -1.7, y)
+    assert torch.equal(y, ref) or float((y - ref).abs().max()) <= 1e-15
+    # nothing outside the vector was touched
+    assert torch.equal(yb[:offset], guard[:offset]) and torch.equal(yb[offset + n:], guard[offset + n:])
+
+
+def test_mfma_peak_kernel_runs():
+    import torch
+
+    from palace_amd import linalg
+
+    ctx = linalg.Context()
+    s = torch.zeros(8, dtype=torch.float64, device="cuda")
+    flops = ctx.bench_mfma_f64(16, 64, s)
+    torch.cuda.synchronize()
+    assert flops == 2.0 * 16 * 16 * 4 * 8 * 16 * 4 * 64 and float(s.abs().max()) == 0.0
