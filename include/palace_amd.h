@@ -215,6 +215,19 @@ int pa_op_add_sub(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
 int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
                         const pa_dense_basis_desc *basis, int32_t qfunction, const void *ctx,
                         size_t ctx_size, uint32_t trial_ops, uint32_t test_ops);
+/* SURVEY.md 8(f)-1, behind BuildParSumOperator (linalg/rap.cpp:843-919) and SpaceOperator::GetSystemMatrix
+ * (models/spaceoperator.cpp:786-804): sum_k coeffs[k] * (integrator k) over H(curl) integrators that share the
+ * geometry data and the space -- K (PA_QF_HDIV_33), M and C (PA_QF_HCURL_33), K + M (PA_QF_HDIVMASS_33) -- added as ONE
+ * sub-operator.  D is linear in the material coefficient, so the sum is a single curl-curl + mass pass whose two
+ * contexts are the weighted sums of the terms' contexts per mesh attribute: one pass over the geometry data instead of
+ * one per term (a0 K + a2 M for the real part, a1 C for the imaginary part of A(omega) = K + i omega C - omega^2 M).
+ * qfunctions[k] / ctxs[k] / ctx_sizes[k] are what pa_op_add_sub would take for term k. */
+int pa_op_add_sub_sum(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr, const pa_basis_desc *basis,
+                      int32_t nterms, const int32_t *qfunctions, const void *const *ctxs, const size_t *ctx_sizes,
+                      const double *coeffs);
+int pa_op_add_sub_dense_sum(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
+                            const pa_dense_basis_desc *basis, int32_t nterms, const int32_t *qfunctions,
+                            const void *const *ctxs, const size_t *ctx_sizes, const double *coeffs);
 /* Operator::Finalize(), operator.cpp:89-101. */
 int pa_op_finalize(pa_op *op);
 /* CeedOperatorCoarsen (operator.cpp:525-585): same QFunctions, contexts and geometry data as

@@ -256,6 +256,33 @@ class Operator:
                                                    C.c_uint32(ops), C.c_uint32(ops)))
         return self
 
+    @staticmethod
+    def _sum_args(terms):
+        qfs = (C.c_int32 * len(terms))(*[int(t[1]) for t in terms])
+        blobs = [np.ascontiguousarray(t[2]) for t in terms]
+        ptrs = (C.c_void_p * len(terms))(*[b.ctypes.data for b in blobs])
+        sizes = (C.c_size_t * len(terms))(*[b.nbytes for b in blobs])
+        coeffs = (C.c_double * len(terms))(*[float(t[0]) for t in terms])
+        return qfs, ptrs, sizes, coeffs, blobs
+
+    def add_integrator_sum(self, geom: GeomFactorData, space, terms):
+        """sum_k a_k * integrator_k as ONE sub-operator (pa_op_add_sub_sum): terms = [(a, qf, ctx_blob), ...] over
+        the H(curl) integrators K (QF_HDIV_33), M / C (QF_HCURL_33), K + M (QF_HDIVMASS_33) of one space."""
+        r, k1 = _restriction_desc(space)
+        b, k2 = _basis_desc(space, geom.q1d)
+        qfs, ptrs, sizes, coeffs, keep = self._sum_args(terms)
+        _lib.check(_lib.load().pa_op_add_sub_sum(self.handle, geom.handle, C.byref(r), C.byref(b), C.c_int32(len(terms)),
+                                                 qfs, ptrs, sizes, coeffs))
+        return self
+
+    def add_dense_integrator_sum(self, geom: DenseGeomFactorData, block: DenseBlock, terms):
+        """The same for a non-tensor element block (pa_op_add_sub_dense_sum)."""
+        r, b = block.descs()
+        qfs, ptrs, sizes, coeffs, keep = self._sum_args(terms)
+        _lib.check(_lib.load().pa_op_add_sub_dense_sum(self.handle, geom.handle, C.byref(r), C.byref(b),
+                                                       C.c_int32(len(terms)), qfs, ptrs, sizes, coeffs))
+        return self
+
     def finalize(self):
         _lib.check(_lib.load().pa_op_finalize(self.handle))
         return self

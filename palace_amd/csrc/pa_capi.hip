@@ -546,6 +546,125 @@ int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *res
   });
 }
 
+// Weighted sum of H(curl) integrators on one (geometry, space) pair as ONE sub-operator: D is linear in the material
+// coefficient, so sum_k a_k {K(mu^-1), M(eps), C(sigma), ...} is a single curl-curl + mass pass whose two contexts are
+// the weighted sums of the terms' contexts (per attribute).  Returns the combined blob (mass first, like the
+// reference's pair contexts) and the QFunction / eval modes of the fused integrator.
+static std::vector<uint8_t> combine_hcurl_terms(int nterms, const int32_t *qfs, const void *const *ctxs,
+                                                const size_t *ctx_sizes, const double *coeffs, int dim, int &qf_out,
+                                                uint32_t &ops_out) {
+  PA_REQUIRE(nterms >= 1 && qfs && ctxs && ctx_sizes && coeffs, "bad argument");
+  struct Part {
+    std::vector<int32_t> attr_mat;
+    std::vector<double> mat;
+    double a;
+  };
+  std::vector<Part> mass, curl;
+  auto read = [&](const void *blob, size_t bytes, size_t slot_offset, Part &out) -> size_t {
+    const size_t nslots = bytes / 8;
+    const unsigned char *base = static_cast<const unsigned char *>(blob);
+    auto slot_int = [&](size_t i) {
+      PA_REQUIRE(slot_offset + i < nslots, "coefficient context truncated");
+      int32_t v;
+      std::memcpy(&v, base + 8 * (slot_offset + i), 4);
+      return v;
+    };
+    const int nattr = slot_int(0);
+    PA_REQUIRE(nattr >= 0, "negative attribute count in coefficient context");
+    out.attr_mat.resize(nattr);
+    for (int i = 0; i < nattr; i++) out.attr_mat[i] = slot_int(1 + i);
+    const int nmat = slot_int(1 + nattr);
+    PA_REQUIRE(nmat > 0, "coefficient context without materials");
+    out.mat.resize((size_t)nmat * dim * dim);
+    PA_REQUIRE(slot_offset + 2 + nattr + out.mat.size() <= nslots, "coefficient context truncated");
+    std::memcpy(out.mat.data(), base + 8 * (slot_offset + 2 + nattr), 8 * out.mat.size());
+    for (int i = 0; i < nattr; i++)
+      PA_REQUIRE(out.attr_mat[i] >= 0 && out.attr_mat[i] < nmat, "attribute maps to missing material");
+    return 2 + nattr + out.mat.size();
+  };
+  for (int k = 0; k < nterms; k++) {
+    PA_REQUIRE(ctxs[k], "null context");
+    if (qfs[k] == PA_QF_HCURL_33) {
+      mass.emplace_back();
+      mass.back().a = coeffs[k];
+      read(ctxs[k], ctx_sizes[k], 0, mass.back());
+    } else if (qfs[k] == PA_QF_HDIV_33) {
+      curl.emplace_back();
+      curl.back().a = coeffs[k];
+      read(ctxs[k], ctx_sizes[k], 0, curl.back());
+    } else if (qfs[k] == PA_QF_HDIVMASS_33) {
+      mass.emplace_back(), curl.emplace_back();
+      mass.back().a = curl.back().a = coeffs[k];
+      const size_t used = read(ctxs[k], ctx_sizes[k], 0, mass.back());
+      read(ctxs[k], ctx_sizes[k], used, curl.back());
+    } else {
+      throw Error("only the H(curl) curl-curl / mass / curl-curl+mass integrators can be fused into one sum");
+    }
+  }
+  int nattr = 0;
+  for (const auto *v : {&mass, &curl})
+    for (const Part &t : *v) {
+      if (t.attr_mat.empty()) continue;
+      PA_REQUIRE(nattr == 0 || nattr == (int)t.attr_mat.size(), "terms disagree on the number of mesh attributes");
+      nattr = (int)t.attr_mat.size();
+    }
+  const int nout = std::max(nattr, 1), dd = dim * dim;
+  auto pack = [&](const std::vector<Part> &parts, std::vector<uint8_t> &blob) {
+    std::vector<double> m((size_t)nout * dd, 0.0);
+    for (const Part &t : parts)
+      for (int i = 0; i < nout; i++) {
+        const int src = t.attr_mat.empty() ? 0 : t.attr_mat[i];
+        for (int j = 0; j < dd; j++) m[(size_t)i * dd + j] += t.a * t.mat[(size_t)src * dd + j];
+      }
+    const size_t slots = 2 + (size_t)nattr + m.size(), at = blob.size();
+    blob.resize(at + 8 * slots, 0);
+    auto put_int = [&](size_t i, int32_t v) { std::memcpy(blob.data() + at + 8 * i, &v, 4); };
+    put_int(0, nattr);
+    for (int i = 0; i < nattr; i++) put_int(1 + i, i);
+    put_int(1 + nattr, nout);
+    std::memcpy(blob.data() + at + 8 * (2 + (size_t)nattr), m.data(), 8 * m.size());
+  };
+  std::vector<uint8_t> blob;
+  if (!mass.empty()) pack(mass, blob);
+  if (!curl.empty()) pack(curl, blob);
+  qf_out = (!mass.empty() && !curl.empty()) ? PA_QF_HDIVMASS_33 : (!mass.empty() ? PA_QF_HCURL_33 : PA_QF_HDIV_33);
+  ops_out = (!mass.empty() ? (uint32_t)PA_EVAL_INTERP : 0u) | (!curl.empty() ? (uint32_t)PA_EVAL_CURL : 0u);
+  return blob;
+}
+
+int pa_op_add_sub_sum(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr, const pa_basis_desc *basis,
+                      int32_t nterms, const int32_t *qfunctions, const void *const *ctxs, const size_t *ctx_sizes,
+                      const double *coeffs) {
+  int rc = guarded([&] {
+    PA_REQUIRE(op && geom && restr && basis, "null argument");
+    PA_REQUIRE(basis->fe_type == PA_FE_HCURL, "fused sums are built for H(curl) spaces");
+  });
+  if (rc) return rc;
+  int qf = 0;
+  uint32_t ops = 0;
+  std::vector<uint8_t> blob;
+  rc = guarded([&] { blob = combine_hcurl_terms(nterms, qfunctions, ctxs, ctx_sizes, coeffs, 3, qf, ops); });
+  if (rc) return rc;
+  return pa_op_add_sub(op, geom, restr, basis, qf, blob.data(), blob.size(), ops, ops);
+}
+
+int pa_op_add_sub_dense_sum(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
+                            const pa_dense_basis_desc *basis, int32_t nterms, const int32_t *qfunctions,
+                            const void *const *ctxs, const size_t *ctx_sizes, const double *coeffs) {
+  int rc = guarded([&] {
+    PA_REQUIRE(op && geom && restr && basis, "null argument");
+    PA_REQUIRE(basis->fe_type == PA_FE_HCURL && geom->dim == 3 && geom->sdim == 3,
+               "fused sums are built for 3-D H(curl) spaces");
+  });
+  if (rc) return rc;
+  int qf = 0;
+  uint32_t ops = 0;
+  std::vector<uint8_t> blob;
+  rc = guarded([&] { blob = combine_hcurl_terms(nterms, qfunctions, ctxs, ctx_sizes, coeffs, 3, qf, ops); });
+  if (rc) return rc;
+  return pa_op_add_sub_dense(op, geom, restr, basis, qf, blob.data(), blob.size(), ops, ops);
+}
+
 int pa_op_finalize(pa_op *op) {
   return guarded([&] {
     PA_REQUIRE(op, "null argument");
