@@ -298,7 +298,7 @@ def main():
         pcg["config"] = (f"PCG on K+M (eps_r=2.08), p-multigrid levels p={','.join(str(q) for q in prob.orders)}, "
                          f"4th-kind Chebyshev order {max(2 * p, 4)}, 1 V-cycle "
                          "per iteration; 'chebyshev' = plain smoother (reference default for magnetostatics), "
-                         "'hiptmair' = auxiliary-space smoother (reference default for driven/eigenmode); level 0 (stand-in for AMS): "
+                         "'hiptmair' = auxiliary-space smoother (reference default for driven/eigenmode); level 0 assembled to a device CSR matrix like the reference's coarsest level (stand-in for AMS on it): "
                          "Chebyshev-Jacobi order 4 with the plain smoother, 8 Jacobi-PCG iterations with the auxiliary-space one")
 
     tets = None

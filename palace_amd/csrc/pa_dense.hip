@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
   using F0 = FieldTraits<MODE, 0>;
   using F1 = FieldTraits<MODE, 1>;
   constexpr int NCT = M::NCT, KPMAX = 4 * PT, NF = F0::NF, S = ResidentStride<PT>::S;
-  constexpr int NQ0 = F0::NC == 3 ? 6 : (F0::NC == 2 ? 3 : 1), NQ1 = F1::NC == 3 ? 6 : (F1::NC == 2 ? 3 : 1);
+  [[maybe_unused]] constexpr int NQ0 = F0::NC == 3 ? 6 : (F0::NC == 2 ? 3 : 1), NQ1 = F1::NC == 3 ? 6 : (F1::NC == 2 ? 3 : 1);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
 template <int MODE>
 __global__ void dense_qdata_kernel(const DenseArgs a, double *__restrict__ qd) {
   using F0 = FieldTraits<MODE, 0>;
-  using F1 = FieldTraits<MODE, 1>;
+  using F1 [[maybe_unused]] = FieldTraits<MODE, 1>;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int e = (int)(gid / a.Q);
   if (e >= a.ne) return;

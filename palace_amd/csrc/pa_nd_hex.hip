@@ -163,9 +163,7 @@ __device__ __forceinline__ void nd_fwd_comp(const NDArgs<P1, Q1> &a, const int e
                                             double (&U)[3][Q1], double (&CU)[3][Q1]) {
   using L = NDLayout<P1, Q1>;
   constexpr int NC = L::NC;
-  constexpr int P = 3 * P1 * NC * NC;
   constexpr int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
-  constexpr int off = C * P1 * NC * NC;
   const double *TX = (C == 0) ? a.tab.Bo : a.tab.Bc;
   const double *TY = (C == 1) ? a.tab.Bo : a.tab.Bc;
   const double *TZ = (C == 2) ? a.tab.Bo : a.tab.Bc;
@@ -255,9 +253,7 @@ __device__ __forceinline__ void nd_bwd_comp(const NDArgs<P1, Q1> &a, const int e
                                             const double (&V)[3][Q1], const double (&CV)[3][Q1]) {
   using L = NDLayout<P1, Q1>;
   constexpr int NC = L::NC;
-  constexpr int P = 3 * P1 * NC * NC;
   constexpr int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
-  constexpr int off = C * P1 * NC * NC;
   const double *TX = (C == 0) ? a.tab.Bo : a.tab.Bc;
   const double *TY = (C == 1) ? a.tab.Bo : a.tab.Bc;
   const double *TZ = (C == 2) ? a.tab.Bo : a.tab.Bc;
