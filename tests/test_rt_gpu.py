@@ -126,3 +126,53 @@ def test_rt_rejects_other_qfunctions():
     with pytest.raises(RuntimeError, match="H\\(div\\)"):
         ceed.Operator(sp.ndofs, sp.ndofs).add_dense_integrator(geom, block, ceed.QF_HCURL_33,
                                                                ceed.coefficient_context(3), ceed.EVAL_INTERP)
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_rt_hex_mass_and_discrete_curl(cylinder_mesh, p):
+    """Hexahedra (the O-grid cylinder): RT mass through the dense MFMA path, B = C A through the dense interpolator, and
+    the energy identity against the sum-factorised curl-curl operator."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem import rthex
+    from palace_amd.fem.basis1d import gauss_legendre
+    from palace_amd.fem.fespace import NDHexSpace
+
+    mesh = cylinder_mesh
+    q1d = p + 1
+    nd, sp = NDHexSpace(mesh, p), rthex.RTHexSpace(mesh, p)
+    _, wts = po.hex_quadrature(q1d)
+    dgeom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.x, mesh.attr, po.mesh_q2_grad_table(q1d), wts)
+    ogeom = util.oracle_geom(mesh, q1d)
+    rint, _ = rthex.rt_hex_tables(p, gauss_legendre(q1d)[0])
+    c, blob = util.make_ctx("aniso", int(mesh.attr.max()))
+    block = ceed.DenseBlock(ceed.FE_HDIV, sp.ndofs, sp.elem_dof_lex, rint, None, orients=sp.elem_sign_lex < 0)
+    M = ceed.Operator(sp.ndofs, sp.ndofs).add_dense_integrator(dgeom, block, ceed.QF_HDIV_33, blob,
+                                                               ceed.EVAL_INTERP).finalize()
+    orc = po.CeedOperatorOracle(sp.ndofs, sp.elem_dof_lex, sp.elem_sign_lex < 0, rint, rint, ogeom, po.QF_HDIV, c)
+    rng = np.random.default_rng(p)
+    x = rng.uniform(-1, 1, sp.ndofs)
+    y = torch.empty(sp.ndofs, dtype=torch.float64, device="cuda")
+    M.mult(torch.from_numpy(x).cuda(), y)
+    ref = orc.apply_add(x, np.zeros(sp.ndofs))
+    assert np.abs(y.cpu().numpy() - ref).max() < REL * np.abs(ref).max()
+    # flux of a random potential and its energy
+    ctx = linalg.Context()
+    Cm = rthex.hex_curl_matrix(p)
+    dom = dict(offsets=nd.elem_dof_lex, lsize=nd.ndofs, orients=nd.elem_sign_lex < 0)
+    C = linalg.DenseInterp(ctx, dom, sp.restriction(interp_range=True), Cm)
+    a = rng.uniform(-1, 1, nd.ndofs)
+    ad = torch.from_numpy(a).cuda()
+    b = torch.empty(sp.ndofs, dtype=torch.float64, device="cuda")
+    C.mult(ad, b)
+    bref = po.DenseInterpOracle(dom, sp.restriction(interp_range=True), Cm).mult(a)
+    assert np.abs(b.cpu().numpy() - bref).max() < REL * np.abs(bref).max()
+    K = ceed.curlcurl_operator(ceed.GeomFactorData(mesh, q1d), nd, ceed.coefficient_context(3))
+    M1 = ceed.Operator(sp.ndofs, sp.ndofs).add_dense_integrator(dgeom, block, ceed.QF_HDIV_33,
+                                                                ceed.coefficient_context(3), ceed.EVAL_INTERP).finalize()
+    ka, mb = torch.empty_like(ad), torch.empty_like(b)
+    K.mult(ad, ka)
+    M1.mult(b, mb)
+    e_k, e_m = float(ad @ ka), float(b @ mb)
+    assert abs(e_k - e_m) < 1e-11 * abs(e_k)

@@ -111,3 +111,43 @@ def test_discrete_curl_energy_identity(kind, p):
         vhat = np.einsum("dqj,ej->eqd", rint, bF[sp.offsets] * np.where(sp.orients, -1.0, 1.0))
         vphys = np.einsum("eqid,eqd->eqi", J, vhat) / det[..., None]
         assert np.abs(vphys - np.array([0.0, 0.0, 2.0])).max() < 1e-10
+
+
+# ---- hexahedra ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_rt_hex_discrete_curl_energy_identity(cylinder_mesh, p):
+    """On the O-grid cylinder (faces seen in every relative orientation): the flux dofs computed by the elements sharing
+    a face agree (tests the face permutation + sign of RTHexSpace against NDHexSpace's), and (K u, u) = (M_RT C u, C u)
+    with the oracle's operators, whose Nedelec curl tables are evaluated independently (oracle/palace_oracle.py)."""
+    from palace_amd.fem import rthex
+    from palace_amd.fem.basis1d import gauss_legendre
+    from palace_amd.fem.fespace import NDHexSpace
+    from tests import util
+
+    mesh = cylinder_mesh
+    q1d = p + 1
+    nd, rt_ = NDHexSpace(mesh, p), rthex.RTHexSpace(mesh, p)
+    ogeom = util.oracle_geom(mesh, q1d)
+    one = po.CoeffCtx()
+    ident = np.arange(nd.P)
+    interp, curl = po.nd_hex_dense_tables(p, q1d, ident)
+    K = po.CeedOperatorOracle(nd.ndofs, nd.elem_dof_lex, nd.elem_sign_lex < 0, interp, curl, ogeom, po.QF_HDIV, one)
+    rint, rdiv = rthex.rt_hex_tables(p, gauss_legendre(q1d)[0])
+    M = po.CeedOperatorOracle(rt_.ndofs, rt_.elem_dof_lex, rt_.elem_sign_lex < 0, rint, rint, ogeom, po.QF_HDIV, one)
+    Cm = rthex.hex_curl_matrix(p)
+    dom = dict(offsets=nd.elem_dof_lex, lsize=nd.ndofs, orients=nd.elem_sign_lex < 0)
+    C = po.DenseInterpOracle(dom, rt_.restriction(interp_range=True), Cm)
+    u = np.random.default_rng(11).uniform(-1, 1, nd.ndofs)
+    b = C.mult(u)
+    ue = (u[nd.elem_dof_lex] * nd.elem_sign_lex) @ Cm.T
+    ge = b[rt_.elem_dof_lex] * rt_.elem_sign_lex
+    assert np.abs(ue - ge).max() < 1e-10 * np.abs(ue).max()
+    e_k = u @ K.apply_add(u, np.zeros(nd.ndofs))
+    e_m = b @ M.apply_add(b, np.zeros(rt_.ndofs))
+    assert abs(e_k - e_m) < 1e-11 * abs(e_k)
+    # div curl = 0 point-wise (reference divergence of the element flux)
+    assert np.abs(ue @ rdiv.T).max() < 1e-9 * np.abs(ue).max()
+    # every face dof is shared by at most two elements, interior dofs by one
+    cnt = np.bincount(rt_.elem_dof_lex.ravel(), minlength=rt_.ndofs)
+    assert cnt.min() == 1 and cnt.max() == 2 and rt_.ndofs == mesh.nfaces * p * p + mesh.ne * 3 * p * p * (p - 1)
