@@ -109,6 +109,15 @@ int pa_gmg_create_aux(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_inte
 /* Gram-Schmidt variant of (F)GMRES: 0 = MGS (default), 1 = CGS, 2 = CGS2 (config "Orthogonalization",
  * linalg/orthog.hpp:41-89).  The classical variants do all inner products of a column in one pass over
  * the new vector and one all-reduce. */
+/* OrthogonalizeColumnMGS / OrthogonalizeColumnCGS (linalg/orthog.hpp:41-89) as free functions, the form the reference's
+ * own unit tests exercise (test/unit/test-orthog.cpp): H[j] = (w, V[j]), w -= sum_j H[j] V[j] for j < m; kind 0 = MGS,
+ * 1 = CGS, 2 = CGS with one refinement pass.  V[j], w: device vectors of length n (assumed normalised; w is not
+ * normalised on return); H: host.  `weight` (or NULL): (w, v) = v^T W w with a square real operator.  The complex form
+ * takes separate real / imaginary arrays (ComplexVector) and returns H as (re, im) pairs, H[j] = V[j]^H (W) w. */
+int pa_orthogonalize_column(pa_context *ctx, int kind, int m, const double *const *V, double *w, int n, double *H,
+                            pa_par_op *weight);
+int pa_orthogonalize_column_complex(pa_context *ctx, int kind, int m, const double *const *Vr, const double *const *Vi,
+                                    double *wr, double *wi, int n, double *H, pa_par_op *weight);
 int pa_gmres_set_orthogonalization(pa_solver *S, int kind);
 int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess);
 int pa_solver_stats(const pa_solver *S, int *iterations, double *initial_res, double *final_res,

@@ -868,3 +868,38 @@ class DenseInterpOracle:
         y = np.zeros(self.dom["lsize"])
         np.add.at(y, np.asarray(self.dom["offsets"]).ravel(), w.ravel())
         return y
+
+
+# ---------------------------------------------------------------------------------------------
+# Orthogonalisation of a Krylov column (linalg/orthog.hpp:41-89), as the reference's free functions:
+# the inputs V[j] are assumed normalised, w is not normalised on return.
+# ---------------------------------------------------------------------------------------------
+
+def orthogonalize_column(kind, V, w, m, weight=None):
+    """OrthogonalizeColumnMGS (kind "MGS", :41-55) / OrthogonalizeColumnCGS (kind "CGS", "CGS2" = refine, :57-89).
+    Returns (H, w_new).  Inner product dot_op(w, v) = v^H (W w) (LocalDot(x, y) = y^H x, vector.cpp:674-685; the
+    weighted helper of test/unit/test-orthog.cpp:21-68 applies the real W to w first)."""
+    w = np.array(w, dtype=np.result_type(w, *[v for v in V[:m]]) if m else None, copy=True)
+    H = np.zeros(m, dtype=w.dtype)
+
+    def dot(x, y):
+        wx = x if weight is None else weight @ x
+        return np.vdot(y, wx)
+
+    if kind == "MGS":
+        for j in range(m):
+            H[j] = dot(w, V[j])
+            w = w - H[j] * V[j]
+        return H, w
+    if m == 0:
+        return H, w
+    for j in range(m):
+        H[j] = dot(w, V[j])
+    for j in range(m):
+        w = w - H[j] * V[j]
+    if kind == "CGS2":
+        dH = np.array([dot(w, V[j]) for j in range(m)])
+        for j in range(m):
+            H[j] += dH[j]
+            w = w - dH[j] * V[j]
+    return H, w

@@ -116,6 +116,41 @@ void Fill(const Context &c, ComplexVector &x, double s) {
   Fill(c, x.Real(), s);
   Fill(c, x.Imag(), s);
 }
+void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
+                         std::complex<double> *H, int m, const Operator *weight) {
+  PA_REQUIRE(m >= 0 && (size_t)m <= V.size(), "Out of bounds number of columns for orthogonalization!");
+  if (m == 0) return;
+  for (int j = 0; j < m; j++) PA_REQUIRE(V[j].Size() == w.Size(), "size mismatch in OrthogonalizeColumn");
+  ComplexVector ws;
+  if (weight) {
+    PA_REQUIRE(weight->Height() == w.Size() && weight->Width() == w.Size(), "weight operator does not match the vectors");
+    ws.SetSize(w.Size());
+  }
+  auto weighted = [&]() -> const ComplexVector & {
+    if (!weight) return w;
+    weight->Mult(w.Real(), ws.Real());
+    weight->Mult(w.Imag(), ws.Imag());
+    return ws;
+  };
+  if (kind == Orthogonalization::MGS) {
+    for (int j = 0; j < m; j++) {
+      H[j] = Dot(c, weighted(), V[j]);
+      AXPY(c, -H[j], V[j], w);
+    }
+    return;
+  }
+  auto pass = [&](std::complex<double> *h) {
+    const ComplexVector &x = weighted();
+    for (int j = 0; j < m; j++) h[j] = Dot(c, x, V[j]);  // all from the same w
+    for (int j = 0; j < m; j++) AXPY(c, -h[j], V[j], w);
+  };
+  pass(H);
+  if (kind == Orthogonalization::CGS2) {
+    std::vector<std::complex<double>> dH((size_t)m);
+    pass(dH.data());
+    for (int j = 0; j < m; j++) H[j] += dH[j];
+  }
+}
 
 }  // namespace linalg
 

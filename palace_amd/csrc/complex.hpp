@@ -34,6 +34,10 @@ void AXPY(const Context &c, std::complex<double> alpha, const ComplexVector &x, 
 void Scale(const Context &c, double s, ComplexVector &x);
 void Copy(const Context &c, const ComplexVector &x, ComplexVector &y);
 void Fill(const Context &c, ComplexVector &x, double s);
+// complex instantiation of OrthogonalizeColumnMGS / CGS (orthog.hpp:41-89): H[j] = V[j]^H (W) w, w -= sum_j H[j] V[j];
+// `weight` is a real operator applied to the real and the imaginary part (test/unit/test-orthog.cpp:49-67)
+void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
+                         std::complex<double> *H, int m, const Operator *weight = nullptr);
 }  // namespace linalg
 
 class ComplexOperator {

@@ -449,6 +449,36 @@ void MultiAXPY(const Context &c, const double *H, const std::vector<Vector> &V, 
     launch_ew(OpMultiAxpy{a, P, mb, w.Data()}, w.Size(), c.stream);
   }
 }
+void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<Vector> &V, Vector &w, double *H,
+                         int m, const Operator *weight) {
+  PA_REQUIRE(m >= 0 && (size_t)m <= V.size(), "Out of bounds number of columns for orthogonalization!");
+  if (m == 0) return;
+  for (int j = 0; j < m; j++) PA_REQUIRE(V[j].Size() == w.Size(), "size mismatch in OrthogonalizeColumn");
+  Vector ws;
+  if (weight) {
+    PA_REQUIRE(weight->Height() == w.Size() && weight->Width() == w.Size(), "weight operator does not match the vectors");
+    ws.SetSize(w.Size());
+  }
+  if (kind == Orthogonalization::MGS) {  // orthog.hpp:41-55
+    for (int j = 0; j < m; j++) {
+      if (weight) weight->Mult(w, ws);
+      H[j] = Dot(c, weight ? ws : w, V[j]);
+      AXPY(c, -H[j], V[j], w);
+    }
+    return;
+  }
+  // classical Gram-Schmidt: all inner products of a pass from the same w, one reduction (orthog.hpp:57-89)
+  if (weight) weight->Mult(w, ws);
+  MultiDot(c, weight ? ws : w, V, m, H);
+  MultiAXPY(c, H, V, m, w);
+  if (kind == Orthogonalization::CGS2) {
+    std::vector<double> dH((size_t)m);
+    if (weight) weight->Mult(w, ws);
+    MultiDot(c, weight ? ws : w, V, m, dH.data());
+    MultiAXPY(c, dH.data(), V, m, w);
+    for (int j = 0; j < m; j++) H[j] += dH[j];
+  }
+}
 double Norml2(const Context &c, const Vector &x) { return std::sqrt(Dot(c, x, x)); }
 double Normalize(const Context &c, Vector &x) {
   const double nrm = Norml2(c, x);

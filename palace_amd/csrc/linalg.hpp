@@ -326,6 +326,15 @@ public:
 
 enum class Orthogonalization { MGS = 0, CGS = 1, CGS2 = 2 };  // config "Orthogonalization", orthog.hpp:41-89
 
+namespace linalg {
+// OrthogonalizeColumnMGS / OrthogonalizeColumnCGS (linalg/orthog.hpp:41-89): H[j] = (w, V[j]) for j < m and
+// w -= sum_j H[j] V[j]; the inputs are assumed normalised, the output is not normalised.  `weight` (optional, square)
+// makes the inner product (w, v) = v^T W w as the reference's weighted inner-product helpers do
+// (test/unit/test-orthog.cpp:21-68).  CGS2 = CGS with one refinement pass (refine = true).
+void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<Vector> &V, Vector &w, double *H,
+                         int m, const Operator *weight = nullptr);
+}  // namespace linalg
+
 class GmresSolver : public IterativeSolver {
   int max_dim_ = -1;
   bool flexible_ = false;  // FGMRES (right preconditioning, stores Z)

@@ -91,6 +91,29 @@ class Context:
                                           C.byref(fl)))
         return fl.value
 
+    def orthogonalize_column(self, kind, V, w, weight=None):
+        """OrthogonalizeColumnMGS / CGS / CGS2 (orthog.hpp:41-89): returns H, updates w in place.  kind in
+        {"MGS", "CGS", "CGS2"}; V = list of device vectors; weight = ParOperator or None."""
+        m = len(V)
+        k = {"MGS": 0, "CGS": 1, "CGS2": 2}[kind]
+        ptrs = (C.c_void_p * max(m, 1))(*[v.data_ptr() for v in V])
+        H = np.zeros(max(m, 1), dtype=np.float64)
+        _lib.check(_L().pa_orthogonalize_column(self.handle, C.c_int(k), C.c_int(m), ptrs, C.c_void_p(w.data_ptr()),
+                                                C.c_int(w.numel()), _ptr(H), weight.handle if weight else None))
+        return H[:m]
+
+    def orthogonalize_column_complex(self, kind, Vr, Vi, wr, wi, weight=None):
+        """The complex form (ComplexVector = separate real / imaginary vectors): returns complex H."""
+        m = len(Vr)
+        k = {"MGS": 0, "CGS": 1, "CGS2": 2}[kind]
+        pr = (C.c_void_p * max(m, 1))(*[v.data_ptr() for v in Vr])
+        pi = (C.c_void_p * max(m, 1))(*[v.data_ptr() for v in Vi])
+        H = np.zeros(2 * max(m, 1), dtype=np.float64)
+        _lib.check(_L().pa_orthogonalize_column_complex(self.handle, C.c_int(k), C.c_int(m), pr, pi,
+                                                        C.c_void_p(wr.data_ptr()), C.c_void_p(wi.data_ptr()),
+                                                        C.c_int(wr.numel()), _ptr(H), weight.handle if weight else None))
+        return H[0:2 * m:2] + 1j * H[1:2 * m:2]
+
     def set_random(self, x, seed):
         _lib.check(_L().pa_vec_set_random(self.handle, C.c_void_p(x.data_ptr()), x.numel(), seed))
         return x

@@ -1,0 +1,107 @@
+"""OrthogonalizeColumn{MGS,CGS,CGS2} on the device (pa_orthogonalize_column[_complex]) through the cases of the
+reference's own unit test (test/unit/test-orthog.cpp) and against the oracle's restatement on larger random data."""
+import numpy as np
+import pytest
+
+from oracle import palace_oracle as po
+
+pytestmark = pytest.mark.gpu
+KINDS = ["MGS", "CGS", "CGS2"]
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from palace_amd import linalg
+
+    return linalg.Context()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_real_cases_of_the_reference(ctx, kind):
+    # "Real Empty" (test-orthog.cpp:98-121)
+    w = _dev(np.arange(4.0))
+    H = ctx.orthogonalize_column(kind, [], w)
+    assert H.size == 0 and np.array_equal(w.cpu().numpy(), np.arange(4.0))
+    # "Real 2" (:162-229) at communicator size 1: exact second basis vector, known coefficients
+    V = [_dev([1.0, 0, 0, 0]), _dev([0.0, 1, 0, 0])]
+    v1 = V[1].clone()
+    ctx.orthogonalize_column(kind, V[:1], v1)
+    assert np.array_equal(v1.cpu().numpy(), [0.0, 1.0, 0.0, 0.0])
+    w = _dev(np.arange(4.0))
+    H = ctx.orthogonalize_column(kind, V, w)
+    wn = w.cpu().numpy()
+    assert abs(wn[0]) < 1e-12 and abs(wn[1]) < 1e-12 and wn[2] == 2.0 and wn[3] == 3.0
+    assert abs(H[0]) < 1e-15 and H[1] == pytest.approx(1.0)
+
+
+@pytest.mark.parametrize("m", [1, 5, 11])
+@pytest.mark.parametrize("kind", KINDS)
+def test_real_random_vs_oracle(ctx, kind, m):
+    rng = np.random.default_rng(m)
+    n = 1001
+    Q, _ = np.linalg.qr(rng.normal(size=(n, m)))
+    V = [Q[:, j].copy() for j in range(m)]
+    w = rng.normal(size=n)
+    Href, wref = po.orthogonalize_column(kind, V, w, m)
+    wd = _dev(w)
+    H = ctx.orthogonalize_column(kind, [_dev(v) for v in V], wd)
+    assert np.abs(H - Href).max() < 1e-12 * max(1.0, np.abs(Href).max())
+    assert np.abs(wd.cpu().numpy() - wref).max() < 1e-12 * np.abs(wref).max()
+    assert max(abs(np.dot(wd.cpu().numpy(), v)) for v in V) < 1e-12 * np.linalg.norm(w)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_complex_random_vs_oracle(ctx, kind):
+    rng = np.random.default_rng(3)
+    n, m = 513, 4
+    Q, _ = np.linalg.qr(rng.normal(size=(n, m)) + 1j * rng.normal(size=(n, m)))
+    V = [Q[:, j].copy() for j in range(m)]
+    w = rng.normal(size=n) + 1j * rng.normal(size=n)
+    Href, wref = po.orthogonalize_column(kind, V, w, m)
+    wr, wi = _dev(w.real), _dev(w.imag)
+    H = ctx.orthogonalize_column_complex(kind, [_dev(v.real) for v in V], [_dev(v.imag) for v in V], wr, wi)
+    got = wr.cpu().numpy() + 1j * wi.cpu().numpy()
+    assert np.abs(H - Href).max() < 1e-12 * max(1.0, np.abs(Href).max())
+    assert np.abs(got - wref).max() < 1e-12 * np.abs(wref).max()
+    assert max(abs(np.vdot(v, got)) for v in V) < 1e-12 * np.linalg.norm(w)  # Dot(w, V_j) = V_j^H w
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_weighted_by_the_mass_operator(ctx, kind, cylinder_mesh):
+    """"Weighted" cases (:270-374) with the Nedelec mass operator as the SPD weight: the result is M-orthogonal to the
+    M-normalised basis (what the eigensolver's B-orthogonalisation needs)."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem.fespace import NDHexSpace
+
+    nd = NDHexSpace(cylinder_mesh, 1)
+    geom = ceed.GeomFactorData(cylinder_mesh, 2)
+    M = linalg.ParOperator(ctx, ceed.ndmass_operator(geom, nd, ceed.coefficient_context(3)), np.zeros(0, np.int32),
+                           linalg.DIAG_ONE)
+    rng = np.random.default_rng(9)
+    n, m = nd.ndofs, 3
+    V, t = [], torch.empty(n, dtype=torch.float64, device="cuda")
+    for j in range(m):  # M-orthonormal basis by MGS with the device routine itself + explicit normalisation
+        v = _dev(rng.normal(size=n))
+        ctx.orthogonalize_column("MGS", V, v, weight=M)
+        M.mult(v, t)
+        v /= float(torch.sqrt(v @ t))
+        V.append(v)
+    for i in range(m):
+        M.mult(V[i], t)
+        for j in range(m):
+            assert abs(float(V[j] @ t) - (1.0 if i == j else 0.0)) < 1e-12
+    w = _dev(rng.normal(size=n))
+    w0 = w.clone()
+    H = ctx.orthogonalize_column(kind, V, w, weight=M)
+    for j in range(m):
+        M.mult(V[j], t)
+        assert abs(float(w @ t)) < 1e-11 * float(w0.norm())
+        assert H[j] == pytest.approx(float(w0 @ t), rel=1e-10, abs=1e-12)
