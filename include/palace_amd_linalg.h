@@ -73,6 +73,10 @@ int pa_par_op_assemble_diagonal(pa_par_op *A, double *diag);
 
 /* --- vectors (linalg/vector.cpp) ------------------------------------------------------------- */
 int pa_vec_dot(pa_context *ctx, const double *x, const double *y, int n, double *result);
+/* linalg::Sum (global sum of the entries; LocalSum vector.cpp:687-699 + Mpi::GlobalSum; a ComplexVector's sum is the
+ * pair of its parts' sums) and linalg::Sqrt (x = sqrt(s x), vector.cpp:774-781); unit tests test/unit/test-vector.cpp. */
+int pa_vec_sum(pa_context *ctx, const double *x, int n, double *result);
+int pa_vec_sqrt(pa_context *ctx, double *x, int n, double s);
 int pa_vec_axpby(pa_context *ctx, double a, const double *x, double b, double *y, int n);
 /* Measurement aid (SURVEY.md 8d "measure both peaks in the same run"): launches n_blocks x 256 threads that each
  * issue `iters` rounds of eight independent v_mfma_f64_16x16x4_f64; *flops_per_launch receives the flop count.

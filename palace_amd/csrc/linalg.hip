@@ -187,6 +187,18 @@ struct OpChebStep {
   }
   uintptr_t align() const { return bits(di) | bits(t) | bits(r) | bits(d) | bits(y); }
 };
+__device__ __forceinline__ double vsqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ d2 vsqrt(d2 v) { return d2{sqrt(v.x), sqrt(v.y)}; }
+// x = sqrt(s x)   (linalg::Sqrt, vector.cpp:774-781)
+struct OpSqrt {
+  double s;
+  double *x;
+  template <class T>
+  __device__ void at(long long i) const {
+    as<T>(x)[i] = vsqrt(as<T>(x)[i] * s);
+  }
+  uintptr_t align() const { return bits(x); }
+};
 // x += a p;  r -= a z   (the two AXPYs of a CG iteration, iterative.cpp:448-449)
 struct OpCgUpdate {
   double a;
@@ -249,6 +261,22 @@ __global__ __launch_bounds__(256) void k_dot_partial(const double *__restrict__ 
   if (W > 1) {
     const long long j = nv * W + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) s += x[j] * y[j];
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// sum of the entries (linalg::LocalSum, vector.cpp:687-699): same two-stage reduction as the dot product
+template <int W>
+__global__ __launch_bounds__(256) void k_sum_partial(const double *__restrict__ x, long long n,
+                                                     double *__restrict__ partial) {
+  using T = typename Lane<W>::type;
+  const long long nv = n / W;
+  T acc = T{};
+  PA_STRIDE_LOOP(i, nv) acc += as<T>(x)[i];
+  double s = hsum(acc);
+  if (W > 1) {
+    const long long j = nv * W + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) s += x[j];
   }
   s = block_sum(s);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -479,6 +507,23 @@ void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::ve
     for (int j = 0; j < m; j++) H[j] += dH[j];
   }
 }
+double Sum(const Context &c, const Vector &x) {
+  Scratch &s = scratch();
+  if (x.Size() == 0 && !c.comm) return 0.0;
+  const bool wide = (bits(x.Data()) & 15) == 0 && x.Size() >= 2;
+  const int nb = grid_for(wide ? (x.Size() + 1) / 2 : std::max(x.Size(), 1));
+  if (wide)
+    hipLaunchKernelGGL(k_sum_partial<2>, dim3(nb), dim3(kBlock), 0, c.stream, x.Data(), (long long)x.Size(), s.d_partial);
+  else
+    hipLaunchKernelGGL(k_sum_partial<1>, dim3(nb), dim3(kBlock), 0, c.stream, x.Data(), (long long)x.Size(), s.d_partial);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kBlock), 0, c.stream, s.d_partial, nb, s.d_partial + kMaxBlocks);
+  PA_HIP(hipGetLastError());
+  if (c.comm) c.comm->AllReduceSum(s.d_partial + kMaxBlocks, 1, c.stream);  // Mpi::GlobalSum (vector.hpp)
+  PA_HIP(hipMemcpyAsync(s.h_result, s.d_partial + kMaxBlocks, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  PA_HIP(hipStreamSynchronize(c.stream));
+  return s.h_result[0];
+}
+void Sqrt(const Context &c, Vector &x, double s) { launch_ew(OpSqrt{s, x.Data()}, x.Size(), c.stream); }
 double Norml2(const Context &c, const Vector &x) { return std::sqrt(Dot(c, x, x)); }
 double Normalize(const Context &c, Vector &x) {
   const double nrm = Norml2(c, x);

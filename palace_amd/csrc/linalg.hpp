@@ -75,6 +75,9 @@ void Reciprocal(const Context &c, Vector &x);
 // (vector.hpp:247-260).
 double Dot(const Context &c, const Vector &x, const Vector &y);
 double Norml2(const Context &c, const Vector &x);
+// global sum of the entries (vector.hpp Sum -> LocalSum, vector.cpp:687-699) and x = sqrt(s x) (vector.cpp:774-781)
+double Sum(const Context &c, const Vector &x);
+void Sqrt(const Context &c, Vector &x, double s = 1.0);
 // x /= ||x||, returns the norm (vector.hpp:264-270)
 double Normalize(const Context &c, Vector &x);
 // Deterministic uniform [-1, 1) fill from a counter-based generator (stands in for

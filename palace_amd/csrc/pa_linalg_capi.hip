@@ -186,6 +186,20 @@ int pa_vec_dot(pa_context *ctx, const double *x, const double *y, int n, double 
     *result = linalg::Dot(ctx->ctx, vx, vy);
   });
 }
+int pa_vec_sum(pa_context *ctx, const double *x, int n, double *result) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && result && n >= 0, "bad argument");
+    Vector vx(const_cast<double *>(x), n);
+    *result = linalg::Sum(ctx->ctx, vx);
+  });
+}
+int pa_vec_sqrt(pa_context *ctx, double *x, int n, double s) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && n >= 0, "bad argument");
+    Vector vx(x, n);
+    linalg::Sqrt(ctx->ctx, vx, s);
+  });
+}
 int pa_vec_axpby(pa_context *ctx, double a, const double *x, double b, double *y, int n) {
   return guarded([&] {
     Vector vx(const_cast<double *>(x), n), vy(y, n);

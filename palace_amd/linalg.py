@@ -78,6 +78,17 @@ class Context:
                                    C.c_int(x.numel()), C.byref(out)))
         return out.value
 
+    def sum(self, x):
+        """linalg::Sum (vector.cpp:687-699 + global sum)."""
+        out = C.c_double()
+        _lib.check(_L().pa_vec_sum(self.handle, C.c_void_p(x.data_ptr()), C.c_int(x.numel()), C.byref(out)))
+        return out.value
+
+    def sqrt(self, x, s=1.0):
+        """linalg::Sqrt: x = sqrt(s x) (vector.cpp:774-781)."""
+        _lib.check(_L().pa_vec_sqrt(self.handle, C.c_void_p(x.data_ptr()), C.c_int(x.numel()), C.c_double(s)))
+        return x
+
     def axpby(self, a, x, b, y):
         """y = a x + b y (linalg::AXPBY, vector.cpp:530-557)."""
         _lib.check(_L().pa_vec_axpby(self.handle, a, C.c_void_p(x.data_ptr()), b, C.c_void_p(y.data_ptr()),
