@@ -875,10 +875,13 @@ class DenseInterpOracle:
 # the inputs V[j] are assumed normalised, w is not normalised on return.
 # ---------------------------------------------------------------------------------------------
 
-def orthogonalize_column(kind, V, w, m, weight=None):
+def orthogonalize_column(kind, V, w, m, weight=None, global_sum=None):
     """OrthogonalizeColumnMGS (kind "MGS", :41-55) / OrthogonalizeColumnCGS (kind "CGS", "CGS2" = refine, :57-89).
     Returns (H, w_new).  Inner product dot_op(w, v) = v^H (W w) (LocalDot(x, y) = y^H x, vector.cpp:674-685; the
-    weighted helper of test/unit/test-orthog.cpp:21-68 applies the real W to w first)."""
+    weighted helper of test/unit/test-orthog.cpp:21-68 applies the real W to w first).  global_sum(array) -> array is
+    Mpi::GlobalSum over the communicator (identity on one rank): one call per coefficient for MGS, one per pass for
+    CGS."""
+    gs = (lambda a: a) if global_sum is None else global_sum
     w = np.array(w, dtype=np.result_type(w, *[v for v in V[:m]]) if m else None, copy=True)
     H = np.zeros(m, dtype=w.dtype)
 
@@ -888,17 +891,18 @@ def orthogonalize_column(kind, V, w, m, weight=None):
 
     if kind == "MGS":
         for j in range(m):
-            H[j] = dot(w, V[j])
+            H[j] = gs(np.array([dot(w, V[j])]))[0]
             w = w - H[j] * V[j]
         return H, w
     if m == 0:
         return H, w
     for j in range(m):
         H[j] = dot(w, V[j])
+    H[:] = gs(H)
     for j in range(m):
         w = w - H[j] * V[j]
     if kind == "CGS2":
-        dH = np.array([dot(w, V[j]) for j in range(m)])
+        dH = gs(np.array([dot(w, V[j]) for j in range(m)]))
         for j in range(m):
             H[j] += dH[j]
             w = w - dH[j] * V[j]
