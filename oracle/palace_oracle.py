@@ -907,3 +907,34 @@ def orthogonalize_column(kind, V, w, m, weight=None, global_sum=None):
             H[j] += dH[j]
             w = w - dH[j] * V[j]
     return H, w
+
+
+# ---------------------------------------------------------------------------------------------
+# Mixed (trial space != test space) operators: fem/integ/mixedveccurl.cpp
+# ---------------------------------------------------------------------------------------------
+
+class MixedCurlOperatorOracle:
+    """MixedVectorCurlIntegrator with an H(div) test space (mixedveccurl.cpp:22-68): (Q curl u, v) for u in ND, v in RT,
+    y = E_test^T B_test^T D G_trial E_trial x with D = f_apply_hdiv_33 (both factors are H(div)-mapped), trial ops Curl,
+    test ops Interp.  MixedVectorWeakCurlIntegrator with an H(div) trial space (:70-117) is its transpose with the
+    coefficient scaled by -1: `weak=True` applies -(this)^T.
+    trial / test: dicts with offsets [NE, P], lsize and orients | curl_orients (native restrictions)."""
+
+    def __init__(self, trial, test, trial_curl, test_interp, geom, ctx):
+        self.tr = CeedOperatorOracle(trial["lsize"], trial["offsets"], trial.get("orients"), trial_curl, trial_curl, geom,
+                                     QF_HDIV, ctx, curl_orients=trial.get("curl_orients"))
+        self.te = CeedOperatorOracle(test["lsize"], test["offsets"], test.get("orients"), test_interp, test_interp, geom,
+                                     QF_HDIV, ctx, curl_orients=test.get("curl_orients"))
+        self.geom, self.ctx = geom, ctx
+
+    def mult(self, x, chunk=2048, weak=False):
+        a, b = (self.te, self.tr) if weak else (self.tr, self.te)  # a: input side, b: output side
+        y = np.zeros(b.lsize)
+        for s in range(0, a.NE, chunk):
+            sl = slice(s, min(a.NE, s + chunk))
+            ue = a._restrict(x, sl)
+            cu = np.einsum("dqj,ej->edq", a.deriv, ue)      # curl (trial) or value (weak: RT values) at the points
+            cv = apply_hdiv_33(self.ctx, self.geom[sl], cu)  # symmetric coefficients: D^T = D
+            ve = b._restrict_t(np.einsum("dqj,edq->ej", b.deriv, cv), sl)
+            np.add.at(y, b.off[sl].ravel(), ve.ravel())
+        return -y if weak else y
