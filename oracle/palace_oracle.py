@@ -469,6 +469,9 @@ class CeedOperatorOracle:
         if qf == QF_HCURL_32:  # boundary ND mass (surface impedance / absorbing / lumped-port terms)
             u = np.einsum("dqj,ej->edq", self.interp, ue)
             return np.einsum("dqj,edq->ej", self.interp, apply_hcurl_32(self.ctx, geom, u))
+        if qf == QF_HCURL_22 and not self.vector_fe:  # 2-D H1 diffusion: hcurl Piola on grad u (integ/diffusion.cpp)
+            gu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            return np.einsum("dqj,edq->ej", self.deriv, apply_hcurl_22(self.ctx, geom, gu))
         if qf == QF_HCURL_22:  # 2-D ND mass
             u = np.einsum("dqj,ej->edq", self.interp, ue)
             return np.einsum("dqj,edq->ej", self.interp, apply_hcurl_22(self.ctx, geom, u))

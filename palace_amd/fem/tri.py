@@ -232,3 +232,67 @@ class NDTriSpace:
         em = m.boundary_edge_mask if edge_mask is None else edge_mask
         edges = np.nonzero(em)[0]
         return (edges[:, None] * self.p + np.arange(self.p)[None, :]).ravel().astype(np.int32)
+
+
+class H1TriElement:
+    """Nodal H1 triangle of order p on the lattice nodes: vertices, p - 1 per edge (LOCAL_EDGES order, from the edge's
+    first to its second local vertex), interior.  tables(x) -> interp [1, Q, P], grad [2, Q, P]."""
+
+    def __init__(self, p):
+        self.p = p
+        V = REF_VERTS
+        nodes = [V[0], V[1], V[2]]
+        for a, b in LOCAL_EDGES:
+            for k in range(1, p):
+                nodes.append(V[a] + (V[b] - V[a]) * k / p)
+        for j in range(1, p):
+            for i in range(1, p - j):
+                nodes.append(np.array([i / p, j / p]))
+        self.nodes = np.array(nodes)
+        self.P = self.nodes.shape[0]
+        assert self.P == (p + 1) * (p + 2) // 2
+        self.monos = _monos(0, p)
+        Vm = np.array([_mv(e, self.nodes - _C) for e in self.monos]).T
+        self.coef = np.linalg.inv(Vm)
+
+    def tables(self, x):
+        z = x - _C
+        val = np.array([_mv(e, z) for e in self.monos])       # [nm, Q]
+        grd = np.array([_mg(e, z) for e in self.monos])       # [nm, Q, 2]
+        interp = np.einsum("kq,kj->qj", val, self.coef)[None]
+        grad = np.einsum("kqd,kj->dqj", grd, self.coef)
+        return np.ascontiguousarray(interp), np.ascontiguousarray(grad)
+
+
+class H1TriSpace:
+    """Order-p nodal H1 space on a TriMesh: global dofs = vertices | edges | interiors, plain restriction."""
+
+    def __init__(self, mesh: TriMesh, p: int):
+        self.mesh, self.p = mesh, p
+        self.elem = H1TriElement(p)
+        self.P = self.elem.P
+        ne, nv, ned = mesh.ne, mesh.verts.shape[0], mesh.edge_verts.shape[0]
+        n_e, n_i = p - 1, (p - 1) * (p - 2) // 2
+        self.edge_base, self.int_base = nv, nv + ned * n_e
+        self.ndofs = self.int_base + ne * n_i
+        off = np.zeros((ne, self.P), dtype=np.int64)
+        t = mesh.tris
+        off[:, :3] = t
+        for k, (a, b) in enumerate(LOCAL_EDGES):
+            flip = t[:, a] > t[:, b]
+            for m in range(n_e):
+                gm = np.where(flip, n_e - 1 - m, m)
+                off[:, 3 + k * n_e + m] = self.edge_base + mesh.elem_edges[:, k] * n_e + gm
+        for i in range(n_i):
+            off[:, 3 + 3 * n_e + i] = self.int_base + np.arange(ne) * n_i + i
+        self.offsets = off.astype(np.int32)
+
+    def ess_dofs(self, edge_mask=None):
+        m = self.mesh
+        em = m.boundary_edge_mask if edge_mask is None else edge_mask
+        edges = np.nonzero(em)[0]
+        n_e = self.p - 1
+        d = [np.unique(m.edge_verts[edges].ravel()),
+             (self.edge_base + edges[:, None] * n_e + np.arange(n_e)[None, :]).ravel()]
+        return np.unique(np.concatenate(d)).astype(np.int32)
+

@@ -82,3 +82,35 @@ def test_cavity2d_eigenfrequencies():
     f = np.sqrt(lam / (2.08 * (1.0 - 4e-4j))) * 299792458.0 / (2 * np.pi) / 1e9
     np.testing.assert_allclose(f.real, M_["eig_re_GHz"], rtol=1e-7)
     np.testing.assert_allclose(f.imag, M_["eig_im_GHz"], rtol=1e-5)
+
+
+def test_h1_laplace_eigenvalues_on_the_cavity2d_mesh():
+    """2-D H1 path of the oracle (f_apply_hcurl_22 on the gradient = DiffusionIntegrator in 2-D, f_apply_h1_1 mass) on
+    the reference's cavity2d mesh (the 1 x 0.5 rectangle) with order-3 nodal triangles: Dirichlet Laplace eigenvalues
+    pi^2 (m^2 + 4 n^2)."""
+    import scipy.sparse.linalg as spl
+
+    from palace_amd.fem import tri
+
+    M_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "cavity2d_mesh.npz"))
+    en = M_["elem_nodes"].astype(np.int64)
+    used, inv = np.unique(en[:, :3], return_inverse=True)
+    mesh = tri.TriMesh(M_["nodes"][used], inv.reshape(-1, 3), M_["attr"], elem_nodes=en, nodes=M_["nodes"])
+    h1 = tri.H1TriSpace(mesh, 3)
+    assert h1.ndofs == 19288
+    pts, wts = tri.tri_quadrature(4)
+    interp, grad = h1.elem.tables(pts)
+    assert np.abs(interp.sum(axis=2) - 1.0).max() < 1e-13  # partition of unity
+    J = mesh.jacobians(pts)
+    geom = po.build_geom_factor_22(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 4))
+    assert abs(geom[:, 1, :].sum() - 0.5) < 1e-12  # area of the rectangle
+    K = po.CeedOperatorOracle(h1.ndofs, h1.offsets, None, interp, grad, geom, po.QF_HCURL_22, po.CoeffCtx(dim=2),
+                              vector_fe=False).assemble_sparse()
+    M = po.CeedOperatorOracle(h1.ndofs, h1.offsets, None, interp, grad, geom, po.QF_H1MASS, po.CoeffCtx(dim=1),
+                              vector_fe=False).assemble_sparse()
+    assert abs(K - K.T).max() < 1e-12 and abs(K @ np.ones(h1.ndofs)).max() < 1e-10
+    free = np.setdiff1d(np.arange(h1.ndofs), h1.ess_dofs())
+    lam = spl.eigsh(K[free][:, free].tocsc(), k=5, M=M[free][:, free].tocsc(), sigma=0.0, which="LM",
+                    return_eigenvectors=False)
+    ref = np.sort([np.pi ** 2 * (m * m + 4 * n * n) for m in range(1, 6) for n in range(1, 4)])[:5]
+    np.testing.assert_allclose(np.sort(lam), ref, rtol=2e-8)
