@@ -107,8 +107,16 @@ def fixtures_2d():
     np.savez(os.path.join(ROOT, "tests", "golden", "qf2d_golden.npz"), **out)
     m = tri.read_gmsh22_tris("/root/reference/examples/cavity2d/mesh/cavity2d.msh")
     eig = np.loadtxt("/root/reference/test/data/regression/ref/cavity2d/eigenmode/eig.csv", delimiter=",", skiprows=1)
+    # boundary edges (vertex pairs in the node numbering of `nodes`) with their attributes, and the regression values of
+    # the magnetostatic / electrostatic cases on the same mesh (terminal-M.csv, terminal-C.csv)
+    used = np.unique(m.elem_nodes[:, :3])
+    bdr = used[m.bdr_edges]
+    ref = "/root/reference/test/data/regression/ref/cavity2d/"
+    M11 = np.loadtxt(ref + "magnetostatic/terminal-M.csv", delimiter=",", skiprows=1)[1]
+    C11 = np.loadtxt(ref + "electrostatic/terminal-C.csv", delimiter=",", skiprows=1)[1]
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "cavity2d_mesh.npz"), nodes=m.nodes,
-                        elem_nodes=m.elem_nodes.astype(np.int32), attr=m.attr, eig_re_GHz=eig[:, 1], eig_im_GHz=eig[:, 2])
+                        elem_nodes=m.elem_nodes.astype(np.int32), attr=m.attr, eig_re_GHz=eig[:, 1], eig_im_GHz=eig[:, 2],
+                        bdr_edges=bdr.astype(np.int32), bdr_attr=m.bdr_attr.astype(np.int32), M11_H=M11, C11_F=C11)
     print("wrote qf2d_golden.npz, cavity2d_mesh.npz")
 
 

@@ -114,3 +114,68 @@ def test_h1_laplace_eigenvalues_on_the_cavity2d_mesh():
                     return_eigenvectors=False)
     ref = np.sort([np.pi ** 2 * (m * m + 4 * n * n) for m in range(1, 6) for n in range(1, 4)])[:5]
     np.testing.assert_allclose(np.sort(lam), ref, rtol=2e-8)
+
+
+def test_cavity2d_magnetostatic_inductance():
+    """The reference's regression value M11 = 6.283185306350e-07 H (test/data/regression/ref/cavity2d/magnetostatic/
+    terminal-M.csv; examples/cavity2d/cavity2d_magnetostatic.json: order 2, PEC on the walls, unit surface current along
+    +x on the bottom edge) through the oracle's 2-D curl-curl path (f_apply_l2_1 with its q_w input).  The field is the
+    uniform B_z = mu0 J_s, exactly representable, so M = 2 E / I^2 = mu0 * area / width^2 = mu0 / 2 to rounding."""
+    import scipy.sparse.linalg as spl
+
+    from palace_amd.fem import tri
+
+    M_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "cavity2d_mesh.npz"))
+    en = M_["elem_nodes"].astype(np.int64)
+    used, inv = np.unique(en[:, :3], return_inverse=True)
+    mesh = tri.TriMesh(M_["nodes"][used], inv.reshape(-1, 3), M_["attr"], elem_nodes=en, nodes=M_["nodes"])
+    p = 2
+    nd = tri.NDTriSpace(mesh, p)
+    pts, wts = tri.tri_quadrature(3)
+    interp, curl = nd.elem.tables(pts)
+    J = mesh.jacobians(pts)
+    geom = po.build_geom_factor_22(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 4))
+    K = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, interp, curl, geom, po.QF_L2_1, po.CoeffCtx(dim=1),
+                              qw=wts).assemble_sparse().tocsr()
+    Mm = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, interp, curl, geom, po.QF_HCURL_22,
+                               po.CoeffCtx(dim=2)).assemble_sparse().tocsr()
+    # boundary edges -> (element, local edge)
+    bv = np.searchsorted(used, M_["bdr_edges"].astype(np.int64))
+    ekey = {tuple(e): i for i, e in enumerate(map(tuple, mesh.edge_verts))}
+    owner = {}
+    for e in range(mesh.ne):
+        for k in range(3):
+            owner.setdefault(int(mesh.elem_edges[e, k]), (e, k))
+    s, ws = np.polynomial.legendre.leggauss(4)
+    s, ws = 0.5 * (s + 1), 0.5 * ws
+    sgn = np.where(nd.orients, -1.0, 1.0)
+    b = np.zeros(nd.ndofs)
+    pec_mask = np.zeros(mesh.edge_verts.shape[0], dtype=bool)
+    width = 0.0
+    for (va, vb), attr in zip(bv, M_["bdr_attr"]):
+        ge = ekey[(min(va, vb), max(va, vb))]
+        if attr == 3:
+            pec_mask[ge] = True
+            continue
+        e, k = owner[ge]
+        la, lb = tri.LOCAL_EDGES[k]
+        that = tri.REF_VERTS[lb] - tri.REF_VERTS[la]
+        xs = tri.REF_VERTS[la][None, :] + s[:, None] * that[None, :]
+        val, _ = nd.elem.tables(xs)                       # [2, nq, P]
+        loc = np.einsum("dqj,d,q->j", val, that, ws)      # int phi_hat . t_hat ds_hat  (= int phi . t ds, Piola)
+        tphys = mesh.verts[mesh.tris[e, lb]] - mesh.verts[mesh.tris[e, la]]
+        assert abs(tphys[1]) < 1e-12
+        width += abs(tphys[0])
+        np.add.at(b, nd.offsets[e], np.sign(tphys[0]) * sgn[e] * loc)   # J_s = +x
+    assert width == pytest.approx(1.0, abs=1e-12)
+    free = np.setdiff1d(np.arange(nd.ndofs), nd.ess_dofs(pec_mask))
+    Kf, Mf, bf = K[free][:, free], Mm[free][:, free], b[free]
+    # K is singular on gradients; b is orthogonal to them (closed current path through the PEC walls is not needed: the
+    # gradients vanish on the walls and J_s is constant, so int J_s . grad(phi) ds = phi(1,0) - phi(0,0) = 0)
+    x = spl.spsolve((Kf + 1e-9 * Mf).tocsc(), bf)
+    r = Kf @ x - bf
+    assert np.linalg.norm(r) < 1e-6 * np.linalg.norm(bf)
+    energy = x @ (Kf @ x)                                  # = b^T K^+ b = area / width^2
+    assert energy == pytest.approx(0.5, rel=1e-7)
+    mu0 = 1.25663706127e-6                                 # utils/constants.hpp:26
+    assert mu0 * energy == pytest.approx(float(M_["M11_H"]), rel=1e-7)
