@@ -120,6 +120,80 @@ def fixtures_2d():
     print("wrote qf2d_golden.npz, cavity2d_mesh.npz")
 
 
+def spheres_fixture():
+    """The reference's examples/spheres/mesh/spheres.msh (binary Gmsh 2.2, 14 362 tet20 + tri10 boundary faces) as arrays,
+    with the element nodes re-ordered to palace_amd.fem.tet.h1_tet_nodes(3) (vertices, edges, faces; positive
+    orientation), and the regression capacitance matrix test/data/regression/ref/spheres/terminal-C.csv."""
+    import struct
+
+    from palace_amd.fem import tet
+
+    data = open("/root/reference/examples/spheres/mesh/spheres.msh", "rb").read()
+
+    def section(name):
+        a = data.index(b"$" + name + b"\n") + len(name) + 2
+        return a, data.index(b"$End" + name)
+
+    a, _ = section(b"Nodes")
+    nl = data.index(b"\n", a)
+    nn = int(data[a:nl])
+    rec = np.frombuffer(data, dtype=np.dtype([("i", "<i4"), ("x", "<f8", 3)]), count=nn, offset=nl + 1)
+    ids, xyz = rec["i"].astype(np.int64), rec["x"].copy()
+    idmap = np.full(ids.max() + 1, -1, dtype=np.int64)
+    idmap[ids] = np.arange(nn)
+    a, _ = section(b"Elements")
+    nl = data.index(b"\n", a)
+    nelem = int(data[a:nl])
+    npe = {29: 20, 21: 10, 15: 1, 26: 4}
+    vol, vattr, tri, tattr = [], [], [], []
+    off, done = nl + 1, 0
+    while done < nelem:
+        et, nf, nt = struct.unpack_from("<iii", data, off)
+        off += 12
+        w = 1 + nt + npe[et]
+        r = np.frombuffer(data, dtype="<i4", count=w * nf, offset=off).reshape(nf, w)
+        off += 4 * w * nf
+        if et == 29:
+            vol.append(r[:, 1 + nt:]), vattr.append(r[:, 1])
+        elif et == 21:
+            tri.append(r[:, 1 + nt:1 + nt + 3]), tattr.append(r[:, 1])
+        done += nf
+    en = idmap[np.concatenate(vol)]
+    X = xyz[en]                                    # [ne, 20, 3]
+    det = np.einsum("ei,ei->e", np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), X[:, 3] - X[:, 0])
+    # barycentric coordinates (numerators over 3) of every node wrt the element's own four vertices
+    T = np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2)      # columns
+    lam = np.linalg.solve(T[:, None, :, :], (X - X[:, :1])[..., None])[..., 0]           # [ne, 20, 3] = (l1, l2, l3)
+    # Gmsh orders the 20 nodes the same way in every element: read the lattice position of local node n off the
+    # straight-sided elements (most of them), then apply it to all
+    dev = np.abs(3 * lam - np.rint(3 * lam)).max(axis=(1, 2))
+    straight = dev < 1e-6
+    assert straight.sum() > 100
+    k1 = np.rint(3 * lam[straight]).astype(np.int64)
+    assert np.all(k1 == k1[:1]), "node ordering differs between elements"
+    k = np.broadcast_to(k1[0], (en.shape[0], 20, 3)).copy()
+    neg = det < 0
+    k[neg] = k[neg][:, :, [1, 0, 2]]               # swapping vertices 1 and 2 swaps l1 and l2
+    key = k[..., 0] + 4 * k[..., 1] + 16 * k[..., 2]
+    std = np.rint(3 * tet.h1_tet_nodes(3)).astype(np.int64)     # reference coordinates = (l1, l2, l3)
+    skey = std[:, 0] + 4 * std[:, 1] + 16 * std[:, 2]
+    order = np.argsort(key, axis=1)
+    assert np.array_equal(np.take_along_axis(key, order, axis=1), np.broadcast_to(np.sort(skey), key.shape))
+    perm = np.empty_like(order)
+    perm[:, np.argsort(skey)] = order              # perm[e, m] = node of element e at standard lattice point m
+    en_std = np.take_along_axis(en, perm, axis=1)
+    Xs = xyz[en_std]
+    det2 = np.einsum("ei,ei->e", np.cross(Xs[:, 1] - Xs[:, 0], Xs[:, 2] - Xs[:, 0]), Xs[:, 3] - Xs[:, 0])
+    assert det2.min() > 0
+    C = np.loadtxt("/root/reference/test/data/regression/ref/spheres/terminal-C.csv", delimiter=",", skiprows=1)[:, 1:]
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "spheres_mesh.npz"), nodes=xyz,
+                        elem_nodes=en_std.astype(np.int32), attr=np.concatenate(vattr).astype(np.int32),
+                        bdr_tris=idmap[np.concatenate(tri)].astype(np.int32), bdr_attr=np.concatenate(tattr).astype(np.int32),
+                        C_F=C)
+    print("wrote spheres_mesh.npz", en_std.shape, int(neg.sum()), "re-oriented")
+
+
 if __name__ == "__main__":
     mesh_fixture()
     fixtures_2d()
+    spheres_fixture()
