@@ -1,0 +1,72 @@
+"""End-to-end device run of the reference's spheres example (examples/spheres/spheres.json: electrostatics, order-3 H1 on
+14 362 cubic tetrahedra): the Maxwell capacitance matrix through the dense MFMA path (f_apply_hcurl_33 on gradients,
+isoparametric tet20 geometry data built on the device), ParOperator with the Dirichlet dofs, Jacobi-PCG on the GPU.
+
+Expected output: the four entries of test/data/regression/ref/spheres/terminal-C.csv (stored in the fixture); the CPU
+oracle reproduces them to 1.3e-10 (tests/test_oracle_spheres.py).  Needs a GPU:  python examples/spheres/capacitance.py
+
+NOT yet part of the GPU test suite: written at the end of round 1 after the GPU budget was spent; promote it to
+tests/test_spheres_gpu.py once it has run on a device."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from palace_amd import ceed, linalg
+from palace_amd.fem import tet
+
+
+def main():
+    d = np.load(os.path.join(ROOT, "tests", "golden", "spheres_mesh.npz"))
+    nodes, en = d["nodes"], d["elem_nodes"].astype(np.int64)
+    used, inv = np.unique(en[:, :4], return_inverse=True)
+    mesh = tet.TetMesh(nodes[used], inv.reshape(-1, 4), d["attr"])
+    p = 3
+    h1 = tet.H1TetSpace(mesh, p)
+    pts, wts = tet.default_tet_rule(p)
+    interp, grad = h1.elem.tables(pts)
+    G = tet.H1TetElement(3).tables(pts)[1]  # cubic geometry basis on the fixture's node order
+    geom = ceed.DenseGeomFactorData(en, nodes, mesh.attr, G, wts)
+    block = ceed.DenseBlock(ceed.FE_H1, h1.ndofs, h1.offsets, interp, grad)
+    K = ceed.Operator(h1.ndofs, h1.ndofs).add_dense_integrator(geom, block, ceed.QF_HCURL_33, ceed.coefficient_context(3),
+                                                               ceed.EVAL_GRAD).finalize()
+    bt = np.sort(np.searchsorted(used, d["bdr_tris"].astype(np.int64)), axis=1)
+    fkey = {tuple(f): i for i, f in enumerate(map(tuple, mesh.face_verts))}
+    masks = {}
+    for a in (2, 3, 4):
+        m = np.zeros(mesh.face_verts.shape[0], dtype=bool)
+        m[[fkey[tuple(f)] for f in bt[d["bdr_attr"] == a]]] = True
+        masks[a] = h1.ess_dofs(m)
+    ess = np.unique(np.concatenate(list(masks.values()))).astype(np.int32)
+    ctx = linalg.Context()
+    A = linalg.ParOperator(ctx, K, ess, linalg.DIAG_ONE)
+    solver = linalg.cg(ctx, A, linalg.jacobi(ctx, A), rel_tol=1e-13, max_it=5000)
+    n = h1.ndofs
+    phi = []
+    for a in (3, 4):
+        v = torch.zeros(n, dtype=torch.float64, device="cuda")
+        v[torch.from_numpy(masks[a].astype(np.int64)).cuda()] = 1.0
+        b = torch.zeros_like(v)
+        A.eliminate_rhs(v, b)  # b = -K_unconstrained v|ess on the free rows, b[ess] = v[ess]
+        x = torch.zeros_like(v)
+        solver.mult(b, x)
+        phi.append(x)
+    eps0 = 1.0 / (1.25663706127e-6 * 299792458.0 ** 2)
+    L0 = 1.0e-2
+    t = torch.empty(n, dtype=torch.float64, device="cuda")
+    C = np.zeros((2, 2))
+    for i in range(2):
+        K.mult(phi[i], t)  # the unconstrained local operator
+        for j in range(2):
+            C[j, i] = eps0 * L0 * float(phi[j] @ t)
+    ref = d["C_F"]
+    print("C (device)    =", C.ravel())
+    print("C (reference) =", ref.ravel())
+    print("max relative difference:", np.abs(C - ref).max() / np.abs(ref).max(), " PCG iterations:", solver.stats()["iterations"])
+
+
+if __name__ == "__main__":
+    main()
