@@ -256,7 +256,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     }
     so->d_tptr = dev_upload(tptr.data(), tptr.size());
     so->d_tent = dev_upload(tent.data(), tent.size());
-    so->d_ye = dev_alloc<double>(nnz);
+    so->d_ye = dev_alloc<double>((size_t)((r.num_elem + 3) & ~3) * P);  // padded to whole batches of the streaming kernel
   }
   so->h_sidx = std::move(sidx);
 
@@ -333,6 +333,7 @@ static void free_sub(SubOp *so) {
   hipFree(so->d_lidx);
   hipFree(so->d_sidx), hipFree(so->d_sidx_bc), hipFree(so->d_perm), hipFree(so->d_perm_x), hipFree(so->d_shared), hipFree(so->d_shared_bc);
   hipFree(so->d_ye), hipFree(so->d_ye2), hipFree(so->d_tptr), hipFree(so->d_tent);
+  free_stream(*so);
   if (so->qd && --so->qd->refcount == 0) {
     hipFree(so->qd->d);
     delete so->qd;
@@ -354,7 +355,10 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   bool first = true;
   for (const SubOp *so : op->subs) {
     if (so->fe_type == PA_FE_HCURL) {
-      if (so->d_ye) {
+      if (so->d_sidx_s && (!masked || so->d_sidx_s_bc)) {  // streaming kernel + E^T of the shared dofs by runs
+        launch_nd_hex_stream(*so, x, y, masked, s, !(overwrite && first), ess_policy);
+        launch_et_run_gather(*so, y, !(overwrite && first), s, x, ess_policy);
+      } else if (so->d_ye) {
         launch_nd_hex_apply(*so, x, y, so->d_ye, masked, s, !(overwrite && first), ess_policy);
         launch_et_gather(*so, y, !(overwrite && first), s, x, ess_policy);
       } else {
@@ -399,6 +403,7 @@ void finalize_exclusive(pa_op *op) {
   so->d_shared = dev_upload(shared.data(), shared.size());
   so->n_shared = (int)shared.size();
   so->h_shared = std::move(shared);
+  build_stream(*so);
 }
 
 // y0 = A x0, y1 = A x1 (overwrite).  One pass over the index / q-data streams when the operator is a single
@@ -753,6 +758,7 @@ int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
           if (flag[d]) d |= kEssBit;
         hipFree(so->d_shared_bc);
         so->d_shared_bc = dev_upload(lb.data(), lb.size());
+        stream_set_essential(*so, flag);
       }
     op->has_essential = true;
   });

@@ -80,6 +80,7 @@ void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s) {
   PA_HIP(hipStreamSynchronize(s));
   hipFree(d_off), hipFree(d_nodes), hipFree(d_B), hipFree(d_G), hipFree(d_w);
   g.d_attr_e = d_attr;
+  g.h_attr.assign(mesh.attr, mesh.attr + ne);
   g.w1.assign(mesh.qweight1d, mesh.qweight1d + q1d);
 }
 

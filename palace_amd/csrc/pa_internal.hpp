@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/palace_amd.h"
+#include "pa_stream_host.hpp"  // kEssBit, kExclBit
 
 struct pa_op;
 typedef struct pa_op pa_op_fwd;
@@ -74,7 +75,6 @@ T *dev_upload(const T *host, size_t n, hipStream_t s = nullptr) {
   return p;
 }
 
-constexpr int kEssBit = 1 << 30;  // flag in the gather index: read this dof as zero
 constexpr int kExclBit16 = 1 << 15;  // flag in the slot permutation: this entry is the only copy of its dof
 constexpr int kMaxP1 = 6;  // closed nodes p+1 <= 7
 constexpr int kMaxQ1 = 7;
@@ -92,6 +92,7 @@ struct Geom {
   double *d_geom = nullptr;
   QData *metric = nullptr;        // lazily built G = J^T J [ne][6][Q] (tensor hex blocks), see QData
   int32_t *d_attr_e = nullptr;    // [ne] element attributes (metric form: coefficient lookup in the kernel)
+  std::vector<int32_t> h_attr;    // host copy (tensor hex blocks)
   std::vector<double> w1;         // 1-D quadrature weights (tensor hex blocks)
   int refcount = 1;
 };
@@ -126,6 +127,13 @@ struct QData {
   bool metric = false;
 };
 
+// Offset of component c at point q inside one element's block of packed q-data (H(curl) hexahedra).  In general
+// [ncomp][Q]; with 4 points per direction the two points (qz, qz + 1) of a lane's column sit side by side,
+// [ncomp][2][16][2], so the element kernels fetch 16 bytes per lane and instruction.
+__host__ __device__ inline int nd_qd_offset(int q1d, int c, int q) {
+  return q1d == 4 ? ((c * 2 + (q >> 5)) * 16 + (q & 15)) * 2 + ((q >> 4) & 1) : c * q1d * q1d * q1d + q;
+}
+
 struct SubOp {
   Geom *geom = nullptr;
   QData *qd = nullptr;  // nullptr: matrix-free D from the geometry data (the reference default)
@@ -151,6 +159,15 @@ struct SubOp {
   double *d_ye2 = nullptr;     // second E-vector (two right-hand sides), allocated on first use
   int32_t *d_tptr = nullptr;   // [lsize + 1]
   int32_t *d_tent = nullptr;   // [ne * P] signed positions into d_ye
+  // streaming form (pa_nd_hex_stream.hip): index words with the exclusive flag, byte slots, E^T of the shared dofs by runs
+  int32_t *d_sidx_s = nullptr, *d_sidx_s_bc = nullptr;  // [ne][P]: dof | kEssBit | kExclBit; negative: -(1 + word), flipped
+  uint32_t *d_perm_s = nullptr;                         // [ne][ceil(P/64)][16], four 8-bit tensor-order slots per word
+  double *d_coef_s = nullptr;                           // metric form: [ne][2] scalar mass / curl-curl coefficient per element
+  std::vector<int32_t> h_sidx_s;
+  uint32_t *d_rcode = nullptr, *d_rcode_bc = nullptr;   // [n_shared] run << 4 | offset (bit 31: essential)
+  std::vector<uint32_t> h_rcode;
+  int32_t *d_rhdr = nullptr, *d_rpos = nullptr;         // run headers {first dof, first copy entry}; copy positions in d_ye
+  int n_runs = 0;
   std::vector<double> Bc, Gc, Bo;  // full 1-D tables [q1d][n] (host)
   double *d_tab = nullptr;        // the same on the device: [Bo | Bc | Gc]
   bool iso = false;               // every material coefficient is a multiple of the identity
@@ -200,6 +217,14 @@ void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s
 void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
 void launch_nd_hex_metric(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
+// pa_nd_hex_stream.hip
+bool nd_hex_stream_ok(const SubOp &so);
+void build_stream(SubOp &so);
+void stream_set_essential(SubOp &so, const std::vector<char> &flag);
+void free_stream(SubOp &so);
+void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, bool accumulate,
+                          int ess_policy);
+void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, int ess_policy);
 void launch_h1_hex_apply(const SubOp &so, const double *x, bool masked, hipStream_t s);
 void launch_h1_hex_qdata(SubOp &so, hipStream_t s);
 void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);

@@ -1,0 +1,448 @@
+// Streaming form of the fused E -> B/G -> D -> B^T/G^T -> E^T kernel for Nedelec hexahedra with 4 points per
+// direction (p = 3 and its p-coarsened levels) on packed q-data, and E^T of the shared dofs by runs.
+//
+// Same arithmetic and lane mapping as nd_hex_apply_kernel (pa_nd_hex.hip; reference fem/libceed/operator.cpp:148-178
+// and the QFunctions fem/qfunctions/33/{hdiv_33,hcurl_33,hdivmass_33}_qf.h), different schedule: the grid is sized to
+// what is resident on the chip, every wave walks a sequence of 4-element batches of one XCD's contiguous element range
+// and keeps the HBM streams of the NEXT batch in flight while it computes the current one:
+//   top of batch i      q-data of batch i (16 B per lane and instruction), index words of batch i + 1
+//   forward, D          ...
+//   before the transposed passes   x[index] of batch i + 1 (the index words have arrived by now)
+//   transposed passes, E^T stores
+// so the dependent chain index -> x -> compute that opened every wave of the one-shot kernel (two HBM latencies with
+// little else to run) is paid once per wave instead of once per batch.  The index stream is narrower as well: the
+// tensor-order slot of a sorted entry is one byte (P <= 256) and the exclusive-dof flag rides in the index word.
+//
+// E^T: element-local results are signed here and stored to the E-vector in sorted order; dofs with a single copy go
+// straight to y.  The shared dofs are then summed by et_run_gather_kernel: because an element's E-vector block is
+// sorted by global dof, the copies of consecutive dofs of one mesh entity (a face's 12 dofs, an edge's 3) are
+// consecutive in every element that holds them, so the transpose map collapses to runs {first dof, length, first
+// position per copy}: 4 bytes of index per dof instead of 12 + 4 per copy, fixed summation order as before.
+#include <algorithm>
+
+#include "pa_nd_hex_core.hpp"
+
+namespace pa {
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+template <int P1>
+struct NDStreamArgs {
+  int ne, nbatch, chunk;  // chunk: batches per XCD (contiguous range)
+  const int32_t *sidx;    // [ne][P] sorted order: dof | kEssBit | kExclBit; negative: -(1 + word), entry is flipped
+  const uint32_t *perm;   // [ne][NPK + 1][16]: four 8-bit tensor-order slots per word (entries t + 16 r, r = 4 k .. 4 k + 3),
+                          // last word: bit 2 r = entry r is flipped, bit 2 r + 1 = entry r is the only copy of its dof
+  const double *qdata;    // [ne][NG][2][16][2]
+  const double *coef;     // metric form: [ne][2] scalar mass / curl-curl coefficient of the element
+  const double *x;
+  double *y, *ye;
+  int accumulate, ess_policy;
+  NDTab<P1, 4> tab;
+};
+
+// IPOS: where the index words of the next batch are requested (0 top of the batch, 1 before the third forward component,
+// 2 before D); GPOS: where x of the next batch is requested (0 before the transposed passes, 1 / 2 after their first /
+// second component).  Later = fewer live registers, shorter flight.
+template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int IPOS, int GPOS>
+__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
+  constexpr int Q1 = 4;
+  using L = NDLayout<P1, Q1>;
+  constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
+  constexpr int NG = METRIC ? (USE_U ? 7 : 6) : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
+  static_assert(PP <= 256, "8-bit slots");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // batches of this wave: XCD k owns [k chunk, (k + 1) chunk); its waves interleave
+  const int xcd = blockIdx.x & 7;
+  const int stride = (int)(gridDim.x >> 3) * kWavesPerBlock;
+  int b = xcd * a.chunk + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave;
+  const int bend = min((xcd + 1) * a.chunk, a.nbatch);
+  if (b >= bend) return;
+
+  // index words of a batch (every array is padded to a multiple of four elements; pad entries read as zero and are
+  // stored to E-vector rows nobody gathers)
+  auto load_idx = [&](const int bb, const int sub, const int t, int (&s)[NPL], unsigned (&p)[NPK + 1]) {
+    const int e = bb * 4 + sub;
+    const int32_t *si = a.sidx + (size_t)e * PP + t;
+#pragma unroll
+    for (int r = 0; r < NPL; r++) s[r] = (16 * r + 15 < PP || t + 16 * r < PP) ? si[16 * r] : 0;
+    const uint32_t *pp = a.perm + (size_t)e * ((NPK + 1) * 16) + t;
+#pragma unroll
+    for (int k = 0; k <= NPK; k++) p[k] = pp[16 * k];
+  };
+  // raw x of the entries (essential entries are zeroed when staged)
+  auto gather = [&](const int (&s)[NPL], double (&xv)[NPL]) {
+#pragma unroll
+    for (int r = 0; r < NPL; r++) {
+      const int sv = s[r], df = sv >= 0 ? sv : -1 - sv;
+      xv[r] = a.x[df & (kExclBit - 1)];
+    }
+  };
+
+  int sA[NPL];
+  unsigned pA[NPK + 1];
+  double xv[NPL];
+  load_idx(b, lane >> 4, lane & 15, sA, pA);
+  gather(sA, xv);
+
+  for (;;) {
+    // lane constants are re-derived from an opaque copy of the lane id in every iteration: hoisted out of the loop, the
+    // few dozen LDS addresses and predicates of the passes stay live across it and end up in scratch memory
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int sub = lo >> 4, t = lo & 15, ta = t & 3, tb = t >> 2;
+    double *sm = smem + (size_t)(wave * 4 + sub) * L::ELEM_PAD;
+    const int lx = L::parity_xor(sub);
+    const int e = b * 4 + sub;
+    // q-data of this batch: consumed after the forward contraction
+    d2v gq[2 * NG];
+    {
+      const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)e * (2 * (METRIC ? 7 : NG) * 16) + t);
+#pragma unroll
+      for (int k = 0; k < 2 * NG; k++) gq[k] = g[16 * k];
+    }
+    d2v ce = {0.0, 0.0};
+    if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
+    // index words of the next batch (clamped: the last iteration re-reads its own)
+    const int bn = b + stride;
+    const bool more = bn < bend;
+    int sB[NPL];
+    unsigned pB[NPK + 1];
+    if (IPOS == 0) {
+      load_idx(more ? bn : b, sub, t, sB, pB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // E: sorted entries into their tensor-order slots
+#pragma unroll
+    for (int r = 0; r < NPL; r++) {
+      if (16 * r + 15 < PP || t + 16 * r < PP) {
+        const int sv = sA[r], df = sv >= 0 ? sv : -1 - sv;
+        const double v = (df & kEssBit) ? 0.0 : xv[r];
+        sm[(pA[r >> 2] >> (8 * (r & 3))) & 255u] = sv >= 0 ? v : -v;
+      }
+    }
+    wave_sync();
+    double uin[3][NC];
+#pragma unroll
+    for (int C = 0; C < 3; C++) {
+      const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
+      const bool act = ta < nj && tb < nk;
+#pragma unroll
+      for (int i = 0; i < NC; i++) uin[C][i] = (act && i < ni) ? sm[C * P1 * NC * NC + i + ni * (ta + nj * tb)] : 0.0;
+    }
+    wave_sync();
+
+    double U[3][Q1], CU[3][Q1];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int q = 0; q < Q1; q++) U[c][q] = 0.0, CU[c][q] = 0.0;
+    nd_fwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
+    nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
+    if (IPOS == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_idx(more ? bn : b, sub, t, sB, pB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
+    if (IPOS == 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_idx(more ? bn : b, sub, t, sB, pB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // D at the four points of this lane's column
+#pragma unroll
+    for (int qz = 0; qz < Q1; qz++) {
+      double H[NG];
+#pragma unroll
+      for (int c = 0; c < NG; c++) H[c] = gq[2 * c + (qz >> 1)][qz & 1];
+      if (METRIC) {
+        // H = (w / |detJ|) J^T J {00, 01, 02, 11, 12, 22}, H[6] = |detJ| / w:
+        //   (w / detJ) J^T c J = c H,   w detJ adj^T c adj = c (|detJ| / w) adj(H)
+        if (USE_U) {
+          const double cm = H[6] * ce[0];
+          const double m[6] = {cm * (H[3] * H[5] - H[4] * H[4]), cm * (H[2] * H[4] - H[1] * H[5]), cm * (H[1] * H[4] - H[2] * H[3]),
+                               cm * (H[0] * H[5] - H[2] * H[2]), cm * (H[1] * H[2] - H[0] * H[4]), cm * (H[0] * H[3] - H[1] * H[1])};
+          sym_mv(m, U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
+        }
+        if (USE_C) {
+          const double m[6] = {ce[1] * H[0], ce[1] * H[1], ce[1] * H[2], ce[1] * H[3], ce[1] * H[4], ce[1] * H[5]};
+          sym_mv(m, CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one point at a time: short live ranges
+      } else {
+        if (USE_U) sym_mv(&H[0], U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
+        if (USE_C) sym_mv(&H[USE_U ? 6 : 0], CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
+      }
+    }
+
+    // x of the next batch: in flight during the transposed passes
+    double xB[NPL];
+    if (GPOS == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      gather(sB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    nd_bwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
+    if (GPOS == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      gather(sB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    nd_bwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
+    if (GPOS == 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      gather(sB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // index words of the exclusive entries, re-read (their dof and essential flag are needed by the direct store; the
+    // sign and slot of every entry are in the held words): a fraction of the element's index lines, from L2 / MALL
+    int sS[NPL];
+    {
+      unsigned fl = pA[NPK];
+      asm volatile("" : "+v"(fl));  // nothing of the store path is derived before this point
+      __builtin_amdgcn_sched_barrier(0);
+      const int32_t *si = a.sidx + (size_t)e * PP + t;
+#pragma unroll
+      for (int r = 0; r < NPL; r++) {
+        sS[r] = 0;
+        if ((fl >> (2 * r + 1)) & 1u) sS[r] = si[16 * r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    nd_bwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
+    if (GPOS == 3) {
+      __builtin_amdgcn_sched_barrier(0);
+      gather(sB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // E^T: back to tensor order in LDS, out in sorted order, signed; exclusive dofs straight to y
+#pragma unroll
+    for (int C = 0; C < 3; C++) {
+      const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
+      const bool act = ta < nj && tb < nk;
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+        if (act && i < ni) sm[C * P1 * NC * NC + i + ni * (ta + nj * tb)] = uin[C][i];
+    }
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < NPL; r++) {
+      if (16 * r + 15 < PP || t + 16 * r < PP) {
+        const unsigned fl = pA[NPK] >> (2 * r);
+        const double v = sm[(pA[r >> 2] >> (8 * (r & 3))) & 255u];
+        const double sgv = (fl & 1u) ? -v : v;
+        if (fl & 2u) {
+          const int sv = sS[r], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
+          double *dst = &a.y[d];
+          if ((df & kEssBit) && a.ess_policy >= 0)  // ParOperator's essential rows (rap.cpp:223-233), fused
+            *dst = a.ess_policy ? a.x[d] : 0.0;
+          else
+            *dst = a.accumulate ? *dst + sgv : sgv;
+        } else {
+          a.ye[(size_t)e * PP + t + 16 * r] = sgv;
+        }
+      }
+    }
+    wave_sync();  // the LDS strip is reused by the next batch
+    if (GPOS == 4) {
+      __builtin_amdgcn_sched_barrier(0);
+      gather(sB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!more) break;
+    b = bn;
+#pragma unroll
+    for (int r = 0; r < NPL; r++) sA[r] = sB[r], xv[r] = xB[r];
+#pragma unroll
+    for (int k = 0; k <= NPK; k++) pA[k] = pB[k];
+  }
+}
+
+// ---- E^T of the shared dofs by runs -----------------------------------------------------------------------------------
+using streamhost::RunHdr;  // {first dof of the run, first entry of its copies in rpos}
+
+// One thread per shared dof: code = run << 4 | offset in the run (kEssBit32: essential row, fused fix-up).
+__global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const uint32_t *__restrict__ code,
+                                                            const RunHdr *__restrict__ hdr, const int32_t *__restrict__ rpos,
+                                                            const double *__restrict__ ye, double *__restrict__ y,
+                                                            const int accumulate, const double *__restrict__ x,
+                                                            const int ess_policy) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t c = code[k];
+  const int run = (int)((c & 0x7fffffffu) >> 4), j = (int)(c & 15u);
+  const RunHdr h = hdr[run];
+  const int d = h.dof0 + j;
+  if ((c >> 31) && ess_policy >= 0) {
+    y[d] = ess_policy ? x[d] : 0.0;
+    return;
+  }
+  const int pe = hdr[run + 1].ptr;
+  double s = 0.0;
+  int p = h.ptr;
+  for (; p + 2 <= pe; p += 2) {
+    const double v0 = ye[(size_t)rpos[p] + j], v1 = ye[(size_t)rpos[p + 1] + j];
+    s += v0;
+    s += v1;
+  }
+  if (p < pe) s += ye[(size_t)rpos[p] + j];
+  y[d] = accumulate ? y[d] + s : s;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+bool nd_hex_stream_ok(const SubOp &so) {
+  static const bool enabled = !(getenv("PALACE_AMD_STREAM") && atoi(getenv("PALACE_AMD_STREAM")) == 0);
+  if (!enabled) return false;
+  if (so.fe_type != PA_FE_HCURL || so.q1d != 4 || so.p > 3 || !so.qd || !so.d_ye || !so.d_perm_x) return false;
+  return so.qd->metric || so.qd->ncomp == 6;
+}
+
+// Index arrays of the streaming kernel and the run form of the transpose map (after finalize_exclusive: needs the
+// exclusive flags).  Host work proportional to the index array, once per operator.  Every per-element array is padded
+// to a multiple of four elements (one batch); the pad entries are flagged essential (read as zero).
+void build_stream(SubOp &so) {
+  if (so.d_sidx_s || !nd_hex_stream_ok(so)) return;
+  const int P = so.P, ne = so.ne, nep = (ne + 3) & ~3;
+  std::vector<int32_t> ss;
+  std::vector<uint32_t> pp;
+  streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ss, pp);
+  so.h_sidx_s = ss;
+  so.d_sidx_s = dev_upload(ss.data(), ss.size());
+  so.d_perm_s = dev_upload(pp.data(), pp.size());
+  if (so.qd->metric) {  // scalar coefficients per element (coeff_3_qf.h:9-24 resolved on the host)
+    const std::vector<int32_t> &attr = so.geom->h_attr;
+    PA_REQUIRE((int)attr.size() == ne, "element attributes missing");
+    const CoeffHost *cm = nullptr, *cc = nullptr;
+    if (so.qf == PA_QF_HDIV_33) cc = &so.c0;
+    if (so.qf == PA_QF_HCURL_33) cm = &so.c0;
+    if (so.qf == PA_QF_HDIVMASS_33) cm = &so.c0, cc = &so.c1;
+    auto value = [&](const CoeffHost *c, int at) {
+      if (!c) return 0.0;
+      int k = 0;
+      if (!c->attr_mat.empty()) {
+        PA_REQUIRE(at >= 1 && at <= (int)c->attr_mat.size(), "element attribute outside the coefficient's attribute map");
+        k = c->attr_mat[at - 1];
+      }
+      return c->mat[(size_t)9 * k];
+    };
+    std::vector<double> coef((size_t)nep * 2, 0.0);
+    for (int e = 0; e < ne; e++) coef[2 * (size_t)e] = value(cm, attr[e]), coef[2 * (size_t)e + 1] = value(cc, attr[e]);
+    so.d_coef_s = dev_upload(coef.data(), coef.size());
+  }
+
+  std::vector<uint32_t> code;
+  std::vector<RunHdr> hdr;
+  std::vector<int32_t> rpos;
+  streamhost::build_runs(ne, P, so.lsize, so.h_sidx.data(), so.h_shared, code, hdr, rpos);
+  so.h_rcode = code;
+  so.d_rcode = dev_upload(code.data(), code.size());
+  so.d_rhdr = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
+  so.d_rpos = dev_upload(rpos.data(), rpos.size());
+  so.n_runs = (int)hdr.size() - 1;
+}
+
+void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
+  if (!so.d_sidx_s) return;
+  std::vector<int32_t> bc(so.h_sidx_s);
+  const size_t nnz = (size_t)so.ne * so.P;  // (the pad entries are flagged already)
+  for (size_t k = 0; k < nnz; k++) {
+    int32_t &s = bc[k];
+    const int w = s >= 0 ? s : -1 - s;
+    if (flag[w & (kExclBit - 1)]) s = s >= 0 ? (w | kEssBit) : -1 - (w | kEssBit);
+  }
+  hipFree(so.d_sidx_s_bc);
+  so.d_sidx_s_bc = dev_upload(bc.data(), bc.size());
+  std::vector<uint32_t> cb(so.h_rcode);
+  for (size_t k = 0; k < cb.size(); k++)
+    if (flag[so.h_shared[k]]) cb[k] |= 0x80000000u;
+  hipFree(so.d_rcode_bc);
+  so.d_rcode_bc = dev_upload(cb.data(), cb.size());
+}
+
+void free_stream(SubOp &so) {
+  hipFree(so.d_sidx_s), hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s), hipFree(so.d_coef_s);
+  hipFree(so.d_rcode), hipFree(so.d_rcode_bc), hipFree(so.d_rhdr), hipFree(so.d_rpos);
+}
+
+static int device_cus() {
+  static int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  return cus;
+}
+
+// prefetch placement: as early as the registers allow (p = 3 is at the 3 waves / SIMD limit with the late placement)
+template <int P1, bool U, bool C, bool METRIC, int MINW, int IPOS = (P1 == 3 ? 2 : 0), int GPOS = (P1 == 3 ? 2 : 0)>
+static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
+  using L = NDLayout<P1, 4>;
+  for (int i = 0; i < HalfTab<P1, 4>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
+  for (int i = 0; i < HalfTab<P1 + 1, 4>::LEN; i++) a.tab.Bc[i] = so.Bc[i], a.tab.Gc[i] = so.Gc[i];
+  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * L::ELEM_PAD;
+  // resident workgroups per CU: registers (MINW waves per SIMD), LDS (160 KB), at most 8
+  static const int wg_env = getenv("PALACE_AMD_STREAM_WG") ? atoi(getenv("PALACE_AMD_STREAM_WG")) : 0;
+  int per_cu = std::min({MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
+  if (wg_env > 0) per_cu = wg_env;
+  const int per_xcd = std::max(1, device_cus() / 8) * per_cu;
+  a.nbatch = (so.ne + 3) / 4;
+  a.chunk = (a.nbatch + 7) / 8;
+  const int wgx = std::max(1, std::min(per_xcd, (a.chunk + kWavesPerBlock - 1) / kWavesPerBlock));
+  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, IPOS, GPOS>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
+  PA_HIP(hipGetLastError());
+}
+
+template <int P1>
+static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, bool accumulate, int ess_policy) {
+  NDStreamArgs<P1> a;
+  a.ne = so.ne;
+  a.sidx = (masked && so.d_sidx_s_bc) ? so.d_sidx_s_bc : so.d_sidx_s;
+  a.perm = so.d_perm_s;
+  a.qdata = so.qd->d;
+  a.coef = so.d_coef_s;
+  a.x = x, a.y = y, a.ye = so.d_ye;
+  a.accumulate = accumulate ? 1 : 0;
+  a.ess_policy = masked ? ess_policy : -1;
+  const bool m = so.qd->metric;
+  switch (so.qf) {
+    case PA_QF_HDIV_33:
+      if (m) launch_variant<P1, false, true, true, 3>(so, a, s); else launch_variant<P1, false, true, false, 3>(so, a, s);
+      break;
+    case PA_QF_HCURL_33:
+      if (m) launch_variant<P1, true, false, true, 3>(so, a, s); else launch_variant<P1, true, false, false, 3>(so, a, s);
+      break;
+    case PA_QF_HDIVMASS_33:
+      PA_REQUIRE(m, "streaming curl-curl + mass kernel needs the metric form");
+      launch_variant<P1, true, true, true, 2>(so, a, s);
+      break;
+    default: throw Error("QFunction not available for H(curl) hexahedra");
+  }
+}
+
+void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, bool accumulate,
+                          int ess_policy) {
+  switch (so.p) {
+    case 1: launch_p<1>(so, x, y, masked, s, accumulate, ess_policy); break;
+    case 2: launch_p<2>(so, x, y, masked, s, accumulate, ess_policy); break;
+    case 3: launch_p<3>(so, x, y, masked, s, accumulate, ess_policy); break;
+    default: throw Error("no streaming H(curl) hex kernel for this order");
+  }
+}
+
+void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, int ess_policy) {
+  const int n = so.n_shared;
+  if (n == 0) return;
+  const bool bc = ess_policy >= 0 && so.d_rcode_bc;
+  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, bc ? so.d_rcode_bc : so.d_rcode,
+                     reinterpret_cast<const RunHdr *>(so.d_rhdr), so.d_rpos, so.d_ye, y, accumulate ? 1 : 0, x,
+                     bc ? ess_policy : -1);
+  PA_HIP(hipGetLastError());
+}
+
+}  // namespace pa

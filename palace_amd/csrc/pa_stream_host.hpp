@@ -1,0 +1,89 @@
+// Host-side construction of the streaming kernel's index arrays and of the run form of the transpose map
+// (pa_nd_hex_stream.hip).  Plain C++ without HIP so that tests/test_stream_host.py can compile it with g++ and check
+// the encodings against a CPU model of the kernels' decode paths.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+namespace pa {
+
+constexpr int kEssBit = 1 << 30;   // flag in a gather index: read this dof as zero
+constexpr int kExclBit = 1 << 29;  // flag in the streaming kernel's index word: only copy of its dof
+
+namespace streamhost {
+
+struct RunHdr {
+  int32_t dof0, ptr;  // first dof of the run; first entry of its copies in rpos (the next header's ptr ends them)
+};
+
+inline int dof_of(int32_t s) { return s >= 0 ? s : -1 - s; }
+
+// sidx / perm: [ne][P] signed sorted index and tensor-order slot of sorted entry m (make_sub).  Output, padded to a
+// multiple of four elements:
+//   ss [nep][P]              dof | kExclBit (only copy); negative: -(1 + word), the entry is flipped; pad: kEssBit
+//   pp [nep][npk + 1][16]    lane t of an element holds entries m = t + 16 r: word k carries the 8-bit slots of
+//                            r = 4 k .. 4 k + 3, the last word bit 2 r = flipped, bit 2 r + 1 = only copy
+inline void pack_index(int ne, int P, int lsize, const int32_t *sidx, const uint16_t *perm, std::vector<int32_t> &ss,
+                       std::vector<uint32_t> &pp) {
+  if (P > 256) throw std::runtime_error("element too large for 8-bit slots");
+  if (lsize >= kExclBit) throw std::runtime_error("too many local dofs for the streaming index encoding");
+  const int nep = (ne + 3) & ~3, npl = (P + 15) / 16, npk = (npl + 3) / 4;
+  const size_t nnz = (size_t)ne * P;
+  std::vector<int32_t> count((size_t)lsize, 0);
+  for (size_t k = 0; k < nnz; k++) count[dof_of(sidx[k])]++;
+  ss.assign((size_t)nep * P, kEssBit);
+  pp.assign((size_t)nep * (npk + 1) * 16, 0u);
+  for (int e = 0; e < ne; e++)
+    for (int m = 0; m < P; m++) {
+      const size_t k = (size_t)e * P + m;
+      const int32_t s = sidx[k];
+      const int d = dof_of(s);
+      const bool excl = count[d] == 1;
+      const int w = d | (excl ? kExclBit : 0);
+      ss[k] = s >= 0 ? w : -1 - w;
+      const int t = m & 15, r = m >> 4;
+      uint32_t *row = &pp[(size_t)e * (npk + 1) * 16];
+      row[(r >> 2) * 16 + t] |= (uint32_t)(perm[k] & 0xff) << (8 * (r & 3));
+      row[npk * 16 + t] |= ((s < 0 ? 1u : 0u) | (excl ? 2u : 0u)) << (2 * r);
+    }
+}
+
+// Runs over the shared dofs (`shared` increasing: every dof that does not have exactly one copy): consecutive dofs
+// with the same number of copies whose copies sit at consecutive E-vector positions, at most 16 long.
+//   code[k] = run << 4 | offset of shared[k] in its run;  hdr[run] = {first dof, first entry in rpos};
+//   rpos = E-vector position of the run's first dof in every copy, copies in element order (fixed summation order)
+inline void build_runs(int ne, int P, int lsize, const int32_t *sidx, const std::vector<int32_t> &shared,
+                       std::vector<uint32_t> &code, std::vector<RunHdr> &hdr, std::vector<int32_t> &rpos) {
+  const size_t nnz = (size_t)ne * P;
+  std::vector<int32_t> tptr((size_t)lsize + 1, 0);
+  for (size_t k = 0; k < nnz; k++) tptr[(size_t)dof_of(sidx[k]) + 1]++;
+  for (int d = 0; d < lsize; d++) tptr[d + 1] += tptr[d];
+  std::vector<int32_t> tpos(nnz), fill(tptr.begin(), tptr.end() - 1);
+  for (size_t k = 0; k < nnz; k++) tpos[fill[dof_of(sidx[k])]++] = (int32_t)k;
+  code.clear(), hdr.clear(), rpos.clear();
+  code.reserve(shared.size());
+  int prev = -2, len = 0;
+  for (const int32_t d : shared) {
+    const int nc = tptr[d + 1] - tptr[d];
+    bool extend = (d == prev + 1) && len < 16 && !hdr.empty();
+    if (extend) {
+      const RunHdr &h = hdr.back();
+      extend = (int)rpos.size() - h.ptr == nc;
+      for (int c = 0; extend && c < nc; c++) extend = tpos[tptr[d] + c] == rpos[h.ptr + c] + len;
+    }
+    if (!extend) {
+      hdr.push_back(RunHdr{d, (int32_t)rpos.size()});
+      for (int c = 0; c < nc; c++) rpos.push_back(tpos[tptr[d] + c]);
+      len = 0;
+    }
+    if (hdr.size() >= (1u << 27)) throw std::runtime_error("too many runs for the gather code");
+    code.push_back((uint32_t)(hdr.size() - 1) << 4 | (uint32_t)len);
+    len++, prev = d;
+  }
+  hdr.push_back(RunHdr{0, (int32_t)rpos.size()});
+}
+
+}  // namespace streamhost
+}  // namespace pa

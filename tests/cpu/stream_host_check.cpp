@@ -1,0 +1,184 @@
+// CPU check of the streaming kernel's host-side encodings (palace_amd/csrc/pa_stream_host.hpp): a plain C++ model of
+// the decode paths of nd_hex_stream_kernel (E staging, E^T stores) and et_run_gather_kernel is run on random signed
+// element->dof maps and compared with the definition  y = E^T D E x  (D = a diagonal per-entry scaling).
+// Built and run by tests/test_stream_host.py (g++, no GPU).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <random>
+
+#include "pa_stream_host.hpp"
+
+using namespace pa;
+using namespace pa::streamhost;
+
+static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac) {
+  std::mt19937 rng(seed);
+  // element -> dof map in tensor order: each element gets P distinct dofs, drawn so that entity-like runs of
+  // consecutive dofs are shared between elements (blocks of 1..12 consecutive dofs), random signs
+  std::vector<int32_t> lidx((size_t)ne * P);
+  for (int e = 0; e < ne; e++) {
+    std::vector<char> used(lsize, 0);
+    int filled = 0;
+    std::vector<int> dofs;
+    while (filled < P) {
+      const int len = std::min<int>(P - filled, 1 + rng() % 12);
+      const int d0 = rng() % (lsize - len + 1);
+      bool ok = true;
+      for (int j = 0; j < len; j++) ok = ok && !used[d0 + j];
+      if (!ok) continue;
+      for (int j = 0; j < len; j++) used[d0 + j] = 1, dofs.push_back(d0 + j);
+      filled += len;
+    }
+    std::shuffle(dofs.begin(), dofs.end(), rng);
+    for (int l = 0; l < P; l++) lidx[(size_t)e * P + l] = (rng() & 1) ? dofs[l] : -1 - dofs[l];
+  }
+  // sorted order as make_sub builds it
+  std::vector<int32_t> sidx((size_t)ne * P);
+  std::vector<uint16_t> perm((size_t)ne * P);
+  for (int e = 0; e < ne; e++) {
+    std::vector<int> ord(P);
+    std::iota(ord.begin(), ord.end(), 0);
+    const int32_t *le = &lidx[(size_t)e * P];
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return dof_of(le[a]) < dof_of(le[b]); });
+    for (int m = 0; m < P; m++) sidx[(size_t)e * P + m] = le[ord[m]], perm[(size_t)e * P + m] = (uint16_t)ord[m];
+  }
+  std::vector<int32_t> count(lsize, 0);
+  for (auto s : sidx) count[dof_of(s)]++;
+  std::vector<int32_t> shared;
+  for (int d = 0; d < lsize; d++)
+    if (count[d] != 1) shared.push_back(d);
+  std::vector<char> ess(lsize, 0);
+  for (int d = 0; d < lsize; d++) ess[d] = (rng() % 1000) < ess_frac * 1000;
+
+  std::vector<int32_t> ss;
+  std::vector<uint32_t> pp;
+  pack_index(ne, P, lsize, sidx.data(), perm.data(), ss, pp);
+  std::vector<uint32_t> code;
+  std::vector<RunHdr> hdr;
+  std::vector<int32_t> rpos;
+  build_runs(ne, P, lsize, sidx.data(), shared, code, hdr, rpos);
+  // essential flags as stream_set_essential / pa_op_set_essential write them
+  std::vector<int32_t> ssb(ss);
+  for (size_t k = 0; k < (size_t)ne * P; k++) {
+    const int w = ssb[k] >= 0 ? ssb[k] : -1 - ssb[k];
+    if (ess[w & (kExclBit - 1)]) ssb[k] = ssb[k] >= 0 ? (w | kEssBit) : -1 - (w | kEssBit);
+  }
+  std::vector<uint32_t> codeb(code);
+  for (size_t k = 0; k < codeb.size(); k++)
+    if (ess[shared[k]]) codeb[k] |= 0x80000000u;
+
+  std::vector<double> x(lsize), scale((size_t)ne * P);
+  std::uniform_real_distribution<double> U(-1, 1);
+  for (auto &v : x) v = U(rng);
+  for (auto &v : scale) v = U(rng);
+  // reference: y = E^T D E (x with essential entries zeroed), then y[ess] = x[ess] (DIAG_ONE)
+  std::vector<double> yref(lsize, 0.0);
+  for (int e = 0; e < ne; e++)
+    for (int l = 0; l < P; l++) {
+      const int32_t s = lidx[(size_t)e * P + l];
+      const int d = dof_of(s);
+      const double u = ess[d] ? 0.0 : (s >= 0 ? x[d] : -x[d]);
+      const double v = scale[(size_t)e * P + l] * u;
+      yref[d] += s >= 0 ? v : -v;
+    }
+  for (int d = 0; d < lsize; d++)
+    if (ess[d]) yref[d] = x[d];
+
+  // model of the device path
+  const int nep = (ne + 3) & ~3, npl = (P + 15) / 16, npk = (npl + 3) / 4;
+  std::vector<double> ye((size_t)nep * P, 1e300), y(lsize, 1e300), sm(P);
+  for (int e = 0; e < nep; e++) {
+    const uint32_t *row = &pp[(size_t)e * (npk + 1) * 16];
+    // E: sorted entries into tensor-order slots (kernel: stage loop)
+    std::fill(sm.begin(), sm.end(), 0.0);
+    for (int t = 0; t < 16; t++)
+      for (int r = 0; r < npl; r++) {
+        if (t + 16 * r >= P) continue;
+        const int sv = ssb[(size_t)e * P + t + 16 * r], df = sv >= 0 ? sv : -1 - sv;
+        const double xv = x[df & (kExclBit - 1)];
+        const double v = (df & kEssBit) ? 0.0 : xv;
+        sm[(row[(r >> 2) * 16 + t] >> (8 * (r & 3))) & 255u] = sv >= 0 ? v : -v;
+      }
+    // element operator: diagonal scaling in tensor order
+    if (e < ne)
+      for (int l = 0; l < P; l++) sm[l] *= scale[(size_t)e * P + l];
+    // E^T stores
+    for (int t = 0; t < 16; t++)
+      for (int r = 0; r < npl; r++) {
+        if (t + 16 * r >= P) continue;
+        const unsigned fl = row[npk * 16 + t] >> (2 * r);
+        const double v = sm[(row[(r >> 2) * 16 + t] >> (8 * (r & 3))) & 255u];
+        const double sgv = (fl & 1u) ? -v : v;
+        if (fl & 2u) {
+          const int sv = ssb[(size_t)e * P + t + 16 * r], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
+          if (df & kEssBit)
+            y[d] = x[d];
+          else
+            y[d] = sgv;
+        } else {
+          ye[(size_t)e * P + t + 16 * r] = sgv;
+        }
+      }
+  }
+  for (size_t k = 0; k < shared.size(); k++) {
+    const uint32_t c = codeb[k];
+    const int run = (int)((c & 0x7fffffffu) >> 4), j = (int)(c & 15u);
+    const int d = hdr[run].dof0 + j;
+    if (d != shared[k]) return std::printf("run decode: dof %d != %d\n", d, shared[k]), 1;
+    if (c >> 31) {
+      y[d] = x[d];
+      continue;
+    }
+    double s = 0.0;
+    for (int p = hdr[run].ptr; p < hdr[run + 1].ptr; p++) s += ye[(size_t)rpos[p] + j];
+    y[d] = s;
+  }
+  double err = 0.0;
+  for (int d = 0; d < lsize; d++) err = std::max(err, std::fabs(y[d] - yref[d]));
+  const double avg_run = shared.empty() ? 0.0 : (double)shared.size() / (hdr.size() - 1);
+  std::printf("ne=%d P=%d lsize=%d shared=%zu runs=%zu (%.2f dofs/run) max err %.3e\n", ne, P, lsize, shared.size(),
+              hdr.size() - 1, avg_run, err);
+  return err < 1e-13 ? 0 : 1;
+}
+
+int main() {
+  int bad = 0;
+  bad += run_case(37, 144, 2000, 1, 0.05);
+  bad += run_case(8, 54, 300, 2, 0.1);
+  bad += run_case(5, 12, 40, 3, 0.2);
+  bad += run_case(1, 144, 144, 4, 0.0);
+  bad += run_case(130, 144, 6000, 5, 0.02);
+  return bad;
+}
+
+// C entry for tests/test_stream_host.py: statistics of the run form on a real element -> dof map
+// (lidx: signed tensor-order index [ne][P] as pa_capi.hip builds it).  Returns the number of runs, -1 on error.
+extern "C" int stream_host_run_stats(int ne, int P, int lsize, const int32_t *lidx, int *n_shared, int *n_copies) {
+  try {
+    std::vector<int32_t> sidx((size_t)ne * P);
+    for (int e = 0; e < ne; e++) {
+      std::vector<int> ord(P);
+      std::iota(ord.begin(), ord.end(), 0);
+      const int32_t *le = &lidx[(size_t)e * P];
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return dof_of(le[a]) < dof_of(le[b]); });
+      for (int m = 0; m < P; m++) sidx[(size_t)e * P + m] = le[ord[m]];
+    }
+    std::vector<int32_t> count(lsize, 0);
+    for (auto s : sidx) count[dof_of(s)]++;
+    std::vector<int32_t> shared;
+    for (int d = 0; d < lsize; d++)
+      if (count[d] != 1) shared.push_back(d);
+    std::vector<uint32_t> code;
+    std::vector<RunHdr> hdr;
+    std::vector<int32_t> rpos;
+    build_runs(ne, P, lsize, sidx.data(), shared, code, hdr, rpos);
+    *n_shared = (int)shared.size();
+    *n_copies = (int)rpos.size();
+    return (int)hdr.size() - 1;
+  } catch (...) {
+    return -1;
+  }
+}
