@@ -29,6 +29,7 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 template <int P1>
 struct NDStreamArgs {
   int ne, nbatch, chunk;  // chunk: batches per XCD (contiguous range)
+  int32_t *sched;         // [8] next batch of each XCD's range, [8]: waves that have left (self-resetting, see kernel)
   const int32_t *sidx;    // [ne][P] sorted order: dof | kEssBit | kExclBit; negative: -(1 + word), entry is flipped
   const uint32_t *perm;   // [ne][NPK + 1][16]: four 8-bit tensor-order slots per word (entries t + 16 r, r = 4 k .. 4 k + 3),
                           // last word: bit 2 r = entry r is flipped, bit 2 r + 1 = entry r is the only copy of its dof
@@ -53,12 +54,34 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // batches of this wave: XCD k owns [k chunk, (k + 1) chunk); its waves interleave
+  // Batches: XCD k (workgroups are dealt to the XCDs round-robin, a placement used for L2 locality only) owns the range
+  // [k chunk, (k + 1) chunk) and its waves draw batches from it in order through one counter per XCD, two draws ahead
+  // of use so the ticket is back long before it is needed.  Drawing instead of a fixed stride makes the running time
+  // independent of how many of the launched workgroups the hardware really keeps resident (a workgroup that starts
+  // late finds its range drained and leaves) and evens out clock / contention differences between CUs.  The last wave
+  // to leave zeroes the counters for the next launch (stream-ordered; replayable from a graph).
   const int xcd = blockIdx.x & 7;
-  const int stride = (int)(gridDim.x >> 3) * kWavesPerBlock;
-  int b = xcd * a.chunk + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave;
-  const int bend = min((xcd + 1) * a.chunk, a.nbatch);
-  if (b >= bend) return;
+  const int base = xcd * a.chunk, bend = min(base + a.chunk, a.nbatch);
+  auto ticket = [&]() {
+    int v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(a.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;  // valid on lane 0
+  };
+  auto leave = [&]() {
+    if (lane == 0) {
+      const int total = (int)gridDim.x * kWavesPerBlock;
+      if (__hip_atomic_fetch_add(a.sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) __hip_atomic_store(a.sched + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  int b = base + __builtin_amdgcn_readfirstlane(ticket());
+  if (b >= bend) {
+    leave();
+    return;
+  }
+  int tn = ticket();
 
   // index words of a batch (every array is padded to a multiple of four elements; pad entries read as zero and are
   // stored to E-vector rows nobody gathers)
@@ -104,9 +127,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     }
     d2v ce = {0.0, 0.0};
     if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
-    // index words of the next batch (clamped: the last iteration re-reads its own)
-    const int bn = b + stride;
+    // the next batch (ticket drawn one iteration ago), and the draw for the one after; index words of the next batch
+    // are clamped: the last iteration re-reads its own
+    const int bn = base + __builtin_amdgcn_readfirstlane(tn);
     const bool more = bn < bend;
+    tn = ticket();
     int sB[NPL];
     unsigned pB[NPK + 1];
     if (IPOS == 0) {
@@ -261,6 +286,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #pragma unroll
     for (int k = 0; k <= NPK; k++) pA[k] = pB[k];
   }
+  leave();
 }
 
 // ---- E^T of the shared dofs by runs -----------------------------------------------------------------------------------
@@ -312,6 +338,8 @@ void build_stream(SubOp &so) {
   std::vector<uint32_t> pp;
   streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ss, pp);
   so.h_sidx_s = ss;
+  so.d_sched_s = dev_alloc<int32_t>(16);
+  PA_HIP(hipMemset(so.d_sched_s, 0, 16 * sizeof(int32_t)));
   so.d_sidx_s = dev_upload(ss.data(), ss.size());
   so.d_perm_s = dev_upload(pp.data(), pp.size());
   if (so.qd->metric) {  // scalar coefficients per element (coeff_3_qf.h:9-24 resolved on the host)
@@ -365,7 +393,7 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
 }
 
 void free_stream(SubOp &so) {
-  hipFree(so.d_sidx_s), hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s), hipFree(so.d_coef_s);
+  hipFree(so.d_sidx_s), hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s), hipFree(so.d_coef_s), hipFree(so.d_sched_s);
   hipFree(so.d_rcode), hipFree(so.d_rcode_bc), hipFree(so.d_rhdr), hipFree(so.d_rpos);
 }
 
@@ -387,9 +415,17 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
   for (int i = 0; i < HalfTab<P1 + 1, 4>::LEN; i++) a.tab.Bc[i] = so.Bc[i], a.tab.Gc[i] = so.Gc[i];
   const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * L::ELEM_PAD;
   // resident workgroups per CU: registers (MINW waves per SIMD), LDS (160 KB), at most 8
+  // as many workgroups as the occupancy query admits per CU (the batches are drawn, so asking for one too many costs
+  // nothing), never more than there are pairs of batches
   static const int wg_env = getenv("PALACE_AMD_STREAM_WG") ? atoi(getenv("PALACE_AMD_STREAM_WG")) : 0;
-  int per_cu = std::min({MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
-  if (wg_env > 0) per_cu = wg_env;
+  static const int per_cu_query = [&] {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, IPOS, GPOS>,
+                                                     64 * kWavesPerBlock, lds) != hipSuccess || nb <= 0)
+      nb = std::min({MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
+    return nb;
+  }();
+  const int per_cu = wg_env > 0 ? wg_env : per_cu_query;
   const int per_xcd = std::max(1, device_cus() / 8) * per_cu;
   a.nbatch = (so.ne + 3) / 4;
   a.chunk = (a.nbatch + 7) / 8;
@@ -406,13 +442,14 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   a.perm = so.d_perm_s;
   a.qdata = so.qd->d;
   a.coef = so.d_coef_s;
+  a.sched = so.d_sched_s;
   a.x = x, a.y = y, a.ye = so.d_ye;
   a.accumulate = accumulate ? 1 : 0;
   a.ess_policy = masked ? ess_policy : -1;
   const bool m = so.qd->metric;
   switch (so.qf) {
     case PA_QF_HDIV_33:
-      if (m) launch_variant<P1, false, true, true, 3>(so, a, s); else launch_variant<P1, false, true, false, 3>(so, a, s);
+      if (m) launch_variant<P1, false, true, true, (P1 == 3 ? 2 : 3)>(so, a, s); else launch_variant<P1, false, true, false, 3>(so, a, s);
       break;
     case PA_QF_HCURL_33:
       if (m) launch_variant<P1, true, false, true, 3>(so, a, s); else launch_variant<P1, true, false, false, 3>(so, a, s);
