@@ -41,16 +41,17 @@ struct NDStreamArgs {
   NDTab<P1, 4> tab;
 };
 
-// IPOS: where the index words of the next batch are requested (0 top of the batch, 1 before the third forward component,
-// 2 before D); GPOS: where x of the next batch is requested (0 before the transposed passes, 1 / 2 after their first /
-// second component).  Later = fewer live registers, shorter flight.
-template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int IPOS, int GPOS>
+// GPOS: where x of the next batch is requested (0 before the transposed passes, 1 / 2 / 3 after their first / second /
+// third component).  Later = fewer live registers, shorter flight.
+template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
   constexpr int Q1 = 4;
   using L = NDLayout<P1, Q1>;
   constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
   constexpr int NG = METRIC ? (USE_U ? 7 : 6) : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
   static_assert(PP <= 256, "8-bit slots");
+  // LDS per element (doubles): contraction buffers + the batch's index and slot / flag words, kept for the E^T stores
+  constexpr int LDS_ELEM = L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -76,13 +77,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       }
     }
   };
-  int b = base + __builtin_amdgcn_readfirstlane(ticket());
-  if (b >= bend) {
-    leave();
-    return;
-  }
-  int tn = ticket();
-
   // index words of a batch (every array is padded to a multiple of four elements; pad entries read as zero and are
   // stored to E-vector rows nobody gathers)
   auto load_idx = [&](const int bb, const int sub, const int t, int (&s)[NPL], unsigned (&p)[NPK + 1]) {
@@ -102,6 +96,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       xv[r] = a.x[df & (kExclBit - 1)];
     }
   };
+  int b = base + __builtin_amdgcn_readfirstlane(ticket());
+  if (b >= bend) {
+    leave();
+    return;
+  }
 
   int sA[NPL];
   unsigned pA[NPK + 1];
@@ -115,39 +114,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     int lo = lane;
     asm volatile("" : "+v"(lo));
     const int sub = lo >> 4, t = lo & 15, ta = t & 3, tb = t >> 2;
-    double *sm = smem + (size_t)(wave * 4 + sub) * L::ELEM_PAD;
+    double *sm = smem + (size_t)(wave * 4 + sub) * LDS_ELEM;
+    int *side = reinterpret_cast<int *>(sm + L::ELEM_PAD);  // index words of this batch, kept for the E^T stores
     const int lx = L::parity_xor(sub);
     const int e = b * 4 + sub;
-    // q-data of this batch: consumed after the forward contraction
-    d2v gq[2 * NG];
-    {
-      const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)e * (2 * (METRIC ? 7 : NG) * 16) + t);
-#pragma unroll
-      for (int k = 0; k < 2 * NG; k++) gq[k] = g[16 * k];
-    }
-    d2v ce = {0.0, 0.0};
-    if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
-    // the next batch (ticket drawn one iteration ago), and the draw for the one after; index words of the next batch
-    // are clamped: the last iteration re-reads its own
-    const int bn = base + __builtin_amdgcn_readfirstlane(tn);
-    const bool more = bn < bend;
-    tn = ticket();
-    int sB[NPL];
-    unsigned pB[NPK + 1];
-    if (IPOS == 0) {
-      load_idx(more ? bn : b, sub, t, sB, pB);
-      __builtin_amdgcn_sched_barrier(0);
-    }
 
-    // E: sorted entries into their tensor-order slots
+    // E: sorted entries into their tensor-order slots (x of this batch was requested during the previous one)
 #pragma unroll
     for (int r = 0; r < NPL; r++) {
       if (16 * r + 15 < PP || t + 16 * r < PP) {
         const int sv = sA[r], df = sv >= 0 ? sv : -1 - sv;
         const double v = (df & kEssBit) ? 0.0 : xv[r];
         sm[(pA[r >> 2] >> (8 * (r & 3))) & 255u] = sv >= 0 ? v : -v;
+        side[t + 16 * r] = sv;
       }
     }
+#pragma unroll
+    for (int k = 0; k <= NPK; k++) side[2 * ((PP + 1) / 2) + 16 * k + t] = (int)pA[k];
     wave_sync();
     double uin[3][NC];
 #pragma unroll
@@ -159,6 +142,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     }
     wave_sync();
 
+    // q-data of this batch: consumed after the forward contraction
+    d2v gq[2 * NG];
+    {
+      const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)e * (2 * (METRIC ? 7 : NG) * 16) + t);
+#pragma unroll
+      for (int k = 0; k < 2 * NG; k++) gq[k] = g[16 * k];
+    }
+    d2v ce = {0.0, 0.0};
+    if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
+    // Draw for the next batch.  Inline assembly on purpose: the compiler would wait for the returned value right here
+    // (s_waitcnt vmcnt(0): the whole q-data stream just requested); this way the only wait is the explicit one in front
+    // of D, where the q-data is needed anyway.  `tk` is written by the hardware when the atomic returns: nothing may
+    // touch it before that wait (scripts/audit_stream_asm.py checks the generated code).  The compiler's own counted
+    // waits do not see this operation, which can only make them wait for one operation more, never fewer.
+    int tk = 0;
+    if (lane == 0) {
+      const int one = 1, off = 4 * xcd;
+      asm volatile("global_atomic_add %0, %1, %2, %3 sc0 ; PA_TICKET_ISSUE" : "=v"(tk) : "v"(off), "v"(one), "s"(a.sched) : "memory");
+    }
+
     double U[3][Q1], CU[3][Q1];
 #pragma unroll
     for (int c = 0; c < 3; c++)
@@ -166,17 +169,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       for (int q = 0; q < Q1; q++) U[c][q] = 0.0, CU[c][q] = 0.0;
     nd_fwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
     nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
-    if (IPOS == 1) {
-      __builtin_amdgcn_sched_barrier(0);
-      load_idx(more ? bn : b, sub, t, sB, pB);
-      __builtin_amdgcn_sched_barrier(0);
-    }
     nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
-    if (IPOS == 2) {
-      __builtin_amdgcn_sched_barrier(0);
-      load_idx(more ? bn : b, sub, t, sB, pB);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+
+    // the ticket and the q-data have landed; index words of the next batch (clamped: the last iteration re-reads its own)
+    asm volatile("s_waitcnt vmcnt(0) ; PA_TICKET_WAIT %0" : "+v"(tk) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int bn = base + __builtin_amdgcn_readfirstlane(tk);
+    const bool more = bn < bend;
+    int sB[NPL];
+    unsigned pB[NPK + 1];
+    load_idx(more ? bn : b, sub, t, sB, pB);
+    __builtin_amdgcn_sched_barrier(0);
 
     // D at the four points of this lane's column
 #pragma unroll
@@ -223,21 +226,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       gather(sB, xB);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // index words of the exclusive entries, re-read (their dof and essential flag are needed by the direct store; the
-    // sign and slot of every entry are in the held words): a fraction of the element's index lines, from L2 / MALL
-    int sS[NPL];
-    {
-      unsigned fl = pA[NPK];
-      asm volatile("" : "+v"(fl));  // nothing of the store path is derived before this point
-      __builtin_amdgcn_sched_barrier(0);
-      const int32_t *si = a.sidx + (size_t)e * PP + t;
-#pragma unroll
-      for (int r = 0; r < NPL; r++) {
-        sS[r] = 0;
-        if ((fl >> (2 * r + 1)) & 1u) sS[r] = si[16 * r];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
     nd_bwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
     if (GPOS == 3) {
       __builtin_amdgcn_sched_barrier(0);
@@ -258,16 +246,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #pragma unroll
     for (int r = 0; r < NPL; r++) {
       if (16 * r + 15 < PP || t + 16 * r < PP) {
-        const unsigned fl = pA[NPK] >> (2 * r);
-        const double v = sm[(pA[r >> 2] >> (8 * (r & 3))) & 255u];
+        const unsigned fl = (unsigned)side[2 * ((PP + 1) / 2) + 16 * NPK + t] >> (2 * r);
+        const double v = sm[((unsigned)side[2 * ((PP + 1) / 2) + 16 * (r >> 2) + t] >> (8 * (r & 3))) & 255u];
         const double sgv = (fl & 1u) ? -v : v;
         if (fl & 2u) {
-          const int sv = sS[r], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
+          const int sv = side[t + 16 * r], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
           double *dst = &a.y[d];
-          if ((df & kEssBit) && a.ess_policy >= 0)  // ParOperator's essential rows (rap.cpp:223-233), fused
+          // the common case (overwrite, not an essential row) is a plain store on its own path: merged with the two
+          // rare ones the compiler waits for every earlier store before each of these
+          const bool ess_row = (df & kEssBit) && a.ess_policy >= 0;
+          if (!ess_row && !a.accumulate) {
+            *dst = sgv;
+          } else if (ess_row) {  // ParOperator's essential rows (rap.cpp:223-233), fused
             *dst = a.ess_policy ? a.x[d] : 0.0;
-          else
-            *dst = a.accumulate ? *dst + sgv : sgv;
+          } else {
+            *dst = *dst + sgv;
+          }
         } else {
           a.ye[(size_t)e * PP + t + 16 * r] = sgv;
         }
@@ -292,32 +286,70 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 // ---- E^T of the shared dofs by runs -----------------------------------------------------------------------------------
 using streamhost::RunHdr;  // {first dof of the run, first entry of its copies in rpos}
 
-// One thread per shared dof: code = run << 4 | offset in the run (kEssBit32: essential row, fused fix-up).
+// code = run << 4 | offset in the run (bit 31: essential row, fused fix-up).  Every thread walks kGatherILP shared dofs a
+// block width apart with the four dependent loads of each (code -> header -> copy position -> E-vector) issued side by
+// side: one dof per thread leaves the kernel bound by that chain's latency, not by bytes (same 59 us as the CSR form
+// it replaced, measured).
+constexpr int kGatherILP = 4;
 __global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const uint32_t *__restrict__ code,
                                                             const RunHdr *__restrict__ hdr, const int32_t *__restrict__ rpos,
                                                             const double *__restrict__ ye, double *__restrict__ y,
                                                             const int accumulate, const double *__restrict__ x,
                                                             const int ess_policy) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const uint32_t c = code[k];
-  const int run = (int)((c & 0x7fffffffu) >> 4), j = (int)(c & 15u);
-  const RunHdr h = hdr[run];
-  const int d = h.dof0 + j;
-  if ((c >> 31) && ess_policy >= 0) {
-    y[d] = ess_policy ? x[d] : 0.0;
-    return;
+  const int k0 = blockIdx.x * (256 * kGatherILP) + threadIdx.x;
+  uint32_t c[kGatherILP];
+  RunHdr h[kGatherILP];
+  int pe[kGatherILP], d[kGatherILP], j[kGatherILP];
+  bool live[kGatherILP], fix[kGatherILP];
+  double s[kGatherILP], yold[kGatherILP];
+#pragma unroll
+  for (int u = 0; u < kGatherILP; u++) {
+    const int k = k0 + 256 * u;
+    live[u] = k < n;
+    c[u] = live[u] ? code[k] : 0u;
   }
-  const int pe = hdr[run + 1].ptr;
-  double s = 0.0;
-  int p = h.ptr;
-  for (; p + 2 <= pe; p += 2) {
-    const double v0 = ye[(size_t)rpos[p] + j], v1 = ye[(size_t)rpos[p + 1] + j];
-    s += v0;
-    s += v1;
+#pragma unroll
+  for (int u = 0; u < kGatherILP; u++) {
+    const int run = (int)((c[u] & 0x7fffffffu) >> 4);
+    j[u] = (int)(c[u] & 15u);
+    h[u] = hdr[run];
+    pe[u] = hdr[run + 1].ptr;
+    fix[u] = (c[u] >> 31) && ess_policy >= 0;
   }
-  if (p < pe) s += ye[(size_t)rpos[p] + j];
-  y[d] = accumulate ? y[d] + s : s;
+#pragma unroll
+  for (int u = 0; u < kGatherILP; u++) {
+    d[u] = h[u].dof0 + j[u];
+    s[u] = 0.0;
+    yold[u] = 0.0;
+    if (live[u] && fix[u]) {
+      if (ess_policy) s[u] = x[d[u]];
+      pe[u] = h[u].ptr;  // no copies to sum
+    } else if (live[u] && accumulate) {
+      yold[u] = y[d[u]];
+    }
+  }
+  // copies in order (fixed summation order; an absent copy adds an exact zero): the first four of every dof side by
+  // side -- interior faces have 2, edges 4 -- then the rare rest one at a time
+  int pos[kGatherILP][4];
+#pragma unroll
+  for (int u = 0; u < kGatherILP; u++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) pos[u][q] = (live[u] && h[u].ptr + q < pe[u]) ? rpos[h[u].ptr + q] : -1;
+  double v[kGatherILP][4];
+#pragma unroll
+  for (int u = 0; u < kGatherILP; u++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[u][q] = pos[u][q] >= 0 ? ye[(size_t)pos[u][q] + j[u]] : 0.0;
+#pragma unroll
+  for (int u = 0; u < kGatherILP; u++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) s[u] += v[u][q];
+    if (live[u])
+      for (int p = h[u].ptr + 4; p < pe[u]; p++) s[u] += ye[(size_t)rpos[p] + j[u]];
+  }
+#pragma unroll
+  for (int u = 0; u < kGatherILP; u++)
+    if (live[u]) y[d[u]] = yold[u] + s[u];
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -407,20 +439,21 @@ static int device_cus() {
   return cus;
 }
 
-// prefetch placement: as early as the registers allow (p = 3 is at the 3 waves / SIMD limit with the late placement)
-template <int P1, bool U, bool C, bool METRIC, int MINW, int IPOS = (P1 == 3 ? 2 : 0), int GPOS = (P1 == 3 ? 2 : 0)>
-static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
+template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS>
+static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   using L = NDLayout<P1, 4>;
   for (int i = 0; i < HalfTab<P1, 4>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
   for (int i = 0; i < HalfTab<P1 + 1, 4>::LEN; i++) a.tab.Bc[i] = so.Bc[i], a.tab.Gc[i] = so.Gc[i];
-  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * L::ELEM_PAD;
+  constexpr int PP = 3 * P1 * (P1 + 1) * (P1 + 1);
+  constexpr int NPK = ((PP + 15) / 16 + 3) / 4;
+  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * (L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8);
   // resident workgroups per CU: registers (MINW waves per SIMD), LDS (160 KB), at most 8
   // as many workgroups as the occupancy query admits per CU (the batches are drawn, so asking for one too many costs
   // nothing), never more than there are pairs of batches
   static const int wg_env = getenv("PALACE_AMD_STREAM_WG") ? atoi(getenv("PALACE_AMD_STREAM_WG")) : 0;
   static const int per_cu_query = [&] {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, IPOS, GPOS>,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS>,
                                                      64 * kWavesPerBlock, lds) != hipSuccess || nb <= 0)
       nb = std::min({MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
     return nb;
@@ -430,8 +463,21 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
   a.nbatch = (so.ne + 3) / 4;
   a.chunk = (a.nbatch + 7) / 8;
   const int wgx = std::max(1, std::min(per_xcd, (a.chunk + kWavesPerBlock - 1) / kWavesPerBlock));
-  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, IPOS, GPOS>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
+  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
   PA_HIP(hipGetLastError());
+}
+
+// where x of the next batch is requested: after the first transposed component by default (its index words are requested
+// just before D and need time to arrive; x then has the rest of the batch).  PALACE_AMD_STREAM_GPOS = 0 / 1 / 2 for A/B.
+template <int P1, bool U, bool C, bool METRIC, int MINW>
+static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
+  static const int gpos = getenv("PALACE_AMD_STREAM_GPOS") ? atoi(getenv("PALACE_AMD_STREAM_GPOS")) : 1;
+  if (gpos == 0)
+    launch_gpos<P1, U, C, METRIC, MINW, 0>(so, a, s);
+  else if (gpos == 2)
+    launch_gpos<P1, U, C, METRIC, MINW, 2>(so, a, s);
+  else
+    launch_gpos<P1, U, C, METRIC, MINW, 1>(so, a, s);
 }
 
 template <int P1>
@@ -476,7 +522,7 @@ void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream
   const int n = so.n_shared;
   if (n == 0) return;
   const bool bc = ess_policy >= 0 && so.d_rcode_bc;
-  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, bc ? so.d_rcode_bc : so.d_rcode,
+  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n, bc ? so.d_rcode_bc : so.d_rcode,
                      reinterpret_cast<const RunHdr *>(so.d_rhdr), so.d_rpos, so.d_ye, y, accumulate ? 1 : 0, x,
                      bc ? ess_policy : -1);
   PA_HIP(hipGetLastError());

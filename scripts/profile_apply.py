@@ -20,5 +20,8 @@ for _ in range(int(os.environ.get("REPS", "10"))):
 # with the same 8-byte-per-lane accesses as the apply kernels
 for _ in range(5):
     ctx.axpby(0.5, x, 0.5, y)
+if os.environ.get("CAL8"):  # the same stream with 8-byte lanes (views shifted by one entry: not 16-byte aligned)
+    for _ in range(5):
+        ctx.axpby(0.5, x[1:], 0.5, y[1:])
 torch.cuda.synchronize()
 print("done", n)
