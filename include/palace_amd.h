@@ -195,7 +195,9 @@ int pa_geom_layout(const pa_geom *geom, int32_t out[4]);
 int pa_geom_num_rows(const pa_geom *geom);
 int pa_geom_retain(pa_geom *geom);
 void pa_geom_destroy(pa_geom *geom);
-/* Device pointer to the geometry data and its length in doubles (tests / diagnostics). */
+/* Device pointer to the geometry data and its length in doubles (tests / diagnostics).  Tensor blocks keep their elements
+ * in an internal (space-filling-curve) order: row p of the data is the caller's element order[p]. */
+int pa_geom_element_order(const pa_geom *geom, int32_t *order);
 int pa_geom_data(const pa_geom *geom, const double **dev_ptr, size_t *count);
 
 /* --- operator: replaces ceed::Operator (fem/libceed/operator.cpp) ---------------------------- */

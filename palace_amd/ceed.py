@@ -95,7 +95,12 @@ class GeomFactorData:
             __cuda_array_interface__ = dict(shape=(n.value,), typestr="<f8", data=(p.value, False), version=2)
 
         torch.cuda.synchronize()
-        return torch.as_tensor(_View(), device="cuda").cpu().numpy().reshape(self.mesh.ne, 11, self.Q)
+        data = torch.as_tensor(_View(), device="cuda").cpu().numpy().reshape(self.mesh.ne, 11, self.Q)
+        order = np.zeros(self.mesh.ne, dtype=np.int32)  # the library keeps the elements in its own order
+        _lib.check(L.pa_geom_element_order(self.handle, order.ctypes.data_as(C.c_void_p)))
+        out = np.empty_like(data)
+        out[order] = data
+        return out
 
     def __del__(self):
         try:

@@ -201,12 +201,12 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     PA_REQUIRE(n >= 0 && n < P && !seen[n], "dof_map is not a signed permutation");
     seen[n] = 1;
   }
-  for (int e = 0; e < r.num_elem; e++)
+  for (int e = 0; e < r.num_elem; e++)  // internal element order (the geometry data's, pa_geom.hip)
     for (int l = 0; l < P; l++) {
       int n = b.dof_map ? b.dof_map[l] : l;
       bool neg = false;
       if (n < 0) n = -1 - n, neg = true;
-      const size_t k = (size_t)e * P + n;
+      const size_t k = (size_t)(geom->eorder.empty() ? e : geom->eorder[e]) * P + n;
       const int32_t off = r.offsets[k];
       PA_REQUIRE(off >= 0 && off < r.lsize, "restriction offset out of range");
       if (r.orients && r.orients[k]) neg = !neg;
@@ -486,6 +486,13 @@ int pa_geom_layout(const pa_geom *geom, int32_t out[4]) {
 }
 
 int pa_geom_num_rows(const pa_geom *geom) { return geom ? geom->nrows : -1; }
+
+int pa_geom_element_order(const pa_geom *geom, int32_t *order) {
+  return guarded([&] {
+    PA_REQUIRE(geom && order, "null argument");
+    for (int e = 0; e < geom->ne; e++) order[e] = geom->eorder.empty() ? e : geom->eorder[e];
+  });
+}
 
 int pa_geom_retain(pa_geom *geom) {
   return guarded([&] {

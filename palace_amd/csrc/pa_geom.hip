@@ -5,6 +5,8 @@
 // (fem/qfunctions/33/geom_33_qf.h:9-33): per point {attr, w*detJ, adj(J)^T/detJ}, stored
 // [ne][11][Q] (component-major, point index fastest) exactly like the reference's strided
 // CEED_STRIDES_BACKEND q-data (fem/mesh.cpp:188-195).  Set-up only: one thread per point.
+#include <algorithm>
+
 #include "pa_internal.hpp"
 
 namespace pa {
@@ -61,12 +63,67 @@ __global__ void geom_factor_kernel(int ne, int q1d, int m1, const int32_t *__res
   for (int c = 0; c < 9; c++) g[(2 + c) * Q + q] = A[c] / det;
 }
 
+// Internal element order of a tensor hex block: Morton (Z) order of the element centroids.  The element kernels walk the
+// block in this order (eight contiguous ranges, one per XCD, a window of consecutive elements in flight on each), so the
+// x / y lines shared by neighbouring elements are re-used from L2 while they are still there; the caller's order (whatever
+// the mesh generator produced) only decides where an element's rows sit in the descriptors.  PALACE_AMD_REORDER=0 keeps it.
+static std::vector<int32_t> morton_order(const pa_mesh_desc &mesh, int npe) {
+  const int ne = mesh.num_elem;
+  const char *env = getenv("PALACE_AMD_REORDER");
+  if ((env && atoi(env) == 0) || ne < 64) return {};
+  std::vector<double> c((size_t)ne * 3, 0.0);
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int e = 0; e < ne; e++) {
+    for (int n = 0; n < npe; n++) {
+      const int32_t v = mesh.node_offsets[(size_t)e * npe + n];
+      for (int d = 0; d < 3; d++) c[(size_t)e * 3 + d] += mesh.nodes[(size_t)v * 3 + d];
+    }
+    for (int d = 0; d < 3; d++) {
+      c[(size_t)e * 3 + d] /= npe;
+      lo[d] = std::min(lo[d], c[(size_t)e * 3 + d]), hi[d] = std::max(hi[d], c[(size_t)e * 3 + d]);
+    }
+  }
+  // one cell size for the three directions (the curve should see cubes, not the bounding box's aspect ratio)
+  const double span = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300});
+  auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+  };
+  std::vector<std::pair<uint64_t, int32_t>> key(ne);
+  for (int e = 0; e < ne; e++) {
+    uint64_t k = 0;
+    for (int d = 0; d < 3; d++) {
+      const double u = (c[(size_t)e * 3 + d] - lo[d]) / span;
+      k |= spread((uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0))) << d;
+    }
+    key[e] = {k, e};
+  }
+  std::sort(key.begin(), key.end());
+  std::vector<int32_t> order(ne);
+  for (int e = 0; e < ne; e++) order[e] = key[e].second;
+  return order;
+}
+
 void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s) {
   const int m1 = mesh.mesh_order + 1, npe = m1 * m1 * m1;
   const int ne = mesh.num_elem, q1d = mesh.q1d, Q = q1d * q1d * q1d;
-  int32_t *d_off = dev_upload(mesh.node_offsets, (size_t)ne * npe, s);
+  for (size_t k = 0; k < (size_t)ne * npe; k++)
+    PA_REQUIRE(mesh.node_offsets[k] >= 0 && mesh.node_offsets[k] < mesh.num_nodes, "mesh node index out of range");
+  g.eorder = morton_order(mesh, npe);
+  std::vector<int32_t> off((size_t)ne * npe), attr(ne);
+  for (int e = 0; e < ne; e++) {
+    const int eo = g.eorder.empty() ? e : g.eorder[e];
+    std::copy(mesh.node_offsets + (size_t)eo * npe, mesh.node_offsets + (size_t)(eo + 1) * npe, off.begin() + (size_t)e * npe);
+    attr[e] = mesh.attr[eo];
+  }
+  int32_t *d_off = dev_upload(off.data(), (size_t)ne * npe, s);
   double *d_nodes = dev_upload(mesh.nodes, (size_t)mesh.num_nodes * 3, s);
-  int32_t *d_attr = dev_upload(mesh.attr, (size_t)ne, s);
+  int32_t *d_attr = dev_upload(attr.data(), (size_t)ne, s);
   double *d_B = dev_upload(mesh.mesh_B, (size_t)q1d * m1, s);
   double *d_G = dev_upload(mesh.mesh_G, (size_t)q1d * m1, s);
   double *d_w = dev_upload(mesh.qweight1d, (size_t)q1d, s);
@@ -80,7 +137,7 @@ void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s) {
   PA_HIP(hipStreamSynchronize(s));
   hipFree(d_off), hipFree(d_nodes), hipFree(d_B), hipFree(d_G), hipFree(d_w);
   g.d_attr_e = d_attr;
-  g.h_attr.assign(mesh.attr, mesh.attr + ne);
+  g.h_attr = attr;
   g.w1.assign(mesh.qweight1d, mesh.qweight1d + q1d);
 }
 

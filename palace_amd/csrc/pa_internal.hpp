@@ -92,7 +92,8 @@ struct Geom {
   double *d_geom = nullptr;
   QData *metric = nullptr;        // lazily built G = J^T J [ne][6][Q] (tensor hex blocks), see QData
   int32_t *d_attr_e = nullptr;    // [ne] element attributes (metric form: coefficient lookup in the kernel)
-  std::vector<int32_t> h_attr;    // host copy (tensor hex blocks)
+  std::vector<int32_t> h_attr;    // host copy (tensor hex blocks), internal element order
+  std::vector<int32_t> eorder;    // internal element p is the caller's element eorder[p] (empty: same order)
   std::vector<double> w1;         // 1-D quadrature weights (tensor hex blocks)
   int refcount = 1;
 };
@@ -162,7 +163,6 @@ struct SubOp {
   // streaming form (pa_nd_hex_stream.hip): index words with the exclusive flag, byte slots, E^T of the shared dofs by runs
   int32_t *d_sidx_s = nullptr, *d_sidx_s_bc = nullptr;  // [ne][P]: dof | kEssBit | kExclBit; negative: -(1 + word), flipped
   uint32_t *d_perm_s = nullptr;                         // [ne][ceil(P/64)][16], four 8-bit tensor-order slots per word
-  int32_t *d_sched_s = nullptr;                         // batch counters of the streaming kernel (self-resetting)
   double *d_coef_s = nullptr;                           // metric form: [ne][2] scalar mass / curl-curl coefficient per element
   std::vector<int32_t> h_sidx_s;
   uint32_t *d_rcode = nullptr, *d_rcode_bc = nullptr;   // [n_shared] run << 4 | offset (bit 31: essential)

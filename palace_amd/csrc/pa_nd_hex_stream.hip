@@ -26,10 +26,25 @@ namespace pa {
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+// Timeline instrumentation (timing experiments only, -DPA_STREAM_TRACE): wave 0 of the first kTraceWG workgroups stamps
+// s_memtime at the phase boundaries of its first kTraceBatches batches; pa_debug_stream_trace() copies the stamps out.
+#ifdef PA_STREAM_TRACE
+constexpr int kTraceWG = 64, kTraceBatches = 14, kTraceStamps = 12;
+__device__ unsigned long long g_trace[kTraceWG * kTraceBatches * kTraceStamps];
+#define PA_STAMP(k)                                                                                          \
+  do {                                                                                                       \
+    if (tr_on && tr_b < kTraceBatches && lane == 0)                                                          \
+      g_trace[((size_t)blockIdx.x * kTraceBatches + tr_b) * kTraceStamps + (k)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define PA_STAMP(k) \
+  do {              \
+  } while (0)
+#endif
+
 template <int P1>
 struct NDStreamArgs {
   int ne, nbatch, chunk;  // chunk: batches per XCD (contiguous range)
-  int32_t *sched;         // [8] next batch of each XCD's range, [8]: waves that have left (self-resetting, see kernel)
   const int32_t *sidx;    // [ne][P] sorted order: dof | kEssBit | kExclBit; negative: -(1 + word), entry is flipped
   const uint32_t *perm;   // [ne][NPK + 1][16]: four 8-bit tensor-order slots per word (entries t + 16 r, r = 4 k .. 4 k + 3),
                           // last word: bit 2 r = entry r is flipped, bit 2 r + 1 = entry r is the only copy of its dof
@@ -46,6 +61,7 @@ struct NDStreamArgs {
 template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
   constexpr int Q1 = 4;
+  constexpr bool EARLY_IDX = P1 < 3;
   using L = NDLayout<P1, Q1>;
   constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
   constexpr int NG = METRIC ? (USE_U ? 7 : 6) : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
@@ -56,34 +72,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Batches: XCD k (workgroups are dealt to the XCDs round-robin, a placement used for L2 locality only) owns the range
-  // [k chunk, (k + 1) chunk) and its waves draw batches from it in order through one counter per XCD, two draws ahead
-  // of use so the ticket is back long before it is needed.  Drawing instead of a fixed stride makes the running time
-  // independent of how many of the launched workgroups the hardware really keeps resident (a workgroup that starts
-  // late finds its range drained and leaves) and evens out clock / contention differences between CUs.  The last wave
-  // to leave zeroes the counters for the next launch (stream-ordered; replayable from a graph).
+  // [k chunk, (k + 1) chunk); its waves walk it with a fixed stride, so at any time the batches in flight on an XCD are
+  // a window of consecutive ones.  (Drawing batches from a counter instead was measured: every memory wait of the
+  // kernel tripled with one returning device-scope atomic per wave and batch in the mix, 0.47 vs 0.22 ms.)
   const int xcd = blockIdx.x & 7;
   const int base = xcd * a.chunk, bend = min(base + a.chunk, a.nbatch);
-  auto ticket = [&]() {
-    int v = 0;
-    if (lane == 0) v = __hip_atomic_fetch_add(a.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;  // valid on lane 0
-  };
-  auto leave = [&]() {
-    if (lane == 0) {
-      const int total = (int)gridDim.x * kWavesPerBlock;
-      if (__hip_atomic_fetch_add(a.sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) __hip_atomic_store(a.sched + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  };
+  const int stride = (int)(gridDim.x >> 3) * kWavesPerBlock;
+  int b = base + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave;
+  if (b >= bend) return;
   // index words of a batch (every array is padded to a multiple of four elements; pad entries read as zero and are
   // stored to E-vector rows nobody gathers)
   auto load_idx = [&](const int bb, const int sub, const int t, int (&s)[NPL], unsigned (&p)[NPK + 1]) {
     const int e = bb * 4 + sub;
     const int32_t *si = a.sidx + (size_t)e * PP + t;
 #pragma unroll
+#ifdef PA_STREAM_NT_IDX
+    for (int r = 0; r < NPL; r++) s[r] = (16 * r + 15 < PP || t + 16 * r < PP) ? __builtin_nontemporal_load(&si[16 * r]) : 0;
+#else
     for (int r = 0; r < NPL; r++) s[r] = (16 * r + 15 < PP || t + 16 * r < PP) ? si[16 * r] : 0;
+#endif
     const uint32_t *pp = a.perm + (size_t)e * ((NPK + 1) * 16) + t;
 #pragma unroll
     for (int k = 0; k <= NPK; k++) p[k] = pp[16 * k];
@@ -96,19 +103,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       xv[r] = a.x[df & (kExclBit - 1)];
     }
   };
-  int b = base + __builtin_amdgcn_readfirstlane(ticket());
-  if (b >= bend) {
-    leave();
-    return;
-  }
-
   int sA[NPL];
   unsigned pA[NPK + 1];
   double xv[NPL];
   load_idx(b, lane >> 4, lane & 15, sA, pA);
   gather(sA, xv);
 
+#ifdef PA_STREAM_TRACE
+  const bool tr_on = blockIdx.x < kTraceWG && wave == 0;
+  int tr_b = 0;
+#endif
   for (;;) {
+    PA_STAMP(0);
     // lane constants are re-derived from an opaque copy of the lane id in every iteration: hoisted out of the loop, the
     // few dozen LDS addresses and predicates of the passes stay live across it and end up in scratch memory
     int lo = lane;
@@ -118,6 +124,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     int *side = reinterpret_cast<int *>(sm + L::ELEM_PAD);  // index words of this batch, kept for the E^T stores
     const int lx = L::parity_xor(sub);
     const int e = b * 4 + sub;
+
+    // q-data of this batch: consumed after the forward contraction
+    d2v gq[2 * NG];
+    {
+      const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)e * (2 * (METRIC ? 7 : NG) * 16) + t);
+#pragma unroll
+#ifdef PA_STREAM_NT_Q  // ablation: the q-data is read once -- keep it from displacing x / index lines
+      for (int k = 0; k < 2 * NG; k++) gq[k] = __builtin_nontemporal_load(&g[16 * k]);
+#else
+      for (int k = 0; k < 2 * NG; k++) gq[k] = g[16 * k];
+#endif
+    }
+    d2v ce = {0.0, 0.0};
+    if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
 
     // E: sorted entries into their tensor-order slots (x of this batch was requested during the previous one)
 #pragma unroll
@@ -131,6 +151,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     }
 #pragma unroll
     for (int k = 0; k <= NPK; k++) side[2 * ((PP + 1) / 2) + 16 * k + t] = (int)pA[k];
+    PA_STAMP(1);  // x arrived, staged
     wave_sync();
     double uin[3][NC];
 #pragma unroll
@@ -142,26 +163,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     }
     wave_sync();
 
-    // q-data of this batch: consumed after the forward contraction
-    d2v gq[2 * NG];
-    {
-      const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)e * (2 * (METRIC ? 7 : NG) * 16) + t);
-#pragma unroll
-      for (int k = 0; k < 2 * NG; k++) gq[k] = g[16 * k];
+    // index words of the next batch (clamped: the last iteration re-reads its own); first use: the x gather below.
+    // Requested here when the registers allow (p < 3), after the forward passes otherwise.
+    const int bn = b + stride;
+    const bool more = bn < bend;
+    int sB[NPL];
+    unsigned pB[NPK + 1];
+    if (EARLY_IDX) {
+      load_idx(more ? bn : b, sub, t, sB, pB);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    d2v ce = {0.0, 0.0};
-    if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
-    // Draw for the next batch.  Inline assembly on purpose: the compiler would wait for the returned value right here
-    // (s_waitcnt vmcnt(0): the whole q-data stream just requested); this way the only wait is the explicit one in front
-    // of D, where the q-data is needed anyway.  `tk` is written by the hardware when the atomic returns: nothing may
-    // touch it before that wait (scripts/audit_stream_asm.py checks the generated code).  The compiler's own counted
-    // waits do not see this operation, which can only make them wait for one operation more, never fewer.
-    int tk = 0;
-    if (lane == 0) {
-      const int one = 1, off = 4 * xcd;
-      asm volatile("global_atomic_add %0, %1, %2, %3 sc0 ; PA_TICKET_ISSUE" : "=v"(tk) : "v"(off), "v"(one), "s"(a.sched) : "memory");
-    }
-
+    PA_STAMP(2);  // q-data requested
     double U[3][Q1], CU[3][Q1];
 #pragma unroll
     for (int c = 0; c < 3; c++)
@@ -171,15 +183,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
     nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
 
-    // the ticket and the q-data have landed; index words of the next batch (clamped: the last iteration re-reads its own)
-    asm volatile("s_waitcnt vmcnt(0) ; PA_TICKET_WAIT %0" : "+v"(tk) : : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const int bn = base + __builtin_amdgcn_readfirstlane(tk);
-    const bool more = bn < bend;
-    int sB[NPL];
-    unsigned pB[NPK + 1];
-    load_idx(more ? bn : b, sub, t, sB, pB);
-    __builtin_amdgcn_sched_barrier(0);
+    PA_STAMP(3);  // forward done
+    PA_STAMP(4);
+    // index words of the next batch, if not requested at the top
+    if (!EARLY_IDX) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_idx(more ? bn : b, sub, t, sB, pB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     // D at the four points of this lane's column
 #pragma unroll
@@ -207,6 +218,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       }
     }
 
+    PA_STAMP(5);  // D done
     // x of the next batch: in flight during the transposed passes
     double xB[NPL];
     if (GPOS == 0) {
@@ -215,11 +227,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       __builtin_amdgcn_sched_barrier(0);
     }
     nd_bwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
+    PA_STAMP(6);  // first transposed component done
     if (GPOS == 1) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, xB);
       __builtin_amdgcn_sched_barrier(0);
     }
+    PA_STAMP(7);  // (GPOS 1) index words landed, x requested
     nd_bwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
     if (GPOS == 2) {
       __builtin_amdgcn_sched_barrier(0);
@@ -233,6 +247,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    PA_STAMP(8);  // transposed passes done
     // E^T: back to tensor order in LDS, out in sorted order, signed; exclusive dofs straight to y
 #pragma unroll
     for (int C = 0; C < 3; C++) {
@@ -268,6 +283,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       }
     }
     wave_sync();  // the LDS strip is reused by the next batch
+    PA_STAMP(9);  // stores issued
+#ifdef PA_STREAM_TRACE
+    tr_b++;
+#endif
     if (GPOS == 4) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, xB);
@@ -280,7 +299,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #pragma unroll
     for (int k = 0; k <= NPK; k++) pA[k] = pB[k];
   }
-  leave();
 }
 
 // ---- E^T of the shared dofs by runs -----------------------------------------------------------------------------------
@@ -370,8 +388,6 @@ void build_stream(SubOp &so) {
   std::vector<uint32_t> pp;
   streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ss, pp);
   so.h_sidx_s = ss;
-  so.d_sched_s = dev_alloc<int32_t>(16);
-  PA_HIP(hipMemset(so.d_sched_s, 0, 16 * sizeof(int32_t)));
   so.d_sidx_s = dev_upload(ss.data(), ss.size());
   so.d_perm_s = dev_upload(pp.data(), pp.size());
   if (so.qd->metric) {  // scalar coefficients per element (coeff_3_qf.h:9-24 resolved on the host)
@@ -425,7 +441,7 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
 }
 
 void free_stream(SubOp &so) {
-  hipFree(so.d_sidx_s), hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s), hipFree(so.d_coef_s), hipFree(so.d_sched_s);
+  hipFree(so.d_sidx_s), hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s), hipFree(so.d_coef_s);
   hipFree(so.d_rcode), hipFree(so.d_rcode_bc), hipFree(so.d_rhdr), hipFree(so.d_rpos);
 }
 
@@ -448,15 +464,15 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   constexpr int NPK = ((PP + 15) / 16 + 3) / 4;
   const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * (L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8);
   // resident workgroups per CU: registers (MINW waves per SIMD), LDS (160 KB), at most 8
-  // as many workgroups as the occupancy query admits per CU (the batches are drawn, so asking for one too many costs
-  // nothing), never more than there are pairs of batches
+  // workgroups per CU: what the registers (MINW waves per SIMD) and the LDS admit, and not more than the occupancy query
+  // says -- with a fixed stride a workgroup that had to queue would run after the others and double the time
   static const int wg_env = getenv("PALACE_AMD_STREAM_WG") ? atoi(getenv("PALACE_AMD_STREAM_WG")) : 0;
   static const int per_cu_query = [&] {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS>,
                                                      64 * kWavesPerBlock, lds) != hipSuccess || nb <= 0)
-      nb = std::min({MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
-    return nb;
+      nb = 8;
+    return std::min({nb, MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
   }();
   const int per_cu = wg_env > 0 ? wg_env : per_cu_query;
   const int per_xcd = std::max(1, device_cus() / 8) * per_cu;
@@ -488,7 +504,6 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   a.perm = so.d_perm_s;
   a.qdata = so.qd->d;
   a.coef = so.d_coef_s;
-  a.sched = so.d_sched_s;
   a.x = x, a.y = y, a.ye = so.d_ye;
   a.accumulate = accumulate ? 1 : 0;
   a.ess_policy = masked ? ess_policy : -1;
@@ -528,4 +543,14 @@ void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream
   PA_HIP(hipGetLastError());
 }
 
+#ifdef PA_STREAM_TRACE
+}  // namespace pa
+extern "C" int pa_debug_stream_trace(unsigned long long *out, int n) {
+  const int total = pa::kTraceWG * pa::kTraceBatches * pa::kTraceStamps;
+  if (n < total) return -total;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pa::g_trace), sizeof(unsigned long long) * total) != hipSuccess) return -1;
+  return total;
+}
+namespace pa {
+#endif
 }  // namespace pa

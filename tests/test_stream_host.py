@@ -47,23 +47,3 @@ def test_run_statistics_on_cylinder(tmp_path, cylinder_mesh):
     print(f"{mesh.ne} elements, {ns.value} shared dofs in {nruns} runs ({ns.value / nruns:.2f} dofs/run), "
           f"{ncp.value} run copies")
 
-
-def test_ticket_asm_audit(tmp_path):
-    """The streaming kernel draws its next batch with an atomic in inline assembly the compiler does not track: the
-    generated gfx950 code must leave the return register alone until the explicit wait, and must not spill."""
-    import shutil
-    import sys
-
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        import pytest
-
-        pytest.skip("hipcc not available")
-    asm = str(tmp_path / "stream.s")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-w",
-                           "--cuda-device-only", "-S", os.path.join(INC, "pa_nd_hex_stream.hip"), "-o", asm])
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    import audit_stream_asm
-
-    kernels, problems = audit_stream_asm.audit(open(asm).read())
-    assert kernels >= 15 and not problems, problems
