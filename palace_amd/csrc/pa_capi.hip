@@ -355,9 +355,9 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   bool first = true;
   for (const SubOp *so : op->subs) {
     if (so->fe_type == PA_FE_HCURL) {
-      if (so->d_sidx_s && (!masked || so->d_sidx_s_bc)) {  // streaming kernel + E^T of the shared dofs by runs
-        launch_nd_hex_stream(*so, x, y, masked, s, !(overwrite && first), ess_policy);
-        launch_et_run_gather(*so, y, !(overwrite && first), s, x, ess_policy);
+      if (so->d_sidx_s && overwrite && first && (!masked || so->d_sidx_s_bc)) {  // streaming kernel (y = A x) + E^T of the shared dofs by runs
+        launch_nd_hex_stream(*so, x, y, masked, s);
+        launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
       } else if (so->d_ye) {
         launch_nd_hex_apply(*so, x, y, so->d_ye, masked, s, !(overwrite && first), ess_policy);
         launch_et_gather(*so, y, !(overwrite && first), s, x, ess_policy);

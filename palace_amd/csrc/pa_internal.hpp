@@ -162,11 +162,14 @@ struct SubOp {
   int32_t *d_tent = nullptr;   // [ne * P] signed positions into d_ye
   // streaming form (pa_nd_hex_stream.hip): index words with the exclusive flag, byte slots, E^T of the shared dofs by runs
   int32_t *d_sidx_s = nullptr, *d_sidx_s_bc = nullptr;  // [ne][P]: dof | kEssBit | kExclBit; negative: -(1 + word), flipped
+  uint32_t *d_perm_s_bc = nullptr;                      // flag words with the essential dofs taken off the direct path
+  std::vector<uint32_t> h_perm_s;
+  int32_t *d_rhdr_bc = nullptr, *d_rpos_bc = nullptr;   // run list that also owns the essential rows
+  int n_shared_bc = 0;
   uint32_t *d_perm_s = nullptr;                         // [ne][ceil(P/64)][16], four 8-bit tensor-order slots per word
   double *d_coef_s = nullptr;                           // metric form: [ne][2] scalar mass / curl-curl coefficient per element
   std::vector<int32_t> h_sidx_s;
   uint32_t *d_rcode = nullptr, *d_rcode_bc = nullptr;   // [n_shared] run << 4 | offset (bit 31: essential)
-  std::vector<uint32_t> h_rcode;
   int32_t *d_rhdr = nullptr, *d_rpos = nullptr;         // run headers {first dof, first copy entry}; copy positions in d_ye
   int n_runs = 0;
   std::vector<double> Bc, Gc, Bo;  // full 1-D tables [q1d][n] (host)
@@ -223,9 +226,9 @@ bool nd_hex_stream_ok(const SubOp &so);
 void build_stream(SubOp &so);
 void stream_set_essential(SubOp &so, const std::vector<char> &flag);
 void free_stream(SubOp &so);
-void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, bool accumulate,
+void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s);
+void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
                           int ess_policy);
-void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, int ess_policy);
 void launch_h1_hex_apply(const SubOp &so, const double *x, bool masked, hipStream_t s);
 void launch_h1_hex_qdata(SubOp &so, hipStream_t s);
 void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);

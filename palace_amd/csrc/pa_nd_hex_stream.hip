@@ -52,7 +52,6 @@ struct NDStreamArgs {
   const double *coef;     // metric form: [ne][2] scalar mass / curl-curl coefficient of the element
   const double *x;
   double *y, *ye;
-  int accumulate, ess_policy;
   NDTab<P1, 4> tab;
 };
 
@@ -61,7 +60,11 @@ struct NDStreamArgs {
 template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
   constexpr int Q1 = 4;
+#ifdef PA_STREAM_EARLY  // experiment builds
+  constexpr bool EARLY_IDX = true;
+#else
   constexpr bool EARLY_IDX = P1 < 3;
+#endif
   using L = NDLayout<P1, Q1>;
   constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
   constexpr int NG = METRIC ? (USE_U ? 7 : 6) : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
@@ -86,14 +89,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     const int e = bb * 4 + sub;
     const int32_t *si = a.sidx + (size_t)e * PP + t;
 #pragma unroll
-#ifdef PA_STREAM_NT_IDX
     for (int r = 0; r < NPL; r++) s[r] = (16 * r + 15 < PP || t + 16 * r < PP) ? __builtin_nontemporal_load(&si[16 * r]) : 0;
-#else
-    for (int r = 0; r < NPL; r++) s[r] = (16 * r + 15 < PP || t + 16 * r < PP) ? si[16 * r] : 0;
-#endif
     const uint32_t *pp = a.perm + (size_t)e * ((NPK + 1) * 16) + t;
 #pragma unroll
-    for (int k = 0; k <= NPK; k++) p[k] = pp[16 * k];
+    for (int k = 0; k <= NPK; k++) p[k] = __builtin_nontemporal_load(&pp[16 * k]);
   };
   // raw x of the entries (essential entries are zeroed when staged)
   auto gather = [&](const int (&s)[NPL], double (&xv)[NPL]) {
@@ -103,11 +102,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       xv[r] = a.x[df & (kExclBit - 1)];
     }
   };
+  // the slot / flag words requested with the index words are first used at the top of the next batch; taking them as
+  // arrived here (they were requested before the x values above) keeps that wait from being placed behind the stores
+  auto settle = [&](unsigned (&p)[NPK + 1]) {
+#pragma unroll
+    for (int k = 0; k <= NPK; k++) asm volatile("" : "+v"(p[k]));
+  };
   int sA[NPL];
   unsigned pA[NPK + 1];
   double xv[NPL];
   load_idx(b, lane >> 4, lane & 15, sA, pA);
   gather(sA, xv);
+  // the first batch's x is awaited here, outside the loop: with loads still pending at the loop entry the compiler merges
+  // that state into the loop header and the counted waits at the top of every batch (x requested before that batch's nine
+  // stores) degrade to waiting for the stores as well
+#pragma unroll
+  for (int r = 0; r < NPL; r++) asm volatile("" : "+v"(xv[r]));
+  settle(pA);
 
 #ifdef PA_STREAM_TRACE
   const bool tr_on = blockIdx.x < kTraceWG && wave == 0;
@@ -130,11 +141,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     {
       const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)e * (2 * (METRIC ? 7 : NG) * 16) + t);
 #pragma unroll
-#ifdef PA_STREAM_NT_Q  // ablation: the q-data is read once -- keep it from displacing x / index lines
+      // (read once: non-temporal, so the stream does not displace x / y lines in L2; measured 5 - 7 % on the apply)
       for (int k = 0; k < 2 * NG; k++) gq[k] = __builtin_nontemporal_load(&g[16 * k]);
-#else
-      for (int k = 0; k < 2 * NG; k++) gq[k] = g[16 * k];
-#endif
     }
     d2v ce = {0.0, 0.0};
     if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     if (GPOS == 0) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, xB);
+      settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
     nd_bwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     if (GPOS == 1) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, xB);
+      settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
     PA_STAMP(7);  // (GPOS 1) index words landed, x requested
@@ -238,12 +248,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     if (GPOS == 2) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, xB);
+      settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
     nd_bwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
     if (GPOS == 3) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, xB);
+      settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -258,29 +270,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
         if (act && i < ni) sm[C * P1 * NC * NC + i + ni * (ta + nj * tb)] = uin[C][i];
     }
     wave_sync();
+    // One store per entry and lane, unconditionally: exclusive entries (flag) straight to y[dof], the others to the
+    // E-vector -- the address is selected, not the path, so the number of stores is fixed and the waits for the x values
+    // requested before them can be counted instead of waiting for every store to be acknowledged.  Lanes past the last
+    // entry repeat its store.  Essential rows never take the direct path when a fix-up is fused (stream_set_essential
+    // routes them through the run gather, which writes x or 0).  (y = A x only: AddMult keeps the one-shot kernel.)
 #pragma unroll
     for (int r = 0; r < NPL; r++) {
-      if (16 * r + 15 < PP || t + 16 * r < PP) {
-        const unsigned fl = (unsigned)side[2 * ((PP + 1) / 2) + 16 * NPK + t] >> (2 * r);
-        const double v = sm[((unsigned)side[2 * ((PP + 1) / 2) + 16 * (r >> 2) + t] >> (8 * (r & 3))) & 255u];
-        const double sgv = (fl & 1u) ? -v : v;
-        if (fl & 2u) {
-          const int sv = side[t + 16 * r], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
-          double *dst = &a.y[d];
-          // the common case (overwrite, not an essential row) is a plain store on its own path: merged with the two
-          // rare ones the compiler waits for every earlier store before each of these
-          const bool ess_row = (df & kEssBit) && a.ess_policy >= 0;
-          if (!ess_row && !a.accumulate) {
-            *dst = sgv;
-          } else if (ess_row) {  // ParOperator's essential rows (rap.cpp:223-233), fused
-            *dst = a.ess_policy ? a.x[d] : 0.0;
-          } else {
-            *dst = *dst + sgv;
-          }
-        } else {
-          a.ye[(size_t)e * PP + t + 16 * r] = sgv;
-        }
-      }
+      const int m = (16 * r + 15 < PP) ? t + 16 * r : min(t + 16 * r, PP - 1), mt = m & 15, mr = m >> 4;
+      const unsigned fl = (unsigned)side[2 * ((PP + 1) / 2) + 16 * NPK + mt] >> (2 * mr);
+      const double v = sm[((unsigned)side[2 * ((PP + 1) / 2) + 16 * (mr >> 2) + mt] >> (8 * (mr & 3))) & 255u];
+      const int sv = side[m], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
+      double *dst = (fl & 2u) ? a.y + d : a.ye + ((size_t)e * PP + m);
+      *dst = (fl & 1u) ? -v : v;
     }
     wave_sync();  // the LDS strip is reused by the next batch
     PA_STAMP(9);  // stores issued
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     if (GPOS == 4) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, xB);
+      settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!more) break;
@@ -388,6 +391,7 @@ void build_stream(SubOp &so) {
   std::vector<uint32_t> pp;
   streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ss, pp);
   so.h_sidx_s = ss;
+  so.h_perm_s = pp;
   so.d_sidx_s = dev_upload(ss.data(), ss.size());
   so.d_perm_s = dev_upload(pp.data(), pp.size());
   if (so.qd->metric) {  // scalar coefficients per element (coeff_3_qf.h:9-24 resolved on the host)
@@ -415,34 +419,57 @@ void build_stream(SubOp &so) {
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
   streamhost::build_runs(ne, P, so.lsize, so.h_sidx.data(), so.h_shared, code, hdr, rpos);
-  so.h_rcode = code;
   so.d_rcode = dev_upload(code.data(), code.size());
   so.d_rhdr = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
   so.d_rpos = dev_upload(rpos.data(), rpos.size());
   so.n_runs = (int)hdr.size() - 1;
 }
 
+// Essential dofs (pa_op_set_essential): flagged in a copy of the index words (read as zero), never exclusive in a copy of
+// the flag words (their element-local result goes to the E-vector like a shared dof's), and present in a second run list,
+// so that the run gather owns every essential row: it writes x or 0 there when ParOperator's fix-up is fused
+// (rap.cpp:223-233) and the plain sum otherwise.
 void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   if (!so.d_sidx_s) return;
+  const int P = so.P, npl = (P + 15) / 16, npk = (npl + 3) / 4;
   std::vector<int32_t> bc(so.h_sidx_s);
+  std::vector<uint32_t> pb(so.h_perm_s);
   const size_t nnz = (size_t)so.ne * so.P;  // (the pad entries are flagged already)
   for (size_t k = 0; k < nnz; k++) {
     int32_t &s = bc[k];
     const int w = s >= 0 ? s : -1 - s;
-    if (flag[w & (kExclBit - 1)]) s = s >= 0 ? (w | kEssBit) : -1 - (w | kEssBit);
+    if (flag[w & (kExclBit - 1)]) {
+      s = s >= 0 ? (w | kEssBit) : -1 - (w | kEssBit);
+      const size_t e = k / P;
+      const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
+      pb[(e * (npk + 1) + npk) * 16 + t] &= ~(2u << (2 * r));
+    }
   }
-  hipFree(so.d_sidx_s_bc);
+  hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s_bc);
   so.d_sidx_s_bc = dev_upload(bc.data(), bc.size());
-  std::vector<uint32_t> cb(so.h_rcode);
-  for (size_t k = 0; k < cb.size(); k++)
-    if (flag[so.h_shared[k]]) cb[k] |= 0x80000000u;
-  hipFree(so.d_rcode_bc);
-  so.d_rcode_bc = dev_upload(cb.data(), cb.size());
+  so.d_perm_s_bc = dev_upload(pb.data(), pb.size());
+  std::vector<int32_t> count((size_t)so.lsize, 0);
+  for (size_t k = 0; k < nnz; k++) count[streamhost::dof_of(so.h_sidx[k])]++;
+  std::vector<int32_t> shared;
+  shared.reserve(so.h_shared.size());
+  for (int d = 0; d < so.lsize; d++)
+    if (count[d] != 1 || flag[d]) shared.push_back(d);
+  std::vector<uint32_t> code;
+  std::vector<RunHdr> hdr;
+  std::vector<int32_t> rpos;
+  streamhost::build_runs(so.ne, P, so.lsize, so.h_sidx.data(), shared, code, hdr, rpos);
+  for (size_t k = 0; k < code.size(); k++)
+    if (flag[shared[k]]) code[k] |= 0x80000000u;
+  hipFree(so.d_rcode_bc), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
+  so.d_rcode_bc = dev_upload(code.data(), code.size());
+  so.d_rhdr_bc = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
+  so.d_rpos_bc = dev_upload(rpos.data(), rpos.size());
+  so.n_shared_bc = (int)shared.size();
 }
 
 void free_stream(SubOp &so) {
-  hipFree(so.d_sidx_s), hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s), hipFree(so.d_coef_s);
-  hipFree(so.d_rcode), hipFree(so.d_rcode_bc), hipFree(so.d_rhdr), hipFree(so.d_rpos);
+  hipFree(so.d_sidx_s), hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s), hipFree(so.d_perm_s_bc), hipFree(so.d_coef_s);
+  hipFree(so.d_rcode), hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rcode_bc), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
 }
 
 static int device_cus() {
@@ -485,8 +512,13 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
 
 // where x of the next batch is requested: after the first transposed component by default (its index words are requested
 // just before D and need time to arrive; x then has the rest of the batch).  PALACE_AMD_STREAM_GPOS = 0 / 1 / 2 for A/B.
-template <int P1, bool U, bool C, bool METRIC, int MINW>
+template <int P1, bool U, bool C, bool METRIC, int MINW_>
 static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
+#ifdef PA_STREAM_MINW2  // experiment builds: two waves per SIMD everywhere
+  constexpr int MINW = 2;
+#else
+  constexpr int MINW = MINW_;
+#endif
   static const int gpos = getenv("PALACE_AMD_STREAM_GPOS") ? atoi(getenv("PALACE_AMD_STREAM_GPOS")) : 1;
   if (gpos == 0)
     launch_gpos<P1, U, C, METRIC, MINW, 0>(so, a, s);
@@ -497,16 +529,14 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
 }
 
 template <int P1>
-static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, bool accumulate, int ess_policy) {
+static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s) {
   NDStreamArgs<P1> a;
   a.ne = so.ne;
-  a.sidx = (masked && so.d_sidx_s_bc) ? so.d_sidx_s_bc : so.d_sidx_s;
-  a.perm = so.d_perm_s;
+  a.sidx = masked ? so.d_sidx_s_bc : so.d_sidx_s;
+  a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
   a.qdata = so.qd->d;
   a.coef = so.d_coef_s;
   a.x = x, a.y = y, a.ye = so.d_ye;
-  a.accumulate = accumulate ? 1 : 0;
-  a.ess_policy = masked ? ess_policy : -1;
   const bool m = so.qd->metric;
   switch (so.qf) {
     case PA_QF_HDIV_33:
@@ -523,23 +553,24 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   }
 }
 
-void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, bool accumulate,
-                          int ess_policy) {
+void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s) {
   switch (so.p) {
-    case 1: launch_p<1>(so, x, y, masked, s, accumulate, ess_policy); break;
-    case 2: launch_p<2>(so, x, y, masked, s, accumulate, ess_policy); break;
-    case 3: launch_p<3>(so, x, y, masked, s, accumulate, ess_policy); break;
+    case 1: launch_p<1>(so, x, y, masked, s); break;
+    case 2: launch_p<2>(so, x, y, masked, s); break;
+    case 3: launch_p<3>(so, x, y, masked, s); break;
     default: throw Error("no streaming H(curl) hex kernel for this order");
   }
 }
 
-void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, int ess_policy) {
-  const int n = so.n_shared;
+// masked: the run list that owns the essential rows (the element kernel then ran on the _bc index arrays); ess_policy >= 0
+// additionally fuses ParOperator's fix-up y[ess] = x[ess] | 0 into it
+void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
+                          int ess_policy) {
+  const int n = masked ? so.n_shared_bc : so.n_shared;
   if (n == 0) return;
-  const bool bc = ess_policy >= 0 && so.d_rcode_bc;
-  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n, bc ? so.d_rcode_bc : so.d_rcode,
-                     reinterpret_cast<const RunHdr *>(so.d_rhdr), so.d_rpos, so.d_ye, y, accumulate ? 1 : 0, x,
-                     bc ? ess_policy : -1);
+  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
+                     masked ? so.d_rcode_bc : so.d_rcode, reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
+                     masked ? so.d_rpos_bc : so.d_rpos, so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1);
   PA_HIP(hipGetLastError());
 }
 

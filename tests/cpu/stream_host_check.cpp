@@ -56,19 +56,32 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac) {
   std::vector<int32_t> ss;
   std::vector<uint32_t> pp;
   pack_index(ne, P, lsize, sidx.data(), perm.data(), ss, pp);
+  // essential dofs as stream_set_essential handles them: flagged in the index words, off the direct path in the flag
+  // words, owned by the run list
+  const int npl0 = (P + 15) / 16, npk0 = (npl0 + 3) / 4;
+  std::vector<int32_t> ssb(ss);
+  std::vector<uint32_t> ppb(pp);
+  for (size_t k = 0; k < (size_t)ne * P; k++) {
+    const int w = ssb[k] >= 0 ? ssb[k] : -1 - ssb[k];
+    if (ess[w & (kExclBit - 1)]) {
+      ssb[k] = ssb[k] >= 0 ? (w | kEssBit) : -1 - (w | kEssBit);
+      const size_t e = k / P;
+      const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
+      ppb[(e * (npk0 + 1) + npk0) * 16 + t] &= ~(2u << (2 * r));
+    }
+  }
+  std::vector<int32_t> shared_bc;
+  for (int d = 0; d < lsize; d++)
+    if (count[d] != 1 || ess[d]) shared_bc.push_back(d);
   std::vector<uint32_t> code;
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
-  build_runs(ne, P, lsize, sidx.data(), shared, code, hdr, rpos);
-  // essential flags as stream_set_essential / pa_op_set_essential write them
-  std::vector<int32_t> ssb(ss);
-  for (size_t k = 0; k < (size_t)ne * P; k++) {
-    const int w = ssb[k] >= 0 ? ssb[k] : -1 - ssb[k];
-    if (ess[w & (kExclBit - 1)]) ssb[k] = ssb[k] >= 0 ? (w | kEssBit) : -1 - (w | kEssBit);
-  }
+  build_runs(ne, P, lsize, sidx.data(), shared_bc, code, hdr, rpos);
   std::vector<uint32_t> codeb(code);
   for (size_t k = 0; k < codeb.size(); k++)
-    if (ess[shared[k]]) codeb[k] |= 0x80000000u;
+    if (ess[shared_bc[k]]) codeb[k] |= 0x80000000u;
+  shared = shared_bc;
+  pp = ppb;
 
   std::vector<double> x(lsize), scale((size_t)ne * P);
   std::uniform_real_distribution<double> U(-1, 1);
@@ -114,10 +127,8 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac) {
         const double sgv = (fl & 1u) ? -v : v;
         if (fl & 2u) {
           const int sv = ssb[(size_t)e * P + t + 16 * r], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
-          if (df & kEssBit)
-            y[d] = x[d];
-          else
-            y[d] = sgv;
+          if (df & kEssBit) return std::printf("essential dof %d on the direct path\n", d), 1;
+          y[d] = sgv;
         } else {
           ye[(size_t)e * P + t + 16 * r] = sgv;
         }
