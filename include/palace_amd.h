@@ -244,11 +244,20 @@ int pa_op_coarsen_dense(const pa_op *fine, const pa_restriction_desc *restr, con
 int pa_op_apply_add(pa_op *op, const double *x, double *y, void *stream);
 /* Operator::Mult (operator.cpp:182-190): y = A x. */
 int pa_op_mult(pa_op *op, const double *x, double *y, void *stream);
+/* Operator::MultTranspose / AddMultTranspose (fem/libceed/operator.cpp:199-240): y (+)= A^T x.  Trial and test
+ * evaluation coincide for every integrator of this library, so A^T is the forward kernel with the coefficient matrices
+ * transposed; pa_op_is_symmetric tells whether that differs from A at all. */
+int pa_op_mult_transpose(pa_op *op, const double *x, double *y, void *stream);
+int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *stream);
+int pa_op_is_symmetric(const pa_op *op);
 /* Fused form of what ParOperator::Mult does around the local apply for square operators
  * (linalg/rap.cpp:207-220: tx = x; tx[ess] = 0; ly = A P tx): after pa_op_set_essential(list of
  * essential L-dofs), pa_op_mult_essential computes y = A (x with the listed entries read as zero)
  * without copying x.  The rows of y at essential dofs are NOT fixed up here (rap.cpp:223-233 does
  * that after P^T). */
+/* Which list is fused into the operator's index tables: 0 none, 1 this one, -1 a different one (a second
+ * ParOperator with another list must then handle its essential dofs outside the kernels). */
+int pa_op_essential_state(const pa_op *op, const int32_t *ess, int32_t n);
 int pa_op_set_essential(pa_op *op, const int32_t *ess_ldofs, int32_t n);
 int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream);
 /* The same with the row fix-up of rap.cpp:223-233 fused into the E^T kernels when the operator supports it:

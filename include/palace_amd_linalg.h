@@ -90,6 +90,18 @@ int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed);
 int pa_chebyshev_create(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max,
                         int fourth_kind, pa_solver **S);
 int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max);
+/* ChebyshevSmoother1stKind (linalg/chebyshev.cpp:222-293); sf_min <= 0: the optimised lambda_min estimate (:244-247). */
+int pa_chebyshev_create_1st_kind(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max, double sf_min,
+                                 pa_solver **S);
+/* DistRelaxationSmoother (linalg/distrelaxation.cpp:14-151) on its own: A the Nedelec ParOperator, A_aux the auxiliary
+ * H1 ParOperator, G their discrete gradient; the two Chebyshev smoothers' eigenvalue estimates for diagnostics. */
+int pa_dist_relaxation_create(pa_context *ctx, pa_par_op *A, pa_par_op *A_aux, pa_interp *G, int smooth_it,
+                              int cheby_smooth_it, int cheby_order, double cheby_sf_max, double cheby_sf_min,
+                              int cheby_4th_kind, pa_solver **S);
+int pa_dist_relaxation_lambda_max(const pa_solver *S, double *lambda_max, double *lambda_max_aux);
+/* Solver::Mult2 / MultTranspose2 (linalg/solver.hpp, the V-cycle's entry points gmg.cpp:184,204):
+ * y <- y + B (x - A y), starting from y when initial_guess != 0 and from zero otherwise. */
+int pa_solver_mult2(pa_solver *S, const double *x, double *y, int transpose, int initial_guess);
 /* JacobiSmoother (linalg/jacobi.cpp) */
 int pa_jacobi_create(pa_context *ctx, pa_par_op *A, pa_solver **S);
 /* CgSolver / GmresSolver / FgmresSolver (linalg/iterative.cpp).  precond may be NULL. */
@@ -144,6 +156,30 @@ int pa_complex_gmres_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_so
 int pa_csolver_mult(pa_csolver *S, const double *br, const double *bi, double *xr, double *xi, int initial_guess);
 int pa_csolver_stats(const pa_csolver *S, int *iterations, double *initial_res, double *final_res, int *converged);
 void pa_csolver_destroy(pa_csolver *S);
+
+/* --- ComplexParOperator (linalg/rap.hpp:124-221, rap.cpp:393-749): y = P^T (Ar + i Ai) P x over two LOCAL operators
+ *     (either may be NULL), essential dofs handled once on the complex vector (rap.cpp:436-462: the real part carries
+ *     `policy`, the imaginary part DIAG_ZERO).  mode 0 / 1 / 2 = A / A^T / A^H (Mult, MultTranspose,
+ *     MultHermitianTranspose); add != 0 is the AddMult* form y += a op(A) x with complex a.  `local_mult` applies the
+ *     local ComplexWrapperOperator (linalg/operator.cpp:58-413) on L-vectors. */
+typedef struct pa_complex_par_op pa_complex_par_op;
+int pa_complex_par_op_create(pa_context *ctx, pa_op *Ar, pa_op *Ai, int n_true, pa_halo *halo, pa_complex_par_op **A);
+int pa_complex_par_op_set_essential(pa_complex_par_op *A, const int32_t *ess, int n_ess, int policy);
+int pa_complex_par_op_mult(pa_complex_par_op *A, int mode, int add, double a_re, double a_im, const double *xr,
+                           const double *xi, double *yr, double *yi);
+int pa_complex_par_op_local_mult(pa_complex_par_op *A, int mode, int add, double a_re, double a_im, const double *xr,
+                                 const double *xi, double *yr, double *yi);
+int pa_complex_par_op_assemble_diagonal(pa_complex_par_op *A, double *dr, double *di);
+void pa_complex_par_op_destroy(pa_complex_par_op *A);
+/* GmresSolver / FgmresSolver <ComplexOperator> (linalg/iterative.cpp:543-871) on a ComplexParOperator: flexible != 0
+ * = FGMRES; pc_side 0 left / 1 right (iterative.hpp:187-272); orthog 0 MGS / 1 CGS / 2 CGS2. */
+int pa_complex_gmres_create_par(pa_context *ctx, pa_complex_par_op *A, pa_solver *precond, double rel_tol,
+                                double abs_tol, int max_it, int restart, int flexible, int pc_side, int orthog,
+                                int print, pa_csolver **S);
+/* GmresSolver::SetPreconditionerSide (iterative.hpp:214): 0 left (default), 1 right. */
+int pa_gmres_set_pc_side(pa_solver *S, int side);
+/* ParOperator::MultTranspose (linalg/rap.cpp:236-275). */
+int pa_par_op_mult_transpose(pa_par_op *A, const double *x, double *y);
 
 /* --- p-prolongation between two spaces on the same mesh (fem/bilinearform.cpp:203-282,
  *     fem/libceed/basis.cpp:116-165 `InitMfemInterpolatorBasis`, fem/libceed/integrator.cpp:515-548):

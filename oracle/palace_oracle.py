@@ -657,30 +657,90 @@ def spectral_norm_power(mult, n, tol=1e-4, max_it=1000, seed=0, u0=None):
 
 
 class ChebyshevOracle:
-    """chebyshev.cpp:160-220 (4th kind)."""
+    """chebyshev.cpp:160-220 (4th kind, default) and :222-293 (1st kind, `first_kind=True`; sf_min <= 0 takes the
+    optimised lambda_min estimate of Phillips and Fischer, chebyshev.cpp:244-247)."""
 
-    def __init__(self, A, order, sf_max=1.0, lambda_max=None, u0=None):
-        self.A, self.order = A, order
+    def __init__(self, A, order, sf_max=1.0, lambda_max=None, u0=None, first_kind=False, sf_min=0.0, smooth_it=1):
+        self.A, self.order, self.first_kind, self.pc_it = A, order, first_kind, smooth_it
         self.dinv = 1.0 / A.diagonal()
         if lambda_max is None:
             lambda_max = spectral_norm_power(lambda u: self.dinv * A.mult(u), A.n, u0=u0)
         self.lambda_max = sf_max * lambda_max
+        if first_kind:
+            if sf_min <= 0.0:
+                sf_min = 1.69 / (order ** 1.68 + 2.11 * order + 1.98)
+            lambda_min = sf_min * self.lambda_max
+            self.theta = 0.5 * (self.lambda_max + lambda_min)
+            self.delta = 0.5 * (self.lambda_max - lambda_min)
 
     def mult2(self, x, y, initial_guess):
-        if initial_guess:
-            r = x - self.A.mult(y)
-        else:
-            r = x.copy()
-            y = np.zeros_like(x)
-        lam = self.lambda_max
-        d = 4.0 / (3.0 * lam) * self.dinv * r
-        for k in range(1, self.order):
+        for it in range(self.pc_it):
+            if initial_guess or it > 0:
+                r = x - self.A.mult(y)
+            else:
+                r = x.copy()
+                y = np.zeros_like(x)
+            if not self.first_kind:
+                lam = self.lambda_max
+                d = 4.0 / (3.0 * lam) * self.dinv * r
+                for k in range(1, self.order):
+                    y = y + d
+                    r = r - self.A.mult(d)
+                    sd = (2.0 * k - 1.0) / (2.0 * k + 3.0)
+                    sr = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lam)
+                    d = sd * d + sr * self.dinv * r
+            else:
+                d = (1.0 / self.theta) * self.dinv * r
+                rhop = self.delta / self.theta
+                for k in range(1, self.order):
+                    y = y + d
+                    r = r - self.A.mult(d)
+                    rho = 1.0 / (2.0 * self.theta / self.delta - rhop)
+                    d = (rho * rhop) * d + (2.0 * rho / self.delta) * self.dinv * r
+                    rhop = rho
             y = y + d
-            r = r - self.A.mult(d)
-            sd = (2.0 * k - 1.0) / (2.0 * k + 3.0)
-            sr = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lam)
-            d = sd * d + sr * self.dinv * r
-        return y + d
+        return y
+
+    mult_transpose2 = mult2  # chebyshev.hpp: MultTranspose2 forwards to Mult2 (the polynomial in D^-1 A is symmetric)
+
+
+class DistRelaxationOracle:
+    """linalg/distrelaxation.cpp:98-151: Hiptmair distributive relaxation.  A: ParOperatorOracle-like on the Nedelec
+    space, A_G on the auxiliary H1 space, G = (mult, mult_transpose) discrete gradient, B / B_G Chebyshev oracles
+    (cheby_smooth_it = 1 as gmg.cpp:41-47 configures them), ess_G the essential true dofs of the auxiliary space."""
+
+    def __init__(self, A, A_G, G, B, B_G, ess_G, smooth_it=1):
+        self.A, self.A_G, self.G, self.B, self.B_G, self.ess_G, self.pc_it = A, A_G, G, B, B_G, np.asarray(ess_G), smooth_it
+
+    def mult2(self, x, y, initial_guess):
+        for it in range(self.pc_it):
+            # y = y + B (x - A y)
+            y = self.B.mult2(x, y, initial_guess or it > 0)
+            # y = y + G B_G G^T (x - A y)
+            r = x - self.A.mult(y)
+            x_G = self.G[1](r)
+            if self.ess_G.size:
+                x_G[self.ess_G] = 0.0
+            y_G = self.B_G.mult2(x_G, None, False)
+            y = y + self.G[0](y_G)
+        return y
+
+    def mult_transpose2(self, x, y, initial_guess):
+        for it in range(self.pc_it):
+            # y = y + G B_G^T G^T (x - A y)
+            if initial_guess or it > 0:
+                r = x - self.A.mult(y)
+                x_G = self.G[1](r)
+            else:
+                y = np.zeros_like(x)
+                x_G = self.G[1](x)
+            if self.ess_G.size:
+                x_G[self.ess_G] = 0.0
+            y_G = self.B_G.mult_transpose2(x_G, None, False)
+            y = y + self.G[0](y_G)
+            # y = y + B^T (x - A y)
+            y = self.B.mult_transpose2(x, y, True)
+        return y
 
 
 class GMGOracle:
@@ -700,7 +760,7 @@ class GMGOracle:
         xc[self.ess[l - 1]] = 0.0
         yc = self.vcycle(l - 1, xc, None, False)
         y = y + self.P[l - 1][0](yc)
-        return self.B[l].mult2(x, y, True)
+        return self.B[l].mult_transpose2(x, y, True)  # gmg.cpp:202-204
 
     def mult(self, x):
         return self.vcycle(len(self.A) - 1, x, None, False)
@@ -735,6 +795,126 @@ def pcg(A_mult, b, B_mult=None, rel_tol=0.0, abs_tol=0.0, max_it=100):
         converged = res < eps
         it += 1
     return x, it, hist
+
+
+def _generate_plane_rotation(dx, dy):
+    """iterative.cpp:72-166 (d/zlartg; the unscaled branches -- inputs of a Krylov recursion are far from over/underflow)."""
+    if np.iscomplexobj(dx) or np.iscomplexobj(dy):
+        dx, dy = complex(dx), complex(dy)
+        if dy == 0:
+            return 1.0, 0j
+        if dx == 0:
+            return 0.0, np.conj(dy) / abs(dy)
+        dx2, dy2 = abs(dx) ** 2, abs(dy) ** 2
+        dz2 = dx2 + dy2
+        return np.sqrt(dx2 / dz2), np.conj(dy) * (dx / np.sqrt(dx2 * dz2))
+    if dy == 0.0:
+        return 1.0, 0.0
+    if dx == 0.0:
+        return 0.0, np.copysign(1.0, dy)
+    d = np.sqrt(dx * dx + dy * dy)
+    return abs(dx) / d, dy / np.copysign(d, dx)
+
+
+def gmres(A_mult, b, B_mult=None, rel_tol=0.0, abs_tol=0.0, max_it=100, max_dim=-1, pc_side="left", flexible=False,
+          x0=None):
+    """GmresSolver::Mult (iterative.cpp:543-705) and FgmresSolver::Mult (:733-871), MGS (orthog.hpp:41-55), real or
+    complex (Dot(x, y) = y^H x, vector.cpp:674-685).  Returns (x, iterations, residual history, converged)."""
+    cplx = np.iscomplexobj(b)
+    dtype = complex if cplx else float
+    n = b.size
+    if max_dim < 0:
+        max_dim = max_it
+    if flexible:
+        assert B_mult is not None
+        pc_side = "right"
+    left = B_mult is not None and pc_side == "left"
+    right = B_mult is not None and pc_side == "right"
+    initial_guess = x0 is not None
+    x = x0.astype(dtype).copy() if initial_guess else np.zeros(n, dtype=dtype)
+    V = [None] * (max_dim + 1)
+    Z = [None] * (max_dim + 1)
+    H = np.zeros((max_dim + 1, max_dim), dtype=dtype)
+    s = np.zeros(max_dim + 1, dtype=dtype)
+    cs = np.zeros(max_dim + 1)
+    sn = np.zeros(max_dim + 1, dtype=dtype)
+    hist, it, restart, beta, eps, converged = [], 0, 0, 0.0, 0.0, False
+    while it < max_it:
+        guess = initial_guess or restart > 0
+        if left:
+            r = B_mult(b - A_mult(x)) if guess else B_mult(b)
+        else:
+            r = b - A_mult(x) if guess else b.astype(dtype).copy()
+        if not guess:
+            x[:] = 0
+        true_beta = np.linalg.norm(r)
+        if it == 0:
+            if initial_guess:
+                initial_res = np.linalg.norm(B_mult(b)) if left else np.linalg.norm(b)
+            else:
+                initial_res = true_beta
+            eps = max(rel_tol * initial_res, abs_tol)
+        beta = true_beta
+        if beta < eps:
+            converged = True
+            break
+        V[0] = r / beta
+        s[:] = 0
+        s[0] = beta
+        j = 0
+        while True:
+            hist.append(beta)
+            if left:
+                w = B_mult(A_mult(V[j]))
+            elif right:
+                Z[j] = B_mult(V[j])
+                w = A_mult(Z[j])
+            else:
+                w = A_mult(V[j])
+            for i in range(j + 1):
+                H[i, j] = np.vdot(V[i], w)
+                w = w - H[i, j] * V[i]
+            H[j + 1, j] = np.linalg.norm(w)
+            V[j + 1] = w / H[j + 1, j]
+            for k in range(j):
+                t = cs[k] * H[k, j] + sn[k] * H[k + 1, j]
+                H[k + 1, j] = -np.conj(sn[k]) * H[k, j] + cs[k] * H[k + 1, j]
+                H[k, j] = t
+            c, sgn = _generate_plane_rotation(H[j, j], H[j + 1, j])
+            cs[j], sn[j] = c, sgn
+            t = cs[j] * H[j, j] + sn[j] * H[j + 1, j]
+            H[j + 1, j] = -np.conj(sn[j]) * H[j, j] + cs[j] * H[j + 1, j]
+            H[j, j] = t
+            t = cs[j] * s[j] + sn[j] * s[j + 1]
+            s[j + 1] = -np.conj(sn[j]) * s[j] + cs[j] * s[j + 1]
+            s[j] = t
+            beta = abs(s[j + 1])
+            converged = beta < eps
+            if converged or j + 1 == max_dim or it + 1 == max_it:
+                it += 1
+                break
+            j += 1
+            it += 1
+        for i in range(j, -1, -1):
+            s[i] /= H[i, i]
+            for k in range(i - 1, -1, -1):
+                s[k] -= H[k, i] * s[i]
+        if flexible:
+            for k in range(j + 1):
+                x = x + s[k] * Z[k]
+        elif not right:
+            for k in range(j + 1):
+                x = x + s[k] * V[k]
+        else:
+            rr = np.zeros(n, dtype=dtype)
+            for k in range(j + 1):
+                rr = rr + s[k] * V[k]
+            x = x + B_mult(rr)
+        if converged:
+            break
+        restart += 1
+    hist.append(beta)
+    return x, it, hist, converged
 
 
 # ---------------------------------------------------------------------------------------------

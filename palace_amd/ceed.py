@@ -318,6 +318,15 @@ class Operator:
                                            C.c_void_p(y0.data_ptr()), C.c_void_p(y1.data_ptr()), _stream()))
         return y0, y1
 
+    def mult_transpose(self, x, y):
+        """y = A^T x (Operator::MultTranspose, fem/libceed/operator.cpp:214-224)."""
+        _lib.check(_lib.load().pa_op_mult_transpose(self.handle, C.c_void_p(x.data_ptr()),
+                                                    C.c_void_p(y.data_ptr()), _stream()))
+        return y
+
+    def is_symmetric(self):
+        return bool(_lib.load().pa_op_is_symmetric(self.handle))
+
     def add_mult(self, x, y, a=1.0):
         if a != 1.0:  # operator.cpp:194
             raise _lib.PalaceAmdError("ceed::Operator::AddMult only supports coefficient = 1.0!")

@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "comm.hpp"
+#include "krylov_impl.hpp"
 
 namespace palace {
 
@@ -116,6 +117,15 @@ void Fill(const Context &c, ComplexVector &x, double s) {
   Fill(c, x.Real(), s);
   Fill(c, x.Imag(), s);
 }
+void SetSubVector(const Context &c, ComplexVector &x, const int32_t *d_rows, int nrows, double s) {
+  SetSubVector(c, x.Real(), d_rows, nrows, s);
+  SetSubVector(c, x.Imag(), d_rows, nrows, s);
+}
+void SetSubVector(const Context &c, ComplexVector &x, const int32_t *d_rows, int nrows, const ComplexVector &y) {
+  SetSubVector(c, x.Real(), d_rows, nrows, y.Real());
+  SetSubVector(c, x.Imag(), d_rows, nrows, y.Imag());
+}
+void Conj(const Context &c, ComplexVector &x) { Scale(c, -1.0, x.Imag()); }
 void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
                          std::complex<double> *H, int m, const Operator *weight) {
   PA_REQUIRE(m >= 0 && (size_t)m <= V.size(), "Out of bounds number of columns for orthogonalization!");
@@ -154,6 +164,15 @@ void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::ve
 
 }  // namespace linalg
 
+// ---- ComplexOperator defaults (operator.cpp:17-56) -----------------------------------------------------------------
+void ComplexOperator::AssembleDiagonal(ComplexVector &) const { throw pa::Error("Base class ComplexOperator does not implement AssembleDiagonal!"); }
+void ComplexOperator::MultTranspose(const ComplexVector &, ComplexVector &) const { throw pa::Error("Base class ComplexOperator does not implement MultTranspose!"); }
+void ComplexOperator::MultHermitianTranspose(const ComplexVector &, ComplexVector &) const { throw pa::Error("Base class ComplexOperator does not implement MultHermitianTranspose!"); }
+void ComplexOperator::AddMult(const ComplexVector &, ComplexVector &, std::complex<double>) const { throw pa::Error("Base class ComplexOperator does not implement AddMult!"); }
+void ComplexOperator::AddMultTranspose(const ComplexVector &, ComplexVector &, std::complex<double>) const { throw pa::Error("Base class ComplexOperator does not implement AddMultTranspose!"); }
+void ComplexOperator::AddMultHermitianTranspose(const ComplexVector &, ComplexVector &, std::complex<double>) const { throw pa::Error("Base class ComplexOperator does not implement AddMultHermitianTranspose!"); }
+
+// ---- ComplexWrapperOperator (operator.cpp:58-413) ------------------------------------------------------------------
 ComplexWrapperOperator::ComplexWrapperOperator(const Context &ctx, const Operator *Ar, const Operator *Ai)
     : ctx_(&ctx), Ar_(Ar), Ai_(Ai) {
   PA_REQUIRE(Ar || Ai, "Cannot construct ComplexWrapperOperator from an empty matrix!");
@@ -164,8 +183,25 @@ ComplexWrapperOperator::ComplexWrapperOperator(const Context &ctx, const Operato
   t_.SetSize(height);
 }
 
+void ComplexWrapperOperator::AssembleDiagonal(ComplexVector &diag) const {
+  linalg::Fill(*ctx_, diag, 0.0);
+  if (Ar_) Ar_->AssembleDiagonal(diag.Real());
+  if (Ai_) Ai_->AssembleDiagonal(diag.Imag());
+}
+
+void ComplexWrapperOperator::AddReal(const Operator *A, bool transpose, const Vector &x, Vector &y, double s) const {
+  // the reference calls Operator::AddMult(x, y, s); ceed::Operator only accepts s = 1 (operator.cpp:194), so go through
+  // a temporary whenever the coefficient is not 1
+  if (t_.Size() != y.Size()) t_.SetSize(y.Size());
+  if (transpose)
+    A->MultTranspose(x, t_);
+  else
+    A->Mult(x, t_);
+  linalg::AXPY(*ctx_, s, t_, y);
+}
+
 void ComplexWrapperOperator::Mult(const ComplexVector &x, ComplexVector &y) const {
-  // linalg/operator.cpp:98-134: yr = Ar xr - Ai xi, yi = Ai xr + Ar xi
+  // operator.cpp:98-134: yr = Ar xr - Ai xi, yi = Ai xr + Ar xi
   // Each real operator meets both parts of x: with ParOperators the pair goes through one pass over the
   // element data (ParOperator::Mult2), otherwise through two applies as in the reference.
   const Context &c = *ctx_;
@@ -185,130 +221,248 @@ void ComplexWrapperOperator::Mult(const ComplexVector &x, ComplexVector &y) cons
   }
   if (Ar_) {
     if (par_r) {
-      if (t2_.Size() != t_.Size()) t2_.SetSize(t_.Size());
+      if (t_.Size() != height) t_.SetSize(height);
+      if (t2_.Size() != height) t2_.SetSize(height);
       par_r->Mult2(x.Real(), x.Imag(), t_, t2_);
       linalg::AXPY(c, 1.0, t_, y.Real());
       linalg::AXPY(c, 1.0, t2_, y.Imag());
     } else {
-      Ar_->Mult(x.Real(), t_);
-      linalg::AXPY(c, 1.0, t_, y.Real());
-      Ar_->Mult(x.Imag(), t_);
-      linalg::AXPY(c, 1.0, t_, y.Imag());
+      AddReal(Ar_, false, x.Real(), y.Real(), 1.0);
+      AddReal(Ar_, false, x.Imag(), y.Imag(), 1.0);
     }
   }
 }
 
-void ComplexGmresSolver::ApplyB(const ComplexVector &x, ComplexVector &y) const {
-  if (B_) {
+void ComplexWrapperOperator::MultTranspose(const ComplexVector &x, ComplexVector &y) const {
+  // operator.cpp:136-176: yr = Ar^T xr - Ai^T xi, yi = Ai^T xr + Ar^T xi
+  const Context &c = *ctx_;
+  if (Ai_) {
+    Ai_->MultTranspose(x.Imag(), y.Real());
+    linalg::AXPBY(c, 0.0, y.Real(), -1.0, y.Real());
+    Ai_->MultTranspose(x.Real(), y.Imag());
+  } else {
+    linalg::Fill(c, y, 0.0);
+  }
+  if (Ar_) {
+    AddReal(Ar_, true, x.Real(), y.Real(), 1.0);
+    AddReal(Ar_, true, x.Imag(), y.Imag(), 1.0);
+  }
+}
+
+void ComplexWrapperOperator::MultHermitianTranspose(const ComplexVector &x, ComplexVector &y) const {
+  // operator.cpp:178-219: yr = Ar^T xr + Ai^T xi, yi = -Ai^T xr + Ar^T xi
+  const Context &c = *ctx_;
+  if (Ai_) {
+    Ai_->MultTranspose(x.Imag(), y.Real());
+    Ai_->MultTranspose(x.Real(), y.Imag());
+    linalg::AXPBY(c, 0.0, y.Imag(), -1.0, y.Imag());
+  } else {
+    linalg::Fill(c, y, 0.0);
+  }
+  if (Ar_) {
+    AddReal(Ar_, true, x.Real(), y.Real(), 1.0);
+    AddReal(Ar_, true, x.Imag(), y.Imag(), 1.0);
+  }
+}
+
+void ComplexWrapperOperator::AddMult(const ComplexVector &x, ComplexVector &y, std::complex<double> a) const {
+  // operator.cpp:221-283
+  if (a.real() != 0.0 && a.imag() != 0.0) {
+    if (ty_.Size() != height) ty_.SetSize(height);
+    Mult(x, ty_);
+    linalg::AXPY(*ctx_, a, ty_, y);
+  } else if (a.real() != 0.0) {
+    if (Ar_) AddReal(Ar_, false, x.Real(), y.Real(), a.real()), AddReal(Ar_, false, x.Imag(), y.Imag(), a.real());
+    if (Ai_) AddReal(Ai_, false, x.Imag(), y.Real(), -a.real()), AddReal(Ai_, false, x.Real(), y.Imag(), a.real());
+  } else if (a.imag() != 0.0) {
+    if (Ar_) AddReal(Ar_, false, x.Real(), y.Imag(), a.imag()), AddReal(Ar_, false, x.Imag(), y.Real(), -a.imag());
+    if (Ai_) AddReal(Ai_, false, x.Imag(), y.Imag(), -a.imag()), AddReal(Ai_, false, x.Real(), y.Real(), -a.imag());
+  }
+}
+
+void ComplexWrapperOperator::AddMultTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a) const {
+  // operator.cpp:285-347
+  if (a.real() != 0.0 && a.imag() != 0.0) {
+    if (tx_.Size() != width) tx_.SetSize(width);
+    MultTranspose(x, tx_);
+    linalg::AXPY(*ctx_, a, tx_, y);
+  } else if (a.real() != 0.0) {
+    if (Ar_) AddReal(Ar_, true, x.Real(), y.Real(), a.real()), AddReal(Ar_, true, x.Imag(), y.Imag(), a.real());
+    if (Ai_) AddReal(Ai_, true, x.Imag(), y.Real(), -a.real()), AddReal(Ai_, true, x.Real(), y.Imag(), a.real());
+  } else if (a.imag() != 0.0) {
+    if (Ar_) AddReal(Ar_, true, x.Real(), y.Imag(), a.imag()), AddReal(Ar_, true, x.Imag(), y.Real(), -a.imag());
+    if (Ai_) AddReal(Ai_, true, x.Imag(), y.Imag(), -a.imag()), AddReal(Ai_, true, x.Real(), y.Real(), -a.imag());
+  }
+}
+
+void ComplexWrapperOperator::AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a) const {
+  // operator.cpp:349-413
+  if (a.real() != 0.0 && a.imag() != 0.0) {
+    if (tx_.Size() != width) tx_.SetSize(width);
+    MultHermitianTranspose(x, tx_);
+    linalg::AXPY(*ctx_, a, tx_, y);
+  } else if (a.real() != 0.0) {
+    if (Ar_) AddReal(Ar_, true, x.Real(), y.Real(), a.real()), AddReal(Ar_, true, x.Imag(), y.Imag(), a.real());
+    if (Ai_) AddReal(Ai_, true, x.Imag(), y.Real(), a.real()), AddReal(Ai_, true, x.Real(), y.Imag(), -a.real());
+  } else if (a.imag() != 0.0) {
+    if (Ar_) AddReal(Ar_, true, x.Real(), y.Imag(), a.imag()), AddReal(Ar_, true, x.Imag(), y.Real(), -a.imag());
+    if (Ai_) AddReal(Ai_, true, x.Imag(), y.Imag(), a.imag()), AddReal(Ai_, true, x.Real(), y.Real(), a.imag());
+  }
+}
+
+// ---- ComplexParOperator (rap.cpp:393-749) --------------------------------------------------------------------------
+ComplexParOperator::ComplexParOperator(const Context &ctx, const Operator *Ar, const Operator *Ai, int n_true, const Halo *halo)
+    : ComplexOperator(n_true, n_true), ctx_(&ctx), Ar_(Ar), Ai_(Ai), halo_(halo), n_true_(n_true) {
+  A_ = std::make_unique<ComplexWrapperOperator>(ctx, Ar, Ai);
+  PA_REQUIRE(A_->Height() == A_->Width(), "ComplexParOperator needs square local operators");
+  n_local_ = A_->Height();
+  PA_REQUIRE(n_true <= n_local_ && (halo || n_true == n_local_), "local != true dofs requires a halo plan");
+  if (Ar) RAPr_ = std::make_unique<ParOperator>(ctx, *Ar, n_true, nullptr, 0, ParOperator::DiagonalPolicy::DIAG_ONE, halo);
+  if (Ai) RAPi_ = std::make_unique<ParOperator>(ctx, *Ai, n_true, nullptr, 0, ParOperator::DiagonalPolicy::DIAG_ZERO, halo);
+  RAP_ = std::make_unique<ComplexWrapperOperator>(ctx, RAPr_.get(), RAPi_.get());
+  lx_.SetSize(n_local_), ly_.SetSize(n_local_);
+}
+ComplexParOperator::~ComplexParOperator() {
+  if (d_ess_) (void)hipFree(d_ess_);
+}
+
+void ComplexParOperator::SetEssentialTrueDofs(const int32_t *ess_host, int n_ess, ParOperator::DiagonalPolicy policy) {
+  PA_REQUIRE(policy != ParOperator::DiagonalPolicy::DIAG_ONE || RAPr_,
+             "DiagonalPolicy::DIAG_ONE specified for ComplexParOperator with no real part!");
+  for (int i = 0; i < n_ess; i++) PA_REQUIRE(ess_host[i] >= 0 && ess_host[i] < n_true_, "essential dof out of range");
+  if (d_ess_) (void)hipFree(d_ess_);
+  d_ess_ = n_ess ? pa::dev_upload(ess_host, (size_t)n_ess, ctx_->stream) : nullptr;
+  n_ess_ = n_ess, policy_ = policy;
+  // the real ParOperators are rebuilt with the list (real part: the policy; imaginary part: DIAG_ZERO, rap.cpp:450-457)
+  if (Ar_) RAPr_ = std::make_unique<ParOperator>(*ctx_, *Ar_, n_true_, ess_host, n_ess, policy, halo_);
+  if (Ai_) RAPi_ = std::make_unique<ParOperator>(*ctx_, *Ai_, n_true_, ess_host, n_ess, ParOperator::DiagonalPolicy::DIAG_ZERO, halo_);
+  RAP_ = std::make_unique<ComplexWrapperOperator>(*ctx_, RAPr_.get(), RAPi_.get());
+}
+
+ParOperator::DiagonalPolicy ComplexParOperator::GetDiagonalPolicy() const {
+  PA_REQUIRE(n_ess_ > 0, "There is no DiagonalPolicy if no essential dofs have been set!");
+  return policy_;
+}
+
+void ComplexParOperator::AssembleDiagonal(ComplexVector &diag) const {
+  linalg::Fill(*ctx_, diag, 0.0);
+  if (RAPr_) RAPr_->AssembleDiagonal(diag.Real());
+  if (RAPi_) RAPi_->AssembleDiagonal(diag.Imag());
+}
+
+void ComplexParOperator::Prolongate(const ComplexVector &x, ComplexVector &lx) const {
+  const Context &c = *ctx_;
+  ComplexVector tx(lx.Real().Data(), lx.Imag().Data(), n_true_);
+  linalg::Copy(c, x, tx);
+  if (n_ess_) linalg::SetSubVector(c, tx, d_ess_, n_ess_, 0.0);
+  if (halo_) {
+    halo_->Prolongate(lx.Real().Data(), c.stream);
+    halo_->Prolongate(lx.Imag().Data(), c.stream);
+  }
+}
+
+void ComplexParOperator::RestrictFix(const ComplexVector &x, ComplexVector &ly, ComplexVector &y) const {
+  const Context &c = *ctx_;
+  if (halo_) {
+    halo_->RestrictAdd(ly.Real().Data(), c.stream);
+    halo_->RestrictAdd(ly.Imag().Data(), c.stream);
+  }
+  ComplexVector ty(ly.Real().Data(), ly.Imag().Data(), n_true_);
+  linalg::Copy(c, ty, y);
+  if (n_ess_) {
+    if (policy_ == ParOperator::DiagonalPolicy::DIAG_ONE)
+      linalg::SetSubVector(c, y, d_ess_, n_ess_, x);
+    else
+      linalg::SetSubVector(c, y, d_ess_, n_ess_, 0.0);
+  }
+}
+
+void ComplexParOperator::Mult(const ComplexVector &x, ComplexVector &y) const {
+  // rap.cpp:483-519.  One rank: the same result through the two real ParOperators (yr = RAPr xr - RAPi xi has xr on the
+  // essential rows, yi = RAPi xr + RAPr xi has xi, with RAPi's rows zero), BC masking fused into the element kernels.
+  if (!halo_ && x.Real().Data() != y.Real().Data()) return RAP_->Mult(x, y);
+  Prolongate(x, lx_);
+  A_->Mult(lx_, ly_);
+  RestrictFix(x, ly_, y);
+}
+
+void ComplexParOperator::MultTranspose(const ComplexVector &x, ComplexVector &y) const {
+  // rap.cpp:521-556 (conforming spaces: the restriction transposed is the prolongation)
+  Prolongate(x, ly_);
+  A_->MultTranspose(ly_, lx_);
+  RestrictFix(x, lx_, y);
+}
+
+void ComplexParOperator::MultHermitianTranspose(const ComplexVector &x, ComplexVector &y) const {
+  // rap.cpp:558-593
+  Prolongate(x, ly_);
+  A_->MultHermitianTranspose(ly_, lx_);
+  RestrictFix(x, lx_, y);
+}
+
+void ComplexParOperator::AddMult(const ComplexVector &x, ComplexVector &y, std::complex<double> a) const {
+  // rap.cpp:595-635
+  if (tt_.Size() != n_true_) tt_.SetSize(n_true_);
+  Mult(x, tt_);
+  linalg::AXPY(*ctx_, a, tt_, y);
+}
+void ComplexParOperator::AddMultTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a) const {
+  // rap.cpp:637-677
+  if (tt_.Size() != n_true_) tt_.SetSize(n_true_);
+  MultTranspose(x, tt_);
+  linalg::AXPY(*ctx_, a, tt_, y);
+}
+void ComplexParOperator::AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a) const {
+  // rap.cpp:679-719
+  if (tt_.Size() != n_true_) tt_.SetSize(n_true_);
+  MultHermitianTranspose(x, tt_);
+  linalg::AXPY(*ctx_, a, tt_, y);
+}
+
+// ---- GMRES / FGMRES on complex vectors: the shared implementation (krylov_impl.hpp) --------------------------------
+namespace {
+struct ComplexKrylovOps {
+  using Vec = ComplexVector;
+  using Scalar = std::complex<double>;
+  const Context &c;
+  const ComplexOperator *A_;
+  const Solver *B_;
+  int n;
+  void Ensure(Vec &v) const {
+    if (v.Size() != n) v.SetSize(n);
+  }
+  void A(const Vec &x, Vec &y) const { A_->Mult(x, y); }
+  bool HasB() const { return B_ != nullptr; }
+  void B(const Vec &x, Vec &y) const {  // gmg.cpp:147-168: the real preconditioner on both parts
     B_->Mult(x.Real(), y.Real());
     B_->Mult(x.Imag(), y.Imag());
-  } else {
-    linalg::Copy(*ctx_, x, y);
   }
-}
+  void Copy(const Vec &x, Vec &y) const { linalg::Copy(c, x, y); }
+  void Zero(Vec &x) const { linalg::Fill(c, x, 0.0); }
+  void BMinus(const Vec &b, Vec &r) const {
+    linalg::Scale(c, -1.0, r);
+    linalg::AXPY(c, Scalar(1.0, 0.0), b, r);
+  }
+  void Axpy(Scalar a, const Vec &x, Vec &y) const { linalg::AXPY(c, a, x, y); }
+  void Scale(double s, Vec &x) const { linalg::Scale(c, s, x); }
+  double Norm(const Vec &x) const { return linalg::Norml2(c, x); }
+  void Orthogonalize(Orthogonalization kind, const std::vector<Vec> &V, Vec &w, Scalar *H, int m) const {
+    linalg::OrthogonalizeColumn(c, kind, V, w, H, m);
+  }
+};
+}  // namespace
 
 void ComplexGmresSolver::Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess) const {
-  using cd = std::complex<double>;
-  const Context &c = *ctx_;
   PA_REQUIRE(A_, "Operator must be set for GmresSolver::Mult!");
-  const int n = A_->Height();
-  const int m = (max_dim_ > 0) ? std::min(max_dim_, max_it_) : max_it_;
-  if (r_.Size() != n) r_.SetSize(n);
-  if ((int)V_.size() < m + 1) V_.resize(m + 1);
-  auto ensure = [&](int j) {
-    if (V_[j].Size() != n) V_[j].SetSize(n);
-  };
-  std::vector<cd> H((size_t)(m + 1) * m), s(m + 1), sn(m + 1);
-  std::vector<double> cs(m + 1);
-  auto Hij = [&](int i, int j) -> cd & { return H[(size_t)j * (m + 1) + i]; };
-  bool have_guess = initial_guess;
-  auto residual = [&]() {
-    ensure(0);
-    if (have_guess) {
-      A_->Mult(x, r_);
-      linalg::Scale(c, -1.0, r_);
-      linalg::AXPY(c, cd(1.0, 0.0), b, r_);
-    } else {
-      linalg::Copy(c, b, r_);
-      linalg::Fill(c, x, 0.0);
-    }
-    ApplyB(r_, V_[0]);
-    return linalg::Norml2(c, V_[0]);
-  };
-  double beta = residual();
-  if (initial_guess) {
-    ensure(1);
-    ApplyB(b, V_[1]);
-    initial_res_ = linalg::Norml2(c, V_[1]);
-  } else {
-    initial_res_ = beta;
-  }
-  const double eps = std::max(rel_tol_ * initial_res_, abs_tol_);
-  converged_ = beta < eps;
-  double res = beta;
-  int it = 0;
-  while (it < max_it_ && !converged_ && beta > 0.0) {
-    linalg::Scale(c, 1.0 / beta, V_[0]);
-    std::fill(s.begin(), s.end(), cd(0.0));
-    s[0] = beta;
-    int j = 0;
-    for (; j < m && it < max_it_; j++, it++) {
-      ensure(j + 1);
-      ComplexVector &w = V_[j + 1];
-      A_->Mult(V_[j], r_);
-      ApplyB(r_, w);
-      for (int i = 0; i <= j; i++) {  // MGS, Dot(w, v_i) = v_i^H w
-        Hij(i, j) = linalg::Dot(c, w, V_[i]);
-        linalg::AXPY(c, -Hij(i, j), V_[i], w);
-      }
-      const double hn = linalg::Norml2(c, w);
-      Hij(j + 1, j) = hn;
-      if (hn != 0.0) linalg::Scale(c, 1.0 / hn, w);
-      for (int k = 0; k < j; k++) {  // apply previous rotations [c s; -conj(s) c]
-        const cd t = cs[k] * Hij(k, j) + sn[k] * Hij(k + 1, j);
-        Hij(k + 1, j) = -std::conj(sn[k]) * Hij(k, j) + cs[k] * Hij(k + 1, j);
-        Hij(k, j) = t;
-      }
-      {  // new rotation annihilating H(j+1, j)
-        const cd f = Hij(j, j), g = Hij(j + 1, j);
-        if (g == cd(0.0)) {
-          cs[j] = 1.0, sn[j] = 0.0;
-        } else if (f == cd(0.0)) {
-          cs[j] = 0.0, sn[j] = std::conj(g) / std::abs(g);
-        } else {
-          const double nrm = std::sqrt(std::norm(f) + std::norm(g));
-          cs[j] = std::abs(f) / nrm;
-          sn[j] = (f / std::abs(f)) * std::conj(g) / nrm;
-        }
-        Hij(j, j) = cs[j] * f + sn[j] * g;
-        Hij(j + 1, j) = 0.0;
-        const cd t = cs[j] * s[j] + sn[j] * s[j + 1];
-        s[j + 1] = -std::conj(sn[j]) * s[j] + cs[j] * s[j + 1];
-        s[j] = t;
-      }
-      res = std::abs(s[j + 1]);
-      if (print_ > 1) std::printf("  %3d (restart %d) KSP residual norm %.6e\n", it + 1, j + 1, res);
-      converged_ = res < eps;
-      if (converged_) {
-        j++, it++;
-        break;
-      }
-    }
-    for (int i = j - 1; i >= 0; i--) {
-      s[i] /= Hij(i, i);
-      for (int k = i - 1; k >= 0; k--) s[k] -= Hij(k, i) * s[i];
-    }
-    for (int k = 0; k < j; k++) linalg::AXPY(c, s[k], V_[k], x);
-    if (converged_) break;
-    have_guess = true;
-    beta = residual();
-    res = beta;
-    converged_ = beta < eps;
-  }
-  if (print_ > 0)
-    std::printf("  GMRES (complex) %s in %d iterations (res %.3e, initial %.3e)\n",
-                converged_ ? "converged" : "did NOT converge", it, res, initial_res_);
-  final_res_ = res, final_it_ = it;
+  ComplexKrylovOps ops{*ctx_, A_, B_, A_->Height()};
+  krylov::Params p;
+  p.rel_tol = rel_tol_, p.abs_tol = abs_tol_, p.max_it = max_it_, p.max_dim = max_dim_, p.print = print_;
+  p.flexible = flexible_, p.initial_guess = initial_guess;
+  p.pc_side = pc_side_ == PreconditionerSide::RIGHT ? krylov::PreconditionerSide::RIGHT : krylov::PreconditionerSide::LEFT;
+  p.orthog = orthog_, p.name = flexible_ ? "FGMRES (complex)" : "GMRES (complex)";
+  krylov::Result res;
+  krylov::GmresMult(ops, p, b, x, V_, Z_, r_, res);
+  converged_ = res.converged, initial_res_ = res.initial_res, final_res_ = res.final_res, final_it_ = res.final_it;
 }
 
 }  // namespace palace

@@ -8,6 +8,8 @@
 
 #include <complex>
 
+#include <memory>
+
 #include "linalg.hpp"
 
 namespace palace {
@@ -34,55 +36,139 @@ void AXPY(const Context &c, std::complex<double> alpha, const ComplexVector &x, 
 void Scale(const Context &c, double s, ComplexVector &x);
 void Copy(const Context &c, const ComplexVector &x, ComplexVector &y);
 void Fill(const Context &c, ComplexVector &x, double s);
+// x[rows] = s ; x[rows] = y[rows] on both parts (vector.cpp:461-510)
+void SetSubVector(const Context &c, ComplexVector &x, const int32_t *d_rows, int nrows, double s);
+void SetSubVector(const Context &c, ComplexVector &x, const int32_t *d_rows, int nrows, const ComplexVector &y);
+// x = conj(x) (vector.cpp Conj)
+void Conj(const Context &c, ComplexVector &x);
 // complex instantiation of OrthogonalizeColumnMGS / CGS (orthog.hpp:41-89): H[j] = V[j]^H (W) w, w -= sum_j H[j] V[j];
 // `weight` is a real operator applied to the real and the imaginary part (test/unit/test-orthog.cpp:49-67)
 void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
                          std::complex<double> *H, int m, const Operator *weight = nullptr);
 }  // namespace linalg
 
+// ComplexOperator (linalg/operator.hpp:24-68): abstract complex operator on ComplexVectors.  The variants a concrete
+// operator does not provide abort like the reference's base class (operator.cpp:17-56).
 class ComplexOperator {
 protected:
   int height = 0, width = 0;
 
 public:
+  ComplexOperator(int s = 0) : height(s), width(s) {}
+  ComplexOperator(int h, int w) : height(h), width(w) {}
   virtual ~ComplexOperator() = default;
   int Height() const { return height; }
   int Width() const { return width; }
+  virtual bool IsReal() const { return !Imag(); }
+  virtual bool IsImag() const { return !Real(); }
+  virtual const Operator *Real() const { return nullptr; }
+  virtual const Operator *Imag() const { return nullptr; }
+  virtual void AssembleDiagonal(ComplexVector &diag) const;
   virtual void Mult(const ComplexVector &x, ComplexVector &y) const = 0;
+  virtual void MultTranspose(const ComplexVector &x, ComplexVector &y) const;
+  virtual void MultHermitianTranspose(const ComplexVector &x, ComplexVector &y) const;
+  virtual void AddMult(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const;
+  virtual void AddMultTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const;
+  virtual void AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const;
 };
 
+// ComplexWrapperOperator (linalg/operator.hpp:70-111, operator.cpp:58-413): 2 x 2 real-equivalent form
+//   [yr; yi] = [Ar -Ai; Ai Ar] [xr; xi]  over two real operators (either may be null), non-owning.
 class ComplexWrapperOperator : public ComplexOperator {
   const Context *ctx_;
   const Operator *Ar_, *Ai_;
   mutable Vector t_, t2_;
+  mutable ComplexVector tx_, ty_;
+  // y (+)= s op(A) x for one real operator through whatever that operator offers (AddMult with a coefficient or
+  // Mult + AXPY)
+  void AddReal(const Operator *A, bool transpose, const Vector &x, Vector &y, double s) const;
 
 public:
   ComplexWrapperOperator(const Context &ctx, const Operator *Ar, const Operator *Ai);
+  const Operator *Real() const override { return Ar_; }
+  const Operator *Imag() const override { return Ai_; }
+  void AssembleDiagonal(ComplexVector &diag) const override;
   void Mult(const ComplexVector &x, ComplexVector &y) const override;
+  void MultTranspose(const ComplexVector &x, ComplexVector &y) const override;
+  void MultHermitianTranspose(const ComplexVector &x, ComplexVector &y) const override;
+  void AddMult(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
+  void AddMultTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
+  void AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
 };
 
-// Restarted GMRES, left preconditioning, modified Gram-Schmidt, complex Givens rotations.
+// ComplexParOperator (linalg/rap.hpp:124-221, rap.cpp:393-749): y = P^T (Ar + i Ai) P x on true-dof vectors with the
+// essential-dof handling done once on the complex vector (rows: DIAG_ONE copies x, DIAG_ZERO zeroes; the real part carries
+// the policy, the imaginary part is DIAG_ZERO, rap.cpp:450-457).  Ar / Ai are the LOCAL operators (either may be null).
+// Real() / Imag() expose the two real ParOperators the reference also keeps (RAPr / RAPi) for diagonal assembly and for
+// preconditioner set-up.  With one rank Mult runs through them (essential masking fused into the element kernels, both
+// parts of x in one pass over the operator data); the transposed forms run on the L-vectors exactly as written there.
+class ComplexParOperator : public ComplexOperator {
+  const Context *ctx_;
+  const Operator *Ar_, *Ai_;
+  const Halo *halo_;
+  int n_true_, n_local_;
+  std::unique_ptr<ComplexWrapperOperator> A_;  // local (L-vector) operator
+  std::unique_ptr<ParOperator> RAPr_, RAPi_;
+  std::unique_ptr<ComplexWrapperOperator> RAP_;  // wrapper over RAPr / RAPi (single-rank fast path)
+  int32_t *d_ess_ = nullptr;
+  int n_ess_ = 0;
+  ParOperator::DiagonalPolicy policy_ = ParOperator::DiagonalPolicy::DIAG_ONE;
+  mutable ComplexVector lx_, ly_, tt_;
+  void Prolongate(const ComplexVector &x, ComplexVector &lx) const;  // tx = x, tx[ess] = 0, lx = P tx
+  void RestrictFix(const ComplexVector &x, ComplexVector &ly, ComplexVector &y) const;  // y = P^T ly, y[ess] = x | 0
+
+public:
+  ComplexParOperator(const Context &ctx, const Operator *Ar, const Operator *Ai, int n_true, const Halo *halo = nullptr);
+  ~ComplexParOperator() override;
+  // rap.cpp:436-462
+  void SetEssentialTrueDofs(const int32_t *ess_host, int n_ess, ParOperator::DiagonalPolicy policy);
+  const int32_t *GetEssentialTrueDofs() const { return d_ess_; }
+  int NumEssentialTrueDofs() const { return n_ess_; }
+  ParOperator::DiagonalPolicy GetDiagonalPolicy() const;
+  const ComplexOperator &LocalOperator() const { return *A_; }
+  const Operator *Real() const override { return RAPr_.get(); }
+  const Operator *Imag() const override { return RAPi_.get(); }
+  void AssembleDiagonal(ComplexVector &diag) const override;
+  void Mult(const ComplexVector &x, ComplexVector &y) const override;
+  void MultTranspose(const ComplexVector &x, ComplexVector &y) const override;
+  void MultHermitianTranspose(const ComplexVector &x, ComplexVector &y) const override;
+  void AddMult(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
+  void AddMultTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
+  void AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
+};
+
+// GmresSolver<ComplexOperator> / FgmresSolver<ComplexOperator> (linalg/iterative.cpp:543-871): the shared implementation
+// (krylov_impl.hpp) on ComplexVectors; the preconditioner is a real Solver applied to the real and the imaginary part
+// (linalg/gmg.cpp:147-168 `RealMult`).
 class ComplexGmresSolver {
   const Context *ctx_;
   const ComplexOperator *A_ = nullptr;
-  const Solver *B_ = nullptr;  // real preconditioner, applied to both parts
+  const Solver *B_ = nullptr;
   double rel_tol_ = 0.0, abs_tol_ = 0.0;
   int max_it_ = 100, max_dim_ = -1, print_ = 0;
+  bool flexible_ = false;
+  PreconditionerSide pc_side_ = PreconditionerSide::LEFT;
+  Orthogonalization orthog_ = Orthogonalization::MGS;
   mutable bool converged_ = false;
   mutable double initial_res_ = 1.0, final_res_ = 0.0;
   mutable int final_it_ = 0;
-  mutable std::vector<ComplexVector> V_;
+  mutable std::vector<ComplexVector> V_, Z_;
   mutable ComplexVector r_;
-  void ApplyB(const ComplexVector &x, ComplexVector &y) const;
 
 public:
-  explicit ComplexGmresSolver(const Context &ctx, int print = 0) : ctx_(&ctx), print_(print) {}
+  explicit ComplexGmresSolver(const Context &ctx, int print = 0, bool flexible = false)
+      : ctx_(&ctx), print_(print), flexible_(flexible), pc_side_(flexible ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT) {}
   void SetOperator(const ComplexOperator &op) { A_ = &op; }
   void SetPreconditioner(const Solver &pc) { B_ = &pc; }
   void SetTol(double t) { rel_tol_ = t; }
   void SetAbsTol(double t) { abs_tol_ = t; }
   void SetMaxIter(int n) { max_it_ = n; }
   void SetRestartDim(int m) { max_dim_ = m; }
+  void SetOrthogonalization(Orthogonalization o) { orthog_ = o; }
+  void SetPreconditionerSide(PreconditionerSide side) {
+    PA_REQUIRE(!flexible_ || side == PreconditionerSide::RIGHT, "FGMRES solver only supports right preconditioning!");
+    pc_side_ = side;
+  }
   void Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess = false) const;
   bool GetConverged() const { return converged_; }
   double GetInitialRes() const { return initial_res_; }

@@ -107,6 +107,10 @@ void CsrOperator::Apply(const Vector &x, Vector &y, double a, bool add) const {
 }
 
 void CsrOperator::Mult(const Vector &x, Vector &y) const { Apply(x, y, 1.0, false); }
+void CsrOperator::MultTranspose(const Vector &x, Vector &y) const {
+  PA_REQUIRE(m_->symmetric, "MultTranspose of an assembled non-symmetric operator is not available");
+  Apply(x, y, 1.0, false);
+}
 void CsrOperator::AddMult(const Vector &x, Vector &y, double a) const { Apply(x, y, a, true); }
 void CsrOperator::AssembleDiagonal(Vector &diag) const {
   PA_REQUIRE(diag.Size() == height, "size mismatch in CsrOperator::AssembleDiagonal");

@@ -9,6 +9,7 @@
 #include <cstdio>
 
 #include "comm.hpp"
+#include "krylov_impl.hpp"
 
 namespace palace {
 
@@ -44,6 +45,13 @@ constexpr int kMaxBlocks = 2048;  // 256 CUs x 8
 inline int grid_for(long long n) {
   long long b = (n + kBlock - 1) / kBlock;
   return (int)std::max(1LL, std::min<long long>(b, kMaxBlocks));
+}
+// Element-wise kernels: one lane entry per thread (no grid-stride round trips).  Measured on y = a x + b y over 2 x 512 MB
+// (scripts/probes/stream_probe.hip): 5.87 TB/s against 5.11 TB/s for 2048 grid-striding blocks; reductions keep the
+// bounded grid (their partial sums are one per block).
+inline int grid_full(long long n) {
+  long long b = (n + kBlock - 1) / kBlock;
+  return (int)std::max(1LL, std::min<long long>(b, 1LL << 24));
 }
 
 #define PA_STRIDE_LOOP(i, n)                                                                  \
@@ -384,9 +392,9 @@ template <class Op>
 void launch_ew(const Op &op, long long n, hipStream_t stream) {
   if (n <= 0) return;
   if ((op.align() & 15) == 0 && n >= 2)
-    hipLaunchKernelGGL((k_ew<2, Op>), dim3(grid_for((n + 1) / 2)), dim3(kBlock), 0, stream, op, n);
+    hipLaunchKernelGGL((k_ew<2, Op>), dim3(grid_full((n + 1) / 2)), dim3(kBlock), 0, stream, op, n);
   else
-    hipLaunchKernelGGL((k_ew<1, Op>), dim3(grid_for(n)), dim3(kBlock), 0, stream, op, n);
+    hipLaunchKernelGGL((k_ew<1, Op>), dim3(grid_full(n)), dim3(kBlock), 0, stream, op, n);
   PA_HIP(hipGetLastError());
 }
 
@@ -424,6 +432,7 @@ void Scale(const Context &c, const Vector &d, Vector &y) {
   launch_ew(OpScale{d.Data(), y.Data()}, y.Size(), c.stream);
 }
 void Reciprocal(const Context &c, Vector &x) { launch_ew(OpRecip{x.Data()}, x.Size(), c.stream); }
+void Scale(const Context &c, double s, Vector &x) { launch_ew(OpScal{s, x.Data()}, x.Size(), c.stream); }
 
 double Dot(const Context &c, const Vector &x, const Vector &y) {
   PA_REQUIRE(x.Size() == y.Size(), "size mismatch in Dot");
@@ -571,7 +580,9 @@ double SpectralNorm(const Context &c, const Operator &A, const Vector &dinv, dou
 }  // namespace linalg
 
 // ---- Operator defaults ------------------------------------------------------------------------
+void Operator::MultTranspose(const Vector &, Vector &) const { throw pa::Error("MultTranspose not implemented"); }
 void Operator::AddMult(const Vector &, Vector &, double) const { throw pa::Error("AddMult not implemented"); }
+void Operator::AddMultTranspose(const Vector &, Vector &, double) const { throw pa::Error("AddMultTranspose not implemented"); }
 void Operator::AssembleDiagonal(Vector &) const { throw pa::Error("AssembleDiagonal not implemented"); }
 void Solver::Mult2(const Vector &, Vector &, Vector &) const { throw pa::Error("Mult2 not implemented"); }
 
@@ -589,6 +600,14 @@ void Operator::AddMult(const Vector &x, Vector &y, double a) const {
   PA_REQUIRE(a == 1.0, "ceed::Operator::AddMult only supports coefficient = 1.0!");  // operator.cpp:194
   check(pa_op_apply_add(op_, x.Data(), y.Data(), ctx_->stream));
 }
+void Operator::MultTranspose(const Vector &x, Vector &y) const {
+  check(pa_op_mult_transpose(op_, x.Data(), y.Data(), ctx_->stream));
+}
+void Operator::AddMultTranspose(const Vector &x, Vector &y, double a) const {
+  PA_REQUIRE(a == 1.0, "ceed::Operator::AddMultTranspose only supports coefficient = 1.0!");  // operator.cpp:219
+  check(pa_op_apply_add_transpose(op_, x.Data(), y.Data(), ctx_->stream));
+}
+bool Operator::IsSymmetric() const { return pa_op_is_symmetric(op_) != 0; }
 void Operator::AssembleDiagonal(Vector &diag) const { check(pa_op_assemble_diagonal(op_, diag.Data(), ctx_->stream)); }
 void Operator::SetEssential(const int32_t *ess_host, int n) { check(pa_op_set_essential(op_, ess_host, n)); }
 bool Operator::MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const {
@@ -625,6 +644,28 @@ void SumOperator::Mult(const Vector &x, Vector &y) const {
     linalg::AXPY(*ctx_, ops_[k].second, z_, y);
   }
 }
+void SumOperator::MultTranspose(const Vector &x, Vector &y) const {
+  PA_REQUIRE(!ops_.empty(), "empty SumOperator");
+  ops_[0].first->MultTranspose(x, y);
+  if (ops_[0].second != 1.0) linalg::AXPBY(*ctx_, 0.0, y, ops_[0].second, y);
+  for (size_t k = 1; k < ops_.size(); k++) {
+    if (z_.Size() != height) z_.SetSize(height);
+    ops_[k].first->MultTranspose(x, z_);
+    linalg::AXPY(*ctx_, ops_[k].second, z_, y);
+  }
+}
+void SumOperator::AddMultTranspose(const Vector &x, Vector &y, double a) const {
+  if (z_.Size() != height) z_.SetSize(height);
+  for (const auto &[op, c] : ops_) {
+    op->MultTranspose(x, z_);
+    linalg::AXPY(*ctx_, a * c, z_, y);
+  }
+}
+bool SumOperator::IsSymmetric() const {
+  for (const auto &[op, c] : ops_)
+    if (!op->IsSymmetric()) return false;
+  return true;
+}
 void SumOperator::AddMult(const Vector &x, Vector &y, double a) const {
   if (z_.Size() != height) z_.SetSize(height);
   for (const auto &[op, c] : ops_) {
@@ -654,10 +695,13 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
   ly_.SetSize(n_local_);
   // One rank (P = identity): let the element kernel read essential entries as zero and write y
   // in place, instead of copying x and y through the L-vectors.
+  // (the flagged index tables belong to the local operator: if another wrapper has fused a different list into it,
+  // this one masks and fixes its rows outside the kernels instead of overwriting that list)
   if (!halo && n_ess) {
     if (auto *c = dynamic_cast<const ceed::Operator *>(&A)) {
-      const_cast<ceed::Operator *>(c)->SetEssential(ess_host, n_ess);
-      A_fused_ = c;
+      const int st = pa_op_essential_state(c->Handle(), ess_host, n_ess);
+      if (st == 0) const_cast<ceed::Operator *>(c)->SetEssential(ess_host, n_ess);
+      if (st >= 0) A_fused_ = c;
     }
   }
   if (!halo) {
@@ -700,6 +744,34 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
     else
       linalg::SetSubVector(c, y, d_ess_, n_ess_, 0.0);
   }
+}
+
+void ParOperator::MultTranspose(const Vector &x, Vector &y) const {
+  // rap.cpp:236-275.  ty = x, ty[ess] = 0; ly = P ty; lx = A^T ly; y = P^T lx; y[ess] = x[ess] | 0
+  if (A_->IsSymmetric()) return Mult(x, y);
+  const Context &c = *ctx_;
+  Vector tx(lx_.Data(), n_true_);
+  linalg::Copy(c, x, tx);
+  if (n_ess_) linalg::SetSubVector(c, tx, d_ess_, n_ess_, 0.0);
+  if (halo_) halo_->Prolongate(lx_.Data(), c.stream);
+  if (A_csr_)
+    throw pa::Error("transpose of an assembled non-symmetric local operator is not available");
+  A_->MultTranspose(lx_, ly_);
+  if (halo_) halo_->RestrictAdd(ly_.Data(), c.stream);
+  Vector ty(ly_.Data(), n_true_);
+  linalg::Copy(c, ty, y);
+  if (n_ess_) {
+    if (policy_ == DiagonalPolicy::DIAG_ONE)
+      linalg::SetSubVector(c, y, d_ess_, n_ess_, x);
+    else
+      linalg::SetSubVector(c, y, d_ess_, n_ess_, 0.0);
+  }
+}
+
+void ParOperator::AddMultTranspose(const Vector &x, Vector &y, double a) const {
+  if (tt_.Size() != n_true_) tt_.SetSize(n_true_);
+  MultTranspose(x, tt_);
+  linalg::AXPY(*ctx_, a, tt_, y);
 }
 
 void ParOperator::Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const {
@@ -932,133 +1004,44 @@ void CgSolver::Mult(const Vector &b, Vector &x) const {
   final_res_ = res, final_it_ = it;
 }
 
-// ---- GMRES / FGMRES (iterative.cpp:543-871), real scalars, MGS (orthog.hpp:41-55) ---------------
+// ---- GMRES / FGMRES (iterative.cpp:543-871): the shared implementation (krylov_impl.hpp) on real device vectors -------
 namespace {
-// LAPACK dlartg semantics used by the reference (iterative.cpp:72-241): r = sqrt(f^2+g^2)
-inline void GeneratePlaneRotation(double dx, double dy, double &cs, double &sn) {
-  if (dy == 0.0) {
-    cs = 1.0, sn = 0.0;
-  } else if (dx == 0.0) {
-    cs = 0.0, sn = 1.0;
-  } else {
-    const double r = std::copysign(std::hypot(dx, dy), dx);
-    cs = dx / r, sn = dy / r;
+struct RealKrylovOps {
+  using Vec = Vector;
+  using Scalar = double;
+  const Context &c;
+  const Operator *A_;
+  const Solver *B_;
+  int n;
+  void Ensure(Vec &v) const {
+    if (v.Size() != n) v.SetSize(n);
   }
-}
-inline void ApplyPlaneRotation(double &dx, double &dy, double cs, double sn) {
-  const double t = cs * dx + sn * dy;
-  dy = -sn * dx + cs * dy;
-  dx = t;
-}
+  void A(const Vec &x, Vec &y) const { A_->Mult(x, y); }
+  bool HasB() const { return B_ != nullptr; }
+  void B(const Vec &x, Vec &y) const { B_->Mult(x, y); }
+  void Copy(const Vec &x, Vec &y) const { linalg::Copy(c, x, y); }
+  void Zero(Vec &x) const { linalg::Fill(c, x, 0.0); }
+  void BMinus(const Vec &b, Vec &r) const { linalg::AXPBY(c, 1.0, b, -1.0, r); }
+  void Axpy(double a, const Vec &x, Vec &y) const { linalg::AXPY(c, a, x, y); }
+  void Scale(double s, Vec &x) const { linalg::Scale(c, s, x); }
+  double Norm(const Vec &x) const { return linalg::Norml2(c, x); }
+  void Orthogonalize(Orthogonalization kind, const std::vector<Vec> &V, Vec &w, double *H, int m) const {
+    linalg::OrthogonalizeColumn(c, kind, V, w, H, m);
+  }
+};
 }  // namespace
 
 void GmresSolver::Mult(const Vector &b, Vector &x) const {
-  const Context &c = *ctx_;
   PA_REQUIRE(A_, "Operator must be set for GmresSolver::Mult!");
-  const int n = A_->Height();
-  const int m = (max_dim_ > 0) ? std::min(max_dim_, max_it_) : max_it_;
-  r_.SetSize(n);
-  if ((int)V_.size() < m + 1) V_.resize(m + 1);
-  if (flexible_ && (int)Z_.size() < m + 1) Z_.resize(m + 1);
-  std::vector<double> H((size_t)(m + 1) * m, 0.0), s(m + 1), cs(m + 1), sn(m + 1);
-  auto Hij = [&](int i, int j) -> double & { return H[(size_t)j * (m + 1) + i]; };
-  auto ensure = [&](std::vector<Vector> &W, int j) {
-    if (W[j].Size() != n) W[j].SetSize(n);
-  };
-  // residual (left preconditioning for GMRES: r = B (b - A x); FGMRES: r = b - A x)
-  bool initial_guess_or_restart_ = initial_guess;
-  auto initial_residual = [&]() {
-    ensure(V_, 0);
-    if (initial_guess_or_restart_) {
-      A_->Mult(x, r_);
-      linalg::AXPBY(c, 1.0, b, -1.0, r_);
-    } else {
-      linalg::Copy(c, b, r_);
-      linalg::Fill(c, x, 0.0);
-    }
-    if (B_ && !flexible_) B_->Mult(r_, V_[0]); else linalg::Copy(c, r_, V_[0]);
-    return linalg::Norml2(c, V_[0]);
-  };
-  double beta = initial_residual();
-  if (initial_guess) {
-    // initial_res from the preconditioned right-hand side (iterative.cpp:572-584)
-    if (B_ && !flexible_) {
-      ensure(V_, 1);
-      B_->Mult(b, V_[1]);
-      initial_res_ = linalg::Norml2(c, V_[1]);
-    } else {
-      initial_res_ = linalg::Norml2(c, b);
-    }
-  } else {
-    initial_res_ = beta;
-  }
-  const double eps = std::max(rel_tol_ * initial_res_, abs_tol_);
-  converged_ = (beta < eps);
-  int it = 0;
-  double res = beta;
-  while (it < max_it_ && !converged_) {
-    if (beta == 0.0) break;
-    {
-      Vector &v0 = V_[0];
-      launch_ew(OpScal{1.0 / beta, v0.Data()}, n, c.stream);
-    }
-    std::fill(s.begin(), s.end(), 0.0);
-    s[0] = beta;
-    int j = 0;
-    for (; j < m && it < max_it_; j++, it++) {
-      ensure(V_, j + 1);
-      Vector &w = V_[j + 1];
-      if (flexible_) {
-        ensure(Z_, j);
-        if (B_) B_->Mult(V_[j], Z_[j]); else linalg::Copy(c, V_[j], Z_[j]);
-        A_->Mult(Z_[j], w);
-      } else {
-        A_->Mult(V_[j], r_);
-        if (B_) B_->Mult(r_, w); else linalg::Copy(c, r_, w);
-      }
-      if (orthog_ == Orthogonalization::MGS) {  // orthog.hpp:41-55
-        for (int i = 0; i <= j; i++) {
-          Hij(i, j) = linalg::Dot(c, w, V_[i]);
-          linalg::AXPY(c, -Hij(i, j), V_[i], w);
-        }
-      } else {  // classical Gram-Schmidt, optionally iterated once (orthog.hpp:57-89)
-        linalg::MultiDot(c, w, V_, j + 1, &Hij(0, j));
-        linalg::MultiAXPY(c, &Hij(0, j), V_, j + 1, w);
-        if (orthog_ == Orthogonalization::CGS2) {
-          std::vector<double> dH(j + 1);
-          linalg::MultiDot(c, w, V_, j + 1, dH.data());
-          linalg::MultiAXPY(c, dH.data(), V_, j + 1, w);
-          for (int i = 0; i <= j; i++) Hij(i, j) += dH[i];
-        }
-      }
-      Hij(j + 1, j) = linalg::Norml2(c, w);
-      if (Hij(j + 1, j) != 0.0)
-        launch_ew(OpScal{1.0 / Hij(j + 1, j), w.Data()}, n, c.stream);
-      for (int k = 0; k < j; k++) ApplyPlaneRotation(Hij(k, j), Hij(k + 1, j), cs[k], sn[k]);
-      GeneratePlaneRotation(Hij(j, j), Hij(j + 1, j), cs[j], sn[j]);
-      ApplyPlaneRotation(Hij(j, j), Hij(j + 1, j), cs[j], sn[j]);
-      ApplyPlaneRotation(s[j], s[j + 1], cs[j], sn[j]);
-      res = std::abs(s[j + 1]);
-      if (print_ > 1) std::printf("  %3d (restart %d) KSP residual norm %.6e\n", it + 1, j + 1, res);
-      converged_ = (res < eps);
-      if (converged_) { j++, it++; break; }
-    }
-    // back substitution and solution update
-    for (int i = j - 1; i >= 0; i--) {
-      s[i] /= Hij(i, i);
-      for (int k = i - 1; k >= 0; k--) s[k] -= Hij(k, i) * s[i];
-    }
-    for (int k = 0; k < j; k++) linalg::AXPY(c, s[k], flexible_ ? Z_[k] : V_[k], x);
-    if (converged_) break;
-    initial_guess_or_restart_ = true;
-    beta = initial_residual();
-    res = beta;
-    converged_ = (beta < eps);
-  }
-  if (print_ > 0)
-    std::printf("  GMRES solver %s in %d iterations (res %.3e, initial %.3e)\n",
-                converged_ ? "converged" : "did NOT converge", it, res, initial_res_);
-  final_res_ = res, final_it_ = it;
+  RealKrylovOps ops{*ctx_, A_, B_, A_->Height()};
+  krylov::Params p;
+  p.rel_tol = rel_tol_, p.abs_tol = abs_tol_, p.max_it = max_it_, p.max_dim = max_dim_, p.print = print_;
+  p.flexible = flexible_, p.initial_guess = initial_guess;
+  p.pc_side = pc_side_ == PreconditionerSide::RIGHT ? krylov::PreconditionerSide::RIGHT : krylov::PreconditionerSide::LEFT;
+  p.orthog = orthog_, p.name = flexible_ ? "FGMRES" : "GMRES";
+  krylov::Result res;
+  krylov::GmresMult(ops, p, b, x, V_, Z_, r_, res);
+  converged_ = res.converged, initial_res_ = res.initial_res, final_res_ = res.final_res, final_it_ = res.final_it;
 }
 
 // ---- geometric multigrid (gmg.cpp) ---------------------------------------------------------------

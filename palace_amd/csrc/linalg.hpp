@@ -68,8 +68,9 @@ void AXPBYPCZ(const Context &c, double alpha, const Vector &x, double beta, cons
 // x[rows] = s ; x[rows] = y[rows]   (vector.cpp:461-510)
 void SetSubVector(const Context &c, Vector &x, const int32_t *d_rows, int nrows, double s);
 void SetSubVector(const Context &c, Vector &x, const int32_t *d_rows, int nrows, const Vector &y);
-// y = x .* y, x = 1 ./ x
+// y = x .* y, x = 1 ./ x, x *= s
 void Scale(const Context &c, const Vector &d, Vector &y);
+void Scale(const Context &c, double s, Vector &x);
 void Reciprocal(const Context &c, Vector &x);
 // Global inner product of T-vectors: local wavefront/LDS tree reduction + allreduce
 // (vector.hpp:247-260).
@@ -106,10 +107,15 @@ public:
   int Height() const { return height; }
   int Width() const { return width; }
   virtual void Mult(const Vector &x, Vector &y) const = 0;
-  virtual void MultTranspose(const Vector &x, Vector &y) const { Mult(x, y); }
-  // y += a A x
+  // y = A^T x: no default (an operator that is not known to be symmetric must say what its transpose is)
+  virtual void MultTranspose(const Vector &x, Vector &y) const;
+  // y += a A x, y += a A^T x
   virtual void AddMult(const Vector &x, Vector &y, double a = 1.0) const;
+  virtual void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const;
   virtual void AssembleDiagonal(Vector &diag) const;
+  // true when A^T = A is known (symmetric coefficients): lets wrappers forward the transpose to the fused forward paths,
+  // like the reference's SymmetricOperator (fem/libceed/operator.hpp:69-79)
+  virtual bool IsSymmetric() const { return false; }
 };
 
 namespace ceed {
@@ -125,8 +131,11 @@ public:
   ~Operator() override;
   pa_op *Handle() const { return op_; }
   void Mult(const Vector &x, Vector &y) const override;
+  void MultTranspose(const Vector &x, Vector &y) const override;
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
+  void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const override;
   void AssembleDiagonal(Vector &diag) const override;
+  bool IsSymmetric() const override;
   // y = A (x with the essential entries read as zero), no copy of x (pa_op_mult_essential)
   void SetEssential(const int32_t *ess_host, int n);
   void MultEssential(const Vector &x, Vector &y) const;
@@ -151,9 +160,11 @@ public:
   SumOperator(const Context &ctx, int h, int w) : Operator(h, w), ctx_(&ctx) {}
   void AddOperator(const Operator &op, double a = 1.0);
   void Mult(const Vector &x, Vector &y) const override;
-  void MultTranspose(const Vector &x, Vector &y) const override { Mult(x, y); }
+  void MultTranspose(const Vector &x, Vector &y) const override;
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
+  void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const override;
   void AssembleDiagonal(Vector &diag) const override;
+  bool IsSymmetric() const override;
 };
 
 // Local operator held as an assembled CSR matrix in device memory (csr_op.hip): what the reference's coarsest level
@@ -172,8 +183,10 @@ public:
   void EliminateEssential(const int32_t *d_ess, int n_ess, bool diag_one);
   void MultUnconstrained(const Vector &x, Vector &y) const;
   void Mult(const Vector &x, Vector &y) const override;
+  void MultTranspose(const Vector &x, Vector &y) const override;  // symmetric matrices only (pa_csr::symmetric)
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
   void AssembleDiagonal(Vector &diag) const override;
+  bool IsSymmetric() const override { return m_->symmetric; }
 };
 
 // ParOperator (rap.cpp:154-234): y = P^T A P x with essential-dof handling.  True dofs of this
@@ -203,12 +216,13 @@ public:
   int NumEssentialTrueDofs() const { return n_ess_; }
   const Operator &LocalOperator() const { return *A_; }
   void Mult(const Vector &x, Vector &y) const override;
-  // rap.cpp:236-275 (the local operators of this library are symmetric: ceed::Operator forwards its
-  // transpose to the forward apply like the reference's SymmetricOperator, operator.hpp:69-79)
-  void MultTranspose(const Vector &x, Vector &y) const override { Mult(x, y); }
+  // rap.cpp:236-275: y = P^T A^T P x with the same essential-dof handling (a symmetric local operator takes the fused
+  // forward path)
+  void MultTranspose(const Vector &x, Vector &y) const override;
   // y += a A x  (rap.cpp:277-318) / its transpose (:320-361)
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
-  void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const { AddMult(x, y, a); }
+  void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const override;
+  bool IsSymmetric() const override { return A_->IsSymmetric(); }
   // y0 = A x0, y1 = A x1: the real and imaginary parts of a complex vector through one real operator
   void Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const;
   // b -= A_unconstrained (x restricted to the essential dofs); b[ess] = x[ess] | 0  (rap.cpp:56-82)
@@ -288,6 +302,8 @@ public:
                          double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true);
   void SetOperator(const Operator &) override { throw pa::Error("use SetOperators(op, op_G)"); }
   void SetOperators(const Operator &op, const ParOperator &op_G);
+  const ChebyshevSmoother &Primary() const { return *B_; }
+  const ChebyshevSmoother &Auxiliary() const { return *B_G_; }
   void Mult(const Vector &x, Vector &y) const override;
   void Mult2(const Vector &x, Vector &y, Vector &r) const override;
   void MultTranspose2(const Vector &x, Vector &y, Vector &r) const override;
@@ -338,18 +354,35 @@ void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::ve
                          int m, const Operator *weight = nullptr);
 }  // namespace linalg
 
+enum class PreconditionerSide { LEFT = 0, RIGHT = 1 };  // config "PCSide" (iterative.hpp:187-214)
+
+// GmresSolver (iterative.cpp:543-705): restarted GMRES, left (default) or right preconditioning; flexible = true is
+// FgmresSolver (iterative.cpp:733-871): right preconditioning with the preconditioned basis stored.  One implementation
+// for real and complex scalars (krylov_impl.hpp).
 class GmresSolver : public IterativeSolver {
+protected:
   int max_dim_ = -1;
-  bool flexible_ = false;  // FGMRES (right preconditioning, stores Z)
+  bool flexible_ = false;
+  PreconditionerSide pc_side_ = PreconditionerSide::LEFT;
   Orthogonalization orthog_ = Orthogonalization::MGS;
   mutable std::vector<Vector> V_, Z_;
   mutable Vector r_;
 
 public:
-  GmresSolver(const Context &ctx, int print = 0, bool flexible = false) : IterativeSolver(ctx, print), flexible_(flexible) {}
+  GmresSolver(const Context &ctx, int print = 0, bool flexible = false)
+      : IterativeSolver(ctx, print), flexible_(flexible), pc_side_(flexible ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT) {}
   void SetRestartDim(int dim) { max_dim_ = dim; }
   void SetOrthogonalization(Orthogonalization o) { orthog_ = o; }
+  virtual void SetPreconditionerSide(PreconditionerSide side) {
+    PA_REQUIRE(!flexible_ || side == PreconditionerSide::RIGHT, "FGMRES solver only supports right preconditioning!");  // iterative.hpp:268-272
+    pc_side_ = side;
+  }
   void Mult(const Vector &b, Vector &x) const override;
+};
+
+class FgmresSolver : public GmresSolver {
+public:
+  explicit FgmresSolver(const Context &ctx, int print = 0) : GmresSolver(ctx, print, true) {}
 };
 
 // GeometricMultigridSolver (gmg.cpp): levels 0 (coarsest) .. L-1, prolongations P[l]: level l -> l+1

@@ -38,6 +38,27 @@ void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s);
 
 using namespace pa;
 
+namespace {
+// temporaries and the result of pa_op_full_assemble are released if anything in it throws
+struct AssembleGuard {
+  pa_csr *m = nullptr;
+  std::vector<void *> tmp;
+  ~AssembleGuard() {
+    for (void *p : tmp) (void)hipFree(p);
+    if (m) pa_csr_destroy(m);
+  }
+  template <typename T>
+  T *keep(T *p) {
+    tmp.push_back(p);
+    return p;
+  }
+  void release(void *p) {
+    for (auto &q : tmp)
+      if (q == p) q = nullptr;
+  }
+};
+}  // namespace
+
 extern "C" {
 
 int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
@@ -109,11 +130,13 @@ int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
     std::vector<int32_t> row_of((size_t)nnz);
     for (int r = 0; r < n; r++)
       for (int32_t a = rowptr[r]; a < rowptr[r + 1]; a++) row_of[a] = r;
-    auto *m = new pa_csr;
+    AssembleGuard guard;
+    auto *m = guard.m = new pa_csr;
     m->nrows = n;
-    int32_t *d_color = dev_upload(color.data(), color.size(), s), *d_row_of = dev_upload(row_of.data(), row_of.size(), s);
-    int32_t *d_col = dev_upload(col.data(), col.size(), s);
-    double *d_val = dev_alloc<double>((size_t)nnz), *d_x = dev_alloc<double>((size_t)n), *d_y = dev_alloc<double>((size_t)n);
+    m->symmetric = op->symmetric();
+    int32_t *d_color = guard.keep(dev_upload(color.data(), color.size(), s)), *d_row_of = guard.keep(dev_upload(row_of.data(), row_of.size(), s));
+    int32_t *d_col = guard.keep(dev_upload(col.data(), col.size(), s));
+    double *d_val = guard.keep(dev_alloc<double>((size_t)nnz)), *d_x = guard.keep(dev_alloc<double>((size_t)n)), *d_y = guard.keep(dev_alloc<double>((size_t)n));
     PA_HIP(hipMemsetAsync(d_val, 0, sizeof(double) * (size_t)nnz, s));
     for (int c = 0; c < ncolors; c++) {
       hipLaunchKernelGGL(k_probe_vector, dim3((n + 255) / 256), dim3(256), 0, s, n, d_color, c, d_x);
@@ -123,7 +146,6 @@ int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
     }
     PA_HIP(hipGetLastError());
     PA_HIP(hipStreamSynchronize(s));
-    hipFree(d_color), hipFree(d_row_of), hipFree(d_x), hipFree(d_y);
     if (skip_zeros) {  // operator.cpp:262-313: drop the entries that are exactly zero
       std::vector<double> val((size_t)nnz);
       PA_HIP(hipMemcpy(val.data(), d_val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
@@ -132,10 +154,10 @@ int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
       cl.reserve((size_t)nnz), vl.reserve((size_t)nnz);
       for (int r = 0; r < n; r++) {
         for (int32_t a = rowptr[r]; a < rowptr[r + 1]; a++)
-          if (val[a] != 0.0) cl.push_back(col[a]), vl.push_back(val[a]);
+          if (val[a] != 0.0 || col[a] == r)  // the diagonal slot stays: EliminateEssential writes the DIAG_ONE value there
+            cl.push_back(col[a]), vl.push_back(val[a]);
         rp[r + 1] = (int32_t)cl.size();
       }
-      hipFree(d_col), hipFree(d_val);
       m->nnz = (int64_t)cl.size();
       m->d_rowptr = dev_upload(rp.data(), rp.size(), s);
       m->d_col = dev_upload(cl.data(), cl.size(), s);
@@ -144,7 +166,9 @@ int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
       m->nnz = nnz;
       m->d_rowptr = dev_upload(rowptr.data(), rowptr.size(), s);
       m->d_col = d_col, m->d_val = d_val;
+      guard.release(d_col), guard.release(d_val);
     }
+    guard.m = nullptr;
     *out = m;
   });
 }

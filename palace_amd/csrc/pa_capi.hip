@@ -50,6 +50,24 @@ void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t
   out.slots = 2 + nattr + out.mat.size();
   out.d_attr_mat = nattr ? dev_upload(out.attr_mat.data(), (size_t)nattr) : nullptr;
   out.d_mat = dev_upload(out.mat.data(), out.mat.size());
+  // transposed copy for A^T (only when it differs)
+  std::vector<double> mt(out.mat);
+  bool sym = true;
+  for (int k = 0; k < nmat; k++)
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) {
+        mt[(size_t)k * dim * dim + i + dim * j] = out.mat[(size_t)k * dim * dim + j + dim * i];
+        sym = sym && out.mat[(size_t)k * dim * dim + i + dim * j] == out.mat[(size_t)k * dim * dim + j + dim * i];
+      }
+  out.d_mat_t = sym ? nullptr : dev_upload(mt.data(), mt.size());
+}
+
+static thread_local bool g_transpose = false;
+TransposeScope::TransposeScope(bool on) : prev_(g_transpose) { g_transpose = on; }
+TransposeScope::~TransposeScope() { g_transpose = prev_; }
+bool TransposeScope::active() { return g_transpose; }
+CoeffDev CoeffHost::dev() const {
+  return CoeffDev{d_attr_mat, (g_transpose && d_mat_t) ? d_mat_t : d_mat, (int)attr_mat.size()};
 }
 
 static int expected_P(int fe_type, int p) {
@@ -339,8 +357,8 @@ static void free_sub(SubOp *so) {
     delete so->qd;
   }
   hipFree(so->d_tab);
-  hipFree(so->c0.d_attr_mat), hipFree(so->c0.d_mat);
-  hipFree(so->c1.d_attr_mat), hipFree(so->c1.d_mat);
+  hipFree(so->c0.d_attr_mat), hipFree(so->c0.d_mat), hipFree(so->c0.d_mat_t);
+  hipFree(so->c1.d_attr_mat), hipFree(so->c1.d_mat), hipFree(so->c1.d_mat_t);
   pa_geom_destroy(static_cast<pa_geom *>(so->geom));
   delete so;
 }
@@ -428,6 +446,14 @@ static bool apply2(pa_op *op, const double *x0, const double *x1, double *y0, do
 void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s) { apply(op, x, y, true, s); }
 
 }  // namespace pa
+
+bool pa_op::symmetric() const {
+  for (const pa::SubOp *so : subs)
+    if (!so->c0.symmetric() || !so->c1.symmetric()) return false;
+  for (const pa::DenseSub *ds : dsubs)
+    if (!ds->c0.symmetric() || !ds->c1.symmetric()) return false;
+  return true;
+}
 
 using namespace pa;
 
@@ -740,9 +766,46 @@ int pa_op_mult(pa_op *op, const double *x, double *y, void *stream) {
   });
 }
 
+/* A^T: same trial and test evaluation, so A^T = E^T B^T D(C^T) B E -- the forward kernels with every coefficient matrix
+ * transposed (the reference builds a second libCEED operator with trial and test swapped, fem/libceed/operator.cpp:
+ * 199-240; for symmetric coefficients this is the forward apply, like its SymmetricOperator wrapper). */
+int pa_op_mult_transpose(pa_op *op, const double *x, double *y, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && op->height == op->width, "transpose apply needs a square operator");
+    TransposeScope t(!op->symmetric());
+    apply(op, x, y, true, (hipStream_t)stream);
+  });
+}
+
+int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && op->height == op->width, "transpose apply needs a square operator");
+    TransposeScope t(!op->symmetric());
+    apply(op, x, y, false, (hipStream_t)stream);
+  });
+}
+
+int pa_op_is_symmetric(const pa_op *op) { return (op && op->symmetric()) ? 1 : 0; }
+
+/* 0: no essential list set on this operator, 1: this list is set, -1: a different one is */
+int pa_op_essential_state(const pa_op *op, const int32_t *ess, int32_t n) {
+  if (!op || !op->has_essential) return 0;
+  std::vector<int32_t> v(ess, ess + (ess ? n : 0));
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+  return v == op->ess_sorted ? 1 : -1;
+}
+
 int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
   return guarded([&] {
     PA_REQUIRE(op && (ess || n == 0), "null argument");
+    // the flagged index tables live in the operator: a second wrapper with another list must not overwrite them under
+    // the first one's feet (it takes the unfused path instead, linalg.hip ParOperator)
+    PA_REQUIRE(pa_op_essential_state(op, ess, n) >= 0,
+               "a different essential dof list is already fused into this operator (pa_op_essential_state)");
+    op->ess_sorted.assign(ess, ess + n);
+    std::sort(op->ess_sorted.begin(), op->ess_sorted.end());
+    op->ess_sorted.erase(std::unique(op->ess_sorted.begin(), op->ess_sorted.end()), op->ess_sorted.end());
     std::vector<char> flag((size_t)op->width, 0);
     for (int i = 0; i < n; i++) {
       PA_REQUIRE(ess[i] >= 0 && ess[i] < op->width, "essential dof out of range");

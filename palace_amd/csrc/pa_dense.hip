@@ -1195,8 +1195,8 @@ void free_dense_sub(DenseSub *ds) {
   hipFree(ds->d_L), hipFree(ds->d_qdata);
   hipFree(ds->d_off), hipFree(ds->d_cor), hipFree(ds->d_ori);
   hipFree(ds->d_ye), hipFree(ds->d_tptr), hipFree(ds->d_tent);
-  hipFree(ds->c0.d_attr_mat), hipFree(ds->c0.d_mat);
-  hipFree(ds->c1.d_attr_mat), hipFree(ds->c1.d_mat);
+  hipFree(ds->c0.d_attr_mat), hipFree(ds->c0.d_mat), hipFree(ds->c0.d_mat_t);
+  hipFree(ds->c1.d_attr_mat), hipFree(ds->c1.d_mat), hipFree(ds->c1.d_mat_t);
   pa_geom_destroy(static_cast<pa_geom *>(ds->geom));
   delete ds;
 }

@@ -17,6 +17,7 @@ typedef struct pa_op pa_op_fwd;
 
 // CSR of a fully assembled local operator (pa_op_full_assemble), device arrays
 struct pa_csr {
+  bool symmetric = true;  // assembled from a symmetric operator (CsrOperator::MultTranspose relies on it)
   int32_t nrows = 0;
   int64_t nnz = 0;
   int32_t *d_rowptr = nullptr, *d_col = nullptr;
@@ -112,7 +113,21 @@ struct CoeffHost {
   size_t slots = 0;  // number of 8-byte slots this context occupied in the blob
   int32_t *d_attr_mat = nullptr;
   double *d_mat = nullptr;
-  CoeffDev dev() const { return CoeffDev{d_attr_mat, d_mat, (int)attr_mat.size()}; }
+  double *d_mat_t = nullptr;  // every matrix transposed; only when some matrix is not symmetric
+  bool symmetric() const { return d_mat_t == nullptr; }
+  // the device view the kernels read; inside a TransposeScope (pa_op_mult_transpose: A^T = B^T D(C^T) B for the
+  // same trial / test evaluation) the transposed matrices
+  CoeffDev dev() const;
+};
+
+// RAII switch for the launches of one transposed apply (host side, per thread)
+struct TransposeScope {
+  TransposeScope(bool on);
+  ~TransposeScope();
+  static bool active();
+
+private:
+  bool prev_;
 };
 
 // Packed symmetric pointwise operators (pre-assembled D): double[ne][ncomp][Q], the six upper
@@ -254,6 +269,8 @@ struct pa_op {
   int height = 0, width = 0;
   bool finalized = false;
   bool has_essential = false;
+  std::vector<int32_t> ess_sorted;  // the list fused into the index tables (pa_op_set_essential)
+  bool symmetric() const;  // every coefficient matrix of every sub-operator is symmetric => A^T = A
   std::vector<pa::SubOp *> subs;
   std::vector<pa::DenseSub *> dsubs;
 };

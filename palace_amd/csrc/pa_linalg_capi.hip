@@ -44,10 +44,18 @@ struct pa_solver {
   }
 };
 
+struct pa_complex_par_op {
+  pa_context *ctx;
+  std::unique_ptr<ceed::Operator> local_r, local_i;
+  std::unique_ptr<ComplexParOperator> op;
+};
+
 struct pa_csolver {
   pa_context *ctx;
-  std::unique_ptr<ComplexWrapperOperator> A;
+  std::unique_ptr<ComplexWrapperOperator> A;  // owned wrapper (created from two real ParOperators), or
+  const ComplexOperator *Aext = nullptr;      // a ComplexParOperator owned elsewhere
   std::unique_ptr<ComplexGmresSolver> solver;
+  int Height() const { return A ? A->Height() : Aext->Height(); }
 };
 
 using pa::guarded;
@@ -250,6 +258,55 @@ int pa_chebyshev_create(pa_context *ctx, pa_par_op *A, int smooth_it, int order,
     *S = s;
   });
 }
+/* ChebyshevSmoother1stKind (linalg/chebyshev.cpp:222-293); sf_min <= 0 takes the optimised estimate (:244-247) */
+int pa_chebyshev_create_1st_kind(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max, double sf_min,
+                                 pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(order > 0, "Polynomial order for Chebyshev smoothing must be positive!");
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    auto cheb = std::make_unique<ChebyshevSmoother>(ctx->ctx, smooth_it, order, sf_max, false, sf_min);
+    cheb->SetOperator(*A->op);
+    s->solver = std::move(cheb);
+    *S = s;
+  });
+}
+/* DistRelaxationSmoother (linalg/distrelaxation.cpp:14-151) on its own: A the Nedelec ParOperator, A_aux the auxiliary
+ * H1 ParOperator, G the discrete gradient */
+int pa_dist_relaxation_create(pa_context *ctx, pa_par_op *A, pa_par_op *A_aux, pa_interp *G, int smooth_it,
+                              int cheby_smooth_it, int cheby_order, double sf_max, double sf_min, int fourth_kind,
+                              pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && A && A_aux && G && S, "null argument");
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    auto d = std::make_unique<DistRelaxationSmoother>(ctx->ctx, *G->op, smooth_it, cheby_smooth_it, cheby_order, sf_max,
+                                                      sf_min, fourth_kind != 0);
+    d->SetOperators(*A->op, *A_aux->op);
+    s->solver = std::move(d);
+    *S = s;
+  });
+}
+int pa_dist_relaxation_lambda_max(const pa_solver *S, double *lambda_max, double *lambda_max_aux) {
+  return guarded([&] {
+    auto *d = dynamic_cast<const DistRelaxationSmoother *>(S ? S->solver.get() : nullptr);
+    PA_REQUIRE(d && lambda_max && lambda_max_aux, "not a distributive relaxation smoother");
+    *lambda_max = d->Primary().LambdaMax(), *lambda_max_aux = d->Auxiliary().LambdaMax();
+  });
+}
+/* Solver::Mult2 / MultTranspose2 (the entry points of the V-cycle, gmg.cpp:184,204): y <- y + B (x - A y) */
+int pa_solver_mult2(pa_solver *S, const double *x, double *y, int transpose, int initial_guess) {
+  return guarded([&] {
+    PA_REQUIRE(S && x && y, "null argument");
+    const int n = S->solver->Height();
+    Vector vx(const_cast<double *>(x), n), vy(y, n), r(n);
+    S->solver->SetInitialGuess(initial_guess != 0);
+    if (transpose)
+      S->solver->MultTranspose2(vx, vy, r);
+    else
+      S->solver->Mult2(vx, vy, r);
+  });
+}
 int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max) {
   return guarded([&] {
     auto *c = dynamic_cast<const ChebyshevSmoother *>(S->solver.get());
@@ -449,7 +506,7 @@ int pa_complex_gmres_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_so
 }
 int pa_csolver_mult(pa_csolver *S, const double *br, const double *bi, double *xr, double *xi, int initial_guess) {
   return guarded([&] {
-    const int n = S->A->Height();
+    const int n = S->Height();
     ComplexVector b(const_cast<double *>(br), const_cast<double *>(bi), n), x(xr, xi, n);
     S->solver->Mult(b, x, initial_guess != 0);
   });
@@ -463,6 +520,112 @@ int pa_csolver_stats(const pa_csolver *S, int *its, double *initial_res, double 
   });
 }
 void pa_csolver_destroy(pa_csolver *S) { delete S; }
+
+/* ---- ComplexParOperator (linalg/rap.cpp:393-749) over two local operators ---------------------------------------- */
+int pa_complex_par_op_create(pa_context *ctx, pa_op *Ar, pa_op *Ai, int n_true, pa_halo *halo, pa_complex_par_op **A) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && (Ar || Ai) && A, "null argument");
+    auto *p = new pa_complex_par_op;
+    p->ctx = ctx;
+    if (Ar) p->local_r = std::make_unique<ceed::Operator>(ctx->ctx, Ar, false);
+    if (Ai) p->local_i = std::make_unique<ceed::Operator>(ctx->ctx, Ai, false);
+    p->op = std::make_unique<ComplexParOperator>(ctx->ctx, p->local_r.get(), p->local_i.get(), n_true,
+                                                 halo ? halo->halo.get() : nullptr);
+    *A = p;
+  });
+}
+int pa_complex_par_op_set_essential(pa_complex_par_op *A, const int32_t *ess, int n_ess, int policy) {
+  return guarded([&] {
+    PA_REQUIRE(A && (ess || n_ess == 0), "null argument");
+    A->op->SetEssentialTrueDofs(ess, n_ess, policy == PA_DIAG_ONE ? ParOperator::DiagonalPolicy::DIAG_ONE
+                                                                  : ParOperator::DiagonalPolicy::DIAG_ZERO);
+  });
+}
+/* mode 0: y = A x, 1: y = A^T x, 2: y = A^H x; add != 0: y += (a_re + i a_im) op(A) x */
+int pa_complex_par_op_mult(pa_complex_par_op *A, int mode, int add, double a_re, double a_im, const double *xr,
+                           const double *xi, double *yr, double *yi) {
+  return guarded([&] {
+    PA_REQUIRE(A && xr && xi && yr && yi && mode >= 0 && mode <= 2, "bad argument");
+    const int n = A->op->Height();
+    ComplexVector x(const_cast<double *>(xr), const_cast<double *>(xi), n), y(yr, yi, n);
+    const std::complex<double> a(a_re, a_im);
+    if (!add) {
+      if (mode == 0) A->op->Mult(x, y);
+      if (mode == 1) A->op->MultTranspose(x, y);
+      if (mode == 2) A->op->MultHermitianTranspose(x, y);
+    } else {
+      if (mode == 0) A->op->AddMult(x, y, a);
+      if (mode == 1) A->op->AddMultTranspose(x, y, a);
+      if (mode == 2) A->op->AddMultHermitianTranspose(x, y, a);
+    }
+  });
+}
+/* The same three forms of the LOCAL ComplexWrapperOperator (linalg/operator.cpp:58-413) on L-vectors. */
+int pa_complex_par_op_local_mult(pa_complex_par_op *A, int mode, int add, double a_re, double a_im, const double *xr,
+                                 const double *xi, double *yr, double *yi) {
+  return guarded([&] {
+    PA_REQUIRE(A && xr && xi && yr && yi && mode >= 0 && mode <= 2, "bad argument");
+    const ComplexOperator &L = A->op->LocalOperator();
+    const int n = L.Height();
+    ComplexVector x(const_cast<double *>(xr), const_cast<double *>(xi), n), y(yr, yi, n);
+    const std::complex<double> a(a_re, a_im);
+    if (!add) {
+      if (mode == 0) L.Mult(x, y);
+      if (mode == 1) L.MultTranspose(x, y);
+      if (mode == 2) L.MultHermitianTranspose(x, y);
+    } else {
+      if (mode == 0) L.AddMult(x, y, a);
+      if (mode == 1) L.AddMultTranspose(x, y, a);
+      if (mode == 2) L.AddMultHermitianTranspose(x, y, a);
+    }
+  });
+}
+int pa_complex_par_op_assemble_diagonal(pa_complex_par_op *A, double *dr, double *di) {
+  return guarded([&] {
+    PA_REQUIRE(A && dr && di, "null argument");
+    ComplexVector d(dr, di, A->op->Height());
+    A->op->AssembleDiagonal(d);
+  });
+}
+void pa_complex_par_op_destroy(pa_complex_par_op *A) { delete A; }
+
+/* GmresSolver / FgmresSolver <ComplexOperator> on a ComplexParOperator: flexible != 0 is FGMRES, pc_side 0 left /
+ * 1 right (iterative.hpp:187-272), orthog 0 MGS / 1 CGS / 2 CGS2. */
+int pa_complex_gmres_create_par(pa_context *ctx, pa_complex_par_op *A, pa_solver *precond, double rel_tol, double abs_tol,
+                                int max_it, int restart, int flexible, int pc_side, int orthog, int print, pa_csolver **S) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && A && S && orthog >= 0 && orthog <= 2, "bad argument");
+    auto *s = new pa_csolver;
+    s->ctx = ctx;
+    s->Aext = A->op.get();
+    s->solver = std::make_unique<ComplexGmresSolver>(ctx->ctx, print, flexible != 0);
+    s->solver->SetOperator(*s->Aext);
+    if (precond) s->solver->SetPreconditioner(*precond->solver);
+    s->solver->SetTol(rel_tol), s->solver->SetAbsTol(abs_tol), s->solver->SetMaxIter(max_it);
+    s->solver->SetRestartDim(restart);
+    s->solver->SetOrthogonalization(static_cast<Orthogonalization>(orthog));
+    if (!flexible) s->solver->SetPreconditionerSide(pc_side ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT);
+    *S = s;
+  });
+}
+
+/* GmresSolver::SetPreconditionerSide (iterative.hpp:214): 0 left (default), 1 right */
+int pa_gmres_set_pc_side(pa_solver *S, int side) {
+  return guarded([&] {
+    auto *g = dynamic_cast<GmresSolver *>(S ? S->solver.get() : nullptr);
+    PA_REQUIRE(g, "not a GMRES solver");
+    g->SetPreconditionerSide(side ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT);
+  });
+}
+
+/* ParOperator::MultTranspose (rap.cpp:236-275) */
+int pa_par_op_mult_transpose(pa_par_op *A, const double *x, double *y) {
+  return guarded([&] {
+    PA_REQUIRE(A && x && y, "null argument");
+    Vector vx(const_cast<double *>(x), A->op->Width()), vy(y, A->op->Height());
+    A->op->MultTranspose(vx, vy);
+  });
+}
 
 int pa_interp_create(pa_context *ctx, const pa_restriction_desc *rc, const pa_basis_desc *bc,
                      const pa_restriction_desc *rf, const pa_basis_desc *bf, const double *Ic, const double *Io,

@@ -187,6 +187,11 @@ class ParOperator:
         _lib.check(_L().pa_par_op_assemble_diagonal(self.handle, C.c_void_p(d.data_ptr())))
         return d
 
+    def mult_transpose(self, x, y):
+        """ParOperator::MultTranspose (rap.cpp:236-275)."""
+        _lib.check(_L().pa_par_op_mult_transpose(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+        return y
+
     def __del__(self):
         try:
             _L().pa_par_op_destroy(self.handle)
@@ -239,6 +244,17 @@ class Solver:
         _lib.check(_L().pa_solver_stats(self.handle, C.byref(its), C.byref(r0), C.byref(r1), C.byref(conv)))
         return dict(iterations=its.value, initial_res=r0.value, final_res=r1.value, converged=bool(conv.value))
 
+    def mult2(self, x, y, transpose=False, initial_guess=False):
+        """Solver::Mult2 / MultTranspose2: y <- y + B (x - A y)."""
+        _lib.check(_L().pa_solver_mult2(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), int(transpose),
+                                        int(initial_guess)))
+        return y
+
+    def dist_relaxation_lambda_max(self):
+        a, b = C.c_double(), C.c_double()
+        _lib.check(_L().pa_dist_relaxation_lambda_max(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def lambda_max(self):
         v = C.c_double()
         _lib.check(_L().pa_chebyshev_lambda_max(self.handle, C.byref(v)))
@@ -252,10 +268,29 @@ class Solver:
             pass
 
 
-def chebyshev(ctx, A: ParOperator, order, smooth_it=1, sf_max=1.0, fourth_kind=True):
+def chebyshev(ctx, A: ParOperator, order, smooth_it=1, sf_max=1.0, fourth_kind=True, sf_min=0.0):
+    """ChebyshevSmoother (4th kind, chebyshev.cpp:160-220) or ChebyshevSmoother1stKind (:222-293)."""
     h = C.c_void_p()
-    _lib.check(_L().pa_chebyshev_create(ctx.handle, A.handle, smooth_it, order, sf_max, int(fourth_kind), C.byref(h)))
+    if fourth_kind:
+        _lib.check(_L().pa_chebyshev_create(ctx.handle, A.handle, smooth_it, order, sf_max, 1, C.byref(h)))
+    else:
+        L = _L()
+        L.pa_chebyshev_create_1st_kind.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                   C.c_void_p]
+        _lib.check(L.pa_chebyshev_create_1st_kind(ctx.handle, A.handle, smooth_it, order, sf_max, sf_min, C.byref(h)))
     return Solver(ctx, h, (A,))
+
+
+def dist_relaxation(ctx, A: ParOperator, A_aux: ParOperator, G, smooth_it=1, cheby_smooth_it=1, cheby_order=4, sf_max=1.0,
+                    sf_min=0.0, fourth_kind=True):
+    """DistRelaxationSmoother (linalg/distrelaxation.cpp:14-151) on its own."""
+    L = _L()
+    L.pa_dist_relaxation_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_double, C.c_double, C.c_int, C.c_void_p]
+    h = C.c_void_p()
+    _lib.check(L.pa_dist_relaxation_create(ctx.handle, A.handle, A_aux.handle, G.handle, smooth_it, cheby_smooth_it,
+                                           cheby_order, sf_max, sf_min, int(fourth_kind), C.byref(h)))
+    return Solver(ctx, h, (A, A_aux, G))
 
 
 def jacobi(ctx, A: ParOperator):
@@ -272,11 +307,14 @@ def cg(ctx, A: ParOperator, precond=None, rel_tol=0.0, abs_tol=0.0, max_it=100, 
 
 
 def gmres(ctx, A: ParOperator, precond=None, rel_tol=0.0, abs_tol=0.0, max_it=100, restart=-1, flexible=False,
-          print_level=0, orthogonalization="MGS"):
+          print_level=0, orthogonalization="MGS", pc_side="left"):
+    """GmresSolver (iterative.cpp:543-705; pc_side 'left' | 'right') / FgmresSolver (flexible=True, :733-871)."""
     h = C.c_void_p()
     _lib.check(_L().pa_gmres_create(ctx.handle, A.handle, precond.handle if precond else None, rel_tol, abs_tol,
                                     max_it, restart, int(flexible), print_level, C.byref(h)))
     _lib.check(_L().pa_gmres_set_orthogonalization(h, {"MGS": 0, "CGS": 1, "CGS2": 2}[orthogonalization]))
+    if not flexible:
+        _lib.check(_L().pa_gmres_set_pc_side(h, {"left": 0, "right": 1}[pc_side]))
     return Solver(ctx, h, (A, precond))
 
 
@@ -451,3 +489,65 @@ class ComplexGmres:
             _L().pa_csolver_destroy(self.handle)
         except Exception:
             pass
+
+
+class ComplexParOperator:
+    """palace::ComplexParOperator (linalg/rap.cpp:393-749) over two local ceed operators (either may be None)."""
+
+    def __init__(self, ctx, local_r, local_i, ess_tdofs=(), diag_policy=DIAG_ONE, n_true=None, halo=None):
+        L = _L()
+        L.pa_complex_par_op_destroy.restype = None
+        L.pa_complex_par_op_destroy.argtypes = [C.c_void_p]
+        L.pa_complex_par_op_mult.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 4
+        L.pa_complex_par_op_local_mult.argtypes = L.pa_complex_par_op_mult.argtypes
+        self.ctx, self._keep = ctx, (local_r, local_i, halo)
+        any_op = local_r if local_r is not None else local_i
+        self.n = any_op.height if n_true is None else n_true
+        self.handle = C.c_void_p()
+        _lib.check(L.pa_complex_par_op_create(ctx.handle, local_r.handle if local_r else None,
+                                              local_i.handle if local_i else None, self.n,
+                                              halo.handle if halo else None, C.byref(self.handle)))
+        ess = np.ascontiguousarray(ess_tdofs, dtype=np.int32)
+        if ess.size:
+            _lib.check(L.pa_complex_par_op_set_essential(self.handle, _ptr(ess), ess.size, diag_policy))
+
+    _MODES = {"N": 0, "T": 1, "H": 2}
+
+    def mult(self, xr, xi, yr, yi, mode="N", a=None, local=False):
+        """y = op(A) x (a is None) or y += a op(A) x; mode 'N' | 'T' | 'H'; local=True applies the L-vector
+        ComplexWrapperOperator instead."""
+        fn = _L().pa_complex_par_op_local_mult if local else _L().pa_complex_par_op_mult
+        av = complex(a) if a is not None else 0j
+        _lib.check(fn(self.handle, self._MODES[mode], int(a is not None), av.real, av.imag, C.c_void_p(xr.data_ptr()),
+                      C.c_void_p(xi.data_ptr()), C.c_void_p(yr.data_ptr()), C.c_void_p(yi.data_ptr())))
+        return yr, yi
+
+    def assemble_diagonal(self, dr, di):
+        _lib.check(_L().pa_complex_par_op_assemble_diagonal(self.handle, C.c_void_p(dr.data_ptr()),
+                                                            C.c_void_p(di.data_ptr())))
+        return dr, di
+
+    def __del__(self):
+        try:
+            _L().pa_complex_par_op_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class ComplexParGmres(ComplexGmres):
+    """GmresSolver / FgmresSolver <ComplexOperator> (linalg/iterative.cpp:543-871) on a ComplexParOperator."""
+
+    def __init__(self, ctx, A: ComplexParOperator, precond=None, rel_tol=1e-8, abs_tol=0.0, max_it=200, restart=-1,
+                 flexible=False, pc_side="left", orthogonalization="MGS", print_level=0):
+        L = _L()
+        L.pa_complex_gmres_create_par.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.pa_csolver_destroy.restype = None
+        L.pa_csolver_destroy.argtypes = [C.c_void_p]
+        self.ctx, self._keep = ctx, (A, precond)
+        self.handle = C.c_void_p()
+        _lib.check(L.pa_complex_gmres_create_par(ctx.handle, A.handle, precond.handle if precond else None, rel_tol,
+                                                 abs_tol, max_it, restart, int(flexible),
+                                                 {"left": 0, "right": 1}[pc_side],
+                                                 {"MGS": 0, "CGS": 1, "CGS2": 2}[orthogonalization], print_level,
+                                                 C.byref(self.handle)))

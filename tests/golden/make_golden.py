@@ -193,7 +193,21 @@ def spheres_fixture():
     print("wrote spheres_mesh.npz", en_std.shape, int(neg.sum()), "re-oriented")
 
 
+def cpw_fixture():
+    """The reference's examples/cpw/mesh/cpw_lumped_0.msh (binary Gmsh 2.2: 14 628 tet4, boundary tri3 with the port /
+    trace / far-field attributes) as arrays: vertices, positively oriented tetrahedra, volume attributes (1 air, 2 si,
+    3 metal), boundary triangles and their attributes."""
+    from palace_amd.fem import tet
+
+    m = tet.read_gmsh22_tets("/root/reference/examples/cpw/mesh/cpw_lumped_0.msh")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "cpw_mesh.npz"), verts=m.verts, tets=m.tets.astype(np.int32),
+                        attr=m.attr.astype(np.int32), bdr_tris=np.asarray(m.bdr_tris, dtype=np.int32),
+                        bdr_attr=np.asarray(m.bdr_attr, dtype=np.int32))
+    print("wrote cpw_mesh.npz", m.tets.shape, m.verts.shape, np.unique(m.attr), np.unique(m.bdr_attr))
+
+
 if __name__ == "__main__":
     mesh_fixture()
     fixtures_2d()
     spheres_fixture()
+    cpw_fixture()

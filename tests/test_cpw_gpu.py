@@ -1,0 +1,114 @@
+"""Config 3 on the reference's own mesh: examples/cpw/mesh/cpw_lumped_0.msh (14 628 tet4, silicon substrate + air, the
+trace as an internal PEC surface), order-3 Nedelec tetrahedra with the curl-oriented restriction, the driven-type complex
+system A = K - k0^2 eps_r (1 - i tan d) M at 16 GHz solved on the device by FGMRES with the Hiptmair p-multigrid
+(levels p = 1, 2, 3) built on the shifted real matrix K + k0^2 eps_r M -- the reference's configuration for driven
+problems (models/spaceoperator.cpp:316-331, linalg/ksp.cpp).  The device solution is checked with the ORACLE's operators
+(dense tables, native curl-oriented restriction, reference QFunction arithmetic): ||A_oracle x - b|| <= 1e-6 ||b||, and
+the device and oracle applies of both operator parts agree to 1e-12."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_cpw_complex_fgmres_against_oracle_operator():
+    from oracle import palace_oracle as po
+    from palace_amd import ceed, linalg
+    from palace_amd.fem import tet
+    from palace_amd.fem.tetproblem import TetProblem
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cpw_mesh.npz"))
+    mesh = tet.TetMesh(d["verts"], d["tets"], d["attr"], bdr_tris=d["bdr_tris"], bdr_attr=d["bdr_attr"])
+    p = 3
+    ctx = linalg.Context()
+    prob = TetProblem(ctx, mesh, p)  # spaces p = 1..3, geometry data with the order-2p rule of the fine level
+    # PEC: far field (4) and the metal trace (13, an internal surface); the port faces stay natural
+    bt = np.sort(np.asarray(d["bdr_tris"], dtype=np.int64), axis=1)
+    fkey = {tuple(f): i for i, f in enumerate(map(tuple, mesh.face_verts))}
+    fmask = np.zeros(mesh.face_verts.shape[0], dtype=bool)
+    fmask[[fkey[tuple(f)] for f in bt[np.isin(d["bdr_attr"], (4, 13))]]] = True
+    ess = [s.ess_dofs(fmask) for s in prob.spaces]
+    nd, n = prob.spaces[-1], prob.spaces[-1].ndofs
+    k0 = 2 * np.pi * 16.0e9 * 1.0e-6 / 299792458.0  # 16 GHz, mesh in micrometres (cpw_lumped_uniform.json: L0 = 1e-6)
+    eps, tand = np.array([1.0, 11.7]), np.array([0.0, 0.05])  # attributes 1 air, 2 si (lossy for the test)
+
+    def coef(vals):
+        return ceed.coefficient_context(3, attr_mat=[0, 1], mat_coeff=[np.array([vals[0]]), np.array([vals[1]])])
+
+    ident = ceed.coefficient_context(3)
+    blocks = [prob.nd_block(s) for s in prob.spaces]
+
+    def nd_op(block, qf, blob, ops):
+        return ceed.Operator(block.lsize, block.lsize).add_dense_integrator(prob.geom, block, qf, blob, ops).finalize()
+
+    Kr = nd_op(blocks[-1], ceed.QF_HDIVMASS_33, np.concatenate([coef(-k0 ** 2 * eps), ident]), ceed.EVAL_CURL | ceed.EVAL_INTERP)
+    Ki = nd_op(blocks[-1], ceed.QF_HCURL_33, coef(k0 ** 2 * eps * tand), ceed.EVAL_INTERP)
+    A = linalg.ComplexParOperator(ctx, Kr, Ki, ess[-1], linalg.DIAG_ONE)
+
+    # the oracle's view of the same two operators
+    pts, wts = prob.pts, prob.wts
+    interp, curl = nd.elem.tables(pts)
+    J = mesh.jacobians(pts)
+    og = po.build_geom_factor_33(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 9))
+    okw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+
+    def ocoef(vals):
+        return po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([vals[0]]), np.array([vals[1]])])
+
+    oKr = po.CeedOperatorOracle(n, nd.offsets, None, interp, curl, og, po.QF_HDIVMASS, ocoef(-k0 ** 2 * eps), po.CoeffCtx(), **okw)
+    oKi = po.CeedOperatorOracle(n, nd.offsets, None, interp, curl, og, po.QF_HCURL, ocoef(k0 ** 2 * eps * tand), **okw)
+    e = ess[-1]
+
+    def oA(v):  # ComplexParOperator::Mult on the oracle (rap.cpp:483-519)
+        t = v.copy()
+        t[e] = 0.0
+        yr = oKr.apply_add(t.real, np.zeros(n)) - oKi.apply_add(t.imag, np.zeros(n))
+        yi = oKi.apply_add(t.real, np.zeros(n)) + oKr.apply_add(t.imag, np.zeros(n))
+        y = yr + 1j * yi
+        y[e] = v[e]
+        return y
+
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    yr, yi = A.mult(_dev(x.real), _dev(x.imag), torch.empty(n, dtype=torch.float64, device="cuda"),
+                    torch.empty(n, dtype=torch.float64, device="cuda"))
+    y = yr.cpu().numpy() + 1j * yi.cpu().numpy()
+    ref = oA(x)
+    assert np.linalg.norm(y - ref) < 1e-12 * np.linalg.norm(ref)
+
+    # preconditioner: Hiptmair p-multigrid on the shifted SPD matrix K + k0^2 eps M (real), applied to both parts
+    shift = np.concatenate([coef(k0 ** 2 * eps), ident])
+    pfine = nd_op(blocks[-1], ceed.QF_HDIVMASS_33, shift, ceed.EVAL_CURL | ceed.EVAL_INTERP)
+    ploc = [pfine.coarsen_dense(b) for b in blocks[:-1]] + [pfine]
+    Pm = [linalg.ParOperator(ctx, o, es, linalg.DIAG_ONE) for o, es in zip(ploc, ess)]
+    h1s = [tet.H1TetSpace(mesh, q) for q in prob.orders]
+    hb = [prob.h1_block(s) for s in h1s]
+    hfine = ceed.Operator(h1s[-1].ndofs, h1s[-1].ndofs).add_dense_integrator(prob.geom, hb[-1], ceed.QF_HCURL_33,
+                                                                            coef(k0 ** 2 * eps), ceed.EVAL_GRAD).finalize()
+    hloc = [hfine.coarsen_dense(b) for b in hb[:-1]] + [hfine]
+    Ph = [linalg.ParOperator(ctx, o, s.ess_dofs(fmask), linalg.DIAG_ONE) for o, s in zip(hloc, h1s)]
+    G = [linalg.DenseInterp(ctx, h.restriction(), s.restriction(interp_range=True), tet.tet_gradient_matrix(q))
+         for h, s, q in zip(h1s, prob.spaces, prob.orders)]
+    P = [linalg.DenseInterp(ctx, prob.spaces[l].restriction(), prob.spaces[l + 1].restriction(interp_range=True),
+                            tet.nd_tet_transfer_matrix(prob.orders[l], prob.orders[l + 1])) for l in range(len(Pm) - 1)]
+    coarse = linalg.cg(ctx, Pm[0], linalg.jacobi(ctx, Pm[0]), rel_tol=1e-3, max_it=200)
+    B = linalg.gmg(ctx, Pm, P, coarse, cheby_order=4, A_aux=Ph, G=G)
+
+    b = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    b[e] = 0.0
+    S = linalg.ComplexParGmres(ctx, A, B, rel_tol=1e-8, max_it=400, restart=100, flexible=True)
+    xr, xi = S.mult(_dev(b.real), _dev(b.imag), torch.zeros(n, dtype=torch.float64, device="cuda"),
+                    torch.zeros(n, dtype=torch.float64, device="cuda"))
+    st = S.stats()
+    assert st["converged"], st
+    xs = xr.cpu().numpy() + 1j * xi.cpu().numpy()
+    res = np.linalg.norm(oA(xs) - b) / np.linalg.norm(b)
+    assert res < 1e-6, (res, st)
+    print(f"cpw p=3: {n} complex dofs, FGMRES + Hiptmair p-MG: {st['iterations']} iterations, oracle residual {res:.2e}")

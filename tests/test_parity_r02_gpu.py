@@ -1,0 +1,311 @@
+"""Parity of pieces that had code but no oracle comparison: the first-kind Chebyshev smoother, the Hiptmair
+distributive-relaxation smoother (both entry points of the V-cycle), right-preconditioned GMRES and FGMRES (real and
+complex), the transposed operator applies and the complex parallel operator layer.
+
+References: linalg/chebyshev.cpp:222-293, linalg/distrelaxation.cpp:98-151, linalg/iterative.cpp:543-871,
+fem/libceed/operator.cpp:199-240, linalg/rap.cpp:236-275 and :393-749, linalg/operator.cpp:58-413.  There are no unit
+tests for these classes in the reference; the oracle restates them (oracle/palace_oracle.py) and the device code has to
+agree with it: smoother outputs to 1e-10 (tens of operator applies), Krylov iterates to 1e-7 with iteration counts +-1,
+operator-level quantities to 1e-12."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import palace_oracle as po  # noqa: E402
+from palace_amd import ceed, linalg  # noqa: E402
+from palace_amd.fem.fespace import H1HexSpace, NDHexSpace  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _new(n):
+    return torch.zeros(n, dtype=torch.float64, device="cuda")
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+class Setup:
+    """K + eps M on order-p Nedelec hexahedra of the reference's cylinder mesh and the auxiliary H1 diffusion operator
+    with the same eps, device and oracle side by side."""
+
+    def __init__(self, mesh, p):
+        self.mesh, self.p = mesh, p
+        self.q1d = q1d = p + 1
+        self.ctx = linalg.Context()
+        self.geom = ceed.GeomFactorData(mesh, q1d)
+        self.ogeom = util.oracle_geom(mesh, q1d)
+        self.cm, self.bm = util.make_ctx("scalar")
+        self.cc, self.bc = util.make_ctx("identity")
+        self.nd, self.h1 = NDHexSpace(mesh, p), H1HexSpace(mesh, p)
+        self.local = ceed.curlcurlmass_operator(self.geom, self.nd, self.bm, self.bc)
+        self.A = linalg.ParOperator(self.ctx, self.local, self.nd.ess_dofs(), linalg.DIAG_ONE)
+        self.oA = util.FastParOperatorOracle(self.nd, self.ogeom, "hdivmass", np.concatenate([self.bm, self.bc]),
+                                             self.nd.ess_dofs(), q1d, self.cm, self.cc)
+        self.local_G = ceed.diffusion_operator(self.geom, self.h1, self.bm)
+        self.A_G = linalg.ParOperator(self.ctx, self.local_G, self.h1.ess_dofs(), linalg.DIAG_ONE)
+        interp, grad = po.h1_hex_dense_tables(p, q1d)
+        o_h1 = po.CeedOperatorOracle(self.h1.ndofs, self.h1.elem_dof_lex, None, interp, grad, self.ogeom, po.QF_HCURL, self.cm,
+                                     None, vector_fe=False)
+        self.oA_G = po.ParOperatorOracle([o_h1], self.h1.ess_dofs())
+        self.G = linalg.Gradient(self.ctx, self.h1, self.nd)
+        ones = np.ones(self.h1.elem_dof_lex.shape, dtype=np.int8)
+        self.oG = po.InterpOracle(self.h1.elem_dof_lex, ones, self.nd.elem_dof_lex, self.nd.elem_sign_lex, self.h1.ndofs,
+                                  self.nd.ndofs, po.nd_hex_gradient_lex(p))
+
+
+@pytest.fixture(scope="module")
+def setup2(cylinder_mesh):
+    return Setup(cylinder_mesh, 2)
+
+
+def test_chebyshev_first_kind(setup2):
+    """ChebyshevSmoother1stKind::Mult2 (chebyshev.cpp:259-293), both sf_min settings, with and without an initial guess."""
+    s = setup2
+    n = s.nd.ndofs
+    rng = np.random.default_rng(11)
+    b = rng.uniform(-1, 1, n)
+    b[s.nd.ess_dofs()] = 0.0
+    y0 = rng.uniform(-1, 1, n)
+    y0[s.nd.ess_dofs()] = 0.0
+    for sf_min in (0.0, 0.1):
+        S = linalg.chebyshev(s.ctx, s.A, order=5, fourth_kind=False, sf_min=sf_min)
+        o = po.ChebyshevOracle(s.oA, 5, lambda_max=S.lambda_max(), first_kind=True, sf_min=sf_min)
+        y = S.mult2(_dev(b), _new(n), initial_guess=False).cpu().numpy()
+        assert _rel(y, o.mult2(b, None, False)) < 1e-10
+        y = S.mult2(_dev(b), _dev(y0.copy()), initial_guess=True).cpu().numpy()
+        assert _rel(y, o.mult2(b, y0.copy(), True)) < 1e-10
+
+
+@pytest.mark.parametrize("fourth_kind", [True, False])
+def test_dist_relaxation_mult2_and_transpose(setup2, fourth_kind):
+    """DistRelaxationSmoother::Mult2 / MultTranspose2 (distrelaxation.cpp:98-151) against the restatement, with the
+    eigenvalue estimates of the device smoothers handed to the oracle (the power iterations start from different random
+    vectors)."""
+    s = setup2
+    n = s.nd.ndofs
+    order = 4
+    S = linalg.dist_relaxation(s.ctx, s.A, s.A_G, s.G, smooth_it=1, cheby_smooth_it=1, cheby_order=order,
+                               fourth_kind=fourth_kind)
+    lam, lam_G = S.dist_relaxation_lambda_max()
+    B = po.ChebyshevOracle(s.oA, order, lambda_max=lam, first_kind=not fourth_kind)
+    B_G = po.ChebyshevOracle(s.oA_G, order, lambda_max=lam_G, first_kind=not fourth_kind)
+    o = po.DistRelaxationOracle(s.oA, s.oA_G, (s.oG.mult, s.oG.mult_transpose), B, B_G, s.h1.ess_dofs())
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-1, 1, n)
+    x[s.nd.ess_dofs()] = 0.0
+    y0 = rng.uniform(-1, 1, n)
+    y0[s.nd.ess_dofs()] = 0.0
+    for transpose, fn in ((False, o.mult2), (True, o.mult_transpose2)):
+        y = S.mult2(_dev(x), _new(n), transpose=transpose, initial_guess=False).cpu().numpy()
+        assert _rel(y, fn(x, None, False)) < 1e-10, (transpose, "zero guess")
+        y = S.mult2(_dev(x), _dev(y0.copy()), transpose=transpose, initial_guess=True).cpu().numpy()
+        assert _rel(y, fn(x, y0.copy(), True)) < 1e-10, (transpose, "initial guess")
+
+
+@pytest.mark.parametrize("kind", ["left", "right", "fgmres", "right_restart", "fgmres_restart", "none"])
+def test_gmres_variants_match_oracle(setup2, kind):
+    """GmresSolver::Mult with left / right preconditioning and FgmresSolver::Mult (iterative.cpp:543-871): solution,
+    iteration count and final residual estimate against the restatement, also across restarts."""
+    s = setup2
+    n = s.nd.ndofs
+    b = s.oA.mult(np.ones(n))
+    b[s.nd.ess_dofs()] = 0.0
+    dinv = 1.0 / s.oA.diagonal()
+    J = None if kind == "none" else linalg.jacobi(s.ctx, s.A)
+    oB = None if kind == "none" else (lambda r: dinv * r)
+    restart = 12 if kind.endswith("restart") else 200
+    flexible = kind.startswith("fgmres")
+    side = "right" if kind.startswith("right") else "left"
+    K = linalg.gmres(s.ctx, s.A, J, rel_tol=1e-9, max_it=400, restart=restart, flexible=flexible, pc_side=side)
+    x = K.mult(_dev(b), _new(n)).cpu().numpy()
+    xo, it, hist, conv = po.gmres(s.oA.mult, b, oB, rel_tol=1e-9, max_it=400, max_dim=restart, pc_side=side,
+                                  flexible=flexible)
+    st = K.stats()
+    assert st["converged"] == conv and abs(st["iterations"] - it) <= 1, (st, it)
+    assert _rel(x, xo) < 1e-7
+    assert abs(st["final_res"] - hist[-1]) <= 1e-4 * hist[0] or st["iterations"] != it
+    assert np.linalg.norm(s.oA.mult(x) - b) < 1e-6 * np.linalg.norm(b)
+
+
+def test_gmres_initial_guess(setup2):
+    """initial_res comes from the (preconditioned) right-hand side when an initial guess is given (iterative.cpp:572-588)."""
+    s = setup2
+    n = s.nd.ndofs
+    b = s.oA.mult(np.ones(n))
+    b[s.nd.ess_dofs()] = 0.0
+    x0 = 0.9 * np.ones(n)
+    x0[s.nd.ess_dofs()] = 0.0
+    dinv = 1.0 / s.oA.diagonal()
+    for side in ("left", "right"):
+        K = linalg.gmres(s.ctx, s.A, linalg.jacobi(s.ctx, s.A), rel_tol=1e-8, max_it=300, restart=300, pc_side=side)
+        x = K.mult(_dev(b), _dev(x0.copy()), initial_guess=True).cpu().numpy()
+        xo, it, hist, conv = po.gmres(s.oA.mult, b, lambda r: dinv * r, rel_tol=1e-8, max_it=300, pc_side=side, x0=x0)
+        st = K.stats()
+        assert st["converged"] and abs(st["iterations"] - it) <= 1
+        ref0 = np.linalg.norm(dinv * b) if side == "left" else np.linalg.norm(b)
+        assert abs(st["initial_res"] - ref0) < 1e-10 * ref0
+        assert _rel(x, xo) < 1e-7
+
+
+# ---- transposes: a non-symmetric coefficient makes A^T differ from A ---------------------------------------------------
+def _nonsym_problem(mesh, p, qf):
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ogeom = util.oracle_geom(mesh, q1d)
+    c, blob = util.make_ctx("nonsym")
+    import copy
+
+    ct = copy.copy(c)  # the same context with every material matrix transposed
+    ct.mat = np.ascontiguousarray(c.mat.reshape(-1, 3, 3).transpose(0, 2, 1)).reshape(c.mat.shape)
+    if qf == "hdiv":
+        op = ceed.curlcurl_operator(geom, nd, blob)
+    else:
+        op = ceed.ndmass_operator(geom, nd, blob)
+    return nd, q1d, ogeom, op, blob, ct.pack()
+
+
+@pytest.mark.parametrize("qf", ["hdiv", "hcurl"])
+def test_operator_mult_transpose_nonsymmetric(cylinder_mesh, qf):
+    """ceed::Operator::MultTranspose (fem/libceed/operator.cpp:214-224) and ParOperator::MultTranspose (rap.cpp:236-275)
+    with a non-symmetric material matrix: equal to the oracle's operator built from the transposed coefficient, different
+    from A x, and adjoint to Mult."""
+    nd, q1d, ogeom, op, blob, blob_t = _nonsym_problem(cylinder_mesh, 2, qf)
+    assert not op.is_symmetric()
+    n = nd.ndofs
+    rng = np.random.default_rng(3)
+    x, z = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    yt = op.mult_transpose(_dev(x), _new(n)).cpu().numpy()
+    ref_t = util.oracle_apply_c(nd, ogeom, qf, blob_t, x, q1d)
+    ref = util.oracle_apply_c(nd, ogeom, qf, blob, x, q1d)
+    assert _rel(yt, ref_t) < 1e-12
+    assert _rel(yt, ref) > 1e-3  # the transpose is not the forward apply here
+    az = op.mult(_dev(z), _new(n)).cpu().numpy()
+    assert abs(x @ az - z @ yt) < 1e-12 * abs(x @ az)
+    # through ParOperator with essential dofs (DIAG_ONE)
+    ctx = linalg.Context()
+    ess = nd.ess_dofs()
+    A = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+    y = A.mult_transpose(_dev(x), _new(n)).cpu().numpy()
+    tx = x.copy()
+    tx[ess] = 0.0
+    r = util.oracle_apply_c(nd, ogeom, qf, blob_t, tx, q1d)
+    r[ess] = x[ess]
+    assert _rel(y, r) < 1e-12
+    # a symmetric operator keeps forwarding its transpose to the (fused) forward path
+    _, bs = util.make_ctx("aniso")
+    geom = ceed.GeomFactorData(cylinder_mesh, q1d)
+    sym = ceed.curlcurl_operator(geom, nd, bs)
+    assert sym.is_symmetric()
+    assert torch.equal(sym.mult_transpose(_dev(x), _new(n)), sym.mult(_dev(x), _new(n)))
+
+
+# ---- complex parallel operator ---------------------------------------------------------------------------------------
+def _dense(nd, ogeom, qf, ctx, q1d):
+    return util.oracle_operator(nd, ogeom, qf, ctx, None, q1d).assemble_sparse().toarray()
+
+
+@pytest.mark.parametrize("policy", ["DIAG_ONE", "DIAG_ZERO"])
+def test_complex_par_operator(cylinder_mesh, policy):
+    """ComplexParOperator (rap.cpp:393-749) over Ar = curl-curl with a non-symmetric coefficient and Ai = mass: Mult,
+    MultTranspose, MultHermitianTranspose and the AddMult forms (real, imaginary and general coefficient) against dense
+    complex arithmetic on the oracle's assembled matrices; the local ComplexWrapperOperator forms (operator.cpp:58-413)
+    on L-vectors; the diagonal."""
+    mesh, p = cylinder_mesh, 1
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ogeom = util.oracle_geom(mesh, q1d)
+    c_r, b_r = util.make_ctx("nonsym")
+    c_i, b_i = util.make_ctx("scalar")
+    Kr = ceed.curlcurl_operator(geom, nd, b_r)
+    Mi = ceed.ndmass_operator(geom, nd, b_i)
+    Ar = _dense(nd, ogeom, "hdiv", c_r, q1d)
+    Ai = _dense(nd, ogeom, "hcurl", c_i, q1d)
+    Aloc = Ar + 1j * Ai
+    n = nd.ndofs
+    ess = nd.ess_dofs()
+    pol = linalg.DIAG_ONE if policy == "DIAG_ONE" else linalg.DIAG_ZERO
+    ctx = linalg.Context()
+    A = linalg.ComplexParOperator(ctx, Kr, Mi, ess, pol)
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    y0 = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+
+    def ref(mode, v):
+        M = {"N": Aloc, "T": Aloc.T, "H": Aloc.conj().T}[mode]
+        tv = v.copy()
+        tv[ess] = 0.0
+        r = M @ tv
+        r[ess] = v[ess] if policy == "DIAG_ONE" else 0.0
+        return r
+
+    def dev(mode, v, y=None, a=None, local=False):
+        yr, yi = (_new(n), _new(n)) if y is None else (_dev(y.real.copy()), _dev(y.imag.copy()))
+        A.mult(_dev(v.real.copy()), _dev(v.imag.copy()), yr, yi, mode=mode, a=a, local=local)
+        return yr.cpu().numpy() + 1j * yi.cpu().numpy()
+
+    for mode in ("N", "T", "H"):
+        assert _rel(dev(mode, x), ref(mode, x)) < 1e-12, mode
+        for a in (0.7, -0.3j, 0.4 - 1.1j):
+            assert _rel(dev(mode, x, y0, a), y0 + a * ref(mode, x)) < 1e-12, (mode, a)
+        # local wrapper on L-vectors (no essential handling)
+        M = {"N": Aloc, "T": Aloc.T, "H": Aloc.conj().T}[mode]
+        assert _rel(dev(mode, x, local=True), M @ x) < 1e-12, ("local", mode)
+        for a in (0.7, -0.3j, 0.4 - 1.1j):
+            assert _rel(dev(mode, x, y0, a, local=True), y0 + a * (M @ x)) < 1e-12, ("local", mode, a)
+    assert _rel(dev("T", x), dev("N", x)) > 1e-3  # the real part is not symmetric
+    dr, di = A.assemble_diagonal(_new(n), _new(n))
+    d_ref_r, d_ref_i = np.diag(Ar).copy(), np.diag(Ai).copy()
+    d_ref_r[ess] = 1.0 if policy == "DIAG_ONE" else 0.0
+    d_ref_i[ess] = 0.0
+    assert _rel(dr.cpu().numpy(), d_ref_r) < 1e-12 and _rel(di.cpu().numpy(), d_ref_i) < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["left", "right", "fgmres"])
+def test_complex_gmres_variants(cylinder_mesh, kind):
+    """GmresSolver / FgmresSolver <ComplexOperator> (iterative.cpp:543-871) on A = (K - w^2 M) + i w C-like system
+    (real part curl-curl minus a small mass term, imaginary part a mass term), Jacobi of the real part's diagonal as the
+    (real) preconditioner on both parts."""
+    mesh, p = cylinder_mesh, 2
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ogeom = util.oracle_geom(mesh, q1d)
+    cc, bc = util.make_ctx("identity")
+    cm, bm = util.make_ctx("scalar")
+    ctx = linalg.Context()
+    KM = ceed.curlcurlmass_operator(geom, nd, bm, bc)  # real part: K + eps M
+    Mi = ceed.ndmass_operator(geom, nd, bm)             # imaginary part: eps M
+    ess = nd.ess_dofs()
+    A = linalg.ComplexParOperator(ctx, KM, Mi, ess, linalg.DIAG_ONE)
+    oR = util.FastParOperatorOracle(nd, ogeom, "hdivmass", np.concatenate([bm, bc]), ess, q1d, cm, cc)
+    oI = util.FastParOperatorOracle(nd, ogeom, "hcurl", bm, ess, q1d, cm, policy=po.DIAG_ZERO)
+    n = nd.ndofs
+
+    def A_mult(v):
+        return (oR.mult(v.real) - oI.mult(v.imag)) + 1j * (oI.mult(v.real) + oR.mult(v.imag))
+
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    b[ess] = 0.0
+    dinv = 1.0 / oR.diagonal()
+    PR = linalg.ParOperator(ctx, KM, ess, linalg.DIAG_ONE)
+    J = linalg.jacobi(ctx, PR)
+    flexible, side = kind == "fgmres", ("right" if kind == "right" else "left")
+    K = linalg.ComplexParGmres(ctx, A, J, rel_tol=1e-9, max_it=300, restart=60, flexible=flexible, pc_side=side)
+    xr, xi = K.mult(_dev(b.real.copy()), _dev(b.imag.copy()), _new(n), _new(n))
+    x = xr.cpu().numpy() + 1j * xi.cpu().numpy()
+    xo, it, hist, conv = po.gmres(A_mult, b, lambda r: dinv * r, rel_tol=1e-9, max_it=300, max_dim=60, pc_side=side,
+                                  flexible=flexible)
+    st = K.stats()
+    assert st["converged"] == conv and abs(st["iterations"] - it) <= 1, (st, it)
+    assert _rel(x, xo) < 1e-7
+    assert np.linalg.norm(A_mult(x) - b) < 1e-6 * np.linalg.norm(b)
