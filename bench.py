@@ -7,10 +7,12 @@ iterations/s on a ~10M-dof cylinder cavity (BASELINE.json metric), one JSON line
 
 A "step" is one `ParOperator::Mult` (BC masking + P + fused E-B-D-B^T-E^T kernel + P^T) of the
 curl-curl operator over the whole vector.  `value` = true dofs processed per second by all ranks.
-Scaling is weak: every rank owns a z-slab of the cylinder with the same number of elements
-(~10M dofs per GPU); `config.scaling_mode` says so.  Extra keys: `roofline` (fused apply kernel,
-algorithmic bytes of SURVEY.md 8(d) / HIP-event kernel time), `cpu_baseline` (the oracle's C port of
-the reference's dense-table CPU path on a bounded sample), `pcg` (iterations/s of PCG + p-multigrid).
+Scaling is strong by default (BASELINE.json: "10M DOF @1/2/4/8 GPU"): the same ~10M-dof cylinder is cut
+into N z-slabs, one per GPU; `--scaling weak` gives every rank its own ~10M-dof slab instead.  Extra
+keys: `roofline` (element kernel + E^T run gather, algorithmic bytes of SURVEY.md 8(d) / HIP-event
+time), `cpu_baseline` (the oracle's C port of the reference's dense-table CPU path on a bounded sample,
+apply and PCG + p-multigrid), `parity` (this run's device results against the oracle), `pcg`
+(iterations/s of PCG + p-multigrid), `p4` (the order-4 operator of BASELINE config 5 at the same size).
 """
 import argparse
 import json
@@ -33,10 +35,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--order", type=int, default=3)
-    ap.add_argument("--dofs", type=float, default=10.0e6, help="target true dofs per GPU")
+    ap.add_argument("--dofs", type=float, default=10.0e6,
+                    help="target true dofs: of the whole job (strong scaling) or per GPU (weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--pcg-iters", type=int, default=50, help="fixed PCG iterations for iterations/s (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-dofs", type=float, default=1.0e6, help="size of the CPU baseline sample")
+    ap.add_argument("--cpu-pcg-dofs", type=float, default=2.5e5, help="size of the CPU PCG + p-multigrid sample")
+    ap.add_argument("--cpu-pcg-iters", type=int, default=5)
+    ap.add_argument("--no-p4", action="store_true", help="skip the order-4 leg")
     ap.add_argument("--no-tets", action="store_true", help="skip the tetrahedral (dense MFMA path) leg")
     ap.add_argument("--tet-n", type=int, default=36, help="cubes per direction of the Kuhn-split tet mesh")
     ap.add_argument("--force-comm", action="store_true",
@@ -44,29 +51,54 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(order, target_dofs):
-    """The oracle's C restatement of the reference CPU path (dense [3Q x P] tables, libCEED-style
-    blocked E/B/D/B^T/E^T, OpenMP over element ranges) timed on this host's cores, on a smaller
-    cylinder of the same family (bounded sample: ~10-30 s of CPU work)."""
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def cpu_leg(ctx, prob, order, args):
+    """CPU baseline + parity (rank 0, N = 1).  The oracle is the checker and the thing timed as the CPU baseline,
+    never part of the device path.
+
+    cpu_baseline: the oracle's C restatement of the reference CPU path (dense [3Q x P] tables, libCEED-style blocked
+    E/B/D/B^T/E^T, OpenMP over element ranges) timed on this host's cores on a smaller cylinder of the same family
+    (bounded sample, ~10 s), and the oracle PCG + p-multigrid on a yet smaller one (M2's CPU figure).
+    parity: the device results of the same inputs against the oracle: curl-curl apply on the sample mesh and on the
+    full bench mesh, and the PCG + p-multigrid iterate after a fixed number of iterations."""
+    import torch
+
     from oracle import capi
     from oracle import palace_oracle as po
+    from palace_amd import ceed
     from palace_amd.fem.fespace import NDHexSpace
     from palace_amd.fem.mesh import cylinder_for_dofs
+    from palace_amd.fem.partition import SlabProblem
     from tests import util
 
     capi.build(ref=False)
-    mesh = cylinder_for_dofs(target_dofs, order)
-    nd = NDHexSpace(mesh, order)
     q1d = order + 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 64)  # the element loop stops scaling beyond a socket's worth of threads
+    blob = po.CoeffCtx().pack()
+    parity = {"tolerance": "operator 1e-12, PCG iterate 1e-8 (relative l2; tests/ hold the same bounds)"}
+
+    def dev_apply(mesh, nd, x):
+        g = ceed.GeomFactorData(mesh, q1d)
+        op = ceed.curlcurl_operator(g, nd, ceed.coefficient_context(3))
+        y = torch.zeros(nd.ndofs, dtype=torch.float64, device="cuda")
+        op.mult(torch.from_numpy(x).cuda(), y)
+        return y.cpu().numpy()
+
+    # ---- apply: timing on the sample + parity of the device apply on the same mesh and vector
+    mesh = cylinder_for_dofs(args.cpu_dofs, order)
+    nd = NDHexSpace(mesh, order)
     geom = util.oracle_geom(mesh, q1d)
     off, ori = nd.native_restriction()
     interp, curl = po.nd_hex_dense_tables(order, q1d, nd.dof_map_native())
-    blob = po.CoeffCtx().pack()
     x = np.random.default_rng(1).uniform(0, 1, nd.ndofs)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 64)  # the element loop stops scaling beyond a socket's worth of threads
     y = np.zeros(nd.ndofs)
     capi.apply_add(off, ori, interp, curl, geom, capi.QF_HDIV, blob, x, y, threads=cores)  # warm-up
+    parity["rel_l2_y"] = _rel(dev_apply(mesh, nd, x), y)
+    parity["rel_l2_y_sample"] = f"{nd.ndofs} dofs, {mesh.ne} elements"
     reps, t0 = 0, time.perf_counter()
     while True:
         y[:] = 0.0
@@ -75,9 +107,98 @@ def cpu_baseline(order, target_dofs):
         dt = time.perf_counter() - t0
         if dt > 10.0:
             break
-    return {"value": nd.ndofs * reps / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
-            "sample": f"curl-curl apply, ND p={order}, {mesh.ne} hex27 elements, {nd.ndofs} dofs, {reps} applies "
-                      f"in {dt:.1f} s; oracle/oracle_c.c (dense-table libCEED-style CPU path restated), OpenMP"}
+    cpu = {"value": nd.ndofs * reps / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
+           "sample": f"curl-curl apply, ND p={order}, {mesh.ne} hex27 elements, {nd.ndofs} dofs, {reps} applies "
+                     f"in {dt:.1f} s; oracle/oracle_c.c (dense-table libCEED-style CPU path restated), OpenMP"}
+    del geom
+
+    # ---- apply parity at the full bench size (the very operator and mesh of the timed loop), one oracle apply
+    t0 = time.perf_counter()
+    fnd = prob.spaces[-1]
+    fgeom = util.oracle_geom(prob.mesh, q1d)
+    foff, fori = fnd.native_restriction()
+    fx = np.random.default_rng(2).uniform(0, 1, fnd.ndofs)
+    fy = np.zeros(fnd.ndofs)
+    capi.apply_add(foff, fori, interp, curl, fgeom, capi.QF_HDIV, blob, fx, fy, threads=cores)
+    dy = torch.zeros(fnd.ndofs, dtype=torch.float64, device="cuda")
+    prob.local_curlcurl.mult(torch.from_numpy(fx).cuda(), dy)
+    parity["rel_l2_y_full"] = _rel(dy.cpu().numpy(), fy)
+    parity["rel_l2_y_full_size"] = f"{fnd.ndofs} dofs, {prob.mesh.ne} elements ({time.perf_counter() - t0:.1f} s of oracle work)"
+    del fgeom, fx, fy, dy
+
+    # ---- M2 on the CPU: oracle PCG + p-multigrid (plain Chebyshev, Jacobi-PCG(8) on level 0), timed, and the
+    # device iterate of the same configuration (same eigenvalue estimates) against it
+    if args.cpu_pcg_iters > 0:
+        its = args.cpu_pcg_iters
+        sp = SlabProblem(ctx, 0, 1, order, args.cpu_pcg_dofs)
+        solver, b, xs = sp.pcg_gmg_solver(max_it=its, hiptmair=False, coarse="cg")
+        solver.mult(b, xs)
+        xd = xs.cpu().numpy()
+        gmg = sp.last_gmg
+        nl = len(sp.spaces)
+        ogeom = util.oracle_geom(sp.mesh, q1d)
+        cm, bm = util.make_ctx("scalar")
+        cc, bc = util.make_ctx("identity")
+        blob2 = np.concatenate([bm, bc])
+        oA = [util.FastParOperatorOracle(sx, ogeom, "hdivmass", blob2, sx.ess_dofs(), q1d, cm, cc) for sx in sp.spaces]
+        oP = [po.InterpOracle(c.elem_dof_lex, c.elem_sign_lex, f.elem_dof_lex, f.elem_sign_lex, c.ndofs, f.ndofs,
+                              po.nd_hex_interp_lex(c.p, f.p)) for c, f in zip(sp.spaces[:-1], sp.spaces[1:])]
+        ko = max(2 * order, 4)
+        sm = [None] + [po.ChebyshevOracle(oA[l], ko, lambda_max=gmg.gmg_lambda_max(l)) for l in range(1, nl)]
+        d0 = 1.0 / oA[0].diagonal()
+        coarse = lambda r: po.pcg(oA[0].mult, r, lambda v: d0 * v, rel_tol=1e-2, max_it=8)[0]  # noqa: E731
+        oB = po.GMGOracle(oA, [(q.mult, q.mult_transpose) for q in oP], sm, coarse, [sx.ess_dofs() for sx in sp.spaces])
+        n = sp.spaces[-1].ndofs
+        ob = oA[-1].mult(np.ones(n))
+        ob[sp.spaces[-1].ess_dofs()] = 0.0
+        t0 = time.perf_counter()
+        xo, it, hist = po.pcg(oA[-1].mult, ob, oB.mult, rel_tol=0.0, max_it=its)
+        dt = time.perf_counter() - t0
+        parity["rel_l2_pcg"] = _rel(xd, xo)
+        parity["rel_l2_pcg_sample"] = (f"{n} dofs, iterate after {it} PCG + p-multigrid iterations (plain Chebyshev order {ko}, "
+                                       "Jacobi-PCG(8) on level 0), device eigenvalue estimates handed to the oracle")
+        cpu["pcg_iters_per_s"] = it / dt
+        cpu["pcg_sample"] = (f"oracle PCG + p-multigrid on K+M, {n} dofs, {sp.mesh.ne} elements, {it} iterations in {dt:.1f} s "
+                             "(local applies oracle/oracle_c.c with OpenMP, the rest numpy)")
+        sp._keep.clear()
+    return cpu, parity
+
+
+def p4_leg(ctx, dofs, reps=20):
+    """Order 4 (BASELINE config 5's element) on a cylinder of the same size, N = 1: curl-curl and curl-curl + mass
+    `ceed::Operator::Mult` of the one-shot sum-factorised kernel (Q1 = 5: the streaming kernel is Q1 = 4 only)."""
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem.fespace import NDHexSpace
+    from palace_amd.fem.mesh import cylinder_for_dofs
+
+    p = 4
+    mesh = cylinder_for_dofs(dofs, p)
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, p + 1)
+    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
+    ident = ceed.coefficient_context(3)
+    ops = {"curlcurl": ceed.curlcurl_operator(geom, nd, ident),
+           "curlcurl_mass": ceed.curlcurlmass_operator(geom, nd, mass, ident)}
+    x = torch.rand(nd.ndofs, dtype=torch.float64, device="cuda")
+    y = torch.zeros_like(x)
+    out = {"workload": f"ND p=4 hexahedra, {mesh.ne} elements, {nd.ndofs} dofs, P=300, Q=125", "dofs": nd.ndofs}
+    for name, op in ops.items():
+        for _ in range(3):
+            op.mult(x, y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            op.mult(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        alg = op.algorithmic_bytes()
+        out[name] = {"ms": ms, "dof_per_s": nd.ndofs / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
+                     "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS}
+    return out
 
 
 def tets_leg(order, n, reps=20):
@@ -176,7 +297,16 @@ def main():
 
     # ---- set-up (not timed): mesh slab, spaces, geometry factors, operators ---------------------
     t_setup = time.perf_counter()
-    prob = SlabProblem(ctx, rank, world, p, args.dofs, levels=True)
+    if args.scaling == "strong":
+        # one global mesh for every N: the layer count is rounded to a multiple of 8 so that 1, 2, 4 and 8 ranks cut
+        # the very same cylinder into equal z-slabs
+        from palace_amd.fem.partition import strong_shape
+        n_cross, nz = strong_shape(args.dofs, p)
+        if nz % world:
+            raise SystemExit(f"--scaling strong needs a rank count dividing {nz} layers")
+        prob = SlabProblem(ctx, rank, world, p, args.dofs, levels=True, shape=(n_cross, nz // world))
+    else:
+        prob = SlabProblem(ctx, rank, world, p, args.dofs, levels=True)
     K = prob.curlcurl_par_operator()  # ParOperator(curl-curl, mu^-1 = 1), PEC essential dofs, DIAG_ONE
     n_true = prob.n_true[-1]
     n_global = prob.global_true_dofs()
@@ -230,14 +360,15 @@ def main():
     # HBM traffic of the same launch from the PMC passes (collected by scripts/profile_round.sh in separate
     # rocprofv3 --pmc runs, summary committed under profiles/): raw FETCH_SIZE + WRITE_SIZE bytes
     traffic, traffic_note = None, "no PMC summary under profiles/"
-    pmc_file = os.path.join(ROOT, "profiles", "r01_apply_pmc.json")
-    if os.path.exists(pmc_file) and abs(args.dofs - 10.0e6) < 1 and p == 3:
+    pmc_file = os.path.join(ROOT, "profiles", "r02_apply_pmc.json")
+    if os.path.exists(pmc_file) and abs(args.dofs - 10.0e6) < 1 and p == 3 and world == 1 and args.scaling == "strong":
         pmc = json.load(open(pmc_file))
         pb = pmc["per_apply_bytes"]
         traffic = pb.get("traffic_corrected") or pb["traffic_raw"]
-        traffic_note = ("FETCH_SIZE + WRITE_SIZE per apply from profiles/r01_apply_pmc.json (separate --pmc passes of the "
-                        "same kernels at this size), each divided by the fraction the same counters report on a known "
-                        "stream in the same run; " + pmc.get("calibration", "uncalibrated"))
+        traffic_note = ("FETCH_SIZE + WRITE_SIZE per apply from profiles/r02_apply_pmc.json (separate --pmc passes of the "
+                        "same kernels on this mesh; collected at commit " + str(pmc.get("commit", "?")) + "), each divided by "
+                        "the fraction the same counters report on a known stream in the same run; "
+                        + pmc.get("calibration", "uncalibrated"))
     # measured peaks of this GPU in the same run: a streaming y = a x + b y over 2 x 0.5 GB
     # (16 B read + 8 B written per entry) and the FP64 matrix-core micro-kernel; `peak` stays the guide's figure
     def _event_ms(fn, reps):
@@ -263,7 +394,8 @@ def main():
                 "measured_stream_GBps": measured_stream, "frac_of_measured_stream": achieved / measured_stream,
                 "measured_mfma_f64_TFLOPs": measured_mfma,
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                "kernel": "pa::nd_hex_apply_kernel<3,4,curl,qdata> + pa::et_gather_kernel (E^T)", "kernel_ms": kernel_ms,
+                "kernel": "pa::nd_hex_stream_kernel<P1=3, packed q-data> (E, B, D, B^T, signed E-vector / exclusive dofs) + "
+                          "pa::et_run_gather_kernel (E^T over shared-dof runs)", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_formula": "NE*(Q*11*8 + P*5) + 16*N_L (SURVEY.md 8d, G=11)"}
 
@@ -309,9 +441,13 @@ def main():
                 tets[key]["frac_of_measured_mfma_f64"] = tets[key]["table_TFLOPs"] / measured_mfma
                 tets[key]["frac_of_measured_stream"] = tets[key]["algorithmic_GBps"] / measured_stream
 
-    cpu = None
-    if rank == 0 and not args.no_cpu:
-        cpu = cpu_baseline(p, args.cpu_dofs)
+    p4 = None
+    if rank == 0 and world == 1 and not args.no_p4:
+        p4 = p4_leg(ctx, args.dofs)
+
+    cpu, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu, parity = cpu_leg(ctx, prob, p, args)
     if world > 1:
         dist.barrier()
 
@@ -319,14 +455,16 @@ def main():
         out = {
             "metric": "curl-curl Mult DOF/s + PCG iters/s, p=3 H(curl) 10M DOF @1/2/4/8 GPU",
             "value": value, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ND p={p} curl-curl ParOperator::Mult, O-grid cylinder cavity (hex27, PEC), "
                                    f"{n_global} true dofs total", "order": p, "elements_per_gpu": prob.mesh.ne,
                        "true_dofs_per_gpu": n_true, "global_true_dofs": n_global, "q1d": p + 1,
-                       "scaling_mode": "weak: one z-slab of the cylinder per GPU, same element count per GPU",
+                       "scaling_mode": ("strong: one ~10M-dof cylinder cut into N equal z-slabs" if args.scaling == "strong"
+                                        else "weak: one z-slab of the cylinder per GPU, same element count per GPU"),
                        "parallelism": f"element partition x{world}, RCCL halo (P / P^T) + allreduce dots"},
-            "roofline": roofline, "cpu_baseline": cpu, "pcg": pcg, "tets_mfma": tets, "setup_s": t_setup,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "tets_mfma": tets,
+            "setup_s": t_setup,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -90,6 +90,8 @@ int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed);
 int pa_chebyshev_create(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max,
                         int fourth_kind, pa_solver **S);
 int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max);
+/* The same for the Chebyshev smoother of level l >= 1 of a GeometricMultigridSolver (diagnostics / parity checks). */
+int pa_gmg_smoother_lambda_max(const pa_solver *S, int level, double *lambda_max);
 /* ChebyshevSmoother1stKind (linalg/chebyshev.cpp:222-293); sf_min <= 0: the optimised lambda_min estimate (:244-247). */
 int pa_chebyshev_create_1st_kind(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max, double sf_min,
                                  pa_solver **S);

@@ -307,6 +307,16 @@ int pa_solver_mult2(pa_solver *S, const double *x, double *y, int transpose, int
       S->solver->Mult2(vx, vy, r);
   });
 }
+/* eigenvalue estimate of the Chebyshev smoother of multigrid level l >= 1 (plain Chebyshev levels only) */
+int pa_gmg_smoother_lambda_max(const pa_solver *S, int level, double *lambda_max) {
+  return guarded([&] {
+    auto *g = dynamic_cast<const GeometricMultigridSolver *>(S ? S->solver.get() : nullptr);
+    PA_REQUIRE(g && lambda_max, "not a multigrid solver");
+    auto *c = dynamic_cast<const ChebyshevSmoother *>(&g->Smoother(level));
+    PA_REQUIRE(c, "level smoother is not a Chebyshev smoother");
+    *lambda_max = c->LambdaMax();
+  });
+}
 int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max) {
   return guarded([&] {
     auto *c = dynamic_cast<const ChebyshevSmoother *>(S->solver.get());

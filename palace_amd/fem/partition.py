@@ -30,6 +30,13 @@ def slab_shape(dofs_per_rank: float, p: int):
     return n, nz
 
 
+def strong_shape(total_dofs: float, p: int):
+    """(n, nz) of the one global cylinder of a strong-scaling run: the layer count is a multiple of 8, so that
+    1, 2, 4 and 8 ranks cut the very same mesh into equal z-slabs."""
+    n, nz = slab_shape(total_dofs, p)
+    return n, max(8, 8 * ((nz + 4) // 8))
+
+
 def _plane_key(xy: np.ndarray, scale: float) -> np.ndarray:
     q = np.round(xy * scale).astype(np.int64) + (1 << 30)
     return (q[:, 0] << 32) | q[:, 1]
@@ -290,6 +297,7 @@ class SlabProblem:
         b[torch.from_numpy(self.ess[-1].astype(np.int64)).cuda()] = 0.0
         x = torch.zeros_like(b)
         self._keep.append((local, A, P, B))
+        self.last_gmg = B if len(A) > 1 else None
         return K, b, x
 
 

@@ -255,6 +255,11 @@ class Solver:
         _lib.check(_L().pa_dist_relaxation_lambda_max(self.handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def gmg_lambda_max(self, level):
+        v = C.c_double()
+        _lib.check(_L().pa_gmg_smoother_lambda_max(self.handle, int(level), C.byref(v)))
+        return v.value
+
     def lambda_max(self):
         v = C.c_double()
         _lib.check(_L().pa_chebyshev_lambda_max(self.handle, C.byref(v)))

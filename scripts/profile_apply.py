@@ -3,9 +3,10 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from palace_amd import ceed, linalg
-from palace_amd.fem.partition import SlabProblem
+from palace_amd.fem.partition import SlabProblem, strong_shape
 ctx = linalg.Context()
-prob = SlabProblem(ctx, 0, 1, 3, float(os.environ.get("DOFS", "10e6")), levels=False)
+dofs = float(os.environ.get("DOFS", "10e6"))
+prob = SlabProblem(ctx, 0, 1, 3, dofs, levels=False, shape=strong_shape(dofs, 3))  # the bench mesh (bench.py)
 which = os.environ.get("OP", "curl")
 if which == "curl":
     op = prob.local_curlcurl

@@ -10,14 +10,15 @@ OUT=$REPO/gpurun_out
 rm -rf $OUT/prof_bench $OUT/prof_curlmass $OUT/prof_pmc* && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $REPO/bench.py --no-cpu --no-tets > $OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $REPO/bench.py --no-cpu --no-tets --no-p4 > $OUT/prof_bench.log 2>&1
 OP=curlmass REPS=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_curlmass -- python $REPO/scripts/profile_apply.py > $OUT/prof_curlmass.log 2>&1
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
   i=$((i+1))
-  OP=curl REPS=10 timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/prof_pmc$i -- python $REPO/scripts/profile_apply.py > $OUT/prof_pmc$i.log 2>&1
+  OP=curl REPS=10 CAL8=1 timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/prof_pmc$i -- python $REPO/scripts/profile_apply.py > $OUT/prof_pmc$i.log 2>&1
 done
 cd $REPO
-CAL_N=$(grep -h '^done' $OUT/prof_pmc1.log | awk '{print $2}') python scripts/summarize_profiles.py
+grep -h '^done' $OUT/prof_pmc1.log | awk '{print $2}' > $OUT/prof_cal_n.txt
+# then, back in the work tree: CAL_N=$(cat gpurun_out/prof_cal_n.txt) python scripts/summarize_profiles.py
