@@ -1,6 +1,9 @@
-"""Write the descriptor arrays of a small PEC-cavity problem (what Palace's libCEED glue would pass across
-the C ABI: restriction, 1-D tables, mesh nodes, coefficient context, essential dofs) into one binary file
-for the C++ host example.  Usage: python dump_problem.py out.bin [order]"""
+"""Write what Palace's MFEM side would hand over for a small PEC cavity (the arrays fem/libceed/restriction.cpp and
+fem/mesh.cpp:146-209 extract from MFEM today) into one binary file for the C++ host example: the Q2 hex mesh (node
+lattice per element, coordinates, attributes) and, for every multigrid level p = 1 .. order, the element -> dof tables
+with orientation flags of the Nedelec space and of the H1 auxiliary space, their tensor -> native dof maps and the
+essential (PEC) true dofs.  Bases, quadrature, geometry factors, operators and solvers are built by the C++ side.
+Usage: python dump_problem.py out.bin [order] [n] [nz]"""
 import os
 import sys
 
@@ -8,26 +11,22 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from palace_amd import ceed  # noqa: E402
-from palace_amd.fem.basis1d import Tables1D, gauss_legendre  # noqa: E402
-from palace_amd.fem.fespace import NDHexSpace  # noqa: E402
-from palace_amd.fem.mesh import _q2_1d, ogrid_cylinder  # noqa: E402
+from palace_amd.fem.fespace import H1HexSpace, NDHexSpace  # noqa: E402
+from palace_amd.fem.mesh import ogrid_cylinder  # noqa: E402
+from palace_amd.fem.partition import levels_for  # noqa: E402
 
 
-def main(path, p=2):
-    mesh = ogrid_cylinder(2, 4)
-    nd = NDHexSpace(mesh, p)
-    q1d = p + 1
-    t = Tables1D(p, q1d)
-    off, ori = nd.native_restriction()
-    qx, qw = gauss_legendre(q1d)
-    B, G = _q2_1d(qx)
-    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
-    curl = ceed.coefficient_context(3)
-    arrays = [np.array([mesh.ne, nd.P, nd.ndofs, p, q1d, mesh.x.shape[0]], dtype=np.int32),
-              off.astype(np.int32), ori.astype(np.uint8), np.asarray(nd.dof_map_native(), dtype=np.int32),
-              t.Bc, t.Gc, t.Bo, mesh.elem_nodes.astype(np.int32), mesh.x.astype(np.float64), mesh.attr.astype(np.int32),
-              B, G, qw, np.concatenate([mass, curl]), nd.ess_dofs().astype(np.int32)]
+def main(path, p=3, n=3, nz=6):
+    mesh = ogrid_cylinder(n, nz)
+    orders = levels_for(p)
+    arrays = [np.array([mesh.ne, mesh.x.shape[0], p, len(orders)] + orders, dtype=np.int32),
+              mesh.elem_nodes.astype(np.int32), mesh.x.astype(np.float64), mesh.attr.astype(np.int32)]
+    for q in orders:
+        nd, h1 = NDHexSpace(mesh, q), H1HexSpace(mesh, q)
+        off, ori = nd.native_restriction()
+        arrays += [np.array([nd.ndofs, h1.ndofs], dtype=np.int32), off.astype(np.int32), ori.astype(np.uint8),
+                   np.asarray(nd.dof_map_native(), dtype=np.int32), nd.ess_dofs().astype(np.int32),
+                   h1.elem_dof_lex.astype(np.int32), h1.ess_dofs().astype(np.int32)]
     with open(path, "wb") as f:
         f.write(np.array([len(arrays)], dtype=np.int64).tobytes())
         for a in arrays:
@@ -37,4 +36,5 @@ def main(path, p=2):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    a = [int(v) for v in sys.argv[2:]]
+    main(sys.argv[1], *a)

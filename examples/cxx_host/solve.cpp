@@ -1,16 +1,23 @@
-// C++ host example: the classes of palace_amd/csrc/linalg.hpp used the way Palace's drivers use
-// palace::ceed::Operator / ParOperator / CgSolver / ChebyshevSmoother, on descriptor arrays that come
-// from a file instead of MFEM.  Solves (K + eps M) x = b on a small PEC cavity and prints the
-// iteration count, the final residual and a checksum of x.
+// C++ host example: a Palace-style driver without Python and without MFEM.  From the arrays MFEM would provide (mesh
+// nodes, element -> dof tables per level; see dump_problem.py) it builds, with the classes of fem.hpp / ksp.hpp /
+// linalg.hpp used the way Palace's SpaceOperator and drivers use theirs:
+//   Mesh, FiniteElementSpaceHierarchy (p = 1 .. order) + the H1 auxiliary hierarchy,
+//   MaterialPropertyCoefficient, BilinearForm + CurlCurlMassIntegrator / DiffusionIntegrator -> Assemble(hierarchy),
+//   ParOperator per level with the PEC essential dofs, MultigridOperator,
+//   KspSolver (PCG or FGMRES + p-multigrid, Chebyshev or Hiptmair smoothers) from a LinearSolverData,
+// solves (K + eps_r M) x = b and prints iterations, NumTotalMult / NumTotalMultIterations, the residual and a checksum.
 //
-//   hipcc --offload-arch=gfx950 -std=c++17 -I<repo>/palace_amd/csrc solve.cpp -L<repo>/palace_amd/lib
+//   hipcc --offload-arch=gfx950 -std=c++17 -I<repo>/palace_amd/csrc -I<repo>/include solve.cpp -L<repo>/palace_amd/lib
 //         -lpalace_amd -Wl,-rpath,<repo>/palace_amd/lib -o solve
+//   ./solve problem.bin [aux=0|1] [krylov=cg|fgmres] [coarse=cheb|pcg|jacobi]
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
+#include <string>
 #include <vector>
 
-#include "linalg.hpp"
+#include "ksp.hpp"
 
 using namespace palace;
 
@@ -32,61 +39,95 @@ static std::vector<std::vector<char>> read_blobs(const char *path) {
   return out;
 }
 
-static void check(int rc) {
-  if (rc) {
-    std::fprintf(stderr, "palace_amd: %s\n", pa_last_error());  // ceed.hpp:13-33 convention -> MFEM_ABORT in Palace
-    std::exit(1);
-  }
-}
-
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
-  auto blobs = read_blobs(argv[1]);
-  const auto *hdr = reinterpret_cast<const int32_t *>(blobs[0].data());
-  const int ne = hdr[0], P = hdr[1], ndofs = hdr[2], p = hdr[3], q1d = hdr[4], nn = hdr[5];
-  auto as = [&](int i) { return blobs[(size_t)i].data(); };
+  const bool aux = argc > 2 && std::atoi(argv[2]) != 0;
+  const std::string krylov = argc > 3 ? argv[3] : "cg", coarse = argc > 4 ? argv[4] : (aux ? "pcg" : "cheb");
+  try {
+    auto blobs = read_blobs(argv[1]);
+    auto i32 = [&](size_t i) { return reinterpret_cast<const int32_t *>(blobs[i].data()); };
+    auto f64 = [&](size_t i) { return reinterpret_cast<const double *>(blobs[i].data()); };
+    const int ne = i32(0)[0], nn = i32(0)[1], order = i32(0)[2], nlev = i32(0)[3];
 
-  // what InitRestriction / InitBasis / AssembleGeometryData fill for libCEED today
-  pa_restriction_desc r{ne, P, ndofs, (const int32_t *)as(1), (const uint8_t *)as(2), nullptr};
-  pa_basis_desc b{PA_FE_HCURL, p, q1d, (const double *)as(4), (const double *)as(5), (const double *)as(6),
-                  (const int32_t *)as(3), nullptr, nullptr};
-  pa_mesh_desc m{ne, 2, q1d, nn, (const int32_t *)as(7), (const double *)as(8), (const int32_t *)as(9),
-                 (const double *)as(10), (const double *)as(11), (const double *)as(12)};
-  pa_geom *geom = nullptr;
-  check(pa_geom_create(&m, nullptr, &geom));
-  pa_op *op = nullptr;
-  check(pa_op_create(ndofs, ndofs, &op));
-  check(pa_op_add_sub(op, geom, &r, &b, PA_QF_HDIVMASS_33, as(13), blobs[13].size(), PA_EVAL_CURL | PA_EVAL_INTERP,
-                      PA_EVAL_CURL | PA_EVAL_INTERP));
-  check(pa_op_finalize(op));
+    hipStream_t stream;
+    if (hipStreamCreate(&stream) != hipSuccess) throw pa::Error("no HIP device");
+    Context ctx;
+    ctx.stream = stream;
 
-  Context ctx;  // default stream, single process
-  {
-    ceed::Operator local(ctx, op, /*own=*/true);
-    const int n_ess = (int)(blobs[14].size() / 4);
-    ParOperator A(ctx, local, ndofs, (const int32_t *)as(14), n_ess, ParOperator::DiagonalPolicy::DIAG_ONE);
+    // IoData::CheckConfiguration: the quadrature follows the solution order on every level
+    fem::DefaultIntegrationOrder::p_trial = order;
+    Mesh mesh(ctx, ne, 2, nn, i32(1), f64(2), i32(3), fem::DefaultIntegrationOrder::GetQ1d(2 * 3 - 1));
 
-    ChebyshevSmoother smoother(ctx, /*smooth_it=*/1, /*order=*/4);
-    smoother.SetOperator(A);
-    CgSolver pcg(ctx);
-    pcg.SetOperator(A);
-    pcg.SetPreconditioner(smoother);
-    pcg.SetTol(1e-10);
-    pcg.SetMaxIter(500);
+    FiniteElementSpaceHierarchy nd_fespaces, h1_fespaces;
+    for (int l = 0; l < nlev; l++) {
+      const size_t b = 4 + 7 * (size_t)l;
+      const int p = i32(0)[4 + l], nd_size = i32(b)[0], h1_size = i32(b)[1];
+      auto nd = std::make_unique<FiniteElementSpace>(ctx, mesh, PA_FE_HCURL, p, nd_size, i32(b + 1),
+                                                     reinterpret_cast<const uint8_t *>(blobs[b + 2].data()), i32(b + 3));
+      nd->SetEssentialTrueDofs(i32(b + 4), (int)(blobs[b + 4].size() / 4));
+      nd_fespaces.AddLevel(std::move(nd));
+      auto h1 = std::make_unique<FiniteElementSpace>(ctx, mesh, PA_FE_H1, p, h1_size, i32(b + 5), nullptr, nullptr);
+      h1->SetEssentialTrueDofs(i32(b + 6), (int)(blobs[b + 6].size() / 4));
+      h1_fespaces.AddLevel(std::move(h1));
+    }
 
-    Vector ones(ndofs), rhs(ndofs), x(ndofs);
+    // materials: mu_r^-1 = 1, eps_r = 2.08 on attribute 1 (examples/cylinder)
+    MaterialPropertyCoefficient muinv(1), eps(1);
+    muinv.AddMaterialProperty(1, 1.0);
+    eps.AddMaterialProperty(1, 2.08);
+
+    // SpaceOperator::GetStiffnessMatrix-style assembly of K + M on all levels and of the auxiliary diffusion operator
+    BilinearForm::pa_order_threshold = 2;  // the p = 1 level becomes a matrix (the reference assembles it for AMS)
+    BilinearForm a(nd_fespaces.GetFinestFESpace());
+    a.AddDomainIntegrator<CurlCurlMassIntegrator>(muinv, eps);
+    auto a_ops = a.Assemble(nd_fespaces, /*skip_zeros=*/false);
+    auto A = std::make_unique<MultigridOperator>(nd_fespaces.GetNumLevels());
+    for (std::size_t l = 0; l < nd_fespaces.GetNumLevels(); l++) {
+      const auto &fes = nd_fespaces.GetFESpaceAtLevel(l);
+      auto op = std::make_unique<FespaceParOperator>(std::move(a_ops[l]), fes);
+      op->SetEssentialTrueDofs(fes.GetEssentialTrueDofs(), ParOperator::DiagonalPolicy::DIAG_ONE);
+      A->AddOperator(std::move(op));
+    }
+    if (aux) {
+      BilinearForm g(h1_fespaces.GetFinestFESpace());
+      g.AddDomainIntegrator<DiffusionIntegrator>(eps);
+      auto g_ops = g.Assemble(h1_fespaces, false);
+      for (std::size_t l = 0; l < h1_fespaces.GetNumLevels(); l++) {
+        const auto &fes = h1_fespaces.GetFESpaceAtLevel(l);
+        auto op = std::make_unique<FespaceParOperator>(std::move(g_ops[l]), fes);
+        op->SetEssentialTrueDofs(fes.GetEssentialTrueDofs(), ParOperator::DiagonalPolicy::DIAG_ONE);
+        A->AddAuxiliaryOperator(std::move(op));
+      }
+    }
+
+    config::LinearSolverData linear;
+    linear.krylov_solver = krylov == "fgmres" ? KrylovSolver::FGMRES : KrylovSolver::CG;
+    linear.type = coarse == "pcg" ? LinearSolver::JACOBI_PCG : coarse == "jacobi" ? LinearSolver::JACOBI : LinearSolver::CHEBYSHEV_JACOBI;
+    linear.tol = 1e-10, linear.max_it = 400;
+    linear.mg_smooth_aux = aux ? 1 : 0;
+    linear.initial_guess = 0;
+    linear.SetDefaults(order, /*spd_problem=*/true);
+    KspSolver ksp(linear, /*verbose=*/0, nd_fespaces, aux ? &h1_fespaces : nullptr);
+    ksp.SetOperators(*A, *A);
+
+    const int n = A->Height();
+    Vector ones(n), rhs(n), x(n), res(n);
     linalg::Fill(ctx, ones, 1.0);
-    A.Mult(ones, rhs);
-    linalg::SetSubVector(ctx, rhs, A.GetEssentialTrueDofs(), A.NumEssentialTrueDofs(), 0.0);
-    pcg.Mult(rhs, x);
-
-    Vector res(ndofs);
-    A.Mult(x, res);
+    A->Mult(ones, rhs);
+    const auto &ess = A->GetFinestOperator().Par();
+    linalg::SetSubVector(ctx, rhs, ess.GetEssentialTrueDofs(), ess.NumEssentialTrueDofs(), 0.0);
+    ksp.Mult(rhs, x);
+    ksp.Mult(rhs, x);  // a second solve: the counters accumulate (ksp.cpp:330-331)
+    A->Mult(x, res);
     linalg::AXPBY(ctx, 1.0, rhs, -1.0, res);
-    std::printf("cxx_host: ndofs %d  iterations %d  converged %d  |b - A x| / |b| %.3e  sum(x) %.12e\n", ndofs,
-                pcg.GetNumIterations(), (int)pcg.GetConverged(), linalg::Norml2(ctx, res) / linalg::Norml2(ctx, rhs),
-                linalg::Dot(ctx, x, ones));
+    std::printf("cxx_host: order %d  levels %d  ndofs %d  aux %d  krylov %s  coarse %s  iterations %d  converged %d  "
+                "NumTotalMult %d  NumTotalMultIterations %d  |b - A x| / |b| %.3e  sum(x) %.12e\n",
+                order, nlev, n, (int)aux, krylov.c_str(), coarse.c_str(), ksp.GetKrylovSolver().GetNumIterations(),
+                (int)ksp.GetKrylovSolver().GetConverged(), ksp.NumTotalMult(), ksp.NumTotalMultIterations(),
+                linalg::Norml2(ctx, res) / linalg::Norml2(ctx, rhs), linalg::Dot(ctx, x, ones));
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "palace_amd: %s\n", e.what());  // MFEM_ABORT in Palace
+    return 1;
   }
-  pa_geom_destroy(geom);
   return 0;
 }

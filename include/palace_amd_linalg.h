@@ -22,8 +22,13 @@ typedef struct pa_interp pa_interp;   /* p-prolongation / discrete gradient, fem
 typedef struct pa_solver pa_solver;   /* palace::Solver<Operator>, linalg/solver.hpp     */
 typedef struct pa_csolver pa_csolver; /* Krylov solver on ComplexOperator (ComplexVector = two real vectors) */
 
-/* --- context: everything created from it is enqueued on `stream` (a hipStream_t) ------------- */
+/* --- context: everything created from it is enqueued on `stream` (a hipStream_t) -------------
+ * stream == NULL: the context creates a stream of its own with the default (blocking) flag, which is ordered against
+ * the legacy null stream exactly like the null stream itself (callers that fill vectors on the null stream keep their
+ * ordering) and which, unlike the null stream, can be recorded into HIP graphs. */
 int pa_context_create(void *stream, pa_context **ctx);
+/* the hipStream_t the context enqueues on */
+int pa_context_stream(const pa_context *ctx, void **stream);
 void pa_context_destroy(pa_context *ctx);
 int pa_context_synchronize(pa_context *ctx);
 
@@ -90,6 +95,11 @@ int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed);
 int pa_chebyshev_create(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max,
                         int fourth_kind, pa_solver **S);
 int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max);
+/* CgSolver execution mode.  By default the scalars of the recurrence stay on the device (no host round trip per
+ * iteration; an iteration is replayed as a HIP graph) and the host enqueues `lookahead` iterations beyond the last
+ * residual it has read; iterates and iteration counts equal those of the synchronous loop of iterative.cpp:360-486,
+ * which host_scalars != 0 selects literally.  lookahead < 0: never wait (statistics are read when asked for). */
+int pa_cg_set_lookahead(pa_solver *S, int lookahead, int host_scalars);
 /* The same for the Chebyshev smoother of level l >= 1 of a GeometricMultigridSolver (diagnostics / parity checks). */
 int pa_gmg_smoother_lambda_max(const pa_solver *S, int level, double *lambda_max);
 /* ChebyshevSmoother1stKind (linalg/chebyshev.cpp:222-293); sf_min <= 0: the optimised lambda_min estimate (:244-247). */

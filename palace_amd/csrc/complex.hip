@@ -69,15 +69,11 @@ __global__ void k_cscale(double s, double *__restrict__ xr, double *__restrict__
 }
 
 struct CScratch {
-  double *d = nullptr, *h = nullptr;
-  CScratch() {
-    d = pa::dev_alloc<double>(2 * kMaxB + 8);
-    PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&h), 4 * sizeof(double), hipHostMallocDefault));
-  }
+  double *d, *h;
 };
-CScratch &cscratch() {
-  static CScratch s;
-  return s;
+CScratch cscratch(const Context &c) {  // the context's reduction scratch: [2 kMaxB] partial sums, then the results
+  Workspace &w = c.Work();
+  return {w.Device(2 * kMaxB + 8), w.Pinned(4)};
 }
 inline int grid(long long n) { return (int)std::max(1LL, std::min<long long>((n + kB - 1) / kB, kMaxB)); }
 
@@ -87,7 +83,8 @@ namespace linalg {
 
 std::complex<double> Dot(const Context &c, const ComplexVector &x, const ComplexVector &y) {
   PA_REQUIRE(x.Size() == y.Size(), "size mismatch in complex Dot");
-  CScratch &s = cscratch();
+  StreamGraph::RequireNotRecording("linalg::Dot");
+  const CScratch s = cscratch(c);
   const int nb = grid(x.Size());
   hipLaunchKernelGGL(k_cdot_partial, dim3(nb), dim3(kB), 0, c.stream, x.Real().Data(), x.Imag().Data(),
                      y.Real().Data(), y.Imag().Data(), (long long)x.Size(), s.d);

@@ -1,0 +1,176 @@
+// KspSolver (see ksp.hpp).  Host code only.
+#include "ksp.hpp"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace palace {
+
+namespace {
+
+// a few Jacobi-preconditioned CG iterations as one Solver (stand-in coarse solve); never waits for the host
+class JacobiPcgSolver : public Solver {
+  JacobiSmoother jac_;
+  CgSolver cg_;
+
+public:
+  JacobiPcgSolver(const Context &ctx, double tol, int max_it) : jac_(ctx), cg_(ctx) {
+    cg_.SetTol(tol), cg_.SetMaxIter(max_it), cg_.SetLookahead(-1);
+    cg_.SetPreconditioner(jac_);
+  }
+  void SetOperator(const Operator &op) override {
+    height = op.Height(), width = op.Width();
+    jac_.SetOperator(op), cg_.SetOperator(op);
+  }
+  void Mult(const Vector &x, Vector &y) const override {
+    const_cast<CgSolver &>(cg_).SetInitialGuess(initial_guess);
+    cg_.Mult(x, y);
+  }
+};
+
+std::unique_ptr<IterativeSolver> ConfigureKrylovSolver(const config::LinearSolverData &linear, int verbose,
+                                                       const Context &ctx) {
+  // ksp.cpp:27-106
+  std::unique_ptr<IterativeSolver> ksp;
+  const auto type = linear.krylov_solver;
+  switch (type) {
+    case KrylovSolver::CG:
+      ksp = std::make_unique<CgSolver>(ctx, verbose);
+      break;
+    case KrylovSolver::GMRES: {
+      auto gmres = std::make_unique<GmresSolver>(ctx, verbose);
+      gmres->SetRestartDim(linear.max_size);
+      ksp = std::move(gmres);
+    } break;
+    case KrylovSolver::FGMRES: {
+      auto fgmres = std::make_unique<FgmresSolver>(ctx, verbose);
+      fgmres->SetRestartDim(linear.max_size);
+      ksp = std::move(fgmres);
+    } break;
+    default:
+      throw pa::Error("Unexpected solver type for Krylov solver configuration!");
+  }
+  ksp->SetInitialGuess(linear.initial_guess > 0);
+  ksp->SetTol(linear.tol);
+  ksp->SetMaxIter(linear.max_it);
+  if (linear.pc_side != PreconditionerSideOption::DEFAULT && type != KrylovSolver::GMRES) {
+    std::fprintf(stderr, "Warning: Preconditioner side will be ignored for non-GMRES iterative solvers!\n");
+  } else if (type == KrylovSolver::GMRES || type == KrylovSolver::FGMRES) {
+    auto *gmres = static_cast<GmresSolver *>(ksp.get());
+    if (linear.pc_side == PreconditionerSideOption::LEFT) gmres->SetPreconditionerSide(PreconditionerSide::LEFT);
+    if (linear.pc_side == PreconditionerSideOption::RIGHT) gmres->SetPreconditionerSide(PreconditionerSide::RIGHT);
+  }
+  if (type == KrylovSolver::GMRES || type == KrylovSolver::FGMRES)
+    static_cast<GmresSolver *>(ksp.get())->SetOrthogonalization(linear.gs_orthog);
+  return ksp;
+}
+
+std::unique_ptr<Solver> ConfigurePreconditionerSolver(const config::LinearSolverData &linear, int verbose, const Context &ctx,
+                                                      const FiniteElementSpaceHierarchy &fespaces,
+                                                      const FiniteElementSpaceHierarchy *aux_fespaces) {
+  // ksp.cpp:131-258: the solver of the coarsest level (or of the only level), then the multigrid hierarchy around it
+  std::unique_ptr<Solver> pc;
+  switch (linear.type) {
+    case LinearSolver::JACOBI:
+      pc = std::make_unique<JacobiSmoother>(ctx);
+      break;
+    case LinearSolver::CHEBYSHEV_JACOBI:
+      pc = std::make_unique<ChebyshevSmoother>(ctx, 1, linear.coarse_order);
+      break;
+    case LinearSolver::JACOBI_PCG:
+      pc = std::make_unique<JacobiPcgSolver>(ctx, linear.coarse_tol, linear.coarse_max_it);
+      break;
+    case LinearSolver::AMS:
+    case LinearSolver::BOOMER_AMG:
+    case LinearSolver::MUMPS:
+    case LinearSolver::SUPERLU:
+    case LinearSolver::STRUMPACK:
+    case LinearSolver::STRUMPACK_MP:
+    case LinearSolver::CUDSS:
+      throw pa::Error("this coarse solver lives in an external package (HYPRE / sparse direct) and is not part of "
+                      "palace_amd: use JACOBI, CHEBYSHEV_JACOBI or JACOBI_PCG");
+    default:
+      throw pa::Error("Unexpected solver type for preconditioner configuration!");
+  }
+  if (fespaces.GetNumLevels() > 1) {
+    const auto P = fespaces.GetProlongationOperators();
+    const int order = linear.mg_smooth_order > 0 ? linear.mg_smooth_order
+                                                 : std::max(2 * fespaces.GetFinestFESpace().GetMaxElementOrder(), 4);
+    if (linear.mg_smooth_aux > 0) {
+      PA_REQUIRE(aux_fespaces, "Multigrid with auxiliary space smoothers requires both primary space and auxiliary spaces "
+                               "for construction!");
+      const auto G = fespaces.GetDiscreteInterpolators(*aux_fespaces);
+      return std::make_unique<GeometricMultigridSolver>(ctx, std::move(pc), P, std::max(linear.mg_cycle_it, 1),
+                                                        linear.mg_smooth_it, order, linear.mg_smooth_sf_max,
+                                                        linear.mg_smooth_sf_min, linear.mg_smooth_cheby_4th, &G);
+    }
+    return std::make_unique<GeometricMultigridSolver>(ctx, std::move(pc), P, std::max(linear.mg_cycle_it, 1),
+                                                      linear.mg_smooth_it, order, linear.mg_smooth_sf_max,
+                                                      linear.mg_smooth_sf_min, linear.mg_smooth_cheby_4th, nullptr);
+  }
+  (void)verbose;
+  return pc;
+}
+
+}  // namespace
+
+void config::LinearSolverData::SetDefaults(int order, bool spd_problem) {
+  if (krylov_solver == KrylovSolver::DEFAULT) krylov_solver = spd_problem ? KrylovSolver::CG : KrylovSolver::GMRES;
+  if (type == LinearSolver::DEFAULT) type = LinearSolver::JACOBI_PCG;  // (reference: AMS / BoomerAMG / a direct solver)
+  if (max_size < 0) max_size = max_it;
+  if (initial_guess < 0) initial_guess = 1;
+  if (mg_max_levels < 0) mg_max_levels = 100;
+  if (mg_cycle_it < 0) mg_cycle_it = 1;
+  if (mg_smooth_aux < 0) mg_smooth_aux = spd_problem ? 0 : 1;
+  if (mg_smooth_order < 0) mg_smooth_order = std::max(2 * order, 4);
+}
+
+std::vector<int> GetPolynomialOrders(int order, MultigridCoarsening coarsening, int mg_max_levels) {
+  // multigrid.hpp:44-69: LINEAR p -> p - 1, LOGARITHMIC p -> (p + 1) / 2, down to 1
+  std::vector<int> out{order};
+  while (out.back() > 1 && (mg_max_levels < 0 || (int)out.size() < mg_max_levels))
+    out.push_back(coarsening == MultigridCoarsening::LINEAR ? out.back() - 1 : (out.back() + 1) / 2);
+  std::reverse(out.begin(), out.end());
+  return out;
+}
+
+KspSolver::KspSolver(const config::LinearSolverData &linear, int verbose, const FiniteElementSpaceHierarchy &fespaces,
+                     const FiniteElementSpaceHierarchy *aux_fespaces)
+    : KspSolver(ConfigureKrylovSolver(linear, verbose, fespaces.GetFinestFESpace().GetContext()),
+                ConfigurePreconditionerSolver(linear, verbose - 1, fespaces.GetFinestFESpace().GetContext(), fespaces,
+                                              aux_fespaces)) {}
+
+KspSolver::KspSolver(std::unique_ptr<IterativeSolver> &&ksp_, std::unique_ptr<Solver> &&pc_)
+    : ksp(std::move(ksp_)), pc(std::move(pc_)) {
+  if (pc) ksp->SetPreconditioner(*pc);
+}
+
+void KspSolver::SetOperators(const Operator &op, const Operator &pc_op) {
+  // ksp.cpp:295-313; a multigrid preconditioner takes the operators of all levels (gmg.cpp:69-123)
+  ksp->SetOperator(op);
+  if (!pc) return;
+  const auto *mg_op = dynamic_cast<const MultigridOperator *>(&pc_op);
+  auto *mg_pc = dynamic_cast<GeometricMultigridSolver *>(pc.get());
+  if (mg_pc) {
+    PA_REQUIRE(mg_op, "GeometricMultigridSolver requires a MultigridOperator argument provided to SetOperator!");
+    std::vector<const ParOperator *> ops, aux;
+    for (std::size_t l = 0; l < mg_op->GetNumLevels(); l++) ops.push_back(&mg_op->GetOperatorAtLevel(l).Par());
+    for (std::size_t l = 0; l < mg_op->GetNumAuxiliaryLevels(); l++) aux.push_back(&mg_op->GetAuxiliaryOperatorAtLevel(l).Par());
+    mg_pc->SetOperators(ops, mg_op->HasAuxiliaryOperators() ? &aux : nullptr);
+  } else if (mg_op) {
+    pc->SetOperator(mg_op->GetFinestOperator());
+  } else {
+    pc->SetOperator(pc_op);
+  }
+}
+
+void KspSolver::Mult(const Vector &x, Vector &y) const {
+  ksp->Mult(x, y);
+  if (!ksp->GetConverged())
+    std::fprintf(stderr, "Warning: Linear solver did not converge, norm(Ax-b)/norm(b) = %.3e (norm(b) = %.3e)!\n",
+                 ksp->GetFinalRes() / ksp->GetInitialRes(), ksp->GetInitialRes());
+  ksp_mult++;
+  ksp_mult_it += ksp->GetNumIterations();
+}
+
+}  // namespace palace

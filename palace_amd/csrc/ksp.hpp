@@ -1,0 +1,81 @@
+// KspSolver: the linear solver object Palace's drivers hold -- a Krylov solver and its preconditioner configured from
+// the "Linear" section of the configuration (reference linalg/ksp.hpp:36-86, ksp.cpp:27-333; utils/configfile.hpp:994-1122
+// for LinearSolverData, utils/labels.hpp for the enumerations).
+//
+// Coarse-level solvers: the reference's choices on the coarsest multigrid level are external packages (HYPRE AMS /
+// BoomerAMG, sparse direct solvers), which are outside this library.  Until a native auxiliary-space coarse solver
+// exists two device-resident stand-ins are offered besides JACOBI: CHEBYSHEV_JACOBI (a fixed
+// Chebyshev-Jacobi polynomial) and JACOBI_PCG (a few Jacobi-preconditioned CG iterations to a loose tolerance).
+// Asking for AMS / BOOMER_AMG / a direct solver fails loudly.
+#pragma once
+
+#include <memory>
+
+#include "fem.hpp"
+#include "linalg.hpp"
+
+namespace palace {
+
+enum class LinearSolver { DEFAULT, AMS, BOOMER_AMG, MUMPS, SUPERLU, STRUMPACK, STRUMPACK_MP, CUDSS, JACOBI,
+                          CHEBYSHEV_JACOBI, JACOBI_PCG };
+enum class KrylovSolver { DEFAULT, CG, MINRES, GMRES, FGMRES, BICGSTAB };
+enum class PreconditionerSideOption { DEFAULT, RIGHT, LEFT };  // labels.hpp PreconditionerSide (with DEFAULT)
+enum class MultigridCoarsening { LINEAR, LOGARITHMIC };
+
+namespace config {
+
+struct LinearSolverData {
+  LinearSolver type = LinearSolver::DEFAULT;
+  KrylovSolver krylov_solver = KrylovSolver::DEFAULT;
+  double tol = 1.0e-6;    // iterative solver relative tolerance
+  int max_it = 100;       // maximum number of iterations
+  int max_size = -1;      // maximum Krylov space dimension (GMRES / FGMRES restart)
+  int initial_guess = -1; // reuse the previous solution as the initial guess
+  int mg_max_levels = -1;
+  MultigridCoarsening mg_coarsening = MultigridCoarsening::LOGARITHMIC;
+  bool mg_use_mesh = true;
+  int mg_cycle_it = -1;   // V-cycles per preconditioner application
+  int mg_smooth_aux = -1; // auxiliary-space (Hiptmair) smoothers
+  int mg_smooth_it = 1;   // pre- / post-smoothing iterations
+  int mg_smooth_order = -1;  // Chebyshev smoother order (-1: max(2 p, 4), iodata.cpp:533-564)
+  double mg_smooth_sf_max = 1.0, mg_smooth_sf_min = 0.0;
+  bool mg_smooth_cheby_4th = true;
+  PreconditionerSideOption pc_side = PreconditionerSideOption::DEFAULT;
+  Orthogonalization gs_orthog = Orthogonalization::MGS;
+  // stand-in coarse solvers only (not in the reference): iterations / tolerance of JACOBI_PCG, order of CHEBYSHEV_JACOBI
+  int coarse_max_it = 8;
+  double coarse_tol = 1.0e-2;
+  int coarse_order = 4;
+  // fills the -1 / DEFAULT entries the way IoData::CheckConfiguration does for an order-p problem of the given kind
+  // (iodata.cpp:454-564): SPD problems (electrostatic, magnetostatic, transient) use CG and plain smoothers, the
+  // frequency-domain ones GMRES and auxiliary-space smoothers
+  void SetDefaults(int order, bool spd_problem);
+};
+
+}  // namespace config
+
+// p-coarsening sequence of the multigrid hierarchy (fem/multigrid.hpp:44-69): orders from coarsest to finest
+std::vector<int> GetPolynomialOrders(int order, MultigridCoarsening coarsening, int mg_max_levels = -1);
+
+class KspSolver {
+protected:
+  std::unique_ptr<IterativeSolver> ksp;
+  std::unique_ptr<Solver> pc;
+  mutable int ksp_mult = 0, ksp_mult_it = 0;
+
+public:
+  KspSolver(const config::LinearSolverData &linear, int verbose, const FiniteElementSpaceHierarchy &fespaces,
+            const FiniteElementSpaceHierarchy *aux_fespaces = nullptr);
+  KspSolver(std::unique_ptr<IterativeSolver> &&ksp, std::unique_ptr<Solver> &&pc);
+  int NumTotalMult() const { return ksp_mult; }
+  int NumTotalMultIterations() const { return ksp_mult_it; }
+  void SetRelTol(double tol) { ksp->SetTol(tol); }
+  void SetAbsTol(double tol) { ksp->SetAbsTol(tol); }
+  const IterativeSolver &GetKrylovSolver() const { return *ksp; }
+  // op: the system operator; pc_op: the operator the preconditioner is built from (a MultigridOperator when the
+  // preconditioner is geometric multigrid)
+  void SetOperators(const Operator &op, const Operator &pc_op);
+  void Mult(const Vector &x, Vector &y) const;
+};
+
+}  // namespace palace

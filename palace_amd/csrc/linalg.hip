@@ -5,6 +5,7 @@
 #include "linalg.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <complex>
 #include <cstdio>
 
@@ -34,6 +35,103 @@ void Vector::SetSize(int n) {
 void Vector::MakeRef(double *ext, int n) {
   if (own_ && d_) (void)hipFree(d_);
   d_ = ext, n_ = n, own_ = false;
+}
+
+// ---- Workspace / StreamGraph -----------------------------------------------------------------
+Workspace::~Workspace() {
+  if (d_) (void)hipFree(d_);
+  if (h_) (void)hipHostFree(h_);
+}
+double *Workspace::Device(size_t n) {
+  PA_REQUIRE(n <= kDeviceDoubles, "reduction scratch request exceeds the workspace");
+  if (!d_) d_ = pa::dev_alloc<double>(kDeviceDoubles);
+  return d_;
+}
+double *Workspace::Pinned(size_t n) {
+  PA_REQUIRE(n <= kPinnedDoubles, "pinned scratch request exceeds the workspace");
+  if (!h_) PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_), kPinnedDoubles * sizeof(double), hipHostMallocDefault));
+  return h_;
+}
+
+StreamGraph::StreamGraph() {
+  const char *e = std::getenv("PALACE_AMD_GRAPH");
+  disabled_ = e && e[0] == '0';
+}
+StreamGraph::~StreamGraph() { Reset(); }
+void StreamGraph::Reset() {
+  if (exec_) (void)hipGraphExecDestroy(exec_);
+  exec_ = nullptr, seen_ = 0, key_.clear();
+}
+static thread_local int tls_recording = 0;
+bool StreamGraph::Recording() { return tls_recording > 0; }
+void StreamGraph::RequireNotRecording(const char *what) {
+  if (tls_recording > 0)
+    throw pa::Error(std::string(what) + " waits for the device and cannot be part of a recorded launch sequence");
+}
+static bool graph_debug() {
+  static const bool v = std::getenv("PALACE_AMD_GRAPH_DEBUG") != nullptr;
+  return v;
+}
+bool StreamGraph::Capture(const Context &c, const std::function<void()> &body) {
+  hipStream_t cap = c.stream;
+  hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    if (graph_debug()) std::fprintf(stderr, "palace_amd graph: begin capture failed: %s\n", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return false;
+  }
+  hipGraph_t g = nullptr;
+  tls_recording++;
+  try {
+    body();
+  } catch (const std::exception &ex) {
+    // e.g. a solver inside the sequence that needs the host (RequireNotRecording): nothing has run, the sequence is
+    // dropped and the caller runs it directly (where a genuine error shows up again)
+    tls_recording--;
+    if (graph_debug()) std::fprintf(stderr, "palace_amd graph: not recordable: %s\n", ex.what());
+    (void)hipStreamEndCapture(cap, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return false;
+  }
+  tls_recording--;
+  e = hipStreamEndCapture(cap, &g);
+  if (e != hipSuccess || !g) {
+    if (graph_debug()) std::fprintf(stderr, "palace_amd graph: end capture failed: %s\n", hipGetErrorString(e));
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return false;
+  }
+  e = hipGraphInstantiate(&exec_, g, nullptr, nullptr, 0);
+  if (graph_debug()) {
+    size_t nn = 0;
+    (void)hipGraphGetNodes(g, nullptr, &nn);
+    std::fprintf(stderr, "palace_amd graph: recorded %zu nodes, instantiate: %s\n", nn, hipGetErrorString(e));
+  }
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) {
+    exec_ = nullptr;
+    (void)hipGetLastError();
+    return false;
+  }
+  return true;
+}
+void StreamGraph::Run(const Context &c, const std::vector<const void *> &key, const std::function<void()> &body) {
+  if (!c.stream) return body();  // the null stream cannot be recorded
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(c.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return body();  // part of an enclosing recording (the V-cycle inside a PCG iteration)
+  if (!disabled_) {
+    if (key != key_) Reset(), key_ = key;
+    if (!exec_ && seen_++ >= 1) {
+      if (!Capture(c, body)) disabled_ = true;  // nothing of the recording ran: fall through to the direct form
+    }
+    if (exec_) {
+      PA_HIP(hipGraphLaunch(exec_, c.stream));
+      return;
+    }
+  }
+  body();
 }
 
 // ---- kernels ----------------------------------------------------------------------------------
@@ -366,17 +464,79 @@ struct OpMultiAxpy {
   }
 };
 
-struct Scratch {
-  double *d_partial = nullptr;  // [kDotBatch * kMaxBlocks + kDotBatch]
-  double *h_result = nullptr;   // pinned
-  Scratch() {
-    d_partial = pa::dev_alloc<double>((size_t)kDotBatch * kMaxBlocks + kMaxBlocks + kDotBatch);
-    PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_result), kDotBatch * sizeof(double), hipHostMallocDefault));
-  }
+// ---- PCG with device-resident scalars (CgSolver::MultDevice) ---------------------------------------------
+// st[]: the scalars of iterative.cpp:375-486 in device memory
+enum CgSlot { CG_BETA = 0, CG_BETA_PREV, CG_DENOM, CG_RES, CG_EPS, CG_INIT, CG_STOP, CG_IT, CG_BAD, CG_TMP, CG_NSLOT = 16 };
+enum CgStep { CG_STEP_RHS = 0, CG_STEP_START, CG_STEP_DENOM, CG_STEP_BETA };
+struct CgTol {
+  double rel, abs;
+  int use_rhs;  // initial residual from the right-hand side (initial guess given)
 };
-Scratch &scratch() {
-  static Scratch s;
-  return s;
+template <int STEP>
+__device__ __forceinline__ void cg_scalar_step(double *__restrict__ st, const double v, const CgTol tol) {
+  if (STEP == CG_STEP_RHS) {  // (B b, b) or (b, b)
+    st[CG_INIT] = sqrt(fabs(v));
+  } else if (STEP == CG_STEP_START) {  // beta = (z, r), iterative.cpp:400-421
+    const double res = sqrt(fabs(v));
+    st[CG_BETA] = v, st[CG_BETA_PREV] = v, st[CG_RES] = res, st[CG_IT] = 0.0;
+    if (!tol.use_rhs) st[CG_INIT] = res;
+    const double eps = fmax(tol.rel * st[CG_INIT], tol.abs);
+    st[CG_EPS] = eps;
+    const bool bad = !isfinite(v);
+    st[CG_BAD] = bad ? 1.0 : 0.0;
+    st[CG_STOP] = (bad || res < eps) ? 1.0 : 0.0;
+  } else if (st[CG_STOP] == 0.0) {
+    if (STEP == CG_STEP_DENOM) {  // (A p, p), iterative.cpp:444
+      st[CG_DENOM] = v;
+      if (!isfinite(v)) st[CG_BAD] = 2.0, st[CG_STOP] = 1.0;
+    } else {  // beta = (z, r) of the new residual, iterative.cpp:460-474
+      const double res = sqrt(fabs(v));
+      st[CG_BETA_PREV] = st[CG_BETA], st[CG_BETA] = v, st[CG_RES] = res, st[CG_IT] += 1.0;
+      if (!isfinite(v)) st[CG_BAD] = 1.0, st[CG_STOP] = 1.0;
+      if (res < st[CG_EPS]) st[CG_STOP] = 1.0;
+    }
+  }
+}
+// second stage of the inner product fused with the scalar update (single process)
+template <int STEP>
+__global__ void k_cg_dot_final(const double *__restrict__ partial, int nb, double *__restrict__ st, const CgTol tol) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partial[i];
+  s = block_sum(s);
+  if (threadIdx.x == 0) cg_scalar_step<STEP>(st, s, tol);
+}
+// the same update after the all-reduce of st[CG_TMP] (multi-rank)
+template <int STEP>
+__global__ void k_cg_scalar(double *__restrict__ st, const CgTol tol) {
+  cg_scalar_step<STEP>(st, st[CG_TMP], tol);
+}
+// element-wise kernels whose coefficient comes from st[]; they leave the vectors alone once the solve has stopped
+template <int W, class Op>
+__global__ __launch_bounds__(256) void k_ew_cg(Op op, long long n, const double *__restrict__ st) {
+  if (st[CG_STOP] != 0.0) return;
+  op.load(st);
+  using T = typename Lane<W>::type;
+  const long long nv = n / W;
+  PA_STRIDE_LOOP(i, nv) op.template at<T>(i);
+  if (W > 1) {
+    const long long j = nv * W + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) op.template at<double>(j);
+  }
+}
+struct OpCgDirDev : OpAxpby {  // p = z + (beta / beta_prev) p, iterative.cpp:436-441
+  __device__ void load(const double *st) { a = 1.0, b = st[CG_BETA] / st[CG_BETA_PREV]; }
+};
+struct OpCgUpdateDev : OpCgUpdate {  // alpha = beta / (A p, p); x += alpha p; r -= alpha z, iterative.cpp:446-449
+  __device__ void load(const double *st) { a = st[CG_BETA] / st[CG_DENOM]; }
+};
+
+// layout of the context's reduction scratch: [kDotBatch * kMaxBlocks] partial sums, then kMaxBlocks + kDotBatch results
+struct Scratch {
+  double *d_partial, *h_result;
+};
+Scratch scratch(const Context &c) {
+  Workspace &w = c.Work();
+  return {w.Device((size_t)kDotBatch * kMaxBlocks + kMaxBlocks + kDotBatch), w.Pinned(kDotBatch)};
 }
 
 #define PA_LAUNCH(kernel, n, stream, ...)                                                  \
@@ -436,7 +596,8 @@ void Scale(const Context &c, double s, Vector &x) { launch_ew(OpScal{s, x.Data()
 
 double Dot(const Context &c, const Vector &x, const Vector &y) {
   PA_REQUIRE(x.Size() == y.Size(), "size mismatch in Dot");
-  Scratch &s = scratch();
+  StreamGraph::RequireNotRecording("linalg::Dot");
+  const Scratch s = scratch(c);
   const bool wide = ((bits(x.Data()) | bits(y.Data())) & 15) == 0 && x.Size() >= 2;
   const int nb = grid_for(wide ? (x.Size() + 1) / 2 : x.Size());
   if (wide)
@@ -454,7 +615,8 @@ double Dot(const Context &c, const Vector &x, const Vector &y) {
 }
 // H[j] = (w, V[j]) for j < m (global), batches of kDotBatch; w -= sum_j H[j] V[j] if `subtract`
 void MultiDot(const Context &c, const Vector &w, const std::vector<Vector> &V, int m, double *H) {
-  Scratch &s = scratch();
+  StreamGraph::RequireNotRecording("linalg::MultiDot");
+  const Scratch s = scratch(c);
   const int nb = grid_for(w.Size());
   double *d_out = s.d_partial + (size_t)kDotBatch * kMaxBlocks;
   for (int j0 = 0; j0 < m; j0 += kDotBatch) {
@@ -517,7 +679,8 @@ void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::ve
   }
 }
 double Sum(const Context &c, const Vector &x) {
-  Scratch &s = scratch();
+  StreamGraph::RequireNotRecording("linalg::Sum");
+  const Scratch s = scratch(c);
   if (x.Size() == 0 && !c.comm) return 0.0;
   const bool wide = (bits(x.Data()) & 15) == 0 && x.Size() >= 2;
   const int nb = grid_for(wide ? (x.Size() + 1) / 2 : std::max(x.Size(), 1));
@@ -948,7 +1111,191 @@ void DistRelaxationSmoother::MultTranspose2(const Vector &x, Vector &y, Vector &
 }
 
 // ---- PCG (iterative.cpp:360-486) ----------------------------------------------------------------
+struct CgSolver::DeviceState {
+  double *d_st = nullptr;    // the scalars (CgSlot)
+  double *h_ring = nullptr;  // pinned snapshots of d_st, one slot per iteration in flight
+  int ring = 0;
+  std::vector<hipEvent_t> ev;
+  StreamGraph graph;     // one iteration
+  bool pending = false;  // lookahead < 0: the final snapshot has been enqueued but not read
+  ~DeviceState() {
+    if (d_st) (void)hipFree(d_st);
+    if (h_ring) (void)hipHostFree(h_ring);
+    for (auto e : ev) (void)hipEventDestroy(e);
+  }
+  void Setup(int slots) {
+    if (!d_st) d_st = pa::dev_alloc<double>(CG_NSLOT);
+    if (slots > ring) {
+      if (h_ring) PA_HIP(hipHostFree(h_ring));
+      PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_ring), (size_t)slots * CG_NSLOT * sizeof(double), hipHostMallocDefault));
+      while ((int)ev.size() < slots) {
+        hipEvent_t e;
+        PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ev.push_back(e);
+      }
+      ring = slots;
+    }
+  }
+  const double *Slot(int k) const { return h_ring + (size_t)k * CG_NSLOT; }
+  void Snapshot(int k, hipStream_t s, bool with_event) {
+    PA_HIP(hipMemcpyAsync(h_ring + (size_t)k * CG_NSLOT, d_st, CG_NSLOT * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (with_event) PA_HIP(hipEventRecord(ev[k], s));
+  }
+};
+
+namespace {
+// (x, y) into the scalars of the recurrence: local two-stage reduction, all-reduce across ranks, scalar update
+template <int STEP>
+void cg_dot(const Context &c, const Vector &x, const Vector &y, double *st, const CgTol &tol) {
+  const Scratch s = scratch(c);
+  const bool wide = ((bits(x.Data()) | bits(y.Data())) & 15) == 0 && x.Size() >= 2;
+  const int nb = grid_for(wide ? (x.Size() + 1) / 2 : std::max(x.Size(), 1));
+  if (wide)
+    hipLaunchKernelGGL(k_dot_partial<2>, dim3(nb), dim3(kBlock), 0, c.stream, x.Data(), y.Data(), (long long)x.Size(),
+                       s.d_partial);
+  else
+    hipLaunchKernelGGL(k_dot_partial<1>, dim3(nb), dim3(kBlock), 0, c.stream, x.Data(), y.Data(), (long long)x.Size(),
+                       s.d_partial);
+  if (c.comm && c.comm->Size() > 1) {
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kBlock), 0, c.stream, s.d_partial, nb, st + CG_TMP);
+    c.comm->AllReduceSum(st + CG_TMP, 1, c.stream);  // Mpi::GlobalSum, no host in the loop
+    hipLaunchKernelGGL(k_cg_scalar<STEP>, dim3(1), dim3(1), 0, c.stream, st, tol);
+  } else {
+    hipLaunchKernelGGL(k_cg_dot_final<STEP>, dim3(1), dim3(kBlock), 0, c.stream, s.d_partial, nb, st, tol);
+  }
+  PA_HIP(hipGetLastError());
+}
+template <class Op>
+void launch_ew_cg(const Op &op, long long n, const double *st, hipStream_t stream) {
+  if (n <= 0) return;
+  if ((op.align() & 15) == 0 && n >= 2)
+    hipLaunchKernelGGL((k_ew_cg<2, Op>), dim3(grid_full((n + 1) / 2)), dim3(kBlock), 0, stream, op, n, st);
+  else
+    hipLaunchKernelGGL((k_ew_cg<1, Op>), dim3(grid_full(n)), dim3(kBlock), 0, stream, op, n, st);
+  PA_HIP(hipGetLastError());
+}
+bool cg_host_scalars_env() {
+  static const bool v = [] {
+    const char *e = std::getenv("PALACE_AMD_CG_HOST");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+}  // namespace
+
+CgSolver::CgSolver(const Context &ctx, int print) : IterativeSolver(ctx, print) {}
+CgSolver::~CgSolver() = default;
+void CgSolver::SetOperator(const Operator &op) {
+  IterativeSolver::SetOperator(op);
+  if (dev_) dev_->graph.Reset();
+}
+void CgSolver::SetPreconditioner(const Solver &pc) {
+  IterativeSolver::SetPreconditioner(pc);
+  if (dev_) dev_->graph.Reset();
+}
+
 void CgSolver::Mult(const Vector &b, Vector &x) const {
+  if (host_scalars_ || cg_host_scalars_env())
+    MultHost(b, x);
+  else
+    MultDevice(b, x);
+}
+
+void CgSolver::Finish() const {
+  if (!dev_ || !dev_->pending) return;
+  StreamGraph::RequireNotRecording("CgSolver statistics");
+  PA_HIP(hipStreamSynchronize(ctx_->stream));
+  dev_->pending = false;
+  const double *st = dev_->Slot(0);
+  initial_res_ = st[CG_INIT], final_res_ = st[CG_RES], final_it_ = (int)st[CG_IT];
+  converged_ = st[CG_BAD] == 0.0 && st[CG_RES] < st[CG_EPS];
+}
+
+void CgSolver::MultDevice(const Vector &b, Vector &x) const {
+  const Context &c = *ctx_;
+  PA_REQUIRE(A_, "Operator must be set for CgSolver::Mult!");
+  const int n = A_->Height();
+  r_.SetSize(n), z_.SetSize(n), p_.SetSize(n);
+  if (!dev_) dev_ = std::make_unique<DeviceState>();
+  DeviceState &d = *dev_;
+  const int L = StreamGraph::Recording() ? -1 : lookahead_;  // inside a recorded sequence: never wait
+  d.Setup(L >= 0 ? L + 2 : 1);
+  d.pending = false;
+  double *st = d.d_st;
+  const CgTol tol{rel_tol_, abs_tol_, initial_guess ? 1 : 0};
+  auto precond = [&](const Vector &u, Vector &v) {
+    if (B_) B_->Mult(u, v); else linalg::Copy(c, u, v);
+  };
+  auto check = [&](const double *h) {
+    PA_REQUIRE(h[CG_BAD] != 1.0, "PCG preconditioner is not positive definite: (Br, r) not finite");
+    PA_REQUIRE(h[CG_BAD] != 2.0, "PCG operator is not positive definite: (Ap, p) not finite");
+  };
+  // iterative.cpp:375-421
+  if (initial_guess) {
+    A_->Mult(x, r_);
+    linalg::AXPBY(c, 1.0, b, -1.0, r_);
+    if (B_) {
+      B_->Mult(b, p_);
+      cg_dot<CG_STEP_RHS>(c, p_, b, st, tol);
+    } else {
+      cg_dot<CG_STEP_RHS>(c, b, b, st, tol);
+    }
+  } else {
+    linalg::Copy(c, b, r_);
+    linalg::Fill(c, x, 0.0);
+  }
+  precond(r_, z_);
+  cg_dot<CG_STEP_START>(c, z_, r_, st, tol);
+  linalg::Fill(c, p_, 0.0);  // beta_prev = beta at the start: p = z + 1 * 0
+  // one iteration (iterative.cpp:432-474); the same launches for every `it`
+  auto iteration = [&]() {
+    launch_ew_cg(OpCgDirDev{{1.0, z_.Data(), 1.0, p_.Data()}}, n, st, c.stream);
+    A_->Mult(p_, z_);
+    cg_dot<CG_STEP_DENOM>(c, z_, p_, st, tol);
+    launch_ew_cg(OpCgUpdateDev{{0.0, p_.Data(), z_.Data(), x.Data(), r_.Data()}}, n, st, c.stream);
+    precond(r_, z_);
+    cg_dot<CG_STEP_BETA>(c, z_, r_, st, tol);
+  };
+  const std::vector<const void *> key{x.Data(), A_, B_};
+  if (L < 0) {
+    // fixed work, nothing read back: the stop flag freezes x once the tolerance is met
+    for (int it = 0; it < max_it_; it++) d.graph.Run(c, key, iteration);
+    d.Snapshot(0, c.stream, false);
+    d.pending = true;
+    return;
+  }
+  const int R = d.ring;
+  d.Snapshot(0, c.stream, true);
+  PA_HIP(hipEventSynchronize(d.ev[0]));
+  check(d.Slot(0));
+  int last = 0;  // ring slot of the newest snapshot
+  bool stop = d.Slot(0)[CG_STOP] != 0.0;
+  int it = 0;
+  for (; it < max_it_ && !stop; it++) {
+    d.graph.Run(c, key, iteration);
+    last = (it + 1) % R;
+    d.Snapshot(last, c.stream, true);
+    const int j = it - L;  // the newest iteration the host waits for
+    if (j >= 0) {
+      const int sj = (j + 1) % R;
+      PA_HIP(hipEventSynchronize(d.ev[sj]));
+      const double *h = d.Slot(sj);
+      check(h);
+      if (print_ > 1) std::printf("  %3d KSP residual norm ||r||_B = %.6e\n", j + 1, h[CG_RES]);
+      stop = h[CG_STOP] != 0.0;
+    }
+  }
+  PA_HIP(hipEventSynchronize(d.ev[last]));
+  const double *h = d.Slot(last);
+  check(h);
+  initial_res_ = h[CG_INIT], final_res_ = h[CG_RES], final_it_ = (int)h[CG_IT];
+  converged_ = h[CG_RES] < h[CG_EPS];
+  if (print_ > 0)
+    std::printf("  PCG solver %s in %d iterations (res %.3e, initial %.3e)\n",
+                converged_ ? "converged" : "did NOT converge", final_it_, final_res_, initial_res_);
+}
+
+void CgSolver::MultHost(const Vector &b, Vector &x) const {
   const Context &c = *ctx_;
   PA_REQUIRE(A_, "Operator must be set for CgSolver::Mult!");
   const int n = A_->Height();
@@ -1054,6 +1401,8 @@ GeometricMultigridSolver::GeometricMultigridSolver(const Context &ctx, std::uniq
   PA_REQUIRE(!G || G->size() == B_.size(),
              "Invalid input for distributive relaxation smoother auxiliary space transfer operators!");
   B_[0] = std::move(coarse_solver);
+  // a Krylov coarse solve inside the cycle must not stall the stream: fixed work, statistics left on the device
+  if (auto *cg = dynamic_cast<CgSolver *>(B_[0].get())) cg->SetLookahead(-1);
   for (size_t l = 1; l < B_.size(); l++) {
     if (G)  // gmg.cpp:41-47: cheby_smooth_it = 1 inside the distributive relaxation
       B_[l] = std::make_unique<DistRelaxationSmoother>(ctx, *(*G)[l], smooth_it, 1, cheby_order, cheby_sf_max,
@@ -1082,12 +1431,16 @@ void GeometricMultigridSolver::SetOperators(const std::vector<const ParOperator 
     X_[l].SetSize(A_[l]->Height()), Y_[l].SetSize(A_[l]->Height()), R_[l].SetSize(A_[l]->Height());
   }
   height = width = ops.back()->Height();
+  graph_.Reset();
 }
 
 void GeometricMultigridSolver::Mult(const Vector &x, Vector &y) const {
   const int L = (int)A_.size();
   linalg::Copy(*ctx_, x, X_[L - 1]);
-  for (int it = 0; it < pc_it_; it++) VCycle(L - 1, it > 0);
+  // the cycle works on the solver's own vectors: one recording serves every (x, y)
+  graph_.Run(*ctx_, {this}, [&] {
+    for (int it = 0; it < pc_it_; it++) VCycle(L - 1, it > 0);
+  });
   linalg::Copy(*ctx_, Y_[L - 1], y);
 }
 

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -26,11 +27,59 @@ namespace palace {
 class Comm;  // RCCL communicator (comm.hpp); nullptr = single process
 class Halo;  // conforming prolongation of one space across ranks (comm.hpp)
 
+// Reduction scratch of one context (per-block partial sums on the device, a pinned slot for the results); created on
+// first use and shared by the copies of a context -- never by two contexts, whose streams may reduce concurrently.
+class Workspace {
+  double *d_ = nullptr, *h_ = nullptr;
+
+public:
+  static constexpr size_t kDeviceDoubles = 32768, kPinnedDoubles = 64;  // fixed: recorded graphs keep these addresses
+  Workspace() = default;
+  Workspace(const Workspace &) = delete;
+  Workspace &operator=(const Workspace &) = delete;
+  ~Workspace();
+  double *Device(size_t n);  // n <= kDeviceDoubles doubles of device memory
+  double *Pinned(size_t n);  // n <= kPinnedDoubles doubles of page-locked host memory
+};
+
 // Execution context shared by the objects of one solve: the stream everything is enqueued on and
 // the communicator used by global reductions / halo exchanges.
 struct Context {
   hipStream_t stream = nullptr;
   Comm *comm = nullptr;
+  mutable std::shared_ptr<Workspace> ws;
+  Workspace &Work() const {
+    if (!ws) ws = std::make_shared<Workspace>();
+    return *ws;
+  }
+};
+
+// A launch sequence recorded once as a HIP graph and replayed with one hipGraphLaunch: for the fixed-shape inner
+// loops (one PCG iteration, one multigrid V-cycle) whose ~100 small launches cost more host time than device time
+// on the per-rank problem sizes of a strong-scaling run.  `body` must enqueue on c.stream only, must not wait for
+// the device, and must use the same buffers every time it runs with the same key (the pointers the caller passes in);
+// its first run with a key is direct (work vectors get their sizes there), the second one is captured.  A failed
+// capture disables the graph for good and the body runs directly; so does a context on the null stream, which cannot
+// be recorded.  PALACE_AMD_GRAPH=0 disables all graphs.
+class StreamGraph {
+  hipGraphExec_t exec_ = nullptr;
+  std::vector<const void *> key_;
+  int seen_ = 0;
+  bool disabled_ = false;
+  bool Capture(const Context &c, const std::function<void()> &body);
+
+public:
+  StreamGraph();
+  StreamGraph(const StreamGraph &) = delete;
+  StreamGraph &operator=(const StreamGraph &) = delete;
+  ~StreamGraph();
+  void Reset();
+  bool Captured() const { return exec_ != nullptr; }
+  // true while this thread records a sequence; code that has to wait for the device calls RequireNotRecording first
+  // (it throws, the recording is dropped cleanly and the sequence runs directly from then on)
+  static bool Recording();
+  static void RequireNotRecording(const char *what);
+  void Run(const Context &c, const std::vector<const void *> &key, const std::function<void()> &body);
 };
 
 // Device vector: owning, or a view of caller memory (mfem::Vector with device memory in Palace).
@@ -130,6 +179,7 @@ public:
   Operator(const Context &ctx, pa_op *op, bool own);
   ~Operator() override;
   pa_op *Handle() const { return op_; }
+  const Context &GetContext() const { return *ctx_; }
   void Mult(const Vector &x, Vector &y) const override;
   void MultTranspose(const Vector &x, Vector &y) const override;
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
@@ -325,22 +375,47 @@ protected:
 public:
   explicit IterativeSolver(const Context &ctx, int print = 0) : ctx_(&ctx), print_(print) {}
   void SetOperator(const Operator &op) override { A_ = &op, height = op.Height(), width = op.Width(); }
-  void SetPreconditioner(const Solver &pc) { B_ = &pc; }
+  virtual void SetPreconditioner(const Solver &pc) { B_ = &pc; }
   void SetTol(double tol) { rel_tol_ = tol; }
   void SetAbsTol(double tol) { abs_tol_ = tol; }
   void SetMaxIter(int its) { max_it_ = its; }
-  bool GetConverged() const { return converged_; }
-  double GetInitialRes() const { return initial_res_; }
-  double GetFinalRes() const { return final_res_; }
-  int GetNumIterations() const { return final_it_; }
+  bool GetConverged() const { return Finish(), converged_; }
+  double GetInitialRes() const { return Finish(), initial_res_; }
+  double GetFinalRes() const { return Finish(), final_res_; }
+  int GetNumIterations() const { return Finish(), final_it_; }
+
+protected:
+  // solvers that leave their statistics on the device until someone asks (CgSolver with device-resident scalars)
+  virtual void Finish() const {}
 };
 
+// CgSolver (iterative.cpp:360-486).  Default form: the scalars of the recurrence (beta, (Ap, p), alpha, the
+// residual norm, the convergence decision) live on the device and every kernel reads them there, so an iteration is
+// a fixed launch sequence with no host round trip: one fused dot + (multi-rank) one all-reduce per inner product,
+// the iteration recorded as a HIP graph, and the host running `lookahead` iterations ahead of the last residual it
+// has seen.  Once the device decides the solve has converged the remaining enqueued iterations change nothing
+// (every update kernel returns at once), so iterates, iteration counts and residuals are those of the reference's
+// check-every-iteration loop.  SetHostScalars(true) (or PALACE_AMD_CG_HOST=1) gives that loop literally.
 class CgSolver : public IterativeSolver {
   mutable Vector r_, z_, p_;
+  struct DeviceState;
+  mutable std::unique_ptr<DeviceState> dev_;
+  int lookahead_ = 1;
+  bool host_scalars_ = false;
+  void MultHost(const Vector &b, Vector &x) const;
+  void MultDevice(const Vector &b, Vector &x) const;
+  void Finish() const override;
 
 public:
-  using IterativeSolver::IterativeSolver;
+  explicit CgSolver(const Context &ctx, int print = 0);
+  ~CgSolver() override;
   void Mult(const Vector &b, Vector &x) const override;
+  // iterations the host may enqueue beyond the last one whose residual it has read back; < 0: never wait (inner
+  // solvers with a small iteration cap: their statistics stay on the device until asked for)
+  void SetLookahead(int k) { lookahead_ = k; }
+  void SetHostScalars(bool host) { host_scalars_ = host; }
+  void SetOperator(const Operator &op) override;
+  void SetPreconditioner(const Solver &pc) override;
 };
 
 enum class Orthogonalization { MGS = 0, CGS = 1, CGS2 = 2 };  // config "Orthogonalization", orthog.hpp:41-89
@@ -393,6 +468,7 @@ class GeometricMultigridSolver : public Solver {
   std::vector<const ParOperator *> A_;
   std::vector<std::unique_ptr<Solver>> B_;
   mutable std::vector<Vector> X_, Y_, R_;
+  mutable StreamGraph graph_;  // one application (pc_it V-cycles) on X_ / Y_
   void VCycle(int l, bool initial_guess) const;
 
 public:

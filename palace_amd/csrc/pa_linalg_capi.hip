@@ -19,6 +19,10 @@ Operator *make_interp_operator(const Context &ctx, const pa_restriction_desc &rc
 struct pa_context {
   Context ctx;
   std::unique_ptr<Comm> comm;
+  hipStream_t own_stream = nullptr;
+  ~pa_context() {
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
 };
 struct pa_halo {
   std::unique_ptr<Halo> halo;
@@ -67,12 +71,26 @@ int pa_context_create(void *stream, pa_context **ctx) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
       throw pa::Error("no HIP device visible: libpalace_amd has no CPU fallback");
-    auto *c = new pa_context;
-    c->ctx.stream = (hipStream_t)stream;
-    *ctx = c;
+    auto c = std::make_unique<pa_context>();
+    if (stream) {
+      c->ctx.stream = (hipStream_t)stream;
+    } else {
+      // a stream of the context's own with the default (blocking) flag: ordered against the legacy null stream like the
+      // null stream itself, so callers that fill vectors there (PyTorch's default stream) see the same ordering, and --
+      // unlike the null stream -- it can be recorded into HIP graphs
+      PA_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
+      c->ctx.stream = c->own_stream;
+    }
+    *ctx = c.release();
   });
 }
 void pa_context_destroy(pa_context *ctx) { delete ctx; }
+int pa_context_stream(const pa_context *ctx, void **stream) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && stream, "null argument");
+    *stream = (void *)ctx->ctx.stream;
+  });
+}
 int pa_context_synchronize(pa_context *ctx) {
   return guarded([&] { PA_HIP(hipStreamSynchronize(ctx->ctx.stream)); });
 }
@@ -307,6 +325,16 @@ int pa_solver_mult2(pa_solver *S, const double *x, double *y, int transpose, int
       S->solver->Mult2(vx, vy, r);
   });
 }
+/* CgSolver: iterations the host may run ahead of the last residual it has read (default 1; < 0 never waits);
+ * host_scalars != 0 selects the reference's synchronous loop */
+int pa_cg_set_lookahead(pa_solver *S, int lookahead, int host_scalars) {
+  return guarded([&] {
+    auto *k = dynamic_cast<CgSolver *>(S ? S->solver.get() : nullptr);
+    PA_REQUIRE(k, "not a CG solver");
+    k->SetLookahead(lookahead);
+    k->SetHostScalars(host_scalars != 0);
+  });
+}
 /* eigenvalue estimate of the Chebyshev smoother of multigrid level l >= 1 (plain Chebyshev levels only) */
 int pa_gmg_smoother_lambda_max(const pa_solver *S, int level, double *lambda_max) {
   return guarded([&] {
@@ -406,6 +434,8 @@ static void gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_int
       }
     };
     s->owned.push_back(coarse);
+    // a Krylov coarse solve inside the cycle must not stall the stream (see GeometricMultigridSolver's constructor)
+    if (auto *cg = dynamic_cast<CgSolver *>(coarse->solver.get())) cg->SetLookahead(-1);
     auto g = std::make_unique<GeometricMultigridSolver>(ctx->ctx, std::make_unique<Borrowed>(coarse->solver.get()),
                                                         Pv, cycle_it, smooth_it, cheby_order, sf_max, sf_min,
                                                         fourth != 0, G ? &Gv : nullptr);

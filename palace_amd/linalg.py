@@ -41,9 +41,17 @@ class Context:
     def __init__(self, stream=None):
         import torch
 
-        self.torch_stream = torch.cuda.current_stream() if stream is None else stream
         self.handle = C.c_void_p()
-        _lib.check(_L().pa_context_create(C.c_void_p(self.torch_stream.cuda_stream), C.byref(self.handle)))
+        if stream is None and torch.cuda.current_stream().cuda_stream == 0:
+            # PyTorch is on the legacy null stream: let the context create its own blocking stream (same ordering against
+            # the null stream, and recordable into HIP graphs)
+            _lib.check(_L().pa_context_create(None, C.byref(self.handle)))
+            raw = C.c_void_p()
+            _lib.check(_L().pa_context_stream(self.handle, C.byref(raw)))
+            self.torch_stream = torch.cuda.ExternalStream(raw.value)
+        else:
+            self.torch_stream = torch.cuda.current_stream() if stream is None else stream
+            _lib.check(_L().pa_context_create(C.c_void_p(self.torch_stream.cuda_stream), C.byref(self.handle)))
         self.rank, self.size = 0, 1
 
     def init_comm_from_torch_distributed(self):
@@ -254,6 +262,10 @@ class Solver:
         a, b = C.c_double(), C.c_double()
         _lib.check(_L().pa_dist_relaxation_lambda_max(self.handle, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_lookahead(self, lookahead=1, host_scalars=False):
+        _lib.check(_L().pa_cg_set_lookahead(self.handle, int(lookahead), int(bool(host_scalars))))
+        return self
 
     def gmg_lambda_max(self, level):
         v = C.c_double()

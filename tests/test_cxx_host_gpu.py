@@ -1,6 +1,8 @@
-"""The C++ host layer (palace_amd/csrc/linalg.hpp) used directly from a C++ program, as Palace would:
-build examples/cxx_host/solve.cpp with hipcc, run it, and compare with the same solve through the ctypes
-mirror."""
+"""The C++ host layer (palace_amd/csrc/{fem,ksp,linalg}.hpp) used directly from a C++ program, as Palace would: build
+examples/cxx_host/solve.cpp with hipcc -- a driver that goes from MFEM-style arrays through MaterialPropertyCoefficient,
+BilinearForm / integrators, FiniteElementSpaceHierarchy, MultigridOperator and KspSolver (linalg/ksp.cpp:27-333,
+fem/bilinearform.cpp:153-201) to the solved system without Python -- run it in the configurations of bench.py's PCG leg and
+compare iteration counts and the solution checksum with the same solve assembled through the ctypes mirror."""
 import os
 import re
 import shutil
@@ -14,40 +16,77 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
-def test_cxx_host_solve(tmp_path):
+@pytest.fixture(scope="module")
+def built(tmp_path_factory):
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    d = tmp_path_factory.mktemp("cxx_host")
+    exe, blob = str(d / "solve"), str(d / "problem.bin")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "examples", "cxx_host", "dump_problem.py"), blob, "3", "3", "6"])
+    libdir = os.path.join(ROOT, "palace_amd", "lib")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O2", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cxx_host", "solve.cpp"),
+                           "-L" + libdir, "-lpalace_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe, blob
+
+
+def _python_solve(aux, krylov, coarse):
     import torch
 
     from palace_amd import ceed, linalg
-    from palace_amd.fem.fespace import NDHexSpace
+    from palace_amd.fem.fespace import H1HexSpace, NDHexSpace
     from palace_amd.fem.mesh import ogrid_cylinder
 
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    exe, blob = str(tmp_path / "solve"), str(tmp_path / "problem.bin")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "examples", "cxx_host", "dump_problem.py"), blob, "2"])
-    libdir = os.path.join(ROOT, "palace_amd", "lib")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O2", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
-                           os.path.join(ROOT, "examples", "cxx_host", "solve.cpp"), "-L" + libdir, "-lpalace_amd",
-                           "-Wl,-rpath," + libdir, "-o", exe])
-    out = subprocess.check_output([exe, blob], text=True)
-    m = re.search(r"iterations (\d+)\s+converged (\d)\s+\|b - A x\| / \|b\| (\S+)\s+sum\(x\) (\S+)", out)
-    assert m, out
-    its, conv, res, sx = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
-    assert conv == 1 and res < 1e-8
-    # the same solve through the ctypes mirror
     ctx = linalg.Context()
-    mesh = ogrid_cylinder(2, 4)
-    nd = NDHexSpace(mesh, 2)
-    geom = ceed.GeomFactorData(mesh, 3)
+    mesh = ogrid_cylinder(3, 6)
+    orders = [1, 2, 3]
+    nds = [NDHexSpace(mesh, p) for p in orders]
+    geom = ceed.GeomFactorData(mesh, 4)
     mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
-    A = linalg.ParOperator(ctx, ceed.curlcurlmass_operator(geom, nd, mass, ceed.coefficient_context(3)), nd.ess_dofs(),
-                           linalg.DIAG_ONE)
-    K = linalg.cg(ctx, A, linalg.chebyshev(ctx, A, 4), rel_tol=1e-10, max_it=500)
-    ones = torch.ones(nd.ndofs, dtype=torch.float64, device="cuda")
+    fine = ceed.curlcurlmass_operator(geom, nds[-1], mass, ceed.coefficient_context(3))
+    local = [fine.coarsen(geom, s) for s in nds[:-1]] + [fine]
+    A = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE) for op, s in zip(local, nds)]
+    A[0] = linalg.AssembledParOperator(ctx, local[0].full_assemble_device(), nds[0].ess_dofs(), linalg.DIAG_ONE)
+    P = [linalg.Interp(ctx, a, b) for a, b in zip(nds[:-1], nds[1:])]
+    kw, keep = {}, []
+    if aux:
+        h1s = [H1HexSpace(mesh, p) for p in orders]
+        fine_h1 = ceed.diffusion_operator(geom, h1s[-1], mass)
+        loc_h1 = [fine_h1.coarsen(geom, s) for s in h1s[:-1]] + [fine_h1]
+        A_h1 = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE) for op, s in zip(loc_h1, h1s)]
+        G = [linalg.Gradient(ctx, h, n) for h, n in zip(h1s, nds)]
+        kw, keep = dict(A_aux=A_h1, G=G), [h1s, loc_h1]
+    if coarse == "pcg":
+        cs = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=1e-2, max_it=8)
+    else:
+        cs = linalg.chebyshev(ctx, A[0], 4)
+    B = linalg.gmg(ctx, A, P, cs, cheby_order=6, **kw)
+    if krylov == "cg":
+        K = linalg.cg(ctx, A[-1], B, rel_tol=1e-10, max_it=400)
+    else:
+        K = linalg.gmres(ctx, A[-1], B, rel_tol=1e-10, max_it=400, restart=400, flexible=True)
+    n = nds[-1].ndofs
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
     b = torch.empty_like(ones)
-    A.mult(ones, b)
-    b[torch.from_numpy(nd.ess_dofs().astype(np.int64)).cuda()] = 0.0
+    A[-1].mult(ones, b)
+    b[torch.from_numpy(nds[-1].ess_dofs().astype(np.int64)).cuda()] = 0.0
     x = torch.zeros_like(b)
     K.mult(b, x)
-    assert K.stats()["iterations"] == its
-    assert abs(float(x.sum()) - sx) < 1e-9 * abs(sx)
+    return n, K.stats()["iterations"], float(x.sum())
+
+
+@pytest.mark.parametrize("aux,krylov,coarse", [(0, "cg", "cheb"), (1, "cg", "pcg"), (1, "fgmres", "pcg")])
+def test_cxx_host_solve(built, aux, krylov, coarse):
+    exe, blob = built
+    out = subprocess.check_output([exe, blob, str(aux), krylov, coarse], text=True)
+    m = re.search(r"ndofs (\d+) .* iterations (\d+)\s+converged (\d)\s+NumTotalMult (\d+)\s+NumTotalMultIterations (\d+)\s+"
+                  r"\|b - A x\| / \|b\| (\S+)\s+sum\(x\) (\S+)", out)
+    assert m, out
+    n, its, conv, nmult, nmult_it = (int(m.group(i)) for i in range(1, 6))
+    res, sx = float(m.group(6)), float(m.group(7))
+    assert conv == 1 and res < 1e-8, out
+    assert nmult == 2 and nmult_it == 2 * its, out  # ksp.cpp:330-331: counters over both solves
+    n_py, its_py, sx_py = _python_solve(aux, krylov, coarse)
+    assert n == n_py and its == its_py, (out, its_py)
+    assert abs(sx - sx_py) < 1e-9 * abs(sx_py)

@@ -1,0 +1,86 @@
+"""Host-side pieces of the C++ front end (palace_amd/csrc/fem.hpp, ksp.hpp) against the numpy restatements the rest of
+the suite uses: Gauss-Legendre / Gauss-Lobatto points, Lagrange tables, MaterialPropertyCoefficient bookkeeping and the
+coefficient contexts (fem/libceed/coefficient.cpp:51-131), p-coarsening sequences (fem/multigrid.hpp:44-69).  Runs on CPU:
+tests/cpu/fem_host_check.cpp is built with hipcc (host code only) against the in-tree library."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dumped(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    lib = os.path.join(ROOT, "palace_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libpalace_amd.so")):
+        import __graft_entry__ as ge
+        ge.build()
+    exe = str(tmp_path_factory.mktemp("fem_host") / "fem_host_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpu", "fem_host_check.cpp"),
+                           "-L" + lib, "-lpalace_amd", "-Wl,-rpath," + lib, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    vals = {}
+    for line in out.stdout.splitlines():
+        k, *v = line.split()
+        if k.startswith("orders") or k == "q1d":
+            vals[k] = [int(t) for t in v]
+        else:
+            vals[k] = np.array([struct.unpack("<d", struct.pack("<Q", int(t, 16)))[0] for t in v])
+    return vals
+
+
+def test_point_sets_and_tables(dumped):
+    from palace_amd.fem.basis1d import gauss_legendre, gauss_lobatto, lagrange_eval
+
+    for n in range(1, 7):
+        x, w = gauss_legendre(n)
+        assert np.allclose(dumped[f"gl_x{n}"], x, rtol=0, atol=2e-16) and np.allclose(dumped[f"gl_w{n}"], w, rtol=0, atol=1e-15)
+        if n >= 2:
+            assert np.allclose(dumped[f"gll{n}"], gauss_lobatto(n), rtol=0, atol=3e-16)
+    B, G = lagrange_eval(gauss_lobatto(4), gauss_legendre(4)[0])
+    assert np.allclose(dumped["Bc3"], B.reshape(-1), rtol=0, atol=1e-15)
+    assert np.allclose(dumped["Gc3"], G.reshape(-1), rtol=0, atol=2e-14)
+
+
+def test_coefficient_contexts(dumped):
+    from palace_amd.ceed import coefficient_context
+
+    def same(name, ref):
+        got = dumped[name]
+        assert got.size == ref.size, (name, got.size, ref.size)
+        assert np.array_equal(got.view(np.uint64) & 0xFFFFFFFF, ref.view(np.uint64) & 0xFFFFFFFF) or np.allclose(got, ref, rtol=1e-15, atol=0), name
+        # integer slots carry the int in the low half, real slots must agree to rounding
+        assert np.allclose(np.nan_to_num(got), np.nan_to_num(ref), rtol=1e-15, atol=1e-300), name
+
+    M = np.array([2.0, 0.1, 0.2, 0.3, 3.0, 0.4, 0.5, 0.6, 4.0]).reshape(3, 3).T  # from column-major
+    same("ctx_identity", coefficient_context(3, a=1.5))
+    same("ctx_scalar", coefficient_context(3, attr_mat=[0, -1, 0], mat_coeff=[np.array([2.08])]))
+    mixed = [2.08 * np.eye(3), 0.5 * M]
+    same("ctx_mixed", coefficient_context(3, attr_mat=[0, 1, 0], mat_coeff=mixed))
+    same("ctx_mixed_t", coefficient_context(3, attr_mat=[0, 1, 0], mat_coeff=[m.T for m in mixed], a=2.0))
+    upd = [(2.08 - 1.0) * np.eye(3), 0.5 * M]
+    same("ctx_updated", coefficient_context(3, attr_mat=[0, 1, 0], mat_coeff=upd))
+    same("ctx_restricted", coefficient_context(3, attr_mat=[-1, 0, 1], mat_coeff=[upd[1], upd[0]]))
+    pair = np.concatenate([coefficient_context(1, attr_mat=[0, 0, 0], mat_coeff=[np.array([0.7])]),
+                           coefficient_context(3, attr_mat=[-1, 0, 1], mat_coeff=[upd[1], upd[0]])])
+    same("ctx_pair", pair)
+    nrm = np.array([0.0, 0.6, 0.8])
+    same("ctx_normal", coefficient_context(1, attr_mat=[-1, 0, 1], mat_coeff=[np.array([nrm @ upd[1] @ nrm]), np.array([nrm @ upd[0] @ nrm])]))
+
+
+def test_coarsening_sequences_and_quadrature(dumped):
+    from palace_amd.fem.partition import levels_for
+
+    for p in range(1, 7):
+        assert dumped[f"orders_log{p}"] == levels_for(p)
+        assert dumped[f"orders_lin{p}"] == list(range(1, p + 1))
+    assert dumped["q1d"] == [4]  # order-3 solution: 2p = 6 -> 4 Gauss-Legendre points per direction

@@ -237,6 +237,82 @@ def test_gmg_vcycle_and_pcg(prob):
     assert _rel(x, xo) < 1e-6
 
 
+def _pcg_gmg(prob, coarse, **kw):
+    if coarse == "cg":  # a Krylov coarse solve (runs without ever waiting for the host inside the cycle)
+        cs = linalg.cg(prob.ctx, prob.A[0], linalg.jacobi(prob.ctx, prob.A[0]), rel_tol=1e-2, max_it=8)
+    else:
+        cs = linalg.chebyshev(prob.ctx, prob.A[0], 4)
+    B = linalg.gmg(prob.ctx, prob.A, prob.P, cs, cheby_order=6)
+    return linalg.cg(prob.ctx, prob.A[-1], B, **kw), B
+
+
+@pytest.mark.parametrize("coarse", ["chebyshev", "cg"])
+def test_pcg_device_scalars_equal_host_loop(prob, coarse):
+    """CgSolver with the recurrence scalars on the device (no host round trip, the iteration replayed as a HIP graph,
+    the host enqueuing ahead of the residuals it has seen) against the synchronous loop of iterative.cpp:360-486:
+    same iteration count, residuals and iterate to rounding (1e-11), and bit-identical results among all lookahead
+    settings, including the solves that converge while iterations are still queued (those must not touch x any more)."""
+    n = prob.spaces[-1].ndofs
+    b = prob.oA[-1].mult(np.ones(n))
+    b[prob.spaces[-1].ess_dofs()] = 0.0
+    ref, keep = _pcg_gmg(prob, coarse, rel_tol=1e-8, max_it=200)
+    ref.set_lookahead(0, host_scalars=True)
+    x_ref = ref.mult(_dev(b), _new(n)).cpu().numpy()
+    st_ref = ref.stats()
+    assert st_ref["converged"] and 3 < st_ref["iterations"] < 100
+    x_dev = st_dev = None
+    for look in (0, 1, 3, -1):
+        K, keep2 = _pcg_gmg(prob, coarse, rel_tol=1e-8, max_it=200 if look >= 0 else st_ref["iterations"] + 7)
+        K.set_lookahead(look)
+        for rep in range(3):  # direct run, recording run, replay
+            x = K.mult(_dev(b), _new(n)).cpu().numpy()
+            st = K.stats()
+            # against the host loop: alpha = beta / (Ap, p) is a device division instead of a host one (last-bit effects)
+            assert st["converged"] and st["iterations"] == st_ref["iterations"], (look, rep, st, st_ref)
+            assert abs(st["final_res"] - st_ref["final_res"]) < 1e-9 * st_ref["final_res"]
+            assert st["initial_res"] == st_ref["initial_res"]
+            assert _rel(x, x_ref) < 1e-11, (look, rep, _rel(x, x_ref))
+            # among the device forms: the very same bits, whatever was still queued when the solve converged
+            if x_dev is None:
+                x_dev, st_dev = x, st
+            assert np.array_equal(x, x_dev) and st == st_dev, (look, rep)
+    # initial guess: residual measured against the right-hand side (iterative.cpp:407-419)
+    x0 = 0.5 * x_ref
+    xa = ref.mult(_dev(b), _dev(x0), initial_guess=True).cpu().numpy()
+    K, keep2 = _pcg_gmg(prob, coarse, rel_tol=1e-8, max_it=200)
+    xb = K.mult(_dev(b), _dev(x0), initial_guess=True).cpu().numpy()
+    assert K.stats()["iterations"] == ref.stats()["iterations"] and _rel(xb, xa) < 1e-11
+    assert abs(K.stats()["initial_res"] - ref.stats()["initial_res"]) < 1e-13 * ref.stats()["initial_res"]
+
+
+def test_pcg_not_positive_definite_is_reported(prob):
+    """iterative.cpp:402,445,462: a non-finite (Br, r) / (Ap, p) ends the solve with an error, also when the scalars
+    never visit the host inside the loop."""
+    n = prob.spaces[1].ndofs
+    K = linalg.cg(prob.ctx, prob.A[1], linalg.jacobi(prob.ctx, prob.A[1]), rel_tol=1e-8, max_it=50)
+    b = np.ones(n)
+    b[3] = np.inf
+    with pytest.raises(Exception, match="positive definite"):
+        K.mult(_dev(b), _new(n))
+
+
+def test_gmg_graph_replay_matches_direct_application(prob):
+    """The V-cycle recorded as a HIP graph (second application on) gives the bits of the direct run, for any input / output
+    vectors, and GMRES preconditioned with it takes the iterations it takes without graphs."""
+    n = prob.spaces[-1].ndofs
+    B = linalg.gmg(prob.ctx, prob.A, prob.P, linalg.chebyshev(prob.ctx, prob.A[0], 4), cheby_order=6)
+    rng = np.random.default_rng(11)
+    outs = []
+    for rep in range(4):
+        r = rng.uniform(-1, 1, n)
+        r[prob.spaces[-1].ess_dofs()] = 0.0
+        z = B.mult(_dev(r), _new(n)).cpu().numpy()
+        outs.append((r, z))
+    B2 = linalg.gmg(prob.ctx, prob.A, prob.P, linalg.chebyshev(prob.ctx, prob.A[0], 4), cheby_order=6)
+    for r, z in reversed(outs):  # a fresh solver: different direct / replay split for the same inputs
+        assert np.array_equal(B2.mult(_dev(r), _new(n)).cpu().numpy(), z)
+
+
 @pytest.mark.parametrize("offset", [0, 1])
 @pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 100003])
 def test_vector_kernels_any_size_and_alignment(n, offset):
