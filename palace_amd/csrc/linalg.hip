@@ -118,6 +118,7 @@ bool StreamGraph::Capture(const Context &c, const std::function<void()> &body) {
 }
 void StreamGraph::Run(const Context &c, const std::vector<const void *> &key, const std::function<void()> &body) {
   if (!c.stream) return body();  // the null stream cannot be recorded
+  if (c.comm && c.comm->Size() > 1) return body();  // collectives stay outside recordings (RCCL inside a capture is untested here)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(c.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return body();  // part of an enclosing recording (the V-cycle inside a PCG iteration)

@@ -437,6 +437,8 @@ void launch_h1_hex_qdata(SubOp &so, hipStream_t s) {
 struct H1DiagArgs {
   int ne, p, q1;
   const int32_t *lidx;
+  const uint16_t *perm;  // E-vector form (default): entry m of the element in sorted order, see nd_hex_diag_kernel
+  double *ye;
   const double *geom;
   double *y;
   CoeffDev c_mass, c_diff;
@@ -472,7 +474,8 @@ __global__ void h1_hex_diag_kernel(const H1DiagArgs a) {
     }
   }
   __syncthreads();
-  for (int l = threadIdx.x; l < P; l += blockDim.x) {
+  for (int m = threadIdx.x; m < P; m += blockDim.x) {
+    const int l = a.ye ? a.perm[(size_t)e * P + m] : m;
     const int i = l % NC, j = (l / NC) % NC, k = l / (NC * NC);
     double acc = 0.0;
     for (int qz = 0; qz < Q1; qz++)
@@ -486,8 +489,10 @@ __global__ void h1_hex_diag_kernel(const H1DiagArgs a) {
           for (int r2 = 0; r2 < 3; r2++)
             for (int c2 = 0; c2 < 3; c2++) acc += gr[r2] * Mg[9 * q + r2 + 3 * c2] * gr[c2];
         }
-    // dofs of one element are distinct, different elements race => atomic
-    atomicAdd(&a.y[a.lidx[(size_t)e * P + l]], acc);
+    if (a.ye)
+      a.ye[(size_t)e * P + m] = acc;  // summed per dof by et_gather_kernel (fixed order)
+    else
+      atomicAdd(&a.y[a.lidx[(size_t)e * P + l]], acc);  // dofs of one element are distinct, different elements race
   }
 }
 
@@ -495,6 +500,7 @@ void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s) {
   H1DiagArgs a;
   a.ne = so.ne, a.p = so.p, a.q1 = so.q1d;
   a.lidx = so.d_lidx;
+  a.perm = so.d_perm, a.ye = (so.d_tptr && so.d_perm) ? so.d_ye : nullptr;
   a.geom = so.geom->d_geom;
   a.y = diag;
   const int nc = so.p + 1;
@@ -509,6 +515,7 @@ void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s) {
   const size_t lds = sizeof(double) * 10 * (size_t)so.Q;
   hipLaunchKernelGGL(h1_hex_diag_kernel, dim3(so.ne), dim3(128), lds, s, a);
   PA_HIP(hipGetLastError());
+  if (a.ye) launch_et_gather_raw(so.lsize, so.d_tptr, so.d_tent, so.d_ye, diag, true, s);
 }
 
 }  // namespace pa

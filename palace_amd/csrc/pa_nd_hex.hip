@@ -628,6 +628,10 @@ void launch_nd_hex_metric(SubOp &so, hipStream_t s) {
 struct NDDiagArgs {
   int ne, p, q1;
   const int32_t *lidx;
+  // E-vector form (default): entry m of the element in sorted order, summed per dof by et_gather_kernel in a fixed order
+  const int32_t *sidx;
+  const uint16_t *perm;
+  double *ye;
   const double *geom;
   double *y;
   CoeffDev c_mass, c_curl;
@@ -664,7 +668,8 @@ __global__ void nd_hex_diag_kernel(const NDDiagArgs a) {
     }
   }
   __syncthreads();
-  for (int l = threadIdx.x; l < P; l += blockDim.x) {
+  for (int m = threadIdx.x; m < P; m += blockDim.x) {
+    const int l = a.ye ? a.perm[(size_t)e * P + m] : m;
     const int C = l / (P1 * NC * NC);
     const int r = l - C * P1 * NC * NC;
     const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
@@ -691,8 +696,12 @@ __global__ void nd_hex_diag_kernel(const NDDiagArgs a) {
           for (int r2 = 0; r2 < 3; r2++)
             for (int c2 = 0; c2 < 3; c2++) acc += cv[r2] * Mc[9 * q + r2 + 3 * c2] * cv[c2];
         }
-    const int s = a.lidx[(size_t)e * P + l];
-    unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], acc);
+    if (a.ye) {  // the gather applies the orientation sign of the entry: the diagonal does not have one
+      a.ye[(size_t)e * P + m] = a.sidx[(size_t)e * P + m] >= 0 ? acc : -acc;
+    } else {
+      const int s = a.lidx[(size_t)e * P + l];
+      unsafeAtomicAdd(&a.y[s >= 0 ? s : -1 - s], acc);
+    }
   }
 }
 
@@ -700,6 +709,7 @@ void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s) {
   NDDiagArgs a;
   a.ne = so.ne, a.p = so.p, a.q1 = so.q1d;
   a.lidx = so.d_lidx;
+  a.sidx = so.d_sidx, a.perm = so.d_perm, a.ye = (so.d_tptr && so.d_sidx && so.d_perm) ? so.d_ye : nullptr;
   a.geom = so.geom->d_geom;
   a.y = diag;
   const int nc = so.p + 1;
@@ -714,6 +724,9 @@ void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s) {
   const size_t lds = sizeof(double) * 18 * (size_t)so.Q;
   hipLaunchKernelGGL(nd_hex_diag_kernel, dim3(so.ne), dim3(128), lds, s, a);
   PA_HIP(hipGetLastError());
+  // diag += sum of the element diagonals, dof by dof in a fixed order (reproducible: the smoothers' eigenvalue
+  // estimates and with them the iterates do not depend on the run)
+  if (a.ye) launch_et_gather_raw(so.lsize, so.d_tptr, so.d_tent, so.d_ye, diag, true, s);
 }
 
 }  // namespace pa

@@ -270,7 +270,7 @@ def test_pcg_device_scalars_equal_host_loop(prob, coarse):
             # against the host loop: alpha = beta / (Ap, p) is a device division instead of a host one (last-bit effects)
             assert st["converged"] and st["iterations"] == st_ref["iterations"], (look, rep, st, st_ref)
             assert abs(st["final_res"] - st_ref["final_res"]) < 1e-9 * st_ref["final_res"]
-            assert st["initial_res"] == st_ref["initial_res"]
+            assert abs(st["initial_res"] - st_ref["initial_res"]) < 1e-14 * st_ref["initial_res"]  # device sqrt
             assert _rel(x, x_ref) < 1e-11, (look, rep, _rel(x, x_ref))
             # among the device forms: the very same bits, whatever was still queued when the solve converged
             if x_dev is None:
