@@ -9,7 +9,9 @@
 //
 //   hipcc --offload-arch=gfx950 -std=c++17 -I<repo>/palace_amd/csrc -I<repo>/include solve.cpp -L<repo>/palace_amd/lib
 //         -lpalace_amd -Wl,-rpath,<repo>/palace_amd/lib -o solve
-//   ./solve problem.bin [aux=0|1] [krylov=cg|fgmres] [coarse=cheb|pcg|jacobi]
+//   ./solve problem.bin [aux=0|1] [krylov=cg|fgmres|cfgmres] [coarse=cheb|pcg|jacobi]
+// krylov = cfgmres solves the complex (driven-style) system (K - w^2 eps M) x + i w sigma M x = b with ComplexParOperator,
+// ComplexKspSolver (FGMRES) and the real p-multigrid of K + w^2 eps M as the preconditioner on both parts.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -101,6 +103,44 @@ int main(int argc, char **argv) {
     }
 
     config::LinearSolverData linear;
+    if (krylov == "cfgmres") {
+      // A(w) = K - w^2 M(eps) + i w M(sigma): one real operator per part (SpaceOperator::GetSystemMatrix sums the terms into
+      // one K + M sub-operator per part the same way), preconditioner: p-multigrid of the positive-shifted real part
+      const double w = 0.8;
+      MaterialPropertyCoefficient neg_eps(1), sigma(1);
+      neg_eps.AddMaterialProperty(1, 2.08, -w * w);
+      sigma.AddMaterialProperty(1, 0.35, w);
+      BilinearForm ar(nd_fespaces.GetFinestFESpace()), ai(nd_fespaces.GetFinestFESpace());
+      ar.AddDomainIntegrator<CurlCurlMassIntegrator>(muinv, neg_eps);
+      ai.AddDomainIntegrator<VectorFEMassIntegrator>(sigma);
+      auto Ar = ar.PartialAssemble(), Ai = ai.PartialAssemble();
+      const auto &fes = nd_fespaces.GetFinestFESpace();
+      ComplexParOperator Ac(ctx, Ar.get(), Ai.get(), fes.GetTrueVSize(), fes.GetHalo());
+      Ac.SetEssentialTrueDofs(fes.GetEssentialTrueDofs().data(), (int)fes.GetEssentialTrueDofs().size(),
+                              ParOperator::DiagonalPolicy::DIAG_ONE);
+      linear.krylov_solver = KrylovSolver::FGMRES;
+      linear.type = coarse == "pcg" ? LinearSolver::JACOBI_PCG : LinearSolver::CHEBYSHEV_JACOBI;
+      linear.tol = 1e-10, linear.max_it = 400, linear.mg_smooth_aux = aux ? 1 : 0, linear.initial_guess = 0;
+      linear.SetDefaults(order, false);
+      linear.mg_smooth_aux = aux ? 1 : 0;
+      ComplexKspSolver cksp(linear, 0, nd_fespaces, aux ? &h1_fespaces : nullptr);
+      cksp.SetOperators(Ac, *A);
+      const int n = Ac.Height();
+      ComplexVector ones(n), rhs(n), x(n), res(n);
+      linalg::Fill(ctx, ones.Real(), 1.0), linalg::Fill(ctx, ones.Imag(), -0.5);
+      Ac.Mult(ones, rhs);
+      linalg::SetSubVector(ctx, rhs, Ac.GetEssentialTrueDofs(), Ac.NumEssentialTrueDofs(), 0.0);
+      cksp.Mult(rhs, x);
+      Ac.Mult(x, res);
+      linalg::AXPBY(ctx, 1.0, rhs, -1.0, res);
+      const auto sx = linalg::Dot(ctx, x, ones);
+      std::printf("cxx_host: order %d  levels %d  ndofs %d  aux %d  krylov %s  coarse %s  iterations %d  converged %d  "
+                  "NumTotalMult %d  NumTotalMultIterations %d  |b - A x| / |b| %.3e  sum(x) %.12e %.12e\n",
+                  order, nlev, n, (int)aux, krylov.c_str(), coarse.c_str(), cksp.GetKrylovSolver().GetNumIterations(),
+                  (int)cksp.GetKrylovSolver().GetConverged(), cksp.NumTotalMult(), cksp.NumTotalMultIterations(),
+                  linalg::Norml2(ctx, res) / linalg::Norml2(ctx, rhs), sx.real(), sx.imag());
+      return 0;
+    }
     linear.krylov_solver = krylov == "fgmres" ? KrylovSolver::FGMRES : KrylovSolver::CG;
     linear.type = coarse == "pcg" ? LinearSolver::JACOBI_PCG : coarse == "jacobi" ? LinearSolver::JACOBI : LinearSolver::CHEBYSHEV_JACOBI;
     linear.tol = 1e-10, linear.max_it = 400;

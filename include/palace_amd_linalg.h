@@ -21,6 +21,7 @@ typedef struct pa_par_op pa_par_op;   /* palace::ParOperator, linalg/rap.cpp    
 typedef struct pa_interp pa_interp;   /* p-prolongation / discrete gradient, fem/bilinearform.cpp:203-282 */
 typedef struct pa_solver pa_solver;   /* palace::Solver<Operator>, linalg/solver.hpp     */
 typedef struct pa_csolver pa_csolver; /* Krylov solver on ComplexOperator (ComplexVector = two real vectors) */
+typedef struct pa_complex_par_op pa_complex_par_op; /* palace::ComplexParOperator, linalg/rap.hpp:124-221 */
 
 /* --- context: everything created from it is enqueued on `stream` (a hipStream_t) -------------
  * stream == NULL: the context creates a stream of its own with the default (blocking) flag, which is ordered against
@@ -88,6 +89,18 @@ int pa_vec_axpby(pa_context *ctx, double a, const double *x, double b, double *y
  * Time it with events on the context's stream; `scratch` is any device buffer of >= 1 double (never written). */
 int pa_bench_mfma_f64(pa_context *ctx, int iters, int n_blocks, double *scratch, double *flops_per_launch);
 int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed);
+/* ComplexVector members (linalg/vector.hpp:95-146, vector.cpp:172-460) on split real / imaginary device arrays.
+ * op: 0 x *= a | 1 x = |x| | 2 x = 1 ./ x | 3 x = conj(x) | 4 y = a x + b y | 5 z = a x + b y + c z |
+ * 6 out[0..1] = x^T y (no conjugate; global).  coef: the complex coefficients a, b, c as (re, im) pairs (NULL: ones). */
+int pa_cvec_op(pa_context *ctx, int op, int n, const double *coef, double *xr, double *xi, double *yr, double *yi, double *zr,
+               double *zi, double *out);
+/* ComplexVector::SetBlocks: x = [s_0 y_0; s_1 y_1; ...] (s: (re, im) pairs, NULL = ones) */
+int pa_cvec_set_blocks(pa_context *ctx, double *xr, double *xi, int n, int nblocks, const double *const *yr,
+                       const double *const *yi, const int *sizes, const double *s);
+/* DiagonalOperator / ComplexDiagonalOperator (linalg/operator.hpp:354-423): y (+)= a op(diag(d)) x; mode 0 N, 1 T, 2 H;
+ * di == xi == yi == NULL selects the real operator */
+int pa_diag_op_apply(pa_context *ctx, int n, const double *dr, const double *di, const double *xr, const double *xi, double *yr,
+                     double *yi, double ar, double ai, int mode, int add);
 
 /* --- solvers --------------------------------------------------------------------------------- */
 /* ChebyshevSmoother / ChebyshevSmoother1stKind (linalg/chebyshev.cpp); SetOperator(A) is done here:
@@ -95,6 +108,10 @@ int pa_vec_set_random(pa_context *ctx, double *x, int n, uint64_t seed);
 int pa_chebyshev_create(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max,
                         int fourth_kind, pa_solver **S);
 int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max);
+/* ProductOperator / ComplexProductOperator (linalg/operator.hpp:270-352): y (+)= a op(A B) x; mode 0 N, 1 T, 2 H */
+int pa_product_op_apply(pa_par_op *A, pa_par_op *B, const double *x, double *y, int transpose, double a, int add);
+int pa_complex_product_op_apply(pa_complex_par_op *A, pa_complex_par_op *B, const double *xr, const double *xi, double *yr,
+                                double *yi, int mode, double ar, double ai, int add);
 /* CgSolver execution mode.  By default the scalars of the recurrence stay on the device (no host round trip per
  * iteration; an iteration is replayed as a HIP graph) and the host enqueues `lookahead` iterations beyond the last
  * residual it has read; iterates and iteration counts equal those of the synchronous loop of iterative.cpp:360-486,
@@ -174,7 +191,6 @@ void pa_csolver_destroy(pa_csolver *S);
  *     `policy`, the imaginary part DIAG_ZERO).  mode 0 / 1 / 2 = A / A^T / A^H (Mult, MultTranspose,
  *     MultHermitianTranspose); add != 0 is the AddMult* form y += a op(A) x with complex a.  `local_mult` applies the
  *     local ComplexWrapperOperator (linalg/operator.cpp:58-413) on L-vectors. */
-typedef struct pa_complex_par_op pa_complex_par_op;
 int pa_complex_par_op_create(pa_context *ctx, pa_op *Ar, pa_op *Ai, int n_true, pa_halo *halo, pa_complex_par_op **A);
 int pa_complex_par_op_set_essential(pa_complex_par_op *A, const int32_t *ess, int n_ess, int policy);
 int pa_complex_par_op_mult(pa_complex_par_op *A, int mode, int add, double a_re, double a_im, const double *xr,

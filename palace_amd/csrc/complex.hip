@@ -54,6 +54,69 @@ __global__ void k_cdot_final(const double *__restrict__ partial, int nb, double 
     out[0] = a, out[1] = b;
   }
 }
+// the same for x^T y: (xr.yr - xi.yi, xi.yr + xr.yi)
+__global__ void k_ctdot_partial(const double *__restrict__ xr, const double *__restrict__ xi,
+                                const double *__restrict__ yr, const double *__restrict__ yi, long long n,
+                                double *__restrict__ partial) {
+  __shared__ double pr[kB / 64], pi[kB / 64];
+  double sr = 0.0, si = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double a = xr[i], b = xi[i], c = yr[i], d = yi[i];
+    sr += a * c - b * d;
+    si += b * c + a * d;
+  }
+  sr = wsum(sr), si = wsum(si);
+  if ((threadIdx.x & 63) == 0) pr[threadIdx.x >> 6] = sr, pi[threadIdx.x >> 6] = si;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < kB / 64; i++) a += pr[i], b += pi[i];
+    partial[2 * blockIdx.x] = a, partial[2 * blockIdx.x + 1] = b;
+  }
+}
+// z = a x + b y + c z with complex coefficients; HAS_Y = false: z = a x + c z
+template <bool HAS_Y>
+__global__ void k_caxpbypcz(double ar, double ai, const double *__restrict__ xr, const double *__restrict__ xi, double br,
+                            double bi, const double *__restrict__ yr, const double *__restrict__ yi, double cr, double ci,
+                            double *__restrict__ zr, double *__restrict__ zi, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double x0 = xr[i], x1 = xi[i], z0 = zr[i], z1 = zi[i];
+    double r = ar * x0 - ai * x1 + cr * z0 - ci * z1, m = ai * x0 + ar * x1 + ci * z0 + cr * z1;
+    if (HAS_Y) {
+      const double y0 = yr[i], y1 = yi[i];
+      r += br * y0 - bi * y1, m += bi * y0 + br * y1;
+    }
+    zr[i] = r, zi[i] = m;
+  }
+}
+// x = |x| ; x = 1 ./ x ; x = s y (complex s) ; y (+)= a d .* x with d optionally conjugated
+__global__ void k_cabs(double *__restrict__ xr, double *__restrict__ xi, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    xr[i] = sqrt(xr[i] * xr[i] + xi[i] * xi[i]), xi[i] = 0.0;
+}
+__global__ void k_crecip(double *__restrict__ xr, double *__restrict__ xi, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double a = xr[i], b = xi[i], s = 1.0 / (a * a + b * b);
+    xr[i] = a * s, xi[i] = -b * s;
+  }
+}
+__global__ void k_cset_scaled(double sr, double si, const double *__restrict__ yr, const double *__restrict__ yi,
+                              double *__restrict__ xr, double *__restrict__ xi, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double a = yr[i], b = yi[i];
+    xr[i] = sr * a - si * b, xi[i] = si * a + sr * b;
+  }
+}
+__global__ void k_cdiag(double ar, double ai, const double *__restrict__ dr, const double *__restrict__ di, double sgn,
+                        const double *__restrict__ xr, const double *__restrict__ xi, double *__restrict__ yr,
+                        double *__restrict__ yi, int add, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double p = dr[i], q = sgn * di[i], a = xr[i], b = xi[i];
+    const double tr = p * a - q * b, ti = q * a + p * b;  // d .* x
+    const double r = ar * tr - ai * ti, m = ai * tr + ar * ti;
+    yr[i] = add ? yr[i] + r : r, yi[i] = add ? yi[i] + m : m;
+  }
+}
 // y += alpha x (complex alpha)
 __global__ void k_caxpy(double ar, double ai, const double *__restrict__ xr, const double *__restrict__ xi,
                         double *__restrict__ yr, double *__restrict__ yi, long long n) {
@@ -123,6 +186,65 @@ void SetSubVector(const Context &c, ComplexVector &x, const int32_t *d_rows, int
   SetSubVector(c, x.Imag(), d_rows, nrows, y.Imag());
 }
 void Conj(const Context &c, ComplexVector &x) { Scale(c, -1.0, x.Imag()); }
+std::complex<double> TransposeDot(const Context &c, const ComplexVector &x, const ComplexVector &y) {
+  PA_REQUIRE(x.Size() == y.Size(), "size mismatch in complex TransposeDot");
+  StreamGraph::RequireNotRecording("linalg::TransposeDot");
+  const CScratch s = cscratch(c);
+  const int nb = grid(x.Size());
+  hipLaunchKernelGGL(k_ctdot_partial, dim3(nb), dim3(kB), 0, c.stream, x.Real().Data(), x.Imag().Data(),
+                     y.Real().Data(), y.Imag().Data(), (long long)x.Size(), s.d);
+  hipLaunchKernelGGL(k_cdot_final, dim3(1), dim3(kB), 0, c.stream, s.d, nb, s.d + 2 * kMaxB);
+  PA_HIP(hipGetLastError());
+  if (c.comm) c.comm->AllReduceSum(s.d + 2 * kMaxB, 2, c.stream);
+  PA_HIP(hipMemcpyAsync(s.h, s.d + 2 * kMaxB, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  PA_HIP(hipStreamSynchronize(c.stream));
+  return {s.h[0], s.h[1]};
+}
+void Scale(const Context &c, std::complex<double> s, ComplexVector &x) {
+  if (s.imag() == 0.0) return Scale(c, s.real(), x);
+  hipLaunchKernelGGL(k_cset_scaled, dim3(grid(x.Size())), dim3(kB), 0, c.stream, s.real(), s.imag(), x.Real().Data(),
+                     x.Imag().Data(), x.Real().Data(), x.Imag().Data(), (long long)x.Size());
+  PA_HIP(hipGetLastError());
+}
+void Abs(const Context &c, ComplexVector &x) {
+  hipLaunchKernelGGL(k_cabs, dim3(grid(x.Size())), dim3(kB), 0, c.stream, x.Real().Data(), x.Imag().Data(), (long long)x.Size());
+  PA_HIP(hipGetLastError());
+}
+void Reciprocal(const Context &c, ComplexVector &x) {
+  hipLaunchKernelGGL(k_crecip, dim3(grid(x.Size())), dim3(kB), 0, c.stream, x.Real().Data(), x.Imag().Data(), (long long)x.Size());
+  PA_HIP(hipGetLastError());
+}
+void AXPBY(const Context &c, std::complex<double> alpha, const ComplexVector &x, std::complex<double> beta, ComplexVector &y) {
+  PA_REQUIRE(x.Size() == y.Size(), "size mismatch in complex AXPBY");
+  hipLaunchKernelGGL(k_caxpbypcz<false>, dim3(grid(x.Size())), dim3(kB), 0, c.stream, alpha.real(), alpha.imag(),
+                     x.Real().Data(), x.Imag().Data(), 0.0, 0.0, (const double *)nullptr, (const double *)nullptr, beta.real(),
+                     beta.imag(), y.Real().Data(), y.Imag().Data(), (long long)x.Size());
+  PA_HIP(hipGetLastError());
+}
+void AXPBYPCZ(const Context &c, std::complex<double> alpha, const ComplexVector &x, std::complex<double> beta,
+              const ComplexVector &y, std::complex<double> gamma, ComplexVector &z) {
+  PA_REQUIRE(x.Size() == y.Size() && x.Size() == z.Size(), "size mismatch in complex AXPBYPCZ");
+  hipLaunchKernelGGL(k_caxpbypcz<true>, dim3(grid(x.Size())), dim3(kB), 0, c.stream, alpha.real(), alpha.imag(),
+                     x.Real().Data(), x.Imag().Data(), beta.real(), beta.imag(), y.Real().Data(), y.Imag().Data(), gamma.real(),
+                     gamma.imag(), z.Real().Data(), z.Imag().Data(), (long long)x.Size());
+  PA_HIP(hipGetLastError());
+}
+void SetBlocks(const Context &c, ComplexVector &x, const std::vector<const ComplexVector *> &y,
+               const std::vector<std::complex<double>> &s) {
+  PA_REQUIRE(s.empty() || y.size() == s.size(), "Mismatch in dimension of vector blocks and scaling coefficients!");
+  long long off = 0;
+  for (size_t b = 0; b < y.size(); b++) {
+    PA_REQUIRE(y[b] && off + y[b]->Size() <= x.Size() && (b + 1 < y.size() || off + y[b]->Size() == x.Size()),
+               "Mismatch between sum of block dimensions and parent vector dimension!");
+    const std::complex<double> sb = s.empty() ? 1.0 : s[b];
+    const long long n = y[b]->Size();
+    if (n)
+      hipLaunchKernelGGL(k_cset_scaled, dim3(grid(n)), dim3(kB), 0, c.stream, sb.real(), sb.imag(), y[b]->Real().Data(),
+                         y[b]->Imag().Data(), x.Real().Data() + off, x.Imag().Data() + off, n);
+    off += n;
+  }
+  PA_HIP(hipGetLastError());
+}
 void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
                          std::complex<double> *H, int m, const Operator *weight) {
   PA_REQUIRE(m >= 0 && (size_t)m <= V.size(), "Out of bounds number of columns for orthogonalization!");
@@ -170,6 +292,14 @@ void ComplexOperator::AddMultTranspose(const ComplexVector &, ComplexVector &, s
 void ComplexOperator::AddMultHermitianTranspose(const ComplexVector &, ComplexVector &, std::complex<double>) const { throw pa::Error("Base class ComplexOperator does not implement AddMultHermitianTranspose!"); }
 
 // ---- ComplexWrapperOperator (operator.cpp:58-413) ------------------------------------------------------------------
+void ComplexDiagonalOperator::Apply(const ComplexVector &x, ComplexVector &y, std::complex<double> a, bool add, bool conj) const {
+  PA_REQUIRE(x.Size() == d_.Size() && y.Size() == d_.Size(), "size mismatch in ComplexDiagonalOperator");
+  hipLaunchKernelGGL(k_cdiag, dim3(grid(x.Size())), dim3(kB), 0, ctx_->stream, a.real(), a.imag(), d_.Real().Data(),
+                     d_.Imag().Data(), conj ? -1.0 : 1.0, x.Real().Data(), x.Imag().Data(), y.Real().Data(), y.Imag().Data(),
+                     add ? 1 : 0, (long long)x.Size());
+  PA_HIP(hipGetLastError());
+}
+
 ComplexWrapperOperator::ComplexWrapperOperator(const Context &ctx, const Operator *Ar, const Operator *Ai)
     : ctx_(&ctx), Ar_(Ar), Ai_(Ai) {
   PA_REQUIRE(Ar || Ai, "Cannot construct ComplexWrapperOperator from an empty matrix!");

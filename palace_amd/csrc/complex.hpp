@@ -41,6 +41,18 @@ void SetSubVector(const Context &c, ComplexVector &x, const int32_t *d_rows, int
 void SetSubVector(const Context &c, ComplexVector &x, const int32_t *d_rows, int nrows, const ComplexVector &y);
 // x = conj(x) (vector.cpp Conj)
 void Conj(const Context &c, ComplexVector &x);
+// the remaining members of the reference's ComplexVector (linalg/vector.hpp:95-146, vector.cpp:172-460) as free functions:
+// x^T y (no conjugate), x *= s, x = |x| (imaginary part zero), x = 1 ./ x, y = alpha x + beta y,
+// z = alpha x + beta y + gamma z, x = [s_0 y_0; s_1 y_1; ...] (blocks laid end to end)
+std::complex<double> TransposeDot(const Context &c, const ComplexVector &x, const ComplexVector &y);
+void Scale(const Context &c, std::complex<double> s, ComplexVector &x);
+void Abs(const Context &c, ComplexVector &x);
+void Reciprocal(const Context &c, ComplexVector &x);
+void AXPBY(const Context &c, std::complex<double> alpha, const ComplexVector &x, std::complex<double> beta, ComplexVector &y);
+void AXPBYPCZ(const Context &c, std::complex<double> alpha, const ComplexVector &x, std::complex<double> beta,
+              const ComplexVector &y, std::complex<double> gamma, ComplexVector &z);
+void SetBlocks(const Context &c, ComplexVector &x, const std::vector<const ComplexVector *> &y,
+               const std::vector<std::complex<double>> &s);
 // complex instantiation of OrthogonalizeColumnMGS / CGS (orthog.hpp:41-89): H[j] = V[j]^H (W) w, w -= sum_j H[j] V[j];
 // `weight` is a real operator applied to the real and the imaginary part (test/unit/test-orthog.cpp:49-67)
 void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
@@ -94,6 +106,54 @@ public:
   void AddMult(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
   void AddMultTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
   void AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
+};
+
+// BaseProductOperator<ComplexOperator> (linalg/operator.hpp:270-352): y = A (B x), non-owning
+class ComplexProductOperator : public ComplexOperator {
+  const ComplexOperator &A_, &B_;
+  mutable ComplexVector z_;
+
+public:
+  ComplexProductOperator(const ComplexOperator &A, const ComplexOperator &B)
+      : ComplexOperator(A.Height(), B.Width()), A_(A), B_(B), z_(B.Height()) {}
+  void Mult(const ComplexVector &x, ComplexVector &y) const override { B_.Mult(x, z_), A_.Mult(z_, y); }
+  void MultTranspose(const ComplexVector &x, ComplexVector &y) const override {
+    PA_REQUIRE(A_.Height() == A_.Width(), "the transposed product needs a square left factor (shared work vector)");
+    A_.MultTranspose(x, z_), B_.MultTranspose(z_, y);
+  }
+  void MultHermitianTranspose(const ComplexVector &x, ComplexVector &y) const override {
+    PA_REQUIRE(A_.Height() == A_.Width(), "the transposed product needs a square left factor (shared work vector)");
+    A_.MultHermitianTranspose(x, z_), B_.MultHermitianTranspose(z_, y);
+  }
+  void AddMult(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override {
+    B_.Mult(x, z_), A_.AddMult(z_, y, a);
+  }
+  void AddMultTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override {
+    A_.MultTranspose(x, z_), B_.AddMultTranspose(z_, y, a);
+  }
+  void AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override {
+    A_.MultHermitianTranspose(x, z_), B_.AddMultHermitianTranspose(z_, y, a);
+  }
+};
+
+// BaseDiagonalOperator<ComplexOperator> (linalg/operator.hpp:354-423, operator.cpp:415-581): y = d .* x, non-owning
+class ComplexDiagonalOperator : public ComplexOperator {
+  const Context *ctx_;
+  const ComplexVector &d_;
+  void Apply(const ComplexVector &x, ComplexVector &y, std::complex<double> a, bool add, bool conj) const;
+
+public:
+  ComplexDiagonalOperator(const Context &ctx, const ComplexVector &d) : ComplexOperator(d.Size()), ctx_(&ctx), d_(d) {}
+  void Mult(const ComplexVector &x, ComplexVector &y) const override { Apply(x, y, 1.0, false, false); }
+  void MultTranspose(const ComplexVector &x, ComplexVector &y) const override { Apply(x, y, 1.0, false, false); }
+  void MultHermitianTranspose(const ComplexVector &x, ComplexVector &y) const override { Apply(x, y, 1.0, false, true); }
+  void AddMult(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override { Apply(x, y, a, true, false); }
+  void AddMultTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override {
+    Apply(x, y, a, true, false);
+  }
+  void AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override {
+    Apply(x, y, a, true, true);
+  }
 };
 
 // ComplexParOperator (linalg/rap.hpp:124-221, rap.cpp:393-749): y = P^T (Ar + i Ai) P x on true-dof vectors with the

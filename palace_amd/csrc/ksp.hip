@@ -145,12 +145,11 @@ KspSolver::KspSolver(std::unique_ptr<IterativeSolver> &&ksp_, std::unique_ptr<So
   if (pc) ksp->SetPreconditioner(*pc);
 }
 
-void KspSolver::SetOperators(const Operator &op, const Operator &pc_op) {
-  // ksp.cpp:295-313; a multigrid preconditioner takes the operators of all levels (gmg.cpp:69-123)
-  ksp->SetOperator(op);
-  if (!pc) return;
+namespace {
+void SetPreconditionerOperators(Solver &pc_ref, const Operator &pc_op) {
+  Solver *pc = &pc_ref;
   const auto *mg_op = dynamic_cast<const MultigridOperator *>(&pc_op);
-  auto *mg_pc = dynamic_cast<GeometricMultigridSolver *>(pc.get());
+  auto *mg_pc = dynamic_cast<GeometricMultigridSolver *>(pc);
   if (mg_pc) {
     PA_REQUIRE(mg_op, "GeometricMultigridSolver requires a MultigridOperator argument provided to SetOperator!");
     std::vector<const ParOperator *> ops, aux;
@@ -163,9 +162,47 @@ void KspSolver::SetOperators(const Operator &op, const Operator &pc_op) {
     pc->SetOperator(pc_op);
   }
 }
+}  // namespace
+
+void KspSolver::SetOperators(const Operator &op, const Operator &pc_op) {
+  // ksp.cpp:295-313; a multigrid preconditioner takes the operators of all levels (gmg.cpp:69-123)
+  ksp->SetOperator(op);
+  if (pc) SetPreconditionerOperators(*pc, pc_op);
+}
 
 void KspSolver::Mult(const Vector &x, Vector &y) const {
   ksp->Mult(x, y);
+  if (!ksp->GetConverged())
+    std::fprintf(stderr, "Warning: Linear solver did not converge, norm(Ax-b)/norm(b) = %.3e (norm(b) = %.3e)!\n",
+                 ksp->GetFinalRes() / ksp->GetInitialRes(), ksp->GetInitialRes());
+  ksp_mult++;
+  ksp_mult_it += ksp->GetNumIterations();
+}
+
+ComplexKspSolver::ComplexKspSolver(const config::LinearSolverData &linear, int verbose,
+                                   const FiniteElementSpaceHierarchy &fespaces,
+                                   const FiniteElementSpaceHierarchy *aux_fespaces) {
+  const Context &ctx = fespaces.GetFinestFESpace().GetContext();
+  PA_REQUIRE(linear.krylov_solver == KrylovSolver::GMRES || linear.krylov_solver == KrylovSolver::FGMRES,
+             "complex systems are solved with GMRES or FGMRES");
+  const bool flexible = linear.krylov_solver == KrylovSolver::FGMRES;
+  ksp = std::make_unique<ComplexGmresSolver>(ctx, verbose, flexible);
+  ksp->SetRestartDim(linear.max_size), ksp->SetTol(linear.tol), ksp->SetMaxIter(linear.max_it);
+  ksp->SetOrthogonalization(linear.gs_orthog);
+  if (!flexible && linear.pc_side == PreconditionerSideOption::RIGHT) ksp->SetPreconditionerSide(PreconditionerSide::RIGHT);
+  if (!flexible && linear.pc_side == PreconditionerSideOption::LEFT) ksp->SetPreconditionerSide(PreconditionerSide::LEFT);
+  initial_guess = linear.initial_guess > 0;
+  pc = ConfigurePreconditionerSolver(linear, verbose - 1, ctx, fespaces, aux_fespaces);
+  ksp->SetPreconditioner(*pc);
+}
+
+void ComplexKspSolver::SetOperators(const ComplexOperator &op, const Operator &pc_op) {
+  ksp->SetOperator(op);
+  SetPreconditionerOperators(*pc, pc_op);
+}
+
+void ComplexKspSolver::Mult(const ComplexVector &x, ComplexVector &y) const {
+  ksp->Mult(x, y, initial_guess);
   if (!ksp->GetConverged())
     std::fprintf(stderr, "Warning: Linear solver did not converge, norm(Ax-b)/norm(b) = %.3e (norm(b) = %.3e)!\n",
                  ksp->GetFinalRes() / ksp->GetInitialRes(), ksp->GetInitialRes());

@@ -11,6 +11,7 @@
 
 #include <memory>
 
+#include "complex.hpp"
 #include "fem.hpp"
 #include "linalg.hpp"
 
@@ -76,6 +77,28 @@ public:
   // preconditioner is geometric multigrid)
   void SetOperators(const Operator &op, const Operator &pc_op);
   void Mult(const Vector &x, Vector &y) const;
+};
+
+// BaseKspSolver<ComplexOperator>: GMRES / FGMRES on a ComplexOperator with a real-valued preconditioner applied to the
+// real and the imaginary part (the reference's "PCMatReal" construction: the multigrid hierarchy is built from real
+// operators, linalg/gmg.cpp:147-168 applies it part by part).  pc_op is that real operator (a MultigridOperator for
+// geometric multigrid).
+class ComplexKspSolver {
+  std::unique_ptr<ComplexGmresSolver> ksp;
+  std::unique_ptr<Solver> pc;
+  bool initial_guess = false;
+  mutable int ksp_mult = 0, ksp_mult_it = 0;
+
+public:
+  ComplexKspSolver(const config::LinearSolverData &linear, int verbose, const FiniteElementSpaceHierarchy &fespaces,
+                   const FiniteElementSpaceHierarchy *aux_fespaces = nullptr);
+  int NumTotalMult() const { return ksp_mult; }
+  int NumTotalMultIterations() const { return ksp_mult_it; }
+  void SetRelTol(double tol) { ksp->SetTol(tol); }
+  void SetAbsTol(double tol) { ksp->SetAbsTol(tol); }
+  const ComplexGmresSolver &GetKrylovSolver() const { return *ksp; }
+  void SetOperators(const ComplexOperator &op, const Operator &pc_op);
+  void Mult(const ComplexVector &x, ComplexVector &y) const;
 };
 
 }  // namespace palace

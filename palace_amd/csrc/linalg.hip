@@ -232,6 +232,18 @@ struct OpAxpbypcz {
   }
   uintptr_t align() const { return bits(x) | bits(y) | bits(z); }
 };
+struct OpDiagMult {  // y = a d .* x (+ y)
+  double a;
+  const double *d, *x;
+  double *y;
+  int add;
+  template <class T>
+  __device__ void at(long long i) const {
+    const T v = a * (as<T>(d)[i] * as<T>(x)[i]);
+    as<T>(y)[i] = add ? as<T>(y)[i] + v : v;
+  }
+  uintptr_t align() const { return bits(d) | bits(x) | bits(y); }
+};
 struct OpScale {
   const double *d;
   double *y;
@@ -794,6 +806,16 @@ void Operator::MultEssential(const Vector &x, Vector &y) const {
 
 // ---- ParOperator ------------------------------------------------------------------------------
 // ---- SumOperator (operator.hpp:132-270) ---------------------------------------------------------
+void DiagonalOperator::Mult(const Vector &x, Vector &y) const {
+  PA_REQUIRE(x.Size() == d_.Size() && y.Size() == d_.Size(), "size mismatch in DiagonalOperator");
+  launch_ew(OpDiagMult{1.0, d_.Data(), x.Data(), y.Data(), 0}, x.Size(), ctx_->stream);
+}
+void DiagonalOperator::AddMult(const Vector &x, Vector &y, double a) const {
+  PA_REQUIRE(x.Size() == d_.Size() && y.Size() == d_.Size(), "size mismatch in DiagonalOperator");
+  launch_ew(OpDiagMult{a, d_.Data(), x.Data(), y.Data(), 1}, x.Size(), ctx_->stream);
+}
+void DiagonalOperator::AssembleDiagonal(Vector &diag) const { linalg::Copy(*ctx_, d_, diag); }
+
 void SumOperator::AddOperator(const Operator &op, double a) {
   PA_REQUIRE(op.Height() == height && op.Width() == width, "Invalid Operator dimensions for BaseSumOperator!");
   ops_.emplace_back(&op, a);

@@ -217,6 +217,39 @@ public:
   bool IsSymmetric() const override;
 };
 
+// BaseProductOperator<Operator> (linalg/operator.hpp:270-352): y = A (B x), non-owning
+class ProductOperator : public Operator {
+  const Operator &A_, &B_;
+  mutable Vector z_;
+
+public:
+  ProductOperator(const Operator &A, const Operator &B) : Operator(A.Height(), B.Width()), A_(A), B_(B), z_(B.Height()) {}
+  void Mult(const Vector &x, Vector &y) const override { B_.Mult(x, z_), A_.Mult(z_, y); }
+  void MultTranspose(const Vector &x, Vector &y) const override {
+    PA_REQUIRE(A_.Height() == A_.Width(), "the transposed product needs a square left factor (shared work vector)");
+    A_.MultTranspose(x, z_), B_.MultTranspose(z_, y);
+  }
+  void AddMult(const Vector &x, Vector &y, double a = 1.0) const override { B_.Mult(x, z_), A_.AddMult(z_, y, a); }
+  void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const override {
+    A_.MultTranspose(x, z_), B_.AddMultTranspose(z_, y, a);
+  }
+};
+
+// BaseDiagonalOperator<Operator> (linalg/operator.hpp:354-423): y = d .* x, non-owning
+class DiagonalOperator : public Operator {
+  const Context *ctx_;
+  const Vector &d_;
+
+public:
+  DiagonalOperator(const Context &ctx, const Vector &d) : Operator(d.Size(), d.Size()), ctx_(&ctx), d_(d) {}
+  void Mult(const Vector &x, Vector &y) const override;
+  void MultTranspose(const Vector &x, Vector &y) const override { Mult(x, y); }
+  void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
+  void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const override { AddMult(x, y, a); }
+  void AssembleDiagonal(Vector &diag) const override;
+  bool IsSymmetric() const override { return true; }
+};
+
 // Local operator held as an assembled CSR matrix in device memory (csr_op.hip): what the reference's coarsest level
 // becomes through ParOperator::ParallelAssemble (linalg/rap.cpp:84-152).  Non-owning view of a pa_csr.
 class CsrOperator : public Operator {

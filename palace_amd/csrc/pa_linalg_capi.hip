@@ -232,6 +232,96 @@ int pa_vec_axpby(pa_context *ctx, double a, const double *x, double b, double *y
     linalg::AXPBY(ctx->ctx, a, vx, b, vy);
   });
 }
+/* ComplexVector members (linalg/vector.hpp:95-146) on split real / imaginary arrays; op: 0 x *= a, 1 x = |x|, 2 x = 1 ./ x,
+ * 3 x = conj(x), 4 y = a x + b y, 5 z = a x + b y + c z, 6 out = x^T y (no conjugate) */
+int pa_cvec_op(pa_context *ctx, int op, int n, const double *coef, double *xr, double *xi, double *yr, double *yi, double *zr,
+               double *zi, double *out) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && n >= 0 && xr && xi, "bad argument");
+    using cd = std::complex<double>;
+    ComplexVector x(xr, xi, n), y(yr, yi, yr ? n : 0), z(zr, zi, zr ? n : 0);
+    auto co = [&](int k) { return coef ? cd(coef[2 * k], coef[2 * k + 1]) : cd(1.0); };
+    switch (op) {
+      case 0: linalg::Scale(ctx->ctx, co(0), x); break;
+      case 1: linalg::Abs(ctx->ctx, x); break;
+      case 2: linalg::Reciprocal(ctx->ctx, x); break;
+      case 3: linalg::Conj(ctx->ctx, x); break;
+      case 4: PA_REQUIRE(yr && yi, "y missing"); linalg::AXPBY(ctx->ctx, co(0), x, co(1), y); break;
+      case 5: PA_REQUIRE(yr && yi && zr && zi, "y / z missing"); linalg::AXPBYPCZ(ctx->ctx, co(0), x, co(1), y, co(2), z); break;
+      case 6: {
+        PA_REQUIRE(yr && yi && out, "y / out missing");
+        const cd d = linalg::TransposeDot(ctx->ctx, x, y);
+        out[0] = d.real(), out[1] = d.imag();
+      } break;
+      default: throw pa::Error("unknown complex vector operation");
+    }
+  });
+}
+/* ComplexVector::SetBlocks (vector.cpp:172-201): x = [s_0 y_0; s_1 y_1; ...]; s NULL = ones */
+int pa_cvec_set_blocks(pa_context *ctx, double *xr, double *xi, int n, int nblocks, const double *const *yr,
+                       const double *const *yi, const int *sizes, const double *s) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && xr && xi && nblocks >= 0, "bad argument");
+    ComplexVector x(xr, xi, n);
+    std::vector<ComplexVector> blocks;
+    blocks.reserve((size_t)nblocks);
+    std::vector<const ComplexVector *> ptr;
+    std::vector<std::complex<double>> sc;
+    for (int b = 0; b < nblocks; b++) {
+      blocks.emplace_back(const_cast<double *>(yr[b]), const_cast<double *>(yi[b]), sizes[b]);
+      if (s) sc.emplace_back(s[2 * b], s[2 * b + 1]);
+    }
+    for (auto &b : blocks) ptr.push_back(&b);
+    linalg::SetBlocks(ctx->ctx, x, ptr, sc);
+  });
+}
+/* DiagonalOperator / ComplexDiagonalOperator (linalg/operator.hpp:354-423): y (+)= a op(diag(d)) x; mode 0 N, 1 T, 2 H
+ * (imaginary arrays NULL: the real operator) */
+int pa_diag_op_apply(pa_context *ctx, int n, const double *dr, const double *di, const double *xr, const double *xi, double *yr,
+                     double *yi, double ar, double ai, int mode, int add) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && dr && xr && yr, "bad argument");
+    if (!di) {
+      Vector d(const_cast<double *>(dr), n), x(const_cast<double *>(xr), n), y(yr, n);
+      DiagonalOperator D(ctx->ctx, d);
+      if (add) mode ? D.AddMultTranspose(x, y, ar) : D.AddMult(x, y, ar); else mode ? D.MultTranspose(x, y) : D.Mult(x, y);
+      return;
+    }
+    PA_REQUIRE(xi && yi, "imaginary parts missing");
+    ComplexVector d(const_cast<double *>(dr), const_cast<double *>(di), n), x(const_cast<double *>(xr), const_cast<double *>(xi), n),
+        y(yr, yi, n);
+    ComplexDiagonalOperator D(ctx->ctx, d);
+    const std::complex<double> a(ar, ai);
+    if (add)
+      mode == 0 ? D.AddMult(x, y, a) : mode == 1 ? D.AddMultTranspose(x, y, a) : D.AddMultHermitianTranspose(x, y, a);
+    else
+      mode == 0 ? D.Mult(x, y) : mode == 1 ? D.MultTranspose(x, y) : D.MultHermitianTranspose(x, y);
+  });
+}
+/* ProductOperator (linalg/operator.hpp:270-352): y (+)= a op(A B) x over two ParOperators */
+int pa_product_op_apply(pa_par_op *A, pa_par_op *B, const double *x, double *y, int transpose, double a, int add) {
+  return guarded([&] {
+    PA_REQUIRE(A && B && x && y, "null argument");
+    ProductOperator AB(*A->op, *B->op);
+    Vector vx(const_cast<double *>(x), transpose ? AB.Height() : AB.Width()), vy(y, transpose ? AB.Width() : AB.Height());
+    if (add) transpose ? AB.AddMultTranspose(vx, vy, a) : AB.AddMult(vx, vy, a); else transpose ? AB.MultTranspose(vx, vy) : AB.Mult(vx, vy);
+  });
+}
+/* ComplexProductOperator over two ComplexParOperators: mode 0 N, 1 T, 2 H */
+int pa_complex_product_op_apply(pa_complex_par_op *A, pa_complex_par_op *B, const double *xr, const double *xi, double *yr,
+                                double *yi, int mode, double ar, double ai, int add) {
+  return guarded([&] {
+    PA_REQUIRE(A && B && xr && xi && yr && yi, "null argument");
+    ComplexProductOperator AB(*A->op, *B->op);
+    const int n = AB.Height();
+    ComplexVector x(const_cast<double *>(xr), const_cast<double *>(xi), n), y(yr, yi, n);
+    const std::complex<double> a(ar, ai);
+    if (add)
+      mode == 0 ? AB.AddMult(x, y, a) : mode == 1 ? AB.AddMultTranspose(x, y, a) : AB.AddMultHermitianTranspose(x, y, a);
+    else
+      mode == 0 ? AB.Mult(x, y) : mode == 1 ? AB.MultTranspose(x, y) : AB.MultHermitianTranspose(x, y);
+  });
+}
 // Measured FP64 matrix-core peak (bench.py's denominator beside the data-sheet figure): every wave
 // keeps eight independent 16x16 accumulators and issues `iters` rounds of v_mfma_f64_16x16x4_f64 on them.
 typedef double pa_d4 __attribute__((ext_vector_type(4)));

@@ -90,3 +90,58 @@ def test_cxx_host_solve(built, aux, krylov, coarse):
     n_py, its_py, sx_py = _python_solve(aux, krylov, coarse)
     assert n == n_py and its == its_py, (out, its_py)
     assert abs(sx - sx_py) < 1e-9 * abs(sx_py)
+
+
+def test_cxx_host_complex_solve(built):
+    """The driven-style complex system through ComplexParOperator + ComplexKspSolver (FGMRES, real p-multigrid with the
+    Hiptmair smoother on both parts) in C++, against the same solve through the ctypes mirror."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem.fespace import H1HexSpace, NDHexSpace
+    from palace_amd.fem.mesh import ogrid_cylinder
+
+    exe, blob = built
+    out = subprocess.check_output([exe, blob, "1", "cfgmres", "pcg"], text=True)
+    m = re.search(r"ndofs (\d+) .* iterations (\d+)\s+converged (\d)\s+NumTotalMult (\d+)\s+NumTotalMultIterations (\d+)\s+"
+                  r"\|b - A x\| / \|b\| (\S+)\s+sum\(x\) (\S+) (\S+)", out)
+    assert m, out
+    n, its, conv, nmult, nmult_it = (int(m.group(i)) for i in range(1, 6))
+    res, sxr, sxi = float(m.group(6)), float(m.group(7)), float(m.group(8))
+    assert conv == 1 and res < 1e-8 and nmult == 1 and nmult_it == its, out
+    # mirror
+    ctx = linalg.Context()
+    mesh = ogrid_cylinder(3, 6)
+    orders, w = [1, 2, 3], 0.8
+    nds, h1s = [NDHexSpace(mesh, p) for p in orders], [H1HexSpace(mesh, p) for p in orders]
+    geom = ceed.GeomFactorData(mesh, 4)
+    eps = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
+    fine = ceed.curlcurlmass_operator(geom, nds[-1], eps, ceed.coefficient_context(3))
+    local = [fine.coarsen(geom, s) for s in nds[:-1]] + [fine]
+    A = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE) for op, s in zip(local, nds)]
+    A[0] = linalg.AssembledParOperator(ctx, local[0].full_assemble_device(), nds[0].ess_dofs(), linalg.DIAG_ONE)
+    P = [linalg.Interp(ctx, a, b) for a, b in zip(nds[:-1], nds[1:])]
+    fine_h1 = ceed.diffusion_operator(geom, h1s[-1], eps)
+    loc_h1 = [fine_h1.coarsen(geom, s) for s in h1s[:-1]] + [fine_h1]
+    A_h1 = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE) for op, s in zip(loc_h1, h1s)]
+    G = [linalg.Gradient(ctx, h, s) for h, s in zip(h1s, nds)]
+    cs = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=1e-2, max_it=8)
+    B = linalg.gmg(ctx, A, P, cs, cheby_order=6, A_aux=A_h1, G=G)
+    neg_eps = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([-w * w * 2.08])])
+    sigma = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([w * 0.35])])
+    Ar = ceed.curlcurlmass_operator(geom, nds[-1], neg_eps, ceed.coefficient_context(3))
+    Ai = ceed.ndmass_operator(geom, nds[-1], sigma)
+    Ac = linalg.ComplexParOperator(ctx, Ar, Ai, nds[-1].ess_dofs(), linalg.DIAG_ONE)
+    K = linalg.ComplexParGmres(ctx, Ac, B, rel_tol=1e-10, max_it=400, restart=400, flexible=True)
+    nn = nds[-1].ndofs
+    new = lambda v=0.0: torch.full((nn,), v, dtype=torch.float64, device="cuda")  # noqa: E731
+    one_r, one_i, br, bi = new(1.0), new(-0.5), new(), new()
+    Ac.mult(one_r, one_i, br, bi)
+    ess = torch.from_numpy(nds[-1].ess_dofs().astype(np.int64)).cuda()
+    br[ess] = 0.0
+    bi[ess] = 0.0
+    xr, xi = new(), new()
+    K.mult(br, bi, xr, xi)
+    assert n == nn and K.stats()["iterations"] == its
+    s_py = complex(float((xr * one_r + xi * one_i).sum()), float((xi * one_r - xr * one_i).sum()))  # ones^H x
+    assert abs(complex(sxr, sxi) - s_py) < 1e-9 * abs(s_py)

@@ -269,6 +269,56 @@ def test_complex_par_operator(cylinder_mesh, policy):
     assert _rel(dr.cpu().numpy(), d_ref_r) < 1e-12 and _rel(di.cpu().numpy(), d_ref_i) < 1e-12
 
 
+def test_product_operators(cylinder_mesh):
+    """ProductOperator / ComplexProductOperator (linalg/operator.hpp:270-352): y (+)= a op(A B) x over two parallel
+    operators -- all transposition modes -- against the dense products of the oracle's assembled matrices."""
+    import ctypes as C
+
+    from palace_amd import lib as _lib
+
+    L = _lib.load()
+    L.pa_product_op_apply.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_double, C.c_int]
+    L.pa_complex_product_op_apply.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_double, C.c_double, C.c_int]
+    mesh, p = cylinder_mesh, 1
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ogeom = util.oracle_geom(mesh, q1d)
+    c_r, b_r = util.make_ctx("nonsym")
+    c_i, b_i = util.make_ctx("scalar")
+    Kr, Mi = ceed.curlcurl_operator(geom, nd, b_r), ceed.ndmass_operator(geom, nd, b_i)
+    Ar, Ai = _dense(nd, ogeom, "hdiv", c_r, q1d), _dense(nd, ogeom, "hcurl", c_i, q1d)
+    n = nd.ndofs
+    ctx = linalg.Context()
+    none = np.zeros(0, dtype=np.int32)
+    PA, PB = linalg.ParOperator(ctx, Kr, none, linalg.DIAG_ONE), linalg.ParOperator(ctx, Mi, none, linalg.DIAG_ONE)
+    rng = np.random.default_rng(31)
+    x, y0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    dx = _dev(x)
+    for tr, M in ((0, Ar @ Ai), (1, (Ar @ Ai).T)):
+        y = _new(n)
+        _lib.check(L.pa_product_op_apply(PA.handle, PB.handle, P(dx), P(y), tr, 1.0, 0))
+        assert _rel(y.cpu().numpy(), M @ x) < 1e-12
+        y = _dev(y0.copy())
+        _lib.check(L.pa_product_op_apply(PA.handle, PB.handle, P(dx), P(y), tr, -0.6, 1))
+        assert _rel(y.cpu().numpy(), y0 - 0.6 * (M @ x)) < 1e-12
+    CA = linalg.ComplexParOperator(ctx, Kr, Mi)          # Ar + i Ai
+    CB = linalg.ComplexParOperator(ctx, Mi, Kr)          # Ai + i Ar
+    A, B = Ar + 1j * Ai, Ai + 1j * Ar
+    z = x + 1j * rng.uniform(-1, 1, n)
+    w0 = y0 + 1j * rng.uniform(-1, 1, n)
+    a = 0.4 - 1.1j
+    zr, zi = _dev(z.real.copy()), _dev(z.imag.copy())
+    for mode, M in ((0, A @ B), (1, (A @ B).T), (2, (A @ B).conj().T)):
+        yr, yi = _new(n), _new(n)
+        _lib.check(L.pa_complex_product_op_apply(CA.handle, CB.handle, P(zr), P(zi), P(yr), P(yi), mode, 1.0, 0.0, 0))
+        assert _rel(yr.cpu().numpy() + 1j * yi.cpu().numpy(), M @ z) < 1e-12, mode
+        yr, yi = _dev(w0.real.copy()), _dev(w0.imag.copy())
+        _lib.check(L.pa_complex_product_op_apply(CA.handle, CB.handle, P(zr), P(zi), P(yr), P(yi), mode, a.real, a.imag, 1))
+        assert _rel(yr.cpu().numpy() + 1j * yi.cpu().numpy(), w0 + a * (M @ z)) < 1e-12, mode
+
+
 @pytest.mark.parametrize("kind", ["left", "right", "fgmres"])
 def test_complex_gmres_variants(cylinder_mesh, kind):
     """GmresSolver / FgmresSolver <ComplexOperator> (iterative.cpp:543-871) on A = (K - w^2 M) + i w C-like system
