@@ -373,7 +373,7 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   bool first = true;
   for (const SubOp *so : op->subs) {
     if (so->fe_type == PA_FE_HCURL) {
-      if (so->d_sidx_s && overwrite && first && (!masked || so->d_sidx_s_bc)) {  // streaming kernel (y = A x) + E^T of the shared dofs by runs
+      if (so->d_idxc && overwrite && first && (!masked || so->d_perm_s_bc)) {  // streaming kernel (y = A x) + E^T of the shared dofs by runs
         launch_nd_hex_stream(*so, x, y, masked, s);
         launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
       } else if (so->d_ye) {

@@ -176,14 +176,13 @@ struct SubOp {
   int32_t *d_tptr = nullptr;   // [lsize + 1]
   int32_t *d_tent = nullptr;   // [ne * P] signed positions into d_ye
   // streaming form (pa_nd_hex_stream.hip): index words with the exclusive flag, byte slots, E^T of the shared dofs by runs
-  int32_t *d_sidx_s = nullptr, *d_sidx_s_bc = nullptr;  // [ne][P]: dof | kEssBit | kExclBit; negative: -(1 + word), flipped
+  uint32_t *d_idxc = nullptr;  // [ne][kIdxWords] run-compressed sorted element -> dof index (pa_stream_host.hpp)
   uint32_t *d_perm_s_bc = nullptr;                      // flag words with the essential dofs taken off the direct path
   std::vector<uint32_t> h_perm_s;
   int32_t *d_rhdr_bc = nullptr, *d_rpos_bc = nullptr;   // run list that also owns the essential rows
   int n_shared_bc = 0;
   uint32_t *d_perm_s = nullptr;                         // [ne][ceil(P/64)][16], four 8-bit tensor-order slots per word
   double *d_coef_s = nullptr;                           // metric form: [ne][2] scalar mass / curl-curl coefficient per element
-  std::vector<int32_t> h_sidx_s;
   uint32_t *d_rcode = nullptr, *d_rcode_bc = nullptr;   // [n_shared] run << 4 | offset (bit 31: essential)
   int32_t *d_rhdr = nullptr, *d_rpos = nullptr;         // run headers {first dof, first copy entry}; copy positions in d_ye
   int n_runs = 0;

@@ -45,9 +45,10 @@ __device__ unsigned long long g_trace[kTraceWG * kTraceBatches * kTraceStamps];
 template <int P1>
 struct NDStreamArgs {
   int ne, nbatch, chunk;  // chunk: batches per XCD (contiguous range)
-  const int32_t *sidx;    // [ne][P] sorted order: dof | kEssBit | kExclBit; negative: -(1 + word), entry is flipped
+  const uint32_t *idxc;   // [ne][kIdxWords] run-compressed sorted element -> dof index (pa_stream_host.hpp)
   const uint32_t *perm;   // [ne][NPK + 1][16]: four 8-bit tensor-order slots per word (entries t + 16 r, r = 4 k .. 4 k + 3),
-                          // last word: bit 2 r = entry r is flipped, bit 2 r + 1 = entry r is the only copy of its dof
+                          // last word: bit 2 r = entry r is flipped, bit 2 r + 1 = entry r is the only copy of its dof,
+                          // bit 18 + r = essential (read as zero; set in the copy used by masked applies)
   const double *qdata;    // [ne][NG][2][16][2]
   const double *coef;     // metric form: [ne][2] scalar mass / curl-curl coefficient of the element
   const double *x;
@@ -69,8 +70,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
   constexpr int NG = METRIC ? (USE_U ? 7 : 6) : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
   static_assert(PP <= 256, "8-bit slots");
-  // LDS per element (doubles): contraction buffers + the batch's index and slot / flag words, kept for the E^T stores
-  constexpr int LDS_ELEM = L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8;
+  using streamhost::kIdxStart0;
+  using streamhost::kIdxWords;
+  // LDS per element (doubles): contraction buffers + the batch's index and slot / flag words, kept for the E^T stores,
+  // + the run starts of the next batch while its index is decoded
+  constexpr int LDS_SIDE = (PP + 1) / 2 + (NPK + 1) * 8;
+  constexpr int LDS_ELEM = L::ELEM_PAD + LDS_SIDE + 12;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -85,21 +90,35 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   if (b >= bend) return;
   // index words of a batch (every array is padded to a multiple of four elements; pad entries read as zero and are
   // stored to E-vector rows nobody gathers)
-  auto load_idx = [&](const int bb, const int sub, const int t, int (&s)[NPL], unsigned (&p)[NPK + 1]) {
+  // s[0 .. NPL): the slice words (the same word for the 16 lanes of an element), s[NPL], s[NPL + 1]: run starts t, 16 + t
+  auto load_idx = [&](const int bb, const int sub, const int t, int (&s)[NPL + 2], unsigned (&p)[NPK + 1]) {
     const int e = bb * 4 + sub;
-    const int32_t *si = a.sidx + (size_t)e * PP + t;
+    const uint32_t *ic = a.idxc + (size_t)e * kIdxWords;
 #pragma unroll
-    for (int r = 0; r < NPL; r++) s[r] = (16 * r + 15 < PP || t + 16 * r < PP) ? __builtin_nontemporal_load(&si[16 * r]) : 0;
+    for (int r = 0; r < NPL; r++) s[r] = (int)__builtin_nontemporal_load(&ic[r]);
+    s[NPL] = (int)__builtin_nontemporal_load(&ic[kIdxStart0 + t]);
+    s[NPL + 1] = (int)__builtin_nontemporal_load(&ic[kIdxStart0 + 16 + (t & 3)]);
     const uint32_t *pp = a.perm + (size_t)e * ((NPK + 1) * 16) + t;
 #pragma unroll
     for (int k = 0; k <= NPK; k++) p[k] = __builtin_nontemporal_load(&pp[16 * k]);
   };
-  // raw x of the entries (essential entries are zeroed when staged)
-  auto gather = [&](const int (&s)[NPL], double (&xv)[NPL]) {
+  // decodes the index of the batch in place (s[r] becomes dof | kEssBit | kExclBit, negative: -(1 + word), flipped) and
+  // requests the raw x of the entries (essential entries are zeroed when staged).  stab: 20 ints of LDS of this element.
+  auto gather = [&](int (&s)[NPL + 2], const unsigned (&p)[NPK + 1], double (&xv)[NPL], int *stab, const int t) {
+    stab[t] = s[NPL];
+    if (t < 4) stab[16 + t] = s[NPL + 1];
+    wave_sync();
+    const unsigned fw = p[NPK];
 #pragma unroll
     for (int r = 0; r < NPL; r++) {
-      const int sv = s[r], df = sv >= 0 ? sv : -1 - sv;
-      xv[r] = a.x[df & (kExclBit - 1)];
+      const unsigned w = (unsigned)s[r], low = (w & 0xffffu) & ((2u << t) - 1u);
+      const int rid = (int)((w >> 16) & 31u) + __popc(low) - 1;
+      const int pos = low ? 16 * r + 31 - __clz((int)low) : (int)((w >> 21) & 255u);
+      int dof = stab[rid] + (t + 16 * r - pos);
+      if (!(16 * r + 15 < PP) && t + 16 * r >= PP) dof = 0;  // lanes past the last entry
+      xv[r] = a.x[dof];
+      const int word = dof | ((fw >> (2 * r + 1)) & 1u ? kExclBit : 0) | ((fw >> (18 + r)) & 1u ? kEssBit : 0);
+      s[r] = (fw >> (2 * r)) & 1u ? -1 - word : word;
     }
   };
   // the slot / flag words requested with the index words are first used at the top of the next batch; taking them as
@@ -108,11 +127,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #pragma unroll
     for (int k = 0; k <= NPK; k++) asm volatile("" : "+v"(p[k]));
   };
-  int sA[NPL];
+  int sA[NPL + 2];
   unsigned pA[NPK + 1];
   double xv[NPL];
   load_idx(b, lane >> 4, lane & 15, sA, pA);
-  gather(sA, xv);
+  gather(sA, pA, xv,
+         reinterpret_cast<int *>(smem + (size_t)(wave * 4 + (lane >> 4)) * LDS_ELEM + L::ELEM_PAD + LDS_SIDE), lane & 15);
   // the first batch's x is awaited here, outside the loop: with loads still pending at the loop entry the compiler merges
   // that state into the loop header and the counted waits at the top of every batch (x requested before that batch's nine
   // stores) degrade to waiting for the stores as well
@@ -133,6 +153,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     const int sub = lo >> 4, t = lo & 15, ta = t & 3, tb = t >> 2;
     double *sm = smem + (size_t)(wave * 4 + sub) * LDS_ELEM;
     int *side = reinterpret_cast<int *>(sm + L::ELEM_PAD);  // index words of this batch, kept for the E^T stores
+    int *stab = side + 2 * LDS_SIDE;                        // run starts of the next batch (decode)
     const int lx = L::parity_xor(sub);
     const int e = b * 4 + sub;
 
@@ -175,7 +196,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     // Requested here when the registers allow (p < 3), after the forward passes otherwise.
     const int bn = b + stride;
     const bool more = bn < bend;
-    int sB[NPL];
+    int sB[NPL + 2];
     unsigned pB[NPK + 1];
     if (EARLY_IDX) {
       load_idx(more ? bn : b, sub, t, sB, pB);
@@ -231,7 +252,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     double xB[NPL];
     if (GPOS == 0) {
       __builtin_amdgcn_sched_barrier(0);
-      gather(sB, xB);
+      gather(sB, pB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -239,7 +260,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     PA_STAMP(6);  // first transposed component done
     if (GPOS == 1) {
       __builtin_amdgcn_sched_barrier(0);
-      gather(sB, xB);
+      gather(sB, pB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -247,14 +268,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     nd_bwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
     if (GPOS == 2) {
       __builtin_amdgcn_sched_barrier(0);
-      gather(sB, xB);
+      gather(sB, pB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
     nd_bwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
     if (GPOS == 3) {
       __builtin_amdgcn_sched_barrier(0);
-      gather(sB, xB);
+      gather(sB, pB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #endif
     if (GPOS == 4) {
       __builtin_amdgcn_sched_barrier(0);
-      gather(sB, xB);
+      gather(sB, pB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -385,14 +406,13 @@ bool nd_hex_stream_ok(const SubOp &so) {
 // exclusive flags).  Host work proportional to the index array, once per operator.  Every per-element array is padded
 // to a multiple of four elements (one batch); the pad entries are flagged essential (read as zero).
 void build_stream(SubOp &so) {
-  if (so.d_sidx_s || !nd_hex_stream_ok(so)) return;
+  if (so.d_idxc || !nd_hex_stream_ok(so)) return;
   const int P = so.P, ne = so.ne, nep = (ne + 3) & ~3;
-  std::vector<int32_t> ss;
-  std::vector<uint32_t> pp;
-  streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ss, pp);
-  so.h_sidx_s = ss;
+  std::vector<uint32_t> ic, pp;
+  // (a numbering that breaks an element's dofs into more than kIdxMaxRuns runs keeps the one-shot kernel)
+  if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp)) return;
   so.h_perm_s = pp;
-  so.d_sidx_s = dev_upload(ss.data(), ss.size());
+  so.d_idxc = dev_upload(ic.data(), ic.size());
   so.d_perm_s = dev_upload(pp.data(), pp.size());
   if (so.qd->metric) {  // scalar coefficients per element (coeff_3_qf.h:9-24 resolved on the host)
     const std::vector<int32_t> &attr = so.geom->h_attr;
@@ -425,28 +445,25 @@ void build_stream(SubOp &so) {
   so.n_runs = (int)hdr.size() - 1;
 }
 
-// Essential dofs (pa_op_set_essential): flagged in a copy of the index words (read as zero), never exclusive in a copy of
+// Essential dofs (pa_op_set_essential): flagged (read as zero) and never exclusive in a copy of
 // the flag words (their element-local result goes to the E-vector like a shared dof's), and present in a second run list,
 // so that the run gather owns every essential row: it writes x or 0 there when ParOperator's fix-up is fused
 // (rap.cpp:223-233) and the plain sum otherwise.
 void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
-  if (!so.d_sidx_s) return;
+  if (!so.d_idxc) return;
   const int P = so.P, npl = (P + 15) / 16, npk = (npl + 3) / 4;
-  std::vector<int32_t> bc(so.h_sidx_s);
   std::vector<uint32_t> pb(so.h_perm_s);
-  const size_t nnz = (size_t)so.ne * so.P;  // (the pad entries are flagged already)
+  const size_t nnz = (size_t)so.ne * so.P;
   for (size_t k = 0; k < nnz; k++) {
-    int32_t &s = bc[k];
-    const int w = s >= 0 ? s : -1 - s;
-    if (flag[w & (kExclBit - 1)]) {
-      s = s >= 0 ? (w | kEssBit) : -1 - (w | kEssBit);
+    if (flag[streamhost::dof_of(so.h_sidx[k])]) {
       const size_t e = k / P;
       const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
-      pb[(e * (npk + 1) + npk) * 16 + t] &= ~(2u << (2 * r));
+      uint32_t &fw = pb[(e * (npk + 1) + npk) * 16 + t];
+      fw &= ~(2u << (2 * r));  // off the direct path
+      fw |= 1u << (18 + r);    // read as zero
     }
   }
-  hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s_bc);
-  so.d_sidx_s_bc = dev_upload(bc.data(), bc.size());
+  hipFree(so.d_perm_s_bc);
   so.d_perm_s_bc = dev_upload(pb.data(), pb.size());
   std::vector<int32_t> count((size_t)so.lsize, 0);
   for (size_t k = 0; k < nnz; k++) count[streamhost::dof_of(so.h_sidx[k])]++;
@@ -468,7 +485,7 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
 }
 
 void free_stream(SubOp &so) {
-  hipFree(so.d_sidx_s), hipFree(so.d_sidx_s_bc), hipFree(so.d_perm_s), hipFree(so.d_perm_s_bc), hipFree(so.d_coef_s);
+  hipFree(so.d_idxc), hipFree(so.d_perm_s), hipFree(so.d_perm_s_bc), hipFree(so.d_coef_s);
   hipFree(so.d_rcode), hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rcode_bc), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
 }
 
@@ -489,7 +506,7 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   for (int i = 0; i < HalfTab<P1 + 1, 4>::LEN; i++) a.tab.Bc[i] = so.Bc[i], a.tab.Gc[i] = so.Gc[i];
   constexpr int PP = 3 * P1 * (P1 + 1) * (P1 + 1);
   constexpr int NPK = ((PP + 15) / 16 + 3) / 4;
-  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * (L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8);
+  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * (L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8 + 12);
   // resident workgroups per CU: registers (MINW waves per SIMD), LDS (160 KB), at most 8
   // workgroups per CU: what the registers (MINW waves per SIMD) and the LDS admit, and not more than the occupancy query
   // says -- with a fixed stride a workgroup that had to queue would run after the others and double the time
@@ -510,8 +527,11 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   PA_HIP(hipGetLastError());
 }
 
-// where x of the next batch is requested: after the first transposed component by default (its index words are requested
-// just before D and need time to arrive; x then has the rest of the batch).  PALACE_AMD_STREAM_GPOS = 0 / 1 / 2 for A/B.
+// where x of the next batch is requested: after the first transposed component for the curl-curl kernel, after the second
+// for the kernels with a mass term (their index words are requested just before D and need time to arrive and to be
+// decoded; later = fewer live registers: 202 instead of 248 VGPRs for K + M at p = 3; measured on the 10M-dof case with the
+// run-compressed index: curl-curl 0.180 / 0.181 ms, K + M 0.187 / 0.185 ms, mass 0.168 / 0.156 ms for positions 1 / 2).
+// PALACE_AMD_STREAM_GPOS = 0 / 1 / 2 for A/B.
 template <int P1, bool U, bool C, bool METRIC, int MINW_>
 static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
 #ifdef PA_STREAM_MINW2  // experiment builds: two waves per SIMD everywhere
@@ -519,7 +539,7 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
 #else
   constexpr int MINW = MINW_;
 #endif
-  static const int gpos = getenv("PALACE_AMD_STREAM_GPOS") ? atoi(getenv("PALACE_AMD_STREAM_GPOS")) : 1;
+  static const int gpos = getenv("PALACE_AMD_STREAM_GPOS") ? atoi(getenv("PALACE_AMD_STREAM_GPOS")) : (U ? 2 : 1);
   if (gpos == 0)
     launch_gpos<P1, U, C, METRIC, MINW, 0>(so, a, s);
   else if (gpos == 2)
@@ -532,7 +552,7 @@ template <int P1>
 static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s) {
   NDStreamArgs<P1> a;
   a.ne = so.ne;
-  a.sidx = masked ? so.d_sidx_s_bc : so.d_sidx_s;
+  a.idxc = so.d_idxc;
   a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
   a.qdata = so.qd->d;
   a.coef = so.d_coef_s;

@@ -20,34 +20,76 @@ struct RunHdr {
 
 inline int dof_of(int32_t s) { return s >= 0 ? s : -1 - s; }
 
+// Compressed element -> dof index of the streaming kernel.  The P entries of an element are sorted by dof, so they fall
+// into a few runs of consecutive dofs (one per mesh entity: 12 edges, 6 faces and the interior of a hexahedron give at
+// most 19); instead of one word per entry (576 B at p = 3) an element stores kIdxWords = 32 words (128 B):
+//   word r < npl        entries 16 r .. 16 r + 15:  bits 0-15  bit j set = entry 16 r + j starts a run
+//                                                     bits 16-20 number of runs that start before entry 16 r
+//                                                     bits 21-28 position of the last run start before entry 16 r
+//   word kIdxStart0 + k first dof of run k (k < kIdxMaxRuns)
+// dof(m) = start[run(m)] + m - first entry of run(m), see index_dof.  Signs, the only-copy flag and the essential flag
+// travel in the flag word of pp.
+constexpr int kIdxWords = 32, kIdxStart0 = 12, kIdxMaxRuns = 20;
+
+inline int index_dof(const uint32_t *ic, int m) {  // host model of the device decode (nd_hex_stream_kernel: gather)
+  const int r = m >> 4, t = m & 15;
+  const uint32_t w = ic[r], low = (w & 0xffffu) & ((2u << t) - 1u);
+  int bits = 0, top = -1;
+  for (int j = 0; j < 16; j++)
+    if (low >> j & 1u) bits++, top = j;
+  const int rid = (int)((w >> 16) & 31u) + bits - 1;
+  if (rid < 0 || rid >= kIdxMaxRuns) throw std::runtime_error("index decode: entry without a run");
+  const int pos = low ? 16 * r + top : (int)((w >> 21) & 255u);
+  return (int)ic[kIdxStart0 + rid] + (m - pos);
+}
+
 // sidx / perm: [ne][P] signed sorted index and tensor-order slot of sorted entry m (make_sub).  Output, padded to a
 // multiple of four elements:
-//   ss [nep][P]              dof | kExclBit (only copy); negative: -(1 + word), the entry is flipped; pad: kEssBit
+//   ic [nep][kIdxWords]      the compressed index (pad elements: one run starting at dof 0)
 //   pp [nep][npk + 1][16]    lane t of an element holds entries m = t + 16 r: word k carries the 8-bit slots of
 //                            r = 4 k .. 4 k + 3, the last word bit 2 r = flipped, bit 2 r + 1 = only copy
-inline void pack_index(int ne, int P, int lsize, const int32_t *sidx, const uint16_t *perm, std::vector<int32_t> &ss,
+//                            (bits 18 + r: essential, set in the copy stream_set_essential makes)
+// Returns false when an element has more than kIdxMaxRuns runs (the caller keeps the one-shot kernel for that block).
+inline bool pack_index(int ne, int P, int lsize, const int32_t *sidx, const uint16_t *perm, std::vector<uint32_t> &ic,
                        std::vector<uint32_t> &pp) {
   if (P > 256) throw std::runtime_error("element too large for 8-bit slots");
   if (lsize >= kExclBit) throw std::runtime_error("too many local dofs for the streaming index encoding");
   const int nep = (ne + 3) & ~3, npl = (P + 15) / 16, npk = (npl + 3) / 4;
+  if (npl > 9) throw std::runtime_error("element too large for the flag word");
   const size_t nnz = (size_t)ne * P;
   std::vector<int32_t> count((size_t)lsize, 0);
   for (size_t k = 0; k < nnz; k++) count[dof_of(sidx[k])]++;
-  ss.assign((size_t)nep * P, kEssBit);
+  ic.assign((size_t)nep * kIdxWords, 0u);
   pp.assign((size_t)nep * (npk + 1) * 16, 0u);
-  for (int e = 0; e < ne; e++)
+  for (int e = 0; e < nep; e++) {
+    uint32_t *ice = &ic[(size_t)e * kIdxWords];
+    if (e >= ne) {
+      // one run, dof 0 onwards: the pad entries read the first P entries of x and store to unused E-vector rows
+      ice[0] = 1u;
+      for (int r = 1; r < npl; r++) ice[r] = 1u << 16;  // one run started before entry 16 r, at position 0
+      continue;
+    }
+    int nruns = 0, lastpos = 0, prev = -2;
     for (int m = 0; m < P; m++) {
       const size_t k = (size_t)e * P + m;
       const int32_t s = sidx[k];
       const int d = dof_of(s);
-      const bool excl = count[d] == 1;
-      const int w = d | (excl ? kExclBit : 0);
-      ss[k] = s >= 0 ? w : -1 - w;
       const int t = m & 15, r = m >> 4;
+      if (t == 0) ice[r] |= (uint32_t)nruns << 16 | (uint32_t)lastpos << 21;
+      if (d != prev + 1) {
+        if (nruns == kIdxMaxRuns) return false;
+        ice[kIdxStart0 + nruns++] = (uint32_t)d;
+        ice[r] |= 1u << t;
+        lastpos = m;
+      }
+      prev = d;
+      const bool excl = count[d] == 1;
       uint32_t *row = &pp[(size_t)e * (npk + 1) * 16];
       row[(r >> 2) * 16 + t] |= (uint32_t)(perm[k] & 0xff) << (8 * (r & 3));
       row[npk * 16 + t] |= ((s < 0 ? 1u : 0u) | (excl ? 2u : 0u)) << (2 * r);
     }
+  }
+  return true;
 }
 
 // Runs over the shared dofs (`shared` increasing: every dof that does not have exactly one copy): consecutive dofs

@@ -14,7 +14,9 @@
 using namespace pa;
 using namespace pa::streamhost;
 
-static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac) {
+// min_block: shortest block of consecutive dofs an element is made of (mesh entities in a real numbering); small values
+// produce elements with more than kIdxMaxRuns runs, which pack_index has to refuse.
+static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, int min_block = 6, bool expect_ok = true) {
   std::mt19937 rng(seed);
   // element -> dof map in tensor order: each element gets P distinct dofs, drawn so that entity-like runs of
   // consecutive dofs are shared between elements (blocks of 1..12 consecutive dofs), random signs
@@ -23,12 +25,17 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac) {
     std::vector<char> used(lsize, 0);
     int filled = 0;
     std::vector<int> dofs;
+    int tries = 0;
     while (filled < P) {
-      const int len = std::min<int>(P - filled, 1 + rng() % 12);
+      // (after many failed placements -- a nearly full dof range -- fall back to single dofs so the loop always ends)
+      const int len = tries > 200 ? 1 : std::min<int>(P - filled, min_block + rng() % 12);
       const int d0 = rng() % (lsize - len + 1);
       bool ok = true;
       for (int j = 0; j < len; j++) ok = ok && !used[d0 + j];
-      if (!ok) continue;
+      if (!ok) {
+        tries++;
+        continue;
+      }
       for (int j = 0; j < len; j++) used[d0 + j] = 1, dofs.push_back(d0 + j);
       filled += len;
     }
@@ -53,21 +60,26 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac) {
   std::vector<char> ess(lsize, 0);
   for (int d = 0; d < lsize; d++) ess[d] = (rng() % 1000) < ess_frac * 1000;
 
-  std::vector<int32_t> ss;
-  std::vector<uint32_t> pp;
-  pack_index(ne, P, lsize, sidx.data(), perm.data(), ss, pp);
-  // essential dofs as stream_set_essential handles them: flagged in the index words, off the direct path in the flag
-  // words, owned by the run list
+  std::vector<uint32_t> ic, pp;
+  const bool ok = pack_index(ne, P, lsize, sidx.data(), perm.data(), ic, pp);
+  if (ok != expect_ok) return std::printf("pack_index returned %d, expected %d\n", (int)ok, (int)expect_ok), 1;
+  if (!ok) return std::printf("ne=%d P=%d: more than %d runs in an element, refused as expected\n", ne, P, kIdxMaxRuns), 0;
+  // the compressed index reproduces every entry's dof
+  for (int e = 0; e < ne; e++)
+    for (int m = 0; m < P; m++)
+      if (index_dof(&ic[(size_t)e * kIdxWords], m) != dof_of(sidx[(size_t)e * P + m]))
+        return std::printf("index decode: element %d entry %d: %d != %d\n", e, m, index_dof(&ic[(size_t)e * kIdxWords], m),
+                           dof_of(sidx[(size_t)e * P + m])), 1;
+  // essential dofs as stream_set_essential handles them: flagged and off the direct path in the flag words, owned by the
+  // run list
   const int npl0 = (P + 15) / 16, npk0 = (npl0 + 3) / 4;
-  std::vector<int32_t> ssb(ss);
   std::vector<uint32_t> ppb(pp);
   for (size_t k = 0; k < (size_t)ne * P; k++) {
-    const int w = ssb[k] >= 0 ? ssb[k] : -1 - ssb[k];
-    if (ess[w & (kExclBit - 1)]) {
-      ssb[k] = ssb[k] >= 0 ? (w | kEssBit) : -1 - (w | kEssBit);
+    if (ess[dof_of(sidx[k])]) {
       const size_t e = k / P;
       const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
       ppb[(e * (npk0 + 1) + npk0) * 16 + t] &= ~(2u << (2 * r));
+      ppb[(e * (npk0 + 1) + npk0) * 16 + t] |= 1u << (18 + r);
     }
   }
   std::vector<int32_t> shared_bc;
@@ -110,10 +122,11 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac) {
     for (int t = 0; t < 16; t++)
       for (int r = 0; r < npl; r++) {
         if (t + 16 * r >= P) continue;
-        const int sv = ssb[(size_t)e * P + t + 16 * r], df = sv >= 0 ? sv : -1 - sv;
-        const double xv = x[df & (kExclBit - 1)];
-        const double v = (df & kEssBit) ? 0.0 : xv;
-        sm[(row[(r >> 2) * 16 + t] >> (8 * (r & 3))) & 255u] = sv >= 0 ? v : -v;
+        const unsigned fw = row[npk * 16 + t];
+        const int dof = index_dof(&ic[(size_t)e * kIdxWords], t + 16 * r);
+        if (dof < 0 || dof >= lsize) return std::printf("decoded dof %d out of range\n", dof), 1;
+        const double v = (fw >> (18 + r)) & 1u ? 0.0 : x[dof];
+        sm[(row[(r >> 2) * 16 + t] >> (8 * (r & 3))) & 255u] = (fw >> (2 * r)) & 1u ? -v : v;
       }
     // element operator: diagonal scaling in tensor order
     if (e < ne)
@@ -126,8 +139,9 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac) {
         const double v = sm[(row[(r >> 2) * 16 + t] >> (8 * (r & 3))) & 255u];
         const double sgv = (fl & 1u) ? -v : v;
         if (fl & 2u) {
-          const int sv = ssb[(size_t)e * P + t + 16 * r], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
-          if (df & kEssBit) return std::printf("essential dof %d on the direct path\n", d), 1;
+          const int d = index_dof(&ic[(size_t)e * kIdxWords], t + 16 * r);
+          if ((row[npk * 16 + t] >> (18 + r)) & 1u) return std::printf("essential dof %d on the direct path\n", d), 1;
+          if (e >= ne) return std::printf("pad element %d on the direct path\n", e), 1;
           y[d] = sgv;
         } else {
           ye[(size_t)e * P + t + 16 * r] = sgv;
@@ -160,8 +174,9 @@ int main() {
   bad += run_case(37, 144, 2000, 1, 0.05);
   bad += run_case(8, 54, 300, 2, 0.1);
   bad += run_case(5, 12, 40, 3, 0.2);
-  bad += run_case(1, 144, 144, 4, 0.0);
+  bad += run_case(1, 144, 400, 4, 0.0);
   bad += run_case(130, 144, 6000, 5, 0.02);
+  bad += run_case(9, 144, 3000, 6, 0.05, 1, false);  // blocks of 1 .. 12 dofs: ~22 runs per element, over the capacity
   return bad;
 }
 

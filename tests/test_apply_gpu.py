@@ -129,7 +129,9 @@ def test_apply_overintegrated(cylinder_mesh, monkeypatch, p, q1d, qf, variant):
 @pytest.mark.parametrize("qf", ["hdiv", "hdivmass"])
 @pytest.mark.parametrize("coef", ["scalar", "aniso"])
 def test_two_right_hand_sides(cylinder_mesh, p, qf, coef):
-    """pa_op_mult2: both vectors through one pass (bit-identical to two separate applies: same arithmetic per vector)."""
+    """pa_op_mult2: both vectors through one pass of the one-shot kernel against two separate applies (which take the
+    streaming kernel where it exists: the same contractions compiled into another kernel, so the results agree to the last
+    bits -- FMA contraction may differ -- rather than bit for bit)."""
     mesh = _multi_attr(cylinder_mesh)
     nd = NDHexSpace(mesh, p)
     geom = ceed.GeomFactorData(mesh, p + 1)
@@ -142,7 +144,8 @@ def test_two_right_hand_sides(cylinder_mesh, p, qf, coef):
     op.mult2(x0, x1, y0, y1)
     op.mult(x0, r0)
     op.mult(x1, r1)
-    assert torch.equal(y0, r0) and torch.equal(y1, r1)
+    for y, r in ((y0, r0), (y1, r1)):
+        assert float((y - r).abs().max()) <= 4e-15 * float(r.abs().max())
 
 
 @pytest.mark.parametrize("p_coarse,p_fine", [(1, 3), (2, 3), (1, 2), (2, 4), (1, 4)])
