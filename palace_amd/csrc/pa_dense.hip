@@ -680,15 +680,7 @@ __global__ void dense_diag_qd_kernel(const DenseArgs a, const int32_t *__restric
     if (M::NCI > 0) part(interp, M::NCI);
     if (M::NCD > 0) part(deriv, M::NCD);
   }
-  const int32_t *oe = off + (size_t)e * a.P;
-  if (cor) {
-    const int8_t *t = cor + 3 * ((size_t)e * a.P + jd);
-    if (t[1]) unsafeAtomicAdd(&diag[oe[jd]], fabs((double)t[1]) * d);
-    if (jd > 0 && t[0]) unsafeAtomicAdd(&diag[oe[jd - 1]], fabs((double)t[0]) * d);
-    if (jd + 1 < a.P && t[2]) unsafeAtomicAdd(&diag[oe[jd + 1]], fabs((double)t[2]) * d);
-  } else {
-    unsafeAtomicAdd(&diag[oe[jd]], d);
-  }
+  diag[gid] = d;  // element diagonal; dense_diag_slot_kernel pushes it through the transposed unsigned restriction
 }
 
 template <int PT>
@@ -890,15 +882,30 @@ __global__ void dense_diag_kernel(const DenseArgs a, const int32_t *__restrict__
     dense_D<MODE>(a, g[cs + (size_t)q * kEB], adj, (int)g[(size_t)q * kEB], w);
     for (int k = 0; k < M::NCT; k++) d += v[k] * w[k];
   }
-  const int32_t *oe = off + (size_t)e * a.P;
+  diag[gid] = d;  // element diagonal; dense_diag_slot_kernel pushes it through the transposed unsigned restriction
+}
+
+// Second half of the diagonal: the E-vector entry of (element e, local dof j) in the block layout of the apply kernels.
+// Plain / oriented restriction: d_e[j]; curl-oriented: (|T_e|^T d_e)[j] = |T[j][j]| d[j] + |T[j+1][j]| d[j+1] + |T[j-1][j]| d[j-1].
+// The gather that follows applies the orientation sign of the entry, which a diagonal does not have: it is cancelled here.
+// (Fixed summation order: the diagonal -- and with it every smoother built on it -- is identical from run to run.)
+__global__ void dense_diag_slot_kernel(const int ne, const int P, const int KP, const int8_t *__restrict__ cor,
+                                       const int32_t *__restrict__ idx, const double *__restrict__ de,
+                                       double *__restrict__ ye) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / P);
+  if (e >= ne) return;
+  const int j = (int)(gid - (long long)e * P);
+  const double *d = de + (size_t)e * P;
+  double v = d[j];
   if (cor) {
-    const int8_t *t = cor + 3 * ((size_t)e * a.P + jd);
-    if (t[1]) unsafeAtomicAdd(&diag[oe[jd]], fabs((double)t[1]) * d);
-    if (jd > 0 && t[0]) unsafeAtomicAdd(&diag[oe[jd - 1]], fabs((double)t[0]) * d);
-    if (jd + 1 < a.P && t[2]) unsafeAtomicAdd(&diag[oe[jd + 1]], fabs((double)t[2]) * d);
-  } else {
-    unsafeAtomicAdd(&diag[oe[jd]], d);
+    const int8_t *t = cor + 3 * ((size_t)e * P + j);
+    v = fabs((double)t[1]) * d[j];
+    if (j + 1 < P) v += fabs((double)t[3 + 0]) * d[j + 1];
+    if (j > 0) v += fabs((double)t[-3 + 2]) * d[j - 1];
   }
+  const size_t pos = ((size_t)(e / kEB) * 4 * KP + j) * kEB + (e % kEB);
+  ye[pos] = idx[pos] < 0 ? -v : v;
 }
 
 DenseArgs make_args(const DenseSub &ds) {
@@ -1244,10 +1251,11 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
   launch_et_gather_raw(ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye, y, accumulate, s);
 }
 
-void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s) {
+void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
   DenseArgs a = make_args(ds);
   const long long n = (long long)ds.ne * ds.P;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  double *diag = dev_alloc<double>((size_t)n);  // element diagonals [ne][P] (set-up path: allocated per call)
   switch (ds.mode) {
 #define PA_DIAG_CASE(MODE)                                                                                   \
   case MODE:                                                                                                 \
@@ -1271,7 +1279,11 @@ void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s) {
     PA_DIAG2_CASE(MODE_CURLMASS2)
 #undef PA_DIAG2_CASE
   }
+  hipLaunchKernelGGL(dense_diag_slot_kernel, grid, block, 0, s, ds.ne, ds.P, ds.KP, ds.d_cor, ds.d_idx, diag, ds.d_ye);
   PA_HIP(hipGetLastError());
+  launch_et_gather_raw(ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye, diag_out, true, s);
+  PA_HIP(hipStreamSynchronize(s));
+  PA_HIP(hipFree(diag));
 }
 
 }  // namespace pa
