@@ -185,6 +185,23 @@ int pa_complex_gmres_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_so
 int pa_csolver_mult(pa_csolver *S, const double *br, const double *bi, double *xr, double *xi, int initial_guess);
 int pa_csolver_stats(const pa_csolver *S, int *iterations, double *initial_res, double *final_res, int *converged);
 void pa_csolver_destroy(pa_csolver *S);
+/* Solver<ComplexOperator> smoothers on a ComplexParOperator (the reference's complex-valued preconditioner route):
+ * kind 0 JacobiSmoother (linalg/jacobi.cpp), 1 ChebyshevSmoother 4th kind, 2 ChebyshevSmoother1stKind
+ * (linalg/chebyshev.cpp:160-293) with the complex inverse diagonal; y = B x or, with initial_guess, y <- y + B (x - A y) */
+typedef struct pa_cprecond pa_cprecond;
+int pa_complex_smoother_create(pa_context *ctx, pa_complex_par_op *A, int kind, int smooth_it, int order, double sf_max,
+                               double sf_min, pa_cprecond **P);
+int pa_complex_smoother_lambda_max(const pa_cprecond *P, double *lambda_max);
+int pa_complex_smoother_mult(pa_cprecond *P, const double *xr, const double *xi, double *yr, double *yi, int initial_guess);
+int pa_csolver_set_complex_preconditioner(pa_csolver *S, pa_cprecond *P);
+/* GeometricMultigridSolver<ComplexOperator> (linalg/gmg.cpp:16-205): complex operators and Chebyshev smoothers on every level
+ * (coarsest first), the real prolongations on both parts, `coarse` a real solver applied to the real and the imaginary part of
+ * level 0 (MfemWrapperSolver, linalg/solver.hpp:67-120; its SetOperator receives the real part of A[0]); takes ownership of it */
+int pa_complex_gmg_create(pa_context *ctx, int nlevels, pa_complex_par_op *const *A, pa_interp *const *P, pa_solver *coarse,
+                          int cycle_it, int smooth_it, int cheby_order, double sf_max, double sf_min, int fourth,
+                          pa_cprecond **out);
+int pa_complex_gmg_smoother_lambda_max(const pa_cprecond *P, int level, double *lambda_max);
+void pa_complex_smoother_destroy(pa_cprecond *P);
 
 /* --- ComplexParOperator (linalg/rap.hpp:124-221, rap.cpp:393-749): y = P^T (Ar + i Ai) P x over two LOCAL operators
  *     (either may be NULL), essential dofs handled once on the complex vector (rap.cpp:436-462: the real part carries

@@ -117,6 +117,16 @@ __global__ void k_cdiag(double ar, double ai, const double *__restrict__ dr, con
     yr[i] = add ? yr[i] + r : r, yi[i] = add ? yi[i] + m : m;
   }
 }
+// d = sd d + sr dinv .* r (chebyshev.cpp:69-156)
+__global__ void k_ccheb(double sd, double sr, const double *__restrict__ pr, const double *__restrict__ pi,
+                        const double *__restrict__ rr, const double *__restrict__ ri, double *__restrict__ dr,
+                        double *__restrict__ di, int first, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double p = pr[i], q = pi[i], a = rr[i], b = ri[i];
+    const double tr = sr * (p * a - q * b), ti = sr * (q * a + p * b);
+    dr[i] = first ? tr : sd * dr[i] + tr, di[i] = first ? ti : sd * di[i] + ti;
+  }
+}
 // y += alpha x (complex alpha)
 __global__ void k_caxpy(double ar, double ai, const double *__restrict__ xr, const double *__restrict__ xi,
                         double *__restrict__ yr, double *__restrict__ yi, long long n) {
@@ -546,6 +556,152 @@ void ComplexParOperator::AddMultHermitianTranspose(const ComplexVector &x, Compl
   linalg::AXPY(*ctx_, a, tt_, y);
 }
 
+// ---- complex smoothers -----------------------------------------------------------------------------------------------
+void ComplexSolver::Mult2(const ComplexVector &, ComplexVector &, ComplexVector &) const {
+  throw pa::Error("Mult2() with temporary storage vector is not implemented for base class Solver<OperType>!");
+}
+
+namespace linalg {
+double SpectralNorm(const Context &c, const ComplexOperator &A, bool herm, double tol, int max_it, uint64_t seed) {
+  ComplexVector u(A.Height()), v(A.Height());
+  SetRandom(c, u.Real(), seed), SetRandom(c, u.Imag(), seed + 0x51ed27ull);
+  auto normalize = [&](ComplexVector &w) {
+    const double nrm = Norml2(c, w);
+    PA_REQUIRE(nrm > 0.0, "zero vector norm in normalization");
+    Scale(c, 1.0 / nrm, w);
+    return nrm;
+  };
+  normalize(u);
+  double l = 0.0, l0 = 0.0;
+  int it = 0;
+  while (it < max_it) {
+    A.Mult(u, v);
+    if (herm)
+      Copy(c, v, u);
+    else
+      A.MultHermitianTranspose(v, u);
+    l = normalize(u);
+    if (it > 0 && std::abs(l - l0) / l0 < tol) break;
+    l0 = l, it++;
+  }
+  return herm ? l : std::sqrt(l);
+}
+}  // namespace linalg
+
+void ComplexJacobiSmoother::SetOperator(const ComplexOperator &op) {
+  height = op.Height(), width = op.Width();
+  dinv_.SetSize(height);
+  op.AssembleDiagonal(dinv_);
+  linalg::Reciprocal(*ctx_, dinv_);
+}
+void ComplexJacobiSmoother::Mult(const ComplexVector &x, ComplexVector &y) const {
+  PA_REQUIRE(!initial_guess, "JacobiSmoother is not implemented for iterative mode!");
+  ComplexDiagonalOperator(*ctx_, dinv_).Mult(x, y);
+}
+
+void ComplexChebyshevSmoother::SetOperator(const ComplexOperator &op) {
+  A_ = &op, height = op.Height(), width = op.Width();
+  dinv_.SetSize(height), d_.SetSize(height), r_.SetSize(height);
+  op.AssembleDiagonal(dinv_);
+  linalg::Reciprocal(*ctx_, dinv_);
+  ComplexDiagonalOperator Dinv(*ctx_, dinv_);
+  ComplexProductOperator DinvA(Dinv, op);
+  lambda_max_ = sf_max_ * linalg::SpectralNorm(*ctx_, DinvA, op.IsReal());
+  PA_REQUIRE(lambda_max_ > 0.0, "Encountered zero maximum eigenvalue in Chebyshev smoother!");
+  if (!fourth_kind_) {  // chebyshev.cpp:244-255
+    double sf_min = sf_min_;
+    if (sf_min <= 0.0) sf_min = 1.69 / (std::pow(order_, 1.68) + 2.11 * order_ + 1.98);
+    const double lambda_min = sf_min * lambda_max_;
+    theta_ = 0.5 * (lambda_max_ + lambda_min), delta_ = 0.5 * (lambda_max_ - lambda_min);
+  }
+}
+void ComplexChebyshevSmoother::Mult(const ComplexVector &x, ComplexVector &y) const { Mult2(x, y, r_); }
+void ComplexChebyshevSmoother::Mult2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const {
+  const Context &c = *ctx_;
+  auto step = [&](double sd, double sr, bool first) {
+    hipLaunchKernelGGL(k_ccheb, dim3(grid(height)), dim3(kB), 0, c.stream, sd, sr, dinv_.Real().Data(), dinv_.Imag().Data(),
+                       r.Real().Data(), r.Imag().Data(), d_.Real().Data(), d_.Imag().Data(), first ? 1 : 0, (long long)height);
+    PA_HIP(hipGetLastError());
+  };
+  for (int it = 0; it < pc_it_; it++) {
+    if (initial_guess || it > 0) {
+      A_->Mult(y, r);
+      linalg::AXPBY(c, 1.0, x, -1.0, r);
+    } else {
+      linalg::Copy(c, x, r);
+      linalg::Fill(c, y, 0.0);
+    }
+    double rhop = fourth_kind_ ? 0.0 : delta_ / theta_;
+    step(0.0, fourth_kind_ ? 4.0 / (3.0 * lambda_max_) : 1.0 / theta_, true);
+    for (int k = 1; k < order_; k++) {
+      linalg::AXPY(c, 1.0, d_, y);
+      A_->AddMult(d_, r, -1.0);
+      if (fourth_kind_) {
+        step((2.0 * k - 1.0) / (2.0 * k + 3.0), (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lambda_max_), false);
+      } else {
+        const double rho = 1.0 / (2.0 * theta_ / delta_ - rhop);
+        step(rho * rhop, 2.0 * rho / delta_, false);
+        rhop = rho;
+      }
+    }
+    linalg::AXPY(c, 1.0, d_, y);
+  }
+}
+
+// ---- complex geometric multigrid (gmg.cpp:16-205) --------------------------------------------------------------------------
+ComplexGeometricMultigridSolver::ComplexGeometricMultigridSolver(const Context &ctx, std::unique_ptr<ComplexSolver> &&coarse_solver,
+                                                                 const std::vector<const Operator *> &P, int cycle_it,
+                                                                 int smooth_it, int cheby_order, double cheby_sf_max,
+                                                                 double cheby_sf_min, bool cheby_4th_kind)
+    : ctx_(&ctx), pc_it_(cycle_it), P_(P), A_(P.size() + 1), B_(P.size() + 1), X_(P.size() + 1), Y_(P.size() + 1),
+      R_(P.size() + 1) {
+  B_[0] = std::move(coarse_solver);
+  for (size_t l = 1; l < B_.size(); l++)
+    B_[l] = std::make_unique<ComplexChebyshevSmoother>(ctx, smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind, cheby_sf_min);
+}
+
+void ComplexGeometricMultigridSolver::SetOperators(const std::vector<const ComplexParOperator *> &ops) {
+  PA_REQUIRE(ops.size() == A_.size(), "Invalid number of levels for operators in multigrid solver setup!");
+  for (size_t l = 0; l < ops.size(); l++) {
+    A_[l] = ops[l];
+    PA_REQUIRE(A_[l]->Width() == A_[l]->Height(), "Invalid operator sizes for GeometricMultigridSolver!");
+    if (l + 1 < ops.size()) PA_REQUIRE(A_[l]->Height() == P_[l]->Width(), "Prolongation / operator size mismatch");
+    B_[l]->SetOperator(*A_[l]);
+    X_[l].SetSize(A_[l]->Height()), Y_[l].SetSize(A_[l]->Height()), R_[l].SetSize(A_[l]->Height());
+  }
+  height = width = ops.back()->Height();
+}
+
+void ComplexGeometricMultigridSolver::Mult(const ComplexVector &x, ComplexVector &y) const {
+  const int L = (int)A_.size();
+  linalg::Copy(*ctx_, x, X_[L - 1]);
+  for (int it = 0; it < pc_it_; it++) VCycle(L - 1, it > 0);
+  linalg::Copy(*ctx_, Y_[L - 1], y);
+}
+
+void ComplexGeometricMultigridSolver::VCycle(int l, bool initial_guess) const {
+  // gmg.cpp:171-205; the real transfer operators act on the real and the imaginary part (gmg.cpp:147-168)
+  const Context &c = *ctx_;
+  B_[l]->SetInitialGuess(initial_guess);
+  if (l == 0) {
+    B_[l]->Mult(X_[l], Y_[l]);
+    return;
+  }
+  B_[l]->Mult2(X_[l], Y_[l], R_[l]);
+  A_[l]->Mult(Y_[l], R_[l]);
+  linalg::AXPBY(c, 1.0, X_[l], -1.0, R_[l]);
+  P_[l - 1]->MultTranspose(R_[l].Real(), X_[l - 1].Real());
+  P_[l - 1]->MultTranspose(R_[l].Imag(), X_[l - 1].Imag());
+  if (A_[l - 1]->NumEssentialTrueDofs())
+    linalg::SetSubVector(c, X_[l - 1], A_[l - 1]->GetEssentialTrueDofs(), A_[l - 1]->NumEssentialTrueDofs(), 0.0);
+  VCycle(l - 1, false);
+  P_[l - 1]->Mult(Y_[l - 1].Real(), R_[l].Real());
+  P_[l - 1]->Mult(Y_[l - 1].Imag(), R_[l].Imag());
+  linalg::AXPY(c, 1.0, R_[l], Y_[l]);
+  B_[l]->SetInitialGuess(true);
+  B_[l]->MultTranspose2(X_[l], Y_[l], R_[l]);
+}
+
 // ---- GMRES / FGMRES on complex vectors: the shared implementation (krylov_impl.hpp) --------------------------------
 namespace {
 struct ComplexKrylovOps {
@@ -554,14 +710,16 @@ struct ComplexKrylovOps {
   const Context &c;
   const ComplexOperator *A_;
   const Solver *B_;
+  const ComplexSolver *Bc_;
   int n;
   void Ensure(Vec &v) const {
     if (v.Size() != n) v.SetSize(n);
   }
   void A(const Vec &x, Vec &y) const { A_->Mult(x, y); }
-  bool HasB() const { return B_ != nullptr; }
-  void B(const Vec &x, Vec &y) const {  // gmg.cpp:147-168: the real preconditioner on both parts
-    B_->Mult(x.Real(), y.Real());
+  bool HasB() const { return B_ != nullptr || Bc_ != nullptr; }
+  void B(const Vec &x, Vec &y) const {
+    if (Bc_) return Bc_->Mult(x, y);
+    B_->Mult(x.Real(), y.Real());  // gmg.cpp:147-168: the real preconditioner on both parts
     B_->Mult(x.Imag(), y.Imag());
   }
   void Copy(const Vec &x, Vec &y) const { linalg::Copy(c, x, y); }
@@ -581,7 +739,7 @@ struct ComplexKrylovOps {
 
 void ComplexGmresSolver::Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess) const {
   PA_REQUIRE(A_, "Operator must be set for GmresSolver::Mult!");
-  ComplexKrylovOps ops{*ctx_, A_, B_, A_->Height()};
+  ComplexKrylovOps ops{*ctx_, A_, B_, Bc_, A_->Height()};
   krylov::Params p;
   p.rel_tol = rel_tol_, p.abs_tol = abs_tol_, p.max_it = max_it_, p.max_dim = max_dim_, p.print = print_;
   p.flexible = flexible_, p.initial_guess = initial_guess;

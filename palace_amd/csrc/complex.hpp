@@ -197,13 +197,112 @@ public:
   void AddMultHermitianTranspose(const ComplexVector &x, ComplexVector &y, std::complex<double> a = 1.0) const override;
 };
 
+// Solver<ComplexOperator> (linalg/solver.hpp:21-65)
+class ComplexSolver {
+protected:
+  int height = 0, width = 0;
+  bool initial_guess = false;
+
+public:
+  virtual ~ComplexSolver() = default;
+  int Height() const { return height; }
+  virtual void SetOperator(const ComplexOperator &op) = 0;
+  void SetInitialGuess(bool guess = true) { initial_guess = guess; }
+  virtual void Mult(const ComplexVector &x, ComplexVector &y) const = 0;
+  virtual void Mult2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const;
+  virtual void MultTranspose2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const { Mult2(x, y, r); }
+};
+
+namespace linalg {
+// power iteration for ||A||_2 (linalg/operator.cpp:583-631): herm = true iterates with A alone
+double SpectralNorm(const Context &c, const ComplexOperator &A, bool herm, double tol = 1e-4, int max_it = 1000, uint64_t seed = 0);
+}
+
+// JacobiSmoother<ComplexOperator> (linalg/jacobi.cpp): y = D^-1 x with the complex diagonal
+class ComplexJacobiSmoother : public ComplexSolver {
+  const Context *ctx_;
+  ComplexVector dinv_;
+
+public:
+  explicit ComplexJacobiSmoother(const Context &ctx) : ctx_(&ctx) {}
+  void SetOperator(const ComplexOperator &op) override;
+  void Mult(const ComplexVector &x, ComplexVector &y) const override;
+};
+
+// ChebyshevSmoother<ComplexOperator> / ChebyshevSmoother1stKind<ComplexOperator> (linalg/chebyshev.cpp:160-293): the same
+// polynomials in D^-1 A with the complex inverse diagonal; lambda_max by power iteration on D^-1 A (Hermitian iteration when
+// the operator is real, chebyshev.cpp:22-28)
+class ComplexChebyshevSmoother : public ComplexSolver {
+  const Context *ctx_;
+  int pc_it_, order_;
+  double sf_max_, sf_min_, lambda_max_ = 0.0, theta_ = 0.0, delta_ = 0.0;
+  bool fourth_kind_;
+  const ComplexOperator *A_ = nullptr;
+  ComplexVector dinv_;
+  mutable ComplexVector d_, r_;
+
+public:
+  ComplexChebyshevSmoother(const Context &ctx, int smooth_it, int poly_order, double sf_max = 1.0, bool fourth_kind = true,
+                           double sf_min = 0.0)
+      : ctx_(&ctx), pc_it_(smooth_it), order_(poly_order), sf_max_(sf_max), sf_min_(sf_min), fourth_kind_(fourth_kind) {
+    PA_REQUIRE(poly_order > 0, "Polynomial order for Chebyshev smoothing must be positive!");
+  }
+  void SetOperator(const ComplexOperator &op) override;
+  double LambdaMax() const { return lambda_max_; }
+  void Mult(const ComplexVector &x, ComplexVector &y) const override;
+  void Mult2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const override;
+};
+
+// MfemWrapperSolver<ComplexOperator> (linalg/solver.hpp:67-120, solver.cpp): a real-valued solver applied to the real and
+// the imaginary part of a complex vector; SetOperator hands it the real part of the complex operator (the reference's
+// pc_mat_real construction for its coarse solvers).  Non-owning.
+class ComplexWrapperSolver : public ComplexSolver {
+  Solver *pc_;
+
+public:
+  explicit ComplexWrapperSolver(Solver &pc) : pc_(&pc) {}
+  void SetOperator(const ComplexOperator &op) override {
+    PA_REQUIRE(op.Real(), "the wrapped real solver needs the real part of the operator");
+    height = op.Height(), width = op.Width();
+    pc_->SetOperator(*op.Real());
+  }
+  void Mult(const ComplexVector &x, ComplexVector &y) const override {
+    pc_->SetInitialGuess(initial_guess);
+    pc_->Mult(x.Real(), y.Real());
+    pc_->Mult(x.Imag(), y.Imag());
+  }
+};
+
+// GeometricMultigridSolver<ComplexOperator> (linalg/gmg.cpp:16-205) with plain Chebyshev smoothers: complex operators and
+// smoothers on every level, the real prolongations applied to both parts, the coarse solver any ComplexSolver (typically a
+// ComplexWrapperSolver around a real one).  Levels 0 (coarsest) .. L-1.
+class ComplexGeometricMultigridSolver : public ComplexSolver {
+  const Context *ctx_;
+  int pc_it_;
+  std::vector<const Operator *> P_;
+  std::vector<const ComplexParOperator *> A_;
+  std::vector<std::unique_ptr<ComplexSolver>> B_;
+  mutable std::vector<ComplexVector> X_, Y_, R_;
+  void VCycle(int l, bool initial_guess) const;
+
+public:
+  ComplexGeometricMultigridSolver(const Context &ctx, std::unique_ptr<ComplexSolver> &&coarse_solver,
+                                  const std::vector<const Operator *> &P, int cycle_it, int smooth_it, int cheby_order,
+                                  double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true);
+  void SetOperators(const std::vector<const ComplexParOperator *> &ops);
+  void SetOperator(const ComplexOperator &) override { throw pa::Error("use SetOperators for multigrid"); }
+  void Mult(const ComplexVector &x, ComplexVector &y) const override;
+  const ComplexSolver &Smoother(int l) const { return *B_[l]; }
+};
+
 // GmresSolver<ComplexOperator> / FgmresSolver<ComplexOperator> (linalg/iterative.cpp:543-871): the shared implementation
 // (krylov_impl.hpp) on ComplexVectors; the preconditioner is a real Solver applied to the real and the imaginary part
 // (linalg/gmg.cpp:147-168 `RealMult`).
 class ComplexGmresSolver {
   const Context *ctx_;
   const ComplexOperator *A_ = nullptr;
-  const Solver *B_ = nullptr;
+  const Solver *B_ = nullptr;          // real preconditioner applied to both parts, or
+  const ComplexSolver *Bc_ = nullptr;  // a complex one
   double rel_tol_ = 0.0, abs_tol_ = 0.0;
   int max_it_ = 100, max_dim_ = -1, print_ = 0;
   bool flexible_ = false;
@@ -219,7 +318,8 @@ public:
   explicit ComplexGmresSolver(const Context &ctx, int print = 0, bool flexible = false)
       : ctx_(&ctx), print_(print), flexible_(flexible), pc_side_(flexible ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT) {}
   void SetOperator(const ComplexOperator &op) { A_ = &op; }
-  void SetPreconditioner(const Solver &pc) { B_ = &pc; }
+  void SetPreconditioner(const Solver &pc) { B_ = &pc, Bc_ = nullptr; }
+  void SetPreconditioner(const ComplexSolver &pc) { Bc_ = &pc, B_ = nullptr; }
   void SetTol(double t) { rel_tol_ = t; }
   void SetAbsTol(double t) { abs_tol_ = t; }
   void SetMaxIter(int n) { max_it_ = n; }

@@ -651,6 +651,87 @@ int pa_csolver_stats(const pa_csolver *S, int *its, double *initial_res, double 
 }
 void pa_csolver_destroy(pa_csolver *S) { delete S; }
 
+/* Solver<ComplexOperator> smoothers on a ComplexParOperator: kind 0 JacobiSmoother, 1 ChebyshevSmoother (4th kind),
+ * 2 ChebyshevSmoother1stKind (linalg/jacobi.cpp, chebyshev.cpp:160-293) */
+struct pa_cprecond {
+  pa_context *ctx;
+  std::unique_ptr<ComplexSolver> solver;
+  int n = 0;
+  pa_solver *owned_real = nullptr;  // real coarse solver wrapped by a multigrid solver
+  ~pa_cprecond() {
+    solver.reset();
+    delete owned_real;
+  }
+};
+int pa_complex_smoother_create(pa_context *ctx, pa_complex_par_op *A, int kind, int smooth_it, int order, double sf_max,
+                               double sf_min, pa_cprecond **P) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && A && P, "null argument");
+    auto p = std::make_unique<pa_cprecond>();
+    p->ctx = ctx, p->n = A->op->Height();
+    if (kind == 0)
+      p->solver = std::make_unique<ComplexJacobiSmoother>(ctx->ctx);
+    else
+      p->solver = std::make_unique<ComplexChebyshevSmoother>(ctx->ctx, smooth_it, order, sf_max, kind == 1, sf_min);
+    p->solver->SetOperator(*A->op);
+    *P = p.release();
+  });
+}
+int pa_complex_smoother_lambda_max(const pa_cprecond *P, double *lambda_max) {
+  return guarded([&] {
+    auto *c = dynamic_cast<const ComplexChebyshevSmoother *>(P ? P->solver.get() : nullptr);
+    PA_REQUIRE(c && lambda_max, "not a Chebyshev smoother");
+    *lambda_max = c->LambdaMax();
+  });
+}
+/* y = B x (initial_guess == 0) or y <- y + B (x - A y) */
+int pa_complex_smoother_mult(pa_cprecond *P, const double *xr, const double *xi, double *yr, double *yi, int initial_guess) {
+  return guarded([&] {
+    PA_REQUIRE(P && xr && xi && yr && yi, "null argument");
+    ComplexVector x(const_cast<double *>(xr), const_cast<double *>(xi), P->n), y(yr, yi, P->n);
+    P->solver->SetInitialGuess(initial_guess != 0);
+    P->solver->Mult(x, y);
+    P->solver->SetInitialGuess(false);
+  });
+}
+int pa_csolver_set_complex_preconditioner(pa_csolver *S, pa_cprecond *P) {
+  return guarded([&] {
+    PA_REQUIRE(S && P, "null argument");
+    S->solver->SetPreconditioner(*P->solver);
+  });
+}
+/* GeometricMultigridSolver<ComplexOperator> (gmg.cpp:16-205) over ComplexParOperators A[0 .. nlevels) (coarsest first), real
+ * prolongations P[0 .. nlevels - 1), complex Chebyshev smoothers and `coarse`, a real solver applied to the real and the
+ * imaginary part of the coarsest level (MfemWrapperSolver); takes ownership of `coarse` */
+int pa_complex_gmg_create(pa_context *ctx, int nlevels, pa_complex_par_op *const *A, pa_interp *const *P, pa_solver *coarse,
+                          int cycle_it, int smooth_it, int cheby_order, double sf_max, double sf_min, int fourth,
+                          pa_cprecond **out) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && nlevels >= 1 && A && coarse && out, "Empty finite element space hierarchy during multigrid solver setup!");
+    std::vector<const Operator *> Pv;
+    std::vector<const ComplexParOperator *> Av;
+    for (int l = 0; l + 1 < nlevels; l++) Pv.push_back(P[l]->op.get());
+    for (int l = 0; l < nlevels; l++) Av.push_back(A[l]->op.get());
+    auto p = std::make_unique<pa_cprecond>();
+    p->ctx = ctx, p->n = Av.back()->Height(), p->owned_real = coarse;
+    auto g = std::make_unique<ComplexGeometricMultigridSolver>(ctx->ctx, std::make_unique<ComplexWrapperSolver>(*coarse->solver), Pv,
+                                                               cycle_it, smooth_it, cheby_order, sf_max, sf_min, fourth != 0);
+    g->SetOperators(Av);
+    p->solver = std::move(g);
+    *out = p.release();
+  });
+}
+int pa_complex_gmg_smoother_lambda_max(const pa_cprecond *P, int level, double *lambda_max) {
+  return guarded([&] {
+    auto *g = dynamic_cast<const ComplexGeometricMultigridSolver *>(P ? P->solver.get() : nullptr);
+    PA_REQUIRE(g && lambda_max, "not a complex multigrid solver");
+    auto *c = dynamic_cast<const ComplexChebyshevSmoother *>(&g->Smoother(level));
+    PA_REQUIRE(c, "level smoother is not a Chebyshev smoother");
+    *lambda_max = c->LambdaMax();
+  });
+}
+void pa_complex_smoother_destroy(pa_cprecond *P) { delete P; }
+
 /* ---- ComplexParOperator (linalg/rap.cpp:393-749) over two local operators ---------------------------------------- */
 int pa_complex_par_op_create(pa_context *ctx, pa_op *Ar, pa_op *Ai, int n_true, pa_halo *halo, pa_complex_par_op **A) {
   return guarded([&] {

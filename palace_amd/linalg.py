@@ -552,7 +552,13 @@ class ComplexParOperator:
 
 
 class ComplexParGmres(ComplexGmres):
-    """GmresSolver / FgmresSolver <ComplexOperator> (linalg/iterative.cpp:543-871) on a ComplexParOperator."""
+    """GmresSolver / FgmresSolver <ComplexOperator> (linalg/iterative.cpp:543-871) on a ComplexParOperator.  `precond`: a real
+    Solver (applied to both parts) or None; set_complex_preconditioner installs a ComplexSmoother instead."""
+
+    def set_complex_preconditioner(self, smoother):
+        _lib.check(_L().pa_csolver_set_complex_preconditioner(self.handle, smoother.handle))
+        self._keep = self._keep + (smoother,)
+        return self
 
     def __init__(self, ctx, A: ComplexParOperator, precond=None, rel_tol=1e-8, abs_tol=0.0, max_it=200, restart=-1,
                  flexible=False, pc_side="left", orthogonalization="MGS", print_level=0):
@@ -568,3 +574,61 @@ class ComplexParGmres(ComplexGmres):
                                                  {"left": 0, "right": 1}[pc_side],
                                                  {"MGS": 0, "CGS": 1, "CGS2": 2}[orthogonalization], print_level,
                                                  C.byref(self.handle)))
+
+
+class ComplexSmoother:
+    """Solver<ComplexOperator> smoothers on a ComplexParOperator: 'jacobi', 'chebyshev' (4th kind), 'chebyshev1'
+    (linalg/jacobi.cpp, chebyshev.cpp:160-293 with the complex inverse diagonal)."""
+
+    def __init__(self, ctx, A: ComplexParOperator, kind="chebyshev", order=4, smooth_it=1, sf_max=1.0, sf_min=0.0):
+        L = _L()
+        L.pa_complex_smoother_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                 C.c_void_p]
+        L.pa_complex_smoother_destroy.restype = None
+        L.pa_complex_smoother_destroy.argtypes = [C.c_void_p]
+        self.ctx, self._keep = ctx, A
+        self.handle = C.c_void_p()
+        _lib.check(L.pa_complex_smoother_create(ctx.handle, A.handle, {"jacobi": 0, "chebyshev": 1, "chebyshev1": 2}[kind],
+                                                smooth_it, order, sf_max, sf_min, C.byref(self.handle)))
+
+    def lambda_max(self):
+        v = C.c_double()
+        _lib.check(_L().pa_complex_smoother_lambda_max(self.handle, C.byref(v)))
+        return v.value
+
+    def mult(self, xr, xi, yr, yi, initial_guess=False):
+        _lib.check(_L().pa_complex_smoother_mult(self.handle, C.c_void_p(xr.data_ptr()), C.c_void_p(xi.data_ptr()),
+                                                 C.c_void_p(yr.data_ptr()), C.c_void_p(yi.data_ptr()), int(initial_guess)))
+        return yr, yi
+
+    def __del__(self):
+        try:
+            _L().pa_complex_smoother_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class ComplexGmg(ComplexSmoother):
+    """GeometricMultigridSolver<ComplexOperator> (gmg.cpp:16-205): ComplexParOperators per level (coarsest first), real
+    prolongations, complex Chebyshev smoothers, a real coarse solver on both parts; takes ownership of `coarse`."""
+
+    def __init__(self, ctx, A_levels, P_levels, coarse, cycle_it=1, smooth_it=1, cheby_order=4, sf_max=1.0, sf_min=0.0,
+                 fourth_kind=True):
+        L = _L()
+        L.pa_complex_gmg_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.pa_complex_smoother_destroy.restype = None
+        L.pa_complex_smoother_destroy.argtypes = [C.c_void_p]
+        n = len(A_levels)
+        Ah = (C.c_void_p * n)(*[a.handle for a in A_levels])
+        Ph = (C.c_void_p * max(1, n - 1))(*[q.handle for q in P_levels])
+        self.ctx, self._keep = ctx, (A_levels, P_levels, coarse)
+        self.handle = C.c_void_p()
+        _lib.check(L.pa_complex_gmg_create(ctx.handle, n, Ah, Ph, coarse.handle, cycle_it, smooth_it, cheby_order, sf_max, sf_min,
+                                           int(fourth_kind), C.byref(self.handle)))
+        coarse._owned_by_parent = True
+
+    def level_lambda_max(self, level):
+        v = C.c_double()
+        _lib.check(_L().pa_complex_gmg_smoother_lambda_max(self.handle, int(level), C.byref(v)))
+        return v.value

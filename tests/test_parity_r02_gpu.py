@@ -359,3 +359,138 @@ def test_complex_gmres_variants(cylinder_mesh, kind):
     assert st["converged"] == conv and abs(st["iterations"] - it) <= 1, (st, it)
     assert _rel(x, xo) < 1e-7
     assert np.linalg.norm(A_mult(x) - b) < 1e-6 * np.linalg.norm(b)
+
+
+class _ComplexOracleOp:
+    """(Ar + i Ai) over two real oracle operators, with the interface ChebyshevOracle expects."""
+
+    def __init__(self, oR, oI):
+        self.oR, self.oI, self.n = oR, oI, oR.n
+
+    def mult(self, v):
+        return (self.oR.mult(v.real) - self.oI.mult(v.imag)) + 1j * (self.oI.mult(v.real) + self.oR.mult(v.imag))
+
+    def diagonal(self):
+        return self.oR.diagonal() + 1j * self.oI.diagonal()
+
+
+@pytest.mark.parametrize("kind", ["chebyshev", "chebyshev1"])
+def test_complex_chebyshev_smoothers(cylinder_mesh, kind):
+    """ChebyshevSmoother<ComplexOperator> / ChebyshevSmoother1stKind<ComplexOperator> (chebyshev.cpp:160-293): the complex
+    inverse diagonal, lambda_max of D^-1 A by the non-Hermitian power iteration (operator.cpp:583-631), Mult with and without
+    an initial guess -- against the oracle's polynomial evaluated in numpy complex arithmetic with the device's lambda_max;
+    then the reference's complex-preconditioner route end to end: FGMRES with the complex smoother as the preconditioner."""
+    mesh, p = cylinder_mesh, 2
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ogeom = util.oracle_geom(mesh, q1d)
+    cc, bc = util.make_ctx("identity")
+    cm, bm = util.make_ctx("scalar")
+    ctx = linalg.Context()
+    KM = ceed.curlcurlmass_operator(geom, nd, bm, bc)
+    Mi = ceed.ndmass_operator(geom, nd, bm)
+    ess = nd.ess_dofs()
+    A = linalg.ComplexParOperator(ctx, KM, Mi, ess, linalg.DIAG_ONE)
+    oA = _ComplexOracleOp(util.FastParOperatorOracle(nd, ogeom, "hdivmass", np.concatenate([bm, bc]), ess, q1d, cm, cc),
+                          util.FastParOperatorOracle(nd, ogeom, "hcurl", bm, ess, q1d, cm, policy=po.DIAG_ZERO))
+    n = nd.ndofs
+    S = linalg.ComplexSmoother(ctx, A, kind, order=5, sf_min=0.0)
+    lam = S.lambda_max()
+    # the power iteration on D^-1 A: the spectral norm of the (non-Hermitian) operator, checked against a dense computation
+    Ad = np.array([oA.mult(e) for e in np.eye(n)]).T if n <= 2500 else None
+    if Ad is not None:
+        ref = np.linalg.norm((1.0 / oA.diagonal())[:, None] * Ad, 2)
+        assert abs(lam - ref) < 1e-2 * ref, (lam, ref)  # power iteration stopped at a 1e-4 change (operator.cpp:609-616)
+    oS = po.ChebyshevOracle(oA, 5, lambda_max=lam, first_kind=kind == "chebyshev1")
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    y0 = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    xr, xi = _dev(x.real.copy()), _dev(x.imag.copy())
+    yr, yi = S.mult(xr, xi, _new(n), _new(n))
+    assert _rel(yr.cpu().numpy() + 1j * yi.cpu().numpy(), oS.mult2(x, None, False)) < 1e-10
+    yr, yi = S.mult(xr, xi, _dev(y0.real.copy()), _dev(y0.imag.copy()), initial_guess=True)
+    assert _rel(yr.cpu().numpy() + 1j * yi.cpu().numpy(), oS.mult2(x, y0.copy(), True)) < 1e-10
+    # FGMRES with the complex smoother as the preconditioner
+    b = x.copy()
+    b[ess] = 0.0
+    K = linalg.ComplexParGmres(ctx, A, None, rel_tol=1e-9, max_it=300, restart=80, flexible=True)
+    K.set_complex_preconditioner(S)
+    sr, si = K.mult(_dev(b.real.copy()), _dev(b.imag.copy()), _new(n), _new(n))
+    sol = sr.cpu().numpy() + 1j * si.cpu().numpy()
+    xo, it, hist, conv = po.gmres(oA.mult, b, lambda r: oS.mult2(r, None, False), rel_tol=1e-9, max_it=300, max_dim=80,
+                                  pc_side="right", flexible=True)
+    st = K.stats()
+    assert st["converged"] and conv and abs(st["iterations"] - it) <= 1, (st, it)
+    assert _rel(sol, xo) < 1e-7
+
+
+def test_complex_jacobi_smoother(cylinder_mesh):
+    """JacobiSmoother<ComplexOperator> (linalg/jacobi.cpp): y = D^-1 x with the complex diagonal."""
+    mesh, p = cylinder_mesh, 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, p + 1)
+    ogeom = util.oracle_geom(mesh, p + 1)
+    cc, bc = util.make_ctx("identity")
+    cm, bm = util.make_ctx("scalar")
+    ctx = linalg.Context()
+    ess = nd.ess_dofs()
+    A = linalg.ComplexParOperator(ctx, ceed.curlcurlmass_operator(geom, nd, bm, bc), ceed.ndmass_operator(geom, nd, bm), ess,
+                                  linalg.DIAG_ONE)
+    oA = _ComplexOracleOp(util.FastParOperatorOracle(nd, ogeom, "hdivmass", np.concatenate([bm, bc]), ess, p + 1, cm, cc),
+                          util.FastParOperatorOracle(nd, ogeom, "hcurl", bm, ess, p + 1, cm, policy=po.DIAG_ZERO))
+    n = nd.ndofs
+    J = linalg.ComplexSmoother(ctx, A, "jacobi")
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    yr, yi = J.mult(_dev(x.real.copy()), _dev(x.imag.copy()), _new(n), _new(n))
+    assert _rel(yr.cpu().numpy() + 1j * yi.cpu().numpy(), x / oA.diagonal()) < 1e-13
+
+
+def test_complex_multigrid_preconditioner(cylinder_mesh):
+    """GeometricMultigridSolver<ComplexOperator> (gmg.cpp:16-205): complex operators (K + eps M) + i eps M on the levels
+    p = 1, 2, complex 4th-kind Chebyshev smoothers, the real prolongation on both parts, a real Chebyshev-Jacobi coarse solver
+    on both parts (MfemWrapperSolver) -- one V-cycle against the oracle's V-cycle in complex arithmetic, then FGMRES
+    preconditioned with it against the oracle's FGMRES."""
+    mesh = cylinder_mesh
+    orders, q1d = [1, 2], 3
+    nds = [NDHexSpace(mesh, p) for p in orders]
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ogeom = util.oracle_geom(mesh, q1d)
+    cc, bc = util.make_ctx("identity")
+    cm, bm = util.make_ctx("scalar")
+    ctx = linalg.Context()
+    fine_r = ceed.curlcurlmass_operator(geom, nds[-1], bm, bc)
+    fine_i = ceed.ndmass_operator(geom, nds[-1], bm)
+    loc_r = [fine_r.coarsen(geom, nds[0]), fine_r]
+    loc_i = [fine_i.coarsen(geom, nds[0]), fine_i]
+    A = [linalg.ComplexParOperator(ctx, r, i, s.ess_dofs(), linalg.DIAG_ONE) for r, i, s in zip(loc_r, loc_i, nds)]
+    P = [linalg.Interp(ctx, nds[0], nds[1])]
+    PR0 = linalg.ParOperator(ctx, loc_r[0], nds[0].ess_dofs(), linalg.DIAG_ONE)
+    coarse = linalg.chebyshev(ctx, PR0, 4)
+    lam0 = coarse.lambda_max()
+    B = linalg.ComplexGmg(ctx, A, P, coarse, cheby_order=4)
+    blob = np.concatenate([bm, bc])
+    oR = [util.FastParOperatorOracle(s, ogeom, "hdivmass", blob, s.ess_dofs(), q1d, cm, cc) for s in nds]
+    oI = [util.FastParOperatorOracle(s, ogeom, "hcurl", bm, s.ess_dofs(), q1d, cm, policy=po.DIAG_ZERO) for s in nds]
+    oA = [_ComplexOracleOp(r, i) for r, i in zip(oR, oI)]
+    oP = po.InterpOracle(nds[0].elem_dof_lex, nds[0].elem_sign_lex, nds[1].elem_dof_lex, nds[1].elem_sign_lex, nds[0].ndofs,
+                         nds[1].ndofs, po.nd_hex_interp_lex(1, 2))
+    parts = lambda f: (lambda v: f(np.ascontiguousarray(v.real)) + 1j * f(np.ascontiguousarray(v.imag)))  # noqa: E731
+    sm = [None, po.ChebyshevOracle(oA[1], 4, lambda_max=B.level_lambda_max(1))]
+    oc = po.ChebyshevOracle(oR[0], 4, lambda_max=lam0)
+    oB = po.GMGOracle(oA, [(parts(oP.mult), parts(oP.mult_transpose))], sm, parts(lambda r: oc.mult2(r, None, False)),
+                      [s.ess_dofs() for s in nds])
+    n = nds[-1].ndofs
+    rng = np.random.default_rng(23)
+    r = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    r[nds[-1].ess_dofs()] = 0.0
+    zr, zi = B.mult(_dev(r.real.copy()), _dev(r.imag.copy()), _new(n), _new(n))
+    assert _rel(zr.cpu().numpy() + 1j * zi.cpu().numpy(), oB.mult(r)) < 1e-9
+    K = linalg.ComplexParGmres(ctx, A[-1], None, rel_tol=1e-9, max_it=200, restart=80, flexible=True)
+    K.set_complex_preconditioner(B)
+    sr, si = K.mult(_dev(r.real.copy()), _dev(r.imag.copy()), _new(n), _new(n))
+    xo, it, hist, conv = po.gmres(oA[-1].mult, r, oB.mult, rel_tol=1e-9, max_it=200, max_dim=80, pc_side="right", flexible=True)
+    st = K.stats()
+    assert st["converged"] and conv and abs(st["iterations"] - it) <= 1, (st, it)
+    assert _rel(sr.cpu().numpy() + 1j * si.cpu().numpy(), xo) < 1e-7
