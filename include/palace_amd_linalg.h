@@ -196,10 +196,13 @@ int pa_complex_smoother_mult(pa_cprecond *P, const double *xr, const double *xi,
 int pa_csolver_set_complex_preconditioner(pa_csolver *S, pa_cprecond *P);
 /* GeometricMultigridSolver<ComplexOperator> (linalg/gmg.cpp:16-205): complex operators and Chebyshev smoothers on every level
  * (coarsest first), the real prolongations on both parts, `coarse` a real solver applied to the real and the imaginary part of
- * level 0 (MfemWrapperSolver, linalg/solver.hpp:67-120; its SetOperator receives the real part of A[0]); takes ownership of it */
-int pa_complex_gmg_create(pa_context *ctx, int nlevels, pa_complex_par_op *const *A, pa_interp *const *P, pa_solver *coarse,
-                          int cycle_it, int smooth_it, int cheby_order, double sf_max, double sf_min, int fourth,
-                          pa_cprecond **out);
+ * level 0 (MfemWrapperSolver, linalg/solver.hpp:67-120; its SetOperator receives the real part of A[0]); takes ownership of it.
+ * A_aux / G (both or neither): complex auxiliary-space operators and discrete gradients per level => the smoothers are
+ * DistRelaxationSmoother<ComplexOperator> (linalg/distrelaxation.cpp:14-151).  lambda_max: two values per level {primary,
+ * auxiliary (0 for plain Chebyshev)} */
+int pa_complex_gmg_create(pa_context *ctx, int nlevels, pa_complex_par_op *const *A, pa_interp *const *P,
+                          pa_complex_par_op *const *A_aux, pa_interp *const *G, pa_solver *coarse, int cycle_it, int smooth_it,
+                          int cheby_order, double sf_max, double sf_min, int fourth, pa_cprecond **out);
 int pa_complex_gmg_smoother_lambda_max(const pa_cprecond *P, int level, double *lambda_max);
 void pa_complex_smoother_destroy(pa_cprecond *P);
 

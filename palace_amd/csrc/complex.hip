@@ -648,25 +648,100 @@ void ComplexChebyshevSmoother::Mult2(const ComplexVector &x, ComplexVector &y, C
   }
 }
 
+ComplexDistRelaxationSmoother::ComplexDistRelaxationSmoother(const Context &ctx, const Operator &G, int smooth_it,
+                                                             int cheby_smooth_it, int cheby_order, double cheby_sf_max,
+                                                             double cheby_sf_min, bool cheby_4th_kind)
+    : ctx_(&ctx), pc_it_(smooth_it), G_(&G) {
+  B_ = std::make_unique<ComplexChebyshevSmoother>(ctx, cheby_smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind, cheby_sf_min);
+  B_G_ = std::make_unique<ComplexChebyshevSmoother>(ctx, cheby_smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind, cheby_sf_min);
+}
+void ComplexDistRelaxationSmoother::SetOperators(const ComplexOperator &op, const ComplexParOperator &op_G) {
+  PA_REQUIRE(op.Height() == G_->Height() && op.Width() == G_->Height() && op_G.Height() == G_->Width() &&
+                 op_G.Width() == G_->Width(),
+             "Invalid operator sizes for DistRelaxationSmoother!");
+  A_ = &op, A_G_ = &op_G;
+  x_G_.SetSize(op_G.Height()), y_G_.SetSize(op_G.Height()), r_G_.SetSize(op_G.Height()), t_.SetSize(op.Height());
+  B_->SetOperator(op);
+  B_G_->SetOperator(op_G);
+  height = op.Height(), width = op.Width();
+}
+void ComplexDistRelaxationSmoother::Mult2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const {
+  // distrelaxation.cpp:98-123
+  const Context &c = *ctx_;
+  for (int it = 0; it < pc_it_; it++) {
+    B_->SetInitialGuess(initial_guess || it > 0);
+    B_->Mult2(x, y, r);
+    A_->Mult(y, r);
+    linalg::AXPBY(c, 1.0, x, -1.0, r);
+    G_->MultTranspose(r.Real(), x_G_.Real());
+    G_->MultTranspose(r.Imag(), x_G_.Imag());
+    if (A_G_->NumEssentialTrueDofs())
+      linalg::SetSubVector(c, x_G_, A_G_->GetEssentialTrueDofs(), A_G_->NumEssentialTrueDofs(), 0.0);
+    B_G_->SetInitialGuess(false);
+    B_G_->Mult2(x_G_, y_G_, r_G_);
+    G_->Mult(y_G_.Real(), r.Real());
+    G_->Mult(y_G_.Imag(), r.Imag());
+    linalg::AXPY(c, 1.0, r, y);
+  }
+}
+void ComplexDistRelaxationSmoother::MultTranspose2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const {
+  // distrelaxation.cpp:125-151
+  const Context &c = *ctx_;
+  B_->SetInitialGuess(true);
+  for (int it = 0; it < pc_it_; it++) {
+    if (initial_guess || it > 0) {
+      A_->Mult(y, r);
+      linalg::AXPBY(c, 1.0, x, -1.0, r);
+      G_->MultTranspose(r.Real(), x_G_.Real());
+      G_->MultTranspose(r.Imag(), x_G_.Imag());
+    } else {
+      linalg::Fill(c, y, 0.0);
+      G_->MultTranspose(x.Real(), x_G_.Real());
+      G_->MultTranspose(x.Imag(), x_G_.Imag());
+    }
+    if (A_G_->NumEssentialTrueDofs())
+      linalg::SetSubVector(c, x_G_, A_G_->GetEssentialTrueDofs(), A_G_->NumEssentialTrueDofs(), 0.0);
+    B_G_->SetInitialGuess(false);
+    B_G_->MultTranspose2(x_G_, y_G_, r_G_);
+    G_->Mult(y_G_.Real(), r.Real());
+    G_->Mult(y_G_.Imag(), r.Imag());
+    linalg::AXPY(c, 1.0, r, y);
+    B_->MultTranspose2(x, y, r);
+  }
+}
+
 // ---- complex geometric multigrid (gmg.cpp:16-205) --------------------------------------------------------------------------
 ComplexGeometricMultigridSolver::ComplexGeometricMultigridSolver(const Context &ctx, std::unique_ptr<ComplexSolver> &&coarse_solver,
                                                                  const std::vector<const Operator *> &P, int cycle_it,
                                                                  int smooth_it, int cheby_order, double cheby_sf_max,
-                                                                 double cheby_sf_min, bool cheby_4th_kind)
+                                                                 double cheby_sf_min, bool cheby_4th_kind,
+                                                                 const std::vector<const Operator *> *G)
     : ctx_(&ctx), pc_it_(cycle_it), P_(P), A_(P.size() + 1), B_(P.size() + 1), X_(P.size() + 1), Y_(P.size() + 1),
       R_(P.size() + 1) {
+  PA_REQUIRE(!G || G->size() == B_.size(), "Invalid input for distributive relaxation smoother auxiliary space transfer operators!");
   B_[0] = std::move(coarse_solver);
-  for (size_t l = 1; l < B_.size(); l++)
-    B_[l] = std::make_unique<ComplexChebyshevSmoother>(ctx, smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind, cheby_sf_min);
+  for (size_t l = 1; l < B_.size(); l++) {
+    if (G)  // gmg.cpp:41-47
+      B_[l] = std::make_unique<ComplexDistRelaxationSmoother>(ctx, *(*G)[l], smooth_it, 1, cheby_order, cheby_sf_max, cheby_sf_min,
+                                                              cheby_4th_kind);
+    else
+      B_[l] = std::make_unique<ComplexChebyshevSmoother>(ctx, smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind, cheby_sf_min);
+  }
 }
 
-void ComplexGeometricMultigridSolver::SetOperators(const std::vector<const ComplexParOperator *> &ops) {
+void ComplexGeometricMultigridSolver::SetOperators(const std::vector<const ComplexParOperator *> &ops,
+                                                   const std::vector<const ComplexParOperator *> *aux_ops) {
   PA_REQUIRE(ops.size() == A_.size(), "Invalid number of levels for operators in multigrid solver setup!");
   for (size_t l = 0; l < ops.size(); l++) {
     A_[l] = ops[l];
     PA_REQUIRE(A_[l]->Width() == A_[l]->Height(), "Invalid operator sizes for GeometricMultigridSolver!");
     if (l + 1 < ops.size()) PA_REQUIRE(A_[l]->Height() == P_[l]->Width(), "Prolongation / operator size mismatch");
-    B_[l]->SetOperator(*A_[l]);
+    if (auto *dist = dynamic_cast<ComplexDistRelaxationSmoother *>(B_[l].get())) {
+      PA_REQUIRE(aux_ops && aux_ops->size() == ops.size(),
+                 "Distributive relaxation smoother relies on both primary space and auxiliary space operators!");
+      dist->SetOperators(*A_[l], *(*aux_ops)[l]);
+    } else
+      B_[l]->SetOperator(*A_[l]);
     X_[l].SetSize(A_[l]->Height()), Y_[l].SetSize(A_[l]->Height()), R_[l].SetSize(A_[l]->Height());
   }
   height = width = ops.back()->Height();

@@ -253,6 +253,29 @@ public:
   void Mult2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const override;
 };
 
+// DistRelaxationSmoother<ComplexOperator> (linalg/distrelaxation.cpp:14-151): Chebyshev on the complex Nedelec operator, then
+// Chebyshev on the complex auxiliary (H1) operator through the real discrete gradient G applied to both parts
+class ComplexDistRelaxationSmoother : public ComplexSolver {
+  const Context *ctx_;
+  int pc_it_;
+  const Operator *G_;
+  const ComplexOperator *A_ = nullptr;
+  const ComplexParOperator *A_G_ = nullptr;
+  std::unique_ptr<ComplexChebyshevSmoother> B_, B_G_;
+  mutable ComplexVector x_G_, y_G_, r_G_, t_;
+
+public:
+  ComplexDistRelaxationSmoother(const Context &ctx, const Operator &G, int smooth_it, int cheby_smooth_it, int cheby_order,
+                                double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true);
+  void SetOperator(const ComplexOperator &) override { throw pa::Error("use SetOperators(op, op_G)"); }
+  void SetOperators(const ComplexOperator &op, const ComplexParOperator &op_G);
+  const ComplexChebyshevSmoother &Primary() const { return *B_; }
+  const ComplexChebyshevSmoother &Auxiliary() const { return *B_G_; }
+  void Mult(const ComplexVector &x, ComplexVector &y) const override { Mult2(x, y, t_); }
+  void Mult2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const override;
+  void MultTranspose2(const ComplexVector &x, ComplexVector &y, ComplexVector &r) const override;
+};
+
 // MfemWrapperSolver<ComplexOperator> (linalg/solver.hpp:67-120, solver.cpp): a real-valued solver applied to the real and
 // the imaginary part of a complex vector; SetOperator hands it the real part of the complex operator (the reference's
 // pc_mat_real construction for its coarse solvers).  Non-owning.
@@ -273,9 +296,9 @@ public:
   }
 };
 
-// GeometricMultigridSolver<ComplexOperator> (linalg/gmg.cpp:16-205) with plain Chebyshev smoothers: complex operators and
-// smoothers on every level, the real prolongations applied to both parts, the coarse solver any ComplexSolver (typically a
-// ComplexWrapperSolver around a real one).  Levels 0 (coarsest) .. L-1.
+// GeometricMultigridSolver<ComplexOperator> (linalg/gmg.cpp:16-205): complex operators and smoothers (Chebyshev, or the
+// auxiliary-space smoother when the discrete gradients G are given) on every level, the real prolongations applied to both
+// parts, the coarse solver any ComplexSolver (typically a ComplexWrapperSolver around a real one).  Levels 0 (coarsest) .. L-1.
 class ComplexGeometricMultigridSolver : public ComplexSolver {
   const Context *ctx_;
   int pc_it_;
@@ -288,8 +311,10 @@ class ComplexGeometricMultigridSolver : public ComplexSolver {
 public:
   ComplexGeometricMultigridSolver(const Context &ctx, std::unique_ptr<ComplexSolver> &&coarse_solver,
                                   const std::vector<const Operator *> &P, int cycle_it, int smooth_it, int cheby_order,
-                                  double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true);
-  void SetOperators(const std::vector<const ComplexParOperator *> &ops);
+                                  double cheby_sf_max = 1.0, double cheby_sf_min = 0.0, bool cheby_4th_kind = true,
+                                  const std::vector<const Operator *> *G = nullptr);
+  void SetOperators(const std::vector<const ComplexParOperator *> &ops,
+                    const std::vector<const ComplexParOperator *> *aux_ops = nullptr);
   void SetOperator(const ComplexOperator &) override { throw pa::Error("use SetOperators for multigrid"); }
   void Mult(const ComplexVector &x, ComplexVector &y) const override;
   const ComplexSolver &Smoother(int l) const { return *B_[l]; }

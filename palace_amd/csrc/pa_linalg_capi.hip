@@ -703,20 +703,24 @@ int pa_csolver_set_complex_preconditioner(pa_csolver *S, pa_cprecond *P) {
 /* GeometricMultigridSolver<ComplexOperator> (gmg.cpp:16-205) over ComplexParOperators A[0 .. nlevels) (coarsest first), real
  * prolongations P[0 .. nlevels - 1), complex Chebyshev smoothers and `coarse`, a real solver applied to the real and the
  * imaginary part of the coarsest level (MfemWrapperSolver); takes ownership of `coarse` */
-int pa_complex_gmg_create(pa_context *ctx, int nlevels, pa_complex_par_op *const *A, pa_interp *const *P, pa_solver *coarse,
-                          int cycle_it, int smooth_it, int cheby_order, double sf_max, double sf_min, int fourth,
-                          pa_cprecond **out) {
+int pa_complex_gmg_create(pa_context *ctx, int nlevels, pa_complex_par_op *const *A, pa_interp *const *P,
+                          pa_complex_par_op *const *A_aux, pa_interp *const *G, pa_solver *coarse, int cycle_it, int smooth_it,
+                          int cheby_order, double sf_max, double sf_min, int fourth, pa_cprecond **out) {
   return guarded([&] {
     PA_REQUIRE(ctx && nlevels >= 1 && A && coarse && out, "Empty finite element space hierarchy during multigrid solver setup!");
-    std::vector<const Operator *> Pv;
-    std::vector<const ComplexParOperator *> Av;
+    PA_REQUIRE((A_aux == nullptr) == (G == nullptr), "auxiliary operators and discrete gradients come together");
+    std::vector<const Operator *> Pv, Gv;
+    std::vector<const ComplexParOperator *> Av, Xv;
     for (int l = 0; l + 1 < nlevels; l++) Pv.push_back(P[l]->op.get());
     for (int l = 0; l < nlevels; l++) Av.push_back(A[l]->op.get());
+    if (G)
+      for (int l = 0; l < nlevels; l++) Gv.push_back(G[l] ? G[l]->op.get() : nullptr), Xv.push_back(A_aux[l] ? A_aux[l]->op.get() : nullptr);
     auto p = std::make_unique<pa_cprecond>();
     p->ctx = ctx, p->n = Av.back()->Height(), p->owned_real = coarse;
     auto g = std::make_unique<ComplexGeometricMultigridSolver>(ctx->ctx, std::make_unique<ComplexWrapperSolver>(*coarse->solver), Pv,
-                                                               cycle_it, smooth_it, cheby_order, sf_max, sf_min, fourth != 0);
-    g->SetOperators(Av);
+                                                               cycle_it, smooth_it, cheby_order, sf_max, sf_min, fourth != 0,
+                                                               G ? &Gv : nullptr);
+    g->SetOperators(Av, G ? &Xv : nullptr);
     p->solver = std::move(g);
     *out = p.release();
   });
@@ -725,9 +729,14 @@ int pa_complex_gmg_smoother_lambda_max(const pa_cprecond *P, int level, double *
   return guarded([&] {
     auto *g = dynamic_cast<const ComplexGeometricMultigridSolver *>(P ? P->solver.get() : nullptr);
     PA_REQUIRE(g && lambda_max, "not a complex multigrid solver");
-    auto *c = dynamic_cast<const ComplexChebyshevSmoother *>(&g->Smoother(level));
+    const ComplexSolver &s = g->Smoother(level);
+    if (auto *d = dynamic_cast<const ComplexDistRelaxationSmoother *>(&s)) {  // {primary, auxiliary}
+      lambda_max[0] = d->Primary().LambdaMax(), lambda_max[1] = d->Auxiliary().LambdaMax();
+      return;
+    }
+    auto *c = dynamic_cast<const ComplexChebyshevSmoother *>(&s);
     PA_REQUIRE(c, "level smoother is not a Chebyshev smoother");
-    *lambda_max = c->LambdaMax();
+    lambda_max[0] = c->LambdaMax(), lambda_max[1] = 0.0;
   });
 }
 void pa_complex_smoother_destroy(pa_cprecond *P) { delete P; }

@@ -613,22 +613,27 @@ class ComplexGmg(ComplexSmoother):
     prolongations, complex Chebyshev smoothers, a real coarse solver on both parts; takes ownership of `coarse`."""
 
     def __init__(self, ctx, A_levels, P_levels, coarse, cycle_it=1, smooth_it=1, cheby_order=4, sf_max=1.0, sf_min=0.0,
-                 fourth_kind=True):
+                 fourth_kind=True, A_aux=None, G=None):
         L = _L()
-        L.pa_complex_gmg_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                            C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.pa_complex_gmg_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.pa_complex_smoother_destroy.restype = None
         L.pa_complex_smoother_destroy.argtypes = [C.c_void_p]
         n = len(A_levels)
         Ah = (C.c_void_p * n)(*[a.handle for a in A_levels])
         Ph = (C.c_void_p * max(1, n - 1))(*[q.handle for q in P_levels])
-        self.ctx, self._keep = ctx, (A_levels, P_levels, coarse)
+        self.ctx, self._keep = ctx, (A_levels, P_levels, coarse, A_aux, G)
         self.handle = C.c_void_p()
-        _lib.check(L.pa_complex_gmg_create(ctx.handle, n, Ah, Ph, coarse.handle, cycle_it, smooth_it, cheby_order, sf_max, sf_min,
-                                           int(fourth_kind), C.byref(self.handle)))
+        Xh = Gh = None
+        if G is not None:
+            Xh = (C.c_void_p * n)(*[a.handle if a is not None else None for a in A_aux])
+            Gh = (C.c_void_p * n)(*[g.handle if g is not None else None for g in G])
+        _lib.check(L.pa_complex_gmg_create(ctx.handle, n, Ah, Ph, Xh, Gh, coarse.handle, cycle_it, smooth_it, cheby_order, sf_max,
+                                           sf_min, int(fourth_kind), C.byref(self.handle)))
         coarse._owned_by_parent = True
 
     def level_lambda_max(self, level):
-        v = C.c_double()
-        _lib.check(_L().pa_complex_gmg_smoother_lambda_max(self.handle, int(level), C.byref(v)))
-        return v.value
+        """(primary, auxiliary) eigenvalue estimates of the level's smoother (auxiliary = 0 for plain Chebyshev)."""
+        v = (C.c_double * 2)()
+        _lib.check(_L().pa_complex_gmg_smoother_lambda_max(self.handle, int(level), v))
+        return v[0], v[1]

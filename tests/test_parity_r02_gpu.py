@@ -447,11 +447,13 @@ def test_complex_jacobi_smoother(cylinder_mesh):
     assert _rel(yr.cpu().numpy() + 1j * yi.cpu().numpy(), x / oA.diagonal()) < 1e-13
 
 
-def test_complex_multigrid_preconditioner(cylinder_mesh):
+@pytest.mark.parametrize("hiptmair", [False, True])
+def test_complex_multigrid_preconditioner(cylinder_mesh, hiptmair):
     """GeometricMultigridSolver<ComplexOperator> (gmg.cpp:16-205): complex operators (K + eps M) + i eps M on the levels
-    p = 1, 2, complex 4th-kind Chebyshev smoothers, the real prolongation on both parts, a real Chebyshev-Jacobi coarse solver
-    on both parts (MfemWrapperSolver) -- one V-cycle against the oracle's V-cycle in complex arithmetic, then FGMRES
-    preconditioned with it against the oracle's FGMRES."""
+    p = 1, 2, complex 4th-kind Chebyshev smoothers -- or the complex auxiliary-space smoother (DistRelaxationSmoother
+    <ComplexOperator>, distrelaxation.cpp:14-151, over the complex H1 operators eps (grad, grad) + i eps (grad, grad) / 2) --
+    the real prolongation on both parts, a real Chebyshev-Jacobi coarse solver on both parts (MfemWrapperSolver): one
+    V-cycle against the oracle's V-cycle in complex arithmetic, then FGMRES preconditioned with it against the oracle's."""
     mesh = cylinder_mesh
     orders, q1d = [1, 2], 3
     nds = [NDHexSpace(mesh, p) for p in orders]
@@ -469,17 +471,44 @@ def test_complex_multigrid_preconditioner(cylinder_mesh):
     PR0 = linalg.ParOperator(ctx, loc_r[0], nds[0].ess_dofs(), linalg.DIAG_ONE)
     coarse = linalg.chebyshev(ctx, PR0, 4)
     lam0 = coarse.lambda_max()
-    B = linalg.ComplexGmg(ctx, A, P, coarse, cheby_order=4)
     blob = np.concatenate([bm, bc])
     oR = [util.FastParOperatorOracle(s, ogeom, "hdivmass", blob, s.ess_dofs(), q1d, cm, cc) for s in nds]
     oI = [util.FastParOperatorOracle(s, ogeom, "hcurl", bm, s.ess_dofs(), q1d, cm, policy=po.DIAG_ZERO) for s in nds]
     oA = [_ComplexOracleOp(r, i) for r, i in zip(oR, oI)]
+    parts = lambda f: (lambda v: f(np.ascontiguousarray(v.real)) + 1j * f(np.ascontiguousarray(v.imag)))  # noqa: E731
+    kw, keep = {}, []
+    if hiptmair:
+        half = po.CoeffCtx(attr_mat=[0], mat_coeff=[np.array([1.04])])  # eps / 2
+        b_half = half.pack()
+        h1s = [H1HexSpace(mesh, p) for p in orders]
+        fr = ceed.diffusion_operator(geom, h1s[-1], bm)
+        fi = ceed.diffusion_operator(geom, h1s[-1], b_half)
+        lr, li = [fr.coarsen(geom, h1s[0]), fr], [fi.coarsen(geom, h1s[0]), fi]
+        A_aux = [linalg.ComplexParOperator(ctx, r, i, s.ess_dofs(), linalg.DIAG_ONE) for r, i, s in zip(lr, li, h1s)]
+        G = [linalg.Gradient(ctx, h, s) for h, s in zip(h1s, nds)]
+        kw, keep = dict(A_aux=A_aux, G=G), [h1s, lr, li]
+    B = linalg.ComplexGmg(ctx, A, P, coarse, cheby_order=4, **kw)
     oP = po.InterpOracle(nds[0].elem_dof_lex, nds[0].elem_sign_lex, nds[1].elem_dof_lex, nds[1].elem_sign_lex, nds[0].ndofs,
                          nds[1].ndofs, po.nd_hex_interp_lex(1, 2))
-    parts = lambda f: (lambda v: f(np.ascontiguousarray(v.real)) + 1j * f(np.ascontiguousarray(v.imag)))  # noqa: E731
-    sm = [None, po.ChebyshevOracle(oA[1], 4, lambda_max=B.level_lambda_max(1))]
+    lam_p, lam_a = B.level_lambda_max(1)
+    sm_p = po.ChebyshevOracle(oA[1], 4, lambda_max=lam_p)
+    if hiptmair:
+        h1 = h1s[1]
+        interp, grad = po.h1_hex_dense_tables(2, q1d)
+        mk = lambda c, pol: po.ParOperatorOracle([po.CeedOperatorOracle(h1.ndofs, h1.elem_dof_lex, None, interp, grad, ogeom,  # noqa: E731
+                                                                        po.QF_HCURL, c, None, vector_fe=False)], h1.ess_dofs(),
+                                                 diag_policy=pol)
+        oAG = _ComplexOracleOp(mk(cm, po.DIAG_ONE), mk(half, po.DIAG_ZERO))
+        oAG.n = h1.ndofs
+        ones = np.ones(h1.elem_dof_lex.shape, dtype=np.int8)
+        oG = po.InterpOracle(h1.elem_dof_lex, ones, nds[1].elem_dof_lex, nds[1].elem_sign_lex, h1.ndofs, nds[1].ndofs,
+                             po.nd_hex_gradient_lex(2))
+        sm_a = po.ChebyshevOracle(oAG, 4, lambda_max=lam_a)
+        sm1 = po.DistRelaxationOracle(oA[1], oAG, (parts(oG.mult), parts(oG.mult_transpose)), sm_p, sm_a, h1.ess_dofs())
+    else:
+        sm1 = sm_p
     oc = po.ChebyshevOracle(oR[0], 4, lambda_max=lam0)
-    oB = po.GMGOracle(oA, [(parts(oP.mult), parts(oP.mult_transpose))], sm, parts(lambda r: oc.mult2(r, None, False)),
+    oB = po.GMGOracle(oA, [(parts(oP.mult), parts(oP.mult_transpose))], [None, sm1], parts(lambda r: oc.mult2(r, None, False)),
                       [s.ess_dofs() for s in nds])
     n = nds[-1].ndofs
     rng = np.random.default_rng(23)
