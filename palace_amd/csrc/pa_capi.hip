@@ -383,6 +383,9 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
         if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
         launch_nd_hex_apply(*so, x, y, nullptr, masked, s);
       }
+    } else if (so->d_idxc && overwrite && first && (!masked || so->d_perm_s_bc)) {  // streaming form, see above
+      launch_h1_hex_stream(*so, x, y, masked, s);
+      launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
     } else {
       launch_h1_hex_apply(*so, x, masked, s);
       launch_et_gather(*so, y, !(overwrite && first), s);
@@ -403,7 +406,20 @@ void finalize_exclusive(pa_op *op) {
   if (mode && std::string(mode) == "0") return;
   if (op->subs.size() != 1 || !op->dsubs.empty()) return;
   SubOp *so = op->subs[0];
-  if (so->fe_type != PA_FE_HCURL || !so->d_ye || so->d_perm_x) return;
+  if (!so->d_ye || so->d_perm_x || !so->h_shared.empty()) return;
+  if (so->fe_type == PA_FE_H1) {
+    // H1 blocks: only the streaming kernel stores exclusive dofs directly; the one-shot kernel and its gather keep the
+    // full dof list (no d_perm_x / d_shared), the streaming arrays get the list of shared dofs
+    if (!h1_hex_stream_ok(*so)) return;
+    std::vector<int32_t> cnt((size_t)so->lsize, 0);
+    for (const int32_t s : so->h_sidx) cnt[s >= 0 ? s : -1 - s]++;
+    for (int d = 0; d < so->lsize; d++)
+      if (cnt[d] != 1) so->h_shared.push_back(d);
+    so->n_shared = (int)so->h_shared.size();
+    build_stream(*so);
+    return;
+  }
+  if (so->fe_type != PA_FE_HCURL) return;
   const size_t nnz = so->h_sidx.size();
   std::vector<int32_t> count((size_t)so->lsize, 0);
   for (size_t k = 0; k < nnz; k++) count[so->h_sidx[k] >= 0 ? so->h_sidx[k] : -1 - so->h_sidx[k]]++;
@@ -821,15 +837,16 @@ int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
       so->d_sidx_bc = dev_upload(bc.data(), bc.size());
     }
     for (DenseSub *ds : op->dsubs) dense_set_essential(*ds, flag);
-    for (SubOp *so : op->subs)
+    for (SubOp *so : op->subs) {
       if (so->d_shared) {  // flagged copy of the gather list: essential rows are fixed up inside the gather kernel
         std::vector<int32_t> lb(so->h_shared);
         for (auto &d : lb)
           if (flag[d]) d |= kEssBit;
         hipFree(so->d_shared_bc);
         so->d_shared_bc = dev_upload(lb.data(), lb.size());
-        stream_set_essential(*so, flag);
       }
+      if (so->d_idxc) stream_set_essential(*so, flag);
+    }
     op->has_essential = true;
   });
 }
@@ -844,7 +861,9 @@ int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream) {
 int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_policy, void *stream, int *handled) {
   return guarded([&] {
     PA_REQUIRE(op && op->has_essential && handled, "pa_op_set_essential has not been called");
-    const bool fuse = op->subs.size() == 1 && op->dsubs.empty() && nd_hex_fuses_essential(*op->subs[0]);
+    const bool fuse = op->subs.size() == 1 && op->dsubs.empty() &&
+                      (op->subs[0]->fe_type == PA_FE_HCURL ? nd_hex_fuses_essential(*op->subs[0])
+                                                           : (op->subs[0]->d_idxc && op->subs[0]->d_perm_s_bc));
     apply(op, x, y, true, (hipStream_t)stream, true, fuse ? (diag_policy ? 1 : 0) : -1);
     *handled = fuse ? 1 : 0;
   });

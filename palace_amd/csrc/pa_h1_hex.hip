@@ -422,7 +422,11 @@ void launch_h1_hex_qdata(SubOp &so, hipStream_t s) {
   const bool use_g = so.qf == PA_QF_HCURL_33 || so.qf == PA_QF_HCURLMASS_33;
   auto *qd = new QData;
   qd->ncomp = (int)use_v + 6 * (int)use_g;
-  qd->d = dev_alloc<double>((size_t)so.ne * qd->ncomp * so.Q);
+  {  // padded to whole batches of four elements (the streaming kernel reads them), pad = 0
+    const size_t nq = (size_t)((so.ne + 3) & ~3) * qd->ncomp * so.Q;
+    qd->d = dev_alloc<double>(nq);
+    PA_HIP(hipMemsetAsync(qd->d, 0, nq * sizeof(double), s));
+  }
   CoeffDev cm{}, cd{};
   if (so.qf == PA_QF_H1_1) cm = so.c0.dev();
   if (so.qf == PA_QF_HCURL_33) cd = so.c0.dev();

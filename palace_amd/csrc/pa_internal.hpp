@@ -236,6 +236,8 @@ void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
 void launch_nd_hex_metric(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 // pa_nd_hex_stream.hip
+bool h1_hex_stream_ok(const SubOp &so);
+void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s);
 bool nd_hex_stream_ok(const SubOp &so);
 void build_stream(SubOp &so);
 void stream_set_essential(SubOp &so, const std::vector<char> &flag);

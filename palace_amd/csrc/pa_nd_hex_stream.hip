@@ -406,11 +406,13 @@ bool nd_hex_stream_ok(const SubOp &so) {
 // exclusive flags).  Host work proportional to the index array, once per operator.  Every per-element array is padded
 // to a multiple of four elements (one batch); the pad entries are flagged essential (read as zero).
 void build_stream(SubOp &so) {
-  if (so.d_idxc || !nd_hex_stream_ok(so)) return;
+  if (so.d_idxc || !(nd_hex_stream_ok(so) || h1_hex_stream_ok(so))) return;
   const int P = so.P, ne = so.ne, nep = (ne + 3) & ~3;
   std::vector<uint32_t> ic, pp;
   // (a numbering that breaks an element's dofs into more than kIdxMaxRuns runs keeps the one-shot kernel)
-  if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp)) return;
+  if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp,
+                              so.fe_type == PA_FE_H1 ? streamhost::kIdxStart0H1 : streamhost::kIdxStart0))
+    return;
   so.h_perm_s = pp;
   so.d_idxc = dev_upload(ic.data(), ic.size());
   so.d_perm_s = dev_upload(pp.data(), pp.size());

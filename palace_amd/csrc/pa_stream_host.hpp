@@ -26,21 +26,22 @@ inline int dof_of(int32_t s) { return s >= 0 ? s : -1 - s; }
 //   word r < npl        entries 16 r .. 16 r + 15:  bits 0-15  bit j set = entry 16 r + j starts a run
 //                                                     bits 16-20 number of runs that start before entry 16 r
 //                                                     bits 21-28 position of the last run start before entry 16 r
-//   word kIdxStart0 + k first dof of run k (k < kIdxMaxRuns)
+//   word start0 + k     first dof of run k (k < kIdxWords - start0)
 // dof(m) = start[run(m)] + m - first entry of run(m), see index_dof.  Signs, the only-copy flag and the essential flag
-// travel in the flag word of pp.
-constexpr int kIdxWords = 32, kIdxStart0 = 12, kIdxMaxRuns = 20;
+// travel in the flag word of pp.  start0 = kIdxStart0 (20 runs) for H(curl) elements (up to 9 slice words); H1 elements
+// (at most 4 slice words, but 27 entities: 8 vertices + 12 edges + 6 faces + interior) use kIdxStart0H1 (28 runs).
+constexpr int kIdxWords = 32, kIdxStart0 = 12, kIdxMaxRuns = kIdxWords - kIdxStart0, kIdxStart0H1 = 4;
 
-inline int index_dof(const uint32_t *ic, int m) {  // host model of the device decode (nd_hex_stream_kernel: gather)
+inline int index_dof(const uint32_t *ic, int m, int start0 = kIdxStart0) {  // host model of the device decode (gather lambdas)
   const int r = m >> 4, t = m & 15;
   const uint32_t w = ic[r], low = (w & 0xffffu) & ((2u << t) - 1u);
   int bits = 0, top = -1;
   for (int j = 0; j < 16; j++)
     if (low >> j & 1u) bits++, top = j;
   const int rid = (int)((w >> 16) & 31u) + bits - 1;
-  if (rid < 0 || rid >= kIdxMaxRuns) throw std::runtime_error("index decode: entry without a run");
+  if (rid < 0 || rid >= kIdxWords - start0) throw std::runtime_error("index decode: entry without a run");
   const int pos = low ? 16 * r + top : (int)((w >> 21) & 255u);
-  return (int)ic[kIdxStart0 + rid] + (m - pos);
+  return (int)ic[start0 + rid] + (m - pos);
 }
 
 // sidx / perm: [ne][P] signed sorted index and tensor-order slot of sorted entry m (make_sub).  Output, padded to a
@@ -49,13 +50,14 @@ inline int index_dof(const uint32_t *ic, int m) {  // host model of the device d
 //   pp [nep][npk + 1][16]    lane t of an element holds entries m = t + 16 r: word k carries the 8-bit slots of
 //                            r = 4 k .. 4 k + 3, the last word bit 2 r = flipped, bit 2 r + 1 = only copy
 //                            (bits 18 + r: essential, set in the copy stream_set_essential makes)
-// Returns false when an element has more than kIdxMaxRuns runs (the caller keeps the one-shot kernel for that block).
+// Returns false when an element has more than kIdxWords - start0 runs (the caller keeps the one-shot kernel for that block).
 inline bool pack_index(int ne, int P, int lsize, const int32_t *sidx, const uint16_t *perm, std::vector<uint32_t> &ic,
-                       std::vector<uint32_t> &pp) {
+                       std::vector<uint32_t> &pp, int start0 = kIdxStart0) {
   if (P > 256) throw std::runtime_error("element too large for 8-bit slots");
   if (lsize >= kExclBit) throw std::runtime_error("too many local dofs for the streaming index encoding");
   const int nep = (ne + 3) & ~3, npl = (P + 15) / 16, npk = (npl + 3) / 4;
-  if (npl > 9) throw std::runtime_error("element too large for the flag word");
+  if (npl > 9 || npl > start0) throw std::runtime_error("element too large for the flag word / slice words");
+  const int max_runs = kIdxWords - start0;
   const size_t nnz = (size_t)ne * P;
   std::vector<int32_t> count((size_t)lsize, 0);
   for (size_t k = 0; k < nnz; k++) count[dof_of(sidx[k])]++;
@@ -77,8 +79,8 @@ inline bool pack_index(int ne, int P, int lsize, const int32_t *sidx, const uint
       const int t = m & 15, r = m >> 4;
       if (t == 0) ice[r] |= (uint32_t)nruns << 16 | (uint32_t)lastpos << 21;
       if (d != prev + 1) {
-        if (nruns == kIdxMaxRuns) return false;
-        ice[kIdxStart0 + nruns++] = (uint32_t)d;
+        if (nruns == max_runs) return false;
+        ice[start0 + nruns++] = (uint32_t)d;
         ice[r] |= 1u << t;
         lastpos = m;
       }

@@ -16,7 +16,8 @@ using namespace pa::streamhost;
 
 // min_block: shortest block of consecutive dofs an element is made of (mesh entities in a real numbering); small values
 // produce elements with more than kIdxMaxRuns runs, which pack_index has to refuse.
-static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, int min_block = 6, bool expect_ok = true) {
+static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, int min_block = 6, bool expect_ok = true,
+                    int start0 = kIdxStart0) {
   std::mt19937 rng(seed);
   // element -> dof map in tensor order: each element gets P distinct dofs, drawn so that entity-like runs of
   // consecutive dofs are shared between elements (blocks of 1..12 consecutive dofs), random signs
@@ -61,14 +62,14 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, in
   for (int d = 0; d < lsize; d++) ess[d] = (rng() % 1000) < ess_frac * 1000;
 
   std::vector<uint32_t> ic, pp;
-  const bool ok = pack_index(ne, P, lsize, sidx.data(), perm.data(), ic, pp);
+  const bool ok = pack_index(ne, P, lsize, sidx.data(), perm.data(), ic, pp, start0);
   if (ok != expect_ok) return std::printf("pack_index returned %d, expected %d\n", (int)ok, (int)expect_ok), 1;
   if (!ok) return std::printf("ne=%d P=%d: more than %d runs in an element, refused as expected\n", ne, P, kIdxMaxRuns), 0;
   // the compressed index reproduces every entry's dof
   for (int e = 0; e < ne; e++)
     for (int m = 0; m < P; m++)
-      if (index_dof(&ic[(size_t)e * kIdxWords], m) != dof_of(sidx[(size_t)e * P + m]))
-        return std::printf("index decode: element %d entry %d: %d != %d\n", e, m, index_dof(&ic[(size_t)e * kIdxWords], m),
+      if (index_dof(&ic[(size_t)e * kIdxWords], m, start0) != dof_of(sidx[(size_t)e * P + m]))
+        return std::printf("index decode: element %d entry %d: %d != %d\n", e, m, index_dof(&ic[(size_t)e * kIdxWords], m, start0),
                            dof_of(sidx[(size_t)e * P + m])), 1;
   // essential dofs as stream_set_essential handles them: flagged and off the direct path in the flag words, owned by the
   // run list
@@ -123,7 +124,7 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, in
       for (int r = 0; r < npl; r++) {
         if (t + 16 * r >= P) continue;
         const unsigned fw = row[npk * 16 + t];
-        const int dof = index_dof(&ic[(size_t)e * kIdxWords], t + 16 * r);
+        const int dof = index_dof(&ic[(size_t)e * kIdxWords], t + 16 * r, start0);
         if (dof < 0 || dof >= lsize) return std::printf("decoded dof %d out of range\n", dof), 1;
         const double v = (fw >> (18 + r)) & 1u ? 0.0 : x[dof];
         sm[(row[(r >> 2) * 16 + t] >> (8 * (r & 3))) & 255u] = (fw >> (2 * r)) & 1u ? -v : v;
@@ -139,7 +140,7 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, in
         const double v = sm[(row[(r >> 2) * 16 + t] >> (8 * (r & 3))) & 255u];
         const double sgv = (fl & 1u) ? -v : v;
         if (fl & 2u) {
-          const int d = index_dof(&ic[(size_t)e * kIdxWords], t + 16 * r);
+          const int d = index_dof(&ic[(size_t)e * kIdxWords], t + 16 * r, start0);
           if ((row[npk * 16 + t] >> (18 + r)) & 1u) return std::printf("essential dof %d on the direct path\n", d), 1;
           if (e >= ne) return std::printf("pad element %d on the direct path\n", e), 1;
           y[d] = sgv;
@@ -177,6 +178,8 @@ int main() {
   bad += run_case(1, 144, 400, 4, 0.0);
   bad += run_case(130, 144, 6000, 5, 0.02);
   bad += run_case(9, 144, 3000, 6, 0.05, 1, false);  // blocks of 1 .. 12 dofs: ~22 runs per element, over the capacity
+  bad += run_case(40, 64, 900, 7, 0.05, 1, true, kIdxStart0H1);  // H1 layout: 4 slice words, up to 28 runs
+  bad += run_case(11, 27, 300, 8, 0.1, 1, true, kIdxStart0H1);
   return bad;
 }
 

@@ -109,3 +109,57 @@ def test_h1_prolongation(cylinder_mesh):
         xf = np.random.default_rng(4).uniform(-1, 1, hf.ndofs)
         yc = P.mult_transpose(_dev(xf), _new(hc.ndofs)).cpu().numpy()
         assert _rel(yc, o.mult_transpose(xf)) < 1e-13
+
+
+def test_h1_streaming_kernel_all_orders():
+    """The streaming H1 kernel (pa_h1_hex_stream.hip) is on by default at p = 3 only; PALACE_AMD_STREAM_H1=all switches it on
+    for every order (the switch is read once per process, hence the subprocess): diffusion, mass and diffusion + mass at
+    p = 1, 2, 3 with four quadrature points per direction, with and without essential dofs, against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from oracle import palace_oracle as po
+from palace_amd import ceed, linalg
+from palace_amd.fem.fespace import H1HexSpace
+from palace_amd.fem.mesh import HexMesh
+from tests import util
+from tests.test_h1_gpu import _multi_attr, _oracle, _ctxs, _dev, _new, _rel
+d = np.load(%r)
+mesh = _multi_attr(HexMesh(x=d["x"], elem_nodes=d["elem_nodes"].astype(np.int64), attr=d["attr"], bdr_faces=d["bdr_faces"],
+                           bdr_attr=d["bdr_attr"]))
+q1d = 4
+geom = ceed.GeomFactorData(mesh, q1d)
+ogeom = util.oracle_geom(mesh, q1d)
+c_mass, c_diff = _ctxs()
+ctx = linalg.Context()
+for p in (1, 2, 3):
+    h1 = H1HexSpace(mesh, p)
+    for qf in ("diffusion", "mass", "diffusionmass"):
+        if qf == "diffusion":
+            op, o = ceed.diffusion_operator(geom, h1, c_diff.pack()), _oracle(h1, ogeom, po.QF_HCURL, c_diff, None, q1d)
+        elif qf == "mass":
+            op, o = ceed.h1mass_operator(geom, h1, c_mass.pack()), _oracle(h1, ogeom, po.QF_H1MASS, c_mass, None, q1d)
+        else:
+            op, o = (ceed.diffusionmass_operator(geom, h1, c_mass.pack(), c_diff.pack()),
+                     _oracle(h1, ogeom, po.QF_HCURLMASS, c_mass, c_diff, q1d))
+        x = np.random.default_rng(p).uniform(-1, 1, h1.ndofs)
+        y = op.mult(_dev(x), _new(h1.ndofs)).cpu().numpy()
+        ref = o.apply_add(x, np.zeros(h1.ndofs))
+        assert _rel(y, ref) < 1e-12, (p, qf, _rel(y, ref))
+        ess = h1.ess_dofs()
+        A = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+        ya = A.mult(_dev(x), _new(h1.ndofs)).cpu().numpy()
+        tx = x.copy(); tx[ess] = 0.0
+        rb = o.apply_add(tx, np.zeros(h1.ndofs)); rb[ess] = x[ess]
+        assert _rel(ya, rb) < 1e-12, (p, qf, "bc", _rel(ya, rb))
+print("OK")
+''' % (root, os.path.join(root, "tests", "golden", "cylinder_hex_mesh.npz"))
+    env = dict(os.environ, PALACE_AMD_STREAM_H1="all")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
