@@ -50,8 +50,14 @@ enum pa_qfunction {
   PA_QF_L2_1 = 6,         /* f_apply_l2_1         fem/qfunctions/1/l2_1_qf.h:10-24          curl-curl (scalar curl, q_w input) */
   PA_QF_HDIVMASS_22 = 7,  /* f_apply_hdivmass_22  fem/qfunctions/22/hdivmass_22_qf.h:11-37  curl-curl + mass */
   /* boundary elements (dim = 2 in space_dim = 3; dense-table path only) */
-  PA_QF_HCURL_32 = 8      /* f_apply_hcurl_32     fem/qfunctions/32/hcurl_32_qf.h:10-30     ND surface mass (impedance,
+  PA_QF_HCURL_32 = 8,     /* f_apply_hcurl_32     fem/qfunctions/32/hcurl_32_qf.h:10-30     ND surface mass (impedance,
                              absorbing and lumped-port boundary terms) */
+  /* mixed H(curl) / H(div) Piola maps on one H(curl) space (the Floquet-periodic terms of SpaceOperator,
+   * models/spaceoperator.cpp:305-309); tensor-product hexahedra, matrix-free D */
+  PA_QF_HCURLHDIV_33 = 9, /* f_apply_hcurlhdiv_33 fem/qfunctions/33/hcurlhdiv_33_qf.h:10-31 MixedVectorWeakCurlIntegrator:
+                             (C u, curl v), trial Interp, test Curl */
+  PA_QF_HDIVHCURL_33 = 10 /* f_apply_hdivhcurl_33 fem/qfunctions/33/hcurlhdiv_33_qf.h:33-54 MixedVectorCurlIntegrator:
+                             (C curl u, v), trial Curl, test Interp */
 };
 
 enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1, PA_FE_HDIV = 2 /* dense path only: RT mass (Interp + hdiv_33) */ };

@@ -312,6 +312,28 @@ def apply_hdiv_33(ctx: CoeffCtx, geom, u):
     return np.transpose(wdetJ[..., None] * v, (0, 2, 1))
 
 
+def apply_hcurlhdiv_33(ctx: CoeffCtx, geom, u):
+    """hcurlhdiv_33_qf.h:10-31 (f_apply_hcurlhdiv_33): v = w detJ (J/detJ)^T C adjJt u -- H(curl) values in, H(div)
+    (curl) test functions out: the weak curl (C u, curl v) of MixedVectorWeakCurlIntegrator (integ/mixedveccurl.cpp:75-120)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    wdetJ = geom[:, 1, :]
+    adj = np.transpose(geom[:, 2:, :], (0, 2, 1))
+    Jl, _ = adjJt33(adj)
+    v = mult_AtBCx33(Jl, ctx.unpack3(attr), adj, np.transpose(u, (0, 2, 1)))
+    return np.transpose(wdetJ[..., None] * v, (0, 2, 1))
+
+
+def apply_hdivhcurl_33(ctx: CoeffCtx, geom, u):
+    """hcurlhdiv_33_qf.h:33-54 (f_apply_hdivhcurl_33): v = w detJ adjJt^T C (J/detJ) u -- curls in, H(curl) test values
+    out: (C curl u, v) of MixedVectorCurlIntegrator (integ/mixedveccurl.cpp:21-73)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    wdetJ = geom[:, 1, :]
+    adj = np.transpose(geom[:, 2:, :], (0, 2, 1))
+    Jl, _ = adjJt33(adj)
+    v = mult_AtBCx33(adj, ctx.unpack3(attr), Jl, np.transpose(u, (0, 2, 1)))
+    return np.transpose(wdetJ[..., None] * v, (0, 2, 1))
+
+
 def apply_hdivmass_33(ctx_mass: CoeffCtx, ctx_curl: CoeffCtx, geom, u, curlu):
     """hdivmass_33_qf.h:10-44 (mass coefficient first, then the curl-curl one)."""
     return apply_hcurl_33(ctx_mass, geom, u), apply_hdiv_33(ctx_curl, geom, curlu)
@@ -408,6 +430,7 @@ def apply_hcurl_32(ctx, geom, u):
 QF_HCURL_32 = "hcurl_32"
 QF_HDIV, QF_HCURL, QF_HDIVMASS, QF_HCURLMASS, QF_H1MASS = "hdiv_33", "hcurl_33", "hdivmass_33", "hcurlmass_33", "h1_1"
 QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22 = "hcurl_22", "l2_1", "hdivmass_22"
+QF_HCURLHDIV, QF_HDIVHCURL = "hcurlhdiv_33", "hdivhcurl_33"  # weak curl (Interp -> Curl), mixed curl (Curl -> Interp)
 
 
 class CeedOperatorOracle:
@@ -480,6 +503,12 @@ class CeedOperatorOracle:
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
             v, cv = apply_hdivmass_22(self.ctx, self.ctx2, geom, self.qw, u, cu)
             return np.einsum("dqj,edq->ej", self.interp, v) + np.einsum("dqj,edq->ej", self.deriv, cv)
+        if qf == QF_HCURLHDIV:  # (C u, curl v): trial Interp, test Curl (integ/mixedveccurl.cpp:75-120, same H(curl) space)
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            return np.einsum("dqj,edq->ej", self.deriv, apply_hcurlhdiv_33(self.ctx, geom, u))
+        if qf == QF_HDIVHCURL:  # (C curl u, v): trial Curl, test Interp (integ/mixedveccurl.cpp:21-73)
+            cu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            return np.einsum("dqj,edq->ej", self.interp, apply_hdivhcurl_33(self.ctx, geom, cu))
         if qf == QF_HDIV:      # curl-curl (integ/curlcurl.cpp:48-52,60-61)
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
             cv = apply_hdiv_33(self.ctx, geom, cu)

@@ -20,6 +20,7 @@ from .fem.fespace import H1HexSpace, NDHexSpace
 from .fem.mesh import HexMesh, _q2_1d
 
 QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1, QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22, QF_HCURL_32 = range(9)
+QF_HCURLHDIV_33, QF_HDIVHCURL_33 = 9, 10  # weak curl (trial Interp, test Curl) / mixed curl (trial Curl, test Interp)
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
 FE_H1, FE_HCURL, FE_HDIV = 0, 1, 2
 
@@ -243,13 +244,13 @@ class Operator:
         if handle is None:
             _lib.check(_lib.load().pa_op_create(height, width, C.byref(self.handle)))
 
-    def add_integrator(self, geom: GeomFactorData, space, qf, ctx_blob, ops, dense=None):
+    def add_integrator(self, geom: GeomFactorData, space, qf, ctx_blob, ops, dense=None, test_ops=None):
         r, k1 = _restriction_desc(space)
         b, k2 = _basis_desc(space, geom.q1d, dense)
         ctx = np.ascontiguousarray(ctx_blob)
         _lib.check(_lib.load().pa_op_add_sub(self.handle, geom.handle, C.byref(r), C.byref(b),
                                              C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes),
-                                             C.c_uint32(ops), C.c_uint32(ops)))
+                                             C.c_uint32(ops), C.c_uint32(ops if test_ops is None else test_ops)))
         return self
 
     def add_dense_integrator(self, geom: DenseGeomFactorData, block: DenseBlock, qf, ctx_blob, ops):
@@ -399,6 +400,18 @@ def curlcurlmass_operator(geom, nd: NDHexSpace, ctx_mass, ctx_curl, dense=None):
     ctx = np.concatenate([ctx_mass, ctx_curl])
     return Operator(nd.ndofs, nd.ndofs).add_integrator(
         geom, nd, QF_HDIVMASS_33, ctx, EVAL_CURL | EVAL_INTERP, dense).finalize()
+
+
+def weakcurl_operator(geom, nd: NDHexSpace, ctx):
+    """MixedVectorWeakCurlIntegrator on one H(curl) space (fem/integ/mixedveccurl.cpp:75-120): (C u, curl v),
+    f_apply_hcurlhdiv_33, trial Interp / test Curl."""
+    return Operator(nd.ndofs, nd.ndofs).add_integrator(geom, nd, QF_HCURLHDIV_33, ctx, EVAL_INTERP, test_ops=EVAL_CURL).finalize()
+
+
+def mixedcurl_operator(geom, nd: NDHexSpace, ctx):
+    """MixedVectorCurlIntegrator on one H(curl) space (fem/integ/mixedveccurl.cpp:21-73): (C curl u, v),
+    f_apply_hdivhcurl_33, trial Curl / test Interp."""
+    return Operator(nd.ndofs, nd.ndofs).add_integrator(geom, nd, QF_HDIVHCURL_33, ctx, EVAL_CURL, test_ops=EVAL_INTERP).finalize()
 
 
 def diffusion_operator(geom, h1: H1HexSpace, ctx_diff, dense=None):

@@ -429,6 +429,18 @@ void CurlCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, co
   AssembleCeedOperator(op, trial, test, PA_QF_HDIV_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_CURL,
                        PA_EVAL_CURL);
 }
+void MixedVectorCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
+  PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_HCURL,
+             "MixedVectorCurlIntegrator: H(curl) test space only (the H(div) test space of the flux estimator is not built)");
+  AssembleCeedOperator(op, trial, test, PA_QF_HDIVHCURL_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_CURL,
+                       PA_EVAL_INTERP);
+}
+void MixedVectorWeakCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
+  PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_HCURL,
+             "MixedVectorWeakCurlIntegrator: H(curl) trial space only");
+  AssembleCeedOperator(op, trial, test, PA_QF_HCURLHDIV_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_INTERP,
+                       PA_EVAL_CURL);
+}
 void DiffusionMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   AssembleCeedOperator(op, trial, test, PA_QF_HCURLMASS_33,
                        ceed::PopulateCoefficientContext(1, Q_mass, 3, Q, transpose_mass, transpose),

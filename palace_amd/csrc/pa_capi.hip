@@ -157,9 +157,19 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
   const int P = expected_P(b.fe_type, b.order);
   PA_REQUIRE(r.elem_size == P, "restriction element size does not match the basis");
   PA_REQUIRE(r.offsets, "restriction offsets missing");
-  PA_REQUIRE(trial_ops == test_ops, "only symmetric trial/test evaluation modes are supported");
+  const bool cross = qf == PA_QF_HCURLHDIV_33 || qf == PA_QF_HDIVHCURL_33;
+  if (cross) {  // integ/mixedveccurl.cpp:21-120 on one H(curl) space
+    PA_REQUIRE(b.fe_type == PA_FE_HCURL, "the mixed curl QFunctions need an H(curl) space");
+    const uint32_t ti = qf == PA_QF_HCURLHDIV_33 ? PA_EVAL_INTERP : PA_EVAL_CURL;
+    const uint32_t te = qf == PA_QF_HCURLHDIV_33 ? PA_EVAL_CURL : PA_EVAL_INTERP;
+    PA_REQUIRE(trial_ops == ti && test_ops == te, "evaluation modes do not match the QFunction's inputs");
+  } else {
+    PA_REQUIRE(trial_ops == test_ops, "trial and test evaluation modes differ only for the mixed curl QFunctions");
+  }
   uint32_t want = 0;
   switch (qf) {
+    case PA_QF_HCURLHDIV_33:
+    case PA_QF_HDIVHCURL_33: want = trial_ops; break;
     case PA_QF_HDIV_33: want = PA_EVAL_CURL; break;
     case PA_QF_HCURL_33: want = b.fe_type == PA_FE_HCURL ? PA_EVAL_INTERP : PA_EVAL_GRAD; break;
     case PA_QF_HDIVMASS_33: want = PA_EVAL_CURL | PA_EVAL_INTERP; break;
@@ -168,7 +178,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     default: throw Error("unknown QFunction id");
   }
   PA_REQUIRE(trial_ops == want, "evaluation modes do not match the QFunction's inputs");
-  const bool nd_qf = qf == PA_QF_HDIV_33 || qf == PA_QF_HDIVMASS_33 ||
+  const bool nd_qf = qf == PA_QF_HDIV_33 || qf == PA_QF_HDIVMASS_33 || cross ||
                      (qf == PA_QF_HCURL_33 && b.fe_type == PA_FE_HCURL);
   PA_REQUIRE(nd_qf == (b.fe_type == PA_FE_HCURL), "QFunction does not match the element type");
 
@@ -283,6 +293,8 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
   switch (qf) {
     case PA_QF_HDIV_33:
     case PA_QF_HCURL_33:
+    case PA_QF_HCURLHDIV_33:
+    case PA_QF_HDIVHCURL_33:
       parse_coeff(ctx, ctx_size, 3, so->c0, 0);
       break;
     case PA_QF_HDIVMASS_33:
@@ -306,7 +318,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
       }
     return true;
   };
-  so->iso = is_iso(so->c0) && (so->c1.mat.empty() || is_iso(so->c1));
+  so->iso = !cross && is_iso(so->c0) && (so->c1.mat.empty() || is_iso(so->c1));
   // Pre-assembled packed symmetric D (default for symmetric coefficients; PALACE_AMD_QDATA=0 keeps
   // the reference-default matrix-free D from the geometry factors)
   auto is_sym = [](const CoeffHost &c) {
@@ -316,7 +328,7 @@ static SubOp *make_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_bas
     return true;
   };
   const char *qmode = getenv("PALACE_AMD_QDATA");
-  const bool want_qd = !(qmode && std::string(qmode) == "0") && is_sym(so->c0) &&
+  const bool want_qd = !cross && !(qmode && std::string(qmode) == "0") && is_sym(so->c0) &&  // (mixed forms: matrix-free D)
                        (so->c1.mat.empty() || is_sym(so->c1));
   // D stage of the curl-curl + mass operator on H(curl) hexes when every coefficient is isotropic: the metric
   // form, 7 doubles per point shared by all such operators and p-levels of a mesh instead of 12 per operator
@@ -464,6 +476,8 @@ void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s) { 
 }  // namespace pa
 
 bool pa_op::symmetric() const {
+  for (const pa::SubOp *so : subs)  // (C u, curl v) and (C curl u, v) are each other's transposes, never their own
+    if (so->qf == PA_QF_HCURLHDIV_33 || so->qf == PA_QF_HDIVHCURL_33) return false;
   for (const pa::SubOp *so : subs)
     if (!so->c0.symmetric() || !so->c1.symmetric()) return false;
   for (const pa::DenseSub *ds : dsubs)

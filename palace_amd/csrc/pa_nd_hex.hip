@@ -46,6 +46,7 @@ struct NDArgs {
   int accumulate;  // for those: y += v instead of y = v
   int xcd_chunk;   // > 0: workgroups are dealt to the 8 XCDs round-robin; give each XCD one contiguous element range
   int ess_policy;  // -1, or ParOperator's row fix-up fused in: y[ess] = x[ess] (1) / 0 (0) (rap.cpp:223-233)
+  int cross = 0;   // 1 / 2: the mixed curl forms of hcurlhdiv_33_qf.h (matrix-free D, coefficient in c_mass)
   CoeffDev c_mass, c_curl;
   NDTab<P1, Q1> tab;
   const int32_t *attr_e;     // metric form: element attributes
@@ -228,6 +229,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
         adjJt33(adj, Jl);
         mult_AtAx33(Jl, CU[0][qz], CU[1][qz], CU[2][qz], wdetJ * c, CU[0][qz], CU[1][qz], CU[2][qz]);
       }
+    } else if (USE_U && USE_C && a.cross) {
+      // hcurlhdiv_33_qf.h: cross 1 = f_apply_hcurlhdiv_33 (values in, curl test functions out), 2 = f_apply_hdivhcurl_33
+      double Cm[9], Jl[9], o0, o1, o2;
+      coeff_unpack3(a.c_mass, attr[gq * qz], Cm);
+      adjJt33(adj, Jl);
+      if (a.cross == 1) {
+        mult_AtBCx33(Jl, Cm, adj, U[0][qz], U[1][qz], U[2][qz], wdetJ, o0, o1, o2);
+        CU[0][qz] = o0, CU[1][qz] = o1, CU[2][qz] = o2;
+        U[0][qz] = U[1][qz] = U[2][qz] = 0.0;
+      } else {
+        mult_AtBCx33(adj, Cm, Jl, CU[0][qz], CU[1][qz], CU[2][qz], wdetJ, o0, o1, o2);
+        U[0][qz] = o0, U[1][qz] = o1, U[2][qz] = o2;
+        CU[0][qz] = CU[1][qz] = CU[2][qz] = 0.0;
+      }
     } else {
       double Cm[9];
       if (USE_U) {
@@ -388,6 +403,14 @@ static void launch_pq(const SubOp &so, const double *x, double *y, double *ye, b
       a.c_mass = so.c0.dev();
       a.c_curl = so.c1.dev();
       launch_iso<P1, Q1, true, true>(a, so.iso, grid, block, lds, s);
+      break;
+    case PA_QF_HCURLHDIV_33:
+    case PA_QF_HDIVHCURL_33:
+      // both fields are evaluated, D couples values and curls (matrix-free, general 3 x 3 coefficient); the transposed
+      // operator of one form is the other one with the transposed coefficient (TransposeScope swaps the latter)
+      a.c_mass = a.c_curl = so.c0.dev();
+      a.cross = ((so.qf == PA_QF_HCURLHDIV_33) != TransposeScope::active()) ? 1 : 2;
+      launch_iso<P1, Q1, true, true>(a, false, grid, block, lds, s);
       break;
     default:
       throw Error("QFunction not available for H(curl) hexahedra");
@@ -637,6 +660,7 @@ struct NDDiagArgs {
   CoeffDev c_mass, c_curl;
   const double *Bo, *Bc, *Gc;  // device, full [q1][n]
   bool use_u, use_c;
+  int cross;  // 1 / 2: the mixed forms (hcurlhdiv_33_qf.h), coefficient in c_mass
 };
 
 __global__ void nd_hex_diag_kernel(const NDDiagArgs a) {
@@ -665,6 +689,16 @@ __global__ void nd_hex_diag_kernel(const NDDiagArgs a) {
         mult_AtBCx33(Jl, Cm, Jl, e0, e1, e2, w, y0, y1, y2);
       }
       Mc[9 * q + 0 + 3 * col] = y0, Mc[9 * q + 1 + 3 * col] = y1, Mc[9 * q + 2 + 3 * col] = y2;
+      if (a.cross) {  // column `col` of  w detJ Jl^T C adj  (cross 1) or  w detJ adj^T C Jl  (cross 2), kept in Mm
+        coeff_unpack3(a.c_mass, attr, Cm);
+        adjJt33(adj, Jl);
+        if (a.cross == 1)
+          mult_AtBCx33(Jl, Cm, adj, e0, e1, e2, w, y0, y1, y2);
+        else
+          mult_AtBCx33(adj, Cm, Jl, e0, e1, e2, w, y0, y1, y2);
+        Mm[9 * q + 0 + 3 * col] = y0, Mm[9 * q + 1 + 3 * col] = y1, Mm[9 * q + 2 + 3 * col] = y2;
+        Mc[9 * q + 0 + 3 * col] = Mc[9 * q + 1 + 3 * col] = Mc[9 * q + 2 + 3 * col] = 0.0;
+      }
     }
   }
   __syncthreads();
@@ -692,9 +726,15 @@ __global__ void nd_hex_diag_kernel(const NDDiagArgs a) {
           if (C == 0) cv[0] = 0.0, cv[1] = dz, cv[2] = -dy;
           if (C == 1) cv[0] = -dz, cv[1] = 0.0, cv[2] = dx;
           if (C == 2) cv[0] = dy, cv[1] = -dx, cv[2] = 0.0;
-          acc += Mm[9 * q + C + 3 * C] * f * f;
-          for (int r2 = 0; r2 < 3; r2++)
-            for (int c2 = 0; c2 < 3; c2++) acc += cv[r2] * Mc[9 * q + r2 + 3 * c2] * cv[c2];
+          if (a.cross == 1) {  // test: curl, trial: value f e_C
+            for (int r2 = 0; r2 < 3; r2++) acc += cv[r2] * Mm[9 * q + r2 + 3 * C] * f;
+          } else if (a.cross == 2) {  // test: value f e_C, trial: curl
+            for (int c2 = 0; c2 < 3; c2++) acc += f * Mm[9 * q + C + 3 * c2] * cv[c2];
+          } else {
+            acc += Mm[9 * q + C + 3 * C] * f * f;
+            for (int r2 = 0; r2 < 3; r2++)
+              for (int c2 = 0; c2 < 3; c2++) acc += cv[r2] * Mc[9 * q + r2 + 3 * c2] * cv[c2];
+          }
         }
     if (a.ye) {  // the gather applies the orientation sign of the entry: the diagonal does not have one
       a.ye[(size_t)e * P + m] = a.sidx[(size_t)e * P + m] >= 0 ? acc : -acc;
@@ -715,7 +755,10 @@ void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s) {
   const int nc = so.p + 1;
   a.Bo = so.d_tab, a.Bc = so.d_tab + so.q1d * so.p, a.Gc = a.Bc + so.q1d * nc;
   a.use_u = a.use_c = false;
+  a.cross = 0;
   switch (so.qf) {
+    case PA_QF_HCURLHDIV_33: a.c_mass = so.c0.dev(), a.cross = 1; break;
+    case PA_QF_HDIVHCURL_33: a.c_mass = so.c0.dev(), a.cross = 2; break;
     case PA_QF_HDIV_33: a.c_curl = so.c0.dev(), a.use_c = true; break;
     case PA_QF_HCURL_33: a.c_mass = so.c0.dev(), a.use_u = true; break;
     case PA_QF_HDIVMASS_33: a.c_mass = so.c0.dev(), a.c_curl = so.c1.dev(), a.use_u = a.use_c = true; break;

@@ -44,6 +44,13 @@ def main():
         v = np.zeros((3, Q))
         capi.ref_call("f_apply_hdiv_33", blob, Q, [geom, cu], [v])
         out["hdiv_" + tag] = v
+    for tag, blob in (("a", ctx_a.pack()), ("b", ctx_b.pack())):  # the mixed H(curl) / H(div) QFunctions (hcurlhdiv_33_qf.h)
+        v = np.zeros((3, Q))
+        capi.ref_call("f_apply_hcurlhdiv_33", blob, Q, [geom, u], [v])
+        out["hcurlhdiv_" + tag] = v
+        v = np.zeros((3, Q))
+        capi.ref_call("f_apply_hdivhcurl_33", blob, Q, [geom, cu], [v])
+        out["hdivhcurl_" + tag] = v
     v, cv = np.zeros((3, Q)), np.zeros((3, Q))
     capi.ref_call("f_apply_hdivmass_33", po.pack_pair(ctx_a, ctx_b), Q, [geom, u, cu], [v, cv])
     out["hdivmass_v"], out["hdivmass_cv"] = v, cv

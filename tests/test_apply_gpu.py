@@ -13,6 +13,7 @@ torch = pytest.importorskip("torch")
 from palace_amd import ceed  # noqa: E402
 from palace_amd.fem.fespace import NDHexSpace  # noqa: E402
 from palace_amd.fem.mesh import ogrid_cylinder, refine_uniform  # noqa: E402
+from oracle import palace_oracle as po  # noqa: E402
 from tests import util  # noqa: E402
 
 RTOL = 1e-12
@@ -146,6 +147,52 @@ def test_two_right_hand_sides(cylinder_mesh, p, qf, coef):
     op.mult(x1, r1)
     for y, r in ((y0, r0), (y1, r1)):
         assert float((y - r).abs().max()) <= 4e-15 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+@pytest.mark.parametrize("coef", ["aniso", "nonsym"])
+def test_mixed_curl_forms(cylinder_mesh, p, coef):
+    """MixedVectorWeakCurlIntegrator (C u, curl v) and MixedVectorCurlIntegrator (C curl u, v) on one H(curl) space
+    (fem/integ/mixedveccurl.cpp:21-120; f_apply_hcurlhdiv_33 / f_apply_hdivhcurl_33, the oracle's restatements are pinned on
+    vectors from the reference header): apply, the transposes (each form is the other one's transpose with C^T), the
+    diagonal, and the sum of the pair SpaceOperator adds for Floquet-periodic problems (spaceoperator.cpp:305-309: weak curl
+    with C, mixed curl with C transposed -- a skew pair when C is symmetric)."""
+    mesh = _multi_attr(cylinder_mesh)
+    q1d = p + 1
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ogeom = util.oracle_geom(mesh, q1d)
+    c, blob = util.make_ctx(coef, nattr=3)
+    ct = po.CoeffCtx.__new__(po.CoeffCtx)
+    ct.dim, ct.attr_mat = c.dim, c.attr_mat
+    ct.mat = np.array([m.reshape(3, 3).T.reshape(-1) for m in c.mat])  # C^T per material
+    x = np.random.default_rng(p).uniform(-1, 1, nd.ndofs)
+    new = lambda: torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")  # noqa: E731
+    for kind, other, build in (("hcurlhdiv", "hdivhcurl", ceed.weakcurl_operator), ("hdivhcurl", "hcurlhdiv", ceed.mixedcurl_operator)):
+        op = build(geom, nd, blob)
+        o = util.oracle_operator(nd, ogeom, kind, c, None, q1d)
+        ref = o.apply_add(x, np.zeros(nd.ndofs))
+        assert np.linalg.norm(ref) > 1e-3
+        assert _rel(op.mult(_dev(x), new()).cpu().numpy(), ref) < RTOL, kind
+        y0 = np.random.default_rng(7).uniform(-1, 1, nd.ndofs)
+        ya = _dev(y0.copy())
+        op.add_mult(_dev(x), ya)
+        assert _rel(ya.cpu().numpy(), y0 + ref) < RTOL, kind
+        assert not op.is_symmetric()
+        ot = util.oracle_operator(nd, ogeom, other, ct, None, q1d)
+        assert _rel(op.mult_transpose(_dev(x), new()).cpu().numpy(), ot.apply_add(x, np.zeros(nd.ndofs))) < RTOL, (kind, "T")
+        if p <= 2:
+            d = op.assemble_diagonal(new()).cpu().numpy()
+            dref = o.diagonal()
+            assert np.abs(d - dref).max() < 1e-12 * max(1.0, np.abs(dref).max()), kind
+    # the Floquet pair in one operator (two sub-operators)
+    pair = ceed.Operator(nd.ndofs, nd.ndofs)
+    pair.add_integrator(geom, nd, ceed.QF_HCURLHDIV_33, blob, ceed.EVAL_INTERP, test_ops=ceed.EVAL_CURL)
+    pair.add_integrator(geom, nd, ceed.QF_HDIVHCURL_33, ct.pack(), ceed.EVAL_CURL, test_ops=ceed.EVAL_INTERP)
+    pair.finalize()
+    ref = (util.oracle_operator(nd, ogeom, "hcurlhdiv", c, None, q1d).apply_add(x, np.zeros(nd.ndofs))
+           + util.oracle_operator(nd, ogeom, "hdivhcurl", ct, None, q1d).apply_add(x, np.zeros(nd.ndofs)))
+    assert _rel(pair.mult(_dev(x), new()).cpu().numpy(), ref) < RTOL
 
 
 @pytest.mark.parametrize("p_coarse,p_fine", [(1, 3), (2, 3), (1, 2), (2, 4), (1, 4)])

@@ -45,6 +45,17 @@ def test_hcurl_hdiv_numpy(tag):
     np.testing.assert_allclose(cv, G["hdiv_" + tag], rtol=TOL, atol=TOL)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_mixed_hcurl_hdiv_numpy(tag):
+    """f_apply_hcurlhdiv_33 / f_apply_hdivhcurl_33 (hcurlhdiv_33_qf.h: the weak-curl and mixed-curl integrators) against the
+    vectors produced by the reference header (anisotropic SPD and non-symmetric coefficients: the latter exposes a swapped
+    A / C argument order)."""
+    ctx, _ = _ctx_from_blob(G["ctx_" + tag])
+    geom = G["geom"][None]
+    np.testing.assert_allclose(po.apply_hcurlhdiv_33(ctx, geom, G["u"][None])[0], G["hcurlhdiv_" + tag], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(po.apply_hdivhcurl_33(ctx, geom, G["cu"][None])[0], G["hdivhcurl_" + tag], rtol=TOL, atol=TOL)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "id"])
 def test_hcurl_hdiv_c(tag):
     blob = G["ctx_" + tag]

@@ -46,7 +46,8 @@ def make_ctx(kind, nattr=1):
     return c, c.pack()
 
 
-QF_MAP = {"hdiv": (po.QF_HDIV, capi.QF_HDIV), "hcurl": (po.QF_HCURL, capi.QF_HCURL),
+QF_MAP = {"hcurlhdiv": (po.QF_HCURLHDIV, None), "hdivhcurl": (po.QF_HDIVHCURL, None),  # numpy oracle only
+          "hdiv": (po.QF_HDIV, capi.QF_HDIV), "hcurl": (po.QF_HCURL, capi.QF_HCURL),
           "hdivmass": (po.QF_HDIVMASS, capi.QF_HDIVMASS)}
 
 
