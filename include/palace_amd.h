@@ -256,6 +256,9 @@ int pa_op_mult(pa_op *op, const double *x, double *y, void *stream);
 int pa_op_mult_transpose(pa_op *op, const double *x, double *y, void *stream);
 int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *stream);
 int pa_op_is_symmetric(const pa_op *op);
+/* 1 if y = A x runs on the streaming kernels (single tensor-product block, Q1 = 4, packed q-data): callers choosing between
+ * pa_op_mult2 and two pa_op_mult calls prefer the latter then */
+int pa_op_streams(const pa_op *op);
 /* Fused form of what ParOperator::Mult does around the local apply for square operators
  * (linalg/rap.cpp:207-220: tx = x; tx[ess] = 0; ly = A P tx): after pa_op_set_essential(list of
  * essential L-dofs), pa_op_mult_essential computes y = A (x with the listed entries read as zero)

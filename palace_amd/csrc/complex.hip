@@ -342,31 +342,32 @@ void ComplexWrapperOperator::Mult(const ComplexVector &x, ComplexVector &y) cons
   // Each real operator meets both parts of x: with ParOperators the pair goes through one pass over the
   // element data (ParOperator::Mult2), otherwise through two applies as in the reference.
   const Context &c = *ctx_;
-  static const bool pair = !(getenv("PALACE_AMD_MULT2") && std::string(getenv("PALACE_AMD_MULT2")) == "0");  // A/B switch
+  // whether a pair of applies shares one pass over the element data is ParOperator::Mult2's decision (it does when the
+  // operator has no streaming form); PALACE_AMD_MULT2=0 forces separate applies for A/B runs
+  static const bool pair = !(getenv("PALACE_AMD_MULT2") && std::string(getenv("PALACE_AMD_MULT2")) == "0");
   const auto *par_i = pair ? dynamic_cast<const ParOperator *>(Ai_) : nullptr;
   const auto *par_r = pair ? dynamic_cast<const ParOperator *>(Ar_) : nullptr;
-  if (Ai_) {
-    if (par_i) {
-      par_i->Mult2(x.Imag(), x.Real(), y.Real(), y.Imag());
+  if (Ar_) {  // yr = Ar xr, yi = Ar xi
+    if (par_r) {
+      par_r->Mult2(x.Real(), x.Imag(), y.Real(), y.Imag());
     } else {
-      Ai_->Mult(x.Imag(), y.Real());
-      Ai_->Mult(x.Real(), y.Imag());
+      Ar_->Mult(x.Real(), y.Real());
+      Ar_->Mult(x.Imag(), y.Imag());
     }
-    linalg::AXPBY(c, 0.0, y.Real(), -1.0, y.Real());
   } else {
     linalg::Fill(c, y, 0.0);
   }
-  if (Ar_) {
-    if (par_r) {
-      if (t_.Size() != height) t_.SetSize(height);
-      if (t2_.Size() != height) t2_.SetSize(height);
-      par_r->Mult2(x.Real(), x.Imag(), t_, t2_);
-      linalg::AXPY(c, 1.0, t_, y.Real());
-      linalg::AXPY(c, 1.0, t2_, y.Imag());
+  if (Ai_) {  // yr -= Ai xi, yi += Ai xr
+    if (t_.Size() != height) t_.SetSize(height);
+    if (t2_.Size() != height) t2_.SetSize(height);
+    if (par_i) {
+      par_i->Mult2(x.Imag(), x.Real(), t_, t2_);
     } else {
-      AddReal(Ar_, false, x.Real(), y.Real(), 1.0);
-      AddReal(Ar_, false, x.Imag(), y.Imag(), 1.0);
+      Ai_->Mult(x.Imag(), t_);
+      Ai_->Mult(x.Real(), t2_);
     }
+    linalg::AXPY(c, -1.0, t_, y.Real());
+    linalg::AXPY(c, 1.0, t2_, y.Imag());
   }
 }
 

@@ -962,7 +962,9 @@ void ParOperator::AddMultTranspose(const Vector &x, Vector &y, double a) const {
 
 void ParOperator::Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const {
   const Context &c = *ctx_;
-  if (A_fused_) {
+  // two right-hand sides in one pass of the one-shot kernel pay off only where there is no streaming kernel: with it, two
+  // separate applies are faster (complex K - w^2 M + i w C apply on 9.95M dofs: 0.86 ms against 1.00 ms)
+  if (A_fused_ && !A_fused_->Streams()) {
     const bool one = policy_ == DiagonalPolicy::DIAG_ONE;
     if (!A_fused_->Mult2EssentialDiag(x0, x1, y0, y1, one)) {
       if (one)

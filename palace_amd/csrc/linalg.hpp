@@ -180,6 +180,7 @@ public:
   ~Operator() override;
   pa_op *Handle() const { return op_; }
   const Context &GetContext() const { return *ctx_; }
+  bool Streams() const { return pa_op_streams(op_) != 0; }  // y = A x runs on the streaming kernels
   void Mult(const Vector &x, Vector &y) const override;
   void MultTranspose(const Vector &x, Vector &y) const override;
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;

@@ -816,6 +816,9 @@ int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *strea
 }
 
 int pa_op_is_symmetric(const pa_op *op) { return (op && op->symmetric()) ? 1 : 0; }
+int pa_op_streams(const pa_op *op) {
+  return (op && op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->d_idxc) ? 1 : 0;
+}
 
 /* 0: no essential list set on this operator, 1: this list is set, -1: a different one is */
 int pa_op_essential_state(const pa_op *op, const int32_t *ess, int32_t n) {

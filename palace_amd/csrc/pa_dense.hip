@@ -456,15 +456,44 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
   const size_t cs = (size_t)a.Q4 * kEB;
   const int ngroups = a.Q4 / 4;
 
+  // Software pipeline over the wave's blocks (up to 16 dof slots per lane: beyond that the extra registers spill): the index
+  // words of the next block are requested while the current one is in the matrix cores, its x values once the products
+  // are done (the q-data registers are free then) so that they fly during the E^T stores; a block starts with its
+  // operands in registers instead of two dependent memory round trips.
+  constexpr bool PREFETCH_IDX = KPMAX <= 16, PREFETCH_X = KPMAX <= 12;
+  int sgn[PREFETCH_IDX ? KPMAX : 1];
+  double un[PREFETCH_X ? KPMAX : 1];
+  auto gather_x = [&](const int (&sg_)[PREFETCH_IDX ? KPMAX : 1], double (&out)[PREFETCH_X ? KPMAX : 1]) {
+#pragma unroll
+    for (int s = 0; s < (PREFETCH_X ? KPMAX : 1); s++) {
+      out[s] = 0.0;
+      if (s < KP) {
+        const int sg = sg_[s];
+        const int d = sg >= 0 ? sg : -1 - sg;
+        const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
+        out[s] = sg >= 0 ? xv : -xv;
+      }
+    }
+  };
+  if (PREFETCH_IDX) {
+    const int b0 = blockIdx.x * kResWaves + wave;
+    const int32_t *idx0 = a.idx + (size_t)(b0 < a.nb ? b0 : 0) * KP * 64;
+#pragma unroll
+    for (int s = 0; s < KPMAX; s++) sgn[s] = (s < KP) ? idx0[s * 64 + lane] : 0;
+    if (PREFETCH_X) gather_x(sgn, un);
+  }
   for (int b = blockIdx.x * kResWaves + wave; b < a.nb; b += gridDim.x * kResWaves) {
     // ---- E
     double u[KPMAX];
-    const int32_t *idx = a.idx + (size_t)b * KP * 64;
 #pragma unroll
     for (int s = 0; s < KPMAX; s++) {
       u[s] = 0.0;
       if (s < KP) {
-        const int sg = idx[s * 64 + lane];
+        if (PREFETCH_X) {
+          u[s] = un[s];
+          continue;
+        }
+        const int sg = PREFETCH_IDX ? sgn[s] : a.idx[(size_t)b * KP * 64 + s * 64 + lane];
         const int d = sg >= 0 ? sg : -1 - sg;
 #ifdef PA_ABLATION
         const double xv = (a.dbg & 1) ? (double)d : ((d & kEssBit) ? 0.0 : a.x[d & ~kEssBit]);
@@ -507,6 +536,13 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
     double4_t yacc[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; pt++) yacc[pt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (PREFETCH_IDX) {  // index words of the next block (clamped on the last one)
+      const int bn = b + (int)gridDim.x * kResWaves;
+      const int32_t *idxn = a.idx + (size_t)(bn < a.nb ? bn : b) * KP * 64;
+#pragma unroll
+      for (int s = 0; s < KPMAX; s++)
+        if (s < KP) sgn[s] = idxn[s * 64 + lane];
+    }
 
 #ifdef PA_ABLATION
     const int nch_eff = (a.dbg & 4) ? 0 : a.nch;
@@ -538,6 +574,8 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
         resident_field<PT, MODE, 1>(Lf + (r0 + 16 * F0::NC) * S, Lb + (r0 + 16 * F0::NC) * S, KP, u, qn, yacc);
       }
     }
+
+    if (PREFETCH_X) gather_x(sgn, un);  // x of the next block (its index words arrived during the products)
 
     // ---- E^T, first half
 #ifdef PA_ABLATION
