@@ -268,6 +268,12 @@ int pa_op_streams(const pa_op *op);
  * ParOperator with another list must then handle its essential dofs outside the kernels). */
 int pa_op_essential_state(const pa_op *op, const int32_t *ess, int32_t n);
 int pa_op_set_essential(pa_op *op, const int32_t *ess_ldofs, int32_t n);
+/* Multi-rank applies (ParOperator::Mult, rap.cpp:195-234, with the conforming prolongation in flight): the local dofs that
+ * take part in the halo exchange are declared once; pa_op_mult_after then computes y = A x where the entries of x on those
+ * dofs become valid only when `event` (a hipEvent_t recorded on the exchange stream) has completed -- element batches that
+ * touch none of them run first, the others after the event.  Operators without the streaming kernels wait up front. */
+int pa_op_set_interface_dofs(pa_op *op, const int32_t *ldofs, int32_t n);
+int pa_op_mult_after(pa_op *op, const double *x, double *y, void *stream, void *event);
 int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream);
 /* The same with the row fix-up of rap.cpp:223-233 fused into the E^T kernels when the operator supports it:
  * y[ess] = x[ess] (diag_policy 1, DIAG_ONE) or 0 (DIAG_ZERO).  *handled = 1 if the rows were written, 0 if the

@@ -1,5 +1,7 @@
 #include "comm.hpp"
 
+#include <algorithm>
+
 #include <dlfcn.h>
 
 #include <cstring>
@@ -108,6 +110,10 @@ Halo::Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int3
   send_off_.assign(send_off, send_off + nnbr + 1);
   recv_off_.assign(recv_off, recv_off + nnbr + 1);
   nsend_ = send_off_[nnbr], nrecv_ = recv_off_[nnbr];
+  iface_.assign(send_idx, send_idx + nsend_);
+  iface_.insert(iface_.end(), recv_idx, recv_idx + nrecv_);
+  std::sort(iface_.begin(), iface_.end());
+  iface_.erase(std::unique(iface_.begin(), iface_.end()), iface_.end());
   d_send_idx_ = pa::dev_upload(send_idx, (size_t)nsend_);
   d_recv_idx_ = pa::dev_upload(recv_idx, (size_t)nrecv_);
   const int nbuf = std::max(nsend_, nrecv_);

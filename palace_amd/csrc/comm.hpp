@@ -45,11 +45,14 @@ class Halo {
   int32_t *d_recv_idx_ = nullptr;  // ghost slots this rank receives in P (and sends in P^T)
   double *d_sendbuf_ = nullptr, *d_recvbuf_ = nullptr;
   int nsend_ = 0, nrecv_ = 0;
+  std::vector<int32_t> iface_;  // every local dof that is sent or received (host copy, sorted, unique)
 
 public:
   Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int32_t *send_idx, const int *recv_off,
        const int32_t *recv_idx);
   ~Halo();
+  // the local dofs the exchange touches: elements without any of them do not depend on it
+  const std::vector<int32_t> &InterfaceDofs() const { return iface_; }
   // lx[ghosts] <- owners' values   (P)
   void Prolongate(double *d_lx, hipStream_t s) const;
   // ly[owned shared] += sharers' ghost contributions   (P^T)

@@ -41,6 +41,21 @@ void Vector::MakeRef(double *ext, int n) {
 Workspace::~Workspace() {
   if (d_) (void)hipFree(d_);
   if (h_) (void)hipHostFree(h_);
+  if (halo_stream_) (void)hipStreamDestroy(halo_stream_);
+  if (ev_ready_) (void)hipEventDestroy(ev_ready_);
+  if (ev_done_) (void)hipEventDestroy(ev_done_);
+}
+hipStream_t Workspace::HaloStream() {
+  if (!halo_stream_) PA_HIP(hipStreamCreateWithFlags(&halo_stream_, hipStreamNonBlocking));
+  return halo_stream_;
+}
+hipEvent_t Workspace::ReadyEvent() {
+  if (!ev_ready_) PA_HIP(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
+  return ev_ready_;
+}
+hipEvent_t Workspace::DoneEvent() {
+  if (!ev_done_) PA_HIP(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
+  return ev_done_;
 }
 double *Workspace::Device(size_t n) {
   PA_REQUIRE(n <= kDeviceDoubles, "reduction scratch request exceeds the workspace");
@@ -785,6 +800,12 @@ void Operator::AddMultTranspose(const Vector &x, Vector &y, double a) const {
 }
 bool Operator::IsSymmetric() const { return pa_op_is_symmetric(op_) != 0; }
 void Operator::AssembleDiagonal(Vector &diag) const { check(pa_op_assemble_diagonal(op_, diag.Data(), ctx_->stream)); }
+void Operator::SetInterfaceDofs(const std::vector<int32_t> &ldofs) {
+  if (pa_op_set_interface_dofs(op_, ldofs.data(), (int32_t)ldofs.size())) throw pa::Error(pa_last_error());
+}
+void Operator::MultAfter(const Vector &x, Vector &y, hipEvent_t after) const {
+  if (pa_op_mult_after(op_, x.Data(), y.Data(), ctx_->stream, after)) throw pa::Error(pa_last_error());
+}
 void Operator::SetEssential(const int32_t *ess_host, int n) { check(pa_op_set_essential(op_, ess_host, n)); }
 bool Operator::MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const {
   int handled = 0;
@@ -890,6 +911,17 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
       if (st >= 0) A_fused_ = c;
     }
   }
+  if (halo) {
+    // interior element batches overlap with the exchange of the ghosts (PALACE_AMD_OVERLAP=0: everything in one stream)
+    static const bool enabled = [] {
+      const char *e = std::getenv("PALACE_AMD_OVERLAP");
+      return !(e && e[0] == '0');
+    }();
+    if (auto *c = dynamic_cast<const ceed::Operator *>(&A); c && enabled) {
+      const_cast<ceed::Operator *>(c)->SetInterfaceDofs(halo->InterfaceDofs());
+      A_overlap_ = c;
+    }
+  }
   if (!halo) {
     if (auto *m = dynamic_cast<const CsrOperator *>(&A)) {
       const_cast<CsrOperator *>(m)->EliminateEssential(d_ess_, n_ess, policy == DiagonalPolicy::DIAG_ONE);
@@ -919,8 +951,19 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
   Vector tx(lx_.Data(), n_true_);
   linalg::Copy(c, x, tx);
   if (n_ess_) linalg::SetSubVector(c, tx, d_ess_, n_ess_, 0.0);
-  if (halo_) halo_->Prolongate(lx_.Data(), c.stream);  // owners -> sharers (P)
-  A_->Mult(lx_, ly_);
+  if (halo_ && A_overlap_ && !StreamGraph::Recording()) {
+    // P on a second stream: fork after tx is complete, the apply joins before its interface batches
+    Workspace &w = c.Work();
+    hipStream_t hs = w.HaloStream();
+    PA_HIP(hipEventRecord(w.ReadyEvent(), c.stream));
+    PA_HIP(hipStreamWaitEvent(hs, w.ReadyEvent(), 0));
+    halo_->Prolongate(lx_.Data(), hs);
+    PA_HIP(hipEventRecord(w.DoneEvent(), hs));
+    A_overlap_->MultAfter(lx_, ly_, w.DoneEvent());
+  } else {
+    if (halo_) halo_->Prolongate(lx_.Data(), c.stream);  // owners -> sharers (P)
+    A_->Mult(lx_, ly_);
+  }
   if (halo_) halo_->RestrictAdd(ly_.Data(), c.stream);  // sharers -> owners, summed (P^T)
   Vector ty(ly_.Data(), n_true_);
   linalg::Copy(c, ty, y);

@@ -31,6 +31,8 @@ class Halo;  // conforming prolongation of one space across ranks (comm.hpp)
 // first use and shared by the copies of a context -- never by two contexts, whose streams may reduce concurrently.
 class Workspace {
   double *d_ = nullptr, *h_ = nullptr;
+  hipStream_t halo_stream_ = nullptr;
+  hipEvent_t ev_ready_ = nullptr, ev_done_ = nullptr;
 
 public:
   static constexpr size_t kDeviceDoubles = 32768, kPinnedDoubles = 64;  // fixed: recorded graphs keep these addresses
@@ -40,6 +42,11 @@ public:
   ~Workspace();
   double *Device(size_t n);  // n <= kDeviceDoubles doubles of device memory
   double *Pinned(size_t n);  // n <= kPinnedDoubles doubles of page-locked host memory
+  // second stream for halo exchanges that overlap with interior element work, and the two events of the fork / join
+  // (ready: the vector to exchange is complete on the main stream; done: the ghosts have arrived on the halo stream)
+  hipStream_t HaloStream();
+  hipEvent_t ReadyEvent();
+  hipEvent_t DoneEvent();
 };
 
 // Execution context shared by the objects of one solve: the stream everything is enqueued on and
@@ -187,6 +194,10 @@ public:
   void AddMultTranspose(const Vector &x, Vector &y, double a = 1.0) const override;
   void AssembleDiagonal(Vector &diag) const override;
   bool IsSymmetric() const override;
+  // multi-rank applies: the local dofs that take part in the halo exchange; MultAfter computes y = A x where those entries
+  // of x are complete only once `after` has fired (interior element batches do not wait for it)
+  void SetInterfaceDofs(const std::vector<int32_t> &ldofs);
+  void MultAfter(const Vector &x, Vector &y, hipEvent_t after) const;
   // y = A (x with the essential entries read as zero), no copy of x (pa_op_mult_essential)
   void SetEssential(const int32_t *ess_host, int n);
   void MultEssential(const Vector &x, Vector &y) const;
@@ -284,6 +295,7 @@ private:
   const Context *ctx_;
   const Operator *A_;
   const ceed::Operator *A_fused_ = nullptr;  // single rank: BC masking fused into the local apply
+  const ceed::Operator *A_overlap_ = nullptr;  // with a halo: interior elements run while the ghosts are exchanged
   const CsrOperator *A_csr_ = nullptr;       // single rank, assembled local operator: BCs eliminated in the matrix
   const Halo *halo_;
   int n_true_, n_local_;

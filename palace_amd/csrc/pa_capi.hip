@@ -377,15 +377,25 @@ static void free_sub(SubOp *so) {
 
 // y (+)= A x.  overwrite: the first sub-operator writes y instead of accumulating (Mult without a
 // separate memset when E^T runs as a gather).
+// after: an event the entries of x that take part in the halo exchange wait for (multi-rank applies, pa_op_mult_after): a
+// streaming block with interface batch lists runs its interior batches first; everything else simply waits up front
 static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s, bool masked = false,
-                  int ess_policy = -1) {
+                  int ess_policy = -1, hipEvent_t after = nullptr) {
   PA_REQUIRE(op && x && y, "null argument");
   PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty(), "operator has no sub-operators");
   PA_REQUIRE(x != y, "in-place apply is not supported");
   bool first = true;
+  const bool split = after && op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->fe_type == PA_FE_HCURL &&
+                     op->subs[0]->d_idxc && op->subs[0]->has_blist && overwrite && (!masked || op->subs[0]->d_perm_s_bc);
+  if (after && !split) PA_HIP(hipStreamWaitEvent(s, after, 0));
   for (const SubOp *so : op->subs) {
     if (so->fe_type == PA_FE_HCURL) {
-      if (so->d_idxc && overwrite && first && (!masked || so->d_perm_s_bc)) {  // streaming kernel (y = A x) + E^T of the shared dofs by runs
+      if (split) {
+        launch_nd_hex_stream(*so, x, y, masked, s, 0);  // batches that touch no exchanged dof
+        PA_HIP(hipStreamWaitEvent(s, after, 0));
+        launch_nd_hex_stream(*so, x, y, masked, s, 1);
+        launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
+      } else if (so->d_idxc && overwrite && first && (!masked || so->d_perm_s_bc)) {  // streaming kernel (y = A x) + E^T of the shared dofs by runs
         launch_nd_hex_stream(*so, x, y, masked, s);
         launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
       } else if (so->d_ye) {
@@ -866,6 +876,22 @@ int pa_op_set_essential(pa_op *op, const int32_t *ess, int32_t n) {
     }
     op->has_essential = true;
   });
+}
+
+int pa_op_set_interface_dofs(pa_op *op, const int32_t *ldofs, int32_t n) {
+  return guarded([&] {
+    PA_REQUIRE(op && (ldofs || n == 0), "null argument");
+    std::vector<char> flag((size_t)op->width, 0);
+    for (int i = 0; i < n; i++) {
+      PA_REQUIRE(ldofs[i] >= 0 && ldofs[i] < op->width, "interface dof out of range");
+      flag[ldofs[i]] = 1;
+    }
+    for (SubOp *so : op->subs) stream_set_interface(*so, flag);
+  });
+}
+
+int pa_op_mult_after(pa_op *op, const double *x, double *y, void *stream, void *event) {
+  return guarded([&] { apply(op, x, y, true, (hipStream_t)stream, false, -1, (hipEvent_t)event); });
 }
 
 int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream) {

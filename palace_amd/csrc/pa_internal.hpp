@@ -177,6 +177,9 @@ struct SubOp {
   int32_t *d_tent = nullptr;   // [ne * P] signed positions into d_ye
   // streaming form (pa_nd_hex_stream.hip): index words with the exclusive flag, byte slots, E^T of the shared dofs by runs
   uint32_t *d_idxc = nullptr;  // [ne][kIdxWords] run-compressed sorted element -> dof index (pa_stream_host.hpp)
+  int32_t *d_blist[2] = {nullptr, nullptr};  // batch lists of the interior / interface phases (stream_set_interface)
+  int n_blist[2] = {0, 0};
+  bool has_blist = false;
   uint32_t *d_perm_s_bc = nullptr;                      // flag words with the essential dofs taken off the direct path
   std::vector<uint32_t> h_perm_s;
   int32_t *d_rhdr_bc = nullptr, *d_rpos_bc = nullptr;   // run list that also owns the essential rows
@@ -242,7 +245,8 @@ bool nd_hex_stream_ok(const SubOp &so);
 void build_stream(SubOp &so);
 void stream_set_essential(SubOp &so, const std::vector<char> &flag);
 void free_stream(SubOp &so);
-void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s);
+void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase = -1);
+void stream_set_interface(SubOp &so, const std::vector<char> &flag);
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
                           int ess_policy);
 void launch_h1_hex_apply(const SubOp &so, const double *x, bool masked, hipStream_t s);

@@ -45,6 +45,7 @@ __device__ unsigned long long g_trace[kTraceWG * kTraceBatches * kTraceStamps];
 template <int P1>
 struct NDStreamArgs {
   int ne, nbatch, chunk;  // chunk: batches per XCD (contiguous range)
+  const int32_t *blist;   // optional list of batches to process (nbatch entries, increasing); NULL: all of 0 .. nbatch - 1
   const uint32_t *idxc;   // [ne][kIdxWords] run-compressed sorted element -> dof index (pa_stream_host.hpp)
   const uint32_t *perm;   // [ne][NPK + 1][16]: four 8-bit tensor-order slots per word (entries t + 16 r, r = 4 k .. 4 k + 3),
                           // last word: bit 2 r = entry r is flipped, bit 2 r + 1 = entry r is the only copy of its dof,
@@ -86,8 +87,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   const int xcd = blockIdx.x & 7;
   const int base = xcd * a.chunk, bend = min(base + a.chunk, a.nbatch);
   const int stride = (int)(gridDim.x >> 3) * kWavesPerBlock;
-  int b = base + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave;
-  if (b >= bend) return;
+  // (with a batch list -- the interior / interface phases of a multi-rank apply -- positions in the list are walked)
+  int k = base + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave;
+  if (k >= bend) return;
+  int b = a.blist ? a.blist[k] : k;
   // index words of a batch (every array is padded to a multiple of four elements; pad entries read as zero and are
   // stored to E-vector rows nobody gathers)
   // s[0 .. NPL): the slice words (the same word for the 16 lanes of an element), s[NPL], s[NPL + 1]: run starts t, 16 + t
@@ -194,12 +197,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 
     // index words of the next batch (clamped: the last iteration re-reads its own); first use: the x gather below.
     // Requested here when the registers allow (p < 3), after the forward passes otherwise.
-    const int bn = b + stride;
-    const bool more = bn < bend;
+    const int kn = k + stride;
+    const bool more = kn < bend;
+    const int bn = more ? (a.blist ? a.blist[kn] : kn) : b;
     int sB[NPL + 2];
     unsigned pB[NPK + 1];
     if (EARLY_IDX) {
-      load_idx(more ? bn : b, sub, t, sB, pB);
+      load_idx(bn, sub, t, sB, pB);
       __builtin_amdgcn_sched_barrier(0);
     }
     PA_STAMP(2);  // q-data requested
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     // index words of the next batch, if not requested at the top
     if (!EARLY_IDX) {
       __builtin_amdgcn_sched_barrier(0);
-      load_idx(more ? bn : b, sub, t, sB, pB);
+      load_idx(bn, sub, t, sB, pB);
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!more) break;
-    b = bn;
+    k = kn, b = bn;
 #pragma unroll
     for (int r = 0; r < NPL; r++) sA[r] = sB[r], xv[r] = xB[r];
 #pragma unroll
@@ -486,7 +490,29 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   so.n_shared_bc = (int)shared.size();
 }
 
+// Interior / interface split for multi-rank applies: flag[d] != 0 marks the local dofs that take part in the halo exchange
+// (ghosts and the owned dofs other ranks hold as ghosts).  Batches (four consecutive elements) without any such dof form
+// list 0 and can run while the exchange is in flight; the others form list 1.
+void stream_set_interface(SubOp &so, const std::vector<char> &flag) {
+  if (!so.d_idxc) return;
+  const int nb = (so.ne + 3) / 4, P = so.P;
+  std::vector<int32_t> lists[2];
+  for (int b = 0; b < nb; b++) {
+    bool iface = false;
+    for (int e = 4 * b; e < std::min(4 * b + 4, so.ne) && !iface; e++)
+      for (int m = 0; m < P && !iface; m++) iface = flag[streamhost::dof_of(so.h_sidx[(size_t)e * P + m])] != 0;
+    lists[iface ? 1 : 0].push_back(b);
+  }
+  for (int ph = 0; ph < 2; ph++) {
+    hipFree(so.d_blist[ph]);
+    so.d_blist[ph] = lists[ph].empty() ? nullptr : dev_upload(lists[ph].data(), lists[ph].size());
+    so.n_blist[ph] = (int)lists[ph].size();
+  }
+  so.has_blist = true;
+}
+
 void free_stream(SubOp &so) {
+  hipFree(so.d_blist[0]), hipFree(so.d_blist[1]);
   hipFree(so.d_idxc), hipFree(so.d_perm_s), hipFree(so.d_perm_s_bc), hipFree(so.d_coef_s);
   hipFree(so.d_rcode), hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rcode_bc), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
 }
@@ -522,7 +548,8 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   }();
   const int per_cu = wg_env > 0 ? wg_env : per_cu_query;
   const int per_xcd = std::max(1, device_cus() / 8) * per_cu;
-  a.nbatch = (so.ne + 3) / 4;
+  if (!a.blist) a.nbatch = (so.ne + 3) / 4;  // (else: the length of the list, set by the caller)
+  if (a.nbatch == 0) return;
   a.chunk = (a.nbatch + 7) / 8;
   const int wgx = std::max(1, std::min(per_xcd, (a.chunk + kWavesPerBlock - 1) / kWavesPerBlock));
   hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
@@ -551,9 +578,15 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
 }
 
 template <int P1>
-static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s) {
+static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase) {
   NDStreamArgs<P1> a;
   a.ne = so.ne;
+  a.blist = nullptr, a.nbatch = 0;
+  if (phase >= 0) {  // 0: batches without interface elements, 1: the others (stream_set_interface)
+    PA_REQUIRE(so.d_blist[phase] || so.n_blist[phase] == 0, "interface batch lists missing");
+    a.blist = so.d_blist[phase], a.nbatch = so.n_blist[phase];
+    if (a.nbatch == 0) return;
+  }
   a.idxc = so.d_idxc;
   a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
   a.qdata = so.qd->d;
@@ -575,11 +608,11 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   }
 }
 
-void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s) {
+void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase) {
   switch (so.p) {
-    case 1: launch_p<1>(so, x, y, masked, s); break;
-    case 2: launch_p<2>(so, x, y, masked, s); break;
-    case 3: launch_p<3>(so, x, y, masked, s); break;
+    case 1: launch_p<1>(so, x, y, masked, s, phase); break;
+    case 2: launch_p<2>(so, x, y, masked, s, phase); break;
+    case 3: launch_p<3>(so, x, y, masked, s, phase); break;
     default: throw Error("no streaming H(curl) hex kernel for this order");
   }
 }
