@@ -259,6 +259,10 @@ int pa_op_is_symmetric(const pa_op *op);
 /* 1 if y = A x runs on the streaming kernels (single tensor-product block, Q1 = 4, packed q-data): callers choosing between
  * pa_op_mult2 and two pa_op_mult calls prefer the latter then */
 int pa_op_streams(const pa_op *op);
+/* number of dense sub-operators that run in the affine form: every element of the block has a constant Jacobian (straight-sided
+ * simplices), so the pre-assembled D of a quadrature point is the D of the first point times w_q / w_0 and the kernel reads 6
+ * values per field and element instead of 6 Q (PALACE_AMD_DENSE_AFFINE=0 at creation time keeps the general form) */
+int pa_op_dense_affine(const pa_op *op);
 /* Fused form of what ParOperator::Mult does around the local apply for square operators
  * (linalg/rap.cpp:207-220: tx = x; tx[ess] = 0; ly = A P tx): after pa_op_set_essential(list of
  * essential L-dofs), pa_op_mult_essential computes y = A (x with the listed entries read as zero)

@@ -328,6 +328,10 @@ class Operator:
     def is_symmetric(self):
         return bool(_lib.load().pa_op_is_symmetric(self.handle))
 
+    def dense_affine(self):
+        """Number of dense sub-operators running in the affine (constant Jacobian) form (pa_op_dense_affine)."""
+        return int(_lib.load().pa_op_dense_affine(self.handle))
+
     def add_mult(self, x, y, a=1.0):
         if a != 1.0:  # operator.cpp:194
             raise _lib.PalaceAmdError("ceed::Operator::AddMult only supports coefficient = 1.0!")

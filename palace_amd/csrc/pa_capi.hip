@@ -826,6 +826,12 @@ int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *strea
 }
 
 int pa_op_is_symmetric(const pa_op *op) { return (op && op->symmetric()) ? 1 : 0; }
+int pa_op_dense_affine(const pa_op *op) {
+  int n = 0;
+  if (op)
+    for (const DenseSub *ds : op->dsubs) n += ds->d_affine ? 1 : 0;
+  return n;
+}
 int pa_op_streams(const pa_op *op) {
   return (op && op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->d_idxc) ? 1 : 0;
 }

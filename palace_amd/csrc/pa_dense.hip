@@ -102,6 +102,8 @@ struct DenseArgs {
   const double *L;      // resident form of the tables: [rows][S], rows in tile order (see make_dense_sub)
   const double *qdata;  // packed pre-assembled D: [nb][ncq][Qpad][16]
   int ncq, Q4;  // q-data components and its point stride (Q rounded up to a multiple of 4)
+  const uint8_t *affine;  // non-null: every element has a constant Jacobian, D_q = (w_q / w_0) D_0
+  const double *wrel;     // [Q4] w_q / w_0
   int dbg;  // ablation bits (PA_ABLATION builds only)
   const double *x;
   double *ye;
@@ -389,10 +391,11 @@ __device__ __forceinline__ void dense_D_packed(const double *m, double *v) {
   }
 }
 
+// wrel != nullptr (affine elements): qd[0] holds the D of point 0, the D of point group gl is wrel[4 gl] times that
 template <int PT, int MODE, int F>
 __device__ __forceinline__ void resident_field(const double *__restrict__ Lf, const double *__restrict__ Lb, const int,
-                                               const double (&u)[4 * PT], const double (&qd)[4][6],
-                                               double4_t (&yacc)[PT]) {
+                                               const double (&u)[4 * PT], const double (*qd)[6],
+                                               double4_t (&yacc)[PT], const double *__restrict__ wrel = nullptr) {
   using FT = FieldTraits<MODE, F>;
   constexpr int NC = FT::NC, KPMAX = 4 * PT, S = ResidentStride<PT>::S, KP = KPMAX;
   double4_t acc[NC];
@@ -411,7 +414,14 @@ __device__ __forceinline__ void resident_field(const double *__restrict__ Lf, co
     double v[NC];
 #pragma unroll
     for (int k = 0; k < NC; k++) v[k] = acc[(gl * NC + k) >> 2][(gl * NC + k) & 3];
-    dense_D_packed<MODE, F>(qd[gl], v);
+    if (wrel) {
+      dense_D_packed<MODE, F>(qd[0], v);
+      const double w = wrel[4 * gl];
+#pragma unroll
+      for (int k = 0; k < NC; k++) v[k] *= w;
+    } else {
+      dense_D_packed<MODE, F>(qd[gl], v);
+    }
 #pragma unroll
     for (int k = 0; k < NC; k++) acc[(gl * NC + k) >> 2][(gl * NC + k) & 3] = v[k];
   }
@@ -433,8 +443,12 @@ __device__ __forceinline__ void load_qd(const double *__restrict__ q, const size
     for (int k = 0; k < NQ; k++) qd[gl][k] = (gl < ng) ? q[k * cs + gl * 64] : 0.0;
 }
 
-template <int PT, int MODE>
-__global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel(const DenseArgs a, const int rows) {
+// AFFINE: every block consists of elements with a constant Jacobian (dense_affine_kernel): the D of a point is the D of point 0
+// times the relative quadrature weight -- 6 values per field and element instead of 6 Q, and no q-data registers to rotate.
+constexpr int kAffWaves = 12;  // the affine form needs fewer registers: three waves per SIMD
+template <int PT, int MODE, bool AFFINE>
+__global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dense_apply_resident_kernel(const DenseArgs a, const int rows) {
+  constexpr int NW = AFFINE ? kAffWaves : kResWaves;
   using M = ModeTraits<MODE>;
   using F0 = FieldTraits<MODE, 0>;
   using F1 = FieldTraits<MODE, 1>;
@@ -444,11 +458,14 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
   constexpr int KP = 4 * PT;  // the host pads every element block to 4 PT dof slots
-  double *L = smem;
-  double *sm = smem + (size_t)rows * S + (size_t)wave * KPMAX * 64;
+  const int woff = (a.Q4 + 31) / 32 * 32;  // relative quadrature weights first (a multiple of 32 doubles: L keeps its banks)
+  const double *wl = smem;
+  double *L = smem + woff;
+  double *sm = L + (size_t)rows * S + (size_t)wave * KPMAX * 64;
   {
+    for (int i = tid; i < woff; i += 64 * NW) smem[i] = (a.wrel && i < a.Q4) ? a.wrel[i] : 0.0;
     const int n = rows * S;
-    for (int i = tid; i < n; i += 64 * kResWaves) L[i] = a.L[i];
+    for (int i = tid; i < n; i += 64 * NW) L[i] = a.L[i];
   }
   __syncthreads();
   const double *Lf = L + j * S + kq;   // forward operand of this lane:   row 16 t + i, column 4 s + kq
@@ -463,6 +480,24 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
   constexpr bool PREFETCH_IDX = KPMAX <= 16, PREFETCH_X = KPMAX <= 12;
   int sgn[PREFETCH_IDX ? KPMAX : 1];
   double un[PREFETCH_X ? KPMAX : 1];
+  // likewise the first chunk of q-data and the curl-orientation words of the next block (values the compiler cannot hold in
+  // vector registers go to the accumulation registers, which two waves per SIMD leave free)
+  double qdn[4][6];
+  int con[PREFETCH_X ? KPMAX : 1];
+  // first chunk of field 0 of block bq, or for an affine block the point-0 values of both fields (raw, scaled at use)
+  auto request_qd = [&](const size_t bq, double (&out)[4][6]) {
+    const double *qb = a.qdata + bq * a.ncq * cs;
+    if (AFFINE) {
+#pragma unroll
+      for (int k = 0; k < NQ0; k++) out[0][k] = qb[k * cs + j];
+      if (NF == 2) {
+#pragma unroll
+        for (int k = 0; k < NQ1; k++) out[1][k] = qb[(NQ0 + k) * cs + j];
+      }
+    } else {
+      load_qd<MODE, 0>(qb + lane, cs, ngroups, out);
+    }
+  };
   auto gather_x = [&](const int (&sg_)[PREFETCH_IDX ? KPMAX : 1], double (&out)[PREFETCH_X ? KPMAX : 1]) {
 #pragma unroll
     for (int s = 0; s < (PREFETCH_X ? KPMAX : 1); s++) {
@@ -476,13 +511,21 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
     }
   };
   if (PREFETCH_IDX) {
-    const int b0 = blockIdx.x * kResWaves + wave;
+    const int b0 = blockIdx.x * NW + wave;
     const int32_t *idx0 = a.idx + (size_t)(b0 < a.nb ? b0 : 0) * KP * 64;
 #pragma unroll
     for (int s = 0; s < KPMAX; s++) sgn[s] = (s < KP) ? idx0[s * 64 + lane] : 0;
-    if (PREFETCH_X) gather_x(sgn, un);
+    if (PREFETCH_X) {
+      gather_x(sgn, un);
+      const size_t bq = (size_t)(b0 < a.nb ? b0 : 0);
+      request_qd(bq, qdn);
+      if (a.co) {
+#pragma unroll
+        for (int s = 0; s < KPMAX; s++) con[s] = a.co[bq * KP * 64 + s * 64 + lane];
+      }
+    }
   }
-  for (int b = blockIdx.x * kResWaves + wave; b < a.nb; b += gridDim.x * kResWaves) {
+  for (int b = blockIdx.x * NW + wave; b < a.nb; b += gridDim.x * NW) {
     // ---- E
     double u[KPMAX];
 #pragma unroll
@@ -509,7 +552,16 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
     const double *q = a.qdata + (size_t)b * a.ncq * cs + lane;
 #endif
     double qd[4][6];
-    load_qd<MODE, 0>(q, cs, ngroups, qd);
+    if (AFFINE) {  // qdn[0], qdn[1]: point-0 values of the two fields, kept until the next request
+      if (!PREFETCH_X) request_qd((size_t)b, qdn);
+    } else if (!PREFETCH_X) {
+      load_qd<MODE, 0>(q, cs, ngroups, qd);
+    } else {
+#pragma unroll
+      for (int gl = 0; gl < 4; gl++)
+#pragma unroll
+        for (int k = 0; k < NQ0; k++) qd[gl][k] = qdn[gl][k];
+    }
 #ifdef PA_ABLATION
     const uint16_t *co = (a.co && !(a.dbg & 16)) ? a.co + (size_t)b * KP * 64 : nullptr;
 #else
@@ -523,7 +575,7 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
 #pragma unroll
       for (int s = 0; s < KPMAX; s++) {
         if (s < KP) {
-          const int c = co[s * 64 + lane];
+          const int c = PREFETCH_X ? con[s] : (int)co[s * 64 + lane];
           const int dof = 4 * s + kq;
           // out-of-range neighbours have a zero coefficient: clamp the address instead of branching
           const double lo = sm[max(dof - 1, 0) * 16 + j];
@@ -536,12 +588,17 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
     double4_t yacc[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; pt++) yacc[pt] = double4_t{0.0, 0.0, 0.0, 0.0};
-    if (PREFETCH_IDX) {  // index words of the next block (clamped on the last one)
-      const int bn = b + (int)gridDim.x * kResWaves;
-      const int32_t *idxn = a.idx + (size_t)(bn < a.nb ? bn : b) * KP * 64;
+    const int bn = b + (int)gridDim.x * NW;
+    const size_t bnc = (size_t)(bn < a.nb ? bn : b);  // the next block (clamped on the last one)
+    if (PREFETCH_IDX) {  // its index words
+      const int32_t *idxn = a.idx + bnc * KP * 64;
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
         if (s < KP) sgn[s] = idxn[s * 64 + lane];
+      if (PREFETCH_X && co) {
+#pragma unroll
+        for (int s = 0; s < KPMAX; s++) con[s] = a.co[bnc * KP * 64 + s * 64 + lane];
+      }
     }
 
 #ifdef PA_ABLATION
@@ -556,7 +613,12 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
 #endif
     for (int c = 0; c < nch_eff; c++) {
       const int r0 = c * NCT * 16;
-      if (NF == 1) {
+      if (AFFINE) {
+        const double *wc = wl + 16 * c + kq;
+        resident_field<PT, MODE, 0>(Lf + r0 * S, Lb + r0 * S, KP, u, qdn, yacc, wc);
+        if (NF == 2)
+          resident_field<PT, MODE, 1>(Lf + (r0 + 16 * F0::NC) * S, Lb + (r0 + 16 * F0::NC) * S, KP, u, qdn + 1, yacc, wc);
+      } else if (NF == 1) {
         double qn[4][6];
         if (c + 1 < a.nch) load_qd<MODE, 0>(q + 16 * (c + 1) * kEB, cs, ngroups - 4 * (c + 1), qn);
         resident_field<PT, MODE, 0>(Lf + r0 * S, Lb + r0 * S, KP, u, qd, yacc);
@@ -575,11 +637,14 @@ __global__ __launch_bounds__(64 * kResWaves, 1) void dense_apply_resident_kernel
       }
     }
 
-    if (PREFETCH_X) gather_x(sgn, un);  // x of the next block (its index words arrived during the products)
+    if (PREFETCH_X) {  // x and the first q-data chunk of the next block (its index words arrived during the products)
+      gather_x(sgn, un);
+      request_qd(bnc, qdn);
+    }
 
     // ---- E^T, first half
 #ifdef PA_ABLATION
-    double *ye = a.ye + ((a.dbg & 8) ? (size_t)(blockIdx.x * kResWaves + wave) : (size_t)b) * KP * 64;
+    double *ye = a.ye + ((a.dbg & 8) ? (size_t)(blockIdx.x * NW + wave) : (size_t)b) * KP * 64;
 #else
     double *ye = a.ye + (size_t)b * KP * 64;
 #endif
@@ -724,19 +789,27 @@ __global__ void dense_diag_qd_kernel(const DenseArgs a, const int32_t *__restric
 template <int PT>
 void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
   const int rows = ds.L_rows;
-  const size_t shm = sizeof(double) * ((size_t)rows * ResidentStride<PT>::S + (ds.d_co ? (size_t)kResWaves * 4 * PT * 64 : 0));
-  int grid = (ds.nb + kResWaves - 1) / kResWaves;
+  const bool affine = a.affine && PT <= 3;  // (make_dense_sub: larger blocks have no registers for the values kept across the block)
+  const int nw = affine ? kAffWaves : kResWaves;
+  const size_t shm = sizeof(double) * ((size_t)(a.Q4 + 31) / 32 * 32 + (size_t)rows * ResidentStride<PT>::S +
+                                      (ds.d_co ? (size_t)nw * 4 * PT * 64 : 0));
+  int grid = (ds.nb + nw - 1) / nw;
   if (grid > ds.num_cu) grid = ds.num_cu;
   switch (ds.mode) {
 #define PA_RES_CASE(MODE)                                                                                \
   case MODE: {                                                                                           \
     static bool attr_set = false;                                                                        \
     if (!attr_set) {                                                                                     \
-      PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE>,                    \
+      PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE, false>,             \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
+      PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE, (PT <= 3)>,         \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
       attr_set = true;                                                                                   \
     }                                                                                                    \
-    hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows); \
+    if (affine)                                                                                          \
+      hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE, (PT <= 3)>), dim3(grid), dim3(64 * nw), shm, s, a, rows); \
+    else                                                                                                 \
+      hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE, false>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows); \
   } break;
     PA_RES_CASE(MODE_CURL)
     PA_RES_CASE(MODE_VMASS)
@@ -946,11 +1019,35 @@ __global__ void dense_diag_slot_kernel(const int ne, const int P, const int KP, 
   ye[pos] = idx[pos] < 0 ? -v : v;
 }
 
+// Blocks whose packed D depends on the point through the quadrature weight only (constant Jacobian and attribute: straight-sided
+// simplices): w_0 D_q = w_q D_0 up to a few roundings.  One thread per (block, element slot).
+__global__ void dense_affine_kernel(const int nb, const int ncq, const int Q, const int Q4, const double *__restrict__ qd,
+                                    const double *__restrict__ wq, unsigned int *__restrict__ not_affine) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= nb * kEB) return;
+  const int b = gid / kEB, j = gid % kEB;
+  const size_t cs = (size_t)Q4 * kEB;
+  const double *e = qd + (size_t)b * ncq * cs + j;
+  double scale = 0.0;
+  for (int k = 0; k < ncq; k++) scale = fmax(scale, fabs(e[k * cs]));
+  bool ok = true;
+  for (int k = 0; k < ncq && ok; k++) {
+    const double d0 = e[k * cs];
+    for (int q = 1; q < Q; q++)
+      if (fabs(e[k * cs + (size_t)q * kEB] * wq[0] - d0 * wq[q]) > 1e-14 * scale * fabs(wq[q])) {
+        ok = false;
+        break;
+      }
+  }
+  if (!ok) atomicOr(&not_affine[b], 1u);
+}
+
 DenseArgs make_args(const DenseSub &ds) {
   DenseArgs a;
   a.ne = ds.ne, a.nb = ds.nb, a.P = ds.P, a.Q = ds.Q, a.Qpad = ds.Qpad, a.nch = ds.nch, a.KP = ds.KP;
   a.idx = ds.d_idx, a.co = ds.d_co, a.geom = ds.geom->d_geom, a.qw = ds.geom->d_qw, a.Tf = ds.d_Tf, a.Tt = ds.d_Tt;
   a.L = ds.d_L, a.qdata = ds.d_qdata, a.ncq = ds.ncq, a.Q4 = (ds.Q + 3) / 4 * 4;
+  a.affine = ds.d_affine, a.wrel = ds.d_wrel;
   a.dbg = 0;
 #ifdef PA_ABLATION
   a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
@@ -981,6 +1078,7 @@ void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
   g.ne = ne, g.q1d = 0, g.Q = Q, g.eb = kEB, g.Qpad = (Q + 15) / 16 * 16;
   g.dim = dim, g.sdim = sdim, g.nrows = dim == 3 ? 11 : (sdim == 3 ? 8 : 6);
   g.d_qw = dev_upload(mesh.qweight, (size_t)Q, s);
+  g.wq.assign(mesh.qweight, mesh.qweight + Q);
   const size_t nb = (size_t)(ne + kEB - 1) / kEB, count = nb * g.nrows * g.Qpad * kEB;
   g.d_geom = dev_alloc<double>(count);
   PA_HIP(hipMemsetAsync(g.d_geom, 0, sizeof(double) * count, s));
@@ -1227,6 +1325,30 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       }
       PA_HIP(hipGetLastError());
       PA_HIP(hipStreamSynchronize(nullptr));
+      // affine blocks read one point of q-data (PALACE_AMD_DENSE_AFFINE=0: every block reads all of it)
+      const char *aff_env = getenv("PALACE_AMD_DENSE_AFFINE");
+      const size_t lds_aff = sizeof(double) * ((size_t)((Q + 3) / 4 * 4 + 31) / 32 * 32 + (size_t)rows * S +
+                                               (r.curl_orients ? (size_t)kAffWaves * 4 * PT * 64 : 0));
+      if (!(aff_env && aff_env[0] == '0') && PT <= 3 && lds_aff <= 160 * 1024 && (int)geom->wq.size() == Q && Q > 1 &&
+          geom->wq[0] != 0.0) {
+        const int Q4 = (Q + 3) / 4 * 4;
+        unsigned int *d_na = dev_alloc<unsigned int>((size_t)nb);
+        PA_HIP(hipMemset(d_na, 0, sizeof(unsigned int) * nb));
+        hipLaunchKernelGGL(dense_affine_kernel, dim3((unsigned)((nb * kEB + 255) / 256)), dim3(256), 0, nullptr, nb, ds->ncq, Q,
+                           Q4, ds->d_qdata, geom->d_qw, d_na);
+        PA_HIP(hipGetLastError());
+        std::vector<unsigned int> na((size_t)nb);
+        PA_HIP(hipMemcpy(na.data(), d_na, sizeof(unsigned int) * nb, hipMemcpyDeviceToHost));
+        hipFree(d_na);
+        std::vector<uint8_t> flag((size_t)nb);
+        for (int i = 0; i < nb; i++) flag[i] = na[i] ? 0 : 1, ds->n_affine += flag[i];
+        if (ds->n_affine == nb) {  // all or nothing (a mixed mesh keeps the general kernel)
+          std::vector<double> wrel((size_t)Q4, 0.0);
+          for (int i = 0; i < Q; i++) wrel[i] = geom->wq[i] / geom->wq[0];
+          ds->d_affine = dev_upload(flag.data(), flag.size());
+          ds->d_wrel = dev_upload(wrel.data(), wrel.size());
+        }
+      }
     }
   }
   PA_REQUIRE(dim == 3 || ds->d_L, "2-D blocks need symmetric coefficients and tables that fit in LDS (fast path only)");
@@ -1234,6 +1356,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
 }
 
 void free_dense_sub(DenseSub *ds) {
+  if (ds) hipFree(ds->d_affine), hipFree(ds->d_wrel);
   if (!ds) return;
   hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co);
   hipFree(ds->d_Tf), hipFree(ds->d_Tt), hipFree(ds->d_interp), hipFree(ds->d_deriv);

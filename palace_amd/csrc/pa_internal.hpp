@@ -96,6 +96,7 @@ struct Geom {
   std::vector<int32_t> h_attr;    // host copy (tensor hex blocks), internal element order
   std::vector<int32_t> eorder;    // internal element p is the caller's element eorder[p] (empty: same order)
   std::vector<double> w1;         // 1-D quadrature weights (tensor hex blocks)
+  std::vector<double> wq;         // quadrature weights (dense blocks), host copy
   int refcount = 1;
 };
 
@@ -210,6 +211,9 @@ struct DenseSub {
   double *d_Tf = nullptr, *d_Tt = nullptr;  // MFMA A-operand fragments of the tables (forward / transposed)
   double *d_L = nullptr;       // LDS-resident form of the tables (fast path) or nullptr
   double *d_qdata = nullptr;   // packed pre-assembled D [nb][ncq][Qpad][16] (fast path)
+  uint8_t *d_affine = nullptr; // [nb] blocks whose elements all have a constant Jacobian (D_q = (w_q / w_0) D_0) or nullptr
+  double *d_wrel = nullptr;    // [Q4] w_q / w_0
+  int n_affine = 0;
   int L_rows = 0, ncq = 0, num_cu = 0;
   double *d_interp = nullptr, *d_deriv = nullptr;  // plain tables (diagonal assembly)
   int32_t *d_off = nullptr;    // plain [ne][P] offsets (diagonal assembly)

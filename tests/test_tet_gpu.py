@@ -87,6 +87,12 @@ def test_nd_tet_apply(kind, p, mode):
                                     curl_orients=nd.curl_orients)
     ops = sum({"C": ceed.EVAL_CURL, "I": ceed.EVAL_INTERP}[c] for c in ops_s)
     op = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(geom, block, getattr(ceed, qf_name), blob, ops).finalize()
+    # straight-sided tets run in the affine form (D of one point per element and field), curved ones in the general form
+    # (unless the tables of the two fields leave no LDS for twelve waves: p = 3 with this 64-point rule)
+    if kind == "tet10":
+        assert op.dense_affine() == 0
+    elif not (p == 3 and name == "curlmass"):
+        assert op.dense_affine() == 1
     rng = np.random.default_rng(p)
     x = rng.uniform(-1, 1, nd.ndofs)
     y_ref = orc.apply_add(x, np.zeros(nd.ndofs))
@@ -95,6 +101,18 @@ def test_nd_tet_apply(kind, p, mode):
     op.mult(xd, yd)
     err = np.abs(yd.cpu().numpy() - y_ref).max() / np.abs(y_ref).max()
     assert err < REL, f"Mult rel err {err:.3e}"
+    if op.dense_affine():  # the general form on the same elements: same result up to the rounding of w_q / w_0
+        import os
+
+        os.environ["PALACE_AMD_DENSE_AFFINE"] = "0"
+        try:
+            op_g = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(geom, block, getattr(ceed, qf_name), blob, ops).finalize()
+        finally:
+            del os.environ["PALACE_AMD_DENSE_AFFINE"]
+        assert op_g.dense_affine() == 0
+        yg = torch.empty_like(xd)
+        op_g.mult(xd, yg)
+        assert (yg - yd).abs().max().item() <= 1e-14 * yd.abs().max().item()
     d_ref = orc.diagonal()
     dd = torch.empty_like(xd)
     op.assemble_diagonal(dd)
