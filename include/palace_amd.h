@@ -56,8 +56,12 @@ enum pa_qfunction {
    * models/spaceoperator.cpp:305-309); tensor-product hexahedra, matrix-free D */
   PA_QF_HCURLHDIV_33 = 9, /* f_apply_hcurlhdiv_33 fem/qfunctions/33/hcurlhdiv_33_qf.h:10-31 MixedVectorWeakCurlIntegrator:
                              (C u, curl v), trial Interp, test Curl */
-  PA_QF_HDIVHCURL_33 = 10 /* f_apply_hdivhcurl_33 fem/qfunctions/33/hcurlhdiv_33_qf.h:33-54 MixedVectorCurlIntegrator:
-                             (C curl u, v), trial Curl, test Interp */
+  PA_QF_HDIVHCURL_33 = 10, /* f_apply_hdivhcurl_33 fem/qfunctions/33/hcurlhdiv_33_qf.h:33-54 MixedVectorCurlIntegrator:
+                             (C curl u, v), trial Curl, test Interp.  Both also with two different spaces, Interp / Interp:
+                             pa_op_add_sub_dense_mixed */
+  /* element error integrators (pa_error_op_create), two inputs with the Piola maps of their spaces */
+  PA_QF_HCURLHDIV_ERROR_33 = 11, /* f_apply_hcurlhdiv_error_33 fem/qfunctions/33/hcurlhdiv_error_33_qf.h:10-43 */
+  PA_QF_HDIVHCURL_ERROR_33 = 12  /* f_apply_hdivhcurl_error_33 fem/qfunctions/33/hcurlhdiv_error_33_qf.h:45-78 */
 };
 
 enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1, PA_FE_HDIV = 2 /* dense path only: RT mass (Interp + hdiv_33) */ };
@@ -223,6 +227,25 @@ int pa_op_add_sub(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
 int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr,
                         const pa_dense_basis_desc *basis, int32_t qfunction, const void *ctx,
                         size_t ctx_size, uint32_t trial_ops, uint32_t test_ops);
+/* Trial space != test space on the same elements: BilinearForm(trial_fespace, test_fespace) with VectorFEMassIntegrator, which
+ * picks f_apply_hcurlhdiv_33 (H(curl) trial, H(div) test) or f_apply_hdivhcurl_33 (the other way round) from the map types of
+ * the two elements (fem/integ/vecfemass.cpp:88-101) -- the `Flux` operator of FluxProjector (linalg/errorestimator.cpp:164-176).
+ * Both evaluation modes are Interp; the H(div) basis carries its value table in `interp`.  op: height = test lsize, width =
+ * trial lsize.  No transposed, essential-dof, diagonal or assembled form. */
+int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
+                              const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
+                              const pa_dense_basis_desc *test_basis, int32_t qfunction, const void *ctx, size_t ctx_size);
+/* AssembleCeedElementErrorIntegrator (fem/libceed/integrator.cpp:550-626) as the flux error estimators use it
+ * (linalg/errorestimator.cpp:345-349, :485-489): estimates[e] += int_e |C_2 u_2 - C_1 u_1|^2 for L-vectors u_1, u_2 of two spaces
+ * on the elements of `geom`; `ctx` is the pair context PopulateCoefficientContext(dim, first, dim, second) packs.  One value per
+ * element, in the element order of `geom`. */
+typedef struct pa_error_op pa_error_op;
+int pa_error_op_create(pa_geom *geom, const pa_restriction_desc *restr1, const pa_dense_basis_desc *basis1,
+                       const pa_restriction_desc *restr2, const pa_dense_basis_desc *basis2, int32_t qfunction,
+                       const void *ctx, size_t ctx_size, pa_error_op **out);
+int pa_error_op_apply_add(pa_error_op *e, const double *u1, const double *u2, double *estimates, void *stream);
+int pa_error_op_num_elem(const pa_error_op *e);
+void pa_error_op_destroy(pa_error_op *e);
 /* SURVEY.md 8(f)-1, behind BuildParSumOperator (linalg/rap.cpp:843-919) and SpaceOperator::GetSystemMatrix
  * (models/spaceoperator.cpp:786-804): sum_k coeffs[k] * (integrator k) over H(curl) integrators that share the
  * geometry data and the space -- K (PA_QF_HDIV_33), M and C (PA_QF_HCURL_33), K + M (PA_QF_HDIVMASS_33) -- added as ONE

@@ -334,6 +334,45 @@ def apply_hdivhcurl_33(ctx: CoeffCtx, geom, u):
     return np.transpose(wdetJ[..., None] * v, (0, 2, 1))
 
 
+def mult_BAx33(A, B, x):
+    """utils_33_qf.h:86-101: y = B (A x), matrices [..., 9] column-major, x [..., 3]."""
+    z0 = A[..., 0] * x[..., 0] + A[..., 3] * x[..., 1] + A[..., 6] * x[..., 2]
+    z1 = A[..., 1] * x[..., 0] + A[..., 4] * x[..., 1] + A[..., 7] * x[..., 2]
+    z2 = A[..., 2] * x[..., 0] + A[..., 5] * x[..., 1] + A[..., 8] * x[..., 2]
+    out = np.empty(np.broadcast_shapes(z0.shape, B[..., 0].shape) + (3,))
+    out[..., 0] = B[..., 0] * z0 + B[..., 3] * z1 + B[..., 6] * z2
+    out[..., 1] = B[..., 1] * z0 + B[..., 4] * z1 + B[..., 7] * z2
+    out[..., 2] = B[..., 2] * z0 + B[..., 5] * z1 + B[..., 8] * z2
+    return out
+
+
+def apply_hcurlhdiv_error_33(ctx1: CoeffCtx, ctx2: CoeffCtx, geom, u1, u2):
+    """hcurlhdiv_error_33_qf.h:10-43 (f_apply_hcurlhdiv_error_33): u1 [NE, 3, Q] reference values of an H(curl) function,
+    u2 of an H(div) function; returns w detJ |C2 (J/detJ) u2 - C1 adjJt u1|^2  [NE, Q] (the integrand of the element error of
+    GradFluxErrorEstimator, linalg/errorestimator.cpp:318-349)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    wdetJ = geom[:, 1, :]
+    adj = np.transpose(geom[:, 2:, :], (0, 2, 1))
+    Jl, _ = adjJt33(adj)
+    v1 = mult_BAx33(adj, ctx1.unpack3(attr), np.transpose(u1, (0, 2, 1)))
+    v2 = mult_BAx33(Jl, ctx2.unpack3(attr), np.transpose(u2, (0, 2, 1)))
+    d = v2 - v1
+    return wdetJ * (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
+
+
+def apply_hdivhcurl_error_33(ctx1: CoeffCtx, ctx2: CoeffCtx, geom, u1, u2):
+    """hcurlhdiv_error_33_qf.h:45-78 (f_apply_hdivhcurl_error_33): the first input in H(div), the second in H(curl)
+    (CurlFluxErrorEstimator, linalg/errorestimator.cpp:448-489)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    wdetJ = geom[:, 1, :]
+    adj = np.transpose(geom[:, 2:, :], (0, 2, 1))
+    Jl, _ = adjJt33(adj)
+    v1 = mult_BAx33(Jl, ctx1.unpack3(attr), np.transpose(u1, (0, 2, 1)))
+    v2 = mult_BAx33(adj, ctx2.unpack3(attr), np.transpose(u2, (0, 2, 1)))
+    d = v2 - v1
+    return wdetJ * (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
+
+
 def apply_hdivmass_33(ctx_mass: CoeffCtx, ctx_curl: CoeffCtx, geom, u, curlu):
     """hdivmass_33_qf.h:10-44 (mass coefficient first, then the curl-curl one)."""
     return apply_hcurl_33(ctx_mass, geom, u), apply_hdiv_33(ctx_curl, geom, curlu)
@@ -430,6 +469,7 @@ def apply_hcurl_32(ctx, geom, u):
 QF_HCURL_32 = "hcurl_32"
 QF_HDIV, QF_HCURL, QF_HDIVMASS, QF_HCURLMASS, QF_H1MASS = "hdiv_33", "hcurl_33", "hdivmass_33", "hcurlmass_33", "h1_1"
 QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22 = "hcurl_22", "l2_1", "hdivmass_22"
+QF_HCURLHDIV_ERROR, QF_HDIVHCURL_ERROR = "hcurlhdiv_error_33", "hdivhcurl_error_33"
 QF_HCURLHDIV, QF_HDIVHCURL = "hcurlhdiv_33", "hdivhcurl_33"  # weak curl (Interp -> Curl), mixed curl (Curl -> Interp)
 
 
@@ -619,6 +659,37 @@ class CeedOperatorOracle:
 
 DIAG_ONE, DIAG_ZERO = 1, 0
 
+
+
+class MixedSpaceOracle:
+    """Two spaces on one element block: the mixed mass operator (v, C u) of BilinearForm(trial, test) +
+    VectorFEMassIntegrator (fem/integ/vecfemass.cpp:88-101: f_apply_hcurlhdiv_33 for an H(curl) trial and an H(div) test
+    space, f_apply_hdivhcurl_33 the other way round) and the element error integrator of
+    AssembleCeedElementErrorIntegrator (fem/libceed/integrator.cpp:550-626).  `first` / `second` are CeedOperatorOracle
+    objects used for their restrictions and value tables only (trial / test, or input 1 / input 2)."""
+
+    def __init__(self, first, second, geom, qf, ctx, ctx2=None):
+        self.a, self.b, self.geom, self.qf, self.ctx, self.ctx2 = first, second, geom, qf, ctx, ctx2
+        assert first.NE == second.NE == geom.shape[0]
+
+    def apply_add(self, x, y, chunk=2048):
+        f = {QF_HCURLHDIV: apply_hcurlhdiv_33, QF_HDIVHCURL: apply_hdivhcurl_33}[self.qf]
+        for s0 in range(0, self.a.NE, chunk):
+            sl = slice(s0, min(self.a.NE, s0 + chunk))
+            u = np.einsum("dqj,ej->edq", self.a.interp, self.a._restrict(x, sl))
+            ve = np.einsum("dqj,edq->ej", self.b.interp, f(self.ctx, self.geom[sl], u))
+            np.add.at(y, self.b.off[sl].ravel(), self.b._restrict_t(ve, sl).ravel())
+        return y
+
+    def error_add(self, u1, u2, est, chunk=2048):
+        """est[e] += sum_q of the error QFunction (the all-ones `mesh_elem_basis`, integrator.cpp:560-574)."""
+        f = {QF_HCURLHDIV_ERROR: apply_hcurlhdiv_error_33, QF_HDIVHCURL_ERROR: apply_hdivhcurl_error_33}[self.qf]
+        for s0 in range(0, self.a.NE, chunk):
+            sl = slice(s0, min(self.a.NE, s0 + chunk))
+            q1 = np.einsum("dqj,ej->edq", self.a.interp, self.a._restrict(u1, sl))
+            q2 = np.einsum("dqj,ej->edq", self.b.interp, self.b._restrict(u2, sl))
+            est[sl] += f(self.ctx, self.ctx2, self.geom[sl], q1, q2).sum(axis=1)
+        return est
 
 class ParOperatorOracle:
     """rap.cpp:195-234 with a trivial prolongation (one rank)."""

@@ -13,6 +13,7 @@ typedef double CeedScalar;
 #include "fem/qfunctions/33/hdiv_33_qf.h"
 #include "fem/qfunctions/33/hdivmass_33_qf.h"
 #include "fem/qfunctions/33/hcurlhdiv_33_qf.h"
+#include "fem/qfunctions/33/hcurlhdiv_error_33_qf.h"
 #include "fem/qfunctions/33/hcurlmass_33_qf.h"
 #include "fem/qfunctions/1/h1_1_qf.h"
 #include "fem/qfunctions/22/geom_22_qf.h"

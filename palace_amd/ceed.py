@@ -20,6 +20,7 @@ from .fem.fespace import H1HexSpace, NDHexSpace
 from .fem.mesh import HexMesh, _q2_1d
 
 QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1, QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22, QF_HCURL_32 = range(9)
+QF_HCURLHDIV_ERROR_33, QF_HDIVHCURL_ERROR_33 = 11, 12
 QF_HCURLHDIV_33, QF_HDIVHCURL_33 = 9, 10  # weak curl (trial Interp, test Curl) / mixed curl (trial Curl, test Interp)
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
 FE_H1, FE_HCURL, FE_HDIV = 0, 1, 2
@@ -161,6 +162,32 @@ class DenseGeomFactorData:
             pass
 
 
+class ElementErrorIntegrator:
+    """AssembleCeedElementErrorIntegrator (fem/libceed/integrator.cpp:550-626) on the device (pa_error_op_*): per-element
+    int |C_2 u_2 - C_1 u_1|^2 for L-vectors of two spaces; qf = QF_HCURLHDIV_ERROR_33 (first input in H(curl)) or
+    QF_HDIVHCURL_ERROR_33; ctx_pair = the two coefficient contexts, first input's first."""
+
+    def __init__(self, geom, first: "DenseBlock", second: "DenseBlock", qf, ctx_pair):
+        r1, b1 = first.descs()
+        r2, b2 = second.descs()
+        ctx = np.ascontiguousarray(ctx_pair)
+        self.handle = C.c_void_p()
+        self._keep = (geom, first, second)
+        _lib.check(_lib.load().pa_error_op_create(geom.handle, C.byref(r1), C.byref(b1), C.byref(r2), C.byref(b2),
+                                                  C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes), C.byref(self.handle)))
+        self.ne = int(_lib.load().pa_error_op_num_elem(self.handle))
+
+    def apply_add(self, u1, u2, estimates):
+        _lib.check(_lib.load().pa_error_op_apply_add(self.handle, C.c_void_p(u1.data_ptr()), C.c_void_p(u2.data_ptr()),
+                                                     C.c_void_p(estimates.data_ptr()), _stream()))
+        return estimates
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            _lib.load().pa_error_op_destroy(self.handle)
+            self.handle = None
+
+
 class DenseBlock:
     """What Palace hands to libCEED for one (geometry, space) pair on the non-tensor path: the native
     restriction (fem/libceed/restriction.cpp:207-385: offsets + bool orients, or + int8 tridiagonal
@@ -260,6 +287,16 @@ class Operator:
         _lib.check(_lib.load().pa_op_add_sub_dense(self.handle, geom.handle, C.byref(r), C.byref(b),
                                                    C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes),
                                                    C.c_uint32(ops), C.c_uint32(ops)))
+        return self
+
+    def add_dense_mixed_integrator(self, geom: DenseGeomFactorData, trial: DenseBlock, test: DenseBlock, qf, ctx_blob):
+        """BilinearForm(trial_fespace, test_fespace) + VectorFEMassIntegrator between an H(curl) and an H(div) space
+        (pa_op_add_sub_dense_mixed): qf = QF_HCURLHDIV_33 (H(curl) trial) or QF_HDIVHCURL_33 (H(div) trial)."""
+        r1, b1 = trial.descs()
+        r2, b2 = test.descs()
+        ctx = np.ascontiguousarray(ctx_blob)
+        _lib.check(_lib.load().pa_op_add_sub_dense_mixed(self.handle, geom.handle, C.byref(r1), C.byref(b1), C.byref(r2),
+                                                         C.byref(b2), C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes)))
         return self
 
     @staticmethod

@@ -73,6 +73,7 @@ int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
       std::vector<int32_t> off;
     };
     std::vector<Conn> conns;
+    PA_REQUIRE(op->msubs.empty(), "mixed-space operators are not assembled");
     for (const SubOp *so : op->subs) {
       Conn c{so->ne, so->P, {}};
       c.off.resize(so->h_sidx.size());

@@ -382,8 +382,10 @@ static void free_sub(SubOp *so) {
 static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s, bool masked = false,
                   int ess_policy = -1, hipEvent_t after = nullptr) {
   PA_REQUIRE(op && x && y, "null argument");
-  PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty(), "operator has no sub-operators");
+  PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty() || !op->msubs.empty(), "operator has no sub-operators");
   PA_REQUIRE(x != y, "in-place apply is not supported");
+  PA_REQUIRE(op->msubs.empty() || (!masked && !TransposeScope::active()),
+             "mixed-space sub-operators have no essential-dof or transposed form");
   bool first = true;
   const bool split = after && op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->fe_type == PA_FE_HCURL &&
                      op->subs[0]->d_idxc && op->subs[0]->has_blist && overwrite && (!masked || op->subs[0]->d_perm_s_bc);
@@ -417,6 +419,10 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   for (const DenseSub *ds : op->dsubs) {
     launch_dense_apply(*ds, x, masked, s);
     launch_dense_gather(*ds, y, !(overwrite && first), s);
+    first = false;
+  }
+  for (const MixedSub *ms : op->msubs) {
+    launch_mixed_apply(*ms, x, y, !(overwrite && first), s);
     first = false;
   }
 }
@@ -492,6 +498,7 @@ bool pa_op::symmetric() const {
     if (!so->c0.symmetric() || !so->c1.symmetric()) return false;
   for (const pa::DenseSub *ds : dsubs)
     if (!ds->c0.symmetric() || !ds->c1.symmetric()) return false;
+  if (!msubs.empty()) return false;
   return true;
 }
 
@@ -624,6 +631,57 @@ int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *res
   });
 }
 
+int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
+                              const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
+                              const pa_dense_basis_desc *test_basis, int32_t qfunction, const void *ctx, size_t ctx_size) {
+  return guarded([&] {
+    require_device();
+    PA_REQUIRE(op && geom && trial_restr && trial_basis && test_restr && test_basis, "null argument");
+    PA_REQUIRE(!op->finalized, "operator already finalized");
+    PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_33 || qfunction == PA_QF_HDIVHCURL_33, "not a mixed-space QFunction");
+    PA_REQUIRE(test_restr->lsize == op->height && trial_restr->lsize == op->width,
+               "dimensions mismatch for sub-operator");  // operator.cpp:69-71
+    op->msubs.push_back(make_mixed_sub(geom, *trial_restr, *trial_basis, *test_restr, *test_basis, qfunction, ctx, ctx_size));
+  });
+}
+
+struct pa_error_op {
+  MixedSub *ms = nullptr;
+};
+
+int pa_error_op_create(pa_geom *geom, const pa_restriction_desc *restr1, const pa_dense_basis_desc *basis1,
+                       const pa_restriction_desc *restr2, const pa_dense_basis_desc *basis2, int32_t qfunction,
+                       const void *ctx, size_t ctx_size, pa_error_op **out) {
+  return guarded([&] {
+    require_device();
+    PA_REQUIRE(geom && restr1 && basis1 && restr2 && basis2 && out, "null argument");
+    PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_ERROR_33 || qfunction == PA_QF_HDIVHCURL_ERROR_33, "not an error QFunction");
+    auto *e = new pa_error_op;
+    try {
+      e->ms = make_mixed_sub(geom, *restr1, *basis1, *restr2, *basis2, qfunction, ctx, ctx_size);
+    } catch (...) {
+      delete e;
+      throw;
+    }
+    *out = e;
+  });
+}
+
+int pa_error_op_apply_add(pa_error_op *e, const double *u1, const double *u2, double *estimates, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(e && e->ms && u1 && u2 && estimates, "null argument");
+    launch_mixed_error(*e->ms, u1, u2, estimates, (hipStream_t)stream);
+  });
+}
+
+int pa_error_op_num_elem(const pa_error_op *e) { return (e && e->ms) ? e->ms->ne : -1; }
+
+void pa_error_op_destroy(pa_error_op *e) {
+  if (!e) return;
+  free_mixed_sub(e->ms);
+  delete e;
+}
+
 // Weighted sum of H(curl) integrators on one (geometry, space) pair as ONE sub-operator: D is linear in the material
 // coefficient, so sum_k a_k {K(mu^-1), M(eps), C(sigma), ...} is a single curl-curl + mass pass whose two contexts are
 // the weighted sums of the terms' contexts (per attribute).  Returns the combined blob (mass first, like the
@@ -746,7 +804,7 @@ int pa_op_add_sub_dense_sum(pa_op *op, pa_geom *geom, const pa_restriction_desc 
 int pa_op_finalize(pa_op *op) {
   return guarded([&] {
     PA_REQUIRE(op, "null argument");
-    PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty(), "operator has no sub-operators");
+    PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty() || !op->msubs.empty(), "operator has no sub-operators");
     finalize_exclusive(op);
     op->finalized = true;
   });
@@ -933,6 +991,7 @@ int pa_op_mult2_essential_diag(pa_op *op, const double *x0, const double *x1, do
 int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream) {
   return guarded([&] {
     PA_REQUIRE(op && diag, "null argument");
+    PA_REQUIRE(op->msubs.empty(), "mixed-space operators have no diagonal");
     PA_HIP(hipMemsetAsync(diag, 0, sizeof(double) * (size_t)op->height, (hipStream_t)stream));
     for (const SubOp *so : op->subs) {
       if (so->fe_type == PA_FE_HCURL)
@@ -960,6 +1019,7 @@ void pa_op_destroy(pa_op *op) {
   if (!op) return;
   for (SubOp *so : op->subs) free_sub(so);
   for (DenseSub *ds : op->dsubs) free_dense_sub(ds);
+  for (MixedSub *ms : op->msubs) free_mixed_sub(ms);
   delete op;
 }
 

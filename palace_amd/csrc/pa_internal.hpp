@@ -225,6 +225,23 @@ struct DenseSub {
   CoeffHost c0, c1;
 };
 
+// pa_mixed.hip: one space of a mixed-space operator (plain [ne][P] layouts) and the operator / error integrator itself
+struct MixedSide {
+  int fe_type = 0, P = 0, lsize = 0;
+  int32_t *d_sidx = nullptr;
+  int8_t *d_cor = nullptr;
+  double *d_tabF = nullptr, *d_tabT = nullptr;
+  int32_t *d_tptr = nullptr, *d_tent = nullptr;
+};
+struct MixedSub {
+  Geom *geom = nullptr;
+  int ne = 0, Q = 0, qf = 0;
+  bool error = false;
+  MixedSide s1, s2;  // apply: trial, test; error: first and second input
+  CoeffHost c0, c1;
+  double *d_ye = nullptr;
+};
+
 void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t slot_offset);
 
 // kernels (pa_geom.hip, pa_nd_hex.hip, pa_h1_hex.hip)
@@ -270,6 +287,14 @@ void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const
                           bool accumulate, hipStream_t s, const int32_t *list = nullptr, const double *x = nullptr,
                           int ess_policy = -1);
 
+// pa_mixed.hip
+MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_dense_basis_desc &b1,
+                         const pa_restriction_desc &r2, const pa_dense_basis_desc &b2, int qf, const void *ctx,
+                         size_t ctx_size);
+void free_mixed_sub(MixedSub *ms);
+void launch_mixed_apply(const MixedSub &ms, const double *x, double *y, bool accumulate, hipStream_t s);
+void launch_mixed_error(const MixedSub &ms, const double *u1, const double *u2, double *out, hipStream_t s);
+
 }  // namespace pa
 
 struct pa_geom : pa::Geom {};
@@ -282,4 +307,5 @@ struct pa_op {
   bool symmetric() const;  // every coefficient matrix of every sub-operator is symmetric => A^T = A
   std::vector<pa::SubOp *> subs;
   std::vector<pa::DenseSub *> dsubs;
+  std::vector<pa::MixedSub *> msubs;  // trial space != test space (pa_op_add_sub_dense_mixed)
 };

@@ -1,0 +1,282 @@
+// Operators between two different spaces on the same elements, and the element-wise error integrators built on them: the
+// pieces of the flux error estimators (linalg/errorestimator.cpp) that are not same-space bilinear forms.
+//
+//  * mixed mass  (v, C u)  with u in H(curl) and v in H(div) or the other way round: FluxProjector's `Flux` operator
+//    (errorestimator.cpp:164-176, BilinearForm(rhs_fespace, smooth_fespace) + VectorFEMassIntegrator, which picks
+//    f_apply_hcurlhdiv_33 / f_apply_hdivhcurl_33 by the map types of the two elements, fem/integ/vecfemass.cpp:88-101);
+//  * element error  eta_e^2 += int_e |C_2 u_2 - C_1 u_1|^2  for u_1, u_2 in those two spaces
+//    (AssembleCeedElementErrorIntegrator, fem/libceed/integrator.cpp:550-626, with f_apply_hcurlhdiv_error_33 /
+//    f_apply_hdivhcurl_error_33, fem/qfunctions/33/hcurlhdiv_error_33_qf.h:10-78).
+//
+// These run once per solve (post-processing), not inside the Krylov loop: one wave per element, dense tables read through the
+// caches (q fastest for the forward product, dof fastest for the transposed one: coalesced either way), the pointwise arithmetic
+// exactly the reference QFunctions' on the element-blocked geometry data of pa_geom_create_dense, E^T as E-vector + the
+// deterministic gather.  Any element type the caller has dense tables for (tetrahedra and hexahedra are tested).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "pa_device.hpp"
+
+namespace pa {
+
+namespace {
+
+constexpr int kMixWaves = 4;
+constexpr int kEBm = 16;  // element block of the dense geometry layout
+
+struct MixSideDev {
+  int P;
+  const int32_t *sidx;  // [ne][P] L-vector index, -(1 + index) when the sign is flipped
+  const int8_t *cor;    // [ne][P][3] rows of the tridiagonal dof transformation or nullptr
+  const double *tabF;   // [3][P][Q] values at the quadrature points, point fastest
+  const double *tabT;   // [3][Q][P] the same, dof fastest
+};
+
+struct MixArgs {
+  int ne, Q, Qpad, stride;
+  const double *geom;
+  MixSideDev s1, s2;
+  CoeffDev c0, c1;
+  const double *x1, *x2;
+  double *ye;   // [ne][P2] (apply)
+  double *out;  // [ne] (error)
+};
+
+// u_e = T_e (signed gather of x): restriction.cpp:299-369 for the curl-oriented case
+__device__ __forceinline__ void mix_gather(const MixSideDev &sd, const int e, const int lane, const double *__restrict__ x,
+                                           double *dst, double *tmp) {
+  double *raw = sd.cor ? tmp : dst;
+  for (int d = lane; d < sd.P; d += 64) {
+    const int sg = sd.sidx[(size_t)e * sd.P + d];
+    const double v = x[sg >= 0 ? sg : -1 - sg];
+    raw[d] = sg >= 0 ? v : -v;
+  }
+  wave_sync();
+  if (sd.cor) {
+    for (int d = lane; d < sd.P; d += 64) {
+      const int8_t *t = sd.cor + 3 * ((size_t)e * sd.P + d);
+      const double lo = d > 0 ? tmp[d - 1] : 0.0, hi = d + 1 < sd.P ? tmp[d + 1] : 0.0;
+      dst[d] = (double)t[0] * lo + (double)t[1] * tmp[d] + (double)t[2] * hi;
+    }
+    wave_sync();
+  }
+}
+
+__device__ __forceinline__ void mix_eval(const MixSideDev &sd, const int Q, const int q, const double *xs, double (&u)[3]) {
+  u[0] = u[1] = u[2] = 0.0;
+  for (int d = 0; d < sd.P; d++) {
+    const double xv = xs[d];
+    u[0] += sd.tabF[((size_t)0 * sd.P + d) * Q + q] * xv;
+    u[1] += sd.tabF[((size_t)1 * sd.P + d) * Q + q] * xv;
+    u[2] += sd.tabF[((size_t)2 * sd.P + d) * Q + q] * xv;
+  }
+}
+
+// y = B (A x), column-major 3x3 (utils_33_qf.h:86-101)
+__device__ __forceinline__ void mult_BAx33(const double A[9], const double B[9], const double (&x)[3], double (&y)[3]) {
+  const double z0 = A[0] * x[0] + A[3] * x[1] + A[6] * x[2];
+  const double z1 = A[1] * x[0] + A[4] * x[1] + A[7] * x[2];
+  const double z2 = A[2] * x[0] + A[5] * x[1] + A[8] * x[2];
+  y[0] = B[0] * z0 + B[3] * z1 + B[6] * z2;
+  y[1] = B[1] * z0 + B[4] * z1 + B[7] * z2;
+  y[2] = B[2] * z0 + B[5] * z1 + B[8] * z2;
+}
+
+// KIND 0: f_apply_hcurlhdiv_33, 1: f_apply_hdivhcurl_33, 2: f_apply_hcurlhdiv_error_33, 3: f_apply_hdivhcurl_error_33
+template <int KIND>
+__global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * kMixWaves + wave;
+  if (e >= a.ne) return;  // no workgroup barriers below
+  constexpr bool ERR = KIND >= 2;
+  const int P1 = a.s1.P, P2 = a.s2.P, Q = a.Q;
+  double *xa = smem + (size_t)wave * a.stride;
+  double *xb = xa + P1;
+  double *tmp = xb + P2;
+  double *vq = tmp + max(P1, P2);
+
+  mix_gather(a.s1, e, lane, a.x1, xa, tmp);
+  if (ERR) mix_gather(a.s2, e, lane, a.x2, xb, tmp);
+
+  const double *g = a.geom + ((size_t)(e / kEBm) * 11 * a.Qpad) * kEBm + (e % kEBm);
+  double err = 0.0;
+  for (int q = lane; q < Q; q += 64) {
+    double u1[3];
+    mix_eval(a.s1, Q, q, xa, u1);
+    const int attr = (a.c0.nattr > 0 || a.c1.nattr > 0) ? max(1, (int)g[(size_t)q * kEBm]) : 1;
+    const double wdetJ = g[((size_t)a.Qpad + q) * kEBm];
+    double adj[9], Jl[9], Cm[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) adj[k] = g[((size_t)(2 + k) * a.Qpad + q) * kEBm];
+    adjJt33(adj, Jl);
+    coeff_unpack3(a.c0, attr, Cm);
+    if (!ERR) {
+      double v0, v1, v2;
+      if (KIND == 0)  // hcurlhdiv_33_qf.h:10-31: H(curl) trial (adj(J)^T / det J), H(div) test (J / det J)
+        mult_AtBCx33(Jl, Cm, adj, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
+      else  // hcurlhdiv_33_qf.h:33-54
+        mult_AtBCx33(adj, Cm, Jl, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
+      vq[q] = v0, vq[Q + q] = v1, vq[2 * Q + q] = v2;
+    } else {
+      double u2[3], w1[3], w2[3], C2[9];
+      mix_eval(a.s2, Q, q, xb, u2);
+      coeff_unpack3(a.c1, attr, C2);
+      if (KIND == 2) {  // hcurlhdiv_error_33_qf.h:10-43
+        mult_BAx33(adj, Cm, u1, w1);
+        mult_BAx33(Jl, C2, u2, w2);
+      } else {  // :45-78
+        mult_BAx33(Jl, Cm, u1, w1);
+        mult_BAx33(adj, C2, u2, w2);
+      }
+      w2[0] -= w1[0], w2[1] -= w1[1], w2[2] -= w1[2];
+      err += wdetJ * (w2[0] * w2[0] + w2[1] * w2[1] + w2[2] * w2[2]);
+    }
+  }
+  if (ERR) {
+    // sum over the points of the element (the all-ones basis of integrator.cpp:560-574), fixed tree
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) err += __shfl_xor(err, m, 64);
+    if (lane == 0) a.out[e] += err;
+    return;
+  }
+  wave_sync();
+  // B^T on the test side, then T_e^T and the E-vector
+  double *yt = tmp;
+  for (int i = lane; i < P2; i += 64) {
+    double s = 0.0;
+    for (int c = 0; c < 3; c++)
+      for (int q = 0; q < Q; q++) s += a.s2.tabT[((size_t)c * Q + q) * P2 + i] * vq[c * Q + q];
+    yt[i] = s;
+  }
+  wave_sync();
+  for (int i = lane; i < P2; i += 64) {
+    double s = yt[i];
+    if (a.s2.cor) {
+      const int8_t *t = a.s2.cor + 3 * ((size_t)e * P2 + i);
+      s = (double)t[1] * yt[i];
+      if (i > 0) s += (double)t[-3 + 2] * yt[i - 1];       // T[i-1][i]
+      if (i + 1 < P2) s += (double)t[3 + 0] * yt[i + 1];    // T[i+1][i]
+    }
+    a.ye[(size_t)e * P2 + i] = s;
+  }
+}
+
+void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, MixedSide &sd) {
+  PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_HDIV, "mixed operators take H(curl) and H(div) elements");
+  PA_REQUIRE(b.num_dofs > 0 && b.num_qpts == Q && b.interp, "basis does not match the quadrature rule, or has no value table");
+  PA_REQUIRE(r.elem_size == b.num_dofs && r.offsets && r.lsize > 0, "restriction does not match the basis");
+  PA_REQUIRE(!(r.orients && r.curl_orients), "restriction is either oriented or curl-oriented");
+  const int P = b.num_dofs, ne = r.num_elem;
+  sd.fe_type = b.fe_type, sd.P = P, sd.lsize = r.lsize;
+  std::vector<int32_t> sidx((size_t)ne * P);
+  for (size_t k = 0; k < sidx.size(); k++) {
+    const int32_t off = r.offsets[k];
+    PA_REQUIRE(off >= 0 && off < r.lsize, "restriction offset out of range");
+    sidx[k] = (r.orients && r.orients[k]) ? -1 - off : off;
+  }
+  sd.d_sidx = dev_upload(sidx.data(), sidx.size());
+  if (r.curl_orients) sd.d_cor = dev_upload(r.curl_orients, (size_t)3 * ne * P);
+  std::vector<double> F((size_t)3 * P * Q);
+  for (int c = 0; c < 3; c++)
+    for (int q = 0; q < Q; q++)
+      for (int d = 0; d < P; d++) F[((size_t)c * P + d) * Q + q] = b.interp[((size_t)c * Q + q) * P + d];
+  sd.d_tabF = dev_upload(F.data(), F.size());
+  sd.d_tabT = dev_upload(b.interp, (size_t)3 * Q * P);
+  // transpose map of the signed plain-layout index (counting sort by dof, element order preserved)
+  std::vector<int32_t> tptr((size_t)r.lsize + 1, 0), tent((size_t)ne * P);
+  for (size_t k = 0; k < (size_t)ne * P; k++) tptr[(size_t)r.offsets[k] + 1]++;
+  for (int d = 0; d < r.lsize; d++) tptr[d + 1] += tptr[d];
+  std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+  for (size_t k = 0; k < (size_t)ne * P; k++) {
+    const bool flip = r.orients && r.orients[k];
+    tent[fill[r.offsets[k]]++] = flip ? -1 - (int32_t)k : (int32_t)k;
+  }
+  sd.d_tptr = dev_upload(tptr.data(), tptr.size());
+  sd.d_tent = dev_upload(tent.data(), tent.size());
+}
+
+void free_side(MixedSide &sd) {
+  hipFree(sd.d_sidx), hipFree(sd.d_cor), hipFree(sd.d_tabF), hipFree(sd.d_tabT), hipFree(sd.d_tptr), hipFree(sd.d_tent);
+}
+
+MixSideDev dev_side(const MixedSide &sd) { return MixSideDev{sd.P, sd.d_sidx, sd.d_cor, sd.d_tabF, sd.d_tabT}; }
+
+void launch(const MixedSub &ms, const double *x1, const double *x2, double *out, hipStream_t s) {
+  MixArgs a;
+  a.ne = ms.ne, a.Q = ms.Q, a.Qpad = ms.geom->Qpad;
+  a.stride = (ms.s1.P + ms.s2.P + std::max(ms.s1.P, ms.s2.P) + 3 * ms.Q + 1) & ~1;
+  a.geom = ms.geom->d_geom;
+  a.s1 = dev_side(ms.s1), a.s2 = dev_side(ms.s2);
+  a.c0 = ms.c0.dev(), a.c1 = ms.c1.dev();
+  a.x1 = x1, a.x2 = x2, a.ye = ms.d_ye, a.out = out;
+  const size_t shm = sizeof(double) * (size_t)a.stride * kMixWaves;
+  PA_REQUIRE(shm <= 64 * 1024, "element too large for the mixed-space kernels");
+  const dim3 grid((ms.ne + kMixWaves - 1) / kMixWaves), block(64 * kMixWaves);
+  switch (ms.qf) {
+    case PA_QF_HCURLHDIV_33: hipLaunchKernelGGL(mixed_kernel<0>, grid, block, shm, s, a); break;
+    case PA_QF_HDIVHCURL_33: hipLaunchKernelGGL(mixed_kernel<1>, grid, block, shm, s, a); break;
+    case PA_QF_HCURLHDIV_ERROR_33: hipLaunchKernelGGL(mixed_kernel<2>, grid, block, shm, s, a); break;
+    case PA_QF_HDIVHCURL_ERROR_33: hipLaunchKernelGGL(mixed_kernel<3>, grid, block, shm, s, a); break;
+    default: throw Error("not a mixed-space QFunction");
+  }
+  PA_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_dense_basis_desc &b1,
+                         const pa_restriction_desc &r2, const pa_dense_basis_desc &b2, int qf, const void *ctx,
+                         size_t ctx_size) {
+  PA_REQUIRE(geom && geom->eb == kEBm && geom->dim == 3 && geom->sdim == 3,
+             "mixed-space operators need 3-D geometry data from pa_geom_create_dense");
+  PA_REQUIRE(r1.num_elem == geom->ne && r2.num_elem == geom->ne, "restrictions do not match the mesh");
+  const bool err = qf == PA_QF_HCURLHDIV_ERROR_33 || qf == PA_QF_HDIVHCURL_ERROR_33;
+  PA_REQUIRE(err || qf == PA_QF_HCURLHDIV_33 || qf == PA_QF_HDIVHCURL_33, "not a mixed-space QFunction");
+  // first space / second space by the Piola map the QFunction applies to each input
+  const bool curl_first = qf == PA_QF_HCURLHDIV_33 || qf == PA_QF_HCURLHDIV_ERROR_33;
+  PA_REQUIRE(b1.fe_type == (curl_first ? PA_FE_HCURL : PA_FE_HDIV) && b2.fe_type == (curl_first ? PA_FE_HDIV : PA_FE_HCURL),
+             "element types do not match the QFunction (vecfemass.cpp:88-101)");
+  PA_REQUIRE(ctx && ctx_size >= 16 && ctx_size % 8 == 0, "bad coefficient context");
+  auto *ms = new MixedSub;
+  try {
+    ms->geom = geom;
+    geom->refcount++;
+    ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->error = err;
+    build_side(r1, b1, geom->Q, ms->s1);
+    build_side(r2, b2, geom->Q, ms->s2);
+    parse_coeff(ctx, ctx_size, 3, ms->c0, 0);
+    if (err) parse_coeff(ctx, ctx_size, 3, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
+    if (!err) ms->d_ye = dev_alloc<double>((size_t)ms->ne * ms->s2.P);
+  } catch (...) {
+    free_mixed_sub(ms);
+    throw;
+  }
+  return ms;
+}
+
+void free_mixed_sub(MixedSub *ms) {
+  if (!ms) return;
+  free_side(ms->s1), free_side(ms->s2);
+  hipFree(ms->d_ye);
+  hipFree(ms->c0.d_attr_mat), hipFree(ms->c0.d_mat), hipFree(ms->c0.d_mat_t);
+  hipFree(ms->c1.d_attr_mat), hipFree(ms->c1.d_mat), hipFree(ms->c1.d_mat_t);
+  pa_geom_destroy(static_cast<pa_geom *>(ms->geom));
+  delete ms;
+}
+
+void launch_mixed_apply(const MixedSub &ms, const double *x, double *y, bool accumulate, hipStream_t s) {
+  PA_REQUIRE(!ms.error, "error integrators have no apply");
+  launch(ms, x, nullptr, nullptr, s);
+  launch_et_gather_raw(ms.s2.lsize, ms.s2.d_tptr, ms.s2.d_tent, ms.d_ye, y, accumulate, s);
+}
+
+void launch_mixed_error(const MixedSub &ms, const double *u1, const double *u2, double *out, hipStream_t s) {
+  PA_REQUIRE(ms.error, "not an error integrator");
+  launch(ms, u1, u2, out, s);
+}
+
+}  // namespace pa

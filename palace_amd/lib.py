@@ -64,7 +64,7 @@ def load():
     lib.pa_version.restype = C.c_char_p
     lib.pa_op_algorithmic_bytes.restype = C.c_double
     lib.pa_op_algorithmic_bytes.argtypes = [C.c_void_p]
-    for name in ("pa_geom_destroy", "pa_op_destroy"):
+    for name in ("pa_geom_destroy", "pa_op_destroy", "pa_error_op_destroy"):
         getattr(lib, name).restype = None
         getattr(lib, name).argtypes = [C.c_void_p]
     _lib = lib

@@ -51,6 +51,11 @@ def main():
         v = np.zeros((3, Q))
         capi.ref_call("f_apply_hdivhcurl_33", blob, Q, [geom, cu], [v])
         out["hdivhcurl_" + tag] = v
+    # the error QFunctions of the flux estimators (hcurlhdiv_error_33_qf.h): two inputs, pair context, one value per point
+    for name in ("hcurlhdiv_error", "hdivhcurl_error"):
+        w = np.zeros((1, Q))
+        capi.ref_call("f_apply_%s_33" % name, po.pack_pair(ctx_a, ctx_b), Q, [geom, u, cu], [w])
+        out[name] = w[0]
     v, cv = np.zeros((3, Q)), np.zeros((3, Q))
     capi.ref_call("f_apply_hdivmass_33", po.pack_pair(ctx_a, ctx_b), Q, [geom, u, cu], [v, cv])
     out["hdivmass_v"], out["hdivmass_cv"] = v, cv

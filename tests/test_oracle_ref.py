@@ -56,6 +56,19 @@ def test_mixed_hcurl_hdiv_numpy(tag):
     np.testing.assert_allclose(po.apply_hdivhcurl_33(ctx, geom, G["cu"][None])[0], G["hdivhcurl_" + tag], rtol=TOL, atol=TOL)
 
 
+def test_error_qfunctions_numpy():
+    """f_apply_hcurlhdiv_error_33 / f_apply_hdivhcurl_error_33 (hcurlhdiv_error_33_qf.h, the integrands of the flux error
+    estimators) against the vectors of the reference header: pair context (anisotropic first, non-symmetric second)."""
+    c1, n1 = _ctx_from_blob(G["ctx_pair"])
+    c2, _ = _ctx_from_blob(G["ctx_pair"][n1:])
+    geom = G["geom"][None]
+    np.testing.assert_allclose(po.apply_hcurlhdiv_error_33(c1, c2, geom, G["u"][None], G["cu"][None])[0], G["hcurlhdiv_error"],
+                               rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(po.apply_hdivhcurl_error_33(c1, c2, geom, G["u"][None], G["cu"][None])[0], G["hdivhcurl_error"],
+                               rtol=TOL, atol=TOL)
+    assert G["hcurlhdiv_error"].min() > 0 and not np.allclose(G["hcurlhdiv_error"], G["hdivhcurl_error"])
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "id"])
 def test_hcurl_hdiv_c(tag):
     blob = G["ctx_" + tag]
