@@ -1,0 +1,89 @@
+// C++ host example: the flux error estimators of a Palace post-processing step without Python and without MFEM.  From the
+// arrays MFEM would provide for a tetrahedral mesh (see dump_estimator_problem.py) it builds a dense Mesh, the Nedelec and
+// Raviart-Thomas FiniteElementSpaces, MaterialTensors for eps and mu^-1, and runs
+//   GradFluxErrorEstimator::AddErrorIndicator(E), CurlFluxErrorEstimator::AddErrorIndicator(B),
+//   TimeDependentFluxErrorEstimator::AddErrorIndicator(E, B)
+// (linalg/errorestimator.cpp:271-541) into ErrorIndicators; prints the indicator norms, PCG iteration counts and writes
+// the three indicator vectors to a file.
+//   ./estimate problem.bin out.bin
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <vector>
+
+#include "errorestimator.hpp"
+
+using namespace palace;
+
+static std::vector<std::vector<char>> read_blobs(const char *path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) {
+    std::fprintf(stderr, "cannot open %s\n", path);
+    std::exit(2);
+  }
+  int64_t n = 0;
+  f.read(reinterpret_cast<char *>(&n), 8);
+  std::vector<std::vector<char>> out((size_t)n);
+  for (auto &b : out) {
+    int64_t bytes = 0;
+    f.read(reinterpret_cast<char *>(&bytes), 8);
+    b.resize((size_t)bytes);
+    f.read(b.data(), bytes);
+  }
+  return out;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 2;
+  try {
+    auto blobs = read_blobs(argv[1]);
+    auto i32 = [&](size_t i) { return reinterpret_cast<const int32_t *>(blobs[i].data()); };
+    auto f64 = [&](size_t i) { return reinterpret_cast<const double *>(blobs[i].data()); };
+    const int ne = i32(0)[0], npe = i32(0)[1], nq = i32(0)[2], nn = i32(0)[3], p = i32(0)[4], nd_size = i32(0)[5],
+              nd_P = i32(0)[6], rt_size = i32(0)[7], rt_P = i32(0)[8], nd_diag = i32(0)[9];
+    hipStream_t stream;
+    if (hipStreamCreate(&stream) != hipSuccess) throw pa::Error("no HIP device");
+    Context ctx;
+    ctx.stream = stream;
+
+    pa_mesh_dense_desc md{ne, npe, nq, nn, i32(1), f64(2), i32(3), f64(4), f64(5), 3, 0};
+    Mesh mesh(ctx, md);
+    FiniteElementSpace nd(ctx, mesh, PA_FE_HCURL, p, nd_P, nd_size, i32(6),
+                          nd_diag ? reinterpret_cast<const uint8_t *>(blobs[7].data()) : nullptr,
+                          nd_diag ? nullptr : reinterpret_cast<const int8_t *>(blobs[8].data()), f64(9), f64(10));
+    FiniteElementSpace rt(ctx, mesh, PA_FE_HDIV, p, rt_P, rt_size, i32(11), reinterpret_cast<const uint8_t *>(blobs[12].data()),
+                          nullptr, f64(13), nullptr);
+    MaterialTensors eps{{0, 1}, std::vector<double>(f64(14), f64(14) + 18)};
+    MaterialTensors muinv{{0, 1}, std::vector<double>(f64(15), f64(15) + 18)};
+
+    Vector E(nd_size), B(rt_size);
+    hipMemcpy(E.Data(), f64(16), sizeof(double) * nd_size, hipMemcpyHostToDevice);
+    hipMemcpy(B.Data(), f64(17), sizeof(double) * rt_size, hipMemcpyHostToDevice);
+
+    const double tol = 1e-12;
+    GradFluxErrorEstimator grad(eps, nd, rt, tol, 500, 0);
+    CurlFluxErrorEstimator curl(muinv, rt, nd, tol, 500, 0);
+    TimeDependentFluxErrorEstimator both(eps, muinv, nd, rt, tol, 500, 0);
+    ErrorIndicator ig(ctx), ic(ctx), it(ctx);
+    const double Et = 0.37;
+    grad.AddErrorIndicator(E, Et, ig);
+    curl.AddErrorIndicator(B, Et, ic);
+    both.AddErrorIndicator(E, B, Et, it);
+    both.AddErrorIndicator(E, B, 0.0, it);  // a second sample: running root mean square (errorindicator.cpp:11-47)
+    std::printf("elements %d nd %d rt %d\n", ne, nd_size, rt_size);
+    std::printf("grad: norm %.15e pcg_its %d\n", ig.Norml2(), grad.GetProjector().NumIterations());
+    std::printf("curl: norm %.15e pcg_its %d\n", ic.Norml2(), curl.GetProjector().NumIterations());
+    std::printf("both: norm %.15e samples %d\n", it.Norml2(), it.NumSamples());
+    std::vector<double> out((size_t)3 * ne);
+    hipStreamSynchronize(stream);
+    hipMemcpy(out.data(), ig.Local().Data(), sizeof(double) * ne, hipMemcpyDeviceToHost);
+    hipMemcpy(out.data() + ne, ic.Local().Data(), sizeof(double) * ne, hipMemcpyDeviceToHost);
+    hipMemcpy(out.data() + 2 * (size_t)ne, it.Local().Data(), sizeof(double) * ne, hipMemcpyDeviceToHost);
+    std::ofstream(argv[2], std::ios::binary).write(reinterpret_cast<const char *>(out.data()), sizeof(double) * out.size());
+    std::printf("OK\n");
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

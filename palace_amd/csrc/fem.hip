@@ -320,6 +320,10 @@ Mesh::Mesh(const Context &ctx, int num_elem, int mesh_order, int num_nodes, cons
   pa_mesh_desc m{num_elem, mesh_order, q1d, num_nodes, node_offsets, nodes, attr, B.data(), G.data(), qw.data()};
   check(pa_geom_create(&m, ctx.stream, &geom_));
 }
+Mesh::Mesh(const Context &ctx, const pa_mesh_dense_desc &desc)
+    : ne_(desc.num_elem), q1d_(0), mesh_order_(0), nq_dense_(desc.num_qpts) {
+  check(pa_geom_create_dense(&desc, ctx.stream, &geom_));
+}
 Mesh::~Mesh() {
   if (geom_) pa_geom_destroy(geom_);
 }
@@ -344,9 +348,31 @@ FiniteElementSpace::FiniteElementSpace(const Context &ctx, const Mesh &mesh, int
   fem::LagrangeEval(ox, qx, Bo_, Go);
 }
 
+FiniteElementSpace::FiniteElementSpace(const Context &ctx, const Mesh &mesh, int fe_type, int order, int elem_size, int vsize,
+                                       const int32_t *offsets, const uint8_t *orients, const int8_t *curl_orients,
+                                       const double *interp, const double *deriv, int n_true, const Halo *halo)
+    : ctx_(&ctx), mesh_(&mesh), fe_type_(fe_type), order_(order), elem_size_(elem_size), vsize_(vsize),
+      true_vsize_(n_true < 0 ? vsize : n_true), halo_(halo) {
+  PA_REQUIRE(mesh.IsDense(), "a space given by dense tables needs a dense Mesh");
+  PA_REQUIRE(fe_type == PA_FE_HCURL || fe_type == PA_FE_H1 || fe_type == PA_FE_HDIV, "unknown element type");
+  PA_REQUIRE(elem_size > 0 && offsets && (interp || deriv) && !(orients && curl_orients), "invalid finite element space description");
+  const size_t n = (size_t)mesh.GetNE() * elem_size, Q = (size_t)mesh.GetNumQuadraturePoints();
+  offsets_.assign(offsets, offsets + n);
+  if (orients) orients_.assign(orients, orients + n);
+  if (curl_orients) curl_orients_.assign(curl_orients, curl_orients + 3 * n);
+  const size_t qcomp = fe_type == PA_FE_H1 ? 1 : 3;
+  if (interp) interp_.assign(interp, interp + qcomp * Q * elem_size);
+  if (deriv) deriv_.assign(deriv, deriv + 3 * Q * elem_size);
+}
+
 pa_restriction_desc FiniteElementSpace::GetCeedElemRestriction() const {
   return pa_restriction_desc{mesh_->GetNE(), elem_size_, vsize_, offsets_.data(), orients_.empty() ? nullptr : orients_.data(),
-                             nullptr};
+                             curl_orients_.empty() ? nullptr : curl_orients_.data()};
+}
+pa_dense_basis_desc FiniteElementSpace::GetCeedDenseBasis() const {
+  PA_REQUIRE(IsDense(), "the space has no dense tables");
+  return pa_dense_basis_desc{fe_type_, elem_size_, mesh_->GetNumQuadraturePoints(), interp_.empty() ? nullptr : interp_.data(),
+                             deriv_.empty() ? nullptr : deriv_.data()};
 }
 pa_basis_desc FiniteElementSpace::GetCeedBasis() const {
   return pa_basis_desc{fe_type_, order_, mesh_->GetQ1d(), Bc_.data(), Gc_.data(), Bo_.data(),
@@ -406,6 +432,22 @@ std::vector<const Operator *> FiniteElementSpaceHierarchy::GetDiscreteInterpolat
 // ---- integrators ----------------------------------------------------------------------------------------------------
 void BilinearFormIntegrator::AssembleCeedOperator(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test,
                                                   int qf, const std::vector<double> &ctx, int trial_ops, int test_ops) {
+  if (trial.IsDense() || test.IsDense()) {
+    PA_REQUIRE(trial.IsDense() && test.IsDense() && &trial.GetMesh() == &test.GetMesh(), "dense spaces on one dense mesh expected");
+    const auto r = trial.GetCeedElemRestriction();
+    const auto b = trial.GetCeedDenseBasis();
+    if (&trial == &test) {
+      check(pa_op_add_sub_dense(op, trial.GetMesh().GetCeedGeomFactorData(), &r, &b, qf, ctx.data(), ctx.size() * sizeof(double),
+                                trial_ops, test_ops));
+    } else {  // two spaces: the mixed mass forms only (Interp / Interp)
+      PA_REQUIRE(trial_ops == PA_EVAL_INTERP && test_ops == PA_EVAL_INTERP, "mixed-space forms evaluate values on both sides");
+      const auto r2 = test.GetCeedElemRestriction();
+      const auto b2 = test.GetCeedDenseBasis();
+      check(pa_op_add_sub_dense_mixed(op, trial.GetMesh().GetCeedGeomFactorData(), &r, &b, &r2, &b2, qf, ctx.data(),
+                                      ctx.size() * sizeof(double)));
+    }
+    return;
+  }
   PA_REQUIRE(&trial == &test, "square forms only: test and trial space must be the same object");
   const auto r = trial.GetCeedElemRestriction();
   const auto b = trial.GetCeedBasis();
@@ -418,8 +460,12 @@ void MassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const 
                        PA_EVAL_INTERP);
 }
 void VectorFEMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
-  AssembleCeedOperator(op, trial, test, PA_QF_HCURL_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_INTERP,
-                       PA_EVAL_INTERP);
+  // the QFunction follows the map types of the two elements (vecfemass.cpp:75-101)
+  const bool tc = trial.GetFEType() == PA_FE_HCURL, sc = test.GetFEType() == PA_FE_HCURL;
+  PA_REQUIRE((tc || trial.GetFEType() == PA_FE_HDIV) && (sc || test.GetFEType() == PA_FE_HDIV),
+             "Invalid trial/test element map type for VectorFEMassIntegrator!");
+  const int qf = tc ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33) : (sc ? PA_QF_HDIVHCURL_33 : PA_QF_HDIV_33);
+  AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_INTERP, PA_EVAL_INTERP);
 }
 void DiffusionIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   AssembleCeedOperator(op, trial, test, PA_QF_HCURL_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_GRAD,

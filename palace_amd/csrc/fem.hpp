@@ -96,14 +96,19 @@ struct DefaultIntegrationOrder {
 class Mesh {
   pa_geom *geom_ = nullptr;
   int ne_, q1d_, mesh_order_;
+  int nq_dense_ = 0;  // > 0: element block described by dense tables (tetrahedra, ...), that many quadrature points
 
 public:
   // node_offsets [ne][(mesh_order + 1)^3] lattice order, nodes [num_nodes][3], attr [ne] (1-based); the quadrature is
   // the tensor Gauss-Legendre rule with q1d points (fem::DefaultIntegrationOrder::GetQ1d)
   Mesh(const Context &ctx, int num_elem, int mesh_order, int num_nodes, const int32_t *node_offsets, const double *nodes,
        const int32_t *attr, int q1d);
+  // any element type: what AssembleCeedGeometryData gets for a non-tensor block (pa_geom_create_dense)
+  Mesh(const Context &ctx, const pa_mesh_dense_desc &desc);
   Mesh(const Mesh &) = delete;
   ~Mesh();
+  bool IsDense() const { return nq_dense_ > 0; }
+  int GetNumQuadraturePoints() const { return nq_dense_ > 0 ? nq_dense_ : q1d_ * q1d_ * q1d_; }
   pa_geom *GetCeedGeomFactorData() const { return geom_; }
   int GetNE() const { return ne_; }
   int GetQ1d() const { return q1d_; }
@@ -118,6 +123,8 @@ class FiniteElementSpace {
   std::vector<int32_t> offsets_, dof_map_;
   std::vector<uint8_t> orients_;
   std::vector<double> Bc_, Gc_, Bo_;
+  std::vector<int8_t> curl_orients_;     // dense spaces: the tridiagonal dof transformation (ND tetrahedra, p >= 2)
+  std::vector<double> interp_, deriv_;   // dense spaces: [qcomp Q][P] value and [3 Q][P] curl / gradient tables
   std::vector<int32_t> ess_tdofs_;
   const Halo *halo_;
   mutable std::map<const FiniteElementSpace *, std::unique_ptr<Operator>> G_;
@@ -127,6 +134,14 @@ public:
   // dof_map the tensor -> native local ordering (NULL: lexicographic).  n_true < 0: one rank, every dof is a true dof
   FiniteElementSpace(const Context &ctx, const Mesh &mesh, int fe_type, int order, int vsize, const int32_t *offsets,
                      const uint8_t *orients, const int32_t *dof_map, int n_true = -1, const Halo *halo = nullptr);
+  // The same for a space given by dense tables on a dense Mesh (fem/libceed/basis.cpp:40-85, restriction.cpp:207-385):
+  // fe_type PA_FE_HCURL | PA_FE_H1 | PA_FE_HDIV, elem_size dofs per element, interp [qcomp Q][P], deriv [3 Q][P] or NULL,
+  // orients or curl_orients [ne][P][3] (not both)
+  FiniteElementSpace(const Context &ctx, const Mesh &mesh, int fe_type, int order, int elem_size, int vsize,
+                     const int32_t *offsets, const uint8_t *orients, const int8_t *curl_orients, const double *interp,
+                     const double *deriv, int n_true = -1, const Halo *halo = nullptr);
+  bool IsDense() const { return !interp_.empty() || !deriv_.empty(); }
+  pa_dense_basis_desc GetCeedDenseBasis() const;
   const Context &GetContext() const { return *ctx_; }
   const Mesh &GetMesh() const { return *mesh_; }
   int GetFEType() const { return fe_type_; }
@@ -189,7 +204,7 @@ public:
     void Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const override; \
   }
 PA_DECLARE_INTEGRATOR(MassIntegrator);          // H1, (Q u, v)                      fem/integ/mass.cpp
-PA_DECLARE_INTEGRATOR(VectorFEMassIntegrator);  // H(curl), (Q u, v)                 fem/integ/vecfemass.cpp
+PA_DECLARE_INTEGRATOR(VectorFEMassIntegrator);  // H(curl) / H(div) and the two mixed pairs, (Q u, v)   fem/integ/vecfemass.cpp
 PA_DECLARE_INTEGRATOR(DiffusionIntegrator);     // H1, (Q grad u, grad v)            fem/integ/diffusion.cpp
 PA_DECLARE_INTEGRATOR(CurlCurlIntegrator);      // H(curl), (Q curl u, curl v)       fem/integ/curlcurl.cpp:23-75
 PA_DECLARE_INTEGRATOR(MixedVectorCurlIntegrator);      // H(curl) x H(curl), (Q curl u, v)   fem/integ/mixedveccurl.cpp:21-73

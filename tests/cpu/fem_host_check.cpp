@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "errorestimator.hpp"
 #include "ksp.hpp"
 
 using namespace palace;
@@ -63,5 +64,17 @@ int main() {
   }
   fem::DefaultIntegrationOrder::p_trial = 3;
   std::printf("q1d %d\n", fem::DefaultIntegrationOrder::GetQ1d(5));
+  {  // linalg::MatrixSqrt / MatrixPow on the material tensors of the estimators (densematrix.cpp:222-252)
+    const double S[9] = {2.0, 0.3, 0.0, 0.3, 1.5, 0.1, 0.0, 0.1, 1.2};
+    const auto r = linalg::MatrixSqrt(S), ir = linalg::MatrixPow(S, -0.5);
+    dump("mat_sqrt", std::vector<double>(r.begin(), r.end()));
+    dump("mat_invsqrt", std::vector<double>(ir.begin(), ir.end()));
+    const double D[9] = {4.0, 0, 0, 0, 9.0, 0, 0, 0, 0.25};  // already diagonal, and a repeated eigenvalue
+    const auto rd = linalg::MatrixSqrt(D);
+    dump("mat_sqrt_diag", std::vector<double>(rd.begin(), rd.end()));
+    const double R[9] = {3.0, 1.0, 0, 1.0, 3.0, 0, 0, 0, 2.0};  // eigenvalues 2, 2, 4
+    const auto rr = linalg::MatrixPow(R, 2.0);
+    dump("mat_square", std::vector<double>(rr.begin(), rr.end()));
+  }
   return 0;
 }

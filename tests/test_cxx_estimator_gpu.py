@@ -1,0 +1,84 @@
+"""The C++ flux error estimators (palace_amd/csrc/errorestimator.hpp: FluxProjector, GradFluxErrorEstimator,
+CurlFluxErrorEstimator, TimeDependentFluxErrorEstimator, ErrorIndicator -- linalg/errorestimator.cpp:111-541,
+fem/errorindicator.cpp:11-47) used from a C++ program on dense-table tetrahedral spaces: build examples/cxx_host/estimate.cpp
+with hipcc, run it on a dumped problem and compare the element indicators with the same procedure carried out with the
+oracle's operators and dense solves."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import palace_oracle as po
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples", "cxx_host"))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    d = tmp_path_factory.mktemp("cxx_est")
+    out = str(d / "estimate")
+    libdir = os.path.join(ROOT, "palace_amd", "lib")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O2", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cxx_host", "estimate.cpp"),
+                           "-L" + libdir, "-lpalace_amd", "-Wl,-rpath," + libdir, "-o", out])
+    return out, d
+
+
+def _sym_fun(M, f):
+    w, V = np.linalg.eigh(M)
+    return (V * f(w)) @ V.T
+
+
+def _oracle_indicators(P, Et):
+    m, nd, sp = P["mesh"], P["nd"], P["rt"]
+    J = m.jacobians(P["pts"])
+    og = po.build_geom_factor_33(m.attr.astype(np.float64), P["wts"], np.transpose(J, (0, 1, 3, 2)).reshape(m.ne, -1, 9))
+    cid = po.CoeffCtx()
+    kw = dict(curl_orients=nd.curl_orients) if not nd.diagonal_transform else {}
+    ndo = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients if nd.diagonal_transform else None, P["nint"], P["ncurl"], og,
+                                po.QF_HCURL, cid, **kw)
+    rto = po.CeedOperatorOracle(sp.ndofs, sp.offsets, sp.orients, P["rint"], P["rint"], og, po.QF_HDIV, cid)
+    Mn = np.stack([ndo.apply_add(e, np.zeros(ndo.lsize)) for e in np.eye(ndo.lsize)], axis=1)
+    Mr = np.stack([rto.apply_add(e, np.zeros(rto.lsize)) for e in np.eye(rto.lsize)], axis=1)
+
+    def ctx(mats):
+        return po.CoeffCtx(attr_mat=[0, 1], mat_coeff=list(mats))
+
+    eps, mui = P["eps"], P["muinv"]
+    D = np.linalg.solve(Mr, po.MixedSpaceOracle(ndo, rto, og, po.QF_HCURLHDIV, ctx(eps)).apply_add(P["E"], np.zeros(rto.lsize)))
+    eg = po.MixedSpaceOracle(ndo, rto, og, po.QF_HCURLHDIV_ERROR, ctx([_sym_fun(e, np.sqrt) for e in eps]),
+                             ctx([_sym_fun(e, lambda w: w ** -0.5) for e in eps])).error_add(P["E"], D, np.zeros(m.ne))
+    H = np.linalg.solve(Mn, po.MixedSpaceOracle(rto, ndo, og, po.QF_HDIVHCURL, ctx(mui)).apply_add(P["B"], np.zeros(ndo.lsize)))
+    ec = po.MixedSpaceOracle(rto, ndo, og, po.QF_HDIVHCURL_ERROR, ctx([_sym_fun(e, np.sqrt) for e in mui]),
+                             ctx([_sym_fun(e, lambda w: w ** -0.5) for e in mui])).error_add(P["B"], H, np.zeros(m.ne))
+    s1, s2 = np.sqrt((eg + ec) * 0.5 / Et), np.sqrt(eg + ec)
+    return np.sqrt(eg * 0.5 / Et), np.sqrt(ec * 0.5 / Et), np.sqrt((s1 ** 2 + s2 ** 2) / 2)
+
+
+@pytest.mark.parametrize("curved", [0, 1])
+def test_cxx_flux_error_estimators(exe, curved):
+    import dump_estimator_problem as dp
+
+    binary, d = exe
+    blob, out = str(d / f"problem{curved}.bin"), str(d / f"ind{curved}.bin")
+    dp.main(blob, 2, 2, curved)
+    r = subprocess.run([binary, blob, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    P = dp.problem(2, 2, curved)
+    ne = P["mesh"].ne
+    got = np.fromfile(out, dtype=np.float64).reshape(3, ne)
+    ref = _oracle_indicators(P, 0.37)
+    for g, e, name in zip(got, ref, ("grad", "curl", "time-dependent")):
+        assert e.min() > 0
+        assert np.abs(g - e).max() < 1e-8 * e.max(), (name, np.abs(g - e).max(), e.max())
+    norms = [float(l.split()[2]) for l in r.stdout.splitlines() if "norm" in l]
+    for n, e in zip(norms, ref):
+        assert abs(n - np.linalg.norm(e)) < 1e-8 * np.linalg.norm(e)

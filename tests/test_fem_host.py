@@ -84,3 +84,15 @@ def test_coarsening_sequences_and_quadrature(dumped):
         assert dumped[f"orders_log{p}"] == levels_for(p)
         assert dumped[f"orders_lin{p}"] == list(range(1, p + 1))
     assert dumped["q1d"] == [4]  # order-3 solution: 2p = 6 -> 4 Gauss-Legendre points per direction
+
+
+def test_matrix_functions(dumped):
+    """MatrixSqrt / MatrixPow (linalg/densematrix.cpp:222-252) as the flux estimators use them on symmetric material tensors."""
+    S = np.array([[2.0, 0.3, 0.0], [0.3, 1.5, 0.1], [0.0, 0.1, 1.2]])
+    w, V = np.linalg.eigh(S)
+    assert np.allclose(dumped["mat_sqrt"].reshape(3, 3), (V * np.sqrt(w)) @ V.T, rtol=0, atol=1e-14)
+    assert np.allclose(dumped["mat_invsqrt"].reshape(3, 3), (V / np.sqrt(w)) @ V.T, rtol=0, atol=1e-14)
+    assert np.allclose(dumped["mat_sqrt"].reshape(3, 3) @ dumped["mat_sqrt"].reshape(3, 3), S, rtol=0, atol=1e-14)
+    assert np.allclose(dumped["mat_sqrt_diag"].reshape(3, 3), np.diag([2.0, 3.0, 0.5]), rtol=0, atol=1e-15)
+    R = np.array([[3.0, 1.0, 0], [1.0, 3.0, 0], [0, 0, 2.0]])
+    assert np.allclose(dumped["mat_square"].reshape(3, 3), R @ R, rtol=0, atol=1e-13)
