@@ -61,7 +61,14 @@ enum pa_qfunction {
                              pa_op_add_sub_dense_mixed */
   /* element error integrators (pa_error_op_create), two inputs with the Piola maps of their spaces */
   PA_QF_HCURLHDIV_ERROR_33 = 11, /* f_apply_hcurlhdiv_error_33 fem/qfunctions/33/hcurlhdiv_error_33_qf.h:10-43 */
-  PA_QF_HDIVHCURL_ERROR_33 = 12  /* f_apply_hdivhcurl_error_33 fem/qfunctions/33/hcurlhdiv_error_33_qf.h:45-78 */
+  PA_QF_HDIVHCURL_ERROR_33 = 12, /* f_apply_hdivhcurl_error_33 fem/qfunctions/33/hcurlhdiv_error_33_qf.h:45-78 */
+  /* the remaining 2-D and boundary-element (2-D elements in 3-D space) forms, dense tables; the boundary ones on geometry
+   * data with space_dim = 3.  On boundary elements PA_QF_L2_1 (surface curl-curl) and PA_QF_H1_1 (H1 mass) are the same
+   * QFunctions as in the plane: they only read w detJ */
+  PA_QF_HDIVMASS_32 = 13,  /* f_apply_hdivmass_32  fem/qfunctions/32/hdivmass_32_qf.h   ND boundary curl-curl + mass */
+  PA_QF_HCURLMASS_22 = 14, /* f_apply_hcurlmass_22 fem/qfunctions/22/hcurlmass_22_qf.h  2-D H1 diffusion + mass */
+  PA_QF_HCURLMASS_32 = 15  /* f_apply_hcurlmass_32 fem/qfunctions/32/hcurlmass_32_qf.h  H1 boundary diffusion + mass;
+                              H1 diffusion alone: PA_QF_HCURL_22 / PA_QF_HCURL_32 with EVAL_GRAD (fem/integ/diffusion.cpp) */
 };
 
 enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1, PA_FE_HDIV = 2 /* dense path only: RT mass (Interp + hdiv_33) */ };

@@ -462,6 +462,24 @@ def apply_hcurl_32(ctx, geom, u):
                      wdetJ * (A[3] * z[0] + A[4] * z[1] + A[5] * z[2])], axis=1)
 
 
+def apply_hdivmass_32(ctx_mass, ctx_curl, geom, qw, u, curlu):
+    """hdivmass_32_qf.h:11-42: ND mass on a boundary element (3x3 material, first context) + the scalar surface curl-curl
+    c qw^2 / (w detJ) (second context, dim 1)."""
+    return apply_hcurl_32(ctx_mass, geom, u), apply_l2_1(ctx_curl, geom, qw, curlu)
+
+
+def apply_hcurlmass_22(ctx_mass, ctx, geom, u, gradu):
+    """hcurlmass_22_qf.h:13-38: H1 mass c w detJ u (first context, dim 1) + diffusion on grad u (second, 2x2)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    return (_unpack1(ctx_mass, attr) * geom[:, 1, :])[:, None, :] * u, apply_hcurl_22(ctx, geom, gradu)
+
+
+def apply_hcurlmass_32(ctx_mass, ctx, geom, u, gradu):
+    """hcurlmass_32_qf.h:11-38: the same on a boundary element (3x3 material for the diffusion part)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    return (_unpack1(ctx_mass, attr) * geom[:, 1, :])[:, None, :] * u, apply_hcurl_32(ctx, geom, gradu)
+
+
 # ---------------------------------------------------------------------------------------------
 # Operator: E, B, D, B^T, E^T
 # ---------------------------------------------------------------------------------------------
@@ -469,6 +487,7 @@ def apply_hcurl_32(ctx, geom, u):
 QF_HCURL_32 = "hcurl_32"
 QF_HDIV, QF_HCURL, QF_HDIVMASS, QF_HCURLMASS, QF_H1MASS = "hdiv_33", "hcurl_33", "hdivmass_33", "hcurlmass_33", "h1_1"
 QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22 = "hcurl_22", "l2_1", "hdivmass_22"
+QF_HDIVMASS_32, QF_HCURLMASS_22, QF_HCURLMASS_32 = "hdivmass_32", "hcurlmass_22", "hcurlmass_32"
 QF_HCURLHDIV_ERROR, QF_HDIVHCURL_ERROR = "hcurlhdiv_error_33", "hdivhcurl_error_33"
 QF_HCURLHDIV, QF_HDIVHCURL = "hcurlhdiv_33", "hdivhcurl_33"  # weak curl (Interp -> Curl), mixed curl (Curl -> Interp)
 
@@ -529,6 +548,19 @@ class CeedOperatorOracle:
         if qf == QF_L2_1:      # 2-D curl-curl
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
             return np.einsum("dqj,edq->ej", self.deriv, apply_l2_1(self.ctx, geom, self.qw, cu))
+        if qf == QF_HCURL_32 and not self.vector_fe:  # H1 diffusion on boundary elements (integ/diffusion.cpp, case 32)
+            gu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            return np.einsum("dqj,edq->ej", self.deriv, apply_hcurl_32(self.ctx, geom, gu))
+        if qf in (QF_HCURLMASS_22, QF_HCURLMASS_32):  # 2-D / boundary H1 diffusion + mass: scalar mass context first
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            gu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            v, gv = (apply_hcurlmass_22 if qf == QF_HCURLMASS_22 else apply_hcurlmass_32)(self.ctx, self.ctx2, geom, u, gu)
+            return np.einsum("dqj,edq->ej", self.interp, v) + np.einsum("dqj,edq->ej", self.deriv, gv)
+        if qf == QF_HDIVMASS_32:  # ND boundary curl-curl + mass (integ/curlcurlmass.cpp, case 32)
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            cu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            v, cv = apply_hdivmass_32(self.ctx, self.ctx2, geom, self.qw, u, cu)
+            return np.einsum("dqj,edq->ej", self.interp, v) + np.einsum("dqj,edq->ej", self.deriv, cv)
         if qf == QF_HCURL_32:  # boundary ND mass (surface impedance / absorbing / lumped-port terms)
             u = np.einsum("dqj,ej->edq", self.interp, ue)
             return np.einsum("dqj,edq->ej", self.interp, apply_hcurl_32(self.ctx, geom, u))

@@ -19,6 +19,9 @@ typedef double CeedScalar;
 #include "fem/qfunctions/22/geom_22_qf.h"
 #include "fem/qfunctions/22/hcurl_22_qf.h"
 #include "fem/qfunctions/22/hdivmass_22_qf.h"
+#include "fem/qfunctions/22/hcurlmass_22_qf.h"
 #include "fem/qfunctions/1/l2_1_qf.h"
 #include "fem/qfunctions/32/geom_32_qf.h"
 #include "fem/qfunctions/32/hcurl_32_qf.h"
+#include "fem/qfunctions/32/hdivmass_32_qf.h"
+#include "fem/qfunctions/32/hcurlmass_32_qf.h"

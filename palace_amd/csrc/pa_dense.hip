@@ -48,29 +48,36 @@ enum DenseMode {
   // 2-D (fast path only: tables resident in LDS + packed D)
   MODE_CURL2 = 6,     // 2-D ND curl-curl          f_apply_l2_1 on the scalar curl (q_w input)
   MODE_VMASS2 = 7,    // 2-D ND mass               f_apply_hcurl_22
-  MODE_CURLMASS2 = 8  // 2-D ND curl-curl + mass   f_apply_hdivmass_22
+  MODE_CURLMASS2 = 8, // 2-D ND curl-curl + mass   f_apply_hdivmass_22 / _32
+  MODE_DIFF2 = 9,     // 2-D H1 diffusion          f_apply_hcurl_22 / _32 on grad u
+  MODE_DIFFMASS2 = 10 // 2-D H1 diffusion + mass   f_apply_hcurlmass_22 / _32
+  // (MODE_MASS serves the 2-D H1 mass too: f_apply_h1_1 only reads w detJ)
 };
 
 template <int MODE>
 struct ModeTraits {
   static constexpr int NCI = (MODE == MODE_VMASS || MODE == MODE_CURLMASS) ? 3
                              : (MODE == MODE_VMASS2 || MODE == MODE_CURLMASS2) ? 2
-                             : (MODE == MODE_DIFFMASS || MODE == MODE_MASS) ? 1 : 0;
+                             : (MODE == MODE_DIFFMASS || MODE == MODE_MASS || MODE == MODE_DIFFMASS2) ? 1 : 0;
   static constexpr int NCD = (MODE == MODE_VMASS || MODE == MODE_MASS || MODE == MODE_VMASS2) ? 0
-                             : (MODE == MODE_CURL2 || MODE == MODE_CURLMASS2) ? 1 : 3;
+                             : (MODE == MODE_CURL2 || MODE == MODE_CURLMASS2) ? 1
+                             : (MODE == MODE_DIFF2 || MODE == MODE_DIFFMASS2) ? 2 : 3;
   static constexpr int NCT = NCI + NCD;
 };
 
 int mode_of(int fe_type, int qf, int dim, int sdim) {
-  if (dim == 2 && sdim == 3) {
-    if (fe_type == PA_FE_HCURL && qf == PA_QF_HCURL_32) return MODE_VMASS2;  // same apply, D from the 3x2 geometry
-    throw Error("QFunction does not match an H(curl) boundary element");
-  }
-  if (dim == 2) {
-    if (fe_type == PA_FE_HCURL && qf == PA_QF_L2_1) return MODE_CURL2;
-    if (fe_type == PA_FE_HCURL && qf == PA_QF_HCURL_22) return MODE_VMASS2;
-    if (fe_type == PA_FE_HCURL && qf == PA_QF_HDIVMASS_22) return MODE_CURLMASS2;
-    throw Error("QFunction does not match a 2-D H(curl) element");
+  if (dim == 2) {  // the same applies for plane elements and for boundary elements in 3-D: only D differs (3x2 geometry)
+    const bool bdr = sdim == 3;
+    if (fe_type == PA_FE_HCURL) {
+      if (qf == PA_QF_L2_1) return MODE_CURL2;
+      if (qf == (bdr ? PA_QF_HCURL_32 : PA_QF_HCURL_22)) return MODE_VMASS2;
+      if (qf == (bdr ? PA_QF_HDIVMASS_32 : PA_QF_HDIVMASS_22)) return MODE_CURLMASS2;
+      throw Error(bdr ? "QFunction does not match an H(curl) boundary element" : "QFunction does not match a 2-D H(curl) element");
+    }
+    if (qf == PA_QF_H1_1) return MODE_MASS;
+    if (qf == (bdr ? PA_QF_HCURL_32 : PA_QF_HCURL_22)) return MODE_DIFF2;
+    if (qf == (bdr ? PA_QF_HCURLMASS_32 : PA_QF_HCURLMASS_22)) return MODE_DIFFMASS2;
+    throw Error(bdr ? "QFunction does not match an H1 boundary element" : "QFunction does not match a 2-D H1 element");
   }
   if (fe_type == PA_FE_HCURL) {
     if (qf == PA_QF_HDIV_33) return MODE_CURL;
@@ -87,9 +94,10 @@ int mode_of(int fe_type, int qf, int dim, int sdim) {
 void mode_comps(int mode, int &nci, int &ncd) {
   nci = (mode == MODE_VMASS || mode == MODE_CURLMASS) ? 3
         : (mode == MODE_VMASS2 || mode == MODE_CURLMASS2) ? 2
-        : (mode == MODE_DIFFMASS || mode == MODE_MASS) ? 1 : 0;
+        : (mode == MODE_DIFFMASS || mode == MODE_MASS || mode == MODE_DIFFMASS2) ? 1 : 0;
   ncd = (mode == MODE_VMASS || mode == MODE_MASS || mode == MODE_VMASS2) ? 0
-        : (mode == MODE_CURL2 || mode == MODE_CURLMASS2) ? 1 : 3;
+        : (mode == MODE_CURL2 || mode == MODE_CURLMASS2) ? 1
+        : (mode == MODE_DIFF2 || mode == MODE_DIFFMASS2) ? 2 : 3;
 }
 
 struct DenseArgs {
@@ -717,34 +725,58 @@ __global__ void dense_qdata_kernel(const DenseArgs a, double *__restrict__ qd) {
   if (F0::NF == 2) field(std::integral_constant<int, 1>{});
 }
 
-// 2-D: packed D from the 6-row geometry data {attr, w detJ, adj(J)^T/detJ} and the quadrature weights
-// (hcurl_22_qf.h:10-30 -> symmetric 2x2 {00, 01, 11};  l2_1_qf.h:10-24 -> the scalar c qw^2 / (w detJ))
-template <int MODE>
+// 2-D elements, in the plane (6-row geometry data {attr, w detJ, adj(J)^T/detJ 2x2}, 2x2 materials) or on the boundary of a 3-D
+// mesh (BDR: 8 rows with the 3x2 adj(J)^T/detJ, 3x3 materials): packed D per field in the order {values, derivatives} --
+//   symmetric 2x2 {00, 01, 11} = w detJ A^T C A    hcurl_22_qf.h:10-30, hcurl_32_qf.h:10-30 (ND mass, H1 diffusion)
+//   c qw^2 / (w detJ)                              l2_1_qf.h:10-24, second half of hdivmass_22 / _32 (scalar curl)
+//   c w detJ                                       h1_1_qf.h, first half of hcurlmass_22 / _32 (H1 mass)
+template <int MODE, bool BDR>
 __global__ void dense_qdata2_kernel(const DenseArgs a, double *__restrict__ qd) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int e = (int)(gid / a.Q);
   if (e >= a.ne) return;
   const int q = (int)(gid - (long long)e * a.Q);
+  constexpr int NROWS = BDR ? 8 : 6;
   const size_t cs = (size_t)a.Qpad * kEB, os = (size_t)a.Q4 * kEB;
-  const double *g = a.geom + ((size_t)(e / kEB) * 6 * a.Qpad + q) * kEB + (e % kEB);
+  const double *g = a.geom + ((size_t)(e / kEB) * NROWS * a.Qpad + q) * kEB + (e % kEB);
   double *out = qd + ((size_t)(e / kEB) * a.ncq * a.Q4 + q) * kEB + (e % kEB);
   const int attr = (int)g[0];
   const double wdetJ = g[cs];
-  const double A[4] = {g[2 * cs], g[3 * cs], g[4 * cs], g[5 * cs]};
   int o = 0;
-  if (MODE == MODE_VMASS2 || MODE == MODE_CURLMASS2) {
-    const double *C = a.c0.mat + 4 * coeff_index(a.c0, attr);  // CoeffUnpack2, column-major
+  auto block22 = [&](const CoeffDev &cc) {
     double Mx[4];
-    for (int col = 0; col < 2; col++) {  // MultAtBCx22(adjJt, coeff, adjJt, e_col) * wdetJ (utils_22_qf.h)
-      const double x0 = col == 0 ? 1.0 : 0.0, x1 = col == 1 ? 1.0 : 0.0;
-      const double y0 = A[0] * x0 + A[2] * x1, y1 = A[1] * x0 + A[3] * x1;
-      const double z0 = C[0] * y0 + C[2] * y1, z1 = C[1] * y0 + C[3] * y1;
-      Mx[0 + 2 * col] = wdetJ * (A[0] * z0 + A[1] * z1);
-      Mx[1 + 2 * col] = wdetJ * (A[2] * z0 + A[3] * z1);
+    if (BDR) {  // MultAtBCx32(adjJt, coeff, adjJt, e_col) * wdetJ (utils_32_qf.h:53-72)
+      double A[6], C[9];
+      for (int k = 0; k < 6; k++) A[k] = g[(2 + k) * cs];
+      coeff_unpack3(cc, attr, C);
+      for (int col = 0; col < 2; col++) {
+        const double x0 = col == 0 ? 1.0 : 0.0, x1 = col == 1 ? 1.0 : 0.0;
+        const double y0 = A[0] * x0 + A[3] * x1, y1 = A[1] * x0 + A[4] * x1, t = A[2] * x0 + A[5] * x1;
+        const double z0 = C[0] * y0 + C[3] * y1 + C[6] * t, z1 = C[1] * y0 + C[4] * y1 + C[7] * t,
+                     z2 = C[2] * y0 + C[5] * y1 + C[8] * t;
+        Mx[0 + 2 * col] = wdetJ * (A[0] * z0 + A[1] * z1 + A[2] * z2);
+        Mx[1 + 2 * col] = wdetJ * (A[3] * z0 + A[4] * z1 + A[5] * z2);
+      }
+    } else {  // MultAtBCx22 (utils_22_qf.h)
+      const double A[4] = {g[2 * cs], g[3 * cs], g[4 * cs], g[5 * cs]};
+      const double *C = cc.mat + 4 * coeff_index(cc, attr);  // CoeffUnpack2, column-major
+      for (int col = 0; col < 2; col++) {
+        const double x0 = col == 0 ? 1.0 : 0.0, x1 = col == 1 ? 1.0 : 0.0;
+        const double y0 = A[0] * x0 + A[2] * x1, y1 = A[1] * x0 + A[3] * x1;
+        const double z0 = C[0] * y0 + C[2] * y1, z1 = C[1] * y0 + C[3] * y1;
+        Mx[0 + 2 * col] = wdetJ * (A[0] * z0 + A[1] * z1);
+        Mx[1 + 2 * col] = wdetJ * (A[2] * z0 + A[3] * z1);
+      }
     }
-    out[0] = Mx[0], out[os] = 0.5 * (Mx[1] + Mx[2]), out[2 * os] = Mx[3];
-    o = 3;
+    out[o * os] = Mx[0], out[(o + 1) * os] = 0.5 * (Mx[1] + Mx[2]), out[(o + 2) * os] = Mx[3];
+    o += 3;
+  };
+  if (MODE == MODE_MASS || MODE == MODE_DIFFMASS2) {  // values of a scalar field first
+    out[o * os] = a.c0.mat[coeff_index(a.c0, attr)] * wdetJ;
+    o += 1;
   }
+  if (MODE == MODE_VMASS2 || MODE == MODE_CURLMASS2 || MODE == MODE_DIFF2) block22(a.c0);
+  if (MODE == MODE_DIFFMASS2) block22(a.c1);
   if (MODE == MODE_CURL2 || MODE == MODE_CURLMASS2) {
     const CoeffDev &cc = (MODE == MODE_CURL2) ? a.c0 : a.c1;
     const double w = a.qw[q];
@@ -820,6 +852,8 @@ void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
     PA_RES_CASE(MODE_CURL2)
     PA_RES_CASE(MODE_VMASS2)
     PA_RES_CASE(MODE_CURLMASS2)
+    PA_RES_CASE(MODE_DIFF2)
+    PA_RES_CASE(MODE_DIFFMASS2)
 #undef PA_RES_CASE
   }
 }
@@ -940,32 +974,6 @@ __global__ void geom_dense32_kernel(const int ne, const int Q, const int Qpad, c
     g[(2 + k) * cs] = (G * J[k] - F * J[3 + k]) / d / d;
     g[(5 + k) * cs] = (E * J[3 + k] - F * J[k]) / d / d;
   }
-}
-
-// packed 2x2 D of the boundary mass: w detJ A^T C A with A = adjJt (3x2), C 3x3 (hcurl_32_qf.h:10-30,
-// MultAtBCx32 utils_32_qf.h:53-72)
-__global__ void dense_qdata32_kernel(const DenseArgs a, double *__restrict__ qd) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int e = (int)(gid / a.Q);
-  if (e >= a.ne) return;
-  const int q = (int)(gid - (long long)e * a.Q);
-  const size_t cs = (size_t)a.Qpad * kEB, os = (size_t)a.Q4 * kEB;
-  const double *g = a.geom + ((size_t)(e / kEB) * 8 * a.Qpad + q) * kEB + (e % kEB);
-  double *out = qd + ((size_t)(e / kEB) * a.ncq * a.Q4 + q) * kEB + (e % kEB);
-  const int attr = (int)g[0];
-  const double wdetJ = g[cs];
-  double A[6], C[9], Mx[4];
-  for (int k = 0; k < 6; k++) A[k] = g[(2 + k) * cs];
-  coeff_unpack3(a.c0, attr, C);
-  for (int col = 0; col < 2; col++) {
-    const double x0 = col == 0 ? 1.0 : 0.0, x1 = col == 1 ? 1.0 : 0.0;
-    const double y0 = A[0] * x0 + A[3] * x1, y1 = A[1] * x0 + A[4] * x1, t = A[2] * x0 + A[5] * x1;
-    const double z0 = C[0] * y0 + C[3] * y1 + C[6] * t, z1 = C[1] * y0 + C[4] * y1 + C[7] * t,
-                 z2 = C[2] * y0 + C[5] * y1 + C[8] * t;
-    Mx[0 + 2 * col] = wdetJ * (A[0] * z0 + A[1] * z1 + A[2] * z2);
-    Mx[1 + 2 * col] = wdetJ * (A[3] * z0 + A[4] * z1 + A[5] * z2);
-  }
-  out[0] = Mx[0], out[os] = 0.5 * (Mx[1] + Mx[2]), out[2 * os] = Mx[3];
 }
 
 // ---- diagonal (set-up): one thread per (element, local dof) --------------------------------------
@@ -1250,11 +1258,16 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       parse_coeff(ctx, ctx_size, 1, ds->c0, 0);
       break;
     case MODE_VMASS2:
+    case MODE_DIFF2:
       parse_coeff(ctx, ctx_size, sdim == 3 ? 3 : 2, ds->c0, 0);  // boundary elements take the 3x3 material
       break;
     case MODE_CURLMASS2:
-      parse_coeff(ctx, ctx_size, 2, ds->c0, 0);
+      parse_coeff(ctx, ctx_size, sdim == 3 ? 3 : 2, ds->c0, 0);
       parse_coeff(ctx, ctx_size, 1, ds->c1, ds->c0.slots);
+      break;
+    case MODE_DIFFMASS2:
+      parse_coeff(ctx, ctx_size, 1, ds->c0, 0);
+      parse_coeff(ctx, ctx_size, sdim == 3 ? 3 : 2, ds->c1, ds->c0.slots);
       break;
   }
 
@@ -1291,7 +1304,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
         }
       ds->d_L = dev_upload(L.data(), L.size());
       ds->L_rows = rows;
-      ds->ncq = (nci == 3 ? 6 : (nci == 2 ? 3 : nci)) + (ncd == 3 ? 6 : ncd);
+      ds->ncq = (nci == 3 ? 6 : (nci == 2 ? 3 : nci)) + (ncd == 3 ? 6 : (ncd == 2 ? 3 : ncd));
       const size_t nq = (size_t)nb * ds->ncq * ((Q + 3) / 4 * 4) * kEB;
       ds->d_qdata = dev_alloc<double>(nq);
       PA_HIP(hipMemset(ds->d_qdata, 0, sizeof(double) * nq));
@@ -1303,8 +1316,23 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       DenseArgs a = make_args(*ds);
       const long long n = (long long)ne * Q;
       const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-      if (dim == 2 && sdim == 3) {
-        hipLaunchKernelGGL(dense_qdata32_kernel, grid, block, 0, nullptr, a, ds->d_qdata);
+      if (dim == 2) {
+        switch (mode) {
+#define PA_QD2_CASE(MODE)                                                                              \
+  case MODE:                                                                                           \
+    if (sdim == 3)                                                                                     \
+      hipLaunchKernelGGL((dense_qdata2_kernel<MODE, true>), grid, block, 0, nullptr, a, ds->d_qdata);  \
+    else                                                                                               \
+      hipLaunchKernelGGL((dense_qdata2_kernel<MODE, false>), grid, block, 0, nullptr, a, ds->d_qdata); \
+    break;
+          PA_QD2_CASE(MODE_CURL2)
+          PA_QD2_CASE(MODE_VMASS2)
+          PA_QD2_CASE(MODE_CURLMASS2)
+          PA_QD2_CASE(MODE_MASS)
+          PA_QD2_CASE(MODE_DIFF2)
+          PA_QD2_CASE(MODE_DIFFMASS2)
+#undef PA_QD2_CASE
+        }
       } else
       switch (mode) {
 #define PA_QD_CASE(MODE) \
@@ -1316,12 +1344,6 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
         PA_QD_CASE(MODE_DIFFMASS)
         PA_QD_CASE(MODE_MASS)
 #undef PA_QD_CASE
-#define PA_QD2_CASE(MODE) \
-  case MODE: hipLaunchKernelGGL((dense_qdata2_kernel<MODE>), grid, block, 0, nullptr, a, ds->d_qdata); break;
-        PA_QD2_CASE(MODE_CURL2)
-        PA_QD2_CASE(MODE_VMASS2)
-        PA_QD2_CASE(MODE_CURLMASS2)
-#undef PA_QD2_CASE
       }
       PA_HIP(hipGetLastError());
       PA_HIP(hipStreamSynchronize(nullptr));
@@ -1417,7 +1439,7 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
   const long long n = (long long)ds.ne * ds.P;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   double *diag = dev_alloc<double>((size_t)n);  // element diagonals [ne][P] (set-up path: allocated per call)
-  switch (ds.mode) {
+  if (ds.geom->dim == 3) switch (ds.mode) {
 #define PA_DIAG_CASE(MODE)                                                                                   \
   case MODE:                                                                                                 \
     hipLaunchKernelGGL((dense_diag_kernel<MODE>), grid, block, 0, s, a, ds.d_off, ds.d_cor, ds.d_interp, ds.d_deriv, \
@@ -1430,6 +1452,9 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
     PA_DIAG_CASE(MODE_DIFFMASS)
     PA_DIAG_CASE(MODE_MASS)
 #undef PA_DIAG_CASE
+    default: break;
+  }
+  else switch (ds.mode) {  // 2-D blocks have q-data only
 #define PA_DIAG2_CASE(MODE)                                                                                     \
   case MODE:                                                                                                    \
     hipLaunchKernelGGL((dense_diag_qd_kernel<MODE>), grid, block, 0, s, a, ds.d_off, ds.d_cor, ds.d_interp, ds.d_deriv, \
@@ -1438,7 +1463,11 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
     PA_DIAG2_CASE(MODE_CURL2)
     PA_DIAG2_CASE(MODE_VMASS2)
     PA_DIAG2_CASE(MODE_CURLMASS2)
+    PA_DIAG2_CASE(MODE_MASS)
+    PA_DIAG2_CASE(MODE_DIFF2)
+    PA_DIAG2_CASE(MODE_DIFFMASS2)
 #undef PA_DIAG2_CASE
+    default: break;
   }
   hipLaunchKernelGGL(dense_diag_slot_kernel, grid, block, 0, s, ds.ne, ds.P, ds.KP, ds.d_cor, ds.d_idx, diag, ds.d_ye);
   PA_HIP(hipGetLastError());

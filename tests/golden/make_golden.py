@@ -116,7 +116,26 @@ def fixtures_2d():
     v32 = np.zeros((2, Q))
     capi.ref_call("f_apply_hcurl_32", c3.pack(), Q, [g32, u], [v32])
     out.update(J32=J32, geom32=g32, ctx3=c3.pack(), hcurl_32=v32)
+    # the remaining pair QFunctions in the plane and on boundary elements (no new random draws: earlier keys keep their bits)
+    pair_h1 = np.concatenate([c1.pack(), c2.pack()])  # scalar mass first, then the 2x2 diffusion coefficient
+    s22, g22 = np.zeros((1, Q)), np.zeros((2, Q))
+    capi.ref_call("f_apply_hcurlmass_22", pair_h1, Q, [geom, cu, u], [s22, g22])
+    pair_nd32 = np.concatenate([c3.pack(), c1.pack()])  # 3x3 mass first, then the scalar curl-curl coefficient
+    v3, w3 = np.zeros((2, Q)), np.zeros((1, Q))
+    capi.ref_call("f_apply_hdivmass_32", pair_nd32, Q, [g32, qw, u, cu], [v3, w3])
+    pair_h132 = np.concatenate([c1.pack(), c3.pack()])
+    s32, g32v = np.zeros((1, Q)), np.zeros((2, Q))
+    capi.ref_call("f_apply_hcurlmass_32", pair_h132, Q, [g32, cu, u], [s32, g32v])
+    out.update(hcurlmass_22_v=s22, hcurlmass_22_gv=g22, hdivmass_32_v=v3, hdivmass_32_cv=w3, hcurlmass_32_v=s32,
+               hcurlmass_32_gv=g32v)
     np.savez(os.path.join(ROOT, "tests", "golden", "qf2d_golden.npz"), **out)
+    print("wrote qf2d_golden.npz")
+
+
+def cavity2d_fixture():
+    """The reference's cavity2d mesh and its regression values (eig.csv, terminal-M.csv, terminal-C.csv)."""
+    from palace_amd.fem import tri
+
     m = tri.read_gmsh22_tris("/root/reference/examples/cavity2d/mesh/cavity2d.msh")
     eig = np.loadtxt("/root/reference/test/data/regression/ref/cavity2d/eigenmode/eig.csv", delimiter=",", skiprows=1)
     # boundary edges (vertex pairs in the node numbering of `nodes`) with their attributes, and the regression values of
@@ -129,7 +148,7 @@ def fixtures_2d():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "cavity2d_mesh.npz"), nodes=m.nodes,
                         elem_nodes=m.elem_nodes.astype(np.int32), attr=m.attr, eig_re_GHz=eig[:, 1], eig_im_GHz=eig[:, 2],
                         bdr_edges=bdr.astype(np.int32), bdr_attr=m.bdr_attr.astype(np.int32), M11_H=M11, C11_F=C11)
-    print("wrote qf2d_golden.npz, cavity2d_mesh.npz")
+    print("wrote cavity2d_mesh.npz")
 
 
 def spheres_fixture():
@@ -221,5 +240,6 @@ def cpw_fixture():
 if __name__ == "__main__":
     mesh_fixture()
     fixtures_2d()
+    cavity2d_fixture()
     spheres_fixture()
     cpw_fixture()

@@ -75,6 +75,70 @@ def test_apply_2d(p, mode):
     assert np.abs(d.cpu().numpy() - dref).max() < 1e-12 * np.abs(dref).max()
 
 
+@pytest.mark.parametrize("surface", [False, True])
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["diff", "mass", "diffmass"])
+def test_h1_apply_2d_and_surface(p, mode, surface):
+    """Nodal H1 triangles through the dense path: diffusion (f_apply_hcurl_22 / _32 on grad u, integ/diffusion.cpp), mass
+    (f_apply_h1_1) and diffusion + mass (f_apply_hcurlmass_22 / _32) in the plane and on the same triangulation lifted to
+    a curved surface in 3-D (2-D elements in 3-D space: what the auxiliary-space boundary terms of the preconditioner use,
+    models/spaceoperator.cpp:321-326)."""
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import tri
+
+    mesh, _ = _mesh()
+    sp = tri.H1TriSpace(mesh, p)
+    pts, wts = tri.tri_quadrature(p + 1)
+    interp, grad = sp.elem.tables(pts)
+    G = mesh.geometry_grad_table(pts)
+    rng = np.random.default_rng(10 * p + surface)
+    if surface:
+        xy = mesh.nodes
+        L = np.ptp(xy[:, 0])
+        nodes = np.column_stack([xy, 0.15 * L * np.sin(3.0 * xy[:, 0] / L) + 0.3 * xy[:, 0] * xy[:, 1] / L])
+        J = np.einsum("dqn,eni->eqid", G, nodes[mesh.elem_nodes])  # [e, q, 3, 2]
+        ogeom = po.build_geom_factor_32(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 6))
+        B = rng.uniform(-1, 1, (3, 3))
+        cm = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[B @ B.T + 2 * np.eye(3), np.array([0.8])], a=0.9)
+        qf_d, oqf_d, qf_dm, oqf_dm = ceed.QF_HCURL_32, po.QF_HCURL_32, ceed.QF_HCURLMASS_32, po.QF_HCURLMASS_32
+    else:
+        nodes = mesh.nodes
+        J = mesh.jacobians(pts)
+        ogeom = po.build_geom_factor_22(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 4))
+        A = rng.uniform(-1, 1, (2, 2))
+        cm = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[A @ A.T + 2 * np.eye(2), np.array([0.6])], a=1.2, dim=2)
+        qf_d, oqf_d, qf_dm, oqf_dm = ceed.QF_HCURL_22, po.QF_HCURL_22, ceed.QF_HCURLMASS_22, po.QF_HCURLMASS_22
+    geom = ceed.DenseGeomFactorData(mesh.elem_nodes, nodes, mesh.attr, G, wts)
+    got = geom.to_numpy()
+    assert got.shape == ogeom.shape and np.abs(got - ogeom).max() <= 1e-13 * np.abs(ogeom).max()
+    c1 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([1.9]), np.array([0.4])], dim=1)
+    if mode == "diff":
+        qf, oqf, blob, ctxs, ops = qf_d, oqf_d, cm.pack(), (cm, None), ceed.EVAL_GRAD
+    elif mode == "mass":
+        qf, oqf, blob, ctxs, ops = ceed.QF_H1_1, po.QF_H1MASS, c1.pack(), (c1, None), ceed.EVAL_INTERP
+    else:
+        qf, oqf, blob, ctxs, ops = qf_dm, oqf_dm, np.concatenate([c1.pack(), cm.pack()]), (c1, cm), ceed.EVAL_GRAD | ceed.EVAL_INTERP
+    block = ceed.DenseBlock(ceed.FE_H1, sp.ndofs, sp.offsets, interp, grad)
+    op = ceed.Operator(sp.ndofs, sp.ndofs).add_dense_integrator(geom, block, qf, blob, ops).finalize()
+    orc = po.CeedOperatorOracle(sp.ndofs, sp.offsets, None, interp, grad, ogeom, oqf, *ctxs, vector_fe=False)
+    x = rng.uniform(-1, 1, sp.ndofs)
+    ref = orc.apply_add(x, np.zeros(sp.ndofs))
+    y = torch.empty(sp.ndofs, dtype=torch.float64, device="cuda")
+    op.mult(torch.from_numpy(x).cuda(), y)
+    assert np.abs(y.cpu().numpy() - ref).max() < 1e-12 * np.abs(ref).max()
+    d = torch.empty_like(y)
+    op.assemble_diagonal(d)
+    dref = orc.diagonal()
+    assert np.abs(d.cpu().numpy() - dref).max() < 1e-12 * np.abs(dref).max()
+    if mode != "mass":  # constants are in the kernel of the diffusion part
+        ones = torch.ones_like(y)
+        op.mult(ones, d)
+        if mode == "diff":
+            assert float(d.abs().max()) < 1e-12 * float(y.abs().max())
+
+
 def test_cavity2d_first_mode_on_device():
     """Rayleigh quotient of the oracle's first eigenvector evaluated with the DEVICE operators reproduces the
     reference's first eigenfrequency (eig.csv, 0.1039343283770 GHz)."""

@@ -49,6 +49,24 @@ def test_boundary_qfunctions_32():
     np.testing.assert_allclose(v, G["hcurl_32"], rtol=1e-12, atol=1e-13)
 
 
+def test_pair_qfunctions_22_32():
+    """f_apply_hcurlmass_22, f_apply_hdivmass_32, f_apply_hcurlmass_32 (2-D / boundary H1 diffusion + mass, boundary ND
+    curl-curl + mass) against the reference headers: pair contexts of different dimensions, the scalar one first or second."""
+    c1, _ = _ctx(G["ctx1"], 1)
+    c2, _ = _ctx(G["ctx2"], 2)
+    c3, _ = _ctx(G["ctx3"], 3)
+    u, cu = G["u"][None], G["cu"][None]
+    v, gv = po.apply_hcurlmass_22(c1, c2, G["geom"][None], cu, u)
+    np.testing.assert_allclose(v[0], G["hcurlmass_22_v"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(gv[0], G["hcurlmass_22_gv"], rtol=TOL, atol=TOL)
+    v, cv = po.apply_hdivmass_32(c3, c1, G["geom32"][None], G["qw"], u, cu)
+    np.testing.assert_allclose(v[0], G["hdivmass_32_v"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(cv[0], G["hdivmass_32_cv"], rtol=1e-12, atol=1e-13)
+    v, gv = po.apply_hcurlmass_32(c1, c3, G["geom32"][None], cu, u)
+    np.testing.assert_allclose(v[0], G["hcurlmass_32_v"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(gv[0], G["hcurlmass_32_gv"], rtol=1e-12, atol=1e-13)
+
+
 def test_cavity2d_eigenfrequencies():
     """Order-2 Nedelec triangles on the reference's own mesh, eps_r = 2.08 with loss tangent 4e-4, PEC:
     K x = omega^2 eps M x  ->  f = sqrt(lambda / (eps_r (1 - i tan d))) c0 / 2 pi."""

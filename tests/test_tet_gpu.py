@@ -166,6 +166,47 @@ def test_h1_tet_apply(p, mode):
 
 @pytest.mark.parametrize("p", [1, 2, 3])
 @pytest.mark.parametrize("kind", ["tet4", "tet10"])
+def test_nd_tet_boundary_curlcurl_and_pair(kind, p):
+    """The other ND boundary terms of SpaceOperator (models/spaceoperator.cpp:292-302): the surface curl-curl
+    (CurlCurlIntegrator on boundary elements: f_apply_l2_1 on the scalar surface curl, with the q_w input) and curl-curl + mass
+    in one QFunction (f_apply_hdivmass_32) on the boundary triangles of a tet mesh."""
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import tet, tri
+
+    mesh = _mesh(kind)
+    nd = tet.NDTetSpace(mesh, p)
+    faces = np.nonzero(mesh.boundary_face_mask)[0]
+    blk = tet.NDTetBoundaryBlock(nd, faces, 1 + (np.arange(faces.size) % 2))
+    pts, wts = tri.tri_quadrature(p + 1)
+    interp, curl = blk.elem.tables(pts)
+    bgeom = ceed.DenseGeomFactorData(blk.elem_nodes, blk.nodes, blk.attr, blk.geometry_grad_table(pts), wts)
+    J = blk.jacobians(pts)
+    og = po.build_geom_factor_32(blk.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(blk.ne, -1, 6))
+    c3, b3 = util.make_ctx("aniso", 2)
+    c1 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([1.9]), np.array([0.4])], dim=1)
+    block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, blk.offsets, interp, curl, orients=blk.orients)
+    x = np.random.default_rng(p).uniform(-1, 1, nd.ndofs)
+    xd = torch.from_numpy(x).cuda()
+    for qf, oqf, blob, ctxs, ops in (
+            (ceed.QF_L2_1, po.QF_L2_1, c1.pack(), (c1, None), ceed.EVAL_CURL | ceed.EVAL_WEIGHT),
+            (ceed.QF_HDIVMASS_32, po.QF_HDIVMASS_32, np.concatenate([b3, c1.pack()]), (c3, c1),
+             ceed.EVAL_CURL | ceed.EVAL_INTERP | ceed.EVAL_WEIGHT)):
+        op = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(bgeom, block, qf, blob, ops).finalize()
+        orc = po.CeedOperatorOracle(nd.ndofs, blk.offsets, blk.orients, interp, curl, og, oqf, *ctxs, qw=wts)
+        ref = orc.apply_add(x, np.zeros(nd.ndofs))
+        y = torch.empty(nd.ndofs, dtype=torch.float64, device="cuda")
+        op.mult(xd, y)
+        assert np.abs(y.cpu().numpy() - ref).max() < REL * np.abs(ref).max(), oqf
+        d = torch.empty_like(y)
+        op.assemble_diagonal(d)
+        dref = orc.diagonal()
+        assert np.abs(d.cpu().numpy() - dref).max() < REL * np.abs(dref).max(), oqf
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["tet4", "tet10"])
 def test_nd_tet_boundary_mass(kind, p):
     """Surface (impedance / absorbing-boundary type) mass term on the boundary triangles of a tet mesh:
     f_apply_hcurl_32 on 2-D Nedelec triangles in 3-D space whose dofs are the tetrahedral space's face / edge dofs
