@@ -322,6 +322,8 @@ Mesh::Mesh(const Context &ctx, int num_elem, int mesh_order, int num_nodes, cons
 }
 Mesh::Mesh(const Context &ctx, const pa_mesh_dense_desc &desc)
     : ne_(desc.num_elem), q1d_(0), mesh_order_(0), nq_dense_(desc.num_qpts) {
+  dim_ = desc.dim == 0 ? 3 : desc.dim;
+  sdim_ = desc.space_dim == 0 ? dim_ : desc.space_dim;
   check(pa_geom_create_dense(&desc, ctx.stream, &geom_));
 }
 Mesh::~Mesh() {
@@ -360,9 +362,12 @@ FiniteElementSpace::FiniteElementSpace(const Context &ctx, const Mesh &mesh, int
   offsets_.assign(offsets, offsets + n);
   if (orients) orients_.assign(orients, orients + n);
   if (curl_orients) curl_orients_.assign(curl_orients, curl_orients + 3 * n);
-  const size_t qcomp = fe_type == PA_FE_H1 ? 1 : 3;
+  // components of the reference-space values and derivatives (basis.cpp:40-85): vectors have dim components, the curl of a
+  // 2-D Nedelec element is a scalar
+  const size_t dim = (size_t)mesh.Dimension();
+  const size_t qcomp = fe_type == PA_FE_H1 ? 1 : dim, dcomp = (fe_type == PA_FE_HCURL && dim == 2) ? 1 : dim;
   if (interp) interp_.assign(interp, interp + qcomp * Q * elem_size);
-  if (deriv) deriv_.assign(deriv, deriv + 3 * Q * elem_size);
+  if (deriv) deriv_.assign(deriv, deriv + dcomp * Q * elem_size);
 }
 
 pa_restriction_desc FiniteElementSpace::GetCeedElemRestriction() const {
@@ -455,6 +460,11 @@ void BilinearFormIntegrator::AssembleCeedOperator(pa_op *op, const FiniteElement
                       trial_ops, test_ops));
 }
 
+namespace {
+// 10 * space_dim + dim of the element block, as the reference's integrators switch on it
+int dims_of(const FiniteElementSpace &fes) { return 10 * fes.GetMesh().SpaceDimension() + fes.GetMesh().Dimension(); }
+}  // namespace
+
 void MassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   AssembleCeedOperator(op, trial, test, PA_QF_H1_1, ceed::PopulateCoefficientContext(1, Q, transpose), PA_EVAL_INTERP,
                        PA_EVAL_INTERP);
@@ -464,16 +474,29 @@ void VectorFEMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial
   const bool tc = trial.GetFEType() == PA_FE_HCURL, sc = test.GetFEType() == PA_FE_HCURL;
   PA_REQUIRE((tc || trial.GetFEType() == PA_FE_HDIV) && (sc || test.GetFEType() == PA_FE_HDIV),
              "Invalid trial/test element map type for VectorFEMassIntegrator!");
-  const int qf = tc ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33) : (sc ? PA_QF_HDIVHCURL_33 : PA_QF_HDIV_33);
-  AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_INTERP, PA_EVAL_INTERP);
+  const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
+  int qf;
+  if (d == 33) {
+    qf = tc ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33) : (sc ? PA_QF_HDIVHCURL_33 : PA_QF_HDIV_33);
+  } else {
+    PA_REQUIRE(tc && sc && (d == 22 || d == 32), "VectorFEMassIntegrator: H(curl) spaces only on 2-D / boundary elements");
+    qf = d == 22 ? PA_QF_HCURL_22 : PA_QF_HCURL_32;
+  }
+  AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_INTERP, PA_EVAL_INTERP);
 }
 void DiffusionIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
-  AssembleCeedOperator(op, trial, test, PA_QF_HCURL_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_GRAD,
-                       PA_EVAL_GRAD);
+  const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
+  PA_REQUIRE(d == 33 || d == 22 || d == 32, "Invalid value of (dim, space_dim) for DiffusionIntegrator!");
+  AssembleCeedOperator(op, trial, test, d == 33 ? PA_QF_HCURL_33 : (d == 22 ? PA_QF_HCURL_22 : PA_QF_HCURL_32),
+                       ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_GRAD, PA_EVAL_GRAD);
 }
 void CurlCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
-  AssembleCeedOperator(op, trial, test, PA_QF_HDIV_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_CURL,
-                       PA_EVAL_CURL);
+  const int d = dims_of(trial), dim = trial.GetMesh().Dimension();
+  PA_REQUIRE(d == 33 || d == 22 || d == 32, "Invalid value of (dim, space_dim) for CurlCurlIntegrator!");
+  // the curl of a 2-D element has a single component: scalar coefficient, Weight input on the trial side (curlcurl.cpp:40-72)
+  AssembleCeedOperator(op, trial, test, d == 33 ? PA_QF_HDIV_33 : PA_QF_L2_1,
+                       ceed::PopulateCoefficientContext(dim < 3 ? 1 : dim, Q, transpose),
+                       PA_EVAL_CURL | (dim < 3 ? PA_EVAL_WEIGHT : 0), PA_EVAL_CURL);
 }
 void MixedVectorCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_HCURL,
@@ -488,14 +511,18 @@ void MixedVectorWeakCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace
                        PA_EVAL_CURL);
 }
 void DiffusionMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
-  AssembleCeedOperator(op, trial, test, PA_QF_HCURLMASS_33,
-                       ceed::PopulateCoefficientContext(1, Q_mass, 3, Q, transpose_mass, transpose),
+  const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
+  PA_REQUIRE(d == 33 || d == 22 || d == 32, "Invalid value of (dim, space_dim) for DiffusionMassIntegrator!");
+  AssembleCeedOperator(op, trial, test, d == 33 ? PA_QF_HCURLMASS_33 : (d == 22 ? PA_QF_HCURLMASS_22 : PA_QF_HCURLMASS_32),
+                       ceed::PopulateCoefficientContext(1, Q_mass, sdim, Q, transpose_mass, transpose),
                        PA_EVAL_GRAD | PA_EVAL_INTERP, PA_EVAL_GRAD | PA_EVAL_INTERP);
 }
 void CurlCurlMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
-  AssembleCeedOperator(op, trial, test, PA_QF_HDIVMASS_33,
-                       ceed::PopulateCoefficientContext(3, Q_mass, 3, Q, transpose_mass, transpose),
-                       PA_EVAL_CURL | PA_EVAL_INTERP, PA_EVAL_CURL | PA_EVAL_INTERP);
+  const int d = dims_of(trial), dim = trial.GetMesh().Dimension(), sdim = trial.GetMesh().SpaceDimension();
+  PA_REQUIRE(d == 33 || d == 22 || d == 32, "Invalid value of (dim, space_dim) for CurlCurlMassIntegrator!");
+  AssembleCeedOperator(op, trial, test, d == 33 ? PA_QF_HDIVMASS_33 : (d == 22 ? PA_QF_HDIVMASS_22 : PA_QF_HDIVMASS_32),
+                       ceed::PopulateCoefficientContext(sdim, Q_mass, dim < 3 ? 1 : dim, Q, transpose_mass, transpose),
+                       PA_EVAL_CURL | PA_EVAL_INTERP | (dim < 3 ? PA_EVAL_WEIGHT : 0), PA_EVAL_CURL | PA_EVAL_INTERP);
 }
 
 // ---- BilinearForm (bilinearform.cpp:27-201) -------------------------------------------------------------------------
@@ -505,6 +532,11 @@ std::unique_ptr<ceed::Operator> BilinearForm::PartialAssemble(const FiniteElemen
   check(pa_op_create(test.GetVSize(), trial.GetVSize(), &op));
   auto out = std::make_unique<ceed::Operator>(trial.GetContext(), op, /*own=*/true);
   for (const auto &integ : domain_integs) integ->Assemble(op, trial, test);
+  for (const auto &[bfes, integ] : boundary_integs) {
+    PA_REQUIRE(&trial == &test && bfes->GetVSize() == trial.GetVSize() && bfes->GetMesh().Dimension() == 2,
+               "a boundary integrator needs the boundary-element view of the form's (square) space");
+    integ->Assemble(op, *bfes, *bfes);
+  }
   check(pa_op_finalize(op));
   return out;
 }
@@ -526,6 +558,7 @@ std::vector<std::unique_ptr<Operator>> BilinearForm::Assemble(const FiniteElemen
              "Assembly on a FiniteElementSpaceHierarchy should have the same BilinearForm spaces and fine space of the "
              "hierarchy!");
   PA_REQUIRE(l0 < fespaces.GetNumLevels(), "No levels available for operator coarsening!");
+  PA_REQUIRE(boundary_integs.empty(), "forms with boundary integrators are assembled level by level (one boundary view per level)");
   std::vector<std::unique_ptr<ceed::Operator>> pa_ops;
   for (std::size_t l = l0; l < fespaces.GetNumLevels(); l++) {
     if (l > l0 && &fespaces.GetFESpaceAtLevel(l).GetMesh() == &fespaces.GetFESpaceAtLevel(l - 1).GetMesh())

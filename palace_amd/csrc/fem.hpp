@@ -97,6 +97,7 @@ class Mesh {
   pa_geom *geom_ = nullptr;
   int ne_, q1d_, mesh_order_;
   int nq_dense_ = 0;  // > 0: element block described by dense tables (tetrahedra, ...), that many quadrature points
+  int dim_ = 3, sdim_ = 3;
 
 public:
   // node_offsets [ne][(mesh_order + 1)^3] lattice order, nodes [num_nodes][3], attr [ne] (1-based); the quadrature is
@@ -108,6 +109,9 @@ public:
   Mesh(const Mesh &) = delete;
   ~Mesh();
   bool IsDense() const { return nq_dense_ > 0; }
+  // element and space dimension: 3 / 3, 2 / 2 (plane problems) or 2 / 3 (a block of boundary elements of a 3-D mesh)
+  int Dimension() const { return dim_; }
+  int SpaceDimension() const { return sdim_; }
   int GetNumQuadraturePoints() const { return nq_dense_ > 0 ? nq_dense_ : q1d_ * q1d_ * q1d_; }
   pa_geom *GetCeedGeomFactorData() const { return geom_; }
   int GetNE() const { return ne_; }
@@ -238,6 +242,7 @@ class BilinearForm {
 protected:
   const FiniteElementSpace &trial_fespace, &test_fespace;
   std::vector<std::unique_ptr<BilinearFormIntegrator>> domain_integs;
+  std::vector<std::pair<const FiniteElementSpace *, std::unique_ptr<BilinearFormIntegrator>>> boundary_integs;
   std::unique_ptr<ceed::Operator> PartialAssemble(const FiniteElementSpace &trial, const FiniteElementSpace &test) const;
 
 public:
@@ -250,6 +255,14 @@ public:
   template <typename T, typename... U>
   void AddDomainIntegrator(U &&...args) {
     domain_integs.push_back(std::make_unique<T>(std::forward<U>(args)...));
+  }
+  // Boundary integrators act on a block of boundary elements: `bdr_fespace` is the view of the form's space on that block
+  // (a dense-table space on a Mesh with Dimension() = 2, SpaceDimension() = 3 whose restriction indexes the same L-vector --
+  // what FiniteElementSpace::GetCeedElemRestriction(ceed, geom, indices) returns for boundary elements,
+  // fem/libceed/restriction.cpp:15-111); bilinearform.cpp:60-100 adds them as further sub-operators of the same operator.
+  template <typename T, typename... U>
+  void AddBoundaryIntegrator(const FiniteElementSpace &bdr_fespace, U &&...args) {
+    boundary_integs.emplace_back(&bdr_fespace, std::make_unique<T>(std::forward<U>(args)...));
   }
   std::unique_ptr<ceed::Operator> PartialAssemble() const { return PartialAssemble(trial_fespace, test_fespace); }
   std::unique_ptr<CsrMatrix> FullAssemble(bool skip_zeros) const { return FullAssemble(*PartialAssemble(), skip_zeros); }
