@@ -71,7 +71,12 @@ enum pa_qfunction {
                               H1 diffusion alone: PA_QF_HCURL_22 / PA_QF_HCURL_32 with EVAL_GRAD (fem/integ/diffusion.cpp) */
 };
 
-enum pa_fe_type { PA_FE_H1 = 0, PA_FE_HCURL = 1, PA_FE_HDIV = 2 /* dense path only: RT mass (Interp + hdiv_33) */ };
+enum pa_fe_type {
+  PA_FE_H1 = 0,
+  PA_FE_HCURL = 1,
+  PA_FE_HDIV = 2 /* dense path only: RT mass (Interp + PA_QF_HDIV_33, interp = values [3 Q][P]) and div-div (Div | Weight +
+                    PA_QF_L2_1, fem/integ/divdiv.cpp; deriv = divergence [Q][P]); mixed mass with an H(curl) space */
+};
 
 /*
  * Element restriction E — what Palace hands to CeedElemRestrictionCreate / ...CreateOriented

@@ -500,7 +500,7 @@ class CeedOperatorOracle:
     """
 
     def __init__(self, lsize, offsets, orients, interp, deriv, geom, qf, ctx, ctx2=None, vector_fe=True,
-                 curl_orients=None, qw=None):
+                 curl_orients=None, qw=None, deriv_comps=None):
         self.qw = qw  # quadrature weights: the extra q_w input of the 2-D curl-curl QFunctions
         self.lsize = int(lsize)
         self.off = np.asarray(offsets)
@@ -517,7 +517,9 @@ class CeedOperatorOracle:
             self.interp = np.asarray(interp).reshape(dim, self.Q, self.P)
         else:
             self.interp = np.asarray(interp).reshape(1, self.Q, self.P)
-        self.deriv = np.asarray(deriv).reshape(1 if (dim == 2 and vector_fe) else dim, self.Q, self.P)
+        # deriv_comps: components of the derivative table when it is not the default (1: the divergence of an H(div) element)
+        dc = deriv_comps if deriv_comps is not None else (1 if (dim == 2 and vector_fe) else dim)
+        self.deriv = np.asarray(deriv).reshape(dc, self.Q, self.P)
         self.geom, self.qf, self.ctx, self.ctx2 = geom, qf, ctx, ctx2
 
     def _restrict(self, x, sl):
@@ -545,7 +547,7 @@ class CeedOperatorOracle:
     def _qfunction(self, geom, ue):
         """B, D, B^T on element-local vectors ue [ne, P] -> ve [ne, P]."""
         qf = self.qf
-        if qf == QF_L2_1:      # 2-D curl-curl
+        if qf == QF_L2_1:      # 2-D curl-curl; div-div with the divergence table (integ/divdiv.cpp: l2_1 for one component)
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
             return np.einsum("dqj,edq->ej", self.deriv, apply_l2_1(self.ctx, geom, self.qw, cu))
         if qf == QF_HCURL_32 and not self.vector_fe:  # H1 diffusion on boundary elements (integ/diffusion.cpp, case 32)

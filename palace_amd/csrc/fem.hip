@@ -365,7 +365,8 @@ FiniteElementSpace::FiniteElementSpace(const Context &ctx, const Mesh &mesh, int
   // components of the reference-space values and derivatives (basis.cpp:40-85): vectors have dim components, the curl of a
   // 2-D Nedelec element is a scalar
   const size_t dim = (size_t)mesh.Dimension();
-  const size_t qcomp = fe_type == PA_FE_H1 ? 1 : dim, dcomp = (fe_type == PA_FE_HCURL && dim == 2) ? 1 : dim;
+  const size_t qcomp = fe_type == PA_FE_H1 ? 1 : dim;
+  const size_t dcomp = (fe_type == PA_FE_HDIV || (fe_type == PA_FE_HCURL && dim == 2)) ? 1 : dim;  // divergence, 2-D curl: scalars
   if (interp) interp_.assign(interp, interp + qcomp * Q * elem_size);
   if (deriv) deriv_.assign(deriv, deriv + dcomp * Q * elem_size);
 }
@@ -497,6 +498,11 @@ void CurlCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, co
   AssembleCeedOperator(op, trial, test, d == 33 ? PA_QF_HDIV_33 : PA_QF_L2_1,
                        ceed::PopulateCoefficientContext(dim < 3 ? 1 : dim, Q, transpose),
                        PA_EVAL_CURL | (dim < 3 ? PA_EVAL_WEIGHT : 0), PA_EVAL_CURL);
+}
+void DivDivIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
+  PA_REQUIRE(trial.GetFEType() == PA_FE_HDIV && test.GetFEType() == PA_FE_HDIV, "DivDivIntegrator: H(div) spaces expected");
+  AssembleCeedOperator(op, trial, test, PA_QF_L2_1, ceed::PopulateCoefficientContext(1, Q, transpose),
+                       PA_EVAL_DIV | PA_EVAL_WEIGHT, PA_EVAL_DIV);  // divdiv.cpp:31-57 (single-component elements)
 }
 void MixedVectorCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_HCURL,

@@ -80,6 +80,7 @@ int mode_of(int fe_type, int qf, int dim, int sdim) {
     throw Error(bdr ? "QFunction does not match an H1 boundary element" : "QFunction does not match a 2-D H1 element");
   }
   if (fe_type == PA_FE_HCURL) {
+    if (qf == PA_QF_L2_1) return MODE_CURL2;  // (reached through the H(div) alias: div-div, a scalar derivative in 3-D)
     if (qf == PA_QF_HDIV_33) return MODE_CURL;
     if (qf == PA_QF_HCURL_33) return MODE_VMASS;
     if (qf == PA_QF_HDIVMASS_33) return MODE_CURLMASS;
@@ -730,13 +731,13 @@ __global__ void dense_qdata_kernel(const DenseArgs a, double *__restrict__ qd) {
 //   symmetric 2x2 {00, 01, 11} = w detJ A^T C A    hcurl_22_qf.h:10-30, hcurl_32_qf.h:10-30 (ND mass, H1 diffusion)
 //   c qw^2 / (w detJ)                              l2_1_qf.h:10-24, second half of hdivmass_22 / _32 (scalar curl)
 //   c w detJ                                       h1_1_qf.h, first half of hcurlmass_22 / _32 (H1 mass)
-template <int MODE, bool BDR>
+template <int MODE, int NROWS>
 __global__ void dense_qdata2_kernel(const DenseArgs a, double *__restrict__ qd) {
+  constexpr bool BDR = NROWS == 8;  // (NROWS = 11: 3-D geometry data, scalar forms only -- div-div on Raviart-Thomas elements)
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int e = (int)(gid / a.Q);
   if (e >= a.ne) return;
   const int q = (int)(gid - (long long)e * a.Q);
-  constexpr int NROWS = BDR ? 8 : 6;
   const size_t cs = (size_t)a.Qpad * kEB, os = (size_t)a.Q4 * kEB;
   const double *g = a.geom + ((size_t)(e / kEB) * NROWS * a.Qpad + q) * kEB + (e % kEB);
   double *out = qd + ((size_t)(e / kEB) * a.ncq * a.Q4 + q) * kEB + (e % kEB);
@@ -1112,10 +1113,19 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   if (b.fe_type == PA_FE_HDIV) {
     // H(div) mass (fem/integ/vecfemass.cpp with an RT space: Interp + f_apply_hdiv_33, the contravariant Piola map) is
     // the arithmetic of the curl-curl operator with the value table in the place of the curl table
-    PA_REQUIRE(qf == PA_QF_HDIV_33 && trial_ops == PA_EVAL_INTERP && test_ops == PA_EVAL_INTERP && geom->dim == 3 &&
-                   geom->sdim == 3,
-               "H(div) elements: only the mass operator (Interp, hdiv_33) in 3-D is supported");
+    PA_REQUIRE(geom->dim == 3 && geom->sdim == 3, "H(div) elements: 3-D only");
     pa_dense_basis_desc alias = b;
+    if (qf == PA_QF_L2_1) {
+      // div-div (fem/integ/divdiv.cpp: Div | Weight, f_apply_l2_1 for single-component elements): the scalar-derivative
+      // arithmetic of the 2-D curl-curl, c qw^2 / (w detJ), with the divergence table [Q][P] in the place of the curl table
+      PA_REQUIRE((trial_ops & ~(uint32_t)PA_EVAL_WEIGHT) == PA_EVAL_DIV && (test_ops & ~(uint32_t)PA_EVAL_WEIGHT) == PA_EVAL_DIV &&
+                     b.deriv,
+                 "H(div) elements: the div-div operator takes the divergence table with Div (| Weight)");
+      alias.fe_type = PA_FE_HCURL, alias.interp = nullptr;
+      return make_dense_sub(geom, r, alias, qf, ctx, ctx_size, PA_EVAL_CURL, PA_EVAL_CURL, height);
+    }
+    PA_REQUIRE(qf == PA_QF_HDIV_33 && trial_ops == PA_EVAL_INTERP && test_ops == PA_EVAL_INTERP,
+               "H(div) elements: the mass operator (Interp, hdiv_33) and div-div (Div, l2_1) are supported");
     alias.fe_type = PA_FE_HCURL, alias.deriv = b.interp, alias.interp = nullptr;
     return make_dense_sub(geom, r, alias, qf, ctx, ctx_size, PA_EVAL_CURL, PA_EVAL_CURL, height);
   }
@@ -1317,14 +1327,16 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       DenseArgs a = make_args(*ds);
       const long long n = (long long)ne * Q;
       const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-      if (dim == 2) {
+      if (dim == 3 && mode == MODE_CURL2) {
+        hipLaunchKernelGGL((dense_qdata2_kernel<MODE_CURL2, 11>), grid, block, 0, nullptr, a, ds->d_qdata);
+      } else if (dim == 2) {
         switch (mode) {
-#define PA_QD2_CASE(MODE)                                                                              \
-  case MODE:                                                                                           \
-    if (sdim == 3)                                                                                     \
-      hipLaunchKernelGGL((dense_qdata2_kernel<MODE, true>), grid, block, 0, nullptr, a, ds->d_qdata);  \
-    else                                                                                               \
-      hipLaunchKernelGGL((dense_qdata2_kernel<MODE, false>), grid, block, 0, nullptr, a, ds->d_qdata); \
+#define PA_QD2_CASE(MODE)                                                                          \
+  case MODE:                                                                                       \
+    if (sdim == 3)                                                                                 \
+      hipLaunchKernelGGL((dense_qdata2_kernel<MODE, 8>), grid, block, 0, nullptr, a, ds->d_qdata); \
+    else                                                                                           \
+      hipLaunchKernelGGL((dense_qdata2_kernel<MODE, 6>), grid, block, 0, nullptr, a, ds->d_qdata); \
     break;
           PA_QD2_CASE(MODE_CURL2)
           PA_QD2_CASE(MODE_VMASS2)
@@ -1374,7 +1386,8 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       }
     }
   }
-  PA_REQUIRE(dim == 3 || ds->d_L, "2-D blocks need symmetric coefficients and tables that fit in LDS (fast path only)");
+  PA_REQUIRE((dim == 3 && mode < MODE_CURL2) || ds->d_L,
+             "2-D blocks and div-div need symmetric coefficients and tables that fit in LDS (fast path only)");
   return ds;
 }
 
@@ -1440,7 +1453,7 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
   const long long n = (long long)ds.ne * ds.P;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   double *diag = dev_alloc<double>((size_t)n);  // element diagonals [ne][P] (set-up path: allocated per call)
-  if (ds.geom->dim == 3) switch (ds.mode) {
+  if (ds.geom->dim == 3 && ds.mode < MODE_CURL2) switch (ds.mode) {
 #define PA_DIAG_CASE(MODE)                                                                                   \
   case MODE:                                                                                                 \
     hipLaunchKernelGGL((dense_diag_kernel<MODE>), grid, block, 0, s, a, ds.d_off, ds.d_cor, ds.d_interp, ds.d_deriv, \
@@ -1455,7 +1468,7 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
 #undef PA_DIAG_CASE
     default: break;
   }
-  else switch (ds.mode) {  // 2-D blocks have q-data only
+  else switch (ds.mode) {  // 2-D blocks (and div-div) have q-data only
 #define PA_DIAG2_CASE(MODE)                                                                                     \
   case MODE:                                                                                                    \
     hipLaunchKernelGGL((dense_diag_qd_kernel<MODE>), grid, block, 0, s, a, ds.d_off, ds.d_cor, ds.d_interp, ds.d_deriv, \

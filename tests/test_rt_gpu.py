@@ -70,6 +70,47 @@ def test_rt_mass_apply(kind, p, coeff):
 
 
 @pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["tet4", "tet10"])
+def test_rt_divdiv_apply(kind, p):
+    """DivDivIntegrator on a Raviart-Thomas space (fem/integ/divdiv.cpp:31-57: Div | Weight, f_apply_l2_1 with a scalar
+    coefficient): (c div u, div v) vs the oracle; the divergence of a discrete curl vanishes."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem import rt, tet
+
+    mesh = _mesh(kind)
+    sp = rt.RTTetSpace(mesh, p)
+    pts, wts = tet.tet_quadrature(p + 1)
+    interp, div = sp.elem.tables(pts)
+    geom, ogeom = _geom(mesh, pts, wts)
+    c1 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([1.9]), np.array([0.4])], dim=1)
+    block = ceed.DenseBlock(ceed.FE_HDIV, sp.ndofs, sp.offsets, interp, div[None], orients=sp.orients)
+    op = ceed.Operator(sp.ndofs, sp.ndofs).add_dense_integrator(geom, block, ceed.QF_L2_1, c1.pack(),
+                                                                ceed.EVAL_DIV | ceed.EVAL_WEIGHT).finalize()
+    orc = po.CeedOperatorOracle(sp.ndofs, sp.offsets, sp.orients, interp, div, ogeom, po.QF_L2_1, c1, qw=wts, deriv_comps=1)
+    x = np.random.default_rng(p).uniform(-1, 1, sp.ndofs)
+    ref = orc.apply_add(x, np.zeros(sp.ndofs))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    op.mult(xd, yd)
+    assert np.abs(yd.cpu().numpy() - ref).max() < REL * np.abs(ref).max()
+    dd = torch.empty_like(xd)
+    op.assemble_diagonal(dd)
+    dref = orc.diagonal()
+    assert np.abs(dd.cpu().numpy() - dref).max() < REL * np.abs(dref).max()
+    # div curl = 0: the flux of any Nedelec potential is in the kernel
+    nd = tet.NDTetSpace(mesh, p)
+    ctx = linalg.Context()
+    C = linalg.DenseInterp(ctx, nd.restriction(), sp.restriction(interp_range=True), rt.tet_curl_matrix(p))
+    a = torch.from_numpy(np.random.default_rng(p + 7).uniform(-1, 1, nd.ndofs)).cuda()
+    b = torch.empty_like(xd)
+    C.mult(a, b)
+    op.mult(b, yd)
+    assert float(yd.abs().max()) < 1e-11 * float(b.abs().max()) * float(dd.abs().max())
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
 def test_discrete_curl_and_flux_energy(p):
     """B = C A on the device = the oracle's interpolator; (K A, A) = (M_RT B, B) with all three operators on the GPU."""
     import torch
