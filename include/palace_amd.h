@@ -291,6 +291,17 @@ int pa_op_mult(pa_op *op, const double *x, double *y, void *stream);
 int pa_op_mult_transpose(pa_op *op, const double *x, double *y, void *stream);
 int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *stream);
 int pa_op_is_symmetric(const pa_op *op);
+/* SURVEY.md 8(f)-1, ComplexWrapperOperator::Mult (linalg/operator.cpp:98-134) for A = A_r + i A_i: y_r = A_r x_r - A_i x_i,
+ * y_i = A_i x_r + A_r x_i in ONE pass over the element data instead of four applies.  Available (pa_op_complex_fused = 1) when both
+ * operators are single H(curl) tensor-hexahedron blocks on the same space and geometry in the streaming metric form (isotropic
+ * materials, Q1 = 4) -- e.g. op_r from pa_op_add_sub_sum for K - w^2 M and op_i = w C: they then share index arrays and
+ * quadrature data and differ by per-element scalar coefficients, so the kernel carries the real and the imaginary part of x in
+ * neighbouring lane groups and multiplies by (a_r + i a_i) at the quadrature points.  ess_policy: -1 plain; 0 / 1: with the
+ * essential list fused into op_r (pa_op_set_essential), entries read as zero and rows set to 0 / x (the real ParOperator's
+ * policy; the imaginary one is DIAG_ZERO, linalg/rap.cpp:450-457). */
+int pa_op_complex_fused(const pa_op *op_r, const pa_op *op_i);
+int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double *xi, double *yr, double *yi, int ess_policy,
+                       void *stream);
 /* 1 if y = A x runs on the streaming kernels (single tensor-product block, Q1 = 4, packed q-data): callers choosing between
  * pa_op_mult2 and two pa_op_mult calls prefer the latter then */
 int pa_op_streams(const pa_op *op);

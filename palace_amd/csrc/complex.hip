@@ -1,5 +1,7 @@
 #include "complex.hpp"
 
+#include <algorithm>
+
 #include <cstdlib>
 #include <string>
 
@@ -318,6 +320,28 @@ ComplexWrapperOperator::ComplexWrapperOperator(const Context &ctx, const Operato
   height = Ar ? Ar->Height() : Ai->Height();
   width = Ar ? Ar->Width() : Ai->Width();
   t_.SetSize(height);
+  const auto *cr = dynamic_cast<const ceed::Operator *>(Ar), *ci = dynamic_cast<const ceed::Operator *>(Ai);
+  fused_ = cr && ci && ceed::Operator::ComplexFused(*cr, *ci);
+  const auto *pr = dynamic_cast<const ParOperator *>(Ar), *pi = dynamic_cast<const ParOperator *>(Ai);
+  if (pr && pi && !pr->GetHalo() && !pi->GetHalo()) {
+    const auto *lr = dynamic_cast<const ceed::Operator *>(&pr->LocalOperator());
+    const auto *li = dynamic_cast<const ceed::Operator *>(&pi->LocalOperator());
+    const int ne = pr->NumEssentialTrueDofs();
+    bool same = lr && li && ne == pi->NumEssentialTrueDofs() && (ne == 0 || pr->FusesEssential()) &&
+                (ne == 0 || pi->GetDiagonalPolicy() == ParOperator::DiagonalPolicy::DIAG_ZERO) &&
+                ceed::Operator::ComplexFused(*lr, *li);
+    if (same && ne) {  // the two lists, once
+      std::vector<int32_t> a((size_t)ne), b((size_t)ne);
+      PA_HIP(hipMemcpy(a.data(), pr->GetEssentialTrueDofs(), sizeof(int32_t) * ne, hipMemcpyDeviceToHost));
+      PA_HIP(hipMemcpy(b.data(), pi->GetEssentialTrueDofs(), sizeof(int32_t) * ne, hipMemcpyDeviceToHost));
+      std::sort(a.begin(), a.end()), std::sort(b.begin(), b.end());
+      same = a == b;
+    }
+    if (same) {
+      par_fused_r_ = lr, par_fused_i_ = li;
+      par_fused_policy_ = ne ? (pr->GetDiagonalPolicy() == ParOperator::DiagonalPolicy::DIAG_ONE ? 1 : 0) : -1;
+    }
+  }
 }
 
 void ComplexWrapperOperator::AssembleDiagonal(ComplexVector &diag) const {
@@ -342,6 +366,15 @@ void ComplexWrapperOperator::Mult(const ComplexVector &x, ComplexVector &y) cons
   // Each real operator meets both parts of x: with ParOperators the pair goes through one pass over the
   // element data (ParOperator::Mult2), otherwise through two applies as in the reference.
   const Context &c = *ctx_;
+  if (par_fused_r_ && x.Real().Data() != y.Real().Data()) {
+    ceed::Operator::MultComplex(*par_fused_r_, *par_fused_i_, x.Real(), x.Imag(), y.Real(), y.Imag(), par_fused_policy_);
+    return;
+  }
+  if (fused_) {  // both parts in one pass over the element data
+    ceed::Operator::MultComplex(*static_cast<const ceed::Operator *>(Ar_), *static_cast<const ceed::Operator *>(Ai_), x.Real(),
+                                x.Imag(), y.Real(), y.Imag());
+    return;
+  }
   // whether a pair of applies shares one pass over the element data is ParOperator::Mult2's decision (it does when the
   // operator has no streaming form); PALACE_AMD_MULT2=0 forces separate applies for A/B runs
   static const bool pair = !(getenv("PALACE_AMD_MULT2") && std::string(getenv("PALACE_AMD_MULT2")) == "0");
@@ -459,6 +492,14 @@ ComplexParOperator::ComplexParOperator(const Context &ctx, const Operator *Ar, c
   if (Ai) RAPi_ = std::make_unique<ParOperator>(ctx, *Ai, n_true, nullptr, 0, ParOperator::DiagonalPolicy::DIAG_ZERO, halo);
   RAP_ = std::make_unique<ComplexWrapperOperator>(ctx, RAPr_.get(), RAPi_.get());
   lx_.SetSize(n_local_), ly_.SetSize(n_local_);
+  UpdateFused();
+}
+void ComplexParOperator::UpdateFused() {
+  fused_r_ = fused_i_ = nullptr;
+  const auto *cr = dynamic_cast<const ceed::Operator *>(Ar_), *ci = dynamic_cast<const ceed::Operator *>(Ai_);
+  if (halo_ || !cr || !ci || !ceed::Operator::ComplexFused(*cr, *ci)) return;
+  if (n_ess_ && !(RAPr_ && RAPr_->FusesEssential())) return;  // (another wrapper owns the operator's essential tables)
+  fused_r_ = cr, fused_i_ = ci;
 }
 ComplexParOperator::~ComplexParOperator() {
   if (d_ess_) (void)hipFree(d_ess_);
@@ -475,6 +516,7 @@ void ComplexParOperator::SetEssentialTrueDofs(const int32_t *ess_host, int n_ess
   if (Ar_) RAPr_ = std::make_unique<ParOperator>(*ctx_, *Ar_, n_true_, ess_host, n_ess, policy, halo_);
   if (Ai_) RAPi_ = std::make_unique<ParOperator>(*ctx_, *Ai_, n_true_, ess_host, n_ess, ParOperator::DiagonalPolicy::DIAG_ZERO, halo_);
   RAP_ = std::make_unique<ComplexWrapperOperator>(*ctx_, RAPr_.get(), RAPi_.get());
+  UpdateFused();
 }
 
 ParOperator::DiagonalPolicy ComplexParOperator::GetDiagonalPolicy() const {
@@ -518,7 +560,14 @@ void ComplexParOperator::RestrictFix(const ComplexVector &x, ComplexVector &ly, 
 void ComplexParOperator::Mult(const ComplexVector &x, ComplexVector &y) const {
   // rap.cpp:483-519.  One rank: the same result through the two real ParOperators (yr = RAPr xr - RAPi xi has xr on the
   // essential rows, yi = RAPi xr + RAPr xi has xi, with RAPi's rows zero), BC masking fused into the element kernels.
-  if (!halo_ && x.Real().Data() != y.Real().Data()) return RAP_->Mult(x, y);
+  if (!halo_ && x.Real().Data() != y.Real().Data()) {
+    if (fused_r_) {  // essential dofs handled inside the fused kernel and its gathers
+      ceed::Operator::MultComplex(*fused_r_, *fused_i_, x.Real(), x.Imag(), y.Real(), y.Imag(),
+                                  n_ess_ ? (policy_ == ParOperator::DiagonalPolicy::DIAG_ONE ? 1 : 0) : -1);
+      return;
+    }
+    return RAP_->Mult(x, y);
+  }
   Prolongate(x, lx_);
   A_->Mult(lx_, ly_);
   RestrictFix(x, ly_, y);

@@ -89,6 +89,11 @@ public:
 class ComplexWrapperOperator : public ComplexOperator {
   const Context *ctx_;
   const Operator *Ar_, *Ai_;
+  bool fused_ = false;  // both parts are ceed::Operators with a one-pass complex form (pa_op_complex_fused)
+  // ... or single-rank ParOperators around such a pair with the same essential dofs (real part: its policy; imaginary
+  // part: DIAG_ZERO): the local operators and the policy of the fused masked apply
+  const ceed::Operator *par_fused_r_ = nullptr, *par_fused_i_ = nullptr;
+  int par_fused_policy_ = -1;
   mutable Vector t_, t2_;
   mutable ComplexVector tx_, ty_;
   // y (+)= s op(A) x for one real operator through whatever that operator offers (AddMult with a coefficient or
@@ -170,6 +175,8 @@ class ComplexParOperator : public ComplexOperator {
   std::unique_ptr<ComplexWrapperOperator> A_;  // local (L-vector) operator
   std::unique_ptr<ParOperator> RAPr_, RAPi_;
   std::unique_ptr<ComplexWrapperOperator> RAP_;  // wrapper over RAPr / RAPi (single-rank fast path)
+  const ceed::Operator *fused_r_ = nullptr, *fused_i_ = nullptr;  // single rank: one pass for both parts (pa_op_mult_complex)
+  void UpdateFused();
   int32_t *d_ess_ = nullptr;
   int n_ess_ = 0;
   ParOperator::DiagonalPolicy policy_ = ParOperator::DiagonalPolicy::DIAG_ONE;

@@ -800,6 +800,11 @@ void Operator::AddMultTranspose(const Vector &x, Vector &y, double a) const {
 }
 bool Operator::IsSymmetric() const { return pa_op_is_symmetric(op_) != 0; }
 void Operator::AssembleDiagonal(Vector &diag) const { check(pa_op_assemble_diagonal(op_, diag.Data(), ctx_->stream)); }
+void Operator::MultComplex(const Operator &Ar, const Operator &Ai, const Vector &xr, const Vector &xi, Vector &yr, Vector &yi,
+                           int ess_policy) {
+  if (pa_op_mult_complex(Ar.op_, Ai.op_, xr.Data(), xi.Data(), yr.Data(), yi.Data(), ess_policy, Ar.ctx_->stream))
+    throw pa::Error(pa_last_error());
+}
 void Operator::SetInterfaceDofs(const std::vector<int32_t> &ldofs) {
   if (pa_op_set_interface_dofs(op_, ldofs.data(), (int32_t)ldofs.size())) throw pa::Error(pa_last_error());
 }

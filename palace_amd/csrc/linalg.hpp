@@ -203,6 +203,11 @@ public:
   void MultEssential(const Vector &x, Vector &y) const;
   // the same + y[ess] = x[ess] | 0 inside the E^T kernels; returns false if the caller must fix the rows up
   bool MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const;
+  // y = (Ar + i Ai) x in one pass over the element data (pa_op_mult_complex); ess_policy -1: plain, 0 / 1: with Ar's fused
+  // essential list, rows set to 0 / x
+  static bool ComplexFused(const Operator &Ar, const Operator &Ai) { return pa_op_complex_fused(Ar.op_, Ai.op_) != 0; }
+  static void MultComplex(const Operator &Ar, const Operator &Ai, const Vector &xr, const Vector &xi, Vector &yr, Vector &yi,
+                          int ess_policy = -1);
   // two right-hand sides in one pass over the element data (pa_op_mult2 / pa_op_mult2_essential_diag)
   void Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const;
   bool Mult2EssentialDiag(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1, bool diag_one) const;
@@ -311,6 +316,9 @@ public:
   const int32_t *GetEssentialTrueDofs() const { return d_ess_; }
   int NumEssentialTrueDofs() const { return n_ess_; }
   const Operator &LocalOperator() const { return *A_; }
+  bool FusesEssential() const { return A_fused_ != nullptr; }  // the essential list lives in the local operator's index tables
+  DiagonalPolicy GetDiagonalPolicy() const { return policy_; }
+  const Halo *GetHalo() const { return halo_; }
   void Mult(const Vector &x, Vector &y) const override;
   // rap.cpp:236-275: y = P^T A^T P x with the same essential-dof handling (a symmetric local operator takes the fused
   // forward path)

@@ -1,6 +1,7 @@
 // C ABI of libpalace_amd.so (declared in include/palace_amd.h): object lifetime, descriptor
 // validation and set-up on the host; all arithmetic lives in the HIP kernels.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -476,7 +477,7 @@ static bool apply2(pa_op *op, const double *x0, const double *x1, double *y0, do
   PA_REQUIRE(x0 != y0 && x0 != y1 && x1 != y0 && x1 != y1 && y0 != y1, "in-place apply is not supported");
   if (op->subs.size() == 1 && op->dsubs.empty() && nd_hex_supports_two_rhs(*op->subs[0])) {
     SubOp *so = op->subs[0];
-    if (!so->d_ye2) so->d_ye2 = dev_alloc<double>((size_t)so->ne * so->P);
+    if (!so->d_ye2) so->d_ye2 = dev_alloc<double>((size_t)((so->ne + 3) & ~3) * so->P);
     const int pol = nd_hex_fuses_essential(*so) ? ess_policy : -1;
     launch_nd_hex_apply(*so, x0, y0, so->d_ye, masked, s, false, pol, x1, y1, so->d_ye2);
     launch_et_gather2(*so, y0, y1, false, s, x0, x1, pol);
@@ -490,6 +491,11 @@ static bool apply2(pa_op *op, const double *x0, const double *x1, double *y0, do
 void apply_for_assembly(pa_op *op, const double *x, double *y, hipStream_t s) { apply(op, x, y, true, s); }
 
 }  // namespace pa
+
+static uint64_t next_op_id() {
+  static std::atomic<uint64_t> counter{0};
+  return ++counter;
+}
 
 bool pa_op::symmetric() const {
   for (const pa::SubOp *so : subs)  // (C u, curl v) and (C curl u, v) are each other's transposes, never their own
@@ -601,6 +607,7 @@ int pa_op_create(int32_t height, int32_t width, pa_op **op) {
   return guarded([&] {
     PA_REQUIRE(op && height > 0 && width > 0, "bad operator size");
     auto *o = new pa_op;
+    o->id = next_op_id();
     o->height = height, o->width = width;
     *op = o;
   });
@@ -816,6 +823,7 @@ int pa_op_coarsen(const pa_op *fine, const pa_restriction_desc *restr, const pa_
     PA_REQUIRE(fine && restr && basis && coarse, "null argument");
     PA_REQUIRE(!fine->subs.empty(), "fine operator has no sub-operators");
     auto *o = new pa_op;
+    o->id = next_op_id();
     o->height = o->width = restr->lsize;
     try {
       for (const SubOp *fs : fine->subs) {
@@ -840,6 +848,7 @@ int pa_op_coarsen_dense(const pa_op *fine, const pa_restriction_desc *restr, con
     PA_REQUIRE(fine && restr && basis && coarse, "null argument");
     PA_REQUIRE(fine->finalized && fine->subs.empty() && !fine->dsubs.empty(), "fine operator has no dense sub-operators");
     auto *o = new pa_op;
+    o->id = next_op_id();
     o->height = o->width = restr->lsize;
     try {
       for (const DenseSub *fs : fine->dsubs)
@@ -880,6 +889,36 @@ int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *strea
     PA_REQUIRE(op && op->height == op->width, "transpose apply needs a square operator");
     TransposeScope t(!op->symmetric());
     apply(op, x, y, false, (hipStream_t)stream);
+  });
+}
+
+int pa_op_complex_fused(const pa_op *op_r, const pa_op *op_i) {
+  if (!op_r || !op_i || op_r->subs.size() != 1 || op_i->subs.size() != 1 || !op_r->dsubs.empty() || !op_i->dsubs.empty() ||
+      !op_r->msubs.empty() || !op_i->msubs.empty() || op_r->height != op_i->height || op_r->width != op_i->width)
+    return 0;
+  // (the check compares the two restrictions on the host: once per pair)
+  if (op_r->cplx_partner != op_i->id) {
+    op_r->cplx_ok = nd_hex_stream_complex_ok(*op_r->subs[0], *op_i->subs[0]) ? 1 : 0;
+    op_r->cplx_partner = op_i->id;
+  }
+  return op_r->cplx_ok;
+}
+
+int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double *xi, double *yr, double *yi, int ess_policy,
+                       void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op_r && op_i && xr && xi && yr && yi, "null argument");
+    PA_REQUIRE(pa_op_complex_fused(op_r, op_i), "the two operators have no fused complex form (pa_op_complex_fused)");
+    PA_REQUIRE(xr != yr && xr != yi && xi != yr && xi != yi, "in-place apply is not supported");
+    SubOp *sr = op_r->subs[0];
+    const bool masked = ess_policy >= 0;
+    PA_REQUIRE(!masked || (op_r->has_essential && sr->d_perm_s_bc), "pa_op_set_essential has not been called on the real operator");
+    if (!sr->d_ye2) sr->d_ye2 = dev_alloc<double>((size_t)((sr->ne + 3) & ~3) * sr->P);
+    stream_element_coefficients(*op_i->subs[0]);
+    hipStream_t s = (hipStream_t)stream;
+    launch_nd_hex_stream_complex(*sr, *op_i->subs[0], xr, xi, yr, yi, sr->d_ye2, masked, s);
+    launch_et_run_gather(*sr, yr, false, s, xr, masked, ess_policy);
+    launch_et_run_gather(*sr, yi, false, s, xi, masked, ess_policy, sr->d_ye2);
   });
 }
 

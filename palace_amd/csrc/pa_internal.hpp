@@ -269,7 +269,11 @@ void free_stream(SubOp &so);
 void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase = -1);
 void stream_set_interface(SubOp &so, const std::vector<char> &flag);
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
-                          int ess_policy);
+                          int ess_policy, const double *ye = nullptr);
+void stream_element_coefficients(SubOp &so);
+bool nd_hex_stream_complex_ok(const SubOp &sr, const SubOp &si);
+void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
+                                  double *ye_i, bool masked, hipStream_t s);
 void launch_h1_hex_apply(const SubOp &so, const double *x, bool masked, hipStream_t s);
 void launch_h1_hex_qdata(SubOp &so, hipStream_t s);
 void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);
@@ -300,6 +304,9 @@ void launch_mixed_error(const MixedSub &ms, const double *u1, const double *u2, 
 struct pa_geom : pa::Geom {};
 
 struct pa_op {
+  uint64_t id = 0;  // unique per operator object (pa_op_create / coarsen)
+  mutable uint64_t cplx_partner = 0;  // id of the operator the complex-form check below was last made against, and its answer
+  mutable int cplx_ok = 0;
   int height = 0, width = 0;
   bool finalized = false;
   bool has_essential = false;

@@ -54,13 +54,22 @@ struct NDStreamArgs {
   const double *coef;     // metric form: [ne][2] scalar mass / curl-curl coefficient of the element
   const double *x;
   double *y, *ye;
+  // complex form (CPLX): imaginary parts of x, y and of the E-vector, coefficients of the imaginary operator
+  const double *x1, *coef1;
+  double *y1, *ye1;
   NDTab<P1, 4> tab;
 };
 
 // GPOS: where x of the next batch is requested (0 before the transposed passes, 1 / 2 / 3 after their first / second /
 // third component).  Later = fewer live registers, shorter flight.
-template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS>
+// CPLX (metric form only): y = (A_r + i A_i) x for two operators on the same space and geometry whose D differ by the scalar
+// coefficients of their elements only -- (a_r + i a_i)(u_r + i u_i) at every quadrature point.  A batch is two elements times
+// the two parts of x: the even 16-lane groups of a wave carry the real part, the odd ones the imaginary part of the same
+// element, both read the element's index words and q-data (one HBM read), exchange their quadrature values with the
+// neighbouring group once and store to the real / imaginary y and E-vector.  One pass over the geometry data instead of four.
+template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS, bool CPLX = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
+  static_assert(!CPLX || (METRIC && USE_U && USE_C), "the complex form is built on the metric curl-curl + mass kernel");
   constexpr int Q1 = 4;
 #ifdef PA_STREAM_EARLY  // experiment builds
   constexpr bool EARLY_IDX = true;
@@ -94,8 +103,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   // index words of a batch (every array is padded to a multiple of four elements; pad entries read as zero and are
   // stored to E-vector rows nobody gathers)
   // s[0 .. NPL): the slice words (the same word for the 16 lanes of an element), s[NPL], s[NPL + 1]: run starts t, 16 + t
+  const double *xsel = (CPLX && ((lane >> 4) & 1)) ? a.x1 : a.x;  // the part of x this 16-lane group gathers
   auto load_idx = [&](const int bb, const int sub, const int t, int (&s)[NPL + 2], unsigned (&p)[NPK + 1]) {
-    const int e = bb * 4 + sub;
+    const int e = CPLX ? bb * 2 + (sub >> 1) : bb * 4 + sub;
     const uint32_t *ic = a.idxc + (size_t)e * kIdxWords;
 #pragma unroll
     for (int r = 0; r < NPL; r++) s[r] = (int)__builtin_nontemporal_load(&ic[r]);
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       const int pos = low ? 16 * r + 31 - __clz((int)low) : (int)((w >> 21) & 255u);
       int dof = stab[rid] + (t + 16 * r - pos);
       if (!(16 * r + 15 < PP) && t + 16 * r >= PP) dof = 0;  // lanes past the last entry
-      xv[r] = a.x[dof];
+      xv[r] = xsel[dof];
       const int word = dof | ((fw >> (2 * r + 1)) & 1u ? kExclBit : 0) | ((fw >> (18 + r)) & 1u ? kEssBit : 0);
       s[r] = (fw >> (2 * r)) & 1u ? -1 - word : word;
     }
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     int *side = reinterpret_cast<int *>(sm + L::ELEM_PAD);  // index words of this batch, kept for the E^T stores
     int *stab = side + 2 * LDS_SIDE;                        // run starts of the next batch (decode)
     const int lx = L::parity_xor(sub);
-    const int e = b * 4 + sub;
+    const int e = CPLX ? b * 2 + (sub >> 1) : b * 4 + sub;
 
     // q-data of this batch: consumed after the forward contraction
     d2v gq[2 * NG];
@@ -168,8 +178,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       // (read once: non-temporal, so the stream does not displace x / y lines in L2; measured 5 - 7 % on the apply)
       for (int k = 0; k < 2 * NG; k++) gq[k] = __builtin_nontemporal_load(&g[16 * k]);
     }
-    d2v ce = {0.0, 0.0};
+    d2v ce = {0.0, 0.0}, ci = {0.0, 0.0};
     if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
+    if (CPLX) ci = reinterpret_cast<const d2v *>(a.coef1)[e];
 
     // E: sorted entries into their tensor-order slots (x of this batch was requested during the previous one)
 #pragma unroll
@@ -234,14 +245,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       if (METRIC) {
         // H = (w / |detJ|) J^T J {00, 01, 02, 11, 12, 22}, H[6] = |detJ| / w:
         //   (w / detJ) J^T c J = c H,   w detJ adj^T c adj = c (|detJ| / w) adj(H)
+        double cmass = ce[0], ccurl = ce[1];
+        if (CPLX) {
+          // (a_r + i a_i)(u_r + i u_i): this group's part of the product, the other part's values from the neighbouring
+          // group; D is linear in the coefficient, so the geometric matrices below are applied with unit coefficients
+          const double sg = (sub & 1) ? 1.0 : -1.0;
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const double pu = __shfl_xor(U[c][qz], 16, 64), pcu = __shfl_xor(CU[c][qz], 16, 64);
+            U[c][qz] = ce[0] * U[c][qz] + sg * ci[0] * pu;
+            CU[c][qz] = ce[1] * CU[c][qz] + sg * ci[1] * pcu;
+          }
+          cmass = 1.0, ccurl = 1.0;
+        }
         if (USE_U) {
-          const double cm = H[6] * ce[0];
+          const double cm = H[6] * cmass;
           const double m[6] = {cm * (H[3] * H[5] - H[4] * H[4]), cm * (H[2] * H[4] - H[1] * H[5]), cm * (H[1] * H[4] - H[2] * H[3]),
                                cm * (H[0] * H[5] - H[2] * H[2]), cm * (H[1] * H[2] - H[0] * H[4]), cm * (H[0] * H[3] - H[1] * H[1])};
           sym_mv(m, U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
         }
         if (USE_C) {
-          const double m[6] = {ce[1] * H[0], ce[1] * H[1], ce[1] * H[2], ce[1] * H[3], ce[1] * H[4], ce[1] * H[5]};
+          const double m[6] = {ccurl * H[0], ccurl * H[1], ccurl * H[2], ccurl * H[3], ccurl * H[4], ccurl * H[5]};
           sym_mv(m, CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
         }
         __builtin_amdgcn_sched_barrier(0);  // one point at a time: short live ranges
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       const unsigned fl = (unsigned)side[2 * ((PP + 1) / 2) + 16 * NPK + mt] >> (2 * mr);
       const double v = sm[((unsigned)side[2 * ((PP + 1) / 2) + 16 * (mr >> 2) + mt] >> (8 * (mr & 3))) & 255u];
       const int sv = side[m], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
-      double *dst = (fl & 2u) ? a.y + d : a.ye + ((size_t)e * PP + m);
+      double *dst = (fl & 2u) ? ((CPLX && (sub & 1)) ? a.y1 : a.y) + d : ((CPLX && (sub & 1)) ? a.ye1 : a.ye) + ((size_t)e * PP + m);
       *dst = (fl & 1u) ? -v : v;
     }
     wave_sync();  // the LDS strip is reused by the next batch
@@ -406,12 +430,37 @@ bool nd_hex_stream_ok(const SubOp &so) {
   return so.qd->metric || so.qd->ncomp == 6;
 }
 
+// Scalar mass / curl-curl coefficient of every element (coeff_3_qf.h:9-24 resolved on the host; isotropic materials): what the
+// metric form multiplies its geometric matrices with, [ne padded to 4][2]
+void stream_element_coefficients(SubOp &so) {
+  if (so.d_coef_s) return;
+  const int ne = so.ne, nep = (ne + 3) & ~3;
+  const std::vector<int32_t> &attr = so.geom->h_attr;
+  PA_REQUIRE((int)attr.size() == ne, "element attributes missing");
+  const CoeffHost *cm = nullptr, *cc = nullptr;
+  if (so.qf == PA_QF_HDIV_33) cc = &so.c0;
+  if (so.qf == PA_QF_HCURL_33) cm = &so.c0;
+  if (so.qf == PA_QF_HDIVMASS_33) cm = &so.c0, cc = &so.c1;
+  auto value = [&](const CoeffHost *c, int at) {
+    if (!c) return 0.0;
+    int k = 0;
+    if (!c->attr_mat.empty()) {
+      PA_REQUIRE(at >= 1 && at <= (int)c->attr_mat.size(), "element attribute outside the coefficient's attribute map");
+      k = c->attr_mat[at - 1];
+    }
+    return c->mat[(size_t)9 * k];
+  };
+  std::vector<double> coef((size_t)nep * 2, 0.0);
+  for (int e = 0; e < ne; e++) coef[2 * (size_t)e] = value(cm, attr[e]), coef[2 * (size_t)e + 1] = value(cc, attr[e]);
+  so.d_coef_s = dev_upload(coef.data(), coef.size());
+}
+
 // Index arrays of the streaming kernel and the run form of the transpose map (after finalize_exclusive: needs the
 // exclusive flags).  Host work proportional to the index array, once per operator.  Every per-element array is padded
 // to a multiple of four elements (one batch); the pad entries are flagged essential (read as zero).
 void build_stream(SubOp &so) {
   if (so.d_idxc || !(nd_hex_stream_ok(so) || h1_hex_stream_ok(so))) return;
-  const int P = so.P, ne = so.ne, nep = (ne + 3) & ~3;
+  const int P = so.P, ne = so.ne;
   std::vector<uint32_t> ic, pp;
   // (a numbering that breaks an element's dofs into more than kIdxMaxRuns runs keeps the one-shot kernel)
   if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp,
@@ -420,26 +469,7 @@ void build_stream(SubOp &so) {
   so.h_perm_s = pp;
   so.d_idxc = dev_upload(ic.data(), ic.size());
   so.d_perm_s = dev_upload(pp.data(), pp.size());
-  if (so.qd->metric) {  // scalar coefficients per element (coeff_3_qf.h:9-24 resolved on the host)
-    const std::vector<int32_t> &attr = so.geom->h_attr;
-    PA_REQUIRE((int)attr.size() == ne, "element attributes missing");
-    const CoeffHost *cm = nullptr, *cc = nullptr;
-    if (so.qf == PA_QF_HDIV_33) cc = &so.c0;
-    if (so.qf == PA_QF_HCURL_33) cm = &so.c0;
-    if (so.qf == PA_QF_HDIVMASS_33) cm = &so.c0, cc = &so.c1;
-    auto value = [&](const CoeffHost *c, int at) {
-      if (!c) return 0.0;
-      int k = 0;
-      if (!c->attr_mat.empty()) {
-        PA_REQUIRE(at >= 1 && at <= (int)c->attr_mat.size(), "element attribute outside the coefficient's attribute map");
-        k = c->attr_mat[at - 1];
-      }
-      return c->mat[(size_t)9 * k];
-    };
-    std::vector<double> coef((size_t)nep * 2, 0.0);
-    for (int e = 0; e < ne; e++) coef[2 * (size_t)e] = value(cm, attr[e]), coef[2 * (size_t)e + 1] = value(cc, attr[e]);
-    so.d_coef_s = dev_upload(coef.data(), coef.size());
-  }
+  if (so.qd->metric) stream_element_coefficients(so);
 
   std::vector<uint32_t> code;
   std::vector<RunHdr> hdr;
@@ -527,7 +557,7 @@ static int device_cus() {
   return cus;
 }
 
-template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS>
+template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS, bool CPLX = false>
 static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   using L = NDLayout<P1, 4>;
   for (int i = 0; i < HalfTab<P1, 4>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
@@ -541,18 +571,20 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   static const int wg_env = getenv("PALACE_AMD_STREAM_WG") ? atoi(getenv("PALACE_AMD_STREAM_WG")) : 0;
   static const int per_cu_query = [&] {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS>,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX>,
                                                      64 * kWavesPerBlock, lds) != hipSuccess || nb <= 0)
       nb = 8;
     return std::min({nb, MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
   }();
   const int per_cu = wg_env > 0 ? wg_env : per_cu_query;
   const int per_xcd = std::max(1, device_cus() / 8) * per_cu;
-  if (!a.blist) a.nbatch = (so.ne + 3) / 4;  // (else: the length of the list, set by the caller)
+  if (CPLX) a.nbatch = (so.ne + 1) / 2;  // two elements times two parts per batch
+  else if (!a.blist) a.nbatch = (so.ne + 3) / 4;  // (else: the length of the list, set by the caller)
   if (a.nbatch == 0) return;
   a.chunk = (a.nbatch + 7) / 8;
   const int wgx = std::max(1, std::min(per_xcd, (a.chunk + kWavesPerBlock - 1) / kWavesPerBlock));
-  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
+  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s,
+                     a);
   PA_HIP(hipGetLastError());
 }
 
@@ -617,15 +649,55 @@ void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool mask
   }
 }
 
+// ---- complex form: y = (A_r + i A_i) x in one pass ---------------------------------------------------
+// Both operators are metric-form (isotropic materials) H(curl) blocks on the same space and geometry with curl-curl and / or
+// mass terms: they share the index arrays and the q-data and differ by their per-element scalar coefficients only.
+bool nd_hex_stream_complex_ok(const SubOp &sr, const SubOp &si) {
+  static const bool enabled = !(getenv("PALACE_AMD_COMPLEX_FUSED") && atoi(getenv("PALACE_AMD_COMPLEX_FUSED")) == 0);
+  // the real operator provides the kernel's arrays (metric form: the q-data is the geometry's J^T J, shared by every such
+  // operator on it); the imaginary one only its per-element scalars (stream_element_coefficients)
+  auto kind_ok = [](const SubOp &so) {
+    return so.fe_type == PA_FE_HCURL && so.iso && so.q1d == 4 && so.p <= 3 && !so.geom->h_attr.empty() &&
+           (so.qf == PA_QF_HDIV_33 || so.qf == PA_QF_HCURL_33 || so.qf == PA_QF_HDIVMASS_33);
+  };
+  if (!enabled || !kind_ok(sr) || !kind_ok(si)) return false;
+  if (!(sr.d_idxc && sr.d_coef_s && sr.qd && sr.qd->metric)) return false;
+  if (sr.geom != si.geom || sr.ne != si.ne || sr.p != si.p || sr.P != si.P) return false;
+  return sr.h_sidx == si.h_sidx;  // same restriction (host compare; the callers cache the answer)
+}
+
+template <int P1>
+static void launch_complex_p(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
+                             double *ye_i, bool masked, hipStream_t s) {
+  NDStreamArgs<P1> a;
+  a.ne = sr.ne, a.blist = nullptr, a.nbatch = 0;
+  a.idxc = sr.d_idxc;
+  a.perm = masked ? sr.d_perm_s_bc : sr.d_perm_s;
+  a.qdata = sr.qd->d;
+  a.coef = sr.d_coef_s, a.coef1 = si.d_coef_s;
+  a.x = xr, a.x1 = xi, a.y = yr, a.y1 = yi, a.ye = sr.d_ye, a.ye1 = ye_i;
+  launch_gpos<P1, true, true, true, 2, 2, true>(sr, a, s);
+}
+
+void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
+                                  double *ye_i, bool masked, hipStream_t s) {
+  switch (sr.p) {
+    case 1: launch_complex_p<1>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;
+    case 2: launch_complex_p<2>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;
+    case 3: launch_complex_p<3>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;
+    default: throw Error("no streaming H(curl) hex kernel for this order");
+  }
+}
+
 // masked: the run list that owns the essential rows (the element kernel then ran on the _bc index arrays); ess_policy >= 0
 // additionally fuses ParOperator's fix-up y[ess] = x[ess] | 0 into it
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
-                          int ess_policy) {
+                          int ess_policy, const double *ye) {
   const int n = masked ? so.n_shared_bc : so.n_shared;
   if (n == 0) return;
   hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
                      masked ? so.d_rcode_bc : so.d_rcode, reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
-                     masked ? so.d_rpos_bc : so.d_rpos, so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1);
+                     masked ? so.d_rpos_bc : so.d_rpos, ye ? ye : so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1);
   PA_HIP(hipGetLastError());
 }
 

@@ -15,10 +15,17 @@ n = nd.ndofs
 xr, xi = torch.rand(n, dtype=torch.float64, device="cuda"), torch.rand(n, dtype=torch.float64, device="cuda")
 yr, yi = torch.empty_like(xr), torch.empty_like(xr)
 A = linalg.ComplexOperator(ctx, Ar, Ai)
-for _ in range(3): A.mult(xr, xi, yr, yi)
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-torch.cuda.synchronize(); e0.record()
-for _ in range(20): A.mult(xr, xi, yr, yi)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 20
-print(f"complex Mult (Ar = K - w^2 M, Ai = w C), {n} complex dofs: {ms:.4f} ms  {n/ms/1e6:.2f} G complex dof/s")
+# the same system as a ComplexParOperator over the local operators: on one rank its Mult is the one-pass complex kernel
+# (pa_op_mult_complex) when the pair has that form; PALACE_AMD_COMPLEX_FUSED=0 gives the four separate applies
+Ap = linalg.ComplexParOperator(ctx, Ar.local, Ai.local, prob.ess[-1], linalg.DIAG_ONE)
+reps = int(os.environ.get("REPS", "100"))
+for name, f in (("ComplexWrapperOperator over two ParOperators", lambda: A.mult(xr, xi, yr, yi)),
+                ("ComplexParOperator", lambda: Ap.mult(xr, xi, yr, yi))):
+    for _ in range(20): f()
+    with torch.cuda.stream(ctx.torch_stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(reps): f()
+        e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"{name}: Mult (Ar = K - w^2 M, Ai = w C), {n} complex dofs: {ms:.4f} ms  {n/ms/1e6:.2f} G complex dof/s")

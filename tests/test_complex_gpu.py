@@ -73,3 +73,88 @@ def test_complex_wrapper_and_gmres(cylinder_mesh):
     ref = spla.spsolve(Ao, b)
     assert np.linalg.norm(Ao @ xs - b) < 1e-7 * np.linalg.norm(b)
     assert np.linalg.norm(xs - ref) < 1e-6 * np.linalg.norm(ref)
+
+
+FUSED_CHECK = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from palace_amd import ceed, linalg
+from palace_amd.fem.fespace import NDHexSpace
+from palace_amd.fem.mesh import ogrid_cylinder
+p = int(sys.argv[1])
+ctx = linalg.Context()
+mesh = ogrid_cylinder(2, 3)
+mesh.attr[:] = 1 + (np.arange(mesh.ne) %% 2)
+nd = NDHexSpace(mesh, p)
+geom = ceed.GeomFactorData(mesh, 4)
+two = lambda a, b: ceed.coefficient_context(3, attr_mat=[0, 1], mat_coeff=[np.array([a]), np.array([b])])
+Ar = ceed.curlcurlmass_operator(geom, nd, two(-0.9, -0.35), two(1.0, 0.6))
+Ai = ceed.ndmass_operator(geom, nd, two(0.21, 0.05))
+ess = nd.ess_dofs()
+n = nd.ndofs
+rng = np.random.default_rng(3)
+x = [torch.from_numpy(rng.uniform(-1, 1, n)).cuda() for _ in range(2)]
+out = {}
+for tag, e in (("plain", np.zeros(0, np.int32)), ("ess", ess)):
+    A = linalg.ComplexParOperator(ctx, Ar, Ai, e, linalg.DIAG_ONE)
+    yr, yi = torch.empty_like(x[0]), torch.empty_like(x[0])
+    A.mult(x[0], x[1], yr, yi)
+    out[tag] = (yr.cpu().numpy(), yi.cpu().numpy())
+    lr, li = torch.empty_like(x[0]), torch.empty_like(x[0])
+    A.mult(x[0], x[1], lr, li, local=True)  # the L-vector ComplexWrapperOperator (no essential dofs)
+    out[tag + "_local"] = (lr.cpu().numpy(), li.cpu().numpy())
+np.savez(sys.argv[2], fused=ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle),
+         **{k + "_" + c: v[i] for k, v in out.items() for i, c in enumerate("ri")}, xr=x[0].cpu().numpy(), xi=x[1].cpu().numpy())
+print("OK")
+'''
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_fused_complex_apply(p, tmp_path):
+    """y = (A_r + i A_i) x in one pass over the element data (pa_op_mult_complex, SURVEY.md 8(f)-1): the complex streaming
+    kernel against the four separate applies (PALACE_AMD_COMPLEX_FUSED=0, the path of linalg/operator.cpp:98-134) and against the
+    oracle's operators, with two materials, plain and with essential dofs (DIAG_ONE on the real, DIAG_ZERO on the imaginary part)."""
+    import os
+    import subprocess
+    import sys
+
+    from palace_amd.fem.mesh import ogrid_cylinder
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for fused in (1, 0):
+        f = str(tmp_path / f"out{fused}.npz")
+        r = subprocess.run([sys.executable, "-c", FUSED_CHECK % root, str(p), f], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PALACE_AMD_COMPLEX_FUSED=str(fused)))
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+        res[fused] = np.load(f)
+    assert int(res[1]["fused"]) == 1 and int(res[0]["fused"]) == 0
+    for k in ("plain_r", "plain_i", "ess_r", "ess_i", "plain_local_r", "plain_local_i"):
+        a, b = res[1][k], res[0][k]
+        assert np.abs(a - b).max() < 1e-13 * np.abs(b).max(), k
+    # oracle
+    mesh = ogrid_cylinder(2, 3)
+    mesh.attr[:] = 1 + (np.arange(mesh.ne) % 2)
+    nd = NDHexSpace(mesh, p)
+    ogeom = util.oracle_geom(mesh, 4)
+    off, ori = nd.native_restriction()
+    interp, curl = util.dense_tables(nd, 4)
+    two = lambda a, b: po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([a]), np.array([b])])  # noqa: E731
+    Aro = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HDIVMASS, two(-0.9, -0.35), two(1.0, 0.6))
+    Aio = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HCURL, two(0.21, 0.05))
+    xr, xi = res[1]["xr"], res[1]["xi"]
+    z = lambda: np.zeros(nd.ndofs)  # noqa: E731
+    yr = Aro.apply_add(xr, z()) - Aio.apply_add(xi, z())
+    yi = Aio.apply_add(xr, z()) + Aro.apply_add(xi, z())
+    assert np.abs(res[1]["plain_r"] - yr).max() < 1e-12 * np.abs(yr).max()
+    assert np.abs(res[1]["plain_i"] - yi).max() < 1e-12 * np.abs(yi).max()
+    ess = nd.ess_dofs()
+    txr, txi = xr.copy(), xi.copy()
+    txr[ess] = 0.0
+    txi[ess] = 0.0
+    er = Aro.apply_add(txr, z()) - Aio.apply_add(txi, z())
+    ei = Aio.apply_add(txr, z()) + Aro.apply_add(txi, z())
+    er[ess], ei[ess] = xr[ess], xi[ess]
+    assert np.abs(res[1]["ess_r"] - er).max() < 1e-12 * np.abs(er).max()
+    assert np.abs(res[1]["ess_i"] - ei).max() < 1e-12 * np.abs(ei).max()
