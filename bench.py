@@ -204,6 +204,38 @@ def p4_leg(ctx, dofs, reps=20):
     return out
 
 
+def complex_leg(ctx, prob, reps=50):
+    """BASELINE config 3's operator shape on the bench mesh, N = 1: y = (K - w^2 eps M + i w sigma M) x through
+    ComplexParOperator::Mult -- both parts in one pass over the element data (pa_op_mult_complex, SURVEY.md 8(f)-1)."""
+    import torch
+
+    from palace_amd import ceed, linalg
+
+    nd = prob.spaces[-1]
+    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([-2.08 * 0.3])])
+    cond = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([0.05])])
+    Ar = ceed.curlcurlmass_operator(prob.geom, nd, mass, ceed.coefficient_context(3))
+    Ai = ceed.ndmass_operator(prob.geom, nd, cond)
+    A = linalg.ComplexParOperator(ctx, Ar, Ai, prob.ess[-1], linalg.DIAG_ONE)
+    n = nd.ndofs
+    xr, xi = (torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(2))
+    yr, yi = torch.empty_like(xr), torch.empty_like(xr)
+    for _ in range(10):
+        A.mult(xr, xi, yr, yi)
+    with torch.cuda.stream(ctx.torch_stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            A.mult(xr, xi, yr, yi)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fused = bool(ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle))
+    return {"workload": f"ComplexParOperator::Mult, A = (K - w^2 eps M) + i w sigma M, ND p=3, {n} complex dofs",
+            "one_pass": fused, "ms": ms, "complex_dof_per_s": n / (ms * 1e-3)}
+
+
 def tets_leg(order, n, reps=20):
     """The non-tensor path (dense tables on the FP64 matrix cores): Nedelec tets of the same order on a
     Kuhn-split cube, curl-curl and curl-curl+mass `ceed::Operator::Mult`, order-2p symmetric quadrature
@@ -455,6 +487,9 @@ def main():
     p4 = None
     if rank == 0 and world == 1 and not args.no_p4:
         p4 = p4_leg(ctx, args.dofs)
+    cplx = None
+    if rank == 0 and world == 1 and not args.no_p4:
+        cplx = complex_leg(ctx, prob)
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -474,7 +509,7 @@ def main():
                        "scaling_mode": ("strong: one ~10M-dof cylinder cut into N equal z-slabs" if args.scaling == "strong"
                                         else "weak: one z-slab of the cylinder per GPU, same element count per GPU"),
                        "parallelism": f"element partition x{world}, RCCL halo (P / P^T) + allreduce dots"},
-            "pre_warm_steps": args.pre_warm, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "tets_mfma": tets,
+            "pre_warm_steps": args.pre_warm, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "tets_mfma": tets,
             "setup_s": t_setup,
         }
         print(json.dumps(out), flush=True)

@@ -321,15 +321,15 @@ ComplexWrapperOperator::ComplexWrapperOperator(const Context &ctx, const Operato
   width = Ar ? Ar->Width() : Ai->Width();
   t_.SetSize(height);
   const auto *cr = dynamic_cast<const ceed::Operator *>(Ar), *ci = dynamic_cast<const ceed::Operator *>(Ai);
-  fused_ = cr && ci && ceed::Operator::ComplexFused(*cr, *ci);
+  fused_ = cr && ci && ceed::Operator::ComplexFused(*cr, *ci) != 0;
   const auto *pr = dynamic_cast<const ParOperator *>(Ar), *pi = dynamic_cast<const ParOperator *>(Ai);
   if (pr && pi && !pr->GetHalo() && !pi->GetHalo()) {
     const auto *lr = dynamic_cast<const ceed::Operator *>(&pr->LocalOperator());
     const auto *li = dynamic_cast<const ceed::Operator *>(&pi->LocalOperator());
     const int ne = pr->NumEssentialTrueDofs();
-    bool same = lr && li && ne == pi->NumEssentialTrueDofs() && (ne == 0 || pr->FusesEssential()) &&
-                (ne == 0 || pi->GetDiagonalPolicy() == ParOperator::DiagonalPolicy::DIAG_ZERO) &&
-                ceed::Operator::ComplexFused(*lr, *li);
+    const int kind = (lr && li) ? ceed::Operator::ComplexFused(*lr, *li) : 0;
+    bool same = kind != 0 && ne == pi->NumEssentialTrueDofs() && (ne == 0 || (kind == 1 && pr->FusesEssential())) &&
+                (ne == 0 || pi->GetDiagonalPolicy() == ParOperator::DiagonalPolicy::DIAG_ZERO);
     if (same && ne) {  // the two lists, once
       std::vector<int32_t> a((size_t)ne), b((size_t)ne);
       PA_HIP(hipMemcpy(a.data(), pr->GetEssentialTrueDofs(), sizeof(int32_t) * ne, hipMemcpyDeviceToHost));
@@ -497,8 +497,10 @@ ComplexParOperator::ComplexParOperator(const Context &ctx, const Operator *Ar, c
 void ComplexParOperator::UpdateFused() {
   fused_r_ = fused_i_ = nullptr;
   const auto *cr = dynamic_cast<const ceed::Operator *>(Ar_), *ci = dynamic_cast<const ceed::Operator *>(Ai_);
-  if (halo_ || !cr || !ci || !ceed::Operator::ComplexFused(*cr, *ci)) return;
-  if (n_ess_ && !(RAPr_ && RAPr_->FusesEssential())) return;  // (another wrapper owns the operator's essential tables)
+  const int kind = (!halo_ && cr && ci) ? ceed::Operator::ComplexFused(*cr, *ci) : 0;
+  if (!kind) return;
+  // essential dofs inside the kernel: the hexahedral form only, and only if this wrapper's list is the one fused into Ar
+  if (n_ess_ && !(kind == 1 && RAPr_ && RAPr_->FusesEssential())) return;
   fused_r_ = cr, fused_i_ = ci;
 }
 ComplexParOperator::~ComplexParOperator() {
@@ -566,7 +568,8 @@ void ComplexParOperator::Mult(const ComplexVector &x, ComplexVector &y) const {
                                   n_ess_ ? (policy_ == ParOperator::DiagonalPolicy::DIAG_ONE ? 1 : 0) : -1);
       return;
     }
-    return RAP_->Mult(x, y);
+    // (a fused local operator without fused essential dofs -- dense blocks: copy / mask / apply / fix below)
+    if (!A_->Fused()) return RAP_->Mult(x, y);
   }
   Prolongate(x, lx_);
   A_->Mult(lx_, ly_);

@@ -104,6 +104,7 @@ public:
   ComplexWrapperOperator(const Context &ctx, const Operator *Ar, const Operator *Ai);
   const Operator *Real() const override { return Ar_; }
   const Operator *Imag() const override { return Ai_; }
+  bool Fused() const { return fused_; }  // Mult is one pass over the element data for both parts
   void AssembleDiagonal(ComplexVector &diag) const override;
   void Mult(const ComplexVector &x, ComplexVector &y) const override;
   void MultTranspose(const ComplexVector &x, ComplexVector &y) const override;

@@ -205,7 +205,8 @@ public:
   bool MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const;
   // y = (Ar + i Ai) x in one pass over the element data (pa_op_mult_complex); ess_policy -1: plain, 0 / 1: with Ar's fused
   // essential list, rows set to 0 / x
-  static bool ComplexFused(const Operator &Ar, const Operator &Ai) { return pa_op_complex_fused(Ar.op_, Ai.op_) != 0; }
+  // 0: no such form; 1: tensor hexahedra (essential dofs can be fused); 2: dense tables (plain form only)
+  static int ComplexFused(const Operator &Ar, const Operator &Ai) { return pa_op_complex_fused(Ar.op_, Ai.op_); }
   static void MultComplex(const Operator &Ar, const Operator &Ai, const Vector &xr, const Vector &xi, Vector &yr, Vector &yi,
                           int ess_policy = -1);
   // two right-hand sides in one pass over the element data (pa_op_mult2 / pa_op_mult2_essential_diag)

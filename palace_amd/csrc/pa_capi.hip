@@ -893,12 +893,15 @@ int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *strea
 }
 
 int pa_op_complex_fused(const pa_op *op_r, const pa_op *op_i) {
-  if (!op_r || !op_i || op_r->subs.size() != 1 || op_i->subs.size() != 1 || !op_r->dsubs.empty() || !op_i->dsubs.empty() ||
-      !op_r->msubs.empty() || !op_i->msubs.empty() || op_r->height != op_i->height || op_r->width != op_i->width)
+  if (!op_r || !op_i || !op_r->msubs.empty() || !op_i->msubs.empty() || op_r->height != op_i->height || op_r->width != op_i->width)
     return 0;
+  const bool hex = op_r->subs.size() == 1 && op_i->subs.size() == 1 && op_r->dsubs.empty() && op_i->dsubs.empty();
+  const bool dense = op_r->dsubs.size() == 1 && op_i->dsubs.size() == 1 && op_r->subs.empty() && op_i->subs.empty();
+  if (!hex && !dense) return 0;
   // (the check compares the two restrictions on the host: once per pair)
   if (op_r->cplx_partner != op_i->id) {
-    op_r->cplx_ok = nd_hex_stream_complex_ok(*op_r->subs[0], *op_i->subs[0]) ? 1 : 0;
+    op_r->cplx_ok = hex ? (nd_hex_stream_complex_ok(*op_r->subs[0], *op_i->subs[0]) ? 1 : 0)
+                        : (dense_complex_ok(*op_r->dsubs[0], *op_i->dsubs[0]) ? 2 : 0);
     op_r->cplx_partner = op_i->id;
   }
   return op_r->cplx_ok;
@@ -908,8 +911,18 @@ int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double 
                        void *stream) {
   return guarded([&] {
     PA_REQUIRE(op_r && op_i && xr && xi && yr && yi, "null argument");
-    PA_REQUIRE(pa_op_complex_fused(op_r, op_i), "the two operators have no fused complex form (pa_op_complex_fused)");
+    const int kind = pa_op_complex_fused(op_r, op_i);
+    PA_REQUIRE(kind, "the two operators have no fused complex form (pa_op_complex_fused)");
     PA_REQUIRE(xr != yr && xr != yi && xi != yr && xi != yi, "in-place apply is not supported");
+    if (kind == 2) {  // dense tables (tetrahedra, ...): plain form only
+      PA_REQUIRE(ess_policy < 0, "the complex form of dense blocks has no fused essential-dof handling (pa_op_complex_fused = 2)");
+      DenseSub *dr = op_r->dsubs[0];
+      if (!dr->d_ye2) dr->d_ye2 = dev_alloc<double>((size_t)dr->nb * dr->KP * 64);
+      launch_dense_complex(*dr, *op_i->dsubs[0], xr, xi, dr->d_ye2, (hipStream_t)stream);
+      launch_dense_gather(*dr, yr, false, (hipStream_t)stream);
+      launch_dense_gather(*dr, yi, false, (hipStream_t)stream, dr->d_ye2);
+      return;
+    }
     SubOp *sr = op_r->subs[0];
     const bool masked = ess_policy >= 0;
     PA_REQUIRE(!masked || (op_r->has_essential && sr->d_perm_s_bc), "pa_op_set_essential has not been called on the real operator");

@@ -112,6 +112,12 @@ struct DenseArgs {
   const double *qdata;  // packed pre-assembled D: [nb][ncq][Qpad][16]
   int ncq, Q4;  // q-data components and its point stride (Q rounded up to a multiple of 4)
   const uint8_t *affine;  // non-null: every element has a constant Jacobian, D_q = (w_q / w_0) D_0
+  // complex form (CPLX): imaginary parts of x and of the E-vector; packed D of the imaginary operator with the offsets of its
+  // mass / curl-curl components (-1: no such term)
+  const double *x1;
+  double *ye1;
+  const double *qdata_i;
+  int ncq_i, qi_mass, qi_curl;
   const double *wrel;     // [Q4] w_q / w_0
   int dbg;  // ablation bits (PA_ABLATION builds only)
   const double *x;
@@ -404,7 +410,8 @@ __device__ __forceinline__ void dense_D_packed(const double *m, double *v) {
 template <int PT, int MODE, int F>
 __device__ __forceinline__ void resident_field(const double *__restrict__ Lf, const double *__restrict__ Lb, const int,
                                                const double (&u)[4 * PT], const double (*qd)[6],
-                                               double4_t (&yacc)[PT], const double *__restrict__ wrel = nullptr) {
+                                               double4_t (&yacc)[PT], const double *__restrict__ wrel = nullptr,
+                                               const double *qdi = nullptr, const double sg = 0.0) {
   using FT = FieldTraits<MODE, F>;
   constexpr int NC = FT::NC, KPMAX = 4 * PT, S = ResidentStride<PT>::S, KP = KPMAX;
   double4_t acc[NC];
@@ -424,7 +431,17 @@ __device__ __forceinline__ void resident_field(const double *__restrict__ Lf, co
 #pragma unroll
     for (int k = 0; k < NC; k++) v[k] = acc[(gl * NC + k) >> 2][(gl * NC + k) & 3];
     if (wrel) {
-      dense_D_packed<MODE, F>(qd[0], v);
+      if (qdi) {  // complex form: (D_r + i D_i)(v_r + i v_i), the other part of v from the lane of the same element 8 columns away
+        double vp[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) vp[k] = __shfl_xor(v[k], 8, 64);
+        dense_D_packed<MODE, F>(qd[0], v);
+        dense_D_packed<MODE, F>(qdi, vp);
+#pragma unroll
+        for (int k = 0; k < NC; k++) v[k] += sg * vp[k];
+      } else {
+        dense_D_packed<MODE, F>(qd[0], v);
+      }
       const double w = wrel[4 * gl];
 #pragma unroll
       for (int k = 0; k < NC; k++) v[k] *= w;
@@ -455,9 +472,14 @@ __device__ __forceinline__ void load_qd(const double *__restrict__ q, const size
 // AFFINE: every block consists of elements with a constant Jacobian (dense_affine_kernel): the D of a point is the D of point 0
 // times the relative quadrature weight -- 6 values per field and element instead of 6 Q, and no q-data registers to rotate.
 constexpr int kAffWaves = 12;  // the affine form needs fewer registers: three waves per SIMD
-template <int PT, int MODE, bool AFFINE>
-__global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dense_apply_resident_kernel(const DenseArgs a, const int rows) {
-  constexpr int NW = AFFINE ? kAffWaves : kResWaves;
+// CPLX (affine curl-curl + mass blocks): y = (A_r + i A_i) x for two operators on the same space and geometry.  A work unit is half
+// an element block: the 16 element columns of the matrix-core products carry 8 elements x {real, imaginary} part of x; both
+// parts read the element's index words and the D of both operators (one HBM read), the tables in LDS serve both as before,
+// and the D stage combines the two parts across the columns of an element.  One pass instead of four.
+template <int PT, int MODE, bool AFFINE, bool CPLX = false>
+__global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1) void dense_apply_resident_kernel(const DenseArgs a, const int rows) {
+  static_assert(!CPLX || (AFFINE && MODE == MODE_CURLMASS && PT <= 3), "complex form: affine curl-curl + mass blocks");
+  constexpr int NW = (AFFINE && !CPLX) ? kAffWaves : kResWaves;
   using M = ModeTraits<MODE>;
   using F0 = FieldTraits<MODE, 0>;
   using F1 = FieldTraits<MODE, 1>;
@@ -481,6 +503,15 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
   const double *Lb = L + kq * S + j;   // transposed operand of this lane: row 4 pi + kq, column 16 pt + i
   const size_t cs = (size_t)a.Q4 * kEB;
   const int ngroups = a.Q4 / 4;
+  // work units: element blocks, or (CPLX) half blocks -- unit w is columns 8 (w & 1) .. + 7 of block w >> 1, and lane (kq, j)
+  // works on element column 8 (w & 1) + (j & 7), part j >> 3
+  const int nunits = CPLX ? 2 * a.nb : a.nb;
+  const int j8 = j & 7;
+  auto ublock = [&](const int w) { return (size_t)(CPLX ? w >> 1 : w); };
+  auto ucol = [&](const int w) { return CPLX ? 8 * (w & 1) + j8 : j; };          // element column in the block's arrays
+  auto ulane = [&](const int w) { return CPLX ? kq * 16 + 8 * (w & 1) + j8 : lane; };  // position in a [.][64] row
+  const double *xsel = (CPLX && (j >> 3)) ? a.x1 : a.x;
+  const double part_sign = (j >> 3) ? 1.0 : -1.0;  // real part: - A_i x_i, imaginary part: + A_i x_r
 
   // Software pipeline over the wave's blocks (up to 16 dof slots per lane: beyond that the extra registers spill): the index
   // words of the next block are requested while the current one is in the matrix cores, its x values once the products
@@ -492,16 +523,26 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
   // likewise the first chunk of q-data and the curl-orientation words of the next block (values the compiler cannot hold in
   // vector registers go to the accumulation registers, which two waves per SIMD leave free)
   double qdn[4][6];
+  double qdi[CPLX ? 2 : 1][6];  // complex form: point-0 D of the imaginary operator {mass, curl-curl}
   int con[PREFETCH_X ? KPMAX : 1];
-  // first chunk of field 0 of block bq, or for an affine block the point-0 values of both fields (raw, scaled at use)
-  auto request_qd = [&](const size_t bq, double (&out)[4][6]) {
-    const double *qb = a.qdata + bq * a.ncq * cs;
+  // first chunk of field 0 of unit w, or for an affine block the point-0 values of both fields (raw, scaled at use)
+  auto request_qd = [&](const int w, double (&out)[4][6]) {
+    const double *qb = a.qdata + ublock(w) * a.ncq * cs;
     if (AFFINE) {
+      const int col = ucol(w);
 #pragma unroll
-      for (int k = 0; k < NQ0; k++) out[0][k] = qb[k * cs + j];
+      for (int k = 0; k < NQ0; k++) out[0][k] = qb[k * cs + col];
       if (NF == 2) {
 #pragma unroll
-        for (int k = 0; k < NQ1; k++) out[1][k] = qb[(NQ0 + k) * cs + j];
+        for (int k = 0; k < NQ1; k++) out[1][k] = qb[(NQ0 + k) * cs + col];
+      }
+      if (CPLX) {
+        const double *qi = a.qdata_i + ublock(w) * a.ncq_i * cs + col;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          qdi[0][k] = a.qi_mass >= 0 ? qi[(a.qi_mass + k) * cs] : 0.0;
+          qdi[CPLX ? 1 : 0][k] = a.qi_curl >= 0 ? qi[(a.qi_curl + k) * cs] : 0.0;
+        }
       }
     } else {
       load_qd<MODE, 0>(qb + lane, cs, ngroups, out);
@@ -514,27 +555,28 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
       if (s < KP) {
         const int sg = sg_[s];
         const int d = sg >= 0 ? sg : -1 - sg;
-        const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
+        const double xv = (d & kEssBit) ? 0.0 : xsel[d & ~kEssBit];
         out[s] = sg >= 0 ? xv : -xv;
       }
     }
   };
   if (PREFETCH_IDX) {
-    const int b0 = blockIdx.x * NW + wave;
-    const int32_t *idx0 = a.idx + (size_t)(b0 < a.nb ? b0 : 0) * KP * 64;
+    const int b0 = blockIdx.x * NW + wave, w0 = b0 < nunits ? b0 : 0;
+    const int32_t *idx0 = a.idx + ublock(w0) * KP * 64 + ulane(w0);
 #pragma unroll
-    for (int s = 0; s < KPMAX; s++) sgn[s] = (s < KP) ? idx0[s * 64 + lane] : 0;
+    for (int s = 0; s < KPMAX; s++) sgn[s] = (s < KP) ? idx0[s * 64] : 0;
     if (PREFETCH_X) {
       gather_x(sgn, un);
-      const size_t bq = (size_t)(b0 < a.nb ? b0 : 0);
-      request_qd(bq, qdn);
+      request_qd(w0, qdn);
       if (a.co) {
 #pragma unroll
-        for (int s = 0; s < KPMAX; s++) con[s] = a.co[bq * KP * 64 + s * 64 + lane];
+        for (int s = 0; s < KPMAX; s++) con[s] = a.co[ublock(w0) * KP * 64 + s * 64 + ulane(w0)];
       }
     }
   }
-  for (int b = blockIdx.x * NW + wave; b < a.nb; b += gridDim.x * NW) {
+  for (int b = blockIdx.x * NW + wave; b < nunits; b += gridDim.x * NW) {
+    const size_t bb = ublock(b);  // the element block of this unit
+    const int gln = ulane(b);     // this lane's position in its [.][64] rows
     // ---- E
     double u[KPMAX];
 #pragma unroll
@@ -545,24 +587,24 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
           u[s] = un[s];
           continue;
         }
-        const int sg = PREFETCH_IDX ? sgn[s] : a.idx[(size_t)b * KP * 64 + s * 64 + lane];
+        const int sg = PREFETCH_IDX ? sgn[s] : a.idx[bb * KP * 64 + s * 64 + gln];
         const int d = sg >= 0 ? sg : -1 - sg;
 #ifdef PA_ABLATION
-        const double xv = (a.dbg & 1) ? (double)d : ((d & kEssBit) ? 0.0 : a.x[d & ~kEssBit]);
+        const double xv = (a.dbg & 1) ? (double)d : ((d & kEssBit) ? 0.0 : xsel[d & ~kEssBit]);
 #else
-        const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
+        const double xv = (d & kEssBit) ? 0.0 : xsel[d & ~kEssBit];
 #endif
         u[s] = sg >= 0 ? xv : -xv;
       }
     }
 #ifdef PA_ABLATION
-    const double *q = a.qdata + ((a.dbg & 2) ? (size_t)0 : (size_t)b * a.ncq * cs) + lane;
+    const double *q = a.qdata + ((a.dbg & 2) ? (size_t)0 : bb * a.ncq * cs) + lane;
 #else
-    const double *q = a.qdata + (size_t)b * a.ncq * cs + lane;
+    const double *q = a.qdata + bb * a.ncq * cs + lane;
 #endif
     double qd[4][6];
     if (AFFINE) {  // qdn[0], qdn[1]: point-0 values of the two fields, kept until the next request
-      if (!PREFETCH_X) request_qd((size_t)b, qdn);
+      if (!PREFETCH_X) request_qd(b, qdn);
     } else if (!PREFETCH_X) {
       load_qd<MODE, 0>(q, cs, ngroups, qd);
     } else {
@@ -572,9 +614,9 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
         for (int k = 0; k < NQ0; k++) qd[gl][k] = qdn[gl][k];
     }
 #ifdef PA_ABLATION
-    const uint16_t *co = (a.co && !(a.dbg & 16)) ? a.co + (size_t)b * KP * 64 : nullptr;
+    const uint16_t *co = (a.co && !(a.dbg & 16)) ? a.co + bb * KP * 64 : nullptr;
 #else
-    const uint16_t *co = a.co ? a.co + (size_t)b * KP * 64 : nullptr;
+    const uint16_t *co = a.co ? a.co + bb * KP * 64 : nullptr;
 #endif
     if (co) {
 #pragma unroll
@@ -584,7 +626,7 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
 #pragma unroll
       for (int s = 0; s < KPMAX; s++) {
         if (s < KP) {
-          const int c = PREFETCH_X ? con[s] : (int)co[s * 64 + lane];
+          const int c = PREFETCH_X ? con[s] : (int)co[s * 64 + gln];
           const int dof = 4 * s + kq;
           // out-of-range neighbours have a zero coefficient: clamp the address instead of branching
           const double lo = sm[max(dof - 1, 0) * 16 + j];
@@ -598,15 +640,23 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
 #pragma unroll
     for (int pt = 0; pt < PT; pt++) yacc[pt] = double4_t{0.0, 0.0, 0.0, 0.0};
     const int bn = b + (int)gridDim.x * NW;
-    const size_t bnc = (size_t)(bn < a.nb ? bn : b);  // the next block (clamped on the last one)
+    const int bnc = bn < nunits ? bn : b;  // the next unit (clamped on the last one)
+    // complex form: the D of the imaginary operator is needed until the products below are done; its next request overwrites it
+    double qdic[CPLX ? 2 : 1][6];
+    if (CPLX) {
+#pragma unroll
+      for (int f = 0; f < (CPLX ? 2 : 1); f++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) qdic[f][k] = qdi[f][k];
+    }
     if (PREFETCH_IDX) {  // its index words
-      const int32_t *idxn = a.idx + bnc * KP * 64;
+      const int32_t *idxn = a.idx + ublock(bnc) * KP * 64 + ulane(bnc);
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
-        if (s < KP) sgn[s] = idxn[s * 64 + lane];
+        if (s < KP) sgn[s] = idxn[s * 64];
       if (PREFETCH_X && co) {
 #pragma unroll
-        for (int s = 0; s < KPMAX; s++) con[s] = a.co[bnc * KP * 64 + s * 64 + lane];
+        for (int s = 0; s < KPMAX; s++) con[s] = a.co[ublock(bnc) * KP * 64 + s * 64 + ulane(bnc)];
       }
     }
 
@@ -624,9 +674,10 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
       const int r0 = c * NCT * 16;
       if (AFFINE) {
         const double *wc = wl + 16 * c + kq;
-        resident_field<PT, MODE, 0>(Lf + r0 * S, Lb + r0 * S, KP, u, qdn, yacc, wc);
+        resident_field<PT, MODE, 0>(Lf + r0 * S, Lb + r0 * S, KP, u, qdn, yacc, wc, CPLX ? qdic[0] : nullptr, part_sign);
         if (NF == 2)
-          resident_field<PT, MODE, 1>(Lf + (r0 + 16 * F0::NC) * S, Lb + (r0 + 16 * F0::NC) * S, KP, u, qdn + 1, yacc, wc);
+          resident_field<PT, MODE, 1>(Lf + (r0 + 16 * F0::NC) * S, Lb + (r0 + 16 * F0::NC) * S, KP, u, qdn + 1, yacc, wc,
+                                      CPLX ? qdic[CPLX ? 1 : 0] : nullptr, part_sign);
       } else if (NF == 1) {
         double qn[4][6];
         if (c + 1 < a.nch) load_qd<MODE, 0>(q + 16 * (c + 1) * kEB, cs, ngroups - 4 * (c + 1), qn);
@@ -653,9 +704,9 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
 
     // ---- E^T, first half
 #ifdef PA_ABLATION
-    double *ye = a.ye + ((a.dbg & 8) ? (size_t)(blockIdx.x * NW + wave) : (size_t)b) * KP * 64;
+    double *ye = a.ye + ((a.dbg & 8) ? (size_t)(blockIdx.x * NW + wave) : bb) * KP * 64;
 #else
-    double *ye = a.ye + (size_t)b * KP * 64;
+    double *ye = ((CPLX && (j >> 3)) ? a.ye1 : a.ye) + bb * KP * 64;
 #endif
     if (co) {
 #pragma unroll
@@ -666,16 +717,16 @@ __global__ __launch_bounds__(64 * (AFFINE ? kAffWaves : kResWaves), 1) void dens
       for (int s = 0; s < KPMAX; s++) {
         if (s < KP) {
           const int dof = 4 * s + kq;
-          const int cm = co[s * 64 + lane];
-          ye[s * 64 + lane] = co_field(cm, 1) * yacc[s >> 2][s & 3] + co_field(cm, 3) * sm[max(dof - 1, 0) * 16 + j] +
-                              co_field(cm, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
+          const int cm = co[s * 64 + gln];
+          ye[s * 64 + gln] = co_field(cm, 1) * yacc[s >> 2][s & 3] + co_field(cm, 3) * sm[max(dof - 1, 0) * 16 + j] +
+                             co_field(cm, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
         }
       }
       wave_sync();
     } else {
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
-        if (s < KP) ye[s * 64 + lane] = yacc[s >> 2][s & 3];
+        if (s < KP) ye[s * 64 + gln] = yacc[s >> 2][s & 3];
     }
   }
 }
@@ -1057,6 +1108,7 @@ DenseArgs make_args(const DenseSub &ds) {
   a.idx = ds.d_idx, a.co = ds.d_co, a.geom = ds.geom->d_geom, a.qw = ds.geom->d_qw, a.Tf = ds.d_Tf, a.Tt = ds.d_Tt;
   a.L = ds.d_L, a.qdata = ds.d_qdata, a.ncq = ds.ncq, a.Q4 = (ds.Q + 3) / 4 * 4;
   a.affine = ds.d_affine, a.wrel = ds.d_wrel;
+  a.x1 = nullptr, a.ye1 = nullptr, a.qdata_i = nullptr, a.ncq_i = 0, a.qi_mass = a.qi_curl = -1;
   a.dbg = 0;
 #ifdef PA_ABLATION
   a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
@@ -1191,6 +1243,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   }
   ds->d_idx = dev_upload(idx.data(), nslot);
   if (r.curl_orients) ds->d_co = dev_upload(co.data(), nslot);
+  ds->h_co = co;
   // transpose map for the gather form of E^T (counting sort by dof, element order preserved)
   {
     std::vector<int32_t> tptr((size_t)r.lsize + 1, 0), tent((size_t)ne * P);
@@ -1240,6 +1293,15 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   }
   ds->d_Tf = dev_upload(Tf.data(), Tf.size());
   ds->d_Tt = dev_upload(Tt.data(), Tt.size());
+  {  // position-weighted checksums of the two tables (two sub-operators on "the same basis" are compared through them)
+    auto chk = [&](const double *t, int nc) {
+      double c = 0.0;
+      if (t)
+        for (size_t i = 0; i < (size_t)nc * Q * P; i++) c += t[i] * (double)(1 + i % 1021);
+      return c;
+    };
+    ds->chk_interp = chk(b.interp, nci), ds->chk_deriv = chk(b.deriv, ncd);
+  }
   // plain copies for the diagonal kernel
   if (nci) ds->d_interp = dev_upload(b.interp, (size_t)nci * Q * P);
   if (ncd) ds->d_deriv = dev_upload(b.deriv, (size_t)ncd * Q * P);
@@ -1392,7 +1454,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
 }
 
 void free_dense_sub(DenseSub *ds) {
-  if (ds) hipFree(ds->d_affine), hipFree(ds->d_wrel);
+  if (ds) hipFree(ds->d_affine), hipFree(ds->d_wrel), hipFree(ds->d_ye2);
   if (!ds) return;
   hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co);
   hipFree(ds->d_Tf), hipFree(ds->d_Tt), hipFree(ds->d_interp), hipFree(ds->d_deriv);
@@ -1444,7 +1506,56 @@ void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStr
   PA_HIP(hipGetLastError());
 }
 
-void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s) {
+// ---- complex form (SURVEY.md 8(f)-1 on the non-tensor path) ---------------------------------------------------------------
+// dr: curl-curl + mass in the affine resident form (the kernel's tables, index arrays, E-vector); di: mass, curl-curl or both on
+// the same space and geometry, also affine (only the D of its first point is read)
+bool dense_complex_ok(const DenseSub &dr, const DenseSub &di) {
+  static const bool enabled = !(getenv("PALACE_AMD_COMPLEX_FUSED") && atoi(getenv("PALACE_AMD_COMPLEX_FUSED")) == 0);
+  if (!enabled || dr.fe_type != PA_FE_HCURL || di.fe_type != PA_FE_HCURL || dr.geom != di.geom || dr.geom->dim != 3) return false;
+  if (dr.mode != MODE_CURLMASS || !dr.d_L || !dr.d_affine || dr.PT > 3) return false;
+  if (!(di.mode == MODE_CURLMASS || di.mode == MODE_VMASS || di.mode == MODE_CURL) || !di.d_qdata || !di.d_affine) return false;
+  if (dr.ne != di.ne || dr.P != di.P || dr.Q != di.Q || dr.lsize != di.lsize) return false;
+  if (di.mode != MODE_CURL && di.chk_interp != dr.chk_interp) return false;
+  if (di.mode != MODE_VMASS && di.chk_deriv != dr.chk_deriv) return false;
+  return dr.h_idx == di.h_idx && dr.h_co == di.h_co;  // same restriction (host compare; the callers cache the answer)
+}
+
+template <int PT>
+static void launch_resident_complex_pt(const DenseSub &dr, const DenseArgs &a, hipStream_t s) {
+  const int rows = dr.L_rows;
+  const size_t shm = sizeof(double) * ((size_t)(a.Q4 + 31) / 32 * 32 + (size_t)rows * ResidentStride<PT>::S +
+                                      (dr.d_co ? (size_t)kResWaves * 4 * PT * 64 : 0));
+  int grid = (2 * dr.nb + kResWaves - 1) / kResWaves;
+  if (grid > dr.num_cu) grid = dr.num_cu;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);
+}
+
+void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s) {
+  DenseArgs a = make_args(dr);
+  a.x = xr, a.x1 = xi, a.ye1 = ye_i;
+  a.qdata_i = di.d_qdata, a.ncq_i = di.ncq;
+  a.qi_mass = di.mode == MODE_CURL ? -1 : 0;
+  a.qi_curl = di.mode == MODE_CURL ? 0 : (di.mode == MODE_CURLMASS ? 6 : -1);
+  switch (dr.PT) {
+    case 1: launch_resident_complex_pt<1>(dr, a, s); break;
+    case 2: launch_resident_complex_pt<2>(dr, a, s); break;
+    case 3: launch_resident_complex_pt<3>(dr, a, s); break;
+    default: throw Error("complex dense kernel not instantiated for this element size");
+  }
+  PA_HIP(hipGetLastError());
+}
+
+void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye) {
+  if (ye) {
+    launch_et_gather_raw(ds.lsize, ds.d_tptr, ds.d_tent, ye, y, accumulate, s);
+    return;
+  }
   launch_et_gather_raw(ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye, y, accumulate, s);
 }
 

@@ -211,6 +211,9 @@ struct DenseSub {
   double *d_Tf = nullptr, *d_Tt = nullptr;  // MFMA A-operand fragments of the tables (forward / transposed)
   double *d_L = nullptr;       // LDS-resident form of the tables (fast path) or nullptr
   double *d_qdata = nullptr;   // packed pre-assembled D [nb][ncq][Qpad][16] (fast path)
+  std::vector<uint16_t> h_co;  // host copy of d_co (restriction compare of the complex form)
+  double chk_interp = 0.0, chk_deriv = 0.0;  // checksums of the basis tables (same)
+  double *d_ye2 = nullptr;     // second E-vector (imaginary part of the complex form), allocated on first use
   uint8_t *d_affine = nullptr; // [nb] blocks whose elements all have a constant Jacobian (D_q = (w_q / w_0) D_0) or nullptr
   double *d_wrel = nullptr;    // [Q4] w_q / w_0
   int n_affine = 0;
@@ -285,7 +288,9 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
 void free_dense_sub(DenseSub *ds);
 void dense_set_essential(DenseSub &ds, const std::vector<char> &flag);
 void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStream_t s);
-void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s);
+void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye = nullptr);
+bool dense_complex_ok(const DenseSub &dr, const DenseSub &di);
+void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s);
 void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s);
 void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y,
                           bool accumulate, hipStream_t s, const int32_t *list = nullptr, const double *x = nullptr,

@@ -158,3 +158,87 @@ def test_fused_complex_apply(p, tmp_path):
     er[ess], ei[ess] = xr[ess], xi[ess]
     assert np.abs(res[1]["ess_r"] - er).max() < 1e-12 * np.abs(er).max()
     assert np.abs(res[1]["ess_i"] - ei).max() < 1e-12 * np.abs(ei).max()
+
+
+FUSED_TET_CHECK = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from palace_amd import ceed, linalg
+from palace_amd.fem import tet
+from tests import util
+p, kind, imode = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+ctx = linalg.Context()
+mesh = tet.cube_tet_mesh(3)
+mesh.attr[:] = 1 + (np.arange(mesh.ne) %% 2)
+if kind == "tet10":
+    warp = lambda X: np.stack([X[:, 0] + 0.04 * np.sin(2 * X[:, 1] + X[:, 2]), X[:, 1] + 0.05 * X[:, 0] * X[:, 2],
+                               X[:, 2] - 0.03 * np.cos(3 * X[:, 0]) * X[:, 1]], axis=1)
+    m2 = tet.to_quadratic(mesh, warp); m2.attr[:] = mesh.attr; mesh = m2
+nd = tet.NDTetSpace(mesh, p)
+pts, wts = tet.default_tet_rule(p)
+interp, curl = nd.elem.tables(pts)
+geom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, mesh.geometry_grad_table(pts), wts)
+kw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, **kw)
+_, b3 = util.make_ctx("aniso", 2)
+_, bm = util.make_ctx("scalar", 2)
+_, bi = util.make_ctx("aniso", 2)
+n = nd.ndofs
+Ar = ceed.Operator(n, n).add_dense_integrator(geom, block, ceed.QF_HDIVMASS_33, np.concatenate([bm, b3]), ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
+if imode == "mass":
+    Ai = ceed.Operator(n, n).add_dense_integrator(geom, block, ceed.QF_HCURL_33, bi, ceed.EVAL_INTERP).finalize()
+elif imode == "curl":
+    Ai = ceed.Operator(n, n).add_dense_integrator(geom, block, ceed.QF_HDIV_33, bi, ceed.EVAL_CURL).finalize()
+else:
+    Ai = ceed.Operator(n, n).add_dense_integrator(geom, block, ceed.QF_HDIVMASS_33, np.concatenate([bi, bm]), ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
+ess = nd.ess_dofs()
+rng = np.random.default_rng(3)
+x = [torch.from_numpy(rng.uniform(-1, 1, n)).cuda() for _ in range(2)]
+out = {}
+for tag, e in (("plain", np.zeros(0, np.int32)), ("ess", ess)):
+    A = linalg.ComplexParOperator(ctx, Ar, Ai, e, linalg.DIAG_ONE)
+    yr, yi = torch.empty_like(x[0]), torch.empty_like(x[0])
+    A.mult(x[0], x[1], yr, yi)
+    out[tag] = (yr.cpu().numpy(), yi.cpu().numpy())
+np.savez(sys.argv[4], fused=ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle),
+         **{k + "_" + c: v[i] for k, v in out.items() for i, c in enumerate("ri")})
+print("OK")
+'''
+
+
+@pytest.mark.parametrize("imode", ["mass", "curl", "both"])
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_fused_complex_apply_tets(p, imode, tmp_path):
+    """The dense-table form of the one-pass complex apply (straight-sided tetrahedra, anisotropic materials, curl-oriented
+    restriction for p >= 2): 8 elements x {real, imaginary} part in the 16 columns of the matrix-core products, against the
+    four separate applies; essential dofs go through ComplexParOperator's copy / mask / fix path around the fused local apply."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for fused in (1, 0):
+        f = str(tmp_path / f"out{fused}.npz")
+        r = subprocess.run([sys.executable, "-c", FUSED_TET_CHECK % root, str(p), "tet4", imode, f], capture_output=True,
+                           text=True, timeout=300, env=dict(os.environ, PALACE_AMD_COMPLEX_FUSED=str(fused)))
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+        res[fused] = np.load(f)
+    assert int(res[1]["fused"]) == 2 and int(res[0]["fused"]) == 0
+    for k in ("plain_r", "plain_i", "ess_r", "ess_i"):
+        a, b = res[1][k], res[0][k]
+        assert np.abs(a - b).max() < 1e-13 * np.abs(b).max(), k
+
+
+def test_fused_complex_apply_not_for_curved_tets(tmp_path):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = str(tmp_path / "out.npz")
+    r = subprocess.run([sys.executable, "-c", FUSED_TET_CHECK % root, "2", "tet10", "mass", f], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert int(np.load(f)["fused"]) == 0
