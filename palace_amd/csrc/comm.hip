@@ -1,6 +1,7 @@
 #include "comm.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include <dlfcn.h>
 
@@ -116,6 +117,12 @@ Halo::Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int3
   iface_.erase(std::unique(iface_.begin(), iface_.end()), iface_.end());
   d_send_idx_ = pa::dev_upload(send_idx, (size_t)nsend_);
   d_recv_idx_ = pa::dev_upload(recv_idx, (size_t)nrecv_);
+  {
+    bool contiguous = nrecv_ > 0;
+    for (int i = 1; i < nrecv_ && contiguous; i++) contiguous = recv_idx[i] == recv_idx[0] + i;
+    const char *e = std::getenv("PALACE_AMD_HALO_INPLACE");
+    if (contiguous && !(e && e[0] == '0')) recv_first_ = recv_idx[0];
+  }
   const int nbuf = std::max(nsend_, nrecv_);
   d_sendbuf_ = pa::dev_alloc<double>((size_t)nbuf);
   d_recvbuf_ = pa::dev_alloc<double>((size_t)nbuf);
@@ -140,10 +147,12 @@ void Halo::Prolongate(double *d_lx, hipStream_t s) const {
   for (size_t k = 0; k < nbr_.size(); k++) {
     const int ns = send_off_[k + 1] - send_off_[k], nr = recv_off_[k + 1] - recv_off_[k];
     if (ns) PA_NCCL(rccl().Send(d_sendbuf_ + send_off_[k], (size_t)ns, kNcclFloat64, nbr_[k], nccl_, s));
-    if (nr) PA_NCCL(rccl().Recv(d_recvbuf_ + recv_off_[k], (size_t)nr, kNcclFloat64, nbr_[k], nccl_, s));
+    double *dst = recv_first_ >= 0 ? d_lx + recv_first_ : d_recvbuf_;  // contiguous ghosts: no unpack pass
+    if (nr) PA_NCCL(rccl().Recv(dst + recv_off_[k], (size_t)nr, kNcclFloat64, nbr_[k], nccl_, s));
   }
   PA_NCCL(rccl().GroupEnd());
-  if (nrecv_) hipLaunchKernelGGL(k_unpack, dim3(blocks(nrecv_)), dim3(256), 0, s, d_lx, d_recv_idx_, nrecv_, d_recvbuf_);
+  if (nrecv_ && recv_first_ < 0)
+    hipLaunchKernelGGL(k_unpack, dim3(blocks(nrecv_)), dim3(256), 0, s, d_lx, d_recv_idx_, nrecv_, d_recvbuf_);
   PA_HIP(hipGetLastError());
 }
 
@@ -151,11 +160,13 @@ void Halo::RestrictAdd(double *d_ly, hipStream_t s) const {
   void *nccl_ = comm_->nccl_;
   if (nbr_.empty()) return;
   // roles reversed: ghosts are packed and sent to their owners
-  if (nrecv_) hipLaunchKernelGGL(k_pack, dim3(blocks(nrecv_)), dim3(256), 0, s, d_ly, d_recv_idx_, nrecv_, d_sendbuf_);
+  if (nrecv_ && recv_first_ < 0)
+    hipLaunchKernelGGL(k_pack, dim3(blocks(nrecv_)), dim3(256), 0, s, d_ly, d_recv_idx_, nrecv_, d_sendbuf_);
+  const double *src = recv_first_ >= 0 ? d_ly + recv_first_ : d_sendbuf_;  // contiguous ghosts: sent from the vector itself
   PA_NCCL(rccl().GroupStart());
   for (size_t k = 0; k < nbr_.size(); k++) {
     const int ns = recv_off_[k + 1] - recv_off_[k], nr = send_off_[k + 1] - send_off_[k];
-    if (ns) PA_NCCL(rccl().Send(d_sendbuf_ + recv_off_[k], (size_t)ns, kNcclFloat64, nbr_[k], nccl_, s));
+    if (ns) PA_NCCL(rccl().Send(src + recv_off_[k], (size_t)ns, kNcclFloat64, nbr_[k], nccl_, s));
     if (nr) PA_NCCL(rccl().Recv(d_recvbuf_ + send_off_[k], (size_t)nr, kNcclFloat64, nbr_[k], nccl_, s));
   }
   PA_NCCL(rccl().GroupEnd());

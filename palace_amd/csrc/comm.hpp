@@ -44,6 +44,8 @@ class Halo {
   int32_t *d_send_idx_ = nullptr;  // owned dofs this rank sends in P (and receives-into in P^T)
   int32_t *d_recv_idx_ = nullptr;  // ghost slots this rank receives in P (and sends in P^T)
   double *d_sendbuf_ = nullptr, *d_recvbuf_ = nullptr;
+  int recv_first_ = -1;  // >= 0: the ghosts are the contiguous range [recv_first_, recv_first_ + nrecv_) of the local vector in
+                         // receive order (ghosts last: the usual numbering) -- received into / sent from it in place
   int nsend_ = 0, nrecv_ = 0;
   std::vector<int32_t> iface_;  // every local dof that is sent or received (host copy, sorted, unique)
 

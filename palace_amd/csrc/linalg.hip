@@ -894,6 +894,19 @@ void SumOperator::AssembleDiagonal(Vector &diag) const {
   }
 }
 
+namespace {
+// multi-rank ParOperator::Mult: tx = x with the essential entries zeroed; y = ly with the essential rows set to x or 0
+__global__ void k_copy_masked(const double *__restrict__ x, const uint8_t *__restrict__ mask, double *__restrict__ out, const int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = mask[i] ? 0.0 : x[i];
+}
+__global__ void k_copy_fix(const double *__restrict__ ly, const double *__restrict__ x, const uint8_t *__restrict__ mask,
+                           const int one, double *__restrict__ y, const int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = mask[i] ? (one ? x[i] : 0.0) : ly[i];
+}
+}  // namespace
+
 ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, const int32_t *ess_host, int n_ess,
                          DiagonalPolicy policy, const Halo *halo)
     : Operator(n_true, n_true), ctx_(&ctx), A_(&A), halo_(halo), n_true_(n_true), n_local_(A.Height()),
@@ -916,11 +929,19 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
       if (st >= 0) A_fused_ = c;
     }
   }
+  if (halo && n_ess) {
+    std::vector<uint8_t> mask((size_t)n_true, 0);
+    for (int i = 0; i < n_ess; i++) mask[ess_host[i]] = 1;
+    d_ess_mask_ = pa::dev_upload(mask.data(), mask.size(), ctx.stream);
+  }
   if (halo) {
-    // interior element batches overlap with the exchange of the ghosts (PALACE_AMD_OVERLAP=0: everything in one stream)
+    // interior element batches can overlap with the exchange of the ghosts (PALACE_AMD_OVERLAP=1).  Off by default: on one GPU
+    // with the exchanges redirected to the rank itself (scripts/time_halo_mult.py, the 1/8 slab of the strong-scaling bench)
+    // the fork / join of the second stream costs 29 us per apply (104 us against 75 us), more than the transfer of the
+    // 0.57 MB interface it could hide behind the interior batches; it pays only for exchanges slower than that.
     static const bool enabled = [] {
       const char *e = std::getenv("PALACE_AMD_OVERLAP");
-      return !(e && e[0] == '0');
+      return e && e[0] == '1';
     }();
     if (auto *c = dynamic_cast<const ceed::Operator *>(&A); c && enabled) {
       const_cast<ceed::Operator *>(c)->SetInterfaceDofs(halo->InterfaceDofs());
@@ -935,6 +956,7 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
   }
 }
 ParOperator::~ParOperator() {
+  if (d_ess_mask_) (void)hipFree(d_ess_mask_);
   if (d_ess_) (void)hipFree(d_ess_);
 }
 
@@ -954,8 +976,13 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
     return;
   }
   Vector tx(lx_.Data(), n_true_);
-  linalg::Copy(c, x, tx);
-  if (n_ess_) linalg::SetSubVector(c, tx, d_ess_, n_ess_, 0.0);
+  const bool one_launch = d_ess_mask_ && x.Data() != y.Data();
+  if (one_launch) {
+    hipLaunchKernelGGL(k_copy_masked, dim3((n_true_ + 255) / 256), dim3(256), 0, c.stream, x.Data(), d_ess_mask_, tx.Data(), n_true_);
+  } else {
+    linalg::Copy(c, x, tx);
+    if (n_ess_) linalg::SetSubVector(c, tx, d_ess_, n_ess_, 0.0);  // (before P: the ghost copies of essential dofs must be zero too)
+  }
   if (halo_ && A_overlap_ && !StreamGraph::Recording()) {
     // P on a second stream: fork after tx is complete, the apply joins before its interface batches
     Workspace &w = c.Work();
@@ -971,6 +998,11 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
   }
   if (halo_) halo_->RestrictAdd(ly_.Data(), c.stream);  // sharers -> owners, summed (P^T)
   Vector ty(ly_.Data(), n_true_);
+  if (one_launch) {
+    hipLaunchKernelGGL(k_copy_fix, dim3((n_true_ + 255) / 256), dim3(256), 0, c.stream, ty.Data(), x.Data(), d_ess_mask_,
+                       policy_ == DiagonalPolicy::DIAG_ONE ? 1 : 0, y.Data(), n_true_);
+    return;
+  }
   linalg::Copy(c, ty, y);
   if (n_ess_) {
     if (policy_ == DiagonalPolicy::DIAG_ONE)

@@ -307,6 +307,7 @@ private:
   int n_true_, n_local_;
   int32_t *d_ess_ = nullptr;
   int n_ess_ = 0;
+  uint8_t *d_ess_mask_ = nullptr;  // with a halo: one byte per true dof, so that copy + mask and copy + fix-up are one launch each
   DiagonalPolicy policy_;
   mutable Vector lx_, ly_;
 

@@ -69,8 +69,8 @@ print("OK")
 '''
 
 
-def _self_halo(p, overlap):
-    env = dict(os.environ, PALACE_AMD_OVERLAP="1" if overlap else "0")
+def _self_halo(p, overlap, inplace=True):
+    env = dict(os.environ, PALACE_AMD_OVERLAP="1" if overlap else "0", PALACE_AMD_HALO_INPLACE="1" if inplace else "0")
     try:
         out = subprocess.run([sys.executable, "-c", SELF_HALO % ROOT, str(p)], capture_output=True, text=True, timeout=240,
                              env=env)
@@ -84,11 +84,14 @@ def _self_halo(p, overlap):
 
 @pytest.mark.parametrize("p", [1, 2, 3])
 def test_halo_self_neighbour_one_gpu(p):
-    """p = 2, 3: the streaming kernel runs the interior batches before it waits for the ghosts (pa_op_mult_after's split);
-    p = 1: no split, the whole apply waits.  Either way the result is the one of the single-stream path, bit for bit."""
+    """With PALACE_AMD_OVERLAP=1 (off by default, see linalg.hip) the ghosts are exchanged on a second stream; p = 2, 3: the
+    streaming kernel runs the interior batches before it waits for them (pa_op_mult_after's split); p = 1: no split, the whole
+    apply waits.  Either way the result is the one of the single-stream path, bit for bit."""
     a = _self_halo(p, True)
     b = _self_halo(p, False)
     assert a == b
+    # ghosts received into / sent from the local vector in place (contiguous ghosts) or through the buffers
+    assert _self_halo(p, False, inplace=False) == b
 
 
 def _worker(rank, world, port, out):
