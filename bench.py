@@ -299,6 +299,7 @@ def tets_leg(order, n, reps=20):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL across processes)
     import torch
     import torch.distributed as dist
 
