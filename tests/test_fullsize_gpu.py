@@ -100,3 +100,77 @@ def test_midsize_matches_oracle():
     op.mult(torch.from_numpy(x).cuda(), y)
     ref = util.oracle_apply_c(nd, util.oracle_geom(mesh, 4), "hdiv", po.CoeffCtx().pack(), x, 4)
     assert np.abs(y.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_fullsize_complex_one_pass_equals_separate_applies(big):
+    """The one-pass complex apply (pa_op_mult_complex) at the bench size: y = (A_r + i A_i) x equals the four
+    separate real applies, with essential dofs, is deterministic, and is complex-linear."""
+    from palace_amd import ceed, linalg
+
+    ctx, prob = big
+    nd = prob.spaces[-1]
+    n = nd.ndofs
+    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([-2.08 * 0.3])])
+    cond = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([0.05])])
+    Ar = ceed.curlcurlmass_operator(prob.geom, nd, mass, ceed.coefficient_context(3))
+    Ai = ceed.ndmass_operator(prob.geom, nd, cond)
+    assert ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle) == 1
+    A = linalg.ComplexParOperator(ctx, Ar, Ai, prob.ess[-1], linalg.DIAG_ONE)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    xr, xi = (torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 0.5 for _ in range(2))
+    yr, yi = torch.empty_like(xr), torch.empty_like(xr)
+    A.mult(xr, xi, yr, yi)
+    y2r, y2i = torch.empty_like(xr), torch.empty_like(xr)
+    A.mult(xr, xi, y2r, y2i)
+    assert torch.equal(yr, y2r) and torch.equal(yi, y2i)
+    # four real applies through the real ParOperators (fused essential handling of the real kernels)
+    Pr = linalg.ParOperator(ctx, Ar, prob.ess[-1], linalg.DIAG_ONE)
+    Pi = linalg.ParOperator(ctx, ceed.ndmass_operator(prob.geom, nd, cond), prob.ess[-1], linalg.DIAG_ZERO)
+    t = [torch.empty_like(xr) for _ in range(4)]
+    Pr.mult(xr, t[0]), Pi.mult(xi, t[1]), Pi.mult(xr, t[2]), Pr.mult(xi, t[3])
+    rr, ri = t[0] - t[1], t[2] + t[3]
+    assert float((yr - rr).abs().max()) <= 1e-13 * float(rr.abs().max())
+    assert float((yi - ri).abs().max()) <= 1e-13 * float(ri.abs().max())
+    # multiplication by i: A (i x) = i A x  (x -> (-xi, xr), y -> (-yi, yr)); essential rows carry x itself, so they follow too
+    zr, zi = torch.empty_like(xr), torch.empty_like(xr)
+    A.mult(-xi, xr, zr, zi)
+    assert float((zr + yi).abs().max()) <= 1e-13 * float(yi.abs().max())
+    assert float((zi - yr).abs().max()) <= 1e-13 * float(yr.abs().max())
+
+
+def test_fullsize_tets_affine_form_equals_general_form():
+    """280k straight-sided tetrahedra (the bench's tetrahedral leg): the affine form of the dense kernel (first-point D scaled by
+    relative quadrature weights, 12 waves per CU) against the general form on the same elements."""
+    import os
+
+    from palace_amd import ceed
+    from palace_amd.fem import tet
+
+    mesh = tet.cube_tet_mesh(36)
+    nd = tet.NDTetSpace(mesh, 3)
+    pts, wts = tet.default_tet_rule(3)
+    interp, curl = nd.elem.tables(pts)
+    geom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, mesh.geometry_grad_table(pts), wts)
+    block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, curl_orients=nd.curl_orients)
+    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
+    blob = np.concatenate([mass, ceed.coefficient_context(3)])
+    n = nd.ndofs
+
+    def build():
+        return ceed.Operator(n, n).add_dense_integrator(geom, block, ceed.QF_HDIVMASS_33, blob, ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
+
+    A = build()
+    os.environ["PALACE_AMD_DENSE_AFFINE"] = "0"
+    try:
+        B = build()
+    finally:
+        del os.environ["PALACE_AMD_DENSE_AFFINE"]
+    assert A.dense_affine() == 1 and B.dense_affine() == 0
+    x = torch.rand(n, dtype=torch.float64, device="cuda") - 0.5
+    ya, yb = torch.empty_like(x), torch.empty_like(x)
+    A.mult(x, ya)
+    B.mult(x, yb)
+    assert float((ya - yb).abs().max()) <= 1e-14 * float(yb.abs().max())
+    y2 = torch.empty_like(x)
+    A.mult(x, y2)
+    assert torch.equal(ya, y2)
