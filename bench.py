@@ -300,6 +300,11 @@ def tets_leg(order, n, reps=20):
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL across processes)
+    # stdout carries the one JSON line and nothing else: whatever libraries print there (RCCL's version banner at communicator
+    # creation) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -513,7 +518,8 @@ def main():
             "pre_warm_steps": args.pre_warm, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "tets_mfma": tets,
             "setup_s": t_setup,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
