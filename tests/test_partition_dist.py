@@ -172,3 +172,23 @@ def test_two_rank_operator_matches_serial(p):
         assert r[5] < 1e-12, "ghost values after P differ from the local interpolant"
         for a, b in zip(r[1:4], s[1:4]):
             assert abs(a - b) <= 1e-11 * abs(b), (q, r, s)
+
+
+@pytest.mark.parametrize("world,rank", [(2, 0), (2, 1), (8, 0), (8, 3), (8, 7)])
+def test_ghosts_are_the_contiguous_tail_of_the_local_vector(world, rank):
+    """The C++ Halo receives ghosts into, and sends them from, the local vector in place when they are one contiguous range in
+    receive order (comm.hip: recv_first_): the slab plans of every level (Nedelec and H1) have that form -- owned dofs first, the
+    ghosts of the lower interface last -- and send lists only address owned dofs."""
+    from palace_amd.fem.partition import SlabH1Space, SlabProblem
+
+    prob = SlabProblem(None, rank, world, 3, 0, shape=(2, 2), device=False)
+    z_lo = rank * prob.height
+    h1s = [SlabH1Space(prob.mesh, q, rank, world, z_lo, z_lo + prob.height, prob.radius) for q in prob.orders]
+    for s in list(prob.spaces) + h1s:
+        recv = np.concatenate(s.recv) if s.recv else np.zeros(0, np.int32)
+        send = np.concatenate(s.send) if s.send else np.zeros(0, np.int32)
+        assert recv.size == s.ndofs - s.n_true
+        if recv.size:
+            assert np.array_equal(recv, np.arange(s.n_true, s.ndofs))
+        if send.size:
+            assert send.min() >= 0 and send.max() < s.n_true and np.unique(send).size == send.size
