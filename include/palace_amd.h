@@ -67,8 +67,14 @@ enum pa_qfunction {
    * QFunctions as in the plane: they only read w detJ */
   PA_QF_HDIVMASS_32 = 13,  /* f_apply_hdivmass_32  fem/qfunctions/32/hdivmass_32_qf.h   ND boundary curl-curl + mass */
   PA_QF_HCURLMASS_22 = 14, /* f_apply_hcurlmass_22 fem/qfunctions/22/hcurlmass_22_qf.h  2-D H1 diffusion + mass */
-  PA_QF_HCURLMASS_32 = 15  /* f_apply_hcurlmass_32 fem/qfunctions/32/hcurlmass_32_qf.h  H1 boundary diffusion + mass;
+  PA_QF_HCURLMASS_32 = 15, /* f_apply_hcurlmass_32 fem/qfunctions/32/hcurlmass_32_qf.h  H1 boundary diffusion + mass;
                               H1 diffusion alone: PA_QF_HCURL_22 / PA_QF_HCURL_32 with EVAL_GRAD (fem/integ/diffusion.cpp) */
+  /* line elements (pa_mesh_dense_desc dim = 1, space_dim = 2 or 3: boundaries of plane problems, curves in space), dense tables:
+   * ND mass with Interp, H1 diffusion with Grad (one derivative), H1 diffusion + mass; H1 mass is PA_QF_H1_1 */
+  PA_QF_HCURL_21 = 16,     /* f_apply_hcurl_21     fem/qfunctions/21/hcurl_21_qf.h:10-29 */
+  PA_QF_HCURL_31 = 17,     /* f_apply_hcurl_31     fem/qfunctions/31/hcurl_31_qf.h */
+  PA_QF_HCURLMASS_21 = 18, /* f_apply_hcurlmass_21 fem/qfunctions/21/hcurlmass_21_qf.h */
+  PA_QF_HCURLMASS_31 = 19  /* f_apply_hcurlmass_31 fem/qfunctions/31/hcurlmass_31_qf.h:10-38 */
 };
 
 enum pa_fe_type {
@@ -193,7 +199,8 @@ typedef struct {
    * (fem/qfunctions/22/geom_22_qf.h:9-30). */
   int32_t dim;
   /* space dimension when it differs from the element dimension: 3 with dim = 2 for boundary elements
-   * (nodes [num_nodes][3], 8 geometry rows {attr, w detJ, adj(J)^T/detJ (3x2)}, geom_32_qf.h:9-33);
+   * (nodes [num_nodes][3], 8 geometry rows {attr, w detJ, adj(J)^T/detJ (3x2)}, geom_32_qf.h:9-33); 2 or 3 with dim = 1 for
+   * line elements (mesh_grad [1][Q][npe], 2 + space_dim rows {attr, w |J|, J / |J|^2}, geom_21_qf.h, geom_31_qf.h);
    * 0 = same as dim. */
   int32_t space_dim;
 } pa_mesh_dense_desc;

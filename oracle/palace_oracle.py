@@ -462,6 +462,41 @@ def apply_hcurl_32(ctx, geom, u):
                      wdetJ * (A[3] * z[0] + A[4] * z[1] + A[5] * z[2])], axis=1)
 
 
+# ---- line elements (dim = 1 in space_dim = 2 or 3): fem/qfunctions/21/*.h, fem/qfunctions/31/*.h ----------------------
+
+def build_geom_factor_line(attr, qw, J):
+    """geom_21_qf.h:9-30 / geom_31_qf.h:9-31.  J [NE, Q, sdim] (the tangent dx/dxi).  Returns geom [NE, 2 + sdim, Q]:
+    attr, w |J|, adj(J)^T / detJ = J / |J|^2 (utils_21_qf.h:20-31)."""
+    d = np.sqrt((J * J).sum(axis=-1))
+    NE, Q, sdim = J.shape
+    geom = np.empty((NE, 2 + sdim, Q))
+    geom[:, 0, :] = attr[:, None]
+    geom[:, 1, :] = qw[None, :] * d
+    for i in range(sdim):
+        geom[:, 2 + i, :] = (J[..., i] / d) / d
+    return geom
+
+
+def apply_hcurl_line(ctx, geom, u):
+    """hcurl_21_qf.h:10-29 / hcurl_31_qf.h: v = w detJ a^T C a u with a = adjJt (sdim entries), C sdim x sdim column-major
+    (MultAtBCx21 / MultAtBCx31, utils_31_qf.h:41-59).  u, v [NE, 1, Q]."""
+    sdim = geom.shape[1] - 2
+    attr = geom[:, 0, :].astype(np.int32)
+    a = [geom[:, 2 + i, :] for i in range(sdim)]
+    C = (_unpack2(ctx, attr) if sdim == 2 else ctx.unpack3(attr))
+    s = 0.0
+    for i in range(sdim):
+        z = sum(C[..., i + sdim * j] * a[j] for j in range(sdim))
+        s = s + a[i] * z
+    return (geom[:, 1, :] * s)[:, None, :] * u
+
+
+def apply_hcurlmass_line(ctx_mass, ctx, geom, u, gradu):
+    """hcurlmass_21_qf.h / hcurlmass_31_qf.h:10-38: H1 mass c w detJ u (first context, dim 1) + the line form above on du/dxi."""
+    attr = geom[:, 0, :].astype(np.int32)
+    return (_unpack1(ctx_mass, attr) * geom[:, 1, :])[:, None, :] * u, apply_hcurl_line(ctx, geom, gradu)
+
+
 def apply_hdivmass_32(ctx_mass, ctx_curl, geom, qw, u, curlu):
     """hdivmass_32_qf.h:11-42: ND mass on a boundary element (3x3 material, first context) + the scalar surface curl-curl
     c qw^2 / (w detJ) (second context, dim 1)."""
@@ -488,6 +523,7 @@ QF_HCURL_32 = "hcurl_32"
 QF_HDIV, QF_HCURL, QF_HDIVMASS, QF_HCURLMASS, QF_H1MASS = "hdiv_33", "hcurl_33", "hdivmass_33", "hcurlmass_33", "h1_1"
 QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22 = "hcurl_22", "l2_1", "hdivmass_22"
 QF_HDIVMASS_32, QF_HCURLMASS_22, QF_HCURLMASS_32 = "hdivmass_32", "hcurlmass_22", "hcurlmass_32"
+QF_HCURL_LINE, QF_HCURLMASS_LINE = "hcurl_21|31", "hcurlmass_21|31"  # line elements: the geometry data tells 21 from 31
 QF_HCURLHDIV_ERROR, QF_HDIVHCURL_ERROR = "hcurlhdiv_error_33", "hdivhcurl_error_33"
 QF_HCURLHDIV, QF_HDIVHCURL = "hcurlhdiv_33", "hdivhcurl_33"  # weak curl (Interp -> Curl), mixed curl (Curl -> Interp)
 
@@ -512,7 +548,8 @@ class CeedOperatorOracle:
         assert self.sgn is None or self.cor is None
         self.Q = geom.shape[2]
         self.vector_fe = vector_fe
-        dim = 2 if geom.shape[1] in (6, 8) else 3  # 6 rows: 2-D; 8 rows: boundary elements (2 in 3)
+        # 6 rows: 2-D; 8 rows: boundary elements (2 in 3); 4 / 5 rows: line elements in the plane / in space
+        dim = 2 if geom.shape[1] in (6, 8) else (1 if geom.shape[1] in (4, 5) else 3)
         if vector_fe:
             self.interp = np.asarray(interp).reshape(dim, self.Q, self.P)
         else:
@@ -550,6 +587,14 @@ class CeedOperatorOracle:
         if qf == QF_L2_1:      # 2-D curl-curl; div-div with the divergence table (integ/divdiv.cpp: l2_1 for one component)
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
             return np.einsum("dqj,edq->ej", self.deriv, apply_l2_1(self.ctx, geom, self.qw, cu))
+        if qf == QF_HCURL_LINE:  # ND mass (values) or H1 diffusion (du/dxi) on a line element
+            tabl = self.interp if self.vector_fe else self.deriv
+            return np.einsum("dqj,edq->ej", tabl, apply_hcurl_line(self.ctx, geom, np.einsum("dqj,ej->edq", tabl, ue)))
+        if qf == QF_HCURLMASS_LINE:
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            gu = np.einsum("dqj,ej->edq", self.deriv, ue)
+            v, gv = apply_hcurlmass_line(self.ctx, self.ctx2, geom, u, gu)
+            return np.einsum("dqj,edq->ej", self.interp, v) + np.einsum("dqj,edq->ej", self.deriv, gv)
         if qf == QF_HCURL_32 and not self.vector_fe:  # H1 diffusion on boundary elements (integ/diffusion.cpp, case 32)
             gu = np.einsum("dqj,ej->edq", self.deriv, ue)
             return np.einsum("dqj,edq->ej", self.deriv, apply_hcurl_32(self.ctx, geom, gu))

@@ -21,6 +21,12 @@ typedef double CeedScalar;
 #include "fem/qfunctions/22/hdivmass_22_qf.h"
 #include "fem/qfunctions/22/hcurlmass_22_qf.h"
 #include "fem/qfunctions/1/l2_1_qf.h"
+#include "fem/qfunctions/21/geom_21_qf.h"
+#include "fem/qfunctions/21/hcurl_21_qf.h"
+#include "fem/qfunctions/21/hcurlmass_21_qf.h"
+#include "fem/qfunctions/31/geom_31_qf.h"
+#include "fem/qfunctions/31/hcurl_31_qf.h"
+#include "fem/qfunctions/31/hcurlmass_31_qf.h"
 #include "fem/qfunctions/32/geom_32_qf.h"
 #include "fem/qfunctions/32/hcurl_32_qf.h"
 #include "fem/qfunctions/32/hdivmass_32_qf.h"

@@ -22,6 +22,7 @@ from .fem.mesh import HexMesh, _q2_1d
 QF_HDIV_33, QF_HCURL_33, QF_HDIVMASS_33, QF_HCURLMASS_33, QF_H1_1, QF_HCURL_22, QF_L2_1, QF_HDIVMASS_22, QF_HCURL_32 = range(9)
 QF_HCURLHDIV_ERROR_33, QF_HDIVHCURL_ERROR_33 = 11, 12
 QF_HDIVMASS_32, QF_HCURLMASS_22, QF_HCURLMASS_32 = 13, 14, 15  # the remaining 2-D / boundary-element pair forms
+QF_HCURL_21, QF_HCURL_31, QF_HCURLMASS_21, QF_HCURLMASS_31 = 16, 17, 18, 19  # line elements in the plane / in space
 QF_HCURLHDIV_33, QF_HDIVHCURL_33 = 9, 10  # weak curl (trial Interp, test Curl) / mixed curl (trial Curl, test Interp)
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
 FE_H1, FE_HCURL, FE_HDIV = 0, 1, 2

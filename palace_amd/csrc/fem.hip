@@ -480,15 +480,18 @@ void VectorFEMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial
   if (d == 33) {
     qf = tc ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33) : (sc ? PA_QF_HDIVHCURL_33 : PA_QF_HDIV_33);
   } else {
-    PA_REQUIRE(tc && sc && (d == 22 || d == 32), "VectorFEMassIntegrator: H(curl) spaces only on 2-D / boundary elements");
-    qf = d == 22 ? PA_QF_HCURL_22 : PA_QF_HCURL_32;
+    PA_REQUIRE(tc && sc && (d == 22 || d == 32 || d == 21 || d == 31),
+               "VectorFEMassIntegrator: H(curl) spaces only on 2-D, boundary and line elements");
+    qf = d == 22 ? PA_QF_HCURL_22 : (d == 32 ? PA_QF_HCURL_32 : (d == 21 ? PA_QF_HCURL_21 : PA_QF_HCURL_31));
   }
   AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_INTERP, PA_EVAL_INTERP);
 }
 void DiffusionIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
-  PA_REQUIRE(d == 33 || d == 22 || d == 32, "Invalid value of (dim, space_dim) for DiffusionIntegrator!");
-  AssembleCeedOperator(op, trial, test, d == 33 ? PA_QF_HCURL_33 : (d == 22 ? PA_QF_HCURL_22 : PA_QF_HCURL_32),
+  PA_REQUIRE(d == 33 || d == 22 || d == 32 || d == 21 || d == 31, "Invalid value of (dim, space_dim) for DiffusionIntegrator!");
+  const int qf_diff = d == 33 ? PA_QF_HCURL_33
+                      : (d == 22 ? PA_QF_HCURL_22 : (d == 32 ? PA_QF_HCURL_32 : (d == 21 ? PA_QF_HCURL_21 : PA_QF_HCURL_31)));
+  AssembleCeedOperator(op, trial, test, qf_diff,
                        ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_GRAD, PA_EVAL_GRAD);
 }
 void CurlCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
@@ -518,8 +521,11 @@ void MixedVectorWeakCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace
 }
 void DiffusionMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
-  PA_REQUIRE(d == 33 || d == 22 || d == 32, "Invalid value of (dim, space_dim) for DiffusionMassIntegrator!");
-  AssembleCeedOperator(op, trial, test, d == 33 ? PA_QF_HCURLMASS_33 : (d == 22 ? PA_QF_HCURLMASS_22 : PA_QF_HCURLMASS_32),
+  PA_REQUIRE(d == 33 || d == 22 || d == 32 || d == 21 || d == 31, "Invalid value of (dim, space_dim) for DiffusionMassIntegrator!");
+  const int qf_dm = d == 33 ? PA_QF_HCURLMASS_33
+                    : (d == 22 ? PA_QF_HCURLMASS_22
+                               : (d == 32 ? PA_QF_HCURLMASS_32 : (d == 21 ? PA_QF_HCURLMASS_21 : PA_QF_HCURLMASS_31)));
+  AssembleCeedOperator(op, trial, test, qf_dm,
                        ceed::PopulateCoefficientContext(1, Q_mass, sdim, Q, transpose_mass, transpose),
                        PA_EVAL_GRAD | PA_EVAL_INTERP, PA_EVAL_GRAD | PA_EVAL_INTERP);
 }
@@ -539,7 +545,8 @@ std::unique_ptr<ceed::Operator> BilinearForm::PartialAssemble(const FiniteElemen
   auto out = std::make_unique<ceed::Operator>(trial.GetContext(), op, /*own=*/true);
   for (const auto &integ : domain_integs) integ->Assemble(op, trial, test);
   for (const auto &[bfes, integ] : boundary_integs) {
-    PA_REQUIRE(&trial == &test && bfes->GetVSize() == trial.GetVSize() && bfes->GetMesh().Dimension() == 2,
+    PA_REQUIRE(&trial == &test && bfes->GetVSize() == trial.GetVSize() &&
+                   bfes->GetMesh().Dimension() == trial.GetMesh().Dimension() - 1,
                "a boundary integrator needs the boundary-element view of the form's (square) space");
     integ->Assemble(op, *bfes, *bfes);
   }

@@ -50,22 +50,35 @@ enum DenseMode {
   MODE_VMASS2 = 7,    // 2-D ND mass               f_apply_hcurl_22
   MODE_CURLMASS2 = 8, // 2-D ND curl-curl + mass   f_apply_hdivmass_22 / _32
   MODE_DIFF2 = 9,     // 2-D H1 diffusion          f_apply_hcurl_22 / _32 on grad u
-  MODE_DIFFMASS2 = 10 // 2-D H1 diffusion + mass   f_apply_hcurlmass_22 / _32
-  // (MODE_MASS serves the 2-D H1 mass too: f_apply_h1_1 only reads w detJ)
+  MODE_DIFFMASS2 = 10, // 2-D H1 diffusion + mass   f_apply_hcurlmass_22 / _32
+  // (MODE_MASS serves the 2-D and 1-D H1 mass too: f_apply_h1_1 only reads w detJ)
+  // line elements (boundaries of plane problems, curves in space): every D is a scalar per point
+  MODE_VMASS1 = 11,    // ND mass on a line         f_apply_hcurl_21 / _31
+  MODE_DIFF1 = 12,     // H1 diffusion on a line    f_apply_hcurl_21 / _31 on du/dxi
+  MODE_DIFFMASS1 = 13  // H1 diffusion + mass       f_apply_hcurlmass_21 / _31
 };
 
 template <int MODE>
 struct ModeTraits {
   static constexpr int NCI = (MODE == MODE_VMASS || MODE == MODE_CURLMASS) ? 3
                              : (MODE == MODE_VMASS2 || MODE == MODE_CURLMASS2) ? 2
-                             : (MODE == MODE_DIFFMASS || MODE == MODE_MASS || MODE == MODE_DIFFMASS2) ? 1 : 0;
-  static constexpr int NCD = (MODE == MODE_VMASS || MODE == MODE_MASS || MODE == MODE_VMASS2) ? 0
-                             : (MODE == MODE_CURL2 || MODE == MODE_CURLMASS2) ? 1
+                             : (MODE == MODE_DIFFMASS || MODE == MODE_MASS || MODE == MODE_DIFFMASS2 || MODE == MODE_VMASS1 ||
+                                MODE == MODE_DIFFMASS1) ? 1 : 0;
+  static constexpr int NCD = (MODE == MODE_VMASS || MODE == MODE_MASS || MODE == MODE_VMASS2 || MODE == MODE_VMASS1) ? 0
+                             : (MODE == MODE_CURL2 || MODE == MODE_CURLMASS2 || MODE == MODE_DIFF1 || MODE == MODE_DIFFMASS1) ? 1
                              : (MODE == MODE_DIFF2 || MODE == MODE_DIFFMASS2) ? 2 : 3;
   static constexpr int NCT = NCI + NCD;
 };
 
 int mode_of(int fe_type, int qf, int dim, int sdim) {
+  if (dim == 1) {  // line elements in the plane (21) or in space (31)
+    const int q_vec = sdim == 3 ? PA_QF_HCURL_31 : PA_QF_HCURL_21, q_pair = sdim == 3 ? PA_QF_HCURLMASS_31 : PA_QF_HCURLMASS_21;
+    if (fe_type == PA_FE_HCURL && qf == q_vec) return MODE_VMASS1;
+    if (fe_type == PA_FE_H1 && qf == PA_QF_H1_1) return MODE_MASS;
+    if (fe_type == PA_FE_H1 && qf == q_vec) return MODE_DIFF1;
+    if (fe_type == PA_FE_H1 && qf == q_pair) return MODE_DIFFMASS1;
+    throw Error("QFunction does not match a line element");
+  }
   if (dim == 2) {  // the same applies for plane elements and for boundary elements in 3-D: only D differs (3x2 geometry)
     const bool bdr = sdim == 3;
     if (fe_type == PA_FE_HCURL) {
@@ -95,9 +108,10 @@ int mode_of(int fe_type, int qf, int dim, int sdim) {
 void mode_comps(int mode, int &nci, int &ncd) {
   nci = (mode == MODE_VMASS || mode == MODE_CURLMASS) ? 3
         : (mode == MODE_VMASS2 || mode == MODE_CURLMASS2) ? 2
-        : (mode == MODE_DIFFMASS || mode == MODE_MASS || mode == MODE_DIFFMASS2) ? 1 : 0;
-  ncd = (mode == MODE_VMASS || mode == MODE_MASS || mode == MODE_VMASS2) ? 0
-        : (mode == MODE_CURL2 || mode == MODE_CURLMASS2) ? 1
+        : (mode == MODE_DIFFMASS || mode == MODE_MASS || mode == MODE_DIFFMASS2 || mode == MODE_VMASS1 || mode == MODE_DIFFMASS1) ? 1
+        : 0;
+  ncd = (mode == MODE_VMASS || mode == MODE_MASS || mode == MODE_VMASS2 || mode == MODE_VMASS1) ? 0
+        : (mode == MODE_CURL2 || mode == MODE_CURLMASS2 || mode == MODE_DIFF1 || mode == MODE_DIFFMASS1) ? 1
         : (mode == MODE_DIFF2 || mode == MODE_DIFFMASS2) ? 2 : 3;
 }
 
@@ -777,6 +791,60 @@ __global__ void dense_qdata_kernel(const DenseArgs a, double *__restrict__ qd) {
   if (F0::NF == 2) field(std::integral_constant<int, 1>{});
 }
 
+// Line elements: geometry data {attr, w |J|, J / |J|^2 (SDIM rows)} (geom_21_qf.h:9-30, geom_31_qf.h:9-31) and the scalar D of
+// every form on them:  w detJ a^T C a with a = adj(J)^T / detJ (hcurl_21_qf.h:10-29, hcurl_31_qf.h; C is SDIM x SDIM), c w detJ
+// (h1_1_qf.h, first half of hcurlmass_21 / _31)
+template <int SDIM>
+__global__ void geom_dense1_kernel(const int ne, const int Q, const int Qpad, const int npe, const int32_t *__restrict__ off,
+                                   const double *__restrict__ nodes, const int32_t *__restrict__ attr,
+                                   const double *__restrict__ grad, const double *__restrict__ w, double *__restrict__ geom) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / Q);
+  if (e >= ne) return;
+  const int q = (int)(gid - (long long)e * Q);
+  double J[SDIM] = {};
+  for (int n = 0; n < npe; n++) {
+    const double gq = grad[(size_t)q * npe + n];
+    const double *x = nodes + (size_t)off[(size_t)e * npe + n] * SDIM;
+    for (int i = 0; i < SDIM; i++) J[i] += gq * x[i];
+  }
+  double d2 = 0.0;
+  for (int i = 0; i < SDIM; i++) d2 += J[i] * J[i];
+  const double d = sqrt(d2);
+  const size_t cs = (size_t)Qpad * kEB;
+  double *g = geom + ((size_t)(e / kEB) * (2 + SDIM) * Qpad + q) * kEB + (e % kEB);
+  g[0] = (double)attr[e];
+  g[cs] = w[q] * d;
+  for (int i = 0; i < SDIM; i++) g[(2 + i) * cs] = (J[i] / d) / d;
+}
+
+template <int MODE, int SDIM>
+__global__ void dense_qdata1_kernel(const DenseArgs a, double *__restrict__ qd) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gid / a.Q);
+  if (e >= a.ne) return;
+  const int q = (int)(gid - (long long)e * a.Q);
+  const size_t cs = (size_t)a.Qpad * kEB, os = (size_t)a.Q4 * kEB;
+  const double *g = a.geom + ((size_t)(e / kEB) * (2 + SDIM) * a.Qpad + q) * kEB + (e % kEB);
+  double *out = qd + ((size_t)(e / kEB) * a.ncq * a.Q4 + q) * kEB + (e % kEB);
+  const int attr = (int)g[0];
+  const double wdetJ = g[cs];
+  int o = 0;
+  if (MODE == MODE_MASS || MODE == MODE_DIFFMASS1) out[(o++) * os] = a.c0.mat[coeff_index(a.c0, attr)] * wdetJ;
+  if (MODE != MODE_MASS) {  // MultAtBCx21 / MultAtBCx31 with x = 1 (utils_21_qf.h, utils_31_qf.h:41-59)
+    const CoeffDev &cc = (MODE == MODE_DIFFMASS1) ? a.c1 : a.c0;
+    const double *C = cc.mat + SDIM * SDIM * coeff_index(cc, attr);
+    double av[SDIM], s = 0.0;
+    for (int i = 0; i < SDIM; i++) av[i] = g[(2 + i) * cs];
+    for (int i = 0; i < SDIM; i++) {
+      double z = 0.0;
+      for (int j = 0; j < SDIM; j++) z += C[i + SDIM * j] * av[j];
+      s += av[i] * z;
+    }
+    out[o * os] = wdetJ * s;
+  }
+}
+
 // 2-D elements, in the plane (6-row geometry data {attr, w detJ, adj(J)^T/detJ 2x2}, 2x2 materials) or on the boundary of a 3-D
 // mesh (BDR: 8 rows with the 3x2 adj(J)^T/detJ, 3x3 materials): packed D per field in the order {values, derivatives} --
 //   symmetric 2x2 {00, 01, 11} = w detJ A^T C A    hcurl_22_qf.h:10-30, hcurl_32_qf.h:10-30 (ND mass, H1 diffusion)
@@ -906,6 +974,9 @@ void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
     PA_RES_CASE(MODE_CURLMASS2)
     PA_RES_CASE(MODE_DIFF2)
     PA_RES_CASE(MODE_DIFFMASS2)
+    PA_RES_CASE(MODE_VMASS1)
+    PA_RES_CASE(MODE_DIFF1)
+    PA_RES_CASE(MODE_DIFFMASS1)
 #undef PA_RES_CASE
   }
 }
@@ -1124,8 +1195,9 @@ void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
   const int ne = mesh.num_elem, npe = mesh.nodes_per_elem, Q = mesh.num_qpts;
   const int dim = mesh.dim == 0 ? 3 : mesh.dim;
   const int sdim = mesh.space_dim == 0 ? dim : mesh.space_dim;
-  PA_REQUIRE(dim == 2 || dim == 3, "element dimension must be 2 or 3");
-  PA_REQUIRE(sdim == dim || (dim == 2 && sdim == 3), "space dimension must equal the element dimension, or be 3 for 2-D elements");
+  PA_REQUIRE(dim >= 1 && dim <= 3, "element dimension must be 1, 2 or 3");
+  PA_REQUIRE(dim == 1 ? (sdim == 2 || sdim == 3) : (sdim == dim || (dim == 2 && sdim == 3)),
+             "space dimension: that of the element, 3 for boundary elements, 2 or 3 for line elements");
   PA_REQUIRE(ne > 0 && npe > 0 && Q > 0 && mesh.num_nodes > 0, "empty mesh description");
   PA_REQUIRE(mesh.node_offsets && mesh.nodes && mesh.attr && mesh.mesh_grad && mesh.qweight, "null mesh array");
   for (size_t i = 0; i < (size_t)ne * npe; i++)
@@ -1137,7 +1209,7 @@ void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
   double *d_grad = dev_upload(mesh.mesh_grad, (size_t)dim * Q * npe, s);
   double *d_w = dev_upload(mesh.qweight, (size_t)Q, s);
   g.ne = ne, g.q1d = 0, g.Q = Q, g.eb = kEB, g.Qpad = (Q + 15) / 16 * 16;
-  g.dim = dim, g.sdim = sdim, g.nrows = dim == 3 ? 11 : (sdim == 3 ? 8 : 6);
+  g.dim = dim, g.sdim = sdim, g.nrows = dim == 1 ? 2 + sdim : (dim == 3 ? 11 : (sdim == 3 ? 8 : 6));
   g.d_qw = dev_upload(mesh.qweight, (size_t)Q, s);
   g.wq.assign(mesh.qweight, mesh.qweight + Q);
   const size_t nb = (size_t)(ne + kEB - 1) / kEB, count = nb * g.nrows * g.Qpad * kEB;
@@ -1145,7 +1217,13 @@ void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
   PA_HIP(hipMemsetAsync(g.d_geom, 0, sizeof(double) * count, s));
   const long long n = (long long)ne * Q;
   const int bs = 256;
-  if (dim == 2 && sdim == 3)
+  if (dim == 1 && sdim == 3)
+    hipLaunchKernelGGL(geom_dense1_kernel<3>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, ne, Q, g.Qpad, npe, d_off,
+                       d_nodes, d_attr, d_grad, d_w, g.d_geom);
+  else if (dim == 1)
+    hipLaunchKernelGGL(geom_dense1_kernel<2>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, ne, Q, g.Qpad, npe, d_off,
+                       d_nodes, d_attr, d_grad, d_w, g.d_geom);
+  else if (dim == 2 && sdim == 3)
     hipLaunchKernelGGL(geom_dense32_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, ne, Q, g.Qpad, npe, d_off,
                        d_nodes, d_attr, d_grad, d_w, g.d_geom);
   else if (dim == 2)
@@ -1339,8 +1417,13 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       parse_coeff(ctx, ctx_size, 1, ds->c1, ds->c0.slots);
       break;
     case MODE_DIFFMASS2:
+    case MODE_DIFFMASS1:
       parse_coeff(ctx, ctx_size, 1, ds->c0, 0);
       parse_coeff(ctx, ctx_size, sdim == 3 ? 3 : 2, ds->c1, ds->c0.slots);
+      break;
+    case MODE_VMASS1:
+    case MODE_DIFF1:
+      parse_coeff(ctx, ctx_size, sdim == 3 ? 3 : 2, ds->c0, 0);
       break;
   }
 
@@ -1389,7 +1472,22 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       DenseArgs a = make_args(*ds);
       const long long n = (long long)ne * Q;
       const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-      if (dim == 3 && mode == MODE_CURL2) {
+      if (dim == 1) {
+        switch (mode) {
+#define PA_QD1_CASE(MODE)                                                                          \
+  case MODE:                                                                                       \
+    if (sdim == 3)                                                                                 \
+      hipLaunchKernelGGL((dense_qdata1_kernel<MODE, 3>), grid, block, 0, nullptr, a, ds->d_qdata); \
+    else                                                                                           \
+      hipLaunchKernelGGL((dense_qdata1_kernel<MODE, 2>), grid, block, 0, nullptr, a, ds->d_qdata); \
+    break;
+          PA_QD1_CASE(MODE_MASS)
+          PA_QD1_CASE(MODE_VMASS1)
+          PA_QD1_CASE(MODE_DIFF1)
+          PA_QD1_CASE(MODE_DIFFMASS1)
+#undef PA_QD1_CASE
+        }
+      } else if (dim == 3 && mode == MODE_CURL2) {
         hipLaunchKernelGGL((dense_qdata2_kernel<MODE_CURL2, 11>), grid, block, 0, nullptr, a, ds->d_qdata);
       } else if (dim == 2) {
         switch (mode) {
@@ -1591,6 +1689,9 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
     PA_DIAG2_CASE(MODE_MASS)
     PA_DIAG2_CASE(MODE_DIFF2)
     PA_DIAG2_CASE(MODE_DIFFMASS2)
+    PA_DIAG2_CASE(MODE_VMASS1)
+    PA_DIAG2_CASE(MODE_DIFF1)
+    PA_DIAG2_CASE(MODE_DIFFMASS1)
 #undef PA_DIAG2_CASE
     default: break;
   }

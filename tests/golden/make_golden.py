@@ -132,6 +132,33 @@ def fixtures_2d():
     print("wrote qf2d_golden.npz")
 
 
+def fixtures_line():
+    """Line-element QFunction vectors (fem/qfunctions/21, 31) through the reference headers."""
+    capi.build(ref=True)
+    rng = np.random.default_rng(20260927)
+    Q = 20
+    attr = rng.integers(1, 3, Q).astype(np.float64)
+    qw = rng.uniform(0.01, 0.2, Q)
+    u, gu = rng.uniform(-1, 1, (1, Q)), rng.uniform(-1, 1, (1, Q))
+    A2, A3 = rng.uniform(-1, 1, (2, 2)), rng.uniform(-1, 1, (3, 3))
+    c2 = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[A2 + 2 * np.eye(2), np.array([0.6])], a=1.2, dim=2)  # non-symmetric on purpose
+    c3 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([0.8]), A3 + 2 * np.eye(3)], a=0.9)
+    c1 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([1.9]), np.array([0.4])], dim=1)
+    out = dict(Q=Q, attr=attr, qw=qw, u=u, gu=gu, ctx1=c1.pack(), ctx2=c2.pack(), ctx3=c3.pack())
+    for sdim, cm in ((2, c2), (3, c3)):
+        J = rng.uniform(-1, 1, (sdim, Q)) + np.array([1.0, 0.3, -0.2][:sdim]).reshape(sdim, 1)
+        g = np.zeros((2 + sdim, Q))
+        capi.ref_call("f_build_geom_factor_%d1" % sdim, None, Q, [attr, qw, np.ascontiguousarray(J)], [g])
+        v = np.zeros((1, Q))
+        capi.ref_call("f_apply_hcurl_%d1" % sdim, cm.pack(), Q, [g, u], [v])
+        mv, gv = np.zeros((1, Q)), np.zeros((1, Q))
+        capi.ref_call("f_apply_hcurlmass_%d1" % sdim, np.concatenate([c1.pack(), cm.pack()]), Q, [g, u, gu], [mv, gv])
+        out.update({"J%d1" % sdim: J, "geom%d1" % sdim: g, "hcurl_%d1" % sdim: v, "hcurlmass_%d1_v" % sdim: mv,
+                    "hcurlmass_%d1_gv" % sdim: gv})
+    np.savez(os.path.join(ROOT, "tests", "golden", "qf1d_golden.npz"), **out)
+    print("wrote qf1d_golden.npz")
+
+
 def cavity2d_fixture():
     """The reference's cavity2d mesh and its regression values (eig.csv, terminal-M.csv, terminal-C.csv)."""
     from palace_amd.fem import tri
@@ -240,6 +267,7 @@ def cpw_fixture():
 if __name__ == "__main__":
     mesh_fixture()
     fixtures_2d()
+    fixtures_line()
     cavity2d_fixture()
     spheres_fixture()
     cpw_fixture()

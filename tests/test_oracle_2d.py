@@ -67,6 +67,22 @@ def test_pair_qfunctions_22_32():
     np.testing.assert_allclose(gv[0], G["hcurlmass_32_gv"], rtol=1e-12, atol=1e-13)
 
 
+def test_line_element_qfunctions_21_31():
+    """geom_21 / geom_31, f_apply_hcurl_21 / _31, f_apply_hcurlmass_21 / _31 (line elements: boundaries of plane problems, curves
+    in space) against vectors produced by the reference headers (tests/golden/make_golden.py: fixtures_line)."""
+    L = np.load(os.path.join(os.path.dirname(__file__), "golden", "qf1d_golden.npz"))
+    c1, _ = _ctx(L["ctx1"], 1)
+    for sdim in (2, 3):
+        cm, _ = _ctx(L["ctx%d" % sdim], sdim)
+        geom = po.build_geom_factor_line(np.ones(1), L["qw"], L["J%d1" % sdim].T[None])
+        np.testing.assert_allclose(geom[0, 1:], L["geom%d1" % sdim][1:], rtol=1e-13, atol=1e-13)
+        g = L["geom%d1" % sdim][None]
+        np.testing.assert_allclose(po.apply_hcurl_line(cm, g, L["u"][None])[0], L["hcurl_%d1" % sdim], rtol=1e-13, atol=1e-13)
+        mv, gv = po.apply_hcurlmass_line(c1, cm, g, L["u"][None], L["gu"][None])
+        np.testing.assert_allclose(mv[0], L["hcurlmass_%d1_v" % sdim], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(gv[0], L["hcurlmass_%d1_gv" % sdim], rtol=1e-13, atol=1e-13)
+
+
 def test_cavity2d_eigenfrequencies():
     """Order-2 Nedelec triangles on the reference's own mesh, eps_r = 2.08 with loss tangent 4e-4, PEC:
     K x = omega^2 eps M x  ->  f = sqrt(lambda / (eps_r (1 - i tan d))) c0 / 2 pi."""
