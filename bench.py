@@ -278,8 +278,32 @@ def tets_leg(order, n, reps=20):
         out[name] = {"ms": ms, "dof_per_s": nd.ndofs / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
                      "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
                      "table_TFLOPs": mesh.ne * (2 * 2 * nct * len(wts) * nd.P) / ms / 1e9}
-    # PCG + p-multigrid (p = 1..order) with the auxiliary-space smoother on the same mesh
+    # complex apply (BASELINE config 3's shape): (K - w^2 eps M) + i w sigma M in one pass (pa_op_mult_complex, dense form)
     from palace_amd import linalg
+
+    cctx = linalg.Context()
+    neg = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([-2.08 * 0.3])])
+    cond = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([0.05])])
+    Ar = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(geom, block, ceed.QF_HDIVMASS_33, np.concatenate([neg, ident]),
+                                                               ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
+    Ai = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(geom, block, ceed.QF_HCURL_33, cond, ceed.EVAL_INTERP).finalize()
+    Ac = linalg.ComplexParOperator(cctx, Ar, Ai)
+    xi, yi = torch.rand_like(x), torch.zeros_like(x)
+    for _ in range(5):
+        Ac.mult(x, xi, y, yi)
+    with torch.cuda.stream(cctx.torch_stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            Ac.mult(x, xi, y, yi)
+        e1.record()
+        torch.cuda.synchronize()
+    cms = e0.elapsed_time(e1) / reps
+    out["complex"] = {"one_pass": int(ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle)), "ms": cms,
+                      "complex_dof_per_s": nd.ndofs / (cms * 1e-3)}
+    del Ac, Ar, Ai
+    # PCG + p-multigrid (p = 1..order) with the auxiliary-space smoother on the same mesh
     from palace_amd.fem.tetproblem import TetProblem
 
     prob = TetProblem(linalg.Context(), mesh, order)
