@@ -37,6 +37,13 @@ int pa_context_synchronize(pa_context *ctx);
 /* rank 0 fills 128 bytes; the caller broadcasts them to all ranks by any means */
 int pa_comm_unique_id(char *out128);
 int pa_context_init_comm(pa_context *ctx, int rank, int size, const char *unique_id128);
+/* Test harness for the multi-rank code paths on a one-GPU machine: `size` ranks as threads of ONE process, each with its own
+ * context (and stream); collectives rendezvous on a host barrier and copy through device memory instead of RCCL.  Every rank
+ * thread must make the same sequence of collective calls.  Not a product path (tests/test_multirank_local_gpu.py). */
+typedef struct pa_local_group pa_local_group;
+int pa_local_group_create(int size, pa_local_group **group);
+void pa_local_group_destroy(pa_local_group *group);
+int pa_context_init_comm_local(pa_context *ctx, int rank, pa_local_group *group);
 int pa_context_rank(const pa_context *ctx);
 int pa_context_size(const pa_context *ctx);
 /* in-place sum of n doubles (device memory) over all ranks */

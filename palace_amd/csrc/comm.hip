@@ -96,8 +96,22 @@ Comm::Comm(int rank, int size, const char *unique_id) : rank_(rank), size_(size)
   PA_NCCL(rccl().CommInitRank(&nccl_, size, id, rank));
 }
 
+Comm::Comm(int rank, LocalGroup &group) : rank_(rank), size_(group.Size()), local_(&group) {}
+
 Comm::~Comm() {
   if (nccl_) rccl().CommDestroy(nccl_);
+}
+
+void LocalGroup::Arrive() {
+  std::unique_lock<std::mutex> lk(m_);
+  const long gen = generation_;
+  if (++waiting_ == size_) {
+    waiting_ = 0;
+    generation_++;
+    cv_.notify_all();
+  } else {
+    cv_.wait(lk, [&] { return generation_ != gen; });
+  }
 }
 
 Halo::~Halo() {
@@ -130,6 +144,20 @@ Halo::Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int3
 
 void Comm::AllReduceSum(double *d_buf, int n, hipStream_t s) {
   if (size_ == 1) return;
+  if (local_) {  // values to the host, barrier, sum in rank order (the same on every rank), barrier, back to the device
+    PA_REQUIRE(n <= LocalGroup::kMaxValues, "too many values for the in-process all-reduce");
+    double *mine = local_->slots_.data() + (size_t)rank_ * LocalGroup::kMaxValues;
+    PA_HIP(hipMemcpyAsync(mine, d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipStreamSynchronize(s));
+    local_->Arrive();
+    std::vector<double> sum((size_t)n, 0.0);
+    for (int r = 0; r < size_; r++)
+      for (int i = 0; i < n; i++) sum[i] += local_->slots_[(size_t)r * LocalGroup::kMaxValues + i];
+    local_->Arrive();
+    PA_HIP(hipMemcpyAsync(d_buf, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+    PA_HIP(hipStreamSynchronize(s));
+    return;
+  }
   PA_NCCL(rccl().AllReduce(d_buf, d_buf, (size_t)n, kNcclFloat64, kNcclSum, nccl_, s));
 }
 
@@ -139,10 +167,37 @@ void Comm::Barrier(hipStream_t s) {
   PA_HIP(hipStreamSynchronize(s));
 }
 
+void Halo::ExchangeLocal(const double *sendbase, const std::vector<int> &send_off, double *recvbase,
+                         const std::vector<int> &recv_off, hipStream_t s) const {
+  LocalGroup &g = *comm_->local_;
+  const int me = comm_->rank_;
+  PA_HIP(hipStreamSynchronize(s));  // my send pieces are complete
+  g.box_[me] = LocalGroup::Box{sendbase, nbr_.data(), send_off.data(), (int)nbr_.size()};
+  g.Arrive();
+  for (size_t k = 0; k < nbr_.size(); k++) {
+    const int nr = recv_off[k + 1] - recv_off[k];
+    if (!nr) continue;
+    const LocalGroup::Box &b = g.box_[nbr_[k]];
+    int j = 0;
+    while (j < b.nnbr && b.nbr[j] != me) j++;
+    PA_REQUIRE(j < b.nnbr && b.off[j + 1] - b.off[j] == nr, "halo plans of two ranks do not match");
+    PA_HIP(hipMemcpyAsync(recvbase + recv_off[k], b.buf + b.off[j], sizeof(double) * nr, hipMemcpyDeviceToDevice, s));
+  }
+  PA_HIP(hipStreamSynchronize(s));
+  g.Arrive();  // the send buffers may be reused
+}
+
 void Halo::Prolongate(double *d_lx, hipStream_t s) const {
   void *nccl_ = comm_->nccl_;
-  if (nbr_.empty()) return;
+  if (nbr_.empty() && !comm_->local_) return;
   if (nsend_) hipLaunchKernelGGL(k_pack, dim3(blocks(nsend_)), dim3(256), 0, s, d_lx, d_send_idx_, nsend_, d_sendbuf_);
+  if (comm_->local_) {
+    ExchangeLocal(d_sendbuf_, send_off_, recv_first_ >= 0 ? d_lx + recv_first_ : d_recvbuf_, recv_off_, s);
+    if (nrecv_ && recv_first_ < 0)
+      hipLaunchKernelGGL(k_unpack, dim3(blocks(nrecv_)), dim3(256), 0, s, d_lx, d_recv_idx_, nrecv_, d_recvbuf_);
+    PA_HIP(hipGetLastError());
+    return;
+  }
   PA_NCCL(rccl().GroupStart());
   for (size_t k = 0; k < nbr_.size(); k++) {
     const int ns = send_off_[k + 1] - send_off_[k], nr = recv_off_[k + 1] - recv_off_[k];
@@ -158,11 +213,22 @@ void Halo::Prolongate(double *d_lx, hipStream_t s) const {
 
 void Halo::RestrictAdd(double *d_ly, hipStream_t s) const {
   void *nccl_ = comm_->nccl_;
-  if (nbr_.empty()) return;
+  if (nbr_.empty() && !comm_->local_) return;
   // roles reversed: ghosts are packed and sent to their owners
   if (nrecv_ && recv_first_ < 0)
     hipLaunchKernelGGL(k_pack, dim3(blocks(nrecv_)), dim3(256), 0, s, d_ly, d_recv_idx_, nrecv_, d_sendbuf_);
   const double *src = recv_first_ >= 0 ? d_ly + recv_first_ : d_sendbuf_;  // contiguous ghosts: sent from the vector itself
+  if (comm_->local_) {
+    ExchangeLocal(src, recv_off_, d_recvbuf_, send_off_, s);
+    for (size_t k = 0; k < nbr_.size(); k++) {
+      const int nr = send_off_[k + 1] - send_off_[k];
+      if (nr)
+        hipLaunchKernelGGL(k_unpack_add, dim3(blocks(nr)), dim3(256), 0, s, d_ly, d_send_idx_ + send_off_[k], nr,
+                           d_recvbuf_ + send_off_[k]);
+    }
+    PA_HIP(hipGetLastError());
+    return;
+  }
   PA_NCCL(rccl().GroupStart());
   for (size_t k = 0; k < nbr_.size(); k++) {
     const int ns = recv_off_[k + 1] - recv_off_[k], nr = send_off_[k + 1] - send_off_[k];

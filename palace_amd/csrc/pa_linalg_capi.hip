@@ -105,6 +105,24 @@ int pa_context_init_comm(pa_context *ctx, int rank, int size, const char *id) {
     ctx->ctx.comm = ctx->comm.get();
   });
 }
+struct pa_local_group {
+  LocalGroup group;
+  explicit pa_local_group(int size) : group(size) {}
+};
+int pa_local_group_create(int size, pa_local_group **out) {
+  return guarded([&] {
+    PA_REQUIRE(size >= 1 && out, "bad group size");
+    *out = new pa_local_group(size);
+  });
+}
+void pa_local_group_destroy(pa_local_group *g) { delete g; }
+int pa_context_init_comm_local(pa_context *ctx, int rank, pa_local_group *g) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && g && rank >= 0 && rank < g->group.Size(), "bad communicator arguments");
+    ctx->comm = std::make_unique<Comm>(rank, g->group);
+    ctx->ctx.comm = ctx->comm.get();
+  });
+}
 int pa_context_rank(const pa_context *ctx) { return ctx && ctx->comm ? ctx->comm->Rank() : 0; }
 int pa_context_size(const pa_context *ctx) { return ctx && ctx->comm ? ctx->comm->Size() : 1; }
 int pa_allreduce_sum(pa_context *ctx, double *buf, int n) {

@@ -70,6 +70,11 @@ class Context:
         _lib.check(L.pa_context_init_comm(self.handle, rank, size, raw))
         self.rank, self.size = rank, size
 
+    def init_comm_local(self, group, rank):
+        """Rank `rank` of an in-process group of rank THREADS on one GPU (pa_local_group_*: test harness of the multi-rank paths)."""
+        _lib.check(_L().pa_context_init_comm_local(self.handle, int(rank), group.handle))
+        self.rank, self.size, self._group = int(rank), group.size, group
+
     def init_comm_single(self):
         """One-rank communicator (exercises RCCL init / allreduce without a second GPU)."""
         L = _L()
@@ -140,6 +145,24 @@ class Context:
     def __del__(self):
         try:
             _L().pa_context_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class LocalGroup:
+    """pa_local_group: the rendezvous object shared by the rank threads of an in-process group."""
+
+    def __init__(self, size):
+        L = _L()
+        L.pa_local_group_destroy.restype = None
+        L.pa_local_group_destroy.argtypes = [C.c_void_p]
+        self.size = int(size)
+        self.handle = C.c_void_p()
+        _lib.check(L.pa_local_group_create(self.size, C.byref(self.handle)))
+
+    def __del__(self):
+        try:
+            _L().pa_local_group_destroy(self.handle)
         except Exception:
             pass
 

@@ -1,0 +1,97 @@
+"""The multi-rank C++ code paths on ONE GPU: `world` ranks run as threads of this process, each with its own Context / stream and
+its slab of the cylinder (palace_amd/fem/partition.py), joined by the in-process communicator (pa_local_group_*, comm.hpp:
+LocalGroup -- the same Halo plans, pack / unpack kernels, in-place ghost ranges, ParOperator P / P^T, transfers and discrete
+gradients with ghosts, global dots and the device-resident PCG scalars as under RCCL; only the transport differs).  The
+basis-independent results -- PCG iteration count, ||b||^2, ||x||^2, x.Ax and the number of true dofs -- must equal those of the
+undivided problem on one rank.  (The RCCL transport itself is exercised by tests/test_halo_gpu.py.)"""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+NZ = 8
+
+
+def _rank_main(group, rank, world, p, hiptmair, out, errors):
+    try:
+        import torch
+
+        from palace_amd import linalg
+        from palace_amd.fem.partition import SlabProblem
+
+        torch.cuda.set_device(0)
+        ctx = linalg.Context()
+        if world > 1:
+            ctx.init_comm_local(group, rank)
+        prob = SlabProblem(ctx, rank, world, p, 0, shape=(2, NZ // world))
+        K, b, x = prob.pcg_gmg_solver(max_it=200, rel_tol=1e-9, hiptmair=hiptmair, coarse="cg")
+        K.mult(b, x)
+        st = K.stats()
+        A = prob._keep[-1][1][-1]
+        y = torch.zeros_like(x)
+        A.mult(x, y)
+        # one more application of the fine operator alone, on a vector that is not a solve result
+        z = torch.zeros_like(x)
+        A.mult(b, z)
+        out[rank] = dict(st, n=int(prob.n_true[-1]), xx=ctx.dot(x, x), xAx=ctx.dot(x, y), bb=ctx.dot(b, b), bAb=ctx.dot(b, z),
+                         zz=ctx.dot(z, z))
+        ctx.synchronize()
+    except Exception as e:  # a failing rank must not leave the others waiting at a barrier for ever
+        errors.append((rank, repr(e)))
+        raise
+
+
+def _run(world, p, hiptmair):
+    from palace_amd import linalg
+
+    group = linalg.LocalGroup(world) if world > 1 else None
+    out, errors = [None] * world, []
+    threads = [threading.Thread(target=_rank_main, args=(group, r, world, p, hiptmair, out, errors), daemon=True)
+               for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank thread is stuck (collective sequence out of step?)"
+    res = dict(out[0])
+    res["n"] = sum(o["n"] for o in out)
+    for o in out[1:]:  # the reductions are global: every rank holds the same values
+        for k in ("xx", "xAx", "bb", "bAb", "zz", "iterations"):
+            assert o[k] == out[0][k], (k, o[k], out[0][k])
+    return res
+
+
+@pytest.mark.parametrize("hiptmair", [False, True])
+@pytest.mark.parametrize("p", [2, 3])
+def test_ranks_as_threads_match_one_rank(p, hiptmair):
+    one = _run(1, p, hiptmair)
+    assert one["converged"]
+    for world in (2, 4, 8):
+        many = _run(world, p, hiptmair)
+        assert many["converged"] and many["n"] == one["n"], (world, many["n"], one["n"])
+        assert abs(many["iterations"] - one["iterations"]) <= 1, (world, many["iterations"], one["iterations"])
+        for k in ("bb", "bAb", "zz"):  # operator applies: rounding only
+            assert abs(many[k] - one[k]) < 1e-11 * abs(one[k]), (world, k, many[k], one[k])
+        for k in ("xx", "xAx"):  # solves to 1e-9
+            assert abs(many[k] - one[k]) < 1e-6 * abs(one[k]), (world, k, many[k], one[k])
+
+
+def test_ranks_as_threads_with_halo_stream_overlap():
+    """The same with PALACE_AMD_OVERLAP=1: ghosts exchanged on the second stream while the interior element batches run."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests.test_multirank_local_gpu import _run\n"
+            "one, four = _run(1, 3, True), _run(4, 3, True)\n"
+            "assert four['converged'] and four['n'] == one['n'] and abs(four['iterations'] - one['iterations']) <= 1\n"
+            "for k in ('bb', 'bAb', 'zz'):\n"
+            "    assert abs(four[k] - one[k]) < 1e-11 * abs(one[k]), (k, four[k], one[k])\n"
+            "print('OK')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PALACE_AMD_OVERLAP="1"))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
