@@ -34,8 +34,20 @@ def _rank_main(group, rank, world, p, hiptmair, out, errors):
         # one more application of the fine operator alone, on a vector that is not a solve result
         z = torch.zeros_like(x)
         A.mult(b, z)
+        # the complex layer across ranks: (A_r + i A_i)(b + i z) through ComplexParOperator with a halo (copy / mask / P,
+        # one-pass local apply, P^T / fix-up), global complex dots
+        from palace_amd import ceed
+
+        nd = prob.spaces[-1]
+        neg = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([-0.7])])
+        cond = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([0.05])])
+        Ar = ceed.curlcurlmass_operator(prob.geom, nd, neg, ceed.coefficient_context(3))
+        Ai = ceed.ndmass_operator(prob.geom, nd, cond)
+        Ac = linalg.ComplexParOperator(ctx, Ar, Ai, prob.ess[-1], linalg.DIAG_ONE, n_true=prob.n_true[-1], halo=prob.halos[-1])
+        cr, ci = torch.zeros_like(x), torch.zeros_like(x)
+        Ac.mult(b, z, cr, ci)
         out[rank] = dict(st, n=int(prob.n_true[-1]), xx=ctx.dot(x, x), xAx=ctx.dot(x, y), bb=ctx.dot(b, b), bAb=ctx.dot(b, z),
-                         zz=ctx.dot(z, z))
+                         zz=ctx.dot(z, z), crcr=ctx.dot(cr, cr), cici=ctx.dot(ci, ci), crci=ctx.dot(cr, ci))
         ctx.synchronize()
     except Exception as e:  # a failing rank must not leave the others waiting at a barrier for ever
         errors.append((rank, repr(e)))
@@ -58,7 +70,7 @@ def _run(world, p, hiptmair):
     res = dict(out[0])
     res["n"] = sum(o["n"] for o in out)
     for o in out[1:]:  # the reductions are global: every rank holds the same values
-        for k in ("xx", "xAx", "bb", "bAb", "zz", "iterations"):
+        for k in ("xx", "xAx", "bb", "bAb", "zz", "crcr", "cici", "crci", "iterations"):
             assert o[k] == out[0][k], (k, o[k], out[0][k])
     return res
 
@@ -72,7 +84,7 @@ def test_ranks_as_threads_match_one_rank(p, hiptmair):
         many = _run(world, p, hiptmair)
         assert many["converged"] and many["n"] == one["n"], (world, many["n"], one["n"])
         assert abs(many["iterations"] - one["iterations"]) <= 1, (world, many["iterations"], one["iterations"])
-        for k in ("bb", "bAb", "zz"):  # operator applies: rounding only
+        for k in ("bb", "bAb", "zz", "crcr", "cici", "crci"):  # operator applies: rounding only
             assert abs(many[k] - one[k]) < 1e-11 * abs(one[k]), (world, k, many[k], one[k])
         for k in ("xx", "xAx"):  # solves to 1e-9
             assert abs(many[k] - one[k]) < 1e-6 * abs(one[k]), (world, k, many[k], one[k])
