@@ -126,6 +126,8 @@ struct DenseArgs {
   const double *qdata;  // packed pre-assembled D: [nb][ncq][Qpad][16]
   int ncq, Q4;  // q-data components and its point stride (Q rounded up to a multiple of 4)
   const uint8_t *affine;  // non-null: every element has a constant Jacobian, D_q = (w_q / w_0) D_0
+  const int32_t *blist;   // optional list of the element blocks this launch works on (nblist entries): a mesh with affine and
+  int nblist;             // curved blocks runs the affine kernel on the former and the general one on the latter
   // complex form (CPLX): imaginary parts of x and of the E-vector; packed D of the imaginary operator with the offsets of its
   // mass / curl-curl components (-1: no such term)
   const double *x1;
@@ -519,9 +521,9 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
   const int ngroups = a.Q4 / 4;
   // work units: element blocks, or (CPLX) half blocks -- unit w is columns 8 (w & 1) .. + 7 of block w >> 1, and lane (kq, j)
   // works on element column 8 (w & 1) + (j & 7), part j >> 3
-  const int nunits = CPLX ? 2 * a.nb : a.nb;
+  const int nunits = CPLX ? 2 * a.nb : (a.blist ? a.nblist : a.nb);
   const int j8 = j & 7;
-  auto ublock = [&](const int w) { return (size_t)(CPLX ? w >> 1 : w); };
+  auto ublock = [&](const int w) { return (size_t)(CPLX ? w >> 1 : (a.blist ? a.blist[w] : w)); };
   auto ucol = [&](const int w) { return CPLX ? 8 * (w & 1) + j8 : j; };          // element column in the block's arrays
   auto ulane = [&](const int w) { return CPLX ? kq * 16 + 8 * (w & 1) + j8 : lane; };  // position in a [.][64] row
   const double *xsel = (CPLX && (j >> 3)) ? a.x1 : a.x;
@@ -941,11 +943,21 @@ __global__ void dense_diag_qd_kernel(const DenseArgs a, const int32_t *__restric
 template <int PT>
 void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
   const int rows = ds.L_rows;
+  if (ds.d_blist[0] && !a.blist) {  // affine and curved blocks: one launch each on its list (they write disjoint E-vector blocks)
+    DenseArgs aa = a, ag = a;
+    aa.blist = ds.d_blist[0], aa.nblist = ds.n_blist[0];
+    ag.blist = ds.d_blist[1], ag.nblist = ds.n_blist[1], ag.affine = nullptr;
+    launch_resident_pt<PT>(ds, aa, s);
+    launch_resident_pt<PT>(ds, ag, s);
+    return;
+  }
   const bool affine = a.affine && PT <= 3;  // (make_dense_sub: larger blocks have no registers for the values kept across the block)
   const int nw = affine ? kAffWaves : kResWaves;
   const size_t shm = sizeof(double) * ((size_t)(a.Q4 + 31) / 32 * 32 + (size_t)rows * ResidentStride<PT>::S +
                                       (ds.d_co ? (size_t)nw * 4 * PT * 64 : 0));
-  int grid = (ds.nb + nw - 1) / nw;
+  const int nblocks = a.blist ? a.nblist : ds.nb;
+  if (nblocks == 0) return;
+  int grid = (nblocks + nw - 1) / nw;
   if (grid > ds.num_cu) grid = ds.num_cu;
   switch (ds.mode) {
 #define PA_RES_CASE(MODE)                                                                                \
@@ -1180,6 +1192,7 @@ DenseArgs make_args(const DenseSub &ds) {
   a.L = ds.d_L, a.qdata = ds.d_qdata, a.ncq = ds.ncq, a.Q4 = (ds.Q + 3) / 4 * 4;
   a.affine = ds.d_affine, a.wrel = ds.d_wrel;
   a.x1 = nullptr, a.ye1 = nullptr, a.qdata_i = nullptr, a.ncq_i = 0, a.qi_mass = a.qi_curl = -1;
+  a.blist = nullptr, a.nblist = 0;
   a.dbg = 0;
 #ifdef PA_ABLATION
   a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
@@ -1537,7 +1550,12 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
         hipFree(d_na);
         std::vector<uint8_t> flag((size_t)nb);
         for (int i = 0; i < nb; i++) flag[i] = na[i] ? 0 : 1, ds->n_affine += flag[i];
-        if (ds->n_affine == nb) {  // all or nothing (a mixed mesh keeps the general kernel)
+        if (ds->n_affine < nb && ds->n_affine * 4 >= nb) {  // a mesh with curved parts: the affine blocks get the affine kernel
+          std::vector<int32_t> lists[2];
+          for (int i = 0; i < nb; i++) lists[flag[i] ? 0 : 1].push_back(i);
+          for (int k = 0; k < 2; k++) ds->d_blist[k] = dev_upload(lists[k].data(), lists[k].size()), ds->n_blist[k] = (int)lists[k].size();
+        }
+        if (ds->n_affine == nb || ds->d_blist[0]) {
           std::vector<double> wrel((size_t)Q4, 0.0);
           for (int i = 0; i < Q; i++) wrel[i] = geom->wq[i] / geom->wq[0];
           ds->d_affine = dev_upload(flag.data(), flag.size());
@@ -1552,7 +1570,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
 }
 
 void free_dense_sub(DenseSub *ds) {
-  if (ds) hipFree(ds->d_affine), hipFree(ds->d_wrel), hipFree(ds->d_ye2);
+  if (ds) hipFree(ds->d_affine), hipFree(ds->d_wrel), hipFree(ds->d_ye2), hipFree(ds->d_blist[0]), hipFree(ds->d_blist[1]);
   if (!ds) return;
   hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co);
   hipFree(ds->d_Tf), hipFree(ds->d_Tt), hipFree(ds->d_interp), hipFree(ds->d_deriv);
@@ -1610,8 +1628,8 @@ void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStr
 bool dense_complex_ok(const DenseSub &dr, const DenseSub &di) {
   static const bool enabled = !(getenv("PALACE_AMD_COMPLEX_FUSED") && atoi(getenv("PALACE_AMD_COMPLEX_FUSED")) == 0);
   if (!enabled || dr.fe_type != PA_FE_HCURL || di.fe_type != PA_FE_HCURL || dr.geom != di.geom || dr.geom->dim != 3) return false;
-  if (dr.mode != MODE_CURLMASS || !dr.d_L || !dr.d_affine || dr.PT > 3) return false;
-  if (!(di.mode == MODE_CURLMASS || di.mode == MODE_VMASS || di.mode == MODE_CURL) || !di.d_qdata || !di.d_affine) return false;
+  if (dr.mode != MODE_CURLMASS || !dr.d_L || !dr.d_affine || dr.d_blist[0] || dr.PT > 3) return false;
+  if (!(di.mode == MODE_CURLMASS || di.mode == MODE_VMASS || di.mode == MODE_CURL) || !di.d_qdata || !di.d_affine || di.d_blist[0]) return false;
   if (dr.ne != di.ne || dr.P != di.P || dr.Q != di.Q || dr.lsize != di.lsize) return false;
   if (di.mode != MODE_CURL && di.chk_interp != dr.chk_interp) return false;
   if (di.mode != MODE_VMASS && di.chk_deriv != dr.chk_deriv) return false;

@@ -217,6 +217,8 @@ struct DenseSub {
   uint8_t *d_affine = nullptr; // [nb] blocks whose elements all have a constant Jacobian (D_q = (w_q / w_0) D_0) or nullptr
   double *d_wrel = nullptr;    // [Q4] w_q / w_0
   int n_affine = 0;
+  int32_t *d_blist[2] = {nullptr, nullptr};  // mixed meshes: the affine blocks / the others (else nullptr: one kind only)
+  int n_blist[2] = {0, 0};
   int L_rows = 0, ncq = 0, num_cu = 0;
   double *d_interp = nullptr, *d_deriv = nullptr;  // plain tables (diagonal assembly)
   int32_t *d_off = nullptr;    // plain [ne][P] offsets (diagonal assembly)

@@ -164,6 +164,52 @@ def test_h1_tet_apply(p, mode):
         assert float(yd.abs().max()) < 1e-11 * float(np.abs(y_ref).max())
 
 
+@pytest.mark.parametrize("mode", ND_MODES, ids=[m[0] for m in ND_MODES])
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_nd_tet_apply_partly_curved_mesh(p, mode):
+    """A tet10 mesh that is curved in one half only (what a Palace mesh with a curved boundary looks like): the blocks of
+    straight elements run the affine form, the others the general one, in two launches on block lists."""
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import tet
+
+    name, qf_name, qf_o, ops_s = mode
+    base = tet.cube_tet_mesh(5)
+
+    def half_warp(X):
+        w = np.clip(X[:, 0] - 0.45, 0.0, None) ** 2  # identity for x <= 0.45
+        return X + np.stack([0.3 * w * np.sin(3 * X[:, 1]), 0.4 * w * X[:, 2], -0.35 * w * np.cos(2 * X[:, 1])], axis=1)
+
+    mesh = tet.to_quadratic(base, half_warp)
+    mesh.attr[:] = 1 + (np.arange(mesh.ne) % 2)
+    nd = tet.NDTetSpace(mesh, p)
+    pts, wts = tet.tet_quadrature(p + 1) if not (p == 3 and name == "curlmass") else tet.default_tet_rule(p)
+    interp, curl = nd.elem.tables(pts)
+    geom, ogeom = _geom(mesh, pts, wts)
+    c3, b3 = util.make_ctx("aniso", 2)
+    cm, bm = util.make_ctx("scalar", 2)
+    ctxs, blob = ((cm, c3), np.concatenate([bm, b3])) if name == "curlmass" else ((c3, None), b3)
+    kw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+    okw = dict(curl_orients=nd.curl_orients) if not nd.diagonal_transform else {}
+    block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, **kw)
+    orc = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients if nd.diagonal_transform else None, interp, curl, ogeom, qf_o,
+                                *ctxs, **okw)
+    ops = sum({"C": ceed.EVAL_CURL, "I": ceed.EVAL_INTERP}[c] for c in ops_s)
+    op = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(geom, block, getattr(ceed, qf_name), blob, ops).finalize()
+    assert op.dense_affine() == 1  # (some blocks: the straight half)
+    x = np.random.default_rng(p).uniform(-1, 1, nd.ndofs)
+    y_ref = orc.apply_add(x, np.zeros(nd.ndofs))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    op.mult(xd, yd)
+    assert np.abs(yd.cpu().numpy() - y_ref).max() / np.abs(y_ref).max() < REL
+    dd = torch.empty_like(xd)
+    op.assemble_diagonal(dd)
+    d_ref = orc.diagonal()
+    assert np.abs(dd.cpu().numpy() - d_ref).max() / np.abs(d_ref).max() < REL
+
+
 @pytest.mark.parametrize("p", [1, 2, 3])
 @pytest.mark.parametrize("kind", ["tet4", "tet10"])
 def test_nd_tet_boundary_curlcurl_and_pair(kind, p):
