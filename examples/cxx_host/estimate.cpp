@@ -4,11 +4,14 @@
 //   GradFluxErrorEstimator::AddErrorIndicator(E), CurlFluxErrorEstimator::AddErrorIndicator(B),
 //   TimeDependentFluxErrorEstimator::AddErrorIndicator(E, B)
 // (linalg/errorestimator.cpp:271-541) into ErrorIndicators; prints the indicator norms, PCG iteration counts and writes
-// the three indicator vectors to a file.
+// the three indicator vectors to a file.  With the H1 space of the dump it also applies
+//   BilinearForm(h1, nd) + MixedVectorGradientIntegrator(eps)   and   BilinearForm(h1, rt) + MixedVectorGradientIntegrator(eps)
+// (fem/integ/mixedvecgrad.cpp; the form of models/modeeigensolver.cpp:52) to a potential and writes both results to out.bin.grad.
 //   ./estimate problem.bin out.bin
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <string>
 #include <vector>
 
 #include "errorestimator.hpp"
@@ -80,6 +83,26 @@ int main(int argc, char **argv) {
     hipMemcpy(out.data() + ne, ic.Local().Data(), sizeof(double) * ne, hipMemcpyDeviceToHost);
     hipMemcpy(out.data() + 2 * (size_t)ne, it.Local().Data(), sizeof(double) * ne, hipMemcpyDeviceToHost);
     std::ofstream(argv[2], std::ios::binary).write(reinterpret_cast<const char *>(out.data()), sizeof(double) * out.size());
+    if (blobs.size() >= 23) {
+      const int h1_size = i32(18)[0], h1_P = i32(18)[1];
+      FiniteElementSpace h1(ctx, mesh, PA_FE_H1, p, h1_P, h1_size, i32(19), nullptr, nullptr, f64(20), f64(21));
+      const auto eps_c = eps.Coefficient();
+      Vector phi(h1_size), gn(nd_size), gr(rt_size);
+      hipMemcpy(phi.Data(), f64(22), sizeof(double) * h1_size, hipMemcpyHostToDevice);
+      BilinearForm to_nd(h1, nd), to_rt(h1, rt);
+      to_nd.AddDomainIntegrator<MixedVectorGradientIntegrator>(eps_c);
+      to_rt.AddDomainIntegrator<MixedVectorGradientIntegrator>(eps_c);
+      const auto op_nd = to_nd.PartialAssemble(), op_rt = to_rt.PartialAssemble();
+      op_nd->Mult(phi, gn);
+      op_rt->Mult(phi, gr);
+      hipStreamSynchronize(stream);
+      std::vector<double> g((size_t)nd_size + rt_size);
+      hipMemcpy(g.data(), gn.Data(), sizeof(double) * nd_size, hipMemcpyDeviceToHost);
+      hipMemcpy(g.data() + nd_size, gr.Data(), sizeof(double) * rt_size, hipMemcpyDeviceToHost);
+      std::ofstream(std::string(argv[2]) + ".grad", std::ios::binary)
+          .write(reinterpret_cast<const char *>(g.data()), sizeof(double) * g.size());
+      std::printf("mixed gradient: h1 %d\n", h1_size);
+    }
     std::printf("OK\n");
   } catch (const std::exception &e) {
     std::fprintf(stderr, "error: %s\n", e.what());

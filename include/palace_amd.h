@@ -74,7 +74,14 @@ enum pa_qfunction {
   PA_QF_HCURL_21 = 16,     /* f_apply_hcurl_21     fem/qfunctions/21/hcurl_21_qf.h:10-29 */
   PA_QF_HCURL_31 = 17,     /* f_apply_hcurl_31     fem/qfunctions/31/hcurl_31_qf.h */
   PA_QF_HCURLMASS_21 = 18, /* f_apply_hcurlmass_21 fem/qfunctions/21/hcurlmass_21_qf.h */
-  PA_QF_HCURLMASS_31 = 19  /* f_apply_hcurlmass_31 fem/qfunctions/31/hcurlmass_31_qf.h:10-38 */
+  PA_QF_HCURLMASS_31 = 19, /* f_apply_hcurlmass_31 fem/qfunctions/31/hcurlmass_31_qf.h:10-38 */
+  /* two spaces on plane elements (pa_op_add_sub_dense_mixed, pa_error_op_create with 2-D geometry data) */
+  PA_QF_HCURLHDIV_22 = 20,       /* f_apply_hcurlhdiv_22       fem/qfunctions/22/hcurlhdiv_22_qf.h:10-30 */
+  PA_QF_HDIVHCURL_22 = 21,       /* f_apply_hdivhcurl_22       fem/qfunctions/22/hcurlhdiv_22_qf.h:32-52 */
+  PA_QF_HCURLHDIV_ERROR_22 = 22, /* f_apply_hcurlhdiv_error_22 fem/qfunctions/22/hcurlhdiv_error_22_qf.h:10-41 */
+  PA_QF_HDIVHCURL_ERROR_22 = 23, /* f_apply_hdivhcurl_error_22 fem/qfunctions/22/hcurlhdiv_error_22_qf.h:43-74 */
+  PA_QF_HDIV_22 = 24             /* f_apply_hdiv_22 fem/qfunctions/22/hdiv_22_qf.h:10-30: mass of a plane H(div) space
+                                    (pa_op_add_sub_dense with PA_FE_HDIV, Interp) */
 };
 
 enum pa_fe_type {
@@ -249,8 +256,11 @@ int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *res
 /* Trial space != test space on the same elements: BilinearForm(trial_fespace, test_fespace) with VectorFEMassIntegrator, which
  * picks f_apply_hcurlhdiv_33 (H(curl) trial, H(div) test) or f_apply_hdivhcurl_33 (the other way round) from the map types of
  * the two elements (fem/integ/vecfemass.cpp:88-101) -- the `Flux` operator of FluxProjector (linalg/errorestimator.cpp:164-176).
- * Both evaluation modes are Interp; the H(div) basis carries its value table in `interp`.  op: height = test lsize, width =
- * trial lsize.  No transposed, essential-dof, diagonal or assembled form. */
+ * Both evaluation modes are Interp; the H(div) basis carries its value table in `interp`.  An H1 basis on a covariant side
+ * enters with its gradient table (`deriv`, Grad): with PA_QF_HCURL_33 / PA_QF_HCURL_22 that is MixedVectorGradientIntegrator
+ * (C grad phi, v), H1 trial and H(curl) test (fem/integ/mixedvecgrad.cpp:43-76; models/modeeigensolver.cpp:52), and with
+ * PA_QF_HCURLHDIV_* its H(div)-test form (mixedvecgrad.cpp:50-55).  Plane elements: the _22 QFunctions with 2-D geometry
+ * data.  op: height = test lsize, width = trial lsize.  No transposed, essential-dof, diagonal or assembled form. */
 int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
                               const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
                               const pa_dense_basis_desc *test_basis, int32_t qfunction, const void *ctx, size_t ctx_size);

@@ -419,6 +419,71 @@ def apply_hcurl_22(ctx, geom, u):
     return np.stack([wdetJ * (A[0] * z0 + A[1] * z1), wdetJ * (A[2] * z0 + A[3] * z1)], axis=1)
 
 
+def _mult_AtBCx22(A, B, C, x0, x1):
+    """utils_22_qf.h:49-65: y = A^T B C x, matrices as lists / [..., 4] column-major."""
+    y0 = C[0] * x0 + C[2] * x1
+    y1 = C[1] * x0 + C[3] * x1
+    z0 = B[0] * y0 + B[2] * y1
+    z1 = B[1] * y0 + B[3] * y1
+    return A[0] * z0 + A[1] * z1, A[2] * z0 + A[3] * z1
+
+
+def _mult_BAx22(A, B, x0, x1):
+    """utils_22_qf.h:67-79: y = B (A x)."""
+    z0 = A[0] * x0 + A[2] * x1
+    z1 = A[1] * x0 + A[3] * x1
+    return B[0] * z0 + B[2] * z1, B[1] * z0 + B[3] * z1
+
+
+def _geom22(ctx, geom):
+    attr = geom[:, 0, :].astype(np.int32)
+    A = [geom[:, 2 + k, :] for k in range(4)]
+    Jl = [A[3], -A[2], -A[1], A[0]]  # AdjJt22 of adjJt (utils_22_qf.h:19-29): J / detJ
+    Cm = _unpack2(ctx, attr)
+    return geom[:, 1, :], A, Jl, [Cm[..., k] for k in range(4)]
+
+
+def apply_hdiv_22(ctx, geom, u):
+    """hdiv_22_qf.h:10-30 (f_apply_hdiv_22): v = w detJ (J/detJ)^T C (J/detJ) u -- mass of a plane H(div) space."""
+    wdetJ, A, Jl, C = _geom22(ctx, geom)
+    v0, v1 = _mult_AtBCx22(Jl, C, Jl, u[:, 0, :], u[:, 1, :])
+    return np.stack([wdetJ * v0, wdetJ * v1], axis=1)
+
+
+def apply_hcurlhdiv_22(ctx, geom, u):
+    """hcurlhdiv_22_qf.h:10-30 (f_apply_hcurlhdiv_22): v = w detJ (J/detJ)^T C adjJt u."""
+    wdetJ, A, Jl, C = _geom22(ctx, geom)
+    v0, v1 = _mult_AtBCx22(Jl, C, A, u[:, 0, :], u[:, 1, :])
+    return np.stack([wdetJ * v0, wdetJ * v1], axis=1)
+
+
+def apply_hdivhcurl_22(ctx, geom, u):
+    """hcurlhdiv_22_qf.h:32-52 (f_apply_hdivhcurl_22): v = w detJ adjJt^T C (J/detJ) u."""
+    wdetJ, A, Jl, C = _geom22(ctx, geom)
+    v0, v1 = _mult_AtBCx22(A, C, Jl, u[:, 0, :], u[:, 1, :])
+    return np.stack([wdetJ * v0, wdetJ * v1], axis=1)
+
+
+def apply_hcurlhdiv_error_22(ctx1, ctx2, geom, u1, u2):
+    """hcurlhdiv_error_22_qf.h:10-41: w detJ |C2 (J/detJ) u2 - C1 adjJt u1|^2 with u1 in H(curl), u2 in H(div)  [NE, Q]."""
+    wdetJ, A, Jl, C1 = _geom22(ctx1, geom)
+    C2 = _geom22(ctx2, geom)[3]
+    a0, a1 = _mult_BAx22(A, C1, u1[:, 0, :], u1[:, 1, :])
+    b0, b1 = _mult_BAx22(Jl, C2, u2[:, 0, :], u2[:, 1, :])
+    b0, b1 = b0 - a0, b1 - a1
+    return wdetJ * (b0 * b0 + b1 * b1)
+
+
+def apply_hdivhcurl_error_22(ctx1, ctx2, geom, u1, u2):
+    """hcurlhdiv_error_22_qf.h:43-74: the first input in H(div), the second in H(curl)."""
+    wdetJ, A, Jl, C1 = _geom22(ctx1, geom)
+    C2 = _geom22(ctx2, geom)[3]
+    a0, a1 = _mult_BAx22(Jl, C1, u1[:, 0, :], u1[:, 1, :])
+    b0, b1 = _mult_BAx22(A, C2, u2[:, 0, :], u2[:, 1, :])
+    b0, b1 = b0 - a0, b1 - a1
+    return wdetJ * (b0 * b0 + b1 * b1)
+
+
 def apply_l2_1(ctx, geom, qw, u):
     """l2_1_qf.h:10-24 (2-D curl-curl, integ/curlcurl.cpp:43-47,65-68): v = (c qw^2 / w detJ) u, scalar."""
     attr = geom[:, 0, :].astype(np.int32)
@@ -526,6 +591,8 @@ QF_HDIVMASS_32, QF_HCURLMASS_22, QF_HCURLMASS_32 = "hdivmass_32", "hcurlmass_22"
 QF_HCURL_LINE, QF_HCURLMASS_LINE = "hcurl_21|31", "hcurlmass_21|31"  # line elements: the geometry data tells 21 from 31
 QF_HCURLHDIV_ERROR, QF_HDIVHCURL_ERROR = "hcurlhdiv_error_33", "hdivhcurl_error_33"
 QF_HCURLHDIV, QF_HDIVHCURL = "hcurlhdiv_33", "hdivhcurl_33"  # weak curl (Interp -> Curl), mixed curl (Curl -> Interp)
+QF_HCURLHDIV_22, QF_HDIVHCURL_22, QF_HDIV_22 = "hcurlhdiv_22", "hdivhcurl_22", "hdiv_22"
+QF_HCURLHDIV_ERROR_22, QF_HDIVHCURL_ERROR_22 = "hcurlhdiv_error_22", "hdivhcurl_error_22"
 
 
 class CeedOperatorOracle:
@@ -617,6 +684,9 @@ class CeedOperatorOracle:
         if qf == QF_HCURL_22:  # 2-D ND mass
             u = np.einsum("dqj,ej->edq", self.interp, ue)
             return np.einsum("dqj,edq->ej", self.interp, apply_hcurl_22(self.ctx, geom, u))
+        if qf == QF_HDIV_22:  # plane H(div) mass (integ/vecfemass.cpp:75-87 with an RT space)
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            return np.einsum("dqj,edq->ej", self.interp, apply_hdiv_22(self.ctx, geom, u))
         if qf == QF_HDIVMASS_22:
             u = np.einsum("dqj,ej->edq", self.interp, ue)
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
@@ -745,28 +815,35 @@ class MixedSpaceOracle:
     VectorFEMassIntegrator (fem/integ/vecfemass.cpp:88-101: f_apply_hcurlhdiv_33 for an H(curl) trial and an H(div) test
     space, f_apply_hdivhcurl_33 the other way round) and the element error integrator of
     AssembleCeedElementErrorIntegrator (fem/libceed/integrator.cpp:550-626).  `first` / `second` are CeedOperatorOracle
-    objects used for their restrictions and value tables only (trial / test, or input 1 / input 2)."""
+    objects used for their restrictions and value tables only (trial / test, or input 1 / input 2).  `first_tab` /
+    `second_tab`: the [dim, Q, P] table each side enters with -- by default its value table (Interp); the gradient table
+    (Grad) of an H1 space for MixedVectorGradientIntegrator (fem/integ/mixedvecgrad.cpp:43-76: f_apply_hcurl_33 | _22 with an
+    H(curl) test space, f_apply_hcurlhdiv_33 | _22 with an H(div) one).  The _22 QFunctions go with plane geometry data."""
 
-    def __init__(self, first, second, geom, qf, ctx, ctx2=None):
+    def __init__(self, first, second, geom, qf, ctx, ctx2=None, first_tab=None, second_tab=None):
         self.a, self.b, self.geom, self.qf, self.ctx, self.ctx2 = first, second, geom, qf, ctx, ctx2
+        self.ta = first.interp if first_tab is None else first_tab
+        self.tb = second.interp if second_tab is None else second_tab
         assert first.NE == second.NE == geom.shape[0]
 
     def apply_add(self, x, y, chunk=2048):
-        f = {QF_HCURLHDIV: apply_hcurlhdiv_33, QF_HDIVHCURL: apply_hdivhcurl_33}[self.qf]
+        f = {QF_HCURLHDIV: apply_hcurlhdiv_33, QF_HDIVHCURL: apply_hdivhcurl_33, QF_HCURL: apply_hcurl_33,
+             QF_HCURLHDIV_22: apply_hcurlhdiv_22, QF_HDIVHCURL_22: apply_hdivhcurl_22, QF_HCURL_22: apply_hcurl_22}[self.qf]
         for s0 in range(0, self.a.NE, chunk):
             sl = slice(s0, min(self.a.NE, s0 + chunk))
-            u = np.einsum("dqj,ej->edq", self.a.interp, self.a._restrict(x, sl))
-            ve = np.einsum("dqj,edq->ej", self.b.interp, f(self.ctx, self.geom[sl], u))
+            u = np.einsum("dqj,ej->edq", self.ta, self.a._restrict(x, sl))
+            ve = np.einsum("dqj,edq->ej", self.tb, f(self.ctx, self.geom[sl], u))
             np.add.at(y, self.b.off[sl].ravel(), self.b._restrict_t(ve, sl).ravel())
         return y
 
     def error_add(self, u1, u2, est, chunk=2048):
         """est[e] += sum_q of the error QFunction (the all-ones `mesh_elem_basis`, integrator.cpp:560-574)."""
-        f = {QF_HCURLHDIV_ERROR: apply_hcurlhdiv_error_33, QF_HDIVHCURL_ERROR: apply_hdivhcurl_error_33}[self.qf]
+        f = {QF_HCURLHDIV_ERROR: apply_hcurlhdiv_error_33, QF_HDIVHCURL_ERROR: apply_hdivhcurl_error_33,
+             QF_HCURLHDIV_ERROR_22: apply_hcurlhdiv_error_22, QF_HDIVHCURL_ERROR_22: apply_hdivhcurl_error_22}[self.qf]
         for s0 in range(0, self.a.NE, chunk):
             sl = slice(s0, min(self.a.NE, s0 + chunk))
-            q1 = np.einsum("dqj,ej->edq", self.a.interp, self.a._restrict(u1, sl))
-            q2 = np.einsum("dqj,ej->edq", self.b.interp, self.b._restrict(u2, sl))
+            q1 = np.einsum("dqj,ej->edq", self.ta, self.a._restrict(u1, sl))
+            q2 = np.einsum("dqj,ej->edq", self.tb, self.b._restrict(u2, sl))
             est[sl] += f(self.ctx, self.ctx2, self.geom[sl], q1, q2).sum(axis=1)
         return est
 

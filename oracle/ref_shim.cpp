@@ -20,6 +20,9 @@ typedef double CeedScalar;
 #include "fem/qfunctions/22/hcurl_22_qf.h"
 #include "fem/qfunctions/22/hdivmass_22_qf.h"
 #include "fem/qfunctions/22/hcurlmass_22_qf.h"
+#include "fem/qfunctions/22/hcurlhdiv_22_qf.h"
+#include "fem/qfunctions/22/hdiv_22_qf.h"
+#include "fem/qfunctions/22/hcurlhdiv_error_22_qf.h"
 #include "fem/qfunctions/1/l2_1_qf.h"
 #include "fem/qfunctions/21/geom_21_qf.h"
 #include "fem/qfunctions/21/hcurl_21_qf.h"

@@ -24,6 +24,8 @@ QF_HCURLHDIV_ERROR_33, QF_HDIVHCURL_ERROR_33 = 11, 12
 QF_HDIVMASS_32, QF_HCURLMASS_22, QF_HCURLMASS_32 = 13, 14, 15  # the remaining 2-D / boundary-element pair forms
 QF_HCURL_21, QF_HCURL_31, QF_HCURLMASS_21, QF_HCURLMASS_31 = 16, 17, 18, 19  # line elements in the plane / in space
 QF_HCURLHDIV_33, QF_HDIVHCURL_33 = 9, 10  # weak curl (trial Interp, test Curl) / mixed curl (trial Curl, test Interp)
+QF_HCURLHDIV_22, QF_HDIVHCURL_22, QF_HCURLHDIV_ERROR_22, QF_HDIVHCURL_ERROR_22 = 20, 21, 22, 23  # two spaces, plane elements
+QF_HDIV_22 = 24  # mass of a plane H(div) space (FE_HDIV block, Interp)
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
 FE_H1, FE_HCURL, FE_HDIV = 0, 1, 2
 
@@ -293,7 +295,9 @@ class Operator:
 
     def add_dense_mixed_integrator(self, geom: DenseGeomFactorData, trial: DenseBlock, test: DenseBlock, qf, ctx_blob):
         """BilinearForm(trial_fespace, test_fespace) + VectorFEMassIntegrator between an H(curl) and an H(div) space
-        (pa_op_add_sub_dense_mixed): qf = QF_HCURLHDIV_33 (H(curl) trial) or QF_HDIVHCURL_33 (H(div) trial)."""
+        (pa_op_add_sub_dense_mixed): qf = QF_HCURLHDIV_33 (H(curl) trial) or QF_HDIVHCURL_33 (H(div) trial).  An H1 block on
+        an H(curl) side enters with its gradient table: qf = QF_HCURL_33 with an H1 trial and an H(curl) test block is
+        MixedVectorGradientIntegrator (C grad phi, v) (fem/integ/mixedvecgrad.cpp:43-76).  Plane elements: the _22 QFunctions."""
         r1, b1 = trial.descs()
         r2, b2 = test.descs()
         ctx = np.ascontiguousarray(ctx_blob)

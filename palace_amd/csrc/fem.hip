@@ -445,8 +445,10 @@ void BilinearFormIntegrator::AssembleCeedOperator(pa_op *op, const FiniteElement
     if (&trial == &test) {
       check(pa_op_add_sub_dense(op, trial.GetMesh().GetCeedGeomFactorData(), &r, &b, qf, ctx.data(), ctx.size() * sizeof(double),
                                 trial_ops, test_ops));
-    } else {  // two spaces: the mixed mass forms only (Interp / Interp)
-      PA_REQUIRE(trial_ops == PA_EVAL_INTERP && test_ops == PA_EVAL_INTERP, "mixed-space forms evaluate values on both sides");
+    } else {  // two spaces: values of vector elements, gradients of H1 elements (pa_op_add_sub_dense_mixed)
+      PA_REQUIRE(trial_ops == (trial.GetFEType() == PA_FE_H1 ? PA_EVAL_GRAD : PA_EVAL_INTERP) &&
+                     test_ops == (test.GetFEType() == PA_FE_H1 ? PA_EVAL_GRAD : PA_EVAL_INTERP),
+                 "mixed-space forms evaluate the values of vector elements and the gradients of H1 elements");
       const auto r2 = test.GetCeedElemRestriction();
       const auto b2 = test.GetCeedDenseBasis();
       check(pa_op_add_sub_dense_mixed(op, trial.GetMesh().GetCeedGeomFactorData(), &r, &b, &r2, &b2, qf, ctx.data(),
@@ -479,6 +481,8 @@ void VectorFEMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial
   int qf;
   if (d == 33) {
     qf = tc ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33) : (sc ? PA_QF_HDIVHCURL_33 : PA_QF_HDIV_33);
+  } else if (d == 22 && !(tc && sc)) {
+    qf = tc ? PA_QF_HCURLHDIV_22 : (sc ? PA_QF_HDIVHCURL_22 : PA_QF_HDIV_22);
   } else {
     PA_REQUIRE(tc && sc && (d == 22 || d == 32 || d == 21 || d == 31),
                "VectorFEMassIntegrator: H(curl) spaces only on 2-D, boundary and line elements");
@@ -506,6 +510,16 @@ void DivDivIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, cons
   PA_REQUIRE(trial.GetFEType() == PA_FE_HDIV && test.GetFEType() == PA_FE_HDIV, "DivDivIntegrator: H(div) spaces expected");
   AssembleCeedOperator(op, trial, test, PA_QF_L2_1, ceed::PopulateCoefficientContext(1, Q, transpose),
                        PA_EVAL_DIV | PA_EVAL_WEIGHT, PA_EVAL_DIV);  // divdiv.cpp:31-57 (single-component elements)
+}
+void MixedVectorGradientIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
+  // mixedvecgrad.cpp:43-76: the QFunction follows the map type of the test element; trial Grad, test Interp (:117-118)
+  const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
+  const bool sc = test.GetFEType() == PA_FE_HCURL;
+  PA_REQUIRE(trial.GetFEType() == PA_FE_H1 && (sc || test.GetFEType() == PA_FE_HDIV),
+             "Invalid trial/test element map type for MixedVectorGradientIntegrator!");
+  PA_REQUIRE(d == 33 || d == 22, "MixedVectorGradientIntegrator: volume and plane elements only");
+  const int qf = d == 33 ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33) : (sc ? PA_QF_HCURL_22 : PA_QF_HCURLHDIV_22);
+  AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_GRAD, PA_EVAL_INTERP);
 }
 void MixedVectorCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_HCURL,

@@ -212,6 +212,7 @@ PA_DECLARE_INTEGRATOR(VectorFEMassIntegrator);  // H(curl) / H(div) and the two 
 PA_DECLARE_INTEGRATOR(DiffusionIntegrator);     // H1, (Q grad u, grad v)            fem/integ/diffusion.cpp
 PA_DECLARE_INTEGRATOR(CurlCurlIntegrator);      // H(curl), (Q curl u, curl v)       fem/integ/curlcurl.cpp:23-75
 PA_DECLARE_INTEGRATOR(DivDivIntegrator);        // H(div), (Q div u, div v)          fem/integ/divdiv.cpp
+PA_DECLARE_INTEGRATOR(MixedVectorGradientIntegrator);  // H1 x H(curl) | H(div), (Q grad u, v)  fem/integ/mixedvecgrad.cpp
 PA_DECLARE_INTEGRATOR(MixedVectorCurlIntegrator);      // H(curl) x H(curl), (Q curl u, v)   fem/integ/mixedveccurl.cpp:21-73
 PA_DECLARE_INTEGRATOR(MixedVectorWeakCurlIntegrator);  // H(curl) x H(curl), (Q u, curl v)   fem/integ/mixedveccurl.cpp:75-120
 #undef PA_DECLARE_INTEGRATOR

@@ -645,7 +645,9 @@ int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_des
     require_device();
     PA_REQUIRE(op && geom && trial_restr && trial_basis && test_restr && test_basis, "null argument");
     PA_REQUIRE(!op->finalized, "operator already finalized");
-    PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_33 || qfunction == PA_QF_HDIVHCURL_33, "not a mixed-space QFunction");
+    PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_33 || qfunction == PA_QF_HDIVHCURL_33 || qfunction == PA_QF_HCURL_33 ||
+                   qfunction == PA_QF_HCURLHDIV_22 || qfunction == PA_QF_HDIVHCURL_22 || qfunction == PA_QF_HCURL_22,
+               "not a mixed-space QFunction");
     PA_REQUIRE(test_restr->lsize == op->height && trial_restr->lsize == op->width,
                "dimensions mismatch for sub-operator");  // operator.cpp:69-71
     op->msubs.push_back(make_mixed_sub(geom, *trial_restr, *trial_basis, *test_restr, *test_basis, qfunction, ctx, ctx_size));
@@ -662,7 +664,9 @@ int pa_error_op_create(pa_geom *geom, const pa_restriction_desc *restr1, const p
   return guarded([&] {
     require_device();
     PA_REQUIRE(geom && restr1 && basis1 && restr2 && basis2 && out, "null argument");
-    PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_ERROR_33 || qfunction == PA_QF_HDIVHCURL_ERROR_33, "not an error QFunction");
+    PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_ERROR_33 || qfunction == PA_QF_HDIVHCURL_ERROR_33 ||
+                   qfunction == PA_QF_HCURLHDIV_ERROR_22 || qfunction == PA_QF_HDIVHCURL_ERROR_22,
+               "not an error QFunction");
     auto *e = new pa_error_op;
     try {
       e->ms = make_mixed_sub(geom, *restr1, *basis1, *restr2, *basis2, qfunction, ctx, ctx_size);
@@ -853,7 +857,7 @@ int pa_op_coarsen_dense(const pa_op *fine, const pa_restriction_desc *restr, con
     try {
       for (const DenseSub *fs : fine->dsubs)
         o->dsubs.push_back(make_dense_sub(static_cast<pa_geom *>(fs->geom), *restr, *basis, fs->qf, fs->ctx_blob.data(),
-                                          fs->ctx_blob.size(), fs->trial_ops, fs->test_ops, o->height));
+                                          fs->ctx_blob.size(), fs->trial_ops, fs->test_ops, o->height, fs->contra));
     } catch (...) {
       pa_op_destroy(o);
       throw;

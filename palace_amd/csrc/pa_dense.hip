@@ -121,6 +121,7 @@ struct DenseArgs {
   const uint16_t *co;  // 2-bit fields {sub, main, super} of row d of T_e and {T[d-1][d], T[d+1][d]} of column d
   const double *geom;
   const double *qw;     // quadrature weights (2-D curl-curl)
+  int contra;           // plane vector mass with the contravariant map J / detJ (f_apply_hdiv_22) instead of adj(J)^T / detJ
   const double *Tf, *Tt;
   const double *L;      // resident form of the tables: [rows][S], rows in tile order (see make_dense_sub)
   const double *qdata;  // packed pre-assembled D: [nb][ncq][Qpad][16]
@@ -882,8 +883,10 @@ __global__ void dense_qdata2_kernel(const DenseArgs a, double *__restrict__ qd) 
         Mx[0 + 2 * col] = wdetJ * (A[0] * z0 + A[1] * z1 + A[2] * z2);
         Mx[1 + 2 * col] = wdetJ * (A[3] * z0 + A[4] * z1 + A[5] * z2);
       }
-    } else {  // MultAtBCx22 (utils_22_qf.h)
-      const double A[4] = {g[2 * cs], g[3 * cs], g[4 * cs], g[5 * cs]};
+    } else {  // MultAtBCx22 (utils_22_qf.h); f_apply_hdiv_22 (hdiv_22_qf.h:10-30) first takes AdjJt22 of the stored matrix
+      const double G4[4] = {g[2 * cs], g[3 * cs], g[4 * cs], g[5 * cs]};
+      const double A[4] = {a.contra ? G4[3] : G4[0], a.contra ? -G4[2] : G4[1], a.contra ? -G4[1] : G4[2],
+                           a.contra ? G4[0] : G4[3]};
       const double *C = cc.mat + 4 * coeff_index(cc, attr);  // CoeffUnpack2, column-major
       for (int col = 0; col < 2; col++) {
         const double x0 = col == 0 ? 1.0 : 0.0, x1 = col == 1 ? 1.0 : 0.0;
@@ -1202,6 +1205,7 @@ DenseArgs make_args(const DenseSub &ds) {
   DenseArgs a;
   a.ne = ds.ne, a.nb = ds.nb, a.P = ds.P, a.Q = ds.Q, a.Qpad = ds.Qpad, a.nch = ds.nch, a.KP = ds.KP;
   a.idx = ds.d_idx, a.co = ds.d_co, a.geom = ds.geom->d_geom, a.qw = ds.geom->d_qw, a.Tf = ds.d_Tf, a.Tt = ds.d_Tt;
+  a.contra = ds.contra ? 1 : 0;
   a.L = ds.d_L, a.qdata = ds.d_qdata, a.ncq = ds.ncq, a.Q4 = (ds.Q + 3) / 4 * 4;
   a.affine = ds.d_affine, a.wrel = ds.d_wrel;
   a.x1 = nullptr, a.ye1 = nullptr, a.qdata_i = nullptr, a.ncq_i = 0, a.qi_mass = a.qi_curl = -1;
@@ -1264,8 +1268,17 @@ void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
 }
 
 DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_dense_basis_desc &b, int qf,
-                         const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops, int height) {
+                         const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops, int height, bool contra) {
   PA_REQUIRE(geom && geom->eb == kEB, "geometry data must come from pa_geom_create_dense");
+  if (b.fe_type == PA_FE_HDIV && geom->dim == 2 && geom->sdim == 2) {
+    // plane H(div) mass (vecfemass.cpp:75-87 with an RT space: Interp + f_apply_hdiv_22): the 2-D vector mass with
+    // J / detJ = AdjJt22(adjJt) in the place of adjJt
+    PA_REQUIRE(qf == PA_QF_HDIV_22 && trial_ops == PA_EVAL_INTERP && test_ops == PA_EVAL_INTERP,
+               "plane H(div) elements: the mass operator (Interp, hdiv_22) is supported");
+    pa_dense_basis_desc alias = b;
+    alias.fe_type = PA_FE_HCURL;
+    return make_dense_sub(geom, r, alias, PA_QF_HCURL_22, ctx, ctx_size, trial_ops, test_ops, height, true);
+  }
   if (b.fe_type == PA_FE_HDIV) {
     // H(div) mass (fem/integ/vecfemass.cpp with an RT space: Interp + f_apply_hdiv_33, the contravariant Piola map) is
     // the arithmetic of the curl-curl operator with the value table in the place of the curl table
@@ -1322,7 +1335,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   geom->refcount++;
   ds->fe_type = b.fe_type, ds->P = P, ds->Q = Q, ds->Qpad = geom->Qpad, ds->nch = geom->Qpad / 16;
   ds->ne = ne, ds->nb = (ne + kEB - 1) / kEB, ds->lsize = r.lsize, ds->KP = 4 * PT, ds->PT = PT;
-  ds->qf = qf, ds->mode = mode, ds->trial_ops = trial_ops, ds->test_ops = test_ops;
+  ds->qf = qf, ds->mode = mode, ds->trial_ops = trial_ops, ds->test_ops = test_ops, ds->contra = contra;
   const int KP = ds->KP, nb = ds->nb, nch = ds->nch;
 
   // ---- E: block-transposed index (+ packed tridiagonal rows)

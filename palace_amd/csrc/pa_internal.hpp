@@ -202,6 +202,7 @@ struct DenseSub {
   Geom *geom = nullptr;
   int fe_type = 0, P = 0, Q = 0, Qpad = 0, nch = 0, ne = 0, nb = 0, lsize = 0, KP = 0, PT = 0;
   int qf = 0, mode = 0;
+  bool contra = false;  // plane H(div) mass: contravariant map in the vector-mass D (f_apply_hdiv_22)
   uint32_t trial_ops = 0, test_ops = 0;
   int32_t *d_idx = nullptr;     // [nb][4 KP][16] signed index (oriented: <0 => -(1+dof) flipped); pads read zero
   int32_t *d_idx_bc = nullptr;  // copy with kEssBit on essential dofs
@@ -232,7 +233,7 @@ struct DenseSub {
 
 // pa_mixed.hip: one space of a mixed-space operator (plain [ne][P] layouts) and the operator / error integrator itself
 struct MixedSide {
-  int fe_type = 0, P = 0, lsize = 0;
+  int fe_type = 0, P = 0, lsize = 0, nc = 3;
   int32_t *d_sidx = nullptr;
   int8_t *d_cor = nullptr;
   double *d_tabF = nullptr, *d_tabT = nullptr;
@@ -240,7 +241,7 @@ struct MixedSide {
 };
 struct MixedSub {
   Geom *geom = nullptr;
-  int ne = 0, Q = 0, qf = 0;
+  int ne = 0, Q = 0, qf = 0, kind = 0;
   bool error = false;
   MixedSide s1, s2;  // apply: trial, test; error: first and second input
   CoeffHost c0, c1;
@@ -286,7 +287,7 @@ void launch_h1_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 // pa_dense.hip
 void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s);
 DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_dense_basis_desc &b, int qf,
-                         const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops, int height);
+                         const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops, int height, bool contra = false);
 void free_dense_sub(DenseSub *ds);
 void dense_set_essential(DenseSub &ds, const std::vector<char> &flag);
 void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStream_t s);

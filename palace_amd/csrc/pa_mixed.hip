@@ -8,6 +8,13 @@
 //    (AssembleCeedElementErrorIntegrator, fem/libceed/integrator.cpp:550-626, with f_apply_hcurlhdiv_error_33 /
 //    f_apply_hdivhcurl_error_33, fem/qfunctions/33/hcurlhdiv_error_33_qf.h:10-78).
 //
+//  * the same-map mixed form  (C grad phi, v)  with phi in H1 and v in H(curl): MixedVectorGradientIntegrator
+//    (fem/integ/mixedvecgrad.cpp:43-76, f_apply_hcurl_33 / f_apply_hcurl_22 with trial Grad and test Interp) -- the `Atn` block
+//    of the boundary-mode eigenproblem (models/modeeigensolver.cpp:52); an H1 side enters with its gradient table;
+//  * all of them on triangles / quadrilaterals in the plane (qfunctions/22/hcurlhdiv_22_qf.h, hcurlhdiv_error_22_qf.h): the
+//    2 x 2 Jacobian adjugate and coefficient are embedded in 3 x 3 matrices (third component of every field zero), which
+//    makes the 3-D arithmetic below the reference's 2-D arithmetic term by term.
+//
 // These run once per solve (post-processing), not inside the Krylov loop: one wave per element, dense tables read through the
 // caches (q fastest for the forward product, dof fastest for the transposed one: coalesced either way), the pointwise arithmetic
 // exactly the reference QFunctions' on the element-blocked geometry data of pa_geom_create_dense, E^T as E-vector + the
@@ -28,15 +35,15 @@ constexpr int kMixWaves = 4;
 constexpr int kEBm = 16;  // element block of the dense geometry layout
 
 struct MixSideDev {
-  int P;
+  int P, nc;  // dofs per element, components of the value table (2 in the plane)
   const int32_t *sidx;  // [ne][P] L-vector index, -(1 + index) when the sign is flipped
   const int8_t *cor;    // [ne][P][3] rows of the tridiagonal dof transformation or nullptr
-  const double *tabF;   // [3][P][Q] values at the quadrature points, point fastest
-  const double *tabT;   // [3][Q][P] the same, dof fastest
+  const double *tabF;   // [nc][P][Q] values at the quadrature points, point fastest
+  const double *tabT;   // [nc][Q][P] the same, dof fastest
 };
 
 struct MixArgs {
-  int ne, Q, Qpad, stride;
+  int ne, Q, Qpad, stride, dim;
   const double *geom;
   MixSideDev s1, s2;
   CoeffDev c0, c1;
@@ -67,11 +74,19 @@ __device__ __forceinline__ void mix_gather(const MixSideDev &sd, const int e, co
 
 __device__ __forceinline__ void mix_eval(const MixSideDev &sd, const int Q, const int q, const double *xs, double (&u)[3]) {
   u[0] = u[1] = u[2] = 0.0;
-  for (int d = 0; d < sd.P; d++) {
-    const double xv = xs[d];
-    u[0] += sd.tabF[((size_t)0 * sd.P + d) * Q + q] * xv;
-    u[1] += sd.tabF[((size_t)1 * sd.P + d) * Q + q] * xv;
-    u[2] += sd.tabF[((size_t)2 * sd.P + d) * Q + q] * xv;
+  if (sd.nc == 3) {
+    for (int d = 0; d < sd.P; d++) {
+      const double xv = xs[d];
+      u[0] += sd.tabF[((size_t)0 * sd.P + d) * Q + q] * xv;
+      u[1] += sd.tabF[((size_t)1 * sd.P + d) * Q + q] * xv;
+      u[2] += sd.tabF[((size_t)2 * sd.P + d) * Q + q] * xv;
+    }
+  } else {
+    for (int d = 0; d < sd.P; d++) {
+      const double xv = xs[d];
+      u[0] += sd.tabF[((size_t)0 * sd.P + d) * Q + q] * xv;
+      u[1] += sd.tabF[((size_t)1 * sd.P + d) * Q + q] * xv;
+    }
   }
 }
 
@@ -85,14 +100,25 @@ __device__ __forceinline__ void mult_BAx33(const double A[9], const double B[9],
   y[2] = B[2] * z0 + B[5] * z1 + B[8] * z2;
 }
 
-// KIND 0: f_apply_hcurlhdiv_33, 1: f_apply_hdivhcurl_33, 2: f_apply_hcurlhdiv_error_33, 3: f_apply_hdivhcurl_error_33
+// A 2 x 2 column-major matrix as the leading block of a 3 x 3 one
+__device__ __forceinline__ void embed22(double m0, double m1, double m2, double m3, double corner, double M[9]) {
+  M[0] = m0, M[1] = m1, M[2] = 0.0, M[3] = m2, M[4] = m3, M[5] = 0.0, M[6] = 0.0, M[7] = 0.0, M[8] = corner;
+}
+// CoeffUnpack2 (coeff/coeff_2_qf.h) into that form
+__device__ __forceinline__ void coeff_unpack2in3(const CoeffDev &c, int attr, double C[9]) {
+  const double *m = c.mat + 4 * coeff_index(c, attr);
+  embed22(m[0], m[1], m[2], m[3], 0.0, C);
+}
+
+// KIND 0: f_apply_hcurlhdiv_33 | _22, 1: f_apply_hdivhcurl_33 | _22, 2: f_apply_hcurlhdiv_error_33 | _22,
+// 3: f_apply_hdivhcurl_error_33 | _22, 4: f_apply_hcurl_33 | _22 between two spaces
 template <int KIND>
 __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * kMixWaves + wave;
   if (e >= a.ne) return;  // no workgroup barriers below
-  constexpr bool ERR = KIND >= 2;
+  constexpr bool ERR = KIND == 2 || KIND == 3;
   const int P1 = a.s1.P, P2 = a.s2.P, Q = a.Q;
   double *xa = smem + (size_t)wave * a.stride;
   double *xb = xa + P1;
@@ -102,7 +128,8 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
   mix_gather(a.s1, e, lane, a.x1, xa, tmp);
   if (ERR) mix_gather(a.s2, e, lane, a.x2, xb, tmp);
 
-  const double *g = a.geom + ((size_t)(e / kEBm) * 11 * a.Qpad) * kEBm + (e % kEBm);
+  const int nrows = a.dim == 3 ? 11 : 6;
+  const double *g = a.geom + ((size_t)(e / kEBm) * nrows * a.Qpad) * kEBm + (e % kEBm);
   double err = 0.0;
   for (int q = lane; q < Q; q += 64) {
     double u1[3];
@@ -110,21 +137,33 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
     const int attr = (a.c0.nattr > 0 || a.c1.nattr > 0) ? max(1, (int)g[(size_t)q * kEBm]) : 1;
     const double wdetJ = g[((size_t)a.Qpad + q) * kEBm];
     double adj[9], Jl[9], Cm[9];
+    if (a.dim == 3) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) adj[k] = g[((size_t)(2 + k) * a.Qpad + q) * kEBm];
-    adjJt33(adj, Jl);
-    coeff_unpack3(a.c0, attr, Cm);
+      for (int k = 0; k < 9; k++) adj[k] = g[((size_t)(2 + k) * a.Qpad + q) * kEBm];
+      coeff_unpack3(a.c0, attr, Cm);
+    } else {
+      embed22(g[((size_t)2 * a.Qpad + q) * kEBm], g[((size_t)3 * a.Qpad + q) * kEBm], g[((size_t)4 * a.Qpad + q) * kEBm],
+              g[((size_t)5 * a.Qpad + q) * kEBm], 1.0, adj);
+      coeff_unpack2in3(a.c0, attr, Cm);
+    }
+    adjJt33(adj, Jl);  // in the plane: AdjJt22 (utils_22_qf.h:19-29) in the leading 2 x 2 block
     if (!ERR) {
       double v0, v1, v2;
       if (KIND == 0)  // hcurlhdiv_33_qf.h:10-31: H(curl) trial (adj(J)^T / det J), H(div) test (J / det J)
         mult_AtBCx33(Jl, Cm, adj, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
-      else  // hcurlhdiv_33_qf.h:33-54
+      else if (KIND == 1)  // hcurlhdiv_33_qf.h:33-54
         mult_AtBCx33(adj, Cm, Jl, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
-      vq[q] = v0, vq[Q + q] = v1, vq[2 * Q + q] = v2;
+      else  // hcurl_33_qf.h:10-28
+        mult_AtBCx33(adj, Cm, adj, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
+      vq[q] = v0, vq[Q + q] = v1;
+      if (a.dim == 3) vq[2 * Q + q] = v2;
     } else {
       double u2[3], w1[3], w2[3], C2[9];
       mix_eval(a.s2, Q, q, xb, u2);
-      coeff_unpack3(a.c1, attr, C2);
+      if (a.dim == 3)
+        coeff_unpack3(a.c1, attr, C2);
+      else
+        coeff_unpack2in3(a.c1, attr, C2);
       if (KIND == 2) {  // hcurlhdiv_error_33_qf.h:10-43
         mult_BAx33(adj, Cm, u1, w1);
         mult_BAx33(Jl, C2, u2, w2);
@@ -148,7 +187,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
   double *yt = tmp;
   for (int i = lane; i < P2; i += 64) {
     double s = 0.0;
-    for (int c = 0; c < 3; c++)
+    for (int c = 0; c < a.s2.nc; c++)
       for (int q = 0; q < Q; q++) s += a.s2.tabT[((size_t)c * Q + q) * P2 + i] * vq[c * Q + q];
     yt[i] = s;
   }
@@ -165,13 +204,16 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
   }
 }
 
-void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, MixedSide &sd) {
-  PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_HDIV, "mixed operators take H(curl) and H(div) elements");
-  PA_REQUIRE(b.num_dofs > 0 && b.num_qpts == Q && b.interp, "basis does not match the quadrature rule, or has no value table");
+// H(curl) and H(div) sides enter with their value tables (Interp), an H1 side with its gradient table (Grad): the covariant
+// map of H(curl) values is the map of gradients.
+void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, int nc, MixedSide &sd) {
+  PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_HDIV || b.fe_type == PA_FE_H1, "unknown element type");
+  const double *tab = b.fe_type == PA_FE_H1 ? b.deriv : b.interp;
+  PA_REQUIRE(b.num_dofs > 0 && b.num_qpts == Q && tab, "basis does not match the quadrature rule, or has no value / gradient table");
   PA_REQUIRE(r.elem_size == b.num_dofs && r.offsets && r.lsize > 0, "restriction does not match the basis");
   PA_REQUIRE(!(r.orients && r.curl_orients), "restriction is either oriented or curl-oriented");
   const int P = b.num_dofs, ne = r.num_elem;
-  sd.fe_type = b.fe_type, sd.P = P, sd.lsize = r.lsize;
+  sd.fe_type = b.fe_type, sd.P = P, sd.lsize = r.lsize, sd.nc = nc;
   std::vector<int32_t> sidx((size_t)ne * P);
   for (size_t k = 0; k < sidx.size(); k++) {
     const int32_t off = r.offsets[k];
@@ -180,12 +222,12 @@ void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int 
   }
   sd.d_sidx = dev_upload(sidx.data(), sidx.size());
   if (r.curl_orients) sd.d_cor = dev_upload(r.curl_orients, (size_t)3 * ne * P);
-  std::vector<double> F((size_t)3 * P * Q);
-  for (int c = 0; c < 3; c++)
+  std::vector<double> F((size_t)nc * P * Q);
+  for (int c = 0; c < nc; c++)
     for (int q = 0; q < Q; q++)
-      for (int d = 0; d < P; d++) F[((size_t)c * P + d) * Q + q] = b.interp[((size_t)c * Q + q) * P + d];
+      for (int d = 0; d < P; d++) F[((size_t)c * P + d) * Q + q] = tab[((size_t)c * Q + q) * P + d];
   sd.d_tabF = dev_upload(F.data(), F.size());
-  sd.d_tabT = dev_upload(b.interp, (size_t)3 * Q * P);
+  sd.d_tabT = dev_upload(tab, (size_t)nc * Q * P);
   // transpose map of the signed plain-layout index (counting sort by dof, element order preserved)
   std::vector<int32_t> tptr((size_t)r.lsize + 1, 0), tent((size_t)ne * P);
   for (size_t k = 0; k < (size_t)ne * P; k++) tptr[(size_t)r.offsets[k] + 1]++;
@@ -203,11 +245,11 @@ void free_side(MixedSide &sd) {
   hipFree(sd.d_sidx), hipFree(sd.d_cor), hipFree(sd.d_tabF), hipFree(sd.d_tabT), hipFree(sd.d_tptr), hipFree(sd.d_tent);
 }
 
-MixSideDev dev_side(const MixedSide &sd) { return MixSideDev{sd.P, sd.d_sidx, sd.d_cor, sd.d_tabF, sd.d_tabT}; }
+MixSideDev dev_side(const MixedSide &sd) { return MixSideDev{sd.P, sd.nc, sd.d_sidx, sd.d_cor, sd.d_tabF, sd.d_tabT}; }
 
 void launch(const MixedSub &ms, const double *x1, const double *x2, double *out, hipStream_t s) {
   MixArgs a;
-  a.ne = ms.ne, a.Q = ms.Q, a.Qpad = ms.geom->Qpad;
+  a.ne = ms.ne, a.Q = ms.Q, a.Qpad = ms.geom->Qpad, a.dim = ms.geom->dim;
   a.stride = (ms.s1.P + ms.s2.P + std::max(ms.s1.P, ms.s2.P) + 3 * ms.Q + 1) & ~1;
   a.geom = ms.geom->d_geom;
   a.s1 = dev_side(ms.s1), a.s2 = dev_side(ms.s2);
@@ -216,11 +258,12 @@ void launch(const MixedSub &ms, const double *x1, const double *x2, double *out,
   const size_t shm = sizeof(double) * (size_t)a.stride * kMixWaves;
   PA_REQUIRE(shm <= 64 * 1024, "element too large for the mixed-space kernels");
   const dim3 grid((ms.ne + kMixWaves - 1) / kMixWaves), block(64 * kMixWaves);
-  switch (ms.qf) {
-    case PA_QF_HCURLHDIV_33: hipLaunchKernelGGL(mixed_kernel<0>, grid, block, shm, s, a); break;
-    case PA_QF_HDIVHCURL_33: hipLaunchKernelGGL(mixed_kernel<1>, grid, block, shm, s, a); break;
-    case PA_QF_HCURLHDIV_ERROR_33: hipLaunchKernelGGL(mixed_kernel<2>, grid, block, shm, s, a); break;
-    case PA_QF_HDIVHCURL_ERROR_33: hipLaunchKernelGGL(mixed_kernel<3>, grid, block, shm, s, a); break;
+  switch (ms.kind) {
+    case 0: hipLaunchKernelGGL(mixed_kernel<0>, grid, block, shm, s, a); break;
+    case 1: hipLaunchKernelGGL(mixed_kernel<1>, grid, block, shm, s, a); break;
+    case 2: hipLaunchKernelGGL(mixed_kernel<2>, grid, block, shm, s, a); break;
+    case 3: hipLaunchKernelGGL(mixed_kernel<3>, grid, block, shm, s, a); break;
+    case 4: hipLaunchKernelGGL(mixed_kernel<4>, grid, block, shm, s, a); break;
     default: throw Error("not a mixed-space QFunction");
   }
   PA_HIP(hipGetLastError());
@@ -231,25 +274,39 @@ void launch(const MixedSub &ms, const double *x1, const double *x2, double *out,
 MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_dense_basis_desc &b1,
                          const pa_restriction_desc &r2, const pa_dense_basis_desc &b2, int qf, const void *ctx,
                          size_t ctx_size) {
-  PA_REQUIRE(geom && geom->eb == kEBm && geom->dim == 3 && geom->sdim == 3,
-             "mixed-space operators need 3-D geometry data from pa_geom_create_dense");
+  PA_REQUIRE(geom && geom->eb == kEBm && geom->dim == geom->sdim && (geom->dim == 3 || geom->dim == 2),
+             "mixed-space operators need 3-D or plane geometry data from pa_geom_create_dense");
   PA_REQUIRE(r1.num_elem == geom->ne && r2.num_elem == geom->ne, "restrictions do not match the mesh");
-  const bool err = qf == PA_QF_HCURLHDIV_ERROR_33 || qf == PA_QF_HDIVHCURL_ERROR_33;
-  PA_REQUIRE(err || qf == PA_QF_HCURLHDIV_33 || qf == PA_QF_HDIVHCURL_33, "not a mixed-space QFunction");
-  // first space / second space by the Piola map the QFunction applies to each input
-  const bool curl_first = qf == PA_QF_HCURLHDIV_33 || qf == PA_QF_HCURLHDIV_ERROR_33;
-  PA_REQUIRE(b1.fe_type == (curl_first ? PA_FE_HCURL : PA_FE_HDIV) && b2.fe_type == (curl_first ? PA_FE_HDIV : PA_FE_HCURL),
-             "element types do not match the QFunction (vecfemass.cpp:88-101)");
+  const int dim = geom->dim;
+  int kind = -1;  // the QFunction family; its _33 / _22 member must be the one of the geometry data
+  switch (qf) {
+    case PA_QF_HCURLHDIV_33: case PA_QF_HCURLHDIV_22: kind = 0; break;
+    case PA_QF_HDIVHCURL_33: case PA_QF_HDIVHCURL_22: kind = 1; break;
+    case PA_QF_HCURLHDIV_ERROR_33: case PA_QF_HCURLHDIV_ERROR_22: kind = 2; break;
+    case PA_QF_HDIVHCURL_ERROR_33: case PA_QF_HDIVHCURL_ERROR_22: kind = 3; break;
+    case PA_QF_HCURL_33: case PA_QF_HCURL_22: kind = 4; break;
+    default: throw Error("not a mixed-space QFunction");
+  }
+  const bool is22 = qf == PA_QF_HCURLHDIV_22 || qf == PA_QF_HDIVHCURL_22 || qf == PA_QF_HCURLHDIV_ERROR_22 ||
+                    qf == PA_QF_HDIVHCURL_ERROR_22 || qf == PA_QF_HCURL_22;
+  PA_REQUIRE(is22 == (dim == 2), "QFunction does not match the dimension of the geometry data");
+  const bool err = kind == 2 || kind == 3;
+  // first space / second space by the Piola map the QFunction applies to each input: covariant (H(curl) values, H1
+  // gradients) or contravariant (H(div) values)
+  auto covariant = [](const pa_dense_basis_desc &b) { return b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_H1; };
+  const bool cov1 = kind == 0 || kind == 2 || kind == 4, cov2 = kind == 1 || kind == 3 || kind == 4;
+  PA_REQUIRE((cov1 ? covariant(b1) : b1.fe_type == PA_FE_HDIV) && (cov2 ? covariant(b2) : b2.fe_type == PA_FE_HDIV),
+             "element types do not match the QFunction (vecfemass.cpp:88-101, mixedvecgrad.cpp:43-76)");
   PA_REQUIRE(ctx && ctx_size >= 16 && ctx_size % 8 == 0, "bad coefficient context");
   auto *ms = new MixedSub;
   try {
     ms->geom = geom;
     geom->refcount++;
-    ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->error = err;
-    build_side(r1, b1, geom->Q, ms->s1);
-    build_side(r2, b2, geom->Q, ms->s2);
-    parse_coeff(ctx, ctx_size, 3, ms->c0, 0);
-    if (err) parse_coeff(ctx, ctx_size, 3, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
+    ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->kind = kind, ms->error = err;
+    build_side(r1, b1, geom->Q, dim, ms->s1);
+    build_side(r2, b2, geom->Q, dim, ms->s2);
+    parse_coeff(ctx, ctx_size, dim, ms->c0, 0);
+    if (err) parse_coeff(ctx, ctx_size, dim, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
     if (!err) ms->d_ye = dev_alloc<double>((size_t)ms->ne * ms->s2.P);
   } catch (...) {
     free_mixed_sub(ms);

@@ -128,6 +128,20 @@ def fixtures_2d():
     capi.ref_call("f_apply_hcurlmass_32", pair_h132, Q, [g32, cu, u], [s32, g32v])
     out.update(hcurlmass_22_v=s22, hcurlmass_22_gv=g22, hdivmass_32_v=v3, hdivmass_32_cv=w3, hcurlmass_32_v=s32,
                hcurlmass_32_gv=g32v)
+    # two-space QFunctions in the plane (hcurlhdiv_22_qf.h, hcurlhdiv_error_22_qf.h); new draws come last
+    N2 = rng.uniform(-1, 1, (2, 2))
+    c2n = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([0.7]), N2 + 2 * np.eye(2)], a=0.8, dim=2)  # non-symmetric
+    u2 = rng.uniform(-1, 1, (2, Q))
+    for name in ("hcurlhdiv_22", "hdivhcurl_22", "hdiv_22"):
+        vv = np.zeros((2, Q))
+        capi.ref_call("f_apply_" + name, c2n.pack(), Q, [geom, u], [vv])
+        out[name] = vv
+    pair22 = np.concatenate([c2n.pack(), c2.pack()])
+    for name in ("hcurlhdiv_error_22", "hdivhcurl_error_22"):
+        ee = np.zeros((1, Q))
+        capi.ref_call("f_apply_" + name, pair22, Q, [geom, u, u2], [ee])
+        out[name] = ee[0]
+    out.update(ctx2n=c2n.pack(), u2=u2)
     np.savez(os.path.join(ROOT, "tests", "golden", "qf2d_golden.npz"), **out)
     print("wrote qf2d_golden.npz")
 

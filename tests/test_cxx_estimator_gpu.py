@@ -79,6 +79,20 @@ def test_cxx_flux_error_estimators(exe, curved):
     for g, e, name in zip(got, ref, ("grad", "curl", "time-dependent")):
         assert e.min() > 0
         assert np.abs(g - e).max() < 1e-8 * e.max(), (name, np.abs(g - e).max(), e.max())
+    # MixedVectorGradientIntegrator through the C++ front end (BilinearForm(h1, nd | rt)) vs the oracle
+    m, nd, sp, h1 = P["mesh"], P["nd"], P["rt"], P["h1"]
+    J = m.jacobians(P["pts"])
+    og = po.build_geom_factor_33(m.attr.astype(np.float64), P["wts"], np.transpose(J, (0, 1, 3, 2)).reshape(m.ne, -1, 9))
+    kw = dict(curl_orients=nd.curl_orients) if not nd.diagonal_transform else {}
+    ndo = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients if nd.diagonal_transform else None, P["nint"], P["ncurl"], og,
+                                po.QF_HCURL, None, **kw)
+    rto = po.CeedOperatorOracle(sp.ndofs, sp.offsets, sp.orients, P["rint"], P["rint"], og, po.QF_HDIV, None)
+    h1o = po.CeedOperatorOracle(h1.ndofs, h1.offsets, None, P["hint"], P["hgrad"], og, po.QF_HCURL, None, vector_fe=False)
+    c_eps = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=list(P["eps"]))
+    gg = np.fromfile(out + ".grad", dtype=np.float64)
+    for got_g, (to, qfo) in zip((gg[: nd.ndofs], gg[nd.ndofs :]), ((ndo, po.QF_HCURL), (rto, po.QF_HCURLHDIV))):
+        ref_g = po.MixedSpaceOracle(h1o, to, og, qfo, c_eps, first_tab=h1o.deriv).apply_add(P["phi"], np.zeros(to.lsize))
+        assert np.abs(got_g - ref_g).max() < 1e-12 * np.abs(ref_g).max(), qfo
     norms = [float(l.split()[2]) for l in r.stdout.splitlines() if "norm" in l]
     for n, e in zip(norms, ref):
         assert abs(n - np.linalg.norm(e)) < 1e-8 * np.linalg.norm(e)

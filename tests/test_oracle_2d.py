@@ -67,6 +67,23 @@ def test_pair_qfunctions_22_32():
     np.testing.assert_allclose(gv[0], G["hcurlmass_32_gv"], rtol=1e-12, atol=1e-13)
 
 
+def test_two_space_qfunctions_22():
+    """f_apply_hcurlhdiv_22 / f_apply_hdivhcurl_22 and the error integrands f_apply_hcurlhdiv_error_22 /
+    f_apply_hdivhcurl_error_22 (2-D flux projection and estimators, linalg/errorestimator.cpp:345-349) against the reference
+    headers, with a non-symmetric coefficient."""
+    geom = G["geom"][None]
+    cn, _ = _ctx(G["ctx2n"], 2)
+    c2, _ = _ctx(G["ctx2"], 2)
+    u, u2 = G["u"][None], G["u2"][None]
+    np.testing.assert_allclose(po.apply_hcurlhdiv_22(cn, geom, u)[0], G["hcurlhdiv_22"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(po.apply_hdivhcurl_22(cn, geom, u)[0], G["hdivhcurl_22"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(po.apply_hdiv_22(cn, geom, u)[0], G["hdiv_22"], rtol=TOL, atol=TOL)
+    assert not np.allclose(G["hcurlhdiv_22"], G["hdivhcurl_22"])
+    np.testing.assert_allclose(po.apply_hcurlhdiv_error_22(cn, c2, geom, u, u2)[0], G["hcurlhdiv_error_22"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(po.apply_hdivhcurl_error_22(cn, c2, geom, u, u2)[0], G["hdivhcurl_error_22"], rtol=TOL, atol=TOL)
+    assert G["hcurlhdiv_error_22"].min() > 0 and not np.allclose(G["hcurlhdiv_error_22"], G["hdivhcurl_error_22"])
+
+
 def test_line_element_qfunctions_21_31():
     """geom_21 / geom_31, f_apply_hcurl_21 / _31, f_apply_hcurlmass_21 / _31 (line elements: boundaries of plane problems, curves
     in space) against vectors produced by the reference headers (tests/golden/make_golden.py: fixtures_line)."""
