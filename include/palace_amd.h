@@ -80,8 +80,11 @@ enum pa_qfunction {
   PA_QF_HDIVHCURL_22 = 21,       /* f_apply_hdivhcurl_22       fem/qfunctions/22/hcurlhdiv_22_qf.h:32-52 */
   PA_QF_HCURLHDIV_ERROR_22 = 22, /* f_apply_hcurlhdiv_error_22 fem/qfunctions/22/hcurlhdiv_error_22_qf.h:10-41 */
   PA_QF_HDIVHCURL_ERROR_22 = 23, /* f_apply_hdivhcurl_error_22 fem/qfunctions/22/hcurlhdiv_error_22_qf.h:43-74 */
-  PA_QF_HDIV_22 = 24             /* f_apply_hdiv_22 fem/qfunctions/22/hdiv_22_qf.h:10-30: mass of a plane H(div) space
+  PA_QF_HDIV_22 = 24,            /* f_apply_hdiv_22 fem/qfunctions/22/hdiv_22_qf.h:10-30: mass of a plane H(div) space
                                     (pa_op_add_sub_dense with PA_FE_HDIV, Interp) */
+  PA_QF_L2H1_ERROR = 25          /* f_apply_l2h1_error fem/qfunctions/l2h1_error_qf.h:14-30: element error between two scalar
+                                    fields (the scalar curl of a plane field and its H1 recovery, errorestimator.cpp:466-472);
+                                    pa_error_op_create with two scalar (PA_FE_H1 descriptor) bases, 1 x 1 pair context */
 };
 
 enum pa_fe_type {
@@ -260,7 +263,8 @@ int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *res
  * enters with its gradient table (`deriv`, Grad): with PA_QF_HCURL_33 / PA_QF_HCURL_22 that is MixedVectorGradientIntegrator
  * (C grad phi, v), H1 trial and H(curl) test (fem/integ/mixedvecgrad.cpp:43-76; models/modeeigensolver.cpp:52), and with
  * PA_QF_HCURLHDIV_* its H(div)-test form (mixedvecgrad.cpp:50-55).  Plane elements: the _22 QFunctions with 2-D geometry
- * data.  op: height = test lsize, width = trial lsize.  No transposed, essential-dof, diagonal or assembled form. */
+ * data.  PA_QF_H1_1 with two scalar bases (PA_FE_H1 descriptors, value tables): MassIntegrator between two scalar spaces, the
+ * `Flux` operator of the scalar-flux FluxProjector (errorestimator.cpp:122-160).  op: height = test lsize, width = trial lsize.  No transposed, essential-dof, diagonal or assembled form. */
 int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
                               const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
                               const pa_dense_basis_desc *test_basis, int32_t qfunction, const void *ctx, size_t ctx_size);

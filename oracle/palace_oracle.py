@@ -443,6 +443,20 @@ def _geom22(ctx, geom):
     return geom[:, 1, :], A, Jl, [Cm[..., k] for k in range(4)]
 
 
+def apply_l2h1_error(ctx1, ctx2, geom, u1, u2):
+    """l2h1_error_qf.h:14-30 (f_apply_l2h1_error): w detJ (c1 u1 - c2 u2)^2 for two scalar fields [NE, 1, Q] -> [NE, Q]; any
+    geometry data (only rows 0, 1 are read)."""
+    attr = geom[:, 0, :].astype(np.int32)
+    d = _unpack1(ctx1, attr) * u1[:, 0, :] - _unpack1(ctx2, attr) * u2[:, 0, :]
+    return geom[:, 1, :] * d * d
+
+
+def apply_h1_1(ctx, geom, u):
+    """h1_1_qf.h:10-24 (f_apply_h1_1): v = c w detJ u, scalar."""
+    attr = geom[:, 0, :].astype(np.int32)
+    return (_unpack1(ctx, attr) * geom[:, 1, :])[:, None, :] * u
+
+
 def apply_hdiv_22(ctx, geom, u):
     """hdiv_22_qf.h:10-30 (f_apply_hdiv_22): v = w detJ (J/detJ)^T C (J/detJ) u -- mass of a plane H(div) space."""
     wdetJ, A, Jl, C = _geom22(ctx, geom)
@@ -593,6 +607,7 @@ QF_HCURLHDIV_ERROR, QF_HDIVHCURL_ERROR = "hcurlhdiv_error_33", "hdivhcurl_error_
 QF_HCURLHDIV, QF_HDIVHCURL = "hcurlhdiv_33", "hdivhcurl_33"  # weak curl (Interp -> Curl), mixed curl (Curl -> Interp)
 QF_HCURLHDIV_22, QF_HDIVHCURL_22, QF_HDIV_22 = "hcurlhdiv_22", "hdivhcurl_22", "hdiv_22"
 QF_HCURLHDIV_ERROR_22, QF_HDIVHCURL_ERROR_22 = "hcurlhdiv_error_22", "hdivhcurl_error_22"
+QF_L2H1_ERROR = "l2h1_error"
 
 
 class CeedOperatorOracle:
@@ -828,7 +843,8 @@ class MixedSpaceOracle:
 
     def apply_add(self, x, y, chunk=2048):
         f = {QF_HCURLHDIV: apply_hcurlhdiv_33, QF_HDIVHCURL: apply_hdivhcurl_33, QF_HCURL: apply_hcurl_33,
-             QF_HCURLHDIV_22: apply_hcurlhdiv_22, QF_HDIVHCURL_22: apply_hdivhcurl_22, QF_HCURL_22: apply_hcurl_22}[self.qf]
+             QF_HCURLHDIV_22: apply_hcurlhdiv_22, QF_HDIVHCURL_22: apply_hdivhcurl_22, QF_HCURL_22: apply_hcurl_22,
+             QF_H1MASS: apply_h1_1}[self.qf]  # QF_H1MASS: MassIntegrator between two scalar spaces (dim-1 context)
         for s0 in range(0, self.a.NE, chunk):
             sl = slice(s0, min(self.a.NE, s0 + chunk))
             u = np.einsum("dqj,ej->edq", self.ta, self.a._restrict(x, sl))
@@ -839,7 +855,8 @@ class MixedSpaceOracle:
     def error_add(self, u1, u2, est, chunk=2048):
         """est[e] += sum_q of the error QFunction (the all-ones `mesh_elem_basis`, integrator.cpp:560-574)."""
         f = {QF_HCURLHDIV_ERROR: apply_hcurlhdiv_error_33, QF_HDIVHCURL_ERROR: apply_hdivhcurl_error_33,
-             QF_HCURLHDIV_ERROR_22: apply_hcurlhdiv_error_22, QF_HDIVHCURL_ERROR_22: apply_hdivhcurl_error_22}[self.qf]
+             QF_HCURLHDIV_ERROR_22: apply_hcurlhdiv_error_22, QF_HDIVHCURL_ERROR_22: apply_hdivhcurl_error_22,
+             QF_L2H1_ERROR: apply_l2h1_error}[self.qf]
         for s0 in range(0, self.a.NE, chunk):
             sl = slice(s0, min(self.a.NE, s0 + chunk))
             q1 = np.einsum("dqj,ej->edq", self.ta, self.a._restrict(u1, sl))

@@ -24,6 +24,7 @@ typedef double CeedScalar;
 #include "fem/qfunctions/22/hdiv_22_qf.h"
 #include "fem/qfunctions/22/hcurlhdiv_error_22_qf.h"
 #include "fem/qfunctions/1/l2_1_qf.h"
+#include "fem/qfunctions/l2h1_error_qf.h"
 #include "fem/qfunctions/21/geom_21_qf.h"
 #include "fem/qfunctions/21/hcurl_21_qf.h"
 #include "fem/qfunctions/21/hcurlmass_21_qf.h"

@@ -26,6 +26,7 @@ QF_HCURL_21, QF_HCURL_31, QF_HCURLMASS_21, QF_HCURLMASS_31 = 16, 17, 18, 19  # l
 QF_HCURLHDIV_33, QF_HDIVHCURL_33 = 9, 10  # weak curl (trial Interp, test Curl) / mixed curl (trial Curl, test Interp)
 QF_HCURLHDIV_22, QF_HDIVHCURL_22, QF_HCURLHDIV_ERROR_22, QF_HDIVHCURL_ERROR_22 = 20, 21, 22, 23  # two spaces, plane elements
 QF_HDIV_22 = 24  # mass of a plane H(div) space (FE_HDIV block, Interp)
+QF_L2H1_ERROR = 25  # element error between two scalar fields (ElementErrorIntegrator with two scalar blocks)
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
 FE_H1, FE_HCURL, FE_HDIV = 0, 1, 2
 

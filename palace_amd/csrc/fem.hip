@@ -446,9 +446,10 @@ void BilinearFormIntegrator::AssembleCeedOperator(pa_op *op, const FiniteElement
       check(pa_op_add_sub_dense(op, trial.GetMesh().GetCeedGeomFactorData(), &r, &b, qf, ctx.data(), ctx.size() * sizeof(double),
                                 trial_ops, test_ops));
     } else {  // two spaces: values of vector elements, gradients of H1 elements (pa_op_add_sub_dense_mixed)
-      PA_REQUIRE(trial_ops == (trial.GetFEType() == PA_FE_H1 ? PA_EVAL_GRAD : PA_EVAL_INTERP) &&
-                     test_ops == (test.GetFEType() == PA_FE_H1 ? PA_EVAL_GRAD : PA_EVAL_INTERP),
-                 "mixed-space forms evaluate the values of vector elements and the gradients of H1 elements");
+      const bool scalar = qf == PA_QF_H1_1;  // MassIntegrator between two scalar spaces: values on both sides
+      PA_REQUIRE(trial_ops == ((trial.GetFEType() == PA_FE_H1 && !scalar) ? PA_EVAL_GRAD : PA_EVAL_INTERP) &&
+                     test_ops == ((test.GetFEType() == PA_FE_H1 && !scalar) ? PA_EVAL_GRAD : PA_EVAL_INTERP),
+                 "mixed-space forms evaluate the values of vector or scalar elements and the gradients of H1 elements");
       const auto r2 = test.GetCeedElemRestriction();
       const auto b2 = test.GetCeedDenseBasis();
       check(pa_op_add_sub_dense_mixed(op, trial.GetMesh().GetCeedGeomFactorData(), &r, &b, &r2, &b2, qf, ctx.data(),

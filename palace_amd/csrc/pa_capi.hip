@@ -646,7 +646,8 @@ int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_des
     PA_REQUIRE(op && geom && trial_restr && trial_basis && test_restr && test_basis, "null argument");
     PA_REQUIRE(!op->finalized, "operator already finalized");
     PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_33 || qfunction == PA_QF_HDIVHCURL_33 || qfunction == PA_QF_HCURL_33 ||
-                   qfunction == PA_QF_HCURLHDIV_22 || qfunction == PA_QF_HDIVHCURL_22 || qfunction == PA_QF_HCURL_22,
+                   qfunction == PA_QF_HCURLHDIV_22 || qfunction == PA_QF_HDIVHCURL_22 || qfunction == PA_QF_HCURL_22 ||
+                   qfunction == PA_QF_H1_1,
                "not a mixed-space QFunction");
     PA_REQUIRE(test_restr->lsize == op->height && trial_restr->lsize == op->width,
                "dimensions mismatch for sub-operator");  // operator.cpp:69-71
@@ -665,7 +666,8 @@ int pa_error_op_create(pa_geom *geom, const pa_restriction_desc *restr1, const p
     require_device();
     PA_REQUIRE(geom && restr1 && basis1 && restr2 && basis2 && out, "null argument");
     PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_ERROR_33 || qfunction == PA_QF_HDIVHCURL_ERROR_33 ||
-                   qfunction == PA_QF_HCURLHDIV_ERROR_22 || qfunction == PA_QF_HDIVHCURL_ERROR_22,
+                   qfunction == PA_QF_HCURLHDIV_ERROR_22 || qfunction == PA_QF_HDIVHCURL_ERROR_22 ||
+                   qfunction == PA_QF_L2H1_ERROR,
                "not an error QFunction");
     auto *e = new pa_error_op;
     try {

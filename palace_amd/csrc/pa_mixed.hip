@@ -11,6 +11,9 @@
 //  * the same-map mixed form  (C grad phi, v)  with phi in H1 and v in H(curl): MixedVectorGradientIntegrator
 //    (fem/integ/mixedvecgrad.cpp:43-76, f_apply_hcurl_33 / f_apply_hcurl_22 with trial Grad and test Interp) -- the `Atn` block
 //    of the boundary-mode eigenproblem (models/modeeigensolver.cpp:52); an H1 side enters with its gradient table;
+//  * the scalar pair of the 2-D curl flux estimator (errorestimator.cpp:122-160, :446-474: the curl of a plane field is a
+//    scalar): mass (c u, v) between two scalar spaces (MassIntegrator, f_apply_h1_1) and the element error
+//    f_apply_l2h1_error (fem/qfunctions/l2h1_error_qf.h:14-30), scalar coefficients, only w detJ of the geometry data;
 //  * all of them on triangles / quadrilaterals in the plane (qfunctions/22/hcurlhdiv_22_qf.h, hcurlhdiv_error_22_qf.h): the
 //    2 x 2 Jacobian adjugate and coefficient are embedded in 3 x 3 matrices (third component of every field zero), which
 //    makes the 3-D arithmetic below the reference's 2-D arithmetic term by term.
@@ -74,7 +77,9 @@ __device__ __forceinline__ void mix_gather(const MixSideDev &sd, const int e, co
 
 __device__ __forceinline__ void mix_eval(const MixSideDev &sd, const int Q, const int q, const double *xs, double (&u)[3]) {
   u[0] = u[1] = u[2] = 0.0;
-  if (sd.nc == 3) {
+  if (sd.nc == 1) {
+    for (int d = 0; d < sd.P; d++) u[0] += sd.tabF[(size_t)d * Q + q] * xs[d];
+  } else if (sd.nc == 3) {
     for (int d = 0; d < sd.P; d++) {
       const double xv = xs[d];
       u[0] += sd.tabF[((size_t)0 * sd.P + d) * Q + q] * xv;
@@ -111,14 +116,16 @@ __device__ __forceinline__ void coeff_unpack2in3(const CoeffDev &c, int attr, do
 }
 
 // KIND 0: f_apply_hcurlhdiv_33 | _22, 1: f_apply_hdivhcurl_33 | _22, 2: f_apply_hcurlhdiv_error_33 | _22,
-// 3: f_apply_hdivhcurl_error_33 | _22, 4: f_apply_hcurl_33 | _22 between two spaces
+// 3: f_apply_hdivhcurl_error_33 | _22, 4: f_apply_hcurl_33 | _22 between two spaces, 5: f_apply_h1_1 between two scalar
+// spaces, 6: f_apply_l2h1_error
 template <int KIND>
 __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * kMixWaves + wave;
   if (e >= a.ne) return;  // no workgroup barriers below
-  constexpr bool ERR = KIND == 2 || KIND == 3;
+  constexpr bool ERR = KIND == 2 || KIND == 3 || KIND == 6;
+  constexpr bool SCALAR = KIND >= 5;
   const int P1 = a.s1.P, P2 = a.s2.P, Q = a.Q;
   double *xa = smem + (size_t)wave * a.stride;
   double *xb = xa + P1;
@@ -136,6 +143,18 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
     mix_eval(a.s1, Q, q, xa, u1);
     const int attr = (a.c0.nattr > 0 || a.c1.nattr > 0) ? max(1, (int)g[(size_t)q * kEBm]) : 1;
     const double wdetJ = g[((size_t)a.Qpad + q) * kEBm];
+    if (SCALAR) {
+      const double c1 = a.c0.mat[coeff_index(a.c0, attr)];
+      if (KIND == 5) {  // h1_1_qf.h:10-24
+        vq[q] = c1 * wdetJ * u1[0];
+      } else {  // l2h1_error_qf.h:14-30
+        double u2[3];
+        mix_eval(a.s2, Q, q, xb, u2);
+        const double diff = c1 * u1[0] - a.c1.mat[coeff_index(a.c1, attr)] * u2[0];
+        err += wdetJ * diff * diff;
+      }
+      continue;
+    }
     double adj[9], Jl[9], Cm[9];
     if (a.dim == 3) {
 #pragma unroll
@@ -208,7 +227,8 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
 // map of H(curl) values is the map of gradients.
 void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, int nc, MixedSide &sd) {
   PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_HDIV || b.fe_type == PA_FE_H1, "unknown element type");
-  const double *tab = b.fe_type == PA_FE_H1 ? b.deriv : b.interp;
+  PA_REQUIRE(nc > 1 || b.fe_type == PA_FE_H1, "scalar QFunctions take scalar (PA_FE_H1 descriptor) elements");
+  const double *tab = (b.fe_type == PA_FE_H1 && nc > 1) ? b.deriv : b.interp;  // nc == 1: values of a scalar space
   PA_REQUIRE(b.num_dofs > 0 && b.num_qpts == Q && tab, "basis does not match the quadrature rule, or has no value / gradient table");
   PA_REQUIRE(r.elem_size == b.num_dofs && r.offsets && r.lsize > 0, "restriction does not match the basis");
   PA_REQUIRE(!(r.orients && r.curl_orients), "restriction is either oriented or curl-oriented");
@@ -264,6 +284,8 @@ void launch(const MixedSub &ms, const double *x1, const double *x2, double *out,
     case 2: hipLaunchKernelGGL(mixed_kernel<2>, grid, block, shm, s, a); break;
     case 3: hipLaunchKernelGGL(mixed_kernel<3>, grid, block, shm, s, a); break;
     case 4: hipLaunchKernelGGL(mixed_kernel<4>, grid, block, shm, s, a); break;
+    case 5: hipLaunchKernelGGL(mixed_kernel<5>, grid, block, shm, s, a); break;
+    case 6: hipLaunchKernelGGL(mixed_kernel<6>, grid, block, shm, s, a); break;
     default: throw Error("not a mixed-space QFunction");
   }
   PA_HIP(hipGetLastError());
@@ -285,17 +307,20 @@ MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_
     case PA_QF_HCURLHDIV_ERROR_33: case PA_QF_HCURLHDIV_ERROR_22: kind = 2; break;
     case PA_QF_HDIVHCURL_ERROR_33: case PA_QF_HDIVHCURL_ERROR_22: kind = 3; break;
     case PA_QF_HCURL_33: case PA_QF_HCURL_22: kind = 4; break;
+    case PA_QF_H1_1: kind = 5; break;
+    case PA_QF_L2H1_ERROR: kind = 6; break;
     default: throw Error("not a mixed-space QFunction");
   }
   const bool is22 = qf == PA_QF_HCURLHDIV_22 || qf == PA_QF_HDIVHCURL_22 || qf == PA_QF_HCURLHDIV_ERROR_22 ||
                     qf == PA_QF_HDIVHCURL_ERROR_22 || qf == PA_QF_HCURL_22;
-  PA_REQUIRE(is22 == (dim == 2), "QFunction does not match the dimension of the geometry data");
-  const bool err = kind == 2 || kind == 3;
+  const bool scalar = kind >= 5;  // dimension-independent: reads w detJ only
+  PA_REQUIRE(scalar || is22 == (dim == 2), "QFunction does not match the dimension of the geometry data");
+  const bool err = kind == 2 || kind == 3 || kind == 6;
   // first space / second space by the Piola map the QFunction applies to each input: covariant (H(curl) values, H1
   // gradients) or contravariant (H(div) values)
   auto covariant = [](const pa_dense_basis_desc &b) { return b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_H1; };
   const bool cov1 = kind == 0 || kind == 2 || kind == 4, cov2 = kind == 1 || kind == 3 || kind == 4;
-  PA_REQUIRE((cov1 ? covariant(b1) : b1.fe_type == PA_FE_HDIV) && (cov2 ? covariant(b2) : b2.fe_type == PA_FE_HDIV),
+  PA_REQUIRE(scalar || ((cov1 ? covariant(b1) : b1.fe_type == PA_FE_HDIV) && (cov2 ? covariant(b2) : b2.fe_type == PA_FE_HDIV)),
              "element types do not match the QFunction (vecfemass.cpp:88-101, mixedvecgrad.cpp:43-76)");
   PA_REQUIRE(ctx && ctx_size >= 16 && ctx_size % 8 == 0, "bad coefficient context");
   auto *ms = new MixedSub;
@@ -303,10 +328,10 @@ MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_
     ms->geom = geom;
     geom->refcount++;
     ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->kind = kind, ms->error = err;
-    build_side(r1, b1, geom->Q, dim, ms->s1);
-    build_side(r2, b2, geom->Q, dim, ms->s2);
-    parse_coeff(ctx, ctx_size, dim, ms->c0, 0);
-    if (err) parse_coeff(ctx, ctx_size, dim, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
+    build_side(r1, b1, geom->Q, scalar ? 1 : dim, ms->s1);
+    build_side(r2, b2, geom->Q, scalar ? 1 : dim, ms->s2);
+    parse_coeff(ctx, ctx_size, scalar ? 1 : dim, ms->c0, 0);
+    if (err) parse_coeff(ctx, ctx_size, scalar ? 1 : dim, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
     if (!err) ms->d_ye = dev_alloc<double>((size_t)ms->ne * ms->s2.P);
   } catch (...) {
     free_mixed_sub(ms);

@@ -141,6 +141,12 @@ def fixtures_2d():
         ee = np.zeros((1, Q))
         capi.ref_call("f_apply_" + name, pair22, Q, [geom, u, u2], [ee])
         out[name] = ee[0]
+    # the scalar error integrand of the 2-D curl flux estimator (l2h1_error_qf.h), 1 x 1 pair context
+    c1b = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([0.9]), np.array([1.3])], dim=1)
+    cu2 = rng.uniform(-1, 1, (1, Q))
+    ee = np.zeros((1, Q))
+    capi.ref_call("f_apply_l2h1_error", np.concatenate([c1.pack(), c1b.pack()]), Q, [geom, cu, cu2], [ee])
+    out.update(l2h1_error=ee[0], ctx1b=c1b.pack(), cu2=cu2)
     out.update(ctx2n=c2n.pack(), u2=u2)
     np.savez(os.path.join(ROOT, "tests", "golden", "qf2d_golden.npz"), **out)
     print("wrote qf2d_golden.npz")

@@ -257,6 +257,59 @@ def test_plane_flux_estimate():
     assert est_o.min() > 0
 
 
+def _scalar_pair(kind, p):
+    """A discontinuous scalar space (the L2 space the scalar curl of a plane Nedelec field lives in; here with the nodal
+    basis of order p on every element and no sharing) and the continuous H1 space of order p, on triangles or tetrahedra."""
+    from palace_amd import ceed
+
+    if kind == "tri":
+        geom, ogeom, (h1b, h1o, hgrad), _, _ = _tri_blocks(p)
+    else:
+        geom, ogeom, (h1b, h1o, hgrad), _, _ = _tet_blocks(kind, p)
+    ne, P = h1b.offsets.shape
+    off = np.arange(ne * P, dtype=np.int32).reshape(ne, P)
+    l2b = ceed.DenseBlock(ceed.FE_H1, ne * P, off, h1b.interp, h1b.deriv)
+    l2o = po.CeedOperatorOracle(ne * P, off, None, h1b.interp, h1b.deriv, ogeom, po.QF_H1MASS, None, vector_fe=False)
+    return geom, ogeom, (l2b, l2o), (h1b, h1o)
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["tri", "tet10"])
+def test_scalar_flux_pair(kind, p):
+    """The scalar branch of the flux estimators (2-D curl: errorestimator.cpp:122-160, :446-474): MassIntegrator from a
+    discontinuous scalar space into H1 (f_apply_h1_1 between two spaces) and the element error f_apply_l2h1_error."""
+    import torch
+
+    from palace_amd import ceed
+
+    geom, ogeom, (l2b, l2o), (h1b, h1o) = _scalar_pair(kind, p)
+    rng = np.random.default_rng(60 + p)
+    c1 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([1.9]), np.array([0.4])], dim=1)
+    c2 = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([0.9]), np.array([1.3])], dim=1)
+    op = ceed.Operator(h1b.lsize, l2b.lsize).add_dense_mixed_integrator(geom, l2b, h1b, ceed.QF_H1_1, c1.pack()).finalize()
+    x = rng.uniform(-1, 1, l2b.lsize)
+    ref = po.MixedSpaceOracle(l2o, h1o, ogeom, po.QF_H1MASS, c1).apply_add(x, np.zeros(h1b.lsize))
+    assert np.abs(_mult(op, x, h1b.lsize) - ref).max() < REL * np.abs(ref).max()
+    # the continuous field embedded in the discontinuous space gives the H1 mass operator
+    m = ceed.Operator(h1b.lsize, h1b.lsize).add_dense_integrator(geom, h1b, ceed.QF_H1_1, c1.pack(), ceed.EVAL_INTERP).finalize()
+    xc = rng.uniform(-1, 1, h1b.lsize)
+    ym = _mult(m, xc, h1b.lsize)
+    assert np.abs(_mult(op, xc[h1b.offsets].ravel(), h1b.lsize) - ym).max() < 1e-11 * np.abs(ym).max()
+    integ = ceed.ElementErrorIntegrator(geom, l2b, h1b, ceed.QF_L2H1_ERROR, np.concatenate([c1.pack(), c2.pack()]))
+    u2 = rng.uniform(-1, 1, h1b.lsize)
+    e0 = rng.uniform(0, 1, integ.ne)
+    ref = po.MixedSpaceOracle(l2o, h1o, ogeom, po.QF_L2H1_ERROR, c1, c2).error_add(x, u2, e0.copy())
+    est = torch.from_numpy(e0.copy()).cuda()
+    integ.apply_add(torch.from_numpy(x).cuda(), torch.from_numpy(u2).cuda(), est)
+    assert np.abs(est.cpu().numpy() - ref).max() < REL * np.abs(ref).max()
+    assert (ref - e0).min() > 0
+    # equal fields with equal coefficients: no error
+    est.zero_()
+    same = ceed.ElementErrorIntegrator(geom, l2b, h1b, ceed.QF_L2H1_ERROR, np.concatenate([c1.pack(), c1.pack()]))
+    same.apply_add(torch.from_numpy(xc[h1b.offsets].ravel().copy()).cuda(), torch.from_numpy(xc).cuda(), est)
+    assert float(est.abs().max()) < 1e-24 + 1e-26 * float(np.abs(ref).max())
+
+
 def test_two_space_argument_checks_2d():
     from palace_amd import ceed
     from palace_amd.lib import PalaceAmdError

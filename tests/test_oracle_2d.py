@@ -84,6 +84,15 @@ def test_two_space_qfunctions_22():
     assert G["hcurlhdiv_error_22"].min() > 0 and not np.allclose(G["hcurlhdiv_error_22"], G["hdivhcurl_error_22"])
 
 
+def test_scalar_error_qfunction():
+    """f_apply_l2h1_error (l2h1_error_qf.h: the 2-D curl flux estimator's integrand) against the reference header."""
+    c1, _ = _ctx(G["ctx1"], 1)
+    c1b, _ = _ctx(G["ctx1b"], 1)
+    got = po.apply_l2h1_error(c1, c1b, G["geom"][None], G["cu"][None], G["cu2"][None])[0]
+    np.testing.assert_allclose(got, G["l2h1_error"], rtol=TOL, atol=TOL)
+    assert G["l2h1_error"].min() > 0
+
+
 def test_line_element_qfunctions_21_31():
     """geom_21 / geom_31, f_apply_hcurl_21 / _31, f_apply_hcurlmass_21 / _31 (line elements: boundaries of plane problems, curves
     in space) against vectors produced by the reference headers (tests/golden/make_golden.py: fixtures_line)."""
