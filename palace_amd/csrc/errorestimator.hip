@@ -96,16 +96,24 @@ double ErrorIndicator::Norml2() const { return n_ ? std::sqrt(linalg::Dot(*ctx_,
 FluxProjector::FluxProjector(const MaterialPropertyCoefficient &coeff, const FiniteElementSpace &smooth_fespace,
                              const FiniteElementSpace &rhs_fespace, double tol, int max_it, int print)
     : ctx_(&smooth_fespace.GetContext()), smooth_(&smooth_fespace), rhs_space_(&rhs_fespace) {
+  // :117-120: a scalar smooth space (the H1 recovery of the scalar curl of a plane field) takes MassIntegrator
+  const bool scalar_flux = smooth_fespace.GetFEType() == PA_FE_H1;
   {  // errorestimator.cpp:125-153 (use_mg = false): the mass matrix of the smooth space, no coefficient
     BilinearForm m(smooth_fespace);
-    m.AddDomainIntegrator<VectorFEMassIntegrator>((const MaterialPropertyCoefficient *)nullptr);
+    if (scalar_flux)
+      m.AddDomainIntegrator<MassIntegrator>((const MaterialPropertyCoefficient *)nullptr);
+    else
+      m.AddDomainIntegrator<VectorFEMassIntegrator>((const MaterialPropertyCoefficient *)nullptr);
     mass_ = m.PartialAssemble();
     M_ = std::make_unique<ParOperator>(*ctx_, *mass_, smooth_fespace.GetTrueVSize(), nullptr, 0,
                                        ParOperator::DiagonalPolicy::DIAG_ONE, smooth_fespace.GetHalo());
   }
   {  // :154-176: the flux operator is always partially assembled
     BilinearForm flux(rhs_fespace, smooth_fespace);
-    flux.AddDomainIntegrator<VectorFEMassIntegrator>(coeff);
+    if (scalar_flux)
+      flux.AddDomainIntegrator<MassIntegrator>(coeff);
+    else
+      flux.AddDomainIntegrator<VectorFEMassIntegrator>(coeff);
     flux_ = flux.PartialAssemble();
   }
   // ConfigureLinearSolver (:66-107): the system matrix is real, SPD and diagonally dominant
@@ -155,7 +163,8 @@ FluxErrorEstimatorBase::FluxErrorEstimatorBase(const FiniteElementSpace &fespace
   PA_REQUIRE(fespace.IsDense() && smooth_fespace.IsDense() && &fespace.GetMesh() == &smooth_fespace.GetMesh(),
              "the estimators take two dense-table spaces on one mesh");
   const auto c1 = first.Coefficient(), c2 = second.Coefficient();
-  const auto ctx = ceed::PopulateCoefficientContext(3, &c1, 3, &c2);  // errorestimator.cpp:326-329, :459-460
+  PA_REQUIRE(first.dim == second.dim, "the two coefficients of an error integrator have one dimension");
+  const auto ctx = ceed::PopulateCoefficientContext(first.dim, &c1, second.dim, &c2);  // errorestimator.cpp:326-329, :459-460
   const auto r1 = fespace.GetCeedElemRestriction(), r2 = smooth_fespace.GetCeedElemRestriction();
   const auto b1 = fespace.GetCeedDenseBasis(), b2 = smooth_fespace.GetCeedDenseBasis();
   check(pa_error_op_create(fespace.GetMesh().GetCeedGeomFactorData(), &r1, &b1, &r2, &b2, error_qf, ctx.data(),
@@ -200,13 +209,15 @@ void FluxErrorEstimatorBase::AddErrorIndicator(const Vector &F, double Et, Error
 
 GradFluxErrorEstimator::GradFluxErrorEstimator(const MaterialTensors &epsilon, const FiniteElementSpace &nd_fespace,
                                                const FiniteElementSpace &rt_fespace, double tol, int max_it, int print)
-    : FluxErrorEstimatorBase(nd_fespace, rt_fespace, epsilon.Coefficient(), PA_QF_HCURLHDIV_ERROR_33,
+    : FluxErrorEstimatorBase(nd_fespace, rt_fespace, epsilon.Coefficient(),
+                             nd_fespace.GetMesh().Dimension() == 2 ? PA_QF_HCURLHDIV_ERROR_22 : PA_QF_HCURLHDIV_ERROR_33,  // :343-356
                              epsilon.Map([](const double *m) { return linalg::MatrixSqrt(m); }),
                              epsilon.Map([](const double *m) { return linalg::MatrixPow(m, -0.5); }), tol, max_it, print) {}
 
 CurlFluxErrorEstimator::CurlFluxErrorEstimator(const MaterialTensors &muinv, const FiniteElementSpace &rt_fespace,
                                                const FiniteElementSpace &nd_fespace, double tol, int max_it, int print)
-    : FluxErrorEstimatorBase(rt_fespace, nd_fespace, muinv.Coefficient(), PA_QF_HDIVHCURL_ERROR_33,
+    : FluxErrorEstimatorBase(rt_fespace, nd_fespace, muinv.Coefficient(),
+                             rt_fespace.GetMesh().Dimension() == 2 ? PA_QF_L2H1_ERROR : PA_QF_HDIVHCURL_ERROR_33,  // :464-480
                              muinv.Map([](const double *m) { return linalg::MatrixSqrt(m); }),
                              muinv.Map([](const double *m) { return linalg::MatrixPow(m, -0.5); }), tol, max_it, print) {}
 

@@ -37,21 +37,30 @@ public:
   int NumSamples() const { return n_; }
 };
 
-// what MaterialOperator hands to the estimators: attribute -> material index and one symmetric 3x3 tensor per material
-// (mat_op.GetAttributeToMaterial() with GetPermittivityReal() or GetInvPermeability(), column-major)
+// what MaterialOperator hands to the estimators: attribute -> material index and one symmetric dim x dim tensor per material
+// (mat_op.GetAttributeToMaterial() with GetPermittivityReal(), GetInvPermeability() or, for the scalar curl of a plane
+// problem, the 1 x 1 GetCurlCurlInvPermeability(); column-major).  dim = 3 unless stated.
 struct MaterialTensors {
   std::vector<int> attr_mat;
-  std::vector<double> mat;  // [num_mat][9]
+  std::vector<double> mat;  // [num_mat][dim * dim]
+  int dim = 3;
+  // f acts on symmetric 3 x 3 matrices: smaller tensors are bordered with an identity block, which f maps to itself
+  // up to f(1) and which is dropped again
   template <typename F>
   MaterialTensors Map(F &&f) const {
-    MaterialTensors out{attr_mat, mat};
-    for (size_t k = 0; k + 9 <= mat.size(); k += 9) {
-      const auto m = f(&mat[k]);
-      std::copy(m.begin(), m.end(), out.mat.begin() + k);
+    MaterialTensors out{attr_mat, mat, dim};
+    const size_t dd = (size_t)dim * dim;
+    for (size_t k = 0; k + dd <= mat.size(); k += dd) {
+      double M[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+      for (int j = 0; j < dim; j++)
+        for (int i = 0; i < dim; i++) M[i + 3 * j] = mat[k + i + (size_t)dim * j];
+      const auto m = f(M);
+      for (int j = 0; j < dim; j++)
+        for (int i = 0; i < dim; i++) out.mat[k + i + (size_t)dim * j] = m[i + 3 * j];
     }
     return out;
   }
-  MaterialPropertyCoefficient Coefficient() const { return MaterialPropertyCoefficient(attr_mat, 3, mat); }
+  MaterialPropertyCoefficient Coefficient() const { return MaterialPropertyCoefficient(attr_mat, dim, mat); }
 };
 
 // errorestimator.hpp:34-58, .cpp:111-187: y = M^-1 Flux x with M the mass matrix of the smooth space and Flux the
@@ -104,7 +113,8 @@ public:
                          const FiniteElementSpace &rt_fespace, double tol, int max_it, int print);
 };
 
-// eta_e^2 = || mu^1/2 H - mu^-1/2 B ||^2_e with H the ND recovery of mu^-1 B (B in RT)
+// eta_e^2 = || mu^1/2 H - mu^-1/2 B ||^2_e with H the ND recovery of mu^-1 B (B in RT).  Plane problems: B = curl E is a scalar
+// in a discontinuous space, H its H1 recovery, muinv the 1 x 1 curl-curl tensor (errorestimator.cpp:446-472, f_apply_l2h1_error)
 class CurlFluxErrorEstimator : public FluxErrorEstimatorBase {
 public:
   CurlFluxErrorEstimator(const MaterialTensors &muinv, const FiniteElementSpace &rt_fespace,

@@ -18,18 +18,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "examples", "cxx_host"))
 
 
-@pytest.fixture(scope="module")
-def exe(tmp_path_factory):
+def _build(tmp_path_factory, name):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    d = tmp_path_factory.mktemp("cxx_est")
-    out = str(d / "estimate")
+    d = tmp_path_factory.mktemp("cxx_" + name)
+    out = str(d / name)
     libdir = os.path.join(ROOT, "palace_amd", "lib")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O2", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
-                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cxx_host", "estimate.cpp"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cxx_host", name + ".cpp"),
                            "-L" + libdir, "-lpalace_amd", "-Wl,-rpath," + libdir, "-o", out])
     return out, d
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    return _build(tmp_path_factory, "estimate")
+
+
+@pytest.fixture(scope="module")
+def exe2d(tmp_path_factory):
+    return _build(tmp_path_factory, "estimate2d")
 
 
 def _sym_fun(M, f):
@@ -96,3 +105,44 @@ def test_cxx_flux_error_estimators(exe, curved):
     norms = [float(l.split()[2]) for l in r.stdout.splitlines() if "norm" in l]
     for n, e in zip(norms, ref):
         assert abs(n - np.linalg.norm(e)) < 1e-8 * np.linalg.norm(e)
+
+
+def test_cxx_plane_flux_error_estimators(exe2d):
+    """The plane branch (errorestimator.cpp:343-349, :446-472) through the C++ classes: GradFluxErrorEstimator with 2 x 2
+    tensors on (ND, RT) and CurlFluxErrorEstimator with the scalar curl in a discontinuous space, its H1 recovery and 1 x 1
+    tensors, on the triangles of the reference's cavity2d mesh; against the oracle operators with sparse direct solves."""
+    import scipy.sparse.linalg as spla
+
+    import dump_estimator_problem_2d as dp
+
+    binary, d = exe2d
+    blob, out = str(d / "problem2d.bin"), str(d / "ind2d.bin")
+    dp.main(blob, 1)
+    r = subprocess.run([binary, blob, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    P = dp.problem(1)
+    m, nd, h1 = P["mesh"], P["nd"], P["h1"]
+    J = m.jacobians(P["pts"])
+    og = po.build_geom_factor_22(m.attr.astype(np.float64), P["wts"], np.transpose(J, (0, 1, 3, 2)).reshape(m.ne, -1, 4))
+    c2, c1 = po.CoeffCtx(dim=2), po.CoeffCtx(dim=1)
+    ndo = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, P["nint"], P["ncurl"], og, po.QF_HCURL_22, c2, qw=P["wts"])
+    rto = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, P["rint"], P["ncurl"], og, po.QF_HDIV_22, c2, qw=P["wts"])
+    h1o = po.CeedOperatorOracle(h1.ndofs, h1.offsets, None, P["hint"], P["hgrad"], og, po.QF_H1MASS, c1, vector_fe=False)
+    l2o = po.CeedOperatorOracle(P["l2_off"].size, P["l2_off"], None, P["hint"], P["hgrad"], og, po.QF_H1MASS, c1, vector_fe=False)
+
+    def ctx(mats, dim):
+        return po.CoeffCtx(attr_mat=[0, 1], mat_coeff=list(mats), dim=dim)
+
+    eps, mui = P["eps"], P["muinv"]
+    D = spla.spsolve(rto.assemble_sparse().tocsc(),
+                     po.MixedSpaceOracle(ndo, rto, og, po.QF_HCURLHDIV_22, ctx(eps, 2)).apply_add(P["E"], np.zeros(rto.lsize)))
+    eg = po.MixedSpaceOracle(ndo, rto, og, po.QF_HCURLHDIV_ERROR_22, ctx([_sym_fun(e, np.sqrt) for e in eps], 2),
+                             ctx([_sym_fun(e, lambda w: w ** -0.5) for e in eps], 2)).error_add(P["E"], D, np.zeros(m.ne))
+    H = spla.spsolve(h1o.assemble_sparse().tocsc(),
+                     po.MixedSpaceOracle(l2o, h1o, og, po.QF_H1MASS, ctx(mui, 1)).apply_add(P["B"], np.zeros(h1o.lsize)))
+    ec = po.MixedSpaceOracle(l2o, h1o, og, po.QF_L2H1_ERROR, ctx([np.sqrt(e) for e in mui], 1),
+                             ctx([e ** -0.5 for e in mui], 1)).error_add(P["B"], H, np.zeros(m.ne))
+    got = np.fromfile(out, dtype=np.float64).reshape(2, m.ne)
+    for g, e, name in zip(got, (np.sqrt(eg * 0.5 / 0.37), np.sqrt(ec * 0.5 / 0.37)), ("grad", "curl")):
+        assert e.min() > 0
+        assert np.abs(g - e).max() < 1e-8 * e.max(), (name, np.abs(g - e).max(), e.max())

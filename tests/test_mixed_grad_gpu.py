@@ -212,7 +212,7 @@ def test_plane_flux_estimate():
 
     from palace_amd import ceed, linalg
 
-    p = 2
+    p = 1
     geom, ogeom, _, (ndb, ndo), (rtb, rto) = _tri_blocks(p)
     c_id = po.CoeffCtx(dim=2)
     ctx = linalg.Context()
