@@ -188,9 +188,12 @@ class ElementErrorIntegrator:
         return estimates
 
     def __del__(self):
-        if getattr(self, "handle", None):
-            _lib.load().pa_error_op_destroy(self.handle)
-            self.handle = None
+        try:  # (module globals may already be gone at interpreter shutdown)
+            if getattr(self, "handle", None):
+                _lib.load().pa_error_op_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class DenseBlock:
