@@ -264,7 +264,9 @@ int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *res
  * (C grad phi, v), H1 trial and H(curl) test (fem/integ/mixedvecgrad.cpp:43-76; models/modeeigensolver.cpp:52), and with
  * PA_QF_HCURLHDIV_* its H(div)-test form (mixedvecgrad.cpp:50-55).  Plane elements: the _22 QFunctions with 2-D geometry
  * data.  PA_QF_H1_1 with two scalar bases (PA_FE_H1 descriptors, value tables): MassIntegrator between two scalar spaces, the
- * `Flux` operator of the scalar-flux FluxProjector (errorestimator.cpp:122-160).  op: height = test lsize, width = trial lsize.  No transposed, essential-dof, diagonal or assembled form. */
+ * `Flux` operator of the scalar-flux FluxProjector (errorestimator.cpp:122-160).  op: height = test lsize, width = trial lsize.
+ * pa_op_mult_transpose applies the transposed form (test -> trial: the other member of the QFunction pair with the transposed
+ * coefficient; Btn = -Atn^T of models/modeeigensolver.cpp:410-418 without assembling).  No essential-dof, diagonal or assembled form. */
 int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
                               const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
                               const pa_dense_basis_desc *test_basis, int32_t qfunction, const void *ctx, size_t ctx_size);

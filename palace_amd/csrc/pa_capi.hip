@@ -385,8 +385,9 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
   PA_REQUIRE(op && x && y, "null argument");
   PA_REQUIRE(!op->subs.empty() || !op->dsubs.empty() || !op->msubs.empty(), "operator has no sub-operators");
   PA_REQUIRE(x != y, "in-place apply is not supported");
-  PA_REQUIRE(op->msubs.empty() || (!masked && !TransposeScope::active()),
-             "mixed-space sub-operators have no essential-dof or transposed form");
+  PA_REQUIRE(op->msubs.empty() || !masked, "mixed-space sub-operators have no essential-dof form");
+  PA_REQUIRE(op->msubs.empty() || !TransposeScope::active() || (op->subs.empty() && op->dsubs.empty()),
+             "transposed apply of an operator with two-space sub-operators: those only");
   bool first = true;
   const bool split = after && op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->fe_type == PA_FE_HCURL &&
                      op->subs[0]->d_idxc && op->subs[0]->has_blist && overwrite && (!masked || op->subs[0]->d_perm_s_bc);
@@ -423,7 +424,7 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
     first = false;
   }
   for (const MixedSub *ms : op->msubs) {
-    launch_mixed_apply(*ms, x, y, !(overwrite && first), s);
+    launch_mixed_apply(*ms, x, y, !(overwrite && first), s, TransposeScope::active());
     first = false;
   }
 }
@@ -884,7 +885,8 @@ int pa_op_mult(pa_op *op, const double *x, double *y, void *stream) {
  * 199-240; for symmetric coefficients this is the forward apply, like its SymmetricOperator wrapper). */
 int pa_op_mult_transpose(pa_op *op, const double *x, double *y, void *stream) {
   return guarded([&] {
-    PA_REQUIRE(op && op->height == op->width, "transpose apply needs a square operator");
+    // (two-space operators: x has the size of the test space, y of the trial space)
+    PA_REQUIRE(op && (op->height == op->width || (op->subs.empty() && op->dsubs.empty())), "transpose apply needs a square operator");
     TransposeScope t(!op->symmetric());
     apply(op, x, y, true, (hipStream_t)stream);
   });
@@ -892,7 +894,7 @@ int pa_op_mult_transpose(pa_op *op, const double *x, double *y, void *stream) {
 
 int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *stream) {
   return guarded([&] {
-    PA_REQUIRE(op && op->height == op->width, "transpose apply needs a square operator");
+    PA_REQUIRE(op && (op->height == op->width || (op->subs.empty() && op->dsubs.empty())), "transpose apply needs a square operator");
     TransposeScope t(!op->symmetric());
     apply(op, x, y, false, (hipStream_t)stream);
   });

@@ -246,6 +246,7 @@ struct MixedSub {
   MixedSide s1, s2;  // apply: trial, test; error: first and second input
   CoeffHost c0, c1;
   double *d_ye = nullptr;
+  mutable double *d_ye_t = nullptr;  // E-vector of the transposed apply (trial side), allocated at its first use
 };
 
 void parse_coeff(const void *blob, size_t bytes, int dim, CoeffHost &out, size_t slot_offset);
@@ -304,7 +305,7 @@ MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_
                          const pa_restriction_desc &r2, const pa_dense_basis_desc &b2, int qf, const void *ctx,
                          size_t ctx_size);
 void free_mixed_sub(MixedSub *ms);
-void launch_mixed_apply(const MixedSub &ms, const double *x, double *y, bool accumulate, hipStream_t s);
+void launch_mixed_apply(const MixedSub &ms, const double *x, double *y, bool accumulate, hipStream_t s, bool transpose = false);
 void launch_mixed_error(const MixedSub &ms, const double *u1, const double *u2, double *out, hipStream_t s);
 
 }  // namespace pa

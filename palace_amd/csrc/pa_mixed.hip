@@ -267,18 +267,23 @@ void free_side(MixedSide &sd) {
 
 MixSideDev dev_side(const MixedSide &sd) { return MixSideDev{sd.P, sd.nc, sd.d_sidx, sd.d_cor, sd.d_tabF, sd.d_tabT}; }
 
-void launch(const MixedSub &ms, const double *x1, const double *x2, double *out, hipStream_t s) {
+// transpose: A^T = B_1^T W^T B_2 -- the two sides change places, W^T is the other member of the QFunction pair (Jl^T C adj and
+// adj^T C Jl are each other's transposes, adj^T C adj and the scalar mass their own) with the transposed coefficient, which
+// CoeffHost::dev() hands out inside the TransposeScope of pa_op_mult_transpose
+void launch(const MixedSub &ms, const double *x1, const double *x2, double *out, hipStream_t s, bool transpose = false) {
   MixArgs a;
   a.ne = ms.ne, a.Q = ms.Q, a.Qpad = ms.geom->Qpad, a.dim = ms.geom->dim;
   a.stride = (ms.s1.P + ms.s2.P + std::max(ms.s1.P, ms.s2.P) + 3 * ms.Q + 1) & ~1;
   a.geom = ms.geom->d_geom;
-  a.s1 = dev_side(ms.s1), a.s2 = dev_side(ms.s2);
+  a.s1 = dev_side(transpose ? ms.s2 : ms.s1), a.s2 = dev_side(transpose ? ms.s1 : ms.s2);
   a.c0 = ms.c0.dev(), a.c1 = ms.c1.dev();
-  a.x1 = x1, a.x2 = x2, a.ye = ms.d_ye, a.out = out;
+  if (transpose && !ms.d_ye_t) ms.d_ye_t = dev_alloc<double>((size_t)ms.ne * ms.s1.P);
+  a.x1 = x1, a.x2 = x2, a.ye = transpose ? ms.d_ye_t : ms.d_ye, a.out = out;
+  const int kind = !transpose ? ms.kind : (ms.kind == 0 ? 1 : (ms.kind == 1 ? 0 : ms.kind));
   const size_t shm = sizeof(double) * (size_t)a.stride * kMixWaves;
   PA_REQUIRE(shm <= 64 * 1024, "element too large for the mixed-space kernels");
   const dim3 grid((ms.ne + kMixWaves - 1) / kMixWaves), block(64 * kMixWaves);
-  switch (ms.kind) {
+  switch (kind) {
     case 0: hipLaunchKernelGGL(mixed_kernel<0>, grid, block, shm, s, a); break;
     case 1: hipLaunchKernelGGL(mixed_kernel<1>, grid, block, shm, s, a); break;
     case 2: hipLaunchKernelGGL(mixed_kernel<2>, grid, block, shm, s, a); break;
@@ -343,17 +348,18 @@ MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_
 void free_mixed_sub(MixedSub *ms) {
   if (!ms) return;
   free_side(ms->s1), free_side(ms->s2);
-  hipFree(ms->d_ye);
+  hipFree(ms->d_ye), hipFree(ms->d_ye_t);
   hipFree(ms->c0.d_attr_mat), hipFree(ms->c0.d_mat), hipFree(ms->c0.d_mat_t);
   hipFree(ms->c1.d_attr_mat), hipFree(ms->c1.d_mat), hipFree(ms->c1.d_mat_t);
   pa_geom_destroy(static_cast<pa_geom *>(ms->geom));
   delete ms;
 }
 
-void launch_mixed_apply(const MixedSub &ms, const double *x, double *y, bool accumulate, hipStream_t s) {
+void launch_mixed_apply(const MixedSub &ms, const double *x, double *y, bool accumulate, hipStream_t s, bool transpose) {
   PA_REQUIRE(!ms.error, "error integrators have no apply");
-  launch(ms, x, nullptr, nullptr, s);
-  launch_et_gather_raw(ms.s2.lsize, ms.s2.d_tptr, ms.s2.d_tent, ms.d_ye, y, accumulate, s);
+  launch(ms, x, nullptr, nullptr, s, transpose);
+  const MixedSide &out = transpose ? ms.s1 : ms.s2;
+  launch_et_gather_raw(out.lsize, out.d_tptr, out.d_tent, transpose ? ms.d_ye_t : ms.d_ye, y, accumulate, s);
 }
 
 void launch_mixed_error(const MixedSub &ms, const double *u1, const double *u2, double *out, hipStream_t s) {

@@ -116,6 +116,42 @@ def test_mixed_vector_gradient_equals_mass_times_discrete_gradient(kind, p):
     assert float((lhs - rhs).abs().max()) < 1e-11 * float(rhs.abs().max())
 
 
+def _mult_t(op, x, n):
+    import torch
+
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    op.mult_transpose(torch.from_numpy(np.ascontiguousarray(x)).cuda(), y)
+    return y.cpu().numpy()
+
+
+@pytest.mark.parametrize("p", [1, 2])
+@pytest.mark.parametrize("kind", ["tet4", "tet10"])
+def test_two_space_transposes(kind, p):
+    """pa_op_mult_transpose of two-space operators (Btn = -Atn^T of models/modeeigensolver.cpp:410-418 without assembling):
+    against the oracle operator with trial and test exchanged, the paired QFunction and the transposed coefficient, and
+    <A x, y> = <x, A^T y> on the device."""
+    from palace_amd import ceed
+
+    geom, ogeom, (h1b, h1o, hgrad), (ndb, ndo, _), (rtb, rto) = _tet_blocks(kind, p)
+    c_ns, b_ns = util.make_ctx("nonsym", 2)
+    import copy
+
+    c_t = copy.deepcopy(c_ns)
+    c_t.mat = c_ns.mat.reshape(-1, 3, 3).transpose(0, 2, 1).reshape(-1, 9).copy()
+    rng = np.random.default_rng(80 + p)
+    cases = ((ceed.QF_HCURL_33, (h1b, h1o, hgrad), (ndb, ndo, None), po.QF_HCURL),          # Atn and its transpose
+             (ceed.QF_HCURLHDIV_33, (ndb, ndo, None), (rtb, rto, None), po.QF_HDIVHCURL),    # Flux of the Grad estimator
+             (ceed.QF_HDIVHCURL_33, (rtb, rto, None), (ndb, ndo, None), po.QF_HCURLHDIV))
+    for qf, (tb, to, tt), (sb, so, st), qfo_t in cases:
+        op = ceed.Operator(sb.lsize, tb.lsize).add_dense_mixed_integrator(geom, tb, sb, qf, b_ns).finalize()
+        x, y = rng.uniform(-1, 1, tb.lsize), rng.uniform(-1, 1, sb.lsize)
+        ref = po.MixedSpaceOracle(so, to, ogeom, qfo_t, c_t, first_tab=st, second_tab=tt).apply_add(y, np.zeros(tb.lsize))
+        got = _mult_t(op, y, tb.lsize)
+        assert np.abs(got - ref).max() < REL * np.abs(ref).max(), qfo_t
+        lhs, rhs = _mult(op, x, sb.lsize) @ y, x @ got
+        assert abs(lhs - rhs) < 1e-12 * (np.abs(ref).max() * np.abs(x).sum())
+
+
 # ---- plane elements -----------------------------------------------------------------------------------------------------
 
 
