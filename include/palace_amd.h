@@ -374,6 +374,9 @@ int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **csr);
 /* Device pointers (int32 row pointers / column indices, double values); any output may be NULL. */
 int pa_csr_get(const pa_csr *csr, int32_t *nrows, int64_t *nnz, const int32_t **rowptr, const int32_t **colidx,
                const double **values);
+/* Columns of an assembled operator: its row count unless it was assembled from a two-space operator (BilinearForm(trial,
+ * test)::FullAssemble, e.g. Atn of models/modeeigensolver.cpp:45-56: rows = test dofs, columns = trial dofs). */
+int pa_csr_num_cols(const pa_csr *csr);
 void pa_csr_destroy(pa_csr *csr);
 int pa_op_height(const pa_op *op);
 int pa_op_width(const pa_op *op);

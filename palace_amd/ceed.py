@@ -259,6 +259,9 @@ class DeviceCsr:
         n, nnz = C.c_int32(), C.c_int64()
         _lib.check(L.pa_csr_get(self.handle, C.byref(n), C.byref(nnz), None, None, None))
         self.nrows, self.nnz = n.value, nnz.value
+        L.pa_csr_num_cols.restype = C.c_int
+        L.pa_csr_num_cols.argtypes = [C.c_void_p]
+        self.ncols = int(L.pa_csr_num_cols(self.handle))
 
     def __del__(self):
         try:
@@ -419,8 +422,11 @@ class Operator:
         val = view(va, max(1, nnz.value), "<f8", np.float64)[: nnz.value]
         L.pa_csr_destroy.restype = None
         L.pa_csr_destroy.argtypes = [C.c_void_p]
+        L.pa_csr_num_cols.restype = C.c_int
+        L.pa_csr_num_cols.argtypes = [C.c_void_p]
+        ncols = int(L.pa_csr_num_cols(h))  # = rows unless the operator has two spaces
         L.pa_csr_destroy(h)
-        return sp.csr_matrix((val, col, rowptr), shape=(n.value, n.value))
+        return sp.csr_matrix((val, col, rowptr), shape=(n.value, ncols))
 
     def algorithmic_bytes(self):
         return _lib.load().pa_op_algorithmic_bytes(self.handle)

@@ -59,7 +59,8 @@ __global__ void k_csr_diag(const int n, const int32_t *__restrict__ rowptr, cons
 
 }  // namespace
 
-CsrOperator::CsrOperator(const Context &ctx, const pa_csr *m) : Operator(m->nrows, m->nrows), ctx_(&ctx), m_(m) {
+CsrOperator::CsrOperator(const Context &ctx, const pa_csr *m)
+    : Operator(m->nrows, m->ncols ? m->ncols : m->nrows), ctx_(&ctx), m_(m) {
   const double avg = m->nrows ? (double)m->nnz / m->nrows : 0.0;
   lanes_ = avg > 24.0 ? 16 : (avg > 12.0 ? 8 : 4);
 }

@@ -57,6 +57,109 @@ struct AssembleGuard {
       if (q == p) q = nullptr;
   }
 };
+
+// Two-space operators (BilinearForm(trial, test)::FullAssemble, e.g. Atn of models/modeeigensolver.cpp:45-56): rows are test
+// dofs, columns trial dofs.  Same probing as below; two columns may share a colour when no row holds both, which takes the
+// transposed pattern (column -> rows) next to the pattern itself.
+void assemble_two_space(pa_op *op, bool skip_zeros, hipStream_t s, pa_csr **out) {
+  const int nr = op->height, nc = op->width;
+  std::vector<int64_t> cnt((size_t)nr + 1, 0);
+  for (const MixedSub *ms : op->msubs) {
+    PA_REQUIRE(!ms->error && (int)ms->s1.h_off.size() == ms->ne * ms->s1.P && (int)ms->s2.h_off.size() == ms->ne * ms->s2.P,
+               "sub-operator has no assembled form");
+    for (int32_t r : ms->s2.h_off) cnt[(size_t)r + 1] += ms->s1.P;
+  }
+  for (int r = 0; r < nr; r++) cnt[r + 1] += cnt[r];
+  PA_REQUIRE(cnt[nr] < (int64_t)1 << 31, "operator too large for full assembly (int32 CSR)");
+  std::vector<int32_t> cols((size_t)cnt[nr]);
+  {
+    std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+    for (const MixedSub *ms : op->msubs)
+      for (int e = 0; e < ms->ne; e++) {
+        const int32_t *re = &ms->s2.h_off[(size_t)e * ms->s2.P], *ce = &ms->s1.h_off[(size_t)e * ms->s1.P];
+        for (int i = 0; i < ms->s2.P; i++) {
+          int64_t &f = fill[re[i]];
+          for (int j = 0; j < ms->s1.P; j++) cols[(size_t)f++] = ce[j];
+        }
+      }
+  }
+  std::vector<int32_t> rowptr((size_t)nr + 1, 0), col;
+  for (int r = 0; r < nr; r++) {
+    auto b = cols.begin() + cnt[r], e = cols.begin() + cnt[r + 1];
+    std::sort(b, e);
+    e = std::unique(b, e);
+    col.insert(col.end(), b, e);
+    rowptr[r + 1] = (int32_t)col.size();
+  }
+  cols.clear();
+  cols.shrink_to_fit();
+  const int64_t nnz = (int64_t)col.size();
+  // transposed pattern
+  std::vector<int32_t> cptr((size_t)nc + 1, 0), rows_of_col((size_t)nnz), row_of((size_t)nnz);
+  for (int64_t k = 0; k < nnz; k++) cptr[(size_t)col[k] + 1]++;
+  for (int d = 0; d < nc; d++) cptr[d + 1] += cptr[d];
+  {
+    std::vector<int32_t> fill(cptr.begin(), cptr.end() - 1);
+    for (int r = 0; r < nr; r++)
+      for (int32_t a = rowptr[r]; a < rowptr[r + 1]; a++) rows_of_col[fill[col[a]]++] = r, row_of[a] = r;
+  }
+  // greedy colouring of the columns: d conflicts with every column of every row it appears in
+  std::vector<int32_t> color((size_t)nc, -1), mark;
+  int ncolors = 0;
+  for (int d = 0; d < nc; d++) {
+    if ((int)mark.size() < ncolors + 1) mark.resize(ncolors + 1, -1);
+    for (int32_t a = cptr[d]; a < cptr[d + 1]; a++) {
+      const int r = rows_of_col[a];
+      for (int32_t b2 = rowptr[r]; b2 < rowptr[r + 1]; b2++) {
+        const int cc = color[col[b2]];
+        if (cc >= 0) mark[cc] = d;
+      }
+    }
+    int c = 0;
+    while (c < ncolors && mark[c] == d) c++;
+    if (c == ncolors) ncolors++, mark.push_back(-1);
+    color[d] = c;
+  }
+  AssembleGuard guard;
+  auto *m = guard.m = new pa_csr;
+  m->nrows = nr, m->ncols = nc;
+  m->symmetric = false;
+  int32_t *d_color = guard.keep(dev_upload(color.data(), color.size(), s)), *d_row_of = guard.keep(dev_upload(row_of.data(), row_of.size(), s));
+  int32_t *d_col = guard.keep(dev_upload(col.data(), col.size(), s));
+  double *d_val = guard.keep(dev_alloc<double>((size_t)std::max<int64_t>(nnz, 1))), *d_x = guard.keep(dev_alloc<double>((size_t)nc)),
+         *d_y = guard.keep(dev_alloc<double>((size_t)nr));
+  PA_HIP(hipMemsetAsync(d_val, 0, sizeof(double) * (size_t)nnz, s));
+  for (int c = 0; c < ncolors; c++) {
+    hipLaunchKernelGGL(k_probe_vector, dim3((nc + 255) / 256), dim3(256), 0, s, nc, d_color, c, d_x);
+    apply_for_assembly(op, d_x, d_y, s);
+    hipLaunchKernelGGL(k_extract, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, (long long)nnz, d_row_of, d_col, d_color, c,
+                       d_y, d_val);
+  }
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(s));
+  if (skip_zeros) {  // operator.cpp:262-313: drop the entries that are exactly zero
+    std::vector<double> val((size_t)nnz);
+    PA_HIP(hipMemcpy(val.data(), d_val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
+    std::vector<int32_t> rp((size_t)nr + 1, 0), cl;
+    std::vector<double> vl;
+    for (int r = 0; r < nr; r++) {
+      for (int32_t a = rowptr[r]; a < rowptr[r + 1]; a++)
+        if (val[a] != 0.0) cl.push_back(col[a]), vl.push_back(val[a]);
+      rp[r + 1] = (int32_t)cl.size();
+    }
+    m->nnz = (int64_t)cl.size();
+    m->d_rowptr = dev_upload(rp.data(), rp.size(), s);
+    m->d_col = cl.empty() ? nullptr : dev_upload(cl.data(), cl.size(), s);
+    m->d_val = vl.empty() ? nullptr : dev_upload(vl.data(), vl.size(), s);
+  } else {
+    m->nnz = nnz;
+    m->d_rowptr = dev_upload(rowptr.data(), rowptr.size(), s);
+    m->d_col = d_col, m->d_val = d_val;
+    guard.release(d_col), guard.release(d_val);
+  }
+  guard.m = nullptr;
+  *out = m;
+}
 }  // namespace
 
 extern "C" {
@@ -64,8 +167,14 @@ extern "C" {
 int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
   return guarded([&] {
     PA_REQUIRE(op && out, "null argument");
-    PA_REQUIRE(op->finalized && op->height == op->width, "full assembly needs a finalized square operator");
+    PA_REQUIRE(op->finalized, "full assembly needs a finalized operator");
     hipStream_t s = (hipStream_t)stream;
+    if (!op->msubs.empty()) {  // two-space operator: rectangular
+      PA_REQUIRE(op->subs.empty() && op->dsubs.empty(), "two-space sub-operators are assembled on their own");
+      assemble_two_space(op, skip_zeros != 0, s, out);
+      return;
+    }
+    PA_REQUIRE(op->height == op->width, "full assembly needs a square operator");
     const int n = op->height;
     // ---- pattern: union of the element connectivities
     struct Conn {
@@ -73,7 +182,6 @@ int pa_op_full_assemble(pa_op *op, int skip_zeros, void *stream, pa_csr **out) {
       std::vector<int32_t> off;
     };
     std::vector<Conn> conns;
-    PA_REQUIRE(op->msubs.empty(), "mixed-space operators are not assembled");
     for (const SubOp *so : op->subs) {
       Conn c{so->ne, so->P, {}};
       c.off.resize(so->h_sidx.size());
@@ -178,13 +286,15 @@ int pa_csr_get(const pa_csr *m, int32_t *nrows, int64_t *nnz, const int32_t **ro
                const double **values) {
   return guarded([&] {
     PA_REQUIRE(m, "null argument");
-    if (nrows) *nrows = m->nrows;
+    if (nrows) *nrows = m->nrows;  // (columns: pa_csr_num_cols)
     if (nnz) *nnz = m->nnz;
     if (rowptr) *rowptr = m->d_rowptr;
     if (colidx) *colidx = m->d_col;
     if (values) *values = m->d_val;
   });
 }
+
+int pa_csr_num_cols(const pa_csr *m) { return m ? (m->ncols ? m->ncols : m->nrows) : -1; }
 
 void pa_csr_destroy(pa_csr *m) {
   if (!m) return;

@@ -19,6 +19,7 @@ typedef struct pa_op pa_op_fwd;
 struct pa_csr {
   bool symmetric = true;  // assembled from a symmetric operator (CsrOperator::MultTranspose relies on it)
   int32_t nrows = 0;
+  int32_t ncols = 0;  // 0: square
   int64_t nnz = 0;
   int32_t *d_rowptr = nullptr, *d_col = nullptr;
   double *d_val = nullptr;
@@ -234,6 +235,7 @@ struct DenseSub {
 // pa_mixed.hip: one space of a mixed-space operator (plain [ne][P] layouts) and the operator / error integrator itself
 struct MixedSide {
   int fe_type = 0, P = 0, lsize = 0, nc = 3;
+  std::vector<int32_t> h_off;  // [ne][P] L-vector indices (full assembly)
   int32_t *d_sidx = nullptr;
   int8_t *d_cor = nullptr;
   double *d_tabF = nullptr, *d_tabT = nullptr;

@@ -241,6 +241,7 @@ void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int 
     sidx[k] = (r.orients && r.orients[k]) ? -1 - off : off;
   }
   sd.d_sidx = dev_upload(sidx.data(), sidx.size());
+  sd.h_off.assign(r.offsets, r.offsets + (size_t)ne * P);
   if (r.curl_orients) sd.d_cor = dev_upload(r.curl_orients, (size_t)3 * ne * P);
   std::vector<double> F((size_t)nc * P * Q);
   for (int c = 0; c < nc; c++)

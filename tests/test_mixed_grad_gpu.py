@@ -152,6 +152,30 @@ def test_two_space_transposes(kind, p):
         assert abs(lhs - rhs) < 1e-12 * (np.abs(ref).max() * np.abs(x).sum())
 
 
+@pytest.mark.parametrize("p", [1, 2])
+def test_two_space_full_assembly(p):
+    """BilinearForm(h1, nd)::FullAssemble of Atn (models/modeeigensolver.cpp:45-56): the rectangular CSR matrix of a two-space
+    operator by coloured probing -- every entry is what the apply produces; against the apply, its transpose and the oracle."""
+    from palace_amd import ceed
+
+    geom, ogeom, (h1b, h1o, hgrad), (ndb, ndo, _), (rtb, rto) = _tet_blocks("tet10", p)
+    c_ns, b_ns = util.make_ctx("nonsym", 2)
+    rng = np.random.default_rng(90 + p)
+    for qf, qfo, (tb, to, tt), (sb, so) in ((ceed.QF_HCURL_33, po.QF_HCURL, (h1b, h1o, hgrad), (ndb, ndo)),
+                                            (ceed.QF_HCURLHDIV_33, po.QF_HCURLHDIV, (ndb, ndo, None), (rtb, rto))):
+        op = ceed.Operator(sb.lsize, tb.lsize).add_dense_mixed_integrator(geom, tb, sb, qf, b_ns).finalize()
+        A = op.full_assemble()
+        assert A.shape == (sb.lsize, tb.lsize)
+        x, y = rng.uniform(-1, 1, tb.lsize), rng.uniform(-1, 1, sb.lsize)
+        ref = po.MixedSpaceOracle(to, so, ogeom, qfo, c_ns, first_tab=tt).apply_add(x, np.zeros(sb.lsize))
+        assert np.abs(A @ x - ref).max() < REL * np.abs(ref).max()
+        assert np.abs(A @ x - _mult(op, x, sb.lsize)).max() < 1e-13 * np.abs(ref).max()
+        aty = _mult_t(op, y, tb.lsize)
+        assert np.abs(A.T @ y - aty).max() < 1e-12 * np.abs(aty).max()
+        As = op.full_assemble(skip_zeros=True)
+        assert As.nnz <= A.nnz and abs(As - A).max() == 0.0
+
+
 # ---- plane elements -----------------------------------------------------------------------------------------------------
 
 
