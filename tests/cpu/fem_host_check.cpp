@@ -75,6 +75,16 @@ int main() {
     const double R[9] = {3.0, 1.0, 0, 1.0, 3.0, 0, 0, 0, 2.0};  // eigenvalues 2, 2, 4
     const auto rr = linalg::MatrixPow(R, 2.0);
     dump("mat_square", std::vector<double>(rr.begin(), rr.end()));
+    // MaterialTensors of a plane problem: 2 x 2 permittivities and the 1 x 1 curl-curl inverse permeability
+    // (errorestimator.cpp:331-336, :452-459); the matrix functions see them bordered with an identity block
+    const MaterialTensors eps2{{0, 1}, {2.0, 0.3, 0.3, 1.5, 3.1, 0.0, 0.0, 3.1}, 2};
+    const auto s2 = eps2.Map([](const double *m) { return linalg::MatrixSqrt(m); });
+    const auto i2 = eps2.Map([](const double *m) { return linalg::MatrixPow(m, -0.5); });
+    dump("mat2_sqrt", s2.mat);
+    dump("mat2_invsqrt", i2.mat);
+    const MaterialTensors mu1{{0, 1}, {0.8, 1.4}, 1};
+    dump("mat1_sqrt", mu1.Map([](const double *m) { return linalg::MatrixSqrt(m); }).mat);
+    std::printf("mat_dims %d %d\n", s2.dim, (int)s2.mat.size());
   }
   return 0;
 }

@@ -31,7 +31,7 @@ def dumped(tmp_path_factory):
     vals = {}
     for line in out.stdout.splitlines():
         k, *v = line.split()
-        if k.startswith("orders") or k == "q1d":
+        if k.startswith("orders") or k in ("q1d", "mat_dims"):
             vals[k] = [int(t) for t in v]
         else:
             vals[k] = np.array([struct.unpack("<d", struct.pack("<Q", int(t, 16)))[0] for t in v])
@@ -96,3 +96,13 @@ def test_matrix_functions(dumped):
     assert np.allclose(dumped["mat_sqrt_diag"].reshape(3, 3), np.diag([2.0, 3.0, 0.5]), rtol=0, atol=1e-15)
     R = np.array([[3.0, 1.0, 0], [1.0, 3.0, 0], [0, 0, 2.0]])
     assert np.allclose(dumped["mat_square"].reshape(3, 3), R @ R, rtol=0, atol=1e-13)
+    # plane problems: 2 x 2 and 1 x 1 MaterialTensors (the matrix functions act on the tensor bordered with an identity block)
+    E2 = np.array([[2.0, 0.3], [0.3, 1.5]])
+    w, V = np.linalg.eigh(E2)
+    got = dumped["mat2_sqrt"].reshape(2, 2, 2)
+    assert np.allclose(got[0], (V * np.sqrt(w)) @ V.T, rtol=0, atol=1e-14)
+    assert np.allclose(got[1], np.sqrt(3.1) * np.eye(2), rtol=0, atol=1e-14)
+    inv = dumped["mat2_invsqrt"].reshape(2, 2, 2)
+    assert np.allclose(inv[0] @ got[0], np.eye(2), rtol=0, atol=1e-14)
+    assert np.allclose(dumped["mat1_sqrt"], np.sqrt([0.8, 1.4]), rtol=0, atol=1e-15)
+    assert dumped["mat_dims"][:2] == [2, 8]
