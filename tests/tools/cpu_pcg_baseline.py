@@ -1,7 +1,8 @@
 """CPU baseline for M2 ("the restated PCG + GMG on CPU"): PCG on K + M with the p-multigrid V-cycle
 (levels p = 1, 2, 3; 4th-kind Chebyshev order 6) entirely through the oracle -- local applies by oracle/oracle_c.c
 (dense tables, OpenMP), everything else numpy -- on a cylinder of about DOFS unknowns.  Prints one JSON line.
-CPU only: python scripts/cpu_pcg_baseline.py [DOFS] [ITERS]"""
+CPU only: python tests/tools/cpu_pcg_baseline.py [DOFS] [ITERS]
+Lives under tests/: it runs the oracle (test infrastructure), which nothing outside tests/, smoke() and the cpu_baseline leg of bench.py may do."""
 import json
 import os
 import sys
