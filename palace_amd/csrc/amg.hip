@@ -1,0 +1,179 @@
+// Smoothed-aggregation set-up on the host (see amg.hpp).  No device code in this file.
+#include "amg.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "pa_internal.hpp"
+
+namespace palace::amg {
+
+HostCsr Transpose(const HostCsr &A) {
+  HostCsr T;
+  T.nrows = A.ncols, T.ncols = A.nrows;
+  T.rowptr.assign((size_t)T.nrows + 1, 0);
+  for (int c : A.col) T.rowptr[(size_t)c + 1]++;
+  for (int r = 0; r < T.nrows; r++) T.rowptr[r + 1] += T.rowptr[r];
+  T.col.resize(A.col.size()), T.val.resize(A.val.size());
+  std::vector<int> fill(T.rowptr.begin(), T.rowptr.end() - 1);
+  for (int r = 0; r < A.nrows; r++)  // rows visited in order: the columns of T come out sorted
+    for (int a = A.rowptr[r]; a < A.rowptr[r + 1]; a++) {
+      const int k = fill[A.col[a]]++;
+      T.col[k] = r, T.val[k] = A.val[a];
+    }
+  return T;
+}
+
+HostCsr Multiply(const HostCsr &A, const HostCsr &B) {
+  PA_REQUIRE(A.ncols == B.nrows, "dimension mismatch in the sparse product");
+  HostCsr C;
+  C.nrows = A.nrows, C.ncols = B.ncols;
+  C.rowptr.assign((size_t)C.nrows + 1, 0);
+  std::vector<double> acc((size_t)B.ncols, 0.0);
+  std::vector<int> mark((size_t)B.ncols, -1), cols;
+  for (int r = 0; r < A.nrows; r++) {
+    cols.clear();
+    for (int a = A.rowptr[r]; a < A.rowptr[r + 1]; a++) {
+      const int k = A.col[a];
+      const double v = A.val[a];
+      for (int b = B.rowptr[k]; b < B.rowptr[k + 1]; b++) {
+        const int c = B.col[b];
+        if (mark[c] != r) mark[c] = r, acc[c] = 0.0, cols.push_back(c);
+        acc[c] += v * B.val[b];
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols)
+      if (acc[c] != 0.0) C.col.push_back(c), C.val.push_back(acc[c]);
+    C.rowptr[r + 1] = (int)C.col.size();
+  }
+  return C;
+}
+
+void Mult(const HostCsr &A, const std::vector<double> &x, std::vector<double> &y) {
+  y.assign((size_t)A.nrows, 0.0);
+  for (int r = 0; r < A.nrows; r++) {
+    double s = 0.0;
+    for (int a = A.rowptr[r]; a < A.rowptr[r + 1]; a++) s += A.val[a] * x[A.col[a]];
+    y[r] = s;
+  }
+}
+
+namespace {
+std::vector<double> diagonal(const HostCsr &A) {
+  std::vector<double> d((size_t)A.nrows, 0.0);
+  for (int r = 0; r < A.nrows; r++)
+    for (int a = A.rowptr[r]; a < A.rowptr[r + 1]; a++)
+      if (A.col[a] == r) d[r] = A.val[a];
+  return d;
+}
+inline bool strong(double aij, double dii, double djj, double theta) {
+  return aij * aij >= theta * theta * std::abs(dii * djj);
+}
+}  // namespace
+
+std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) {
+  PA_REQUIRE(A.nrows == A.ncols, "aggregation needs a square matrix");
+  const int n = A.nrows;
+  const std::vector<double> d = diagonal(A);
+  std::vector<int> agg((size_t)n, -1);
+  int na = 0;
+  // pass 1: a node whose strong neighbours are all free founds an aggregate with them
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    bool free_nbrs = true, any = false;
+    for (int a = A.rowptr[i]; a < A.rowptr[i + 1] && free_nbrs; a++) {
+      const int j = A.col[a];
+      if (j == i || !strong(A.val[a], d[i], d[j], theta)) continue;
+      any = true;
+      if (agg[j] >= 0) free_nbrs = false;
+    }
+    if (!free_nbrs || !any) continue;
+    agg[i] = na;
+    for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
+      const int j = A.col[a];
+      if (j != i && strong(A.val[a], d[i], d[j], theta)) agg[j] = na;
+    }
+    na++;
+  }
+  // pass 2: the rest joins the aggregate (as formed in pass 1) it is most strongly tied to
+  const std::vector<int> pass1(agg);
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    double best = 0.0;
+    int to = -1;
+    for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
+      const int j = A.col[a];
+      if (j == i || pass1[j] < 0 || !strong(A.val[a], d[i], d[j], theta)) continue;
+      if (std::abs(A.val[a]) > best) best = std::abs(A.val[a]), to = pass1[j];
+    }
+    if (to >= 0) agg[i] = to;
+  }
+  // pass 3: what is still free (no strong tie to any aggregate) forms aggregates with its free strong neighbours
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    agg[i] = na;
+    for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
+      const int j = A.col[a];
+      if (j != i && agg[j] < 0 && strong(A.val[a], d[i], d[j], theta)) agg[j] = na;
+    }
+    na++;
+  }
+  num_aggregates = na;
+  return agg;
+}
+
+HostCsr TentativeProlongator(const std::vector<int> &aggregate, int num_aggregates) {
+  HostCsr T;
+  T.nrows = (int)aggregate.size(), T.ncols = num_aggregates;
+  std::vector<int> size((size_t)num_aggregates, 0);
+  for (int a : aggregate) size[a]++;
+  T.rowptr.resize((size_t)T.nrows + 1);
+  std::iota(T.rowptr.begin(), T.rowptr.end(), 0);
+  T.col = aggregate;
+  T.val.resize(aggregate.size());
+  for (size_t i = 0; i < aggregate.size(); i++) T.val[i] = 1.0 / std::sqrt((double)size[aggregate[i]]);
+  return T;
+}
+
+HostCsr SmoothProlongator(const HostCsr &A, const HostCsr &T, double theta, double omega) {
+  // filtered matrix: weak off-diagonal entries are dropped and added to the diagonal (row sums kept)
+  const std::vector<double> d = diagonal(A);
+  HostCsr S;  // S = I - omega D_F^-1 A_F
+  S.nrows = S.ncols = A.nrows;
+  S.rowptr.assign((size_t)A.nrows + 1, 0);
+  for (int i = 0; i < A.nrows; i++) {
+    double dii = d[i];
+    for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++)
+      if (A.col[a] != i && !strong(A.val[a], d[i], d[A.col[a]], theta)) dii += A.val[a];
+    PA_REQUIRE(dii != 0.0, "zero diagonal in the prolongator smoother");
+    for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
+      const int j = A.col[a];
+      if (j == i)
+        S.col.push_back(j), S.val.push_back(1.0 - omega);
+      else if (strong(A.val[a], d[i], d[j], theta))
+        S.col.push_back(j), S.val.push_back(-omega * A.val[a] / dii);
+    }
+    S.rowptr[i + 1] = (int)S.col.size();
+  }
+  return Multiply(S, T);
+}
+
+Hierarchy Setup(const HostCsr &A0, int max_levels, int coarse_size, double theta, double omega) {
+  Hierarchy h;
+  h.A.push_back(A0);
+  while ((int)h.A.size() < max_levels && h.A.back().nrows > coarse_size) {
+    const HostCsr &A = h.A.back();
+    int na = 0;
+    const std::vector<int> agg = Aggregate(A, theta, na);
+    if (na == 0 || na >= A.nrows) break;  // no coarsening left
+    HostCsr P = SmoothProlongator(A, TentativeProlongator(agg, na), theta, omega);
+    HostCsr Ac = Multiply(Transpose(P), Multiply(A, P));
+    h.P.push_back(std::move(P));
+    h.A.push_back(std::move(Ac));
+  }
+  return h;
+}
+
+}  // namespace palace::amg

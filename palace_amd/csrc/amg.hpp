@@ -1,0 +1,45 @@
+// Host-side set-up of a smoothed-aggregation hierarchy for an assembled (CSR) coarse-level matrix.
+//
+// The reference hands its coarsest p-multigrid level to HYPRE (BoomerAMG for H1 problems, AMS for H(curl) ones:
+// linalg/amg.cpp:12-49, linalg/ams.cpp:18-224) -- third-party code that is not part of /root/reference.  This is the
+// set-up half of the native replacement SURVEY.md 8 f3 asks for: strength graph, greedy aggregation, tentative and
+// Jacobi-smoothed prolongators, Galerkin products.  It runs once per operator on the host, on the matrix
+// pa_op_full_assemble produces (p = 1 levels: a few 10^5 rows); the solve half is the existing device machinery
+// (CsrOperator as A_l and P_l, Chebyshev / Jacobi smoothers, GeometricMultigridSolver's V-cycle), wired up in the next round
+// once it can be measured.  Checked on the CPU by tests/test_fem_host.py (tests/cpu/fem_host_check.cpp).
+#pragma once
+
+#include <vector>
+
+namespace palace::amg {
+
+struct HostCsr {
+  int nrows = 0, ncols = 0;
+  std::vector<int> rowptr, col;  // columns sorted within a row
+  std::vector<double> val;
+  long long nnz() const { return (long long)col.size(); }
+};
+
+HostCsr Transpose(const HostCsr &A);
+HostCsr Multiply(const HostCsr &A, const HostCsr &B);  // C = A B, exact zeros kept out
+void Mult(const HostCsr &A, const std::vector<double> &x, std::vector<double> &y);
+
+// Standard aggregation on the strength graph |a_ij| >= theta sqrt(a_ii a_jj): pass 1 forms an aggregate from every node
+// whose strong neighbourhood is still free, pass 2 attaches the remaining nodes to the neighbouring aggregate they are
+// most strongly tied to (isolated nodes become their own aggregates).  Returns the aggregate of each row.
+std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates);
+
+// Piecewise-constant prolongator with normalised columns: T^T T = I
+HostCsr TentativeProlongator(const std::vector<int> &aggregate, int num_aggregates);
+
+// P = (I - omega D^-1 A_F) T with the filtered matrix A_F (weak off-diagonal entries lumped onto the diagonal)
+HostCsr SmoothProlongator(const HostCsr &A, const HostCsr &T, double theta, double omega);
+
+struct Hierarchy {
+  std::vector<HostCsr> A;  // A[0] the input, A[l+1] = P[l]^T A[l] P[l]
+  std::vector<HostCsr> P;  // P[l]: level l+1 -> level l
+};
+// Levels are added until a level has at most `coarse_size` rows, stops coarsening, or `max_levels` is reached
+Hierarchy Setup(const HostCsr &A, int max_levels = 10, int coarse_size = 200, double theta = 0.08, double omega = 2.0 / 3.0);
+
+}  // namespace palace::amg

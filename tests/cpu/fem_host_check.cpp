@@ -2,9 +2,11 @@
 // compares them with the numpy restatements the rest of the test-suite is built on: 1-D point sets and Lagrange tables,
 // MaterialPropertyCoefficient bookkeeping (materialoperator.cpp:586-868) and the QFunction coefficient contexts
 // (coefficient.cpp:51-131), the p-coarsening sequences (multigrid.hpp:44-69).  No device is touched.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
+#include "amg.hpp"
 #include "errorestimator.hpp"
 #include "ksp.hpp"
 
@@ -19,6 +21,71 @@ static void dump(const char *name, const std::vector<double> &v) {
   }
   std::printf("\n");
 }
+
+namespace {
+// 5-point operator -ex u_xx - ey u_yy on an n x n grid, homogeneous Dirichlet data
+palace::amg::HostCsr grid_laplacian(int n, double ex, double ey) {
+  palace::amg::HostCsr A;
+  A.nrows = A.ncols = n * n;
+  A.rowptr.push_back(0);
+  for (int j = 0; j < n; j++)
+    for (int i = 0; i < n; i++) {
+      auto put = [&](int ii, int jj, double v) {
+        if (ii >= 0 && ii < n && jj >= 0 && jj < n) A.col.push_back(jj * n + ii), A.val.push_back(v);
+      };
+      put(i, j - 1, -ey), put(i - 1, j, -ex), put(i, j, 2 * ex + 2 * ey), put(i + 1, j, -ex), put(i, j + 1, -ey);
+      A.rowptr.push_back((int)A.col.size());
+    }
+  return A;
+}
+std::vector<double> dense_of(const palace::amg::HostCsr &A) {
+  std::vector<double> d((size_t)A.nrows * A.ncols, 0.0);
+  for (int r = 0; r < A.nrows; r++)
+    for (int a = A.rowptr[r]; a < A.rowptr[r + 1]; a++) d[(size_t)r * A.ncols + A.col[a]] = A.val[a];
+  return d;
+}
+// one V-cycle of the hierarchy: nu weighted-Jacobi sweeps before and after, dense elimination on the last level
+void vcycle(const palace::amg::Hierarchy &h, size_t l, const std::vector<double> &b, std::vector<double> &x) {
+  const auto &A = h.A[l];
+  const int n = A.nrows;
+  if (l + 1 == h.A.size()) {
+    std::vector<double> M = dense_of(A), r = b;
+    for (int k = 0; k < n; k++)
+      for (int i = k + 1; i < n; i++) {
+        const double f = M[(size_t)i * n + k] / M[(size_t)k * n + k];
+        for (int j = k; j < n; j++) M[(size_t)i * n + j] -= f * M[(size_t)k * n + j];
+        r[i] -= f * r[k];
+      }
+    x.assign(n, 0.0);
+    for (int i = n - 1; i >= 0; i--) {
+      double s = r[i];
+      for (int j = i + 1; j < n; j++) s -= M[(size_t)i * n + j] * x[j];
+      x[i] = s / M[(size_t)i * n + i];
+    }
+    return;
+  }
+  std::vector<double> d(n), t;
+  for (int r = 0; r < n; r++)
+    for (int a = A.rowptr[r]; a < A.rowptr[r + 1]; a++)
+      if (A.col[a] == r) d[r] = A.val[a];
+  auto smooth = [&]() {
+    for (int it = 0; it < 2; it++) {
+      palace::amg::Mult(A, x, t);
+      for (int i = 0; i < n; i++) x[i] += (2.0 / 3.0) * (b[i] - t[i]) / d[i];
+    }
+  };
+  smooth();
+  palace::amg::Mult(A, x, t);
+  std::vector<double> res(n), rc, ec, corr;
+  for (int i = 0; i < n; i++) res[i] = b[i] - t[i];
+  palace::amg::Mult(palace::amg::Transpose(h.P[l]), res, rc);
+  ec.assign(rc.size(), 0.0);
+  vcycle(h, l + 1, rc, ec);
+  palace::amg::Mult(h.P[l], ec, corr);
+  for (int i = 0; i < n; i++) x[i] += corr[i];
+  smooth();
+}
+}  // namespace
 
 int main() {
   for (int n = 1; n <= 6; n++) {
@@ -85,6 +152,44 @@ int main() {
     const MaterialTensors mu1{{0, 1}, {0.8, 1.4}, 1};
     dump("mat1_sqrt", mu1.Map([](const double *m) { return linalg::MatrixSqrt(m); }).mat);
     std::printf("mat_dims %d %d\n", s2.dim, (int)s2.mat.size());
+  }
+  {  // smoothed-aggregation set-up (amg.hpp): small problem dumped densely, larger ones through their V-cycle convergence
+    using namespace palace::amg;
+    const HostCsr A = grid_laplacian(10, 1.0, 1.0);
+    int na = 0;
+    const auto agg = Aggregate(A, 0.08, na);
+    const HostCsr T = TentativeProlongator(agg, na);
+    const Hierarchy h = Setup(A, 2, 10);
+    std::printf("amg_small %d %d %d\n", na, (int)h.A.size(), h.A.back().nrows);
+    dump("amg_T", dense_of(T));
+    dump("amg_P", dense_of(h.P.at(0)));
+    dump("amg_A1", dense_of(h.A.at(1)));
+    for (int cas = 0; cas < 2; cas++) {
+      const HostCsr B = grid_laplacian(48, 1.0, cas == 0 ? 1.0 : 0.01);  // isotropic, then strongly anisotropic
+      const Hierarchy hb = Setup(B, 10, 60);
+      std::printf("amg_levels%d", cas);
+      for (const auto &L : hb.A) std::printf(" %d", L.nrows);
+      std::printf("\n");
+      std::vector<double> b(B.nrows), x(B.nrows, 0.0), t, fac;
+      for (int i = 0; i < B.nrows; i++) b[i] = std::sin(0.37 * i) + 0.5;
+      double prev = 0.0;
+      for (double v : b) prev += v * v;
+      prev = std::sqrt(prev);
+      for (int it = 0; it < 12; it++) {
+        std::vector<double> r(B.nrows), e(B.nrows, 0.0);
+        Mult(B, x, t);
+        for (int i = 0; i < B.nrows; i++) r[i] = b[i] - t[i];
+        vcycle(hb, 0, r, e);
+        for (int i = 0; i < B.nrows; i++) x[i] += e[i];
+        Mult(B, x, t);
+        double nr = 0.0;
+        for (int i = 0; i < B.nrows; i++) nr += (b[i] - t[i]) * (b[i] - t[i]);
+        nr = std::sqrt(nr);
+        fac.push_back(nr / prev);
+        prev = nr;
+      }
+      dump(cas == 0 ? "amg_factors_iso" : "amg_factors_aniso", fac);
+    }
   }
   return 0;
 }

@@ -31,7 +31,7 @@ def dumped(tmp_path_factory):
     vals = {}
     for line in out.stdout.splitlines():
         k, *v = line.split()
-        if k.startswith("orders") or k in ("q1d", "mat_dims"):
+        if k.startswith("orders") or k.startswith("amg_levels") or k in ("q1d", "mat_dims", "amg_small"):
             vals[k] = [int(t) for t in v]
         else:
             vals[k] = np.array([struct.unpack("<d", struct.pack("<Q", int(t, 16)))[0] for t in v])
@@ -106,3 +106,32 @@ def test_matrix_functions(dumped):
     assert np.allclose(inv[0] @ got[0], np.eye(2), rtol=0, atol=1e-14)
     assert np.allclose(dumped["mat1_sqrt"], np.sqrt([0.8, 1.4]), rtol=0, atol=1e-15)
     assert dumped["mat_dims"][:2] == [2, 8]
+
+
+def test_smoothed_aggregation_setup(dumped):
+    """The host set-up of the native coarse-level hierarchy (palace_amd/csrc/amg.hpp; stands where the reference calls HYPRE,
+    linalg/amg.cpp:12-49): aggregates cover every node once, the tentative prolongator has orthonormal columns, the smoothed one
+    keeps constants away from the boundary, the coarse matrix is the Galerkin product, and V-cycles with two Jacobi sweeps
+    converge at a grid-independent rate -- also for a strongly anisotropic operator, where the strength filter matters."""
+    na, nlev, ncoarse = dumped["amg_small"]
+    n = 100
+    T = dumped["amg_T"].reshape(n, na)
+    assert np.all((T != 0).sum(axis=1) == 1) and np.allclose(T.T @ T, np.eye(na), atol=1e-14)
+    assert 3 <= na <= n // 4 and nlev == 2 and ncoarse == na
+    P = dumped["amg_P"].reshape(n, na)
+    A1 = dumped["amg_A1"].reshape(na, na)
+    g = np.arange(10)
+    L1 = 2 * np.eye(10) - np.diag(np.ones(9), 1) - np.diag(np.ones(9), -1)
+    A0 = np.kron(np.eye(10), L1) + np.kron(L1, np.eye(10))
+    assert np.abs(A1 - P.T @ A0 @ P).max() < 1e-13
+    assert np.abs(A1 - A1.T).max() < 1e-14 and np.linalg.eigvalsh(A1).min() > 0
+    # interior rows: the smoothed prolongator reproduces the (scaled) constant that the tentative one reproduces
+    interior = np.array([j * 10 + i for j in range(2, 8) for i in range(2, 8)])
+    w = np.linalg.lstsq(T, np.ones(n), rcond=None)[0]
+    assert np.abs((P @ w)[interior] - 1.0).max() < 1e-12
+    for key, lev in (("amg_factors_iso", "amg_levels0"), ("amg_factors_aniso", "amg_levels1")):
+        sizes = dumped[lev]
+        assert sizes[0] == 48 * 48 and len(sizes) >= 3 and sizes[-1] <= 60
+        assert sizes[1] < 0.5 * sizes[0] and all(b < 0.7 * a for a, b in zip(sizes, sizes[1:]))  # (line aggregates: 1/3 per level)
+        f = dumped[key]
+        assert f.max() < 0.65 and np.exp(np.log(f[3:]).mean()) < 0.5, (key, f)  # stationary V(2,2), damped Jacobi
