@@ -147,9 +147,17 @@ struct QData {
 
 // Offset of component c at point q inside one element's block of packed q-data (H(curl) hexahedra).  In general
 // [ncomp][Q]; with 4 points per direction the two points (qz, qz + 1) of a lane's column sit side by side,
-// [ncomp][2][16][2], so the element kernels fetch 16 bytes per lane and instruction.
+// [ncomp][2][16][2], so the element kernels fetch 16 bytes per lane and instruction; with 5 points per direction
+// [ncomp][126]: the pairs (qz 0, 1) and (qz 2, 3) of the 25 columns side by side, [2][25][2], then the points qz = 4, [25],
+// and one pad entry that keeps every component 16-byte aligned.
+__host__ __device__ inline int nd_qd_cstride(int q1d) { return q1d == 5 ? 126 : q1d * q1d * q1d; }
 __host__ __device__ inline int nd_qd_offset(int q1d, int c, int q) {
-  return q1d == 4 ? ((c * 2 + (q >> 5)) * 16 + (q & 15)) * 2 + ((q >> 4) & 1) : c * q1d * q1d * q1d + q;
+  if (q1d == 4) return ((c * 2 + (q >> 5)) * 16 + (q & 15)) * 2 + ((q >> 4) & 1);
+  if (q1d == 5) {
+    const int qz = q / 25, t = q - 25 * qz;
+    return c * 126 + (qz < 4 ? (qz >> 1) * 50 + 2 * t + (qz & 1) : 100 + t);
+  }
+  return c * q1d * q1d * q1d + q;
 }
 
 struct SubOp {
@@ -277,6 +285,8 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag);
 void free_stream(SubOp &so);
 void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase = -1);
 void stream_set_interface(SubOp &so, const std::vector<char> &flag);
+bool nd_hex_stream5_ok(const SubOp &so);
+void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase);
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
                           int ess_policy, const double *ye = nullptr);
 void stream_element_coefficients(SubOp &so);

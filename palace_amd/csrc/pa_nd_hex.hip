@@ -93,9 +93,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_apply_kernel(co
   int attr[LATE ? 1 : Q1];
   const double *glate = a.geom + (size_t)(active ? e : 0) * 11 * Q + ta + Q1 * tb;
   // (Q1 == 4: the two points (qz, qz + 1) of a lane's column are stored side by side, nd_qd_offset)
-  const double *gq_late = a.qdata + (size_t)(active ? e : 0) * 7 * Q;
+  const double *gq_late = a.qdata + (size_t)(active ? e : 0) * 7 * nd_qd_cstride(Q1);
   if (QD && !LATEQ) {
-    const double *g = a.qdata + (size_t)(active ? e : 0) * (METRIC ? 7 : NG) * Q;
+    const double *g = a.qdata + (size_t)(active ? e : 0) * (METRIC ? 7 : NG) * nd_qd_cstride(Q1);
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
       constexpr int gs = LATE ? 0 : 1;
@@ -532,7 +532,10 @@ void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const
   PA_HIP(hipGetLastError());
 }
 
-bool nd_hex_fuses_essential(const SubOp &so) { return use_direct(so) && so.d_shared_bc != nullptr; }
+bool nd_hex_fuses_essential(const SubOp &so) {
+  // (five points per direction: only the streaming kernel's run gather owns the essential rows, pa_nd_hex_stream5.hip)
+  return (use_direct(so) && so.d_shared_bc != nullptr) || (so.q1d == 5 && so.d_idxc && so.d_perm_s_bc);
+}
 
 void launch_et_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, int ess_policy) {
   if (use_direct(so) && ess_policy >= 0 && so.d_shared_bc)
@@ -554,7 +557,7 @@ __global__ void nd_hex_qdata_kernel(const int ne, const int Q, const int q1d, co
   const int q = (int)(gid - (long long)e * Q);
   const double *g = geom + (size_t)e * 11 * Q;
   const int ncomp = 6 * (use_u + use_c);
-  double *out = qd + (size_t)e * ncomp * Q;
+  double *out = qd + (size_t)e * ncomp * nd_qd_cstride(q1d);
   double adj[9], Cm[9], Jl[9], M[9];
   const int attr = (int)g[q];
   const double w = g[Q + q];
@@ -588,7 +591,7 @@ void launch_nd_hex_qdata(SubOp &so, hipStream_t s) {
   auto *qd = new QData;
   qd->ncomp = 6 * ((int)use_u + (int)use_c);
   // (padded to a multiple of four elements for the streaming kernel; the pad is never used in a result)
-  const size_t nq = (size_t)((so.ne + 3) & ~3) * qd->ncomp * so.Q;
+  const size_t nq = (size_t)((so.ne + 3) & ~3) * qd->ncomp * nd_qd_cstride(so.q1d);
   qd->d = dev_alloc<double>(nq);
   PA_HIP(hipMemsetAsync(qd->d, 0, nq * sizeof(double), s));
   CoeffDev cm{}, cc{};
@@ -618,7 +621,7 @@ __global__ void nd_hex_metric_kernel(const int ne, const int q1d, const double *
   const double w = w1[q % q1d] * w1[(q / q1d) % q1d] * w1[q / (q1d * q1d)];
   const double det = g[Q + q] / w;
   const double k = w * fabs(det);  // (w / |det|) (det Jl)^T (det Jl) = w |det| Jl^T Jl
-  double *out = qd + (size_t)e * 7 * Q;
+  double *out = qd + (size_t)e * 7 * nd_qd_cstride(q1d);
   int o = 0;
   for (int i = 0; i < 3; i++)
     for (int j = i; j < 3; j++)
@@ -630,7 +633,7 @@ void launch_nd_hex_metric(SubOp &so, hipStream_t s) {
   Geom &g = *so.geom;
   auto *qd = new QData;
   qd->ncomp = 7, qd->metric = true;
-  const size_t nq = (size_t)((so.ne + 3) & ~3) * 7 * so.Q;
+  const size_t nq = (size_t)((so.ne + 3) & ~3) * 7 * nd_qd_cstride(so.q1d);
   qd->d = dev_alloc<double>(nq);
   PA_HIP(hipMemsetAsync(qd->d, 0, nq * sizeof(double), s));
   double *d_w = dev_upload(g.w1.data(), g.w1.size(), s);

@@ -3,6 +3,8 @@
 // vector component.  See pa_nd_hex.hip for the mapping of elements and lines to lanes.
 #pragma once
 
+#include <type_traits>
+
 #include "pa_internal.hpp"
 #include "pa_device.hpp"
 
@@ -108,13 +110,37 @@ struct NDLayout<3, 4> {
   __device__ static __forceinline__ int parity_xor(int sub) { return (sub & 1) << 4; }
 };
 
+// The same strides with the two buffers on top of each other (A and B both start at 0): pass Y reads A and writes B, pass
+// Y^T reads B and writes A, every lane loads all its inputs before its first store, and the LDS executes a wave's operations
+// in order -- so with a compiler fence between the loads and the stores of those two passes (INPLACE below) a lane can never
+// see another lane's output where it expects an input.  3/5 of the LDS of the separate buffers (five points per direction,
+// where LDS limits the resident waves: pa_nd_hex_stream5.hip).
+template <int P1, int Q1>
+struct NDLayoutInPlace {
+  using S = NDStrides<P1, Q1>;
+  static constexpr int NC = P1 + 1;
+  static constexpr int A_FIELD = S::Sq * Q1, B_FIELD = S::Tq * Q1;
+  static constexpr int ELEM = (2 * A_FIELD > 3 * B_FIELD) ? 2 * A_FIELD : 3 * B_FIELD;
+  static constexpr bool INPLACE = true;
+  __device__ static __forceinline__ int ia(int f, int qx, int j, int k) { return f * A_FIELD + qx * S::Sq + j * S::Sj + k; }
+  __device__ static __forceinline__ int ib(int f, int qx, int qy, int k) { return f * B_FIELD + qx * S::Tq + qy * S::Ty + k; }
+};
+template <class LT, class = void>
+struct NDInPlace {
+  static constexpr bool value = false;
+};
+template <class LT>
+struct NDInPlace<LT, decltype((void)LT::INPLACE)> {
+  static constexpr bool value = LT::INPLACE;
+};
+
 // ---- forward passes for component C -------------------------------------------------------
-template <int C, int P1, int Q1, bool USE_U, bool USE_C, class Args>
+template <int C, int P1, int Q1, bool USE_U, bool USE_C, class LT = void, class Args>
 __device__ __forceinline__ void nd_fwd_comp(const Args &a, const int e, const bool active,
                                             const bool lane_ok, const int ta, const int tb, const int lx,
                                             double *__restrict__ sm, const double (&u)[P1 + 1],
                                             double (&U)[3][Q1], double (&CU)[3][Q1]) {
-  using L = NDLayout<P1, Q1>;
+  using L = typename std::conditional<std::is_void<LT>::value, NDLayout<P1, Q1>, LT>::type;
   constexpr int NC = L::NC;
   constexpr int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
   const double *TX = (C == 0) ? a.tab.Bo : a.tab.Bc;
@@ -150,6 +176,7 @@ __device__ __forceinline__ void nd_fwd_comp(const Args &a, const int e, const bo
       v[j] = sm[L::ia(0, ta, j, act ? tb : 0) ^ lx];
       if (DX) d[j] = sm[L::ia(1, ta, j, act ? tb : 0) ^ lx];
     }
+    if (NDInPlace<L>::value) wave_sync();  // in-place layouts: every lane's loads before any lane's stores
 #pragma unroll
     for (int qy = 0; qy < Q1; qy++) {
       double vv = 0.0, vd = 0.0, dv = 0.0;
@@ -199,12 +226,12 @@ __device__ __forceinline__ void nd_fwd_comp(const Args &a, const int e, const bo
 }
 
 // ---- transposed passes for component C ------------------------------------------------------
-template <int C, int P1, int Q1, bool USE_U, bool USE_C, class Args>
+template <int C, int P1, int Q1, bool USE_U, bool USE_C, class LT = void, class Args>
 __device__ __forceinline__ void nd_bwd_comp(const Args &a, const int e, const bool active,
                                             const bool lane_ok, const int ta, const int tb, const int lx,
                                             double *__restrict__ sm, double (&rout)[P1 + 1],
                                             const double (&V)[3][Q1], const double (&CV)[3][Q1]) {
-  using L = NDLayout<P1, Q1>;
+  using L = typename std::conditional<std::is_void<LT>::value, NDLayout<P1, Q1>, LT>::type;
   constexpr int NC = L::NC;
   constexpr int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
   const double *TX = (C == 0) ? a.tab.Bo : a.tab.Bc;
@@ -250,6 +277,7 @@ __device__ __forceinline__ void nd_bwd_comp(const Args &a, const int e, const bo
       if (DY) vd[qy] = sm[L::ib(1, ta, qy, act ? tb : 0) ^ lx];
       if (DX) dv[qy] = sm[L::ib(2, ta, qy, act ? tb : 0) ^ lx];
     }
+    if (NDInPlace<L>::value) wave_sync();  // in-place layouts: every lane's loads before any lane's stores
 #pragma unroll
     for (int j = 0; j < nj; j++) {
       double v = 0.0, d = 0.0;

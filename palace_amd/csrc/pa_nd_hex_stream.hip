@@ -426,9 +426,12 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const u
 bool nd_hex_stream_ok(const SubOp &so) {
   static const bool enabled = !(getenv("PALACE_AMD_STREAM") && atoi(getenv("PALACE_AMD_STREAM")) == 0);
   if (!enabled) return false;
+  if (so.q1d == 5) return nd_hex_stream5_ok(so);  // five points per direction: pa_nd_hex_stream5.hip
   if (so.fe_type != PA_FE_HCURL || so.q1d != 4 || so.p > 3 || !so.qd || !so.d_ye || !so.d_perm_x) return false;
   return so.qd->metric || so.qd->ncomp == 6;
 }
+
+static bool wide_form(const SubOp &so) { return so.fe_type == PA_FE_HCURL && so.q1d == 5; }
 
 // Scalar mass / curl-curl coefficient of every element (coeff_3_qf.h:9-24 resolved on the host; isotropic materials): what the
 // metric form multiplies its geometric matrices with, [ne padded to 4][2]
@@ -463,8 +466,10 @@ void build_stream(SubOp &so) {
   const int P = so.P, ne = so.ne;
   std::vector<uint32_t> ic, pp;
   // (a numbering that breaks an element's dofs into more than kIdxMaxRuns runs keeps the one-shot kernel)
-  if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp,
-                              so.fe_type == PA_FE_H1 ? streamhost::kIdxStart0H1 : streamhost::kIdxStart0))
+  if (wide_form(so)) {
+    if (!streamhost::pack_index_wide(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp)) return;
+  } else if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp,
+                                     so.fe_type == PA_FE_H1 ? streamhost::kIdxStart0H1 : streamhost::kIdxStart0))
     return;
   so.h_perm_s = pp;
   so.d_idxc = dev_upload(ic.data(), ic.size());
@@ -490,9 +495,18 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   const int P = so.P, npl = (P + 15) / 16, npk = (npl + 3) / 4;
   std::vector<uint32_t> pb(so.h_perm_s);
   const size_t nnz = (size_t)so.ne * so.P;
+  const bool wide = wide_form(so);
+  const int npkw = ((P + 31) / 32 + 1) / 2;
   for (size_t k = 0; k < nnz; k++) {
     if (flag[streamhost::dof_of(so.h_sidx[k])]) {
       const size_t e = k / P;
+      if (wide) {  // flags ride in the slot half-words (pack_index_wide)
+        const int m = (int)(k - e * P), t = m & 31, r = m >> 5;
+        uint32_t &w = pb[(e * npkw + (r >> 1)) * 32 + t];
+        w &= ~(streamhost::kWideExcl << (16 * (r & 1)));
+        w |= streamhost::kWideEss << (16 * (r & 1));
+        continue;
+      }
       const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
       uint32_t &fw = pb[(e * (npk + 1) + npk) * 16 + t];
       fw &= ~(2u << (2 * r));  // off the direct path
@@ -525,11 +539,12 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
 // list 0 and can run while the exchange is in flight; the others form list 1.
 void stream_set_interface(SubOp &so, const std::vector<char> &flag) {
   if (!so.d_idxc) return;
-  const int nb = (so.ne + 3) / 4, P = so.P;
+  const int epb = wide_form(so) ? 2 : 4;  // elements per batch (one wave)
+  const int nb = (so.ne + epb - 1) / epb, P = so.P;
   std::vector<int32_t> lists[2];
   for (int b = 0; b < nb; b++) {
     bool iface = false;
-    for (int e = 4 * b; e < std::min(4 * b + 4, so.ne) && !iface; e++)
+    for (int e = epb * b; e < std::min(epb * b + epb, so.ne) && !iface; e++)
       for (int m = 0; m < P && !iface; m++) iface = flag[streamhost::dof_of(so.h_sidx[(size_t)e * P + m])] != 0;
     lists[iface ? 1 : 0].push_back(b);
   }
@@ -641,6 +656,7 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
 }
 
 void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase) {
+  if (wide_form(so)) return launch_nd_hex_stream5(so, x, y, masked, s, phase);
   switch (so.p) {
     case 1: launch_p<1>(so, x, y, masked, s, phase); break;
     case 2: launch_p<2>(so, x, y, masked, s, phase); break;

@@ -94,6 +94,72 @@ inline bool pack_index(int ne, int P, int lsize, const int32_t *sidx, const uint
   return true;
 }
 
+// ---- wide form: one element per 32 lanes (five points per direction, pa_nd_hex_stream5.hip) ----------------------------
+// The same idea with 32-entry slices, for elements of up to 320 entries (p = 4: P = 300).  Index block of an element,
+// kWideWords = 48 words, fetched by its 32 lanes with two loads and decoded from LDS:
+//   word 2 r       entries 32 r .. 32 r + 31: bit j set = entry 32 r + j starts a run
+//   word 2 r + 1   bits 0-7 number of runs that start before entry 32 r, bits 8-16 position of the last one
+//   word 20 + k    first dof of run k (k < kWideMaxRuns)
+// Slot words pp [nep][npk][32], nep = ne padded to two elements (one batch), npk = ceil(npl / 2): lane t of an element
+// holds entries m = t + 32 r, word r >> 1 carries the half-words of r = 2 k, 2 k + 1:
+//   bits 0-8 tensor-order slot, bit 9 flipped, bit 10 only copy of its dof, bit 11 essential (read as zero; set in the
+//   copy stream_set_essential makes, which also takes the entry off the direct path)
+constexpr int kWideWords = 48, kWideStart0 = 20, kWideMaxRuns = 24, kWideMaxSlices = 10;
+constexpr uint32_t kWideSlotMask = 511u, kWideFlip = 1u << 9, kWideExcl = 1u << 10, kWideEss = 1u << 11;
+
+inline int index_dof_wide(const uint32_t *ic, int m) {  // host model of the device decode
+  const int r = m >> 5, t = m & 31;
+  const uint32_t w = ic[2 * r], info = ic[2 * r + 1], low = w & ((2u << t) - 1u);
+  int bits = 0, top = -1;
+  for (int j = 0; j < 32; j++)
+    if (low >> j & 1u) bits++, top = j;
+  const int rid = (int)(info & 255u) + bits - 1;
+  if (rid < 0 || rid >= kWideMaxRuns) throw std::runtime_error("wide index decode: entry without a run");
+  const int pos = low ? 32 * r + top : (int)((info >> 8) & 511u);
+  return (int)ic[kWideStart0 + rid] + (m - pos);
+}
+
+inline bool pack_index_wide(int ne, int P, int lsize, const int32_t *sidx, const uint16_t *perm, std::vector<uint32_t> &ic,
+                            std::vector<uint32_t> &pp) {
+  if (P > 32 * kWideMaxSlices) throw std::runtime_error("element too large for the wide streaming index");
+  if (lsize >= kExclBit) throw std::runtime_error("too many local dofs for the streaming index encoding");
+  const int nep = (ne + 1) & ~1, npl = (P + 31) / 32, npk = (npl + 1) / 2;
+  const size_t nnz = (size_t)ne * P;
+  std::vector<int32_t> count((size_t)lsize, 0);
+  for (size_t k = 0; k < nnz; k++) count[dof_of(sidx[k])]++;
+  ic.assign((size_t)nep * kWideWords, 0u);
+  pp.assign((size_t)nep * npk * 32, 0u);
+  for (int e = 0; e < nep; e++) {
+    uint32_t *ice = &ic[(size_t)e * kWideWords];
+    uint32_t *row = &pp[(size_t)e * npk * 32];
+    if (e >= ne) {
+      // pad element: one run, dof 0 onwards, every entry read as zero, results stored to E-vector rows nobody gathers
+      ice[0] = 1u;
+      for (int r = 1; r < npl; r++) ice[2 * r + 1] = 1u;
+      for (int m = 0; m < P; m++) row[(m >> 6) * 32 + (m & 31)] |= ((uint32_t)m | kWideEss) << (16 * ((m >> 5) & 1));
+      continue;
+    }
+    int nruns = 0, lastpos = 0, prev = -2;
+    for (int m = 0; m < P; m++) {
+      const size_t k = (size_t)e * P + m;
+      const int32_t s = sidx[k];
+      const int d = dof_of(s);
+      const int t = m & 31, r = m >> 5;
+      if (t == 0) ice[2 * r + 1] = (uint32_t)nruns | (uint32_t)lastpos << 8;
+      if (d != prev + 1) {
+        if (nruns == kWideMaxRuns) return false;
+        ice[kWideStart0 + nruns++] = (uint32_t)d;
+        ice[2 * r] |= 1u << t;
+        lastpos = m;
+      }
+      prev = d;
+      const uint32_t h = (uint32_t)(perm[k] & kWideSlotMask) | (s < 0 ? kWideFlip : 0u) | (count[d] == 1 ? kWideExcl : 0u);
+      row[(r >> 1) * 32 + t] |= h << (16 * (r & 1));
+    }
+  }
+  return true;
+}
+
 // Runs over the shared dofs (`shared` increasing: every dof that does not have exactly one copy): consecutive dofs
 // with the same number of copies whose copies sit at consecutive E-vector positions, at most 16 long.
 //   code[k] = run << 4 | offset of shared[k] in its run;  hdr[run] = {first dof, first entry in rpos};

@@ -170,6 +170,133 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, in
   return err < 1e-13 ? 0 : 1;
 }
 
+// The wide form (pa_nd_hex_stream5.hip: one element per 32 lanes, 16-bit slot half-words with the flags, 48-word index
+// block): the same model of E staging, E^T stores and the run gather.
+static int run_case_wide(int ne, int P, int lsize, unsigned seed, double ess_frac, int min_block = 6, bool expect_ok = true) {
+  std::mt19937 rng(seed);
+  std::vector<int32_t> lidx((size_t)ne * P);
+  for (int e = 0; e < ne; e++) {
+    std::vector<char> used(lsize, 0);
+    int filled = 0, tries = 0;
+    std::vector<int> dofs;
+    while (filled < P) {
+      const int len = tries > 200 ? 1 : std::min<int>(P - filled, min_block + rng() % 24);
+      const int d0 = rng() % (lsize - len + 1);
+      bool ok = true;
+      for (int j = 0; j < len; j++) ok = ok && !used[d0 + j];
+      if (!ok) {
+        tries++;
+        continue;
+      }
+      for (int j = 0; j < len; j++) used[d0 + j] = 1, dofs.push_back(d0 + j);
+      filled += len;
+    }
+    std::shuffle(dofs.begin(), dofs.end(), rng);
+    for (int l = 0; l < P; l++) lidx[(size_t)e * P + l] = (rng() & 1) ? dofs[l] : -1 - dofs[l];
+  }
+  std::vector<int32_t> sidx((size_t)ne * P);
+  std::vector<uint16_t> perm((size_t)ne * P);
+  for (int e = 0; e < ne; e++) {
+    std::vector<int> ord(P);
+    std::iota(ord.begin(), ord.end(), 0);
+    const int32_t *le = &lidx[(size_t)e * P];
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return dof_of(le[a]) < dof_of(le[b]); });
+    for (int m = 0; m < P; m++) sidx[(size_t)e * P + m] = le[ord[m]], perm[(size_t)e * P + m] = (uint16_t)ord[m];
+  }
+  std::vector<int32_t> count(lsize, 0);
+  for (auto s : sidx) count[dof_of(s)]++;
+  std::vector<char> ess(lsize, 0);
+  for (int d = 0; d < lsize; d++) ess[d] = (rng() % 1000) < ess_frac * 1000;
+
+  std::vector<uint32_t> ic, pp;
+  const bool ok = pack_index_wide(ne, P, lsize, sidx.data(), perm.data(), ic, pp);
+  if (ok != expect_ok) return std::printf("pack_index_wide returned %d, expected %d\n", (int)ok, (int)expect_ok), 1;
+  if (!ok) return std::printf("wide ne=%d P=%d: more than %d runs in an element, refused as expected\n", ne, P, kWideMaxRuns), 0;
+  for (int e = 0; e < ne; e++)
+    for (int m = 0; m < P; m++)
+      if (index_dof_wide(&ic[(size_t)e * kWideWords], m) != dof_of(sidx[(size_t)e * P + m]))
+        return std::printf("wide index decode: element %d entry %d\n", e, m), 1;
+  const int nep = (ne + 1) & ~1, npl = (P + 31) / 32, npk = (npl + 1) / 2;
+  // essential dofs as stream_set_essential handles them in the wide form
+  for (size_t k = 0; k < (size_t)ne * P; k++)
+    if (ess[dof_of(sidx[k])]) {
+      const size_t e = k / P;
+      const int m = (int)(k - e * P), t = m & 31, r = m >> 5;
+      uint32_t &w = pp[(e * npk + (r >> 1)) * 32 + t];
+      w &= ~(kWideExcl << (16 * (r & 1)));
+      w |= kWideEss << (16 * (r & 1));
+    }
+  std::vector<int32_t> shared;
+  for (int d = 0; d < lsize; d++)
+    if (count[d] != 1 || ess[d]) shared.push_back(d);
+  std::vector<uint32_t> code;
+  std::vector<RunHdr> hdr;
+  std::vector<int32_t> rpos;
+  build_runs(ne, P, lsize, sidx.data(), shared, code, hdr, rpos);
+  for (size_t k = 0; k < code.size(); k++)
+    if (ess[shared[k]]) code[k] |= 0x80000000u;
+
+  std::vector<double> x(lsize), scale((size_t)ne * P);
+  std::uniform_real_distribution<double> U(-1, 1);
+  for (auto &v : x) v = U(rng);
+  for (auto &v : scale) v = U(rng);
+  std::vector<double> yref(lsize, 0.0);
+  for (int e = 0; e < ne; e++)
+    for (int l = 0; l < P; l++) {
+      const int32_t s = lidx[(size_t)e * P + l];
+      const int d = dof_of(s);
+      const double u = ess[d] ? 0.0 : (s >= 0 ? x[d] : -x[d]);
+      const double v = scale[(size_t)e * P + l] * u;
+      yref[d] += s >= 0 ? v : -v;
+    }
+  for (int d = 0; d < lsize; d++)
+    if (ess[d]) yref[d] = x[d];
+
+  std::vector<double> ye((size_t)nep * P, 1e300), y(lsize, 1e300), sm(P);
+  auto half = [&](int e, int m) { return (pp[((size_t)e * npk + (m >> 6)) * 32 + (m & 31)] >> (16 * ((m >> 5) & 1))) & 0xffffu; };
+  for (int e = 0; e < nep; e++) {
+    std::fill(sm.begin(), sm.end(), 0.0);
+    for (int m = 0; m < P; m++) {
+      const uint32_t h = half(e, m);
+      const int dof = index_dof_wide(&ic[(size_t)e * kWideWords], m);
+      if (dof < 0 || dof >= lsize) return std::printf("wide: decoded dof %d out of range\n", dof), 1;
+      if ((int)(h & kWideSlotMask) >= P) return std::printf("wide: slot out of range\n"), 1;
+      const double v = (h & kWideEss) ? 0.0 : x[dof];
+      sm[h & kWideSlotMask] = (h & kWideFlip) ? -v : v;
+    }
+    if (e < ne)
+      for (int l = 0; l < P; l++) sm[l] *= scale[(size_t)e * P + l];
+    for (int m = 0; m < P; m++) {
+      const uint32_t h = half(e, m);
+      const double v = sm[h & kWideSlotMask], sgv = (h & kWideFlip) ? -v : v;
+      if (h & kWideExcl) {
+        if (h & kWideEss) return std::printf("wide: essential dof on the direct path\n"), 1;
+        if (e >= ne) return std::printf("wide: pad element %d on the direct path\n", e), 1;
+        y[index_dof_wide(&ic[(size_t)e * kWideWords], m)] = sgv;
+      } else {
+        ye[(size_t)e * P + m] = sgv;
+      }
+    }
+  }
+  for (size_t k = 0; k < shared.size(); k++) {
+    const uint32_t c = code[k];
+    const int run = (int)((c & 0x7fffffffu) >> 4), j = (int)(c & 15u);
+    const int d = hdr[run].dof0 + j;
+    if (d != shared[k]) return std::printf("wide run decode: dof %d != %d\n", d, shared[k]), 1;
+    if (c >> 31) {
+      y[d] = x[d];
+      continue;
+    }
+    double s = 0.0;
+    for (int p = hdr[run].ptr; p < hdr[run + 1].ptr; p++) s += ye[(size_t)rpos[p] + j];
+    y[d] = s;
+  }
+  double err = 0.0;
+  for (int d = 0; d < lsize; d++) err = std::max(err, std::fabs(y[d] - yref[d]));
+  std::printf("wide ne=%d P=%d lsize=%d shared=%zu runs=%zu max err %.3e\n", ne, P, lsize, shared.size(), hdr.size() - 1, err);
+  return err < 1e-13 ? 0 : 1;
+}
+
 int main() {
   int bad = 0;
   bad += run_case(37, 144, 2000, 1, 0.05);
@@ -180,6 +307,12 @@ int main() {
   bad += run_case(9, 144, 3000, 6, 0.05, 1, false);  // blocks of 1 .. 12 dofs: ~22 runs per element, over the capacity
   bad += run_case(40, 64, 900, 7, 0.05, 1, true, kIdxStart0H1);  // H1 layout: 4 slice words, up to 28 runs
   bad += run_case(11, 27, 300, 8, 0.1, 1, true, kIdxStart0H1);
+  bad += run_case_wide(23, 300, 5000, 11, 0.05, 12);  // p = 4
+  bad += run_case_wide(7, 144, 1200, 12, 0.1);         // p = 3 on five points
+  bad += run_case_wide(6, 54, 400, 13, 0.1);
+  bad += run_case_wide(5, 12, 60, 14, 0.2, 1);
+  bad += run_case_wide(1, 300, 900, 15, 0.0, 12);
+  bad += run_case_wide(4, 300, 6000, 16, 0.05, 1, false);  // short blocks: more than 24 runs, refused
   return bad;
 }
 
