@@ -520,9 +520,13 @@ def main():
     pcg = None
     if args.pcg_iters > 0:
         pcg = {}
-        for name, hip in (("chebyshev", False), ("hiptmair", True)):
+        # level 0: the stand-ins of rounds 1-2 (comparable numbers), and the native auxiliary-space solver (AMS) where the
+        # reference calls HYPRE's (one rank: it works on the rank's own matrix)
+        legs = [("chebyshev", False, "chebyshev"), ("hiptmair", True, "cg")]
+        if world == 1:
+            legs += [("chebyshev_ams", False, "ams"), ("hiptmair_ams", True, "ams")]
+        for name, hip, coarse in legs:
             try:  # a failing secondary leg is reported in the line, it does not take the headline measurement with it
-                coarse = "cg" if hip else "chebyshev"
                 solver, b, xs = prob.pcg_gmg_solver(max_it=args.pcg_iters, hiptmair=hip, coarse=coarse)
                 solver.mult(b, xs)  # warm-up solve (also first-touch of all work vectors)
                 barrier()
@@ -550,7 +554,9 @@ def main():
                          f"4th-kind Chebyshev order {max(2 * p, 4)}, 1 V-cycle "
                          "per iteration; 'chebyshev' = plain smoother (reference default for magnetostatics), "
                          "'hiptmair' = auxiliary-space smoother (reference default for driven/eigenmode); level 0 assembled to a device CSR matrix like the reference's coarsest level (stand-in for AMS on it): "
-                         "Chebyshev-Jacobi order 4 with the plain smoother, 8 Jacobi-PCG iterations with the auxiliary-space one")
+                         "Chebyshev-Jacobi order 4 with the plain smoother, 8 Jacobi-PCG iterations with the auxiliary-space one; '*_ams' = the "
+                         "native auxiliary-space solver on level 0 (amg_solver.hip: smoothed-aggregation AMG on G^T A G and on the "
+                         "three Pi_c^T A Pi_c, HYPRE AMS cycle 14, where the reference calls HYPRE's AMS)")
 
     tets = None
     def _leg(fn, *a):

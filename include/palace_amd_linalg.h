@@ -140,6 +140,32 @@ int pa_dist_relaxation_lambda_max(const pa_solver *S, double *lambda_max, double
 int pa_solver_mult2(pa_solver *S, const double *x, double *y, int transpose, int initial_guess);
 /* JacobiSmoother (linalg/jacobi.cpp) */
 int pa_jacobi_create(pa_context *ctx, pa_par_op *A, pa_solver **S);
+
+/* Native coarse-level solvers (palace_amd/csrc/amg_solver.hpp), standing where the reference calls HYPRE on its coarsest
+ * multigrid level: BoomerAmgSolver (linalg/amg.cpp:12-49; wiring linalg/ksp.cpp:187-200) and HypreAmsSolver
+ * (linalg/ams.cpp:18-224; ksp.cpp:166-186).  The matrix is the assembled level (pa_op_full_assemble: what
+ * ParOperator::ParallelAssemble gives HYPRE, rap.cpp:84-152); `ess` are the essential true dofs ParOperator eliminates in it
+ * (rap.cpp:131-149).  Zero / negative option fields take the defaults of AmgOptions / AmsOptions.  One rank. */
+typedef struct {
+  int max_levels, coarse_size, smooth_order;
+  double theta;
+} pa_amg_options;
+typedef struct {
+  int cycle_it, smooth_order, singular;
+  pa_amg_options amg;
+} pa_ams_options;
+int pa_amg_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_ess, const pa_amg_options *opt, pa_solver **S);
+/* G: the discrete gradient [rows of A x n_vert] as host CSR arrays (HYPRE_AMSSetDiscreteGradient, ams.cpp:204), coords: the
+ * vertex coordinates [n_vert][dim] on the host (HYPRE_AMSSetCoordinateVectors, ams.cpp:206-210: lowest-order spaces). */
+int pa_ams_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_ess, int n_vert, const int32_t *G_rowptr,
+                  const int32_t *G_col, const double *G_val, const double *coords, int dim, const pa_ams_options *opt,
+                  pa_solver **S);
+/* The hierarchy of an AMG solver (which = 0) or of the gradient-space (1) / nodal-space (2) solver inside an AMS solver:
+ * number of levels; and copies of its matrices -- kind 0: A_level, 1: P_level (level + 1 -> level), 2: the dense inverse used
+ * on the last level (row-major in val, rowptr / col untouched).  Null output arrays: sizes only. */
+int pa_amg_num_levels(const pa_solver *S, int which, int *nlevels);
+int pa_amg_get_matrix(const pa_solver *S, int which, int level, int kind, int32_t *nrows, int32_t *ncols, int64_t *nnz,
+                      int32_t *rowptr, int32_t *col, double *val);
 /* CgSolver / GmresSolver / FgmresSolver (linalg/iterative.cpp).  precond may be NULL. */
 int pa_cg_create(pa_context *ctx, pa_par_op *A, pa_solver *precond, double rel_tol, double abs_tol,
                  int max_it, int print, pa_solver **S);

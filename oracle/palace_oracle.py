@@ -1394,3 +1394,65 @@ class MixedCurlOperatorOracle:
             ve = b._restrict_t(np.einsum("dqj,edq->ej", b.deriv, cv), sl)
             np.add.at(y, b.off[sl].ravel(), ve.ravel())
         return -y if weak else y
+
+
+# ---- native coarse solvers: the cycles restated on host matrices (checker for palace_amd/csrc/amg_solver.hip) ---------------
+# The reference calls HYPRE here (linalg/amg.cpp:12-49, linalg/ams.cpp:18-224); HYPRE is not in /root/reference, so there is no
+# reference output to pin these on: "parity unpinned" for the coarse solvers themselves.  What IS checked: the device cycle
+# equals this restatement on the very hierarchy the library built (tests/test_ams_gpu.py, 1e-10), the preconditioners are
+# symmetric positive definite, and the preconditioned solves reproduce sparse direct solutions.
+
+def cheb4_l1(A, b, x, order, zero_guess):
+    """4th-kind Chebyshev smoothing (chebyshev.cpp:190-220) on D_l1^-1 A with lambda_max = 1, D_l1 = diag(sum_j |a_ij|)."""
+    l1 = np.asarray(abs(A).sum(axis=1)).ravel()
+    dinv = np.where(l1 > 0.0, 1.0 / np.where(l1 > 0.0, l1, 1.0), 0.0)
+    if zero_guess:
+        r = b.copy()
+        x = np.zeros_like(b)
+    else:
+        r = b - A @ x
+    d = (4.0 / 3.0) * dinv * r
+    for k in range(1, order):
+        x = x + d
+        r = r - A @ d
+        d = (2.0 * k - 1.0) / (2.0 * k + 3.0) * d + (8.0 * k + 4.0) / (2.0 * k + 3.0) * dinv * r
+    return x + d
+
+
+def amg_vcycle(A, P, cinv, b, order=2, level=0):
+    """One V-cycle from a zero guess over the hierarchy (A[l], P[l]) with the dense inverse `cinv` on the last level."""
+    if level + 1 == len(A):
+        return cinv @ b
+    x = cheb4_l1(A[level], b, None, order, True)
+    r = b - A[level] @ x
+    xc = amg_vcycle(A, P, cinv, P[level].T @ r, order, level + 1)
+    x = x + P[level] @ xc
+    return cheb4_l1(A[level], b, x, order, False)
+
+
+def ams_cycle(A, G, Pi, amg_G, amg_Pi, b, order=2, singular=False):
+    """HYPRE AMS cycle type 14 (ams.cpp:24-28: 0 1 (3 + 4 + 5) 1 0) from a zero guess: smoothing on A, gradient-space
+    correction, additive scalar nodal-space corrections (one block-diagonal solve), gradient space, smoothing.
+    amg_G / amg_Pi: callables applying the auxiliary-space solves."""
+    x = cheb4_l1(A, b, None, order, True)
+
+    def correct(T, B, x):
+        return x + T @ B(T.T @ (b - A @ x))
+
+    if not singular:
+        x = correct(G, amg_G, x)
+    x = correct(Pi, amg_Pi, x)
+    if not singular:
+        x = correct(G, amg_G, x)
+    return cheb4_l1(A, b, x, order, False)
+
+
+def ams_nodal_interpolation(G, coords, ess_flag):
+    """Pi = [Pi_x Pi_y Pi_z], Pi_c = |G| diag(G x_c) / 2 (HYPRE_AMSSetCoordinateVectors), rows of essential edges dropped;
+    returns (G without those rows, Pi)."""
+    import scipy.sparse as sp
+
+    keep = sp.diags((~np.asarray(ess_flag, dtype=bool)).astype(np.float64))
+    Gb = (keep @ G).tocsr()
+    blocks = [(sp.diags(0.5 * (G @ coords[:, c])) @ abs(Gb)).tocsr() for c in range(coords.shape[1])]
+    return Gb, sp.hstack(blocks).tocsr()

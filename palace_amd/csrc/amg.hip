@@ -71,6 +71,44 @@ std::vector<double> diagonal(const HostCsr &A) {
 inline bool strong(double aij, double dii, double djj, double theta) {
   return aij * aij >= theta * theta * std::abs(dii * djj);
 }
+// spectral radius of D_F^-1 A_F (filtered matrix of SmoothProlongator), a few power iterations from a fixed vector
+double filtered_radius(const HostCsr &A, double theta) {
+  const std::vector<double> d = diagonal(A);
+  const int n = A.nrows;
+  std::vector<double> dF((size_t)n), u((size_t)n), v((size_t)n);
+  for (int i = 0; i < n; i++) {
+    double dii = d[i];
+    for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++)
+      if (A.col[a] != i && !strong(A.val[a], d[i], d[A.col[a]], theta)) dii += A.val[a];
+    if (!(std::abs(dii) > 0.1 * std::abs(d[i]))) dii = d[i];
+    dF[i] = dii != 0.0 ? dii : 1.0;
+    u[i] = 1.0 + 0.5 * std::sin(1.7 * i + 0.3);  // deterministic, not orthogonal to the top of the spectrum in practice
+  }
+  double rho = 0.0;
+  for (int it = 0; it < 20; it++) {
+    double nrm = 0.0;
+    for (int i = 0; i < n; i++) nrm += u[i] * u[i];
+    nrm = std::sqrt(nrm);
+    if (nrm == 0.0) break;
+    for (int i = 0; i < n; i++) u[i] /= nrm;
+    for (int i = 0; i < n; i++) {
+      double s = 0.0;
+      for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
+        const int j = A.col[a];
+        if (j == i)
+          s += dF[i] * u[i];
+        else if (strong(A.val[a], d[i], d[j], theta))
+          s += A.val[a] * u[j];
+      }
+      v[i] = s / dF[i];
+    }
+    double r = 0.0;
+    for (int i = 0; i < n; i++) r += v[i] * v[i];
+    rho = std::sqrt(r);
+    u.swap(v);
+  }
+  return rho;
+}
 }  // namespace
 
 std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) {
@@ -78,10 +116,16 @@ std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) 
   const int n = A.nrows;
   const std::vector<double> d = diagonal(A);
   std::vector<int> agg((size_t)n, -1);
+  // rows without a strong off-diagonal entry (eliminated essential dofs: a lone diagonal) stay out of the coarse problem:
+  // the smoother solves them, and carried along they would form one aggregate each and stop the coarsening
+  std::vector<char> isolated((size_t)n, 1);
+  for (int i = 0; i < n; i++)
+    for (int a = A.rowptr[i]; a < A.rowptr[i + 1] && isolated[i]; a++)
+      if (A.col[a] != i && strong(A.val[a], d[i], d[A.col[a]], theta)) isolated[i] = 0;
   int na = 0;
   // pass 1: a node whose strong neighbours are all free founds an aggregate with them
   for (int i = 0; i < n; i++) {
-    if (agg[i] >= 0) continue;
+    if (agg[i] >= 0 || isolated[i]) continue;
     bool free_nbrs = true, any = false;
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1] && free_nbrs; a++) {
       const int j = A.col[a];
@@ -100,7 +144,7 @@ std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) 
   // pass 2: the rest joins the aggregate (as formed in pass 1) it is most strongly tied to
   const std::vector<int> pass1(agg);
   for (int i = 0; i < n; i++) {
-    if (agg[i] >= 0) continue;
+    if (agg[i] >= 0 || isolated[i]) continue;
     double best = 0.0;
     int to = -1;
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
@@ -112,11 +156,11 @@ std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) 
   }
   // pass 3: what is still free (no strong tie to any aggregate) forms aggregates with its free strong neighbours
   for (int i = 0; i < n; i++) {
-    if (agg[i] >= 0) continue;
+    if (agg[i] >= 0 || isolated[i]) continue;
     agg[i] = na;
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
       const int j = A.col[a];
-      if (j != i && agg[j] < 0 && strong(A.val[a], d[i], d[j], theta)) agg[j] = na;
+      if (j != i && agg[j] < 0 && !isolated[j] && strong(A.val[a], d[i], d[j], theta)) agg[j] = na;
     }
     na++;
   }
@@ -128,16 +172,19 @@ HostCsr TentativeProlongator(const std::vector<int> &aggregate, int num_aggregat
   HostCsr T;
   T.nrows = (int)aggregate.size(), T.ncols = num_aggregates;
   std::vector<int> size((size_t)num_aggregates, 0);
-  for (int a : aggregate) size[a]++;
-  T.rowptr.resize((size_t)T.nrows + 1);
-  std::iota(T.rowptr.begin(), T.rowptr.end(), 0);
-  T.col = aggregate;
-  T.val.resize(aggregate.size());
-  for (size_t i = 0; i < aggregate.size(); i++) T.val[i] = 1.0 / std::sqrt((double)size[aggregate[i]]);
+  for (int a : aggregate)
+    if (a >= 0) size[a]++;
+  T.rowptr.assign((size_t)T.nrows + 1, 0);
+  for (size_t i = 0; i < aggregate.size(); i++) {  // (rows outside every aggregate stay empty)
+    if (aggregate[i] >= 0) T.col.push_back(aggregate[i]), T.val.push_back(1.0 / std::sqrt((double)size[aggregate[i]]));
+    T.rowptr[i + 1] = (int)T.col.size();
+  }
   return T;
 }
 
 HostCsr SmoothProlongator(const HostCsr &A, const HostCsr &T, double theta, double omega) {
+  // omega = 4 / (3 rho(D_F^-1 A_F)) unless given (rho padded by 10 %: the power iteration approaches it from below)
+  if (omega <= 0.0) omega = 4.0 / (3.0 * std::max(1.0, 1.1 * filtered_radius(A, theta)));
   // filtered matrix: weak off-diagonal entries are dropped and added to the diagonal (row sums kept)
   const std::vector<double> d = diagonal(A);
   HostCsr S;  // S = I - omega D_F^-1 A_F
@@ -147,7 +194,12 @@ HostCsr SmoothProlongator(const HostCsr &A, const HostCsr &T, double theta, doub
     double dii = d[i];
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++)
       if (A.col[a] != i && !strong(A.val[a], d[i], d[A.col[a]], theta)) dii += A.val[a];
-    PA_REQUIRE(dii != 0.0, "zero diagonal in the prolongator smoother");
+    if (!(std::abs(dii) > 0.1 * std::abs(d[i]))) dii = d[i];  // lumping must not cancel the diagonal
+    if (dii == 0.0) {  // an empty row: nothing to smooth, the row of P stays what T has (nothing, for an isolated dof)
+      S.col.push_back(i), S.val.push_back(1.0);
+      S.rowptr[i + 1] = (int)S.col.size();
+      continue;
+    }
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
       const int j = A.col[a];
       if (j == i)
@@ -159,6 +211,20 @@ HostCsr SmoothProlongator(const HostCsr &A, const HostCsr &T, double theta, doub
   }
   return Multiply(S, T);
 }
+
+HostCsr DropRows(const HostCsr &A, const std::vector<char> &flag) {
+  PA_REQUIRE((int)flag.size() == A.nrows, "flag size mismatch");
+  HostCsr B;
+  B.nrows = A.nrows, B.ncols = A.ncols;
+  B.rowptr.assign((size_t)A.nrows + 1, 0);
+  for (int i = 0; i < A.nrows; i++) {
+    if (!flag[i])
+      for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) B.col.push_back(A.col[a]), B.val.push_back(A.val[a]);
+    B.rowptr[i + 1] = (int)B.col.size();
+  }
+  return B;
+}
+
 
 Hierarchy Setup(const HostCsr &A0, int max_levels, int coarse_size, double theta, double omega) {
   Hierarchy h;

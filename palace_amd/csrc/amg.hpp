@@ -4,9 +4,9 @@
 // linalg/amg.cpp:12-49, linalg/ams.cpp:18-224) -- third-party code that is not part of /root/reference.  This is the
 // set-up half of the native replacement SURVEY.md 8 f3 asks for: strength graph, greedy aggregation, tentative and
 // Jacobi-smoothed prolongators, Galerkin products.  It runs once per operator on the host, on the matrix
-// pa_op_full_assemble produces (p = 1 levels: a few 10^5 rows); the solve half is the existing device machinery
-// (CsrOperator as A_l and P_l, Chebyshev / Jacobi smoothers, GeometricMultigridSolver's V-cycle), wired up in the next round
-// once it can be measured.  Checked on the CPU by tests/test_fem_host.py (tests/cpu/fem_host_check.cpp).
+// pa_op_full_assemble produces (p = 1 levels: a few 10^5 rows); the solve half runs on the device (amg_solver.hpp:
+// AmgSolver = V-cycle over this hierarchy, AmsSolver = the two-space preconditioner for H(curl) built on it).
+// Checked on the CPU by tests/test_fem_host.py (tests/cpu/fem_host_check.cpp) and on the GPU by tests/test_ams_gpu.py.
 #pragma once
 
 #include <vector>
@@ -32,14 +32,18 @@ std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates);
 // Piecewise-constant prolongator with normalised columns: T^T T = I
 HostCsr TentativeProlongator(const std::vector<int> &aggregate, int num_aggregates);
 
-// P = (I - omega D^-1 A_F) T with the filtered matrix A_F (weak off-diagonal entries lumped onto the diagonal)
+// P = (I - omega D^-1 A_F) T with the filtered matrix A_F (weak off-diagonal entries lumped onto the diagonal).
+// omega <= 0: omega = 4 / (3 rho) with rho an estimate of the spectral radius of D^-1 A_F (a few power iterations; the
+// classical 2/3 is this value for rho = 2, which Poisson-like matrices have and Galerkin products of H(curl) matrices do not)
 HostCsr SmoothProlongator(const HostCsr &A, const HostCsr &T, double theta, double omega);
+// rows of the flagged dofs emptied: essential dofs taken out of a transfer matrix
+HostCsr DropRows(const HostCsr &A, const std::vector<char> &flag);
 
 struct Hierarchy {
   std::vector<HostCsr> A;  // A[0] the input, A[l+1] = P[l]^T A[l] P[l]
   std::vector<HostCsr> P;  // P[l]: level l+1 -> level l
 };
 // Levels are added until a level has at most `coarse_size` rows, stops coarsening, or `max_levels` is reached
-Hierarchy Setup(const HostCsr &A, int max_levels = 10, int coarse_size = 200, double theta = 0.08, double omega = 2.0 / 3.0);
+Hierarchy Setup(const HostCsr &A, int max_levels = 10, int coarse_size = 200, double theta = 0.08, double omega = 0.0);
 
 }  // namespace palace::amg

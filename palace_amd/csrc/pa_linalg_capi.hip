@@ -4,6 +4,7 @@
 #include "../../include/palace_amd_linalg.h"
 #include "comm.hpp"
 #include "complex.hpp"
+#include "amg_solver.hpp"
 #include "linalg.hpp"
 
 using namespace palace;
@@ -468,6 +469,98 @@ int pa_jacobi_create(pa_context *ctx, pa_par_op *A, pa_solver **S) {
     j->SetOperator(*A->op);
     s->solver = std::move(j);
     *S = s;
+  });
+}
+static AmgOptions amg_options(const pa_amg_options *o) {
+  AmgOptions a;
+  if (o) {
+    if (o->max_levels > 0) a.max_levels = o->max_levels;
+    if (o->coarse_size > 0) a.coarse_size = o->coarse_size;
+    if (o->smooth_order > 0) a.smooth_order = o->smooth_order;
+    if (o->theta > 0.0) a.theta = o->theta;
+  }
+  return a;
+}
+int pa_amg_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_ess, const pa_amg_options *opt, pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && A && S && (ess || n_ess == 0), "null argument");
+    PA_REQUIRE(!ctx->ctx.comm || pa_context_size(ctx) == 1, "the native AMG works on one rank's matrix");
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    s->solver = std::make_unique<AmgSolver>(ctx->ctx, DownloadCsr(*A, ess, n_ess), amg_options(opt));
+    *S = s;
+  });
+}
+int pa_ams_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_ess, int n_vert, const int32_t *G_rowptr,
+                  const int32_t *G_col, const double *G_val, const double *coords, int dim, const pa_ams_options *opt,
+                  pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && A && S && G_rowptr && G_col && G_val && coords && (ess || n_ess == 0), "null argument");
+    PA_REQUIRE(!ctx->ctx.comm || pa_context_size(ctx) == 1, "the native AMS works on one rank's matrix");
+    amg::HostCsr G;
+    G.nrows = A->nrows, G.ncols = n_vert;
+    G.rowptr.assign(G_rowptr, G_rowptr + A->nrows + 1);
+    G.col.assign(G_col, G_col + G.rowptr.back());
+    G.val.assign(G_val, G_val + G.rowptr.back());
+    for (int c : G.col) PA_REQUIRE(c >= 0 && c < n_vert, "discrete gradient column out of range");
+    std::vector<char> flag((size_t)A->nrows, 0);
+    for (int i = 0; i < n_ess; i++) {
+      PA_REQUIRE(ess[i] >= 0 && ess[i] < A->nrows, "essential dof out of range");
+      flag[ess[i]] = 1;
+    }
+    AmsOptions o;
+    if (opt) {
+      if (opt->cycle_it > 0) o.cycle_it = opt->cycle_it;
+      if (opt->smooth_order > 0) o.smooth_order = opt->smooth_order;
+      o.singular = opt->singular != 0;
+      o.amg = amg_options(&opt->amg);
+    }
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    s->solver = std::make_unique<AmsSolver>(ctx->ctx, DownloadCsr(*A, ess, n_ess), G, coords, dim, flag, o);
+    *S = s;
+  });
+}
+static const AmgSolver &amg_of(const pa_solver *S, int which) {
+  PA_REQUIRE(S && S->solver, "null solver");
+  if (which == 0) {
+    auto *a = dynamic_cast<const AmgSolver *>(S->solver.get());
+    PA_REQUIRE(a, "not an AMG solver");
+    return *a;
+  }
+  auto *m = dynamic_cast<const AmsSolver *>(S->solver.get());
+  PA_REQUIRE(m && (which == 1 || which == 2), "not an AMS solver / unknown component");
+  return which == 1 ? m->GradientSpaceSolver() : m->NodalSpaceSolver();
+}
+int pa_amg_num_levels(const pa_solver *S, int which, int *nlevels) {
+  return guarded([&] {
+    PA_REQUIRE(nlevels, "null argument");
+    *nlevels = amg_of(S, which).NumLevels();
+  });
+}
+int pa_amg_get_matrix(const pa_solver *S, int which, int level, int kind, int32_t *nrows, int32_t *ncols, int64_t *nnz,
+                      int32_t *rowptr, int32_t *col, double *val) {
+  return guarded([&] {
+    const AmgSolver &a = amg_of(S, which);
+    const amg::Hierarchy &h = a.HostHierarchy();
+    if (kind == 2) {
+      const int n = h.A.back().nrows;
+      PA_REQUIRE(!a.HostCoarseInverse().empty() || n == 0, "no direct solve on the last level of this hierarchy");
+      if (nrows) *nrows = n;
+      if (ncols) *ncols = n;
+      if (nnz) *nnz = (int64_t)n * n;
+      if (val) std::copy(a.HostCoarseInverse().begin(), a.HostCoarseInverse().end(), val);
+      return;
+    }
+    PA_REQUIRE(kind == 0 || kind == 1, "unknown matrix kind");
+    PA_REQUIRE(level >= 0 && level < (int)(kind == 0 ? h.A.size() : h.P.size()), "level out of range");
+    const amg::HostCsr &m = kind == 0 ? h.A[level] : h.P[level];
+    if (nrows) *nrows = m.nrows;
+    if (ncols) *ncols = m.ncols;
+    if (nnz) *nnz = m.nnz();
+    if (rowptr) std::copy(m.rowptr.begin(), m.rowptr.end(), rowptr);
+    if (col) std::copy(m.col.begin(), m.col.end(), col);
+    if (val) std::copy(m.val.begin(), m.val.end(), val);
   });
 }
 static void configure(IterativeSolver &k, pa_par_op *A, pa_solver *pc, double rel, double abs, int max_it) {

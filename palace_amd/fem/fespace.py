@@ -359,3 +359,57 @@ class NDHexBoundaryBlock:
                 grad[1, q] = np.outer(G2[qv], B2[qu]).ravel()
         w = np.outer(t.qw, t.qw).ravel()
         return interp, grad, w
+
+
+# ---- lowest-order auxiliary-space data (what the reference hands to HYPRE's AMS, linalg/ams.cpp:46-100) ------------------
+
+def lowest_order_gradient(h1, nd):
+    """Discrete gradient G [nd.ndofs x h1.ndofs] of the order-1 spaces on a hex mesh as a scipy CSR matrix: the edge dof of
+    the lowest-order Nedelec element is the difference of the nodal values at its end points, taken in the direction of the
+    reference edge and signed with the element's orientation of the dof (every element sharing an edge gives the same row)."""
+    import scipy.sparse as sp
+
+    assert h1.p == 1 and nd.p == 1
+    ne = nd.elem_dof_lex.shape[0]
+    rows, cols, vals = [], [], []
+
+    def lex(i, j, k):
+        return i + 2 * (j + 2 * k)
+
+    loc = []  # (local ND dof, local H1 tail, local H1 head), ND lexicographic order: component-major, first index fastest
+    for k in range(2):
+        for j in range(2):
+            loc.append((len(loc), lex(0, j, k), lex(1, j, k)))  # x-directed edges, dof (j, k)
+    for k in range(2):
+        for i in range(2):
+            loc.append((len(loc), lex(i, 0, k), lex(i, 1, k)))  # y-directed, dof (i, k)
+    for j in range(2):
+        for i in range(2):
+            loc.append((len(loc), lex(i, j, 0), lex(i, j, 1)))  # z-directed, dof (i, j)
+    sgn = nd.elem_sign_lex.astype(np.float64)
+    for l, a, b in loc:
+        r = nd.elem_dof_lex[:, l].astype(np.int64)
+        rows += [r, r]
+        cols += [h1.elem_dof_lex[:, a].astype(np.int64), h1.elem_dof_lex[:, b].astype(np.int64)]
+        vals += [-sgn[:, l], sgn[:, l]]
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    # one copy per (edge, vertex): all copies are equal
+    key = rows * h1.ndofs + cols
+    _, first = np.unique(key, return_index=True)
+    G = sp.csr_matrix((vals[first], (rows[first], cols[first])), shape=(nd.ndofs, h1.ndofs))
+    assert ne == 0 or (np.diff(G.indptr) == 2).all()
+    return G
+
+
+def vertex_coordinates(h1):
+    """Coordinates [h1.ndofs, 3] of the dofs of an order-1 H1 space (the mesh vertices in the space's numbering)."""
+    from .mesh import _CORNER_LATTICE
+
+    assert h1.p == 1
+    xyz = np.zeros((h1.ndofs, 3))
+    ec = h1.mesh.elem_coords()  # [ne, 27, 3], lexicographic 3 x 3 x 3 lattice
+    # corners of the lattice in the lexicographic order of the order-1 element: (i, j, k) -> lattice (2 i, 2 j, 2 k)
+    corner = [2 * i + 3 * (2 * j + 3 * 2 * k) for k in range(2) for j in range(2) for i in range(2)]
+    for m, c in enumerate(corner):
+        xyz[h1.elem_dof_lex[:, m]] = ec[:, c]
+    return xyz

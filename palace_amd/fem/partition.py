@@ -284,6 +284,14 @@ class SlabProblem:
             # a nonlinear preconditioner and costs the outer PCG 40 % more iterations; scripts/coarse_tune.py)
             if coarse == "chebyshev":
                 csolver = linalg.chebyshev(ctx, A[0], 4)
+            elif coarse == "ams":
+                # the native auxiliary-space solver on the assembled level (linalg/ams.cpp; ksp.cpp:166-186), one rank
+                from .fespace import H1HexSpace, lowest_order_gradient, vertex_coordinates
+
+                assert self.world == 1 and self.orders[0] == 1 and coarse_assembled, "AMS: one rank, assembled order-1 level"
+                h1_0 = H1HexSpace(self.mesh, 1)
+                csolver = linalg.ams(ctx, csr0, self.ess[0], lowest_order_gradient(h1_0, self.spaces[0]),
+                                     vertex_coordinates(h1_0))
             else:
                 csolver = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
             B = linalg.gmg(ctx, A, P, csolver, cheby_order=max(2 * self.p, 4), **aux)

@@ -339,6 +339,80 @@ def jacobi(ctx, A: ParOperator):
     return Solver(ctx, h, (A,))
 
 
+class _AmgOptions(C.Structure):
+    _fields_ = [("max_levels", C.c_int), ("coarse_size", C.c_int), ("smooth_order", C.c_int), ("theta", C.c_double)]
+
+
+class _AmsOptions(C.Structure):
+    _fields_ = [("cycle_it", C.c_int), ("smooth_order", C.c_int), ("singular", C.c_int), ("amg", _AmgOptions)]
+
+
+def amg(ctx, csr, ess_tdofs=(), max_levels=0, coarse_size=0, smooth_order=0, theta=0.0):
+    """Native algebraic multigrid V-cycle on an assembled matrix (`csr`: ceed.DeviceCsr), where the reference calls
+    BoomerAMG (linalg/amg.cpp:12-49).  Zero options: the library's defaults."""
+    ess = np.ascontiguousarray(ess_tdofs, dtype=np.int32)
+    opt = _AmgOptions(max_levels, coarse_size, smooth_order, theta)
+    h = C.c_void_p()
+    L = _L()
+    L.pa_amg_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _lib.check(L.pa_amg_create(ctx.handle, csr.handle, _ptr(ess), ess.size, C.byref(opt), C.byref(h)))
+    return Solver(ctx, h, (csr,))
+
+
+def ams(ctx, csr, ess_tdofs, G, coords, cycle_it=0, smooth_order=0, singular=False, amg_coarse_size=0, amg_smooth_order=0,
+        amg_theta=0.0):
+    """Native auxiliary-space (Hiptmair-Xu) preconditioner for an assembled lowest-order H(curl) matrix, where the reference
+    calls HYPRE's AMS (linalg/ams.cpp:18-224).  G: scipy CSR discrete gradient [edges x vertices], coords: [vertices, dim]."""
+    ess = np.ascontiguousarray(ess_tdofs, dtype=np.int32)
+    G = G.tocsr()
+    G.sort_indices()
+    rp = np.ascontiguousarray(G.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(G.indices, dtype=np.int32)
+    va = np.ascontiguousarray(G.data, dtype=np.float64)
+    xy = np.ascontiguousarray(coords, dtype=np.float64)
+    assert xy.shape[0] == G.shape[1]
+    opt = _AmsOptions(cycle_it, smooth_order, int(singular), _AmgOptions(0, amg_coarse_size, amg_smooth_order, amg_theta))
+    h = C.c_void_p()
+    L = _L()
+    L.pa_ams_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _lib.check(L.pa_ams_create(ctx.handle, csr.handle, _ptr(ess), ess.size, G.shape[1], _ptr(rp), _ptr(ci), _ptr(va),
+                               _ptr(xy), xy.shape[1], C.byref(opt), C.byref(h)))
+    return Solver(ctx, h, (csr,))
+
+
+def amg_hierarchy(solver, which=0):
+    """Host copies of an AMG hierarchy (which: 0 the solver itself, 1 / 2 the gradient- / nodal-space solver of an AMS solver):
+    (A_levels, P_levels, dense inverse of the last level or None) as scipy / numpy objects."""
+    import scipy.sparse as sp
+
+    L = _L()
+    L.pa_amg_get_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
+    nl = C.c_int()
+    _lib.check(L.pa_amg_num_levels(solver.handle, which, C.byref(nl)))
+
+    def get(level, kind):
+        nr, nc, nnz = C.c_int32(), C.c_int32(), C.c_int64()
+        _lib.check(L.pa_amg_get_matrix(solver.handle, which, level, kind, C.byref(nr), C.byref(nc), C.byref(nnz), None, None,
+                                       None))
+        if kind == 2:
+            val = np.empty(nnz.value)
+            _lib.check(L.pa_amg_get_matrix(solver.handle, which, level, kind, None, None, None, None, None, _ptr(val)))
+            return val.reshape(nr.value, nr.value)
+        rp, ci, va = np.empty(nr.value + 1, np.int32), np.empty(nnz.value, np.int32), np.empty(nnz.value)
+        _lib.check(L.pa_amg_get_matrix(solver.handle, which, level, kind, None, None, None, _ptr(rp), _ptr(ci), _ptr(va)))
+        return sp.csr_matrix((va, ci, rp), shape=(nr.value, nc.value))
+
+    A = [get(l, 0) for l in range(nl.value)]
+    P = [get(l, 1) for l in range(nl.value - 1)]
+    try:
+        cinv = get(0, 2)
+    except RuntimeError:
+        cinv = None
+    return A, P, cinv
+
+
 def cg(ctx, A: ParOperator, precond=None, rel_tol=0.0, abs_tol=0.0, max_it=100, print_level=0):
     h = C.c_void_p()
     _lib.check(_L().pa_cg_create(ctx.handle, A.handle, precond.handle if precond else None, rel_tol, abs_tol,
