@@ -44,6 +44,20 @@ typedef struct pa_local_group pa_local_group;
 int pa_local_group_create(int size, pa_local_group **group);
 void pa_local_group_destroy(pa_local_group *group);
 int pa_context_init_comm_local(pa_context *ctx, int rank, pa_local_group *group);
+/* Peer transport (palace_amd/csrc/comm.hpp): halo exchanges and global sums as direct stores into the other ranks' device
+ * memory (xGMI between the GPUs of a node) -- plain kernels on the context's stream, recordable in HIP graphs.  Every rank owns
+ * one arena; the caller gathers the 64-byte IPC handles of all ranks (MPI_Allgather in Palace: utils/communication.hpp) and
+ * hands the table to pa_comm_peer_connect.  pa_context_init_comm_peer makes a communicator that uses nothing else (no RCCL:
+ * also what lets two processes share one GPU); on an RCCL communicator (pa_context_init_comm) connecting the arenas moves the
+ * halo exchanges and the sums to the peer transport as well (PALACE_AMD_HALO=rccl keeps RCCL's send / receive groups).
+ * pa_comm_peer_check raises if a wait of the transport has timed out (a rank died, mismatched plans). */
+int pa_context_init_comm_peer(pa_context *ctx, int rank, int size);
+int pa_comm_peer_handle(pa_context *ctx, char *out64);
+int pa_comm_peer_connect(pa_context *ctx, const char *handles /* [size][64] */);
+int pa_comm_peer_disconnect(pa_context *ctx); /* RCCL communicators: back to send / receive groups and ncclAllReduce */
+int pa_comm_peer_ready(const pa_context *ctx);
+int pa_comm_peer_check(pa_context *ctx);
+int pa_halo_uses_peer(const pa_halo *halo);
 int pa_context_rank(const pa_context *ctx);
 int pa_context_size(const pa_context *ctx);
 /* in-place sum of n doubles (device memory) over all ranks */

@@ -81,6 +81,8 @@ __global__ void k_unpack_add(double *__restrict__ v, const int32_t *__restrict__
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[idx[i]] += buf[i];
 }
 inline int blocks(int n) { return std::max(1, std::min(1024, (n + 255) / 256)); }
+// blocks that touch a mailbox: few, walking it with a stride (each of them bumps a counter before the flags go up)
+inline int mail_blocks(int n) { return std::max(1, std::min(64, (n + 255) / 256)); }
 
 }  // namespace
 
@@ -100,6 +102,12 @@ Comm::Comm(int rank, LocalGroup &group) : rank_(rank), size_(group.Size()), loca
 
 Comm::~Comm() {
   if (nccl_) rccl().CommDestroy(nccl_);
+  if (d_one_) (void)hipFree(d_one_);
+  for (size_t r = 0; r < remote_.size(); r++)
+    if (remote_ipc_[r]) (void)hipIpcCloseMemHandle(remote_[r]);
+  if (d_remote_) (void)hipFree(d_remote_);
+  if (setup_stream_) (void)hipStreamDestroy(setup_stream_);
+  if (arena_) (void)hipFree(arena_);
 }
 
 void LocalGroup::Arrive() {
@@ -116,6 +124,7 @@ void LocalGroup::Arrive() {
 
 Halo::~Halo() {
   (void)hipFree(d_send_idx_), (void)hipFree(d_recv_idx_), (void)hipFree(d_sendbuf_), (void)hipFree(d_recvbuf_);
+  FreePeer();
 }
 
 Halo::Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int32_t *send_idx, const int *recv_off,
@@ -140,10 +149,16 @@ Halo::Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int3
   const int nbuf = std::max(nsend_, nrecv_);
   d_sendbuf_ = pa::dev_alloc<double>((size_t)nbuf);
   d_recvbuf_ = pa::dev_alloc<double>((size_t)nbuf);
+  // direct stores into the neighbours' mailboxes where the ranks' arenas are connected (PALACE_AMD_HALO=rccl: the RCCL
+  // send / receive groups -- or, in an in-process group, the host-barrier copies -- instead)
+  const char *mode = std::getenv("PALACE_AMD_HALO");
+  // (one rank whose plan names itself as the neighbour -- the per-rank cost proxy of scripts/time_halo_mult.py -- included)
+  if (comm.PeerReady() && (comm.Size() > 1 || nnbr > 0) && !(mode && std::string(mode) == "rccl")) PeerSetup(send_idx);
 }
 
 void Comm::AllReduceSum(double *d_buf, int n, hipStream_t s) {
   if (size_ == 1) return;
+  if (PeerReady() && n <= kMaxReduce && !std::getenv("PALACE_AMD_PEER_NO_REDUCE")) return PeerAllReduce(d_buf, n, s);
   if (local_) {  // values to the host, barrier, sum in rank order (the same on every rank), barrier, back to the device
     PA_REQUIRE(n <= LocalGroup::kMaxValues, "too many values for the in-process all-reduce");
     double *mine = local_->slots_.data() + (size_t)rank_ * LocalGroup::kMaxValues;
@@ -162,8 +177,11 @@ void Comm::AllReduceSum(double *d_buf, int n, hipStream_t s) {
 }
 
 void Comm::Barrier(hipStream_t s) {
-  static double *d_one = pa::dev_alloc<double>(1);
-  AllReduceSum(d_one, 1, s);
+  if (!d_one_) {
+    d_one_ = pa::dev_alloc<double>(1);
+    PA_HIP(hipMemset(d_one_, 0, sizeof(double)));
+  }
+  AllReduceSum(d_one_, 1, s);
   PA_HIP(hipStreamSynchronize(s));
 }
 
@@ -189,6 +207,7 @@ void Halo::ExchangeLocal(const double *sendbase, const std::vector<int> &send_of
 
 void Halo::Prolongate(double *d_lx, hipStream_t s) const {
   void *nccl_ = comm_->nccl_;
+  if (peer_) return PeerExchange(0, d_lx, s);
   if (nbr_.empty() && !comm_->local_) return;
   if (nsend_) hipLaunchKernelGGL(k_pack, dim3(blocks(nsend_)), dim3(256), 0, s, d_lx, d_send_idx_, nsend_, d_sendbuf_);
   if (comm_->local_) {
@@ -213,6 +232,7 @@ void Halo::Prolongate(double *d_lx, hipStream_t s) const {
 
 void Halo::RestrictAdd(double *d_ly, hipStream_t s) const {
   void *nccl_ = comm_->nccl_;
+  if (peer_) return PeerExchange(1, d_ly, s);
   if (nbr_.empty() && !comm_->local_) return;
   // roles reversed: ghosts are packed and sent to their owners
   if (nrecv_ && recv_first_ < 0)
@@ -242,6 +262,513 @@ void Halo::RestrictAdd(double *d_ly, hipStream_t s) const {
       hipLaunchKernelGGL(k_unpack_add, dim3(blocks(nr)), dim3(256), 0, s, d_ly, d_send_idx_ + send_off_[k], nr,
                          d_recvbuf_ + send_off_[k]);
   }
+  PA_HIP(hipGetLastError());
+}
+
+// ---- peer transport -------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr unsigned long long kDescMagic = 0x70616c6163654844ull;
+// arena layout (bytes): error word | all-reduce sequence | all-reduce flags [kMaxRanks] | all-reduce slots
+// [2][kMaxRanks][kMaxReduce] | halo descriptors [kMaxHalos] | mailboxes ...
+constexpr size_t kOffErr = 0, kOffArSeq = 8, kOffArFlags = 64;
+constexpr size_t kOffArSlots = 1024;
+constexpr size_t kArSlotBytes = 2ull * Comm::kMaxRanks * Comm::kMaxReduce * sizeof(double);
+constexpr size_t kOffDesc = ((kOffArSlots + kArSlotBytes + 4095) / 4096) * 4096;
+
+struct HaloDesc {
+  unsigned long long ready;  // kDescMagic once the owner has filled it
+  int nnbr, nrecv, nsend, pad;
+  int nbr[Comm::kMaxNbr], recv_off[Comm::kMaxNbr + 1], send_off[Comm::kMaxNbr + 1];
+  unsigned long long off_mb[2], off_local;  // byte offsets in the owner's arena: mailboxes of P / P^T, its PeerLocal
+};
+constexpr size_t kOffDynamic = ((kOffDesc + sizeof(HaloDesc) * Comm::kMaxHalos + 4095) / 4096) * 4096;
+
+// flags of one halo in its owner's arena (dir 0: P, owners -> ghosts; 1: P^T, ghosts -> owners)
+struct PeerLocal {
+  unsigned long long flag[2][Comm::kMaxNbr];  // written by neighbour k: the sequence number of the message it has delivered
+  unsigned long long ack[2][Comm::kMaxNbr];   // written by neighbour k: the last message of mine it has consumed
+};
+// my own counters: ordinary (cached) device memory -- a thousand blocks bumping a counter in uncached memory cost more than
+// the exchange itself (measured: 14 us per kernel)
+struct PeerCounters {
+  unsigned long long seq[2];      // my exchange counters (advanced on the device: graphs replay)
+  unsigned int done[2], cons[2];  // block counters of the send / consume kernels
+};
+// one neighbour as the kernels see it
+struct PeerNbr {
+  double *dst[2];               // where my piece starts in the neighbour's mailbox of direction d (buffer 0)
+  long long stride[2];          // doubles between the neighbour's two buffers
+  unsigned long long *flag[2];  // my slot of the neighbour's PeerLocal::flag / ack
+  unsigned long long *ack[2];
+  int off[2], n[2];             // my pieces: what I send in P (send list) / in P^T (ghosts)
+  int rn[2];                    // what I receive from it in P / P^T
+};
+
+constexpr long long kSpinTimeoutTicks = 500000000ll;  // wall_clock64 runs at 100 MHz: five seconds
+
+// Memory ordering without system-scope fences.  A release / acquire fence at system scope writes back / invalidates the
+// whole L2 -- with megabytes of freshly written vector data in it that costs more than the exchange (measured: every block
+// of the first version did one).  The arena is uncached (or fine-grained) memory and every access to it below is a relaxed
+// system-scope atomic, i.e. a plain load / store that bypasses the caches; what remains to be ordered is "my data stores
+// have been performed before the flag store is issued": s_waitcnt vmcnt(0) (stores are acknowledged once they are performed)
+// and the block counter in front of the flag stores.
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double ld_sys_f64(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ void st_sys_f64(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void stores_performed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// waits until *p >= want; gives up (and raises *err) after kSpinTimeoutTicks so that a lost message cannot hang the GPU
+__device__ bool spin_ge(const unsigned long long *p, unsigned long long want, unsigned long long *err) {
+  const long long t0 = wall_clock64();
+  while (ld_sys(p) < want) {
+    if (wall_clock64() - t0 > kSpinTimeoutTicks) {
+      st_sys(err, 1ull);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return true;
+}
+
+// true in the block that finishes last of `nblocks` (every one's stores have been performed by then)
+__device__ __forceinline__ bool last_block(unsigned int *counter, const unsigned int nblocks) {
+  __shared__ bool last;
+  stores_performed();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == nblocks - 1;
+  __syncthreads();
+  return last;
+}
+
+// every block waits (its first threads, one per neighbour) for the messages of exchange s of direction dir, and for the
+// acknowledgement of my message s - 1 (so that message s + 1 may overwrite its buffer)
+__device__ __forceinline__ void wait_exchange(const PeerNbr *nb, const int nnbr, const PeerLocal *L, const int dir,
+                                              const unsigned long long s, unsigned long long *err) {
+  for (int k = threadIdx.x; k < nnbr; k += blockDim.x) {
+    if (nb[k].rn[dir] > 0) spin_ge(&L->flag[dir][k], s, err);
+    if (nb[k].n[dir] > 0 && s > 0) spin_ge(&L->ack[dir][k], s - 1ull, err);
+  }
+  __syncthreads();
+}
+
+// (1) my pieces of direction `dir` into the neighbours' mailboxes, then their flags.  Source v[idx[i]] (idx == nullptr:
+// v[first + i]).  FUSED (P only, ParOperator::Mult): the vector is built on the way -- lx[i] = mask[i] & 1 ? 0 : x[i] for the
+// true dofs, the same masked values into the mailboxes (rap.cpp:207-216: tx = x, tx[ess] = 0, lx = P tx).
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_peer_send(const PeerNbr *__restrict__ nb, const int nnbr, PeerCounters *__restrict__ L,
+                                                    const int dir, const int total, const double *__restrict__ v,
+                                                    const int32_t *__restrict__ idx, const int first,
+                                                    const uint8_t *__restrict__ mask, double *__restrict__ lx, const int n_true,
+                                                    const int mblk) {
+  // Blocks [0, mblk) walk the mailbox entries (and are the only ones counted before the flags go up: a block counter that
+  // thousands of blocks bump costs 13 ns per block, measured -- more than the whole exchange); FUSED: the blocks behind
+  // them copy the true dofs, one per thread.
+  if (FUSED && (int)blockIdx.x >= mblk) {
+    const int d = ((int)blockIdx.x - mblk) * blockDim.x + threadIdx.x;
+    if (d < n_true) lx[d] = (mask[d] & 1) ? 0.0 : v[d];
+    return;
+  }
+  const unsigned long long s = L->seq[dir] + 1ull;
+  const int par = (int)(s & 1ull);
+  // four entries per thread and round, their loads side by side (a stride loop of dependent loads is latency-bound)
+  const int stride = mblk * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {
+    int d[4];
+    double val[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = i0 + j * stride;
+      d[j] = i < total ? (idx ? idx[i] : first + i) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) val[j] = d[j] >= 0 ? ((FUSED && (mask[d[j]] & 1)) ? 0.0 : v[d[j]]) : 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = i0 + j * stride;
+      if (i >= total) break;
+      int k = 0;
+      while (k + 1 < nnbr && i >= nb[k].off[dir] + nb[k].n[dir]) k++;
+      st_sys_f64(&nb[k].dst[dir][(long long)par * nb[k].stride[dir] + (i - nb[k].off[dir])], val[j]);
+    }
+  }
+  if (!last_block(&L->done[dir], mblk)) return;
+  for (int k = threadIdx.x; k < nnbr; k += blockDim.x)
+    if (nb[k].n[dir] > 0) st_sys(nb[k].flag[dir], s);
+  if (threadIdx.x == 0) {
+    L->done[dir] = 0;
+    L->seq[dir] = s;
+  }
+}
+
+// (2a) P: mailbox -> ghost slots, then the acknowledgements
+__global__ __launch_bounds__(256) void k_peer_consume_p(const PeerNbr *__restrict__ nb, const int nnbr,
+                                                         const PeerLocal *__restrict__ F, PeerCounters *__restrict__ L,
+                                                         const double *__restrict__ mb, const int nrecv, double *__restrict__ v,
+                                                         const int32_t *__restrict__ idx, const int first,
+                                                         unsigned long long *err) {
+  const unsigned long long s = L->seq[0];
+  wait_exchange(nb, nnbr, F, 0, s, err);
+  const double *src = mb + (size_t)(s & 1ull) * nrecv;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nrecv; i0 += 4 * stride) {
+    double val[4];
+    int d[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = i0 + j * stride;
+      val[j] = i < nrecv ? ld_sys_f64(&src[i]) : 0.0;
+      d[j] = i < nrecv ? (idx ? idx[i] : first + i) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (d[j] >= 0) v[d[j]] = val[j];
+  }
+  if (!last_block(&L->cons[0], gridDim.x)) return;
+  for (int k = threadIdx.x; k < nnbr; k += blockDim.x)
+    if (nb[k].rn[0] > 0) st_sys(nb[k].ack[0], s);
+  if (threadIdx.x == 0) L->cons[0] = 0;
+}
+
+// (2b) P^T: every owned dof that has sharers adds their contributions, neighbour by neighbour in plan order (fixed summation
+// order: the result does not depend on arrival times).  FUSED (ParOperator::Mult): the result goes to y with ParOperator's
+// essential rows fixed on the way (rap.cpp:222-233): y[i] = ess ? (x[i] | 0) : ly[i] + contributions, mask bit 1 = essential,
+// bit 2 = the dof has sharers (its row of the contribution lists is found by bisection)
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_peer_consume_r(const PeerNbr *__restrict__ nb, const int nnbr,
+                                                         const PeerLocal *__restrict__ F, PeerCounters *__restrict__ L,
+                                                         const double *__restrict__ mb, const int nsend, double *__restrict__ v,
+                                                         const int ndof, const int4 *__restrict__ rinfo,
+                                                         const int32_t *__restrict__ rptr, const int32_t *__restrict__ rpos,
+                                                         unsigned long long *err, const uint8_t *__restrict__ mask,
+                                                         const double *__restrict__ x, const int diag_one, double *__restrict__ y,
+                                                         const int n_true, const int sblk) {
+  // Blocks [0, sblk) own the dofs with sharers (they wait for the messages, read the mailbox and acknowledge); FUSED: the
+  // blocks behind them write every other true dof, one per thread, without waiting for anybody.
+  if (FUSED && (int)blockIdx.x >= sblk) {
+    const int i = ((int)blockIdx.x - sblk) * blockDim.x + threadIdx.x;
+    if (i < n_true) {
+      const uint8_t m = mask[i];
+      if (!(m & 2)) y[i] = (m & 1) ? (diag_one ? x[i] : 0.0) : v[i];
+    }
+    return;
+  }
+  const unsigned long long s = L->seq[1];
+  wait_exchange(nb, nnbr, F, 1, s, err);
+  const double *src = mb + (size_t)(s & 1ull) * nsend;
+  // rinfo[i] = {dof, position of its first contribution, of its second one or -1, first entry of the others in rpos or -1}:
+  // one 16-byte load, then the vector entry and the first two contributions side by side (the usual case: one or two sharers)
+  const int stride = sblk * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < ndof; i0 += 2 * stride) {
+    int4 info[2];
+    double sum[2], c0[2], c1[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int i = i0 + j * stride;
+      info[j] = i < ndof ? rinfo[i] : make_int4(-1, -1, -1, -1);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      sum[j] = info[j].x >= 0 ? v[info[j].x] : 0.0;
+      c0[j] = info[j].y >= 0 ? ld_sys_f64(&src[info[j].y]) : 0.0;
+      c1[j] = info[j].z >= 0 ? ld_sys_f64(&src[info[j].z]) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int i = i0 + j * stride, d = info[j].x;
+      if (d < 0) break;
+      double t = sum[j] + c0[j];
+      if (info[j].z >= 0) t += c1[j];
+      if (info[j].w >= 0)
+        for (int a = info[j].w; a < rptr[i + 1]; a++) t += ld_sys_f64(&src[rpos[a]]);
+      if (FUSED)
+        y[d] = (mask[d] & 1) ? (diag_one ? x[d] : 0.0) : t;
+      else
+        v[d] = t;
+    }
+  }
+  if (!last_block(&L->cons[1], sblk)) return;
+  for (int k = threadIdx.x; k < nnbr; k += blockDim.x)
+    if (nb[k].rn[1] > 0) st_sys(nb[k].ack[1], s);
+  if (threadIdx.x == 0) L->cons[1] = 0;
+}
+
+// global sum: my values into everybody's slot of me, flags; then wait for everybody and add in rank order (the same result,
+// bit for bit, on every rank).  Double-buffered: a rank can be one sum ahead of another, never two (it needs the other's flag
+// of the sum in between).
+__global__ void k_ar_send(char *const *__restrict__ remote, const int me, const int size, char *__restrict__ mine,
+                          const double *__restrict__ vals, const int n) {
+  unsigned long long *seq = reinterpret_cast<unsigned long long *>(mine + kOffArSeq);
+  const unsigned long long s = *seq + 1ull;
+  const size_t par = (size_t)(s & 1ull);
+  for (int t = threadIdx.x; t < size * n; t += blockDim.x) {
+    const int r = t / n, i = t - r * n;
+    double *slots = reinterpret_cast<double *>(remote[r] + kOffArSlots);
+    st_sys_f64(&slots[(par * Comm::kMaxRanks + me) * Comm::kMaxReduce + i], vals[i]);
+  }
+  stores_performed();
+  __syncthreads();
+  for (int r = threadIdx.x; r < size; r += blockDim.x)
+    st_sys(reinterpret_cast<unsigned long long *>(remote[r] + kOffArFlags) + me, s);
+  if (threadIdx.x == 0) *seq = s;
+}
+__global__ void k_ar_sum(char *__restrict__ mine, const int size, const int n, double *__restrict__ out) {
+  const unsigned long long s = *reinterpret_cast<const unsigned long long *>(mine + kOffArSeq);
+  unsigned long long *err = reinterpret_cast<unsigned long long *>(mine + kOffErr);
+  const unsigned long long *flags = reinterpret_cast<const unsigned long long *>(mine + kOffArFlags);
+  for (int r = threadIdx.x; r < size; r += blockDim.x) spin_ge(&flags[r], s, err);
+  __syncthreads();
+  const double *slots = reinterpret_cast<const double *>(mine + kOffArSlots) + (size_t)(s & 1ull) * Comm::kMaxRanks * Comm::kMaxReduce;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double sum = 0.0;
+    for (int r = 0; r < size; r++) sum += ld_sys_f64(&slots[(size_t)r * Comm::kMaxReduce + i]);
+    out[i] = sum;
+  }
+}
+
+}  // namespace
+
+void Comm::AllocArena() {
+  const char *mb = std::getenv("PALACE_AMD_PEER_ARENA_MB");
+  arena_bytes_ = (size_t)(mb ? std::max(8, atoi(mb)) : 256) << 20;
+  PA_REQUIRE(size_ <= kMaxRanks, "too many ranks for the peer transport");
+  // flags polled by one device while another one writes them: memory that is not cached incoherently
+  const char *mode = std::getenv("PALACE_AMD_PEER_MEM");
+  const std::string m = mode ? mode : "uncached";
+  void *p = nullptr;
+  hipError_t rc = hipErrorUnknown;
+  if (m == "uncached") rc = hipExtMallocWithFlags(&p, arena_bytes_, hipDeviceMallocUncached);
+  if (rc != hipSuccess && m != "plain") rc = hipExtMallocWithFlags(&p, arena_bytes_, hipDeviceMallocFinegrained);
+  if (rc != hipSuccess) {
+    (void)hipGetLastError();
+    PA_HIP(hipMalloc(&p, arena_bytes_));
+  }
+  arena_ = static_cast<char *>(p);
+  PA_HIP(hipMemset(arena_, 0, kOffDynamic));
+  arena_used_ = kOffDynamic;
+  PA_HIP(hipStreamCreateWithFlags(&setup_stream_, hipStreamNonBlocking));
+}
+
+Comm::Comm(int rank, int size) : rank_(rank), size_(size) {
+  PA_REQUIRE(size >= 1 && rank >= 0 && rank < size, "bad communicator arguments");
+  AllocArena();
+  if (size == 1) {
+    remote_.assign(1, arena_), remote_ipc_.assign(1, 0);
+    d_remote_ = pa::dev_upload(remote_.data(), 1);
+  }
+}
+
+void Comm::PeerHandle(char *out) {
+  if (!arena_) AllocArena();
+  static_assert(sizeof(hipIpcMemHandle_t) == kPeerHandleBytes, "IPC handle size");
+  hipIpcMemHandle_t h;
+  PA_HIP(hipIpcGetMemHandle(&h, arena_));
+  std::memcpy(out, &h, sizeof(h));
+}
+
+void Comm::PeerConnect(const char *handles) {
+  PA_REQUIRE(arena_ && handles, "peer transport: no arena");
+  PA_REQUIRE(remote_.empty() || size_ == 1, "peer transport is already connected");
+  remote_.assign((size_t)size_, nullptr), remote_ipc_.assign((size_t)size_, 0);
+  for (int r = 0; r < size_; r++) {
+    if (r == rank_) {
+      remote_[r] = arena_;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + (size_t)r * kPeerHandleBytes, sizeof(h));
+    void *p = nullptr;
+    PA_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    remote_[r] = static_cast<char *>(p), remote_ipc_[r] = 1;
+  }
+  if (d_remote_) (void)hipFree(d_remote_);
+  d_remote_ = pa::dev_upload(remote_.data(), remote_.size());
+}
+
+void Comm::PeerDisconnect() {
+  PA_REQUIRE(nccl_ || size_ == 1, "a communicator without RCCL cannot give up the peer transport");
+  for (size_t r = 0; r < remote_.size(); r++)
+    if (remote_ipc_[r]) (void)hipIpcCloseMemHandle(remote_[r]);
+  remote_.clear(), remote_ipc_.clear();
+}
+
+size_t Comm::PeerAlloc(size_t bytes) {
+  const size_t off = (arena_used_ + 255) & ~size_t(255);
+  PA_REQUIRE(off + bytes <= arena_bytes_, "peer arena exhausted (PALACE_AMD_PEER_ARENA_MB)");
+  arena_used_ = off + bytes;
+  PA_HIP(hipMemset(arena_ + off, 0, bytes));
+  return off;
+}
+
+bool Comm::GraphSafe() const {
+  if (size_ == 1) return true;
+  const char *mode = std::getenv("PALACE_AMD_HALO");
+  return PeerReady() && !(mode && std::string(mode) == "rccl") && !std::getenv("PALACE_AMD_PEER_NO_REDUCE");
+}
+
+void Comm::PeerCheck(hipStream_t s) {
+  if (!arena_) return;
+  unsigned long long e = 0;
+  PA_HIP(hipMemcpyAsync(&e, arena_ + kOffErr, sizeof(e), hipMemcpyDeviceToHost, s));
+  PA_HIP(hipStreamSynchronize(s));
+  if (e) {
+    PA_HIP(hipMemsetAsync(arena_ + kOffErr, 0, sizeof(e), s));
+    throw pa::Error("peer transport: a wait for another rank's message timed out (a rank stopped, or the plans of two "
+                    "ranks do not match)");
+  }
+}
+
+void Comm::PeerAllReduce(double *d_buf, int n, hipStream_t s) {
+  PA_REQUIRE(n <= kMaxReduce, "too many values for the peer all-reduce");
+  hipLaunchKernelGGL(k_ar_send, dim3(1), dim3(256), 0, s, d_remote_, rank_, size_, arena_, d_buf, n);
+  hipLaunchKernelGGL(k_ar_sum, dim3(1), dim3(256), 0, s, arena_, size_, n, d_buf);
+  PA_HIP(hipGetLastError());
+}
+
+struct Halo::PeerPlan {
+  PeerNbr *d_nbr = nullptr;
+  PeerLocal *local = nullptr;       // in the arena
+  PeerCounters *counters = nullptr;  // ordinary device memory
+  double *mb[2] = {nullptr, nullptr};
+  int nnbr = 0, n_rdof = 0;
+  int4 *d_rinfo = nullptr;
+  int32_t *d_rptr = nullptr, *d_rpos = nullptr;
+  unsigned long long *d_err = nullptr;
+};
+
+void Halo::PeerSetup(const int32_t *send_idx) {
+  Comm &c = *comm_;
+  const int nn = (int)nbr_.size();
+  PA_REQUIRE(nn <= Comm::kMaxNbr, "too many neighbours for the peer transport");
+  const int id = c.next_halo_++;
+  PA_REQUIRE(id < Comm::kMaxHalos, "too many halo plans for the peer transport");
+  HaloDesc d;
+  std::memset(&d, 0, sizeof(d));
+  d.nnbr = nn, d.nrecv = nrecv_, d.nsend = nsend_;
+  for (int k = 0; k < nn; k++) d.nbr[k] = nbr_[k];
+  for (int k = 0; k <= nn; k++) d.recv_off[k] = recv_off_[k], d.send_off[k] = send_off_[k];
+  d.off_mb[0] = c.PeerAlloc(sizeof(double) * 2 * (size_t)std::max(1, nrecv_));
+  d.off_mb[1] = c.PeerAlloc(sizeof(double) * 2 * (size_t)std::max(1, nsend_));
+  d.off_local = c.PeerAlloc(sizeof(PeerLocal));
+  d.ready = kDescMagic;
+  PA_HIP(hipMemcpy(c.arena_ + kOffDesc + sizeof(HaloDesc) * (size_t)id, &d, sizeof(d), hipMemcpyHostToDevice));
+  c.Barrier(c.setup_stream_);  // every rank has published plan `id`
+  auto *pp = new PeerPlan;
+  pp->nnbr = nn;
+  pp->local = reinterpret_cast<PeerLocal *>(c.arena_ + d.off_local);
+  pp->counters = pa::dev_alloc<PeerCounters>(1);
+  PA_HIP(hipMemset(pp->counters, 0, sizeof(PeerCounters)));
+  pp->mb[0] = reinterpret_cast<double *>(c.arena_ + d.off_mb[0]);
+  pp->mb[1] = reinterpret_cast<double *>(c.arena_ + d.off_mb[1]);
+  pp->d_err = reinterpret_cast<unsigned long long *>(c.arena_ + kOffErr);
+  std::vector<PeerNbr> nb((size_t)nn);
+  for (int k = 0; k < nn; k++) {
+    const int r = nbr_[k];
+    HaloDesc rd;
+    PA_HIP(hipMemcpy(&rd, c.remote_[r] + kOffDesc + sizeof(HaloDesc) * (size_t)id, sizeof(rd), hipMemcpyDeviceToHost));
+    PA_REQUIRE(rd.ready == kDescMagic, "peer transport: a neighbour has not published its halo plan");
+    int j = 0;
+    while (j < rd.nnbr && rd.nbr[j] != c.rank_) j++;
+    const int ns = send_off_[k + 1] - send_off_[k], nr = recv_off_[k + 1] - recv_off_[k];
+    PA_REQUIRE(j < rd.nnbr && rd.recv_off[j + 1] - rd.recv_off[j] == ns && rd.send_off[j + 1] - rd.send_off[j] == nr,
+               "halo plans of two ranks do not match");
+    PeerNbr &q = nb[k];
+    char *rb = c.remote_[r];
+    PeerLocal *rl = reinterpret_cast<PeerLocal *>(rb + rd.off_local);
+    q.dst[0] = reinterpret_cast<double *>(rb + rd.off_mb[0]) + rd.recv_off[j], q.stride[0] = rd.nrecv;
+    q.dst[1] = reinterpret_cast<double *>(rb + rd.off_mb[1]) + rd.send_off[j], q.stride[1] = rd.nsend;
+    for (int dir = 0; dir < 2; dir++) q.flag[dir] = &rl->flag[dir][j], q.ack[dir] = &rl->ack[dir][j];
+    q.off[0] = send_off_[k], q.n[0] = ns, q.rn[0] = nr;
+    q.off[1] = recv_off_[k], q.n[1] = nr, q.rn[1] = ns;
+  }
+  pp->d_nbr = pa::dev_upload(nb.data(), nb.size());
+  // P^T: the owned dofs with sharers and the positions of their contributions in the mailbox, neighbour-major
+  {
+    std::vector<int32_t> order((size_t)nsend_);
+    for (int i = 0; i < nsend_; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return send_idx[a] < send_idx[b]; });
+    std::vector<int32_t> rdof, rptr(1, 0), rpos;
+    for (int i = 0; i < nsend_; i++) {
+      if (i == 0 || send_idx[order[i]] != send_idx[order[i - 1]]) {
+        if (i) rptr.push_back((int32_t)rpos.size());
+        rdof.push_back(send_idx[order[i]]);
+      }
+      rpos.push_back(order[i]);
+    }
+    if (nsend_) rptr.push_back((int32_t)rpos.size());
+    pp->n_rdof = (int)rdof.size();
+    shared_owned_.assign(rdof.begin(), rdof.end());
+    std::vector<int4> rinfo(rdof.size());
+    for (size_t i = 0; i < rdof.size(); i++) {
+      const int b = rptr[i], e = rptr[i + 1];
+      rinfo[i] = make_int4(rdof[i], rpos[b], e - b > 1 ? rpos[b + 1] : -1, e - b > 2 ? b + 2 : -1);
+    }
+    pp->d_rinfo = pa::dev_upload(rinfo.data(), rinfo.size());
+    pp->d_rptr = pa::dev_upload(rptr.data(), rptr.size());
+    pp->d_rpos = pa::dev_upload(rpos.data(), rpos.size());
+  }
+  peer_ = pp;
+}
+
+void Halo::FreePeer() {
+  if (!peer_) return;
+  (void)hipFree(peer_->counters), (void)hipFree(peer_->d_nbr), (void)hipFree(peer_->d_rinfo), (void)hipFree(peer_->d_rptr), (void)hipFree(peer_->d_rpos);
+  delete peer_;
+  peer_ = nullptr;
+}
+
+// dir 0: P (owners -> ghosts), 1: P^T (ghosts -> owners, added)
+void Halo::PeerExchange(int dir, double *d_v, hipStream_t s) const {
+  const PeerPlan &p = *peer_;
+  const int total = dir == 0 ? nsend_ : nrecv_;
+  const int32_t *sidx = dir == 0 ? d_send_idx_ : (recv_first_ >= 0 ? nullptr : d_recv_idx_);
+  const int mb = mail_blocks(total);
+  hipLaunchKernelGGL(k_peer_send<false>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, dir, total, d_v, sidx,
+                     dir == 0 ? 0 : recv_first_, nullptr, nullptr, 0, mb);
+  if (dir == 0) {
+    hipLaunchKernelGGL(k_peer_consume_p, dim3(mail_blocks(nrecv_)), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[0],
+                       nrecv_, d_v, recv_first_ >= 0 ? nullptr : d_recv_idx_, recv_first_, p.d_err);
+  } else {
+    const int sb = mail_blocks(p.n_rdof);
+    hipLaunchKernelGGL(k_peer_consume_r<false>, dim3(sb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[1], nsend_,
+                       d_v, p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, nullptr, nullptr, 0, nullptr, 0, sb);
+  }
+  PA_HIP(hipGetLastError());
+}
+
+// The two exchanges of ParOperator::Mult with the vector copies around them folded in (peer transport only):
+//   lx = P (x with the essential entries zeroed)                 one send kernel + the ghost unpack
+//   y  = P^T ly with the essential rows set to x | 0             one send kernel + one kernel for everything else
+// mask [n_true]: bit 1 essential, bit 2 owned dof with sharers (SharedOwnedDofs()).
+void Halo::ProlongateFused(const double *d_x, const uint8_t *d_mask, int n_true, double *d_lx, hipStream_t s) const {
+  const PeerPlan &p = *peer_;
+  const int mb = mail_blocks(nsend_);
+  hipLaunchKernelGGL(k_peer_send<true>, dim3(mb + (n_true + 255) / 256), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 0, nsend_,
+                     d_x, d_send_idx_, 0, d_mask, d_lx, n_true, mb);
+  hipLaunchKernelGGL(k_peer_consume_p, dim3(mail_blocks(nrecv_)), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[0],
+                     nrecv_, d_lx, recv_first_ >= 0 ? nullptr : d_recv_idx_, recv_first_, p.d_err);
+  PA_HIP(hipGetLastError());
+}
+void Halo::RestrictAddFused(const double *d_ly, const double *d_x, const uint8_t *d_mask, bool diag_one, int n_true, double *d_y,
+                            hipStream_t s) const {
+  const PeerPlan &p = *peer_;
+  const int mb = mail_blocks(nrecv_), sb = mail_blocks(p.n_rdof);
+  hipLaunchKernelGGL(k_peer_send<false>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 1, nrecv_, d_ly,
+                     recv_first_ >= 0 ? nullptr : d_recv_idx_, recv_first_, nullptr, nullptr, 0, mb);
+  hipLaunchKernelGGL(k_peer_consume_r<true>, dim3(sb + (n_true + 255) / 256), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local,
+                     p.counters, p.mb[1], nsend_, const_cast<double *>(d_ly), p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err,
+                     d_mask, d_x, diag_one ? 1 : 0, d_y, n_true, sb);
   PA_HIP(hipGetLastError());
 }
 

@@ -9,6 +9,14 @@
 // ghost slots of the sharers; P^T adds ghost contributions back onto the owners.  Both are sparse
 // neighbour exchanges: every pair of GPUs has its own xGMI link, so all neighbours are served
 // concurrently inside one ncclGroup (no ring, no staging through the host).
+//
+// Peer transport (default where it can be set up): every rank owns one device arena that the other ranks of the node map
+// into their address space (hipIpcGetMemHandle / hipIpcOpenMemHandle).  A halo exchange is
+// then three plain kernels on the caller's stream -- (1) pack my pieces straight into the neighbours' mailboxes (stores that
+// travel over xGMI) and raise their flags, (2) one small block that waits for my flags, (3) unpack -- and a global sum is two:
+// no RCCL call, nothing the host has to order, so the sequence can be recorded in a HIP graph like the one-rank solvers'.
+// Mailboxes are double-buffered and acknowledged; sequence numbers live in device memory (a replayed graph advances them);
+// every wait loop gives up after a few seconds and raises an error word instead of hanging the GPU.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -55,15 +63,44 @@ class Comm {
   void *nccl_ = nullptr;  // ncclComm_t
   LocalGroup *local_ = nullptr;
   friend class Halo;
+  // ---- peer transport ----
+  char *arena_ = nullptr;              // my arena (device memory the other ranks map)
+  size_t arena_bytes_ = 0, arena_used_ = 0;
+  std::vector<char *> remote_;         // [size] arena of rank r as mapped here (remote_[rank_] == arena_); empty: not connected
+  std::vector<char> remote_ipc_;       // [size] 1: opened with hipIpcOpenMemHandle (to be closed)
+  int next_halo_ = 0;
+  char **d_remote_ = nullptr;          // device copy of remote_
+  double *d_one_ = nullptr;            // Barrier's operand (per communicator)
+  hipStream_t setup_stream_ = nullptr; // the transport's own stream for set-up barriers (never the shared null stream:
+                                       // the rank threads of an in-process group would queue behind each other's waits)
+  void AllocArena();
+  void PeerAllReduce(double *d_buf, int n, hipStream_t s);
 
 public:
   static constexpr int kUniqueIdBytes = 128;
+  static constexpr int kPeerHandleBytes = 64;  // sizeof(hipIpcMemHandle_t)
+  static constexpr int kMaxRanks = 64, kMaxReduce = 512, kMaxHalos = 512, kMaxNbr = 32;
   static void GetUniqueId(char *out);
   Comm(int rank, int size, const char *unique_id);
   Comm(int rank, LocalGroup &group);  // rank of an in-process group (see LocalGroup)
+  // Communicator without RCCL: the peer transport carries the halo exchanges and the global sums.  The caller gathers
+  // the arena handles of all ranks (PeerHandle; with MPI in Palace, torch.distributed in the tests) and hands them to
+  // PeerConnect -- also what lets two processes share ONE GPU, which RCCL refuses.
+  Comm(int rank, int size);
   ~Comm();
   int Rank() const { return rank_; }
   int Size() const { return size_; }
+  void PeerHandle(char *out64);
+  void PeerConnect(const char *handles);  // [size][kPeerHandleBytes]
+  bool PeerReady() const { return !remote_.empty(); }
+  void PeerDisconnect();  // back to RCCL (a failed self-test of the transport on this machine)
+  // halo exchanges and global sums are plain kernels on the caller's stream: sequences containing them can be recorded
+  bool GraphSafe() const;
+  // raises if a wait loop of the peer transport has timed out since the last check (waits for the stream)
+  void PeerCheck(hipStream_t s);
+  // offset of a fresh piece of my arena
+  size_t PeerAlloc(size_t bytes);
+  char *PeerBase(int r) const { return remote_[r]; }
   // in-place sum over ranks of n doubles in device memory (Mpi::GlobalSum)
   void AllReduceSum(double *d_buf, int n, hipStream_t s);
   void Barrier(hipStream_t s);
@@ -85,8 +122,23 @@ class Halo {
   void ExchangeLocal(const double *sendbase, const std::vector<int> &send_off, double *recvbase, const std::vector<int> &recv_off,
                      hipStream_t s) const;
   std::vector<int32_t> iface_;  // every local dof that is sent or received (host copy, sorted, unique)
+  // peer transport (Comm::PeerReady): device-side plan of this halo, see comm.hip
+  struct PeerPlan;
+  PeerPlan *peer_ = nullptr;
+  void PeerSetup(const int32_t *send_idx);
+  void FreePeer();
+  void PeerExchange(int dir, double *d_v, hipStream_t s) const;
+
+  std::vector<int32_t> shared_owned_;  // peer transport: the owned dofs that have sharers (sorted)
 
 public:
+  bool UsesPeerTransport() const { return peer_ != nullptr; }
+  // peer transport: ParOperator::Mult's two exchanges with the copies x -> lx / ly -> y and the essential-dof handling
+  // folded into their kernels (see comm.hip); mask [n_true]: bit 1 essential, bit 2 owned dof with sharers
+  const std::vector<int32_t> &SharedOwnedDofs() const { return shared_owned_; }
+  void ProlongateFused(const double *d_x, const uint8_t *d_mask, int n_true, double *d_lx, hipStream_t s) const;
+  void RestrictAddFused(const double *d_ly, const double *d_x, const uint8_t *d_mask, bool diag_one, int n_true, double *d_y,
+                        hipStream_t s) const;
   Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int32_t *send_idx, const int *recv_off,
        const int32_t *recv_idx);
   ~Halo();

@@ -133,7 +133,8 @@ bool StreamGraph::Capture(const Context &c, const std::function<void()> &body) {
 }
 void StreamGraph::Run(const Context &c, const std::vector<const void *> &key, const std::function<void()> &body) {
   if (!c.stream) return body();  // the null stream cannot be recorded
-  if (c.comm && c.comm->Size() > 1) return body();  // collectives stay outside recordings (RCCL inside a capture is untested here)
+  // RCCL calls stay outside recordings (untested inside a capture here); the peer transport is plain kernels
+  if (c.comm && !c.comm->GraphSafe()) return body();
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(c.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return body();  // part of an enclosing recording (the V-cycle inside a PCG iteration)
@@ -898,12 +899,12 @@ namespace {
 // multi-rank ParOperator::Mult: tx = x with the essential entries zeroed; y = ly with the essential rows set to x or 0
 __global__ void k_copy_masked(const double *__restrict__ x, const uint8_t *__restrict__ mask, double *__restrict__ out, const int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = mask[i] ? 0.0 : x[i];
+  if (i < n) out[i] = (mask[i] & 1) ? 0.0 : x[i];
 }
 __global__ void k_copy_fix(const double *__restrict__ ly, const double *__restrict__ x, const uint8_t *__restrict__ mask,
                            const int one, double *__restrict__ y, const int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] = mask[i] ? (one ? x[i] : 0.0) : ly[i];
+  if (i < n) y[i] = (mask[i] & 1) ? (one ? x[i] : 0.0) : ly[i];
 }
 }  // namespace
 
@@ -929,9 +930,12 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
       if (st >= 0) A_fused_ = c;
     }
   }
-  if (halo && n_ess) {
+  if (halo && (n_ess || halo->UsesPeerTransport())) {
+    // one byte per true dof: bit 1 essential, bit 2 (peer transport) an owned dof other ranks hold as a ghost
     std::vector<uint8_t> mask((size_t)n_true, 0);
     for (int i = 0; i < n_ess; i++) mask[ess_host[i]] = 1;
+    for (const int32_t d : halo->SharedOwnedDofs())
+      if (d < n_true) mask[d] |= 2;
     d_ess_mask_ = pa::dev_upload(mask.data(), mask.size(), ctx.stream);
   }
   if (halo) {
@@ -973,6 +977,13 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
   }
   if (A_csr_ && x.Data() != y.Data()) {
     A_csr_->Mult(x, y);  // essential rows / columns live in the matrix
+    return;
+  }
+  if (halo_ && halo_->UsesPeerTransport() && d_ess_mask_ && x.Data() != y.Data() && !A_overlap_) {
+    // peer transport: the copies x -> lx, ly -> y and the essential-dof handling ride in the exchange kernels
+    halo_->ProlongateFused(x.Data(), d_ess_mask_, n_true_, lx_.Data(), c.stream);
+    A_->Mult(lx_, ly_);
+    halo_->RestrictAddFused(ly_.Data(), x.Data(), d_ess_mask_, policy_ == DiagonalPolicy::DIAG_ONE, n_true_, y.Data(), c.stream);
     return;
   }
   Vector tx(lx_.Data(), n_true_);

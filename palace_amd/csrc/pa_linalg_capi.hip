@@ -124,6 +124,38 @@ int pa_context_init_comm_local(pa_context *ctx, int rank, pa_local_group *g) {
     ctx->ctx.comm = ctx->comm.get();
   });
 }
+int pa_context_init_comm_peer(pa_context *ctx, int rank, int size) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && size >= 1 && rank >= 0 && rank < size, "bad communicator arguments");
+    ctx->comm = std::make_unique<Comm>(rank, size);
+    ctx->ctx.comm = ctx->comm.get();
+  });
+}
+int pa_comm_peer_handle(pa_context *ctx, char *out64) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && ctx->comm && out64, "no communicator");
+    ctx->comm->PeerHandle(out64);
+  });
+}
+int pa_comm_peer_connect(pa_context *ctx, const char *handles) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && ctx->comm && handles, "no communicator");
+    ctx->comm->PeerConnect(handles);
+  });
+}
+int pa_comm_peer_disconnect(pa_context *ctx) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && ctx->comm, "no communicator");
+    ctx->comm->PeerDisconnect();
+  });
+}
+int pa_comm_peer_ready(const pa_context *ctx) { return ctx && ctx->comm && ctx->comm->PeerReady() ? 1 : 0; }
+int pa_comm_peer_check(pa_context *ctx) {
+  return guarded([&] {
+    if (ctx && ctx->comm) ctx->comm->PeerCheck(ctx->ctx.stream);
+  });
+}
+int pa_halo_uses_peer(const pa_halo *halo) { return halo && halo->halo->UsesPeerTransport() ? 1 : 0; }
 int pa_context_rank(const pa_context *ctx) { return ctx && ctx->comm ? ctx->comm->Rank() : 0; }
 int pa_context_size(const pa_context *ctx) { return ctx && ctx->comm ? ctx->comm->Size() : 1; }
 int pa_allreduce_sum(pa_context *ctx, double *buf, int n) {

@@ -4,6 +4,7 @@ multigrid and the p-prolongation, all on float64 CUDA tensors owned by torch."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -69,11 +70,99 @@ class Context:
         raw = bytes(t.cpu().numpy().tobytes())
         _lib.check(L.pa_context_init_comm(self.handle, rank, size, raw))
         self.rank, self.size = rank, size
+        # halo exchanges and sums over the peer transport (direct xGMI stores, recordable in HIP graphs) unless
+        # PALACE_AMD_HALO=rccl asks for RCCL's send / receive groups; RCCL stays the fallback if the arenas cannot be mapped
+        if size > 1 and os.environ.get("PALACE_AMD_HALO", "peer") != "rccl":
+            try:
+                self._peer_connect_over_torch_distributed("cuda")
+                self._peer_self_test()
+            except Exception as exc:  # noqa: BLE001
+                import sys
+                print(f"palace_amd: peer transport not available ({exc}); using RCCL send / receive", file=sys.stderr)
+                if _L().pa_comm_peer_ready(self.handle):
+                    _lib.check(_L().pa_comm_peer_disconnect(self.handle))
+
+    def _peer_self_test(self):
+        """One global sum and one ring exchange with known answers through the peer transport (every rank raises together if
+        any rank saw a wrong value or a timed-out wait): the transport has to prove itself on the machine it runs on before
+        the solvers rely on it."""
+        import torch
+        import torch.distributed as dist
+
+        rank, size = self.rank, self.size
+        v = torch.tensor([float(rank + 1), 0.5 * rank], dtype=torch.float64, device="cuda")
+        _lib.check(_L().pa_allreduce_sum(self.handle, C.c_void_p(v.data_ptr()), 2))
+        ok = bool(torch.allclose(v.cpu(), torch.tensor([size * (size + 1) / 2.0, 0.25 * size * (size - 1)], dtype=torch.float64)))
+        # ring: rank r owns entries [0, 8) and holds ghosts [8, 16) owned by its left neighbour
+        n = 8
+        left, right = (rank - 1) % size, (rank + 1) % size
+        if size == 2:
+            nbr, send, recv = [left], [np.arange(n, dtype=np.int32)], [np.arange(n, 2 * n, dtype=np.int32)]
+        else:
+            nbr = [left, right]
+            send = [np.zeros(0, np.int32), np.arange(n, dtype=np.int32)]
+            recv = [np.arange(n, 2 * n, dtype=np.int32), np.zeros(0, np.int32)]
+        h = Halo(self, nbr, send, recv)
+        for rep in range(3):  # (more than two: both mailbox buffers and the acknowledgements)
+            lx = torch.zeros(2 * n, dtype=torch.float64, device="cuda")
+            lx[:n] = torch.arange(n, dtype=torch.float64, device="cuda") + 100.0 * rank + rep
+            _lib.check(_L().pa_halo_prolongate(self.handle, h.handle, C.c_void_p(lx.data_ptr())))
+            want = torch.arange(n, dtype=torch.float64) + 100.0 * left + rep
+            ok = ok and bool(torch.equal(lx[n:].cpu(), want))
+            _lib.check(_L().pa_halo_restrict_add(self.handle, h.handle, C.c_void_p(lx.data_ptr())))
+            want = (torch.arange(n, dtype=torch.float64) + 100.0 * rank + rep) * 2.0
+            ok = ok and bool(torch.equal(lx[:n].cpu(), want))
+        try:
+            self.peer_check()
+        except Exception:  # noqa: BLE001
+            ok = False
+        flag = torch.tensor([0.0 if ok else 1.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag)
+        del h
+        if float(flag.item()) != 0.0:
+            raise RuntimeError("self-test of the peer transport failed")
 
     def init_comm_local(self, group, rank):
         """Rank `rank` of an in-process group of rank THREADS on one GPU (pa_local_group_*: test harness of the multi-rank paths)."""
         _lib.check(_L().pa_context_init_comm_local(self.handle, int(rank), group.handle))
         self.rank, self.size, self._group = int(rank), group.size, group
+
+    def _peer_connect_over_torch_distributed(self, device):
+        """Gather the arena handles of all ranks over torch.distributed and map them (pa_comm_peer_connect)."""
+        import torch
+        import torch.distributed as dist
+
+        L = _L()
+        buf = C.create_string_buffer(64)
+        _lib.check(L.pa_comm_peer_handle(self.handle, buf))
+        mine = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(device)
+        parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        table = b"".join(bytes(t.cpu().numpy().tobytes()) for t in parts)
+        _lib.check(L.pa_comm_peer_connect(self.handle, table))
+
+    def init_comm_peer_from_torch_distributed(self):
+        """Communicator on the peer transport alone (no RCCL): halo exchanges and global sums as direct stores between the
+        ranks' device arenas.  torch.distributed (any backend, e.g. gloo) only carries the 64-byte IPC handles once.  Works
+        for several processes on ONE GPU as well, which RCCL refuses."""
+        import torch.distributed as dist
+
+        rank, size = dist.get_rank(), dist.get_world_size()
+        _lib.check(_L().pa_context_init_comm_peer(self.handle, rank, size))
+        self.rank, self.size = rank, size
+        self._peer_connect_over_torch_distributed("cuda" if dist.get_backend() == "nccl" else "cpu")
+        if size > 1:
+            self._peer_self_test()
+
+    def init_comm_peer_single(self):
+        """One-rank communicator on the peer transport (a plan naming rank 0 as its own neighbour exercises every kernel of
+        an exchange without a second rank: scripts/time_halo_mult.py)."""
+        _lib.check(_L().pa_context_init_comm_peer(self.handle, 0, 1))
+        self.rank, self.size = 0, 1
+
+    def peer_check(self):
+        """Raises if a wait of the peer transport has timed out."""
+        _lib.check(_L().pa_comm_peer_check(self.handle))
 
     def init_comm_single(self):
         """One-rank communicator (exercises RCCL init / allreduce without a second GPU)."""

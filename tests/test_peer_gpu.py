@@ -1,0 +1,73 @@
+"""The peer transport (palace_amd/csrc/comm.hpp: halo exchanges and global sums as direct stores into the other ranks' device
+arenas, plain kernels on the solver's stream) -- between PROCESSES sharing one GPU (hipIpc handles gathered over gloo; RCCL
+refuses two ranks on one device).  Same checks as the other multi-rank tests: the basis-independent results of a PCG +
+p-multigrid solve equal those of the undivided problem, also when the recorded iteration (HIP graph) is replayed.
+(Rank THREADS of one process cannot use this transport: they share the process's legacy null stream, and a rank's wait kernel
+would hold up null-stream work another rank has to finish first -- the in-process group keeps its host-barrier copies.)"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)  # every rank on the same GPU
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from palace_amd import lib as _lib
+        from palace_amd import linalg
+        from palace_amd.fem.partition import SlabProblem
+
+        ctx = linalg.Context()
+        if world > 1:
+            ctx.init_comm_peer_from_torch_distributed()
+        prob = SlabProblem(ctx, rank, world, 2, 0, shape=(2, 4 // world))
+        if world > 1:
+            assert all(_lib.load().pa_halo_uses_peer(h.handle) for h in prob.halos)
+        K, b, x = prob.pcg_gmg_solver(max_it=100, rel_tol=1e-8, hiptmair=True, coarse="cg")
+        K.mult(b, x)
+        st = K.stats()
+        A = prob._keep[-1][1][-1]
+        y = torch.zeros_like(x)
+        A.mult(x, y)
+        z = torch.zeros_like(x)
+        A.mult(b, z)
+        nt = torch.tensor([prob.n_true[-1]], dtype=torch.int64)
+        dist.all_reduce(nt)
+        res = dict(st, n=int(nt.item()), xx=ctx.dot(x, x), xAx=ctx.dot(x, y), bb=ctx.dot(b, b), bAb=ctx.dot(b, z))
+        ctx.peer_check() if world > 1 else None
+        # the same solve again: the recorded iteration (HIP graph) replays across ranks
+        x.zero_()
+        K.mult(b, x)
+        res["xx2"] = ctx.dot(x, x)
+        if world > 1:
+            ctx.peer_check()
+        if rank == 0:
+            out.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_match_one_rank():
+    import torch.multiprocessing as mp
+
+    results = {}
+    for world, port in ((1, 29621), (2, 29622)):
+        q = mp.get_context("spawn").SimpleQueue()
+        mp.spawn(_worker, args=(world, port, q), nprocs=world, join=True)
+        results[world] = q.get()
+    one, two = results[1], results[2]
+    assert one["n"] == two["n"] and one["converged"] and two["converged"]
+    assert abs(one["iterations"] - two["iterations"]) <= 1
+    for k in ("bb", "bAb"):
+        assert abs(one[k] - two[k]) < 1e-11 * abs(one[k]), (k, one[k], two[k])
+    for k in ("xx", "xAx", "xx2"):
+        assert abs(one[k] - two[k]) < 1e-6 * abs(one[k]), (k, one[k], two[k])
