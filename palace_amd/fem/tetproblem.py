@@ -1,5 +1,7 @@
 """A PEC cavity problem on a tetrahedral mesh, all p-levels: spaces, dense-path operators, dense
-interpolators — the tetrahedral counterpart of partition.SlabProblem (one rank)."""
+interpolators — the tetrahedral counterpart of partition.SlabProblem.  With world > 1 the elements are partitioned by
+recursive coordinate bisection (rcb.py; the reference: METIS parts of the serial mesh, utils/geodata.cpp:3587-3596) and every
+operator, transfer and auxiliary space works on the rank's view with its halo plan."""
 from __future__ import annotations
 
 import numpy as np
@@ -8,16 +10,26 @@ from . import tet
 
 
 class TetProblem:
-    def __init__(self, ctx, mesh: tet.TetMesh, p: int, orders=None):
-        from .. import ceed
+    def __init__(self, ctx, mesh: tet.TetMesh, p: int, orders=None, rank=0, world=1):
+        from .. import ceed, linalg
 
-        self.ctx, self.mesh, self.p = ctx, mesh, p
+        self.ctx, self.mesh, self.p, self.rank, self.world = ctx, mesh, p, rank, world
         self.orders = list(range(1, p + 1)) if orders is None else list(orders)
         self.spaces = [tet.NDTetSpace(mesh, q) for q in self.orders]
         self.pts, self.wts = tet.default_tet_rule(p)  # every level integrates with the fine rule
-        self.geom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr,
+        elems = np.arange(mesh.ne)
+        self.part = None
+        if world > 1:
+            from .rcb import PartitionedSpace, rcb
+
+            self.part = rcb(mesh.nodes[mesh.elem_nodes[:, :4]].mean(axis=1), world)
+            self.spaces = [PartitionedSpace(s, self.part, rank, world) for s in self.spaces]
+            elems = self.spaces[0].elems
+        self.geom = ceed.DenseGeomFactorData(mesh.elem_nodes[elems], mesh.nodes, mesh.attr[elems],
                                              mesh.geometry_grad_table(self.pts), self.wts)
         self.ess = [s.ess_dofs() for s in self.spaces]
+        self.n_true = [getattr(s, "n_true", s.ndofs) for s in self.spaces]
+        self.halos = [linalg.Halo(ctx, s.nbr, s.send, s.recv) if world > 1 else None for s in self.spaces]
         self._keep = []
 
     def nd_block(self, s):
@@ -48,24 +60,35 @@ class TetProblem:
             self.geom, blocks[-1], ceed.QF_HDIVMASS_33, np.concatenate([mass, curl]),
             ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
         local = [fine.coarsen_dense(b) for b in blocks[:-1]] + [fine]
-        A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE) for op, e in zip(local, self.ess)]
+        A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE, n_true=nt, halo=h)
+             for op, e, nt, h in zip(local, self.ess, self.n_true, self.halos)]
         if coarse_assembled and len(A) > 1:  # coarsest level as a device CSR matrix (rap.cpp:84-152)
-            A[0] = linalg.AssembledParOperator(ctx, local[0].full_assemble_device(), self.ess[0], linalg.DIAG_ONE)
+            A[0] = linalg.AssembledParOperator(ctx, local[0].full_assemble_device(), self.ess[0], linalg.DIAG_ONE,
+                                               n_true=self.n_true[0], halo=self.halos[0])
         P = [linalg.DenseInterp(ctx, self.spaces[l].restriction(), self.spaces[l + 1].restriction(interp_range=True),
-                                tet.nd_tet_transfer_matrix(self.orders[l], self.orders[l + 1]))
+                                tet.nd_tet_transfer_matrix(self.orders[l], self.orders[l + 1]), dom_halo=self.halos[l],
+                                n_true_dom=self.n_true[l], n_true_rng=self.n_true[l + 1])
              for l in range(len(A) - 1)]
         aux = {}
         if hiptmair:
             h1s = [tet.H1TetSpace(self.mesh, q) for q in self.orders]
+            if self.world > 1:
+                from .rcb import PartitionedSpace
+
+                h1s = [PartitionedSpace(s, self.part, self.rank, self.world) for s in h1s]
+            h1_nt = [getattr(s, "n_true", s.ndofs) for s in h1s]
+            h1_halos = [linalg.Halo(ctx, s.nbr, s.send, s.recv) if self.world > 1 else None for s in h1s]
             hb = [self.h1_block(s) for s in h1s]
             fine_h1 = ceed.Operator(h1s[-1].ndofs, h1s[-1].ndofs).add_dense_integrator(
                 self.geom, hb[-1], ceed.QF_HCURL_33, mass, ceed.EVAL_GRAD).finalize()
             loc_h1 = [fine_h1.coarsen_dense(b) for b in hb[:-1]] + [fine_h1]
-            A_h1 = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE) for op, s in zip(loc_h1, h1s)]
-            G = [linalg.DenseInterp(ctx, h.restriction(), n.restriction(interp_range=True), tet.tet_gradient_matrix(q))
-                 for h, n, q in zip(h1s, self.spaces, self.orders)]
+            A_h1 = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE, n_true=nt, halo=h)
+                    for op, s, nt, h in zip(loc_h1, h1s, h1_nt, h1_halos)]
+            G = [linalg.DenseInterp(ctx, h.restriction(), n.restriction(interp_range=True), tet.tet_gradient_matrix(q),
+                                    dom_halo=hh, n_true_dom=hn, n_true_rng=nn)
+                 for h, n, q, hh, hn, nn in zip(h1s, self.spaces, self.orders, h1_halos, h1_nt, self.n_true)]
             aux = dict(A_aux=A_h1, G=G)
-            self._keep.append((h1s, loc_h1, hb))
+            self._keep.append((h1s, loc_h1, hb, h1_halos))
         if len(A) > 1:
             # level 0: the reference calls AMS (HYPRE) here.  Stand-ins: "cg" = a few Jacobi-PCG iterations (needed by
             # the auxiliary-space configuration, where level 0 must really reduce the error), "chebyshev" = a fixed
@@ -79,7 +102,7 @@ class TetProblem:
         else:
             B = linalg.jacobi(ctx, A[0])
         K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)
-        n = self.spaces[-1].ndofs
+        n = self.n_true[-1]
         ones = torch.ones(n, dtype=torch.float64, device="cuda")
         b = torch.empty_like(ones)
         A[-1].mult(ones, b)
