@@ -270,6 +270,53 @@ def complex_leg(ctx, prob, reps=50):
             "one_pass": fused, "ms": ms, "complex_dof_per_s": n / (ms * 1e-3)}
 
 
+def h1_leg(ctx, prob, order=2, reps=200, pcg_iters=50):
+    """BASELINE config 4's system on the same cylinder, N = 1: H1 order-2 diffusion (eps grad u, grad v) -- `ParOperator::Mult`
+    and PCG + p-multigrid (levels 1, 2; plain Chebyshev smoothers) with the native algebraic V-cycle on the assembled order-1
+    level, where the reference calls BoomerAMG."""
+    import torch
+
+    out = {}
+    for coarse in ("amg", "chebyshev"):
+        solver, b, xs = prob.h1_pcg_gmg_solver(order=order, max_it=pcg_iters, coarse=coarse)
+        A = prob.h1_fine
+        n = b.numel()
+        if "apply" not in out:
+            xx, yy = torch.rand_like(b), torch.empty_like(b)
+            with torch.cuda.stream(ctx.torch_stream):
+                for _ in range(30):
+                    A.mult(xx, yy)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    A.mult(xx, yy)
+                e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            out["workload"] = f"H1 p={order} hexahedra, {prob.mesh.ne} elements, {n} dofs, diffusion (eps_r = 2.08), Dirichlet boundary"
+            out["dofs"] = n
+            out["apply"] = {"ms": ms, "dof_per_s": n / (ms * 1e-3)}
+        solver.mult(b, xs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.mult(b, xs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = solver.stats()
+        entry = {"iters_per_s": st["iterations"] / dt, "iterations": st["iterations"], "seconds": dt}
+        solver, b, xs = prob.h1_pcg_gmg_solver(order=order, max_it=400, rel_tol=1e-8, coarse=coarse)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.mult(b, xs)
+        torch.cuda.synchronize()
+        st = solver.stats()
+        entry.update({"iterations_to_1e-8": st["iterations"], "seconds_to_1e-8": time.perf_counter() - t0,
+                      "converged": st["converged"]})
+        out["pcg_" + coarse] = entry
+        prob._keep.clear()
+    return out
+
+
 def tets_leg(order, n, reps=20):
     """The non-tensor path (dense tables on the FP64 matrix cores): Nedelec tets of the same order on a
     Kuhn-split cube, curl-curl and curl-curl+mass `ceed::Operator::Mult`, order-2p symmetric quadrature
@@ -312,6 +359,22 @@ def tets_leg(order, n, reps=20):
         out[name] = {"ms": ms, "dof_per_s": nd.ndofs / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
                      "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
                      "table_TFLOPs": mesh.ne * (2 * 2 * nct * len(wts) * nd.P) / ms / 1e9}
+    # the curl-curl apply at this size against the numpy oracle (CeedOperatorOracle: restriction with the tridiagonal dof
+    # transformation, dense tables, the qfunction, and back), one oracle apply
+    from oracle import palace_oracle as po
+
+    t0 = time.perf_counter()
+    J = mesh.jacobians(pts)
+    og = po.build_geom_factor_33(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 9))
+    orc = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients if nd.diagonal_transform else None, interp, curl, og,
+                                po.QF_HDIV, po.CoeffCtx(), curl_orients=None if nd.diagonal_transform else nd.curl_orients)
+    hx = np.random.default_rng(6).uniform(0, 1, nd.ndofs)
+    hy = orc.apply_add(hx, np.zeros(nd.ndofs))
+    dy = torch.empty_like(x)
+    ops["curlcurl"][0].mult(torch.from_numpy(hx).cuda(), dy)
+    out["parity"] = {"rel_l2_y_full": _rel(dy.cpu().numpy(), hy), "tolerance": 1e-12,
+                     "size": f"{nd.ndofs} dofs, {mesh.ne} tets ({time.perf_counter() - t0:.1f} s of oracle work)"}
+    del J, og, orc, hx, hy, dy
     # complex apply (BASELINE config 3's shape): (K - w^2 eps M) + i w sigma M in one pass (pa_op_mult_complex, dense form)
     from palace_amd import linalg
 
@@ -575,9 +638,10 @@ def main():
     p4 = None
     if rank == 0 and world == 1 and not args.no_p4:
         p4 = _leg(p4_leg, ctx, args.dofs)
-    cplx = None
+    cplx = h1 = None
     if rank == 0 and world == 1 and not args.no_p4:
         cplx = _leg(complex_leg, ctx, prob)
+        h1 = _leg(h1_leg, ctx, prob)
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -600,7 +664,7 @@ def main():
                        "scaling_mode": ("strong: one ~10M-dof cylinder cut into N equal z-slabs" if args.scaling == "strong"
                                         else "weak: one z-slab of the cylinder per GPU, same element count per GPU"),
                        "parallelism": f"element partition x{world}, RCCL halo (P / P^T) + allreduce dots"},
-            "pre_warm_steps": args.pre_warm, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "tets_mfma": tets,
+            "pre_warm_steps": args.pre_warm, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "tets_mfma": tets,
             "setup_s": t_setup,
         }
         sys.stdout.flush()

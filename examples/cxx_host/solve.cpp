@@ -9,7 +9,8 @@
 //
 //   hipcc --offload-arch=gfx950 -std=c++17 -I<repo>/palace_amd/csrc -I<repo>/include solve.cpp -L<repo>/palace_amd/lib
 //         -lpalace_amd -Wl,-rpath,<repo>/palace_amd/lib -o solve
-//   ./solve problem.bin [aux=0|1] [krylov=cg|fgmres|cfgmres] [coarse=cheb|pcg|jacobi]
+//   ./solve problem.bin [aux=0|1] [krylov=cg|fgmres|cfgmres] [coarse=cheb|pcg|jacobi|ams|amg]
+// coarse = ams | amg: LinearSolver::AMS / BOOMER_AMG (the native algebraic cycles of amg_solver.hpp on the assembled p = 1 level)
 // krylov = cfgmres solves the complex (driven-style) system (K - w^2 eps M) x + i w sigma M x = b with ComplexParOperator,
 // ComplexKspSolver (FGMRES) and the real p-multigrid of K + w^2 eps M as the preconditioner on both parts.
 #include <cstdio>
@@ -142,12 +143,16 @@ int main(int argc, char **argv) {
       return 0;
     }
     linear.krylov_solver = krylov == "fgmres" ? KrylovSolver::FGMRES : KrylovSolver::CG;
-    linear.type = coarse == "pcg" ? LinearSolver::JACOBI_PCG : coarse == "jacobi" ? LinearSolver::JACOBI : LinearSolver::CHEBYSHEV_JACOBI;
+    linear.type = coarse == "pcg"      ? LinearSolver::JACOBI_PCG
+                  : coarse == "jacobi" ? LinearSolver::JACOBI
+                  : coarse == "ams"    ? LinearSolver::AMS
+                  : coarse == "amg"    ? LinearSolver::BOOMER_AMG
+                                       : LinearSolver::CHEBYSHEV_JACOBI;
     linear.tol = 1e-10, linear.max_it = 400;
     linear.mg_smooth_aux = aux ? 1 : 0;
     linear.initial_guess = 0;
     linear.SetDefaults(order, /*spd_problem=*/true);
-    KspSolver ksp(linear, /*verbose=*/0, nd_fespaces, aux ? &h1_fespaces : nullptr);
+    KspSolver ksp(linear, /*verbose=*/0, nd_fespaces, (aux || coarse == "ams") ? &h1_fespaces : nullptr);
     ksp.SetOperators(*A, *A);
 
     const int n = A->Height();

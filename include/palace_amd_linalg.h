@@ -43,6 +43,8 @@ int pa_context_init_comm(pa_context *ctx, int rank, int size, const char *unique
 typedef struct pa_local_group pa_local_group;
 int pa_local_group_create(int size, pa_local_group **group);
 void pa_local_group_destroy(pa_local_group *group);
+/* a rank thread that fails calls this so that the others leave their barriers with an error instead of waiting for ever */
+void pa_local_group_abort(pa_local_group *group);
 int pa_context_init_comm_local(pa_context *ctx, int rank, pa_local_group *group);
 /* Peer transport (palace_amd/csrc/comm.hpp): halo exchanges and global sums as direct stores into the other ranks' device
  * memory (xGMI between the GPUs of a node) -- plain kernels on the context's stream, recordable in HIP graphs.  Every rank owns
@@ -212,6 +214,19 @@ int pa_orthogonalize_column_complex(pa_context *ctx, int kind, int m, const doub
                                     double *wr, double *wi, int n, double *H, pa_par_op *weight);
 int pa_gmres_set_orthogonalization(pa_solver *S, int kind);
 int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess);
+/* Named host ranges for profilers (roctx; rocprofv3 --marker-trace).  The library itself brackets the reference's BlockTimer
+ * phases (utils/timer.hpp:29-84: "Linear Solve", "Linear Solve / Setup", "Preconditioner", "Coarse Solve", "Operator
+ * Construction", "Estimation" ...); a driver adds its own (Timer::TS, EPS, POSTPRO ...) with this pair.  Nestable; no-ops when
+ * no roctx library is found or PALACE_AMD_ROCTX=0. */
+typedef struct pa_range pa_range;
+pa_range *pa_range_push(const char *name);
+void pa_range_pop(pa_range *range);
+
+/* Surface what nested solvers could only note on the device while they ran inside a recorded sequence (the coarse PCG of a
+ * multigrid cycle meeting a non-finite (Br, r) / (Ap, p): the reference's CheckDot abort, iterative.cpp:39-45).  Krylov
+ * solvers call this on their preconditioner after every solve; a caller applying a preconditioner directly may call it
+ * whenever it is willing to wait for the stream.  Returns PA_ERROR with the message of the failure, PA_OK otherwise. */
+int pa_solver_check_status(const pa_solver *S);
 int pa_solver_stats(const pa_solver *S, int *iterations, double *initial_res, double *final_res,
                     int *converged);
 void pa_solver_destroy(pa_solver *S);

@@ -1,11 +1,13 @@
 #include "comm.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 #include <dlfcn.h>
 
 #include <cstring>
+#include <limits>
 #include <string>
 
 #include "pa_internal.hpp"
@@ -112,14 +114,25 @@ Comm::~Comm() {
 
 void LocalGroup::Arrive() {
   std::unique_lock<std::mutex> lk(m_);
+  PA_REQUIRE(!aborted_, "in-process rank group aborted: another rank failed");
   const long gen = generation_;
   if (++waiting_ == size_) {
     waiting_ = 0;
     generation_++;
     cv_.notify_all();
   } else {
-    cv_.wait(lk, [&] { return generation_ != gen; });
+    // a rank that throws between two barriers calls Abort() (pa_local_group_abort) and releases the others; a rank that
+    // simply never arrives is caught by the time limit
+    const bool ok = cv_.wait_for(lk, std::chrono::seconds(timeout_s_), [&] { return generation_ != gen || aborted_; });
+    if (!ok) aborted_ = true, cv_.notify_all();
+    PA_REQUIRE(ok, "in-process rank group: a rank did not reach the barrier in time");
+    PA_REQUIRE(generation_ != gen, "in-process rank group aborted: another rank failed");
   }
+}
+void LocalGroup::Abort() {
+  std::lock_guard<std::mutex> lk(m_);
+  aborted_ = true;
+  cv_.notify_all();
 }
 
 Halo::~Halo() {
@@ -138,6 +151,9 @@ Halo::Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int3
   iface_.insert(iface_.end(), recv_idx, recv_idx + nrecv_);
   std::sort(iface_.begin(), iface_.end());
   iface_.erase(std::unique(iface_.begin(), iface_.end()), iface_.end());
+  send_min_ = recv_min_ = std::numeric_limits<int>::max(), send_max_ = recv_max_ = -1;
+  for (int i = 0; i < nsend_; i++) send_min_ = std::min(send_min_, send_idx[i]), send_max_ = std::max(send_max_, send_idx[i]);
+  for (int i = 0; i < nrecv_; i++) recv_min_ = std::min(recv_min_, recv_idx[i]), recv_max_ = std::max(recv_max_, recv_idx[i]);
   d_send_idx_ = pa::dev_upload(send_idx, (size_t)nsend_);
   d_recv_idx_ = pa::dev_upload(recv_idx, (size_t)nrecv_);
   {
@@ -154,6 +170,13 @@ Halo::Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int3
   const char *mode = std::getenv("PALACE_AMD_HALO");
   // (one rank whose plan names itself as the neighbour -- the per-rank cost proxy of scripts/time_halo_mult.py -- included)
   if (comm.PeerReady() && (comm.Size() > 1 || nnbr > 0) && !(mode && std::string(mode) == "rccl")) PeerSetup(send_idx);
+}
+
+void Halo::Validate(int n_true, int n_local) const {
+  PA_REQUIRE(send_min_ >= 0 && send_max_ < n_true, "halo plan: a dof to send is not a true dof of this vector");
+  PA_REQUIRE(recv_min_ >= n_true && recv_max_ < n_local, "halo plan: a ghost slot lies outside [n_true, n_local)");
+  if (recv_first_ >= 0)
+    PA_REQUIRE(recv_first_ >= n_true && recv_first_ + nrecv_ <= n_local, "halo plan: in-place ghost range outside the vector");
 }
 
 void Comm::AllReduceSum(double *d_buf, int n, hipStream_t s) {

@@ -42,6 +42,8 @@ class LocalGroup {
   std::condition_variable cv_;
   int waiting_ = 0;
   long generation_ = 0;
+  bool aborted_ = false;
+  int timeout_s_ = 300;
   std::vector<double> slots_;  // [size][kMaxValues] staging of AllReduceSum
   struct Box {
     const double *buf = nullptr;  // published send buffer of a rank ...
@@ -55,7 +57,8 @@ public:
   static constexpr int kMaxValues = 512;
   explicit LocalGroup(int size) : size_(size), slots_((size_t)size * kMaxValues), box_((size_t)size) {}
   int Size() const { return size_; }
-  void Arrive();  // barrier over the ranks (threads)
+  void Arrive();  // barrier over the ranks (threads); throws once the group is aborted or a rank is 300 s late
+  void Abort();   // a failing rank releases the others (they throw out of their barrier)
 };
 
 class Comm {
@@ -118,6 +121,7 @@ class Halo {
   int recv_first_ = -1;  // >= 0: the ghosts are the contiguous range [recv_first_, recv_first_ + nrecv_) of the local vector in
                          // receive order (ghosts last: the usual numbering) -- received into / sent from it in place
   int nsend_ = 0, nrecv_ = 0;
+  int send_min_ = 0, send_max_ = -1, recv_min_ = 0, recv_max_ = -1;  // index ranges of the plan (Validate)
   // in-process group: pieces [off[k], off[k + 1]) of `sendbase` go to neighbour k, pieces of the same sizes as `recv_off` arrive
   void ExchangeLocal(const double *sendbase, const std::vector<int> &send_off, double *recvbase, const std::vector<int> &recv_off,
                      hipStream_t s) const;
@@ -144,6 +148,9 @@ public:
   ~Halo();
   // the local dofs the exchange touches: elements without any of them do not depend on it
   const std::vector<int32_t> &InterfaceDofs() const { return iface_; }
+  // The plan against the vector it will be used on: owned dofs sent are true dofs, ghosts lie in [n_true, n_local) -- in
+  // particular the contiguous ghost range received into / sent from in place.  Called by every operator that takes a plan.
+  void Validate(int n_true, int n_local) const;
   // lx[ghosts] <- owners' values   (P)
   void Prolongate(double *d_lx, hipStream_t s) const;
   // ly[owned shared] += sharers' ghost contributions   (P^T)

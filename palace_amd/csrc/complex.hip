@@ -508,6 +508,7 @@ ComplexParOperator::~ComplexParOperator() {
 }
 
 void ComplexParOperator::SetEssentialTrueDofs(const int32_t *ess_host, int n_ess, ParOperator::DiagonalPolicy policy) {
+  StreamGraph::Invalidate();
   PA_REQUIRE(policy != ParOperator::DiagonalPolicy::DIAG_ONE || RAPr_,
              "DiagonalPolicy::DIAG_ONE specified for ComplexParOperator with no real part!");
   for (int i = 0; i < n_ess; i++) PA_REQUIRE(ess_host[i] >= 0 && ess_host[i] < n_true_, "essential dof out of range");
@@ -642,6 +643,7 @@ double SpectralNorm(const Context &c, const ComplexOperator &A, bool herm, doubl
 }  // namespace linalg
 
 void ComplexJacobiSmoother::SetOperator(const ComplexOperator &op) {
+  StreamGraph::Invalidate();
   height = op.Height(), width = op.Width();
   dinv_.SetSize(height);
   op.AssembleDiagonal(dinv_);
@@ -653,6 +655,7 @@ void ComplexJacobiSmoother::Mult(const ComplexVector &x, ComplexVector &y) const
 }
 
 void ComplexChebyshevSmoother::SetOperator(const ComplexOperator &op) {
+  StreamGraph::Invalidate();
   A_ = &op, height = op.Height(), width = op.Width();
   dinv_.SetSize(height), d_.SetSize(height), r_.SetSize(height);
   op.AssembleDiagonal(dinv_);
@@ -709,6 +712,7 @@ ComplexDistRelaxationSmoother::ComplexDistRelaxationSmoother(const Context &ctx,
   B_G_ = std::make_unique<ComplexChebyshevSmoother>(ctx, cheby_smooth_it, cheby_order, cheby_sf_max, cheby_4th_kind, cheby_sf_min);
 }
 void ComplexDistRelaxationSmoother::SetOperators(const ComplexOperator &op, const ComplexParOperator &op_G) {
+  StreamGraph::Invalidate();
   PA_REQUIRE(op.Height() == G_->Height() && op.Width() == G_->Height() && op_G.Height() == G_->Width() &&
                  op_G.Width() == G_->Width(),
              "Invalid operator sizes for DistRelaxationSmoother!");
@@ -784,6 +788,7 @@ ComplexGeometricMultigridSolver::ComplexGeometricMultigridSolver(const Context &
 
 void ComplexGeometricMultigridSolver::SetOperators(const std::vector<const ComplexParOperator *> &ops,
                                                    const std::vector<const ComplexParOperator *> *aux_ops) {
+  StreamGraph::Invalidate();
   PA_REQUIRE(ops.size() == A_.size(), "Invalid number of levels for operators in multigrid solver setup!");
   for (size_t l = 0; l < ops.size(); l++) {
     A_[l] = ops[l];
@@ -846,6 +851,7 @@ struct ComplexKrylovOps {
   void A(const Vec &x, Vec &y) const { A_->Mult(x, y); }
   bool HasB() const { return B_ != nullptr || Bc_ != nullptr; }
   void B(const Vec &x, Vec &y) const {
+    PhaseRange range("Preconditioner");  // iterative.cpp:247
     if (Bc_) return Bc_->Mult(x, y);
     B_->Mult(x.Real(), y.Real());  // gmg.cpp:147-168: the real preconditioner on both parts
     B_->Mult(x.Imag(), y.Imag());

@@ -66,12 +66,11 @@ CsrOperator::CsrOperator(const Context &ctx, const pa_csr *m)
 }
 
 CsrOperator::~CsrOperator() {
-  if (d_val_bc_) (void)hipFree(d_val_bc_);
 }
 
-void CsrOperator::EliminateEssential(const int32_t *d_ess, int n_ess, bool diag_one) {
-  if (!height) return;
-  if (!d_val_bc_) d_val_bc_ = pa::dev_alloc<double>((size_t)m_->nnz);
+double *CsrOperator::EliminatedValues(const int32_t *d_ess, int n_ess, bool diag_one) const {
+  if (!height) return nullptr;
+  double *d_val_bc_ = pa::dev_alloc<double>((size_t)m_->nnz);
   uint8_t *flag = pa::dev_alloc<uint8_t>((size_t)height);
   PA_HIP(hipMemsetAsync(flag, 0, (size_t)height, ctx_->stream));
   if (n_ess) hipLaunchKernelGGL(k_flag, dim3((n_ess + 255) / 256), dim3(256), 0, ctx_->stream, n_ess, d_ess, flag);
@@ -80,19 +79,14 @@ void CsrOperator::EliminateEssential(const int32_t *d_ess, int n_ess, bool diag_
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(ctx_->stream));
   PA_HIP(hipFree(flag));
+  return d_val_bc_;
 }
 
-void CsrOperator::MultUnconstrained(const Vector &x, Vector &y) const {
-  double *keep = d_val_bc_;
-  d_val_bc_ = nullptr;
-  Apply(x, y, 1.0, false);
-  d_val_bc_ = keep;
-}
+void CsrOperator::MultValues(const double *d_vals, const Vector &x, Vector &y) const { Apply(d_vals, x, y, 1.0, false); }
 
-void CsrOperator::Apply(const Vector &x, Vector &y, double a, bool add) const {
+void CsrOperator::Apply(const double *vals, const Vector &x, Vector &y, double a, bool add) const {
   PA_REQUIRE(x.Size() == width && y.Size() == height, "size mismatch in CsrOperator");
   if (!height) return;
-  const double *vals = d_val_bc_ ? d_val_bc_ : m_->d_val;
   const long long threads = (long long)height * lanes_;
   const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
   if (lanes_ == 16)
@@ -107,17 +101,17 @@ void CsrOperator::Apply(const Vector &x, Vector &y, double a, bool add) const {
   PA_HIP(hipGetLastError());
 }
 
-void CsrOperator::Mult(const Vector &x, Vector &y) const { Apply(x, y, 1.0, false); }
+void CsrOperator::Mult(const Vector &x, Vector &y) const { Apply(m_->d_val, x, y, 1.0, false); }
 void CsrOperator::MultTranspose(const Vector &x, Vector &y) const {
   PA_REQUIRE(m_->symmetric, "MultTranspose of an assembled non-symmetric operator is not available");
-  Apply(x, y, 1.0, false);
+  Apply(m_->d_val, x, y, 1.0, false);
 }
-void CsrOperator::AddMult(const Vector &x, Vector &y, double a) const { Apply(x, y, a, true); }
+void CsrOperator::AddMult(const Vector &x, Vector &y, double a) const { Apply(m_->d_val, x, y, a, true); }
 void CsrOperator::AssembleDiagonal(Vector &diag) const {
   PA_REQUIRE(diag.Size() == height, "size mismatch in CsrOperator::AssembleDiagonal");
   if (!height) return;
   hipLaunchKernelGGL(k_csr_diag, dim3((height + 255) / 256), dim3(256), 0, ctx_->stream, height, m_->d_rowptr, m_->d_col,
-                     d_val_bc_ ? d_val_bc_ : m_->d_val, diag.Data());
+                     m_->d_val, diag.Data());
   PA_HIP(hipGetLastError());
 }
 

@@ -96,6 +96,7 @@ double ErrorIndicator::Norml2() const { return n_ ? std::sqrt(linalg::Dot(*ctx_,
 FluxProjector::FluxProjector(const MaterialPropertyCoefficient &coeff, const FiniteElementSpace &smooth_fespace,
                              const FiniteElementSpace &rhs_fespace, double tol, int max_it, int print)
     : ctx_(&smooth_fespace.GetContext()), smooth_(&smooth_fespace), rhs_space_(&rhs_fespace) {
+  PhaseRange range("Estimation / Construction");  // errorestimator.cpp:114
   // :117-120: a scalar smooth space (the H1 recovery of the scalar curl of a plane field) takes MassIntegrator
   const bool scalar_flux = smooth_fespace.GetFEType() == PA_FE_H1;
   {  // errorestimator.cpp:125-153 (use_mg = false): the mass matrix of the smooth space, no coefficient
@@ -132,6 +133,7 @@ FluxProjector::FluxProjector(const MaterialPropertyCoefficient &coeff, const Fin
 }
 
 void FluxProjector::Mult(const Vector &x, Vector &y) const {
+  PhaseRange range("Estimation / Solve");  // errorestimator.cpp:172
   PA_REQUIRE(x.Size() == rhs_space_->GetTrueVSize() && y.Size() == rhs_.Size(), "Invalid vector dimensions for FluxProjector::Mult!");
   // Flux as a ParOperator between two spaces (rap.cpp:207-220 without essential dofs): P_test^T A P_trial
   const Halo *hx = rhs_space_->GetHalo(), *hy = smooth_->GetHalo();
@@ -200,6 +202,7 @@ void FluxErrorEstimatorBase::AddErrorEstimates(const Vector &F, Vector &estimate
 }
 
 void FluxErrorEstimatorBase::AddErrorIndicator(const Vector &F, double Et, ErrorIndicator &indicator) const {
+  PhaseRange range("Estimation");  // errorestimator.cpp:192
   Vector estimates(fespace_.GetMesh().GetNE());
   linalg::Fill(*ctx_, estimates, 0.0);
   AddErrorEstimates(F, estimates);

@@ -319,12 +319,41 @@ Mesh::Mesh(const Context &ctx, int num_elem, int mesh_order, int num_nodes, cons
   fem::LagrangeEval(fem::GaussLobatto(mesh_order + 1), qx, B, G);
   pa_mesh_desc m{num_elem, mesh_order, q1d, num_nodes, node_offsets, nodes, attr, B.data(), G.data(), qw.data()};
   check(pa_geom_create(&m, ctx.stream, &geom_));
+  const int n1 = mesh_order + 1, npe = n1 * n1 * n1;
+  ncorner_ = 8;
+  corner_nodes_.resize((size_t)num_elem * 8);
+  for (int e = 0; e < num_elem; e++)
+    for (int c = 0; c < 8; c++) {
+      const int i = (c & 1) * mesh_order, j = ((c >> 1) & 1) * mesh_order, k = ((c >> 2) & 1) * mesh_order;
+      corner_nodes_[(size_t)e * 8 + c] = node_offsets[(size_t)e * npe + i + n1 * (j + n1 * k)];
+    }
+  nodes_.assign(nodes, nodes + (size_t)num_nodes * 3);
 }
 Mesh::Mesh(const Context &ctx, const pa_mesh_dense_desc &desc)
     : ne_(desc.num_elem), q1d_(0), mesh_order_(0), nq_dense_(desc.num_qpts) {
   dim_ = desc.dim == 0 ? 3 : desc.dim;
   sdim_ = desc.space_dim == 0 ? dim_ : desc.space_dim;
   check(pa_geom_create_dense(&desc, ctx.stream, &geom_));
+  if (desc.nodes_per_elem >= dim_ + 1) {  // simplices: the vertices are the first dim + 1 nodes (MFEM's node order)
+    ncorner_ = dim_ + 1;
+    corner_nodes_.resize((size_t)desc.num_elem * ncorner_);
+    for (int e = 0; e < desc.num_elem; e++)
+      for (int c = 0; c < ncorner_; c++)
+        corner_nodes_[(size_t)e * ncorner_ + c] = desc.node_offsets[(size_t)e * desc.nodes_per_elem + c];
+    nodes_.assign(desc.nodes, desc.nodes + (size_t)desc.num_nodes * sdim_);
+  }
+}
+std::vector<double> Mesh::VertexCoordinates(const FiniteElementSpace &h1) const {
+  PA_REQUIRE(&h1.GetMesh() == this && h1.GetFEType() == PA_FE_H1 && h1.GetMaxElementOrder() == 1 &&
+                 h1.GetElemSize() == ncorner_,
+             "vertex coordinates: a lowest-order H1 space on this mesh expected");
+  std::vector<double> xyz((size_t)h1.GetVSize() * sdim_, 0.0);
+  for (int e = 0; e < ne_; e++)
+    for (int c = 0; c < ncorner_; c++) {
+      const int32_t d = h1.GetElementDof(e, c), nd = corner_nodes_[(size_t)e * ncorner_ + c];
+      for (int k = 0; k < sdim_; k++) xyz[(size_t)d * sdim_ + k] = nodes_[(size_t)nd * sdim_ + k];
+    }
+  return xyz;
 }
 Mesh::~Mesh() {
   if (geom_) pa_geom_destroy(geom_);
@@ -582,6 +611,7 @@ std::unique_ptr<Operator> BilinearForm::Assemble(bool skip_zeros) const {
 
 std::vector<std::unique_ptr<Operator>> BilinearForm::Assemble(const FiniteElementSpaceHierarchy &fespaces, bool skip_zeros,
                                                               std::size_t l0) const {
+  PhaseRange range("Operator Construction");  // the drivers hold Timer::CONSTRUCT around SpaceOperator assembly
   PA_REQUIRE(&trial_fespace == &test_fespace && &fespaces.GetFinestFESpace() == &trial_fespace,
              "Assembly on a FiniteElementSpaceHierarchy should have the same BilinearForm spaces and fine space of the "
              "hierarchy!");
@@ -625,6 +655,7 @@ FespaceParOperator::FespaceParOperator(std::unique_ptr<Operator> &&A, const Fini
 }
 
 void FespaceParOperator::SetEssentialTrueDofs(const std::vector<int32_t> &tdofs, ParOperator::DiagonalPolicy policy) {
+  ess_tdofs_ = tdofs;
   par_.reset();  // (releases the fused essential list of the local operator before a new wrapper claims it)
   par_ = std::make_unique<ParOperator>(*ctx_, *local_, fespace_->GetTrueVSize(), tdofs.data(), (int)tdofs.size(), policy,
                                        fespace_->GetHalo());

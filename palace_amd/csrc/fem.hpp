@@ -98,6 +98,11 @@ class Mesh {
   int ne_, q1d_, mesh_order_;
   int nq_dense_ = 0;  // > 0: element block described by dense tables (tetrahedra, ...), that many quadrature points
   int dim_ = 3, sdim_ = 3;
+  // host copy of the vertices: corner nodes per element (tensor blocks: lexicographic corners; dense blocks: the first
+  // dim + 1 nodes of a simplex) and the node coordinates -- what the AMS set-up reads from the ParMesh (hypre/ams.cpp:64-100)
+  int ncorner_ = 0;
+  std::vector<int32_t> corner_nodes_;
+  std::vector<double> nodes_;
 
 public:
   // node_offsets [ne][(mesh_order + 1)^3] lattice order, nodes [num_nodes][3], attr [ne] (1-based); the quadrature is
@@ -117,6 +122,8 @@ public:
   int GetNE() const { return ne_; }
   int GetQ1d() const { return q1d_; }
   int GetMeshOrder() const { return mesh_order_; }
+  // coordinates [GetVSize()][SpaceDimension()] of the dofs of a lowest-order H1 space on this mesh (its dofs are the vertices)
+  std::vector<double> VertexCoordinates(const class FiniteElementSpace &h1_p1) const;
 };
 
 // ---- finite element spaces ------------------------------------------------------------------------------------------
@@ -152,6 +159,12 @@ public:
   int GetMaxElementOrder() const { return order_; }
   int GetVSize() const { return vsize_; }
   int GetTrueVSize() const { return true_vsize_; }
+  int GetElemSize() const { return elem_size_; }
+  // local dof of tensor (lexicographic) index t of element e (dense spaces: of native index t)
+  int32_t GetElementDof(int e, int t) const {
+    const int j = dof_map_.empty() ? t : (dof_map_[t] >= 0 ? dof_map_[t] : -1 - dof_map_[t]);
+    return offsets_[(size_t)e * elem_size_ + j];
+  }
   const Halo *GetHalo() const { return halo_; }
   pa_restriction_desc GetCeedElemRestriction() const;
   pa_basis_desc GetCeedBasis() const;
@@ -288,8 +301,10 @@ class FespaceParOperator : public Operator {
   std::unique_ptr<Operator> local_;
   const FiniteElementSpace *fespace_;
   std::unique_ptr<ParOperator> par_;
+  std::vector<int32_t> ess_tdofs_;
 
 public:
+  const std::vector<int32_t> &GetEssentialTrueDofsHost() const { return ess_tdofs_; }
   FespaceParOperator(std::unique_ptr<Operator> &&A, const FiniteElementSpace &fespace);
   void SetEssentialTrueDofs(const std::vector<int32_t> &tdofs, ParOperator::DiagonalPolicy policy);
   const ParOperator &Par() const { return *par_; }

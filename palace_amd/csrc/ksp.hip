@@ -2,7 +2,10 @@
 #include "ksp.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
+
+#include "amg_solver.hpp"
 
 namespace palace {
 
@@ -25,6 +28,127 @@ public:
   void Mult(const Vector &x, Vector &y) const override {
     const_cast<CgSolver &>(cg_).SetInitialGuess(initial_guess);
     cg_.Mult(x, y);
+  }
+  void CheckStatus() const override { cg_.CheckStatus(); }
+};
+
+// ---- native algebraic coarse solvers (amg_solver.hpp) behind the reference's configuration names ----------------------
+// The reference hands the assembled coarse operator to HYPRE (BoomerAmgSolver, linalg/amg.cpp; HypreAmsSolver, linalg/ams.cpp).
+// HYPRE is an external package outside /root/reference; LinearSolver::BOOMER_AMG / AMS select the smoothed-aggregation
+// V-cycle / the auxiliary-space Maxwell cycle of amg_solver.hip instead (same role, same inputs: the assembled matrix of
+// the level, and for AMS the lowest-order discrete gradient and the vertex coordinates, ams.cpp:64-100).  One rank only.
+amg::HostCsr AssembledLevelMatrix(const Operator &op, std::vector<char> &ess_flag) {
+  const auto *fop = dynamic_cast<const FespaceParOperator *>(&op);
+  const ParOperator *par = fop ? &fop->Par() : dynamic_cast<const ParOperator *>(&op);
+  PA_REQUIRE(par, "the algebraic coarse solvers need a ParOperator (the level operator of the multigrid hierarchy)");
+  PA_REQUIRE(!par->GetHalo(), "the native AMG / AMS coarse solvers run on one rank (multi-rank: JACOBI_PCG or "
+                              "CHEBYSHEV_JACOBI)");
+  const auto &ess = par->GetEssentialTrueDofsHost();
+  ess_flag.assign((size_t)op.Height(), 0);
+  for (const int32_t d : ess) ess_flag[d] = 1;
+  if (const auto *csr = dynamic_cast<const CsrOperator *>(&par->LocalOperator()))
+    return DownloadCsr(csr->Matrix(), ess.data(), (int)ess.size());
+  const auto *pa = dynamic_cast<const ceed::Operator *>(&par->LocalOperator());
+  PA_REQUIRE(pa, "the coarse operator is neither assembled nor a partially assembled operator");
+  const auto m = BilinearForm::FullAssemble(*pa, /*skip_zeros=*/false);  // rap.cpp:84-152 does this for HYPRE
+  return DownloadCsr(m->Matrix(), ess.data(), (int)ess.size());
+}
+
+class NativeAmgSolver : public Solver {  // LinearSolver::BOOMER_AMG
+  const Context *ctx_;
+  int cycle_it_;
+  std::unique_ptr<AmgSolver> amg_;
+  mutable Vector r_, z_;
+
+public:
+  NativeAmgSolver(const Context &ctx, int cycle_it) : ctx_(&ctx), cycle_it_(std::max(cycle_it, 1)) {}
+  void SetOperator(const Operator &op) override {
+    StreamGraph::Invalidate();
+    height = op.Height(), width = op.Width();
+    A_ = &op;
+    std::vector<char> ess_flag;
+    amg_ = std::make_unique<AmgSolver>(*ctx_, AssembledLevelMatrix(op, ess_flag));
+  }
+  void Mult(const Vector &b, Vector &x) const override {
+    PA_REQUIRE(amg_, "NativeAmgSolver: SetOperator first");
+    amg_->Mult(b, x);
+    for (int it = 1; it < cycle_it_; it++) {  // further cycles as stationary iterations x += B (b - A x)
+      r_.SetSize(height), z_.SetSize(height);
+      A_->Mult(x, r_);
+      linalg::AXPBY(*ctx_, 1.0, b, -1.0, r_);
+      amg_->Mult(r_, z_);
+      linalg::AXPY(*ctx_, 1.0, z_, x);
+    }
+  }
+
+private:
+  const Operator *A_ = nullptr;
+};
+
+class NativeAmsSolver : public Solver {  // LinearSolver::AMS
+  const Context *ctx_;
+  const FiniteElementSpace *nd_, *h1_;
+  AmsOptions opt_;
+  std::unique_ptr<AmsSolver> ams_;
+
+  // the lowest-order discrete gradient as a matrix: every row is +1 at the edge's head and -1 at its tail, so two applications
+  // (to the vertex numbers and to their squares) identify both vertices of every edge
+  amg::HostCsr GradientMatrix() const {
+    const Operator &G = nd_->GetDiscreteInterpolator(*h1_);
+    const int nv = h1_->GetTrueVSize(), ne = nd_->GetTrueVSize();
+    PA_REQUIRE((double)nv * nv < 9.0e15, "too many vertices for the two-probe reconstruction of the gradient");
+    std::vector<double> x1((size_t)nv), x2((size_t)nv), d((size_t)ne), q((size_t)ne);
+    for (int v = 0; v < nv; v++) x1[v] = v + 1.0, x2[v] = (v + 1.0) * (v + 1.0);
+    Vector dx(nv), dy(ne);
+    auto apply = [&](const std::vector<double> &in, std::vector<double> &out) {
+      PA_HIP(hipMemcpyAsync(dx.Data(), in.data(), sizeof(double) * (size_t)nv, hipMemcpyHostToDevice, ctx_->stream));
+      G.Mult(dx, dy);
+      PA_HIP(hipMemcpyAsync(out.data(), dy.Data(), sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost, ctx_->stream));
+      PA_HIP(hipStreamSynchronize(ctx_->stream));
+    };
+    apply(x1, d), apply(x2, q);
+    amg::HostCsr Gm;
+    Gm.nrows = ne, Gm.ncols = nv;
+    Gm.rowptr.resize((size_t)ne + 1);
+    Gm.col.resize((size_t)2 * ne), Gm.val.resize((size_t)2 * ne);
+    for (int e = 0; e < ne; e++) {
+      const double diff = std::round(d[e]);
+      PA_REQUIRE(diff != 0.0 && std::abs(d[e] - diff) < 1e-6, "the discrete gradient is not an edge-vertex incidence matrix "
+                                                              "(AMS needs the lowest-order spaces on level 0)");
+      const double sum = std::round(q[e] / diff);
+      const int head = (int)((sum + diff) / 2) - 1, tail = (int)((sum - diff) / 2) - 1;
+      PA_REQUIRE(head >= 0 && head < nv && tail >= 0 && tail < nv && head != tail, "gradient reconstruction failed");
+      Gm.rowptr[e] = 2 * e;
+      const bool head_first = head < tail;
+      Gm.col[2 * e] = head_first ? head : tail, Gm.val[2 * e] = head_first ? 1.0 : -1.0;
+      Gm.col[2 * e + 1] = head_first ? tail : head, Gm.val[2 * e + 1] = head_first ? -1.0 : 1.0;
+    }
+    Gm.rowptr[ne] = 2 * ne;
+    return Gm;
+  }
+
+public:
+  NativeAmsSolver(const Context &ctx, const FiniteElementSpace &nd, const FiniteElementSpace &h1, int cycle_it, int singular)
+      : ctx_(&ctx), nd_(&nd), h1_(&h1) {
+    PA_REQUIRE(nd.GetMaxElementOrder() == 1 && h1.GetMaxElementOrder() == 1,
+               "the native AMS solver is built for the lowest-order level (the reference's default coarse level); use it as "
+               "the coarse solver of a p-multigrid hierarchy");
+    PA_REQUIRE(!nd.GetHalo() && !h1.GetHalo(), "the native AMS coarse solver runs on one rank");
+    opt_.cycle_it = std::max(cycle_it, 1);
+    opt_.singular = singular > 0;
+  }
+  void SetOperator(const Operator &op) override {
+    StreamGraph::Invalidate();
+    height = op.Height(), width = op.Width();
+    std::vector<char> ess_flag;
+    const amg::HostCsr A = AssembledLevelMatrix(op, ess_flag);
+    const amg::HostCsr G = GradientMatrix();
+    const std::vector<double> xyz = nd_->GetMesh().VertexCoordinates(*h1_);
+    ams_ = std::make_unique<AmsSolver>(*ctx_, A, G, xyz.data(), nd_->GetMesh().SpaceDimension(), ess_flag, opt_);
+  }
+  void Mult(const Vector &b, Vector &x) const override {
+    PA_REQUIRE(ams_, "NativeAmsSolver: SetOperator first");
+    ams_->Mult(b, x);
   }
 };
 
@@ -80,15 +204,23 @@ std::unique_ptr<Solver> ConfigurePreconditionerSolver(const config::LinearSolver
     case LinearSolver::JACOBI_PCG:
       pc = std::make_unique<JacobiPcgSolver>(ctx, linear.coarse_tol, linear.coarse_max_it);
       break;
-    case LinearSolver::AMS:
+    case LinearSolver::AMS: {
+      // ksp.cpp:143-152: the coarse solve of the multigrid hierarchy or the solver of the only level
+      PA_REQUIRE(aux_fespaces, "AMS solver relies on both primary space and auxiliary spaces for construction!");
+      const bool coarse_solver = fespaces.GetNumLevels() > 1;
+      pc = std::make_unique<NativeAmsSolver>(ctx, fespaces.GetFESpaceAtLevel(0), aux_fespaces->GetFESpaceAtLevel(0),
+                                             coarse_solver ? linear.ams_max_it : linear.mg_cycle_it, linear.ams_singular_op);
+    } break;
     case LinearSolver::BOOMER_AMG:
+      pc = std::make_unique<NativeAmgSolver>(ctx, fespaces.GetNumLevels() > 1 ? 1 : linear.mg_cycle_it);  // ksp.cpp:153-157
+      break;
     case LinearSolver::MUMPS:
     case LinearSolver::SUPERLU:
     case LinearSolver::STRUMPACK:
     case LinearSolver::STRUMPACK_MP:
     case LinearSolver::CUDSS:
-      throw pa::Error("this coarse solver lives in an external package (HYPRE / sparse direct) and is not part of "
-                      "palace_amd: use JACOBI, CHEBYSHEV_JACOBI or JACOBI_PCG");
+      throw pa::Error("the sparse direct solvers live in external packages and are not part of palace_amd: use AMS, "
+                      "BOOMER_AMG (native algebraic cycles), JACOBI, CHEBYSHEV_JACOBI or JACOBI_PCG");
     default:
       throw pa::Error("Unexpected solver type for preconditioner configuration!");
   }
@@ -117,6 +249,8 @@ std::unique_ptr<Solver> ConfigurePreconditionerSolver(const config::LinearSolver
 void config::LinearSolverData::SetDefaults(int order, bool spd_problem) {
   if (krylov_solver == KrylovSolver::DEFAULT) krylov_solver = spd_problem ? KrylovSolver::CG : KrylovSolver::GMRES;
   if (type == LinearSolver::DEFAULT) type = LinearSolver::JACOBI_PCG;  // (reference: AMS / BoomerAMG / a direct solver)
+  if (ams_max_it < 0) ams_max_it = 1;       // iodata.cpp: one AMS cycle per coarse solve
+  if (ams_singular_op < 0) ams_singular_op = 0;
   if (max_size < 0) max_size = max_it;
   if (initial_guess < 0) initial_guess = 1;
   if (mg_max_levels < 0) mg_max_levels = 100;
@@ -166,11 +300,13 @@ void SetPreconditionerOperators(Solver &pc_ref, const Operator &pc_op) {
 
 void KspSolver::SetOperators(const Operator &op, const Operator &pc_op) {
   // ksp.cpp:295-313; a multigrid preconditioner takes the operators of all levels (gmg.cpp:69-123)
+  PhaseRange range("Linear Solve / Setup");  // ksp.cpp:297
   ksp->SetOperator(op);
   if (pc) SetPreconditionerOperators(*pc, pc_op);
 }
 
 void KspSolver::Mult(const Vector &x, Vector &y) const {
+  PhaseRange range("Linear Solve");  // ksp.cpp:317
   ksp->Mult(x, y);
   if (!ksp->GetConverged())
     std::fprintf(stderr, "Warning: Linear solver did not converge, norm(Ax-b)/norm(b) = %.3e (norm(b) = %.3e)!\n",
@@ -197,11 +333,13 @@ ComplexKspSolver::ComplexKspSolver(const config::LinearSolverData &linear, int v
 }
 
 void ComplexKspSolver::SetOperators(const ComplexOperator &op, const Operator &pc_op) {
+  PhaseRange range("Linear Solve / Setup");
   ksp->SetOperator(op);
   SetPreconditionerOperators(*pc, pc_op);
 }
 
 void ComplexKspSolver::Mult(const ComplexVector &x, ComplexVector &y) const {
+  PhaseRange range("Linear Solve");
   ksp->Mult(x, y, initial_guess);
   if (!ksp->GetConverged())
     std::fprintf(stderr, "Warning: Linear solver did not converge, norm(Ax-b)/norm(b) = %.3e (norm(b) = %.3e)!\n",

@@ -43,6 +43,9 @@ struct LinearSolverData {
   bool mg_smooth_cheby_4th = true;
   PreconditionerSideOption pc_side = PreconditionerSideOption::DEFAULT;
   Orthogonalization gs_orthog = Orthogonalization::MGS;
+  // AMS (configfile.hpp:1087-1098): cycles per coarse solve, singular operator (no mass term: magnetostatics)
+  int ams_max_it = -1;
+  int ams_singular_op = -1;
   // stand-in coarse solvers only (not in the reference): iterations / tolerance of JACOBI_PCG, order of CHEBYSHEV_JACOBI
   int coarse_max_it = 8;
   double coarse_tol = 1.0e-2;

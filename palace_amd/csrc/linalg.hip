@@ -4,6 +4,8 @@
 // so the summation order (and with it iteration counts) is reproducible run to run.
 #include "linalg.hpp"
 
+#include <atomic>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdlib>
 #include <complex>
@@ -131,6 +133,39 @@ bool StreamGraph::Capture(const Context &c, const std::function<void()> &body) {
   }
   return true;
 }
+namespace {
+std::atomic<unsigned long long> g_config_epoch{1};
+
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char *e = std::getenv("PALACE_AMD_ROCTX");
+    if (e && e[0] == '0') return;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr, pop = nullptr;
+      }
+    }
+  }
+};
+const Roctx &roctx() {
+  static const Roctx r;
+  return r;
+}
+}  // namespace
+PhaseRange::PhaseRange(const char *name) : on_(roctx().push != nullptr) {
+  if (on_) roctx().push(name);
+}
+PhaseRange::~PhaseRange() {
+  if (on_) roctx().pop();
+}
+void StreamGraph::Invalidate() { g_config_epoch.fetch_add(1, std::memory_order_relaxed); }
+unsigned long long StreamGraph::Epoch() { return g_config_epoch.load(std::memory_order_relaxed); }
+
 void StreamGraph::Run(const Context &c, const std::vector<const void *> &key, const std::function<void()> &body) {
   if (!c.stream) return body();  // the null stream cannot be recorded
   // RCCL calls stay outside recordings (untested inside a capture here); the peer transport is plain kernels
@@ -139,7 +174,7 @@ void StreamGraph::Run(const Context &c, const std::vector<const void *> &key, co
   if (hipStreamIsCapturing(c.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return body();  // part of an enclosing recording (the V-cycle inside a PCG iteration)
   if (!disabled_) {
-    if (key != key_) Reset(), key_ = key;
+    if (key != key_ || epoch_ != Epoch()) Reset(), key_ = key, epoch_ = Epoch();
     if (!exec_ && seen_++ >= 1) {
       if (!Capture(c, body)) disabled_ = true;  // nothing of the recording ran: fall through to the direct form
     }
@@ -499,12 +534,14 @@ enum CgSlot { CG_BETA = 0, CG_BETA_PREV, CG_DENOM, CG_RES, CG_EPS, CG_INIT, CG_S
 enum CgStep { CG_STEP_RHS = 0, CG_STEP_START, CG_STEP_DENOM, CG_STEP_BETA };
 struct CgTol {
   double rel, abs;
-  int use_rhs;  // initial residual from the right-hand side (initial guess given)
+  int use_rhs;  // initial residual from the right-hand side (initial guess given): 1 = (B b, b), 2 = no preconditioner
 };
 template <int STEP>
 __device__ __forceinline__ void cg_scalar_step(double *__restrict__ st, const double v, const CgTol tol) {
-  if (STEP == CG_STEP_RHS) {  // (B b, b) or (b, b)
-    st[CG_INIT] = sqrt(fabs(v));
+  if (STEP == CG_STEP_RHS) {
+    // (B b, b) -> sqrt |.|; without a preconditioner the reference takes sqrt |Norml2(b)| (iterative.cpp:406-411: the
+    // norm, not its square, goes under the root) and so does MultHost -- v = (b, b) here
+    st[CG_INIT] = tol.use_rhs == 2 ? sqrt(sqrt(fabs(v))) : sqrt(fabs(v));
   } else if (STEP == CG_STEP_START) {  // beta = (z, r), iterative.cpp:400-421
     const double res = sqrt(fabs(v));
     st[CG_BETA] = v, st[CG_BETA_PREV] = v, st[CG_RES] = res, st[CG_IT] = 0.0;
@@ -807,12 +844,16 @@ void Operator::MultComplex(const Operator &Ar, const Operator &Ai, const Vector 
     throw pa::Error(pa_last_error());
 }
 void Operator::SetInterfaceDofs(const std::vector<int32_t> &ldofs) {
+  StreamGraph::Invalidate();
   if (pa_op_set_interface_dofs(op_, ldofs.data(), (int32_t)ldofs.size())) throw pa::Error(pa_last_error());
 }
 void Operator::MultAfter(const Vector &x, Vector &y, hipEvent_t after) const {
   if (pa_op_mult_after(op_, x.Data(), y.Data(), ctx_->stream, after)) throw pa::Error(pa_last_error());
 }
-void Operator::SetEssential(const int32_t *ess_host, int n) { check(pa_op_set_essential(op_, ess_host, n)); }
+void Operator::SetEssential(const int32_t *ess_host, int n) {
+  StreamGraph::Invalidate();
+  check(pa_op_set_essential(op_, ess_host, n));
+}
 bool Operator::MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const {
   int handled = 0;
   check(pa_op_mult_essential_diag(op_, x.Data(), y.Data(), diag_one ? 1 : 0, ctx_->stream, &handled));
@@ -844,6 +885,7 @@ void DiagonalOperator::AddMult(const Vector &x, Vector &y, double a) const {
 void DiagonalOperator::AssembleDiagonal(Vector &diag) const { linalg::Copy(*ctx_, d_, diag); }
 
 void SumOperator::AddOperator(const Operator &op, double a) {
+  StreamGraph::Invalidate();
   PA_REQUIRE(op.Height() == height && op.Width() == width, "Invalid Operator dimensions for BaseSumOperator!");
   ops_.emplace_back(&op, a);
 }
@@ -915,8 +957,10 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
   PA_REQUIRE(A.Height() == A.Width(), "ParOperator needs a square local operator");
   PA_REQUIRE(n_true <= n_local_, "more true dofs than local dofs");
   PA_REQUIRE(halo != nullptr || n_true == n_local_, "local != true dofs requires a halo plan");
+  if (halo) halo->Validate(n_true, n_local_);
   for (int i = 0; i < n_ess; i++) PA_REQUIRE(ess_host[i] >= 0 && ess_host[i] < n_true, "essential dof out of range");
   if (n_ess) d_ess_ = pa::dev_upload(ess_host, (size_t)n_ess, ctx.stream);
+  if (n_ess) ess_host_.assign(ess_host, ess_host + n_ess);
   lx_.SetSize(n_local_);
   ly_.SetSize(n_local_);
   // One rank (P = identity): let the element kernel read essential entries as zero and write y
@@ -954,14 +998,15 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
   }
   if (!halo) {
     if (auto *m = dynamic_cast<const CsrOperator *>(&A)) {
-      const_cast<CsrOperator *>(m)->EliminateEssential(d_ess_, n_ess, policy == DiagonalPolicy::DIAG_ONE);
-      A_csr_ = m;
+      d_csr_bc_ = m->EliminatedValues(d_ess_, n_ess, policy == DiagonalPolicy::DIAG_ONE);
+      if (d_csr_bc_) A_csr_ = m;
     }
   }
 }
 ParOperator::~ParOperator() {
   if (d_ess_mask_) (void)hipFree(d_ess_mask_);
   if (d_ess_) (void)hipFree(d_ess_);
+  if (d_csr_bc_) (void)hipFree(d_csr_bc_);
 }
 
 void ParOperator::Mult(const Vector &x, Vector &y) const {
@@ -976,7 +1021,7 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
     return;
   }
   if (A_csr_ && x.Data() != y.Data()) {
-    A_csr_->Mult(x, y);  // essential rows / columns live in the matrix
+    A_csr_->MultValues(d_csr_bc_, x, y);  // essential rows / columns live in this wrapper's copy of the values
     return;
   }
   if (halo_ && halo_->UsesPeerTransport() && d_ess_mask_ && x.Data() != y.Data() && !A_overlap_) {
@@ -1084,10 +1129,7 @@ void ParOperator::EliminateRHS(const Vector &x, Vector &b) const {
   if (halo_) halo_->Prolongate(lx_.Data(), c.stream);
   else if (n_local_ > n_true_)
     PA_HIP(hipMemsetAsync(lx_.Data() + n_true_, 0, sizeof(double) * (size_t)(n_local_ - n_true_), c.stream));
-  if (A_csr_)
-    A_csr_->MultUnconstrained(lx_, ly_);
-  else
-    A_->Mult(lx_, ly_);
+  A_->Mult(lx_, ly_);
   if (halo_) halo_->RestrictAdd(ly_.Data(), c.stream);
   Vector ty(ly_.Data(), n_true_);
   linalg::AXPY(c, -1.0, ty, b);
@@ -1111,6 +1153,7 @@ void ParOperator::AssembleDiagonal(Vector &diag) const {
 
 // ---- smoothers --------------------------------------------------------------------------------
 void JacobiSmoother::SetOperator(const Operator &op) {
+  StreamGraph::Invalidate();
   A_ = &op, height = op.Height(), width = op.Width();
   dinv_.SetSize(height);
   op.AssembleDiagonal(dinv_);
@@ -1122,6 +1165,7 @@ void JacobiSmoother::Mult(const Vector &x, Vector &y) const {
 }
 
 void ChebyshevSmoother::SetOperator(const Operator &op) {
+  StreamGraph::Invalidate();
   // chebyshev.cpp:169-188 (4th kind) / :232-257 (1st kind)
   A_ = &op, height = op.Height(), width = op.Width();
   d_.SetSize(height), dinv_.SetSize(height), r_.SetSize(height), t_.SetSize(height);
@@ -1175,6 +1219,7 @@ DistRelaxationSmoother::DistRelaxationSmoother(const Context &ctx, const Operato
   B_G_->SetInitialGuess(false);
 }
 void DistRelaxationSmoother::SetOperators(const Operator &op, const ParOperator &op_G) {
+  StreamGraph::Invalidate();
   PA_REQUIRE(op.Height() == G_->Height() && op.Width() == G_->Height() && op_G.Height() == G_->Width() &&
                  op_G.Width() == G_->Width(),
              "Invalid operator sizes for DistRelaxationSmoother!");
@@ -1325,6 +1370,9 @@ void CgSolver::Finish() const {
   const double *st = dev_->Slot(0);
   initial_res_ = st[CG_INIT], final_res_ = st[CG_RES], final_it_ = (int)st[CG_IT];
   converged_ = st[CG_BAD] == 0.0 && st[CG_RES] < st[CG_EPS];
+  // the solve ran without the host looking (inside a recorded sequence): raise now what CheckDot would have raised then
+  PA_REQUIRE(st[CG_BAD] != 1.0, "PCG preconditioner is not positive definite: (Br, r) not finite");
+  PA_REQUIRE(st[CG_BAD] != 2.0, "PCG operator is not positive definite: (Ap, p) not finite");
 }
 
 void CgSolver::MultDevice(const Vector &b, Vector &x) const {
@@ -1338,8 +1386,9 @@ void CgSolver::MultDevice(const Vector &b, Vector &x) const {
   d.Setup(L >= 0 ? L + 2 : 1);
   d.pending = false;
   double *st = d.d_st;
-  const CgTol tol{rel_tol_, abs_tol_, initial_guess ? 1 : 0};
+  const CgTol tol{rel_tol_, abs_tol_, initial_guess ? (B_ ? 1 : 2) : 0};
   auto precond = [&](const Vector &u, Vector &v) {
+    PhaseRange range("Preconditioner");  // iterative.cpp:247
     if (B_) B_->Mult(u, v); else linalg::Copy(c, u, v);
   };
   auto check = [&](const double *h) {
@@ -1406,6 +1455,7 @@ void CgSolver::MultDevice(const Vector &b, Vector &x) const {
   check(h);
   initial_res_ = h[CG_INIT], final_res_ = h[CG_RES], final_it_ = (int)h[CG_IT];
   converged_ = h[CG_RES] < h[CG_EPS];
+  if (B_) B_->CheckStatus();  // deferred failures of nested solvers (the coarse PCG inside the recorded V-cycle)
   if (print_ > 0)
     std::printf("  PCG solver %s in %d iterations (res %.3e, initial %.3e)\n",
                 converged_ ? "converged" : "did NOT converge", final_it_, final_res_, initial_res_);
@@ -1481,7 +1531,10 @@ struct RealKrylovOps {
   }
   void A(const Vec &x, Vec &y) const { A_->Mult(x, y); }
   bool HasB() const { return B_ != nullptr; }
-  void B(const Vec &x, Vec &y) const { B_->Mult(x, y); }
+  void B(const Vec &x, Vec &y) const {
+    PhaseRange range("Preconditioner");  // iterative.cpp:247
+    B_->Mult(x, y);
+  }
   void Copy(const Vec &x, Vec &y) const { linalg::Copy(c, x, y); }
   void Zero(Vec &x) const { linalg::Fill(c, x, 0.0); }
   void BMinus(const Vec &b, Vec &r) const { linalg::AXPBY(c, 1.0, b, -1.0, r); }
@@ -1505,6 +1558,7 @@ void GmresSolver::Mult(const Vector &b, Vector &x) const {
   krylov::Result res;
   krylov::GmresMult(ops, p, b, x, V_, Z_, r_, res);
   converged_ = res.converged, initial_res_ = res.initial_res, final_res_ = res.final_res, final_it_ = res.final_it;
+  if (B_) B_->CheckStatus();
 }
 
 // ---- geometric multigrid (gmg.cpp) ---------------------------------------------------------------
@@ -1531,6 +1585,7 @@ GeometricMultigridSolver::GeometricMultigridSolver(const Context &ctx, std::uniq
 
 void GeometricMultigridSolver::SetOperators(const std::vector<const ParOperator *> &ops,
                                             const std::vector<const ParOperator *> *aux_ops) {
+  StreamGraph::Invalidate();
   PA_REQUIRE(ops.size() == A_.size(), "Invalid number of levels for operators in multigrid solver setup!");
   for (size_t l = 0; l < ops.size(); l++) {
     A_[l] = ops[l];
@@ -1565,6 +1620,7 @@ void GeometricMultigridSolver::VCycle(int l, bool initial_guess) const {
   const Context &c = *ctx_;
   B_[l]->SetInitialGuess(initial_guess);
   if (l == 0) {
+    PhaseRange range("Coarse Solve");  // gmg.cpp:180
     B_[l]->Mult(X_[l], Y_[l]);
     return;
   }

@@ -68,9 +68,15 @@ struct Context {
 // its first run with a key is direct (work vectors get their sizes there), the second one is captured.  A failed
 // capture disables the graph for good and the body runs directly; so does a context on the null stream, which cannot
 // be recorded.  PALACE_AMD_GRAPH=0 disables all graphs.
+//
+// Staleness: a recording bakes in kernel arguments (operator and smoother device pointers, Chebyshev lambda_max, essential
+// lists, tolerances).  Every call that re-configures an operator or solver in place (SetOperator(s), SetPreconditioner,
+// SetEssential, SetTol/SetMaxIter, coefficient changes of a SumOperator, ...) calls StreamGraph::Invalidate(), which bumps a
+// process-wide configuration epoch; a recording made under an older epoch is dropped and made again on its next Run.
 class StreamGraph {
   hipGraphExec_t exec_ = nullptr;
   std::vector<const void *> key_;
+  unsigned long long epoch_ = 0;
   int seen_ = 0;
   bool disabled_ = false;
   bool Capture(const Context &c, const std::function<void()> &body);
@@ -86,7 +92,24 @@ public:
   // (it throws, the recording is dropped cleanly and the sequence runs directly from then on)
   static bool Recording();
   static void RequireNotRecording(const char *what);
+  static void Invalidate();  // some operator/solver was re-configured: every recording is stale
+  static unsigned long long Epoch();
   void Run(const Context &c, const std::vector<const void *> &key, const std::function<void()> &body);
+};
+
+// Named host ranges for profilers, after the reference's BlockTimer phases (utils/timer.hpp:29-56, :59-84): "Linear Solve",
+// "  Setup", "  Preconditioner", "  Coarse Solve", "Operator Construction", "Estimation" ... -- emitted as roctx ranges
+// (rocprofv3 --marker-trace shows them over the kernels of the phase).  The roctx library is looked up at run time on
+// first use; without it, or with PALACE_AMD_ROCTX=0, a range costs one branch.  Ranges inside a recorded sequence appear on
+// the runs that execute the host code (the first two), not on graph replays.
+class PhaseRange {
+  bool on_;
+
+public:
+  explicit PhaseRange(const char *name);
+  ~PhaseRange();
+  PhaseRange(const PhaseRange &) = delete;
+  PhaseRange &operator=(const PhaseRange &) = delete;
 };
 
 // Device vector: owning, or a view of caller memory (mfem::Vector with device memory in Palace).
@@ -274,20 +297,22 @@ class CsrOperator : public Operator {
   const Context *ctx_;
   const pa_csr *m_;
   int lanes_;
-  mutable double *d_val_bc_ = nullptr;  // values with the essential rows / columns eliminated (owned)
-  void Apply(const Vector &x, Vector &y, double a, bool add) const;
+  void Apply(const double *vals, const Vector &x, Vector &y, double a, bool add) const;
 
 public:
   CsrOperator(const Context &ctx, const pa_csr *m);
   ~CsrOperator() override;
-  // one rank: fold ParOperator's essential-dof handling into the matrix (rows and columns zeroed, diagonal 1 | 0)
-  void EliminateEssential(const int32_t *d_ess, int n_ess, bool diag_one);
-  void MultUnconstrained(const Vector &x, Vector &y) const;
+  // one rank: ParOperator's essential-dof handling folded into a copy of the values (rows and columns zeroed, diagonal
+  // 1 | 0).  The copy belongs to the caller (hipFree): several wrappers with different essential lists can share one matrix,
+  // and this operator itself always applies the unconstrained values.
+  double *EliminatedValues(const int32_t *d_ess, int n_ess, bool diag_one) const;
+  void MultValues(const double *d_vals, const Vector &x, Vector &y) const;  // y = A' x, A' = this pattern with `d_vals`
   void Mult(const Vector &x, Vector &y) const override;
   void MultTranspose(const Vector &x, Vector &y) const override;  // symmetric matrices only (pa_csr::symmetric)
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
   void AssembleDiagonal(Vector &diag) const override;
   bool IsSymmetric() const override { return m_->symmetric; }
+  const pa_csr &Matrix() const { return *m_; }
 };
 
 // ParOperator (rap.cpp:154-234): y = P^T A P x with essential-dof handling.  True dofs of this
@@ -302,11 +327,13 @@ private:
   const Operator *A_;
   const ceed::Operator *A_fused_ = nullptr;  // single rank: BC masking fused into the local apply
   const ceed::Operator *A_overlap_ = nullptr;  // with a halo: interior elements run while the ghosts are exchanged
-  const CsrOperator *A_csr_ = nullptr;       // single rank, assembled local operator: BCs eliminated in the matrix
+  const CsrOperator *A_csr_ = nullptr;       // single rank, assembled local operator: BCs eliminated in the matrix values
+  double *d_csr_bc_ = nullptr;               // ... this wrapper's copy of them (CsrOperator::EliminatedValues)
   const Halo *halo_;
   int n_true_, n_local_;
   int32_t *d_ess_ = nullptr;
   int n_ess_ = 0;
+  std::vector<int32_t> ess_host_;
   uint8_t *d_ess_mask_ = nullptr;  // with a halo: one byte per true dof, so that copy + mask and copy + fix-up are one launch each
   DiagonalPolicy policy_;
   mutable Vector lx_, ly_;
@@ -317,6 +344,7 @@ public:
   ~ParOperator() override;
   const int32_t *GetEssentialTrueDofs() const { return d_ess_; }
   int NumEssentialTrueDofs() const { return n_ess_; }
+  const std::vector<int32_t> &GetEssentialTrueDofsHost() const { return ess_host_; }
   const Operator &LocalOperator() const { return *A_; }
   bool FusesEssential() const { return A_fused_ != nullptr; }  // the essential list lives in the local operator's index tables
   DiagonalPolicy GetDiagonalPolicy() const { return policy_; }
@@ -346,10 +374,15 @@ protected:
 
 public:
   virtual void SetOperator(const Operator &op) = 0;
+  // (not a re-configuration in the StreamGraph sense: composite solvers flip it inside their own recorded sequence)
   void SetInitialGuess(bool guess = true) { initial_guess = guess; }
   // y <- y + B (x - A y) style entry points used by the V-cycle (gmg.cpp:184,204)
   virtual void Mult2(const Vector &x, Vector &y, Vector &r) const;
   virtual void MultTranspose2(const Vector &x, Vector &y, Vector &r) const { Mult2(x, y, r); }
+  // Surface failures a nested solver could only note on the device while it ran inside a recorded sequence (the inner PCG
+  // of a multigrid cycle: non-finite (Br, r) / (Ap, p), the reference's CheckDot abort, iterative.cpp:39-45).  Outer Krylov
+  // solvers call this on their preconditioner after a solve; composite solvers forward it to their parts.
+  virtual void CheckStatus() const {}
 };
 
 namespace linalg {
@@ -430,11 +463,18 @@ protected:
 
 public:
   explicit IterativeSolver(const Context &ctx, int print = 0) : ctx_(&ctx), print_(print) {}
-  void SetOperator(const Operator &op) override { A_ = &op, height = op.Height(), width = op.Width(); }
-  virtual void SetPreconditioner(const Solver &pc) { B_ = &pc; }
-  void SetTol(double tol) { rel_tol_ = tol; }
-  void SetAbsTol(double tol) { abs_tol_ = tol; }
-  void SetMaxIter(int its) { max_it_ = its; }
+  void SetOperator(const Operator &op) override {
+    A_ = &op, height = op.Height(), width = op.Width();
+    StreamGraph::Invalidate();
+  }
+  virtual void SetPreconditioner(const Solver &pc) { B_ = &pc, StreamGraph::Invalidate(); }
+  void SetTol(double tol) { rel_tol_ = tol, StreamGraph::Invalidate(); }
+  void SetAbsTol(double tol) { abs_tol_ = tol, StreamGraph::Invalidate(); }
+  void SetMaxIter(int its) { max_it_ = its, StreamGraph::Invalidate(); }
+  void CheckStatus() const override {
+    Finish();
+    if (B_) B_->CheckStatus();
+  }
   bool GetConverged() const { return Finish(), converged_; }
   double GetInitialRes() const { return Finish(), initial_res_; }
   double GetFinalRes() const { return Finish(), final_res_; }
@@ -540,6 +580,9 @@ public:
   void SetOperator(const Operator &) override { throw pa::Error("use SetOperators for multigrid"); }
   void Mult(const Vector &x, Vector &y) const override;
   const Solver &Smoother(int l) const { return *B_[l]; }
+  void CheckStatus() const override {
+    for (const auto &b : B_) b->CheckStatus();
+  }
 };
 
 }  // namespace palace

@@ -23,6 +23,7 @@
 //
 // No LDS is needed except for the neighbour exchange of the curl-oriented (tridiagonal) restriction.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <type_traits>
@@ -968,7 +969,7 @@ void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
   switch (ds.mode) {
 #define PA_RES_CASE(MODE)                                                                                \
   case MODE: {                                                                                           \
-    static bool attr_set = false;                                                                        \
+    static std::atomic<bool> attr_set{false}; /* idempotent set-up; rank threads may race here */ \
     if (!attr_set) {                                                                                     \
       PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE, false>,             \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
@@ -1016,7 +1017,7 @@ void launch_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
   switch (ds.mode) {
 #define PA_DENSE_CASE(MODE)                                                                              \
   case MODE: {                                                                                           \
-    static bool attr_set = false;                                                                        \
+    static std::atomic<bool> attr_set{false}; /* idempotent set-up; rank threads may race here */ \
     if (!attr_set) {                                                                                     \
       PA_HIP(hipFuncSetAttribute((const void *)dense_apply_kernel<PT, MODE>,                             \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
@@ -1669,7 +1670,7 @@ static void launch_resident_complex_pt(const DenseSub &dr, const DenseArgs &a, h
                                       (dr.d_co ? (size_t)kResWaves * 4 * PT * 64 : 0));
   int grid = (2 * dr.nb + kResWaves - 1) / kResWaves;
   if (grid > dr.num_cu) grid = dr.num_cu;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent set-up, may race between rank threads
   if (!attr_set) {
     PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -117,6 +117,9 @@ int pa_local_group_create(int size, pa_local_group **out) {
   });
 }
 void pa_local_group_destroy(pa_local_group *g) { delete g; }
+void pa_local_group_abort(pa_local_group *g) {
+  if (g) g->group.Abort();
+}
 int pa_context_init_comm_local(pa_context *ctx, int rank, pa_local_group *g) {
   return guarded([&] {
     PA_REQUIRE(ctx && g && rank >= 0 && rank < g->group.Size(), "bad communicator arguments");
@@ -665,6 +668,7 @@ static void gmg_create(pa_context *ctx, int nlevels, pa_par_op *const *A, pa_int
         inner->SetInitialGuess(false);
         inner->Mult(x, y);
       }
+      void CheckStatus() const override { inner->CheckStatus(); }
     };
     s->owned.push_back(coarse);
     // a Krylov coarse solve inside the cycle must not stall the stream (see GeometricMultigridSolver's constructor)
@@ -719,6 +723,15 @@ int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess) 
     S->solver->SetInitialGuess(initial_guess != 0);
     S->solver->Mult(vb, vx);
   });
+}
+struct pa_range {
+  PhaseRange r;
+  explicit pa_range(const char *name) : r(name) {}
+};
+pa_range *pa_range_push(const char *name) { return new pa_range(name ? name : ""); }
+void pa_range_pop(pa_range *r) { delete r; }
+int pa_solver_check_status(const pa_solver *S) {
+  return guarded([&] { S->solver->CheckStatus(); });
 }
 int pa_solver_stats(const pa_solver *S, int *its, double *initial_res, double *final_res, int *converged) {
   return guarded([&] {

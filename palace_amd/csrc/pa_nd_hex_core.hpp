@@ -125,6 +125,18 @@ struct NDLayoutInPlace {
   __device__ static __forceinline__ int ia(int f, int qx, int j, int k) { return f * A_FIELD + qx * S::Sq + j * S::Sj + k; }
   __device__ static __forceinline__ int ib(int f, int qx, int qy, int k) { return f * B_FIELD + qx * S::Tq + qy * S::Ty + k; }
 };
+// ... and for four points per direction with the XOR swizzle of NDLayout<3, 4> (p = 3)
+struct NDLayoutInPlaceSwz3 {
+  static constexpr int NC = 4, A_FIELD = 64, B_FIELD = 64, ELEM = 192, ELEM_PAD = 192;
+  static constexpr bool INPLACE = true;
+  __device__ static __forceinline__ int ia(int f, int qx, int j, int k) {
+    return f * 64 + qx * 16 + (((j ^ qx) & 3) << 2) + ((k ^ qx) & 3);
+  }
+  __device__ static __forceinline__ int ib(int f, int qx, int qy, int k) {
+    return f * 64 + qx * 16 + (((qy ^ qx) & 3) << 2) + ((k ^ qx) & 3);
+  }
+  __device__ static __forceinline__ int parity_xor(int sub) { return (sub & 1) << 4; }
+};
 template <class LT, class = void>
 struct NDInPlace {
   static constexpr bool value = false;

@@ -76,7 +76,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #else
   constexpr bool EARLY_IDX = P1 < 3;
 #endif
-  using L = NDLayout<P1, Q1>;
+  // p = 3 curl-curl: the two contraction buffers share their LDS (pa_nd_hex_core.hpp: in-place layout), 2.4 instead of
+  // 3.4 KB per element, so that the twelve waves per CU its 168 registers allow are resident instead of ten (measured on the
+  // 10M-dof case: 174 -> 167 us per ParOperator::Mult; the kernels with a mass term, two waves per SIMD, gain nothing and the
+  // mass kernel loses 2 %, so they keep the separate buffers)
+  using L = typename std::conditional<P1 == 3 && !CPLX && USE_C && !USE_U, NDLayoutInPlaceSwz3, NDLayout<P1, Q1>>::type;
   constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
   constexpr int NG = METRIC ? (USE_U ? 7 : 6) : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
   static_assert(PP <= 256, "8-bit slots");
@@ -223,9 +227,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     for (int c = 0; c < 3; c++)
 #pragma unroll
       for (int q = 0; q < Q1; q++) U[c][q] = 0.0, CU[c][q] = 0.0;
-    nd_fwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
-    nd_fwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
-    nd_fwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
+    nd_fwd_comp<0, P1, Q1, USE_U, USE_C, L>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
+    nd_fwd_comp<1, P1, Q1, USE_U, USE_C, L>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
+    nd_fwd_comp<2, P1, Q1, USE_U, USE_C, L>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
 
     PA_STAMP(3);  // forward done
     PA_STAMP(4);
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
-    nd_bwd_comp<0, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
+    nd_bwd_comp<0, P1, Q1, USE_U, USE_C, L>(a, e, true, true, ta, tb, lx, sm, uin[0], U, CU);
     PA_STAMP(6);  // first transposed component done
     if (GPOS == 1) {
       __builtin_amdgcn_sched_barrier(0);
@@ -293,14 +297,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       __builtin_amdgcn_sched_barrier(0);
     }
     PA_STAMP(7);  // (GPOS 1) index words landed, x requested
-    nd_bwd_comp<1, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
+    nd_bwd_comp<1, P1, Q1, USE_U, USE_C, L>(a, e, true, true, ta, tb, lx, sm, uin[1], U, CU);
     if (GPOS == 2) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, pB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
-    nd_bwd_comp<2, P1, Q1, USE_U, USE_C>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
+    nd_bwd_comp<2, P1, Q1, USE_U, USE_C, L>(a, e, true, true, ta, tb, lx, sm, uin[2], U, CU);
     if (GPOS == 3) {
       __builtin_amdgcn_sched_barrier(0);
       gather(sB, pB, xB, stab, t);
@@ -574,7 +578,7 @@ static int device_cus() {
 
 template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS, bool CPLX = false>
 static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
-  using L = NDLayout<P1, 4>;
+  using L = typename std::conditional<P1 == 3 && !CPLX && C && !U, NDLayoutInPlaceSwz3, NDLayout<P1, 4>>::type;  // (as in the kernel)
   for (int i = 0; i < HalfTab<P1, 4>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
   for (int i = 0; i < HalfTab<P1 + 1, 4>::LEN; i++) a.tab.Bc[i] = so.Bc[i], a.tab.Gc[i] = so.Gc[i];
   constexpr int PP = 3 * P1 * (P1 + 1) * (P1 + 1);

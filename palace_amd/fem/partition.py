@@ -309,6 +309,54 @@ class SlabProblem:
         return K, b, x
 
 
+    def h1_pcg_gmg_solver(self, order=2, max_it=50, rel_tol=0.0, eps_r=2.08, coarse="amg"):
+        """The electrostatic-type system of BASELINE config 4: H1 order-`order` diffusion (eps grad u, grad v), Dirichlet data
+        on the whole boundary, PCG with p-multigrid (levels 1..order, 4th-kind Chebyshev of order max(2p, 4), plain smoothers:
+        iodata.cpp:533-564 for the SPD problem types) and on the assembled order-1 level the algebraic V-cycle (`coarse` =
+        "amg": where the reference calls BoomerAMG, linalg/amg.cpp; one rank) or Chebyshev-Jacobi of order 4 ("chebyshev")."""
+        import torch
+
+        from .. import ceed, linalg
+
+        ctx = self.ctx
+        eps = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([eps_r])])
+        z_lo = self.rank * self.height
+        orders = list(range(1, order + 1))
+        h1s = [SlabH1Space(self.mesh, q, self.rank, self.world, z_lo, z_lo + self.height, self.radius) for q in orders]
+        halos = [linalg.Halo(ctx, s.nbr, s.send, s.recv) if self.world > 1 else None for s in h1s]
+        geom = self.geom if order + 1 == self.geom.q1d else ceed.GeomFactorData(self.mesh, order + 1)
+        fine = ceed.diffusion_operator(geom, h1s[-1], eps)
+        local = [fine.coarsen(geom, s) for s in h1s[:-1]] + [fine]
+        ess = [s.ess_dofs() for s in h1s]
+        A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE, n_true=s.n_true, halo=h)
+             for op, e, s, h in zip(local, ess, h1s, halos)]
+        csr0 = None
+        if len(A) > 1:
+            csr0 = local[0].full_assemble_device()
+            A[0] = linalg.AssembledParOperator(ctx, csr0, ess[0], linalg.DIAG_ONE, n_true=h1s[0].n_true, halo=halos[0])
+        P = [linalg.Interp(ctx, h1s[l], h1s[l + 1], coarse_halo=halos[l], n_true_c=h1s[l].n_true, n_true_f=h1s[l + 1].n_true)
+             for l in range(len(A) - 1)]
+        if len(A) > 1:
+            if coarse == "amg":
+                assert self.world == 1, "the native AMG cycle works on one rank's matrix"
+                csolver = linalg.amg(ctx, csr0, ess[0])
+            else:
+                csolver = linalg.chebyshev(ctx, A[0], 4)
+            B = linalg.gmg(ctx, A, P, csolver, cheby_order=max(2 * order, 4))
+        else:
+            B = linalg.jacobi(ctx, A[0])
+        K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)
+        n = h1s[-1].n_true
+        ones = torch.ones(n, dtype=torch.float64, device="cuda")
+        b = torch.empty_like(ones)
+        A[-1].mult(ones * torch.linspace(0.0, 1.0, n, dtype=torch.float64, device="cuda"), b)
+        b[torch.from_numpy(ess[-1].astype(np.int64)).cuda()] = 0.0
+        x = torch.zeros_like(b)
+        self._keep.append((h1s, halos, local, A, P, B, csr0, geom))
+        self.h1_fine = A[-1]
+        return K, b, x
+
+
 # ---- host-side executors of a halo plan over torch.distributed (CPU tests, gloo) -------------
 
 def prolongate_dist(space, lx):

@@ -238,6 +238,27 @@ class Context:
             pass
 
 
+class phase_range:
+    """`with phase_range("Time Stepping"): ...` -- a named roctx range around a phase (pa_range_push / pa_range_pop)."""
+
+    def __init__(self, name):
+        self.name, self.h = name, None
+
+    def __enter__(self):
+        L = _L()
+        L.pa_range_push.restype = C.c_void_p
+        L.pa_range_push.argtypes = [C.c_char_p]
+        self.h = L.pa_range_push(self.name.encode())
+        return self
+
+    def __exit__(self, *exc):
+        L = _L()
+        L.pa_range_pop.restype = None
+        L.pa_range_pop.argtypes = [C.c_void_p]
+        L.pa_range_pop(self.h)
+        return False
+
+
 class LocalGroup:
     """pa_local_group: the rendezvous object shared by the rank threads of an in-process group."""
 
@@ -248,6 +269,13 @@ class LocalGroup:
         self.size = int(size)
         self.handle = C.c_void_p()
         _lib.check(L.pa_local_group_create(self.size, C.byref(self.handle)))
+
+    def abort(self):
+        """Called by a failing rank thread: the others leave their barriers with an error."""
+        L = _L()
+        L.pa_local_group_abort.restype = None
+        L.pa_local_group_abort.argtypes = [C.c_void_p]
+        L.pa_local_group_abort(self.handle)
 
     def __del__(self):
         try:
@@ -363,6 +391,10 @@ class Solver:
         r0, r1 = C.c_double(), C.c_double()
         _lib.check(_L().pa_solver_stats(self.handle, C.byref(its), C.byref(r0), C.byref(r1), C.byref(conv)))
         return dict(iterations=its.value, initial_res=r0.value, final_res=r1.value, converged=bool(conv.value))
+
+    def check_status(self):
+        """Raise what a nested solver noted on the device while it ran unattended (Solver::CheckStatus)."""
+        _lib.check(_L().pa_solver_check_status(self.handle))
 
     def mult2(self, x, y, transpose=False, initial_guess=False):
         """Solver::Mult2 / MultTranspose2: y <- y + B (x - A y)."""

@@ -57,7 +57,14 @@ def _python_solve(aux, krylov, coarse):
         A_h1 = [linalg.ParOperator(ctx, op, s.ess_dofs(), linalg.DIAG_ONE) for op, s in zip(loc_h1, h1s)]
         G = [linalg.Gradient(ctx, h, n) for h, n in zip(h1s, nds)]
         kw, keep = dict(A_aux=A_h1, G=G), [h1s, loc_h1]
-    if coarse == "pcg":
+    if coarse == "ams":
+        from palace_amd.fem.fespace import lowest_order_gradient, vertex_coordinates
+
+        h1_0 = H1HexSpace(mesh, 1)
+        cs = linalg.ams(ctx, A[0].local, nds[0].ess_dofs(), lowest_order_gradient(h1_0, nds[0]), vertex_coordinates(h1_0))
+    elif coarse == "amg":
+        cs = linalg.amg(ctx, A[0].local, nds[0].ess_dofs())
+    elif coarse == "pcg":
         cs = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=1e-2, max_it=8)
     else:
         cs = linalg.chebyshev(ctx, A[0], 4)
@@ -76,7 +83,8 @@ def _python_solve(aux, krylov, coarse):
     return n, K.stats()["iterations"], float(x.sum())
 
 
-@pytest.mark.parametrize("aux,krylov,coarse", [(0, "cg", "cheb"), (1, "cg", "pcg"), (1, "fgmres", "pcg")])
+@pytest.mark.parametrize("aux,krylov,coarse", [(0, "cg", "cheb"), (1, "cg", "pcg"), (1, "fgmres", "pcg"), (1, "cg", "ams"),
+                                               (0, "cg", "ams"), (0, "cg", "amg")])
 def test_cxx_host_solve(built, aux, krylov, coarse):
     exe, blob = built
     out = subprocess.check_output([exe, blob, str(aux), krylov, coarse], text=True)

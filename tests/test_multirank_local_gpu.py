@@ -51,6 +51,8 @@ def _rank_main(group, rank, world, p, hiptmair, out, errors):
         ctx.synchronize()
     except Exception as e:  # a failing rank must not leave the others waiting at a barrier for ever
         errors.append((rank, repr(e)))
+        if group is not None:
+            group.abort()
         raise
 
 
@@ -137,6 +139,8 @@ def _tet_rank_main(group, rank, world, hiptmair, out, errors):
         ctx.synchronize()
     except Exception as e:
         errors.append((rank, repr(e)))
+        if group is not None:
+            group.abort()
         raise
 
 
@@ -179,3 +183,36 @@ def test_tet_ranks_under_rcb_partition_match_one_rank(hiptmair):
             assert abs(many[k] - one[k]) < 1e-11 * abs(one[k]), (world, k, many[k], one[k])
         for k in ("xx", "xAx"):
             assert abs(many[k] - one[k]) < 1e-6 * abs(one[k]), (world, k, many[k], one[k])
+
+
+def test_failing_rank_releases_the_group():
+    """A rank thread that throws between two barriers aborts the group: the other ranks leave their all-reduce with an error
+    instead of waiting for ever (LocalGroup::Abort)."""
+    import torch
+
+    from palace_amd import linalg
+
+    group = linalg.LocalGroup(2)
+    seen = []
+
+    def rank_main(rank):
+        ctx = linalg.Context()
+        ctx.init_comm_local(group, rank)
+        x = torch.ones(8, dtype=torch.float64, device="cuda")
+        try:
+            if rank == 1:
+                raise RuntimeError("rank 1 fails before the reduction")
+            ctx.dot(x, x)
+            seen.append("rank 0 came back")
+        except RuntimeError as e:
+            if rank == 1:
+                group.abort()
+            seen.append((rank, str(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert all(not t.is_alive() for t in ts), "rank 0 is stuck at the barrier"
+    assert any(isinstance(s, tuple) and s[0] == 0 and "aborted" in s[1] for s in seen), seen

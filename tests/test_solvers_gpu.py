@@ -296,6 +296,68 @@ def test_pcg_not_positive_definite_is_reported(prob):
         K.mult(_dev(b), _new(n))
 
 
+def test_pcg_initial_guess_without_preconditioner_device_equals_host(prob):
+    """iterative.cpp:406-411: without a preconditioner the reference measures the initial residual of a solve with an
+    initial guess as sqrt(|Norml2(b)|) -- the norm (not its square) under the root.  The device-scalar form and the host
+    loop must take the same value (it sets eps = rel_tol * initial_res and with it the iteration count)."""
+    n = prob.spaces[1].ndofs
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, n)
+    b[prob.spaces[1].ess_dofs()] = 0.0
+    x0 = rng.uniform(-1e-3, 1e-3, n)
+    x0[prob.spaces[1].ess_dofs()] = 0.0
+    host = linalg.cg(prob.ctx, prob.A[1], None, rel_tol=1e-3, max_it=400)
+    host.set_lookahead(0, host_scalars=True)
+    xa = host.mult(_dev(b), _dev(x0), initial_guess=True).cpu().numpy()
+    dev = linalg.cg(prob.ctx, prob.A[1], None, rel_tol=1e-3, max_it=400)
+    xb = dev.mult(_dev(b), _dev(x0), initial_guess=True).cpu().numpy()
+    sa, sb = host.stats(), dev.stats()
+    assert abs(sa["initial_res"] - np.sqrt(np.linalg.norm(b))) < 1e-13 * sa["initial_res"]
+    assert abs(sb["initial_res"] - sa["initial_res"]) < 1e-13 * sa["initial_res"]
+    assert sa["iterations"] == sb["iterations"] and sa["iterations"] > 3
+    assert _rel(xb, xa) < 1e-10
+
+
+def test_inner_pcg_failure_inside_the_cycle_is_reported(prob):
+    """A coarse PCG inside the recorded V-cycle cannot stop the host when (Ap, p) is not finite; the outer solver asks its
+    preconditioner afterwards (Solver::CheckStatus) and the error of iterative.cpp:445 is raised then."""
+    n = prob.spaces[-1].ndofs
+    K, B = _pcg_gmg(prob, "cg", rel_tol=1e-8, max_it=5)
+    b = np.ones(n)
+    b[prob.spaces[-1].ess_dofs()] = 0.0
+    K.mult(_dev(b), _new(n))  # a healthy solve first: nothing raised
+    B.check_status()
+    r = b.copy()
+    free = np.setdiff1d(np.arange(n), prob.spaces[-1].ess_dofs())
+    r[free[len(free) // 2]] = np.nan  # (an essential entry would be masked away before it reaches the coarse level)
+    for _ in range(3):  # direct, recording, replay: the cycle itself never stops
+        B.mult(_dev(r), _new(n))
+    with pytest.raises(Exception, match="positive definite"):
+        B.check_status()
+    with pytest.raises(Exception, match="positive definite"):
+        K.mult(_dev(r), _new(n))
+
+
+def test_recorded_iteration_follows_reconfiguration(prob):
+    """A recorded PCG iteration bakes in kernel arguments; re-configuring any solver in place (here: the tolerance and
+    the essential rows are untouched, the iteration cap changes) drops the recordings, so the next solve is not a stale
+    replay."""
+    n = prob.spaces[1].ndofs
+    b = np.random.default_rng(8).uniform(-1, 1, n)
+    b[prob.spaces[1].ess_dofs()] = 0.0
+    J = linalg.jacobi(prob.ctx, prob.A[1])
+    K = linalg.cg(prob.ctx, prob.A[1], J, rel_tol=1e-10, max_it=300)
+    for _ in range(3):
+        xa = K.mult(_dev(b), _new(n)).cpu().numpy()
+    its = K.stats()["iterations"]
+    assert K.stats()["converged"]
+    K2 = linalg.cg(prob.ctx, prob.A[1], J, rel_tol=1e-4, max_it=300)  # configuration epoch moves on
+    K2.mult(_dev(b), _new(n))
+    assert K2.stats()["iterations"] < its
+    xb = K.mult(_dev(b), _new(n)).cpu().numpy()  # re-recorded, same result
+    assert K.stats()["iterations"] == its and np.array_equal(xa, xb)
+
+
 def test_gmg_graph_replay_matches_direct_application(prob):
     """The V-cycle recorded as a HIP graph (second application on) gives the bits of the direct run, for any input / output
     vectors, and GMRES preconditioned with it takes the iterations it takes without graphs."""
@@ -349,3 +411,12 @@ def test_mfma_peak_kernel_runs():
     flops = ctx.bench_mfma_f64(16, 64, s)
     torch.cuda.synchronize()
     assert flops == 2.0 * 16 * 16 * 4 * 8 * 16 * 4 * 64 and float(s.abs().max()) == 0.0
+
+
+def test_phase_ranges_are_harmless(prob):
+    """The roctx phase ranges (utils/timer.hpp's BlockTimer phases) nest and cost nothing when no profiler listens."""
+    n = prob.spaces[1].ndofs
+    with linalg.phase_range("Linear Solve"):
+        with linalg.phase_range("Preconditioner"):
+            y = prob.A[1].mult(_dev(np.ones(n)), _new(n))
+    assert torch.isfinite(y).all()
