@@ -317,6 +317,88 @@ def h1_leg(ctx, prob, order=2, reps=200, pcg_iters=50):
     return out
 
 
+def cpw_leg(order=3, refine=1, reps=20):
+    """BASELINE config 3 on the reference's own mesh: examples/cpw/mesh/cpw_lumped_0.msh (committed as tests/golden/cpw_mesh.npz,
+    14 628 tetrahedra) uniformly refined `refine` times, order-3 Nedelec tetrahedra, the driven-type complex system
+    A = K - k0^2 eps_r (1 - i tan d) M at 16 GHz, FGMRES + Hiptmair p-multigrid (p = 1, 2, 3) with the native AMS cycle on the
+    assembled order-1 level: complex applies/s, iterations to 1e-8 and iterations/s; the real part against the numpy oracle."""
+    import torch
+
+    from palace_amd import linalg
+    from palace_amd.fem import tet
+    from palace_amd.fem.tetproblem import TetProblem
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "cpw_mesh.npz"))
+    mesh = tet.TetMesh(d["verts"], d["tets"], d["attr"], bdr_tris=d["bdr_tris"], bdr_attr=d["bdr_attr"])
+    for _ in range(refine):
+        mesh = tet.refine_uniform(mesh)
+    ctx = linalg.Context()
+    prob = TetProblem(ctx, mesh, order)
+    bt = np.sort(np.asarray(mesh.bdr_tris, dtype=np.int64), axis=1)
+    pec = bt[np.isin(mesh.bdr_attr, (4, 13))]  # far field and the metal trace; the port faces stay natural
+    fv = mesh.face_verts
+    nvt = mesh.nv
+    key = lambda f: (f[:, 0] * nvt + f[:, 1]) * nvt + f[:, 2]
+    order_f = np.argsort(key(fv))
+    fmask = np.zeros(fv.shape[0], dtype=bool)
+    fmask[order_f[np.searchsorted(key(fv)[order_f], key(pec))]] = True
+    k0 = 2 * np.pi * 16.0e9 * 1.0e-6 / 299792458.0
+    # reference defaults: Chebyshev order max(2p, 4), no restart before max_it (iodata.cpp:533-564: max_size = max_it)
+    sys_ = prob.driven_solver(fmask, k0, eps=[1.0, 11.7], tand=[0.0, 0.05], coarse="ams", cheby_order=max(2 * order, 4),
+                              max_it=600, restart=600)
+    A, S, ess, n = sys_["A"], sys_["solver"], sys_["ess"], sys_["n"]
+    rng = np.random.default_rng(4)
+    b = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    b[ess] = 0.0
+    br, bi = torch.from_numpy(b.real.copy()).cuda(), torch.from_numpy(b.imag.copy()).cuda()
+    out = {"workload": f"examples/cpw mesh refined x{refine}: {mesh.ne} tetrahedra, ND p={order}, {n} complex dofs, 16 GHz, "
+                       "eps_r = (1, 11.7), tan d = (0, 0.05), white-noise right-hand side; FGMRES (no restart) + Hiptmair p-multigrid (p = 1..3, "
+                       "Chebyshev order 6) + native AMS on level 0 (with the Jacobi-PCG stand-in there the solve does not converge in 600 "
+                       "iterations on this mesh: scripts/cpw_explore.py)",
+           "complex_dofs": n}
+    yr, yi = torch.empty_like(br), torch.empty_like(br)
+    with torch.cuda.stream(ctx.torch_stream):
+        for _ in range(5):
+            A.mult(br, bi, yr, yi)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            A.mult(br, bi, yr, yi)
+        e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out["complex_apply"] = {"ms": ms, "complex_dof_per_s": n / (ms * 1e-3)}
+    xr, xi = torch.zeros_like(br), torch.zeros_like(br)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    S.mult(br, bi, xr, xi)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = S.stats()
+    A.mult(xr, xi, yr, yi)
+    res = float(torch.sqrt(((yr - br) ** 2 + (yi - bi) ** 2).sum()) / torch.sqrt((br ** 2 + bi ** 2).sum()))
+    out["fgmres"] = {"iterations_to_1e-8": st["iterations"], "seconds": dt, "iters_per_s": st["iterations"] / dt,
+                     "converged": st["converged"], "true_rel_residual": res}
+    # the real-part operator at this size against the numpy oracle (one oracle apply)
+    from oracle import palace_oracle as po
+
+    t0 = time.perf_counter()
+    nd = prob.spaces[-1]
+    interp, curl = nd.elem.tables(prob.pts)
+    J = mesh.jacobians(prob.pts)
+    og = po.build_geom_factor_33(mesh.attr.astype(np.float64), prob.wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 9))
+    okw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+    oc = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([-k0 ** 2 * 1.0]), np.array([-k0 ** 2 * 11.7])])
+    orc = po.CeedOperatorOracle(n, nd.offsets, None, interp, curl, og, po.QF_HDIVMASS, oc, po.CoeffCtx(), **okw)
+    hx = rng.uniform(0, 1, n)
+    hy = orc.apply_add(hx, np.zeros(n))
+    dy = torch.empty_like(br)
+    sys_["Kr"].mult(torch.from_numpy(hx).cuda(), dy)
+    out["parity"] = {"rel_l2_y_full": _rel(dy.cpu().numpy(), hy), "tolerance": 1e-12,
+                     "size": f"{n} dofs, {mesh.ne} tets ({time.perf_counter() - t0:.1f} s of oracle work)"}
+    return out
+
+
 def tets_leg(order, n, reps=20):
     """The non-tensor path (dense tables on the FP64 matrix cores): Nedelec tets of the same order on a
     Kuhn-split cube, curl-curl and curl-curl+mass `ceed::Operator::Mult`, order-2p symmetric quadrature
@@ -642,6 +724,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_p4:
         cplx = _leg(complex_leg, ctx, prob)
         h1 = _leg(h1_leg, ctx, prob)
+    cpw = None
+    if rank == 0 and world == 1 and not args.no_tets:
+        cpw = _leg(cpw_leg, p)
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -664,7 +749,7 @@ def main():
                        "scaling_mode": ("strong: one ~10M-dof cylinder cut into N equal z-slabs" if args.scaling == "strong"
                                         else "weak: one z-slab of the cylinder per GPU, same element count per GPU"),
                        "parallelism": f"element partition x{world}, RCCL halo (P / P^T) + allreduce dots"},
-            "pre_warm_steps": args.pre_warm, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "tets_mfma": tets,
+            "pre_warm_steps": args.pre_warm, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "cpw": cpw, "tets_mfma": tets,
             "setup_s": t_setup,
         }
         sys.stdout.flush()

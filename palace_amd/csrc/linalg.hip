@@ -1279,6 +1279,8 @@ struct CgSolver::DeviceState {
   std::vector<hipEvent_t> ev;
   StreamGraph graph;     // one iteration
   bool pending = false;  // lookahead < 0: the final snapshot has been enqueued but not read
+  bool deferred = false; // the last solve ran in the never-wait form: replays of an enclosing recording refresh the snapshot
+                         // without running this host code, so the statistics are (re)read whenever someone asks
   ~DeviceState() {
     if (d_st) (void)hipFree(d_st);
     if (h_ring) (void)hipHostFree(h_ring);
@@ -1363,7 +1365,7 @@ void CgSolver::Mult(const Vector &b, Vector &x) const {
 }
 
 void CgSolver::Finish() const {
-  if (!dev_ || !dev_->pending) return;
+  if (!dev_ || !(dev_->pending || dev_->deferred)) return;
   StreamGraph::RequireNotRecording("CgSolver statistics");
   PA_HIP(hipStreamSynchronize(ctx_->stream));
   dev_->pending = false;
@@ -1384,7 +1386,7 @@ void CgSolver::MultDevice(const Vector &b, Vector &x) const {
   DeviceState &d = *dev_;
   const int L = StreamGraph::Recording() ? -1 : lookahead_;  // inside a recorded sequence: never wait
   d.Setup(L >= 0 ? L + 2 : 1);
-  d.pending = false;
+  d.pending = false, d.deferred = false;
   double *st = d.d_st;
   const CgTol tol{rel_tol_, abs_tol_, initial_guess ? (B_ ? 1 : 2) : 0};
   auto precond = [&](const Vector &u, Vector &v) {
@@ -1426,7 +1428,7 @@ void CgSolver::MultDevice(const Vector &b, Vector &x) const {
     // fixed work, nothing read back: the stop flag freezes x once the tolerance is met
     for (int it = 0; it < max_it_; it++) d.graph.Run(c, key, iteration);
     d.Snapshot(0, c.stream, false);
-    d.pending = true;
+    d.pending = true, d.deferred = true;
     return;
   }
   const int R = d.ring;

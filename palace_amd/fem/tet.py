@@ -310,6 +310,39 @@ class TetMesh:
         return np.einsum("dqn,eni->eqid", G, self.nodes[self.elem_nodes])
 
 
+def refine_uniform(mesh: "TetMesh") -> "TetMesh":
+    """One level of uniform (red) refinement of a straight-sided mesh: every tetrahedron into 8 (the 4 corner children and the
+    inner octahedron cut along the diagonal m02-m13: Bey's refinement, what mfem::Mesh::UniformRefinement does to tetrahedra
+    up to the choice of the diagonal), every boundary triangle into 4; attributes are inherited."""
+    if mesh.mesh_order != 1:
+        raise ValueError("uniform refinement is implemented for straight-sided tetrahedra")
+    nv = mesh.nv
+    mid = nv + mesh.elem_edges  # [ne, 6] vertex number of the midpoint of local edge k (LOCAL_EDGES order)
+    verts = np.concatenate([mesh.verts, 0.5 * (mesh.verts[mesh.edge_verts[:, 0]] + mesh.verts[mesh.edge_verts[:, 1]])])
+    ek = {tuple(e): k for k, e in enumerate(LOCAL_EDGES)}
+    m = lambda a, b: mid[:, ek[(min(a, b), max(a, b))]]
+    v = [mesh.tets[:, i] for i in range(4)]
+    m01, m02, m03, m12, m13, m23 = m(0, 1), m(0, 2), m(0, 3), m(1, 2), m(1, 3), m(2, 3)
+    kids = [(v[0], m01, m02, m03), (m01, v[1], m12, m13), (m02, m12, v[2], m23), (m03, m13, m23, v[3]),
+            (m01, m02, m03, m13), (m01, m02, m12, m13), (m02, m03, m13, m23), (m02, m12, m13, m23)]
+    tets = np.stack([np.stack(k, axis=1) for k in kids], axis=1).reshape(-1, 4)
+    X = verts[tets]
+    det = np.einsum("ei,ei->e", np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), X[:, 3] - X[:, 0])
+    neg = det < 0
+    tets[neg] = tets[neg][:, [0, 2, 1, 3]]
+    attr = np.repeat(mesh.attr, 8)
+    bt = ba = None
+    if mesh.bdr_tris is not None:
+        b = np.asarray(mesh.bdr_tris, dtype=np.int64)
+        eid = {tuple(e): i for i, e in enumerate(map(tuple, mesh.edge_verts))}
+        bm = lambda i, j: np.array([nv + eid[(min(x, y), max(x, y))] for x, y in zip(b[:, i], b[:, j])], dtype=np.int64)
+        a01, a12, a02 = bm(0, 1), bm(1, 2), bm(0, 2)
+        bt = np.stack([np.stack(t, axis=1) for t in ((b[:, 0], a01, a02), (a01, b[:, 1], a12), (a02, a12, b[:, 2]),
+                                                     (a01, a12, a02))], axis=1).reshape(-1, 3)
+        ba = None if mesh.bdr_attr is None else np.repeat(np.asarray(mesh.bdr_attr), 4)
+    return TetMesh(verts, tets, attr, bdr_tris=bt, bdr_attr=ba)
+
+
 def cube_tet_mesh(n, L=1.0, attr=None):
     """n^3 cubes of [0, L]^3, each split into the 6 Kuhn tetrahedra (conforming)."""
     g = np.linspace(0.0, L, n + 1)
@@ -662,6 +695,37 @@ class H1TetSpace:
              (self.edge_base + edges[:, None] * n_e + np.arange(n_e)[None, :]).ravel(),
              (self.face_base + faces[:, None] * n_f + np.arange(n_f)[None, :]).ravel()]
         return np.unique(np.concatenate(d)).astype(np.int32)
+
+
+def lowest_order_gradient(h1, nd):
+    """Discrete gradient [nd.ndofs x h1.ndofs] of the order-1 spaces on a tetrahedral mesh as a scipy CSR matrix: the element
+    matrix tet_gradient_matrix(1) with the element's orientation of every edge dof, one copy per (edge, vertex) -- all
+    elements sharing an edge give the same row (+1 at the head, -1 at the tail of the global edge)."""
+    import scipy.sparse as sp
+
+    assert h1.p == 1 and nd.p == 1 and nd.diagonal_transform
+    Gel = tet_gradient_matrix(1)  # [6, 4]
+    sgn = np.where(np.asarray(nd.orients, dtype=bool), -1.0, 1.0)  # [ne, 6]
+    rows, cols, vals = [], [], []
+    for i in range(Gel.shape[0]):
+        for j in range(Gel.shape[1]):
+            if Gel[i, j] != 0.0:
+                rows.append(nd.offsets[:, i].astype(np.int64))
+                cols.append(h1.offsets[:, j].astype(np.int64))
+                vals.append(sgn[:, i] * Gel[i, j])
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    _, first = np.unique(rows * h1.ndofs + cols, return_index=True)
+    G = sp.csr_matrix((vals[first], (rows[first], cols[first])), shape=(nd.ndofs, h1.ndofs))
+    assert (np.diff(G.indptr) == 2).all() and abs(G.sum(axis=1)).max() == 0
+    return G
+
+
+def vertex_coordinates(h1):
+    """Coordinates [h1.ndofs, 3] of the dofs of an order-1 H1 space on a tetrahedral mesh (the vertices, in its numbering)."""
+    assert h1.p == 1
+    xyz = np.zeros((h1.ndofs, 3))
+    xyz[np.asarray(h1.offsets).ravel()] = h1.mesh.verts[h1.mesh.tets.ravel()]
+    return xyz
 
 
 def to_quadratic(mesh: TetMesh, warp=None) -> TetMesh:

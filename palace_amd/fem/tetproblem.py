@@ -111,3 +111,57 @@ class TetProblem:
         self._keep.append((blocks, local, A, P, B))
         self.A = A
         return K, b, x
+
+    def driven_solver(self, pec_faces, k0, eps, tand, coarse="ams", rel_tol=1e-8, max_it=400, restart=100, cheby_order=4,
+                      coarse_tol=1e-3, coarse_max_it=200):
+        """The driven-type complex system of BASELINE config 3 on this mesh and its solver, configured as the reference does for
+        frequency-domain problems (models/spaceoperator.cpp:316-331, linalg/ksp.cpp): A = K - k0^2 eps_r (1 - i tan d) M with
+        PEC on the faces `pec_faces` (bool mask over mesh.face_verts), FGMRES preconditioned by the Hiptmair p-multigrid of the
+        shifted real matrix K + k0^2 eps_r M applied to both parts; level 0: `coarse` = "ams" (the native auxiliary-space cycle
+        on the assembled order-1 matrix, where the reference calls HYPRE's AMS) or "cg" (Jacobi-PCG to coarse_tol).  eps, tand:
+        per attribute (1-based attribute a -> entry a - 1).  One rank.  Returns dict(A, solver, ess, n)."""
+        from .. import ceed, linalg
+
+        assert self.world == 1
+        ctx, mesh = self.ctx, self.mesh
+        eps, tand = np.asarray(eps, dtype=np.float64), np.asarray(tand, dtype=np.float64)
+        amap = list(range(len(eps)))
+
+        def coef(vals):
+            return ceed.coefficient_context(3, attr_mat=amap, mat_coeff=[np.array([v]) for v in vals])
+
+        ident = ceed.coefficient_context(3)
+        ess = [s.ess_dofs(pec_faces) for s in self.spaces]
+        blocks = [self.nd_block(s) for s in self.spaces]
+
+        def nd_op(block, qf, blob, ops):
+            return ceed.Operator(block.lsize, block.lsize).add_dense_integrator(self.geom, block, qf, blob, ops).finalize()
+
+        Kr = nd_op(blocks[-1], ceed.QF_HDIVMASS_33, np.concatenate([coef(-k0 ** 2 * eps), ident]), ceed.EVAL_CURL | ceed.EVAL_INTERP)
+        Ki = nd_op(blocks[-1], ceed.QF_HCURL_33, coef(k0 ** 2 * eps * tand), ceed.EVAL_INTERP)
+        A = linalg.ComplexParOperator(ctx, Kr, Ki, ess[-1], linalg.DIAG_ONE)
+        pfine = nd_op(blocks[-1], ceed.QF_HDIVMASS_33, np.concatenate([coef(k0 ** 2 * eps), ident]), ceed.EVAL_CURL | ceed.EVAL_INTERP)
+        ploc = [pfine.coarsen_dense(b) for b in blocks[:-1]] + [pfine]
+        Pm = [linalg.ParOperator(ctx, o, es, linalg.DIAG_ONE) for o, es in zip(ploc, ess)]
+        h1s = [tet.H1TetSpace(mesh, q) for q in self.orders]
+        hb = [self.h1_block(s) for s in h1s]
+        hfine = ceed.Operator(h1s[-1].ndofs, h1s[-1].ndofs).add_dense_integrator(self.geom, hb[-1], ceed.QF_HCURL_33,
+                                                                                coef(k0 ** 2 * eps), ceed.EVAL_GRAD).finalize()
+        hloc = [hfine.coarsen_dense(b) for b in hb[:-1]] + [hfine]
+        Ph = [linalg.ParOperator(ctx, o, s.ess_dofs(pec_faces), linalg.DIAG_ONE) for o, s in zip(hloc, h1s)]
+        G = [linalg.DenseInterp(ctx, h.restriction(), s.restriction(interp_range=True), tet.tet_gradient_matrix(q))
+             for h, s, q in zip(h1s, self.spaces, self.orders)]
+        P = [linalg.DenseInterp(ctx, self.spaces[l].restriction(), self.spaces[l + 1].restriction(interp_range=True),
+                                tet.nd_tet_transfer_matrix(self.orders[l], self.orders[l + 1])) for l in range(len(Pm) - 1)]
+        csr0 = None
+        if coarse == "ams":
+            assert self.orders[0] == 1
+            csr0 = ploc[0].full_assemble_device()
+            Pm[0] = linalg.AssembledParOperator(ctx, csr0, ess[0], linalg.DIAG_ONE)
+            csolver = linalg.ams(ctx, csr0, ess[0], tet.lowest_order_gradient(h1s[0], self.spaces[0]), tet.vertex_coordinates(h1s[0]))
+        else:
+            csolver = linalg.cg(ctx, Pm[0], linalg.jacobi(ctx, Pm[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
+        B = linalg.gmg(ctx, Pm, P, csolver, cheby_order=cheby_order, A_aux=Ph, G=G) if len(Pm) > 1 else csolver
+        S = linalg.ComplexParGmres(ctx, A, B, rel_tol=rel_tol, max_it=max_it, restart=restart, flexible=True)
+        self._keep.append((Kr, Ki, blocks, ploc, Pm, h1s, hb, hloc, Ph, G, P, csr0, csolver, B))
+        return dict(A=A, solver=S, ess=ess[-1], n=self.spaces[-1].ndofs, Kr=Kr, Ki=Ki)

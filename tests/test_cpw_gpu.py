@@ -112,3 +112,51 @@ def test_cpw_complex_fgmres_against_oracle_operator():
     res = np.linalg.norm(oA(xs) - b) / np.linalg.norm(b)
     assert res < 1e-6, (res, st)
     print(f"cpw p=3: {n} complex dofs, FGMRES + Hiptmair p-MG: {st['iterations']} iterations, oracle residual {res:.2e}")
+
+
+def test_cpw_driven_solver_with_native_ams_and_refinement():
+    """TetProblem.driven_solver (the configuration bench.py's cpw leg runs) on the reference mesh: the native AMS cycle on the
+    assembled order-1 level inside the Hiptmair p-multigrid; the same system with the Jacobi-PCG coarse solve gives the same
+    solution.  And one uniform refinement of the mesh (tet.refine_uniform) keeps volume, attributes and boundary tags."""
+    from palace_amd import linalg
+    from palace_amd.fem import tet
+    from palace_amd.fem.tetproblem import TetProblem
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cpw_mesh.npz"))
+    mesh = tet.TetMesh(d["verts"], d["tets"], d["attr"], bdr_tris=d["bdr_tris"], bdr_attr=d["bdr_attr"])
+    fine = tet.refine_uniform(mesh)
+
+    def vol(m, a):
+        X = m.verts[m.tets[m.attr == a]]
+        return np.einsum("ei,ei->e", np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), X[:, 3] - X[:, 0]).sum() / 6
+
+    assert fine.ne == 8 * mesh.ne and len(fine.bdr_tris) == 4 * len(mesh.bdr_tris)
+    for a in (1, 2):
+        assert abs(vol(fine, a) - vol(mesh, a)) < 1e-12 * vol(mesh, a)
+    assert fine.boundary_face_mask.sum() == 4 * mesh.boundary_face_mask.sum()
+
+    bt = np.sort(np.asarray(d["bdr_tris"], dtype=np.int64), axis=1)
+    fkey = {tuple(f): i for i, f in enumerate(map(tuple, mesh.face_verts))}
+    fmask = np.zeros(mesh.face_verts.shape[0], dtype=bool)
+    fmask[[fkey[tuple(f)] for f in bt[np.isin(d["bdr_attr"], (4, 13))]]] = True
+    k0 = 2 * np.pi * 16.0e9 * 1.0e-6 / 299792458.0
+    sols, its = [], []
+    for coarse in ("ams", "cg"):
+        prob = TetProblem(linalg.Context(), mesh, 2)
+        s = prob.driven_solver(fmask, k0, eps=[1.0, 11.7], tand=[0.0, 0.05], coarse=coarse, rel_tol=1e-10)
+        n = s["n"]
+        rng = np.random.default_rng(4)
+        b = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+        b[s["ess"]] = 0.0
+        xr, xi = s["solver"].mult(_dev(b.real), _dev(b.imag), torch.zeros(n, dtype=torch.float64, device="cuda"),
+                                  torch.zeros(n, dtype=torch.float64, device="cuda"))
+        st = s["solver"].stats()
+        assert st["converged"], (coarse, st)
+        yr, yi = s["A"].mult(xr, xi, torch.empty_like(xr), torch.empty_like(xr))
+        r = np.hypot(np.linalg.norm(yr.cpu().numpy() - b.real), np.linalg.norm(yi.cpu().numpy() - b.imag)) / np.linalg.norm(b)
+        assert r < 1e-8, (coarse, r)
+        sols.append(xr.cpu().numpy() + 1j * xi.cpu().numpy())
+        its.append(st["iterations"])
+    assert np.linalg.norm(sols[0] - sols[1]) < 1e-6 * np.linalg.norm(sols[1])
+    assert its[0] <= 1.5 * its[1] + 5, its  # the one-cycle AMS coarse solve is not far from the converged PCG one
+    print("cpw p=2 FGMRES iterations: AMS", its[0], " Jacobi-PCG(1e-3)", its[1])
