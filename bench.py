@@ -485,18 +485,20 @@ def tets_leg(order, n, reps=20):
     # PCG + p-multigrid (p = 1..order) with the auxiliary-space smoother on the same mesh
     from palace_amd.fem.tetproblem import TetProblem
 
-    prob = TetProblem(linalg.Context(), mesh, order)
-    solver, b, xs = prob.pcg_gmg_solver(max_it=400, rel_tol=1e-8, hiptmair=True)
-    solver.mult(b, xs)  # warm-up
-    xs.zero_()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    solver.mult(b, xs)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st = solver.stats()
-    out["pcg_hiptmair"] = {"iterations_to_1e-8": st["iterations"], "seconds": dt, "iters_per_s": st["iterations"] / dt,
-                           "converged": st["converged"]}
+    for name, coarse in (("pcg_hiptmair", "cg"), ("pcg_hiptmair_ams", "ams")):
+        prob = TetProblem(linalg.Context(), mesh, order)
+        solver, b, xs = prob.pcg_gmg_solver(max_it=400, rel_tol=1e-8, hiptmair=True, coarse=coarse)
+        solver.mult(b, xs)  # warm-up
+        xs.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.mult(b, xs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = solver.stats()
+        out[name] = {"iterations_to_1e-8": st["iterations"], "seconds": dt, "iters_per_s": st["iterations"] / dt,
+                     "converged": st["converged"]}
+        del prob, solver
     return out
 
 
@@ -619,12 +621,14 @@ def main():
     # HBM traffic of the same launch from the PMC passes (collected by scripts/profile_round.sh in separate
     # rocprofv3 --pmc runs, summary committed under profiles/): raw FETCH_SIZE + WRITE_SIZE bytes
     traffic, traffic_note = None, "no PMC summary under profiles/"
-    pmc_file = os.path.join(ROOT, "profiles", "r02_apply_pmc.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r03_apply_pmc.json")
+    if not os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, "profiles", "r02_apply_pmc.json")
     if os.path.exists(pmc_file) and abs(args.dofs - 10.0e6) < 1 and p == 3 and world == 1 and args.scaling == "strong":
         pmc = json.load(open(pmc_file))
         pb = pmc["per_apply_bytes"]
         traffic = pb.get("traffic_corrected") or pb["traffic_raw"]
-        traffic_note = ("FETCH_SIZE + WRITE_SIZE per apply from profiles/r02_apply_pmc.json (separate --pmc passes of the "
+        traffic_note = ("FETCH_SIZE + WRITE_SIZE per apply from profiles/" + os.path.basename(pmc_file) + " (separate --pmc passes of the "
                         "same kernels on this mesh; collected at commit " + str(pmc.get("commit", "?")) + "), each divided by "
                         "the fraction the same counters report on a known stream in the same run; "
                         + pmc.get("calibration", "uncalibrated"))

@@ -96,6 +96,11 @@ class TetProblem:
             # a nonlinear preconditioner and costs the outer PCG 40 % more iterations; scripts/coarse_tune.py)
             if coarse == "chebyshev":
                 csolver = linalg.chebyshev(ctx, A[0], 4)
+            elif coarse == "ams":  # the native auxiliary-space cycle on the assembled order-1 level (one rank)
+                assert self.world == 1 and coarse_assembled and self.orders[0] == 1
+                h1_0 = tet.H1TetSpace(self.mesh, 1)
+                csolver = linalg.ams(ctx, A[0].local, self.ess[0], tet.lowest_order_gradient(h1_0, self.spaces[0]),
+                                     tet.vertex_coordinates(h1_0))
             else:
                 csolver = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
             B = linalg.gmg(ctx, A, P, csolver, cheby_order=max(2 * self.p, 4), **aux)

@@ -1,4 +1,5 @@
-"""Profile target: a few launches of the fused ND p=3 apply kernel at the bench size."""
+"""Profile target: a few launches of the fused ND apply kernels at the bench size (ORDER=3 default, ORDER=4: the five-point
+streaming kernel on the bench's p = 4 mesh)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -6,7 +7,11 @@ from palace_amd import ceed, linalg
 from palace_amd.fem.partition import SlabProblem, strong_shape
 ctx = linalg.Context()
 dofs = float(os.environ.get("DOFS", "10e6"))
-prob = SlabProblem(ctx, 0, 1, 3, dofs, levels=False, shape=strong_shape(dofs, 3))  # the bench mesh (bench.py)
+order = int(os.environ.get("ORDER", "3"))
+if order == 3:
+    prob = SlabProblem(ctx, 0, 1, 3, dofs, levels=False, shape=strong_shape(dofs, 3))  # the bench mesh (bench.py)
+else:
+    prob = SlabProblem(ctx, 0, 1, order, dofs, levels=False)  # bench.py's p4 leg
 which = os.environ.get("OP", "curl")
 if which == "curl":
     op = prob.local_curlcurl

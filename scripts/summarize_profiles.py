@@ -3,7 +3,7 @@
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-TAG = os.environ.get("ROUND_TAG", "r02")
+TAG = os.environ.get("ROUND_TAG", "r03")
 try:
     COMMIT = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
@@ -16,10 +16,54 @@ def find(d, suffix):
     f = glob.glob(os.path.join(OUT, d, "**", "*" + suffix), recursive=True)
     return max(f, key=os.path.getmtime) if f else None
 
-for d, name in (("prof_bench", "bench_kernel_stats.csv"), ("prof_curlmass", "apply_curlmass_kernel_stats.csv")):
+for d, name in (("prof_bench", "bench_kernel_stats.csv"), ("prof_curlmass", "apply_curlmass_kernel_stats.csv"),
+                ("prof_p4_curl", "p4_kernel_stats.csv"), ("prof_p4_curlmass", "p4_curlmass_kernel_stats.csv")):
     f = find(d, "kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(PROF, f"{TAG}_{name}"))
+f = find("prof_bench", "marker_api_trace.csv") or find("prof_bench", "marker_trace.csv")
+if f:  # the roctx phase ranges of the bench run: name -> count, total ms
+    acc = {}
+    for row in csv.DictReader(open(f)):
+        name = row.get("Function") or row.get("Name") or "?"
+        try:
+            dt = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+        except Exception:
+            continue
+        c, t = acc.get(name, (0, 0.0))
+        acc[name] = (c + 1, t + dt)
+    with open(os.path.join(PROF, f"{TAG}_bench_phase_ranges.csv"), "w") as g:
+        g.write("range,count,total_ms\n")
+        for k, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            g.write(f"{k},{c},{t:.3f}\n")
+# p = 4: FETCH_SIZE / WRITE_SIZE of the five-point streaming kernel and its run gather, per dispatch
+p4 = {}
+for d in sorted(glob.glob(os.path.join(OUT, "prof_p4pmc_*"))):
+    f = find(os.path.basename(d), "counter_collection.csv")
+    if not f:
+        continue
+    op = "curlcurl_mass" if "curlmass" in os.path.basename(d) else "curlcurl"
+    acc = {}
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        k = "nd_hex_stream5_kernel" if "nd_hex_stream5" in k else ("et_run_gather_kernel" if "et_run_gather" in k else None)
+        if not k:
+            continue
+        key = (k, row["Counter_Name"])
+        s_, n_ = acc.get(key, (0.0, set()))
+        n_.add(row["Dispatch_Id"])
+        acc[key] = (s_ + float(row["Counter_Value"]), n_)
+    for (k, c), (s_, n_) in acc.items():
+        p4.setdefault(op, {}).setdefault(k, {})[c] = s_ / max(1, len(n_))
+if p4:
+    for op, ks in p4.items():
+        f_ = sum(v.get("FETCH_SIZE", 0.0) for v in ks.values()) * 1024
+        w_ = sum(v.get("WRITE_SIZE", 0.0) for v in ks.values()) * 1024
+        ks["per_apply_bytes"] = {"fetch_raw": f_, "fetch_x2": 2 * f_, "write_raw": w_, "traffic_x2": 2 * f_ + w_}
+    json.dump({"note": "p = 4 (Q1 = 5) streaming kernel, bench.py's p4 mesh (52 920 elements, 10 263 720 dofs): rocprofv3 --pmc FETCH_SIZE / "
+                       "WRITE_SIZE (KiB, one counter per run), averages per dispatch; fetch_x2 applies the gfx950 correction for 16-B/lane "
+                       "streaming loads (MI355X_MICROARCH.md); algorithmic bytes (SURVEY 8d, G = 11): 52 920 x 12 500 + 16 x 10 263 720 = 825.7 MB",
+               "commit": COMMIT, "kernels": p4}, open(os.path.join(PROF, f"{TAG}_p4_pmc.json"), "w"), indent=1)
 log = os.path.join(OUT, "prof_bench.log")
 if os.path.exists(log):
     for line in open(log):

@@ -12,13 +12,16 @@ ctx = linalg.Context()
 MODE = os.environ.get("HALO_MODE", "peer")  # peer: direct stores into the (own) mailboxes; rccl: send / receive groups to self
 if MODE == "peer":
     ctx.init_comm_peer_single()
-else:
+elif MODE != "none":  # none: the same slab as a one-rank problem (no halos at all): what the launch count alone costs at this size
     ctx.init_comm_single()
 n, nz = strong_shape(10e6, 3)
 PCG = int(os.environ.get("PCG", "0"))  # > 0: also PCG + p-multigrid iterations / s on the slab, halo exchanges on every level
 prob = SlabProblem(ctx, 1, N, 3, 0, levels=bool(PCG), shape=(n, nz // N), device=False)  # an interior slab: two neighbours
-prob.world = N  # (> 1: halos are built)
-for s in prob.spaces:  # both neighbours become the rank itself: what it sends up it receives as its own bottom ghosts
+if MODE == "none":
+    prob = SlabProblem(ctx, 0, 1, 3, 0, levels=bool(PCG), shape=(n, nz // N), device=False)
+else:
+    prob.world = N  # (> 1: halos are built)
+for s in (prob.spaces if MODE != "none" else []):  # both neighbours become the rank itself: what it sends up it receives as its own bottom ghosts
     send = np.concatenate(s.send).astype(np.int32); recv = np.concatenate(s.recv).astype(np.int32)
     assert send.size == recv.size
     s.nbr, s.send, s.recv = [0], [send], [recv]
@@ -43,7 +46,7 @@ with torch.cuda.stream(ctx.torch_stream):
 ml = e0.elapsed_time(e1) / reps
 if MODE == "peer":
     ctx.peer_check()
-print(f"[{MODE}] slab of 1/{N}: {prob.mesh.ne} elements, {nt} true dofs, halo {prob.spaces[-1].send[0].size} dofs each way: "
+print(f"[{MODE}] slab of 1/{N}: {prob.mesh.ne} elements, {nt} true dofs, halo {prob.spaces[-1].send[0].size if MODE != 'none' else 0} dofs each way: "
       f"ParOperator::Mult {ms*1e3:.1f} us, local apply alone {ml*1e3:.1f} us, ideal (1-GPU time / {N}) {178.0/N:.1f} us")
 
 if PCG:
@@ -56,7 +59,8 @@ if PCG:
             super().__init__(*a, **k)
             send = np.concatenate(self.send).astype(np.int32); recv = np.concatenate(self.recv).astype(np.int32)
             self.nbr, self.send, self.recv = [0], [send], [recv]
-    _pt.SlabH1Space = _SelfH1
+    if MODE != "none":
+        _pt.SlabH1Space = _SelfH1
     for hip in (False, True):
         solver, b, xs = prob.pcg_gmg_solver(max_it=PCG, hiptmair=hip, coarse="cg" if hip else "chebyshev")
         solver.mult(b, xs); solver.mult(b, xs)
