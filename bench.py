@@ -660,8 +660,18 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                 "kernel": "pa::nd_hex_stream_kernel<P1=3, packed q-data> (E, B, D, B^T, signed E-vector / exclusive dofs) + "
                           "pa::et_run_gather_kernel (E^T over shared-dof runs)", "kernel_ms": kernel_ms,
+                "kernel_reps": nk, "kernel_warmup": 50,
+                # the two clocks of this line must tell the same story (round-2 review): events around nk applies on the launch
+                # stream against the wall clock around --steps applies
+                "consistent_with_ms_per_step": bool(world > 1 or kernel_ms <= 1.05 * ms_per_step),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_formula": "NE*(Q*11*8 + P*5) + 16*N_L (SURVEY.md 8d, G=11)"}
+                "bytes_formula": "NE*(Q*11*8 + P*5) + 16*N_L (SURVEY.md 8d, G=11)",
+                # what this design has to move at least: packed q-data 6 doubles / point + 384 B of index per element + one pass
+                # over x and y (the E-vector round trip of the shared dofs comes on top)
+                "design_floor_bytes": design_floor,
+                "traffic_over_design_floor": (traffic / design_floor) if (traffic and design_floor) else None}
+    if world == 1 and not roofline["consistent_with_ms_per_step"]:
+        print(f"bench.py: roofline leg {kernel_ms:.4f} ms per apply against {ms_per_step:.4f} ms per step", file=sys.stderr)
 
     # ---- M2: PCG + p-multigrid on (K + M) x = b ---------------------------------------------------
     # iterations/s over a fixed number of iterations (rel_tol = 0, so the count is the same on any

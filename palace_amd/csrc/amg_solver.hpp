@@ -10,7 +10,7 @@
 //         a correction from the space of gradients (G^T A G, AMG), additive corrections from the three scalar nodal spaces
 //         (Pi_c^T A Pi_c, AMG; Pi_c = the lowest-order Nedelec interpolation of a nodal field times e_c, built from G and the
 //         vertex coordinates exactly as HYPRE_AMSSetCoordinateVectors does: Pi_c = |G| diag(G x_c) / 2), again gradients,
-//         again smoothing.  `singular` (ams.cpp:175-178, magnetostatics without a mass term) skips the gradient corrections.
+//         again smoothing.  `singular` (ams.cpp:28-30, :149-152, magnetostatics without a mass term) skips the gradient corrections.
 // Set-up (aggregation, Galerkin products: amg.hpp) runs on the host once per matrix; every application runs on the device
 // as sparse matrix-vector products and fused vector kernels on the context's stream, without host synchronisation, so it can
 // sit inside a recorded V-cycle (StreamGraph).  One rank: the matrices are the rank's own (local) ones.
@@ -82,7 +82,7 @@ private:
 struct AmsOptions {
   int cycle_it = 1;      // AMS cycles per application (ams.cpp: ams_it)
   int smooth_order = 2;  // Chebyshev order of the smoother on A (ams.cpp: one sweep of an l1 smoother)
-  bool singular = false; // no mass term: skip the gradient-space corrections (ams.cpp:175-178)
+  bool singular = false; // no mass term: skip the gradient-space corrections (ams.cpp:28-30, :149-152)
   AmgOptions amg;
 };
 
