@@ -677,7 +677,8 @@ bool nd_hex_stream_complex_ok(const SubOp &sr, const SubOp &si) {
   // the real operator provides the kernel's arrays (metric form: the q-data is the geometry's J^T J, shared by every such
   // operator on it); the imaginary one only its per-element scalars (stream_element_coefficients)
   auto kind_ok = [](const SubOp &so) {
-    return so.fe_type == PA_FE_HCURL && so.iso && so.q1d == 4 && so.p <= 3 && !so.geom->h_attr.empty() &&
+    return so.fe_type == PA_FE_HCURL && so.iso && ((so.q1d == 4 && so.p <= 3) || (so.q1d == 5 && so.p <= 4 && nd_hex_stream5_ok(so))) &&
+           !so.geom->h_attr.empty() &&
            (so.qf == PA_QF_HDIV_33 || so.qf == PA_QF_HCURL_33 || so.qf == PA_QF_HDIVMASS_33);
   };
   if (!enabled || !kind_ok(sr) || !kind_ok(si)) return false;
@@ -701,6 +702,7 @@ static void launch_complex_p(const SubOp &sr, const SubOp &si, const double *xr,
 
 void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
                                   double *ye_i, bool masked, hipStream_t s) {
+  if (sr.q1d == 5) return launch_nd_hex_stream5_complex(sr, si, xr, xi, yr, yi, ye_i, masked, s);
   switch (sr.p) {
     case 1: launch_complex_p<1>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;
     case 2: launch_complex_p<2>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;

@@ -28,15 +28,21 @@ struct NDStream5Args {
   const uint32_t *perm;   // [nep][NPK][32] slot half-words
   const double *qdata;    // [nep][NG][126]
   const double *coef;     // metric form: [nep][2] scalar mass / curl-curl coefficient of the element
-  const double *x;
-  double *y, *ye;
+  const double *coef1;    // complex form: the same of the imaginary-part operator
+  const double *x, *x1;   // (x1, y1, ye1: the imaginary part of the complex form)
+  double *y, *ye, *y1, *ye1;
   NDTab<P1, 5> tab;
 };
 
 // QPOS: where the q-data of the batch is requested: 0 at the top of the batch, 1 / 2 after the first / second forward
 // component (later = shorter live range of its 60 - 70 registers; curl-curl + mass at p = 4 does not fit 256 otherwise)
-template <int P1, bool USE_U, bool USE_C, bool METRIC, int GPOS, int QPOS>
+// CPLX: y = (A_r + i A_i)(x_r + i x_i) in one pass (pa_op_mult_complex; the complex form of the four-point kernel, DESIGN.md
+// 3.1c, carried over): ONE element per wave, its two 32-lane halves hold the real and the imaginary part of x / y; both read
+// the same index block and q-data, the parts meet at the D stage (the coefficients are per-element scalars in the metric
+// form: the half's own values times the real coefficient -/+ the other half's times the imaginary one).
+template <int P1, bool USE_U, bool USE_C, bool METRIC, int GPOS, int QPOS, bool CPLX = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(const NDStream5Args<P1> a) {
+  static_assert(!CPLX || (USE_U && USE_C && METRIC), "the complex form is the metric curl-curl + mass kernel");
   constexpr int Q1 = 5;
   using L = NDLayoutInPlace<P1, Q1>;  // (LDS limits the resident waves here)
   using streamhost::kWideEss;
@@ -68,8 +74,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
   int b = a.blist ? a.blist[k] : k;
 
   // index block and slot words of a batch (arrays padded to whole batches; pad entries read as zero)
+  const double *xsel = (CPLX && (lane >> 5)) ? a.x1 : a.x;  // the part of x this half gathers
   auto load_idx = [&](const int bb, const int sub, const int t, unsigned (&w)[2], unsigned (&p)[NPK]) {
-    const int e = bb * 2 + sub;
+    const int e = CPLX ? bb : bb * 2 + sub;
     const uint32_t *ic = a.idxw + (size_t)e * kWideWords;
     w[0] = __builtin_nontemporal_load(&ic[t]);
     w[1] = __builtin_nontemporal_load(&ic[32 + (t & 15)]);
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
     for (int r = 0; r < NPL; r++) {
       int dof = decode(stab, r, t);
       if (!(32 * r + 31 < PP) && t + 32 * r >= PP) dof = 0;  // lanes past the last entry
-      xv[r] = a.x[dof];
+      xv[r] = xsel[dof];
     }
   };
   auto settle = [&](unsigned (&p)[NPK]) {
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
     int *spw = reinterpret_cast<int *>(stg + STG_D);
     int *stab_cur = spw + 2 * SPW_D + par * kWideWords;
     int *stab = spw + 2 * SPW_D + (par ^ 1) * kWideWords;  // of the next batch
-    const int e = b * 2 + sub;
+    const int e = CPLX ? b : b * 2 + sub;
     // the next batch (clamped: the last iteration re-reads its own).  Looked up first thing: a batch-list load issued
     // behind the q-data loads would make its use wait for all of them (vmcnt retires in order)
     const int kn = k + stride;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
     // q-data of this batch: consumed after the forward contraction (read once: non-temporal)
     d2v5 gq[2 * NG];
     double g4[NG];
-    d2v5 ce = {0.0, 0.0};
+    d2v5 ce = {0.0, 0.0}, ci = {0.0, 0.0};
     auto load_qdata = [&]() {
       const double *g = a.qdata + (size_t)e * ((METRIC ? 7 : NG) * CS);  // (the metric form always stores 7 per point)
 #pragma unroll
@@ -143,6 +150,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
         g4[c] = __builtin_nontemporal_load(&g[c * CS + 100 + tc]);
       }
       if (METRIC) ce = reinterpret_cast<const d2v5 *>(a.coef)[e];
+      if (CPLX) ci = reinterpret_cast<const d2v5 *>(a.coef1)[e];
     };
     if (QPOS == 0) load_qdata();
 
@@ -225,14 +233,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
       if (METRIC) {
         // H = (w / |detJ|) J^T J {00, 01, 02, 11, 12, 22}, H[6] = |detJ| / w:
         //   (w / detJ) J^T c J = c H,   w detJ adj^T c adj = c (|detJ| / w) adj(H)
+        double cmass = ce[0], ccurl = ce[1];
+        if (CPLX) {
+          // (a_r + i a_i)(u_r + i u_i): this half's part of the product, the other part's values from the other half; D is
+          // linear in the coefficient, so the geometric matrices below are applied with unit coefficients
+          const double sg = sub ? 1.0 : -1.0;
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const double pu = __shfl_xor(U[c][qz], 32, 64), pcu = __shfl_xor(CU[c][qz], 32, 64);
+            U[c][qz] = ce[0] * U[c][qz] + sg * ci[0] * pu;
+            CU[c][qz] = ce[1] * CU[c][qz] + sg * ci[1] * pcu;
+          }
+          cmass = 1.0, ccurl = 1.0;
+        }
         if (USE_U) {
-          const double cm = H[6] * ce[0];
+          const double cm = H[6] * cmass;
           const double m[6] = {cm * (H[3] * H[5] - H[4] * H[4]), cm * (H[2] * H[4] - H[1] * H[5]), cm * (H[1] * H[4] - H[2] * H[3]),
                                cm * (H[0] * H[5] - H[2] * H[2]), cm * (H[1] * H[2] - H[0] * H[4]), cm * (H[0] * H[3] - H[1] * H[1])};
           sym_mv(m, U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
         }
         if (USE_C) {
-          const double m[6] = {ce[1] * H[0], ce[1] * H[1], ce[1] * H[2], ce[1] * H[3], ce[1] * H[4], ce[1] * H[5]};
+          const double m[6] = {ccurl * H[0], ccurl * H[1], ccurl * H[2], ccurl * H[3], ccurl * H[4], ccurl * H[5]};
           sym_mv(m, CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
         }
         __builtin_amdgcn_sched_barrier(0);  // one point at a time: short live ranges
@@ -278,7 +299,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
       const double v = stg[h & kWideSlotMask];
       int d = decode(stab_cur, mr, mt);
       asm volatile("" : "+v"(d));  // (decoded unconditionally: sunk into a branch otherwise, and the stores stop being counted)
-      double *dst = (h & kWideExcl) ? a.y + d : a.ye + ((size_t)e * PP + m);
+      double *dst = (h & kWideExcl) ? ((CPLX && sub) ? a.y1 : a.y) + d : ((CPLX && sub) ? a.ye1 : a.ye) + ((size_t)e * PP + m);
       *dst = (h & kWideFlip) ? -v : v;
     }
     wave_sync();  // the LDS strip is reused by the next batch
@@ -310,7 +331,7 @@ static int device_cus5() {
   return cus;
 }
 
-template <int P1, bool U, bool C, bool METRIC, int GPOS, int QPOS>
+template <int P1, bool U, bool C, bool METRIC, int GPOS, int QPOS, bool CPLX = false>
 static void launch5_gpos(const SubOp &so, NDStream5Args<P1> &a, hipStream_t s) {
   using L = NDLayoutInPlace<P1, 5>;
   for (int i = 0; i < HalfTab<P1, 5>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
@@ -322,20 +343,20 @@ static void launch5_gpos(const SubOp &so, NDStream5Args<P1> &a, hipStream_t s) {
   // (with a fixed stride a workgroup that had to queue would run after the others and double the time)
   static const int per_cu_query = [&] {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream5_kernel<P1, U, C, METRIC, GPOS, QPOS>, 64 * kWavesPerBlock, lds) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream5_kernel<P1, U, C, METRIC, GPOS, QPOS, CPLX>, 64 * kWavesPerBlock, lds) !=
             hipSuccess || nb <= 0)
       nb = 4;
     return std::min({nb, (int)(160 * 1024 / lds), 8});
   }();
   const int per_cu = wg_env > 0 ? wg_env : per_cu_query;
   const int per_xcd = std::max(1, device_cus5() / 8) * per_cu;
-  if (!a.blist) a.nbatch = (so.ne + 1) / 2;
+  if (!a.blist) a.nbatch = CPLX ? so.ne : (so.ne + 1) / 2;  // (complex form: one element per wave)
   if (a.nbatch == 0) return;
   a.chunk = (a.nbatch + 7) / 8;
   int wgx = std::max(1, std::min(per_xcd, (a.chunk + kWavesPerBlock - 1) / kWavesPerBlock));
   // PALACE_AMD_STREAM_WGX caps the workgroups per XCD (tests: many batches per wave on a small mesh)
   if (const char *cap = getenv("PALACE_AMD_STREAM_WGX")) wgx = std::max(1, std::min(wgx, atoi(cap)));
-  hipLaunchKernelGGL((nd_hex_stream5_kernel<P1, U, C, METRIC, GPOS, QPOS>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
+  hipLaunchKernelGGL((nd_hex_stream5_kernel<P1, U, C, METRIC, GPOS, QPOS, CPLX>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
   PA_HIP(hipGetLastError());
 }
 
@@ -369,8 +390,9 @@ static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, 
   a.idxw = so.d_idxc;
   a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
   a.qdata = so.qd->d;
-  a.coef = so.d_coef_s;
+  a.coef = so.d_coef_s, a.coef1 = nullptr;
   a.x = x, a.y = y, a.ye = so.d_ye;
+  a.x1 = nullptr, a.y1 = nullptr, a.ye1 = nullptr;
   const bool m = so.qd->metric;
   switch (so.qf) {
     case PA_QF_HDIV_33:
@@ -393,6 +415,33 @@ void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool mas
     case 2: launch5_p<2>(so, x, y, masked, s, phase); break;
     case 3: launch5_p<3>(so, x, y, masked, s, phase); break;
     case 4: launch5_p<4>(so, x, y, masked, s, phase); break;
+    default: throw Error("no five-point streaming H(curl) hex kernel for this order");
+  }
+}
+template <int P1>
+static void launch5_complex_p(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
+                              double *ye_i, bool masked, hipStream_t s) {
+  NDStream5Args<P1> a;
+  a.ne = sr.ne, a.blist = nullptr, a.nbatch = 0;
+  a.idxw = sr.d_idxc;
+  a.perm = masked ? sr.d_perm_s_bc : sr.d_perm_s;
+  a.qdata = sr.qd->d;
+  a.coef = sr.d_coef_s, a.coef1 = si.d_coef_s;
+  a.x = xr, a.x1 = xi, a.y = yr, a.y1 = yi, a.ye = sr.d_ye, a.ye1 = ye_i;
+  if constexpr (P1 == 4)
+    launch5_gpos<P1, true, true, true, 2, 2, true>(sr, a, s);
+  else
+    launch5_gpos<P1, true, true, true, 2, 0, true>(sr, a, s);
+}
+
+// the complex form at five points per direction (pa_op_mult_complex; eligibility: nd_hex_stream_complex_ok)
+void launch_nd_hex_stream5_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
+                                   double *ye_i, bool masked, hipStream_t s) {
+  switch (sr.p) {
+    case 1: launch5_complex_p<1>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;
+    case 2: launch5_complex_p<2>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;
+    case 3: launch5_complex_p<3>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;
+    case 4: launch5_complex_p<4>(sr, si, xr, xi, yr, yi, ye_i, masked, s); break;
     default: throw Error("no five-point streaming H(curl) hex kernel for this order");
   }
 }

@@ -82,12 +82,12 @@ sys.path.insert(0, %r)
 from palace_amd import ceed, linalg
 from palace_amd.fem.fespace import NDHexSpace
 from palace_amd.fem.mesh import ogrid_cylinder
-p = int(sys.argv[1])
+p, q1d = int(sys.argv[1]), int(sys.argv[3])
 ctx = linalg.Context()
 mesh = ogrid_cylinder(2, 3)
 mesh.attr[:] = 1 + (np.arange(mesh.ne) %% 2)
 nd = NDHexSpace(mesh, p)
-geom = ceed.GeomFactorData(mesh, 4)
+geom = ceed.GeomFactorData(mesh, q1d)
 two = lambda a, b: ceed.coefficient_context(3, attr_mat=[0, 1], mat_coeff=[np.array([a]), np.array([b])])
 Ar = ceed.curlcurlmass_operator(geom, nd, two(-0.9, -0.35), two(1.0, 0.6))
 Ai = ceed.ndmass_operator(geom, nd, two(0.21, 0.05))
@@ -110,10 +110,11 @@ print("OK")
 '''
 
 
-@pytest.mark.parametrize("p", [1, 2, 3])
-def test_fused_complex_apply(p, tmp_path):
+@pytest.mark.parametrize("p,q1d", [(1, 4), (2, 4), (3, 4), (4, 5), (2, 5), (1, 5)])
+def test_fused_complex_apply(p, q1d, tmp_path):
     """y = (A_r + i A_i) x in one pass over the element data (pa_op_mult_complex): the complex streaming
-    kernel against the four separate applies (PALACE_AMD_COMPLEX_FUSED=0, the path of linalg/operator.cpp:98-134) and against the
+    kernel (four points per direction: pa_nd_hex_stream.hip, five: pa_nd_hex_stream5.hip -- order 4 and the coarsened levels of an
+    order-4 problem) against the four separate applies (PALACE_AMD_COMPLEX_FUSED=0, the path of linalg/operator.cpp:98-134) and against the
     oracle's operators, with two materials, plain and with essential dofs (DIAG_ONE on the real, DIAG_ZERO on the imaginary part)."""
     import os
     import subprocess
@@ -125,7 +126,7 @@ def test_fused_complex_apply(p, tmp_path):
     res = {}
     for fused in (1, 0):
         f = str(tmp_path / f"out{fused}.npz")
-        r = subprocess.run([sys.executable, "-c", FUSED_CHECK % root, str(p), f], capture_output=True, text=True, timeout=300,
+        r = subprocess.run([sys.executable, "-c", FUSED_CHECK % root, str(p), f, str(q1d)], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, PALACE_AMD_COMPLEX_FUSED=str(fused)))
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
         res[fused] = np.load(f)
@@ -137,9 +138,9 @@ def test_fused_complex_apply(p, tmp_path):
     mesh = ogrid_cylinder(2, 3)
     mesh.attr[:] = 1 + (np.arange(mesh.ne) % 2)
     nd = NDHexSpace(mesh, p)
-    ogeom = util.oracle_geom(mesh, 4)
+    ogeom = util.oracle_geom(mesh, q1d)
     off, ori = nd.native_restriction()
-    interp, curl = util.dense_tables(nd, 4)
+    interp, curl = util.dense_tables(nd, q1d)
     two = lambda a, b: po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([a]), np.array([b])])  # noqa: E731
     Aro = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HDIVMASS, two(-0.9, -0.35), two(1.0, 0.6))
     Aio = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HCURL, two(0.21, 0.05))
