@@ -355,6 +355,19 @@ int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream);
  * y[ess] = x[ess] (diag_policy 1, DIAG_ONE) or 0 (DIAG_ZERO).  *handled = 1 if the rows were written, 0 if the
  * caller still has to do it. */
 int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_policy, void *stream, int *handled);
+
+/* Split vectors: y = A x for a multi-rank apply without L-vector copies.  The local dofs [0, n_true) of the operator are read
+ * from x and written to y (the caller's true-dof vectors); the ghosts [n_true, lsize) are read from xg0 or xg1 -- two buffers of
+ * lsize - n_true doubles, the one to use is given by the parity of the device-resident counter *sel at the time the kernel runs
+ * (sel == NULL: xg0), which is how the peer transport's double-buffered mailboxes are read in place and inside recorded graphs
+ * (palace_amd/csrc/comm.hpp) -- and written to yg.  ess_policy >= 0: the essential list of pa_op_set_essential (true dofs) is
+ * masked on input and the rows are fixed on output as in pa_op_mult_essential_diag (1: y = x there, 0: y = 0); < 0: plain.
+ * What the reference does with three copies around CeedOperatorApplyAdd (linalg/rap.cpp:195-234: tx = x, lx = P tx, ly = A lx,
+ * y = P^T ly) when P is a halo exchange.  pa_op_supports_split: 1 for a single H(curl) hexahedral block on the four-point
+ * streaming kernel (orders 1-3), 0 otherwise (the caller keeps the L-vector path). */
+int pa_op_supports_split(const pa_op *op);
+int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y,
+                     double *yg, int n_true, int ess_policy, void *stream);
 /* Two right-hand sides in one pass: y0 = A x0, y1 = A x1.  This is what ComplexWrapperOperator::Mult needs
  * (linalg/operator.cpp:98-134: Ar and Ai are each applied to the real and to the imaginary part); the element's index
  * arrays and D-stage data are read once for both vectors.  The *_essential_diag form is the two-vector version of

@@ -363,6 +363,26 @@ class Operator:
                                           C.c_void_p(y.data_ptr()), _stream()))
         return y
 
+    def set_essential(self, ess):
+        """pa_op_set_essential: fuse a list of essential dofs into the operator's index tables (masked applies)."""
+        e = np.ascontiguousarray(ess, dtype=np.int32)
+        _lib.check(_lib.load().pa_op_set_essential(self.handle, e.ctypes.data_as(C.c_void_p), int(e.size)))
+        self._ess_keep = e
+
+    def supports_split(self):
+        return bool(_lib.load().pa_op_supports_split(self.handle))
+
+    def mult_split(self, x, xg0, y, yg, ess_policy=-1, xg1=None, sel=None):
+        """pa_op_mult_split: true dofs in x / y (len n_true), ghosts read from xg0 (or xg1 when the uint64 device scalar `sel`
+        is odd) and written to yg."""
+        L = _lib.load()
+        L.pa_op_mult_split.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]
+        _lib.check(L.pa_op_mult_split(self.handle, C.c_void_p(x.data_ptr()), C.c_void_p(xg0.data_ptr()),
+                                      C.c_void_p(xg1.data_ptr()) if xg1 is not None else None,
+                                      C.c_void_p(sel.data_ptr()) if sel is not None else None, C.c_void_p(y.data_ptr()),
+                                      C.c_void_p(yg.data_ptr()), int(x.numel()), int(ess_policy), _stream()))
+        return y, yg
+
     def mult2(self, x0, x1, y0, y1):
         """y0 = A x0, y1 = A x1 in one pass over the element data (pa_op_mult2)."""
         _lib.check(_lib.load().pa_op_mult2(self.handle, C.c_void_p(x0.data_ptr()), C.c_void_p(x1.data_ptr()),

@@ -84,7 +84,10 @@ __global__ void k_unpack_add(double *__restrict__ v, const int32_t *__restrict__
 }
 inline int blocks(int n) { return std::max(1, std::min(1024, (n + 255) / 256)); }
 // blocks that touch a mailbox: few, walking it with a stride (each of them bumps a counter before the flags go up)
-inline int mail_blocks(int n) { return std::max(1, std::min(64, (n + 255) / 256)); }
+// blocks of the exchange kernels: one round of their unrolled loops per thread where the two-level block counter (last_block)
+// keeps the completion detection cheap -- 4 entries per thread in the send / unpack kernels, 2 in the summing one
+inline int mail_blocks(int n) { return std::max(1, std::min(256, (n + 1023) / 1024)); }
+inline int sum_blocks(int n) { return std::max(1, std::min(512, (n + 511) / 512)); }
 
 }  // namespace
 
@@ -137,6 +140,7 @@ void LocalGroup::Abort() {
 
 Halo::~Halo() {
   (void)hipFree(d_send_idx_), (void)hipFree(d_recv_idx_), (void)hipFree(d_sendbuf_), (void)hipFree(d_recvbuf_);
+  if (d_ghost_out_) (void)hipFree(d_ghost_out_);
   FreePeer();
 }
 
@@ -316,7 +320,13 @@ struct PeerLocal {
 // the exchange itself (measured: 14 us per kernel)
 struct PeerCounters {
   unsigned long long seq[2];      // my exchange counters (advanced on the device: graphs replay)
-  unsigned int done[2], cons[2];  // block counters of the send / consume kernels
+  // block counters of the send / consume kernels, two levels: a block bumps the counter of its group (block index mod 16, each
+  // in its own 64-byte line), the last of a group bumps `top` -- a single counter costs 13 ns per block (measured), which capped
+  // the kernels at 64 blocks and left their threads several dependent round trips to uncached memory each
+  struct BlockCounter {
+    unsigned int top, pad[15];
+    unsigned int grp[16][16];
+  } done[2], cons[2];
 };
 // one neighbour as the kernels see it
 struct PeerNbr {
@@ -366,11 +376,20 @@ __device__ bool spin_ge(const unsigned long long *p, unsigned long long want, un
 }
 
 // true in the block that finishes last of `nblocks` (every one's stores have been performed by then)
-__device__ __forceinline__ bool last_block(unsigned int *counter, const unsigned int nblocks) {
+__device__ __forceinline__ bool last_block(PeerCounters::BlockCounter *c, const unsigned int nblocks) {
   __shared__ bool last;
   stores_performed();
   __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == nblocks - 1;
+  if (threadIdx.x == 0) {
+    const unsigned int g = blockIdx.x & 15u, ng = (nblocks - g + 15u) / 16u, ngroups = nblocks < 16u ? nblocks : 16u;
+    bool l = false;
+    if (atomicAdd(&c->grp[g][0], 1u) == ng - 1u) {
+      c->grp[g][0] = 0;  // (every block of the group has arrived: free for the next launch)
+      l = atomicAdd(&c->top, 1u) == ngroups - 1u;
+      if (l) c->top = 0;
+    }
+    last = l;
+  }
   __syncthreads();
   return last;
 }
@@ -389,12 +408,19 @@ __device__ __forceinline__ void wait_exchange(const PeerNbr *nb, const int nnbr,
 // (1) my pieces of direction `dir` into the neighbours' mailboxes, then their flags.  Source v[idx[i]] (idx == nullptr:
 // v[first + i]).  FUSED (P only, ParOperator::Mult): the vector is built on the way -- lx[i] = mask[i] & 1 ? 0 : x[i] for the
 // true dofs, the same masked values into the mailboxes (rap.cpp:207-216: tx = x, tx[ess] = 0, lx = P tx).
-template <bool FUSED>
+// MODE 2 (direct form of ParOperator::Mult, P only): the masked values straight from x, no L-vector; the last block then waits
+// for the neighbours' messages of this exchange, so that the kernel behind this one may read the mailbox in place.
+// ack_p (P^T of the direct form): the last block also acknowledges the P messages of this Mult -- the element kernel that
+// read them from the mailbox has finished by now.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_peer_send(const PeerNbr *__restrict__ nb, const int nnbr, PeerCounters *__restrict__ L,
                                                     const int dir, const int total, const double *__restrict__ v,
                                                     const int32_t *__restrict__ idx, const int first,
                                                     const uint8_t *__restrict__ mask, double *__restrict__ lx, const int n_true,
-                                                    const int mblk) {
+                                                    const int mblk, const PeerLocal *__restrict__ F, unsigned long long *err,
+                                                    const int ack_p) {
+  constexpr bool FUSED = MODE == 1;
+  constexpr bool MASKED = MODE != 0;
   // Blocks [0, mblk) walk the mailbox entries (and are the only ones counted before the flags go up: a block counter that
   // thousands of blocks bump costs 13 ns per block, measured -- more than the whole exchange); FUSED: the blocks behind
   // them copy the true dofs, one per thread.
@@ -416,7 +442,7 @@ __global__ __launch_bounds__(256) void k_peer_send(const PeerNbr *__restrict__ n
       d[j] = i < total ? (idx ? idx[i] : first + i) : -1;
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) val[j] = d[j] >= 0 ? ((FUSED && (mask[d[j]] & 1)) ? 0.0 : v[d[j]]) : 0.0;
+    for (int j = 0; j < 4; j++) val[j] = d[j] >= 0 ? ((MASKED && (mask[d[j]] & 1)) ? 0.0 : v[d[j]]) : 0.0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int i = i0 + j * stride;
@@ -427,12 +453,12 @@ __global__ __launch_bounds__(256) void k_peer_send(const PeerNbr *__restrict__ n
     }
   }
   if (!last_block(&L->done[dir], mblk)) return;
-  for (int k = threadIdx.x; k < nnbr; k += blockDim.x)
+  for (int k = threadIdx.x; k < nnbr; k += blockDim.x) {
     if (nb[k].n[dir] > 0) st_sys(nb[k].flag[dir], s);
-  if (threadIdx.x == 0) {
-    L->done[dir] = 0;
-    L->seq[dir] = s;
+    if (ack_p && nb[k].rn[0] > 0) st_sys(nb[k].ack[0], L->seq[0]);
   }
+  if (threadIdx.x == 0) L->seq[dir] = s;
+  if (MODE == 2) wait_exchange(nb, nnbr, F, dir, s, err);
 }
 
 // (2a) P: mailbox -> ghost slots, then the acknowledgements
@@ -461,14 +487,15 @@ __global__ __launch_bounds__(256) void k_peer_consume_p(const PeerNbr *__restric
   if (!last_block(&L->cons[0], gridDim.x)) return;
   for (int k = threadIdx.x; k < nnbr; k += blockDim.x)
     if (nb[k].rn[0] > 0) st_sys(nb[k].ack[0], s);
-  if (threadIdx.x == 0) L->cons[0] = 0;
 }
 
 // (2b) P^T: every owned dof that has sharers adds their contributions, neighbour by neighbour in plan order (fixed summation
 // order: the result does not depend on arrival times).  FUSED (ParOperator::Mult): the result goes to y with ParOperator's
 // essential rows fixed on the way (rap.cpp:222-233): y[i] = ess ? (x[i] | 0) : ly[i] + contributions, mask bit 1 = essential,
 // bit 2 = the dof has sharers (its row of the contribution lists is found by bisection)
-template <bool FUSED>
+// MODE 2 (direct form): v = y already holds the local sums of the true dofs (the run gather wrote them, essential rows fixed);
+// the contributions are added in place, essential rows are left alone
+template <int MODE>
 __global__ __launch_bounds__(256) void k_peer_consume_r(const PeerNbr *__restrict__ nb, const int nnbr,
                                                          const PeerLocal *__restrict__ F, PeerCounters *__restrict__ L,
                                                          const double *__restrict__ mb, const int nsend, double *__restrict__ v,
@@ -477,6 +504,7 @@ __global__ __launch_bounds__(256) void k_peer_consume_r(const PeerNbr *__restric
                                                          unsigned long long *err, const uint8_t *__restrict__ mask,
                                                          const double *__restrict__ x, const int diag_one, double *__restrict__ y,
                                                          const int n_true, const int sblk) {
+  constexpr bool FUSED = MODE == 1;
   // Blocks [0, sblk) own the dofs with sharers (they wait for the messages, read the mailbox and acknowledge); FUSED: the
   // blocks behind them write every other true dof, one per thread, without waiting for anybody.
   if (FUSED && (int)blockIdx.x >= sblk) {
@@ -517,14 +545,15 @@ __global__ __launch_bounds__(256) void k_peer_consume_r(const PeerNbr *__restric
         for (int a = info[j].w; a < rptr[i + 1]; a++) t += ld_sys_f64(&src[rpos[a]]);
       if (FUSED)
         y[d] = (mask[d] & 1) ? (diag_one ? x[d] : 0.0) : t;
-      else
+      else if (MODE == 2) {
+        if (!(mask[d] & 1)) v[d] = t;
+      } else
         v[d] = t;
     }
   }
   if (!last_block(&L->cons[1], sblk)) return;
   for (int k = threadIdx.x; k < nnbr; k += blockDim.x)
     if (nb[k].rn[1] > 0) st_sys(nb[k].ack[1], s);
-  if (threadIdx.x == 0) L->cons[1] = 0;
 }
 
 // global sum: my values into everybody's slot of me, flags; then wait for everybody and add in rank order (the same result,
@@ -572,6 +601,7 @@ void Comm::AllocArena() {
   void *p = nullptr;
   hipError_t rc = hipErrorUnknown;
   if (m == "uncached") rc = hipExtMallocWithFlags(&p, arena_bytes_, hipDeviceMallocUncached);
+  arena_uncached_ = rc == hipSuccess;  // (plain loads of other kernels may read the mailboxes in place: Halo::DirectOk)
   if (rc != hipSuccess && m != "plain") rc = hipExtMallocWithFlags(&p, arena_bytes_, hipDeviceMallocFinegrained);
   if (rc != hipSuccess) {
     (void)hipGetLastError();
@@ -757,14 +787,14 @@ void Halo::PeerExchange(int dir, double *d_v, hipStream_t s) const {
   const int total = dir == 0 ? nsend_ : nrecv_;
   const int32_t *sidx = dir == 0 ? d_send_idx_ : (recv_first_ >= 0 ? nullptr : d_recv_idx_);
   const int mb = mail_blocks(total);
-  hipLaunchKernelGGL(k_peer_send<false>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, dir, total, d_v, sidx,
-                     dir == 0 ? 0 : recv_first_, nullptr, nullptr, 0, mb);
+  hipLaunchKernelGGL(k_peer_send<0>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, dir, total, d_v, sidx,
+                     dir == 0 ? 0 : recv_first_, nullptr, nullptr, 0, mb, nullptr, nullptr, 0);
   if (dir == 0) {
     hipLaunchKernelGGL(k_peer_consume_p, dim3(mail_blocks(nrecv_)), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[0],
                        nrecv_, d_v, recv_first_ >= 0 ? nullptr : d_recv_idx_, recv_first_, p.d_err);
   } else {
-    const int sb = mail_blocks(p.n_rdof);
-    hipLaunchKernelGGL(k_peer_consume_r<false>, dim3(sb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[1], nsend_,
+    const int sb = sum_blocks(p.n_rdof);
+    hipLaunchKernelGGL(k_peer_consume_r<0>, dim3(sb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[1], nsend_,
                        d_v, p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, nullptr, nullptr, 0, nullptr, 0, sb);
   }
   PA_HIP(hipGetLastError());
@@ -777,8 +807,8 @@ void Halo::PeerExchange(int dir, double *d_v, hipStream_t s) const {
 void Halo::ProlongateFused(const double *d_x, const uint8_t *d_mask, int n_true, double *d_lx, hipStream_t s) const {
   const PeerPlan &p = *peer_;
   const int mb = mail_blocks(nsend_);
-  hipLaunchKernelGGL(k_peer_send<true>, dim3(mb + (n_true + 255) / 256), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 0, nsend_,
-                     d_x, d_send_idx_, 0, d_mask, d_lx, n_true, mb);
+  hipLaunchKernelGGL(k_peer_send<1>, dim3(mb + (n_true + 255) / 256), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 0, nsend_,
+                     d_x, d_send_idx_, 0, d_mask, d_lx, n_true, mb, nullptr, nullptr, 0);
   hipLaunchKernelGGL(k_peer_consume_p, dim3(mail_blocks(nrecv_)), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[0],
                      nrecv_, d_lx, recv_first_ >= 0 ? nullptr : d_recv_idx_, recv_first_, p.d_err);
   PA_HIP(hipGetLastError());
@@ -786,12 +816,45 @@ void Halo::ProlongateFused(const double *d_x, const uint8_t *d_mask, int n_true,
 void Halo::RestrictAddFused(const double *d_ly, const double *d_x, const uint8_t *d_mask, bool diag_one, int n_true, double *d_y,
                             hipStream_t s) const {
   const PeerPlan &p = *peer_;
-  const int mb = mail_blocks(nrecv_), sb = mail_blocks(p.n_rdof);
-  hipLaunchKernelGGL(k_peer_send<false>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 1, nrecv_, d_ly,
-                     recv_first_ >= 0 ? nullptr : d_recv_idx_, recv_first_, nullptr, nullptr, 0, mb);
-  hipLaunchKernelGGL(k_peer_consume_r<true>, dim3(sb + (n_true + 255) / 256), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local,
+  const int mb = mail_blocks(nrecv_), sb = sum_blocks(p.n_rdof);
+  hipLaunchKernelGGL(k_peer_send<0>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 1, nrecv_, d_ly,
+                     recv_first_ >= 0 ? nullptr : d_recv_idx_, recv_first_, nullptr, nullptr, 0, mb, nullptr, nullptr, 0);
+  hipLaunchKernelGGL(k_peer_consume_r<1>, dim3(sb + (n_true + 255) / 256), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local,
                      p.counters, p.mb[1], nsend_, const_cast<double *>(d_ly), p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err,
                      d_mask, d_x, diag_one ? 1 : 0, d_y, n_true, sb);
+  PA_HIP(hipGetLastError());
+}
+
+// The direct form of ParOperator::Mult (no L-vectors; local operators with a split-vector apply, pa_op_mult_split):
+//   SendDirect:        masked x of the owned dofs with sharers -> the neighbours' mailboxes; returns when theirs have arrived
+//   GhostIn*:          where the element kernel then reads the ghosts: the mailbox itself (two buffers, the parity of the
+//                      device-resident exchange counter says which -- the kernels are recordable)
+//   RestrictAddDirect: ghost rows (GhostOut) -> the owners' mailboxes, acknowledgement of the P messages; then every owned dof
+//                      with sharers adds their contributions to y in place (essential rows are left as the gather fixed them)
+bool Halo::DirectOk(int n_true, int n_local) const {
+  // (the element kernel reads the mailbox with plain loads: only from an uncached arena, where no stale line can be hit)
+  return peer_ != nullptr && comm_->arena_uncached_ && nrecv_ == n_local - n_true && (nrecv_ == 0 || recv_first_ == n_true);
+}
+const double *Halo::GhostIn(int buffer) const { return peer_->mb[0] + (size_t)buffer * nrecv_; }
+const unsigned long long *Halo::GhostInSelector() const { return &peer_->counters->seq[0]; }
+double *Halo::GhostOut() const {
+  if (!d_ghost_out_) d_ghost_out_ = pa::dev_alloc<double>((size_t)std::max(1, nrecv_));
+  return d_ghost_out_;
+}
+void Halo::SendDirect(const double *d_x, const uint8_t *d_mask, hipStream_t s) const {
+  const PeerPlan &p = *peer_;
+  const int mb = mail_blocks(nsend_);
+  hipLaunchKernelGGL(k_peer_send<2>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 0, nsend_, d_x, d_send_idx_, 0, d_mask,
+                     nullptr, 0, mb, p.local, p.d_err, 0);
+  PA_HIP(hipGetLastError());
+}
+void Halo::RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) const {
+  const PeerPlan &p = *peer_;
+  const int mb = mail_blocks(nrecv_), sb = sum_blocks(p.n_rdof);
+  hipLaunchKernelGGL(k_peer_send<0>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 1, nrecv_, GhostOut(), nullptr, 0,
+                     nullptr, nullptr, 0, mb, nullptr, nullptr, 1);
+  hipLaunchKernelGGL(k_peer_consume_r<2>, dim3(sb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[1], nsend_, d_y,
+                     p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, d_mask, nullptr, 0, nullptr, 0, sb);
   PA_HIP(hipGetLastError());
 }
 

@@ -69,6 +69,7 @@ class Comm {
   // ---- peer transport ----
   char *arena_ = nullptr;              // my arena (device memory the other ranks map)
   size_t arena_bytes_ = 0, arena_used_ = 0;
+  bool arena_uncached_ = false;
   std::vector<char *> remote_;         // [size] arena of rank r as mapped here (remote_[rank_] == arena_); empty: not connected
   std::vector<char> remote_ipc_;       // [size] 1: opened with hipIpcOpenMemHandle (to be closed)
   int next_halo_ = 0;
@@ -134,6 +135,7 @@ class Halo {
   void PeerExchange(int dir, double *d_v, hipStream_t s) const;
 
   std::vector<int32_t> shared_owned_;  // peer transport: the owned dofs that have sharers (sorted)
+  mutable double *d_ghost_out_ = nullptr;  // direct form: the ghost rows of the local apply
 
 public:
   bool UsesPeerTransport() const { return peer_ != nullptr; }
@@ -143,6 +145,14 @@ public:
   void ProlongateFused(const double *d_x, const uint8_t *d_mask, int n_true, double *d_lx, hipStream_t s) const;
   void RestrictAddFused(const double *d_ly, const double *d_x, const uint8_t *d_mask, bool diag_one, int n_true, double *d_y,
                         hipStream_t s) const;
+  // Direct form (no L-vectors; the local operator reads the ghosts from the mailbox and writes the ghost rows to GhostOut():
+  // pa_op_mult_split).  DirectOk: peer transport and the ghosts are the contiguous tail [n_true, n_local) in receive order.
+  bool DirectOk(int n_true, int n_local) const;
+  void SendDirect(const double *d_x, const uint8_t *d_mask, hipStream_t s) const;
+  const double *GhostIn(int buffer) const;             // the two mailbox buffers of P ...
+  const unsigned long long *GhostInSelector() const;   // ... and the device counter whose parity names the current one
+  double *GhostOut() const;
+  void RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) const;
   Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int32_t *send_idx, const int *recv_off,
        const int32_t *recv_idx);
   ~Halo();

@@ -854,6 +854,11 @@ void Operator::SetEssential(const int32_t *ess_host, int n) {
   StreamGraph::Invalidate();
   check(pa_op_set_essential(op_, ess_host, n));
 }
+bool Operator::SupportsSplit() const { return pa_op_supports_split(op_) != 0; }
+void Operator::MultSplit(const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y, double *yg,
+                         int n_true, int ess_policy) const {
+  check(pa_op_mult_split(op_, x, xg0, xg1, sel, y, yg, n_true, ess_policy, ctx_->stream));
+}
 bool Operator::MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const {
   int handled = 0;
   check(pa_op_mult_essential_diag(op_, x.Data(), y.Data(), diag_one ? 1 : 0, ctx_->stream, &handled));
@@ -974,6 +979,23 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
       if (st >= 0) A_fused_ = c;
     }
   }
+  // Peer transport and a local operator that applies to split vectors: no L-vector copies at all (Mult below).  The essential
+  // list is fused into the operator's index tables as on one rank (unless another wrapper has fused a different one).
+  static const bool direct_env = !(std::getenv("PALACE_AMD_HALO_DIRECT") && std::getenv("PALACE_AMD_HALO_DIRECT")[0] == '0');
+  if (halo && direct_env && halo->DirectOk(n_true, n_local_)) {
+    if (auto *c = dynamic_cast<const ceed::Operator *>(&A)) {
+      if (c->SupportsSplit() && c->IsSymmetric()) {
+        bool ok = true;
+        if (n_ess) {
+          const int st = pa_op_essential_state(c->Handle(), ess_host, n_ess);
+          if (st == 0) const_cast<ceed::Operator *>(c)->SetEssential(ess_host, n_ess);
+          ok = st >= 0;
+          split_ess_ = ok;
+        }
+        if (ok) A_split_ = c;
+      }
+    }
+  }
   if (halo && (n_ess || halo->UsesPeerTransport())) {
     // one byte per true dof: bit 1 essential, bit 2 (peer transport) an owned dof other ranks hold as a ghost
     std::vector<uint8_t> mask((size_t)n_true, 0);
@@ -1022,6 +1044,16 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
   }
   if (A_csr_ && x.Data() != y.Data()) {
     A_csr_->MultValues(d_csr_bc_, x, y);  // essential rows / columns live in this wrapper's copy of the values
+    return;
+  }
+  if (A_split_ && d_ess_mask_ && x.Data() != y.Data()) {
+    // peer transport, direct form: masked owned values to the neighbours (the kernel returns when theirs have arrived), the element
+    // kernel reads x and the mailbox, the run gather writes y (essential rows fixed) and the ghost rows, those go to their owners
+    // and are added to y in place -- five launches, no L-vector
+    halo_->SendDirect(x.Data(), d_ess_mask_, c.stream);
+    A_split_->MultSplit(x.Data(), halo_->GhostIn(0), halo_->GhostIn(1), halo_->GhostInSelector(), y.Data(), halo_->GhostOut(),
+                        n_true_, split_ess_ ? (policy_ == DiagonalPolicy::DIAG_ONE ? 1 : 0) : -1);
+    halo_->RestrictAddDirect(d_ess_mask_, y.Data(), c.stream);
     return;
   }
   if (halo_ && halo_->UsesPeerTransport() && d_ess_mask_ && x.Data() != y.Data() && !A_overlap_) {

@@ -226,6 +226,10 @@ public:
   void MultEssential(const Vector &x, Vector &y) const;
   // the same + y[ess] = x[ess] | 0 inside the E^T kernels; returns false if the caller must fix the rows up
   bool MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const;
+  // split vectors (pa_op_mult_split): true dofs in x / y, ghosts read from xg0 | xg1 (parity of *sel) and written to yg
+  bool SupportsSplit() const;
+  void MultSplit(const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y, double *yg,
+                 int n_true, int ess_policy) const;
   // y = (Ar + i Ai) x in one pass over the element data (pa_op_mult_complex); ess_policy -1: plain, 0 / 1: with Ar's fused
   // essential list, rows set to 0 / x
   // 0: no such form; 1: tensor hexahedra (essential dofs can be fused); 2: dense tables (plain form only)
@@ -327,6 +331,8 @@ private:
   const Operator *A_;
   const ceed::Operator *A_fused_ = nullptr;  // single rank: BC masking fused into the local apply
   const ceed::Operator *A_overlap_ = nullptr;  // with a halo: interior elements run while the ghosts are exchanged
+  const ceed::Operator *A_split_ = nullptr;    // peer transport: the local operator applies to split vectors (no L-vector copies)
+  bool split_ess_ = false;                     // ... with this wrapper's essential list fused into its index tables
   const CsrOperator *A_csr_ = nullptr;       // single rank, assembled local operator: BCs eliminated in the matrix values
   double *d_csr_bc_ = nullptr;               // ... this wrapper's copy of them (CsrOperator::EliminatedValues)
   const Halo *halo_;

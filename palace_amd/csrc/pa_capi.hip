@@ -1036,6 +1036,27 @@ int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_po
   });
 }
 
+int pa_op_supports_split(const pa_op *op) {
+  return (op && op->subs.size() == 1 && op->dsubs.empty() && op->msubs.empty() && nd_hex_stream_split_ok(*op->subs[0])) ? 1 : 0;
+}
+
+int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y,
+                     double *yg, int n_true, int ess_policy, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && x && y && xg0 && yg, "null argument");
+    PA_REQUIRE(pa_op_supports_split(op), "the operator has no split-vector form (pa_op_supports_split)");
+    PA_REQUIRE(x != y, "in-place apply is not supported");
+    PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed split apply of a non-symmetric operator");
+    SubOp *so = op->subs[0];
+    const bool masked = ess_policy >= 0;
+    PA_REQUIRE(!masked || (op->has_essential && so->d_perm_s_bc), "pa_op_set_essential has not been called");
+    const SplitIO io{n_true, xg0, xg1, sel, yg};
+    hipStream_t s = (hipStream_t)stream;
+    launch_nd_hex_stream(*so, x, y, masked, s, -1, &io);
+    launch_et_run_gather(*so, y, false, s, x, masked, ess_policy, nullptr, &io);
+  });
+}
+
 int pa_op_mult2(pa_op *op, const double *x0, const double *x1, double *y0, double *y1, void *stream) {
   return guarded([&] { apply2(op, x0, x1, y0, y1, (hipStream_t)stream, false, -1); });
 }

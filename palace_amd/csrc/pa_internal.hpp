@@ -283,14 +283,25 @@ bool nd_hex_stream_ok(const SubOp &so);
 void build_stream(SubOp &so);
 void stream_set_essential(SubOp &so, const std::vector<char> &flag);
 void free_stream(SubOp &so);
-void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase = -1);
+// Split vectors of a multi-rank apply without L-vector copies: local dofs [0, n_true) are read from x and written to y,
+// the ghosts [n_true, lsize) are read from xg0 or xg1 (the parity of the device-resident counter *sel picks the buffer; sel ==
+// NULL: xg0) and written to yg (all three unshifted: entry 0 is local dof n_true)
+struct SplitIO {
+  int n_true;
+  const double *xg0, *xg1;
+  const unsigned long long *sel;
+  double *yg;
+};
+bool nd_hex_stream_split_ok(const SubOp &so);
+void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase = -1,
+                          const SplitIO *split = nullptr);
 void stream_set_interface(SubOp &so, const std::vector<char> &flag);
 bool nd_hex_stream5_ok(const SubOp &so);
 void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase);
 void launch_nd_hex_stream5_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
                                    double *ye_i, bool masked, hipStream_t s);
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
-                          int ess_policy, const double *ye = nullptr);
+                          int ess_policy, const double *ye = nullptr, const SplitIO *split = nullptr);
 void stream_element_coefficients(SubOp &so);
 bool nd_hex_stream_complex_ok(const SubOp &sr, const SubOp &si);
 void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,

@@ -57,6 +57,13 @@ struct NDStreamArgs {
   // complex form (CPLX): imaginary parts of x, y and of the E-vector, coefficients of the imaginary operator
   const double *x1, *coef1;
   double *y1, *ye1;
+  // split vectors (SPLIT; multi-rank applies without L-vector copies): local dofs [0, nsplit) live in x / y, the ghosts
+  // [nsplit, lsize) in xg (input: one of two buffers, chosen by the parity of *xg_sel, a device-resident exchange counter) and
+  // yg (output).  xg0 / xg1 / yg are stored shifted by -nsplit, so that they are indexed with the local dof itself.
+  int nsplit;
+  const double *xg0, *xg1;
+  const unsigned long long *xg_sel;
+  double *yg;
   NDTab<P1, 4> tab;
 };
 
@@ -67,9 +74,10 @@ struct NDStreamArgs {
 // the two parts of x: the even 16-lane groups of a wave carry the real part, the odd ones the imaginary part of the same
 // element, both read the element's index words and q-data (one HBM read), exchange their quadrature values with the
 // neighbouring group once and store to the real / imaginary y and E-vector.  One pass over the geometry data instead of four.
-template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS, bool CPLX = false>
+template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
   static_assert(!CPLX || (METRIC && USE_U && USE_C), "the complex form is built on the metric curl-curl + mass kernel");
+  static_assert(!(CPLX && SPLIT), "no split-vector form of the complex kernel");
   constexpr int Q1 = 4;
 #ifdef PA_STREAM_EARLY  // experiment builds
   constexpr bool EARLY_IDX = true;
@@ -108,6 +116,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   // stored to E-vector rows nobody gathers)
   // s[0 .. NPL): the slice words (the same word for the 16 lanes of an element), s[NPL], s[NPL + 1]: run starts t, 16 + t
   const double *xsel = (CPLX && ((lane >> 4) & 1)) ? a.x1 : a.x;  // the part of x this 16-lane group gathers
+  const double *xgh = nullptr;  // SPLIT: where the ghost entries are read (shifted: indexed with the local dof)
+  if (SPLIT) xgh = ((a.xg_sel ? *a.xg_sel : 0ull) & 1ull) ? a.xg1 : a.xg0;
   auto load_idx = [&](const int bb, const int sub, const int t, int (&s)[NPL + 2], unsigned (&p)[NPK + 1]) {
     const int e = CPLX ? bb * 2 + (sub >> 1) : bb * 4 + sub;
     const uint32_t *ic = a.idxc + (size_t)e * kIdxWords;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       const int pos = low ? 16 * r + 31 - __clz((int)low) : (int)((w >> 21) & 255u);
       int dof = stab[rid] + (t + 16 * r - pos);
       if (!(16 * r + 15 < PP) && t + 16 * r >= PP) dof = 0;  // lanes past the last entry
-      xv[r] = xsel[dof];
+      xv[r] = SPLIT ? (dof < a.nsplit ? xsel : xgh)[dof] : xsel[dof];
       const int word = dof | ((fw >> (2 * r + 1)) & 1u ? kExclBit : 0) | ((fw >> (18 + r)) & 1u ? kEssBit : 0);
       s[r] = (fw >> (2 * r)) & 1u ? -1 - word : word;
     }
@@ -334,7 +344,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       const unsigned fl = (unsigned)side[2 * ((PP + 1) / 2) + 16 * NPK + mt] >> (2 * mr);
       const double v = sm[((unsigned)side[2 * ((PP + 1) / 2) + 16 * (mr >> 2) + mt] >> (8 * (mr & 3))) & 255u];
       const int sv = side[m], df = sv >= 0 ? sv : -1 - sv, d = df & (kExclBit - 1);
-      double *dst = (fl & 2u) ? ((CPLX && (sub & 1)) ? a.y1 : a.y) + d : ((CPLX && (sub & 1)) ? a.ye1 : a.ye) + ((size_t)e * PP + m);
+      double *yd = (CPLX && (sub & 1)) ? a.y1 : a.y;
+      if (SPLIT) yd = d < a.nsplit ? a.y : a.yg;
+      double *dst = (fl & 2u) ? yd + d : ((CPLX && (sub & 1)) ? a.ye1 : a.ye) + ((size_t)e * PP + m);
       *dst = (fl & 1u) ? -v : v;
     }
     wave_sync();  // the LDS strip is reused by the next batch
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const u
                                                             const RunHdr *__restrict__ hdr, const int32_t *__restrict__ rpos,
                                                             const double *__restrict__ ye, double *__restrict__ y,
                                                             const int accumulate, const double *__restrict__ x,
-                                                            const int ess_policy) {
+                                                            const int ess_policy, const int nsplit, double *__restrict__ yg) {
   const int k0 = blockIdx.x * (256 * kGatherILP) + threadIdx.x;
   uint32_t c[kGatherILP];
   RunHdr h[kGatherILP];
@@ -421,9 +433,10 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const u
     if (live[u])
       for (int p = h[u].ptr + 4; p < pe[u]; p++) s[u] += ye[(size_t)rpos[p] + j[u]];
   }
+  // (split vectors: rows [nsplit, ...) are ghosts and go to yg, stored shifted by -nsplit; nsplit = INT_MAX otherwise)
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++)
-    if (live[u]) y[d[u]] = yold[u] + s[u];
+    if (live[u]) (d[u] < nsplit ? y : yg)[d[u]] = yold[u] + s[u];
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -576,7 +589,7 @@ static int device_cus() {
   return cus;
 }
 
-template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS, bool CPLX = false>
+template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false>
 static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   using L = typename std::conditional<P1 == 3 && !CPLX && C && !U, NDLayoutInPlaceSwz3, NDLayout<P1, 4>>::type;  // (as in the kernel)
   for (int i = 0; i < HalfTab<P1, 4>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
@@ -590,7 +603,7 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   static const int wg_env = getenv("PALACE_AMD_STREAM_WG") ? atoi(getenv("PALACE_AMD_STREAM_WG")) : 0;
   static const int per_cu_query = [&] {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX>,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX, SPLIT>,
                                                      64 * kWavesPerBlock, lds) != hipSuccess || nb <= 0)
       nb = 8;
     return std::min({nb, MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
@@ -602,8 +615,8 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   if (a.nbatch == 0) return;
   a.chunk = (a.nbatch + 7) / 8;
   const int wgx = std::max(1, std::min(per_xcd, (a.chunk + kWavesPerBlock - 1) / kWavesPerBlock));
-  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s,
-                     a);
+  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX, SPLIT>), dim3(8 * wgx), dim3(64 * kWavesPerBlock),
+                     lds, s, a);
   PA_HIP(hipGetLastError());
 }
 
@@ -620,6 +633,8 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
   constexpr int MINW = MINW_;
 #endif
   static const int gpos = getenv("PALACE_AMD_STREAM_GPOS") ? atoi(getenv("PALACE_AMD_STREAM_GPOS")) : (U ? 2 : 1);
+  if (a.nsplit >= 0)  // split vectors: the default gather position only (one more instantiation per operator kind)
+    return launch_gpos<P1, U, C, METRIC, MINW, (U ? 2 : 1), false, true>(so, a, s);
   if (gpos == 0)
     launch_gpos<P1, U, C, METRIC, MINW, 0>(so, a, s);
   else if (gpos == 2)
@@ -629,8 +644,15 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
 }
 
 template <int P1>
-static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase) {
+static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
   NDStreamArgs<P1> a;
+  a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
+  if (split) {
+    PA_REQUIRE(split->n_true >= 0 && split->n_true <= so.lsize, "split point outside the local vector");
+    a.nsplit = split->n_true;
+    a.xg0 = split->xg0 - split->n_true, a.xg1 = (split->xg1 ? split->xg1 : split->xg0) - split->n_true;
+    a.xg_sel = split->sel, a.yg = split->yg - split->n_true;
+  }
   a.ne = so.ne;
   a.blist = nullptr, a.nbatch = 0;
   if (phase >= 0) {  // 0: batches without interface elements, 1: the others (stream_set_interface)
@@ -659,12 +681,17 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   }
 }
 
-void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase) {
-  if (wide_form(so)) return launch_nd_hex_stream5(so, x, y, masked, s, phase);
+bool nd_hex_stream_split_ok(const SubOp &so) { return so.fe_type == PA_FE_HCURL && so.q1d == 4 && so.d_idxc && !wide_form(so); }
+
+void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
+  if (wide_form(so)) {
+    PA_REQUIRE(!split, "no split-vector form of the five-point kernel");
+    return launch_nd_hex_stream5(so, x, y, masked, s, phase);
+  }
   switch (so.p) {
-    case 1: launch_p<1>(so, x, y, masked, s, phase); break;
-    case 2: launch_p<2>(so, x, y, masked, s, phase); break;
-    case 3: launch_p<3>(so, x, y, masked, s, phase); break;
+    case 1: launch_p<1>(so, x, y, masked, s, phase, split); break;
+    case 2: launch_p<2>(so, x, y, masked, s, phase, split); break;
+    case 3: launch_p<3>(so, x, y, masked, s, phase, split); break;
     default: throw Error("no streaming H(curl) hex kernel for this order");
   }
 }
@@ -697,6 +724,7 @@ static void launch_complex_p(const SubOp &sr, const SubOp &si, const double *xr,
   a.qdata = sr.qd->d;
   a.coef = sr.d_coef_s, a.coef1 = si.d_coef_s;
   a.x = xr, a.x1 = xi, a.y = yr, a.y1 = yi, a.ye = sr.d_ye, a.ye1 = ye_i;
+  a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
   launch_gpos<P1, true, true, true, 2, 2, true>(sr, a, s);
 }
 
@@ -714,12 +742,14 @@ void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double
 // masked: the run list that owns the essential rows (the element kernel then ran on the _bc index arrays); ess_policy >= 0
 // additionally fuses ParOperator's fix-up y[ess] = x[ess] | 0 into it
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
-                          int ess_policy, const double *ye) {
+                          int ess_policy, const double *ye, const SplitIO *split) {
   const int n = masked ? so.n_shared_bc : so.n_shared;
   if (n == 0) return;
+  PA_REQUIRE(!split || !accumulate, "split vectors: y = A x only");
   hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
                      masked ? so.d_rcode_bc : so.d_rcode, reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
-                     masked ? so.d_rpos_bc : so.d_rpos, ye ? ye : so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1);
+                     masked ? so.d_rpos_bc : so.d_rpos, ye ? ye : so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1,
+                     split ? split->n_true : 0x7fffffff, split ? split->yg - split->n_true : nullptr);
   PA_HIP(hipGetLastError());
 }
 

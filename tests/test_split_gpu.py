@@ -1,0 +1,68 @@
+"""pa_op_mult_split: the local apply on split vectors (true dofs in the caller's x / y, ghosts read from one of two buffers
+chosen by a device-resident counter and written to their own array) -- what lets a multi-rank ParOperator::Mult run without
+L-vector copies (linalg/rap.cpp:195-234 does tx = x, lx = P tx, ly = A lx, y = P^T ly).  Against the plain apply on the
+concatenated vectors, bit for bit: the same kernels read and write the same numbers through two base pointers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from palace_amd import ceed  # noqa: E402
+from palace_amd.fem.fespace import NDHexSpace  # noqa: E402
+
+
+@pytest.mark.parametrize("kind", ["curl", "curlmass", "mass"])
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_split_apply_equals_plain_apply(cylinder_mesh, p, kind):
+    mesh = cylinder_mesh
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, 4)
+    mass = ceed.coefficient_context(3, attr_mat=[0] * int(mesh.attr.max()), mat_coeff=[np.array([2.08])])
+    ident = ceed.coefficient_context(3)
+    make = {"curl": lambda: ceed.curlcurl_operator(geom, nd, ident),
+            "curlmass": lambda: ceed.curlcurlmass_operator(geom, nd, mass, ident),
+            "mass": lambda: ceed.ndmass_operator(geom, nd, mass)}[kind]
+    n = nd.ndofs
+    rng = np.random.default_rng(p)
+    x = torch.from_numpy(rng.uniform(-1, 1, n)).cuda()
+    for n_true in (n, int(0.7 * n), 1):
+        ng = n - n_true
+        op = make()
+        assert op.supports_split()
+        ref = torch.empty_like(x)
+        op.mult(x, ref)
+        # the ghost input in the second of two buffers, the first one poisoned: the selector's parity must be honoured
+        xg0 = torch.full((max(ng, 1),), float("nan"), dtype=torch.float64, device="cuda")
+        xg1 = x[n_true:].clone() if ng else torch.zeros(1, dtype=torch.float64, device="cuda")
+        sel = torch.tensor([7], dtype=torch.int64, device="cuda")
+        y, yg = torch.empty(n_true, dtype=torch.float64, device="cuda"), torch.zeros(max(ng, 1), dtype=torch.float64, device="cuda")
+        op.mult_split(x[:n_true].clone(), xg0, y, yg, xg1=xg1, sel=sel)
+        assert torch.equal(y, ref[:n_true])
+        if ng:
+            assert torch.equal(yg, ref[n_true:])
+        # essential dofs among the true dofs: masked on input, rows fixed on output (policy 1: y = x, 0: y = 0)
+        ess = np.sort(rng.choice(n_true, size=max(1, n_true // 7), replace=False)).astype(np.int32)
+        op2 = make()
+        op2.set_essential(ess)
+        xm = x.clone()
+        xm[torch.from_numpy(ess.astype(np.int64)).cuda()] = 0.0
+        op.mult(xm, ref)
+        for policy in (1, 0):
+            want = ref.clone()
+            ie = torch.from_numpy(ess.astype(np.int64)).cuda()
+            want[ie] = x[ie] if policy else 0.0
+            xg = x[n_true:].clone() if ng else torch.zeros(1, dtype=torch.float64, device="cuda")
+            op2.mult_split(x[:n_true].clone(), xg, y, yg, ess_policy=policy)
+            assert torch.equal(y, want[:n_true]), (kind, p, n_true, policy)
+            if ng:
+                assert torch.equal(yg, want[n_true:])
+
+
+def test_split_apply_is_refused_where_there_is_no_such_form(cylinder_mesh):
+    nd = NDHexSpace(cylinder_mesh, 4)
+    op = ceed.curlcurl_operator(ceed.GeomFactorData(cylinder_mesh, 5), nd, ceed.coefficient_context(3))
+    assert not op.supports_split()
+    x = torch.zeros(nd.ndofs, dtype=torch.float64, device="cuda")
+    with pytest.raises(Exception, match="split"):
+        op.mult_split(x[:10].clone(), x[10:].clone(), torch.empty(10, dtype=torch.float64, device="cuda"), x[10:].clone())
