@@ -563,6 +563,29 @@ def main():
     ctx.set_random(x, 1 + rank)
     x.add_(1.0).mul_(0.5)  # uniform [0, 1)
     x[torch.from_numpy(prob.ess[-1].astype(np.int64)).cuda()] = 0.0
+    # multi-rank: which halo transport runs, and a cross-check of the two forms of the peer transport on the bench operator itself
+    # (direct form: the element kernel reads the neighbours' stores from the mailbox with plain loads; L-vector form: they are
+    # copied out with system-scope loads first -- the form the start-up self-test of the transport exercises).  A mismatch
+    # keeps the L-vector form for everything that follows and is reported in the line.
+    halo_info = None
+    if world > 1:
+        halo_info = {"transport": "peer (direct stores over IPC-mapped arenas)" if ctx.peer_ready() else "rccl send / receive groups",
+                     "direct_form": K.direct_form()}
+        if K.direct_form() == 1:
+            y2 = torch.empty_like(y)
+            K.mult(x, y)
+            K.set_direct(False)
+            K.mult(x, y2)
+            err = torch.tensor([float((y - y2).abs().max()), float(y2.abs().max())], dtype=torch.float64, device="cuda")
+            dist.all_reduce(err, op=dist.ReduceOp.MAX)
+            rel = float(err[0] / err[1]) if float(err[1]) > 0 else float("inf")
+            halo_info["direct_vs_lvector_rel_err"] = rel
+            if rel < 1e-13:
+                K.set_direct(True)
+            else:
+                os.environ["PALACE_AMD_HALO_DIRECT"] = "0"  # (read once per process: before any other ParOperator is made)
+                halo_info["direct_form"] = 0
+            del y2
     for _ in range(args.pre_warm):  # bring the clocks to their steady state (part of the set-up, not of the measurement)
         K.mult(x, y)
     torch.cuda.synchronize()
@@ -765,7 +788,7 @@ def main():
                        "scaling_mode": ("strong: one ~10M-dof cylinder cut into N equal z-slabs" if args.scaling == "strong"
                                         else "weak: one z-slab of the cylinder per GPU, same element count per GPU"),
                        "parallelism": f"element partition x{world}, RCCL halo (P / P^T) + allreduce dots"},
-            "pre_warm_steps": args.pre_warm, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "cpw": cpw, "tets_mfma": tets,
+            "pre_warm_steps": args.pre_warm, "halo": halo_info, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "cpw": cpw, "tets_mfma": tets,
             "setup_s": t_setup,
         }
         sys.stdout.flush()

@@ -94,6 +94,11 @@ int pa_par_op_create_assembled(pa_context *ctx, const pa_csr *csr, int n_true, c
                                int diag_policy, pa_halo *halo, pa_par_op **A);
 void pa_par_op_destroy(pa_par_op *A);
 int pa_par_op_mult(pa_par_op *A, const double *x, double *y);
+/* The direct form of a multi-rank Mult (peer transport + pa_op_mult_split: no L-vector copies).
+ * pa_par_op_direct_form: 1 in use, 0 available but switched off, -1 not available for this operator / transport.
+ * pa_par_op_set_direct(A, 0) selects the L-vector form (A / B runs, cross-checks of the two forms); (A, 1) back. */
+int pa_par_op_direct_form(const pa_par_op *A);
+int pa_par_op_set_direct(pa_par_op *A, int on);
 /* ParOperator::AddMult (rap.cpp:277-318): y += a (P^T A P with the essential-dof handling) x. */
 int pa_par_op_add_mult(pa_par_op *A, const double *x, double *y, double a);
 /* ParOperator::EliminateRHS (rap.cpp:56-82): b -= A_unconstrained x|ess ; b[ess] = x[ess] (DIAG_ONE) or 0. */

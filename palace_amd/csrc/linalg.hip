@@ -981,7 +981,8 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
   }
   // Peer transport and a local operator that applies to split vectors: no L-vector copies at all (Mult below).  The essential
   // list is fused into the operator's index tables as on one rank (unless another wrapper has fused a different one).
-  static const bool direct_env = !(std::getenv("PALACE_AMD_HALO_DIRECT") && std::getenv("PALACE_AMD_HALO_DIRECT")[0] == '0');
+  // (read at every construction: a driver that finds the two forms disagreeing switches the direct one off for what it builds next)
+  const bool direct_env = !(std::getenv("PALACE_AMD_HALO_DIRECT") && std::getenv("PALACE_AMD_HALO_DIRECT")[0] == '0');
   if (halo && direct_env && halo->DirectOk(n_true, n_local_)) {
     if (auto *c = dynamic_cast<const ceed::Operator *>(&A)) {
       if (c->SupportsSplit() && c->IsSymmetric()) {
@@ -992,7 +993,7 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
           ok = st >= 0;
           split_ess_ = ok;
         }
-        if (ok) A_split_ = c;
+        if (ok) A_split_ = A_split_avail_ = c;
       }
     }
   }

@@ -332,6 +332,7 @@ private:
   const ceed::Operator *A_fused_ = nullptr;  // single rank: BC masking fused into the local apply
   const ceed::Operator *A_overlap_ = nullptr;  // with a halo: interior elements run while the ghosts are exchanged
   const ceed::Operator *A_split_ = nullptr;    // peer transport: the local operator applies to split vectors (no L-vector copies)
+  const ceed::Operator *A_split_avail_ = nullptr;
   bool split_ess_ = false;                     // ... with this wrapper's essential list fused into its index tables
   const CsrOperator *A_csr_ = nullptr;       // single rank, assembled local operator: BCs eliminated in the matrix values
   double *d_csr_bc_ = nullptr;               // ... this wrapper's copy of them (CsrOperator::EliminatedValues)
@@ -352,6 +353,10 @@ public:
   int NumEssentialTrueDofs() const { return n_ess_; }
   const std::vector<int32_t> &GetEssentialTrueDofsHost() const { return ess_host_; }
   const Operator &LocalOperator() const { return *A_; }
+  // the direct form of the multi-rank Mult (no L-vector copies; peer transport + a local operator with a split-vector apply):
+  // 1 in use, 0 available but switched off, -1 not available.  SetDirect(false) selects the L-vector form (A / B, verification).
+  int DirectForm() const { return A_split_ ? 1 : (A_split_avail_ ? 0 : -1); }
+  void SetDirect(bool on) { A_split_ = on ? A_split_avail_ : nullptr, StreamGraph::Invalidate(); }
   bool FusesEssential() const { return A_fused_ != nullptr; }  // the essential list lives in the local operator's index tables
   DiagonalPolicy GetDiagonalPolicy() const { return policy_; }
   const Halo *GetHalo() const { return halo_; }

@@ -233,6 +233,13 @@ int pa_par_sum_op_create(pa_context *ctx, int nterms, pa_op *const *locals, cons
   });
 }
 void pa_par_op_destroy(pa_par_op *A) { delete A; }
+int pa_par_op_direct_form(const pa_par_op *A) { return (A && A->op) ? A->op->DirectForm() : -1; }
+int pa_par_op_set_direct(pa_par_op *A, int on) {
+  return guarded([&] {
+    PA_REQUIRE(A && A->op, "null argument");
+    A->op->SetDirect(on != 0);
+  });
+}
 int pa_par_op_mult(pa_par_op *A, const double *x, double *y) {
   return guarded([&] {
     Vector vx(const_cast<double *>(x), A->op->Width()), vy(y, A->op->Height());

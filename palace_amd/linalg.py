@@ -160,6 +160,10 @@ class Context:
         _lib.check(_L().pa_context_init_comm_peer(self.handle, 0, 1))
         self.rank, self.size = 0, 1
 
+    def peer_ready(self):
+        """True when halo exchanges and global sums run over the peer transport (arenas connected)."""
+        return bool(_L().pa_comm_peer_ready(self.handle))
+
     def peer_check(self):
         """Raises if a wait of the peer transport has timed out."""
         _lib.check(_L().pa_comm_peer_check(self.handle))
@@ -308,6 +312,13 @@ class Halo:
 
 class ParOperator:
     """palace::ParOperator (rap.cpp:154-234) on T-vectors."""
+
+    def direct_form(self):
+        """1: the multi-rank Mult runs without L-vector copies (peer transport + split-vector apply), 0: available, off, -1: n/a."""
+        return int(_L().pa_par_op_direct_form(self.handle))
+
+    def set_direct(self, on=True):
+        _lib.check(_L().pa_par_op_set_direct(self.handle, int(bool(on))))
 
     def __init__(self, ctx: Context, local: Operator, ess_tdofs, diag_policy=DIAG_ONE, n_true=None, halo=None):
         self.ctx, self.local, self.halo = ctx, local, halo

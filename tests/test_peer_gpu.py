@@ -28,7 +28,7 @@ def _worker(rank, world, port, out):
         ctx = linalg.Context()
         if world > 1:
             ctx.init_comm_peer_from_torch_distributed()
-        prob = SlabProblem(ctx, rank, world, 2, 0, shape=(2, 4 // world))
+        prob = SlabProblem(ctx, rank, world, 3, 0, shape=(2, 4 // world))  # (order 3: the four-point kernels, direct form)
         if world > 1:
             assert all(_lib.load().pa_halo_uses_peer(h.handle) for h in prob.halos)
         K, b, x = prob.pcg_gmg_solver(max_it=100, rel_tol=1e-8, hiptmair=True, coarse="cg")
@@ -43,6 +43,16 @@ def _worker(rank, world, port, out):
         dist.all_reduce(nt)
         res = dict(st, n=int(nt.item()), xx=ctx.dot(x, x), xAx=ctx.dot(x, y), bb=ctx.dot(b, b), bAb=ctx.dot(b, z))
         ctx.peer_check() if world > 1 else None
+        if world > 1:
+            # the two forms of the multi-rank Mult (direct: no L-vector copies, ghosts read from the mailbox; L-vector form) give
+            # the same bits: the same numbers are summed in the same order
+            assert A.direct_form() == 1
+            A.set_direct(False)
+            assert A.direct_form() == 0
+            z2 = torch.zeros_like(z)
+            A.mult(b, z2)
+            A.set_direct(True)
+            res["forms_equal"] = bool(torch.equal(z, z2))
         # the same solve again: the recorded iteration (HIP graph) replays across ranks
         x.zero_()
         K.mult(b, x)
@@ -67,6 +77,7 @@ def test_two_processes_on_one_gpu_match_one_rank():
     one, two = results[1], results[2]
     assert one["n"] == two["n"] and one["converged"] and two["converged"]
     assert abs(one["iterations"] - two["iterations"]) <= 1
+    assert two["forms_equal"]
     for k in ("bb", "bAb"):
         assert abs(one[k] - two[k]) < 1e-11 * abs(one[k]), (k, one[k], two[k])
     for k in ("xx", "xAx", "xx2"):
