@@ -6,7 +6,7 @@
 //     preconditioned basis Z stored (:795, :824-827);
 //   * the residual estimate from the Givens recursion, the restart logic and the exit conditions of the inner loop
 //     (`converged || j + 1 == max_dim || it + 1 == max_it`, :638-643);
-//   * plane rotations as LAPACK's d/zlartg (iterative.cpp:72-181).
+//   * plane rotations: LAPACK's d/zlartg (safe scaling; the reference restates the same routine, iterative.cpp:72-181).
 // The scalar type, the vectors and the operator applies come from an `Ops` policy (real: linalg.hip, complex:
 // complex.hip); nothing here touches the device directly.
 #pragma once
@@ -23,121 +23,89 @@
 namespace palace {
 namespace krylov {
 
-// ---- plane rotations (iterative.cpp:45-181) ----------------------------------------------------------------------
-inline double SafeMin() {
-  constexpr int fradix = std::numeric_limits<double>::radix;
-  constexpr int expm = std::numeric_limits<double>::min_exponent, expM = std::numeric_limits<double>::max_exponent;
-  return std::max(std::pow((double)fradix, (double)(expm - 1)), std::pow((double)fradix, (double)(1 - expM)));
-}
-inline double SafeMax() {
-  constexpr int fradix = std::numeric_limits<double>::radix;
-  constexpr int expm = std::numeric_limits<double>::min_exponent, expM = std::numeric_limits<double>::max_exponent;
-  return std::min(std::pow((double)fradix, (double)(1 - expm)), std::pow((double)fradix, (double)(expM - 1)));
+// ---- plane rotations -------------------------------------------------------------------------------------------------
+// LAPACK's safe-scaling Givens rotation, la_lartg (LAPACK >= 3.10, SRC/dlartg.f90 / zlartg.f90; E. Anderson, "Algorithm 978: Safe
+// scaling in the level 1 BLAS", ACM TOMS 44 (2017)) -- what the reference's GeneratePlaneRotation restates as well
+// (linalg/iterative.cpp:45-181), so the Hessenberg recursion and with it the residual history agree to the last bit.  Written
+// here once for both scalar types: f and g are brought into the range where |.|^2 neither over- nor underflows by a power-of-two
+// independent scaling (u for both, a second one v for a much smaller f, undone by w = v / u), after which ONE set of formulas
+// applies; without scaling u = w = 1 and the formulas are LAPACK's unscaled branch literally.
+struct LartgRange {
+  double tiny, huge;  // LAPACK's safmin / safmax: the smallest number whose reciprocal does not overflow, and that reciprocal
+  LartgRange() {
+    using lim = std::numeric_limits<double>;
+    tiny = std::max(std::ldexp(1.0, lim::min_exponent - 1), std::ldexp(1.0, 1 - lim::max_exponent));
+    huge = std::min(std::ldexp(1.0, 1 - lim::min_exponent), std::ldexp(1.0, lim::max_exponent - 1));
+  }
+  double Clamp(double a) const { return std::min(huge, std::max(tiny, a)); }
+};
+inline double MaxPart(double z) { return std::abs(z); }
+inline double MaxPart(const std::complex<double> &z) { return std::max(std::abs(z.real()), std::abs(z.imag())); }
+inline double SumSquares(double z) { return z * z; }
+inline double SumSquares(const std::complex<double> &z) { return z.real() * z.real() + z.imag() * z.imag(); }
+
+// [ c  s; -conj(s)  c ] [f; g] = [r; 0] with c real
+inline void GeneratePlaneRotation(const double f, const double g, double &c, double &s) {
+  static const LartgRange R;
+  if (g == 0.0) {
+    c = 1.0, s = 0.0;
+    return;
+  }
+  if (f == 0.0) {
+    c = 0.0, s = std::copysign(1.0, g);
+    return;
+  }
+  const double lo = std::sqrt(R.tiny), hi = std::sqrt(R.huge / 2), af = std::abs(f), ag = std::abs(g);
+  const bool safe = af > lo && af < hi && ag > lo && ag < hi;
+  const double u = safe ? 1.0 : R.Clamp(std::max(af, ag));
+  const double fs = safe ? f : f / u, gs = safe ? g : g / u;
+  const double h = std::sqrt(fs * fs + gs * gs);
+  c = std::abs(fs) / h;
+  s = gs / std::copysign(h, f);
 }
 
-inline void GeneratePlaneRotation(const double dx, const double dy, double &cs, double &sn) {
-  const double safmin = SafeMin(), safmax = SafeMax();
-  const double root_min = std::sqrt(safmin), root_max = std::sqrt(safmax / 2);
-  if (dy == 0.0) {
-    cs = 1.0, sn = 0.0;
+inline void GeneratePlaneRotation(const std::complex<double> f, const std::complex<double> g, double &c, std::complex<double> &s) {
+  static const LartgRange R;
+  if (g == 0.0) {
+    c = 1.0, s = 0.0;
     return;
   }
-  if (dx == 0.0) {
-    cs = 0.0, sn = std::copysign(1.0, dy);
-    return;
-  }
-  const double dx1 = std::abs(dx), dy1 = std::abs(dy);
-  if (dx1 > root_min && dx1 < root_max && dy1 > root_min && dy1 < root_max) {
-    const double d = std::sqrt(dx * dx + dy * dy);
-    cs = dx1 / d;
-    sn = dy / std::copysign(d, dx);
-  } else {
-    const double u = std::min(safmax, std::max(safmin, std::max(dx1, dy1)));
-    const double dxs = dx / u, dys = dy / u;
-    const double d = std::sqrt(dxs * dxs + dys * dys);
-    cs = std::abs(dxs) / d;
-    sn = dys / std::copysign(d, dx);
-  }
-}
-
-inline void GeneratePlaneRotation(const std::complex<double> dx, const std::complex<double> dy, double &cs,
-                                  std::complex<double> &sn) {
-  // [ cs  sn; -conj(sn)  cs ] [dx; dy] = [r; 0], cs real (zlartg)
-  using T = double;
-  const T safmin = SafeMin(), safmax = SafeMax();
-  if (dy == 0.0) {
-    cs = 1.0, sn = 0.0;
-    return;
-  }
-  if (dx == 0.0) {
-    cs = 0.0;
-    if (dy.real() == 0.0) {
-      sn = std::conj(dy) / std::abs(dy.imag());
-    } else if (dy.imag() == 0.0) {
-      sn = std::conj(dy) / std::abs(dy.real());
+  const double lo = std::sqrt(R.tiny), ag = MaxPart(g);
+  if (f == 0.0) {  // r = |g|: only the modulus of g is needed, computed without overflow
+    c = 0.0;
+    if (g.real() == 0.0 || g.imag() == 0.0) {
+      s = std::conj(g) / ag;
     } else {
-      const T root_min = std::sqrt(safmin), root_max = std::sqrt(safmax / 2);
-      const T dy1 = std::max(std::abs(dy.real()), std::abs(dy.imag()));
-      if (dy1 > root_min && dy1 < root_max) {
-        sn = std::conj(dy) / std::sqrt(dy.real() * dy.real() + dy.imag() * dy.imag());
-      } else {
-        const T u = std::min(safmax, std::max(safmin, dy1));
-        const std::complex<T> dys = dy / u;
-        sn = std::conj(dys) / std::sqrt(dys.real() * dys.real() + dys.imag() * dys.imag());
-      }
+      const double hi = std::sqrt(R.huge / 2);
+      const std::complex<double> gs = (ag > lo && ag < hi) ? g : g / R.Clamp(ag);
+      s = std::conj(gs) / std::sqrt(SumSquares(gs));
     }
     return;
   }
-  const T root_min = std::sqrt(safmin), root_max = std::sqrt(safmax / 4);
-  const T dx1 = std::max(std::abs(dx.real()), std::abs(dx.imag()));
-  const T dy1 = std::max(std::abs(dy.real()), std::abs(dy.imag()));
-  if (dx1 > root_min && dx1 < root_max && dy1 > root_min && dy1 < root_max) {
-    const T dx2 = dx.real() * dx.real() + dx.imag() * dx.imag();
-    const T dy2 = dy.real() * dy.real() + dy.imag() * dy.imag();
-    const T dz2 = dx2 + dy2;
-    if (dx2 >= dz2 * safmin) {
-      cs = std::sqrt(dx2 / dz2);
-      if (dx2 > root_min && dz2 < root_max * 2)
-        sn = std::conj(dy) * (dx / std::sqrt(dx2 * dz2));
-      else
-        sn = std::conj(dy) * ((dx / cs) / dz2);
+  const double hi = std::sqrt(R.huge / 4), af = MaxPart(f);
+  std::complex<double> fs = f, gs = g;
+  double w = 1.0;
+  bool rescaled_f = false;
+  if (!(af > lo && af < hi && ag > lo && ag < hi)) {
+    const double u = R.Clamp(std::max(af, ag));
+    gs = g / u;
+    if (af / u < lo) {  // f much smaller than g: its own scaling, undone in c at the end
+      const double v = R.Clamp(af);
+      w = v / u, fs = f / v, rescaled_f = true;
     } else {
-      const T d = std::sqrt(dx2 * dz2);
-      cs = dx2 / d;
-      sn = std::conj(dy) * (dx / d);
+      fs = f / u;
     }
-  } else {
-    const T u = std::min(safmax, std::max(safmin, std::max(dx1, dy1)));
-    T w;
-    const std::complex<T> dys = dy / u;
-    std::complex<T> dxs;
-    const T dy2 = dys.real() * dys.real() + dys.imag() * dys.imag();
-    T dx2, dz2;
-    if (dx1 / u < root_min) {
-      const T v = std::min(safmax, std::max(safmin, dx1));
-      w = v / u;
-      dxs = dx / v;
-      dx2 = dxs.real() * dxs.real() + dxs.imag() * dxs.imag();
-      dz2 = dx2 * w * w + dy2;
-    } else {
-      w = 1.0;
-      dxs = dx / u;
-      dx2 = dxs.real() * dxs.real() + dxs.imag() * dxs.imag();
-      dz2 = dx2 + dy2;
-    }
-    if (dx2 >= dz2 * safmin) {
-      cs = std::sqrt(dx2 / dz2);
-      if (dx2 > root_min && dz2 < root_max * 2)
-        sn = std::conj(dys) * (dxs / std::sqrt(dx2 * dz2));
-      else
-        sn = std::conj(dys) * ((dxs / cs) / dz2);
-    } else {
-      const T d = std::sqrt(dx2 * dz2);
-      cs = dx2 / d;
-      sn = std::conj(dys) * (dxs / d);
-    }
-    cs *= w;
   }
+  const double f2 = SumSquares(fs), g2 = SumSquares(gs), h2 = rescaled_f ? f2 * w * w + g2 : f2 + g2;
+  if (f2 >= h2 * R.tiny) {
+    c = std::sqrt(f2 / h2);
+    s = std::conj(gs) * ((f2 > lo && h2 < hi * 2) ? fs / std::sqrt(f2 * h2) : (fs / c) / h2);
+  } else {  // c would underflow through f2 / h2
+    const double d = std::sqrt(f2 * h2);
+    c = f2 / d;
+    s = std::conj(gs) * (fs / d);
+  }
+  c *= w;
 }
 
 inline void ApplyPlaneRotation(double &dx, double &dy, const double cs, const double sn) {

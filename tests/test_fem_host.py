@@ -135,3 +135,15 @@ def test_smoothed_aggregation_setup(dumped):
         assert sizes[1] < 0.5 * sizes[0] and all(b < 0.7 * a for a, b in zip(sizes, sizes[1:]))  # (line aggregates: 1/3 per level)
         f = dumped[key]
         assert f.max() < 0.65 and np.exp(np.log(f[3:]).mean()) < 0.5, (key, f)  # stationary V(2,2), damped Jacobi
+
+
+def test_plane_rotations_over_the_whole_exponent_range(tmp_path):
+    """krylov_impl.hpp's GeneratePlaneRotation (LAPACK d/zlartg, safe scaling) in tests/cpu/rotation_check.cpp: host code only."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "rotation_check")
+    subprocess.check_call([hipcc, "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpu", "rotation_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "worst deviation" in out.stdout, out.stdout + out.stderr
