@@ -363,8 +363,8 @@ int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_po
  * (palace_amd/csrc/comm.hpp) -- and written to yg.  ess_policy >= 0: the essential list of pa_op_set_essential (true dofs) is
  * masked on input and the rows are fixed on output as in pa_op_mult_essential_diag (1: y = x there, 0: y = 0); < 0: plain.
  * What the reference does with three copies around CeedOperatorApplyAdd (linalg/rap.cpp:195-234: tx = x, lx = P tx, ly = A lx,
- * y = P^T ly) when P is a halo exchange.  pa_op_supports_split: 1 for a single H(curl) hexahedral block on the four-point
- * streaming kernel (orders 1-3), 0 otherwise (the caller keeps the L-vector path). */
+ * y = P^T ly) when P is a halo exchange.  pa_op_supports_split: 1 for a single H(curl) hexahedral block on the
+ * streaming kernels (four or five points per direction: orders 1-4), 0 otherwise (the caller keeps the L-vector path). */
 int pa_op_supports_split(const pa_op *op);
 int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y,
                      double *yg, int n_true, int ess_policy, void *stream);

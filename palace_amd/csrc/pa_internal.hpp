@@ -297,7 +297,8 @@ void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool mask
                           const SplitIO *split = nullptr);
 void stream_set_interface(SubOp &so, const std::vector<char> &flag);
 bool nd_hex_stream5_ok(const SubOp &so);
-void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase);
+void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase,
+                           const SplitIO *split = nullptr);
 void launch_nd_hex_stream5_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
                                    double *ye_i, bool masked, hipStream_t s);
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,

@@ -681,13 +681,12 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   }
 }
 
-bool nd_hex_stream_split_ok(const SubOp &so) { return so.fe_type == PA_FE_HCURL && so.q1d == 4 && so.d_idxc && !wide_form(so); }
+bool nd_hex_stream_split_ok(const SubOp &so) {
+  return so.fe_type == PA_FE_HCURL && so.d_idxc && (so.q1d == 4 || (wide_form(so) && nd_hex_stream5_ok(so)));
+}
 
 void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
-  if (wide_form(so)) {
-    PA_REQUIRE(!split, "no split-vector form of the five-point kernel");
-    return launch_nd_hex_stream5(so, x, y, masked, s, phase);
-  }
+  if (wide_form(so)) return launch_nd_hex_stream5(so, x, y, masked, s, phase, split);
   switch (so.p) {
     case 1: launch_p<1>(so, x, y, masked, s, phase, split); break;
     case 2: launch_p<2>(so, x, y, masked, s, phase, split); break;

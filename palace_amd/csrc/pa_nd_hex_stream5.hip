@@ -31,6 +31,12 @@ struct NDStream5Args {
   const double *coef1;    // complex form: the same of the imaginary-part operator
   const double *x, *x1;   // (x1, y1, ye1: the imaginary part of the complex form)
   double *y, *ye, *y1, *ye1;
+  // split vectors (SPLIT; NDStreamArgs in pa_nd_hex_stream.hip): ghosts [nsplit, lsize) read from xg0 | xg1 (parity of *xg_sel),
+  // written to yg; the three pointers are stored shifted by -nsplit
+  int nsplit;
+  const double *xg0, *xg1;
+  const unsigned long long *xg_sel;
+  double *yg;
   NDTab<P1, 5> tab;
 };
 
@@ -40,9 +46,10 @@ struct NDStream5Args {
 // 3.1c, carried over): ONE element per wave, its two 32-lane halves hold the real and the imaginary part of x / y; both read
 // the same index block and q-data, the parts meet at the D stage (the coefficients are per-element scalars in the metric
 // form: the half's own values times the real coefficient -/+ the other half's times the imaginary one).
-template <int P1, bool USE_U, bool USE_C, bool METRIC, int GPOS, int QPOS, bool CPLX = false>
+template <int P1, bool USE_U, bool USE_C, bool METRIC, int GPOS, int QPOS, bool CPLX = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(const NDStream5Args<P1> a) {
   static_assert(!CPLX || (USE_U && USE_C && METRIC), "the complex form is the metric curl-curl + mass kernel");
+  static_assert(!(CPLX && SPLIT), "no split-vector form of the complex kernel");
   constexpr int Q1 = 5;
   using L = NDLayoutInPlace<P1, Q1>;  // (LDS limits the resident waves here)
   using streamhost::kWideEss;
@@ -75,6 +82,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
 
   // index block and slot words of a batch (arrays padded to whole batches; pad entries read as zero)
   const double *xsel = (CPLX && (lane >> 5)) ? a.x1 : a.x;  // the part of x this half gathers
+  const double *xgh = nullptr;  // SPLIT: where the ghost entries are read (shifted: indexed with the local dof)
+  if (SPLIT) xgh = ((a.xg_sel ? *a.xg_sel : 0ull) & 1ull) ? a.xg1 : a.xg0;
   auto load_idx = [&](const int bb, const int sub, const int t, unsigned (&w)[2], unsigned (&p)[NPK]) {
     const int e = CPLX ? bb : bb * 2 + sub;
     const uint32_t *ic = a.idxw + (size_t)e * kWideWords;
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
     for (int r = 0; r < NPL; r++) {
       int dof = decode(stab, r, t);
       if (!(32 * r + 31 < PP) && t + 32 * r >= PP) dof = 0;  // lanes past the last entry
-      xv[r] = xsel[dof];
+      xv[r] = SPLIT ? (dof < a.nsplit ? xsel : xgh)[dof] : xsel[dof];
     }
   };
   auto settle = [&](unsigned (&p)[NPK]) {
@@ -299,7 +308,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
       const double v = stg[h & kWideSlotMask];
       int d = decode(stab_cur, mr, mt);
       asm volatile("" : "+v"(d));  // (decoded unconditionally: sunk into a branch otherwise, and the stores stop being counted)
-      double *dst = (h & kWideExcl) ? ((CPLX && sub) ? a.y1 : a.y) + d : ((CPLX && sub) ? a.ye1 : a.ye) + ((size_t)e * PP + m);
+      double *yd = (CPLX && sub) ? a.y1 : a.y;
+      if (SPLIT) yd = d < a.nsplit ? a.y : a.yg;
+      double *dst = (h & kWideExcl) ? yd + d : ((CPLX && sub) ? a.ye1 : a.ye) + ((size_t)e * PP + m);
       *dst = (h & kWideFlip) ? -v : v;
     }
     wave_sync();  // the LDS strip is reused by the next batch
@@ -331,7 +342,7 @@ static int device_cus5() {
   return cus;
 }
 
-template <int P1, bool U, bool C, bool METRIC, int GPOS, int QPOS, bool CPLX = false>
+template <int P1, bool U, bool C, bool METRIC, int GPOS, int QPOS, bool CPLX = false, bool SPLIT = false>
 static void launch5_gpos(const SubOp &so, NDStream5Args<P1> &a, hipStream_t s) {
   using L = NDLayoutInPlace<P1, 5>;
   for (int i = 0; i < HalfTab<P1, 5>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
@@ -343,7 +354,7 @@ static void launch5_gpos(const SubOp &so, NDStream5Args<P1> &a, hipStream_t s) {
   // (with a fixed stride a workgroup that had to queue would run after the others and double the time)
   static const int per_cu_query = [&] {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream5_kernel<P1, U, C, METRIC, GPOS, QPOS, CPLX>, 64 * kWavesPerBlock, lds) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream5_kernel<P1, U, C, METRIC, GPOS, QPOS, CPLX, SPLIT>, 64 * kWavesPerBlock, lds) !=
             hipSuccess || nb <= 0)
       nb = 4;
     return std::min({nb, (int)(160 * 1024 / lds), 8});
@@ -356,7 +367,7 @@ static void launch5_gpos(const SubOp &so, NDStream5Args<P1> &a, hipStream_t s) {
   int wgx = std::max(1, std::min(per_xcd, (a.chunk + kWavesPerBlock - 1) / kWavesPerBlock));
   // PALACE_AMD_STREAM_WGX caps the workgroups per XCD (tests: many batches per wave on a small mesh)
   if (const char *cap = getenv("PALACE_AMD_STREAM_WGX")) wgx = std::max(1, std::min(wgx, atoi(cap)));
-  hipLaunchKernelGGL((nd_hex_stream5_kernel<P1, U, C, METRIC, GPOS, QPOS, CPLX>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
+  hipLaunchKernelGGL((nd_hex_stream5_kernel<P1, U, C, METRIC, GPOS, QPOS, CPLX, SPLIT>), dim3(8 * wgx), dim3(64 * kWavesPerBlock), lds, s, a);
   PA_HIP(hipGetLastError());
 }
 
@@ -364,6 +375,12 @@ template <int P1, bool U, bool C, bool METRIC>
 static void launch5_variant(const SubOp &so, NDStream5Args<P1> &a, hipStream_t s) {
   auto env = [](const char *name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; };
   const int gpos = env("PALACE_AMD_STREAM5_GPOS", U ? 2 : 1);
+  if (a.nsplit >= 0) {  // split vectors: the default positions only
+    if constexpr (P1 == 4)
+      return launch5_gpos<P1, U, C, METRIC, (U ? 2 : 1), ((U && C) ? 2 : 0), false, true>(so, a, s);
+    else
+      return launch5_gpos<P1, U, C, METRIC, (U ? 2 : 1), 0, false, true>(so, a, s);
+  }
   if constexpr (P1 == 4) {  // A/B switches of the order-4 kernels (scripts/time_p4.py)
     const int qpos = env("PALACE_AMD_STREAM5_QPOS", (U && C) ? 2 : 0);
 #define PA_S5_LAUNCH(G, Q) launch5_gpos<P1, U, C, METRIC, G, Q>(so, a, s)
@@ -378,8 +395,15 @@ static void launch5_variant(const SubOp &so, NDStream5Args<P1> &a, hipStream_t s
 }
 
 template <int P1>
-static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase) {
+static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
   NDStream5Args<P1> a;
+  a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
+  if (split) {
+    PA_REQUIRE(split->n_true >= 0 && split->n_true <= so.lsize, "split point outside the local vector");
+    a.nsplit = split->n_true;
+    a.xg0 = split->xg0 - split->n_true, a.xg1 = (split->xg1 ? split->xg1 : split->xg0) - split->n_true;
+    a.xg_sel = split->sel, a.yg = split->yg - split->n_true;
+  }
   a.ne = so.ne;
   a.blist = nullptr, a.nbatch = 0;
   if (phase >= 0) {
@@ -409,12 +433,12 @@ static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, 
   }
 }
 
-void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase) {
+void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
   switch (so.p) {
-    case 1: launch5_p<1>(so, x, y, masked, s, phase); break;
-    case 2: launch5_p<2>(so, x, y, masked, s, phase); break;
-    case 3: launch5_p<3>(so, x, y, masked, s, phase); break;
-    case 4: launch5_p<4>(so, x, y, masked, s, phase); break;
+    case 1: launch5_p<1>(so, x, y, masked, s, phase, split); break;
+    case 2: launch5_p<2>(so, x, y, masked, s, phase, split); break;
+    case 3: launch5_p<3>(so, x, y, masked, s, phase, split); break;
+    case 4: launch5_p<4>(so, x, y, masked, s, phase, split); break;
     default: throw Error("no five-point streaming H(curl) hex kernel for this order");
   }
 }
@@ -428,6 +452,7 @@ static void launch5_complex_p(const SubOp &sr, const SubOp &si, const double *xr
   a.qdata = sr.qd->d;
   a.coef = sr.d_coef_s, a.coef1 = si.d_coef_s;
   a.x = xr, a.x1 = xi, a.y = yr, a.y1 = yi, a.ye = sr.d_ye, a.ye1 = ye_i;
+  a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
   if constexpr (P1 == 4)
     launch5_gpos<P1, true, true, true, 2, 2, true>(sr, a, s);
   else

@@ -13,11 +13,12 @@ from palace_amd.fem.fespace import NDHexSpace  # noqa: E402
 
 
 @pytest.mark.parametrize("kind", ["curl", "curlmass", "mass"])
-@pytest.mark.parametrize("p", [1, 2, 3])
-def test_split_apply_equals_plain_apply(cylinder_mesh, p, kind):
+@pytest.mark.parametrize("p,q1d", [(1, 4), (2, 4), (3, 4), (4, 5), (2, 5)])
+def test_split_apply_equals_plain_apply(cylinder_mesh, p, q1d, kind):
+    """Four-point kernels (orders 1-3) and the five-point ones (order 4 and a coarsened level of an order-4 problem)."""
     mesh = cylinder_mesh
     nd = NDHexSpace(mesh, p)
-    geom = ceed.GeomFactorData(mesh, 4)
+    geom = ceed.GeomFactorData(mesh, q1d)
     mass = ceed.coefficient_context(3, attr_mat=[0] * int(mesh.attr.max()), mat_coeff=[np.array([2.08])])
     ident = ceed.coefficient_context(3)
     make = {"curl": lambda: ceed.curlcurl_operator(geom, nd, ident),
@@ -60,8 +61,10 @@ def test_split_apply_equals_plain_apply(cylinder_mesh, p, kind):
 
 
 def test_split_apply_is_refused_where_there_is_no_such_form(cylinder_mesh):
-    nd = NDHexSpace(cylinder_mesh, 4)
-    op = ceed.curlcurl_operator(ceed.GeomFactorData(cylinder_mesh, 5), nd, ceed.coefficient_context(3))
+    from palace_amd.fem.fespace import H1HexSpace
+
+    nd = H1HexSpace(cylinder_mesh, 2)
+    op = ceed.diffusion_operator(ceed.GeomFactorData(cylinder_mesh, 3), nd, ceed.coefficient_context(3))
     assert not op.supports_split()
     x = torch.zeros(nd.ndofs, dtype=torch.float64, device="cuda")
     with pytest.raises(Exception, match="split"):
