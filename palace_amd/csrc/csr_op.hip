@@ -29,6 +29,30 @@ __global__ __launch_bounds__(256) void k_csr_spmv(const int n, const int32_t *__
   if (row < n && l == 0) y[row] = add ? y[row] + a * s : a * s;
 }
 
+// the same on split vectors (multi-rank applies without L-vector copies): rows / columns [0, nsplit) live in y / x,
+// the ghosts behind them in yg / one of two ghost buffers (parity of the device-resident counter *sel); xg*, yg shifted by -nsplit
+template <int LPR>
+__global__ __launch_bounds__(256) void k_csr_spmv_split(const int n, const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                        const double *__restrict__ x, const double *__restrict__ xg0,
+                                                        const double *__restrict__ xg1, const unsigned long long *__restrict__ sel,
+                                                        double *__restrict__ y, double *__restrict__ yg, const int nsplit) {
+  const int row = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPR);
+  const int l = threadIdx.x % LPR;
+  const double *xg = ((sel ? *sel : 0ull) & 1ull) ? xg1 : xg0;
+  double s = 0.0;
+  if (row < n) {
+    const int32_t b = rowptr[row], e = rowptr[row + 1];
+    for (int32_t k = b + l; k < e; k += LPR) {
+      const int c = col[k];
+      s += val[k] * (c < nsplit ? x : xg)[c];
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LPR);
+  if (row < n && l == 0) (row < nsplit ? y : yg)[row] = s;
+}
+
 // ParOperator's essential-dof handling applied to the matrix once (what the reference's ParallelAssemble does through
 // EliminateBC, linalg/rap.cpp:131-149): rows and columns of essential dofs are zeroed, their diagonal is 1 or 0
 __global__ void k_csr_eliminate(const int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -83,6 +107,28 @@ double *CsrOperator::EliminatedValues(const int32_t *d_ess, int n_ess, bool diag
 }
 
 void CsrOperator::MultValues(const double *d_vals, const Vector &x, Vector &y) const { Apply(d_vals, x, y, 1.0, false); }
+
+void CsrOperator::MultSplit(const double *d_vals, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel,
+                            double *y, double *yg, int n_true) const {
+  PA_REQUIRE(height == width && n_true >= 0 && n_true <= height, "split apply of a square assembled operator");
+  if (!height) return;
+  const double *vals = d_vals ? d_vals : m_->d_val;
+  const long long threads = (long long)height * lanes_;
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  const double *g0 = xg0 - n_true, *g1 = (xg1 ? xg1 : xg0) - n_true;
+  double *go = yg - n_true;
+#define PA_CSR_SPLIT(L)                                                                                                   \
+  hipLaunchKernelGGL(k_csr_spmv_split<L>, grid, block, 0, ctx_->stream, height, m_->d_rowptr, m_->d_col, vals, x, g0, g1, sel, y, go, \
+                     n_true)
+  if (lanes_ == 16)
+    PA_CSR_SPLIT(16);
+  else if (lanes_ == 8)
+    PA_CSR_SPLIT(8);
+  else
+    PA_CSR_SPLIT(4);
+#undef PA_CSR_SPLIT
+  PA_HIP(hipGetLastError());
+}
 
 void CsrOperator::Apply(const double *vals, const Vector &x, Vector &y, double a, bool add) const {
   PA_REQUIRE(x.Size() == width && y.Size() == height, "size mismatch in CsrOperator");

@@ -995,6 +995,10 @@ ParOperator::ParOperator(const Context &ctx, const Operator &A, int n_true, cons
         }
         if (ok) A_split_ = A_split_avail_ = c;
       }
+    } else if (auto *m = dynamic_cast<const CsrOperator *>(&A)) {
+      // assembled local operator: this wrapper's essential rows / columns folded into its own copy of the values
+      d_csr_bc_ = m->EliminatedValues(d_ess_, n_ess, policy == DiagonalPolicy::DIAG_ONE);
+      if (d_csr_bc_) A_csr_split_ = A_csr_split_avail_ = m;
     }
   }
   if (halo && (n_ess || halo->UsesPeerTransport())) {
@@ -1054,6 +1058,13 @@ void ParOperator::Mult(const Vector &x, Vector &y) const {
     halo_->SendDirect(x.Data(), d_ess_mask_, c.stream);
     A_split_->MultSplit(x.Data(), halo_->GhostIn(0), halo_->GhostIn(1), halo_->GhostInSelector(), y.Data(), halo_->GhostOut(),
                         n_true_, split_ess_ ? (policy_ == DiagonalPolicy::DIAG_ONE ? 1 : 0) : -1);
+    halo_->RestrictAddDirect(d_ess_mask_, y.Data(), c.stream);
+    return;
+  }
+  if (A_csr_split_ && d_ess_mask_ && x.Data() != y.Data()) {  // the same with an assembled local operator
+    halo_->SendDirect(x.Data(), d_ess_mask_, c.stream);
+    A_csr_split_->MultSplit(d_csr_bc_, x.Data(), halo_->GhostIn(0), halo_->GhostIn(1), halo_->GhostInSelector(), y.Data(),
+                            halo_->GhostOut(), n_true_);
     halo_->RestrictAddDirect(d_ess_mask_, y.Data(), c.stream);
     return;
   }

@@ -311,6 +311,10 @@ public:
   // and this operator itself always applies the unconstrained values.
   double *EliminatedValues(const int32_t *d_ess, int n_ess, bool diag_one) const;
   void MultValues(const double *d_vals, const Vector &x, Vector &y) const;  // y = A' x, A' = this pattern with `d_vals`
+  // the same on split vectors (pa_op_mult_split's contract: true dofs in x / y, ghosts read from xg0 | xg1 by the parity of *sel
+  // and written to yg); d_vals == nullptr: the unconstrained values
+  void MultSplit(const double *d_vals, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y,
+                 double *yg, int n_true) const;
   void Mult(const Vector &x, Vector &y) const override;
   void MultTranspose(const Vector &x, Vector &y) const override;  // symmetric matrices only (pa_csr::symmetric)
   void AddMult(const Vector &x, Vector &y, double a = 1.0) const override;
@@ -333,6 +337,7 @@ private:
   const ceed::Operator *A_overlap_ = nullptr;  // with a halo: interior elements run while the ghosts are exchanged
   const ceed::Operator *A_split_ = nullptr;    // peer transport: the local operator applies to split vectors (no L-vector copies)
   const ceed::Operator *A_split_avail_ = nullptr;
+  const CsrOperator *A_csr_split_ = nullptr, *A_csr_split_avail_ = nullptr;  // the same for an assembled local operator
   bool split_ess_ = false;                     // ... with this wrapper's essential list fused into its index tables
   const CsrOperator *A_csr_ = nullptr;       // single rank, assembled local operator: BCs eliminated in the matrix values
   double *d_csr_bc_ = nullptr;               // ... this wrapper's copy of them (CsrOperator::EliminatedValues)
@@ -355,8 +360,11 @@ public:
   const Operator &LocalOperator() const { return *A_; }
   // the direct form of the multi-rank Mult (no L-vector copies; peer transport + a local operator with a split-vector apply):
   // 1 in use, 0 available but switched off, -1 not available.  SetDirect(false) selects the L-vector form (A / B, verification).
-  int DirectForm() const { return A_split_ ? 1 : (A_split_avail_ ? 0 : -1); }
-  void SetDirect(bool on) { A_split_ = on ? A_split_avail_ : nullptr, StreamGraph::Invalidate(); }
+  int DirectForm() const { return (A_split_ || A_csr_split_) ? 1 : ((A_split_avail_ || A_csr_split_avail_) ? 0 : -1); }
+  void SetDirect(bool on) {
+    A_split_ = on ? A_split_avail_ : nullptr, A_csr_split_ = on ? A_csr_split_avail_ : nullptr;
+    StreamGraph::Invalidate();
+  }
   bool FusesEssential() const { return A_fused_ != nullptr; }  // the essential list lives in the local operator's index tables
   DiagonalPolicy GetDiagonalPolicy() const { return policy_; }
   const Halo *GetHalo() const { return halo_; }

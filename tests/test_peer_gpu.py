@@ -53,6 +53,17 @@ def _worker(rank, world, port, out):
             A.mult(b, z2)
             A.set_direct(True)
             res["forms_equal"] = bool(torch.equal(z, z2))
+            # the assembled coarsest level (CSR product on split vectors)
+            A0 = prob._keep[-1][1][0]
+            assert A0.direct_form() == 1
+            n0 = prob.n_true[0]
+            v = torch.rand(n0, dtype=torch.float64, device="cuda")
+            w1, w2 = torch.zeros_like(v), torch.zeros_like(v)
+            A0.mult(v, w1)
+            A0.set_direct(False)
+            A0.mult(v, w2)
+            A0.set_direct(True)
+            res["forms_equal"] = res["forms_equal"] and bool(torch.allclose(w1, w2, rtol=1e-14, atol=1e-14 * float(w2.abs().max())))
         # the same solve again: the recorded iteration (HIP graph) replays across ranks
         x.zero_()
         K.mult(b, x)
