@@ -357,6 +357,27 @@ struct OpChebStep {
   }
   uintptr_t align() const { return bits(di) | bits(t) | bits(r) | bits(d) | bits(y); }
 };
+// the same step written for the accumulated correction e_k = d_0 + ... + d_{k-1} (so d_{k-1} = e_k - e_{k-1} and r_k = r_0 - A e_k):
+//   out (+)= e_k + sd (e_k - e_{k-1}) + sr dinv .* (r_0 - t),  t = A e_k
+// r_0 is only read (it can be the caller's right-hand side itself), y is touched once, at the last step: 48 instead of 64 bytes
+// per entry and step.  ep == nullptr: e_{k-1} = 0 (the first step).  `out` may be the buffer of e_{k-1}.
+struct OpChebStep3 {
+  double sd, sr;
+  const double *di, *t, *r0, *ek, *ep;
+  double *out;
+  int add;
+  template <class T>
+  __device__ void at(long long i) const {
+    const T e = as<T>(ek)[i], dinv = as<T>(di)[i], rv = as<T>(r0)[i] - as<T>(t)[i];
+    T dk = sr * dinv * rv;
+    if (ep) dk += sd * (e - as<T>(ep)[i]);
+    else dk += sd * e;
+    T v = e + dk;
+    if (add) v += as<T>(out)[i];
+    as<T>(out)[i] = v;
+  }
+  uintptr_t align() const { return bits(di) | bits(t) | bits(r0) | bits(ek) | bits(ep) | bits(out); }
+};
 __device__ __forceinline__ double vsqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ d2 vsqrt(d2 v) { return d2{sqrt(v.x), sqrt(v.y)}; }
 // x = sqrt(s x)   (linalg::Sqrt, vector.cpp:774-781)
@@ -779,6 +800,11 @@ void ChebyOrder0(const Context &c, double sr, const Vector &dinv, const Vector &
 void ChebyStep(const Context &c, double sd, double sr, const Vector &dinv, const Vector &t, Vector &r, Vector &d,
                Vector &y) {
   launch_ew(OpChebStep{sd, sr, dinv.Data(), t.Data(), r.Data(), d.Data(), y.Data()}, d.Size(), c.stream);
+}
+void ChebyStep3(const Context &c, double sd, double sr, const Vector &dinv, const Vector &t, const Vector &r0, const Vector &ek,
+                const Vector *ep, Vector &out, bool add) {
+  launch_ew(OpChebStep3{sd, sr, dinv.Data(), t.Data(), r0.Data(), ek.Data(), ep ? ep->Data() : nullptr, out.Data(), add ? 1 : 0},
+            out.Size(), c.stream);
 }
 void CgUpdate(const Context &c, double a, const Vector &p, const Vector &z, Vector &x, Vector &r) {
   launch_ew(OpCgUpdate{a, p.Data(), z.Data(), x.Data(), r.Data()}, x.Size(), c.stream);
@@ -1212,7 +1238,7 @@ void ChebyshevSmoother::SetOperator(const Operator &op) {
   StreamGraph::Invalidate();
   // chebyshev.cpp:169-188 (4th kind) / :232-257 (1st kind)
   A_ = &op, height = op.Height(), width = op.Width();
-  d_.SetSize(height), dinv_.SetSize(height), r_.SetSize(height), t_.SetSize(height);
+  d_.SetSize(height), dinv_.SetSize(height), r_.SetSize(height), t_.SetSize(height), w_.SetSize(height);
   op.AssembleDiagonal(dinv_);
   linalg::Reciprocal(*ctx_, dinv_);
   lambda_max_ = sf_max_ * linalg::SpectralNorm(*ctx_, op, dinv_);
@@ -1221,36 +1247,79 @@ void ChebyshevSmoother::SetOperator(const Operator &op) {
 }
 void ChebyshevSmoother::Mult(const Vector &x, Vector &y) const { Mult2(x, y, r_); }
 void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
+  // chebyshev.cpp:160-220 (4th kind) and :222-293 (1st kind).  The reference's recurrence -- d_0 = c_0 D^-1 r; then for every
+  // further order  y += d, r -= A d, d = sd_k d + sr_k D^-1 r; finally y += d -- is carried here by the accumulated correction
+  // e_k = d_0 + ... + d_{k-1} (d_{k-1} = e_k - e_{k-1}, r_k = r_0 - A e_k): the same polynomial, but r_0 is only read (with a
+  // zero guess it is the right-hand side x itself: no copy), y is written once, and a step moves 48 instead of 64 bytes per entry
+  // (DESIGN.md 3.7).  PALACE_AMD_CHEBY_FORM=d selects the literal form.
   const Context &c = *ctx_;
+  static const bool literal = [] {
+    const char *e = std::getenv("PALACE_AMD_CHEBY_FORM");
+    return e && e[0] == 'd';
+  }();
+  const double lmax = lambda_max_, lmin = sf_min_ * lmax;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  // coefficients of order k (k = 0: the scale of the first direction)
+  auto first = [&]() { return fourth_kind_ ? 4.0 / (3.0 * lmax) : 1.0 / theta; };
   for (int it = 0; it < pc_it_; it++) {
-    if (initial_guess || it > 0) {
-      A_->Mult(y, r);
-      linalg::AXPBY(c, 1.0, x, -1.0, r);
-    } else {
-      linalg::Copy(c, x, r);
-      linalg::Fill(c, y, 0.0);
-    }
-    if (fourth_kind_) {  // chebyshev.cpp:204-218
-      linalg::ChebyOrder0(c, 4.0 / (3.0 * lambda_max_), dinv_, r, d_);
+    const bool zero = !(initial_guess || it > 0);
+    if (literal) {
+      if (!zero) {
+        A_->Mult(y, r);
+        linalg::AXPBY(c, 1.0, x, -1.0, r);
+      } else {
+        linalg::Copy(c, x, r);
+        linalg::Fill(c, y, 0.0);
+      }
+      linalg::ChebyOrder0(c, first(), dinv_, r, d_);
+      double rhop = delta / theta;
       for (int k = 1; k < order_; k++) {
-        const double sd = (2.0 * k - 1.0) / (2.0 * k + 3.0);
-        const double sr = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lambda_max_);
+        double sd, sr;
+        if (fourth_kind_) {  // chebyshev.cpp:204-218
+          sd = (2.0 * k - 1.0) / (2.0 * k + 3.0), sr = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lmax);
+        } else {  // chebyshev.cpp:275-291
+          const double rho = 1.0 / (2.0 * theta / delta - rhop);
+          sd = rho * rhop, sr = 2.0 * rho / delta, rhop = rho;
+        }
         A_->Mult(d_, t_);
         linalg::ChebyStep(c, sd, sr, dinv_, t_, r, d_, y);  // y += d; r -= A d; d = sd d + sr D^-1 r
       }
-    } else {  // chebyshev.cpp:275-291
-      const double lmax = lambda_max_, lmin = sf_min_ * lmax;
-      const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
-      linalg::ChebyOrder0(c, 1.0 / theta, dinv_, r, d_);
-      double rhop = delta / theta;
-      for (int k = 1; k < order_; k++) {
-        const double rho = 1.0 / (2.0 * theta / delta - rhop);
-        A_->Mult(d_, t_);
-        linalg::ChebyStep(c, rho * rhop, 2.0 * rho / delta, dinv_, t_, r, d_, y);
-        rhop = rho;
-      }
+      linalg::AXPY(c, 1.0, d_, y);
+      continue;
     }
-    linalg::AXPY(c, 1.0, d_, y);
+    const Vector *r0 = &x;
+    if (!zero) {  // r_0 = x - A y
+      A_->Mult(y, r);
+      linalg::AXPBY(c, 1.0, x, -1.0, r);
+      r0 = &r;
+    }
+    if (order_ <= 1) {  // y (+)= c_0 D^-1 r_0
+      if (zero) {
+        linalg::ChebyOrder0(c, first(), dinv_, *r0, y);
+      } else {
+        linalg::ChebyOrder0(c, first(), dinv_, *r0, d_);
+        linalg::AXPY(c, 1.0, d_, y);
+      }
+      continue;
+    }
+    // e_k and the buffer e_{k+1} goes to (zero guess: the caller's work vector r is free for that -- unless it is x itself)
+    Vector *ek = &d_, *ep = (zero && r.Data() != x.Data()) ? &r : &w_;
+    linalg::ChebyOrder0(c, first(), dinv_, *r0, *ek);  // e_1 = d_0
+    double rhop = delta / theta;
+    for (int k = 1; k < order_; k++) {
+      double sd, sr;
+      if (fourth_kind_) {
+        sd = (2.0 * k - 1.0) / (2.0 * k + 3.0), sr = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * lmax);
+      } else {
+        const double rho = 1.0 / (2.0 * theta / delta - rhop);
+        sd = rho * rhop, sr = 2.0 * rho / delta, rhop = rho;
+      }
+      A_->Mult(*ek, t_);
+      const bool last = k == order_ - 1;
+      // e_{k+1} = e_k + sd (e_k - e_{k-1}) + sr D^-1 (r_0 - A e_k); the last one goes (is added) to y
+      linalg::ChebyStep3(c, sd, sr, dinv_, t_, *r0, *ek, k == 1 ? nullptr : ep, last ? y : *ep, last && !zero);
+      if (!last) std::swap(ek, ep);
+    }
   }
 }
 

@@ -169,6 +169,10 @@ void ChebyOrderK(const Context &c, double sd, double sr, const Vector &dinv, con
 // fused forms of consecutive reference kernels (same arithmetic, one pass):
 //   ChebyStep: y += d; r -= t; d = sd d + sr dinv .* r      (chebyshev.cpp:208-216, t = A d)
 //   CgUpdate : x += a p; r -= a z                            (iterative.cpp:448-449)
+//   ChebyStep3: out (+)= e_k + sd (e_k - e_prev) + sr dinv .* (r0 - t), t = A e_k  (the same step for the accumulated correction;
+//   e_prev == nullptr: zero)
+void ChebyStep3(const Context &c, double sd, double sr, const Vector &dinv, const Vector &t, const Vector &r0, const Vector &ek,
+                const Vector *e_prev, Vector &out, bool add);
 void ChebyStep(const Context &c, double sd, double sr, const Vector &dinv, const Vector &t, Vector &r, Vector &d,
                Vector &y);
 void CgUpdate(const Context &c, double a, const Vector &p, const Vector &z, Vector &x, Vector &r);
@@ -431,7 +435,7 @@ class ChebyshevSmoother : public Solver {
   double sf_min_;
   const Operator *A_ = nullptr;
   Vector dinv_;
-  mutable Vector d_, r_, t_;
+  mutable Vector d_, r_, t_, w_;
 
 public:
   ChebyshevSmoother(const Context &ctx, int smooth_it, int poly_order, double sf_max = 1.0, bool fourth_kind = true,
