@@ -571,7 +571,9 @@ def main():
     if world > 1:
         halo_info = {"transport": "peer (direct stores over IPC-mapped arenas)" if ctx.peer_ready() else "rccl send / receive groups",
                      "direct_form": K.direct_form()}
-        if K.direct_form() == 1:
+        df = torch.tensor([K.direct_form()], dtype=torch.int64, device="cuda")
+        dist.all_reduce(df, op=dist.ReduceOp.MIN)  # (the check below is collective: every rank or none)
+        if int(df.item()) == 1:
             y2 = torch.empty_like(y)
             K.mult(x, y)
             K.set_direct(False)
