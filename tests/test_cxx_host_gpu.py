@@ -153,3 +153,32 @@ def test_cxx_host_complex_solve(built):
     assert n == nn and K.stats()["iterations"] == its
     s_py = complex(float((xr * one_r + xi * one_i).sum()), float((xi * one_r - xr * one_i).sum()))  # ones^H x
     assert abs(complex(sxr, sxi) - s_py) < 1e-9 * abs(s_py)
+
+
+def test_cxx_host_solve_against_the_oracle(built):
+    """The C++ driver's PCG + p-multigrid solve (KspSolver from a LinearSolverData: Chebyshev-Jacobi on level 0, plain
+    Chebyshev smoothers) against the ORACLE's restatement of the same loop (oracle pcg + GMGOracle + ChebyshevOracle on the
+    oracle's operators) -- not only against the ctypes mirror: iteration count +- 1 and the solution checksum to 1e-6.  The
+    smoothers' eigenvalue estimates are taken from the device (the same power iteration the driver runs) and handed to the oracle."""
+    from oracle import palace_oracle as po
+    from palace_amd import linalg
+    from palace_amd.fem.mesh import ogrid_cylinder
+    from tests.test_solvers_gpu import Problem
+
+    exe, blob = built
+    out = subprocess.check_output([exe, blob, "0", "cg", "cheb"], text=True)
+    m = re.search(r"ndofs (\d+) .* iterations (\d+)\s+converged (\d).*sum\(x\) (\S+)", out)
+    assert m, out
+    n, its, conv, sx = int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4))
+    prob = Problem(ogrid_cylinder(3, 6), [1, 2, 3])
+    assert prob.spaces[-1].ndofs == n and conv == 1
+    lam = [linalg.chebyshev(prob.ctx, prob.A[l], order=(4 if l == 0 else 6)).lambda_max() for l in range(3)]
+    sm = [None] + [po.ChebyshevOracle(prob.oA[l], 6, lambda_max=lam[l]) for l in (1, 2)]
+    c0 = po.ChebyshevOracle(prob.oA[0], 4, lambda_max=lam[0])
+    oP = [(p.mult, p.mult_transpose) for p in prob.oP]
+    oB = po.GMGOracle(prob.oA, oP, sm, lambda r: c0.mult2(r, None, False), [s.ess_dofs() for s in prob.spaces])
+    b = prob.oA[-1].mult(np.ones(n))
+    b[prob.spaces[-1].ess_dofs()] = 0.0
+    xo, it_o, _ = po.pcg(prob.oA[-1].mult, b, oB.mult, rel_tol=1e-10, max_it=400)
+    assert abs(its - it_o) <= 1, (its, it_o)
+    assert abs(sx - xo.sum()) < 1e-6 * abs(xo.sum()), (sx, xo.sum())
