@@ -291,6 +291,11 @@ void pa_complex_par_op_destroy(pa_complex_par_op *A);
 int pa_complex_gmres_create_par(pa_context *ctx, pa_complex_par_op *A, pa_solver *precond, double rel_tol,
                                 double abs_tol, int max_it, int restart, int flexible, int pc_side, int orthog,
                                 int print, pa_csolver **S);
+/* CgSolver<ComplexOperator> (linalg/iterative.cpp:360-486) on a ComplexParOperator: PCG for Hermitian positive definite systems
+ * (complex scalars, inner products y^H x, residual in the preconditioner's inner product); precond: a real solver applied to both
+ * parts or NULL.  Solved with pa_csolver_mult / read with pa_csolver_stats like the GMRES solvers. */
+int pa_complex_cg_create_par(pa_context *ctx, pa_complex_par_op *A, pa_solver *precond, double rel_tol, double abs_tol, int max_it,
+                             int print, pa_csolver **S);
 /* GmresSolver::SetPreconditionerSide (iterative.hpp:214): 0 left (default), 1 right. */
 int pa_gmres_set_pc_side(pa_solver *S, int side);
 /* ParOperator::MultTranspose (linalg/rap.cpp:236-275). */

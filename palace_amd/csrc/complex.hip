@@ -871,6 +871,77 @@ struct ComplexKrylovOps {
 };
 }  // namespace
 
+void ComplexIterativeSolver::ApplyB(const ComplexVector &x, ComplexVector &y) const {
+  PhaseRange range("Preconditioner");  // iterative.cpp:247
+  if (Bc_) return Bc_->Mult(x, y);
+  B_->Mult(x.Real(), y.Real());  // gmg.cpp:147-168: the real preconditioner on both parts
+  B_->Mult(x.Imag(), y.Imag());
+}
+
+void ComplexCgSolver::Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess) const {
+  // iterative.cpp:360-486 with ScalarType = std::complex<double>
+  using cplx = std::complex<double>;
+  const Context &c = *ctx_;
+  PA_REQUIRE(A_, "Operator must be set for CgSolver::Mult!");
+  const int n = A_->Height();
+  if (r_.Size() != n) r_.SetSize(n), z_.SetSize(n), p_.SetSize(n);
+  const bool haveB = B_ || Bc_;
+  auto check = [](cplx dot, const char *msg) {  // CheckDot, iterative.cpp:27-32
+    PA_REQUIRE(std::isfinite(dot.real()) && std::isfinite(dot.imag()) && dot.real() >= 0.0, msg);
+  };
+  cplx beta, beta_prev = 0.0;
+  if (initial_guess) {
+    A_->Mult(x, r_);
+    linalg::AXPBY(c, cplx(1.0), b, cplx(-1.0), r_);
+  } else {
+    linalg::Copy(c, b, r_);
+    linalg::Fill(c, x, 0.0);
+  }
+  if (haveB) ApplyB(r_, z_); else linalg::Copy(c, r_, z_);
+  beta = linalg::Dot(c, z_, r_);
+  check(beta, "PCG preconditioner is not positive definite: (Br, r) is not a finite non-negative number");
+  double res = std::sqrt(std::abs(beta));
+  if (initial_guess) {
+    cplx beta_rhs;
+    if (haveB) {
+      ApplyB(b, p_);
+      beta_rhs = linalg::Dot(c, p_, b);
+    } else {
+      beta_rhs = linalg::Norml2(c, b);  // (the norm, not its square: iterative.cpp:406-411)
+    }
+    check(beta_rhs, "PCG preconditioner is not positive definite: (Bb, b) is not a finite non-negative number");
+    initial_res_ = std::sqrt(std::abs(beta_rhs));
+  } else {
+    initial_res_ = res;
+  }
+  const double eps = std::max(rel_tol_ * initial_res_, abs_tol_);
+  converged_ = res < eps;
+  int it = 0;
+  for (; it < max_it_ && !converged_; it++) {
+    if (print_ > 1) std::printf("  %3d KSP residual norm ||r||_B = %.6e\n", it, res);
+    if (!it)
+      linalg::Copy(c, z_, p_);
+    else
+      linalg::AXPBY(c, cplx(1.0), z_, beta / beta_prev, p_);
+    A_->Mult(p_, z_);
+    const cplx denom = linalg::Dot(c, z_, p_);
+    check(denom, "PCG operator is not positive definite: (Ap, p) is not a finite non-negative number");
+    const cplx alpha = beta / denom;
+    linalg::AXPY(c, alpha, p_, x);
+    linalg::AXPY(c, -alpha, z_, r_);
+    beta_prev = beta;
+    if (haveB) ApplyB(r_, z_); else linalg::Copy(c, r_, z_);
+    beta = linalg::Dot(c, z_, r_);
+    check(beta, "PCG preconditioner is not positive definite: (Br, r) is not a finite non-negative number");
+    res = std::sqrt(std::abs(beta));
+    converged_ = res < eps;
+  }
+  if (print_ > 0)
+    std::printf("  PCG (complex) solver %s in %d iterations (res %.3e, initial %.3e)\n", converged_ ? "converged" : "did NOT converge",
+                it, res, initial_res_);
+  final_res_ = res, final_it_ = it;
+}
+
 void ComplexGmresSolver::Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess) const {
   PA_REQUIRE(A_, "Operator must be set for GmresSolver::Mult!");
   ComplexKrylovOps ops{*ctx_, A_, B_, Bc_, A_->Height()};

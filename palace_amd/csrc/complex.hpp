@@ -331,42 +331,68 @@ public:
 // GmresSolver<ComplexOperator> / FgmresSolver<ComplexOperator> (linalg/iterative.cpp:543-871): the shared implementation
 // (krylov_impl.hpp) on ComplexVectors; the preconditioner is a real Solver applied to the real and the imaginary part
 // (linalg/gmg.cpp:147-168 `RealMult`).
-class ComplexGmresSolver {
+// Krylov solvers on ComplexOperators with a real preconditioner applied to both parts (or a complex one): the common part of
+// IterativeSolver<ComplexOperator> (linalg/iterative.hpp:25-115)
+class ComplexIterativeSolver {
+protected:
   const Context *ctx_;
   const ComplexOperator *A_ = nullptr;
   const Solver *B_ = nullptr;          // real preconditioner applied to both parts, or
   const ComplexSolver *Bc_ = nullptr;  // a complex one
   double rel_tol_ = 0.0, abs_tol_ = 0.0;
-  int max_it_ = 100, max_dim_ = -1, print_ = 0;
-  bool flexible_ = false;
-  PreconditionerSide pc_side_ = PreconditionerSide::LEFT;
-  Orthogonalization orthog_ = Orthogonalization::MGS;
+  int max_it_ = 100, print_ = 0;
   mutable bool converged_ = false;
   mutable double initial_res_ = 1.0, final_res_ = 0.0;
   mutable int final_it_ = 0;
-  mutable std::vector<ComplexVector> V_, Z_;
-  mutable ComplexVector r_;
+  void ApplyB(const ComplexVector &x, ComplexVector &y) const;  // iterative.cpp:243-256 (+ the "Preconditioner" phase range)
 
 public:
-  explicit ComplexGmresSolver(const Context &ctx, int print = 0, bool flexible = false)
-      : ctx_(&ctx), print_(print), flexible_(flexible), pc_side_(flexible ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT) {}
+  explicit ComplexIterativeSolver(const Context &ctx, int print = 0) : ctx_(&ctx), print_(print) {}
+  virtual ~ComplexIterativeSolver() = default;
   void SetOperator(const ComplexOperator &op) { A_ = &op; }
   void SetPreconditioner(const Solver &pc) { B_ = &pc, Bc_ = nullptr; }
   void SetPreconditioner(const ComplexSolver &pc) { Bc_ = &pc, B_ = nullptr; }
   void SetTol(double t) { rel_tol_ = t; }
   void SetAbsTol(double t) { abs_tol_ = t; }
   void SetMaxIter(int n) { max_it_ = n; }
+  virtual void Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess = false) const = 0;
+  bool GetConverged() const { return converged_; }
+  double GetInitialRes() const { return initial_res_; }
+  double GetFinalRes() const { return final_res_; }
+  int GetNumIterations() const { return final_it_; }
+};
+
+// GmresSolver / FgmresSolver<ComplexOperator> (iterative.cpp:543-871) over krylov_impl.hpp
+class ComplexGmresSolver : public ComplexIterativeSolver {
+  int max_dim_ = -1;
+  bool flexible_ = false;
+  PreconditionerSide pc_side_ = PreconditionerSide::LEFT;
+  Orthogonalization orthog_ = Orthogonalization::MGS;
+  mutable std::vector<ComplexVector> V_, Z_;
+  mutable ComplexVector r_;
+
+public:
+  explicit ComplexGmresSolver(const Context &ctx, int print = 0, bool flexible = false)
+      : ComplexIterativeSolver(ctx, print), flexible_(flexible),
+        pc_side_(flexible ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT) {}
   void SetRestartDim(int m) { max_dim_ = m; }
   void SetOrthogonalization(Orthogonalization o) { orthog_ = o; }
   void SetPreconditionerSide(PreconditionerSide side) {
     PA_REQUIRE(!flexible_ || side == PreconditionerSide::RIGHT, "FGMRES solver only supports right preconditioning!");
     pc_side_ = side;
   }
-  void Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess = false) const;
-  bool GetConverged() const { return converged_; }
-  double GetInitialRes() const { return initial_res_; }
-  double GetFinalRes() const { return final_res_; }
-  int GetNumIterations() const { return final_it_; }
+  void Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess = false) const override;
+};
+
+// CgSolver<ComplexOperator> (iterative.cpp:360-486): PCG for Hermitian positive definite systems, the scalars of the recurrence
+// complex (inner products y^H x), the residual measured in the preconditioner's inner product.  Host-side scalars: one
+// synchronisation per inner product, as in the reference.
+class ComplexCgSolver : public ComplexIterativeSolver {
+  mutable ComplexVector r_, z_, p_;
+
+public:
+  explicit ComplexCgSolver(const Context &ctx, int print = 0) : ComplexIterativeSolver(ctx, print) {}
+  void Mult(const ComplexVector &b, ComplexVector &x, bool initial_guess = false) const override;
 };
 
 }  // namespace palace

@@ -319,14 +319,27 @@ ComplexKspSolver::ComplexKspSolver(const config::LinearSolverData &linear, int v
                                    const FiniteElementSpaceHierarchy &fespaces,
                                    const FiniteElementSpaceHierarchy *aux_fespaces) {
   const Context &ctx = fespaces.GetFinestFESpace().GetContext();
-  PA_REQUIRE(linear.krylov_solver == KrylovSolver::GMRES || linear.krylov_solver == KrylovSolver::FGMRES,
-             "complex systems are solved with GMRES or FGMRES");
-  const bool flexible = linear.krylov_solver == KrylovSolver::FGMRES;
-  ksp = std::make_unique<ComplexGmresSolver>(ctx, verbose, flexible);
-  ksp->SetRestartDim(linear.max_size), ksp->SetTol(linear.tol), ksp->SetMaxIter(linear.max_it);
-  ksp->SetOrthogonalization(linear.gs_orthog);
-  if (!flexible && linear.pc_side == PreconditionerSideOption::RIGHT) ksp->SetPreconditionerSide(PreconditionerSide::RIGHT);
-  if (!flexible && linear.pc_side == PreconditionerSideOption::LEFT) ksp->SetPreconditionerSide(PreconditionerSide::LEFT);
+  // ksp.cpp:27-106 for OperType = ComplexOperator
+  switch (linear.krylov_solver) {
+    case KrylovSolver::CG:
+      ksp = std::make_unique<ComplexCgSolver>(ctx, verbose);
+      if (linear.pc_side != PreconditionerSideOption::DEFAULT)
+        std::fprintf(stderr, "Warning: Preconditioner side will be ignored for non-GMRES iterative solvers!\n");
+      break;
+    case KrylovSolver::GMRES:
+    case KrylovSolver::FGMRES: {
+      const bool flexible = linear.krylov_solver == KrylovSolver::FGMRES;
+      auto gmres = std::make_unique<ComplexGmresSolver>(ctx, verbose, flexible);
+      gmres->SetRestartDim(linear.max_size);
+      gmres->SetOrthogonalization(linear.gs_orthog);
+      if (!flexible && linear.pc_side == PreconditionerSideOption::RIGHT) gmres->SetPreconditionerSide(PreconditionerSide::RIGHT);
+      if (!flexible && linear.pc_side == PreconditionerSideOption::LEFT) gmres->SetPreconditionerSide(PreconditionerSide::LEFT);
+      ksp = std::move(gmres);
+    } break;
+    default:
+      throw pa::Error("Unexpected solver type for Krylov solver configuration!");
+  }
+  ksp->SetTol(linear.tol), ksp->SetMaxIter(linear.max_it);
   initial_guess = linear.initial_guess > 0;
   pc = ConfigurePreconditionerSolver(linear, verbose - 1, ctx, fespaces, aux_fespaces);
   ksp->SetPreconditioner(*pc);

@@ -82,12 +82,12 @@ public:
   void Mult(const Vector &x, Vector &y) const;
 };
 
-// BaseKspSolver<ComplexOperator>: GMRES / FGMRES on a ComplexOperator with a real-valued preconditioner applied to the
+// BaseKspSolver<ComplexOperator>: CG (Hermitian positive definite systems) / GMRES / FGMRES on a ComplexOperator with a real-valued preconditioner applied to the
 // real and the imaginary part (the reference's "PCMatReal" construction: the multigrid hierarchy is built from real
 // operators, linalg/gmg.cpp:147-168 applies it part by part).  pc_op is that real operator (a MultigridOperator for
 // geometric multigrid).
 class ComplexKspSolver {
-  std::unique_ptr<ComplexGmresSolver> ksp;
+  std::unique_ptr<ComplexIterativeSolver> ksp;
   std::unique_ptr<Solver> pc;
   bool initial_guess = false;
   mutable int ksp_mult = 0, ksp_mult_it = 0;
@@ -99,7 +99,7 @@ public:
   int NumTotalMultIterations() const { return ksp_mult_it; }
   void SetRelTol(double tol) { ksp->SetTol(tol); }
   void SetAbsTol(double tol) { ksp->SetAbsTol(tol); }
-  const ComplexGmresSolver &GetKrylovSolver() const { return *ksp; }
+  const ComplexIterativeSolver &GetKrylovSolver() const { return *ksp; }
   void SetOperators(const ComplexOperator &op, const Operator &pc_op);
   void Mult(const ComplexVector &x, ComplexVector &y) const;
 };

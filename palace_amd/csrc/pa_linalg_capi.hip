@@ -59,7 +59,7 @@ struct pa_csolver {
   pa_context *ctx;
   std::unique_ptr<ComplexWrapperOperator> A;  // owned wrapper (created from two real ParOperators), or
   const ComplexOperator *Aext = nullptr;      // a ComplexParOperator owned elsewhere
-  std::unique_ptr<ComplexGmresSolver> solver;
+  std::unique_ptr<ComplexIterativeSolver> solver;
   int Height() const { return A ? A->Height() : Aext->Height(); }
 };
 
@@ -789,11 +789,12 @@ int pa_complex_gmres_create(pa_context *ctx, pa_par_op *Ar, pa_par_op *Ai, pa_so
     auto *s = new pa_csolver;
     s->ctx = ctx;
     s->A = std::make_unique<ComplexWrapperOperator>(ctx->ctx, Ar ? Ar->op.get() : nullptr, Ai ? Ai->op.get() : nullptr);
-    s->solver = std::make_unique<ComplexGmresSolver>(ctx->ctx, print);
-    s->solver->SetOperator(*s->A);
-    if (precond) s->solver->SetPreconditioner(*precond->solver);
-    s->solver->SetTol(rel_tol), s->solver->SetAbsTol(abs_tol), s->solver->SetMaxIter(max_it);
-    s->solver->SetRestartDim(restart);
+    auto g = std::make_unique<ComplexGmresSolver>(ctx->ctx, print);
+    g->SetOperator(*s->A);
+    if (precond) g->SetPreconditioner(*precond->solver);
+    g->SetTol(rel_tol), g->SetAbsTol(abs_tol), g->SetMaxIter(max_it);
+    g->SetRestartDim(restart);
+    s->solver = std::move(g);
     *S = s;
   });
 }
@@ -981,13 +982,30 @@ int pa_complex_gmres_create_par(pa_context *ctx, pa_complex_par_op *A, pa_solver
     auto *s = new pa_csolver;
     s->ctx = ctx;
     s->Aext = A->op.get();
-    s->solver = std::make_unique<ComplexGmresSolver>(ctx->ctx, print, flexible != 0);
+    auto g = std::make_unique<ComplexGmresSolver>(ctx->ctx, print, flexible != 0);
+    g->SetOperator(*s->Aext);
+    if (precond) g->SetPreconditioner(*precond->solver);
+    g->SetTol(rel_tol), g->SetAbsTol(abs_tol), g->SetMaxIter(max_it);
+    g->SetRestartDim(restart);
+    g->SetOrthogonalization(static_cast<Orthogonalization>(orthog));
+    if (!flexible) g->SetPreconditionerSide(pc_side ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT);
+    s->solver = std::move(g);
+    *S = s;
+  });
+}
+
+/* CgSolver<ComplexOperator> (iterative.cpp:360-486) on a ComplexParOperator: Hermitian positive definite systems */
+int pa_complex_cg_create_par(pa_context *ctx, pa_complex_par_op *A, pa_solver *precond, double rel_tol, double abs_tol, int max_it,
+                             int print, pa_csolver **S) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && A && S, "bad argument");
+    auto *s = new pa_csolver;
+    s->ctx = ctx;
+    s->Aext = A->op.get();
+    s->solver = std::make_unique<ComplexCgSolver>(ctx->ctx, print);
     s->solver->SetOperator(*s->Aext);
     if (precond) s->solver->SetPreconditioner(*precond->solver);
     s->solver->SetTol(rel_tol), s->solver->SetAbsTol(abs_tol), s->solver->SetMaxIter(max_it);
-    s->solver->SetRestartDim(restart);
-    s->solver->SetOrthogonalization(static_cast<Orthogonalization>(orthog));
-    if (!flexible) s->solver->SetPreconditionerSide(pc_side ? PreconditionerSide::RIGHT : PreconditionerSide::LEFT);
     *S = s;
   });
 }

@@ -805,6 +805,21 @@ class ComplexParGmres(ComplexGmres):
                                                  C.byref(self.handle)))
 
 
+class ComplexParCg(ComplexGmres):
+    """CgSolver<ComplexOperator> (linalg/iterative.cpp:360-486) on a ComplexParOperator (Hermitian positive definite systems)."""
+
+    def __init__(self, ctx, A: ComplexParOperator, precond=None, rel_tol=1e-8, abs_tol=0.0, max_it=200, print_level=0):
+        L = _L()
+        L.pa_complex_cg_create_par.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                               C.c_void_p]
+        L.pa_csolver_destroy.restype = None
+        L.pa_csolver_destroy.argtypes = [C.c_void_p]
+        self.ctx, self._keep = ctx, (A, precond)
+        self.handle = C.c_void_p()
+        _lib.check(L.pa_complex_cg_create_par(ctx.handle, A.handle, precond.handle if precond else None, rel_tol, abs_tol,
+                                              max_it, print_level, C.byref(self.handle)))
+
+
 class ComplexSmoother:
     """Solver<ComplexOperator> smoothers on a ComplexParOperator: 'jacobi', 'chebyshev' (4th kind), 'chebyshev1'
     (linalg/jacobi.cpp, chebyshev.cpp:160-293 with the complex inverse diagonal)."""

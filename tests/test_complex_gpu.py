@@ -243,3 +243,70 @@ def test_fused_complex_apply_not_for_curved_tets(tmp_path):
                        timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert int(np.load(f)["fused"]) == 0
+
+
+def test_complex_pcg_on_a_hermitian_positive_definite_system(cylinder_mesh):
+    """CgSolver<ComplexOperator> (linalg/iterative.cpp:360-486): complex right-hand side and iterate, the real positive
+    definite K + M as the operator (a ComplexParOperator without an imaginary part), Jacobi preconditioner applied to both parts.
+    Against a numpy restatement of the same recurrence on the oracle's matrix: iteration count, residual norms in the
+    preconditioner's inner product, iterate; with and without an initial guess."""
+    mesh, p, q1d = cylinder_mesh, 2, 3
+    ctx = linalg.Context()
+    nd = NDHexSpace(mesh, p)
+    n, ess = nd.ndofs, nd.ess_dofs()
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ident = ceed.coefficient_context(3)
+    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
+    op = ceed.curlcurlmass_operator(geom, nd, mass, ident)
+    A = linalg.ComplexParOperator(ctx, op, None, ess, linalg.DIAG_ONE)
+    Ar = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+    J = linalg.jacobi(ctx, Ar)
+    ogeom = util.oracle_geom(mesh, q1d)
+    off, ori = nd.native_restriction()
+    interp, curl = po.nd_hex_dense_tables(p, q1d, nd.dof_map_native())
+    Ao = po.CeedOperatorOracle(n, off, ori, interp, curl, ogeom, po.QF_HDIVMASS,
+                               po.CoeffCtx(attr_mat=[0], mat_coeff=[np.array([2.08])]), po.CoeffCtx()).assemble_sparse().tolil()
+    for d in ess:
+        Ao[d, :] = 0
+        Ao[:, d] = 0
+        Ao[d, d] = 1.0
+    Ao = Ao.tocsr()
+    dinv = 1.0 / Ao.diagonal()
+
+    def pcg(b, x0, rel_tol, max_it):  # iterative.cpp:360-486, ScalarType complex, Dot(x, y) = y^H x
+        x = np.zeros_like(b) if x0 is None else x0.copy()
+        r = b - Ao @ x if x0 is not None else b.copy()
+        z = dinv * r
+        beta = np.vdot(r, z)
+        res = np.sqrt(abs(beta))
+        init = np.sqrt(abs(np.vdot(b, dinv * b))) if x0 is not None else res
+        eps, it, beta_prev, pv = rel_tol * init, 0, 0.0, None
+        while it < max_it and not res < eps:
+            pv = z.copy() if it == 0 else z + (beta / beta_prev) * pv
+            z = Ao @ pv
+            alpha = beta / np.vdot(pv, z)
+            x, r = x + alpha * pv, r - alpha * z
+            beta_prev = beta
+            z = dinv * r
+            beta = np.vdot(r, z)
+            res = np.sqrt(abs(beta))
+            it += 1
+        return x, it, init, res
+
+    rng = np.random.default_rng(21)
+    b = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    b[ess] = 0.0
+    S = linalg.ComplexParCg(ctx, A, J, rel_tol=1e-10, max_it=2000)
+    for x0 in (None, 0.3 * (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))):
+        if x0 is not None:
+            x0[ess] = 0.0
+        xo, it_o, init_o, res_o = pcg(b, x0, 1e-10, 2000)
+        xr = _dev(x0.real) if x0 is not None else torch.zeros(n, dtype=torch.float64, device="cuda")
+        xi = _dev(x0.imag) if x0 is not None else torch.zeros(n, dtype=torch.float64, device="cuda")
+        S.mult(_dev(b.real), _dev(b.imag), xr, xi, initial_guess=x0 is not None)
+        st = S.stats()
+        assert st["converged"] and abs(st["iterations"] - it_o) <= 1, (st, it_o)
+        assert abs(st["initial_res"] - init_o) < 1e-12 * init_o
+        xs = xr.cpu().numpy() + 1j * xi.cpu().numpy()
+        assert np.linalg.norm(xs - xo) < 1e-8 * np.linalg.norm(xo)
+        assert np.linalg.norm(Ao @ xs - b) < 1e-8 * np.linalg.norm(b)
