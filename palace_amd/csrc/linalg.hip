@@ -1717,17 +1717,34 @@ void GeometricMultigridSolver::SetOperators(const std::vector<const ParOperator 
     X_[l].SetSize(A_[l]->Height()), Y_[l].SetSize(A_[l]->Height()), R_[l].SetSize(A_[l]->Height());
   }
   height = width = ops.back()->Height();
-  graph_.Reset();
+  graph_.Reset(), graph_alias_.Reset();
+  last_x_ = last_y_ = nullptr;
 }
 
 void GeometricMultigridSolver::Mult(const Vector &x, Vector &y) const {
   const int L = (int)A_.size();
-  linalg::Copy(*ctx_, x, X_[L - 1]);
-  // the cycle works on the solver's own vectors: one recording serves every (x, y)
+  // A caller that comes back with the same pair of vectors (PCG: r, z at every iteration) gets the cycle on those vectors
+  // themselves -- x is only read by the cycle, y is written by the first smoother: two copies of the finest vectors less per
+  // application -- with its own recording.  Everybody else (GMRES / FGMRES hand over a different basis vector every time) goes
+  // through the solver's own vectors, so that ONE recording serves every (x, y).
+  const bool same_pair = x.Data() == last_x_ && y.Data() == last_y_ && x.Data() != y.Data();
+  last_x_ = x.Data(), last_y_ = y.Data();
+  if (same_pair) {
+    X_[L - 1].MakeRef(const_cast<double *>(x.Data()), x.Size());
+    Y_[L - 1].MakeRef(y.Data(), y.Size());
+    graph_alias_.Run(*ctx_, {this, x.Data(), y.Data()}, [&] {
+      for (int it = 0; it < pc_it_; it++) VCycle(L - 1, it > 0);
+    });
+    return;
+  }
+  if (Xown_.Size() != x.Size()) Xown_.SetSize(x.Size()), Yown_.SetSize(x.Size());
+  linalg::Copy(*ctx_, x, Xown_);
+  X_[L - 1].MakeRef(Xown_.Data(), x.Size());
+  Y_[L - 1].MakeRef(Yown_.Data(), x.Size());
   graph_.Run(*ctx_, {this}, [&] {
     for (int it = 0; it < pc_it_; it++) VCycle(L - 1, it > 0);
   });
-  linalg::Copy(*ctx_, Y_[L - 1], y);
+  linalg::Copy(*ctx_, Yown_, y);
 }
 
 void GeometricMultigridSolver::VCycle(int l, bool initial_guess) const {

@@ -586,8 +586,10 @@ class GeometricMultigridSolver : public Solver {
   std::vector<const Operator *> P_;
   std::vector<const ParOperator *> A_;
   std::vector<std::unique_ptr<Solver>> B_;
-  mutable std::vector<Vector> X_, Y_, R_;
-  mutable StreamGraph graph_;  // one application (pc_it V-cycles) on X_ / Y_
+  mutable std::vector<Vector> X_, Y_, R_;  // (the finest X_ / Y_ are views of the caller's vectors: Mult)
+  mutable Vector Xown_, Yown_;              // the finest vectors of applications to varying (x, y)
+  mutable StreamGraph graph_, graph_alias_;  // one application (pc_it V-cycles): on the solver's vectors / on a caller's recurring pair
+  mutable const double *last_x_ = nullptr, *last_y_ = nullptr;
   void VCycle(int l, bool initial_guess) const;
 
 public:
