@@ -128,3 +128,42 @@ def test_tet_prolongation_and_gradient_oracle(pc, pf):
     g = G.mult(phi)
     ref = ndf_s.interpolate(_field(pf))
     assert np.abs(g - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+def test_uniform_refinement_and_lowest_order_gradient():
+    """tet.refine_uniform (every tetrahedron into 8, every boundary triangle into 4: volume, attributes and boundary tags kept,
+    conforming) and tet.lowest_order_gradient / vertex_coordinates (the inputs of the native AMS solver on tetrahedra): the
+    incidence matrix is in the kernel of the oracle's curl-curl operator, and G applied to a coordinate gives the edge vectors --
+    the Nedelec interpolant of a constant field, whose mass energy is the volume."""
+    from oracle import palace_oracle as po
+    from palace_amd.fem import tet
+
+    m = tet.cube_tet_mesh(2)
+    m.attr[:] = 1 + (np.arange(m.ne) % 2)
+    bf = m.face_verts[m.boundary_face_mask]
+    m.bdr_tris, m.bdr_attr = bf, 1 + (np.arange(bf.shape[0]) % 3)
+    r = tet.refine_uniform(m)
+    assert r.ne == 8 * m.ne and len(r.bdr_tris) == 4 * len(m.bdr_tris)
+    assert r.boundary_face_mask.sum() == 4 * m.boundary_face_mask.sum()  # conforming: no new boundary faces inside
+    vol = lambda msh, a: np.einsum("ei,ei->e", np.cross(*(msh.verts[msh.tets[msh.attr == a]][:, k] - msh.verts[msh.tets[msh.attr == a]][:, 0]
+                                                         for k in (1, 2))), msh.verts[msh.tets[msh.attr == a]][:, 3] - msh.verts[msh.tets[msh.attr == a]][:, 0]).sum() / 6  # noqa: E731
+    for a in (1, 2):
+        assert abs(vol(r, a) - vol(m, a)) < 1e-13
+    assert np.array_equal(np.bincount(r.bdr_attr), 4 * np.bincount(m.bdr_attr))
+    # every refined boundary triangle is a boundary face of the refined mesh
+    key = {tuple(f) for f in map(tuple, r.face_verts[r.boundary_face_mask])}
+    assert all(tuple(sorted(t)) in key for t in np.asarray(r.bdr_tris))
+
+    nd, h1 = tet.NDTetSpace(r, 1), tet.H1TetSpace(r, 1)
+    G = tet.lowest_order_gradient(h1, nd)
+    xyz = tet.vertex_coordinates(h1)
+    pts, wts = tet.default_tet_rule(1)
+    interp, curl = nd.elem.tables(pts)
+    J = r.jacobians(pts)
+    og = po.build_geom_factor_33(np.ones(r.ne), wts, np.transpose(J, (0, 1, 3, 2)).reshape(r.ne, -1, 9))
+    K = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, interp, curl, og, po.QF_HDIV, po.CoeffCtx()).assemble_sparse()
+    M = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, interp, curl, og, po.QF_HCURL, po.CoeffCtx()).assemble_sparse()
+    assert abs(K @ G).max() < 1e-12 * abs(K).max()
+    for c in range(3):
+        u = G @ xyz[:, c]
+        assert abs(u @ (M @ u) - 1.0) < 1e-12  # |e_c|^2 over the unit cube
