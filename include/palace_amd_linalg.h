@@ -162,11 +162,22 @@ int pa_solver_mult2(pa_solver *S, const double *x, double *y, int transpose, int
 /* JacobiSmoother (linalg/jacobi.cpp) */
 int pa_jacobi_create(pa_context *ctx, pa_par_op *A, pa_solver **S);
 
+/* A small global problem solved redundantly by every rank (the coarsest multigrid level across ranks, where the reference runs
+ * HYPRE's distributed AMS / BoomerAMG: linalg/ksp.cpp:143-157).  `inner` solves the GLOBAL problem (n_global unknowns, global
+ * numbering, identical on every rank -- pa_ams_create / pa_amg_create on the globally assembled matrix); `gather` is a halo plan
+ * on a global-numbered vector (send lists: this rank's true dofs by global number, receive lists: the other ranks'); mine[i] is
+ * the global number of true dof i.  y = S x on T-vectors: scatter to global positions, gather from all ranks, inner solve, keep
+ * the own entries.  Neither `gather` nor `inner` is owned. */
+int pa_replicated_solver_create(pa_context *ctx, pa_halo *gather, pa_solver *inner, const int32_t *mine, int n_true, int n_global,
+                                pa_solver **S);
+
 /* Native coarse-level solvers (palace_amd/csrc/amg_solver.hpp), standing where the reference calls HYPRE on its coarsest
  * multigrid level: BoomerAmgSolver (linalg/amg.cpp:12-49; wiring linalg/ksp.cpp:187-200) and HypreAmsSolver
  * (linalg/ams.cpp:18-224; ksp.cpp:166-186).  The matrix is the assembled level (pa_op_full_assemble: what
  * ParOperator::ParallelAssemble gives HYPRE, rap.cpp:84-152); `ess` are the essential true dofs ParOperator eliminates in it
- * (rap.cpp:131-149).  Zero / negative option fields take the defaults of AmgOptions / AmsOptions.  One rank. */
+ * (rap.cpp:131-149).  Zero / negative option fields take the defaults of AmgOptions / AmsOptions.  The matrix is the COMPLETE
+ * problem: the cycles are rank-local (no halo, no global reductions); across ranks wrap the solver of the globally assembled
+ * matrix in pa_replicated_solver_create. */
 typedef struct {
   int max_levels, coarse_size, smooth_order;
   double theta;

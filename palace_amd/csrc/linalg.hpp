@@ -579,6 +579,28 @@ public:
   explicit FgmresSolver(const Context &ctx, int print = 0) : GmresSolver(ctx, print, true) {}
 };
 
+// A problem small enough to be solved redundantly by every rank -- the coarsest multigrid level, where the reference runs
+// HYPRE's distributed AMS / BoomerAMG (linalg/ams.cpp, amg.cpp; ksp.cpp:143-157) and the native cycles of amg_solver.hpp work on
+// one rank's matrix: the right-hand side, distributed as T-vectors, is gathered into a vector in GLOBAL numbering on every rank
+// (a halo plan over that vector: each rank sends its true dofs, receives everybody else's), every rank applies the same solver
+// to the same global vector -- same matrix, same numbering, hence the same bits everywhere -- and keeps its own entries.  The
+// coarse problem is 1 / 27 of the fine one at p = 3; replicating it costs no communication besides the gather.
+class ReplicatedSolver : public Solver {
+  const Context *ctx_;
+  const Halo *gather_;    // plan on the global-numbered vector: send = my true dofs (global numbers), recv = the other ranks'
+  const Solver *inner_;   // solver of the global problem (n_global x n_global)
+  int n_true_, n_global_;
+  int32_t *d_mine_ = nullptr;  // [n_true] global number of my true dof i
+  mutable Vector gx_, gy_;
+
+public:
+  ReplicatedSolver(const Context &ctx, const Halo &gather, const Solver &inner, const int32_t *mine_host, int n_true, int n_global);
+  ~ReplicatedSolver() override;
+  void SetOperator(const Operator &) override {}  // the global problem is the inner solver's
+  void Mult(const Vector &x, Vector &y) const override;
+  void CheckStatus() const override { inner_->CheckStatus(); }
+};
+
 // GeometricMultigridSolver (gmg.cpp): levels 0 (coarsest) .. L-1, prolongations P[l]: level l -> l+1
 class GeometricMultigridSolver : public Solver {
   const Context *ctx_;

@@ -503,6 +503,16 @@ int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max) {
     *lambda_max = c->LambdaMax();
   });
 }
+int pa_replicated_solver_create(pa_context *ctx, pa_halo *gather, pa_solver *inner, const int32_t *mine, int n_true, int n_global,
+                                pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && gather && inner && S && (mine || n_true == 0), "null argument");
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    s->solver = std::make_unique<ReplicatedSolver>(ctx->ctx, *gather->halo, *inner->solver, mine, n_true, n_global);
+    *S = s;
+  });
+}
 int pa_jacobi_create(pa_context *ctx, pa_par_op *A, pa_solver **S) {
   return guarded([&] {
     auto *s = new pa_solver;
@@ -526,7 +536,6 @@ static AmgOptions amg_options(const pa_amg_options *o) {
 int pa_amg_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_ess, const pa_amg_options *opt, pa_solver **S) {
   return guarded([&] {
     PA_REQUIRE(ctx && A && S && (ess || n_ess == 0), "null argument");
-    PA_REQUIRE(!ctx->ctx.comm || pa_context_size(ctx) == 1, "the native AMG works on one rank's matrix");
     auto *s = new pa_solver;
     s->ctx = ctx;
     s->solver = std::make_unique<AmgSolver>(ctx->ctx, DownloadCsr(*A, ess, n_ess), amg_options(opt));
@@ -538,7 +547,6 @@ int pa_ams_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_es
                   pa_solver **S) {
   return guarded([&] {
     PA_REQUIRE(ctx && A && S && G_rowptr && G_col && G_val && coords && (ess || n_ess == 0), "null argument");
-    PA_REQUIRE(!ctx->ctx.comm || pa_context_size(ctx) == 1, "the native AMS works on one rank's matrix");
     amg::HostCsr G;
     G.nrows = A->nrows, G.ncols = n_vert;
     G.rowptr.assign(G_rowptr, G_rowptr + A->nrows + 1);

@@ -47,6 +47,7 @@ def _elem_dofs(space):
 class PartitionedSpace:
     """Rank `rank`'s view of `space` (global: every element, global dof numbers) under the element partition `part`.
 
+    owner      [space.ndofs] owning rank of every global dof
     elems      global numbers of the rank's elements (increasing)
     l2g        [ndofs] global dof of local dof: owned dofs first (increasing global number), then the ghosts grouped by owner
                rank (increasing), each group by global number -- a T-vector is a prefix of the L-vector
@@ -66,6 +67,7 @@ class PartitionedSpace:
         # owner of every global dof: the lowest rank that has it
         owner = np.full(n_glob, world, dtype=np.int64)
         np.minimum.at(owner, eg.ravel(), np.repeat(part.astype(np.int64), eg.shape[1]))
+        self.owner = owner  # [n_glob] owning rank of every global dof
         self.elems = np.nonzero(part == rank)[0]
         mine = np.unique(eg[self.elems].ravel())
         owned = mine[owner[mine] == rank]

@@ -96,11 +96,32 @@ class TetProblem:
             # a nonlinear preconditioner and costs the outer PCG 40 % more iterations; scripts/coarse_tune.py)
             if coarse == "chebyshev":
                 csolver = linalg.chebyshev(ctx, A[0], 4)
-            elif coarse == "ams":  # the native auxiliary-space cycle on the assembled order-1 level (one rank)
-                assert self.world == 1 and coarse_assembled and self.orders[0] == 1
+            elif coarse == "ams" and self.world == 1:  # the native auxiliary-space cycle on the assembled order-1 level
+                assert coarse_assembled and self.orders[0] == 1
                 h1_0 = tet.H1TetSpace(self.mesh, 1)
                 csolver = linalg.ams(ctx, A[0].local, self.ess[0], tet.lowest_order_gradient(h1_0, self.spaces[0]),
                                      tet.vertex_coordinates(h1_0))
+            elif coarse == "ams":
+                # several ranks: the order-1 problem is solved redundantly by every rank (linalg.replicated): the GLOBAL level-0
+                # matrix is assembled here from the serial mesh every rank holds, the same AMS solver is built on it everywhere,
+                # and the distributed right-hand side is gathered through a halo plan on the global-numbered vector
+                assert self.orders[0] == 1
+                ps = self.spaces[0]
+                g0 = ps.space
+                geom_g = ceed.DenseGeomFactorData(self.mesh.elem_nodes, self.mesh.nodes, self.mesh.attr,
+                                                  self.mesh.geometry_grad_table(self.pts), self.wts)
+                op_g = ceed.Operator(g0.ndofs, g0.ndofs).add_dense_integrator(
+                    geom_g, self.nd_block(g0), ceed.QF_HDIVMASS_33, np.concatenate([mass, curl]),
+                    ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
+                csr_g = op_g.full_assemble_device()
+                h1_g = tet.H1TetSpace(self.mesh, 1)
+                inner = linalg.ams(ctx, csr_g, g0.ess_dofs(), tet.lowest_order_gradient(h1_g, g0), tet.vertex_coordinates(h1_g))
+                mine = ps.l2g[: ps.n_true].astype(np.int32)
+                others = [q for q in range(self.world) if q != self.rank]
+                gather = linalg.Halo(ctx, others, [mine for _ in others],
+                                     [np.nonzero(ps.owner == q)[0].astype(np.int32) for q in others])
+                csolver = linalg.replicated(ctx, gather, inner, mine, g0.ndofs)
+                self._keep.append((geom_g, op_g, csr_g, inner, gather))
             else:
                 csolver = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
             B = linalg.gmg(ctx, A, P, csolver, cheby_order=max(2 * self.p, 4), **aux)

@@ -113,7 +113,7 @@ def test_ranks_as_threads_with_halo_stream_overlap():
 
 # ---- tetrahedra under a general (recursive coordinate bisection) element partition -------------------------------------------
 
-def _tet_rank_main(group, rank, world, hiptmair, out, errors):
+def _tet_rank_main(group, rank, world, hiptmair, out, errors, coarse="cg"):
     try:
         import torch
 
@@ -127,7 +127,7 @@ def _tet_rank_main(group, rank, world, hiptmair, out, errors):
             ctx.init_comm_local(group, rank)
         mesh = tet.to_quadratic(tet.cube_tet_mesh(4), warp=lambda x: x + 0.02 * np.sin(2.0 * x[:, [1, 2, 0]]))
         prob = TetProblem(ctx, mesh, 2, rank=rank, world=world)
-        K, b, x = prob.pcg_gmg_solver(max_it=300, rel_tol=1e-9, hiptmair=hiptmair, coarse="cg")
+        K, b, x = prob.pcg_gmg_solver(max_it=300, rel_tol=1e-9, hiptmair=hiptmair, coarse=coarse)
         K.mult(b, x)
         st = K.stats()
         A = prob.A[-1]
@@ -144,12 +144,12 @@ def _tet_rank_main(group, rank, world, hiptmair, out, errors):
         raise
 
 
-def _tet_run(world, hiptmair):
+def _tet_run(world, hiptmair, coarse="cg"):
     from palace_amd import linalg
 
     group = linalg.LocalGroup(world) if world > 1 else None
     out, errors = [None] * world, []
-    threads = [threading.Thread(target=_tet_rank_main, args=(group, r, world, hiptmair, out, errors), daemon=True)
+    threads = [threading.Thread(target=_tet_rank_main, args=(group, r, world, hiptmair, out, errors, coarse), daemon=True)
                for r in range(world)]
     for t in threads:
         t.start()
@@ -179,6 +179,24 @@ def test_tet_ranks_under_rcb_partition_match_one_rank(hiptmair):
         # rank-dependent random vectors: the count moves by a few per cent; with the auxiliary-space smoother it is sharp)
         assert abs(many["iterations"] - one["iterations"]) <= max(1, 0.06 * one["iterations"]), (world, many["iterations"],
                                                                                                 one["iterations"])
+        for k in ("bb", "bAb", "zz"):
+            assert abs(many[k] - one[k]) < 1e-11 * abs(one[k]), (world, k, many[k], one[k])
+        for k in ("xx", "xAx"):
+            assert abs(many[k] - one[k]) < 1e-6 * abs(one[k]), (world, k, many[k], one[k])
+
+
+def test_tet_ranks_with_the_replicated_ams_coarse_solve():
+    """The native AMS cycle on level 0 across ranks: every rank assembles the global order-1 matrix, builds the same solver and
+    applies it to the gathered right-hand side (ReplicatedSolver) -- what HYPRE's distributed AMS is for in the reference.  Same
+    solve as on one rank: iteration count (the coarse solve is bit-identical on every rank; the smoothers' eigenvalue estimates
+    are not), solution norms; and far fewer iterations than with the Jacobi-PCG stand-in."""
+    one = _tet_run(1, True, "ams")
+    ref = _tet_run(1, True, "cg")
+    assert one["converged"] and one["iterations"] <= ref["iterations"]
+    for world in (2, 3):
+        many = _tet_run(world, True, "ams")
+        assert many["converged"] and many["n"] == one["n"]
+        assert abs(many["iterations"] - one["iterations"]) <= 1, (world, many["iterations"], one["iterations"])
         for k in ("bb", "bAb", "zz"):
             assert abs(many[k] - one[k]) < 1e-11 * abs(one[k]), (world, k, many[k], one[k])
         for k in ("xx", "xAx"):
