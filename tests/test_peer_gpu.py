@@ -93,3 +93,54 @@ def test_two_processes_on_one_gpu_match_one_rank():
         assert abs(one[k] - two[k]) < 1e-11 * abs(one[k]), (k, one[k], two[k])
     for k in ("xx", "xAx", "xx2"):
         assert abs(one[k] - two[k]) < 1e-6 * abs(one[k]), (k, one[k], two[k])
+
+
+def _tet_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from palace_amd import linalg
+        from palace_amd.fem import tet
+        from palace_amd.fem.tetproblem import TetProblem
+
+        ctx = linalg.Context()
+        if world > 1:
+            ctx.init_comm_peer_from_torch_distributed()
+        mesh = tet.cube_tet_mesh(4)
+        prob = TetProblem(ctx, mesh, 2, rank=rank, world=world)
+        K, b, x = prob.pcg_gmg_solver(max_it=200, rel_tol=1e-9, hiptmair=True, coarse="ams")
+        res = {}
+        for rep in range(3):  # direct run, recording, replay: the gather of the replicated coarse solve is part of the recording
+            x.zero_()
+            K.mult(b, x)
+            st = K.stats()
+            res[f"its{rep}"], res[f"xx{rep}"] = st["iterations"], ctx.dot(x, x)
+            assert st["converged"]
+        if world > 1:
+            ctx.peer_check()
+        if rank == 0:
+            out.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicated_ams_over_the_peer_transport():
+    """The replicated level-0 solve (every rank applies the native AMS to the right-hand side gathered from all ranks) with the
+    gather running over the peer transport between two processes, inside the recorded multigrid cycle."""
+    import torch.multiprocessing as mp
+
+    results = {}
+    for world, port in ((1, 29641), (2, 29642)):
+        q = mp.get_context("spawn").SimpleQueue()
+        mp.spawn(_tet_worker, args=(world, port, q), nprocs=world, join=True)
+        results[world] = q.get()
+    one, two = results[1], results[2]
+    for rep in range(3):
+        assert abs(one[f"its{rep}"] - two[f"its{rep}"]) <= 1, (one, two)
+        assert abs(one[f"xx{rep}"] - two[f"xx{rep}"]) < 1e-6 * one[f"xx{rep}"], (one, two)
+    assert two["its0"] == two["its1"] == two["its2"] and two["xx1"] == two["xx2"]
