@@ -166,10 +166,11 @@ int pa_jacobi_create(pa_context *ctx, pa_par_op *A, pa_solver **S);
  * HYPRE's distributed AMS / BoomerAMG: linalg/ksp.cpp:143-157).  `inner` solves the GLOBAL problem (n_global unknowns, global
  * numbering, identical on every rank -- pa_ams_create / pa_amg_create on the globally assembled matrix); `gather` is a halo plan
  * on a global-numbered vector (send lists: this rank's true dofs by global number, receive lists: the other ranks'); mine[i] is
- * the global number of true dof i.  y = S x on T-vectors: scatter to global positions, gather from all ranks, inner solve, keep
- * the own entries.  Neither `gather` nor `inner` is owned. */
-int pa_replicated_solver_create(pa_context *ctx, pa_halo *gather, pa_solver *inner, const int32_t *mine, int n_true, int n_global,
-                                pa_solver **S);
+ * the global number of true dof i and sign[i] = +-1 its orientation relative to the global dof (NULL: all +1; a rank-local mesh may
+ * orient an edge against the global numbering).  y = S x on T-vectors: scatter to global positions, gather from all ranks, inner
+ * solve, keep the own entries.  Neither `gather` nor `inner` is owned. */
+int pa_replicated_solver_create(pa_context *ctx, pa_halo *gather, pa_solver *inner, const int32_t *mine, const double *sign,
+                                int n_true, int n_global, pa_solver **S);
 
 /* Native coarse-level solvers (palace_amd/csrc/amg_solver.hpp), standing where the reference calls HYPRE on its coarsest
  * multigrid level: BoomerAmgSolver (linalg/amg.cpp:12-49; wiring linalg/ksp.cpp:187-200) and HypreAmsSolver

@@ -1678,39 +1678,45 @@ void GmresSolver::Mult(const Vector &b, Vector &x) const {
 
 // ---- replicated solve of a small global problem ---------------------------------------------------------------------------
 namespace {
-__global__ void k_scatter_rows(const int n, const int32_t *__restrict__ rows, const double *__restrict__ x, double *__restrict__ g) {
+__global__ void k_scatter_rows(const int n, const int32_t *__restrict__ rows, const double *__restrict__ sgn,
+                               const double *__restrict__ x, double *__restrict__ g) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) g[rows[i]] = x[i];
+  if (i < n) g[rows[i]] = sgn ? sgn[i] * x[i] : x[i];
 }
-__global__ void k_gather_rows(const int n, const int32_t *__restrict__ rows, const double *__restrict__ g, double *__restrict__ y) {
+__global__ void k_gather_rows(const int n, const int32_t *__restrict__ rows, const double *__restrict__ sgn,
+                              const double *__restrict__ g, double *__restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] = g[rows[i]];
+  if (i < n) y[i] = sgn ? sgn[i] * g[rows[i]] : g[rows[i]];
 }
 }  // namespace
 ReplicatedSolver::ReplicatedSolver(const Context &ctx, const Halo &gather, const Solver &inner, const int32_t *mine_host, int n_true,
-                                   int n_global)
+                                   int n_global, const double *sign_host)
     : ctx_(&ctx), gather_(&gather), inner_(&inner), n_true_(n_true), n_global_(n_global) {
   PA_REQUIRE(n_true >= 0 && n_true <= n_global && inner.Height() == n_global, "replicated solver: sizes do not match");
   for (int i = 0; i < n_true; i++) PA_REQUIRE(mine_host[i] >= 0 && mine_host[i] < n_global, "global dof number out of range");
   height = width = n_true;
   if (n_true) d_mine_ = pa::dev_upload(mine_host, (size_t)n_true, ctx.stream);
+  if (n_true && sign_host) d_sign_ = pa::dev_upload(sign_host, (size_t)n_true, ctx.stream);
   gx_.SetSize(n_global), gy_.SetSize(n_global);
   linalg::Fill(ctx, gx_, 0.0);
 }
 ReplicatedSolver::~ReplicatedSolver() {
   if (d_mine_) (void)hipFree(d_mine_);
+  if (d_sign_) (void)hipFree(d_sign_);
 }
 void ReplicatedSolver::Mult(const Vector &x, Vector &y) const {
   PhaseRange range("Coarse Solve / Replicated");
   const Context &c = *ctx_;
   PA_REQUIRE(x.Size() == n_true_ && y.Size() == n_true_, "size mismatch in ReplicatedSolver");
   if (n_true_)
-    hipLaunchKernelGGL(k_scatter_rows, dim3((n_true_ + 255) / 256), dim3(256), 0, c.stream, n_true_, d_mine_, x.Data(), gx_.Data());
+    hipLaunchKernelGGL(k_scatter_rows, dim3((n_true_ + 255) / 256), dim3(256), 0, c.stream, n_true_, d_mine_, d_sign_, x.Data(),
+                       gx_.Data());
   gather_->Prolongate(gx_.Data(), c.stream);  // owners -> everybody: the global right-hand side on every rank
   const_cast<Solver *>(inner_)->SetInitialGuess(false);
   inner_->Mult(gx_, gy_);
   if (n_true_)
-    hipLaunchKernelGGL(k_gather_rows, dim3((n_true_ + 255) / 256), dim3(256), 0, c.stream, n_true_, d_mine_, gy_.Data(), y.Data());
+    hipLaunchKernelGGL(k_gather_rows, dim3((n_true_ + 255) / 256), dim3(256), 0, c.stream, n_true_, d_mine_, d_sign_, gy_.Data(),
+                       y.Data());
   PA_HIP(hipGetLastError());
 }
 

@@ -591,10 +591,14 @@ class ReplicatedSolver : public Solver {
   const Solver *inner_;   // solver of the global problem (n_global x n_global)
   int n_true_, n_global_;
   int32_t *d_mine_ = nullptr;  // [n_true] global number of my true dof i
+  double *d_sign_ = nullptr;   // [n_true] +-1: orientation of my dof relative to the global one (nullptr: all +1)
   mutable Vector gx_, gy_;
 
 public:
-  ReplicatedSolver(const Context &ctx, const Halo &gather, const Solver &inner, const int32_t *mine_host, int n_true, int n_global);
+  // sign_host (optional): dof i of this rank is sign[i] times global dof mine[i] -- rank-local meshes may orient an edge against
+  // the global numbering
+  ReplicatedSolver(const Context &ctx, const Halo &gather, const Solver &inner, const int32_t *mine_host, int n_true, int n_global,
+                   const double *sign_host = nullptr);
   ~ReplicatedSolver() override;
   void SetOperator(const Operator &) override {}  // the global problem is the inner solver's
   void Mult(const Vector &x, Vector &y) const override;

@@ -503,13 +503,13 @@ int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max) {
     *lambda_max = c->LambdaMax();
   });
 }
-int pa_replicated_solver_create(pa_context *ctx, pa_halo *gather, pa_solver *inner, const int32_t *mine, int n_true, int n_global,
-                                pa_solver **S) {
+int pa_replicated_solver_create(pa_context *ctx, pa_halo *gather, pa_solver *inner, const int32_t *mine, const double *sign,
+                                int n_true, int n_global, pa_solver **S) {
   return guarded([&] {
     PA_REQUIRE(ctx && gather && inner && S && (mine || n_true == 0), "null argument");
     auto *s = new pa_solver;
     s->ctx = ctx;
-    s->solver = std::make_unique<ReplicatedSolver>(ctx->ctx, *gather->halo, *inner->solver, mine, n_true, n_global);
+    s->solver = std::make_unique<ReplicatedSolver>(ctx->ctx, *gather->halo, *inner->solver, mine, n_true, n_global, sign);
     *S = s;
   });
 }

@@ -188,6 +188,55 @@ def levels_for(p: int):
     return out[::-1]
 
 
+def global_edge_map(slab_space, global_space, slab_height: float, world: int):
+    """Order-1 Nedelec dofs (edges) of one slab against those of the whole cylinder: for the slab's TRUE dofs the global dof number
+    and the relative orientation (+-1: an edge dof points from the lower to the higher vertex number, and the two meshes number
+    their vertices independently), and for every global dof its owning rank (the lowest slab that contains the edge, as in
+    SlabNDSpace).  Matching is geometric: rounded coordinates of the edge's end points."""
+    assert slab_space.p == 1 and global_space.p == 1
+    ms, mg = slab_space.mesh, global_space.mesh
+    scale = 1.0e6 / max(1.0, float(np.abs(mg.vert_coords).max()))
+
+    def keys(vc):
+        q = np.round(vc * scale).astype(np.int64) + (1 << 20)
+        return (q[:, 0] << 42) | (q[:, 1] << 21) | q[:, 2]
+
+    kg, ks = keys(mg.vert_coords), keys(ms.vert_coords)
+    order = np.argsort(kg)
+    pos = np.searchsorted(kg[order], ks)
+    assert (kg[order][pos] == ks).all(), "a slab vertex is not a vertex of the global mesh"
+    v_s2g = order[pos]  # slab vertex -> global vertex
+    ev_s = ms.edge_verts  # [nedges, 2], lower vertex number first: the direction of the dof
+    a, b = v_s2g[ev_s[:, 0]], v_s2g[ev_s[:, 1]]
+    nvg = mg.vert_coords.shape[0]
+    ekey_g = mg.edge_verts[:, 0].astype(np.int64) * nvg + mg.edge_verts[:, 1]
+    eorder = np.argsort(ekey_g)
+    ekey_s = np.minimum(a, b) * nvg + np.maximum(a, b)
+    epos = np.searchsorted(ekey_g[eorder], ekey_s)
+    assert (ekey_g[eorder][epos] == ekey_s).all(), "a slab edge is not an edge of the global mesh"
+    e_s2g = eorder[epos]
+    sgn = np.where(a < b, 1.0, -1.0)  # same direction as the global dof (lower global vertex first) or against it
+    ldof = slab_space._perm[slab_space.edge_base + np.arange(ms.nedges)]  # (one dof per edge at order 1)
+    true = ldof < slab_space.n_true
+    mine = np.empty(slab_space.n_true, dtype=np.int32)
+    sign = np.empty(slab_space.n_true, dtype=np.float64)
+    mine[ldof[true]] = global_space.edge_base + e_s2g[true]
+    sign[ldof[true]] = sgn[true]
+    # owners: the lowest slab whose z-range contains both end points
+    z = mg.vert_coords[:, 2]
+    tol = 1e-6 * max(1.0, float(np.abs(z).max()))
+    zlo = np.minimum(z[mg.edge_verts[:, 0]], z[mg.edge_verts[:, 1]])
+    owner = np.clip(np.floor((zlo + tol) / slab_height).astype(np.int64), 0, world - 1)
+    # an edge lying in the plane between slabs q - 1 and q (zlo = zhi = q H) belongs to the lower one
+    zhi = np.maximum(z[mg.edge_verts[:, 0]], z[mg.edge_verts[:, 1]])
+    in_plane = (np.abs(zhi - zlo) < tol) & (np.abs(zlo / slab_height - np.round(zlo / slab_height)) < 1e-6) & (owner > 0)
+    on_boundary = np.abs(zlo - owner * slab_height) < tol
+    owner[in_plane & on_boundary] -= 1
+    full = np.zeros(global_space.ndofs, dtype=np.int64)
+    full[global_space.edge_base + np.arange(mg.nedges)] = owner
+    return mine, sign, full
+
+
 class SlabProblem:
     """Everything bench.py / the multi-rank tests need on one rank: the slab mesh, the level spaces,
     device geometry data, operators, halo objects and solvers."""
@@ -195,6 +244,7 @@ class SlabProblem:
     def __init__(self, ctx, rank, world, p, dofs_per_rank, levels=True, radius=2.74, shape=None, device=True):
         self.ctx, self.rank, self.world, self.p = ctx, rank, world, p
         n, nz = shape if shape is not None else slab_shape(dofs_per_rank, p)
+        self.shape = (n, nz)
         h_layer = 2.0 * radius / max(1, round(1.15 * n))  # roughly isotropic elements
         self.height = nz * h_layer
         z_lo = rank * self.height
@@ -284,14 +334,33 @@ class SlabProblem:
             # a nonlinear preconditioner and costs the outer PCG 40 % more iterations; scripts/coarse_tune.py)
             if coarse == "chebyshev":
                 csolver = linalg.chebyshev(ctx, A[0], 4)
-            elif coarse == "ams":
-                # the native auxiliary-space solver on the assembled level (linalg/ams.cpp; ksp.cpp:166-186), one rank
+            elif coarse == "ams" and self.world == 1:
+                # the native auxiliary-space solver on the assembled level (linalg/ams.cpp; ksp.cpp:166-186)
                 from .fespace import H1HexSpace, lowest_order_gradient, vertex_coordinates
 
-                assert self.world == 1 and self.orders[0] == 1 and coarse_assembled, "AMS: one rank, assembled order-1 level"
+                assert self.orders[0] == 1 and coarse_assembled, "AMS: assembled order-1 level"
                 h1_0 = H1HexSpace(self.mesh, 1)
                 csolver = linalg.ams(ctx, csr0, self.ess[0], lowest_order_gradient(h1_0, self.spaces[0]),
                                      vertex_coordinates(h1_0))
+            elif coarse == "ams":
+                # several ranks: the order-1 problem of the WHOLE cylinder is assembled and solved redundantly by every rank
+                # (linalg.replicated: the right-hand side gathered through a halo plan on the global-numbered vector)
+                from .fespace import H1HexSpace, NDHexSpace, lowest_order_gradient, vertex_coordinates
+
+                assert self.orders[0] == 1, "AMS: order-1 level"
+                n, nz = self.shape
+                gmesh = ogrid_cylinder(n, nz * self.world, radius=self.radius, height=self.height * self.world)
+                g_nd, g_h1 = NDHexSpace(gmesh, 1), H1HexSpace(gmesh, 1)
+                geom_g = ceed.GeomFactorData(gmesh, self.q1d)
+                op_g = ceed.curlcurlmass_operator(geom_g, g_nd, mass, curl)
+                csr_g = op_g.full_assemble_device()
+                inner = linalg.ams(ctx, csr_g, g_nd.ess_dofs(), lowest_order_gradient(g_h1, g_nd), vertex_coordinates(g_h1))
+                mine, sign, owner = global_edge_map(self.spaces[0], g_nd, self.height, self.world)
+                others = [q for q in range(self.world) if q != self.rank]
+                gather = linalg.Halo(ctx, others, [np.sort(mine).astype(np.int32) for _ in others],
+                                     [np.nonzero(owner == q)[0].astype(np.int32) for q in others])
+                csolver = linalg.replicated(ctx, gather, inner, mine, g_nd.ndofs, sign=sign)
+                self._keep.append((geom_g, op_g, csr_g, inner, gather))
             else:
                 csolver = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
             B = linalg.gmg(ctx, A, P, csolver, cheby_order=max(2 * self.p, 4), **aux)

@@ -491,16 +491,18 @@ def amg(ctx, csr, ess_tdofs=(), max_levels=0, coarse_size=0, smooth_order=0, the
     return Solver(ctx, h, (csr,))
 
 
-def replicated(ctx, gather_halo, inner, mine_global, n_global):
+def replicated(ctx, gather_halo, inner, mine_global, n_global, sign=None):
     """ReplicatedSolver: `inner` (a solver of the global problem, the same on every rank) applied to the right-hand side gathered
-    from all ranks through `gather_halo` (a Halo on the global-numbered vector); mine_global[i] = global number of true dof i."""
+    from all ranks through `gather_halo` (a Halo on the global-numbered vector); mine_global[i] = global number of true dof i,
+    sign[i] = +-1 its orientation relative to the global dof (None: all +1)."""
     mine = np.ascontiguousarray(mine_global, dtype=np.int32)
+    sg = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
     h = C.c_void_p()
     L = _L()
-    L.pa_replicated_solver_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    _lib.check(L.pa_replicated_solver_create(ctx.handle, gather_halo.handle, inner.handle, _ptr(mine), mine.size, int(n_global),
-                                             C.byref(h)))
-    return Solver(ctx, h, (gather_halo, inner, mine))
+    L.pa_replicated_solver_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    _lib.check(L.pa_replicated_solver_create(ctx.handle, gather_halo.handle, inner.handle, _ptr(mine),
+                                             _ptr(sg) if sg is not None else None, mine.size, int(n_global), C.byref(h)))
+    return Solver(ctx, h, (gather_halo, inner, mine, sg))
 
 
 def ams(ctx, csr, ess_tdofs, G, coords, cycle_it=0, smooth_order=0, singular=False, amg_coarse_size=0, amg_smooth_order=0,

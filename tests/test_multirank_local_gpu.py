@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 NZ = 8
 
 
-def _rank_main(group, rank, world, p, hiptmair, out, errors):
+def _rank_main(group, rank, world, p, hiptmair, out, errors, coarse="cg"):
     try:
         import torch
 
@@ -25,7 +25,7 @@ def _rank_main(group, rank, world, p, hiptmair, out, errors):
         if world > 1:
             ctx.init_comm_local(group, rank)
         prob = SlabProblem(ctx, rank, world, p, 0, shape=(2, NZ // world))
-        K, b, x = prob.pcg_gmg_solver(max_it=200, rel_tol=1e-9, hiptmair=hiptmair, coarse="cg")
+        K, b, x = prob.pcg_gmg_solver(max_it=200, rel_tol=1e-9, hiptmair=hiptmair, coarse=coarse)
         K.mult(b, x)
         st = K.stats()
         A = prob._keep[-1][1][-1]
@@ -56,12 +56,12 @@ def _rank_main(group, rank, world, p, hiptmair, out, errors):
         raise
 
 
-def _run(world, p, hiptmair):
+def _run(world, p, hiptmair, coarse="cg"):
     from palace_amd import linalg
 
     group = linalg.LocalGroup(world) if world > 1 else None
     out, errors = [None] * world, []
-    threads = [threading.Thread(target=_rank_main, args=(group, r, world, p, hiptmair, out, errors), daemon=True)
+    threads = [threading.Thread(target=_rank_main, args=(group, r, world, p, hiptmair, out, errors, coarse), daemon=True)
                for r in range(world)]
     for t in threads:
         t.start()
@@ -89,6 +89,22 @@ def test_ranks_as_threads_match_one_rank(p, hiptmair):
         for k in ("bb", "bAb", "zz", "crcr", "cici", "crci"):  # operator applies: rounding only
             assert abs(many[k] - one[k]) < 1e-11 * abs(one[k]), (world, k, many[k], one[k])
         for k in ("xx", "xAx"):  # solves to 1e-9
+            assert abs(many[k] - one[k]) < 1e-6 * abs(one[k]), (world, k, many[k], one[k])
+
+
+def test_slab_ranks_with_the_replicated_ams_coarse_solve():
+    """The hexahedral cylinder cut into z-slabs (bench.py's partition) with the native AMS on level 0 across ranks: every rank
+    assembles the order-1 problem of the whole cylinder and applies the same solver to the gathered right-hand side
+    (partition.global_edge_map gives the global dof and the orientation sign of every slab edge).  Same solve as on one rank."""
+    one = _run(1, 3, True, "ams")
+    assert one["converged"]
+    for world in (2, 4):
+        many = _run(world, 3, True, "ams")
+        assert many["converged"] and many["n"] == one["n"]
+        assert abs(many["iterations"] - one["iterations"]) <= 1, (world, many["iterations"], one["iterations"])
+        for k in ("bb", "bAb", "zz"):
+            assert abs(many[k] - one[k]) < 1e-11 * abs(one[k]), (world, k, many[k], one[k])
+        for k in ("xx", "xAx"):
             assert abs(many[k] - one[k]) < 1e-6 * abs(one[k]), (world, k, many[k], one[k])
 
 

@@ -192,3 +192,28 @@ def test_ghosts_are_the_contiguous_tail_of_the_local_vector(world, rank):
             assert np.array_equal(recv, np.arange(s.n_true, s.ndofs))
         if send.size:
             assert send.min() >= 0 and send.max() < s.n_true and np.unique(send).size == send.size
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_edges_against_the_global_order_one_space(world):
+    """partition.global_edge_map (the replicated level-0 solve of the slab problems): every global edge dof has exactly one owner
+    among the slabs, the slabs' true dofs map onto them one to one, and with the orientation signs the Nedelec interpolant of a
+    field on a slab equals the global interpolant entry by entry."""
+    from palace_amd.fem.fespace import NDHexSpace
+    from palace_amd.fem.mesh import ogrid_cylinder
+    from palace_amd.fem.partition import SlabProblem, global_edge_map
+    from tests import util
+
+    probs = [SlabProblem(None, r, world, 3, 0, shape=(2, 2), device=False) for r in range(world)]
+    gm = ogrid_cylinder(2, 2 * world, radius=probs[0].radius, height=probs[0].height * world)
+    g = NDHexSpace(gm, 1)
+    ug = util.nd_interpolate(g, _field)
+    seen = np.zeros(g.ndofs, dtype=int)
+    for r, pr in enumerate(probs):
+        s0 = pr.spaces[0]
+        mine, sign, owner = global_edge_map(s0, g, pr.height, world)
+        assert (owner[mine] == r).all() and set(np.nonzero(owner == r)[0]) == set(mine.tolist())
+        seen[mine] += 1
+        ul = util.nd_interpolate(s0, _field)[: s0.n_true]
+        assert np.abs(sign * ul - ug[mine]).max() < 1e-12
+    assert (seen == 1).all()
