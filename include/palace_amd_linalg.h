@@ -59,6 +59,21 @@ int pa_comm_peer_connect(pa_context *ctx, const char *handles /* [size][64] */);
 int pa_comm_peer_disconnect(pa_context *ctx); /* RCCL communicators: back to send / receive groups and ncclAllReduce */
 int pa_comm_peer_ready(const pa_context *ctx);
 int pa_comm_peer_check(pa_context *ctx);
+/* Ordering tier of the transport (process-wide): 0 (default) relaxed system-scope atomics + s_waitcnt around the flag stores,
+ * 1 system-scope release / acquire fences (an L2 write-back per exchange kernel: slower; the fall-back if the relaxed protocol
+ * fails pa_comm_peer_stress on a machine).  PALACE_AMD_PEER_FENCE=1 selects it from the environment. */
+int pa_comm_peer_set_fenced(int on);
+int pa_comm_peer_fenced(void);
+/* time limit of the device-side waits of the transport, seconds (default 60, PALACE_AMD_PEER_TIMEOUT_S): after it a wait gives
+ * up, the rank's error word is raised and every host synchronisation point of the library (dots, sums, solver statistics,
+ * pa_context_synchronize, pa_comm_peer_check) returns an error.  Longer than any skew between ranks. */
+int pa_comm_peer_set_timeout(double seconds);
+/* Stress test: `rounds` rounds of P, P^T (direct = 0: through the local vector, 1: the direct form of ParOperator::Mult, ghosts
+ * read from the mailbox in place) and a global sum on a RING plan (`ring`: pa_halo over a vector of 2 n entries -- owned
+ * [0, n) sent to rank + 1, ghosts [n, 2 n) owned by rank - 1), payloads that change every round, every received value checked
+ * on the device against its closed form; graph != 0: the round is recorded once and replayed (what the solvers do).
+ * *failures = wrong values seen by this rank; a timed-out wait is an error return.  Collective. */
+int pa_comm_peer_stress(pa_context *ctx, pa_halo *ring, int n, int rounds, int direct, int graph, long long *failures);
 int pa_halo_uses_peer(const pa_halo *halo);
 int pa_context_rank(const pa_context *ctx);
 int pa_context_size(const pa_context *ctx);

@@ -105,8 +105,9 @@ public:
             const std::vector<char> &ess_flag, const AmsOptions &opt = AmsOptions());
   void SetOperator(const Operator &) override {}
   void Mult(const Vector &b, Vector &x) const override;
-  const AmgSolver &GradientSpaceSolver() const { return *BG_; }
-  const AmgSolver &NodalSpaceSolver() const { return *BPi_; }
+  // (null for a singular operator: no gradient-space correction, ams.cpp:28-30)
+  const AmgSolver *GradientSpaceSolver() const { return BG_.get(); }
+  const AmgSolver *NodalSpaceSolver() const { return BPi_.get(); }
 };
 
 }  // namespace palace

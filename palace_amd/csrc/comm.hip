@@ -113,6 +113,7 @@ Comm::~Comm() {
   if (d_remote_) (void)hipFree(d_remote_);
   if (setup_stream_) (void)hipStreamDestroy(setup_stream_);
   if (arena_) (void)hipFree(arena_);
+  if (h_err_) (void)hipHostFree(h_err_);
 }
 
 void LocalGroup::Arrive() {
@@ -185,7 +186,11 @@ void Halo::Validate(int n_true, int n_local) const {
 
 void Comm::AllReduceSum(double *d_buf, int n, hipStream_t s) {
   if (size_ == 1) return;
-  if (PeerReady() && n <= kMaxReduce && !std::getenv("PALACE_AMD_PEER_NO_REDUCE")) return PeerAllReduce(d_buf, n, s);
+  if (PeerReady() && (!nccl_ || !std::getenv("PALACE_AMD_PEER_NO_REDUCE"))) {
+    // (more values than one message holds: in pieces -- a communicator without RCCL has no other way)
+    for (int i0 = 0; i0 < n; i0 += kMaxReduce) PeerAllReduce(d_buf + i0, std::min(kMaxReduce, n - i0), s);
+    return;
+  }
   if (local_) {  // values to the host, barrier, sum in rank order (the same on every rank), barrier, back to the device
     PA_REQUIRE(n <= LocalGroup::kMaxValues, "too many values for the in-process all-reduce");
     double *mine = local_->slots_.data() + (size_t)rank_ * LocalGroup::kMaxValues;
@@ -200,6 +205,7 @@ void Comm::AllReduceSum(double *d_buf, int n, hipStream_t s) {
     PA_HIP(hipStreamSynchronize(s));
     return;
   }
+  PA_REQUIRE(nccl_, "global sum: this communicator has neither RCCL nor a connected peer transport");
   PA_NCCL(rccl().AllReduce(d_buf, d_buf, (size_t)n, kNcclFloat64, kNcclSum, nccl_, s));
 }
 
@@ -208,8 +214,14 @@ void Comm::Barrier(hipStream_t s) {
     d_one_ = pa::dev_alloc<double>(1);
     PA_HIP(hipMemset(d_one_, 0, sizeof(double)));
   }
-  AllReduceSum(d_one_, 1, s);
+  // peer transport: the set-up channel (own sequence counter, flags and slots), so that a barrier on another stream than the
+  // solvers' (PeerSetup) never touches the counters of all-reduces still queued there
+  if (size_ > 1 && PeerReady())
+    PeerAllReduce(d_one_, 1, s, 1);
+  else
+    AllReduceSum(d_one_, 1, s);
   PA_HIP(hipStreamSynchronize(s));
+  PeerCheckNow();
 }
 
 void Halo::ExchangeLocal(const double *sendbase, const std::vector<int> &send_off, double *recvbase,
@@ -298,13 +310,17 @@ namespace {
 constexpr unsigned long long kDescMagic = 0x70616c6163654844ull;
 // arena layout (bytes): error word | all-reduce sequence | all-reduce flags [kMaxRanks] | all-reduce slots
 // [2][kMaxRanks][kMaxReduce] | halo descriptors [kMaxHalos] | mailboxes ...
-constexpr size_t kOffErr = 0, kOffArSeq = 8, kOffArFlags = 64;
-constexpr size_t kOffArSlots = 1024;
-constexpr size_t kArSlotBytes = 2ull * Comm::kMaxRanks * Comm::kMaxReduce * sizeof(double);
-constexpr size_t kOffDesc = ((kOffArSlots + kArSlotBytes + 4095) / 4096) * 4096;
+// two all-reduce channels: 0 = the solvers' global sums (context stream), 1 = set-up barriers (Comm::Barrier)
+constexpr size_t kOffArSeq[2] = {8, 16};
+constexpr size_t kOffArFlags[2] = {64, 64 + 8 * Comm::kMaxRanks};
+constexpr size_t kOffArSlots[2] = {2048, 2048 + 2ull * Comm::kMaxRanks * Comm::kMaxReduce * sizeof(double)};
+constexpr int kArMaxN[2] = {Comm::kMaxReduce, Comm::kMaxReduceSetup};
+constexpr size_t kArSlotBytes = 2ull * Comm::kMaxRanks * (Comm::kMaxReduce + Comm::kMaxReduceSetup) * sizeof(double);
+static_assert(kOffArFlags[1] + 8 * Comm::kMaxRanks <= kOffArSlots[0], "arena header layout");
+constexpr size_t kOffDesc = ((kOffArSlots[0] + kArSlotBytes + 4095) / 4096) * 4096;
 
 struct HaloDesc {
-  unsigned long long ready;  // kDescMagic once the owner has filled it
+  unsigned long long ready;  // kDescMagic + plan id once the owner has filled it (a slot is reused by plan id + kMaxHalos)
   int nnbr, nrecv, nsend, pad;
   int nbr[Comm::kMaxNbr], recv_off[Comm::kMaxNbr + 1], send_off[Comm::kMaxNbr + 1];
   unsigned long long off_mb[2], off_local;  // byte offsets in the owner's arena: mailboxes of P / P^T, its PeerLocal
@@ -338,7 +354,13 @@ struct PeerNbr {
   int rn[2];                    // what I receive from it in P / P^T
 };
 
-constexpr long long kSpinTimeoutTicks = 500000000ll;  // wall_clock64 runs at 100 MHz: five seconds
+// wall_clock64 runs at 100 MHz.  The limit only exists so that a lost message cannot hang the GPU for good; it has to be
+// longer than any skew between ranks (host-side set-up of a coarse solver, graph instantiation, rank-0 I/O): one minute by
+// default, PALACE_AMD_PEER_TIMEOUT_S.  A rank whose wait has timed out raises its error word (host memory: every host
+// synchronisation point of the library looks at it) and gives up on every later wait at once instead of queueing minutes of
+// further time-outs.
+__device__ long long g_spin_ticks = 6000000000ll;
+__device__ int g_peer_fence = 0;  // 1: system-scope release / acquire fences (Comm::SetFenced)
 
 // Memory ordering without system-scope fences.  A release / acquire fence at system scope writes back / invalidates the
 // whole L2 -- with megabytes of freshly written vector data in it that costs more than the exchange (measured: every block
@@ -360,19 +382,29 @@ __device__ __forceinline__ void st_sys_f64(double *p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ void stores_performed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void stores_performed() {
+  if (g_peer_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (system scope: L2 write-back, then the wait)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void messages_arrived() {
+  if (g_peer_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
 
-// waits until *p >= want; gives up (and raises *err) after kSpinTimeoutTicks so that a lost message cannot hang the GPU
+// waits until *p >= want; gives up (and raises *err) after g_spin_ticks so that a lost message cannot hang the GPU
 __device__ bool spin_ge(const unsigned long long *p, unsigned long long want, unsigned long long *err) {
+  if (ld_sys(p) >= want) return true;
   const long long t0 = wall_clock64();
-  while (ld_sys(p) < want) {
-    if (wall_clock64() - t0 > kSpinTimeoutTicks) {
-      st_sys(err, 1ull);
-      return false;
+  for (unsigned it = 1;; it++) {
+    if (ld_sys(p) >= want) return true;
+    if ((it & 255u) == 0) {
+      if (ld_sys(err)) return false;  // this rank has already given up on a wait
+      if (wall_clock64() - t0 > g_spin_ticks) {
+        st_sys(err, 1ull);
+        return false;
+      }
     }
     __builtin_amdgcn_s_sleep(4);
   }
-  return true;
 }
 
 // true in the block that finishes last of `nblocks` (every one's stores have been performed by then)
@@ -402,6 +434,7 @@ __device__ __forceinline__ void wait_exchange(const PeerNbr *nb, const int nnbr,
     if (nb[k].rn[dir] > 0) spin_ge(&L->flag[dir][k], s, err);
     if (nb[k].n[dir] > 0 && s > 0) spin_ge(&L->ack[dir][k], s - 1ull, err);
   }
+  messages_arrived();
   __syncthreads();
 }
 
@@ -559,32 +592,37 @@ __global__ __launch_bounds__(256) void k_peer_consume_r(const PeerNbr *__restric
 // global sum: my values into everybody's slot of me, flags; then wait for everybody and add in rank order (the same result,
 // bit for bit, on every rank).  Double-buffered: a rank can be one sum ahead of another, never two (it needs the other's flag
 // of the sum in between).
+struct ArChannel {
+  size_t seq, flags, slots;  // byte offsets in every rank's arena
+  int maxn;                  // doubles per rank and buffer
+};
 __global__ void k_ar_send(char *const *__restrict__ remote, const int me, const int size, char *__restrict__ mine,
-                          const double *__restrict__ vals, const int n) {
-  unsigned long long *seq = reinterpret_cast<unsigned long long *>(mine + kOffArSeq);
+                          const double *__restrict__ vals, const int n, const ArChannel ch) {
+  unsigned long long *seq = reinterpret_cast<unsigned long long *>(mine + ch.seq);
   const unsigned long long s = *seq + 1ull;
   const size_t par = (size_t)(s & 1ull);
   for (int t = threadIdx.x; t < size * n; t += blockDim.x) {
     const int r = t / n, i = t - r * n;
-    double *slots = reinterpret_cast<double *>(remote[r] + kOffArSlots);
-    st_sys_f64(&slots[(par * Comm::kMaxRanks + me) * Comm::kMaxReduce + i], vals[i]);
+    double *slots = reinterpret_cast<double *>(remote[r] + ch.slots);
+    st_sys_f64(&slots[(par * Comm::kMaxRanks + me) * ch.maxn + i], vals[i]);
   }
   stores_performed();
   __syncthreads();
   for (int r = threadIdx.x; r < size; r += blockDim.x)
-    st_sys(reinterpret_cast<unsigned long long *>(remote[r] + kOffArFlags) + me, s);
+    st_sys(reinterpret_cast<unsigned long long *>(remote[r] + ch.flags) + me, s);
   if (threadIdx.x == 0) *seq = s;
 }
-__global__ void k_ar_sum(char *__restrict__ mine, const int size, const int n, double *__restrict__ out) {
-  const unsigned long long s = *reinterpret_cast<const unsigned long long *>(mine + kOffArSeq);
-  unsigned long long *err = reinterpret_cast<unsigned long long *>(mine + kOffErr);
-  const unsigned long long *flags = reinterpret_cast<const unsigned long long *>(mine + kOffArFlags);
+__global__ void k_ar_sum(char *__restrict__ mine, const int size, const int n, double *__restrict__ out, const ArChannel ch,
+                         unsigned long long *err) {
+  const unsigned long long s = *reinterpret_cast<const unsigned long long *>(mine + ch.seq);
+  const unsigned long long *flags = reinterpret_cast<const unsigned long long *>(mine + ch.flags);
   for (int r = threadIdx.x; r < size; r += blockDim.x) spin_ge(&flags[r], s, err);
+  messages_arrived();
   __syncthreads();
-  const double *slots = reinterpret_cast<const double *>(mine + kOffArSlots) + (size_t)(s & 1ull) * Comm::kMaxRanks * Comm::kMaxReduce;
+  const double *slots = reinterpret_cast<const double *>(mine + ch.slots) + (size_t)(s & 1ull) * Comm::kMaxRanks * ch.maxn;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     double sum = 0.0;
-    for (int r = 0; r < size; r++) sum += ld_sys_f64(&slots[(size_t)r * Comm::kMaxReduce + i]);
+    for (int r = 0; r < size; r++) sum += ld_sys_f64(&slots[(size_t)r * ch.maxn + i]);
     out[i] = sum;
   }
 }
@@ -610,8 +648,32 @@ void Comm::AllocArena() {
   arena_ = static_cast<char *>(p);
   PA_HIP(hipMemset(arena_, 0, kOffDynamic));
   arena_used_ = kOffDynamic;
+  halo_live_.assign((size_t)kMaxHalos, 0);
   PA_HIP(hipStreamCreateWithFlags(&setup_stream_, hipStreamNonBlocking));
+  // the error word of the wait loops: host memory mapped into the device (written by a kernel only when a wait times out)
+  void *he = nullptr;
+  PA_HIP(hipHostMalloc(&he, 64, hipHostMallocMapped));
+  h_err_ = static_cast<unsigned long long *>(he);
+  *h_err_ = 0ull;
+  if (const char *t = std::getenv("PALACE_AMD_PEER_TIMEOUT_S")) SetTimeout(atof(t));
+  if (const char *f = std::getenv("PALACE_AMD_PEER_FENCE")) SetFenced(atoi(f) != 0);
 }
+
+namespace {
+bool g_fenced_host = false;
+}
+void Comm::SetTimeout(double seconds) {
+  const long long ticks = (long long)(std::max(0.01, seconds) * 1.0e8);
+  PA_HIP(hipDeviceSynchronize());
+  PA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_spin_ticks), &ticks, sizeof(ticks)));
+}
+void Comm::SetFenced(bool on) {
+  const int v = on ? 1 : 0;
+  PA_HIP(hipDeviceSynchronize());
+  PA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_peer_fence), &v, sizeof(v)));
+  g_fenced_host = on;
+}
+bool Comm::Fenced() { return g_fenced_host; }
 
 Comm::Comm(int rank, int size) : rank_(rank), size_(size) {
   PA_REQUIRE(size >= 1 && rank >= 0 && rank < size, "bad communicator arguments");
@@ -642,7 +704,15 @@ void Comm::PeerConnect(const char *handles) {
     hipIpcMemHandle_t h;
     std::memcpy(&h, handles + (size_t)r * kPeerHandleBytes, sizeof(h));
     void *p = nullptr;
-    PA_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    const hipError_t rc = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (rc != hipSuccess) {  // all or nothing: a half-connected transport must not look ready
+      (void)hipGetLastError();
+      for (size_t q = 0; q < remote_.size(); q++)
+        if (remote_ipc_[q]) (void)hipIpcCloseMemHandle(remote_[q]);
+      remote_.clear(), remote_ipc_.clear();
+      if (size_ == 1) remote_.assign(1, arena_), remote_ipc_.assign(1, 0);
+      throw pa::Error(std::string("peer transport: cannot map the arena of rank ") + std::to_string(r) + ": " + hipGetErrorString(rc));
+    }
     remote_[r] = static_cast<char *>(p), remote_ipc_[r] = 1;
   }
   if (d_remote_) (void)hipFree(d_remote_);
@@ -654,15 +724,30 @@ void Comm::PeerDisconnect() {
   for (size_t r = 0; r < remote_.size(); r++)
     if (remote_ipc_[r]) (void)hipIpcCloseMemHandle(remote_[r]);
   remote_.clear(), remote_ipc_.clear();
+  if (h_err_) *h_err_ = 0ull;  // (what the transport noted no longer concerns the RCCL path)
 }
 
 size_t Comm::PeerAlloc(size_t bytes) {
-  const size_t off = (arena_used_ + 255) & ~size_t(255);
-  PA_REQUIRE(off + bytes <= arena_bytes_, "peer arena exhausted (PALACE_AMD_PEER_ARENA_MB)");
-  arena_used_ = off + bytes;
+  bytes = (bytes + 255) & ~size_t(255);
+  // a block a destroyed plan gave back (best fit, at most twice the size), else fresh space
+  size_t best = arena_free_.size();
+  for (size_t i = 0; i < arena_free_.size(); i++)
+    if (arena_free_[i].second >= bytes && arena_free_[i].second <= 2 * bytes &&
+        (best == arena_free_.size() || arena_free_[i].second < arena_free_[best].second))
+      best = i;
+  size_t off;
+  if (best < arena_free_.size()) {
+    off = arena_free_[best].first;
+    arena_free_.erase(arena_free_.begin() + (long)best);
+  } else {
+    off = (arena_used_ + 255) & ~size_t(255);
+    PA_REQUIRE(off + bytes <= arena_bytes_, "peer arena exhausted (PALACE_AMD_PEER_ARENA_MB)");
+    arena_used_ = off + bytes;
+  }
   PA_HIP(hipMemset(arena_ + off, 0, bytes));
   return off;
 }
+void Comm::PeerFree(size_t off, size_t bytes) { arena_free_.emplace_back(off, (bytes + 255) & ~size_t(255)); }
 
 bool Comm::GraphSafe() const {
   if (size_ == 1) return true;
@@ -671,21 +756,24 @@ bool Comm::GraphSafe() const {
 }
 
 void Comm::PeerCheck(hipStream_t s) {
-  if (!arena_) return;
-  unsigned long long e = 0;
-  PA_HIP(hipMemcpyAsync(&e, arena_ + kOffErr, sizeof(e), hipMemcpyDeviceToHost, s));
+  if (!h_err_) return;
   PA_HIP(hipStreamSynchronize(s));
-  if (e) {
-    PA_HIP(hipMemsetAsync(arena_ + kOffErr, 0, sizeof(e), s));
-    throw pa::Error("peer transport: a wait for another rank's message timed out (a rank stopped, or the plans of two "
-                    "ranks do not match)");
+  PeerCheckNow();
+}
+void Comm::PeerCheckNow() {
+  if (!h_err_) return;
+  if (*static_cast<volatile unsigned long long *>(h_err_)) {
+    // (the word stays raised: the ranks are out of step from here on, every later check reports it again)
+    throw pa::Error("peer transport: a wait for another rank's message timed out (a rank stopped or fell more than "
+                    "PALACE_AMD_PEER_TIMEOUT_S behind, or the plans of two ranks do not match); results after this point are not valid");
   }
 }
 
-void Comm::PeerAllReduce(double *d_buf, int n, hipStream_t s) {
-  PA_REQUIRE(n <= kMaxReduce, "too many values for the peer all-reduce");
-  hipLaunchKernelGGL(k_ar_send, dim3(1), dim3(256), 0, s, d_remote_, rank_, size_, arena_, d_buf, n);
-  hipLaunchKernelGGL(k_ar_sum, dim3(1), dim3(256), 0, s, arena_, size_, n, d_buf);
+void Comm::PeerAllReduce(double *d_buf, int n, hipStream_t s, int channel) {
+  PA_REQUIRE(channel >= 0 && channel < 2 && n <= kArMaxN[channel], "too many values for the peer all-reduce");
+  const ArChannel ch{kOffArSeq[channel], kOffArFlags[channel], kOffArSlots[channel], kArMaxN[channel]};
+  hipLaunchKernelGGL(k_ar_send, dim3(1), dim3(256), 0, s, d_remote_, rank_, size_, arena_, d_buf, n, ch);
+  hipLaunchKernelGGL(k_ar_sum, dim3(1), dim3(256), 0, s, arena_, size_, n, d_buf, ch, h_err_);
   PA_HIP(hipGetLastError());
 }
 
@@ -698,39 +786,73 @@ struct Halo::PeerPlan {
   int4 *d_rinfo = nullptr;
   int32_t *d_rptr = nullptr, *d_rpos = nullptr;
   unsigned long long *d_err = nullptr;
+  int slot = -1;                    // descriptor slot (given back with the plan)
+  size_t off[3] = {0, 0, 0}, bytes[3] = {0, 0, 0};  // my arena blocks: mailboxes of P / P^T, flags
 };
 
 void Halo::PeerSetup(const int32_t *send_idx) {
   Comm &c = *comm_;
   const int nn = (int)nbr_.size();
-  PA_REQUIRE(nn <= Comm::kMaxNbr, "too many neighbours for the peer transport");
+  // Plan ids count the plans made on this communicator (collective: the same on every rank); the descriptor lives in slot
+  // id mod kMaxHalos and carries its id, slots and arena blocks of destroyed plans are used again.  Everything that can fail
+  // locally is decided BEFORE the barrier, and a rank that fails still publishes (an invalid descriptor) and takes part in the
+  // barrier, so that the others fail on its descriptor instead of waiting for it.
   const int id = c.next_halo_++;
-  PA_REQUIRE(id < Comm::kMaxHalos, "too many halo plans for the peer transport");
+  const int slot = id % Comm::kMaxHalos;
+  std::string fail;
+  if (nn > Comm::kMaxNbr) fail = "too many neighbours for the peer transport";
+  if (c.halo_live_[(size_t)slot]) fail = "too many live halo plans for the peer transport";
+  const size_t want[3] = {sizeof(double) * 2 * (size_t)std::max(1, nrecv_), sizeof(double) * 2 * (size_t)std::max(1, nsend_),
+                          sizeof(PeerLocal)};
   HaloDesc d;
   std::memset(&d, 0, sizeof(d));
-  d.nnbr = nn, d.nrecv = nrecv_, d.nsend = nsend_;
-  for (int k = 0; k < nn; k++) d.nbr[k] = nbr_[k];
-  for (int k = 0; k <= nn; k++) d.recv_off[k] = recv_off_[k], d.send_off[k] = send_off_[k];
-  d.off_mb[0] = c.PeerAlloc(sizeof(double) * 2 * (size_t)std::max(1, nrecv_));
-  d.off_mb[1] = c.PeerAlloc(sizeof(double) * 2 * (size_t)std::max(1, nsend_));
-  d.off_local = c.PeerAlloc(sizeof(PeerLocal));
-  d.ready = kDescMagic;
-  PA_HIP(hipMemcpy(c.arena_ + kOffDesc + sizeof(HaloDesc) * (size_t)id, &d, sizeof(d), hipMemcpyHostToDevice));
-  c.Barrier(c.setup_stream_);  // every rank has published plan `id`
   auto *pp = new PeerPlan;
+  if (fail.empty()) {
+    try {
+      for (int b = 0; b < 3; b++) pp->off[b] = c.PeerAlloc(want[b]), pp->bytes[b] = want[b];
+    } catch (const pa::Error &e) {
+      fail = e.what();
+      for (int b = 0; b < 3; b++)
+        if (pp->bytes[b]) c.PeerFree(pp->off[b], pp->bytes[b]), pp->bytes[b] = 0;
+    }
+  }
+  if (fail.empty()) {
+    d.nnbr = nn, d.nrecv = nrecv_, d.nsend = nsend_;
+    for (int k = 0; k < nn; k++) d.nbr[k] = nbr_[k];
+    for (int k = 0; k <= nn; k++) d.recv_off[k] = recv_off_[k], d.send_off[k] = send_off_[k];
+    d.off_mb[0] = pp->off[0], d.off_mb[1] = pp->off[1], d.off_local = pp->off[2];
+    d.ready = kDescMagic + (unsigned long long)id;
+  }
+  PA_HIP(hipMemcpy(c.arena_ + kOffDesc + sizeof(HaloDesc) * (size_t)slot, &d, sizeof(d), hipMemcpyHostToDevice));
+  try {
+    c.Barrier(c.setup_stream_);  // every rank has published plan `id`
+  } catch (...) {
+    delete pp;
+    throw;
+  }
+  if (!fail.empty()) {
+    delete pp;
+    throw pa::Error(fail);
+  }
+  c.halo_live_[(size_t)slot] = 1;
+  pp->slot = slot;
+  peer_ = pp;
+  try {  // (a throwing constructor runs no destructor: the slot and the blocks go back here)
   pp->nnbr = nn;
   pp->local = reinterpret_cast<PeerLocal *>(c.arena_ + d.off_local);
   pp->counters = pa::dev_alloc<PeerCounters>(1);
   PA_HIP(hipMemset(pp->counters, 0, sizeof(PeerCounters)));
   pp->mb[0] = reinterpret_cast<double *>(c.arena_ + d.off_mb[0]);
   pp->mb[1] = reinterpret_cast<double *>(c.arena_ + d.off_mb[1]);
-  pp->d_err = reinterpret_cast<unsigned long long *>(c.arena_ + kOffErr);
+  pp->d_err = c.h_err_;
   std::vector<PeerNbr> nb((size_t)nn);
   for (int k = 0; k < nn; k++) {
     const int r = nbr_[k];
     HaloDesc rd;
-    PA_HIP(hipMemcpy(&rd, c.remote_[r] + kOffDesc + sizeof(HaloDesc) * (size_t)id, sizeof(rd), hipMemcpyDeviceToHost));
-    PA_REQUIRE(rd.ready == kDescMagic, "peer transport: a neighbour has not published its halo plan");
+    PA_HIP(hipMemcpy(&rd, c.remote_[r] + kOffDesc + sizeof(HaloDesc) * (size_t)slot, sizeof(rd), hipMemcpyDeviceToHost));
+    PA_REQUIRE(rd.ready == kDescMagic + (unsigned long long)id,
+               "peer transport: a neighbour has not published this halo plan (it failed to set it up, or the ranks create "
+               "their plans in different orders)");
     int j = 0;
     while (j < rd.nnbr && rd.nbr[j] != c.rank_) j++;
     const int ns = send_off_[k + 1] - send_off_[k], nr = recv_off_[k + 1] - recv_off_[k];
@@ -771,12 +893,20 @@ void Halo::PeerSetup(const int32_t *send_idx) {
     pp->d_rptr = pa::dev_upload(rptr.data(), rptr.size());
     pp->d_rpos = pa::dev_upload(rpos.data(), rpos.size());
   }
-  peer_ = pp;
+  } catch (...) {
+    FreePeer();
+    throw;
+  }
 }
 
 void Halo::FreePeer() {
   if (!peer_) return;
+  // (hipFree waits for the device: no exchange of this plan is in flight on this rank when its blocks go back to the arena;
+  // the neighbours stop using their views of them with their own plan objects -- plans are created and destroyed collectively)
   (void)hipFree(peer_->counters), (void)hipFree(peer_->d_nbr), (void)hipFree(peer_->d_rinfo), (void)hipFree(peer_->d_rptr), (void)hipFree(peer_->d_rpos);
+  for (int b = 0; b < 3; b++)
+    if (peer_->bytes[b]) comm_->PeerFree(peer_->off[b], peer_->bytes[b]);
+  if (peer_->slot >= 0) comm_->halo_live_[(size_t)peer_->slot] = 0;
   delete peer_;
   peer_ = nullptr;
 }
@@ -856,6 +986,109 @@ void Halo::RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) 
   hipLaunchKernelGGL(k_peer_consume_r<2>, dim3(sb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[1], nsend_, d_y,
                      p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, d_mask, nullptr, 0, nullptr, 0, sb);
   PA_HIP(hipGetLastError());
+}
+
+// ---- stress test of the transport (Comm::StressRing) ----------------------------------------------------------------------
+namespace {
+
+// payloads: small integers (exact in double, exact sums), different for every rank, round, entry and purpose
+__device__ __forceinline__ double stress_val(const int rank, const unsigned long long round, const int i, const unsigned salt) {
+  const unsigned h = (unsigned)rank * 1315423911u + (unsigned)round * 2654435761u + (unsigned)i * 97u + salt * 40503u;
+  return (double)((h ^ (h >> 13)) & 0xfffffu);
+}
+// lx[0, n) = owned payload of this round, ghosts poisoned
+__global__ void k_stress_fill(double *lx, const int n, const int rank, const unsigned long long *round) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lx[i] = stress_val(rank, *round, i, 1u), lx[n + i] = -1.0;
+}
+// after P: ghost i (read from `g`, the L-vector tail or the mailbox buffer the exchange counter names) = the left neighbour's
+// owned value; then the ghost rows of P^T are written to `gout`
+__global__ void k_stress_check_p(const double *g0, const double *g1, const unsigned long long *sel, double *gout, const int n,
+                                 const int rank, const int left, const unsigned long long *round, unsigned long long *fail) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double *g = (sel && (*sel & 1ull)) ? g1 : g0;
+  if (g[i] != stress_val(left, *round, i, 1u)) atomicAdd(fail, 1ull);
+  gout[i] = stress_val(rank, *round, i, 2u);
+}
+// after P^T: owned i = its own value + the right neighbour's ghost row
+__global__ void k_stress_check_r(const double *y, const int n, const int rank, const int right, const unsigned long long *round,
+                                 unsigned long long *fail, double *red, const int nred) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && y[i] != stress_val(rank, *round, i, 1u) + stress_val(right, *round, i, 2u)) atomicAdd(fail, 1ull);
+  if (i < nred) red[i] = stress_val(rank, *round, i, 3u);
+}
+__global__ void k_stress_check_sum(const double *red, const int nred, const int size, unsigned long long *round,
+                                   unsigned long long *fail) {
+  const int i = threadIdx.x;
+  if (i < nred) {
+    double want = 0.0;
+    for (int r = 0; r < size; r++) want += stress_val(r, *round, i, 3u);
+    if (red[i] != want) atomicAdd(fail, 1ull);
+  }
+  __syncthreads();
+  if (i == 0) *round += 1ull;
+}
+
+}  // namespace
+
+long long Comm::StressRing(const Halo &ring, int n, int rounds, bool direct, bool graph, hipStream_t s) {
+  PA_REQUIRE(size_ > 1 && PeerReady() && ring.UsesPeerTransport(), "stress test: needs the connected peer transport");
+  PA_REQUIRE(!direct || ring.DirectOk(n, 2 * n), "stress test: the plan has no direct form");
+  const int left = (rank_ + size_ - 1) % size_, right = (rank_ + 1) % size_, nred = 5, nb = (n + 255) / 256;
+  double *lx = pa::dev_alloc<double>((size_t)2 * n), *red = pa::dev_alloc<double>(8);
+  unsigned long long *st = pa::dev_alloc<unsigned long long>(2);  // {round, failures}
+  uint8_t *mask = pa::dev_alloc<uint8_t>((size_t)n);
+  PA_HIP(hipMemsetAsync(st, 0, 2 * sizeof(unsigned long long), s));
+  PA_HIP(hipMemsetAsync(mask, 0, (size_t)n, s));
+  auto round = [&] {
+    hipLaunchKernelGGL(k_stress_fill, dim3(nb), dim3(256), 0, s, lx, n, rank_, st);
+    if (direct) {
+      // ParOperator::Mult's direct form: ghosts are read from the mailbox in place, ghost rows leave from GhostOut()
+      ring.SendDirect(lx, mask, s);
+      hipLaunchKernelGGL(k_stress_check_p, dim3(nb), dim3(256), 0, s, ring.GhostIn(0), ring.GhostIn(1), ring.GhostInSelector(),
+                         ring.GhostOut(), n, rank_, left, st, st + 1);
+      ring.RestrictAddDirect(mask, lx, s);
+    } else {
+      ring.Prolongate(lx, s);
+      hipLaunchKernelGGL(k_stress_check_p, dim3(nb), dim3(256), 0, s, lx + n, lx + n, (const unsigned long long *)nullptr, lx + n,
+                         n, rank_, left, st, st + 1);
+      ring.RestrictAdd(lx, s);
+    }
+    hipLaunchKernelGGL(k_stress_check_r, dim3(nb), dim3(256), 0, s, lx, n, rank_, right, st, st + 1, red, nred);
+    PeerAllReduce(red, nred, s);
+    hipLaunchKernelGGL(k_stress_check_sum, dim3(1), dim3(64), 0, s, red, nred, size_, st, st + 1);
+    PA_HIP(hipGetLastError());
+  };
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  int done = 0;
+  if (graph && rounds > 2) {
+    round(), round(), done = 2;  // (both mailbox buffers have been used once: what a recorded solver iteration starts from)
+    PA_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    round();
+    PA_HIP(hipStreamEndCapture(s, &g));
+    PA_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  }
+  for (; done < rounds; done++) {
+    if (ge)
+      PA_HIP(hipGraphLaunch(ge, s));
+    else
+      round();
+    if ((done & 1023) == 1023) {  // (bounded queue depth; a time-out surfaces here instead of after minutes of them)
+      PA_HIP(hipStreamSynchronize(s));
+      PeerCheckNow();
+    }
+  }
+  unsigned long long h[2] = {0, 0};
+  PA_HIP(hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, s));
+  PA_HIP(hipStreamSynchronize(s));
+  if (ge) (void)hipGraphExecDestroy(ge);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipFree(lx), (void)hipFree(red), (void)hipFree(st), (void)hipFree(mask);
+  PeerCheckNow();
+  PA_REQUIRE((int)h[0] == rounds, "stress test: round counter out of step");
+  return (long long)h[1];
 }
 
 }  // namespace palace

@@ -72,18 +72,25 @@ class Comm {
   bool arena_uncached_ = false;
   std::vector<char *> remote_;         // [size] arena of rank r as mapped here (remote_[rank_] == arena_); empty: not connected
   std::vector<char> remote_ipc_;       // [size] 1: opened with hipIpcOpenMemHandle (to be closed)
-  int next_halo_ = 0;
+  int next_halo_ = 0;                  // halo plans made so far (collective, monotonic: plan id; its descriptor slot is id % kMaxHalos)
+  std::vector<char> halo_live_;        // [kMaxHalos] descriptor slot in use
+  std::vector<std::pair<size_t, size_t>> arena_free_;  // {offset, bytes} blocks given back by destroyed plans
+  unsigned long long *h_err_ = nullptr;  // error word of the wait loops: page-locked host memory the kernels write on a
+                                         // time-out, so that every host synchronisation point can look at it for free
   char **d_remote_ = nullptr;          // device copy of remote_
   double *d_one_ = nullptr;            // Barrier's operand (per communicator)
   hipStream_t setup_stream_ = nullptr; // the transport's own stream for set-up barriers (never the shared null stream:
                                        // the rank threads of an in-process group would queue behind each other's waits)
   void AllocArena();
-  void PeerAllReduce(double *d_buf, int n, hipStream_t s);
+  void PeerAllReduce(double *d_buf, int n, hipStream_t s, int channel = 0);
+  void PeerFree(size_t off, size_t bytes);
 
 public:
   static constexpr int kUniqueIdBytes = 128;
   static constexpr int kPeerHandleBytes = 64;  // sizeof(hipIpcMemHandle_t)
-  static constexpr int kMaxRanks = 64, kMaxReduce = 512, kMaxHalos = 512, kMaxNbr = 32;
+  // (kMaxNbr = kMaxRanks: the gather plan of a replicated coarse solve names every other rank as a neighbour)
+  static constexpr int kMaxRanks = 64, kMaxReduce = 512, kMaxHalos = 512, kMaxNbr = 64;
+  static constexpr int kMaxReduceSetup = 8;  // values of the set-up channel (barriers of PeerSetup: own counters and slots)
   static void GetUniqueId(char *out);
   Comm(int rank, int size, const char *unique_id);
   Comm(int rank, LocalGroup &group);  // rank of an in-process group (see LocalGroup)
@@ -102,6 +109,21 @@ public:
   bool GraphSafe() const;
   // raises if a wait loop of the peer transport has timed out since the last check (waits for the stream)
   void PeerCheck(hipStream_t s);
+  // the same without waiting: for code that has just synchronised the stream anyway (every Dot / Sum / solver statistic
+  // read-back calls it, so a lost message surfaces as an error at the next host synchronisation point, not as a wrong result)
+  void PeerCheckNow();
+  // conservative ordering: system-scope release / acquire fences around the flag stores and waits instead of relaxed atomics +
+  // s_waitcnt (an L2 write-back per exchange kernel: slower; the fall-back tier if the relaxed protocol fails its self-test
+  // on a machine).  Process-wide.
+  static void SetFenced(bool on);
+  static bool Fenced();
+  // time limit of the device-side waits (default 60 s, PALACE_AMD_PEER_TIMEOUT_S); process-wide
+  static void SetTimeout(double seconds);
+  // Stress test of the transport on a ring plan of this communicator (`ring`: Halo over a vector of 2 n entries, owned [0, n),
+  // ghosts [n, 2 n) owned by the left neighbour and sent to the right one): `rounds` rounds of P, P^T (L-vector or direct
+  // form) and a global sum with payloads that change every round, every value verified ON THE DEVICE against its closed form;
+  // graph: the round is recorded once and replayed.  Returns the number of wrong values seen by this rank (time-outs throw).
+  long long StressRing(const class Halo &ring, int n, int rounds, bool direct, bool graph, hipStream_t s);
   // offset of a fresh piece of my arena
   size_t PeerAlloc(size_t bytes);
   char *PeerBase(int r) const { return remote_[r]; }

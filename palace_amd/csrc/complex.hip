@@ -168,6 +168,7 @@ std::complex<double> Dot(const Context &c, const ComplexVector &x, const Complex
   if (c.comm) c.comm->AllReduceSum(s.d + 2 * kMaxB, 2, c.stream);
   PA_HIP(hipMemcpyAsync(s.h, s.d + 2 * kMaxB, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   PA_HIP(hipStreamSynchronize(c.stream));
+  if (c.comm) c.comm->PeerCheckNow();
   return {s.h[0], s.h[1]};
 }
 double Norml2(const Context &c, const ComplexVector &x) { return std::sqrt(std::abs(Dot(c, x, x).real())); }
@@ -210,6 +211,7 @@ std::complex<double> TransposeDot(const Context &c, const ComplexVector &x, cons
   if (c.comm) c.comm->AllReduceSum(s.d + 2 * kMaxB, 2, c.stream);
   PA_HIP(hipMemcpyAsync(s.h, s.d + 2 * kMaxB, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   PA_HIP(hipStreamSynchronize(c.stream));
+  if (c.comm) c.comm->PeerCheckNow();
   return {s.h[0], s.h[1]};
 }
 void Scale(const Context &c, std::complex<double> s, ComplexVector &x) {

@@ -71,8 +71,9 @@ public:
   }
   void Mult(const Vector &b, Vector &x) const override {
     PA_REQUIRE(amg_, "NativeAmgSolver: SetOperator first");
-    amg_->Mult(b, x);
-    for (int it = 1; it < cycle_it_; it++) {  // further cycles as stationary iterations x += B (b - A x)
+    // the cycle itself starts from zero; a caller's guess (Solver::SetInitialGuess) enters as the first stationary step
+    if (!initial_guess) amg_->Mult(b, x);
+    for (int it = initial_guess ? 0 : 1; it < cycle_it_; it++) {  // (further) cycles as stationary iterations x += B (b - A x)
       r_.SetSize(height), z_.SetSize(height);
       A_->Mult(x, r_);
       linalg::AXPBY(*ctx_, 1.0, b, -1.0, r_);
@@ -105,6 +106,7 @@ class NativeAmsSolver : public Solver {  // LinearSolver::AMS
       G.Mult(dx, dy);
       PA_HIP(hipMemcpyAsync(out.data(), dy.Data(), sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost, ctx_->stream));
       PA_HIP(hipStreamSynchronize(ctx_->stream));
+      if (ctx_->comm) ctx_->comm->PeerCheckNow();
     };
     apply(x1, d), apply(x2, q);
     amg::HostCsr Gm;
@@ -148,6 +150,7 @@ public:
   }
   void Mult(const Vector &b, Vector &x) const override {
     PA_REQUIRE(ams_, "NativeAmsSolver: SetOperator first");
+    ams_->SetInitialGuess(initial_guess);  // (the cycles of AmsSolver::Mult honour it in their first smoothing step)
     ams_->Mult(b, x);
   }
 };

@@ -698,6 +698,7 @@ double Dot(const Context &c, const Vector &x, const Vector &y) {
   if (c.comm) c.comm->AllReduceSum(s.d_partial + kMaxBlocks, 1, c.stream);  // Mpi::GlobalSum
   PA_HIP(hipMemcpyAsync(s.h_result, s.d_partial + kMaxBlocks, sizeof(double), hipMemcpyDeviceToHost, c.stream));
   PA_HIP(hipStreamSynchronize(c.stream));
+  if (c.comm) c.comm->PeerCheckNow();  // (a timed-out wait of the peer transport surfaces here, not as a wrong sum)
   return s.h_result[0];
 }
 // H[j] = (w, V[j]) for j < m (global), batches of kDotBatch; w -= sum_j H[j] V[j] if `subtract`
@@ -723,6 +724,8 @@ void MultiDot(const Context &c, const Vector &w, const std::vector<Vector> &V, i
     if (c.comm) c.comm->AllReduceSum(d_out, mb, c.stream);
     PA_HIP(hipMemcpyAsync(s.h_result, d_out, sizeof(double) * mb, hipMemcpyDeviceToHost, c.stream));
     PA_HIP(hipStreamSynchronize(c.stream));
+    if (c.comm) c.comm->PeerCheckNow();
+  if (c.comm) c.comm->PeerCheckNow();  // (a timed-out wait of the peer transport surfaces here, not as a wrong sum)
     for (int j = 0; j < mb; j++) H[j0 + j] = s.h_result[j];
   }
 }
@@ -780,6 +783,7 @@ double Sum(const Context &c, const Vector &x) {
   if (c.comm) c.comm->AllReduceSum(s.d_partial + kMaxBlocks, 1, c.stream);  // Mpi::GlobalSum (vector.hpp)
   PA_HIP(hipMemcpyAsync(s.h_result, s.d_partial + kMaxBlocks, sizeof(double), hipMemcpyDeviceToHost, c.stream));
   PA_HIP(hipStreamSynchronize(c.stream));
+  if (c.comm) c.comm->PeerCheckNow();  // (a timed-out wait of the peer transport surfaces here, not as a wrong sum)
   return s.h_result[0];
 }
 void Sqrt(const Context &c, Vector &x, double s) { launch_ew(OpSqrt{s, x.Data()}, x.Size(), c.stream); }
@@ -1481,6 +1485,7 @@ void CgSolver::Finish() const {
   if (!dev_ || !(dev_->pending || dev_->deferred)) return;
   StreamGraph::RequireNotRecording("CgSolver statistics");
   PA_HIP(hipStreamSynchronize(ctx_->stream));
+  if (ctx_->comm) ctx_->comm->PeerCheckNow();
   dev_->pending = false;
   const double *st = dev_->Slot(0);
   initial_res_ = st[CG_INIT], final_res_ = st[CG_RES], final_it_ = (int)st[CG_IT];
@@ -1547,6 +1552,7 @@ void CgSolver::MultDevice(const Vector &b, Vector &x) const {
   const int R = d.ring;
   d.Snapshot(0, c.stream, true);
   PA_HIP(hipEventSynchronize(d.ev[0]));
+  if (c.comm) c.comm->PeerCheckNow();
   check(d.Slot(0));
   int last = 0;  // ring slot of the newest snapshot
   bool stop = d.Slot(0)[CG_STOP] != 0.0;
@@ -1559,6 +1565,7 @@ void CgSolver::MultDevice(const Vector &b, Vector &x) const {
     if (j >= 0) {
       const int sj = (j + 1) % R;
       PA_HIP(hipEventSynchronize(d.ev[sj]));
+      if (c.comm) c.comm->PeerCheckNow();
       const double *h = d.Slot(sj);
       check(h);
       if (print_ > 1) std::printf("  %3d KSP residual norm ||r||_B = %.6e\n", j + 1, h[CG_RES]);
@@ -1566,6 +1573,7 @@ void CgSolver::MultDevice(const Vector &b, Vector &x) const {
     }
   }
   PA_HIP(hipEventSynchronize(d.ev[last]));
+  if (c.comm) c.comm->PeerCheckNow();
   const double *h = d.Slot(last);
   check(h);
   initial_res_ = h[CG_INIT], final_res_ = h[CG_RES], final_it_ = (int)h[CG_IT];

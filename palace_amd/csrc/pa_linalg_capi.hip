@@ -93,7 +93,10 @@ int pa_context_stream(const pa_context *ctx, void **stream) {
   });
 }
 int pa_context_synchronize(pa_context *ctx) {
-  return guarded([&] { PA_HIP(hipStreamSynchronize(ctx->ctx.stream)); });
+  return guarded([&] {
+    PA_HIP(hipStreamSynchronize(ctx->ctx.stream));
+    if (ctx->comm) ctx->comm->PeerCheckNow();
+  });
 }
 
 int pa_comm_unique_id(char *out128) {
@@ -156,6 +159,19 @@ int pa_comm_peer_ready(const pa_context *ctx) { return ctx && ctx->comm && ctx->
 int pa_comm_peer_check(pa_context *ctx) {
   return guarded([&] {
     if (ctx && ctx->comm) ctx->comm->PeerCheck(ctx->ctx.stream);
+  });
+}
+int pa_comm_peer_set_fenced(int on) {
+  return guarded([&] { Comm::SetFenced(on != 0); });
+}
+int pa_comm_peer_fenced(void) { return Comm::Fenced() ? 1 : 0; }
+int pa_comm_peer_set_timeout(double seconds) {
+  return guarded([&] { Comm::SetTimeout(seconds); });
+}
+int pa_comm_peer_stress(pa_context *ctx, pa_halo *ring, int n, int rounds, int direct, int graph, long long *failures) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && ctx->comm && ring && failures && n > 0 && rounds > 0, "bad arguments");
+    *failures = ctx->comm->StressRing(*ring->halo, n, rounds, direct != 0, graph != 0, ctx->ctx.stream);
   });
 }
 int pa_halo_uses_peer(const pa_halo *halo) { return halo && halo->halo->UsesPeerTransport() ? 1 : 0; }
@@ -580,7 +596,9 @@ static const AmgSolver &amg_of(const pa_solver *S, int which) {
   }
   auto *m = dynamic_cast<const AmsSolver *>(S->solver.get());
   PA_REQUIRE(m && (which == 1 || which == 2), "not an AMS solver / unknown component");
-  return which == 1 ? m->GradientSpaceSolver() : m->NodalSpaceSolver();
+  const AmgSolver *a = which == 1 ? m->GradientSpaceSolver() : m->NodalSpaceSolver();
+  PA_REQUIRE(a, "this AMS solver has no such component (singular operator: no gradient-space solver)");
+  return *a;
 }
 int pa_amg_num_levels(const pa_solver *S, int which, int *nlevels) {
   return guarded([&] {

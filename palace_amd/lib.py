@@ -71,6 +71,11 @@ def load():
     return lib
 
 
+def last_error():
+    """The message of this thread's last failed call (pa_last_error)."""
+    return load().pa_last_error().decode()
+
+
 def check(rc):
     if rc != 0:
-        raise PalaceAmdError(load().pa_last_error().decode())
+        raise PalaceAmdError(last_error())

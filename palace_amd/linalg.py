@@ -4,6 +4,7 @@ multigrid and the p-prolongation, all on float64 CUDA tensors owned by torch."""
 from __future__ import annotations
 
 import ctypes as C
+import json
 import os
 
 import numpy as np
@@ -56,7 +57,9 @@ class Context:
         self.rank, self.size = 0, 1
 
     def init_comm_from_torch_distributed(self):
-        """Create the RCCL communicator; the 128-byte unique id travels over torch.distributed."""
+        """Create the RCCL communicator; the 128-byte unique id travels over torch.distributed.  Halo exchanges and global sums
+        then move to the peer transport if -- and only if -- EVERY rank could map every arena and the transport passed its
+        self-test on this machine; the decision is collective (a rank never ends up on another transport than its peers)."""
         import torch
         import torch.distributed as dist
 
@@ -70,89 +73,156 @@ class Context:
         raw = bytes(t.cpu().numpy().tobytes())
         _lib.check(L.pa_context_init_comm(self.handle, rank, size, raw))
         self.rank, self.size = rank, size
-        # halo exchanges and sums over the peer transport (direct xGMI stores, recordable in HIP graphs) unless
-        # PALACE_AMD_HALO=rccl asks for RCCL's send / receive groups; RCCL stays the fallback if the arenas cannot be mapped
+        self.transport_report = {"transport": "rccl"}
         if size > 1 and os.environ.get("PALACE_AMD_HALO", "peer") != "rccl":
-            try:
-                self._peer_connect_over_torch_distributed("cuda")
-                self._peer_self_test()
-            except Exception as exc:  # noqa: BLE001
-                import sys
-                print(f"palace_amd: peer transport not available ({exc}); using RCCL send / receive", file=sys.stderr)
-                if _L().pa_comm_peer_ready(self.handle):
-                    _lib.check(_L().pa_comm_peer_disconnect(self.handle))
+            self._peer_bring_up(fallback=True)
 
-    def _peer_self_test(self):
-        """One global sum and one ring exchange with known answers through the peer transport (every rank raises together if
-        any rank saw a wrong value or a timed-out wait): the transport has to prove itself on the machine it runs on before
-        the solvers rely on it."""
+    # ---- peer transport: collective bring-up ------------------------------------------------------------------------------
+    def _all_ok(self, ok):
+        """Logical AND of `ok` over the ranks (one small all-reduce on torch.distributed's own backend)."""
         import torch
         import torch.distributed as dist
 
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def _peer_bring_up(self, fallback):
+        """Map the arenas of all ranks and prove the transport on this machine, every step decided by all ranks together:
+        (1) every rank exports its arena handle, (2) the table is gathered, (3) every rank maps every arena, (4) self-test with
+        the relaxed ordering protocol, (5) if -- and only if -- that saw wrong VALUES (no lost message), the same test with
+        system-scope fences; otherwise (6) every rank disconnects and RCCL carries the exchanges (`fallback`; a communicator
+        without RCCL raises instead).  Local failures never skip a collective call: they only turn this rank's vote to 'no'."""
+        import sys
+
+        import torch
+        import torch.distributed as dist
+
+        L = _L()
+        L.pa_comm_peer_set_timeout.argtypes = [C.c_double]
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        rep = {"transport": "peer", "ordering": "relaxed"}
+        why = ""
+        buf = C.create_string_buffer(64)
+        ok = L.pa_comm_peer_handle(self.handle, buf) == 0
+        if not ok:
+            why = _lib.last_error()
+        mine = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)  # (also by a rank whose export failed: its vote below says so)
+        ok = self._all_ok(ok)
+        if ok:
+            table = b"".join(bytes(t.cpu().numpy().tobytes()) for t in parts)
+            ok = L.pa_comm_peer_connect(self.handle, table) == 0
+            if not ok:
+                why = _lib.last_error()
+            ok = self._all_ok(ok)
+            if not ok and L.pa_comm_peer_ready(self.handle):
+                L.pa_comm_peer_disconnect(self.handle)  # (some other rank could not map: nobody uses the transport)
+        if ok:
+            # a lost message in the self-test must not stall the start-up for a minute per wait
+            user_timeout = float(os.environ.get("PALACE_AMD_PEER_TIMEOUT_S", "60"))
+            _lib.check(L.pa_comm_peer_set_timeout(min(user_timeout, 10.0)))
+            ok, values_only, rep["self_test"] = self._peer_self_test()
+            if not ok and values_only and not L.pa_comm_peer_fenced():
+                _lib.check(L.pa_comm_peer_set_fenced(1))
+                rep["ordering"] = "system-scope fences (the relaxed protocol failed its self-test here)"
+                ok, values_only, rep["self_test_fenced"] = self._peer_self_test()
+            _lib.check(L.pa_comm_peer_set_timeout(user_timeout))
+            if not ok:
+                why = "self-test failed: " + json.dumps(rep)
+        if not ok:
+            if L.pa_comm_peer_ready(self.handle) and fallback:
+                _lib.check(L.pa_comm_peer_disconnect(self.handle))
+            if not fallback:
+                raise RuntimeError(f"peer transport not available ({why or 'another rank failed'})")
+            rep = {"transport": "rccl", "peer_failed": why or "on another rank"}
+            if self.rank == 0:
+                print(f"palace_amd: peer transport not available ({why or 'another rank failed'}); using RCCL send / receive",
+                      file=sys.stderr)
+        self.transport_report = rep
+        return ok
+
+    def _ring_plan(self, n):
+        """Ring plan over a vector of 2 n entries: owned [0, n) go to rank + 1, ghosts [n, 2 n) are owned by rank - 1."""
         rank, size = self.rank, self.size
-        v = torch.tensor([float(rank + 1), 0.5 * rank], dtype=torch.float64, device="cuda")
-        _lib.check(_L().pa_allreduce_sum(self.handle, C.c_void_p(v.data_ptr()), 2))
-        ok = bool(torch.allclose(v.cpu(), torch.tensor([size * (size + 1) / 2.0, 0.25 * size * (size - 1)], dtype=torch.float64)))
-        # ring: rank r owns entries [0, 8) and holds ghosts [8, 16) owned by its left neighbour
-        n = 8
         left, right = (rank - 1) % size, (rank + 1) % size
+        own, gh = np.arange(n, dtype=np.int32), np.arange(n, 2 * n, dtype=np.int32)
         if size == 2:
-            nbr, send, recv = [left], [np.arange(n, dtype=np.int32)], [np.arange(n, 2 * n, dtype=np.int32)]
-        else:
-            nbr = [left, right]
-            send = [np.zeros(0, np.int32), np.arange(n, dtype=np.int32)]
-            recv = [np.arange(n, 2 * n, dtype=np.int32), np.zeros(0, np.int32)]
-        h = Halo(self, nbr, send, recv)
-        for rep in range(3):  # (more than two: both mailbox buffers and the acknowledgements)
-            lx = torch.zeros(2 * n, dtype=torch.float64, device="cuda")
-            lx[:n] = torch.arange(n, dtype=torch.float64, device="cuda") + 100.0 * rank + rep
-            _lib.check(_L().pa_halo_prolongate(self.handle, h.handle, C.c_void_p(lx.data_ptr())))
-            want = torch.arange(n, dtype=torch.float64) + 100.0 * left + rep
-            ok = ok and bool(torch.equal(lx[n:].cpu(), want))
-            _lib.check(_L().pa_halo_restrict_add(self.handle, h.handle, C.c_void_p(lx.data_ptr())))
-            want = (torch.arange(n, dtype=torch.float64) + 100.0 * rank + rep) * 2.0
-            ok = ok and bool(torch.equal(lx[:n].cpu(), want))
+            return Halo(self, [left], [own], [gh])
+        return Halo(self, [left, right], [np.zeros(0, np.int32), own], [gh, np.zeros(0, np.int32)])
+
+    def peer_stress(self, rounds, n=4096, direct=False, graph=False, ring=None):
+        """pa_comm_peer_stress on a ring plan: the number of wrong values this rank saw (raises on a timed-out wait)."""
+        L = _L()
+        L.pa_comm_peer_stress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+        h = ring if ring is not None else self._ring_plan(n)
+        bad = C.c_longlong(0)
+        _lib.check(L.pa_comm_peer_stress(self.handle, h.handle, int(n), int(rounds), int(bool(direct)), int(bool(graph)),
+                                         C.byref(bad)))
+        return int(bad.value)
+
+    def _peer_self_test(self, rounds=None):
+        """The transport has to prove itself on the machine it runs on before the solvers rely on it: one global sum and three
+        ring exchanges with known answers, then `rounds` (default 1 000 each, PALACE_AMD_PEER_SELFTEST_ROUNDS) back-to-back
+        rounds of P / P^T / all-reduce with payloads that change every round and are verified on the device -- through the local
+        vector, in the direct form of ParOperator::Mult (ghosts read from the mailbox in place), and as a recorded round replayed
+        as a HIP graph.  Returns (ok on every rank, failures were wrong values only -- no timed-out wait --, report)."""
+        import torch
+
+        rank, size = self.rank, self.size
+        rounds = int(os.environ.get("PALACE_AMD_PEER_SELFTEST_ROUNDS", "1000")) if rounds is None else int(rounds)
+        ok, lost, rep = True, False, {"rounds": rounds}
         try:
+            v = torch.tensor([float(rank + 1), 0.5 * rank], dtype=torch.float64, device="cuda")
+            _lib.check(_L().pa_allreduce_sum(self.handle, C.c_void_p(v.data_ptr()), 2))
+            ok = bool(torch.allclose(v.cpu(), torch.tensor([size * (size + 1) / 2.0, 0.25 * size * (size - 1)], dtype=torch.float64)))
+            n = 8
+            left = (rank - 1) % size
+            h = self._ring_plan(n)
+            for rep_i in range(3):  # (more than two: both mailbox buffers and the acknowledgements)
+                lx = torch.zeros(2 * n, dtype=torch.float64, device="cuda")
+                lx[:n] = torch.arange(n, dtype=torch.float64, device="cuda") + 100.0 * rank + rep_i
+                _lib.check(_L().pa_halo_prolongate(self.handle, h.handle, C.c_void_p(lx.data_ptr())))
+                want = torch.arange(n, dtype=torch.float64) + 100.0 * left + rep_i
+                ok = ok and bool(torch.equal(lx[n:].cpu(), want))
+                _lib.check(_L().pa_halo_restrict_add(self.handle, h.handle, C.c_void_p(lx.data_ptr())))
+                want = (torch.arange(n, dtype=torch.float64) + 100.0 * rank + rep_i) * 2.0
+                ok = ok and bool(torch.equal(lx[:n].cpu(), want))
             self.peer_check()
-        except Exception:  # noqa: BLE001
-            ok = False
-        flag = torch.tensor([0.0 if ok else 1.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag)
-        del h
-        if float(flag.item()) != 0.0:
-            raise RuntimeError("self-test of the peer transport failed")
+            del h
+            rep["known_answers"] = ok
+            ring = self._ring_plan(4096)
+            for name, direct, graph in (("lvector", False, False), ("direct", True, False), ("direct_graph", True, True)):
+                bad = self.peer_stress(rounds, 4096, direct=direct, graph=graph, ring=ring)
+                rep[name + "_wrong_values"] = bad
+                ok = ok and bad == 0
+            del ring
+        except Exception as exc:  # noqa: BLE001 -- a timed-out wait or a set-up failure: this rank votes 'no'
+            ok, lost = False, True
+            rep["error"] = str(exc)[:200]
+        all_ok = self._all_ok(ok)
+        values_only = self._all_ok(not lost)
+        return all_ok, values_only, rep
 
     def init_comm_local(self, group, rank):
         """Rank `rank` of an in-process group of rank THREADS on one GPU (pa_local_group_*: test harness of the multi-rank paths)."""
         _lib.check(_L().pa_context_init_comm_local(self.handle, int(rank), group.handle))
         self.rank, self.size, self._group = int(rank), group.size, group
 
-    def _peer_connect_over_torch_distributed(self, device):
-        """Gather the arena handles of all ranks over torch.distributed and map them (pa_comm_peer_connect)."""
-        import torch
-        import torch.distributed as dist
-
-        L = _L()
-        buf = C.create_string_buffer(64)
-        _lib.check(L.pa_comm_peer_handle(self.handle, buf))
-        mine = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(device)
-        parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-        dist.all_gather(parts, mine)
-        table = b"".join(bytes(t.cpu().numpy().tobytes()) for t in parts)
-        _lib.check(L.pa_comm_peer_connect(self.handle, table))
-
     def init_comm_peer_from_torch_distributed(self):
         """Communicator on the peer transport alone (no RCCL): halo exchanges and global sums as direct stores between the
         ranks' device arenas.  torch.distributed (any backend, e.g. gloo) only carries the 64-byte IPC handles once.  Works
-        for several processes on ONE GPU as well, which RCCL refuses."""
+        for several processes on ONE GPU as well, which RCCL refuses.  Raises (on every rank) if the transport cannot be
+        brought up: there is nothing to fall back to."""
         import torch.distributed as dist
 
         rank, size = dist.get_rank(), dist.get_world_size()
         _lib.check(_L().pa_context_init_comm_peer(self.handle, rank, size))
         self.rank, self.size = rank, size
-        self._peer_connect_over_torch_distributed("cuda" if dist.get_backend() == "nccl" else "cpu")
+        self.transport_report = {"transport": "peer"}
         if size > 1:
-            self._peer_self_test()
+            self._peer_bring_up(fallback=False)
 
     def init_comm_peer_single(self):
         """One-rank communicator on the peer transport (a plan naming rank 0 as its own neighbour exercises every kernel of
