@@ -51,7 +51,53 @@ def parse():
     ap.add_argument("--tet-n", type=int, default=36, help="cubes per direction of the Kuhn-split tet mesh")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the RCCL communicator even with one rank (exercises the multi-GPU code path)")
+    ap.add_argument("--rehearse", type=int, default=0, metavar="N",
+                    help="rehearsal of the N-GPU run on ONE GPU: N processes on device 0, torch.distributed over gloo, halo "
+                         "exchanges and sums over the peer transport (RCCL refuses several ranks per device); runs the very "
+                         "code of `--gpus N` -- partition, halo plans, direct form, every N > 1 leg -- and prints its line "
+                         "with \"rehearsal\": true.  Timings are those of N ranks sharing one GPU, not a scaling result.")
+    ap.add_argument("--no-nranks-legs", action="store_true", help="N > 1: skip the order-4 and tetrahedral legs")
     return ap.parse_args()
+
+
+def rehearse(args):
+    """Parent of a rehearsal: starts the N rank processes (the same launch contract as torch.distributed.run: RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT in the environment), passes rank 0's line through."""
+    import socket
+    import subprocess
+
+    n = args.rehearse
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    for i, a in enumerate(argv):  # drop --rehearse N / --rehearse=N, force --gpus N
+        if a == "--rehearse":
+            argv[i:i + 2] = []
+            break
+        if a.startswith("--rehearse="):
+            argv[i:i + 1] = []
+            break
+    for i, a in enumerate(argv):
+        if a == "--gpus":
+            argv[i:i + 2] = []
+            break
+        if a.startswith("--gpus="):
+            argv[i:i + 1] = []
+            break
+    argv += ["--gpus", str(n)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PALACE_AMD_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"rehearsal: rank exit codes {rcs}")
 
 
 def _rel(a, b):
@@ -504,8 +550,110 @@ def tets_leg(order, n, reps=20):
     return out
 
 
+def partition_report(space, halo_space_name="ND"):
+    """Quality of the element partition as this rank sees it (surface / volume, neighbour counts)."""
+    nbr = list(getattr(space, "nbr", []))
+    ns = int(sum(len(q) for q in getattr(space, "send", [])))
+    nr = int(sum(len(q) for q in getattr(space, "recv", [])))
+    nt = int(getattr(space, "n_true", space.ndofs))
+    return {"space": halo_space_name, "neighbours": len(nbr), "true_dofs": nt, "ghost_dofs": nr, "owned_dofs_sent": ns,
+            "surface_to_volume": (ns + nr) / max(1, nt)}
+
+
+def nranks_legs(ctx, rank, world, args, barrier, max_over_ranks):
+    """N > 1: the other two element families of BASELINE's configs on the same N ranks -- order-4 hexahedra (config 5) as z-slabs
+    of the strong-scaling cylinder, and order-`--order` Nedelec tetrahedra (configs 3 / 4 shape) cut by recursive coordinate
+    bisection -- `ParOperator::Mult` throughput of the whole job and PCG + p-multigrid iterations/s, with the partition quality
+    of each.  Every timed region is bracketed by barriers and the maximum over ranks is reported, like the headline."""
+    import torch
+
+    from palace_amd.fem.partition import SlabProblem, strong_shape
+
+    def timed(fn, reps, warm):
+        for _ in range(warm):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0) / reps
+
+    out = {}
+    try:
+        n_cross, nz = strong_shape(args.dofs, 4)
+        if nz % world:
+            raise ValueError(f"{nz} layers do not divide into {world} slabs")
+        prob = SlabProblem(ctx, rank, world, 4, args.dofs, levels=True, shape=(n_cross, nz // world))
+        K = prob.curlcurl_par_operator()
+        n = prob.n_true[-1]
+        x = torch.rand(n, dtype=torch.float64, device="cuda")
+        y = torch.empty_like(x)
+        ng = prob.global_true_dofs()
+        sec = timed(lambda: K.mult(x, y), 200, 30)
+        e = {"workload": f"ND p=4 hexahedra, strong z-slabs x{world}, {ng} true dofs total", "global_true_dofs": ng,
+             "direct_form": K.direct_form(), "mult_ms": 1e3 * sec, "dof_per_s": ng / sec,
+             "partition": partition_report(prob.spaces[-1], "ND p=4, z-slabs")}
+        solver, b, xs = prob.pcg_gmg_solver(max_it=20, hiptmair=False, coarse="chebyshev")
+        solver.mult(b, xs)
+        barrier()
+        t0 = time.perf_counter()
+        solver.mult(b, xs)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        st = solver.stats()
+        e["pcg_chebyshev"] = {"iters_per_s": st["iterations"] / dt, "iterations": st["iterations"], "seconds": dt,
+                              "levels": ",".join(str(q) for q in prob.orders)}
+        prob._keep.clear()
+        del prob, K, solver
+        out["p4"] = e
+    except Exception as exc:  # noqa: BLE001 -- reported in the line
+        out["p4"] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:
+        from palace_amd.fem import tet
+        from palace_amd.fem.tetproblem import TetProblem
+
+        mesh = tet.cube_tet_mesh(args.tet_n)
+        prob = TetProblem(ctx, mesh, args.order, rank=rank, world=world)
+        solver, b, xs = prob.pcg_gmg_solver(max_it=400, rel_tol=1e-8, hiptmair=True, coarse="ams")
+        A = prob.A[-1]
+        n = prob.n_true[-1]
+        ngt = torch.tensor([n], dtype=torch.int64)
+        import torch.distributed as dist
+
+        if dist.get_backend() == "nccl":
+            ngt = ngt.cuda()
+        dist.all_reduce(ngt)
+        ng = int(ngt.item())
+        x = torch.rand(n, dtype=torch.float64, device="cuda")
+        y = torch.empty_like(x)
+        sec = timed(lambda: A.mult(x, y), 50, 10)
+        e = {"workload": f"ND p={args.order} tetrahedra (dense MFMA path), {mesh.ne} tets cut into {world} parts by recursive "
+                         f"coordinate bisection, {ng} true dofs total; K + M ParOperator::Mult and PCG + Hiptmair p-multigrid "
+                         "with the replicated native AMS on level 0",
+             "global_true_dofs": ng, "direct_form": A.direct_form(), "mult_ms": 1e3 * sec, "dof_per_s": ng / sec,
+             "partition": partition_report(prob.spaces[-1], f"ND p={args.order} tets, RCB")}
+        solver.mult(b, xs)  # warm-up (records the iteration)
+        xs.zero_()
+        barrier()
+        t0 = time.perf_counter()
+        solver.mult(b, xs)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        st = solver.stats()
+        e["pcg_hiptmair_ams"] = {"iterations_to_1e-8": st["iterations"], "seconds": dt, "iters_per_s": st["iterations"] / dt,
+                                 "converged": st["converged"]}
+        prob._keep.clear()
+        out["tets"] = e
+    except Exception as exc:  # noqa: BLE001
+        out["tets"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
 def main():
     args = parse()
+    if args.rehearse > 1:
+        return rehearse(args)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL across processes)
     # stdout carries the one JSON line and nothing else: whatever libraries print there (RCCL's version banner at communicator
     # creation) goes to stderr
@@ -521,9 +669,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # rehearsal (bench.py --rehearse N): every rank on device 0, gloo instead of RCCL -- everything below is the same code
+    rehearsal = os.environ.get("PALACE_AMD_BENCH_REHEARSE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    cdev = "cpu" if rehearsal else "cuda"  # where the tensors of torch.distributed's own collectives live
 
     import __graft_entry__ as ge
 
@@ -539,7 +695,10 @@ def main():
     p = args.order
     ctx = linalg.Context()
     if world > 1:
-        ctx.init_comm_from_torch_distributed()
+        if rehearsal:
+            ctx.init_comm_peer_from_torch_distributed()
+        else:
+            ctx.init_comm_from_torch_distributed()
     elif args.force_comm:
         ctx.init_comm_single()
 
@@ -570,15 +729,16 @@ def main():
     halo_info = None
     if world > 1:
         halo_info = {"transport": "peer (direct stores over IPC-mapped arenas)" if ctx.peer_ready() else "rccl send / receive groups",
-                     "direct_form": K.direct_form()}
-        df = torch.tensor([K.direct_form()], dtype=torch.int64, device="cuda")
+                     "bring_up": getattr(ctx, "transport_report", None), "direct_form": K.direct_form(),
+                     "partition": partition_report(prob.spaces[-1], f"ND p={p}, z-slabs")}
+        df = torch.tensor([K.direct_form()], dtype=torch.int64, device=cdev)
         dist.all_reduce(df, op=dist.ReduceOp.MIN)  # (the check below is collective: every rank or none)
         if int(df.item()) == 1:
             y2 = torch.empty_like(y)
             K.mult(x, y)
             K.set_direct(False)
             K.mult(x, y2)
-            err = torch.tensor([float((y - y2).abs().max()), float(y2.abs().max())], dtype=torch.float64, device="cuda")
+            err = torch.tensor([float((y - y2).abs().max()), float(y2.abs().max())], dtype=torch.float64, device=cdev)
             dist.all_reduce(err, op=dist.ReduceOp.MAX)
             rel = float(err[0] / err[1]) if float(err[1]) > 0 else float("inf")
             halo_info["direct_vs_lvector_rel_err"] = rel
@@ -608,7 +768,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -711,6 +871,8 @@ def main():
         legs = [("chebyshev", False, "chebyshev"), ("hiptmair", True, "cg")]
         if world == 1:
             legs += [("chebyshev_ams", False, "ams"), ("hiptmair_ams", True, "ams")]
+        else:  # several ranks: level 0 solved redundantly by every rank (ReplicatedSolver around the native AMS)
+            legs += [("hiptmair_ams", True, "ams")]
         for name, hip, coarse in legs:
             try:  # a failing secondary leg is reported in the line, it does not take the headline measurement with it
                 solver, b, xs = prob.pcg_gmg_solver(max_it=args.pcg_iters, hiptmair=hip, coarse=coarse)
@@ -731,6 +893,22 @@ def main():
                 st = solver.stats()
                 entry.update({"iterations_to_1e-8": st["iterations"], "seconds_to_1e-8": time.perf_counter() - t0,
                               "converged": st["converged"]})
+                if world > 1 and coarse == "ams":
+                    # what the replicated level-0 solve costs per application (gather over the transport + the AMS cycle of
+                    # the whole cylinder's order-1 problem on every rank) against one PCG iteration: the part that does not scale
+                    cs, n0 = prob.last_coarse, prob.n_true[0]
+                    r0 = torch.rand(n0, dtype=torch.float64, device="cuda")
+                    z0 = torch.zeros_like(r0)
+                    for _ in range(3):
+                        cs.mult(r0, z0)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        cs.mult(r0, z0)
+                    barrier()
+                    ms0 = 1e3 * (time.perf_counter() - t0) / 20
+                    entry["replicated_level0"] = {"ms_per_application": ms0,
+                                                  "share_of_iteration": ms0 * 1e-3 * entry["iters_per_s"]}
                 pcg[name] = entry
                 prob._keep.clear()
             except Exception as exc:  # noqa: BLE001
@@ -769,6 +947,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_tets:
         cpw = _leg(cpw_leg, p)
 
+    nranks = None
+    if world > 1 and not args.no_nranks_legs:
+        def max_over_ranks(v):
+            t = torch.tensor([v], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        nranks = nranks_legs(ctx, rank, world, args, barrier, max_over_ranks)
+        try:  # whatever the transport noted while the legs ran
+            ctx.peer_check()
+            nranks["peer_check"] = "ok"
+        except Exception as exc:  # noqa: BLE001
+            nranks["peer_check"] = str(exc)
+
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
@@ -789,8 +981,10 @@ def main():
                        "true_dofs_per_gpu": n_true, "global_true_dofs": n_global, "q1d": p + 1,
                        "scaling_mode": ("strong: one ~10M-dof cylinder cut into N equal z-slabs" if args.scaling == "strong"
                                         else "weak: one z-slab of the cylinder per GPU, same element count per GPU"),
-                       "parallelism": f"element partition x{world}, RCCL halo (P / P^T) + allreduce dots"},
-            "pre_warm_steps": args.pre_warm, "halo": halo_info, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "cpw": cpw, "tets_mfma": tets,
+                       "parallelism": f"element partition x{world}, halo (P / P^T) and global sums over "
+                                      + ("the peer transport (direct xGMI stores; RCCL as the fall-back)" if (world > 1 and ctx.peer_ready())
+                                         else "RCCL")},
+            "rehearsal": rehearsal, "pre_warm_steps": args.pre_warm, "halo": halo_info, "n_ranks_legs": nranks, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "cpw": cpw, "tets_mfma": tets,
             "setup_s": t_setup,
         }
         sys.stdout.flush()

@@ -747,7 +747,9 @@ size_t Comm::PeerAlloc(size_t bytes) {
   PA_HIP(hipMemset(arena_ + off, 0, bytes));
   return off;
 }
-void Comm::PeerFree(size_t off, size_t bytes) { arena_free_.emplace_back(off, (bytes + 255) & ~size_t(255)); }
+// A block given back may still receive a neighbour's last acknowledgement (its kernels run on its own clock): it waits in
+// quarantine until the next set-up barrier, before which every rank drains its device (PeerSetup), and only then is used again.
+void Comm::PeerFree(size_t off, size_t bytes) { arena_quarantine_.emplace_back(off, (bytes + 255) & ~size_t(255)); }
 
 bool Comm::GraphSafe() const {
   if (size_ == 1) return true;
@@ -799,6 +801,7 @@ void Halo::PeerSetup(const int32_t *send_idx) {
   // barrier, so that the others fail on its descriptor instead of waiting for it.
   const int id = c.next_halo_++;
   const int slot = id % Comm::kMaxHalos;
+  PA_HIP(hipDeviceSynchronize());  // (my stores into other ranks' arenas -- acknowledgements of destroyed plans -- are performed)
   std::string fail;
   if (nn > Comm::kMaxNbr) fail = "too many neighbours for the peer transport";
   if (c.halo_live_[(size_t)slot]) fail = "too many live halo plans for the peer transport";
@@ -830,6 +833,9 @@ void Halo::PeerSetup(const int32_t *send_idx) {
     delete pp;
     throw;
   }
+  // every rank has drained its device and passed the barrier: what was given back before it can be used again
+  c.arena_free_.insert(c.arena_free_.end(), c.arena_quarantine_.begin(), c.arena_quarantine_.end());
+  c.arena_quarantine_.clear();
   if (!fail.empty()) {
     delete pp;
     throw pa::Error(fail);

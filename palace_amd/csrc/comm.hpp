@@ -75,6 +75,7 @@ class Comm {
   int next_halo_ = 0;                  // halo plans made so far (collective, monotonic: plan id; its descriptor slot is id % kMaxHalos)
   std::vector<char> halo_live_;        // [kMaxHalos] descriptor slot in use
   std::vector<std::pair<size_t, size_t>> arena_free_;  // {offset, bytes} blocks given back by destroyed plans
+  std::vector<std::pair<size_t, size_t>> arena_quarantine_;  // ... since the last set-up barrier (not yet reusable)
   unsigned long long *h_err_ = nullptr;  // error word of the wait loops: page-locked host memory the kernels write on a
                                          // time-out, so that every host synchronisation point can look at it for free
   char **d_remote_ = nullptr;          // device copy of remote_

@@ -380,6 +380,10 @@ static void free_sub(SubOp *so) {
 // separate memset when E^T runs as a gather).
 // after: an event the entries of x that take part in the halo exchange wait for (multi-rank applies, pa_op_mult_after): a
 // streaming block with interface batch lists runs its interior batches first; everything else simply waits up front
+// timing experiments (scripts/price_evec_cache.py): 1 = element kernel only, 2 = E^T run gather only (of the streaming form)
+static int g_debug_phase = 0;
+extern "C" void pa_debug_apply_phase(int phase) { g_debug_phase = phase; }
+
 static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s, bool masked = false,
                   int ess_policy = -1, hipEvent_t after = nullptr) {
   PA_REQUIRE(op && x && y, "null argument");
@@ -400,8 +404,8 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
         launch_nd_hex_stream(*so, x, y, masked, s, 1);
         launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
       } else if (so->d_idxc && overwrite && first && (!masked || so->d_perm_s_bc)) {  // streaming kernel (y = A x) + E^T of the shared dofs by runs
-        launch_nd_hex_stream(*so, x, y, masked, s);
-        launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
+        if (g_debug_phase != 2) launch_nd_hex_stream(*so, x, y, masked, s);
+        if (g_debug_phase != 1) launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
       } else if (so->d_ye) {
         launch_nd_hex_apply(*so, x, y, so->d_ye, masked, s, !(overwrite && first), ess_policy);
         launch_et_gather(*so, y, !(overwrite && first), s, x, ess_policy);

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(64 * kH1StreamWaves, MINW) void h1_hex_stream_kerne
   constexpr int Q1 = 4, NC = P1 + 1, PP = NC * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
   constexpr int NG = (USE_V ? 1 : 0) + (USE_G ? 6 : 0);
   constexpr int LDS_SIDE = (PP + 1) / 2 + (NPK + 1) * 8;
-  constexpr int LDS_ELEM = L::ELEM_PAD + LDS_SIDE + 14;
+  // (element stride 16 mod 32 doubles: the two elements of a 32-lane ds_read_b64 group on opposite halves of the banks --
+  // see stream_lds_elem in pa_nd_hex_stream.hip)
+  constexpr int LDS_ELEM = (L::ELEM_PAD + LDS_SIDE + 14 + 15) / 32 * 32 + 16;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -360,7 +362,7 @@ void launch_vg(const SubOp &so, H1StreamArgs<P1> &a, hipStream_t s) {
   constexpr int MINW = 3;
   constexpr int NC = P1 + 1, PP = NC * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
   for (int i = 0; i < 2 * NC; i++) a.tab.Bc[i] = so.Bc[i], a.tab.Gc[i] = so.Gc[i];
-  const size_t lds = sizeof(double) * (size_t)(kH1StreamWaves * 4) * (L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8 + 14);
+  const size_t lds = sizeof(double) * (size_t)(kH1StreamWaves * 4) * ((L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8 + 14 + 15) / 32 * 32 + 16);
   static const int per_cu = [&] {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h1_hex_stream_kernel<P1, V, G, MINW>, 64 * kH1StreamWaves, lds) != hipSuccess ||

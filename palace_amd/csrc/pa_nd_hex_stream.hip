@@ -22,6 +22,10 @@
 
 #include "pa_nd_hex_core.hpp"
 
+#ifndef PA_KM_MINW
+#define PA_KM_MINW 2  // waves per SIMD the p = 3 curl-curl + mass instantiation is compiled for (experiment builds: 3)
+#endif
+
 namespace pa {
 
 typedef double d2v __attribute__((ext_vector_type(2)));
@@ -40,6 +44,20 @@ __device__ unsigned long long g_trace[kTraceWG * kTraceBatches * kTraceStamps];
 #define PA_STAMP(k) \
   do {              \
   } while (0)
+#endif
+
+// Element stride in LDS (doubles).  A wave holds four elements; ds_read_b64 serves lanes 0-31 and 32-63 -- two elements each --
+// in one cycle when they touch 32 different 8-byte banks.  Every contraction layout (swizzled p = 3, padded p < 3) spreads
+// the 16 lanes of one element over 16 of the 32 banks and its image shifted by 16 doubles over the other 16, so the stride
+// has to be 16 (mod 32) doubles.  Rounds 1-3 took the contraction buffers' own stride (ELEM_PAD, which has that property, or
+// the parity flip of the swizzled layouts, which assumes 0 mod 32) PLUS the side buffers appended behind them -- 300 doubles
+// at p = 3 -- and so ran every second read two- to four-way conflicted: 236 extra LDS cycles per batch on 204
+// (scripts/lds_conflict_model.py restates the kernel's access patterns under the guide's banking rules; SQ_LDS_BANK_CONFLICT
+// in profiles/r03_apply_pmc.json saw them).
+#ifdef PA_STREAM_OLD_LDS  // (A / B builds: the element stride and parity flip of rounds 1-3)
+__host__ __device__ constexpr int stream_lds_elem(const int raw) { return raw; }
+#else
+__host__ __device__ constexpr int stream_lds_elem(const int raw) { return (raw + 15) / 32 * 32 + 16; }
 #endif
 
 template <int P1>
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   // LDS per element (doubles): contraction buffers + the batch's index and slot / flag words, kept for the E^T stores,
   // + the run starts of the next batch while its index is decoded
   constexpr int LDS_SIDE = (PP + 1) / 2 + (NPK + 1) * 8;
-  constexpr int LDS_ELEM = L::ELEM_PAD + LDS_SIDE + 12;
+  constexpr int LDS_ELEM = stream_lds_elem(L::ELEM_PAD + LDS_SIDE + 12);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -181,7 +199,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     double *sm = smem + (size_t)(wave * 4 + sub) * LDS_ELEM;
     int *side = reinterpret_cast<int *>(sm + L::ELEM_PAD);  // index words of this batch, kept for the E^T stores
     int *stab = side + 2 * LDS_SIDE;                        // run starts of the next batch (decode)
+    // (no parity flip of the swizzled layouts here: the element stride itself puts the two elements of a 32-lane read group
+    // on opposite halves of the banks, stream_lds_elem)
+#ifdef PA_STREAM_OLD_LDS
     const int lx = L::parity_xor(sub);
+#else
+    constexpr int lx = 0;
+#endif
     const int e = CPLX ? b * 2 + (sub >> 1) : b * 4 + sub;
 
     // q-data of this batch: consumed after the forward contraction
@@ -596,7 +620,7 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   for (int i = 0; i < HalfTab<P1 + 1, 4>::LEN; i++) a.tab.Bc[i] = so.Bc[i], a.tab.Gc[i] = so.Gc[i];
   constexpr int PP = 3 * P1 * (P1 + 1) * (P1 + 1);
   constexpr int NPK = ((PP + 15) / 16 + 3) / 4;
-  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * (L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8 + 12);
+  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * stream_lds_elem(L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8 + 12);
   // resident workgroups per CU: registers (MINW waves per SIMD), LDS (160 KB), at most 8
   // workgroups per CU: what the registers (MINW waves per SIMD) and the LDS admit, and not more than the occupancy query
   // says -- with a fixed stride a workgroup that had to queue would run after the others and double the time
@@ -675,7 +699,7 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
       break;
     case PA_QF_HDIVMASS_33:
       PA_REQUIRE(m, "streaming curl-curl + mass kernel needs the metric form");
-      launch_variant<P1, true, true, true, 2>(so, a, s);
+      launch_variant<P1, true, true, true, (P1 == 3 ? PA_KM_MINW : 2)>(so, a, s);
       break;
     default: throw Error("QFunction not available for H(curl) hexahedra");
   }

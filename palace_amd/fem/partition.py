@@ -276,7 +276,7 @@ class SlabProblem:
         import torch
         import torch.distributed as dist
 
-        t = torch.tensor([self.n_true[-1]], dtype=torch.int64, device="cuda")
+        t = torch.tensor([self.n_true[-1]], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t)
         return int(t.item())
 
@@ -364,6 +364,7 @@ class SlabProblem:
             else:
                 csolver = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=coarse_tol, max_it=coarse_max_it)
             B = linalg.gmg(ctx, A, P, csolver, cheby_order=max(2 * self.p, 4), **aux)
+            self.last_coarse = csolver
         else:
             B = linalg.jacobi(ctx, A[0])
         K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)

@@ -144,3 +144,51 @@ def test_replicated_ams_over_the_peer_transport():
         assert abs(one[f"its{rep}"] - two[f"its{rep}"]) <= 1, (one, two)
         assert abs(one[f"xx{rep}"] - two[f"xx{rep}"]) < 1e-6 * one[f"xx{rep}"], (one, two)
     assert two["its0"] == two["its1"] == two["its2"] and two["xx1"] == two["xx2"]
+
+
+def _stress_worker(rank, world, port, rounds, out):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from palace_amd import linalg
+
+        ctx = linalg.Context()
+        ctx.init_comm_peer_from_torch_distributed()  # (runs the start-up self-test: 3 x 1 000 rounds)
+        res = {"bring_up": ctx.transport_report}
+        ring = ctx._ring_plan(4096)
+        # both buffer parities (odd and even round counts leave the next call starting on the other buffer), inside and
+        # outside graph replay, the L-vector and the direct form interleaved on ONE plan
+        for name, r, direct, graph in (("lvector", rounds, False, False), ("direct", rounds + 1, True, False),
+                                       ("lvector_graph", rounds, False, True), ("direct_graph", rounds + 1, True, True),
+                                       ("lvector_again", 7, False, False)):
+            res[name] = ctx.peer_stress(r, 4096, direct=direct, graph=graph, ring=ring)
+        ctx.peer_check()
+        # plans come and go: the descriptor slots and arena blocks of destroyed plans are used again (more plans than slots)
+        for _ in range(600):
+            h = ctx._ring_plan(64)
+            del h
+        res["after_churn"] = ctx.peer_stress(50, 4096, direct=True, graph=False)
+        if rank == 0:
+            out.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_flag_protocol_stress(world):
+    """>= 1e5 back-to-back P / P^T exchanges + all-reduces per variant between processes on one GPU, payloads that change every round,
+    every received value verified on the device: a reordering of data and flag stores would show up as a wrong value."""
+    import torch.multiprocessing as mp
+
+    rounds = 100000 if world == 2 else 20000
+    q = mp.get_context("spawn").SimpleQueue()
+    mp.spawn(_stress_worker, args=(world, 29660 + world, rounds, q), nprocs=world, join=True)
+    res = q.get()
+    assert res["bring_up"]["transport"] == "peer" and res["bring_up"]["ordering"] == "relaxed", res
+    for k in ("lvector", "direct", "lvector_graph", "direct_graph", "lvector_again", "after_churn"):
+        assert res[k] == 0, res
