@@ -116,6 +116,20 @@ Comm::~Comm() {
   if (h_err_) (void)hipHostFree(h_err_);
 }
 
+std::vector<double> Comm::SetupGather(double mine, hipStream_t s) {
+  PA_REQUIRE(PeerReady() && size_ <= kMaxReduceSetup, "set-up gather: peer transport only");
+  std::vector<double> v((size_t)size_, 0.0);
+  v[(size_t)rank_] = mine;
+  if (size_ == 1) return v;
+  double *d = pa::dev_upload(v.data(), v.size(), s);
+  PeerAllReduce(d, size_, s, 1);  // (every rank contributes zeros outside its own entry: the sum is the gather)
+  PA_HIP(hipMemcpyAsync(v.data(), d, sizeof(double) * v.size(), hipMemcpyDeviceToHost, s));
+  PA_HIP(hipStreamSynchronize(s));
+  (void)hipFree(d);
+  PeerCheckNow();
+  return v;
+}
+
 void LocalGroup::Arrive() {
   std::unique_lock<std::mutex> lk(m_);
   PA_REQUIRE(!aborted_, "in-process rank group aborted: another rank failed");
@@ -795,16 +809,18 @@ struct Halo::PeerPlan {
 void Halo::PeerSetup(const int32_t *send_idx) {
   Comm &c = *comm_;
   const int nn = (int)nbr_.size();
-  // Plan ids count the plans made on this communicator (collective: the same on every rank); the descriptor lives in slot
-  // id mod kMaxHalos and carries its id, slots and arena blocks of destroyed plans are used again.  Everything that can fail
-  // locally is decided BEFORE the barrier, and a rank that fails still publishes (an invalid descriptor) and takes part in the
-  // barrier, so that the others fail on its descriptor instead of waiting for it.
+  // Plan ids count the plans made on this communicator (collective: the same on every rank).  A rank keeps the plan's
+  // descriptor in any free slot of its table (slots and arena blocks of destroyed plans are used again -- each rank on its own
+  // clock: destructors run when the host language gets to them) and tells the others which one in the set-up barrier; the
+  // descriptor carries the plan id.  Everything that can fail locally is decided BEFORE the barrier, and a rank that fails
+  // still takes part in it (reporting slot -1), so that the others fail on that instead of waiting for it.
   const int id = c.next_halo_++;
-  const int slot = id % Comm::kMaxHalos;
+  int slot = 0;
+  while (slot < Comm::kMaxHalos && c.halo_live_[(size_t)slot]) slot++;
   PA_HIP(hipDeviceSynchronize());  // (my stores into other ranks' arenas -- acknowledgements of destroyed plans -- are performed)
   std::string fail;
   if (nn > Comm::kMaxNbr) fail = "too many neighbours for the peer transport";
-  if (c.halo_live_[(size_t)slot]) fail = "too many live halo plans for the peer transport";
+  if (slot == Comm::kMaxHalos) fail = "too many live halo plans for the peer transport", slot = -1;
   const size_t want[3] = {sizeof(double) * 2 * (size_t)std::max(1, nrecv_), sizeof(double) * 2 * (size_t)std::max(1, nsend_),
                           sizeof(PeerLocal)};
   HaloDesc d;
@@ -826,9 +842,10 @@ void Halo::PeerSetup(const int32_t *send_idx) {
     d.off_mb[0] = pp->off[0], d.off_mb[1] = pp->off[1], d.off_local = pp->off[2];
     d.ready = kDescMagic + (unsigned long long)id;
   }
-  PA_HIP(hipMemcpy(c.arena_ + kOffDesc + sizeof(HaloDesc) * (size_t)slot, &d, sizeof(d), hipMemcpyHostToDevice));
+  if (slot >= 0) PA_HIP(hipMemcpy(c.arena_ + kOffDesc + sizeof(HaloDesc) * (size_t)slot, &d, sizeof(d), hipMemcpyHostToDevice));
+  std::vector<double> slots;
   try {
-    c.Barrier(c.setup_stream_);  // every rank has published plan `id`
+    slots = c.SetupGather(fail.empty() ? (double)slot : -1.0, c.setup_stream_);  // every rank has published plan `id`
   } catch (...) {
     delete pp;
     throw;
@@ -855,7 +872,9 @@ void Halo::PeerSetup(const int32_t *send_idx) {
   for (int k = 0; k < nn; k++) {
     const int r = nbr_[k];
     HaloDesc rd;
-    PA_HIP(hipMemcpy(&rd, c.remote_[r] + kOffDesc + sizeof(HaloDesc) * (size_t)slot, sizeof(rd), hipMemcpyDeviceToHost));
+    const int rslot = (int)slots[(size_t)r];
+    PA_REQUIRE(rslot >= 0 && rslot < Comm::kMaxHalos, "peer transport: a neighbour could not set up this halo plan");
+    PA_HIP(hipMemcpy(&rd, c.remote_[r] + kOffDesc + sizeof(HaloDesc) * (size_t)rslot, sizeof(rd), hipMemcpyDeviceToHost));
     PA_REQUIRE(rd.ready == kDescMagic + (unsigned long long)id,
                "peer transport: a neighbour has not published this halo plan (it failed to set it up, or the ranks create "
                "their plans in different orders)");

@@ -72,7 +72,7 @@ class Comm {
   bool arena_uncached_ = false;
   std::vector<char *> remote_;         // [size] arena of rank r as mapped here (remote_[rank_] == arena_); empty: not connected
   std::vector<char> remote_ipc_;       // [size] 1: opened with hipIpcOpenMemHandle (to be closed)
-  int next_halo_ = 0;                  // halo plans made so far (collective, monotonic: plan id; its descriptor slot is id % kMaxHalos)
+  int next_halo_ = 0;                  // halo plans made so far (collective, monotonic: plan id)
   std::vector<char> halo_live_;        // [kMaxHalos] descriptor slot in use
   std::vector<std::pair<size_t, size_t>> arena_free_;  // {offset, bytes} blocks given back by destroyed plans
   std::vector<std::pair<size_t, size_t>> arena_quarantine_;  // ... since the last set-up barrier (not yet reusable)
@@ -91,7 +91,7 @@ public:
   static constexpr int kPeerHandleBytes = 64;  // sizeof(hipIpcMemHandle_t)
   // (kMaxNbr = kMaxRanks: the gather plan of a replicated coarse solve names every other rank as a neighbour)
   static constexpr int kMaxRanks = 64, kMaxReduce = 512, kMaxHalos = 512, kMaxNbr = 64;
-  static constexpr int kMaxReduceSetup = 8;  // values of the set-up channel (barriers of PeerSetup: own counters and slots)
+  static constexpr int kMaxReduceSetup = kMaxRanks;  // values of the set-up channel (barriers / gathers of PeerSetup: own counters and slots)
   static void GetUniqueId(char *out);
   Comm(int rank, int size, const char *unique_id);
   Comm(int rank, LocalGroup &group);  // rank of an in-process group (see LocalGroup)
@@ -131,6 +131,8 @@ public:
   // in-place sum over ranks of n doubles in device memory (Mpi::GlobalSum)
   void AllReduceSum(double *d_buf, int n, hipStream_t s);
   void Barrier(hipStream_t s);
+  // barrier that also tells every rank one number of every other rank (set-up channel of the peer transport; size > 1)
+  std::vector<double> SetupGather(double mine, hipStream_t s);
 };
 
 // The conforming prolongation of one finite element space (one multigrid level): which owned dofs

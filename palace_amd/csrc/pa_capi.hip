@@ -413,7 +413,7 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
         if (overwrite && first) PA_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)op->height, s));
         launch_nd_hex_apply(*so, x, y, nullptr, masked, s);
       }
-    } else if (so->d_idxc && overwrite && first && (!masked || so->d_perm_s_bc)) {  // streaming form, see above
+    } else if (so->d_idxc && so->stream_default && overwrite && first && (!masked || so->d_perm_s_bc)) {  // streaming form, see above
       launch_h1_hex_stream(*so, x, y, masked, s);
       launch_et_run_gather(*so, y, false, s, x, masked, ess_policy);
     } else {
@@ -444,7 +444,8 @@ void finalize_exclusive(pa_op *op) {
   if (so->fe_type == PA_FE_H1) {
     // H1 blocks: only the streaming kernel stores exclusive dofs directly; the one-shot kernel and its gather keep the
     // full dof list (no d_perm_x / d_shared), the streaming arrays get the list of shared dofs
-    if (!h1_hex_stream_ok(*so)) return;
+    if (!h1_hex_stream_capable(*so)) return;
+    so->stream_default = h1_hex_stream_ok(*so);
     std::vector<int32_t> cnt((size_t)so->lsize, 0);
     for (const int32_t s : so->h_sidx) cnt[s >= 0 ? s : -1 - s]++;
     for (int d = 0; d < so->lsize; d++)
@@ -955,7 +956,7 @@ int pa_op_dense_affine(const pa_op *op) {
   return n;
 }
 int pa_op_streams(const pa_op *op) {
-  return (op && op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->d_idxc) ? 1 : 0;
+  return (op && op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->d_idxc && op->subs[0]->stream_default) ? 1 : 0;
 }
 
 /* 0: no essential list set on this operator, 1: this list is set, -1: a different one is */
@@ -1034,14 +1035,21 @@ int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_po
     PA_REQUIRE(op && op->has_essential && handled, "pa_op_set_essential has not been called");
     const bool fuse = op->subs.size() == 1 && op->dsubs.empty() &&
                       (op->subs[0]->fe_type == PA_FE_HCURL ? nd_hex_fuses_essential(*op->subs[0])
-                                                           : (op->subs[0]->d_idxc && op->subs[0]->d_perm_s_bc));
+                                                           : (op->subs[0]->d_idxc && op->subs[0]->stream_default && op->subs[0]->d_perm_s_bc));
     apply(op, x, y, true, (hipStream_t)stream, true, fuse ? (diag_policy ? 1 : 0) : -1);
     *handled = fuse ? 1 : 0;
   });
 }
 
 int pa_op_supports_split(const pa_op *op) {
-  return (op && op->subs.size() == 1 && op->dsubs.empty() && op->msubs.empty() && nd_hex_stream_split_ok(*op->subs[0])) ? 1 : 0;
+  if (!op || !op->msubs.empty()) return 0;
+  if (op->subs.size() == 1 && op->dsubs.empty()) {
+    const SubOp &so = *op->subs[0];
+    return (nd_hex_stream_split_ok(so) || (so.fe_type == PA_FE_H1 && so.d_idxc)) ? 1 : 0;
+  }
+  // dense-table blocks (tetrahedra, ...): one block on the resident kernel
+  if (op->subs.empty() && op->dsubs.size() == 1) return dense_split_ok(*op->dsubs[0]) ? 1 : 0;
+  return 0;
 }
 
 int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y,
@@ -1051,12 +1059,23 @@ int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double
     PA_REQUIRE(pa_op_supports_split(op), "the operator has no split-vector form (pa_op_supports_split)");
     PA_REQUIRE(x != y, "in-place apply is not supported");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed split apply of a non-symmetric operator");
-    SubOp *so = op->subs[0];
     const bool masked = ess_policy >= 0;
-    PA_REQUIRE(!masked || (op->has_essential && so->d_perm_s_bc), "pa_op_set_essential has not been called");
     const SplitIO io{n_true, xg0, xg1, sel, yg};
     hipStream_t s = (hipStream_t)stream;
-    launch_nd_hex_stream(*so, x, y, masked, s, -1, &io);
+    if (!op->dsubs.empty()) {  // dense-table block: the essential entries are flagged in the masked index copy, the rows are
+                               // fixed by its gather
+      DenseSub *ds = op->dsubs[0];
+      PA_REQUIRE(!masked || op->has_essential, "pa_op_set_essential has not been called");
+      launch_dense_apply(*ds, x, masked, s, &io);
+      launch_dense_gather(*ds, y, false, s, nullptr, &io, x, ess_policy);
+      return;
+    }
+    SubOp *so = op->subs[0];
+    PA_REQUIRE(!masked || (op->has_essential && so->d_perm_s_bc), "pa_op_set_essential has not been called");
+    if (so->fe_type == PA_FE_H1)
+      launch_h1_hex_stream(*so, x, y, masked, s, &io);
+    else
+      launch_nd_hex_stream(*so, x, y, masked, s, -1, &io);
     launch_et_run_gather(*so, y, false, s, x, masked, ess_policy, nullptr, &io);
   });
 }

@@ -140,8 +140,21 @@ struct DenseArgs {
   int dbg;  // ablation bits (PA_ABLATION builds only)
   const double *x;
   double *ye;
+  // split vectors (multi-rank applies without L-vector copies): local dofs >= nsplit are read from xg0 / xg1 (the parity of
+  // *xg_sel picks the buffer; both stored shifted by -nsplit); nsplit = INT_MAX otherwise
+  int nsplit;
+  const double *xg0, *xg1;
+  const unsigned long long *xg_sel;
   CoeffDev c0, c1;
 };
+// where dof d of the input is read (d without its flag bits)
+__device__ __forceinline__ const double *dense_xbase(const DenseArgs &a, const double *x, const double *xg, const int d) {
+  return d < a.nsplit ? x : xg;
+}
+__device__ __forceinline__ const double *dense_ghosts(const DenseArgs &a) {
+  if (a.nsplit == 0x7fffffff) return a.x;
+  return ((a.xg_sel ? *a.xg_sel : 0ull) & 1ull) ? a.xg1 : a.xg0;
+}
 
 // 2-bit two's-complement field k of a packed curl-orientation word: -1, 0 or 1
 __device__ __forceinline__ double co_field(const int c, const int k) {
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(kDenseThreads, (PT <= 4 ? 2 : 1)) void dense_apply_
 
   // ---- E: gather straight into the MFMA B-operand layout
   double u[KPMAX];
+  const double *xgh = dense_ghosts(a);
   const int32_t *idx = a.idx + (size_t)b * KP * 64;
 #pragma unroll
   for (int s = 0; s < KPMAX; s++) {
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(kDenseThreads, (PT <= 4 ? 2 : 1)) void dense_apply_
     if (s < KP) {
       const int sg = idx[s * 64 + lane];
       const int d = sg >= 0 ? sg : -1 - sg;
-      const double xv = (d & kEssBit) ? 0.0 : a.x[d & ~kEssBit];
+      const double xv = (d & kEssBit) ? 0.0 : dense_xbase(a, a.x, xgh, d & ~kEssBit)[d & ~kEssBit];
       u[s] = sg >= 0 ? xv : -xv;
     }
   }
@@ -496,9 +510,12 @@ constexpr int kAffWaves = 12;  // the affine form needs fewer registers: three w
 // and the D stage combines the two parts across the columns of an element.  One pass instead of four.
 // LIST: the launch works on the element blocks listed in a.blist (meshes with affine and curved parts); a separate instantiation so
 // that the common single-kind launches carry no list look-up in their prefetch address chains (measured: 0.182 -> 0.211 ms with it)
-template <int PT, int MODE, bool AFFINE, bool CPLX = false, bool LIST = false>
+// SPLIT: split-vector input (multi-rank applies without L-vector copies); its own instantiation, because a per-lane choice of the
+// base pointer costs the affine kernels the two registers they have left at three waves per SIMD
+template <int PT, int MODE, bool AFFINE, bool CPLX = false, bool LIST = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1) void dense_apply_resident_kernel(const DenseArgs a, const int rows) {
   static_assert(!(CPLX && LIST), "the complex form runs on whole operators");
+  static_assert(!SPLIT || (!CPLX && !LIST), "split vectors: whole real operators");
   static_assert(!CPLX || (AFFINE && MODE == MODE_CURLMASS && PT <= 3), "complex form: affine curl-curl + mass blocks");
   constexpr int NW = (AFFINE && !CPLX) ? kAffWaves : kResWaves;
   using M = ModeTraits<MODE>;
@@ -532,6 +549,7 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
   auto ucol = [&](const int w) { return CPLX ? 8 * (w & 1) + j8 : j; };          // element column in the block's arrays
   auto ulane = [&](const int w) { return CPLX ? kq * 16 + 8 * (w & 1) + j8 : lane; };  // position in a [.][64] row
   const double *xsel = (CPLX && (j >> 3)) ? a.x1 : a.x;
+  [[maybe_unused]] const double *xgh = SPLIT ? dense_ghosts(a) : xsel;
   const double part_sign = (j >> 3) ? 1.0 : -1.0;  // real part: - A_i x_i, imaginary part: + A_i x_r
 
   // Software pipeline over the wave's blocks (up to 16 dof slots per lane: beyond that the extra registers spill): the index
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
       if (s < KP) {
         const int sg = sg_[s];
         const int d = sg >= 0 ? sg : -1 - sg;
-        const double xv = (d & kEssBit) ? 0.0 : xsel[d & ~kEssBit];
+        const double xv = (d & kEssBit) ? 0.0 : (SPLIT ? dense_xbase(a, xsel, xgh, d & ~kEssBit) : xsel)[d & ~kEssBit];
         out[s] = sg >= 0 ? xv : -xv;
       }
     }
@@ -611,9 +629,9 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
         const int sg = PREFETCH_IDX ? sgn[s] : a.idx[bb * KP * 64 + s * 64 + gln];
         const int d = sg >= 0 ? sg : -1 - sg;
 #ifdef PA_ABLATION
-        const double xv = (a.dbg & 1) ? (double)d : ((d & kEssBit) ? 0.0 : xsel[d & ~kEssBit]);
+        const double xv = (a.dbg & 1) ? (double)d : ((d & kEssBit) ? 0.0 : (SPLIT ? dense_xbase(a, xsel, xgh, d & ~kEssBit) : xsel)[d & ~kEssBit]);
 #else
-        const double xv = (d & kEssBit) ? 0.0 : xsel[d & ~kEssBit];
+        const double xv = (d & kEssBit) ? 0.0 : (SPLIT ? dense_xbase(a, xsel, xgh, d & ~kEssBit) : xsel)[d & ~kEssBit];
 #endif
         u[s] = sg >= 0 ? xv : -xv;
       }
@@ -947,6 +965,43 @@ __global__ void dense_diag_qd_kernel(const DenseArgs a, const int32_t *__restric
   diag[gid] = d;  // element diagonal; dense_diag_slot_kernel pushes it through the transposed unsigned restriction
 }
 
+// split-vector launches: the 3-D forms a multi-rank solve applies (curl-curl, vector mass, both, diffusion), PT <= 3, one kind of block
+static bool resident_split_mode(int mode) { return mode == MODE_CURL || mode == MODE_VMASS || mode == MODE_CURLMASS || mode == MODE_DIFF; }
+template <int PT>
+void launch_resident_split(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
+  const int rows = ds.L_rows;
+  const bool affine = a.affine != nullptr;
+  const int nw = affine ? kAffWaves : kResWaves;
+  const size_t shm = sizeof(double) * ((size_t)(a.Q4 + 31) / 32 * 32 + (size_t)rows * ResidentStride<PT>::S +
+                                      (ds.d_co ? (size_t)nw * 4 * PT * 64 : 0));
+  if (ds.nb == 0) return;
+  const int grid = std::min((ds.nb + nw - 1) / nw, ds.num_cu);
+  switch (ds.mode) {
+#define PA_RES_SPLIT_CASE(MODE)                                                                                          \
+  case MODE: {                                                                                                           \
+    static std::atomic<bool> attr_set{false};                                                                            \
+    if (!attr_set) {                                                                                                     \
+      PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE, false, false, false, true>,         \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
+      PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE, true, false, false, true>,          \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    if (affine)                                                                                                          \
+      hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE, true, false, false, true>), dim3(grid), dim3(64 * nw), shm, s, a, rows); \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE, false, false, false, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows); \
+  } break;
+    PA_RES_SPLIT_CASE(MODE_CURL)
+    PA_RES_SPLIT_CASE(MODE_VMASS)
+    PA_RES_SPLIT_CASE(MODE_CURLMASS)
+    PA_RES_SPLIT_CASE(MODE_DIFF)
+#undef PA_RES_SPLIT_CASE
+    default: throw Error("no split-vector form of this dense block");
+  }
+  PA_HIP(hipGetLastError());
+}
+
 template <int PT>
 void launch_resident_pt(const DenseSub &ds, const DenseArgs &a, hipStream_t s) {
   const int rows = ds.L_rows;
@@ -1216,6 +1271,7 @@ DenseArgs make_args(const DenseSub &ds) {
   a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
 #endif
   a.x = nullptr, a.ye = ds.d_ye;
+  a.nsplit = 0x7fffffff, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr;
   a.c0 = ds.c0.dev(), a.c1 = ds.c1.dev();
   return a;
 }
@@ -1599,7 +1655,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
 void free_dense_sub(DenseSub *ds) {
   if (ds) hipFree(ds->d_affine), hipFree(ds->d_wrel), hipFree(ds->d_ye2), hipFree(ds->d_blist[0]), hipFree(ds->d_blist[1]);
   if (!ds) return;
-  hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co);
+  hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co), hipFree(ds->d_ess_flag);
   hipFree(ds->d_Tf), hipFree(ds->d_Tt), hipFree(ds->d_interp), hipFree(ds->d_deriv);
   hipFree(ds->d_L), hipFree(ds->d_qdata);
   hipFree(ds->d_off), hipFree(ds->d_cor), hipFree(ds->d_ori);
@@ -1619,11 +1675,34 @@ void dense_set_essential(DenseSub &ds, const std::vector<char> &flag) {
   }
   hipFree(ds.d_idx_bc);
   ds.d_idx_bc = dev_upload(bc.data(), bc.size());
+  std::vector<uint8_t> ef((size_t)ds.lsize, 0);
+  for (int d = 0; d < ds.lsize && d < (int)flag.size(); d++) ef[d] = flag[d] ? 1 : 0;
+  hipFree(ds.d_ess_flag);
+  ds.d_ess_flag = dev_upload(ef.data(), ef.size());
 }
 
-void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStream_t s) {
+// split-vector applies (pa_op_mult_split): the LDS-resident kernel and the staged one read x through dense_xbase
+bool dense_split_ok(const DenseSub &ds) {
+  return ds.d_ye && ds.d_tptr && ds.d_L && ds.PT <= 3 && !ds.d_blist[0] && resident_split_mode(ds.mode);
+}
+
+void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStream_t s, const SplitIO *split) {
   DenseArgs a = make_args(ds);
   a.x = x;
+  if (split) {
+    PA_REQUIRE(split->n_true >= 0 && split->n_true <= ds.lsize, "split point outside the local vector");
+    a.nsplit = split->n_true;
+    a.xg0 = split->xg0 - split->n_true, a.xg1 = (split->xg1 ? split->xg1 : split->xg0) - split->n_true;
+    a.xg_sel = split->sel;
+    PA_REQUIRE(dense_split_ok(ds), "no split-vector form of this dense block");
+    if (masked && ds.d_idx_bc) a.idx = ds.d_idx_bc;
+    switch (ds.PT) {
+      case 1: launch_resident_split<1>(ds, a, s); break;
+      case 2: launch_resident_split<2>(ds, a, s); break;
+      default: launch_resident_split<3>(ds, a, s); break;
+    }
+    return;
+  }
   if (masked && ds.d_idx_bc) a.idx = ds.d_idx_bc;
   if (ds.d_L) {
     switch (ds.PT) {
@@ -1694,7 +1773,37 @@ void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *
   PA_HIP(hipGetLastError());
 }
 
-void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye) {
+// E^T of a split-vector apply: the sum of et_gather_kernel (same order, hence the same bits), rows >= nsplit to the ghost-row
+// buffer, ParOperator's essential rows fixed on the way (rap.cpp:223-233)
+__global__ void et_gather_split_kernel(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                                       const double *__restrict__ ye, double *__restrict__ y, double *__restrict__ yg,
+                                       const int nsplit, const uint8_t *__restrict__ ess, const double *__restrict__ x,
+                                       const int ess_policy) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  if (ess_policy >= 0 && ess && ess[d] && d < nsplit) {
+    y[d] = ess_policy ? x[d] : 0.0;
+    return;
+  }
+  double s = 0.0;
+  for (int k = tptr[d]; k < tptr[d + 1]; k++) {
+    const int t = tent[k];
+    const double v = ye[t >= 0 ? t : -1 - t];
+    s += t >= 0 ? v : -v;
+  }
+  (d < nsplit ? y : yg)[d] = s;
+}
+
+void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye, const SplitIO *split,
+                         const double *x, int ess_policy) {
+  if (split) {
+    PA_REQUIRE(!accumulate, "split vectors: y = A x only");
+    PA_REQUIRE(ess_policy < 0 || (ds.d_ess_flag && x), "essential rows of a split apply: pa_op_set_essential first");
+    hipLaunchKernelGGL(et_gather_split_kernel, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent,
+                       ye ? ye : ds.d_ye, y, split->yg - split->n_true, split->n_true, ds.d_ess_flag, x, ess_policy);
+    PA_HIP(hipGetLastError());
+    return;
+  }
   if (ye) {
     launch_et_gather_raw(ds.lsize, ds.d_tptr, ds.d_tent, ye, y, accumulate, s);
     return;

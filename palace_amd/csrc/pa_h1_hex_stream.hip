@@ -41,6 +41,12 @@ struct H1StreamArgs {
   const double *qdata;   // [ne][NG][64]
   const double *x;
   double *y, *ye;
+  // split vectors (SPLIT, as in pa_nd_hex_stream.hip): local dofs [0, nsplit) live in x / y, the ghosts in xg0 / xg1 (the parity
+  // of *xg_sel picks the buffer) and yg, all three stored shifted by -nsplit
+  int nsplit;
+  const double *xg0, *xg1;
+  const unsigned long long *xg_sel;
+  double *yg;
   H1StreamTab<P1> tab;
 };
 
@@ -60,7 +66,7 @@ struct H1SLayout {  // H1Layout<P1, 4> of pa_h1_hex.hip
   __device__ static __forceinline__ int ib(int f, int qx, int qy, int k) { return 2 * A_FIELD + f * B_FIELD + (qx * Q1 + qy) * NC + k; }
 };
 
-template <int P1, bool USE_V, bool USE_G, int MINW>
+template <int P1, bool USE_V, bool USE_G, int MINW, bool SPLIT = false>
 __global__ __launch_bounds__(64 * kH1StreamWaves, MINW) void h1_hex_stream_kernel(const H1StreamArgs<P1> a) {
   using L = H1SLayout<P1>;
   constexpr int Q1 = 4, NC = P1 + 1, PP = NC * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
@@ -78,6 +84,8 @@ __global__ __launch_bounds__(64 * kH1StreamWaves, MINW) void h1_hex_stream_kerne
   int b = base + (int)(blockIdx.x >> 3) * kH1StreamWaves + wave;
   if (b >= bend) return;
   const double *Bc = a.tab.Bc, *Gc = a.tab.Gc;
+  const double *xgh = nullptr;  // SPLIT: where the ghost entries are read
+  if (SPLIT) xgh = ((a.xg_sel ? *a.xg_sel : 0ull) & 1ull) ? a.xg1 : a.xg0;
 
   auto load_idx = [&](const int bb, const int sub, const int t, int (&s)[NPL + 2], unsigned (&p)[NPK + 1]) {
     const int e = bb * 4 + sub;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(64 * kH1StreamWaves, MINW) void h1_hex_stream_kerne
       const int pos = low ? 16 * r + 31 - __clz((int)low) : (int)((w >> 21) & 255u);
       int dof = stab[rid] + (t + 16 * r - pos);
       if (!(16 * r + 15 < PP) && t + 16 * r >= PP) dof = 0;
-      xv[r] = a.x[dof];
+      xv[r] = SPLIT ? (dof < a.nsplit ? a.x : xgh)[dof] : a.x[dof];
       s[r] = dof | ((fw >> (2 * r + 1)) & 1u ? kExclBit : 0) | ((fw >> (18 + r)) & 1u ? kEssBit : 0);
     }
   };
@@ -333,7 +341,9 @@ __global__ __launch_bounds__(64 * kH1StreamWaves, MINW) void h1_hex_stream_kerne
       const unsigned fl = (unsigned)side[2 * ((PP + 1) / 2) + 16 * NPK + mt] >> (2 * mr);
       const double v = sm[((unsigned)side[2 * ((PP + 1) / 2) + 16 * (mr >> 2) + mt] >> (8 * (mr & 3))) & 255u];
       const int d = side[m] & (kExclBit - 1);
-      double *dst = (fl & 2u) ? a.y + d : a.ye + ((size_t)e * PP + m);
+      double *yd = a.y;
+      if (SPLIT) yd = d < a.nsplit ? a.y : a.yg;
+      double *dst = (fl & 2u) ? yd + d : a.ye + ((size_t)e * PP + m);
       *dst = v;
     }
     hs_sync();
@@ -356,7 +366,7 @@ int device_cus_h1() {
   return cus;
 }
 
-template <int P1, bool V, bool G>
+template <int P1, bool V, bool G, bool SPLIT = false>
 void launch_vg(const SubOp &so, H1StreamArgs<P1> &a, hipStream_t s) {
   using L = H1SLayout<P1>;
   constexpr int MINW = 3;
@@ -365,7 +375,7 @@ void launch_vg(const SubOp &so, H1StreamArgs<P1> &a, hipStream_t s) {
   const size_t lds = sizeof(double) * (size_t)(kH1StreamWaves * 4) * ((L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8 + 14 + 15) / 32 * 32 + 16);
   static const int per_cu = [&] {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h1_hex_stream_kernel<P1, V, G, MINW>, 64 * kH1StreamWaves, lds) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h1_hex_stream_kernel<P1, V, G, MINW, SPLIT>, 64 * kH1StreamWaves, lds) != hipSuccess ||
         nb <= 0)
       nb = 2;
     return std::max(1, std::min(std::min(nb, MINW * 2), 8));
@@ -376,18 +386,32 @@ void launch_vg(const SubOp &so, H1StreamArgs<P1> &a, hipStream_t s) {
   // (workgroups are dealt to the XCDs round-robin: the grid is a multiple of 8)
   int grid = std::max(8, std::min(per_cu * cus, ((a.nbatch + kH1StreamWaves - 1) / kH1StreamWaves + 7) / 8 * 8));
   grid = (grid + 7) / 8 * 8;
-  hipLaunchKernelGGL((h1_hex_stream_kernel<P1, V, G, MINW>), dim3(grid), dim3(64 * kH1StreamWaves), lds, s, a);
+  hipLaunchKernelGGL((h1_hex_stream_kernel<P1, V, G, MINW, SPLIT>), dim3(grid), dim3(64 * kH1StreamWaves), lds, s, a);
   PA_HIP(hipGetLastError());
 }
 
 template <int P1>
-void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s) {
+void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split) {
   H1StreamArgs<P1> a;
   a.ne = so.ne;
   a.idxc = so.d_idxc;
   a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
   a.qdata = so.qd->d;
   a.x = x, a.y = y, a.ye = so.d_ye;
+  a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
+  if (split) {
+    PA_REQUIRE(split->n_true >= 0 && split->n_true <= so.lsize, "split point outside the local vector");
+    a.nsplit = split->n_true;
+    a.xg0 = split->xg0 - split->n_true, a.xg1 = (split->xg1 ? split->xg1 : split->xg0) - split->n_true;
+    a.xg_sel = split->sel, a.yg = split->yg - split->n_true;
+    switch (so.qf) {
+      case PA_QF_HCURL_33: launch_vg<P1, false, true, true>(so, a, s); break;
+      case PA_QF_H1_1: launch_vg<P1, true, false, true>(so, a, s); break;
+      case PA_QF_HCURLMASS_33: launch_vg<P1, true, true, true>(so, a, s); break;
+      default: throw Error("QFunction not available for H1 hexahedra");
+    }
+    return;
+  }
   switch (so.qf) {
     case PA_QF_HCURL_33: launch_vg<P1, false, true>(so, a, s); break;
     case PA_QF_H1_1: launch_vg<P1, true, false>(so, a, s); break;
@@ -398,6 +422,17 @@ void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStrea
 
 }  // namespace
 
+// the tables of the streaming form can be built (every order the kernel is instantiated for): the split-vector apply of a
+// multi-rank ParOperator::Mult always takes this form
+bool h1_hex_stream_capable(const SubOp &so) {
+  static const bool enabled = [] {
+    const char *e = getenv("PALACE_AMD_STREAM"), *h = getenv("PALACE_AMD_STREAM_H1");  // A/B switches
+    return !(e && e[0] == '0') && !(h && h[0] == '0');
+  }();
+  return enabled && so.fe_type == PA_FE_H1 && so.q1d == 4 && so.p >= 1 && so.p <= 3 && so.qd && so.qd->d && so.d_ye && so.d_tptr;
+}
+
+// ... and it is the default form of y = A x
 bool h1_hex_stream_ok(const SubOp &so) {
   static const bool enabled = [] {
     const char *e = getenv("PALACE_AMD_STREAM"), *h = getenv("PALACE_AMD_STREAM_H1");  // A/B switches
@@ -414,11 +449,11 @@ bool h1_hex_stream_ok(const SubOp &so) {
   return so.fe_type == PA_FE_H1 && so.q1d == 4 && so.p >= (all ? 1 : 3) && so.p <= 3 && so.qd && so.qd->d && so.d_ye && so.d_tptr;
 }
 
-void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s) {
+void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split) {
   switch (so.p) {
-    case 1: launch_p<1>(so, x, y, masked, s); break;
-    case 2: launch_p<2>(so, x, y, masked, s); break;
-    case 3: launch_p<3>(so, x, y, masked, s); break;
+    case 1: launch_p<1>(so, x, y, masked, s, split); break;
+    case 2: launch_p<2>(so, x, y, masked, s, split); break;
+    case 3: launch_p<3>(so, x, y, masked, s, split); break;
     default: throw Error("no streaming H1 kernel for this order");
   }
 }

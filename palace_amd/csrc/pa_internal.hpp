@@ -187,6 +187,7 @@ struct SubOp {
   int32_t *d_tent = nullptr;   // [ne * P] signed positions into d_ye
   // streaming form (pa_nd_hex_stream.hip): index words with the exclusive flag, byte slots, E^T of the shared dofs by runs
   uint32_t *d_idxc = nullptr;  // [ne][kIdxWords] run-compressed sorted element -> dof index (pa_stream_host.hpp)
+  bool stream_default = true;  // false: the tables exist for the split-vector apply only, y = A x keeps the one-shot kernel (H1, p < 3)
   int32_t *d_blist[2] = {nullptr, nullptr};  // batch lists of the interior / interface phases (stream_set_interface)
   int n_blist[2] = {0, 0};
   bool has_blist = false;
@@ -215,6 +216,7 @@ struct DenseSub {
   uint32_t trial_ops = 0, test_ops = 0;
   int32_t *d_idx = nullptr;     // [nb][4 KP][16] signed index (oriented: <0 => -(1+dof) flipped); pads read zero
   int32_t *d_idx_bc = nullptr;  // copy with kEssBit on essential dofs
+  uint8_t *d_ess_flag = nullptr;  // [lsize] 1 on essential dofs (row fix-up of the split-vector gather)
   uint16_t *d_co = nullptr;     // [nb][4 KP][16] packed int8 rows / columns of T_e (curl-oriented) or nullptr
   std::vector<int32_t> h_idx;
   std::vector<int32_t> h_off;  // plain [ne][P] offsets (full assembly)
@@ -277,8 +279,10 @@ void launch_nd_hex_qdata(SubOp &so, hipStream_t s);
 void launch_nd_hex_metric(SubOp &so, hipStream_t s);
 void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 // pa_nd_hex_stream.hip
-bool h1_hex_stream_ok(const SubOp &so);
-void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s);
+struct SplitIO;
+bool h1_hex_stream_ok(const SubOp &so);       // the streaming form is the default for y = A x
+bool h1_hex_stream_capable(const SubOp &so);  // ... its tables can be built (split-vector applies use it at every order)
+void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split = nullptr);
 bool nd_hex_stream_ok(const SubOp &so);
 void build_stream(SubOp &so);
 void stream_set_essential(SubOp &so, const std::vector<char> &flag);
@@ -317,8 +321,11 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
                          const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops, int height, bool contra = false);
 void free_dense_sub(DenseSub *ds);
 void dense_set_essential(DenseSub &ds, const std::vector<char> &flag);
-void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStream_t s);
-void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye = nullptr);
+void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStream_t s, const SplitIO *split = nullptr);
+// split: rows >= n_true go to split->yg; ess_policy >= 0 (with split only): essential rows are set to x (1) or 0 (0) here
+void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye = nullptr,
+                         const SplitIO *split = nullptr, const double *x = nullptr, int ess_policy = -1);
+bool dense_split_ok(const DenseSub &ds);
 bool dense_complex_ok(const DenseSub &dr, const DenseSub &di);
 void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s);
 void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s);

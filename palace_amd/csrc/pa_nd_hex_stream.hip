@@ -22,6 +22,9 @@
 
 #include "pa_nd_hex_core.hpp"
 
+#ifndef PA_STREAM_QAHEAD
+#define PA_STREAM_QAHEAD 0  // 1: the instantiations compiled for two waves per SIMD request the q-data one batch ahead
+#endif
 #ifndef PA_KM_MINW
 #define PA_KM_MINW 2  // waves per SIMD the p = 3 curl-curl + mass instantiation is compiled for (experiment builds: 3)
 #endif
@@ -185,6 +188,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   for (int r = 0; r < NPL; r++) asm volatile("" : "+v"(xv[r]));
   settle(pA);
 
+  // QAHEAD (kernels compiled for two waves per SIMD: they have the registers): the q-data of a batch is requested right after
+  // the D stage of the batch before it -- its registers are free from there on -- instead of at the top of its own batch, where
+  // only the E stage and the forward passes of the same batch (short at p < 3) stand between the request and the first use
+  constexpr bool QAHEAD = PA_STREAM_QAHEAD && MINW == 2 && !CPLX;
+  d2v gq[2 * NG];
+  auto load_q = [&](const int ee, const int t) {
+    const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)ee * (2 * (METRIC ? 7 : NG) * 16) + t);
+#pragma unroll
+    // (read once: non-temporal, so the stream does not displace x / y lines in L2; measured 5 - 7 % on the apply)
+    for (int k = 0; k < 2 * NG; k++) gq[k] = __builtin_nontemporal_load(&g[16 * k]);
+  };
+  if (QAHEAD) {
+    load_q(CPLX ? b * 2 + (lane >> 5) : b * 4 + (lane >> 4), lane & 15);
+#pragma unroll
+    for (int k = 0; k < 2 * NG; k++) asm volatile("" : "+v"(gq[k]));
+  }
 #ifdef PA_STREAM_TRACE
   const bool tr_on = blockIdx.x < kTraceWG && wave == 0;
   int tr_b = 0;
@@ -209,13 +228,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     const int e = CPLX ? b * 2 + (sub >> 1) : b * 4 + sub;
 
     // q-data of this batch: consumed after the forward contraction
-    d2v gq[2 * NG];
-    {
-      const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)e * (2 * (METRIC ? 7 : NG) * 16) + t);
-#pragma unroll
-      // (read once: non-temporal, so the stream does not displace x / y lines in L2; measured 5 - 7 % on the apply)
-      for (int k = 0; k < 2 * NG; k++) gq[k] = __builtin_nontemporal_load(&g[16 * k]);
-    }
+    if (!QAHEAD) load_q(e, t);
     d2v ce = {0.0, 0.0}, ci = {0.0, 0.0};
     if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
     if (CPLX) ci = reinterpret_cast<const d2v *>(a.coef1)[e];
@@ -314,6 +327,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     }
 
     PA_STAMP(5);  // D done
+    if (QAHEAD) {  // q-data of the next batch (the last one re-reads its own)
+      __builtin_amdgcn_sched_barrier(0);
+      load_q(CPLX ? bn * 2 + (sub >> 1) : bn * 4 + sub, t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // x of the next batch: in flight during the transposed passes
     double xB[NPL];
     if (GPOS == 0) {
@@ -503,7 +521,7 @@ void stream_element_coefficients(SubOp &so) {
 // exclusive flags).  Host work proportional to the index array, once per operator.  Every per-element array is padded
 // to a multiple of four elements (one batch); the pad entries are flagged essential (read as zero).
 void build_stream(SubOp &so) {
-  if (so.d_idxc || !(nd_hex_stream_ok(so) || h1_hex_stream_ok(so))) return;
+  if (so.d_idxc || !(nd_hex_stream_ok(so) || h1_hex_stream_capable(so))) return;
   const int P = so.P, ne = so.ne;
   std::vector<uint32_t> ic, pp;
   // (a numbering that breaks an element's dofs into more than kIdxMaxRuns runs keeps the one-shot kernel)
