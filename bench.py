@@ -57,6 +57,7 @@ def parse():
                          "code of `--gpus N` -- partition, halo plans, direct form, every N > 1 leg -- and prints its line "
                          "with \"rehearsal\": true.  Timings are those of N ranks sharing one GPU, not a scaling result.")
     ap.add_argument("--no-nranks-legs", action="store_true", help="N > 1: skip the order-4 and tetrahedral legs")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child processes that measure roofline.traffic")
     return ap.parse_args()
 
 
@@ -102,6 +103,32 @@ def rehearse(args):
 
 def _rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+_ORACLE_CACHE = {}
+
+
+def oracle_hex_data(prob, order):
+    """The C oracle's inputs for the finest space of a SlabProblem (geometry data, restriction, dense tables), built once per
+    problem: several legs check their device results against it at the full size."""
+    key = (id(prob), order)
+    if key not in _ORACLE_CACHE:
+        from oracle import capi
+        from oracle import palace_oracle as po
+        from tests import util
+
+        capi.build(ref=False)
+        nd = prob.spaces[-1]
+        off, ori = nd.native_restriction()
+        interp, curl = po.nd_hex_dense_tables(order, order + 1, nd.dof_map_native())
+        _ORACLE_CACHE.clear()  # (one problem at a time: the geometry data of the 10M-dof mesh is 0.7 GB)
+        _ORACLE_CACHE[key] = dict(geom=util.oracle_geom(prob.mesh, order + 1), off=off, ori=ori, interp=interp, curl=curl)
+    return _ORACLE_CACHE[key]
+
+
+def host_cores():
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return min(cores, 64)  # the element loop stops scaling beyond a socket's worth of threads
 
 
 def cpu_leg(ctx, prob, order, args):
@@ -164,8 +191,8 @@ def cpu_leg(ctx, prob, order, args):
     # ---- apply parity at the full bench size (the very operator and mesh of the timed loop), one oracle apply
     t0 = time.perf_counter()
     fnd = prob.spaces[-1]
-    fgeom = util.oracle_geom(prob.mesh, q1d)
-    foff, fori = fnd.native_restriction()
+    od = oracle_hex_data(prob, order)
+    fgeom, foff, fori = od["geom"], od["off"], od["ori"]
     fx = np.random.default_rng(2).uniform(0, 1, fnd.ndofs)
     fy = np.zeros(fnd.ndofs)
     capi.apply_add(foff, fori, interp, curl, fgeom, capi.QF_HDIV, blob, fx, fy, threads=cores)
@@ -256,10 +283,9 @@ def p4_leg(ctx, dofs, reps=200, pcg_iters=20, parity=True):
 
         capi.build(ref=False)
         t0 = time.perf_counter()
-        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
-        og = util.oracle_geom(mesh, p + 1)
-        off, ori = nd.native_restriction()
-        interp, curl = po.nd_hex_dense_tables(p, p + 1, nd.dof_map_native())
+        cores = host_cores()
+        od = oracle_hex_data(prob, p)
+        og, off, ori, interp, curl = od["geom"], od["off"], od["ori"], od["interp"], od["curl"]
         hx = np.random.default_rng(4).uniform(0, 1, nd.ndofs)
         hy = np.zeros(nd.ndofs)
         capi.apply_add(off, ori, interp, curl, og, capi.QF_HDIV, po.CoeffCtx().pack(), hx, hy, threads=cores)
@@ -267,9 +293,9 @@ def p4_leg(ctx, dofs, reps=200, pcg_iters=20, parity=True):
         prob.local_curlcurl.mult(torch.from_numpy(hx).cuda(), dy)
         out["parity"] = {"rel_l2_y_full": _rel(dy.cpu().numpy(), hy), "tolerance": 1e-12,
                          "size": f"{nd.ndofs} dofs, {mesh.ne} elements ({time.perf_counter() - t0:.1f} s of oracle work)"}
-        del og, hx, hy, dy
-    cl = complex_leg(ctx, prob)  # the complex form of the five-point kernel
-    out["complex"] = {k: cl[k] for k in ("one_pass", "ms", "complex_dof_per_s")}
+        del hx, hy, dy
+    cl = complex_leg(ctx, prob, parity=parity)  # the complex form of the five-point kernel
+    out["complex"] = {k: cl[k] for k in ("one_pass", "ms", "complex_dof_per_s", "hbm_frac", "parity") if k in cl}
     if pcg_iters > 0:
         solver, b, xs = prob.pcg_gmg_solver(max_it=pcg_iters, hiptmair=False, coarse="chebyshev")
         solver.mult(b, xs)
@@ -286,9 +312,11 @@ def p4_leg(ctx, dofs, reps=200, pcg_iters=20, parity=True):
     return out
 
 
-def complex_leg(ctx, prob, reps=50):
+def complex_leg(ctx, prob, reps=50, parity=True):
     """BASELINE config 3's operator shape on the bench mesh, N = 1: y = (K - w^2 eps M + i w sigma M) x through
-    ComplexParOperator::Mult -- both parts in one pass over the element data (pa_op_mult_complex, SURVEY.md 8(f)-1)."""
+    ComplexParOperator::Mult -- both parts in one pass over the element data (pa_op_mult_complex, SURVEY.md 8(f)-1).
+    hbm_frac: the algorithmic bytes of ONE pass over the element data (SURVEY.md 8d with G = 11) plus the second part of x and
+    y, over the measured time; parity: the device result against the C oracle's four real applies at this size."""
     import torch
 
     from palace_amd import ceed, linalg
@@ -314,8 +342,37 @@ def complex_leg(ctx, prob, reps=50):
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fused = bool(ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle))
-    return {"workload": f"ComplexParOperator::Mult, A = (K - w^2 eps M) + i w sigma M, ND p={nd.p}, {n} complex dofs",
-            "one_pass": fused, "ms": ms, "complex_dof_per_s": n / (ms * 1e-3)}
+    alg = Ar.algorithmic_bytes() + 16.0 * n
+    out = {"workload": f"ComplexParOperator::Mult, A = (K - w^2 eps M) + i w sigma M, ND p={nd.p}, {n} complex dofs",
+           "one_pass": fused, "ms": ms, "complex_dof_per_s": n / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
+           "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
+           "bytes_formula": "NE*(Q*11*8 + P*5) + 32*N_L: one pass over the element data, both parts of x and y"}
+    if parity:
+        from oracle import capi
+
+        t0 = time.perf_counter()
+        od = oracle_hex_data(prob, nd.p)
+        cores = host_cores()
+        ess = prob.ess[-1].astype(np.int64)
+        hr, hi = xr.cpu().numpy(), xi.cpu().numpy()
+        mr, mi = hr.copy(), hi.copy()
+        mr[ess] = 0.0
+        mi[ess] = 0.0
+        blob_r = np.concatenate([mass, ceed.coefficient_context(3)])
+
+        def oapply(qf, blob, v):
+            w = np.zeros(n)
+            capi.apply_add(od["off"], od["ori"], od["interp"], od["curl"], od["geom"], qf, blob, v, w, threads=cores)
+            return w
+
+        wr = oapply(capi.QF_HDIVMASS, blob_r, mr) - oapply(capi.QF_HCURL, cond, mi)
+        wi = oapply(capi.QF_HDIVMASS, blob_r, mi) + oapply(capi.QF_HCURL, cond, mr)
+        wr[ess], wi[ess] = hr[ess], hi[ess]  # DIAG_ONE (rap.cpp:450-457)
+        A.mult(xr, xi, yr, yi)
+        d = np.concatenate([yr.cpu().numpy() - wr, yi.cpu().numpy() - wi])
+        out["parity"] = {"rel_l2_y_full": float(np.linalg.norm(d) / np.linalg.norm(np.concatenate([wr, wi]))), "tolerance": 1e-12,
+                         "size": f"{n} complex dofs ({time.perf_counter() - t0:.1f} s of oracle work: four real applies of the C oracle)"}
+    return out
 
 
 def h1_leg(ctx, prob, order=2, reps=200, pcg_iters=50):
@@ -343,7 +400,27 @@ def h1_leg(ctx, prob, order=2, reps=200, pcg_iters=50):
             ms = e0.elapsed_time(e1) / reps
             out["workload"] = f"H1 p={order} hexahedra, {prob.mesh.ne} elements, {n} dofs, diffusion (eps_r = 2.08), Dirichlet boundary"
             out["dofs"] = n
-            out["apply"] = {"ms": ms, "dof_per_s": n / (ms * 1e-3)}
+            alg = A.local.algorithmic_bytes()
+            out["apply"] = {"ms": ms, "dof_per_s": n / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
+                            "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
+                            "bytes_formula": "NE*(Q*11*8 + P*4) + 16*N_L (SURVEY.md 8d, G = 11; Q = 27 at order 2)"}
+            # the local diffusion apply at this size against the numpy oracle (dense [3Q x P] gradient table, f_apply_hcurl_33)
+            from oracle import palace_oracle as po
+            from tests import util
+
+            t0 = time.perf_counter()
+            h1 = prob._keep[-1][0][-1]
+            q1 = order + 1
+            interp, grad = po.h1_hex_dense_tables(order, q1)
+            orc = po.CeedOperatorOracle(h1.ndofs, h1.elem_dof_lex, None, interp, grad, util.oracle_geom(prob.mesh, q1), po.QF_HCURL,
+                                        po.CoeffCtx(attr_mat=[0], mat_coeff=[np.array([2.08])]), None, vector_fe=False)
+            hx = np.random.default_rng(8).uniform(-1, 1, h1.ndofs)
+            hy = orc.apply_add(hx, np.zeros(h1.ndofs))
+            dy = torch.empty(h1.ndofs, dtype=torch.float64, device="cuda")
+            A.local.mult(torch.from_numpy(hx).cuda(), dy)
+            out["parity"] = {"rel_l2_y_full": _rel(dy.cpu().numpy(), hy), "tolerance": 1e-12,
+                             "size": f"{h1.ndofs} dofs, {prob.mesh.ne} elements ({time.perf_counter() - t0:.1f} s of oracle work)"}
+            del orc, hx, hy, dy
         solver.mult(b, xs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -415,7 +492,10 @@ def cpw_leg(order=3, refine=1, reps=20):
         e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    out["complex_apply"] = {"ms": ms, "complex_dof_per_s": n / (ms * 1e-3)}
+    alg = sys_["Kr"].algorithmic_bytes() + 16.0 * n
+    out["complex_apply"] = {"ms": ms, "complex_dof_per_s": n / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
+                            "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
+                            "bytes_formula": "NE*(Q*11*8 + P*7) + 32*N_L: one pass over the element data, both parts of x and y"}
     xr, xi = torch.zeros_like(br), torch.zeros_like(br)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -444,6 +524,31 @@ def cpw_leg(order=3, refine=1, reps=20):
     sys_["Kr"].mult(torch.from_numpy(hx).cuda(), dy)
     out["parity"] = {"rel_l2_y_full": _rel(dy.cpu().numpy(), hy), "tolerance": 1e-12,
                      "size": f"{n} dofs, {mesh.ne} tets ({time.perf_counter() - t0:.1f} s of oracle work)"}
+    # the COMPLEX operator: ComplexParOperator::Mult (one pass on the device) against the oracle's real and imaginary operators
+    # applied to both parts, essential rows as rap.cpp:450-457; and the FGMRES solution in the ORACLE's operator: the residual the
+    # reference's own arithmetic assigns to the device's answer
+    t0 = time.perf_counter()
+    oi = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([k0 ** 2 * 1.0 * 0.0]), np.array([k0 ** 2 * 11.7 * 0.05])])
+    orci = po.CeedOperatorOracle(n, nd.offsets, None, interp, curl, og, po.QF_HCURL, oi, **okw)
+
+    def o_complex(vr, vi):
+        mr, mi = vr.copy(), vi.copy()
+        mr[ess], mi[ess] = 0.0, 0.0
+        z = np.zeros(n)
+        wr = orc.apply_add(mr, z.copy()) - orci.apply_add(mi, z.copy())
+        wi = orc.apply_add(mi, z.copy()) + orci.apply_add(mr, z.copy())
+        wr[ess], wi[ess] = vr[ess], vi[ess]
+        return wr, wi
+
+    cr, ci = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    wr, wi = o_complex(cr, ci)
+    A.mult(torch.from_numpy(cr).cuda(), torch.from_numpy(ci).cuda(), yr, yi)
+    dd = np.concatenate([yr.cpu().numpy() - wr, yi.cpu().numpy() - wi])
+    out["parity"]["complex_apply_rel_l2"] = float(np.linalg.norm(dd) / np.linalg.norm(np.concatenate([wr, wi])))
+    sr, si = o_complex(xr.cpu().numpy(), xi.cpu().numpy())
+    rr = np.concatenate([sr - b.real, si - b.imag])
+    out["parity"]["fgmres_solution_rel_residual_in_the_oracle_operator"] = float(np.linalg.norm(rr) / np.linalg.norm(np.concatenate([b.real, b.imag])))
+    out["parity"]["complex_size"] = f"{n} complex dofs ({time.perf_counter() - t0:.1f} s of oracle work: eight real applies of the numpy oracle)"
     return out
 
 
@@ -650,6 +755,175 @@ def nranks_legs(ctx, rank, world, args, barrier, max_over_ranks):
     return out
 
 
+def spheres_leg(orders=(2, 3), reps=50):
+    """BASELINE config 4 on the reference's own mesh: examples/spheres/mesh/spheres.msh (14 362 cubic tetrahedra, committed as
+    tests/golden/spheres_mesh.npz), electrostatics: H1 order-p diffusion through the dense MFMA path, PCG + p-multigrid
+    (levels 1..p, Chebyshev smoothers) with the native algebraic V-cycle on the assembled order-1 level where the reference calls
+    BoomerAMG, one solve per terminal, the Maxwell capacitance matrix from the two potentials -- checked in-line against
+    test/data/regression/ref/spheres/terminal-C.csv (the reference runs the example at order 3; its own gate is 1e-4)."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem import tet
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "spheres_mesh.npz"))
+    nodes, en = d["nodes"], d["elem_nodes"].astype(np.int64)
+    used, inv = np.unique(en[:, :4], return_inverse=True)
+    mesh = tet.TetMesh(nodes[used], inv.reshape(-1, 4), d["attr"])
+    bt = np.sort(np.searchsorted(used, d["bdr_tris"].astype(np.int64)), axis=1)
+    fkey = {tuple(fv): i for i, fv in enumerate(map(tuple, mesh.face_verts))}
+    fm = {}
+    for a in (2, 3, 4):  # 2 far field (ground), 3 sphere A, 4 sphere B
+        m = np.zeros(mesh.face_verts.shape[0], dtype=bool)
+        m[[fkey[tuple(fv)] for fv in bt[d["bdr_attr"] == a]]] = True
+        fm[a] = m
+    all_m = fm[2] | fm[3] | fm[4]
+    ref = d["C_F"]
+    eps0 = 1.0 / (1.25663706127e-6 * 299792458.0 ** 2)  # utils/constants.hpp:21-30; the mesh is in cm (L0 = 1e-2)
+    out = {"workload": f"examples/spheres mesh: {mesh.ne} cubic tetrahedra, electrostatics (H1 diffusion, three Dirichlet boundaries), "
+                       "PCG + p-multigrid + native AMG on level 0, capacitance matrix against ref/spheres/terminal-C.csv",
+           "terminal_C_reference_F": ref.tolist()}
+    for p in orders:
+        levels = list(range(1, p + 1))
+        h1s = [tet.H1TetSpace(mesh, q) for q in levels]
+        pts, wts = tet.default_tet_rule(p)
+        G = tet.H1TetElement(3).tables(pts)[1]  # cubic geometry basis on the fixture's node order
+        geom = ceed.DenseGeomFactorData(en, nodes, mesh.attr, G, wts)
+        blocks = []
+        for sp in h1s:
+            interp, grad = sp.elem.tables(pts)
+            blocks.append(ceed.DenseBlock(ceed.FE_H1, sp.ndofs, sp.offsets, interp, grad))
+        fine = ceed.Operator(h1s[-1].ndofs, h1s[-1].ndofs).add_dense_integrator(geom, blocks[-1], ceed.QF_HCURL_33,
+                                                                               ceed.coefficient_context(3), ceed.EVAL_GRAD).finalize()
+        local = [fine.coarsen_dense(b) for b in blocks[:-1]] + [fine]
+        ess = [sp.ess_dofs(all_m).astype(np.int32) for sp in h1s]
+        ctx = linalg.Context()
+        A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE) for op, e in zip(local, ess)]
+        csr0 = local[0].full_assemble_device()
+        A[0] = linalg.AssembledParOperator(ctx, csr0, ess[0], linalg.DIAG_ONE)
+        P = [linalg.DenseInterp(ctx, h1s[l].restriction(), h1s[l + 1].restriction(),
+                                tet.h1_tet_transfer_matrix(levels[l], levels[l + 1])) for l in range(len(levels) - 1)]
+        B = linalg.gmg(ctx, A, P, linalg.amg(ctx, csr0, ess[0]), cheby_order=max(2 * p, 4))
+        solver = linalg.cg(ctx, A[-1], B, rel_tol=1e-12, max_it=300)
+        n = h1s[-1].ndofs
+        x = torch.rand(n, dtype=torch.float64, device="cuda")
+        y = torch.empty_like(x)
+        with torch.cuda.stream(ctx.torch_stream):
+            for _ in range(10):
+                fine.mult(x, y)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fine.mult(x, y)
+            e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        alg = fine.algorithmic_bytes()
+        phi, its, secs = [], [], []
+        for a in (3, 4):
+            v = torch.zeros(n, dtype=torch.float64, device="cuda")
+            v[torch.from_numpy(h1s[-1].ess_dofs(fm[a]).astype(np.int64)).cuda()] = 1.0
+            b = torch.zeros_like(v)
+            A[-1].eliminate_rhs(v, b)
+            xs = torch.zeros_like(v)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            solver.mult(b, xs)
+            torch.cuda.synchronize()
+            secs.append(time.perf_counter() - t0)
+            its.append(solver.stats()["iterations"])
+            phi.append(xs)
+        t = torch.empty(n, dtype=torch.float64, device="cuda")
+        Cm = np.zeros((2, 2))
+        for i in range(2):
+            fine.mult(phi[i], t)
+            for j in range(2):
+                Cm[j, i] = eps0 * 1.0e-2 * float(phi[j] @ t)
+        out[f"p{p}"] = {"dofs": n, "levels": ",".join(str(q) for q in levels),
+                        "apply": {"ms": ms, "dof_per_s": n / (ms * 1e-3), "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
+                                  "note": "14 362 elements: a launch of 56 us cannot fill the GPU; the number is here for completeness"},
+                        "pcg_iterations_to_1e-12": its, "pcg_seconds": secs, "iters_per_s": sum(its) / sum(secs),
+                        "terminal_C_F": Cm.tolist(), "rel_dev_from_terminal_C_csv": float(np.abs(Cm - ref).max() / np.abs(ref).max()),
+                        "gate": "order 3 (the order of the reference's regression run): 1e-6; order 2: discretisation difference only"}
+        del solver, B, A, P, local, fine, geom
+    return out
+
+
+def magnetostatic_leg(ctx, prob, iters=400):
+    """The singular magnetostatic system on the bench cylinder: curl-curl alone (no mass term), PCG + p-multigrid with plain
+    Chebyshev smoothers (the reference's configuration for magnetostatics, iodata.cpp:533-564) and the native AMS on level 0 in
+    its singular mode (ams_singular_op: no gradient-space correction, linalg/ams.cpp:28-30, :149-152); the right-hand side is in
+    the range of K (K times a random vector), iterations to 1e-8 in the preconditioned residual."""
+    import torch
+
+    solver, b, xs = prob.pcg_gmg_solver(max_it=iters, rel_tol=1e-8, hiptmair=False, coarse="ams", eps_r=0.0, singular=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    solver.mult(b, xs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = solver.stats()
+    prob._keep.clear()
+    return {"workload": f"K x = b (curl-curl only, singular), ND p={prob.p}, {b.numel()} dofs, b = K (random)", "iterations_to_1e-8": st["iterations"],
+            "seconds": dt, "iters_per_s": st["iterations"] / dt, "converged": st["converged"],
+            "final_rel_res": st["final_res"] / st["initial_res"]}
+
+
+def measure_traffic(dofs, timeout=240):
+    """HBM-side traffic of ONE curl-curl apply (element kernel + run gather), measured in this run: two `rocprofv3 --pmc` child
+    processes (FETCH_SIZE, WRITE_SIZE: separate passes, counters only with --kernel-trace, as MI355X_MICROARCH.md prescribes)
+    over scripts/profile_apply.py -- the bench mesh, 10 applies, then a calibration stream y = a x + b y with known bytes in the
+    same process -- each counter divided by the fraction it reports of that known stream (the gfx950 FETCH_SIZE halving of
+    16-byte-lane loads included).  Returns (bytes per apply or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals, n_cal = {}, None
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pa_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT, OP="curl", REPS="10", DOFS=str(dofs))
+        try:
+            p = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "scripts", "profile_apply.py")], cwd="/tmp", env=env, capture_output=True, timeout=timeout)
+            for ln in p.stdout.decode(errors="replace").splitlines():
+                if ln.startswith("done"):
+                    n_cal = int(ln.split()[1])
+            acc = {}
+            for fcsv in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(fcsv)):
+                    k = row["Kernel_Name"]
+                    tag = ("elem" if "nd_hex_stream_kernel" in k else "gather" if "et_run_gather_kernel" in k else
+                           "cal" if ("OpAxpby" in k and ("k_ew<2" in k or "k_ew<(int)2" in k)) else None)
+                    if tag and row["Counter_Name"] == ctr:
+                        sm, ids = acc.get(tag, (0.0, set()))
+                        ids.add(row["Dispatch_Id"])
+                        acc[tag] = (sm + float(row["Counter_Value"]), ids)
+            for tag, (sm, ids) in acc.items():
+                vals[(tag, ctr)] = sm / max(1, len(ids)) * 1024.0  # (KiB per dispatch)
+        except Exception as exc:  # noqa: BLE001
+            return None, f"rocprofv3 --pmc {ctr} failed: {type(exc).__name__}: {exc}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    need = [("elem", "FETCH_SIZE"), ("gather", "FETCH_SIZE"), ("cal", "FETCH_SIZE"), ("elem", "WRITE_SIZE"), ("gather", "WRITE_SIZE"),
+            ("cal", "WRITE_SIZE")]
+    if n_cal is None or any(k not in vals for k in need):
+        return None, "counter output incomplete: " + ", ".join(f"{a}.{b}" for a, b in need if (a, b) not in vals)
+    rf = vals[("cal", "FETCH_SIZE")] / (16.0 * n_cal)
+    rw = vals[("cal", "WRITE_SIZE")] / (8.0 * n_cal)
+    traffic = (vals[("elem", "FETCH_SIZE")] + vals[("gather", "FETCH_SIZE")]) / rf + (vals[("elem", "WRITE_SIZE")] + vals[("gather", "WRITE_SIZE")]) / rw
+    note = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes) over 10 applies on the bench mesh; per apply: "
+            f"element kernel {vals[('elem', 'FETCH_SIZE')] / 1e6:.1f} MB fetched (raw) + {vals[('elem', 'WRITE_SIZE')] / 1e6:.1f} MB written, run gather "
+            f"{vals[('gather', 'FETCH_SIZE')] / 1e6:.1f} + {vals[('gather', 'WRITE_SIZE')] / 1e6:.1f}; calibration on y = a x + b y over {n_cal} doubles "
+            f"in the same process: FETCH_SIZE reports {rf:.3f} of the known read bytes, WRITE_SIZE {rw:.3f} of the written ones; raw counters divided by those")
+    return traffic, note
+
+
 def main():
     args = parse()
     if args.rehearse > 1:
@@ -808,9 +1082,9 @@ def main():
     # HBM traffic of the same launch from the PMC passes (collected by scripts/profile_round.sh in separate
     # rocprofv3 --pmc runs, summary committed under profiles/): raw FETCH_SIZE + WRITE_SIZE bytes
     traffic, traffic_note = None, "no PMC summary under profiles/"
-    pmc_file = os.path.join(ROOT, "profiles", "r03_apply_pmc.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r04_apply_pmc.json")  # (fall-back when the in-run measurement below is not available)
     if not os.path.exists(pmc_file):
-        pmc_file = os.path.join(ROOT, "profiles", "r02_apply_pmc.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r03_apply_pmc.json")
     if os.path.exists(pmc_file) and abs(args.dofs - 10.0e6) < 1 and p == 3 and world == 1 and args.scaling == "strong":
         pmc = json.load(open(pmc_file))
         pb = pmc["per_apply_bytes"]
@@ -943,9 +1217,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_p4:
         cplx = _leg(complex_leg, ctx, prob)
         h1 = _leg(h1_leg, ctx, prob)
-    cpw = None
+    cpw = sph = mag = None
     if rank == 0 and world == 1 and not args.no_tets:
         cpw = _leg(cpw_leg, p)
+        sph = _leg(spheres_leg)
+    if rank == 0 and world == 1 and not args.no_p4:
+        mag = _leg(magnetostatic_leg, ctx, prob)
 
     nranks = None
     if world > 1 and not args.no_nranks_legs:
@@ -967,6 +1244,14 @@ def main():
             cpu, parity = cpu_leg(ctx, prob, p, args)
         except Exception as exc:  # noqa: BLE001
             cpu, parity = {"error": f"{type(exc).__name__}: {exc}"}, None
+    if rank == 0 and world == 1 and not args.no_traffic and abs(args.dofs - 10.0e6) < 1 and p == 3 and args.scaling == "strong":
+        tr, note = measure_traffic(args.dofs)
+        if tr is not None:
+            roofline["traffic"], roofline["traffic_note"] = tr, note
+            roofline["traffic_over_design_floor"] = (tr / design_floor) if design_floor else None
+            roofline["traffic_over_algorithmic"] = tr / alg_bytes
+        else:
+            roofline["traffic_note"] = f"in-run measurement unavailable ({note}); " + roofline["traffic_note"]
     if world > 1:
         dist.barrier()
 
@@ -984,7 +1269,7 @@ def main():
                        "parallelism": f"element partition x{world}, halo (P / P^T) and global sums over "
                                       + ("the peer transport (direct xGMI stores; RCCL as the fall-back)" if (world > 1 and ctx.peer_ready())
                                          else "RCCL")},
-            "rehearsal": rehearsal, "pre_warm_steps": args.pre_warm, "halo": halo_info, "n_ranks_legs": nranks, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "cpw": cpw, "tets_mfma": tets,
+            "rehearsal": rehearsal, "pre_warm_steps": args.pre_warm, "halo": halo_info, "n_ranks_legs": nranks, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "cpw": cpw, "spheres": sph, "magnetostatic": mag, "tets_mfma": tets,
             "setup_s": t_setup,
         }
         sys.stdout.flush()

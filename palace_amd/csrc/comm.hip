@@ -603,6 +603,77 @@ __global__ __launch_bounds__(256) void k_peer_consume_r(const PeerNbr *__restric
     if (nb[k].rn[1] > 0) st_sys(nb[k].ack[1], s);
 }
 
+// (3) P^T of the direct form in ONE kernel: ghost rows (contiguous: the local apply wrote them to GhostOut) into the owners' mailboxes,
+// flags, acknowledgement of this Mult's P messages -- then the same blocks wait for the neighbours' rows and add them to y in place
+// (k_peer_send<0> + k_peer_consume_r<2> behind one launch: at the per-rank sizes of a strong-scaling run a launch costs what
+// the exchange does).  Every block takes part in both phases; the exchange counter is advanced by the block that finishes last,
+// after every block has read it.  A block spinning in the second phase waits for OTHER ranks' first phases only, which never wait.
+__global__ __launch_bounds__(256) void k_peer_restrict_direct(const PeerNbr *__restrict__ nb, const int nnbr, const PeerLocal *__restrict__ F,
+                                                               PeerCounters *__restrict__ L, const int total,
+                                                               const double *__restrict__ gout, const double *__restrict__ mb,
+                                                               const int nsend, double *__restrict__ y, const int ndof,
+                                                               const int4 *__restrict__ rinfo, const int32_t *__restrict__ rptr,
+                                                               const int32_t *__restrict__ rpos, unsigned long long *err,
+                                                               const uint8_t *__restrict__ mask) {
+  const int dir = 1;
+  const unsigned long long s = L->seq[1] + 1ull;
+  const int par = (int)(s & 1ull);
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {
+    double val[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = i0 + j * stride;
+      val[j] = i < total ? gout[i] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = i0 + j * stride;
+      if (i >= total) break;
+      int k = 0;
+      while (k + 1 < nnbr && i >= nb[k].off[dir] + nb[k].n[dir]) k++;
+      st_sys_f64(&nb[k].dst[dir][(long long)par * nb[k].stride[dir] + (i - nb[k].off[dir])], val[j]);
+    }
+  }
+  if (last_block(&L->done[1], gridDim.x)) {
+    for (int k = threadIdx.x; k < nnbr; k += blockDim.x) {
+      if (nb[k].n[dir] > 0) st_sys(nb[k].flag[dir], s);
+      if (nb[k].rn[0] > 0) st_sys(nb[k].ack[0], L->seq[0]);  // the element kernel that read the P messages in place has finished
+    }
+  }
+  wait_exchange(nb, nnbr, F, 1, s, err);
+  const double *src = mb + (size_t)par * nsend;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < ndof; i0 += 2 * stride) {
+    int4 info[2];
+    double sum[2], c0[2], c1[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int i = i0 + j * stride;
+      info[j] = i < ndof ? rinfo[i] : make_int4(-1, -1, -1, -1);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      sum[j] = info[j].x >= 0 ? y[info[j].x] : 0.0;
+      c0[j] = info[j].y >= 0 ? ld_sys_f64(&src[info[j].y]) : 0.0;
+      c1[j] = info[j].z >= 0 ? ld_sys_f64(&src[info[j].z]) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int i = i0 + j * stride, d = info[j].x;
+      if (d < 0) break;
+      double t = sum[j] + c0[j];
+      if (info[j].z >= 0) t += c1[j];
+      if (info[j].w >= 0)
+        for (int a = info[j].w; a < rptr[i + 1]; a++) t += ld_sys_f64(&src[rpos[a]]);
+      if (!(mask[d] & 1)) y[d] = t;
+    }
+  }
+  if (!last_block(&L->cons[1], gridDim.x)) return;
+  for (int k = threadIdx.x; k < nnbr; k += blockDim.x)
+    if (nb[k].rn[1] > 0) st_sys(nb[k].ack[1], s);
+  if (threadIdx.x == 0) L->seq[1] = s;
+}
+
 // global sum: my values into everybody's slot of me, flags; then wait for everybody and add in rank order (the same result,
 // bit for bit, on every rank).  Double-buffered: a rank can be one sum ahead of another, never two (it needs the other's flag
 // of the sum in between).
@@ -1006,6 +1077,13 @@ void Halo::SendDirect(const double *d_x, const uint8_t *d_mask, hipStream_t s) c
 void Halo::RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) const {
   const PeerPlan &p = *peer_;
   const int mb = mail_blocks(nrecv_), sb = sum_blocks(p.n_rdof);
+  static const bool merged = !(std::getenv("PALACE_AMD_HALO_MERGED") && std::getenv("PALACE_AMD_HALO_MERGED")[0] == '0');
+  if (merged) {  // one launch for both halves (PALACE_AMD_HALO_MERGED=0: the two kernels of round 3)
+    hipLaunchKernelGGL(k_peer_restrict_direct, dim3(std::max(mb, sb)), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, nrecv_,
+                       GhostOut(), p.mb[1], nsend_, d_y, p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, d_mask);
+    PA_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(k_peer_send<0>, dim3(mb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.counters, 1, nrecv_, GhostOut(), nullptr, 0,
                      nullptr, nullptr, 0, mb, nullptr, nullptr, 1);
   hipLaunchKernelGGL(k_peer_consume_r<2>, dim3(sb), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, p.mb[1], nsend_, d_y,

@@ -1033,6 +1033,15 @@ int pa_op_mult_essential(pa_op *op, const double *x, double *y, void *stream) {
 int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_policy, void *stream, int *handled) {
   return guarded([&] {
     PA_REQUIRE(op && op->has_essential && handled, "pa_op_set_essential has not been called");
+    if (op->subs.empty() && op->msubs.empty() && op->dsubs.size() == 1 && op->dsubs[0]->d_ess_flag && x != y &&
+        !TransposeScope::active()) {
+      // one dense-table block: essential entries read as zero through the flagged index copy, rows fixed by the gather
+      const DenseSub &ds = *op->dsubs[0];
+      launch_dense_apply(ds, x, true, (hipStream_t)stream);
+      launch_dense_gather(ds, y, false, (hipStream_t)stream, nullptr, nullptr, x, diag_policy ? 1 : 0);
+      *handled = 1;
+      return;
+    }
     const bool fuse = op->subs.size() == 1 && op->dsubs.empty() &&
                       (op->subs[0]->fe_type == PA_FE_HCURL ? nd_hex_fuses_essential(*op->subs[0])
                                                            : (op->subs[0]->d_idxc && op->subs[0]->stream_default && op->subs[0]->d_perm_s_bc));
@@ -1113,7 +1122,8 @@ int pa_op_width(const pa_op *op) { return op ? op->width : -1; }
 double pa_op_algorithmic_bytes(const pa_op *op) {
   if (!op) return 0.0;
   double bytes = 0.0;
-  for (const SubOp *so : op->subs) bytes += (double)so->ne * ((double)so->Q * 11 * 8 + (double)so->P * 5);
+  // (o = 1 orientation byte per entry for the oriented restriction of H(curl) blocks, none for H1: SURVEY.md 8d)
+  for (const SubOp *so : op->subs) bytes += (double)so->ne * ((double)so->Q * 11 * 8 + (double)so->P * (so->fe_type == PA_FE_H1 ? 4 : 5));
   for (const DenseSub *ds : op->dsubs)  // o = 3 for the curl-oriented restriction; G = 11 (3-D) or 6 (2-D)
     bytes += (double)ds->ne * ((double)ds->Q * ds->geom->nrows * 8 + (double)ds->P * (ds->d_co ? 7 : 5));
   return bytes + 16.0 * op->height;

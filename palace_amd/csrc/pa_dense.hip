@@ -1796,11 +1796,12 @@ __global__ void et_gather_split_kernel(const int n, const int32_t *__restrict__ 
 
 void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye, const SplitIO *split,
                          const double *x, int ess_policy) {
-  if (split) {
-    PA_REQUIRE(!accumulate, "split vectors: y = A x only");
-    PA_REQUIRE(ess_policy < 0 || (ds.d_ess_flag && x), "essential rows of a split apply: pa_op_set_essential first");
+  if (split || ess_policy >= 0) {  // (one vector with the essential rows fixed on the way: the same kernel, nothing beyond y)
+    PA_REQUIRE(!accumulate, "split vectors / fused essential rows: y = A x only");
+    PA_REQUIRE(ess_policy < 0 || (ds.d_ess_flag && x), "essential rows fused into the gather: pa_op_set_essential first");
     hipLaunchKernelGGL(et_gather_split_kernel, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent,
-                       ye ? ye : ds.d_ye, y, split->yg - split->n_true, split->n_true, ds.d_ess_flag, x, ess_policy);
+                       ye ? ye : ds.d_ye, y, split ? split->yg - split->n_true : y, split ? split->n_true : 0x7fffffff,
+                       ds.d_ess_flag, x, ess_policy);
     PA_HIP(hipGetLastError());
     return;
   }

@@ -287,7 +287,7 @@ class SlabProblem:
                                   n_true=self.n_true[-1], halo=self.halos[-1])
 
     def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False,
-                       coarse="cg", coarse_assembled=True):
+                       coarse="cg", coarse_assembled=True, singular=False):
         """PCG on (K + M) with the p-multigrid preconditioner configured as the reference does for
         p = 3 (iodata.cpp:533-564: 4th-kind Chebyshev of order max(2p, 4), 1 smoothing step, 1 V-cycle);
         level 0 is solved by Jacobi-PCG (the reference uses AMS from HYPRE there, linalg/ams.cpp)."""
@@ -341,7 +341,7 @@ class SlabProblem:
                 assert self.orders[0] == 1 and coarse_assembled, "AMS: assembled order-1 level"
                 h1_0 = H1HexSpace(self.mesh, 1)
                 csolver = linalg.ams(ctx, csr0, self.ess[0], lowest_order_gradient(h1_0, self.spaces[0]),
-                                     vertex_coordinates(h1_0))
+                                     vertex_coordinates(h1_0), singular=singular)
             elif coarse == "ams":
                 # several ranks: the order-1 problem of the WHOLE cylinder is assembled and solved redundantly by every rank
                 # (linalg.replicated: the right-hand side gathered through a halo plan on the global-numbered vector)
@@ -370,6 +370,8 @@ class SlabProblem:
         K = linalg.cg(ctx, A[-1], B, rel_tol=rel_tol, max_it=max_it)
         n = self.n_true[-1]
         ones = torch.ones(n, dtype=torch.float64, device="cuda")
+        if singular:  # a right-hand side in the range of the singular operator
+            ctx.set_random(ones, 11 + self.rank)
         b = torch.empty_like(ones)
         A[-1].mult(ones, b)
         b[torch.from_numpy(self.ess[-1].astype(np.int64)).cuda()] = 0.0

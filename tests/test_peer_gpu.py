@@ -168,7 +168,7 @@ def _stress_worker(rank, world, port, rounds, out):
             res[name] = ctx.peer_stress(r, 4096, direct=direct, graph=graph, ring=ring)
         ctx.peer_check()
         # plans come and go: the descriptor slots and arena blocks of destroyed plans are used again (more plans than slots)
-        for _ in range(600):
+        for _ in range(560):
             h = ctx._ring_plan(64)
             del h
         res["after_churn"] = ctx.peer_stress(50, 4096, direct=True, graph=False)
@@ -185,7 +185,7 @@ def test_flag_protocol_stress(world):
     every received value verified on the device: a reordering of data and flag stores would show up as a wrong value."""
     import torch.multiprocessing as mp
 
-    rounds = 100000 if world == 2 else 20000
+    rounds = 100000 if world == 2 else 5000
     q = mp.get_context("spawn").SimpleQueue()
     mp.spawn(_stress_worker, args=(world, 29660 + world, rounds, q), nprocs=world, join=True)
     res = q.get()
