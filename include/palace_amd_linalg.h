@@ -208,6 +208,14 @@ int pa_amg_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_es
 int pa_ams_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_ess, int n_vert, const int32_t *G_rowptr,
                   const int32_t *G_col, const double *G_val, const double *coords, int dim, const pa_ams_options *opt,
                   pa_solver **S);
+/* The coarsest level of a MULTI-RANK hierarchy solved redundantly by every rank with the native cycles (the reference runs HYPRE's
+ * distributed AMS / BoomerAMG there: linalg/ksp.cpp:129-239).  Built from what each rank holds -- `level0`: the level's ParOperator
+ * (halo plan, essential dofs, assembled or partially assembled local operator); G (AMS; NULL: the AMG cycle): the lowest-order
+ * discrete gradient between the ranks' H1 and H(curl) true dofs; xyz_true [nv_true][dim]: coordinates of this rank's true
+ * vertices -- by numbering the true dofs rank by rank, gathering triplets, gradient rows and coordinates over the communicator and
+ * assembling the same global problem everywhere (ksp.hpp: ReplicatedCoarseSolver).  Collective. */
+int pa_replicated_coarse_create(pa_context *ctx, pa_par_op *level0, pa_interp *G, int nv_true, const double *xyz_true, int dim,
+                                int cycle_it, int singular, pa_solver **S);
 /* The hierarchy of an AMG solver (which = 0) or of the gradient-space (1) / nodal-space (2) solver inside an AMS solver:
  * number of levels; and copies of its matrices -- kind 0: A_level, 1: P_level (level + 1 -> level), 2: the dense inverse used
  * on the last level (row-major in val, rowptr / col untouched).  Null output arrays: sizes only. */

@@ -90,7 +90,7 @@ public:
   static constexpr int kUniqueIdBytes = 128;
   static constexpr int kPeerHandleBytes = 64;  // sizeof(hipIpcMemHandle_t)
   // (kMaxNbr = kMaxRanks: the gather plan of a replicated coarse solve names every other rank as a neighbour)
-  static constexpr int kMaxRanks = 64, kMaxReduce = 512, kMaxHalos = 512, kMaxNbr = 64;
+  static constexpr int kMaxRanks = 64, kMaxReduce = 4096, kMaxHalos = 512, kMaxNbr = 64;
   static constexpr int kMaxReduceSetup = kMaxRanks;  // values of the set-up channel (barriers / gathers of PeerSetup: own counters and slots)
   static void GetUniqueId(char *out);
   Comm(int rank, int size, const char *unique_id);

@@ -54,10 +54,219 @@ amg::HostCsr AssembledLevelMatrix(const Operator &op, std::vector<char> &ess_fla
   return DownloadCsr(m->Matrix(), ess.data(), (int)ess.size());
 }
 
+// ---- the coarsest level across ranks: replicated (ksp.hpp: ReplicatedCoarseSolver) ------------------------------------------
+// in-place sum over the ranks of a host array (Mpi::GlobalSum on a std::vector)
+void GlobalSumHost(const Context &ctx, std::vector<double> &v) {
+  if (!ctx.comm || ctx.comm->Size() == 1 || v.empty()) return;
+  double *d = pa::dev_upload(v.data(), v.size(), ctx.stream);
+  ctx.comm->AllReduceSum(d, (int)v.size(), ctx.stream);
+  PA_HIP(hipMemcpyAsync(v.data(), d, sizeof(double) * v.size(), hipMemcpyDeviceToHost, ctx.stream));
+  PA_HIP(hipStreamSynchronize(ctx.stream));
+  (void)hipFree(d);
+  ctx.comm->PeerCheckNow();
+}
+// the pieces of all ranks one after the other (rank order); counts / offsets of the pieces on request
+std::vector<double> AllGatherV(const Context &ctx, const std::vector<double> &mine, std::vector<long long> *offsets = nullptr) {
+  const int size = ctx.comm ? ctx.comm->Size() : 1, rank = ctx.comm ? ctx.comm->Rank() : 0;
+  std::vector<double> cnt((size_t)size, 0.0);
+  cnt[(size_t)rank] = (double)mine.size();
+  GlobalSumHost(ctx, cnt);
+  std::vector<long long> off((size_t)size + 1, 0);
+  for (int r = 0; r < size; r++) off[(size_t)r + 1] = off[(size_t)r] + (long long)cnt[(size_t)r];
+  PA_REQUIRE(off[(size_t)size] < (1ll << 31), "replicated coarse level: too many entries to gather");
+  std::vector<double> all((size_t)off[(size_t)size], 0.0);
+  std::copy(mine.begin(), mine.end(), all.begin() + off[(size_t)rank]);
+  GlobalSumHost(ctx, all);  // (zeros outside a rank's own segment: the sum is the concatenation, exactly)
+  if (offsets) *offsets = off;
+  return all;
+}
+// local CSR of the level operator in L-vector numbering, nothing eliminated
+amg::HostCsr LocalLevelMatrix(const ParOperator &par) {
+  if (const auto *csr = dynamic_cast<const CsrOperator *>(&par.LocalOperator())) return DownloadCsr(csr->Matrix(), nullptr, 0);
+  const auto *pa = dynamic_cast<const ceed::Operator *>(&par.LocalOperator());
+  PA_REQUIRE(pa, "the coarse operator is neither assembled nor a partially assembled operator");
+  const auto m = BilinearForm::FullAssemble(*pa, /*skip_zeros=*/false);
+  return DownloadCsr(m->Matrix(), nullptr, 0);
+}
+
+}  // namespace
+
+struct ReplicatedCoarseSolver::Impl {
+  std::unique_ptr<Solver> inner;  // AmsSolver / AmgSolver of the global problem
+  std::unique_ptr<Halo> gather;
+  std::unique_ptr<ReplicatedSolver> rep;
+  int n_global = 0;
+};
+ReplicatedCoarseSolver::~ReplicatedCoarseSolver() = default;
+int ReplicatedCoarseSolver::GlobalSize() const { return impl_->n_global; }
+void ReplicatedCoarseSolver::Mult(const Vector &x, Vector &y) const { impl_->rep->Mult(x, y); }
+
+ReplicatedCoarseSolver::ReplicatedCoarseSolver(const Context &ctx, const Operator &level0, const Operator *G, int nv_true,
+                                               const double *xyz_true, int dim, int cycle_it, bool singular)
+    : impl_(new Impl) {
+  StreamGraph::RequireNotRecording("ReplicatedCoarseSolver set-up");
+  const auto *fop = dynamic_cast<const FespaceParOperator *>(&level0);
+  const ParOperator *par = fop ? &fop->Par() : dynamic_cast<const ParOperator *>(&level0);
+  PA_REQUIRE(par && ctx.comm, "replicated coarse solver: needs the level's ParOperator and a communicator");
+  const Halo *halo = par->GetHalo();
+  PA_REQUIRE(halo, "replicated coarse solver: the level has no halo plan (one rank: use the solver directly)");
+  const int size = ctx.comm->Size(), rank = ctx.comm->Rank();
+  const int n_true = level0.Height(), n_local = par->LocalOperator().Height();
+  height = width = n_true;
+  // ---- global numbers: true dofs rank by rank, ghosts through the halo plan
+  std::vector<long long> off;
+  {
+    std::vector<double> one((size_t)n_true, 1.0);  // (only the piece sizes are wanted)
+    std::vector<double> cnt((size_t)size, 0.0);
+    cnt[(size_t)rank] = (double)n_true;
+    GlobalSumHost(ctx, cnt);
+    off.assign((size_t)size + 1, 0);
+    for (int r = 0; r < size; r++) off[(size_t)r + 1] = off[(size_t)r] + (long long)cnt[(size_t)r];
+  }
+  const long long n_global = off[(size_t)size];
+  PA_REQUIRE(n_global < (1ll << 31), "replicated coarse level: too many global dofs");
+  impl_->n_global = (int)n_global;
+  std::vector<double> gid((size_t)n_local, -1.0);
+  for (int i = 0; i < n_true; i++) gid[(size_t)i] = (double)(off[(size_t)rank] + i);
+  {
+    Vector lx(n_local);
+    PA_HIP(hipMemcpyAsync(lx.Data(), gid.data(), sizeof(double) * (size_t)n_local, hipMemcpyHostToDevice, ctx.stream));
+    halo->Prolongate(lx.Data(), ctx.stream);
+    PA_HIP(hipMemcpyAsync(gid.data(), lx.Data(), sizeof(double) * (size_t)n_local, hipMemcpyDeviceToHost, ctx.stream));
+    PA_HIP(hipStreamSynchronize(ctx.stream));
+    ctx.comm->PeerCheckNow();
+  }
+  for (int i = 0; i < n_local; i++) PA_REQUIRE(gid[(size_t)i] >= 0.0 && gid[(size_t)i] < (double)n_global, "replicated coarse level: a ghost has no owner");
+  // ---- the global matrix: triplets of every rank's local matrix in global numbers
+  amg::HostCsr Ag;
+  {
+    const amg::HostCsr Al = LocalLevelMatrix(*par);
+    PA_REQUIRE(Al.nrows == n_local && Al.ncols == n_local, "replicated coarse level: local matrix size");
+    std::vector<double> ti((size_t)Al.nnz()), tj((size_t)Al.nnz());
+    for (int r = 0; r < n_local; r++)
+      for (int a = Al.rowptr[(size_t)r]; a < Al.rowptr[(size_t)r + 1]; a++) ti[(size_t)a] = gid[(size_t)r], tj[(size_t)a] = gid[(size_t)Al.col[(size_t)a]];
+    const std::vector<double> gi = AllGatherV(ctx, ti), gj = AllGatherV(ctx, tj), gv = AllGatherV(ctx, Al.val);
+    const size_t nt = gi.size();
+    // rows by counting (entries of a row stay in gathered order: rank by rank), then columns sorted, duplicates summed in that
+    // order -- the same arithmetic on every rank
+    std::vector<int> rp((size_t)n_global + 1, 0);
+    for (size_t k = 0; k < nt; k++) rp[(size_t)gi[k] + 1]++;
+    for (long long r = 0; r < n_global; r++) rp[(size_t)r + 1] += rp[(size_t)r];
+    std::vector<int> pos(rp.begin(), rp.end() - 1), ord(nt);
+    for (size_t k = 0; k < nt; k++) ord[(size_t)pos[(size_t)gi[k]]++] = (int)k;
+    Ag.nrows = Ag.ncols = (int)n_global;
+    Ag.rowptr.assign((size_t)n_global + 1, 0);
+    for (long long r = 0; r < n_global; r++) {
+      auto b = ord.begin() + rp[(size_t)r], e = ord.begin() + rp[(size_t)r + 1];
+      std::stable_sort(b, e, [&](int x, int y) { return gj[(size_t)x] < gj[(size_t)y]; });
+      for (auto it = b; it != e; ++it) {
+        const int c = (int)gj[(size_t)*it];
+        if (!Ag.col.empty() && (int)Ag.col.size() > Ag.rowptr[(size_t)r] && Ag.col.back() == c)
+          Ag.val.back() += gv[(size_t)*it];
+        else
+          Ag.col.push_back(c), Ag.val.push_back(gv[(size_t)*it]);
+      }
+      Ag.rowptr[(size_t)r + 1] = (int)Ag.col.size();
+    }
+  }
+  // ---- essential dofs (global flags), eliminated from the matrix like ParOperator::ParallelAssemble does (rap.cpp:131-149)
+  std::vector<char> ess_flag((size_t)n_global, 0);
+  {
+    const auto &ess = par->GetEssentialTrueDofsHost();
+    std::vector<double> eg(ess.size());
+    for (size_t i = 0; i < ess.size(); i++) eg[i] = gid[(size_t)ess[i]];
+    for (const double g : AllGatherV(ctx, eg)) ess_flag[(size_t)g] = 1;
+    amg::HostCsr e;
+    e.nrows = e.ncols = Ag.nrows;
+    e.rowptr.assign((size_t)Ag.nrows + 1, 0);
+    for (int r = 0; r < Ag.nrows; r++) {
+      if (ess_flag[(size_t)r]) {
+        e.col.push_back(r), e.val.push_back(1.0);
+      } else {
+        for (int a = Ag.rowptr[(size_t)r]; a < Ag.rowptr[(size_t)r + 1]; a++)
+          if (!ess_flag[(size_t)Ag.col[(size_t)a]]) e.col.push_back(Ag.col[(size_t)a]), e.val.push_back(Ag.val[(size_t)a]);
+      }
+      e.rowptr[(size_t)r + 1] = (int)e.col.size();
+    }
+    Ag = std::move(e);
+  }
+  if (G) {
+    // ---- the lowest-order discrete gradient in global numbers: two applications of the (multi-rank) operator to the global
+    // vertex numbers and their squares identify both ends of every true edge of this rank; rows gathered in rank order are
+    // the rows of the global matrix
+    PA_REQUIRE(G->Height() == n_true && G->Width() == nv_true && xyz_true, "replicated AMS: gradient / coordinates do not match the level");
+    std::vector<long long> voff;
+    std::vector<double> xyz_all;
+    {
+      std::vector<double> mine(xyz_true, xyz_true + (size_t)nv_true * dim);
+      xyz_all = AllGatherV(ctx, mine, &voff);
+    }
+    const long long nv_global = voff[(size_t)size] / dim;
+    PA_REQUIRE((double)nv_global * (double)nv_global < 9.0e15, "too many vertices for the two-probe reconstruction of the gradient");
+    const long long v0 = voff[(size_t)rank] / dim;
+    std::vector<double> x1((size_t)nv_true), x2((size_t)nv_true), d((size_t)n_true), q((size_t)n_true);
+    for (int v = 0; v < nv_true; v++) x1[(size_t)v] = (double)(v0 + v) + 1.0, x2[(size_t)v] = x1[(size_t)v] * x1[(size_t)v];
+    Vector dx(nv_true), dy(n_true);
+    auto apply = [&](const std::vector<double> &in, std::vector<double> &out) {
+      PA_HIP(hipMemcpyAsync(dx.Data(), in.data(), sizeof(double) * (size_t)nv_true, hipMemcpyHostToDevice, ctx.stream));
+      G->Mult(dx, dy);
+      PA_HIP(hipMemcpyAsync(out.data(), dy.Data(), sizeof(double) * (size_t)n_true, hipMemcpyDeviceToHost, ctx.stream));
+      PA_HIP(hipStreamSynchronize(ctx.stream));
+      ctx.comm->PeerCheckNow();
+    };
+    apply(x1, d), apply(x2, q);
+    std::vector<double> head((size_t)n_true), tail((size_t)n_true);
+    for (int e = 0; e < n_true; e++) {
+      const double diff = std::round(d[(size_t)e]);
+      PA_REQUIRE(diff != 0.0 && std::abs(d[(size_t)e] - diff) < 1e-6, "the discrete gradient is not an edge-vertex incidence matrix "
+                                                                        "(AMS needs the lowest-order spaces on level 0)");
+      const double sum = std::round(q[(size_t)e] / diff);
+      head[(size_t)e] = (sum + diff) / 2 - 1, tail[(size_t)e] = (sum - diff) / 2 - 1;
+    }
+    const std::vector<double> gh = AllGatherV(ctx, head), gt = AllGatherV(ctx, tail);
+    PA_REQUIRE((long long)gh.size() == n_global, "replicated AMS: gathered gradient rows");
+    amg::HostCsr Gm;
+    Gm.nrows = (int)n_global, Gm.ncols = (int)nv_global;
+    Gm.rowptr.resize((size_t)n_global + 1);
+    Gm.col.resize((size_t)2 * n_global), Gm.val.resize((size_t)2 * n_global);
+    for (long long e = 0; e < n_global; e++) {
+      const int h = (int)gh[(size_t)e], t = (int)gt[(size_t)e];
+      PA_REQUIRE(h >= 0 && h < nv_global && t >= 0 && t < nv_global && h != t, "gradient reconstruction failed");
+      Gm.rowptr[(size_t)e] = (int)(2 * e);
+      const bool hf = h < t;
+      Gm.col[(size_t)(2 * e)] = hf ? h : t, Gm.val[(size_t)(2 * e)] = hf ? 1.0 : -1.0;
+      Gm.col[(size_t)(2 * e + 1)] = hf ? t : h, Gm.val[(size_t)(2 * e + 1)] = hf ? -1.0 : 1.0;
+    }
+    Gm.rowptr[(size_t)n_global] = (int)(2 * n_global);
+    AmsOptions opt;
+    opt.cycle_it = std::max(cycle_it, 1), opt.singular = singular;
+    impl_->inner = std::make_unique<AmsSolver>(ctx, Ag, Gm, xyz_all.data(), dim, ess_flag, opt);
+  } else {
+    impl_->inner = std::make_unique<AmgSolver>(ctx, Ag);
+  }
+  // ---- the gather plan on the global-numbered vector: my true dofs to everybody, everybody else's pieces (contiguous) in
+  std::vector<int> nbr, soff(1, 0), roff(1, 0);
+  std::vector<int32_t> sidx, ridx, mine((size_t)n_true);
+  for (int i = 0; i < n_true; i++) mine[(size_t)i] = (int32_t)(off[(size_t)rank] + i);
+  for (int r = 0; r < size; r++) {
+    if (r == rank) continue;
+    nbr.push_back(r);
+    sidx.insert(sidx.end(), mine.begin(), mine.end());
+    soff.push_back((int)sidx.size());
+    for (long long g = off[(size_t)r]; g < off[(size_t)r + 1]; g++) ridx.push_back((int32_t)g);
+    roff.push_back((int)ridx.size());
+  }
+  impl_->gather = std::make_unique<Halo>(*ctx.comm, (int)nbr.size(), nbr.data(), soff.data(), sidx.data(), roff.data(), ridx.data());
+  impl_->rep = std::make_unique<ReplicatedSolver>(ctx, *impl_->gather, *impl_->inner, mine.data(), n_true, (int)n_global);
+}
+
+namespace {
+
 class NativeAmgSolver : public Solver {  // LinearSolver::BOOMER_AMG
   const Context *ctx_;
   int cycle_it_;
   std::unique_ptr<AmgSolver> amg_;
+  std::unique_ptr<ReplicatedCoarseSolver> rep_;  // several ranks: the global level solved redundantly
   mutable Vector r_, z_;
 
 public:
@@ -66,10 +275,30 @@ public:
     StreamGraph::Invalidate();
     height = op.Height(), width = op.Width();
     A_ = &op;
+    const auto *fop = dynamic_cast<const FespaceParOperator *>(&op);
+    const ParOperator *par = fop ? &fop->Par() : dynamic_cast<const ParOperator *>(&op);
+    if (par && par->GetHalo()) {
+      amg_.reset();
+      rep_ = std::make_unique<ReplicatedCoarseSolver>(*ctx_, op, nullptr, 0, nullptr, 3, 1, false);
+      return;
+    }
+    rep_.reset();
     std::vector<char> ess_flag;
     amg_ = std::make_unique<AmgSolver>(*ctx_, AssembledLevelMatrix(op, ess_flag));
   }
   void Mult(const Vector &b, Vector &x) const override {
+    if (rep_) {
+      // (further cycles as stationary iterations, as below)
+      if (!initial_guess) rep_->Mult(b, x);
+      for (int it = initial_guess ? 0 : 1; it < cycle_it_; it++) {
+        r_.SetSize(height), z_.SetSize(height);
+        A_->Mult(x, r_);
+        linalg::AXPBY(*ctx_, 1.0, b, -1.0, r_);
+        rep_->Mult(r_, z_);
+        linalg::AXPY(*ctx_, 1.0, z_, x);
+      }
+      return;
+    }
     PA_REQUIRE(amg_, "NativeAmgSolver: SetOperator first");
     // the cycle itself starts from zero; a caller's guess (Solver::SetInitialGuess) enters as the first stationary step
     if (!initial_guess) amg_->Mult(b, x);
@@ -91,6 +320,7 @@ class NativeAmsSolver : public Solver {  // LinearSolver::AMS
   const FiniteElementSpace *nd_, *h1_;
   AmsOptions opt_;
   std::unique_ptr<AmsSolver> ams_;
+  std::unique_ptr<ReplicatedCoarseSolver> rep_;  // several ranks: the global level solved redundantly
 
   // the lowest-order discrete gradient as a matrix: every row is +1 at the edge's head and -1 at its tail, so two applications
   // (to the vertex numbers and to their squares) identify both vertices of every edge
@@ -135,13 +365,20 @@ public:
     PA_REQUIRE(nd.GetMaxElementOrder() == 1 && h1.GetMaxElementOrder() == 1,
                "the native AMS solver is built for the lowest-order level (the reference's default coarse level); use it as "
                "the coarse solver of a p-multigrid hierarchy");
-    PA_REQUIRE(!nd.GetHalo() && !h1.GetHalo(), "the native AMS coarse solver runs on one rank");
     opt_.cycle_it = std::max(cycle_it, 1);
     opt_.singular = singular > 0;
   }
   void SetOperator(const Operator &op) override {
     StreamGraph::Invalidate();
     height = op.Height(), width = op.Width();
+    if (nd_->GetHalo()) {  // several ranks (ksp.cpp:129-239 hands HYPRE the distributed matrix; here: gathered, solved everywhere)
+      ams_.reset();
+      const std::vector<double> xyz = nd_->GetMesh().VertexCoordinates(*h1_);  // (true vertices first: the first GetTrueVSize() rows)
+      rep_ = std::make_unique<ReplicatedCoarseSolver>(*ctx_, op, &nd_->GetDiscreteInterpolator(*h1_), h1_->GetTrueVSize(), xyz.data(),
+                                                      nd_->GetMesh().SpaceDimension(), opt_.cycle_it, opt_.singular);
+      return;
+    }
+    rep_.reset();
     std::vector<char> ess_flag;
     const amg::HostCsr A = AssembledLevelMatrix(op, ess_flag);
     const amg::HostCsr G = GradientMatrix();
@@ -149,6 +386,7 @@ public:
     ams_ = std::make_unique<AmsSolver>(*ctx_, A, G, xyz.data(), nd_->GetMesh().SpaceDimension(), ess_flag, opt_);
   }
   void Mult(const Vector &b, Vector &x) const override {
+    if (rep_) return rep_->Mult(b, x);
     PA_REQUIRE(ams_, "NativeAmsSolver: SetOperator first");
     ams_->SetInitialGuess(initial_guess);  // (the cycles of AmsSolver::Mult honour it in their first smoothing step)
     ams_->Mult(b, x);

@@ -58,6 +58,29 @@ struct LinearSolverData {
 
 }  // namespace config
 
+// The coarsest level of a multi-rank hierarchy solved redundantly by every rank with the native algebraic cycles (where the
+// reference runs HYPRE's distributed AMS / BoomerAMG on it: linalg/ams.cpp:18-224, amg.cpp:12-49, wiring ksp.cpp:129-239).
+// Built from what each rank holds: its assembled local matrix (L-vector numbering, ghost rows with their partial sums), the
+// halo plan of the space, its essential true dofs and -- AMS -- the discrete gradient operator and the coordinates of its true
+// vertices.  True dofs are numbered rank by rank (offset of the rank + local true index), the ghosts learn their owners'
+// numbers through the halo plan itself, the triplets / gradient rows / coordinates of all ranks are gathered with the
+// communicator's global sum (every rank contributes zeros outside its own segment), and every rank assembles the SAME global
+// matrix and builds the SAME solver on it; an application gathers the distributed right-hand side (ReplicatedSolver).
+// G == nullptr: the AMG V-cycle (H1 problems); else the AMS cycle.  `level0` must be a ParOperator around an assembled
+// (CsrOperator) or partially assembled local operator.
+class ReplicatedCoarseSolver : public Solver {
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+
+public:
+  ReplicatedCoarseSolver(const Context &ctx, const Operator &level0, const Operator *G, int nv_true, const double *xyz_true, int dim,
+                         int cycle_it, bool singular);
+  ~ReplicatedCoarseSolver() override;
+  void SetOperator(const Operator &) override {}
+  void Mult(const Vector &x, Vector &y) const override;
+  int GlobalSize() const;
+};
+
 // p-coarsening sequence of the multigrid hierarchy (fem/multigrid.hpp:44-69): orders from coarsest to finest
 std::vector<int> GetPolynomialOrders(int order, MultigridCoarsening coarsening, int mg_max_levels = -1);
 

@@ -5,6 +5,7 @@
 #include "comm.hpp"
 #include "complex.hpp"
 #include "amg_solver.hpp"
+#include "ksp.hpp"
 #include "linalg.hpp"
 
 using namespace palace;
@@ -584,6 +585,17 @@ int pa_ams_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_es
     auto *s = new pa_solver;
     s->ctx = ctx;
     s->solver = std::make_unique<AmsSolver>(ctx->ctx, DownloadCsr(*A, ess, n_ess), G, coords, dim, flag, o);
+    *S = s;
+  });
+}
+int pa_replicated_coarse_create(pa_context *ctx, pa_par_op *level0, pa_interp *G, int nv_true, const double *xyz_true, int dim,
+                                int cycle_it, int singular, pa_solver **S) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && level0 && level0->op && S && (!G || (G->op && xyz_true)), "null argument");
+    auto *s = new pa_solver;
+    s->ctx = ctx;
+    s->solver = std::make_unique<ReplicatedCoarseSolver>(ctx->ctx, *level0->op, G ? G->op.get() : nullptr, nv_true, xyz_true, dim,
+                                                         cycle_it, singular != 0);
     *S = s;
   });
 }

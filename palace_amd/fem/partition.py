@@ -342,6 +342,21 @@ class SlabProblem:
                 h1_0 = H1HexSpace(self.mesh, 1)
                 csolver = linalg.ams(ctx, csr0, self.ess[0], lowest_order_gradient(h1_0, self.spaces[0]),
                                      vertex_coordinates(h1_0), singular=singular)
+            elif coarse == "ams_dist":
+                # several ranks, nothing but the ranks' own pieces: the C++ layer numbers the true dofs rank by rank, gathers the
+                # local matrices / gradient rows / vertex coordinates over the communicator, and every rank builds the same AMS
+                # solver of the global level (ksp.hpp: ReplicatedCoarseSolver -- what KspSolver's LinearSolver::AMS does on a space
+                # with a halo; the reference: HYPRE's distributed AMS, linalg/ksp.cpp:129-239)
+                from .fespace import vertex_coordinates
+
+                assert self.world > 1 and self.orders[0] == 1, "ams_dist: several ranks, order-1 level"
+                z_lo = self.rank * self.height
+                h1_0 = SlabH1Space(self.mesh, 1, self.rank, self.world, z_lo, z_lo + self.height, self.radius)
+                h1_halo0 = linalg.Halo(ctx, h1_0.nbr, h1_0.send, h1_0.recv)
+                G0 = linalg.Gradient(ctx, h1_0, self.spaces[0], h1_halo=h1_halo0, n_true_h1=h1_0.n_true, n_true_nd=self.n_true[0])
+                csolver = linalg.replicated_coarse(ctx, A[0], G0, h1_0.n_true, vertex_coordinates(h1_0)[: h1_0.n_true],
+                                                   singular=singular)
+                self._keep.append((h1_0, h1_halo0, G0))
             elif coarse == "ams":
                 # several ranks: the order-1 problem of the WHOLE cylinder is assembled and solved redundantly by every rank
                 # (linalg.replicated: the right-hand side gathered through a halo plan on the global-numbered vector)

@@ -575,6 +575,22 @@ def replicated(ctx, gather_halo, inner, mine_global, n_global, sign=None):
     return Solver(ctx, h, (gather_halo, inner, mine, sg))
 
 
+def replicated_coarse(ctx, level0: "ParOperator", G=None, nv_true=0, xyz_true=None, cycle_it=1, singular=False):
+    """ReplicatedCoarseSolver (ksp.hpp): the coarsest level of a multi-rank hierarchy solved redundantly by every rank with the
+    native AMS (G: the level's discrete gradient, xyz_true [nv_true, dim]: this rank's true vertices) or AMG (G = None) cycle,
+    assembled by the C++ layer from the ranks' own pieces -- what KspSolver's LinearSolver::AMS / BOOMER_AMG do on a space with a
+    halo.  Collective."""
+    L = _L()
+    L.pa_replicated_coarse_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p]
+    xyz = None if xyz_true is None else np.ascontiguousarray(xyz_true, dtype=np.float64)
+    dim = 3 if xyz is None else int(xyz.shape[1])
+    h = C.c_void_p()
+    _lib.check(L.pa_replicated_coarse_create(ctx.handle, level0.handle, G.handle if G is not None else None, int(nv_true),
+                                             _ptr(xyz) if xyz is not None else None, dim, int(cycle_it), int(bool(singular)), C.byref(h)))
+    return Solver(ctx, h, (level0, G))
+
+
 def ams(ctx, csr, ess_tdofs, G, coords, cycle_it=0, smooth_order=0, singular=False, amg_coarse_size=0, amg_smooth_order=0,
         amg_theta=0.0):
     """Native auxiliary-space (Hiptmair-Xu) preconditioner for an assembled lowest-order H(curl) matrix, where the reference

@@ -192,3 +192,55 @@ def test_flag_protocol_stress(world):
     assert res["bring_up"]["transport"] == "peer" and res["bring_up"]["ordering"] == "relaxed", res
     for k in ("lvector", "direct", "lvector_graph", "direct_graph", "lvector_again", "after_churn"):
         assert res[k] == 0, res
+
+
+def _dist_coarse_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from palace_amd import linalg
+        from palace_amd.fem.partition import SlabProblem
+
+        ctx = linalg.Context()
+        if world > 1:
+            ctx.init_comm_peer_from_torch_distributed()
+        prob = SlabProblem(ctx, rank, world, 2, 0, shape=(2, 4 // world))
+        res = {}
+        for kind in (("ams",) if world == 1 else ("ams", "ams_dist")):
+            K, b, x = prob.pcg_gmg_solver(max_it=100, rel_tol=1e-9, hiptmair=True, coarse=kind)
+            K.mult(b, x)
+            st = K.stats()
+            assert st["converged"], (kind, st)
+            res[kind] = (st["iterations"], ctx.dot(x, x))
+            x.zero_()
+            K.mult(b, x)  # (the recorded iteration replays: the gather of the replicated solve is part of it)
+            res[kind + "_again"] = (K.stats()["iterations"], ctx.dot(x, x))
+        if world > 1:
+            ctx.peer_check()
+        if rank == 0:
+            out.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicated_coarse_solver_assembled_from_the_ranks_pieces():
+    """LinearSolver::AMS on a space with a halo (ksp.hpp: ReplicatedCoarseSolver): the C++ layer builds the global level-0 problem
+    from the ranks' local matrices, gradient rows and vertex coordinates alone.  Against the replicated solver built from the
+    global mesh (two processes) and the one-rank solve: iterations +- 1, the same solution."""
+    import torch.multiprocessing as mp
+
+    results = {}
+    for world, port in ((1, 29671), (2, 29672)):
+        q = mp.get_context("spawn").SimpleQueue()
+        mp.spawn(_dist_coarse_worker, args=(world, port, q), nprocs=world, join=True)
+        results[world] = q.get()
+    one, two = results[1], results[2]
+    for kind in ("ams", "ams_dist"):
+        assert abs(two[kind][0] - one["ams"][0]) <= 1, (kind, one, two)
+        assert abs(two[kind][1] - one["ams"][1]) < 1e-6 * one["ams"][1], (kind, one, two)
+        assert two[kind + "_again"][0] == two[kind][0]
