@@ -196,10 +196,14 @@ struct SubOp {
   int32_t *d_rhdr_bc = nullptr, *d_rpos_bc = nullptr;   // run list that also owns the essential rows
   int n_shared_bc = 0;
   uint32_t *d_perm_s = nullptr;                         // [ne][ceil(P/64)][16], four 8-bit tensor-order slots per word
+  // four-point H(curl) kernel: the flag words on their own ([ne][16]; _bc: the copy with the essential dofs) and the slot words
+  // through a dictionary -- elements whose sorted -> tensor-order permutation agrees share one entry (a structured mesh has a
+  // handful: 10 on the 125 440-element bench cylinder), the element's entry number rides in a spare word of its index block
+  uint32_t *d_flagw = nullptr, *d_flagw_bc = nullptr, *d_slots = nullptr;
+  int n_slot_patterns = 0;
   double *d_coef_s = nullptr;                           // metric form: [ne][2] scalar mass / curl-curl coefficient per element
-  uint32_t *d_rcode = nullptr, *d_rcode_bc = nullptr;   // [n_shared] run << 4 | offset (bit 31: essential)
-  int32_t *d_rhdr = nullptr, *d_rpos = nullptr;         // run headers {first dof, first copy entry}; copy positions in d_ye
-  int n_runs = 0;
+  int32_t *d_rhdr = nullptr, *d_rpos = nullptr;         // run headers {first dof | length - 1 | essential, first copy entry}; copy positions in d_ye
+  int n_runs = 0, n_runs_bc = 0;
   std::vector<double> Bc, Gc, Bo;  // full 1-D tables [q1d][n] (host)
   double *d_tab = nullptr;        // the same on the device: [Bo | Bc | Gc]
   bool iso = false;               // every material coefficient is a multiple of the identity

@@ -19,6 +19,7 @@
 // consecutive in every element that holds them, so the transpose map collapses to runs {first dof, length, first
 // position per copy}: 4 bytes of index per dof instead of 12 + 4 per copy, fixed summation order as before.
 #include <algorithm>
+#include <map>
 
 #include "pa_nd_hex_core.hpp"
 
@@ -68,9 +69,11 @@ struct NDStreamArgs {
   int ne, nbatch, chunk;  // chunk: batches per XCD (contiguous range)
   const int32_t *blist;   // optional list of batches to process (nbatch entries, increasing); NULL: all of 0 .. nbatch - 1
   const uint32_t *idxc;   // [ne][kIdxWords] run-compressed sorted element -> dof index (pa_stream_host.hpp)
-  const uint32_t *perm;   // [ne][NPK + 1][16]: four 8-bit tensor-order slots per word (entries t + 16 r, r = 4 k .. 4 k + 3),
-                          // last word: bit 2 r = entry r is flipped, bit 2 r + 1 = entry r is the only copy of its dof,
+  const uint32_t *flagw;  // [ne][16]: bit 2 r = entry t + 16 r is flipped, bit 2 r + 1 = it is the only copy of its dof,
                           // bit 18 + r = essential (read as zero; set in the copy used by masked applies)
+  const uint32_t *slots;  // [patterns][NPK][16]: four 8-bit tensor-order slots per word (entries t + 16 r, r = 4 k .. 4 k + 3) of
+                          // the sorted -> tensor-order permutation; an element names its pattern in word kIdxPattern of its index
+                          // block (elements with the same permutation share one: the table stays in L2)
   const double *qdata;    // [ne][NG][2][16][2]
   const double *coef;     // metric form: [ne][2] scalar mass / curl-curl coefficient of the element
   const double *x;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
   constexpr int NG = METRIC ? (USE_U ? 7 : 6) : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
   static_assert(PP <= 256, "8-bit slots");
+  using streamhost::kIdxPattern;
   using streamhost::kIdxStart0;
   using streamhost::kIdxWords;
   // LDS per element (doubles): contraction buffers + the batch's index and slot / flag words, kept for the E^T stores,
@@ -146,17 +150,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     for (int r = 0; r < NPL; r++) s[r] = (int)__builtin_nontemporal_load(&ic[r]);
     s[NPL] = (int)__builtin_nontemporal_load(&ic[kIdxStart0 + t]);
     s[NPL + 1] = (int)__builtin_nontemporal_load(&ic[kIdxStart0 + 16 + (t & 3)]);
-    const uint32_t *pp = a.perm + (size_t)e * ((NPK + 1) * 16) + t;
-#pragma unroll
-    for (int k = 0; k <= NPK; k++) p[k] = __builtin_nontemporal_load(&pp[16 * k]);
+    // flag word now, the slot words when the pattern number has arrived (gather): p[0] carries the number until then
+    p[NPK] = __builtin_nontemporal_load(&a.flagw[(size_t)e * 16 + t]);
+    p[0] = __builtin_nontemporal_load(&ic[kIdxPattern]);
   };
   // decodes the index of the batch in place (s[r] becomes dof | kEssBit | kExclBit, negative: -(1 + word), flipped) and
   // requests the raw x of the entries (essential entries are zeroed when staged).  stab: 20 ints of LDS of this element.
-  auto gather = [&](int (&s)[NPL + 2], const unsigned (&p)[NPK + 1], double (&xv)[NPL], int *stab, const int t) {
+  auto gather = [&](int (&s)[NPL + 2], unsigned (&p)[NPK + 1], double (&xv)[NPL], int *stab, const int t) {
     stab[t] = s[NPL];
     if (t < 4) stab[16 + t] = s[NPL + 1];
     wave_sync();
     const unsigned fw = p[NPK];
+    {  // the slot words of the element's pattern (first use: the E stage of the next batch)
+      const uint32_t *sl = a.slots + (size_t)p[0] * (NPK * 16) + t;
+#pragma unroll
+      for (int k = 0; k < NPK; k++) p[k] = sl[16 * k];
+    }
 #pragma unroll
     for (int r = 0; r < NPL; r++) {
       const unsigned w = (unsigned)s[r], low = (w & 0xffffu) & ((2u << t) - 1u);
@@ -171,10 +180,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   };
   // the slot / flag words requested with the index words are first used at the top of the next batch; taking them as
   // arrived here (they were requested before the x values above) keeps that wait from being placed behind the stores
-  auto settle = [&](unsigned (&p)[NPK + 1]) {
-#pragma unroll
-    for (int k = 0; k <= NPK; k++) asm volatile("" : "+v"(p[k]));
-  };
+  auto settle = [&](unsigned (&p)[NPK + 1]) { asm volatile("" : "+v"(p[NPK])); };
   int sA[NPL + 2];
   unsigned pA[NPK + 1];
   double xv[NPL];
@@ -412,41 +418,38 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 }
 
 // ---- E^T of the shared dofs by runs -----------------------------------------------------------------------------------
-using streamhost::RunHdr;  // {first dof of the run, first entry of its copies in rpos}
+using streamhost::RunHdr;  // {first dof of the run | length - 1 | essential, first entry of its copies in rpos}
+__device__ __forceinline__ int streamhost_run_len(const uint32_t dof0) { return (int)((dof0 >> 27) & 15u) + 1; }
 
-// code = run << 4 | offset in the run (bit 31: essential row, fused fix-up).  Every thread walks kGatherILP shared dofs a
-// block width apart with the four dependent loads of each (code -> header -> copy position -> E-vector) issued side by
-// side: one dof per thread leaves the kernel bound by that chain's latency, not by bytes (same 59 us as the CSR form
-// it replaced, measured).
+// Sixteen lanes per run (a run = up to 16 consecutive dofs whose copies sit at consecutive E-vector positions: a face's 12 dofs,
+// an edge's 3): lane j sums the copies of dof (first dof of the run) + j.  The header {first dof | length | essential, first
+// copy} and the copy positions are the same words for the lanes of a run (one request each), the E-vector reads of a run are
+// contiguous.  Rounds 1-3 walked a per-dof code word (run << 4 | offset: 23 MB per apply on the bench mesh, and one more level
+// in the chain of dependent loads) with one thread per dof.  kGatherILP runs per thread, a block width apart, their loads side
+// by side: the chain header -> copy position -> E-vector is latency-bound otherwise.
 constexpr int kGatherILP = 4;
-__global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const uint32_t *__restrict__ code,
-                                                            const RunHdr *__restrict__ hdr, const int32_t *__restrict__ rpos,
-                                                            const double *__restrict__ ye, double *__restrict__ y,
-                                                            const int accumulate, const double *__restrict__ x,
+__global__ __launch_bounds__(256) void et_run_gather_kernel(const int nruns, const RunHdr *__restrict__ hdr,
+                                                            const int32_t *__restrict__ rpos, const double *__restrict__ ye,
+                                                            double *__restrict__ y, const int accumulate, const double *__restrict__ x,
                                                             const int ess_policy, const int nsplit, double *__restrict__ yg) {
-  const int k0 = blockIdx.x * (256 * kGatherILP) + threadIdx.x;
-  uint32_t c[kGatherILP];
+  const int j = threadIdx.x & 15;
+  const int r0 = blockIdx.x * (16 * kGatherILP) + (threadIdx.x >> 4);
   RunHdr h[kGatherILP];
-  int pe[kGatherILP], d[kGatherILP], j[kGatherILP];
+  int pe[kGatherILP], d[kGatherILP];
   bool live[kGatherILP], fix[kGatherILP];
   double s[kGatherILP], yold[kGatherILP];
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++) {
-    const int k = k0 + 256 * u;
-    live[u] = k < n;
-    c[u] = live[u] ? code[k] : 0u;
+    const int run = r0 + 16 * u;
+    const bool in = run < nruns;
+    h[u] = hdr[in ? run : 0];
+    pe[u] = hdr[in ? run + 1 : 0].ptr;
+    live[u] = in && j < streamhost_run_len(h[u].dof0);
+    fix[u] = (h[u].dof0 >> 31) && ess_policy >= 0;
+    d[u] = (int)(h[u].dof0 & streamhost::kRunDofMask) + j;
   }
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++) {
-    const int run = (int)((c[u] & 0x7fffffffu) >> 4);
-    j[u] = (int)(c[u] & 15u);
-    h[u] = hdr[run];
-    pe[u] = hdr[run + 1].ptr;
-    fix[u] = (c[u] >> 31) && ess_policy >= 0;
-  }
-#pragma unroll
-  for (int u = 0; u < kGatherILP; u++) {
-    d[u] = h[u].dof0 + j[u];
     s[u] = 0.0;
     yold[u] = 0.0;
     if (live[u] && fix[u]) {
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const u
       yold[u] = y[d[u]];
     }
   }
-  // copies in order (fixed summation order; an absent copy adds an exact zero): the first four of every dof side by
+  // copies in order (fixed summation order; an absent copy adds an exact zero): the first four of every run side by
   // side -- interior faces have 2, edges 4 -- then the rare rest one at a time
   int pos[kGatherILP][4];
 #pragma unroll
@@ -467,13 +470,13 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const u
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++)
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[u][q] = pos[u][q] >= 0 ? ye[(size_t)pos[u][q] + j[u]] : 0.0;
+    for (int q = 0; q < 4; q++) v[u][q] = pos[u][q] >= 0 ? ye[(size_t)pos[u][q] + j] : 0.0;
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++) {
 #pragma unroll
     for (int q = 0; q < 4; q++) s[u] += v[u][q];
     if (live[u])
-      for (int p = h[u].ptr + 4; p < pe[u]; p++) s[u] += ye[(size_t)rpos[p] + j[u]];
+      for (int p = h[u].ptr + 4; p < pe[u]; p++) s[u] += ye[(size_t)rpos[p] + j];
   }
   // (split vectors: rows [nsplit, ...) are ghosts and go to yg, stored shifted by -nsplit; nsplit = INT_MAX otherwise)
 #pragma unroll
@@ -531,6 +534,27 @@ void build_stream(SubOp &so) {
                                      so.fe_type == PA_FE_H1 ? streamhost::kIdxStart0H1 : streamhost::kIdxStart0))
     return;
   so.h_perm_s = pp;
+  if (so.fe_type == PA_FE_HCURL && !wide_form(so)) {
+    // four-point H(curl) kernel: flag words on their own, slot words through the pattern dictionary (pa_internal.hpp)
+    const int npl = (P + 15) / 16, npk = (npl + 3) / 4, nep = (ne + 3) & ~3, sw = npk * 16;
+    std::vector<uint32_t> flagw((size_t)nep * 16), slots;
+    std::map<std::vector<uint32_t>, uint32_t> dict;
+    std::vector<uint32_t> key((size_t)sw);
+    for (int e = 0; e < nep; e++) {
+      const uint32_t *row = &pp[(size_t)e * (npk + 1) * 16];
+      std::copy(row + sw, row + sw + 16, flagw.begin() + (size_t)e * 16);
+      key.assign(row, row + sw);
+      auto it = dict.find(key);
+      if (it == dict.end()) {
+        it = dict.emplace(key, (uint32_t)dict.size()).first;
+        slots.insert(slots.end(), key.begin(), key.end());
+      }
+      ic[(size_t)e * streamhost::kIdxWords + streamhost::kIdxPattern] = it->second;
+    }
+    so.n_slot_patterns = (int)dict.size();
+    so.d_flagw = dev_upload(flagw.data(), flagw.size());
+    so.d_slots = dev_upload(slots.data(), slots.size());
+  }
   so.d_idxc = dev_upload(ic.data(), ic.size());
   so.d_perm_s = dev_upload(pp.data(), pp.size());
   if (so.qd->metric) stream_element_coefficients(so);
@@ -539,7 +563,6 @@ void build_stream(SubOp &so) {
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
   streamhost::build_runs(ne, P, so.lsize, so.h_sidx.data(), so.h_shared, code, hdr, rpos);
-  so.d_rcode = dev_upload(code.data(), code.size());
   so.d_rhdr = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
   so.d_rpos = dev_upload(rpos.data(), rpos.size());
   so.n_runs = (int)hdr.size() - 1;
@@ -574,6 +597,13 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   }
   hipFree(so.d_perm_s_bc);
   so.d_perm_s_bc = dev_upload(pb.data(), pb.size());
+  if (so.d_flagw) {  // (the flag words of the masked copy; the slot words are the same)
+    const int nep = (so.ne + 3) & ~3;
+    std::vector<uint32_t> fb((size_t)nep * 16);
+    for (int e = 0; e < nep; e++) std::copy(&pb[((size_t)e * (npk + 1) + npk) * 16], &pb[((size_t)e * (npk + 1) + npk) * 16] + 16, fb.begin() + (size_t)e * 16);
+    hipFree(so.d_flagw_bc);
+    so.d_flagw_bc = dev_upload(fb.data(), fb.size());
+  }
   std::vector<int32_t> count((size_t)so.lsize, 0);
   for (size_t k = 0; k < nnz; k++) count[streamhost::dof_of(so.h_sidx[k])]++;
   std::vector<int32_t> shared;
@@ -583,14 +613,12 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   std::vector<uint32_t> code;
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
-  streamhost::build_runs(so.ne, P, so.lsize, so.h_sidx.data(), shared, code, hdr, rpos);
-  for (size_t k = 0; k < code.size(); k++)
-    if (flag[shared[k]]) code[k] |= 0x80000000u;
-  hipFree(so.d_rcode_bc), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
-  so.d_rcode_bc = dev_upload(code.data(), code.size());
+  streamhost::build_runs(so.ne, P, so.lsize, so.h_sidx.data(), shared, code, hdr, rpos, flag.data());  // (runs: all essential or none)
+  hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
   so.d_rhdr_bc = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
   so.d_rpos_bc = dev_upload(rpos.data(), rpos.size());
   so.n_shared_bc = (int)shared.size();
+  so.n_runs_bc = (int)hdr.size() - 1;
 }
 
 // Interior / interface split for multi-rank applies: flag[d] != 0 marks the local dofs that take part in the halo exchange
@@ -618,7 +646,8 @@ void stream_set_interface(SubOp &so, const std::vector<char> &flag) {
 void free_stream(SubOp &so) {
   hipFree(so.d_blist[0]), hipFree(so.d_blist[1]);
   hipFree(so.d_idxc), hipFree(so.d_perm_s), hipFree(so.d_perm_s_bc), hipFree(so.d_coef_s);
-  hipFree(so.d_rcode), hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rcode_bc), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
+  hipFree(so.d_flagw), hipFree(so.d_flagw_bc), hipFree(so.d_slots);
+  hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
 }
 
 static int device_cus() {
@@ -703,7 +732,8 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
     if (a.nbatch == 0) return;
   }
   a.idxc = so.d_idxc;
-  a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
+  a.flagw = masked ? so.d_flagw_bc : so.d_flagw;
+  a.slots = so.d_slots;
   a.qdata = so.qd->d;
   a.coef = so.d_coef_s;
   a.x = x, a.y = y, a.ye = so.d_ye;
@@ -761,7 +791,8 @@ static void launch_complex_p(const SubOp &sr, const SubOp &si, const double *xr,
   NDStreamArgs<P1> a;
   a.ne = sr.ne, a.blist = nullptr, a.nbatch = 0;
   a.idxc = sr.d_idxc;
-  a.perm = masked ? sr.d_perm_s_bc : sr.d_perm_s;
+  a.flagw = masked ? sr.d_flagw_bc : sr.d_flagw;
+  a.slots = sr.d_slots;
   a.qdata = sr.qd->d;
   a.coef = sr.d_coef_s, a.coef1 = si.d_coef_s;
   a.x = xr, a.x1 = xi, a.y = yr, a.y1 = yi, a.ye = sr.d_ye, a.ye1 = ye_i;
@@ -784,11 +815,11 @@ void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double
 // additionally fuses ParOperator's fix-up y[ess] = x[ess] | 0 into it
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
                           int ess_policy, const double *ye, const SplitIO *split) {
-  const int n = masked ? so.n_shared_bc : so.n_shared;
+  const int n = masked ? so.n_runs_bc : so.n_runs;
   if (n == 0) return;
   PA_REQUIRE(!split || !accumulate, "split vectors: y = A x only");
-  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
-                     masked ? so.d_rcode_bc : so.d_rcode, reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
+  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 16 * kGatherILP - 1) / (16 * kGatherILP)), dim3(256), 0, s, n,
+                     reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
                      masked ? so.d_rpos_bc : so.d_rpos, ye ? ye : so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1,
                      split ? split->n_true : 0x7fffffff, split ? split->yg - split->n_true : nullptr);
   PA_HIP(hipGetLastError());

@@ -15,8 +15,15 @@ constexpr int kExclBit = 1 << 29;  // flag in the streaming kernel's index word:
 namespace streamhost {
 
 struct RunHdr {
-  int32_t dof0, ptr;  // first dof of the run; first entry of its copies in rpos (the next header's ptr ends them)
+  // bits 0-26 first dof of the run, bits 27-30 its length - 1, bit 31 essential row (ParOperator's fix-up fused into the gather);
+  // first entry of its copies in rpos (the next header's ptr ends them)
+  uint32_t dof0;
+  int32_t ptr;
 };
+constexpr uint32_t kRunDofMask = (1u << 27) - 1u;
+inline int run_dof0(const RunHdr &h) { return (int)(h.dof0 & kRunDofMask); }
+inline int run_len(const RunHdr &h) { return (int)((h.dof0 >> 27) & 15u) + 1; }
+inline bool run_ess(const RunHdr &h) { return (h.dof0 >> 31) != 0; }
 
 inline int dof_of(int32_t s) { return s >= 0 ? s : -1 - s; }
 
@@ -31,6 +38,9 @@ inline int dof_of(int32_t s) { return s >= 0 ? s : -1 - s; }
 // travel in the flag word of pp.  start0 = kIdxStart0 (20 runs) for H(curl) elements (up to 9 slice words); H1 elements
 // (at most 4 slice words, but 27 entities: 8 vertices + 12 edges + 6 faces + interior) use kIdxStart0H1 (28 runs).
 constexpr int kIdxWords = 32, kIdxStart0 = 12, kIdxMaxRuns = kIdxWords - kIdxStart0, kIdxStart0H1 = 4;
+// H(curl) blocks (at most 9 slice words before the run starts at word 12): word 11 names the element's entry in the dictionary
+// of sorted -> tensor-order slot patterns (pa_nd_hex_stream.hip: build_stream)
+constexpr int kIdxPattern = 11;
 
 inline int index_dof(const uint32_t *ic, int m, int start0 = kIdxStart0) {  // host model of the device decode (gather lambdas)
   const int r = m >> 4, t = m & 15;
@@ -161,11 +171,16 @@ inline bool pack_index_wide(int ne, int P, int lsize, const int32_t *sidx, const
 }
 
 // Runs over the shared dofs (`shared` increasing: every dof that does not have exactly one copy): consecutive dofs
-// with the same number of copies whose copies sit at consecutive E-vector positions, at most 16 long.
-//   code[k] = run << 4 | offset of shared[k] in its run;  hdr[run] = {first dof, first entry in rpos};
+// with the same number of copies whose copies sit at consecutive E-vector positions, at most 16 long, all essential or none
+// (ess: optional flags per dof).
+//   hdr[run] = {first dof | length - 1 | essential, first entry in rpos};
 //   rpos = E-vector position of the run's first dof in every copy, copies in element order (fixed summation order)
+//   code[k] = run << 4 | offset of shared[k] in its run (host-side checks only: the gather kernel walks the headers, sixteen
+//   lanes per run)
 inline void build_runs(int ne, int P, int lsize, const int32_t *sidx, const std::vector<int32_t> &shared,
-                       std::vector<uint32_t> &code, std::vector<RunHdr> &hdr, std::vector<int32_t> &rpos) {
+                       std::vector<uint32_t> &code, std::vector<RunHdr> &hdr, std::vector<int32_t> &rpos,
+                       const char *ess = nullptr) {
+  if (lsize > (int)kRunDofMask) throw std::runtime_error("too many local dofs for the run headers");
   const size_t nnz = (size_t)ne * P;
   std::vector<int32_t> tptr((size_t)lsize + 1, 0);
   for (size_t k = 0; k < nnz; k++) tptr[(size_t)dof_of(sidx[k]) + 1]++;
@@ -177,22 +192,24 @@ inline void build_runs(int ne, int P, int lsize, const int32_t *sidx, const std:
   int prev = -2, len = 0;
   for (const int32_t d : shared) {
     const int nc = tptr[d + 1] - tptr[d];
+    const bool de = ess && ess[d];
     bool extend = (d == prev + 1) && len < 16 && !hdr.empty();
     if (extend) {
       const RunHdr &h = hdr.back();
-      extend = (int)rpos.size() - h.ptr == nc;
+      extend = (int)rpos.size() - h.ptr == nc && run_ess(h) == de;
       for (int c = 0; extend && c < nc; c++) extend = tpos[tptr[d] + c] == rpos[h.ptr + c] + len;
     }
     if (!extend) {
-      hdr.push_back(RunHdr{d, (int32_t)rpos.size()});
+      hdr.push_back(RunHdr{(uint32_t)d | (de ? 1u << 31 : 0u), (int32_t)rpos.size()});
       for (int c = 0; c < nc; c++) rpos.push_back(tpos[tptr[d] + c]);
       len = 0;
     }
     if (hdr.size() >= (1u << 27)) throw std::runtime_error("too many runs for the gather code");
     code.push_back((uint32_t)(hdr.size() - 1) << 4 | (uint32_t)len);
+    hdr.back().dof0 = (hdr.back().dof0 & ~(15u << 27)) | ((uint32_t)len << 27);  // length - 1 so far
     len++, prev = d;
   }
-  hdr.push_back(RunHdr{0, (int32_t)rpos.size()});
+  hdr.push_back(RunHdr{0u, (int32_t)rpos.size()});
 }
 
 }  // namespace streamhost

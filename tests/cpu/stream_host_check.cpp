@@ -89,10 +89,18 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, in
   std::vector<uint32_t> code;
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
-  build_runs(ne, P, lsize, sidx.data(), shared_bc, code, hdr, rpos);
+  build_runs(ne, P, lsize, sidx.data(), shared_bc, code, hdr, rpos, ess.data());
   std::vector<uint32_t> codeb(code);
   for (size_t k = 0; k < codeb.size(); k++)
     if (ess[shared_bc[k]]) codeb[k] |= 0x80000000u;
+  {  // what the gather kernel sees: the headers alone name every shared dof exactly once, with its flag
+    size_t k = 0;
+    for (size_t r = 0; r + 1 < hdr.size(); r++)
+      for (int j = 0; j < run_len(hdr[r]); j++, k++)
+        if (k >= shared_bc.size() || run_dof0(hdr[r]) + j != shared_bc[k] || run_ess(hdr[r]) != (ess[shared_bc[k]] != 0))
+          return std::printf("run headers: run %zu entry %d does not name shared dof %zu\n", r, j, k), 1;
+    if (k != shared_bc.size()) return std::printf("run headers: %zu of %zu shared dofs\n", k, shared_bc.size()), 1;
+  }
   shared = shared_bc;
   pp = ppb;
 
@@ -152,7 +160,7 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, in
   for (size_t k = 0; k < shared.size(); k++) {
     const uint32_t c = codeb[k];
     const int run = (int)((c & 0x7fffffffu) >> 4), j = (int)(c & 15u);
-    const int d = hdr[run].dof0 + j;
+    const int d = run_dof0(hdr[run]) + j;
     if (d != shared[k]) return std::printf("run decode: dof %d != %d\n", d, shared[k]), 1;
     if (c >> 31) {
       y[d] = x[d];
@@ -232,7 +240,7 @@ static int run_case_wide(int ne, int P, int lsize, unsigned seed, double ess_fra
   std::vector<uint32_t> code;
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
-  build_runs(ne, P, lsize, sidx.data(), shared, code, hdr, rpos);
+  build_runs(ne, P, lsize, sidx.data(), shared, code, hdr, rpos, ess.data());
   for (size_t k = 0; k < code.size(); k++)
     if (ess[shared[k]]) code[k] |= 0x80000000u;
 
@@ -281,7 +289,7 @@ static int run_case_wide(int ne, int P, int lsize, unsigned seed, double ess_fra
   for (size_t k = 0; k < shared.size(); k++) {
     const uint32_t c = code[k];
     const int run = (int)((c & 0x7fffffffu) >> 4), j = (int)(c & 15u);
-    const int d = hdr[run].dof0 + j;
+    const int d = run_dof0(hdr[run]) + j;
     if (d != shared[k]) return std::printf("wide run decode: dof %d != %d\n", d, shared[k]), 1;
     if (c >> 31) {
       y[d] = x[d];
