@@ -204,6 +204,7 @@ struct SubOp {
   double *d_coef_s = nullptr;                           // metric form: [ne][2] scalar mass / curl-curl coefficient per element
   int32_t *d_rhdr = nullptr, *d_rpos = nullptr;         // run headers {first dof | length - 1 | essential, first copy entry}; copy positions in d_ye
   int n_runs = 0, n_runs_bc = 0;
+  uint32_t *d_rchunk = nullptr, *d_rchunk_bc = nullptr;  // [ceil(n_shared / 64)] RunChunk: run-start mask of 64 shared dofs + run / offset of the first
   std::vector<double> Bc, Gc, Bo;  // full 1-D tables [q1d][n] (host)
   double *d_tab = nullptr;        // the same on the device: [Bo | Bc | Gc]
   bool iso = false;               // every material coefficient is a multiple of the identity

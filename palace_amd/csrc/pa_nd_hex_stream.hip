@@ -419,37 +419,46 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 
 // ---- E^T of the shared dofs by runs -----------------------------------------------------------------------------------
 using streamhost::RunHdr;  // {first dof of the run | length - 1 | essential, first entry of its copies in rpos}
-__device__ __forceinline__ int streamhost_run_len(const uint32_t dof0) { return (int)((dof0 >> 27) & 15u) + 1; }
+using streamhost::RunChunk;
 
-// Sixteen lanes per run (a run = up to 16 consecutive dofs whose copies sit at consecutive E-vector positions: a face's 12 dofs,
-// an edge's 3): lane j sums the copies of dof (first dof of the run) + j.  The header {first dof | length | essential, first
-// copy} and the copy positions are the same words for the lanes of a run (one request each), the E-vector reads of a run are
-// contiguous.  Rounds 1-3 walked a per-dof code word (run << 4 | offset: 23 MB per apply on the bench mesh, and one more level
-// in the chain of dependent loads) with one thread per dof.  kGatherILP runs per thread, a block width apart, their loads side
-// by side: the chain header -> copy position -> E-vector is latency-bound otherwise.
+// One thread per shared dof.  Which run a dof belongs to, and where in it, comes from 12 bytes per 64 dofs (RunChunk: a mask of
+// the dofs that start a run + the run and offset of the chunk's first dof; popcount and count-leading-zeros as in the element
+// index): rounds 1-3 read a code word per dof (run << 4 | offset: 23 MB per apply on the bench mesh).  The essential flag and the
+// length ride in the run header.  Every thread walks kGatherILP shared dofs a block width apart with the dependent loads of each
+// (header -> copy position -> E-vector) issued side by side: one dof per thread leaves the kernel bound by that chain's latency.
+// (Sixteen lanes per run walking the headers alone -- no per-dof data at all -- was measured too: 42.7 against 39.6 us, the idle
+// lanes of the short runs cost more instructions than the mask saves.)
 constexpr int kGatherILP = 4;
-__global__ __launch_bounds__(256) void et_run_gather_kernel(const int nruns, const RunHdr *__restrict__ hdr,
-                                                            const int32_t *__restrict__ rpos, const double *__restrict__ ye,
-                                                            double *__restrict__ y, const int accumulate, const double *__restrict__ x,
+__global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const RunChunk *__restrict__ chunk,
+                                                            const RunHdr *__restrict__ hdr, const int32_t *__restrict__ rpos,
+                                                            const double *__restrict__ ye, double *__restrict__ y,
+                                                            const int accumulate, const double *__restrict__ x,
                                                             const int ess_policy, const int nsplit, double *__restrict__ yg) {
-  const int j = threadIdx.x & 15;
-  const int r0 = blockIdx.x * (16 * kGatherILP) + (threadIdx.x >> 4);
+  const int k0 = blockIdx.x * (256 * kGatherILP) + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   RunHdr h[kGatherILP];
-  int pe[kGatherILP], d[kGatherILP];
+  int pe[kGatherILP], d[kGatherILP], j[kGatherILP], run[kGatherILP];
   bool live[kGatherILP], fix[kGatherILP];
   double s[kGatherILP], yold[kGatherILP];
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++) {
-    const int run = r0 + 16 * u;
-    const bool in = run < nruns;
-    h[u] = hdr[in ? run : 0];
-    pe[u] = hdr[in ? run + 1 : 0].ptr;
-    live[u] = in && j < streamhost_run_len(h[u].dof0);
-    fix[u] = (h[u].dof0 >> 31) && ess_policy >= 0;
-    d[u] = (int)(h[u].dof0 & streamhost::kRunDofMask) + j;
+    const int k = k0 + 256 * u;
+    live[u] = k < n;
+    const RunChunk c = chunk[live[u] ? (k >> 6) : 0];  // (the same 16 bytes for the 64 lanes of a wave)
+    const unsigned long long low = (c.starts & ~1ull) & ((2ull << lane) - 1ull);  // run starts in (first dof of the chunk, this dof]
+    const int nc = __popcll(low);
+    run[u] = (int)(c.first >> 4) + nc;
+    j[u] = nc ? lane - (63 - __clzll((long long)low)) : (int)(c.first & 15u) + lane;
   }
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++) {
+    h[u] = hdr[live[u] ? run[u] : 0];
+    pe[u] = hdr[live[u] ? run[u] + 1 : 0].ptr;
+    fix[u] = (h[u].dof0 >> 31) && ess_policy >= 0;
+  }
+#pragma unroll
+  for (int u = 0; u < kGatherILP; u++) {
+    d[u] = (int)(h[u].dof0 & streamhost::kRunDofMask) + j[u];
     s[u] = 0.0;
     yold[u] = 0.0;
     if (live[u] && fix[u]) {
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int nruns, con
       yold[u] = y[d[u]];
     }
   }
-  // copies in order (fixed summation order; an absent copy adds an exact zero): the first four of every run side by
+  // copies in order (fixed summation order; an absent copy adds an exact zero): the first four of every dof side by
   // side -- interior faces have 2, edges 4 -- then the rare rest one at a time
   int pos[kGatherILP][4];
 #pragma unroll
@@ -470,13 +479,13 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int nruns, con
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++)
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[u][q] = pos[u][q] >= 0 ? ye[(size_t)pos[u][q] + j] : 0.0;
+    for (int q = 0; q < 4; q++) v[u][q] = pos[u][q] >= 0 ? ye[(size_t)pos[u][q] + j[u]] : 0.0;
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++) {
 #pragma unroll
     for (int q = 0; q < 4; q++) s[u] += v[u][q];
     if (live[u])
-      for (int p = h[u].ptr + 4; p < pe[u]; p++) s[u] += ye[(size_t)rpos[p] + j];
+      for (int p = h[u].ptr + 4; p < pe[u]; p++) s[u] += ye[(size_t)rpos[p] + j[u]];
   }
   // (split vectors: rows [nsplit, ...) are ghosts and go to yg, stored shifted by -nsplit; nsplit = INT_MAX otherwise)
 #pragma unroll
@@ -563,6 +572,10 @@ void build_stream(SubOp &so) {
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
   streamhost::build_runs(ne, P, so.lsize, so.h_sidx.data(), so.h_shared, code, hdr, rpos);
+  {
+    const std::vector<RunChunk> ch = streamhost::run_chunks(code);
+    so.d_rchunk = dev_upload(reinterpret_cast<const uint32_t *>(ch.data()), 4 * ch.size());
+  }
   so.d_rhdr = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
   so.d_rpos = dev_upload(rpos.data(), rpos.size());
   so.n_runs = (int)hdr.size() - 1;
@@ -614,7 +627,11 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
   streamhost::build_runs(so.ne, P, so.lsize, so.h_sidx.data(), shared, code, hdr, rpos, flag.data());  // (runs: all essential or none)
-  hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
+  hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc), hipFree(so.d_rchunk_bc);
+  {
+    const std::vector<RunChunk> ch = streamhost::run_chunks(code);
+    so.d_rchunk_bc = dev_upload(reinterpret_cast<const uint32_t *>(ch.data()), 4 * ch.size());
+  }
   so.d_rhdr_bc = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
   so.d_rpos_bc = dev_upload(rpos.data(), rpos.size());
   so.n_shared_bc = (int)shared.size();
@@ -647,7 +664,7 @@ void free_stream(SubOp &so) {
   hipFree(so.d_blist[0]), hipFree(so.d_blist[1]);
   hipFree(so.d_idxc), hipFree(so.d_perm_s), hipFree(so.d_perm_s_bc), hipFree(so.d_coef_s);
   hipFree(so.d_flagw), hipFree(so.d_flagw_bc), hipFree(so.d_slots);
-  hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc);
+  hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc), hipFree(so.d_rchunk), hipFree(so.d_rchunk_bc);
 }
 
 static int device_cus() {
@@ -815,10 +832,11 @@ void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double
 // additionally fuses ParOperator's fix-up y[ess] = x[ess] | 0 into it
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,
                           int ess_policy, const double *ye, const SplitIO *split) {
-  const int n = masked ? so.n_runs_bc : so.n_runs;
+  const int n = masked ? so.n_shared_bc : so.n_shared;
   if (n == 0) return;
   PA_REQUIRE(!split || !accumulate, "split vectors: y = A x only");
-  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 16 * kGatherILP - 1) / (16 * kGatherILP)), dim3(256), 0, s, n,
+  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
+                     reinterpret_cast<const RunChunk *>(masked ? so.d_rchunk_bc : so.d_rchunk),
                      reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
                      masked ? so.d_rpos_bc : so.d_rpos, ye ? ye : so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1,
                      split ? split->n_true : 0x7fffffff, split ? split->yg - split->n_true : nullptr);

@@ -212,5 +212,33 @@ inline void build_runs(int ne, int P, int lsize, const int32_t *sidx, const std:
   hdr.push_back(RunHdr{0u, (int32_t)rpos.size()});
 }
 
+// Where the shared dofs sit in their runs, 16 bytes per 64 of them: bit i of `starts` = shared dof 64 c + i starts a run (bit 0
+// is redundant: `first` says where the chunk's first dof is), first = run of that dof << 4 | its offset in the run.  The gather's
+// thread for dof 64 c + i: run = (first >> 4) + popcount(starts bits 1 .. i), offset = i - (highest such bit) or (first & 15) + i.
+struct RunChunk {
+  unsigned long long starts;
+  uint32_t first, pad;
+};
+inline std::vector<RunChunk> run_chunks(const std::vector<uint32_t> &code) {
+  std::vector<RunChunk> ch((code.size() + 63) / 64, RunChunk{0ull, 0u, 0u});
+  for (size_t k = 0; k < code.size(); k++) {
+    const uint32_t c = code[k] & 0x7fffffffu;
+    if ((k & 63) == 0) ch[k >> 6].first = c;
+    if ((c & 15u) == 0) ch[k >> 6].starts |= 1ull << (k & 63);
+  }
+  return ch;
+}
+// host model of the device decode: {run, offset} of shared dof k
+inline void chunk_decode(const std::vector<RunChunk> &ch, size_t k, int &run, int &off) {
+  const RunChunk &c = ch[k >> 6];
+  const int lane = (int)(k & 63);
+  const unsigned long long low = (c.starts & ~1ull) & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  int nc = 0, top = -1;
+  for (int i = 0; i < 64; i++)
+    if (low >> i & 1ull) nc++, top = i;
+  run = (int)(c.first >> 4) + nc;
+  off = nc ? lane - top : (int)(c.first & 15u) + lane;
+}
+
 }  // namespace streamhost
 }  // namespace pa

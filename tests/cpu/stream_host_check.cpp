@@ -100,6 +100,15 @@ static int run_case(int ne, int P, int lsize, unsigned seed, double ess_frac, in
         if (k >= shared_bc.size() || run_dof0(hdr[r]) + j != shared_bc[k] || run_ess(hdr[r]) != (ess[shared_bc[k]] != 0))
           return std::printf("run headers: run %zu entry %d does not name shared dof %zu\n", r, j, k), 1;
     if (k != shared_bc.size()) return std::printf("run headers: %zu of %zu shared dofs\n", k, shared_bc.size()), 1;
+    // ... and the chunk masks place every shared dof in its run (the gather's decode: popcount / count-leading-zeros)
+    const std::vector<RunChunk> ch = run_chunks(code);
+    for (size_t q = 0; q < code.size(); q++) {
+      int run, off;
+      chunk_decode(ch, q, run, off);
+      if (run != (int)((code[q] & 0x7fffffffu) >> 4) || off != (int)(code[q] & 15u))
+        return std::printf("run chunks: shared dof %zu decodes to run %d offset %d, code says %u / %u\n", q, run, off,
+                           (code[q] & 0x7fffffffu) >> 4, code[q] & 15u), 1;
+    }
   }
   shared = shared_bc;
   pp = ppb;
