@@ -64,23 +64,6 @@ __host__ __device__ constexpr int stream_lds_elem(const int raw) { return raw; }
 __host__ __device__ constexpr int stream_lds_elem(const int raw) { return (raw + 15) / 32 * 32 + 16; }
 #endif
 
-// Tensor-order staging rows of the E / E^T stages: lane (ta, tb) of component C reads / writes entries i = 0 .. ni - 1 of its line
-// L = ta + nj tb.  With ni = 4 (p = 3, components 1 and 2) the plain index i + 4 L puts the 16 lanes of an element on four of the
-// sixteen 8-byte write banks (three-way conflicts, 96 extra LDS cycles per batch: scripts/lds_conflict_model.py); rotating the
-// entries of a line by L / 4 makes both the reads and the writes conflict-free.  The slot table carries the same map
-// (stream_stage_slot below: build_stream applies it to the tensor-order slots before they are packed).
-template <int P1>
-__device__ __forceinline__ int nd_stage_index(const int C, const int i, const int ni, const int L) {
-  constexpr int NC = P1 + 1;
-  if (P1 == 3 && C != 0) return C * P1 * NC * NC + 4 * L + ((i + (L >> 2)) & 3);
-  return C * P1 * NC * NC + i + ni * L;
-}
-inline int stream_stage_slot(const int p, const int s) {  // host: where tensor-order slot s of an order-p element is staged
-  if (p != 3 || s < 48) return s;
-  const int C = s / 48, r = s % 48, i = r & 3, L = r >> 2;
-  return C * 48 + 4 * L + ((i + (L >> 2)) & 3);
-}
-
 template <int P1>
 struct NDStreamArgs {
   int ne, nbatch, chunk;  // chunk: batches per XCD (contiguous range)
@@ -276,7 +259,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       const int ni = (C == 0) ? P1 : NC, nj = (C == 1) ? P1 : NC, nk = (C == 2) ? P1 : NC;
       const bool act = ta < nj && tb < nk;
 #pragma unroll
-      for (int i = 0; i < NC; i++) uin[C][i] = (act && i < ni) ? sm[nd_stage_index<P1>(C, i, ni, ta + nj * tb)] : 0.0;
+      for (int i = 0; i < NC; i++) uin[C][i] = (act && i < ni) ? sm[C * P1 * NC * NC + i + ni * (ta + nj * tb)] : 0.0;
     }
     wave_sync();
 
@@ -395,7 +378,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       const bool act = ta < nj && tb < nk;
 #pragma unroll
       for (int i = 0; i < NC; i++)
-        if (act && i < ni) sm[nd_stage_index<P1>(C, i, ni, ta + nj * tb)] = uin[C][i];
+        if (act && i < ni) sm[C * P1 * NC * NC + i + ni * (ta + nj * tb)] = uin[C][i];
     }
     wave_sync();
     // One store per entry and lane, unconditionally: exclusive entries (flag) straight to y[dof], the others to the
@@ -556,14 +539,9 @@ void build_stream(SubOp &so) {
   // (a numbering that breaks an element's dofs into more than kIdxMaxRuns runs keeps the one-shot kernel)
   if (wide_form(so)) {
     if (!streamhost::pack_index_wide(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp)) return;
-  } else {
-    std::vector<uint16_t> staged(so.h_perm);  // (H(curl), p = 3: the conflict-free staging order of the four-point kernel)
-    if (so.fe_type == PA_FE_HCURL)
-      for (auto &q : staged) q = (uint16_t)stream_stage_slot(so.p, (int)q);
-    if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), staged.data(), ic, pp,
-                                so.fe_type == PA_FE_H1 ? streamhost::kIdxStart0H1 : streamhost::kIdxStart0))
-      return;
-  }
+  } else if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp,
+                                     so.fe_type == PA_FE_H1 ? streamhost::kIdxStart0H1 : streamhost::kIdxStart0))
+    return;
   so.h_perm_s = pp;
   if (so.fe_type == PA_FE_HCURL && !wide_form(so)) {
     // four-point H(curl) kernel: flag words on their own, slot words through the pattern dictionary (pa_internal.hpp)
@@ -584,28 +562,6 @@ void build_stream(SubOp &so) {
     }
     so.n_slot_patterns = (int)dict.size();
     so.d_flagw = dev_upload(flagw.data(), flagw.size());
-    so.d_slots = dev_upload(slots.data(), slots.size());
-  }
-  if (so.fe_type == PA_FE_HCURL && wide_form(so)) {
-    // five-point kernel: the same dictionary over the slot half-words with their flag bits (9-11 of each half) taken out;
-    // the flags travel as one word per lane and element
-    const int npl = (P + 31) / 32, npk = (npl + 1) / 2, nep = (ne + 1) & ~1, sw = npk * 32;
-    std::vector<uint32_t> slots;
-    std::map<std::vector<uint32_t>, uint32_t> dict;
-    std::vector<uint32_t> key((size_t)sw);
-    for (int e = 0; e < nep; e++) {
-      const uint32_t *row = &pp[(size_t)e * sw];
-      for (int i = 0; i < sw; i++) key[(size_t)i] = row[i] & ~((7u << 9) | (7u << 25));
-      auto it = dict.find(key);
-      if (it == dict.end()) {
-        it = dict.emplace(key, (uint32_t)dict.size()).first;
-        slots.insert(slots.end(), key.begin(), key.end());
-      }
-      ic[(size_t)e * streamhost::kWideWords + streamhost::kWidePattern] = it->second;
-    }
-    so.n_slot_patterns = (int)dict.size();
-    const std::vector<uint32_t> fw = streamhost::wide_flag_words(pp, nep, npk);
-    so.d_flagw = dev_upload(fw.data(), fw.size());
     so.d_slots = dev_upload(slots.data(), slots.size());
   }
   so.d_idxc = dev_upload(ic.data(), ic.size());
@@ -654,11 +610,7 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   }
   hipFree(so.d_perm_s_bc);
   so.d_perm_s_bc = dev_upload(pb.data(), pb.size());
-  if (so.d_flagw && wide) {
-    const std::vector<uint32_t> fb = streamhost::wide_flag_words(pb, (so.ne + 1) & ~1, npkw);
-    hipFree(so.d_flagw_bc);
-    so.d_flagw_bc = dev_upload(fb.data(), fb.size());
-  } else if (so.d_flagw) {  // (the flag words of the masked copy; the slot words are the same)
+  if (so.d_flagw) {  // (the flag words of the masked copy; the slot words are the same)
     const int nep = (so.ne + 3) & ~3;
     std::vector<uint32_t> fb((size_t)nep * 16);
     for (int e = 0; e < nep; e++) std::copy(&pb[((size_t)e * (npk + 1) + npk) * 16], &pb[((size_t)e * (npk + 1) + npk) * 16] + 16, fb.begin() + (size_t)e * 16);

@@ -25,10 +25,7 @@ struct NDStream5Args {
   int ne, nbatch, chunk;  // chunk: batches per XCD (contiguous range)
   const int32_t *blist;   // optional list of batches (interior / interface phases of a multi-rank apply)
   const uint32_t *idxw;   // [nep][kWideWords]
-  const uint32_t *slots;  // [patterns][NPK][32] slot half-words (bits 0-8 of each half: the tensor-order slot) of the sorted -> tensor-order
-                          // permutation; word kWidePattern of an element's index block names its pattern (pa_nd_hex_stream.hip:
-                          // build_stream; 3 patterns ... a few dozen on a structured mesh, so the table stays in L2)
-  const uint32_t *flagw;  // [nep][32]: lane t's entries t + 32 r: bits 3 r .. 3 r + 2 = flipped, only copy, essential
+  const uint32_t *perm;   // [nep][NPK][32] slot half-words
   const double *qdata;    // [nep][NG][126]
   const double *coef;     // metric form: [nep][2] scalar mass / curl-curl coefficient of the element
   const double *coef1;    // complex form: the same of the imaginary-part operator
@@ -87,13 +84,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
   const double *xsel = (CPLX && (lane >> 5)) ? a.x1 : a.x;  // the part of x this half gathers
   const double *xgh = nullptr;  // SPLIT: where the ghost entries are read (shifted: indexed with the local dof)
   if (SPLIT) xgh = ((a.xg_sel ? *a.xg_sel : 0ull) & 1ull) ? a.xg1 : a.xg0;
-  // (p[NPK]: the lane's flag word; the slot half-words follow in gather, when the pattern number has been parked in LDS)
-  auto load_idx = [&](const int bb, const int sub, const int t, unsigned (&w)[2], unsigned (&p)[NPK + 1]) {
+  auto load_idx = [&](const int bb, const int sub, const int t, unsigned (&w)[2], unsigned (&p)[NPK]) {
     const int e = CPLX ? bb : bb * 2 + sub;
     const uint32_t *ic = a.idxw + (size_t)e * kWideWords;
     w[0] = __builtin_nontemporal_load(&ic[t]);
     w[1] = __builtin_nontemporal_load(&ic[32 + (t & 15)]);
-    p[NPK] = __builtin_nontemporal_load(&a.flagw[(size_t)e * 32 + t]);
+    const uint32_t *pp = a.perm + (size_t)e * (NPK * 32) + t;
+#pragma unroll
+    for (int q = 0; q < NPK; q++) p[q] = __builtin_nontemporal_load(&pp[32 * q]);
   };
   // dof of entry t + 32 r from an index block in LDS (pa_stream_host.hpp: index_dof_wide)
   auto decode = [&](const int *stab, const int r, const int t) {
@@ -103,17 +101,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
     return stab[kWideStart0 + rid] + (t + 32 * r - pos);
   };
   // parks the index block of a batch in LDS, decodes the dofs and requests x of the entries
-  auto gather = [&](const unsigned (&w)[2], unsigned (&p)[NPK + 1], double (&xv)[NPL], int *stab, const int t) {
+  auto gather = [&](const unsigned (&w)[2], double (&xv)[NPL], int *stab, const int t) {
     stab[t] = (int)w[0];
     if (t < 16) stab[32 + t] = (int)w[1];
     wave_sync();
-    {  // slot half-words of the element's pattern, the lane's flip / only-copy / essential bits merged in (bits 9-11 of a half)
-      const uint32_t *sl = a.slots + (size_t)(unsigned)stab[streamhost::kWidePattern] * (NPK * 32) + t;
-      const unsigned fl = p[NPK];
-#pragma unroll
-      for (int q = 0; q < NPK; q++)
-        p[q] = sl[32 * q] | (((fl >> (6 * q)) & 7u) << 9) | (((fl >> (6 * q + 3)) & 7u) << 25);
-    }
 #pragma unroll
     for (int r = 0; r < NPL; r++) {
       int dof = decode(stab, r, t);
@@ -121,12 +112,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
       xv[r] = SPLIT ? (dof < a.nsplit ? xsel : xgh)[dof] : xsel[dof];
     }
   };
-  auto settle = [&](unsigned (&p)[NPK + 1]) { asm volatile("" : "+v"(p[NPK])); };
-  unsigned wA[2], pA[NPK + 1];
+  auto settle = [&](unsigned (&p)[NPK]) {
+#pragma unroll
+    for (int q = 0; q < NPK; q++) asm volatile("" : "+v"(p[q]));
+  };
+  unsigned wA[2], pA[NPK];
   double xv[NPL];
   int par = 0;  // which of the two index-block strips holds the current batch
   load_idx(b, lane >> 5, lane & 31, wA, pA);
-  gather(wA, pA, xv, reinterpret_cast<int *>(smem + (size_t)(wave * 2 + (lane >> 5)) * LDS_ELEM + CONTR_D + STG_D + SPW_D), lane & 31);
+  gather(wA, xv, reinterpret_cast<int *>(smem + (size_t)(wave * 2 + (lane >> 5)) * LDS_ELEM + CONTR_D + STG_D + SPW_D), lane & 31);
 #pragma unroll
   for (int r = 0; r < NPL; r++) asm volatile("" : "+v"(xv[r]));
   settle(pA);
@@ -197,7 +191,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
     };
 
     // index block of the next batch; first use: the x gather below
-    unsigned wB[2], pB[NPK + 1];
+    unsigned wB[2], pB[NPK];
     if (EARLY_IDX) {
       load_idx(bn, sub, t, wB, pB);
       __builtin_amdgcn_sched_barrier(0);
@@ -282,21 +276,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void nd_hex_stream5_kernel(
     double xB[NPL];
     if (GPOS == 0) {
       __builtin_amdgcn_sched_barrier(0);
-      gather(wB, pB, xB, stab, t);
+      gather(wB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
     PA_S5_BWD(0);
     if (GPOS == 1) {
       __builtin_amdgcn_sched_barrier(0);
-      gather(wB, pB, xB, stab, t);
+      gather(wB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
     PA_S5_BWD(1);
     if (GPOS == 2) {
       __builtin_amdgcn_sched_barrier(0);
-      gather(wB, pB, xB, stab, t);
+      gather(wB, xB, stab, t);
       settle(pB);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -418,7 +412,7 @@ static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, 
     if (a.nbatch == 0) return;
   }
   a.idxw = so.d_idxc;
-  a.slots = so.d_slots, a.flagw = masked ? so.d_flagw_bc : so.d_flagw;
+  a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
   a.qdata = so.qd->d;
   a.coef = so.d_coef_s, a.coef1 = nullptr;
   a.x = x, a.y = y, a.ye = so.d_ye;
@@ -454,7 +448,7 @@ static void launch5_complex_p(const SubOp &sr, const SubOp &si, const double *xr
   NDStream5Args<P1> a;
   a.ne = sr.ne, a.blist = nullptr, a.nbatch = 0;
   a.idxw = sr.d_idxc;
-  a.slots = sr.d_slots, a.flagw = masked ? sr.d_flagw_bc : sr.d_flagw;
+  a.perm = masked ? sr.d_perm_s_bc : sr.d_perm_s;
   a.qdata = sr.qd->d;
   a.coef = sr.d_coef_s, a.coef1 = si.d_coef_s;
   a.x = xr, a.x1 = xi, a.y = yr, a.y1 = yi, a.ye = sr.d_ye, a.ye1 = ye_i;

@@ -115,7 +115,6 @@ inline bool pack_index(int ne, int P, int lsize, const int32_t *sidx, const uint
 //   bits 0-8 tensor-order slot, bit 9 flipped, bit 10 only copy of its dof, bit 11 essential (read as zero; set in the
 //   copy stream_set_essential makes, which also takes the entry off the direct path)
 constexpr int kWideWords = 48, kWideStart0 = 20, kWideMaxRuns = 24, kWideMaxSlices = 10;
-constexpr int kWidePattern = kWideStart0 + kWideMaxRuns;  // word 44: the element's entry in the dictionary of slot patterns
 constexpr uint32_t kWideSlotMask = 511u, kWideFlip = 1u << 9, kWideExcl = 1u << 10, kWideEss = 1u << 11;
 
 inline int index_dof_wide(const uint32_t *ic, int m) {  // host model of the device decode
@@ -169,19 +168,6 @@ inline bool pack_index_wide(int ne, int P, int lsize, const int32_t *sidx, const
     }
   }
   return true;
-}
-
-// Flag bits of the wide slot half-words on their own: [nep][32] words, lane t's entries t + 32 r at bits 3 r .. 3 r + 2
-// (flipped, only copy, essential) -- the device merges them back into the half-words of the element's slot pattern
-inline std::vector<uint32_t> wide_flag_words(const std::vector<uint32_t> &pp, int nep, int npk) {
-  std::vector<uint32_t> fw((size_t)nep * 32, 0u);
-  for (int e = 0; e < nep; e++)
-    for (int q = 0; q < npk; q++)
-      for (int t = 0; t < 32; t++) {
-        const uint32_t w = pp[((size_t)e * npk + q) * 32 + t];
-        fw[(size_t)e * 32 + t] |= (((w >> 9) & 7u) << (6 * q)) | (((w >> 25) & 7u) << (6 * q + 3));
-      }
-  return fw;
 }
 
 // Runs over the shared dofs (`shared` increasing: every dof that does not have exactly one copy): consecutive dofs

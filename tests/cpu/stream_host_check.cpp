@@ -243,16 +243,6 @@ static int run_case_wide(int ne, int P, int lsize, unsigned seed, double ess_fra
       w &= ~(kWideExcl << (16 * (r & 1)));
       w |= kWideEss << (16 * (r & 1));
     }
-  {  // the flag bits on their own (what the device reads next to the slot-pattern dictionary) merge back into the half-words
-    const std::vector<uint32_t> fw = wide_flag_words(pp, nep, npk);
-    for (int e = 0; e < nep; e++)
-      for (int q = 0; q < npk; q++)
-        for (int t = 0; t < 32; t++) {
-          const uint32_t w = pp[((size_t)e * npk + q) * 32 + t], fl = fw[(size_t)e * 32 + t];
-          const uint32_t merged = (w & ~((7u << 9) | (7u << 25))) | (((fl >> (6 * q)) & 7u) << 9) | (((fl >> (6 * q + 3)) & 7u) << 25);
-          if (merged != w) return std::printf("wide flag words: element %d word %d lane %d\n", e, q, t), 1;
-        }
-  }
   std::vector<int32_t> shared;
   for (int d = 0; d < lsize; d++)
     if (count[d] != 1 || ess[d]) shared.push_back(d);
