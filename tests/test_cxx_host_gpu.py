@@ -182,3 +182,37 @@ def test_cxx_host_solve_against_the_oracle(built):
     xo, it_o, _ = po.pcg(prob.oA[-1].mult, b, oB.mult, rel_tol=1e-10, max_it=400)
     assert abs(its - it_o) <= 1, (its, it_o)
     assert abs(sx - xo.sum()) < 1e-6 * abs(xo.sum()), (sx, xo.sum())
+
+
+def test_cxx_host_ranks_ams_through_ksp_solver(tmp_path):
+    """Several ranks in C++ only (examples/cxx_host/solve_ranks.cpp: one process per rank, arena handles exchanged through files,
+    halo plans from a file): KspSolver with LinearSolver::AMS on a space with a halo = the ReplicatedCoarseSolver assembled from the
+    ranks' pieces (ksp.hpp; the reference: HYPRE's distributed AMS, linalg/ksp.cpp:129-239).  Two processes on this GPU against the
+    same program on one rank: iterations +- 1, the same solution."""
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "solve_ranks")
+    libdir = os.path.join(ROOT, "palace_amd", "lib")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O2", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cxx_host", "solve_ranks.cpp"),
+                           "-L" + libdir, "-lpalace_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    res = {}
+    for world in (1, 2):
+        prefix = str(tmp_path / f"w{world}")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "examples", "cxx_host", "dump_problem_ranks.py"), prefix, str(world),
+                               "2", "2", "4"])
+        d = tmp_path / f"handles{world}"
+        d.mkdir()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PALACE_AMD_PEER_TIMEOUT_S="30")
+        procs = [subprocess.Popen([exe, prefix, str(r), str(world), str(d), "ams"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                 for r in range(world)]
+        outs = [p.communicate(timeout=300) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1].decode()[-600:] for o in outs]
+        m = re.search(r"global ndofs (\d+) .* iterations (\d+)\s+converged (\d)\s+\|b - A x\| / \|b\| (\S+)\s+sum\(x\) (\S+)", outs[0][0].decode())
+        assert m, outs[0][0].decode()
+        res[world] = (int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4)), float(m.group(5)))
+    one, two = res[1], res[2]
+    assert one[0] == two[0] and one[2] == 1 and two[2] == 1 and one[3] < 1e-8 and two[3] < 1e-8, res
+    assert abs(one[1] - two[1]) <= 1, res
+    assert abs(one[4] - two[4]) < 1e-7 * abs(one[4]), res
