@@ -146,11 +146,13 @@ def test_replicated_ams_over_the_peer_transport():
     assert two["its0"] == two["its1"] == two["its2"] and two["xx1"] == two["xx2"]
 
 
-def _stress_worker(rank, world, port, rounds, out):
+def _stress_worker(rank, world, port, rounds, out, fenced=False):
     import torch
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if fenced:
+        os.environ["PALACE_AMD_PEER_FENCE"] = "1"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -158,7 +160,7 @@ def _stress_worker(rank, world, port, rounds, out):
 
         ctx = linalg.Context()
         ctx.init_comm_peer_from_torch_distributed()  # (runs the start-up self-test: 3 x 1 000 rounds)
-        res = {"bring_up": ctx.transport_report}
+        res = {"bring_up": ctx.transport_report, "fenced": bool(linalg._L().pa_comm_peer_fenced())}
         ring = ctx._ring_plan(4096)
         # both buffer parities (odd and even round counts leave the next call starting on the other buffer), inside and
         # outside graph replay, the L-vector and the direct form interleaved on ONE plan
@@ -245,3 +247,17 @@ def test_replicated_coarse_solver_assembled_from_the_ranks_pieces():
         assert abs(two[kind][0] - one["ams"][0]) <= 1, (kind, one, two)
         assert abs(two[kind][1] - one["ams"][1]) < 1e-6 * one["ams"][1], (kind, one, two)
         assert two[kind + "_again"][0] == two[kind][0]
+
+
+def test_flag_protocol_stress_with_system_scope_fences():
+    """The fall-back tier of the transport (PALACE_AMD_PEER_FENCE=1 / pa_comm_peer_set_fenced: system-scope release / acquire fences
+    around the flag stores and waits instead of relaxed atomics + s_waitcnt) runs the same stress test: it must be there when the
+    relaxed protocol fails its self-test on some machine."""
+    import torch.multiprocessing as mp
+
+    q = mp.get_context("spawn").SimpleQueue()
+    mp.spawn(_stress_worker, args=(2, 29669, 4000, q, True), nprocs=2, join=True)
+    res = q.get()
+    assert res["fenced"] and res["bring_up"]["transport"] == "peer", res
+    for k in ("lvector", "direct", "lvector_graph", "direct_graph", "lvector_again", "after_churn"):
+        assert res[k] == 0, res
