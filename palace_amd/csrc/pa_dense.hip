@@ -1434,6 +1434,17 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
     ds->d_tptr = dev_upload(tptr.data(), tptr.size());
     ds->d_tent = dev_upload(tent.data(), tent.size());
     ds->d_ye = dev_alloc<double>(nslot);
+    // ... and its run form (the apply's gather; the CSR form stays for the diagonal and as PALACE_AMD_DENSE_GATHER=csr)
+    static const bool runs = !(getenv("PALACE_AMD_DENSE_GATHER") && std::string(getenv("PALACE_AMD_DENSE_GATHER")) == "csr");
+    if (runs) {
+      std::vector<uint32_t> code, rpos;
+      std::vector<streamhost::RunHdr> hdr;
+      streamhost::build_runs_dense(ne, P, KP, r.lsize, r.offsets, r.orients, code, hdr, rpos);
+      const std::vector<streamhost::RunChunk> ch = streamhost::run_chunks(code);
+      ds->d_rchunk = dev_upload(reinterpret_cast<const uint32_t *>(ch.data()), 4 * ch.size());
+      ds->d_rhdr = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
+      ds->d_rpos_run = dev_upload(rpos.data(), std::max<size_t>(rpos.size(), 1));
+    }
   }
   ds->h_idx = std::move(idx);
 
@@ -1660,6 +1671,7 @@ void free_dense_sub(DenseSub *ds) {
   hipFree(ds->d_L), hipFree(ds->d_qdata);
   hipFree(ds->d_off), hipFree(ds->d_cor), hipFree(ds->d_ori);
   hipFree(ds->d_ye), hipFree(ds->d_tptr), hipFree(ds->d_tent);
+  hipFree(ds->d_rchunk), hipFree(ds->d_rhdr), hipFree(ds->d_rpos_run);
   hipFree(ds->c0.d_attr_mat), hipFree(ds->c0.d_mat), hipFree(ds->c0.d_mat_t);
   hipFree(ds->c1.d_attr_mat), hipFree(ds->c1.d_mat), hipFree(ds->c1.d_mat_t);
   pa_geom_destroy(static_cast<pa_geom *>(ds->geom));
@@ -1794,8 +1806,95 @@ __global__ void et_gather_split_kernel(const int n, const int32_t *__restrict__ 
   (d < nsplit ? y : yg)[d] = s;
 }
 
+// E^T of the dense path by runs (pa_stream_host.hpp: build_runs_dense): one thread per L-dof, its run and offset from the chunk
+// masks (12 bytes per 64 dofs), ONE position word per run and copy instead of one per dof and copy -- the copies of the dofs of an
+// edge or a face sit 16 doubles apart in the element's E-vector column, forwards or backwards -- same copies in the same order as
+// the CSR form (et_gather_kernel), hence the same bits.  kDenseGatherILP dofs per thread, a block width apart, their loads side by
+// side.  Split vectors (rows >= nsplit to yg) and ParOperator's essential rows (ess flags + policy) as in et_gather_split_kernel.
+constexpr int kDenseGatherILP = 4;
+__global__ __launch_bounds__(256) void et_run_gather_dense_kernel(const int n, const streamhost::RunChunk *__restrict__ chunk,
+                                                                  const streamhost::RunHdr *__restrict__ hdr,
+                                                                  const uint32_t *__restrict__ rpos, const double *__restrict__ ye,
+                                                                  double *__restrict__ y, double *__restrict__ yg, const int nsplit,
+                                                                  const int accumulate, const uint8_t *__restrict__ ess,
+                                                                  const double *__restrict__ x, const int ess_policy) {
+  const int k0 = blockIdx.x * (256 * kDenseGatherILP) + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int pb[kDenseGatherILP], pe[kDenseGatherILP], j[kDenseGatherILP], run[kDenseGatherILP];
+  bool live[kDenseGatherILP];
+  double s[kDenseGatherILP], yold[kDenseGatherILP];
+#pragma unroll
+  for (int u = 0; u < kDenseGatherILP; u++) {
+    const int k = k0 + 256 * u;
+    live[u] = k < n;
+    const streamhost::RunChunk c = chunk[live[u] ? (k >> 6) : 0];
+    const unsigned long long low = (c.starts & ~1ull) & ((2ull << lane) - 1ull);
+    const int nc = __popcll(low);
+    run[u] = (int)(c.first >> 4) + nc;
+    j[u] = nc ? lane - (63 - __clzll((long long)low)) : (int)(c.first & 15u) + lane;
+  }
+#pragma unroll
+  for (int u = 0; u < kDenseGatherILP; u++) {
+    pb[u] = hdr[live[u] ? run[u] : 0].ptr;
+    pe[u] = hdr[live[u] ? run[u] + 1 : 0].ptr;
+    s[u] = 0.0, yold[u] = 0.0;
+    if (live[u] && ess_policy >= 0 && ess && ess[k0 + 256 * u] && k0 + 256 * u < nsplit) {
+      s[u] = ess_policy ? x[k0 + 256 * u] : 0.0;  // essential row: no copies to sum
+      pe[u] = pb[u];
+    } else if (live[u] && accumulate) {
+      yold[u] = y[k0 + 256 * u];
+    }
+  }
+  unsigned r4[kDenseGatherILP][4];
+#pragma unroll
+  for (int u = 0; u < kDenseGatherILP; u++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) r4[u][q] = (live[u] && pb[u] + q < pe[u]) ? rpos[pb[u] + q] : 0xffffffffu;
+  double v[kDenseGatherILP][4];
+#pragma unroll
+  for (int u = 0; u < kDenseGatherILP; u++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const unsigned r = r4[u][q];
+      const bool have = live[u] && pb[u] + q < pe[u];
+      const long long at = (long long)(r & streamhost::kDenseRunPosMask) + ((r & streamhost::kDenseRunBack) ? -16 * j[u] : 16 * j[u]);
+      const double w = have ? ye[at] : 0.0;
+      v[u][q] = (r & streamhost::kDenseRunNeg) ? -w : w;
+    }
+#pragma unroll
+  for (int u = 0; u < kDenseGatherILP; u++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (live[u] && pb[u] + q < pe[u]) s[u] += v[u][q];
+    if (live[u])
+      for (int p = pb[u] + 4; p < pe[u]; p++) {
+        const unsigned r = rpos[p];
+        const double w = ye[(long long)(r & streamhost::kDenseRunPosMask) + ((r & streamhost::kDenseRunBack) ? -16 * j[u] : 16 * j[u])];
+        s[u] += (r & streamhost::kDenseRunNeg) ? -w : w;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < kDenseGatherILP; u++) {
+    const int d = k0 + 256 * u;
+    if (live[u]) (d < nsplit ? y : yg)[d] = yold[u] + s[u];  // (y + sum of the copies: the CSR form's order)
+  }
+}
+
 void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye, const SplitIO *split,
                          const double *x, int ess_policy) {
+  if (ds.d_rchunk) {
+    PA_REQUIRE(!(split || ess_policy >= 0) || !accumulate, "split vectors / fused essential rows: y = A x only");
+    PA_REQUIRE(ess_policy < 0 || (ds.d_ess_flag && x), "essential rows fused into the gather: pa_op_set_essential first");
+    const int n = ds.lsize;
+    if (n == 0) return;
+    hipLaunchKernelGGL(et_run_gather_dense_kernel, dim3((n + 256 * kDenseGatherILP - 1) / (256 * kDenseGatherILP)), dim3(256), 0, s, n,
+                       reinterpret_cast<const streamhost::RunChunk *>(ds.d_rchunk),
+                       reinterpret_cast<const streamhost::RunHdr *>(ds.d_rhdr), ds.d_rpos_run, ye ? ye : ds.d_ye, y,
+                       split ? split->yg - split->n_true : y, split ? split->n_true : 0x7fffffff, accumulate ? 1 : 0,
+                       ess_policy >= 0 ? ds.d_ess_flag : nullptr, x, ess_policy);
+    PA_HIP(hipGetLastError());
+    return;
+  }
   if (split || ess_policy >= 0) {  // (one vector with the essential rows fixed on the way: the same kernel, nothing beyond y)
     PA_REQUIRE(!accumulate, "split vectors / fused essential rows: y = A x only");
     PA_REQUIRE(ess_policy < 0 || (ds.d_ess_flag && x), "essential rows fused into the gather: pa_op_set_essential first");

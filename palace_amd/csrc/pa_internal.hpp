@@ -243,6 +243,9 @@ struct DenseSub {
   uint8_t *d_ori = nullptr;
   double *d_ye = nullptr;      // E-vector [nb][4 KP][16]
   int32_t *d_tptr = nullptr, *d_tent = nullptr;
+  // run form of the same map (pa_stream_host.hpp: build_runs_dense): chunk masks, run headers, one position per run and copy
+  uint32_t *d_rchunk = nullptr, *d_rpos_run = nullptr;
+  int32_t *d_rhdr = nullptr;
   std::vector<uint8_t> ctx_blob;
   CoeffHost c0, c1;
 };

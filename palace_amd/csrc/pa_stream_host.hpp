@@ -240,5 +240,64 @@ inline void chunk_decode(const std::vector<RunChunk> &ch, size_t k, int &run, in
   off = nc ? lane - top : (int)(c.first & 15u) + lane;
 }
 
+// ---- run form of the transpose map of the dense-table path (pa_dense.hip) ------------------------------------------------------
+// E-vector position of local dof l of element e: ((e / 16) 4 KP + l) 16 + e % 16 -- consecutive local dofs of an element are 16
+// doubles apart.  A run = up to 16 consecutive L-dofs (ALL dofs: the dense gather owns every row) with the same number of copies,
+// each copy in the same element with local dofs that step by +1 or -1 (an edge seen against its orientation) and the same sign.
+//   hdr[run]  = {first dof | length - 1, first entry in rpos}
+//   rpos      = per run and copy (element order: the summation order of the CSR form): position of the run's FIRST dof in that copy
+//               | bit 30: the following dofs step backwards | bit 31: the copy enters with a minus sign
+//   code[d]   = run << 4 | offset (host checks; the device reads run_chunks(code))
+constexpr uint32_t kDenseRunBack = 1u << 30, kDenseRunNeg = 1u << 31, kDenseRunPosMask = kDenseRunBack - 1u;
+inline void build_runs_dense(int ne, int P, int KP, int lsize, const int32_t *offsets, const uint8_t *orients,
+                             std::vector<uint32_t> &code, std::vector<RunHdr> &hdr, std::vector<uint32_t> &rpos) {
+  if (lsize > (int)kRunDofMask) throw std::runtime_error("too many local dofs for the run headers");
+  const size_t nnz = (size_t)ne * P;
+  std::vector<int32_t> tptr((size_t)lsize + 1, 0);
+  for (size_t k = 0; k < nnz; k++) tptr[(size_t)offsets[k] + 1]++;
+  for (int d = 0; d < lsize; d++) tptr[d + 1] += tptr[d];
+  std::vector<int32_t> tk(nnz), fill(tptr.begin(), tptr.end() - 1);
+  for (size_t k = 0; k < nnz; k++) tk[fill[offsets[k]]++] = (int32_t)k;  // copies of a dof in element order
+  auto position = [&](int e, int l) { return ((size_t)(e / 16) * 4 * KP + l) * 16 + (size_t)(e % 16); };
+  if (position(ne - 1, P - 1) >= kDenseRunBack) throw std::runtime_error("E-vector too large for the dense run positions");
+  code.assign((size_t)lsize, 0u), hdr.clear(), rpos.clear();
+  std::vector<int32_t> k0;   // first (element, local dof) of every run copy, as e P + l
+  std::vector<int8_t> step;  // its local-dof step: 0 not known yet, +1, -1
+  int len = 0;
+  for (int d = 0; d < lsize; d++) {
+    const int nc = tptr[d + 1] - tptr[d];
+    bool extend = d > 0 && len > 0 && len < 16 && !hdr.empty();
+    if (extend) {
+      const RunHdr &h = hdr.back();
+      extend = (int)rpos.size() - h.ptr == nc;
+      for (int c = 0; extend && c < nc; c++) {
+        const int k = tk[tptr[d] + c], e = k / P, l = k % P, e0 = k0[h.ptr + c] / P, l0 = k0[h.ptr + c] % P;
+        const bool flip = orients && orients[k], flip0 = (rpos[h.ptr + c] & kDenseRunNeg) != 0;
+        const int dl = l - l0;
+        extend = e == e0 && flip == flip0 && (step[h.ptr + c] == 0 ? (len == 1 && (dl == 1 || dl == -1)) : dl == step[h.ptr + c] * len);
+      }
+      if (extend)
+        for (int c = 0; c < nc; c++)
+          if (step[hdr.back().ptr + c] == 0) step[hdr.back().ptr + c] = (int8_t)(tk[tptr[d] + c] % P - k0[hdr.back().ptr + c] % P);
+    }
+    if (!extend) {
+      hdr.push_back(RunHdr{(uint32_t)d, (int32_t)rpos.size()});
+      for (int c = 0; c < nc; c++) {
+        const int k = tk[tptr[d] + c];
+        k0.push_back(k), step.push_back(0);
+        rpos.push_back((uint32_t)position(k / P, k % P) | ((orients && orients[k]) ? kDenseRunNeg : 0u));
+      }
+      len = 0;
+    }
+    if (hdr.size() >= (1u << 27)) throw std::runtime_error("too many runs for the gather code");
+    code[(size_t)d] = (uint32_t)(hdr.size() - 1) << 4 | (uint32_t)len;
+    hdr.back().dof0 = (hdr.back().dof0 & ~(15u << 27)) | ((uint32_t)len << 27);
+    len++;
+  }
+  for (size_t i = 0; i < rpos.size(); i++)
+    if (step[i] < 0) rpos[i] |= kDenseRunBack;
+  hdr.push_back(RunHdr{0u, (int32_t)rpos.size()});
+}
+
 }  // namespace streamhost
 }  // namespace pa

@@ -314,6 +314,77 @@ static int run_case_wide(int ne, int P, int lsize, unsigned seed, double ess_fra
   return err < 1e-13 ? 0 : 1;
 }
 
+// ---- dense path: build_runs_dense against the CSR form of the transpose map -------------------------------------------------------
+// Elements of P local dofs made of "entities" of 1 .. 6 consecutive global dofs, each placed at consecutive local positions forwards
+// or backwards (an edge seen against its orientation), signs per (element, entity) or -- per_dof_signs -- per entry (runs then break
+// inside an entity).  The run form (chunk masks + headers + one position per run and copy) must give exactly the sums of the CSR form.
+static int run_case_dense(int ne, int P, int KP, int nent, unsigned seed, bool per_dof_signs) {
+  std::mt19937 rng(seed);
+  std::vector<int> ent_first, ent_len;
+  int lsize = 0;
+  for (int k = 0; k < nent; k++) {
+    const int len = 1 + (int)(rng() % 6);
+    ent_first.push_back(lsize), ent_len.push_back(len), lsize += len;
+  }
+  lsize += 3;  // a few dofs no element touches (rows the gather writes as zero)
+  std::vector<int32_t> offsets((size_t)ne * P);
+  std::vector<uint8_t> orients((size_t)ne * P, 0);
+  for (int e = 0; e < ne; e++) {
+    std::vector<int> order(nent);
+    std::iota(order.begin(), order.end(), 0);
+    std::shuffle(order.begin(), order.end(), rng);
+    int l = 0;
+    for (int q = 0; q < nent && l < P; q++) {
+      const int k = order[q], len = std::min(ent_len[k], P - l);
+      const bool back = rng() & 1u, neg = rng() & 1u;
+      for (int i = 0; i < len; i++) {
+        offsets[(size_t)e * P + l + i] = ent_first[k] + (back ? len - 1 - i : i);
+        orients[(size_t)e * P + l + i] = per_dof_signs ? (uint8_t)(rng() & 1u) : (uint8_t)neg;
+      }
+      l += len;
+    }
+    if (l < P) return std::printf("dense case: not enough entities to fill an element\n"), 1;
+  }
+  const int nb = (ne + 15) / 16;
+  std::vector<double> ye((size_t)nb * 4 * KP * 16);
+  std::uniform_real_distribution<double> U(-1, 1);
+  for (auto &v : ye) v = U(rng);
+  auto position = [&](int e, int l) { return ((size_t)(e / 16) * 4 * KP + l) * 16 + (size_t)(e % 16); };
+  std::vector<double> yref(lsize, 0.0);
+  for (int d = 0; d < lsize; d++) {  // CSR form: copies in element order
+    double sum = 0.0;
+    for (int e = 0; e < ne; e++)
+      for (int l = 0; l < P; l++)
+        if (offsets[(size_t)e * P + l] == d) {
+          const double v = ye[position(e, l)];
+          sum += orients[(size_t)e * P + l] ? -v : v;
+        }
+    yref[d] = sum;
+  }
+  std::vector<uint32_t> code, rpos;
+  std::vector<RunHdr> hdr;
+  build_runs_dense(ne, P, KP, lsize, offsets.data(), orients.data(), code, hdr, rpos);
+  const std::vector<RunChunk> ch = run_chunks(code);
+  size_t ncopies = 0;
+  for (int d = 0; d < lsize; d++) {
+    int run, j;
+    chunk_decode(ch, (size_t)d, run, j);
+    if (run_dof0(hdr[run]) + j != d || j >= run_len(hdr[run])) return std::printf("dense runs: dof %d decodes to run %d offset %d\n", d, run, j), 1;
+    double sum = 0.0;
+    for (int p = hdr[run].ptr; p < hdr[run + 1].ptr; p++) {
+      const uint32_t r = rpos[p];
+      const long long at = (long long)(r & kDenseRunPosMask) + ((r & kDenseRunBack) ? -16 * j : 16 * j);
+      const double v = ye[(size_t)at];
+      sum += (r & kDenseRunNeg) ? -v : v;
+    }
+    if (sum != yref[d]) return std::printf("dense runs: dof %d: %.17g != %.17g\n", d, sum, yref[d]), 1;
+    ncopies += (size_t)(hdr[run + 1].ptr - hdr[run].ptr);
+  }
+  std::printf("dense ne=%d P=%d lsize=%d runs=%zu positions=%zu (CSR entries %zu) exact\n", ne, P, lsize, hdr.size() - 1, rpos.size(),
+              (size_t)ne * P);
+  return 0;
+}
+
 int main() {
   int bad = 0;
   bad += run_case(37, 144, 2000, 1, 0.05);
@@ -330,6 +401,10 @@ int main() {
   bad += run_case_wide(5, 12, 60, 14, 0.2, 1);
   bad += run_case_wide(1, 300, 900, 15, 0.0, 12);
   bad += run_case_wide(4, 300, 6000, 16, 0.05, 1, false);  // short blocks: more than 24 runs, refused
+  bad += run_case_dense(40, 45, 12, 60, 21, false);  // order-3 Nedelec tetrahedron: P = 45, KP = 12
+  bad += run_case_dense(33, 20, 8, 25, 22, false);
+  bad += run_case_dense(19, 45, 12, 40, 23, true);   // signs per entry: runs break inside the entities
+  bad += run_case_dense(1, 10, 4, 6, 24, false);
   return bad;
 }
 
