@@ -1434,8 +1434,11 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
     ds->d_tptr = dev_upload(tptr.data(), tptr.size());
     ds->d_tent = dev_upload(tent.data(), tent.size());
     ds->d_ye = dev_alloc<double>(nslot);
-    // ... and its run form (the apply's gather; the CSR form stays for the diagonal and as PALACE_AMD_DENSE_GATHER=csr)
-    static const bool runs = !(getenv("PALACE_AMD_DENSE_GATHER") && std::string(getenv("PALACE_AMD_DENSE_GATHER")) == "csr");
+    // ... and, on request (PALACE_AMD_DENSE_GATHER=runs), its run form.  Measured on 279 936 order-3 tetrahedra, alternating on one box:
+    // curl-curl 0.1857 / 0.1866 ms with the CSR form against 0.1839 / 0.1846 ms by runs, K + M 0.2631 / 0.2633 against 0.2613 / 0.2618
+    // (-1 %: the gather is bound by its scattered 8-byte E-vector reads, not by the position words), and SLOWER on small blocks
+    // (14 362 cubic H1 tetrahedra: 0.076 against 0.031 ms, four dofs per thread leave 65 workgroups) -- the CSR form stays the default.
+    static const bool runs = getenv("PALACE_AMD_DENSE_GATHER") && std::string(getenv("PALACE_AMD_DENSE_GATHER")) == "runs";
     if (runs) {
       std::vector<uint32_t> code, rpos;
       std::vector<streamhost::RunHdr> hdr;

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=gpurun_out
 ( time timeout 2400 python -m pytest -q -m gpu tests --durations=5 ) > $O/r12_tests.log 2>&1
 echo "tests exit $?" >> $O/r12_tests.log; grep -E "passed|failed" $O/r12_tests.log | tail -2
-for g in csr runs csr runs; do
+for g in csr runs csr runs; do  # (call 12 ran with the run form as the default)
   PALACE_AMD_DENSE_GATHER=$g N=36 REPS=200 timeout 300 python scripts/time_tet.py 2>&1 | grep -E "mult" | tr '\n' ' ' | sed "s/^/[$g] /" | tee -a $O/r12_time_tet.log; echo | tee -a $O/r12_time_tet.log
 done
 ( time timeout 1500 python bench.py ) > $O/r12_bench.json 2> $O/r12_bench.err
