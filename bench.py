@@ -506,7 +506,24 @@ def cpw_leg(order=3, refine=1, reps=20):
     A.mult(xr, xi, yr, yi)
     res = float(torch.sqrt(((yr - br) ** 2 + (yi - bi) ** 2).sum()) / torch.sqrt((br ** 2 + bi ** 2).sum()))
     out["fgmres"] = {"iterations_to_1e-8": st["iterations"], "seconds": dt, "iters_per_s": st["iterations"] / dt,
-                     "converged": st["converged"], "true_rel_residual": res}
+                     "converged": st["converged"], "true_rel_residual": res, "orthogonalization": "MGS (the reference's default)"}
+    # the same solve with the batched orthogonalisation (OrthogonalizeColumnCGS2, linalg/orthog.hpp:57-89: two reductions per step
+    # instead of j + 1): same preconditioner object
+    try:
+        S2 = linalg.ComplexParGmres(ctx, A, sys_["B"], rel_tol=1e-8, max_it=600, restart=600, flexible=True, orthogonalization="CGS2")
+        xr2, xi2 = torch.zeros_like(br), torch.zeros_like(br)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        S2.mult(br, bi, xr2, xi2)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        st2 = S2.stats()
+        dx = float(torch.sqrt(((xr2 - xr) ** 2 + (xi2 - xi) ** 2).sum()) / torch.sqrt((xr ** 2 + xi ** 2).sum()))
+        out["fgmres_cgs2"] = {"iterations_to_1e-8": st2["iterations"], "seconds": dt2, "iters_per_s": st2["iterations"] / dt2,
+                              "converged": st2["converged"], "rel_diff_of_the_solution_from_the_MGS_solve": dx}
+        del S2, xr2, xi2
+    except Exception as exc:  # noqa: BLE001
+        out["fgmres_cgs2"] = {"error": f"{type(exc).__name__}: {exc}"}
     # the real-part operator at this size against the numpy oracle (one oracle apply)
     from oracle import palace_oracle as po
 

@@ -190,4 +190,4 @@ class TetProblem:
         B = linalg.gmg(ctx, Pm, P, csolver, cheby_order=cheby_order, A_aux=Ph, G=G) if len(Pm) > 1 else csolver
         S = linalg.ComplexParGmres(ctx, A, B, rel_tol=rel_tol, max_it=max_it, restart=restart, flexible=True)
         self._keep.append((Kr, Ki, blocks, ploc, Pm, h1s, hb, hloc, Ph, G, P, csr0, csolver, B))
-        return dict(A=A, solver=S, ess=ess[-1], n=self.spaces[-1].ndofs, Kr=Kr, Ki=Ki)
+        return dict(A=A, solver=S, ess=ess[-1], n=self.spaces[-1].ndofs, Kr=Kr, Ki=Ki, B=B)
