@@ -594,6 +594,109 @@ def apply_hcurlmass_32(ctx_mass, ctx, geom, u, gradu):
     return (_unpack1(ctx_mass, attr) * geom[:, 1, :])[:, None, :] * u, apply_hcurl_32(ctx, geom, gradu)
 
 
+# ---- the contravariant (H(div)) members on boundary and line elements, the div-div + mass pairs, the gradient form ------
+
+def _adjJt32(A):
+    """utils_32_qf.h:23-40 (AdjJt32) applied to the stored adj(J)^T / detJ (six arrays, 3 x 2 column-major): the matrix the
+    `hdiv_32` family maps H(div) values with."""
+    E = A[0] * A[0] + A[1] * A[1] + A[2] * A[2]
+    G = A[3] * A[3] + A[4] * A[4] + A[5] * A[5]
+    F = A[0] * A[3] + A[1] * A[4] + A[2] * A[5]
+    d = np.sqrt(E * G - F * F)
+    return [(G * A[k] - F * A[3 + k]) / d for k in range(3)] + [(E * A[3 + k] - F * A[k]) / d for k in range(3)]
+
+
+def _mult_AtBCx32(A, B, C, x0, x1):
+    """utils_32_qf.h:53-72: y = A^T B C x; A, C 3 x 2 (six arrays), B [..., 9] column-major."""
+    y = [C[0] * x0 + C[3] * x1, C[1] * x0 + C[4] * x1, C[2] * x0 + C[5] * x1]
+    z = [B[..., 0 + r] * y[0] + B[..., 3 + r] * y[1] + B[..., 6 + r] * y[2] for r in range(3)]
+    return A[0] * z[0] + A[1] * z[1] + A[2] * z[2], A[3] * z[0] + A[4] * z[1] + A[5] * z[2]
+
+
+def _geom32(ctx, geom):
+    attr = geom[:, 0, :].astype(np.int32)
+    A = [geom[:, 2 + k, :] for k in range(6)]
+    return geom[:, 1, :], A, _adjJt32(A), ctx.unpack3(attr)
+
+
+def apply_hdiv_32(ctx, geom, u):
+    """hdiv_32_qf.h:10-31 (f_apply_hdiv_32): v = w detJ Jl^T C Jl u, Jl = AdjJt32(adjJt) -- H(div) mass on boundary elements."""
+    wdetJ, A, Jl, C = _geom32(ctx, geom)
+    v0, v1 = _mult_AtBCx32(Jl, C, Jl, u[:, 0, :], u[:, 1, :])
+    return np.stack([wdetJ * v0, wdetJ * v1], axis=1)
+
+
+def apply_hcurlhdiv_32(ctx, geom, u):
+    """hcurlhdiv_32_qf.h:10-30 (f_apply_hcurlhdiv_32): v = w detJ Jl^T C adjJt u."""
+    wdetJ, A, Jl, C = _geom32(ctx, geom)
+    v0, v1 = _mult_AtBCx32(Jl, C, A, u[:, 0, :], u[:, 1, :])
+    return np.stack([wdetJ * v0, wdetJ * v1], axis=1)
+
+
+def apply_hdivhcurl_32(ctx, geom, u):
+    """hcurlhdiv_32_qf.h:32-52 (f_apply_hdivhcurl_32): v = w detJ adjJt^T C Jl u."""
+    wdetJ, A, Jl, C = _geom32(ctx, geom)
+    v0, v1 = _mult_AtBCx32(A, C, Jl, u[:, 0, :], u[:, 1, :])
+    return np.stack([wdetJ * v0, wdetJ * v1], axis=1)
+
+
+def _geom_line(ctx, geom):
+    """Line elements: (w detJ, a = adjJt, AdjJt21 / AdjJt31 of it = a / |a| (utils_21_qf.h:19-28, utils_31_qf.h:19-31), C)."""
+    sdim = geom.shape[1] - 2
+    attr = geom[:, 0, :].astype(np.int32)
+    a = [geom[:, 2 + i, :] for i in range(sdim)]
+    d = np.sqrt(sum(ai * ai for ai in a))
+    C = (_unpack2(ctx, attr) if sdim == 2 else ctx.unpack3(attr))
+    return sdim, geom[:, 1, :], a, [ai / d for ai in a], C
+
+
+def _line_form(sdim, L, C, R):
+    """MultAtBCx21 / MultAtBCx31 with x = 1 (utils_21_qf.h, utils_31_qf.h:41-59): L^T C R for column vectors L, R."""
+    s = 0.0
+    for i in range(sdim):
+        s = s + L[i] * sum(C[..., i + sdim * j] * R[j] for j in range(sdim))
+    return s
+
+
+def apply_hdiv_line(ctx, geom, u):
+    """hdiv_21_qf.h / hdiv_31_qf.h:10-28 (f_apply_hdiv_21 | _31): v = w detJ t^T C t u with t = AdjJt(adjJt)."""
+    sdim, wdetJ, a, t, C = _geom_line(ctx, geom)
+    return (wdetJ * _line_form(sdim, t, C, t))[:, None, :] * u
+
+
+def apply_hcurlhdiv_line(ctx, geom, u):
+    """hcurlhdiv_21_qf.h / hcurlhdiv_31_qf.h:10-28 (f_apply_hcurlhdiv_21 | _31): v = w detJ t^T C adjJt u."""
+    sdim, wdetJ, a, t, C = _geom_line(ctx, geom)
+    return (wdetJ * _line_form(sdim, t, C, a))[:, None, :] * u
+
+
+def apply_hdivhcurl_line(ctx, geom, u):
+    """hcurlhdiv_21_qf.h / hcurlhdiv_31_qf.h:30-48 (f_apply_hdivhcurl_21 | _31): v = w detJ adjJt^T C t u."""
+    sdim, wdetJ, a, t, C = _geom_line(ctx, geom)
+    return (wdetJ * _line_form(sdim, a, C, t))[:, None, :] * u
+
+
+def apply_l2mass(ctx_mass, ctx_div, geom, qw, u, divu):
+    """l2mass_{22,33,21,31,32}_qf.h (f_apply_l2mass_*): the H(div) mass of the geometry (first context, space_dim x space_dim) on
+    the values + c qw^2 / (w detJ) on the divergence (second context, scalar): DivDivMassIntegrator, integ/divdivmass.cpp."""
+    rows = geom.shape[1]
+    mass = {11: apply_hdiv_33, 6: apply_hdiv_22, 8: apply_hdiv_32, 4: apply_hdiv_line, 5: apply_hdiv_line}[rows]
+    return mass(ctx_mass, geom, u), apply_l2_1(ctx_div, geom, qw, divu)
+
+
+def apply_hcurlh1d(ctx, geom, u):
+    """hcurlh1d_{22,33,21,31,32}_qf.h (f_apply_hcurlh1d_*): v = w detJ C (adjJt u) -- reference gradient (dim components) in,
+    space_dim physical components out (MultBAx*): GradientIntegrator, integ/grad.cpp:16-72 (trial Grad, test Interp on a
+    vector H1 space)."""
+    rows = geom.shape[1]
+    sdim, dim = {11: (3, 3), 6: (2, 2), 8: (3, 2), 4: (2, 1), 5: (3, 1)}[rows]
+    attr = geom[:, 0, :].astype(np.int32)
+    A = [geom[:, 2 + k, :] for k in range(sdim * dim)]  # column-major sdim x dim
+    C = _unpack2(ctx, attr) if sdim == 2 else ctx.unpack3(attr)
+    z = [sum(A[i + sdim * j] * u[:, j, :] for j in range(dim)) for i in range(sdim)]
+    return np.stack([geom[:, 1, :] * sum(C[..., i + sdim * j] * z[j] for j in range(sdim)) for i in range(sdim)], axis=1)
+
+
 # ---------------------------------------------------------------------------------------------
 # Operator: E, B, D, B^T, E^T
 # ---------------------------------------------------------------------------------------------
@@ -608,6 +711,11 @@ QF_HCURLHDIV, QF_HDIVHCURL = "hcurlhdiv_33", "hdivhcurl_33"  # weak curl (Interp
 QF_HCURLHDIV_22, QF_HDIVHCURL_22, QF_HDIV_22 = "hcurlhdiv_22", "hdivhcurl_22", "hdiv_22"
 QF_HCURLHDIV_ERROR_22, QF_HDIVHCURL_ERROR_22 = "hcurlhdiv_error_22", "hdivhcurl_error_22"
 QF_L2H1_ERROR = "l2h1_error"
+QF_HDIV_32, QF_HDIV_LINE = "hdiv_32", "hdiv_21|31"  # H(div) mass on boundary / line elements
+QF_L2MASS = "l2mass_*"  # div-div + H(div) mass; the geometry data tells the member (22, 33, 21, 31, 32)
+QF_HCURLHDIV_32, QF_HDIVHCURL_32 = "hcurlhdiv_32", "hdivhcurl_32"
+QF_HCURLHDIV_LINE, QF_HDIVHCURL_LINE = "hcurlhdiv_21|31", "hdivhcurl_21|31"
+QF_HCURLH1D = "hcurlh1d_*"  # (C grad u, v) with v in a vector H1 space
 
 
 class CeedOperatorOracle:
@@ -666,6 +774,14 @@ class CeedOperatorOracle:
     def _qfunction(self, geom, ue):
         """B, D, B^T on element-local vectors ue [ne, P] -> ve [ne, P]."""
         qf = self.qf
+        if qf in (QF_HDIV_32, QF_HDIV_LINE):  # H(div) mass on boundary / line elements (integ/vecfemass.cpp, cases 32 | 21 | 31)
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            return np.einsum("dqj,edq->ej", self.interp, (apply_hdiv_32 if qf == QF_HDIV_32 else apply_hdiv_line)(self.ctx, geom, u))
+        if qf == QF_L2MASS:  # div-div + mass on an H(div) space (integ/divdivmass.cpp): mass context first, then the scalar one
+            u = np.einsum("dqj,ej->edq", self.interp, ue)
+            du = np.einsum("dqj,ej->edq", self.deriv, ue)
+            v, dv = apply_l2mass(self.ctx, self.ctx2, geom, self.qw, u, du)
+            return np.einsum("dqj,edq->ej", self.interp, v) + np.einsum("dqj,edq->ej", self.deriv, dv)
         if qf == QF_L2_1:      # 2-D curl-curl; div-div with the divergence table (integ/divdiv.cpp: l2_1 for one component)
             cu = np.einsum("dqj,ej->edq", self.deriv, ue)
             return np.einsum("dqj,edq->ej", self.deriv, apply_l2_1(self.ctx, geom, self.qw, cu))
@@ -844,12 +960,27 @@ class MixedSpaceOracle:
     def apply_add(self, x, y, chunk=2048):
         f = {QF_HCURLHDIV: apply_hcurlhdiv_33, QF_HDIVHCURL: apply_hdivhcurl_33, QF_HCURL: apply_hcurl_33,
              QF_HCURLHDIV_22: apply_hcurlhdiv_22, QF_HDIVHCURL_22: apply_hdivhcurl_22, QF_HCURL_22: apply_hcurl_22,
+             QF_HCURLHDIV_32: apply_hcurlhdiv_32, QF_HDIVHCURL_32: apply_hdivhcurl_32, QF_HCURL_32: apply_hcurl_32,
+             QF_HCURLHDIV_LINE: apply_hcurlhdiv_line, QF_HDIVHCURL_LINE: apply_hdivhcurl_line, QF_HCURL_LINE: apply_hcurl_line,
              QF_H1MASS: apply_h1_1}[self.qf]  # QF_H1MASS: MassIntegrator between two scalar spaces (dim-1 context)
         for s0 in range(0, self.a.NE, chunk):
             sl = slice(s0, min(self.a.NE, s0 + chunk))
             u = np.einsum("dqj,ej->edq", self.ta, self.a._restrict(x, sl))
             ve = np.einsum("dqj,edq->ej", self.tb, f(self.ctx, self.geom[sl], u))
             np.add.at(y, self.b.off[sl].ravel(), self.b._restrict_t(ve, sl).ravel())
+        return y
+
+    def gradient_add(self, x, y, comp_stride, chunk=2048):
+        """GradientIntegrator (integ/grad.cpp:16-72, f_apply_hcurlh1d_*): `first` is the scalar H1 trial space (its gradient
+        table passed as `first_tab`), `second` the scalar space whose value table every component of the vector H1 test
+        space uses; component c of test dof j lives at y[c * comp_stride + j] (restriction.cpp:137-142, byNODES)."""
+        for s0 in range(0, self.a.NE, chunk):
+            sl = slice(s0, min(self.a.NE, s0 + chunk))
+            gu = np.einsum("dqj,ej->edq", self.ta, self.a._restrict(x, sl))
+            v = apply_hcurlh1d(self.ctx, self.geom[sl], gu)  # [ne, sdim, Q]
+            for c in range(v.shape[1]):
+                ve = np.einsum("qj,eq->ej", self.tb[0], v[:, c, :])
+                np.add.at(y, (c * comp_stride + self.b.off[sl]).ravel(), self.b._restrict_t(ve, sl).ravel())
         return y
 
     def error_add(self, u1, u2, est, chunk=2048):

@@ -35,3 +35,20 @@ typedef double CeedScalar;
 #include "fem/qfunctions/32/hcurl_32_qf.h"
 #include "fem/qfunctions/32/hdivmass_32_qf.h"
 #include "fem/qfunctions/32/hcurlmass_32_qf.h"
+// the remaining members of the 32 | 31 | 21 families and the div-div + mass / gradient forms (round 4)
+#include "fem/qfunctions/32/hdiv_32_qf.h"
+#include "fem/qfunctions/31/hdiv_31_qf.h"
+#include "fem/qfunctions/21/hdiv_21_qf.h"
+#include "fem/qfunctions/32/hcurlhdiv_32_qf.h"
+#include "fem/qfunctions/31/hcurlhdiv_31_qf.h"
+#include "fem/qfunctions/21/hcurlhdiv_21_qf.h"
+#include "fem/qfunctions/22/l2mass_22_qf.h"
+#include "fem/qfunctions/33/l2mass_33_qf.h"
+#include "fem/qfunctions/32/l2mass_32_qf.h"
+#include "fem/qfunctions/31/l2mass_31_qf.h"
+#include "fem/qfunctions/21/l2mass_21_qf.h"
+#include "fem/qfunctions/22/hcurlh1d_22_qf.h"
+#include "fem/qfunctions/33/hcurlh1d_33_qf.h"
+#include "fem/qfunctions/32/hcurlh1d_32_qf.h"
+#include "fem/qfunctions/31/hcurlh1d_31_qf.h"
+#include "fem/qfunctions/21/hcurlh1d_21_qf.h"

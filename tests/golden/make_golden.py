@@ -179,6 +179,45 @@ def fixtures_line():
     print("wrote qf1d_golden.npz")
 
 
+def fixtures_rest():
+    """The members of the QFunction families added last (round 4) through the reference headers: H(div) mass on boundary and line
+    elements (hdiv_32 | _31 | _21), the mixed H(curl) / H(div) forms there (hcurlhdiv_32 | _31 | _21), div-div + mass
+    (l2mass_22 | _33 | _32 | _31 | _21) and the gradient form (hcurlh1d_22 | _33 | _32 | _31 | _21), one geometry each."""
+    capi.build(ref=True)
+    rng = np.random.default_rng(20260928)
+    Q = 24
+    attr = rng.integers(1, 3, Q).astype(np.float64)
+    qw = rng.uniform(0.01, 0.2, Q)
+    A2, A3 = rng.uniform(-1, 1, (2, 2)), rng.uniform(-1, 1, (3, 3))
+    c2 = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[A2 + 2 * np.eye(2), np.array([0.6])], a=1.2, dim=2)  # non-symmetric on purpose
+    c3 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([0.8]), A3 + 2 * np.eye(3)], a=0.9)
+    c1 = po.CoeffCtx(attr_mat=[1, 0], mat_coeff=[np.array([1.9]), np.array([0.4])], dim=1)
+    out = dict(Q=Q, attr=attr, qw=qw, ctx1=c1.pack(), ctx2=c2.pack(), ctx3=c3.pack())
+    base = {33: np.eye(3).reshape(9, 1), 22: np.eye(2).reshape(4, 1), 32: np.array([1, 0, 0, 0, 1, 0.3]).reshape(6, 1),
+            31: np.array([1.0, 0.3, -0.2]).reshape(3, 1), 21: np.array([1.0, 0.3]).reshape(2, 1)}
+    for tag in (33, 22, 32, 31, 21):
+        sdim, dim = tag // 10, tag % 10
+        cm = c3 if sdim == 3 else c2
+        J = base[tag] + 0.4 * rng.uniform(-1, 1, (sdim * dim, Q))
+        g = np.zeros((2 + sdim * dim, Q))
+        capi.ref_call("f_build_geom_factor_%d" % tag, None, Q, [attr, qw, np.ascontiguousarray(J)], [g])
+        u, du = rng.uniform(-1, 1, (dim, Q)), rng.uniform(-1, 1, (1, Q))
+        out.update({"J%d" % tag: J, "geom%d" % tag: g, "u%d" % tag: u, "du%d" % tag: du})
+        if tag in (32, 31, 21):
+            for name in ("hdiv", "hcurlhdiv", "hdivhcurl"):
+                v = np.zeros((dim, Q))
+                capi.ref_call("f_apply_%s_%d" % (name, tag), cm.pack(), Q, [g, u], [v])
+                out["%s_%d" % (name, tag)] = v
+        v, dv = np.zeros((dim, Q)), np.zeros((1, Q))
+        capi.ref_call("f_apply_l2mass_%d" % tag, np.concatenate([cm.pack(), c1.pack()]), Q, [g, qw, u, du], [v, dv])
+        out.update({"l2mass_%d_v" % tag: v, "l2mass_%d_dv" % tag: dv})
+        gv = np.zeros((sdim, Q))
+        capi.ref_call("f_apply_hcurlh1d_%d" % tag, cm.pack(), Q, [g, u], [gv])
+        out["hcurlh1d_%d" % tag] = gv
+    np.savez(os.path.join(ROOT, "tests", "golden", "qf_rest_golden.npz"), **out)
+    print("wrote qf_rest_golden.npz")
+
+
 def cavity2d_fixture():
     """The reference's cavity2d mesh and its regression values (eig.csv, terminal-M.csv, terminal-C.csv)."""
     from palace_amd.fem import tri
