@@ -82,16 +82,41 @@ enum pa_qfunction {
   PA_QF_HDIVHCURL_ERROR_22 = 23, /* f_apply_hdivhcurl_error_22 fem/qfunctions/22/hcurlhdiv_error_22_qf.h:43-74 */
   PA_QF_HDIV_22 = 24,            /* f_apply_hdiv_22 fem/qfunctions/22/hdiv_22_qf.h:10-30: mass of a plane H(div) space
                                     (pa_op_add_sub_dense with PA_FE_HDIV, Interp) */
-  PA_QF_L2H1_ERROR = 25          /* f_apply_l2h1_error fem/qfunctions/l2h1_error_qf.h:14-30: element error between two scalar
+  PA_QF_L2H1_ERROR = 25,         /* f_apply_l2h1_error fem/qfunctions/l2h1_error_qf.h:14-30: element error between two scalar
                                     fields (the scalar curl of a plane field and its H1 recovery, errorestimator.cpp:466-472);
                                     pa_error_op_create with two scalar (PA_FE_H1 descriptor) bases, 1 x 1 pair context */
+  /* The members of the 32 | 31 | 21 families with the contravariant map, the div-div + mass pair and the gradient form.  No
+   * integrator that Palace's drivers add uses them (fem/integ/{vecfemass,mixedvecgrad,divdivmass,grad}.cpp select them for
+   * H(div) spaces on boundary / line elements, DivDivMassIntegrator and GradientIntegrator); built for completeness of the
+   * QFunction table, on the dense path (PA_FE_HDIV descriptors; pa_op_add_sub_dense / _mixed / _gradient). */
+  PA_QF_HDIV_32 = 26,      /* f_apply_hdiv_32      fem/qfunctions/32/hdiv_32_qf.h:10-31  H(div) mass, boundary elements */
+  PA_QF_HDIV_21 = 27,      /* f_apply_hdiv_21      fem/qfunctions/21/hdiv_21_qf.h        ... line elements in the plane */
+  PA_QF_HDIV_31 = 28,      /* f_apply_hdiv_31      fem/qfunctions/31/hdiv_31_qf.h:10-28  ... line elements in space */
+  PA_QF_L2MASS_22 = 29,    /* f_apply_l2mass_22    fem/qfunctions/22/l2mass_22_qf.h      div-div + H(div) mass (Interp | Div |
+                              Weight; pair context: space_dim x space_dim mass coefficient first, then the scalar one) */
+  PA_QF_L2MASS_33 = 30,    /* f_apply_l2mass_33    fem/qfunctions/33/l2mass_33_qf.h:10-42 */
+  PA_QF_L2MASS_32 = 31,    /* f_apply_l2mass_32    fem/qfunctions/32/l2mass_32_qf.h:10-42 */
+  PA_QF_L2MASS_21 = 32,    /* f_apply_l2mass_21    fem/qfunctions/21/l2mass_21_qf.h:10-40 */
+  PA_QF_L2MASS_31 = 33,    /* f_apply_l2mass_31    fem/qfunctions/31/l2mass_31_qf.h */
+  PA_QF_HCURLHDIV_32 = 34, /* f_apply_hcurlhdiv_32 fem/qfunctions/32/hcurlhdiv_32_qf.h:10-30  two spaces (pa_op_add_sub_dense_mixed) */
+  PA_QF_HDIVHCURL_32 = 35, /* f_apply_hdivhcurl_32 fem/qfunctions/32/hcurlhdiv_32_qf.h:32-52 */
+  PA_QF_HCURLHDIV_21 = 36, /* f_apply_hcurlhdiv_21 fem/qfunctions/21/hcurlhdiv_21_qf.h */
+  PA_QF_HDIVHCURL_21 = 37,
+  PA_QF_HCURLHDIV_31 = 38, /* f_apply_hcurlhdiv_31 fem/qfunctions/31/hcurlhdiv_31_qf.h:10-28 */
+  PA_QF_HDIVHCURL_31 = 39, /* f_apply_hdivhcurl_31 fem/qfunctions/31/hcurlhdiv_31_qf.h:30-48 */
+  PA_QF_HCURLH1D_22 = 40,  /* f_apply_hcurlh1d_22  fem/qfunctions/22/hcurlh1d_22_qf.h  (C grad u, v), v in a vector H1 space */
+  PA_QF_HCURLH1D_33 = 41,  /* f_apply_hcurlh1d_33  fem/qfunctions/33/hcurlh1d_33_qf.h:10-30 (pa_op_add_sub_dense_gradient) */
+  PA_QF_HCURLH1D_32 = 42,  /* f_apply_hcurlh1d_32  fem/qfunctions/32/hcurlh1d_32_qf.h:10-31 */
+  PA_QF_HCURLH1D_21 = 43,  /* f_apply_hcurlh1d_21  fem/qfunctions/21/hcurlh1d_21_qf.h:10-29 */
+  PA_QF_HCURLH1D_31 = 44   /* f_apply_hcurlh1d_31  fem/qfunctions/31/hcurlh1d_31_qf.h */
 };
 
 enum pa_fe_type {
   PA_FE_H1 = 0,
   PA_FE_HCURL = 1,
-  PA_FE_HDIV = 2 /* dense path only: RT mass (Interp + PA_QF_HDIV_33, interp = values [3 Q][P]) and div-div (Div | Weight +
-                    PA_QF_L2_1, fem/integ/divdiv.cpp; deriv = divergence [Q][P]); mixed mass with an H(curl) space */
+  PA_FE_HDIV = 2 /* dense path only: RT mass (Interp + PA_QF_HDIV_33 | _22 | _32 | _21 | _31 by the geometry data, interp = values
+                    [dim Q][P]), div-div (Div | Weight + PA_QF_L2_1, fem/integ/divdiv.cpp; deriv = divergence [Q][P]), both in
+                    one pass (Interp | Div | Weight + PA_QF_L2MASS_*, fem/integ/divdivmass.cpp); mixed mass with an H(curl) space */
 };
 
 /*
@@ -263,13 +288,24 @@ int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *res
  * enters with its gradient table (`deriv`, Grad): with PA_QF_HCURL_33 / PA_QF_HCURL_22 that is MixedVectorGradientIntegrator
  * (C grad phi, v), H1 trial and H(curl) test (fem/integ/mixedvecgrad.cpp:43-76; models/modeeigensolver.cpp:52), and with
  * PA_QF_HCURLHDIV_* its H(div)-test form (mixedvecgrad.cpp:50-55).  Plane elements: the _22 QFunctions with 2-D geometry
- * data.  PA_QF_H1_1 with two scalar bases (PA_FE_H1 descriptors, value tables): MassIntegrator between two scalar spaces, the
+ * data; boundary and line elements: the _32 | _31 | _21 members (PA_QF_HCURL_32 ..., PA_QF_HCURLHDIV_32 ..., PA_QF_HDIVHCURL_32
+ * ...; mixedvecgrad.cpp:78-130, vecfemass.cpp).  PA_QF_H1_1 with two scalar bases (PA_FE_H1 descriptors, value tables): MassIntegrator between two scalar spaces, the
  * `Flux` operator of the scalar-flux FluxProjector (errorestimator.cpp:122-160).  op: height = test lsize, width = trial lsize.
  * pa_op_mult_transpose applies the transposed form (test -> trial: the other member of the QFunction pair with the transposed
  * coefficient; Btn = -Atn^T of models/modeeigensolver.cpp:410-418 without assembling).  No essential-dof, diagonal or assembled form. */
 int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
                               const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
                               const pa_dense_basis_desc *test_basis, int32_t qfunction, const void *ctx, size_t ctx_size);
+/* GradientIntegrator (fem/integ/grad.cpp:16-72; f_apply_hcurlh1d_22 | _33 | _21 | _31 | _32 by the geometry data): (C grad u, v)
+ * with u in a scalar H1 space (trial, Grad: `trial_basis->deriv`) and v in a vector H1 space with space_dim components (test,
+ * Interp).  `test_restr` / `test_basis` describe ONE component of the test space -- the scalar value table, offsets = L-vector
+ * index of component 0 (already multiplied by the vector dimension for byVDIM ordering, restriction.cpp:137-142) --, component c
+ * of a dof lives `comp_stride` entries further (the libCEED comp_stride: 1 for byVDIM, the number of dofs for byNODES), and
+ * test_restr->lsize is the size of the whole vector L-vector (= the operator's height).  No transposed, diagonal or assembled form. */
+int pa_op_add_sub_dense_gradient(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
+                                 const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
+                                 const pa_dense_basis_desc *test_basis, int32_t comp_stride, int32_t qfunction, const void *ctx,
+                                 size_t ctx_size);
 /* AssembleCeedElementErrorIntegrator (fem/libceed/integrator.cpp:550-626) as the flux error estimators use it
  * (linalg/errorestimator.cpp:345-349, :485-489): estimates[e] += int_e |C_2 u_2 - C_1 u_1|^2 for L-vectors u_1, u_2 of two spaces
  * on the elements of `geom`; `ctx` is the pair context PopulateCoefficientContext(dim, first, dim, second) packs.  One value per

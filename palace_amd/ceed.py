@@ -27,6 +27,11 @@ QF_HCURLHDIV_33, QF_HDIVHCURL_33 = 9, 10  # weak curl (trial Interp, test Curl) 
 QF_HCURLHDIV_22, QF_HDIVHCURL_22, QF_HCURLHDIV_ERROR_22, QF_HDIVHCURL_ERROR_22 = 20, 21, 22, 23  # two spaces, plane elements
 QF_HDIV_22 = 24  # mass of a plane H(div) space (FE_HDIV block, Interp)
 QF_L2H1_ERROR = 25  # element error between two scalar fields (ElementErrorIntegrator with two scalar blocks)
+# the contravariant members on boundary / line elements, div-div + mass, the gradient form (include/palace_amd.h)
+QF_HDIV_32, QF_HDIV_21, QF_HDIV_31 = 26, 27, 28
+QF_L2MASS_22, QF_L2MASS_33, QF_L2MASS_32, QF_L2MASS_21, QF_L2MASS_31 = 29, 30, 31, 32, 33
+QF_HCURLHDIV_32, QF_HDIVHCURL_32, QF_HCURLHDIV_21, QF_HDIVHCURL_21, QF_HCURLHDIV_31, QF_HDIVHCURL_31 = 34, 35, 36, 37, 38, 39
+QF_HCURLH1D_22, QF_HCURLH1D_33, QF_HCURLH1D_32, QF_HCURLH1D_21, QF_HCURLH1D_31 = 40, 41, 42, 43, 44
 EVAL_WEIGHT, EVAL_NONE, EVAL_INTERP, EVAL_GRAD, EVAL_DIV, EVAL_CURL = (1 << i for i in range(6))
 FE_H1, FE_HCURL, FE_HDIV = 0, 1, 2
 
@@ -310,6 +315,18 @@ class Operator:
         ctx = np.ascontiguousarray(ctx_blob)
         _lib.check(_lib.load().pa_op_add_sub_dense_mixed(self.handle, geom.handle, C.byref(r1), C.byref(b1), C.byref(r2),
                                                          C.byref(b2), C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes)))
+        return self
+
+    def add_dense_gradient_integrator(self, geom: DenseGeomFactorData, trial: DenseBlock, test: DenseBlock, comp_stride, qf, ctx_blob):
+        """GradientIntegrator (fem/integ/grad.cpp:16-72, pa_op_add_sub_dense_gradient): `trial` a scalar H1 block (gradient
+        table), `test` ONE component of the vector H1 test space (value table; its lsize = the size of the whole vector
+        L-vector), the other components `comp_stride` entries further; qf = QF_HCURLH1D_* of the geometry data."""
+        r1, b1 = trial.descs()
+        r2, b2 = test.descs()
+        ctx = np.ascontiguousarray(ctx_blob)
+        L = _lib.load()
+        _lib.check(L.pa_op_add_sub_dense_gradient(self.handle, geom.handle, C.byref(r1), C.byref(b1), C.byref(r2), C.byref(b2),
+                                                  C.c_int32(int(comp_stride)), C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes)))
         return self
 
     @staticmethod

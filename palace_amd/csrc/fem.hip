@@ -508,16 +508,14 @@ void VectorFEMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial
   PA_REQUIRE((tc || trial.GetFEType() == PA_FE_HDIV) && (sc || test.GetFEType() == PA_FE_HDIV),
              "Invalid trial/test element map type for VectorFEMassIntegrator!");
   const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
-  int qf;
-  if (d == 33) {
-    qf = tc ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33) : (sc ? PA_QF_HDIVHCURL_33 : PA_QF_HDIV_33);
-  } else if (d == 22 && !(tc && sc)) {
-    qf = tc ? PA_QF_HCURLHDIV_22 : (sc ? PA_QF_HDIVHCURL_22 : PA_QF_HDIV_22);
-  } else {
-    PA_REQUIRE(tc && sc && (d == 22 || d == 32 || d == 21 || d == 31),
-               "VectorFEMassIntegrator: H(curl) spaces only on 2-D, boundary and line elements");
-    qf = d == 22 ? PA_QF_HCURL_22 : (d == 32 ? PA_QF_HCURL_32 : (d == 21 ? PA_QF_HCURL_21 : PA_QF_HCURL_31));
-  }
+  PA_REQUIRE(d == 33 || d == 22 || d == 32 || d == 21 || d == 31, "Invalid value of (dim, space_dim) for VectorFEMassIntegrator!");
+  // {H(curl) x H(curl), H(curl) trial x H(div) test, H(div) trial x H(curl) test, H(div) x H(div)} of every geometry
+  static const int table[5][4] = {{PA_QF_HCURL_33, PA_QF_HCURLHDIV_33, PA_QF_HDIVHCURL_33, PA_QF_HDIV_33},
+                                  {PA_QF_HCURL_22, PA_QF_HCURLHDIV_22, PA_QF_HDIVHCURL_22, PA_QF_HDIV_22},
+                                  {PA_QF_HCURL_32, PA_QF_HCURLHDIV_32, PA_QF_HDIVHCURL_32, PA_QF_HDIV_32},
+                                  {PA_QF_HCURL_21, PA_QF_HCURLHDIV_21, PA_QF_HDIVHCURL_21, PA_QF_HDIV_21},
+                                  {PA_QF_HCURL_31, PA_QF_HCURLHDIV_31, PA_QF_HDIVHCURL_31, PA_QF_HDIV_31}};
+  const int qf = table[d == 33 ? 0 : d == 22 ? 1 : d == 32 ? 2 : d == 21 ? 3 : 4][tc ? (sc ? 0 : 1) : (sc ? 2 : 3)];
   AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_INTERP, PA_EVAL_INTERP);
 }
 void DiffusionIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
@@ -547,8 +545,13 @@ void MixedVectorGradientIntegrator::Assemble(pa_op *op, const FiniteElementSpace
   const bool sc = test.GetFEType() == PA_FE_HCURL;
   PA_REQUIRE(trial.GetFEType() == PA_FE_H1 && (sc || test.GetFEType() == PA_FE_HDIV),
              "Invalid trial/test element map type for MixedVectorGradientIntegrator!");
-  PA_REQUIRE(d == 33 || d == 22, "MixedVectorGradientIntegrator: volume and plane elements only");
-  const int qf = d == 33 ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33) : (sc ? PA_QF_HCURL_22 : PA_QF_HCURLHDIV_22);
+  PA_REQUIRE(d == 33 || d == 22 || d == 32 || d == 21 || d == 31,
+             "Invalid value of (dim, space_dim) for MixedVectorGradientIntegrator!");
+  const int qf = d == 33   ? (sc ? PA_QF_HCURL_33 : PA_QF_HCURLHDIV_33)
+                 : d == 22 ? (sc ? PA_QF_HCURL_22 : PA_QF_HCURLHDIV_22)
+                 : d == 32 ? (sc ? PA_QF_HCURL_32 : PA_QF_HCURLHDIV_32)
+                 : d == 21 ? (sc ? PA_QF_HCURL_21 : PA_QF_HCURLHDIV_21)
+                           : (sc ? PA_QF_HCURL_31 : PA_QF_HCURLHDIV_31);
   AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_GRAD, PA_EVAL_INTERP);
 }
 void MixedVectorCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
@@ -572,6 +575,16 @@ void DiffusionMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &tria
   AssembleCeedOperator(op, trial, test, qf_dm,
                        ceed::PopulateCoefficientContext(1, Q_mass, sdim, Q, transpose_mass, transpose),
                        PA_EVAL_GRAD | PA_EVAL_INTERP, PA_EVAL_GRAD | PA_EVAL_INTERP);
+}
+void DivDivMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
+  // divdivmass.cpp:16-78: f_apply_l2mass_* of the geometry; Interp | Div | Weight on the trial side, mass context first
+  PA_REQUIRE(trial.GetFEType() == PA_FE_HDIV && test.GetFEType() == PA_FE_HDIV, "DivDivMassIntegrator: H(div) spaces expected");
+  const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
+  PA_REQUIRE(d == 33 || d == 22 || d == 32 || d == 21 || d == 31, "Invalid value of (dim, space_dim) for DivDivMassIntegrator!");
+  const int qf = d == 33 ? PA_QF_L2MASS_33
+                 : (d == 22 ? PA_QF_L2MASS_22 : (d == 32 ? PA_QF_L2MASS_32 : (d == 21 ? PA_QF_L2MASS_21 : PA_QF_L2MASS_31)));
+  AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q_mass, 1, Q, transpose_mass, transpose),
+                       PA_EVAL_DIV | PA_EVAL_INTERP | PA_EVAL_WEIGHT, PA_EVAL_DIV | PA_EVAL_INTERP);
 }
 void CurlCurlMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   const int d = dims_of(trial), dim = trial.GetMesh().Dimension(), sdim = trial.GetMesh().SpaceDimension();

@@ -242,6 +242,7 @@ PA_DECLARE_INTEGRATOR(MixedVectorWeakCurlIntegrator);  // H(curl) x H(curl), (Q 
   }
 PA_DECLARE_INTEGRATOR2(DiffusionMassIntegrator);  // H1, (Q grad u, grad v) + (Q_mass u, v)     fem/integ/diffusionmass.cpp
 PA_DECLARE_INTEGRATOR2(CurlCurlMassIntegrator);   // H(curl), (Q curl u, curl v) + (Q_mass u, v) fem/integ/curlcurlmass.cpp:16-68
+PA_DECLARE_INTEGRATOR2(DivDivMassIntegrator);     // H(div), (Q div u, div v) + (Q_mass u, v)     fem/integ/divdivmass.cpp
 #undef PA_DECLARE_INTEGRATOR2
 
 // An assembled local operator that owns its matrix (what FullAssemble returns; hypre::HypreCSRMatrix in the reference)

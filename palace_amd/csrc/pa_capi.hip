@@ -651,13 +651,33 @@ int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_des
     require_device();
     PA_REQUIRE(op && geom && trial_restr && trial_basis && test_restr && test_basis, "null argument");
     PA_REQUIRE(!op->finalized, "operator already finalized");
-    PA_REQUIRE(qfunction == PA_QF_HCURLHDIV_33 || qfunction == PA_QF_HDIVHCURL_33 || qfunction == PA_QF_HCURL_33 ||
-                   qfunction == PA_QF_HCURLHDIV_22 || qfunction == PA_QF_HDIVHCURL_22 || qfunction == PA_QF_HCURL_22 ||
-                   qfunction == PA_QF_H1_1,
-               "not a mixed-space QFunction");
+    switch (qfunction) {
+      case PA_QF_HCURLHDIV_33: case PA_QF_HDIVHCURL_33: case PA_QF_HCURL_33:
+      case PA_QF_HCURLHDIV_22: case PA_QF_HDIVHCURL_22: case PA_QF_HCURL_22:
+      case PA_QF_HCURLHDIV_32: case PA_QF_HDIVHCURL_32: case PA_QF_HCURL_32:
+      case PA_QF_HCURLHDIV_31: case PA_QF_HDIVHCURL_31: case PA_QF_HCURL_31:
+      case PA_QF_HCURLHDIV_21: case PA_QF_HDIVHCURL_21: case PA_QF_HCURL_21:
+      case PA_QF_H1_1: break;
+      default: throw Error("not a mixed-space QFunction");
+    }
     PA_REQUIRE(test_restr->lsize == op->height && trial_restr->lsize == op->width,
                "dimensions mismatch for sub-operator");  // operator.cpp:69-71
     op->msubs.push_back(make_mixed_sub(geom, *trial_restr, *trial_basis, *test_restr, *test_basis, qfunction, ctx, ctx_size));
+  });
+}
+
+int pa_op_add_sub_dense_gradient(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
+                                 const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
+                                 const pa_dense_basis_desc *test_basis, int32_t comp_stride, int32_t qfunction, const void *ctx,
+                                 size_t ctx_size) {
+  return guarded([&] {
+    require_device();
+    PA_REQUIRE(op && geom && trial_restr && trial_basis && test_restr && test_basis, "null argument");
+    PA_REQUIRE(!op->finalized, "operator already finalized");
+    PA_REQUIRE(test_restr->lsize == op->height && trial_restr->lsize == op->width,
+               "dimensions mismatch for sub-operator");  // operator.cpp:69-71
+    op->msubs.push_back(make_mixed_gradient_sub(geom, *trial_restr, *trial_basis, *test_restr, *test_basis, comp_stride, qfunction,
+                                                ctx, ctx_size));
   });
 }
 

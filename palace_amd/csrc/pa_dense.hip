@@ -122,7 +122,8 @@ struct DenseArgs {
   const uint16_t *co;  // 2-bit fields {sub, main, super} of row d of T_e and {T[d-1][d], T[d+1][d]} of column d
   const double *geom;
   const double *qw;     // quadrature weights (2-D curl-curl)
-  int contra;           // plane vector mass with the contravariant map J / detJ (f_apply_hdiv_22) instead of adj(J)^T / detJ
+  int contra;           // vector mass with the contravariant map of H(div) values (f_apply_hdiv_22 | _32 | _21 | _31: AdjJt of the
+                        // stored adj(J)^T / detJ) instead of adj(J)^T / detJ; with a pair mode: the div-div + mass forms f_apply_l2mass_*
   const double *Tf, *Tt;
   const double *L;      // resident form of the tables: [rows][S], rows in tile order (see make_dense_sub)
   const double *qdata;  // packed pre-assembled D: [nb][ncq][Qpad][16]
@@ -788,6 +789,20 @@ __global__ void dense_qdata_kernel(const DenseArgs a, double *__restrict__ qd) {
   const double wdetJ = g[cs];
   const int attr = (int)g[0];
   int o = 0;
+  if (MODE == MODE_DIFFMASS && a.contra) {
+    // f_apply_l2mass_33 (l2mass_33_qf.h:10-42) on the tables of an H(div) element, divergence in the place of the values and values
+    // in the place of the gradient: c qw^2 / (w detJ) (second context), then the H(div) mass w detJ Jl^T C Jl (first context)
+    out[0] = a.c0.mat[coeff_index(a.c0, attr)] * a.qw[q] * a.qw[q] / wdetJ;
+    double Jl[9], Cm[9], Mx[9];
+    coeff_unpack3(a.c1, attr, Cm);
+    adjJt33(adj, Jl);
+    for (int col = 0; col < 3; col++)
+      mult_AtBCx33(Jl, Cm, Jl, col == 0 ? 1.0 : 0.0, col == 1 ? 1.0 : 0.0, col == 2 ? 1.0 : 0.0, wdetJ, Mx[0 + 3 * col],
+                   Mx[1 + 3 * col], Mx[2 + 3 * col]);
+    out[1 * os] = Mx[0], out[2 * os] = 0.5 * (Mx[3] + Mx[1]), out[3 * os] = 0.5 * (Mx[6] + Mx[2]);
+    out[4 * os] = Mx[4], out[5 * os] = 0.5 * (Mx[7] + Mx[5]), out[6 * os] = Mx[8];
+    return;
+  }
   auto field = [&](auto tag) {
     constexpr int F = decltype(tag)::value;
     constexpr int NC = FieldTraits<MODE, F>::NC;
@@ -855,12 +870,24 @@ __global__ void dense_qdata1_kernel(const DenseArgs a, double *__restrict__ qd) 
   const int attr = (int)g[0];
   const double wdetJ = g[cs];
   int o = 0;
-  if (MODE == MODE_MASS || MODE == MODE_DIFFMASS1) out[(o++) * os] = a.c0.mat[coeff_index(a.c0, attr)] * wdetJ;
+  if (MODE == MODE_DIFFMASS1 && a.contra) {
+    // f_apply_l2mass_21 | _31 (l2mass_21_qf.h:10-40): H(div) mass on the values (below, first context), c qw^2 / (w detJ) on the
+    // divergence (second context)
+    out[os] = a.c1.mat[coeff_index(a.c1, attr)] * a.qw[q] * a.qw[q] / wdetJ;
+  } else if (MODE == MODE_MASS || MODE == MODE_DIFFMASS1) {
+    out[(o++) * os] = a.c0.mat[coeff_index(a.c0, attr)] * wdetJ;
+  }
   if (MODE != MODE_MASS) {  // MultAtBCx21 / MultAtBCx31 with x = 1 (utils_21_qf.h, utils_31_qf.h:41-59)
-    const CoeffDev &cc = (MODE == MODE_DIFFMASS1) ? a.c1 : a.c0;
+    const CoeffDev &cc = (MODE == MODE_DIFFMASS1 && !a.contra) ? a.c1 : a.c0;
     const double *C = cc.mat + SDIM * SDIM * coeff_index(cc, attr);
     double av[SDIM], s = 0.0;
     for (int i = 0; i < SDIM; i++) av[i] = g[(2 + i) * cs];
+    if (a.contra) {  // AdjJt21 / AdjJt31 of the stored vector (utils_21_qf.h:19-28, utils_31_qf.h:19-31): a / |a|
+      double n2 = 0.0;
+      for (int i = 0; i < SDIM; i++) n2 += av[i] * av[i];
+      const double d = sqrt(n2);
+      for (int i = 0; i < SDIM; i++) av[i] /= d;
+    }
     for (int i = 0; i < SDIM; i++) {
       double z = 0.0;
       for (int j = 0; j < SDIM; j++) z += C[i + SDIM * j] * av[j];
@@ -893,6 +920,13 @@ __global__ void dense_qdata2_kernel(const DenseArgs a, double *__restrict__ qd) 
     if (BDR) {  // MultAtBCx32(adjJt, coeff, adjJt, e_col) * wdetJ (utils_32_qf.h:53-72)
       double A[6], C[9];
       for (int k = 0; k < 6; k++) A[k] = g[(2 + k) * cs];
+      if (a.contra) {  // f_apply_hdiv_32 (hdiv_32_qf.h:10-31) first takes AdjJt32 of the stored matrix (utils_32_qf.h:23-40)
+        const double E = A[0] * A[0] + A[1] * A[1] + A[2] * A[2], G = A[3] * A[3] + A[4] * A[4] + A[5] * A[5];
+        const double F = A[0] * A[3] + A[1] * A[4] + A[2] * A[5], d = sqrt(E * G - F * F);
+        const double B6[6] = {(G * A[0] - F * A[3]) / d, (G * A[1] - F * A[4]) / d, (G * A[2] - F * A[5]) / d,
+                              (E * A[3] - F * A[0]) / d, (E * A[4] - F * A[1]) / d, (E * A[5] - F * A[2]) / d};
+        for (int k = 0; k < 6; k++) A[k] = B6[k];
+      }
       coeff_unpack3(cc, attr, C);
       for (int col = 0; col < 2; col++) {
         const double x0 = col == 0 ? 1.0 : 0.0, x1 = col == 1 ? 1.0 : 0.0;
@@ -1327,33 +1361,59 @@ void launch_geom_dense(const pa_mesh_dense_desc &mesh, Geom &g, hipStream_t s) {
 DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_dense_basis_desc &b, int qf,
                          const void *ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops, int height, bool contra) {
   PA_REQUIRE(geom && geom->eb == kEB, "geometry data must come from pa_geom_create_dense");
-  if (b.fe_type == PA_FE_HDIV && geom->dim == 2 && geom->sdim == 2) {
-    // plane H(div) mass (vecfemass.cpp:75-87 with an RT space: Interp + f_apply_hdiv_22): the 2-D vector mass with
-    // J / detJ = AdjJt22(adjJt) in the place of adjJt
-    PA_REQUIRE(qf == PA_QF_HDIV_22 && trial_ops == PA_EVAL_INTERP && test_ops == PA_EVAL_INTERP,
-               "plane H(div) elements: the mass operator (Interp, hdiv_22) is supported");
-    pa_dense_basis_desc alias = b;
-    alias.fe_type = PA_FE_HCURL;
-    return make_dense_sub(geom, r, alias, PA_QF_HCURL_22, ctx, ctx_size, trial_ops, test_ops, height, true);
-  }
   if (b.fe_type == PA_FE_HDIV) {
-    // H(div) mass (fem/integ/vecfemass.cpp with an RT space: Interp + f_apply_hdiv_33, the contravariant Piola map) is
-    // the arithmetic of the curl-curl operator with the value table in the place of the curl table
-    PA_REQUIRE(geom->dim == 3 && geom->sdim == 3, "H(div) elements: 3-D only");
+    // H(div) elements run on the arithmetic of an existing mode: the tables change places, the D of the values takes the
+    // contravariant map (`contra`: AdjJt of the stored adj(J)^T / detJ, what f_apply_hdiv_* do first).
+    const int d = 10 * geom->sdim + geom->dim;
+    const uint32_t t_ops = trial_ops & ~(uint32_t)PA_EVAL_WEIGHT, s_ops = test_ops & ~(uint32_t)PA_EVAL_WEIGHT;
     pa_dense_basis_desc alias = b;
     if (qf == PA_QF_L2_1) {
       // div-div (fem/integ/divdiv.cpp: Div | Weight, f_apply_l2_1 for single-component elements): the scalar-derivative
       // arithmetic of the 2-D curl-curl, c qw^2 / (w detJ), with the divergence table [Q][P] in the place of the curl table
-      PA_REQUIRE((trial_ops & ~(uint32_t)PA_EVAL_WEIGHT) == PA_EVAL_DIV && (test_ops & ~(uint32_t)PA_EVAL_WEIGHT) == PA_EVAL_DIV &&
-                     b.deriv,
+      PA_REQUIRE((d == 33 || d == 22 || d == 32) && t_ops == PA_EVAL_DIV && s_ops == PA_EVAL_DIV && b.deriv,
                  "H(div) elements: the div-div operator takes the divergence table with Div (| Weight)");
       alias.fe_type = PA_FE_HCURL, alias.interp = nullptr;
       return make_dense_sub(geom, r, alias, qf, ctx, ctx_size, PA_EVAL_CURL, PA_EVAL_CURL, height);
     }
-    PA_REQUIRE(qf == PA_QF_HDIV_33 && trial_ops == PA_EVAL_INTERP && test_ops == PA_EVAL_INTERP,
-               "H(div) elements: the mass operator (Interp, hdiv_33) and div-div (Div, l2_1) are supported");
-    alias.fe_type = PA_FE_HCURL, alias.deriv = b.interp, alias.interp = nullptr;
-    return make_dense_sub(geom, r, alias, qf, ctx, ctx_size, PA_EVAL_CURL, PA_EVAL_CURL, height);
+    const int q_mass = d == 33 ? PA_QF_HDIV_33 : d == 22 ? PA_QF_HDIV_22 : d == 32 ? PA_QF_HDIV_32 : d == 21 ? PA_QF_HDIV_21 : PA_QF_HDIV_31;
+    const int q_pair = d == 33   ? PA_QF_L2MASS_33
+                       : d == 22 ? PA_QF_L2MASS_22
+                       : d == 32 ? PA_QF_L2MASS_32
+                       : d == 21 ? PA_QF_L2MASS_21
+                                 : PA_QF_L2MASS_31;
+    if (qf == q_mass) {
+      PA_REQUIRE(t_ops == PA_EVAL_INTERP && s_ops == PA_EVAL_INTERP && b.interp, "H(div) mass: Interp on the value table");
+      if (d == 33) {
+        // (fem/integ/vecfemass.cpp with an RT space: Interp + f_apply_hdiv_33) the arithmetic of the curl-curl operator with the
+        // value table in the place of the curl table
+        alias.fe_type = PA_FE_HCURL, alias.deriv = b.interp, alias.interp = nullptr;
+        return make_dense_sub(geom, r, alias, qf, ctx, ctx_size, PA_EVAL_CURL, PA_EVAL_CURL, height);
+      }
+      // plane, boundary and line elements (f_apply_hdiv_22 | _32 | _21 | _31): the vector mass of the geometry with the
+      // contravariant map in the place of adjJt
+      alias.fe_type = PA_FE_HCURL;
+      const int q_cov = d == 22 ? PA_QF_HCURL_22 : d == 32 ? PA_QF_HCURL_32 : d == 21 ? PA_QF_HCURL_21 : PA_QF_HCURL_31;
+      return make_dense_sub(geom, r, alias, q_cov, ctx, ctx_size, PA_EVAL_INTERP, PA_EVAL_INTERP, height, true);
+    }
+    PA_REQUIRE(qf == q_pair, "H(div) elements: the mass operator (Interp, hdiv_*), div-div (Div, l2_1) and div-div + mass "
+                             "(Interp | Div, l2mass_*) of the geometry's dimensions are supported");
+    // DivDivMassIntegrator (fem/integ/divdivmass.cpp: Interp | Div | Weight, f_apply_l2mass_*; pair context: mass first)
+    PA_REQUIRE(t_ops == (PA_EVAL_INTERP | PA_EVAL_DIV) && s_ops == t_ops && b.interp && b.deriv,
+               "div-div + mass: value and divergence tables with Interp | Div (| Weight)");
+    if (d == 22 || d == 32) {  // the plane / boundary curl-curl + mass: two values, one scalar derivative
+      alias.fe_type = PA_FE_HCURL;
+      return make_dense_sub(geom, r, alias, d == 22 ? PA_QF_HDIVMASS_22 : PA_QF_HDIVMASS_32, ctx, ctx_size,
+                            PA_EVAL_INTERP | PA_EVAL_CURL, PA_EVAL_INTERP | PA_EVAL_CURL, height, true);
+    }
+    alias.fe_type = PA_FE_H1;
+    if (d == 33) {  // diffusion + mass with the roles exchanged: one "value" (the divergence), three "derivatives" (the values)
+      alias.interp = b.deriv, alias.deriv = b.interp;
+      return make_dense_sub(geom, r, alias, PA_QF_HCURLMASS_33, ctx, ctx_size, PA_EVAL_INTERP | PA_EVAL_GRAD,
+                            PA_EVAL_INTERP | PA_EVAL_GRAD, height, true);
+    }
+    // line elements: one value, one derivative -- the tables stay where they are
+    return make_dense_sub(geom, r, alias, d == 21 ? PA_QF_HCURLMASS_21 : PA_QF_HCURLMASS_31, ctx, ctx_size,
+                          PA_EVAL_INTERP | PA_EVAL_GRAD, PA_EVAL_INTERP | PA_EVAL_GRAD, height, true);
   }
   PA_REQUIRE(b.fe_type == PA_FE_H1 || b.fe_type == PA_FE_HCURL, "unknown element type");
   PA_REQUIRE(b.num_dofs > 0 && b.num_qpts == geom->Q, "basis and geometry data disagree on the quadrature rule");
@@ -1511,6 +1571,11 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       parse_coeff(ctx, ctx_size, 3, ds->c1, ds->c0.slots);
       break;
     case MODE_DIFFMASS:
+      if (contra) {  // l2mass_33: the 3 x 3 mass coefficient comes first, then the scalar one of the divergence
+        parse_coeff(ctx, ctx_size, 3, ds->c1, 0);
+        parse_coeff(ctx, ctx_size, 1, ds->c0, ds->c1.slots);
+        break;
+      }
       parse_coeff(ctx, ctx_size, 1, ds->c0, 0);
       parse_coeff(ctx, ctx_size, 3, ds->c1, ds->c0.slots);
       break;
@@ -1528,6 +1593,11 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       break;
     case MODE_DIFFMASS2:
     case MODE_DIFFMASS1:
+      if (mode == MODE_DIFFMASS1 && contra) {  // l2mass_21 | _31: the mass coefficient matrix first, then the scalar one
+        parse_coeff(ctx, ctx_size, sdim == 3 ? 3 : 2, ds->c0, 0);
+        parse_coeff(ctx, ctx_size, 1, ds->c1, ds->c0.slots);
+        break;
+      }
       parse_coeff(ctx, ctx_size, 1, ds->c0, 0);
       parse_coeff(ctx, ctx_size, sdim == 3 ? 3 : 2, ds->c1, ds->c0.slots);
       break;
@@ -1661,8 +1731,8 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
       }
     }
   }
-  PA_REQUIRE((dim == 3 && mode < MODE_CURL2) || ds->d_L,
-             "2-D blocks and div-div need symmetric coefficients and tables that fit in LDS (fast path only)");
+  PA_REQUIRE((dim == 3 && mode < MODE_CURL2 && !contra) || ds->d_L,
+             "2-D blocks, div-div and div-div + mass need symmetric coefficients and tables that fit in LDS (fast path only)");
   return ds;
 }
 
@@ -1919,7 +1989,7 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
   const long long n = (long long)ds.ne * ds.P;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   double *diag = dev_alloc<double>((size_t)n);  // element diagonals [ne][P] (set-up path: allocated per call)
-  if (ds.geom->dim == 3 && ds.mode < MODE_CURL2) switch (ds.mode) {
+  if (ds.geom->dim == 3 && ds.mode < MODE_CURL2 && !ds.contra) switch (ds.mode) {
 #define PA_DIAG_CASE(MODE)                                                                                   \
   case MODE:                                                                                                 \
     hipLaunchKernelGGL((dense_diag_kernel<MODE>), grid, block, 0, s, a, ds.d_off, ds.d_cor, ds.d_interp, ds.d_deriv, \
@@ -1946,6 +2016,7 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
     PA_DIAG2_CASE(MODE_MASS)
     PA_DIAG2_CASE(MODE_DIFF2)
     PA_DIAG2_CASE(MODE_DIFFMASS2)
+    PA_DIAG2_CASE(MODE_DIFFMASS)  // (l2mass_33: the div-div + mass pair on 3-D H(div) elements has q-data only)
     PA_DIAG2_CASE(MODE_VMASS1)
     PA_DIAG2_CASE(MODE_DIFF1)
     PA_DIAG2_CASE(MODE_DIFFMASS1)

@@ -345,6 +345,9 @@ void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const
 MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_dense_basis_desc &b1,
                          const pa_restriction_desc &r2, const pa_dense_basis_desc &b2, int qf, const void *ctx,
                          size_t ctx_size);
+MixedSub *make_mixed_gradient_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_dense_basis_desc &b1,
+                                  const pa_restriction_desc &r2, const pa_dense_basis_desc &b2, int comp_stride, int qf,
+                                  const void *ctx, size_t ctx_size);
 void free_mixed_sub(MixedSub *ms);
 void launch_mixed_apply(const MixedSub &ms, const double *x, double *y, bool accumulate, hipStream_t s, bool transpose = false);
 void launch_mixed_error(const MixedSub &ms, const double *u1, const double *u2, double *out, hipStream_t s);

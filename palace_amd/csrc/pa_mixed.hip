@@ -18,6 +18,10 @@
 //    2 x 2 Jacobian adjugate and coefficient are embedded in 3 x 3 matrices (third component of every field zero), which
 //    makes the 3-D arithmetic below the reference's 2-D arithmetic term by term.
 //
+//  * the members of those families on boundary and line elements (qfunctions/32 | 31 | 21: hcurlhdiv_*, hcurl_* between two
+//    spaces) and the gradient form  (C grad u, v)  with v in a vector H1 space (GradientIntegrator, fem/integ/grad.cpp:16-72,
+//    f_apply_hcurlh1d_* on every geometry): mixed_embedded_kernel below.  No driver of the reference adds them.
+//
 // These run once per solve (post-processing), not inside the Krylov loop: one wave per element, dense tables read through the
 // caches (q fastest for the forward product, dof fastest for the transposed one: coalesced either way), the pointwise arithmetic
 // exactly the reference QFunctions' on the element-blocked geometry data of pa_geom_create_dense, E^T as E-vector + the
@@ -223,6 +227,115 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
   }
 }
 
+// Geometry data whose adj(J)^T / detJ is SDIM x DIM (2 + SDIM DIM rows): boundary (3, 2) and line (3, 1), (2, 1) elements with
+// KIND 0 / 1 / 4 as above -- f_apply_hcurlhdiv_*, f_apply_hdivhcurl_*, f_apply_hcurl_* between two spaces, DIM components on
+// both sides (MultAtBCx32 / 31 / 21: v = w detJ L^T C R u, L / R = the stored matrix or AdjJt32 / 31 / 21 of it) -- and, on
+// every geometry, KIND 7: f_apply_hcurlh1d_* (hcurlh1d_33_qf.h:10-30, MultBAx*: v = w detJ C (adjJt u)), the DIM reference
+// components of the trial gradient to the SDIM components of a vector H1 test space; each component uses the scalar value
+// table of s2 and is one row [P2] of the element's E-vector block [SDIM][P2].
+template <int KIND, int SDIM, int DIM>
+__global__ __launch_bounds__(64 * kMixWaves) void mixed_embedded_kernel(const MixArgs a) {
+  static_assert(KIND == 0 || KIND == 1 || KIND == 4 || KIND == 7, "apply forms only");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * kMixWaves + wave;
+  if (e >= a.ne) return;  // no workgroup barriers below
+  const int P1 = a.s1.P, P2 = a.s2.P, Q = a.Q;
+  double *xa = smem + (size_t)wave * a.stride;
+  double *xb = xa + P1;
+  double *tmp = xb + P2;
+  double *vq = tmp + max(P1, P2);
+  constexpr int NV = KIND == 7 ? SDIM : DIM;
+
+  mix_gather(a.s1, e, lane, a.x1, xa, tmp);
+  const double *g = a.geom + ((size_t)(e / kEBm) * (2 + SDIM * DIM) * a.Qpad) * kEBm + (e % kEBm);
+  for (int q = lane; q < Q; q += 64) {
+    double u1[3];
+    mix_eval(a.s1, Q, q, xa, u1);
+    const int attr = a.c0.nattr > 0 ? max(1, (int)g[(size_t)q * kEBm]) : 1;
+    const double wdetJ = g[((size_t)a.Qpad + q) * kEBm];
+    double A[SDIM * DIM], C[SDIM * SDIM];
+#pragma unroll
+    for (int k = 0; k < SDIM * DIM; k++) A[k] = g[((size_t)(2 + k) * a.Qpad + q) * kEBm];
+    {
+      const double *m = a.c0.mat + SDIM * SDIM * coeff_index(a.c0, attr);  // CoeffUnpack2 / CoeffUnpack3, column-major
+#pragma unroll
+      for (int k = 0; k < SDIM * SDIM; k++) C[k] = m[k];
+    }
+    double T[SDIM * DIM];  // the contravariant map
+    if (KIND == 0 || KIND == 1) {
+      if (DIM == 2) {  // AdjJt32 (utils_32_qf.h:23-40)
+        const double E = A[0] * A[0] + A[1] * A[1] + A[2] * A[2], G = A[3] * A[3] + A[4] * A[4] + A[5] * A[5];
+        const double F = A[0] * A[3] + A[1] * A[4] + A[2] * A[5], d = sqrt(E * G - F * F);
+#pragma unroll
+        for (int k = 0; k < 3; k++) T[k] = (G * A[k] - F * A[3 + k]) / d, T[3 + k] = (E * A[3 + k] - F * A[k]) / d;
+      } else {  // AdjJt21 / AdjJt31 (utils_21_qf.h:19-28, utils_31_qf.h:19-31)
+        double n2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < SDIM; i++) n2 += A[i] * A[i];
+        const double d = sqrt(n2);
+#pragma unroll
+        for (int i = 0; i < SDIM; i++) T[i] = A[i] / d;
+      }
+    }
+    const double *L = KIND == 0 ? T : A, *R = KIND == 1 ? T : A;
+    double y[SDIM], z[SDIM];
+#pragma unroll
+    for (int i = 0; i < SDIM; i++) {
+      y[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) y[i] += R[i + SDIM * j] * u1[j];
+    }
+#pragma unroll
+    for (int i = 0; i < SDIM; i++) {
+      z[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < SDIM; j++) z[i] += C[i + SDIM * j] * y[j];
+    }
+    if (KIND == 7) {
+#pragma unroll
+      for (int i = 0; i < SDIM; i++) vq[i * Q + q] = wdetJ * z[i];
+    } else {
+#pragma unroll
+      for (int j = 0; j < DIM; j++) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < SDIM; i++) v += L[i + SDIM * j] * z[i];
+        vq[j * Q + q] = wdetJ * v;
+      }
+    }
+  }
+  wave_sync();
+  double *yt = tmp;
+  if (KIND == 7) {  // every component through the scalar table, one E-vector row each (no dof transformation on H1 spaces)
+    for (int c = 0; c < NV; c++) {
+      for (int i = lane; i < P2; i += 64) {
+        double s = 0.0;
+        for (int q = 0; q < Q; q++) s += a.s2.tabT[(size_t)q * P2 + i] * vq[c * Q + q];
+        a.ye[((size_t)e * NV + c) * P2 + i] = s;
+      }
+    }
+    return;
+  }
+  for (int i = lane; i < P2; i += 64) {
+    double s = 0.0;
+    for (int c = 0; c < DIM; c++)
+      for (int q = 0; q < Q; q++) s += a.s2.tabT[((size_t)c * Q + q) * P2 + i] * vq[c * Q + q];
+    yt[i] = s;
+  }
+  wave_sync();
+  for (int i = lane; i < P2; i += 64) {
+    double s = yt[i];
+    if (a.s2.cor) {
+      const int8_t *t = a.s2.cor + 3 * ((size_t)e * P2 + i);
+      s = (double)t[1] * yt[i];
+      if (i > 0) s += (double)t[-3 + 2] * yt[i - 1];       // T[i-1][i]
+      if (i + 1 < P2) s += (double)t[3 + 0] * yt[i + 1];    // T[i+1][i]
+    }
+    a.ye[(size_t)e * P2 + i] = s;
+  }
+}
+
 // H(curl) and H(div) sides enter with their value tables (Interp), an H1 side with its gradient table (Grad): the covariant
 // map of H(curl) values is the map of gradients.
 void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, int nc, MixedSide &sd) {
@@ -284,6 +397,24 @@ void launch(const MixedSub &ms, const double *x1, const double *x2, double *out,
   const size_t shm = sizeof(double) * (size_t)a.stride * kMixWaves;
   PA_REQUIRE(shm <= 64 * 1024, "element too large for the mixed-space kernels");
   const dim3 grid((ms.ne + kMixWaves - 1) / kMixWaves), block(64 * kMixWaves);
+  const int dims = 10 * ms.geom->sdim + ms.geom->dim;
+  if (kind == 7 || dims == 32 || dims == 31 || dims == 21) {
+    PA_REQUIRE(kind != 7 || !transpose, "the gradient form has no transposed apply");
+    bool done = true;
+#define PA_MIX_EMB(K, SD, D)                                                                  \
+  if (kind == K && dims == 10 * SD + D)                                                       \
+    hipLaunchKernelGGL((mixed_embedded_kernel<K, SD, D>), grid, block, shm, s, a);            \
+  else
+    PA_MIX_EMB(0, 3, 2) PA_MIX_EMB(1, 3, 2) PA_MIX_EMB(4, 3, 2)
+    PA_MIX_EMB(0, 3, 1) PA_MIX_EMB(1, 3, 1) PA_MIX_EMB(4, 3, 1)
+    PA_MIX_EMB(0, 2, 1) PA_MIX_EMB(1, 2, 1) PA_MIX_EMB(4, 2, 1)
+    PA_MIX_EMB(7, 3, 3) PA_MIX_EMB(7, 2, 2) PA_MIX_EMB(7, 3, 2) PA_MIX_EMB(7, 3, 1) PA_MIX_EMB(7, 2, 1)
+    done = false;
+#undef PA_MIX_EMB
+    PA_REQUIRE(done, "QFunction not built for boundary / line elements");
+    PA_HIP(hipGetLastError());
+    return;
+  }
   switch (kind) {
     case 0: hipLaunchKernelGGL(mixed_kernel<0>, grid, block, shm, s, a); break;
     case 1: hipLaunchKernelGGL(mixed_kernel<1>, grid, block, shm, s, a); break;
@@ -299,28 +430,54 @@ void launch(const MixedSub &ms, const double *x1, const double *x2, double *out,
 
 }  // namespace
 
+namespace {
+// transpose map of a signed index list [n] into an L-vector of lsize entries (counting sort by dof, list order preserved)
+void build_transpose_map(const std::vector<int32_t> &off, const uint8_t *orients, int lsize, MixedSide &sd) {
+  std::vector<int32_t> tptr((size_t)lsize + 1, 0), tent(off.size());
+  for (size_t k = 0; k < off.size(); k++) tptr[(size_t)off[k] + 1]++;
+  for (int d = 0; d < lsize; d++) tptr[d + 1] += tptr[d];
+  std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+  for (size_t k = 0; k < off.size(); k++) tent[fill[off[k]]++] = (orients && orients[k]) ? -1 - (int32_t)k : (int32_t)k;
+  hipFree(sd.d_tptr), hipFree(sd.d_tent);
+  sd.d_tptr = dev_upload(tptr.data(), tptr.size());
+  sd.d_tent = dev_upload(tent.data(), tent.size());
+}
+}  // namespace
+
 MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_dense_basis_desc &b1,
                          const pa_restriction_desc &r2, const pa_dense_basis_desc &b2, int qf, const void *ctx,
                          size_t ctx_size) {
-  PA_REQUIRE(geom && geom->eb == kEBm && geom->dim == geom->sdim && (geom->dim == 3 || geom->dim == 2),
-             "mixed-space operators need 3-D or plane geometry data from pa_geom_create_dense");
+  PA_REQUIRE(geom && geom->eb == kEBm && geom->dim >= 1 && geom->dim <= geom->sdim && geom->sdim <= 3,
+             "mixed-space operators need geometry data from pa_geom_create_dense");
   PA_REQUIRE(r1.num_elem == geom->ne && r2.num_elem == geom->ne, "restrictions do not match the mesh");
-  const int dim = geom->dim;
-  int kind = -1;  // the QFunction family; its _33 / _22 member must be the one of the geometry data
+  const int dim = geom->dim, sdim = geom->sdim, dims = 10 * sdim + dim;
+  int kind = -1, qdims = 0;  // the QFunction family and the member (10 space_dim + dim; 0: any geometry)
   switch (qf) {
-    case PA_QF_HCURLHDIV_33: case PA_QF_HCURLHDIV_22: kind = 0; break;
-    case PA_QF_HDIVHCURL_33: case PA_QF_HDIVHCURL_22: kind = 1; break;
-    case PA_QF_HCURLHDIV_ERROR_33: case PA_QF_HCURLHDIV_ERROR_22: kind = 2; break;
-    case PA_QF_HDIVHCURL_ERROR_33: case PA_QF_HDIVHCURL_ERROR_22: kind = 3; break;
-    case PA_QF_HCURL_33: case PA_QF_HCURL_22: kind = 4; break;
+    case PA_QF_HCURLHDIV_33: kind = 0, qdims = 33; break;
+    case PA_QF_HCURLHDIV_22: kind = 0, qdims = 22; break;
+    case PA_QF_HCURLHDIV_32: kind = 0, qdims = 32; break;
+    case PA_QF_HCURLHDIV_31: kind = 0, qdims = 31; break;
+    case PA_QF_HCURLHDIV_21: kind = 0, qdims = 21; break;
+    case PA_QF_HDIVHCURL_33: kind = 1, qdims = 33; break;
+    case PA_QF_HDIVHCURL_22: kind = 1, qdims = 22; break;
+    case PA_QF_HDIVHCURL_32: kind = 1, qdims = 32; break;
+    case PA_QF_HDIVHCURL_31: kind = 1, qdims = 31; break;
+    case PA_QF_HDIVHCURL_21: kind = 1, qdims = 21; break;
+    case PA_QF_HCURLHDIV_ERROR_33: kind = 2, qdims = 33; break;
+    case PA_QF_HCURLHDIV_ERROR_22: kind = 2, qdims = 22; break;
+    case PA_QF_HDIVHCURL_ERROR_33: kind = 3, qdims = 33; break;
+    case PA_QF_HDIVHCURL_ERROR_22: kind = 3, qdims = 22; break;
+    case PA_QF_HCURL_33: kind = 4, qdims = 33; break;
+    case PA_QF_HCURL_22: kind = 4, qdims = 22; break;
+    case PA_QF_HCURL_32: kind = 4, qdims = 32; break;
+    case PA_QF_HCURL_31: kind = 4, qdims = 31; break;
+    case PA_QF_HCURL_21: kind = 4, qdims = 21; break;
     case PA_QF_H1_1: kind = 5; break;
     case PA_QF_L2H1_ERROR: kind = 6; break;
     default: throw Error("not a mixed-space QFunction");
   }
-  const bool is22 = qf == PA_QF_HCURLHDIV_22 || qf == PA_QF_HDIVHCURL_22 || qf == PA_QF_HCURLHDIV_ERROR_22 ||
-                    qf == PA_QF_HDIVHCURL_ERROR_22 || qf == PA_QF_HCURL_22;
   const bool scalar = kind >= 5;  // dimension-independent: reads w detJ only
-  PA_REQUIRE(scalar || is22 == (dim == 2), "QFunction does not match the dimension of the geometry data");
+  PA_REQUIRE(scalar ? dim == sdim : qdims == dims, "QFunction does not match the dimension of the geometry data");
   const bool err = kind == 2 || kind == 3 || kind == 6;
   // first space / second space by the Piola map the QFunction applies to each input: covariant (H(curl) values, H1
   // gradients) or contravariant (H(div) values)
@@ -336,9 +493,59 @@ MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_
     ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->kind = kind, ms->error = err;
     build_side(r1, b1, geom->Q, scalar ? 1 : dim, ms->s1);
     build_side(r2, b2, geom->Q, scalar ? 1 : dim, ms->s2);
-    parse_coeff(ctx, ctx_size, scalar ? 1 : dim, ms->c0, 0);
-    if (err) parse_coeff(ctx, ctx_size, scalar ? 1 : dim, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
+    parse_coeff(ctx, ctx_size, scalar ? 1 : sdim, ms->c0, 0);
+    if (err) parse_coeff(ctx, ctx_size, scalar ? 1 : sdim, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
     if (!err) ms->d_ye = dev_alloc<double>((size_t)ms->ne * ms->s2.P);
+  } catch (...) {
+    free_mixed_sub(ms);
+    throw;
+  }
+  return ms;
+}
+
+// GradientIntegrator (fem/integ/grad.cpp:16-72): trial = a scalar H1 space (Grad), test = a vector H1 space with space_dim
+// components (Interp); `r2` / `b2` describe ONE component of the test space (its scalar value table; offsets = the L-vector
+// index of component 0), component c of a dof lives comp_stride entries further (restriction.cpp:137-142: 1 for byVDIM, where
+// the offsets are already multiplied by the vector dimension, the number of dofs for byNODES); r2.lsize is the size of the whole
+// vector L-vector.
+MixedSub *make_mixed_gradient_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_dense_basis_desc &b1,
+                                  const pa_restriction_desc &r2, const pa_dense_basis_desc &b2, int comp_stride, int qf,
+                                  const void *ctx, size_t ctx_size) {
+  PA_REQUIRE(geom && geom->eb == kEBm && geom->dim >= 1 && geom->dim <= geom->sdim && geom->sdim <= 3,
+             "the gradient form needs geometry data from pa_geom_create_dense");
+  PA_REQUIRE(r1.num_elem == geom->ne && r2.num_elem == geom->ne, "restrictions do not match the mesh");
+  const int dim = geom->dim, sdim = geom->sdim, dims = 10 * sdim + dim;
+  const int want = dims == 33   ? PA_QF_HCURLH1D_33
+                   : dims == 22 ? PA_QF_HCURLH1D_22
+                   : dims == 32 ? PA_QF_HCURLH1D_32
+                   : dims == 31 ? PA_QF_HCURLH1D_31
+                                : PA_QF_HCURLH1D_21;
+  PA_REQUIRE(qf == want, "QFunction does not match the dimension of the geometry data");
+  PA_REQUIRE(b1.fe_type == PA_FE_H1 && b2.fe_type == PA_FE_H1 && b1.deriv && b2.interp,
+             "GradientIntegrator requires a scalar H1 trial space (gradient table) and an H1 test space (value table)!");
+  PA_REQUIRE(comp_stride >= 1 && !r2.orients && !r2.curl_orients, "bad component stride / oriented H1 restriction");
+  PA_REQUIRE(ctx && ctx_size >= 16 && ctx_size % 8 == 0, "bad coefficient context");
+  auto *ms = new MixedSub;
+  try {
+    ms->geom = geom;
+    geom->refcount++;
+    ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->kind = 7, ms->error = false;
+    build_side(r1, b1, geom->Q, dim, ms->s1);
+    build_side(r2, b2, geom->Q, 1, ms->s2);
+    // the E-vector block of an element is [sdim][P2]: its transpose map over the whole vector L-vector
+    const int P2 = ms->s2.P;
+    std::vector<int32_t> off((size_t)ms->ne * sdim * P2);
+    for (int e = 0; e < ms->ne; e++)
+      for (int c = 0; c < sdim; c++)
+        for (int i = 0; i < P2; i++) {
+          const int64_t v = (int64_t)r2.offsets[(size_t)e * P2 + i] + (int64_t)c * comp_stride;
+          PA_REQUIRE(v < r2.lsize, "component offset out of range (comp_stride and lsize of the vector space)");
+          off[((size_t)e * sdim + c) * P2 + i] = (int32_t)v;
+        }
+    build_transpose_map(off, nullptr, r2.lsize, ms->s2);
+    ms->s2.h_off = off;
+    parse_coeff(ctx, ctx_size, sdim, ms->c0, 0);
+    ms->d_ye = dev_alloc<double>((size_t)ms->ne * sdim * P2);
   } catch (...) {
     free_mixed_sub(ms);
     throw;
