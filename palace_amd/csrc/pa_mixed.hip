@@ -338,10 +338,11 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_embedded_kernel(const Mi
 
 // H(curl) and H(div) sides enter with their value tables (Interp), an H1 side with its gradient table (Grad): the covariant
 // map of H(curl) values is the map of gradients.
-void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, int nc, MixedSide &sd) {
+// `scalar`: the side enters a scalar QFunction (or is one component of a vector H1 space) with the values of a scalar space.
+void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, int nc, MixedSide &sd, bool scalar) {
   PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_HDIV || b.fe_type == PA_FE_H1, "unknown element type");
-  PA_REQUIRE(nc > 1 || b.fe_type == PA_FE_H1, "scalar QFunctions take scalar (PA_FE_H1 descriptor) elements");
-  const double *tab = (b.fe_type == PA_FE_H1 && nc > 1) ? b.deriv : b.interp;  // nc == 1: values of a scalar space
+  PA_REQUIRE(!scalar || (nc == 1 && b.fe_type == PA_FE_H1), "scalar QFunctions take scalar (PA_FE_H1 descriptor) elements");
+  const double *tab = (b.fe_type == PA_FE_H1 && !scalar) ? b.deriv : b.interp;  // (line elements: one component either way)
   PA_REQUIRE(b.num_dofs > 0 && b.num_qpts == Q && tab, "basis does not match the quadrature rule, or has no value / gradient table");
   PA_REQUIRE(r.elem_size == b.num_dofs && r.offsets && r.lsize > 0, "restriction does not match the basis");
   PA_REQUIRE(!(r.orients && r.curl_orients), "restriction is either oriented or curl-oriented");
@@ -491,8 +492,8 @@ MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_
     ms->geom = geom;
     geom->refcount++;
     ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->kind = kind, ms->error = err;
-    build_side(r1, b1, geom->Q, scalar ? 1 : dim, ms->s1);
-    build_side(r2, b2, geom->Q, scalar ? 1 : dim, ms->s2);
+    build_side(r1, b1, geom->Q, scalar ? 1 : dim, ms->s1, scalar);
+    build_side(r2, b2, geom->Q, scalar ? 1 : dim, ms->s2, scalar);
     parse_coeff(ctx, ctx_size, scalar ? 1 : sdim, ms->c0, 0);
     if (err) parse_coeff(ctx, ctx_size, scalar ? 1 : sdim, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
     if (!err) ms->d_ye = dev_alloc<double>((size_t)ms->ne * ms->s2.P);
@@ -530,8 +531,8 @@ MixedSub *make_mixed_gradient_sub(pa_geom *geom, const pa_restriction_desc &r1, 
     ms->geom = geom;
     geom->refcount++;
     ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->kind = 7, ms->error = false;
-    build_side(r1, b1, geom->Q, dim, ms->s1);
-    build_side(r2, b2, geom->Q, 1, ms->s2);
+    build_side(r1, b1, geom->Q, dim, ms->s1, false);
+    build_side(r2, b2, geom->Q, 1, ms->s2, true);
     // the E-vector block of an element is [sdim][P2]: its transpose map over the whole vector L-vector
     const int P2 = ms->s2.P;
     std::vector<int32_t> off((size_t)ms->ne * sdim * P2);
