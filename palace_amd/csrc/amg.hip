@@ -2,12 +2,55 @@
 #include "amg.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <exception>
 #include <numeric>
+#include <thread>
 
 #include "pa_internal.hpp"
 
 namespace palace::amg {
+
+namespace {
+// The set-up is row-parallel almost everywhere (sparse products, the power iteration's matrix-vector products).  Rows are dealt to
+// the threads in fixed blocks and every row is computed exactly as the serial code does, so the hierarchy does not depend on the
+// number of threads (PALACE_AMD_SETUP_THREADS; default: the hardware's, at most 16 -- each keeps a dense accumulator row).
+constexpr int kRowBlock = 2048;
+int setup_threads() {
+  static const int n = [] {
+    const char *e = std::getenv("PALACE_AMD_SETUP_THREADS");
+    int v = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(v, 16));
+  }();
+  return n;
+}
+// fn(thread, block, first row, last row + 1) for every block of kRowBlock rows, blocks handed out in order
+template <class F>
+void for_row_blocks(int nrows, F &&fn) {
+  const int nblocks = (nrows + kRowBlock - 1) / kRowBlock;
+  const int nt = std::min(setup_threads(), std::max(1, nblocks));
+  if (nt == 1) {
+    for (int b = 0; b < nblocks; b++) fn(0, b, b * kRowBlock, std::min(nrows, (b + 1) * kRowBlock));
+    return;
+  }
+  std::atomic<int> next{0};
+  std::vector<std::thread> pool;
+  std::exception_ptr err;
+  std::atomic<bool> failed{false};
+  for (int t = 0; t < nt; t++)
+    pool.emplace_back([&, t] {
+      try {
+        for (int b = next++; b < nblocks; b = next++) fn(t, b, b * kRowBlock, std::min(nrows, (b + 1) * kRowBlock));
+      } catch (...) {
+        if (!failed.exchange(true)) err = std::current_exception();
+      }
+    });
+  for (std::thread &th : pool) th.join();
+  if (failed) std::rethrow_exception(err);
+}
+}  // namespace
 
 HostCsr Transpose(const HostCsr &A) {
   HostCsr T;
@@ -30,24 +73,52 @@ HostCsr Multiply(const HostCsr &A, const HostCsr &B) {
   HostCsr C;
   C.nrows = A.nrows, C.ncols = B.ncols;
   C.rowptr.assign((size_t)C.nrows + 1, 0);
-  std::vector<double> acc((size_t)B.ncols, 0.0);
-  std::vector<int> mark((size_t)B.ncols, -1), cols;
-  for (int r = 0; r < A.nrows; r++) {
-    cols.clear();
-    for (int a = A.rowptr[r]; a < A.rowptr[r + 1]; a++) {
-      const int k = A.col[a];
-      const double v = A.val[a];
-      for (int b = B.rowptr[k]; b < B.rowptr[k + 1]; b++) {
-        const int c = B.col[b];
-        if (mark[c] != r) mark[c] = r, acc[c] = 0.0, cols.push_back(c);
-        acc[c] += v * B.val[b];
+  // row by row with a dense accumulator per thread (Gustavson); the rows of a block go to the block's own arrays, which are
+  // strung together afterwards
+  const int nblocks = (A.nrows + kRowBlock - 1) / kRowBlock;
+  struct Scratch {
+    std::vector<double> acc, val;  // dense accumulator row; the entries of this thread's blocks, one after the other
+    std::vector<int> mark, cols, col;
+  };
+  struct Piece {
+    int thread = 0;
+    size_t first = 0, count = 0;
+  };
+  std::vector<Scratch> scratch((size_t)setup_threads());
+  std::vector<Piece> piece((size_t)nblocks);
+  for_row_blocks(A.nrows, [&](int t, int blk, int r0, int r1) {
+    Scratch &w = scratch[(size_t)t];
+    if (w.mark.empty()) w.acc.assign((size_t)B.ncols, 0.0), w.mark.assign((size_t)B.ncols, -1);
+    const size_t start = w.col.size();
+    for (int r = r0; r < r1; r++) {
+      w.cols.clear();
+      for (int a = A.rowptr[r]; a < A.rowptr[r + 1]; a++) {
+        const int k = A.col[a];
+        const double v = A.val[a];
+        for (int b = B.rowptr[k]; b < B.rowptr[k + 1]; b++) {
+          const int c = B.col[b];
+          if (w.mark[c] != r) w.mark[c] = r, w.acc[c] = 0.0, w.cols.push_back(c);
+          w.acc[c] += v * B.val[b];
+        }
       }
+      std::sort(w.cols.begin(), w.cols.end());
+      for (int c : w.cols)
+        if (w.acc[c] != 0.0) w.col.push_back(c), w.val.push_back(w.acc[c]);
+      C.rowptr[r + 1] = (int)(w.col.size() - start);  // (within the block; made global below)
     }
-    std::sort(cols.begin(), cols.end());
-    for (int c : cols)
-      if (acc[c] != 0.0) C.col.push_back(c), C.val.push_back(acc[c]);
-    C.rowptr[r + 1] = (int)C.col.size();
-  }
+    piece[(size_t)blk] = Piece{t, start, w.col.size() - start};
+  });
+  std::vector<long long> first((size_t)nblocks + 1, 0);
+  for (int b = 0; b < nblocks; b++) first[b + 1] = first[b] + (long long)piece[(size_t)b].count;
+  PA_REQUIRE(first[nblocks] < (1ll << 31), "sparse product too large (int32 CSR)");
+  C.col.resize((size_t)first[nblocks]), C.val.resize((size_t)first[nblocks]);
+  for_row_blocks(A.nrows, [&](int, int blk, int r0, int r1) {
+    const Piece &p = piece[(size_t)blk];
+    const Scratch &w = scratch[(size_t)p.thread];
+    std::copy(w.col.begin() + (long)p.first, w.col.begin() + (long)(p.first + p.count), C.col.begin() + first[blk]);
+    std::copy(w.val.begin() + (long)p.first, w.val.begin() + (long)(p.first + p.count), C.val.begin() + first[blk]);
+    for (int r = r0; r < r1; r++) C.rowptr[r + 1] += (int)first[blk];
+  });
   return C;
 }
 
@@ -91,17 +162,19 @@ double filtered_radius(const HostCsr &A, double theta) {
     nrm = std::sqrt(nrm);
     if (nrm == 0.0) break;
     for (int i = 0; i < n; i++) u[i] /= nrm;
-    for (int i = 0; i < n; i++) {
-      double s = 0.0;
-      for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
-        const int j = A.col[a];
-        if (j == i)
-          s += dF[i] * u[i];
-        else if (strong(A.val[a], d[i], d[j], theta))
-          s += A.val[a] * u[j];
+    for_row_blocks(n, [&](int, int, int i0, int i1) {
+      for (int i = i0; i < i1; i++) {
+        double s = 0.0;
+        for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
+          const int j = A.col[a];
+          if (j == i)
+            s += dF[i] * u[i];
+          else if (strong(A.val[a], d[i], d[j], theta))
+            s += A.val[a] * u[j];
+        }
+        v[i] = s / dF[i];
       }
-      v[i] = s / dF[i];
-    }
+    });
     double r = 0.0;
     for (int i = 0; i < n; i++) r += v[i] * v[i];
     rho = std::sqrt(r);

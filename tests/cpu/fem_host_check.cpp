@@ -191,5 +191,19 @@ int main() {
       dump(cas == 0 ? "amg_factors_iso" : "amg_factors_aniso", fac);
     }
   }
+  {  // the set-up is row-parallel (PALACE_AMD_SETUP_THREADS): a problem with many row blocks, every matrix of its hierarchy
+     // summed with position-dependent weights -- the test runs this program with one and with several threads and compares
+    using namespace palace::amg;
+    const Hierarchy h = Setup(grid_laplacian(160, 1.0, 0.3), 10, 60);
+    double cs = 0.0;
+    long long nnz = 0;
+    for (const std::vector<HostCsr> *v : {&h.A, &h.P})
+      for (const HostCsr &M : *v) {
+        nnz += M.nnz();
+        for (int r = 0; r < M.nrows; r++)
+          for (int a = M.rowptr[r]; a < M.rowptr[r + 1]; a++) cs += M.val[a] * (1.0 + 1e-3 * ((r + 3 * M.col[a]) % 101));
+      }
+    std::printf("amg_threads_checksum %.17g %lld %d\n", cs, nnz, (int)h.A.size());
+  }
   return 0;
 }

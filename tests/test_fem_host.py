@@ -26,11 +26,16 @@ def dumped(tmp_path_factory):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
                            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpu", "fem_host_check.cpp"),
                            "-L" + lib, "-lpalace_amd", "-Wl,-rpath," + lib, "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True)
+    out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, PALACE_AMD_SETUP_THREADS="1"))
     assert out.returncode == 0, out.stdout + out.stderr
+    # the host set-up of the coarse hierarchies is row-parallel: whatever the number of threads, every printed value is the same
+    out4 = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, PALACE_AMD_SETUP_THREADS="4"))
+    assert out4.returncode == 0 and out4.stdout == out.stdout and "amg_threads_checksum" in out.stdout
     vals = {}
     for line in out.stdout.splitlines():
         k, *v = line.split()
+        if k == "amg_threads_checksum":  # (compared as text above)
+            continue
         if k.startswith("orders") or k.startswith("amg_levels") or k in ("q1d", "mat_dims", "amg_small"):
             vals[k] = [int(t) for t in v]
         else:
