@@ -28,7 +28,7 @@ def problem(p=2, n=3, curved=0):
     nd, sp, h1 = tet.NDTetSpace(m, p), rt.RTTetSpace(m, p), tet.H1TetSpace(m, p)
     pts, wts = tet.tet_quadrature(p + 1)
     nint, ncurl = nd.elem.tables(pts)
-    rint, _ = sp.elem.tables(pts)
+    rint, rdiv = sp.elem.tables(pts)
     hint, hgrad = h1.elem.tables(pts)
     eps = [np.array([[2.0, 0.3, 0.0], [0.3, 1.5, 0.1], [0.0, 0.1, 1.2]]), np.diag([1.0, 1.0, 1.0]) * 3.1]
     muinv = [np.diag([0.8, 1.1, 0.9]), np.array([[1.4, -0.2, 0.1], [-0.2, 1.0, 0.0], [0.1, 0.0, 0.7]])]
@@ -36,7 +36,7 @@ def problem(p=2, n=3, curved=0):
     E, B = rng.uniform(-1, 1, nd.ndofs), rng.uniform(-1, 1, sp.ndofs)
     phi = rng.uniform(-1, 1, h1.ndofs)
     return dict(mesh=m, nd=nd, rt=sp, pts=pts, wts=wts, nint=nint, ncurl=ncurl, rint=rint, eps=eps, muinv=muinv, E=E, B=B,
-                h1=h1, hint=hint, hgrad=hgrad, phi=phi)
+                h1=h1, hint=hint, hgrad=hgrad, phi=phi, rdiv=rdiv)
 
 
 def main(path, p=2, n=3, curved=0):
@@ -56,7 +56,9 @@ def main(path, p=2, n=3, curved=0):
               P["E"], P["B"],
               # the H1 space of the same order and a potential: MixedVectorGradientIntegrator (eps grad phi, v) into ND and RT
               np.array([P["h1"].ndofs, P["h1"].P], dtype=np.int32), P["h1"].offsets.astype(np.int32),
-              np.asarray(P["hint"], np.float64), np.asarray(P["hgrad"], np.float64), P["phi"]]
+              np.asarray(P["hint"], np.float64), np.asarray(P["hgrad"], np.float64), P["phi"],
+              # the divergence table of the RT space: DivDivMassIntegrator (muinv B, v) + (c div B, div v) through BilinearForm(rt)
+              np.asarray(P["rdiv"], np.float64)]
     with open(path, "wb") as f:
         f.write(np.array([len(arrays)], dtype=np.int64).tobytes())
         for a in arrays:

@@ -103,6 +103,29 @@ int main(int argc, char **argv) {
           .write(reinterpret_cast<const char *>(g.data()), sizeof(double) * g.size());
       std::printf("mixed gradient: h1 %d\n", h1_size);
     }
+    if (blobs.size() >= 24) {
+      // DivDivMassIntegrator (fem/integ/divdivmass.cpp) on the Raviart-Thomas space with its divergence table: (c div u, div v)
+      // + (muinv u, v) in one operator, and the same as the sum of DivDivIntegrator and VectorFEMassIntegrator
+      FiniteElementSpace rtd(ctx, mesh, PA_FE_HDIV, p, rt_P, rt_size, i32(11), reinterpret_cast<const uint8_t *>(blobs[12].data()),
+                             nullptr, f64(13), f64(23));
+      const MaterialTensors cdiv{{0, 1}, {1.9, 0.4}, 1};
+      const auto q_div = cdiv.Coefficient(), q_mass = muinv.Coefficient();
+      BilinearForm pair(rtd), sum(rtd);
+      pair.AddDomainIntegrator<DivDivMassIntegrator>(q_div, q_mass);
+      sum.AddDomainIntegrator<DivDivIntegrator>(q_div);
+      sum.AddDomainIntegrator<VectorFEMassIntegrator>(q_mass);
+      const auto op_pair = pair.PartialAssemble(), op_sum = sum.PartialAssemble();
+      Vector y1(rt_size), y2(rt_size);
+      op_pair->Mult(B, y1);
+      op_sum->Mult(B, y2);
+      hipStreamSynchronize(stream);
+      std::vector<double> yy((size_t)2 * rt_size);
+      hipMemcpy(yy.data(), y1.Data(), sizeof(double) * rt_size, hipMemcpyDeviceToHost);
+      hipMemcpy(yy.data() + rt_size, y2.Data(), sizeof(double) * rt_size, hipMemcpyDeviceToHost);
+      std::ofstream(std::string(argv[2]) + ".divdivmass", std::ios::binary)
+          .write(reinterpret_cast<const char *>(yy.data()), sizeof(double) * yy.size());
+      std::printf("div-div + mass: rt %d\n", rt_size);
+    }
     std::printf("OK\n");
   } catch (const std::exception &e) {
     std::fprintf(stderr, "error: %s\n", e.what());

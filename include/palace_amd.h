@@ -301,7 +301,8 @@ int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_des
  * Interp).  `test_restr` / `test_basis` describe ONE component of the test space -- the scalar value table, offsets = L-vector
  * index of component 0 (already multiplied by the vector dimension for byVDIM ordering, restriction.cpp:137-142) --, component c
  * of a dof lives `comp_stride` entries further (the libCEED comp_stride: 1 for byVDIM, the number of dofs for byNODES), and
- * test_restr->lsize is the size of the whole vector L-vector (= the operator's height).  No transposed, diagonal or assembled form. */
+ * test_restr->lsize is the size of the whole vector L-vector (= the operator's height).  pa_op_full_assemble gives the rectangular
+ * matrix (rows = the dofs of the vector space); no transposed apply, no diagonal. */
 int pa_op_add_sub_dense_gradient(pa_op *op, pa_geom *geom, const pa_restriction_desc *trial_restr,
                                  const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
                                  const pa_dense_basis_desc *test_basis, int32_t comp_stride, int32_t qfunction, const void *ctx,

@@ -65,7 +65,9 @@ void assemble_two_space(pa_op *op, bool skip_zeros, hipStream_t s, pa_csr **out)
   const int nr = op->height, nc = op->width;
   std::vector<int64_t> cnt((size_t)nr + 1, 0);
   for (const MixedSub *ms : op->msubs) {
-    PA_REQUIRE(!ms->error && (int)ms->s1.h_off.size() == ms->ne * ms->s1.P && (int)ms->s2.h_off.size() == ms->ne * ms->s2.P,
+    // (the gradient form has space_dim rows of test dofs per element: h_off of its test side lists them all)
+    PA_REQUIRE(!ms->error && ms->ne > 0 && (int)ms->s1.h_off.size() == ms->ne * ms->s1.P && !ms->s2.h_off.empty() &&
+                   ms->s2.h_off.size() % ((size_t)ms->ne * ms->s2.P) == 0,
                "sub-operator has no assembled form");
     for (int32_t r : ms->s2.h_off) cnt[(size_t)r + 1] += ms->s1.P;
   }
@@ -76,8 +78,9 @@ void assemble_two_space(pa_op *op, bool skip_zeros, hipStream_t s, pa_csr **out)
     std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
     for (const MixedSub *ms : op->msubs)
       for (int e = 0; e < ms->ne; e++) {
-        const int32_t *re = &ms->s2.h_off[(size_t)e * ms->s2.P], *ce = &ms->s1.h_off[(size_t)e * ms->s1.P];
-        for (int i = 0; i < ms->s2.P; i++) {
+        const int rows_e = (int)(ms->s2.h_off.size() / (size_t)ms->ne);
+        const int32_t *re = &ms->s2.h_off[(size_t)e * rows_e], *ce = &ms->s1.h_off[(size_t)e * ms->s1.P];
+        for (int i = 0; i < rows_e; i++) {
           int64_t &f = fill[re[i]];
           for (int j = 0; j < ms->s1.P; j++) cols[(size_t)f++] = ce[j];
         }

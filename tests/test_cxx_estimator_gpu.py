@@ -105,6 +105,15 @@ def test_cxx_flux_error_estimators(exe, curved):
     norms = [float(l.split()[2]) for l in r.stdout.splitlines() if "norm" in l]
     for n, e in zip(norms, ref):
         assert abs(n - np.linalg.norm(e)) < 1e-8 * np.linalg.norm(e)
+    # DivDivMassIntegrator through the C++ front end (BilinearForm(rt), f_apply_l2mass_33) vs the oracle, and vs the sum of
+    # DivDivIntegrator + VectorFEMassIntegrator assembled next to it
+    yy = np.fromfile(out + ".divdivmass", dtype=np.float64).reshape(2, sp.ndofs)
+    c_mass = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=list(P["muinv"]))
+    c_div = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([1.9]), np.array([0.4])], dim=1)
+    ref_p = po.CeedOperatorOracle(sp.ndofs, sp.offsets, sp.orients, P["rint"], P["rdiv"], og, po.QF_L2MASS, c_mass, c_div,
+                                  qw=P["wts"], deriv_comps=1).apply_add(P["B"], np.zeros(sp.ndofs))
+    assert np.abs(yy[0] - ref_p).max() < 1e-12 * np.abs(ref_p).max()
+    assert np.abs(yy[1] - ref_p).max() < 1e-12 * np.abs(ref_p).max()
 
 
 def test_cxx_plane_flux_error_estimators(exe2d):

@@ -278,3 +278,6 @@ def test_divdiv_mass_and_gradient_on_tetrahedra(kind, p):
     xx = rng.uniform(-1, 1, nh)
     ref = po.MixedSpaceOracle(h1o, h1o, ogeom, po.QF_HCURLH1D, c_ns, first_tab=hgrad).gradient_add(xx, np.zeros(3 * nh), nh)
     assert np.abs(_mult(op, xx, 3 * nh) - ref).max() < REL * np.abs(ref).max()
+    # ... and its assembled form (pa_op_full_assemble: rectangular CSR, rows = the dofs of the vector test space)
+    A = op.full_assemble(skip_zeros=True)
+    assert A.shape == (3 * nh, nh) and np.abs(A @ xx - ref).max() < REL * np.abs(ref).max()
