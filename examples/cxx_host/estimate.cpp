@@ -102,6 +102,19 @@ int main(int argc, char **argv) {
       std::ofstream(std::string(argv[2]) + ".grad", std::ios::binary)
           .write(reinterpret_cast<const char *>(g.data()), sizeof(double) * g.size());
       std::printf("mixed gradient: h1 %d\n", h1_size);
+      // GradientIntegrator (fem/integ/grad.cpp): (eps grad phi, v) with v in (H1)^3, both orderings of the vector space
+      const GradientIntegrator gi(eps_c);
+      std::vector<double> gv((size_t)6 * h1_size);
+      for (int by_vdim = 0; by_vdim < 2; by_vdim++) {
+        const VectorFiniteElementSpace vh1(h1, 3, by_vdim != 0);
+        const auto op_g = gi.PartialAssemble(h1, vh1);
+        Vector gy(vh1.GetVSize());
+        op_g->Mult(phi, gy);
+        hipStreamSynchronize(stream);
+        hipMemcpy(gv.data() + (size_t)by_vdim * 3 * h1_size, gy.Data(), sizeof(double) * 3 * h1_size, hipMemcpyDeviceToHost);
+      }
+      std::ofstream(std::string(argv[2]) + ".vgrad", std::ios::binary)
+          .write(reinterpret_cast<const char *>(gv.data()), sizeof(double) * gv.size());
     }
     if (blobs.size() >= 24) {
       // DivDivMassIntegrator (fem/integ/divdivmass.cpp) on the Raviart-Thomas space with its divergence table: (c div u, div v)

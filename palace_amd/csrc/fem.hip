@@ -404,6 +404,19 @@ pa_restriction_desc FiniteElementSpace::GetCeedElemRestriction() const {
   return pa_restriction_desc{mesh_->GetNE(), elem_size_, vsize_, offsets_.data(), orients_.empty() ? nullptr : orients_.data(),
                              curl_orients_.empty() ? nullptr : curl_orients_.data()};
 }
+VectorFiniteElementSpace::VectorFiniteElementSpace(const FiniteElementSpace &scalar, int vdim, bool by_vdim)
+    : scalar_(&scalar), vdim_(vdim), by_vdim_(by_vdim) {
+  PA_REQUIRE(scalar.GetFEType() == PA_FE_H1 && vdim >= 1 && vdim <= 3, "vector spaces: 1-3 copies of an H1 space");
+  const pa_restriction_desc r = scalar.GetCeedElemRestriction();
+  offsets_.assign(r.offsets, r.offsets + (size_t)r.num_elem * r.elem_size);
+  if (by_vdim)
+    for (int32_t &o : offsets_) o *= vdim;
+}
+pa_restriction_desc VectorFiniteElementSpace::GetCeedElemRestriction() const {
+  pa_restriction_desc r = scalar_->GetCeedElemRestriction();
+  r.offsets = offsets_.data(), r.lsize = GetVSize();
+  return r;
+}
 pa_dense_basis_desc FiniteElementSpace::GetCeedDenseBasis() const {
   PA_REQUIRE(IsDense(), "the space has no dense tables");
   return pa_dense_basis_desc{fe_type_, elem_size_, mesh_->GetNumQuadraturePoints(), interp_.empty() ? nullptr : interp_.data(),
@@ -553,6 +566,34 @@ void MixedVectorGradientIntegrator::Assemble(pa_op *op, const FiniteElementSpace
                  : d == 21 ? (sc ? PA_QF_HCURL_21 : PA_QF_HCURLHDIV_21)
                            : (sc ? PA_QF_HCURL_31 : PA_QF_HCURLHDIV_31);
   AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_GRAD, PA_EVAL_INTERP);
+}
+void GradientIntegrator::Assemble(pa_op *, const FiniteElementSpace &, const FiniteElementSpace &) const {
+  throw pa::Error("GradientIntegrator requires trial space with a single component and test space with space_dim components! "
+                  "(Assemble(op, trial, VectorFiniteElementSpace))");
+}
+void GradientIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const VectorFiniteElementSpace &test) const {
+  const FiniteElementSpace &comp = test.GetScalarSpace();
+  const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
+  PA_REQUIRE(trial.GetFEType() == PA_FE_H1 && test.GetVDim() == sdim && trial.IsDense() && comp.IsDense() &&
+                 &trial.GetMesh() == &comp.GetMesh(),
+             "GradientIntegrator requires trial space with a single component and test space with space_dim components!");
+  PA_REQUIRE(d == 33 || d == 22 || d == 32 || d == 21 || d == 31, "Invalid value of (dim, space_dim) for GradientIntegrator!");
+  const int qf = d == 33 ? PA_QF_HCURLH1D_33
+                 : (d == 22 ? PA_QF_HCURLH1D_22 : (d == 32 ? PA_QF_HCURLH1D_32 : (d == 21 ? PA_QF_HCURLH1D_21 : PA_QF_HCURLH1D_31)));
+  const std::vector<double> ctx = ceed::PopulateCoefficientContext(sdim, Q, transpose);
+  const auto r1 = trial.GetCeedElemRestriction(), r2 = test.GetCeedElemRestriction();
+  const auto b1 = trial.GetCeedDenseBasis(), b2 = comp.GetCeedDenseBasis();
+  check(pa_op_add_sub_dense_gradient(op, trial.GetMesh().GetCeedGeomFactorData(), &r1, &b1, &r2, &b2, test.GetCompStride(), qf,
+                                     ctx.data(), ctx.size() * sizeof(double)));
+}
+std::unique_ptr<ceed::Operator> GradientIntegrator::PartialAssemble(const FiniteElementSpace &trial,
+                                                                    const VectorFiniteElementSpace &test) const {
+  pa_op *op = nullptr;
+  check(pa_op_create(test.GetVSize(), trial.GetVSize(), &op));
+  auto out = std::make_unique<ceed::Operator>(trial.GetContext(), op, /*own=*/true);
+  Assemble(op, trial, test);
+  check(pa_op_finalize(op));
+  return out;
 }
 void MixedVectorCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_HCURL,

@@ -176,6 +176,24 @@ public:
   const Operator &GetDiscreteInterpolator(const FiniteElementSpace &aux) const;
 };
 
+// vdim copies of a scalar space -- mfem::FiniteElementSpace(mesh, fec, vdim, ordering) as far as GradientIntegrator needs it: the
+// libCEED restriction of fem/libceed/restriction.cpp:137-142 (offsets of component 0, times vdim for Ordering::byVDIM, and the
+// component stride: 1 for byVDIM, the number of dofs for byNODES)
+class VectorFiniteElementSpace {
+  const FiniteElementSpace *scalar_;
+  int vdim_;
+  bool by_vdim_;
+  std::vector<int32_t> offsets_;
+
+public:
+  VectorFiniteElementSpace(const FiniteElementSpace &scalar, int vdim, bool by_vdim = false);
+  const FiniteElementSpace &GetScalarSpace() const { return *scalar_; }
+  int GetVDim() const { return vdim_; }
+  int GetVSize() const { return vdim_ * scalar_->GetVSize(); }
+  int GetCompStride() const { return by_vdim_ ? 1 : scalar_->GetVSize(); }
+  pa_restriction_desc GetCeedElemRestriction() const;  // one component; lsize = GetVSize()
+};
+
 class FiniteElementSpaceHierarchy {
   std::vector<std::unique_ptr<FiniteElementSpace>> fespaces_;
   mutable std::vector<std::unique_ptr<Operator>> P_;
@@ -229,6 +247,15 @@ PA_DECLARE_INTEGRATOR(MixedVectorGradientIntegrator);  // H1 x H(curl) | H(div),
 PA_DECLARE_INTEGRATOR(MixedVectorCurlIntegrator);      // H(curl) x H(curl), (Q curl u, v)   fem/integ/mixedveccurl.cpp:21-73
 PA_DECLARE_INTEGRATOR(MixedVectorWeakCurlIntegrator);  // H(curl) x H(curl), (Q u, curl v)   fem/integ/mixedveccurl.cpp:75-120
 #undef PA_DECLARE_INTEGRATOR
+// H1 x (H1)^d, (Q grad u, v): fem/integ/grad.cpp:16-72 (f_apply_hcurlh1d_*).  The test space has space_dim components, which
+// BilinearForm's scalar spaces do not describe: the operator is built directly, height = test.GetVSize(), width = trial.GetVSize()
+class GradientIntegrator : public BilinearFormIntegrator {
+public:
+  using BilinearFormIntegrator::BilinearFormIntegrator;
+  void Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const override;  // (throws: see below)
+  void Assemble(pa_op *op, const FiniteElementSpace &trial, const VectorFiniteElementSpace &test) const;
+  std::unique_ptr<ceed::Operator> PartialAssemble(const FiniteElementSpace &trial, const VectorFiniteElementSpace &test) const;
+};
 #define PA_DECLARE_INTEGRATOR2(Name)                                                                      \
   class Name : public BilinearFormIntegrator {                                                            \
     const MaterialPropertyCoefficient *Q_mass;                                                            \

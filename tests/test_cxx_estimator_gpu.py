@@ -105,6 +105,12 @@ def test_cxx_flux_error_estimators(exe, curved):
     norms = [float(l.split()[2]) for l in r.stdout.splitlines() if "norm" in l]
     for n, e in zip(norms, ref):
         assert abs(n - np.linalg.norm(e)) < 1e-8 * np.linalg.norm(e)
+    # GradientIntegrator through the C++ front end (VectorFiniteElementSpace, byNODES then byVDIM) vs the oracle
+    gv = np.fromfile(out + ".vgrad", dtype=np.float64).reshape(2, 3 * h1.ndofs)
+    ref_v = po.MixedSpaceOracle(h1o, h1o, og, po.QF_HCURLH1D, c_eps, first_tab=h1o.deriv).gradient_add(
+        P["phi"], np.zeros(3 * h1.ndofs), h1.ndofs)
+    assert np.abs(gv[0] - ref_v).max() < 1e-12 * np.abs(ref_v).max()
+    assert np.abs(gv[1] - ref_v.reshape(3, h1.ndofs).T.ravel()).max() < 1e-12 * np.abs(ref_v).max()
     # DivDivMassIntegrator through the C++ front end (BilinearForm(rt), f_apply_l2mass_33) vs the oracle, and vs the sum of
     # DivDivIntegrator + VectorFEMassIntegrator assembled next to it
     yy = np.fromfile(out + ".divdivmass", dtype=np.float64).reshape(2, sp.ndofs)
