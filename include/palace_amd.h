@@ -360,8 +360,8 @@ int pa_op_is_symmetric(const pa_op *op);
  * essential list fused into op_r (pa_op_set_essential), entries read as zero and rows set to 0 / x (the real ParOperator's
  * policy; the imaginary one is DIAG_ZERO, linalg/rap.cpp:450-457).
  * pa_op_complex_fused returns 2 for the dense-table form of the same idea (op_r: curl-curl + mass, op_i: mass / curl-curl / both
- * on the same H(curl) space of straight-sided elements -- tetrahedra; any symmetric materials): the 16 element columns of the
- * matrix-core products carry 8 elements x {real, imaginary} part; plain form only (ess_policy = -1). */
+ * on the same H(curl) space -- tetrahedra, all straight-sided or all curved; any symmetric materials): the 16 element columns of
+ * the matrix-core products carry 8 elements x {real, imaginary} part; plain form only (ess_policy = -1). */
 int pa_op_complex_fused(const pa_op *op_r, const pa_op *op_i);
 int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double *xi, double *yr, double *yi, int ess_policy,
                        void *stream);

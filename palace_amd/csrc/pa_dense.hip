@@ -444,7 +444,8 @@ template <int PT, int MODE, int F>
 __device__ __forceinline__ void resident_field(const double *__restrict__ Lf, const double *__restrict__ Lb, const int,
                                                const double (&u)[4 * PT], const double (*qd)[6],
                                                double4_t (&yacc)[PT], const double *__restrict__ wrel = nullptr,
-                                               const double *qdi = nullptr, const double sg = 0.0) {
+                                               const double *qdi = nullptr, const double sg = 0.0,
+                                               const double (*qdi4)[6] = nullptr) {
   using FT = FieldTraits<MODE, F>;
   constexpr int NC = FT::NC, KPMAX = 4 * PT, S = ResidentStride<PT>::S, KP = KPMAX;
   double4_t acc[NC];
@@ -478,6 +479,14 @@ __device__ __forceinline__ void resident_field(const double *__restrict__ Lf, co
       const double w = wrel[4 * gl];
 #pragma unroll
       for (int k = 0; k < NC; k++) v[k] *= w;
+    } else if (qdi4) {  // complex form on curved elements: the D of both operators at every point group
+      double vp[NC];
+#pragma unroll
+      for (int k = 0; k < NC; k++) vp[k] = __shfl_xor(v[k], 8, 64);
+      dense_D_packed<MODE, F>(qd[gl], v);
+      dense_D_packed<MODE, F>(qdi4[gl], vp);
+#pragma unroll
+      for (int k = 0; k < NC; k++) v[k] += sg * vp[k];
     } else {
       dense_D_packed<MODE, F>(qd[gl], v);
     }
@@ -502,13 +511,24 @@ __device__ __forceinline__ void load_qd(const double *__restrict__ q, const size
     for (int k = 0; k < NQ; k++) qd[gl][k] = (gl < ng) ? q[k * cs + gl * 64] : 0.0;
 }
 
+// six rows (one symmetric 3 x 3 D) of the imaginary operator's q-data for the 4 point groups of a chunk; row0 < 0: that operator
+// has no such term
+__device__ __forceinline__ void load_qd6(const double *__restrict__ q, const int row0, const size_t cs, const int ng,
+                                         double (&qd)[4][6]) {
+#pragma unroll
+  for (int gl = 0; gl < 4; gl++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) qd[gl][k] = (row0 >= 0 && gl < ng) ? q[(size_t)(row0 + k) * cs + gl * 64] : 0.0;
+}
+
 // AFFINE: every block consists of elements with a constant Jacobian (dense_affine_kernel): the D of a point is the D of point 0
 // times the relative quadrature weight -- 6 values per field and element instead of 6 Q, and no q-data registers to rotate.
 constexpr int kAffWaves = 12;  // the affine form needs fewer registers: three waves per SIMD
-// CPLX (affine curl-curl + mass blocks): y = (A_r + i A_i) x for two operators on the same space and geometry.  A work unit is half
+// CPLX (curl-curl + mass blocks, all affine or all curved): y = (A_r + i A_i) x for two operators on the same space and geometry.  A work unit is half
 // an element block: the 16 element columns of the matrix-core products carry 8 elements x {real, imaginary} part of x; both
 // parts read the element's index words and the D of both operators (one HBM read), the tables in LDS serve both as before,
-// and the D stage combines the two parts across the columns of an element.  One pass instead of four.
+// and the D stage combines the two parts across the columns of an element.  One pass instead of four.  (Curved blocks: the D of
+// the imaginary operator is read chunk by chunk right before its use -- no registers left to prefetch it.)
 // LIST: the launch works on the element blocks listed in a.blist (meshes with affine and curved parts); a separate instantiation so
 // that the common single-kind launches carry no list look-up in their prefetch address chains (measured: 0.182 -> 0.211 ms with it)
 // SPLIT: split-vector input (multi-rank applies without L-vector copies); its own instantiation, because a per-lane choice of the
@@ -517,7 +537,7 @@ template <int PT, int MODE, bool AFFINE, bool CPLX = false, bool LIST = false, b
 __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1) void dense_apply_resident_kernel(const DenseArgs a, const int rows) {
   static_assert(!(CPLX && LIST), "the complex form runs on whole operators");
   static_assert(!SPLIT || (!CPLX && !LIST), "split vectors: whole real operators");
-  static_assert(!CPLX || (AFFINE && MODE == MODE_CURLMASS && PT <= 3), "complex form: affine curl-curl + mass blocks");
+  static_assert(!CPLX || (MODE == MODE_CURLMASS && PT <= 3), "complex form: curl-curl + mass blocks");
   constexpr int NW = (AFFINE && !CPLX) ? kAffWaves : kResWaves;
   using M = ModeTraits<MODE>;
   using F0 = FieldTraits<MODE, 0>;
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
         }
       }
     } else {
-      load_qd<MODE, 0>(qb + lane, cs, ngroups, out);
+      load_qd<MODE, 0>(qb + ulane(w), cs, ngroups, out);
     }
   };
   auto gather_x = [&](const int (&sg_)[PREFETCH_IDX ? KPMAX : 1], double (&out)[PREFETCH_X ? KPMAX : 1]) {
@@ -640,8 +660,9 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
 #ifdef PA_ABLATION
     const double *q = a.qdata + ((a.dbg & 2) ? (size_t)0 : bb * a.ncq * cs) + lane;
 #else
-    const double *q = a.qdata + bb * a.ncq * cs + lane;
+    const double *q = a.qdata + bb * a.ncq * cs + gln;
 #endif
+    [[maybe_unused]] const double *qim = (CPLX && !AFFINE) ? a.qdata_i + bb * a.ncq_i * cs + gln : nullptr;
     double qd[4][6];
     if (AFFINE) {  // qdn[0], qdn[1]: point-0 values of the two fields, kept until the next request
       if (!PREFETCH_X) request_qd(b, qdn);
@@ -728,6 +749,15 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
 #pragma unroll
             for (int k = 0; k < NQ0; k++) qd[gl][k] = qn[gl][k];
         }
+      } else if (CPLX) {  // curved blocks, complex form
+        double qn[4][6], qi[4][6];
+        load_qd6(qim + 16 * c * kEB, a.qi_mass, cs, ngroups - 4 * c, qi);
+        load_qd<MODE, 1>(q + NQ0 * cs + 16 * c * kEB, cs, ngroups - 4 * c, qn);
+        resident_field<PT, MODE, 0>(Lf + r0 * S, Lb + r0 * S, KP, u, qd, yacc, nullptr, nullptr, part_sign, qi);
+        load_qd6(qim + 16 * c * kEB, a.qi_curl, cs, ngroups - 4 * c, qi);
+        if (c + 1 < a.nch) load_qd<MODE, 0>(q + 16 * (c + 1) * kEB, cs, ngroups - 4 * (c + 1), qd);
+        resident_field<PT, MODE, 1>(Lf + (r0 + 16 * F0::NC) * S, Lb + (r0 + 16 * F0::NC) * S, KP, u, qn, yacc, nullptr, nullptr,
+                                    part_sign, qi);
       } else {
         double qn[4][6];
         load_qd<MODE, 1>(q + NQ0 * cs + 16 * c * kEB, cs, ngroups - 4 * c, qn);
@@ -1814,13 +1844,15 @@ void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStr
 }
 
 // ---- complex form (SURVEY.md 8(f)-1 on the non-tensor path) ---------------------------------------------------------------
-// dr: curl-curl + mass in the affine resident form (the kernel's tables, index arrays, E-vector); di: mass, curl-curl or both on
-// the same space and geometry, also affine (only the D of its first point is read)
+// dr: curl-curl + mass in the resident form (the kernel's tables, index arrays, E-vector); di: mass, curl-curl or both on the same
+// space and geometry; both affine (only the D of the first point of di is read) or both curved (round 4: its D at every point)
 bool dense_complex_ok(const DenseSub &dr, const DenseSub &di) {
   static const bool enabled = !(getenv("PALACE_AMD_COMPLEX_FUSED") && atoi(getenv("PALACE_AMD_COMPLEX_FUSED")) == 0);
   if (!enabled || dr.fe_type != PA_FE_HCURL || di.fe_type != PA_FE_HCURL || dr.geom != di.geom || dr.geom->dim != 3) return false;
-  if (dr.mode != MODE_CURLMASS || !dr.d_L || !dr.d_affine || dr.d_blist[0] || dr.PT > 3) return false;
-  if (!(di.mode == MODE_CURLMASS || di.mode == MODE_VMASS || di.mode == MODE_CURL) || !di.d_qdata || !di.d_affine || di.d_blist[0]) return false;
+  // (all blocks affine, or none: a mesh with both kinds keeps the four real applies)
+  if (dr.mode != MODE_CURLMASS || !dr.d_L || dr.d_blist[0] || dr.PT > 3) return false;
+  if (!(di.mode == MODE_CURLMASS || di.mode == MODE_VMASS || di.mode == MODE_CURL) || !di.d_qdata || di.d_blist[0]) return false;
+  if ((dr.d_affine != nullptr) != (di.d_affine != nullptr)) return false;
   if (dr.ne != di.ne || dr.P != di.P || dr.Q != di.Q || dr.lsize != di.lsize) return false;
   if (di.mode != MODE_CURL && di.chk_interp != dr.chk_interp) return false;
   if (di.mode != MODE_VMASS && di.chk_deriv != dr.chk_deriv) return false;
@@ -1838,9 +1870,14 @@ static void launch_resident_complex_pt(const DenseSub &dr, const DenseArgs &a, h
   if (!attr_set) {
     PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE_CURLMASS, false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);
+  if (a.affine)
+    hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);
+  else
+    hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, false, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);
 }
 
 void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s) {

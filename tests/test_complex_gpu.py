@@ -208,12 +208,13 @@ print("OK")
 '''
 
 
-@pytest.mark.parametrize("imode", ["mass", "curl", "both"])
-@pytest.mark.parametrize("p", [1, 2, 3])
-def test_fused_complex_apply_tets(p, imode, tmp_path):
-    """The dense-table form of the one-pass complex apply (straight-sided tetrahedra, anisotropic materials, curl-oriented
-    restriction for p >= 2): 8 elements x {real, imaginary} part in the 16 columns of the matrix-core products, against the
-    four separate applies; essential dofs go through ComplexParOperator's copy / mask / fix path around the fused local apply."""
+@pytest.mark.parametrize("p,imode,kind", [(p, m, "tet4") for p in (1, 2, 3) for m in ("mass", "curl", "both")] +
+                         [(1, "both", "tet10"), (2, "mass", "tet10"), (2, "curl", "tet10"), (2, "both", "tet10"), (3, "both", "tet10")])
+def test_fused_complex_apply_tets(p, imode, kind, tmp_path):
+    """The dense-table form of the one-pass complex apply (straight-sided tetrahedra: the D of one point per element; curved
+    ones, round 4: the D of both operators at every point; anisotropic materials, curl-oriented restriction for p >= 2):
+    8 elements x {real, imaginary} part in the 16 columns of the matrix-core products, against the four separate applies;
+    essential dofs go through ComplexParOperator's copy / mask / fix path around the fused local apply."""
     import os
     import subprocess
     import sys
@@ -222,7 +223,7 @@ def test_fused_complex_apply_tets(p, imode, tmp_path):
     res = {}
     for fused in (1, 0):
         f = str(tmp_path / f"out{fused}.npz")
-        r = subprocess.run([sys.executable, "-c", FUSED_TET_CHECK % root, str(p), "tet4", imode, f], capture_output=True,
+        r = subprocess.run([sys.executable, "-c", FUSED_TET_CHECK % root, str(p), kind, imode, f], capture_output=True,
                            text=True, timeout=300, env=dict(os.environ, PALACE_AMD_COMPLEX_FUSED=str(fused)))
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
         res[fused] = np.load(f)
@@ -230,19 +231,6 @@ def test_fused_complex_apply_tets(p, imode, tmp_path):
     for k in ("plain_r", "plain_i", "ess_r", "ess_i"):
         a, b = res[1][k], res[0][k]
         assert np.abs(a - b).max() < 1e-13 * np.abs(b).max(), k
-
-
-def test_fused_complex_apply_not_for_curved_tets(tmp_path):
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    f = str(tmp_path / "out.npz")
-    r = subprocess.run([sys.executable, "-c", FUSED_TET_CHECK % root, "2", "tet10", "mass", f], capture_output=True, text=True,
-                       timeout=300)
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
-    assert int(np.load(f)["fused"]) == 0
 
 
 def test_complex_pcg_on_a_hermitian_positive_definite_system(cylinder_mesh):
