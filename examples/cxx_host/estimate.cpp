@@ -115,6 +115,24 @@ int main(int argc, char **argv) {
       }
       std::ofstream(std::string(argv[2]) + ".vgrad", std::ios::binary)
           .write(reinterpret_cast<const char *>(gv.data()), sizeof(double) * gv.size());
+      // MixedVectorWeakDivergenceIntegrator -(eps E, grad v) into H1, and MassIntegrator on (H1)^3 with the 3 x 3 tensor eps
+      BilinearForm wd(nd, h1);
+      wd.AddDomainIntegrator<MixedVectorWeakDivergenceIntegrator>(eps_c);
+      Vector wy(h1_size);
+      wd.PartialAssemble()->Mult(E, wy);
+      const VectorFiniteElementSpace vh(h1, 3, false);
+      const VectorMassIntegrator vm(eps_c);
+      Vector vx(3 * h1_size), vy(3 * h1_size);
+      hipMemset(vx.Data(), 0, sizeof(double) * 3 * h1_size);
+      for (int c = 0; c < 3; c++)  // (phi, 2 phi, 3 phi) as the vector field
+        linalg::AXPBY(ctx, c + 1.0, phi, 0.0, *std::make_unique<Vector>(vx.Data() + (size_t)c * h1_size, h1_size));
+      vm.PartialAssemble(vh)->Mult(vx, vy);
+      hipStreamSynchronize(stream);
+      std::vector<double> wv((size_t)4 * h1_size);
+      hipMemcpy(wv.data(), wy.Data(), sizeof(double) * h1_size, hipMemcpyDeviceToHost);
+      hipMemcpy(wv.data() + h1_size, vy.Data(), sizeof(double) * 3 * h1_size, hipMemcpyDeviceToHost);
+      std::ofstream(std::string(argv[2]) + ".wdiv", std::ios::binary)
+          .write(reinterpret_cast<const char *>(wv.data()), sizeof(double) * wv.size());
     }
     if (blobs.size() >= 24) {
       // DivDivMassIntegrator (fem/integ/divdivmass.cpp) on the Raviart-Thomas space with its divergence table: (c div u, div v)

@@ -307,6 +307,13 @@ int pa_op_add_sub_dense_gradient(pa_op *op, pa_geom *geom, const pa_restriction_
                                  const pa_dense_basis_desc *trial_basis, const pa_restriction_desc *test_restr,
                                  const pa_dense_basis_desc *test_basis, int32_t comp_stride, int32_t qfunction, const void *ctx,
                                  size_t ctx_size);
+/* MassIntegrator on a vector-valued H1 space (fem/integ/mass.cpp:35-48: f_apply_h1_2 | _3, fem/qfunctions/{2,3}/h1_*_qf.h;
+ * num_comp x num_comp coefficient): `restr` / `basis` describe ONE component as in pa_op_add_sub_dense_gradient (offsets of component
+ * 0, comp_stride to the next, restr->lsize = the whole vector = the operator's height and width).  Built from the scalar mass
+ * between two scalar spaces (PA_QF_H1_1), one term per non-zero entry of the coefficient: apply, transpose and full assembly; no
+ * diagonal.  Volume / plane elements.  (No driver of the reference uses more than one component.) */
+int pa_op_add_sub_dense_vector_mass(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr, const pa_dense_basis_desc *basis,
+                                    int32_t num_comp, int32_t comp_stride, const void *ctx, size_t ctx_size);
 /* AssembleCeedElementErrorIntegrator (fem/libceed/integrator.cpp:550-626) as the flux error estimators use it
  * (linalg/errorestimator.cpp:345-349, :485-489): estimates[e] += int_e |C_2 u_2 - C_1 u_1|^2 for L-vectors u_1, u_2 of two spaces
  * on the elements of `geom`; `ctx` is the pair context PopulateCoefficientContext(dim, first, dim, second) packs.  One value per

@@ -684,6 +684,25 @@ def apply_l2mass(ctx_mass, ctx_div, geom, qw, u, divu):
     return mass(ctx_mass, geom, u), apply_l2_1(ctx_div, geom, qw, divu)
 
 
+def apply_h1_vec(ctx, geom, u):
+    """h1_2_qf.h / h1_3_qf.h:10-33 (f_apply_h1_2 | _3): v = w detJ C u for the N = 2 | 3 components of a vector-valued scalar
+    space, C an N x N coefficient (MassIntegrator with num_comp components, integ/mass.cpp:35-48); any geometry data."""
+    n = u.shape[1]
+    attr = geom[:, 0, :].astype(np.int32)
+    C = _unpack2(ctx, attr) if n == 2 else ctx.unpack3(attr)
+    return np.stack([geom[:, 1, :] * sum(C[..., i + n * j] * u[:, j, :] for j in range(n)) for i in range(n)], axis=1)
+
+
+def apply_l2_vec(ctx, geom, qw, u):
+    """l2_2_qf.h / l2_3_qf.h:10-34 (f_apply_l2_2 | _3): v = (qw^2 / w detJ) C u, the same with the weight of the scalar-derivative
+    forms (DivDivIntegrator with num_comp components, integ/divdiv.cpp:36-47; no element of the hot path has such a divergence)."""
+    n = u.shape[1]
+    attr = geom[:, 0, :].astype(np.int32)
+    C = _unpack2(ctx, attr) if n == 2 else ctx.unpack3(attr)
+    w = qw[None, :] ** 2 / geom[:, 1, :]
+    return np.stack([w * sum(C[..., i + n * j] * u[:, j, :] for j in range(n)) for i in range(n)], axis=1)
+
+
 def apply_hcurlh1d(ctx, geom, u):
     """hcurlh1d_{22,33,21,31,32}_qf.h (f_apply_hcurlh1d_*): v = w detJ C (adjJt u) -- reference gradient (dim components) in,
     space_dim physical components out (MultBAx*): GradientIntegrator, integ/grad.cpp:16-72 (trial Grad, test Interp on a

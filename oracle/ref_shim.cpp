@@ -52,3 +52,8 @@ typedef double CeedScalar;
 #include "fem/qfunctions/32/hcurlh1d_32_qf.h"
 #include "fem/qfunctions/31/hcurlh1d_31_qf.h"
 #include "fem/qfunctions/21/hcurlh1d_21_qf.h"
+// vector-valued scalar spaces: MassIntegrator / DivDivIntegrator with 2 or 3 components (fem/integ/mass.cpp, divdiv.cpp)
+#include "fem/qfunctions/2/h1_2_qf.h"
+#include "fem/qfunctions/3/h1_3_qf.h"
+#include "fem/qfunctions/2/l2_2_qf.h"
+#include "fem/qfunctions/3/l2_3_qf.h"

@@ -329,6 +329,15 @@ class Operator:
                                                   C.c_int32(int(comp_stride)), C.c_int32(qf), _ptr(ctx), C.c_size_t(ctx.nbytes)))
         return self
 
+    def add_dense_vector_mass_integrator(self, geom: DenseGeomFactorData, comp: DenseBlock, num_comp, comp_stride, ctx_blob):
+        """MassIntegrator on a vector H1 space with 2 or 3 components (f_apply_h1_2 | _3, pa_op_add_sub_dense_vector_mass): `comp`
+        one component of the space (its lsize = the size of the whole vector L-vector)."""
+        r, b = comp.descs()
+        ctx = np.ascontiguousarray(ctx_blob)
+        _lib.check(_lib.load().pa_op_add_sub_dense_vector_mass(self.handle, geom.handle, C.byref(r), C.byref(b), C.c_int32(int(num_comp)),
+                                                               C.c_int32(int(comp_stride)), _ptr(ctx), C.c_size_t(ctx.nbytes)))
+        return self
+
     @staticmethod
     def _sum_args(terms):
         qfs = (C.c_int32 * len(terms))(*[int(t[1]) for t in terms])

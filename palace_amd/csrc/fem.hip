@@ -567,6 +567,36 @@ void MixedVectorGradientIntegrator::Assemble(pa_op *op, const FiniteElementSpace
                            : (sc ? PA_QF_HCURL_31 : PA_QF_HCURLHDIV_31);
   AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q, transpose), PA_EVAL_GRAD, PA_EVAL_INTERP);
 }
+void MixedVectorWeakDivergenceIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
+  // mixedvecgrad.cpp:146-202: f_apply_hcurl_* of the geometry, trial Interp, test Grad, the coefficient scaled by -1
+  const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();
+  PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_H1,
+             "MixedVectorWeakDivergenceIntegrator: H(curl) trial space, H1 test space");
+  PA_REQUIRE(d == 33 || d == 22 || d == 32 || d == 21 || d == 31,
+             "Invalid value of (dim, space_dim) for MixedVectorWeakDivergenceIntegrator!");
+  const int qf = d == 33 ? PA_QF_HCURL_33 : (d == 22 ? PA_QF_HCURL_22 : (d == 32 ? PA_QF_HCURL_32 : (d == 21 ? PA_QF_HCURL_21 : PA_QF_HCURL_31)));
+  AssembleCeedOperator(op, trial, test, qf, ceed::PopulateCoefficientContext(sdim, Q, transpose, -1.0), PA_EVAL_INTERP, PA_EVAL_GRAD);
+}
+void VectorMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
+  AssembleCeedOperator(op, trial, test, PA_QF_H1_1, ceed::PopulateCoefficientContext(1, Q, transpose), PA_EVAL_INTERP, PA_EVAL_INTERP);
+}
+void VectorMassIntegrator::Assemble(pa_op *op, const VectorFiniteElementSpace &fes) const {
+  const FiniteElementSpace &comp = fes.GetScalarSpace();
+  PA_REQUIRE(comp.IsDense() && fes.GetVDim() >= 2, "MassIntegrator with several components: a dense-table H1 space, 2 or 3 copies");
+  const std::vector<double> ctx = ceed::PopulateCoefficientContext(fes.GetVDim(), Q, transpose);
+  const auto r = fes.GetCeedElemRestriction();
+  const auto b = comp.GetCeedDenseBasis();
+  check(pa_op_add_sub_dense_vector_mass(op, comp.GetMesh().GetCeedGeomFactorData(), &r, &b, fes.GetVDim(), fes.GetCompStride(),
+                                        ctx.data(), ctx.size() * sizeof(double)));
+}
+std::unique_ptr<ceed::Operator> VectorMassIntegrator::PartialAssemble(const VectorFiniteElementSpace &fes) const {
+  pa_op *op = nullptr;
+  check(pa_op_create(fes.GetVSize(), fes.GetVSize(), &op));
+  auto out = std::make_unique<ceed::Operator>(fes.GetScalarSpace().GetContext(), op, /*own=*/true);
+  Assemble(op, fes);
+  check(pa_op_finalize(op));
+  return out;
+}
 void GradientIntegrator::Assemble(pa_op *, const FiniteElementSpace &, const FiniteElementSpace &) const {
   throw pa::Error("GradientIntegrator requires trial space with a single component and test space with space_dim components! "
                   "(Assemble(op, trial, VectorFiniteElementSpace))");

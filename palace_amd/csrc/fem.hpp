@@ -244,9 +244,19 @@ PA_DECLARE_INTEGRATOR(DiffusionIntegrator);     // H1, (Q grad u, grad v)       
 PA_DECLARE_INTEGRATOR(CurlCurlIntegrator);      // H(curl), (Q curl u, curl v)       fem/integ/curlcurl.cpp:23-75
 PA_DECLARE_INTEGRATOR(DivDivIntegrator);        // H(div), (Q div u, div v)          fem/integ/divdiv.cpp
 PA_DECLARE_INTEGRATOR(MixedVectorGradientIntegrator);  // H1 x H(curl) | H(div), (Q grad u, v)  fem/integ/mixedvecgrad.cpp
+PA_DECLARE_INTEGRATOR(MixedVectorWeakDivergenceIntegrator);  // H(curl) x H1, -(Q u, grad v)  fem/integ/mixedvecgrad.cpp:146-202
 PA_DECLARE_INTEGRATOR(MixedVectorCurlIntegrator);      // H(curl) x H(curl), (Q curl u, v)   fem/integ/mixedveccurl.cpp:21-73
 PA_DECLARE_INTEGRATOR(MixedVectorWeakCurlIntegrator);  // H(curl) x H(curl), (Q u, curl v)   fem/integ/mixedveccurl.cpp:75-120
 #undef PA_DECLARE_INTEGRATOR
+// (H1)^d, (Q u, v) with a d x d coefficient: MassIntegrator with num_comp = 2 | 3 components (fem/integ/mass.cpp:35-48,
+// f_apply_h1_2 | _3); like GradientIntegrator below it takes a VectorFiniteElementSpace and builds its operator directly
+class VectorMassIntegrator : public BilinearFormIntegrator {
+public:
+  using BilinearFormIntegrator::BilinearFormIntegrator;
+  void Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const override;  // (the scalar form)
+  void Assemble(pa_op *op, const VectorFiniteElementSpace &fes) const;
+  std::unique_ptr<ceed::Operator> PartialAssemble(const VectorFiniteElementSpace &fes) const;
+};
 // H1 x (H1)^d, (Q grad u, v): fem/integ/grad.cpp:16-72 (f_apply_hcurlh1d_*).  The test space has space_dim components, which
 // BilinearForm's scalar spaces do not describe: the operator is built directly, height = test.GetVSize(), width = trial.GetVSize()
 class GradientIntegrator : public BilinearFormIntegrator {

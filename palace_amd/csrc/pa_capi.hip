@@ -681,6 +681,54 @@ int pa_op_add_sub_dense_gradient(pa_op *op, pa_geom *geom, const pa_restriction_
   });
 }
 
+int pa_op_add_sub_dense_vector_mass(pa_op *op, pa_geom *geom, const pa_restriction_desc *restr, const pa_dense_basis_desc *basis,
+                                    int32_t num_comp, int32_t comp_stride, const void *ctx, size_t ctx_size) {
+  return guarded([&] {
+    require_device();
+    PA_REQUIRE(op && geom && restr && basis && ctx, "null argument");
+    PA_REQUIRE(!op->finalized, "operator already finalized");
+    PA_REQUIRE((num_comp == 2 || num_comp == 3) && comp_stride >= 1, "MassIntegrator: 1 (pa_op_add_sub_dense), 2 or 3 components");
+    PA_REQUIRE(restr->lsize == op->height && restr->lsize == op->width, "dimensions mismatch for sub-operator");
+    PA_REQUIRE(basis->fe_type == PA_FE_H1 && !restr->orients && !restr->curl_orients, "vector mass: a scalar H1 basis per component");
+    // f_apply_h1_2 | _3: v_r = w detJ sum_c C[r][c] u_c -- one scalar mass (f_apply_h1_1 between two scalar spaces) per non-zero
+    // entry of the coefficient, from component c to component r
+    CoeffHost C;
+    parse_coeff(ctx, ctx_size, num_comp, C, 0);
+    const int nattr = (int)C.attr_mat.size(), nmat = (int)(C.mat.size() / ((size_t)num_comp * num_comp));
+    hipFree(C.d_attr_mat), hipFree(C.d_mat), hipFree(C.d_mat_t);
+    const size_t ndof = (size_t)restr->num_elem * restr->elem_size;
+    std::vector<std::vector<int32_t>> off((size_t)num_comp, std::vector<int32_t>(ndof));
+    for (int c = 0; c < num_comp; c++)
+      for (size_t k = 0; k < ndof; k++) {
+        const int64_t v = (int64_t)restr->offsets[k] + (int64_t)c * comp_stride;
+        PA_REQUIRE(restr->offsets[k] >= 0 && v < restr->lsize, "component offset out of range (comp_stride and lsize of the vector space)");
+        off[(size_t)c][k] = (int32_t)v;
+      }
+    auto slot_int = [](int32_t v) {
+      double d = 0.0;
+      std::memcpy(&d, &v, 4);
+      return d;
+    };
+    for (int r = 0; r < num_comp; r++)
+      for (int c = 0; c < num_comp; c++) {
+        std::vector<double> blob;  // the 1 x 1 context of entry (r, c): same attributes, one scalar per material
+        blob.push_back(slot_int(nattr));
+        for (int a = 0; a < nattr; a++) blob.push_back(slot_int(C.attr_mat[(size_t)a]));
+        blob.push_back(slot_int(nmat));
+        bool any = false;
+        for (int m = 0; m < nmat; m++) {
+          const double v = C.mat[(size_t)m * num_comp * num_comp + r + (size_t)num_comp * c];
+          any = any || v != 0.0;
+          blob.push_back(v);
+        }
+        if (!any) continue;
+        pa_restriction_desc rt = *restr, rs = *restr;
+        rt.offsets = off[(size_t)c].data(), rs.offsets = off[(size_t)r].data();
+        op->msubs.push_back(make_mixed_sub(geom, rt, *basis, rs, *basis, PA_QF_H1_1, blob.data(), blob.size() * sizeof(double)));
+      }
+  });
+}
+
 struct pa_error_op {
   MixedSub *ms = nullptr;
 };

@@ -214,6 +214,14 @@ def fixtures_rest():
         gv = np.zeros((sdim, Q))
         capi.ref_call("f_apply_hcurlh1d_%d" % tag, cm.pack(), Q, [g, u], [gv])
         out["hcurlh1d_%d" % tag] = gv
+    # vector-valued scalar spaces (h1_2 | _3, l2_2 | _3: they read attr and w detJ only, any geometry data); new draws come last
+    for n, cm, tag in ((2, c2, 22), (3, c3, 33)):
+        uv = rng.uniform(-1, 1, (n, Q))
+        g = out["geom%d" % tag]
+        v, w = np.zeros((n, Q)), np.zeros((n, Q))
+        capi.ref_call("f_apply_h1_%d" % n, cm.pack(), Q, [g, uv], [v])
+        capi.ref_call("f_apply_l2_%d" % n, cm.pack(), Q, [g, qw, uv], [w])
+        out.update({"uv%d" % n: uv, "h1_%d" % n: v, "l2_%d" % n: w})
     np.savez(os.path.join(ROOT, "tests", "golden", "qf_rest_golden.npz"), **out)
     print("wrote qf_rest_golden.npz")
 

@@ -111,6 +111,17 @@ def test_cxx_flux_error_estimators(exe, curved):
         P["phi"], np.zeros(3 * h1.ndofs), h1.ndofs)
     assert np.abs(gv[0] - ref_v).max() < 1e-12 * np.abs(ref_v).max()
     assert np.abs(gv[1] - ref_v.reshape(3, h1.ndofs).T.ravel()).max() < 1e-12 * np.abs(ref_v).max()
+    # MixedVectorWeakDivergenceIntegrator -(eps E, grad v) and the vector H1 mass (f_apply_h1_3) through the C++ front end
+    wv = np.fromfile(out + ".wdiv", dtype=np.float64)
+    c_neg = po.CoeffCtx(attr_mat=[0, 1], mat_coeff=list(P["eps"]), a=-1.0)
+    ref_w = po.MixedSpaceOracle(ndo, h1o, og, po.QF_HCURL, c_neg, second_tab=h1o.deriv).apply_add(P["E"], np.zeros(h1.ndofs))
+    assert np.abs(wv[: h1.ndofs] - ref_w).max() < 1e-12 * np.abs(ref_w).max()
+    uq = np.einsum("qj,ej->eq", h1o.interp[0], P["phi"][h1.offsets])  # values of phi at the points
+    vq = po.apply_h1_vec(c_eps, og, np.stack([uq, 2 * uq, 3 * uq], axis=1))
+    ref_m = np.zeros(3 * h1.ndofs)
+    for c in range(3):
+        np.add.at(ref_m, (c * h1.ndofs + h1.offsets).ravel(), np.einsum("qj,eq->ej", h1o.interp[0], vq[:, c, :]).ravel())
+    assert np.abs(wv[h1.ndofs :] - ref_m).max() < 1e-12 * np.abs(ref_m).max()
     # DivDivMassIntegrator through the C++ front end (BilinearForm(rt), f_apply_l2mass_33) vs the oracle, and vs the sum of
     # DivDivIntegrator + VectorFEMassIntegrator assembled next to it
     yy = np.fromfile(out + ".divdivmass", dtype=np.float64).reshape(2, sp.ndofs)

@@ -52,6 +52,15 @@ def test_divdiv_mass_and_gradient_forms(tag):
     np.testing.assert_allclose(gv[0], G["hcurlh1d_%d" % tag], **TOL)
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_vector_valued_scalar_spaces(n):
+    """f_apply_h1_2 | _3 (MassIntegrator on a vector H1 space) and f_apply_l2_2 | _3 (non-symmetric N x N coefficient)."""
+    tag = 11 * n
+    geom, uv = G["geom%d" % tag][None], G["uv%d" % n][None]
+    np.testing.assert_allclose(po.apply_h1_vec(_cm(tag), geom, uv)[0], G["h1_%d" % n], **TOL)
+    np.testing.assert_allclose(po.apply_l2_vec(_cm(tag), geom, G["qw"], uv)[0], G["l2_%d" % n], **TOL)
+
+
 def test_live_reference_headers_when_present():
     """The same functions against oracle/_ref (the reference's headers compiled in place) on fresh random draws."""
     from oracle import capi

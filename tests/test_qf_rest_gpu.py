@@ -278,6 +278,17 @@ def test_divdiv_mass_and_gradient_on_tetrahedra(kind, p):
     xx = rng.uniform(-1, 1, nh)
     ref = po.MixedSpaceOracle(h1o, h1o, ogeom, po.QF_HCURLH1D, c_ns, first_tab=hgrad).gradient_add(xx, np.zeros(3 * nh), nh)
     assert np.abs(_mult(op, xx, 3 * nh) - ref).max() < REL * np.abs(ref).max()
+    # MassIntegrator on the vector space (f_apply_h1_3, non-symmetric 3 x 3 coefficient), byNODES, and its transpose
+    vm = ceed.Operator(3 * nh, 3 * nh).add_dense_vector_mass_integrator(geom, vtest, 3, nh, c_ns.pack()).finalize()
+    xv, yv = rng.uniform(-1, 1, 3 * nh), rng.uniform(-1, 1, 3 * nh)
+    uq = np.einsum("qj,cej->ecq", hint.reshape(-1, hint.shape[-1]), xv.reshape(3, nh)[:, h1.offsets])
+    vq = po.apply_h1_vec(c_ns, ogeom, uq)
+    ref_m = np.zeros(3 * nh)
+    for c in range(3):
+        np.add.at(ref_m, (c * nh + h1.offsets).ravel(), np.einsum("qj,eq->ej", hint.reshape(-1, hint.shape[-1]), vq[:, c, :]).ravel())
+    mv = _mult(vm, xv, 3 * nh)
+    assert np.abs(mv - ref_m).max() < REL * np.abs(ref_m).max()
+    assert abs(yv @ mv - _mult_t(vm, yv, 3 * nh) @ xv) < 1e-11 * np.abs(yv).sum() * np.abs(mv).max()
     # ... and its assembled form (pa_op_full_assemble: rectangular CSR, rows = the dofs of the vector test space)
     A = op.full_assemble(skip_zeros=True)
     assert A.shape == (3 * nh, nh) and np.abs(A @ xx - ref).max() < REL * np.abs(ref).max()
