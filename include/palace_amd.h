@@ -288,7 +288,9 @@ int pa_op_add_sub_dense(pa_op *op, pa_geom *geom, const pa_restriction_desc *res
  * enters with its gradient table (`deriv`, Grad): with PA_QF_HCURL_33 / PA_QF_HCURL_22 that is MixedVectorGradientIntegrator
  * (C grad phi, v), H1 trial and H(curl) test (fem/integ/mixedvecgrad.cpp:43-76; models/modeeigensolver.cpp:52), and with
  * PA_QF_HCURLHDIV_* its H(div)-test form (mixedvecgrad.cpp:50-55).  Plane elements: the _22 QFunctions with 2-D geometry
- * data; boundary and line elements: the _32 | _31 | _21 members (PA_QF_HCURL_32 ..., PA_QF_HCURLHDIV_32 ..., PA_QF_HDIVHCURL_32
+ * data.  PA_QF_HDIV_33 between two spaces: (C curl u, v) with u in H(curl) (its curl table, `deriv`) and v in H(div) --
+ * MixedVectorCurlIntegrator with an H(div) test space (fem/integ/mixedveccurl.cpp:41-46); transposed: the weak curl with an H(div)
+ * trial space (:88-93; the factor -1 of :111 is the caller's coefficient).  Boundary and line elements: the _32 | _31 | _21 members (PA_QF_HCURL_32 ..., PA_QF_HCURLHDIV_32 ..., PA_QF_HDIVHCURL_32
  * ...; mixedvecgrad.cpp:78-130, vecfemass.cpp).  PA_QF_H1_1 with two scalar bases (PA_FE_H1 descriptors, value tables): MassIntegrator between two scalar spaces, the
  * `Flux` operator of the scalar-flux FluxProjector (errorestimator.cpp:122-160).  op: height = test lsize, width = trial lsize.
  * pa_op_mult_transpose applies the transposed form (test -> trial: the other member of the QFunction pair with the transposed

@@ -981,6 +981,7 @@ class MixedSpaceOracle:
              QF_HCURLHDIV_22: apply_hcurlhdiv_22, QF_HDIVHCURL_22: apply_hdivhcurl_22, QF_HCURL_22: apply_hcurl_22,
              QF_HCURLHDIV_32: apply_hcurlhdiv_32, QF_HDIVHCURL_32: apply_hdivhcurl_32, QF_HCURL_32: apply_hcurl_32,
              QF_HCURLHDIV_LINE: apply_hcurlhdiv_line, QF_HDIVHCURL_LINE: apply_hdivhcurl_line, QF_HCURL_LINE: apply_hcurl_line,
+             QF_HDIV: apply_hdiv_33,  # curls of an H(curl) side (pass its curl table) and values of an H(div) one: mixedveccurl.cpp:41-46
              QF_H1MASS: apply_h1_1}[self.qf]  # QF_H1MASS: MassIntegrator between two scalar spaces (dim-1 context)
         for s0 in range(0, self.a.NE, chunk):
             sl = slice(s0, min(self.a.NE, s0 + chunk))

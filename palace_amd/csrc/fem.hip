@@ -489,9 +489,14 @@ void BilinearFormIntegrator::AssembleCeedOperator(pa_op *op, const FiniteElement
                                 trial_ops, test_ops));
     } else {  // two spaces: values of vector elements, gradients of H1 elements (pa_op_add_sub_dense_mixed)
       const bool scalar = qf == PA_QF_H1_1;  // MassIntegrator between two scalar spaces: values on both sides
-      PA_REQUIRE(trial_ops == ((trial.GetFEType() == PA_FE_H1 && !scalar) ? PA_EVAL_GRAD : PA_EVAL_INTERP) &&
-                     test_ops == ((test.GetFEType() == PA_FE_H1 && !scalar) ? PA_EVAL_GRAD : PA_EVAL_INTERP),
-                 "mixed-space forms evaluate the values of vector or scalar elements and the gradients of H1 elements");
+      const bool curls = qf == PA_QF_HDIV_33;  // ... f_apply_hdiv_33 between two spaces: the curls of an H(curl) side
+      auto want = [&](const FiniteElementSpace &fes) {
+        if (curls && fes.GetFEType() == PA_FE_HCURL) return (int)PA_EVAL_CURL;
+        return (int)((fes.GetFEType() == PA_FE_H1 && !scalar) ? PA_EVAL_GRAD : PA_EVAL_INTERP);
+      };
+      PA_REQUIRE(trial_ops == want(trial) && test_ops == want(test),
+                 "mixed-space forms evaluate the values of vector or scalar elements, the gradients of H1 elements and, with "
+                 "f_apply_hdiv_33, the curls of H(curl) elements");
       const auto r2 = test.GetCeedElemRestriction();
       const auto b2 = test.GetCeedDenseBasis();
       check(pa_op_add_sub_dense_mixed(op, trial.GetMesh().GetCeedGeomFactorData(), &r, &b, &r2, &b2, qf, ctx.data(),
@@ -626,16 +631,23 @@ std::unique_ptr<ceed::Operator> GradientIntegrator::PartialAssemble(const Finite
   return out;
 }
 void MixedVectorCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
-  PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_HCURL,
-             "MixedVectorCurlIntegrator: H(curl) test space only (the H(div) test space of the flux estimator is not built)");
-  AssembleCeedOperator(op, trial, test, PA_QF_HDIVHCURL_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_CURL,
-                       PA_EVAL_INTERP);
+  // mixedveccurl.cpp:21-73: (Q curl u, v); the QFunction follows the map type of the test element
+  const bool sc = test.GetFEType() == PA_FE_HCURL;
+  PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && (sc || test.GetFEType() == PA_FE_HDIV),
+             "Invalid trial/test element map type for MixedVectorCurlIntegrator!");
+  PA_REQUIRE(dims_of(trial) == 33, "MixedVectorCurlIntegrator is only available in 3D!");
+  AssembleCeedOperator(op, trial, test, sc ? PA_QF_HDIVHCURL_33 : PA_QF_HDIV_33, ceed::PopulateCoefficientContext(3, Q, transpose),
+                       PA_EVAL_CURL, PA_EVAL_INTERP);
 }
 void MixedVectorWeakCurlIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
-  PA_REQUIRE(trial.GetFEType() == PA_FE_HCURL && test.GetFEType() == PA_FE_HCURL,
-             "MixedVectorWeakCurlIntegrator: H(curl) trial space only");
-  AssembleCeedOperator(op, trial, test, PA_QF_HCURLHDIV_33, ceed::PopulateCoefficientContext(3, Q, transpose), PA_EVAL_INTERP,
-                       PA_EVAL_CURL);
+  // mixedveccurl.cpp:75-120: -(Q u, curl v) -- the coefficient enters scaled by -1 (:111); the QFunction follows the map type of
+  // the trial element
+  const bool tc = trial.GetFEType() == PA_FE_HCURL;
+  PA_REQUIRE(test.GetFEType() == PA_FE_HCURL && (tc || trial.GetFEType() == PA_FE_HDIV),
+             "Invalid trial/test element map type for MixedVectorWeakCurlIntegrator!");
+  PA_REQUIRE(dims_of(trial) == 33, "MixedVectorWeakCurlIntegrator is only available in 3D!");
+  AssembleCeedOperator(op, trial, test, tc ? PA_QF_HCURLHDIV_33 : PA_QF_HDIV_33,
+                       ceed::PopulateCoefficientContext(3, Q, transpose, -1.0), PA_EVAL_INTERP, PA_EVAL_CURL);
 }
 void DiffusionMassIntegrator::Assemble(pa_op *op, const FiniteElementSpace &trial, const FiniteElementSpace &test) const {
   const int d = dims_of(trial), sdim = trial.GetMesh().SpaceDimension();

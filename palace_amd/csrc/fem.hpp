@@ -245,8 +245,8 @@ PA_DECLARE_INTEGRATOR(CurlCurlIntegrator);      // H(curl), (Q curl u, curl v)  
 PA_DECLARE_INTEGRATOR(DivDivIntegrator);        // H(div), (Q div u, div v)          fem/integ/divdiv.cpp
 PA_DECLARE_INTEGRATOR(MixedVectorGradientIntegrator);  // H1 x H(curl) | H(div), (Q grad u, v)  fem/integ/mixedvecgrad.cpp
 PA_DECLARE_INTEGRATOR(MixedVectorWeakDivergenceIntegrator);  // H(curl) x H1, -(Q u, grad v)  fem/integ/mixedvecgrad.cpp:146-202
-PA_DECLARE_INTEGRATOR(MixedVectorCurlIntegrator);      // H(curl) x H(curl), (Q curl u, v)   fem/integ/mixedveccurl.cpp:21-73
-PA_DECLARE_INTEGRATOR(MixedVectorWeakCurlIntegrator);  // H(curl) x H(curl), (Q u, curl v)   fem/integ/mixedveccurl.cpp:75-120
+PA_DECLARE_INTEGRATOR(MixedVectorCurlIntegrator);      // H(curl) x H(curl) | H(div), (Q curl u, v)    fem/integ/mixedveccurl.cpp:21-73
+PA_DECLARE_INTEGRATOR(MixedVectorWeakCurlIntegrator);  // H(curl) | H(div) x H(curl), -(Q u, curl v)   fem/integ/mixedveccurl.cpp:75-120
 #undef PA_DECLARE_INTEGRATOR
 // (H1)^d, (Q u, v) with a d x d coefficient: MassIntegrator with num_comp = 2 | 3 components (fem/integ/mass.cpp:35-48,
 // f_apply_h1_2 | _3); like GradientIntegrator below it takes a VectorFiniteElementSpace and builds its operator directly

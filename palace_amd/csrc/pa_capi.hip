@@ -657,7 +657,7 @@ int pa_op_add_sub_dense_mixed(pa_op *op, pa_geom *geom, const pa_restriction_des
       case PA_QF_HCURLHDIV_32: case PA_QF_HDIVHCURL_32: case PA_QF_HCURL_32:
       case PA_QF_HCURLHDIV_31: case PA_QF_HDIVHCURL_31: case PA_QF_HCURL_31:
       case PA_QF_HCURLHDIV_21: case PA_QF_HDIVHCURL_21: case PA_QF_HCURL_21:
-      case PA_QF_H1_1: break;
+      case PA_QF_H1_1: case PA_QF_HDIV_33: break;
       default: throw Error("not a mixed-space QFunction");
     }
     PA_REQUIRE(test_restr->lsize == op->height && trial_restr->lsize == op->width,

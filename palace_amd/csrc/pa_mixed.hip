@@ -119,6 +119,8 @@ __device__ __forceinline__ void coeff_unpack2in3(const CoeffDev &c, int attr, do
   embed22(m[0], m[1], m[2], m[3], 0.0, C);
 }
 
+// (KIND 8: f_apply_hdiv_33 between two spaces -- MixedVectorCurlIntegrator with an H(div) test space, an H(curl) side entering with
+// its curl table, mixedveccurl.cpp:41-46; 7 is the gradient form of mixed_embedded_kernel)
 // KIND 0: f_apply_hcurlhdiv_33 | _22, 1: f_apply_hdivhcurl_33 | _22, 2: f_apply_hcurlhdiv_error_33 | _22,
 // 3: f_apply_hdivhcurl_error_33 | _22, 4: f_apply_hcurl_33 | _22 between two spaces, 5: f_apply_h1_1 between two scalar
 // spaces, 6: f_apply_l2h1_error
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
   const int e = blockIdx.x * kMixWaves + wave;
   if (e >= a.ne) return;  // no workgroup barriers below
   constexpr bool ERR = KIND == 2 || KIND == 3 || KIND == 6;
-  constexpr bool SCALAR = KIND >= 5;
+  constexpr bool SCALAR = KIND == 5 || KIND == 6;
   const int P1 = a.s1.P, P2 = a.s2.P, Q = a.Q;
   double *xa = smem + (size_t)wave * a.stride;
   double *xb = xa + P1;
@@ -176,6 +178,8 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_kernel(const MixArgs a) 
         mult_AtBCx33(Jl, Cm, adj, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
       else if (KIND == 1)  // hcurlhdiv_33_qf.h:33-54
         mult_AtBCx33(adj, Cm, Jl, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
+      else if (KIND == 8)  // hdiv_33_qf.h:10-30 between two spaces: both sides contravariant (curls of H(curl), values of H(div))
+        mult_AtBCx33(Jl, Cm, Jl, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
       else  // hcurl_33_qf.h:10-28
         mult_AtBCx33(adj, Cm, adj, u1[0], u1[1], u1[2], wdetJ, v0, v1, v2);
       vq[q] = v0, vq[Q + q] = v1;
@@ -339,10 +343,12 @@ __global__ __launch_bounds__(64 * kMixWaves) void mixed_embedded_kernel(const Mi
 // H(curl) and H(div) sides enter with their value tables (Interp), an H1 side with its gradient table (Grad): the covariant
 // map of H(curl) values is the map of gradients.
 // `scalar`: the side enters a scalar QFunction (or is one component of a vector H1 space) with the values of a scalar space.
-void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, int nc, MixedSide &sd, bool scalar) {
+// `curl`: an H(curl) side enters with its curl table (Curl) instead of its values.
+void build_side(const pa_restriction_desc &r, const pa_dense_basis_desc &b, int Q, int nc, MixedSide &sd, bool scalar,
+                bool curl = false) {
   PA_REQUIRE(b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_HDIV || b.fe_type == PA_FE_H1, "unknown element type");
   PA_REQUIRE(!scalar || (nc == 1 && b.fe_type == PA_FE_H1), "scalar QFunctions take scalar (PA_FE_H1 descriptor) elements");
-  const double *tab = (b.fe_type == PA_FE_H1 && !scalar) ? b.deriv : b.interp;  // (line elements: one component either way)
+  const double *tab = ((b.fe_type == PA_FE_H1 && !scalar) || (curl && b.fe_type == PA_FE_HCURL)) ? b.deriv : b.interp;
   PA_REQUIRE(b.num_dofs > 0 && b.num_qpts == Q && tab, "basis does not match the quadrature rule, or has no value / gradient table");
   PA_REQUIRE(r.elem_size == b.num_dofs && r.offsets && r.lsize > 0, "restriction does not match the basis");
   PA_REQUIRE(!(r.orients && r.curl_orients), "restriction is either oriented or curl-oriented");
@@ -424,6 +430,7 @@ void launch(const MixedSub &ms, const double *x1, const double *x2, double *out,
     case 4: hipLaunchKernelGGL(mixed_kernel<4>, grid, block, shm, s, a); break;
     case 5: hipLaunchKernelGGL(mixed_kernel<5>, grid, block, shm, s, a); break;
     case 6: hipLaunchKernelGGL(mixed_kernel<6>, grid, block, shm, s, a); break;
+    case 8: hipLaunchKernelGGL(mixed_kernel<8>, grid, block, shm, s, a); break;
     default: throw Error("not a mixed-space QFunction");
   }
   PA_HIP(hipGetLastError());
@@ -475,25 +482,29 @@ MixedSub *make_mixed_sub(pa_geom *geom, const pa_restriction_desc &r1, const pa_
     case PA_QF_HCURL_21: kind = 4, qdims = 21; break;
     case PA_QF_H1_1: kind = 5; break;
     case PA_QF_L2H1_ERROR: kind = 6; break;
+    case PA_QF_HDIV_33: kind = 8, qdims = 33; break;
     default: throw Error("not a mixed-space QFunction");
   }
-  const bool scalar = kind >= 5;  // dimension-independent: reads w detJ only
+  const bool scalar = kind == 5 || kind == 6;  // dimension-independent: reads w detJ only
   PA_REQUIRE(scalar ? dim == sdim : qdims == dims, "QFunction does not match the dimension of the geometry data");
   const bool err = kind == 2 || kind == 3 || kind == 6;
   // first space / second space by the Piola map the QFunction applies to each input: covariant (H(curl) values, H1
   // gradients) or contravariant (H(div) values)
   auto covariant = [](const pa_dense_basis_desc &b) { return b.fe_type == PA_FE_HCURL || b.fe_type == PA_FE_H1; };
   const bool cov1 = kind == 0 || kind == 2 || kind == 4, cov2 = kind == 1 || kind == 3 || kind == 4;
-  PA_REQUIRE(scalar || ((cov1 ? covariant(b1) : b1.fe_type == PA_FE_HDIV) && (cov2 ? covariant(b2) : b2.fe_type == PA_FE_HDIV)),
-             "element types do not match the QFunction (vecfemass.cpp:88-101, mixedvecgrad.cpp:43-76)");
+  // (f_apply_hdiv_33: the curls of an H(curl) space are contravariant like the values of an H(div) one)
+  auto contra8 = [](const pa_dense_basis_desc &b) { return b.fe_type == PA_FE_HDIV || (b.fe_type == PA_FE_HCURL && b.deriv); };
+  PA_REQUIRE(scalar || (kind == 8 ? (contra8(b1) && contra8(b2))
+                                  : ((cov1 ? covariant(b1) : b1.fe_type == PA_FE_HDIV) && (cov2 ? covariant(b2) : b2.fe_type == PA_FE_HDIV))),
+             "element types do not match the QFunction (vecfemass.cpp:88-101, mixedvecgrad.cpp:43-76, mixedveccurl.cpp:41-58)");
   PA_REQUIRE(ctx && ctx_size >= 16 && ctx_size % 8 == 0, "bad coefficient context");
   auto *ms = new MixedSub;
   try {
     ms->geom = geom;
     geom->refcount++;
     ms->ne = geom->ne, ms->Q = geom->Q, ms->qf = qf, ms->kind = kind, ms->error = err;
-    build_side(r1, b1, geom->Q, scalar ? 1 : dim, ms->s1, scalar);
-    build_side(r2, b2, geom->Q, scalar ? 1 : dim, ms->s2, scalar);
+    build_side(r1, b1, geom->Q, scalar ? 1 : dim, ms->s1, scalar, kind == 8);
+    build_side(r2, b2, geom->Q, scalar ? 1 : dim, ms->s2, scalar, kind == 8);
     parse_coeff(ctx, ctx_size, scalar ? 1 : sdim, ms->c0, 0);
     if (err) parse_coeff(ctx, ctx_size, scalar ? 1 : sdim, ms->c1, ms->c0.slots);  // PopulateCoefficientContext(dim, first, dim, second)
     if (!err) ms->d_ye = dev_alloc<double>((size_t)ms->ne * ms->s2.P);

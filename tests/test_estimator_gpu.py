@@ -129,8 +129,8 @@ def test_mixed_operator_argument_checks():
         ceed.Operator(rtb.lsize, ndb.lsize).add_dense_mixed_integrator(geom, ndb, rtb, ceed.QF_HDIVHCURL_33, blob)
     with pytest.raises(PalaceAmdError, match="dimensions"):
         ceed.Operator(ndb.lsize, rtb.lsize).add_dense_mixed_integrator(geom, ndb, rtb, ceed.QF_HCURLHDIV_33, blob)
-    with pytest.raises(PalaceAmdError, match="mixed-space"):
-        ceed.Operator(rtb.lsize, ndb.lsize).add_dense_mixed_integrator(geom, ndb, rtb, ceed.QF_HDIV_33, blob)
+    with pytest.raises(PalaceAmdError, match="mixed-space"):  # (a pair QFunction: no two-space form)
+        ceed.Operator(rtb.lsize, ndb.lsize).add_dense_mixed_integrator(geom, ndb, rtb, ceed.QF_HDIVMASS_33, blob)
     op = ceed.Operator(rtb.lsize, ndb.lsize).add_dense_mixed_integrator(geom, ndb, rtb, ceed.QF_HCURLHDIV_33, blob).finalize()
     import torch
 

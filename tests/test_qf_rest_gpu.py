@@ -278,6 +278,22 @@ def test_divdiv_mass_and_gradient_on_tetrahedra(kind, p):
     xx = rng.uniform(-1, 1, nh)
     ref = po.MixedSpaceOracle(h1o, h1o, ogeom, po.QF_HCURLH1D, c_ns, first_tab=hgrad).gradient_add(xx, np.zeros(3 * nh), nh)
     assert np.abs(_mult(op, xx, 3 * nh) - ref).max() < REL * np.abs(ref).max()
+    # MixedVectorCurlIntegrator with an H(div) test space: (C curl u, v), f_apply_hdiv_33 between the Nedelec space (curl table) and
+    # the Raviart-Thomas one; its transpose is the weak curl with an H(div) trial space
+    nd = tet.NDTetSpace(mesh, p)
+    nint, ncurl = nd.elem.tables(pts)
+    kw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+    ndb = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, nint, ncurl, **kw)
+    rtb = ceed.DenseBlock(ceed.FE_HDIV, n, sp.offsets, interp, None, orients=sp.orients)
+    okw = dict(curl_orients=nd.curl_orients) if not nd.diagonal_transform else {}
+    ndo = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients if nd.diagonal_transform else None, nint, ncurl, ogeom, None, None, **okw)
+    rto = po.CeedOperatorOracle(n, sp.offsets, sp.orients, interp, interp, ogeom, None, None)
+    mc = ceed.Operator(n, nd.ndofs).add_dense_mixed_integrator(geom, ndb, rtb, ceed.QF_HDIV_33, c_ns.pack()).finalize()
+    xa, yb = rng.uniform(-1, 1, nd.ndofs), rng.uniform(-1, 1, n)
+    ref_c = po.MixedSpaceOracle(ndo, rto, ogeom, po.QF_HDIV, c_ns, first_tab=ndo.deriv).apply_add(xa, np.zeros(n))
+    ax = _mult(mc, xa, n)
+    assert np.abs(ax - ref_c).max() < REL * np.abs(ref_c).max()
+    assert abs(yb @ ax - _mult_t(mc, yb, nd.ndofs) @ xa) < 1e-11 * np.abs(yb).sum() * np.abs(ax).max()
     # MassIntegrator on the vector space (f_apply_h1_3, non-symmetric 3 x 3 coefficient), byNODES, and its transpose
     vm = ceed.Operator(3 * nh, 3 * nh).add_dense_vector_mass_integrator(geom, vtest, 3, nh, c_ns.pack()).finalize()
     xv, yv = rng.uniform(-1, 1, 3 * nh), rng.uniform(-1, 1, 3 * nh)
