@@ -506,7 +506,7 @@ def cpw_leg(order=3, refine=1, reps=20):
     A.mult(xr, xi, yr, yi)
     res = float(torch.sqrt(((yr - br) ** 2 + (yi - bi) ** 2).sum()) / torch.sqrt((br ** 2 + bi ** 2).sum()))
     out["fgmres"] = {"iterations_to_1e-8": st["iterations"], "seconds": dt, "iters_per_s": st["iterations"] / dt,
-                     "converged": st["converged"], "true_rel_residual": res, "orthogonalization": "MGS (the reference's default)"}
+                     "converged": st["converged"], "true_rel_residual": res, "orthogonalization": "MGS (the reference's default), coefficients on the device: one host synchronisation per column (orthog.hip)"}
     # the same solve with the batched orthogonalisation (OrthogonalizeColumnCGS2, linalg/orthog.hpp:57-89: two reductions per step
     # instead of j + 1): same preconditioner object
     try:
@@ -524,6 +524,24 @@ def cpw_leg(order=3, refine=1, reps=20):
         del S2, xr2, xi2
     except Exception as exc:  # noqa: BLE001
         out["fgmres_cgs2"] = {"error": f"{type(exc).__name__}: {exc}"}
+    # A / B: the same MGS solve with the host driving every inner product (rounds 1-4: one synchronisation per basis vector)
+    try:
+        linalg.Context.set_device_orthogonalization(False)
+        xr3, xi3 = torch.zeros_like(br), torch.zeros_like(br)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        S.mult(br, bi, xr3, xi3)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        st3 = S.stats()
+        dx3 = float(torch.sqrt(((xr3 - xr) ** 2 + (xi3 - xi) ** 2).sum()) / torch.sqrt((xr ** 2 + xi ** 2).sum()))
+        out["fgmres_host_driven_mgs"] = {"iterations_to_1e-8": st3["iterations"], "seconds": dt3, "iters_per_s": st3["iterations"] / dt3,
+                                         "rel_diff_of_the_solution_from_the_device_chained_solve": dx3}
+        del xr3, xi3
+    except Exception as exc:  # noqa: BLE001
+        out["fgmres_host_driven_mgs"] = {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        linalg.Context.set_device_orthogonalization(True)
     # the real-part operator at this size against the numpy oracle (one oracle apply)
     from oracle import palace_oracle as po
 

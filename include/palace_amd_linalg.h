@@ -252,6 +252,15 @@ int pa_orthogonalize_column(pa_context *ctx, int kind, int m, const double *cons
                             pa_par_op *weight);
 int pa_orthogonalize_column_complex(pa_context *ctx, int kind, int m, const double *const *Vr, const double *const *Vi,
                                     double *wr, double *wi, int n, double *H, pa_par_op *weight);
+/* One Arnoldi column as (F)GMRES does it (linalg/iterative.cpp:629-633, :820-824): orthogonalise w against V[0 .. m) with the
+ * chosen Gram-Schmidt variant, *hn = ||w||, w /= *hn.  The coefficients stay on the device between the kernels and the
+ * update kernels read them from there: one host synchronisation per column (palace_amd/csrc/orthog.hip).  H as above. */
+int pa_orthonormalize_column(pa_context *ctx, int kind, int m, const double *const *V, double *w, int n, double *H, double *hn);
+int pa_orthonormalize_column_complex(pa_context *ctx, int kind, int m, const double *const *Vr, const double *const *Vi,
+                                     double *wr, double *wi, int n, double *H, double *hn);
+/* A / B switch of the above inside (F)GMRES and pa_orthogonalize_column: 0 = the host drives every inner product and update
+ * (one synchronisation per inner product, the form of rounds 1-4), 1 = device-resident coefficients (default). */
+int pa_set_device_orthogonalization(int on);
 int pa_gmres_set_orthogonalization(pa_solver *S, int kind);
 int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess);
 /* Named host ranges for profilers (roctx; rocprofv3 --marker-trace).  The library itself brackets the reference's BlockTimer

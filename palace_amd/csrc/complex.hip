@@ -275,6 +275,18 @@ void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::ve
     weight->Mult(w.Imag(), ws.Imag());
     return ws;
   };
+  if (DeviceOrthogonalization() && !(weight && kind == Orthogonalization::MGS)) {  // orthog.hip: coefficients stay on the device
+    const int passes = (weight && kind == Orthogonalization::CGS2) ? 2 : 1;
+    const Orthogonalization k1 = weight ? Orthogonalization::CGS : kind;
+    std::vector<std::complex<double>> dH;
+    for (int pass = 0; pass < passes; pass++) {
+      const ComplexVector &x = weighted();
+      if (pass) dH.resize((size_t)m);
+      OrthogonalizeColumnDevice(c, k1, V, w, weight ? &x : nullptr, pass ? dH.data() : H, m, false, nullptr);
+    }
+    for (size_t j = 0; j < dH.size(); j++) H[j] += dH[j];
+    return;
+  }
   if (kind == Orthogonalization::MGS) {
     for (int j = 0; j < m; j++) {
       H[j] = Dot(c, weighted(), V[j]);
@@ -867,8 +879,8 @@ struct ComplexKrylovOps {
   void Axpy(Scalar a, const Vec &x, Vec &y) const { linalg::AXPY(c, a, x, y); }
   void Scale(double s, Vec &x) const { linalg::Scale(c, s, x); }
   double Norm(const Vec &x) const { return linalg::Norml2(c, x); }
-  void Orthogonalize(Orthogonalization kind, const std::vector<Vec> &V, Vec &w, Scalar *H, int m) const {
-    linalg::OrthogonalizeColumn(c, kind, V, w, H, m);
+  double Orthonormalize(Orthogonalization kind, const std::vector<Vec> &V, Vec &w, Scalar *H, int m) const {
+    return linalg::OrthonormalizeColumn(c, kind, V, w, H, m);
   }
 };
 }  // namespace

@@ -57,6 +57,11 @@ void SetBlocks(const Context &c, ComplexVector &x, const std::vector<const Compl
 // `weight` is a real operator applied to the real and the imaginary part (test/unit/test-orthog.cpp:49-67)
 void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
                          std::complex<double> *H, int m, const Operator *weight = nullptr);
+// orthogonalise + norm + normalise with the coefficients on the device (orthog.hip; linalg.hpp: OrthonormalizeColumn)
+double OrthonormalizeColumn(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
+                            std::complex<double> *H, int m);
+void OrthogonalizeColumnDevice(const Context &c, Orthogonalization kind, const std::vector<ComplexVector> &V, ComplexVector &w,
+                               const ComplexVector *x, std::complex<double> *H, int m, bool normalize, double *hn);
 }  // namespace linalg
 
 // ComplexOperator (linalg/operator.hpp:24-68): abstract complex operator on ComplexVectors.  The variants a concrete

@@ -140,7 +140,8 @@ struct Params {
 // Ops: { using Vec; using Scalar; int Size(); void Ensure(Vec &); void A(const Vec &, Vec &); bool HasB();
 //        void B(const Vec &, Vec &); void Copy(const Vec &, Vec &); void Zero(Vec &); void BMinus(const Vec &b, Vec &r)
 //        [r = b - r]; void Axpy(Scalar, const Vec &, Vec &); void Scale(double, Vec &); double Norm(const Vec &);
-//        void Orthogonalize(Orthogonalization, const std::vector<Vec> &, Vec &w, Scalar *H, int m); }
+//        double Orthonormalize(Orthogonalization, const std::vector<Vec> &, Vec &w, Scalar *H, int m) [returns ||w|| before
+//        the normalisation]; }
 template <class Ops>
 void GmresMult(Ops &ops, const Params &p, const typename Ops::Vec &b, typename Ops::Vec &x,
                std::vector<typename Ops::Vec> &V, std::vector<typename Ops::Vec> &Z, typename Ops::Vec &r, Result &out) {
@@ -234,10 +235,9 @@ void GmresMult(Ops &ops, const Params &p, const typename Ops::Vec &b, typename O
         ops.A(V[j], w);
       }
       Scalar *Hj = H.data() + (size_t)j * (max_dim + 1);
-      ops.Orthogonalize(p.orthog, V, w, Hj, j + 1);
-      const double hn = ops.Norm(w);
-      Hj[j + 1] = hn;
-      ops.Scale(1.0 / hn, w);
+      // H(0 .. j, j) from the orthogonalisation, H(j+1, j) = ||w||, w /= H(j+1, j) (iterative.cpp:629-633): one call, so that the
+      // scalars can stay on the device between the kernels (orthog.hip)
+      Hj[j + 1] = ops.Orthonormalize(p.orthog, V, w, Hj, j + 1);
       for (int k = 0; k < j; k++) ApplyPlaneRotation(Hj[k], Hj[k + 1], cs[k], sn[k]);
       GeneratePlaneRotation(Hj[j], Hj[j + 1], cs[j], sn[j]);
       ApplyPlaneRotation(Hj[j], Hj[j + 1], cs[j], sn[j]);

@@ -43,6 +43,8 @@ void Vector::MakeRef(double *ext, int n) {
 Workspace::~Workspace() {
   if (d_) (void)hipFree(d_);
   if (h_) (void)hipHostFree(h_);
+  if (gs_d_) (void)hipFree(gs_d_);
+  if (gs_h_) (void)hipHostFree(gs_h_);
   if (halo_stream_) (void)hipStreamDestroy(halo_stream_);
   if (ev_ready_) (void)hipEventDestroy(ev_ready_);
   if (ev_done_) (void)hipEventDestroy(ev_done_);
@@ -68,6 +70,30 @@ double *Workspace::Pinned(size_t n) {
   PA_REQUIRE(n <= kPinnedDoubles, "pinned scratch request exceeds the workspace");
   if (!h_) PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_), kPinnedDoubles * sizeof(double), hipHostMallocDefault));
   return h_;
+}
+
+double *Workspace::GsDevice(size_t n) {
+  if (n > gs_dn_) {  // (the stream that used the old buffer has been synchronised: every column ends with a copy to the host)
+    if (gs_d_) {
+      PA_HIP(hipDeviceSynchronize());
+      (void)hipFree(gs_d_);
+    }
+    gs_dn_ = std::max<size_t>(2 * n, 32768);
+    gs_d_ = pa::dev_alloc<double>(gs_dn_);
+    PA_HIP(hipMemset(gs_d_, 0, gs_dn_ * sizeof(double)));
+  }
+  return gs_d_;
+}
+double *Workspace::GsPinned(size_t n) {
+  if (n > gs_hn_) {
+    if (gs_h_) {
+      PA_HIP(hipDeviceSynchronize());
+      (void)hipHostFree(gs_h_);
+    }
+    gs_hn_ = std::max<size_t>(2 * n, 1024);
+    PA_HIP(hipHostMalloc(reinterpret_cast<void **>(&gs_h_), gs_hn_ * sizeof(double), hipHostMallocDefault));
+  }
+  return gs_h_;
 }
 
 StreamGraph::StreamGraph() {
@@ -724,8 +750,7 @@ void MultiDot(const Context &c, const Vector &w, const std::vector<Vector> &V, i
     if (c.comm) c.comm->AllReduceSum(d_out, mb, c.stream);
     PA_HIP(hipMemcpyAsync(s.h_result, d_out, sizeof(double) * mb, hipMemcpyDeviceToHost, c.stream));
     PA_HIP(hipStreamSynchronize(c.stream));
-    if (c.comm) c.comm->PeerCheckNow();
-  if (c.comm) c.comm->PeerCheckNow();  // (a timed-out wait of the peer transport surfaces here, not as a wrong sum)
+    if (c.comm) c.comm->PeerCheckNow();  // (a timed-out wait of the peer transport surfaces here, not as a wrong sum)
     for (int j = 0; j < mb; j++) H[j0 + j] = s.h_result[j];
   }
 }
@@ -747,6 +772,18 @@ void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::ve
   if (weight) {
     PA_REQUIRE(weight->Height() == w.Size() && weight->Width() == w.Size(), "weight operator does not match the vectors");
     ws.SetSize(w.Size());
+  }
+  if (DeviceOrthogonalization() && !(weight && kind == Orthogonalization::MGS)) {  // orthog.hip: coefficients stay on the device
+    const int passes = (weight && kind == Orthogonalization::CGS2) ? 2 : 1;  // (W w of the refinement pass is recomputed here)
+    const Orthogonalization k1 = weight ? Orthogonalization::CGS : kind;
+    std::vector<double> dH;
+    for (int pass = 0; pass < passes; pass++) {
+      if (weight) weight->Mult(w, ws);
+      if (pass) dH.resize((size_t)m);
+      OrthogonalizeColumnDevice(c, k1, V, w, weight ? &ws : nullptr, pass ? dH.data() : H, m, false, nullptr);
+    }
+    for (size_t j = 0; j < dH.size(); j++) H[j] += dH[j];
+    return;
   }
   if (kind == Orthogonalization::MGS) {  // orthog.hpp:41-55
     for (int j = 0; j < m; j++) {
@@ -1664,8 +1701,8 @@ struct RealKrylovOps {
   void Axpy(double a, const Vec &x, Vec &y) const { linalg::AXPY(c, a, x, y); }
   void Scale(double s, Vec &x) const { linalg::Scale(c, s, x); }
   double Norm(const Vec &x) const { return linalg::Norml2(c, x); }
-  void Orthogonalize(Orthogonalization kind, const std::vector<Vec> &V, Vec &w, double *H, int m) const {
-    linalg::OrthogonalizeColumn(c, kind, V, w, H, m);
+  double Orthonormalize(Orthogonalization kind, const std::vector<Vec> &V, Vec &w, double *H, int m) const {
+    return linalg::OrthonormalizeColumn(c, kind, V, w, H, m);
   }
 };
 }  // namespace

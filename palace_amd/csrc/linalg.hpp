@@ -30,7 +30,8 @@ class Halo;  // conforming prolongation of one space across ranks (comm.hpp)
 // Reduction scratch of one context (per-block partial sums on the device, a pinned slot for the results); created on
 // first use and shared by the copies of a context -- never by two contexts, whose streams may reduce concurrently.
 class Workspace {
-  double *d_ = nullptr, *h_ = nullptr;
+  double *d_ = nullptr, *h_ = nullptr, *gs_d_ = nullptr, *gs_h_ = nullptr;
+  size_t gs_dn_ = 0, gs_hn_ = 0;
   hipStream_t halo_stream_ = nullptr;
   hipEvent_t ev_ready_ = nullptr, ev_done_ = nullptr;
 
@@ -42,6 +43,10 @@ public:
   ~Workspace();
   double *Device(size_t n);  // n <= kDeviceDoubles doubles of device memory
   double *Pinned(size_t n);  // n <= kPinnedDoubles doubles of page-locked host memory
+  // scratch of the device-side Gram-Schmidt (orthog.hip): grows with the restart length, zero-filled when (re)allocated;
+  // never part of a recorded sequence
+  double *GsDevice(size_t n);
+  double *GsPinned(size_t n);
   // second stream for halo exchanges that overlap with interior element work, and the two events of the fork / join
   // (ready: the vector to exchange is complete on the main stream; done: the ghosts have arrived on the halo stream)
   hipStream_t HaloStream();
@@ -546,6 +551,15 @@ namespace linalg {
 // (test/unit/test-orthog.cpp:21-68).  CGS2 = CGS with one refinement pass (refine = true).
 void OrthogonalizeColumn(const Context &c, Orthogonalization kind, const std::vector<Vector> &V, Vector &w, double *H,
                          int m, const Operator *weight = nullptr);
+// The three statements of a GMRES step (iterative.cpp:629-633): orthogonalise w against V[0 .. m), return H(m, .) = ||w|| and
+// normalise w -- with the coefficients kept on the device between the kernels (orthog.hip): one host synchronisation per column.
+// PALACE_AMD_GS=host runs the three calls one after the other with the host in between (the form of rounds 1-4).
+double OrthonormalizeColumn(const Context &c, Orthogonalization kind, const std::vector<Vector> &V, Vector &w, double *H, int m);
+// (device form of OrthogonalizeColumn: inner products of `x` when given -- W w of a weighted inner product --, else of w)
+void OrthogonalizeColumnDevice(const Context &c, Orthogonalization kind, const std::vector<Vector> &V, Vector &w, const Vector *x,
+                               double *H, int m, bool normalize, double *hn);
+bool DeviceOrthogonalization();
+void SetDeviceOrthogonalization(bool on);  // A / B switch (default on; PALACE_AMD_GS=host starts with it off)
 }  // namespace linalg
 
 enum class PreconditionerSide { LEFT = 0, RIGHT = 1 };  // config "PCSide" (iterative.hpp:187-214)

@@ -753,6 +753,33 @@ int pa_orthogonalize_column_complex(pa_context *ctx, int kind, int m, const doub
     for (int j = 0; j < m; j++) H[2 * j] = h[j].real(), H[2 * j + 1] = h[j].imag();
   });
 }
+int pa_orthonormalize_column(pa_context *ctx, int kind, int m, const double *const *V, double *w, int n, double *H, double *hn) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && kind >= 0 && kind <= 2 && m >= 0 && (m == 0 || (V && H)) && w && n >= 0 && hn, "bad argument");
+    std::vector<Vector> basis;
+    basis.reserve((size_t)m);
+    for (int j = 0; j < m; j++) basis.emplace_back(const_cast<double *>(V[j]), n);
+    Vector vw(w, n);
+    *hn = linalg::OrthonormalizeColumn(ctx->ctx, static_cast<Orthogonalization>(kind), basis, vw, H, m);
+  });
+}
+int pa_orthonormalize_column_complex(pa_context *ctx, int kind, int m, const double *const *Vr, const double *const *Vi,
+                                     double *wr, double *wi, int n, double *H, double *hn) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && kind >= 0 && kind <= 2 && m >= 0 && (m == 0 || (Vr && Vi && H)) && wr && wi && n >= 0 && hn,
+               "bad argument");
+    std::vector<ComplexVector> basis;
+    basis.reserve((size_t)m);
+    for (int j = 0; j < m; j++) basis.emplace_back(const_cast<double *>(Vr[j]), const_cast<double *>(Vi[j]), n);
+    ComplexVector vw(wr, wi, n);
+    std::vector<std::complex<double>> h((size_t)m);
+    *hn = linalg::OrthonormalizeColumn(ctx->ctx, static_cast<Orthogonalization>(kind), basis, vw, h.data(), m);
+    for (int j = 0; j < m; j++) H[2 * j] = h[j].real(), H[2 * j + 1] = h[j].imag();
+  });
+}
+int pa_set_device_orthogonalization(int on) {
+  return guarded([&] { linalg::SetDeviceOrthogonalization(on != 0); });
+}
 int pa_gmres_set_orthogonalization(pa_solver *S, int kind) {
   return guarded([&] {
     PA_REQUIRE(S && kind >= 0 && kind <= 2, "bad argument");

@@ -301,6 +301,33 @@ class Context:
                                                         C.c_int(wr.numel()), _ptr(H), weight.handle if weight else None))
         return H[0:2 * m:2] + 1j * H[1:2 * m:2]
 
+    @staticmethod
+    def set_device_orthogonalization(on):
+        _lib.check(_L().pa_set_device_orthogonalization(C.c_int(1 if on else 0)))
+
+    def orthonormalize_column(self, kind, V, w):
+        """One Arnoldi column (iterative.cpp:629-633): orthogonalise, norm, normalise; returns (H, hn)."""
+        m = len(V)
+        k = {"MGS": 0, "CGS": 1, "CGS2": 2}[kind]
+        ptrs = (C.c_void_p * max(m, 1))(*[v.data_ptr() for v in V])
+        H = np.zeros(max(m, 1), dtype=np.float64)
+        hn = C.c_double(0.0)
+        _lib.check(_L().pa_orthonormalize_column(self.handle, C.c_int(k), C.c_int(m), ptrs, C.c_void_p(w.data_ptr()),
+                                                 C.c_int(w.numel()), _ptr(H), C.byref(hn)))
+        return H[:m], hn.value
+
+    def orthonormalize_column_complex(self, kind, Vr, Vi, wr, wi):
+        m = len(Vr)
+        k = {"MGS": 0, "CGS": 1, "CGS2": 2}[kind]
+        pr = (C.c_void_p * max(m, 1))(*[v.data_ptr() for v in Vr])
+        pi = (C.c_void_p * max(m, 1))(*[v.data_ptr() for v in Vi])
+        H = np.zeros(2 * max(m, 1), dtype=np.float64)
+        hn = C.c_double(0.0)
+        _lib.check(_L().pa_orthonormalize_column_complex(self.handle, C.c_int(k), C.c_int(m), pr, pi,
+                                                         C.c_void_p(wr.data_ptr()), C.c_void_p(wi.data_ptr()),
+                                                         C.c_int(wr.numel()), _ptr(H), C.byref(hn)))
+        return H[0:2 * m:2] + 1j * H[1:2 * m:2], hn.value
+
     def set_random(self, x, seed):
         _lib.check(_L().pa_vec_set_random(self.handle, C.c_void_p(x.data_ptr()), x.numel(), seed))
         return x

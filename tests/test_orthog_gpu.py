@@ -105,3 +105,67 @@ def test_weighted_by_the_mass_operator(ctx, kind, cylinder_mesh):
         M.mult(V[j], t)
         assert abs(float(w @ t)) < 1e-11 * float(w0.norm())
         assert H[j] == pytest.approx(float(w0 @ t), rel=1e-10, abs=1e-12)
+
+
+# ---- the Arnoldi column with the coefficients on the device (orthog.hip; round 5) ------------------------------------------------
+@pytest.mark.parametrize("n,off", [(4097, 0), (1000, 0), (777, 1), (3, 0)])
+@pytest.mark.parametrize("m", [0, 1, 8, 9, 27])
+@pytest.mark.parametrize("kind", KINDS)
+def test_orthonormalize_column_real(ctx, kind, m, n, off):
+    """H, the norm and the normalised vector against the oracle's three statements (orthogonalise, norm, scale); m crosses the
+    batch of eight, n is odd / tiny, `off` shifts every vector by one double so that the 16-byte lanes are not usable."""
+    if m >= n:
+        pytest.skip("more basis vectors than entries")
+    rng = np.random.default_rng(100 + m)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, max(m, 1))))
+    V = [Q[:, j].copy() for j in range(m)]
+    w = rng.normal(size=n)
+    Href, wref = po.orthogonalize_column(kind, V, w, m) if m else (np.zeros(0), w.copy())
+    hn_ref = np.linalg.norm(wref)
+    bufs = [_dev(np.concatenate([np.zeros(off), v])) for v in V]
+    wd = _dev(np.concatenate([np.zeros(off), w]))
+    H, hn = ctx.orthonormalize_column(kind, [b[off:] for b in bufs], wd[off:])
+    tol = 1e-12 * max(1.0, np.abs(w).max())
+    assert np.abs(H - Href).max(initial=0.0) < tol
+    assert abs(hn - hn_ref) < 1e-12 * hn_ref
+    assert np.abs(wd[off:].cpu().numpy() - wref / hn_ref).max() < 1e-11
+    for b, v in zip(bufs, V):  # the basis is not written
+        assert np.array_equal(b[off:].cpu().numpy(), v)
+
+
+@pytest.mark.parametrize("n,off", [(2049, 0), (512, 1)])
+@pytest.mark.parametrize("m", [0, 1, 8, 13])
+@pytest.mark.parametrize("kind", KINDS)
+def test_orthonormalize_column_complex(ctx, kind, m, n, off):
+    rng = np.random.default_rng(200 + m)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, max(m, 1))) + 1j * rng.normal(size=(n, max(m, 1))))
+    V = [Q[:, j].copy() for j in range(m)]
+    w = rng.normal(size=n) + 1j * rng.normal(size=n)
+    Href, wref = po.orthogonalize_column(kind, V, w, m) if m else (np.zeros(0, complex), w.copy())
+    hn_ref = np.linalg.norm(wref)
+    pad = np.zeros(off)
+    Vr = [_dev(np.concatenate([pad, v.real])) for v in V]
+    Vi = [_dev(np.concatenate([pad, v.imag])) for v in V]
+    wr, wi = _dev(np.concatenate([pad, w.real])), _dev(np.concatenate([pad, w.imag]))
+    H, hn = ctx.orthonormalize_column_complex(kind, [v[off:] for v in Vr], [v[off:] for v in Vi], wr[off:], wi[off:])
+    got = wr[off:].cpu().numpy() + 1j * wi[off:].cpu().numpy()
+    assert np.abs(H - Href).max(initial=0.0) < 1e-12 * max(1.0, np.abs(w).max())
+    assert abs(hn - hn_ref) < 1e-12 * hn_ref
+    assert np.abs(got - wref / hn_ref).max() < 1e-11
+    if m:
+        assert max(abs(np.vdot(v, got)) for v in V) < 1e-12
+
+
+def test_orthonormalize_column_is_reproducible(ctx):
+    """The last-block reduction adds the partial sums in block order: two runs on the same data agree to the bit."""
+    rng = np.random.default_rng(7)
+    n, m = 300001, 10
+    V = [_dev(rng.normal(size=n) / np.sqrt(n)) for _ in range(m)]
+    w0 = rng.normal(size=n)
+    out = []
+    for _ in range(3):
+        w = _dev(w0)
+        H, hn = ctx.orthonormalize_column("CGS2", V, w)
+        out.append((H.copy(), hn, w.cpu().numpy()))
+    for H, hn, w in out[1:]:
+        assert np.array_equal(H, out[0][0]) and hn == out[0][1] and np.array_equal(w, out[0][2])
