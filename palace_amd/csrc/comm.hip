@@ -1079,7 +1079,19 @@ void Halo::RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) 
   const int mb = mail_blocks(nrecv_), sb = sum_blocks(p.n_rdof);
   static const bool merged = !(std::getenv("PALACE_AMD_HALO_MERGED") && std::getenv("PALACE_AMD_HALO_MERGED")[0] == '0');
   if (merged) {  // one launch for both halves (PALACE_AMD_HALO_MERGED=0: the two kernels of round 3)
-    hipLaunchKernelGGL(k_peer_restrict_direct, dim3(std::max(mb, sb)), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, nrecv_,
+    // Every block of this kernel takes part in both phases: a block spinning in the second one waits for the FIRST phase of other
+    // ranks' grids, so each grid has to be resident as a whole -- also when the ranks share one device (rehearsals, CU-masked or
+    // partitioned devices).  Both loops are grid-stride: clamp the grid to this rank's share of what the device holds at once.
+    static const int resident = [] {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop{};
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peer_restrict_direct, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1)
+        prop.multiProcessorCount = 32;
+      return per_cu * prop.multiProcessorCount;
+    }();
+    const int cap = std::max(1, resident / std::max(1, comm_->Size()));
+    hipLaunchKernelGGL(k_peer_restrict_direct, dim3(std::min(cap, std::max(mb, sb))), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, nrecv_,
                        GhostOut(), p.mb[1], nsend_, d_y, p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, d_mask);
     PA_HIP(hipGetLastError());
     return;

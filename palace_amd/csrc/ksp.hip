@@ -321,6 +321,8 @@ class NativeAmsSolver : public Solver {  // LinearSolver::AMS
   AmsOptions opt_;
   std::unique_ptr<AmsSolver> ams_;
   std::unique_ptr<ReplicatedCoarseSolver> rep_;  // several ranks: the global level solved redundantly
+  const Operator *A_ = nullptr;
+  mutable Vector r_, z_;
 
   // the lowest-order discrete gradient as a matrix: every row is +1 at the edge's head and -1 at its tail, so two applications
   // (to the vertex numbers and to their squares) identify both vertices of every edge
@@ -371,6 +373,7 @@ public:
   void SetOperator(const Operator &op) override {
     StreamGraph::Invalidate();
     height = op.Height(), width = op.Width();
+    A_ = &op;
     if (nd_->GetHalo()) {  // several ranks (ksp.cpp:129-239 hands HYPRE the distributed matrix; here: gathered, solved everywhere)
       ams_.reset();
       const std::vector<double> xyz = nd_->GetMesh().VertexCoordinates(*h1_);  // (true vertices first: the first GetTrueVSize() rows)
@@ -386,7 +389,15 @@ public:
     ams_ = std::make_unique<AmsSolver>(*ctx_, A, G, xyz.data(), nd_->GetMesh().SpaceDimension(), ess_flag, opt_);
   }
   void Mult(const Vector &b, Vector &x) const override {
-    if (rep_) return rep_->Mult(b, x);
+    if (rep_) {  // several ranks: the replicated solve starts from zero; a caller's guess enters as one residual correction
+      if (!initial_guess) return rep_->Mult(b, x);  // (the same rule as NativeAmgSolver above, and as on one rank)
+      r_.SetSize(height), z_.SetSize(height);
+      A_->Mult(x, r_);
+      linalg::AXPBY(*ctx_, 1.0, b, -1.0, r_);
+      rep_->Mult(r_, z_);
+      linalg::AXPY(*ctx_, 1.0, z_, x);
+      return;
+    }
     PA_REQUIRE(ams_, "NativeAmsSolver: SetOperator first");
     ams_->SetInitialGuess(initial_guess);  // (the cycles of AmsSolver::Mult honour it in their first smoothing step)
     ams_->Mult(b, x);

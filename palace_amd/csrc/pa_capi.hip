@@ -381,8 +381,12 @@ static void free_sub(SubOp *so) {
 // after: an event the entries of x that take part in the halo exchange wait for (multi-rank applies, pa_op_mult_after): a
 // streaming block with interface batch lists runs its interior batches first; everything else simply waits up front
 // timing experiments (scripts/price_evec_cache.py): 1 = element kernel only, 2 = E^T run gather only (of the streaming form)
+#ifdef PA_ABLATION  // (the ablation library only, `make ablate`: the product library has no such switch)
 static int g_debug_phase = 0;
 extern "C" void pa_debug_apply_phase(int phase) { g_debug_phase = phase; }
+#else
+constexpr int g_debug_phase = 0;
+#endif
 
 static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStream_t s, bool masked = false,
                   int ess_policy = -1, hipEvent_t after = nullptr) {

@@ -592,11 +592,11 @@ int pa_replicated_coarse_create(pa_context *ctx, pa_par_op *level0, pa_interp *G
                                 int cycle_it, int singular, pa_solver **S) {
   return guarded([&] {
     PA_REQUIRE(ctx && level0 && level0->op && S && (!G || (G->op && xyz_true)), "null argument");
-    auto *s = new pa_solver;
+    auto s = std::make_unique<pa_solver>();  // (released only once the constructor below has not thrown)
     s->ctx = ctx;
     s->solver = std::make_unique<ReplicatedCoarseSolver>(ctx->ctx, *level0->op, G ? G->op.get() : nullptr, nv_true, xyz_true, dim,
                                                          cycle_it, singular != 0);
-    *S = s;
+    *S = s.release();
   });
 }
 static const AmgSolver &amg_of(const pa_solver *S, int which) {
