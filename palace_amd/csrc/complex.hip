@@ -342,7 +342,7 @@ ComplexWrapperOperator::ComplexWrapperOperator(const Context &ctx, const Operato
     const auto *li = dynamic_cast<const ceed::Operator *>(&pi->LocalOperator());
     const int ne = pr->NumEssentialTrueDofs();
     const int kind = (lr && li) ? ceed::Operator::ComplexFused(*lr, *li) : 0;
-    bool same = kind != 0 && ne == pi->NumEssentialTrueDofs() && (ne == 0 || (kind == 1 && pr->FusesEssential())) &&
+    bool same = kind != 0 && ne == pi->NumEssentialTrueDofs() && (ne == 0 || pr->FusesEssential()) &&  // (round 5: the dense form too)
                 (ne == 0 || pi->GetDiagonalPolicy() == ParOperator::DiagonalPolicy::DIAG_ZERO);
     if (same && ne) {  // the two lists, once
       std::vector<int32_t> a((size_t)ne), b((size_t)ne);
@@ -513,8 +513,9 @@ void ComplexParOperator::UpdateFused() {
   const auto *cr = dynamic_cast<const ceed::Operator *>(Ar_), *ci = dynamic_cast<const ceed::Operator *>(Ai_);
   const int kind = (!halo_ && cr && ci) ? ceed::Operator::ComplexFused(*cr, *ci) : 0;
   if (!kind) return;
-  // essential dofs inside the kernel: the hexahedral form only, and only if this wrapper's list is the one fused into Ar
-  if (n_ess_ && !(kind == 1 && RAPr_ && RAPr_->FusesEssential())) return;
+  // essential dofs inside the kernel (hexahedral form; round 5: dense blocks too, through the flagged index copy of Ar's block and
+  // its gathers): only if this wrapper's list is the one fused into Ar
+  if (n_ess_ && !(RAPr_ && RAPr_->FusesEssential())) return;
   fused_r_ = cr, fused_i_ = ci;
 }
 ComplexParOperator::~ComplexParOperator() {

@@ -999,13 +999,17 @@ int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double 
     const int kind = pa_op_complex_fused(op_r, op_i);
     PA_REQUIRE(kind, "the two operators have no fused complex form (pa_op_complex_fused)");
     PA_REQUIRE(xr != yr && xr != yi && xi != yr && xi != yi, "in-place apply is not supported");
-    if (kind == 2) {  // dense tables (tetrahedra, ...): plain form only
-      PA_REQUIRE(ess_policy < 0, "the complex form of dense blocks has no fused essential-dof handling (pa_op_complex_fused = 2)");
+    if (kind == 2) {  // dense tables (tetrahedra, ...)
       DenseSub *dr = op_r->dsubs[0];
+      // ParOperator's essential dofs (round 5): entries read as zero through the flagged index copy of the REAL operator, rows
+      // fixed by the two gathers -- yr[ess] = xr[ess] | 0, yi[ess] = xi[ess] | 0 (rap.cpp:450-457 on one rank, as the hex form)
+      const bool masked = ess_policy >= 0;
+      PA_REQUIRE(!masked || (op_r->has_essential && dr->d_idx_bc && dr->d_ess_flag),
+                 "pa_op_set_essential has not been called on the real operator");
       if (!dr->d_ye2) dr->d_ye2 = dev_alloc<double>((size_t)dr->nb * dr->KP * 64);
-      launch_dense_complex(*dr, *op_i->dsubs[0], xr, xi, dr->d_ye2, (hipStream_t)stream);
-      launch_dense_gather(*dr, yr, false, (hipStream_t)stream);
-      launch_dense_gather(*dr, yi, false, (hipStream_t)stream, dr->d_ye2);
+      launch_dense_complex(*dr, *op_i->dsubs[0], xr, xi, dr->d_ye2, (hipStream_t)stream, masked);
+      launch_dense_gather(*dr, yr, false, (hipStream_t)stream, nullptr, nullptr, masked ? xr : nullptr, ess_policy);
+      launch_dense_gather(*dr, yi, false, (hipStream_t)stream, dr->d_ye2, nullptr, masked ? xi : nullptr, ess_policy);
       return;
     }
     SubOp *sr = op_r->subs[0];

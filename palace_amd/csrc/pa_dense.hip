@@ -1880,9 +1880,11 @@ static void launch_resident_complex_pt(const DenseSub &dr, const DenseArgs &a, h
     hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, false, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);
 }
 
-void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s) {
+void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s,
+                          bool masked) {
   DenseArgs a = make_args(dr);
   a.x = xr, a.x1 = xi, a.ye1 = ye_i;
+  if (masked && dr.d_idx_bc) a.idx = dr.d_idx_bc;  // essential entries of both parts read as zero
   a.qdata_i = di.d_qdata, a.ncq_i = di.ncq;
   a.qi_mass = di.mode == MODE_CURL ? -1 : 0;
   a.qi_curl = di.mode == MODE_CURL ? 0 : (di.mode == MODE_CURLMASS ? 6 : -1);

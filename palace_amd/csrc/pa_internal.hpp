@@ -335,7 +335,8 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
                          const SplitIO *split = nullptr, const double *x = nullptr, int ess_policy = -1);
 bool dense_split_ok(const DenseSub &ds);
 bool dense_complex_ok(const DenseSub &dr, const DenseSub &di);
-void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s);
+void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s,
+                          bool masked = false);
 void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s);
 void launch_et_gather_raw(int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y,
                           bool accumulate, hipStream_t s, const int32_t *list = nullptr, const double *x = nullptr,
