@@ -702,11 +702,11 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   else if (!a.blist) a.nbatch = (so.ne + 3) / 4;  // (else: the length of the list, set by the caller)
   if (a.nbatch == 0) return;
   a.chunk = (a.nbatch + 7) / 8;
-  // Few rounds (the per-rank size of a strong-scaling run: 490 batches per XCD over 384 resident waves = 1.28 rounds): size the grid so
-  // that every wave walks the SAME number of batches -- 245 waves x 2 instead of 106 x 2 + 278 x 1: the critical path is two batches
-  // either way, but fewer waves compete for the memory system while it runs (PALACE_AMD_STREAM_BALANCE=0: the full grid; =N: balance
-  // up to N rounds, default 3).  Many rounds (the bench size: 10.2): the full grid, as before.
-  static const int balance = getenv("PALACE_AMD_STREAM_BALANCE") ? atoi(getenv("PALACE_AMD_STREAM_BALANCE")) : 3;
+  // Few rounds (the per-rank size of a strong-scaling run: 490 batches per XCD over 384 resident waves = 1.28 rounds): the grid can
+  // be sized so that every wave walks the SAME number of batches -- 245 waves x 2 instead of 106 x 2 + 278 x 1
+  // (PALACE_AMD_STREAM_BALANCE=N: balance up to N rounds).  Measured neutral on the 1/8 slab (round 5, profiles/r05_halo_proxy.log:
+  // local apply 29.0 against 29.1 us, ParOperator::Mult 45.3 both): the critical path is two batches either way.  Default off.
+  static const int balance = getenv("PALACE_AMD_STREAM_BALANCE") ? atoi(getenv("PALACE_AMD_STREAM_BALANCE")) : 0;
   const int max_waves = per_xcd * kWavesPerBlock;
   int waves = std::min(max_waves, a.chunk);
   const int rounds = (a.chunk + max_waves - 1) / max_waves;
