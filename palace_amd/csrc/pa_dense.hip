@@ -120,6 +120,7 @@ struct DenseArgs {
   int ne, nb, P, Q, Qpad, nch, KP;
   const int32_t *idx;
   const uint16_t *co;  // 2-bit fields {sub, main, super} of row d of T_e and {T[d-1][d], T[d+1][d]} of column d
+  const uint32_t *co2; // the same, the words of dof slots 2 s and 2 s + 1 of a lane in one register: [nb][KP / 2][64] (resident kernel)
   const double *geom;
   const double *qw;     // quadrature weights (2-D curl-curl)
   int contra;           // vector mass with the contravariant map of H(div) values (f_apply_hdiv_22 | _32 | _21 | _31: AdjJt of the
@@ -160,6 +161,11 @@ __device__ __forceinline__ const double *dense_ghosts(const DenseArgs &a) {
 // 2-bit two's-complement field k of a packed curl-orientation word: -1, 0 or 1
 __device__ __forceinline__ double co_field(const int c, const int k) {
   return (double)((c << (30 - 2 * k)) >> 30);
+}
+
+// the same from a register holding two 16-bit words (word `odd` = 0 | 1): the left shift drops the other word's bits
+__device__ __forceinline__ double co_field_pk(const unsigned w, const int odd, const int k) {
+  return (double)(((int)(w << (30 - 2 * k - 16 * odd))) >> 30);
 }
 
 // The pointwise D stage on the NCT components of one quadrature point (in place).
@@ -545,7 +551,10 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
   constexpr int NCT = M::NCT, KPMAX = 4 * PT, NF = F0::NF, S = ResidentStride<PT>::S;
   [[maybe_unused]] constexpr int NQ0 = F0::NC == 3 ? 6 : (F0::NC == 2 ? 3 : 1), NQ1 = F1::NC == 3 ? 6 : (F1::NC == 2 ? 3 : 1);
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave number as a scalar: block numbers and with them the bases of the index / orientation / q-data / E-vector rows
+  // live in SGPRs, the lanes add a 32-bit offset -- as 64-bit per-lane pointers they cost the registers whose spill put a
+  // scratch reload + vmcnt(0) between the index prefetch and the matrix products)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   constexpr int KP = 4 * PT;  // the host pads every element block to 4 PT dof slots
   const int woff = (a.Q4 + 31) / 32 * 32;  // relative quadrature weights first (a multiple of 32 doubles: L keeps its banks)
@@ -558,8 +567,6 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
     for (int i = tid; i < n; i += 64 * NW) L[i] = a.L[i];
   }
   __syncthreads();
-  const double *Lf = L + j * S + kq;   // forward operand of this lane:   row 16 t + i, column 4 s + kq
-  const double *Lb = L + kq * S + j;   // transposed operand of this lane: row 4 pi + kq, column 16 pt + i
   const size_t cs = (size_t)a.Q4 * kEB;
   const int ngroups = a.Q4 / 4;
   // work units: element blocks, or (CPLX) half blocks -- unit w is columns 8 (w & 1) .. + 7 of block w >> 1, and lane (kq, j)
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
   // vector registers go to the accumulation registers, which two waves per SIMD leave free)
   double qdn[4][6];
   double qdi[CPLX ? 2 : 1][6];  // complex form: point-0 D of the imaginary operator {mass, curl-curl}
-  int con[PREFETCH_X ? KPMAX : 1];
+  unsigned con[PREFETCH_X ? KPMAX / 2 : 1];  // (two 16-bit words per register: a.co2)
   // first chunk of field 0 of unit w, or for an affine block the point-0 values of both fields (raw, scaled at use)
   auto request_qd = [&](const int w, double (&out)[4][6]) {
     const double *qb = a.qdata + ublock(w) * a.ncq * cs;
@@ -622,15 +629,17 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
   };
   if (PREFETCH_IDX) {
     const int b0 = blockIdx.x * NW + wave, w0 = b0 < nunits ? b0 : 0;
-    const int32_t *idx0 = a.idx + ublock(w0) * KP * 64 + ulane(w0);
+    // (uniform row base + 32-bit lane offset: the address stays "SGPR pair + VGPR", nothing per lane to keep across the loop)
+    const int32_t *idx0 = a.idx + ublock(w0) * KP * 64;
+    const unsigned l0 = (unsigned)ulane(w0);
 #pragma unroll
-    for (int s = 0; s < KPMAX; s++) sgn[s] = (s < KP) ? idx0[s * 64] : 0;
+    for (int s = 0; s < KPMAX; s++) sgn[s] = (s < KP) ? idx0[s * 64u + l0] : 0;
     if (PREFETCH_X) {
       gather_x(sgn, un);
       request_qd(w0, qdn);
-      if (a.co) {
+      if (a.co2) {
 #pragma unroll
-        for (int s = 0; s < KPMAX; s++) con[s] = a.co[ublock(w0) * KP * 64 + s * 64 + ulane(w0)];
+        for (int s = 0; s < KPMAX / 2; s++) con[s] = (a.co2 + ublock(w0) * (KP / 2) * 64)[s * 64u + (unsigned)ulane(w0)];
       }
     }
   }
@@ -675,11 +684,18 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
         for (int k = 0; k < NQ0; k++) qd[gl][k] = qdn[gl][k];
     }
 #ifdef PA_ABLATION
-    const uint16_t *co = (a.co && !(a.dbg & 16)) ? a.co + bb * KP * 64 : nullptr;
+    const bool co = a.co2 && !(a.dbg & 16);
 #else
-    const uint16_t *co = a.co ? a.co + bb * KP * 64 : nullptr;
+    const bool co = a.co2 != nullptr;
 #endif
+    // this block's curl-orientation words, two per register, kept for E^T: re-reading them from memory there put twelve
+    // load -> wait -> store round trips behind the x gather of the NEXT block (one in-order counter for loads and stores),
+    // i.e. the whole latency the software pipeline exists to hide was paid once per block (round 5, found in the ISA;
+    // stage ablation: 39 of 139 us)
+    unsigned cpk[KPMAX / 2];
     if (co) {
+#pragma unroll
+      for (int s = 0; s < KPMAX / 2; s++) cpk[s] = PREFETCH_X ? con[s] : (a.co2 + bb * (KP / 2) * 64)[s * 64u + (unsigned)gln];
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
         if (s < KP) sm[s * 64 + lane] = u[s];
@@ -687,12 +703,12 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
 #pragma unroll
       for (int s = 0; s < KPMAX; s++) {
         if (s < KP) {
-          const int c = PREFETCH_X ? con[s] : (int)co[s * 64 + gln];
+          const unsigned c = cpk[s >> 1];
           const int dof = 4 * s + kq;
           // out-of-range neighbours have a zero coefficient: clamp the address instead of branching
           const double lo = sm[max(dof - 1, 0) * 16 + j];
           const double hi = sm[min(dof + 1, 4 * KP - 1) * 16 + j];
-          u[s] = co_field(c, 0) * lo + co_field(c, 1) * u[s] + co_field(c, 2) * hi;
+          u[s] = co_field_pk(c, s & 1, 0) * lo + co_field_pk(c, s & 1, 1) * u[s] + co_field_pk(c, s & 1, 2) * hi;
         }
       }
       wave_sync();
@@ -711,13 +727,18 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
         for (int k = 0; k < 6; k++) qdic[f][k] = qdi[f][k];
     }
     if (PREFETCH_IDX) {  // its index words
-      const int32_t *idxn = a.idx + ublock(bnc) * KP * 64 + ulane(bnc);
+      // (the lane offset through an opaque copy: hoisted out of the loop as 64-bit per-lane pointers these two addresses were
+      // spilled, and their scratch reload put a vmcnt(0) between the index prefetch and the matrix products)
+      int ln = ulane(bnc);
+      asm volatile("" : "+v"(ln));
+      const int32_t *idxn = a.idx + ublock(bnc) * KP * 64 + ln;
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
         if (s < KP) sgn[s] = idxn[s * 64];
       if (PREFETCH_X && co) {
+        const uint32_t *con_n = a.co2 + ublock(bnc) * (KP / 2) * 64 + ln;
 #pragma unroll
-        for (int s = 0; s < KPMAX; s++) con[s] = a.co[ublock(bnc) * KP * 64 + s * 64 + ulane(bnc)];
+        for (int s = 0; s < KPMAX / 2; s++) con[s] = con_n[s * 64];
       }
     }
 
@@ -731,6 +752,12 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
 #else
     const int nch_eff = a.nch;
 #endif
+    // (the table addresses of this lane re-derived from an opaque copy of the lane id: kept across the E / E^T stages they are
+    // what the register allocator spills, and a scratch reload here waits -- one in-order counter -- for the index prefetch)
+    int lo_ = lane;
+    asm volatile("" : "+v"(lo_));
+    const double *Lf = L + (lo_ & 15) * S + (lo_ >> 4);  // forward operand of this lane:   row 16 t + i, column 4 s + kq
+    const double *Lb = L + (lo_ >> 4) * S + (lo_ & 15);  // transposed operand of this lane: row 4 pi + kq, column 16 pt + i
     for (int c = 0; c < nch_eff; c++) {
       const int r0 = c * NCT * 16;
       if (AFFINE) {
@@ -787,9 +814,9 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
       for (int s = 0; s < KPMAX; s++) {
         if (s < KP) {
           const int dof = 4 * s + kq;
-          const int cm = co[s * 64 + gln];
-          ye[s * 64 + gln] = co_field(cm, 1) * yacc[s >> 2][s & 3] + co_field(cm, 3) * sm[max(dof - 1, 0) * 16 + j] +
-                             co_field(cm, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
+          const unsigned cm = cpk[s >> 1];
+          ye[s * 64 + gln] = co_field_pk(cm, s & 1, 1) * yacc[s >> 2][s & 3] + co_field_pk(cm, s & 1, 3) * sm[max(dof - 1, 0) * 16 + j] +
+                             co_field_pk(cm, s & 1, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
         }
       }
       wave_sync();
@@ -1324,7 +1351,7 @@ __global__ void dense_affine_kernel(const int nb, const int ncq, const int Q, co
 DenseArgs make_args(const DenseSub &ds) {
   DenseArgs a;
   a.ne = ds.ne, a.nb = ds.nb, a.P = ds.P, a.Q = ds.Q, a.Qpad = ds.Qpad, a.nch = ds.nch, a.KP = ds.KP;
-  a.idx = ds.d_idx, a.co = ds.d_co, a.geom = ds.geom->d_geom, a.qw = ds.geom->d_qw, a.Tf = ds.d_Tf, a.Tt = ds.d_Tt;
+  a.idx = ds.d_idx, a.co = ds.d_co, a.co2 = ds.d_co2, a.geom = ds.geom->d_geom, a.qw = ds.geom->d_qw, a.Tf = ds.d_Tf, a.Tt = ds.d_Tt;
   a.contra = ds.contra ? 1 : 0;
   a.L = ds.d_L, a.qdata = ds.d_qdata, a.ncq = ds.ncq, a.Q4 = (ds.Q + 3) / 4 * 4;
   a.affine = ds.d_affine, a.wrel = ds.d_wrel;
@@ -1506,7 +1533,16 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
     }
   }
   ds->d_idx = dev_upload(idx.data(), nslot);
-  if (r.curl_orients) ds->d_co = dev_upload(co.data(), nslot);
+  if (r.curl_orients) {
+    ds->d_co = dev_upload(co.data(), nslot);
+    // the resident kernel takes the words of slots 2 s, 2 s + 1 of a lane together (half the loads and registers)
+    std::vector<uint32_t> co2(nslot / 2);
+    for (size_t b = 0; b < (size_t)nb; b++)
+      for (int s2 = 0; s2 < KP / 2; s2++)
+        for (int l = 0; l < 64; l++)
+          co2[(b * (KP / 2) + s2) * 64 + l] = (uint32_t)co[(b * KP + 2 * s2) * 64 + l] | ((uint32_t)co[(b * KP + 2 * s2 + 1) * 64 + l] << 16);
+    ds->d_co2 = dev_upload(co2.data(), co2.size());
+  }
   ds->h_co = co;
   // transpose map for the gather form of E^T (counting sort by dof, element order preserved)
   {
@@ -1769,7 +1805,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
 void free_dense_sub(DenseSub *ds) {
   if (ds) hipFree(ds->d_affine), hipFree(ds->d_wrel), hipFree(ds->d_ye2), hipFree(ds->d_blist[0]), hipFree(ds->d_blist[1]);
   if (!ds) return;
-  hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co), hipFree(ds->d_ess_flag);
+  hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co), hipFree(ds->d_co2), hipFree(ds->d_ess_flag);
   hipFree(ds->d_Tf), hipFree(ds->d_Tt), hipFree(ds->d_interp), hipFree(ds->d_deriv);
   hipFree(ds->d_L), hipFree(ds->d_qdata);
   hipFree(ds->d_off), hipFree(ds->d_cor), hipFree(ds->d_ori);
