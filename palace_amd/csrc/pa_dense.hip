@@ -31,6 +31,10 @@
 #include "pa_device.hpp"
 #include "pa_internal.hpp"
 
+#ifndef PA_DENSE_XEARLY
+#define PA_DENSE_XEARLY 0
+#endif
+
 namespace pa {
 
 namespace {
@@ -529,7 +533,10 @@ __device__ __forceinline__ void load_qd6(const double *__restrict__ q, const int
 
 // AFFINE: every block consists of elements with a constant Jacobian (dense_affine_kernel): the D of a point is the D of point 0
 // times the relative quadrature weight -- 6 values per field and element instead of 6 Q, and no q-data registers to rotate.
-constexpr int kAffWaves = 12;  // the affine form needs fewer registers: three waves per SIMD
+#ifndef PA_DENSE_AFF_WAVES
+#define PA_DENSE_AFF_WAVES 12
+#endif
+constexpr int kAffWaves = PA_DENSE_AFF_WAVES;  // the affine form needs fewer registers: three waves per SIMD
 // CPLX (curl-curl + mass blocks, all affine or all curved): y = (A_r + i A_i) x for two operators on the same space and geometry.  A work unit is half
 // an element block: the 16 element columns of the matrix-core products carry 8 elements x {real, imaginary} part of x; both
 // parts read the element's index words and the D of both operators (one HBM read), the tables in LDS serve both as before,
@@ -585,6 +592,11 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
   // are done (the q-data registers are free then) so that they fly during the E^T stores; a block starts with its
   // operands in registers instead of two dependent memory round trips.
   constexpr bool PREFETCH_IDX = KPMAX <= 16, PREFETCH_X = KPMAX <= 12;
+  // XEARLY (experiment builds, -DPA_DENSE_XEARLY=1): x of the next block requested BEFORE the matrix products of the current one,
+  // the index words two blocks ahead.  Measured in round 5 on 280k tets (profiles/r05_dense_ab.log): at twelve waves per
+  // workgroup the 24 extra live registers spill (0.190 / 0.286 ms against 0.183 / 0.265), at eight waves it equals the
+  // one-block distance at twelve (0.183 / 0.268): the kernel is not waiting for x.  Default off.
+  constexpr bool XEARLY = PREFETCH_X && AFFINE && !CPLX && (PA_DENSE_XEARLY != 0);
   int sgn[PREFETCH_IDX ? KPMAX : 1];
   double un[PREFETCH_X ? KPMAX : 1];
   // likewise the first chunk of q-data and the curl-orientation words of the next block (values the compiler cannot hold in
@@ -640,6 +652,13 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
       if (a.co2) {
 #pragma unroll
         for (int s = 0; s < KPMAX / 2; s++) con[s] = (a.co2 + ublock(w0) * (KP / 2) * 64)[s * 64u + (unsigned)ulane(w0)];
+      }
+      if (XEARLY) {  // index words of the second block of this wave (clamped): its x is requested inside the first iteration
+        const int b1 = b0 + (int)gridDim.x * NW, w1 = b1 < nunits ? b1 : w0;
+        const int32_t *idx1 = a.idx + ublock(w1) * KP * 64;
+        const unsigned l1 = (unsigned)ulane(w1);
+#pragma unroll
+        for (int s = 0; s < KPMAX; s++) sgn[s] = (s < KP) ? idx1[s * 64u + l1] : 0;
       }
     }
   }
@@ -726,12 +745,18 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
 #pragma unroll
         for (int k = 0; k < 6; k++) qdic[f][k] = qdi[f][k];
     }
+    // XEARLY: the x values of the NEXT block are requested here, before the matrix products (they fly during the products instead of
+    // during the short E^T stage; its index words were requested one block earlier still, so the index prefetch below runs two
+    // blocks ahead)
+    if (XEARLY) gather_x(sgn, un);
     if (PREFETCH_IDX) {  // its index words
       // (the lane offset through an opaque copy: hoisted out of the loop as 64-bit per-lane pointers these two addresses were
       // spilled, and their scratch reload put a vmcnt(0) between the index prefetch and the matrix products)
       int ln = ulane(bnc);
       asm volatile("" : "+v"(ln));
-      const int32_t *idxn = a.idx + ublock(bnc) * KP * 64 + ln;
+      const int bn2 = bn + (int)gridDim.x * NW;
+      const int bic = XEARLY ? (bn2 < nunits ? bn2 : bnc) : bnc;  // whose index words: two blocks ahead with XEARLY
+      const int32_t *idxn = a.idx + ublock(bic) * KP * 64 + (XEARLY ? ulane(bic) : ln);
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
         if (s < KP) sgn[s] = idxn[s * 64];
@@ -794,8 +819,8 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
       }
     }
 
-    if (PREFETCH_X) {  // x and the first q-data chunk of the next block (its index words arrived during the products)
-      gather_x(sgn, un);
+    if (PREFETCH_X) {  // the first q-data chunk of the next block (and its x values, unless they were requested before the products)
+      if (!XEARLY) gather_x(sgn, un);
       request_qd(bnc, qdn);
     }
 
