@@ -793,3 +793,53 @@ class NDTetBoundaryBlock:
     def jacobians(self, x):
         """J[e, q, i, d]: 3 x 2."""
         return np.einsum("dqn,eni->eqid", self.geometry_grad_table(x), self.nodes[self.elem_nodes])
+
+
+class H1TetBoundaryBlock:
+    """The boundary-element block of an H1TetSpace over a set of faces (surface DiffusionIntegrator of the auxiliary-space
+    operators, spaceoperator.cpp:318-330 AddAuxIntegrators): nodal H1 triangles in 3-D space whose dofs are the tetrahedral
+    space's vertex / edge / face dofs.  Triangle vertices in ascending global order (the frame the space numbers its face nodes
+    in), plain restriction."""
+
+    def __init__(self, space: H1TetSpace, faces, attr=None):
+        from . import tri
+
+        mesh, p = space.mesh, space.p
+        self.space, self.faces = space, np.asarray(faces, dtype=np.int64)
+        fv = mesh.face_verts[self.faces]
+        self.ne = fv.shape[0]
+        self.elem = tri.H1TriElement(p)
+        self.P = self.elem.P
+        n_e, n_f = p - 1, (p - 1) * (p - 2) // 2
+        ekey = {tuple(e): i for i, e in enumerate(map(tuple, mesh.edge_verts))}
+        off = np.zeros((self.ne, self.P), dtype=np.int64)
+        off[:, :3] = fv
+        for k, (a, b) in enumerate(tri.LOCAL_EDGES):
+            flip = a > b  # local vertices are in ascending global order: the space counts edge nodes from the smaller vertex
+            ge = np.array([ekey[(min(f[a], f[b]), max(f[a], f[b]))] for f in fv]) if self.ne else np.zeros(0, dtype=np.int64)
+            for i in range(n_e):
+                off[:, 3 + k * n_e + i] = space.edge_base + ge * n_e + (n_e - 1 - i if flip else i)
+        if n_f:
+            fb = _interior_lattice(2, p, p - 3)
+            key = {tuple(np.round(np.array(l) * p).astype(int)): m for m, l in enumerate(fb)}
+            m = 0
+            for jj in range(1, p):          # H1TriElement's interior nodes: (i / p, j / p), barycentric (p - i - j, i, j) / p
+                for ii in range(1, p - jj):
+                    off[:, 3 + 3 * n_e + m] = space.face_base + self.faces * n_f + key[(p - ii - jj, ii, jj)]
+                    m += 1
+        self.offsets = off.astype(np.int32)
+        self.attr = np.ones(self.ne, dtype=np.int32) if attr is None else np.asarray(attr, dtype=np.int32)
+        assert mesh.mesh_order == 1, "H1TetBoundaryBlock: straight-sided meshes"
+        self.nodes, self.elem_nodes = mesh.verts, fv
+
+    def geometry_grad_table(self, x):
+        from . import tri
+
+        return tri.TriMesh.geometry_grad_table(self, x)
+
+    @property
+    def mesh_order(self):
+        return 1
+
+    def jacobians(self, x):
+        return np.einsum("dqn,eni->eqid", self.geometry_grad_table(x), self.nodes[self.elem_nodes])

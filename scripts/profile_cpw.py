@@ -4,8 +4,9 @@ import json
 import os
 import sys
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
-out = bench.cpw_leg(int(os.environ.get("ORDER", "3")), int(os.environ.get("REFINE", "1")))
+leg = bench.cpw_iso_leg if os.environ.get("ISO") else bench.cpw_leg  # ISO=1: the surrogate isotropic leg of rounds 3-4
+out = leg(int(os.environ.get("ORDER", "3")), int(os.environ.get("REFINE", "1")))
 print("cpw:", json.dumps({k: v for k, v in out.items() if k != "workload"}), flush=True)

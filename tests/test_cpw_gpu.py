@@ -160,3 +160,87 @@ def test_cpw_driven_solver_with_native_ams_and_refinement():
     assert np.linalg.norm(sols[0] - sols[1]) < 1e-6 * np.linalg.norm(sols[1])
     assert its[0] <= 1.5 * its[1] + 5, its  # the one-cycle AMS coarse solve is not far from the converged PCG one
     print("cpw p=2 FGMRES iterations: AMS", its[0], " Jacobi-PCG(1e-3)", its[1])
+
+
+# reference values: test/data/regression/ref/cpw/lumped_uniform/port-S.csv, first row (2 GHz), excitation 1:
+# |S[j][1]| in dB and arg(S[j][1]) in degrees for j = 1..4 (the reference's regression gate: rtol 2e-2 per column)
+PORT_S_2GHZ = {1: (-1.701793831224e+01, -1.148548267446e+02), 2: (-8.860531101837e-02, -2.478868071247e+01),
+               3: (-5.250206957228e+01, +6.419829438631e+01), 4: (-6.287205660151e+01, +4.353831980561e+01)}
+
+
+def test_cpw_lumped_uniform_as_the_reference_defines_it():
+    """examples/cpw/cpw_lumped_uniform.json on the reference's mesh and order (14 628 tet4, ND p = 2): sapphire tensors, first-order
+    absorbing boundary, four resistive lumped ports (surface f_apply_hcurl_32 terms in the imaginary part), PEC trace, uniform port
+    excitation, 2 GHz.  (1) the device's complex operator against the oracle's volume and surface operators, 1e-12;
+    (2) FGMRES + Hiptmair p-multigrid + AMS converges to 1e-8; (3) S[1..4][1] from the device solution against the one published pin
+    of this configuration, port-S.csv (the reference gates each dB / degree column at rtol 2e-2)."""
+    from oracle import palace_oracle as po
+    from palace_amd import linalg
+    from palace_amd.fem import tet
+    from palace_amd.fem.tetproblem import CPW_LUMPED_UNIFORM, DrivenReferenceSystem, TetProblem
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cpw_mesh.npz"))
+    mesh = tet.TetMesh(d["verts"], d["tets"], d["attr"], bdr_tris=d["bdr_tris"], bdr_attr=d["bdr_attr"])
+    ctx = linalg.Context()
+    prob = TetProblem(ctx, mesh, 2)
+    ds = DrivenReferenceSystem(prob, 2.0, CPW_LUMPED_UNIFORM, rel_tol=1e-10, max_it=400)
+    nd, n, k0 = ds.nd, ds.n, ds.k0
+    # port geometry as lumpedelement.cpp derives it from the bounding boxes: 18 um squares, two elements per port
+    for e in ds.port_elems.values():
+        assert abs(e["width"] - 18.0) < 1e-9 and abs(e["length"] - 18.0) < 1e-9
+        assert abs(e["Rs"] - 56.02 / 376.730313668 * 2.0) < 1e-12
+    # ---- (1) operator parity: oracle volume operators (tensor coefficients) + oracle surface mass
+    pts, wts = prob.pts, prob.wts
+    interp, curl = nd.elem.tables(pts)
+    J = mesh.jacobians(pts)
+    og = po.build_geom_factor_33(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 9))
+    okw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+    v = ds._vol
+    o_r = po.CeedOperatorOracle(n, nd.offsets, None, interp, curl, og, po.QF_HDIVMASS,
+                                po.CoeffCtx(attr_mat=v["amap"], mat_coeff=[-k0 ** 2 * m for m in v["eps"]]),
+                                po.CoeffCtx(attr_mat=v["amap"], mat_coeff=v["mu_inv"]), **okw)
+    o_iv = po.CeedOperatorOracle(n, nd.offsets, None, interp, curl, og, po.QF_HCURL,
+                                 po.CoeffCtx(attr_mat=v["amap"], mat_coeff=[k0 ** 2 * m for m in v["eps_tand"]]), **okw)
+    sint, scurl = ds.sblk.elem.tables(ds.spts)
+    Js = ds.sblk.jacobians(ds.spts)
+    ogs = po.build_geom_factor_32(ds.sblk.attr.astype(np.float64), ds.swts, np.transpose(Js, (0, 1, 3, 2)).reshape(ds.sblk.ne, -1, 6))
+    o_is = po.CeedOperatorOracle(n, ds.sblk.offsets, ds.sblk.orients, sint, scurl, ogs, po.QF_HCURL_32,
+                                 po.CoeffCtx(attr_mat=list(range(len(ds.scoef))), mat_coeff=[k0 * c for c in ds.scoef]))
+    ess = ds.ess
+    rng = np.random.default_rng(5)
+    xr, xi = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+
+    def o_complex(vr, vi):
+        mr, mi = vr.copy(), vi.copy()
+        mr[ess], mi[ess] = 0.0, 0.0
+        z = np.zeros(n)
+        ai = lambda w: o_iv.apply_add(w, z.copy()) + o_is.apply_add(w, z.copy())  # noqa: E731
+        wr = o_r.apply_add(mr, z.copy()) - ai(mi)
+        wi = o_r.apply_add(mi, z.copy()) + ai(mr)
+        wr[ess], wi[ess] = vr[ess], vi[ess]
+        return wr, wi
+
+    wr, wi = o_complex(xr, xi)
+    yr, yi = torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
+    ds.A.mult(_dev(xr), _dev(xi), yr, yi)
+    err = np.linalg.norm(np.concatenate([yr.cpu().numpy() - wr, yi.cpu().numpy() - wi])) / np.linalg.norm(np.concatenate([wr, wi]))
+    assert err < 1e-12, err
+    # ---- (2) the solve, excitation 1
+    br, bi = ds.excitation(1)
+    assert float(bi.abs().max()) > 0.0
+    sr, si = torch.zeros_like(br), torch.zeros_like(br)
+    ds.solver.mult(br, bi, sr, si)
+    st = ds.solver.stats()
+    assert st["converged"], st
+    # the residual of the device solution in the ORACLE's operator
+    ar, ai_ = o_complex(sr.cpu().numpy(), si.cpu().numpy())
+    res = np.linalg.norm(np.concatenate([ar - br.cpu().numpy(), ai_ - bi.cpu().numpy()])) / float(torch.sqrt(bi @ bi))
+    assert res < 1e-8, res
+    # ---- (3) S-parameters against port-S.csv
+    S = ds.s_parameters(sr, si, excited=1)
+    got = {j: (20.0 * np.log10(abs(s)), np.degrees(np.angle(s))) for j, s in S.items()}
+    print("S[j][1] (dB, deg):", got, "iterations", st["iterations"])
+    for j, (db, deg) in PORT_S_2GHZ.items():
+        assert abs(got[j][0] - db) <= 2.0e-2 * abs(db) + 1e-11, (j, got[j], (db, deg))
+        dphi = (got[j][1] - deg + 180.0) % 360.0 - 180.0
+        assert abs(dphi) <= 2.0e-2 * abs(deg) + 1e-11, (j, got[j], (db, deg))
