@@ -177,6 +177,7 @@ struct SubOp {
   int32_t *d_shared = nullptr;   // list of the dofs the gather kernel still has to sum
   int32_t *d_shared_bc = nullptr;  // the same with kEssBit on essential dofs (pa_op_set_essential)
   std::vector<int32_t> h_shared;
+  std::vector<char> h_price_skip;  // pricing experiment only (PALACE_AMD_PRICE_BLOCK): E-vector entries taken off the gather
   int n_shared = 0;
   std::vector<uint16_t> h_perm;
   std::vector<int32_t> h_sidx;   // host copy (needed to build d_sidx_bc)

@@ -542,6 +542,40 @@ void build_stream(SubOp &so) {
   } else if (!streamhost::pack_index(ne, P, so.lsize, so.h_sidx.data(), so.h_perm.data(), ic, pp,
                                      so.fe_type == PA_FE_H1 ? streamhost::kIdxStart0H1 : streamhost::kIdxStart0))
     return;
+  // PRICING EXPERIMENT (wrong results, right bytes; never set in product runs): PALACE_AMD_PRICE_BLOCK=G with G = 4 (the elements of
+  // one wave) or 8 (of one workgroup) prices an E-vector in which the copies of a dof inside a group of G consecutive elements
+  // are assembled on chip before the store: every copy but the group's first is taken off the E-vector (its store goes
+  // straight to y instead, like an exclusive dof's) and out of the run lists; a dof whose copies all sit in one group leaves
+  // the gather altogether.  What is NOT priced: the LDS traffic and barrier of the on-chip assembly itself.
+  const int price_group = (so.fe_type == PA_FE_HCURL && !wide_form(so) && getenv("PALACE_AMD_PRICE_BLOCK")) ? atoi(getenv("PALACE_AMD_PRICE_BLOCK")) : 0;
+  if (price_group > 1) {
+    const size_t nnz = (size_t)ne * P;
+    const int npl = (P + 15) / 16, npk = (npl + 3) / 4;
+    so.h_price_skip.assign(nnz, 0);
+    std::vector<int32_t> seen((size_t)so.lsize, -1), cnt((size_t)so.lsize, 0), cnt2((size_t)so.lsize, 0);
+    for (size_t k = 0; k < nnz; k++) {
+      const int d = streamhost::dof_of(so.h_sidx[k]), g = (int)(k / P) / price_group;
+      cnt[d]++;
+      if (seen[d] == g) so.h_price_skip[k] = 1; else seen[d] = g, cnt2[d]++;
+    }
+    size_t dropped = 0, freed = 0;
+    for (size_t k = 0; k < nnz; k++) {
+      const int d = streamhost::dof_of(so.h_sidx[k]);
+      const bool direct = so.h_price_skip[k] || (cnt2[d] == 1 && cnt[d] > 1);
+      if (!direct) continue;
+      const size_t e = k / P;
+      const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
+      pp[(e * (npk + 1) + npk) * 16 + t] |= 2u << (2 * r);
+      dropped += so.h_price_skip[k] ? 1 : 0, freed += so.h_price_skip[k] ? 0 : 1;
+    }
+    std::vector<int32_t> shared2;
+    for (int d = 0; d < so.lsize; d++)
+      if (cnt2[d] > 1) shared2.push_back(d);
+    fprintf(stderr, "PALACE_AMD_PRICE_BLOCK=%d: %zu of %zu E-vector entries dropped, %zu more leave the gather; shared dofs %zu -> %zu\n",
+            price_group, dropped, nnz, freed, so.h_shared.size(), shared2.size());
+    so.h_shared = shared2;
+    so.n_shared = (int)shared2.size();
+  }
   so.h_perm_s = pp;
   if (so.fe_type == PA_FE_HCURL && !wide_form(so)) {
     // four-point H(curl) kernel: flag words on their own, slot words through the pattern dictionary (pa_internal.hpp)
@@ -571,7 +605,8 @@ void build_stream(SubOp &so) {
   std::vector<uint32_t> code;
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
-  streamhost::build_runs(ne, P, so.lsize, so.h_sidx.data(), so.h_shared, code, hdr, rpos);
+  streamhost::build_runs(ne, P, so.lsize, so.h_sidx.data(), so.h_shared, code, hdr, rpos, nullptr,
+                         so.h_price_skip.empty() ? nullptr : so.h_price_skip.data());
   {
     const std::vector<RunChunk> ch = streamhost::run_chunks(code);
     so.d_rchunk = dev_upload(reinterpret_cast<const uint32_t *>(ch.data()), 4 * ch.size());
@@ -621,12 +656,18 @@ void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   for (size_t k = 0; k < nnz; k++) count[streamhost::dof_of(so.h_sidx[k])]++;
   std::vector<int32_t> shared;
   shared.reserve(so.h_shared.size());
+  if (!so.h_price_skip.empty()) {  // (pricing experiment: copies taken off the E-vector are not copies)
+    std::fill(count.begin(), count.end(), 0);
+    for (size_t k = 0; k < nnz; k++)
+      if (!so.h_price_skip[k]) count[streamhost::dof_of(so.h_sidx[k])]++;
+  }
   for (int d = 0; d < so.lsize; d++)
     if (count[d] != 1 || flag[d]) shared.push_back(d);
   std::vector<uint32_t> code;
   std::vector<RunHdr> hdr;
   std::vector<int32_t> rpos;
-  streamhost::build_runs(so.ne, P, so.lsize, so.h_sidx.data(), shared, code, hdr, rpos, flag.data());  // (runs: all essential or none)
+  streamhost::build_runs(so.ne, P, so.lsize, so.h_sidx.data(), shared, code, hdr, rpos, flag.data(),  // (runs: all essential or none)
+                         so.h_price_skip.empty() ? nullptr : so.h_price_skip.data());
   hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc), hipFree(so.d_rchunk_bc);
   {
     const std::vector<RunChunk> ch = streamhost::run_chunks(code);

@@ -179,14 +179,17 @@ inline bool pack_index_wide(int ne, int P, int lsize, const int32_t *sidx, const
 //   lanes per run)
 inline void build_runs(int ne, int P, int lsize, const int32_t *sidx, const std::vector<int32_t> &shared,
                        std::vector<uint32_t> &code, std::vector<RunHdr> &hdr, std::vector<int32_t> &rpos,
-                       const char *ess = nullptr) {
+                       const char *ess = nullptr, const char *skip = nullptr) {
+  // (skip: entries that are not copies -- the pricing experiment of PALACE_AMD_PRICE_BLOCK, pa_nd_hex_stream.hip: build_stream)
   if (lsize > (int)kRunDofMask) throw std::runtime_error("too many local dofs for the run headers");
   const size_t nnz = (size_t)ne * P;
   std::vector<int32_t> tptr((size_t)lsize + 1, 0);
-  for (size_t k = 0; k < nnz; k++) tptr[(size_t)dof_of(sidx[k]) + 1]++;
+  for (size_t k = 0; k < nnz; k++)
+    if (!skip || !skip[k]) tptr[(size_t)dof_of(sidx[k]) + 1]++;
   for (int d = 0; d < lsize; d++) tptr[d + 1] += tptr[d];
   std::vector<int32_t> tpos(nnz), fill(tptr.begin(), tptr.end() - 1);
-  for (size_t k = 0; k < nnz; k++) tpos[fill[dof_of(sidx[k])]++] = (int32_t)k;
+  for (size_t k = 0; k < nnz; k++)
+    if (!skip || !skip[k]) tpos[fill[dof_of(sidx[k])]++] = (int32_t)k;
   code.clear(), hdr.clear(), rpos.clear();
   code.reserve(shared.size());
   int prev = -2, len = 0;
