@@ -981,7 +981,9 @@ int pa_op_complex_fused(const pa_op *op_r, const pa_op *op_i) {
   if (!op_r || !op_i || !op_r->msubs.empty() || !op_i->msubs.empty() || op_r->height != op_i->height || op_r->width != op_i->width)
     return 0;
   const bool hex = op_r->subs.size() == 1 && op_i->subs.size() == 1 && op_r->dsubs.empty() && op_i->dsubs.empty();
-  const bool dense = op_r->dsubs.size() == 1 && op_i->dsubs.size() == 1 && op_r->subs.empty() && op_i->subs.empty();
+  // dense blocks: the first sub-operator of the imaginary part pairs with the real part's block; further ones (the surface terms
+  // of a driven problem: absorbing boundary, lumped ports -- a handful of boundary faces) are applied after the fused pass
+  const bool dense = op_r->dsubs.size() == 1 && op_i->dsubs.size() >= 1 && op_r->subs.empty() && op_i->subs.empty();
   if (!hex && !dense) return 0;
   // (the check compares the two restrictions on the host: once per pair)
   if (op_r->cplx_partner != op_i->id) {
@@ -1010,6 +1012,16 @@ int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double 
       launch_dense_complex(*dr, *op_i->dsubs[0], xr, xi, dr->d_ye2, (hipStream_t)stream, masked);
       launch_dense_gather(*dr, yr, false, (hipStream_t)stream, nullptr, nullptr, masked ? xr : nullptr, ess_policy);
       launch_dense_gather(*dr, yi, false, (hipStream_t)stream, dr->d_ye2, nullptr, masked ? xi : nullptr, ess_policy);
+      // the remaining sub-operators B of the imaginary part: yi += B xr, yr -= B xi (operator.cpp:98-134), essential entries of
+      // x read as zero through B's own flagged index copy, essential rows of y left as the gathers above fixed them
+      for (size_t k = 1; k < op_i->dsubs.size(); k++) {
+        const DenseSub &b = *op_i->dsubs[k];
+        PA_REQUIRE(!masked || (op_i->has_essential && b.d_ess_flag), "pa_op_set_essential has not been called on the imaginary operator");
+        launch_dense_apply(b, xr, masked, (hipStream_t)stream);
+        launch_dense_gather_signed(b, yi, +1.0, masked, (hipStream_t)stream);
+        launch_dense_apply(b, xi, masked, (hipStream_t)stream);
+        launch_dense_gather_signed(b, yr, -1.0, masked, (hipStream_t)stream);
+      }
       return;
     }
     SubOp *sr = op_r->subs[0];

@@ -2053,6 +2053,31 @@ __global__ __launch_bounds__(256) void et_run_gather_dense_kernel(const int n, c
   }
 }
 
+// y[d] += sign * sum of the copies of d (CSR form, the copies in element order), rows without copies and -- skip_ess -- essential rows
+// untouched: the small sub-operators added to a vector another operator has already written (pa_op_mult_complex)
+__global__ void et_gather_signed_kernel(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                                        const double *__restrict__ ye, double *__restrict__ y, const double sign,
+                                        const uint8_t *__restrict__ ess) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const int k0 = tptr[d], k1 = tptr[d + 1];
+  if (k0 == k1 || (ess && ess[d])) return;
+  double s = 0.0;
+  for (int k = k0; k < k1; k++) {
+    const int t = tent[k];
+    const double v = ye[t >= 0 ? t : -1 - t];
+    s += t >= 0 ? v : -v;
+  }
+  y[d] += sign * s;
+}
+void launch_dense_gather_signed(const DenseSub &ds, double *y, double sign, bool skip_ess, hipStream_t s) {
+  if (ds.lsize == 0) return;
+  PA_REQUIRE(!skip_ess || ds.d_ess_flag, "essential rows: pa_op_set_essential first");
+  hipLaunchKernelGGL(et_gather_signed_kernel, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye, y,
+                     sign, skip_ess ? ds.d_ess_flag : nullptr);
+  PA_HIP(hipGetLastError());
+}
+
 void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStream_t s, const double *ye, const SplitIO *split,
                          const double *x, int ess_policy) {
   if (ds.d_rchunk) {

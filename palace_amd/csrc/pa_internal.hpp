@@ -337,6 +337,7 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
                          const SplitIO *split = nullptr, const double *x = nullptr, int ess_policy = -1);
 bool dense_split_ok(const DenseSub &ds);
 bool dense_complex_ok(const DenseSub &dr, const DenseSub &di);
+void launch_dense_gather_signed(const DenseSub &ds, double *y, double sign, bool skip_ess, hipStream_t s);
 void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s,
                           bool masked = false);
 void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s);
