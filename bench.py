@@ -1441,6 +1441,25 @@ def main():
                 # over x and y (the E-vector round trip of the shared dofs comes on top)
                 "design_floor_bytes": design_floor,
                 "traffic_over_design_floor": (traffic / design_floor) if (traffic and design_floor) else None}
+    # The "second line" of SURVEY.md 8(d): the same apply with the geometry recomputed from the 27 nodes of every element (648 B per
+    # element instead of 3 072 B of packed D; PALACE_AMD_STREAM_GEOM=nodes, read at every launch).  It moves fewer bytes and is
+    # SLOWER on this chip (the 27 partial sums per lane cost a wave per SIMD): reported, not used for `value`.
+    if world == 1 and p == 3:
+        try:
+            K.mult(x, y)
+            y_packed = y.clone()
+            os.environ["PALACE_AMD_STREAM_GEOM"] = "nodes"
+            K.mult(x, y)
+            reld = float((y - y_packed).norm() / y_packed.norm())
+            gms = _event_ms(lambda: [K.mult(x, y) for _ in range(50)], 6) / 50
+            roofline["geometry_from_nodes"] = {"ms": gms, "dof_per_s": n_global / (gms * 1e-3), "rel_diff_from_the_packed_form": reld,
+                                               "bytes_per_element": "27 x 3 x 8 = 648 (nodes) instead of 64 x 6 x 8 = 3 072 (packed D)",
+                                               "used_for_value": False}
+            del y_packed
+        except Exception as exc:  # noqa: BLE001
+            roofline["geometry_from_nodes"] = {"error": f"{type(exc).__name__}: {exc}"}
+        finally:
+            os.environ.pop("PALACE_AMD_STREAM_GEOM", None)
     if world == 1 and not roofline["consistent_with_ms_per_step"]:
         print(f"bench.py: roofline leg {kernel_ms:.4f} ms per apply against {ms_per_step:.4f} ms per step", file=sys.stderr)
 

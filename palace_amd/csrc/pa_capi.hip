@@ -596,6 +596,7 @@ void pa_geom_destroy(pa_geom *geom) {
     hipFree(geom->d_geom);
     hipFree(geom->d_qw);
     hipFree(geom->d_attr_e);
+    hipFree(geom->d_xnodes), hipFree(geom->d_gtab);
     if (geom->metric) {
       hipFree(geom->metric->d);
       delete geom->metric;

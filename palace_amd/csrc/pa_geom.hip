@@ -136,6 +136,25 @@ void launch_geom(const pa_mesh_desc &mesh, Geom &g, hipStream_t s) {
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(s));
   hipFree(d_off), hipFree(d_nodes), hipFree(d_B), hipFree(d_G), hipFree(d_w);
+  if (m1 == 3 && q1d == 4) {  // what the GEOMN form of the streaming kernel reads instead of packed q-data: 648 B per element
+    const size_t nep = (size_t)((ne + 3) & ~3);
+    std::vector<double> xn(nep * 81, 0.0);
+    for (int e = 0; e < ne; e++)
+      for (int n = 0; n < 27; n++)
+        for (int c = 0; c < 3; c++) xn[((size_t)e * 27 + n) * 3 + c] = mesh.nodes[3 * (size_t)off[(size_t)e * 27 + n] + c];
+    for (size_t e = ne; e < nep; e++)  // pad elements: a unit cube (a regular Jacobian: nothing of theirs reaches a result)
+      for (int n = 0; n < 27; n++) {
+        xn[(e * 27 + n) * 3 + 0] = 0.5 * (n % 3), xn[(e * 27 + n) * 3 + 1] = 0.5 * ((n / 3) % 3), xn[(e * 27 + n) * 3 + 2] = 0.5 * (n / 9);
+      }
+    g.d_xnodes = dev_upload(xn.data(), xn.size(), s);
+    std::vector<double> gt(28);
+    for (int q = 0; q < 4; q++) {
+      for (int i = 0; i < 3; i++) gt[q * 3 + i] = mesh.mesh_B[q * 3 + i], gt[12 + q * 3 + i] = mesh.mesh_G[q * 3 + i];
+      gt[24 + q] = mesh.qweight1d[q];
+    }
+    g.d_gtab = dev_upload(gt.data(), gt.size(), s);
+    PA_HIP(hipStreamSynchronize(s));
+  }
   g.d_attr_e = d_attr;
   g.h_attr = attr;
   g.w1.assign(mesh.qweight1d, mesh.qweight1d + q1d);

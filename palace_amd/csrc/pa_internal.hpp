@@ -97,6 +97,10 @@ struct Geom {
   std::vector<int32_t> h_attr;    // host copy (tensor hex blocks), internal element order
   std::vector<int32_t> eorder;    // internal element p is the caller's element eorder[p] (empty: same order)
   std::vector<double> w1;         // 1-D quadrature weights (tensor hex blocks)
+  // geometry from the nodes (hex27 blocks at four points per direction: the streaming curl-curl kernel's GEOMN form, round 5):
+  // the 27 x 3 node coordinates of every element in internal element order, [ne padded to 4][27][3], and the 1-D geometry basis
+  // at the quadrature points {B [4][3], G [4][3], weights [4]} (device)
+  double *d_xnodes = nullptr, *d_gtab = nullptr;
   std::vector<double> wq;         // quadrature weights (dense blocks), host copy
   int refcount = 1;
 };

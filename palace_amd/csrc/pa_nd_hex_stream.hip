@@ -76,6 +76,8 @@ struct NDStreamArgs {
                           // block (elements with the same permutation share one: the table stays in L2)
   const double *qdata;    // [ne][NG][2][16][2]
   const double *coef;     // metric form: [ne][2] scalar mass / curl-curl coefficient of the element
+  // GEOMN form (geometry from the nodes): [ne][27][3] node coordinates, {B [4][3], G [4][3], w [4]} of the 1-D geometry basis
+  const double *xn, *gtab;
   const double *x;
   double *y, *ye;
   // complex form (CPLX): imaginary parts of x, y and of the E-vector, coefficients of the imaginary operator
@@ -98,10 +100,16 @@ struct NDStreamArgs {
 // the two parts of x: the even 16-lane groups of a wave carry the real part, the odd ones the imaginary part of the same
 // element, both read the element's index words and q-data (one HBM read), exchange their quadrature values with the
 // neighbouring group once and store to the real / imaginary y and E-vector.  One pass over the geometry data instead of four.
-template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false>
+// GEOMN (curl-curl with isotropic coefficients on hex27 elements; round 5): D = (c w / det J) J^T J is recomputed from the 27 nodes
+// of the element -- 648 B per element instead of 3 072 B of packed D.  The nodes are requested at the top of the batch (81 doubles
+// per element, 6 per lane), parked in the element's LDS strip after the forward passes, and every lane contracts them with its own
+// in-plane basis values into 27 partial sums P[k][c][v] (v: d/dxi, d/deta, value; k: node layer), from which the Jacobian at its
+// four points along the column costs 27 multiply-adds each.
+template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false, bool GEOMN = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
   static_assert(!CPLX || (METRIC && USE_U && USE_C), "the complex form is built on the metric curl-curl + mass kernel");
   static_assert(!(CPLX && SPLIT), "no split-vector form of the complex kernel");
+  static_assert(!GEOMN || (!USE_U && USE_C && !METRIC && !CPLX), "geometry from the nodes: the curl-curl kernel");
   constexpr int Q1 = 4;
 #ifdef PA_STREAM_EARLY  // experiment builds
   constexpr bool EARLY_IDX = true;
@@ -122,7 +130,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   // LDS per element (doubles): contraction buffers + the batch's index and slot / flag words, kept for the E^T stores,
   // + the run starts of the next batch while its index is decoded
   constexpr int LDS_SIDE = (PP + 1) / 2 + (NPK + 1) * 8;
-  constexpr int LDS_ELEM = stream_lds_elem(L::ELEM_PAD + LDS_SIDE + 12);
+  constexpr int LDS_XN = GEOMN ? 82 : 0;  // the element's node coordinates (GEOMN)
+  constexpr int LDS_ELEM = stream_lds_elem(L::ELEM_PAD + LDS_SIDE + 12 + LDS_XN);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -198,12 +207,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   // the D stage of the batch before it -- its registers are free from there on -- instead of at the top of its own batch, where
   // only the E stage and the forward passes of the same batch (short at p < 3) stand between the request and the first use
   constexpr bool QAHEAD = PA_STREAM_QAHEAD && MINW == 2 && !CPLX;
-  d2v gq[2 * NG];
+  d2v gq[GEOMN ? 1 : 2 * NG];
+  double xl[GEOMN ? 6 : 1];  // GEOMN: this lane's six of the element's 81 node coordinates, in flight during the forward passes
+  auto load_xn = [&](const int ee, const int t) {
+    const double *xp = a.xn + (size_t)ee * 81;
+#pragma unroll
+    for (int r = 0; r < (GEOMN ? 6 : 1); r++) xl[r] = (t + 16 * r < 81) ? __builtin_nontemporal_load(&xp[t + 16 * r]) : 0.0;
+  };
   auto load_q = [&](const int ee, const int t) {
+    if (GEOMN) return load_xn(ee, t);  // (the nodes of the batch: consumed in its D stage)
     const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)ee * (2 * (METRIC ? 7 : NG) * 16) + t);
 #pragma unroll
     // (read once: non-temporal, so the stream does not displace x / y lines in L2; measured 5 - 7 % on the apply)
-    for (int k = 0; k < 2 * NG; k++) gq[k] = __builtin_nontemporal_load(&g[16 * k]);
+    for (int k = 0; k < (GEOMN ? 1 : 2 * NG); k++) gq[k] = __builtin_nontemporal_load(&g[16 * k]);
   };
   if (QAHEAD) {
     load_q(CPLX ? b * 2 + (lane >> 5) : b * 4 + (lane >> 4), lane & 15);
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     // q-data of this batch: consumed after the forward contraction
     if (!QAHEAD) load_q(e, t);
     d2v ce = {0.0, 0.0}, ci = {0.0, 0.0};
-    if (METRIC) ce = reinterpret_cast<const d2v *>(a.coef)[e];
+    if (METRIC || GEOMN) ce = reinterpret_cast<const d2v *>(a.coef)[e];
     if (CPLX) ci = reinterpret_cast<const d2v *>(a.coef1)[e];
 
     // E: sorted entries into their tensor-order slots (x of this batch was requested during the previous one)
@@ -293,12 +309,67 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    // GEOMN: the node coordinates (requested at the top of the batch) into the element's LDS strip, then this lane's partial sums
+    // P[k][c][v] over the in-plane nodes of layer k (v: d/dxi, d/deta, value)
+    double Pz[GEOMN ? 3 : 1][3][3];
+    double cw = 0.0;
+    if (GEOMN) {
+      double *xs = sm + L::ELEM_PAD + LDS_SIDE + 12;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+        if (t + 16 * r < 81) xs[t + 16 * r] = xl[r];
+      wave_sync();
+      const double *gt = a.gtab;
+      double bx[3], gx[3], by[3], gy[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) bx[i] = gt[ta * 3 + i], gx[i] = gt[12 + ta * 3 + i], by[i] = gt[tb * 3 + i], gy[i] = gt[12 + tb * 3 + i];
+      cw = ce[1] * gt[24 + ta] * gt[24 + tb];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) Pz[k][c][0] = 0.0, Pz[k][c][1] = 0.0, Pz[k][c][2] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const double w0 = gx[i] * by[j], w1 = bx[i] * gy[j], w2 = bx[i] * by[j];
+            const double *X = xs + 3 * (i + 3 * (j + 3 * k));
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const double xc = X[c];
+              Pz[k][c][0] += xc * w0, Pz[k][c][1] += xc * w1, Pz[k][c][2] += xc * w2;
+            }
+          }
+        }
+      }
+    }
     // D at the four points of this lane's column
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
       double H[NG];
+      if (GEOMN) {
+        // J[c][d] = d x_c / d xi_d at (ta, tb, qz): the layers combined with the 1-D basis (value for d = 0, 1; derivative for d = 2)
+        const double *gt = a.gtab;
+        double J[3][3];
 #pragma unroll
-      for (int c = 0; c < NG; c++) H[c] = gq[2 * c + (qz >> 1)][qz & 1];
+        for (int c = 0; c < 3; c++) {
+          J[c][0] = gt[qz * 3] * Pz[0][c][0] + gt[qz * 3 + 1] * Pz[1][c][0] + gt[qz * 3 + 2] * Pz[2][c][0];
+          J[c][1] = gt[qz * 3] * Pz[0][c][1] + gt[qz * 3 + 1] * Pz[1][c][1] + gt[qz * 3 + 2] * Pz[2][c][1];
+          J[c][2] = gt[12 + qz * 3] * Pz[0][c][2] + gt[12 + qz * 3 + 1] * Pz[1][c][2] + gt[12 + qz * 3 + 2] * Pz[2][c][2];
+        }
+        const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                           J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        const double sc = cw * gt[24 + qz] / det;  // (w det J) (J / det)^T c (J / det), hdiv_33_qf.h:10-30 with c I
+        H[0] = sc * (J[0][0] * J[0][0] + J[1][0] * J[1][0] + J[2][0] * J[2][0]);
+        H[1] = sc * (J[0][0] * J[0][1] + J[1][0] * J[1][1] + J[2][0] * J[2][1]);
+        H[2] = sc * (J[0][0] * J[0][2] + J[1][0] * J[1][2] + J[2][0] * J[2][2]);
+        H[3] = sc * (J[0][1] * J[0][1] + J[1][1] * J[1][1] + J[2][1] * J[2][1]);
+        H[4] = sc * (J[0][1] * J[0][2] + J[1][1] * J[1][2] + J[2][1] * J[2][2]);
+        H[5] = sc * (J[0][2] * J[0][2] + J[1][2] * J[1][2] + J[2][2] * J[2][2]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NG; c++) H[c] = gq[2 * c + (qz >> 1)][qz & 1];
+      }
       if (METRIC) {
         // H = (w / |detJ|) J^T J {00, 01, 02, 11, 12, 22}, H[6] = |detJ| / w:
         //   (w / detJ) J^T c J = c H,   w detJ adj^T c adj = c (|detJ| / w) adj(H)
@@ -333,6 +404,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     }
 
     PA_STAMP(5);  // D done
+
     if (QAHEAD) {  // q-data of the next batch (the last one re-reads its own)
       __builtin_amdgcn_sched_barrier(0);
       load_q(CPLX ? bn * 2 + (sub >> 1) : bn * 4 + sub, t);
@@ -600,7 +672,7 @@ void build_stream(SubOp &so) {
   }
   so.d_idxc = dev_upload(ic.data(), ic.size());
   so.d_perm_s = dev_upload(pp.data(), pp.size());
-  if (so.qd->metric) stream_element_coefficients(so);
+  if (so.qd->metric || (so.iso && so.qf == PA_QF_HDIV_33 && so.geom->d_xnodes)) stream_element_coefficients(so);
 
   std::vector<uint32_t> code;
   std::vector<RunHdr> hdr;
@@ -718,21 +790,22 @@ static int device_cus() {
   return cus;
 }
 
-template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false>
+template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false, bool GEOMN = false>
 static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   using L = typename std::conditional<P1 == 3 && !CPLX && C && !U, NDLayoutInPlaceSwz3, NDLayout<P1, 4>>::type;  // (as in the kernel)
   for (int i = 0; i < HalfTab<P1, 4>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
   for (int i = 0; i < HalfTab<P1 + 1, 4>::LEN; i++) a.tab.Bc[i] = so.Bc[i], a.tab.Gc[i] = so.Gc[i];
   constexpr int PP = 3 * P1 * (P1 + 1) * (P1 + 1);
   constexpr int NPK = ((PP + 15) / 16 + 3) / 4;
-  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) * stream_lds_elem(L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8 + 12);
+  const size_t lds = sizeof(double) * (size_t)(kWavesPerBlock * 4) *
+                     stream_lds_elem(L::ELEM_PAD + (PP + 1) / 2 + (NPK + 1) * 8 + 12 + (GEOMN ? 82 : 0));
   // resident workgroups per CU: registers (MINW waves per SIMD), LDS (160 KB), at most 8
   // workgroups per CU: what the registers (MINW waves per SIMD) and the LDS admit, and not more than the occupancy query
   // says -- with a fixed stride a workgroup that had to queue would run after the others and double the time
   static const int wg_env = getenv("PALACE_AMD_STREAM_WG") ? atoi(getenv("PALACE_AMD_STREAM_WG")) : 0;
   static const int per_cu_query = [&] {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX, SPLIT>,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX, SPLIT, GEOMN>,
                                                      64 * kWavesPerBlock, lds) != hipSuccess || nb <= 0)
       nb = 8;
     return std::min({nb, MINW * 4 / kWavesPerBlock, (int)(160 * 1024 / lds), 8});
@@ -753,7 +826,7 @@ static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   const int rounds = (a.chunk + max_waves - 1) / max_waves;
   if (rounds >= 2 && rounds <= balance) waves = (a.chunk + rounds - 1) / rounds;
   const int wgx = std::max(1, (waves + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX, SPLIT>), dim3(8 * wgx), dim3(64 * kWavesPerBlock),
+  hipLaunchKernelGGL((nd_hex_stream_kernel<P1, U, C, METRIC, MINW, GPOS, CPLX, SPLIT, GEOMN>), dim3(8 * wgx), dim3(64 * kWavesPerBlock),
                      lds, s, a);
   PA_HIP(hipGetLastError());
 }
@@ -803,12 +876,27 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   a.slots = so.d_slots;
   a.qdata = so.qd->d;
   a.coef = so.d_coef_s;
+  a.xn = nullptr, a.gtab = nullptr;
   a.x = x, a.y = y, a.ye = so.d_ye;
   const bool m = so.qd->metric;
   switch (so.qf) {
-    case PA_QF_HDIV_33:
+    case PA_QF_HDIV_33: {
+      // geometry from the nodes (PALACE_AMD_STREAM_GEOM=nodes; order 3, isotropic coefficient, hex27 geometry, one vector): see the kernel
+      // (read at every launch: the bench times both forms of one operator in one process)
+      const char *ge = getenv("PALACE_AMD_STREAM_GEOM");
+      const bool geomn = ge && std::string(ge) == "nodes";
+      if (!m && geomn && P1 == 3 && so.iso && so.geom->d_xnodes && so.d_coef_s && !split) {
+        a.xn = so.geom->d_xnodes, a.gtab = so.geom->d_gtab;
+        // two waves per SIMD: the 27 partial sums are 54 more live registers in the D stage (222-244 in all; compiled for three
+        // waves per SIMD the kernel spills 32-47 of them and runs at 284-331 us instead of 199: profiles/r05_geomn_first_form.log);
+        // PALACE_AMD_GEOMN_VARIANT=w2g2 requests x of the next batch one transposed component later
+        const char *ve = getenv("PALACE_AMD_GEOMN_VARIANT");
+        if (ve && std::string(ve) == "w2g2") launch_gpos<P1, false, true, false, 2, 2, false, false, (P1 == 3)>(so, a, s);
+        else launch_gpos<P1, false, true, false, 2, 1, false, false, (P1 == 3)>(so, a, s);
+        break;
+      }
       if (m) launch_variant<P1, false, true, true, (P1 == 3 ? 2 : 3)>(so, a, s); else launch_variant<P1, false, true, false, 3>(so, a, s);
-      break;
+    } break;
     case PA_QF_HCURL_33:
       if (m) launch_variant<P1, true, false, true, 3>(so, a, s); else launch_variant<P1, true, false, false, 3>(so, a, s);
       break;

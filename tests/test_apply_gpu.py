@@ -282,3 +282,38 @@ def test_error_paths(cylinder_mesh):
     x = torch.zeros(nd.ndofs, dtype=torch.float64, device="cuda")
     with pytest.raises(lib.PalaceAmdError, match="coefficient = 1.0"):
         op.add_mult(x, x, a=2.0)
+
+
+@pytest.mark.parametrize("variant", ["w2g1", "w2g2"])
+def test_geometry_from_the_nodes(cylinder_mesh, monkeypatch, variant):
+    """The streaming curl-curl kernel with D recomputed from the 27 nodes of every element (PALACE_AMD_STREAM_GEOM=nodes: 648 B per
+    element instead of 3 072 B of packed D; round 5) against the oracle, with a different isotropic coefficient per attribute, with and
+    without essential dofs fused, on the reference's curved cylinder mesh once refined (a ragged last batch included)."""
+    from palace_amd import linalg
+
+    mesh = _multi_attr(refine_uniform(cylinder_mesh))
+    p, q1d = 3, 4
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    coefs = [np.array([0.7]), np.array([1.9]), np.array([1.0])]
+    blob = ceed.coefficient_context(3, attr_mat=[0, 1, 2], mat_coeff=coefs)
+    octx = po.CoeffCtx(attr_mat=[0, 1, 2], mat_coeff=coefs)
+    op = ceed.curlcurl_operator(geom, nd, blob)
+    x = np.random.default_rng(11).uniform(-1, 1, nd.ndofs)
+    ref = util.oracle_apply_c(nd, util.oracle_geom(mesh, q1d), "hdiv", octx.pack(), x, q1d)
+    xd = _dev(x)
+    y0 = op.mult(xd, torch.empty_like(xd)).cpu().numpy()
+    monkeypatch.setenv("PALACE_AMD_STREAM_GEOM", "nodes")
+    monkeypatch.setenv("PALACE_AMD_GEOMN_VARIANT", variant)
+    y1 = op.mult(xd, torch.empty_like(xd)).cpu().numpy()
+    assert _rel(y0, ref) < RTOL and _rel(y1, ref) < RTOL
+    assert not np.array_equal(y0, y1)  # (the switch did take the other kernel: the two forms differ in the last bits)
+    ctx = linalg.Context()
+    ess = nd.ess_dofs()
+    K = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+    yk = K.mult(xd, torch.empty_like(xd)).cpu().numpy()
+    xm = x.copy()
+    xm[ess] = 0.0
+    refk = util.oracle_apply_c(nd, util.oracle_geom(mesh, q1d), "hdiv", octx.pack(), xm, q1d)
+    refk[ess] = x[ess]
+    assert _rel(yk, refk) < RTOL
