@@ -548,7 +548,6 @@ constexpr int kAffWaves = PA_DENSE_AFF_WAVES;  // the affine form needs fewer re
 // base pointer costs the affine kernels the two registers they have left at three waves per SIMD
 template <int PT, int MODE, bool AFFINE, bool CPLX = false, bool LIST = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1) void dense_apply_resident_kernel(const DenseArgs a, const int rows) {
-  static_assert(!(CPLX && LIST), "the complex form runs on whole operators");
   static_assert(!SPLIT || (!CPLX && !LIST), "split vectors: whole real operators");
   static_assert(!CPLX || (MODE == MODE_CURLMASS && PT <= 3), "complex form: curl-curl + mass blocks");
   constexpr int NW = (AFFINE && !CPLX) ? kAffWaves : kResWaves;
@@ -578,9 +577,12 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
   const int ngroups = a.Q4 / 4;
   // work units: element blocks, or (CPLX) half blocks -- unit w is columns 8 (w & 1) .. + 7 of block w >> 1, and lane (kq, j)
   // works on element column 8 (w & 1) + (j & 7), part j >> 3
-  const int nunits = CPLX ? 2 * a.nb : (LIST ? a.nblist : a.nb);
+  const int nunits = (CPLX ? 2 : 1) * (LIST ? a.nblist : a.nb);  // (LIST: the blocks of one kind of a mesh with affine and curved ones)
   const int j8 = j & 7;
-  auto ublock = [&](const int w) { return (size_t)(CPLX ? w >> 1 : (LIST ? __builtin_amdgcn_readfirstlane(a.blist[w]) : w)); };
+  auto ublock = [&](const int w) {
+    const int bw = CPLX ? w >> 1 : w;
+    return (size_t)(LIST ? __builtin_amdgcn_readfirstlane(a.blist[bw]) : bw);
+  };
   auto ucol = [&](const int w) { return CPLX ? 8 * (w & 1) + j8 : j; };          // element column in the block's arrays
   auto ulane = [&](const int w) { return CPLX ? kq * 16 + 8 * (w & 1) + j8 : lane; };  // position in a [.][64] row
   const double *xsel = (CPLX && (j >> 3)) ? a.x1 : a.x;
@@ -1910,10 +1912,19 @@ void launch_dense_apply(const DenseSub &ds, const double *x, bool masked, hipStr
 bool dense_complex_ok(const DenseSub &dr, const DenseSub &di) {
   static const bool enabled = !(getenv("PALACE_AMD_COMPLEX_FUSED") && atoi(getenv("PALACE_AMD_COMPLEX_FUSED")) == 0);
   if (!enabled || dr.fe_type != PA_FE_HCURL || di.fe_type != PA_FE_HCURL || dr.geom != di.geom || dr.geom->dim != 3) return false;
-  // (all blocks affine, or none: a mesh with both kinds keeps the four real applies)
-  if (dr.mode != MODE_CURLMASS || !dr.d_L || dr.d_blist[0] || dr.PT > 3) return false;
-  if (!(di.mode == MODE_CURLMASS || di.mode == MODE_VMASS || di.mode == MODE_CURL) || !di.d_qdata || di.d_blist[0]) return false;
+  // all blocks affine, or none, or (round 5) a mesh with both kinds whose two operators split their blocks the same way: then the
+  // affine form runs on the list of the affine blocks and the curved form on the list of the others, like the real apply
+  if (dr.mode != MODE_CURLMASS || !dr.d_L || dr.PT > 3) return false;
+  if (!(di.mode == MODE_CURLMASS || di.mode == MODE_VMASS || di.mode == MODE_CURL) || !di.d_qdata) return false;
   if ((dr.d_affine != nullptr) != (di.d_affine != nullptr)) return false;
+  if ((dr.d_blist[0] != nullptr) != (di.d_blist[0] != nullptr)) return false;
+  if (dr.d_blist[0]) {
+    if (dr.nb != di.nb || dr.n_blist[0] != di.n_blist[0] || dr.n_blist[1] != di.n_blist[1] || !dr.d_affine) return false;
+    std::vector<uint8_t> fr((size_t)dr.nb), fi((size_t)di.nb);
+    PA_HIP(hipMemcpy(fr.data(), dr.d_affine, fr.size(), hipMemcpyDeviceToHost));
+    PA_HIP(hipMemcpy(fi.data(), di.d_affine, fi.size(), hipMemcpyDeviceToHost));
+    if (fr != fi) return false;
+  }
   if (dr.ne != di.ne || dr.P != di.P || dr.Q != di.Q || dr.lsize != di.lsize) return false;
   if (di.mode != MODE_CURL && di.chk_interp != dr.chk_interp) return false;
   if (di.mode != MODE_VMASS && di.chk_deriv != dr.chk_deriv) return false;
@@ -1925,7 +1936,17 @@ static void launch_resident_complex_pt(const DenseSub &dr, const DenseArgs &a, h
   const int rows = dr.L_rows;
   const size_t shm = sizeof(double) * ((size_t)(a.Q4 + 31) / 32 * 32 + (size_t)rows * ResidentStride<PT>::S +
                                       (dr.d_co ? (size_t)kResWaves * 4 * PT * 64 : 0));
-  int grid = (2 * dr.nb + kResWaves - 1) / kResWaves;
+  if (dr.d_blist[0] && !a.blist) {  // affine and curved blocks: one launch each on its list (they write disjoint E-vector blocks)
+    DenseArgs aa = a, ag = a;
+    aa.blist = dr.d_blist[0], aa.nblist = dr.n_blist[0];
+    ag.blist = dr.d_blist[1], ag.nblist = dr.n_blist[1], ag.affine = nullptr;
+    launch_resident_complex_pt<PT>(dr, aa, s);
+    launch_resident_complex_pt<PT>(dr, ag, s);
+    return;
+  }
+  const int nblocks = a.blist ? a.nblist : dr.nb;
+  if (nblocks == 0) return;
+  int grid = (2 * nblocks + kResWaves - 1) / kResWaves;
   if (grid > dr.num_cu) grid = dr.num_cu;
   static std::atomic<bool> attr_set{false};  // idempotent set-up, may race between rank threads
   if (!attr_set) {
@@ -1933,9 +1954,17 @@ static void launch_resident_complex_pt(const DenseSub &dr, const DenseArgs &a, h
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE_CURLMASS, false, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PA_HIP(hipFuncSetAttribute((const void *)dense_apply_resident_kernel<PT, MODE_CURLMASS, false, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  if (a.affine)
+  if (a.blist && a.affine)
+    hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);
+  else if (a.blist)
+    hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, false, true, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);
+  else if (a.affine)
     hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, true, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);
   else
     hipLaunchKernelGGL((dense_apply_resident_kernel<PT, MODE_CURLMASS, false, true>), dim3(grid), dim3(64 * kResWaves), shm, s, a, rows);

@@ -176,6 +176,13 @@ if kind == "tet10":
     warp = lambda X: np.stack([X[:, 0] + 0.04 * np.sin(2 * X[:, 1] + X[:, 2]), X[:, 1] + 0.05 * X[:, 0] * X[:, 2],
                                X[:, 2] - 0.03 * np.cos(3 * X[:, 0]) * X[:, 1]], axis=1)
     m2 = tet.to_quadratic(mesh, warp); m2.attr[:] = mesh.attr; mesh = m2
+if kind == "mixed":  # curved in one half only (a mesh with a curved boundary): affine blocks and curved blocks, one launch each
+    mesh = tet.cube_tet_mesh(5)
+    mesh.attr[:] = 1 + (np.arange(mesh.ne) %% 2)
+    def half_warp(X):
+        w = np.clip(X[:, 0] - 0.45, 0.0, None) ** 2
+        return X + np.stack([0.3 * w * np.sin(3 * X[:, 1]), 0.4 * w * X[:, 2], -0.35 * w * np.cos(2 * X[:, 1])], axis=1)
+    m2 = tet.to_quadratic(mesh, half_warp); m2.attr[:] = mesh.attr; mesh = m2
 nd = tet.NDTetSpace(mesh, p)
 pts, wts = tet.default_tet_rule(p)
 interp, curl = nd.elem.tables(pts)
@@ -202,14 +209,15 @@ for tag, e in (("plain", np.zeros(0, np.int32)), ("ess", ess)):
     yr, yi = torch.empty_like(x[0]), torch.empty_like(x[0])
     A.mult(x[0], x[1], yr, yi)
     out[tag] = (yr.cpu().numpy(), yi.cpu().numpy())
-np.savez(sys.argv[4], fused=ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle),
+np.savez(sys.argv[4], fused=ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle), affine=Ar.dense_affine(),
          **{k + "_" + c: v[i] for k, v in out.items() for i, c in enumerate("ri")})
 print("OK")
 '''
 
 
 @pytest.mark.parametrize("p,imode,kind", [(p, m, "tet4") for p in (1, 2, 3) for m in ("mass", "curl", "both")] +
-                         [(1, "both", "tet10"), (2, "mass", "tet10"), (2, "curl", "tet10"), (2, "both", "tet10"), (3, "both", "tet10")])
+                         [(1, "both", "tet10"), (2, "mass", "tet10"), (2, "curl", "tet10"), (2, "both", "tet10"), (3, "both", "tet10")] +
+                         [(2, "both", "mixed"), (3, "mass", "mixed"), (3, "both", "mixed")])  # (round 5: affine and curved blocks in one mesh)
 def test_fused_complex_apply_tets(p, imode, kind, tmp_path):
     """The dense-table form of the one-pass complex apply (straight-sided tetrahedra: the D of one point per element; curved
     ones, round 4: the D of both operators at every point; anisotropic materials, curl-oriented restriction for p >= 2):
