@@ -167,3 +167,52 @@ def test_uniform_refinement_and_lowest_order_gradient():
     for c in range(3):
         u = G @ xyz[:, c]
         assert abs(u @ (M @ u) - 1.0) < 1e-12  # |e_c|^2 over the unit cube
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_h1_boundary_block_numbering(p):
+    """H1TetBoundaryBlock (round 5: the surface blocks of the auxiliary H1 operators, spaceoperator.cpp AddAuxIntegrators): the
+    triangle element's nodes, taken in the ascending-vertex frame of every boundary face, carry the tetrahedral space's dof values
+    (vertices, edge nodes counted from the smaller vertex, face nodes in the sorted-vertex lattice)."""
+    from palace_amd.fem import tet
+
+    mesh = tet.cube_tet_mesh(2)
+    h1 = tet.H1TetSpace(mesh, p)
+    V = mesh.verts[mesh.tets]
+    nodes = h1.elem.nodes
+    lam = np.stack([1 - nodes.sum(1), *nodes.T], 1)
+    X = np.einsum("pn,eni->epi", lam, V)
+    f = lambda X: (1.0 + 0.3 * X[..., 0] - 0.7 * X[..., 1] + 0.2 * X[..., 2]) ** p  # noqa: E731
+    x = np.zeros(h1.ndofs)
+    x[h1.offsets.ravel()] = f(X).ravel()
+    faces = np.nonzero(mesh.boundary_face_mask)[0]
+    blk = tet.H1TetBoundaryBlock(h1, faces)
+    tn = blk.elem.nodes
+    lt = np.stack([1 - tn.sum(1), tn[:, 0], tn[:, 1]], 1)
+    Xt = np.einsum("pn,eni->epi", lt, mesh.verts[blk.elem_nodes])
+    assert blk.P == (p + 1) * (p + 2) // 2
+    assert np.abs(x[blk.offsets] - f(Xt)).max() < 1e-12
+    # the surface diffusion form of a linear function: sum over the faces of area * |tangential gradient|^2
+    if p >= 1:
+        from palace_amd.fem import tri
+
+        pts, wts = tri.tri_quadrature(p + 1)
+        _, grad = blk.elem.tables(pts)                      # [2, Q, P]
+        J = blk.jacobians(pts)                              # [ne, Q, 3, 2]
+        g = np.array([0.3, -0.7, 0.2])
+        xl = np.zeros(h1.ndofs)
+        xl[h1.offsets.ravel()] = (1.0 + X @ g).ravel()
+        total, want = 0.0, 0.0
+        for e in range(blk.ne):
+            for q in range(len(wts)):
+                Jq = J[e, q]
+                G = Jq.T @ Jq
+                dref = grad[:, q, :] @ xl[blk.offsets[e]]   # reference gradient
+                gs = Jq @ np.linalg.solve(G, dref)          # surface gradient in 3-D
+                total += wts[q] * np.sqrt(np.linalg.det(G)) * (gs @ gs)
+            n = np.cross(J[e, 0][:, 0], J[e, 0][:, 1])
+            area = 0.5 * np.linalg.norm(n)
+            nh = n / np.linalg.norm(n)
+            gt = g - (g @ nh) * nh
+            want += area * (gt @ gt)
+        assert abs(total - want) < 1e-12 * want
