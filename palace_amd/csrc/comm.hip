@@ -206,7 +206,10 @@ void Comm::AllReduceSum(double *d_buf, int n, hipStream_t s) {
     return;
   }
   if (local_) {  // values to the host, barrier, sum in rank order (the same on every rank), barrier, back to the device
-    PA_REQUIRE(n <= LocalGroup::kMaxValues, "too many values for the in-process all-reduce");
+    if (n > LocalGroup::kMaxValues) {  // (a whole Gram-Schmidt column: in pieces, like the peer transport above)
+      for (int i0 = 0; i0 < n; i0 += LocalGroup::kMaxValues) AllReduceSum(d_buf + i0, std::min(LocalGroup::kMaxValues, n - i0), s);
+      return;
+    }
     double *mine = local_->slots_.data() + (size_t)rank_ * LocalGroup::kMaxValues;
     PA_HIP(hipMemcpyAsync(mine, d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     PA_HIP(hipStreamSynchronize(s));
