@@ -1587,6 +1587,16 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
     ds->d_tptr = dev_upload(tptr.data(), tptr.size());
     ds->d_tent = dev_upload(tent.data(), tent.size());
     ds->d_ye = dev_alloc<double>(nslot);
+    // a block that touches few of the dofs (the surface terms of a driven problem: a few thousand boundary faces in a space of
+    // millions) adds its result through the list of the rows it has: its gather was a pass over the whole vector, 58 times per
+    // FGMRES iteration of config 3 (round 5: 3.7 % of that solve's device time)
+    if ((size_t)ne * P * 4 < (size_t)r.lsize) {
+      std::vector<int32_t> rows;
+      for (int d = 0; d < r.lsize; d++)
+        if (tptr[d + 1] > tptr[d]) rows.push_back(d);
+      ds->n_rows = (int)rows.size();
+      ds->d_rows = dev_upload(rows.data(), std::max<size_t>(rows.size(), 1));
+    }
     // ... and, on request (PALACE_AMD_DENSE_GATHER=runs), its run form.  Measured on 279 936 order-3 tetrahedra, alternating on one box:
     // curl-curl 0.1857 / 0.1866 ms with the CSR form against 0.1839 / 0.1846 ms by runs, K + M 0.2631 / 0.2633 against 0.2613 / 0.2618
     // (-1 %: the gather is bound by its scattered 8-byte E-vector reads, not by the position words), and SLOWER on small blocks
@@ -1832,7 +1842,7 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
 void free_dense_sub(DenseSub *ds) {
   if (ds) hipFree(ds->d_affine), hipFree(ds->d_wrel), hipFree(ds->d_ye2), hipFree(ds->d_blist[0]), hipFree(ds->d_blist[1]);
   if (!ds) return;
-  hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co), hipFree(ds->d_co2), hipFree(ds->d_ess_flag);
+  hipFree(ds->d_idx), hipFree(ds->d_idx_bc), hipFree(ds->d_co), hipFree(ds->d_co2), hipFree(ds->d_ess_flag), hipFree(ds->d_rows);
   hipFree(ds->d_Tf), hipFree(ds->d_Tt), hipFree(ds->d_interp), hipFree(ds->d_deriv);
   hipFree(ds->d_L), hipFree(ds->d_qdata);
   hipFree(ds->d_off), hipFree(ds->d_cor), hipFree(ds->d_ori);
@@ -2084,11 +2094,12 @@ __global__ __launch_bounds__(256) void et_run_gather_dense_kernel(const int n, c
 
 // y[d] += sign * sum of the copies of d (CSR form, the copies in element order), rows without copies and -- skip_ess -- essential rows
 // untouched: the small sub-operators added to a vector another operator has already written (pa_op_mult_complex)
-__global__ void et_gather_signed_kernel(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
-                                        const double *__restrict__ ye, double *__restrict__ y, const double sign,
-                                        const uint8_t *__restrict__ ess) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= n) return;
+__global__ void et_gather_signed_kernel(const int n, const int32_t *__restrict__ rows, const int32_t *__restrict__ tptr,
+                                        const int32_t *__restrict__ tent, const double *__restrict__ ye, double *__restrict__ y,
+                                        const double sign, const uint8_t *__restrict__ ess) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = rows ? rows[i] : i;  // (a block with few rows walks its row list)
   const int k0 = tptr[d], k1 = tptr[d + 1];
   if (k0 == k1 || (ess && ess[d])) return;
   double s = 0.0;
@@ -2102,7 +2113,9 @@ __global__ void et_gather_signed_kernel(const int n, const int32_t *__restrict__
 void launch_dense_gather_signed(const DenseSub &ds, double *y, double sign, bool skip_ess, hipStream_t s) {
   if (ds.lsize == 0) return;
   PA_REQUIRE(!skip_ess || ds.d_ess_flag, "essential rows: pa_op_set_essential first");
-  hipLaunchKernelGGL(et_gather_signed_kernel, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye, y,
+  const int nr = ds.d_rows ? ds.n_rows : ds.lsize;
+  if (nr == 0) return;
+  hipLaunchKernelGGL(et_gather_signed_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, nr, ds.d_rows, ds.d_tptr, ds.d_tent, ds.d_ye, y,
                      sign, skip_ess ? ds.d_ess_flag : nullptr);
   PA_HIP(hipGetLastError());
 }
@@ -2129,6 +2142,10 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
                        ye ? ye : ds.d_ye, y, split ? split->yg - split->n_true : y, split ? split->n_true : 0x7fffffff,
                        ds.d_ess_flag, x, ess_policy);
     PA_HIP(hipGetLastError());
+    return;
+  }
+  if (ds.d_rows && accumulate) {  // (few rows: only those; an overwriting apply still takes the pass over the whole vector)
+    launch_et_gather_raw(ds.n_rows, ds.d_tptr, ds.d_tent, ye ? ye : ds.d_ye, y, true, s, ds.d_rows);
     return;
   }
   if (ye) {

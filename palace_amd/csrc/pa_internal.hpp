@@ -229,6 +229,8 @@ struct DenseSub {
   uint8_t *d_ess_flag = nullptr;  // [lsize] 1 on essential dofs (row fix-up of the split-vector gather)
   uint16_t *d_co = nullptr;     // [nb][4 KP][16] packed int8 rows / columns of T_e (curl-oriented) or nullptr
   uint32_t *d_co2 = nullptr;    // the same, two dof slots per word: [nb][KP / 2][64] (resident kernel)
+  int32_t *d_rows = nullptr;    // blocks that touch few dofs: the rows they have (sorted), n_rows of them; else nullptr
+  int n_rows = 0;
   std::vector<int32_t> h_idx;
   std::vector<int32_t> h_off;  // plain [ne][P] offsets (full assembly)
   double *d_Tf = nullptr, *d_Tt = nullptr;  // MFMA A-operand fragments of the tables (forward / transposed)

@@ -169,3 +169,66 @@ def test_orthonormalize_column_is_reproducible(ctx):
         out.append((H.copy(), hn, w.cpu().numpy()))
     for H, hn, w in out[1:]:
         assert np.array_equal(H, out[0][0]) and hn == out[0][1] and np.array_equal(w, out[0][2])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("cplx", [False, True])
+def test_orthonormalize_column_across_rank_threads(kind, cplx):
+    """The device-resident Gram-Schmidt with a communicator (round 5): the entries of every vector are split over three ranks (threads
+    of this process on one GPU, in-process communicator); the coefficients are summed over the ranks ON THE DEVICE between the
+    kernels (m + 1 all-reduces for the modified variant, one per pass for the classical ones -- 26 (complex) values: more than one
+    message of the in-process transport would be a different code path, so m = 13 keeps both in play with the batch of eight) and
+    every rank must return the H, the norm and its slice of the normalised vector of the undivided computation."""
+    import threading
+
+    import torch
+
+    from palace_amd import linalg
+
+    world, n, m = 3, 3001, 13
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(n, m)) + (1j * rng.normal(size=(n, m)) if cplx else 0.0)
+    Q, _ = np.linalg.qr(A)
+    V = [Q[:, j].copy() for j in range(m)]
+    w = rng.normal(size=n) + (1j * rng.normal(size=n) if cplx else 0.0)
+    Href, wref = po.orthogonalize_column(kind, V, w, m)
+    hn_ref = np.linalg.norm(wref)
+    cuts = [0, 1000, 2100, n]
+    group = linalg.LocalGroup(world)
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            c = linalg.Context()
+            c.init_comm_local(group, r)
+            sl = slice(cuts[r], cuts[r + 1])
+            if cplx:
+                Vr, Vi = [_dev(v.real[sl]) for v in V], [_dev(v.imag[sl]) for v in V]
+                wr, wi = _dev(w.real[sl]), _dev(w.imag[sl])
+                H, hn = c.orthonormalize_column_complex(kind, Vr, Vi, wr, wi)
+                out[r] = (H, hn, wr.cpu().numpy() + 1j * wi.cpu().numpy())
+            else:
+                Vd = [_dev(v[sl]) for v in V]
+                wd = _dev(w[sl])
+                H, hn = c.orthonormalize_column(kind, Vd, wd)
+                out[r] = (H, hn, wd.cpu().numpy())
+            c.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            group.abort()
+            raise
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads)
+    for r in range(world):
+        H, hn, ws = out[r]
+        assert np.abs(H - Href).max() < 1e-12 * max(1.0, np.abs(Href).max())
+        assert abs(hn - hn_ref) < 1e-12 * hn_ref
+        assert np.abs(ws - wref[cuts[r]:cuts[r + 1]] / hn_ref).max() < 1e-11
+        assert np.array_equal(H, out[0][0]) and hn == out[0][1]  # (the sums are global: the same bits on every rank)
