@@ -105,7 +105,7 @@ struct NDStreamArgs {
 // per element, 6 per lane), parked in the element's LDS strip after the forward passes, and every lane contracts them with its own
 // in-plane basis values into 27 partial sums P[k][c][v] (v: d/dxi, d/deta, value; k: node layer), from which the Jacobian at its
 // four points along the column costs 27 multiply-adds each.
-template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false, bool GEOMN = false>
+template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false, int GEOMN = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
   static_assert(!CPLX || (METRIC && USE_U && USE_C), "the complex form is built on the metric curl-curl + mass kernel");
   static_assert(!(CPLX && SPLIT), "no split-vector form of the complex kernel");
@@ -310,11 +310,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     }
 
     // GEOMN: the node coordinates (requested at the top of the batch) into the element's LDS strip, then this lane's partial sums
-    // P[k][c][v] over the in-plane nodes of layer k (v: d/dxi, d/deta, value)
-    double Pz[GEOMN ? 3 : 1][3][3];
+    // P[k][c][v] over the in-plane nodes of layer k (v: d/dxi, d/deta, value).  GEOMN = 1 keeps the 27 sums in registers (54: the
+    // kernel then needs 222-244 and two waves per SIMD).  GEOMN = 2 parks 17 of them in the LDS the element does not use during the
+    // D stage -- the contraction buffers between the forward and the transposed passes (12 slots of 16 lanes), the node strip once
+    // its last layer has been read (5 slots) -- every lane reading back only what it wrote itself (no synchronisation), and keeps
+    // P[.][.][0] and one more in registers.
+    constexpr bool PARK = GEOMN == 2;
+    double Pz[GEOMN ? 3 : 1][3][PARK ? 1 : 3];
+    double Pl = 0.0;  // PARK: P[2][2][2]
     double cw = 0.0;
+    double *xs = sm + L::ELEM_PAD + LDS_SIDE + 12;
+    // slot q of this lane: the contraction buffers hold 12, the node strip 5 more
+    auto park = [&](const int q) -> double * { return (q < 12 ? sm + 16 * q : xs + 16 * (q - 12)) + t; };
     if (GEOMN) {
-      double *xs = sm + L::ELEM_PAD + LDS_SIDE + 12;
 #pragma unroll
       for (int r = 0; r < 6; r++)
         if (t + 16 * r < 81) xs[t + 16 * r] = xl[r];
@@ -326,8 +334,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       cw = ce[1] * gt[24 + ta] * gt[24 + tb];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
+        double acc[3][3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) Pz[k][c][0] = 0.0, Pz[k][c][1] = 0.0, Pz[k][c][2] = 0.0;
+        for (int c = 0; c < 3; c++) acc[c][0] = 0.0, acc[c][1] = 0.0, acc[c][2] = 0.0;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
 #pragma unroll
@@ -337,10 +346,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #pragma unroll
             for (int c = 0; c < 3; c++) {
               const double xc = X[c];
-              Pz[k][c][0] += xc * w0, Pz[k][c][1] += xc * w1, Pz[k][c][2] += xc * w2;
+              acc[c][0] += xc * w0, acc[c][1] += xc * w1, acc[c][2] += xc * w2;
             }
           }
         }
+        if (PARK && k == 2) wave_sync();  // (every lane has read the last layer of the nodes: their strip takes parked sums now)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          Pz[k][c][0] = acc[c][0];
+          if (!PARK) {
+            Pz[k][c][PARK ? 0 : 1] = acc[c][1], Pz[k][c][PARK ? 0 : 2] = acc[c][2];
+          } else {
+            *park(6 * k + 2 * c) = acc[c][1];
+            if (k == 2 && c == 2) Pl = acc[c][2]; else *park(6 * k + 2 * c + 1) = acc[c][2];
+          }
+        }
+        if (PARK) __builtin_amdgcn_sched_barrier(0);  // (a layer at a time: nine accumulators, not twenty-seven)
       }
     }
     // D at the four points of this lane's column
@@ -354,8 +375,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           J[c][0] = gt[qz * 3] * Pz[0][c][0] + gt[qz * 3 + 1] * Pz[1][c][0] + gt[qz * 3 + 2] * Pz[2][c][0];
-          J[c][1] = gt[qz * 3] * Pz[0][c][1] + gt[qz * 3 + 1] * Pz[1][c][1] + gt[qz * 3 + 2] * Pz[2][c][1];
-          J[c][2] = gt[12 + qz * 3] * Pz[0][c][2] + gt[12 + qz * 3 + 1] * Pz[1][c][2] + gt[12 + qz * 3 + 2] * Pz[2][c][2];
+          if (!PARK) {
+            J[c][1] = gt[qz * 3] * Pz[0][c][PARK ? 0 : 1] + gt[qz * 3 + 1] * Pz[1][c][PARK ? 0 : 1] + gt[qz * 3 + 2] * Pz[2][c][PARK ? 0 : 1];
+            J[c][2] = gt[12 + qz * 3] * Pz[0][c][PARK ? 0 : 2] + gt[12 + qz * 3 + 1] * Pz[1][c][PARK ? 0 : 2] +
+                      gt[12 + qz * 3 + 2] * Pz[2][c][PARK ? 0 : 2];
+          } else {
+            J[c][1] = gt[qz * 3] * *park(2 * c) + gt[qz * 3 + 1] * *park(6 + 2 * c) + gt[qz * 3 + 2] * *park(12 + 2 * c);
+            J[c][2] = gt[12 + qz * 3] * *park(2 * c + 1) + gt[12 + qz * 3 + 1] * *park(6 + 2 * c + 1) +
+                      gt[12 + qz * 3 + 2] * (c == 2 ? Pl : *park(12 + 2 * c + 1));
+          }
         }
         const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
                            J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
@@ -366,6 +394,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
         H[3] = sc * (J[0][1] * J[0][1] + J[1][1] * J[1][1] + J[2][1] * J[2][1]);
         H[4] = sc * (J[0][1] * J[0][2] + J[1][1] * J[1][2] + J[2][1] * J[2][2]);
         H[5] = sc * (J[0][2] * J[0][2] + J[1][2] * J[1][2] + J[2][2] * J[2][2]);
+        if (PARK) {  // one point at a time
+          sym_mv(&H[0], CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
       } else {
 #pragma unroll
         for (int c = 0; c < NG; c++) H[c] = gq[2 * c + (qz >> 1)][qz & 1];
@@ -403,6 +436,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       }
     }
 
+    if (GEOMN == 2) wave_sync();  // (the parked sums have been read: the contraction buffers are the transposed passes' again)
     PA_STAMP(5);  // D done
 
     if (QAHEAD) {  // q-data of the next batch (the last one re-reads its own)
@@ -790,7 +824,7 @@ static int device_cus() {
   return cus;
 }
 
-template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false, bool GEOMN = false>
+template <int P1, bool U, bool C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false, int GEOMN = 0>
 static void launch_gpos(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) {
   using L = typename std::conditional<P1 == 3 && !CPLX && C && !U, NDLayoutInPlaceSwz3, NDLayout<P1, 4>>::type;  // (as in the kernel)
   for (int i = 0; i < HalfTab<P1, 4>::LEN; i++) a.tab.Bo[i] = so.Bo[i];
@@ -891,8 +925,10 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
         // waves per SIMD the kernel spills 32-47 of them and runs at 284-331 us instead of 199: profiles/r05_geomn_first_form.log);
         // PALACE_AMD_GEOMN_VARIANT=w2g2 requests x of the next batch one transposed component later
         const char *ve = getenv("PALACE_AMD_GEOMN_VARIANT");
-        if (ve && std::string(ve) == "w2g2") launch_gpos<P1, false, true, false, 2, 2, false, false, (P1 == 3)>(so, a, s);
-        else launch_gpos<P1, false, true, false, 2, 1, false, false, (P1 == 3)>(so, a, s);
+        if (ve && std::string(ve) == "w2g2") launch_gpos<P1, false, true, false, 2, 2, false, false, (P1 == 3 ? 1 : 0)>(so, a, s);
+        else if (ve && std::string(ve) == "park3g1") launch_gpos<P1, false, true, false, 3, 1, false, false, (P1 == 3 ? 2 : 0)>(so, a, s);
+        else if (ve && std::string(ve) == "park3g2") launch_gpos<P1, false, true, false, 3, 2, false, false, (P1 == 3 ? 2 : 0)>(so, a, s);
+        else launch_gpos<P1, false, true, false, 2, 1, false, false, (P1 == 3 ? 1 : 0)>(so, a, s);
         break;
       }
       if (m) launch_variant<P1, false, true, true, (P1 == 3 ? 2 : 3)>(so, a, s); else launch_variant<P1, false, true, false, 3>(so, a, s);

@@ -284,7 +284,7 @@ def test_error_paths(cylinder_mesh):
         op.add_mult(x, x, a=2.0)
 
 
-@pytest.mark.parametrize("variant", ["w2g1", "w2g2"])
+@pytest.mark.parametrize("variant", ["w2g1", "w2g2", "park3g1", "park3g2"])
 def test_geometry_from_the_nodes(cylinder_mesh, monkeypatch, variant):
     """The streaming curl-curl kernel with D recomputed from the 27 nodes of every element (PALACE_AMD_STREAM_GEOM=nodes: 648 B per
     element instead of 3 072 B of packed D; round 5) against the oracle, with a different isotropic coefficient per attribute, with and
