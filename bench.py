@@ -365,11 +365,14 @@ def p4_leg(ctx, dofs, reps=200, pcg_iters=20, parity=True, big_dofs=40.0e6):
     return out
 
 
-def complex_leg(ctx, prob, reps=50, parity=True):
+def complex_leg(ctx, prob, reps=50, parity=True, aniso=False):
     """BASELINE config 3's operator shape on the bench mesh, N = 1: y = (K - w^2 eps M + i w sigma M) x through
     ComplexParOperator::Mult -- both parts in one pass over the element data (pa_op_mult_complex, SURVEY.md 8(f)-1).
     hbm_frac: the algorithmic bytes of ONE pass over the element data (SURVEY.md 8d with G = 11) plus the second part of x and
-    y, over the measured time; parity: the device result against the C oracle's four real applies at this size."""
+    y, over the measured time; parity: the device result against the C oracle's four real applies at this size.
+    aniso: the materials of the reference's driven example (examples/cpw/cpw_lumped_uniform.json:24-28, sapphire: permittivity
+    [9.3, 9.3, 11.5], loss tangent [3.0e-5, 3.0e-5, 8.6e-5]) rotated out of the mesh axes -- the packed-D form of the complex kernel
+    (two operators' symmetric D at every point: 12 + 6 doubles instead of the metric form's 7)."""
     import torch
 
     from palace_amd import ceed, linalg
@@ -377,6 +380,14 @@ def complex_leg(ctx, prob, reps=50, parity=True):
     nd = prob.spaces[-1]
     mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([-2.08 * 0.3])])
     cond = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([0.05])])
+    if aniso:
+        c, s_ = np.cos(0.3), np.sin(0.3)
+        R = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]]) @ np.array([[1.0, 0.0, 0.0], [0.0, c, -s_], [0.0, s_, c]])
+        eps = R @ np.diag([9.3, 9.3, 11.5]) @ R.T
+        loss = R @ np.diag([9.3 * 3.0e-5, 9.3 * 3.0e-5, 11.5 * 8.6e-5]) @ R.T
+        eps, loss = 0.5 * (eps + eps.T), 0.5 * (loss + loss.T)  # (exactly symmetric: the packed form is chosen on an exact test)
+        mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[-0.3 * eps])
+        cond = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[0.3 * loss])
     Ar = ceed.curlcurlmass_operator(prob.geom, nd, mass, ceed.coefficient_context(3))
     Ai = ceed.ndmass_operator(prob.geom, nd, cond)
     A = linalg.ComplexParOperator(ctx, Ar, Ai, prob.ess[-1], linalg.DIAG_ONE)
@@ -396,7 +407,8 @@ def complex_leg(ctx, prob, reps=50, parity=True):
     ms = e0.elapsed_time(e1) / reps
     fused = bool(ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle))
     alg = Ar.algorithmic_bytes() + 16.0 * n
-    out = {"workload": f"ComplexParOperator::Mult, A = (K - w^2 eps M) + i w sigma M, ND p={nd.p}, {n} complex dofs",
+    out = {"workload": f"ComplexParOperator::Mult, A = (K - w^2 eps M) + i w sigma M, ND p={nd.p}, {n} complex dofs" +
+                       (", anisotropic eps and sigma (sapphire tensors, rotated)" if aniso else ""),
            "one_pass": fused, "ms": ms, "complex_dof_per_s": n / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
            "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
            "bytes_formula": "NE*(Q*11*8 + P*5) + 32*N_L: one pass over the element data, both parts of x and y"}
@@ -1542,9 +1554,10 @@ def main():
     p4 = None
     if rank == 0 and world == 1 and not args.no_p4:
         p4 = _leg(p4_leg, ctx, args.dofs)
-    cplx = h1 = None
+    cplx = cplx_aniso = h1 = None
     if rank == 0 and world == 1 and not args.no_p4:
         cplx = _leg(complex_leg, ctx, prob)
+        cplx_aniso = _leg(complex_leg, ctx, prob, 50, True, True)
         h1 = _leg(h1_leg, ctx, prob)
     eig = None
     if rank == 0 and world == 1 and not args.no_p4:
@@ -1604,7 +1617,7 @@ def main():
                        "parallelism": f"element partition x{world}, halo (P / P^T) and global sums over "
                                       + ("the peer transport (direct xGMI stores; RCCL as the fall-back)" if (world > 1 and ctx.peer_ready())
                                          else "RCCL")},
-            "rehearsal": rehearsal, "pre_warm_steps": args.pre_warm, "halo": halo_info, "n_ranks_legs": nranks, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "h1": h1, "eigenmode": eig, "cpw": cpw, "cpw_iso": cpw_iso, "spheres": sph, "magnetostatic": mag, "tets_mfma": tets,
+            "rehearsal": rehearsal, "pre_warm_steps": args.pre_warm, "halo": halo_info, "n_ranks_legs": nranks, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "complex_aniso": cplx_aniso, "h1": h1, "eigenmode": eig, "cpw": cpw, "cpw_iso": cpw_iso, "spheres": sph, "magnetostatic": mag, "tets_mfma": tets,
             "setup_s": t_setup,
         }
         sys.stdout.flush()

@@ -370,7 +370,15 @@ int pa_op_is_symmetric(const pa_op *op);
  * policy; the imaginary one is DIAG_ZERO, linalg/rap.cpp:450-457).
  * pa_op_complex_fused returns 2 for the dense-table form of the same idea (op_r: curl-curl + mass, op_i: mass / curl-curl / both
  * on the same H(curl) space -- tetrahedra, all straight-sided or all curved; any symmetric materials): the 16 element columns of
- * the matrix-core products carry 8 elements x {real, imaginary} part; plain form only (ess_policy = -1). */
+ * the matrix-core products carry 8 elements x {real, imaginary} part; meshes mixing straight and curved elements and the essential
+ * list too (round 5).
+ * Round 5, hexahedra with ANISOTROPIC materials (return value 1 as well): both operators in the packed form (symmetric D of each
+ * term at every point, 6 or 12 doubles, Q1 = 4, p <= 3) -- the even lane groups load the real operator's D, the odd ones the
+ * imaginary operator's, each applies its D to both parts of the quadrature values and hands over the product that belongs to the
+ * other part; every byte of both operators' D read once.
+ * Return values 2 and 3 (3: hexahedral form): the FIRST sub-operators of op_r and op_i pair up in the one pass; every further
+ * dense sub-operator of either (surface terms: absorbing boundaries, lumped ports, the A2(omega) terms of
+ * models/spaceoperator.cpp:786-804) is applied after it to both parts of x, with the signs of operator.cpp:98-134. */
 int pa_op_complex_fused(const pa_op *op_r, const pa_op *op_i);
 int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double *xi, double *yr, double *yi, int ess_policy,
                        void *stream);

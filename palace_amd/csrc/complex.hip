@@ -342,7 +342,7 @@ ComplexWrapperOperator::ComplexWrapperOperator(const Context &ctx, const Operato
     const auto *li = dynamic_cast<const ceed::Operator *>(&pi->LocalOperator());
     const int ne = pr->NumEssentialTrueDofs();
     const int kind = (lr && li) ? ceed::Operator::ComplexFused(*lr, *li) : 0;
-    bool same = kind != 0 && ne == pi->NumEssentialTrueDofs() && (ne == 0 || (pr->FusesEssential() && (kind != 2 || pi->FusesEssential()))) &&  // (round 5: the dense form too)
+    bool same = kind != 0 && ne == pi->NumEssentialTrueDofs() && (ne == 0 || (pr->FusesEssential() && (kind == 1 || pi->FusesEssential()))) &&  // (round 5: the forms with further sub-operators too)
                 (ne == 0 || pi->GetDiagonalPolicy() == ParOperator::DiagonalPolicy::DIAG_ZERO);
     if (same && ne) {  // the two lists, once
       std::vector<int32_t> a((size_t)ne), b((size_t)ne);
@@ -517,7 +517,7 @@ void ComplexParOperator::UpdateFused() {
   // its gathers): only if this wrapper's list is the one fused into Ar
   if (n_ess_ && !(RAPr_ && RAPr_->FusesEssential())) return;
   // (dense form: the imaginary operator may carry further sub-operators -- surface terms -- that mask x through their own index copies)
-  if (n_ess_ && kind == 2 && !(RAPi_ && RAPi_->FusesEssential())) return;
+  if (n_ess_ && kind != 1 && !(RAPi_ && RAPi_->FusesEssential())) return;
   fused_r_ = cr, fused_i_ = ci;
 }
 ComplexParOperator::~ComplexParOperator() {

@@ -438,11 +438,12 @@ static void apply(pa_op *op, const double *x, double *y, bool overwrite, hipStre
 }
 
 // Operators with a single H(curl) hex block: dofs with exactly one element copy skip the E-vector
-// (PALACE_AMD_DIRECT=0 keeps every dof on the gather path).
+// (PALACE_AMD_DIRECT=0 keeps every dof on the gather path).  Dense sub-operators next to it (round 5: the surface terms of a
+// volume operator) do not change that: apply() runs the hex block first, overwriting, and they accumulate after its gather.
 void finalize_exclusive(pa_op *op) {
   const char *mode = getenv("PALACE_AMD_DIRECT");
   if (mode && std::string(mode) == "0") return;
-  if (op->subs.size() != 1 || !op->dsubs.empty()) return;
+  if (op->subs.size() != 1 || !op->msubs.empty()) return;
   SubOp *so = op->subs[0];
   if (!so->d_ye || so->d_perm_x || !so->h_shared.empty()) return;
   if (so->fe_type == PA_FE_H1) {
@@ -978,17 +979,19 @@ int pa_op_apply_add_transpose(pa_op *op, const double *x, double *y, void *strea
   });
 }
 
+/* 0: no fused form; 1: hexahedral streaming form; 2: dense-table form; 3: hexahedral form followed by further (surface)
+ * sub-operators.  In forms 2 and 3 the FIRST sub-operators of the two parts pair up in one pass over the element data; every further
+ * dense sub-operator of either part (the surface terms of a driven problem -- absorbing boundary, lumped ports, the A2(omega)
+ * terms of spaceoperator.cpp:786-804: a handful of boundary faces) is applied after it on both parts of x. */
 int pa_op_complex_fused(const pa_op *op_r, const pa_op *op_i) {
   if (!op_r || !op_i || !op_r->msubs.empty() || !op_i->msubs.empty() || op_r->height != op_i->height || op_r->width != op_i->width)
     return 0;
-  const bool hex = op_r->subs.size() == 1 && op_i->subs.size() == 1 && op_r->dsubs.empty() && op_i->dsubs.empty();
-  // dense blocks: the first sub-operator of the imaginary part pairs with the real part's block; further ones (the surface terms
-  // of a driven problem: absorbing boundary, lumped ports -- a handful of boundary faces) are applied after the fused pass
-  const bool dense = op_r->dsubs.size() == 1 && op_i->dsubs.size() >= 1 && op_r->subs.empty() && op_i->subs.empty();
+  const bool hex = op_r->subs.size() == 1 && op_i->subs.size() == 1;
+  const bool dense = op_r->dsubs.size() >= 1 && op_i->dsubs.size() >= 1 && op_r->subs.empty() && op_i->subs.empty();
   if (!hex && !dense) return 0;
   // (the check compares the two restrictions on the host: once per pair)
   if (op_r->cplx_partner != op_i->id) {
-    op_r->cplx_ok = hex ? (nd_hex_stream_complex_ok(*op_r->subs[0], *op_i->subs[0]) ? 1 : 0)
+    op_r->cplx_ok = hex ? (nd_hex_stream_complex_ok(*op_r->subs[0], *op_i->subs[0]) ? ((op_r->dsubs.empty() && op_i->dsubs.empty()) ? 1 : 3) : 0)
                         : (dense_complex_ok(*op_r->dsubs[0], *op_i->dsubs[0]) ? 2 : 0);
     op_r->cplx_partner = op_i->id;
   }
@@ -1002,38 +1005,43 @@ int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double 
     const int kind = pa_op_complex_fused(op_r, op_i);
     PA_REQUIRE(kind, "the two operators have no fused complex form (pa_op_complex_fused)");
     PA_REQUIRE(xr != yr && xr != yi && xi != yr && xi != yi, "in-place apply is not supported");
+    const bool masked = ess_policy >= 0;
+    hipStream_t s = (hipStream_t)stream;
     if (kind == 2) {  // dense tables (tetrahedra, ...)
       DenseSub *dr = op_r->dsubs[0];
       // ParOperator's essential dofs (round 5): entries read as zero through the flagged index copy of the REAL operator, rows
       // fixed by the two gathers -- yr[ess] = xr[ess] | 0, yi[ess] = xi[ess] | 0 (rap.cpp:450-457 on one rank, as the hex form)
-      const bool masked = ess_policy >= 0;
       PA_REQUIRE(!masked || (op_r->has_essential && dr->d_idx_bc && dr->d_ess_flag),
                  "pa_op_set_essential has not been called on the real operator");
       if (!dr->d_ye2) dr->d_ye2 = dev_alloc<double>((size_t)dr->nb * dr->KP * 64);
-      launch_dense_complex(*dr, *op_i->dsubs[0], xr, xi, dr->d_ye2, (hipStream_t)stream, masked);
-      launch_dense_gather(*dr, yr, false, (hipStream_t)stream, nullptr, nullptr, masked ? xr : nullptr, ess_policy);
-      launch_dense_gather(*dr, yi, false, (hipStream_t)stream, dr->d_ye2, nullptr, masked ? xi : nullptr, ess_policy);
-      // the remaining sub-operators B of the imaginary part: yi += B xr, yr -= B xi (operator.cpp:98-134), essential entries of
-      // x read as zero through B's own flagged index copy, essential rows of y left as the gathers above fixed them
-      for (size_t k = 1; k < op_i->dsubs.size(); k++) {
-        const DenseSub &b = *op_i->dsubs[k];
-        PA_REQUIRE(!masked || (op_i->has_essential && b.d_ess_flag), "pa_op_set_essential has not been called on the imaginary operator");
-        launch_dense_apply(b, xr, masked, (hipStream_t)stream);
-        launch_dense_gather_signed(b, yi, +1.0, masked, (hipStream_t)stream);
-        launch_dense_apply(b, xi, masked, (hipStream_t)stream);
-        launch_dense_gather_signed(b, yr, -1.0, masked, (hipStream_t)stream);
-      }
-      return;
+      launch_dense_complex(*dr, *op_i->dsubs[0], xr, xi, dr->d_ye2, s, masked);
+      launch_dense_gather(*dr, yr, false, s, nullptr, nullptr, masked ? xr : nullptr, ess_policy);
+      launch_dense_gather(*dr, yi, false, s, dr->d_ye2, nullptr, masked ? xi : nullptr, ess_policy);
+    } else {
+      SubOp *sr = op_r->subs[0];
+      PA_REQUIRE(!masked || (op_r->has_essential && sr->d_perm_s_bc), "pa_op_set_essential has not been called on the real operator");
+      if (!sr->d_ye2) sr->d_ye2 = dev_alloc<double>((size_t)((sr->ne + 3) & ~3) * sr->P);
+      if (sr->qd->metric) stream_element_coefficients(*op_i->subs[0]);
+      launch_nd_hex_stream_complex(*sr, *op_i->subs[0], xr, xi, yr, yi, sr->d_ye2, masked, s);
+      launch_et_run_gather(*sr, yr, false, s, xr, masked, ess_policy);
+      launch_et_run_gather(*sr, yi, false, s, xi, masked, ess_policy, sr->d_ye2);
     }
-    SubOp *sr = op_r->subs[0];
-    const bool masked = ess_policy >= 0;
-    PA_REQUIRE(!masked || (op_r->has_essential && sr->d_perm_s_bc), "pa_op_set_essential has not been called on the real operator");
-    if (!sr->d_ye2) sr->d_ye2 = dev_alloc<double>((size_t)((sr->ne + 3) & ~3) * sr->P);
-    stream_element_coefficients(*op_i->subs[0]);
-    hipStream_t s = (hipStream_t)stream;
-    launch_nd_hex_stream_complex(*sr, *op_i->subs[0], xr, xi, yr, yi, sr->d_ye2, masked, s);
-    launch_et_run_gather(*sr, yr, false, s, xr, masked, ess_policy);
-    launch_et_run_gather(*sr, yi, false, s, xi, masked, ess_policy, sr->d_ye2);
+    // the remaining sub-operators (operator.cpp:98-134 term by term): B of the real part, yr += B xr, yi += B xi; B of the
+    // imaginary part, yi += B xr, yr -= B xi; essential entries of x read as zero through B's own flagged index copy, essential
+    // rows of y left as the gathers above fixed them
+    for (int part = 0; part < 2; part++) {
+      const pa_op *op = part ? op_i : op_r;
+      for (size_t k = (kind == 2 ? 1 : 0); k < op->dsubs.size(); k++) {
+        const DenseSub &b = *op->dsubs[k];
+        PA_REQUIRE(!masked || (op->has_essential && b.d_ess_flag),
+                   part ? "pa_op_set_essential has not been called on the imaginary operator"
+                        : "pa_op_set_essential has not been called on the real operator");
+        launch_dense_apply(b, xr, masked, s);
+        launch_dense_gather_signed(b, part ? yi : yr, +1.0, masked, s);
+        launch_dense_apply(b, xi, masked, s);
+        launch_dense_gather_signed(b, part ? yr : yi, part ? -1.0 : +1.0, masked, s);
+      }
+    }
   });
 }
 

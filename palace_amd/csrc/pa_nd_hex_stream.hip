@@ -83,6 +83,10 @@ struct NDStreamArgs {
   // complex form (CPLX): imaginary parts of x, y and of the E-vector, coefficients of the imaginary operator
   const double *x1, *coef1;
   double *y1, *ye1;
+  // complex form on packed D (anisotropic materials): q-data of the imaginary operator, and where the mass / curl-curl components of
+  // each operator start in its packed block (-1: the operator has no such term), components per point (6 or 12)
+  const double *qdata1;
+  int qm[2], qc[2], qn[2];
   // split vectors (SPLIT; multi-rank applies without L-vector copies): local dofs [0, nsplit) live in x / y, the ghosts
   // [nsplit, lsize) in xg (input: one of two buffers, chosen by the parity of *xg_sel, a device-resident exchange counter) and
   // yg (output).  xg0 / xg1 / yg are stored shifted by -nsplit, so that they are indexed with the local dof itself.
@@ -100,6 +104,11 @@ struct NDStreamArgs {
 // the two parts of x: the even 16-lane groups of a wave carry the real part, the odd ones the imaginary part of the same
 // element, both read the element's index words and q-data (one HBM read), exchange their quadrature values with the
 // neighbouring group once and store to the real / imaginary y and E-vector.  One pass over the geometry data instead of four.
+// CPLX on packed D (!METRIC; anisotropic materials, round 5): the two operators' symmetric D (mass and / or curl-curl, six doubles per
+// point each) do not share a geometric factor, so the even groups load the REAL operator's D and the odd groups the IMAGINARY
+// operator's -- every byte of both read once, 96 registers of q-data per lane as in the real kernel -- and each group applies its D
+// to BOTH parts of the quadrature values (its own and the neighbouring group's), keeps the product that belongs to its part of y
+// and hands the other one over: y_r = D_r u_r - D_i u_i, y_i = D_i u_r + D_r u_i (linalg/operator.cpp:98-134 at the points).
 // GEOMN (curl-curl with isotropic coefficients on hex27 elements; round 5): D = (c w / det J) J^T J is recomputed from the 27 nodes
 // of the element -- 648 B per element instead of 3 072 B of packed D.  The nodes are requested at the top of the batch (81 doubles
 // per element, 6 per lane), parked in the element's LDS strip after the forward passes, and every lane contracts them with its own
@@ -107,7 +116,7 @@ struct NDStreamArgs {
 // four points along the column costs 27 multiply-adds each.
 template <int P1, bool USE_U, bool USE_C, bool METRIC, int MINW, int GPOS, bool CPLX = false, bool SPLIT = false, int GEOMN = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kernel(const NDStreamArgs<P1> a) {
-  static_assert(!CPLX || (METRIC && USE_U && USE_C), "the complex form is built on the metric curl-curl + mass kernel");
+  static_assert(!CPLX || (USE_U && USE_C), "the complex form is built on the curl-curl + mass kernels");
   static_assert(!(CPLX && SPLIT), "no split-vector form of the complex kernel");
   static_assert(!GEOMN || (!USE_U && USE_C && !METRIC && !CPLX), "geometry from the nodes: the curl-curl kernel");
   constexpr int Q1 = 4;
@@ -216,6 +225,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   };
   auto load_q = [&](const int ee, const int t) {
     if (GEOMN) return load_xn(ee, t);  // (the nodes of the batch: consumed in its D stage)
+    if (CPLX && !METRIC) {  // this group's operator: mass components into gq[0 .. 11], curl-curl into gq[12 .. 23]
+      const int grp = (lane >> 4) & 1;
+      const int mo = a.qm[grp], co = a.qc[grp];
+      const d2v *g = reinterpret_cast<const d2v *>(grp ? a.qdata1 : a.qdata) + ((size_t)ee * (2 * a.qn[grp] * 16) + t);
+      const d2v zero = {0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        gq[k] = mo >= 0 ? __builtin_nontemporal_load(&g[16 * (2 * mo + k)]) : zero;
+        gq[12 + k] = co >= 0 ? __builtin_nontemporal_load(&g[16 * (2 * co + k)]) : zero;
+      }
+      return;
+    }
     const d2v *g = reinterpret_cast<const d2v *>(a.qdata) + ((size_t)ee * (2 * (METRIC ? 7 : NG) * 16) + t);
 #pragma unroll
     // (read once: non-temporal, so the stream does not displace x / y lines in L2; measured 5 - 7 % on the apply)
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     if (!QAHEAD) load_q(e, t);
     d2v ce = {0.0, 0.0}, ci = {0.0, 0.0};
     if (METRIC || GEOMN) ce = reinterpret_cast<const d2v *>(a.coef)[e];
-    if (CPLX) ci = reinterpret_cast<const d2v *>(a.coef1)[e];
+    if (CPLX && METRIC) ci = reinterpret_cast<const d2v *>(a.coef1)[e];
 
     // E: sorted entries into their tensor-order slots (x of this batch was requested during the previous one)
 #pragma unroll
@@ -428,6 +449,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
         if (USE_C) {
           const double m[6] = {ccurl * H[0], ccurl * H[1], ccurl * H[2], ccurl * H[3], ccurl * H[4], ccurl * H[5]};
           sym_mv(m, CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one point at a time: short live ranges
+      } else if (CPLX) {
+        // this group's D on both parts: the product with the real part stays (D_r u_r for y_r, D_i u_r for y_i), the product with
+        // the imaginary part goes to the other group (D_i u_i, subtracted from y_r; D_r u_i, added to y_i)
+        const bool im = sub & 1;
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+          double(&W)[3][Q1] = f ? CU : U;
+          double ur[3], ui[3], ar[3], ai[3];
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const double pv = __shfl_xor(W[c][qz], 16, 64);
+            ur[c] = im ? pv : W[c][qz], ui[c] = im ? W[c][qz] : pv;
+          }
+          sym_mv(&H[6 * f], ur[0], ur[1], ur[2], ar[0], ar[1], ar[2]);
+          sym_mv(&H[6 * f], ui[0], ui[1], ui[2], ai[0], ai[1], ai[2]);
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const double got = __shfl_xor(ai[c], 16, 64);
+            W[c][qz] = im ? ar[c] + got : ar[c] - got;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);  // one point at a time: short live ranges
       } else {
@@ -605,7 +648,7 @@ bool nd_hex_stream_ok(const SubOp &so) {
   if (!enabled) return false;
   if (so.q1d == 5) return nd_hex_stream5_ok(so);  // five points per direction: pa_nd_hex_stream5.hip
   if (so.fe_type != PA_FE_HCURL || so.q1d != 4 || so.p > 3 || !so.qd || !so.d_ye || !so.d_perm_x) return false;
-  return so.qd->metric || so.qd->ncomp == 6;
+  return so.qd->metric || so.qd->ncomp == 6 || (so.qd->ncomp == 12 && so.qf == PA_QF_HDIVMASS_33);
 }
 
 static bool wide_form(const SubOp &so) { return so.fe_type == PA_FE_HCURL && so.q1d == 5; }
@@ -937,8 +980,9 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
       if (m) launch_variant<P1, true, false, true, 3>(so, a, s); else launch_variant<P1, true, false, false, 3>(so, a, s);
       break;
     case PA_QF_HDIVMASS_33:
-      PA_REQUIRE(m, "streaming curl-curl + mass kernel needs the metric form");
-      launch_variant<P1, true, true, true, (P1 == 3 ? PA_KM_MINW : 2)>(so, a, s);
+      // (packed D of both terms, anisotropic materials: twelve doubles per point, 96 registers of q-data per lane; round 5)
+      if (m) launch_variant<P1, true, true, true, (P1 == 3 ? PA_KM_MINW : 2)>(so, a, s);
+      else launch_variant<P1, true, true, false, 2>(so, a, s);
       break;
     default: throw Error("QFunction not available for H(curl) hexahedra");
   }
@@ -963,16 +1007,23 @@ void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool mask
 // mass terms: they share the index arrays and the q-data and differ by their per-element scalar coefficients only.
 bool nd_hex_stream_complex_ok(const SubOp &sr, const SubOp &si) {
   static const bool enabled = !(getenv("PALACE_AMD_COMPLEX_FUSED") && atoi(getenv("PALACE_AMD_COMPLEX_FUSED")) == 0);
-  // the real operator provides the kernel's arrays (metric form: the q-data is the geometry's J^T J, shared by every such
-  // operator on it); the imaginary one only its per-element scalars (stream_element_coefficients)
-  auto kind_ok = [](const SubOp &so) {
-    return so.fe_type == PA_FE_HCURL && so.iso && ((so.q1d == 4 && so.p <= 3) || (so.q1d == 5 && so.p <= 4 && nd_hex_stream5_ok(so))) &&
-           !so.geom->h_attr.empty() &&
-           (so.qf == PA_QF_HDIV_33 || so.qf == PA_QF_HCURL_33 || so.qf == PA_QF_HDIVMASS_33);
+  auto qf_ok = [](const SubOp &so) {
+    return so.fe_type == PA_FE_HCURL && (so.qf == PA_QF_HDIV_33 || so.qf == PA_QF_HCURL_33 || so.qf == PA_QF_HDIVMASS_33);
   };
-  if (!enabled || !kind_ok(sr) || !kind_ok(si)) return false;
-  if (!(sr.d_idxc && sr.d_coef_s && sr.qd && sr.qd->metric)) return false;
-  if (sr.geom != si.geom || sr.ne != si.ne || sr.p != si.p || sr.P != si.P) return false;
+  if (!enabled || !qf_ok(sr) || !qf_ok(si)) return false;
+  if (sr.geom != si.geom || sr.ne != si.ne || sr.p != si.p || sr.P != si.P || sr.q1d != si.q1d) return false;
+  // metric form (isotropic materials): the real operator provides the kernel's arrays (the q-data is the geometry's J^T J, shared by
+  // every such operator on it); the imaginary one only its per-element scalars (stream_element_coefficients)
+  auto iso_ok = [](const SubOp &so) {
+    return so.iso && ((so.q1d == 4 && so.p <= 3) || (so.q1d == 5 && so.p <= 4 && nd_hex_stream5_ok(so))) && !so.geom->h_attr.empty();
+  };
+  const bool metric = iso_ok(sr) && iso_ok(si) && sr.d_idxc && sr.d_coef_s && sr.qd && sr.qd->metric;
+  // packed form (anisotropic materials, four points per direction; round 5): each operator's own packed symmetric D, 6 or 12 per point
+  auto packed_ok = [](const SubOp &so) {
+    return so.q1d == 4 && so.p <= 3 && so.qd && !so.qd->metric && so.qd->ncomp == (so.qf == PA_QF_HDIVMASS_33 ? 12 : 6);
+  };
+  const bool packed = packed_ok(sr) && packed_ok(si) && sr.d_idxc;
+  if (!metric && !packed) return false;
   return sr.h_sidx == si.h_sidx;  // same restriction (host compare; the callers cache the answer)
 }
 
@@ -986,9 +1037,20 @@ static void launch_complex_p(const SubOp &sr, const SubOp &si, const double *xr,
   a.slots = sr.d_slots;
   a.qdata = sr.qd->d;
   a.coef = sr.d_coef_s, a.coef1 = si.d_coef_s;
+  a.xn = nullptr, a.gtab = nullptr;
   a.x = xr, a.x1 = xi, a.y = yr, a.y1 = yi, a.ye = sr.d_ye, a.ye1 = ye_i;
   a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
-  launch_gpos<P1, true, true, true, 2, 2, true>(sr, a, s);
+  a.qdata1 = nullptr;
+  if (sr.qd->metric) return launch_gpos<P1, true, true, true, 2, 2, true>(sr, a, s);
+  const SubOp *ops[2] = {&sr, &si};
+  for (int g = 0; g < 2; g++) {  // (pa_nd_hex.hip: packed q-data holds the mass block first, then the curl-curl block)
+    const int qf = ops[g]->qf;
+    a.qn[g] = ops[g]->qd->ncomp;
+    a.qm[g] = (qf == PA_QF_HCURL_33 || qf == PA_QF_HDIVMASS_33) ? 0 : -1;
+    a.qc[g] = qf == PA_QF_HDIV_33 ? 0 : (qf == PA_QF_HDIVMASS_33 ? 6 : -1);
+  }
+  a.qdata1 = si.qd->d;
+  launch_gpos<P1, true, true, false, 2, 2, true>(sr, a, s);
 }
 
 void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,

@@ -88,9 +88,16 @@ mesh = ogrid_cylinder(2, 3)
 mesh.attr[:] = 1 + (np.arange(mesh.ne) %% 2)
 nd = NDHexSpace(mesh, p)
 geom = ceed.GeomFactorData(mesh, q1d)
-two = lambda a, b: ceed.coefficient_context(3, attr_mat=[0, 1], mat_coeff=[np.array([a]), np.array([b])])
-Ar = ceed.curlcurlmass_operator(geom, nd, two(-0.9, -0.35), two(1.0, 0.6))
-Ai = ceed.ndmass_operator(geom, nd, two(0.21, 0.05))
+mat = sys.argv[4] if len(sys.argv) > 4 else "iso"
+two = lambda a, b: ceed.coefficient_context(3, attr_mat=[0, 1], mat_coeff=[np.asarray(a, float), np.asarray(b, float)])
+if mat == "iso":
+    Ar = ceed.curlcurlmass_operator(geom, nd, two(-0.9, -0.35), two(1.0, 0.6))
+    Ai = ceed.ndmass_operator(geom, nd, two(0.21, 0.05))
+else:  # symmetric material tensors (tests/test_complex_gpu.py: _tensors): packed D of each operator, the complex kernel on them
+    T = np.load(sys.argv[5])
+    Ar = ceed.curlcurlmass_operator(geom, nd, two(T["mr0"], T["mr1"]), two(T["cr0"], T["cr1"]))
+    Ai = (ceed.ndmass_operator(geom, nd, two(T["mi0"], T["mi1"])) if mat == "aniso" else
+          ceed.curlcurlmass_operator(geom, nd, two(T["mi0"], T["mi1"]), two(T["ci0"], T["ci1"])))
 ess = nd.ess_dofs()
 n = nd.ndofs
 rng = np.random.default_rng(3)
@@ -110,8 +117,22 @@ print("OK")
 '''
 
 
-@pytest.mark.parametrize("p,q1d", [(1, 4), (2, 4), (3, 4), (4, 5), (2, 5), (1, 5)])
-def test_fused_complex_apply(p, q1d, tmp_path):
+def _tensors():
+    """Two materials' symmetric tensors: mass (indefinite real part as in K - w^2 eps M, a loss tensor for the imaginary part) and
+    curl-curl (inverse permeability; a second one for an imaginary curl-curl term)."""
+    rng = np.random.default_rng(21)
+
+    def spd(scale):
+        a = rng.uniform(-1, 1, (3, 3))
+        return scale * (a @ a.T + 1.5 * np.eye(3))
+
+    return dict(mr0=-spd(0.4), mr1=-spd(0.2), cr0=spd(0.5), cr1=np.diag([0.6, 0.6, 0.9]), mi0=spd(0.1), mi1=np.diag([0.02, 0.02, 0.05]),
+                ci0=spd(0.07), ci1=spd(0.03))
+
+
+@pytest.mark.parametrize("p,q1d,mat", [(1, 4, "iso"), (2, 4, "iso"), (3, 4, "iso"), (4, 5, "iso"), (2, 5, "iso"), (1, 5, "iso"),
+                                       (1, 4, "aniso"), (2, 4, "aniso"), (3, 4, "aniso"), (3, 4, "aniso2"), (2, 4, "aniso2")])
+def test_fused_complex_apply(p, q1d, mat, tmp_path):
     """y = (A_r + i A_i) x in one pass over the element data (pa_op_mult_complex): the complex streaming
     kernel (four points per direction: pa_nd_hex_stream.hip, five: pa_nd_hex_stream5.hip -- order 4 and the coarsened levels of an
     order-4 problem) against the four separate applies (PALACE_AMD_COMPLEX_FUSED=0, the path of linalg/operator.cpp:98-134) and against the
@@ -126,7 +147,9 @@ def test_fused_complex_apply(p, q1d, tmp_path):
     res = {}
     for fused in (1, 0):
         f = str(tmp_path / f"out{fused}.npz")
-        r = subprocess.run([sys.executable, "-c", FUSED_CHECK % root, str(p), f, str(q1d)], capture_output=True, text=True, timeout=300,
+        tf = str(tmp_path / "tensors.npz")
+        np.savez(tf, **_tensors())
+        r = subprocess.run([sys.executable, "-c", FUSED_CHECK % root, str(p), f, str(q1d), mat, tf], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, PALACE_AMD_COMPLEX_FUSED=str(fused)))
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
         res[fused] = np.load(f)
@@ -141,9 +164,17 @@ def test_fused_complex_apply(p, q1d, tmp_path):
     ogeom = util.oracle_geom(mesh, q1d)
     off, ori = nd.native_restriction()
     interp, curl = util.dense_tables(nd, q1d)
-    two = lambda a, b: po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.array([a]), np.array([b])])  # noqa: E731
-    Aro = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HDIVMASS, two(-0.9, -0.35), two(1.0, 0.6))
-    Aio = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HCURL, two(0.21, 0.05))
+    two = lambda a, b: po.CoeffCtx(attr_mat=[0, 1], mat_coeff=[np.asarray(a, float), np.asarray(b, float)])  # noqa: E731
+    T = _tensors()
+    if mat == "iso":
+        Aro = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HDIVMASS, two(-0.9, -0.35), two(1.0, 0.6))
+        Aio = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HCURL, two(0.21, 0.05))
+    else:
+        Aro = po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HDIVMASS, two(T["mr0"], T["mr1"]),
+                                    two(T["cr0"], T["cr1"]))
+        Aio = (po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HCURL, two(T["mi0"], T["mi1"])) if mat == "aniso" else
+               po.CeedOperatorOracle(nd.ndofs, off, ori, interp, curl, ogeom, po.QF_HDIVMASS, two(T["mi0"], T["mi1"]),
+                                     two(T["ci0"], T["ci1"])))
     xr, xi = res[1]["xr"], res[1]["xi"]
     z = lambda: np.zeros(nd.ndofs)  # noqa: E731
     yr = Aro.apply_add(xr, z()) - Aio.apply_add(xi, z())
@@ -306,3 +337,98 @@ def test_complex_pcg_on_a_hermitian_positive_definite_system(cylinder_mesh):
         xs = xr.cpu().numpy() + 1j * xi.cpu().numpy()
         assert np.linalg.norm(xs - xo) < 1e-8 * np.linalg.norm(xo)
         assert np.linalg.norm(Ao @ xs - b) < 1e-8 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("elements,mat", [("hex", "iso"), ("hex", "aniso"), ("tet", "aniso")])
+def test_fused_complex_apply_with_surface_terms(elements, mat):
+    """A(omega) = K + i omega C - omega^2 M + A2(omega) with surface terms in BOTH parts (models/spaceoperator.cpp:786-804: impedance /
+    absorbing boundaries and ports add f_apply_hcurl_32 terms to C, A2 adds them to the real and the imaginary part): the volume
+    operators pair up in the one-pass kernel (pa_op_complex_fused = 3 on hexahedra, 2 on tetrahedra), every further sub-operator of
+    either part is applied after it to both parts of x.  Against the SAME operators applied one by one and combined term by term
+    as linalg/operator.cpp:98-134 does (each of them is checked against the oracle in test_apply_gpu / test_dense_gpu /
+    test_tet_gpu), plain and through ComplexParOperator with essential dofs (rap.cpp:450-457)."""
+    from palace_amd.fem.mesh import ogrid_cylinder
+
+    ctx = linalg.Context()
+    T = _tensors()
+    two = lambda a, b: ceed.coefficient_context(3, attr_mat=[0, 1], mat_coeff=[np.asarray(a, float), np.asarray(b, float)])  # noqa: E731
+    if mat == "iso":
+        cm_r, cc_r, cm_i = two(-0.9, -0.35), two(1.0, 0.6), two(0.21, 0.05)
+    else:
+        cm_r, cc_r, cm_i = two(T["mr0"], T["mr1"]), two(T["cr0"], T["cr1"]), two(T["mi0"], T["mi1"])
+    if elements == "hex":
+        from palace_amd.fem.fespace import NDHexBoundaryBlock
+
+        mesh = ogrid_cylinder(2, 3)
+        mesh.attr[:] = 1 + (np.arange(mesh.ne) % 2)
+        nd = NDHexSpace(mesh, 3)
+        vgeom = ceed.GeomFactorData(mesh, 4)
+        nb = int(mesh.boundary_face_mask[mesh.elem_faces].sum())
+        blk = NDHexBoundaryBlock(nd, attr=1 + (np.arange(nb) % 2))
+        interp, grad, w = blk.tables(4)
+        sgeom = ceed.DenseGeomFactorData(blk.elem_nodes, blk.nodes, blk.attr, grad, w)
+        sblock = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, blk.offsets, interp, None, orients=blk.orients)
+
+        def volume(op, qf, blob, ev):
+            return op.add_integrator(vgeom, nd, qf, blob, ev)
+
+        ess = nd.ess_dofs()[::2].copy()  # (part of the boundary: the surface terms touch free and essential dofs)
+    else:
+        from palace_amd.fem import tet, tri
+
+        mesh = tet.cube_tet_mesh(3)
+        mesh.attr[:] = 1 + (np.arange(mesh.ne) % 2)
+        nd = tet.NDTetSpace(mesh, 2)
+        pts, wts = tet.default_tet_rule(2)
+        vi, vc = nd.elem.tables(pts)
+        vgeom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, mesh.geometry_grad_table(pts), wts)
+        kw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+        vblock = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, vi, vc, **kw)
+        faces = np.nonzero(mesh.boundary_face_mask)[0]
+        blk = tet.NDTetBoundaryBlock(nd, faces, 1 + (np.arange(faces.size) % 2))
+        spts, swts = tri.tri_quadrature(3)
+        si, _ = blk.elem.tables(spts)
+        sgeom = ceed.DenseGeomFactorData(blk.elem_nodes, blk.nodes, blk.attr, blk.geometry_grad_table(spts), swts)
+        sblock = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, blk.offsets, si, None, orients=blk.orients)
+
+        def volume(op, qf, blob, ev):
+            return op.add_dense_integrator(vgeom, vblock, qf, blob, ev)
+
+        ess = nd.ess_dofs()[::2].copy()
+    n = nd.ndofs
+    s_r, s_i = two(0.11, -0.07), two(0.4, 0.25)  # A2's real part (a reactive surface term) and the damping surface term
+
+    def surface(op, blob):
+        return op.add_dense_integrator(sgeom, sblock, ceed.QF_HCURL_32, blob, ceed.EVAL_INTERP)
+
+    new = lambda: ceed.Operator(n, n)  # noqa: E731
+    both = ceed.EVAL_CURL | ceed.EVAL_INTERP
+    Ar = surface(volume(new(), ceed.QF_HDIVMASS_33, np.concatenate([cm_r, cc_r]), both), s_r).finalize()
+    Ai = surface(volume(new(), ceed.QF_HCURL_33, cm_i, ceed.EVAL_INTERP), s_i).finalize()
+    parts = [volume(new(), ceed.QF_HDIVMASS_33, np.concatenate([cm_r, cc_r]), both).finalize(), surface(new(), s_r).finalize(),
+             volume(new(), ceed.QF_HCURL_33, cm_i, ceed.EVAL_INTERP).finalize(), surface(new(), s_i).finalize()]
+    assert ceed._lib.load().pa_op_complex_fused(Ar.handle, Ai.handle) == (3 if elements == "hex" else 2)
+    rng = np.random.default_rng(8)
+    xr, xi = (_dev(rng.uniform(-1, 1, n)) for _ in range(2))
+
+    def term_by_term(vr, vi):
+        def app(o, v):
+            y = torch.empty_like(v)
+            o.mult(v, y)
+            return y
+
+        a_r = lambda v: app(parts[0], v) + app(parts[1], v)  # noqa: E731
+        a_i = lambda v: app(parts[2], v) + app(parts[3], v)  # noqa: E731
+        return a_r(vr) - a_i(vi), a_i(vr) + a_r(vi)
+
+    for e in (np.zeros(0, np.int32), ess):
+        A = linalg.ComplexParOperator(ctx, Ar, Ai, e, linalg.DIAG_ONE)
+        yr, yi = torch.empty_like(xr), torch.empty_like(xr)
+        A.mult(xr, xi, yr, yi)
+        mr, mi = xr.clone(), xi.clone()
+        ed = torch.from_numpy(e.astype(np.int64)).cuda()
+        mr[ed], mi[ed] = 0.0, 0.0
+        wr, wi = term_by_term(mr, mi)
+        wr[ed], wi[ed] = xr[ed], xi[ed]
+        scale = float(torch.maximum(wr.abs().max(), wi.abs().max()))
+        assert float((yr - wr).abs().max()) < 1e-13 * scale and float((yi - wi).abs().max()) < 1e-13 * scale, (elements, mat, e.size)
