@@ -7,7 +7,12 @@
 // With a halo on that level AMS is the ReplicatedCoarseSolver (ksp.hpp): the global level-0 problem is assembled from the ranks'
 // pieces by the C++ layer and solved redundantly -- where the reference hands HYPRE the distributed matrix (linalg/ksp.cpp:129-239).
 //
-//   ./solve_ranks prefix rank world dir [coarse=ams|pcg]
+// coarse = amg (round 5): the H1 problem of BASELINE config 4's shape instead -- (eps grad u, grad v) = b on the H1 spaces, PCG +
+// p-multigrid with LinearSolver::BOOMER_AMG on the lowest-order level.  With a halo that is the native V-cycle with its solve
+// DISTRIBUTED over the ranks (amg_dist.hpp; every rank its rows of every algebraic level, one halo exchange per product);
+// PALACE_AMD_COARSE_SOLVE=replicated: the whole cycle on the gathered problem on every rank (rounds 3-4).
+//
+//   ./solve_ranks prefix rank world dir [coarse=ams|pcg|amg]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -110,6 +115,50 @@ int main(int argc, char **argv) {
     muinv.AddMaterialProperty(1, 1.0);
     eps.AddMaterialProperty(1, 2.08);
     BilinearForm::pa_order_threshold = 2;  // the p = 1 level becomes a matrix (the reference assembles it for AMS)
+    if (coarse == "amg") {  // the scalar problem: H1 spaces only
+      BilinearForm g(h1_fespaces.GetFinestFESpace());
+      g.AddDomainIntegrator<DiffusionIntegrator>(eps);
+      auto g_ops = g.Assemble(h1_fespaces, false);
+      auto A = std::make_unique<MultigridOperator>(h1_fespaces.GetNumLevels());
+      for (std::size_t l = 0; l < h1_fespaces.GetNumLevels(); l++) {
+        const auto &fes = h1_fespaces.GetFESpaceAtLevel(l);
+        auto op = std::make_unique<FespaceParOperator>(std::move(g_ops[l]), fes);
+        op->SetEssentialTrueDofs(fes.GetEssentialTrueDofs(), ParOperator::DiagonalPolicy::DIAG_ONE);
+        A->AddOperator(std::move(op));
+      }
+      config::LinearSolverData linear;
+      linear.krylov_solver = KrylovSolver::CG;
+      linear.type = LinearSolver::BOOMER_AMG;
+      linear.tol = 1e-10, linear.max_it = 400;
+      linear.initial_guess = 0;
+      linear.SetDefaults(order, /*spd_problem=*/true);
+      KspSolver ksp(linear, /*verbose=*/0, h1_fespaces);
+      ksp.SetOperators(*A, *A);
+      const int n = A->Height();
+      Vector ones(n), rhs(n), x(n), res(n);
+      linalg::Fill(ctx, ones, 1.0);
+      {  // b = M 1: the load vector of a constant source (the same function whatever the partition)
+        BilinearForm m(h1_fespaces.GetFinestFESpace());
+        m.AddDomainIntegrator<MassIntegrator>(eps);
+        auto m_ops = m.Assemble(h1_fespaces, false);
+        FespaceParOperator M(std::move(m_ops.back()), h1_fespaces.GetFinestFESpace());
+        M.Mult(ones, rhs);
+      }
+      const auto &ess = A->GetFinestOperator().Par();
+      linalg::SetSubVector(ctx, rhs, ess.GetEssentialTrueDofs(), ess.NumEssentialTrueDofs(), 0.0);
+      ksp.Mult(rhs, x);
+      A->Mult(x, res);
+      linalg::AXPBY(ctx, 1.0, rhs, -1.0, res);
+      const double rn = linalg::Norml2(ctx, res) / linalg::Norml2(ctx, rhs), sx = linalg::Dot(ctx, x, ones), nglob = linalg::Dot(ctx, ones, ones);
+      comm.PeerCheck(stream);
+      if (rank == 0)
+        std::printf("cxx_host_ranks: world %d  order %d  levels %d  global ndofs %d  coarse %s  iterations %d  converged %d  "
+                    "|b - A x| / |b| %.3e  sum(x) %.12e\n",
+                    world, order, nlev, (int)std::lround(nglob), coarse.c_str(), ksp.GetKrylovSolver().GetNumIterations(),
+                    (int)ksp.GetKrylovSolver().GetConverged(), rn, sx);
+      if (world > 1) comm.Barrier(stream);
+      return 0;
+    }
     BilinearForm a(nd_fespaces.GetFinestFESpace());
     a.AddDomainIntegrator<CurlCurlMassIntegrator>(muinv, eps);
     auto a_ops = a.Assemble(nd_fespaces, /*skip_zeros=*/false);

@@ -184,17 +184,54 @@ double filtered_radius(const HostCsr &A, double theta) {
 }
 }  // namespace
 
-std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) {
+namespace {
+std::vector<int> aggregate_impl(const HostCsr &A, double theta, int &num_aggregates, const int *blk);
+}
+std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) { return aggregate_impl(A, theta, num_aggregates, nullptr); }
+
+std::vector<int> AggregateBlocks(const HostCsr &A, double theta, const std::vector<int> &block_off, int &num_aggregates,
+                                 std::vector<int> &agg_off) {
+  const int nb = (int)block_off.size() - 1;
+  PA_REQUIRE(nb >= 1 && block_off.front() == 0 && block_off.back() == A.nrows, "row blocks do not cover the matrix");
+  std::vector<int> blk((size_t)A.nrows);
+  for (int b = 0; b < nb; b++)
+    for (int i = block_off[(size_t)b]; i < block_off[(size_t)b + 1]; i++) blk[(size_t)i] = b;
+  int na = 0;
+  std::vector<int> agg = aggregate_impl(A, theta, na, blk.data());
+  // aggregates block by block, in the order of their first row inside a block
+  std::vector<int> ablk((size_t)na, -1), renum((size_t)na, -1);
+  for (int i = 0; i < A.nrows; i++)
+    if (agg[(size_t)i] >= 0 && ablk[(size_t)agg[(size_t)i]] < 0) ablk[(size_t)agg[(size_t)i]] = blk[(size_t)i];
+  agg_off.assign((size_t)nb + 1, 0);
+  for (int a = 0; a < na; a++) agg_off[(size_t)ablk[(size_t)a] + 1]++;
+  for (int b = 0; b < nb; b++) agg_off[(size_t)b + 1] += agg_off[(size_t)b];
+  std::vector<int> next(agg_off.begin(), agg_off.end() - 1);
+  for (int i = 0; i < A.nrows; i++) {
+    const int a = agg[(size_t)i];
+    if (a >= 0 && renum[(size_t)a] < 0) renum[(size_t)a] = next[(size_t)ablk[(size_t)a]]++;
+  }
+  for (int i = 0; i < A.nrows; i++)
+    if (agg[(size_t)i] >= 0) agg[(size_t)i] = renum[(size_t)agg[(size_t)i]];
+  num_aggregates = na;
+  return agg;
+}
+
+namespace {
+std::vector<int> aggregate_impl(const HostCsr &A, double theta, int &num_aggregates, const int *blk) {
   PA_REQUIRE(A.nrows == A.ncols, "aggregation needs a square matrix");
   const int n = A.nrows;
   const std::vector<double> d = diagonal(A);
+  // (blk: ties between rows of different blocks do not count)
+  auto strong = [&](double aij, double dii, double djj, double th, int i, int j) {
+    return (!blk || blk[i] == blk[j]) && palace::amg::strong(aij, dii, djj, th);
+  };
   std::vector<int> agg((size_t)n, -1);
   // rows without a strong off-diagonal entry (eliminated essential dofs: a lone diagonal) stay out of the coarse problem:
   // the smoother solves them, and carried along they would form one aggregate each and stop the coarsening
   std::vector<char> isolated((size_t)n, 1);
   for (int i = 0; i < n; i++)
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1] && isolated[i]; a++)
-      if (A.col[a] != i && strong(A.val[a], d[i], d[A.col[a]], theta)) isolated[i] = 0;
+      if (A.col[a] != i && strong(A.val[a], d[i], d[A.col[a]], theta, i, A.col[a])) isolated[i] = 0;
   int na = 0;
   // pass 1: a node whose strong neighbours are all free founds an aggregate with them
   for (int i = 0; i < n; i++) {
@@ -202,7 +239,7 @@ std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) 
     bool free_nbrs = true, any = false;
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1] && free_nbrs; a++) {
       const int j = A.col[a];
-      if (j == i || !strong(A.val[a], d[i], d[j], theta)) continue;
+      if (j == i || !strong(A.val[a], d[i], d[j], theta, i, j)) continue;
       any = true;
       if (agg[j] >= 0) free_nbrs = false;
     }
@@ -210,7 +247,7 @@ std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) 
     agg[i] = na;
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
       const int j = A.col[a];
-      if (j != i && strong(A.val[a], d[i], d[j], theta)) agg[j] = na;
+      if (j != i && strong(A.val[a], d[i], d[j], theta, i, j)) agg[j] = na;
     }
     na++;
   }
@@ -222,7 +259,7 @@ std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) 
     int to = -1;
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
       const int j = A.col[a];
-      if (j == i || pass1[j] < 0 || !strong(A.val[a], d[i], d[j], theta)) continue;
+      if (j == i || pass1[j] < 0 || !strong(A.val[a], d[i], d[j], theta, i, j)) continue;
       if (std::abs(A.val[a]) > best) best = std::abs(A.val[a]), to = pass1[j];
     }
     if (to >= 0) agg[i] = to;
@@ -233,13 +270,14 @@ std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates) 
     agg[i] = na;
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1]; a++) {
       const int j = A.col[a];
-      if (j != i && agg[j] < 0 && !isolated[j] && strong(A.val[a], d[i], d[j], theta)) agg[j] = na;
+      if (j != i && agg[j] < 0 && !isolated[j] && strong(A.val[a], d[i], d[j], theta, i, j)) agg[j] = na;
     }
     na++;
   }
   num_aggregates = na;
   return agg;
 }
+}  // namespace
 
 HostCsr TentativeProlongator(const std::vector<int> &aggregate, int num_aggregates) {
   HostCsr T;
@@ -298,6 +336,26 @@ HostCsr DropRows(const HostCsr &A, const std::vector<char> &flag) {
   return B;
 }
 
+
+Hierarchy SetupBlocks(const HostCsr &A0, const std::vector<int> &block_off, std::vector<std::vector<int>> &level_off, int max_levels,
+                      int coarse_size, double theta, double omega) {
+  Hierarchy h;
+  h.A.push_back(A0);
+  level_off.assign(1, block_off);
+  while ((int)h.A.size() < max_levels && h.A.back().nrows > coarse_size) {
+    const HostCsr &A = h.A.back();
+    int na = 0;
+    std::vector<int> next_off;
+    const std::vector<int> agg = AggregateBlocks(A, theta, level_off.back(), na, next_off);
+    if (na == 0 || na >= A.nrows) break;  // no coarsening left
+    HostCsr P = SmoothProlongator(A, TentativeProlongator(agg, na), theta, omega);
+    HostCsr Ac = Multiply(Transpose(P), Multiply(A, P));
+    h.P.push_back(std::move(P));
+    h.A.push_back(std::move(Ac));
+    level_off.push_back(std::move(next_off));
+  }
+  return h;
+}
 
 Hierarchy Setup(const HostCsr &A0, int max_levels, int coarse_size, double theta, double omega) {
   Hierarchy h;

@@ -28,6 +28,11 @@ void Mult(const HostCsr &A, const std::vector<double> &x, std::vector<double> &y
 // whose strong neighbourhood is still free, pass 2 attaches the remaining nodes to the neighbouring aggregate they are
 // most strongly tied to (isolated nodes become their own aggregates).  Returns the aggregate of each row.
 std::vector<int> Aggregate(const HostCsr &A, double theta, int &num_aggregates);
+// The same confined to blocks of consecutive rows (the rows a rank owns, block_off [nblocks + 1]): ties across blocks are not
+// strength ties, so that every aggregate lies inside one block, and the aggregates are numbered block by block
+// (agg_off [nblocks + 1]: the coarse rows of a block are consecutive again -- the next level's blocks).
+std::vector<int> AggregateBlocks(const HostCsr &A, double theta, const std::vector<int> &block_off, int &num_aggregates,
+                                 std::vector<int> &agg_off);
 
 // Piecewise-constant prolongator with normalised columns: T^T T = I
 HostCsr TentativeProlongator(const std::vector<int> &aggregate, int num_aggregates);
@@ -45,5 +50,9 @@ struct Hierarchy {
 };
 // Levels are added until a level has at most `coarse_size` rows, stops coarsening, or `max_levels` is reached
 Hierarchy Setup(const HostCsr &A, int max_levels = 10, int coarse_size = 200, double theta = 0.08, double omega = 0.0);
+// Hierarchy for a row-distributed solve: aggregation confined to the ranks' row blocks (AggregateBlocks), prolongator smoothing and
+// Galerkin products on the whole matrix as above.  level_off[l] [nblocks + 1]: the row blocks of level l.
+Hierarchy SetupBlocks(const HostCsr &A, const std::vector<int> &block_off, std::vector<std::vector<int>> &level_off, int max_levels = 10,
+                      int coarse_size = 200, double theta = 0.08, double omega = 0.0);
 
 }  // namespace palace::amg

@@ -4,7 +4,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 
+#include "amg_dist.hpp"
 #include "amg_solver.hpp"
 
 namespace palace {
@@ -92,6 +95,7 @@ amg::HostCsr LocalLevelMatrix(const ParOperator &par) {
 }  // namespace
 
 struct ReplicatedCoarseSolver::Impl {
+  std::unique_ptr<Solver> dist;  // distributed solve (round 5: DistAmgSolver / DistAmsSolver): owned pieces in, owned pieces out
   std::unique_ptr<Solver> inner;  // AmsSolver / AmgSolver of the global problem
   std::unique_ptr<Halo> gather;
   std::unique_ptr<ReplicatedSolver> rep;
@@ -99,7 +103,12 @@ struct ReplicatedCoarseSolver::Impl {
 };
 ReplicatedCoarseSolver::~ReplicatedCoarseSolver() = default;
 int ReplicatedCoarseSolver::GlobalSize() const { return impl_->n_global; }
-void ReplicatedCoarseSolver::Mult(const Vector &x, Vector &y) const { impl_->rep->Mult(x, y); }
+bool ReplicatedCoarseSolver::Distributed() const { return impl_->dist != nullptr; }
+const Solver *ReplicatedCoarseSolver::DistributedSolver() const { return impl_->dist.get(); }
+void ReplicatedCoarseSolver::Mult(const Vector &x, Vector &y) const {
+  if (impl_->dist) return impl_->dist->Mult(x, y);
+  impl_->rep->Mult(x, y);
+}
 
 ReplicatedCoarseSolver::ReplicatedCoarseSolver(const Context &ctx, const Operator &level0, const Operator *G, int nv_true,
                                                const double *xyz_true, int dim, int cycle_it, bool singular)
@@ -190,6 +199,12 @@ ReplicatedCoarseSolver::ReplicatedCoarseSolver(const Context &ctx, const Operato
     }
     Ag = std::move(e);
   }
+  // The SOLVE distributed over the ranks (amg_dist.hpp: every rank keeps and applies its rows of every level of the algebraic
+  // hierarchies, one owner -> ghost exchange per product) unless PALACE_AMD_COARSE_SOLVE=replicated (read at construction): the
+  // whole cycle on the gathered problem on every rank, rounds 3-4
+  const char *mode = std::getenv("PALACE_AMD_COARSE_SOLVE");
+  const bool distributed = !(mode && std::string(mode) == "replicated");
+  const std::vector<int> ioff(off.begin(), off.end());
   if (G) {
     // ---- the lowest-order discrete gradient in global numbers: two applications of the (multi-rank) operator to the global
     // vertex numbers and their squares identify both ends of every true edge of this rank; rows gathered in rank order are
@@ -240,8 +255,18 @@ ReplicatedCoarseSolver::ReplicatedCoarseSolver(const Context &ctx, const Operato
     Gm.rowptr[(size_t)n_global] = (int)(2 * n_global);
     AmsOptions opt;
     opt.cycle_it = std::max(cycle_it, 1), opt.singular = singular;
+    if (distributed) {
+      std::vector<int> ivoff((size_t)size + 1);
+      for (int r = 0; r <= size; r++) ivoff[(size_t)r] = (int)(voff[(size_t)r] / dim);
+      impl_->dist = std::make_unique<DistAmsSolver>(ctx, Ag, Gm, xyz_all.data(), dim, ess_flag, ioff, ivoff, opt);
+      return;
+    }
     impl_->inner = std::make_unique<AmsSolver>(ctx, Ag, Gm, xyz_all.data(), dim, ess_flag, opt);
   } else {
+    if (distributed) {
+      impl_->dist = std::make_unique<DistAmgSolver>(ctx, Ag, ioff);
+      return;
+    }
     impl_->inner = std::make_unique<AmgSolver>(ctx, Ag);
   }
   // ---- the gather plan on the global-numbered vector: my true dofs to everybody, everybody else's pieces (contiguous) in

@@ -79,6 +79,12 @@ public:
   void SetOperator(const Operator &) override {}
   void Mult(const Vector &x, Vector &y) const override;
   int GlobalSize() const;
+  // Round 5: the SOLVE is distributed -- every rank keeps and applies its own rows of every level of the algebraic hierarchies
+  // (amg_dist.hpp: DistAmgSolver / DistAmsSolver; the set-up still gathers the global matrix and builds the same hierarchy on
+  // every rank); PALACE_AMD_COARSE_SOLVE=replicated at construction keeps the whole cycle on every rank (the gather + the
+  // one-rank solvers, rounds 3-4)
+  bool Distributed() const;
+  const Solver *DistributedSolver() const;
 };
 
 // p-coarsening sequence of the multigrid hierarchy (fem/multigrid.hpp:44-69): orders from coarsest to finest

@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstring>
 
+#include <memory>
 #include "amg.hpp"
+#include "amg_dist.hpp"
 #include "errorestimator.hpp"
 #include "ksp.hpp"
 
@@ -189,6 +191,76 @@ int main() {
         prev = nr;
       }
       dump(cas == 0 ? "amg_factors_iso" : "amg_factors_aniso", fac);
+    }
+  }
+  {  // the hierarchy of the distributed solve (amg.hpp: SetupBlocks; amg_dist.hpp: DistSpace): aggregates confined to the ranks' row
+     // blocks and numbered block by block; every rank's rows of A_l, R_l, P_l in its local numbering [own | ghosts] times the
+     // local copy of a global vector = the rows of the global product; V-cycle convergence beside the unconfined hierarchy's
+    using namespace palace::amg;
+    const HostCsr A = grid_laplacian(40, 1.0, 0.6);
+    const std::vector<int> off = {0, 530, 1111, 1600};
+    const int size = 3;
+    int na = 0;
+    std::vector<int> aoff;
+    const std::vector<int> agg = AggregateBlocks(A, 0.08, off, na, aoff);
+    int confined = (int)aoff.size() == size + 1 && aoff.back() == na;
+    for (int b = 0; b < size && confined; b++)
+      for (int i = off[b]; i < off[b + 1]; i++) confined = confined && (agg[i] < 0 || (agg[i] >= aoff[b] && agg[i] < aoff[b + 1]));
+    std::vector<std::vector<int>> loff;
+    const Hierarchy h = SetupBlocks(A, off, loff, 10, 60);
+    const Hierarchy hg = Setup(A, 10, 60);
+    std::printf("amg_blocks %d %d %d %d\n", confined, (int)h.A.size(), h.A.back().nrows, (int)hg.A.size());
+    double worst = 0.0;
+    long long ghosts = 0;
+    const size_t nl = h.A.size();
+    std::vector<HostCsr> R(nl - 1);
+    for (size_t l = 0; l + 1 < nl; l++) R[l] = Transpose(h.P[l]);
+    for (int rank = 0; rank < size; rank++) {
+      std::vector<std::unique_ptr<palace::DistSpace>> sp(nl);
+      for (size_t l = 0; l < nl; l++) {
+        sp[l] = std::make_unique<palace::DistSpace>(rank, size, loff[l]);
+        sp[l]->Need(h.A[l], loff[l]);
+        if (l + 1 < nl) sp[l]->Need(R[l], loff[l + 1]);
+        if (l > 0) sp[l]->Need(h.P[l - 1], loff[l - 1]);
+        sp[l]->Finalize(nullptr);
+        ghosts += sp[l]->NumGhosts();
+      }
+      auto check = [&](const HostCsr &M, const std::vector<int> &row_off, const palace::DistSpace &cols) {
+        const HostCsr L = cols.Localize(M, row_off);
+        std::vector<double> xg((size_t)M.ncols), yg, xl((size_t)cols.NumLocal()), yl;
+        for (int i = 0; i < M.ncols; i++) xg[i] = std::sin(0.7 * i + 0.1 * rank) + 0.3;
+        for (int i = 0; i < cols.NumOwned(); i++) xl[i] = xg[cols.Offset() + i];
+        for (int k = 0; k < cols.NumGhosts(); k++) xl[cols.NumOwned() + k] = xg[cols.Ghosts()[k]];
+        Mult(M, xg, yg), Mult(L, xl, yl);
+        for (int r = 0; r < L.nrows; r++) worst = std::max(worst, std::abs(yl[r] - yg[row_off[rank] + r]));
+      };
+      for (size_t l = 0; l < nl; l++) {
+        check(h.A[l], loff[l], *sp[l]);
+        if (l + 1 < nl) check(R[l], loff[l + 1], *sp[l]), check(h.P[l], loff[l], *sp[l + 1]);
+      }
+    }
+    dump("amg_blocks_products", std::vector<double>{worst, (double)ghosts});
+    for (int cas = 0; cas < 2; cas++) {
+      const Hierarchy &hh = cas ? hg : h;
+      std::vector<double> b(A.nrows), x(A.nrows, 0.0), t, fac;
+      for (int i = 0; i < A.nrows; i++) b[i] = std::sin(0.37 * i) + 0.5;
+      double prev = 0.0;
+      for (double v : b) prev += v * v;
+      prev = std::sqrt(prev);
+      for (int it = 0; it < 10; it++) {
+        std::vector<double> r(A.nrows), e(A.nrows, 0.0);
+        Mult(A, x, t);
+        for (int i = 0; i < A.nrows; i++) r[i] = b[i] - t[i];
+        vcycle(hh, 0, r, e);
+        for (int i = 0; i < A.nrows; i++) x[i] += e[i];
+        Mult(A, x, t);
+        double nr = 0.0;
+        for (int i = 0; i < A.nrows; i++) nr += (b[i] - t[i]) * (b[i] - t[i]);
+        nr = std::sqrt(nr);
+        fac.push_back(nr / prev);
+        prev = nr;
+      }
+      dump(cas ? "amg_factors_global" : "amg_factors_blocks", fac);
     }
   }
   {  // the set-up is row-parallel (PALACE_AMD_SETUP_THREADS): a problem with many row blocks, every matrix of its hierarchy

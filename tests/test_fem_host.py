@@ -36,7 +36,7 @@ def dumped(tmp_path_factory):
         k, *v = line.split()
         if k == "amg_threads_checksum":  # (compared as text above)
             continue
-        if k.startswith("orders") or k.startswith("amg_levels") or k in ("q1d", "mat_dims", "amg_small"):
+        if k.startswith("orders") or k.startswith("amg_levels") or k in ("q1d", "mat_dims", "amg_small", "amg_blocks"):
             vals[k] = [int(t) for t in v]
         else:
             vals[k] = np.array([struct.unpack("<d", struct.pack("<Q", int(t, 16)))[0] for t in v])
@@ -140,6 +140,20 @@ def test_smoothed_aggregation_setup(dumped):
         assert sizes[1] < 0.5 * sizes[0] and all(b < 0.7 * a for a, b in zip(sizes, sizes[1:]))  # (line aggregates: 1/3 per level)
         f = dumped[key]
         assert f.max() < 0.65 and np.exp(np.log(f[3:]).mean()) < 0.5, (key, f)  # stationary V(2,2), damped Jacobi
+
+
+def test_hierarchy_of_the_distributed_solve(dumped):
+    """amg.hpp: SetupBlocks / amg_dist.hpp: DistSpace (the row-distributed V-cycle that stands where the reference runs HYPRE's
+    BoomerAMG on the distributed matrix, linalg/amg.cpp:12-49): aggregates stay inside the ranks' row blocks and are numbered block by
+    block; a rank's rows of A_l, R_l, P_l in its local numbering [own | ghosts] reproduce the rows of the global products; and the
+    confined hierarchy converges like the unconfined one (stationary V(2,2) with damped Jacobi)."""
+    confined, nlev, ncoarse, nlev_global = dumped["amg_blocks"]
+    assert confined == 1 and nlev >= 3 and ncoarse <= 60 and abs(nlev - nlev_global) <= 1
+    worst, ghosts = dumped["amg_blocks_products"]
+    assert worst < 1e-13 and ghosts > 0
+    fb, fg = dumped["amg_factors_blocks"], dumped["amg_factors_global"]
+    mean = lambda f: np.exp(np.log(f[3:]).mean())  # noqa: E731
+    assert fb.max() < 0.65 and mean(fb) < 0.5 and mean(fb) < mean(fg) + 0.1, (fb, fg)
 
 
 def test_plane_rotations_over_the_whole_exponent_range(tmp_path):
