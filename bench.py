@@ -1488,6 +1488,9 @@ def main():
             legs += [("chebyshev_ams", False, "ams"), ("hiptmair_ams", True, "ams")]
         else:  # several ranks: level 0 solved redundantly by every rank (ReplicatedSolver around the native AMS)
             legs += [("hiptmair_ams", True, "ams")]
+            # round 5: the same cycle with its SOLVE distributed (amg_dist.hpp: every rank its rows of every algebraic level;
+            # assembled by the C++ layer from the ranks' own pieces)
+            legs += [("hiptmair_ams_distributed", True, "ams_dist")]
         for name, hip, coarse in legs:
             try:  # a failing secondary leg is reported in the line, it does not take the headline measurement with it
                 solver, b, xs = prob.pcg_gmg_solver(max_it=args.pcg_iters, hiptmair=hip, coarse=coarse)
@@ -1508,7 +1511,7 @@ def main():
                 st = solver.stats()
                 entry.update({"iterations_to_1e-8": st["iterations"], "seconds_to_1e-8": time.perf_counter() - t0,
                               "converged": st["converged"]})
-                if world > 1 and coarse == "ams":
+                if world > 1 and coarse in ("ams", "ams_dist"):
                     # what the replicated level-0 solve costs per application (gather over the transport + the AMS cycle of
                     # the whole cylinder's order-1 problem on every rank) against one PCG iteration: the part that does not scale
                     cs, n0 = prob.last_coarse, prob.n_true[0]
@@ -1522,8 +1525,8 @@ def main():
                         cs.mult(r0, z0)
                     barrier()
                     ms0 = 1e3 * (time.perf_counter() - t0) / 20
-                    entry["replicated_level0"] = {"ms_per_application": ms0,
-                                                  "share_of_iteration": ms0 * 1e-3 * entry["iters_per_s"]}
+                    entry["replicated_level0" if coarse == "ams" else "distributed_level0"] = {
+                        "ms_per_application": ms0, "share_of_iteration": ms0 * 1e-3 * entry["iters_per_s"]}
                 pcg[name] = entry
                 prob._keep.clear()
             except Exception as exc:  # noqa: BLE001

@@ -258,13 +258,33 @@ ReplicatedCoarseSolver::ReplicatedCoarseSolver(const Context &ctx, const Operato
     if (distributed) {
       std::vector<int> ivoff((size_t)size + 1);
       for (int r = 0; r <= size; r++) ivoff[(size_t)r] = (int)(voff[(size_t)r] / dim);
-      impl_->dist = std::make_unique<DistAmsSolver>(ctx, Ag, Gm, xyz_all.data(), dim, ess_flag, ioff, ivoff, opt);
+      auto ams = std::make_unique<DistAmsSolver>(ctx, Ag, Gm, xyz_all.data(), dim, ess_flag, ioff, ivoff, opt);
+      if (std::getenv("PALACE_AMD_COARSE_VERBOSE")) {
+        for (const DistAmgSolver *amg : {ams->GradientSpaceSolver(), ams->NodalSpaceSolver()}) {
+          if (!amg) continue;
+          std::string msg = "palace_amd: distributed AMS, rank " + std::to_string(rank) +
+                            (amg == ams->NodalSpaceSolver() ? ", nodal spaces:" : ", gradient space:");
+          for (int l = 0; l < amg->NumLevels(); l++)
+            msg += " [" + std::to_string(amg->LevelRows(l)) + " rows, " + std::to_string(amg->LevelOwned(l)) + " owned + " +
+                   std::to_string(amg->LevelGhosts(l)) + " ghosts]";
+          std::fprintf(stderr, "%s\n", msg.c_str());
+        }
+      }
+      impl_->dist = std::move(ams);
       return;
     }
     impl_->inner = std::make_unique<AmsSolver>(ctx, Ag, Gm, xyz_all.data(), dim, ess_flag, opt);
   } else {
     if (distributed) {
-      impl_->dist = std::make_unique<DistAmgSolver>(ctx, Ag, ioff);
+      auto amg = std::make_unique<DistAmgSolver>(ctx, Ag, ioff);
+      if (std::getenv("PALACE_AMD_COARSE_VERBOSE")) {  // the hierarchy as this rank holds it
+        std::string msg = "palace_amd: distributed AMG, rank " + std::to_string(rank) + ":";
+        for (int l = 0; l < amg->NumLevels(); l++)
+          msg += " [" + std::to_string(amg->LevelRows(l)) + " rows, " + std::to_string(amg->LevelOwned(l)) + " owned + " +
+                 std::to_string(amg->LevelGhosts(l)) + " ghosts]";
+        std::fprintf(stderr, "%s\n", msg.c_str());
+      }
+      impl_->dist = std::move(amg);
       return;
     }
     impl_->inner = std::make_unique<AmgSolver>(ctx, Ag);

@@ -49,14 +49,17 @@ def test_rehearsal_line(n, one_rank):
     if n == 8:
         assert out["pcg"] is None and out["n_ranks_legs"] is None
         return
-    for leg in ("chebyshev", "hiptmair", "hiptmair_ams"):
+    for leg in ("chebyshev", "hiptmair", "hiptmair_ams", "hiptmair_ams_distributed"):
         e = out["pcg"][leg]
         assert "error" not in e, e
         assert e["converged"], (leg, e)
-    for leg, ref in (("chebyshev", "chebyshev"), ("hiptmair", "hiptmair"), ("hiptmair_ams", "hiptmair_ams")):
+    # (hiptmair_ams_distributed, round 5: the algebraic level-0 cycle with its solve distributed over the ranks, amg_dist.hpp)
+    for leg, ref in (("chebyshev", "chebyshev"), ("hiptmair", "hiptmair"), ("hiptmair_ams", "hiptmair_ams"),
+                     ("hiptmair_ams_distributed", "hiptmair_ams")):
         a, b = out["pcg"][leg]["iterations_to_1e-8"], one_rank["pcg"][ref]["iterations_to_1e-8"]
         assert abs(a - b) <= max(2, b // 10), (leg, a, b)
     assert 0.0 < out["pcg"]["hiptmair_ams"]["replicated_level0"]["share_of_iteration"] < 1.0
+    assert 0.0 < out["pcg"]["hiptmair_ams_distributed"]["distributed_level0"]["share_of_iteration"] < 1.0
     legs = out["n_ranks_legs"]
     if n == 4:
         assert legs is None
