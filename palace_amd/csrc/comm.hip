@@ -916,7 +916,13 @@ void Halo::PeerSetup(const int32_t *send_idx) {
     d.off_mb[0] = pp->off[0], d.off_mb[1] = pp->off[1], d.off_local = pp->off[2];
     d.ready = kDescMagic + (unsigned long long)id;
   }
-  if (slot >= 0) PA_HIP(hipMemcpy(c.arena_ + kOffDesc + sizeof(HaloDesc) * (size_t)slot, &d, sizeof(d), hipMemcpyHostToDevice));
+  if (slot >= 0) {
+    // On the set-up stream, and waited for: a synchronous copy from pageable memory may return when the descriptor has reached
+    // the staging buffer, not the arena -- a neighbour released by the barrier below (another stream) could then read the
+    // descriptor of the plan that held this slot before (seen once in 1 100 plan creations of the churn test, round 5).
+    PA_HIP(hipMemcpyAsync(c.arena_ + kOffDesc + sizeof(HaloDesc) * (size_t)slot, &d, sizeof(d), hipMemcpyHostToDevice, c.setup_stream_));
+    PA_HIP(hipStreamSynchronize(c.setup_stream_));
+  }
   std::vector<double> slots;
   try {
     slots = c.SetupGather(fail.empty() ? (double)slot : -1.0, c.setup_stream_);  // every rank has published plan `id`
