@@ -84,7 +84,8 @@ from palace_amd.fem.fespace import NDHexSpace
 from palace_amd.fem.mesh import ogrid_cylinder
 p, q1d = int(sys.argv[1]), int(sys.argv[3])
 ctx = linalg.Context()
-mesh = ogrid_cylinder(2, 3)
+shape = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (2, 3)
+mesh = ogrid_cylinder(*shape)
 mesh.attr[:] = 1 + (np.arange(mesh.ne) %% 2)
 nd = NDHexSpace(mesh, p)
 geom = ceed.GeomFactorData(mesh, q1d)
@@ -131,7 +132,8 @@ def _tensors():
 
 
 @pytest.mark.parametrize("p,q1d,mat", [(1, 4, "iso"), (2, 4, "iso"), (3, 4, "iso"), (4, 5, "iso"), (2, 5, "iso"), (1, 5, "iso"),
-                                       (1, 4, "aniso"), (2, 4, "aniso"), (3, 4, "aniso"), (3, 4, "aniso2"), (2, 4, "aniso2")])
+                                       (1, 4, "aniso"), (2, 4, "aniso"), (3, 4, "aniso"), (3, 4, "aniso2"), (2, 4, "aniso2"),
+                                       (3, 4, "iso-odd"), (2, 4, "aniso-odd"), (3, 4, "aniso2-odd")])
 def test_fused_complex_apply(p, q1d, mat, tmp_path):
     """y = (A_r + i A_i) x in one pass over the element data (pa_op_mult_complex): the complex streaming
     kernel (four points per direction: pa_nd_hex_stream.hip, five: pa_nd_hex_stream5.hip -- order 4 and the coarsened levels of an
@@ -143,13 +145,16 @@ def test_fused_complex_apply(p, q1d, mat, tmp_path):
 
     from palace_amd.fem.mesh import ogrid_cylinder
 
+    # "-odd": 15 elements -- the complex kernel's batches are two elements, the last one is half empty (ragged input)
+    shape = (1, 3) if mat.endswith("-odd") else (2, 3)
+    mat = mat.replace("-odd", "")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for fused in (1, 0):
         f = str(tmp_path / f"out{fused}.npz")
         tf = str(tmp_path / "tensors.npz")
         np.savez(tf, **_tensors())
-        r = subprocess.run([sys.executable, "-c", FUSED_CHECK % root, str(p), f, str(q1d), mat, tf], capture_output=True, text=True, timeout=300,
+        r = subprocess.run([sys.executable, "-c", FUSED_CHECK % root, str(p), f, str(q1d), mat, tf, str(shape[0]), str(shape[1])], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, PALACE_AMD_COMPLEX_FUSED=str(fused)))
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
         res[fused] = np.load(f)
@@ -158,7 +163,8 @@ def test_fused_complex_apply(p, q1d, mat, tmp_path):
         a, b = res[1][k], res[0][k]
         assert np.abs(a - b).max() < 1e-13 * np.abs(b).max(), k
     # oracle
-    mesh = ogrid_cylinder(2, 3)
+    mesh = ogrid_cylinder(*shape)
+    assert mesh.ne % 2 == (1 if shape == (1, 3) else 0)
     mesh.attr[:] = 1 + (np.arange(mesh.ne) % 2)
     nd = NDHexSpace(mesh, p)
     ogeom = util.oracle_geom(mesh, q1d)
