@@ -23,6 +23,9 @@
 
 #include "pa_nd_hex_core.hpp"
 
+#ifndef PA_CPLX_QAHEAD
+#define PA_CPLX_QAHEAD 0  // (with PA_STREAM_QAHEAD: also the packed complex form)
+#endif
 #ifndef PA_STREAM_QAHEAD
 #define PA_STREAM_QAHEAD 0  // 1: the instantiations compiled for two waves per SIMD request the q-data one batch ahead
 #endif
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   // QAHEAD (kernels compiled for two waves per SIMD: they have the registers): the q-data of a batch is requested right after
   // the D stage of the batch before it -- its registers are free from there on -- instead of at the top of its own batch, where
   // only the E stage and the forward passes of the same batch (short at p < 3) stand between the request and the first use
-  constexpr bool QAHEAD = PA_STREAM_QAHEAD && MINW == 2 && !CPLX;
+  constexpr bool QAHEAD = PA_STREAM_QAHEAD && MINW == 2 && (!CPLX || (PA_CPLX_QAHEAD && !METRIC));
   d2v gq[GEOMN ? 1 : 2 * NG];
   double xl[GEOMN ? 6 : 1];  // GEOMN: this lane's six of the element's 81 node coordinates, in flight during the forward passes
   auto load_xn = [&](const int ee, const int t) {
