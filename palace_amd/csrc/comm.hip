@@ -130,6 +130,48 @@ std::vector<double> Comm::SetupGather(double mine, hipStream_t s) {
   return v;
 }
 
+std::vector<double> Comm::AllGatherVHost(const std::vector<double> &mine, std::vector<long long> *offsets) {
+  PA_REQUIRE(PeerReady() && size_ > 1, "all-gather-v over the peer transport: not connected");
+  const std::vector<double> cnt = SetupGather((double)mine.size(), setup_stream_);
+  std::vector<long long> off((size_t)size_ + 1, 0);
+  long long longest = 0;
+  for (int r = 0; r < size_; r++) {
+    off[(size_t)r + 1] = off[(size_t)r] + (long long)cnt[(size_t)r];
+    longest = std::max(longest, (long long)cnt[(size_t)r]);
+  }
+  PA_REQUIRE(off[(size_t)size_] < (1ll << 31), "all-gather-v: too many entries");
+  std::vector<double> all((size_t)off[(size_t)size_], 0.0);
+  std::copy(mine.begin(), mine.end(), all.begin() + off[(size_t)rank_]);
+  if (offsets) *offsets = off;
+  if (longest == 0) return all;
+  const long long chunk = std::min<long long>(longest, 1ll << 19);  // doubles per rank and round (4 MB)
+  const size_t bytes = sizeof(double) * (size_t)chunk;
+  const size_t block = PeerAlloc(bytes);
+  // every rank's block offset (blocks of destroyed plans are reused rank by rank: the offsets may differ)
+  const std::vector<double> blocks = SetupGather((double)block, setup_stream_);
+  try {
+    for (long long c0 = 0; c0 < longest; c0 += chunk) {
+      const long long n_mine = std::max(0ll, std::min(chunk, (long long)mine.size() - c0));
+      if (n_mine) PA_HIP(hipMemcpyAsync(arena_ + block, mine.data() + c0, sizeof(double) * (size_t)n_mine, hipMemcpyHostToDevice, setup_stream_));
+      PA_HIP(hipStreamSynchronize(setup_stream_));  // (the arena holds the chunk before the barrier releases the readers)
+      (void)SetupGather(0.0, setup_stream_);
+      for (int r = 0; r < size_; r++) {
+        if (r == rank_) continue;
+        const long long n_r = std::max(0ll, std::min(chunk, (long long)cnt[(size_t)r] - c0));
+        if (n_r)
+          PA_HIP(hipMemcpy(all.data() + off[(size_t)r] + c0, remote_[(size_t)r] + (size_t)blocks[(size_t)r], sizeof(double) * (size_t)n_r,
+                           hipMemcpyDeviceToHost));
+      }
+      (void)SetupGather(0.0, setup_stream_);  // every rank has read this round: the blocks may be overwritten
+    }
+  } catch (...) {
+    PeerFree(block, bytes);
+    throw;
+  }
+  PeerFree(block, bytes);
+  return all;
+}
+
 void LocalGroup::Arrive() {
   std::unique_lock<std::mutex> lk(m_);
   PA_REQUIRE(!aborted_, "in-process rank group aborted: another rank failed");
@@ -717,6 +759,11 @@ __global__ void k_ar_sum(char *__restrict__ mine, const int size, const int n, d
 
 }  // namespace
 
+namespace {
+bool g_fenced_host = false;      // what Comm::SetFenced / SetTimeout were last called with in this process (the current device's symbols
+double g_timeout_host = 0.0;     // hold them; AllocArena re-applies them on the device of a new communicator); 0: default time-out
+}  // namespace
+
 void Comm::AllocArena() {
   const char *mb = std::getenv("PALACE_AMD_PEER_ARENA_MB");
   arena_bytes_ = (size_t)(mb ? std::max(8, atoi(mb)) : 256) << 20;
@@ -743,17 +790,20 @@ void Comm::AllocArena() {
   PA_HIP(hipHostMalloc(&he, 64, hipHostMallocMapped));
   h_err_ = static_cast<unsigned long long *>(he);
   *h_err_ = 0ull;
+  // The two settings live in __device__ symbols, i.e. once per DEVICE, while SetTimeout / SetFenced are process-wide: a
+  // communicator brought up on a device after they were called re-applies the process's values there (a process that drives
+  // several devices would otherwise run them with different time-outs or fence modes while Fenced() reports one value).
   if (const char *t = std::getenv("PALACE_AMD_PEER_TIMEOUT_S")) SetTimeout(atof(t));
+  else if (g_timeout_host > 0.0) SetTimeout(g_timeout_host);
   if (const char *f = std::getenv("PALACE_AMD_PEER_FENCE")) SetFenced(atoi(f) != 0);
+  else if (g_fenced_host) SetFenced(true);
 }
 
-namespace {
-bool g_fenced_host = false;
-}
 void Comm::SetTimeout(double seconds) {
   const long long ticks = (long long)(std::max(0.01, seconds) * 1.0e8);
   PA_HIP(hipDeviceSynchronize());
   PA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_spin_ticks), &ticks, sizeof(ticks)));
+  g_timeout_host = seconds;
 }
 void Comm::SetFenced(bool on) {
   const int v = on ? 1 : 0;

@@ -133,6 +133,11 @@ public:
   void Barrier(hipStream_t s);
   // barrier that also tells every rank one number of every other rank (set-up channel of the peer transport; size > 1)
   std::vector<double> SetupGather(double mine, hipStream_t s);
+  // Set-up time all-gather-v of host arrays over the peer transport (PeerReady): every rank stages its piece, a chunk at a time,
+  // in a block of its own arena and reads the other ranks' chunks through their mappings -- each value crosses once per reader,
+  // where the sum of zero-padded global arrays moved size times as much through 4096-value messages.  Returns the pieces in rank
+  // order; offsets [size + 1] on request.  Collective.
+  std::vector<double> AllGatherVHost(const std::vector<double> &mine, std::vector<long long> *offsets = nullptr);
 };
 
 // The conforming prolongation of one finite element space (one multigrid level): which owned dofs

@@ -71,6 +71,12 @@ void GlobalSumHost(const Context &ctx, std::vector<double> &v) {
 // the pieces of all ranks one after the other (rank order); counts / offsets of the pieces on request
 std::vector<double> AllGatherV(const Context &ctx, const std::vector<double> &mine, std::vector<long long> *offsets = nullptr) {
   const int size = ctx.comm ? ctx.comm->Size() : 1, rank = ctx.comm ? ctx.comm->Rank() : 0;
+  // peer transport: a real gather (every value crosses once per reader); RCCL-only and in-process communicators: as a sum of
+  // zero-padded global arrays (below)
+  if (ctx.comm && size > 1 && ctx.comm->PeerReady() && !std::getenv("PALACE_AMD_GATHER_BY_SUM")) {
+    PA_HIP(hipStreamSynchronize(ctx.stream));
+    return ctx.comm->AllGatherVHost(mine, offsets);
+  }
   std::vector<double> cnt((size_t)size, 0.0);
   cnt[(size_t)rank] = (double)mine.size();
   GlobalSumHost(ctx, cnt);
