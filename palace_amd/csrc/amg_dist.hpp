@@ -22,6 +22,7 @@
 // VERDICT r4 item 6; it changes the set-up time, not an application.)
 #pragma once
 
+#include <cstdint>
 #include <memory>
 #include <vector>
 
@@ -45,6 +46,10 @@ public:
   void Need(const amg::HostCsr &M, const std::vector<int> &row_off);
   // ghost lists, local numbering and the halo plan (collective: every rank, same order); comm == nullptr: one rank
   void Finalize(Comm *comm);
+  // the plan itself as Halo's constructor takes it (after Finalize, before Release): neighbours, pieces of owned entries to send
+  // (local numbers) and of ghost slots to receive, both in ascending global order -- the order the two sides of a piece agree on
+  void Plan(std::vector<int> &nbr, std::vector<int> &send_off, std::vector<int32_t> &send_idx, std::vector<int> &recv_off,
+            std::vector<int32_t> &recv_idx) const;
   void Release();  // the set-up tables (after the last Localize)
   int Offset() const { return off_[(size_t)rank_]; }
   int NumOwned() const { return off_[(size_t)rank_ + 1] - off_[(size_t)rank_]; }

@@ -433,10 +433,21 @@ void DistSpace::Finalize(Comm *comm) {
   for (int i = 0; i < n_own; i++) local_of_[(size_t)(lo + i)] = i;
   for (size_t k = 0; k < ghosts_.size(); k++) local_of_[(size_t)ghosts_[k]] = n_own + (int)k;
   if (!comm || size_ == 1 || total == 0) return;  // (no coupling across ranks on this level anywhere: every rank decides the same)
+  std::vector<int> nbr, soff, roff;
+  std::vector<int32_t> sidx, ridx;
+  Plan(nbr, soff, sidx, roff, ridx);
+  halo_ = std::make_unique<Halo>(*comm, (int)nbr.size(), nbr.data(), soff.data(), sidx.data(), roff.data(), ridx.data());
+  halo_->Validate(n_own, NumLocal());
+}
+
+void DistSpace::Plan(std::vector<int> &nbr, std::vector<int> &soff, std::vector<int32_t> &sidx, std::vector<int> &roff,
+                     std::vector<int32_t> &ridx) const {
+  PA_REQUIRE((int)need_.size() == size_, "distributed level: Plan after Release");
   // what I receive: my ghosts by owner (ascending global numbers = rank by rank = contiguous pieces of the ghost tail);
   // what I send: the entries of my range in the other ranks' lists
-  std::vector<int> nbr, soff(1, 0), roff(1, 0);
-  std::vector<int32_t> sidx, ridx;
+  const int lo = off_[(size_t)rank_], n_own = NumOwned();
+  nbr.clear(), sidx.clear(), ridx.clear();
+  soff.assign(1, 0), roff.assign(1, 0);
   for (int s = 0; s < size_; s++) {
     if (s == rank_) continue;
     const auto g0 = std::lower_bound(ghosts_.begin(), ghosts_.end(), off_[(size_t)s]);
@@ -449,8 +460,6 @@ void DistSpace::Finalize(Comm *comm) {
     for (auto it = g0; it != g1; ++it) ridx.push_back((int32_t)(n_own + (int)(it - ghosts_.begin())));
     soff.push_back((int)sidx.size()), roff.push_back((int)ridx.size());
   }
-  halo_ = std::make_unique<Halo>(*comm, (int)nbr.size(), nbr.data(), soff.data(), sidx.data(), roff.data(), ridx.data());
-  halo_->Validate(n_own, NumLocal());
 }
 
 void DistSpace::Release() {

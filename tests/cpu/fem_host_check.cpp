@@ -211,8 +211,39 @@ int main() {
     const Hierarchy hg = Setup(A, 10, 60);
     std::printf("amg_blocks %d %d %d %d\n", confined, (int)h.A.size(), h.A.back().nrows, (int)hg.A.size());
     double worst = 0.0;
-    long long ghosts = 0;
+    long long ghosts = 0, plan_mismatch = 0, plan_entries = 0;
     const size_t nl = h.A.size();
+    // the exchange plans of level 0 as every rank derives them on its own: what rank r sends to s is, entry by entry, what s
+    // expects from r (the transport matches the two sides of a piece by position)
+    {
+      std::vector<std::unique_ptr<palace::DistSpace>> sp(size);
+      std::vector<std::vector<int>> nbr(size), so(size), ro(size);
+      std::vector<std::vector<int32_t>> si(size), ri(size);
+      const HostCsr R0 = Transpose(h.P[0]);
+      for (int r = 0; r < size; r++) {
+        sp[r] = std::make_unique<palace::DistSpace>(r, size, loff[0]);
+        sp[r]->Need(h.A[0], loff[0]);
+        sp[r]->Need(R0, loff[1]);
+        sp[r]->Finalize(nullptr);
+        sp[r]->Plan(nbr[r], so[r], si[r], ro[r], ri[r]);
+      }
+      for (int r = 0; r < size; r++)
+        for (size_t k = 0; k < nbr[r].size(); k++) {
+          const int s = nbr[r][k];
+          size_t j = 0;
+          while (j < nbr[s].size() && nbr[s][j] != r) j++;
+          if (j == nbr[s].size() || so[r][k + 1] - so[r][k] != ro[s][j + 1] - ro[s][j]) {
+            plan_mismatch++;
+            continue;
+          }
+          for (int i = 0; i < so[r][k + 1] - so[r][k]; i++) {
+            const int sent = sp[r]->Offset() + si[r][so[r][k] + i];                              // global number of what r sends
+            const int slot = ri[s][ro[s][j] + i] - sp[s]->NumOwned();                            // ghost slot s fills with it
+            plan_mismatch += (slot < 0 || slot >= sp[s]->NumGhosts() || sp[s]->Ghosts()[slot] != sent) ? 1 : 0;
+            plan_entries++;
+          }
+        }
+    }
     std::vector<HostCsr> R(nl - 1);
     for (size_t l = 0; l + 1 < nl; l++) R[l] = Transpose(h.P[l]);
     for (int rank = 0; rank < size; rank++) {
@@ -239,7 +270,7 @@ int main() {
         if (l + 1 < nl) check(R[l], loff[l + 1], *sp[l]), check(h.P[l], loff[l], *sp[l + 1]);
       }
     }
-    dump("amg_blocks_products", std::vector<double>{worst, (double)ghosts});
+    dump("amg_blocks_products", std::vector<double>{worst, (double)ghosts, (double)plan_mismatch, (double)plan_entries});
     for (int cas = 0; cas < 2; cas++) {
       const Hierarchy &hh = cas ? hg : h;
       std::vector<double> b(A.nrows), x(A.nrows, 0.0), t, fac;

@@ -149,8 +149,10 @@ def test_hierarchy_of_the_distributed_solve(dumped):
     confined hierarchy converges like the unconfined one (stationary V(2,2) with damped Jacobi)."""
     confined, nlev, ncoarse, nlev_global = dumped["amg_blocks"]
     assert confined == 1 and nlev >= 3 and ncoarse <= 60 and abs(nlev - nlev_global) <= 1
-    worst, ghosts = dumped["amg_blocks_products"]
+    worst, ghosts, plan_mismatch, plan_entries = dumped["amg_blocks_products"]
     assert worst < 1e-13 and ghosts > 0
+    # the ranks' exchange plans, each derived on its own: every entry a rank sends lands in the slot of that entry on the receiver
+    assert plan_mismatch == 0 and plan_entries > 0
     fb, fg = dumped["amg_factors_blocks"], dumped["amg_factors_global"]
     mean = lambda f: np.exp(np.log(f[3:]).mean())  # noqa: E731
     assert fb.max() < 0.65 and mean(fb) < 0.5 and mean(fb) < mean(fg) + 0.1, (fb, fg)
