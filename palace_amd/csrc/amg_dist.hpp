@@ -20,6 +20,7 @@
 // same hierarchy and keeps its own rows of it; the neighbours' needs follow from the same data, so the halo plans need no
 // negotiation.  (A set-up that never forms the global matrix -- rank-local Galerkin products with halo rows -- is what remains of
 // VERDICT r4 item 6; it changes the set-up time, not an application.)
+// (Implemented at the end of amg_solver.hip: it shares that file's set-up helpers -- l1 scaling, pseudo-inverse, the AMS transfers.)
 #pragma once
 
 #include <cstdint>
