@@ -1053,7 +1053,13 @@ static void launch_complex_p(const SubOp &sr, const SubOp &si, const double *xr,
     a.qc[g] = qf == PA_QF_HDIV_33 ? 0 : (qf == PA_QF_HDIVMASS_33 ? 6 : -1);
   }
   a.qdata1 = si.qd->d;
-  launch_gpos<P1, true, true, false, 2, 2, true>(sr, a, s);
+  // (where x of the next batch is requested: after the second transposed component, as in the real K + M kernel;
+  // PALACE_AMD_CPLX_GPOS=1 / 3 for A / B, read at every launch)
+  const char *ge = getenv("PALACE_AMD_CPLX_GPOS");
+  const int gpos = ge ? atoi(ge) : 2;
+  if (gpos == 1) launch_gpos<P1, true, true, false, 2, 1, true>(sr, a, s);
+  else if (gpos == 3) launch_gpos<P1, true, true, false, 2, 3, true>(sr, a, s);
+  else launch_gpos<P1, true, true, false, 2, 2, true>(sr, a, s);
 }
 
 void launch_nd_hex_stream_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
