@@ -1527,6 +1527,9 @@ def main():
                     ms0 = 1e3 * (time.perf_counter() - t0) / 20
                     entry["replicated_level0" if coarse == "ams" else "distributed_level0"] = {
                         "ms_per_application": ms0, "share_of_iteration": ms0 * 1e-3 * entry["iters_per_s"]}
+                    if coarse == "ams_dist":  # (what the C++ layer built: amg_dist.hpp unless PALACE_AMD_COARSE_SOLVE=replicated)
+                        entry["distributed_level0"].update({"distributed": bool(getattr(cs, "distributed", False)),
+                                                            "algebraic_levels": int(getattr(cs, "algebraic_levels", 0))})
                 pcg[name] = entry
                 prob._keep.clear()
             except Exception as exc:  # noqa: BLE001

@@ -216,6 +216,11 @@ int pa_ams_create(pa_context *ctx, const pa_csr *A, const int32_t *ess, int n_es
  * assembling the same global problem everywhere (ksp.hpp: ReplicatedCoarseSolver).  Collective. */
 int pa_replicated_coarse_create(pa_context *ctx, pa_par_op *level0, pa_interp *G, int nv_true, const double *xyz_true, int dim,
                                 int cycle_it, int singular, pa_solver **S);
+/* Round 5: the solver keeps and applies each rank's ROWS of every level of its algebraic hierarchies (amg_dist.hpp; one owner ->
+ * ghost exchange per product; where the reference runs HYPRE on the distributed matrix, linalg/ksp.cpp:129-239) unless
+ * PALACE_AMD_COARSE_SOLVE=replicated was set when it was created.  *distributed = 1 | 0; *levels (may be NULL): levels of the AMG
+ * hierarchy (AMS: of its nodal-space hierarchy) as this rank holds them, 0 for the replicated form. */
+int pa_replicated_coarse_info(const pa_solver *S, int *distributed, int *levels);
 /* The hierarchy of an AMG solver (which = 0) or of the gradient-space (1) / nodal-space (2) solver inside an AMS solver:
  * number of levels; and copies of its matrices -- kind 0: A_level, 1: P_level (level + 1 -> level), 2: the dense inverse used
  * on the last level (row-major in val, rowptr / col untouched).  Null output arrays: sizes only. */

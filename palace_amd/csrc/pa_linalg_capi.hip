@@ -4,6 +4,7 @@
 #include "../../include/palace_amd_linalg.h"
 #include "comm.hpp"
 #include "complex.hpp"
+#include "amg_dist.hpp"
 #include "amg_solver.hpp"
 #include "ksp.hpp"
 #include "linalg.hpp"
@@ -597,6 +598,19 @@ int pa_replicated_coarse_create(pa_context *ctx, pa_par_op *level0, pa_interp *G
     s->solver = std::make_unique<ReplicatedCoarseSolver>(ctx->ctx, *level0->op, G ? G->op.get() : nullptr, nv_true, xyz_true, dim,
                                                          cycle_it, singular != 0);
     *S = s.release();
+  });
+}
+int pa_replicated_coarse_info(const pa_solver *S, int *distributed, int *levels) {
+  return guarded([&] {
+    PA_REQUIRE(S && S->solver && distributed, "null argument");
+    const auto *r = dynamic_cast<const ReplicatedCoarseSolver *>(S->solver.get());
+    PA_REQUIRE(r, "not a multi-rank coarse solver (pa_replicated_coarse_create)");
+    *distributed = r->Distributed() ? 1 : 0;
+    if (levels) {
+      *levels = 0;
+      if (const auto *a = dynamic_cast<const DistAmgSolver *>(r->DistributedSolver())) *levels = a->NumLevels();
+      if (const auto *m = dynamic_cast<const DistAmsSolver *>(r->DistributedSolver())) *levels = m->NodalSpaceSolver()->NumLevels();
+    }
   });
 }
 static const AmgSolver &amg_of(const pa_solver *S, int which) {

@@ -615,7 +615,12 @@ def replicated_coarse(ctx, level0: "ParOperator", G=None, nv_true=0, xyz_true=No
     h = C.c_void_p()
     _lib.check(L.pa_replicated_coarse_create(ctx.handle, level0.handle, G.handle if G is not None else None, int(nv_true),
                                              _ptr(xyz) if xyz is not None else None, dim, int(cycle_it), int(bool(singular)), C.byref(h)))
-    return Solver(ctx, h, (level0, G))
+    s = Solver(ctx, h, (level0, G))
+    dist, lev = C.c_int(0), C.c_int(0)
+    L.pa_replicated_coarse_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib.check(L.pa_replicated_coarse_info(h, C.byref(dist), C.byref(lev)))
+    s.distributed, s.algebraic_levels = bool(dist.value), int(lev.value)  # (amg_dist.hpp; PALACE_AMD_COARSE_SOLVE=replicated: False)
+    return s
 
 
 def ams(ctx, csr, ess_tdofs, G, coords, cycle_it=0, smooth_order=0, singular=False, amg_coarse_size=0, amg_smooth_order=0,

@@ -219,6 +219,8 @@ def _dist_coarse_worker(rank, world, port, out):
             st = K.stats()
             assert st["converged"], (kind, st)
             res[kind] = (st["iterations"], ctx.dot(x, x))
+            if kind == "ams_dist":  # (round 5: the C++ layer's solver applies its rows of every algebraic level, amg_dist.hpp)
+                res["ams_dist_form"] = (bool(prob.last_coarse.distributed), int(prob.last_coarse.algebraic_levels))
             x.zero_()
             K.mult(b, x)  # (the recorded iteration replays: the gather of the replicated solve is part of it)
             res[kind + "_again"] = (K.stats()["iterations"], ctx.dot(x, x))
@@ -243,6 +245,7 @@ def test_replicated_coarse_solver_assembled_from_the_ranks_pieces():
         mp.spawn(_dist_coarse_worker, args=(world, port, q), nprocs=world, join=True)
         results[world] = q.get()
     one, two = results[1], results[2]
+    assert two["ams_dist_form"][0] is True and two["ams_dist_form"][1] >= 1, two
     for kind in ("ams", "ams_dist"):
         assert abs(two[kind][0] - one["ams"][0]) <= 1, (kind, one, two)
         assert abs(two[kind][1] - one["ams"][1]) < 1e-6 * one["ams"][1], (kind, one, two)
