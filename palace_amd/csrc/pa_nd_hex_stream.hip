@@ -936,7 +936,7 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
 
 template <int P1>
 static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
-  NDStreamArgs<P1> a;
+  NDStreamArgs<P1> a{};  // (every field the chosen form does not use: zero)
   a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
   if (split) {
     PA_REQUIRE(split->n_true >= 0 && split->n_true <= so.lsize, "split point outside the local vector");
@@ -1033,7 +1033,7 @@ bool nd_hex_stream_complex_ok(const SubOp &sr, const SubOp &si) {
 template <int P1>
 static void launch_complex_p(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
                              double *ye_i, bool masked, hipStream_t s) {
-  NDStreamArgs<P1> a;
+  NDStreamArgs<P1> a{};  // (every field the chosen form does not use: zero)
   a.ne = sr.ne, a.blist = nullptr, a.nbatch = 0;
   a.idxc = sr.d_idxc;
   a.flagw = masked ? sr.d_flagw_bc : sr.d_flagw;
