@@ -240,7 +240,7 @@ def test_cxx_host_ranks_distributed_amg_through_ksp_solver(tmp_path):
     for world, mode in ((1, "distributed"), (2, "distributed"), (2, "replicated")):
         prefix = str(tmp_path / f"w{world}")
         subprocess.check_call([sys.executable, os.path.join(ROOT, "examples", "cxx_host", "dump_problem_ranks.py"), prefix, str(world),
-                               "2", "6", "12"])
+                               "2", "10", "20"])  # (11k vertices on level 0: three algebraic levels, the middle one smoothed across the ranks)
         d = tmp_path / f"handles{world}{mode}"
         d.mkdir()
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PALACE_AMD_PEER_TIMEOUT_S="30", PALACE_AMD_COARSE_SOLVE=mode)
