@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-dofs", type=float, default=1.0e6, help="size of the CPU baseline sample")
     ap.add_argument("--cpu-pcg-dofs", type=float, default=2.5e5, help="size of the CPU PCG + p-multigrid sample")
     ap.add_argument("--cpu-pcg-iters", type=int, default=5)
+    ap.add_argument("--cpu-pcg-full-iters", type=int, default=1, help="oracle PCG + p-multigrid iterations ON THE BENCH MESH (M2's CPU "
+                    "baseline at size; 0 = skip)")
     ap.add_argument("--no-p4", action="store_true", help="skip the order-4 leg")
     ap.add_argument("--no-tets", action="store_true", help="skip the tetrahedral (dense MFMA path) leg")
     ap.add_argument("--tet-n", type=int, default=36, help="cubes per direction of the Kuhn-split tet mesh")
@@ -253,6 +255,67 @@ def cpu_leg(ctx, prob, order, args):
         cpu["pcg_sample"] = (f"oracle PCG + p-multigrid on K+M, {n} dofs, {sp.mesh.ne} elements, {it} iterations in {dt:.1f} s "
                              "(local applies oracle/oracle_c.c with OpenMP, the rest numpy)")
         sp._keep.clear()
+
+    # ---- M2's CPU figure AT THE BENCH SIZE (round 6): the same oracle loop on the bench mesh itself, --cpu-pcg-full-iters
+    # iterations (default 1: one iteration is ~17 fine-level and ~14 order-2 applies of the C oracle on `cores` OpenMP threads;
+    # the vector work is numpy, single-threaded).  The operator diagonals and eigenvalue estimates the smoothers need are taken
+    # from the device objects (set-up, outside the timed region: the numpy diagonal of 125k dense element matrices takes
+    # minutes); the device iterate after the same number of iterations is checked against the oracle's.
+    if args.cpu_pcg_full_iters > 0:
+        its = args.cpu_pcg_full_iters
+        solver, b, xs = prob.pcg_gmg_solver(max_it=its, hiptmair=False, coarse="cg")
+        solver.mult(b, xs)
+        xd = xs.cpu().numpy()
+        gmg, dA = prob.last_gmg, prob.last_A
+        nl = len(prob.spaces)
+        cm, bm = util.make_ctx("scalar")
+        cc, bc = util.make_ctx("identity")
+        blob2 = np.concatenate([bm, bc])
+        ogeom = oracle_hex_data(prob, order)["geom"]
+
+        class _Level:  # ParOperatorOracle's Mult with the C apply on `cores` threads; diagonal handed over from the device
+            def __init__(self, sx, dev):
+                self.off, self.ori = sx.native_restriction()
+                self.off = np.ascontiguousarray(self.off, dtype=np.int32)
+                self.tab = po.nd_hex_dense_tables(sx.p, q1d, sx.dof_map_native())
+                self.ess, self.n = sx.ess_dofs().astype(np.int64), sx.ndofs
+                d = torch.empty(sx.ndofs, dtype=torch.float64, device="cuda")
+                dev.assemble_diagonal(d)
+                self._diag = d.cpu().numpy()
+
+            def mult(self, v):
+                tv = v.copy()
+                tv[self.ess] = 0.0
+                out = np.zeros(self.n)
+                capi.apply_add(self.off, self.ori, self.tab[0], self.tab[1], ogeom, capi.QF_HDIVMASS, blob2, tv, out, threads=cores)
+                out[self.ess] = v[self.ess]
+                return out
+
+            def diagonal(self):
+                return self._diag
+
+        oA = [_Level(sx, da) for sx, da in zip(prob.spaces, dA)]
+        oP = [po.InterpOracle(c.elem_dof_lex, c.elem_sign_lex, f.elem_dof_lex, f.elem_sign_lex, c.ndofs, f.ndofs,
+                              po.nd_hex_interp_lex(c.p, f.p)) for c, f in zip(prob.spaces[:-1], prob.spaces[1:])]
+        ko = max(2 * order, 4)
+        sm = [None] + [po.ChebyshevOracle(oA[l], ko, lambda_max=gmg.gmg_lambda_max(l)) for l in range(1, nl)]
+        d0 = 1.0 / oA[0].diagonal()
+        coarse = lambda r: po.pcg(oA[0].mult, r, lambda v: d0 * v, rel_tol=1e-2, max_it=8)[0]  # noqa: E731
+        oB = po.GMGOracle(oA, [(q.mult, q.mult_transpose) for q in oP], sm, coarse, [sx.ess_dofs() for sx in prob.spaces])
+        n = prob.spaces[-1].ndofs
+        ob = oA[-1].mult(np.ones(n))
+        ob[prob.spaces[-1].ess_dofs()] = 0.0
+        t0 = time.perf_counter()
+        xo, it, hist = po.pcg(oA[-1].mult, ob, oB.mult, rel_tol=0.0, max_it=its)
+        dt = time.perf_counter() - t0
+        parity["rel_l2_pcg_full"] = _rel(xd, xo)
+        parity["rel_l2_pcg_full_size"] = f"{n} dofs (the bench mesh), iterate after {it} PCG + p-multigrid iteration(s)"
+        cpu["pcg_iters_per_s_sample"] = cpu.get("pcg_iters_per_s")
+        cpu["pcg_iters_per_s"] = it / dt
+        cpu["pcg_full_size_sample"] = (f"oracle PCG + p-multigrid on K+M ON THE BENCH MESH: {n} dofs, {prob.mesh.ne} elements, {it} iteration(s) in "
+                                       f"{dt:.1f} s; local applies oracle/oracle_c.c on {cores} OpenMP threads, vector work and transfers numpy "
+                                       "(1 thread); operator diagonals and eigenvalue estimates handed over from the device (set-up, untimed)")
+        prob._keep.clear()
     return cpu, parity
 
 

@@ -445,6 +445,13 @@ int pa_csr_get(const pa_csr *csr, int32_t *nrows, int64_t *nnz, const int32_t **
  * test)::FullAssemble, e.g. Atn of models/modeeigensolver.cpp:45-56: rows = test dofs, columns = trial dofs). */
 int pa_csr_num_cols(const pa_csr *csr);
 void pa_csr_destroy(pa_csr *csr);
+/* Operator::Size() (operator.hpp:46): number of sub-operators added so far. */
+int pa_op_num_sub(const pa_op *op);
+/* Operator::DestroyAssemblyData() (operator.cpp:103-114: CeedOperatorAssemblyDataStrip on every sub-operator after
+ * BilinearForm::Assemble has built the coarse matrix, bilinearform.cpp:133-141).  This library keeps no assembly state
+ * between calls -- pa_op_full_assemble and pa_op_assemble_diagonal release their workspaces before returning -- so the call
+ * only validates the handle; it exists so that the reference's call sequence maps one to one. */
+int pa_op_destroy_assembly_data(const pa_op *op);
 int pa_op_height(const pa_op *op);
 int pa_op_width(const pa_op *op);
 /* Algorithmic HBM bytes of one apply_add by SURVEY.md 8(d)'s formula

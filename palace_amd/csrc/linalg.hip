@@ -891,16 +891,65 @@ Operator::~Operator() {
 static void check(int rc) {
   if (rc) throw pa::Error(pa_last_error());
 }
-void Operator::Mult(const Vector &x, Vector &y) const { check(pa_op_mult(op_, x.Data(), y.Data(), ctx_->stream)); }
+static pa_op *create_op(int h, int w) {
+  pa_op *op = nullptr;
+  check(pa_op_create(h, w, &op));
+  return op;
+}
+Operator::Operator(const Context &ctx, int h, int w) : palace::Operator(h, w), op_(create_op(h, w)), own_(true), ctx_(&ctx) {}
+void Operator::AddSubOperator(pa_geom *geom, const pa_restriction_desc &restr, const pa_basis_desc &basis, int qfunction,
+                              const void *qf_ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops) {
+  check(pa_op_add_sub(op_, geom, &restr, &basis, qfunction, qf_ctx, ctx_size, trial_ops, test_ops));
+}
+void Operator::AddSubOperator(pa_geom *geom, const pa_restriction_desc &restr, const pa_dense_basis_desc &basis, int qfunction,
+                              const void *qf_ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops) {
+  check(pa_op_add_sub_dense(op_, geom, &restr, &basis, qfunction, qf_ctx, ctx_size, trial_ops, test_ops));
+}
+void Operator::Finalize() {
+  StreamGraph::Invalidate();
+  check(pa_op_finalize(op_));
+}
+void Operator::DestroyAssemblyData() const { check(pa_op_destroy_assembly_data(op_)); }
+std::size_t Operator::Size() const { return (std::size_t)pa_op_num_sub(op_); }
+void Operator::SetDofMultiplicity(Vector &&mult) {
+  PA_REQUIRE(mult.Size() == 0 || mult.Size() == height, "dof multiplicity: one entry per row of the operator");
+  StreamGraph::Invalidate();
+  dof_multiplicity_ = std::move(mult);
+}
+void Operator::Mult(const Vector &x, Vector &y) const {
+  check(pa_op_mult(op_, x.Data(), y.Data(), ctx_->stream));
+  if (dof_multiplicity_.Size() > 0) linalg::Scale(*ctx_, dof_multiplicity_, y);  // operator.cpp:186-189
+}
 void Operator::AddMult(const Vector &x, Vector &y, double a) const {
   PA_REQUIRE(a == 1.0, "ceed::Operator::AddMult only supports coefficient = 1.0!");  // operator.cpp:194
+  if (dof_multiplicity_.Size() > 0) {  // operator.cpp:195-207
+    if (temp_.Size() != height) temp_.SetSize(height);
+    check(pa_op_mult(op_, x.Data(), temp_.Data(), ctx_->stream));
+    linalg::Scale(*ctx_, dof_multiplicity_, temp_);
+    linalg::AXPY(*ctx_, 1.0, temp_, y);
+    return;
+  }
   check(pa_op_apply_add(op_, x.Data(), y.Data(), ctx_->stream));
 }
 void Operator::MultTranspose(const Vector &x, Vector &y) const {
+  if (dof_multiplicity_.Size() > 0) {  // operator.cpp:213-217 -> :224-235: y = A^T (d .* x)
+    if (temp_.Size() != height) temp_.SetSize(height);
+    linalg::Copy(*ctx_, x, temp_);
+    linalg::Scale(*ctx_, dof_multiplicity_, temp_);
+    check(pa_op_mult_transpose(op_, temp_.Data(), y.Data(), ctx_->stream));
+    return;
+  }
   check(pa_op_mult_transpose(op_, x.Data(), y.Data(), ctx_->stream));
 }
 void Operator::AddMultTranspose(const Vector &x, Vector &y, double a) const {
   PA_REQUIRE(a == 1.0, "ceed::Operator::AddMultTranspose only supports coefficient = 1.0!");  // operator.cpp:219
+  if (dof_multiplicity_.Size() > 0) {
+    if (temp_.Size() != height) temp_.SetSize(height);
+    linalg::Copy(*ctx_, x, temp_);
+    linalg::Scale(*ctx_, dof_multiplicity_, temp_);
+    check(pa_op_apply_add_transpose(op_, temp_.Data(), y.Data(), ctx_->stream));
+    return;
+  }
   check(pa_op_apply_add_transpose(op_, x.Data(), y.Data(), ctx_->stream));
 }
 bool Operator::IsSymmetric() const { return pa_op_is_symmetric(op_) != 0; }

@@ -214,10 +214,32 @@ class Operator : public palace::Operator {
   bool own_;
   const Context *ctx_;
 
+  Vector dof_multiplicity_;  // SetDofMultiplicity (operator.hpp:35, :54): empty = none
+  mutable Vector temp_;
+
 public:
   Operator(const Context &ctx, pa_op *op, bool own);
+  // Operator::Operator(h, w) (fem/libceed/operator.cpp:17-42): an empty composite, filled by AddSubOperator, closed by Finalize
+  Operator(const Context &ctx, int h, int w);
   ~Operator() override;
   pa_op *Handle() const { return op_; }
+  // AddSubOperator (operator.cpp:60-87).  The reference hands over a CeedOperator built by AssembleCeedOperator
+  // (fem/libceed/integrator.cpp:423-513) from (geometry data, restriction, basis, QFunction, context); here the same five
+  // things are the sub-operator (tensor or dense basis tables).  The transpose sub-operator of the reference's second
+  // argument is implied: every sub-operator carries its transposed form (pa_op_mult_transpose).
+  void AddSubOperator(pa_geom *geom, const pa_restriction_desc &restr, const pa_basis_desc &basis, int qfunction, const void *qf_ctx,
+                      size_t ctx_size, uint32_t trial_ops, uint32_t test_ops);
+  void AddSubOperator(pa_geom *geom, const pa_restriction_desc &restr, const pa_dense_basis_desc &basis, int qfunction,
+                      const void *qf_ctx, size_t ctx_size, uint32_t trial_ops, uint32_t test_ops);
+  void Finalize();  // operator.cpp:89-101
+  // operator.cpp:103-114: the reference strips libCEED's assembly caches; this library keeps none between calls (the probing
+  // workspace of pa_op_full_assemble and the diagonal's E-vector are released before those calls return), so there is nothing
+  // to free -- kept so that callers (BilinearForm::Assemble, bilinearform.cpp:133-141) compile unchanged
+  void DestroyAssemblyData() const;
+  // operator.hpp:54; bilinearform.cpp:279 (discrete interpolators: the inverse multiplicity of the range dofs).  Mult /
+  // AddMult scale the result, AddMultTranspose scales the input, as operator.cpp:181-240
+  void SetDofMultiplicity(Vector &&mult);
+  std::size_t Size() const;  // number of sub-operators (operator.hpp:46)
   const Context &GetContext() const { return *ctx_; }
   bool Streams() const { return pa_op_streams(op_) != 0; }  // y = A x runs on the streaming kernels
   void Mult(const Vector &x, Vector &y) const override;

@@ -1213,6 +1213,10 @@ int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream) {
   });
 }
 
+int pa_op_num_sub(const pa_op *op) { return op ? (int)(op->subs.size() + op->dsubs.size() + op->msubs.size()) : -1; }
+int pa_op_destroy_assembly_data(const pa_op *op) {
+  return guarded([&] { PA_REQUIRE(op, "null operator"); });
+}
 int pa_op_height(const pa_op *op) { return op ? op->height : -1; }
 int pa_op_width(const pa_op *op) { return op ? op->width : -1; }
 

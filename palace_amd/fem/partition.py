@@ -393,6 +393,7 @@ class SlabProblem:
         x = torch.zeros_like(b)
         self._keep.append((local, A, P, B))
         self.last_gmg = B if len(A) > 1 else None
+        self.last_A = A
         return K, b, x
 
 

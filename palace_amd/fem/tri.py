@@ -296,3 +296,92 @@ class H1TriSpace:
              (self.edge_base + edges[:, None] * n_e + np.arange(n_e)[None, :]).ravel()]
         return np.unique(np.concatenate(d)).astype(np.int32)
 
+
+
+def nd_tri_transfer_matrix(pc, pf):
+    """Element matrix of the p-prolongation ND(pc) -> ND(pf) on the triangle (MFEM GetTransferMatrix, basis.cpp:132-138):
+    the fine dof functionals applied to the coarse basis, [P_f, P_c]."""
+    fine = NDTriElement(pf)
+    interp, _ = NDTriElement(pc).tables(fine.dof_pts)      # [2, P_f, P_c]
+    return np.ascontiguousarray(np.einsum("dji,jd->ji", interp, fine.dof_tans))
+
+
+def tri_gradient_matrix(p):
+    """Element matrix of the discrete gradient H1(p) -> ND(p) on the triangle (basis.cpp:139-143), [P_nd, P_h1]."""
+    nd = NDTriElement(p)
+    _, grad = H1TriElement(p).tables(nd.dof_pts)           # [2, P_nd, P_h1]
+    return np.ascontiguousarray(np.einsum("dji,jd->ji", grad, nd.dof_tans))
+
+
+def restriction(space):
+    """dict(offsets, lsize[, orients]) of a triangle space as the C ABI's dense interpolators take it (the 2-D restriction is
+    the oriented one, its own inverse: fem/libceed/restriction.cpp:234-238)."""
+    r = dict(offsets=space.offsets, lsize=space.ndofs)
+    if getattr(space, "orients", None) is not None:
+        r["orients"] = space.orients
+    return r
+
+
+def lowest_order_gradient(h1, nd):
+    """Discrete gradient [nd.ndofs x h1.ndofs] of the order-1 spaces on a TriMesh as a scipy CSR matrix (+1 at the head, -1 at
+    the tail of every global edge), built from the element matrix and the element's edge orientations like the tetrahedral one
+    (tet.lowest_order_gradient)."""
+    import scipy.sparse as sp
+
+    assert h1.p == 1 and nd.p == 1
+    Gel = tri_gradient_matrix(1)  # [3, 3]
+    sgn = np.where(np.asarray(nd.orients, dtype=bool), -1.0, 1.0)
+    rows, cols, vals = [], [], []
+    for i in range(Gel.shape[0]):
+        for j in range(Gel.shape[1]):
+            if abs(Gel[i, j]) > 1e-14:
+                rows.append(nd.offsets[:, i].astype(np.int64))
+                cols.append(h1.offsets[:, j].astype(np.int64))
+                vals.append(sgn[:, i] * Gel[i, j])
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    _, first = np.unique(rows * h1.ndofs + cols, return_index=True)
+    G = sp.csr_matrix((vals[first], (rows[first], cols[first])), shape=(nd.ndofs, h1.ndofs))
+    assert (np.diff(G.indptr) == 2).all() and abs(G.sum(axis=1)).max() < 1e-13
+    return G
+
+
+def vertex_coordinates(h1):
+    """Coordinates [h1.ndofs, 2] of the dofs of an order-1 H1 space on a TriMesh."""
+    assert h1.p == 1
+    xy = np.zeros((h1.ndofs, 2))
+    xy[np.asarray(h1.offsets).ravel()] = h1.mesh.verts[h1.mesh.tris.ravel()]
+    return xy
+
+
+def edge_current_load(nd, bdr_verts, bdr_attr, source_attr, direction):
+    """Load vector of a unit surface current on the boundary edges with attribute `source_attr` (the reference's
+    SurfaceCurrentOperator on a 2-D mesh, models/surfacecurrentoperator.cpp: b_i = int_Gamma J_s . phi_i ds with J_s the
+    unit vector `direction` along the edge) and the mask of the remaining boundary edges.  bdr_verts [nb, 2]: vertex ids
+    (the space's mesh numbering) of every boundary edge.  Returns (b, other_edge_mask, total source length)."""
+    mesh = nd.mesh
+    ekey = {tuple(e): i for i, e in enumerate(map(tuple, mesh.edge_verts))}
+    owner = {}
+    for e in range(mesh.ne):
+        for k in range(3):
+            owner.setdefault(int(mesh.elem_edges[e, k]), (e, k))
+    s, ws = gauss_legendre(nd.p + 2)
+    sgn = np.where(nd.orients, -1.0, 1.0)
+    b = np.zeros(nd.ndofs)
+    other = np.zeros(mesh.edge_verts.shape[0], dtype=bool)
+    length = 0.0
+    direction = np.asarray(direction, dtype=np.float64)
+    for (va, vb), attr in zip(bdr_verts, bdr_attr):
+        ge = ekey[(min(va, vb), max(va, vb))]
+        if attr != source_attr:
+            other[ge] = True
+            continue
+        e, k = owner[ge]
+        la, lb = LOCAL_EDGES[k]
+        that = REF_VERTS[lb] - REF_VERTS[la]
+        xs = REF_VERTS[la][None, :] + s[:, None] * that[None, :]
+        val, _ = nd.elem.tables(xs)                       # [2, nq, P]
+        loc = np.einsum("dqj,d,q->j", val, that, ws)      # int phi_hat . t_hat ds_hat (= int phi . t ds: covariant Piola)
+        tphys = mesh.verts[mesh.tris[e, lb]] - mesh.verts[mesh.tris[e, la]]
+        length += float(np.linalg.norm(tphys))
+        np.add.at(b, nd.offsets[e], np.sign(tphys @ direction) * sgn[e] * loc)
+    return b, other, length

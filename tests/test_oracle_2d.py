@@ -239,3 +239,41 @@ def test_cavity2d_magnetostatic_inductance():
     assert energy == pytest.approx(0.5, rel=1e-7)
     mu0 = 1.25663706127e-6                                 # utils/constants.hpp:26
     assert mu0 * energy == pytest.approx(float(M_["M11_H"]), rel=1e-7)
+
+
+def test_tri_transfer_and_gradient_commute_with_the_curl():
+    """Host tables of the 2-D p-multigrid on triangles (tri.nd_tri_transfer_matrix, tri.lowest_order_gradient) against the
+    oracle's curl-curl: the order-1 gradients, prolonged to order 2, stay in the null space of the order-2 curl-curl
+    (curl P G = 0), and the Galerkin product P^T K_2 P is the order-1 curl-curl (nested spaces, same quadrature)."""
+    import scipy.sparse as sp
+
+    from palace_amd.fem import tri
+
+    M_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "cavity2d_mesh.npz"))
+    en = M_["elem_nodes"].astype(np.int64)[:400]
+    used, inv = np.unique(en[:, :3], return_inverse=True)
+    allused, allinv = np.unique(en, return_inverse=True)
+    mesh = tri.TriMesh(M_["nodes"][used], inv.reshape(-1, 3), None, elem_nodes=allinv.reshape(en.shape), nodes=M_["nodes"][allused])
+    s1, s2, h1 = tri.NDTriSpace(mesh, 1), tri.NDTriSpace(mesh, 2), tri.H1TriSpace(mesh, 1)
+    pts, wts = tri.tri_quadrature(3)
+    J = mesh.jacobians(pts)
+    geom = po.build_geom_factor_22(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 4))
+    Ks = []
+    for s in (s1, s2):
+        interp, curl = s.elem.tables(pts)
+        Ks.append(po.CeedOperatorOracle(s.ndofs, s.offsets, s.orients, interp, curl, geom, po.QF_L2_1, po.CoeffCtx(dim=1),
+                                        qw=wts).assemble_sparse().tocsr())
+    T = tri.nd_tri_transfer_matrix(1, 2)
+    sg1, sg2 = np.where(s1.orients, -1.0, 1.0), np.where(s2.orients, -1.0, 1.0)
+    rows = np.repeat(s2.offsets[:, :, None], 3, axis=2).ravel()
+    cols = np.repeat(s1.offsets[:, None, :], 8, axis=1).ravel()
+    vals = (sg2[:, :, None] * T[None] * sg1[:, None, :]).ravel()
+    _, first = np.unique(rows.astype(np.int64) * s1.ndofs + cols, return_index=True)  # every element gives the same entry
+    P = sp.csr_matrix((vals[first], (rows[first], cols[first])), shape=(s2.ndofs, s1.ndofs))
+    G = tri.lowest_order_gradient(h1, s1)
+    scale = abs(Ks[1]).max()
+    assert abs(Ks[1] @ (P @ G)).max() < 1e-11 * scale
+    assert abs(P.T @ Ks[1] @ P - Ks[0]).max() < 1e-11 * scale
+    xy = tri.vertex_coordinates(h1)
+    ev = mesh.verts[mesh.edge_verts[:, 1]] - mesh.verts[mesh.edge_verts[:, 0]]
+    assert np.abs(np.abs(G @ xy) - np.abs(ev)).max() < 1e-13  # gradient of the coordinates = the edge vectors
