@@ -385,6 +385,12 @@ int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double 
 /* 1 if y = A x runs on the streaming kernels (single tensor-product block, Q1 = 4, packed q-data): callers choosing between
  * pa_op_mult2 and two pa_op_mult calls prefer the latter then */
 int pa_op_streams(const pa_op *op);
+/* Affine-element compression of the streaming H(curl) hex kernel (round 6): an element with a constant Jacobian has
+ * D(q) = w_q D_e, and a batch of four such elements reads 6 | 7 | 12 numbers per ELEMENT instead of per point (the reference
+ * stores per-point data unconditionally, fem/mesh.cpp:146-209; the results agree to the rounding noise of the element's
+ * Jacobian, gate 1e-13).  out[0] elements, out[1] affine elements found, out[2] of them in all-affine batches (compressed);
+ * first tensor H(curl) sub-operator; all zero when there is none or the form is off (PALACE_AMD_STREAM_AFFINE=0). */
+int pa_op_stream_affine(const pa_op *op, int32_t out[3]);
 /* number of dense sub-operators that run in the affine form: every element of the block has a constant Jacobian (straight-sided
  * simplices), so the pre-assembled D of a quadrature point is the D of the first point times w_q / w_0 and the kernel reads 6
  * values per field and element instead of 6 Q (PALACE_AMD_DENSE_AFFINE=0 at creation time keeps the general form) */

@@ -428,6 +428,16 @@ class Operator:
         """Number of dense sub-operators running in the affine (constant Jacobian) form (pa_op_dense_affine)."""
         return int(_lib.load().pa_op_dense_affine(self.handle))
 
+    def streams(self):
+        """True when y = A x runs on the streaming kernels (pa_op_streams)."""
+        return bool(_lib.load().pa_op_streams(self.handle))
+
+    def stream_affine(self):
+        """(elements, affine elements, of them compressed) of the streaming H(curl) hex kernel (pa_op_stream_affine)."""
+        out = (C.c_int32 * 3)()
+        _lib.check(_lib.load().pa_op_stream_affine(self.handle, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def add_mult(self, x, y, a=1.0):
         if a != 1.0:  # operator.cpp:194
             raise _lib.PalaceAmdError("ceed::Operator::AddMult only supports coefficient = 1.0!")

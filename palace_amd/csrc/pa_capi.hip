@@ -366,7 +366,7 @@ static void free_sub(SubOp *so) {
   hipFree(so->d_ye), hipFree(so->d_ye2), hipFree(so->d_tptr), hipFree(so->d_tent);
   free_stream(*so);
   if (so->qd && --so->qd->refcount == 0) {
-    hipFree(so->qd->d);
+    hipFree(so->qd->d), hipFree(so->qd->d_aff);
     delete so->qd;
   }
   hipFree(so->d_tab);
@@ -599,7 +599,7 @@ void pa_geom_destroy(pa_geom *geom) {
     hipFree(geom->d_attr_e);
     hipFree(geom->d_xnodes), hipFree(geom->d_gtab);
     if (geom->metric) {
-      hipFree(geom->metric->d);
+      hipFree(geom->metric->d), hipFree(geom->metric->d_aff);
       delete geom->metric;
     }
     delete geom;
@@ -1213,6 +1213,17 @@ int pa_op_assemble_diagonal(pa_op *op, double *diag, void *stream) {
   });
 }
 
+int pa_op_stream_affine(const pa_op *op, int32_t out[3]) {
+  return guarded([&] {
+    PA_REQUIRE(op && out, "null argument");
+    out[0] = out[1] = out[2] = 0;
+    for (const SubOp *so : op->subs)
+      if (so->fe_type == PA_FE_HCURL && so->qd) {
+        out[0] = so->ne, out[1] = so->qd->n_aff_elems, out[2] = so->qd->d_aff ? so->qd->n_aff_batch_elems : 0;
+        return;
+      }
+  });
+}
 int pa_op_num_sub(const pa_op *op) { return op ? (int)(op->subs.size() + op->dsubs.size() + op->msubs.size()) : -1; }
 int pa_op_destroy_assembly_data(const pa_op *op) {
   return guarded([&] { PA_REQUIRE(op, "null operator"); });

@@ -147,6 +147,19 @@ struct QData {
   // property of the mesh alone, shared by every operator and p-level on it.  Both pointwise operators follow
   // from it in registers:  (w / detJ) J^T c J = c H,   w detJ adj^T c adj = c (|detJ| / w) adj(H).
   bool metric = false;
+  // Affine elements (round 6; four points per direction, the streaming H(curl) kernel): an element whose Jacobian is constant has
+  // D(q) = w_q D_e -- 6 | 7 | 12 numbers per element instead of per point.  d_aff [ne padded to 4][2 ncomp] pairs of doubles: row
+  // 2 c + h of element e = r_c {wz(2h), wz(2h + 1)} with r_c the point-independent factor of component c and wz the 1-D weight
+  // along the lane's column (metric component 6, |detJ| / w: g {1 / wz(2h), 1 / wz(2h + 1)}); the kernel multiplies the result of
+  // the D stage by the in-plane weight w(ta) w(tb).  batch_aff[b] != 0: the four elements of batch b are all affine (the
+  // streaming kernel then reads 4 x 2 ncomp x 16 B instead of 4 x ncomp x 512 B).  The per-point data stays in place: every
+  // other consumer (one-shot kernels, diagonal, assembly, the complex forms) is unaffected.  Built once per QData by
+  // stream_affine_setup (pa_nd_hex_stream.hip) -- coarsened operators share it with the q-data.
+  double *d_aff = nullptr;
+  std::vector<unsigned char> batch_aff;
+  bool aff_done = false;
+  int n_aff_elems = 0, n_aff_batch_elems = 0;  // affine elements found / of them in all-affine batches (compressed)
+  double wq2[2] = {0.0, 0.0};                  // the two distinct 1-D weights (symmetric four-point rule)
 };
 
 // Offset of component c at point q inside one element's block of packed q-data (H(curl) hexahedra).  In general

@@ -78,6 +78,9 @@ struct NDStreamArgs {
                           // the sorted -> tensor-order permutation; an element names its pattern in word kIdxPattern of its index
                           // block (elements with the same permutation share one: the table stays in L2)
   const double *qdata;    // [ne][NG][2][16][2]
+  const double *qaff;     // [ne][2 NG] pairs: the compact D of affine elements (QData::d_aff); read by the batches whose flag words
+                          // carry kAffBit (all four elements affine) instead of qdata
+  double wq2[2];          // 1-D quadrature weights {w(0) = w(3), w(1) = w(2)}: the in-plane factor of an affine batch's D
   const double *coef;     // metric form: [ne][2] scalar mass / curl-curl coefficient of the element
   // GEOMN form (geometry from the nodes): [ne][27][3] node coordinates, {B [4][3], G [4][3], w [4]} of the 1-D geometry basis
   const double *xn, *gtab;
@@ -123,6 +126,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   static_assert(!(CPLX && SPLIT), "no split-vector form of the complex kernel");
   static_assert(!GEOMN || (!USE_U && USE_C && !METRIC && !CPLX), "geometry from the nodes: the curl-curl kernel");
   constexpr int Q1 = 4;
+  // affine batches (round 6): D(q) = w_q D_e read from the compact rows of QData::d_aff (same number of loads, 16 bytes per row
+  // for the whole element instead of per lane) and the D stage's result scaled by the in-plane weight; real forms on packed data
+  constexpr bool AFF = !CPLX && !GEOMN && !(PA_STREAM_QAHEAD && MINW == 2);
 #ifdef PA_STREAM_EARLY  // experiment builds
   constexpr bool EARLY_IDX = true;
 #else
@@ -226,8 +232,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 #pragma unroll
     for (int r = 0; r < (GEOMN ? 6 : 1); r++) xl[r] = (t + 16 * r < 81) ? __builtin_nontemporal_load(&xp[t + 16 * r]) : 0.0;
   };
-  auto load_q = [&](const int ee, const int t) {
+  auto load_q = [&](const int ee, const int t, const int aff) {
     if (GEOMN) return load_xn(ee, t);  // (the nodes of the batch: consumed in its D stage)
+    if (AFF) {
+      // one instruction stream for both kinds of batch (the counted waits below depend on the number of loads in flight): the
+      // wave-uniform flag selects the base, the lane offset and the row stride
+      constexpr int NS = METRIC ? 7 : NG;
+      const int rs = aff ? 1 : 16;
+      const d2v *g = aff ? reinterpret_cast<const d2v *>(a.qaff) + (size_t)ee * (2 * NS)
+                         : reinterpret_cast<const d2v *>(a.qdata) + ((size_t)ee * (2 * NS * 16) + t);
+#pragma unroll
+      for (int k = 0; k < 2 * NG; k++) gq[k] = __builtin_nontemporal_load(&g[rs * k]);
+      return;
+    }
     if (CPLX && !METRIC) {  // this group's operator: mass components into gq[0 .. 11], curl-curl into gq[12 .. 23]
       const int grp = (lane >> 4) & 1;
       const int mo = a.qm[grp], co = a.qc[grp];
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     for (int k = 0; k < (GEOMN ? 1 : 2 * NG); k++) gq[k] = __builtin_nontemporal_load(&g[16 * k]);
   };
   if (QAHEAD) {
-    load_q(CPLX ? b * 2 + (lane >> 5) : b * 4 + (lane >> 4), lane & 15);
+    load_q(CPLX ? b * 2 + (lane >> 5) : b * 4 + (lane >> 4), lane & 15, 0);
 #pragma unroll
     for (int k = 0; k < 2 * NG; k++) asm volatile("" : "+v"(gq[k]));
   }
@@ -274,7 +291,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     const int e = CPLX ? b * 2 + (sub >> 1) : b * 4 + sub;
 
     // q-data of this batch: consumed after the forward contraction
-    if (!QAHEAD) load_q(e, t);
+    const int aff = AFF ? __builtin_amdgcn_readfirstlane((int)(pA[NPK] >> 31)) : 0;  // (the same for the 64 lanes: build_stream)
+    if (!QAHEAD) load_q(e, t, aff);
     d2v ce = {0.0, 0.0}, ci = {0.0, 0.0};
     if (METRIC || GEOMN) ce = reinterpret_cast<const d2v *>(a.coef)[e];
     if (CPLX && METRIC) ci = reinterpret_cast<const d2v *>(a.coef1)[e];
@@ -389,6 +407,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       }
     }
     // D at the four points of this lane's column
+    double wab = 1.0;  // affine batch: the in-plane weight w(ta) w(tb) its compact D leaves out (1: exact no-op otherwise)
+    if (AFF) {
+      const double wa = (ta == 0 || ta == 3) ? a.wq2[0] : a.wq2[1], wb = (tb == 0 || tb == 3) ? a.wq2[0] : a.wq2[1];
+      wab = aff ? wa * wb : 1.0;
+    }
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
       double H[NG];
@@ -453,6 +476,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
           const double m[6] = {ccurl * H[0], ccurl * H[1], ccurl * H[2], ccurl * H[3], ccurl * H[4], ccurl * H[5]};
           sym_mv(m, CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
         }
+        if (AFF) {
+          // compact rows: H' = H / wab, H'[6] = H[6] wab  =>  both products above came out divided by wab
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            if (USE_U) U[c][qz] *= wab;
+            if (USE_C) CU[c][qz] *= wab;
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);  // one point at a time: short live ranges
       } else if (CPLX) {
         // this group's D on both parts: the product with the real part stays (D_r u_r for y_r, D_i u_r for y_i), the product with
@@ -479,6 +510,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
       } else {
         if (USE_U) sym_mv(&H[0], U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
         if (USE_C) sym_mv(&H[USE_U ? 6 : 0], CU[0][qz], CU[1][qz], CU[2][qz], CU[0][qz], CU[1][qz], CU[2][qz]);
+        if (AFF) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            if (USE_U) U[c][qz] *= wab;
+            if (USE_C) CU[c][qz] *= wab;
+          }
+        }
       }
     }
 
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
 
     if (QAHEAD) {  // q-data of the next batch (the last one re-reads its own)
       __builtin_amdgcn_sched_barrier(0);
-      load_q(CPLX ? bn * 2 + (sub >> 1) : bn * 4 + sub, t);
+      load_q(CPLX ? bn * 2 + (sub >> 1) : bn * 4 + sub, t, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // x of the next batch: in flight during the transposed passes
@@ -681,6 +719,88 @@ void stream_element_coefficients(SubOp &so) {
   so.d_coef_s = dev_upload(coef.data(), coef.size());
 }
 
+// Affine elements: one wave per element looks at the packed q-data [ncomp][2][16][2] (nd_qd_offset, four points per direction).
+// Component c is w_q r_c(q) (the metric form's component 6: r / w_q); the element is affine when every r_c is the same at the 64
+// points to `tol` relative to the largest |mean r| of its group of six (mass / curl-curl / metric matrix; component 6 on its own).
+// Writes the compact rows (means) and the flag.
+__global__ __launch_bounds__(64) void stream_affine_kernel(const int ne, const int ncomp, const int metric, const double *__restrict__ qd,
+                                                           const double w0, const double w1, const double tol,
+                                                           double *__restrict__ aff, unsigned char *__restrict__ flag) {
+  const int e = blockIdx.x, q = threadIdx.x;
+  if (e >= ne) return;
+  auto w1d = [&](const int i) { return (i == 0 || i == 3) ? w0 : w1; };
+  const double wq = w1d(q & 3) * w1d((q >> 2) & 3) * w1d(q >> 4);
+  auto wave_sum = [](double v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  };
+  auto wave_max = [](double v) {
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    return v;
+  };
+  bool ok = true;
+  for (int g0 = 0; g0 < ncomp; g0 += 6) {
+    const int gn = min(6, ncomp - g0);
+    double mean[6], dev = 0.0, scale = 0.0;
+    for (int c = 0; c < gn; c++) {
+      const double v = qd[(size_t)e * ncomp * 64 + nd_qd_offset(4, g0 + c, q)];
+      const double r = (metric && g0 + c == 6) ? v * wq : v / wq;
+      mean[c] = wave_sum(r) * (1.0 / 64.0);
+      dev = fmax(dev, wave_max(fabs(r - mean[c])));
+      scale = fmax(scale, fabs(mean[c]));
+    }
+    ok = ok && dev <= tol * scale;
+    if (q < 2 * gn) {  // row 2 c + h: {r wz(2h), r wz(2h + 1)}, component 6 of the metric form: r / wz
+      const int c = q >> 1, h = q & 1;
+      const bool inv = metric && g0 + c == 6;
+      double *row = aff + ((size_t)e * 2 * ncomp + 2 * (g0 + c) + h) * 2;
+      double m = 0.0;
+      for (int k = 0; k < 6; k++) m = (k == c) ? mean[k] : m;  // (no dynamic register indexing)
+      row[0] = inv ? m / w1d(2 * h) : m * w1d(2 * h);
+      row[1] = inv ? m / w1d(2 * h + 1) : m * w1d(2 * h + 1);
+    }
+  }
+  if (q == 0) flag[e] = ok ? 1 : 0;
+}
+
+// Once per QData (the p-coarsened operators share it): which elements are affine, which batches of four consist of such
+// elements only, the compact rows.  PALACE_AMD_STREAM_AFFINE=0 switches the form off (A / B runs; read when the data is built).
+static void stream_affine_setup(SubOp &so) {
+  QData &qd = *so.qd;
+  if (qd.aff_done) return;
+  qd.aff_done = true;
+  const bool enabled = !(getenv("PALACE_AMD_STREAM_AFFINE") && atoi(getenv("PALACE_AMD_STREAM_AFFINE")) == 0);
+  if (!enabled || so.q1d != 4 || (int)so.geom->w1.size() != 4) return;
+  const std::vector<double> &w = so.geom->w1;
+  if (w[0] != w[3] || w[1] != w[2]) return;  // (not a symmetric rule: keep the per-point data)
+  const int ne = so.ne, nep = (ne + 3) & ~3;
+  const size_t nrow = (size_t)nep * 2 * qd.ncomp * 2;
+  double *d_aff = nullptr;
+  unsigned char *d_flag = nullptr;
+  PA_HIP(hipMalloc(&d_aff, nrow * sizeof(double)));
+  PA_HIP(hipMemset(d_aff, 0, nrow * sizeof(double)));
+  PA_HIP(hipMalloc(&d_flag, (size_t)nep));
+  PA_HIP(hipMemset(d_flag, 0, (size_t)nep));
+  const double tol = getenv("PALACE_AMD_AFFINE_TOL") ? atof(getenv("PALACE_AMD_AFFINE_TOL")) : 1e-13;
+  hipLaunchKernelGGL(stream_affine_kernel, dim3(ne), dim3(64), 0, nullptr, ne, qd.ncomp, qd.metric ? 1 : 0, qd.d, w[0], w[1], tol, d_aff,
+                     d_flag);
+  PA_HIP(hipGetLastError());
+  std::vector<unsigned char> flag((size_t)nep, 0);
+  PA_HIP(hipMemcpy(flag.data(), d_flag, (size_t)nep, hipMemcpyDeviceToHost));
+  (void)hipFree(d_flag);
+  qd.batch_aff.assign((size_t)nep / 4, 0);
+  for (int e = 0; e < ne; e++) qd.n_aff_elems += flag[e];
+  for (int b = 0; b < nep / 4; b++)
+    if (flag[4 * b] && flag[4 * b + 1] && flag[4 * b + 2] && flag[4 * b + 3]) qd.batch_aff[b] = 1, qd.n_aff_batch_elems += 4;
+  if (qd.n_aff_batch_elems == 0) {
+    (void)hipFree(d_aff);
+    qd.batch_aff.clear();
+    return;
+  }
+  qd.d_aff = d_aff;
+  qd.wq2[0] = w[0], qd.wq2[1] = w[1];
+}
+
 // Index arrays of the streaming kernel and the run form of the transpose map (after finalize_exclusive: needs the
 // exclusive flags).  Host work proportional to the index array, once per operator.  Every per-element array is padded
 // to a multiple of four elements (one batch); the pad entries are flagged essential (read as zero).
@@ -699,7 +819,11 @@ void build_stream(SubOp &so) {
   // are assembled on chip before the store: every copy but the group's first is taken off the E-vector (its store goes
   // straight to y instead, like an exclusive dof's) and out of the run lists; a dof whose copies all sit in one group leaves
   // the gather altogether.  What is NOT priced: the LDS traffic and barrier of the on-chip assembly itself.
+#ifdef PA_ABLATION  // (the ablation library only, `make ablate`: the product library has no such switch)
   const int price_group = (so.fe_type == PA_FE_HCURL && !wide_form(so) && getenv("PALACE_AMD_PRICE_BLOCK")) ? atoi(getenv("PALACE_AMD_PRICE_BLOCK")) : 0;
+#else
+  constexpr int price_group = 0;
+#endif
   if (price_group > 1) {
     const size_t nnz = (size_t)ne * P;
     const int npl = (P + 15) / 16, npk = (npl + 3) / 4;
@@ -727,6 +851,16 @@ void build_stream(SubOp &so) {
             price_group, dropped, nnz, freed, so.h_shared.size(), shared2.size());
     so.h_shared = shared2;
     so.n_shared = (int)shared2.size();
+  }
+  if (so.fe_type == PA_FE_HCURL && !wide_form(so)) {
+    // batches of four affine elements: kAffBit in the flag words of their 4 x 16 (element, lane) pairs -- the flag arrives with the
+    // index words, one batch ahead of the q-data request it steers
+    stream_affine_setup(so);
+    const int npl = (P + 15) / 16, npk = (npl + 3) / 4;
+    for (size_t b = 0; b < so.qd->batch_aff.size(); b++)
+      if (so.qd->batch_aff[b])
+        for (size_t e = 4 * b; e < 4 * b + 4; e++)
+          for (int t = 0; t < 16; t++) pp[(e * (npk + 1) + npk) * 16 + t] |= streamhost::kAffBit;
   }
   so.h_perm_s = pp;
   if (so.fe_type == PA_FE_HCURL && !wide_form(so)) {
@@ -955,6 +1089,7 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   a.flagw = masked ? so.d_flagw_bc : so.d_flagw;
   a.slots = so.d_slots;
   a.qdata = so.qd->d;
+  a.qaff = so.qd->d_aff, a.wq2[0] = so.qd->wq2[0], a.wq2[1] = so.qd->wq2[1];
   a.coef = so.d_coef_s;
   a.xn = nullptr, a.gtab = nullptr;
   a.x = x, a.y = y, a.ye = so.d_ye;

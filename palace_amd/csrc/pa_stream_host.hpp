@@ -41,6 +41,9 @@ constexpr int kIdxWords = 32, kIdxStart0 = 12, kIdxMaxRuns = kIdxWords - kIdxSta
 // H(curl) blocks (at most 9 slice words before the run starts at word 12): word 11 names the element's entry in the dictionary
 // of sorted -> tensor-order slot patterns (pa_nd_hex_stream.hip: build_stream)
 constexpr int kIdxPattern = 11;
+// flag words (four-point H(curl) kernel): bits 0-17 flip / exclusive, 18-26 essential; bit 31: the element's batch is affine
+// (QData::batch_aff: the kernel reads the compact D of QData::d_aff)
+constexpr uint32_t kAffBit = 1u << 31;
 
 inline int index_dof(const uint32_t *ic, int m, int start0 = kIdxStart0) {  // host model of the device decode (gather lambdas)
   const int r = m >> 4, t = m & 15;

@@ -179,63 +179,30 @@ def test_cavity2d_first_mode_on_device():
 def test_cavity2d_magnetostatic_inductance_on_device():
     """Config 4's magnetostatic half on the reference's own case (examples/cavity2d/cavity2d_magnetostatic.json: order 2, PEC
     walls, unit surface current along +x on the bottom edge; "Linear": AMS + CG, Tol 1e-8): the singular 2-D curl-curl system
-    solved ON THE DEVICE -- PCG + p-multigrid (orders 1, 2; plain Chebyshev smoothers, iodata.cpp:533-564) with the native AMS
-    in its singular mode on the assembled order-1 level (linalg/ams.cpp:28-30) -- and M11 = x^T K x * mu0 against the
-    reference's regression value 6.283185306350e-07 H (test/data/regression/ref/cavity2d/magnetostatic/terminal-M.csv) at the
-    reference's gate for that file (rtol 1e-6... here 1e-7: the field is exactly representable)."""
-    import torch
+    solved ON THE DEVICE (palace_amd/fem/triproblem.py: PCG + p-multigrid of orders 1, 2 with plain Chebyshev smoothers,
+    iodata.cpp:533-564, the native AMS in its singular mode on the assembled order-1 level, linalg/ams.cpp:28-30) and
+    M11 against the reference's regression value 6.283185306350e-07 H (test/data/regression/ref/cavity2d/magnetostatic/
+    terminal-M.csv) to 1e-7 (the field is exactly representable; the reference's own gate for this file is looser)."""
+    from palace_amd import linalg
+    from palace_amd.fem import tri, triproblem
 
-    from palace_amd import ceed, linalg
-    from palace_amd.fem import tri
-
-    M_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "cavity2d_mesh.npz"))
-    en = M_["elem_nodes"].astype(np.int64)
-    used, inv = np.unique(en[:, :3], return_inverse=True)
-    mesh = tri.TriMesh(M_["nodes"][used], inv.reshape(-1, 3), M_["attr"], elem_nodes=en, nodes=M_["nodes"])
-    orders = [1, 2]
-    spaces = [tri.NDTriSpace(mesh, q) for q in orders]
-    pts, wts = tri.tri_quadrature(3)
-    geom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, mesh.geometry_grad_table(pts), wts)
-    blocks = []
-    for s in spaces:
-        interp, curl = s.elem.tables(pts)
-        blocks.append(ceed.DenseBlock(ceed.FE_HCURL, s.ndofs, s.offsets, interp, curl, orients=s.orients))
-    fine = ceed.Operator(spaces[1].ndofs, spaces[1].ndofs).add_dense_integrator(
-        geom, blocks[1], ceed.QF_L2_1, ceed.coefficient_context(1), ceed.EVAL_CURL | ceed.EVAL_WEIGHT).finalize()
-    local = [fine.coarsen_dense(blocks[0]), fine]
-    bv = np.searchsorted(used, M_["bdr_edges"].astype(np.int64))
-    b, pec, width = tri.edge_current_load(spaces[1], bv, M_["bdr_attr"], 2, [1.0, 0.0])
-    assert width == pytest.approx(1.0, abs=1e-12)
-    ess = [s.ess_dofs(pec) for s in spaces]
+    mesh, bv, battr, M_ = triproblem.load_cavity2d(os.path.join(os.path.dirname(__file__), "golden", "cavity2d_mesh.npz"))
     ctx = linalg.Context()
-    A = [linalg.AssembledParOperator(ctx, local[0].full_assemble_device(), ess[0], linalg.DIAG_ONE),
-         linalg.ParOperator(ctx, local[1], ess[1], linalg.DIAG_ONE)]
-    P = [linalg.DenseInterp(ctx, tri.restriction(spaces[0]), tri.restriction(spaces[1]), tri.nd_tri_transfer_matrix(1, 2))]
-    h1 = tri.H1TriSpace(mesh, 1)
-    coarse = linalg.ams(ctx, A[0].local, ess[0], tri.lowest_order_gradient(h1, spaces[0]), tri.vertex_coordinates(h1),
-                        singular=True)
-    B = linalg.gmg(ctx, A, P, coarse, cheby_order=4)
-    K = linalg.cg(ctx, A[1], B, rel_tol=1e-8, max_it=100)
-    b[ess[1]] = 0.0
-    bd = torch.from_numpy(b).cuda()
-    x = torch.zeros_like(bd)
-    K.mult(bd, x)
-    st = K.stats()
-    assert st["converged"] and st["iterations"] <= 40, st
-    kx = torch.empty_like(x)
-    A[1].mult(x, kx)
-    r = float((kx - bd).norm() / bd.norm())
-    assert r < 1e-6, r
-    energy = float(x @ kx)                                 # = b^T K^+ b = area / width^2 = 1/2
-    mu0 = 1.25663706127e-6                                 # utils/constants.hpp:26
-    assert mu0 * energy == pytest.approx(float(M_["M11_H"]), rel=1e-7)
-    # the same load through the oracle's operator (CPU restatement of f_apply_l2_1) gives the same energy functional
+    out = triproblem.magnetostatic_inductance(ctx, mesh, bv, battr, 2, [1.0, 0.0], order=2, rel_tol=1e-8, max_it=100)
+    assert out["width"] == pytest.approx(1.0, abs=1e-12)
+    assert out["converged"] and out["iterations"] <= 40, out["iterations"]
+    assert out["rel_residual"] < 1e-6, out["rel_residual"]
+    assert out["M11"] == pytest.approx(float(M_["M11_H"]), rel=1e-7)
+    # the device operator of the solve against the oracle's (CPU restatement of f_apply_l2_1) on the computed field
+    nd, ess = out["spaces"][-1], out["ess"][-1]
+    pts, wts = tri.tri_quadrature(3)
     J = mesh.jacobians(pts)
     og = po.build_geom_factor_22(mesh.attr.astype(np.float64), wts, np.transpose(J, (0, 1, 3, 2)).reshape(mesh.ne, -1, 4))
-    interp, curl = spaces[1].elem.tables(pts)
-    Ko = po.CeedOperatorOracle(spaces[1].ndofs, spaces[1].offsets, spaces[1].orients, interp, curl, og, po.QF_L2_1,
-                               po.CoeffCtx(dim=1), qw=wts)
-    xo = x.cpu().numpy()
-    ko = Ko.apply_add(xo, np.zeros_like(xo))
-    ko[ess[1]] = xo[ess[1]]
-    assert np.linalg.norm(ko - kx.cpu().numpy()) < 1e-11 * np.linalg.norm(ko)
+    interp, curl = nd.elem.tables(pts)
+    Ko = po.CeedOperatorOracle(nd.ndofs, nd.offsets, nd.orients, interp, curl, og, po.QF_L2_1, po.CoeffCtx(dim=1), qw=wts)
+    xo = out["x"].cpu().numpy()
+    xz = xo.copy()
+    xz[ess] = 0.0
+    ko = Ko.apply_add(xz, np.zeros_like(xo))
+    ko[ess] = xo[ess]
+    assert np.linalg.norm(ko - out["Kx"].cpu().numpy()) < 1e-11 * np.linalg.norm(ko)

@@ -317,3 +317,60 @@ def test_geometry_from_the_nodes(cylinder_mesh, monkeypatch, variant):
     refk = util.oracle_apply_c(nd, util.oracle_geom(mesh, q1d), "hdiv", octx.pack(), xm, q1d)
     refk[ess] = x[ess]
     assert _rel(yk, refk) < RTOL
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("form", ["curl_packed", "mass_packed", "km_metric", "km_packed12", "curl_metric"])
+def test_affine_batches_of_the_streaming_kernel(monkeypatch, p, form):
+    """Round 6: batches of four elements with constant Jacobians (the central block of the O-grid: 20 % of the elements) read the
+    compact D -- 6 | 7 | 12 numbers per element instead of per point -- in the streaming kernel.  Every D form against the C
+    oracle, plain and with essential dofs fused, next to the same operator built with the form switched off
+    (PALACE_AMD_STREAM_AFFINE=0) and to the one-shot kernel (AddMult), which always reads the per-point data."""
+    from palace_amd import linalg
+    from palace_amd.fem.mesh import ogrid_cylinder
+
+    mesh = _multi_attr(ogrid_cylinder(4, 5))
+    q1d = 4
+    nd = NDHexSpace(mesh, p)
+    ogeom = util.oracle_geom(mesh, q1d)
+    if form == "curl_metric":
+        monkeypatch.setenv("PALACE_AMD_DSTAGE", "metric")
+    _, b_a = util.make_ctx("aniso", nattr=3)
+    _, b_s = util.make_ctx("scalar", nattr=3)
+
+    def build():
+        geom = ceed.GeomFactorData(mesh, q1d)
+        if form in ("curl_packed", "curl_metric"):
+            return geom, ceed.curlcurl_operator(geom, nd, b_s if form == "curl_metric" else b_a), "hdiv", (b_s if form == "curl_metric" else b_a)
+        if form == "mass_packed":
+            return geom, ceed.ndmass_operator(geom, nd, b_a), "hcurl", b_a
+        if form == "km_metric":
+            return geom, ceed.curlcurlmass_operator(geom, nd, b_s, b_s), "hdivmass", np.concatenate([b_s, b_s])
+        return geom, ceed.curlcurlmass_operator(geom, nd, b_a, b_a), "hdivmass", np.concatenate([b_a, b_a])
+
+    x = np.random.default_rng(3).uniform(-1, 1, nd.ndofs)
+    xd = _dev(x)
+    geom, op, qf, blob = build()
+    assert op.streams()
+    ne, n_aff, n_comp = op.stream_affine()
+    assert ne == mesh.ne and n_aff == mesh.ne // 5 and 0 < n_comp <= n_aff and n_comp % 4 == 0, (ne, n_aff, n_comp)
+    ref = util.oracle_apply_c(nd, ogeom, qf, blob, x, q1d)
+    y = op.mult(xd, torch.empty_like(xd)).cpu().numpy()
+    assert _rel(y, ref) < RTOL
+    y_one_shot = op.add_mult(xd, torch.zeros_like(xd)).cpu().numpy()
+    assert _rel(y_one_shot, ref) < RTOL
+    ctx = linalg.Context()
+    ess = nd.ess_dofs()
+    K = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+    yk = K.mult(xd, torch.empty_like(xd)).cpu().numpy()
+    xm = x.copy()
+    xm[ess] = 0.0
+    refk = util.oracle_apply_c(nd, ogeom, qf, blob, xm, q1d)
+    refk[ess] = x[ess]
+    assert _rel(yk, refk) < RTOL
+    monkeypatch.setenv("PALACE_AMD_STREAM_AFFINE", "0")
+    geom0, op0, _, _ = build()
+    assert op0.stream_affine()[2] == 0
+    y0 = op0.mult(xd, torch.empty_like(xd)).cpu().numpy()
+    assert _rel(y0, ref) < RTOL and _rel(y, y0) < 1e-13
+    assert not np.array_equal(y, y0)  # (the compact rows were read: the two forms differ in the last bits)
