@@ -379,6 +379,19 @@ int pa_gradient_create(pa_context *ctx, const pa_restriction_desc *h1_restr, con
 int pa_interp_create_dense(pa_context *ctx, const pa_restriction_desc *domain_restr,
                            const pa_restriction_desc *range_restr, const double *M, pa_halo *domain_halo,
                            int n_true_domain, int n_true_range, pa_interp **P);
+/* Transfer between the spaces of one finite element collection on a mesh and on its uniform refinement -- the
+ * mfem::TransferOperator the reference wraps for two levels on DIFFERENT meshes (fem/fespace.cpp:246-251; the h-levels of
+ * ConstructFiniteElementSpaceHierarchy, fem/multigrid.hpp:103-112).  The elements are the FINE mesh's:
+ *   domain_restr  [ne_fine][P]: the dofs (and orientations) of the PARENT of every fine element in the coarse space,
+ *   range_restr   [ne_fine][P]: the fine space's own restriction,
+ *   M [nmat][P][P], mat_id [ne_fine]: the local interpolation matrix (fine dof functionals of the child applied to the
+ *                 parent's basis, mfem::FiniteElement::GetLocalInterpolation) of the child's place in its parent -- what
+ *                 mfem::Mesh::GetRefinementTransforms() calls embeddings[e].matrix; nmat <= 256.
+ * Every copy of a shared fine dof receives the same value (conforming spaces): one owner copy is stored, and the transpose
+ * (the restriction of the V-cycle) reads through the same owner mask.  Mult / MultTranspose: pa_interp_mult[_transpose]. */
+int pa_interp_create_refinement(pa_context *ctx, const pa_restriction_desc *domain_restr, const pa_restriction_desc *range_restr,
+                                int nmat, const double *M, const uint8_t *mat_id, pa_halo *domain_halo, int n_true_domain,
+                                int n_true_range, pa_interp **P);
 int pa_interp_mult(pa_interp *P, const double *x_coarse, double *y_fine);
 int pa_interp_mult_transpose(pa_interp *P, const double *x_fine, double *y_coarse);
 void pa_interp_destroy(pa_interp *P);

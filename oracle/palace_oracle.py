@@ -1402,6 +1402,72 @@ class InterpOracle:
         return y
 
 
+# ---------------------------------------------------------------------------------------------
+# h-refinement transfer: the prolongation between the spaces of one collection on a mesh and on its uniform refinement,
+# mfem::TransferOperator for two different meshes (reference fem/fespace.cpp:246-251, the h-levels of
+# fem/multigrid.hpp:103-112).  MFEM [external, published behaviour: FiniteElementSpace::RefinementOperator built from
+# Mesh::GetRefinementTransforms()] applies, element by element of the fine mesh, the local interpolation matrix
+# FiniteElement::GetLocalInterpolation(T) of the child's embedding T into its parent: row k = the fine dof functional k of
+# the child applied to the parent's basis.  For a covariant (H(curl)) element with the affine embedding x_parent = o + A x_child
+# that functional is  phi_parent(o + A x_k) . (A t_k); for H1 the point value.  Every copy of a shared fine dof gets the same
+# value (conforming spaces): MFEM keeps one, which is the D^-1 sum of equal copies InterpOracle computes.
+# ---------------------------------------------------------------------------------------------
+
+def hex_refinement_matrices(p, hcurl=True):
+    """[8][P, P] local interpolation matrices of the eight children (octant a + 2 b + 4 c of the parent's reference cube, the
+    order of palace_amd.fem.mesh.refine_uniform) of an order-p tensor element, tensor (lexicographic) dof order on both sides."""
+    cp, op = gll_points(p + 1), (gl_points(p)[0] if hcurl else None)
+
+    def one_d(nodes, half, scale):
+        # rows: child nodes mapped into the parent, columns: parent 1-D basis functions
+        return np.array([[scale * lagrange(nodes, 0.5 * (half + x), j)[0] for j in range(len(nodes))] for x in nodes])
+
+    out = []
+    for c in range(2):
+        for b in range(2):
+            for a in range(2):
+                h = (a, b, c)
+                if not hcurl:
+                    M = np.kron(one_d(cp, h[2], 1.0), np.kron(one_d(cp, h[1], 1.0), one_d(cp, h[0], 1.0)))
+                else:
+                    blocks = []
+                    for comp in range(3):
+                        m1 = [one_d(op, h[d], 0.5) if d == comp else one_d(cp, h[d], 1.0) for d in range(3)]
+                        blocks.append(np.kron(m1[2], np.kron(m1[1], m1[0])))
+                    n = blocks[0].shape[0]
+                    M = np.zeros((3 * n, 3 * n))
+                    for comp in range(3):
+                        M[comp * n:(comp + 1) * n, comp * n:(comp + 1) * n] = blocks[comp]
+                out.append(M)
+    return np.array(out)
+
+
+class RefinementTransferOracle:
+    """y_f = D^-1 sum_e E_f^T M[mat_id[e]] E_parent(e) x_c over the FINE elements e, and its transpose (serial).
+    dof_c / sgn_c [ne_f, P_c]: dofs and signs of every fine element's PARENT in the coarse space."""
+
+    def __init__(self, dof_c, sgn_c, dof_f, sgn_f, n_c, n_f, Ms, mat_id):
+        self.dc, self.sc, self.df, self.sf = dof_c, sgn_c.astype(np.float64), dof_f, sgn_f.astype(np.float64)
+        self.nc, self.nf, self.Ms, self.mid = n_c, n_f, np.asarray(Ms), np.asarray(mat_id)
+        mult = np.zeros(n_f)
+        np.add.at(mult, dof_f.ravel(), 1.0)
+        self.inv_mult = 1.0 / mult
+
+    def mult(self, x):
+        ue = x[self.dc] * self.sc
+        ve = np.einsum("eij,ej->ei", self.Ms[self.mid], ue) * self.sf
+        y = np.zeros(self.nf)
+        np.add.at(y, self.df.ravel(), ve.ravel())
+        return y * self.inv_mult
+
+    def mult_transpose(self, x):
+        ue = (x * self.inv_mult)[self.df] * self.sf
+        ve = np.einsum("eij,ei->ej", self.Ms[self.mid], ue) * self.sc
+        y = np.zeros(self.nc)
+        np.add.at(y, self.dc.ravel(), ve.ravel())
+        return y
+
+
 def nd_hex_gradient_lex(p):
     """Dense [P_ND, P_H1] discrete gradient of the order-p hex pair in tensor dof order: the ND dof
     (C; i, j, k) of grad(phi) is d/dx_C of the H1 interpolant at the ND node (nodal interpolation of

@@ -384,7 +384,8 @@ struct DenseInterpArgs {
   const int32_t *off_d, *off_r;   // [ne][P]; range offsets carry kOwnBit on the owner copy
   const int8_t *sgn_d, *sgn_r;    // oriented: +-1 per entry, or nullptr
   const int8_t *T_d, *B_r;        // curl-oriented: [ne][P][3] {sub, main, super}, or nullptr
-  const double *M;                // [Pr][Pd]
+  const double *M;                // [nmat][Pr][Pd]
+  const uint8_t *mat_id;          // [ne] which matrix an element uses (refinement transfers: the child's place in its parent), or nullptr
   const double *x;
   double *y;     // forward: range L-vector
   double *ye_d;  // transpose: domain E-vector [ne][Pd]
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(64) void dense_interp_kernel(const DenseInterpArgs 
   __shared__ double s0[kDenseInterpMaxP], s1[kDenseInterpMaxP];
   const int e = blockIdx.x, lane = threadIdx.x;
   const int32_t *od = a.off_d + (size_t)e * a.Pd, *orr = a.off_r + (size_t)e * a.Pr;
+  const double *Me = a.M + (a.mat_id ? (size_t)a.mat_id[e] * a.Pr * a.Pd : 0);
   if (!TRANSPOSE) {
     for (int i = lane; i < a.Pd; i += 64) {
       double v = a.x[od[i]];
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(64) void dense_interp_kernel(const DenseInterpArgs 
       wsync();
     }
     for (int j = lane; j < a.Pr; j += 64) {  // v = M u
-      const double *row = a.M + (size_t)j * a.Pd;
+      const double *row = Me + (size_t)j * a.Pd;
       double v = 0.0;
       for (int i = 0; i < a.Pd; i++) v += row[i] * s0[i];
       s1[j] = v;
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(64) void dense_interp_kernel(const DenseInterpArgs 
     }
     for (int i = lane; i < a.Pd; i += 64) {  // u = M^T v
       double v = 0.0;
-      for (int j = 0; j < a.Pr; j++) v += a.M[(size_t)j * a.Pd + i] * s0[j];
+      for (int j = 0; j < a.Pr; j++) v += Me[(size_t)j * a.Pd + i] * s0[j];
       s1[i] = v;
     }
     wsync();
@@ -479,11 +481,12 @@ class DenseInterpOperator : public Operator {
   int32_t *d_off_d_ = nullptr, *d_off_r_ = nullptr, *d_tptr_ = nullptr, *d_tent_ = nullptr;
   int8_t *d_sgn_d_ = nullptr, *d_sgn_r_ = nullptr, *d_T_d_ = nullptr, *d_B_r_ = nullptr;
   double *d_M_ = nullptr, *d_ye_ = nullptr;
+  uint8_t *d_mat_id_ = nullptr;
   mutable Vector ld_, lr_;
 
   template <bool TR>
   void launch(const double *x, double *y) const {
-    DenseInterpArgs a{ne_, Pd_, Pr_, d_off_d_, d_off_r_, d_sgn_d_, d_sgn_r_, d_T_d_, d_B_r_, d_M_, x, y, d_ye_};
+    DenseInterpArgs a{ne_, Pd_, Pr_, d_off_d_, d_off_r_, d_sgn_d_, d_sgn_r_, d_T_d_, d_B_r_, d_M_, d_mat_id_, x, y, d_ye_};
     hipLaunchKernelGGL((dense_interp_kernel<TR>), dim3(ne_), dim3(64), 0, ctx_->stream, a);
     PA_HIP(hipGetLastError());
   }
@@ -495,11 +498,17 @@ class DenseInterpOperator : public Operator {
   }
 
 public:
+  // nmat > 1 with mat_id [ne]: element e uses M[mat_id[e]] -- the transfer between a mesh and its uniform refinement
+  // (mfem::TransferOperator between different meshes, fem/fespace.cpp:246-251): the elements are the FINE mesh's, the domain
+  // restriction lists the dofs of each one's PARENT, the matrix is the local interpolation for the child's place in its parent
   DenseInterpOperator(const Context &ctx, const pa_restriction_desc &rd, const pa_restriction_desc &rr, const double *M,
-                      const Halo *halo_d, int nt_d, int nt_r)
+                      const Halo *halo_d, int nt_d, int nt_r, int nmat = 1, const uint8_t *mat_id = nullptr)
       : Operator(nt_r, nt_d), ctx_(&ctx), halo_d_(halo_d), ne_(rd.num_elem), Pd_(rd.elem_size), Pr_(rr.elem_size),
         nl_d_(rd.lsize), nl_r_(rr.lsize), nt_d_(nt_d), nt_r_(nt_r) {
-    PA_REQUIRE(rd.num_elem == rr.num_elem, "interpolation needs the same mesh on both sides");
+    PA_REQUIRE(rd.num_elem == rr.num_elem, "interpolation needs the same elements on both sides");
+    PA_REQUIRE(nmat >= 1 && nmat <= 256 && (nmat == 1 || mat_id), "element matrices: one, or up to 256 with an index per element");
+    if (mat_id)
+      for (int e = 0; e < ne_; e++) PA_REQUIRE(mat_id[e] < nmat, "element matrix index out of range");
     PA_REQUIRE(M && rd.offsets && rr.offsets, "null argument");
     PA_REQUIRE(Pd_ <= kDenseInterpMaxP && Pr_ <= kDenseInterpMaxP, "element too large for the dense interpolator");
     PA_REQUIRE(!(rd.orients && rd.curl_orients) && !(rr.orients && rr.curl_orients), "restriction is oriented or curl-oriented");
@@ -533,13 +542,14 @@ public:
     d_sgn_d_ = signs(rd, ctx.stream), d_sgn_r_ = signs(rr, ctx.stream);
     if (rd.curl_orients) d_T_d_ = pa::dev_upload(rd.curl_orients, 3 * nd, ctx.stream);
     if (rr.curl_orients) d_B_r_ = pa::dev_upload(rr.curl_orients, 3 * nr, ctx.stream);
-    d_M_ = pa::dev_upload(M, (size_t)Pr_ * Pd_, ctx.stream);
+    d_M_ = pa::dev_upload(M, (size_t)nmat * Pr_ * Pd_, ctx.stream);
+    if (mat_id) d_mat_id_ = pa::dev_upload(mat_id, (size_t)ne_, ctx.stream);
     ld_.SetSize(nl_d_), lr_.SetSize(nl_r_);
   }
   ~DenseInterpOperator() override {
     (void)hipFree(d_off_d_), (void)hipFree(d_off_r_), (void)hipFree(d_tptr_), (void)hipFree(d_tent_);
     (void)hipFree(d_sgn_d_), (void)hipFree(d_sgn_r_), (void)hipFree(d_T_d_), (void)hipFree(d_B_r_);
-    (void)hipFree(d_M_), (void)hipFree(d_ye_);
+    (void)hipFree(d_M_), (void)hipFree(d_ye_), (void)hipFree(d_mat_id_);
   }
   void Mult(const Vector &x, Vector &y) const override {
     const Context &c = *ctx_;
@@ -579,8 +589,8 @@ public:
 }  // namespace
 
 Operator *make_dense_interp_operator(const Context &ctx, const pa_restriction_desc &rd, const pa_restriction_desc &rr,
-                                     const double *M, const Halo *halo_d, int nt_d, int nt_r) {
-  return new DenseInterpOperator(ctx, rd, rr, M, halo_d, nt_d, nt_r);
+                                     const double *M, const Halo *halo_d, int nt_d, int nt_r, int nmat, const uint8_t *mat_id) {
+  return new DenseInterpOperator(ctx, rd, rr, M, halo_d, nt_d, nt_r, nmat, mat_id);
 }
 
 // The prolongation as an Operator on T-vectors: Mult coarse -> fine, MultTranspose fine -> coarse.

@@ -13,7 +13,8 @@ using namespace palace;
 
 namespace palace {
 Operator *make_dense_interp_operator(const Context &ctx, const pa_restriction_desc &rd, const pa_restriction_desc &rr,
-                                     const double *M, const Halo *halo_d, int nt_d, int nt_r);
+                                     const double *M, const Halo *halo_d, int nt_d, int nt_r, int nmat = 1,
+                                     const uint8_t *mat_id = nullptr);
 Operator *make_interp_operator(const Context &ctx, const pa_restriction_desc &rc, const pa_basis_desc &bc,
                                const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic,
                                const double *Io, const Halo *halo_c, int nt_c, int nt_f, int kind);
@@ -1142,6 +1143,17 @@ int pa_interp_create_dense(pa_context *ctx, const pa_restriction_desc *dom, cons
     p->ctx = ctx;
     p->op.reset(make_dense_interp_operator(ctx->ctx, *dom, *range, M, dom_halo ? dom_halo->halo.get() : nullptr, nt_dom,
                                            nt_range));
+    *P = p;
+  });
+}
+int pa_interp_create_refinement(pa_context *ctx, const pa_restriction_desc *dom, const pa_restriction_desc *range, int nmat,
+                                const double *M, const uint8_t *mat_id, pa_halo *dom_halo, int nt_dom, int nt_range, pa_interp **P) {
+  return guarded([&] {
+    PA_REQUIRE(ctx && dom && range && M && mat_id && P, "null argument");
+    auto *p = new pa_interp;
+    p->ctx = ctx;
+    p->op.reset(make_dense_interp_operator(ctx->ctx, *dom, *range, M, dom_halo ? dom_halo->halo.get() : nullptr, nt_dom,
+                                           nt_range, nmat, mat_id));
     *P = p;
   });
 }

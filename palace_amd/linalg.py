@@ -758,6 +758,36 @@ class DenseInterp(Interp):
                                                C.byref(self.handle)))
 
 
+class RefinementTransfer(Interp):
+    """Prolongation between the spaces of one collection on a mesh and on its uniform refinement (mfem::TransferOperator for
+    two levels on different meshes, fem/fespace.cpp:246-251): pa_interp_create_refinement.  `dom`: dict(offsets [ne_fine, P]
+    = the PARENT's dofs per fine element, lsize[, orients]), `rng`: the fine space's restriction, M [nmat, P, P] the local
+    interpolation matrices, mat_id [ne_fine] (fem/htransfer.py builds all four)."""
+
+    def __init__(self, ctx, dom, rng, M, mat_id, dom_halo=None, n_true_dom=None, n_true_rng=None):
+        self.ctx = ctx
+        keep = []
+
+        def desc(r):
+            off = np.ascontiguousarray(r["offsets"], dtype=np.int32)
+            ori = None if r.get("orients") is None else np.ascontiguousarray(r["orients"], dtype=np.uint8)
+            keep.extend([off, ori])
+            return _lib.RestrictionDesc(off.shape[0], off.shape[1], int(r["lsize"]), _ptr(off), _ptr(ori), None)
+
+        rd, rr = desc(dom), desc(rng)
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        mid = np.ascontiguousarray(mat_id, dtype=np.uint8)
+        assert M.ndim == 3 and M.shape[1:] == (rng["offsets"].shape[1], dom["offsets"].shape[1]) and mid.size == rd.num_elem
+        self.handle = C.c_void_p()
+        L = _L()
+        L.pa_interp_create_refinement.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int, C.c_int, C.c_void_p]
+        _lib.check(L.pa_interp_create_refinement(ctx.handle, C.byref(rd), C.byref(rr), M.shape[0], _ptr(M), _ptr(mid),
+                                                 dom_halo.handle if dom_halo else None,
+                                                 int(dom["lsize"]) if n_true_dom is None else n_true_dom,
+                                                 int(rng["lsize"]) if n_true_rng is None else n_true_rng, C.byref(self.handle)))
+
+
 class Gradient(Interp):
     """Discrete gradient G : H1(p) -> ND(p) (the auxiliary-space transfer of the Hiptmair smoother)."""
 

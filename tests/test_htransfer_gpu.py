@@ -1,0 +1,140 @@
+"""h-levels of the multigrid hierarchy on the device (reference fem/multigrid.hpp:103-112, fem/fespace.cpp:246-251):
+the refinement transfer (pa_interp_create_refinement) against the oracle restatement on hexahedra and tetrahedra, and PCG with
+the V-cycle over [h-levels] + [p-levels] against the oracle's PCG + V-cycle (iteration counts, iterate)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import palace_oracle as po
+from palace_amd import linalg
+from palace_amd.fem import htransfer
+from palace_amd.fem.fespace import H1HexSpace, NDHexSpace
+from palace_amd.fem.mesh import ogrid_cylinder, refine_uniform
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def _hex_oracle(c, f, hcurl):
+    parent = np.arange(f.mesh.ne) // 8
+    sc = c.elem_sign_lex if hcurl else np.ones_like(c.elem_dof_lex, dtype=np.int8)
+    sf = f.elem_sign_lex if hcurl else np.ones_like(f.elem_dof_lex, dtype=np.int8)
+    return po.RefinementTransferOracle(c.elem_dof_lex[parent], sc[parent], f.elem_dof_lex, sf, c.ndofs, f.ndofs,
+                                       po.hex_refinement_matrices(c.p, hcurl), np.arange(f.mesh.ne) % 8)
+
+
+@pytest.mark.parametrize("p", [1, 2])
+@pytest.mark.parametrize("hcurl", [True, False])
+def test_hex_refinement_transfer_matches_the_oracle(cylinder_mesh, p, hcurl):
+    mc = cylinder_mesh
+    mf = refine_uniform(mc)
+    Space = NDHexSpace if hcurl else H1HexSpace
+    c, f = Space(mc, p), Space(mf, p)
+    ctx = linalg.Context()
+    P = linalg.RefinementTransfer(ctx, *htransfer.hex_refinement(c, f))
+    oP = _hex_oracle(c, f, hcurl)
+    rng = np.random.default_rng(1)
+    xc, xf = rng.uniform(-1, 1, c.ndofs), rng.uniform(-1, 1, f.ndofs)
+    y = P.mult(_dev(xc), torch.full((f.ndofs,), np.nan, dtype=torch.float64, device="cuda")).cpu().numpy()
+    assert _rel(y, oP.mult(xc)) < 1e-13
+    z = P.mult_transpose(_dev(xf), torch.full((c.ndofs,), np.nan, dtype=torch.float64, device="cuda")).cpu().numpy()
+    assert _rel(z, oP.mult_transpose(xf)) < 1e-13
+    assert abs(xf @ y - z @ xc) < 1e-12 * np.linalg.norm(xf) * np.linalg.norm(y)
+
+
+def test_tet_refinement_transfer_matches_the_oracle():
+    from palace_amd.fem import tet
+
+    mc = tet.cube_tet_mesh(3)
+    mf = tet.refine_uniform(mc)
+    ctx = linalg.Context()
+    sg = lambda o: np.where(o, -1.0, 1.0)  # noqa: E731
+    for Space in (tet.NDTetSpace, tet.H1TetSpace):
+        c, f = Space(mc, 1), Space(mf, 1)
+        dom, rng_, Ms, mid = htransfer.tet_refinement(c, f)
+        P = linalg.RefinementTransfer(ctx, dom, rng_, Ms, mid)
+        one = np.ones_like(dom["offsets"], dtype=np.float64)
+        oP = po.RefinementTransferOracle(dom["offsets"], sg(dom["orients"]) if "orients" in dom else one, rng_["offsets"],
+                                         sg(rng_["orients"]) if "orients" in rng_ else np.ones_like(rng_["offsets"], dtype=np.float64),
+                                         c.ndofs, f.ndofs, Ms, mid)
+        rng = np.random.default_rng(2)
+        xc, xf = rng.uniform(-1, 1, c.ndofs), rng.uniform(-1, 1, f.ndofs)
+        y = P.mult(_dev(xc), torch.empty(f.ndofs, dtype=torch.float64, device="cuda")).cpu().numpy()
+        z = P.mult_transpose(_dev(xf), torch.empty(c.ndofs, dtype=torch.float64, device="cuda")).cpu().numpy()
+        assert _rel(y, oP.mult(xc)) < 1e-13 and _rel(z, oP.mult_transpose(xf)) < 1e-13
+
+
+def test_pcg_with_an_h_level_under_the_p_levels_matches_the_oracle(cylinder_mesh):
+    """The reference cylinder once refined, hierarchy = [order 1 on the coarse mesh] + [orders 1, 2, 3 on the fine mesh]
+    (fem/multigrid.hpp:103-123), plain Chebyshev smoothers of order 6, Jacobi-PCG(8) on the coarsest level: the V-cycle and the
+    PCG iteration count against the oracle's, the solution against the one of the p-levels-only hierarchy."""
+    from palace_amd.fem.hproblem import HpProblem
+
+    ctx = linalg.Context()
+    prob = HpProblem(ctx, cylinder_mesh, 1, 3)
+    assert [(m, q) for m, q in prob.levels] == [(0, 1), (1, 1), (1, 2), (1, 3)]
+    K, b, x = prob.pcg_gmg_solver(max_it=200, rel_tol=1e-8, hiptmair=False, coarse="cg")
+    K.mult(b, x)
+    st = K.stats()
+    assert st["converged"], st
+    # oracle: the same hierarchy
+    q1d = 4
+    cm, bm = util.make_ctx("scalar")
+    cc, bc = util.make_ctx("identity")
+    blob = np.concatenate([bm, bc])
+    ogeoms = [util.oracle_geom(m, q1d) for m in prob.meshes]
+    oA = [util.FastParOperatorOracle(s, ogeoms[m], "hdivmass", blob, s.ess_dofs(), q1d, cm, cc) for s, (m, _) in zip(prob.spaces, prob.levels)]
+    oP = []
+    for l in range(len(prob.levels) - 1):
+        c, f = prob.spaces[l], prob.spaces[l + 1]
+        if prob.levels[l][0] == prob.levels[l + 1][0]:
+            o = po.InterpOracle(c.elem_dof_lex, c.elem_sign_lex, f.elem_dof_lex, f.elem_sign_lex, c.ndofs, f.ndofs, po.nd_hex_interp_lex(c.p, f.p))
+        else:
+            o = _hex_oracle(c, f, True)
+        oP.append((o.mult, o.mult_transpose))
+    nl = len(prob.levels)
+    sm = [None] + [po.ChebyshevOracle(oA[l], 6, lambda_max=prob.last_gmg.gmg_lambda_max(l)) for l in range(1, nl)]
+    d0 = 1.0 / oA[0].diagonal()
+    coarse = lambda r: po.pcg(oA[0].mult, r, lambda v: d0 * v, rel_tol=1e-2, max_it=8)[0]  # noqa: E731
+    oB = po.GMGOracle(oA, oP, sm, coarse, [s.ess_dofs() for s in prob.spaces])
+    n = prob.spaces[-1].ndofs
+    r = np.random.default_rng(8).uniform(-1, 1, n)
+    r[prob.ess[-1]] = 0.0
+    z = prob.last_gmg.mult(_dev(r), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    assert _rel(z, oB.mult(r)) < 1e-8
+    xo, it, hist = po.pcg(oA[-1].mult, b.cpu().numpy(), oB.mult, rel_tol=1e-8, max_it=200)
+    assert abs(st["iterations"] - it) <= 1, (st, it)
+    assert _rel(x.cpu().numpy(), xo) < 1e-6
+    # the p-levels alone on the fine mesh reach the same solution; the h-level under them does not cost iterations
+    prob0 = HpProblem(ctx, prob.meshes[1], 0, 3)
+    K0, b0, x0 = prob0.pcg_gmg_solver(max_it=200, rel_tol=1e-8, hiptmair=False, coarse="cg")
+    K0.mult(b0, x0)
+    assert _rel(x.cpu().numpy(), x0.cpu().numpy()) < 1e-6
+    assert st["iterations"] <= K0.stats()["iterations"] + 2, (st, K0.stats())
+
+
+@pytest.mark.parametrize("hiptmair", [False, True])
+def test_h_and_p_levels_with_ams_on_the_coarse_mesh(hiptmair):
+    """Two h-levels under p = 1, 2 with the native AMS on the 64x smaller coarsest mesh, plain and auxiliary-space smoothers:
+    converges to the solution of the one-mesh hierarchy."""
+    from palace_amd.fem.hproblem import HpProblem
+
+    ctx = linalg.Context()
+    prob = HpProblem(ctx, ogrid_cylinder(2, 2), 2, 2)
+    K, b, x = prob.pcg_gmg_solver(max_it=100, rel_tol=1e-10, hiptmair=hiptmair, coarse="ams")
+    K.mult(b, x)
+    st = K.stats()
+    assert st["converged"] and st["iterations"] <= (20 if hiptmair else 60), st
+    prob0 = HpProblem(ctx, prob.meshes[-1], 0, 2)
+    K0, b0, x0 = prob0.pcg_gmg_solver(max_it=200, rel_tol=1e-10, hiptmair=hiptmair, coarse="ams")
+    K0.mult(b0, x0)
+    assert K0.stats()["converged"]
+    assert _rel(x.cpu().numpy(), x0.cpu().numpy()) < 1e-7
