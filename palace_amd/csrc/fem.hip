@@ -11,6 +11,9 @@ Operator *make_interp_operator(const Context &ctx, const pa_restriction_desc &rc
                                const pa_restriction_desc &rf, const pa_basis_desc &bf, const double *Ic,
                                const double *Io, const Halo *halo_c, int nt_c, int nt_f, int kind);
 
+Operator *make_dense_interp_operator(const Context &ctx, const pa_restriction_desc &rd, const pa_restriction_desc &rr,
+                                     const double *M, const Halo *halo_d, int nt_d, int nt_r, int nmat, const uint8_t *mat_id);
+
 namespace {
 void check(int rc) {
   if (rc) throw pa::Error(pa_last_error());
@@ -355,6 +358,20 @@ std::vector<double> Mesh::VertexCoordinates(const FiniteElementSpace &h1) const 
     }
   return xyz;
 }
+void Mesh::SetRefinementTransforms(const Mesh &parent, const int32_t *embed_parent, const int32_t *embed_matrix, int nmat,
+                                   const double *point_matrices) {
+  PA_REQUIRE(embed_parent && embed_matrix && point_matrices && nmat >= 1 && nmat <= 256, "invalid refinement transforms");
+  PA_REQUIRE(parent.dim_ == dim_ && parent.ncorner_ == ncorner_ && ncorner_ > 0, "parent and child meshes of one element type expected");
+  for (int e = 0; e < ne_; e++) {
+    PA_REQUIRE(embed_parent[e] >= 0 && embed_parent[e] < parent.ne_, "refinement: parent element out of range");
+    PA_REQUIRE(embed_matrix[e] >= 0 && embed_matrix[e] < nmat, "refinement: point matrix out of range");
+  }
+  parent_ = &parent;
+  embed_parent_.assign(embed_parent, embed_parent + ne_);
+  embed_matrix_.assign(embed_matrix, embed_matrix + ne_);
+  n_point_matrices_ = nmat;
+  point_matrices_.assign(point_matrices, point_matrices + (size_t)nmat * ncorner_ * dim_);
+}
 Mesh::~Mesh() {
   if (geom_) pa_geom_destroy(geom_);
 }
@@ -427,6 +444,22 @@ pa_basis_desc FiniteElementSpace::GetCeedBasis() const {
                        dof_map_.empty() ? nullptr : dof_map_.data(), nullptr, nullptr};
 }
 
+std::pair<int32_t, bool> FiniteElementSpace::GetElementDofSigned(int e, int t) const {
+  bool neg = false;
+  int j = t;
+  if (!dof_map_.empty()) {
+    j = dof_map_[t];
+    if (j < 0) j = -1 - j, neg = true;
+  }
+  const size_t k = (size_t)e * elem_size_ + j;
+  if (!orients_.empty() && orients_[k]) neg = !neg;
+  return {offsets_[k], neg};
+}
+void FiniteElementSpace::SetLocalInterpolation(const double *M, int nmat) {
+  PA_REQUIRE(IsDense() && M && nmat == mesh_->GetNumPointMatrices(), "local interpolation: one matrix per point matrix of the dense mesh");
+  local_interp_.assign(M, M + (size_t)nmat * elem_size_ * elem_size_);
+}
+
 const Operator &FiniteElementSpace::GetDiscreteInterpolator(const FiniteElementSpace &aux) const {
   auto it = G_.find(&aux);
   if (it != G_.end()) return *it->second;
@@ -450,7 +483,89 @@ const Operator &FiniteElementSpaceHierarchy::BuildProlongationAtLevel(std::size_
   // p-prolongation on one mesh (fespace.cpp:188-203 + bilinearform.cpp:203-282): Kronecker products of the 1-D nodal
   // interpolation matrices between the closed / open point sets of the two orders
   const FiniteElementSpace &c = *fespaces_.at(l), &f = *fespaces_.at(l + 1);
-  PA_REQUIRE(&c.GetMesh() == &f.GetMesh(), "levels on different meshes (h-refinement) are not built here");
+  if (&c.GetMesh() != &f.GetMesh()) {
+    // two meshes: the refinement transfer (fespace.cpp:246-251, mfem::TransferOperator): over the FINE elements, the parent's
+    // dofs -> the child's dofs through the local interpolation matrix of the child's embedding
+    const Mesh &mf = f.GetMesh();
+    PA_REQUIRE(mf.GetParent() == &c.GetMesh(), "levels on different meshes: the finer mesh must be a refinement of the coarser one "
+                                               "(Mesh::SetRefinementTransforms)");
+    PA_REQUIRE(c.GetFEType() == f.GetFEType() && c.GetMaxElementOrder() == f.GetMaxElementOrder() && c.GetElemSize() == f.GetElemSize(),
+               "h-levels carry the same finite element collection on every mesh (fem/multigrid.hpp:103-112)");
+    PA_REQUIRE(c.IsDense() == f.IsDense() && !c.GetHalo() && !f.GetHalo(), "refinement transfer: one rank, one kind of space");
+    const int P = f.GetElemSize(), nef = mf.GetNE(), nmat = mf.GetNumPointMatrices(), p = f.GetMaxElementOrder();
+    std::vector<double> M;
+    if (f.IsDense()) {
+      M = f.GetLocalInterpolation();
+      PA_REQUIRE(M.size() == (size_t)nmat * P * P, "dense spaces on a refined mesh need FiniteElementSpace::SetLocalInterpolation");
+    } else {
+      // tensor elements: child = an axis-aligned box o + s x of the parent's reference cube (corners in lexicographic order);
+      // closed directions: parent basis at the child's nodes; open direction (H(curl)): the same times the tangent's scale s
+      PA_REQUIRE(mf.GetNumCorners() == 8 && mf.Dimension() == 3, "tensor blocks of hexahedra expected");
+      const bool hcurl = f.GetFEType() == PA_FE_HCURL;
+      const std::vector<double> cp = fem::GaussLobatto(p + 1);
+      std::vector<double> op, ow;
+      if (hcurl) fem::GaussLegendre(p, op, ow);
+      M.assign((size_t)nmat * P * P, 0.0);
+      for (int m = 0; m < nmat; m++) {
+        const double *pm = mf.GetPointMatrices().data() + (size_t)m * 8 * 3;
+        double o[3], sc[3];
+        for (int d = 0; d < 3; d++) o[d] = pm[d], sc[d] = pm[3 * (1 << d) + d] - pm[d];
+        for (int v = 0; v < 8; v++)
+          for (int d = 0; d < 3; d++)
+            PA_REQUIRE(std::fabs(pm[3 * v + d] - (o[d] + ((v >> d) & 1) * sc[d])) < 1e-12 && sc[d] > 0.0,
+                       "refinement: the child is not an axis-aligned box of its parent's reference cube");
+        // 1-D matrices [child node][parent function] per direction, closed and open
+        std::vector<double> Ic[3], Io[3], tmp, x;
+        for (int d = 0; d < 3; d++) {
+          x.resize(cp.size());
+          for (size_t i = 0; i < cp.size(); i++) x[i] = o[d] + sc[d] * cp[i];
+          fem::LagrangeEval(cp, x, Ic[d], tmp);
+          if (hcurl) {
+            x.resize(op.size());
+            for (size_t i = 0; i < op.size(); i++) x[i] = o[d] + sc[d] * op[i];
+            fem::LagrangeEval(op, x, Io[d], tmp);
+            for (double &v : Io[d]) v *= sc[d];
+          }
+        }
+        double *Mm = M.data() + (size_t)m * P * P;
+        const int n1 = p + 1, ncomp = hcurl ? 3 : 1, nblk = hcurl ? p * n1 * n1 : n1 * n1 * n1;
+        for (int comp = 0; comp < ncomp; comp++) {
+          int nd[3] = {n1, n1, n1};
+          const std::vector<double> *I1[3] = {&Ic[0], &Ic[1], &Ic[2]};
+          if (hcurl) nd[comp] = p, I1[comp] = &Io[comp];
+          for (int kf = 0; kf < nd[2]; kf++)
+            for (int jf = 0; jf < nd[1]; jf++)
+              for (int i_f = 0; i_f < nd[0]; i_f++)
+                for (int kc = 0; kc < nd[2]; kc++)
+                  for (int jc = 0; jc < nd[1]; jc++)
+                    for (int ic = 0; ic < nd[0]; ic++) {
+                      const int row = comp * nblk + i_f + nd[0] * (jf + nd[1] * kf), col = comp * nblk + ic + nd[0] * (jc + nd[1] * kc);
+                      Mm[(size_t)row * P + col] = (*I1[0])[(size_t)i_f * nd[0] + ic] * (*I1[1])[(size_t)jf * nd[1] + jc] *
+                                                  (*I1[2])[(size_t)kf * nd[2] + kc];
+                    }
+        }
+      }
+    }
+    // restrictions in the order of the matrices (tensor order for tensor spaces, native for dense ones)
+    std::vector<int32_t> off_d((size_t)nef * P), off_r((size_t)nef * P);
+    std::vector<uint8_t> ori_d((size_t)nef * P), ori_r((size_t)nef * P), mid((size_t)nef);
+    bool any_sign = false;
+    for (int e = 0; e < nef; e++) {
+      const int E = mf.GetEmbeddingParents()[e];
+      mid[e] = (uint8_t)mf.GetEmbeddingMatrices()[e];
+      for (int t = 0; t < P; t++) {
+        const auto dc = c.GetElementDofSigned(E, t), df = f.GetElementDofSigned(e, t);
+        off_d[(size_t)e * P + t] = dc.first, ori_d[(size_t)e * P + t] = dc.second;
+        off_r[(size_t)e * P + t] = df.first, ori_r[(size_t)e * P + t] = df.second;
+        any_sign = any_sign || dc.second || df.second;
+      }
+    }
+    const pa_restriction_desc rd{nef, P, c.GetVSize(), off_d.data(), any_sign ? ori_d.data() : nullptr, nullptr};
+    const pa_restriction_desc rr{nef, P, f.GetVSize(), off_r.data(), any_sign ? ori_r.data() : nullptr, nullptr};
+    P_[l].reset(make_dense_interp_operator(c.GetContext(), rd, rr, M.data(), nullptr, c.GetTrueVSize(), f.GetTrueVSize(), nmat,
+                                           mid.data()));
+    return *P_[l];
+  }
   std::vector<double> Ic, Io, tmp, xc, wc, xf, wf;
   fem::LagrangeEval(fem::GaussLobatto(c.GetMaxElementOrder() + 1), fem::GaussLobatto(f.GetMaxElementOrder() + 1), Ic, tmp);
   fem::GaussLegendre(c.GetMaxElementOrder(), xc, wc);

@@ -103,6 +103,11 @@ class Mesh {
   int ncorner_ = 0;
   std::vector<int32_t> corner_nodes_;
   std::vector<double> nodes_;
+  // this mesh as the uniform refinement of another one (SetRefinementTransforms)
+  const Mesh *parent_ = nullptr;
+  std::vector<int32_t> embed_parent_, embed_matrix_;
+  int n_point_matrices_ = 0;
+  std::vector<double> point_matrices_;
 
 public:
   // node_offsets [ne][(mesh_order + 1)^3] lattice order, nodes [num_nodes][3], attr [ne] (1-based); the quadrature is
@@ -124,6 +129,19 @@ public:
   int GetMeshOrder() const { return mesh_order_; }
   // coordinates [GetVSize()][SpaceDimension()] of the dofs of a lowest-order H1 space on this mesh (its dofs are the vertices)
   std::vector<double> VertexCoordinates(const class FiniteElementSpace &h1_p1) const;
+  // This mesh is a refinement of `parent` (utils/geodata.cpp:426-460 keeps every uniformly refined mesh of the sequence as a
+  // multigrid level): what mfem::Mesh::GetRefinementTransforms() returns -- embeddings[e] = {parent element, matrix} and the
+  // point matrices [nmat][vertices per element][Dimension()]: the vertices of the child in the PARENT's reference coordinates
+  // (tensor blocks: the eight corners in lexicographic order).  FiniteElementSpaceHierarchy builds the prolongation between
+  // two levels on the two meshes from it (fespace.cpp:246-251).
+  void SetRefinementTransforms(const Mesh &parent, const int32_t *embed_parent, const int32_t *embed_matrix, int nmat,
+                               const double *point_matrices);
+  const Mesh *GetParent() const { return parent_; }
+  int GetNumPointMatrices() const { return n_point_matrices_; }
+  int GetNumCorners() const { return ncorner_; }
+  const std::vector<int32_t> &GetEmbeddingParents() const { return embed_parent_; }
+  const std::vector<int32_t> &GetEmbeddingMatrices() const { return embed_matrix_; }
+  const std::vector<double> &GetPointMatrices() const { return point_matrices_; }
 };
 
 // ---- finite element spaces ------------------------------------------------------------------------------------------
@@ -174,6 +192,16 @@ public:
   const std::vector<int32_t> &GetEssentialTrueDofs() const { return ess_tdofs_; }
   // discrete gradient from the H1 space `aux` of the same order into this Nedelec space (fespace.cpp:171-186)
   const Operator &GetDiscreteInterpolator(const FiniteElementSpace &aux) const;
+  // dof and sign (true: flipped) of tensor (lexicographic) index t of element e -- native index t for dense spaces
+  std::pair<int32_t, bool> GetElementDofSigned(int e, int t) const;
+  // Dense spaces on a refined mesh: the local interpolation matrices [GetNumPointMatrices()][P][P] of this space's element for
+  // the mesh's point matrices (mfem::FiniteElement::GetLocalInterpolation; row = fine dof, column = parent dof, native order).
+  // Tensor spaces compute theirs from the 1-D bases and need none.
+  void SetLocalInterpolation(const double *M, int nmat);
+  const std::vector<double> &GetLocalInterpolation() const { return local_interp_; }
+
+private:
+  std::vector<double> local_interp_;
 };
 
 // vdim copies of a scalar space -- mfem::FiniteElementSpace(mesh, fec, vdim, ordering) as far as GradientIntegrator needs it: the
