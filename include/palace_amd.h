@@ -425,6 +425,23 @@ int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_po
  * What the reference does with three copies around CeedOperatorApplyAdd (linalg/rap.cpp:195-234: tx = x, lx = P tx, ly = A lx,
  * y = P^T ly) when P is a halo exchange.  pa_op_supports_split: 1 for a single H(curl) hexahedral block on the
  * streaming kernels (four or five points per direction: orders 1-4), 0 otherwise (the caller keeps the L-vector path). */
+/* One step of a polynomial smoother consumed inside E^T (round 6).  The accumulated form of the Chebyshev recurrence of
+ * linalg/chebyshev.cpp:204-218 (e_k = d_0 + ... + d_{k-1}) needs t = A e_k only once, in
+ *     out (+)= e_k + sd (e_k - e_prev) + sr dinv .* (r0 - t);
+ * pa_op_mult_cheb_step applies the operator to x = e_k with the essential list of pa_op_set_essential fused (rows of t set to
+ * x or 0 by diag_policy, as pa_op_mult_essential_diag) and evaluates that line in the epilogue of the E^T gather, which then owns
+ * every dof: t is never stored or re-read.  e_prev may be NULL (zero); out may be e_prev's buffer; add != 0: out += ...
+ * pa_op_prepare_fused_step builds the index copies this needs, once, outside any stream capture: *available = 0 when the operator
+ * has no such form (anything but one tensor H(curl) block on the four-point streaming kernel), and the caller keeps
+ * pa_op_mult_essential_diag + its own vector kernel. */
+typedef struct {
+  double sd, sr;
+  const double *dinv, *r0, *e_prev;
+  double *out;
+  int32_t add;
+} pa_cheb_step;
+int pa_op_prepare_fused_step(pa_op *op, int *available);
+int pa_op_mult_cheb_step(pa_op *op, const double *x, const pa_cheb_step *step, int diag_policy, void *stream);
 int pa_op_supports_split(const pa_op *op);
 int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y,
                      double *yg, int n_true, int ess_policy, void *stream);

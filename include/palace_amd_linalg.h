@@ -151,6 +151,9 @@ int pa_diag_op_apply(pa_context *ctx, int n, const double *dr, const double *di,
 int pa_chebyshev_create(pa_context *ctx, pa_par_op *A, int smooth_it, int order, double sf_max,
                         int fourth_kind, pa_solver **S);
 int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max);
+/* *fused = 1 when the smoother's steps run inside the operator's E^T (pa_op_mult_cheb_step, palace_amd.h) instead of as an apply
+ * followed by a vector kernel.  level < 0: S is a Chebyshev smoother; level >= 1: that level's smoother of a multigrid solver. */
+int pa_chebyshev_fused_step(const pa_solver *S, int level, int *fused);
 /* ProductOperator / ComplexProductOperator (linalg/operator.hpp:270-352): y (+)= a op(A B) x; mode 0 N, 1 T, 2 H */
 int pa_product_op_apply(pa_par_op *A, pa_par_op *B, const double *x, double *y, int transpose, double a, int add);
 int pa_complex_product_op_apply(pa_complex_par_op *A, pa_complex_par_op *B, const double *xr, const double *xi, double *yr,

@@ -880,6 +880,7 @@ void Operator::MultTranspose(const Vector &, Vector &) const { throw pa::Error("
 void Operator::AddMult(const Vector &, Vector &, double) const { throw pa::Error("AddMult not implemented"); }
 void Operator::AddMultTranspose(const Vector &, Vector &, double) const { throw pa::Error("AddMultTranspose not implemented"); }
 void Operator::AssembleDiagonal(Vector &) const { throw pa::Error("AssembleDiagonal not implemented"); }
+void Operator::MultChebyStep(const Vector &, const ChebyStepArgs &) const { throw pa::Error("MultChebyStep not implemented"); }
 void Solver::Mult2(const Vector &, Vector &, Vector &) const { throw pa::Error("Mult2 not implemented"); }
 
 namespace ceed {
@@ -979,6 +980,15 @@ bool Operator::MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) cons
   int handled = 0;
   check(pa_op_mult_essential_diag(op_, x.Data(), y.Data(), diag_one ? 1 : 0, ctx_->stream, &handled));
   return handled != 0;
+}
+bool Operator::PrepareFusedStep() const {
+  int ok = 0;
+  check(pa_op_prepare_fused_step(op_, &ok));
+  return ok != 0;
+}
+void Operator::MultChebyStepEssential(const Vector &x, const ChebyStepArgs &a, bool diag_one) const {
+  const pa_cheb_step st{a.sd, a.sr, a.dinv->Data(), a.r0->Data(), a.e_prev ? a.e_prev->Data() : nullptr, a.out->Data(), a.add ? 1 : 0};
+  check(pa_op_mult_cheb_step(op_, x.Data(), &st, diag_one ? 1 : 0, ctx_->stream));
 }
 void Operator::Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const {
   check(pa_op_mult2(op_, x0.Data(), x1.Data(), y0.Data(), y1.Data(), ctx_->stream));
@@ -1152,6 +1162,11 @@ ParOperator::~ParOperator() {
   if (d_csr_bc_) (void)hipFree(d_csr_bc_);
 }
 
+bool ParOperator::PrepareChebyStep() const { return A_fused_ && !halo_ && A_fused_->PrepareFusedStep(); }
+void ParOperator::MultChebyStep(const Vector &x, const ChebyStepArgs &a) const {
+  PA_REQUIRE(A_fused_, "MultChebyStep: PrepareChebyStep found no fused form");
+  A_fused_->MultChebyStepEssential(x, a, policy_ == DiagonalPolicy::DIAG_ONE);
+}
 void ParOperator::Mult(const Vector &x, Vector &y) const {
   // rap.cpp:195-234.  tx = x, tx[ess] = 0; lx = P tx; ly = A lx; y = P^T ly; y[ess] = x[ess] | 0
   const Context &c = *ctx_;
@@ -1334,6 +1349,9 @@ void ChebyshevSmoother::SetOperator(const Operator &op) {
   lambda_max_ = sf_max_ * linalg::SpectralNorm(*ctx_, op, dinv_);
   PA_REQUIRE(lambda_max_ > 0.0, "Encountered zero maximum eigenvalue in Chebyshev smoother!");
   if (!fourth_kind_ && sf_min_ <= 0.0) sf_min_ = 1.69 / (std::pow(order_, 1.68) + 2.11 * order_ + 1.98);
+  // (read at every set-up: PALACE_AMD_FUSED_STEP=0 keeps the apply + vector kernel pair, for A / B runs in one process)
+  const char *fe = std::getenv("PALACE_AMD_FUSED_STEP");
+  fused_step_ = !(fe && fe[0] == '0') && order_ > 1 && op.PrepareChebyStep();
 }
 void ChebyshevSmoother::Mult(const Vector &x, Vector &y) const { Mult2(x, y, r_); }
 void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
@@ -1404,10 +1422,14 @@ void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
         const double rho = 1.0 / (2.0 * theta / delta - rhop);
         sd = rho * rhop, sr = 2.0 * rho / delta, rhop = rho;
       }
-      A_->Mult(*ek, t_);
       const bool last = k == order_ - 1;
       // e_{k+1} = e_k + sd (e_k - e_{k-1}) + sr D^-1 (r_0 - A e_k); the last one goes (is added) to y
-      linalg::ChebyStep3(c, sd, sr, dinv_, t_, *r0, *ek, k == 1 ? nullptr : ep, last ? y : *ep, last && !zero);
+      if (fused_step_) {  // ... inside the operator's E^T: A e_k is consumed where it is produced (round 6)
+        A_->MultChebyStep(*ek, Operator::ChebyStepArgs{sd, sr, &dinv_, r0, k == 1 ? nullptr : ep, last ? &y : ep, last && !zero});
+      } else {
+        A_->Mult(*ek, t_);
+        linalg::ChebyStep3(c, sd, sr, dinv_, t_, *r0, *ek, k == 1 ? nullptr : ep, last ? y : *ep, last && !zero);
+      }
       if (!last) std::swap(ek, ep);
     }
   }

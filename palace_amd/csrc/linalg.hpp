@@ -204,6 +204,17 @@ public:
   // true when A^T = A is known (symmetric coefficients): lets wrappers forward the transpose to the fused forward paths,
   // like the reference's SymmetricOperator (fem/libceed/operator.hpp:69-79)
   virtual bool IsSymmetric() const { return false; }
+  // One step of the accumulated Chebyshev recurrence (chebyshev.cpp:204-218; linalg::ChebyStep3) with t = A x consumed where the
+  // operator produces it:  out (+)= x + sd (x - e_prev) + sr dinv .* (r0 - A x).  PrepareChebyStep (set-up time, never inside a
+  // recorded sequence): true when the operator has such a form; otherwise the smoother applies A and runs the vector kernel.
+  struct ChebyStepArgs {
+    double sd, sr;
+    const Vector *dinv, *r0, *e_prev;  // e_prev == nullptr: zero
+    Vector *out;
+    bool add;
+  };
+  virtual bool PrepareChebyStep() const { return false; }
+  virtual void MultChebyStep(const Vector &x, const ChebyStepArgs &a) const;
 };
 
 namespace ceed {
@@ -257,6 +268,9 @@ public:
   void MultEssential(const Vector &x, Vector &y) const;
   // the same + y[ess] = x[ess] | 0 inside the E^T kernels; returns false if the caller must fix the rows up
   bool MultEssentialDiag(const Vector &x, Vector &y, bool diag_one) const;
+  // the Chebyshev step fused into E^T (pa_op_prepare_fused_step / pa_op_mult_cheb_step), essential list fused
+  bool PrepareFusedStep() const;
+  void MultChebyStepEssential(const Vector &x, const ChebyStepArgs &a, bool diag_one) const;
   // split vectors (pa_op_mult_split): true dofs in x / y, ghosts read from xg0 | xg1 (parity of *sel) and written to yg
   bool SupportsSplit() const;
   void MultSplit(const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y, double *yg,
@@ -396,7 +410,9 @@ public:
     A_split_ = on ? A_split_avail_ : nullptr, A_csr_split_ = on ? A_csr_split_avail_ : nullptr;
     StreamGraph::Invalidate();
   }
-  bool FusesEssential() const { return A_fused_ != nullptr; }  // the essential list lives in the local operator's index tables
+  bool FusesEssential() const { return A_fused_ != nullptr; }
+  bool PrepareChebyStep() const override;
+  void MultChebyStep(const Vector &x, const ChebyStepArgs &a) const override;  // the essential list lives in the local operator's index tables
   DiagonalPolicy GetDiagonalPolicy() const { return policy_; }
   const Halo *GetHalo() const { return halo_; }
   void Mult(const Vector &x, Vector &y) const override;
@@ -461,6 +477,7 @@ class ChebyshevSmoother : public Solver {
   bool fourth_kind_;
   double sf_min_;
   const Operator *A_ = nullptr;
+  bool fused_step_ = false;  // A_ consumes A e_k inside its E^T (Operator::MultChebyStep)
   Vector dinv_;
   mutable Vector d_, r_, t_, w_;
 
@@ -471,6 +488,7 @@ public:
         sf_min_(sf_min) {}
   void SetOperator(const Operator &op) override;
   double LambdaMax() const { return lambda_max_; }
+  bool FusedStep() const { return fused_step_; }
   void Mult(const Vector &x, Vector &y) const override;
   void Mult2(const Vector &x, Vector &y, Vector &r) const override;
 };

@@ -1147,6 +1147,31 @@ int pa_op_mult_essential_diag(pa_op *op, const double *x, double *y, int diag_po
   });
 }
 
+int pa_op_prepare_fused_step(pa_op *op, int *available) {
+  return guarded([&] {
+    PA_REQUIRE(op && available, "null argument");
+    *available = 0;
+    const bool enabled = !(getenv("PALACE_AMD_FUSED_STEP") && atoi(getenv("PALACE_AMD_FUSED_STEP")) == 0);
+    if (!enabled || !op->has_essential || op->subs.size() != 1 || !op->dsubs.empty() || !op->msubs.empty()) return;
+    SubOp *so = op->subs[0];
+    if (so->fe_type != PA_FE_HCURL || so->q1d != 4 || !so->d_idxc || !so->d_perm_s_bc || !nd_hex_stream_ok(*so)) return;
+    *available = stream_build_all(*so) ? 1 : 0;
+  });
+}
+
+int pa_op_mult_cheb_step(pa_op *op, const double *x, const pa_cheb_step *step, int diag_policy, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && x && step && step->dinv && step->r0 && step->out, "null argument");
+    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->d_flagw_all, "pa_op_prepare_fused_step has not been called (or found no fused form)");
+    PA_REQUIRE(x != step->out, "the step cannot overwrite its own input");
+    PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
+    const SubOp &so = *op->subs[0];
+    launch_nd_hex_stream_all(so, x, (hipStream_t)stream);
+    launch_et_run_gather_step(so, x, GatherStep{step->sd, step->sr, step->dinv, step->r0, step->e_prev, step->out, step->add},
+                              diag_policy ? 1 : 0, (hipStream_t)stream);
+  });
+}
+
 int pa_op_supports_split(const pa_op *op) {
   if (!op || !op->msubs.empty()) return 0;
   if (op->subs.size() == 1 && op->dsubs.empty()) {

@@ -223,6 +223,13 @@ struct SubOp {
   int32_t *d_rhdr = nullptr, *d_rpos = nullptr;         // run headers {first dof | length - 1 | essential, first copy entry}; copy positions in d_ye
   int n_runs = 0, n_runs_bc = 0;
   uint32_t *d_rchunk = nullptr, *d_rchunk_bc = nullptr;  // [ceil(n_shared / 64)] RunChunk: run-start mask of 64 shared dofs + run / offset of the first
+  // third form (round 6, stream_build_all): EVERY dof goes through the E-vector and is owned by the run gather -- no entry is
+  // exclusive in this copy of the flag words -- so that the gather's epilogue can consume the result instead of storing it (the
+  // fused Chebyshev step, launch_et_run_gather_step); essential dofs flagged as in the _bc copy
+  uint32_t *d_flagw_all = nullptr, *d_rchunk_all = nullptr;
+  int32_t *d_rhdr_all = nullptr, *d_rpos_all = nullptr;
+  int n_all = 0, n_runs_all = 0;
+  std::vector<char> h_ess_flag;  // the essential flags last fused (stream_set_essential), for stream_build_all
   std::vector<double> Bc, Gc, Bo;  // full 1-D tables [q1d][n] (host)
   double *d_tab = nullptr;        // the same on the device: [Bo | Bc | Gc]
   bool iso = false;               // every material coefficient is a multiple of the identity
@@ -329,6 +336,18 @@ bool nd_hex_stream_split_ok(const SubOp &so);
 void launch_nd_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase = -1,
                           const SplitIO *split = nullptr);
 void stream_set_interface(SubOp &so, const std::vector<char> &flag);
+// One step of a smoother recurrence consumed inside E^T (round 6): with t = (A x)[d] (the essential rows fixed as in the masked
+// apply) the run gather writes  out[d] (+)= x[d] + sd (x[d] - ep[d]) + sr dinv[d] (r0[d] - t)  for every dof and never stores t:
+// the Chebyshev step of chebyshev.cpp:204-218 in its accumulated form (linalg.hip: OpChebStep3) without the round trip of A x.
+struct GatherStep {
+  double sd, sr;
+  const double *dinv, *r0, *ep;  // ep == nullptr: e_{k-1} = 0
+  double *out;
+  int add;
+};
+bool stream_build_all(SubOp &so);  // the index copies the fused step needs (idempotent; false: this block has no such form)
+void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s);
+void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s);
 bool nd_hex_stream5_ok(const SubOp &so);
 void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase,
                            const SplitIO *split = nullptr);

@@ -515,6 +515,23 @@ int pa_gmg_smoother_lambda_max(const pa_solver *S, int level, double *lambda_max
     *lambda_max = c->LambdaMax();
   });
 }
+/* 1 when the Chebyshev smoother (level >= 1 of a multigrid solver, or the solver itself with level < 0) runs its steps inside
+ * the operator's E^T (Operator::MultChebyStep, pa_op_mult_cheb_step) */
+int pa_chebyshev_fused_step(const pa_solver *S, int level, int *fused) {
+  return guarded([&] {
+    PA_REQUIRE(S && S->solver && fused, "null argument");
+    const ChebyshevSmoother *c = nullptr;
+    if (level < 0) {
+      c = dynamic_cast<const ChebyshevSmoother *>(S->solver.get());
+    } else {
+      auto *g = dynamic_cast<const GeometricMultigridSolver *>(S->solver.get());
+      PA_REQUIRE(g, "not a multigrid solver");
+      c = dynamic_cast<const ChebyshevSmoother *>(&g->Smoother(level));
+    }
+    PA_REQUIRE(c, "not a Chebyshev smoother");
+    *fused = c->FusedStep() ? 1 : 0;
+  });
+}
 int pa_chebyshev_lambda_max(const pa_solver *S, double *lambda_max) {
   return guarded([&] {
     auto *c = dynamic_cast<const ChebyshevSmoother *>(S->solver.get());

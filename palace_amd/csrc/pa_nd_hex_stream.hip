@@ -619,11 +619,14 @@ using streamhost::RunChunk;
 // (Sixteen lanes per run walking the headers alone -- no per-dof data at all -- was measured too: 42.7 against 39.6 us, the idle
 // lanes of the short runs cost more instructions than the mask saves.)
 constexpr int kGatherILP = 4;
-__global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const RunChunk *__restrict__ chunk,
-                                                            const RunHdr *__restrict__ hdr, const int32_t *__restrict__ rpos,
-                                                            const double *__restrict__ ye, double *__restrict__ y,
-                                                            const int accumulate, const double *__restrict__ x,
-                                                            const int ess_policy, const int nsplit, double *__restrict__ yg) {
+// STEP: the sum is not stored but consumed by a smoother step (GatherStep; y, accumulate, the split arguments unused)
+template <bool STEP>
+__global__ __launch_bounds__(256) void et_run_gather_kernel_t(const int n, const RunChunk *__restrict__ chunk,
+                                                              const RunHdr *__restrict__ hdr, const int32_t *__restrict__ rpos,
+                                                              const double *__restrict__ ye, double *__restrict__ y,
+                                                              const int accumulate, const double *__restrict__ x,
+                                                              const int ess_policy, const int nsplit, double *__restrict__ yg,
+                                                              const GatherStep st) {
   const int k0 = blockIdx.x * (256 * kGatherILP) + threadIdx.x;
   const int lane = threadIdx.x & 63;
   RunHdr h[kGatherILP];
@@ -654,8 +657,20 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const R
     if (live[u] && fix[u]) {
       if (ess_policy) s[u] = x[d[u]];
       pe[u] = h[u].ptr;  // no copies to sum
-    } else if (live[u] && accumulate) {
+    } else if (!STEP && live[u] && accumulate) {
       yold[u] = y[d[u]];
+    }
+  }
+  // STEP: the vectors of the recurrence, requested with the copies
+  double se[STEP ? kGatherILP : 1], sdi[STEP ? kGatherILP : 1], sr0[STEP ? kGatherILP : 1], sep[STEP ? kGatherILP : 1],
+      so[STEP ? kGatherILP : 1];
+  if (STEP) {
+#pragma unroll
+    for (int u = 0; u < kGatherILP; u++) {
+      const int dd = live[u] ? d[u] : 0;
+      se[u] = x[dd], sdi[u] = st.dinv[dd], sr0[u] = st.r0[dd];
+      sep[u] = st.ep ? st.ep[dd] : 0.0;
+      so[u] = st.add ? st.out[dd] : 0.0;
     }
   }
   // copies in order (fixed summation order; an absent copy adds an exact zero): the first four of every dof side by
@@ -678,6 +693,17 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel(const int n, const R
       for (int p = h[u].ptr + 4; p < pe[u]; p++) s[u] += ye[(size_t)rpos[p] + j[u]];
   }
   // (split vectors: rows [nsplit, ...) are ghosts and go to yg, stored shifted by -nsplit; nsplit = INT_MAX otherwise)
+  if (STEP) {
+    // OpChebStep3 (linalg.hip) with t = s: out (+)= e + sd (e - e_prev) + sr dinv (r0 - t)
+#pragma unroll
+    for (int u = 0; u < kGatherILP; u++) {
+      if (!live[u]) continue;
+      double dk = st.sr * sdi[u] * (sr0[u] - s[u]);
+      dk += st.sd * (se[u] - sep[u]);
+      st.out[d[u]] = so[u] + (se[u] + dk);
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++)
     if (live[u]) (d[u] < nsplit ? y : yg)[d[u]] = yold[u] + s[u];
@@ -908,6 +934,11 @@ void build_stream(SubOp &so) {
 // (rap.cpp:223-233) and the plain sum otherwise.
 void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   if (!so.d_idxc) return;
+  so.h_ess_flag = flag;
+  if (so.d_flagw_all) {  // (built for another list: again on the next pa_op_prepare_fused_step)
+    hipFree(so.d_flagw_all), hipFree(so.d_rchunk_all), hipFree(so.d_rhdr_all), hipFree(so.d_rpos_all);
+    so.d_flagw_all = nullptr, so.d_rchunk_all = nullptr, so.d_rhdr_all = so.d_rpos_all = nullptr;
+  }
   const int P = so.P, npl = (P + 15) / 16, npk = (npl + 3) / 4;
   std::vector<uint32_t> pb(so.h_perm_s);
   const size_t nnz = (size_t)so.ne * so.P;
@@ -991,6 +1022,8 @@ void free_stream(SubOp &so) {
   hipFree(so.d_blist[0]), hipFree(so.d_blist[1]);
   hipFree(so.d_idxc), hipFree(so.d_perm_s), hipFree(so.d_perm_s_bc), hipFree(so.d_coef_s);
   hipFree(so.d_flagw), hipFree(so.d_flagw_bc), hipFree(so.d_slots);
+  hipFree(so.d_flagw_all), hipFree(so.d_rchunk_all), hipFree(so.d_rhdr_all), hipFree(so.d_rpos_all);
+  so.d_flagw_all = nullptr, so.d_rchunk_all = nullptr, so.d_rhdr_all = so.d_rpos_all = nullptr;
   hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc), hipFree(so.d_rchunk), hipFree(so.d_rchunk_bc);
 }
 
@@ -1069,7 +1102,8 @@ static void launch_variant(const SubOp &so, NDStreamArgs<P1> &a, hipStream_t s) 
 }
 
 template <int P1>
-static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
+static void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split,
+                     bool all = false) {
   NDStreamArgs<P1> a{};  // (every field the chosen form does not use: zero)
   a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
   if (split) {
@@ -1086,7 +1120,7 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
     if (a.nbatch == 0) return;
   }
   a.idxc = so.d_idxc;
-  a.flagw = masked ? so.d_flagw_bc : so.d_flagw;
+  a.flagw = all ? so.d_flagw_all : (masked ? so.d_flagw_bc : so.d_flagw);
   a.slots = so.d_slots;
   a.qdata = so.qd->d;
   a.qaff = so.qd->d_aff, a.wq2[0] = so.qd->wq2[0], a.wq2[1] = so.qd->wq2[1];
@@ -1123,6 +1157,17 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
       else launch_variant<P1, true, true, false, 2>(so, a, s);
       break;
     default: throw Error("QFunction not available for H(curl) hexahedra");
+  }
+}
+
+void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s) {
+  PA_REQUIRE(so.d_flagw_all && !wide_form(so), "stream_build_all has not been called");
+  double *unused = so.d_ye;  // (no entry is exclusive in this form: y is never written)
+  switch (so.p) {
+    case 1: launch_p<1>(so, x, unused, true, s, -1, nullptr, true); break;
+    case 2: launch_p<2>(so, x, unused, true, s, -1, nullptr, true); break;
+    case 3: launch_p<3>(so, x, unused, true, s, -1, nullptr, true); break;
+    default: throw Error("no streaming H(curl) hex kernel for this order");
   }
 }
 
@@ -1215,11 +1260,63 @@ void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream
   const int n = masked ? so.n_shared_bc : so.n_shared;
   if (n == 0) return;
   PA_REQUIRE(!split || !accumulate, "split vectors: y = A x only");
-  hipLaunchKernelGGL(et_run_gather_kernel, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
+  hipLaunchKernelGGL(et_run_gather_kernel_t<false>, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
                      reinterpret_cast<const RunChunk *>(masked ? so.d_rchunk_bc : so.d_rchunk),
                      reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
                      masked ? so.d_rpos_bc : so.d_rpos, ye ? ye : so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1,
-                     split ? split->n_true : 0x7fffffff, split ? split->yg - split->n_true : nullptr);
+                     split ? split->n_true : 0x7fffffff, split ? split->yg - split->n_true : nullptr, GatherStep{});
+  PA_HIP(hipGetLastError());
+}
+
+// ---- the fused smoother step: every dof through the E-vector, consumed by the gather's epilogue -------------------------------
+bool stream_build_all(SubOp &so) {
+  if (so.d_flagw_all) return true;
+  if (!so.d_idxc || !so.d_flagw || wide_form(so) || so.fe_type != PA_FE_HCURL) return false;
+  const int P = so.P, npl = (P + 15) / 16, npk = (npl + 3) / 4, nep = (so.ne + 3) & ~3;
+  const size_t nnz = (size_t)so.ne * P;
+  std::vector<char> flag(so.h_ess_flag);
+  flag.resize((size_t)so.lsize, 0);
+  std::vector<uint32_t> fw((size_t)nep * 16);
+  for (int e = 0; e < nep; e++)
+    for (int t = 0; t < 16; t++) {
+      uint32_t w = so.h_perm_s[((size_t)e * (npk + 1) + npk) * 16 + t];
+      for (int r = 0; r < npl; r++) w &= ~(2u << (2 * r));  // nothing takes the direct path
+      fw[(size_t)e * 16 + t] = w;
+    }
+  std::vector<char> present((size_t)so.lsize, 0);
+  for (size_t k = 0; k < nnz; k++) {
+    const int d = streamhost::dof_of(so.h_sidx[k]);
+    present[d] = 1;
+    if (flag[d]) {
+      const size_t e = k / P;
+      const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
+      fw[e * 16 + t] |= 1u << (18 + r);  // read as zero
+    }
+  }
+  std::vector<int32_t> all;
+  all.reserve((size_t)so.lsize);
+  for (int d = 0; d < so.lsize; d++)
+    if (present[d] || flag[d]) all.push_back(d);
+  if ((int)all.size() != so.lsize) return false;  // (a dof no element holds: the plain forms leave it alone, the step must not)
+  std::vector<uint32_t> code;
+  std::vector<RunHdr> hdr;
+  std::vector<int32_t> rpos;
+  streamhost::build_runs(so.ne, P, so.lsize, so.h_sidx.data(), all, code, hdr, rpos, flag.data(), nullptr);
+  const std::vector<RunChunk> ch = streamhost::run_chunks(code);
+  so.d_rchunk_all = dev_upload(reinterpret_cast<const uint32_t *>(ch.data()), 4 * ch.size());
+  so.d_rhdr_all = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
+  so.d_rpos_all = dev_upload(rpos.data(), rpos.size());
+  so.n_all = (int)all.size(), so.n_runs_all = (int)hdr.size() - 1;
+  so.d_flagw_all = dev_upload(fw.data(), fw.size());
+  return true;
+}
+
+void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s) {
+  PA_REQUIRE(so.d_flagw_all && so.n_all > 0, "stream_build_all has not been called");
+  const int n = so.n_all;
+  hipLaunchKernelGGL(et_run_gather_kernel_t<true>, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
+                     reinterpret_cast<const RunChunk *>(so.d_rchunk_all), reinterpret_cast<const RunHdr *>(so.d_rhdr_all), so.d_rpos_all,
+                     so.d_ye, nullptr, 0, x, ess_policy, 0x7fffffff, nullptr, step);
   PA_HIP(hipGetLastError());
 }
 

@@ -529,6 +529,13 @@ class Solver:
         _lib.check(_L().pa_chebyshev_lambda_max(self.handle, C.byref(v)))
         return v.value
 
+    def fused_step(self, level=-1):
+        """True when the Chebyshev smoother (this solver, or level `level` of a multigrid solver) runs its steps inside the
+        operator's E^T (pa_chebyshev_fused_step)."""
+        v = C.c_int()
+        _lib.check(_L().pa_chebyshev_fused_step(self.handle, level, C.byref(v)))
+        return bool(v.value)
+
     def __del__(self):
         try:
             if not self._owned_by_parent:

@@ -154,6 +154,37 @@ def test_chebyshev_smoother(prob):
     assert _rel(y, o.mult2(b, None, False)) < 1e-11
 
 
+@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("first_kind", [False, True])
+def test_chebyshev_steps_fused_into_the_gather(prob, monkeypatch, level, first_kind):
+    """Round 6: the smoother's step  e_{k+1} = e_k + sd (e_k - e_{k-1}) + sr D^-1 (r_0 - A e_k)  evaluated in the epilogue of the
+    E^T run gather (pa_op_mult_cheb_step: A e_k is never stored) against the oracle's recurrence (chebyshev.cpp:204-218,
+    :275-291) and against the same smoother built with the step as a separate vector kernel (PALACE_AMD_FUSED_STEP=0), zero and
+    non-zero initial guess, on a level with essential dofs."""
+    n = prob.spaces[level].ndofs
+    S = linalg.chebyshev(prob.ctx, prob.A[level], order=6, fourth_kind=not first_kind)
+    assert S.fused_step()
+    monkeypatch.setenv("PALACE_AMD_FUSED_STEP", "0")
+    S0 = linalg.chebyshev(prob.ctx, prob.A[level], order=6, fourth_kind=not first_kind)
+    assert not S0.fused_step()
+    lam = S.lambda_max()
+    assert lam == S0.lambda_max()
+    o = po.ChebyshevOracle(prob.oA[level], 6, lambda_max=lam, first_kind=first_kind)
+    rng = np.random.default_rng(16)
+    b = rng.uniform(-1, 1, n)
+    b[prob.spaces[level].ess_dofs()] = 0.0
+    y = S.mult(_dev(b), _new(n)).cpu().numpy()
+    y0 = S0.mult(_dev(b), _new(n)).cpu().numpy()
+    ref = o.mult2(b, None, False)
+    assert _rel(y, ref) < 1e-11 and _rel(y0, ref) < 1e-11 and _rel(y, y0) < 1e-13
+    g = rng.uniform(-1, 1, n)
+    g[prob.spaces[level].ess_dofs()] = 0.0
+    z = S.mult(_dev(b), _dev(g.copy()), initial_guess=True).cpu().numpy()
+    z0 = S0.mult(_dev(b), _dev(g.copy()), initial_guess=True).cpu().numpy()
+    refz = o.mult2(b, g.copy(), True)
+    assert _rel(z, refz) < 1e-11 and _rel(z0, refz) < 1e-11 and _rel(z, z0) < 1e-13
+
+
 def _coarse_solver(prob):
     """Level-0 solve: Jacobi-PCG to 1e-3 (stand-in for the reference's AMS, linalg/ams.cpp)."""
     return linalg.cg(prob.ctx, prob.A[0], linalg.jacobi(prob.ctx, prob.A[0]), rel_tol=1e-3, max_it=200)
