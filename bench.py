@@ -1217,6 +1217,45 @@ def spheres_leg(orders=(2, 3), reps=50):
     return out
 
 
+def hlevels_leg(ctx, prob, order):
+    """The reference's FULL hierarchy at the bench size (fem/multigrid.hpp:103-123, utils/geodata.cpp:426-460:
+    the meshes of a uniform-refinement sequence are multigrid levels): a cylinder with 1/8 of the bench mesh's elements refined
+    once, hierarchy = [order 1 on the coarse mesh] + [orders 1 .. p on the fine mesh], PCG on K + M with the auxiliary-space
+    smoothers and the native AMS on the coarsest level -- which is now 8x smaller than with the p-levels alone -- against the
+    same fine problem with the p-levels only.  Iterations to 1e-8 and iterations/s."""
+    import torch
+
+    from palace_amd.fem.hproblem import HpProblem
+    from palace_amd.fem.mesh import ogrid_cylinder
+
+    n, nz = prob.shape
+    coarse = ogrid_cylinder(max(1, n // 2), max(1, nz // 2))
+    out = {}
+    hp = HpProblem(ctx, coarse, 1, order)
+    for name, pr in (("h_and_p_levels", hp), ("p_levels_only", None)):
+        if pr is None:
+            pr = HpProblem(ctx, hp.meshes[-1], 0, order)
+        K, b, x = pr.pcg_gmg_solver(max_it=400, rel_tol=1e-8, hiptmair=True, coarse="ams")
+        K.mult(b, x)  # (first solve: work vectors, graph recording)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K.mult(b, x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = K.stats()
+        out[name] = {"levels": [f"mesh {m} ({pr.meshes[m].ne} elements), order {q}" for m, q in pr.levels],
+                     "dofs_per_level": [s.ndofs for s in pr.spaces], "iterations_to_1e-8": st["iterations"], "converged": bool(st["converged"]),
+                     "seconds": dt, "iters_per_s": st["iterations"] / dt}
+        if name == "h_and_p_levels":
+            xs = x.clone()
+        else:
+            out["rel_diff_of_the_two_solutions"] = float((x - xs).norm() / x.norm())
+        pr._keep.clear()
+    out["workload"] = (f"PCG on K + M (eps_r = 2.08), ND p={order}, {hp.spaces[-1].ndofs} dofs on {hp.meshes[-1].ne} hex27 elements (a once-refined "
+                       f"{hp.meshes[0].ne}-element cylinder), Hiptmair smoothers, AMS on the coarsest level")
+    return out
+
+
 def magnetostatic_leg(ctx, prob, iters=400):
     """The singular magnetostatic system on the bench cylinder: curl-curl alone (no mass term), PCG + p-multigrid with plain
     Chebyshev smoothers (the reference's configuration for magnetostatics, iodata.cpp:533-564) and the native AMS on level 0 in
@@ -1553,6 +1592,13 @@ def main():
             roofline["geometry_from_nodes"] = {"error": f"{type(exc).__name__}: {exc}"}
         finally:
             os.environ.pop("PALACE_AMD_STREAM_GEOM", None)
+    try:  # affine batches of the streaming kernel (round 6): how many elements read the compact per-element D
+        ne_, na_, nc_ = prob.local_curlcurl.stream_affine()
+        roofline["affine_elements"] = {"elements": ne_, "affine": na_, "compressed_in_batches_of_4": nc_, "fraction_compressed": nc_ / max(1, ne_),
+                                       "note": "elements with a constant Jacobian (the central block of the O-grid) read 6 numbers per element "
+                                               "instead of per point; every other element is unchanged (PALACE_AMD_STREAM_AFFINE=0 switches the form off)"}
+    except Exception as exc:  # noqa: BLE001
+        roofline["affine_elements"] = {"error": str(exc)}
     if world == 1 and not roofline["consistent_with_ms_per_step"]:
         print(f"bench.py: roofline leg {kernel_ms:.4f} ms per apply against {ms_per_step:.4f} ms per step", file=sys.stderr)
 
@@ -1584,6 +1630,11 @@ def main():
                 st = solver.stats()
                 entry = {"iters_per_s": st["iterations"] / dt, "iterations": st["iterations"], "seconds": dt,
                          "final_rel_res": st["final_res"] / st["initial_res"]}
+                if not hip:  # (plain Chebyshev levels: are their steps evaluated inside the operator's E^T gather?)
+                    try:
+                        entry["chebyshev_steps_fused_into_the_gather"] = [bool(prob.last_gmg.fused_step(l)) for l in range(1, len(prob.spaces))]
+                    except Exception:  # noqa: BLE001
+                        pass
                 solver, b, xs = prob.pcg_gmg_solver(max_it=400, rel_tol=1e-8, hiptmair=hip, coarse=coarse)
                 barrier()
                 t0 = time.perf_counter()
@@ -1655,8 +1706,10 @@ def main():
         cpw = _leg(cpw_leg, p)
         cpw_iso = _leg(cpw_iso_leg, p)
         sph = _leg(spheres_leg)
+    hlev = None
     if rank == 0 and world == 1 and not args.no_p4:
         mag = _leg(magnetostatic_leg, ctx, prob)
+        hlev = _leg(hlevels_leg, ctx, prob, p)
 
     nranks = None
     if world > 1 and not args.no_nranks_legs:
@@ -1704,7 +1757,7 @@ def main():
                        "parallelism": f"element partition x{world}, halo (P / P^T) and global sums over "
                                       + ("the peer transport (direct xGMI stores; RCCL as the fall-back)" if (world > 1 and ctx.peer_ready())
                                          else "RCCL")},
-            "rehearsal": rehearsal, "pre_warm_steps": args.pre_warm, "halo": halo_info, "n_ranks_legs": nranks, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "complex_aniso": cplx_aniso, "h1": h1, "eigenmode": eig, "cpw": cpw, "cpw_iso": cpw_iso, "spheres": sph, "magnetostatic": mag, "tets_mfma": tets,
+            "rehearsal": rehearsal, "pre_warm_steps": args.pre_warm, "halo": halo_info, "n_ranks_legs": nranks, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "pcg": pcg, "p4": p4, "complex": cplx, "complex_aniso": cplx_aniso, "h1": h1, "eigenmode": eig, "cpw": cpw, "cpw_iso": cpw_iso, "spheres": sph, "magnetostatic": mag, "h_levels": hlev, "tets_mfma": tets,
             "setup_s": t_setup,
         }
         sys.stdout.flush()

@@ -442,6 +442,11 @@ typedef struct {
 } pa_cheb_step;
 int pa_op_prepare_fused_step(pa_op *op, int *available);
 int pa_op_mult_cheb_step(pa_op *op, const double *x, const pa_cheb_step *step, int diag_policy, void *stream);
+/* The residual in the same place: res = b - A y (gmg.cpp:186-188; chebyshev.cpp:196-200 with an initial guess) and, when d0 is
+ * given, the polynomial's first direction d0 = c0 dinv .* (b - A y) (chebyshev.cpp:201-203) -- A y is not stored.  Either output
+ * may be NULL; the essential rows of A y are x | 0 as in pa_op_mult_essential_diag.  Needs pa_op_prepare_fused_step. */
+int pa_op_mult_residual(pa_op *op, const double *y, const double *b, double *res, const double *dinv, double c0, double *d0,
+                        int diag_policy, void *stream);
 int pa_op_supports_split(const pa_op *op);
 int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y,
                      double *yg, int n_true, int ess_policy, void *stream);

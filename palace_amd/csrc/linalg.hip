@@ -881,6 +881,9 @@ void Operator::AddMult(const Vector &, Vector &, double) const { throw pa::Error
 void Operator::AddMultTranspose(const Vector &, Vector &, double) const { throw pa::Error("AddMultTranspose not implemented"); }
 void Operator::AssembleDiagonal(Vector &) const { throw pa::Error("AssembleDiagonal not implemented"); }
 void Operator::MultChebyStep(const Vector &, const ChebyStepArgs &) const { throw pa::Error("MultChebyStep not implemented"); }
+void Operator::MultResidual(const Vector &, const Vector &, Vector *, const Vector *, double, Vector *) const {
+  throw pa::Error("MultResidual not implemented");
+}
 void Solver::Mult2(const Vector &, Vector &, Vector &) const { throw pa::Error("Mult2 not implemented"); }
 
 namespace ceed {
@@ -989,6 +992,11 @@ bool Operator::PrepareFusedStep() const {
 void Operator::MultChebyStepEssential(const Vector &x, const ChebyStepArgs &a, bool diag_one) const {
   const pa_cheb_step st{a.sd, a.sr, a.dinv->Data(), a.r0->Data(), a.e_prev ? a.e_prev->Data() : nullptr, a.out->Data(), a.add ? 1 : 0};
   check(pa_op_mult_cheb_step(op_, x.Data(), &st, diag_one ? 1 : 0, ctx_->stream));
+}
+void Operator::MultResidualEssential(const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0,
+                                     bool diag_one) const {
+  check(pa_op_mult_residual(op_, y.Data(), b.Data(), res ? res->Data() : nullptr, dinv ? dinv->Data() : nullptr, c0,
+                            d0 ? d0->Data() : nullptr, diag_one ? 1 : 0, ctx_->stream));
 }
 void Operator::Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const {
   check(pa_op_mult2(op_, x0.Data(), x1.Data(), y0.Data(), y1.Data(), ctx_->stream));
@@ -1166,6 +1174,10 @@ bool ParOperator::PrepareChebyStep() const { return A_fused_ && !halo_ && A_fuse
 void ParOperator::MultChebyStep(const Vector &x, const ChebyStepArgs &a) const {
   PA_REQUIRE(A_fused_, "MultChebyStep: PrepareChebyStep found no fused form");
   A_fused_->MultChebyStepEssential(x, a, policy_ == DiagonalPolicy::DIAG_ONE);
+}
+void ParOperator::MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0) const {
+  PA_REQUIRE(A_fused_, "MultResidual: PrepareChebyStep found no fused form");
+  A_fused_->MultResidualEssential(y, b, res, dinv, c0, d0, policy_ == DiagonalPolicy::DIAG_ONE);
 }
 void ParOperator::Mult(const Vector &x, Vector &y) const {
   // rap.cpp:195-234.  tx = x, tx[ess] = 0; lx = P tx; ly = A lx; y = P^T ly; y[ess] = x[ess] | 0
@@ -1396,7 +1408,12 @@ void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
       continue;
     }
     const Vector *r0 = &x;
-    if (!zero) {  // r_0 = x - A y
+    bool have_e1 = false;
+    if (!zero && fused_step_ && order_ > 1 && r.Data() != x.Data()) {
+      // r_0 = x - A y and e_1 = c_0 D^-1 r_0 in the epilogue of the operator's E^T (A y is not stored)
+      A_->MultResidual(y, x, &r, &dinv_, first(), &d_);
+      r0 = &r, have_e1 = true;
+    } else if (!zero) {  // r_0 = x - A y
       A_->Mult(y, r);
       linalg::AXPBY(c, 1.0, x, -1.0, r);
       r0 = &r;
@@ -1412,7 +1429,7 @@ void ChebyshevSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const {
     }
     // e_k and the buffer e_{k+1} goes to (zero guess: the caller's work vector r is free for that -- unless it is x itself)
     Vector *ek = &d_, *ep = (zero && r.Data() != x.Data()) ? &r : &w_;
-    linalg::ChebyOrder0(c, first(), dinv_, *r0, *ek);  // e_1 = d_0
+    if (!have_e1) linalg::ChebyOrder0(c, first(), dinv_, *r0, *ek);  // e_1 = d_0
     double rhop = delta / theta;
     for (int k = 1; k < order_; k++) {
       double sd, sr;
@@ -1463,8 +1480,12 @@ void DistRelaxationSmoother::Mult2(const Vector &x, Vector &y, Vector &r) const 
     B_->SetInitialGuess(initial_guess || it > 0);
     B_->Mult2(x, y, r);
     // y = y + G B_G G^T (x - A y)
-    A_->Mult(y, r);
-    linalg::AXPBY(c, 1.0, x, -1.0, r);
+    if (B_->FusedStep() && r.Data() != x.Data()) {  // (the residual out of the operator's E^T epilogue, round 6)
+      A_->MultResidual(y, x, &r);
+    } else {
+      A_->Mult(y, r);
+      linalg::AXPBY(c, 1.0, x, -1.0, r);
+    }
     G_->MultTranspose(r, x_G_);
     if (A_G_->NumEssentialTrueDofs())
       linalg::SetSubVector(c, x_G_, A_G_->GetEssentialTrueDofs(), A_G_->NumEssentialTrueDofs(), 0.0);
@@ -1478,7 +1499,10 @@ void DistRelaxationSmoother::MultTranspose2(const Vector &x, Vector &y, Vector &
   B_->SetInitialGuess(true);
   for (int it = 0; it < pc_it_; it++) {
     // y = y + G B_G^T G^T (x - A y)
-    if (initial_guess || it > 0) {
+    if ((initial_guess || it > 0) && B_->FusedStep() && r.Data() != x.Data()) {
+      A_->MultResidual(y, x, &r);
+      G_->MultTranspose(r, x_G_);
+    } else if (initial_guess || it > 0) {
       A_->Mult(y, r);
       linalg::AXPBY(c, 1.0, x, -1.0, r);
       G_->MultTranspose(r, x_G_);
@@ -1876,6 +1900,11 @@ void GeometricMultigridSolver::SetOperators(const std::vector<const ParOperator 
     }
     X_[l].SetSize(A_[l]->Height()), Y_[l].SetSize(A_[l]->Height()), R_[l].SetSize(A_[l]->Height());
   }
+  fused_res_.assign(ops.size(), 0);
+  {
+    const char *fe = std::getenv("PALACE_AMD_FUSED_STEP");
+    for (size_t l = 1; l < ops.size(); l++) fused_res_[l] = !(fe && fe[0] == '0') && A_[l]->PrepareChebyStep();
+  }
   height = width = ops.back()->Height();
   graph_.Reset(), graph_alias_.Reset();
   last_x_ = last_y_ = nullptr;
@@ -1917,8 +1946,12 @@ void GeometricMultigridSolver::VCycle(int l, bool initial_guess) const {
     return;
   }
   B_[l]->Mult2(X_[l], Y_[l], R_[l]);
-  A_[l]->Mult(Y_[l], R_[l]);
-  linalg::AXPBY(c, 1.0, X_[l], -1.0, R_[l]);
+  if (fused_res_[l]) {  // r = x - A y in the epilogue of the operator's E^T (round 6)
+    A_[l]->MultResidual(Y_[l], X_[l], &R_[l]);
+  } else {
+    A_[l]->Mult(Y_[l], R_[l]);
+    linalg::AXPBY(c, 1.0, X_[l], -1.0, R_[l]);
+  }
   P_[l - 1]->MultTranspose(R_[l], X_[l - 1]);
   if (A_[l - 1]->NumEssentialTrueDofs())
     linalg::SetSubVector(c, X_[l - 1], A_[l - 1]->GetEssentialTrueDofs(), A_[l - 1]->NumEssentialTrueDofs(), 0.0);

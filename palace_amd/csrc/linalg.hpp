@@ -215,6 +215,9 @@ public:
   };
   virtual bool PrepareChebyStep() const { return false; }
   virtual void MultChebyStep(const Vector &x, const ChebyStepArgs &a) const;
+  // res = b - A y and / or d0 = c0 dinv .* (b - A y) in the same place (operators with PrepareChebyStep() only)
+  virtual void MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv = nullptr, double c0 = 0.0,
+                            Vector *d0 = nullptr) const;
 };
 
 namespace ceed {
@@ -271,6 +274,7 @@ public:
   // the Chebyshev step fused into E^T (pa_op_prepare_fused_step / pa_op_mult_cheb_step), essential list fused
   bool PrepareFusedStep() const;
   void MultChebyStepEssential(const Vector &x, const ChebyStepArgs &a, bool diag_one) const;
+  void MultResidualEssential(const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0, bool diag_one) const;
   // split vectors (pa_op_mult_split): true dofs in x / y, ghosts read from xg0 | xg1 (parity of *sel) and written to yg
   bool SupportsSplit() const;
   void MultSplit(const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y, double *yg,
@@ -412,7 +416,9 @@ public:
   }
   bool FusesEssential() const { return A_fused_ != nullptr; }
   bool PrepareChebyStep() const override;
-  void MultChebyStep(const Vector &x, const ChebyStepArgs &a) const override;  // the essential list lives in the local operator's index tables
+  void MultChebyStep(const Vector &x, const ChebyStepArgs &a) const override;
+  void MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv = nullptr, double c0 = 0.0,
+                    Vector *d0 = nullptr) const override;  // the essential list lives in the local operator's index tables
   DiagonalPolicy GetDiagonalPolicy() const { return policy_; }
   const Halo *GetHalo() const { return halo_; }
   void Mult(const Vector &x, Vector &y) const override;
@@ -670,6 +676,7 @@ class GeometricMultigridSolver : public Solver {
   mutable Vector Xown_, Yown_;              // the finest vectors of applications to varying (x, y)
   mutable StreamGraph graph_, graph_alias_;  // one application (pc_it V-cycles): on the solver's vectors / on a caller's recurring pair
   mutable const double *last_x_ = nullptr, *last_y_ = nullptr;
+  std::vector<char> fused_res_;  // level l: r = x - A y comes out of the operator's E^T epilogue (Operator::MultResidual)
   void VCycle(int l, bool initial_guess) const;
 
 public:

@@ -1167,8 +1167,21 @@ int pa_op_mult_cheb_step(pa_op *op, const double *x, const pa_cheb_step *step, i
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
     const SubOp &so = *op->subs[0];
     launch_nd_hex_stream_all(so, x, (hipStream_t)stream);
-    launch_et_run_gather_step(so, x, GatherStep{step->sd, step->sr, step->dinv, step->r0, step->e_prev, step->out, step->add},
+    launch_et_run_gather_step(so, x, GatherStep{step->sd, step->sr, step->dinv, step->r0, step->e_prev, step->out, step->add, nullptr, 1},
                               diag_policy ? 1 : 0, (hipStream_t)stream);
+  });
+}
+
+int pa_op_mult_residual(pa_op *op, const double *y, const double *b, double *res, const double *dinv, double c0, double *d0,
+                        int diag_policy, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && y && b && (res || d0) && (!d0 || dinv), "null argument");
+    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->d_flagw_all, "pa_op_prepare_fused_step has not been called (or found no fused form)");
+    PA_REQUIRE(y != res && y != d0, "the residual cannot overwrite the operator's input");
+    PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
+    const SubOp &so = *op->subs[0];
+    launch_nd_hex_stream_all(so, y, (hipStream_t)stream);
+    launch_et_run_gather_step(so, y, GatherStep{0.0, c0, dinv, b, nullptr, d0, 0, res, 2}, diag_policy ? 1 : 0, (hipStream_t)stream);
   });
 }
 

@@ -339,11 +339,15 @@ void stream_set_interface(SubOp &so, const std::vector<char> &flag);
 // One step of a smoother recurrence consumed inside E^T (round 6): with t = (A x)[d] (the essential rows fixed as in the masked
 // apply) the run gather writes  out[d] (+)= x[d] + sd (x[d] - ep[d]) + sr dinv[d] (r0[d] - t)  for every dof and never stores t:
 // the Chebyshev step of chebyshev.cpp:204-218 in its accumulated form (linalg.hip: OpChebStep3) without the round trip of A x.
+// mode 2, the residual form: with r = r0[d] - t the gather writes  res[d] = r  (if res) and  out[d] = sr dinv[d] r  (if out) --
+// r = b - A y of gmg.cpp:186-188 / chebyshev.cpp:196-200 and the first direction d_0 = c_0 D^-1 r of the polynomial.
 struct GatherStep {
   double sd, sr;
   const double *dinv, *r0, *ep;  // ep == nullptr: e_{k-1} = 0
   double *out;
   int add;
+  double *res;
+  int mode;  // 1: Chebyshev step, 2: residual
 };
 bool stream_build_all(SubOp &so);  // the index copies the fused step needs (idempotent; false: this block has no such form)
 void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s);

@@ -668,9 +668,11 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel_t(const int n, const
 #pragma unroll
     for (int u = 0; u < kGatherILP; u++) {
       const int dd = live[u] ? d[u] : 0;
-      se[u] = x[dd], sdi[u] = st.dinv[dd], sr0[u] = st.r0[dd];
-      sep[u] = st.ep ? st.ep[dd] : 0.0;
-      so[u] = st.add ? st.out[dd] : 0.0;
+      sr0[u] = st.r0[dd];
+      sdi[u] = st.dinv ? st.dinv[dd] : 0.0;
+      se[u] = st.mode == 1 ? x[dd] : 0.0;
+      sep[u] = (st.mode == 1 && st.ep) ? st.ep[dd] : 0.0;
+      so[u] = (st.mode == 1 && st.add) ? st.out[dd] : 0.0;
     }
   }
   // copies in order (fixed summation order; an absent copy adds an exact zero): the first four of every dof side by
@@ -698,7 +700,13 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel_t(const int n, const
 #pragma unroll
     for (int u = 0; u < kGatherILP; u++) {
       if (!live[u]) continue;
-      double dk = st.sr * sdi[u] * (sr0[u] - s[u]);
+      const double rv = sr0[u] - s[u];
+      if (st.mode == 2) {  // residual (and the first direction of the polynomial)
+        if (st.res) st.res[d[u]] = rv;
+        if (st.out) st.out[d[u]] = st.sr * sdi[u] * rv;
+        continue;
+      }
+      double dk = st.sr * sdi[u] * rv;
       dk += st.sd * (se[u] - sep[u]);
       st.out[d[u]] = so[u] + (se[u] + dk);
     }
