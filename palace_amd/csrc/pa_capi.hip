@@ -1023,8 +1023,14 @@ int pa_op_mult_complex(pa_op *op_r, pa_op *op_i, const double *xr, const double 
       if (!sr->d_ye2) sr->d_ye2 = dev_alloc<double>((size_t)((sr->ne + 3) & ~3) * sr->P);
       if (sr->qd->metric) stream_element_coefficients(*op_i->subs[0]);
       launch_nd_hex_stream_complex(*sr, *op_i->subs[0], xr, xi, yr, yi, sr->d_ye2, masked, s);
-      launch_et_run_gather(*sr, yr, false, s, xr, masked, ess_policy);
-      launch_et_run_gather(*sr, yi, false, s, xi, masked, ess_policy, sr->d_ye2);
+      // (q1d = 5: the wide kernel's gather keeps its two launches)
+      static const bool one_gather = !(getenv("PALACE_AMD_CPLX_GATHER2") && atoi(getenv("PALACE_AMD_CPLX_GATHER2")) == 0);
+      if (one_gather) {  // both parts in one launch: headers and copy positions read once (round 6)
+        launch_et_run_gather2(*sr, yr, yi, s, xr, xi, masked, ess_policy, sr->d_ye2);
+      } else {
+        launch_et_run_gather(*sr, yr, false, s, xr, masked, ess_policy);
+        launch_et_run_gather(*sr, yi, false, s, xi, masked, ess_policy, sr->d_ye2);
+      }
     }
     // the remaining sub-operators (operator.cpp:98-134 term by term): B of the real part, yr += B xr, yi += B xi; B of the
     // imaginary part, yi += B xr, yr -= B xi; essential entries of x read as zero through B's own flagged index copy, essential

@@ -349,6 +349,8 @@ struct GatherStep {
   double *res;
   int mode;  // 1: Chebyshev step, 2: residual
 };
+void launch_et_run_gather2(const SubOp &so, double *y, double *y1, hipStream_t s, const double *x, const double *x1, bool masked,
+                           int ess_policy, const double *ye1);
 bool stream_build_all(SubOp &so);  // the index copies the fused step needs (idempotent; false: this block has no such form)
 void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s);
 void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s);

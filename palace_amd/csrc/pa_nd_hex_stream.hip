@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   constexpr int Q1 = 4;
   // affine batches (round 6): D(q) = w_q D_e read from the compact rows of QData::d_aff (same number of loads, 16 bytes per row
   // for the whole element instead of per lane) and the D stage's result scaled by the in-plane weight; real forms on packed data
-  constexpr bool AFF = !CPLX && !GEOMN && !(PA_STREAM_QAHEAD && MINW == 2);
+  constexpr bool AFF = (!CPLX || METRIC) && !GEOMN && !(PA_STREAM_QAHEAD && MINW == 2);
 #ifdef PA_STREAM_EARLY  // experiment builds
   constexpr bool EARLY_IDX = true;
 #else
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   };
   auto load_q = [&](const int ee, const int t, const int aff) {
     if (GEOMN) return load_xn(ee, t);  // (the nodes of the batch: consumed in its D stage)
-    if (AFF) {
+    if (AFF && !(CPLX && !METRIC)) {
       // one instruction stream for both kinds of batch (the counted waits below depend on the number of loads in flight): the
       // wave-uniform flag selects the base, the lane offset and the row stride
       constexpr int NS = METRIC ? 7 : NG;
@@ -620,13 +620,19 @@ using streamhost::RunChunk;
 // lanes of the short runs cost more instructions than the mask saves.)
 constexpr int kGatherILP = 4;
 // STEP: the sum is not stored but consumed by a smoother step (GatherStep; y, accumulate, the split arguments unused)
-template <bool STEP>
+// Two parts in one launch (the one-pass complex apply: the copy positions of the real and the imaginary E-vector are the same):
+// ye1 / y1 / x1 != nullptr sums the second E-vector into y1 alongside, every header and position word read once.
+struct GatherPart2 {
+  const double *ye1, *x1;
+  double *y1;
+};
+template <bool STEP, bool DUAL = false>
 __global__ __launch_bounds__(256) void et_run_gather_kernel_t(const int n, const RunChunk *__restrict__ chunk,
                                                               const RunHdr *__restrict__ hdr, const int32_t *__restrict__ rpos,
                                                               const double *__restrict__ ye, double *__restrict__ y,
                                                               const int accumulate, const double *__restrict__ x,
                                                               const int ess_policy, const int nsplit, double *__restrict__ yg,
-                                                              const GatherStep st) {
+                                                              const GatherStep st, const GatherPart2 p2) {
   const int k0 = blockIdx.x * (256 * kGatherILP) + threadIdx.x;
   const int lane = threadIdx.x & 63;
   RunHdr h[kGatherILP];
@@ -687,6 +693,22 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel_t(const int n, const
   for (int u = 0; u < kGatherILP; u++)
 #pragma unroll
     for (int q = 0; q < 4; q++) v[u][q] = pos[u][q] >= 0 ? ye[(size_t)pos[u][q] + j[u]] : 0.0;
+  if (DUAL) {  // the second part: same positions, its own E-vector
+    double w[kGatherILP][4], s1[kGatherILP];
+#pragma unroll
+    for (int u = 0; u < kGatherILP; u++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) w[u][q] = pos[u][q] >= 0 ? p2.ye1[(size_t)pos[u][q] + j[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < kGatherILP; u++) {
+      s1[u] = (live[u] && fix[u] && ess_policy) ? p2.x1[d[u]] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) s1[u] += w[u][q];
+      if (live[u])
+        for (int p = h[u].ptr + 4; p < pe[u]; p++) s1[u] += p2.ye1[(size_t)rpos[p] + j[u]];
+      if (live[u]) p2.y1[d[u]] = s1[u];
+    }
+  }
 #pragma unroll
   for (int u = 0; u < kGatherILP; u++) {
 #pragma unroll
@@ -1227,6 +1249,7 @@ static void launch_complex_p(const SubOp &sr, const SubOp &si, const double *xr,
   a.flagw = masked ? sr.d_flagw_bc : sr.d_flagw;
   a.slots = sr.d_slots;
   a.qdata = sr.qd->d;
+  if (sr.qd->metric) a.qaff = sr.qd->d_aff, a.wq2[0] = sr.qd->wq2[0], a.wq2[1] = sr.qd->wq2[1];  // (affine batches: the metric form)
   a.coef = sr.d_coef_s, a.coef1 = si.d_coef_s;
   a.xn = nullptr, a.gtab = nullptr;
   a.x = xr, a.x1 = xi, a.y = yr, a.y1 = yi, a.ye = sr.d_ye, a.ye1 = ye_i;
@@ -1272,7 +1295,20 @@ void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream
                      reinterpret_cast<const RunChunk *>(masked ? so.d_rchunk_bc : so.d_rchunk),
                      reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
                      masked ? so.d_rpos_bc : so.d_rpos, ye ? ye : so.d_ye, y, accumulate ? 1 : 0, x, masked ? ess_policy : -1,
-                     split ? split->n_true : 0x7fffffff, split ? split->yg - split->n_true : nullptr, GatherStep{});
+                     split ? split->n_true : 0x7fffffff, split ? split->yg - split->n_true : nullptr, GatherStep{}, GatherPart2{});
+  PA_HIP(hipGetLastError());
+}
+
+// the two parts of a one-pass complex apply in one launch: y = sum of `so.d_ye`, y1 = sum of ye1 (same runs, same order)
+void launch_et_run_gather2(const SubOp &so, double *y, double *y1, hipStream_t s, const double *x, const double *x1, bool masked,
+                           int ess_policy, const double *ye1) {
+  const int n = masked ? so.n_shared_bc : so.n_shared;
+  if (n == 0) return;
+  hipLaunchKernelGGL((et_run_gather_kernel_t<false, true>), dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
+                     reinterpret_cast<const RunChunk *>(masked ? so.d_rchunk_bc : so.d_rchunk),
+                     reinterpret_cast<const RunHdr *>(masked ? so.d_rhdr_bc : so.d_rhdr),
+                     masked ? so.d_rpos_bc : so.d_rpos, so.d_ye, y, 0, x, masked ? ess_policy : -1, 0x7fffffff, nullptr, GatherStep{},
+                     GatherPart2{ye1, x1, y1});
   PA_HIP(hipGetLastError());
 }
 
@@ -1324,7 +1360,7 @@ void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherSte
   const int n = so.n_all;
   hipLaunchKernelGGL(et_run_gather_kernel_t<true>, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
                      reinterpret_cast<const RunChunk *>(so.d_rchunk_all), reinterpret_cast<const RunHdr *>(so.d_rhdr_all), so.d_rpos_all,
-                     so.d_ye, nullptr, 0, x, ess_policy, 0x7fffffff, nullptr, step);
+                     so.d_ye, nullptr, 0, x, ess_policy, 0x7fffffff, nullptr, step, GatherPart2{});
   PA_HIP(hipGetLastError());
 }
 

@@ -48,6 +48,8 @@ R = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]]) @ np.array([[1.0, 0
 eps = R @ np.diag([9.3, 9.3, 11.5]) @ R.T
 loss = R @ np.diag([9.3 * 3.0e-5, 9.3 * 3.0e-5, 11.5 * 8.6e-5]) @ R.T
 eps, loss = 0.5 * (eps + eps.T), 0.5 * (loss + loss.T)
+if os.environ.get("ISO", "0") == "1":  # (round 6: the isotropic -- metric-form -- complex kernel, bench.py: complex_leg(aniso=False))
+    eps, loss = np.array([2.08]), np.array([0.05 / 0.3])
 Ar = ceed.curlcurlmass_operator(prob.geom, nd, ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[-0.3 * eps]), ceed.coefficient_context(3))
 Ai = ceed.ndmass_operator(prob.geom, nd, ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[0.3 * loss]))
 A = linalg.ComplexParOperator(ctx, Ar, Ai, prob.ess[-1], linalg.DIAG_ONE)
