@@ -195,123 +195,168 @@ __global__ __launch_bounds__(256) void interp_kernel(const InterpArgs a) {
 
 // ---- specialised forms (orders known at compile time, pf <= 4): loops unrolled, line data in registers,
 // 1-D matrices as scalar operands.  Same passes and the same owner-copy semantics as above.
-template <bool TRANSPOSE, int NC0, int NC1, int NC2, int NF0, int NF1, int NF2, int N1>
-__device__ __forceinline__ void interp_block_s(const InterpArgs &a, const int e, const bool active, const bool lane_ok,
-                                               const int ta, const int tb, double *sm, const bool accumulate,
-                                               const int off_c, const int off_f, const int Pc, const int Pf,
-                                               const double *M0, const double *M1, const double *M2) {
-  double *sA = sm, *sB = sm + N1 * N1 * N1;
-  if (!TRANSPOSE) {
-    {
-      const bool act = ta < NC1 && tb < NC2;
-      double u[NC0];
+//
+// Round 6: the memory side of the three component blocks is issued up front.  The first form of this kernel ran each block as
+// index load -> x load -> three passes -> fine index load -> store, one block after the other, with 24-30 registers: four
+// dependent global round trips per block and at most a handful of loads in flight per wave (p2 -> p3 prolongation 122 us for
+// ~210 MB of necessary traffic).  Now: (A) every index word of the element -- coarse and fine, all blocks -- is requested first,
+// (B) then every input value, (C) then the passes run block by block out of registers and (D) the stores go out.  The discrete
+// gradient reads its H1 line once for the three blocks and its transpose adds the three blocks in registers before one store
+// (the first form re-read and re-wrote the coarse E-vector entries twice).
+template <int NC0_, int NC1_, int NC2_, int NF0_, int NF1_, int NF2_>
+struct BlkDims {
+  static constexpr int NC0 = NC0_, NC1 = NC1_, NC2 = NC2_, NF0 = NF0_, NF1 = NF1_, NF2 = NF2_;
+};
+
+// (A) forward: signed coarse index words of the lane's line (i = 0 .. NC0) and the fine index words of its output line
+template <class D>
+__device__ __forceinline__ void blk_idx_fwd(const InterpArgs &a, const int e, const bool active, const int ta, const int tb, const int off_c,
+                                            const int off_f, const int Pc, const int Pf, int (&sc)[kMaxN], int (&sf)[kMaxN],
+                                            const bool want_c) {
+  const bool actc = ta < D::NC1 && tb < D::NC2, actf = ta < D::NF0 && tb < D::NF1;
 #pragma unroll
-      for (int i = 0; i < NC0; i++) {
-        double v = 0.0;
-        if (active && act) {
-          const int s = a.lidx_c[(size_t)e * Pc + off_c + i + NC0 * (ta + NC1 * tb)];
-          const double xv = a.x[s >= 0 ? s : -1 - s];
-          v = s >= 0 ? xv : -xv;
-        }
-        u[i] = v;
-      }
+  for (int i = 0; i < D::NC0; i++)
+    sc[i] = (want_c && active && actc) ? a.lidx_c[(size_t)e * Pc + off_c + i + D::NC0 * (ta + D::NC1 * tb)] : 0;
 #pragma unroll
-      for (int fi = 0; fi < NF0; fi++) {
-        double v = 0.0;
+  for (int fk = 0; fk < D::NF2; fk++)
+    sf[fk] = (active && actf) ? a.lidx_f[(size_t)e * Pf + off_f + ta + D::NF0 * (tb + D::NF1 * fk)] : 0;
+}
+// (B) forward: the coarse values
+template <class D>
+__device__ __forceinline__ void blk_x_fwd(const InterpArgs &a, const bool active, const int ta, const int tb, const int (&sc)[kMaxN],
+                                          double (&u)[kMaxN]) {
+  const bool act = active && ta < D::NC1 && tb < D::NC2;
 #pragma unroll
-        for (int i = 0; i < NC0; i++) v += M0[fi * NC0 + i] * u[i];
-        if (lane_ok && act) sA[(fi * NC1 + ta) * NC2 + tb] = v;
-      }
-    }
-    wsync();
-    {
-      const bool act = ta < NF0 && tb < NC2;
-      double u[NC1];
-#pragma unroll
-      for (int j = 0; j < NC1; j++) u[j] = sA[((act ? ta : 0) * NC1 + j) * NC2 + (act ? tb : 0)];
-#pragma unroll
-      for (int fj = 0; fj < NF1; fj++) {
-        double v = 0.0;
-#pragma unroll
-        for (int j = 0; j < NC1; j++) v += M1[fj * NC1 + j] * u[j];
-        if (lane_ok && act) sB[(ta * NF1 + fj) * NC2 + tb] = v;
-      }
-    }
-    wsync();
-    {
-      const bool act = ta < NF0 && tb < NF1;
-      double u[NC2];
-#pragma unroll
-      for (int k = 0; k < NC2; k++) u[k] = sB[((act ? ta : 0) * NF1 + (act ? tb : 0)) * NC2 + k];
-#pragma unroll
-      for (int fk = 0; fk < NF2; fk++) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < NC2; k++) v += M2[fk * NC2 + k] * u[k];
-        if (active && act) {
-          const int s = a.lidx_f[(size_t)e * Pf + off_f + ta + NF0 * (tb + NF1 * fk)];
-          const int g = s >= 0 ? s : -1 - s;
-          if (g & kOwnBit) a.y[g & ~kOwnBit] = s >= 0 ? v : -v;
-        }
-      }
-    }
-    wsync();
-  } else {
-    {
-      const bool act = ta < NF0 && tb < NF1;
-      double u[NF2];
-#pragma unroll
-      for (int fk = 0; fk < NF2; fk++) {
-        double v = 0.0;
-        if (active && act) {
-          const int s = a.lidx_f[(size_t)e * Pf + off_f + ta + NF0 * (tb + NF1 * fk)];
-          const int g = s >= 0 ? s : -1 - s;
-          const double xv = (g & kOwnBit) ? a.x[g & ~kOwnBit] : 0.0;
-          v = s >= 0 ? xv : -xv;
-        }
-        u[fk] = v;
-      }
-#pragma unroll
-      for (int k = 0; k < NC2; k++) {
-        double v = 0.0;
-#pragma unroll
-        for (int fk = 0; fk < NF2; fk++) v += M2[fk * NC2 + k] * u[fk];
-        if (lane_ok && act) sB[(ta * NF1 + tb) * NC2 + k] = v;
-      }
-    }
-    wsync();
-    {
-      const bool act = ta < NF0 && tb < NC2;
-      double u[NF1];
-#pragma unroll
-      for (int fj = 0; fj < NF1; fj++) u[fj] = sB[((act ? ta : 0) * NF1 + fj) * NC2 + (act ? tb : 0)];
-#pragma unroll
-      for (int j = 0; j < NC1; j++) {
-        double v = 0.0;
-#pragma unroll
-        for (int fj = 0; fj < NF1; fj++) v += M1[fj * NC1 + j] * u[fj];
-        if (lane_ok && act) sA[(ta * NC1 + j) * NC2 + tb] = v;
-      }
-    }
-    wsync();
-    {
-      const bool act = ta < NC1 && tb < NC2;
-      double u[NF0];
-#pragma unroll
-      for (int fi = 0; fi < NF0; fi++) u[fi] = sA[(fi * NC1 + (act ? ta : 0)) * NC2 + (act ? tb : 0)];
-#pragma unroll
-      for (int i = 0; i < NC0; i++) {
-        double v = 0.0;
-#pragma unroll
-        for (int fi = 0; fi < NF0; fi++) v += M0[fi * NC0 + i] * u[fi];
-        if (active && act) {
-          double *dst = &a.ye_c[(size_t)e * Pc + off_c + i + NC0 * (ta + NC1 * tb)];
-          *dst = accumulate ? *dst + v : v;
-        }
-      }
-    }
-    wsync();
+  for (int i = 0; i < D::NC0; i++) {
+    const int s = sc[i];
+    const double xv = act ? a.x[s >= 0 ? s : -1 - s] : 0.0;
+    u[i] = s >= 0 ? xv : -xv;
   }
+}
+// (C, D) forward: passes X, Y, Z and the owner stores
+template <class D, int N1>
+__device__ __forceinline__ void blk_apply_fwd(const InterpArgs &a, const bool active, const bool lane_ok, const int ta, const int tb,
+                                              double *sm, const double (&uin)[kMaxN], const int (&sf)[kMaxN], const double *M0,
+                                              const double *M1, const double *M2) {
+  constexpr int NC0 = D::NC0, NC1 = D::NC1, NC2 = D::NC2, NF0 = D::NF0, NF1 = D::NF1, NF2 = D::NF2;
+  double *sA = sm, *sB = sm + N1 * N1 * N1;
+  {
+    const bool act = ta < NC1 && tb < NC2;
+#pragma unroll
+    for (int fi = 0; fi < NF0; fi++) {
+      double v = 0.0;
+#pragma unroll
+      for (int i = 0; i < NC0; i++) v += M0[fi * NC0 + i] * uin[i];
+      if (lane_ok && act) sA[(fi * NC1 + ta) * NC2 + tb] = v;
+    }
+  }
+  wsync();
+  {
+    const bool act = ta < NF0 && tb < NC2;
+    double u[NC1];
+#pragma unroll
+    for (int j = 0; j < NC1; j++) u[j] = sA[((act ? ta : 0) * NC1 + j) * NC2 + (act ? tb : 0)];
+#pragma unroll
+    for (int fj = 0; fj < NF1; fj++) {
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j < NC1; j++) v += M1[fj * NC1 + j] * u[j];
+      if (lane_ok && act) sB[(ta * NF1 + fj) * NC2 + tb] = v;
+    }
+  }
+  wsync();
+  {
+    const bool act = ta < NF0 && tb < NF1;
+    double u[NC2];
+#pragma unroll
+    for (int k = 0; k < NC2; k++) u[k] = sB[((act ? ta : 0) * NF1 + (act ? tb : 0)) * NC2 + k];
+#pragma unroll
+    for (int fk = 0; fk < NF2; fk++) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < NC2; k++) v += M2[fk * NC2 + k] * u[k];
+      if (active && act) {
+        const int s = sf[fk];
+        const int g = s >= 0 ? s : -1 - s;
+        if (g & kOwnBit) a.y[g & ~kOwnBit] = s >= 0 ? v : -v;
+      }
+    }
+  }
+  wsync();
+}
+// (A) transpose: the fine index words of the lane's line; (B) the owner-masked fine values
+template <class D>
+__device__ __forceinline__ void blk_idx_tr(const InterpArgs &a, const int e, const bool active, const int ta, const int tb, const int off_f,
+                                           const int Pf, int (&sf)[kMaxN]) {
+  const bool act = active && ta < D::NF0 && tb < D::NF1;
+#pragma unroll
+  for (int fk = 0; fk < D::NF2; fk++) sf[fk] = act ? a.lidx_f[(size_t)e * Pf + off_f + ta + D::NF0 * (tb + D::NF1 * fk)] : 0;
+}
+template <class D>
+__device__ __forceinline__ void blk_x_tr(const InterpArgs &a, const bool active, const int ta, const int tb, const int (&sf)[kMaxN],
+                                         double (&u)[kMaxN]) {
+  const bool act = active && ta < D::NF0 && tb < D::NF1;
+#pragma unroll
+  for (int fk = 0; fk < D::NF2; fk++) {
+    const int s = sf[fk];
+    const int g = s >= 0 ? s : -1 - s;
+    const double xv = (act && (g & kOwnBit)) ? a.x[g & ~kOwnBit] : 0.0;
+    u[fk] = s >= 0 ? xv : -xv;
+  }
+}
+// (C) transpose: passes Z^T, Y^T, X^T; the lane's coarse line is returned in out[0 .. NC0) (added to it when `accumulate`)
+template <class D, int N1>
+__device__ __forceinline__ void blk_apply_tr(const bool lane_ok, const int ta, const int tb, double *sm, const double (&uin)[kMaxN],
+                                             double (&out)[kMaxN], const bool accumulate, const double *M0, const double *M1,
+                                             const double *M2) {
+  constexpr int NC0 = D::NC0, NC1 = D::NC1, NC2 = D::NC2, NF0 = D::NF0, NF1 = D::NF1, NF2 = D::NF2;
+  double *sA = sm, *sB = sm + N1 * N1 * N1;
+  {
+    const bool act = ta < NF0 && tb < NF1;
+#pragma unroll
+    for (int k = 0; k < NC2; k++) {
+      double v = 0.0;
+#pragma unroll
+      for (int fk = 0; fk < NF2; fk++) v += M2[fk * NC2 + k] * uin[fk];
+      if (lane_ok && act) sB[(ta * NF1 + tb) * NC2 + k] = v;
+    }
+  }
+  wsync();
+  {
+    const bool act = ta < NF0 && tb < NC2;
+    double u[NF1];
+#pragma unroll
+    for (int fj = 0; fj < NF1; fj++) u[fj] = sB[((act ? ta : 0) * NF1 + fj) * NC2 + (act ? tb : 0)];
+#pragma unroll
+    for (int j = 0; j < NC1; j++) {
+      double v = 0.0;
+#pragma unroll
+      for (int fj = 0; fj < NF1; fj++) v += M1[fj * NC1 + j] * u[fj];
+      if (lane_ok && act) sA[(ta * NC1 + j) * NC2 + tb] = v;
+    }
+  }
+  wsync();
+  {
+    const bool act = ta < NC1 && tb < NC2;
+    double u[NF0];
+#pragma unroll
+    for (int fi = 0; fi < NF0; fi++) u[fi] = sA[(fi * NC1 + (act ? ta : 0)) * NC2 + (act ? tb : 0)];
+#pragma unroll
+    for (int i = 0; i < NC0; i++) {
+      double v = 0.0;
+#pragma unroll
+      for (int fi = 0; fi < NF0; fi++) v += M0[fi * NC0 + i] * u[fi];
+      out[i] = accumulate ? out[i] + v : v;
+    }
+  }
+  wsync();
+}
+template <class D>
+__device__ __forceinline__ void blk_store_tr(const InterpArgs &a, const int e, const bool active, const int ta, const int tb, const int off_c,
+                                             const int Pc, const double (&out)[kMaxN]) {
+  if (!(active && ta < D::NC1 && tb < D::NC2)) return;
+#pragma unroll
+  for (int i = 0; i < D::NC0; i++) a.ye_c[(size_t)e * Pc + off_c + i + D::NC0 * (ta + D::NC1 * tb)] = out[i];
 }
 
 // KIND 0: ND prolongation, 1: discrete gradient H1(PF) -> ND(PF), 2: H1 prolongation
@@ -327,18 +372,59 @@ __global__ __launch_bounds__(256) void interp_kernel_s(const InterpArgs a) {
   const bool active = lane_ok && e < a.ne;
   double *sm = smem + (size_t)(wave * EPW + (lane_ok ? sub : 0)) * (2 * N1 * N1 * N1);
   const double *Ic = a.Ic_s, *Io = a.Io_s;
-  if (KIND == 1) {
-    constexpr int Pc = NFC * NFC * NFC, Pf = 3 * PF * NFC * NFC;
-    interp_block_s<TRANSPOSE, NFC, NFC, NFC, PF, NFC, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, false, 0, 0, Pc, Pf, Io, Ic, Ic);
-    interp_block_s<TRANSPOSE, NFC, NFC, NFC, NFC, PF, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, true, 0, PF * NFC * NFC, Pc, Pf, Ic, Io, Ic);
-    interp_block_s<TRANSPOSE, NFC, NFC, NFC, NFC, NFC, PF, N1>(a, e, active, lane_ok, ta, tb, sm, true, 0, 2 * PF * NFC * NFC, Pc, Pf, Ic, Ic, Io);
-  } else if (KIND == 0) {
-    constexpr int Pc = 3 * PC * NCC * NCC, Pf = 3 * PF * NFC * NFC;
-    interp_block_s<TRANSPOSE, PC, NCC, NCC, PF, NFC, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, false, 0, 0, Pc, Pf, Io, Ic, Ic);
-    interp_block_s<TRANSPOSE, NCC, PC, NCC, NFC, PF, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, false, PC * NCC * NCC, PF * NFC * NFC, Pc, Pf, Ic, Io, Ic);
-    interp_block_s<TRANSPOSE, NCC, NCC, PC, NFC, NFC, PF, N1>(a, e, active, lane_ok, ta, tb, sm, false, 2 * PC * NCC * NCC, 2 * PF * NFC * NFC, Pc, Pf, Ic, Ic, Io);
+  if (KIND == 2) {
+    using D = BlkDims<NCC, NCC, NCC, NFC, NFC, NFC>;
+    constexpr int Pc = NCC * NCC * NCC, Pf = NFC * NFC * NFC;
+    int sc[kMaxN], sf[kMaxN];
+    double u[kMaxN], o[kMaxN];
+    if (!TRANSPOSE) {
+      blk_idx_fwd<D>(a, e, active, ta, tb, 0, 0, Pc, Pf, sc, sf, true);
+      blk_x_fwd<D>(a, active, ta, tb, sc, u);
+      blk_apply_fwd<D, N1>(a, active, lane_ok, ta, tb, sm, u, sf, Ic, Ic, Ic);
+    } else {
+      blk_idx_tr<D>(a, e, active, ta, tb, 0, Pf, sf);
+      blk_x_tr<D>(a, active, ta, tb, sf, u);
+      blk_apply_tr<D, N1>(lane_ok, ta, tb, sm, u, o, false, Ic, Ic, Ic);
+      blk_store_tr<D>(a, e, active, ta, tb, 0, Pc, o);
+    }
+    return;
+  }
+  // three component blocks: the open direction of block C is C
+  using D0 = typename std::conditional<KIND == 1, BlkDims<NFC, NFC, NFC, PF, NFC, NFC>, BlkDims<PC, NCC, NCC, PF, NFC, NFC>>::type;
+  using D1 = typename std::conditional<KIND == 1, BlkDims<NFC, NFC, NFC, NFC, PF, NFC>, BlkDims<NCC, PC, NCC, NFC, PF, NFC>>::type;
+  using D2 = typename std::conditional<KIND == 1, BlkDims<NFC, NFC, NFC, NFC, NFC, PF>, BlkDims<NCC, NCC, PC, NFC, NFC, PF>>::type;
+  constexpr int Pc = KIND == 1 ? NFC * NFC * NFC : 3 * PC * NCC * NCC, Pf = 3 * PF * NFC * NFC;
+  constexpr int bc = KIND == 1 ? 0 : PC * NCC * NCC, bf = PF * NFC * NFC;  // block strides in the coarse / fine element vectors
+  int sf0[kMaxN], sf1[kMaxN], sf2[kMaxN];
+  double u0[kMaxN], u1[kMaxN], u2[kMaxN];
+  if (!TRANSPOSE) {
+    int sc0[kMaxN], sc1[kMaxN], sc2[kMaxN];
+    blk_idx_fwd<D0>(a, e, active, ta, tb, 0, 0, Pc, Pf, sc0, sf0, true);
+    blk_idx_fwd<D1>(a, e, active, ta, tb, bc, bf, Pc, Pf, sc1, sf1, KIND != 1);
+    blk_idx_fwd<D2>(a, e, active, ta, tb, 2 * bc, 2 * bf, Pc, Pf, sc2, sf2, KIND != 1);
+    blk_x_fwd<D0>(a, active, ta, tb, sc0, u0);
+    if (KIND != 1) {
+      blk_x_fwd<D1>(a, active, ta, tb, sc1, u1);
+      blk_x_fwd<D2>(a, active, ta, tb, sc2, u2);
+    }
+    // (the gradient's three blocks contract the same H1 line: u0)
+    blk_apply_fwd<D0, N1>(a, active, lane_ok, ta, tb, sm, u0, sf0, Io, Ic, Ic);
+    blk_apply_fwd<D1, N1>(a, active, lane_ok, ta, tb, sm, KIND == 1 ? u0 : u1, sf1, Ic, Io, Ic);
+    blk_apply_fwd<D2, N1>(a, active, lane_ok, ta, tb, sm, KIND == 1 ? u0 : u2, sf2, Ic, Ic, Io);
   } else {
-    interp_block_s<TRANSPOSE, NCC, NCC, NCC, NFC, NFC, NFC, N1>(a, e, active, lane_ok, ta, tb, sm, false, 0, 0, NCC * NCC * NCC, NFC * NFC * NFC, Ic, Ic, Ic);
+    blk_idx_tr<D0>(a, e, active, ta, tb, 0, Pf, sf0);
+    blk_idx_tr<D1>(a, e, active, ta, tb, bf, Pf, sf1);
+    blk_idx_tr<D2>(a, e, active, ta, tb, 2 * bf, Pf, sf2);
+    blk_x_tr<D0>(a, active, ta, tb, sf0, u0);
+    blk_x_tr<D1>(a, active, ta, tb, sf1, u1);
+    blk_x_tr<D2>(a, active, ta, tb, sf2, u2);
+    double o[kMaxN];
+    blk_apply_tr<D0, N1>(lane_ok, ta, tb, sm, u0, o, false, Io, Ic, Ic);
+    if (KIND != 1) blk_store_tr<D0>(a, e, active, ta, tb, 0, Pc, o);
+    blk_apply_tr<D1, N1>(lane_ok, ta, tb, sm, u1, o, KIND == 1, Ic, Io, Ic);
+    if (KIND != 1) blk_store_tr<D1>(a, e, active, ta, tb, bc, Pc, o);
+    blk_apply_tr<D2, N1>(lane_ok, ta, tb, sm, u2, o, KIND == 1, Ic, Ic, Io);
+    blk_store_tr<D2>(a, e, active, ta, tb, 2 * bc, Pc, o);  // (gradient: the sum of the three blocks, stored once)
   }
 }
 
