@@ -130,6 +130,25 @@ std::vector<double> Comm::SetupGather(double mine, hipStream_t s) {
   return v;
 }
 
+int Comm::RanksOnMyDevice(hipStream_t s) {
+  if (ranks_on_device_ > 0) return ranks_on_device_;
+  if (size_ == 1 || local_ || !PeerReady() || size_ > kMaxReduceSetup) {
+    // one rank; the threads of an in-process group (one device by construction); no set-up channel: assume the worst
+    ranks_on_device_ = (size_ == 1) ? 1 : size_;
+    return ranks_on_device_;
+  }
+  int dev = 0;
+  hipDeviceProp_t prop{};
+  double id = -1.0;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    id = (double)(((long long)prop.pciDomainID << 24) | ((long long)(prop.pciBusID & 0xff) << 16) | ((long long)(prop.pciDeviceID & 0xff) << 8)) + 1.0;
+  const std::vector<double> ids = SetupGather(id, s);
+  int same = 0;
+  for (const double v : ids) same += (id < 0.0 || v < 0.0 || v == id) ? 1 : 0;  // (an unknown identity counts as shared)
+  ranks_on_device_ = std::max(1, same);
+  return ranks_on_device_;
+}
+
 std::vector<double> Comm::AllGatherVHost(const std::vector<double> &mine, std::vector<long long> *offsets) {
   PA_REQUIRE(PeerReady() && size_ > 1, "all-gather-v over the peer transport: not connected");
   const std::vector<double> cnt = SetupGather((double)mine.size(), setup_stream_);
@@ -927,6 +946,7 @@ struct Halo::PeerPlan {
   int32_t *d_rptr = nullptr, *d_rpos = nullptr;
   unsigned long long *d_err = nullptr;
   int slot = -1;                    // descriptor slot (given back with the plan)
+  int ranks_on_device = 1;          // Comm::RanksOnMyDevice at set-up: the share of the device a resident grid may take
   size_t off[3] = {0, 0, 0}, bytes[3] = {0, 0, 0};  // my arena blocks: mailboxes of P / P^T, flags
 };
 
@@ -989,6 +1009,11 @@ void Halo::PeerSetup(const int32_t *send_idx) {
   }
   c.halo_live_[(size_t)slot] = 1;
   pp->slot = slot;
+  try {
+    pp->ranks_on_device = c.RanksOnMyDevice(c.setup_stream_);  // (collective at its first call: every rank is here)
+  } catch (...) {
+    pp->ranks_on_device = c.Size();
+  }
   peer_ = pp;
   try {  // (a throwing constructor runs no destructor: the slot and the blocks go back here)
   pp->nnbr = nn;
@@ -1149,7 +1174,9 @@ void Halo::RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) 
         prop.multiProcessorCount = 32;
       return per_cu * prop.multiProcessorCount;
     }();
-    const int cap = std::max(1, resident / std::max(1, comm_->Size()));
+    // (this rank's share: the ranks on THIS device -- one per GPU on the target node, where nothing has to be shared; a
+    // rehearsal or a partitioned device puts several on one.  Determined at the plan's set-up, PeerSetup.)
+    const int cap = std::max(1, resident / std::max(1, p.ranks_on_device));
     hipLaunchKernelGGL(k_peer_restrict_direct, dim3(std::min(cap, std::max(mb, sb))), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, nrecv_,
                        GhostOut(), p.mb[1], nsend_, d_y, p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, d_mask);
     PA_HIP(hipGetLastError());

@@ -73,6 +73,7 @@ class Comm {
   std::vector<char *> remote_;         // [size] arena of rank r as mapped here (remote_[rank_] == arena_); empty: not connected
   std::vector<char> remote_ipc_;       // [size] 1: opened with hipIpcOpenMemHandle (to be closed)
   int next_halo_ = 0;                  // halo plans made so far (collective, monotonic: plan id)
+  int ranks_on_device_ = 0;            // RanksOnMyDevice (0: not determined yet)
   std::vector<char> halo_live_;        // [kMaxHalos] descriptor slot in use
   std::vector<std::pair<size_t, size_t>> arena_free_;  // {offset, bytes} blocks given back by destroyed plans
   std::vector<std::pair<size_t, size_t>> arena_quarantine_;  // ... since the last set-up barrier (not yet reusable)
@@ -133,6 +134,9 @@ public:
   void Barrier(hipStream_t s);
   // barrier that also tells every rank one number of every other rank (set-up channel of the peer transport; size > 1)
   std::vector<double> SetupGather(double mine, hipStream_t s);
+  // how many ranks of this communicator run on the same device as this one (PCI identity exchanged once over the set-up
+  // channel; in-process groups share one device by construction).  Collective at its first call (Halo set-up).
+  int RanksOnMyDevice(hipStream_t s);
   // Set-up time all-gather-v of host arrays over the peer transport (PeerReady): every rank stages its piece, a chunk at a time,
   // in a block of its own arena and reads the other ranks' chunks through their mappings -- each value crosses once per reader,
   // where the sum of zero-padded global arrays moved size times as much through 4096-value messages.  Returns the pieces in rank

@@ -209,7 +209,16 @@ ReplicatedCoarseSolver::ReplicatedCoarseSolver(const Context &ctx, const Operato
   // hierarchies, one owner -> ghost exchange per product) unless PALACE_AMD_COARSE_SOLVE=replicated (read at construction): the
   // whole cycle on the gathered problem on every rank, rounds 3-4
   const char *mode = std::getenv("PALACE_AMD_COARSE_SOLVE");
-  const bool distributed = !(mode && std::string(mode) == "replicated");
+  bool distributed = !(mode && std::string(mode) == "replicated");
+  {
+    // the mode is read per process: agree on it before branching (a rank with a different environment would skip the collective
+    // halo constructions of the distributed form and the others would wait for it until the peer time-out) -- replicated if ANY
+    // rank asks for it
+    std::vector<double> votes((size_t)size, 0.0);
+    votes[(size_t)rank] = distributed ? 0.0 : 1.0;
+    GlobalSumHost(ctx, votes);
+    for (const double v : votes) distributed = distributed && v == 0.0;
+  }
   const std::vector<int> ioff(off.begin(), off.end());
   if (G) {
     // ---- the lowest-order discrete gradient in global numbers: two applications of the (multi-rank) operator to the global

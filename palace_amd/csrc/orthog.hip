@@ -82,15 +82,30 @@ __device__ __forceinline__ void grid_reduce(double (&v)[NV], int nv, double *__r
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < kBlk / 64; q++) s += sm[threadIdx.x][q];
+#if defined(__gfx90a__) || defined(__gfx942__) || defined(__gfx950__)
+    // ARCHITECTURE ASSUMPTION (gfx9 family: one in-order counter, vmcnt, covers loads AND stores, and agent-scope stores are
+    // written through to the level every XCD sees): waiting for the relaxed store to be performed orders it before the ticket
+    // below WITHOUT a release fence -- a fence writes the whole L2 back, once per block: measured 100 us per launch.  The
+    // run-to-run bit-reproducibility test (tests/test_orthog_gpu.py) is the gate.
     __hip_atomic_store(&partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (agent-scope stores go through to the level every XCD sees; waiting for them to be performed orders them before the
-    // ticket below WITHOUT a release fence -- a fence writes the whole L2 back, once per block: measured 100 us per launch)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    // any other target (separate store counter, other cache policies): the HIP memory model's release / acquire pair
+    __hip_atomic_store(&partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
   }
   __syncthreads();
+#if defined(__gfx90a__) || defined(__gfx942__) || defined(__gfx950__)
   if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   __syncthreads();
   if (ticket != gridDim.x - 1) return;
+#if !(defined(__gfx90a__) || defined(__gfx942__) || defined(__gfx950__))
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   for (int k = 0; k < nv; k++) {
     double s = 0.0;
     for (int b = threadIdx.x; b < (int)gridDim.x; b += kBlk)
