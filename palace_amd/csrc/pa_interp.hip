@@ -429,16 +429,45 @@ __global__ __launch_bounds__(256) void interp_kernel_s(const InterpArgs a) {
 }
 
 // coarse E^T as a gather (same scheme as pa::et_gather_kernel)
-__global__ void k_gather(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
-                         const double *__restrict__ ye, double *__restrict__ y) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= n) return;
-  double s = 0.0;
-  for (int k = tptr[d]; k < tptr[d + 1]; k++) {
-    const int t = tent[k];
-    s += t >= 0 ? ye[t] : -ye[-1 - t];
+// (round 6: four dofs per thread, a block width apart, and the first four copies of each requested side by side -- one dof per
+// thread with the chain tptr -> tent -> ye walked copy by copy left the kernel waiting on one load at a time: 43 us for the 3M
+// coarse dofs of the p3 -> p2 restriction.  Same copies in the same order: same bits.)
+constexpr int kGatherDofs = 4;
+__global__ __launch_bounds__(256) void k_gather(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                                                const double *__restrict__ ye, double *__restrict__ y) {
+  const int d0 = blockIdx.x * (256 * kGatherDofs) + threadIdx.x;
+  int b[kGatherDofs], e[kGatherDofs], t[kGatherDofs][4];
+  double v[kGatherDofs][4];
+#pragma unroll
+  for (int u = 0; u < kGatherDofs; u++) {
+    const int d = d0 + 256 * u;
+    b[u] = d < n ? tptr[d] : 0, e[u] = d < n ? tptr[d + 1] : 0;
   }
-  y[d] = s;
+#pragma unroll
+  for (int u = 0; u < kGatherDofs; u++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) t[u][q] = b[u] + q < e[u] ? tent[b[u] + q] : 0;
+#pragma unroll
+  for (int u = 0; u < kGatherDofs; u++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int tt = t[u][q];
+      const double w = b[u] + q < e[u] ? ye[tt >= 0 ? tt : -1 - tt] : 0.0;
+      v[u][q] = tt >= 0 ? w : -w;
+    }
+#pragma unroll
+  for (int u = 0; u < kGatherDofs; u++) {
+    const int d = d0 + 256 * u;
+    if (d >= n) continue;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) s += v[u][q];  // (an absent copy adds an exact zero)
+    for (int k = b[u] + 4; k < e[u]; k++) {
+      const int tt = tent[k];
+      s += tt >= 0 ? ye[tt] : -ye[-1 - tt];
+    }
+    y[d] = s;
+  }
 }
 
 std::vector<int32_t> signed_lex_index(const pa_restriction_desc &r, const pa_basis_desc &b, int P) {
@@ -662,7 +691,7 @@ public:
         PA_HIP(hipMemsetAsync(lr_.Data() + nt_r_, 0, sizeof(double) * (size_t)(nl_r_ - nt_r_), c.stream));
     }
     launch<true>(serial ? x.Data() : lr_.Data(), nullptr);
-    hipLaunchKernelGGL(k_gather, dim3((nl_d_ + 255) / 256), dim3(256), 0, c.stream, nl_d_, d_tptr_, d_tent_, d_ye_,
+    hipLaunchKernelGGL(k_gather, dim3((nl_d_ + 256 * kGatherDofs - 1) / (256 * kGatherDofs)), dim3(256), 0, c.stream, nl_d_, d_tptr_, d_tent_, d_ye_,
                        serial ? y.Data() : ld_.Data());
     PA_HIP(hipGetLastError());
     if (serial) return;
@@ -803,7 +832,7 @@ public:
     PA_REQUIRE(x.Size() == nt_f_ && y.Size() == nt_c_, "size mismatch in restriction");
     if (!halo_c_ && nt_c_ == nl_c_ && nt_f_ == nl_f_) {
       launch<true>(x.Data(), nullptr);
-      hipLaunchKernelGGL(k_gather, dim3((nl_c_ + 255) / 256), dim3(256), 0, c.stream, nl_c_, d_tptr_c_, d_tent_c_,
+      hipLaunchKernelGGL(k_gather, dim3((nl_c_ + 256 * kGatherDofs - 1) / (256 * kGatherDofs)), dim3(256), 0, c.stream, nl_c_, d_tptr_c_, d_tent_c_,
                          d_ye_c_, y.Data());
       PA_HIP(hipGetLastError());
       return;
@@ -813,7 +842,7 @@ public:
     if (nl_f_ > nt_f_)
       PA_HIP(hipMemsetAsync(lf_.Data() + nt_f_, 0, sizeof(double) * (size_t)(nl_f_ - nt_f_), c.stream));
     launch<true>(lf_.Data(), nullptr);
-    hipLaunchKernelGGL(k_gather, dim3((nl_c_ + 255) / 256), dim3(256), 0, c.stream, nl_c_, d_tptr_c_, d_tent_c_,
+    hipLaunchKernelGGL(k_gather, dim3((nl_c_ + 256 * kGatherDofs - 1) / (256 * kGatherDofs)), dim3(256), 0, c.stream, nl_c_, d_tptr_c_, d_tent_c_,
                        d_ye_c_, lc_.Data());
     PA_HIP(hipGetLastError());
     if (halo_c_) halo_c_->RestrictAdd(lc_.Data(), c.stream);
