@@ -228,10 +228,13 @@ std::vector<int> aggregate_impl(const HostCsr &A, double theta, int &num_aggrega
   std::vector<int> agg((size_t)n, -1);
   // rows without a strong off-diagonal entry (eliminated essential dofs: a lone diagonal) stay out of the coarse problem:
   // the smoother solves them, and carried along they would form one aggregate each and stop the coarsening
+  // (decided with the UNMASKED strength test: a row whose strong neighbours all belong to other blocks -- an interface row of a
+  // thin partition -- is not isolated; it founds or joins an aggregate of its own block in passes 1-3, a singleton at worst, so the
+  // coarse space does not lose rows because of where the partition cuts.  Round-5 advisor finding.)
   std::vector<char> isolated((size_t)n, 1);
   for (int i = 0; i < n; i++)
     for (int a = A.rowptr[i]; a < A.rowptr[i + 1] && isolated[i]; a++)
-      if (A.col[a] != i && strong(A.val[a], d[i], d[A.col[a]], theta, i, A.col[a])) isolated[i] = 0;
+      if (A.col[a] != i && palace::amg::strong(A.val[a], d[i], d[A.col[a]], theta)) isolated[i] = 0;
   int na = 0;
   // pass 1: a node whose strong neighbours are all free founds an aggregate with them
   for (int i = 0; i < n; i++) {

@@ -432,9 +432,11 @@ __global__ __launch_bounds__(256) void interp_kernel_s(const InterpArgs a) {
 // (round 6: four dofs per thread, a block width apart, and the first four copies of each requested side by side -- one dof per
 // thread with the chain tptr -> tent -> ye walked copy by copy left the kernel waiting on one load at a time: 43 us for the 3M
 // coarse dofs of the p3 -> p2 restriction.  Same copies in the same order: same bits.)
-constexpr int kGatherDofs = 4;
-__global__ __launch_bounds__(256) void k_gather(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
-                                                const double *__restrict__ ye, double *__restrict__ y) {
+// (small vectors -- the coarse levels of small problems, where the launch itself is the cost -- keep one dof per thread: more
+// blocks in flight)
+template <int kGatherDofs>
+__global__ __launch_bounds__(256) void k_gather_t(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                                                  const double *__restrict__ ye, double *__restrict__ y) {
   const int d0 = blockIdx.x * (256 * kGatherDofs) + threadIdx.x;
   int b[kGatherDofs], e[kGatherDofs], t[kGatherDofs][4];
   double v[kGatherDofs][4];
@@ -468,6 +470,12 @@ __global__ __launch_bounds__(256) void k_gather(const int n, const int32_t *__re
     }
     y[d] = s;
   }
+}
+void launch_k_gather(const int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y, hipStream_t s) {
+  if (n >= (1 << 18))
+    hipLaunchKernelGGL(k_gather_t<4>, dim3((n + 1023) / 1024), dim3(256), 0, s, n, tptr, tent, ye, y);
+  else
+    hipLaunchKernelGGL(k_gather_t<1>, dim3((n + 255) / 256), dim3(256), 0, s, n, tptr, tent, ye, y);
 }
 
 std::vector<int32_t> signed_lex_index(const pa_restriction_desc &r, const pa_basis_desc &b, int P) {
@@ -691,8 +699,7 @@ public:
         PA_HIP(hipMemsetAsync(lr_.Data() + nt_r_, 0, sizeof(double) * (size_t)(nl_r_ - nt_r_), c.stream));
     }
     launch<true>(serial ? x.Data() : lr_.Data(), nullptr);
-    hipLaunchKernelGGL(k_gather, dim3((nl_d_ + 256 * kGatherDofs - 1) / (256 * kGatherDofs)), dim3(256), 0, c.stream, nl_d_, d_tptr_, d_tent_, d_ye_,
-                       serial ? y.Data() : ld_.Data());
+    launch_k_gather(nl_d_, d_tptr_, d_tent_, d_ye_, serial ? y.Data() : ld_.Data(), c.stream);
     PA_HIP(hipGetLastError());
     if (serial) return;
     if (halo_d_) halo_d_->RestrictAdd(ld_.Data(), c.stream);
@@ -832,8 +839,7 @@ public:
     PA_REQUIRE(x.Size() == nt_f_ && y.Size() == nt_c_, "size mismatch in restriction");
     if (!halo_c_ && nt_c_ == nl_c_ && nt_f_ == nl_f_) {
       launch<true>(x.Data(), nullptr);
-      hipLaunchKernelGGL(k_gather, dim3((nl_c_ + 256 * kGatherDofs - 1) / (256 * kGatherDofs)), dim3(256), 0, c.stream, nl_c_, d_tptr_c_, d_tent_c_,
-                         d_ye_c_, y.Data());
+      launch_k_gather(nl_c_, d_tptr_c_, d_tent_c_, d_ye_c_, y.Data(), c.stream);
       PA_HIP(hipGetLastError());
       return;
     }
@@ -842,8 +848,7 @@ public:
     if (nl_f_ > nt_f_)
       PA_HIP(hipMemsetAsync(lf_.Data() + nt_f_, 0, sizeof(double) * (size_t)(nl_f_ - nt_f_), c.stream));
     launch<true>(lf_.Data(), nullptr);
-    hipLaunchKernelGGL(k_gather, dim3((nl_c_ + 256 * kGatherDofs - 1) / (256 * kGatherDofs)), dim3(256), 0, c.stream, nl_c_, d_tptr_c_, d_tent_c_,
-                       d_ye_c_, lc_.Data());
+    launch_k_gather(nl_c_, d_tptr_c_, d_tent_c_, d_ye_c_, lc_.Data(), c.stream);
     PA_HIP(hipGetLastError());
     if (halo_c_) halo_c_->RestrictAdd(lc_.Data(), c.stream);
     Vector tc(lc_.Data(), nt_c_);

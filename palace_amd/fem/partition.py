@@ -287,10 +287,14 @@ class SlabProblem:
                                   n_true=self.n_true[-1], halo=self.halos[-1])
 
     def pcg_gmg_solver(self, max_it=50, rel_tol=0.0, eps_r=2.08, coarse_tol=1e-2, coarse_max_it=8, hiptmair=False,
-                       coarse="cg", coarse_assembled=True, singular=False):
+                       coarse="cg", coarse_assembled=True, singular=False, level_rule="fine"):
         """PCG on (K + M) with the p-multigrid preconditioner configured as the reference does for
         p = 3 (iodata.cpp:533-564: 4th-kind Chebyshev of order max(2p, 4), 1 smoothing step, 1 V-cycle);
-        level 0 is solved by Jacobi-PCG (the reference uses AMS from HYPRE there, linalg/ams.cpp)."""
+        level 0 is solved by Jacobi-PCG (the reference uses AMS from HYPRE there, linalg/ams.cpp).
+        level_rule: "fine" -- the p-coarsened levels reuse the fine level's quadrature data, as the reference's
+        CeedOperatorCoarsen does (fem/libceed/operator.cpp:528-546; a 54-dof order-2 element then streams 64 points); "own" --
+        every level is assembled on the rule of its own order (p_l + 1 points per direction: 27 for order 2).  NOT the
+        reference's behaviour: an option, measured beside it (a different, equally symmetric positive definite, preconditioner)."""
         import torch
 
         from .. import ceed, linalg
@@ -299,7 +303,13 @@ class SlabProblem:
         mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([eps_r])])
         curl = ceed.coefficient_context(3)
         fine = ceed.curlcurlmass_operator(self.geom, self.spaces[-1], mass, curl)
-        local = [fine.coarsen(self.geom, s) for s in self.spaces[:-1]] + [fine]
+        if level_rule == "own":
+            assert self.world == 1 and not hiptmair, "level_rule='own': one rank, plain smoothers"
+            geoms = [ceed.GeomFactorData(self.mesh, s.p + 1) for s in self.spaces[:-1]]
+            local = [ceed.curlcurlmass_operator(g, s, mass, curl) for g, s in zip(geoms, self.spaces[:-1])] + [fine]
+            self._keep.append(geoms)
+        else:
+            local = [fine.coarsen(self.geom, s) for s in self.spaces[:-1]] + [fine]
         A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE, n_true=nt, halo=h)
              for op, e, nt, h in zip(local, self.ess, self.n_true, self.halos)]
         if coarse_assembled and len(A) > 1:

@@ -2,6 +2,11 @@
 (PALACE_AMD_PRICE_BLOCK=4 | 8: wrong results, right bytes -- see build_stream): the headline ParOperator::Mult at the bench size.
   for g in 0 4 8; do PALACE_AMD_PRICE_BLOCK=$g python scripts/price_block.py; done"""
 import os, sys
+# (the pricing switches live in the ABLATION library only -- `make -C palace_amd/csrc ablate` -- never in the product library)
+_abl = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "palace_amd", "lib", "libpalace_amd_ablate.so")
+if not os.path.exists(_abl):
+    sys.exit("build the ablation library first: make -C palace_amd/csrc ablate")
+os.environ.setdefault("PALACE_AMD_LIB", _abl)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from palace_amd import linalg

@@ -13,6 +13,12 @@ import ctypes as C
 import os
 import sys
 
+# (pa_debug_apply_phase lives in the ABLATION library only -- `make -C palace_amd/csrc ablate` -- never in the product library)
+_abl = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "palace_amd", "lib", "libpalace_amd_ablate.so")
+if not os.path.exists(_abl):
+    sys.exit("build the ablation library first: make -C palace_amd/csrc ablate")
+os.environ.setdefault("PALACE_AMD_LIB", _abl)
+
 sys.path.insert(0, os.getcwd())
 import torch
 

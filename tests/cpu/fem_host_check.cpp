@@ -210,6 +210,19 @@ int main() {
     const Hierarchy h = SetupBlocks(A, off, loff, 10, 60);
     const Hierarchy hg = Setup(A, 10, 60);
     std::printf("amg_blocks %d %d %d %d\n", confined, (int)h.A.size(), h.A.back().nrows, (int)hg.A.size());
+    {  // thin partitions (round-5 advisor finding): strong ties along y only, row blocks of one and of two grid lines -- every strong
+       // neighbour of a row of a one-line block belongs to another block.  No row may drop out of the coarse space for that.
+      const HostCsr T = grid_laplacian(24, 0.05, 1.0);
+      int dropped[2] = {0, 0}, nagg[2] = {0, 0};
+      for (int lines = 1; lines <= 2; lines++) {
+        std::vector<int> toff;
+        for (int r = 0; r <= 24 * 24; r += 24 * lines) toff.push_back(r);
+        std::vector<int> taoff;
+        const std::vector<int> tagg = AggregateBlocks(T, 0.08, toff, nagg[lines - 1], taoff);
+        for (int a : tagg) dropped[lines - 1] += a < 0;
+      }
+      std::printf("amg_thin_blocks %d %d %d %d\n", dropped[0], nagg[0], dropped[1], nagg[1]);
+    }
     double worst = 0.0;
     long long ghosts = 0, plan_mismatch = 0, plan_entries = 0;
     const size_t nl = h.A.size();

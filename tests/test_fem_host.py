@@ -36,7 +36,7 @@ def dumped(tmp_path_factory):
         k, *v = line.split()
         if k == "amg_threads_checksum":  # (compared as text above)
             continue
-        if k.startswith("orders") or k.startswith("amg_levels") or k in ("q1d", "mat_dims", "amg_small", "amg_blocks"):
+        if k.startswith("orders") or k.startswith("amg_levels") or k in ("q1d", "mat_dims", "amg_small", "amg_blocks", "amg_thin_blocks"):
             vals[k] = [int(t) for t in v]
         else:
             vals[k] = np.array([struct.unpack("<d", struct.pack("<Q", int(t, 16)))[0] for t in v])
@@ -153,6 +153,10 @@ def test_hierarchy_of_the_distributed_solve(dumped):
     assert worst < 1e-13 and ghosts > 0
     # the ranks' exchange plans, each derived on its own: every entry a rank sends lands in the slot of that entry on the receiver
     assert plan_mismatch == 0 and plan_entries > 0
+    # thin row blocks whose strong ties all cross the partition: nobody leaves the coarse space (one line per block: singletons;
+    # two lines: pairs along the strong direction)
+    d1, n1, d2, n2 = dumped["amg_thin_blocks"]
+    assert d1 == 0 and d2 == 0 and n1 == 24 * 24 and n2 <= 24 * 24 // 2 + 24, (d1, n1, d2, n2)
     fb, fg = dumped["amg_factors_blocks"], dumped["amg_factors_global"]
     mean = lambda f: np.exp(np.log(f[3:]).mean())  # noqa: E731
     assert fb.max() < 0.65 and mean(fb) < 0.5 and mean(fb) < mean(fg) + 0.1, (fb, fg)
