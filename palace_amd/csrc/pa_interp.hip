@@ -515,13 +515,31 @@ struct DenseInterpArgs {
 };
 
 constexpr int kDenseInterpMaxP = 256;
+constexpr int kDenseInterpWaves = 4;
 
+// Round 6: four waves per workgroup, each walking elements with a grid stride, and the element matrices staged in LDS once per
+// workgroup when they fit (lds_mats > 0: all `nmat` matrices; 16 KB for the 45 x 45 matrix of order-3 Nedelec tetrahedra).  The
+// first form launched one 64-lane workgroup per element and read the matrix through the vector cache for every element: 16 KB
+// of cache traffic for 0.7 KB of vector data (config 3's solver loop: 10 % of its device time in these two kernels).
 template <bool TRANSPOSE>
-__global__ __launch_bounds__(64) void dense_interp_kernel(const DenseInterpArgs a) {
-  __shared__ double s0[kDenseInterpMaxP], s1[kDenseInterpMaxP];
-  const int e = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kDenseInterpWaves) void dense_interp_kernel(const DenseInterpArgs a, const int lds_mats, const int pmax) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (rows of the LDS copy an odd number of doubles apart: lane j reads row j in the forward product)
+  const int ms = lds_mats > 0 ? (a.Pd | 1) : a.Pd, msz = a.Pr * ms;
+  double *sM = dsm;                                                  // [lds_mats][Pr][Pd | 1]
+  double *s0 = dsm + (size_t)lds_mats * msz + (size_t)wave * 2 * pmax, *s1 = s0 + pmax;
+  if (lds_mats > 0) {
+    for (int k = threadIdx.x; k < lds_mats * a.Pr * a.Pd; k += 64 * kDenseInterpWaves) {
+      const int r = k / a.Pd, c = k - r * a.Pd;  // (r runs over all rows of all matrices)
+      sM[(size_t)r * ms + c] = a.M[k];
+    }
+    __syncthreads();
+  }
+  for (int e = blockIdx.x * kDenseInterpWaves + wave; e < a.ne; e += gridDim.x * kDenseInterpWaves) {
   const int32_t *od = a.off_d + (size_t)e * a.Pd, *orr = a.off_r + (size_t)e * a.Pr;
-  const double *Me = a.M + (a.mat_id ? (size_t)a.mat_id[e] * a.Pr * a.Pd : 0);
+  const int mid = a.mat_id ? a.mat_id[e] : 0;
+  const double *Me = lds_mats > 0 ? sM + (size_t)mid * msz : a.M + (size_t)mid * msz;
   if (!TRANSPOSE) {
     for (int i = lane; i < a.Pd; i += 64) {
       double v = a.x[od[i]];
@@ -539,7 +557,7 @@ __global__ __launch_bounds__(64) void dense_interp_kernel(const DenseInterpArgs 
       wsync();
     }
     for (int j = lane; j < a.Pr; j += 64) {  // v = M u
-      const double *row = Me + (size_t)j * a.Pd;
+      const double *row = Me + (size_t)j * ms;
       double v = 0.0;
       for (int i = 0; i < a.Pd; i++) v += row[i] * s0[i];
       s1[j] = v;
@@ -578,7 +596,7 @@ __global__ __launch_bounds__(64) void dense_interp_kernel(const DenseInterpArgs 
     }
     for (int i = lane; i < a.Pd; i += 64) {  // u = M^T v
       double v = 0.0;
-      for (int j = 0; j < a.Pr; j++) v += Me[(size_t)j * a.Pd + i] * s0[j];
+      for (int j = 0; j < a.Pr; j++) v += Me[(size_t)j * ms + i] * s0[j];
       s1[i] = v;
     }
     wsync();
@@ -595,6 +613,8 @@ __global__ __launch_bounds__(64) void dense_interp_kernel(const DenseInterpArgs 
       a.ye_d[(size_t)e * a.Pd + i] = w;
     }
   }
+  wsync();  // (the wave's strips are reused by its next element)
+  }
 }
 
 class DenseInterpOperator : public Operator {
@@ -607,10 +627,18 @@ class DenseInterpOperator : public Operator {
   uint8_t *d_mat_id_ = nullptr;
   mutable Vector ld_, lr_;
 
+  int nmat_ = 1;
   template <bool TR>
   void launch(const double *x, double *y) const {
     DenseInterpArgs a{ne_, Pd_, Pr_, d_off_d_, d_off_r_, d_sgn_d_, d_sgn_r_, d_T_d_, d_B_r_, d_M_, d_mat_id_, x, y, d_ye_};
-    hipLaunchKernelGGL((dense_interp_kernel<TR>), dim3(ne_), dim3(64), 0, ctx_->stream, a);
+    const int pmax = (std::max(Pd_, Pr_) + 1) & ~1;
+    // the matrices in LDS when all of them fit beside the waves' strips in 48 KB (eight such workgroups per CU)
+    const size_t strips = sizeof(double) * (size_t)kDenseInterpWaves * 2 * pmax, mats = sizeof(double) * (size_t)nmat_ * Pr_ * (Pd_ | 1);
+    const int lds_mats = strips + mats <= 48 * 1024 ? nmat_ : 0;
+    const size_t lds = strips + (lds_mats ? mats : 0);
+    // eight elements per wave (the matrix copy is amortised over 32 elements of a workgroup), every CU busy
+    const int grid = std::max(1, std::min((ne_ + kDenseInterpWaves - 1) / kDenseInterpWaves, std::max(2048, (ne_ + 8 * kDenseInterpWaves - 1) / (8 * kDenseInterpWaves))));
+    hipLaunchKernelGGL((dense_interp_kernel<TR>), dim3(grid), dim3(64 * kDenseInterpWaves), lds, ctx_->stream, a, lds_mats, pmax);
     PA_HIP(hipGetLastError());
   }
   static int8_t *signs(const pa_restriction_desc &r, hipStream_t s) {
@@ -666,6 +694,7 @@ public:
     if (rd.curl_orients) d_T_d_ = pa::dev_upload(rd.curl_orients, 3 * nd, ctx.stream);
     if (rr.curl_orients) d_B_r_ = pa::dev_upload(rr.curl_orients, 3 * nr, ctx.stream);
     d_M_ = pa::dev_upload(M, (size_t)nmat * Pr_ * Pd_, ctx.stream);
+    nmat_ = nmat;
     if (mat_id) d_mat_id_ = pa::dev_upload(mat_id, (size_t)ne_, ctx.stream);
     ld_.SetSize(nl_d_), lr_.SetSize(nl_r_);
   }
