@@ -438,37 +438,41 @@ template <int kGatherDofs>
 __global__ __launch_bounds__(256) void k_gather_t(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
                                                   const double *__restrict__ ye, double *__restrict__ y) {
   const int d0 = blockIdx.x * (256 * kGatherDofs) + threadIdx.x;
-  int b[kGatherDofs], e[kGatherDofs], t[kGatherDofs][4];
-  double v[kGatherDofs][4];
+  int b[kGatherDofs], e[kGatherDofs];
+  double s[kGatherDofs];
+  int longest = 0;
 #pragma unroll
   for (int u = 0; u < kGatherDofs; u++) {
     const int d = d0 + 256 * u;
     b[u] = d < n ? tptr[d] : 0, e[u] = d < n ? tptr[d + 1] : 0;
+    s[u] = 0.0;
+    longest = max(longest, e[u] - b[u]);
   }
+  // four copies of each dof at a time, side by side; a dof's copies are added in their order (an absent copy adds an exact zero)
+  for (int q0 = 0; q0 < longest; q0 += 4) {
+    int t[kGatherDofs][4];
+    double v[kGatherDofs][4];
 #pragma unroll
-  for (int u = 0; u < kGatherDofs; u++)
+    for (int u = 0; u < kGatherDofs; u++)
 #pragma unroll
-    for (int q = 0; q < 4; q++) t[u][q] = b[u] + q < e[u] ? tent[b[u] + q] : 0;
+      for (int q = 0; q < 4; q++) t[u][q] = b[u] + q0 + q < e[u] ? tent[b[u] + q0 + q] : 0;
 #pragma unroll
-  for (int u = 0; u < kGatherDofs; u++)
+    for (int u = 0; u < kGatherDofs; u++)
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int tt = t[u][q];
-      const double w = b[u] + q < e[u] ? ye[tt >= 0 ? tt : -1 - tt] : 0.0;
-      v[u][q] = tt >= 0 ? w : -w;
-    }
+      for (int q = 0; q < 4; q++) {
+        const int tt = t[u][q];
+        const double w = b[u] + q0 + q < e[u] ? ye[tt >= 0 ? tt : -1 - tt] : 0.0;
+        v[u][q] = tt >= 0 ? w : -w;
+      }
+#pragma unroll
+    for (int u = 0; u < kGatherDofs; u++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) s[u] += v[u][q];
+  }
 #pragma unroll
   for (int u = 0; u < kGatherDofs; u++) {
     const int d = d0 + 256 * u;
-    if (d >= n) continue;
-    double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) s += v[u][q];  // (an absent copy adds an exact zero)
-    for (int k = b[u] + 4; k < e[u]; k++) {
-      const int tt = tent[k];
-      s += tt >= 0 ? ye[tt] : -ye[-1 - tt];
-    }
-    y[d] = s;
+    if (d < n) y[d] = s[u];
   }
 }
 void launch_k_gather(const int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y, hipStream_t s) {
@@ -521,10 +525,21 @@ constexpr int kDenseInterpWaves = 4;
 // workgroup when they fit (lds_mats > 0: all `nmat` matrices; 16 KB for the 45 x 45 matrix of order-3 Nedelec tetrahedra).  The
 // first form launched one 64-lane workgroup per element and read the matrix through the vector cache for every element: 16 KB
 // of cache traffic for 0.7 KB of vector data (config 3's solver loop: 10 % of its device time in these two kernels).
-template <bool TRANSPOSE>
+// NR > 0 (one matrix, P <= NR on the contracted side and <= 64 on the other): every lane keeps ITS row (forward) or column (transpose)
+// of the matrix in NR registers for all the elements its wave walks; per element only the input strip is read from LDS, one broadcast
+// per entry.  (With the matrix in LDS the product read 2 x 45 x 45 doubles per order-3 Nedelec element: the LDS pipe was the bound,
+// ~190 us for 280k tetrahedra either way.)  NR == 0: the matrix from LDS / memory, any size, one of `nmat` per element.
+template <bool TRANSPOSE, int NR = 0>
 __global__ __launch_bounds__(64 * kDenseInterpWaves) void dense_interp_kernel(const DenseInterpArgs a, const int lds_mats, const int pmax) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double mreg[NR > 0 ? NR : 1];
+  if (NR > 0) {
+    const int nk = TRANSPOSE ? a.Pr : a.Pd, nl = TRANSPOSE ? a.Pd : a.Pr;  // contracted / lane-owned side
+#pragma unroll
+    for (int k = 0; k < NR; k++)
+      mreg[k] = (k < nk && lane < nl) ? (TRANSPOSE ? a.M[(size_t)k * a.Pd + lane] : a.M[(size_t)lane * a.Pd + k]) : 0.0;
+  }
   // (rows of the LDS copy an odd number of doubles apart: lane j reads row j in the forward product)
   const int ms = lds_mats > 0 ? (a.Pd | 1) : a.Pd, msz = a.Pr * ms;
   double *sM = dsm;                                                  // [lds_mats][Pr][Pd | 1]
@@ -556,11 +571,19 @@ __global__ __launch_bounds__(64 * kDenseInterpWaves) void dense_interp_kernel(co
       for (int i = lane; i < a.Pd; i += 64) s0[i] = s1[i];
       wsync();
     }
-    for (int j = lane; j < a.Pr; j += 64) {  // v = M u
-      const double *row = Me + (size_t)j * ms;
+    if (NR > 0) {  // v = M u: the lane's row from registers, u broadcast from the strip
       double v = 0.0;
-      for (int i = 0; i < a.Pd; i++) v += row[i] * s0[i];
-      s1[j] = v;
+#pragma unroll
+      for (int i = 0; i < NR; i++)
+        if (i < a.Pd) v += mreg[i] * s0[i];
+      if (lane < a.Pr) s1[lane] = v;
+    } else {
+      for (int j = lane; j < a.Pr; j += 64) {  // v = M u
+        const double *row = Me + (size_t)j * ms;
+        double v = 0.0;
+        for (int i = 0; i < a.Pd; i++) v += row[i] * s0[i];
+        s1[j] = v;
+      }
     }
     wsync();
     const int8_t *B = a.B_r ? a.B_r + 3 * (size_t)e * a.Pr : nullptr;
@@ -594,10 +617,18 @@ __global__ __launch_bounds__(64 * kDenseInterpWaves) void dense_interp_kernel(co
       for (int j = lane; j < a.Pr; j += 64) s0[j] = s1[j];
       wsync();
     }
-    for (int i = lane; i < a.Pd; i += 64) {  // u = M^T v
+    if (NR > 0) {  // u = M^T v: the lane's column from registers
       double v = 0.0;
-      for (int j = 0; j < a.Pr; j++) v += Me[(size_t)j * ms + i] * s0[j];
-      s1[i] = v;
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        if (j < a.Pr) v += mreg[j] * s0[j];
+      if (lane < a.Pd) s1[lane] = v;
+    } else {
+      for (int i = lane; i < a.Pd; i += 64) {  // u = M^T v
+        double v = 0.0;
+        for (int j = 0; j < a.Pr; j++) v += Me[(size_t)j * ms + i] * s0[j];
+        s1[i] = v;
+      }
     }
     wsync();
     const int8_t *T = a.T_d ? a.T_d + 3 * (size_t)e * a.Pd : nullptr;
@@ -634,11 +665,21 @@ class DenseInterpOperator : public Operator {
     const int pmax = (std::max(Pd_, Pr_) + 1) & ~1;
     // the matrices in LDS when all of them fit beside the waves' strips in 48 KB (eight such workgroups per CU)
     const size_t strips = sizeof(double) * (size_t)kDenseInterpWaves * 2 * pmax, mats = sizeof(double) * (size_t)nmat_ * Pr_ * (Pd_ | 1);
-    const int lds_mats = strips + mats <= 48 * 1024 ? nmat_ : 0;
+    // one matrix whose contracted side fits 48 registers and whose other side one wave: rows / columns in registers
+    const int nk = TR ? Pr_ : Pd_, nl = TR ? Pd_ : Pr_;
+    const int nr = (nmat_ == 1 && nl <= 64 && nk <= 48) ? (nk <= 8 ? 8 : nk <= 24 ? 24 : 48) : 0;
+    const int lds_mats = (nr == 0 && strips + mats <= 48 * 1024) ? nmat_ : 0;
     const size_t lds = strips + (lds_mats ? mats : 0);
     // eight elements per wave (the matrix copy is amortised over 32 elements of a workgroup), every CU busy
     const int grid = std::max(1, std::min((ne_ + kDenseInterpWaves - 1) / kDenseInterpWaves, std::max(2048, (ne_ + 8 * kDenseInterpWaves - 1) / (8 * kDenseInterpWaves))));
-    hipLaunchKernelGGL((dense_interp_kernel<TR>), dim3(grid), dim3(64 * kDenseInterpWaves), lds, ctx_->stream, a, lds_mats, pmax);
+    if (nr == 8)
+      hipLaunchKernelGGL((dense_interp_kernel<TR, 8>), dim3(grid), dim3(64 * kDenseInterpWaves), lds, ctx_->stream, a, 0, pmax);
+    else if (nr == 24)
+      hipLaunchKernelGGL((dense_interp_kernel<TR, 24>), dim3(grid), dim3(64 * kDenseInterpWaves), lds, ctx_->stream, a, 0, pmax);
+    else if (nr == 48)
+      hipLaunchKernelGGL((dense_interp_kernel<TR, 48>), dim3(grid), dim3(64 * kDenseInterpWaves), lds, ctx_->stream, a, 0, pmax);
+    else
+      hipLaunchKernelGGL((dense_interp_kernel<TR, 0>), dim3(grid), dim3(64 * kDenseInterpWaves), lds, ctx_->stream, a, lds_mats, pmax);
     PA_HIP(hipGetLastError());
   }
   static int8_t *signs(const pa_restriction_desc &r, hipStream_t s) {
