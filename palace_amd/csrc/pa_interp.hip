@@ -520,6 +520,7 @@ struct DenseInterpArgs {
 
 constexpr int kDenseInterpMaxP = 256;
 constexpr int kDenseInterpWaves = 4;
+constexpr int kDenseInterpEPW = 4;  // elements per wave and step
 
 // Round 6: four waves per workgroup, each walking elements with a grid stride, and the element matrices staged in LDS once per
 // workgroup when they fit (lds_mats > 0: all `nmat` matrices; 16 KB for the 45 x 45 matrix of order-3 Nedelec tetrahedra).  The
@@ -543,7 +544,6 @@ __global__ __launch_bounds__(64 * kDenseInterpWaves) void dense_interp_kernel(co
   // (rows of the LDS copy an odd number of doubles apart: lane j reads row j in the forward product)
   const int ms = lds_mats > 0 ? (a.Pd | 1) : a.Pd, msz = a.Pr * ms;
   double *sM = dsm;                                                  // [lds_mats][Pr][Pd | 1]
-  double *s0 = dsm + (size_t)lds_mats * msz + (size_t)wave * 2 * pmax, *s1 = s0 + pmax;
   if (lds_mats > 0) {
     for (int k = threadIdx.x; k < lds_mats * a.Pr * a.Pd; k += 64 * kDenseInterpWaves) {
       const int r = k / a.Pd, c = k - r * a.Pd;  // (r runs over all rows of all matrices)
@@ -551,100 +551,182 @@ __global__ __launch_bounds__(64 * kDenseInterpWaves) void dense_interp_kernel(co
     }
     __syncthreads();
   }
-  for (int e = blockIdx.x * kDenseInterpWaves + wave; e < a.ne; e += gridDim.x * kDenseInterpWaves) {
-  const int32_t *od = a.off_d + (size_t)e * a.Pd, *orr = a.off_r + (size_t)e * a.Pr;
-  const int mid = a.mat_id ? a.mat_id[e] : 0;
-  const double *Me = lds_mats > 0 ? sM + (size_t)mid * msz : a.M + (size_t)mid * msz;
-  if (!TRANSPOSE) {
-    for (int i = lane; i < a.Pd; i += 64) {
-      double v = a.x[od[i]];
-      if (a.sgn_d) v *= (double)a.sgn_d[(size_t)e * a.Pd + i];
-      s0[i] = v;
-    }
-    wsync();
-    if (a.T_d) {  // u = T x_e
-      const int8_t *T = a.T_d + 3 * (size_t)e * a.Pd;
-      for (int i = lane; i < a.Pd; i += 64)
-        s1[i] = (double)T[3 * i] * s0[max(i - 1, 0)] + (double)T[3 * i + 1] * s0[i] +
-                (double)T[3 * i + 2] * s0[min(i + 1, a.Pd - 1)];
-      wsync();
-      for (int i = lane; i < a.Pd; i += 64) s0[i] = s1[i];
-      wsync();
-    }
-    if (NR > 0) {  // v = M u: the lane's row from registers, u broadcast from the strip
-      double v = 0.0;
+  // kDenseInterpEPW consecutive elements per wave and step, every phase over all of them before the next synchronisation: their
+  // index and value loads are in flight together (one element at a time left the wave waiting on one dependent chain)
+  double *strip = dsm + (size_t)lds_mats * msz + (size_t)wave * (2 * kDenseInterpEPW) * pmax;
+  for (int g = blockIdx.x * kDenseInterpWaves + wave; g * kDenseInterpEPW < a.ne; g += gridDim.x * kDenseInterpWaves) {
+    const int e0 = g * kDenseInterpEPW;
+    if (!TRANSPOSE) {
 #pragma unroll
-      for (int i = 0; i < NR; i++)
-        if (i < a.Pd) v += mreg[i] * s0[i];
-      if (lane < a.Pr) s1[lane] = v;
-    } else {
-      for (int j = lane; j < a.Pr; j += 64) {  // v = M u
-        const double *row = Me + (size_t)j * ms;
-        double v = 0.0;
-        for (int i = 0; i < a.Pd; i++) v += row[i] * s0[i];
-        s1[j] = v;
+      for (int h = 0; h < kDenseInterpEPW; h++) {
+        const int e = e0 + h;
+        double *s0 = strip + (2 * h) * pmax;
+        if (e < a.ne)
+          for (int i = lane; i < a.Pd; i += 64) {
+            double v = a.x[a.off_d[(size_t)e * a.Pd + i]];
+            if (a.sgn_d) v *= (double)a.sgn_d[(size_t)e * a.Pd + i];
+            s0[i] = v;
+          }
       }
-    }
-    wsync();
-    const int8_t *B = a.B_r ? a.B_r + 3 * (size_t)e * a.Pr : nullptr;
-    for (int j = lane; j < a.Pr; j += 64) {  // w = B^T v (or the sign), owner copy stored
-      const int o = orr[j];
-      if (!(o & kOwnBit)) continue;
-      double w;
-      if (B) {
-        w = (double)B[3 * j + 1] * s1[j];
-        if (j > 0) w += (double)B[3 * (j - 1) + 2] * s1[j - 1];
-        if (j + 1 < a.Pr) w += (double)B[3 * (j + 1)] * s1[j + 1];
-      } else {
-        w = a.sgn_r ? (double)a.sgn_r[(size_t)e * a.Pr + j] * s1[j] : s1[j];
-      }
-      a.y[o & ~kOwnBit] = w;
-    }
-  } else {
-    for (int j = lane; j < a.Pr; j += 64) {  // z = owner-masked range values
-      const int o = orr[j];
-      double v = (o & kOwnBit) ? a.x[o & ~kOwnBit] : 0.0;
-      if (a.sgn_r) v *= (double)a.sgn_r[(size_t)e * a.Pr + j];
-      s0[j] = v;
-    }
-    wsync();
-    if (a.B_r) {  // v = B z
-      const int8_t *B = a.B_r + 3 * (size_t)e * a.Pr;
-      for (int j = lane; j < a.Pr; j += 64)
-        s1[j] = (double)B[3 * j] * s0[max(j - 1, 0)] + (double)B[3 * j + 1] * s0[j] +
-                (double)B[3 * j + 2] * s0[min(j + 1, a.Pr - 1)];
       wsync();
-      for (int j = lane; j < a.Pr; j += 64) s0[j] = s1[j];
-      wsync();
-    }
-    if (NR > 0) {  // u = M^T v: the lane's column from registers
-      double v = 0.0;
+      if (a.T_d) {  // u = T x_e
 #pragma unroll
-      for (int j = 0; j < NR; j++)
-        if (j < a.Pr) v += mreg[j] * s0[j];
-      if (lane < a.Pd) s1[lane] = v;
-    } else {
-      for (int i = lane; i < a.Pd; i += 64) {  // u = M^T v
-        double v = 0.0;
-        for (int j = 0; j < a.Pr; j++) v += Me[(size_t)j * ms + i] * s0[j];
-        s1[i] = v;
+        for (int h = 0; h < kDenseInterpEPW; h++) {
+          const int e = e0 + h;
+          double *s0 = strip + (2 * h) * pmax, *s1 = s0 + pmax;
+          if (e < a.ne) {
+            const int8_t *T = a.T_d + 3 * (size_t)e * a.Pd;
+            for (int i = lane; i < a.Pd; i += 64)
+              s1[i] = (double)T[3 * i] * s0[max(i - 1, 0)] + (double)T[3 * i + 1] * s0[i] + (double)T[3 * i + 2] * s0[min(i + 1, a.Pd - 1)];
+          }
+        }
+        wsync();
+#pragma unroll
+        for (int h = 0; h < kDenseInterpEPW; h++) {
+          double *s0 = strip + (2 * h) * pmax, *s1 = s0 + pmax;
+          if (e0 + h < a.ne)
+            for (int i = lane; i < a.Pd; i += 64) s0[i] = s1[i];
+        }
+        wsync();
       }
-    }
-    wsync();
-    const int8_t *T = a.T_d ? a.T_d + 3 * (size_t)e * a.Pd : nullptr;
-    for (int i = lane; i < a.Pd; i += 64) {  // w = T^T u (or the sign) into the domain E-vector
-      double w;
-      if (T) {
-        w = (double)T[3 * i + 1] * s1[i];
-        if (i > 0) w += (double)T[3 * (i - 1) + 2] * s1[i - 1];
-        if (i + 1 < a.Pd) w += (double)T[3 * (i + 1)] * s1[i + 1];
+      if (NR > 0) {  // v = M u: the lane's row from registers, u broadcast from the strips
+        double v[kDenseInterpEPW];
+#pragma unroll
+        for (int h = 0; h < kDenseInterpEPW; h++) v[h] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; i++)
+          if (i < a.Pd) {
+#pragma unroll
+            for (int h = 0; h < kDenseInterpEPW; h++) v[h] += mreg[i] * strip[(2 * h) * pmax + i];
+          }
+        if (lane < a.Pr) {
+#pragma unroll
+          for (int h = 0; h < kDenseInterpEPW; h++) strip[(2 * h + 1) * pmax + lane] = v[h];
+        }
       } else {
-        w = a.sgn_d ? (double)a.sgn_d[(size_t)e * a.Pd + i] * s1[i] : s1[i];
+#pragma unroll
+        for (int h = 0; h < kDenseInterpEPW; h++) {
+          const int e = e0 + h;
+          if (e >= a.ne) continue;
+          const double *s0 = strip + (2 * h) * pmax;
+          double *s1 = strip + (2 * h + 1) * pmax;
+          const int mid = a.mat_id ? a.mat_id[e] : 0;
+          const double *Me = lds_mats > 0 ? sM + (size_t)mid * msz : a.M + (size_t)mid * msz;
+          for (int j = lane; j < a.Pr; j += 64) {  // v = M u
+            const double *row = Me + (size_t)j * ms;
+            double v = 0.0;
+            for (int i = 0; i < a.Pd; i++) v += row[i] * s0[i];
+            s1[j] = v;
+          }
+        }
       }
-      a.ye_d[(size_t)e * a.Pd + i] = w;
+      wsync();
+#pragma unroll
+      for (int h = 0; h < kDenseInterpEPW; h++) {
+        const int e = e0 + h;
+        if (e >= a.ne) continue;
+        const double *s1 = strip + (2 * h + 1) * pmax;
+        const int32_t *orr = a.off_r + (size_t)e * a.Pr;
+        const int8_t *B = a.B_r ? a.B_r + 3 * (size_t)e * a.Pr : nullptr;
+        for (int j = lane; j < a.Pr; j += 64) {  // w = B^T v (or the sign), owner copy stored
+          const int o = orr[j];
+          if (!(o & kOwnBit)) continue;
+          double w;
+          if (B) {
+            w = (double)B[3 * j + 1] * s1[j];
+            if (j > 0) w += (double)B[3 * (j - 1) + 2] * s1[j - 1];
+            if (j + 1 < a.Pr) w += (double)B[3 * (j + 1)] * s1[j + 1];
+          } else {
+            w = a.sgn_r ? (double)a.sgn_r[(size_t)e * a.Pr + j] * s1[j] : s1[j];
+          }
+          a.y[o & ~kOwnBit] = w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < kDenseInterpEPW; h++) {
+        const int e = e0 + h;
+        double *s0 = strip + (2 * h) * pmax;
+        if (e < a.ne)
+          for (int j = lane; j < a.Pr; j += 64) {  // z = owner-masked range values
+            const int o = a.off_r[(size_t)e * a.Pr + j];
+            double v = (o & kOwnBit) ? a.x[o & ~kOwnBit] : 0.0;
+            if (a.sgn_r) v *= (double)a.sgn_r[(size_t)e * a.Pr + j];
+            s0[j] = v;
+          }
+      }
+      wsync();
+      if (a.B_r) {  // v = B z
+#pragma unroll
+        for (int h = 0; h < kDenseInterpEPW; h++) {
+          const int e = e0 + h;
+          double *s0 = strip + (2 * h) * pmax, *s1 = s0 + pmax;
+          if (e < a.ne) {
+            const int8_t *B = a.B_r + 3 * (size_t)e * a.Pr;
+            for (int j = lane; j < a.Pr; j += 64)
+              s1[j] = (double)B[3 * j] * s0[max(j - 1, 0)] + (double)B[3 * j + 1] * s0[j] + (double)B[3 * j + 2] * s0[min(j + 1, a.Pr - 1)];
+          }
+        }
+        wsync();
+#pragma unroll
+        for (int h = 0; h < kDenseInterpEPW; h++) {
+          double *s0 = strip + (2 * h) * pmax, *s1 = s0 + pmax;
+          if (e0 + h < a.ne)
+            for (int j = lane; j < a.Pr; j += 64) s0[j] = s1[j];
+        }
+        wsync();
+      }
+      if (NR > 0) {  // u = M^T v: the lane's column from registers
+        double v[kDenseInterpEPW];
+#pragma unroll
+        for (int h = 0; h < kDenseInterpEPW; h++) v[h] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NR; j++)
+          if (j < a.Pr) {
+#pragma unroll
+            for (int h = 0; h < kDenseInterpEPW; h++) v[h] += mreg[j] * strip[(2 * h) * pmax + j];
+          }
+        if (lane < a.Pd) {
+#pragma unroll
+          for (int h = 0; h < kDenseInterpEPW; h++) strip[(2 * h + 1) * pmax + lane] = v[h];
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < kDenseInterpEPW; h++) {
+          const int e = e0 + h;
+          if (e >= a.ne) continue;
+          const double *s0 = strip + (2 * h) * pmax;
+          double *s1 = strip + (2 * h + 1) * pmax;
+          const int mid = a.mat_id ? a.mat_id[e] : 0;
+          const double *Me = lds_mats > 0 ? sM + (size_t)mid * msz : a.M + (size_t)mid * msz;
+          for (int i = lane; i < a.Pd; i += 64) {  // u = M^T v
+            double v = 0.0;
+            for (int j = 0; j < a.Pr; j++) v += Me[(size_t)j * ms + i] * s0[j];
+            s1[i] = v;
+          }
+        }
+      }
+      wsync();
+#pragma unroll
+      for (int h = 0; h < kDenseInterpEPW; h++) {
+        const int e = e0 + h;
+        if (e >= a.ne) continue;
+        const double *s1 = strip + (2 * h + 1) * pmax;
+        const int8_t *T = a.T_d ? a.T_d + 3 * (size_t)e * a.Pd : nullptr;
+        for (int i = lane; i < a.Pd; i += 64) {  // w = T^T u (or the sign) into the domain E-vector
+          double w;
+          if (T) {
+            w = (double)T[3 * i + 1] * s1[i];
+            if (i > 0) w += (double)T[3 * (i - 1) + 2] * s1[i - 1];
+            if (i + 1 < a.Pd) w += (double)T[3 * (i + 1)] * s1[i + 1];
+          } else {
+            w = a.sgn_d ? (double)a.sgn_d[(size_t)e * a.Pd + i] * s1[i] : s1[i];
+          }
+          a.ye_d[(size_t)e * a.Pd + i] = w;
+        }
+      }
     }
-  }
-  wsync();  // (the wave's strips are reused by its next element)
+    wsync();  // (the wave's strips are reused by its next group)
   }
 }
 
@@ -664,14 +746,15 @@ class DenseInterpOperator : public Operator {
     DenseInterpArgs a{ne_, Pd_, Pr_, d_off_d_, d_off_r_, d_sgn_d_, d_sgn_r_, d_T_d_, d_B_r_, d_M_, d_mat_id_, x, y, d_ye_};
     const int pmax = (std::max(Pd_, Pr_) + 1) & ~1;
     // the matrices in LDS when all of them fit beside the waves' strips in 48 KB (eight such workgroups per CU)
-    const size_t strips = sizeof(double) * (size_t)kDenseInterpWaves * 2 * pmax, mats = sizeof(double) * (size_t)nmat_ * Pr_ * (Pd_ | 1);
+    const size_t strips = sizeof(double) * (size_t)kDenseInterpWaves * 2 * kDenseInterpEPW * pmax, mats = sizeof(double) * (size_t)nmat_ * Pr_ * (Pd_ | 1);
     // one matrix whose contracted side fits 48 registers and whose other side one wave: rows / columns in registers
     const int nk = TR ? Pr_ : Pd_, nl = TR ? Pd_ : Pr_;
     const int nr = (nmat_ == 1 && nl <= 64 && nk <= 48) ? (nk <= 8 ? 8 : nk <= 24 ? 24 : 48) : 0;
     const int lds_mats = (nr == 0 && strips + mats <= 48 * 1024) ? nmat_ : 0;
     const size_t lds = strips + (lds_mats ? mats : 0);
     // eight elements per wave (the matrix copy is amortised over 32 elements of a workgroup), every CU busy
-    const int grid = std::max(1, std::min((ne_ + kDenseInterpWaves - 1) / kDenseInterpWaves, std::max(2048, (ne_ + 8 * kDenseInterpWaves - 1) / (8 * kDenseInterpWaves))));
+    const int groups = (ne_ + kDenseInterpEPW - 1) / kDenseInterpEPW;  // of elements: one per wave and step; two steps per wave at size
+    const int grid = std::max(1, std::min((groups + kDenseInterpWaves - 1) / kDenseInterpWaves, std::max(2048, (groups + 2 * kDenseInterpWaves - 1) / (2 * kDenseInterpWaves))));
     if (nr == 8)
       hipLaunchKernelGGL((dense_interp_kernel<TR, 8>), dim3(grid), dim3(64 * kDenseInterpWaves), lds, ctx_->stream, a, 0, pmax);
     else if (nr == 24)
