@@ -1160,7 +1160,8 @@ int pa_op_prepare_fused_step(pa_op *op, int *available) {
     const bool enabled = !(getenv("PALACE_AMD_FUSED_STEP") && atoi(getenv("PALACE_AMD_FUSED_STEP")) == 0);
     if (!enabled || !op->has_essential || op->subs.size() != 1 || !op->dsubs.empty() || !op->msubs.empty()) return;
     SubOp *so = op->subs[0];
-    if (so->fe_type != PA_FE_HCURL || so->q1d != 4 || !so->d_idxc || !so->d_perm_s_bc || !nd_hex_stream_ok(*so)) return;
+    // (four points per direction: pa_nd_hex_stream.hip; five: pa_nd_hex_stream5.hip -- nd_hex_stream_ok covers both)
+    if (so->fe_type != PA_FE_HCURL || (so->q1d != 4 && so->q1d != 5) || !so->d_idxc || !so->d_perm_s_bc || !nd_hex_stream_ok(*so)) return;
     *available = stream_build_all(*so) ? 1 : 0;
   });
 }
@@ -1168,7 +1169,7 @@ int pa_op_prepare_fused_step(pa_op *op, int *available) {
 int pa_op_mult_cheb_step(pa_op *op, const double *x, const pa_cheb_step *step, int diag_policy, void *stream) {
   return guarded([&] {
     PA_REQUIRE(op && x && step && step->dinv && step->r0 && step->out, "null argument");
-    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->d_flagw_all, "pa_op_prepare_fused_step has not been called (or found no fused form)");
+    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->n_all > 0, "pa_op_prepare_fused_step has not been called (or found no fused form)");
     PA_REQUIRE(x != step->out, "the step cannot overwrite its own input");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
     const SubOp &so = *op->subs[0];
@@ -1182,7 +1183,7 @@ int pa_op_mult_residual(pa_op *op, const double *y, const double *b, double *res
                         int diag_policy, void *stream) {
   return guarded([&] {
     PA_REQUIRE(op && y && b && (res || d0) && (!d0 || dinv), "null argument");
-    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->d_flagw_all, "pa_op_prepare_fused_step has not been called (or found no fused form)");
+    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->n_all > 0, "pa_op_prepare_fused_step has not been called (or found no fused form)");
     PA_REQUIRE(y != res && y != d0, "the residual cannot overwrite the operator's input");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
     const SubOp &so = *op->subs[0];

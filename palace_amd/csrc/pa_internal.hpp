@@ -227,6 +227,7 @@ struct SubOp {
   // exclusive in this copy of the flag words -- so that the gather's epilogue can consume the result instead of storing it (the
   // fused Chebyshev step, launch_et_run_gather_step); essential dofs flagged as in the _bc copy
   uint32_t *d_flagw_all = nullptr, *d_rchunk_all = nullptr;
+  uint32_t *d_perm_s_all = nullptr;  // the same for the five-point kernel, whose flags ride in the slot half-words
   int32_t *d_rhdr_all = nullptr, *d_rpos_all = nullptr;
   int n_all = 0, n_runs_all = 0;
   std::vector<char> h_ess_flag;  // the essential flags last fused (stream_set_essential), for stream_build_all
@@ -356,7 +357,7 @@ void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s);
 void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s);
 bool nd_hex_stream5_ok(const SubOp &so);
 void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase,
-                           const SplitIO *split = nullptr);
+                           const SplitIO *split = nullptr, bool all = false);
 void launch_nd_hex_stream5_complex(const SubOp &sr, const SubOp &si, const double *xr, const double *xi, double *yr, double *yi,
                                    double *ye_i, bool masked, hipStream_t s);
 void launch_et_run_gather(const SubOp &so, double *y, bool accumulate, hipStream_t s, const double *x, bool masked,

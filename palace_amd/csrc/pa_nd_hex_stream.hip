@@ -965,9 +965,9 @@ void build_stream(SubOp &so) {
 void stream_set_essential(SubOp &so, const std::vector<char> &flag) {
   if (!so.d_idxc) return;
   so.h_ess_flag = flag;
-  if (so.d_flagw_all) {  // (built for another list: again on the next pa_op_prepare_fused_step)
-    hipFree(so.d_flagw_all), hipFree(so.d_rchunk_all), hipFree(so.d_rhdr_all), hipFree(so.d_rpos_all);
-    so.d_flagw_all = nullptr, so.d_rchunk_all = nullptr, so.d_rhdr_all = so.d_rpos_all = nullptr;
+  if (so.n_all > 0) {  // (built for another list: again on the next pa_op_prepare_fused_step)
+    hipFree(so.d_flagw_all), hipFree(so.d_perm_s_all), hipFree(so.d_rchunk_all), hipFree(so.d_rhdr_all), hipFree(so.d_rpos_all);
+    so.d_flagw_all = so.d_perm_s_all = nullptr, so.d_rchunk_all = nullptr, so.d_rhdr_all = so.d_rpos_all = nullptr, so.n_all = 0;
   }
   const int P = so.P, npl = (P + 15) / 16, npk = (npl + 3) / 4;
   std::vector<uint32_t> pb(so.h_perm_s);
@@ -1052,8 +1052,8 @@ void free_stream(SubOp &so) {
   hipFree(so.d_blist[0]), hipFree(so.d_blist[1]);
   hipFree(so.d_idxc), hipFree(so.d_perm_s), hipFree(so.d_perm_s_bc), hipFree(so.d_coef_s);
   hipFree(so.d_flagw), hipFree(so.d_flagw_bc), hipFree(so.d_slots);
-  hipFree(so.d_flagw_all), hipFree(so.d_rchunk_all), hipFree(so.d_rhdr_all), hipFree(so.d_rpos_all);
-  so.d_flagw_all = nullptr, so.d_rchunk_all = nullptr, so.d_rhdr_all = so.d_rpos_all = nullptr;
+  hipFree(so.d_flagw_all), hipFree(so.d_perm_s_all), hipFree(so.d_rchunk_all), hipFree(so.d_rhdr_all), hipFree(so.d_rpos_all);
+  so.d_flagw_all = so.d_perm_s_all = nullptr, so.d_rchunk_all = nullptr, so.d_rhdr_all = so.d_rpos_all = nullptr, so.n_all = 0;
   hipFree(so.d_rhdr), hipFree(so.d_rpos), hipFree(so.d_rhdr_bc), hipFree(so.d_rpos_bc), hipFree(so.d_rchunk), hipFree(so.d_rchunk_bc);
 }
 
@@ -1191,8 +1191,9 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
 }
 
 void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s) {
-  PA_REQUIRE(so.d_flagw_all && !wide_form(so), "stream_build_all has not been called");
+  PA_REQUIRE(so.n_all > 0, "stream_build_all has not been called");
   double *unused = so.d_ye;  // (no entry is exclusive in this form: y is never written)
+  if (wide_form(so)) return launch_nd_hex_stream5(so, x, unused, true, s, -1, nullptr, true);
   switch (so.p) {
     case 1: launch_p<1>(so, x, unused, true, s, -1, nullptr, true); break;
     case 2: launch_p<2>(so, x, unused, true, s, -1, nullptr, true); break;
@@ -1314,27 +1315,40 @@ void launch_et_run_gather2(const SubOp &so, double *y, double *y1, hipStream_t s
 
 // ---- the fused smoother step: every dof through the E-vector, consumed by the gather's epilogue -------------------------------
 bool stream_build_all(SubOp &so) {
-  if (so.d_flagw_all) return true;
-  if (!so.d_idxc || !so.d_flagw || wide_form(so) || so.fe_type != PA_FE_HCURL) return false;
+  if (so.n_all > 0) return true;
+  const bool wide = wide_form(so);
+  if (!so.d_idxc || so.fe_type != PA_FE_HCURL || (!wide && !so.d_flagw) || so.h_perm_s.empty()) return false;
   const int P = so.P, npl = (P + 15) / 16, npk = (npl + 3) / 4, nep = (so.ne + 3) & ~3;
   const size_t nnz = (size_t)so.ne * P;
   std::vector<char> flag(so.h_ess_flag);
   flag.resize((size_t)so.lsize, 0);
-  std::vector<uint32_t> fw((size_t)nep * 16);
-  for (int e = 0; e < nep; e++)
-    for (int t = 0; t < 16; t++) {
-      uint32_t w = so.h_perm_s[((size_t)e * (npk + 1) + npk) * 16 + t];
-      for (int r = 0; r < npl; r++) w &= ~(2u << (2 * r));  // nothing takes the direct path
-      fw[(size_t)e * 16 + t] = w;
-    }
+  std::vector<uint32_t> fw;  // four-point kernel: the flag words; five-point kernel: the slot half-words with their flags
+  const int npkw = ((P + 31) / 32 + 1) / 2;
+  if (wide) {
+    fw = so.h_perm_s;
+    for (uint32_t &w : fw) w &= ~(streamhost::kWideExcl | (streamhost::kWideExcl << 16));  // nothing takes the direct path
+  } else {
+    fw.resize((size_t)nep * 16);
+    for (int e = 0; e < nep; e++)
+      for (int t = 0; t < 16; t++) {
+        uint32_t w = so.h_perm_s[((size_t)e * (npk + 1) + npk) * 16 + t];
+        for (int r = 0; r < npl; r++) w &= ~(2u << (2 * r));  // nothing takes the direct path
+        fw[(size_t)e * 16 + t] = w;
+      }
+  }
   std::vector<char> present((size_t)so.lsize, 0);
   for (size_t k = 0; k < nnz; k++) {
     const int d = streamhost::dof_of(so.h_sidx[k]);
     present[d] = 1;
     if (flag[d]) {
       const size_t e = k / P;
-      const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
-      fw[e * 16 + t] |= 1u << (18 + r);  // read as zero
+      if (wide) {
+        const int m = (int)(k - e * P), t = m & 31, r = m >> 5;
+        fw[(e * npkw + (r >> 1)) * 32 + t] |= streamhost::kWideEss << (16 * (r & 1));  // read as zero
+      } else {
+        const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
+        fw[e * 16 + t] |= 1u << (18 + r);  // read as zero
+      }
     }
   }
   std::vector<int32_t> all;
@@ -1351,12 +1365,15 @@ bool stream_build_all(SubOp &so) {
   so.d_rhdr_all = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
   so.d_rpos_all = dev_upload(rpos.data(), rpos.size());
   so.n_all = (int)all.size(), so.n_runs_all = (int)hdr.size() - 1;
-  so.d_flagw_all = dev_upload(fw.data(), fw.size());
+  if (wide)
+    so.d_perm_s_all = dev_upload(fw.data(), fw.size());
+  else
+    so.d_flagw_all = dev_upload(fw.data(), fw.size());
   return true;
 }
 
 void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s) {
-  PA_REQUIRE(so.d_flagw_all && so.n_all > 0, "stream_build_all has not been called");
+  PA_REQUIRE(so.n_all > 0, "stream_build_all has not been called");
   const int n = so.n_all;
   hipLaunchKernelGGL(et_run_gather_kernel_t<true>, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
                      reinterpret_cast<const RunChunk *>(so.d_rchunk_all), reinterpret_cast<const RunHdr *>(so.d_rhdr_all), so.d_rpos_all,

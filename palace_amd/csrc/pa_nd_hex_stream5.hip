@@ -395,7 +395,8 @@ static void launch5_variant(const SubOp &so, NDStream5Args<P1> &a, hipStream_t s
 }
 
 template <int P1>
-static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
+static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split,
+                      bool all = false) {
   NDStream5Args<P1> a;
   a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
   if (split) {
@@ -412,7 +413,7 @@ static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, 
     if (a.nbatch == 0) return;
   }
   a.idxw = so.d_idxc;
-  a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
+  a.perm = all ? so.d_perm_s_all : (masked ? so.d_perm_s_bc : so.d_perm_s);  // (all: no entry exclusive -- the fused smoother step)
   a.qdata = so.qd->d;
   a.coef = so.d_coef_s, a.coef1 = nullptr;
   a.x = x, a.y = y, a.ye = so.d_ye;
@@ -433,12 +434,13 @@ static void launch5_p(const SubOp &so, const double *x, double *y, bool masked, 
   }
 }
 
-void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split) {
+void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase, const SplitIO *split,
+                           bool all) {
   switch (so.p) {
-    case 1: launch5_p<1>(so, x, y, masked, s, phase, split); break;
-    case 2: launch5_p<2>(so, x, y, masked, s, phase, split); break;
-    case 3: launch5_p<3>(so, x, y, masked, s, phase, split); break;
-    case 4: launch5_p<4>(so, x, y, masked, s, phase, split); break;
+    case 1: launch5_p<1>(so, x, y, masked, s, phase, split, all); break;
+    case 2: launch5_p<2>(so, x, y, masked, s, phase, split, all); break;
+    case 3: launch5_p<3>(so, x, y, masked, s, phase, split, all); break;
+    case 4: launch5_p<4>(so, x, y, masked, s, phase, split, all); break;
     default: throw Error("no five-point streaming H(curl) hex kernel for this order");
   }
 }

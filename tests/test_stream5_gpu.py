@@ -108,6 +108,44 @@ def test_stream5_par_operator_essential_rows(mesh640, monkeypatch, p, policy):
     assert np.array_equal(y[ess], x[ess] if policy == "one" else np.zeros(ess.size))
 
 
+@pytest.mark.parametrize("p", [2, 4])
+@pytest.mark.parametrize("policy", ["one", "zero"])
+def test_stream5_chebyshev_steps_fused_into_the_gather(mesh640, monkeypatch, p, policy):
+    """Round 6: the smoother step evaluated in the E^T epilogue (pa_op_mult_cheb_step) on the five-point kernel -- config 5's
+    element and its p-coarsened levels: the fused smoother against the same smoother with the step as a vector kernel
+    (PALACE_AMD_FUSED_STEP=0) and against the oracle's recurrence, zero and non-zero initial guess, both diagonal policies."""
+    mesh = mesh640
+    nd = NDHexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, Q1D)
+    cm, bm = util.make_ctx("scalar", nattr=3)
+    cc, bc = util.make_ctx("identity")
+    local = ceed.curlcurlmass_operator(geom, nd, bm, bc)
+    ess = nd.ess_dofs()
+    ctx = linalg.Context()
+    pol = linalg.DIAG_ONE if policy == "one" else linalg.DIAG_ZERO
+    A = linalg.ParOperator(ctx, local, ess, pol)
+    S = linalg.chebyshev(ctx, A, order=4)
+    assert S.fused_step()
+    monkeypatch.setenv("PALACE_AMD_FUSED_STEP", "0")
+    S0 = linalg.chebyshev(ctx, A, order=4)
+    assert not S0.fused_step() and S0.lambda_max() == S.lambda_max()
+    n = nd.ndofs
+    rng = np.random.default_rng(21)
+    b, g = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    b[ess] = 0.0
+    g[ess] = 0.0
+    y = S.mult(_dev(b), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    y0 = S0.mult(_dev(b), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    z = S.mult(_dev(b), _dev(g.copy()), initial_guess=True).cpu().numpy()
+    z0 = S0.mult(_dev(b), _dev(g.copy()), initial_guess=True).cpu().numpy()
+    assert _rel(y, y0) < 1e-13 and _rel(z, z0) < 1e-13
+    if policy == "one":
+        oracle = util.FastParOperatorOracle(nd, util.oracle_geom(mesh, Q1D), "hdivmass", np.concatenate([bm, bc]), ess, Q1D, cm, cc)
+        oracle._diag = A.assemble_diagonal(torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+        o = po.ChebyshevOracle(oracle, 4, lambda_max=S.lambda_max())
+        assert _rel(y, o.mult2(b, None, False)) < 1e-11 and _rel(z, o.mult2(b, g.copy(), True)) < 1e-11
+
+
 def test_stream5_ragged_and_tiny_meshes(cylinder_mesh):
     """Odd element counts (the last batch holds one element and one pad), fewer batches than XCDs."""
     from palace_amd.fem.mesh import ogrid_cylinder
