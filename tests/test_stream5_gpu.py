@@ -109,11 +109,11 @@ def test_stream5_par_operator_essential_rows(mesh640, monkeypatch, p, policy):
 
 
 @pytest.mark.parametrize("p", [2, 4])
-@pytest.mark.parametrize("policy", ["one", "zero"])
+@pytest.mark.parametrize("policy", ["one"])  # (a Jacobi-scaled smoother needs the unit diagonal on the essential rows)
 def test_stream5_chebyshev_steps_fused_into_the_gather(mesh640, monkeypatch, p, policy):
     """Round 6: the smoother step evaluated in the E^T epilogue (pa_op_mult_cheb_step) on the five-point kernel -- config 5's
     element and its p-coarsened levels: the fused smoother against the same smoother with the step as a vector kernel
-    (PALACE_AMD_FUSED_STEP=0) and against the oracle's recurrence, zero and non-zero initial guess, both diagonal policies."""
+    (PALACE_AMD_FUSED_STEP=0) and against the oracle's recurrence, zero and non-zero initial guess."""
     mesh = mesh640
     nd = NDHexSpace(mesh, p)
     geom = ceed.GeomFactorData(mesh, Q1D)
