@@ -447,6 +447,23 @@ int pa_op_mult_cheb_step(pa_op *op, const double *x, const pa_cheb_step *step, i
  * may be NULL; the essential rows of A y are x | 0 as in pa_op_mult_essential_diag.  Needs pa_op_prepare_fused_step. */
 int pa_op_mult_residual(pa_op *op, const double *y, const double *b, double *res, const double *dinv, double c0, double *d0,
                         int diag_policy, void *stream);
+/* The same two fused forms on SPLIT vectors (pa_op_mult_split: a multi-rank ParOperator::Mult without L-vector copies).  This rank's
+ * gather cannot finish the owned dofs other ranks hold as ghosts (bit 2 of iface_mask[d], d < n_true): their partial sums go to
+ * t_iface[d], the ghost rows to yg as in pa_op_mult_split, and the caller's halo kernel (comm.hpp: Halo::RestrictAddDirectStep) adds
+ * the neighbours' rows and applies the step there.  mode 1: the Chebyshev step of pa_op_mult_cheb_step; mode 2: the residual of
+ * pa_op_mult_residual (res / out as there; sd unused, sr = c0).  ess_policy >= 0: the essential list fused as in pa_op_mult_split. */
+typedef struct {
+  int32_t mode;
+  double sd, sr;
+  const double *dinv, *r0, *e_prev;
+  double *out;
+  int32_t add;
+  double *res;
+  const uint8_t *iface_mask;
+  double *t_iface;
+} pa_split_step;
+int pa_op_mult_split_step(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *yg,
+                          int n_true, int ess_policy, const pa_split_step *step, void *stream);
 int pa_op_supports_split(const pa_op *op);
 int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y,
                      double *yg, int n_true, int ess_policy, void *stream);

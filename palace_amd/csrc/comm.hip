@@ -672,13 +672,16 @@ __global__ __launch_bounds__(256) void k_peer_consume_r(const PeerNbr *__restric
 // (k_peer_send<0> + k_peer_consume_r<2> behind one launch: at the per-rank sizes of a strong-scaling run a launch costs what
 // the exchange does).  Every block takes part in both phases; the exchange counter is advanced by the block that finishes last,
 // after every block has read it.  A block spinning in the second phase waits for OTHER ranks' first phases only, which never wait.
-__global__ __launch_bounds__(256) void k_peer_restrict_direct(const PeerNbr *__restrict__ nb, const int nnbr, const PeerLocal *__restrict__ F,
-                                                               PeerCounters *__restrict__ L, const int total,
-                                                               const double *__restrict__ gout, const double *__restrict__ mb,
-                                                               const int nsend, double *__restrict__ y, const int ndof,
-                                                               const int4 *__restrict__ rinfo, const int32_t *__restrict__ rptr,
-                                                               const int32_t *__restrict__ rpos, unsigned long long *err,
-                                                               const uint8_t *__restrict__ mask) {
+// STEP: y is read only (this rank's partial sums of the interface dofs) and the completed sum is consumed by the smoother step
+// `st` instead of being stored (Halo::Step)
+template <bool STEP>
+__global__ __launch_bounds__(256) void k_peer_restrict_direct_t(const PeerNbr *__restrict__ nb, const int nnbr, const PeerLocal *__restrict__ F,
+                                                                 PeerCounters *__restrict__ L, const int total,
+                                                                 const double *__restrict__ gout, const double *__restrict__ mb,
+                                                                 const int nsend, double *__restrict__ y, const int ndof,
+                                                                 const int4 *__restrict__ rinfo, const int32_t *__restrict__ rptr,
+                                                                 const int32_t *__restrict__ rpos, unsigned long long *err,
+                                                                 const uint8_t *__restrict__ mask, const Halo::Step st) {
   const int dir = 1;
   const unsigned long long s = L->seq[1] + 1ull;
   const int par = (int)(s & 1ull);
@@ -729,7 +732,21 @@ __global__ __launch_bounds__(256) void k_peer_restrict_direct(const PeerNbr *__r
       if (info[j].z >= 0) t += c1[j];
       if (info[j].w >= 0)
         for (int a = info[j].w; a < rptr[i + 1]; a++) t += ld_sys_f64(&src[rpos[a]]);
-      if (!(mask[d] & 1)) y[d] = t;
+      if (STEP) {
+        const double tt = (mask[d] & 1) ? sum[j] : t;  // (essential rows: the local gather fixed them)
+        const double rv = st.r0[d] - tt;
+        if (st.mode == 2) {
+          if (st.res) st.res[d] = rv;
+          if (st.out) st.out[d] = st.sr * st.dinv[d] * rv;
+        } else {
+          const double e = st.ek[d];
+          double dk = st.sr * st.dinv[d] * rv;
+          dk += st.sd * (e - (st.ep ? st.ep[d] : 0.0));
+          st.out[d] = (st.add ? st.out[d] : 0.0) + (e + dk);
+        }
+      } else if (!(mask[d] & 1)) {
+        y[d] = t;
+      }
     }
   }
   if (!last_block(&L->cons[1], gridDim.x)) return;
@@ -1158,6 +1175,35 @@ void Halo::SendDirect(const double *d_x, const uint8_t *d_mask, hipStream_t s) c
                      nullptr, 0, mb, p.local, p.d_err, 0);
   PA_HIP(hipGetLastError());
 }
+namespace {
+bool halo_merged() {
+  static const bool merged = !(std::getenv("PALACE_AMD_HALO_MERGED") && std::getenv("PALACE_AMD_HALO_MERGED")[0] == '0');
+  return merged;
+}
+int restrict_resident_blocks() {
+  static const int resident = [] {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop{};
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peer_restrict_direct_t<true>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1)
+      prop.multiProcessorCount = 32;
+    return per_cu * prop.multiProcessorCount;
+  }();
+  return resident;
+}
+}  // namespace
+bool Halo::StepOk() const { return peer_ != nullptr && halo_merged(); }
+void Halo::RestrictAddDirectStep(const uint8_t *d_mask, const double *d_t_iface, const Step &st, hipStream_t s) const {
+  PA_REQUIRE(StepOk() && d_mask && d_t_iface && st.r0 && (st.mode == 1 ? (st.dinv && st.ek && st.out) : (st.mode == 2 && (st.res || st.out))),
+             "halo step: peer transport in its merged form and a complete step expected");
+  const PeerPlan &p = *peer_;
+  const int mb = mail_blocks(nrecv_), sb = sum_blocks(p.n_rdof);
+  const int cap = std::max(1, restrict_resident_blocks() / std::max(1, p.ranks_on_device));
+  hipLaunchKernelGGL(k_peer_restrict_direct_t<true>, dim3(std::min(cap, std::max(mb, sb))), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local,
+                     p.counters, nrecv_, GhostOut(), p.mb[1], nsend_, const_cast<double *>(d_t_iface), p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos,
+                     p.d_err, d_mask, st);
+  PA_HIP(hipGetLastError());
+}
 void Halo::RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) const {
   const PeerPlan &p = *peer_;
   const int mb = mail_blocks(nrecv_), sb = sum_blocks(p.n_rdof);
@@ -1169,7 +1215,7 @@ void Halo::RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) 
     static const int resident = [] {
       int per_cu = 0, dev = 0;
       hipDeviceProp_t prop{};
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peer_restrict_direct, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peer_restrict_direct_t<true>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1)
         prop.multiProcessorCount = 32;
       return per_cu * prop.multiProcessorCount;
@@ -1177,8 +1223,8 @@ void Halo::RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) 
     // (this rank's share: the ranks on THIS device -- one per GPU on the target node, where nothing has to be shared; a
     // rehearsal or a partitioned device puts several on one.  Determined at the plan's set-up, PeerSetup.)
     const int cap = std::max(1, resident / std::max(1, p.ranks_on_device));
-    hipLaunchKernelGGL(k_peer_restrict_direct, dim3(std::min(cap, std::max(mb, sb))), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, nrecv_,
-                       GhostOut(), p.mb[1], nsend_, d_y, p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, d_mask);
+    hipLaunchKernelGGL(k_peer_restrict_direct_t<false>, dim3(std::min(cap, std::max(mb, sb))), dim3(256), 0, s, p.d_nbr, p.nnbr, p.local, p.counters, nrecv_,
+                       GhostOut(), p.mb[1], nsend_, d_y, p.n_rdof, p.d_rinfo, p.d_rptr, p.d_rpos, p.d_err, d_mask, Step{});
     PA_HIP(hipGetLastError());
     return;
   }

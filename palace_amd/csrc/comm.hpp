@@ -144,6 +144,16 @@ public:
   std::vector<double> AllGatherVHost(const std::vector<double> &mine, std::vector<long long> *offsets = nullptr);
 };
 
+// A smoother step consumed by the halo kernel (Halo::RestrictAddDirectStep)
+struct HaloStep {
+  int mode;
+  double sd, sr;
+  const double *dinv, *r0, *ek, *ep;
+  double *out;
+  int add;
+  double *res;
+};
+
 // The conforming prolongation of one finite element space (one multigrid level): which owned dofs
 // go to which neighbour and which ghost slots are filled by whom.
 class Halo {
@@ -187,6 +197,13 @@ public:
   const unsigned long long *GhostInSelector() const;   // ... and the device counter whose parity names the current one
   double *GhostOut() const;
   void RestrictAddDirect(const uint8_t *d_mask, double *d_y, hipStream_t s) const;
+  // The same with a smoother step consumed where the sum over the ranks is formed (round 6; linalg.hpp: Operator::MultChebyStep on
+  // split vectors): for every owned dof with sharers t = t_iface[d] + the neighbours' rows (essential rows: t_iface[d] alone), then
+  //   mode 1:  out[d] (+)= ek[d] + sd (ek[d] - ep[d]) + sr dinv[d] (r0[d] - t)      mode 2:  res[d] = r0[d] - t,  out[d] = sr dinv[d] (r0[d] - t)
+  // -- the line the local gather evaluates for the dofs no other rank shares (pa_op_mult_split_step).  Merged form of P^T only.
+  using Step = HaloStep;
+  bool StepOk() const;
+  void RestrictAddDirectStep(const uint8_t *d_mask, const double *d_t_iface, const Step &st, hipStream_t s) const;
   Halo(Comm &comm, int nnbr, const int *nbr, const int *send_off, const int32_t *send_idx, const int *recv_off,
        const int32_t *recv_idx);
   ~Halo();

@@ -998,6 +998,10 @@ void Operator::MultResidualEssential(const Vector &y, const Vector &b, Vector *r
   check(pa_op_mult_residual(op_, y.Data(), b.Data(), res ? res->Data() : nullptr, dinv ? dinv->Data() : nullptr, c0,
                             d0 ? d0->Data() : nullptr, diag_one ? 1 : 0, ctx_->stream));
 }
+void Operator::MultSplitStep(const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *yg, int n_true,
+                             int ess_policy, const pa_split_step &st) const {
+  check(pa_op_mult_split_step(op_, x, xg0, xg1, sel, yg, n_true, ess_policy, &st, ctx_->stream));
+}
 void Operator::Mult2(const Vector &x0, const Vector &x1, Vector &y0, Vector &y1) const {
   check(pa_op_mult2(op_, x0.Data(), x1.Data(), y0.Data(), y1.Data(), ctx_->stream));
 }
@@ -1170,14 +1174,37 @@ ParOperator::~ParOperator() {
   if (d_csr_bc_) (void)hipFree(d_csr_bc_);
 }
 
-bool ParOperator::PrepareChebyStep() const { return A_fused_ && !halo_ && A_fused_->PrepareFusedStep(); }
+bool ParOperator::PrepareChebyStep() const {
+  if (A_fused_ && !halo_) return A_fused_->PrepareFusedStep();
+  // several ranks, direct form of the peer transport (round 6): the local gather consumes the dofs no other rank shares, the merged
+  // P^T kernel the interface dofs (Halo::RestrictAddDirectStep); needs the essential list fused (split_ess_) and the mask
+  static const bool halo_step = !(std::getenv("PALACE_AMD_FUSED_STEP_HALO") && std::getenv("PALACE_AMD_FUSED_STEP_HALO")[0] == '0');
+  if (halo_step && A_split_ && halo_ && d_ess_mask_ && split_ess_ && halo_->StepOk()) return A_split_->PrepareFusedStep();
+  return false;
+}
+void ParOperator::SplitStep(const Vector &x, const pa_split_step &st0, const HaloStep &hs) const {
+  const Context &c = *ctx_;
+  pa_split_step st = st0;
+  st.iface_mask = d_ess_mask_, st.t_iface = ly_.Data();  // (the L-vector scratch is free in the direct form)
+  halo_->SendDirect(x.Data(), d_ess_mask_, c.stream);
+  A_split_->MultSplitStep(x.Data(), halo_->GhostIn(0), halo_->GhostIn(1), halo_->GhostInSelector(), halo_->GhostOut(), n_true_,
+                          policy_ == DiagonalPolicy::DIAG_ONE ? 1 : 0, st);
+  halo_->RestrictAddDirectStep(d_ess_mask_, ly_.Data(), hs, c.stream);
+}
 void ParOperator::MultChebyStep(const Vector &x, const ChebyStepArgs &a) const {
-  PA_REQUIRE(A_fused_, "MultChebyStep: PrepareChebyStep found no fused form");
-  A_fused_->MultChebyStepEssential(x, a, policy_ == DiagonalPolicy::DIAG_ONE);
+  if (A_fused_ && !halo_) return A_fused_->MultChebyStepEssential(x, a, policy_ == DiagonalPolicy::DIAG_ONE);
+  PA_REQUIRE(A_split_ && halo_, "MultChebyStep: PrepareChebyStep found no fused form");
+  const double *ep = a.e_prev ? a.e_prev->Data() : nullptr;
+  SplitStep(x, pa_split_step{1, a.sd, a.sr, a.dinv->Data(), a.r0->Data(), ep, a.out->Data(), a.add ? 1 : 0, nullptr, nullptr, nullptr},
+            HaloStep{1, a.sd, a.sr, a.dinv->Data(), a.r0->Data(), x.Data(), ep, a.out->Data(), a.add ? 1 : 0, nullptr});
 }
 void ParOperator::MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0) const {
-  PA_REQUIRE(A_fused_, "MultResidual: PrepareChebyStep found no fused form");
-  A_fused_->MultResidualEssential(y, b, res, dinv, c0, d0, policy_ == DiagonalPolicy::DIAG_ONE);
+  if (A_fused_ && !halo_) return A_fused_->MultResidualEssential(y, b, res, dinv, c0, d0, policy_ == DiagonalPolicy::DIAG_ONE);
+  PA_REQUIRE(A_split_ && halo_, "MultResidual: PrepareChebyStep found no fused form");
+  const double *di = dinv ? dinv->Data() : nullptr;
+  double *r = res ? res->Data() : nullptr, *o = d0 ? d0->Data() : nullptr;
+  SplitStep(y, pa_split_step{2, 0.0, c0, di, b.Data(), nullptr, o, 0, r, nullptr, nullptr},
+            HaloStep{2, 0.0, c0, di, b.Data(), nullptr, nullptr, o, 0, r});
 }
 void ParOperator::Mult(const Vector &x, Vector &y) const {
   // rap.cpp:195-234.  tx = x, tx[ess] = 0; lx = P tx; ly = A lx; y = P^T ly; y[ess] = x[ess] | 0

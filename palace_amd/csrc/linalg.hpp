@@ -26,6 +26,7 @@ namespace palace {
 
 class Comm;  // RCCL communicator (comm.hpp); nullptr = single process
 class Halo;  // conforming prolongation of one space across ranks (comm.hpp)
+struct HaloStep;
 
 // Reduction scratch of one context (per-block partial sums on the device, a pinned slot for the results); created on
 // first use and shared by the copies of a context -- never by two contexts, whose streams may reduce concurrently.
@@ -275,6 +276,9 @@ public:
   bool PrepareFusedStep() const;
   void MultChebyStepEssential(const Vector &x, const ChebyStepArgs &a, bool diag_one) const;
   void MultResidualEssential(const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0, bool diag_one) const;
+  // the fused forms on split vectors (pa_op_mult_split_step): interface dofs left to the halo kernel
+  void MultSplitStep(const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *yg, int n_true,
+                     int ess_policy, const pa_split_step &st) const;
   // split vectors (pa_op_mult_split): true dofs in x / y, ghosts read from xg0 | xg1 (parity of *sel) and written to yg
   bool SupportsSplit() const;
   void MultSplit(const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *y, double *yg,
@@ -416,6 +420,7 @@ public:
   }
   bool FusesEssential() const { return A_fused_ != nullptr; }
   bool PrepareChebyStep() const override;
+  void SplitStep(const Vector &x, const pa_split_step &st, const HaloStep &hs) const;
   void MultChebyStep(const Vector &x, const ChebyStepArgs &a) const override;
   void MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv = nullptr, double c0 = 0.0,
                     Vector *d0 = nullptr) const override;  // the essential list lives in the local operator's index tables

@@ -1231,6 +1231,25 @@ int pa_op_mult_split(pa_op *op, const double *x, const double *xg0, const double
   });
 }
 
+int pa_op_mult_split_step(pa_op *op, const double *x, const double *xg0, const double *xg1, const unsigned long long *sel, double *yg,
+                          int n_true, int ess_policy, const pa_split_step *st, void *stream) {
+  return guarded([&] {
+    PA_REQUIRE(op && x && xg0 && yg && st && st->r0 && st->iface_mask && st->t_iface, "null argument");
+    PA_REQUIRE(st->mode == 1 ? (st->dinv && st->out) : (st->mode == 2 && (st->res || st->out) && (!st->out || st->dinv)), "invalid step");
+    PA_REQUIRE(op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->n_all > 0 && op->subs[0]->fe_type == PA_FE_HCURL,
+               "pa_op_prepare_fused_step has not been called (or found no fused form)");
+    PA_REQUIRE(x != st->out && x != st->res, "the step cannot overwrite the operator's input");
+    PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed split apply of a non-symmetric operator");
+    PA_REQUIRE(ess_policy < 0 || op->has_essential, "pa_op_set_essential has not been called");
+    const SubOp &so = *op->subs[0];
+    const SplitIO io{n_true, xg0, xg1, sel, yg};
+    hipStream_t s = (hipStream_t)stream;
+    launch_nd_hex_stream_all(so, x, s, &io);
+    launch_et_run_gather_step(so, x, GatherStep{st->sd, st->sr, st->dinv, st->r0, st->e_prev, st->out, st->add, st->res, st->mode,
+                                                st->iface_mask, st->t_iface}, ess_policy, s, &io);
+  });
+}
+
 int pa_op_mult2(pa_op *op, const double *x0, const double *x1, double *y0, double *y1, void *stream) {
   return guarded([&] { apply2(op, x0, x1, y0, y1, (hipStream_t)stream, false, -1); });
 }

@@ -349,12 +349,18 @@ struct GatherStep {
   int add;
   double *res;
   int mode;  // 1: Chebyshev step, 2: residual
+  // multi-rank (split-vector) form: owned dofs other ranks hold as ghosts (bit 2 of iface_mask[d]) are not finished by this rank's
+  // gather -- their sum goes to t_iface[d] and the halo kernel that adds the neighbours' rows applies the step (comm.hip:
+  // RestrictAddDirectStep); ghost rows go to the ghost output as in the plain split form.  nullptr: one rank.
+  const unsigned char *iface_mask;
+  double *t_iface;
 };
 void launch_et_run_gather2(const SubOp &so, double *y, double *y1, hipStream_t s, const double *x, const double *x1, bool masked,
                            int ess_policy, const double *ye1);
 bool stream_build_all(SubOp &so);  // the index copies the fused step needs (idempotent; false: this block has no such form)
-void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s);
-void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s);
+void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s, const SplitIO *split = nullptr);
+void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s,
+                               const SplitIO *split = nullptr);
 bool nd_hex_stream5_ok(const SubOp &so);
 void launch_nd_hex_stream5(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, int phase,
                            const SplitIO *split = nullptr, bool all = false);

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel_t(const int n, const
   if (STEP) {
 #pragma unroll
     for (int u = 0; u < kGatherILP; u++) {
-      const int dd = live[u] ? d[u] : 0;
+      const int dd = (live[u] && d[u] < nsplit) ? d[u] : 0;  // (ghost rows -- split form -- take no part in the recurrence)
       sr0[u] = st.r0[dd];
       sdi[u] = st.dinv ? st.dinv[dd] : 0.0;
       se[u] = st.mode == 1 ? x[dd] : 0.0;
@@ -722,6 +722,14 @@ __global__ __launch_bounds__(256) void et_run_gather_kernel_t(const int n, const
 #pragma unroll
     for (int u = 0; u < kGatherILP; u++) {
       if (!live[u]) continue;
+      if (d[u] >= nsplit) {  // a ghost row: to its owner through the halo kernel
+        yg[d[u]] = s[u];
+        continue;
+      }
+      if (st.iface_mask && (st.iface_mask[d[u]] & 2)) {  // an owned dof with sharers: the halo kernel completes the sum and the step
+        st.t_iface[d[u]] = s[u];
+        continue;
+      }
       const double rv = sr0[u] - s[u];
       if (st.mode == 2) {  // residual (and the first direction of the polynomial)
         if (st.res) st.res[d[u]] = rv;
@@ -1190,14 +1198,14 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   }
 }
 
-void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s) {
+void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s, const SplitIO *split) {
   PA_REQUIRE(so.n_all > 0, "stream_build_all has not been called");
   double *unused = so.d_ye;  // (no entry is exclusive in this form: y is never written)
-  if (wide_form(so)) return launch_nd_hex_stream5(so, x, unused, true, s, -1, nullptr, true);
+  if (wide_form(so)) return launch_nd_hex_stream5(so, x, unused, true, s, -1, split, true);
   switch (so.p) {
-    case 1: launch_p<1>(so, x, unused, true, s, -1, nullptr, true); break;
-    case 2: launch_p<2>(so, x, unused, true, s, -1, nullptr, true); break;
-    case 3: launch_p<3>(so, x, unused, true, s, -1, nullptr, true); break;
+    case 1: launch_p<1>(so, x, unused, true, s, -1, split, true); break;
+    case 2: launch_p<2>(so, x, unused, true, s, -1, split, true); break;
+    case 3: launch_p<3>(so, x, unused, true, s, -1, split, true); break;
     default: throw Error("no streaming H(curl) hex kernel for this order");
   }
 }
@@ -1372,12 +1380,15 @@ bool stream_build_all(SubOp &so) {
   return true;
 }
 
-void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s) {
+void launch_et_run_gather_step(const SubOp &so, const double *x, const GatherStep &step, int ess_policy, hipStream_t s,
+                               const SplitIO *split) {
   PA_REQUIRE(so.n_all > 0, "stream_build_all has not been called");
+  PA_REQUIRE(!split || (step.iface_mask && step.t_iface), "split form of the fused step: interface mask and buffer missing");
   const int n = so.n_all;
   hipLaunchKernelGGL(et_run_gather_kernel_t<true>, dim3((n + 256 * kGatherILP - 1) / (256 * kGatherILP)), dim3(256), 0, s, n,
                      reinterpret_cast<const RunChunk *>(so.d_rchunk_all), reinterpret_cast<const RunHdr *>(so.d_rhdr_all), so.d_rpos_all,
-                     so.d_ye, nullptr, 0, x, ess_policy, 0x7fffffff, nullptr, step, GatherPart2{});
+                     so.d_ye, nullptr, 0, x, ess_policy, split ? split->n_true : 0x7fffffff, split ? split->yg - split->n_true : nullptr,
+                     step, GatherPart2{});
   PA_HIP(hipGetLastError());
 }
 

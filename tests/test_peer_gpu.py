@@ -13,6 +13,12 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+def ctx_dot_vec(ctx, v):
+    import torch
+
+    return torch.tensor(ctx.dot(v, v), dtype=torch.float64)
+
+
 def _worker(rank, world, port, out):
     import torch
     import torch.distributed as dist
@@ -64,6 +70,22 @@ def _worker(rank, world, port, out):
             A0.mult(v, w2)
             A0.set_direct(True)
             res["forms_equal"] = res["forms_equal"] and bool(torch.allclose(w1, w2, rtol=1e-14, atol=1e-14 * float(w2.abs().max())))
+        # round 6: the smoother step consumed where A e_k is produced -- on one rank in the E^T gather, with a halo in the gather
+        # (dofs no other rank shares) and in the merged P^T kernel (interface dofs): against the same smoother with the step as a
+        # vector kernel, zero and non-zero initial guess; the V-cycle's fused residual rides in the solves above
+        S1 = linalg.chebyshev(ctx, A, order=4)
+        os.environ["PALACE_AMD_FUSED_STEP"] = "0"
+        S0 = linalg.chebyshev(ctx, A, order=4)
+        os.environ.pop("PALACE_AMD_FUSED_STEP")
+        res["fused"] = (S1.fused_step(), S0.fused_step())
+        assert S1.lambda_max() == S0.lambda_max()
+        y1, y0 = S1.mult(b, torch.zeros_like(b)), S0.mult(b, torch.zeros_like(b))
+        g = 0.3 * z
+        g1, g0 = S1.mult(b, g.clone(), initial_guess=True), S0.mult(b, g.clone(), initial_guess=True)
+        dd = torch.stack([ctx_dot_vec(ctx, y1 - y0), ctx_dot_vec(ctx, y0), ctx_dot_vec(ctx, g1 - g0), ctx_dot_vec(ctx, g0)])
+        res["cheb_rel"] = (float(dd[0] / dd[1]) ** 0.5, float(dd[2] / dd[3]) ** 0.5)
+        if world > 1:
+            ctx.peer_check()
         # the same solve again: the recorded iteration (HIP graph) replays across ranks
         x.zero_()
         K.mult(b, x)
@@ -89,6 +111,9 @@ def test_two_processes_on_one_gpu_match_one_rank():
     assert one["n"] == two["n"] and one["converged"] and two["converged"]
     assert abs(one["iterations"] - two["iterations"]) <= 1
     assert two["forms_equal"]
+    # the fused smoother step: taken on one rank and with the halo, equal to the unfused smoother
+    assert one["fused"] == (True, False) and two["fused"] == (True, False), (one["fused"], two["fused"])
+    assert max(one["cheb_rel"]) < 1e-13 and max(two["cheb_rel"]) < 1e-13, (one["cheb_rel"], two["cheb_rel"])
     for k in ("bb", "bAb"):
         assert abs(one[k] - two[k]) < 1e-11 * abs(one[k]), (k, one[k], two[k])
     for k in ("xx", "xAx", "xx2"):
