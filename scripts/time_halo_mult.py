@@ -68,8 +68,12 @@ if PCG:
         solver.mult(b, xs)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         st = solver.stats()
+        try:
+            fused = [bool(prob.last_gmg.fused_step(l)) for l in range(1, len(prob.spaces))] if not hip else "-"
+        except Exception as exc:  # noqa: BLE001
+            fused = f"? ({exc})"
         print(f"[{MODE}] PCG + p-MG ({'hiptmair' if hip else 'chebyshev'}) on the slab with halos: {st['iterations'] / dt:.0f} it/s "
-              f"({st['iterations']} iterations, {dt * 1e3:.1f} ms)")
+              f"({st['iterations']} iterations, {dt * 1e3:.1f} ms; smoother steps fused per level: {fused})")
         prob._keep.clear()
     if MODE == "peer":
         ctx.peer_check()
