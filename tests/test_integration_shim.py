@@ -29,10 +29,10 @@ def shim_exe(tmp_path_factory):
     assert block, "INTEGRATION.md section 1 lost its shim"
     (d / "integration_shim.hpp").write_text(block.group(1))
     exe = str(d / "integration_shim_check")
-    subprocess.check_call([hipcc, "-std=c++17", "-O1", "-Wall", "-Werror", "-Wno-unused-result", "-I" + str(d),
-                           "-I" + os.path.join(ROOT, "tests", "cpu"), "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
-                           "-x", "c++", os.path.join(ROOT, "tests", "cpu", "integration_shim_check.cpp"),
-                           "-L" + lib, "-lpalace_amd", "-lamdhip64", "-L/opt/rocm/lib", "-Wl,-rpath," + lib, "-o", exe])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O1", "-Wall", "-Werror", "-Wno-unused-result", "-I" + str(d),
+                           "-I" + os.path.join(ROOT, "tests", "cpu"), "-I" + os.path.join(ROOT, "include"),
+                           "-x", "hip", os.path.join(ROOT, "tests", "cpu", "integration_shim_check.cpp"),
+                           "-L" + lib, "-lpalace_amd", "-Wl,-rpath," + lib, "-o", exe])
     return exe
 
 
