@@ -22,7 +22,22 @@ __global__ __launch_bounds__(256) void k_csr_spmv(const int n, const int32_t *__
   double s = 0.0;
   if (row < n) {
     const int32_t b = rowptr[row], e = rowptr[row + 1];
-    for (int32_t k = b + l; k < e; k += LPR) s += val[k] * x[col[k]];
+    // (round 6: the first four entries of the lane requested side by side -- col, val, then x -- instead of one dependent chain per
+    // entry; same entries in the same order: same bits)
+    int32_t c[4];
+    double v[4], xv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int32_t k = b + l + q * LPR;
+      c[q] = k < e ? col[k] : -1;
+      v[q] = k < e ? val[k] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) xv[q] = c[q] >= 0 ? x[c[q]] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (c[q] >= 0) s += v[q] * xv[q];
+    for (int32_t k = b + l + 4 * LPR; k < e; k += LPR) s += val[k] * x[col[k]];
   }
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LPR);
