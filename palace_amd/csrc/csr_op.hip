@@ -22,6 +22,9 @@ __global__ __launch_bounds__(256) void k_csr_spmv(const int n, const int32_t *__
   double s = 0.0;
   if (row < n) {
     const int32_t b = rowptr[row], e = rowptr[row + 1];
+#ifdef PA_CSR_OLD  // (A / B builds: the loop of rounds 1-5)
+    for (int32_t k = b + l; k < e; k += LPR) s += val[k] * x[col[k]];
+#else
     // (round 6: the first four entries of the lane requested side by side -- col, val, then x -- instead of one dependent chain per
     // entry; same entries in the same order: same bits)
     int32_t c[4];
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(256) void k_csr_spmv(const int n, const int32_t *__
     for (int q = 0; q < 4; q++)
       if (c[q] >= 0) s += v[q] * xv[q];
     for (int32_t k = b + l + 4 * LPR; k < e; k += LPR) s += val[k] * x[col[k]];
+#endif
   }
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LPR);
