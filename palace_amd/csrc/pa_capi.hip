@@ -1160,8 +1160,13 @@ int pa_op_prepare_fused_step(pa_op *op, int *available) {
     const bool enabled = !(getenv("PALACE_AMD_FUSED_STEP") && atoi(getenv("PALACE_AMD_FUSED_STEP")) == 0);
     if (!enabled || !op->has_essential || op->subs.size() != 1 || !op->dsubs.empty() || !op->msubs.empty()) return;
     SubOp *so = op->subs[0];
-    // (four points per direction: pa_nd_hex_stream.hip; five: pa_nd_hex_stream5.hip -- nd_hex_stream_ok covers both)
-    if (so->fe_type != PA_FE_HCURL || (so->q1d != 4 && so->q1d != 5) || !so->d_idxc || !so->d_perm_s_bc || !nd_hex_stream_ok(*so)) return;
+    // (four points per direction: pa_nd_hex_stream.hip; five: pa_nd_hex_stream5.hip -- nd_hex_stream_ok covers both; H1 blocks
+    // whose y = A x runs on the streaming kernel: pa_h1_hex_stream.hip)
+    if (so->fe_type == PA_FE_H1) {
+      if (!so->d_idxc || !so->stream_default || !so->d_perm_s_bc || !h1_hex_stream_ok(*so)) return;
+    } else if (so->fe_type != PA_FE_HCURL || (so->q1d != 4 && so->q1d != 5) || !so->d_idxc || !so->d_perm_s_bc || !nd_hex_stream_ok(*so)) {
+      return;
+    }
     *available = stream_build_all(*so) ? 1 : 0;
   });
 }
@@ -1236,7 +1241,7 @@ int pa_op_mult_split_step(pa_op *op, const double *x, const double *xg0, const d
   return guarded([&] {
     PA_REQUIRE(op && x && xg0 && yg && st && st->r0 && st->iface_mask && st->t_iface, "null argument");
     PA_REQUIRE(st->mode == 1 ? (st->dinv && st->out) : (st->mode == 2 && (st->res || st->out) && (!st->out || st->dinv)), "invalid step");
-    PA_REQUIRE(op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->n_all > 0 && op->subs[0]->fe_type == PA_FE_HCURL,
+    PA_REQUIRE(op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->n_all > 0,
                "pa_op_prepare_fused_step has not been called (or found no fused form)");
     PA_REQUIRE(x != st->out && x != st->res, "the step cannot overwrite the operator's input");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed split apply of a non-symmetric operator");

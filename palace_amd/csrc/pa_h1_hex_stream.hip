@@ -391,11 +391,11 @@ void launch_vg(const SubOp &so, H1StreamArgs<P1> &a, hipStream_t s) {
 }
 
 template <int P1>
-void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split) {
+void launch_p(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split, bool all) {
   H1StreamArgs<P1> a;
   a.ne = so.ne;
   a.idxc = so.d_idxc;
-  a.perm = masked ? so.d_perm_s_bc : so.d_perm_s;
+  a.perm = all ? so.d_perm_s_all : (masked ? so.d_perm_s_bc : so.d_perm_s);  // (all: no entry exclusive -- the fused smoother step)
   a.qdata = so.qd->d;
   a.x = x, a.y = y, a.ye = so.d_ye;
   a.nsplit = -1, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr, a.yg = nullptr;
@@ -449,11 +449,11 @@ bool h1_hex_stream_ok(const SubOp &so) {
   return so.fe_type == PA_FE_H1 && so.q1d == 4 && so.p >= (all ? 1 : 3) && so.p <= 3 && so.qd && so.qd->d && so.d_ye && so.d_tptr;
 }
 
-void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split) {
+void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split, bool all) {
   switch (so.p) {
-    case 1: launch_p<1>(so, x, y, masked, s, split); break;
-    case 2: launch_p<2>(so, x, y, masked, s, split); break;
-    case 3: launch_p<3>(so, x, y, masked, s, split); break;
+    case 1: launch_p<1>(so, x, y, masked, s, split, all); break;
+    case 2: launch_p<2>(so, x, y, masked, s, split, all); break;
+    case 3: launch_p<3>(so, x, y, masked, s, split, all); break;
     default: throw Error("no streaming H1 kernel for this order");
   }
 }

@@ -319,7 +319,8 @@ void launch_nd_hex_diag(const SubOp &so, double *diag, hipStream_t s);
 struct SplitIO;
 bool h1_hex_stream_ok(const SubOp &so);       // the streaming form is the default for y = A x
 bool h1_hex_stream_capable(const SubOp &so);  // ... its tables can be built (split-vector applies use it at every order)
-void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split = nullptr);
+void launch_h1_hex_stream(const SubOp &so, const double *x, double *y, bool masked, hipStream_t s, const SplitIO *split = nullptr,
+                          bool all = false);
 bool nd_hex_stream_ok(const SubOp &so);
 void build_stream(SubOp &so);
 void stream_set_essential(SubOp &so, const std::vector<char> &flag);

@@ -1201,6 +1201,7 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
 void launch_nd_hex_stream_all(const SubOp &so, const double *x, hipStream_t s, const SplitIO *split) {
   PA_REQUIRE(so.n_all > 0, "stream_build_all has not been called");
   double *unused = so.d_ye;  // (no entry is exclusive in this form: y is never written)
+  if (so.fe_type == PA_FE_H1) return launch_h1_hex_stream(so, x, unused, true, s, split, true);
   if (wide_form(so)) return launch_nd_hex_stream5(so, x, unused, true, s, -1, split, true);
   switch (so.p) {
     case 1: launch_p<1>(so, x, unused, true, s, -1, split, true); break;
@@ -1324,8 +1325,9 @@ void launch_et_run_gather2(const SubOp &so, double *y, double *y1, hipStream_t s
 // ---- the fused smoother step: every dof through the E-vector, consumed by the gather's epilogue -------------------------------
 bool stream_build_all(SubOp &so) {
   if (so.n_all > 0) return true;
-  const bool wide = wide_form(so);
-  if (!so.d_idxc || so.fe_type != PA_FE_HCURL || (!wide && !so.d_flagw) || so.h_perm_s.empty()) return false;
+  const bool wide = wide_form(so), h1 = so.fe_type == PA_FE_H1;
+  // (H1 blocks on the streaming kernel: the flag word is the last row of the element's block of slot words, pa_h1_hex_stream.hip)
+  if (!so.d_idxc || (!h1 && so.fe_type != PA_FE_HCURL) || (!wide && !h1 && !so.d_flagw) || so.h_perm_s.empty()) return false;
   const int P = so.P, npl = (P + 15) / 16, npk = (npl + 3) / 4, nep = (so.ne + 3) & ~3;
   const size_t nnz = (size_t)so.ne * P;
   std::vector<char> flag(so.h_ess_flag);
@@ -1335,6 +1337,11 @@ bool stream_build_all(SubOp &so) {
   if (wide) {
     fw = so.h_perm_s;
     for (uint32_t &w : fw) w &= ~(streamhost::kWideExcl | (streamhost::kWideExcl << 16));  // nothing takes the direct path
+  } else if (h1) {
+    fw = so.h_perm_s;  // [nep][npk + 1][16]: the flag words are row npk
+    for (int e = 0; e < nep; e++)
+      for (int t = 0; t < 16; t++)
+        for (int r = 0; r < npl; r++) fw[((size_t)e * (npk + 1) + npk) * 16 + t] &= ~(2u << (2 * r));
   } else {
     fw.resize((size_t)nep * 16);
     for (int e = 0; e < nep; e++)
@@ -1353,6 +1360,9 @@ bool stream_build_all(SubOp &so) {
       if (wide) {
         const int m = (int)(k - e * P), t = m & 31, r = m >> 5;
         fw[(e * npkw + (r >> 1)) * 32 + t] |= streamhost::kWideEss << (16 * (r & 1));  // read as zero
+      } else if (h1) {
+        const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
+        fw[(e * (npk + 1) + npk) * 16 + t] |= 1u << (18 + r);
       } else {
         const int m = (int)(k - e * P), t = m & 15, r = m >> 4;
         fw[e * 16 + t] |= 1u << (18 + r);  // read as zero
@@ -1373,7 +1383,7 @@ bool stream_build_all(SubOp &so) {
   so.d_rhdr_all = dev_upload(reinterpret_cast<const int32_t *>(hdr.data()), 2 * hdr.size());
   so.d_rpos_all = dev_upload(rpos.data(), rpos.size());
   so.n_all = (int)all.size(), so.n_runs_all = (int)hdr.size() - 1;
-  if (wide)
+  if (wide || h1)
     so.d_perm_s_all = dev_upload(fw.data(), fw.size());
   else
     so.d_flagw_all = dev_upload(fw.data(), fw.size());

@@ -163,3 +163,57 @@ print("OK")
     env = dict(os.environ, PALACE_AMD_STREAM_H1="all")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("qf", ["diffusion", "diffusionmass"])
+def test_h1_chebyshev_steps_fused_into_the_gather(cylinder_mesh, monkeypatch, qf):
+    """Round 6: the smoother step in the epilogue of the E^T gather on the H1 streaming kernel (order 3: the auxiliary-space
+    operators of the Hiptmair smoother): against the same smoother with the step as a vector kernel (PALACE_AMD_FUSED_STEP=0), zero
+    and non-zero initial guess, and against the oracle's recurrence."""
+    mesh = _multi_attr(cylinder_mesh)
+    p, q1d = 3, 4
+    h1 = H1HexSpace(mesh, p)
+    geom = ceed.GeomFactorData(mesh, q1d)
+    ogeom = util.oracle_geom(mesh, q1d)
+    c_mass, c_diff = _ctxs()
+    if qf == "diffusion":
+        op, o = ceed.diffusion_operator(geom, h1, c_diff.pack()), _oracle(h1, ogeom, po.QF_HCURL, c_diff, None, q1d)
+    else:
+        op, o = (ceed.diffusionmass_operator(geom, h1, c_mass.pack(), c_diff.pack()),
+                 _oracle(h1, ogeom, po.QF_HCURLMASS, c_mass, c_diff, q1d))
+    ess = h1.ess_dofs()
+    ctx = linalg.Context()
+    A = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+    S = linalg.chebyshev(ctx, A, order=4)
+    assert S.fused_step()
+    monkeypatch.setenv("PALACE_AMD_FUSED_STEP", "0")
+    S0 = linalg.chebyshev(ctx, A, order=4)
+    assert not S0.fused_step() and S0.lambda_max() == S.lambda_max()
+    n = h1.ndofs
+    rng = np.random.default_rng(31)
+    b, g = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    b[ess] = 0.0
+    g[ess] = 0.0
+    y = S.mult(_dev(b), _new(n)).cpu().numpy()
+    y0 = S0.mult(_dev(b), _new(n)).cpu().numpy()
+    z = S.mult(_dev(b), _dev(g.copy()), initial_guess=True).cpu().numpy()
+    z0 = S0.mult(_dev(b), _dev(g.copy()), initial_guess=True).cpu().numpy()
+    assert _rel(y, y0) < 1e-13 and _rel(z, z0) < 1e-13
+
+    class _Par:  # the oracle's ParOperator semantics around its local operator (rap.cpp:195-234), diagonal from the device
+        def __init__(self):
+            self.n = n
+            self._d = A.assemble_diagonal(_new(n)).cpu().numpy()
+
+        def mult(self, v):
+            t = v.copy()
+            t[ess] = 0.0
+            w = o.apply_add(t, np.zeros(n))
+            w[ess] = v[ess]
+            return w
+
+        def diagonal(self):
+            return self._d
+
+    ch = po.ChebyshevOracle(_Par(), 4, lambda_max=S.lambda_max())
+    assert _rel(y, ch.mult2(b, None, False)) < 1e-11 and _rel(z, ch.mult2(b, g.copy(), True)) < 1e-11
