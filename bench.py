@@ -322,7 +322,7 @@ def main():
                 "measured_mfma_f64_TFLOPs": measured_mfma,
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                 "kernel": "pa::nd_hex_stream_kernel<P1=3, packed q-data> (E, B, D, B^T, signed E-vector / exclusive dofs) + "
-                          "pa::et_run_gather_kernel (E^T over shared-dof runs)", "kernel_ms": kernel_ms,
+                          "pa::et_run_gather_kernel_t<false, false> (E^T over shared-dof runs)", "kernel_ms": kernel_ms,
                 "kernel_reps": nk, "kernel_warmup": 300,
                 # the two clocks of this line must tell the same story (round-2 review): events around nk applies on the launch
                 # stream against the wall clock around --steps applies
