@@ -186,3 +186,57 @@ def test_cxx_hierarchy_with_h_levels(tmp_path):
         st = K.stats()
         assert st["converged"] and abs(st["iterations"] - its) <= 1, (out, st)
         assert abs(float(x.sum()) - sx) < 1e-7 * abs(sx), (out, float(x.sum()))
+
+
+def test_tet_pcg_with_an_h_level_under_the_p_levels():
+    """Tetrahedra: hierarchy [order 1 on the coarse mesh] + [orders 1, 2 on its uniform refinement] (the refinement transfer with one
+    local interpolation matrix per child embedding, then the element-matrix p-prolongation), dense MFMA operators assembled per mesh,
+    PCG: same solution as the p-levels alone on the fine mesh, not more iterations."""
+    from palace_amd import ceed
+    from palace_amd.fem import tet
+    from palace_amd.fem.tetproblem import TetProblem
+
+    ctx = linalg.Context()
+    mc = tet.cube_tet_mesh(3)
+    mf = tet.refine_uniform(mc)
+    fine = TetProblem(ctx, mf, 2)            # orders 1, 2 on the fine mesh
+    coarse = TetProblem(ctx, mc, 1)          # order 1 on the coarse mesh
+    # both problems integrate with the rule of the solution order (the fine problem's): rebuild the coarse geometry on it
+    coarse.pts, coarse.wts = fine.pts, fine.wts
+    coarse.geom = ceed.DenseGeomFactorData(mc.elem_nodes, mc.nodes, mc.attr, mc.geometry_grad_table(fine.pts), fine.wts)
+    mass = ceed.coefficient_context(3, attr_mat=[0] * int(mf.attr.max()), mat_coeff=[np.array([2.08])])
+    curl = ceed.coefficient_context(3)
+    blob = np.concatenate([mass, curl])
+
+    def assemble(prob, s):
+        return ceed.Operator(s.ndofs, s.ndofs).add_dense_integrator(prob.geom, prob.nd_block(s), ceed.QF_HDIVMASS_33, blob,
+                                                                    ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
+
+    f2 = assemble(fine, fine.spaces[1])
+    f1 = f2.coarsen_dense(fine.nd_block(fine.spaces[0]))
+    c1 = assemble(coarse, coarse.spaces[0])
+    spaces = [coarse.spaces[0], fine.spaces[0], fine.spaces[1]]
+    ess = [s.ess_dofs() for s in spaces]
+    local = [c1, f1, f2]
+    A = [linalg.ParOperator(ctx, op, e, linalg.DIAG_ONE) for op, e in zip(local, ess)]
+    A[0] = linalg.AssembledParOperator(ctx, c1.full_assemble_device(), ess[0], linalg.DIAG_ONE)
+    P = [linalg.RefinementTransfer(ctx, *htransfer.tet_refinement(spaces[0], spaces[1])),
+         linalg.DenseInterp(ctx, spaces[1].restriction(), spaces[2].restriction(interp_range=True), tet.nd_tet_transfer_matrix(1, 2))]
+    cs = linalg.cg(ctx, A[0], linalg.jacobi(ctx, A[0]), rel_tol=1e-2, max_it=8)
+    B = linalg.gmg(ctx, A, P, cs, cheby_order=4)
+    K = linalg.cg(ctx, A[-1], B, rel_tol=1e-9, max_it=300)
+    n = spaces[-1].ndofs
+    b = torch.empty(n, dtype=torch.float64, device="cuda")
+    A[-1].mult(torch.ones(n, dtype=torch.float64, device="cuda"), b)
+    b[torch.from_numpy(ess[-1].astype(np.int64)).cuda()] = 0.0
+    x = torch.zeros_like(b)
+    K.mult(b, x)
+    st = K.stats()
+    assert st["converged"], st
+    K0, b0, x0 = fine.pcg_gmg_solver(max_it=300, rel_tol=1e-9, hiptmair=False, coarse="cg")
+    K0.mult(b0, x0)
+    st0 = K0.stats()
+    assert st0["converged"]
+    assert _rel(b.cpu().numpy(), b0.cpu().numpy()) < 1e-12
+    assert _rel(x.cpu().numpy(), x0.cpu().numpy()) < 1e-6
+    assert st["iterations"] <= st0["iterations"] + 3, (st, st0)
