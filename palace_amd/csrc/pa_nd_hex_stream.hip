@@ -140,7 +140,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
   // mass kernel loses 2 %, so they keep the separate buffers)
   using L = typename std::conditional<P1 == 3 && !CPLX && USE_C && !USE_U, NDLayoutInPlaceSwz3, NDLayout<P1, Q1>>::type;
   constexpr int NC = P1 + 1, PP = 3 * P1 * NC * NC, NPL = (PP + 15) / 16, NPK = (NPL + 3) / 4;
+#ifdef PA_METRIC6  // experiment build: |detJ| / w of the metric form recomputed as w^2 / det(H) instead of read (6 rows instead of 7)
+  constexpr int NG = METRIC ? 6 : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
+#else
   constexpr int NG = METRIC ? (USE_U ? 7 : 6) : 6 * ((USE_U ? 1 : 0) + (USE_C ? 1 : 0));
+#endif
   static_assert(PP <= 256, "8-bit slots");
   using streamhost::kIdxPattern;
   using streamhost::kIdxStart0;
@@ -408,9 +412,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
     }
     // D at the four points of this lane's column
     double wab = 1.0;  // affine batch: the in-plane weight w(ta) w(tb) its compact D leaves out (1: exact no-op otherwise)
+    double wxy = 1.0;
     if (AFF) {
       const double wa = (ta == 0 || ta == 3) ? a.wq2[0] : a.wq2[1], wb = (tb == 0 || tb == 3) ? a.wq2[0] : a.wq2[1];
-      wab = aff ? wa * wb : 1.0;
+      wxy = wa * wb;
+      wab = aff ? wxy : 1.0;
     }
 #pragma unroll
     for (int qz = 0; qz < Q1; qz++) {
@@ -467,7 +473,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void nd_hex_stream_kerne
           cmass = 1.0, ccurl = 1.0;
         }
         if (USE_U) {
+#ifdef PA_METRIC6
+          // |detJ| / w = w^2 / det(H)  (det(H) = w^3 / |detJ|); affine rows are H / wab: the factor becomes wz^2 and the common
+          // scaling by wab below completes it
+          const double c00 = H[3] * H[5] - H[4] * H[4], c01 = H[2] * H[4] - H[1] * H[5], c02 = H[1] * H[4] - H[2] * H[3];
+          const double det = H[0] * c00 + H[1] * c01 + H[2] * c02;
+          const double wq_ = (aff ? 1.0 : wxy) * ((qz == 0 || qz == 3) ? a.wq2[0] : a.wq2[1]);
+          const double cm = cmass * wq_ * wq_ / det;
+#else
           const double cm = H[6] * cmass;
+#endif
           const double m[6] = {cm * (H[3] * H[5] - H[4] * H[4]), cm * (H[2] * H[4] - H[1] * H[5]), cm * (H[1] * H[4] - H[2] * H[3]),
                                cm * (H[0] * H[5] - H[2] * H[2]), cm * (H[1] * H[2] - H[0] * H[4]), cm * (H[0] * H[3] - H[1] * H[1])};
           sym_mv(m, U[0][qz], U[1][qz], U[2][qz], U[0][qz], U[1][qz], U[2][qz]);
@@ -1162,6 +1177,9 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
   a.slots = so.d_slots;
   a.qdata = so.qd->d;
   a.qaff = so.qd->d_aff, a.wq2[0] = so.qd->wq2[0], a.wq2[1] = so.qd->wq2[1];
+#ifdef PA_METRIC6
+  if (so.geom->w1.size() == 4) a.wq2[0] = so.geom->w1[0], a.wq2[1] = so.geom->w1[1];
+#endif
   a.coef = so.d_coef_s;
   a.xn = nullptr, a.gtab = nullptr;
   a.x = x, a.y = y, a.ye = so.d_ye;
