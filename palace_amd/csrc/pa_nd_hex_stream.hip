@@ -29,6 +29,9 @@
 #ifndef PA_STREAM_QAHEAD
 #define PA_STREAM_QAHEAD 0  // 1: the instantiations compiled for two waves per SIMD request the q-data one batch ahead
 #endif
+#ifndef PA_KM_MINW_LOW
+#define PA_KM_MINW_LOW 2  // ... and its p < 3 instantiations (the p-coarsened levels); experiment builds: 3
+#endif
 #ifndef PA_KM_MINW
 #define PA_KM_MINW 2  // waves per SIMD the p = 3 curl-curl + mass instantiation is compiled for (experiment builds: 3)
 #endif
@@ -1209,7 +1212,7 @@ static void launch_p(const SubOp &so, const double *x, double *y, bool masked, h
       break;
     case PA_QF_HDIVMASS_33:
       // (packed D of both terms, anisotropic materials: twelve doubles per point, 96 registers of q-data per lane; round 5)
-      if (m) launch_variant<P1, true, true, true, (P1 == 3 ? PA_KM_MINW : 2)>(so, a, s);
+      if (m) launch_variant<P1, true, true, true, (P1 == 3 ? PA_KM_MINW : PA_KM_MINW_LOW)>(so, a, s);
       else launch_variant<P1, true, true, false, 2>(so, a, s);
       break;
     default: throw Error("QFunction not available for H(curl) hexahedra");
