@@ -1158,7 +1158,12 @@ int pa_op_prepare_fused_step(pa_op *op, int *available) {
     PA_REQUIRE(op && available, "null argument");
     *available = 0;
     const bool enabled = !(getenv("PALACE_AMD_FUSED_STEP") && atoi(getenv("PALACE_AMD_FUSED_STEP")) == 0);
-    if (!enabled || !op->has_essential || op->subs.size() != 1 || !op->dsubs.empty() || !op->msubs.empty()) return;
+    if (!enabled || !op->has_essential || !op->msubs.empty()) return;
+    if (op->subs.empty() && op->dsubs.size() == 1) {  // one dense-table block: its CSR-form gather owns every row already
+      *available = dense_fused_step_ok(*op->dsubs[0]) ? 1 : 0;
+      return;
+    }
+    if (op->subs.size() != 1 || !op->dsubs.empty()) return;
     SubOp *so = op->subs[0];
     // (four points per direction: pa_nd_hex_stream.hip; five: pa_nd_hex_stream5.hip -- nd_hex_stream_ok covers both; H1 blocks
     // whose y = A x runs on the streaming kernel: pa_h1_hex_stream.hip)
@@ -1174,9 +1179,16 @@ int pa_op_prepare_fused_step(pa_op *op, int *available) {
 int pa_op_mult_cheb_step(pa_op *op, const double *x, const pa_cheb_step *step, int diag_policy, void *stream) {
   return guarded([&] {
     PA_REQUIRE(op && x && step && step->dinv && step->r0 && step->out, "null argument");
-    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->n_all > 0, "pa_op_prepare_fused_step has not been called (or found no fused form)");
     PA_REQUIRE(x != step->out, "the step cannot overwrite its own input");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
+    if (op->subs.empty() && op->dsubs.size() == 1 && dense_fused_step_ok(*op->dsubs[0])) {
+      const DenseSub &ds = *op->dsubs[0];
+      launch_dense_apply(ds, x, true, (hipStream_t)stream);
+      launch_dense_gather_step(ds, x, GatherStep{step->sd, step->sr, step->dinv, step->r0, step->e_prev, step->out, step->add, nullptr, 1},
+                               diag_policy ? 1 : 0, (hipStream_t)stream);
+      return;
+    }
+    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->n_all > 0, "pa_op_prepare_fused_step has not been called (or found no fused form)");
     const SubOp &so = *op->subs[0];
     launch_nd_hex_stream_all(so, x, (hipStream_t)stream);
     launch_et_run_gather_step(so, x, GatherStep{step->sd, step->sr, step->dinv, step->r0, step->e_prev, step->out, step->add, nullptr, 1},
@@ -1188,9 +1200,15 @@ int pa_op_mult_residual(pa_op *op, const double *y, const double *b, double *res
                         int diag_policy, void *stream) {
   return guarded([&] {
     PA_REQUIRE(op && y && b && (res || d0) && (!d0 || dinv), "null argument");
-    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->n_all > 0, "pa_op_prepare_fused_step has not been called (or found no fused form)");
     PA_REQUIRE(y != res && y != d0, "the residual cannot overwrite the operator's input");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
+    if (op->subs.empty() && op->dsubs.size() == 1 && dense_fused_step_ok(*op->dsubs[0])) {
+      const DenseSub &ds = *op->dsubs[0];
+      launch_dense_apply(ds, y, true, (hipStream_t)stream);
+      launch_dense_gather_step(ds, y, GatherStep{0.0, c0, dinv, b, nullptr, d0, 0, res, 2}, diag_policy ? 1 : 0, (hipStream_t)stream);
+      return;
+    }
+    PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->n_all > 0, "pa_op_prepare_fused_step has not been called (or found no fused form)");
     const SubOp &so = *op->subs[0];
     launch_nd_hex_stream_all(so, y, (hipStream_t)stream);
     launch_et_run_gather_step(so, y, GatherStep{0.0, c0, dinv, b, nullptr, d0, 0, res, 2}, diag_policy ? 1 : 0, (hipStream_t)stream);
@@ -1241,14 +1259,21 @@ int pa_op_mult_split_step(pa_op *op, const double *x, const double *xg0, const d
   return guarded([&] {
     PA_REQUIRE(op && x && xg0 && yg && st && st->r0 && st->iface_mask && st->t_iface, "null argument");
     PA_REQUIRE(st->mode == 1 ? (st->dinv && st->out) : (st->mode == 2 && (st->res || st->out) && (!st->out || st->dinv)), "invalid step");
-    PA_REQUIRE(op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->n_all > 0,
-               "pa_op_prepare_fused_step has not been called (or found no fused form)");
     PA_REQUIRE(x != st->out && x != st->res, "the step cannot overwrite the operator's input");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed split apply of a non-symmetric operator");
     PA_REQUIRE(ess_policy < 0 || op->has_essential, "pa_op_set_essential has not been called");
-    const SubOp &so = *op->subs[0];
     const SplitIO io{n_true, xg0, xg1, sel, yg};
     hipStream_t s = (hipStream_t)stream;
+    if (op->subs.empty() && op->dsubs.size() == 1 && dense_fused_step_ok(*op->dsubs[0]) && dense_split_ok(*op->dsubs[0])) {
+      const DenseSub &ds = *op->dsubs[0];
+      launch_dense_apply(ds, x, ess_policy >= 0, s, &io);
+      launch_dense_gather_step(ds, x, GatherStep{st->sd, st->sr, st->dinv, st->r0, st->e_prev, st->out, st->add, st->res, st->mode,
+                                                 st->iface_mask, st->t_iface}, ess_policy, s, &io);
+      return;
+    }
+    PA_REQUIRE(op->subs.size() == 1 && op->dsubs.empty() && op->subs[0]->n_all > 0,
+               "pa_op_prepare_fused_step has not been called (or found no fused form)");
+    const SubOp &so = *op->subs[0];
     launch_nd_hex_stream_all(so, x, s, &io);
     launch_et_run_gather_step(so, x, GatherStep{st->sd, st->sr, st->dinv, st->r0, st->e_prev, st->out, st->add, st->res, st->mode,
                                                 st->iface_mask, st->t_iface}, ess_policy, s, &io);

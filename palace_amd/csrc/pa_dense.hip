@@ -1999,23 +1999,52 @@ void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *
 
 // E^T of a split-vector apply: the sum of et_gather_kernel (same order, hence the same bits), rows >= nsplit to the ghost-row
 // buffer, ParOperator's essential rows fixed on the way (rap.cpp:223-233)
-__global__ void et_gather_split_kernel(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
-                                       const double *__restrict__ ye, double *__restrict__ y, double *__restrict__ yg,
-                                       const int nsplit, const uint8_t *__restrict__ ess, const double *__restrict__ x,
-                                       const int ess_policy) {
+// STEP (round 6): the sum is consumed by a smoother step / residual (GatherStep, pa_internal.hpp) instead of being stored -- the dense
+// gather owns every row, so the epilogue is all there is to it; interface dofs of a multi-rank apply leave their partial sum in
+// t_iface for the halo kernel, ghost rows go to yg as in the plain form
+template <bool STEP>
+__global__ void et_gather_split_kernel_t(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                                         const double *__restrict__ ye, double *__restrict__ y, double *__restrict__ yg,
+                                         const int nsplit, const uint8_t *__restrict__ ess, const double *__restrict__ x,
+                                         const int ess_policy, const GatherStep st) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n) return;
+  double s = 0.0;
   if (ess_policy >= 0 && ess && ess[d] && d < nsplit) {
-    y[d] = ess_policy ? x[d] : 0.0;
+    s = ess_policy ? x[d] : 0.0;
+    if (!STEP) {
+      y[d] = s;
+      return;
+    }
+  } else {
+    for (int k = tptr[d]; k < tptr[d + 1]; k++) {
+      const int t = tent[k];
+      const double v = ye[t >= 0 ? t : -1 - t];
+      s += t >= 0 ? v : -v;
+    }
+  }
+  if (!STEP) {
+    (d < nsplit ? y : yg)[d] = s;
     return;
   }
-  double s = 0.0;
-  for (int k = tptr[d]; k < tptr[d + 1]; k++) {
-    const int t = tent[k];
-    const double v = ye[t >= 0 ? t : -1 - t];
-    s += t >= 0 ? v : -v;
+  if (d >= nsplit) {
+    yg[d] = s;
+    return;
   }
-  (d < nsplit ? y : yg)[d] = s;
+  if (st.iface_mask && (st.iface_mask[d] & 2)) {
+    st.t_iface[d] = s;
+    return;
+  }
+  const double rv = st.r0[d] - s;
+  if (st.mode == 2) {
+    if (st.res) st.res[d] = rv;
+    if (st.out) st.out[d] = st.sr * st.dinv[d] * rv;
+    return;
+  }
+  const double e = x[d];
+  double dk = st.sr * st.dinv[d] * rv;
+  dk += st.sd * (e - (st.ep ? st.ep[d] : 0.0));
+  st.out[d] = (st.add ? st.out[d] : 0.0) + (e + dk);
 }
 
 // E^T of the dense path by runs (pa_stream_host.hpp: build_runs_dense): one thread per L-dof, its run and offset from the chunk
@@ -2138,9 +2167,9 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
   if (split || ess_policy >= 0) {  // (one vector with the essential rows fixed on the way: the same kernel, nothing beyond y)
     PA_REQUIRE(!accumulate, "split vectors / fused essential rows: y = A x only");
     PA_REQUIRE(ess_policy < 0 || (ds.d_ess_flag && x), "essential rows fused into the gather: pa_op_set_essential first");
-    hipLaunchKernelGGL(et_gather_split_kernel, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent,
+    hipLaunchKernelGGL(et_gather_split_kernel_t<false>, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent,
                        ye ? ye : ds.d_ye, y, split ? split->yg - split->n_true : y, split ? split->n_true : 0x7fffffff,
-                       ds.d_ess_flag, x, ess_policy);
+                       ds.d_ess_flag, x, ess_policy, GatherStep{});
     PA_HIP(hipGetLastError());
     return;
   }
@@ -2153,6 +2182,18 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
     return;
   }
   launch_et_gather_raw(ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye, y, accumulate, s);
+}
+
+bool dense_fused_step_ok(const DenseSub &ds) { return ds.d_ess_flag && !ds.d_rchunk && ds.d_tptr && ds.d_tent && ds.d_ye; }
+void launch_dense_gather_step(const DenseSub &ds, const double *x, const GatherStep &step, int ess_policy, hipStream_t s,
+                              const SplitIO *split) {
+  PA_REQUIRE(dense_fused_step_ok(ds) && x, "dense fused step: essential list fused (pa_op_set_essential) and the CSR-form gather expected");
+  PA_REQUIRE(!split || (step.iface_mask && step.t_iface), "split form of the fused step: interface mask and buffer missing");
+  if (ds.lsize == 0) return;
+  hipLaunchKernelGGL(et_gather_split_kernel_t<true>, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye,
+                     nullptr, split ? split->yg - split->n_true : nullptr, split ? split->n_true : 0x7fffffff, ds.d_ess_flag, x,
+                     ess_policy, step);
+  PA_HIP(hipGetLastError());
 }
 
 void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {

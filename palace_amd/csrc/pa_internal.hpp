@@ -390,6 +390,10 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
 bool dense_split_ok(const DenseSub &ds);
 bool dense_complex_ok(const DenseSub &dr, const DenseSub &di);
 void launch_dense_gather_signed(const DenseSub &ds, double *y, double sign, bool skip_ess, hipStream_t s);
+// the fused smoother step / residual on a dense block (round 6): the CSR-form gather owns every row; its epilogue consumes the sum
+bool dense_fused_step_ok(const DenseSub &ds);
+void launch_dense_gather_step(const DenseSub &ds, const double *x, const GatherStep &step, int ess_policy, hipStream_t s,
+                              const SplitIO *split = nullptr);
 void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s,
                           bool masked = false);
 void launch_dense_diag(const DenseSub &ds, double *diag, hipStream_t s);

@@ -107,3 +107,44 @@ def test_tet_pcg_gmg_converges_to_direct_solution(hiptmair):
     ref = spl.spsolve(A.tocsc(), b.cpu().numpy())
     err = np.abs(x.cpu().numpy() - ref).max() / np.abs(ref).max()
     assert err < 1e-8, err
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_tet_chebyshev_steps_fused_into_the_gather(monkeypatch, p):
+    """Round 6: on a dense-table block the E^T gather owns every row, so the smoother step / residual is its epilogue
+    (pa_op_mult_cheb_step, dense branch): Chebyshev on K + M of Nedelec tetrahedra (oriented and curl-oriented restrictions, curved
+    elements) with essential dofs, fused against the same smoother with the step as a vector kernel (PALACE_AMD_FUSED_STEP=0), zero
+    and non-zero initial guess; the PCG + p-multigrid solves of this file run through it as well."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem import tet
+    from palace_amd.fem.tetproblem import TetProblem
+
+    ctx = linalg.Context()
+    mesh = tet.to_quadratic(tet.cube_tet_mesh(3), _warp)
+    prob = TetProblem(ctx, mesh, p, orders=[p])
+    s = prob.spaces[0]
+    mass = ceed.coefficient_context(3, attr_mat=[0], mat_coeff=[np.array([2.08])])
+    op = ceed.Operator(s.ndofs, s.ndofs).add_dense_integrator(prob.geom, prob.nd_block(s), ceed.QF_HDIVMASS_33,
+                                                              np.concatenate([mass, ceed.coefficient_context(3)]),
+                                                              ceed.EVAL_CURL | ceed.EVAL_INTERP).finalize()
+    ess = s.ess_dofs()
+    A = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+    S = linalg.chebyshev(ctx, A, order=4)
+    assert S.fused_step()
+    monkeypatch.setenv("PALACE_AMD_FUSED_STEP", "0")
+    S0 = linalg.chebyshev(ctx, A, order=4)
+    assert not S0.fused_step() and S0.lambda_max() == S.lambda_max()
+    n = s.ndofs
+    rng = np.random.default_rng(41 + p)
+    b, g = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    b[ess] = 0.0
+    g[ess] = 0.0
+    dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    y = S.mult(dev(b), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    y0 = S0.mult(dev(b), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    z = S.mult(dev(b), dev(g.copy()), initial_guess=True).cpu().numpy()
+    z0 = S0.mult(dev(b), dev(g.copy()), initial_guess=True).cpu().numpy()
+    assert np.linalg.norm(y - y0) < 1e-13 * np.linalg.norm(y0) and np.linalg.norm(z - z0) < 1e-13 * np.linalg.norm(z0)
+    assert np.all(y[ess] == 0.0 * y[ess] + y0[ess])
