@@ -269,6 +269,11 @@ int pa_orthonormalize_column_complex(pa_context *ctx, int kind, int m, const dou
 /* A / B switch of the above inside (F)GMRES and pa_orthogonalize_column: 0 = the host drives every inner product and update
  * (one synchronisation per inner product, the form of rounds 1-4), 1 = device-resident coefficients (default). */
 int pa_set_device_orthogonalization(int on);
+/* Round 6: modified Gram-Schmidt columns (one rank, 16-byte aligned vectors that fit the register file: a few million entries)
+ * keep w in registers for the whole column -- one pass over every basis vector instead of four vector passes per basis vector
+ * (orthog.hip: k_mgs_resident; PALACE_AMD_GS_RESIDENT=0 keeps the chained form).  Returns how many columns this process has
+ * orthogonalised that way so far (tests and the bench line tell the two forms apart with it). */
+long long pa_orthog_resident_columns(void);
 int pa_gmres_set_orthogonalization(pa_solver *S, int kind);
 int pa_solver_mult(pa_solver *S, const double *b, double *x, int initial_guess);
 /* Named host ranges for profilers (roctx; rocprofv3 --marker-trace).  The library itself brackets the reference's BlockTimer

@@ -610,6 +610,7 @@ double OrthonormalizeColumn(const Context &c, Orthogonalization kind, const std:
 void OrthogonalizeColumnDevice(const Context &c, Orthogonalization kind, const std::vector<Vector> &V, Vector &w, const Vector *x,
                                double *H, int m, bool normalize, double *hn);
 bool DeviceOrthogonalization();
+long long ResidentColumns();  // columns orthogonalised with w resident in registers so far (orthog.hip: k_mgs_resident)
 void SetDeviceOrthogonalization(bool on);  // A / B switch (default on; PALACE_AMD_GS=host starts with it off)
 }  // namespace linalg
 

@@ -237,6 +237,189 @@ __global__ __launch_bounds__(kBlk) void k_gs_scale(double *__restrict__ wr, doub
   }
 }
 
+// ---- modified Gram-Schmidt with w RESIDENT IN THE REGISTER FILE (round 6) ---------------------------------------------------------
+// The chained form above passes over w once per basis vector (read w, v_j, v_{j+1}, write w: four vector passes per column of
+// H).  MI355X has 128 MB of vector registers: a Krylov vector of a few million entries fits in them, spread over one block per
+// compute unit.  This kernel loads w ONCE, keeps it in registers for the whole column, reads every v_j once (its slice stays in
+// registers between the inner product and the update), and stores w once -- normalised.  The inner product of step j is a grid-wide
+// sum: per-block partial sums, a grid barrier (monotonic two-level counters, agent scope), then EVERY block adds the partial sums
+// in block order, so every block subtracts the same h_j, bit for bit, and the result is reproducible run to run.
+// Same arithmetic as orthog.hpp:41-62 + iterative.cpp:629-633 (h_j = (w, v_j) of the UPDATED w, w -= h_j v_j, then the norm).
+// Launched as a cooperative kernel (every block resident: the barrier cannot dead-lock); one rank only (the sum over ranks of the
+// chained form is a stream operation between two launches).
+constexpr int kResBlk = 512, kResMaxGrid = 1024;
+struct ResArgs {
+  double *wr, *wi;
+  const double *const *vr, *const *vi;
+  int m, normalize;
+  long long n;
+  double *partial;  // [2 parities][2 components][kResMaxGrid]
+  unsigned *bar;    // group counters at [16 g], g < 16 (one 64-byte line each); the top counter at [256]; zero at launch
+  double *coef, *nrm2;
+};
+
+// sums v[0 .. NV) over the block; the result is valid in thread 0 only
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double (*sm)[kResBlk / 64]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const double s = wave_sum(v[k]);
+    if (lane == 0) sm[k][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < kResBlk / 64; q++) t += sm[k][q];
+      v[k] = t;
+    }
+  }
+  __syncthreads();
+}
+
+// a 16-byte lane at `base + off` with `base` wave-uniform (scalar registers) and a 32-bit per-lane byte offset: one address register
+// per thread for every slot of every vector, instead of a 64-bit pair per slot.  The basis pointers are read from memory: the cast
+// tells the compiler they are device memory (global_load, not flat_load).
+#define PA_GLOBAL __attribute__((address_space(1)))
+typedef double d2n __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned long long scalar_u64(unsigned long long u) {  // (pins a wave-uniform value to scalar registers)
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double2 ld_lane(const double *base, unsigned off) {
+  const d2n v = *reinterpret_cast<const PA_GLOBAL d2n *>((const PA_GLOBAL char *)scalar_u64((unsigned long long)base) + off);
+  return double2{v.x, v.y};
+}
+__device__ __forceinline__ void st_lane(double *base, unsigned off, double2 v) {
+  *reinterpret_cast<PA_GLOBAL d2n *>((PA_GLOBAL char *)scalar_u64((unsigned long long)base) + off) = d2n{v.x, v.y};
+}
+
+template <bool CPLX, int R>
+__global__ __launch_bounds__(kResBlk) void k_mgs_resident(const ResArgs A) {
+  constexpr int NC = CPLX ? 2 : 1;
+  __shared__ double sm[2][kResBlk / 64];
+  __shared__ double hb[2];
+  const long long nv = A.n / 2, stride = (long long)gridDim.x * kResBlk;
+  const long long i0 = (long long)blockIdx.x * kResBlk + threadIdx.x;
+  const bool tail = (A.n & 1) && blockIdx.x == 0 && threadIdx.x == 0;  // the odd last entry
+  const unsigned G = gridDim.x, grp = blockIdx.x & 15u, ng = (G - grp + 15u) / 16u, ngroups = G < 16u ? G : 16u;
+  // slots r < R - 1 are in range for every thread (the host checks (R - 1) stride <= nv): only the last one is predicated -- a
+  // select per slot keeps the loaded and the selected value alive side by side, 8 R registers more
+  const bool in_last = i0 + (R - 1) * stride < nv;
+  const unsigned o = 16u * (unsigned)i0;  // (bytes; i0 < 2^19: the per-slot offset r * stride goes into the scalar base)
+  double2 a[R], b[R];
+  double at = 0.0, bt = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const bool in = r < R - 1 || in_last;
+    a[r] = in ? ld_lane(A.wr + 2 * r * stride, o) : double2{0.0, 0.0};
+    b[r] = (CPLX && in) ? ld_lane(A.wi + 2 * r * stride, o) : double2{0.0, 0.0};
+  }
+  if (tail) at = A.wr[A.n - 1], bt = CPLX ? A.wi[A.n - 1] : 0.0;
+  // grid-wide sum of (v[0], v[1]) in step `step` (the barrier's round): the result in every thread of every block, the same bits
+  auto grid_sum = [&](double (&v)[2], const int step, const bool two) {
+    block_sum<2>(v, sm);
+    double *part = A.partial + (size_t)(step & 1) * 2 * kResMaxGrid;
+    if (threadIdx.x == 0) {
+      // (gfx9: one in-order counter covers loads and stores, agent-scope stores are written through -- grid_reduce above)
+      __hip_atomic_store(&part[blockIdx.x], v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (two) __hip_atomic_store(&part[kResMaxGrid + blockIdx.x], v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // grid barrier: the last block of a group bumps the top counter; everybody waits for the top counter
+      if (__hip_atomic_fetch_add(&A.bar[16u * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)step * ng + ng - 1u)
+        __hip_atomic_fetch_add(&A.bar[256], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(&A.bar[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1) * ngroups)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    // every block adds the partial sums of all blocks in the same order
+    double h[2] = {0.0, 0.0};
+    for (unsigned q = threadIdx.x; q < G; q += kResBlk) {
+      h[0] += __hip_atomic_load(&part[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (two) h[1] += __hip_atomic_load(&part[kResMaxGrid + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    block_sum<2>(h, sm);
+    if (threadIdx.x == 0) hb[0] = h[0], hb[1] = h[1];
+    __syncthreads();
+    v[0] = hb[0], v[1] = hb[1];
+  };
+  for (int j = 0; j < A.m; j++) {
+    const double *pr = A.vr[j], *pi = CPLX ? A.vi[j] : nullptr;
+    double2 c[R], d[R];
+    double ct = 0.0, dt = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const bool in = r < R - 1 || in_last;
+      c[r] = in ? ld_lane(pr + 2 * r * stride, o) : double2{0.0, 0.0};
+      d[r] = (CPLX && in) ? ld_lane(pi + 2 * r * stride, o) : double2{0.0, 0.0};
+    }
+    if (tail) ct = pr[A.n - 1], dt = CPLX ? pi[A.n - 1] : 0.0;
+    double2 t0{0.0, 0.0}, t1{0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < R; r++) {  // (w, v_j) = v_j^H w (vector.cpp:674-685)
+      t0 = mul_acc(t0, a[r], c[r]);
+      if (CPLX) {
+        t0 = mul_acc(t0, b[r], d[r]);
+        t1 = mul_sub(mul_acc(t1, b[r], c[r]), a[r], d[r]);
+      }
+    }
+    double v[2] = {hsum(t0), hsum(t1)};
+    if (tail) {
+      v[0] += at * ct;
+      if (CPLX) v[0] += bt * dt, v[1] += bt * ct - at * dt;
+    }
+    grid_sum(v, j, CPLX);
+    const double hr = v[0], hi = v[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      A.coef[NC * j] = hr;
+      if (CPLX) A.coef[NC * j + 1] = hi;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {  // (hr + i hi)(c + i d) = (hr c - hi d) + i (hr d + hi c)
+      a[r] = mul_sub(a[r], double2{hr, hr}, c[r]);
+      if (CPLX) {
+        a[r] = mul_acc(a[r], double2{hi, hi}, d[r]);
+        b[r] = mul_sub(mul_sub(b[r], double2{hr, hr}, d[r]), double2{hi, hi}, c[r]);
+      }
+    }
+    if (tail) {
+      at -= hr * ct;
+      if (CPLX) at += hi * dt, bt = bt - hr * dt - hi * ct;
+    }
+  }
+  double s = 1.0;
+  if (A.normalize) {  // iterative.cpp:632-633: w *= 1 / ||w||
+    double2 t0{0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      t0 = mul_acc(t0, a[r], a[r]);
+      if (CPLX) t0 = mul_acc(t0, b[r], b[r]);
+    }
+    double v[2] = {hsum(t0), 0.0};
+    if (tail) {
+      v[0] += at * at;
+      if (CPLX) v[0] += bt * bt;
+    }
+    grid_sum(v, A.m, false);
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.nrm2[0] = v[0];
+    s = 1.0 / sqrt(fabs(v[0]));
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    if (r < R - 1 || in_last) {
+      st_lane(A.wr + 2 * r * stride, o, double2{a[r].x * s, a[r].y * s});
+      if (CPLX) st_lane(A.wi + 2 * r * stride, o, double2{b[r].x * s, b[r].y * s});
+    }
+  }
+  if (tail) {
+    A.wr[A.n - 1] = at * s;
+    if (CPLX) A.wi[A.n - 1] = bt * s;
+  }
+}
+
 inline int grid_for(long long n) { return (int)std::max(1LL, std::min<long long>((n + kBlk - 1) / kBlk, kMaxBlk)); }
 inline uintptr_t bits(const void *p) { return reinterpret_cast<uintptr_t>(p); }
 
@@ -248,17 +431,88 @@ struct Column {  // the vectors of one column as raw pointers (imaginary parts n
   int m;
 };
 
-// device scratch: [counter | partial sums 2 kGB kMaxBlk | coefficients pass 1 (NC m) | pass 2 (NC m) | ||w||^2]
+// device scratch: [counter | partial sums 2 kGB kMaxBlk | barrier words of the resident form (160 doubles) | coefficients pass 1
+// (NC m) | pass 2 (NC m) | ||w||^2 | pad | basis pointers of the resident form (2 m)]; pinned: [the H column as on the device |
+// basis pointers]
+constexpr size_t kBarDoubles = 160;
 struct GsBuffers {
   unsigned *counter;
   double *partial, *coef1, *coef2, *nrm2, *host;
+  unsigned *bar;
+  const double **ptrs, **host_ptrs;
 };
 GsBuffers buffers(const Context &c, int m) {
   Workspace &w = c.Work();
-  const size_t head = 2 + (size_t)2 * kGB * kMaxBlk;
-  double *d = w.GsDevice(head + 4 * (size_t)m + 2);
-  return {reinterpret_cast<unsigned *>(d), d + 2, d + head, d + head + 2 * (size_t)m, d + head + 4 * (size_t)m,
-          w.GsPinned(4 * (size_t)m + 2)};  // (m >= 1 here)
+  static_assert(sizeof(double *) == sizeof(double), "pointer lists share the double scratch");
+  const size_t head = 2 + (size_t)2 * kGB * kMaxBlk + kBarDoubles;
+  double *d = w.GsDevice(head + 6 * (size_t)m + 2);
+  double *h = w.GsPinned(6 * (size_t)m + 2);  // (m >= 1 here)
+  return {reinterpret_cast<unsigned *>(d), d + 2, d + head, d + head + 2 * (size_t)m, d + head + 4 * (size_t)m, h,
+          reinterpret_cast<unsigned *>(d + head - kBarDoubles), reinterpret_cast<const double **>(d + head + 4 * (size_t)m + 2),
+          reinterpret_cast<const double **>(h + 4 * (size_t)m + 2)};
+}
+
+// The resident form (k_mgs_resident): true if it ran.  One block of 1 024 threads per compute unit, R 16-byte lanes of w (and of
+// v_j) per thread; the smallest R that holds the vector is taken, a vector that does not fit keeps the chained form.
+long long g_resident_columns = 0;
+bool g_resident_failed = false;  // the cooperative launch has failed once: the chained form from then on
+bool resident_mode() {           // PALACE_AMD_GS_RESIDENT=0 (read at every column: A / B runs in one process) keeps the chained form
+  const char *e = std::getenv("PALACE_AMD_GS_RESIDENT");
+  return !g_resident_failed && !(e && e[0] == '0');
+}
+template <bool CPLX, int R>
+int resident_capacity_blocks() {  // blocks of k_mgs_resident<CPLX, R> the device holds at once (0: no cooperative launch)
+  static int cap = -1;
+  if (cap < 0) {
+    int dev = 0, coop = 0, nb = 0, n_cu = 0;
+    PA_HIP(hipGetDevice(&dev));
+    PA_HIP(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev));
+    PA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_resident<CPLX, R>, kResBlk, 0) != hipSuccess) nb = 0;
+    cap = coop ? std::min(n_cu * nb, kResMaxGrid) : 0;
+  }
+  return cap;
+}
+template <bool CPLX, int R>
+bool launch_resident(const Context &c, const ResArgs &A0, long long nv, bool &fits) {
+  const long long need = std::max<long long>(1, (nv + (long long)kResBlk * R - 1) / ((long long)kResBlk * R));
+  fits = need <= resident_capacity_blocks<CPLX, R>();
+  if (!fits) return false;
+  if ((long long)(R - 1) * need * kResBlk > nv) return false;  // (the kernel predicates its last slot only; cannot happen for the
+                                                                // smallest R that fits unless the device holds very few blocks)
+  ResArgs A = A0;
+  PA_HIP(hipMemsetAsync(A.bar, 0, 257 * sizeof(unsigned), c.stream));
+  void *args[] = {&A};
+  const hipError_t rc = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_mgs_resident<CPLX, R>), dim3((unsigned)need),
+                                                   dim3(kResBlk), args, 0, c.stream);
+  if (rc != hipSuccess) {
+    (void)hipGetLastError();
+    g_resident_failed = true;
+    return false;
+  }
+  return true;
+}
+template <bool CPLX>
+bool run_resident(const Context &c, const Column &col, bool normalize, const GsBuffers &B) {
+  const int m = col.m;
+  for (int j = 0; j < m; j++) B.host_ptrs[j] = col.vr[j], B.host_ptrs[m + j] = CPLX ? col.vi[j] : nullptr;
+  PA_HIP(hipMemcpyAsync(B.ptrs, B.host_ptrs, sizeof(double *) * 2 * (size_t)m, hipMemcpyHostToDevice, c.stream));
+  const ResArgs A{col.wr, col.wi, B.ptrs, B.ptrs + m, m, normalize ? 1 : 0, col.n, B.partial, B.bar, B.coef1, B.nrm2};
+  const long long nv = col.n / 2;
+  bool fits = false;
+#define PA_TRY_RESIDENT(R)                                       \
+  {                                                              \
+    const bool ran = launch_resident<CPLX, R>(c, A, nv, fits);   \
+    if (fits) return ran;                                        \
+  }
+  // the smallest register footprint that holds the vector (more blocks per compute unit while it is small)
+  if constexpr (CPLX) {
+    PA_TRY_RESIDENT(1) PA_TRY_RESIDENT(2) PA_TRY_RESIDENT(4) PA_TRY_RESIDENT(8) PA_TRY_RESIDENT(10) PA_TRY_RESIDENT(12)
+  } else {
+    PA_TRY_RESIDENT(1) PA_TRY_RESIDENT(2) PA_TRY_RESIDENT(4) PA_TRY_RESIDENT(8) PA_TRY_RESIDENT(16) PA_TRY_RESIDENT(20) PA_TRY_RESIDENT(24)
+  }
+#undef PA_TRY_RESIDENT
+  return false;
 }
 
 template <bool CPLX>
@@ -313,9 +567,13 @@ void run_column(const Context &c, Orthogonalization kind, const Column &col, boo
     PA_HIP(hipGetLastError());
   };
 
-  bool two_passes = false;
+  bool two_passes = false, resident = false;
   if (m == 0) {
     if (normalize) update(0, 0, B.coef1, TAIL_NORM, nullptr, nullptr, B.nrm2);
+  } else if (kind == Orthogonalization::MGS && !weighted && !c.comm && wide && resident_mode() &&
+             run_resident<CPLX>(c, col, normalize, B)) {
+    resident = true;  // (w stayed in registers for the whole column, normalised there)
+    g_resident_columns++;
   } else if (kind == Orthogonalization::MGS) {
     PA_REQUIRE(!weighted, "the device-chained modified Gram-Schmidt takes the plain inner product");
     update(0, 0, B.coef1, TAIL_DOT, col.vr[0], CPLX ? col.vi[0] : nullptr, B.coef1);  // (w, v_0)
@@ -337,7 +595,7 @@ void run_column(const Context &c, Orthogonalization kind, const Column &col, boo
       two_passes = true;
     }
   }
-  if (normalize) {
+  if (normalize && !resident) {
     if (c.comm) c.comm->AllReduceSum(B.nrm2, 1, c.stream);
     hipLaunchKernelGGL((k_gs_scale<CPLX>), dim3(grid_for(col.n)), dim3(kBlk), 0, c.stream, col.wr, col.wi, col.n, B.nrm2);
     PA_HIP(hipGetLastError());
@@ -364,6 +622,7 @@ bool device_gs() { return gs_mode() != 0; }
 namespace linalg {
 
 bool DeviceOrthogonalization() { return device_gs(); }
+long long ResidentColumns() { return g_resident_columns; }
 void SetDeviceOrthogonalization(bool on) { gs_mode() = on ? 1 : 0; }
 
 void OrthogonalizeColumnDevice(const Context &c, Orthogonalization kind, const std::vector<Vector> &V, Vector &w, const Vector *x,

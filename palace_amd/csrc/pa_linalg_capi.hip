@@ -812,6 +812,7 @@ int pa_orthonormalize_column_complex(pa_context *ctx, int kind, int m, const dou
 int pa_set_device_orthogonalization(int on) {
   return guarded([&] { linalg::SetDeviceOrthogonalization(on != 0); });
 }
+long long pa_orthog_resident_columns(void) { return linalg::ResidentColumns(); }
 int pa_gmres_set_orthogonalization(pa_solver *S, int kind) {
   return guarded([&] {
     PA_REQUIRE(S && kind >= 0 && kind <= 2, "bad argument");

@@ -305,6 +305,13 @@ class Context:
     def set_device_orthogonalization(on):
         _lib.check(_L().pa_set_device_orthogonalization(C.c_int(1 if on else 0)))
 
+    @staticmethod
+    def resident_columns():
+        """Columns orthogonalised so far with w resident in the register file (orthog.hip: k_mgs_resident)."""
+        f = _L().pa_orthog_resident_columns
+        f.restype = C.c_longlong
+        return int(f())
+
     def orthonormalize_column(self, kind, V, w):
         """One Arnoldi column (iterative.cpp:629-633): orthogonalise, norm, normalise; returns (H, hn)."""
         m = len(V)

@@ -232,3 +232,66 @@ def test_orthonormalize_column_across_rank_threads(kind, cplx):
         assert abs(hn - hn_ref) < 1e-12 * hn_ref
         assert np.abs(ws - wref[cuts[r]:cuts[r + 1]] / hn_ref).max() < 1e-11
         assert np.array_equal(H, out[0][0]) and hn == out[0][1]  # (the sums are global: the same bits on every rank)
+
+
+# ---- modified Gram-Schmidt with w resident in the register file (orthog.hip: k_mgs_resident; round 6) ----------------------------
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,m", [(2, 1), (3, 2), (1000, 9), (4097, 27), (300001, 10), (1500001, 5), (2180208, 12)])
+def test_resident_mgs_against_the_chained_form_and_the_oracle(ctx, monkeypatch, cplx, n, m):
+    """The same column with w kept in registers (one pass over every basis vector) and with the chained kernels of round 5
+    (PALACE_AMD_GS_RESIDENT=0, read per column): H, the norm and the normalised vector agree to rounding; against the oracle's three
+    statements (orthog.hpp:41-62, iterative.cpp:629-633) where the oracle is quick; the resident form is reproducible to the
+    bit; sizes: one 16-byte lane, an odd tail, every slot count up to config 3's vector (2 180 208 complex entries)."""
+    rng = np.random.default_rng(300 + m)
+    scale = 1.0 / np.sqrt(n)
+    mk = lambda: rng.normal(size=n) * scale
+    Vr = [_dev(mk()) for _ in range(m)]
+    Vi = [_dev(mk()) for _ in range(m)] if cplx else None
+    w0r, w0i = mk() * np.sqrt(n), mk() * np.sqrt(n)
+
+    def run():
+        wr, wi = _dev(w0r), _dev(w0i)
+        if cplx:
+            H, hn = ctx.orthonormalize_column_complex("MGS", Vr, Vi, wr, wi)
+            return H, hn, wr.cpu().numpy() + 1j * wi.cpu().numpy()
+        H, hn = ctx.orthonormalize_column("MGS", Vr, wr)
+        return H, hn, wr.cpu().numpy()
+
+    before = ctx.resident_columns()
+    H1, hn1, w1 = run()
+    assert ctx.resident_columns() == before + 1, "the resident form did not run"
+    H2, hn2, w2 = run()
+    assert np.array_equal(H1, H2) and hn1 == hn2 and np.array_equal(w1, w2)
+    monkeypatch.setenv("PALACE_AMD_GS_RESIDENT", "0")
+    H0, hn0, w0 = run()
+    assert ctx.resident_columns() == before + 2
+    tol = 1e-13 * max(1.0, np.abs(H0).max())
+    assert np.abs(H1 - H0).max() < tol and abs(hn1 - hn0) < 1e-13 * hn0 and np.abs(w1 - w0).max() < 1e-13 * np.abs(w0).max() * max(m, 4)
+    if n <= 300001:
+        V = [Vr[j].cpu().numpy() + (1j * Vi[j].cpu().numpy() if cplx else 0.0) for j in range(m)]
+        Href, wref = po.orthogonalize_column("MGS", V, w0r + (1j * w0i if cplx else 0.0), m)
+        hn_ref = np.linalg.norm(wref)
+        assert np.abs(H1 - Href).max() < 1e-12 * max(1.0, np.abs(Href).max())
+        assert abs(hn1 - hn_ref) < 1e-12 * hn_ref and np.abs(w1 - wref / hn_ref).max() < 1e-11
+
+
+def test_resident_mgs_falls_back_when_it_does_not_apply(ctx):
+    """Vectors off the 16-byte grid, and vectors that do not fit the register file, keep the chained form (same results as ever:
+    the tests above them in this file)."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    n = 4097
+    buf = [_dev(rng.normal(size=n + 1)) for _ in range(3)]
+    w = _dev(rng.normal(size=n + 1))
+    before = ctx.resident_columns()
+    ctx.orthonormalize_column("MGS", [b[1:] for b in buf], w[1:])
+    assert ctx.resident_columns() == before
+    n = 16_000_001  # 128 MB per vector: more than the register file holds beside the basis slice
+    V = [torch.randn(n, dtype=torch.float64, device="cuda") / np.sqrt(n) for _ in range(2)]
+    w = torch.randn(n, dtype=torch.float64, device="cuda")
+    w0 = w.clone()
+    H, hn = ctx.orthonormalize_column("MGS", V, w)
+    assert ctx.resident_columns() == before
+    h0 = float(V[0] @ w0)
+    assert abs(H[0] - h0) < 1e-10 * max(1.0, abs(h0)) and abs(float(w.norm()) - 1.0) < 1e-12
