@@ -391,6 +391,11 @@ int pa_op_streams(const pa_op *op);
  * Jacobian, gate 1e-13).  out[0] elements, out[1] affine elements found, out[2] of them in all-affine batches (compressed);
  * first tensor H(curl) sub-operator; all zero when there is none or the form is off (PALACE_AMD_STREAM_AFFINE=0). */
 int pa_op_stream_affine(const pa_op *op, int32_t out[3]);
+/* The E^T gather of the first dense-table sub-operator (round 6): out[0] = 1 if its E-vector keeps the dofs of an ELEMENT together
+ * (chosen at creation by counting the 64-byte sectors the gather would read in either layout; PALACE_AMD_DENSE_ELAYOUT=rows | block
+ * overrides), 0 for the rows by dof; out[1] = lanes that share the copies of one dof (1, 2, 4, 8: near the average number of copies;
+ * PALACE_AMD_DENSE_GATHER_GROUP overrides).  Both zero when the operator has no dense block. */
+int pa_op_dense_gather_form(const pa_op *op, int32_t out[2]);
 /* number of dense sub-operators that run in the affine form: every element of the block has a constant Jacobian (straight-sided
  * simplices), so the pre-assembled D of a quadrature point is the D of the first point times w_q / w_0 and the kernel reads 6
  * values per field and element instead of 6 Q (PALACE_AMD_DENSE_AFFINE=0 at creation time keeps the general form) */

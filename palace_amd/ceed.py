@@ -438,6 +438,12 @@ class Operator:
         _lib.check(_lib.load().pa_op_stream_affine(self.handle, out))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def dense_gather_form(self):
+        """(E-vector rows by element?, lanes per dof) of the first dense-table block's E^T gather (pa_op_dense_gather_form)."""
+        out = (C.c_int32 * 2)()
+        _lib.check(_lib.load().pa_op_dense_gather_form(self.handle, out))
+        return bool(out[0]), int(out[1])
+
     def add_mult(self, x, y, a=1.0):
         if a != 1.0:  # operator.cpp:194
             raise _lib.PalaceAmdError("ceed::Operator::AddMult only supports coefficient = 1.0!")

@@ -1318,6 +1318,13 @@ int pa_op_stream_affine(const pa_op *op, int32_t out[3]) {
       }
   });
 }
+int pa_op_dense_gather_form(const pa_op *op, int32_t out[2]) {
+  return guarded([&] {
+    PA_REQUIRE(op && out, "null argument");
+    out[0] = out[1] = 0;
+    if (!op->dsubs.empty()) out[0] = op->dsubs[0]->ye_rows ? 1 : 0, out[1] = dense_gather_group(*op->dsubs[0]);
+  });
+}
 int pa_op_num_sub(const pa_op *op) { return op ? (int)(op->subs.size() + op->dsubs.size() + op->msubs.size()) : -1; }
 int pa_op_destroy_assembly_data(const pa_op *op) {
   return guarded([&] { PA_REQUIRE(op, "null operator"); });

@@ -120,6 +120,15 @@ void mode_comps(int mode, int &nci, int &ncd) {
         : (mode == MODE_DIFF2 || mode == MODE_DIFFMASS2) ? 2 : 3;
 }
 
+// position of (dof slot s, lane) of a block's E-vector: lane = kq * 16 + element, dof = 4 s + kq
+__device__ __forceinline__ int ye_pos(const int rows, const int KP, const int s, const int lane) {
+  return rows ? (lane & 15) * (4 * KP) + 4 * s + (lane >> 4) : s * 64 + lane;
+}
+inline size_t ye_pos_host(bool rows, int KP, int e, int d) {  // (element e, local dof d) in the whole E-vector
+  const size_t blk = (size_t)(e / kEB) * 4 * KP * kEB;
+  return rows ? blk + (size_t)(e % kEB) * 4 * KP + d : blk + (size_t)d * kEB + (e % kEB);
+}
+
 struct DenseArgs {
   int ne, nb, P, Q, Qpad, nch, KP;
   const int32_t *idx;
@@ -146,6 +155,9 @@ struct DenseArgs {
   int dbg;  // ablation bits (PA_ABLATION builds only)
   const double *x;
   double *ye;
+  int ye_rows;  // E-vector layout inside a block of 16 elements: 0 = [dof][element] (one 128-byte row per dof: what the kernels' lanes
+                // hold side by side), 1 = [element][dof] (round 6: the gather reads the dofs of an edge / a face of one element from
+                // ONE 64-byte sector instead of one sector per 8-byte entry -- it is bound by those sectors)
   // split vectors (multi-rank applies without L-vector copies): local dofs >= nsplit are read from xg0 / xg1 (the parity of
   // *xg_sel picks the buffer; both stored shifted by -nsplit); nsplit = INT_MAX otherwise
   int nsplit;
@@ -412,14 +424,14 @@ __global__ __launch_bounds__(kDenseThreads, (PT <= 4 ? 2 : 1)) void dense_apply_
       if (s < KP) {
         const int dof = 4 * s + kq;
         const int cm = co[s * 64 + lane];
-        ye[s * 64 + lane] = co_field(cm, 1) * yacc[s >> 2][s & 3] + co_field(cm, 3) * sm[max(dof - 1, 0) * 16 + j] +
+        ye[ye_pos(a.ye_rows, KP, s, lane)] = co_field(cm, 1) * yacc[s >> 2][s & 3] + co_field(cm, 3) * sm[max(dof - 1, 0) * 16 + j] +
                             co_field(cm, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
       }
     }
   } else {
 #pragma unroll
     for (int s = 0; s < KPMAX; s++)
-      if (s < KP) ye[s * 64 + lane] = yacc[s >> 2][s & 3];
+      if (s < KP) ye[ye_pos(a.ye_rows, KP, s, lane)] = yacc[s >> 2][s & 3];
   }
 }
 
@@ -842,7 +854,7 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
         if (s < KP) {
           const int dof = 4 * s + kq;
           const unsigned cm = cpk[s >> 1];
-          ye[s * 64 + gln] = co_field_pk(cm, s & 1, 1) * yacc[s >> 2][s & 3] + co_field_pk(cm, s & 1, 3) * sm[max(dof - 1, 0) * 16 + j] +
+          ye[ye_pos(a.ye_rows, KP, s, gln)] = co_field_pk(cm, s & 1, 1) * yacc[s >> 2][s & 3] + co_field_pk(cm, s & 1, 3) * sm[max(dof - 1, 0) * 16 + j] +
                              co_field_pk(cm, s & 1, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
         }
       }
@@ -850,7 +862,7 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
     } else {
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
-        if (s < KP) ye[s * 64 + gln] = yacc[s >> 2][s & 3];
+        if (s < KP) ye[ye_pos(a.ye_rows, KP, s, gln)] = yacc[s >> 2][s & 3];
     }
   }
 }
@@ -1333,7 +1345,7 @@ __global__ void dense_diag_kernel(const DenseArgs a, const int32_t *__restrict__
 // (Fixed summation order: the diagonal -- and with it every smoother built on it -- is identical from run to run.)
 __global__ void dense_diag_slot_kernel(const int ne, const int P, const int KP, const int8_t *__restrict__ cor,
                                        const int32_t *__restrict__ idx, const double *__restrict__ de,
-                                       double *__restrict__ ye) {
+                                       double *__restrict__ ye, const int ye_rows) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int e = (int)(gid / P);
   if (e >= ne) return;
@@ -1346,8 +1358,9 @@ __global__ void dense_diag_slot_kernel(const int ne, const int P, const int KP, 
     if (j + 1 < P) v += fabs((double)t[3 + 0]) * d[j + 1];
     if (j > 0) v += fabs((double)t[-3 + 2]) * d[j - 1];
   }
-  const size_t pos = ((size_t)(e / kEB) * 4 * KP + j) * kEB + (e % kEB);
-  ye[pos] = idx[pos] < 0 ? -v : v;
+  const size_t pos = ((size_t)(e / kEB) * 4 * KP + j) * kEB + (e % kEB);  // (the index table keeps the [dof][element] rows)
+  const size_t blk = (size_t)(e / kEB) * 4 * KP * kEB;
+  ye[ye_rows ? blk + (size_t)(e % kEB) * 4 * KP + j : pos] = idx[pos] < 0 ? -v : v;
 }
 
 // Blocks whose packed D depends on the point through the quadrature weight only (constant Jacobian and attribute: straight-sided
@@ -1388,7 +1401,7 @@ DenseArgs make_args(const DenseSub &ds) {
 #ifdef PA_ABLATION
   a.dbg = getenv("PA_DBG") ? atoi(getenv("PA_DBG")) : 0;
 #endif
-  a.x = nullptr, a.ye = ds.d_ye;
+  a.x = nullptr, a.ye = ds.d_ye, a.ye_rows = ds.ye_rows ? 1 : 0;
   a.nsplit = 0x7fffffff, a.xg0 = a.xg1 = nullptr, a.xg_sel = nullptr;
   a.c0 = ds.c0.dev(), a.c1 = ds.c1.dev();
   return a;
@@ -1573,20 +1586,52 @@ DenseSub *make_dense_sub(pa_geom *geom, const pa_restriction_desc &r, const pa_d
   ds->h_co = co;
   // transpose map for the gather form of E^T (counting sort by dof, element order preserved)
   {
-    std::vector<int32_t> tptr((size_t)r.lsize + 1, 0), tent((size_t)ne * P);
+    // Which rows the E-vector gets (DenseArgs::ye_rows) is decided by what the GATHER does with them, MEASURED here on blocks large
+    // enough for it to matter: a mesh numbered with locality in the [dof] rows (a Kuhn-split cube: consecutive elements share
+    // entities at the same local index, and neighbouring waves of the gather re-read each other's rows from L2) keeps them -- there
+    // the rows by element only cost the apply kernel its coalesced stores (+3 us of 186) -- an unstructured mesh (config 3's) reads
+    // one 64-byte sector per 8-byte entry from the [dof] rows and a third of that from the rows by element (gather of 2.18M order-3
+    // dofs: 64 -> 37 us).  The sums do not depend on the choice (same copies, same order): timing noise cannot change a result.
+    // PALACE_AMD_DENSE_ELAYOUT=rows | block overrides (read at every creation: A / B runs in one process); the run form of the
+    // gather is written for the [dof] rows.
+    std::vector<int32_t> tptr((size_t)r.lsize + 1, 0), tent((size_t)ne * P), ted((size_t)ne * P);
     for (size_t k = 0; k < (size_t)ne * P; k++) tptr[(size_t)r.offsets[k] + 1]++;
     for (int d = 0; d < r.lsize; d++) tptr[d + 1] += tptr[d];
-    std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
-    for (int e = 0; e < ne; e++)
-      for (int d = 0; d < P; d++) {
-        const int32_t off = r.offsets[(size_t)e * P + d];
-        const int32_t pos = (int32_t)(((size_t)(e / kEB) * 4 * KP + d) * kEB + (e % kEB));
+    {
+      std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+      for (int e = 0; e < ne; e++)
+        for (int d = 0; d < P; d++) ted[fill[r.offsets[(size_t)e * P + d]]++] = e * P + d;
+    }
+    auto fill_tent = [&](bool rows) {
+      for (size_t k = 0; k < (size_t)ne * P; k++) {
+        const int e = ted[k] / P, d = ted[k] % P;
+        const int32_t pos = (int32_t)ye_pos_host(rows, KP, e, d);
         const bool flip = r.orients && r.orients[(size_t)e * P + d];
-        tent[fill[off]++] = flip ? -1 - pos : pos;
+        tent[k] = flip ? -1 - pos : pos;
       }
+    };
     ds->d_tptr = dev_upload(tptr.data(), tptr.size());
-    ds->d_tent = dev_upload(tent.data(), tent.size());
     ds->d_ye = dev_alloc<double>(nslot);
+    const char *gl = getenv("PALACE_AMD_DENSE_ELAYOUT"), *gg = getenv("PALACE_AMD_DENSE_GATHER");
+    const bool runs_form = gg && std::string(gg) == "runs";
+    if (gl && std::string(gl) == "rows") ds->ye_rows = true;
+    else if ((gl && std::string(gl) == "block") || runs_form || r.lsize < (1 << 17)) ds->ye_rows = false;
+    else {
+      PA_HIP(hipMemset(ds->d_ye, 0, nslot * sizeof(double)));
+      double t[2];
+      for (int rows = 0; rows < 2; rows++) {
+        fill_tent(rows != 0);
+        int32_t *d_t = dev_upload(tent.data(), tent.size());
+        t[rows] = time_dense_gather(*ds, d_t);
+        (void)hipFree(d_t);
+      }
+      ds->ye_rows = t[1] < 0.85 * t[0];
+      if (getenv("PALACE_AMD_DENSE_VERBOSE"))
+        std::fprintf(stderr, "[palace_amd] dense block %d elements x %d dofs: gather %.1f us by dof rows, %.1f us by element rows -> %s\n", ne,
+                     P, 1e3 * t[0], 1e3 * t[1], ds->ye_rows ? "element rows" : "dof rows");
+    }
+    fill_tent(ds->ye_rows);
+    ds->d_tent = dev_upload(tent.data(), tent.size());
     // a block that touches few of the dofs (the surface terms of a driven problem: a few thousand boundary faces in a space of
     // millions) adds its result through the list of the rows it has: its gather was a pass over the whole vector, 58 times per
     // FGMRES iteration of config 3 (round 5: 3.7 % of that solve's device time)
@@ -2002,27 +2047,134 @@ void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *
 // STEP (round 6): the sum is consumed by a smoother step / residual (GatherStep, pa_internal.hpp) instead of being stored -- the dense
 // gather owns every row, so the epilogue is all there is to it; interface dofs of a multi-rank apply leave their partial sum in
 // t_iface for the halo kernel, ghost rows go to yg as in the plain form
-template <bool STEP>
-__global__ void et_gather_split_kernel_t(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
-                                         const double *__restrict__ ye, double *__restrict__ y, double *__restrict__ yg,
-                                         const int nsplit, const uint8_t *__restrict__ ess, const double *__restrict__ x,
-                                         const int ess_policy, const GatherStep st) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= n) return;
-  double s = 0.0;
-  if (ess_policy >= 0 && ess && ess[d] && d < nsplit) {
-    s = ess_policy ? x[d] : 0.0;
-    if (!STEP) {
-      y[d] = s;
-      return;
+// DOFS dofs per thread, a block width apart, and the copies of each in chunks of four: index words, then E-vector entries, then the
+// vectors of the step side by side (one dof per thread walked its copies one dependent load pair at a time: latency-bound; the
+// transfer gathers of pa_interp.hip got 2x from the same change).  A dof's copies are added in their order, an absent copy adds
+// an exact zero: the sums are those of the one-dof form.
+[[maybe_unused]] constexpr int kGatherWideFrom = 1 << 30;  // (DOFS = 4 is SLOWER on tetrahedra -- 46 -> 60 us, the longest of 4 x 64 rows sets a wave's
+                                         // trip count -- one dof per thread with its copies in chunks of four: 46 -> 40 us)
+template <bool STEP, int DOFS = 1>
+__global__ __launch_bounds__(256) void et_gather_split_kernel_t(const int n, const int32_t *__restrict__ tptr,
+                                                                const int32_t *__restrict__ tent, const double *__restrict__ ye,
+                                                                double *__restrict__ y, double *__restrict__ yg, const int nsplit,
+                                                                const uint8_t *__restrict__ ess, const double *__restrict__ x,
+                                                                const int ess_policy, const GatherStep st) {
+  const int d0 = blockIdx.x * (256 * DOFS) + threadIdx.x;
+  int b[DOFS], e[DOFS];
+  double s[DOFS];
+  bool fixed[DOFS];  // ParOperator's essential row (rap.cpp:223-233): x or 0, no copies to add
+  int longest = 0;
+#pragma unroll
+  for (int u = 0; u < DOFS; u++) {
+    const int d = d0 + 256 * u;
+    b[u] = d < n ? tptr[d] : 0, e[u] = d < n ? tptr[d + 1] : 0;
+    fixed[u] = d < n && ess_policy >= 0 && ess && ess[d] && d < nsplit;
+    s[u] = 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < DOFS; u++) {
+    if (fixed[u]) {
+      s[u] = ess_policy ? x[d0 + 256 * u] : 0.0;
+      e[u] = b[u];
     }
-  } else {
-    for (int k = tptr[d]; k < tptr[d + 1]; k++) {
-      const int t = tent[k];
-      const double v = ye[t >= 0 ? t : -1 - t];
-      s += t >= 0 ? v : -v;
+    longest = max(longest, e[u] - b[u]);
+  }
+  for (int q0 = 0; q0 < longest; q0 += 4) {
+    int t[DOFS][4];
+    double v[DOFS][4];
+#pragma unroll
+    for (int u = 0; u < DOFS; u++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) t[u][q] = b[u] + q0 + q < e[u] ? tent[b[u] + q0 + q] : 0;
+#pragma unroll
+    for (int u = 0; u < DOFS; u++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int tt = t[u][q];
+        const double w = b[u] + q0 + q < e[u] ? ye[tt >= 0 ? tt : -1 - tt] : 0.0;
+        v[u][q] = tt >= 0 ? w : -w;
+      }
+#pragma unroll
+    for (int u = 0; u < DOFS; u++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) s[u] += v[u][q];
+  }
+  if (!STEP) {
+#pragma unroll
+    for (int u = 0; u < DOFS; u++) {
+      const int d = d0 + 256 * u;
+      if (d < n) (d < nsplit ? y : yg)[d] = s[u];
+    }
+    return;
+  }
+  // the step: 0 = ghost row (to yg), 1 = interface dof (partial sum to t_iface), 2 = consumed here
+  int kind[DOFS];
+  double r0[DOFS], dinv[DOFS], ev[DOFS], epv[DOFS], old[DOFS];
+#pragma unroll
+  for (int u = 0; u < DOFS; u++) {
+    const int d = d0 + 256 * u;
+    kind[u] = d >= n ? -1 : d >= nsplit ? 0 : (st.iface_mask && (st.iface_mask[d] & 2)) ? 1 : 2;
+  }
+#pragma unroll
+  for (int u = 0; u < DOFS; u++) {
+    const int d = d0 + 256 * u;
+    const bool use = kind[u] == 2;
+    r0[u] = use ? st.r0[d] : 0.0;
+    dinv[u] = (use && (st.mode != 2 || st.out)) ? st.dinv[d] : 0.0;
+    ev[u] = (use && st.mode != 2) ? x[d] : 0.0;
+    epv[u] = (use && st.mode != 2 && st.ep) ? st.ep[d] : 0.0;
+    old[u] = (use && st.mode != 2 && st.add) ? st.out[d] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < DOFS; u++) {
+    const int d = d0 + 256 * u;
+    if (kind[u] == 0) {
+      yg[d] = s[u];
+    } else if (kind[u] == 1) {
+      st.t_iface[d] = s[u];
+    } else if (kind[u] == 2) {
+      const double rv = r0[u] - s[u];
+      if (st.mode == 2) {
+        if (st.res) st.res[d] = rv;
+        if (st.out) st.out[d] = st.sr * dinv[u] * rv;
+      } else {
+        double dk = st.sr * dinv[u] * rv;
+        dk += st.sd * (ev[u] - epv[u]);
+        st.out[d] = old[u] + (ev[u] + dk);
+      }
     }
   }
+}
+
+// The same gather with G lanes per dof (G = 2, 4, 8: a power of two near the average number of copies).  On tetrahedra the
+// number of copies varies widely -- an order-2 H1 vertex dof has ~24, its edge dofs ~5, and a wave of the one-thread-per-dof form
+// runs as long as its longest row (159k dofs took 26 us) -- so the copies of a dof are dealt to the lanes of its group (lane g
+// adds copies g, g + G, ... in order), the group's partial sums are combined by a butterfly, and lane 0 of the group does the
+// epilogue.  Deterministic (fixed assignment, fixed combination order), but NOT the bits of the serial order.
+template <bool STEP, int G>
+__global__ __launch_bounds__(256) void et_gather_group_kernel(const int n, const int32_t *__restrict__ tptr,
+                                                              const int32_t *__restrict__ tent, const double *__restrict__ ye,
+                                                              double *__restrict__ y, double *__restrict__ yg, const int nsplit,
+                                                              const uint8_t *__restrict__ ess, const double *__restrict__ x,
+                                                              const int ess_policy, const GatherStep st) {
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int d = (int)(tid / G), g = (int)(tid % G);
+  const bool live = d < n;
+  int b = live ? tptr[d] : 0, e = live ? tptr[d + 1] : 0;
+  const bool fixed = live && ess_policy >= 0 && ess && ess[d] && d < nsplit;  // ParOperator's essential row (rap.cpp:223-233)
+  if (fixed) e = b;
+  double s = 0.0;
+  for (int k = b + g; k < e; k += 2 * G) {  // two of the lane's copies side by side
+    const int t0 = tent[k], t1 = k + G < e ? tent[k + G] : 0;
+    const double v0 = ye[t0 >= 0 ? t0 : -1 - t0];
+    const double v1 = k + G < e ? ye[t1 >= 0 ? t1 : -1 - t1] : 0.0;
+    s += t0 >= 0 ? v0 : -v0;
+    s += t1 >= 0 ? v1 : -v1;
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (!live || g != 0) return;
+  if (fixed) s = ess_policy ? x[d] : 0.0;
   if (!STEP) {
     (d < nsplit ? y : yg)[d] = s;
     return;
@@ -2041,10 +2193,58 @@ __global__ void et_gather_split_kernel_t(const int n, const int32_t *__restrict_
     if (st.out) st.out[d] = st.sr * st.dinv[d] * rv;
     return;
   }
-  const double e = x[d];
+  const double ev = x[d];
   double dk = st.sr * st.dinv[d] * rv;
-  dk += st.sd * (e - (st.ep ? st.ep[d] : 0.0));
-  st.out[d] = (st.add ? st.out[d] : 0.0) + (e + dk);
+  dk += st.sd * (ev - (st.ep ? st.ep[d] : 0.0));
+  st.out[d] = (st.add ? st.out[d] : 0.0) + (ev + dk);
+}
+// lanes per dof for a block with `nnz` E-vector entries on `n` dofs (PALACE_AMD_DENSE_GATHER_GROUP=0: the one-thread-per-dof form)
+int gather_group(long long nnz, int n) {
+  const char *e = std::getenv("PALACE_AMD_DENSE_GATHER_GROUP");
+  if (e && e[0] == '0') return 1;
+  if (e && (e[0] == '2' || e[0] == '4' || e[0] == '8') && !e[1]) return e[0] - '0';
+  const double avg = n > 0 ? (double)nnz / n : 1.0;
+  return avg < 1.5 ? 1 : avg < 2.5 ? 2 : avg < 5.0 ? 4 : 8;
+}
+int dense_gather_group(const DenseSub &ds) { return gather_group((long long)ds.ne * ds.P, ds.lsize); }
+template <bool STEP>
+void launch_gather_split(const DenseSub &ds, const double *ye, double *y, double *yg, int nsplit, const double *x, int ess_policy,
+                         const GatherStep &st, hipStream_t s) {
+  const int G = gather_group((long long)ds.ne * ds.P, ds.lsize);
+  const unsigned nb = (unsigned)(((long long)ds.lsize * G + 255) / 256);
+#define PA_GATHER_GROUP(GG)                                                                                                         \
+  hipLaunchKernelGGL((et_gather_group_kernel<STEP, GG>), dim3(nb), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent, ye, y, yg, nsplit, \
+                     ds.d_ess_flag, x, ess_policy, st)
+  if (G == 8) PA_GATHER_GROUP(8);
+  else if (G == 4) PA_GATHER_GROUP(4);
+  else if (G == 2) PA_GATHER_GROUP(2);
+  else
+    hipLaunchKernelGGL((et_gather_split_kernel_t<STEP, 1>), dim3(nb), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent, ye, y, yg, nsplit,
+                       ds.d_ess_flag, x, ess_policy, st);
+#undef PA_GATHER_GROUP
+}
+
+double time_dense_gather(const DenseSub &ds, const int32_t *d_tent) {
+  DenseSub probe = ds;  // (a shallow copy with the map under test; nothing of it is freed here)
+  probe.d_tent = const_cast<int32_t *>(d_tent);
+  probe.d_ess_flag = nullptr;
+  double *y = dev_alloc<double>((size_t)ds.lsize);
+  hipEvent_t e0, e1;
+  PA_HIP(hipEventCreate(&e0));
+  PA_HIP(hipEventCreate(&e1));
+  const int reps = 5;
+  for (int it = 0; it < 2; it++)
+    launch_gather_split<false>(probe, ds.d_ye, y, y, 0x7fffffff, nullptr, -1, GatherStep{}, nullptr);
+  PA_HIP(hipEventRecord(e0, nullptr));
+  for (int it = 0; it < reps; it++)
+    launch_gather_split<false>(probe, ds.d_ye, y, y, 0x7fffffff, nullptr, -1, GatherStep{}, nullptr);
+  PA_HIP(hipEventRecord(e1, nullptr));
+  PA_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+  (void)hipFree(y);
+  return ms / reps;
 }
 
 // E^T of the dense path by runs (pa_stream_host.hpp: build_runs_dense): one thread per L-dof, its run and offset from the chunk
@@ -2167,9 +2367,8 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
   if (split || ess_policy >= 0) {  // (one vector with the essential rows fixed on the way: the same kernel, nothing beyond y)
     PA_REQUIRE(!accumulate, "split vectors / fused essential rows: y = A x only");
     PA_REQUIRE(ess_policy < 0 || (ds.d_ess_flag && x), "essential rows fused into the gather: pa_op_set_essential first");
-    hipLaunchKernelGGL(et_gather_split_kernel_t<false>, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent,
-                       ye ? ye : ds.d_ye, y, split ? split->yg - split->n_true : y, split ? split->n_true : 0x7fffffff,
-                       ds.d_ess_flag, x, ess_policy, GatherStep{});
+    launch_gather_split<false>(ds, ye ? ye : ds.d_ye, y, split ? split->yg - split->n_true : y, split ? split->n_true : 0x7fffffff, x,
+                               ess_policy, GatherStep{}, s);
     PA_HIP(hipGetLastError());
     return;
   }
@@ -2190,9 +2389,8 @@ void launch_dense_gather_step(const DenseSub &ds, const double *x, const GatherS
   PA_REQUIRE(dense_fused_step_ok(ds) && x, "dense fused step: essential list fused (pa_op_set_essential) and the CSR-form gather expected");
   PA_REQUIRE(!split || (step.iface_mask && step.t_iface), "split form of the fused step: interface mask and buffer missing");
   if (ds.lsize == 0) return;
-  hipLaunchKernelGGL(et_gather_split_kernel_t<true>, dim3((ds.lsize + 255) / 256), dim3(256), 0, s, ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye,
-                     nullptr, split ? split->yg - split->n_true : nullptr, split ? split->n_true : 0x7fffffff, ds.d_ess_flag, x,
-                     ess_policy, step);
+  launch_gather_split<true>(ds, ds.d_ye, nullptr, split ? split->yg - split->n_true : nullptr, split ? split->n_true : 0x7fffffff, x,
+                            ess_policy, step, s);
   PA_HIP(hipGetLastError());
 }
 
@@ -2235,7 +2433,7 @@ void launch_dense_diag(const DenseSub &ds, double *diag_out, hipStream_t s) {
 #undef PA_DIAG2_CASE
     default: break;
   }
-  hipLaunchKernelGGL(dense_diag_slot_kernel, grid, block, 0, s, ds.ne, ds.P, ds.KP, ds.d_cor, ds.d_idx, diag, ds.d_ye);
+  hipLaunchKernelGGL(dense_diag_slot_kernel, grid, block, 0, s, ds.ne, ds.P, ds.KP, ds.d_cor, ds.d_idx, diag, ds.d_ye, ds.ye_rows ? 1 : 0);
   PA_HIP(hipGetLastError());
   launch_et_gather_raw(ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye, diag_out, true, s);
   PA_HIP(hipStreamSynchronize(s));

@@ -244,6 +244,7 @@ struct DenseSub {
   int fe_type = 0, P = 0, Q = 0, Qpad = 0, nch = 0, ne = 0, nb = 0, lsize = 0, KP = 0, PT = 0;
   int qf = 0, mode = 0;
   bool contra = false;  // plane H(div) mass: contravariant map in the vector-mass D (f_apply_hdiv_22)
+  bool ye_rows = false;  // E-vector rows by element ([block][element][dof]) instead of by dof (pa_dense.hip: DenseArgs::ye_rows)
   uint32_t trial_ops = 0, test_ops = 0;
   int32_t *d_idx = nullptr;     // [nb][4 KP][16] signed index (oriented: <0 => -(1+dof) flipped); pads read zero
   int32_t *d_idx_bc = nullptr;  // copy with kEssBit on essential dofs
@@ -392,6 +393,8 @@ bool dense_complex_ok(const DenseSub &dr, const DenseSub &di);
 void launch_dense_gather_signed(const DenseSub &ds, double *y, double sign, bool skip_ess, hipStream_t s);
 // the fused smoother step / residual on a dense block (round 6): the CSR-form gather owns every row; its epilogue consumes the sum
 bool dense_fused_step_ok(const DenseSub &ds);
+double time_dense_gather(const DenseSub &ds, const int32_t *d_tent);  // ms per launch of the plain E^T gather with this map (set-up)
+int dense_gather_group(const DenseSub &ds);  // lanes per dof of the CSR-form gather (pa_dense.hip: et_gather_group_kernel)
 void launch_dense_gather_step(const DenseSub &ds, const double *x, const GatherStep &step, int ess_policy, hipStream_t s,
                               const SplitIO *split = nullptr);
 void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s,

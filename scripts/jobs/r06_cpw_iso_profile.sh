@@ -7,4 +7,5 @@ grep -v rocprofv3 gpurun_out/r06_cpw_iso_profile.log | tail -5
 find gpurun_out/cpwprof | head
 f=$(find gpurun_out/cpwprof -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/r06_cpw_iso_kernel_stats.csv
+python scripts/trace_by_grid.py $(find gpurun_out/cpwprof -name "*kernel_trace.csv" | head -1) 10 > gpurun_out/r06_cpw_iso_by_level.txt
 rm -rf gpurun_out/cpwprof

@@ -304,3 +304,88 @@ def test_nd_tet_boundary_mass(kind, p):
         xd = torch.from_numpy(xe).cuda()
         ident.mult(xd, y)
         assert abs(float(xd @ y) - 56.0) < 1e-11 * 56.0
+
+
+@pytest.mark.parametrize("group", ["0", "2", "4", "8"])
+@pytest.mark.parametrize("layout", ["rows", "block"])
+@pytest.mark.parametrize("p", [2, 3])
+def test_nd_tet_gather_forms(monkeypatch, p, layout, group):
+    """Round 6: the dense path's E-vector with the dofs of an element together (`rows`) or one row per dof (`block`), and its E^T
+    gather with 1 / 2 / 4 / 8 lanes per dof: curl-curl + mass `Mult` and the diagonal against the oracle on curved, curl-oriented
+    tetrahedra -- and the fused smoother step (the gather's epilogue) against the unfused one in every form."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem import tet
+
+    monkeypatch.setenv("PALACE_AMD_DENSE_ELAYOUT", layout)
+    monkeypatch.setenv("PALACE_AMD_DENSE_GATHER_GROUP", group)
+    mesh = _mesh("tet10")
+    nd = tet.NDTetSpace(mesh, p)
+    pts, wts = tet.tet_quadrature(p + 1)
+    interp, curl = nd.elem.tables(pts)
+    geom, ogeom = _geom(mesh, pts, wts)
+    c3, b3 = util.make_ctx("aniso", 2)
+    cm, bm = util.make_ctx("scalar", 2)
+    block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, curl_orients=nd.curl_orients)
+    orc = po.CeedOperatorOracle(nd.ndofs, nd.offsets, None, interp, curl, ogeom, po.QF_HDIVMASS, cm, c3, curl_orients=nd.curl_orients)
+    op = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(geom, block, ceed.QF_HDIVMASS_33, np.concatenate([bm, b3]),
+                                                                 ceed.EVAL_CURL + ceed.EVAL_INTERP).finalize()
+    rows, lanes = op.dense_gather_form()
+    assert rows == (layout == "rows") and lanes == (1 if group == "0" else int(group))
+    x = np.random.default_rng(p).uniform(-1, 1, nd.ndofs)
+    y_ref = orc.apply_add(x, np.zeros(nd.ndofs))
+    xd = torch.from_numpy(x).cuda()
+    yd = op.mult(xd, torch.full_like(xd, np.nan))
+    assert np.abs(yd.cpu().numpy() - y_ref).max() / np.abs(y_ref).max() < REL
+    dd = op.assemble_diagonal(torch.empty_like(xd))
+    d_ref = orc.diagonal()
+    assert np.abs(dd.cpu().numpy() - d_ref).max() / np.abs(d_ref).max() < REL
+    # ParOperator with essential rows + the Chebyshev smoother, fused step against PALACE_AMD_FUSED_STEP=0
+    ess = np.unique(nd.offsets[:5].ravel())[:40].astype(np.int32)
+    ctx = linalg.Context()
+    A = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+    S = linalg.chebyshev(ctx, A, order=3)
+    assert S.fused_step()
+    monkeypatch.setenv("PALACE_AMD_FUSED_STEP", "0")
+    S0 = linalg.chebyshev(ctx, A, order=3)
+    assert not S0.fused_step()
+    b = np.random.default_rng(5).uniform(-1, 1, nd.ndofs)
+    b[ess] = 0.0
+    bd = torch.from_numpy(b).cuda()
+    z = S.mult(bd, torch.empty_like(bd)).cpu().numpy()
+    z0 = S0.mult(bd, torch.empty_like(bd)).cpu().numpy()
+    assert np.linalg.norm(z - z0) < 1e-12 * np.linalg.norm(z0)
+
+
+def test_dense_e_vector_layout_follows_the_mesh_numbering(capfd, monkeypatch):
+    """The layout of a large block is chosen by timing its gather both ways at creation: a Kuhn-split cube, numbered element by element
+    with shared entities at the same local index, keeps one row per dof; the same mesh with its elements shuffled (what an unstructured
+    mesh looks like to the gather) gets the rows by element.  Either way `Mult` gives the same bits (same copies, same order)."""
+    import torch
+
+    from palace_amd import ceed
+    from palace_amd.fem import tet
+
+    monkeypatch.setenv("PALACE_AMD_DENSE_VERBOSE", "1")
+
+    def make(mesh):
+        nd = tet.NDTetSpace(mesh, 3)
+        pts, wts = tet.tet_quadrature(4)
+        interp, curl = nd.elem.tables(pts)
+        geom, _ = _geom(mesh, pts, wts)
+        _, b3 = util.make_ctx("identity")
+        block = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, interp, curl, curl_orients=nd.curl_orients)
+        return nd, ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(geom, block, ceed.QF_HDIV_33, b3, ceed.EVAL_CURL).finalize()
+
+    m = tet.cube_tet_mesh(20)  # 48 000 tetrahedra, 0.9M order-3 dofs
+    nd, op = make(m)
+    assert op.dense_gather_form()[0] is False, capfd.readouterr().err
+    perm = np.random.default_rng(0).permutation(m.ne)
+    nds, ops = make(tet.TetMesh(m.nodes, m.elem_nodes[perm], m.attr[perm]))
+    assert ops.dense_gather_form()[0] is True, capfd.readouterr().err
+    monkeypatch.setenv("PALACE_AMD_DENSE_ELAYOUT", "block")
+    _, opb = make(tet.TetMesh(m.nodes, m.elem_nodes[perm], m.attr[perm]))
+    assert opb.dense_gather_form()[0] is False
+    x = torch.rand(nds.ndofs, dtype=torch.float64, device="cuda")
+    assert torch.equal(ops.mult(x, torch.empty_like(x)), opb.mult(x, torch.empty_like(x)))
