@@ -9,6 +9,10 @@ import numpy as np  # noqa: F401
 from .common import HBM_PEAK_GBS, ROOT, _rel, host_cores, oracle_hex_data  # noqa: F401
 
 
+MGS_NOTE = ("MGS (the reference's default), coefficients on the device, one host synchronisation per column; round 6: the column stays in the "
+            "register file for all its inner products and updates, every basis vector is read once (orthog.hip: k_mgs_resident)")
+
+
 def cpw_iso_leg(order=3, refine=1, reps=20, ab=False):
     """(rounds 3-4's form of the leg, kept for continuity: surrogate isotropic materials, white-noise right-hand side)
     BASELINE config 3 on the reference's own mesh: examples/cpw/mesh/cpw_lumped_0.msh (committed as tests/golden/cpw_mesh.npz,
@@ -64,7 +68,9 @@ def cpw_iso_leg(order=3, refine=1, reps=20, ab=False):
     out["complex_apply"] = {"ms": ms, "complex_dof_per_s": n / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
                             "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
                             "bytes_formula": "NE*(Q*11*8 + P*7) + 32*N_L: one pass over the element data, both parts of x and y"}
+    out["dense_gather"] = dict(zip(("e_vector_rows_by_element", "lanes_per_dof"), sys_["Kr"].dense_gather_form()))
     xr, xi = torch.zeros_like(br), torch.zeros_like(br)
+    rc0 = linalg.Context.resident_columns()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     S.mult(br, bi, xr, xi)
@@ -74,7 +80,7 @@ def cpw_iso_leg(order=3, refine=1, reps=20, ab=False):
     A.mult(xr, xi, yr, yi)
     res = float(torch.sqrt(((yr - br) ** 2 + (yi - bi) ** 2).sum()) / torch.sqrt((br ** 2 + bi ** 2).sum()))
     out["fgmres"] = {"iterations_to_1e-8": st["iterations"], "seconds": dt, "iters_per_s": st["iterations"] / dt,
-                     "converged": st["converged"], "true_rel_residual": res, "orthogonalization": "MGS (the reference's default), coefficients on the device: one host synchronisation per column (orthog.hip)"}
+                     "converged": st["converged"], "true_rel_residual": res, "orthogonalization": MGS_NOTE, "mgs_columns_with_w_resident_in_registers": linalg.Context.resident_columns() - rc0}
     # the same solve with the batched orthogonalisation (OrthogonalizeColumnCGS2, linalg/orthog.hpp:57-89: two reductions per step
     # instead of j + 1): same preconditioner object
     try:
@@ -219,6 +225,7 @@ def cpw_leg(order=3, refine=1, reps=20, freq_ghz=17.0):
     out["complex_apply"] = {"ms": ms, "complex_dof_per_s": n / (ms * 1e-3), "algorithmic_GBps": alg / ms / 1e6,
                             "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS, "one_pass": int(A.fused()) if hasattr(A, "fused") else None,
                             "bytes_formula": "NE*(Q*11*8 + P*7) + 32*N_L (volume elements; the surface blocks are 0.4 % of the faces)"}
+    out["dense_gather"] = dict(zip(("e_vector_rows_by_element", "lanes_per_dof"), ds.Ar.dense_gather_form()))
 
     def solve(label, device_gs=True, solver=None):
         sv = S if solver is None else solver
@@ -236,8 +243,10 @@ def cpw_leg(order=3, refine=1, reps=20, freq_ghz=17.0):
         finally:
             linalg.Context.set_device_orthogonalization(True)
 
+    rc0 = linalg.Context.resident_columns()
     sr, si = solve("fgmres")
-    out["fgmres"]["orthogonalization"] = "MGS (the reference's default), coefficients on the device: one host synchronisation per column (orthog.hip)"
+    out["fgmres"]["orthogonalization"] = MGS_NOTE
+    out["fgmres"]["mgs_columns_with_w_resident_in_registers"] = linalg.Context.resident_columns() - rc0
     A.mult(sr, si, yr, yi)
     out["fgmres"]["true_rel_residual"] = float(torch.sqrt(((yr - br) ** 2 + (yi - bi) ** 2).sum()) / torch.sqrt((br ** 2 + bi ** 2).sum()))
     Sp = ds.s_parameters(sr, si, excited=1)
