@@ -475,7 +475,37 @@ __global__ __launch_bounds__(256) void k_gather_t(const int n, const int32_t *__
     if (d < n) y[d] = s[u];
   }
 }
-void launch_k_gather(const int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y, hipStream_t s) {
+// G lanes per dof (G = 2, 4, 8), each adding its share of the copies, a butterfly over the group: for rows of very different lengths
+// (tetrahedra: a vertex dof of an H1 space has ~24 copies, an edge dof ~5 -- a wave of the forms above runs as long as its longest
+// row).  Deterministic; not the bits of the serial order.  (pa_dense.hip: et_gather_group_kernel is the same idea.)
+template <int G>
+__global__ __launch_bounds__(256) void k_gather_group(const int n, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tent,
+                                                      const double *__restrict__ ye, double *__restrict__ y) {
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int d = (int)(tid / G), g = (int)(tid % G);
+  const bool live = d < n;
+  const int b = live ? tptr[d] : 0, e = live ? tptr[d + 1] : 0;
+  double s = 0.0;
+  for (int k = b + g; k < e; k += 2 * G) {
+    const int t0 = tent[k], t1 = k + G < e ? tent[k + G] : 0;
+    const double v0 = ye[t0 >= 0 ? t0 : -1 - t0];
+    const double v1 = k + G < e ? ye[t1 >= 0 ? t1 : -1 - t1] : 0.0;
+    s += t0 >= 0 ? v0 : -v0;
+    s += t1 >= 0 ? v1 : -v1;
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (live && g == 0) y[d] = s;
+}
+// group = lanes per dof (1: the forms above); callers with irregular rows pass the power of two near their average row length
+void launch_k_gather(const int n, const int32_t *tptr, const int32_t *tent, const double *ye, double *y, hipStream_t s, const int group = 1) {
+  if (group > 1) {
+    const unsigned nb = (unsigned)(((long long)n * group + 255) / 256);
+    if (group >= 8) hipLaunchKernelGGL(k_gather_group<8>, dim3(nb), dim3(256), 0, s, n, tptr, tent, ye, y);
+    else if (group >= 4) hipLaunchKernelGGL(k_gather_group<4>, dim3(nb), dim3(256), 0, s, n, tptr, tent, ye, y);
+    else hipLaunchKernelGGL(k_gather_group<2>, dim3(nb), dim3(256), 0, s, n, tptr, tent, ye, y);
+    return;
+  }
   if (n >= (1 << 18))
     hipLaunchKernelGGL(k_gather_t<4>, dim3((n + 1023) / 1024), dim3(256), 0, s, n, tptr, tent, ye, y);
   else
@@ -730,6 +760,98 @@ __global__ __launch_bounds__(64 * kDenseInterpWaves) void dense_interp_kernel(co
   }
 }
 
+// ---- the same operator with NOTHING BUT REGISTERS between the gather and the store (round 6) --------------------------------------
+// One matrix, both element sizes <= 64, the contracted side <= 48: the LDS form above spends a wave-step of four elements on five
+// dependent stages (index -> value -> strip -> synchronise -> product -> synchronise -> store), 12 us per step on config 3's mesh
+// (84 us for 117k elements, of which the memory system accounts for ~20).  Here a lane keeps its row (column) of the matrix in NR
+// registers as before, the tridiagonal orientation transforms take their neighbours by lane shuffles, the product takes the input
+// vector entry by entry with v_readlane (a scalar operand of the FMA: no LDS, no barrier anywhere), and the loop is software-pipelined:
+// index words two steps ahead, gathered values and orientation words one step ahead.  Orientation data comes as ONE packed word
+// per entry, prepared on the host: the three coefficients a lane multiplies {previous, own, next} with (rows of T / B for the input
+// side, columns for the output side, zero beyond the ends; plain or sign-only restrictions are the tridiagonal (0, +-1, 0)).
+struct DenseInterpRegArgs {
+  int ne, Pd, Pr;
+  const int32_t *off_in, *off_r;  // input side index ([ne][Pin]; transposed: the range offsets with kOwnBit), range offsets (forward store)
+  const int32_t *pk_in, *pk_out;  // packed {prev, own, next} coefficients of the input / output side
+  const double *M, *x;
+  double *y, *ye_d;
+};
+__device__ __forceinline__ double readlane_f64(const double v, const int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double tri3(const int pk, const double m, const double c, const double p) {
+  return (double)(int8_t)(pk & 0xff) * m + (double)(int8_t)((pk >> 8) & 0xff) * c + (double)(int8_t)((pk >> 16) & 0xff) * p;
+}
+constexpr int kRegE = 4;  // elements per wave and step
+template <bool TRANSPOSE, int NR>
+__global__ __launch_bounds__(256) void dense_interp_reg_kernel(const DenseInterpRegArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int Pin = TRANSPOSE ? a.Pr : a.Pd, Pout = TRANSPOSE ? a.Pd : a.Pr;
+  double mreg[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++)
+    mreg[k] = (k < Pin && lane < Pout) ? (TRANSPOSE ? a.M[(size_t)k * a.Pd + lane] : a.M[(size_t)lane * a.Pd + k]) : 0.0;
+  const int ngroups = (a.ne + kRegE - 1) / kRegE, nw = gridDim.x * 4;
+  int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= ngroups) return;
+  const bool lin = lane < Pin, lout = lane < Pout;
+  auto el = [&](const int gg, const int h) { return min(gg * kRegE + h, a.ne - 1); };  // (clamped: loads stay in range, stores are masked)
+  auto load_idx = [&](const int gg, int (&idx)[kRegE]) {
+#pragma unroll
+    for (int h = 0; h < kRegE; h++) idx[h] = lin ? a.off_in[(size_t)el(gg, h) * Pin + lane] : 0;
+  };
+  auto load_x = [&](const int (&idx)[kRegE], double (&xv)[kRegE]) {
+#pragma unroll
+    for (int h = 0; h < kRegE; h++) {
+      if (TRANSPOSE) xv[h] = (lin && (idx[h] & kOwnBit)) ? a.x[idx[h] & ~kOwnBit] : 0.0;  // owner-masked range values
+      else xv[h] = lin ? a.x[idx[h]] : 0.0;
+    }
+  };
+  auto load_or = [&](const int gg, int (&pin)[kRegE], int (&pout)[kRegE], int (&oo)[kRegE]) {
+#pragma unroll
+    for (int h = 0; h < kRegE; h++) {
+      const size_t e = (size_t)el(gg, h);
+      pin[h] = lin ? a.pk_in[e * Pin + lane] : 0;
+      pout[h] = lout ? a.pk_out[e * Pout + lane] : 0;
+      oo[h] = (!TRANSPOSE && lout) ? a.off_r[e * Pout + lane] : 0;
+    }
+  };
+  int idx1[kRegE], idx2[kRegE], pin0[kRegE], pout0[kRegE], oo0[kRegE], pin1[kRegE], pout1[kRegE], oo1[kRegE];
+  double x0[kRegE], x1[kRegE];
+  // prologue: everything of the first step, the index words of the second
+  load_idx(g, idx1);
+  load_or(g, pin0, pout0, oo0);
+  load_x(idx1, x0);
+  load_idx(min(g + nw, ngroups - 1), idx1);
+  for (; g < ngroups; g += nw) {
+    const int g1 = min(g + nw, ngroups - 1), g2 = min(g + 2 * nw, ngroups - 1);
+    load_x(idx1, x1);             // values of the next step (its index words were requested a step ago)
+    load_idx(g2, idx2);           // index words two steps ahead
+    load_or(g1, pin1, pout1, oo1);  // orientation words and store offsets of the next step
+#pragma unroll
+    for (int h = 0; h < kRegE; h++) {
+      const double u = x0[h];
+      // (the shuffles outside the selects: inside, the last lane in range would read a neighbour that is masked off)
+      const double su = __shfl_up(u, 1, 64), sd = __shfl_down(u, 1, 64);
+      const double um = lane > 0 ? su : u, up = lane + 1 < Pin ? sd : u;
+      const double t = lin ? tri3(pin0[h], um, u, up) : 0.0;  // T x_e (forward) / B z (transposed)
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < NR; k++) v += mreg[k] * readlane_f64(t, k);
+      const double vm = __shfl_up(v, 1, 64), vp = __shfl_down(v, 1, 64);
+      const double w = tri3(pout0[h], vm, v, vp);  // B^T v (forward) / T^T u (transposed): the word is zero beyond the ends
+      const int e = g * kRegE + h;
+      if (e < a.ne && lout) {
+        if (TRANSPOSE) a.ye_d[(size_t)e * a.Pd + lane] = w;
+        else if (oo0[h] & kOwnBit) a.y[oo0[h] & ~kOwnBit] = w;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < kRegE; h++) x0[h] = x1[h], pin0[h] = pin1[h], pout0[h] = pout1[h], oo0[h] = oo1[h], idx1[h] = idx2[h];
+  }
+}
+
 class DenseInterpOperator : public Operator {
   const Context *ctx_;
   const Halo *halo_d_;
@@ -738,11 +860,33 @@ class DenseInterpOperator : public Operator {
   int8_t *d_sgn_d_ = nullptr, *d_sgn_r_ = nullptr, *d_T_d_ = nullptr, *d_B_r_ = nullptr;
   double *d_M_ = nullptr, *d_ye_ = nullptr;
   uint8_t *d_mat_id_ = nullptr;
+  int32_t *d_pk_[4] = {nullptr, nullptr, nullptr, nullptr};  // register form: {domain rows, domain columns, range rows, range columns}
   mutable Vector ld_, lr_;
 
-  int nmat_ = 1;
+  int nmat_ = 1, gather_group_ = 1;
   template <bool TR>
   void launch(const double *x, double *y) const {
+    if (d_pk_[0]) {  // one matrix, both sides within a wave: registers only (dense_interp_reg_kernel)
+      const DenseInterpRegArgs r{ne_, Pd_, Pr_, TR ? d_off_r_ : d_off_d_, d_off_r_, TR ? d_pk_[2] : d_pk_[0], TR ? d_pk_[1] : d_pk_[3],
+                                 d_M_, x, y, d_ye_};
+      const int nkr = TR ? Pr_ : Pd_, ngroups = (ne_ + kRegE - 1) / kRegE;
+      auto go = [&](auto kernel) {
+        static int per_cu = 0, n_cu = 0;  // (per instantiation: the lambda's statics belong to its closure type)
+        if (!per_cu) {
+          int dev = 0;
+          PA_HIP(hipGetDevice(&dev));
+          PA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        }
+        const int grid = std::max(1, std::min((ngroups + 3) / 4, n_cu * per_cu));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, ctx_->stream, r);
+      };
+      if (nkr <= 8) go(dense_interp_reg_kernel<TR, 8>);
+      else if (nkr <= 24) go(dense_interp_reg_kernel<TR, 24>);
+      else go(dense_interp_reg_kernel<TR, 48>);
+      PA_HIP(hipGetLastError());
+      return;
+    }
     DenseInterpArgs a{ne_, Pd_, Pr_, d_off_d_, d_off_r_, d_sgn_d_, d_sgn_r_, d_T_d_, d_B_r_, d_M_, d_mat_id_, x, y, d_ye_};
     const int pmax = (std::max(Pd_, Pr_) + 1) & ~1;
     // the matrices in LDS when all of them fit beside the waves' strips in 48 KB (eight such workgroups per CU)
@@ -811,6 +955,12 @@ public:
       d_tptr_ = pa::dev_upload(tptr.data(), tptr.size(), ctx.stream);
       d_tent_ = pa::dev_upload(tent.data(), tent.size(), ctx.stream);
       d_ye_ = pa::dev_alloc<double>(nd);
+      // rows of very different lengths (simplices): several lanes per dof in the transposed gather (PALACE_AMD_INTERP_GATHER_GROUP=0: off)
+      int longest = 0;
+      for (int d = 0; d < nl_d_; d++) longest = std::max(longest, tptr[d + 1] - tptr[d]);
+      const double avg = nl_d_ > 0 ? (double)nd / nl_d_ : 1.0;
+      const char *ge = std::getenv("PALACE_AMD_INTERP_GATHER_GROUP");
+      if (longest >= 12 && !(ge && ge[0] == '0')) gather_group_ = avg < 2.5 ? 2 : avg < 5.0 ? 4 : 8;
     }
     d_off_d_ = pa::dev_upload(rd.offsets, nd, ctx.stream);
     d_off_r_ = pa::dev_upload(offr.data(), nr, ctx.stream);
@@ -820,12 +970,35 @@ public:
     d_M_ = pa::dev_upload(M, (size_t)nmat * Pr_ * Pd_, ctx.stream);
     nmat_ = nmat;
     if (mat_id) d_mat_id_ = pa::dev_upload(mat_id, (size_t)ne_, ctx.stream);
+    // the register form (read at creation: PALACE_AMD_DENSE_INTERP=lds keeps the strips in LDS)
+    const char *form = std::getenv("PALACE_AMD_DENSE_INTERP");
+    if (nmat == 1 && Pd_ <= 64 && Pr_ <= 64 && std::min(Pd_, Pr_) >= 1 && std::max(Pd_, Pr_) <= 48 && !(form && std::string(form) == "lds")) {
+      auto pack = [&](const pa_restriction_desc &r, int P, bool columns) {
+        std::vector<int32_t> pk((size_t)ne_ * P);
+        for (int e = 0; e < ne_; e++)
+          for (int i = 0; i < P; i++) {
+            const size_t k = (size_t)e * P + i;
+            int8_t b0 = 0, b1 = 1, b2 = 0;
+            if (r.curl_orients) {
+              const int8_t *t = r.curl_orients + 3 * k;
+              if (columns) b0 = i > 0 ? t[-3 + 2] : 0, b1 = t[1], b2 = i + 1 < P ? t[3 + 0] : 0;  // T[i-1][i], T[i][i], T[i+1][i]
+              else b0 = t[0], b1 = t[1], b2 = t[2];
+            } else if (r.orients) {
+              b1 = r.orients[k] ? -1 : 1;
+            }
+            pk[k] = (int32_t)((uint32_t)(uint8_t)b0 | ((uint32_t)(uint8_t)b1 << 8) | ((uint32_t)(uint8_t)b2 << 16));
+          }
+        return pa::dev_upload(pk.data(), pk.size(), ctx.stream);
+      };
+      d_pk_[0] = pack(rd, Pd_, false), d_pk_[1] = pack(rd, Pd_, true), d_pk_[2] = pack(rr, Pr_, false), d_pk_[3] = pack(rr, Pr_, true);
+    }
     ld_.SetSize(nl_d_), lr_.SetSize(nl_r_);
   }
   ~DenseInterpOperator() override {
     (void)hipFree(d_off_d_), (void)hipFree(d_off_r_), (void)hipFree(d_tptr_), (void)hipFree(d_tent_);
     (void)hipFree(d_sgn_d_), (void)hipFree(d_sgn_r_), (void)hipFree(d_T_d_), (void)hipFree(d_B_r_);
     (void)hipFree(d_M_), (void)hipFree(d_ye_), (void)hipFree(d_mat_id_);
+    for (int32_t *p : d_pk_) (void)hipFree(p);
   }
   void Mult(const Vector &x, Vector &y) const override {
     const Context &c = *ctx_;
@@ -852,7 +1025,7 @@ public:
         PA_HIP(hipMemsetAsync(lr_.Data() + nt_r_, 0, sizeof(double) * (size_t)(nl_r_ - nt_r_), c.stream));
     }
     launch<true>(serial ? x.Data() : lr_.Data(), nullptr);
-    launch_k_gather(nl_d_, d_tptr_, d_tent_, d_ye_, serial ? y.Data() : ld_.Data(), c.stream);
+    launch_k_gather(nl_d_, d_tptr_, d_tent_, d_ye_, serial ? y.Data() : ld_.Data(), c.stream, gather_group_);
     PA_HIP(hipGetLastError());
     if (serial) return;
     if (halo_d_) halo_d_->RestrictAdd(ld_.Data(), c.stream);
