@@ -2364,7 +2364,10 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
     PA_HIP(hipGetLastError());
     return;
   }
-  if (split || ess_policy >= 0) {  // (one vector with the essential rows fixed on the way: the same kernel, nothing beyond y)
+  // every overwriting gather takes the same kernel (plain, split vectors, essential rows fixed on the way): y = A x has the same bits
+  // whichever entry point computed it (tests/test_split_gpu.py compares them with torch.equal); the accumulating forms below keep the
+  // serial order of et_gather_kernel
+  if (split || ess_policy >= 0 || !accumulate) {
     PA_REQUIRE(!accumulate, "split vectors / fused essential rows: y = A x only");
     PA_REQUIRE(ess_policy < 0 || (ds.d_ess_flag && x), "essential rows fused into the gather: pa_op_set_essential first");
     launch_gather_split<false>(ds, ye ? ye : ds.d_ye, y, split ? split->yg - split->n_true : y, split ? split->n_true : 0x7fffffff, x,
