@@ -179,7 +179,28 @@ amg::HostCsr dense_to_csr(const std::vector<double> &M, int n) {
 // 4th-kind Chebyshev smoothing of order k on D^-1 A with lambda_max = 1 (chebyshev.cpp:190-220 with the eigenvalue bound of
 // the l1 scaling): x <- x + p(D^-1 A) D^-1 (b - A x).  r, d, t: work vectors of the size of x.
 void cheb4(const Context &c, const Operator &A, const Vector &dinv, int order, const Vector &b, Vector &x, bool zero_guess,
-           Vector &r, Vector &d, Vector &t) {
+           Vector &r, Vector &d, Vector &t, bool fused = false) {
+  if (fused) {
+    // Round 6: the same polynomial in its accumulated form (linalg.hip: ChebyshevSmoother, e_k = d_0 + ... + d_{k-1}) with every
+    // product consumed in the sparse product's epilogue (CsrOperator::MultResidual / MultChebyStep): order 2 is TWO launches
+    // instead of six.  e_{k+1} = e_k + sd (e_k - e_{k-1}) + sr D^-1 (r_0 - A e_k); r_0 is the right-hand side itself with a zero guess.
+    const Vector *r0 = &b;
+    if (zero_guess) {
+      linalg::ChebyOrder0(c, 4.0 / 3.0, dinv, b, order > 1 ? d : x);  // e_1 (order 1: the result)
+    } else {
+      A.MultResidual(x, b, &r, &dinv, 4.0 / 3.0, &d);  // r_0 = b - A x, e_1 = c_0 D^-1 r_0
+      r0 = &r;
+      if (order <= 1) linalg::AXPY(c, 1.0, d, x);
+    }
+    Vector *ek = &d, *ep = &t;
+    for (int k = 1; k < order; k++) {
+      const double sd = (2.0 * k - 1.0) / (2.0 * k + 3.0), sr = (8.0 * k + 4.0) / (2.0 * k + 3.0);
+      const bool last = k == order - 1;
+      A.MultChebyStep(*ek, Operator::ChebyStepArgs{sd, sr, &dinv, r0, k == 1 ? nullptr : ep, last ? &x : ep, last && !zero_guess});
+      if (!last) std::swap(ek, ep);
+    }
+    return;
+  }
   if (zero_guess) {
     linalg::Copy(c, b, r);
     linalg::Fill(c, x, 0.0);
@@ -229,10 +250,11 @@ AmgSolver::AmgSolver(const Context &ctx, const amg::HostCsr &A, const AmgOptions
   } else {
     lv_.back().dinv = upload(ctx, l1_inverse(Ac));
   }
+  fused_ = !lv_.empty() && lv_[0].A->Op().PrepareChebyStep();
 }
 
 void AmgSolver::Smooth(const Level &L, const Vector &b, Vector &x, bool zero_guess) const {
-  cheb4(*ctx_, L.A->Op(), L.dinv, opt_.smooth_order, b, x, zero_guess, L.r, L.d, L.t);
+  cheb4(*ctx_, L.A->Op(), L.dinv, opt_.smooth_order, b, x, zero_guess, L.r, L.d, L.t, fused_);
 }
 
 void AmgSolver::Cycle(size_t l, const Vector &b, Vector &x) const {
@@ -248,8 +270,12 @@ void AmgSolver::Cycle(size_t l, const Vector &b, Vector &x) const {
     return;
   }
   Smooth(L, b, x, true);
-  L.A->Op().Mult(x, L.r);
-  linalg::AXPBY(c, 1.0, b, -1.0, L.r);
+  if (fused_) {
+    L.A->Op().MultResidual(x, b, &L.r);  // r = b - A x in the product's epilogue
+  } else {
+    L.A->Op().Mult(x, L.r);
+    linalg::AXPBY(c, 1.0, b, -1.0, L.r);
+  }
   const Level &N = lv_[l + 1];
   L.R->Op().Mult(L.r, N.b);
   Cycle(l + 1, N.b, N.x);
@@ -378,17 +404,22 @@ AmsSolver::AmsSolver(const Context &ctx, const amg::HostCsr &A, const amg::HostC
   bp_.SetSize(dim * nv), xp_.SetSize(dim * nv);
   dinv_ = upload(ctx, l1_inverse(A));
   r_.SetSize(ne), d_.SetSize(ne), t_.SetSize(ne);
+  fused_ = A_->Op().PrepareChebyStep();
 }
 
 void AmsSolver::Smooth(const Vector &b, Vector &x, bool zero_guess) const {
-  cheb4(*ctx_, A_->Op(), dinv_, opt_.smooth_order, b, x, zero_guess, r_, d_, t_);
+  cheb4(*ctx_, A_->Op(), dinv_, opt_.smooth_order, b, x, zero_guess, r_, d_, t_, fused_);
 }
 
 // x += T B T^T (b - A x)
 void AmsSolver::Correct(const DeviceCsr &T, const DeviceCsr &Tt, const AmgSolver &B, const Vector &b, Vector &x, Vector &bc,
                         Vector &xc) const {
-  A_->Op().Mult(x, r_);
-  linalg::AXPBY(*ctx_, 1.0, b, -1.0, r_);
+  if (fused_) {
+    A_->Op().MultResidual(x, b, &r_);
+  } else {
+    A_->Op().Mult(x, r_);
+    linalg::AXPBY(*ctx_, 1.0, b, -1.0, r_);
+  }
   Tt.Op().Mult(r_, bc);
   B.Mult(bc, xc);
   T.Op().AddMult(xc, x, 1.0);

@@ -58,6 +58,7 @@ class AmgSolver : public Solver {
   };
   const Context *ctx_;
   AmgOptions opt_;
+  bool fused_ = false;  // smoother steps and residuals in the sparse products' epilogues (CsrOperator::PrepareChebyStep, round 6)
   std::vector<Level> lv_;
   std::unique_ptr<DeviceCsr> Cinv_;  // pseudo-inverse of the last level's matrix (dense, stored as CSR)
   void Smooth(const Level &L, const Vector &b, Vector &x, bool zero_guess) const;
@@ -89,6 +90,7 @@ struct AmsOptions {
 class AmsSolver : public Solver {
   const Context *ctx_;
   AmsOptions opt_;
+  bool fused_ = false;  // as in AmgSolver
   std::unique_ptr<DeviceCsr> A_, G_, Gt_, Pi_, Pit_;
   std::unique_ptr<AmgSolver> BG_, BPi_;
   Vector dinv_;

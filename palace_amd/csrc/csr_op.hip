@@ -5,6 +5,7 @@
 // (AMS / BoomerAMG through HYPRE) needs a matrix.  Here the matrix comes from pa_op_full_assemble and stays in
 // HBM; the apply is a sparse matrix-vector product, which at p = 1 moves ~3x fewer bytes than the matrix-free
 // operator carrying the fine level's quadrature data.
+#include <cstdlib>
 #include "linalg.hpp"
 
 namespace palace {
@@ -46,6 +47,56 @@ __global__ __launch_bounds__(256) void k_csr_spmv(const int n, const int32_t *__
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LPR);
   if (row < n && l == 0) y[row] = add ? y[row] + a * s : a * s;
+}
+
+// y = A x consumed where it is produced (round 6: Operator::MultChebyStep / MultResidual for assembled matrices -- the smoothers of the
+// algebraic levels are six launches of a few microseconds each per smoothing; with the step in the product's epilogue they are two):
+//   mode 1:  out (+)= x + sd (x - ep) + sr dinv .* (r0 - A x)        (one step of the accumulated Chebyshev recurrence)
+//   mode 2:  res = r0 - A x  and / or  out = sr dinv .* (r0 - A x)    (residual, first direction)
+// `out`, `res` must not alias x (other rows read it).
+struct CsrStep {
+  int mode, add;
+  double sd, sr;
+  const double *dinv, *r0, *ep;
+  double *out, *res;
+};
+template <int LPR>
+__global__ __launch_bounds__(256) void k_csr_spmv_step(const int n, const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                       const double *__restrict__ x, const CsrStep st) {
+  const int row = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPR);
+  const int l = threadIdx.x % LPR;
+  double s = 0.0;
+  if (row < n) {
+    const int32_t b = rowptr[row], e = rowptr[row + 1];
+    int32_t c[4];
+    double v[4], xv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int32_t k = b + l + q * LPR;
+      c[q] = k < e ? col[k] : -1;
+      v[q] = k < e ? val[k] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) xv[q] = c[q] >= 0 ? x[c[q]] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (c[q] >= 0) s += v[q] * xv[q];
+    for (int32_t k = b + l + 4 * LPR; k < e; k += LPR) s += val[k] * x[col[k]];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_down(s, o, LPR);
+  if (row >= n || l != 0) return;
+  const double rv = st.r0[row] - s;
+  if (st.mode == 2) {
+    if (st.res) st.res[row] = rv;
+    if (st.out) st.out[row] = st.sr * st.dinv[row] * rv;
+    return;
+  }
+  const double ev = x[row];
+  double dk = st.sr * st.dinv[row] * rv;
+  dk += st.sd * (ev - (st.ep ? st.ep[row] : 0.0));
+  st.out[row] = (st.add ? st.out[row] : 0.0) + (ev + dk);
 }
 
 // the same on split vectors (multi-rank applies without L-vector copies): rows / columns [0, nsplit) live in y / x,
@@ -166,6 +217,33 @@ void CsrOperator::Apply(const double *vals, const Vector &x, Vector &y, double a
   PA_HIP(hipGetLastError());
 }
 
+namespace {
+void launch_csr_step(const Context &c, const pa_csr *m, int lanes, int n, const double *x, const CsrStep &st) {
+  if (!n) return;
+  const long long threads = (long long)n * lanes;
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  if (lanes == 16) hipLaunchKernelGGL(k_csr_spmv_step<16>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, m->d_val, x, st);
+  else if (lanes == 8) hipLaunchKernelGGL(k_csr_spmv_step<8>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, m->d_val, x, st);
+  else hipLaunchKernelGGL(k_csr_spmv_step<4>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, m->d_val, x, st);
+  PA_HIP(hipGetLastError());
+}
+}  // namespace
+bool CsrOperator::PrepareChebyStep() const {
+  const char *e = std::getenv("PALACE_AMD_FUSED_STEP_CSR");  // (read at every set-up: A / B runs in one process)
+  return height == width && !(e && e[0] == '0');
+}
+void CsrOperator::MultChebyStep(const Vector &x, const ChebyStepArgs &a) const {
+  PA_REQUIRE(x.Size() == width && a.out && a.out->Size() == height && a.dinv && a.r0, "size mismatch in CsrOperator::MultChebyStep");
+  PA_REQUIRE(a.out->Data() != x.Data(), "CsrOperator::MultChebyStep: the result must not alias the vector the matrix multiplies");
+  launch_csr_step(*ctx_, m_, lanes_, height, x.Data(),
+                  CsrStep{1, a.add ? 1 : 0, a.sd, a.sr, a.dinv->Data(), a.r0->Data(), a.e_prev ? a.e_prev->Data() : nullptr, a.out->Data(), nullptr});
+}
+void CsrOperator::MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0) const {
+  PA_REQUIRE(y.Size() == width && b.Size() == height && (res || d0) && (!d0 || dinv), "bad arguments of CsrOperator::MultResidual");
+  PA_REQUIRE((!res || res->Data() != y.Data()) && (!d0 || d0->Data() != y.Data()), "CsrOperator::MultResidual: results must not alias y");
+  launch_csr_step(*ctx_, m_, lanes_, height, y.Data(),
+                  CsrStep{2, 0, 0.0, c0, dinv ? dinv->Data() : nullptr, b.Data(), nullptr, d0 ? d0->Data() : nullptr, res ? res->Data() : nullptr});
+}
 void CsrOperator::Mult(const Vector &x, Vector &y) const { Apply(m_->d_val, x, y, 1.0, false); }
 void CsrOperator::MultTranspose(const Vector &x, Vector &y) const {
   PA_REQUIRE(m_->symmetric, "MultTranspose of an assembled non-symmetric operator is not available");

@@ -374,6 +374,11 @@ public:
   void AssembleDiagonal(Vector &diag) const override;
   bool IsSymmetric() const override { return m_->symmetric; }
   const pa_csr &Matrix() const { return *m_; }
+  // round 6: smoother steps / residuals in the epilogue of the sparse product (k_csr_spmv_step; PALACE_AMD_FUSED_STEP_CSR=0: off)
+  bool PrepareChebyStep() const override;
+  void MultChebyStep(const Vector &x, const ChebyStepArgs &a) const override;
+  void MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv = nullptr, double c0 = 0.0,
+                    Vector *d0 = nullptr) const override;
 };
 
 // ParOperator (rap.cpp:154-234): y = P^T A P x with essential-dof handling.  True dofs of this

@@ -151,3 +151,25 @@ def test_pmg_with_ams_on_the_coarsest_level():
         prob._keep.clear()
     assert out["ams"][0] <= out["cg"][0], (out["ams"][0], out["cg"][0])
     assert _rel(out["ams"][1], out["cg"][1]) < 1e-7
+
+
+def test_cycles_with_the_steps_in_the_sparse_products_epilogues(problem, monkeypatch):
+    """Round 6: the smoothers and residuals of the algebraic cycles run as CsrOperator::MultChebyStep / MultResidual (the accumulated
+    form of the same polynomial, two launches per smoothing instead of six); PALACE_AMD_FUSED_STEP_CSR=0 at creation keeps product +
+    vector kernel.  One AMG and one AMS application either way: equal to rounding (and each equal to the restated cycle: the tests
+    above run with the default, fused, form)."""
+    nd, h1, geom = problem["nd"], problem["h1"], problem["geom"]
+    ctx = linalg.Context()
+    rng = np.random.default_rng(3)
+    op = ceed.curlcurlmass_operator(geom, nd, problem["mass"], problem["ident"])
+    ess = nd.ess_dofs()
+    G, X = lowest_order_gradient(h1, nd), vertex_coordinates(h1)
+    csr = op.full_assemble_device()
+    b = rng.uniform(-1, 1, nd.ndofs)
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("PALACE_AMD_FUSED_STEP_CSR", form)
+        B = linalg.ams(ctx, csr, ess, G, X, amg_coarse_size=60)
+        out[form] = B.mult(_dev(b), torch.full((nd.ndofs,), np.nan, dtype=torch.float64, device="cuda")).cpu().numpy()
+    assert _rel(out["1"], out["0"]) < 1e-12
+    assert not np.array_equal(out["1"], out["0"]), "both runs took the same form?"
