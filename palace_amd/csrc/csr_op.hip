@@ -218,13 +218,14 @@ void CsrOperator::Apply(const double *vals, const Vector &x, Vector &y, double a
 }
 
 namespace {
-void launch_csr_step(const Context &c, const pa_csr *m, int lanes, int n, const double *x, const CsrStep &st) {
+void launch_csr_step(const Context &c, const pa_csr *m, int lanes, int n, const double *x, const CsrStep &st, const double *vals = nullptr) {
   if (!n) return;
+  if (!vals) vals = m->d_val;
   const long long threads = (long long)n * lanes;
   const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-  if (lanes == 16) hipLaunchKernelGGL(k_csr_spmv_step<16>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, m->d_val, x, st);
-  else if (lanes == 8) hipLaunchKernelGGL(k_csr_spmv_step<8>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, m->d_val, x, st);
-  else hipLaunchKernelGGL(k_csr_spmv_step<4>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, m->d_val, x, st);
+  if (lanes == 16) hipLaunchKernelGGL(k_csr_spmv_step<16>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, vals, x, st);
+  else if (lanes == 8) hipLaunchKernelGGL(k_csr_spmv_step<8>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, vals, x, st);
+  else hipLaunchKernelGGL(k_csr_spmv_step<4>, grid, block, 0, c.stream, n, m->d_rowptr, m->d_col, vals, x, st);
   PA_HIP(hipGetLastError());
 }
 }  // namespace
@@ -237,6 +238,21 @@ void CsrOperator::MultChebyStep(const Vector &x, const ChebyStepArgs &a) const {
   PA_REQUIRE(a.out->Data() != x.Data(), "CsrOperator::MultChebyStep: the result must not alias the vector the matrix multiplies");
   launch_csr_step(*ctx_, m_, lanes_, height, x.Data(),
                   CsrStep{1, a.add ? 1 : 0, a.sd, a.sr, a.dinv->Data(), a.r0->Data(), a.e_prev ? a.e_prev->Data() : nullptr, a.out->Data(), nullptr});
+}
+void CsrOperator::MultChebyStepValues(const double *d_vals, const Vector &x, const ChebyStepArgs &a) const {
+  PA_REQUIRE(x.Size() == width && a.out && a.out->Size() == height && a.dinv && a.r0, "size mismatch in CsrOperator::MultChebyStep");
+  PA_REQUIRE(a.out->Data() != x.Data(), "CsrOperator::MultChebyStep: the result must not alias the vector the matrix multiplies");
+  launch_csr_step(*ctx_, m_, lanes_, height, x.Data(),
+                  CsrStep{1, a.add ? 1 : 0, a.sd, a.sr, a.dinv->Data(), a.r0->Data(), a.e_prev ? a.e_prev->Data() : nullptr, a.out->Data(), nullptr},
+                  d_vals);
+}
+void CsrOperator::MultResidualValues(const double *d_vals, const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0,
+                                     Vector *d0) const {
+  PA_REQUIRE(y.Size() == width && b.Size() == height && (res || d0) && (!d0 || dinv), "bad arguments of CsrOperator::MultResidual");
+  PA_REQUIRE((!res || res->Data() != y.Data()) && (!d0 || d0->Data() != y.Data()), "CsrOperator::MultResidual: results must not alias y");
+  launch_csr_step(*ctx_, m_, lanes_, height, y.Data(),
+                  CsrStep{2, 0, 0.0, c0, dinv ? dinv->Data() : nullptr, b.Data(), nullptr, d0 ? d0->Data() : nullptr, res ? res->Data() : nullptr},
+                  d_vals);
 }
 void CsrOperator::MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0) const {
   PA_REQUIRE(y.Size() == width && b.Size() == height && (res || d0) && (!d0 || dinv), "bad arguments of CsrOperator::MultResidual");

@@ -1176,6 +1176,7 @@ ParOperator::~ParOperator() {
 
 bool ParOperator::PrepareChebyStep() const {
   if (A_fused_ && !halo_) return A_fused_->PrepareFusedStep();
+  if (A_csr_ && !halo_) return A_csr_->PrepareChebyStep();  // assembled local operator, one rank: the step in the sparse product (csr_op.hip)
   // several ranks, direct form of the peer transport (round 6): the local gather consumes the dofs no other rank shares, the merged
   // P^T kernel the interface dofs (Halo::RestrictAddDirectStep); needs the essential list fused (split_ess_) and the mask
   static const bool halo_step = !(std::getenv("PALACE_AMD_FUSED_STEP_HALO") && std::getenv("PALACE_AMD_FUSED_STEP_HALO")[0] == '0');
@@ -1193,6 +1194,7 @@ void ParOperator::SplitStep(const Vector &x, const pa_split_step &st0, const Hal
 }
 void ParOperator::MultChebyStep(const Vector &x, const ChebyStepArgs &a) const {
   if (A_fused_ && !halo_) return A_fused_->MultChebyStepEssential(x, a, policy_ == DiagonalPolicy::DIAG_ONE);
+  if (A_csr_ && !halo_) return A_csr_->MultChebyStepValues(d_csr_bc_, x, a);  // (essential rows / columns live in the values)
   PA_REQUIRE(A_split_ && halo_, "MultChebyStep: PrepareChebyStep found no fused form");
   const double *ep = a.e_prev ? a.e_prev->Data() : nullptr;
   SplitStep(x, pa_split_step{1, a.sd, a.sr, a.dinv->Data(), a.r0->Data(), ep, a.out->Data(), a.add ? 1 : 0, nullptr, nullptr, nullptr},
@@ -1200,6 +1202,7 @@ void ParOperator::MultChebyStep(const Vector &x, const ChebyStepArgs &a) const {
 }
 void ParOperator::MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0) const {
   if (A_fused_ && !halo_) return A_fused_->MultResidualEssential(y, b, res, dinv, c0, d0, policy_ == DiagonalPolicy::DIAG_ONE);
+  if (A_csr_ && !halo_) return A_csr_->MultResidualValues(d_csr_bc_, y, b, res, dinv, c0, d0);
   PA_REQUIRE(A_split_ && halo_, "MultResidual: PrepareChebyStep found no fused form");
   const double *di = dinv ? dinv->Data() : nullptr;
   double *r = res ? res->Data() : nullptr, *o = d0 ? d0->Data() : nullptr;

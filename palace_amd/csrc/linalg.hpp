@@ -379,6 +379,9 @@ public:
   void MultChebyStep(const Vector &x, const ChebyStepArgs &a) const override;
   void MultResidual(const Vector &y, const Vector &b, Vector *res, const Vector *dinv = nullptr, double c0 = 0.0,
                     Vector *d0 = nullptr) const override;
+  // the same with a caller's copy of the values (ParOperator's eliminated rows / columns: EliminatedValues)
+  void MultChebyStepValues(const double *d_vals, const Vector &x, const ChebyStepArgs &a) const;
+  void MultResidualValues(const double *d_vals, const Vector &y, const Vector &b, Vector *res, const Vector *dinv, double c0, Vector *d0) const;
 };
 
 // ParOperator (rap.cpp:154-234): y = P^T A P x with essential-dof handling.  True dofs of this

@@ -173,3 +173,33 @@ def test_cycles_with_the_steps_in_the_sparse_products_epilogues(problem, monkeyp
         out[form] = B.mult(_dev(b), torch.full((nd.ndofs,), np.nan, dtype=torch.float64, device="cuda")).cpu().numpy()
     assert _rel(out["1"], out["0"]) < 1e-12
     assert not np.array_equal(out["1"], out["0"]), "both runs took the same form?"
+
+
+@pytest.mark.parametrize("policy", ["one", "zero"])
+def test_chebyshev_on_an_assembled_operator_with_the_step_in_the_sparse_product(problem, monkeypatch, policy):
+    """ChebyshevSmoother over ParOperator(CsrOperator) -- the level-0 smoother of the bench's plain p-multigrid: the step in the
+    product's epilogue against product + vector kernel, zero and non-zero initial guess."""
+    nd, geom = problem["nd"], problem["geom"]
+    op = ceed.curlcurlmass_operator(geom, nd, problem["mass"], problem["ident"])
+    ess = nd.ess_dofs()
+    ctx = linalg.Context()
+    csr = op.full_assemble_device()
+    pol = linalg.DIAG_ONE if policy == "one" else linalg.DIAG_ZERO
+    A = linalg.AssembledParOperator(ctx, csr, ess, pol)
+    if policy == "zero":
+        pytest.skip("a Jacobi-scaled smoother needs the unit diagonal on the essential rows")
+    S = linalg.chebyshev(ctx, A, order=4)
+    assert S.fused_step()
+    monkeypatch.setenv("PALACE_AMD_FUSED_STEP_CSR", "0")
+    S0 = linalg.chebyshev(ctx, A, order=4)
+    assert not S0.fused_step() and S0.lambda_max() == S.lambda_max()
+    rng = np.random.default_rng(8)
+    n = nd.ndofs
+    b, g = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    b[ess] = 0.0
+    g[ess] = 0.0
+    y = S.mult(_dev(b), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    y0 = S0.mult(_dev(b), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    z = S.mult(_dev(b), _dev(g.copy()), initial_guess=True).cpu().numpy()
+    z0 = S0.mult(_dev(b), _dev(g.copy()), initial_guess=True).cpu().numpy()
+    assert _rel(y, y0) < 1e-13 and _rel(z, z0) < 1e-13
