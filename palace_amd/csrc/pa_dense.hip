@@ -2203,8 +2203,11 @@ int gather_group(long long nnz, int n) {
   const char *e = std::getenv("PALACE_AMD_DENSE_GATHER_GROUP");
   if (e && e[0] == '0') return 1;
   if (e && (e[0] == '2' || e[0] == '4' || e[0] == '8') && !e[1]) return e[0] - '0';
+  // (a deterministic rule, not a timing: the group size changes the order of the sums.  Measured: order-3 Nedelec tetrahedra, 2.4
+  // copies per dof, gain nothing from two lanes per dof on either mesh -- 62 -> 64 us on config 3's, 0.184 -> 0.195 ms per apply on the
+  // Kuhn cube; spaces with vertex dofs, >= 3 copies on average, gain up to 2x)
   const double avg = n > 0 ? (double)nnz / n : 1.0;
-  return avg < 1.5 ? 1 : avg < 2.5 ? 2 : avg < 5.0 ? 4 : 8;
+  return avg < 3.0 ? 1 : avg < 5.5 ? 4 : 8;
 }
 int dense_gather_group(const DenseSub &ds) { return gather_group((long long)ds.ne * ds.P, ds.lsize); }
 template <bool STEP>

@@ -306,7 +306,7 @@ def test_nd_tet_boundary_mass(kind, p):
         assert abs(float(xd @ y) - 56.0) < 1e-11 * 56.0
 
 
-@pytest.mark.parametrize("group", ["0", "2", "4", "8"])
+@pytest.mark.parametrize("group", ["0", "2", "4", "8"])  # (2: reachable through the switch only)
 @pytest.mark.parametrize("layout", ["rows", "block"])
 @pytest.mark.parametrize("p", [2, 3])
 def test_nd_tet_gather_forms(monkeypatch, p, layout, group):
