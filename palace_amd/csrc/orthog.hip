@@ -253,6 +253,7 @@ struct ResArgs {
   const double *const *vr, *const *vi;
   int m, normalize;
   long long n;
+  int prefetch;     // 1: v_{j+1} travels to LDS while the grid barrier of step j is pending (PALACE_AMD_GS_PREFETCH=0: off)
   double *partial;  // [2 parities][2 components][kResMaxGrid]
   unsigned *bar;    // group counters at [16 g], g < 16 (one 64-byte line each); the top counter at [256]; zero at launch
   double *coef, *nrm2;
@@ -297,11 +298,20 @@ __device__ __forceinline__ void st_lane(double *base, unsigned off, double2 v) {
   *reinterpret_cast<PA_GLOBAL d2n *>((PA_GLOBAL char *)scalar_u64((unsigned long long)base) + off) = d2n{v.x, v.y};
 }
 
+// slots of v_{j+1} that wait in LDS (16-byte lanes per thread and part): 144 KB of the 160 KB of a compute unit at the largest
+template <bool CPLX, int R>
+constexpr int res_lds_slots() { return R < (CPLX ? 9 : 18) ? R : (CPLX ? 9 : 18); }
+template <bool CPLX, int R>
+constexpr size_t res_lds_bytes() { return (size_t)res_lds_slots<CPLX, R>() * (CPLX ? 2 : 1) * kResBlk * 16; }
+
 template <bool CPLX, int R>
 __global__ __launch_bounds__(kResBlk) void k_mgs_resident(const ResArgs A) {
   constexpr int NC = CPLX ? 2 : 1;
+  constexpr int LS = res_lds_slots<CPLX, R>();
+  extern __shared__ __attribute__((aligned(16))) double2 pre[];  // [LS][NC][kResBlk]: every thread reads what it wrote itself
   __shared__ double sm[2][kResBlk / 64];
   __shared__ double hb[2];
+  const bool pf = A.prefetch != 0;
   const long long nv = A.n / 2, stride = (long long)gridDim.x * kResBlk;
   const long long i0 = (long long)blockIdx.x * kResBlk + threadIdx.x;
   const bool tail = (A.n & 1) && blockIdx.x == 0 && threadIdx.x == 0;  // the odd last entry
@@ -320,7 +330,8 @@ __global__ __launch_bounds__(kResBlk) void k_mgs_resident(const ResArgs A) {
   }
   if (tail) at = A.wr[A.n - 1], bt = CPLX ? A.wi[A.n - 1] : 0.0;
   // grid-wide sum of (v[0], v[1]) in step `step` (the barrier's round): the result in every thread of every block, the same bits
-  auto grid_sum = [&](double (&v)[2], const int step, const bool two) {
+  // ... in two halves, so that the block can do something useful between its arrival at the barrier and the barrier's completion
+  auto arrive = [&](double (&v)[2], const int step, const bool two) {
     block_sum<2>(v, sm);
     double *part = A.partial + (size_t)(step & 1) * 2 * kResMaxGrid;
     if (threadIdx.x == 0) {
@@ -331,6 +342,11 @@ __global__ __launch_bounds__(kResBlk) void k_mgs_resident(const ResArgs A) {
       // grid barrier: the last block of a group bumps the top counter; everybody waits for the top counter
       if (__hip_atomic_fetch_add(&A.bar[16u * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)step * ng + ng - 1u)
         __hip_atomic_fetch_add(&A.bar[256], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto complete = [&](double (&v)[2], const int step, const bool two) {
+    double *part = A.partial + (size_t)(step & 1) * 2 * kResMaxGrid;
+    if (threadIdx.x == 0) {
       while (__hip_atomic_load(&A.bar[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1) * ngroups)
         __builtin_amdgcn_s_sleep(1);
     }
@@ -346,15 +362,47 @@ __global__ __launch_bounds__(kResBlk) void k_mgs_resident(const ResArgs A) {
     __syncthreads();
     v[0] = hb[0], v[1] = hb[1];
   };
+  // the first LS slots of basis vector jj into this thread's LDS words, three slots at a time through spare registers
+  auto prefetch = [&](const int jj) {
+    const double *qr = A.vr[jj], *qi = CPLX ? A.vi[jj] : nullptr;
+    constexpr int CH = 3;
+#pragma unroll
+    for (int r0 = 0; r0 < LS; r0 += CH) {
+      double2 tr[CH], ti[CH];
+#pragma unroll
+      for (int q = 0; q < CH; q++) {
+        const int r = r0 + q;
+        if (r < LS) {
+          const bool in = r < R - 1 || in_last;
+          tr[q] = in ? ld_lane(qr + 2 * r * stride, o) : double2{0.0, 0.0};
+          ti[q] = (CPLX && in) ? ld_lane(qi + 2 * r * stride, o) : double2{0.0, 0.0};
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CH; q++) {
+        const int r = r0 + q;
+        if (r < LS) {
+          pre[(r * NC) * kResBlk + threadIdx.x] = tr[q];
+          if (CPLX) pre[(r * NC + 1) * kResBlk + threadIdx.x] = ti[q];
+        }
+      }
+    }
+  };
+  if (pf && A.m > 0) prefetch(0);
   for (int j = 0; j < A.m; j++) {
     const double *pr = A.vr[j], *pi = CPLX ? A.vi[j] : nullptr;
     double2 c[R], d[R];
     double ct = 0.0, dt = 0.0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      const bool in = r < R - 1 || in_last;
-      c[r] = in ? ld_lane(pr + 2 * r * stride, o) : double2{0.0, 0.0};
-      d[r] = (CPLX && in) ? ld_lane(pi + 2 * r * stride, o) : double2{0.0, 0.0};
+      if (pf && r < LS) {  // (requested while the previous step's barrier was pending)
+        c[r] = pre[(r * NC) * kResBlk + threadIdx.x];
+        d[r] = CPLX ? pre[(r * NC + 1) * kResBlk + threadIdx.x] : double2{0.0, 0.0};
+      } else {
+        const bool in = r < R - 1 || in_last;
+        c[r] = in ? ld_lane(pr + 2 * r * stride, o) : double2{0.0, 0.0};
+        d[r] = (CPLX && in) ? ld_lane(pi + 2 * r * stride, o) : double2{0.0, 0.0};
+      }
     }
     if (tail) ct = pr[A.n - 1], dt = CPLX ? pi[A.n - 1] : 0.0;
     double2 t0{0.0, 0.0}, t1{0.0, 0.0};
@@ -371,7 +419,9 @@ __global__ __launch_bounds__(kResBlk) void k_mgs_resident(const ResArgs A) {
       v[0] += at * ct;
       if (CPLX) v[0] += bt * dt, v[1] += bt * ct - at * dt;
     }
-    grid_sum(v, j, CPLX);
+    arrive(v, j, CPLX);
+    if (pf && j + 1 < A.m) prefetch(j + 1);  // (v_j is in registers: the LDS words are free)
+    complete(v, j, CPLX);
     const double hr = v[0], hi = v[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       A.coef[NC * j] = hr;
@@ -403,7 +453,8 @@ __global__ __launch_bounds__(kResBlk) void k_mgs_resident(const ResArgs A) {
       v[0] += at * at;
       if (CPLX) v[0] += bt * bt;
     }
-    grid_sum(v, A.m, false);
+    arrive(v, A.m, false);
+    complete(v, A.m, false);
     if (blockIdx.x == 0 && threadIdx.x == 0) A.nrm2[0] = v[0];
     s = 1.0 / sqrt(fabs(v[0]));
   }
@@ -468,7 +519,13 @@ int resident_capacity_blocks() {  // blocks of k_mgs_resident<CPLX, R> the devic
     PA_HIP(hipGetDevice(&dev));
     PA_HIP(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev));
     PA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_resident<CPLX, R>, kResBlk, 0) != hipSuccess) nb = 0;
+    // (the LDS words of the prefetch are dynamic: above 64 KB they have to be asked for)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mgs_resident<CPLX, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)res_lds_bytes<CPLX, R>()) != hipSuccess) {
+      (void)hipGetLastError();
+      coop = 0;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_resident<CPLX, R>, kResBlk, res_lds_bytes<CPLX, R>()) != hipSuccess) nb = 0;
     cap = coop ? std::min(n_cu * nb, kResMaxGrid) : 0;
   }
   return cap;
@@ -484,7 +541,7 @@ bool launch_resident(const Context &c, const ResArgs &A0, long long nv, bool &fi
   PA_HIP(hipMemsetAsync(A.bar, 0, 257 * sizeof(unsigned), c.stream));
   void *args[] = {&A};
   const hipError_t rc = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_mgs_resident<CPLX, R>), dim3((unsigned)need),
-                                                   dim3(kResBlk), args, 0, c.stream);
+                                                   dim3(kResBlk), args, (unsigned)res_lds_bytes<CPLX, R>(), c.stream);
   if (rc != hipSuccess) {
     (void)hipGetLastError();
     g_resident_failed = true;
@@ -497,7 +554,8 @@ bool run_resident(const Context &c, const Column &col, bool normalize, const GsB
   const int m = col.m;
   for (int j = 0; j < m; j++) B.host_ptrs[j] = col.vr[j], B.host_ptrs[m + j] = CPLX ? col.vi[j] : nullptr;
   PA_HIP(hipMemcpyAsync(B.ptrs, B.host_ptrs, sizeof(double *) * 2 * (size_t)m, hipMemcpyHostToDevice, c.stream));
-  const ResArgs A{col.wr, col.wi, B.ptrs, B.ptrs + m, m, normalize ? 1 : 0, col.n, B.partial, B.bar, B.coef1, B.nrm2};
+  const char *pe = std::getenv("PALACE_AMD_GS_PREFETCH");
+  const ResArgs A{col.wr, col.wi, B.ptrs, B.ptrs + m, m, normalize ? 1 : 0, col.n, (pe && pe[0] == '0') ? 0 : 1, B.partial, B.bar, B.coef1, B.nrm2};
   const long long nv = col.n / 2;
   bool fits = false;
 #define PA_TRY_RESIDENT(R)                                       \
