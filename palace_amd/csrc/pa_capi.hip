@@ -1163,6 +1163,50 @@ int pa_op_prepare_fused_step(pa_op *op, int *available) {
       *available = dense_fused_step_ok(*op->dsubs[0]) ? 1 : 0;
       return;
     }
+    if (op->subs.empty() && op->dsubs.size() > 1) {
+      // a volume block and row-limited surface blocks (the absorbing boundary and the lumped ports of a driven problem: a few
+      // thousand faces in a space of millions): the surface blocks accumulate into a side vector first, the volume block's gather
+      // adds it and runs the step.  PALACE_AMD_FUSED_STEP_SURFACE=0: off.
+      const char *e = getenv("PALACE_AMD_FUSED_STEP_SURFACE");
+      if ((e && e[0] == '0') || !dense_fused_step_ok(*op->dsubs[0]) || op->dsubs[0]->d_rows) return;
+      for (size_t k = 1; k < op->dsubs.size(); k++)
+        if (!op->dsubs[k]->d_rows || !op->dsubs[k]->d_idx_bc) return;
+      if (!op->d_t_extra) {
+        std::vector<int32_t> rows;
+        for (size_t k = 1; k < op->dsubs.size(); k++) {
+          std::vector<int32_t> r((size_t)op->dsubs[k]->n_rows);
+          if (!r.empty()) PA_HIP(hipMemcpy(r.data(), op->dsubs[k]->d_rows, r.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+          rows.insert(rows.end(), r.begin(), r.end());
+        }
+        std::sort(rows.begin(), rows.end());
+        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+        op->n_extra_rows = (int)rows.size();
+        op->d_extra_rows = dev_upload(rows.data(), std::max<size_t>(rows.size(), 1));
+        if (op->dsubs.size() - 1 <= (size_t)kMaxSurfaceBlocks) {  // one gather for all the surface blocks (else: one each, accumulating)
+          std::vector<int32_t> uptr(rows.size() + 1, 0), uent;
+          std::vector<uint8_t> ublk;
+          std::vector<std::vector<int32_t>> tptr(op->dsubs.size()), tent(op->dsubs.size());
+          for (size_t k = 1; k < op->dsubs.size(); k++) {
+            const DenseSub &d = *op->dsubs[k];
+            tptr[k].resize((size_t)d.lsize + 1), tent[k].resize((size_t)d.ne * d.P);
+            PA_HIP(hipMemcpy(tptr[k].data(), d.d_tptr, tptr[k].size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            PA_HIP(hipMemcpy(tent[k].data(), d.d_tent, tent[k].size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+          }
+          for (size_t i = 0; i < rows.size(); i++) {
+            for (size_t k = 1; k < op->dsubs.size(); k++)
+              for (int32_t a = tptr[k][(size_t)rows[i]]; a < tptr[k][(size_t)rows[i] + 1]; a++) uent.push_back(tent[k][(size_t)a]), ublk.push_back((uint8_t)(k - 1));
+            uptr[i + 1] = (int32_t)uent.size();
+          }
+          op->d_urow_ptr = dev_upload(uptr.data(), uptr.size());
+          op->d_uent = dev_upload(uent.data(), std::max<size_t>(uent.size(), 1));
+          op->d_ublk = dev_upload(ublk.data(), std::max<size_t>(ublk.size(), 1));
+        }
+        op->d_t_extra = dev_alloc<double>((size_t)op->height);
+        PA_HIP(hipMemset(op->d_t_extra, 0, sizeof(double) * (size_t)op->height));
+      }
+      *available = 1;
+      return;
+    }
     if (op->subs.size() != 1 || !op->dsubs.empty()) return;
     SubOp *so = op->subs[0];
     // (four points per direction: pa_nd_hex_stream.hip; five: pa_nd_hex_stream5.hip -- nd_hex_stream_ok covers both; H1 blocks
@@ -1176,15 +1220,38 @@ int pa_op_prepare_fused_step(pa_op *op, int *available) {
   });
 }
 
+// the surface blocks of a dense operator prepared for the fused step: their contributions to t_extra (pa_op_prepare_fused_step)
+static const double *dense_surface_terms(pa_op *op, const double *x, hipStream_t s) {
+  if (op->dsubs.size() < 2) return nullptr;
+  PA_REQUIRE(op->d_t_extra, "pa_op_prepare_fused_step has not been called (or found no fused form)");
+  if (op->d_urow_ptr) {  // every surface block's element kernel, then ONE gather over the union of their rows (it overwrites them)
+    SurfaceYe ye{};
+    for (size_t k = 1; k < op->dsubs.size(); k++) {
+      launch_dense_apply(*op->dsubs[k], x, true, s);
+      ye.ye[k - 1] = op->dsubs[k]->d_ye;
+    }
+    launch_surface_rows(op->d_extra_rows, op->n_extra_rows, op->d_urow_ptr, op->d_uent, op->d_ublk, ye, op->d_t_extra, s);
+    return op->d_t_extra;
+  }
+  launch_zero_rows(op->d_t_extra, op->d_extra_rows, op->n_extra_rows, s);
+  for (size_t k = 1; k < op->dsubs.size(); k++) {
+    launch_dense_apply(*op->dsubs[k], x, true, s);
+    launch_dense_gather(*op->dsubs[k], op->d_t_extra, true, s);
+  }
+  return op->d_t_extra;
+}
+
 int pa_op_mult_cheb_step(pa_op *op, const double *x, const pa_cheb_step *step, int diag_policy, void *stream) {
   return guarded([&] {
     PA_REQUIRE(op && x && step && step->dinv && step->r0 && step->out, "null argument");
     PA_REQUIRE(x != step->out, "the step cannot overwrite its own input");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
-    if (op->subs.empty() && op->dsubs.size() == 1 && dense_fused_step_ok(*op->dsubs[0])) {
+    if (op->subs.empty() && !op->dsubs.empty() && dense_fused_step_ok(*op->dsubs[0])) {
       const DenseSub &ds = *op->dsubs[0];
+      const double *t_add = dense_surface_terms(op, x, (hipStream_t)stream);
       launch_dense_apply(ds, x, true, (hipStream_t)stream);
-      launch_dense_gather_step(ds, x, GatherStep{step->sd, step->sr, step->dinv, step->r0, step->e_prev, step->out, step->add, nullptr, 1},
+      launch_dense_gather_step(ds, x, GatherStep{step->sd, step->sr, step->dinv, step->r0, step->e_prev, step->out, step->add, nullptr, 1,
+                                                nullptr, nullptr, t_add},
                                diag_policy ? 1 : 0, (hipStream_t)stream);
       return;
     }
@@ -1202,10 +1269,12 @@ int pa_op_mult_residual(pa_op *op, const double *y, const double *b, double *res
     PA_REQUIRE(op && y && b && (res || d0) && (!d0 || dinv), "null argument");
     PA_REQUIRE(y != res && y != d0, "the residual cannot overwrite the operator's input");
     PA_REQUIRE(!TransposeScope::active() || op->symmetric(), "transposed step of a non-symmetric operator");
-    if (op->subs.empty() && op->dsubs.size() == 1 && dense_fused_step_ok(*op->dsubs[0])) {
+    if (op->subs.empty() && !op->dsubs.empty() && dense_fused_step_ok(*op->dsubs[0])) {
       const DenseSub &ds = *op->dsubs[0];
+      const double *t_add = dense_surface_terms(op, y, (hipStream_t)stream);
       launch_dense_apply(ds, y, true, (hipStream_t)stream);
-      launch_dense_gather_step(ds, y, GatherStep{0.0, c0, dinv, b, nullptr, d0, 0, res, 2}, diag_policy ? 1 : 0, (hipStream_t)stream);
+      launch_dense_gather_step(ds, y, GatherStep{0.0, c0, dinv, b, nullptr, d0, 0, res, 2, nullptr, nullptr, t_add}, diag_policy ? 1 : 0,
+                               (hipStream_t)stream);
       return;
     }
     PA_REQUIRE(op->subs.size() == 1 && op->subs[0]->n_all > 0, "pa_op_prepare_fused_step has not been called (or found no fused form)");
@@ -1347,6 +1416,8 @@ void pa_op_destroy(pa_op *op) {
   for (SubOp *so : op->subs) free_sub(so);
   for (DenseSub *ds : op->dsubs) free_dense_sub(ds);
   for (MixedSub *ms : op->msubs) free_mixed_sub(ms);
+  (void)hipFree(op->d_t_extra), (void)hipFree(op->d_extra_rows);
+  (void)hipFree(op->d_urow_ptr), (void)hipFree(op->d_uent), (void)hipFree(op->d_ublk);
   delete op;
 }
 

@@ -2133,6 +2133,7 @@ __global__ __launch_bounds__(256) void et_gather_split_kernel_t(const int n, con
     } else if (kind[u] == 1) {
       st.t_iface[d] = s[u];
     } else if (kind[u] == 2) {
+      if (st.t_add && !fixed[u]) s[u] += st.t_add[d];  // (the surface blocks' contributions)
       const double rv = r0[u] - s[u];
       if (st.mode == 2) {
         if (st.res) st.res[d] = rv;
@@ -2187,6 +2188,7 @@ __global__ __launch_bounds__(256) void et_gather_group_kernel(const int n, const
     st.t_iface[d] = s;
     return;
   }
+  if (st.t_add && !fixed) s += st.t_add[d];  // (the surface blocks' contributions)
   const double rv = st.r0[d] - s;
   if (st.mode == 2) {
     if (st.res) st.res[d] = rv;
@@ -2387,6 +2389,36 @@ void launch_dense_gather(const DenseSub &ds, double *y, bool accumulate, hipStre
     return;
   }
   launch_et_gather_raw(ds.lsize, ds.d_tptr, ds.d_tent, ds.d_ye, y, accumulate, s);
+}
+
+__global__ void k_zero_rows(double *__restrict__ v, const int32_t *__restrict__ rows, const int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[rows[i]] = 0.0;
+}
+void launch_zero_rows(double *v, const int32_t *rows, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_zero_rows, dim3((n + 255) / 256), dim3(256), 0, s, v, rows, n);
+  PA_HIP(hipGetLastError());
+}
+
+__global__ void k_surface_rows(const int32_t *__restrict__ rows, const int n, const int32_t *__restrict__ row_ptr,
+                               const int32_t *__restrict__ ent, const uint8_t *__restrict__ blk, const SurfaceYe ye,
+                               double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+    const int t = ent[e];
+    const double v = ye.ye[blk[e]][t >= 0 ? t : -1 - t];
+    s += t >= 0 ? v : -v;
+  }
+  out[rows[i]] = s;
+}
+void launch_surface_rows(const int32_t *rows, int n, const int32_t *row_ptr, const int32_t *ent, const uint8_t *blk, const SurfaceYe &ye,
+                         double *out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_surface_rows, dim3((n + 255) / 256), dim3(256), 0, s, rows, n, row_ptr, ent, blk, ye, out);
+  PA_HIP(hipGetLastError());
 }
 
 bool dense_fused_step_ok(const DenseSub &ds) { return ds.d_ess_flag && !ds.d_rchunk && ds.d_tptr && ds.d_tent && ds.d_ye; }

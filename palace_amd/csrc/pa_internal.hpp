@@ -356,6 +356,9 @@ struct GatherStep {
   // RestrictAddDirectStep); ghost rows go to the ghost output as in the plain split form.  nullptr: one rank.
   const unsigned char *iface_mask;
   double *t_iface;
+  // operators with further (surface) blocks beside the one whose gather runs the step: their contributions, accumulated beforehand,
+  // are added to the sum of every row that is not an essential one (nullptr: none).  Dense path only.
+  const double *t_add;
 };
 void launch_et_run_gather2(const SubOp &so, double *y, double *y1, hipStream_t s, const double *x, const double *x1, bool masked,
                            int ess_policy, const double *ye1);
@@ -394,7 +397,15 @@ void launch_dense_gather_signed(const DenseSub &ds, double *y, double sign, bool
 // the fused smoother step / residual on a dense block (round 6): the CSR-form gather owns every row; its epilogue consumes the sum
 bool dense_fused_step_ok(const DenseSub &ds);
 double time_dense_gather(const DenseSub &ds, const int32_t *d_tent);  // ms per launch of the plain E^T gather with this map (set-up)
-int dense_gather_group(const DenseSub &ds);  // lanes per dof of the CSR-form gather (pa_dense.hip: et_gather_group_kernel)
+int dense_gather_group(const DenseSub &ds);
+void launch_zero_rows(double *v, const int32_t *rows, int n, hipStream_t s);  // v[rows[i]] = 0
+constexpr int kMaxSurfaceBlocks = 8;
+struct SurfaceYe {
+  const double *ye[kMaxSurfaceBlocks];
+};
+// out[rows[i]] = sum over the entries of row i (block blk[e], signed position ent[e]) -- the surface blocks of a dense operator in one launch
+void launch_surface_rows(const int32_t *rows, int n, const int32_t *row_ptr, const int32_t *ent, const uint8_t *blk, const SurfaceYe &ye,
+                         double *out, hipStream_t s);  // lanes per dof of the CSR-form gather (pa_dense.hip: et_gather_group_kernel)
 void launch_dense_gather_step(const DenseSub &ds, const double *x, const GatherStep &step, int ess_policy, hipStream_t s,
                               const SplitIO *split = nullptr);
 void launch_dense_complex(const DenseSub &dr, const DenseSub &di, const double *xr, const double *xi, double *ye_i, hipStream_t s,
@@ -431,4 +442,13 @@ struct pa_op {
   std::vector<pa::SubOp *> subs;
   std::vector<pa::DenseSub *> dsubs;
   std::vector<pa::MixedSub *> msubs;  // trial space != test space (pa_op_add_sub_dense_mixed)
+  // fused smoother step of a dense operator with surface blocks (round 6, pa_op_prepare_fused_step): the surface blocks accumulate into
+  // t_extra (zero outside their rows; the union of their rows is reset before every use), the volume block's gather adds it
+  double *d_t_extra = nullptr;
+  int32_t *d_extra_rows = nullptr;
+  int n_extra_rows = 0;
+  // ... by ONE gather over the union of their rows (entries of every surface block, block by block: the order of the accumulating
+  // gathers it replaces): row pointers, signed E-vector positions, block numbers
+  int32_t *d_urow_ptr = nullptr, *d_uent = nullptr;
+  uint8_t *d_ublk = nullptr;
 };

@@ -148,3 +148,62 @@ def test_tet_chebyshev_steps_fused_into_the_gather(monkeypatch, p):
     z0 = S0.mult(dev(b), dev(g.copy()), initial_guess=True).cpu().numpy()
     assert np.linalg.norm(y - y0) < 1e-13 * np.linalg.norm(y0) and np.linalg.norm(z - z0) < 1e-13 * np.linalg.norm(z0)
     assert np.all(y[ess] == 0.0 * y[ess] + y0[ess])
+
+
+@pytest.mark.parametrize("p", [2, 3])
+def test_tet_chebyshev_step_with_surface_blocks(monkeypatch, p):
+    """Round 6: a driven problem's operator is a volume block plus a few row-limited surface blocks (absorbing boundary, ports).  The
+    fused smoother step takes them too: the surface blocks' element kernels, ONE gather over the union of their rows into a side
+    vector, the volume block's gather adds it and runs the step.  Against the unfused smoother (PALACE_AMD_FUSED_STEP_SURFACE=0 at
+    set-up: apply + essential rows + vector kernel), zero and non-zero initial guess."""
+    import torch
+
+    from palace_amd import ceed, linalg
+    from palace_amd.fem import tet, tri
+    from tests import util
+
+    mesh = tet.cube_tet_mesh(6)
+    nd = tet.NDTetSpace(mesh, p)
+    vpts, vwts = tet.default_tet_rule(p)
+    vint, vcurl = nd.elem.tables(vpts)
+    vgeom = ceed.DenseGeomFactorData(mesh.elem_nodes, mesh.nodes, mesh.attr, mesh.geometry_grad_table(vpts), vwts)
+    kw = dict(orients=nd.orients) if nd.diagonal_transform else dict(curl_orients=nd.curl_orients)
+    vblock = ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, nd.offsets, vint, vcurl, **kw)
+    _, bm = util.make_ctx("scalar", 1)
+    _, bc = util.make_ctx("identity")
+    _, b3 = util.make_ctx("aniso", 1)
+    op = ceed.Operator(nd.ndofs, nd.ndofs).add_dense_integrator(vgeom, vblock, ceed.QF_HDIVMASS_33, np.concatenate([bm, bc]),
+                                                                 ceed.EVAL_CURL + ceed.EVAL_INTERP)
+    faces = np.nonzero(mesh.boundary_face_mask)[0]
+    pts, wts = tri.tri_quadrature(p + 1)
+    for sub in (faces[:30], faces[20:55]):  # two surface blocks with common rows
+        blk = tet.NDTetBoundaryBlock(nd, sub, np.ones(sub.size, dtype=np.int32))
+        interp, _ = blk.elem.tables(pts)
+        bgeom = ceed.DenseGeomFactorData(blk.elem_nodes, blk.nodes, blk.attr, blk.geometry_grad_table(pts), wts)
+        op.add_dense_integrator(bgeom, ceed.DenseBlock(ceed.FE_HCURL, nd.ndofs, blk.offsets, interp, None, orients=blk.orients),
+                                ceed.QF_HCURL_32, b3, ceed.EVAL_INTERP)
+    op.finalize()
+    ess = np.unique(nd.offsets[:8].ravel())[:60].astype(np.int32)
+    ctx = linalg.Context()
+    A = linalg.ParOperator(ctx, op, ess, linalg.DIAG_ONE)
+    S = linalg.chebyshev(ctx, A, order=4)
+    assert S.fused_step(), "the surface blocks are not row-limited on this mesh?"
+    monkeypatch.setenv("PALACE_AMD_FUSED_STEP_SURFACE", "0")
+    S0 = linalg.chebyshev(ctx, A, order=4)
+    assert not S0.fused_step() and S0.lambda_max() == S.lambda_max()
+    rng = np.random.default_rng(4)
+    n = nd.ndofs
+    b, g = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    b[ess] = 0.0
+    g[ess] = 0.0
+    dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    y = S.mult(dev(b), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    y0 = S0.mult(dev(b), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    z = S.mult(dev(b), dev(g.copy()), initial_guess=True).cpu().numpy()
+    z0 = S0.mult(dev(b), dev(g.copy()), initial_guess=True).cpu().numpy()
+    rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)  # noqa: E731
+    assert rel(y, y0) < 1e-13 and rel(z, z0) < 1e-13
+    # the plain apply is what it was
+    x = rng.uniform(-1, 1, n)
+    t0 = A.mult(dev(x), torch.empty(n, dtype=torch.float64, device="cuda")).cpu().numpy()
+    assert np.array_equal(t0[ess], x[ess])
