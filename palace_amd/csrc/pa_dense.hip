@@ -844,6 +844,9 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
 #else
     double *ye = ((CPLX && (j >> 3)) ? a.ye1 : a.ye) + bb * KP * 64;
 #endif
+    // position of dof slot s of this lane: base + s * stride (ye_pos; two integers instead of the expression per slot)
+    const int ye_stride = a.ye_rows ? 4 : 64;
+    double *yel = ye + (a.ye_rows ? (gln & 15) * (4 * KP) + (gln >> 4) : gln);
     if (co) {
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
         if (s < KP) {
           const int dof = 4 * s + kq;
           const unsigned cm = cpk[s >> 1];
-          ye[ye_pos(a.ye_rows, KP, s, gln)] = co_field_pk(cm, s & 1, 1) * yacc[s >> 2][s & 3] + co_field_pk(cm, s & 1, 3) * sm[max(dof - 1, 0) * 16 + j] +
+          yel[s * ye_stride] = co_field_pk(cm, s & 1, 1) * yacc[s >> 2][s & 3] + co_field_pk(cm, s & 1, 3) * sm[max(dof - 1, 0) * 16 + j] +
                              co_field_pk(cm, s & 1, 4) * sm[min(dof + 1, 4 * KP - 1) * 16 + j];
         }
       }
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(64 * ((AFFINE && !CPLX) ? kAffWaves : kResWaves), 1
     } else {
 #pragma unroll
       for (int s = 0; s < KPMAX; s++)
-        if (s < KP) ye[ye_pos(a.ye_rows, KP, s, gln)] = yacc[s >> 2][s & 3];
+        if (s < KP) yel[s * ye_stride] = yacc[s >> 2][s & 3];
     }
   }
 }
