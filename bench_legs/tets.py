@@ -70,6 +70,16 @@ def cpw_iso_leg(order=3, refine=1, reps=20, ab=False):
                             "bytes_formula": "NE*(Q*11*8 + P*7) + 32*N_L: one pass over the element data, both parts of x and y"}
     out["dense_gather"] = dict(zip(("e_vector_rows_by_element", "lanes_per_dof"), sys_["Kr"].dense_gather_form()))
     xr, xi = torch.zeros_like(br), torch.zeros_like(br)
+    # the first solve allocates the Krylov basis (2 x 2 x 17 MB per column: ~0.3 s of hipMalloc inside a 2.7 s solve, more in a process
+    # whose memory has been through other legs) and records the V-cycle's graphs: reported, but `fgmres` is the solve a driver's
+    # second right-hand side / next frequency sees
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    S.mult(br, bi, xr, xi)
+    torch.cuda.synchronize()
+    out["fgmres_first_solve"] = {"iterations_to_1e-8": S.stats()["iterations"], "seconds": time.perf_counter() - t0,
+                                 "note": "includes the allocation of the Krylov basis and the graph recordings"}
+    xr.zero_(), xi.zero_()
     rc0 = linalg.Context.resident_columns()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -243,6 +253,10 @@ def cpw_leg(order=3, refine=1, reps=20, freq_ghz=17.0):
         finally:
             linalg.Context.set_device_orthogonalization(True)
 
+    # (first solve: allocates the Krylov basis and records the graphs -- reported; `fgmres` is the solve after it, what the next
+    # frequency point of a driven sweep sees)
+    solve("fgmres_first_solve")
+    out["fgmres_first_solve"]["note"] = "includes the allocation of the Krylov basis (2 x 2 x 17 MB per column) and the graph recordings"
     rc0 = linalg.Context.resident_columns()
     sr, si = solve("fgmres")
     out["fgmres"]["orthogonalization"] = MGS_NOTE
