@@ -2233,9 +2233,9 @@ void launch_gather_split(const DenseSub &ds, const double *ye, double *y, double
 }
 
 double time_dense_gather(const DenseSub &ds, const int32_t *d_tent) {
-  DenseSub probe = ds;  // (a shallow copy with the map under test; nothing of it is freed here)
+  DenseSub probe;  // (only what launch_gather_split reads: sizes and the map under test; nothing of it is freed here)
+  probe.ne = ds.ne, probe.P = ds.P, probe.lsize = ds.lsize, probe.d_tptr = ds.d_tptr;
   probe.d_tent = const_cast<int32_t *>(d_tent);
-  probe.d_ess_flag = nullptr;
   double *y = dev_alloc<double>((size_t)ds.lsize);
   hipEvent_t e0, e1;
   PA_HIP(hipEventCreate(&e0));
